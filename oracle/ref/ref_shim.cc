@@ -1,0 +1,214 @@
+// TEST INFRASTRUCTURE ONLY — never linked into the product library.
+//
+// Flat C wrapper around the REAL reference engines, compiled in place from
+// /root/reference/cpp_src (sources are #included / compiled where they lie, nothing
+// is copied into this repository).  Output: oracle/_ref/libref_oracle.so.
+//
+// Wrapped reference entry points:
+//   vector_dists::L2SqrDistance / InnerProductDistance   tools/distances/l2_dist.h:21-30, ip_dist.h:21-30
+//   ann::CalculateL2Module / NormalizeCopyVector          tools/normalize.h:16-22
+//   hnswlib::BruteforceSearch                            core/index/float_vector/hnswlib/bruteforce.h:14-66
+//   hnswlib::HierarchicalNSWImpl<float, None>            core/index/float_vector/hnswlib/hnswalg.h:206-2073
+//     (constructed exactly like HierarchicalNSW<>::Impl::Impl, hnsw.cc:74-78: seed 100, ReplaceDeleted_True)
+// The same usage pattern as the reference's own engine-level test
+// gtests/tests/unit/hnsw_streaming_search_test.cc:22-25,38,53,161-162.
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <span>
+#include <string>
+#include <vector>
+
+#include "core/index/float_vector/hnswlib/bruteforce.h"
+#include "core/index/float_vector/hnswlib/hnswalg.h"
+#include "tools/cpucheck.h"
+#include "tools/distances/ip_dist.h"
+#include "tools/distances/l2_dist.h"
+#include "tools/normalize.h"
+
+using reindexer::ConstFloatVectorView;
+using reindexer::FloatVectorId;
+using reindexer::IdType;
+using reindexer::VectorMetric;
+
+namespace {
+using HnswT = hnswlib::HierarchicalNSWImpl<float, hnswlib::Synchronization::None>;
+thread_local std::string g_err;
+
+VectorMetric toMetric(int m) { return m == 0 ? VectorMetric::L2 : (m == 1 ? VectorMetric::InnerProduct : VectorMetric::Cosine); }
+
+// Drains a reference result heap back-to-front so that out[0] is the best hit — the same
+// order HnswIndexBase<Map>::select produces (hnsw_index.cc:258-273).
+size_t drain(hnswlib::SearchResultQueue& q, float* outDist, uint64_t* outLabel, size_t cap) {
+	const size_t n = q.size();
+	size_t i = n;
+	for (; !q.empty(); q.pop()) {
+		--i;
+		if (i < cap) {
+			outDist[i] = q.top().first;
+			outLabel[i] = q.top().second;
+		}
+	}
+	return n;
+}
+}  // namespace
+
+extern "C" {
+
+const char* ref_last_error() { return g_err.c_str(); }
+
+// 3 = avx512, 2 = avx2, 1 = avx, 0 = sse  (cpucheck.cc:201-231; env RX_TARGET_INSTRUCTIONS)
+int ref_simd_level() {
+	if (reindexer::IsAVX512Allowed()) return 3;
+	if (reindexer::IsAVX2Allowed()) return 2;
+	if (reindexer::IsAVXAllowed()) return 1;
+	return 0;
+}
+
+float ref_l2sqr(const float* a, const float* b, size_t d) { return reindexer::vector_dists::L2SqrDistance(a, b, d); }
+float ref_ip(const float* a, const float* b, size_t d) { return reindexer::vector_dists::InnerProductDistance(a, b, d); }
+void ref_l2sqr_many(const float* q, const float* rows, size_t n, size_t d, float* out) {
+	for (size_t i = 0; i < n; ++i) out[i] = reindexer::vector_dists::L2SqrDistance(q, rows + i * d, d);
+}
+void ref_ip_many(const float* q, const float* rows, size_t n, size_t d, float* out) {
+	for (size_t i = 0; i < n; ++i) out[i] = reindexer::vector_dists::InnerProductDistance(q, rows + i * d, d);
+}
+float ref_l2_module(const float* x, int32_t d) { return reindexer::ann::CalculateL2Module(x, d); }
+float ref_normalize_copy(const float* x, int32_t d, float* out) { return reindexer::ann::NormalizeCopyVector(x, d, out); }
+
+// ---------------------------------------------------------------- brute force
+void* ref_bf_create(int metric, size_t dim, size_t maxElements) {
+	try {
+		return new hnswlib::BruteforceSearch(toMetric(metric), dim, maxElements);
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+void ref_bf_destroy(void* h) { delete static_cast<hnswlib::BruteforceSearch*>(h); }
+int ref_bf_add(void* h, const float* vec, size_t dim, uint64_t label) {
+	try {
+		static_cast<hnswlib::BruteforceSearch*>(h)->AddPointNoLock(ConstFloatVectorView{std::span<const float>(vec, dim)},
+																	 FloatVectorId::FromNumber(label));
+		return 0;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+int ref_bf_add_many(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels) {
+	for (size_t i = 0; i < n; ++i) {
+		if (int rc = ref_bf_add(h, vecs + i * dim, dim, labels[i]); rc) return rc;
+	}
+	return 0;
+}
+void ref_bf_remove(void* h, uint64_t label) { static_cast<hnswlib::BruteforceSearch*>(h)->RemovePoint(label); }
+int ref_bf_resize(void* h, size_t n) {
+	try {
+		static_cast<hnswlib::BruteforceSearch*>(h)->ResizeIndex(n);
+		return 0;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+size_t ref_bf_count(void* h) { return static_cast<hnswlib::BruteforceSearch*>(h)->CurrentElementCount(); }
+size_t ref_bf_search_knn(void* h, const float* q, size_t k, float* outDist, uint64_t* outLabel) {
+	auto res = static_cast<const hnswlib::BruteforceSearch*>(h)->SearchKnn(q, std::nullopt, k, 0);
+	return drain(res, outDist, outLabel, k);
+}
+size_t ref_bf_search_range(void* h, const float* q, float radius, float* outDist, uint64_t* outLabel, size_t cap) {
+	auto res = static_cast<const hnswlib::BruteforceSearch*>(h)->SearchRange(q, std::nullopt, radius, 0);
+	return drain(res, outDist, outLabel, cap);
+}
+
+// ---------------------------------------------------------------------- HNSW
+void* ref_hnsw_create(int metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction) {
+	try {
+		return new HnswT(toMetric(metric), dim, maxElements, M, efConstruction, 100, reindexer::ReplaceDeleted_True);
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+void ref_hnsw_destroy(void* h) { delete static_cast<HnswT*>(h); }
+int ref_hnsw_add_many(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels) {
+	try {
+		auto* g = static_cast<HnswT*>(h);
+		for (size_t i = 0; i < n; ++i) g->AddPointNoLock(vecs + i * dim, labels[i]);
+		return 0;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+int ref_hnsw_mark_delete(void* h, uint64_t label) {
+	try {
+		static_cast<HnswT*>(h)->MarkDelete(label);
+		return 0;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+size_t ref_hnsw_count(void* h) { return static_cast<HnswT*>(h)->CurrentElementCount(); }
+size_t ref_hnsw_search_knn(void* h, const float* q, size_t k, size_t ef, float* outDist, uint64_t* outLabel) {
+	auto res = static_cast<const HnswT*>(h)->SearchKnn(q, std::nullopt, k, ef);
+	return drain(res, outDist, outLabel, k);
+}
+size_t ref_hnsw_search_range(void* h, const float* q, float radius, size_t ef, float* outDist, uint64_t* outLabel, size_t cap) {
+	auto res = static_cast<const HnswT*>(h)->SearchRange(q, std::nullopt, radius, ef);
+	return drain(res, outDist, outLabel, cap);
+}
+
+// Graph export (flat form shared by the C restatement and the GPU engine):
+//   info[0]=count info[1]=M info[2]=maxM0 info[3]=maxlevel info[4]=entrypoint info[5]=numDeleted
+void ref_hnsw_info(void* h, int64_t* info) {
+	auto* g = static_cast<HnswT*>(h);
+	info[0] = int64_t(g->cur_element_count.load());
+	info[1] = int64_t(g->M_);
+	info[2] = int64_t(g->maxM0_);
+	info[3] = g->maxlevel_;
+	info[4] = int64_t(g->enterpoint_node_);
+	info[5] = int64_t(g->num_deleted_);
+}
+// links0: [count][1+maxM0] u32 (slot 0 = neighbour count), levels: [count] i32, labels: [count] u64,
+// deleted: [count] u8, vectors (optional): [count][dim] f32.
+void ref_hnsw_export_level0(void* h, uint32_t* links0, int32_t* levels, uint64_t* labels, uint8_t* deleted, float* vectors) {
+	auto* g = static_cast<HnswT*>(h);
+	const size_t n = g->cur_element_count.load();
+	const size_t stride = 1 + g->maxM0_;
+	const size_t dim = g->fstdistfunc_.Dim();
+	for (size_t i = 0; i < n; ++i) {
+		const auto* ll = g->get_linklist0(hnswlib::tableint(i));
+		const unsigned cnt = g->getListCount(ll);
+		links0[i * stride] = cnt;
+		for (unsigned j = 0; j < g->maxM0_; ++j) links0[i * stride + 1 + j] = j < cnt ? hnswlib::readLinkListNeighbor(ll, j) : 0u;
+		levels[i] = g->element_levels_[i];
+		labels[i] = g->ExternalLabel(hnswlib::tableint(i));
+		deleted[i] = g->IsMarkedDeleted(hnswlib::tableint(i)) ? 1 : 0;
+		if (vectors) std::memcpy(vectors + i * dim, g->getDataByInternalId(hnswlib::tableint(i)), dim * sizeof(float));
+	}
+}
+// Upper levels as CSR: upperOff[i] = index (in units of blocks of 1+M u32) of node i's level-1 block;
+// node i owns levels[i] consecutive blocks.  Call with upper == nullptr to get the block count.
+size_t ref_hnsw_export_upper(void* h, uint64_t* upperOff, uint32_t* upper) {
+	auto* g = static_cast<HnswT*>(h);
+	const size_t n = g->cur_element_count.load();
+	const size_t stride = 1 + g->M_;
+	size_t blocks = 0;
+	for (size_t i = 0; i < n; ++i) {
+		if (upperOff) upperOff[i] = blocks;
+		for (int l = 1; l <= g->element_levels_[i]; ++l, ++blocks) {
+			if (!upper) continue;
+			const auto* ll = g->get_linklist(hnswlib::tableint(i), l);
+			const unsigned cnt = g->getListCount(ll);
+			upper[blocks * stride] = cnt;
+			for (unsigned j = 0; j < g->M_; ++j) upper[blocks * stride + 1 + j] = j < cnt ? hnswlib::readLinkListNeighbor(ll, j) : 0u;
+		}
+	}
+	if (upperOff) upperOff[n] = blocks;
+	return blocks;
+}
+
+}  // extern "C"
