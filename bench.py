@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: brute-force KNN queries/s, 10M x 768 fp32 inner product, k = 10 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: ONE query (batch = 1) scanned against the
+whole HBM-resident corpus through the C-ABI (rxgpu_search_knn_device), results left in HBM.  With N > 1 every rank
+holds its own 10M-row shard (weak scaling = BASELINE configs[3]: 80M rows on 8 GPUs); each step then also does the
+per-shard top-k all-gather over RCCL and the k-way merge.  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N = 1 only, outside the timed region):
+  roofline      HIP events recorded by the library around every scan-kernel launch on the launch stream
+  cpu_baseline  the reference's own BruteforceSearch (oracle/_ref, AVX-512 path) — or the plain-C port when the
+                reference build is absent — timed on the host cores on a bounded row-prefix sample
+  parity        GPU result vs that CPU result on the same sample (ids must be identical, distance bits too)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from reindexer_amd import capi  # noqa: E402  (no fallback: raises if librxgpu.so is missing)
+from reindexer_amd.sharded import merge_shard_topk, pack_topk  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="rows per GPU (default: the BASELINE 10M)")
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--metric", default="ip", choices=["l2", "ip", "cosine"])
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-queries", type=int, default=16)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    return ap.parse_args()
+
+
+def make_corpus(rows: int, dim: int, seed: int, device) -> torch.Tensor:
+    """float32 i.i.d. N(0, 0.25^2) — the distribution of the reference's own tests (gtests/tools.h:121-129)."""
+    out = torch.empty((rows, dim), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    chunk = 1 << 20
+    for i, start in enumerate(range(0, rows, chunk)):
+        g.manual_seed(seed * 1_000_003 + i)
+        n = min(chunk, rows - start)
+        out[start:start + n].normal_(0.0, 0.25, generator=g)
+    return out
+
+
+def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, metric_id: int):
+    from oracle import pyoracle  # checker / baseline only
+    s_rows = min(args.cpu_sample_rows, corpus.shape[0])
+    nq = min(args.cpu_queries, queries.shape[0])
+    host_rows = corpus[:s_rows].cpu().numpy()
+    host_q = queries[:nq].cpu().numpy()
+    labels = np.arange(s_rows, dtype=np.uint64) << np.uint64(32)
+    orc = pyoracle.Oracle()
+    ref = pyoracle.ref_or_none()
+    use_ref = ref is not None and ref.simd_level == 3
+    inv = orc.l2_modules(host_rows) if metric_id == 2 else None
+    if metric_id == 2:
+        host_q = np.stack([orc.normalize_copy(q)[0] for q in host_q])
+    ncores = os.cpu_count() or 1
+
+    if use_ref:
+        bf = pyoracle.RefBruteforce(ref, metric_id, args.dim, s_rows)
+        bf.add(host_rows, labels)
+        search = lambda q: bf.search_knn(q, args.k)  # noqa: E731
+        kind = "reference"
+    else:
+        search = lambda q: orc.bf_search_knn(metric_id, host_rows, labels, inv, q, args.k)  # noqa: E731
+        kind = "port"
+
+    t0 = time.perf_counter()
+    cpu_res = [search(host_q[i]) for i in range(nq)]
+    t1 = time.perf_counter()
+    qps_1 = nq / (t1 - t0)
+
+    # all host cores: T concurrent query threads over one shared index (the reference's own concurrency model)
+    threads = min(ncores, 64)
+    per_thread = 2
+    def worker(t):
+        for j in range(per_thread):
+            search(host_q[(t + j) % nq])
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    t2 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    t3 = time.perf_counter()
+    qps_all = threads * per_thread / (t3 - t2)
+
+    scale = s_rows / corpus.shape[0]  # linear scan: time is proportional to rows
+    baseline = {
+        "value": qps_1 * scale, "unit": "queries/s", "cores": 1, "kind": kind,
+        "sample": f"{s_rows}-row prefix of the same corpus, {nq} queries, k={args.k}; measured {qps_1:.3f} q/s on the sample, "
+                  f"scaled by {s_rows}/{corpus.shape[0]} rows (linear scan); SIMD=avx512" ,
+        "all_cores": {"value": qps_all * scale, "cores": threads, "measured_on_sample": qps_all},
+        "gbps_per_core": qps_1 * s_rows * args.dim * 4 / 1e9,
+    }
+
+    # parity on the same sample: GPU through the C-ABI vs the CPU result
+    with capi.VectorIndex(metric_id, args.dim) as ix:
+        d_inv = None
+        if metric_id == 2:
+            d_inv = torch.from_numpy(inv).to(corpus.device)
+        ix.adopt_device_rows(corpus.data_ptr(), s_rows, corpus.shape[1], d_inv.data_ptr() if d_inv is not None else None,
+                             keepalive=(corpus, d_inv))
+        dist, row, cnt = ix.search_knn(host_q, args.k + 1)
+    ids_equal, max_ulps = 0, 0
+    for i in range(nq):
+        wd, wl = cpu_res[i]
+        gl = labels[row[i, :args.k]]
+        ids_equal += int(np.array_equal(gl, wl))
+        ulps = np.abs(dist[i, :args.k].view(np.int32).astype(np.int64) - wd.view(np.int32).astype(np.int64))
+        max_ulps = max(max_ulps, int(ulps.max()))
+    parity = {"ids_equal_frac": ids_equal / nq, "max_ulps_dist": max_ulps, "queries": nq, "rows": s_rows,
+              "recall_at_k": ids_equal / nq if ids_equal == nq else None}
+    if parity["recall_at_k"] is None:
+        rec = 0.0
+        for i in range(nq):
+            rec += len(set(labels[row[i, :args.k]].tolist()) & set(cpu_res[i][1].tolist())) / args.k
+        parity["recall_at_k"] = rec / nq
+    return baseline, parity
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    metric_id = capi.METRICS[args.metric]
+    kk = args.k + 1  # the Map asks for k+1 to detect a distance tie straddling the k-th boundary
+    corpus = make_corpus(args.rows, args.dim, 20260924 + rank, device)
+    total_q = args.steps + args.warmup
+    gq = torch.Generator(device=device)
+    gq.manual_seed(7)  # the same queries on every rank
+    queries = torch.empty((max(total_q, args.cpu_queries), args.dim), dtype=torch.float32, device=device).normal_(0.0, 0.25, generator=gq)
+    d_inv = None
+    if metric_id == 2:
+        d_inv = 1.0 / torch.linalg.vector_norm(corpus, dim=1)
+        queries = queries / torch.linalg.vector_norm(queries, dim=1, keepdim=True)
+
+    ix = capi.VectorIndex(metric_id, args.dim, device=local_rank)
+    ix.adopt_device_rows(corpus.data_ptr(), args.rows, args.dim, d_inv.data_ptr() if d_inv is not None else None, keepalive=(corpus, d_inv))
+    out_dist = torch.empty((total_q, kk), dtype=torch.float32, device=device)
+    out_row = torch.empty((total_q, kk), dtype=torch.int32, device=device)
+    final = torch.empty((total_q, kk, 2), dtype=torch.int64, device=device) if dist_on else None
+    gathered = torch.empty((world, kk), dtype=torch.int64, device=device) if dist_on else None
+    stream = torch.cuda.current_stream(device)
+    esz = 4
+
+    def step(i: int):
+        ix.search_knn_device(queries.data_ptr() + i * args.dim * esz, 1, kk, out_dist.data_ptr() + i * kk * esz,
+                             out_row.data_ptr() + i * kk * esz, None, stream.cuda_stream)
+        if dist_on:
+            packed = pack_topk(out_dist[i], out_row[i], rank * args.rows)
+            dist.all_gather_into_tensor(gathered.view(-1), packed)
+            final[i] = merge_shard_topk(gathered, kk, args.rows)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    ix.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_q):
+        step(i)
+    sync()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launches, scan_ms = ix.profile_read("scan")
+    ix.profile_enable(False)
+
+    qps_global = args.steps / elapsed            # queries/s over the whole (N x rows) corpus
+    value = qps_global * world                   # aggregate in 10M-row-shard scans/s (== queries/s at N = 1)
+    algo_bytes = args.rows * args.dim * 4        # N*D*4 per query (labels/norms excluded)
+    avg_scan_s = (scan_ms / 1e3) / max(launches, 1)
+    achieved = algo_bytes / avg_scan_s / 1e9 if launches else 0.0
+
+    if rank == 0:
+        result = {
+            "metric": "knn_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"brute-force KNN, {args.rows} x {args.dim} fp32 per GPU, metric={args.metric}, k={args.k}, batch=1 "
+                            f"(BASELINE configs[1]{'; x' + str(world) + ' row-sharded = configs[3]' if world > 1 else ''})",
+                "rows_per_gpu": args.rows, "total_rows": args.rows * world, "dim": args.dim, "k": args.k, "batch": 1,
+                "sharding": "row-range shards, RCCL all-gather of per-shard top-k + merge" if world > 1 else "none",
+                "value_definition": "queries/s over the full corpus x n_gpus (each query scans one rows_per_gpu shard per GPU)",
+                "qps_over_full_corpus": qps_global, "arch": capi.device_arch(local_rank),
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "knn_scan_fixed", "launches": launches, "avg_ms": avg_scan_s * 1e3,
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                base, parity = cpu_baseline_and_parity(args, corpus, queries, metric_id)
+                result["cpu_baseline"] = base
+                result["parity"] = parity
+            except Exception as e:  # the bench line must still be printed
+                result["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(result), flush=True)
+    ix.close()
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

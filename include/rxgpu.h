@@ -1,0 +1,128 @@
+/*
+ * rxgpu — C-ABI of the MI355X (gfx950) engines behind Reindexer's float_vector / ft_fast index plugins.
+ *
+ * This header is the drop-in boundary: plain C types, caller-allocated outputs, int return codes
+ * (0 = ok, negative = rxgpu_status), no C++/torch types.  Nothing in the reference knows this ABI; it is
+ * what the GPU `Map` policy of HnswIndexBase<Map> (cpp_src/core/index/float_vector/hnsw_index.h:16-57) and
+ * the GPU branch of Selector<IdCont>::mergeResults (cpp_src/core/ft/ft_fast/selecterimpl.h:611-628) bind.
+ * Each entry point cites the reference interface it stands in for.  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - "row" = internal index of a vector inside one index (the reference's `idx` in bruteforce.cc / `tableint`
+ *     in hnswalg.h).  Labels (FloatVectorId = rowId<<32 | arrayIdx) never cross this boundary: the host Map
+ *     owns the row->label table exactly like the reference owns it inside its AoS rows (bruteforce.h:47-48).
+ *   - Distances are "smaller is better": L2 -> squared distance, IP -> -dot, cosine -> -dot * inv_norm[row]
+ *     (hnswlib.h:147-165,192-197).  They are bit-identical to the reference's AVX-512 path for every dim.
+ *   - All functions are thread-safe for concurrent searches on one index (the reference's read path is
+ *     re-entrant under the namespace shared lock); mutations require external exclusion (namespace write lock).
+ *   - *_device variants take device pointers and a hipStream_t (as void*), enqueue work and return without
+ *     synchronising; everything else synchronises before returning.
+ */
+#ifndef RXGPU_H
+#define RXGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RXGPU_ABI_VERSION 1
+
+typedef enum rxgpu_status {
+	RXGPU_OK = 0,
+	RXGPU_ERR_PARAMS = -3,    /* reindexer errParams (type_consts.h:139-148) */
+	RXGPU_ERR_LOGIC = -4,     /* reindexer errLogic */
+	RXGPU_ERR_NOMEM = -5,     /* std::runtime_error("Not enough memory ...") in bruteforce.cc:15,90 */
+	RXGPU_ERR_DEVICE = -6,    /* HIP runtime failure; text in rxgpu_last_error() */
+	RXGPU_ERR_NOTFOUND = -7,
+	RXGPU_ERR_OVERFLOW = -8   /* caller-provided output buffer too small; required size reported */
+} rxgpu_status;
+
+typedef enum rxgpu_metric { RXGPU_METRIC_L2 = 0, RXGPU_METRIC_IP = 1, RXGPU_METRIC_COSINE = 2 } rxgpu_metric; /* core/enums.h:101 VectorMetric */
+
+typedef struct rxgpu_index rxgpu_index; /* one float_vector index shard resident on one GPU */
+
+/* Thread-local text of the last failure on the calling thread. */
+const char* rxgpu_last_error(void);
+int rxgpu_abi_version(void);
+/* Number of visible HIP devices; <0 on runtime failure. */
+int rxgpu_device_count(void);
+/* Fills name with the gcnArchName of `device` ("gfx950:..."), mirrors the SIMD-level log line of hnsw_index.cc:25-44. */
+int rxgpu_device_arch(int device, char* name, size_t cap);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Vector storage (device mirror of BruteforceSearch / HierarchicalNSW row storage)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* BruteforceSearch::BruteforceSearch(metric, dim, maxElements)  bruteforce.cc:11-18.
+ * Allocates capacity * row_stride floats of HBM on `device` (row_stride = dim rounded up to 4 floats). */
+int rxgpu_index_create(int metric, uint32_t dim, uint64_t capacity, int device, rxgpu_index** out);
+void rxgpu_index_destroy(rxgpu_index* h);
+
+/* BruteforceSearch::ResizeIndex  bruteforce.cc:88-101 (contents preserved; shrinking below count is an error). */
+int rxgpu_index_reserve(rxgpu_index* h, uint64_t capacity);
+
+/* Device side of AddPointNoLock (bruteforce.cc:44-64): copy n host rows (packed [n][dim]) to rows
+ * [first_row, first_row+n) and their 1/|row| coefficients (cosine only, may be NULL otherwise; the host computes
+ * them exactly as DistCalculator::AddNorm does, hnswlib.h:80-92).  count becomes max(count, first_row+n). */
+int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, const float* rows, const float* inv_norms);
+
+/* Zero-copy alternative: adopt caller-owned device memory (e.g. a torch tensor) as the row storage.
+ * d_rows: [n][row_stride] floats, row_stride >= dim, row_stride % 4 == 0, 16-byte aligned; d_inv_norms: [n] or NULL.
+ * The caller keeps ownership and must keep the memory alive and unchanged while adopted. */
+int rxgpu_index_adopt_device_rows(rxgpu_index* h, const void* d_rows, uint64_t n, uint32_t row_stride, const void* d_inv_norms);
+
+/* Device side of RemovePoint's swap-with-last (bruteforce.cc:70-86): copy row `from` over row `to` (incl. norm). */
+int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to);
+/* Set the number of live rows (after a swap-delete, or Reset()). */
+int rxgpu_index_truncate(rxgpu_index* h, uint64_t count);
+
+uint64_t rxgpu_index_count(const rxgpu_index* h);
+uint64_t rxgpu_index_capacity(const rxgpu_index* h);
+uint32_t rxgpu_index_dim(const rxgpu_index* h);
+uint32_t rxgpu_index_row_stride(const rxgpu_index* h);
+int rxgpu_index_metric(const rxgpu_index* h);
+int rxgpu_index_device(const rxgpu_index* h);
+/* HBM bytes held by the index (AllocatedMemSize analogue, bruteforce.h:41-44). */
+uint64_t rxgpu_index_device_bytes(const rxgpu_index* h);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Brute-force search (BruteforceSearch::SearchKnn / SearchRange)
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Exact top-kk of each of nq queries under the total order (dist, row) ascending — the order in which the
+ * reference's (dist,label) max-heap evicts, with row standing in for label (bruteforce.cc:103-127).
+ * queries: host [nq][dim] (cosine: already normalised by the caller, hnsw_index.cc:166-171).
+ * out_dist/out_row: host [nq][kk]; out_count[q] = min(kk, count).
+ * The GPU Map asks for kk = k+1 so it can detect a distance tie straddling the k-th boundary and replay the
+ * reference's admission rule (strict `dist < worst`, bruteforce.cc:121) with rxgpu_search_collect_le(). */
+int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, float* out_dist, uint32_t* out_row,
+					 uint32_t* out_count);
+
+/* Same, device-resident in/out on `stream` (hipStream_t); d_out_count may be NULL.  No synchronisation. */
+int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, void* d_out_dist, void* d_out_row,
+							void* d_out_count, void* stream);
+
+/* BruteforceSearch::SearchRange (bruteforce.cc:129-143): every row with dist < radius (inclusive != 0: dist <= radius;
+ * the inclusive form serves the tie replay above).  Rows are returned sorted by (dist,row); *out_total receives the
+ * number of hits; at most cap are written; RXGPU_ERR_OVERFLOW if out_total > cap (call again with a larger buffer). */
+int rxgpu_search_range(rxgpu_index* h, const float* query, float radius, int inclusive, float* out_dist, uint32_t* out_row,
+					   uint64_t cap, uint64_t* out_total);
+
+/* Distances of one query against an explicit list of rows (DistCalculator::operator()(q,row,id), hnswlib.h:147-165);
+ * used for exact re-scoring and by tests. */
+int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Instrumentation (bench.py roofline leg): HIP-event timing of the dominant kernel on its own stream.
+ * ------------------------------------------------------------------------------------------------------- */
+int rxgpu_profile_enable(rxgpu_index* h, int on);
+/* name: "scan" | "merge" | "range" ...; returns launches recorded since enable and their summed milliseconds. */
+int rxgpu_profile_read(rxgpu_index* h, const char* name, uint64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RXGPU_H */

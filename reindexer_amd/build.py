@@ -1,0 +1,76 @@
+"""In-tree build of the native libraries (gfx950 only).
+
+    python -m reindexer_amd.build            # build what is stale
+    python -m reindexer_amd.build --force
+
+Produces, next to this file:
+    librxgpu.so        HIP kernels + the C-ABI of include/rxgpu.h   (hipcc --offload-arch=gfx950)
+    librxgpu_host.so   C++ host mirror of the reference's Map / select interfaces (g++), links librxgpu.so
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only container too.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+HOST = PKG / "host"
+INCLUDE = ROOT / "include"
+
+HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# -ffp-contract=off: every fused multiply-add in the kernels is an explicit __builtin_fmaf; nothing else may be
+# contracted, or the bit-exact summation order of the reference's AVX-512 kernels is lost.
+HIP_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+    "-fno-gpu-flush-denormals-to-zero",  # x86 keeps f32 subnormals; so must the kernels
+    "-Wall", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}",
+]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", f"-I{INCLUDE}", f"-I{HOST}"]
+
+
+def _stale(target: Path, sources: list[Path]) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(s.stat().st_mtime > t for s in sources)
+
+
+def _run(cmd: list[str]) -> None:
+    print("+", " ".join(str(c) for c in cmd), flush=True)
+    subprocess.run([str(c) for c in cmd], check=True)
+
+
+def build_device(force: bool = False) -> Path:
+    out = PKG / "librxgpu.so"
+    srcs = sorted(CSRC.glob("*.hip"))
+    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    if force or _stale(out, deps):
+        _run([HIPCC, *HIP_FLAGS, *srcs, "-o", out, "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+def build_host(force: bool = False) -> Path | None:
+    srcs = sorted(HOST.glob("*.cc"))
+    if not srcs:
+        return None
+    out = PKG / "librxgpu_host.so"
+    deps = srcs + sorted(HOST.glob("*.h")) + sorted(INCLUDE.glob("*.h")) + [PKG / "librxgpu.so"]
+    if force or _stale(out, deps):
+        _run(["g++", *HOST_FLAGS, *srcs, "-o", out, f"-L{PKG}", "-lrxgpu", "-Wl,-rpath,$ORIGIN", "-lpthread"])
+    return out
+
+
+def build_all(force: bool = False) -> None:
+    build_device(force)
+    build_host(force)
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)

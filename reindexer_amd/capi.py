@@ -1,0 +1,230 @@
+"""ctypes binding of the C-ABI in include/rxgpu.h (librxgpu.so).
+
+Python here is plumbing for tests / bench / multi-GPU launch only: numpy arrays or torch device pointers in,
+numpy arrays out.  There is NO fallback: if the HIP library is missing or fails to load, importing the symbols
+raises — a product path must never silently route around the kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "librxgpu.so"
+
+METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
+METRICS = {"l2": METRIC_L2, "ip": METRIC_IP, "inner_product": METRIC_IP, "cosine": METRIC_COSINE}
+
+RXGPU_OK = 0
+RXGPU_ERR_PARAMS = -3
+RXGPU_ERR_LOGIC = -4
+RXGPU_ERR_NOMEM = -5
+RXGPU_ERR_DEVICE = -6
+RXGPU_ERR_NOTFOUND = -7
+RXGPU_ERR_OVERFLOW = -8
+
+# every symbol include/rxgpu.h declares (tests/test_abi_symbols.py cross-checks this list against the header)
+_vp, _u32, _u64, _i, _f = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_float
+_SIGNATURES = {
+    "rxgpu_last_error": (C.c_char_p, []),
+    "rxgpu_abi_version": (_i, []),
+    "rxgpu_device_count": (_i, []),
+    "rxgpu_device_arch": (_i, [_i, C.c_char_p, C.c_size_t]),
+    "rxgpu_index_create": (_i, [_i, _u32, _u64, _i, C.POINTER(_vp)]),
+    "rxgpu_index_destroy": (None, [_vp]),
+    "rxgpu_index_reserve": (_i, [_vp, _u64]),
+    "rxgpu_index_upload_rows": (_i, [_vp, _u64, _u64, _vp, _vp]),
+    "rxgpu_index_adopt_device_rows": (_i, [_vp, _vp, _u64, _u32, _vp]),
+    "rxgpu_index_move_row": (_i, [_vp, _u64, _u64]),
+    "rxgpu_index_truncate": (_i, [_vp, _u64]),
+    "rxgpu_index_count": (_u64, [_vp]),
+    "rxgpu_index_capacity": (_u64, [_vp]),
+    "rxgpu_index_dim": (_u32, [_vp]),
+    "rxgpu_index_row_stride": (_u32, [_vp]),
+    "rxgpu_index_metric": (_i, [_vp]),
+    "rxgpu_index_device": (_i, [_vp]),
+    "rxgpu_index_device_bytes": (_u64, [_vp]),
+    "rxgpu_search_knn": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "rxgpu_search_knn_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "rxgpu_search_range": (_i, [_vp, _vp, _f, _i, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "rxgpu_distances": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "rxgpu_profile_enable": (_i, [_vp, _i]),
+    "rxgpu_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class RxGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rxgpu error {code}: {msg}")
+        self.code = code
+
+
+def declared_symbols() -> list[str]:
+    return sorted(_SIGNATURES)
+
+
+def lib() -> C.CDLL:
+    """Load librxgpu.so (once). Raises if it is not built — there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m reindexer_amd.build` "
+                "(hipcc --offload-arch=gfx950). The GPU engine has no CPU fallback.")
+        # RTLD_GLOBAL not needed; libamdhip64 resolves by SONAME to whatever the process already loaded (torch's copy)
+        _lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != RXGPU_OK:
+        raise RxGpuError(rc, lib().rxgpu_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = lib().rxgpu_device_count()
+    if n < 0:
+        _check(n)
+    return n
+
+
+def device_arch(device: int = 0) -> str:
+    buf = C.create_string_buffer(256)
+    _check(lib().rxgpu_device_arch(device, buf, 256))
+    return buf.value.decode()
+
+
+def _f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class VectorIndex:
+    """One float_vector index shard on one GPU (thin wrapper over rxgpu_index*)."""
+
+    def __init__(self, metric: int | str, dim: int, capacity: int = 0, device: int = 0):
+        if isinstance(metric, str):
+            metric = METRICS[metric.lower()]
+        self.metric, self.dim = int(metric), int(dim)
+        h = _vp()
+        _check(lib().rxgpu_index_create(self.metric, self.dim, capacity, device, C.byref(h)))
+        self._h = h
+        self._keepalive = None
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().rxgpu_index_destroy(self._h)
+            self._h = None
+            self._keepalive = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- storage
+    @property
+    def count(self) -> int:
+        return lib().rxgpu_index_count(self._h)
+
+    @property
+    def capacity(self) -> int:
+        return lib().rxgpu_index_capacity(self._h)
+
+    @property
+    def row_stride(self) -> int:
+        return lib().rxgpu_index_row_stride(self._h)
+
+    @property
+    def device_bytes(self) -> int:
+        return lib().rxgpu_index_device_bytes(self._h)
+
+    def reserve(self, capacity: int) -> None:
+        _check(lib().rxgpu_index_reserve(self._h, capacity))
+
+    def upload_rows(self, first_row: int, rows, inv_norms=None) -> None:
+        rows = _f32c(rows).reshape(-1, self.dim)
+        nptr = None
+        if inv_norms is not None:
+            inv_norms = _f32c(inv_norms).reshape(-1)
+            assert inv_norms.shape[0] == rows.shape[0]
+            nptr = inv_norms.ctypes.data
+        _check(lib().rxgpu_index_upload_rows(self._h, first_row, rows.shape[0], rows.ctypes.data, nptr))
+
+    def adopt_device_rows(self, d_rows_ptr: int, n: int, row_stride: int, d_inv_norms_ptr: int | None = None, keepalive=None) -> None:
+        _check(lib().rxgpu_index_adopt_device_rows(self._h, d_rows_ptr, n, row_stride, d_inv_norms_ptr))
+        self._keepalive = keepalive
+
+    def move_row(self, src: int, dst: int) -> None:
+        _check(lib().rxgpu_index_move_row(self._h, src, dst))
+
+    def truncate(self, count: int) -> None:
+        _check(lib().rxgpu_index_truncate(self._h, count))
+
+    # ---- search
+    def search_knn(self, queries, kk: int):
+        """-> (dist[nq,kk] f32, row[nq,kk] u32, count[nq] u32); exact top-kk under (dist,row) order."""
+        q = _f32c(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        dist = np.full((nq, max(kk, 1)), np.inf, np.float32)
+        row = np.full((nq, max(kk, 1)), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        _check(lib().rxgpu_search_knn(self._h, q.ctypes.data, nq, kk, dist.ctypes.data, row.ctypes.data, cnt.ctypes.data))
+        return dist[:, :kk], row[:, :kk], cnt
+
+    def search_knn_device(self, d_queries_ptr: int, nq: int, kk: int, d_out_dist_ptr: int, d_out_row_ptr: int,
+                          d_out_count_ptr: int | None, stream_ptr: int) -> None:
+        _check(lib().rxgpu_search_knn_device(self._h, d_queries_ptr, nq, kk, d_out_dist_ptr, d_out_row_ptr, d_out_count_ptr, stream_ptr))
+
+    def search_range(self, query, radius: float, inclusive: bool = False, cap: int = 1 << 16):
+        q = _f32c(query).reshape(self.dim)
+        while True:
+            dist = np.empty(cap, np.float32)
+            row = np.empty(cap, np.uint32)
+            total = _u64(0)
+            rc = lib().rxgpu_search_range(self._h, q.ctypes.data, radius, int(inclusive), dist.ctypes.data, row.ctypes.data, cap, C.byref(total))
+            if rc == RXGPU_ERR_OVERFLOW:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            return dist[: total.value].copy(), row[: total.value].copy()
+
+    def distances(self, query, rows) -> np.ndarray:
+        q = _f32c(query).reshape(self.dim)
+        r = np.ascontiguousarray(rows, dtype=np.uint32).reshape(-1)
+        out = np.empty(r.shape[0], np.float32)
+        _check(lib().rxgpu_distances(self._h, q.ctypes.data, r.ctypes.data, r.shape[0], out.ctypes.data))
+        return out
+
+    # ---- instrumentation
+    def profile_enable(self, on: bool = True) -> None:
+        _check(lib().rxgpu_profile_enable(self._h, int(on)))
+
+    def profile_read(self, name: str) -> tuple[int, float]:
+        n, ms = _u64(0), C.c_double(0.0)
+        _check(lib().rxgpu_profile_read(self._h, name.encode(), C.byref(n), C.byref(ms)))
+        return int(n.value), float(ms.value)
+
+
+def gpu_available() -> bool:
+    if os.environ.get("RXGPU_FORCE_NO_GPU"):
+        return False
+    try:
+        return device_count() > 0
+    except Exception:
+        return False

@@ -1,0 +1,191 @@
+// Brute-force float_vector KNN kernels for gfx950 (MI355X, wave64).
+//
+// What they replace (reference, CPU): BruteforceSearch::SearchKnn / SearchRange
+// (cpp_src/core/index/float_vector/hnswlib/bruteforce.cc:103-143) calling DistCalculator<float>
+// (hnswlib.h:147-165) -> L2SqrAVX512 / InnerProductAVX512 (tools/distances/l2_dist.cc:38-72, ip_dist.cc:31-70).
+//
+// Bit-exactness by construction.  The AVX-512 kernels keep 64 independent fmaf chains, chain L owning the
+// elements i == L (mod 64), then fold them with a fixed tree.  Here a row is owned by a 16-lane group of a
+// wavefront; lane m of the group loads the float4 at floats [64t+4m, 64t+4m+4) for every 64-float block t, so
+// it owns chains 4m..4m+3 completely and in order.  The fold (zmm s0+s1, s2+s3, then _mm512_reduce_add_ps)
+// becomes lane-xor 4, 8 (chain index xor 16, 32), lane-xor 2, 1 (chain xor 8, 4) and an in-lane (a0+a2)+(a1+a3).
+// IEEE add is commutative, so both partners of a butterfly step hold identical bits.  A wavefront therefore
+// scans 4 rows per step with 16-byte loads: 4 fully used 256-byte segments per load instruction.
+//
+// Roofline: HBM-bound, D*4 algorithmic bytes per row, ~0.5 flop/byte — no MFMA here on purpose.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rxgpu {
+
+constexpr int kWave = 64;
+constexpr int kGroup = 16;            // lanes per row
+constexpr int kRowsPerWave = 4;       // rows per wavefront step
+constexpr int kMaxFusedK = 64;        // per-wave register top-k capacity (one (dist,row) pair per lane)
+constexpr uint32_t kInvalidRow = 0xFFFFFFFFu;
+
+enum : int { kL2 = 0, kIP = 1, kCos = 2 };
+
+struct ScanParams {
+	const float* rows;        // [n][stride]
+	const float* inv_norms;   // [n] or nullptr (cosine only)
+	const float* queries;     // [nq][dim]
+	uint64_t n;
+	uint32_t stride;          // floats, multiple of 4
+	uint32_t dim;
+	uint32_t kk;              // entries kept per list (<= kMaxFusedK)
+	float* part_dist;         // [nq][gridDim.x][kk]
+	uint32_t* part_row;       // [nq][gridDim.x][kk]
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte row load; kStream = non-temporal (rows are read exactly once per scan — keep them out of L2/MALL's way)
+template <bool kStream>
+__device__ __forceinline__ float4 load_row4(const float4* p) {
+	f32x4 v;
+	if constexpr (kStream) {
+		v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+	} else {
+		v = *reinterpret_cast<const f32x4*>(p);
+	}
+	return make_float4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ bool pair_lt(float d1, uint32_t i1, float d2, uint32_t i2) {
+	// std::less<std::pair<float,label>> (priority_queue.h comparator of SearchResultQueue)
+	return d1 < d2 || (!(d2 < d1) && i1 < i2);
+}
+
+// Sorted (ascending by (dist,row)) list spread over the lanes of one wavefront: lane i holds the i-th best.
+struct WaveTopK {
+	float bd;
+	uint32_t bi;
+	float thr_d;       // entry kk-1 once the list is full, +inf before
+	uint32_t thr_i;
+	uint32_t filled;
+	uint32_t kk;
+
+	__device__ __forceinline__ void init(uint32_t kk_) {
+		bd = __builtin_inff();
+		bi = kInvalidRow;
+		thr_d = __builtin_inff();
+		thr_i = kInvalidRow;
+		filled = 0;
+		kk = kk_;
+	}
+	// (d, idx) must be wave-uniform.
+	__device__ __forceinline__ void insert(float d, uint32_t idx, int lane) {
+		const bool before = pair_lt(bd, bi, d, idx);
+		const uint32_t pos = __popcll(__ballot(before));
+		const float up_d = __shfl_up(bd, 1);
+		const uint32_t up_i = __shfl_up(bi, 1);
+		if (lane == int(pos)) {
+			bd = d;
+			bi = idx;
+		} else if (lane > int(pos)) {
+			bd = up_d;
+			bi = up_i;
+		}
+		if (filled < kk) ++filled;
+		if (filled == kk) {
+			thr_d = __shfl(bd, int(kk) - 1);
+			thr_i = __shfl(bi, int(kk) - 1);
+		}
+	}
+	__device__ __forceinline__ bool admits(float d, uint32_t idx) const { return filled < kk || pair_lt(d, idx, thr_d, thr_i); }
+};
+
+// Fold of the 64 chains; every lane of the group ends with the row's sum.  `acc` holds chains 4m..4m+3.
+template <bool kIpTail>
+__device__ __forceinline__ float fold_chains(float4 acc, const float* __restrict__ row, const float* __restrict__ q, uint32_t dim,
+											  int m) {
+	// zmm (s0+s1)+(s2+s3): chain L with L^16, then L^32  ==  lane m with m^4, then m^8
+	acc.x += __shfl_xor(acc.x, 4);
+	acc.y += __shfl_xor(acc.y, 4);
+	acc.z += __shfl_xor(acc.z, 4);
+	acc.w += __shfl_xor(acc.w, 4);
+	acc.x += __shfl_xor(acc.x, 8);
+	acc.y += __shfl_xor(acc.y, 8);
+	acc.z += __shfl_xor(acc.z, 8);
+	acc.w += __shfl_xor(acc.w, 8);
+	if constexpr (kIpTail) {
+		// ip_dist.cc:61-65: 16-wide fmadd loop into the folded vector; lane m owns elements 4(m&3)..+3 of it
+		const uint32_t i0 = dim & ~63u, i1 = dim & ~15u;
+		for (uint32_t i = i0; i < i1; i += 16) {
+			const float4 x = *reinterpret_cast<const float4*>(row + i + 4 * (m & 3));
+			const float4 qq = *reinterpret_cast<const float4*>(q + i + 4 * (m & 3));
+			acc.x = __builtin_fmaf(qq.x, x.x, acc.x);
+			acc.y = __builtin_fmaf(qq.y, x.y, acc.y);
+			acc.z = __builtin_fmaf(qq.z, x.z, acc.z);
+			acc.w = __builtin_fmaf(qq.w, x.w, acc.w);
+		}
+	}
+	// _mm512_reduce_add_ps: element c with c^8, then c^4  ==  lane m^2, then m^1; then (t0+t2)+(t1+t3)
+	acc.x += __shfl_xor(acc.x, 2);
+	acc.y += __shfl_xor(acc.y, 2);
+	acc.z += __shfl_xor(acc.z, 2);
+	acc.w += __shfl_xor(acc.w, 2);
+	acc.x += __shfl_xor(acc.x, 1);
+	acc.y += __shfl_xor(acc.y, 1);
+	acc.z += __shfl_xor(acc.z, 1);
+	acc.w += __shfl_xor(acc.w, 1);
+	return (acc.x + acc.z) + (acc.y + acc.w);
+}
+
+template <int kMetric>
+__device__ __forceinline__ void chain_step(float4& acc, const float4 q, const float4 x) {
+	if constexpr (kMetric == kL2) {
+		const float dx = q.x - x.x, dy = q.y - x.y, dz = q.z - x.z, dw = q.w - x.w;
+		acc.x = __builtin_fmaf(dx, dx, acc.x);
+		acc.y = __builtin_fmaf(dy, dy, acc.y);
+		acc.z = __builtin_fmaf(dz, dz, acc.z);
+		acc.w = __builtin_fmaf(dw, dw, acc.w);
+	} else {
+		acc.x = __builtin_fmaf(q.x, x.x, acc.x);
+		acc.y = __builtin_fmaf(q.y, x.y, acc.y);
+		acc.z = __builtin_fmaf(q.z, x.z, acc.z);
+		acc.w = __builtin_fmaf(q.w, x.w, acc.w);
+	}
+}
+
+// DistCalculator epilogue (hnswlib.h:147-165,192-197): alpha2 = 1, corrective offsets = 0 for fp32.
+template <int kMetric>
+__device__ __forceinline__ float metric_epilogue(float sum, const float* __restrict__ inv_norms, uint64_t row) {
+	if constexpr (kMetric == kL2) {
+		return 1.0f * sum + 0.0f + 0.0f;
+	} else {
+		float d = -(1.0f * sum + 0.0f + 0.0f);
+		if constexpr (kMetric == kCos) d *= inv_norms[row];
+		return d;
+	}
+}
+
+// Any-dimension distance of the row owned by this 16-lane group (all 16 lanes return the same bits).
+template <int kMetric>
+__device__ __forceinline__ float group_distance_generic(const float* __restrict__ row, const float* __restrict__ q, uint32_t dim,
+														 int m) {
+	float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+	const uint32_t nb = dim >> 6;
+	const float4* rp = reinterpret_cast<const float4*>(row) + m;
+	const float4* qp = reinterpret_cast<const float4*>(q) + m;
+#pragma unroll 4
+	for (uint32_t t = 0; t < nb; ++t) chain_step<kMetric>(acc, qp[16 * t], rp[16 * t]);
+	const float folded = fold_chains<kMetric != kL2>(acc, row, q, dim, m);
+	// scalar tail: sequential fmaf chain from 0 (l2_dist.cc:12-26 / ip_dist.cc:10-20 as built in the pinned oracle)
+	float tail = 0.0f;
+	const uint32_t t0 = kMetric == kL2 ? (dim & ~63u) : (dim & ~15u);
+	for (uint32_t i = t0; i < dim; ++i) {
+		if constexpr (kMetric == kL2) {
+			const float df = q[i] - row[i];
+			tail = __builtin_fmaf(df, df, tail);
+		} else {
+			tail = __builtin_fmaf(q[i], row[i], tail);
+		}
+	}
+	return folded + tail;
+}
+
+}  // namespace rxgpu

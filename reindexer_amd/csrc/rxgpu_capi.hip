@@ -1,0 +1,555 @@
+// C-ABI implementation (include/rxgpu.h): index storage in HBM, search entry points, instrumentation.
+// Host-side plumbing only — all arithmetic is in the kernels.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/rxgpu.h"
+#include "knn_kernels.hip.h"
+#include "rxgpu_internal.h"
+
+namespace rxgpu {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+}  // namespace rxgpu
+
+using rxgpu::set_error;
+
+#define RX_HIP(expr)                                                                                      \
+	do {                                                                                                  \
+		hipError_t e__ = (expr);                                                                          \
+		if (e__ != hipSuccess) {                                                                          \
+			set_error(std::string(#expr) + ": " + hipGetErrorString(e__));                                \
+			return e__ == hipErrorOutOfMemory ? RXGPU_ERR_NOMEM : RXGPU_ERR_DEVICE;                       \
+		}                                                                                                 \
+	} while (0)
+
+#define RX_CHECK(cond, code, msg) \
+	do {                          \
+		if (!(cond)) {            \
+			set_error(msg);       \
+			return code;          \
+		}                         \
+	} while (0)
+
+int rxgpu_devbuf::ensure(size_t need) {
+	if (need <= bytes) return RXGPU_OK;
+	if (ptr) (void)hipFree(ptr);
+	ptr = nullptr;
+	bytes = 0;
+	const size_t want = std::max<size_t>(need, 4096);
+	RX_HIP(hipMalloc(&ptr, want));
+	bytes = want;
+	return RXGPU_OK;
+}
+void rxgpu_devbuf::release() {
+	if (ptr) (void)hipFree(ptr);
+	ptr = nullptr;
+	bytes = 0;
+}
+int rxgpu_search_ctx::ensure_pinned(size_t need) {
+	if (need <= h_pinned_bytes) return RXGPU_OK;
+	if (h_pinned) (void)hipHostFree(h_pinned);
+	h_pinned = nullptr;
+	h_pinned_bytes = 0;
+	const size_t want = std::max<size_t>(need, 1 << 16);
+	RX_HIP(hipHostMalloc(&h_pinned, want, hipHostMallocDefault));
+	h_pinned_bytes = want;
+	return RXGPU_OK;
+}
+void rxgpu_search_ctx::release() {
+	d_queries.release();
+	d_part_dist.release();
+	d_part_row.release();
+	d_out_dist.release();
+	d_out_row.release();
+	d_out_count.release();
+	d_misc.release();
+	d_select.release();
+	if (h_pinned) (void)hipHostFree(h_pinned);
+	h_pinned = nullptr;
+	if (own_stream && stream) (void)hipStreamDestroy(stream);
+	stream = nullptr;
+}
+
+namespace {
+
+struct DeviceGuard {
+	int prev = -1;
+	bool ok = true;
+	explicit DeviceGuard(int dev) {
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+	}
+	~DeviceGuard() {
+		if (prev >= 0) (void)hipSetDevice(prev);
+	}
+};
+
+// Check out a scratch context with its own stream (host-synchronous searches).
+rxgpu_search_ctx* acquire_ctx(rxgpu_index* h) {
+	{
+		std::lock_guard<std::mutex> lk(h->mtx);
+		if (!h->free_ctx.empty()) {
+			auto* c = h->free_ctx.back();
+			h->free_ctx.pop_back();
+			return c;
+		}
+	}
+	auto* c = new rxgpu_search_ctx();
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete c;
+		set_error("hipStreamCreateWithFlags failed");
+		return nullptr;
+	}
+	c->own_stream = true;
+	return c;
+}
+void release_ctx(rxgpu_index* h, rxgpu_search_ctx* c) {
+	std::lock_guard<std::mutex> lk(h->mtx);
+	h->free_ctx.push_back(c);
+}
+// Scratch bound to a caller-owned stream: stream order makes reuse safe without synchronising.
+rxgpu_search_ctx* stream_ctx(rxgpu_index* h, void* stream) {
+	std::lock_guard<std::mutex> lk(h->mtx);
+	auto it = h->stream_ctx.find(stream);
+	if (it != h->stream_ctx.end()) return it->second;
+	auto* c = new rxgpu_search_ctx();
+	c->stream = static_cast<hipStream_t>(stream);
+	c->own_stream = false;
+	h->stream_ctx[stream] = c;
+	return c;
+}
+
+struct ProfileScope {
+	rxgpu_index* h;
+	const char* name;
+	hipStream_t s;
+	hipEvent_t a = nullptr, b = nullptr;
+	ProfileScope(rxgpu_index* h_, const char* n, hipStream_t s_) : h(h_), name(n), s(s_) {
+		if (!h->profiling) return;
+		if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+			a = b = nullptr;
+			return;
+		}
+		(void)hipEventRecord(a, s);
+	}
+	~ProfileScope() {
+		if (!a) return;
+		(void)hipEventRecord(b, s);
+		std::lock_guard<std::mutex> lk(h->mtx);
+		h->profile[name].events.emplace_back(a, b);
+	}
+};
+
+// Enqueue scan + merge for nq device-resident queries; results land in d_out_* (device).
+int enqueue_knn_fused(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
+					  uint32_t* d_out_row, uint32_t* d_out_count) {
+	const uint32_t gridx = rxgpu::scan_grid_x(h->count, h->cus);
+	const size_t part = size_t(nq) * gridx * kk;
+	if (int rc = c->d_part_dist.ensure(part * sizeof(float)); rc) return rc;
+	if (int rc = c->d_part_row.ensure(part * sizeof(uint32_t)); rc) return rc;
+	rxgpu::ScanParams p{};
+	p.rows = h->d_rows;
+	p.inv_norms = h->d_inv_norms;
+	p.queries = d_queries;
+	p.n = h->count;
+	p.stride = h->stride;
+	p.dim = h->dim;
+	p.kk = kk;
+	p.part_dist = static_cast<float*>(c->d_part_dist.ptr);
+	p.part_row = static_cast<uint32_t*>(c->d_part_row.ptr);
+	{
+		ProfileScope ps(h, "scan", c->stream);
+		rxgpu::launch_scan(h->metric, p, nq, gridx, c->stream);
+	}
+	{
+		ProfileScope ps(h, "merge", c->stream);
+		rxgpu::launch_merge(p.part_dist, p.part_row, gridx, kk, nq, d_out_dist, d_out_row, d_out_count, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	return RXGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rxgpu_last_error(void) { return rxgpu::g_err.c_str(); }
+int rxgpu_abi_version(void) { return RXGPU_ABI_VERSION; }
+
+int rxgpu_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		set_error("hipGetDeviceCount failed");
+		return RXGPU_ERR_DEVICE;
+	}
+	return n;
+}
+
+int rxgpu_device_arch(int device, char* name, size_t cap) {
+	hipDeviceProp_t prop;
+	RX_HIP(hipGetDeviceProperties(&prop, device));
+	std::snprintf(name, cap, "%s", prop.gcnArchName);
+	return RXGPU_OK;
+}
+
+int rxgpu_index_create(int metric, uint32_t dim, uint64_t capacity, int device, rxgpu_index** out) {
+	RX_CHECK(out, RXGPU_ERR_PARAMS, "rxgpu_index_create: out is null");
+	RX_CHECK(metric >= 0 && metric <= 2, RXGPU_ERR_PARAMS, "rxgpu_index_create: unknown metric");
+	RX_CHECK(dim > 0 && dim <= 65535, RXGPU_ERR_PARAMS, "rxgpu_index_create: dimension must be in [1, 65535]");
+	RX_CHECK(capacity < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_index_create: capacity must fit 32-bit rows");
+	int ndev = 0;
+	RX_HIP(hipGetDeviceCount(&ndev));
+	RX_CHECK(device >= 0 && device < ndev, RXGPU_ERR_PARAMS, "rxgpu_index_create: no such device");
+	DeviceGuard dg(device);
+	RX_CHECK(dg.ok, RXGPU_ERR_DEVICE, "rxgpu_index_create: hipSetDevice failed");
+	hipDeviceProp_t prop;
+	RX_HIP(hipGetDeviceProperties(&prop, device));
+	auto* h = new rxgpu_index();
+	h->metric = metric;
+	h->dim = dim;
+	h->stride = (dim + 3u) & ~3u;
+	h->device = device;
+	h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	*out = h;
+	if (capacity) {
+		if (int rc = rxgpu_index_reserve(h, capacity); rc) {
+			delete h;
+			*out = nullptr;
+			return rc;
+		}
+	}
+	return RXGPU_OK;
+}
+
+void rxgpu_index_destroy(rxgpu_index* h) {
+	if (!h) return;
+	DeviceGuard dg(h->device);
+	(void)hipDeviceSynchronize();
+	for (auto* c : h->free_ctx) {
+		c->release();
+		delete c;
+	}
+	for (auto& kv : h->stream_ctx) {
+		kv.second->release();
+		delete kv.second;
+	}
+	for (auto& kv : h->profile) {
+		for (auto& ev : kv.second.events) {
+			(void)hipEventDestroy(ev.first);
+			(void)hipEventDestroy(ev.second);
+		}
+	}
+	if (!h->adopted) {
+		if (h->d_rows) (void)hipFree(h->d_rows);
+		if (h->d_inv_norms) (void)hipFree(h->d_inv_norms);
+	}
+	delete h;
+}
+
+int rxgpu_index_reserve(rxgpu_index* h, uint64_t capacity) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(!h->adopted, RXGPU_ERR_LOGIC, "rxgpu_index_reserve: storage is adopted (caller-owned)");
+	RX_CHECK(capacity >= h->count, RXGPU_ERR_PARAMS, "Cannot resize, max element is less than the current number of elements");
+	RX_CHECK(capacity < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "capacity must fit 32-bit rows");
+	if (capacity == h->capacity) return RXGPU_OK;
+	DeviceGuard dg(h->device);
+	float* nrows = nullptr;
+	float* nnorm = nullptr;
+	if (capacity) {
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&nrows), capacity * h->stride * sizeof(float)));
+		if (h->metric == RXGPU_METRIC_COSINE) {
+			hipError_t e = hipMalloc(reinterpret_cast<void**>(&nnorm), capacity * sizeof(float));
+			if (e != hipSuccess) {
+				(void)hipFree(nrows);
+				set_error("Not enough memory: failed to allocate norm coefficients");
+				return RXGPU_ERR_NOMEM;
+			}
+		}
+		if (h->count) {
+			RX_HIP(hipMemcpy(nrows, h->d_rows, h->count * h->stride * sizeof(float), hipMemcpyDeviceToDevice));
+			if (nnorm) RX_HIP(hipMemcpy(nnorm, h->d_inv_norms, h->count * sizeof(float), hipMemcpyDeviceToDevice));
+		}
+	}
+	if (h->d_rows) (void)hipFree(h->d_rows);
+	if (h->d_inv_norms) (void)hipFree(h->d_inv_norms);
+	h->d_rows = nrows;
+	h->d_inv_norms = nnorm;
+	h->capacity = capacity;
+	return RXGPU_OK;
+}
+
+int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, const float* rows, const float* inv_norms) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(!h->adopted, RXGPU_ERR_LOGIC, "rxgpu_index_upload_rows: storage is adopted (caller-owned)");
+	if (n == 0) return RXGPU_OK;
+	RX_CHECK(rows, RXGPU_ERR_PARAMS, "rxgpu_index_upload_rows: rows is null");
+	RX_CHECK(first_row + n <= h->capacity, RXGPU_ERR_PARAMS, "The number of elements exceeds the specified limit");
+	RX_CHECK(h->metric != RXGPU_METRIC_COSINE || inv_norms, RXGPU_ERR_PARAMS, "cosine index requires inv_norms");
+	DeviceGuard dg(h->device);
+	float* dst = h->d_rows + first_row * h->stride;
+	if (h->stride == h->dim) {
+		RX_HIP(hipMemcpy(dst, rows, n * h->dim * sizeof(float), hipMemcpyHostToDevice));
+	} else {
+		RX_HIP(hipMemcpy2D(dst, h->stride * sizeof(float), rows, h->dim * sizeof(float), h->dim * sizeof(float), n, hipMemcpyHostToDevice));
+	}
+	if (h->metric == RXGPU_METRIC_COSINE) {
+		RX_HIP(hipMemcpy(h->d_inv_norms + first_row, inv_norms, n * sizeof(float), hipMemcpyHostToDevice));
+	}
+	h->count = std::max(h->count, first_row + n);
+	return RXGPU_OK;
+}
+
+int rxgpu_index_adopt_device_rows(rxgpu_index* h, const void* d_rows, uint64_t n, uint32_t row_stride, const void* d_inv_norms) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(d_rows || n == 0, RXGPU_ERR_PARAMS, "rxgpu_index_adopt_device_rows: d_rows is null");
+	RX_CHECK(row_stride >= h->dim && row_stride % 4 == 0, RXGPU_ERR_PARAMS, "row_stride must be >= dim and a multiple of 4 floats");
+	RX_CHECK((reinterpret_cast<uintptr_t>(d_rows) & 15) == 0, RXGPU_ERR_PARAMS, "d_rows must be 16-byte aligned");
+	RX_CHECK(n < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "n must fit 32-bit rows");
+	RX_CHECK(h->metric != RXGPU_METRIC_COSINE || d_inv_norms || n == 0, RXGPU_ERR_PARAMS, "cosine index requires d_inv_norms");
+	DeviceGuard dg(h->device);
+	if (!h->adopted) {
+		if (h->d_rows) (void)hipFree(h->d_rows);
+		if (h->d_inv_norms) (void)hipFree(h->d_inv_norms);
+	}
+	h->adopted = true;
+	h->d_rows = const_cast<float*>(static_cast<const float*>(d_rows));
+	h->d_inv_norms = const_cast<float*>(static_cast<const float*>(d_inv_norms));
+	h->stride = row_stride;
+	h->capacity = n;
+	h->count = n;
+	return RXGPU_OK;
+}
+
+int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(!h->adopted, RXGPU_ERR_LOGIC, "rxgpu_index_move_row: storage is adopted (caller-owned)");
+	RX_CHECK(from < h->count && to < h->count, RXGPU_ERR_PARAMS, "rxgpu_index_move_row: row out of range");
+	if (from == to) return RXGPU_OK;
+	DeviceGuard dg(h->device);
+	RX_HIP(hipMemcpy(h->d_rows + to * h->stride, h->d_rows + from * h->stride, h->stride * sizeof(float), hipMemcpyDeviceToDevice));
+	if (h->d_inv_norms) RX_HIP(hipMemcpy(h->d_inv_norms + to, h->d_inv_norms + from, sizeof(float), hipMemcpyDeviceToDevice));
+	return RXGPU_OK;
+}
+
+int rxgpu_index_truncate(rxgpu_index* h, uint64_t count) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(count <= h->capacity, RXGPU_ERR_PARAMS, "rxgpu_index_truncate: count exceeds capacity");
+	h->count = count;
+	return RXGPU_OK;
+}
+
+uint64_t rxgpu_index_count(const rxgpu_index* h) { return h ? h->count : 0; }
+uint64_t rxgpu_index_capacity(const rxgpu_index* h) { return h ? h->capacity : 0; }
+uint32_t rxgpu_index_dim(const rxgpu_index* h) { return h ? h->dim : 0; }
+uint32_t rxgpu_index_row_stride(const rxgpu_index* h) { return h ? h->stride : 0; }
+int rxgpu_index_metric(const rxgpu_index* h) { return h ? h->metric : -1; }
+int rxgpu_index_device(const rxgpu_index* h) { return h ? h->device : -1; }
+uint64_t rxgpu_index_device_bytes(const rxgpu_index* h) {
+	if (!h) return 0;
+	return h->capacity * h->stride * sizeof(float) + (h->d_inv_norms ? h->capacity * sizeof(float) : 0);
+}
+
+int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, void* d_out_dist, void* d_out_row,
+							void* d_out_count, void* stream) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(nq > 0 && d_queries && d_out_dist && d_out_row, RXGPU_ERR_PARAMS, "rxgpu_search_knn_device: null argument");
+	RX_CHECK(kk > 0 && kk <= uint32_t(rxgpu::kMaxFusedK), RXGPU_ERR_PARAMS, "rxgpu_search_knn_device: kk must be in [1, 64]");
+	RX_CHECK(h->count > 0, RXGPU_ERR_PARAMS, "rxgpu_search_knn_device: index is empty");
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = stream_ctx(h, stream);
+	return enqueue_knn_fused(h, c, static_cast<const float*>(d_queries), nq, kk, static_cast<float*>(d_out_dist),
+							 static_cast<uint32_t*>(d_out_row), static_cast<uint32_t*>(d_out_count));
+}
+
+int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, float* out_dist, uint32_t* out_row,
+					 uint32_t* out_count) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(queries && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_search_knn: null argument");
+	if (nq == 0) return RXGPU_OK;
+	if (h->count == 0 || kk == 0) {   // bruteforce.cc:106-108
+		std::fill(out_count, out_count + nq, 0u);
+		return RXGPU_OK;
+	}
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	const uint32_t eff = uint32_t(std::min<uint64_t>(kk, h->count));
+	const size_t qbytes = size_t(nq) * h->dim * sizeof(float);
+	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, qbytes, hipMemcpyHostToDevice, c->stream));
+
+	if (eff <= uint32_t(rxgpu::kMaxFusedK)) {
+		if (int rc = c->d_out_dist.ensure(size_t(nq) * eff * sizeof(float)); rc) return rc;
+		if (int rc = c->d_out_row.ensure(size_t(nq) * eff * sizeof(uint32_t)); rc) return rc;
+		if (int rc = c->d_out_count.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
+		if (int rc = enqueue_knn_fused(h, c, static_cast<const float*>(c->d_queries.ptr), nq, eff, static_cast<float*>(c->d_out_dist.ptr),
+									   static_cast<uint32_t*>(c->d_out_row.ptr), static_cast<uint32_t*>(c->d_out_count.ptr));
+			rc)
+			return rc;
+		if (eff == kk) {
+			RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * eff * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * eff * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		} else {
+			RX_HIP(hipMemcpy2DAsync(out_dist, kk * sizeof(float), c->d_out_dist.ptr, eff * sizeof(float), eff * sizeof(float), nq,
+									hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpy2DAsync(out_row, kk * sizeof(uint32_t), c->d_out_row.ptr, eff * sizeof(uint32_t), eff * sizeof(uint32_t), nq,
+									hipMemcpyDeviceToHost, c->stream));
+		}
+		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));
+		return RXGPU_OK;
+	}
+
+	// large-k path: distance pass + radix select per query, final (dist,row) sort of kk entries on the host
+	if (int rc = c->d_misc.ensure(h->count * sizeof(float)); rc) return rc;
+	if (int rc = c->d_select.ensure(rxgpu::select_scratch_bytes(h->count)); rc) return rc;
+	if (int rc = c->d_out_dist.ensure(size_t(eff) * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(size_t(eff) * sizeof(uint32_t)); rc) return rc;
+	const uint32_t gridx = rxgpu::scan_grid_x(h->count, h->cus);
+	std::vector<float> hd(eff);
+	std::vector<uint32_t> hr(eff), order(eff);
+	for (uint32_t q = 0; q < nq; ++q) {
+		{
+			ProfileScope ps(h, "scan", c->stream);
+			rxgpu::launch_all_distances(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr) + size_t(q) * h->dim,
+										h->count, h->stride, h->dim, static_cast<float*>(c->d_misc.ptr), gridx, c->stream);
+		}
+		{
+			ProfileScope ps(h, "select", c->stream);
+			rxgpu::launch_select_smallest(static_cast<const float*>(c->d_misc.ptr), h->count, eff, c->d_select.ptr,
+										  static_cast<float*>(c->d_out_dist.ptr), static_cast<uint32_t*>(c->d_out_row.ptr), c->stream);
+		}
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipMemcpyAsync(hd.data(), c->d_out_dist.ptr, size_t(eff) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(hr.data(), c->d_out_row.ptr, size_t(eff) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));
+		std::iota(order.begin(), order.end(), 0u);
+		std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+			return hd[a] < hd[b] || (!(hd[b] < hd[a]) && hr[a] < hr[b]);
+		});
+		for (uint32_t i = 0; i < eff; ++i) {
+			out_dist[size_t(q) * kk + i] = hd[order[i]];
+			out_row[size_t(q) * kk + i] = hr[order[i]];
+		}
+		out_count[q] = eff;
+	}
+	return RXGPU_OK;
+}
+
+int rxgpu_search_range(rxgpu_index* h, const float* query, float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap,
+					   uint64_t* out_total) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(query && out_total && (cap == 0 || (out_dist && out_row)), RXGPU_ERR_PARAMS, "rxgpu_search_range: null argument");
+	*out_total = 0;
+	if (h->count == 0) return RXGPU_OK;   // bruteforce.cc:132-134
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	const uint64_t dcap = std::min<uint64_t>(cap, h->count);
+	if (int rc = c->d_queries.ensure(h->dim * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_dist.ensure(std::max<uint64_t>(dcap, 1) * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(std::max<uint64_t>(dcap, 1) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_out_count.ensure(sizeof(unsigned long long)); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, query, h->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+	RX_HIP(hipMemsetAsync(c->d_out_count.ptr, 0, sizeof(unsigned long long), c->stream));
+	{
+		ProfileScope ps(h, "range", c->stream);
+		rxgpu::launch_range(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr), h->count, h->stride, h->dim,
+							radius, inclusive, static_cast<float*>(c->d_out_dist.ptr), static_cast<uint32_t*>(c->d_out_row.ptr), dcap,
+							static_cast<unsigned long long*>(c->d_out_count.ptr), rxgpu::scan_grid_x(h->count, h->cus), c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	unsigned long long total = 0;
+	RX_HIP(hipMemcpyAsync(&total, c->d_out_count.ptr, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	*out_total = total;
+	if (total > cap) {
+		set_error("rxgpu_search_range: output buffer too small");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	if (total == 0) return RXGPU_OK;
+	std::vector<float> hd(total);
+	std::vector<uint32_t> hr(total), order(total);
+	RX_HIP(hipMemcpy(hd.data(), c->d_out_dist.ptr, total * sizeof(float), hipMemcpyDeviceToHost));
+	RX_HIP(hipMemcpy(hr.data(), c->d_out_row.ptr, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	std::iota(order.begin(), order.end(), 0u);
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hd[a] < hd[b] || (!(hd[b] < hd[a]) && hr[a] < hr[b]); });
+	for (uint64_t i = 0; i < total; ++i) {
+		out_dist[i] = hd[order[i]];
+		out_row[i] = hr[order[i]];
+	}
+	return RXGPU_OK;
+}
+
+int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(query && (n == 0 || (rows && out_dist)), RXGPU_ERR_PARAMS, "rxgpu_distances: null argument");
+	if (n == 0) return RXGPU_OK;
+	for (uint32_t i = 0; i < n; ++i) RX_CHECK(rows[i] < h->count, RXGPU_ERR_PARAMS, "rxgpu_distances: row out of range");
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	if (int rc = c->d_queries.ensure(h->dim * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(size_t(n) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_out_dist.ensure(size_t(n) * sizeof(float)); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, query, h->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+	RX_HIP(hipMemcpyAsync(c->d_out_row.ptr, rows, size_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	rxgpu::launch_distances(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr), h->stride, h->dim,
+							static_cast<const uint32_t*>(c->d_out_row.ptr), n, static_cast<float*>(c->d_out_dist.ptr), c->stream);
+	RX_HIP(hipGetLastError());
+	RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(n) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	return RXGPU_OK;
+}
+
+int rxgpu_profile_enable(rxgpu_index* h, int on) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	for (auto& kv : h->profile) {
+		for (auto& ev : kv.second.events) {
+			(void)hipEventDestroy(ev.first);
+			(void)hipEventDestroy(ev.second);
+		}
+	}
+	h->profile.clear();
+	h->profiling = on != 0;
+	return RXGPU_OK;
+}
+
+int rxgpu_profile_read(rxgpu_index* h, const char* name, uint64_t* launches, double* total_ms) {
+	RX_CHECK(h && name && launches && total_ms, RXGPU_ERR_PARAMS, "rxgpu_profile_read: null argument");
+	*launches = 0;
+	*total_ms = 0.0;
+	std::lock_guard<std::mutex> lk(h->mtx);
+	auto it = h->profile.find(name);
+	if (it == h->profile.end()) return RXGPU_OK;
+	DeviceGuard dg(h->device);
+	for (auto& ev : it->second.events) {
+		RX_HIP(hipEventSynchronize(ev.second));
+		float ms = 0.f;
+		RX_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+		*total_ms += ms;
+		++*launches;
+	}
+	return RXGPU_OK;
+}
+
+}  // extern "C"

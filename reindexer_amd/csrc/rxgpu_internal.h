@@ -1,0 +1,80 @@
+// Internal declarations shared by the C-ABI implementation and the kernel translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace rxgpu {
+
+struct ScanParams;
+
+uint32_t scan_grid_x(uint64_t n, int cus);
+void launch_scan(int metric, const ScanParams& p, uint32_t nq, uint32_t gridx, hipStream_t s);
+void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t nparts, uint32_t kk, uint32_t nq, float* out_dist,
+				  uint32_t* out_row, uint32_t* out_count, hipStream_t s);
+void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,
+				  float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap, unsigned long long* counter,
+				  uint32_t gridx, hipStream_t s);
+void launch_distances(int metric, const float* rows, const float* inv_norms, const float* query, uint32_t stride, uint32_t dim,
+					  const uint32_t* ids, uint32_t n, float* out, hipStream_t s);
+
+// Large-k path (k+1 > 64): distance pass + radix select (knn_select.hip).
+void launch_all_distances(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride,
+						  uint32_t dim, float* out_dist, uint32_t gridx, hipStream_t s);
+size_t select_scratch_bytes(uint64_t n);
+// Finds the kk smallest (dist,row) of d_dist[0..n) ; writes them UNSORTED to d_out_*; *d_out_n (device) = count (== min(kk,n)).
+void launch_select_smallest(const float* d_dist, uint64_t n, uint32_t kk, void* d_scratch, float* d_out_dist, uint32_t* d_out_row,
+							hipStream_t s);
+
+void set_error(const std::string& msg);
+
+}  // namespace rxgpu
+
+// A growable device buffer.
+struct rxgpu_devbuf {
+	void* ptr = nullptr;
+	size_t bytes = 0;
+	int ensure(size_t need);
+	void release();
+};
+
+// Per-search scratch: one is checked out per host-side search call (or bound to a caller stream).
+struct rxgpu_search_ctx {
+	hipStream_t stream = nullptr;
+	bool own_stream = false;
+	rxgpu_devbuf d_queries, d_part_dist, d_part_row, d_out_dist, d_out_row, d_out_count, d_misc, d_select;
+	void* h_pinned = nullptr;
+	size_t h_pinned_bytes = 0;
+	int ensure_pinned(size_t need);
+	void release();
+};
+
+struct rxgpu_profile_slot {
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+
+struct rxgpu_index {
+	int metric = 0;
+	uint32_t dim = 0;
+	uint32_t stride = 0;     // floats per row in HBM
+	uint64_t capacity = 0;   // rows allocated (owned storage only)
+	uint64_t count = 0;
+	int device = 0;
+	int cus = 256;
+
+	float* d_rows = nullptr;       // owned or adopted
+	float* d_inv_norms = nullptr;  // cosine only
+	bool adopted = false;
+
+	std::mutex mtx;  // guards ctx pool + profile state
+	std::vector<rxgpu_search_ctx*> free_ctx;
+	std::map<void*, rxgpu_search_ctx*> stream_ctx;
+
+	bool profiling = false;
+	std::map<std::string, rxgpu_profile_slot> profile;
+};

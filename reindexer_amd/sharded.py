@@ -1,0 +1,111 @@
+"""Row-range sharding of a float_vector index over the GPUs of one node.
+
+One process per GPU.  Every rank holds rows [rank*shard_rows, (rank+1)*shard_rows) of the corpus as its own
+rxgpu index and receives the same query.  The only exchange is one all-gather per query batch of the per-shard top-kk
+(kk * 8 bytes per rank per query: f32 distance + u32 shard-local row) over RCCL/xGMI — latency-bound, so everything for
+one batch goes in ONE collective.  Each rank then merges with the same total order the single-index engine uses:
+(dist, global row) ascending == the eviction order of the reference's (dist,label) max-heap
+(hnswlib/bruteforce.cc:103-127, priority_queue.h), with global row = rank * shard_rows + local row.
+The reference has no counterpart (it has no device notion); the merged result equals what one index over the whole
+corpus returns, which is what the tests assert.
+
+torch / torch.distributed are plumbing here: device memory, streams and the collective.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def _orderable_i32(dist: torch.Tensor) -> torch.Tensor:
+    """float32 -> int32 whose signed order equals the float order; -0.0 and +0.0 map to the same value."""
+    bits = (dist + 0.0).contiguous().view(torch.int32)
+    return bits ^ ((bits >> 31) & 0x7FFFFFFF)
+
+
+def pack_topk(dist: torch.Tensor, row: torch.Tensor, row_base: int = 0) -> torch.Tensor:
+    """Pack a shard-local top list for the wire: int64 [..., kk] = (dist bits << 32) | local row (row_base unused here,
+    kept for symmetry; the rank index supplies the base after the gather)."""
+    del row_base
+    d = dist.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    r = row.to(torch.int64) & 0xFFFFFFFF
+    return (d << 32) | r
+
+
+def unpack_topk(packed: torch.Tensor):
+    d = ((packed >> 32) & 0xFFFFFFFF).to(torch.int32).view(torch.float32)  # low 32 bits reinterpret
+    r = packed & 0xFFFFFFFF
+    return d, r
+
+
+def merge_shard_topk(gathered: torch.Tensor, kk: int, shard_rows: int | None = None, invalid_row: int = 0xFFFFFFFF) -> torch.Tensor:
+    """gathered: int64 [world, kk] (one query) or [world, nq, kk] of pack_topk() lists.
+    Returns int64 [kk] / [nq, kk]: (dist bits << 32 | ...) is not order-preserving, so the result is re-packed as
+    [..., kk, 2] -> (dist bits, global row) pairs in two int64 lanes."""
+    single = gathered.dim() == 2
+    g = gathered.unsqueeze(1) if single else gathered           # [world, nq, kk]
+    world, nq, k_in = g.shape
+    dist_bits = ((g >> 32) & 0xFFFFFFFF).to(torch.int32)
+    local_row = g & 0xFFFFFFFF
+    valid = local_row != invalid_row
+    if shard_rows is None:
+        shard_rows = 1 << 32
+    base = torch.arange(world, device=g.device, dtype=torch.int64).view(world, 1, 1) * shard_rows
+    global_row = local_row + base
+    key_hi = _orderable_i32(dist_bits.view(torch.float32)).to(torch.int64)
+    # sort key: (orderable dist, global row); invalid entries last
+    key_hi = torch.where(valid, key_hi, torch.full_like(key_hi, 1 << 31))
+    flat_hi = key_hi.permute(1, 0, 2).reshape(nq, world * k_in)
+    flat_row = global_row.permute(1, 0, 2).reshape(nq, world * k_in)
+    flat_bits = dist_bits.permute(1, 0, 2).reshape(nq, world * k_in).to(torch.int64) & 0xFFFFFFFF
+    # two-pass stable sort = lexicographic (hi, row)
+    o1 = torch.argsort(flat_row, dim=1, stable=True)
+    hi1 = torch.gather(flat_hi, 1, o1)
+    o2 = torch.argsort(hi1, dim=1, stable=True)
+    order = torch.gather(o1, 1, o2)[:, :kk]
+    out = torch.stack([torch.gather(flat_bits, 1, order), torch.gather(flat_row, 1, order)], dim=-1)  # [nq, kk, 2]
+    bad = torch.gather(flat_hi, 1, order) == (1 << 31)
+    out[..., 1] = torch.where(bad, torch.full_like(out[..., 1], -1), out[..., 1])
+    return out[0] if single else out
+
+
+class ShardedBruteforce:
+    """Row-sharded brute-force KNN: local scan on this rank's GPU + one all-gather + merge.
+
+    local_search(queries[nq,dim] tensor, kk) -> (dist[nq,kk] f32 tensor, row[nq,kk] int tensor) is injected so the
+    exchange/merge logic runs unchanged on CPU under gloo in the tests; on a GPU box it is the rxgpu index of this rank.
+    """
+
+    def __init__(self, local_search, shard_rows: int, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.local_search = local_search
+        self.shard_rows = int(shard_rows)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def search(self, queries: torch.Tensor, kk: int):
+        """-> (dist[nq,kk] f32, global_row[nq,kk] i64) identical on every rank."""
+        d, r = self.local_search(queries, kk)
+        packed = pack_topk(d, r)                                  # [nq, kk]
+        if self.world > 1:
+            gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+            self._dist.all_gather_into_tensor(gathered.view(-1), packed.contiguous().view(-1), group=self.group)
+        else:
+            gathered = packed.unsqueeze(0)
+        merged = merge_shard_topk(gathered, kk, self.shard_rows)  # [nq, kk, 2]
+        dist_out = merged[..., 0].to(torch.int32).view(torch.float32)
+        return dist_out, merged[..., 1]
+
+
+def rxgpu_local_search(index, device):
+    """Adapter: an rxgpu VectorIndex shard as the local_search of ShardedBruteforce (device tensors in/out)."""
+    def run(queries: torch.Tensor, kk: int):
+        q = queries.to(device=device, dtype=torch.float32).contiguous()
+        nq = q.shape[0]
+        d = torch.empty((nq, kk), dtype=torch.float32, device=device)
+        r = torch.empty((nq, kk), dtype=torch.int32, device=device)
+        stream = torch.cuda.current_stream(device)
+        index.search_knn_device(q.data_ptr(), nq, kk, d.data_ptr(), r.data_ptr(), None, stream.cuda_stream)
+        return d, r
+    return run

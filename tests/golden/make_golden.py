@@ -1,0 +1,84 @@
+"""Generates tests/golden/*.npz from the REAL reference engines (oracle/_ref, built in place from
+/root/reference by `make -C oracle ref`).  Run in the build container only:
+
+    RX_TARGET_INSTRUCTIONS=avx512 python tests/golden/make_golden.py
+
+The fixtures pin (a) the plain-C oracle and (b) the HIP kernels on machines where /root/reference does not exist.
+Reference entry points exercised: L2SqrDistance / InnerProductDistance (tools/distances), CalculateL2Module
+(tools/normalize.cc), BruteforceSearch::{AddPointNoLock,RemovePoint,SearchKnn,SearchRange} (hnswlib/bruteforce.cc).
+"""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
+
+from oracle.pyoracle import Ref, RefBruteforce  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+DIMS = [1, 7, 16, 33, 64, 100, 128, 200, 512, 768, 1000]
+
+
+def main():
+    ref = Ref()
+    assert ref.simd_level == 3, "golden vectors must be generated with the AVX-512 dispatch"
+    rng = np.random.default_rng(20260924)
+
+    # ---- distances + norms
+    dist = {}
+    for d in DIMS:
+        rows = rng.normal(0, 0.25, (48, d)).astype(np.float32)
+        q = rng.normal(0, 0.25, d).astype(np.float32)
+        dist[f"rows_{d}"] = rows
+        dist[f"q_{d}"] = q
+        dist[f"l2_{d}"] = ref.dist_many(0, q, rows)
+        dist[f"ip_{d}"] = ref.dist_many(1, q, rows)
+        norm_in = rows.copy()
+        norm_in[0] = norm_in[0] / np.linalg.norm(norm_in[0])  # unit-vector shortcut
+        norm_in[1] = 0
+        dist[f"norm_in_{d}"] = norm_in
+        dist[f"norm_{d}"] = np.array([ref.l2_module(v) for v in norm_in], np.float32)
+    np.savez_compressed(OUT / "distances.npz", **dist)
+
+    # ---- brute-force KNN (with swap-deletes, ties, k > N, range)
+    cases = {}
+    for name, n, d, gen in (("gauss", 800, 128, lambda s: rng.normal(0, 0.25, s).astype(np.float32)),
+                            ("ties", 600, 8, lambda s: rng.integers(-1, 2, s).astype(np.float32))):
+        rows = gen((n, d))
+        labels = ((rng.permutation(n).astype(np.uint64)) << np.uint64(32)) | rng.integers(0, 3, n).astype(np.uint64)
+        victims = rng.choice(n, 25, replace=False)
+        queries = gen((12, d))
+        cases[f"{name}_rows"] = rows
+        cases[f"{name}_labels"] = labels
+        cases[f"{name}_victims"] = victims
+        cases[f"{name}_queries"] = queries
+        for metric in (0, 1, 2):
+            bf = RefBruteforce(ref, metric, d, n)
+            bf.add(rows, labels)
+            for v in victims:
+                bf.remove(labels[v])
+            for qi in range(queries.shape[0]):
+                q = queries[qi]
+                if metric == 2:
+                    q, _ = ref.normalize_copy(q)
+                for k in (1, 10, 64, 100, n):
+                    dd, ll = bf.search_knn(q, k)
+                    cases[f"{name}_m{metric}_q{qi}_k{k}_dist"] = dd
+                    cases[f"{name}_m{metric}_q{qi}_k{k}_label"] = ll
+                dd, ll = bf.search_knn(q, n)
+                radius = np.float32(dd[20])  # strict '<' excludes the 21st itself (and its ties)
+                rd, rl = bf.search_range(q, float(radius))
+                cases[f"{name}_m{metric}_q{qi}_radius"] = np.array([radius], np.float32)
+                cases[f"{name}_m{metric}_q{qi}_range_dist"] = rd
+                cases[f"{name}_m{metric}_q{qi}_range_label"] = rl
+            bf.close()
+    np.savez_compressed(OUT / "bruteforce.npz", **cases)
+    print("wrote", [p.name for p in OUT.glob("*.npz")])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""CPU-only: pins the plain-C restatement (oracle/oracle_knn.c) bit-for-bit to the REAL reference engines
+compiled in place from /root/reference (oracle/_ref).  Skipped where the reference build is absent
+(the GPU box relies on tests/golden/ instead, generated from the same reference build)."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import RefBruteforce
+from .conftest import make_corpus
+
+DIMS = [1, 3, 7, 15, 16, 17, 31, 33, 48, 63, 64, 65, 100, 128, 130, 200, 256, 384, 512, 768, 1000, 1024, 1536]
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("d", DIMS)
+def test_distance_bits_match_reference(oracle, ref, d):
+    rows = make_corpus(100 + d, 4000, d)
+    q = make_corpus(7 + d, 1, d)[0]
+    for metric in (0, 1):
+        want = ref.dist_many(metric, q, rows)
+        got = oracle.dist_many(metric, q, rows) if metric == 0 else -oracle.dist_many(1, q, rows)
+        assert np.array_equal(bits(want), bits(got)), f"metric={metric} d={d}"
+
+
+def test_distance_bits_one_million_pairs(oracle, ref):
+    """the equality is a property of the pinned oracle build; keep a large bitwise test."""
+    for d in (128, 768):
+        n = 1_000_000 * 128 // d // 2
+        rows = make_corpus(11, n, d)
+        for qi in range(2):
+            q = make_corpus(1000 + qi, 1, d)[0]
+            for metric in (0, 1):
+                want = ref.dist_many(metric, q, rows)
+                got = oracle.dist_many(0, q, rows) if metric == 0 else -oracle.dist_many(1, q, rows)
+                assert np.array_equal(bits(want), bits(got))
+
+
+@pytest.mark.parametrize("d", [1, 5, 64, 100, 128, 768])
+def test_norm_coefficient_bits(oracle, ref, d):
+    rng = np.random.default_rng(d)
+    for it in range(300):
+        x = rng.normal(0, 0.25, d).astype(np.float32)
+        if it % 4 == 0:
+            x = (x / max(np.linalg.norm(x), 1e-9)).astype(np.float32)  # exercises the |1-|x|^2| <= 1e-5 shortcut
+        if it % 97 == 0:
+            x[:] = 0
+        assert bits(ref.l2_module(x)) == bits(oracle.l2_module(x))
+        a, ka = ref.normalize_copy(x)
+        b, kb = oracle.normalize_copy(x)
+        assert np.array_equal(bits(a), bits(b)) and bits(ka) == bits(kb)
+
+
+def quantized_corpus(seed, n, d):
+    """Few distinct values per component => many exactly equal distances (tie semantics)."""
+    rng = np.random.default_rng(seed)
+    return rng.integers(-1, 2, (n, d)).astype(np.float32)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("kind", ["gauss", "ties"])
+def test_bruteforce_knn_and_range_match_reference(oracle, ref, metric, kind):
+    d, n = (128, 3000) if kind == "gauss" else (8, 1500)
+    rows = make_corpus(5, n, d) if kind == "gauss" else quantized_corpus(5, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(0)
+    rng = np.random.default_rng(9)
+    labels = labels[rng.permutation(n)]  # label order != insertion order
+    bf = RefBruteforce(ref, metric, d, n)
+    bf.add(rows, labels)
+    # delete some rows: the reference swaps the last row into the hole (bruteforce.cc:70-86)
+    live_rows, live_labels = rows.copy(), labels.copy()
+    cnt = n
+    for victim in rng.choice(n, 40, replace=False):
+        lab = labels[victim]
+        pos = int(np.nonzero(live_labels[:cnt] == lab)[0][0])
+        bf.remove(lab)
+        if pos + 1 != cnt:
+            live_rows[pos] = live_rows[cnt - 1]
+            live_labels[pos] = live_labels[cnt - 1]
+        cnt -= 1
+    assert bf.count == cnt
+    live_rows, live_labels = live_rows[:cnt], live_labels[:cnt]
+    inv = oracle.l2_modules(live_rows) if metric == 2 else None
+    for qi in range(25):
+        q = make_corpus(100 + qi, 1, d)[0] if kind == "gauss" else quantized_corpus(100 + qi, 1, d)[0]
+        if metric == 2:
+            q, _ = oracle.normalize_copy(q)
+        for k in (1, 10, 37, cnt, cnt + 5):
+            wd, wl = bf.search_knn(q, k)
+            gd, gl = oracle.bf_search_knn(metric, live_rows, live_labels, inv, q, k)
+            assert np.array_equal(wl, gl), f"labels differ q={qi} k={k}"
+            assert np.array_equal(bits(wd), bits(gd))
+        radius = float(np.sort(oracle.dist_many(metric, q, live_rows, inv))[50]) + 1e-6
+        wd, wl = bf.search_range(q, radius)
+        gd, gl = oracle.bf_search_range(metric, live_rows, live_labels, inv, q, radius)
+        assert np.array_equal(wl, gl) and np.array_equal(bits(wd), bits(gd))
+    bf.close()
+
+
+def test_empty_and_k0(oracle, ref):
+    bf = RefBruteforce(ref, 0, 16, 8)
+    q = np.zeros(16, np.float32)
+    assert bf.search_knn(q, 5)[0].size == 0
+    rows = make_corpus(1, 4, 16)
+    labels = np.arange(4, dtype=np.uint64)
+    assert oracle.bf_search_knn(0, rows[:0], labels[:0], None, q, 5)[0].size == 0
+    bf.add(rows, labels)
+    assert bf.search_knn(q, 0)[0].size == 0
+    assert oracle.bf_search_knn(0, rows, labels, None, q, 0)[0].size == 0
+    bf.close()

@@ -1,0 +1,93 @@
+"""CPU, world_size = 2, gloo: the N > 1 path (per-shard top-k -> all-gather -> merge) must return exactly what one
+index over the whole corpus returns.  The local scan is the CPU oracle here; on GPUs it is the rxgpu shard."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from .conftest import lex_topk, make_corpus
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, d, kk, nq, ties, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import Oracle
+    from reindexer_amd.sharded import ShardedBruteforce
+    orc = Oracle()
+    rows = _corpus(n, d, ties)
+    shard = n // world
+    mine = rows[rank * shard:(rank + 1) * shard]
+
+    def local_search(queries, k):
+        ds, rs = [], []
+        for q in queries.numpy():
+            alld = orc.dist_many(1, q, mine)
+            dd, rr = lex_topk(alld, k)
+            pad = k - dd.shape[0]
+            ds.append(np.concatenate([dd, np.full(pad, np.inf, np.float32)]))
+            rs.append(np.concatenate([rr.astype(np.int64), np.full(pad, 0xFFFFFFFF, np.int64)]))
+        return torch.from_numpy(np.stack(ds)), torch.from_numpy(np.stack(rs))
+
+    sb = ShardedBruteforce(local_search, shard)
+    queries = torch.from_numpy(_queries(nq, d, ties))
+    dd, rr = sb.search(queries, kk)
+    out_q.put((rank, dd.numpy().copy(), rr.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _corpus(n, d, ties):
+    if ties:
+        return np.random.default_rng(1).integers(-1, 2, (n, d)).astype(np.float32)
+    return make_corpus(1, n, d)
+
+
+def _queries(nq, d, ties):
+    if ties:
+        return np.random.default_rng(2).integers(-1, 2, (nq, d)).astype(np.float32)
+    return make_corpus(2, nq, d)
+
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_two_rank_merge_equals_single_index(oracle, ties):
+    world, n, d, kk, nq = 2, 4000, (8 if ties else 64), 11, 6
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, d, kk, nq, ties, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, queries = _corpus(n, d, ties), _queries(nq, d, ties)
+    for rank, dd, rr in results:
+        for qi in range(nq):
+            wd, wr = lex_topk(oracle.dist_many(1, queries[qi], rows), kk)
+            assert np.array_equal(rr[qi], wr.astype(np.int64)), (rank, qi)
+            assert np.array_equal(dd[qi].view(np.uint32), wd.view(np.uint32))
+
+
+def test_merge_handles_short_shards():
+    """A shard with fewer than kk rows pads with the invalid row; padding must sort last and come back as -1."""
+    from reindexer_amd.sharded import merge_shard_topk, pack_topk
+    d0 = torch.tensor([[0.5, 2.0, float("inf")]])
+    r0 = torch.tensor([[3, 1, 0xFFFFFFFF]])
+    d1 = torch.tensor([[-1.0, float("inf"), float("inf")]])
+    r1 = torch.tensor([[0, 0xFFFFFFFF, 0xFFFFFFFF]])
+    g = torch.stack([pack_topk(d0, r0), pack_topk(d1, r1)])  # [world=2, nq=1, kk=3]
+    m = merge_shard_topk(g, 4, shard_rows=10)
+    assert m[0, :, 1].tolist() == [10, 3, 1, -1]
+    assert m[0, :3, 0].to(torch.int32).view(torch.float32).tolist() == [-1.0, 0.5, 2.0]
