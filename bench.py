@@ -38,6 +38,23 @@ from reindexer_amd.sharded import merge_shard_topk, pack_topk  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
 
+def pmc_traffic(algo_bytes: float):
+    """HBM bytes per scan launch from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command, corrected as the microarch guide prescribes; see tools/summarize_prof.py).  Only reported when
+    the profile is for this workload size (PMC cannot be collected from inside the timed run)."""
+    best = None
+    for p in sorted((ROOT / "profiles").glob("r*_rocprof_summary.json")):
+        try:
+            summ = json.loads(p.read_text())
+        except Exception:
+            continue
+        for name, e in summ.get("kernels", {}).items():
+            t = e.get("hbm_traffic_bytes_per_launch")
+            if "knn_scan" in name and t and abs(t / algo_bytes - 1.0) < 0.25:
+                best = (t, f"profiles/{p.name}")
+    return best
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,6 +235,7 @@ def main():
     achieved = algo_bytes / avg_scan_s / 1e9 if launches else 0.0
 
     if rank == 0:
+        traffic = pmc_traffic(algo_bytes)
         result = {
             "metric": "knn_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -231,7 +249,8 @@ def main():
                 "qps_over_full_corpus": qps_global, "arch": capi.device_arch(local_rank),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "knn_scan_fixed", "launches": launches, "avg_ms": avg_scan_s * 1e3,
+                         "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
+                         "kernel": "knn_scan_fixed", "launches": launches, "avg_ms": avg_scan_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not args.no_cpu:

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void knn_distances(const float* rows, const fl
 
 // Tuning knobs (read once): RXGPU_SCAN_QLDS, RXGPU_SCAN_PREFETCH, RXGPU_SCAN_NT, RXGPU_SCAN_WG_PER_CU.
 struct ScanTuning {
-	int qlds = 1, prefetch = 1, nt = 1, wg_per_cu = 4;
+	int qlds = 1, prefetch = 1, nt = 1, wg_per_cu = 2;   // measured best on MI355X (profiles/r1_tune_ip768.jsonl)
 	ScanTuning() {
 		if (const char* e = getenv("RXGPU_SCAN_QLDS")) qlds = atoi(e);
 		if (const char* e = getenv("RXGPU_SCAN_PREFETCH")) prefetch = atoi(e);

@@ -1,0 +1,285 @@
+#include "gpu_bruteforce_map.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+#include <stdexcept>
+#include <string>
+
+#include "rxgpu.h"
+
+namespace rxgpu::host {
+
+namespace {
+[[noreturn]] void throwDevice(const char* what) { throw std::runtime_error(std::string(what) + ": " + rxgpu_last_error()); }
+}  // namespace
+
+// tools/normalize.cc:10-23: k = 1/sqrt(sum x^2), 1.0 for zero and already-unit (|1 - sum| <= 1e-5) vectors.
+// The reference compiles this under an "imprecise" pragma (compiler-defined summation order); in the pinned
+// oracle build it is a sequential fma chain, which is what this restates (tests/test_host_map.py re-asserts it).
+float CalculateL2Module(const float* x, int32_t d) noexcept {
+	float sq = 0.0f;
+	for (int32_t i = 0; i < d; ++i) sq = std::fmaf(x[i], x[i], sq);
+	float k = 1.0f;
+	if (sq > 0.0f && std::fabs(1.0f - sq) > 0.00001f) k = float(1.0 / double(std::sqrt(sq)));
+	return k;
+}
+
+float NormalizeCopyVector(const float* x, int32_t d, float* out) noexcept {
+	const float k = CalculateL2Module(x, d);
+	for (int32_t i = 0; i < d; ++i) out[i] = x[i] * k;
+	return k;
+}
+
+GpuBruteforceMap::GpuBruteforceMap(VectorMetric metric, size_t dim, size_t maxElements, int device)
+	: metric_(metric), dim_(dim), device_(device), maxElements_(maxElements) {
+	if (dim_ == 0 || dim_ > 65535) throw std::logic_error("GpuBruteforceMap: dimension must be in [1, 65535]");
+	try {
+		rows_.resize(maxElements_ * dim_);
+		labels_.resize(maxElements_);
+		if (metric_ == VectorMetric::Cosine) invNorms_.resize(maxElements_);
+	} catch (const std::bad_alloc&) {
+		throw std::runtime_error("Not enough memory: BruteforceSearch failed to allocate data");
+	}
+	if (rxgpu_index_create(int(metric_), uint32_t(dim_), maxElements_, device_, &dev_) != RXGPU_OK) {
+		throwDevice("GpuBruteforceMap: device index creation failed");
+	}
+}
+
+GpuBruteforceMap::GpuBruteforceMap(const GpuBruteforceMap& other, size_t newMaxElements)
+	: metric_(other.metric_),
+	  dim_(other.dim_),
+	  device_(other.device_),
+	  maxElements_(std::max(other.maxElements_, newMaxElements)),
+	  curElementCount_(other.curElementCount_),
+	  dictExternalToInternal_(other.dictExternalToInternal_) {
+	try {
+		rows_.resize(maxElements_ * dim_);
+		labels_.resize(maxElements_);
+		if (metric_ == VectorMetric::Cosine) invNorms_.resize(maxElements_);
+	} catch (const std::bad_alloc&) {
+		throw std::runtime_error("Not enough memory: BruteforceSearch failed to allocate data");
+	}
+	std::memcpy(rows_.data(), other.rows_.data(), curElementCount_ * dim_ * sizeof(float));
+	std::memcpy(labels_.data(), other.labels_.data(), curElementCount_ * sizeof(labeltype));
+	if (!invNorms_.empty()) std::memcpy(invNorms_.data(), other.invNorms_.data(), curElementCount_ * sizeof(float));
+	if (rxgpu_index_create(int(metric_), uint32_t(dim_), maxElements_, device_, &dev_) != RXGPU_OK) {
+		throwDevice("GpuBruteforceMap: device index creation failed");
+	}
+	dirtyAll_ = true;
+	needSync_ = true;
+}
+
+GpuBruteforceMap::~GpuBruteforceMap() {
+	if (dev_) rxgpu_index_destroy(dev_);
+}
+
+size_t GpuBruteforceMap::AllocatedMemSize() const noexcept {
+	return dictExternalToInternal_.size() * (sizeof(labeltype) + sizeof(size_t) + 2 * sizeof(void*)) +
+		   (MaxElements() - CurrentElementCount()) * ElementSize() + sizeof(GpuBruteforceMap);
+}
+
+size_t GpuBruteforceMap::DeviceMemSize() const noexcept { return dev_ ? rxgpu_index_device_bytes(dev_) : 0; }
+
+const float* GpuBruteforceMap::FloatPtrByExternalLabel(labeltype label) const {
+	auto it = dictExternalToInternal_.find(label);
+	if (it == dictExternalToInternal_.end()) throw std::runtime_error("Label not found");
+	return rows_.data() + it->second * dim_;
+}
+
+void GpuBruteforceMap::markDirty(size_t idx) {
+	needSync_ = true;
+	if (dirtyAll_) return;
+	if (dirtyRows_.size() > 4096 && dirtyRows_.size() * 4 > curElementCount_) {   // cheaper to re-send everything
+		dirtyAll_ = true;
+		dirtyRows_.clear();
+		return;
+	}
+	dirtyRows_.push_back(uint32_t(idx));
+}
+
+// bruteforce.cc:44-64
+void GpuBruteforceMap::AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id) {
+	size_t idx;
+	const labeltype label = id.AsNumber();
+	auto it = dictExternalToInternal_.find(label);
+	if (it != dictExternalToInternal_.end()) {
+		idx = it->second;
+	} else {
+		if (curElementCount_ >= maxElements_) throw std::runtime_error("The number of elements exceeds the specified limit\n");
+		idx = curElementCount_;
+		dictExternalToInternal_[label] = idx;
+		curElementCount_++;
+	}
+	if (metric_ == VectorMetric::Cosine) invNorms_[idx] = CalculateL2Module(vect.Data(), int32_t(dim_));   // AddNorm
+	std::memcpy(rows_.data() + idx * dim_, vect.Data(), dim_ * sizeof(float));
+	labels_[idx] = label;
+	markDirty(idx);
+}
+
+void GpuBruteforceMap::AddPointConcurrent(ConstFloatVectorView, FloatVectorId) {
+	throw std::logic_error("This brute force index does not support concurrent insertions");
+}
+
+// bruteforce.cc:70-86: swap-with-last keeps the scan order the reference's tie rule depends on
+void GpuBruteforceMap::RemovePoint(labeltype curExternal) {
+	auto found = dictExternalToInternal_.find(curExternal);
+	if (found == dictExternalToInternal_.end()) return;
+	const size_t cur = found->second;
+	dictExternalToInternal_.erase(found);
+	const size_t last = curElementCount_ - 1;
+	if (cur != last) {
+		dictExternalToInternal_[labels_[last]] = cur;
+		std::memcpy(rows_.data() + cur * dim_, rows_.data() + last * dim_, dim_ * sizeof(float));
+		labels_[cur] = labels_[last];
+		if (!invNorms_.empty()) invNorms_[cur] = invNorms_[last];   // MoveNorm
+		markDirty(cur);
+	}
+	curElementCount_--;
+	needSync_ = true;
+}
+
+// bruteforce.cc:88-101
+void GpuBruteforceMap::ResizeIndex(size_t newMaxElements) {
+	if (newMaxElements < curElementCount_) {
+		throw std::runtime_error("Cannot resize, max element is less than the current number of elements");
+	}
+	try {
+		rows_.resize(newMaxElements * dim_);
+		labels_.resize(newMaxElements);
+		if (metric_ == VectorMetric::Cosine) invNorms_.resize(newMaxElements);
+	} catch (const std::bad_alloc&) {
+		throw std::runtime_error("Not enough memory: resizeIndex failed to allocate data");
+	}
+	maxElements_ = newMaxElements;
+	needSync_ = true;
+}
+
+// Lazy host -> HBM synchronisation; writers hold the namespace's exclusive lock, readers may race here => mutex.
+void GpuBruteforceMap::syncDevice() const {
+	std::lock_guard<std::mutex> lk(syncMtx_);
+	if (!needSync_) return;
+	if (rxgpu_index_capacity(dev_) != maxElements_) {
+		// keep the live prefix on the device when growing; shrinking below the device count needs a truncate first
+		if (rxgpu_index_count(dev_) > curElementCount_) {
+			if (rxgpu_index_truncate(dev_, curElementCount_) != RXGPU_OK) throwDevice("truncate");
+		}
+		if (rxgpu_index_reserve(dev_, maxElements_) != RXGPU_OK) throwDevice("Not enough memory: resizeIndex failed to allocate data");
+	}
+	const float* norms = invNorms_.empty() ? nullptr : invNorms_.data();
+	auto upload = [&](size_t first, size_t n) {
+		if (n == 0) return;
+		if (rxgpu_index_upload_rows(dev_, first, n, rows_.data() + first * dim_, norms ? norms + first : nullptr) != RXGPU_OK) {
+			throwDevice("row upload failed");
+		}
+	};
+	if (dirtyAll_) {
+		upload(0, curElementCount_);
+	} else if (!dirtyRows_.empty()) {
+		std::sort(dirtyRows_.begin(), dirtyRows_.end());
+		dirtyRows_.erase(std::unique(dirtyRows_.begin(), dirtyRows_.end()), dirtyRows_.end());
+		size_t i = 0;
+		while (i < dirtyRows_.size()) {
+			size_t j = i + 1;
+			while (j < dirtyRows_.size() && dirtyRows_[j] == dirtyRows_[j - 1] + 1) ++j;
+			const size_t first = dirtyRows_[i];
+			if (first < curElementCount_) upload(first, std::min<size_t>(dirtyRows_[j - 1] + 1, curElementCount_) - first);
+			i = j;
+		}
+	}
+	if (rxgpu_index_truncate(dev_, curElementCount_) != RXGPU_OK) throwDevice("truncate");
+	dirtyRows_.clear();
+	dirtyAll_ = false;
+	needSync_ = false;
+}
+
+// bruteforce.cc:103-127.  The kernels return the exact top-(k+1) under the (dist,row) order; the reference keeps a
+// (dist,label) max-heap with STRICT admission (`dist < worst`, :121) over a scan in row order.  Both agree unless an
+// exact distance tie straddles the k-th boundary; then the sequential rule is replayed over every row with
+// dist <= d_k (fetched with an inclusive range scan), which is all the rule can ever look at:
+//   * a row with dist < d_k is always admitted and never evicted;
+//   * while fewer than k rows with dist <= d_k have been seen the worst is > d_k, so such rows are admitted;
+//   * afterwards ties are rejected and every better row evicts the tie with the LARGEST LABEL.
+SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optional<float>, size_t k, size_t) const {
+	SearchResultQueue result;
+	if (curElementCount_ == 0 || k == 0) return result;
+	syncDevice();
+	k = std::min(k, curElementCount_);
+	const uint32_t kk = uint32_t(std::min(k + 1, curElementCount_));
+	std::vector<float> dist(kk);
+	std::vector<uint32_t> row(kk);
+	uint32_t count = 0;
+	if (rxgpu_search_knn(dev_, queryData, 1, kk, dist.data(), row.data(), &count) != RXGPU_OK) throwDevice("SearchKnn");
+	result.reserve(k);
+	const bool tieAcross = count > k && !(dist[k - 1] < dist[k]);
+	if (!tieAcross) {
+		for (size_t i = 0; i < std::min<size_t>(k, count); ++i) result.emplace(dist[i], labels_[row[i]]);
+		return result;
+	}
+	// ---- tie replay
+	{
+		std::lock_guard<std::mutex> lk(syncMtx_);
+		++tieReplays_;
+	}
+	const float dk = dist[k - 1];
+	std::vector<float> rd(std::max<size_t>(4 * k, 256));
+	std::vector<uint32_t> rr(rd.size());
+	uint64_t total = 0;
+	for (;;) {
+		const int rc = rxgpu_search_range(dev_, queryData, dk, /*inclusive*/ 1, rd.data(), rr.data(), rd.size(), &total);
+		if (rc == RXGPU_OK) break;
+		if (rc != RXGPU_ERR_OVERFLOW) throwDevice("SearchKnn (tie replay)");
+		rd.resize(total);
+		rr.resize(total);
+	}
+	std::vector<uint32_t> order(total);
+	for (uint64_t i = 0; i < total; ++i) order[i] = uint32_t(i);
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rr[a] < rr[b]; });   // scan order
+	std::vector<std::pair<float, labeltype>> better;   // dist < dk: permanent members
+	std::priority_queue<labeltype> ties;               // dist == dk members, largest label on top
+	better.reserve(k);
+	for (uint32_t oi : order) {
+		const float d = rd[oi];
+		const labeltype lab = labels_[rr[oi]];
+		const bool isTie = !(d < dk);
+		if (better.size() + ties.size() < k) {
+			if (isTie) {
+				ties.push(lab);
+			} else {
+				better.emplace_back(d, lab);
+			}
+		} else if (!isTie) {
+			ties.pop();   // heap full => worst distance is dk => the evicted pair is the tie with the largest label
+			better.emplace_back(d, lab);
+		}
+	}
+	for (auto& p : better) result.emplace(p.first, p.second);
+	while (!ties.empty()) {
+		result.emplace(dk, ties.top());
+		ties.pop();
+	}
+	return result;
+}
+
+// bruteforce.cc:129-143 (radius already negated by the caller for IP / cosine, hnsw_index.cc:185)
+SearchResultQueue GpuBruteforceMap::SearchRange(const float* queryData, std::optional<float>, float radius, size_t) const {
+	SearchResultQueue result;
+	if (curElementCount_ == 0) return result;
+	syncDevice();
+	std::vector<float> rd(1024);
+	std::vector<uint32_t> rr(1024);
+	uint64_t total = 0;
+	for (;;) {
+		const int rc = rxgpu_search_range(dev_, queryData, radius, /*inclusive*/ 0, rd.data(), rr.data(), rd.size(), &total);
+		if (rc == RXGPU_OK) break;
+		if (rc != RXGPU_ERR_OVERFLOW) throwDevice("SearchRange");
+		rd.resize(total);
+		rr.resize(total);
+	}
+	result.reserve(total);
+	for (uint64_t i = 0; i < total; ++i) result.emplace(rd[i], labels_[rr[i]]);
+	return result;
+}
+
+}  // namespace rxgpu::host

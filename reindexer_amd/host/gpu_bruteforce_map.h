@@ -1,0 +1,84 @@
+// GpuBruteforceMap — the GPU `Map` policy for HnswIndexBase<Map> (cpp_src/core/index/float_vector/hnsw_index.h:16-57),
+// a drop-in for hnswlib::BruteforceSearch (cpp_src/core/index/float_vector/hnswlib/bruteforce.h:14-66): same member
+// names, argument meaning, result type and exceptions, so Index::New (index.cc:78-116) can instantiate
+// HnswIndexBase<GpuBruteforceMap> as a new index type and the planner sees no difference.
+//
+// Host side keeps the master copy (rows, labels, 1/|row|) because results may hand vectors back to the user
+// (FloatPtrByExternalLabel, hnsw_index.cc:363-370); HBM holds a mirror that is synchronised lazily at the first search
+// after a mutation (vector indexes have no Commit(), float_vector_index.cc:200-204).  All arithmetic of a search runs
+// in the HIP kernels behind include/rxgpu.h; there is NO CPU search fallback.
+#pragma once
+
+#include <memory>
+#include <mutex>
+#include <optional>
+#include <unordered_map>
+#include <vector>
+
+#include "rx_types.h"
+
+struct rxgpu_index;
+
+namespace rxgpu::host {
+
+// tools/normalize.h:16-22 — host-side, exactly as DistCalculator::AddNorm / HnswIndexBase::search use them.
+float CalculateL2Module(const float* x, int32_t d) noexcept;
+float NormalizeCopyVector(const float* x, int32_t d, float* out) noexcept;
+
+class GpuBruteforceMap {
+public:
+	GpuBruteforceMap(VectorMetric metric, size_t dim, size_t maxElements, int device = 0);
+	GpuBruteforceMap(const GpuBruteforceMap& other, size_t newMaxElements);   // copy-on-write tx clone (hnsw_index.cc:68-70)
+	~GpuBruteforceMap();
+	GpuBruteforceMap& operator=(const GpuBruteforceMap&) = delete;
+
+	size_t MaxElements() const noexcept { return maxElements_; }
+	size_t CurrentElementCount() const noexcept { return curElementCount_; }
+	size_t ElementSize() const noexcept { return dim_ * sizeof(float) + sizeof(labeltype); }
+	size_t AllocatedMemSize() const noexcept;
+	size_t DeviceMemSize() const noexcept;
+
+	const float* FloatPtrByExternalLabel(labeltype label) const;
+
+	void AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id);
+	[[noreturn]] void AddPointConcurrent(ConstFloatVectorView, FloatVectorId);
+	void RemovePoint(labeltype curExternal);
+	void ResizeIndex(size_t newMaxElements);
+
+	SearchResultQueue SearchKnn(const float* queryData, std::optional<float> queryDataNorm, size_t k, size_t ef = 0) const;
+	SearchResultQueue SearchRange(const float* queryData, std::optional<float> queryDataNorm, float radius, size_t ef) const;
+
+	bool IsQuantized() const noexcept { return false; }
+	bool QuantizationAvailable() const noexcept { return false; }
+
+	VectorMetric Metric() const noexcept { return metric_; }
+	size_t Dim() const noexcept { return dim_; }
+	labeltype LabelByIdx(size_t idx) const noexcept { return labels_[idx]; }
+	// statistics for tests: how many searches needed the tie replay
+	size_t TieReplays() const noexcept { return tieReplays_; }
+
+private:
+	void syncDevice() const;
+	void markDirty(size_t idx);
+
+	const VectorMetric metric_;
+	const size_t dim_;
+	const int device_;
+	size_t maxElements_;
+	size_t curElementCount_ = 0;
+
+	std::vector<float> rows_;       // [maxElements][dim]  host master copy
+	std::vector<labeltype> labels_; // [maxElements]
+	std::vector<float> invNorms_;   // [maxElements], cosine only (DistCalculator::normCoefs_, hnswlib.h:80-92)
+	std::unordered_map<labeltype, size_t> dictExternalToInternal_;
+
+	// device mirror
+	mutable std::mutex syncMtx_;
+	mutable rxgpu_index* dev_ = nullptr;
+	mutable std::vector<uint32_t> dirtyRows_;
+	mutable bool dirtyAll_ = false;
+	mutable bool needSync_ = false;
+	mutable size_t tieReplays_ = 0;
+};
+
+}  // namespace rxgpu::host

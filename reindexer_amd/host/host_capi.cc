@@ -1,0 +1,122 @@
+// Flat C entry points over the C++ host layer so that pytest (ctypes) can drive GpuBruteforceMap / KnnSelect the way
+// the reference's own engine-level tests drive BruteforceSearch (gtests/tests/unit/hnsw_streaming_search_test.cc).
+// Exceptions become return codes + thread-local text, like the Reindexer API boundary turns them into Error values.
+#include <cstring>
+#include <string>
+
+#include "gpu_bruteforce_map.h"
+#include "knn_select.h"
+
+using namespace rxgpu::host;
+
+namespace {
+thread_local std::string g_err;
+template <typename F>
+int guarded(F&& f) {
+	try {
+		f();
+		return 0;
+	} catch (const std::logic_error& e) {
+		g_err = e.what();
+		return -4;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+size_t drain(SearchResultQueue& q, float* outDist, uint64_t* outLabel, size_t cap) {
+	const size_t n = q.size();
+	for (size_t i = n; !q.empty(); q.pop()) {
+		--i;
+		if (i < cap) {
+			outDist[i] = q.top().first;
+			outLabel[i] = q.top().second;
+		}
+	}
+	return n;
+}
+}  // namespace
+
+extern "C" {
+
+const char* rxhost_last_error() { return g_err.c_str(); }
+
+float rxhost_l2_module(const float* x, int32_t d) { return CalculateL2Module(x, d); }
+float rxhost_normalize_copy(const float* x, int32_t d, float* out) { return NormalizeCopyVector(x, d, out); }
+
+void* rxhost_bf_create(int metric, size_t dim, size_t maxElements, int device) {
+	GpuBruteforceMap* m = nullptr;
+	guarded([&] { m = new GpuBruteforceMap(VectorMetric(metric), dim, maxElements, device); });
+	return m;
+}
+void* rxhost_bf_clone(void* h, size_t newMaxElements) {
+	GpuBruteforceMap* m = nullptr;
+	guarded([&] { m = new GpuBruteforceMap(*static_cast<GpuBruteforceMap*>(h), newMaxElements); });
+	return m;
+}
+void rxhost_bf_destroy(void* h) { delete static_cast<GpuBruteforceMap*>(h); }
+int rxhost_bf_add(void* h, const float* vec, size_t dim, uint64_t label) {
+	return guarded([&] { static_cast<GpuBruteforceMap*>(h)->AddPointNoLock(ConstFloatVectorView(vec, dim), FloatVectorId::FromNumber(label)); });
+}
+int rxhost_bf_add_many(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels) {
+	return guarded([&] {
+		auto* m = static_cast<GpuBruteforceMap*>(h);
+		for (size_t i = 0; i < n; ++i) m->AddPointNoLock(ConstFloatVectorView(vecs + i * dim, dim), FloatVectorId::FromNumber(labels[i]));
+	});
+}
+int rxhost_bf_add_concurrent(void* h, const float* vec, size_t dim, uint64_t label) {
+	return guarded([&] { static_cast<GpuBruteforceMap*>(h)->AddPointConcurrent(ConstFloatVectorView(vec, dim), FloatVectorId::FromNumber(label)); });
+}
+int rxhost_bf_remove(void* h, uint64_t label) {
+	return guarded([&] { static_cast<GpuBruteforceMap*>(h)->RemovePoint(label); });
+}
+int rxhost_bf_resize(void* h, size_t n) {
+	return guarded([&] { static_cast<GpuBruteforceMap*>(h)->ResizeIndex(n); });
+}
+size_t rxhost_bf_count(void* h) { return static_cast<GpuBruteforceMap*>(h)->CurrentElementCount(); }
+size_t rxhost_bf_max_elements(void* h) { return static_cast<GpuBruteforceMap*>(h)->MaxElements(); }
+size_t rxhost_bf_element_size(void* h) { return static_cast<GpuBruteforceMap*>(h)->ElementSize(); }
+size_t rxhost_bf_tie_replays(void* h) { return static_cast<GpuBruteforceMap*>(h)->TieReplays(); }
+int rxhost_bf_vector_by_label(void* h, uint64_t label, float* out) {
+	return guarded([&] {
+		auto* m = static_cast<GpuBruteforceMap*>(h);
+		std::memcpy(out, m->FloatPtrByExternalLabel(label), m->Dim() * sizeof(float));
+	});
+}
+// returns hit count (best first in out*), or -1 on error
+long rxhost_bf_search_knn(void* h, const float* q, size_t k, float* outDist, uint64_t* outLabel) {
+	long n = -1;
+	guarded([&] {
+		auto res = static_cast<const GpuBruteforceMap*>(h)->SearchKnn(q, std::nullopt, k, 0);
+		n = long(drain(res, outDist, outLabel, k));
+	});
+	return n;
+}
+long rxhost_bf_search_range(void* h, const float* q, float radius, float* outDist, uint64_t* outLabel, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		auto res = static_cast<const GpuBruteforceMap*>(h)->SearchRange(q, std::nullopt, radius, 0);
+		n = long(drain(res, outDist, outLabel, cap));
+	});
+	return n;
+}
+// HnswIndexBase::select through the Map: k < 0 => no k, has_radius == 0 => no radius.  Returns count or -1.
+long rxhost_bf_select(void* h, const float* key, size_t dim, long k, int has_radius, float radius, int need_sort, int is_array,
+					  int32_t* outIds, float* outRanks, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		KnnSearchParams p;
+		if (k >= 0) p.k = size_t(k);
+		if (has_radius) p.radius = radius;
+		p.Validate(false);
+		auto res = KnnSelect(*static_cast<const GpuBruteforceMap*>(h), ConstFloatVectorView(key, dim), p, need_sort != 0, is_array != 0);
+		n = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
+			outIds[i] = res.ids[i];
+			outRanks[i] = res.ranks[i];
+		}
+	});
+	return n;
+}
+
+}  // extern "C"

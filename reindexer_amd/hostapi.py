@@ -1,0 +1,168 @@
+"""ctypes binding of librxgpu_host.so: the C++ host layer (GpuBruteforceMap, KnnSelect) behind a flat test shim
+(reindexer_amd/host/host_capi.cc).  Used by tests and examples; the reference integrates the C++ classes directly."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+HOST_LIB_PATH = PKG / "librxgpu_host.so"
+
+_vp, _sz, _u64, _f, _i, _l = C.c_void_p, C.c_size_t, C.c_uint64, C.c_float, C.c_int, C.c_long
+_lib = None
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class HostLogicError(HostError):
+    """std::logic_error on the C++ side."""
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not HOST_LIB_PATH.exists():
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: run `python -m reindexer_amd.build`")
+        from . import capi
+        capi.lib()  # librxgpu.so first (same SONAME resolution for libamdhip64 as everything else in the process)
+        L = _lib = C.CDLL(str(HOST_LIB_PATH))
+        L.rxhost_last_error.restype = C.c_char_p
+        L.rxhost_l2_module.restype = _f
+        L.rxhost_l2_module.argtypes = [_vp, C.c_int32]
+        L.rxhost_normalize_copy.restype = _f
+        L.rxhost_normalize_copy.argtypes = [_vp, C.c_int32, _vp]
+        L.rxhost_bf_create.restype = _vp
+        L.rxhost_bf_create.argtypes = [_i, _sz, _sz, _i]
+        L.rxhost_bf_clone.restype = _vp
+        L.rxhost_bf_clone.argtypes = [_vp, _sz]
+        L.rxhost_bf_destroy.argtypes = [_vp]
+        L.rxhost_bf_add.argtypes = [_vp, _vp, _sz, _u64]
+        L.rxhost_bf_add_many.argtypes = [_vp, _vp, _sz, _sz, _vp]
+        L.rxhost_bf_add_concurrent.argtypes = [_vp, _vp, _sz, _u64]
+        L.rxhost_bf_remove.argtypes = [_vp, _u64]
+        L.rxhost_bf_resize.argtypes = [_vp, _sz]
+        for name in ("count", "max_elements", "element_size", "tie_replays"):
+            fn = getattr(L, "rxhost_bf_" + name)
+            fn.restype = _sz
+            fn.argtypes = [_vp]
+        L.rxhost_bf_vector_by_label.argtypes = [_vp, _u64, _vp]
+        L.rxhost_bf_search_knn.restype = _l
+        L.rxhost_bf_search_knn.argtypes = [_vp, _vp, _sz, _vp, _vp]
+        L.rxhost_bf_search_range.restype = _l
+        L.rxhost_bf_search_range.argtypes = [_vp, _vp, _f, _vp, _vp, _sz]
+        L.rxhost_bf_select.restype = _l
+        L.rxhost_bf_select.argtypes = [_vp, _vp, _sz, _l, _i, _f, _i, _i, _vp, _vp, _sz]
+    return _lib
+
+
+def _raise(rc=None):
+    msg = lib().rxhost_last_error().decode(errors="replace")
+    raise (HostLogicError if rc == -4 else HostError)(msg)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def l2_module(x) -> np.float32:
+    x = _f32(x)
+    return np.float32(lib().rxhost_l2_module(x.ctypes.data, x.shape[0]))
+
+
+def normalize_copy(x):
+    x = _f32(x)
+    out = np.empty_like(x)
+    k = lib().rxhost_normalize_copy(x.ctypes.data, x.shape[0], out.ctypes.data)
+    return out, np.float32(k)
+
+
+class GpuBruteforceMap:
+    """rxgpu::host::GpuBruteforceMap (drop-in for hnswlib::BruteforceSearch)."""
+
+    def __init__(self, metric: int, dim: int, max_elements: int, device: int = 0, _handle=None):
+        self.dim = dim
+        self.h = _handle if _handle is not None else lib().rxhost_bf_create(metric, dim, max_elements, device)
+        if not self.h:
+            _raise()
+
+    def clone(self, new_max_elements: int) -> "GpuBruteforceMap":
+        h = lib().rxhost_bf_clone(self.h, new_max_elements)
+        if not h:
+            _raise()
+        return GpuBruteforceMap(0, self.dim, 0, _handle=h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rxhost_bf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, vecs, labels):
+        vecs = _f32(vecs).reshape(-1, self.dim)
+        labels = np.ascontiguousarray(labels, np.uint64).reshape(-1)
+        rc = lib().rxhost_bf_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data)
+        if rc:
+            _raise(rc)
+
+    def add_concurrent(self, vec, label):
+        vec = _f32(vec)
+        rc = lib().rxhost_bf_add_concurrent(self.h, vec.ctypes.data, self.dim, int(label))
+        if rc:
+            _raise(rc)
+
+    def remove(self, label):
+        rc = lib().rxhost_bf_remove(self.h, int(label))
+        if rc:
+            _raise(rc)
+
+    def resize(self, n):
+        rc = lib().rxhost_bf_resize(self.h, n)
+        if rc:
+            _raise(rc)
+
+    count = property(lambda self: lib().rxhost_bf_count(self.h))
+    max_elements = property(lambda self: lib().rxhost_bf_max_elements(self.h))
+    element_size = property(lambda self: lib().rxhost_bf_element_size(self.h))
+    tie_replays = property(lambda self: lib().rxhost_bf_tie_replays(self.h))
+
+    def vector_by_label(self, label):
+        out = np.empty(self.dim, np.float32)
+        rc = lib().rxhost_bf_vector_by_label(self.h, int(label), out.ctypes.data)
+        if rc:
+            _raise(rc)
+        return out
+
+    def search_knn(self, q, k):
+        q = _f32(q)
+        od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+        n = lib().rxhost_bf_search_knn(self.h, q.ctypes.data, k, od.ctypes.data, ol.ctypes.data)
+        if n < 0:
+            _raise()
+        return od[:n].copy(), ol[:n].copy()
+
+    def search_range(self, q, radius, cap=1 << 20):
+        q = _f32(q)
+        od, ol = np.empty(cap, np.float32), np.empty(cap, np.uint64)
+        n = lib().rxhost_bf_search_range(self.h, q.ctypes.data, radius, od.ctypes.data, ol.ctypes.data, cap)
+        if n < 0:
+            _raise()
+        assert n <= cap
+        return od[:n].copy(), ol[:n].copy()
+
+    def select(self, key, k=None, radius=None, need_sort=True, is_array=False, cap=1 << 20):
+        key = _f32(key)
+        ids, ranks = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        n = lib().rxhost_bf_select(self.h, key.ctypes.data, key.shape[0], -1 if k is None else k, int(radius is not None),
+                                   0.0 if radius is None else radius, int(need_sort), int(is_array), ids.ctypes.data, ranks.ctypes.data, cap)
+        if n < 0:
+            _raise()
+        return ids[:n].copy(), ranks[:n].copy()

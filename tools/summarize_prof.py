@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof/{trace,pmc_fetch,pmc_write}) into profiles/<tag>_*.{csv,json}.
+
+    python tools/summarize_prof.py gpurun_out/prof r1
+
+Kernel names are truncated (torch's template names run to kilobytes).  PMC correction per
+/opt/skills/guides/MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE (KiB) counts 128-B requests as 64 B for wide
+coalesced streaming reads, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as reported (KiB).
+"""
+import csv
+import json
+import statistics
+import sys
+from pathlib import Path
+
+
+def main():
+    src, tag = Path(sys.argv[1]), sys.argv[2]
+    out = Path(__file__).resolve().parents[1] / "profiles"
+    out.mkdir(exist_ok=True)
+    stats = list(csv.DictReader(open(src / "trace" / f"{tag}_kernel_stats.csv")))
+    with open(out / f"{tag}_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in stats:
+            w.writerow([r["Name"][:96], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+    summary = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu ; "
+                          "rocprofv3 --pmc FETCH_SIZE -- python bench.py --steps 10 --warmup 2 --no-cpu ; "
+                          "rocprofv3 --pmc WRITE_SIZE -- (same)", "kernels": {}}
+    for r in stats:
+        if "rxgpu" in r["Name"]:
+            summary["kernels"][r["Name"][:96]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                                  "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6}
+    for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        p = src / name / f"{tag}_counter_collection.csv"
+        if not p.exists():
+            continue
+        vals = {}
+        for r in csv.DictReader(open(p)):
+            if "rxgpu" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                vals.setdefault(r["Kernel_Name"][:96], []).append(float(r["Counter_Value"]))
+        for k, v in vals.items():
+            e = summary["kernels"].setdefault(k, {})
+            e[ctr + "_KiB_mean"] = statistics.mean(v)
+            e[ctr + "_launches"] = len(v)
+    for k, e in summary["kernels"].items():
+        if "FETCH_SIZE_KiB_mean" in e:
+            e["hbm_read_bytes_per_launch_corrected"] = 2 * e["FETCH_SIZE_KiB_mean"] * 1024
+        if "WRITE_SIZE_KiB_mean" in e:
+            e["hbm_write_bytes_per_launch"] = e["WRITE_SIZE_KiB_mean"] * 1024
+        if "hbm_read_bytes_per_launch_corrected" in e:
+            e["hbm_traffic_bytes_per_launch"] = e["hbm_read_bytes_per_launch_corrected"] + e.get("hbm_write_bytes_per_launch", 0.0)
+    (out / f"{tag}_rocprof_summary.json").write_text(json.dumps(summary, indent=1) + "\n")
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
