@@ -67,6 +67,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-queries", type=int, default=16)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
+    ap.add_argument("--batch", type=int, default=256, help="extra leg (N=1, untimed region): batched queries on the MFMA path; 0 = skip")
+    ap.add_argument("--batch-iters", type=int, default=3)
     return ap.parse_args()
 
 
@@ -160,6 +162,48 @@ def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, m
     return baseline, parity
 
 
+def batched_leg(args, ix, queries: torch.Tensor, device, kk: int):
+    """BASELINE configs[1] 'batch=256 (MFMA path)': B queries per call, corpus streamed once per call.
+    Reported beside the headline (which stays batch=1): queries/s, fp32 MFMA TFLOP/s of the GEMM kernel vs the 157.3 TF peak,
+    and agreement of the batched result with the batch-1 exact path on the same queries."""
+    B = min(args.batch, queries.shape[0])
+    q = queries[:B].contiguous()
+    od = torch.empty((B, kk), dtype=torch.float32, device=device)
+    orow = torch.empty((B, kk), dtype=torch.int32, device=device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    ix.search_knn_device(q.data_ptr(), B, kk, od.data_ptr(), orow.data_ptr(), None, stream)   # warmup (row statistics, buffers)
+    torch.cuda.synchronize(device)
+    ix.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.batch_iters):
+        ix.search_knn_device(q.data_ptr(), B, kk, od.data_ptr(), orow.data_ptr(), None, stream)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    n_gemm, ms_gemm = ix.profile_read("gemm")
+    n_res, ms_res = ix.profile_read("rescore")
+    n_fb, ms_fb = ix.profile_read("fallback_scan")
+    ix.profile_enable(False)
+    # same queries through the batch-1 exact path
+    sd = torch.empty((B, kk), dtype=torch.float32, device=device)
+    srow = torch.empty((B, kk), dtype=torch.int32, device=device)
+    nchk = min(B, 32)
+    for i in range(nchk):
+        ix.search_knn_device(q.data_ptr() + i * args.dim * 4, 1, kk, sd.data_ptr() + i * kk * 4, srow.data_ptr() + i * kk * 4, None, stream)
+    torch.cuda.synchronize(device)
+    same_rows = bool(torch.equal(srow[:nchk], orow[:nchk]))
+    same_bits = bool(torch.equal(sd[:nchk].view(torch.int32), od[:nchk].view(torch.int32)))
+    per_batch = (t1 - t0) / args.batch_iters
+    mt = 32 if B <= 32 else 64 if B <= 64 else 128 if B <= 128 else 256
+    flops = 2.0 * mt * args.rows * args.dim   # flops actually issued on the matrix cores (padded to the MT tile)
+    gemm_ms = ms_gemm / max(n_gemm, 1)
+    return {"batch": B, "queries_per_sec": B / per_batch, "ms_per_batch": per_batch * 1e3,
+            "roofline": {"bound": "mfma", "achieved": flops / (gemm_ms / 1e3) / 1e12 if n_gemm else None, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": flops / (gemm_ms / 1e3) / 1e12 / 157.3 if n_gemm else None, "kernel": "knn_gemm<FILTER>",
+                         "avg_ms": gemm_ms, "launches": n_gemm, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"},
+            "rescore_ms": ms_res / max(n_res, 1), "fallback_scan_ms": ms_fb / max(n_fb, 1),
+            "equals_batch1_rows": same_rows, "equals_batch1_dist_bits": same_bits, "checked_queries": nchk}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,7 +226,7 @@ def main():
     total_q = args.steps + args.warmup
     gq = torch.Generator(device=device)
     gq.manual_seed(7)  # the same queries on every rank
-    queries = torch.empty((max(total_q, args.cpu_queries), args.dim), dtype=torch.float32, device=device).normal_(0.0, 0.25, generator=gq)
+    queries = torch.empty((max(total_q, args.cpu_queries, args.batch), args.dim), dtype=torch.float32, device=device).normal_(0.0, 0.25, generator=gq)
     d_inv = None
     if metric_id == 2:
         d_inv = 1.0 / torch.linalg.vector_norm(corpus, dim=1)
@@ -253,6 +297,11 @@ def main():
                          "kernel": "knn_scan_fixed", "launches": launches, "avg_ms": avg_scan_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
+        if world == 1 and args.batch > 1:
+            try:
+                result["batched"] = batched_leg(args, ix, queries, device, kk)
+            except Exception as e:
+                result["batched"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             try:
                 base, parity = cpu_baseline_and_parity(args, corpus, queries, metric_id)

@@ -38,6 +38,28 @@ struct ScanParams {
 	uint32_t kk;              // entries kept per list (<= kMaxFusedK)
 	float* part_dist;         // [nq][gridDim.x][kk]
 	uint32_t* part_row;       // [nq][gridDim.x][kk]
+	// optional device-side gate: query blockIdx.y is processed only if gate_cnt[y] > gate_cap (batched-path fallback)
+	const uint32_t* gate_cnt;
+	uint32_t gate_cap;
+};
+
+enum : int { kGemmDense = 0, kGemmFilter = 1 };
+
+struct GemmParams {
+	const float* rows;        // [n][stride]
+	const float* inv_norms;   // cosine
+	const float* row_sq;      // L2: |x|^2 per row
+	const float* queries;     // [MT][q_stride] zero-padded copy (q_stride % 32 == 0, rows >= nq are zero)
+	const float* q_sq;        // L2: |q|^2 per query  [MT]
+	uint64_t n;               // rows covered by this launch (sample or whole corpus)
+	uint32_t stride, dim, nq, q_stride;
+	// DENSE
+	float* dense;             // [MT][n]
+	// FILTER
+	const float* thr;         // [MT]
+	uint32_t* cand_row;       // [MT][cap]
+	uint32_t* cand_cnt;       // [MT]
+	uint32_t cap;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -64,6 +64,7 @@ __device__ __forceinline__ void consider_quad(WaveTopK& top, float dist, uint32_
 template <int kMetric, int NB, bool kQLds, bool kPrefetch, bool kNT>
 __global__ __launch_bounds__(kScanThreads) void knn_scan_fixed(ScanParams p) {
 	__shared__ float4 s_q[kQLds ? NB * 16 : 1];
+	if (p.gate_cnt && p.gate_cnt[blockIdx.y] <= p.gate_cap) return;
 	const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const float4* qg = reinterpret_cast<const float4*>(p.queries + size_t(blockIdx.y) * p.dim);
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan_fixed(ScanParams p) {
 // Any dim (tails included); query read through the caches.
 template <int kMetric>
 __global__ __launch_bounds__(kScanThreads) void knn_scan_generic(ScanParams p) {
+	if (p.gate_cnt && p.gate_cnt[blockIdx.y] <= p.gate_cap) return;
 	const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const float* q = p.queries + size_t(blockIdx.y) * p.dim;
@@ -156,14 +158,15 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan_generic(ScanParams p) {
 	block_merge_and_store(top, p, lane, wave);
 }
 
-// One workgroup per query: fold the per-workgroup lists [nparts][kk] into the final sorted top-kk.
-__global__ __launch_bounds__(kMergeThreads) void knn_merge(const float* part_dist, const uint32_t* part_row, uint32_t nparts,
-															uint32_t kk, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+// One workgroup per query: fold `total` candidate (dist,row) pairs (invalid rows skipped) into the sorted top-kk.
+__global__ __launch_bounds__(kMergeThreads) void knn_merge(const float* part_dist, const uint32_t* part_row, uint32_t total,
+															uint32_t kk, float* out_dist, uint32_t* out_row, uint32_t* out_count,
+															const uint32_t* gate_cnt, uint32_t gate_cap) {
 	__shared__ float s_d[kMergeWaves][kMaxFusedK];
 	__shared__ uint32_t s_i[kMergeWaves][kMaxFusedK];
+	if (gate_cnt && gate_cnt[blockIdx.x] <= gate_cap) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const size_t base = size_t(blockIdx.x) * nparts * kk;
-	const uint32_t total = nparts * kk;
+	const size_t base = size_t(blockIdx.x) * total;
 	WaveTopK top;
 	top.init(kk);
 	for (uint32_t c0 = wave * kWave; c0 < total; c0 += kMergeThreads) {
@@ -330,9 +333,10 @@ void launch_scan(int metric, const ScanParams& p, uint32_t nq, uint32_t gridx, h
 	}
 }
 
-void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t nparts, uint32_t kk, uint32_t nq, float* out_dist,
-				  uint32_t* out_row, uint32_t* out_count, hipStream_t s) {
-	hipLaunchKernelGGL(knn_merge, dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, nparts, kk, out_dist, out_row, out_count);
+void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t total_per_query, uint32_t kk, uint32_t nq, float* out_dist,
+				  uint32_t* out_row, uint32_t* out_count, const uint32_t* gate_cnt, uint32_t gate_cap, hipStream_t s) {
+	hipLaunchKernelGGL(knn_merge, dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, total_per_query, kk, out_dist, out_row, out_count,
+					   gate_cnt, gate_cap);
 }
 
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,

@@ -2,6 +2,7 @@
 // Host-side plumbing only — all arithmetic is in the kernels.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -67,6 +68,12 @@ void rxgpu_search_ctx::release() {
 	d_out_count.release();
 	d_misc.release();
 	d_select.release();
+	d_qpad.release();
+	d_qstats.release();
+	d_dense.release();
+	d_cand_row.release();
+	d_cand_dist.release();
+	d_cand_cnt.release();
 	if (h_pinned) (void)hipHostFree(h_pinned);
 	h_pinned = nullptr;
 	if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -166,10 +173,148 @@ int enqueue_knn_fused(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_querie
 	}
 	{
 		ProfileScope ps(h, "merge", c->stream);
-		rxgpu::launch_merge(p.part_dist, p.part_row, gridx, kk, nq, d_out_dist, d_out_row, d_out_count, c->stream);
+		rxgpu::launch_merge(p.part_dist, p.part_row, gridx * kk, kk, nq, d_out_dist, d_out_row, d_out_count, nullptr, 0, c->stream);
 	}
 	RX_HIP(hipGetLastError());
 	return RXGPU_OK;
+}
+
+// ---- batched path (nq >= 2): MFMA candidate generation + exact re-score, see knn_batched.hip ----------------------
+constexpr uint32_t kBatchSampleRows = 32768;
+
+static int batch_min_queries() {
+	static const int v = [] {
+		const char* e = getenv("RXGPU_BATCH_MIN");
+		return e ? atoi(e) : 2;
+	}();
+	return v;
+}
+
+// Per-row statistics are cached on the index; recomputed (synchronously, under the index mutex) after any mutation.
+int ensure_row_stats(rxgpu_index* h, hipStream_t s) {
+	std::lock_guard<std::mutex> lk(h->mtx);
+	if (h->stats_valid) return RXGPU_OK;
+	if (!h->d_stats) RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stats), 2 * sizeof(unsigned int)));
+	if (h->metric == RXGPU_METRIC_L2 && h->row_sq_capacity < h->count) {
+		if (h->d_row_sq) (void)hipFree(h->d_row_sq);
+		h->d_row_sq = nullptr;
+		h->row_sq_capacity = 0;
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_row_sq), std::max<uint64_t>(h->capacity, h->count) * sizeof(float)));
+		h->row_sq_capacity = std::max<uint64_t>(h->capacity, h->count);
+	}
+	RX_HIP(hipMemsetAsync(h->d_stats, 0, 2 * sizeof(unsigned int), s));
+	rxgpu::launch_row_stats(h->d_rows, h->d_inv_norms, h->count, h->stride, h->dim, h->metric == RXGPU_METRIC_L2 ? h->d_row_sq : nullptr,
+							h->d_stats, h->cus, s);
+	RX_HIP(hipGetLastError());
+	RX_HIP(hipStreamSynchronize(s));
+	h->stats_valid = true;
+	return RXGPU_OK;
+}
+
+int enqueue_knn_batched(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
+						uint32_t* d_out_row, uint32_t* d_out_count) {
+	if (int rc = ensure_row_stats(h, c->stream); rc) return rc;
+	const uint32_t q_stride = (h->dim + 31u) & ~31u;
+	const uint64_t ns = std::min<uint64_t>(h->count, kBatchSampleRows);
+	// expected nominations per query ~ kk * n / ns (plus the eps margin); 4x headroom, overflow falls back to the exact scan
+	uint64_t cap64 = std::max<uint64_t>(4096, 4 * uint64_t(kk) * ((h->count + ns - 1) / ns));
+	cap64 = std::min<uint64_t>(cap64, std::max<uint64_t>(h->count, 64));
+	const uint32_t cap = uint32_t((cap64 + 63) & ~63ull);
+	for (uint32_t q0 = 0; q0 < nq; q0 += 256) {
+		const uint32_t cq = std::min<uint32_t>(256, nq - q0);
+		const int mt = cq <= 32 ? 32 : cq <= 64 ? 64 : cq <= 128 ? 128 : 256;
+		if (int rc = c->d_qpad.ensure(size_t(mt) * q_stride * sizeof(float)); rc) return rc;
+		if (int rc = c->d_qstats.ensure(size_t(3) * mt * sizeof(float)); rc) return rc;
+		if (int rc = c->d_dense.ensure(size_t(mt) * ns * sizeof(float)); rc) return rc;
+		if (int rc = c->d_cand_row.ensure(size_t(mt) * cap * sizeof(uint32_t)); rc) return rc;
+		if (int rc = c->d_cand_dist.ensure(size_t(mt) * cap * sizeof(float)); rc) return rc;
+		if (int rc = c->d_cand_cnt.ensure(size_t(mt) * sizeof(uint32_t)); rc) return rc;
+		float* qpad = static_cast<float*>(c->d_qpad.ptr);
+		float* q_sq = static_cast<float*>(c->d_qstats.ptr);
+		float* margin = q_sq + mt;
+		float* thr = q_sq + 2 * mt;
+		uint32_t* cand_cnt = static_cast<uint32_t*>(c->d_cand_cnt.ptr);
+		RX_HIP(hipMemsetAsync(qpad, 0, size_t(mt) * q_stride * sizeof(float), c->stream));
+		RX_HIP(hipMemcpy2DAsync(qpad, q_stride * sizeof(float), d_queries + size_t(q0) * h->dim, h->dim * sizeof(float),
+								h->dim * sizeof(float), cq, hipMemcpyDeviceToDevice, c->stream));
+		RX_HIP(hipMemsetAsync(cand_cnt, 0, size_t(mt) * sizeof(uint32_t), c->stream));
+		rxgpu::launch_query_stats(h->metric, qpad, cq, mt, q_stride, h->dim, h->d_stats, q_sq, margin, c->stream);
+
+		rxgpu::GemmParams g{};
+		g.rows = h->d_rows;
+		g.inv_norms = h->d_inv_norms;
+		g.row_sq = h->d_row_sq;
+		g.queries = qpad;
+		g.q_sq = q_sq;
+		g.stride = h->stride;
+		g.dim = h->dim;
+		g.nq = cq;
+		g.q_stride = q_stride;
+		const uint32_t wg_per_cu = uint32_t(std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / rxgpu::gemm_lds_bytes(mt))));
+		auto grid_for = [&](uint64_t rows) {
+			const uint64_t tiles = (rows + 127) / 128;
+			return uint32_t(std::max<uint64_t>(1, std::min<uint64_t>(tiles, uint64_t(h->cus) * wg_per_cu)));
+		};
+		// 2. sample
+		g.n = ns;
+		g.dense = static_cast<float*>(c->d_dense.ptr);
+		{
+			ProfileScope ps(h, "gemm_sample", c->stream);
+			RX_HIP(rxgpu::launch_gemm(h->metric, mt, rxgpu::kGemmDense, g, grid_for(ns), c->stream));
+		}
+		// 3. thresholds
+		rxgpu::launch_sample_threshold(g.dense, ns, cq, mt, kk, margin, thr, c->stream);
+		// 4. filter pass over the whole corpus
+		g.n = h->count;
+		g.dense = nullptr;
+		g.thr = thr;
+		g.cand_row = static_cast<uint32_t*>(c->d_cand_row.ptr);
+		g.cand_cnt = cand_cnt;
+		g.cap = cap;
+		{
+			ProfileScope ps(h, "gemm", c->stream);
+			RX_HIP(rxgpu::launch_gemm(h->metric, mt, rxgpu::kGemmFilter, g, grid_for(h->count), c->stream));
+		}
+		// 5. exact re-score, 6. exact top-kk
+		{
+			ProfileScope ps(h, "rescore", c->stream);
+			rxgpu::launch_rescore(h->metric, h->d_rows, h->d_inv_norms, qpad, q_stride, h->stride, h->dim, cq, cap, cand_cnt, g.cand_row,
+								  static_cast<float*>(c->d_cand_dist.ptr), c->stream);
+		}
+		rxgpu::launch_merge(static_cast<float*>(c->d_cand_dist.ptr), g.cand_row, cap, kk, cq, d_out_dist + size_t(q0) * kk,
+							d_out_row + size_t(q0) * kk, d_out_count ? d_out_count + q0 : nullptr, nullptr, 0, c->stream);
+		// overflow fallback, gated on device: exact fused scan only for queries with cand_cnt > cap
+		{
+			const uint32_t gridx = rxgpu::scan_grid_x(h->count, h->cus);
+			const size_t part = size_t(cq) * gridx * kk;
+			if (int rc = c->d_part_dist.ensure(part * sizeof(float)); rc) return rc;
+			if (int rc = c->d_part_row.ensure(part * sizeof(uint32_t)); rc) return rc;
+			rxgpu::ScanParams p{};
+			p.rows = h->d_rows;
+			p.inv_norms = h->d_inv_norms;
+			p.queries = d_queries + size_t(q0) * h->dim;
+			p.n = h->count;
+			p.stride = h->stride;
+			p.dim = h->dim;
+			p.kk = kk;
+			p.part_dist = static_cast<float*>(c->d_part_dist.ptr);
+			p.part_row = static_cast<uint32_t*>(c->d_part_row.ptr);
+			p.gate_cnt = cand_cnt;
+			p.gate_cap = cap;
+			ProfileScope ps(h, "fallback_scan", c->stream);
+			rxgpu::launch_scan(h->metric, p, cq, gridx, c->stream);
+			rxgpu::launch_merge(p.part_dist, p.part_row, gridx * kk, kk, cq, d_out_dist + size_t(q0) * kk, d_out_row + size_t(q0) * kk,
+								d_out_count ? d_out_count + q0 : nullptr, cand_cnt, cap, c->stream);
+		}
+		RX_HIP(hipGetLastError());
+	}
+	return RXGPU_OK;
+}
+
+int enqueue_knn(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
+				uint32_t* d_out_row, uint32_t* d_out_count) {
+	if (int(nq) >= batch_min_queries() && nq >= 2) return enqueue_knn_batched(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
+	return enqueue_knn_fused(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
 }
 
 }  // namespace
@@ -246,6 +391,8 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 		if (h->d_rows) (void)hipFree(h->d_rows);
 		if (h->d_inv_norms) (void)hipFree(h->d_inv_norms);
 	}
+	if (h->d_row_sq) (void)hipFree(h->d_row_sq);
+	if (h->d_stats) (void)hipFree(h->d_stats);
 	delete h;
 }
 
@@ -299,6 +446,7 @@ int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, cons
 		RX_HIP(hipMemcpy(h->d_inv_norms + first_row, inv_norms, n * sizeof(float), hipMemcpyHostToDevice));
 	}
 	h->count = std::max(h->count, first_row + n);
+	h->stats_valid = false;
 	return RXGPU_OK;
 }
 
@@ -320,6 +468,7 @@ int rxgpu_index_adopt_device_rows(rxgpu_index* h, const void* d_rows, uint64_t n
 	h->stride = row_stride;
 	h->capacity = n;
 	h->count = n;
+	h->stats_valid = false;
 	return RXGPU_OK;
 }
 
@@ -331,12 +480,14 @@ int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
 	DeviceGuard dg(h->device);
 	RX_HIP(hipMemcpy(h->d_rows + to * h->stride, h->d_rows + from * h->stride, h->stride * sizeof(float), hipMemcpyDeviceToDevice));
 	if (h->d_inv_norms) RX_HIP(hipMemcpy(h->d_inv_norms + to, h->d_inv_norms + from, sizeof(float), hipMemcpyDeviceToDevice));
+	h->stats_valid = false;
 	return RXGPU_OK;
 }
 
 int rxgpu_index_truncate(rxgpu_index* h, uint64_t count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(count <= h->capacity, RXGPU_ERR_PARAMS, "rxgpu_index_truncate: count exceeds capacity");
+	if (count != h->count) h->stats_valid = false;
 	h->count = count;
 	return RXGPU_OK;
 }
@@ -360,8 +511,8 @@ int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, 
 	RX_CHECK(h->count > 0, RXGPU_ERR_PARAMS, "rxgpu_search_knn_device: index is empty");
 	DeviceGuard dg(h->device);
 	rxgpu_search_ctx* c = stream_ctx(h, stream);
-	return enqueue_knn_fused(h, c, static_cast<const float*>(d_queries), nq, kk, static_cast<float*>(d_out_dist),
-							 static_cast<uint32_t*>(d_out_row), static_cast<uint32_t*>(d_out_count));
+	return enqueue_knn(h, c, static_cast<const float*>(d_queries), nq, kk, static_cast<float*>(d_out_dist),
+					   static_cast<uint32_t*>(d_out_row), static_cast<uint32_t*>(d_out_count));
 }
 
 int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, float* out_dist, uint32_t* out_row,
@@ -390,8 +541,8 @@ int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t
 		if (int rc = c->d_out_dist.ensure(size_t(nq) * eff * sizeof(float)); rc) return rc;
 		if (int rc = c->d_out_row.ensure(size_t(nq) * eff * sizeof(uint32_t)); rc) return rc;
 		if (int rc = c->d_out_count.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
-		if (int rc = enqueue_knn_fused(h, c, static_cast<const float*>(c->d_queries.ptr), nq, eff, static_cast<float*>(c->d_out_dist.ptr),
-									   static_cast<uint32_t*>(c->d_out_row.ptr), static_cast<uint32_t*>(c->d_out_count.ptr));
+		if (int rc = enqueue_knn(h, c, static_cast<const float*>(c->d_queries.ptr), nq, eff, static_cast<float*>(c->d_out_dist.ptr),
+								 static_cast<uint32_t*>(c->d_out_row.ptr), static_cast<uint32_t*>(c->d_out_count.ptr));
 			rc)
 			return rc;
 		if (eff == kk) {

@@ -15,8 +15,8 @@ struct ScanParams;
 
 uint32_t scan_grid_x(uint64_t n, int cus);
 void launch_scan(int metric, const ScanParams& p, uint32_t nq, uint32_t gridx, hipStream_t s);
-void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t nparts, uint32_t kk, uint32_t nq, float* out_dist,
-				  uint32_t* out_row, uint32_t* out_count, hipStream_t s);
+void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t total_per_query, uint32_t kk, uint32_t nq, float* out_dist,
+				  uint32_t* out_row, uint32_t* out_count, const uint32_t* gate_cnt, uint32_t gate_cap, hipStream_t s);
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,
 				  float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap, unsigned long long* counter,
 				  uint32_t gridx, hipStream_t s);
@@ -30,6 +30,19 @@ size_t select_scratch_bytes(uint64_t n);
 // Finds the kk smallest (dist,row) of d_dist[0..n) ; writes them UNSORTED to d_out_*; *d_out_n (device) = count (== min(kk,n)).
 void launch_select_smallest(const float* d_dist, uint64_t n, uint32_t kk, void* d_scratch, float* d_out_dist, uint32_t* d_out_row,
 							hipStream_t s);
+
+// Batched (MFMA) path, knn_batched.hip
+struct GemmParams;
+size_t gemm_lds_bytes(int mt);
+hipError_t launch_gemm(int metric, int mt, int mode, const GemmParams& p, uint32_t grid, hipStream_t s);
+void launch_row_stats(const float* rows, const float* inv_norms, uint64_t n, uint32_t stride, uint32_t dim, float* row_sq,
+					  unsigned int* stats, int cus, hipStream_t s);
+void launch_query_stats(int metric, const float* queries, uint32_t nq, uint32_t mt, uint32_t q_stride, uint32_t dim, const unsigned int* stats,
+						float* q_sq, float* margin, hipStream_t s);
+void launch_sample_threshold(const float* dense, uint64_t ns, uint32_t nq, uint32_t mt, uint32_t kk, const float* margin, float* thr,
+							 hipStream_t s);
+void launch_rescore(int metric, const float* rows, const float* inv_norms, const float* queries, uint32_t q_stride, uint32_t stride,
+					uint32_t dim, uint32_t nq, uint32_t cap, const uint32_t* cand_cnt, uint32_t* cand_row, float* cand_dist, hipStream_t s);
 
 void set_error(const std::string& msg);
 
@@ -48,6 +61,7 @@ struct rxgpu_search_ctx {
 	hipStream_t stream = nullptr;
 	bool own_stream = false;
 	rxgpu_devbuf d_queries, d_part_dist, d_part_row, d_out_dist, d_out_row, d_out_count, d_misc, d_select;
+	rxgpu_devbuf d_qpad, d_qstats, d_dense, d_cand_row, d_cand_dist, d_cand_cnt;   // batched path
 	void* h_pinned = nullptr;
 	size_t h_pinned_bytes = 0;
 	int ensure_pinned(size_t need);
@@ -70,6 +84,12 @@ struct rxgpu_index {
 	float* d_rows = nullptr;       // owned or adopted
 	float* d_inv_norms = nullptr;  // cosine only
 	bool adopted = false;
+
+	// batched path: per-row |x|^2 (L2) and the maxima entering the rounding bound; recomputed lazily after mutations
+	float* d_row_sq = nullptr;
+	uint64_t row_sq_capacity = 0;
+	unsigned int* d_stats = nullptr;
+	bool stats_valid = false;
 
 	std::mutex mtx;  // guards ctx pool + profile state
 	std::vector<rxgpu_search_ctx*> free_ctx;

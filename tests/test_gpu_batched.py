@@ -1,0 +1,103 @@
+"""-m gpu: batched queries (nq >= 2) take the MFMA candidate path (knn_batched.hip): fp32 matrix-core GEMM nominates
+rows, the exact kernels decide.  The contract is unchanged: identical rows and distance bits to per-query exact search
+(the reference has no batched API — a batch is B sequential SearchKnn calls)."""
+import numpy as np
+import pytest
+
+from .conftest import lex_topk, make_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def check_batch(ix, oracle, metric, rows, inv, queries, kk):
+    dist, row, cnt = ix.search_knn(queries, kk)
+    for qi in range(queries.shape[0]):
+        want_all = oracle.dist_many(metric, queries[qi], rows, inv)
+        c = min(kk, rows.shape[0])
+        wd, wr = lex_topk(want_all, c)
+        assert int(cnt[qi]) == c
+        assert np.array_equal(row[qi, :c], wr), (metric, qi, kk)
+        assert np.array_equal(bits(dist[qi, :c]), bits(wd))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("d", [24, 100, 128, 768])
+def test_batched_equals_sequential(rxgpu, oracle, metric, d):
+    n = 40_000 if d <= 128 else 12_000
+    rows = make_corpus(d, n, d)
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    allq = make_corpus(1000 + d, 70, d)
+    if metric == 2:
+        allq = np.stack([oracle.normalize_copy(q)[0] for q in allq])
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, rows, inv)
+        for nq, kk in ((2, 11), (5, 1), (32, 11), (33, 64), (70, 11)):
+            check_batch(ix, oracle, metric, rows, inv, allq[:nq], kk)
+
+
+def test_batched_more_than_256_queries(rxgpu, oracle):
+    n, d = 30_000, 64
+    rows = make_corpus(1, n, d)
+    queries = make_corpus(2, 300, d)
+    with rxgpu.VectorIndex("ip", d, n) as ix:
+        ix.upload_rows(0, rows)
+        check_batch(ix, oracle, 1, rows, None, queries, 11)
+
+
+def test_batched_ties_take_the_gated_fallback(rxgpu, oracle):
+    """Quantised data: thousands of rows tie with the k-th distance, the nomination lists overflow and the device-side
+    gate reruns those queries through the exact fused scan. Results must still be exact."""
+    rng = np.random.default_rng(5)
+    n, d = 60_000, 8
+    rows = rng.integers(-1, 2, (n, d)).astype(np.float32)
+    queries = rng.integers(-1, 2, (40, d)).astype(np.float32)
+    for metric in (0, 1):
+        with rxgpu.VectorIndex(metric, d, n) as ix:
+            ix.upload_rows(0, rows)
+            check_batch(ix, oracle, metric, rows, None, queries, 11)
+
+
+def test_batched_small_index_and_mutation(rxgpu, oracle):
+    """n < kk, n < sample size, and the cached row statistics are invalidated by uploads / moves / truncation."""
+    d = 128
+    rows = make_corpus(3, 5000, d) * np.float32(0.01)
+    queries = make_corpus(4, 8, d)
+    with rxgpu.VectorIndex("l2", d, 6000) as ix:
+        ix.upload_rows(0, rows[:5])
+        check_batch(ix, oracle, 0, rows[:5], None, queries, 11)
+        ix.upload_rows(5, rows[5:])
+        check_batch(ix, oracle, 0, rows, None, queries, 11)
+        big = (make_corpus(5, 1000, d) * np.float32(50.0)).astype(np.float32)   # much larger norms: the bound must be refreshed
+        ix.upload_rows(5000, big)
+        allrows = np.concatenate([rows, big])
+        check_batch(ix, oracle, 0, allrows, None, queries, 11)
+        ix.move_row(5999, 0)
+        ix.truncate(5999)
+        allrows[0] = allrows[5999]
+        check_batch(ix, oracle, 0, allrows[:5999], None, queries, 11)
+
+
+def test_batched_device_api_matches_host_api(rxgpu, oracle):
+    import torch
+    n, d, nq, kk = 50_000, 256, 48, 11
+    rows = make_corpus(7, n, d)
+    queries = make_corpus(8, nq, d)
+    t_rows = torch.from_numpy(rows).cuda()
+    t_q = torch.from_numpy(queries).cuda()
+    od = torch.empty((nq, kk), dtype=torch.float32, device="cuda")
+    orow = torch.empty((nq, kk), dtype=torch.int32, device="cuda")
+    ocnt = torch.empty((nq,), dtype=torch.int32, device="cuda")
+    with rxgpu.VectorIndex("cosine", d) as ix:
+        inv = oracle.l2_modules(rows)
+        t_inv = torch.from_numpy(inv).cuda()
+        ix.adopt_device_rows(t_rows.data_ptr(), n, d, t_inv.data_ptr(), keepalive=(t_rows, t_inv))
+        ix.search_knn_device(t_q.data_ptr(), nq, kk, od.data_ptr(), orow.data_ptr(), ocnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        hd, hr, hc = ix.search_knn(queries, kk)
+        assert np.array_equal(orow.cpu().numpy().view(np.uint32), hr)
+        assert np.array_equal(bits(od.cpu().numpy()), bits(hd))
+        check_batch(ix, oracle, 2, rows, inv, queries[:6], kk)
