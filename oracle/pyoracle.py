@@ -262,3 +262,82 @@ def ref_or_none() -> Ref | None:
         return Ref()
     except (FileNotFoundError, OSError):
         return None
+
+
+class RefHnsw:
+    """hnswlib::HierarchicalNSWImpl<float, None> of the reference (seed 100, ReplaceDeleted_True — hnsw.cc:74-78)."""
+
+    def __init__(self, ref: Ref, metric: int, dim: int, capacity: int, M: int = 16, ef_construction: int = 200):
+        self.ref, self.dim, self.metric = ref, dim, metric
+        self.h = ref.L.ref_hnsw_create(metric, dim, capacity, M, ef_construction)
+        assert self.h
+
+    def close(self):
+        if self.h:
+            self.ref.L.ref_hnsw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def add(self, vecs, labels):
+        vecs = _f32(vecs).reshape(-1, self.dim)
+        labels = np.ascontiguousarray(labels, np.uint64)
+        assert self.ref.L.ref_hnsw_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data) == 0
+
+    def mark_delete(self, label):
+        assert self.ref.L.ref_hnsw_mark_delete(self.h, int(label)) == 0
+
+    @property
+    def count(self):
+        return self.ref.L.ref_hnsw_count(self.h)
+
+    def search_knn(self, q, k, ef=0):
+        q = _f32(q)
+        od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+        c = self.ref.L.ref_hnsw_search_knn(self.h, q.ctypes.data, k, ef, od.ctypes.data, ol.ctypes.data)
+        return od[:c].copy(), ol[:c].copy()
+
+    def export(self, with_vectors=True) -> dict:
+        """Flat graph in the layout shared by the oracle restatement and the GPU engine."""
+        info = np.zeros(6, np.int64)
+        self.ref.L.ref_hnsw_info(self.h, info.ctypes.data)
+        n, M, maxM0, maxlevel, entry, ndel = (int(x) for x in info)
+        links0 = np.zeros((n, 1 + maxM0), np.uint32)
+        levels = np.zeros(n, np.int32)
+        labels = np.zeros(n, np.uint64)
+        deleted = np.zeros(n, np.uint8)
+        vectors = np.zeros((n, self.dim), np.float32) if with_vectors else None
+        self.ref.L.ref_hnsw_export_level0(self.h, links0.ctypes.data, levels.ctypes.data, labels.ctypes.data, deleted.ctypes.data,
+                                          vectors.ctypes.data if with_vectors else None)
+        upper_off = np.zeros(n + 1, np.uint64)
+        blocks = self.ref.L.ref_hnsw_export_upper(self.h, upper_off.ctypes.data, None)
+        upper = np.zeros((max(blocks, 1), 1 + M), np.uint32)
+        self.ref.L.ref_hnsw_export_upper(self.h, upper_off.ctypes.data, upper.ctypes.data)
+        return dict(metric=self.metric, n=n, dim=self.dim, M=M, maxM0=maxM0, maxlevel=maxlevel, entry=entry, num_deleted=ndel,
+                    links0=links0, upper_off=upper_off, upper=upper, levels=levels, labels=labels, deleted=deleted, vectors=vectors)
+
+
+def _hnsw_bind(L):
+    L.orc_hnsw_search_knn.restype = _sz
+    L.orc_hnsw_search_knn.argtypes = [_i, _sz, _sz, _sz, _sz, _i, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]
+    L.orc_hnsw_last_stats.argtypes = [_vp, _vp]
+
+
+def oracle_hnsw_search_knn(orc: Oracle, g: dict, q, k: int, ef: int = 0, inv_norms=None, with_stats=False):
+    """Restated HierarchicalNSWImpl::SearchKnn on a flat graph (oracle/oracle_hnsw.c)."""
+    if not getattr(orc, "_hnsw_bound", False):
+        _hnsw_bind(orc.L)
+        orc._hnsw_bound = True
+    q = _f32(q)
+    od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+    inv = _f32(inv_norms) if inv_norms is not None else None
+    c = orc.L.orc_hnsw_search_knn(g["metric"], g["n"], g["dim"], g["M"], g["maxM0"], g["maxlevel"], g["entry"], g["num_deleted"],
+                                  g["links0"].ctypes.data, g["upper_off"].ctypes.data, g["upper"].ctypes.data, g["levels"].ctypes.data,
+                                  g["labels"].ctypes.data, g["deleted"].ctypes.data, g["vectors"].ctypes.data,
+                                  inv.ctypes.data if inv is not None else None, q.ctypes.data, k, ef, od.ctypes.data, ol.ctypes.data)
+    if with_stats:
+        nd, nh = C.c_long(0), C.c_long(0)
+        orc.L.orc_hnsw_last_stats(C.byref(nd), C.byref(nh))
+        return od[:c].copy(), ol[:c].copy(), int(nd.value), int(nh.value)
+    return od[:c].copy(), ol[:c].copy()

@@ -109,3 +109,33 @@ def test_empty_and_k0(oracle, ref):
     assert bf.search_knn(q, 0)[0].size == 0
     assert oracle.bf_search_knn(0, rows, labels, None, q, 0)[0].size == 0
     bf.close()
+
+
+# ------------------------------------------------------------------------------------------------ HNSW search
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_hnsw_search_restatement_matches_reference(oracle, ref, metric):
+    """Graph built by the REAL engine, exported flat; the C restatement of the search must return exactly what the
+    engine's own SearchKnn returns (same heaps, same tie mechanics) — with and without deleted nodes."""
+    from oracle.pyoracle import RefHnsw, oracle_hnsw_search_knn
+    n, d = 3000, 64
+    rows = make_corpus(21, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    h = RefHnsw(ref, metric, d, n, M=16, ef_construction=200)
+    h.add(rows, labels)
+    for phase in range(2):
+        if phase == 1:
+            for lab in labels[np.random.default_rng(3).choice(n, 150, replace=False)]:
+                h.mark_delete(lab)
+        g = h.export()
+        assert g["num_deleted"] == (150 if phase else 0)
+        inv = oracle.l2_modules(g["vectors"]) if metric == 2 else None
+        for qi in range(40):
+            q = make_corpus(500 + qi, 1, d)[0]
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            for k, ef in ((10, 128), (10, 10), (1, 0), (50, 64)):
+                wd, wl = h.search_knn(q, k, ef)
+                gd, gl = oracle_hnsw_search_knn(oracle, g, q, k, ef, inv)
+                assert np.array_equal(wl, gl), (metric, phase, qi, k, ef)
+                assert np.array_equal(bits(wd), bits(gd))
+    h.close()
