@@ -1,0 +1,343 @@
+#include "hnsw_graph.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+#include <string>
+
+#include "distance_cpu.h"
+#include "gpu_bruteforce_map.h"   // CalculateL2Module
+
+namespace rxgpu::host {
+
+namespace {
+constexpr tableint kNoEntry = std::numeric_limits<tableint>::max();
+}
+
+HnswGraph::HnswGraph(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, size_t randomSeed)
+	: metric_(metric),
+	  dim_(dim),
+	  maxElements_(maxElements),
+	  M_(std::min<size_t>(M, 10'000)),          // hnswalg.h:254-262
+	  maxM0_(2 * M_),
+	  efConstruction_(std::max(efConstruction, M_)),
+	  mult_(1.0 / std::log(1.0 * double(M_))) {
+	if (dim_ == 0) throw std::logic_error("HnswGraph: zero dimension");
+	try {
+		vectors_.resize(maxElements_ * dim_);
+		if (metric_ == VectorMetric::Cosine) invNorms_.resize(maxElements_);
+		links0_.assign(maxElements_ * (1 + maxM0_), 0u);
+		upper_.resize(maxElements_);
+		levels_.assign(maxElements_, 0);
+		labels_.assign(maxElements_, 0);
+		deleted_.assign(maxElements_, 0);
+		visitStamp_.assign(maxElements_, 0);
+	} catch (const std::bad_alloc&) {
+		throw std::runtime_error("Not enough memory: HNSW constructor failed to allocate level0");
+	}
+	levelGenerator_.seed(uint32_t(randomSeed));
+}
+
+HnswGraph::HnswGraph(const HnswGraph& o, size_t newMaxElements)
+	: metric_(o.metric_),
+	  dim_(o.dim_),
+	  maxElements_(std::max(o.maxElements_, newMaxElements)),
+	  M_(o.M_),
+	  maxM0_(o.maxM0_),
+	  efConstruction_(o.efConstruction_),
+	  mult_(o.mult_),
+	  count_(o.count_),
+	  numDeleted_(o.numDeleted_),
+	  maxLevel_(o.maxLevel_),
+	  entryPoint_(o.entryPoint_),
+	  vectors_(o.vectors_),
+	  invNorms_(o.invNorms_),
+	  links0_(o.links0_),
+	  upper_(o.upper_),
+	  levels_(o.levels_),
+	  labels_(o.labels_),
+	  deleted_(o.deleted_),
+	  labelLookup_(o.labelLookup_),
+	  levelGenerator_(o.levelGenerator_),
+	  visitStamp_(o.visitStamp_.size(), 0) {
+	if (maxElements_ != o.maxElements_) {
+		const size_t keep = maxElements_;
+		maxElements_ = o.maxElements_;
+		Resize(keep);
+	}
+}
+
+void HnswGraph::Resize(size_t newMaxElements) {
+	if (newMaxElements < count_) throw std::runtime_error("Cannot resize, max element is less than the current number of elements");
+	try {
+		vectors_.resize(newMaxElements * dim_);
+		if (metric_ == VectorMetric::Cosine) invNorms_.resize(newMaxElements);
+		links0_.resize(newMaxElements * (1 + maxM0_), 0u);
+		upper_.resize(newMaxElements);
+		levels_.resize(newMaxElements, 0);
+		labels_.resize(newMaxElements, 0);
+		deleted_.resize(newMaxElements, 0);
+		visitStamp_.assign(newMaxElements, 0);
+		curStamp_ = 0;
+	} catch (const std::bad_alloc&) {
+		throw std::runtime_error("Not enough memory: resizeIndex failed to allocate base layer");
+	}
+	maxElements_ = newMaxElements;
+}
+
+tableint HnswGraph::InternalId(labeltype label) const {
+	auto it = labelLookup_.find(label);
+	if (it == labelLookup_.end()) throw std::runtime_error("Label not found");
+	return it->second;
+}
+
+size_t HnswGraph::AllocatedMemSize() const noexcept {
+	size_t up = 0;
+	for (size_t i = 0; i < count_; ++i) up += upper_[i].capacity() * sizeof(uint32_t);
+	return vectors_.capacity() * sizeof(float) + links0_.capacity() * sizeof(uint32_t) + up +
+		   labelLookup_.size() * (sizeof(labeltype) + sizeof(tableint) + 2 * sizeof(void*)) + sizeof(HnswGraph);
+}
+
+// DistCalculator<float>::operator()(v1,id1,v2,id2): smaller = closer; cosine multiplies by BOTH stored 1/|v| (hnswlib.h:123-145)
+float HnswGraph::distIds(tableint a, tableint b) const noexcept {
+	const float* va = Vector(a);
+	const float* vb = Vector(b);
+	if (metric_ == VectorMetric::L2) return 1.0f * L2SqrAvx512Order(va, vb, dim_) + 0.0f + 0.0f;
+	float d = -(1.0f * InnerProductAvx512Order(va, vb, dim_) + 0.0f + 0.0f);
+	if (metric_ == VectorMetric::Cosine) {
+		d *= invNorms_[a];
+		d *= invNorms_[b];
+	}
+	return d;
+}
+
+uint32_t* HnswGraph::list(tableint id, int level) noexcept {
+	return level == 0 ? links0_.data() + size_t(id) * (1 + maxM0_) : upper_[id].data() + size_t(level - 1) * (1 + M_);
+}
+const uint32_t* HnswGraph::list(tableint id, int level) const noexcept { return const_cast<HnswGraph*>(this)->list(id, level); }
+
+// level = floor(-ln(U) / ln(M)), U from std::default_random_engine — a fresh distribution object per draw, like the reference
+int HnswGraph::randomLevel() {
+	std::uniform_real_distribution<double> distribution(0.0, 1.0);
+	const double r = -std::log(distribution(levelGenerator_)) * mult_;
+	return int(r);
+}
+
+// Best-first search on one layer with beam efConstruction; returns the beam as a max-heap on distance.
+HnswGraph::Heap HnswGraph::searchBaseLayer(tableint ep, tableint self, int layer) {
+	if (++curStamp_ == 0) {   // stamp wrap-around: clear and restart at 1
+		std::fill(visitStamp_.begin(), visitStamp_.end(), uint16_t(0));
+		curStamp_ = 1;
+	}
+	const uint16_t stamp = curStamp_;
+	Heap beam, frontier;   // beam: worst on top; frontier: keyed by -dist so the closest is on top
+	beam.reserve(256);
+	frontier.reserve(256);
+	float bound;
+	if (!IsDeleted(ep)) {
+		const float d = distIds(self, ep);
+		beam.emplace(d, ep);
+		bound = d;
+		frontier.emplace(-d, ep);
+	} else {
+		bound = std::numeric_limits<float>::max();
+		frontier.emplace(-bound, ep);
+	}
+	visitStamp_[ep] = stamp;
+	while (!frontier.empty()) {
+		const Pair cur = frontier.top();
+		if (-cur.first > bound && beam.size() == efConstruction_) break;
+		frontier.pop();
+		const uint32_t* ll = list(cur.second, layer);
+		const size_t size = ll[0];
+		for (size_t j = 0; j < size; ++j) {
+			const tableint cand = ll[1 + j];
+			if (visitStamp_[cand] == stamp) continue;
+			visitStamp_[cand] = stamp;
+			const float d = distIds(self, cand);
+			if (beam.size() < efConstruction_ || bound > d) {
+				frontier.emplace(-d, cand);
+				if (!IsDeleted(cand)) {
+					if (beam.size() < efConstruction_) {
+						beam.emplace(d, cand);
+					} else {
+						beam.replace_top(Pair(d, cand));
+					}
+				}
+				if (!beam.empty()) bound = beam.top().first;
+			}
+		}
+	}
+	return beam;
+}
+
+// Diversity heuristic: walk candidates closest-first, keep one only if it is closer to the base point than to every
+// neighbour already kept.  In/out: a max-heap on distance (out holds -dist keys exactly like the reference re-push).
+void HnswGraph::selectNeighbors(Heap& candidates, size_t M) const {
+	if (candidates.size() < M) return;
+	ResultHeap<Pair> closest;   // lexicographic (std::less<pair>) on (-dist, id), as in the reference
+	std::vector<Pair> kept;
+	while (candidates.size() > 0) {
+		closest.emplace(-candidates.top().first, candidates.top().second);
+		candidates.pop();
+	}
+	while (closest.size()) {
+		if (kept.size() >= M) break;
+		const Pair cur = closest.top();
+		const float distToBase = -cur.first;
+		closest.pop();
+		bool good = true;
+		for (const Pair& k : kept) {
+			if (distIds(k.second, cur.second) < distToBase) {
+				good = false;
+				break;
+			}
+		}
+		if (good) kept.push_back(cur);
+	}
+	for (const Pair& k : kept) candidates.emplace(-k.first, k.second);
+}
+
+// Link `cur` on `level` to the selected neighbours and back; returns the entry point for the next (lower) level.
+tableint HnswGraph::connect(tableint cur, Heap& candidates, int level) {
+	const size_t mCurMax = level ? M_ : maxM0_;
+	selectNeighbors(candidates, M_);
+	if (candidates.size() > M_) throw std::runtime_error("Should be not be more than M_ candidates returned by the heuristic");
+	std::vector<tableint> selected;
+	selected.reserve(M_);
+	while (candidates.size() > 0) {
+		selected.push_back(candidates.top().second);
+		candidates.pop();
+	}
+	const tableint nextEntry = selected.back();
+	{
+		uint32_t* ll = list(cur, level);
+		if (ll[0] != 0) throw std::runtime_error("The newly inserted element should have blank link list");
+		ll[0] = uint32_t(selected.size());
+		for (size_t i = 0; i < selected.size(); ++i) {
+			if (level > levels_[selected[i]]) throw std::runtime_error("Trying to make a link on a non-existent level");
+			ll[1 + i] = selected[i];
+		}
+	}
+	for (const tableint other : selected) {
+		uint32_t* lo = list(other, level);
+		const size_t sz = lo[0];
+		if (sz > mCurMax) throw std::runtime_error("Bad value of sz_link_list_other");
+		if (other == cur) throw std::runtime_error("Trying to connect an element to itself");
+		if (sz < mCurMax) {
+			lo[1 + sz] = cur;
+			lo[0] = uint32_t(sz + 1);
+		} else {
+			// full: re-select among {cur} U current neighbours of `other`
+			Heap pool;
+			pool.emplace(distIds(cur, other), cur);
+			for (size_t j = 0; j < sz; ++j) pool.emplace(distIds(lo[1 + j], other), lo[1 + j]);
+			selectNeighbors(pool, mCurMax);
+			uint32_t idx = 0;
+			while (pool.size() > 0) {
+				lo[1 + idx] = pool.top().second;
+				pool.pop();
+				++idx;
+			}
+			lo[0] = idx;
+			for (size_t j = idx; j < mCurMax; ++j) lo[1 + j] = 0;   // keep unused slots canonical (the flat export is compared / uploaded verbatim)
+		}
+	}
+	return nextEntry;
+}
+
+tableint HnswGraph::AddPoint(const float* data, labeltype label) {
+	if (labelLookup_.count(label)) {
+		// the reference routes this to updatePoint (hnswalg.h:1709-1724), a path its own comment marks as never exercised
+		throw std::logic_error("HnswGraph::AddPoint: label already present (in-place vector update is not supported)");
+	}
+	if (count_ >= maxElements_) throw std::runtime_error("The number of elements exceeds the specified limit");
+	const tableint cur = tableint(count_);
+	count_++;
+	labelLookup_[label] = cur;
+	if (metric_ == VectorMetric::Cosine) invNorms_[cur] = CalculateL2Module(data, int32_t(dim_));
+
+	const int curLevel = randomLevel();
+	levels_[cur] = curLevel;
+	const int maxLevelCopy = maxLevel_;
+	tableint currObj = entryPoint_;
+
+	std::memset(list(cur, 0), 0, (1 + maxM0_) * sizeof(uint32_t));
+	labels_[cur] = label;
+	deleted_[cur] = 0;
+	std::memcpy(vectors_.data() + size_t(cur) * dim_, data, dim_ * sizeof(float));
+	upper_[cur].assign(size_t(curLevel) * (1 + M_), 0u);
+
+	if (currObj != kNoEntry) {
+		if (curLevel < maxLevelCopy) {
+			float curDist = distIds(cur, currObj);
+			for (int level = maxLevelCopy; level > curLevel; --level) {
+				bool changed = true;
+				while (changed) {
+					changed = false;
+					const uint32_t* ll = list(currObj, level);
+					const int size = int(ll[0]);
+					for (int i = 0; i < size; ++i) {
+						const tableint cand = ll[1 + i];
+						if (cand >= maxElements_) throw std::runtime_error("cand error");
+						const float d = distIds(cur, cand);
+						if (d < curDist) {
+							curDist = d;
+							currObj = cand;
+							changed = true;
+						}
+					}
+				}
+			}
+		}
+		const tableint enterCopy = entryPoint_;
+		for (int level = std::min(curLevel, maxLevelCopy); level >= 0; --level) {
+			Heap top = searchBaseLayer(currObj, cur, level);
+			if (IsDeleted(enterCopy)) {   // hnswalg.h:1819-1828: a deleted entry point is still offered as a neighbour
+				const float d = distIds(cur, enterCopy);
+				if (top.size() < efConstruction_) {
+					top.emplace(d, enterCopy);
+				} else if (top.top().first > d) {
+					top.replace_top(Pair(d, enterCopy));
+				}
+			}
+			currObj = connect(cur, top, level);
+		}
+		if (curLevel > maxLevelCopy) {
+			entryPoint_ = cur;
+			maxLevel_ = curLevel;
+		}
+	} else {
+		maxLevel_ = curLevel;   // first element (hnswalg.h:1839-1848)
+		entryPoint_ = curLevel > maxLevelCopy ? cur : 0;
+	}
+	return cur;
+}
+
+void HnswGraph::MarkDelete(labeltype label) {
+	auto it = labelLookup_.find(label);
+	if (it == labelLookup_.end()) throw std::runtime_error("markDelete: Label not found: " + std::to_string(label));
+	const tableint id = it->second;
+	if (deleted_[id]) throw std::runtime_error("The requested to delete element is already deleted");
+	deleted_[id] = 1;
+	numDeleted_ += 1;
+	labelLookup_.erase(it);   // allow_replace_deleted_ == true in the reference's construction (hnsw.h:72)
+}
+
+void HnswGraph::ExportUpper(std::vector<uint64_t>& off, std::vector<uint32_t>& blocks) const {
+	off.assign(count_ + 1, 0);
+	uint64_t total = 0;
+	for (size_t i = 0; i < count_; ++i) {
+		off[i] = total;
+		total += uint64_t(levels_[i]);
+	}
+	off[count_] = total;
+	blocks.assign(std::max<uint64_t>(total, 1) * (1 + M_), 0u);
+	for (size_t i = 0; i < count_; ++i) {
+		if (levels_[i]) std::memcpy(blocks.data() + off[i] * (1 + M_), upper_[i].data(), upper_[i].size() * sizeof(uint32_t));
+	}
+}
+
+}  // namespace rxgpu::host

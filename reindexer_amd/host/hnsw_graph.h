@@ -1,0 +1,105 @@
+// HnswGraph — host-side construction of the HNSW graph in the FLAT layout the GPU search kernel consumes.
+//
+// Replaces the build half of hnswlib::HierarchicalNSWImpl<float, None> (cpp_src/core/index/float_vector/hnswlib/hnswalg.h):
+//   level draw            getRandomLevel :624-635, seed 100 (hnsw.h:73), mult = 1/ln(M) :219
+//   insertion             addPoint :1694-1852
+//   construction search   searchBaseLayer :644-749
+//   neighbour selection   getNeighborsByHeuristic2 :977-1024
+//   linking               mutuallyConnectNewElement :1042-1180
+//   delete mark           MarkDelete / markDeletedInternal :1303-1339
+// Same algorithm, same RNG stream, same distance bits (distance_cpu.h), same heap tie mechanics (ResultHeap, rx_types.h) =>
+// for sequential inserts the graph equals the reference's link for link (tests/test_hnsw_builder.py).
+//
+// Deliberate difference: slots of deleted elements are not recycled by later inserts (the reference's
+// allow_replace_deleted path, updatePoint :1472-1690, picks the slot from a hash-set iteration order); new points are
+// always appended.  Search semantics with deleted nodes (traversed, never returned) are identical.
+#pragma once
+
+#include <cstdint>
+#include <random>
+#include <unordered_map>
+#include <vector>
+
+#include "rx_types.h"
+
+namespace rxgpu::host {
+
+class HnswGraph {
+public:
+	HnswGraph(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, size_t randomSeed = 100);
+	HnswGraph(const HnswGraph& other, size_t newMaxElements);
+
+	// addPoint<DummyLocker, ExpectConcurrentUpdates::No>(data, label, -1); returns the internal id
+	tableint AddPoint(const float* data, labeltype label);
+	void MarkDelete(labeltype label);
+	void Resize(size_t newMaxElements);
+
+	size_t MaxElements() const noexcept { return maxElements_; }
+	size_t Count() const noexcept { return count_; }
+	size_t DeletedCount() const noexcept { return numDeleted_; }
+	size_t Dim() const noexcept { return dim_; }
+	size_t M() const noexcept { return M_; }
+	size_t MaxM0() const noexcept { return maxM0_; }
+	int MaxLevel() const noexcept { return maxLevel_; }
+	tableint EntryPoint() const noexcept { return entryPoint_; }
+	VectorMetric Metric() const noexcept { return metric_; }
+
+	bool HasLabel(labeltype label) const { return labelLookup_.count(label) != 0; }
+	tableint InternalId(labeltype label) const;   // throws std::runtime_error("Label not found")
+	labeltype Label(tableint id) const noexcept { return labels_[id]; }
+	bool IsDeleted(tableint id) const noexcept { return deleted_[id] != 0; }
+	const float* Vector(tableint id) const noexcept { return vectors_.data() + size_t(id) * dim_; }
+	float InvNorm(tableint id) const noexcept { return invNorms_.empty() ? 1.f : invNorms_[id]; }
+
+	// flat views for the device upload (see include/rxgpu.h: rxgpu_hnsw_attach_graph)
+	const float* Vectors() const noexcept { return vectors_.data(); }
+	const float* InvNorms() const noexcept { return invNorms_.empty() ? nullptr : invNorms_.data(); }
+	const uint32_t* Links0() const noexcept { return links0_.data(); }      // [count][1 + maxM0]
+	const int32_t* Levels() const noexcept { return levels_.data(); }
+	const uint8_t* Deleted() const noexcept { return deleted_.data(); }
+	const labeltype* Labels() const noexcept { return labels_.data(); }
+	// upper levels as CSR blocks of (1 + M) u32: node i owns levels[i] consecutive blocks starting at off[i]
+	void ExportUpper(std::vector<uint64_t>& off, std::vector<uint32_t>& blocks) const;
+
+	size_t AllocatedMemSize() const noexcept;
+
+private:
+	using Pair = std::pair<float, tableint>;
+	struct ByFirst {
+		bool operator()(const Pair& a, const Pair& b) const noexcept { return a.first < b.first; }
+	};
+	using Heap = ResultHeap<Pair, ByFirst>;
+
+	float distIds(tableint a, tableint b) const noexcept;               // DistCalculator(v1,id1,v2,id2) hnswlib.h:123-145
+	uint32_t* list(tableint id, int level) noexcept;
+	const uint32_t* list(tableint id, int level) const noexcept;
+	int randomLevel();
+	Heap searchBaseLayer(tableint ep, tableint self, int layer);
+	void selectNeighbors(Heap& candidates, size_t M) const;
+	tableint connect(tableint cur, Heap& candidates, int level);
+
+	const VectorMetric metric_;
+	const size_t dim_;
+	size_t maxElements_;
+	const size_t M_, maxM0_, efConstruction_;
+	const double mult_;
+	size_t count_ = 0, numDeleted_ = 0;
+	int maxLevel_ = -1;
+	tableint entryPoint_ = 0xFFFFFFFFu;
+
+	std::vector<float> vectors_;
+	std::vector<float> invNorms_;
+	std::vector<uint32_t> links0_;
+	std::vector<std::vector<uint32_t>> upper_;   // per node: levels * (1 + M)
+	std::vector<int32_t> levels_;
+	std::vector<labeltype> labels_;
+	std::vector<uint8_t> deleted_;
+	std::unordered_map<labeltype, tableint> labelLookup_;
+	std::default_random_engine levelGenerator_;
+
+	// construction scratch: visit stamps (VisitedListPool, visited_list_pool.h:13-36)
+	std::vector<uint16_t> visitStamp_;
+	uint16_t curStamp_ = 0;
+};
+
+}  // namespace rxgpu::host

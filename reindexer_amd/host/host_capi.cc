@@ -120,3 +120,52 @@ long rxhost_bf_select(void* h, const float* key, size_t dim, long k, int has_rad
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- HNSW graph builder
+#include "hnsw_graph.h"
+
+extern "C" {
+
+void* rxhost_graph_create(int metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction) {
+	HnswGraph* g = nullptr;
+	guarded([&] { g = new HnswGraph(VectorMetric(metric), dim, maxElements, M, efConstruction); });
+	return g;
+}
+void rxhost_graph_destroy(void* h) { delete static_cast<HnswGraph*>(h); }
+int rxhost_graph_add_many(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels) {
+	return guarded([&] {
+		auto* g = static_cast<HnswGraph*>(h);
+		for (size_t i = 0; i < n; ++i) g->AddPoint(vecs + i * dim, labels[i]);
+	});
+}
+int rxhost_graph_mark_delete(void* h, uint64_t label) {
+	return guarded([&] { static_cast<HnswGraph*>(h)->MarkDelete(label); });
+}
+// info[0]=count [1]=M [2]=maxM0 [3]=maxlevel [4]=entry [5]=numDeleted [6]=upper blocks
+void rxhost_graph_info(void* h, int64_t* info) {
+	auto* g = static_cast<HnswGraph*>(h);
+	info[0] = int64_t(g->Count());
+	info[1] = int64_t(g->M());
+	info[2] = int64_t(g->MaxM0());
+	info[3] = g->MaxLevel();
+	info[4] = int64_t(g->EntryPoint());
+	info[5] = int64_t(g->DeletedCount());
+	int64_t blocks = 0;
+	for (size_t i = 0; i < g->Count(); ++i) blocks += g->Levels()[i];
+	info[6] = blocks;
+}
+void rxhost_graph_export(void* h, uint32_t* links0, int32_t* levels, uint64_t* labels, uint8_t* deleted, uint64_t* upperOff, uint32_t* upper) {
+	auto* g = static_cast<HnswGraph*>(h);
+	const size_t n = g->Count();
+	std::memcpy(links0, g->Links0(), n * (1 + g->MaxM0()) * sizeof(uint32_t));
+	std::memcpy(levels, g->Levels(), n * sizeof(int32_t));
+	std::memcpy(labels, g->Labels(), n * sizeof(uint64_t));
+	std::memcpy(deleted, g->Deleted(), n);
+	std::vector<uint64_t> off;
+	std::vector<uint32_t> blocks;
+	g->ExportUpper(off, blocks);
+	std::memcpy(upperOff, off.data(), off.size() * sizeof(uint64_t));
+	if (off[n]) std::memcpy(upper, blocks.data(), off[n] * (1 + g->M()) * sizeof(uint32_t));
+}
+
+}  // extern "C"

@@ -166,3 +166,61 @@ class GpuBruteforceMap:
         if n < 0:
             _raise()
         return ids[:n].copy(), ranks[:n].copy()
+
+
+class HnswGraph:
+    """rxgpu::host::HnswGraph — the host-side graph builder (no GPU needed to BUILD)."""
+
+    def __init__(self, metric: int, dim: int, max_elements: int, M: int = 16, ef_construction: int = 200):
+        L = lib()
+        if not hasattr(L, "_graph_bound"):
+            L.rxhost_graph_create.restype = _vp
+            L.rxhost_graph_create.argtypes = [_i, _sz, _sz, _sz, _sz]
+            L.rxhost_graph_destroy.argtypes = [_vp]
+            L.rxhost_graph_add_many.argtypes = [_vp, _vp, _sz, _sz, _vp]
+            L.rxhost_graph_mark_delete.argtypes = [_vp, _u64]
+            L.rxhost_graph_info.argtypes = [_vp, _vp]
+            L.rxhost_graph_export.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
+            L._graph_bound = True
+        self.dim, self.metric = dim, metric
+        self.h = L.rxhost_graph_create(metric, dim, max_elements, M, ef_construction)
+        if not self.h:
+            _raise()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rxhost_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, vecs, labels):
+        vecs = _f32(vecs).reshape(-1, self.dim)
+        labels = np.ascontiguousarray(labels, np.uint64).reshape(-1)
+        rc = lib().rxhost_graph_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data)
+        if rc:
+            _raise(rc)
+
+    def mark_delete(self, label):
+        rc = lib().rxhost_graph_mark_delete(self.h, int(label))
+        if rc:
+            _raise(rc)
+
+    def export(self) -> dict:
+        info = np.zeros(7, np.int64)
+        lib().rxhost_graph_info(self.h, info.ctypes.data)
+        n, M, maxM0, maxlevel, entry, ndel, blocks = (int(x) for x in info)
+        links0 = np.zeros((n, 1 + maxM0), np.uint32)
+        levels = np.zeros(n, np.int32)
+        labels = np.zeros(n, np.uint64)
+        deleted = np.zeros(n, np.uint8)
+        upper_off = np.zeros(n + 1, np.uint64)
+        upper = np.zeros((max(blocks, 1), 1 + M), np.uint32)
+        lib().rxhost_graph_export(self.h, links0.ctypes.data, levels.ctypes.data, labels.ctypes.data, deleted.ctypes.data,
+                                  upper_off.ctypes.data, upper.ctypes.data)
+        return dict(metric=self.metric, n=n, dim=self.dim, M=M, maxM0=maxM0, maxlevel=maxlevel, entry=entry & 0xFFFFFFFF, num_deleted=ndel,
+                    links0=links0, upper_off=upper_off, upper=upper, levels=levels, labels=labels, deleted=deleted)

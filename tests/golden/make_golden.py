@@ -17,7 +17,7 @@ ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
 
-from oracle.pyoracle import Ref, RefBruteforce  # noqa: E402
+from oracle.pyoracle import Ref, RefBruteforce, RefHnsw  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
 DIMS = [1, 7, 16, 33, 64, 100, 128, 200, 512, 768, 1000]
@@ -77,6 +77,31 @@ def main():
                 cases[f"{name}_m{metric}_q{qi}_range_label"] = rl
             bf.close()
     np.savez_compressed(OUT / "bruteforce.npz", **cases)
+    # ---- HNSW: graph built by the real engine (seed 100, sequential inserts) + SearchKnn results, before/after deletes
+    n, d, M, efc, metric = 1500, 48, 16, 200, 2
+    rows = rng.normal(0, 0.25, (n, d)).astype(np.float32)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    h = RefHnsw(ref, metric, d, n, M=M, ef_construction=efc)
+    h.add(rows, labels)
+    g = h.export(with_vectors=False)
+    hz = dict(rows=rows, labels=labels, metric=np.int64(metric), M=np.int64(M), efc=np.int64(efc), maxlevel=np.int64(g["maxlevel"]),
+              entry=np.int64(g["entry"]), links0=g["links0"], levels=g["levels"], upper=g["upper"], upper_off=g["upper_off"])
+    queries = rng.normal(0, 0.25, (16, d)).astype(np.float32)
+    hz["queries"] = queries
+    victims = rng.choice(n, 60, replace=False)
+    hz["victims"] = victims
+    for phase in (0, 1):
+        if phase:
+            for v in victims:
+                h.mark_delete(labels[v])
+        for qi in range(queries.shape[0]):
+            qn, _ = ref.normalize_copy(queries[qi])
+            for k, ef in ((10, 128), (10, 10), (1, 0), (40, 64)):
+                dd, ll = h.search_knn(qn, k, ef)
+                hz[f"p{phase}_q{qi}_k{k}_ef{ef}_dist"] = dd
+                hz[f"p{phase}_q{qi}_k{k}_ef{ef}_label"] = ll
+    h.close()
+    np.savez_compressed(OUT / "hnsw.npz", **hz)
     print("wrote", [p.name for p in OUT.glob("*.npz")])
 
 

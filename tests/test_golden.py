@@ -111,3 +111,29 @@ def test_gpu_bruteforce_matches_golden_gauss(rxgpu, oracle, gbf, metric):
             rd, rr = ix.search_range(q, radius)
             assert np.array_equal(labels[rr], gbf[f"gauss_m{metric}_q{qi}_range_label"])
             assert np.array_equal(bits(rd), bits(gbf[f"gauss_m{metric}_q{qi}_range_dist"]))
+
+
+# ------------------------------------------------------------------------------------------- HNSW (golden graph + results)
+def golden_hnsw_graph(oracle, phase):
+    z = np.load(G / "hnsw.npz")
+    n, d = z["rows"].shape
+    deleted = np.zeros(n, np.uint8)
+    if phase:
+        deleted[z["victims"]] = 1
+    g = dict(metric=int(z["metric"]), n=n, dim=d, M=int(z["M"]), maxM0=2 * int(z["M"]), maxlevel=int(z["maxlevel"]), entry=int(z["entry"]),
+             num_deleted=int(deleted.sum()), links0=z["links0"], upper_off=z["upper_off"], upper=z["upper"], levels=z["levels"],
+             labels=z["labels"], deleted=deleted, vectors=np.ascontiguousarray(z["rows"]))
+    return z, g
+
+
+@pytest.mark.parametrize("phase", [0, 1])
+def test_oracle_hnsw_search_matches_golden(oracle, phase):
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    z, g = golden_hnsw_graph(oracle, phase)
+    inv = oracle.l2_modules(g["vectors"])
+    for qi in range(z["queries"].shape[0]):
+        qn, _ = oracle.normalize_copy(z["queries"][qi])
+        for k, ef in ((10, 128), (10, 10), (1, 0), (40, 64)):
+            gd, gl = oracle_hnsw_search_knn(oracle, g, qn, k, ef, inv)
+            assert np.array_equal(gl, z[f"p{phase}_q{qi}_k{k}_ef{ef}_label"]), (phase, qi, k, ef)
+            assert np.array_equal(bits(gd), bits(z[f"p{phase}_q{qi}_k{k}_ef{ef}_dist"]))
