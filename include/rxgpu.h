@@ -116,6 +116,32 @@ int rxgpu_search_range(rxgpu_index* h, const float* query, float radius, int inc
 int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * HNSW search (HierarchicalNSWImpl<float>::SearchKnn, hnswalg.h:1988-2012) over a host-built graph
+ * ------------------------------------------------------------------------------------------------------- */
+
+/* Mirror the graph of an HNSW index into HBM.  The vectors are the index rows (rxgpu_index_upload_rows, internal id == row);
+ * the graph is the flat form of HierarchicalNSWImpl's storage (hnswalg.h:216-240), built on the host by the GPU Map:
+ *   links0     u32 [count][1 + max_m0]   slot 0 = neighbour count, then the level-0 links in stored order
+ *   upper      u32 [upper_blocks][1 + M] per-level lists of the upper layers; node i owns its `level_i` blocks starting at
+ *   upper_off  u64 [count + 1]           block upper_off[i] (level 1 first)
+ *   deleted    u8  [count]               DELETE_MARK flags (hnswalg.h:1366-1374)
+ * entry / maxlevel = enterpoint_node_ / maxlevel_; num_deleted selects the bare-bone search (hnswalg.h:1982).
+ * Limits of the GPU engine: max_m0 <= 128 (M <= 64). */
+int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, uint64_t upper_blocks,
+							const uint8_t* deleted, uint32_t M, uint32_t max_m0, int32_t maxlevel, uint32_t entry, uint64_t num_deleted);
+/* MarkDelete mirror (hnswalg.h:1303-1339): refresh only the flags. */
+int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t num_deleted);
+
+/* SearchKnn for nq queries (host in/out).  ef == 0 means k*3/2 like the engine (hnswalg.h:1995); ef <= 1024.
+ * Writes, per query, the members of the reference's top_candidates after trimming to k (UNORDERED: the Map pushes them into the
+ * (dist,label) result heap exactly as hnswalg.h:2002-2010 does): out_dist/out_row [nq][k], out_count[q] <= k.
+ * The traversal replays the reference's heaps step for step, so on the same graph the sets are identical. */
+int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
+						  uint32_t* out_count);
+/* Counters accumulated since the last call (for the roofline accounting: bytes = evals*dim*4 + hops*(1+2M)*4). */
+int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Instrumentation (bench.py roofline leg): HIP-event timing of the dominant kernel on its own stream.
  * ------------------------------------------------------------------------------------------------------- */
 int rxgpu_profile_enable(rxgpu_index* h, int on);

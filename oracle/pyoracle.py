@@ -298,6 +298,13 @@ class RefHnsw:
         c = self.ref.L.ref_hnsw_search_knn(self.h, q.ctypes.data, k, ef, od.ctypes.data, ol.ctypes.data)
         return od[:c].copy(), ol[:c].copy()
 
+    def search_range(self, q, radius, ef, cap=1 << 20):
+        q = _f32(q)
+        od, ol = np.empty(cap, np.float32), np.empty(cap, np.uint64)
+        c = self.ref.L.ref_hnsw_search_range(self.h, q.ctypes.data, radius, ef, od.ctypes.data, ol.ctypes.data, cap)
+        assert c <= cap
+        return od[:c].copy(), ol[:c].copy()
+
     def export(self, with_vectors=True) -> dict:
         """Flat graph in the layout shared by the oracle restatement and the GPU engine."""
         info = np.zeros(6, np.int64)

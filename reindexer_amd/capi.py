@@ -51,6 +51,10 @@ _SIGNATURES = {
     "rxgpu_search_knn_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_search_range": (_i, [_vp, _vp, _f, _i, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_distances": (_i, [_vp, _vp, _vp, _u32, _vp]),
+    "rxgpu_hnsw_attach_graph": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _u32, _u32, C.c_int32, _u32, _u64]),
+    "rxgpu_hnsw_update_deleted": (_i, [_vp, _vp, _u64]),
+    "rxgpu_hnsw_search_knn": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_profile_enable": (_i, [_vp, _i]),
     "rxgpu_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
 }
@@ -210,6 +214,35 @@ class VectorIndex:
         out = np.empty(r.shape[0], np.float32)
         _check(lib().rxgpu_distances(self._h, q.ctypes.data, r.ctypes.data, r.shape[0], out.ctypes.data))
         return out
+
+    # ---- HNSW
+    def hnsw_attach_graph(self, g: dict) -> None:
+        """g: flat graph dict (links0, upper_off, upper, deleted, M, maxM0, maxlevel, entry, num_deleted)."""
+        links0 = np.ascontiguousarray(g["links0"], np.uint32)
+        upper_off = np.ascontiguousarray(g["upper_off"], np.uint64)
+        upper = np.ascontiguousarray(g["upper"], np.uint32)
+        deleted = np.ascontiguousarray(g["deleted"], np.uint8)
+        blocks = int(upper_off[-1])
+        _check(lib().rxgpu_hnsw_attach_graph(self._h, links0.ctypes.data, upper_off.ctypes.data, upper.ctypes.data, blocks, deleted.ctypes.data,
+                                             g["M"], g["maxM0"], g["maxlevel"], g["entry"], g["num_deleted"]))
+
+    def hnsw_update_deleted(self, deleted, num_deleted: int) -> None:
+        deleted = np.ascontiguousarray(deleted, np.uint8)
+        _check(lib().rxgpu_hnsw_update_deleted(self._h, deleted.ctypes.data, num_deleted))
+
+    def hnsw_search_knn(self, queries, k: int, ef: int = 0):
+        q = _f32(queries).reshape(-1, self.dim)
+        nq = q.shape[0]
+        dist = np.full((nq, max(k, 1)), np.inf, np.float32)
+        row = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        _check(lib().rxgpu_hnsw_search_knn(self._h, q.ctypes.data, nq, k, ef, dist.ctypes.data, row.ctypes.data, cnt.ctypes.data))
+        return dist[:, :k], row[:, :k], cnt
+
+    def hnsw_read_stats(self):
+        a, b = _u64(0), _u64(0)
+        _check(lib().rxgpu_hnsw_read_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     # ---- instrumentation
     def profile_enable(self, on: bool = True) -> None:

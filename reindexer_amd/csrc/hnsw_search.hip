@@ -1,0 +1,266 @@
+// HNSW search on gfx950: one wavefront per query, traversal IDENTICAL to the reference's.
+//
+// Replaces (cpp_src/core/index/float_vector/hnswlib/hnswalg.h): getLayer0EntryPoint :799-827, initLayer0SearchState :829-858,
+// layer0ShouldStopBeforePop :860-869, runLayer0Step :871-963 (non-streaming), searchBaseLayerST :966-975, SearchKnn :1988-2012.
+//
+// Why the result can be *equal*, not just "recall-close": every distance is bit-identical to the CPU engine's
+// (knn_kernels.hip.h), the graph is the same flat graph, and the two working heaps (PriorityQueue + CompareByFirst,
+// priority_queue.h:7-152 / hnswalg.h:581-585) are replayed with the reference's sift mechanics, so ties break the same way.
+// The best-first search is sequential per query; parallelism comes from
+//   * lanes: the <=2M neighbours of the popped node are fetched/visited-tested one per lane, their distances computed
+//     4 rows at a time (16 lanes per row, 16-byte loads), and
+//   * queries: thousands of independent wavefronts in flight — the kernel is bound by random 3 KB row gathers from HBM.
+// Per query state: candidate heap + result heap in LDS (heap updates by lane 0 in neighbour order), visited bitset in HBM
+// (one atomicOr per neighbour is both the test and the mark).  A query whose candidate heap outgrows LDS is flagged and
+// re-run with the heap in a global scratch (still on the GPU) — never on the CPU.
+#include "knn_kernels.hip.h"
+#include "rxgpu_internal.h"
+
+namespace rxgpu {
+
+// --- PriorityQueue<pair<float,tableint>, vector, CompareByFirst> restated on raw arrays (executed by ONE lane) ---
+__device__ __forceinline__ void hp_sift_up(float* d, uint32_t* id, int child) {
+	const float vd = d[child];
+	const uint32_t vi = id[child];
+	while (child > 0) {
+		const int parent = (child - 1) / 2;
+		if (!(d[parent] < vd)) break;
+		d[child] = d[parent];
+		id[child] = id[parent];
+		child = parent;
+	}
+	d[child] = vd;
+	id[child] = vi;
+}
+__device__ __forceinline__ void hp_sift_down(float* d, uint32_t* id, int parent, int size) {
+	const float vd = d[parent];
+	const uint32_t vi = id[parent];
+	for (;;) {
+		const int left = parent * 2 + 1;
+		if (left >= size) break;
+		int best = left;
+		const int right = left + 1;
+		if (right < size && d[left] < d[right]) best = right;
+		if (!(vd < d[best])) break;
+		d[parent] = d[best];
+		id[parent] = id[best];
+		parent = best;
+	}
+	d[parent] = vd;
+	id[parent] = vi;
+}
+__device__ __forceinline__ void hp_emplace(float* d, uint32_t* id, int& n, float vd, uint32_t vi) {
+	d[n] = vd;
+	id[n] = vi;
+	++n;
+	if (n >= 2) hp_sift_up(d, id, n - 1);
+}
+__device__ __forceinline__ void hp_pop(float* d, uint32_t* id, int& n) {
+	if (n >= 2) {
+		const float td = d[0];
+		const uint32_t ti = id[0];
+		d[0] = d[n - 1];
+		id[0] = id[n - 1];
+		d[n - 1] = td;
+		id[n - 1] = ti;
+		if (n > 2) hp_sift_down(d, id, 0, n - 1);
+	}
+	--n;
+}
+__device__ __forceinline__ void hp_replace_top(float* d, uint32_t* id, int n, float vd, uint32_t vi) {
+	d[0] = vd;
+	id[0] = vi;
+	hp_sift_down(d, id, 0, n);
+}
+
+// Distances of `cnt` rows (ids in LDS) to the query, 4 rows per step; every lane participates in every step.
+template <int kMetric>
+__device__ __forceinline__ void batch_distances(const HnswParams& p, const float* q, const uint32_t* ids, int cnt, float* dists, int lane) {
+	const int m = lane & 15, g = lane >> 4;
+	for (int base = 0; base < cnt; base += kRowsPerWave) {
+		const int idx = base + g;
+		const bool ok = idx < cnt;
+		const uint64_t row = ids[ok ? idx : base];
+		const float sum = group_distance_generic<kMetric>(p.rows + row * p.stride, q, p.dim, m);
+		const float dist = 1.0f * metric_epilogue<kMetric>(sum, p.inv_norms, row);   // normCoef == 1 (hnswalg.h:1855-1863)
+		if (ok && m == 0) dists[idx] = dist;
+	}
+}
+
+template <int kMetric, bool kGlobalCand>
+__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
+	__shared__ float top_d[kHnswMaxEf];
+	__shared__ uint32_t top_i[kHnswMaxEf];
+	__shared__ float lcand_d[kGlobalCand ? 1 : kHnswCandLds];
+	__shared__ uint32_t lcand_i[kGlobalCand ? 1 : kHnswCandLds];
+	__shared__ uint32_t nb_id[kHnswMaxNeighbors];
+	__shared__ float nb_d[kHnswMaxNeighbors];
+	__shared__ uint8_t nb_del[kHnswMaxNeighbors];
+	__shared__ uint32_t s_cur;
+	__shared__ int s_flag;
+
+	const int lane = threadIdx.x;
+	const uint32_t slot = blockIdx.x;
+	const uint32_t qi = p.only ? p.only[slot] : slot;
+	const float* q = p.queries + size_t(qi) * p.dim;
+	uint32_t* visited = p.visited + size_t(slot) * p.visited_words;
+	float* cand_d = kGlobalCand ? p.gcand_d + size_t(slot) * p.gcand_cap : lcand_d;
+	uint32_t* cand_i = kGlobalCand ? p.gcand_i + size_t(slot) * p.gcand_cap : lcand_i;
+	const uint64_t cand_cap = kGlobalCand ? p.gcand_cap : uint64_t(p.lds_cand_cap);
+	unsigned long long ndist = 0, hops = 0;
+
+	// ---- upper levels: greedy descent (getLayer0EntryPoint)
+	uint32_t cur = p.entry;
+	if (lane == 0) nb_id[0] = cur;
+	__syncthreads();
+	batch_distances<kMetric>(p, q, nb_id, 1, nb_d, lane);
+	__syncthreads();
+	float curdist = nb_d[0];
+	ndist += 1;
+	for (int level = p.maxlevel; level > 0; --level) {
+		bool changed = true;
+		while (changed) {
+			__syncthreads();
+			const uint32_t* ll = p.upper + (p.upper_off[cur] + uint64_t(level - 1)) * (1 + p.M);
+			const int cnt = int(ll[0]);
+			for (int j = lane; j < cnt; j += 64) nb_id[j] = ll[1 + j];
+			__syncthreads();
+			batch_distances<kMetric>(p, q, nb_id, cnt, nb_d, lane);
+			__syncthreads();
+			ndist += cnt;
+			changed = false;
+			for (int i = 0; i < cnt; ++i) {   // uniform scalar-style scan (every lane computes the same thing)
+				const float d = nb_d[i];
+				if (d < curdist) {
+					curdist = d;
+					cur = nb_id[i];
+					changed = true;
+				}
+			}
+		}
+	}
+
+	// ---- layer 0: initLayer0SearchState
+	int top_n = 0, cand_n = 0;
+	float lower;
+	bool overflow = false;
+	{
+		const bool ep_ok = p.bare || !p.deleted[cur];
+		if (lane == 0) {
+			if (ep_ok) {
+				hp_emplace(top_d, top_i, top_n, curdist, cur);
+				hp_emplace(cand_d, cand_i, cand_n, -curdist, cur);
+			} else {
+				hp_emplace(cand_d, cand_i, cand_n, -3.402823466e+38f, cur);
+			}
+			atomicOr(&visited[cur >> 5], 1u << (cur & 31));
+		}
+		lower = ep_ok ? curdist : 3.402823466e+38f;
+		if (ep_ok) ndist += 1;   // the reference recomputes the entry distance here (same value)
+	}
+
+	for (;;) {
+		// layer0ShouldStopBeforePop + pop (lane 0), broadcast through LDS
+		if (lane == 0) {
+			int flag = 0;
+			if (cand_n == 0 || overflow) {
+				flag = 1;
+			} else {
+				const float cdist = -cand_d[0];
+				if (p.bare ? (cdist > lower) : (cdist > lower && top_n >= int(p.ef))) {
+					flag = 1;
+				} else {
+					s_cur = cand_i[0];
+					hp_pop(cand_d, cand_i, cand_n);
+				}
+			}
+			s_flag = flag;
+		}
+		__syncthreads();
+		if (s_flag) break;
+		const uint32_t node = s_cur;
+		hops += 1;
+		// neighbours: one per lane; atomicOr = visited test + mark
+		const uint32_t* ll = p.links0 + size_t(node) * (1 + p.maxM0);
+		const int cnt = int(ll[0]);
+		int nfresh = 0;
+		for (int base = 0; base < cnt; base += 64) {
+			const int j = base + lane;
+			bool fresh = false;
+			uint32_t id = 0;
+			if (j < cnt) {
+				id = ll[1 + j];
+				const uint32_t bit = 1u << (id & 31);
+				fresh = !(atomicOr(&visited[id >> 5], bit) & bit);
+			}
+			const uint64_t fm = __ballot(fresh);
+			if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = id;
+			nfresh += __popcll(fm);
+		}
+		__syncthreads();
+		batch_distances<kMetric>(p, q, nb_id, nfresh, nb_d, lane);
+		if (!p.bare) {
+			for (int j = lane; j < nfresh; j += 64) nb_del[j] = p.deleted[nb_id[j]];
+		}
+		ndist += nfresh;
+		__syncthreads();
+		if (lane == 0) {   // sequential heap updates in neighbour order (runLayer0Step :932-960)
+			for (int i = 0; i < nfresh; ++i) {
+				const float d = nb_d[i];
+				const uint32_t id = nb_id[i];
+				if (top_n < int(p.ef) || lower > d) {
+					if (uint64_t(cand_n) >= cand_cap) {
+						overflow = true;
+						break;
+					}
+					hp_emplace(cand_d, cand_i, cand_n, -d, id);
+					if (p.bare || !nb_del[i]) {
+						if (top_n < int(p.ef)) {
+							hp_emplace(top_d, top_i, top_n, d, id);
+						} else {
+							hp_replace_top(top_d, top_i, top_n, d, id);
+						}
+					}
+					if (top_n) lower = top_d[0];
+				}
+			}
+		}
+		__syncthreads();
+	}
+
+	if (lane == 0) {
+		if (overflow) {
+			p.out_count[qi] = kHnswOverflow;
+		} else {
+			while (top_n > int(p.k)) hp_pop(top_d, top_i, top_n);   // SearchKnn :1998-2000
+			for (int i = 0; i < top_n; ++i) {
+				p.out_dist[size_t(qi) * p.k + i] = top_d[i];
+				p.out_row[size_t(qi) * p.k + i] = top_i[i];
+			}
+			p.out_count[qi] = uint32_t(top_n);
+		}
+		if (p.stats) {
+			atomicAdd(&p.stats[0], ndist);
+			atomicAdd(&p.stats[1], hops);
+		}
+	}
+}
+
+template <bool kGlobalCand>
+static void launch_hnsw_mode(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
+	switch (metric) {
+		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand>), dim3(blocks), dim3(64), 0, s, p); break;
+		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand>), dim3(blocks), dim3(64), 0, s, p); break;
+		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand>), dim3(blocks), dim3(64), 0, s, p); break;
+	}
+}
+
+void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s) {
+	if (global_cand) {
+		launch_hnsw_mode<true>(metric, p, blocks, s);
+	} else {
+		launch_hnsw_mode<false>(metric, p, blocks, s);
+	}
+}
+
+}  // namespace rxgpu

@@ -62,6 +62,38 @@ struct GemmParams {
 	uint32_t cap;
 };
 
+constexpr int kHnswMaxEf = 1024;        // result-heap capacity in LDS
+constexpr int kHnswCandLds = 2048;      // candidate-heap capacity in LDS
+constexpr int kHnswMaxNeighbors = 128;  // 2*M <= 128
+constexpr uint32_t kHnswOverflow = 0xFFFFFFFFu;
+
+struct HnswParams {
+	const float* rows;
+	const float* inv_norms;
+	const uint32_t* links0;
+	const uint64_t* upper_off;
+	const uint32_t* upper;
+	const uint8_t* deleted;
+	const float* queries;
+	uint64_t n;
+	uint32_t stride, dim, M, maxM0;
+	int maxlevel;
+	uint32_t entry;
+	int bare;                 // num_deleted == 0 (hnswalg.h:1982)
+	uint32_t nq, k, ef;
+	uint32_t* visited;        // [slots][visited_words], zeroed by the launcher
+	uint64_t visited_words;
+	float* out_dist;          // [nq][k]
+	uint32_t* out_row;
+	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode)
+	const uint32_t* only;     // optional: list of query indices to process (blockIdx.x indexes this list)
+	float* gcand_d;           // global-mode candidate heap storage [slots][gcand_cap]
+	uint32_t* gcand_i;
+	uint64_t gcand_cap;
+	unsigned long long* stats;   // optional [2]: distance evaluations, hops
+	uint32_t lds_cand_cap;       // <= kHnswCandLds (tests shrink it to force the global-heap re-run)
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte row load; kStream = non-temporal (rows are read exactly once per scan — keep them out of L2/MALL's way)

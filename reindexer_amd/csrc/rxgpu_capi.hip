@@ -74,6 +74,10 @@ void rxgpu_search_ctx::release() {
 	d_cand_row.release();
 	d_cand_dist.release();
 	d_cand_cnt.release();
+	d_visited.release();
+	d_gcand_d.release();
+	d_gcand_i.release();
+	d_redo.release();
 	if (h_pinned) (void)hipHostFree(h_pinned);
 	h_pinned = nullptr;
 	if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -393,6 +397,11 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 	}
 	if (h->d_row_sq) (void)hipFree(h->d_row_sq);
 	if (h->d_stats) (void)hipFree(h->d_stats);
+	if (h->d_links0) (void)hipFree(h->d_links0);
+	if (h->d_upper_off) (void)hipFree(h->d_upper_off);
+	if (h->d_upper) (void)hipFree(h->d_upper);
+	if (h->d_deleted) (void)hipFree(h->d_deleted);
+	if (h->d_hnsw_stats) (void)hipFree(h->d_hnsw_stats);
 	delete h;
 }
 
@@ -668,6 +677,184 @@ int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, ui
 	RX_HIP(hipGetLastError());
 	RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(n) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipStreamSynchronize(c->stream));
+	return RXGPU_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------ HNSW */
+
+int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, uint64_t upper_blocks,
+							const uint8_t* deleted, uint32_t M, uint32_t max_m0, int32_t maxlevel, uint32_t entry, uint64_t num_deleted) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	const uint64_t n = h->count;
+	RX_CHECK(n == 0 || (links0 && upper_off && deleted), RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_graph: null argument");
+	RX_CHECK(upper_blocks == 0 || upper, RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_graph: upper is null");
+	RX_CHECK(M >= 1 && max_m0 <= uint32_t(rxgpu::kHnswMaxNeighbors) && M <= max_m0, RXGPU_ERR_PARAMS,
+			 "rxgpu_hnsw_attach_graph: the GPU engine supports M <= 64 (2*M <= 128)");
+	RX_CHECK(n == 0 || entry < n, RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_graph: entry point out of range");
+	DeviceGuard dg(h->device);
+	RX_HIP(hipDeviceSynchronize());
+	auto replace = [&](auto*& dst, const void* src, size_t bytes) -> int {
+		if (dst) (void)hipFree(dst);
+		dst = nullptr;
+		if (bytes == 0) return RXGPU_OK;
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
+		RX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+		return RXGPU_OK;
+	};
+	h->graph_attached = false;
+	if (int rc = replace(h->d_links0, links0, n * (1 + size_t(max_m0)) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = replace(h->d_upper_off, upper_off, (n + 1) * sizeof(uint64_t)); rc) return rc;
+	static const uint32_t kZero[2] = {0, 0};
+	if (int rc = replace(h->d_upper, upper_blocks ? static_cast<const void*>(upper) : static_cast<const void*>(kZero),
+						 upper_blocks ? upper_blocks * (1 + size_t(M)) * sizeof(uint32_t) : sizeof(kZero));
+		rc)
+		return rc;
+	if (int rc = replace(h->d_deleted, deleted, std::max<uint64_t>(n, 1)); rc) return rc;
+	if (!h->d_hnsw_stats) {
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_hnsw_stats), 2 * sizeof(unsigned long long)));
+		RX_HIP(hipMemset(h->d_hnsw_stats, 0, 2 * sizeof(unsigned long long)));
+	}
+	h->graph_n = n;
+	h->graph_M = M;
+	h->graph_maxM0 = max_m0;
+	h->graph_maxlevel = maxlevel;
+	h->graph_entry = entry;
+	h->graph_deleted = num_deleted;
+	h->graph_attached = true;
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t num_deleted) {
+	RX_CHECK(h && h->graph_attached, RXGPU_ERR_LOGIC, "rxgpu_hnsw_update_deleted: no graph attached");
+	RX_CHECK(deleted || h->graph_n == 0, RXGPU_ERR_PARAMS, "rxgpu_hnsw_update_deleted: null argument");
+	DeviceGuard dg(h->device);
+	RX_HIP(hipDeviceSynchronize());
+	if (h->graph_n) RX_HIP(hipMemcpy(h->d_deleted, deleted, h->graph_n, hipMemcpyHostToDevice));
+	h->graph_deleted = num_deleted;
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
+						  uint32_t* out_count) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(queries && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
+	if (nq == 0) return RXGPU_OK;
+	if (h->count == 0 || k == 0) {   // hnswalg.h:1989-1991
+		std::fill(out_count, out_count + nq, 0u);
+		return RXGPU_OK;
+	}
+	RX_CHECK(h->graph_attached && h->graph_n == h->count, RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_knn: graph is not attached / out of date");
+	k = uint32_t(std::min<uint64_t>(k, h->count));
+	if (!ef) ef = k * 3 / 2;                                        // hnswalg.h:1995
+	if (!ef) ef = 1;
+	RX_CHECK(ef <= uint32_t(rxgpu::kHnswMaxEf), RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: ef must be <= 1024 on the GPU engine");
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	const uint64_t words = (h->count + 31) / 32;
+	// visited bitsets are the memory hog: bound one launch to ~2 GiB of them
+	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(8192, (2ull << 30) / (words * 4)));
+	const size_t qbytes = size_t(nq) * h->dim * sizeof(float);
+	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
+	if (int rc = c->d_out_dist.ensure(size_t(nq) * k * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(size_t(nq) * k * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_out_count.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, qbytes, hipMemcpyHostToDevice, c->stream));
+	rxgpu::HnswParams p{};
+	p.rows = h->d_rows;
+	p.inv_norms = h->d_inv_norms;
+	p.links0 = h->d_links0;
+	p.upper_off = h->d_upper_off;
+	p.upper = h->d_upper;
+	p.deleted = h->d_deleted;
+	p.n = h->count;
+	p.stride = h->stride;
+	p.dim = h->dim;
+	p.M = h->graph_M;
+	p.maxM0 = h->graph_maxM0;
+	p.maxlevel = h->graph_maxlevel;
+	p.entry = h->graph_entry;
+	p.bare = h->graph_deleted == 0;
+	p.nq = nq;
+	p.k = k;
+	p.ef = ef;
+	p.visited_words = words;
+	p.out_dist = static_cast<float*>(c->d_out_dist.ptr);
+	p.out_row = static_cast<uint32_t*>(c->d_out_row.ptr);
+	p.out_count = static_cast<uint32_t*>(c->d_out_count.ptr);
+	p.stats = h->d_hnsw_stats;
+	p.lds_cand_cap = uint32_t(rxgpu::kHnswCandLds);
+	if (const char* e = getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // test hook: force the global-heap re-run
+		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, atoi(e))));
+	}
+	for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(max_slots)) {
+		const uint32_t cq = uint32_t(std::min<uint64_t>(max_slots, nq - q0));
+		if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
+		RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+		rxgpu::HnswParams pc = p;
+		pc.queries = static_cast<const float*>(c->d_queries.ptr) + size_t(q0) * h->dim;
+		pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
+		pc.out_dist = p.out_dist + size_t(q0) * k;
+		pc.out_row = p.out_row + size_t(q0) * k;
+		pc.out_count = p.out_count + q0;
+		ProfileScope ps(h, "hnsw", c->stream);
+		rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	// queries whose candidate heap outgrew LDS: re-run with the heap in global scratch (bounded by one entry per node)
+	std::vector<uint32_t> redo;
+	for (uint32_t q = 0; q < nq; ++q) {
+		if (out_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
+	}
+	if (!redo.empty()) {
+		const uint64_t gcap = h->count + 1;
+		const uint64_t redo_slots = std::max<uint64_t>(1, std::min<uint64_t>(max_slots, (1ull << 30) / (gcap * 8)));
+		if (int rc = c->d_redo.ensure(redo.size() * sizeof(uint32_t)); rc) return rc;
+		RX_HIP(hipMemcpyAsync(c->d_redo.ptr, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+		for (size_t r0 = 0; r0 < redo.size(); r0 += redo_slots) {
+			const uint32_t cq = uint32_t(std::min<uint64_t>(redo_slots, redo.size() - r0));
+			if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
+			if (int rc = c->d_gcand_d.ensure(size_t(cq) * gcap * sizeof(float)); rc) return rc;
+			if (int rc = c->d_gcand_i.ensure(size_t(cq) * gcap * sizeof(uint32_t)); rc) return rc;
+			RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+			rxgpu::HnswParams pc = p;
+			pc.queries = static_cast<const float*>(c->d_queries.ptr);
+			pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
+			pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;
+			pc.gcand_d = static_cast<float*>(c->d_gcand_d.ptr);
+			pc.gcand_i = static_cast<uint32_t*>(c->d_gcand_i.ptr);
+			pc.gcand_cap = gcap;
+			ProfileScope ps(h, "hnsw_redo", c->stream);
+			rxgpu::launch_hnsw_search(h->metric, pc, cq, true, c->stream);
+		}
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	}
+	RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops) {
+	RX_CHECK(h && distance_evals && hops, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_stats: null argument");
+	*distance_evals = 0;
+	*hops = 0;
+	if (!h->d_hnsw_stats) return RXGPU_OK;
+	DeviceGuard dg(h->device);
+	unsigned long long v[2] = {0, 0};
+	RX_HIP(hipDeviceSynchronize());
+	RX_HIP(hipMemcpy(v, h->d_hnsw_stats, sizeof(v), hipMemcpyDeviceToHost));
+	RX_HIP(hipMemset(h->d_hnsw_stats, 0, sizeof(v)));
+	*distance_evals = v[0];
+	*hops = v[1];
 	return RXGPU_OK;
 }
 

@@ -44,6 +44,10 @@ void launch_sample_threshold(const float* dense, uint64_t ns, uint32_t nq, uint3
 void launch_rescore(int metric, const float* rows, const float* inv_norms, const float* queries, uint32_t q_stride, uint32_t stride,
 					uint32_t dim, uint32_t nq, uint32_t cap, const uint32_t* cand_cnt, uint32_t* cand_row, float* cand_dist, hipStream_t s);
 
+// HNSW search (hnsw_search.hip)
+struct HnswParams;
+void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s);
+
 void set_error(const std::string& msg);
 
 }  // namespace rxgpu
@@ -62,6 +66,7 @@ struct rxgpu_search_ctx {
 	bool own_stream = false;
 	rxgpu_devbuf d_queries, d_part_dist, d_part_row, d_out_dist, d_out_row, d_out_count, d_misc, d_select;
 	rxgpu_devbuf d_qpad, d_qstats, d_dense, d_cand_row, d_cand_dist, d_cand_cnt;   // batched path
+	rxgpu_devbuf d_visited, d_gcand_d, d_gcand_i, d_redo;                          // HNSW
 	void* h_pinned = nullptr;
 	size_t h_pinned_bytes = 0;
 	int ensure_pinned(size_t need);
@@ -90,6 +95,18 @@ struct rxgpu_index {
 	uint64_t row_sq_capacity = 0;
 	unsigned int* d_stats = nullptr;
 	bool stats_valid = false;
+
+	// HNSW graph mirror (rxgpu_hnsw_attach_graph)
+	uint32_t* d_links0 = nullptr;
+	uint64_t* d_upper_off = nullptr;
+	uint32_t* d_upper = nullptr;
+	uint8_t* d_deleted = nullptr;
+	uint64_t graph_n = 0, graph_deleted = 0;
+	uint32_t graph_M = 0, graph_maxM0 = 0;
+	int graph_maxlevel = -1;
+	uint32_t graph_entry = 0;
+	bool graph_attached = false;
+	unsigned long long* d_hnsw_stats = nullptr;
 
 	std::mutex mtx;  // guards ctx pool + profile state
 	std::vector<rxgpu_search_ctx*> free_ctx;

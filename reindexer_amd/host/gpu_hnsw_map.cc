@@ -1,0 +1,156 @@
+#include "gpu_hnsw_map.h"
+
+#include <algorithm>
+#include <queue>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rxgpu.h"
+
+namespace rxgpu::host {
+
+namespace {
+[[noreturn]] void throwDevice(const char* what) { throw std::runtime_error(std::string(what) + ": " + rxgpu_last_error()); }
+}  // namespace
+
+GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device)
+	: graph_(metric, dim, maxElements, M, efConstruction), device_(device) {
+	if (2 * graph_.M() > 128) throw std::logic_error("GpuHnswMap: the GPU engine supports M <= 64");
+	if (rxgpu_index_create(int(metric), uint32_t(dim), maxElements, device_, &dev_) != RXGPU_OK) {
+		throwDevice("GpuHnswMap: device index creation failed");
+	}
+}
+
+GpuHnswMap::GpuHnswMap(const GpuHnswMap& other, size_t newCapacity) : graph_(other.graph_, newCapacity), device_(other.device_) {
+	if (rxgpu_index_create(int(graph_.Metric()), uint32_t(graph_.Dim()), graph_.MaxElements(), device_, &dev_) != RXGPU_OK) {
+		throwDevice("GpuHnswMap: device index creation failed");
+	}
+}
+
+GpuHnswMap::~GpuHnswMap() {
+	if (dev_) rxgpu_index_destroy(dev_);
+}
+
+void GpuHnswMap::AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id) {
+	graph_.AddPoint(vect.Data(), id.AsNumber());
+	graphDirty_ = true;
+}
+
+void GpuHnswMap::AddPointConcurrent(ConstFloatVectorView, FloatVectorId) {
+	throw std::logic_error("This HNSW index does not support concurrent insertions");   // hnswalg.h:1393-1399 (Synchronization::None)
+}
+
+void GpuHnswMap::MarkDelete(FloatVectorId id) {
+	graph_.MarkDelete(id.AsNumber());
+	deletedDirty_ = true;
+}
+
+void GpuHnswMap::ResizeIndex(size_t newMaxElements) {
+	graph_.Resize(newMaxElements);
+	graphDirty_ = true;
+}
+
+void GpuHnswMap::syncDevice() const {
+	std::lock_guard<std::mutex> lk(syncMtx_);
+	if (!graphDirty_ && !deletedDirty_) return;
+	const size_t n = graph_.Count();
+	if (graphDirty_) {
+		if (rxgpu_index_capacity(dev_) < graph_.MaxElements()) {
+			if (rxgpu_index_reserve(dev_, graph_.MaxElements()) != RXGPU_OK) throwDevice("Not enough memory: resizeIndex failed to allocate base layer");
+		}
+		if (n > syncedRows_) {   // rows never change once inserted: ship only the new ones
+			const float* norms = graph_.InvNorms();
+			if (rxgpu_index_upload_rows(dev_, syncedRows_, n - syncedRows_, graph_.Vectors() + syncedRows_ * graph_.Dim(),
+										norms ? norms + syncedRows_ : nullptr) != RXGPU_OK) {
+				throwDevice("row upload failed");
+			}
+			syncedRows_ = n;
+		}
+		std::vector<uint64_t> off;
+		std::vector<uint32_t> upper;
+		graph_.ExportUpper(off, upper);
+		if (rxgpu_hnsw_attach_graph(dev_, graph_.Links0(), off.data(), upper.data(), off.empty() ? 0 : off[n], graph_.Deleted(), uint32_t(graph_.M()),
+									uint32_t(graph_.MaxM0()), graph_.MaxLevel(), n ? graph_.EntryPoint() : 0, graph_.DeletedCount()) != RXGPU_OK) {
+			throwDevice("graph upload failed");
+		}
+	} else if (deletedDirty_) {
+		if (rxgpu_hnsw_update_deleted(dev_, graph_.Deleted(), graph_.DeletedCount()) != RXGPU_OK) throwDevice("delete-mark upload failed");
+	}
+	graphDirty_ = false;
+	deletedDirty_ = false;
+}
+
+// hnswalg.h:1988-2012
+SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional<float>, size_t k, size_t ef) const {
+	SearchResultQueue result;
+	const size_t n = graph_.Count();
+	if (n == 0 || k == 0) return result;
+	syncDevice();
+	k = std::min(k, n);
+	std::vector<float> dist(k);
+	std::vector<uint32_t> row(k);
+	uint32_t count = 0;
+	if (rxgpu_hnsw_search_knn(dev_, queryDataRaw, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) {
+		throwDevice("SearchKnn");
+	}
+	result.reserve(count);
+	for (uint32_t i = 0; i < count; ++i) result.emplace(dist[i], graph_.Label(row[i]));
+	return result;
+}
+
+// hnswalg.h:2015-2070: ef-search, then breadth-first expansion over level-0 links while dist < radius.
+// The expansion is a closure (its result set does not depend on visiting order); the host walks the frontier and the
+// GPU computes every distance (rxgpu_distances), so no search arithmetic runs on the CPU.
+SearchResultQueue GpuHnswMap::SearchRange(const float* queryDataRaw, std::optional<float>, float radius, size_t ef) const {
+	SearchResultQueue result;
+	const size_t n = graph_.Count();
+	if (n == 0) return result;
+	syncDevice();
+	const size_t efEff = std::max<size_t>(1, std::min<size_t>(ef ? ef : 1, 1024));
+	const size_t kk = std::min(efEff, n);
+	std::vector<float> dist(kk);
+	std::vector<uint32_t> row(kk);
+	uint32_t count = 0;
+	if (rxgpu_hnsw_search_knn(dev_, queryDataRaw, 1, uint32_t(kk), uint32_t(efEff), dist.data(), row.data(), &count) != RXGPU_OK) {
+		throwDevice("SearchRange");
+	}
+	std::vector<uint8_t> visited(n, 0);
+	std::vector<uint32_t> frontier, next, fresh;
+	for (uint32_t i = 0; i < count; ++i) {
+		visited[row[i]] = 1;
+		if (dist[i] < radius) {
+			frontier.push_back(row[i]);
+			result.emplace(dist[i], graph_.Label(row[i]));
+		}
+	}
+	const size_t stride = 1 + graph_.MaxM0();
+	std::vector<float> fd;
+	while (!frontier.empty()) {
+		fresh.clear();
+		for (uint32_t cur : frontier) {
+			const uint32_t* ll = graph_.Links0() + size_t(cur) * stride;
+			for (uint32_t j = 0; j < ll[0]; ++j) {
+				const uint32_t cand = ll[1 + j];
+				if (graph_.IsDeleted(cand) || visited[cand]) continue;
+				visited[cand] = 1;
+				fresh.push_back(cand);
+			}
+		}
+		next.clear();
+		if (!fresh.empty()) {
+			fd.resize(fresh.size());
+			if (rxgpu_distances(dev_, queryDataRaw, fresh.data(), uint32_t(fresh.size()), fd.data()) != RXGPU_OK) throwDevice("SearchRange");
+			for (size_t i = 0; i < fresh.size(); ++i) {
+				if (fd[i] < radius) {
+					next.push_back(fresh[i]);
+					result.emplace(fd[i], graph_.Label(fresh[i]));
+				}
+			}
+		}
+		frontier.swap(next);
+	}
+	return result;
+}
+
+}  // namespace rxgpu::host

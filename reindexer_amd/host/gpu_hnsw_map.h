@@ -1,0 +1,63 @@
+// GpuHnswMap — the GPU `Map` policy for HnswIndexBase<Map> in its HNSW form (hnsw_index.cc:47-58), a drop-in for
+// hnswlib::HierarchicalNSW<Synchronization::None> (cpp_src/core/index/float_vector/hnswlib/hnsw.h:14-126).
+//   build  : host, HnswGraph (hnsw_graph.h) — same graph as the reference builds
+//   search : MI355X, rxgpu_hnsw_search_knn (hnsw_search.hip) — same traversal as the reference, no CPU search path
+#pragma once
+
+#include <memory>
+#include <mutex>
+#include <optional>
+
+#include "hnsw_graph.h"
+#include "rx_types.h"
+
+struct rxgpu_index;
+
+namespace rxgpu::host {
+
+class GpuHnswMap {
+public:
+	GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device = 0);
+	GpuHnswMap(const GpuHnswMap& other, size_t newCapacity);
+	~GpuHnswMap();
+	GpuHnswMap& operator=(const GpuHnswMap&) = delete;
+
+	size_t MaxElements() const noexcept { return graph_.MaxElements(); }
+	size_t CurrentElementCount() const noexcept { return graph_.Count(); }
+	size_t DeletedCountUnsafe() const noexcept { return graph_.DeletedCount(); }
+	size_t AllocatedMemSize() const noexcept { return graph_.AllocatedMemSize(); }
+	// hnswalg.h:216-228: links0 + data + label + hash per element
+	size_t ElementSize() const noexcept { return (1 + graph_.MaxM0()) * sizeof(uint32_t) + graph_.Dim() * sizeof(float) + 16; }
+
+	labeltype ExternalLabel(tableint id) const { return graph_.Label(id); }
+	bool IsMarkedDeleted(tableint id) const noexcept { return graph_.IsDeleted(id); }
+	const float* FloatPtrByExternalLabel(labeltype label) const { return graph_.Vector(graph_.InternalId(label)); }
+
+	void MarkDelete(FloatVectorId id);
+	void AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id);
+	[[noreturn]] void AddPointConcurrent(ConstFloatVectorView, FloatVectorId);
+	void ResizeIndex(size_t newMaxElements);
+
+	SearchResultQueue SearchKnn(const float* queryDataRaw, std::optional<float> queryDataNorm, size_t k, size_t ef = 0) const;
+	SearchResultQueue SearchRange(const float* queryDataRaw, std::optional<float> queryDataNorm, float radius, size_t ef) const;
+
+	bool IsQuantized() const noexcept { return false; }
+	bool QuantizationAvailable() const noexcept { return false; }
+
+	VectorMetric Metric() const noexcept { return graph_.Metric(); }
+	size_t Dim() const noexcept { return graph_.Dim(); }
+	const HnswGraph& Graph() const noexcept { return graph_; }
+
+private:
+	void syncDevice() const;
+
+	HnswGraph graph_;
+	const int device_;
+	mutable std::mutex syncMtx_;
+	mutable rxgpu_index* dev_ = nullptr;
+	mutable size_t syncedRows_ = 0;
+	mutable bool graphDirty_ = true;
+	mutable bool deletedDirty_ = false;
+};
+
+}  // namespace rxgpu::host

@@ -169,3 +169,74 @@ void rxhost_graph_export(void* h, uint32_t* links0, int32_t* levels, uint64_t* l
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- GpuHnswMap
+#include "gpu_hnsw_map.h"
+
+extern "C" {
+
+void* rxhost_hnsw_create(int metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device) {
+	GpuHnswMap* m = nullptr;
+	guarded([&] { m = new GpuHnswMap(VectorMetric(metric), dim, maxElements, M, efConstruction, device); });
+	return m;
+}
+void* rxhost_hnsw_clone(void* h, size_t newCapacity) {
+	GpuHnswMap* m = nullptr;
+	guarded([&] { m = new GpuHnswMap(*static_cast<GpuHnswMap*>(h), newCapacity); });
+	return m;
+}
+void rxhost_hnsw_destroy(void* h) { delete static_cast<GpuHnswMap*>(h); }
+int rxhost_hnsw_add_many(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels) {
+	return guarded([&] {
+		auto* m = static_cast<GpuHnswMap*>(h);
+		for (size_t i = 0; i < n; ++i) m->AddPointNoLock(ConstFloatVectorView(vecs + i * dim, dim), FloatVectorId::FromNumber(labels[i]));
+	});
+}
+int rxhost_hnsw_add_concurrent(void* h, const float* vec, size_t dim, uint64_t label) {
+	return guarded([&] { static_cast<GpuHnswMap*>(h)->AddPointConcurrent(ConstFloatVectorView(vec, dim), FloatVectorId::FromNumber(label)); });
+}
+int rxhost_hnsw_mark_delete(void* h, uint64_t label) {
+	return guarded([&] { static_cast<GpuHnswMap*>(h)->MarkDelete(FloatVectorId::FromNumber(label)); });
+}
+int rxhost_hnsw_resize(void* h, size_t n) {
+	return guarded([&] { static_cast<GpuHnswMap*>(h)->ResizeIndex(n); });
+}
+size_t rxhost_hnsw_count(void* h) { return static_cast<GpuHnswMap*>(h)->CurrentElementCount(); }
+size_t rxhost_hnsw_deleted_count(void* h) { return static_cast<GpuHnswMap*>(h)->DeletedCountUnsafe(); }
+void* rxhost_hnsw_graph(void* h) { return const_cast<HnswGraph*>(&static_cast<GpuHnswMap*>(h)->Graph()); }
+long rxhost_hnsw_search_knn(void* h, const float* q, size_t k, size_t ef, float* outDist, uint64_t* outLabel) {
+	long n = -1;
+	guarded([&] {
+		auto res = static_cast<const GpuHnswMap*>(h)->SearchKnn(q, std::nullopt, k, ef);
+		n = long(drain(res, outDist, outLabel, k));
+	});
+	return n;
+}
+long rxhost_hnsw_search_range(void* h, const float* q, float radius, size_t ef, float* outDist, uint64_t* outLabel, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		auto res = static_cast<const GpuHnswMap*>(h)->SearchRange(q, std::nullopt, radius, ef);
+		n = long(drain(res, outDist, outLabel, cap));
+	});
+	return n;
+}
+long rxhost_hnsw_select(void* h, const float* key, size_t dim, long k, size_t ef, int has_radius, float radius, int need_sort, int is_array,
+						int32_t* outIds, float* outRanks, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		KnnSearchParams p;
+		if (k >= 0) p.k = size_t(k);
+		if (has_radius) p.radius = radius;
+		p.ef = ef;
+		p.Validate(true);
+		auto res = KnnSelect(*static_cast<const GpuHnswMap*>(h), ConstFloatVectorView(key, dim), p, need_sort != 0, is_array != 0);
+		n = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
+			outIds[i] = res.ids[i];
+			outRanks[i] = res.ranks[i];
+		}
+	});
+	return n;
+}
+
+}  // extern "C"

@@ -171,7 +171,8 @@ class GpuBruteforceMap:
 class HnswGraph:
     """rxgpu::host::HnswGraph — the host-side graph builder (no GPU needed to BUILD)."""
 
-    def __init__(self, metric: int, dim: int, max_elements: int, M: int = 16, ef_construction: int = 200):
+    @staticmethod
+    def _bind():
         L = lib()
         if not hasattr(L, "_graph_bound"):
             L.rxhost_graph_create.restype = _vp
@@ -182,6 +183,10 @@ class HnswGraph:
             L.rxhost_graph_info.argtypes = [_vp, _vp]
             L.rxhost_graph_export.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
             L._graph_bound = True
+        return L
+
+    def __init__(self, metric: int, dim: int, max_elements: int, M: int = 16, ef_construction: int = 200):
+        L = self._bind()
         self.dim, self.metric = dim, metric
         self.h = L.rxhost_graph_create(metric, dim, max_elements, M, ef_construction)
         if not self.h:
@@ -224,3 +229,115 @@ class HnswGraph:
                                   upper_off.ctypes.data, upper.ctypes.data)
         return dict(metric=self.metric, n=n, dim=self.dim, M=M, maxM0=maxM0, maxlevel=maxlevel, entry=entry & 0xFFFFFFFF, num_deleted=ndel,
                     links0=links0, upper_off=upper_off, upper=upper, levels=levels, labels=labels, deleted=deleted)
+
+
+class GpuHnswMap:
+    """rxgpu::host::GpuHnswMap (drop-in for hnswlib::HierarchicalNSW<Synchronization::None>)."""
+
+    def __init__(self, metric: int, dim: int, max_elements: int, M: int = 16, ef_construction: int = 200, device: int = 0, _handle=None):
+        L = lib()
+        if not hasattr(L, "_hnsw_bound"):
+            L.rxhost_hnsw_create.restype = _vp
+            L.rxhost_hnsw_create.argtypes = [_i, _sz, _sz, _sz, _sz, _i]
+            L.rxhost_hnsw_clone.restype = _vp
+            L.rxhost_hnsw_clone.argtypes = [_vp, _sz]
+            L.rxhost_hnsw_destroy.argtypes = [_vp]
+            L.rxhost_hnsw_add_many.argtypes = [_vp, _vp, _sz, _sz, _vp]
+            L.rxhost_hnsw_add_concurrent.argtypes = [_vp, _vp, _sz, _u64]
+            L.rxhost_hnsw_mark_delete.argtypes = [_vp, _u64]
+            L.rxhost_hnsw_resize.argtypes = [_vp, _sz]
+            L.rxhost_hnsw_count.restype = _sz
+            L.rxhost_hnsw_count.argtypes = [_vp]
+            L.rxhost_hnsw_deleted_count.restype = _sz
+            L.rxhost_hnsw_deleted_count.argtypes = [_vp]
+            L.rxhost_hnsw_graph.restype = _vp
+            L.rxhost_hnsw_graph.argtypes = [_vp]
+            L.rxhost_hnsw_search_knn.restype = _l
+            L.rxhost_hnsw_search_knn.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+            L.rxhost_hnsw_search_range.restype = _l
+            L.rxhost_hnsw_search_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
+            L.rxhost_hnsw_select.restype = _l
+            L.rxhost_hnsw_select.argtypes = [_vp, _vp, _sz, _l, _sz, _i, _f, _i, _i, _vp, _vp, _sz]
+            L._hnsw_bound = True
+        self.dim, self.metric = dim, metric
+        self.h = _handle if _handle is not None else L.rxhost_hnsw_create(metric, dim, max_elements, M, ef_construction, device)
+        if not self.h:
+            _raise()
+
+    def clone(self, new_capacity: int) -> "GpuHnswMap":
+        h = lib().rxhost_hnsw_clone(self.h, new_capacity)
+        if not h:
+            _raise()
+        return GpuHnswMap(self.metric, self.dim, 0, _handle=h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rxhost_hnsw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add(self, vecs, labels):
+        vecs = _f32(vecs).reshape(-1, self.dim)
+        labels = np.ascontiguousarray(labels, np.uint64).reshape(-1)
+        rc = lib().rxhost_hnsw_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data)
+        if rc:
+            _raise(rc)
+
+    def add_concurrent(self, vec, label):
+        vec = _f32(vec)
+        rc = lib().rxhost_hnsw_add_concurrent(self.h, vec.ctypes.data, self.dim, int(label))
+        if rc:
+            _raise(rc)
+
+    def mark_delete(self, label):
+        rc = lib().rxhost_hnsw_mark_delete(self.h, int(label))
+        if rc:
+            _raise(rc)
+
+    def resize(self, n):
+        rc = lib().rxhost_hnsw_resize(self.h, n)
+        if rc:
+            _raise(rc)
+
+    count = property(lambda self: lib().rxhost_hnsw_count(self.h))
+    deleted_count = property(lambda self: lib().rxhost_hnsw_deleted_count(self.h))
+
+    def export_graph(self) -> dict:
+        """Flat graph of the host builder (borrowed HnswGraph handle)."""
+        HnswGraph._bind()
+        g = HnswGraph.__new__(HnswGraph)
+        g.dim, g.metric, g.h = self.dim, self.metric, lib().rxhost_hnsw_graph(self.h)
+        try:
+            return g.export()
+        finally:
+            g.h = None   # borrowed: owned by the Map
+
+    def search_knn(self, q, k, ef=0):
+        q = _f32(q)
+        od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+        n = lib().rxhost_hnsw_search_knn(self.h, q.ctypes.data, k, ef, od.ctypes.data, ol.ctypes.data)
+        if n < 0:
+            _raise()
+        return od[:n].copy(), ol[:n].copy()
+
+    def search_range(self, q, radius, ef, cap=1 << 20):
+        q = _f32(q)
+        od, ol = np.empty(cap, np.float32), np.empty(cap, np.uint64)
+        n = lib().rxhost_hnsw_search_range(self.h, q.ctypes.data, radius, ef, od.ctypes.data, ol.ctypes.data, cap)
+        if n < 0:
+            _raise()
+        return od[:n].copy(), ol[:n].copy()
+
+    def select(self, key, k=None, ef=0, radius=None, need_sort=True, is_array=False, cap=1 << 16):
+        key = _f32(key)
+        ids, ranks = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        n = lib().rxhost_hnsw_select(self.h, key.ctypes.data, key.shape[0], -1 if k is None else k, ef, int(radius is not None),
+                                     0.0 if radius is None else radius, int(need_sort), int(is_array), ids.ctypes.data, ranks.ctypes.data, cap)
+        if n < 0:
+            _raise()
+        return ids[:n].copy(), ranks[:n].copy()
