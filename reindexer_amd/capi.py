@@ -231,7 +231,7 @@ class VectorIndex:
         _check(lib().rxgpu_hnsw_update_deleted(self._h, deleted.ctypes.data, num_deleted))
 
     def hnsw_search_knn(self, queries, k: int, ef: int = 0):
-        q = _f32(queries).reshape(-1, self.dim)
+        q = _f32c(queries).reshape(-1, self.dim)
         nq = q.shape[0]
         dist = np.full((nq, max(k, 1)), np.inf, np.float32)
         row = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
