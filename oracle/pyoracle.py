@@ -348,3 +348,109 @@ def oracle_hnsw_search_knn(orc: Oracle, g: dict, q, k: int, ef: int = 0, inv_nor
         orc.L.orc_hnsw_last_stats(C.byref(nd), C.byref(nh))
         return od[:c].copy(), ol[:c].copy(), int(nd.value), int(nh.value)
     return od[:c].copy(), ol[:c].copy()
+
+
+# ------------------------------------------------------------------------------------------------ BM25 (oracle_bm25.c)
+class _FtConfig(C.Structure):
+    _fields_ = [("k1", C.c_double), ("b", C.c_double), ("summation_ratio", C.c_double), ("full_match_boost", C.c_double),
+                ("min_rank", C.c_int), ("merge_limit", C.c_uint32), ("num_fields", C.c_uint32),
+                ("bm25_boost", _vp), ("bm25_weight", _vp), ("term_len_boost", _vp), ("term_len_weight", _vp),
+                ("position_boost", _vp), ("position_weight", _vp)]
+
+
+class _FtTermOpts(C.Structure):
+    _fields_ = [("boost", _f), ("term_len_boost", _f), ("field_boost", _vp), ("need_sum_rank", _vp)]
+
+
+class _FtPostings(C.Structure):
+    _fields_ = [("n", _u64), ("doc", _vp), ("ent_off", _vp), ("ent_field", _vp), ("ent_tf", _vp), ("ent_first_pos", _vp), ("proc", _f)]
+
+
+class FtOracle:
+    """Restated ft_fast single-term merge.  cfg / opts are plain dicts (defaults = the reference's FTConfig defaults)."""
+
+    def __init__(self, orc: Oracle):
+        L = self.L = orc.L
+        L.orc_bm25rx_idf.restype = C.c_double
+        L.orc_bm25rx_idf.argtypes = [C.c_double, C.c_double]
+        L.orc_bm25rx_get.restype = C.c_double
+        L.orc_bm25rx_get.argtypes = [C.c_double] * 6
+        L.orc_pos2rank.restype = _f
+        L.orc_pos2rank.argtypes = [C.c_uint]
+        L.orc_bound.restype = _f
+        L.orc_bound.argtypes = [_f, _f, _f]
+        L.orc_calc_term_rank.restype = _f
+        L.orc_calc_term_rank.argtypes = [_vp, _vp, C.c_double, _f, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.orc_ft_merge_simple.restype = _sz
+        L.orc_ft_merge_simple.argtypes = [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp]
+
+    @staticmethod
+    def default_config(num_fields=1, **kw):
+        cfg = dict(k1=2.0, b=0.75, summation_ratio=0.0, full_match_boost=1.1, min_rank=5, merge_limit=20000, num_fields=num_fields,
+                   bm25_boost=[1.0] * num_fields, bm25_weight=[0.1] * num_fields, term_len_boost=[1.0] * num_fields,
+                   term_len_weight=[0.3] * num_fields, position_boost=[1.0] * num_fields, position_weight=[0.1] * num_fields)
+        cfg.update(kw)
+        return cfg
+
+    @staticmethod
+    def default_opts(num_fields=1, **kw):
+        o = dict(boost=1.0, term_len_boost=1.0, field_boost=[1.0] * num_fields, need_sum_rank=[0] * num_fields)
+        o.update(kw)
+        return o
+
+    def _cfg(self, cfg):
+        keep = [np.ascontiguousarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                                   "position_boost", "position_weight")]
+        c = _FtConfig(cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg["min_rank"], cfg["merge_limit"],
+                      cfg["num_fields"], *[a.ctypes.data for a in keep])
+        return c, keep
+
+    def _opts(self, opts):
+        fb = np.ascontiguousarray(opts["field_boost"], np.float32)
+        ns = np.ascontiguousarray(opts["need_sum_rank"], np.uint8)
+        return _FtTermOpts(opts["boost"], opts["term_len_boost"], fb.ctypes.data, ns.ctypes.data), (fb, ns)
+
+    def idf(self, total_docs, matched):
+        return self.L.orc_bm25rx_idf(total_docs, matched)
+
+    def term_rank(self, cfg, opts, idf, proc, ent_field, ent_tf, ent_first_pos, words_in_field, avg_words):
+        c, k1 = self._cfg(cfg)
+        o, k2 = self._opts(opts)
+        ef = np.ascontiguousarray(ent_field, np.uint8)
+        et = np.ascontiguousarray(ent_tf, np.uint32)
+        ep = np.ascontiguousarray(ent_first_pos, np.uint32)
+        w = _f32(words_in_field)
+        a = _f32(avg_words)
+        field = C.c_uint8(0)
+        bn, tl, pr = _f(0), _f(0), _f(0)
+        r = self.L.orc_calc_term_rank(C.byref(c), C.byref(o), idf, proc, ef.shape[0], ef.ctypes.data, et.ctypes.data, ep.ctypes.data,
+                                      w.ctypes.data, a.ctypes.data, C.byref(field), C.byref(bn), C.byref(tl), C.byref(pr))
+        return np.float32(r), int(field.value), np.float32(bn.value), np.float32(tl.value), np.float32(pr.value)
+
+    def merge_simple(self, cfg, opts, total_docs, words, avg_words, removed, excluded, subs, sort_by_rank=True):
+        """subs: list of dicts(doc, ent_off, ent_field, ent_tf, ent_first_pos, proc) already sorted by proc desc."""
+        c, k1 = self._cfg(cfg)
+        o, k2 = self._opts(opts)
+        words = _f32(words)
+        avg = _f32(avg_words)
+        rem = np.ascontiguousarray(removed, np.uint8) if removed is not None else None
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        arr = (_FtPostings * len(subs))()
+        keep = []
+        total = 0
+        for i, s in enumerate(subs):
+            d = np.ascontiguousarray(s["doc"], np.uint32)
+            eo = np.ascontiguousarray(s["ent_off"], np.uint32)
+            ef = np.ascontiguousarray(s["ent_field"], np.uint8)
+            et = np.ascontiguousarray(s["ent_tf"], np.uint32)
+            ep = np.ascontiguousarray(s["ent_first_pos"], np.uint32)
+            keep += [d, eo, ef, et, ep]
+            arr[i] = _FtPostings(d.shape[0], d.ctypes.data, eo.ctypes.data, ef.ctypes.data, et.ctypes.data, ep.ctypes.data, s["proc"])
+            total += d.shape[0]
+        cap = max(1, min(cfg["merge_limit"], total))
+        od, op = np.zeros(cap, np.uint32), np.zeros(cap, np.float32)
+        of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        n = self.L.orc_ft_merge_simple(C.byref(c), C.byref(o), total_docs, words.ctypes.data, avg.ctypes.data,
+                                       rem.ctypes.data if rem is not None else None, exc.ctypes.data if exc is not None else None,
+                                       arr, len(subs), int(sort_by_rank), od.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data)
+        return od[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()

@@ -1,0 +1,123 @@
+"""CPU: pins the BM25 restatement (oracle/oracle_bm25.c) to the reference's OWN golden vectors — the debug_rank() strings of
+cpp_src/gtests/tests/unit/ft/ft_generic.cc:326-443 (test FTGenericApi.DebugInfo).  fmt prints floats in shortest round-trip
+form, so parsing the printed value back to float32 must give EXACTLY the float the merger computed.
+
+Corpus of that test (5 docs + the empty sentinel vdoc, one FT field, default FTConfig):
+  1 "Маша ела кашу. Каша кушалась сама. Машу ругали."            8 words
+  2 "Коля, Сеня гуляли."                                         3 words
+  3 "слово простая фраза что то еще."                            6 words
+  4 "слово начало простая фраза конец что то еще простая фраза слово слово."   12 words
+  5 "жил пил гулял"                                              3 words          => average 6.4 words
+"""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FtOracle
+
+AVG = np.float32(32.0 / 5.0)
+N_DOCS = 5   # totalNumDocs_ - 1 ("first doc is always empty", mergerimpl.h:122-124)
+
+# (matched docs M, tf, words in field, first position, proc, termLenBoost fed by the DSL)  ->  golden strings
+KATS = [
+    # ft_generic.cc:326-327  "маша"
+    dict(M=1, tf=1, words=8, pos=0, proc=100.0, tlb_in=1.0, bm25_norm="0.979844", tlb="1", prank="1", term_rank="97.9844"),
+    dict(M=1, tf=1, words=8, pos=6, proc=80.0, tlb_in=1.0, bm25_norm="0.979844", tlb="1", prank="0.994", term_rank="77.91719"),
+    # :346-347  "коля сеня"
+    dict(M=1, tf=1, words=3, pos=0, proc=100.0, tlb_in=1.0, bm25_norm="1.0223141", tlb="1", prank="1", term_rank="102.23141"),
+    dict(M=1, tf=1, words=3, pos=1, proc=100.0, tlb_in=1.0, bm25_norm="1.0223141", tlb="1", prank="0.999", term_rank="102.12917"),
+    # :363-375  phrases over docs 3 and 4
+    dict(M=2, tf=1, words=6, pos=1, proc=100.0, tlb_in=1.0, bm25_norm="0.9399332", tlb="1", prank="0.999", term_rank="93.89933"),
+    dict(M=2, tf=1, words=6, pos=2, proc=100.0, tlb_in=5.0 / 7.0, bm25_norm="0.9399332", tlb="0.9142857", prank="0.998", term_rank="85.76488"),
+    dict(M=1, tf=1, words=12, pos=1, proc=100.0, tlb_in=6.0 / 7.0, bm25_norm="0.96248657", tlb="0.95714283", prank="0.999", term_rank="92.031586"),
+    dict(M=2, tf=2, words=12, pos=2, proc=100.0, tlb_in=1.0, bm25_norm="0.9436916", tlb="1", prank="0.998", term_rank="94.18042"),
+    dict(M=2, tf=2, words=12, pos=3, proc=100.0, tlb_in=5.0 / 7.0, bm25_norm="0.9436916", tlb="0.9142857", prank="0.997", term_rank="86.02153"),
+    dict(M=1, tf=1, words=12, pos=4, proc=100.0, tlb_in=5.0 / 7.0, bm25_norm="0.96248657", tlb="0.9142857", prank="0.996", term_rank="87.646774"),
+    # :402-410  stemmed variants with fractional proc
+    dict(M=2, tf=1, words=6, pos=1, proc=79.0, tlb_in=1.0, bm25_norm="0.9399332", tlb="1", prank="0.999", term_rank="74.180466"),
+    dict(M=2, tf=1, words=6, pos=2, proc=81.25, tlb_in=7.0 / 8.0, bm25_norm="0.9399332", tlb="0.9625", prank="0.998", term_rank="73.3587"),
+    dict(M=2, tf=2, words=12, pos=2, proc=79.0, tlb_in=1.0, bm25_norm="0.9436916", tlb="1", prank="0.998", term_rank="74.402534"),
+    dict(M=2, tf=2, words=12, pos=3, proc=81.25, tlb_in=7.0 / 8.0, bm25_norm="0.9436916", tlb="0.9625", prank="0.997", term_rank="73.57823"),
+    # :441-443  "жил~ пил" (typo variant with proc 75.99915)
+    dict(M=1, tf=1, words=3, pos=1, proc=75.99915, tlb_in=1.0, bm25_norm="1.0223141", tlb="1", prank="0.999", term_rank="77.61731"),
+]
+
+
+def f32(s):
+    return np.float32(float(s))
+
+
+@pytest.fixture(scope="module")
+def ft(oracle):
+    return FtOracle(oracle)
+
+
+@pytest.mark.parametrize("kat", KATS, ids=[f"{k['term_rank']}" for k in KATS])
+def test_term_rank_matches_reference_golden_strings(ft, kat):
+    cfg, opts = ft.default_config(1), ft.default_opts(1, term_len_boost=np.float32(kat["tlb_in"]))
+    idf = ft.idf(N_DOCS, kat["M"])
+    rank, field, bm25n, tlb, prank = ft.term_rank(cfg, opts, idf, np.float32(kat["proc"]), [0], [kat["tf"]], [kat["pos"]],
+                                                  [np.float32(kat["words"])], [AVG])
+    assert field == 0
+    assert bm25n == f32(kat["bm25_norm"]), (bm25n, kat["bm25_norm"])
+    assert tlb == f32(kat["tlb"])
+    assert prank == f32(kat["prank"])
+    assert rank == f32(kat["term_rank"]), (rank, kat["term_rank"])
+
+
+def test_idf_floor_and_shape(ft):
+    assert ft.idf(5, 1) == pytest.approx(np.log(5) / np.log(6))
+    assert ft.idf(1000, 999) == 0.2          # "saturate min to 0.2" (bm25.h:22-25)
+    assert ft.idf(10, 10) == 0.2
+
+
+def make_postings(rng, total_docs, nfields, n, max_tf=4):
+    docs = np.sort(rng.choice(np.arange(1, total_docs), n, replace=False)).astype(np.uint32)
+    ent_off = [0]
+    ef, et, ep = [], [], []
+    for _ in range(n):
+        fields = np.sort(rng.choice(nfields, rng.integers(1, min(nfields, 3) + 1), replace=False))
+        for f in fields:
+            ef.append(f)
+            et.append(rng.integers(1, max_tf + 1))
+            ep.append(rng.integers(0, 300))
+        ent_off.append(len(ef))
+    return dict(doc=docs, ent_off=np.array(ent_off, np.uint32), ent_field=np.array(ef, np.uint8), ent_tf=np.array(et, np.uint32),
+                ent_first_pos=np.array(ep, np.uint32))
+
+
+def test_merge_simple_semantics(ft):
+    """max over sub-terms with the first max winning, mergeLimit in sequence order, removed/excluded docs, minRank filter,
+    full-match boost, 0..255 normalisation."""
+    rng = np.random.default_rng(1)
+    total, nf = 400, 3
+    words = rng.integers(1, 30, (total, nf)).astype(np.float32)
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    removed = np.zeros(total, np.uint8)
+    removed[rng.choice(total, 20, replace=False)] = 1
+    excluded = np.zeros(total, np.uint8)
+    excluded[rng.choice(total, 20, replace=False)] = 1
+    subs = []
+    for proc in (100.0, 85.0, 60.0):
+        s = make_postings(rng, total, nf, 150)
+        s["proc"] = proc
+        subs.append(s)
+    cfg = ft.default_config(nf, merge_limit=120)
+    opts = ft.default_opts(nf, field_boost=[1.0, 0.5, 0.0])
+    doc, proc, field, norm = ft.merge_simple(cfg, opts, total, words, avg, removed, excluded, subs, sort_by_rank=False)
+    assert 0 < doc.shape[0] <= 120
+    assert not removed[doc].any() and not excluded[doc].any()
+    assert np.all(field != 2)                                      # zero-boost field never wins
+    assert norm.max() == 255 or proc.max() <= 255                  # scaled only when the raw max exceeds 255
+    assert np.all(norm == proc.astype(np.uint8))
+    # admitted docs are the first `merge_limit` distinct valid docs in (sub-term, posting) order
+    seen = []
+    for s in subs:
+        for i, d in enumerate(s["doc"]):
+            fields = s["ent_field"][s["ent_off"][i]:s["ent_off"][i + 1]]
+            if removed[d] or excluded[d] or d in seen or np.all(fields == 2):   # only zero-boost fields => rank 0 => skipped
+                continue
+            seen.append(int(d))
+    assert set(doc.tolist()) <= set(seen[:120])
+    doc2, proc2, field2, norm2 = ft.merge_simple(cfg, opts, total, words, avg, removed, excluded, subs, sort_by_rank=True)
+    assert sorted(doc2.tolist()) == sorted(doc.tolist()) and np.all(np.diff(norm2.astype(int)) <= 0)

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""HNSW leg (BASELINE configs[2], scaled): cosine, M=16, ef_construction=200, ef=128, k=10 on N x 768.
+
+    python tools/bench_hnsw.py --rows 100000 --queries 4096 [--out profiles/r1_hnsw.json]
+
+The full 10M x 768 graph takes hours to build on any CPU (the reference's build is CPU-only too), so this leg runs a scaled
+corpus: graph built on the host by the product's builder, searched (a) on the MI355X through GpuHnswMap / rxgpu_hnsw_search_knn
+and (b) by the reference engine itself (oracle/_ref, AVX-512) on the SAME graph where that library loads — reporting
+queries/s, achieved HBM GB/s from the kernel's own counters (distance evaluations x D x 4 + hops x (1+2M) x 4), the fraction
+of queries whose result equals the reference's, and recall@10 vs exact brute force (computed on the GPU by the exact scan).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
+
+from reindexer_amd import capi, hostapi  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=100_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--queries", type=int, default=4096)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--ef", type=int, default=128)
+    ap.add_argument("--M", type=int, default=16)
+    ap.add_argument("--efc", type=int, default=200)
+    ap.add_argument("--metric", default="cosine")
+    ap.add_argument("--cpu-queries", type=int, default=256)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    metric = capi.METRICS[args.metric]
+    rng = np.random.default_rng(20260924)
+    rows = rng.normal(0, 0.25, (args.rows, args.dim)).astype(np.float32)
+    queries = rng.normal(0, 0.25, (args.queries, args.dim)).astype(np.float32)
+    labels = np.arange(args.rows, dtype=np.uint64) << np.uint64(32)
+    if metric == 2:
+        queries = np.stack([hostapi.normalize_copy(q)[0] for q in queries])
+
+    t0 = time.perf_counter()
+    m = hostapi.GpuHnswMap(metric, args.dim, args.rows, M=args.M, ef_construction=args.efc)
+    m.add(rows, labels)
+    build_s = time.perf_counter() - t0
+    g = m.export_graph()
+
+    # GPU search through the C-ABI in one batched call (the Map's SearchKnn is the nq = 1 case of the same entry point)
+    inv = np.array([hostapi.l2_module(r) for r in rows], np.float32) if metric == 2 else None
+    ix = capi.VectorIndex(metric, args.dim, args.rows)
+    ix.upload_rows(0, rows, inv)
+    ix.hnsw_attach_graph(g)
+    ix.hnsw_search_knn(queries[:64], args.k, args.ef)   # warmup
+    ix.hnsw_read_stats()
+    ix.profile_enable(True)
+    t0 = time.perf_counter()
+    dist, row, cnt = ix.hnsw_search_knn(queries, args.k, args.ef)
+    gpu_s = time.perf_counter() - t0
+    launches, kernel_ms = ix.profile_read("hnsw")
+    ix.profile_enable(False)
+    evals, hops = ix.hnsw_read_stats()
+    bytes_algo = evals * args.dim * 4 + hops * (1 + 2 * args.M) * 4
+    # single-query latency through the Map
+    t0 = time.perf_counter()
+    for q in queries[:32]:
+        m.search_knn(q, args.k, args.ef)
+    lat_ms = (time.perf_counter() - t0) / 32 * 1e3
+
+    # exact ground truth on the GPU (fused scan / batched path)
+    bf = capi.VectorIndex(metric, args.dim, args.rows)
+    bf.upload_rows(0, rows, inv)
+    tq = min(args.queries, 512)
+    _, trow, _ = bf.search_knn(queries[:tq], args.k)
+    recall = float(np.mean([len(set(trow[i].tolist()) & set(row[i, :int(cnt[i])].tolist())) / args.k for i in range(tq)]))
+
+    out = {
+        "workload": f"HNSW {args.metric} M={args.M} efC={args.efc} ef={args.ef} k={args.k}, {args.rows} x {args.dim} (scaled from BASELINE configs[2])",
+        "build_seconds_host_1thread": build_s,
+        "gpu": {"queries": args.queries, "queries_per_sec": args.queries / gpu_s, "kernel_ms_total": kernel_ms, "launches": launches,
+                "queries_per_sec_kernel_only": args.queries / (kernel_ms / 1e3) if kernel_ms else None,
+                "map_single_query_latency_ms": lat_ms, "distance_evals_per_query": evals / args.queries, "hops_per_query": hops / args.queries,
+                "roofline": {"bound": "hbm", "achieved": bytes_algo / (kernel_ms / 1e3) / 1e9 if kernel_ms else None, "peak": 8000.0, "unit": "GB/s",
+                             "frac": bytes_algo / (kernel_ms / 1e3) / 1e9 / 8000.0 if kernel_ms else None,
+                             "algorithmic_bytes": bytes_algo, "note": "random 3 KB row gathers; bytes = evals*D*4 + hops*(1+2M)*4"}},
+        "recall_at_k_vs_exact": recall,
+    }
+    try:
+        from oracle import pyoracle
+        ref = pyoracle.ref_or_none()
+        if ref is not None and ref.simd_level == 3:
+            r = pyoracle.RefHnsw(ref, metric, args.dim, args.rows, M=args.M, ef_construction=args.efc)
+            t0 = time.perf_counter()
+            r.add(rows, labels)
+            ref_build = time.perf_counter() - t0
+            nq = min(args.cpu_queries, args.queries)
+            t0 = time.perf_counter()
+            res = [r.search_knn(queries[i], args.k, args.ef) for i in range(nq)]
+            cpu_s = time.perf_counter() - t0
+            same = 0
+            for i in range(nq):
+                c = int(cnt[i])
+                gl = np.sort(labels[row[i, :c]])
+                same += int(np.array_equal(gl, np.sort(res[i][1])))
+            threads = min(os.cpu_count() or 1, 64)
+            def worker(t):
+                for j in range(8):
+                    r.search_knn(queries[(t * 8 + j) % args.queries], args.k, args.ef)
+            ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+            t0 = time.perf_counter()
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            cpu_all_s = time.perf_counter() - t0
+            out["cpu_baseline"] = {"kind": "reference", "value": nq / cpu_s, "unit": "queries/s", "cores": 1, "sample": f"{nq} queries, same graph",
+                                   "all_cores": {"value": threads * 8 / cpu_all_s, "cores": threads}, "build_seconds": ref_build}
+            out["equal_to_reference_frac"] = same / nq
+            r.close()
+    except Exception as e:  # the GPU numbers are still reported
+        out["cpu_baseline"] = {"error": repr(e)}
+    text = json.dumps(out)
+    print(text)
+    if args.out:
+        Path(args.out).write_text(text + "\n")
+
+
+if __name__ == "__main__":
+    main()
