@@ -142,6 +142,50 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * ft_fast BM25 score accumulation (ft::Merger<..>::mergeSimple, cpp_src/core/ft/ft_fast/mergerimpl.h:194-250)
+ * ------------------------------------------------------------------------------------------------------- */
+
+typedef struct rxgpu_ft_index rxgpu_ft_index; /* device mirror of one ft_fast DataHolder: vdoc statistics + flattened postings */
+
+/* FTConfig fields read by the merge (cpp_src/core/ft/config/ftconfig.h:118-124,151-220); per-field arrays have num_fields entries. */
+typedef struct rxgpu_ft_config {
+	double bm25_k1, bm25_b;                    /* Bm25Config: 2.0, 0.75 */
+	double summation_ranks_by_fields_ratio;    /* 0.0 */
+	double full_match_boost;                   /* 1.1 (applied by the host merger, carried here for completeness) */
+	int32_t min_rank;                          /* 5   (host) */
+	uint32_t merge_limit;                      /* 20000 */
+	uint32_t num_fields;
+	const double *bm25_boost, *bm25_weight, *term_len_boost, *term_len_weight, *position_boost, *position_weight;
+} rxgpu_ft_config;
+
+/* FtDslOpts of the query term (cpp_src/core/ft/ftdsl.h:13-35). */
+typedef struct rxgpu_ft_term_opts {
+	float boost, term_len_boost;
+	const float* field_boost;       /* FtDslFieldOpts::boost per field */
+	const uint8_t* need_sum_rank;   /* FtDslFieldOpts::needSumRank per field (at most 8 set on the GPU engine) */
+} rxgpu_ft_term_opts;
+
+int rxgpu_ft_create(uint32_t num_fields, int device, rxgpu_ft_index** out);
+void rxgpu_ft_destroy(rxgpu_ft_index* h);
+/* The DocsStatsGetter of IndexText (cpp_src/core/index/indextext/indextext.h:245-258): total_docs counts the empty sentinel
+ * vdoc 0 ("first doc is always empty"); words_in_field [total_docs][num_fields] = VDoc::wordCounts_; avg_words [num_fields];
+ * removed [total_docs] or NULL. */
+int rxgpu_ft_set_docs(rxgpu_ft_index* h, uint64_t total_docs, const float* words_in_field, const float* avg_words, const uint8_t* removed);
+/* Posting list of one dictionary word (IdRelVec / PackedIdRelVec, cpp_src/core/ft/idrelset.h:62-294) flattened to SoA: ascending
+ * vdoc ids; per posting a run [ent_off[i], ent_off[i+1]) of (field, occurrences in that field, first position in that field),
+ * fields ascending — exactly what calcTermRankImpl derives from IdRelType::Pos() (phrasemergerimpl.h:24-49). */
+int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uint32_t* doc, const uint32_t* ent_off, const uint8_t* ent_field,
+					  const uint32_t* ent_tf, const uint32_t* ent_first_pos);
+/* Device half of Merger::mergeSimple for a Simple() query: nsub sub-terms (word_ids[], procs[], caller-sorted by proc desc like
+ * SortSubterms), docsExcluded bitmap or NULL.  Writes the admitted documents IN MERGE ORDER with their raw rank and field
+ * (before addFullMatchBoost / postProcessResults, merger.h:100-155, which the host merger applies to these <= merge_limit rows). */
+int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
+							  const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc,
+							  uint8_t* out_field, uint64_t cap, uint64_t* out_n);
+/* Postings scored / kernel milliseconds since the last call (roofline accounting: 20 B per posting). */
+int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Instrumentation (bench.py roofline leg): HIP-event timing of the dominant kernel on its own stream.
  * ------------------------------------------------------------------------------------------------------- */
 int rxgpu_profile_enable(rxgpu_index* h, int on);

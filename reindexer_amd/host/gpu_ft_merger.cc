@@ -1,0 +1,140 @@
+#include "gpu_ft_merger.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+#include "rxgpu.h"
+
+namespace rxgpu::host {
+
+namespace {
+[[noreturn]] void throwDevice(const char* what) { throw std::runtime_error(std::string(what) + ": " + rxgpu_last_error()); }
+}  // namespace
+
+void FlatPostings::Add(uint32_t vdoc, const std::pair<uint32_t, uint32_t>* fieldPos, size_t count) {
+	doc.push_back(vdoc);
+	size_t i = 0;
+	while (i < count) {   // group by field like calcTermRankImpl (phrasemergerimpl.h:24-38)
+		const uint32_t f = fieldPos[i].first;
+		const size_t begin = i;
+		while (i < count && fieldPos[i].first == f) ++i;
+		entField.push_back(uint8_t(f));
+		entTf.push_back(uint32_t(i - begin));
+		entFirstPos.push_back(fieldPos[begin].second);
+	}
+	entOff.push_back(uint32_t(entField.size()));
+}
+
+GpuFtMerger::GpuFtMerger(size_t numFields, int device) : numFields_(numFields) {
+	if (rxgpu_ft_create(uint32_t(numFields), device, &dev_) != RXGPU_OK) throwDevice("GpuFtMerger: device index creation failed");
+}
+
+GpuFtMerger::~GpuFtMerger() {
+	if (dev_) rxgpu_ft_destroy(dev_);
+}
+
+void GpuFtMerger::SetDocs(size_t totalDocs, const float* wordsInField, const float* avgWords, const uint8_t* removed) {
+	if (rxgpu_ft_set_docs(dev_, totalDocs, wordsInField, avgWords, removed) != RXGPU_OK) throwDevice("SetDocs");
+	totalDocs_ = totalDocs;
+	words_.assign(wordsInField, wordsInField + totalDocs * numFields_);
+}
+
+void GpuFtMerger::SetWord(uint32_t wordId, const FlatPostings& p) {
+	if (rxgpu_ft_set_word(dev_, wordId, p.doc.size(), p.doc.data(), p.entOff.data(), p.entField.data(), p.entTf.data(), p.entFirstPos.data()) !=
+		RXGPU_OK) {
+		throwDevice("SetWord");
+	}
+}
+
+void GpuFtMerger::ReadStats(uint64_t& postings, double& kernelMs) const {
+	if (rxgpu_ft_read_stats(dev_, &postings, &kernelMs) != RXGPU_OK) throwDevice("ReadStats");
+}
+
+MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
+							 RankSortType rankSortType) const {
+	MergeData out;
+	if (subterms.empty() || totalDocs_ == 0) return out;   // mergerimpl.h:472-474
+	if (cfg.fieldsCfg.size() != numFields_ || termOpts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
+	// TermResults::SortSubterms (querymergedata.h:62-66): by proc, descending
+	std::stable_sort(subterms.begin(), subterms.end(), [](const SubtermRef& l, const SubtermRef& r) { return l.proc > r.proc; });
+
+	std::vector<double> bm25Boost(numFields_), bm25Weight(numFields_), tlBoost(numFields_), tlWeight(numFields_), posBoost(numFields_), posWeight(numFields_);
+	std::vector<float> fieldBoost(numFields_);
+	std::vector<uint8_t> needSum(numFields_);
+	for (size_t f = 0; f < numFields_; ++f) {
+		bm25Boost[f] = cfg.fieldsCfg[f].bm25Boost;
+		bm25Weight[f] = cfg.fieldsCfg[f].bm25Weight;
+		tlBoost[f] = cfg.fieldsCfg[f].termLenBoost;
+		tlWeight[f] = cfg.fieldsCfg[f].termLenWeight;
+		posBoost[f] = cfg.fieldsCfg[f].positionBoost;
+		posWeight[f] = cfg.fieldsCfg[f].positionWeight;
+		fieldBoost[f] = termOpts.fieldsOpts[f].boost;
+		needSum[f] = termOpts.fieldsOpts[f].needSumRank ? 1 : 0;
+	}
+	rxgpu_ft_config c{};
+	c.bm25_k1 = cfg.bm25k1;
+	c.bm25_b = cfg.bm25b;
+	c.summation_ranks_by_fields_ratio = cfg.summationRanksByFieldsRatio;
+	c.full_match_boost = cfg.fullMatchBoost;
+	c.min_rank = cfg.minRank;
+	c.merge_limit = cfg.mergeLimit;
+	c.num_fields = uint32_t(numFields_);
+	c.bm25_boost = bm25Boost.data();
+	c.bm25_weight = bm25Weight.data();
+	c.term_len_boost = tlBoost.data();
+	c.term_len_weight = tlWeight.data();
+	c.position_boost = posBoost.data();
+	c.position_weight = posWeight.data();
+	rxgpu_ft_term_opts o{termOpts.boost, termOpts.termLenBoost, fieldBoost.data(), needSum.data()};
+
+	std::vector<uint32_t> wordIds(subterms.size());
+	std::vector<float> procs(subterms.size());
+	for (size_t i = 0; i < subterms.size(); ++i) {
+		wordIds[i] = subterms[i].wordId;
+		procs[i] = subterms[i].proc;
+	}
+	const size_t cap = cfg.mergeLimit;
+	std::vector<uint32_t> doc(cap);
+	std::vector<float> proc(cap);
+	std::vector<uint8_t> field(cap);
+	uint64_t n = 0;
+	if (rxgpu_ft_merge_simple_raw(dev_, &c, &o, uint32_t(subterms.size()), wordIds.data(), procs.data(), docsExcluded, doc.data(), proc.data(),
+								  field.data(), cap, &n) != RXGPU_OK) {
+		throwDevice("Merge");
+	}
+	out.resize(n);
+	for (uint64_t i = 0; i < n; ++i) {
+		out[i].id = int32_t(doc[i]);
+		out[i].proc = proc[i];
+		out[i].field = field[i];
+	}
+	// addFullMatchBoost(numTerms = 1) — merger.h:100-109 (mergeDataExtended_ is empty for Simple() queries)
+	for (MergeInfo& md : out) {
+		if (words_[size_t(md.id) * numFields_ + md.field] == float(size_t(1))) md.proc = float(double(md.proc) * cfg.fullMatchBoost);
+	}
+	// postProcessResults — merger.h:111-155
+	float maxProc = 0.0f;
+	for (const MergeInfo& md : out) maxProc = std::max(maxProc, md.proc);
+	const float scalingFactor = float(maxProc > 255 ? 255.0 / double(maxProc) : 1.0);
+	const float minProc = float(cfg.minRank);
+	size_t passed = out.size();
+	while (passed > 0 && out[passed - 1].proc < minProc) passed--;
+	for (size_t i = 0; i + 1 < passed; i++) {
+		if (out[i].proc < minProc) {
+			out[i] = out[passed - 1];
+			passed--;
+			while (passed > i && out[passed - 1].proc < minProc) passed--;
+		}
+	}
+	out.resize(passed);
+	for (MergeInfo& md : out) {
+		md.normalizedProc = uint8_t(md.proc * scalingFactor);
+		md.proc = md.normalizedProc;
+	}
+	if (rankSortType == RankSortType::RankOnly || rankSortType == RankSortType::IDAndPositions) {
+		std::stable_sort(out.begin(), out.end(), [](const MergeInfo& l, const MergeInfo& r) { return l.normalizedProc > r.normalizedProc; });
+	}
+	return out;
+}
+
+}  // namespace rxgpu::host

@@ -1,0 +1,98 @@
+// GpuFtMerger — GPU stand-in for ft::Merger<IdCont, MergeData, uint32_t>::Merge<Bm25Rx> on Simple() queries
+// (cpp_src/core/ft/ft_fast/merger.h:36-57, mergerimpl.h:466-484 -> mergeSimple :194-250), i.e. the call site
+// Selector<IdCont>::mergeResults (selecterimpl.h:611-628) for a query with ONE OR-term and any number of sub-terms
+// (original word, typos, translit, stems, ...).  Same inputs (sub-term posting lists + procs, FtDslOpts, FTConfig, docsExcluded,
+// DocsStatsGetter), same output (MergeData: vdoc id, proc, field, normalizedProc).
+//
+// Device: per-posting BM25 ranks, max per document, mergeLimit admission (bm25.hip via rxgpu_ft_merge_simple_raw).
+// Host:   the O(mergeLimit) tail of the merger — addFullMatchBoost (merger.h:100-109) and postProcessResults (:111-155).
+// Multi-term queries (mergeTerm with position distances), phrases and multi-word synonyms stay on the reference's CPU merger
+// (SURVEY appendix C "scope for the first BM25 kernel"); Supports() tells the caller which way to go.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+struct rxgpu_ft_index;
+
+namespace rxgpu::host {
+
+// ftconfig.h:118-124
+struct FtFieldConfig {
+	double bm25Boost = 1.0, bm25Weight = 0.1;
+	double termLenBoost = 1.0, termLenWeight = 0.3;
+	double positionBoost = 1.0, positionWeight = 0.1;
+};
+// the FTConfig members the merge reads (ftconfig.h:151-220)
+struct FtConfig {
+	explicit FtConfig(size_t fieldsCount) : fieldsCfg(fieldsCount) {}
+	uint32_t mergeLimit = 20000;
+	double bm25k1 = 2.0, bm25b = 0.75;
+	double summationRanksByFieldsRatio = 0.0;
+	double fullMatchBoost = 1.1;
+	int minRank = 5;
+	std::vector<FtFieldConfig> fieldsCfg;
+};
+// ftdsl.h:13-35
+struct FtDslFieldOpts {
+	float boost = 1.0f;
+	bool needSumRank = false;
+};
+struct FtDslOpts {
+	float boost = 1.0f;
+	float termLenBoost = 1.0f;
+	std::vector<FtDslFieldOpts> fieldsOpts;
+};
+// querymergedata.h:14-42: one dictionary word matched by the term + its relevancy
+struct SubtermRef {
+	uint32_t wordId;
+	float proc;
+};
+enum class RankSortType { RankOnly, RankAndID, IDOnly, IDAndPositions };   // core/ft/ft_fast/...: how the caller consumes the result
+// phrasemerger.h:57-62
+struct MergeInfo {
+	int32_t id = 0;
+	float proc = 0;
+	uint8_t field = 0;
+	uint8_t normalizedProc = 0;
+};
+using MergeData = std::vector<MergeInfo>;
+
+// One flattened posting list (IdRelVec of one dictionary word)
+struct FlatPostings {
+	std::vector<uint32_t> doc, entOff{0};
+	std::vector<uint8_t> entField;
+	std::vector<uint32_t> entTf, entFirstPos;
+	// append one IdRelType: positions given as (field, pos) pairs sorted by field then pos (idrelset.h:14-32 ordering)
+	void Add(uint32_t vdoc, const std::pair<uint32_t, uint32_t>* fieldPos, size_t count);
+};
+
+class GpuFtMerger {
+public:
+	GpuFtMerger(size_t numFields, int device = 0);
+	~GpuFtMerger();
+	GpuFtMerger(const GpuFtMerger&) = delete;
+
+	// IndexText side (CommitFulltext): vdoc statistics and posting lists
+	void SetDocs(size_t totalDocs, const float* wordsInField, const float* avgWords, const uint8_t* removed);
+	void SetWord(uint32_t wordId, const FlatPostings& postings);
+
+	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept { return numQueryParts == 1 && !hasPhrases && !hasSynonyms; }
+
+	// Merger::Merge<Bm25Rx> for a Simple() query
+	MergeData Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
+					RankSortType rankSortType) const;
+
+	size_t TotalDocs() const noexcept { return totalDocs_; }
+	void ReadStats(uint64_t& postings, double& kernelMs) const;
+
+private:
+	const size_t numFields_;
+	size_t totalDocs_ = 0;
+	std::vector<float> words_;   // host copy for addFullMatchBoost
+	rxgpu_ft_index* dev_ = nullptr;
+};
+
+}  // namespace rxgpu::host

@@ -240,3 +240,71 @@ long rxhost_hnsw_select(void* h, const float* key, size_t dim, long k, size_t ef
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- GpuFtMerger
+#include "gpu_ft_merger.h"
+
+extern "C" {
+
+void* rxhost_ft_create(size_t numFields, int device) {
+	GpuFtMerger* m = nullptr;
+	guarded([&] { m = new GpuFtMerger(numFields, device); });
+	return m;
+}
+void rxhost_ft_destroy(void* h) { delete static_cast<GpuFtMerger*>(h); }
+int rxhost_ft_set_docs(void* h, size_t totalDocs, const float* words, const float* avg, const uint8_t* removed) {
+	return guarded([&] { static_cast<GpuFtMerger*>(h)->SetDocs(totalDocs, words, avg, removed); });
+}
+// postings given as IdRelType-like records: doc[i] with positions [pos_off[i], pos_off[i+1]) of (field, pos) pairs
+int rxhost_ft_set_word(void* h, uint32_t wordId, size_t n, const uint32_t* doc, const uint32_t* posOff, const uint32_t* posField, const uint32_t* posPos) {
+	return guarded([&] {
+		FlatPostings fp;
+		std::vector<std::pair<uint32_t, uint32_t>> tmp;
+		for (size_t i = 0; i < n; ++i) {
+			tmp.clear();
+			for (uint32_t j = posOff[i]; j < posOff[i + 1]; ++j) tmp.emplace_back(posField[j], posPos[j]);
+			fp.Add(doc[i], tmp.data(), tmp.size());
+		}
+		static_cast<GpuFtMerger*>(h)->SetWord(wordId, fp);
+	});
+}
+// cfgD: [k1, b, summationRatio, fullMatchBoost] ; cfgI: [minRank, mergeLimit] ; fieldCfg: [nf][6] doubles (bm25Boost, bm25Weight,
+// termLenBoost, termLenWeight, positionBoost, positionWeight) ; opts: boost, termLenBoost, fieldBoost[nf], needSum[nf]
+long rxhost_ft_merge(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, float boost, float termLenBoost,
+					 const float* fieldBoost, const uint8_t* needSum, size_t nsub, const uint32_t* wordIds, const float* procs,
+					 const uint8_t* excluded, int sortByRank, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		FtConfig cfg(nf);
+		cfg.bm25k1 = cfgD[0];
+		cfg.bm25b = cfgD[1];
+		cfg.summationRanksByFieldsRatio = cfgD[2];
+		cfg.fullMatchBoost = cfgD[3];
+		cfg.minRank = cfgI[0];
+		cfg.mergeLimit = uint32_t(cfgI[1]);
+		FtDslOpts opts;
+		opts.boost = boost;
+		opts.termLenBoost = termLenBoost;
+		opts.fieldsOpts.resize(nf);
+		for (size_t f = 0; f < nf; ++f) {
+			cfg.fieldsCfg[f] = FtFieldConfig{fieldCfg[f * 6 + 0], fieldCfg[f * 6 + 1], fieldCfg[f * 6 + 2], fieldCfg[f * 6 + 3], fieldCfg[f * 6 + 4], fieldCfg[f * 6 + 5]};
+			opts.fieldsOpts[f] = FtDslFieldOpts{fieldBoost[f], needSum[f] != 0};
+		}
+		std::vector<SubtermRef> subs(nsub);
+		for (size_t i = 0; i < nsub; ++i) subs[i] = SubtermRef{wordIds[i], procs[i]};
+		auto res = static_cast<const GpuFtMerger*>(h)->Merge(cfg, opts, std::move(subs), excluded, sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID);
+		n = long(res.size());
+		for (size_t i = 0; i < res.size() && i < cap; ++i) {
+			outId[i] = res[i].id;
+			outProc[i] = res[i].proc;
+			outField[i] = res[i].field;
+			outNorm[i] = res[i].normalizedProc;
+		}
+	});
+	return n;
+}
+int rxhost_ft_read_stats(void* h, uint64_t* postings, double* ms) {
+	return guarded([&] { static_cast<const GpuFtMerger*>(h)->ReadStats(*postings, *ms); });
+}
+
+}  // extern "C"

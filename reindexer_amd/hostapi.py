@@ -341,3 +341,103 @@ class GpuHnswMap:
         if n < 0:
             _raise()
         return ids[:n].copy(), ranks[:n].copy()
+
+
+class GpuFtMerger:
+    """rxgpu::host::GpuFtMerger — ft_fast single-term BM25 merge on the GPU (stand-in for ft::Merger::Merge<Bm25Rx>)."""
+
+    def __init__(self, num_fields: int, device: int = 0):
+        L = lib()
+        if not hasattr(L, "_ft_bound"):
+            L.rxhost_ft_create.restype = _vp
+            L.rxhost_ft_create.argtypes = [_sz, _i]
+            L.rxhost_ft_destroy.argtypes = [_vp]
+            L.rxhost_ft_set_docs.argtypes = [_vp, _sz, _vp, _vp, _vp]
+            L.rxhost_ft_set_word.argtypes = [_vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp]
+            L.rxhost_ft_merge.restype = _l
+            L.rxhost_ft_merge.argtypes = [_vp, _sz, _vp, _vp, _vp, _f, _f, _vp, _vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz]
+            L.rxhost_ft_read_stats.argtypes = [_vp, _vp, _vp]
+            L._ft_bound = True
+        self.nf = num_fields
+        self.h = L.rxhost_ft_create(num_fields, device)
+        if not self.h:
+            _raise()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rxhost_ft_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_docs(self, words, avg, removed=None):
+        words = _f32(words).reshape(-1, self.nf)
+        avg = _f32(avg)
+        rem = np.ascontiguousarray(removed, np.uint8) if removed is not None else None
+        rc = lib().rxhost_ft_set_docs(self.h, words.shape[0], words.ctypes.data, avg.ctypes.data, rem.ctypes.data if rem is not None else None)
+        if rc:
+            _raise(rc)
+
+    def set_word_flat(self, word_id, s):
+        """s: flat sub-term dict (doc, ent_off, ent_field, ent_tf, ent_first_pos) -> re-expanded to (field,pos) records whose grouping
+        reproduces the same entries (tf positions per field, the first one at ent_first_pos)."""
+        doc = np.ascontiguousarray(s["doc"], np.uint32)
+        pos_off, pf, pp = [0], [], []
+        for i in range(doc.shape[0]):
+            for e in range(int(s["ent_off"][i]), int(s["ent_off"][i + 1])):
+                for t in range(int(s["ent_tf"][e])):
+                    pf.append(int(s["ent_field"][e]))
+                    pp.append(int(s["ent_first_pos"][e]) + t)
+            pos_off.append(len(pf))
+        po, pfa, ppa = np.array(pos_off, np.uint32), np.array(pf, np.uint32), np.array(pp, np.uint32)
+        rc = lib().rxhost_ft_set_word(self.h, word_id, doc.shape[0], doc.ctypes.data, po.ctypes.data, pfa.ctypes.data, ppa.ctypes.data)
+        if rc:
+            _raise(rc)
+
+    def merge(self, cfg: dict, opts: dict, subterms, excluded=None, sort_by_rank=True):
+        """cfg/opts: dicts as built by default_ft_config()/default_ft_opts(); subterms: [(word_id, proc), ...]."""
+        nf = self.nf
+        cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"]], np.float64)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"]], np.int32)
+        fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                               "position_boost", "position_weight")], axis=1).copy()
+        fb = _f32(opts["field_boost"])
+        ns = np.ascontiguousarray(opts["need_sum_rank"], np.uint8)
+        wid = np.array([s[0] for s in subterms], np.uint32)
+        pr = np.array([s[1] for s in subterms], np.float32)
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        cap = int(cfg["merge_limit"])
+        oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        n = lib().rxhost_ft_merge(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, opts["boost"], opts["term_len_boost"],
+                                  fb.ctypes.data, ns.ctypes.data, len(subterms), wid.ctypes.data, pr.ctypes.data,
+                                  exc.ctypes.data if exc is not None else None, int(sort_by_rank), oid.ctypes.data, op.ctypes.data,
+                                  of.ctypes.data, on.ctypes.data, cap)
+        if n < 0:
+            _raise()
+        return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
+
+    def read_stats(self):
+        a, b = _u64(0), C.c_double(0.0)
+        lib().rxhost_ft_read_stats(self.h, C.byref(a), C.byref(b))
+        return int(a.value), float(b.value)
+
+
+def default_ft_config(num_fields=1, **kw):
+    """The FTConfig members the merge reads, with the reference's defaults (ftconfig.h:118-124,151-220)."""
+    cfg = dict(k1=2.0, b=0.75, summation_ratio=0.0, full_match_boost=1.1, min_rank=5, merge_limit=20000, num_fields=num_fields,
+               bm25_boost=[1.0] * num_fields, bm25_weight=[0.1] * num_fields, term_len_boost=[1.0] * num_fields,
+               term_len_weight=[0.3] * num_fields, position_boost=[1.0] * num_fields, position_weight=[0.1] * num_fields)
+    cfg.update(kw)
+    return cfg
+
+
+def default_ft_opts(num_fields=1, **kw):
+    """FtDslOpts defaults (ftdsl.h:13-35)."""
+    o = dict(boost=1.0, term_len_boost=1.0, field_boost=[1.0] * num_fields, need_sum_rank=[0] * num_fields)
+    o.update(kw)
+    return o
