@@ -308,3 +308,17 @@ int rxhost_ft_read_stats(void* h, uint64_t* postings, double* ms) {
 }
 
 }  // extern "C"
+
+extern "C" int rxhost_ft_set_word_flat(void* h, uint32_t wordId, size_t n, const uint32_t* doc, const uint32_t* entOff, const uint8_t* entField,
+										const uint32_t* entTf, const uint32_t* entFirstPos) {
+	return guarded([&] {
+		FlatPostings fp;
+		fp.doc.assign(doc, doc + n);
+		fp.entOff.assign(entOff, entOff + n + 1);
+		const size_t ne = n ? entOff[n] : 0;
+		fp.entField.assign(entField, entField + ne);
+		fp.entTf.assign(entTf, entTf + ne);
+		fp.entFirstPos.assign(entFirstPos, entFirstPos + ne);
+		static_cast<GpuFtMerger*>(h)->SetWord(wordId, fp);
+	});
+}
