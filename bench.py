@@ -33,7 +33,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from reindexer_amd import capi  # noqa: E402  (no fallback: raises if librxgpu.so is missing)
-from reindexer_amd.sharded import merge_shard_topk, pack_topk  # noqa: E402
+from reindexer_amd.sharded import ShardedBruteforceGpu  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 
@@ -236,18 +236,16 @@ def main():
     ix.adopt_device_rows(corpus.data_ptr(), args.rows, args.dim, d_inv.data_ptr() if d_inv is not None else None, keepalive=(corpus, d_inv))
     out_dist = torch.empty((total_q, kk), dtype=torch.float32, device=device)
     out_row = torch.empty((total_q, kk), dtype=torch.int32, device=device)
-    final = torch.empty((total_q, kk, 2), dtype=torch.int64, device=device) if dist_on else None
-    gathered = torch.empty((world, kk), dtype=torch.int64, device=device) if dist_on else None
     stream = torch.cuda.current_stream(device)
     esz = 4
+    sharded = ShardedBruteforceGpu(ix, args.rows, device, 1, kk) if dist_on else None
 
     def step(i: int):
-        ix.search_knn_device(queries.data_ptr() + i * args.dim * esz, 1, kk, out_dist.data_ptr() + i * kk * esz,
-                             out_row.data_ptr() + i * kk * esz, None, stream.cuda_stream)
-        if dist_on:
-            packed = pack_topk(out_dist[i], out_row[i], rank * args.rows)
-            dist.all_gather_into_tensor(gathered.view(-1), packed)
-            final[i] = merge_shard_topk(gathered, kk, args.rows)
+        if dist_on:   # local scan -> one RCCL all-gather of kk*8 B per rank -> device merge; out_row holds GLOBAL rows
+            sharded.search_into(queries.data_ptr() + i * args.dim * esz, 1, out_dist[i:i + 1], out_row[i:i + 1])
+        else:
+            ix.search_knn_device(queries.data_ptr() + i * args.dim * esz, 1, kk, out_dist.data_ptr() + i * kk * esz,
+                                 out_row.data_ptr() + i * kk * esz, None, stream.cuda_stream)
 
     def sync():
         torch.cuda.synchronize(device)

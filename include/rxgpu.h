@@ -105,6 +105,14 @@ int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t
 int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, void* d_out_dist, void* d_out_row,
 							void* d_out_count, void* stream);
 
+/* Multi-GPU merge step (no reference counterpart: the reference has no device notion).  d_gathered = the all-gather of every
+ * rank's search output for one query batch: [world][2][nq][kk] 32-bit words — per rank the [nq][kk] distances followed by the
+ * [nq][kk] shard-local rows (what rxgpu_search_knn_device writes when d_out_row == d_out_dist + nq*kk words).
+ * Writes the global top-kk under (dist, global row = shard*shard_rows + local row): d_out_dist [nq][kk], d_out_row [nq][kk] u32.
+ * Pure device work on `stream`, no synchronisation. */
+int rxgpu_merge_shards_device(const void* d_gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, void* d_out_dist,
+							  void* d_out_row, void* d_out_count, void* stream);
+
 /* BruteforceSearch::SearchRange (bruteforce.cc:129-143): every row with dist < radius (inclusive != 0: dist <= radius;
  * the inclusive form serves the tie replay above).  Rows are returned sorted by (dist,row); *out_total receives the
  * number of hits; at most cap are written; RXGPU_ERR_OVERFLOW if out_total > cap (call again with a larger buffer). */

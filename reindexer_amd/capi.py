@@ -49,6 +49,7 @@ _SIGNATURES = {
     "rxgpu_index_device_bytes": (_u64, [_vp]),
     "rxgpu_search_knn": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_search_knn_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "rxgpu_merge_shards_device": (_i, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_search_range": (_i, [_vp, _vp, _f, _i, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_distances": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "rxgpu_hnsw_attach_graph": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _u32, _u32, C.c_int32, _u32, _u64]),
@@ -258,6 +259,11 @@ class VectorIndex:
         n, ms = _u64(0), C.c_double(0.0)
         _check(lib().rxgpu_profile_read(self._h, name.encode(), C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
+
+
+def merge_shards_device(d_gathered_ptr: int, world: int, nq: int, kk: int, shard_rows: int, d_out_dist_ptr: int, d_out_row_ptr: int,
+                        d_out_count_ptr: int | None, stream_ptr: int) -> None:
+    _check(lib().rxgpu_merge_shards_device(d_gathered_ptr, world, nq, kk, shard_rows, d_out_dist_ptr, d_out_row_ptr, d_out_count_ptr, stream_ptr))
 
 
 def gpu_available() -> bool:

@@ -210,6 +210,41 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge(const float* part_dis
 	if (lane == 0 && out_count) out_count[blockIdx.x] = top.filled;
 }
 
+// Multi-GPU: fold the all-gathered per-shard lists of one query batch into the global top-kk.
+// gathered: [world][2][nq][kk] 32-bit words — per shard the [nq][kk] distances followed by the [nq][kk] shard-local rows (what
+// the scan writes when d_out_row == d_out_dist + nq*kk).  Global row = shard * shard_rows + local row; order = (dist, global row).
+__global__ __launch_bounds__(64) void knn_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows,
+														float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	const int lane = threadIdx.x;
+	const uint32_t q = blockIdx.x;
+	WaveTopK top;
+	top.init(kk);
+	for (uint32_t w = 0; w < world; ++w) {
+		const uint32_t* rec = gathered + size_t(w) * 2 * nq * kk + size_t(q) * kk;
+		float cd = __builtin_inff();
+		uint32_t ci = kInvalidRow;
+		if (lane < int(kk)) {
+			cd = __uint_as_float(rec[lane]);
+			const uint32_t local = rec[size_t(nq) * kk + lane];
+			if (local != kInvalidRow) ci = w * shard_rows + local;
+		}
+		uint64_t pm = __ballot(ci != kInvalidRow);
+		while (pm) {
+			const int src = __builtin_ctzll(pm);
+			pm &= pm - 1;
+			const float d = __shfl(cd, src);
+			const uint32_t i = __shfl(ci, src);
+			if (!top.admits(d, i)) break;   // each shard list is sorted
+			top.insert(d, i, lane);
+		}
+	}
+	if (lane < int(kk)) {
+		out_dist[size_t(q) * kk + lane] = top.bd;
+		out_row[size_t(q) * kk + lane] = top.bi;
+	}
+	if (lane == 0 && out_count) out_count[q] = top.filled;
+}
+
 // BruteforceSearch::SearchRange (bruteforce.cc:129-143): compact every row with dist < radius (or <=).
 struct RangeParams {
 	const float* rows;
@@ -337,6 +372,11 @@ void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t tot
 				  uint32_t* out_row, uint32_t* out_count, const uint32_t* gate_cnt, uint32_t gate_cap, hipStream_t s) {
 	hipLaunchKernelGGL(knn_merge, dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, total_per_query, kk, out_dist, out_row, out_count,
 					   gate_cnt, gate_cap);
+}
+
+void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
+						 uint32_t* out_row, uint32_t* out_count, hipStream_t s) {
+	hipLaunchKernelGGL(knn_merge_shards, dim3(nq), dim3(64), 0, s, gathered, world, nq, kk, shard_rows, out_dist, out_row, out_count);
 }
 
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,

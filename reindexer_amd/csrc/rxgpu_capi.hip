@@ -604,6 +604,17 @@ int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t
 	return RXGPU_OK;
 }
 
+int rxgpu_merge_shards_device(const void* d_gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, void* d_out_dist,
+							  void* d_out_row, void* d_out_count, void* stream) {
+	RX_CHECK(d_gathered && d_out_dist && d_out_row, RXGPU_ERR_PARAMS, "rxgpu_merge_shards_device: null argument");
+	RX_CHECK(world >= 1 && nq >= 1 && kk >= 1 && kk <= uint32_t(rxgpu::kMaxFusedK), RXGPU_ERR_PARAMS, "rxgpu_merge_shards_device: bad shape");
+	RX_CHECK(uint64_t(world) * shard_rows <= 0xFFFFFFFEull, RXGPU_ERR_PARAMS, "rxgpu_merge_shards_device: global rows must fit 32 bits");
+	rxgpu::launch_merge_shards(static_cast<const uint32_t*>(d_gathered), world, nq, kk, shard_rows, static_cast<float*>(d_out_dist),
+							   static_cast<uint32_t*>(d_out_row), static_cast<uint32_t*>(d_out_count), static_cast<hipStream_t>(stream));
+	RX_HIP(hipGetLastError());
+	return RXGPU_OK;
+}
+
 int rxgpu_search_range(rxgpu_index* h, const float* query, float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap,
 					   uint64_t* out_total) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");

@@ -17,6 +17,8 @@ uint32_t scan_grid_x(uint64_t n, int cus);
 void launch_scan(int metric, const ScanParams& p, uint32_t nq, uint32_t gridx, hipStream_t s);
 void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t total_per_query, uint32_t kk, uint32_t nq, float* out_dist,
 				  uint32_t* out_row, uint32_t* out_count, const uint32_t* gate_cnt, uint32_t gate_cap, hipStream_t s);
+void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
+						 uint32_t* out_row, uint32_t* out_count, hipStream_t s);
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,
 				  float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap, unsigned long long* counter,
 				  uint32_t gridx, hipStream_t s);

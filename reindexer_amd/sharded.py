@@ -109,3 +109,30 @@ def rxgpu_local_search(index, device):
         index.search_knn_device(q.data_ptr(), nq, kk, d.data_ptr(), r.data_ptr(), None, stream.cuda_stream)
         return d, r
     return run
+
+
+class ShardedBruteforceGpu:
+    """The all-device form used on GPUs: local scan -> ONE all-gather of the raw [2][nq][kk] output words -> merge kernel.
+    No torch arithmetic in the step: torch only owns the buffers and issues the RCCL collective."""
+
+    def __init__(self, index, shard_rows: int, device, max_queries: int, kk: int, group=None):
+        import torch.distributed as dist
+        self._dist, self.index, self.shard_rows, self.device, self.kk, self.group = dist, index, int(shard_rows), device, kk, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.local = torch.empty((2, max_queries, kk), dtype=torch.int32, device=device)          # dist bits | rows
+        self.gathered = torch.empty((self.world, 2, max_queries, kk), dtype=torch.int32, device=device)
+        self.max_queries = max_queries
+
+    def search_into(self, d_queries_ptr: int, nq: int, out_dist: torch.Tensor, out_row: torch.Tensor) -> None:
+        """queries: device pointer to [nq][dim] f32; out_dist [nq][kk] f32 and out_row [nq][kk] i32 (global rows) device tensors."""
+        from . import capi
+        assert nq == self.max_queries, "buffers are sized for a fixed batch"
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        base = self.local.data_ptr()
+        self.index.search_knn_device(d_queries_ptr, nq, self.kk, base, base + nq * self.kk * 4, None, stream)
+        if self.world > 1:
+            self._dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
+            src = self.gathered.data_ptr()
+        else:
+            src = base
+        capi.merge_shards_device(src, self.world, nq, self.kk, self.shard_rows, out_dist.data_ptr(), out_row.data_ptr(), None, stream)
