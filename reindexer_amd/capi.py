@@ -87,7 +87,14 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m reindexer_amd.build` "
                 "(hipcc --offload-arch=gfx950). The GPU engine has no CPU fallback.")
-        # RTLD_GLOBAL not needed; libamdhip64 resolves by SONAME to whatever the process already loaded (torch's copy)
+        # One process can hold only one HIP runtime.  PyTorch wheels bundle their own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's): whichever is loaded first serves both.  torch must win that race or its device enumeration fails
+        # ("No HIP GPUs are available"), so when torch is installed it is imported before librxgpu.so is opened.
+        if not os.environ.get("RXGPU_NO_TORCH"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         _lib = C.CDLL(str(LIB_PATH))
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(_lib, name)

@@ -19,29 +19,35 @@ namespace rxgpu {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kGemmThreads = 256;     // 4 wavefronts: wave w owns rows [32w, 32w+32) of the tile, all MT queries
+constexpr int kGemmThreads = 256;     // per query split: 4 wavefronts, wave w owns rows [32(w&3), +32) of the tile and 1/QS of the MT queries
 constexpr int kGemmRows = 128;        // corpus rows per tile
 constexpr int kGemmKS = 32;           // floats of the dimension staged per step
 constexpr int kLdsStride = kGemmKS + 1;   // +1 pad: (row + k) mod 32 banks, conflict-free fragment reads
 
-template <int kMetric, int MT, int kMode>
-__global__ __launch_bounds__(kGemmThreads) void knn_gemm(GemmParams p) {
+// QS = 2 runs 8 wavefronts per workgroup (two per SIMD): while one waits on LDS staging / the barrier the other keeps the
+// matrix pipe busy, and each wave carries half the accumulators.
+template <int kMetric, int MT, int kMode, int QS>
+__global__ __launch_bounds__(kGemmThreads * QS) void knn_gemm(GemmParams p) {
 	extern __shared__ __attribute__((aligned(16))) float lds[];
-	constexpr int QB = MT / 32;                       // 32-query blocks per wave
+	constexpr int kThreads = kGemmThreads * QS;
+	constexpr int QB = MT / 32 / QS;                  // 32-query blocks per wave
 	constexpr int kQTile = MT * kLdsStride;           // floats per Q buffer
 	constexpr int kXTile = kGemmRows * kLdsStride;
 	float* q_s = lds;                                 // [2][MT][33]
 	float* x_s = lds + 2 * kQTile;                    // [2][128][33]
 	float* thr_s = x_s + 2 * kXTile;                  // [MT] thresholds (FILTER)
 	float* aux_s = thr_s + MT;                        // [MT] |q|^2 (L2)
-	constexpr int kQLoads = MT * (kGemmKS / 4) / kGemmThreads;      // float4 per thread per step (MT=32 -> 1)
-	constexpr int kXLoads = kGemmRows * (kGemmKS / 4) / kGemmThreads;   // 4
+	constexpr int kQLoads = MT * (kGemmKS / 4) / kThreads;          // float4 per thread per step
+	constexpr int kXLoads = kGemmRows * (kGemmKS / 4) / kThreads;
+	static_assert(kQLoads >= 1 && kXLoads >= 1, "tile too small for the thread count");
 
 	const int tid = threadIdx.x, lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int wave = wave_all & 3;                    // row block
+	const int qs = wave_all >> 2;                     // query split
 	const uint32_t ksteps = (p.dim + kGemmKS - 1) / kGemmKS;
 	const uint64_t ntiles = (p.n + kGemmRows - 1) / kGemmRows;
-	for (int i = tid; i < MT; i += kGemmThreads) {
+	for (int i = tid; i < MT; i += kThreads) {
 		thr_s[i] = kMode == kGemmFilter ? p.thr[i] : 0.f;
 		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
 	}
@@ -60,13 +66,13 @@ __global__ __launch_bounds__(kGemmThreads) void knn_gemm(GemmParams p) {
 			const uint32_t k0 = ks * kGemmKS;
 #pragma unroll
 			for (int i = 0; i < kQLoads; ++i) {
-				const int idx = tid + i * kGemmThreads;
+				const int idx = tid + i * kThreads;
 				const uint32_t qi = idx >> 3, k = k0 + ((idx & 7) << 2);
 				qreg[i] = *reinterpret_cast<const float4*>(p.queries + size_t(qi) * p.q_stride + k);   // padded: always in range
 			}
 #pragma unroll
 			for (int i = 0; i < kXLoads; ++i) {
-				const int idx = tid + i * kGemmThreads;
+				const int idx = tid + i * kThreads;
 				const uint64_t r = row0 + (idx >> 3);
 				const uint32_t k = k0 + ((idx & 7) << 2);
 				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(kGemmThreads) void knn_gemm(GemmParams p) {
 		auto store_step = [&](int buf) {
 #pragma unroll
 			for (int i = 0; i < kQLoads; ++i) {
-				const int idx = tid + i * kGemmThreads;
+				const int idx = tid + i * kThreads;
 				float* d = q_s + buf * kQTile + (idx >> 3) * kLdsStride + ((idx & 7) << 2);
 				d[0] = qreg[i].x;
 				d[1] = qreg[i].y;
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(kGemmThreads) void knn_gemm(GemmParams p) {
 			}
 #pragma unroll
 			for (int i = 0; i < kXLoads; ++i) {
-				const int idx = tid + i * kGemmThreads;
+				const int idx = tid + i * kThreads;
 				float* d = x_s + buf * kXTile + (idx >> 3) * kLdsStride + ((idx & 7) << 2);
 				d[0] = xreg[i].x;
 				d[1] = xreg[i].y;
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(kGemmThreads) void knn_gemm(GemmParams p) {
 			const int buf = ks & 1;
 			if (ks + 1 < ksteps) load_step(ks + 1);
 			const float* xb = x_s + buf * kXTile + (32 * wave + (lane & 31)) * kLdsStride + (lane >> 5);
-			const float* qb = q_s + buf * kQTile + (lane & 31) * kLdsStride + (lane >> 5);
+			const float* qb = q_s + buf * kQTile + (qs * QB * 32 + (lane & 31)) * kLdsStride + (lane >> 5);
 #pragma unroll 4
 			for (int kk = 0; kk < kGemmKS / 2; ++kk) {
 				const float bfrag = xb[2 * kk];
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(kGemmThreads) void knn_gemm(GemmParams p) {
 		const uint64_t row = row0 + 32 * wave + (lane & 31);
 		const bool row_ok = row < p.n;
 		const uint64_t rowc = row_ok ? row : p.n - 1;
-		const int qlane = 4 * (lane >> 5);
+		const int qlane = 4 * (lane >> 5) + qs * QB * 32;
 		float row_term = 0.f;   // per-row factor of the approximate distance
 		if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];
 		if constexpr (kMetric == kCos) row_term = p.inv_norms[rowc];
@@ -328,15 +334,16 @@ size_t gemm_lds_bytes(int mt) { return (size_t(2) * (mt + kGemmRows) * kLdsStrid
 
 template <int kMetric, int MT, int kMode>
 static hipError_t launch_gemm_one(const GemmParams& p, uint32_t grid, hipStream_t s) {
+	constexpr int QS = MT >= 128 ? 2 : 1;
 	const size_t lds = gemm_lds_bytes(MT);
 	static bool attr_set = false;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm<kMetric, MT, kMode>),
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm<kMetric, MT, kMode, QS>),
 										   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL((knn_gemm<kMetric, MT, kMode>), dim3(grid), dim3(kGemmThreads), lds, s, p);
+	hipLaunchKernelGGL((knn_gemm<kMetric, MT, kMode, QS>), dim3(grid), dim3(kGemmThreads * QS), lds, s, p);
 	return hipGetLastError();
 }
 

@@ -229,3 +229,35 @@ def test_property_full_size_roundtrip(rxgpu):
             assert np.all(np.diff(dist[i]) >= 0)
             re = ix.distances(queries[i], row[i])
             assert np.array_equal(bits(re), bits(dist[i]))
+
+
+@pytest.mark.parametrize("nq", [1, 5])
+def test_device_shard_merge_equals_single_index(rxgpu, oracle, nq):
+    """The N>1 step without the collective: two row-range shards searched on the device, their raw outputs laid out as the
+    all-gather would ([world][2][nq][kk] words), merged by knn_merge_shards — must equal one index over all rows."""
+    import torch
+    n, d, kk, world = 30_000, 128, 11, 2
+    rows = make_corpus(77, n, d)
+    rows[n // 2 + 5] = rows[3]          # an exact cross-shard tie: (dist, global row) must order it
+    queries = make_corpus(78, nq, d)
+    shard = n // world
+    t_q = torch.from_numpy(queries).cuda()
+    gathered = torch.empty((world, 2, nq, kk), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    shards = []
+    for w in range(world):
+        ix = rxgpu.VectorIndex("ip", d, shard)
+        ix.upload_rows(0, rows[w * shard:(w + 1) * shard])
+        base = gathered[w].data_ptr()
+        ix.search_knn_device(t_q.data_ptr(), nq, kk, base, base + nq * kk * 4, None, stream)
+        shards.append(ix)
+    od = torch.empty((nq, kk), dtype=torch.float32, device="cuda")
+    orow = torch.empty((nq, kk), dtype=torch.int32, device="cuda")
+    rxgpu.merge_shards_device(gathered.data_ptr(), world, nq, kk, shard, od.data_ptr(), orow.data_ptr(), None, stream)
+    torch.cuda.synchronize()
+    for qi in range(nq):
+        wd, wr = lex_topk(oracle.dist_many(1, queries[qi], rows), kk)
+        assert np.array_equal(orow[qi].cpu().numpy().view(np.uint32), wr)
+        assert np.array_equal(bits(od[qi].cpu().numpy()), bits(wd))
+    for ix in shards:
+        ix.close()
