@@ -125,10 +125,13 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 
 template <int kMetric, bool kGlobalCand, int NB>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
-	__shared__ float top_d[kHnswMaxEf];
-	__shared__ uint32_t top_i[kHnswMaxEf];
-	__shared__ float lcand_d[kGlobalCand ? 1 : kHnswCandLds];
-	__shared__ uint32_t lcand_i[kGlobalCand ? 1 : kHnswCandLds];
+	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
+	// small-ef searches keep more wavefronts resident per CU
+	extern __shared__ __attribute__((aligned(16))) unsigned char hnsw_lds[];
+	float* top_d = reinterpret_cast<float*>(hnsw_lds);
+	uint32_t* top_i = reinterpret_cast<uint32_t*>(top_d + p.ef_cap);
+	float* lcand_d = reinterpret_cast<float*>(top_i + p.ef_cap);
+	uint32_t* lcand_i = reinterpret_cast<uint32_t*>(lcand_d + (kGlobalCand ? 0 : p.lds_cand_cap));
 	__shared__ uint32_t nb_id[kHnswMaxNeighbors];
 	__shared__ float nb_d[kHnswMaxNeighbors];
 	__shared__ uint8_t nb_del[kHnswMaxNeighbors];
@@ -297,10 +300,11 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 
 template <bool kGlobalCand, int NB>
 static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
+	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8;
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB>), dim3(blocks), dim3(64), 0, s, p); break;
-		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB>), dim3(blocks), dim3(64), 0, s, p); break;
-		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB>), dim3(blocks), dim3(64), 0, s, p); break;
+		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;
+		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;
 	}
 }
 

@@ -92,6 +92,7 @@ struct HnswParams {
 	uint64_t gcand_cap;
 	unsigned long long* stats;   // optional [2]: distance evaluations, hops
 	uint32_t lds_cand_cap;       // <= kHnswCandLds (tests shrink it to force the global-heap re-run)
+	uint32_t ef_cap;             // result-heap capacity in LDS: ef rounded up to 64
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -799,7 +799,8 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 	p.out_row = static_cast<uint32_t*>(c->d_out_row.ptr);
 	p.out_count = static_cast<uint32_t*>(c->d_out_count.ptr);
 	p.stats = h->d_hnsw_stats;
-	p.lds_cand_cap = uint32_t(rxgpu::kHnswCandLds);
+	p.ef_cap = (ef + 63u) & ~63u;
+	p.lds_cand_cap = ef <= 256 ? 1024u : uint32_t(rxgpu::kHnswCandLds);   // typical candidate heaps stay within a few x ef
 	if (const char* e = getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // test hook: force the global-heap re-run
 		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, atoi(e))));
 	}

@@ -322,3 +322,47 @@ extern "C" int rxhost_ft_set_word_flat(void* h, uint32_t wordId, size_t n, const
 		static_cast<GpuFtMerger*>(h)->SetWord(wordId, fp);
 	});
 }
+
+// ---------------------------------------------------------------------------------------------- hybrid rank fusion
+#include "hybrid_rerank.h"
+
+extern "C" {
+
+void rxhost_rrf_positions(const float* ranks, size_t n, uint64_t* out) {
+	std::vector<float> r(ranks, ranks + n);
+	auto p = InitRRFPositions(r);
+	for (size_t i = 0; i < n; ++i) out[i] = p[i];
+}
+// kind 0 = RRF (params[0] = rank_const), 1 = linear (params = kKnn, knnDefault, kFt, ftDefault, c). Returns count.
+long rxhost_merge_ranked(int kind, const double* params, int isUnion, int desc, int metric, const int32_t* knnIds, const float* knnRanks, size_t nKnn,
+						 const int32_t* ftIds, const float* ftRanks, size_t nFt, int32_t* outIds, float* outRanks, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		std::vector<int32_t> ki(knnIds, knnIds + nKnn), fi(ftIds, ftIds + nFt);
+		std::vector<float> kr(knnRanks, knnRanks + nKnn), fr(ftRanks, ftRanks + nFt);
+		HybridResult res;
+		const auto type = isUnion ? HybridMergeType::Union : HybridMergeType::Intersection;
+		if (kind == 0) {
+			// FT positions follow the FT result order (rank-sorted), then are re-indexed by ascending id like ftIds_
+			std::vector<size_t> order(nFt);
+			for (size_t i = 0; i < nFt; ++i) order[i] = i;
+			std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return fr[a] > fr[b]; });
+			std::vector<float> sorted(nFt);
+			for (size_t i = 0; i < nFt; ++i) sorted[i] = fr[order[i]];
+			auto posSorted = InitRRFPositions(sorted);
+			std::vector<size_t> pos(nFt);
+			for (size_t i = 0; i < nFt; ++i) pos[order[i]] = posSorted[i];
+			res = MergeRankedRRF(RerankerRRF{params[0]}, type, desc != 0, VectorMetric(metric), ki, kr, fi, pos);
+		} else {
+			res = MergeRankedLinear(RerankerLinear{params[0], params[1], params[2], params[3], params[4]}, type, desc != 0, ki, kr, fi, fr);
+		}
+		n = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
+			outIds[i] = res.ids[i];
+			outRanks[i] = res.ranks[i];
+		}
+	});
+	return n;
+}
+
+}  // extern "C"
