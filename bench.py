@@ -214,10 +214,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    # RXGPU_BENCH_FORCE_DIST=1 exercises the N > 1 code path (RCCL init, all-gather, device merge) on a single rank
+    dist_on = world > 1 or bool(os.environ.get("RXGPU_BENCH_FORCE_DIST"))
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     metric_id = capi.METRICS[args.metric]

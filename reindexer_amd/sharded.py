@@ -130,7 +130,7 @@ class ShardedBruteforceGpu:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         base = self.local.data_ptr()
         self.index.search_knn_device(d_queries_ptr, nq, self.kk, base, base + nq * self.kk * 4, None, stream)
-        if self.world > 1:
+        if self._dist.is_initialized():   # also with world == 1 (a self-copy), so that single-rank runs exercise the same path
             self._dist.all_gather_into_tensor(self.gathered.view(-1), self.local.view(-1), group=self.group)
             src = self.gathered.data_ptr()
         else:
