@@ -454,3 +454,97 @@ class FtOracle:
                                        rem.ctypes.data if rem is not None else None, exc.ctypes.data if exc is not None else None,
                                        arr, len(subs), int(sort_by_rank), od.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data)
         return od[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------------ the REAL ft_fast merger (_ref)
+REF_FT_SO = HERE / "_ref" / "libref_ft.so"
+
+
+class RefFt:
+    """reindexer::ft::Merger<IdRelVec, MergeData, uint32_t>::Merge<Bm25Rx> of the reference (oracle/ref/ref_ft_shim.cc)."""
+
+    OP_OR, OP_AND, OP_NOT = 1, 2, 3
+
+    def __init__(self, num_fields: int):
+        if not REF_FT_SO.exists():
+            raise FileNotFoundError(REF_FT_SO)
+        L = self.L = C.CDLL(str(REF_FT_SO))
+        L.ref_ft_create.restype = _vp
+        L.ref_ft_create.argtypes = [_sz]
+        L.ref_ft_destroy.argtypes = [_vp]
+        L.ref_ft_set_docs.argtypes = [_vp, _sz, _vp, _vp, _vp]
+        L.ref_ft_set_word.argtypes = [_vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]
+        L.ref_ft_set_config.argtypes = [_vp, _vp, _vp, _vp]
+        L.ref_ft_merge.restype = C.c_long
+        L.ref_ft_merge.argtypes = [_vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz]
+        self.nf = num_fields
+        self.h = L.ref_ft_create(num_fields)
+
+    def close(self):
+        if self.h:
+            self.L.ref_ft_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_docs(self, words, avg, removed=None):
+        words = _f32(words).reshape(-1, self.nf)
+        avg = _f32(avg)
+        rem = np.ascontiguousarray(removed, np.uint8) if removed is not None else None
+        self.total = words.shape[0]
+        self.L.ref_ft_set_docs(self.h, words.shape[0], words.ctypes.data, avg.ctypes.data, rem.ctypes.data if rem is not None else None)
+
+    def set_word_positions(self, word_id, doc, pos_off, pos_field, pos_pos):
+        doc = np.ascontiguousarray(doc, np.uint32)
+        po, pf, pp = (np.ascontiguousarray(a, np.uint32) for a in (pos_off, pos_field, pos_pos))
+        self.L.ref_ft_set_word(self.h, word_id, doc.shape[0], doc.ctypes.data, po.ctypes.data, pf.ctypes.data, pp.ctypes.data, None)
+
+    def set_word_flat(self, word_id, s):
+        """Flat sub-term dict (doc, ent_off, ent_field, ent_tf, ent_first_pos) -> positions first_pos, first_pos+1, ... per field."""
+        pos_off, pf, pp = [0], [], []
+        for i in range(len(s["doc"])):
+            for e in range(int(s["ent_off"][i]), int(s["ent_off"][i + 1])):
+                for t in range(int(s["ent_tf"][e])):
+                    pf.append(int(s["ent_field"][e]))
+                    pp.append(int(s["ent_first_pos"][e]) + t)
+            pos_off.append(len(pf))
+        self.set_word_positions(word_id, s["doc"], pos_off, pf, pp)
+
+    def set_config(self, cfg: dict, distance_boost=1.0, distance_weight=0.5):
+        cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], distance_boost, distance_weight], np.float64)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"]], np.int32)
+        fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                               "position_boost", "position_weight")], axis=1).copy()
+        self.L.ref_ft_set_config(self.h, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data)
+
+    def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16):
+        """terms: list of dict(op, opts (FtOracle.default_opts-like), subs=[(word_id, proc), ...])."""
+        nf = self.nf
+        ops = np.array([t["op"] for t in terms], np.int32)
+        boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+        tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+        fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+        ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+        sub_off, sw, sp = [0], [], []
+        for t in terms:
+            for w, p in t["subs"]:
+                sw.append(w)
+                sp.append(p)
+            sub_off.append(len(sw))
+        sub_off, sw, sp = np.array(sub_off, np.uint32), np.array(sw, np.uint32), np.array(sp, np.float32)
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        n = self.L.ref_ft_merge(self.h, len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data,
+                                sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
+                                rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
+        assert 0 <= n <= cap, n
+        return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
+
+
+def ref_ft_or_none(num_fields: int):
+    try:
+        return RefFt(num_fields)
+    except (FileNotFoundError, OSError):
+        return None

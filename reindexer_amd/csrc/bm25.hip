@@ -97,6 +97,35 @@ __global__ __launch_bounds__(256) void bm25_score(FtMergeParams p, FtSubterm s) 
 	atomicMin(&p.first[d], gp);
 }
 
+// All sub-terms in ONE launch: thread gp of the concatenated (sub-term, posting) sequence finds its sub-term by binary search over
+// the sequence bases (nsub is small), then scores exactly like bm25_score.
+__global__ __launch_bounds__(256) void bm25_score_fused(FtMergeParams p, const FtSubterm* subs, uint32_t nsub, uint64_t total) {
+	const uint64_t gp64 = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (gp64 >= total) return;
+	uint32_t lo = 0, hi = nsub - 1;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi + 1) >> 1;
+		if (subs[mid].gp_base <= gp64) {
+			lo = mid;
+		} else {
+			hi = mid - 1;
+		}
+	}
+	const FtSubterm s = subs[lo];
+	const uint64_t i = gp64 - s.gp_base;
+	const uint32_t d = s.doc[i];
+	const uint32_t gp = uint32_t(gp64);
+	p.pfield[gp] = 0xFF;
+	if ((p.excluded && p.excluded[d]) || (p.removed && p.removed[d])) return;
+	uint8_t field;
+	const float rank = ft_term_rank(p, s, s.ent_off[i], s.ent_off[i + 1], d, &field);
+	if (rank == 0.0f) return;
+	p.pfield[gp] = field;
+	const unsigned long long key = (static_cast<unsigned long long>(__float_as_uint(rank)) << 32) | (0xFFFFFFFFu - gp);
+	atomicMax(&p.best[d], key);
+	atomicMin(&p.first[d], gp);
+}
+
 // ---- order-preserving compaction of the add events, cut at max_merged ----
 constexpr int kScanBlock = 1024;
 
@@ -181,6 +210,10 @@ __global__ __launch_bounds__(256) void bm25_emit(FtMergeParams p, FtSubterm s, c
 	}
 }
 
+void launch_bm25_score_fused(const FtMergeParams& p, const FtSubterm* d_subs, uint32_t nsub, uint64_t total, hipStream_t st) {
+	if (total == 0) return;
+	hipLaunchKernelGGL(bm25_score_fused, dim3(uint32_t((total + 255) / 256)), dim3(256), 0, st, p, d_subs, nsub, total);
+}
 void launch_bm25_score(const FtMergeParams& p, const FtSubterm& s, hipStream_t st) {
 	if (s.n == 0) return;
 	hipLaunchKernelGGL(bm25_score, dim3(uint32_t((s.n + 255) / 256)), dim3(256), 0, st, p, s);

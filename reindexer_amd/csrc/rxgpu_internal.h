@@ -83,6 +83,7 @@ struct FtMergeParams {
 	uint8_t* out_field;
 };
 void launch_bm25_score(const FtMergeParams& p, const FtSubterm& s, hipStream_t st);
+void launch_bm25_score_fused(const FtMergeParams& p, const FtSubterm* d_subs, uint32_t nsub, uint64_t total, hipStream_t st);
 uint32_t bm25_scan_blocks_for(uint64_t n);
 void launch_bm25_count_adds(const FtMergeParams& p, const FtSubterm& s, uint32_t* block_counts, hipStream_t st);
 void launch_bm25_scan_blocks(uint32_t* block_counts, uint32_t nblocks, uint32_t* total, hipStream_t st);

@@ -121,3 +121,53 @@ def test_merge_simple_semantics(ft):
     assert set(doc.tolist()) <= set(seen[:120])
     doc2, proc2, field2, norm2 = ft.merge_simple(cfg, opts, total, words, avg, removed, excluded, subs, sort_by_rank=True)
     assert sorted(doc2.tolist()) == sorted(doc.tolist()) and np.all(np.diff(norm2.astype(int)) <= 0)
+
+
+# ------------------------------------------------------------------------------------------- vs the REAL ft::Merger (oracle/_ref)
+def _by_doc(ids, norm, field):
+    o = np.argsort(ids, kind="stable")
+    return ids[o], norm[o], field[o]
+
+
+@pytest.mark.parametrize("nf,limit", [(1, 20000), (3, 20000), (3, 120), (4, 37)])
+def test_restated_merge_simple_equals_real_merger(ft, nf, limit):
+    """The plain-C restatement vs reindexer::ft::Merger itself (compiled in place from the reference tree, libref_ft.so)."""
+    from oracle.pyoracle import ref_ft_or_none
+    real = ref_ft_or_none(nf)
+    if real is None:
+        pytest.skip("oracle/_ref/libref_ft.so not available")
+    rng = np.random.default_rng(nf * 1000 + limit)
+    total = 2500
+    words = rng.integers(1, 40, (total, nf)).astype(np.float32)
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    removed = np.zeros(total, np.uint8)
+    removed[rng.choice(total, 80, replace=False)] = 1
+    excluded = np.zeros(total, np.uint8)
+    excluded[rng.choice(total, 80, replace=False)] = 1
+    real.set_docs(words, avg, removed)
+    subs = []
+    for wid, proc in enumerate((100.0, 91.5, 77.0, 60.25)):
+        s = make_postings(rng, total, nf, int(rng.integers(150, 1200)))
+        s["proc"] = proc
+        subs.append(s)
+        real.set_word_flat(wid, s)
+    for variant in range(3):
+        cfg = ft.default_config(nf, merge_limit=limit)
+        opts = ft.default_opts(nf, field_boost=[1.0, 0.6, 0.0, 1.4][:nf], boost=1.0 + 0.3 * variant, term_len_boost=0.85)
+        if variant == 2 and nf > 1:
+            cfg["summation_ratio"] = 0.4
+            opts["need_sum_rank"] = [1] * nf
+        real.set_config(cfg)
+        for exc in (None, excluded):
+            wd, wp, wf, wn = real.merge([dict(op=real.OP_OR, opts=opts, subs=[(i, s["proc"]) for i, s in enumerate(subs)])], exc, rank_sort_type=1)
+            gd, gp, gf, gn = ft.merge_simple(cfg, opts, total, words, avg, removed, exc, subs, sort_by_rank=False)
+            assert np.array_equal(gd.astype(np.int32), wd), (nf, limit, variant)      # same docs in the same merge order
+            assert np.array_equal(gn, wn) and np.array_equal(gf, wf)
+            assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+            # sorted flavour: pdqsort is unstable in the reference => compare as (doc -> rank) maps
+            wd2, _, wf2, wn2 = real.merge([dict(op=real.OP_OR, opts=opts, subs=[(i, s["proc"]) for i, s in enumerate(subs)])], exc, rank_sort_type=0)
+            assert np.all(np.diff(wn2.astype(int)) <= 0)
+            a, b = _by_doc(wd2, wn2, wf2), _by_doc(gd.astype(np.int32), gn, gf)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    real.close()
