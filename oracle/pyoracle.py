@@ -366,8 +366,16 @@ class _FtPostings(C.Structure):
     _fields_ = [("n", _u64), ("doc", _vp), ("ent_off", _vp), ("ent_field", _vp), ("ent_tf", _vp), ("ent_first_pos", _vp), ("proc", _f)]
 
 
+class _FtPPostings(C.Structure):
+    _fields_ = [("n", _u64), ("doc", _vp), ("pos_off", _vp), ("fpos", _vp), ("proc", _f)]
+
+
+class _FtTerm(C.Structure):
+    _fields_ = [("op", _i), ("opts", _FtTermOpts), ("nsub", C.c_uint32), ("subs", _vp)]
+
+
 class FtOracle:
-    """Restated ft_fast single-term merge.  cfg / opts are plain dicts (defaults = the reference's FTConfig defaults)."""
+    """Restated ft_fast merge (single-term mergeSimple and multi-term mergeTerm).  cfg / opts are plain dicts (defaults = the reference's FTConfig defaults)."""
 
     def __init__(self, orc: Oracle):
         L = self.L = orc.L
@@ -381,6 +389,10 @@ class FtOracle:
         L.orc_bound.argtypes = [_f, _f, _f]
         L.orc_calc_term_rank.restype = _f
         L.orc_calc_term_rank.argtypes = [_vp, _vp, C.c_double, _f, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+        L.orc_ft_merge_query.restype = _sz
+        L.orc_ft_merge_query.argtypes = [_vp, C.c_double, C.c_double, _vp, C.c_uint32, _u64, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]
+        L.orc_positions_distance.restype = C.c_uint
+        L.orc_positions_distance.argtypes = [_vp, C.c_uint32, _vp, C.c_uint32]
         L.orc_ft_merge_simple.restype = _sz
         L.orc_ft_merge_simple.argtypes = [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _i, _vp, _vp, _vp, _vp]
 
@@ -456,6 +468,74 @@ class FtOracle:
         return od[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
 
 
+    def merge_query(self, cfg, terms, total_docs, words, avg_words, removed, excluded, sort_by_rank=True, distance_boost=1.0,
+                    distance_weight=0.5):
+        """Multi-term Merger::Merge.  terms: list of dict(op (1 OR / 2 AND / 3 NOT), opts, subs=[dict(doc, pos_off, fpos, proc), ...]),
+        sub-terms already in SortSubterms order.  Returns (doc, proc, field, norm, preselected)."""
+        c, k1 = self._cfg(cfg)
+        words = _f32(words)
+        avg = _f32(avg_words)
+        rem = np.ascontiguousarray(removed, np.uint8) if removed is not None else None
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        tarr = (_FtTerm * len(terms))()
+        keep = []
+        total = 0
+        for ti, t in enumerate(terms):
+            o, k2 = self._opts(t["opts"])
+            parr = (_FtPPostings * max(1, len(t["subs"])))()
+            for i, s in enumerate(t["subs"]):
+                d = np.ascontiguousarray(s["doc"], np.uint32)
+                po = np.ascontiguousarray(s["pos_off"], np.uint32)
+                fp = np.ascontiguousarray(s["fpos"], np.uint64)
+                keep += [d, po, fp]
+                parr[i] = _FtPPostings(d.shape[0], d.ctypes.data, po.ctypes.data, fp.ctypes.data, s["proc"])
+                total += d.shape[0]
+            keep += [k2, parr]
+            tarr[ti] = _FtTerm(t["op"], o, len(t["subs"]), C.cast(parr, _vp))
+        cap = max(1, min(cfg["merge_limit"], total))
+        od, op = np.zeros(cap, np.uint32), np.zeros(cap, np.float32)
+        of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        pre = C.c_uint8(0)
+        n = self.L.orc_ft_merge_query(C.byref(c), distance_boost, distance_weight, tarr, len(terms), total_docs, words.ctypes.data,
+                                      avg.ctypes.data, rem.ctypes.data if rem is not None else None,
+                                      exc.ctypes.data if exc is not None else None, int(sort_by_rank), od.ctypes.data, op.ctypes.data,
+                                      of.ctypes.data, on.ctypes.data, C.byref(pre))
+        return od[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
+
+    def positions_distance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint64)
+        b = np.ascontiguousarray(b, np.uint64)
+        return int(self.L.orc_positions_distance(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0]))
+
+
+def make_fpos(pos, field, array_idx=0):
+    """PosType word (idrelset.h:14-32): pos | arrayIdx << 28 | field << 56."""
+    return (np.asarray(pos, np.uint64) | (np.asarray(array_idx, np.uint64) << np.uint64(28)) | (np.asarray(field, np.uint64) << np.uint64(56)))
+
+
+def positions_to_entries(s):
+    """Positions-format sub-term dict -> the flat (field, tf, first pos) entry format of merge_simple / rxgpu_ft_set_word."""
+    doc = np.asarray(s["doc"], np.uint32)
+    po = np.asarray(s["pos_off"], np.int64)
+    fp = np.asarray(s["fpos"], np.uint64)
+    fld = (fp >> np.uint64(56)).astype(np.int64)
+    owner = np.repeat(np.arange(doc.shape[0]), np.diff(po))
+    start = np.ones(fp.shape[0], bool)
+    if fp.shape[0] > 1:
+        start[1:] = (owner[1:] != owner[:-1]) | (fld[1:] != fld[:-1])
+    idx = np.flatnonzero(start)
+    ent_field = fld[idx].astype(np.uint8)
+    ent_first = (fp[idx] & np.uint64((1 << 28) - 1)).astype(np.uint32)
+    ent_tf = np.diff(np.append(idx, fp.shape[0])).astype(np.uint32)
+    ent_off = np.zeros(doc.shape[0] + 1, np.uint32)
+    np.add.at(ent_off, owner[idx] + 1, 1)
+    ent_off = np.cumsum(ent_off).astype(np.uint32)
+    out = dict(doc=doc, ent_off=ent_off, ent_field=ent_field, ent_tf=ent_tf, ent_first_pos=ent_first)
+    if "proc" in s:
+        out["proc"] = s["proc"]
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ the REAL ft_fast merger (_ref)
 REF_FT_SO = HERE / "_ref" / "libref_ft.so"
 
@@ -499,6 +579,17 @@ class RefFt:
         doc = np.ascontiguousarray(doc, np.uint32)
         po, pf, pp = (np.ascontiguousarray(a, np.uint32) for a in (pos_off, pos_field, pos_pos))
         self.L.ref_ft_set_word(self.h, word_id, doc.shape[0], doc.ctypes.data, po.ctypes.data, pf.ctypes.data, pp.ctypes.data, None)
+
+    def set_word_fpos(self, word_id, s):
+        """Positions-format sub-term dict (doc, pos_off, fpos)."""
+        fp = np.asarray(s["fpos"], np.uint64)
+        self.L.ref_ft_set_word.argtypes = [_vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]
+        doc = np.ascontiguousarray(s["doc"], np.uint32)
+        po = np.ascontiguousarray(s["pos_off"], np.uint32)
+        pf = (fp >> np.uint64(56)).astype(np.uint32)
+        pp = (fp & np.uint64((1 << 28) - 1)).astype(np.uint32)
+        pa = ((fp >> np.uint64(28)) & np.uint64((1 << 28) - 1)).astype(np.uint32)
+        self.L.ref_ft_set_word(self.h, word_id, doc.shape[0], doc.ctypes.data, po.ctypes.data, pf.ctypes.data, pp.ctypes.data, pa.ctypes.data)
 
     def set_word_flat(self, word_id, s):
         """Flat sub-term dict (doc, ent_off, ent_field, ent_tf, ent_first_pos) -> positions first_pos, first_pos+1, ... per field."""

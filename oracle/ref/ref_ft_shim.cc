@@ -120,16 +120,9 @@ long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, c
 				wid.data = 0;
 				wid.SetID(int32_t(subWord[s]));
 				tr.AddSubterm(*f->postings.at(subWord[s]), std::string_view("w"), wid, subProc[s]);
-				if (o.op == OpOr) q.totalORVids += f->postings.at(subWord[s])->size();
 			}
+			q.totalORVids += tr.MaxVDocs();   // selecterimpl.h:546: every term, whatever its operator
 			q.queryParts.emplace_back(std::move(tr));
-		}
-		// selecterimpl.h: totalORVids counts the vids of OR terms; with only AND terms the merger still needs a positive bound
-		if (q.totalORVids == 0) {
-			for (size_t t = 0; t < nTerms; ++t) {
-				if (ops[t] == OpNot) continue;
-				for (uint32_t s = subOff[t]; s < subOff[t + 1]; ++s) q.totalORVids += f->postings.at(subWord[s])->size();
-			}
 		}
 		FtMergeStatuses::Statuses st;
 		st.resize(f->totalDocs, false);

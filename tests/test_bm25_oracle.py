@@ -171,3 +171,102 @@ def test_restated_merge_simple_equals_real_merger(ft, nf, limit):
             a, b = _by_doc(wd2, wn2, wf2), _by_doc(gd.astype(np.int32), gn, gf)
             assert all(np.array_equal(x, y) for x, y in zip(a, b))
     real.close()
+
+
+# ------------------------------------------------------------------------------------------- multi-term (mergeTerm) vs the real merger
+def make_pos_postings(rng, total, nf, n, proc, array_fields=False, max_pos=40):
+    """A sub-term in positions format: ascending docs, per doc 1..5 PosType words sorted like IdRelType::SortAndUnique."""
+    from oracle.pyoracle import make_fpos
+    doc = np.sort(rng.choice(np.arange(1, total), n, replace=False)).astype(np.uint32)
+    pos_off, fpos = [0], []
+    for _ in range(n):
+        k = int(rng.integers(1, 6))
+        f = rng.integers(0, nf, k)
+        p = rng.integers(0, max_pos, k)
+        a = rng.integers(0, 3, k) if array_fields else np.zeros(k, np.int64)
+        w = np.unique(make_fpos(p, f, a))
+        fpos.extend(w.tolist())
+        pos_off.append(len(fpos))
+    return dict(doc=doc, pos_off=np.array(pos_off, np.uint32), fpos=np.array(fpos, np.uint64), proc=proc)
+
+
+def _multi_case(seed, nf, total, limit, ops, array_fields=False, field_boosts=None, sizes=(150, 900)):
+    from oracle.pyoracle import ref_ft_or_none
+    rng = np.random.default_rng(seed)
+    words = rng.integers(1, 6, (total, nf)).astype(np.float32)
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    removed = np.zeros(total, np.uint8)
+    removed[rng.choice(total, total // 30, replace=False)] = 1
+    excluded = np.zeros(total, np.uint8)
+    excluded[rng.choice(total, total // 30, replace=False)] = 1
+    terms, wid, word_store = [], 0, []
+    for ti, op in enumerate(ops):
+        nsub = int(rng.integers(1, 4))
+        procs = sorted((float(rng.choice([100.0, 85.0, 70.5, 55.0, 40.0])) for _ in range(nsub)), reverse=True)
+        subs = []
+        for pr in procs:
+            s = make_pos_postings(rng, total, nf, int(rng.integers(*sizes)), pr, array_fields)
+            s["word"] = wid
+            word_store.append(s)
+            wid += 1
+            subs.append(s)
+        fb = field_boosts[ti] if field_boosts else [1.0] * nf
+        terms.append(dict(op=op, opts=dict(boost=float(rng.choice([1.0, 1.3, 0.7])), term_len_boost=float(rng.choice([1.0, 0.8])),
+                                            field_boost=fb, need_sum_rank=[0] * nf), subs=subs))
+    return ref_ft_or_none, words, avg, removed, excluded, terms, word_store
+
+
+MULTI_CASES = [
+    # (seed, nf, total, merge_limit, ops, array_fields, field_boosts)
+    (1, 1, 3000, 20000, (1, 1), False, None),
+    (2, 3, 3000, 20000, (1, 1, 1), False, None),
+    (3, 3, 3000, 20000, (2, 1), False, None),
+    (4, 2, 3000, 20000, (1, 2, 3), False, None),
+    (5, 4, 3000, 20000, (2, 2), True, None),
+    (6, 3, 3000, 20000, (1, 3, 1), True, [[1.0, 0.0, 2.0], [1.0, 1.0, 1.0], [0.0, 0.5, 1.0]]),
+    (7, 3, 3000, 20000, (2, 1), False, [[0.0, 1.0, 0.0], [1.0, 0.0, 0.5]]),
+    (8, 2, 3000, 150, (1, 1), False, None),            # mergeLimit reached inside mergeTerm AND the preselect path
+    (9, 3, 3000, 97, (1, 1, 1), True, [[1.0, 0.5, 2.0], [1.0, 1.0, 1.0], [3.0, 0.5, 1.0]]),
+    (10, 2, 3000, 60, (2, 1, 3), False, None),
+    (11, 1, 3000, 500, (1, 1, 1, 1), False, None),
+    (13, 2, 3000, 40, (2, 2), False, None),             # AND-only: the estimate is 0 => no preselect, the limit cuts inside mergeTerm
+    (14, 3, 3000, 25, (2, 2, 3), True, None),
+    (12, 2, 3000, 20000, (3, 1), False, None),          # a NOT term first: queryParts.size() > #merged terms => no full-match boost
+]
+
+
+@pytest.mark.parametrize("seed,nf,total,limit,ops,arr,fbs", MULTI_CASES)
+def test_restated_multi_term_merge_equals_real_merger(ft, seed, nf, total, limit, ops, arr, fbs):
+    ref_ft_or_none, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, fbs)
+    real = ref_ft_or_none(nf)
+    if real is None:
+        pytest.skip("oracle/_ref/libref_ft.so not available")
+    real.set_docs(words, avg, removed)
+    for s in store:
+        real.set_word_fpos(s["word"], s)
+    saw_pre = False
+    for variant, (dboost, dweight) in enumerate([(1.0, 0.5), (1.7, 0.8), (0.0, 1.0)]):
+        cfg = ft.default_config(nf, merge_limit=limit, min_rank=5 if variant != 1 else 60)
+        real.set_config(cfg, distance_boost=dboost, distance_weight=dweight)
+        rterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+        for exc in (None, excluded):
+            wd, wp, wf, wn = real.merge(rterms, exc, rank_sort_type=1)
+            gd, gp, gf, gn, pre = ft.merge_query(cfg, terms, total, words, avg, removed, exc, sort_by_rank=False, distance_boost=dboost,
+                                                 distance_weight=dweight)
+            saw_pre |= pre
+            assert np.array_equal(gd.astype(np.int32), wd), (seed, variant, len(gd), len(wd))
+            assert np.array_equal(gn, wn) and np.array_equal(gf, wf)
+            assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+    assert saw_pre == (limit < 1000 and 1 in ops)     # the small-limit cases must have gone through preselectMostRelevantDocs
+    real.close()
+
+
+def test_positions_distance_restatement(ft):
+    from oracle.pyoracle import make_fpos
+    a = make_fpos([3, 9], [0, 0])
+    assert ft.positions_distance(a, make_fpos([5], [0])) == 2
+    assert ft.positions_distance(a, make_fpos([9], [0])) == 0
+    assert ft.positions_distance(a, make_fpos([10], [0])) == 1
+    assert ft.positions_distance(a, make_fpos([4], [1])) == 0          # other field: no distance -> 0 ("zero for first occurence in field")
+    assert ft.positions_distance(make_fpos([], []), make_fpos([4], [1])) == 0
