@@ -164,6 +164,7 @@ typedef struct rxgpu_ft_config {
 	uint32_t merge_limit;                      /* 20000 */
 	uint32_t num_fields;
 	const double *bm25_boost, *bm25_weight, *term_len_boost, *term_len_weight, *position_boost, *position_weight;
+	double distance_boost, distance_weight;    /* 1.0, 0.5 (ftconfig.h:180-181); read by the multi-term merge only */
 } rxgpu_ft_config;
 
 /* FtDslOpts of the query term (cpp_src/core/ft/ftdsl.h:13-35). */
@@ -190,6 +191,21 @@ int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uin
 int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
 							  const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc,
 							  uint8_t* out_field, uint64_t cap, uint64_t* out_n);
+/* Posting list of one dictionary word WITH its positions, as the multi-term merge needs them (PositionsDistance,
+ * cpp_src/core/ft/ft_fast/mergerimpl.h:20-37): per posting a run [pos_off[i], pos_off[i+1]) of PosType words
+ * (cpp_src/core/ft/idrelset.h:14-32: pos | arrayIdx << 28 | field << 56), ascending like IdRelType::SortAndUnique leaves them.
+ * The (field, tf, first position) entries of rxgpu_ft_set_word are derived from them, so the word serves both merges. */
+int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uint32_t* doc, const uint32_t* pos_off, const uint64_t* fpos);
+/* Device half of Merger::Merge for a query of nterms >= 2 terms without phrases / multi-word synonyms (mergerimpl.h:466-566):
+ * buildRestrictingBitmask (:326-384), the 2-phase gate + preselectMostRelevantDocs (:386-464, 486-490) and mergeTerm (:107-192) for
+ * every term that is not a NOT.  ops[t]: OpType 1 OR / 2 AND / 3 NOT (core/type_consts.h); opts[t]: the term's FtDslOpts; the
+ * sub-terms of term t are word_ids/procs[sub_off[t] .. sub_off[t+1]) sorted by proc descending (SortSubterms).
+ * Writes the merged documents IN MERGE ORDER with raw proc, field and MergerDocumentData::termsCounter (merger.h:24) — the host
+ * merger derives canBeBoostedByFullMatch (:527-531) from it and applies addFullMatchBoost / postProcessResults (merger.h:100-155).
+ * *out_preselected = 1 if the preselect phase ran.  cap >= min(merge_limit, total postings). */
+int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
+							 const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc,
+							 float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n, int32_t* out_preselected);
 /* Postings scored / kernel milliseconds since the last call (roofline accounting: 20 B per posting). */
 int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms);
 

@@ -61,6 +61,8 @@ _SIGNATURES = {
     "rxgpu_ft_set_docs": (_i, [_vp, _u64, _vp, _vp, _vp]),
     "rxgpu_ft_set_word": (_i, [_vp, _u32, _u64, _vp, _vp, _vp, _vp, _vp]),
     "rxgpu_ft_merge_simple_raw": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "rxgpu_ft_set_word_positions": (_i, [_vp, _u32, _u64, _vp, _vp, _vp]),
+    "rxgpu_ft_merge_terms_raw": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_i)]),
     "rxgpu_ft_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
     "rxgpu_profile_enable": (_i, [_vp, _i]),
     "rxgpu_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),

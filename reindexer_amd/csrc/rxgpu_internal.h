@@ -89,6 +89,87 @@ void launch_bm25_count_adds(const FtMergeParams& p, const FtSubterm& s, uint32_t
 void launch_bm25_scan_blocks(uint32_t* block_counts, uint32_t nblocks, uint32_t* total, hipStream_t st);
 void launch_bm25_emit(const FtMergeParams& p, const FtSubterm& s, const uint32_t* block_offsets, hipStream_t st);
 
+// Multi-term merge (ft_terms.hip): Merger::mergeTerm + restricting bitmask + preselect
+struct FtPosSubterm {
+	uint64_t n;
+	const uint32_t* doc;
+	const uint32_t* ent_off;
+	const uint8_t* ent_field;
+	const uint32_t* ent_tf;
+	const uint32_t* ent_first_pos;
+	const uint32_t* pos_off;   // [n + 1]
+	const uint64_t* fpos;      // PosType words (idrelset.h:14-32): pos | arrayIdx << 28 | field << 56
+	double idf;
+	float proc;
+	uint64_t gp_base;          // used by the fused mask kernels only
+};
+struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslOpts of ONE query term
+	uint32_t num_fields;
+	const float* words;
+	const float* avg_words;
+	double k1, b, summation_ratio;
+	float opts_boost, term_len_boost_in;
+	const float* field_boost;
+	const uint8_t* need_sum_rank;
+	const float *bm25_boost, *bm25_weight, *term_len_boost, *term_len_weight, *position_boost, *position_weight;
+};
+struct FtSlots {               // MergeInfo + MergerDocumentData (merger.h:11-34) of the admitted documents, SoA by merge slot
+	uint32_t* doc;
+	float* proc;
+	uint8_t* field;
+	float* rank;               // MergerDocumentData::rank
+	const uint64_t** last_ptr; // lastTermPositions / nextTermPositions as views into the resident posting positions
+	uint32_t* last_cnt;
+	const uint64_t** next_ptr;
+	uint32_t* next_cnt;
+	uint16_t* switched_term;   // lazy switchToNextWord: last term index this slot was switched for
+	uint16_t* last_counted;    // lastTermCounted
+	uint16_t* terms_counter;
+};
+struct FtTermPass {
+	FtTermCfg cfg;
+	FtPosSubterm sub;
+	FtSlots slots;
+	const uint32_t* mask;      // restrictingMask_ bit words
+	const uint8_t* removed;    // null when needToCheckRemoved_ == false (after preselect) or nothing is removed
+	uint32_t* slot_of;         // idoffsets_: [total_docs], 0xFFFFFFFF = not added
+	uint32_t max_merged;
+	uint16_t qp_idx;
+	float distance_weight, distance_boost;
+	const uint32_t* num_docs_in;   // numDocs() before this sub-term
+	uint32_t* num_docs_out;        // ... and after it
+	unsigned long long* lookback;  // [blocks] decoupled look-back words, zeroed
+	uint32_t* ticket;              // dynamic block id, zeroed
+	uint32_t* error_flag;
+};
+struct FtPreselect {
+	const uint32_t* mask_in;
+	uint32_t* mask;
+	uint32_t* term_mask;
+	uint16_t* score;
+	uint32_t* hist;            // [65536]
+	uint32_t* pick;            // [2]: minScore, minScoreDocs
+	uint64_t total_docs;
+	const uint8_t* removed;
+	uint32_t max_merged;
+	unsigned long long* lookback;
+	uint32_t* ticket;
+	uint32_t* error_flag;
+};
+constexpr int kFtPassItems = 4;            // postings per thread in ft_term_pass
+constexpr int kFtPassBlock = 256 * kFtPassItems;
+inline uint32_t ft_pass_blocks(uint64_t n) { return uint32_t((n + kFtPassBlock - 1) / kFtPassBlock); }
+void launch_ft_mask_init(uint32_t* mask, const uint8_t* excluded, uint64_t total_docs, hipStream_t st);
+void launch_ft_term_mask(const FtPosSubterm* d_subs, uint32_t nsub, uint64_t total, const float* field_boost, uint32_t num_fields, uint32_t* term_mask,
+						 hipStream_t st);
+void launch_ft_mask_and(uint32_t* mask, const uint32_t* term_mask, uint64_t nwords, hipStream_t st);
+void launch_ft_mask_exclude(const FtPosSubterm* d_subs, uint32_t nsub, uint64_t total, uint32_t* mask, hipStream_t st);
+void launch_ft_mask_popcount(const uint32_t* mask, uint64_t nwords, uint32_t* out, hipStream_t st);
+void launch_ft_prescore(const FtPosSubterm& sub, const uint32_t* mask, uint32_t* term_mask, uint16_t* score, const float* field_boost, uint32_t num_fields,
+						 bool same_boost, float opts_boost, hipStream_t st);
+void launch_ft_preselect(const FtPreselect& p, hipStream_t st);
+void launch_ft_term_pass(const FtTermPass& p, hipStream_t st);
+
 void set_error(const std::string& msg);
 
 }  // namespace rxgpu

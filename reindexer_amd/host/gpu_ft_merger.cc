@@ -112,6 +112,11 @@ MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std
 	for (MergeInfo& md : out) {
 		if (words_[size_t(md.id) * numFields_ + md.field] == float(size_t(1))) md.proc = float(double(md.proc) * cfg.fullMatchBoost);
 	}
+	postProcess(cfg, out, rankSortType);
+	return out;
+}
+
+void GpuFtMerger::postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const {
 	// postProcessResults — merger.h:111-155
 	float maxProc = 0.0f;
 	for (const MergeInfo& md : out) maxProc = std::max(maxProc, md.proc);
@@ -134,6 +139,92 @@ MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std
 	if (rankSortType == RankSortType::RankOnly || rankSortType == RankSortType::IDAndPositions) {
 		std::stable_sort(out.begin(), out.end(), [](const MergeInfo& l, const MergeInfo& r) { return l.normalizedProc > r.normalizedProc; });
 	}
+}
+
+void GpuFtMerger::SetWord(uint32_t wordId, const PositionPostings& p) {
+	if (rxgpu_ft_set_word_positions(dev_, wordId, p.doc.size(), p.doc.data(), p.posOff.data(), p.fpos.data()) != RXGPU_OK) throwDevice("SetWord");
+}
+
+MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
+								  bool* preselected) const {
+	if (preselected) *preselected = false;
+	MergeData out;
+	// QueryMergeData::Empty() (querymergedata.h:208) / mergerimpl.h:472-474
+	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return out;
+	if (terms.size() == 1) return Merge(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType);   // Simple()
+	if (cfg.fieldsCfg.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
+
+	const size_t nt = terms.size();
+	std::vector<double> bm25Boost(numFields_), bm25Weight(numFields_), tlBoost(numFields_), tlWeight(numFields_), posBoost(numFields_), posWeight(numFields_);
+	for (size_t f = 0; f < numFields_; ++f) {
+		bm25Boost[f] = cfg.fieldsCfg[f].bm25Boost;
+		bm25Weight[f] = cfg.fieldsCfg[f].bm25Weight;
+		tlBoost[f] = cfg.fieldsCfg[f].termLenBoost;
+		tlWeight[f] = cfg.fieldsCfg[f].termLenWeight;
+		posBoost[f] = cfg.fieldsCfg[f].positionBoost;
+		posWeight[f] = cfg.fieldsCfg[f].positionWeight;
+	}
+	rxgpu_ft_config c{};
+	c.bm25_k1 = cfg.bm25k1;
+	c.bm25_b = cfg.bm25b;
+	c.summation_ranks_by_fields_ratio = cfg.summationRanksByFieldsRatio;
+	c.full_match_boost = cfg.fullMatchBoost;
+	c.min_rank = cfg.minRank;
+	c.merge_limit = cfg.mergeLimit;
+	c.num_fields = uint32_t(numFields_);
+	c.bm25_boost = bm25Boost.data();
+	c.bm25_weight = bm25Weight.data();
+	c.term_len_boost = tlBoost.data();
+	c.term_len_weight = tlWeight.data();
+	c.position_boost = posBoost.data();
+	c.position_weight = posWeight.data();
+	c.distance_boost = cfg.distanceBoost;
+	c.distance_weight = cfg.distanceWeight;
+
+	std::vector<int32_t> ops(nt);
+	std::vector<float> fieldBoost(nt * numFields_);
+	std::vector<uint8_t> needSum(nt * numFields_);
+	std::vector<rxgpu_ft_term_opts> opts(nt);
+	std::vector<uint32_t> subOff(nt + 1, 0), wordIds;
+	std::vector<float> procs;
+	for (size_t t = 0; t < nt; ++t) {
+		QueryTerm& qt = terms[t];
+		if (qt.opts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
+		ops[t] = int32_t(qt.op);
+		for (size_t f = 0; f < numFields_; ++f) {
+			fieldBoost[t * numFields_ + f] = qt.opts.fieldsOpts[f].boost;
+			needSum[t * numFields_ + f] = qt.opts.fieldsOpts[f].needSumRank ? 1 : 0;
+		}
+		opts[t] = rxgpu_ft_term_opts{qt.opts.boost, qt.opts.termLenBoost, fieldBoost.data() + t * numFields_, needSum.data() + t * numFields_};
+		// QueryMergeData::SortSubterms (querymergedata.h:196-206)
+		std::stable_sort(qt.subterms.begin(), qt.subterms.end(), [](const SubtermRef& l, const SubtermRef& r) { return l.proc > r.proc; });
+		for (const SubtermRef& sr : qt.subterms) {
+			wordIds.push_back(sr.wordId);
+			procs.push_back(sr.proc);
+		}
+		subOff[t + 1] = uint32_t(wordIds.size());
+	}
+	const size_t cap = cfg.mergeLimit;
+	std::vector<uint32_t> doc(cap);
+	std::vector<float> proc(cap);
+	std::vector<uint8_t> field(cap);
+	std::vector<uint16_t> termsCounter(cap);
+	uint64_t n = 0;
+	int32_t pre = 0;
+	if (rxgpu_ft_merge_terms_raw(dev_, &c, uint32_t(nt), ops.data(), opts.data(), subOff.data(), wordIds.data(), procs.data(), docsExcluded, doc.data(),
+								 proc.data(), field.data(), termsCounter.data(), cap, &n, &pre) != RXGPU_OK) {
+		throwDevice("MergeQuery");
+	}
+	if (preselected) *preselected = pre != 0;
+	out.resize(n);
+	// canBeBoostedByFullMatch: termsCounter == queryParts.size() (mergerimpl.h:527-531); addFullMatchBoost(QueryLength) (merger.h:100-109)
+	for (uint64_t i = 0; i < n; ++i) {
+		out[i].id = int32_t(doc[i]);
+		out[i].proc = proc[i];
+		out[i].field = field[i];
+		if (termsCounter[i] == nt && words_[size_t(doc[i]) * numFields_ + field[i]] == float(nt)) out[i].proc = float(double(proc[i]) * cfg.fullMatchBoost);
+	}
+	postProcess(cfg, out, rankSortType);
 	return out;
 }
 

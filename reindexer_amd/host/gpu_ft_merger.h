@@ -6,8 +6,9 @@
 //
 // Device: per-posting BM25 ranks, max per document, mergeLimit admission (bm25.hip via rxgpu_ft_merge_simple_raw).
 // Host:   the O(mergeLimit) tail of the merger — addFullMatchBoost (merger.h:100-109) and postProcessResults (:111-155).
-// Multi-term queries (mergeTerm with position distances), phrases and multi-word synonyms stay on the reference's CPU merger
-// (SURVEY appendix C "scope for the first BM25 kernel"); Supports() tells the caller which way to go.
+// Multi-term queries (AND / OR / NOT terms: restricting bitmask, preselect, mergeTerm with position distances,
+// mergerimpl.h:107-192, 252-464) go through MergeQuery (ft_terms.hip via rxgpu_ft_merge_terms_raw).
+// Phrases and multi-word synonyms stay on the reference's CPU merger; Supports() tells the caller which way to go.
 #pragma once
 
 #include <cstdint>
@@ -29,6 +30,7 @@ struct FtFieldConfig {
 struct FtConfig {
 	explicit FtConfig(size_t fieldsCount) : fieldsCfg(fieldsCount) {}
 	uint32_t mergeLimit = 20000;
+	double distanceBoost = 1.0, distanceWeight = 0.5;
 	double bm25k1 = 2.0, bm25b = 0.75;
 	double summationRanksByFieldsRatio = 0.0;
 	double fullMatchBoost = 1.1;
@@ -69,6 +71,28 @@ struct FlatPostings {
 	void Add(uint32_t vdoc, const std::pair<uint32_t, uint32_t>* fieldPos, size_t count);
 };
 
+// One posting list WITH positions (what mergeTerm needs): PosType words pos | arrayIdx << 28 | field << 56 (idrelset.h:14-32)
+struct PositionPostings {
+	std::vector<uint32_t> doc, posOff{0};
+	std::vector<uint64_t> fpos;
+	static uint64_t Pos(uint32_t pos, uint32_t field, uint32_t arrayIdx = 0) noexcept {
+		return uint64_t(pos) | (uint64_t(arrayIdx) << 28) | (uint64_t(field) << 56);
+	}
+	// append one IdRelType: positions sorted ascending (IdRelType::SortAndUnique)
+	void Add(uint32_t vdoc, const uint64_t* positions, size_t count) {
+		doc.push_back(vdoc);
+		fpos.insert(fpos.end(), positions, positions + count);
+		posOff.push_back(uint32_t(fpos.size()));
+	}
+};
+enum class OpType { Or = 1, And = 2, Not = 3 };   // core/type_consts.h
+// TermResults (querymergedata.h:46-98): a query term, its FtDslOpts and the dictionary words it matched
+struct QueryTerm {
+	OpType op = OpType::Or;
+	FtDslOpts opts;
+	std::vector<SubtermRef> subterms;
+};
+
 class GpuFtMerger {
 public:
 	GpuFtMerger(size_t numFields, int device = 0);
@@ -79,16 +103,23 @@ public:
 	void SetDocs(size_t totalDocs, const float* wordsInField, const float* avgWords, const uint8_t* removed);
 	void SetWord(uint32_t wordId, const FlatPostings& postings);
 
-	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept { return numQueryParts == 1 && !hasPhrases && !hasSynonyms; }
+	void SetWord(uint32_t wordId, const PositionPostings& postings);   // usable by Merge and MergeQuery
+
+	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept { return numQueryParts >= 1 && !hasPhrases && !hasSynonyms; }
 
 	// Merger::Merge<Bm25Rx> for a Simple() query
 	MergeData Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 					RankSortType rankSortType) const;
 
+	// Merger::Merge<Bm25Rx> for any query made of terms (queryParts without phrases, no synonyms); one OR/AND term -> Merge()
+	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
+						 bool* preselected = nullptr) const;
+
 	size_t TotalDocs() const noexcept { return totalDocs_; }
 	void ReadStats(uint64_t& postings, double& kernelMs) const;
 
 private:
+	void postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const;
 	const size_t numFields_;
 	size_t totalDocs_ = 0;
 	std::vector<float> words_;   // host copy for addFullMatchBoost

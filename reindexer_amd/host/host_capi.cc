@@ -323,6 +323,58 @@ extern "C" int rxhost_ft_set_word_flat(void* h, uint32_t wordId, size_t n, const
 	});
 }
 
+extern "C" int rxhost_ft_set_word_fpos(void* h, uint32_t wordId, size_t n, const uint32_t* doc, const uint32_t* posOff, const uint64_t* fpos) {
+	return guarded([&] {
+		PositionPostings pp;
+		pp.doc.assign(doc, doc + n);
+		pp.posOff.assign(posOff, posOff + n + 1);
+		pp.fpos.assign(fpos, fpos + (n ? posOff[n] : 0));
+		static_cast<GpuFtMerger*>(h)->SetWord(wordId, pp);
+	});
+}
+// cfgD: [k1, b, summationRatio, fullMatchBoost, distanceBoost, distanceWeight]; per term: op, boost, termLenBoost, fieldBoost[nf],
+// needSum[nf], sub-term slice [subOff[t], subOff[t+1]) of (wordId, proc).  Returns the result count, -1 on error.
+extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, const int* ops,
+									  const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
+									  const uint32_t* subOff, const uint32_t* wordIds, const float* procs, const uint8_t* excluded, int sortByRank,
+									  int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap, int* outPreselected) {
+	long n = -1;
+	guarded([&] {
+		FtConfig cfg(nf);
+		cfg.bm25k1 = cfgD[0];
+		cfg.bm25b = cfgD[1];
+		cfg.summationRanksByFieldsRatio = cfgD[2];
+		cfg.fullMatchBoost = cfgD[3];
+		cfg.distanceBoost = cfgD[4];
+		cfg.distanceWeight = cfgD[5];
+		cfg.minRank = cfgI[0];
+		cfg.mergeLimit = uint32_t(cfgI[1]);
+		for (size_t f = 0; f < nf; ++f) {
+			cfg.fieldsCfg[f] = FtFieldConfig{fieldCfg[f * 6 + 0], fieldCfg[f * 6 + 1], fieldCfg[f * 6 + 2], fieldCfg[f * 6 + 3], fieldCfg[f * 6 + 4], fieldCfg[f * 6 + 5]};
+		}
+		std::vector<QueryTerm> terms(nTerms);
+		for (size_t t = 0; t < nTerms; ++t) {
+			terms[t].op = OpType(ops[t]);
+			terms[t].opts.boost = boosts[t];
+			terms[t].opts.termLenBoost = termLenBoosts[t];
+			terms[t].opts.fieldsOpts.resize(nf);
+			for (size_t f = 0; f < nf; ++f) terms[t].opts.fieldsOpts[f] = FtDslFieldOpts{fieldBoost[t * nf + f], needSum[t * nf + f] != 0};
+			for (uint32_t s = subOff[t]; s < subOff[t + 1]; ++s) terms[t].subterms.push_back(SubtermRef{wordIds[s], procs[s]});
+		}
+		bool pre = false;
+		auto res = static_cast<const GpuFtMerger*>(h)->MergeQuery(cfg, std::move(terms), excluded, sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID, &pre);
+		if (outPreselected) *outPreselected = pre ? 1 : 0;
+		n = long(res.size());
+		for (size_t i = 0; i < res.size() && i < cap; ++i) {
+			outId[i] = res[i].id;
+			outProc[i] = res[i].proc;
+			outField[i] = res[i].field;
+			outNorm[i] = res[i].normalizedProc;
+		}
+	});
+	return n;
+}
+
 // ---------------------------------------------------------------------------------------------- hybrid rank fusion
 #include "hybrid_rerank.h"
 

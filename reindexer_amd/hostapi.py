@@ -421,6 +421,56 @@ class GpuFtMerger:
             _raise()
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
 
+    def set_word_fpos(self, word_id, s):
+        """s: positions-format sub-term dict (doc, pos_off, fpos[u64 PosType words]); serves merge() and merge_query()."""
+        L = lib()
+        L.rxhost_ft_set_word_fpos.argtypes = [_vp, C.c_uint32, _sz, _vp, _vp, _vp]
+        doc = np.ascontiguousarray(s["doc"], np.uint32)
+        po = np.ascontiguousarray(s["pos_off"], np.uint32)
+        fp = np.ascontiguousarray(s["fpos"], np.uint64)
+        rc = L.rxhost_ft_set_word_fpos(self.h, word_id, doc.shape[0], doc.ctypes.data, po.ctypes.data, fp.ctypes.data)
+        if rc:
+            _raise(rc)
+
+    OP_OR, OP_AND, OP_NOT = 1, 2, 3
+
+    def merge_query(self, cfg: dict, terms, excluded=None, sort_by_rank=True):
+        """Multi-term Merger::Merge.  terms: [dict(op, opts, subs=[(word_id, proc), ...]), ...].
+        Returns (ids, proc, field, norm, preselected)."""
+        L = lib()
+        L.rxhost_ft_merge_query.restype = _l
+        L.rxhost_ft_merge_query.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]
+        nf = self.nf
+        cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
+                          cfg.get("distance_weight", 0.5)], np.float64)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"]], np.int32)
+        fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                               "position_boost", "position_weight")], axis=1).copy()
+        ops = np.array([t["op"] for t in terms], np.int32)
+        boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+        tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+        fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+        ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+        sub_off, wid, pr = [0], [], []
+        for t in terms:
+            for w, p in t["subs"]:
+                wid.append(w)
+                pr.append(p)
+            sub_off.append(len(wid))
+        sub_off, wid, pr = np.array(sub_off, np.uint32), np.array(wid, np.uint32), np.array(pr, np.float32)
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        cap = int(cfg["merge_limit"])
+        oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        pre = C.c_int(0)
+        n = L.rxhost_ft_merge_query(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, len(terms), ops.ctypes.data, boosts.ctypes.data,
+                                    tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data,
+                                    exc.ctypes.data if exc is not None else None, int(sort_by_rank), oid.ctypes.data, op.ctypes.data,
+                                    of.ctypes.data, on.ctypes.data, cap, C.byref(pre))
+        if n < 0:
+            _raise()
+        return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
+
     def read_stats(self):
         a, b = _u64(0), C.c_double(0.0)
         lib().rxhost_ft_read_stats(self.h, C.byref(a), C.byref(b))

@@ -178,16 +178,18 @@ def make_pos_postings(rng, total, nf, n, proc, array_fields=False, max_pos=40):
     """A sub-term in positions format: ascending docs, per doc 1..5 PosType words sorted like IdRelType::SortAndUnique."""
     from oracle.pyoracle import make_fpos
     doc = np.sort(rng.choice(np.arange(1, total), n, replace=False)).astype(np.uint32)
-    pos_off, fpos = [0], []
-    for _ in range(n):
-        k = int(rng.integers(1, 6))
-        f = rng.integers(0, nf, k)
-        p = rng.integers(0, max_pos, k)
-        a = rng.integers(0, 3, k) if array_fields else np.zeros(k, np.int64)
-        w = np.unique(make_fpos(p, f, a))
-        fpos.extend(w.tolist())
-        pos_off.append(len(fpos))
-    return dict(doc=doc, pos_off=np.array(pos_off, np.uint32), fpos=np.array(fpos, np.uint64), proc=proc)
+    k = rng.integers(1, 6, n)
+    owner = np.repeat(np.arange(n), k)
+    m = owner.shape[0]
+    w = make_fpos(rng.integers(0, max_pos, m), rng.integers(0, nf, m), rng.integers(0, 3, m) if array_fields else np.zeros(m, np.int64))
+    order = np.lexsort((w, owner))
+    owner, w = owner[order], w[order]
+    keep = np.ones(m, bool)
+    keep[1:] = (owner[1:] != owner[:-1]) | (w[1:] != w[:-1])          # SortAndUnique per posting
+    owner, w = owner[keep], w[keep]
+    pos_off = np.zeros(n + 1, np.int64)
+    np.add.at(pos_off, owner + 1, 1)
+    return dict(doc=doc, pos_off=np.cumsum(pos_off).astype(np.uint32), fpos=w.astype(np.uint64), proc=proc)
 
 
 def _multi_case(seed, nf, total, limit, ops, array_fields=False, field_boosts=None, sizes=(150, 900)):

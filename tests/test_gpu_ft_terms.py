@@ -1,0 +1,100 @@
+"""-m gpu: ft_fast MULTI-TERM merge on the GPU (ft_terms.hip through rxgpu_ft_merge_terms_raw and GpuFtMerger::MergeQuery) vs the
+CPU restatement of Merger::Merge, which tests/test_bm25_oracle.py pins bit-exact against the real reference merger.
+Bar: the same documents in the same merge order, the same raw-rank bits, fields and uint8 ranks — for AND / OR / NOT terms, zero field
+boosts, array positions, the mergeLimit cut inside mergeTerm and the preselect phase."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FtOracle
+from .test_bm25_oracle import MULTI_CASES, _multi_case, make_pos_postings
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ft(oracle):
+    return FtOracle(oracle)
+
+
+@pytest.fixture(scope="module")
+def hostapi(rxgpu):
+    from reindexer_amd import hostapi as h
+    h.lib()
+    return h
+
+
+def _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, expect_pre=None, variants=((1.0, 0.5), (1.7, 0.8), (0.0, 1.0))):
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg, removed)
+    for s in store:
+        m.set_word_fpos(s["word"], s)
+    gterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    saw_pre = False
+    for variant, (dboost, dweight) in enumerate(variants):
+        cfg = ft.default_config(nf, merge_limit=limit, min_rank=5 if variant != 1 else 60)
+        cfg["distance_boost"], cfg["distance_weight"] = dboost, dweight
+        for exc in (None, excluded):
+            wd, wp, wf, wn, wpre = ft.merge_query(cfg, terms, total, words, avg, removed, exc, sort_by_rank=False, distance_boost=dboost,
+                                                  distance_weight=dweight)
+            gd, gp, gf, gn, gpre = m.merge_query(cfg, gterms, exc, sort_by_rank=False)
+            saw_pre |= gpre
+            assert gpre == wpre
+            assert np.array_equal(gd, wd.astype(np.int32)), (variant, len(gd), len(wd))
+            assert np.array_equal(gn, wn) and np.array_equal(gf, wf)
+            assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+            # rank-sorted flavour: same (doc -> rank) map, non-increasing ranks
+            sd, _, sf, sn, _ = m.merge_query(cfg, gterms, exc, sort_by_rank=True)
+            assert np.all(np.diff(sn.astype(int)) <= 0)
+            o1, o2 = np.argsort(sd, kind="stable"), np.argsort(gd, kind="stable")
+            assert np.array_equal(sd[o1], gd[o2]) and np.array_equal(sn[o1], gn[o2]) and np.array_equal(sf[o1], gf[o2])
+    if expect_pre is not None:
+        assert saw_pre == expect_pre
+    m.close()
+
+
+@pytest.mark.parametrize("seed,nf,total,limit,ops,arr,fbs", MULTI_CASES)
+def test_gpu_multi_term_merge_equals_restated_merger(hostapi, ft, seed, nf, total, limit, ops, arr, fbs):
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, fbs)
+    _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, expect_pre=(limit < 1000 and 1 in ops))
+
+
+@pytest.mark.parametrize("limit,ops", [(20000, (1, 1)), (3000, (1, 1, 1)), (2500, (2, 1)), (700, (2, 2)), (20000, (1, 3, 2))])
+def test_gpu_multi_term_many_workgroups(hostapi, ft, limit, ops):
+    """Posting lists of 20-90 K documents: dozens of ticket-ordered workgroups per launch, slots assigned across them."""
+    nf, total = 2, 200_000
+    _, words, avg, removed, excluded, terms, store = _multi_case(1000 + limit, nf, total, limit, ops, False, None, sizes=(20_000, 90_000))
+    _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, variants=((1.0, 0.5),))
+
+
+def test_gpu_multi_term_edge_cases(hostapi, ft):
+    nf, total = 2, 500
+    rng = np.random.default_rng(5)
+    words = rng.integers(1, 4, (total, nf)).astype(np.float32)
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg)
+    a = make_pos_postings(rng, total, nf, 60, 100.0)
+    b = make_pos_postings(rng, total, nf, 80, 100.0)
+    m.set_word_fpos(0, a)
+    m.set_word_fpos(1, b)
+    cfg = hostapi.default_ft_config(nf)
+    o = hostapi.default_ft_opts(nf)
+    # Empty(): no terms, or a lone NOT
+    assert len(m.merge_query(cfg, [])[0]) == 0
+    assert len(m.merge_query(cfg, [dict(op=3, opts=o, subs=[(0, 100.0)])])[0]) == 0
+    # one OR term is Simple(): same result as merge()
+    q1 = m.merge_query(cfg, [dict(op=1, opts=o, subs=[(0, 100.0)])], sort_by_rank=False)
+    q2 = m.merge(cfg, o, [(0, 100.0)], sort_by_rank=False)
+    assert all(np.array_equal(x, y) for x, y in zip(q1[:4], q2))
+    # a term without sub-terms: OR contributes nothing, AND empties the result
+    oa = ft.merge_query(cfg, [dict(op=1, opts=o, subs=[]), dict(op=1, opts=o, subs=[b])], total, words, avg, None, None, sort_by_rank=False)
+    ga = m.merge_query(cfg, [dict(op=1, opts=o, subs=[]), dict(op=1, opts=o, subs=[(1, 100.0)])], sort_by_rank=False)
+    assert np.array_equal(ga[0], oa[0].astype(np.int32)) and np.array_equal(ga[3], oa[3])
+    assert len(m.merge_query(cfg, [dict(op=2, opts=o, subs=[]), dict(op=1, opts=o, subs=[(1, 100.0)])])[0]) == 0
+    # a word uploaded without positions cannot take part in a multi-term merge: loud error, no fallback
+    from .test_bm25_oracle import make_postings
+    m.set_word_flat(2, make_postings(rng, total, nf, 30))
+    with pytest.raises(Exception):
+        m.merge_query(cfg, [dict(op=1, opts=o, subs=[(2, 100.0)]), dict(op=1, opts=o, subs=[(1, 100.0)])])
+    m.close()
