@@ -205,25 +205,48 @@ __global__ __launch_bounds__(256) void ft_prescore(FtPosSubterm s, const uint32_
 	}
 }
 
-// mergerimpl.h:416-423: zero the score of masked-out / removed documents, histogram of the rest (wave-aggregated atomics)
+// mergerimpl.h:416-423: zero the score of masked-out / removed documents, histogram of the rest.  Scores take few distinct values,
+// so the counts are aggregated per wave, then per workgroup in a small LDS table, and only then added to the global histogram.
 __global__ __launch_bounds__(256) void ft_prescore_finalize(FtPreselect p) {
-	const uint64_t d = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	uint32_t sc = 0;
-	if (d < p.total_docs) {
-		sc = p.score[d];
-		if (sc && (!mask_bit(p.mask, uint32_t(d)) || (p.removed && p.removed[d]))) {
-			sc = 0;
-			p.score[d] = 0;
+	__shared__ uint32_t keys[256];
+	__shared__ uint32_t cnts[256];
+	keys[threadIdx.x] = 0;   // a score of 0 is never inserted
+	cnts[threadIdx.x] = 0;
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	for (uint64_t base = uint64_t(blockIdx.x) * 256; base < p.total_docs; base += uint64_t(gridDim.x) * 256) {
+		const uint64_t d = base + threadIdx.x;
+		uint32_t sc = 0;
+		if (d < p.total_docs) {
+			sc = p.score[d];
+			if (sc && (!mask_bit(p.mask, uint32_t(d)) || (p.removed && p.removed[d]))) {
+				sc = 0;
+				p.score[d] = 0;
+			}
+		}
+		unsigned long long todo = __ballot(sc != 0);
+		while (todo) {
+			const int leader = __ffsll((long long)todo) - 1;
+			const uint32_t v = __shfl(sc, leader, 64);
+			const unsigned long long same = __ballot(sc == v);
+			if (lane == leader) {
+				const uint32_t c = uint32_t(__popcll(same));
+				uint32_t h = (v * 2654435761u) >> 24;
+				int probes = 0;
+				for (; probes < 256; ++probes, h = (h + 1) & 255u) {
+					const uint32_t old = atomicCAS(&keys[h], 0u, v);
+					if (old == 0u || old == v) {
+						atomicAdd(&cnts[h], c);
+						break;
+					}
+				}
+				if (probes == 256) atomicAdd(&p.hist[v], c);   // more than 256 distinct scores in one workgroup
+			}
+			todo &= ~same;
 		}
 	}
-	unsigned long long todo = __ballot(sc != 0);
-	while (todo) {
-		const int leader = __ffsll((long long)todo) - 1;
-		const uint32_t v = __shfl(sc, leader, 64);
-		const unsigned long long same = __ballot(sc == v);
-		if ((threadIdx.x & 63) == leader) atomicAdd(&p.hist[v], uint32_t(__popcll(same)));
-		todo &= ~same;
-	}
+	__syncthreads();
+	if (keys[threadIdx.x]) atomicAdd(&p.hist[keys[threadIdx.x]], cnts[threadIdx.x]);
 }
 
 // mergerimpl.h:433-446: walk the scores downwards until maxMergedDocs documents are covered
@@ -331,17 +354,52 @@ __global__ __launch_bounds__(256) void ft_term_pass(FtTermPass p) {
 	float c_rank[kFtPassItems];
 	uint8_t c_field[kFtPassItems];
 	uint32_t c_mask = 0;
+	// The gathers of one posting form a dependent chain (doc -> mask word -> slot -> removed flag); the four postings of a thread
+	// are independent, so each stage is issued for all four before anything is consumed.
+	uint32_t docs[kFtPassItems], slots_of[kFtPassItems];
+	bool live[kFtPassItems];
+	static_assert(kFtPassItems == 4, "the vector load below reads four document ids");
+	if (i0 + kFtPassItems <= p.sub.n) {
+		const uint4 v = *reinterpret_cast<const uint4*>(p.sub.doc + i0);   // i0 % 4 == 0 and the list is 256-byte aligned
+		docs[0] = v.x;
+		docs[1] = v.y;
+		docs[2] = v.z;
+		docs[3] = v.w;
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) live[k] = true;
+	} else {
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) {
+			live[k] = i0 + k < p.sub.n;
+			docs[k] = live[k] ? p.sub.doc[i0 + k] : 0u;
+		}
+	}
+	{
+		uint32_t mw[kFtPassItems];
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) mw[k] = live[k] ? p.mask[docs[k] >> 5] : 0u;
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) live[k] = live[k] && ((mw[k] >> (docs[k] & 31)) & 1u);   // restrictingMask_
+	}
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) slots_of[k] = live[k] ? p.slot_of[docs[k]] : kNoSlot;
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) live[k] = live[k] && !(slots_of[k] == kNoSlot && full);   // !docAdded && numDocs() >= maxMergedDocs_
+	if (p.removed) {
+		uint8_t rm[kFtPassItems];
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) rm[k] = live[k] ? p.removed[docs[k]] : uint8_t(0);
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) live[k] = live[k] && !rm[k];
+	}
 #pragma unroll
 	for (int k = 0; k < kFtPassItems; ++k) {
 		const uint64_t i = i0 + k;
 		c_rank[k] = 0.f;
 		c_field[k] = 0;
-		if (i >= p.sub.n) continue;
-		const uint32_t d = p.sub.doc[i];
-		if (!mask_bit(p.mask, d)) continue;                    // restrictingMask_
-		const uint32_t slot = p.slot_of[d];
-		if (slot == kNoSlot && full) continue;                 // !docAdded && numDocs() >= maxMergedDocs_
-		if (p.removed && p.removed[d]) continue;
+		if (!live[k]) continue;
+		const uint32_t d = docs[k];
+		const uint32_t slot = slots_of[k];
 		uint8_t field;
 		const float rank = ft_term_rank(p.cfg, p.sub, p.sub.ent_off[i], p.sub.ent_off[i + 1], d, &field);
 		if (rank == 0.0f) continue;
@@ -435,7 +493,7 @@ void launch_ft_mask_exclude(const FtPosSubterm* d_subs, uint32_t nsub, uint64_t 
 	hipLaunchKernelGGL(ft_mask_exclude, grid_for(total), dim3(256), 0, st, d_subs, nsub, total, mask);
 }
 void launch_ft_mask_popcount(const uint32_t* mask, uint64_t nwords, uint32_t* out, hipStream_t st) {
-	const uint32_t blocks = uint32_t(std::min<uint64_t>((nwords + 255) / 256, 2048));
+	const uint32_t blocks = uint32_t(std::min<uint64_t>((nwords + 255) / 256, 256));
 	hipLaunchKernelGGL(ft_mask_popcount, dim3(blocks ? blocks : 1), dim3(256), 0, st, mask, nwords, out);
 }
 void launch_ft_prescore(const FtPosSubterm& sub, const uint32_t* mask, uint32_t* term_mask, uint16_t* score, const float* field_boost, uint32_t,
@@ -444,7 +502,7 @@ void launch_ft_prescore(const FtPosSubterm& sub, const uint32_t* mask, uint32_t*
 	hipLaunchKernelGGL(ft_prescore, grid_for(sub.n), dim3(256), 0, st, sub, mask, term_mask, score, field_boost, same_boost ? 1u : 0u, opts_boost);
 }
 void launch_ft_preselect(const FtPreselect& p, hipStream_t st) {
-	hipLaunchKernelGGL(ft_prescore_finalize, grid_for(p.total_docs), dim3(256), 0, st, p);
+	hipLaunchKernelGGL(ft_prescore_finalize, dim3(uint32_t(std::min<uint64_t>((p.total_docs + 255) / 256, 2048))), dim3(256), 0, st, p);
 	hipLaunchKernelGGL(ft_preselect_pick, dim3(1), dim3(1024), 0, st, p);
 	const uint64_t nwords = (p.total_docs + 31) / 32;
 	hipLaunchKernelGGL(ft_preselect_apply, grid_for(nwords), dim3(256), 0, st, p, nwords);
