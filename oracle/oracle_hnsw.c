@@ -236,3 +236,149 @@ size_t orc_hnsw_search_knn(int metric, size_t n, size_t dim, size_t M, size_t ma
 	free(res);
 	return total;
 }
+
+/* ================================================================================================================
+ * Streaming (batched) KNN: BeginStreamingSearch / ContinueStreamingSearch (hnswalg.h:1865-1975) with the streaming branches of
+ * initLayer0SearchState (:846-850), layer0ShouldStopBeforePop (:865-868) and runLayer0Step (:882-893, 939-940),
+ * mergeExtrasIntoTopCandidates (:1893-1926), emitStreamingBatch (:1928-1945).
+ * PARITY PINNED: tests/test_oracle_vs_ref.py::test_hnsw_streaming_* replay whole sessions against the real engine (oracle/_ref).
+ */
+typedef struct {
+	orc_hnsw_graph g;
+	float* q;
+	uint8_t* visited;
+	fheap top, extras, cand;
+	float lower;
+	size_t ef;
+	int bare, empty_graph;
+} orc_hnsw_stream;
+
+void* orc_hnsw_stream_begin(int metric, size_t n, size_t dim, size_t M, size_t maxM0, int maxlevel, uint32_t entry, size_t num_deleted,
+							 const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, const int32_t* levels,
+							 const uint64_t* labels, const uint8_t* deleted, const float* vectors, const float* inv_norms, const float* q, size_t ef) {
+	orc_hnsw_stream* s = (orc_hnsw_stream*)calloc(1, sizeof(*s));
+	const orc_hnsw_graph g = {metric, n,     dim,      M,     maxM0,  maxlevel, entry,   num_deleted,
+							  links0, upper_off, upper, levels, labels, deleted,  vectors, inv_norms};
+	s->g = g;
+	s->empty_graph = n == 0;
+	if (n == 0) return s;
+	s->q = (float*)malloc(dim * sizeof(float));
+	memcpy(s->q, q, dim * sizeof(float));
+	s->ef = ef ? ef : 100; /* kDefaultStreamingEf */
+	s->bare = num_deleted == 0;
+	long ndist = 0;
+	const uint32_t ep = entry_point_layer0(&s->g, s->q, &ndist);
+	s->visited = (uint8_t*)calloc(n, 1);
+	if (s->bare || !deleted[ep]) {
+		const float d = gdist(&s->g, s->q, ep);
+		s->lower = d;
+		/* streaming: the entry point is NOT put into top_candidates, it gets there when it is popped */
+		fh_emplace(&s->cand, -d, ep);
+	} else {
+		s->lower = FLT_MAX;
+		fh_emplace(&s->cand, -s->lower, ep);
+	}
+	s->visited[ep] = 1;
+	return s;
+}
+
+static void stream_merge_extras(orc_hnsw_stream* s) { /* hnswalg.h:1893-1926 */
+	if (s->top.n >= s->ef || s->extras.n == 0) return;
+	if (s->top.n) {
+		fheap te = s->extras;
+		fheap fresh = {0};
+		s->extras = fresh;
+		const size_t need = s->ef - s->top.n;
+		size_t delta = te.n > need ? te.n - need : 0;
+		while (delta-- > 0) {
+			fh_emplace(&s->extras, te.c[0].d, te.c[0].id);
+			fh_pop(&te);
+		}
+		while (te.n && s->top.n < s->ef) {
+			fh_emplace(&s->top, te.c[0].d, te.c[0].id);
+			fh_pop(&te);
+		}
+		free(te.c);
+	} else {
+		free(s->top.c);
+		s->top = s->extras;
+		fheap fresh = {0};
+		s->extras = fresh;
+		while (s->top.n > s->ef) {
+			fh_emplace(&s->extras, s->top.c[0].d, s->top.c[0].id);
+			fh_pop(&s->top);
+		}
+	}
+	if (s->top.n) s->lower = s->top.c[0].d;
+}
+
+/* Returns the batch size; out_* in emission order (emitStreamingBatch pops the worst first); *exhausted as the reference reports it. */
+size_t orc_hnsw_stream_continue(void* h, size_t batch, float* out_dist, uint64_t* out_label, int* exhausted) {
+	orc_hnsw_stream* s = (orc_hnsw_stream*)h;
+	*exhausted = 0;
+	if (batch == 0) return 0;
+	if (s->empty_graph) {
+		*exhausted = 1;
+		return 0;
+	}
+	const orc_hnsw_graph* g = &s->g;
+	const size_t orig_ef = s->ef;
+	if (batch > s->ef) s->ef = batch;
+	stream_merge_extras(s);
+	for (;;) {
+		if (s->cand.n == 0) break;
+		const float cdist = -s->cand.c[0].d;
+		if (cdist > s->lower && s->top.n >= s->ef) break;   /* streaming: never the bare-bone shortcut */
+		const float dist = -s->cand.c[0].d;
+		const uint32_t cur = s->cand.c[0].id;
+		fh_pop(&s->cand);
+		if (s->bare || !g->deleted[cur]) {
+			if (s->top.n < s->ef) {
+				fh_emplace(&s->top, dist, cur);
+			} else if (s->lower > dist) {
+				const hpair old = s->top.c[0];
+				fh_replace_top(&s->top, dist, cur);
+				fh_emplace(&s->extras, old.d, old.id);
+			}
+			s->lower = s->top.c[0].d;
+		}
+		const uint32_t* ll = g->links0 + (size_t)cur * (1 + g->maxM0);
+		const size_t size = ll[0];
+		for (size_t j = 0; j < size; j++) {
+			const uint32_t cid = ll[1 + j];
+			if (s->visited[cid]) continue;
+			s->visited[cid] = 1;
+			fh_emplace(&s->cand, -gdist(g, s->q, cid), cid);
+		}
+	}
+	s->ef = orig_ef;
+	/* emitStreamingBatch */
+	fheap tc = s->top;
+	fheap fresh = {0};
+	s->top = fresh;
+	while (tc.n > batch) {
+		fh_emplace(&s->top, tc.c[0].d, tc.c[0].id);
+		fh_pop(&tc);
+	}
+	size_t n = 0;
+	while (tc.n) {
+		out_dist[n] = tc.c[0].d;
+		out_label[n] = g->labels[tc.c[0].id];
+		++n;
+		fh_pop(&tc);
+	}
+	free(tc.c);
+	*exhausted = s->cand.n == 0 && s->top.n == 0 && s->extras.n == 0;
+	return n;
+}
+
+void orc_hnsw_stream_end(void* h) {
+	orc_hnsw_stream* s = (orc_hnsw_stream*)h;
+	if (!s) return;
+	free(s->q);
+	free(s->visited);
+	free(s->top.c);
+	free(s->extras.c);
+	free(s->cand.c);
+	free(s);
+}

@@ -186,6 +186,11 @@ class Ref:
         L.ref_hnsw_count.argtypes = [_vp]
         L.ref_hnsw_search_knn.restype = _sz
         L.ref_hnsw_search_knn.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+        L.ref_hnsw_stream_begin.restype = _vp
+        L.ref_hnsw_stream_begin.argtypes = [_vp, _vp, _sz, _sz]
+        L.ref_hnsw_stream_continue.restype = _sz
+        L.ref_hnsw_stream_continue.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp]
+        L.ref_hnsw_stream_end.argtypes = [_vp]
         L.ref_hnsw_search_range.restype = _sz
         L.ref_hnsw_search_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
         L.ref_hnsw_info.argtypes = [_vp, _vp]
@@ -305,6 +310,10 @@ class RefHnsw:
         assert c <= cap
         return od[:c].copy(), ol[:c].copy()
 
+    def stream(self, q, ef=0):
+        """BeginStreamingSearch: returns a session object with .next(batch) -> (dist, label, exhausted) and .close()."""
+        return _RefStream(self, _f32(q), ef)
+
     def export(self, with_vectors=True) -> dict:
         """Flat graph in the layout shared by the oracle restatement and the GPU engine."""
         info = np.zeros(6, np.int64)
@@ -329,6 +338,52 @@ def _hnsw_bind(L):
     L.orc_hnsw_search_knn.restype = _sz
     L.orc_hnsw_search_knn.argtypes = [_i, _sz, _sz, _sz, _sz, _i, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]
     L.orc_hnsw_last_stats.argtypes = [_vp, _vp]
+
+
+class _RefStream:
+    def __init__(self, owner, q, ef):
+        self.owner, self.q = owner, q
+        self.s = owner.ref.L.ref_hnsw_stream_begin(owner.h, q.ctypes.data, owner.dim, ef)
+
+    def next(self, batch):
+        od, ol = np.empty(max(batch, 1), np.float32), np.empty(max(batch, 1), np.uint64)
+        ex = C.c_int(0)
+        n = self.owner.ref.L.ref_hnsw_stream_continue(self.owner.h, self.s, batch, od.ctypes.data, ol.ctypes.data, C.byref(ex))
+        return od[:n].copy(), ol[:n].copy(), bool(ex.value)
+
+    def close(self):
+        if self.s:
+            self.owner.ref.L.ref_hnsw_stream_end(self.s)
+            self.s = None
+
+
+class OracleHnswStream:
+    """Restated BeginStreamingSearch / ContinueStreamingSearch on a flat graph (oracle/oracle_hnsw.c)."""
+
+    def __init__(self, orc: Oracle, g: dict, q, ef: int = 0, inv_norms=None):
+        L = self.L = orc.L
+        L.orc_hnsw_stream_begin.restype = _vp
+        L.orc_hnsw_stream_begin.argtypes = [_i, _sz, _sz, _sz, _sz, _i, C.c_uint32, _sz] + [_vp] * 9 + [_sz]
+        L.orc_hnsw_stream_continue.restype = _sz
+        L.orc_hnsw_stream_continue.argtypes = [_vp, _sz, _vp, _vp, _vp]
+        L.orc_hnsw_stream_end.argtypes = [_vp]
+        self.keep = (g, _f32(q), _f32(inv_norms) if inv_norms is not None else None)
+        q, inv = self.keep[1], self.keep[2]
+        self.s = L.orc_hnsw_stream_begin(g["metric"], g["n"], g["dim"], g["M"], g["maxM0"], g["maxlevel"], g["entry"], g["num_deleted"],
+                                         g["links0"].ctypes.data, g["upper_off"].ctypes.data, g["upper"].ctypes.data, g["levels"].ctypes.data,
+                                         g["labels"].ctypes.data, g["deleted"].ctypes.data, g["vectors"].ctypes.data,
+                                         inv.ctypes.data if inv is not None else None, q.ctypes.data, ef)
+
+    def next(self, batch):
+        od, ol = np.empty(max(batch, 1), np.float32), np.empty(max(batch, 1), np.uint64)
+        ex = C.c_int(0)
+        n = self.L.orc_hnsw_stream_continue(self.s, batch, od.ctypes.data, ol.ctypes.data, C.byref(ex))
+        return od[:n].copy(), ol[:n].copy(), bool(ex.value)
+
+    def close(self):
+        if self.s:
+            self.L.orc_hnsw_stream_end(self.s)
+            self.s = None
 
 
 def oracle_hnsw_search_knn(orc: Oracle, g: dict, q, k: int, ef: int = 0, inv_norms=None, with_stats=False):

@@ -161,6 +161,34 @@ size_t ref_hnsw_search_range(void* h, const float* q, float radius, size_t ef, f
 	return drain(res, outDist, outLabel, cap);
 }
 
+// Streaming KNN (hnswalg.h:1865-1975), driven like HnswIndexBase<Map>::beginStreaming / continueStreaming (hnsw_index.cc:318-351).
+// The query is copied: hnswlib keeps a raw pointer for float data.
+struct RefStream {
+	std::vector<float> q;
+	std::unique_ptr<hnswlib::StreamingSearchSession> session;
+};
+void* ref_hnsw_stream_begin(void* h, const float* q, size_t dim, size_t ef) {
+	auto* s = new RefStream();
+	s->q.assign(q, q + dim);
+	s->session = std::make_unique<hnswlib::StreamingSearchSession>(
+		static_cast<const HnswT*>(h)->BeginStreamingSearch(s->q.data(), std::nullopt, hnswlib::StreamingSearchOptions{.ef = ef}));
+	return s;
+}
+// Pops the batch's result queue: out_* worst first under (dist, label).  Returns the batch size.
+size_t ref_hnsw_stream_continue(void* h, void* session, size_t batch, float* outDist, uint64_t* outLabel, int* exhausted) {
+	auto* s = static_cast<RefStream*>(session);
+	auto b = static_cast<const HnswT*>(h)->ContinueStreamingSearch(*s->session, batch);
+	*exhausted = b.exhausted ? 1 : 0;
+	size_t n = 0;
+	for (; !b.results.empty(); b.results.pop()) {
+		outDist[n] = b.results.top().first;
+		outLabel[n] = b.results.top().second;
+		++n;
+	}
+	return n;
+}
+void ref_hnsw_stream_end(void* session) { delete static_cast<RefStream*>(session); }
+
 // Graph export (flat form shared by the C restatement and the GPU engine):
 //   info[0]=count info[1]=M info[2]=maxM0 info[3]=maxlevel info[4]=entrypoint info[5]=numDeleted
 void ref_hnsw_info(void* h, int64_t* info) {

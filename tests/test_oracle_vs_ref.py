@@ -139,3 +139,45 @@ def test_hnsw_search_restatement_matches_reference(oracle, ref, metric):
                 assert np.array_equal(wl, gl), (metric, phase, qi, k, ef)
                 assert np.array_equal(bits(wd), bits(gd))
     h.close()
+
+
+def _sorted_batch(d, l):
+    o = np.lexsort((l, d))
+    return d[o], l[o]
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_hnsw_streaming_restatement_matches_reference(oracle, ref, metric):
+    """Whole streaming sessions (BeginStreamingSearch + ContinueStreamingSearch until exhausted, hnswalg.h:1865-1975) against the real
+    engine: every batch must hold exactly the same (dist, label) pairs, and `exhausted` must flip at the same call."""
+    from oracle.pyoracle import OracleHnswStream, RefHnsw
+    n, d = 1200, 32
+    rows = make_corpus(77, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(2)
+    h = RefHnsw(ref, metric, d, n, M=8, ef_construction=100)
+    h.add(rows, labels)
+    for phase in range(2):
+        if phase == 1:
+            for lab in labels[np.random.default_rng(4).choice(n, 100, replace=False)]:
+                h.mark_delete(lab)
+        g = h.export()
+        inv = oracle.l2_modules(g["vectors"]) if metric == 2 else None
+        for qi, (ef, batches) in enumerate([(0, [10] * 8), (16, [5, 40, 1, 300, 7]), (64, [64] * 40), (3, [1] * 30 + [2000])]):
+            q = make_corpus(900 + qi, 1, d)[0]
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            rs, os_ = h.stream(q, ef), OracleHnswStream(oracle, g, q, ef, inv)
+            total = 0
+            for b in batches:
+                wd, wl, wex = rs.next(b)
+                gd, gl, gex = os_.next(b)
+                assert wex == gex and len(wd) == len(gd), (metric, phase, qi, b)
+                a, c = _sorted_batch(wd, wl), _sorted_batch(gd, gl)
+                assert np.array_equal(a[1], c[1]) and np.array_equal(bits(a[0]), bits(c[0])), (metric, phase, qi, b)
+                total += len(wd)
+            if batches[-1] >= n:
+                live = n - (100 if phase else 0)
+                assert wex and 0.95 * live <= total <= live     # a full drain returns every REACHABLE live element exactly once
+            rs.close()
+            os_.close()
+    h.close()
