@@ -149,6 +149,17 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 /* Counters accumulated since the last call (for the roofline accounting: bytes = evals*dim*4 + hops*(1+2M)*4). */
 int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops);
 
+/* Streaming (batched) KNN over the attached graph: HierarchicalNSWImpl::BeginStreamingSearch / ContinueStreamingSearch
+ * (cpp_src/core/index/float_vector/hnswlib/hnswalg.h:1865-1975; interface hnsw_interface.h:18-45, 99-102).  The session owns its
+ * Layer0SearchState (candidate_set, top_candidates, top_candidates_extras, visited set) in device memory.  query: [dim] floats, already
+ * normalised for cosine (hnsw_index.cc:303-314); ef == 0 -> 100.  Every continue(batch) returns <= batch (dist, internal row) pairs,
+ * worst first like emitStreamingBatch pops them, and *exhausted as the reference reports it.  The graph must not change during a
+ * session (the reference requires an external read lock for the same reason). */
+typedef struct rxgpu_hnsw_stream rxgpu_hnsw_stream;
+int rxgpu_hnsw_stream_begin(rxgpu_index* h, const float* query, uint32_t ef, rxgpu_hnsw_stream** out);
+int rxgpu_hnsw_stream_continue(rxgpu_hnsw_stream* s, uint32_t batch, float* out_dist, uint32_t* out_row, uint32_t* out_count, int32_t* exhausted);
+void rxgpu_hnsw_stream_end(rxgpu_hnsw_stream* s);
+
 /* ---------------------------------------------------------------------------------------------------------
  * ft_fast BM25 score accumulation (ft::Merger<..>::mergeSimple, cpp_src/core/ft/ft_fast/mergerimpl.h:194-250)
  * ------------------------------------------------------------------------------------------------------- */

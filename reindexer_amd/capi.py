@@ -56,6 +56,9 @@ _SIGNATURES = {
     "rxgpu_hnsw_update_deleted": (_i, [_vp, _vp, _u64]),
     "rxgpu_hnsw_search_knn": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rxgpu_hnsw_stream_begin": (_i, [_vp, _vp, _u32, C.POINTER(_vp)]),
+    "rxgpu_hnsw_stream_continue": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i)]),
+    "rxgpu_hnsw_stream_end": (None, [_vp]),
     "rxgpu_ft_create": (_i, [_u32, _i, C.POINTER(_vp)]),
     "rxgpu_ft_destroy": (None, [_vp]),
     "rxgpu_ft_set_docs": (_i, [_vp, _u64, _vp, _vp, _vp]),

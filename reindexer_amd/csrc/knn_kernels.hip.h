@@ -95,6 +95,34 @@ struct HnswParams {
 	uint32_t ef_cap;             // result-heap capacity in LDS: ef rounded up to 64
 };
 
+// Streaming session (hnsw_stream.hip): Layer0SearchState (hnswalg.h:741-777) resident in device memory between calls
+constexpr int kStreamBegin = 0, kStreamContinue = 1, kStreamResume = 2;
+constexpr uint32_t kStreamOk = 0, kStreamNeedGlobal = 1, kStreamError = 2;
+constexpr int kStreamLdsTop = 1024;    // top_candidates (two arrays: emitStreamingBatch rebuilds the heap)
+constexpr int kStreamLdsExt = 1024;    // top_candidates_extras (two arrays: mergeExtrasIntoTopCandidates rebuilds it)
+constexpr int kStreamLdsCand = 3072;   // candidate_set
+struct HnswStreamState {
+	int cand_n, top_n, ext_n;
+	float lower;             // lowerBound
+	uint32_t top_sel, ext_sel;
+	uint32_t status, out_count, exhausted;
+};
+struct HnswStream {
+	const float* query;      // [dim], normalised by the host for cosine
+	uint32_t* visited;       // [ceil(n/32)]
+	float* cand_d;           // [cap]
+	uint32_t* cand_i;
+	float* top_d;            // [2][cap]
+	uint32_t* top_i;
+	float* ext_d;            // [2][cap]
+	uint32_t* ext_i;
+	uint32_t cap;            // one entry per node is always enough: a node sits in at most one heap
+	uint32_t ef;             // StreamingSearchOptions::ef (0 -> 100, hnswalg.h:1867)
+	HnswStreamState* state;
+	float* out_dist;         // [batch capacity]
+	uint32_t* out_row;
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // 16-byte row load; kStream = non-temporal (rows are read exactly once per scan — keep them out of L2/MALL's way)

@@ -855,6 +855,159 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 	return RXGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- streaming KNN sessions
+struct rxgpu_hnsw_stream {
+	rxgpu_index* owner = nullptr;
+	uint64_t graph_n = 0;
+	uint32_t ef = 0;
+	hipStream_t stream = nullptr;
+	rxgpu_devbuf d_query, d_visited, d_cand, d_top, d_ext, d_state, d_out;
+	uint32_t out_cap = 0;
+	rxgpu::HnswStreamState host_state{};
+	bool empty_graph = false;
+};
+
+static void fill_hnsw_params(const rxgpu_index* h, rxgpu::HnswParams& p) {
+	p.rows = h->d_rows;
+	p.inv_norms = h->d_inv_norms;
+	p.links0 = h->d_links0;
+	p.upper_off = h->d_upper_off;
+	p.upper = h->d_upper;
+	p.deleted = h->d_deleted;
+	p.n = h->count;
+	p.stride = h->stride;
+	p.dim = h->dim;
+	p.M = h->graph_M;
+	p.maxM0 = h->graph_maxM0;
+	p.maxlevel = h->graph_maxlevel;
+	p.entry = h->graph_entry;
+	p.bare = h->graph_deleted == 0;
+}
+
+static void fill_stream(const rxgpu_hnsw_stream* s, rxgpu::HnswStream& d) {
+	const uint64_t cap = s->graph_n;
+	d.query = static_cast<const float*>(s->d_query.ptr);
+	d.visited = static_cast<uint32_t*>(s->d_visited.ptr);
+	d.cand_d = static_cast<float*>(s->d_cand.ptr);
+	d.cand_i = reinterpret_cast<uint32_t*>(d.cand_d + cap);
+	d.top_d = static_cast<float*>(s->d_top.ptr);
+	d.top_i = reinterpret_cast<uint32_t*>(d.top_d + 2 * cap);
+	d.ext_d = static_cast<float*>(s->d_ext.ptr);
+	d.ext_i = reinterpret_cast<uint32_t*>(d.ext_d + 2 * cap);
+	d.cap = uint32_t(cap);
+	d.ef = s->ef;
+	d.state = static_cast<rxgpu::HnswStreamState*>(s->d_state.ptr);
+	d.out_dist = static_cast<float*>(s->d_out.ptr);
+	d.out_row = reinterpret_cast<uint32_t*>(d.out_dist + s->out_cap);
+}
+
+void rxgpu_hnsw_stream_end(rxgpu_hnsw_stream* s) {
+	if (!s) return;
+	DeviceGuard dg(s->owner->device);
+	if (s->stream) {
+		(void)hipStreamSynchronize(s->stream);
+		(void)hipStreamDestroy(s->stream);
+	}
+	for (rxgpu_devbuf* b : {&s->d_query, &s->d_visited, &s->d_cand, &s->d_top, &s->d_ext, &s->d_state, &s->d_out}) b->release();
+	delete s;
+}
+
+int rxgpu_hnsw_stream_begin(rxgpu_index* h, const float* query, uint32_t ef, rxgpu_hnsw_stream** out) {
+	RX_CHECK(h && query && out, RXGPU_ERR_PARAMS, "rxgpu_hnsw_stream_begin: null argument");
+	*out = nullptr;
+	DeviceGuard dg(h->device);
+	auto* s = new rxgpu_hnsw_stream();
+	s->owner = h;
+	s->ef = ef ? ef : 100;   // kDefaultStreamingEf (hnswalg.h:1867)
+	s->graph_n = h->count;
+	if (h->count == 0) {     // hnswalg.h:1880-1882: an empty graph yields a session that is exhausted at once
+		s->empty_graph = true;
+		*out = s;
+		return RXGPU_OK;
+	}
+	struct Guard {
+		rxgpu_hnsw_stream* s;
+		~Guard() {
+			if (s) rxgpu_hnsw_stream_end(s);
+		}
+	} guard{s};
+	RX_CHECK(h->graph_attached && h->graph_n == h->count, RXGPU_ERR_LOGIC, "rxgpu_hnsw_stream_begin: graph is not attached / out of date");
+	RX_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+	const uint64_t cap = h->count, words = (h->count + 31) / 32;
+	if (int rc = s->d_query.ensure(size_t(h->dim) * 4); rc) return rc;
+	if (int rc = s->d_visited.ensure(words * 4); rc) return rc;
+	if (int rc = s->d_cand.ensure(cap * 8); rc) return rc;
+	if (int rc = s->d_top.ensure(cap * 16); rc) return rc;
+	if (int rc = s->d_ext.ensure(cap * 16); rc) return rc;
+	if (int rc = s->d_state.ensure(sizeof(rxgpu::HnswStreamState)); rc) return rc;
+	RX_HIP(hipMemcpyAsync(s->d_query.ptr, query, size_t(h->dim) * 4, hipMemcpyHostToDevice, s->stream));
+	RX_HIP(hipMemsetAsync(s->d_visited.ptr, 0, words * 4, s->stream));
+	rxgpu::HnswParams p{};
+	fill_hnsw_params(h, p);
+	rxgpu::HnswStream d{};
+	fill_stream(s, d);
+	rxgpu::launch_hnsw_stream(h->metric, p, d, 0, rxgpu::kStreamBegin, false, s->stream);
+	RX_HIP(hipGetLastError());
+	RX_HIP(hipMemcpyAsync(&s->host_state, s->d_state.ptr, sizeof(s->host_state), hipMemcpyDeviceToHost, s->stream));
+	RX_HIP(hipStreamSynchronize(s->stream));
+	guard.s = nullptr;
+	*out = s;
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_stream_continue(rxgpu_hnsw_stream* s, uint32_t batch, float* out_dist, uint32_t* out_row, uint32_t* out_count, int32_t* exhausted) {
+	RX_CHECK(s && out_count && exhausted, RXGPU_ERR_PARAMS, "rxgpu_hnsw_stream_continue: null argument");
+	*out_count = 0;
+	*exhausted = 0;
+	if (batch == 0) return RXGPU_OK;   // hnswalg.h:1956-1958
+	if (s->empty_graph) {
+		*exhausted = 1;
+		return RXGPU_OK;
+	}
+	RX_CHECK(out_dist && out_row, RXGPU_ERR_PARAMS, "rxgpu_hnsw_stream_continue: null argument");
+	rxgpu_index* h = s->owner;
+	// the whole session must run under the caller's read lock (hnsw_interface.h:99): a mutated graph invalidates it
+	RX_CHECK(h->graph_attached && h->graph_n == s->graph_n && h->count == s->graph_n, RXGPU_ERR_LOGIC,
+			 "rxgpu_hnsw_stream_continue: the graph changed under the session");
+	DeviceGuard dg(h->device);
+	const uint32_t out_need = uint32_t(std::min<uint64_t>(batch, s->graph_n));
+	if (out_need > s->out_cap) {
+		if (int rc = s->d_out.ensure(size_t(out_need) * 8); rc) return rc;
+		s->out_cap = out_need;
+	}
+	rxgpu::HnswParams p{};
+	fill_hnsw_params(h, p);
+	rxgpu::HnswStream d{};
+	fill_stream(s, d);
+	const rxgpu::HnswStreamState& hs = s->host_state;
+	const uint32_t ef_eff = std::max(s->ef, batch);
+	bool lds = ef_eff <= uint32_t(rxgpu::kStreamLdsTop) && uint32_t(hs.top_n) <= uint32_t(rxgpu::kStreamLdsTop) &&
+			   uint32_t(hs.ext_n) <= uint32_t(rxgpu::kStreamLdsExt) && uint32_t(hs.cand_n) + h->graph_maxM0 <= uint32_t(rxgpu::kStreamLdsCand);
+	if (getenv("RXGPU_HNSW_STREAM_GLOBAL")) lds = false;   // test hook: run every call with the heaps in HBM
+	int mode = rxgpu::kStreamContinue;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		ProfileScope ps(h, lds ? "hnsw_stream" : "hnsw_stream_global", s->stream);
+		rxgpu::launch_hnsw_stream(h->metric, p, d, batch, mode, lds, s->stream);
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipMemcpyAsync(&s->host_state, s->d_state.ptr, sizeof(s->host_state), hipMemcpyDeviceToHost, s->stream));
+		RX_HIP(hipStreamSynchronize(s->stream));
+		if (s->host_state.status != rxgpu::kStreamNeedGlobal) break;
+		RX_CHECK(lds, RXGPU_ERR_DEVICE, "rxgpu_hnsw_stream_continue: global-heap pass asked for more room");
+		lds = false;                       // outgrew LDS at a step boundary: same call, heaps in HBM, no second mergeExtras
+		mode = rxgpu::kStreamResume;
+	}
+	RX_CHECK(s->host_state.status == rxgpu::kStreamOk, RXGPU_ERR_DEVICE, "rxgpu_hnsw_stream_continue: device-side session error");
+	const uint32_t n = s->host_state.out_count;
+	if (n) {
+		RX_HIP(hipMemcpyAsync(out_dist, d.out_dist, size_t(n) * 4, hipMemcpyDeviceToHost, s->stream));
+		RX_HIP(hipMemcpyAsync(out_row, d.out_row, size_t(n) * 4, hipMemcpyDeviceToHost, s->stream));
+		RX_HIP(hipStreamSynchronize(s->stream));
+	}
+	*out_count = n;
+	*exhausted = s->host_state.exhausted ? 1 : 0;
+	return RXGPU_OK;
+}
+
 int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops) {
 	RX_CHECK(h && distance_evals && hops, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_stats: null argument");
 	*distance_evals = 0;

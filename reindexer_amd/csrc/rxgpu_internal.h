@@ -49,6 +49,8 @@ void launch_rescore(int metric, const float* rows, const float* inv_norms, const
 // HNSW search (hnsw_search.hip)
 struct HnswParams;
 void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s);
+struct HnswStream;
+void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, uint32_t batch, int mode, bool lds, hipStream_t st);
 
 // BM25 merge (bm25.hip)
 struct FtSubterm {

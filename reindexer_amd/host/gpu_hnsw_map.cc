@@ -99,6 +99,50 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 	return result;
 }
 
+StreamingSearchSession::~StreamingSearchSession() {
+	if (impl_) rxgpu_hnsw_stream_end(impl_);
+}
+StreamingSearchSession& StreamingSearchSession::operator=(StreamingSearchSession&& o) noexcept {
+	if (this != &o) {
+		if (impl_) rxgpu_hnsw_stream_end(impl_);
+		impl_ = o.impl_;
+		graph_ = o.graph_;
+		o.impl_ = nullptr;
+	}
+	return *this;
+}
+
+// hnswalg.h:1865-1891
+StreamingSearchSession GpuHnswMap::BeginStreamingSearch(const float* queryDataRaw, std::optional<float>, StreamingSearchOptions opts) const {
+	StreamingSearchSession session;
+	session.graph_ = this;
+	syncDevice();
+	if (rxgpu_hnsw_stream_begin(dev_, queryDataRaw, uint32_t(opts.ef), &session.impl_) != RXGPU_OK) throwDevice("BeginStreamingSearch");
+	return session;
+}
+
+// hnswalg.h:1947-1975
+StreamingBatch GpuHnswMap::ContinueStreamingSearch(StreamingSearchSession& session, size_t batchSize) const {
+	StreamingBatch batch;
+	if (session.graph_ != this || !session.impl_) {
+		batch.exhausted = true;
+		return batch;
+	}
+	if (batchSize == 0) return batch;
+	const size_t cap = std::min(batchSize, std::max<size_t>(1, graph_.Count()));
+	std::vector<float> dist(cap);
+	std::vector<uint32_t> row(cap);
+	uint32_t count = 0;
+	int32_t exhausted = 0;
+	if (rxgpu_hnsw_stream_continue(session.impl_, uint32_t(std::min<size_t>(batchSize, 0xFFFFFFFFu)), dist.data(), row.data(), &count, &exhausted) != RXGPU_OK) {
+		throwDevice("ContinueStreamingSearch");
+	}
+	batch.results.reserve(count);
+	for (uint32_t i = 0; i < count; ++i) batch.results.emplace(dist[i], graph_.Label(row[i]));   // emitStreamingBatch: (dist, ExternalLabel)
+	batch.exhausted = exhausted != 0;
+	return batch;
+}
+
 // hnswalg.h:2015-2070: ef-search, then breadth-first expansion over level-0 links while dist < radius.
 // The expansion is a closure (its result set does not depend on visiting order); the host walks the frontier and the
 // GPU computes every distance (rxgpu_distances), so no search arithmetic runs on the CPU.

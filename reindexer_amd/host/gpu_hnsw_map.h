@@ -12,8 +12,31 @@
 #include "rx_types.h"
 
 struct rxgpu_index;
+struct rxgpu_hnsw_stream;
 
 namespace rxgpu::host {
+
+// hnsw_interface.h:18-45
+struct StreamingSearchOptions {
+	size_t ef = 0;
+};
+struct StreamingBatch {
+	SearchResultQueue results;
+	bool exhausted = false;
+};
+class StreamingSearchSession {
+public:
+	StreamingSearchSession() = default;
+	StreamingSearchSession(StreamingSearchSession&& o) noexcept : impl_(o.impl_), graph_(o.graph_) { o.impl_ = nullptr; }
+	StreamingSearchSession& operator=(StreamingSearchSession&& o) noexcept;
+	StreamingSearchSession(const StreamingSearchSession&) = delete;
+	~StreamingSearchSession();
+
+private:
+	friend class GpuHnswMap;
+	rxgpu_hnsw_stream* impl_ = nullptr;
+	const void* graph_ = nullptr;   // the Map that began the session (hnswalg.h:1953-1956: a foreign session is reported exhausted)
+};
 
 class GpuHnswMap {
 public:
@@ -40,6 +63,10 @@ public:
 
 	SearchResultQueue SearchKnn(const float* queryDataRaw, std::optional<float> queryDataNorm, size_t k, size_t ef = 0) const;
 	SearchResultQueue SearchRange(const float* queryDataRaw, std::optional<float> queryDataNorm, float radius, size_t ef) const;
+
+	// Streaming (batched) KNN, hnswalg.h:1865-1975.  The whole session must run under the caller's read lock, like the reference's.
+	StreamingSearchSession BeginStreamingSearch(const float* queryDataRaw, std::optional<float> queryDataNorm, StreamingSearchOptions opts) const;
+	StreamingBatch ContinueStreamingSearch(StreamingSearchSession& session, size_t batchSize) const;
 
 	bool IsQuantized() const noexcept { return false; }
 	bool QuantizationAvailable() const noexcept { return false; }

@@ -212,6 +212,28 @@ long rxhost_hnsw_search_knn(void* h, const float* q, size_t k, size_t ef, float*
 	});
 	return n;
 }
+// streaming session, driven like HnswIndexBase<Map>::beginStreaming / continueStreaming (hnsw_index.cc:318-351)
+void* rxhost_hnsw_stream_begin(void* h, const float* q, size_t ef) {
+	StreamingSearchSession* s = nullptr;
+	guarded([&] { s = new StreamingSearchSession(static_cast<const GpuHnswMap*>(h)->BeginStreamingSearch(q, std::nullopt, StreamingSearchOptions{ef})); });
+	return s;
+}
+// pops the batch's result queue: worst first under (dist, label).  Returns the count, -1 on error.
+long rxhost_hnsw_stream_continue(void* h, void* session, size_t batch, float* outDist, uint64_t* outLabel, int* exhausted) {
+	long n = -1;
+	guarded([&] {
+		auto b = static_cast<const GpuHnswMap*>(h)->ContinueStreamingSearch(*static_cast<StreamingSearchSession*>(session), batch);
+		*exhausted = b.exhausted ? 1 : 0;
+		n = 0;
+		for (; !b.results.empty(); b.results.pop()) {
+			outDist[n] = b.results.top().first;
+			outLabel[n] = b.results.top().second;
+			++n;
+		}
+	});
+	return n;
+}
+void rxhost_hnsw_stream_end(void* session) { delete static_cast<StreamingSearchSession*>(session); }
 long rxhost_hnsw_search_range(void* h, const float* q, float radius, size_t ef, float* outDist, uint64_t* outLabel, size_t cap) {
 	long n = -1;
 	guarded([&] {

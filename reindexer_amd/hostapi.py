@@ -231,6 +231,40 @@ class HnswGraph:
                     links0=links0, upper_off=upper_off, upper=upper, levels=levels, labels=labels, deleted=deleted)
 
 
+class _HnswStream:
+    def __init__(self, owner, q, ef):
+        L = lib()
+        L.rxhost_hnsw_stream_begin.restype = _vp
+        L.rxhost_hnsw_stream_begin.argtypes = [_vp, _vp, _sz]
+        L.rxhost_hnsw_stream_continue.restype = _l
+        L.rxhost_hnsw_stream_continue.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp]
+        L.rxhost_hnsw_stream_end.argtypes = [_vp]
+        self.owner, self.q = owner, q
+        self.s = L.rxhost_hnsw_stream_begin(owner.h, q.ctypes.data, ef)
+        if not self.s:
+            _raise()
+
+    def next(self, batch):
+        cap = max(1, min(batch, int(self.owner.count) + 1))
+        od, ol = np.empty(cap, np.float32), np.empty(cap, np.uint64)
+        ex = C.c_int(0)
+        n = lib().rxhost_hnsw_stream_continue(self.owner.h, self.s, batch, od.ctypes.data, ol.ctypes.data, C.byref(ex))
+        if n < 0:
+            _raise()
+        return od[:n].copy(), ol[:n].copy(), bool(ex.value)
+
+    def close(self):
+        if getattr(self, "s", None):
+            lib().rxhost_hnsw_stream_end(self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GpuHnswMap:
     """rxgpu::host::GpuHnswMap (drop-in for hnswlib::HierarchicalNSW<Synchronization::None>)."""
 
@@ -324,6 +358,10 @@ class GpuHnswMap:
         if n < 0:
             _raise()
         return od[:n].copy(), ol[:n].copy()
+
+    def stream(self, q, ef=0):
+        """BeginStreamingSearch: session with .next(batch) -> (dist, label, exhausted) (worst first) and .close()."""
+        return _HnswStream(self, _f32(q), ef)
 
     def search_range(self, q, radius, ef, cap=1 << 20):
         q = _f32(q)

@@ -159,3 +159,86 @@ def test_map_vs_reference_engine_when_available(rxgpu, ref, oracle):
         assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd))
     r.close()
     m.close()
+
+
+# ---------------------------------------------------------------------------------------------- streaming (batched) KNN, §8 a15
+def _run_sessions(m, oracle, g, metric, inv, plans, d, expect_global=None):
+    from oracle.pyoracle import OracleHnswStream
+    for qi, (ef, batches) in enumerate(plans):
+        q = make_corpus(900 + qi, 1, d)[0]
+        if metric == 2:
+            q, _ = oracle.normalize_copy(q)
+        gs, os_ = m.stream(q, ef), OracleHnswStream(oracle, g, q, ef, inv)
+        for b in batches:
+            gd, gl, gex = gs.next(b)
+            wd, wl, wex = os_.next(b)
+            assert gex == wex and len(gd) == len(wd), (metric, qi, b, len(gd), len(wd))
+            a, c = as_sorted_pairs(gd, gl), as_sorted_pairs(wd, wl)
+            assert np.array_equal(a[1], c[1]) and np.array_equal(bits(a[0]), bits(c[0])), (metric, qi, b)
+        gs.close()
+        os_.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_streaming_sessions_equal_restated_engine(rxgpu, oracle, metric):
+    """Whole sessions (Begin + Continue ... until exhausted) on the GPU vs the restatement that is pinned batch-for-batch against the real
+    engine: every batch holds exactly the same (dist, label) pairs and `exhausted` flips at the same call — with and without deletes."""
+    from reindexer_amd import hostapi
+    n, d = 3000, 48
+    rows = make_corpus(61, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    m = hostapi.GpuHnswMap(metric, d, n, M=8, ef_construction=100)
+    m.add(rows, labels)
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    plans = [(0, [10] * 6), (16, [5, 40, 1, 300, 7]), (64, [64] * 12), (3, [1] * 20 + [5000]), (100, [1000, 1000, 1000, 1000])]
+    for phase in range(2):
+        if phase:
+            for lab in labels[np.random.default_rng(8).choice(n, 200, replace=False)]:
+                m.mark_delete(lab)
+        g = m.export_graph()
+        g["vectors"] = rows
+        _run_sessions(m, oracle, g, metric, inv, plans, d)
+    m.close()
+
+
+def test_streaming_global_heap_variant_and_lds_handover(rxgpu, oracle, monkeypatch):
+    """The same sessions with every call forced onto the HBM-resident heaps, and a deep session whose candidate set outgrows LDS in the
+    middle of a call (kStreamNeedGlobal -> resumed by the global variant)."""
+    from reindexer_amd import hostapi
+    n, d, metric = 6000, 32, 0
+    rows = make_corpus(62, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32))
+    m = hostapi.GpuHnswMap(metric, d, n, M=16, ef_construction=100)
+    m.add(rows, labels)
+    g = m.export_graph()
+    g["vectors"] = rows
+    deep = [(64, [64] * 60), (200, [1000] * 7)]      # > 3072 evaluated nodes: the LDS candidate heap overflows on the way
+    _run_sessions(m, oracle, g, metric, None, deep, d)
+    monkeypatch.setenv("RXGPU_HNSW_STREAM_GLOBAL", "1")
+    _run_sessions(m, oracle, g, metric, None, [(0, [10] * 4), (16, [5, 40, 1, 300])], d)
+    m.close()
+
+
+def test_streaming_edge_cases(rxgpu, oracle):
+    from reindexer_amd import hostapi
+    d = 16
+    m = hostapi.GpuHnswMap(0, d, 100, M=8, ef_construction=50)
+    s = m.stream(np.zeros(d, np.float32))
+    dist, lab, ex = s.next(10)                       # empty graph: exhausted at once (hnswalg.h:1880-1882)
+    assert len(dist) == 0 and ex
+    s.close()
+    rows = make_corpus(3, 5, d)
+    m.add(rows, np.arange(5, dtype=np.uint64) << np.uint64(32))
+    s = m.stream(rows[2], ef=2)
+    dist, lab, ex = s.next(0)                        # batchSize 0: empty batch, not exhausted (hnswalg.h:1956-1958)
+    assert len(dist) == 0 and not ex
+    got = []
+    for _ in range(6):
+        dist, lab, ex = s.next(2)
+        got += list(lab >> np.uint64(32))
+        if ex:
+            break
+    assert sorted(got) == [0, 1, 2, 3, 4] and ex     # every element exactly once, nearest (itself) in the first batch
+    assert 2 in got[:2]
+    s.close()
+    m.close()
