@@ -263,6 +263,35 @@ long rxhost_hnsw_select(void* h, const float* key, size_t dim, long k, size_t ef
 
 }  // extern "C"
 
+extern "C" {
+// index-level streaming (HnswIndexBase<Map>::beginStreaming / continueStreaming): raw key in, (row id, user-visible rank) best first out
+void* rxhost_hnsw_knn_stream_begin(void* h, const float* key, size_t dim, size_t ef) {
+	using S = decltype(KnnBeginStreaming(*static_cast<const GpuHnswMap*>(h), ConstFloatVectorView(key, dim), ef));
+	S* s = nullptr;
+	guarded([&] { s = new S(KnnBeginStreaming(*static_cast<const GpuHnswMap*>(h), ConstFloatVectorView(key, dim), ef)); });
+	return s;
+}
+long rxhost_hnsw_knn_stream_continue(void* h, void* session, size_t batch, int32_t* outIds, float* outRanks, int* exhausted) {
+	using S = decltype(KnnBeginStreaming(*static_cast<const GpuHnswMap*>(h), ConstFloatVectorView(nullptr, 0), 0));
+	long n = -1;
+	guarded([&] {
+		KnnStreamingBatch b;
+		KnnContinueStreaming(*static_cast<const GpuHnswMap*>(h), *static_cast<S*>(session), batch, b);
+		*exhausted = b.exhausted ? 1 : 0;
+		n = long(b.ids.size());
+		for (size_t i = 0; i < b.ids.size(); ++i) {
+			outIds[i] = b.ids[i];
+			outRanks[i] = b.ranks[i];
+		}
+	});
+	return n;
+}
+void rxhost_hnsw_knn_stream_end(void* h, void* session) {
+	using S = decltype(KnnBeginStreaming(*static_cast<const GpuHnswMap*>(h), ConstFloatVectorView(nullptr, 0), 0));
+	delete static_cast<S*>(session);
+}
+}  // extern "C"
+
 // ---------------------------------------------------------------------------------------------- GpuFtMerger
 #include "gpu_ft_merger.h"
 

@@ -121,4 +121,46 @@ KnnSelectResult KnnSelectRaw(const Map& map, ConstFloatVectorView key, const Knn
 	return KnnSelect(map, key, params, /*needSort*/ false, isArray, indexDefaultRadius);
 }
 
+// hnsw_index.cc:290-351: beginStreaming / continueStreaming (HNSW maps only; the brute-force specialisations throw errQueryExec,
+// hnsw_index.cc:353-361).  The session keeps the normalised cosine query alive like HnswStreamingSessionImpl::queryStorage.
+template <typename Session>
+struct KnnStreamingSession {
+	std::vector<float> queryStorage;
+	Session session;
+};
+struct KnnStreamingBatch {   // core/index/float_vector/knn_streaming.h: best first
+	std::vector<int32_t> ids;
+	std::vector<float> ranks;
+	bool exhausted = false;
+};
+template <typename Map>
+auto KnnBeginStreaming(const Map& map, ConstFloatVectorView key, size_t ef) {
+	using Session = decltype(map.BeginStreamingSearch(nullptr, std::nullopt, {}));
+	KnnStreamingSession<Session> s;
+	const float* keyData = key.Data();
+	std::optional<float> normL2;
+	if (map.Metric() == VectorMetric::Cosine) {
+		s.queryStorage.resize(key.Dimension());
+		normL2 = 1.f / NormalizeCopyVector(key.Data(), int32_t(key.Dimension()), s.queryStorage.data());
+		keyData = s.queryStorage.data();
+	}
+	s.session = map.BeginStreamingSearch(keyData, normL2, {ef});
+	return s;
+}
+template <typename Map, typename Session>
+void KnnContinueStreaming(const Map& map, KnnStreamingSession<Session>& session, size_t batchSize, KnnStreamingBatch& out) {
+	auto hnswBatch = map.ContinueStreamingSearch(session.session, batchSize);
+	auto& results = hnswBatch.results;
+	out.exhausted = hnswBatch.exhausted;
+	const size_t n = results.size();
+	out.ids.resize(n);
+	out.ranks.resize(n);
+	for (size_t i = n; !results.empty(); results.pop()) {
+		--i;
+		// IP and cosine are sorted in reverse order inside the engine and carry the opposite sign (hnsw_index.cc:336-345)
+		out.ranks[i] = map.Metric() == VectorMetric::L2 ? results.top().first : -results.top().first;
+		out.ids[i] = FloatVectorId::FromNumber(results.top().second).RowId();
+	}
+}
+
 }  // namespace rxgpu::host

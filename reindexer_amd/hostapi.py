@@ -265,6 +265,40 @@ class _HnswStream:
             pass
 
 
+class _KnnStream:
+    def __init__(self, owner, key, ef):
+        L = lib()
+        L.rxhost_hnsw_knn_stream_begin.restype = _vp
+        L.rxhost_hnsw_knn_stream_begin.argtypes = [_vp, _vp, _sz, _sz]
+        L.rxhost_hnsw_knn_stream_continue.restype = _l
+        L.rxhost_hnsw_knn_stream_continue.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp]
+        L.rxhost_hnsw_knn_stream_end.argtypes = [_vp, _vp]
+        self.owner, self.key = owner, key
+        self.s = L.rxhost_hnsw_knn_stream_begin(owner.h, key.ctypes.data, key.shape[0], ef)
+        if not self.s:
+            _raise()
+
+    def next(self, batch):
+        cap = max(1, min(batch, int(self.owner.count) + 1))
+        ids, ranks = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        ex = C.c_int(0)
+        n = lib().rxhost_hnsw_knn_stream_continue(self.owner.h, self.s, batch, ids.ctypes.data, ranks.ctypes.data, C.byref(ex))
+        if n < 0:
+            _raise()
+        return ids[:n].copy(), ranks[:n].copy(), bool(ex.value)
+
+    def close(self):
+        if getattr(self, "s", None):
+            lib().rxhost_hnsw_knn_stream_end(self.owner.h, self.s)
+            self.s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class GpuHnswMap:
     """rxgpu::host::GpuHnswMap (drop-in for hnswlib::HierarchicalNSW<Synchronization::None>)."""
 
@@ -362,6 +396,11 @@ class GpuHnswMap:
     def stream(self, q, ef=0):
         """BeginStreamingSearch: session with .next(batch) -> (dist, label, exhausted) (worst first) and .close()."""
         return _HnswStream(self, _f32(q), ef)
+
+    def knn_stream(self, key, ef=0):
+        """Index-level streaming (HnswIndexBase<Map>::beginStreaming / continueStreaming): raw key in; .next(batch) -> (row ids,
+        user-visible ranks, exhausted), best first."""
+        return _KnnStream(self, _f32(key), ef)
 
     def search_range(self, q, radius, ef, cap=1 << 20):
         q = _f32(q)

@@ -69,7 +69,8 @@ def merge_shard_topk(gathered: torch.Tensor, kk: int, shard_rows: int | None = N
 
 
 class ShardedBruteforce:
-    """Row-sharded brute-force KNN: local scan on this rank's GPU + one all-gather + merge.
+    """Row-sharded KNN: local search on this rank's GPU (brute-force scan, or an HNSW graph over the shard's rows) + one all-gather +
+    merge.
 
     local_search(queries[nq,dim] tensor, kk) -> (dist[nq,kk] f32 tensor, row[nq,kk] int tensor) is injected so the
     exchange/merge logic runs unchanged on CPU under gloo in the tests; on a GPU box it is the rxgpu index of this rank.
@@ -108,6 +109,25 @@ def rxgpu_local_search(index, device):
         stream = torch.cuda.current_stream(device)
         index.search_knn_device(q.data_ptr(), nq, kk, d.data_ptr(), r.data_ptr(), None, stream.cuda_stream)
         return d, r
+    return run
+
+
+def rxgpu_hnsw_local_search(index, device=None):
+    """Adapter: an rxgpu VectorIndex shard with an attached HNSW graph (per-shard independent graphs + the same all-gather
+    merge).  Rows are the shard's internal ids; queries must already be normalised for cosine.  ef is fixed per adapter call."""
+    import numpy as np
+
+    def run(queries: torch.Tensor, kk: int, ef: int = 0):
+        q = queries.detach().to("cpu", torch.float32).contiguous().numpy()
+        dist, row, cnt = index.hnsw_search_knn(q, kk, ef)
+        d = np.full((q.shape[0], kk), np.inf, np.float32)
+        r = np.full((q.shape[0], kk), 0xFFFFFFFF, np.int64)
+        for i in range(q.shape[0]):
+            c = int(cnt[i])
+            order = np.lexsort((row[i, :c], dist[i, :c]))          # the engine hands back a heap; the wire format is best first
+            d[i, :c], r[i, :c] = dist[i, :c][order], row[i, :c][order]
+        dt, rt = torch.from_numpy(d), torch.from_numpy(r)
+        return (dt.to(device), rt.to(device)) if device is not None else (dt, rt)
     return run
 
 

@@ -242,3 +242,35 @@ def test_streaming_edge_cases(rxgpu, oracle):
     assert 2 in got[:2]
     s.close()
     m.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_index_level_streaming_best_first_with_user_ranks(rxgpu, oracle, metric):
+    """HnswIndexBase<Map>::continueStreaming (hnsw_index.cc:325-351): batches best first, IP/cosine ranks sign-flipped, row ids from the
+    label's high word; raw (unnormalised) key in, the adapter normalises for cosine."""
+    from oracle.pyoracle import OracleHnswStream
+    from reindexer_amd import hostapi
+    n, d = 2000, 40
+    rows = make_corpus(71, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(5)
+    m = hostapi.GpuHnswMap(metric, d, n, M=8, ef_construction=100)
+    m.add(rows, labels)
+    g = m.export_graph()
+    g["vectors"] = rows
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    key = make_corpus(72, 1, d)[0] * 3.0
+    qn = oracle.normalize_copy(key)[0] if metric == 2 else key
+    ks, os_ = m.knn_stream(key, 32), OracleHnswStream(oracle, g, qn, 32, inv)
+    seen = []
+    for b in (8, 8, 50, 3):
+        ids, ranks, ex = ks.next(b)
+        wd, wl, wex = os_.next(b)
+        o = np.lexsort((wl, wd))                      # the result queue pops worst first under (dist, label) => best first reversed
+        assert ex == wex
+        assert np.array_equal(ids, (wl[o] >> np.uint64(32)).astype(np.int32))
+        assert np.array_equal(bits(ranks), bits(wd[o] if metric == 0 else -wd[o]))
+        seen += ids.tolist()
+    assert len(set(seen)) == len(seen)
+    ks.close()
+    os_.close()
+    m.close()
