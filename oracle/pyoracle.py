@@ -646,6 +646,25 @@ class RefFt:
         pa = ((fp >> np.uint64(28)) & np.uint64((1 << 28) - 1)).astype(np.uint32)
         self.L.ref_ft_set_word(self.h, word_id, doc.shape[0], doc.ctypes.data, po.ctypes.data, pf.ctypes.data, pp.ctypes.data, pa.ctypes.data)
 
+    def pack(self, s):
+        """Positions-format sub-term dict -> (PackedIdRelVec bytes, arrayFoundPos) by the reference's own packer."""
+        L = self.L
+        L.ref_ft_pack.restype = _sz
+        L.ref_ft_pack.argtypes = [_sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+        fp = np.asarray(s["fpos"], np.uint64)
+        doc = np.ascontiguousarray(s["doc"], np.uint32)
+        po = np.ascontiguousarray(s["pos_off"], np.uint32)
+        pf = (fp >> np.uint64(56)).astype(np.uint32)
+        pp = (fp & np.uint64((1 << 28) - 1)).astype(np.uint32)
+        pa = ((fp >> np.uint64(28)) & np.uint64((1 << 28) - 1)).astype(np.uint32)
+        cap = 16 * (doc.shape[0] + fp.shape[0]) + 64
+        out = np.zeros(cap, np.uint8)
+        afp = C.c_uint64(0)
+        n = L.ref_ft_pack(doc.shape[0], doc.ctypes.data, po.ctypes.data, pf.ctypes.data, pp.ctypes.data, pa.ctypes.data, out.ctypes.data, cap,
+                          C.byref(afp))
+        assert n <= cap
+        return out[:n].copy(), int(afp.value)
+
     def set_word_flat(self, word_id, s):
         """Flat sub-term dict (doc, ent_off, ent_field, ent_tf, ent_first_pos) -> positions first_pos, first_pos+1, ... per field."""
         pos_off, pf, pp = [0], [], []

@@ -12,6 +12,9 @@
 #include <vector>
 
 #include "tools/float_comparison.h"
+#define private public   /* test infrastructure only: PackedIdRelVec::data_ / arrayFoundPos_ have no accessors */
+#include "core/ft/idrelset.h"
+#undef private
 #include "core/ft/config/ftconfig.h"
 #include "core/ft/ft_fast/mergerimpl.h"
 
@@ -145,6 +148,24 @@ long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, c
 	} catch (const std::exception&) {
 		return -1;
 	}
+}
+
+// The REAL packer: PackedIdRelVec::insert_back (idrelset.h:229-261) over IdRelType::pack / packWithoutArrayIdxs (idrelset.cc:8-68,
+// 141-189).  Returns the byte count (bytes copied when they fit cap) and the position where array data starts.
+size_t ref_ft_pack(size_t n, const uint32_t* doc, const uint32_t* posOff, const uint32_t* posField, const uint32_t* posPos,
+				   const uint32_t* posArrayIdx, uint8_t* out, size_t cap, uint64_t* arrayFoundPos) {
+	std::vector<IdRelType> v;
+	v.reserve(n);
+	for (size_t i = 0; i < n; ++i) {
+		IdRelType rel(doc[i]);
+		for (uint32_t j = posOff[i]; j < posOff[i + 1]; ++j) rel.Add(posPos[j], posField[j], posArrayIdx ? posArrayIdx[j] : 0);
+		v.emplace_back(std::move(rel));
+	}
+	PackedIdRelVec packed;
+	packed.insert_back(v.begin(), v.end());
+	if (packed.data_.size() <= cap) std::copy(packed.data_.begin(), packed.data_.end(), out);
+	*arrayFoundPos = uint64_t(packed.arrayFoundPos_);
+	return packed.data_.size();
 }
 
 }  // extern "C"

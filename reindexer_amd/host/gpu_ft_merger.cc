@@ -25,6 +25,68 @@ void FlatPostings::Add(uint32_t vdoc, const std::pair<uint32_t, uint32_t>* field
 	entOff.push_back(uint32_t(entField.size()));
 }
 
+namespace {
+// tools/varint.h:122-176: base-128 varint, at most 5 bytes for a uint32 (the 5th byte carries bits 28..31 unmasked)
+uint32_t readVarint(const uint8_t*& p, const uint8_t* end) {
+	uint32_t v = 0;
+	for (unsigned i = 0; i < 5; ++i) {
+		if (p == end) throw std::invalid_argument("PackedIdRelVec: truncated varint");
+		const uint8_t b = *p++;
+		if (i == 4) return v | (uint32_t(b) << 28);
+		v |= uint32_t(b & 0x7f) << (7 * i);
+		if (!(b & 0x80)) return v;
+	}
+	return v;
+}
+}  // namespace
+
+void PositionPostings::AppendPacked(const uint8_t* data, size_t len, size_t arrayFoundPos) {
+	const uint8_t* p = data;
+	const uint8_t* const end = data + len;
+	uint32_t lastId = 0, lastField = 0;   // PackedIdRelVec::state (idrelset.h:166-170)
+	while (p != end) {
+		const bool withArrays = size_t(p - data) >= arrayFoundPos;
+		uint32_t id = readVarint(p, end);
+		uint32_t head = readVarint(p, end);
+		const bool idModified = head & 1, fieldIsSame = head & 2, sizeIs1 = head & 4;
+		const bool arrayIdxIsZero = withArrays ? bool(head & 8) : true;
+		uint32_t pos = head >> (withArrays ? 4 : 3);
+		if (idModified) id += lastId;
+		uint32_t field = fieldIsSame ? lastField : readVarint(p, end);
+		uint32_t arrayIdx = arrayIdxIsZero ? 0 : readVarint(p, end) + 1;
+		const uint32_t size = sizeIs1 ? 1 : readVarint(p, end) + 1;
+		doc.push_back(id);
+		fpos.push_back(Pos(pos, field, arrayIdx));
+		const uint32_t firstField = field;
+		for (uint32_t i = 1; i < size; ++i) {
+			uint32_t next = readVarint(p, end);
+			const bool sameField = next & 1;
+			if (withArrays) {
+				const bool sameArrayIdx = next & 2;
+				next >>= 2;
+				if (sameField && sameArrayIdx) next += pos;
+				if (!sameField) field += readVarint(p, end);
+				if (!sameArrayIdx) {
+					const uint32_t a = readVarint(p, end);
+					arrayIdx = a + (sameField ? arrayIdx : 0);
+				}
+			} else {
+				next >>= 1;
+				if (sameField) {
+					next += pos;
+				} else {
+					field += readVarint(p, end);
+				}
+			}
+			pos = next;
+			fpos.push_back(Pos(pos, field, arrayIdx));
+		}
+		posOff.push_back(uint32_t(fpos.size()));
+		lastId = id;
+		lastField = firstField;
+	}
+}
+
 GpuFtMerger::GpuFtMerger(size_t numFields, int device) : numFields_(numFields) {
 	if (rxgpu_ft_create(uint32_t(numFields), device, &dev_) != RXGPU_OK) throwDevice("GpuFtMerger: device index creation failed");
 }

@@ -84,6 +84,10 @@ struct PositionPostings {
 		fpos.insert(fpos.end(), positions, positions + count);
 		posOff.push_back(uint32_t(fpos.size()));
 	}
+	// Decode a PackedIdRelVec byte stream (cpp_src/core/ft/idrelset.h:155-280: base-128 varints, ids and fields delta-coded against the
+	// previous element; elements stored before byte `arrayFoundPos` use the format without array indexes — idrelset.cc:8-235) and
+	// append its postings.  Throws std::invalid_argument on a truncated / malformed stream.
+	void AppendPacked(const uint8_t* data, size_t len, size_t arrayFoundPos);
 };
 enum class OpType { Or = 1, And = 2, Not = 3 };   // core/type_consts.h
 // TermResults (querymergedata.h:46-98): a query term, its FtDslOpts and the dictionary words it matched

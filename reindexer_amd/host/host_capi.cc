@@ -426,6 +426,30 @@ extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, co
 	return n;
 }
 
+// PackedIdRelVec byte stream -> positions-format postings (host decode, no device needed).  Returns the posting count, -1 on error;
+// with null outputs only counts (*nPositions = total positions).
+extern "C" long rxhost_ft_unpack(const uint8_t* data, size_t len, size_t arrayFoundPos, uint32_t* outDoc, uint32_t* outPosOff, uint64_t* outFpos,
+								 size_t* nPositions) {
+	long n = -1;
+	guarded([&] {
+		PositionPostings pp;
+		pp.AppendPacked(data, len, arrayFoundPos);
+		if (nPositions) *nPositions = pp.fpos.size();
+		if (outDoc) std::copy(pp.doc.begin(), pp.doc.end(), outDoc);
+		if (outPosOff) std::copy(pp.posOff.begin(), pp.posOff.end(), outPosOff);
+		if (outFpos) std::copy(pp.fpos.begin(), pp.fpos.end(), outFpos);
+		n = long(pp.doc.size());
+	});
+	return n;
+}
+extern "C" int rxhost_ft_set_word_packed(void* h, uint32_t wordId, const uint8_t* data, size_t len, size_t arrayFoundPos) {
+	return guarded([&] {
+		PositionPostings pp;
+		pp.AppendPacked(data, len, arrayFoundPos);
+		static_cast<GpuFtMerger*>(h)->SetWord(wordId, pp);
+	});
+}
+
 // ---------------------------------------------------------------------------------------------- hybrid rank fusion
 #include "hybrid_rerank.h"
 

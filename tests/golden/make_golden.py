@@ -102,7 +102,47 @@ def main():
                 hz[f"p{phase}_q{qi}_k{k}_ef{ef}_label"] = ll
     h.close()
     np.savez_compressed(OUT / "hnsw.npz", **hz)
+    make_ft_goldens()
     print("wrote", [p.name for p in OUT.glob("*.npz")])
+
+
+def make_ft_goldens():
+    """ft_fast fixtures from the REAL reference code (oracle/_ref/libref_ft.so): PackedIdRelVec byte streams produced by the reference's
+    own packer, and results of the real ft::Merger on small multi-term queries."""
+    import sys
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_bm25_oracle import MULTI_CASES, _multi_case, make_pos_postings
+    from oracle.pyoracle import RefFt
+    z = {}
+    real = RefFt(3)
+    rng = np.random.default_rng(99)
+    for name, arr in (("plain", False), ("arrays", True)):
+        s = make_pos_postings(rng, 2000, 3, 300, 100.0, array_fields=False, max_pos=3000)
+        if arr:   # array data starts in the middle of the stream: the first 300 postings carry none (packWithoutArrayIdxs)
+            t = make_pos_postings(rng, 2000, 3, 400, 100.0, array_fields=True, max_pos=3000)
+            s = dict(doc=np.concatenate([s["doc"], t["doc"] + np.uint32(2000)]),
+                     pos_off=np.concatenate([s["pos_off"], t["pos_off"][1:] + s["pos_off"][-1]]).astype(np.uint32),
+                     fpos=np.concatenate([s["fpos"], t["fpos"]]), proc=100.0)
+        data, afp = real.pack(s)
+        z[f"packed_{name}_bytes"], z[f"packed_{name}_afp"] = data, np.uint64(afp)
+        for k in ("doc", "pos_off", "fpos"):
+            z[f"packed_{name}_{k}"] = s[k]
+    real.close()
+    for case in MULTI_CASES[:6]:
+        seed, nf, total, limit, ops, arr, fbs = case
+        _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, fbs)
+        real = RefFt(nf)
+        real.set_docs(words, avg, removed)
+        for s in store:
+            real.set_word_fpos(s["word"], s)
+        from oracle.pyoracle import FtOracle
+        cfg = FtOracle.default_config(nf, merge_limit=limit)
+        real.set_config(cfg)
+        rterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+        wd, wp, wf, wn = real.merge(rterms, excluded, rank_sort_type=1)
+        z[f"merge{seed}_doc"], z[f"merge{seed}_proc"], z[f"merge{seed}_field"], z[f"merge{seed}_norm"] = wd, wp, wf, wn
+        real.close()
+    np.savez_compressed(OUT / "ft.npz", **z)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,8 @@ Corpus of that test (5 docs + the empty sentinel vdoc, one FT field, default FTC
   4 "слово начало простая фраза конец что то еще простая фраза слово слово."   12 words
   5 "жил пил гулял"                                              3 words          => average 6.4 words
 """
+from pathlib import Path
+
 import numpy as np
 import pytest
 
@@ -272,3 +274,64 @@ def test_positions_distance_restatement(ft):
     assert ft.positions_distance(a, make_fpos([10], [0])) == 1
     assert ft.positions_distance(a, make_fpos([4], [1])) == 0          # other field: no distance -> 0 ("zero for first occurence in field")
     assert ft.positions_distance(make_fpos([], []), make_fpos([4], [1])) == 0
+
+
+# ------------------------------------------------------------------------------------------- committed fixtures of the real reference (tests/golden/ft.npz)
+FT_GOLDEN = Path(__file__).resolve().parent / "golden" / "ft.npz"
+
+
+def _unpack(data, afp):
+    import ctypes as C
+    from reindexer_amd import hostapi
+    L = hostapi.lib()
+    L.rxhost_ft_unpack.restype = C.c_long
+    L.rxhost_ft_unpack.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    data = np.ascontiguousarray(data, np.uint8)
+    npos = C.c_size_t(0)
+    n = L.rxhost_ft_unpack(data.ctypes.data, data.shape[0], afp, None, None, None, C.byref(npos))
+    if n < 0:
+        raise ValueError(hostapi.last_error() if hasattr(hostapi, "last_error") else "unpack failed")
+    doc, po, fp = np.zeros(n, np.uint32), np.zeros(n + 1, np.uint32), np.zeros(npos.value, np.uint64)
+    assert L.rxhost_ft_unpack(data.ctypes.data, data.shape[0], afp, doc.ctypes.data, po.ctypes.data, fp.ctypes.data, None) == n
+    return doc, po, fp
+
+
+@pytest.mark.parametrize("name", ["plain", "arrays"])
+def test_packed_posting_decoder_against_reference_packer_golden(name):
+    """Byte streams written by the reference's own PackedIdRelVec::insert_back (fixture made by tests/golden/make_golden.py) decode to
+    exactly the postings that were packed — both element formats (with / without array indexes) in one stream."""
+    z = np.load(FT_GOLDEN)
+    afp = int(z[f"packed_{name}_afp"])
+    assert (afp < len(z[f"packed_{name}_bytes"])) == (name == "arrays")
+    doc, po, fp = _unpack(z[f"packed_{name}_bytes"], afp)
+    assert np.array_equal(doc, z[f"packed_{name}_doc"]) and np.array_equal(po, z[f"packed_{name}_pos_off"])
+    assert np.array_equal(fp, z[f"packed_{name}_fpos"])
+    with pytest.raises(Exception):
+        _unpack(z[f"packed_{name}_bytes"][:-1], afp)       # truncated stream: loud error
+
+
+def test_packed_posting_decoder_against_live_reference_packer():
+    from oracle.pyoracle import ref_ft_or_none
+    real = ref_ft_or_none(4)
+    if real is None:
+        pytest.skip("oracle/_ref/libref_ft.so not available")
+    rng = np.random.default_rng(12)
+    for arr in (False, True):
+        for _ in range(3):
+            s = make_pos_postings(rng, 300000, 4, int(rng.integers(1, 3000)), 1.0, array_fields=arr, max_pos=1 << 20)
+            data, afp = real.pack(s)
+            doc, po, fp = _unpack(data, afp)
+            assert np.array_equal(doc, s["doc"]) and np.array_equal(po, s["pos_off"]) and np.array_equal(fp, s["fpos"])
+    real.close()
+
+
+@pytest.mark.parametrize("case", MULTI_CASES[:6])
+def test_restated_multi_term_merge_equals_reference_golden(ft, case):
+    """The same comparison as above against COMMITTED outputs of the real ft::Merger, so it also runs where oracle/_ref is absent."""
+    seed, nf, total, limit, ops, arr, fbs = case
+    z = np.load(FT_GOLDEN)
+    _, words, avg, removed, excluded, terms, _ = _multi_case(seed, nf, total, limit, ops, arr, fbs)
+    cfg = ft.default_config(nf, merge_limit=limit)
+    gd, gp, gf, gn, _ = ft.merge_query(cfg, terms, total, words, avg, removed, excluded, sort_by_rank=False)
+    assert np.array_equal(gd.astype(np.int32), z[f"merge{seed}_doc"]) and np.array_equal(gn, z[f"merge{seed}_norm"])
+    assert np.array_equal(gf, z[f"merge{seed}_field"]) and np.array_equal(gp.view(np.uint32), z[f"merge{seed}_proc"].view(np.uint32))
