@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256) void knn_row_stats(const float* rows, const fl
 }
 
 // |q|^2 and the per-query margin 2*eps_q (see file header); one 64-lane wave per query
-template <int kMetric>
+// kBf16: the nomination runs on bf16-rounded operands (knn_batched_bf16.hip): + (2^-8 + 2^-18)|q||x| for the two roundings
+template <int kMetric, bool kBf16>
 __global__ __launch_bounds__(64) void knn_query_stats(const float* queries, uint32_t nq, uint32_t q_stride, uint32_t dim,
 													   const unsigned int* stats, float* q_sq, float* margin) {
 	const uint32_t qi = blockIdx.x;
@@ -246,7 +247,8 @@ __global__ __launch_bounds__(64) void knn_query_stats(const float* queries, uint
 	if (lane == 0) {
 		q_sq[qi] = s;
 		const float u = 5.9604645e-08f;   // 2^-24
-		const float gamma = 1.1f * float(dim + 64) * u;   // covers both summation trees (D-chain vs 64-chain + fold), 10% slack
+		float gamma = 1.1f * float(dim + 64) * u;   // covers both summation trees (D-chain vs 64-chain + fold), 10% slack
+		if constexpr (kBf16) gamma = gamma * 1.004f + 1.01f * 0.00390625f;   // rne_bf16 on q and x: (1+2^-9)^2 - 1 <= 2^-8 (1 + 2^-10)
 		const float xmax2 = __uint_as_float(stats[0]);
 		float eps;
 		if constexpr (kMetric == kL2) {
@@ -256,7 +258,8 @@ __global__ __launch_bounds__(64) void knn_query_stats(const float* queries, uint
 		} else {
 			eps = (gamma + 4.0f * u) * sqrtf(s) * sqrtf(__uint_as_float(stats[1]));
 		}
-		margin[qi] = 2.0f * eps * 1.01f + 1e-37f;
+		// bf16 MFMA may flush subnormal inputs: at most dim * 2^-126 * (|q| + max|x|), far below the 1e-30 floor added here
+		margin[qi] = 2.0f * eps * 1.01f + (kBf16 ? 1e-30f : 1e-37f);
 	}
 }
 
@@ -382,12 +385,22 @@ void launch_row_stats(const float* rows, const float* inv_norms, uint64_t n, uin
 }
 
 void launch_query_stats(int metric, const float* queries, uint32_t nq, uint32_t mt, uint32_t q_stride, uint32_t dim, const unsigned int* stats,
-						float* q_sq, float* margin, hipStream_t s) {
-	switch (metric) {
-		case kL2: hipLaunchKernelGGL((knn_query_stats<kL2>), dim3(mt), dim3(64), 0, s, queries, nq, q_stride, dim, stats, q_sq, margin); break;
-		case kIP: hipLaunchKernelGGL((knn_query_stats<kIP>), dim3(mt), dim3(64), 0, s, queries, nq, q_stride, dim, stats, q_sq, margin); break;
-		default: hipLaunchKernelGGL((knn_query_stats<kCos>), dim3(mt), dim3(64), 0, s, queries, nq, q_stride, dim, stats, q_sq, margin); break;
+						float* q_sq, float* margin, bool bf16, hipStream_t s) {
+#define RX_QS(M, B) hipLaunchKernelGGL((knn_query_stats<M, B>), dim3(mt), dim3(64), 0, s, queries, nq, q_stride, dim, stats, q_sq, margin)
+	if (bf16) {
+		switch (metric) {
+			case kL2: RX_QS(kL2, true); break;
+			case kIP: RX_QS(kIP, true); break;
+			default: RX_QS(kCos, true); break;
+		}
+	} else {
+		switch (metric) {
+			case kL2: RX_QS(kL2, false); break;
+			case kIP: RX_QS(kIP, false); break;
+			default: RX_QS(kCos, false); break;
+		}
 	}
+#undef RX_QS
 }
 
 void launch_sample_threshold(const float* dense, uint64_t ns, uint32_t nq, uint32_t mt, uint32_t kk, const float* margin, float* thr,

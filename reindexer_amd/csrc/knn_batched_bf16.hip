@@ -1,0 +1,242 @@
+// Batched queries x corpus, nomination pass on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32-input MFMA rate).
+//
+// Same contract as knn_batched.hip: the GEMM only NOMINATES rows under a rigorous error bound, the exact kernels
+// (knn_rescore -> knn_merge, bit-identical to the reference's 64-chain f32 arithmetic) decide.  Because the nomination is allowed
+// to be approximate as long as the bound is sound, it can run on a bf16 shadow copy of the corpus:
+//     x~ = rne_bf16(x), q~ = rne_bf16(q):  |q~.x~ - q.x| <= ((1+2^-9)^2 - 1) * sum|q_i x_i| <= (2^-8 + 2^-18) |q||x|
+//     products of bf16 pairs are exact in f32; the f32 accumulation adds gamma_D * sum|q~_i x~_i|      (knn_query_stats<.., true>)
+// so eps_q = (2^-8 * 1.01 + gamma_D) |q| max|x| and every row of the true top-kk passes thr_q = kk-th best sample + 2 eps_q.
+// Cost of the looser bound: ~3x more nominated rows to re-score exactly (a few thousand 3 KB gathers per query); gain: the
+// corpus pass reads 2 bytes per element instead of 4 and runs on the bf16 MFMA pipe, so a 256-query batch over 10M x 768 is bounded
+// by ~2 ms of HBM (15.4 GB shadow) / ~1.6 ms of MFMA (3.93 TFLOP at 2.5 PFLOP/s) instead of 25 ms of f32-input MFMA.
+//
+// Tile: 256 corpus rows x 256 queries per workgroup (512 threads = 8 waves as 4 row-pairs x 2 query halves; each wave owns
+// 2 x 4 blocks of 32x32 -> 128 accumulator VGPRs), K staged 64 bf16 (one 128-byte line per row) per step through LDS, double
+// buffered, one barrier per step.  Both MFMA operands want 8 k-contiguous bf16 per lane = one ds_read_b128 from a row-major LDS
+// image; rows are pitched 144 B so the 16 lanes of a read phase hit 16 distinct 16-byte bank groups.
+#include "knn_kernels.hip.h"
+#include "rxgpu_internal.h"
+
+namespace rxgpu {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBfThreads = 512;
+constexpr int kBfRows = 256;       // corpus rows per tile
+constexpr int kBfQueries = 256;    // queries per tile (batches are padded to 256)
+constexpr int kBfKS = 64;          // bf16 elements of the dimension per stage (128 B per row)
+constexpr int kBfPitch = 72;       // LDS row pitch in bf16 elements (144 B)
+constexpr int kBfStageElems = kBfRows * kBfPitch;
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+	uint32_t u = __float_as_uint(f);
+	u += 0x7FFFu + ((u >> 16) & 1u);
+	return uint16_t(u >> 16);
+}
+
+// rows [n][stride] f32 -> shadow [n][ld] bf16 (ld = dim rounded up to 64, zero padded); also used for the padded query block
+__global__ __launch_bounds__(256) void knn_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld) {
+	const uint32_t chunks = ld / 8;   // 8 elements (16 B out) per thread
+	const uint64_t total = n * chunks;
+	for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
+		const uint64_t row = i / chunks;
+		const uint32_t k = uint32_t(i % chunks) * 8;
+		const float* s = src + row * stride + k;
+		uint32_t w[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const float a = k + 2 * j < dim ? s[2 * j] : 0.f;
+			const float b = k + 2 * j + 1 < dim ? s[2 * j + 1] : 0.f;
+			w[j] = uint32_t(f32_to_bf16_rne(a)) | (uint32_t(f32_to_bf16_rne(b)) << 16);
+		}
+		*reinterpret_cast<uint4*>(dst + row * ld + k) = make_uint4(w[0], w[1], w[2], w[3]);
+	}
+}
+
+template <int kMetric, int kMode>
+__global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];
+	uint16_t* x_s = reinterpret_cast<uint16_t*>(bf_lds);            // [2][256][72]
+	uint16_t* q_s = x_s + 2 * kBfStageElems;                        // [2][256][72]
+	float* thr_s = reinterpret_cast<float*>(q_s + 2 * kBfStageElems);   // [256]
+	float* aux_s = thr_s + kBfQueries;                              // [256] |q|^2 (L2)
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int rp = wave & 3;    // rows [64 rp, +64) of the tile
+	const int qh = wave >> 2;   // queries [128 qh, +128)
+	const uint32_t stages = p.ld / kBfKS;
+	const uint64_t ntiles = (p.n + kBfRows - 1) / kBfRows;
+	for (int i = tid; i < kBfQueries; i += kBfThreads) {
+		thr_s[i] = kMode == kGemmFilter ? p.thr[i] : 0.f;
+		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
+	}
+
+	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+		const uint64_t row0 = tile * kBfRows;
+		f32x16 acc[2][4];
+#pragma unroll
+		for (int a = 0; a < 2; ++a) {
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+			}
+		}
+		uint4 xr[4], qr[4];
+		auto load_stage = [&](uint32_t s) {
+			const uint32_t k0 = s * kBfKS;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int idx = tid + i * kBfThreads;      // 16-byte chunk: row idx>>3, chunk idx&7 -> 8 lanes cover one 128-byte line
+				const uint32_t r = idx >> 3, c = (idx & 7) << 3;
+				const uint64_t row = row0 + r;
+				if (row < p.n) {
+					const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.rows + row * p.ld + k0 + c));   // streamed once
+					xr[i] = make_uint4(v.x, v.y, v.z, v.w);
+				} else {
+					xr[i] = make_uint4(0, 0, 0, 0);
+				}
+				qr[i] = *reinterpret_cast<const uint4*>(p.queries + size_t(r) * p.ld + k0 + c);
+			}
+		};
+		auto store_stage = [&](int buf) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int idx = tid + i * kBfThreads;
+				const uint32_t off = (idx >> 3) * kBfPitch + ((idx & 7) << 3);
+				*reinterpret_cast<uint4*>(x_s + buf * kBfStageElems + off) = xr[i];
+				*reinterpret_cast<uint4*>(q_s + buf * kBfStageElems + off) = qr[i];
+			}
+		};
+
+		__syncthreads();   // the previous tile's last fragment reads are done before buffer 0 is overwritten
+		load_stage(0);
+		store_stage(0);
+		__syncthreads();
+		for (uint32_t s = 0; s < stages; ++s) {
+			const int buf = s & 1;
+			if (s + 1 < stages) load_stage(s + 1);
+			const uint16_t* xb = x_s + buf * kBfStageElems + (64 * rp + (lane & 31)) * kBfPitch + 8 * (lane >> 5);
+			const uint16_t* qb = q_s + buf * kBfStageElems + (128 * qh + (lane & 31)) * kBfPitch + 8 * (lane >> 5);
+#pragma unroll
+			for (int t = 0; t < kBfKS / 16; ++t) {
+				bf16x8 bfrag[2], afrag[4];
+#pragma unroll
+				for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xb + a * 32 * kBfPitch + 16 * t));
+#pragma unroll
+				for (int b = 0; b < 4; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qb + b * 32 * kBfPitch + 16 * t));
+#pragma unroll
+				for (int a = 0; a < 2; ++a) {
+#pragma unroll
+					for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
+				}
+			}
+			if (s + 1 < stages) store_stage(buf ^ 1);
+			__syncthreads();
+		}
+
+		// epilogue: element (query i, row j) of block (a, b): j = lane&31, i = (r&3) + 8(r>>2) + 4(lane>>5)
+#pragma unroll
+		for (int a = 0; a < 2; ++a) {
+			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
+			const bool row_ok = row < p.n;
+			const uint64_t rowc = row_ok ? row : p.n - 1;
+			float row_term = 0.f;
+			if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];
+			if constexpr (kMetric == kCos) row_term = p.inv_norms[rowc];
+			const int qlane = 4 * (lane >> 5) + 128 * qh;
+			if constexpr (kMode == kGemmDense) {
+				float* dp = p.dense + size_t(qlane) * p.n + row;
+				const size_t n1 = p.n, n5 = 5 * p.n;
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+						float d;
+						if constexpr (kMetric == kL2) {
+							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+						} else if constexpr (kMetric == kIP) {
+							d = -acc[a][b][r];
+						} else {
+							d = -acc[a][b][r] * row_term;
+						}
+						if (row_ok) *dp = d;
+						dp += ((r & 3) == 3) ? n5 : n1;
+						asm volatile("" : "+v"(dp));
+					}
+				}
+			} else {
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					uint32_t mask = 0;
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+						float d;
+						if constexpr (kMetric == kL2) {
+							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+						} else if constexpr (kMetric == kIP) {
+							d = -acc[a][b][r];
+						} else {
+							d = -acc[a][b][r] * row_term;
+						}
+						mask |= (d <= thr_s[qo + qlane]) ? (1u << r) : 0u;   // padded queries carry thr = -inf
+					}
+					if (!row_ok) mask = 0;
+					if (__ballot(mask != 0)) {
+						while (mask) {
+							const int r = __builtin_ctz(mask);
+							mask &= mask - 1;
+							const uint32_t qi = 32 * b + (r & 3) + 8 * (r >> 2) + qlane;
+							const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+							if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(row);
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
+size_t gemm_bf16_lds_bytes() { return size_t(4) * kBfStageElems * sizeof(uint16_t) + 2 * kBfQueries * sizeof(float); }
+
+template <int kMetric, int kMode>
+static hipError_t launch_bf16_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
+	const size_t lds = gemm_bf16_lds_bytes();
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm_bf16<kMetric, kMode>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL((knn_gemm_bf16<kMetric, kMode>), dim3(grid), dim3(kBfThreads), lds, s, p);
+	return hipGetLastError();
+}
+
+hipError_t launch_gemm_bf16(int metric, int mode, const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
+	if (mode == kGemmDense) {
+		switch (metric) {
+			case kL2: return launch_bf16_one<kL2, kGemmDense>(p, grid, s);
+			case kIP: return launch_bf16_one<kIP, kGemmDense>(p, grid, s);
+			default: return launch_bf16_one<kCos, kGemmDense>(p, grid, s);
+		}
+	}
+	switch (metric) {
+		case kL2: return launch_bf16_one<kL2, kGemmFilter>(p, grid, s);
+		case kIP: return launch_bf16_one<kIP, kGemmFilter>(p, grid, s);
+		default: return launch_bf16_one<kCos, kGemmFilter>(p, grid, s);
+	}
+}
+
+void launch_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, int cus, hipStream_t s) {
+	if (!n) return;
+	const uint64_t total = n * (ld / 8);
+	const uint32_t blocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, uint64_t(cus) * 16)));
+	hipLaunchKernelGGL(knn_to_bf16, dim3(blocks), dim3(256), 0, s, src, n, stride, dim, dst, ld);
+}
+
+}  // namespace rxgpu

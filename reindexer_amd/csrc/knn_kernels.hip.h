@@ -62,6 +62,22 @@ struct GemmParams {
 	uint32_t cap;
 };
 
+// bf16 nomination GEMM (knn_batched_bf16.hip): shadow rows / queries as bf16, ld = dim rounded up to 64 (zero padded)
+struct GemmBf16Params {
+	const uint16_t* rows;     // [n][ld]
+	const uint16_t* queries;  // [256][ld], rows >= nq are zero
+	const float* inv_norms;
+	const float* row_sq;
+	const float* q_sq;        // [256]
+	uint64_t n;
+	uint32_t ld, nq;
+	float* dense;             // DENSE: [256][n]
+	const float* thr;         // FILTER: [256]
+	uint32_t* cand_row;       // [256][cap]
+	uint32_t* cand_cnt;
+	uint32_t cap;
+};
+
 constexpr int kHnswMaxEf = 1024;        // result-heap capacity in LDS
 constexpr int kHnswCandLds = 2048;      // candidate-heap capacity in LDS
 constexpr int kHnswMaxNeighbors = 128;  // 2*M <= 128

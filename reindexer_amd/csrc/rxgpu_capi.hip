@@ -185,6 +185,7 @@ int enqueue_knn_fused(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_querie
 
 // ---- batched path (nq >= 2): MFMA candidate generation + exact re-score, see knn_batched.hip ----------------------
 constexpr uint32_t kBatchSampleRows = 32768;
+constexpr uint32_t kBatchSampleRowsBf16 = 131072;   // the sample pass is cheap on the bf16 pipe; a tighter threshold pays for the wider margin
 
 static int batch_min_queries() {
 	static const int v = [] {
@@ -215,6 +216,125 @@ int ensure_row_stats(rxgpu_index* h, hipStream_t s) {
 	return RXGPU_OK;
 }
 
+// bf16 shadow of the rows for the nomination GEMM: 2 bytes per element on top of the 4-byte rows (HBM is 288 GB: 10M x 768 costs 15.4 GB);
+// rebuilt lazily after any mutation, like the row statistics.
+int ensure_bf16_shadow(rxgpu_index* h, hipStream_t s) {
+	std::lock_guard<std::mutex> lk(h->mtx);
+	if (h->bf16_valid) return RXGPU_OK;
+	const uint32_t ld = (h->dim + 63u) & ~63u;
+	const uint64_t need = std::max<uint64_t>(h->capacity, h->count);
+	if (h->bf16_capacity < need) {
+		if (h->d_rows_bf16) (void)hipFree(h->d_rows_bf16);
+		h->d_rows_bf16 = nullptr;
+		h->bf16_capacity = 0;
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_rows_bf16), need * ld * sizeof(uint16_t)));
+		h->bf16_capacity = need;
+	}
+	rxgpu::launch_to_bf16(h->d_rows, h->count, h->stride, h->dim, h->d_rows_bf16, ld, h->cus, s);
+	RX_HIP(hipGetLastError());
+	RX_HIP(hipStreamSynchronize(s));
+	h->bf16_valid = true;
+	return RXGPU_OK;
+}
+
+static int batch_bf16_min_queries() {
+	static const int v = [] {
+		const char* e = getenv("RXGPU_BATCH_BF16_MIN");   // 0 disables the bf16 nomination path
+		return e ? atoi(e) : 65;
+	}();
+	return v;
+}
+
+// Batches of more than 64 queries: nomination on the bf16 MFMA pipe over the bf16 shadow (knn_batched_bf16.hip), then the same exact tail.
+int enqueue_knn_batched_bf16(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t q0, uint32_t cq, uint32_t kk,
+							 float* d_out_dist, uint32_t* d_out_row, uint32_t* d_out_count) {
+	if (int rc = ensure_bf16_shadow(h, c->stream); rc) return rc;
+	constexpr uint32_t mt = 256;
+	const uint32_t ld = (h->dim + 63u) & ~63u;
+	const uint32_t q_stride = ld;   // the f32 copy for the exact re-score shares the padded stride
+	const uint64_t ns = std::min<uint64_t>(h->count, kBatchSampleRowsBf16);
+	// nominations per query ~ kk * n / ns, times ~3 for the bf16 margin; 10x headroom, overflow falls back to the exact scan
+	uint64_t cap64 = std::max<uint64_t>(4096, 10 * uint64_t(kk) * ((h->count + ns - 1) / ns));
+	cap64 = std::min<uint64_t>(cap64, std::max<uint64_t>(h->count, 64));
+	const uint32_t cap = uint32_t((cap64 + 63) & ~63ull);
+	if (int rc = c->d_qpad.ensure(size_t(mt) * q_stride * (sizeof(float) + sizeof(uint16_t))); rc) return rc;
+	if (int rc = c->d_qstats.ensure(size_t(3) * mt * sizeof(float)); rc) return rc;
+	if (int rc = c->d_dense.ensure(size_t(mt) * ns * sizeof(float)); rc) return rc;
+	if (int rc = c->d_cand_row.ensure(size_t(mt) * cap * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_cand_dist.ensure(size_t(mt) * cap * sizeof(float)); rc) return rc;
+	if (int rc = c->d_cand_cnt.ensure(size_t(mt) * sizeof(uint32_t)); rc) return rc;
+	float* qpad = static_cast<float*>(c->d_qpad.ptr);
+	uint16_t* qbf = reinterpret_cast<uint16_t*>(qpad + size_t(mt) * q_stride);
+	float* q_sq = static_cast<float*>(c->d_qstats.ptr);
+	float* margin = q_sq + mt;
+	float* thr = q_sq + 2 * mt;
+	uint32_t* cand_cnt = static_cast<uint32_t*>(c->d_cand_cnt.ptr);
+	RX_HIP(hipMemsetAsync(qpad, 0, size_t(mt) * q_stride * sizeof(float), c->stream));
+	RX_HIP(hipMemcpy2DAsync(qpad, q_stride * sizeof(float), d_queries + size_t(q0) * h->dim, h->dim * sizeof(float), h->dim * sizeof(float), cq,
+							hipMemcpyDeviceToDevice, c->stream));
+	RX_HIP(hipMemsetAsync(cand_cnt, 0, size_t(mt) * sizeof(uint32_t), c->stream));
+	rxgpu::launch_to_bf16(qpad, mt, q_stride, q_stride, qbf, ld, h->cus, c->stream);
+	rxgpu::launch_query_stats(h->metric, qpad, cq, mt, q_stride, h->dim, h->d_stats, q_sq, margin, true, c->stream);
+
+	rxgpu::GemmBf16Params g{};
+	g.rows = h->d_rows_bf16;
+	g.queries = qbf;
+	g.inv_norms = h->d_inv_norms;
+	g.row_sq = h->d_row_sq;
+	g.q_sq = q_sq;
+	g.ld = ld;
+	g.nq = cq;
+	auto grid_for = [&](uint64_t rows) { return uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((rows + 255) / 256, uint64_t(h->cus)))); };
+	g.n = ns;
+	g.dense = static_cast<float*>(c->d_dense.ptr);
+	{
+		ProfileScope ps(h, "gemm_sample", c->stream);
+		RX_HIP(rxgpu::launch_gemm_bf16(h->metric, rxgpu::kGemmDense, g, grid_for(ns), c->stream));
+	}
+	rxgpu::launch_sample_threshold(g.dense, ns, cq, mt, kk, margin, thr, c->stream);
+	g.n = h->count;
+	g.dense = nullptr;
+	g.thr = thr;
+	g.cand_row = static_cast<uint32_t*>(c->d_cand_row.ptr);
+	g.cand_cnt = cand_cnt;
+	g.cap = cap;
+	{
+		ProfileScope ps(h, "gemm", c->stream);
+		RX_HIP(rxgpu::launch_gemm_bf16(h->metric, rxgpu::kGemmFilter, g, grid_for(h->count), c->stream));
+	}
+	{
+		ProfileScope ps(h, "rescore", c->stream);
+		rxgpu::launch_rescore(h->metric, h->d_rows, h->d_inv_norms, qpad, q_stride, h->stride, h->dim, cq, cap, cand_cnt, g.cand_row,
+							  static_cast<float*>(c->d_cand_dist.ptr), c->stream);
+	}
+	rxgpu::launch_merge(static_cast<float*>(c->d_cand_dist.ptr), g.cand_row, cap, kk, cq, d_out_dist + size_t(q0) * kk, d_out_row + size_t(q0) * kk,
+						d_out_count ? d_out_count + q0 : nullptr, nullptr, 0, c->stream);
+	{   // overflow fallback, gated on device
+		const uint32_t gridx = rxgpu::scan_grid_x(h->count, h->cus);
+		const size_t part = size_t(cq) * gridx * kk;
+		if (int rc = c->d_part_dist.ensure(part * sizeof(float)); rc) return rc;
+		if (int rc = c->d_part_row.ensure(part * sizeof(uint32_t)); rc) return rc;
+		rxgpu::ScanParams p{};
+		p.rows = h->d_rows;
+		p.inv_norms = h->d_inv_norms;
+		p.queries = d_queries + size_t(q0) * h->dim;
+		p.n = h->count;
+		p.stride = h->stride;
+		p.dim = h->dim;
+		p.kk = kk;
+		p.part_dist = static_cast<float*>(c->d_part_dist.ptr);
+		p.part_row = static_cast<uint32_t*>(c->d_part_row.ptr);
+		p.gate_cnt = cand_cnt;
+		p.gate_cap = cap;
+		ProfileScope ps(h, "fallback_scan", c->stream);
+		rxgpu::launch_scan(h->metric, p, cq, gridx, c->stream);
+		rxgpu::launch_merge(p.part_dist, p.part_row, gridx * kk, kk, cq, d_out_dist + size_t(q0) * kk, d_out_row + size_t(q0) * kk,
+							d_out_count ? d_out_count + q0 : nullptr, cand_cnt, cap, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	return RXGPU_OK;
+}
+
 int enqueue_knn_batched(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
 						uint32_t* d_out_row, uint32_t* d_out_count) {
 	if (int rc = ensure_row_stats(h, c->stream); rc) return rc;
@@ -226,6 +346,10 @@ int enqueue_knn_batched(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_quer
 	const uint32_t cap = uint32_t((cap64 + 63) & ~63ull);
 	for (uint32_t q0 = 0; q0 < nq; q0 += 256) {
 		const uint32_t cq = std::min<uint32_t>(256, nq - q0);
+		if (batch_bf16_min_queries() > 0 && int(cq) >= batch_bf16_min_queries()) {
+			if (int rc = enqueue_knn_batched_bf16(h, c, d_queries, q0, cq, kk, d_out_dist, d_out_row, d_out_count); rc) return rc;
+			continue;
+		}
 		const int mt = cq <= 32 ? 32 : cq <= 64 ? 64 : cq <= 128 ? 128 : 256;
 		if (int rc = c->d_qpad.ensure(size_t(mt) * q_stride * sizeof(float)); rc) return rc;
 		if (int rc = c->d_qstats.ensure(size_t(3) * mt * sizeof(float)); rc) return rc;
@@ -242,7 +366,7 @@ int enqueue_knn_batched(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_quer
 		RX_HIP(hipMemcpy2DAsync(qpad, q_stride * sizeof(float), d_queries + size_t(q0) * h->dim, h->dim * sizeof(float),
 								h->dim * sizeof(float), cq, hipMemcpyDeviceToDevice, c->stream));
 		RX_HIP(hipMemsetAsync(cand_cnt, 0, size_t(mt) * sizeof(uint32_t), c->stream));
-		rxgpu::launch_query_stats(h->metric, qpad, cq, mt, q_stride, h->dim, h->d_stats, q_sq, margin, c->stream);
+		rxgpu::launch_query_stats(h->metric, qpad, cq, mt, q_stride, h->dim, h->d_stats, q_sq, margin, false, c->stream);
 
 		rxgpu::GemmParams g{};
 		g.rows = h->d_rows;
@@ -396,6 +520,7 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 		if (h->d_inv_norms) (void)hipFree(h->d_inv_norms);
 	}
 	if (h->d_row_sq) (void)hipFree(h->d_row_sq);
+	if (h->d_rows_bf16) (void)hipFree(h->d_rows_bf16);
 	if (h->d_stats) (void)hipFree(h->d_stats);
 	if (h->d_links0) (void)hipFree(h->d_links0);
 	if (h->d_upper_off) (void)hipFree(h->d_upper_off);
@@ -456,6 +581,7 @@ int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, cons
 	}
 	h->count = std::max(h->count, first_row + n);
 	h->stats_valid = false;
+	h->bf16_valid = false;
 	return RXGPU_OK;
 }
 
@@ -478,6 +604,7 @@ int rxgpu_index_adopt_device_rows(rxgpu_index* h, const void* d_rows, uint64_t n
 	h->capacity = n;
 	h->count = n;
 	h->stats_valid = false;
+	h->bf16_valid = false;
 	return RXGPU_OK;
 }
 
@@ -490,13 +617,17 @@ int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
 	RX_HIP(hipMemcpy(h->d_rows + to * h->stride, h->d_rows + from * h->stride, h->stride * sizeof(float), hipMemcpyDeviceToDevice));
 	if (h->d_inv_norms) RX_HIP(hipMemcpy(h->d_inv_norms + to, h->d_inv_norms + from, sizeof(float), hipMemcpyDeviceToDevice));
 	h->stats_valid = false;
+	h->bf16_valid = false;
 	return RXGPU_OK;
 }
 
 int rxgpu_index_truncate(rxgpu_index* h, uint64_t count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(count <= h->capacity, RXGPU_ERR_PARAMS, "rxgpu_index_truncate: count exceeds capacity");
-	if (count != h->count) h->stats_valid = false;
+	if (count != h->count) {
+		h->stats_valid = false;
+		h->bf16_valid = false;
+	}
 	h->count = count;
 	return RXGPU_OK;
 }

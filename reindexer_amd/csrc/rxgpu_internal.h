@@ -40,7 +40,11 @@ hipError_t launch_gemm(int metric, int mt, int mode, const GemmParams& p, uint32
 void launch_row_stats(const float* rows, const float* inv_norms, uint64_t n, uint32_t stride, uint32_t dim, float* row_sq,
 					  unsigned int* stats, int cus, hipStream_t s);
 void launch_query_stats(int metric, const float* queries, uint32_t nq, uint32_t mt, uint32_t q_stride, uint32_t dim, const unsigned int* stats,
-						float* q_sq, float* margin, hipStream_t s);
+						float* q_sq, float* margin, bool bf16, hipStream_t s);
+struct GemmBf16Params;
+size_t gemm_bf16_lds_bytes();
+hipError_t launch_gemm_bf16(int metric, int mode, const GemmBf16Params& p, uint32_t grid, hipStream_t s);
+void launch_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, int cus, hipStream_t s);
 void launch_sample_threshold(const float* dense, uint64_t ns, uint32_t nq, uint32_t mt, uint32_t kk, const float* margin, float* thr,
 							 hipStream_t s);
 void launch_rescore(int metric, const float* rows, const float* inv_norms, const float* queries, uint32_t q_stride, uint32_t stride,
@@ -219,6 +223,9 @@ struct rxgpu_index {
 	uint64_t row_sq_capacity = 0;
 	unsigned int* d_stats = nullptr;
 	bool stats_valid = false;
+	uint16_t* d_rows_bf16 = nullptr;   // bf16 shadow of the rows for the nomination GEMM (built lazily with the row statistics)
+	uint64_t bf16_capacity = 0;
+	bool bf16_valid = false;
 
 	// HNSW graph mirror (rxgpu_hnsw_attach_graph)
 	uint32_t* d_links0 = nullptr;

@@ -101,3 +101,53 @@ def test_batched_device_api_matches_host_api(rxgpu, oracle):
         assert np.array_equal(orow.cpu().numpy().view(np.uint32), hr)
         assert np.array_equal(bits(od.cpu().numpy()), bits(hd))
         check_batch(ix, oracle, 2, rows, inv, queries[:6], kk)
+
+
+# ---------------------------------------------------------------------------------------------- bf16 nomination path (batches > 64 queries)
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("d,n", [(100, 30_000), (768, 20_000), (130, 9_000), (64, 300)])
+def test_bf16_nomination_is_exact(rxgpu, oracle, metric, d, n):
+    """Batches of 65..256 queries are nominated by the bf16 matrix-core GEMM over the bf16 shadow of the rows (knn_batched_bf16.hip) under a
+    rigorous rounding bound; the exact kernels re-score.  Rows and distance bits must equal per-query exact search."""
+    rows = make_corpus(d + 7, n, d)
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    allq = make_corpus(2000 + d, 256, d)
+    if metric == 2:
+        allq = np.stack([oracle.normalize_copy(q)[0] for q in allq])
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, rows, inv)
+        for nq, kk in ((65, 11), (128, 3), (200, 11), (256, 33)):
+            check_batch(ix, oracle, metric, rows, inv, allq[:nq], kk)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_bf16_nomination_adversarial_magnitudes(rxgpu, oracle, metric):
+    """Rows spanning 12 orders of magnitude, queries with huge and tiny components, exact ties between near-duplicate rows that differ below
+    bf16 resolution: the bound must stay sound (no true neighbour lost), whatever it costs in nominated rows."""
+    rng = np.random.default_rng(77)
+    n, d = 20_000, 96
+    rows = (rng.normal(0, 1, (n, d)) * np.exp(rng.uniform(-14, 14, (n, 1)))).astype(np.float32)
+    rows[1000:1200] = rows[0] * (1 + rng.uniform(-1e-4, 1e-4, (200, 1))).astype(np.float32)      # near duplicates of row 0
+    rows[2000:2050] = rows[0]                                                                    # exact duplicates
+    queries = (rng.normal(0, 1, (100, d)) * np.exp(rng.uniform(-6, 6, (100, 1)))).astype(np.float32)
+    queries[:10] = rows[0] * np.float32(1.0) + rng.normal(0, 1e-6, (10, d)).astype(np.float32)
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, rows)
+        check_batch(ix, oracle, metric, rows, None, queries, 11)
+
+
+def test_bf16_shadow_follows_mutations(rxgpu, oracle):
+    rng = np.random.default_rng(9)
+    n, d = 5000, 80
+    rows = make_corpus(3, n, d)
+    queries = make_corpus(4, 80, d)
+    with rxgpu.VectorIndex("l2", d, n + 100) as ix:
+        ix.upload_rows(0, rows)
+        check_batch(ix, oracle, 0, rows, None, queries, 5)
+        rows2 = rows.copy()
+        rows2[17] = queries[3]                       # overwrite a row: the shadow must be rebuilt, the new row is now the nearest
+        ix.upload_rows(17, rows2[17:18])
+        check_batch(ix, oracle, 0, rows2, None, queries, 5)
+        extra = make_corpus(5, 60, d)
+        ix.upload_rows(n, extra)
+        check_batch(ix, oracle, 0, np.concatenate([rows2, extra]), None, queries, 5)

@@ -40,9 +40,16 @@ def main():
     ap.add_argument("--clusters", type=int, default=2000,
                     help="synthetic corpus = cluster centre + noise (embedding-like: low intrinsic dimension); 0 = i.i.d. gaussian, "
                          "the reference tests' distribution, on which ANY graph index has poor recall at 768 dims")
+    ap.add_argument("--graph", default=None, help="graph saved by tools/build_hnsw_graph.py (same corpus seed): skip the host build")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     metric = capi.METRICS[args.metric]
+    saved = None
+    if args.graph:
+        saved = np.load(args.graph)
+        meta = saved["meta"]
+        args.rows, args.dim, args.M, args.clusters, args.efc = int(meta[1]), int(meta[2]), int(meta[3]), int(meta[8]), int(meta[9])
+        assert int(meta[0]) == metric
     rng = np.random.default_rng(20260924)
     if args.clusters:
         centres = rng.normal(0, 0.25, (args.clusters, args.dim)).astype(np.float32)
@@ -55,11 +62,19 @@ def main():
     if metric == 2:
         queries = np.stack([hostapi.normalize_copy(q)[0] for q in queries])
 
-    t0 = time.perf_counter()
-    m = hostapi.GpuHnswMap(metric, args.dim, args.rows, M=args.M, ef_construction=args.efc)
-    m.add(rows, labels)
-    build_s = time.perf_counter() - t0
-    g = m.export_graph()
+    m = None
+    if saved is None:
+        t0 = time.perf_counter()
+        m = hostapi.GpuHnswMap(metric, args.dim, args.rows, M=args.M, ef_construction=args.efc)
+        m.add(rows, labels)
+        build_s = time.perf_counter() - t0
+        g = m.export_graph()
+    else:
+        meta = saved["meta"]
+        build_s = float(saved["build_seconds"])
+        g = dict(metric=metric, n=args.rows, dim=args.dim, M=args.M, maxM0=int(meta[4]), maxlevel=int(meta[5]), entry=int(meta[6]),
+                 num_deleted=int(meta[7]), links0=saved["links0"], upper_off=saved["upper_off"], upper=saved["upper"], levels=saved["levels"],
+                 labels=labels, deleted=saved["deleted"])
 
     # GPU search through the C-ABI in one batched call (the Map's SearchKnn is the nq = 1 case of the same entry point)
     inv = np.array([hostapi.l2_module(r) for r in rows], np.float32) if metric == 2 else None
@@ -76,11 +91,26 @@ def main():
     ix.profile_enable(False)
     evals, hops = ix.hnsw_read_stats()
     bytes_algo = evals * args.dim * 4 + hops * (1 + 2 * args.M) * 4
-    # single-query latency through the Map
+    # single-query latency (through the Map when it was built here, else the nq = 1 case of the same C-ABI entry)
     t0 = time.perf_counter()
     for q in queries[:32]:
-        m.search_knn(q, args.k, args.ef)
+        if m is not None:
+            m.search_knn(q, args.k, args.ef)
+        else:
+            ix.hnsw_search_knn(q[None, :], args.k, args.ef)
     lat_ms = (time.perf_counter() - t0) / 32 * 1e3
+    ix.hnsw_read_stats()
+
+    stream = None
+    if m is not None:   # a15: one streaming session, 10 batches of 10 (the planner's post-filter pattern), per-call latency
+        sess = m.stream(queries[0], args.ef)
+        t0 = time.perf_counter()
+        got = 0
+        for _ in range(10):
+            d_, l_, ex_ = sess.next(10)
+            got += len(d_)
+        stream = {"batches": 10, "batch": 10, "ef": args.ef, "returned": got, "ms_per_continue": (time.perf_counter() - t0) / 10 * 1e3}
+        sess.close()
 
     # exact ground truth on the GPU (fused scan / batched path)
     bf = capi.VectorIndex(metric, args.dim, args.rows)
@@ -100,7 +130,28 @@ def main():
                              "frac": bytes_algo / (kernel_ms / 1e3) / 1e9 / 8000.0 if kernel_ms else None,
                              "algorithmic_bytes": bytes_algo, "note": "random 3 KB row gathers; bytes = evals*D*4 + hops*(1+2M)*4"}},
         "recall_at_k_vs_exact": recall,
+        "streaming_session": stream,
     }
+    if saved is not None:   # CPU baseline on the SAME prebuilt graph: the restated engine (pinned equal to the reference's), 1 thread
+        try:
+            from oracle.pyoracle import Oracle, oracle_hnsw_search_knn
+            orc = Oracle()
+            g2 = dict(g)
+            g2["vectors"] = rows
+            nq = min(args.cpu_queries, args.queries)
+            t0 = time.perf_counter()
+            res = [oracle_hnsw_search_knn(orc, g2, queries[i], args.k, args.ef, inv) for i in range(nq)]
+            cpu_s = time.perf_counter() - t0
+            same = sum(int(np.array_equal(np.sort(labels[row[i, :int(cnt[i])]]), np.sort(res[i][1]))) for i in range(nq))
+            out["cpu_baseline"] = {"kind": "port", "value": nq / cpu_s, "unit": "queries/s", "cores": 1, "sample": f"{nq} queries, same graph"}
+            out["equal_to_reference_frac"] = same / nq
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+        text = json.dumps(out)
+        print(text)
+        if args.out:
+            Path(args.out).write_text(text + "\n")
+        return
     try:
         from oracle import pyoracle
         ref = pyoracle.ref_or_none()
