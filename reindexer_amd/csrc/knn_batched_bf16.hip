@@ -14,6 +14,8 @@
 // 2 x 4 blocks of 32x32 -> 128 accumulator VGPRs), K staged 64 bf16 (one 128-byte line per row) per step through LDS, double
 // buffered, one barrier per step.  Both MFMA operands want 8 k-contiguous bf16 per lane = one ds_read_b128 from a row-major LDS
 // image; rows are pitched 144 B so the 16 lanes of a read phase hit 16 distinct 16-byte bank groups.
+#include <cstdlib>
+
 #include "knn_kernels.hip.h"
 #include "rxgpu_internal.h"
 
@@ -26,8 +28,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBfThreads = 512;
 constexpr int kBfRows = 256;       // corpus rows per tile
 constexpr int kBfQueries = 256;    // queries per tile (batches are padded to 256)
-constexpr int kBfKS = 64;          // bf16 elements of the dimension per stage (128 B per row)
-constexpr int kBfPitch = 72;       // LDS row pitch in bf16 elements (144 B)
+constexpr int kBfKS = 32;          // bf16 elements of the dimension per stage (64 B per row)
+constexpr int kBfPitch = 40;       // LDS row pitch in bf16 elements (80 B): 5r mod 16 is a bijection on every ds_read_b128 lane group
 constexpr int kBfStageElems = kBfRows * kBfPitch;
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
@@ -58,8 +60,8 @@ __global__ __launch_bounds__(256) void knn_to_bf16(const float* src, uint64_t n,
 template <int kMetric, int kMode>
 __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];
-	uint16_t* x_s = reinterpret_cast<uint16_t*>(bf_lds);            // [2][256][72]
-	uint16_t* q_s = x_s + 2 * kBfStageElems;                        // [2][256][72]
+	uint16_t* x_s = reinterpret_cast<uint16_t*>(bf_lds);            // [2][256][pitch]
+	uint16_t* q_s = x_s + 2 * kBfStageElems;                        // [2][256][pitch]
 	float* thr_s = reinterpret_cast<float*>(q_s + 2 * kBfStageElems);   // [256]
 	float* aux_s = thr_s + kBfQueries;                              // [256] |q|^2 (L2)
 
@@ -85,58 +87,63 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
 				for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 			}
 		}
-		uint4 xr[4], qr[4];
-		auto load_stage = [&](uint32_t s) {
-			const uint32_t k0 = s * kBfKS;
+		constexpr int kLoads = kBfRows * kBfKS * 2 / 16 / kBfThreads;   // 16-byte chunks per thread per operand per stage
+		constexpr int kChunks = kBfKS / 8;                              // chunks per row
+		// Per-thread staging addresses: chunk idx = tid + i*512 -> row idx / kChunks, 16-byte chunk idx % kChunks.  Rows past the end are
+		// clamped, not zeroed (their scores are discarded by row_ok in the epilogue); every load is unconditional so that the loads of a
+		// stage stay in flight together behind the MFMAs of the previous one.
+		const uint16_t* xsrc[kLoads];
+		const uint16_t* qsrc[kLoads];
+		uint32_t soff[kLoads];
 #pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				const int idx = tid + i * kBfThreads;      // 16-byte chunk: row idx>>3, chunk idx&7 -> 8 lanes cover one 128-byte line
-				const uint32_t r = idx >> 3, c = (idx & 7) << 3;
-				const uint64_t row = row0 + r;
-				if (row < p.n) {
-					const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.rows + row * p.ld + k0 + c));   // streamed once
-					xr[i] = make_uint4(v.x, v.y, v.z, v.w);
-				} else {
-					xr[i] = make_uint4(0, 0, 0, 0);
-				}
-				qr[i] = *reinterpret_cast<const uint4*>(p.queries + size_t(r) * p.ld + k0 + c);
-			}
-		};
-		auto store_stage = [&](int buf) {
+		for (int i = 0; i < kLoads; ++i) {
+			const int idx = tid + i * kBfThreads;
+			const uint32_t r = idx / kChunks, c = (idx % kChunks) << 3;
+			const uint64_t row = row0 + r < p.n ? row0 + r : p.n - 1;
+			xsrc[i] = p.rows + row * p.ld + c;
+			qsrc[i] = p.queries + size_t(r) * p.ld + c;
+			soff[i] = r * kBfPitch + c;
+		}
+		u32x4 xr[kLoads], qr[kLoads];
 #pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				const int idx = tid + i * kBfThreads;
-				const uint32_t off = (idx >> 3) * kBfPitch + ((idx & 7) << 3);
-				*reinterpret_cast<uint4*>(x_s + buf * kBfStageElems + off) = xr[i];
-				*reinterpret_cast<uint4*>(q_s + buf * kBfStageElems + off) = qr[i];
-			}
-		};
-
-		__syncthreads();   // the previous tile's last fragment reads are done before buffer 0 is overwritten
-		load_stage(0);
-		store_stage(0);
-		__syncthreads();
+		for (int i = 0; i < kLoads; ++i) {
+			xr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i]));
+			qr[i] = *reinterpret_cast<const u32x4*>(qsrc[i]);
+		}
 		for (uint32_t s = 0; s < stages; ++s) {
 			const int buf = s & 1;
-			if (s + 1 < stages) load_stage(s + 1);
+			// stage s: registers -> LDS buffer `buf` (last read two barriers ago), then everyone may read it
+#pragma unroll
+			for (int i = 0; i < kLoads; ++i) {
+				*reinterpret_cast<u32x4*>(x_s + buf * kBfStageElems + soff[i]) = xr[i];
+				*reinterpret_cast<u32x4*>(q_s + buf * kBfStageElems + soff[i]) = qr[i];
+			}
+			__syncthreads();
+			// stage s+1 (wrapping to 0 at the end: a harmless reload) travels while stage s is multiplied
+			const uint32_t kn = (s + 1 < stages ? s + 1 : 0) * kBfKS;
+#pragma unroll
+			for (int i = 0; i < kLoads; ++i) {
+				xr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i] + kn));
+				qr[i] = *reinterpret_cast<const u32x4*>(qsrc[i] + kn);
+			}
+			__builtin_amdgcn_sched_barrier(0);   // keep the loads issued HERE: the scheduler otherwise sinks them below the MFMAs, next to their use
 			const uint16_t* xb = x_s + buf * kBfStageElems + (64 * rp + (lane & 31)) * kBfPitch + 8 * (lane >> 5);
 			const uint16_t* qb = q_s + buf * kBfStageElems + (128 * qh + (lane & 31)) * kBfPitch + 8 * (lane >> 5);
 #pragma unroll
 			for (int t = 0; t < kBfKS / 16; ++t) {
 				bf16x8 bfrag[2], afrag[4];
 #pragma unroll
-				for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xb + a * 32 * kBfPitch + 16 * t));
+				for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + a * 32 * kBfPitch + 16 * t));
 #pragma unroll
-				for (int b = 0; b < 4; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qb + b * 32 * kBfPitch + 16 * t));
+				for (int b = 0; b < 4; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + b * 32 * kBfPitch + 16 * t));
 #pragma unroll
 				for (int a = 0; a < 2; ++a) {
 #pragma unroll
 					for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
 				}
 			}
-			if (s + 1 < stages) store_stage(buf ^ 1);
-			__syncthreads();
 		}
+		__syncthreads();   // the last stage's fragment reads are done before the next tile overwrites buffer 0
 
 		// epilogue: element (query i, row j) of block (a, b): j = lane&31, i = (r&3) + 8(r>>2) + 4(lane>>5)
 #pragma unroll
@@ -202,6 +209,213 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// glds variant: both operands travel global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers, no ds_write pass.
+// One stage = 32 bf16 of the dimension: 256 rows x 64 B + 256 queries x 64 B = 32 KB; 4 LDS buffers, 3 stages in flight, so ~3000
+// MFMA cycles (~1.3 us) of HBM latency are covered; the stream of stages runs ACROSS tiles (the next tile's first stages are already
+// landing during this tile's epilogue).  The DMA writes a lane-linear image (wave base + lane x 16 B), so the bank swizzle is applied on
+// the SOURCE side: LDS slot p = 4 r + cs holds chunk c = cs ^ ((r >> 2) & 3) of row r; a ds_read_b128 lane group (16 rows, one chunk) then
+// covers 16 distinct 16-byte slots.  One raw s_barrier per stage with counted vmcnt (a __syncthreads would drain the DMA queue).
+constexpr int kGlBufs = 4;
+constexpr int kGlAhead = 3;
+constexpr int kGlPartElems = kBfRows * 32;   // one operand of one stage: 256 rows x 32 bf16
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int kMetric, int kMode>
+__global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params p) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];   // the ONLY shared object (a second one de-pipelines the DMA waits)
+	uint16_t* stage_s = reinterpret_cast<uint16_t*>(bf_lds);                                  // [4][x: 256 x 32 | q: 256 x 32]
+	float* thr_s = reinterpret_cast<float*>(bf_lds + size_t(kGlBufs) * 2 * kGlPartElems * 2);   // [256]
+	float* aux_s = thr_s + kBfQueries;
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int rp = wave & 3, qh = wave >> 2;
+	const uint32_t stages = p.ld / 32;
+	const uint64_t ntiles = (p.n + kBfRows - 1) / kBfRows;
+	const uint64_t my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+	const uint64_t total = my_tiles * stages;
+	for (int i = tid; i < kBfQueries; i += kBfThreads) {
+		thr_s[i] = kMode == kGemmFilter ? p.thr[i] : 0.f;
+		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
+	}
+	__syncthreads();
+
+	// DMA source addressing of this thread: instruction j covers LDS slots [512 j, 512 j + 512) of an operand part
+	uint32_t src_r[2], src_c[2];
+#pragma unroll
+	for (int j = 0; j < 2; ++j) {
+		const uint32_t slot = j * kBfThreads + tid;
+		src_r[j] = slot >> 2;
+		src_c[j] = ((slot & 3) ^ ((src_r[j] >> 2) & 3)) << 3;   // element offset of the chunk inside the row's 32-element stage
+	}
+	uint64_t iss_tile = blockIdx.x;   // tile / stage of the NEXT stage to issue
+	uint32_t iss_stage = 0;
+	uint64_t iss_g = 0;
+	const uint16_t* xsrc[2] = {nullptr, nullptr};
+	auto issue = [&]() {
+		if (iss_stage == 0) {
+#pragma unroll
+			for (int j = 0; j < 2; ++j) {
+				const uint64_t row = iss_tile * kBfRows + src_r[j];
+				xsrc[j] = p.rows + (row < p.n ? row : p.n - 1) * p.ld + src_c[j];   // clamped: discarded by row_ok in the epilogue
+			}
+		}
+		const uint32_t k0 = iss_stage * 32;
+		uint16_t* buf = stage_s + size_t(iss_g % kGlBufs) * 2 * kGlPartElems;
+#pragma unroll
+		for (int j = 0; j < 2; ++j) {
+			uint16_t* dx = buf + (j * kBfThreads + wave * 64) * 8;                 // wave-uniform base; the DMA adds lane x 16 B
+			__builtin_amdgcn_global_load_lds(xsrc[j] + k0, (lds_void*)(dx), 16, 0, 0);
+			__builtin_amdgcn_global_load_lds(p.queries + size_t(src_r[j]) * p.ld + src_c[j] + k0, (lds_void*)(dx + kGlPartElems), 16, 0, 0);
+		}
+		++iss_g;
+		if (++iss_stage == stages) {
+			iss_stage = 0;
+			iss_tile += gridDim.x;
+		}
+	};
+	for (int a = 0; a < kGlAhead; ++a) {
+		if (iss_g < total) issue();
+	}
+
+	// fragment addressing: row R of the part, chunk c -> slot 4 R + (c ^ ((R >> 2) & 3)); both rows (lane & 31) + 32 a keep (R >> 2) & 3 = (lane >> 2) & 3
+	const uint32_t half = lane >> 5;
+	const uint32_t swz = (lane >> 2) & 3;
+	const uint32_t xrow = 64 * rp + (lane & 31), qrow = 128 * qh + (lane & 31);
+
+	uint64_t tile = blockIdx.x;
+	uint32_t s = 0;
+	f32x16 acc[2][4];
+#pragma unroll
+	for (int a = 0; a < 2; ++a) {
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+		}
+	}
+	for (uint64_t g = 0; g < total; ++g) {
+		// stage g has landed for THIS wave once at most the younger stages' DMAs (4 per stage) are outstanding
+		const uint64_t younger = iss_g - g - 1;
+		if (younger >= 2) {
+			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+		} else if (younger == 1) {
+			asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+		} else {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		__builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading the buffer the next DMA overwrites
+		asm volatile("" ::: "memory");
+		if (iss_g < total) issue();
+		const uint16_t* buf = stage_s + size_t(g % kGlBufs) * 2 * kGlPartElems;
+#pragma unroll
+		for (int t = 0; t < 2; ++t) {
+			const uint32_t cs = ((2 * t + half) ^ swz) << 3;
+			bf16x8 bfrag[2], afrag[4];
+#pragma unroll
+			for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + (xrow + 32 * a) * 32 + cs));
+#pragma unroll
+			for (int b = 0; b < 4; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + kGlPartElems + (qrow + 32 * b) * 32 + cs));
+#pragma unroll
+			for (int a = 0; a < 2; ++a) {
+#pragma unroll
+				for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
+			}
+		}
+		if (++s < stages) continue;
+		s = 0;
+		// ---- tile epilogue (same element mapping as the register-staged kernel)
+		const uint64_t row0 = tile * kBfRows;
+		tile += gridDim.x;
+#pragma unroll
+		for (int a = 0; a < 2; ++a) {
+			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
+			const bool row_ok = row < p.n;
+			const uint64_t rowc = row_ok ? row : p.n - 1;
+			float row_term = 0.f;
+			if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];
+			if constexpr (kMetric == kCos) row_term = p.inv_norms[rowc];
+			const int qlane = 4 * (lane >> 5) + 128 * qh;
+			if constexpr (kMode == kGemmDense) {
+				float* dp = p.dense + size_t(qlane) * p.n + row;
+				const size_t n1 = p.n, n5 = 5 * p.n;
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+						float d;
+						if constexpr (kMetric == kL2) {
+							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+						} else if constexpr (kMetric == kIP) {
+							d = -acc[a][b][r];
+						} else {
+							d = -acc[a][b][r] * row_term;
+						}
+						if (row_ok) *dp = d;
+						dp += ((r & 3) == 3) ? n5 : n1;
+						asm volatile("" : "+v"(dp));
+						acc[a][b][r] = 0.0f;
+					}
+				}
+			} else {
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					uint32_t mask = 0;
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+						float d;
+						if constexpr (kMetric == kL2) {
+							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+						} else if constexpr (kMetric == kIP) {
+							d = -acc[a][b][r];
+						} else {
+							d = -acc[a][b][r] * row_term;
+						}
+						mask |= (d <= thr_s[qo + qlane]) ? (1u << r) : 0u;
+						acc[a][b][r] = 0.0f;
+					}
+					if (!row_ok) mask = 0;
+					if (__ballot(mask != 0)) {
+						while (mask) {
+							const int r = __builtin_ctz(mask);
+							mask &= mask - 1;
+							const uint32_t qi = 32 * b + (r & 3) + 8 * (r >> 2) + qlane;
+							const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+							if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(row);
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
+size_t gemm_bf16_glds_lds_bytes() { return size_t(kGlBufs) * 2 * kGlPartElems * sizeof(uint16_t) + 2 * kBfQueries * sizeof(float); }
+
+template <int kMetric, int kMode>
+static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
+	const size_t lds = gemm_bf16_glds_lds_bytes();
+	static bool attr_set = false;
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm_bf16_glds<kMetric, kMode>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	hipLaunchKernelGGL((knn_gemm_bf16_glds<kMetric, kMode>), dim3(grid), dim3(kBfThreads), lds, s, p);
+	return hipGetLastError();
+}
+
+static bool bf16_use_glds() {
+	static const bool v = [] {
+		const char* e = getenv("RXGPU_BF16_GLDS");
+		return e ? atoi(e) != 0 : true;
+	}();
+	return v;
+}
+
 size_t gemm_bf16_lds_bytes() { return size_t(4) * kBfStageElems * sizeof(uint16_t) + 2 * kBfQueries * sizeof(float); }
 
 template <int kMetric, int kMode>
@@ -218,6 +432,20 @@ static hipError_t launch_bf16_one(const GemmBf16Params& p, uint32_t grid, hipStr
 }
 
 hipError_t launch_gemm_bf16(int metric, int mode, const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
+	if (bf16_use_glds()) {
+		if (mode == kGemmDense) {
+			switch (metric) {
+				case kL2: return launch_bf16_glds_one<kL2, kGemmDense>(p, grid, s);
+				case kIP: return launch_bf16_glds_one<kIP, kGemmDense>(p, grid, s);
+				default: return launch_bf16_glds_one<kCos, kGemmDense>(p, grid, s);
+			}
+		}
+		switch (metric) {
+			case kL2: return launch_bf16_glds_one<kL2, kGemmFilter>(p, grid, s);
+			case kIP: return launch_bf16_glds_one<kIP, kGemmFilter>(p, grid, s);
+			default: return launch_bf16_glds_one<kCos, kGemmFilter>(p, grid, s);
+		}
+	}
 	if (mode == kGemmDense) {
 		switch (metric) {
 			case kL2: return launch_bf16_one<kL2, kGemmDense>(p, grid, s);
