@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kGemmThreads * QS) void knn_gemm(GemmParams p) {
 				const uint32_t k = k0 + ((idx & 7) << 2);
 				float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 				if (r < p.n) {
-					const float* src = p.rows + r * p.stride + k;
+					const float* src = p.rows + r * p.row_step * p.stride + k;
 					if (k + 3 < p.dim) {
 						v = load_row4<true>(reinterpret_cast<const float4*>(src));
 					} else {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kGemmThreads * QS) void knn_gemm(GemmParams p) {
 		// epilogue: element (query i, row j): j = lane&31, i = 32b + (r&3) + 8(r>>2) + 4(lane>>5)
 		const uint64_t row = row0 + 32 * wave + (lane & 31);
 		const bool row_ok = row < p.n;
-		const uint64_t rowc = row_ok ? row : p.n - 1;
+		const uint64_t rowc = (row_ok ? row : p.n - 1) * p.row_step;
 		const int qlane = 4 * (lane >> 5) + qs * QB * 32;
 		float row_term = 0.f;   // per-row factor of the approximate distance
 		if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];

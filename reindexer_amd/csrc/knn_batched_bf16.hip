@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
 		for (int i = 0; i < kLoads; ++i) {
 			const int idx = tid + i * kBfThreads;
 			const uint32_t r = idx / kChunks, c = (idx % kChunks) << 3;
-			const uint64_t row = row0 + r < p.n ? row0 + r : p.n - 1;
+			const uint64_t row = (row0 + r < p.n ? row0 + r : p.n - 1) * p.row_step;
 			xsrc[i] = p.rows + row * p.ld + c;
 			qsrc[i] = p.queries + size_t(r) * p.ld + c;
 			soff[i] = r * kBfPitch + c;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
 		for (int a = 0; a < 2; ++a) {
 			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
 			const bool row_ok = row < p.n;
-			const uint64_t rowc = row_ok ? row : p.n - 1;
+			const uint64_t rowc = (row_ok ? row : p.n - 1) * p.row_step;
 			float row_term = 0.f;
 			if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];
 			if constexpr (kMetric == kCos) row_term = p.inv_norms[rowc];
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 #pragma unroll
 			for (int j = 0; j < 2; ++j) {
 				const uint64_t row = iss_tile * kBfRows + src_r[j];
-				xsrc[j] = p.rows + (row < p.n ? row : p.n - 1) * p.ld + src_c[j];   // clamped: discarded by row_ok in the epilogue
+				xsrc[j] = p.rows + (row < p.n ? row : p.n - 1) * p.row_step * p.ld + src_c[j];   // clamped: discarded by row_ok in the epilogue
 			}
 		}
 		const uint32_t k0 = iss_stage * 32;
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 		for (int a = 0; a < 2; ++a) {
 			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
 			const bool row_ok = row < p.n;
-			const uint64_t rowc = row_ok ? row : p.n - 1;
+			const uint64_t rowc = (row_ok ? row : p.n - 1) * p.row_step;
 			float row_term = 0.f;
 			if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];
 			if constexpr (kMetric == kCos) row_term = p.inv_norms[rowc];

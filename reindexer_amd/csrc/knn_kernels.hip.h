@@ -53,6 +53,7 @@ struct GemmParams {
 	const float* q_sq;        // L2: |q|^2 per query  [MT]
 	uint64_t n;               // rows covered by this launch (sample or whole corpus)
 	uint32_t stride, dim, nq, q_stride;
+	uint32_t row_step;        // DENSE sample pass: tile row r reads corpus row r * row_step (a strided sample is representative whatever the insertion order); FILTER: 1
 	// DENSE
 	float* dense;             // [MT][n]
 	// FILTER
@@ -71,6 +72,7 @@ struct GemmBf16Params {
 	const float* q_sq;        // [256]
 	uint64_t n;
 	uint32_t ld, nq;
+	uint32_t row_step;        // DENSE: tile row r reads corpus row r * row_step; FILTER: 1
 	float* dense;             // DENSE: [256][n]
 	const float* thr;         // FILTER: [256]
 	uint32_t* cand_row;       // [256][cap]

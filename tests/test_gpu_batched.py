@@ -150,4 +150,28 @@ def test_bf16_shadow_follows_mutations(rxgpu, oracle):
         check_batch(ix, oracle, 0, rows2, None, queries, 5)
         extra = make_corpus(5, 60, d)
         ix.upload_rows(n, extra)
-        check_batch(ix, oracle, 0, np.concatenate([rows2, extra]), None, queries, 5)
+        cur = np.concatenate([rows2, extra])
+        check_batch(ix, oracle, 0, cur, None, queries, 5)
+        # swap-with-last deletes (bruteforce.cc:70-86): the shadow row and |x|^2 travel with the moved row, the tail is cut
+        for victim in (17, 0, 4000):
+            last = cur.shape[0] - 1
+            ix.move_row(last, victim)
+            ix.truncate(last)
+            cur[victim] = cur[last]
+            cur = cur[:last]
+            check_batch(ix, oracle, 0, cur, None, queries, 5)
+
+
+def test_batched_thresholds_on_insertion_ordered_corpus(rxgpu, oracle):
+    """Rows inserted cluster by cluster (the far clusters first): a prefix sample would give useless thresholds; the strided sample keeps the
+    nomination lists short.  Either way the result must be exact."""
+    rng = np.random.default_rng(31)
+    d, per, nc = 48, 1500, 24
+    centres = rng.normal(0, 4.0, (nc, d)).astype(np.float32)
+    rows = np.concatenate([centres[c] + rng.normal(0, 0.3, (per, d)).astype(np.float32) for c in range(nc)])
+    queries = (centres[nc - 1] + rng.normal(0, 0.3, (100, d))).astype(np.float32)       # all queries live in the LAST cluster
+    for metric in (0, 1):
+        with rxgpu.VectorIndex(metric, d, rows.shape[0]) as ix:
+            ix.upload_rows(0, rows)
+            check_batch(ix, oracle, metric, rows, None, queries, 11)
+            check_batch(ix, oracle, metric, rows, None, queries[:40], 11)
