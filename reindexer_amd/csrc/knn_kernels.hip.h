@@ -43,6 +43,17 @@ struct ScanParams {
 	uint32_t gate_cap;
 };
 
+// bf16-pruned scan (knn_scan.hip: knn_scan_bf16 + knn_filter_approx): approximate distances from the bf16 shadow, exact tail
+struct ScanBf16Params {
+	ScanParams sp;            // kk, part_dist / part_row ([nq][gridDim.x][kk]); rows / stride / dim / queries unused here
+	const uint16_t* rows16;   // [n][ld] bf16 shadow
+	const float* queries32;   // [nq][ld] f32, zero padded
+	const float* row_sq;      // L2
+	const float* q_sq;        // L2: [nq]
+	uint32_t ld;
+	float* approx;            // [nq][n] approximate distance of every row
+};
+
 enum : int { kGemmDense = 0, kGemmFilter = 1 };
 
 struct GemmParams {

@@ -1,12 +1,16 @@
 // Streaming brute-force scan + fused wavefront top-k, merge, range and re-score kernels (gfx950).
 // See knn_kernels.hip.h for the arithmetic contract.  Reference being replaced:
 // cpp_src/core/index/float_vector/hnswlib/bruteforce.cc:103-143.
+#include <algorithm>
+
 #include "knn_kernels.hip.h"
 #include "rxgpu_internal.h"
 
 #include <cstdlib>
 
 namespace rxgpu {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kScanThreads = 256;                    // 4 wavefronts per workgroup, one per SIMD
 constexpr int kScanWaves = kScanThreads / kWave;
@@ -156,6 +160,125 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan_generic(ScanParams p) {
 		consider_quad(top, dist, uint32_t(row), valid, lane);
 	}
 	block_merge_and_store(top, p, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// bf16-pruned scan (opt-in, RXGPU_SCAN_BF16=1): half the HBM bytes per query, the SAME result bits.
+//   1. knn_scan_bf16      approximate distance d~ of every row from the bf16 shadow (2 bytes per element), stored ([n] floats) and folded
+//                         into the per-wave top-kk exactly like the f32 scan
+//   2. knn_merge          -> d~_(kk), the kk-th best approximate distance
+//   3. knn_filter_approx  rows with d~ <= d~_(kk) + 2 eps  (eps = the rigorous bf16 bound of knn_query_stats<.., true>)
+//   4. knn_rescore + knn_merge   EXACT distances of those few dozen rows, exact top-kk by (dist, row)
+// Soundness: a row r of the true top-kk has d~_r <= d_r + eps <= D_kk + eps, and D_kk <= kk-th smallest of (d~ + eps) = d~_(kk) + eps.
+// One 16-lane group owns a row: lane m loads the 16-byte chunks m, m + 16, ... (8 bf16 each; 256 contiguous bytes per group per load),
+// widens them to f32 (exact) and runs four fmaf chains against the f32 query fragment it keeps in registers.
+template <int NC>
+__device__ __forceinline__ float bf16_group_dot(const u32x4 (&x)[NC], const float (&q)[NC * 8]) {
+	float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+	for (int t = 0; t < NC; ++t) {
+		a0 = __builtin_fmaf(q[8 * t + 0], __uint_as_float(x[t].x << 16), a0);
+		a1 = __builtin_fmaf(q[8 * t + 1], __uint_as_float(x[t].x & 0xFFFF0000u), a1);
+		a2 = __builtin_fmaf(q[8 * t + 2], __uint_as_float(x[t].y << 16), a2);
+		a3 = __builtin_fmaf(q[8 * t + 3], __uint_as_float(x[t].y & 0xFFFF0000u), a3);
+		a0 = __builtin_fmaf(q[8 * t + 4], __uint_as_float(x[t].z << 16), a0);
+		a1 = __builtin_fmaf(q[8 * t + 5], __uint_as_float(x[t].z & 0xFFFF0000u), a1);
+		a2 = __builtin_fmaf(q[8 * t + 6], __uint_as_float(x[t].w << 16), a2);
+		a3 = __builtin_fmaf(q[8 * t + 7], __uint_as_float(x[t].w & 0xFFFF0000u), a3);
+	}
+	float s = (a0 + a2) + (a1 + a3);
+	s += __shfl_xor(s, 8);
+	s += __shfl_xor(s, 4);
+	s += __shfl_xor(s, 2);
+	s += __shfl_xor(s, 1);
+	return s;
+}
+
+// NC = ld / 128: chunks per lane per row (768 -> 6)
+template <int kMetric, int NC>
+__global__ __launch_bounds__(kScanThreads) void knn_scan_bf16(ScanBf16Params p) {
+	const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint32_t qi = blockIdx.y;
+	float q[NC * 8];
+	{
+		const float4* qg = reinterpret_cast<const float4*>(p.queries32 + size_t(qi) * p.ld);
+#pragma unroll
+		for (int t = 0; t < NC; ++t) {
+			const float4 lo = qg[2 * (m + 16 * t)], hi = qg[2 * (m + 16 * t) + 1];
+			q[8 * t + 0] = lo.x; q[8 * t + 1] = lo.y; q[8 * t + 2] = lo.z; q[8 * t + 3] = lo.w;
+			q[8 * t + 4] = hi.x; q[8 * t + 5] = hi.y; q[8 * t + 6] = hi.z; q[8 * t + 7] = hi.w;
+		}
+	}
+	float q_term = 0.f;
+	if constexpr (kMetric == kL2) q_term = p.q_sq[qi];
+	WaveTopK top;
+	top.init(p.sp.kk);
+	float* approx = p.approx + size_t(qi) * p.sp.n;
+	const uint64_t n = p.sp.n;
+	const uint64_t nquads = (n + kRowsPerWave - 1) / kRowsPerWave;
+	const uint64_t nwaves = uint64_t(gridDim.x) * kScanWaves;
+	const uint64_t first = uint64_t(blockIdx.x) * kScanWaves + wave;
+	auto issue = [&](u32x4 (&x)[NC], uint64_t quad) {
+		uint64_t row = quad * kRowsPerWave + g;
+		if (row >= n) row = n - 1;
+		const u32x4* src = reinterpret_cast<const u32x4*>(p.rows16 + row * p.ld) + m;
+#pragma unroll
+		for (int t = 0; t < NC; ++t) x[t] = __builtin_nontemporal_load(src + 16 * t);
+	};
+	auto reduce = [&](const u32x4 (&x)[NC], uint64_t quad) {
+		if (quad >= nquads) return;
+		const uint64_t row = quad * kRowsPerWave + g;
+		const bool valid = row < n;
+		const uint64_t rowc = valid ? row : n - 1;
+		const float sum = bf16_group_dot<NC>(x, q);
+		float dist;
+		if constexpr (kMetric == kL2) {
+			dist = (q_term + p.row_sq[rowc]) - 2.0f * sum;
+		} else if constexpr (kMetric == kIP) {
+			dist = -sum;
+		} else {
+			dist = -sum * p.sp.inv_norms[rowc];
+		}
+		if (valid && m == 0) approx[row] = dist;
+		consider_quad(top, dist, uint32_t(row), valid, lane);
+	};
+	if (first < nquads) {
+		u32x4 xa[NC], xb[NC];
+		issue(xa, first);
+		for (uint64_t quad = first; quad < nquads; quad += 2 * nwaves) {
+			issue(xb, quad + nwaves);
+			__builtin_amdgcn_sched_barrier(0);
+			reduce(xa, quad);
+			__builtin_amdgcn_sched_barrier(0);
+			issue(xa, quad + 2 * nwaves);
+			__builtin_amdgcn_sched_barrier(0);
+			reduce(xb, quad + nwaves);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+	}
+	block_merge_and_store(top, p.sp, lane, wave);
+}
+
+// rows whose approximate distance is within the bound of the kk-th best approximate distance -> candidate list of the query
+__global__ __launch_bounds__(256) void knn_filter_approx(const float* approx, uint64_t n, const float* top_dist, const uint32_t* top_count, uint32_t kk,
+														 const float* margin, uint32_t* cand_row, uint32_t* cand_cnt, uint32_t cap) {
+	const uint32_t qi = blockIdx.y;
+	const int lane = threadIdx.x & 63;
+	const float thr = (top_count[qi] >= kk ? top_dist[size_t(qi) * kk + kk - 1] : __builtin_inff()) + margin[qi];
+	const float* a = approx + size_t(qi) * n;
+	const uint64_t span = uint64_t(gridDim.x) * blockDim.x;
+	for (uint64_t base = uint64_t(blockIdx.x) * blockDim.x; base < n; base += span) {   // wave-uniform trip count
+		const uint64_t row = base + threadIdx.x;
+		const bool pass = row < n && a[row] <= thr;
+		const uint64_t pm = __ballot(pass);
+		if (!pm) continue;
+		uint32_t pos0 = 0;
+		if (lane == __builtin_ctzll(pm)) pos0 = atomicAdd(&cand_cnt[qi], uint32_t(__popcll(pm)));
+		pos0 = __shfl(pos0, __builtin_ctzll(pm));
+		const uint32_t pos = pos0 + uint32_t(__popcll(pm & ((1ull << lane) - 1)));
+		if (pass && pos < cap) cand_row[size_t(qi) * cap + pos] = uint32_t(row);
+	}
 }
 
 // One workgroup per query: fold `total` candidate (dist,row) pairs (invalid rows skipped) into the sorted top-kk.
@@ -366,6 +489,36 @@ void launch_scan(int metric, const ScanParams& p, uint32_t nq, uint32_t gridx, h
 		case kIP: launch_scan_metric<kIP>(p, grid, s); break;
 		default: launch_scan_metric<kCos>(p, grid, s); break;
 	}
+}
+
+template <int kMetric>
+static bool launch_scan_bf16_metric(const ScanBf16Params& p, dim3 grid, hipStream_t s) {
+	switch (p.ld / 128) {   // ld is a multiple of 64; the per-lane chunk count must be whole (ld % 128 == 0)
+		case 1: hipLaunchKernelGGL((knn_scan_bf16<kMetric, 1>), grid, dim3(kScanThreads), 0, s, p); return true;
+		case 2: hipLaunchKernelGGL((knn_scan_bf16<kMetric, 2>), grid, dim3(kScanThreads), 0, s, p); return true;
+		case 3: hipLaunchKernelGGL((knn_scan_bf16<kMetric, 3>), grid, dim3(kScanThreads), 0, s, p); return true;
+		case 4: hipLaunchKernelGGL((knn_scan_bf16<kMetric, 4>), grid, dim3(kScanThreads), 0, s, p); return true;
+		case 6: hipLaunchKernelGGL((knn_scan_bf16<kMetric, 6>), grid, dim3(kScanThreads), 0, s, p); return true;
+		case 8: hipLaunchKernelGGL((knn_scan_bf16<kMetric, 8>), grid, dim3(kScanThreads), 0, s, p); return true;
+		default: return false;
+	}
+}
+bool scan_bf16_supported(uint32_t ld) {
+	const uint32_t nc = ld / 128;
+	return ld % 128 == 0 && (nc == 1 || nc == 2 || nc == 3 || nc == 4 || nc == 6 || nc == 8);
+}
+void launch_scan_bf16(int metric, const ScanBf16Params& p, uint32_t nq, uint32_t gridx, hipStream_t s) {
+	const dim3 grid(gridx, nq);
+	switch (metric) {
+		case kL2: launch_scan_bf16_metric<kL2>(p, grid, s); break;
+		case kIP: launch_scan_bf16_metric<kIP>(p, grid, s); break;
+		default: launch_scan_bf16_metric<kCos>(p, grid, s); break;
+	}
+}
+void launch_filter_approx(const float* approx, uint64_t n, const float* top_dist, const uint32_t* top_count, uint32_t kk, const float* margin,
+						  uint32_t* cand_row, uint32_t* cand_cnt, uint32_t cap, uint32_t nq, int cus, hipStream_t s) {
+	const uint32_t gx = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, uint64_t(cus) * 8)));
+	hipLaunchKernelGGL(knn_filter_approx, dim3(gx, nq), dim3(256), 0, s, approx, n, top_dist, top_count, kk, margin, cand_row, cand_cnt, cap);
 }
 
 void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t total_per_query, uint32_t kk, uint32_t nq, float* out_dist,

@@ -78,6 +78,7 @@ void rxgpu_search_ctx::release() {
 	d_gcand_d.release();
 	d_gcand_i.release();
 	d_redo.release();
+	d_top.release();
 	if (h_pinned) (void)hipHostFree(h_pinned);
 	h_pinned = nullptr;
 	if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -443,8 +444,96 @@ int enqueue_knn_batched(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_quer
 	return RXGPU_OK;
 }
 
+// bf16-pruned scan for one .. a few queries (opt-in: RXGPU_SCAN_BF16=1): 2 bytes per element from HBM instead of 4, exact result (knn_scan.hip).
+static bool scan_bf16_enabled() {   // read per call: a process can switch it for A/B runs
+	const char* e = getenv("RXGPU_SCAN_BF16");
+	return e && atoi(e) != 0;
+}
+constexpr uint32_t kPrunedMaxQueries = 8;
+constexpr uint32_t kPrunedCap = 4096;
+
+int enqueue_knn_pruned(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
+					   uint32_t* d_out_row, uint32_t* d_out_count) {
+	if (int rc = ensure_row_stats(h, c->stream); rc) return rc;
+	if (int rc = ensure_bf16_shadow(h, c->stream); rc) return rc;
+	const uint32_t ld = (h->dim + 63u) & ~63u;
+	const uint32_t gridx = rxgpu::scan_grid_x(h->count, h->cus);
+	const uint32_t cap = uint32_t(std::min<uint64_t>(kPrunedCap, std::max<uint64_t>(64, (h->count + 63) & ~63ull)));
+	if (int rc = c->d_qpad.ensure(size_t(nq) * ld * sizeof(float)); rc) return rc;
+	if (int rc = c->d_qstats.ensure(size_t(2) * nq * sizeof(float)); rc) return rc;
+	if (int rc = c->d_dense.ensure(size_t(nq) * h->count * sizeof(float)); rc) return rc;
+	if (int rc = c->d_part_dist.ensure(size_t(nq) * gridx * kk * sizeof(float)); rc) return rc;
+	if (int rc = c->d_part_row.ensure(size_t(nq) * gridx * kk * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_top.ensure(size_t(nq) * (2 * kk + 1) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_cand_row.ensure(size_t(nq) * cap * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_cand_dist.ensure(size_t(nq) * cap * sizeof(float)); rc) return rc;
+	if (int rc = c->d_cand_cnt.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
+	float* qpad = static_cast<float*>(c->d_qpad.ptr);
+	float* q_sq = static_cast<float*>(c->d_qstats.ptr);
+	float* margin = q_sq + nq;
+	float* top_dist = static_cast<float*>(c->d_top.ptr);
+	uint32_t* top_row = reinterpret_cast<uint32_t*>(top_dist + size_t(nq) * kk);
+	uint32_t* top_cnt = top_row + size_t(nq) * kk;
+	uint32_t* cand_cnt = static_cast<uint32_t*>(c->d_cand_cnt.ptr);
+	RX_HIP(hipMemsetAsync(qpad, 0, size_t(nq) * ld * sizeof(float), c->stream));
+	RX_HIP(hipMemcpy2DAsync(qpad, ld * sizeof(float), d_queries, h->dim * sizeof(float), h->dim * sizeof(float), nq, hipMemcpyDeviceToDevice, c->stream));
+	RX_HIP(hipMemsetAsync(cand_cnt, 0, size_t(nq) * sizeof(uint32_t), c->stream));
+	rxgpu::launch_query_stats(h->metric, qpad, nq, nq, ld, h->dim, h->d_stats, q_sq, margin, true, c->stream);
+	rxgpu::ScanBf16Params p{};
+	p.sp.inv_norms = h->d_inv_norms;
+	p.sp.n = h->count;
+	p.sp.kk = kk;
+	p.sp.part_dist = static_cast<float*>(c->d_part_dist.ptr);
+	p.sp.part_row = static_cast<uint32_t*>(c->d_part_row.ptr);
+	p.rows16 = h->d_rows_bf16;
+	p.queries32 = qpad;
+	p.row_sq = h->d_row_sq;
+	p.q_sq = q_sq;
+	p.ld = ld;
+	p.approx = static_cast<float*>(c->d_dense.ptr);
+	{
+		ProfileScope ps(h, "scan_bf16", c->stream);
+		rxgpu::launch_scan_bf16(h->metric, p, nq, gridx, c->stream);
+	}
+	rxgpu::launch_merge(p.sp.part_dist, p.sp.part_row, gridx * kk, kk, nq, top_dist, top_row, top_cnt, nullptr, 0, c->stream);
+	{
+		ProfileScope ps(h, "filter_approx", c->stream);
+		rxgpu::launch_filter_approx(p.approx, h->count, top_dist, top_cnt, kk, margin, static_cast<uint32_t*>(c->d_cand_row.ptr), cand_cnt, cap, nq,
+									h->cus, c->stream);
+	}
+	{
+		ProfileScope ps(h, "rescore", c->stream);
+		rxgpu::launch_rescore(h->metric, h->d_rows, h->d_inv_norms, qpad, ld, h->stride, h->dim, nq, cap, cand_cnt,
+							  static_cast<uint32_t*>(c->d_cand_row.ptr), static_cast<float*>(c->d_cand_dist.ptr), c->stream);
+	}
+	rxgpu::launch_merge(static_cast<float*>(c->d_cand_dist.ptr), static_cast<uint32_t*>(c->d_cand_row.ptr), cap, kk, nq, d_out_dist, d_out_row,
+						d_out_count, nullptr, 0, c->stream);
+	{   // more rows inside the bound than the list holds (massive ties): exact scan, gated on device
+		rxgpu::ScanParams e{};
+		e.rows = h->d_rows;
+		e.inv_norms = h->d_inv_norms;
+		e.queries = d_queries;
+		e.n = h->count;
+		e.stride = h->stride;
+		e.dim = h->dim;
+		e.kk = kk;
+		e.part_dist = p.sp.part_dist;
+		e.part_row = p.sp.part_row;
+		e.gate_cnt = cand_cnt;
+		e.gate_cap = cap;
+		ProfileScope ps(h, "fallback_scan", c->stream);
+		rxgpu::launch_scan(h->metric, e, nq, gridx, c->stream);
+		rxgpu::launch_merge(e.part_dist, e.part_row, gridx * kk, kk, nq, d_out_dist, d_out_row, d_out_count, cand_cnt, cap, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	return RXGPU_OK;
+}
+
 int enqueue_knn(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
 				uint32_t* d_out_row, uint32_t* d_out_count) {
+	if (scan_bf16_enabled() && nq <= kPrunedMaxQueries && rxgpu::scan_bf16_supported((h->dim + 63u) & ~63u)) {
+		return enqueue_knn_pruned(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
+	}
 	if (int(nq) >= batch_min_queries() && nq >= 2) return enqueue_knn_batched(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
 	return enqueue_knn_fused(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
 }

@@ -15,6 +15,11 @@ struct ScanParams;
 
 uint32_t scan_grid_x(uint64_t n, int cus);
 void launch_scan(int metric, const ScanParams& p, uint32_t nq, uint32_t gridx, hipStream_t s);
+struct ScanBf16Params;
+bool scan_bf16_supported(uint32_t ld);
+void launch_scan_bf16(int metric, const ScanBf16Params& p, uint32_t nq, uint32_t gridx, hipStream_t s);
+void launch_filter_approx(const float* approx, uint64_t n, const float* top_dist, const uint32_t* top_count, uint32_t kk, const float* margin,
+						  uint32_t* cand_row, uint32_t* cand_cnt, uint32_t cap, uint32_t nq, int cus, hipStream_t s);
 void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t total_per_query, uint32_t kk, uint32_t nq, float* out_dist,
 				  uint32_t* out_row, uint32_t* out_count, const uint32_t* gate_cnt, uint32_t gate_cap, hipStream_t s);
 void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
@@ -195,6 +200,7 @@ struct rxgpu_search_ctx {
 	rxgpu_devbuf d_queries, d_part_dist, d_part_row, d_out_dist, d_out_row, d_out_count, d_misc, d_select;
 	rxgpu_devbuf d_qpad, d_qstats, d_dense, d_cand_row, d_cand_dist, d_cand_cnt;   // batched path
 	rxgpu_devbuf d_visited, d_gcand_d, d_gcand_i, d_redo;                          // HNSW
+	rxgpu_devbuf d_top;                                                            // bf16-pruned scan: approximate top lists
 	void* h_pinned = nullptr;
 	size_t h_pinned_bytes = 0;
 	int ensure_pinned(size_t need);
