@@ -213,7 +213,8 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
 // glds variant: both operands travel global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers, no ds_write pass.
 // One stage = 32 bf16 of the dimension: 256 rows x 64 B + 256 queries x 64 B = 32 KB; 4 LDS buffers, 3 stages in flight, so ~3000
 // MFMA cycles (~1.3 us) of HBM latency are covered; the stream of stages runs ACROSS tiles (the next tile's first stages are already
-// landing during this tile's epilogue).  The DMA writes a lane-linear image (wave base + lane x 16 B), so the bank swizzle is applied on
+// landing during this tile's epilogue).  (A 4-wave / 512-register variant with 128 x 128 wave tiles measured 6.2 ms against 4.9 ms: with one
+// wave per SIMD nothing overlaps its fragment reads with its MFMAs.)  The DMA writes a lane-linear image (wave base + lane x 16 B), so the bank swizzle is applied on
 // the SOURCE side: LDS slot p = 4 r + cs holds chunk c = cs ^ ((r >> 2) & 3) of row r; a ds_read_b128 lane group (16 rows, one chunk) then
 // covers 16 distinct 16-byte slots.  One raw s_barrier per stage with counted vmcnt (a __syncthreads would drain the DMA queue).
 constexpr int kGlBufs = 4;
