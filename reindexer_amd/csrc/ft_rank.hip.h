@@ -1,5 +1,5 @@
 // Device-side calcTermRankImpl (cpp_src/core/ft/ft_fast/phrasemergerimpl.h:13-81) with Bm25Rx (core/ft/bm25.h:8-36) and the
-// FTFieldConfig helpers (core/ft/config/ftconfig.h:127-148), shared by the single-term (bm25.hip) and multi-term (ft_terms.hip)
+// FTFieldConfig helpers (core/ft/config/ftconfig.h:127-148), used by the single-term and multi-term merge kernels (ft_terms.hip)
 // merge kernels.  P supplies the term / field configuration (FtMergeParams or FtTermCfg member names), S the posting arrays.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -409,6 +409,13 @@ __global__ __launch_bounds__(256) void ft_term_pass(FtTermPass p) {
 			c_mask |= 1u << k;
 			continue;
 		}
+		if (p.simple) {   // mergeSimple, mergerimpl.h:234-239: strict <, so the first maximum (and its field) wins
+			if (p.slots.proc[slot] < rank) {
+				p.slots.proc[slot] = rank;
+				p.slots.field[slot] = field;
+			}
+			continue;
+		}
 		// ---- document already merged: mergerimpl.h:171-189
 		const FtSlots& s = p.slots;
 		const uint64_t* pos = p.sub.fpos + p.sub.pos_off[i];
@@ -456,6 +463,11 @@ __global__ __launch_bounds__(256) void ft_term_pass(FtTermPass p) {
 			s.doc[slot] = d;
 			s.proc[slot] = c_rank[k];
 			s.field[slot] = c_field[k];
+			p.slot_of[d] = slot;
+			if (p.simple) {
+				++slot;
+				continue;
+			}
 			s.rank[slot] = c_rank[k];
 			s.last_ptr[slot] = nullptr;
 			s.last_cnt[slot] = 0;
@@ -464,7 +476,6 @@ __global__ __launch_bounds__(256) void ft_term_pass(FtTermPass p) {
 			s.switched_term[slot] = p.qp_idx;
 			s.last_counted[slot] = p.qp_idx;
 			s.terms_counter[slot] = 1;
-			p.slot_of[d] = slot;
 		}
 		++slot;
 	}

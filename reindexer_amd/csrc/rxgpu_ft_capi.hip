@@ -56,7 +56,7 @@ struct rxgpu_ft_index {
 	std::unordered_map<uint32_t, rxgpu_ft_word> words;
 	std::mutex mtx;
 	hipStream_t stream = nullptr;
-	rxgpu_devbuf d_best, d_first, d_pfield, d_blocks, d_total, d_out_doc, d_out_proc, d_out_field, d_excluded, d_cfg, d_subs;
+	rxgpu_devbuf d_excluded, d_cfg, d_subs;
 	rxgpu_devbuf d_mask, d_tmask, d_score, d_hist, d_slot_of, d_slots, d_sync;   // multi-term merge
 	uint64_t stat_postings = 0;
 	double stat_ms = 0.0;
@@ -113,8 +113,7 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
 		if (p) (void)hipFree(p);
 	}
-	for (rxgpu_devbuf* b : {&h->d_best, &h->d_first, &h->d_pfield, &h->d_blocks, &h->d_total, &h->d_out_doc, &h->d_out_proc, &h->d_out_field,
-							&h->d_excluded, &h->d_cfg, &h->d_subs, &h->d_mask, &h->d_tmask, &h->d_score, &h->d_hist, &h->d_slot_of, &h->d_slots,
+	for (rxgpu_devbuf* b : {&h->d_excluded, &h->d_cfg, &h->d_subs, &h->d_mask, &h->d_tmask, &h->d_score, &h->d_hist, &h->d_slot_of, &h->d_slots,
 							&h->d_sync}) {
 		b->release();
 	}
@@ -161,6 +160,53 @@ int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uin
 	return RXGPU_OK;
 }
 
+// Shared by both merges: slot state of the admitted documents (MergeInfo + MergerDocumentData), SoA, 8-byte members first
+static int carve_slots(rxgpu_ft_index* h, size_t M, rxgpu::FtSlots& slots) {
+	const size_t slots_bytes = M * (8 + 8 + 4 * 5 + 2 * 3 + 1) + 64;
+	if (int rc = h->d_slots.ensure(slots_bytes); rc) return rc;
+	char* sp = static_cast<char*>(h->d_slots.ptr);
+	slots.last_ptr = reinterpret_cast<const uint64_t**>(sp);
+	sp += M * 8;
+	slots.next_ptr = reinterpret_cast<const uint64_t**>(sp);
+	sp += M * 8;
+	slots.doc = reinterpret_cast<uint32_t*>(sp);
+	sp += M * 4;
+	slots.proc = reinterpret_cast<float*>(sp);
+	sp += M * 4;
+	slots.rank = reinterpret_cast<float*>(sp);
+	sp += M * 4;
+	slots.last_cnt = reinterpret_cast<uint32_t*>(sp);
+	sp += M * 4;
+	slots.next_cnt = reinterpret_cast<uint32_t*>(sp);
+	sp += M * 4;
+	slots.switched_term = reinterpret_cast<uint16_t*>(sp);
+	sp += M * 2;
+	slots.last_counted = reinterpret_cast<uint16_t*>(sp);
+	sp += M * 2;
+	slots.terms_counter = reinterpret_cast<uint16_t*>(sp);
+	sp += M * 2;
+	slots.field = reinterpret_cast<uint8_t*>(sp);
+	return RXGPU_OK;
+}
+
+static void fill_subterm(const rxgpu_ft_word& w, uint64_t total_docs, float proc, rxgpu::FtPosSubterm& ft) {
+	ft.n = w.n;
+	ft.doc = w.doc;
+	ft.ent_off = w.ent_off;
+	ft.ent_field = w.ent_field;
+	ft.ent_tf = w.ent_tf;
+	ft.ent_first_pos = w.ent_first_pos;
+	ft.pos_off = w.pos_off;
+	ft.fpos = w.fpos;
+	// Bm25Rx::IDF(totalDocCount = totalNumDocs - 1, matchedDocCount = |postings|)  (bm25.h:19-26, mergerimpl.h:123-124, 203-205)
+	const double td = double(total_docs - 1), md = double(w.n);
+	double f = w.n ? std::log((td - md + 1) / md) / std::log(1 + td) : 0.2;
+	if (f < 0.2) f = 0.2;
+	ft.idf = f;
+	ft.proc = proc;
+	ft.gp_base = 0;
+}
+
 int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
 							  const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc,
 							  uint8_t* out_field, uint64_t cap, uint64_t* out_n) {
@@ -169,40 +215,30 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: field count mismatch");
 	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_simple_raw: rxgpu_ft_set_docs was not called");
 	if (nsub == 0) return RXGPU_OK;
-	RX_CHECK(word_ids && procs, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: null argument");
+	RX_CHECK(word_ids && procs && opts->field_boost && opts->need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
 	DevGuard dg(h->device);
-	std::vector<rxgpu::FtSubterm> subs(nsub);
-	uint64_t total = 0;
-	uint32_t nblocks = 0;
+	const uint32_t nf = h->num_fields;
+	const uint64_t N = h->total_docs;
+	std::vector<rxgpu::FtPosSubterm> subs(nsub);
+	uint64_t total = 0, lookback_words = 0;
+	uint32_t launches = 0;
 	for (uint32_t s = 0; s < nsub; ++s) {
 		auto it = h->words.find(word_ids[s]);
 		RX_CHECK(it != h->words.end(), RXGPU_ERR_NOTFOUND, "rxgpu_ft_merge_simple_raw: unknown word id");
-		const rxgpu_ft_word& w = it->second;
-		rxgpu::FtSubterm& ft = subs[s];
-		ft.n = w.n;
-		ft.doc = w.doc;
-		ft.ent_off = w.ent_off;
-		ft.ent_field = w.ent_field;
-		ft.ent_tf = w.ent_tf;
-		ft.ent_first_pos = w.ent_first_pos;
-		// Bm25Rx::IDF(totalDocCount = totalNumDocs - 1, matchedDocCount = |postings|)  (bm25.h:19-26, mergerimpl.h:203-205)
-		const double td = double(h->total_docs - 1), md = double(w.n);
-		double f = w.n ? std::log((td - md + 1) / md) / std::log(1 + td) : 0.2;
-		if (f < 0.2) f = 0.2;
-		ft.idf = f;
-		ft.proc = procs[s];
-		ft.gp_base = total;
-		ft.block_base = nblocks;
-		total += w.n;
-		nblocks += rxgpu::bm25_scan_blocks_for(w.n);
+		fill_subterm(it->second, N, procs[s], subs[s]);
+		total += subs[s].n;
+		if (subs[s].n) {
+			++launches;
+			lookback_words += rxgpu::ft_pass_blocks(subs[s].n);
+		}
 	}
 	RX_CHECK(total < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: more than 2^32 postings in one merge");
 	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, total);   // Merge(): min(mergeLimit, totalORVids)
 	if (max_merged == 0) return RXGPU_OK;
 	RX_CHECK(cap >= max_merged && out_doc && out_proc && out_field, RXGPU_ERR_OVERFLOW, "rxgpu_ft_merge_simple_raw: output buffers too small");
 
-	const uint32_t nf = h->num_fields;
+	hipStream_t st = h->stream;
 	// per-field parameters as floats (bound() takes float arguments), packed in one upload
 	std::vector<float> fcfg(size_t(7) * nf);
 	for (uint32_t f = 0; f < nf; ++f) {
@@ -214,71 +250,83 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 		fcfg[5 * nf + f] = float(cfg->position_boost[f]);
 		fcfg[6 * nf + f] = float(cfg->position_weight[f]);
 	}
-	const size_t cfg_bytes = fcfg.size() * sizeof(float) + nf;
-	if (int rc = h->d_cfg.ensure(cfg_bytes); rc) return rc;
-	if (int rc = h->d_best.ensure(h->total_docs * sizeof(unsigned long long)); rc) return rc;
-	if (int rc = h->d_first.ensure(h->total_docs * sizeof(uint32_t)); rc) return rc;
-	if (int rc = h->d_pfield.ensure(total); rc) return rc;
-	if (int rc = h->d_blocks.ensure(size_t(nblocks) * sizeof(uint32_t)); rc) return rc;
-	if (int rc = h->d_total.ensure(sizeof(uint32_t)); rc) return rc;
-	if (int rc = h->d_out_doc.ensure(max_merged * sizeof(uint32_t)); rc) return rc;
-	if (int rc = h->d_out_proc.ensure(max_merged * sizeof(float)); rc) return rc;
-	if (int rc = h->d_out_field.ensure(max_merged); rc) return rc;
-	hipStream_t st = h->stream;
+	if (int rc = h->d_cfg.ensure(fcfg.size() * sizeof(float) + nf); rc) return rc;
 	RX_HIP(hipMemcpyAsync(h->d_cfg.ptr, fcfg.data(), fcfg.size() * sizeof(float), hipMemcpyHostToDevice, st));
 	RX_HIP(hipMemcpyAsync(static_cast<char*>(h->d_cfg.ptr) + fcfg.size() * sizeof(float), opts->need_sum_rank, nf, hipMemcpyHostToDevice, st));
+	const float* fc = static_cast<const float*>(h->d_cfg.ptr);
+
+	// docsExcluded_ as the restricting mask (mergeSimple tests docsExcluded_[docId] || DocRemoved(docId), mergerimpl.h:209)
+	const uint64_t nwords = (N + 31) / 32;
+	if (int rc = h->d_mask.ensure(nwords * 4); rc) return rc;
 	const uint8_t* d_excl = nullptr;
 	if (excluded) {
-		if (int rc = h->d_excluded.ensure(h->total_docs); rc) return rc;
-		RX_HIP(hipMemcpyAsync(h->d_excluded.ptr, excluded, h->total_docs, hipMemcpyHostToDevice, st));
+		if (int rc = h->d_excluded.ensure(N); rc) return rc;
+		RX_HIP(hipMemcpyAsync(h->d_excluded.ptr, excluded, N, hipMemcpyHostToDevice, st));
 		d_excl = static_cast<const uint8_t*>(h->d_excluded.ptr);
 	}
-	RX_HIP(hipMemsetAsync(h->d_best.ptr, 0, h->total_docs * sizeof(unsigned long long), st));
-	RX_HIP(hipMemsetAsync(h->d_first.ptr, 0xFF, h->total_docs * sizeof(uint32_t), st));
+	rxgpu::launch_ft_mask_init(static_cast<uint32_t*>(h->d_mask.ptr), d_excl, N, st);
 
-	rxgpu::FtMergeParams p{};
-	const float* fc = static_cast<const float*>(h->d_cfg.ptr);
-	p.num_fields = nf;
-	p.words = h->d_words;
-	p.avg_words = h->d_avg;
-	p.removed = h->d_removed;
-	p.excluded = d_excl;
-	p.k1 = cfg->bm25_k1;
-	p.b = cfg->bm25_b;
-	p.summation_ratio = cfg->summation_ranks_by_fields_ratio;
-	p.opts_boost = opts->boost;
-	p.term_len_boost_in = opts->term_len_boost;
-	p.field_boost = fc + 0 * nf;
-	p.bm25_boost = fc + 1 * nf;
-	p.bm25_weight = fc + 2 * nf;
-	p.term_len_boost = fc + 3 * nf;
-	p.term_len_weight = fc + 4 * nf;
-	p.position_boost = fc + 5 * nf;
-	p.position_weight = fc + 6 * nf;
-	p.need_sum_rank = reinterpret_cast<const uint8_t*>(fc + 7 * nf);
-	p.best = static_cast<unsigned long long*>(h->d_best.ptr);
-	p.first = static_cast<uint32_t*>(h->d_first.ptr);
-	p.pfield = static_cast<uint8_t*>(h->d_pfield.ptr);
-	p.max_merged = uint32_t(max_merged);
-	p.out_doc = static_cast<uint32_t*>(h->d_out_doc.ptr);
-	p.out_proc = static_cast<float*>(h->d_out_proc.ptr);
-	p.out_field = static_cast<uint8_t*>(h->d_out_field.ptr);
+	const size_t sync_u32 = 8 + size_t(launches + 1) * 2;
+	const size_t sync_bytes = ((sync_u32 * 4 + 7) & ~size_t(7)) + lookback_words * 8;
+	if (int rc = h->d_sync.ensure(sync_bytes); rc) return rc;
+	RX_HIP(hipMemsetAsync(h->d_sync.ptr, 0, sync_bytes, st));
+	uint32_t* d_sync = static_cast<uint32_t*>(h->d_sync.ptr);
+	uint32_t* d_error = d_sync;
+	uint32_t* d_tickets = d_sync + 8;
+	uint32_t* d_num_docs = d_tickets + launches + 1;
+	unsigned long long* d_lookback = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->d_sync.ptr) + ((sync_u32 * 4 + 7) & ~size_t(7)));
+	if (int rc = h->d_slot_of.ensure(N * 4); rc) return rc;
+	RX_HIP(hipMemsetAsync(h->d_slot_of.ptr, 0xFF, N * 4, st));
+	rxgpu::FtSlots slots{};
+	if (int rc = carve_slots(h, size_t(max_merged), slots); rc) return rc;
 
 	hipEvent_t e0, e1;
 	RX_HIP(hipEventCreate(&e0));
 	RX_HIP(hipEventCreate(&e1));
 	RX_HIP(hipEventRecord(e0, st));
-	if (int rc = h->d_subs.ensure(subs.size() * sizeof(rxgpu::FtSubterm)); rc) return rc;
-	RX_HIP(hipMemcpyAsync(h->d_subs.ptr, subs.data(), subs.size() * sizeof(rxgpu::FtSubterm), hipMemcpyHostToDevice, st));
-	RX_HIP(hipEventRecord(e0, st));   // re-record: time only the scoring launch
-	rxgpu::launch_bm25_score_fused(p, static_cast<const rxgpu::FtSubterm*>(h->d_subs.ptr), nsub, total, st);
+	uint32_t launch = 0;
+	uint64_t lb_used = 0;
+	for (uint32_t s = 0; s < nsub; ++s) {   // sub-terms in SortSubterms order; documents are unique inside one: a launch is race free
+		if (!subs[s].n) continue;
+		rxgpu::FtTermPass p{};
+		p.cfg.num_fields = nf;
+		p.cfg.words = h->d_words;
+		p.cfg.avg_words = h->d_avg;
+		p.cfg.k1 = cfg->bm25_k1;
+		p.cfg.b = cfg->bm25_b;
+		p.cfg.summation_ratio = cfg->summation_ranks_by_fields_ratio;
+		p.cfg.opts_boost = opts->boost;
+		p.cfg.term_len_boost_in = opts->term_len_boost;
+		p.cfg.field_boost = fc + 0 * nf;
+		p.cfg.bm25_boost = fc + 1 * nf;
+		p.cfg.bm25_weight = fc + 2 * nf;
+		p.cfg.term_len_boost = fc + 3 * nf;
+		p.cfg.term_len_weight = fc + 4 * nf;
+		p.cfg.position_boost = fc + 5 * nf;
+		p.cfg.position_weight = fc + 6 * nf;
+		p.cfg.need_sum_rank = reinterpret_cast<const uint8_t*>(fc + 7 * nf);
+		p.sub = subs[s];
+		p.slots = slots;
+		p.mask = static_cast<const uint32_t*>(h->d_mask.ptr);
+		p.removed = h->d_removed;
+		p.slot_of = static_cast<uint32_t*>(h->d_slot_of.ptr);
+		p.max_merged = uint32_t(max_merged);
+		p.qp_idx = 1;
+		p.simple = 1;
+		p.num_docs_in = d_num_docs + launch;
+		p.num_docs_out = d_num_docs + launch + 1;
+		p.lookback = d_lookback + lb_used;
+		p.ticket = d_tickets + launch;
+		p.error_flag = d_error;
+		rxgpu::launch_ft_term_pass(p, st);
+		lb_used += rxgpu::ft_pass_blocks(subs[s].n);
+		++launch;
+	}
 	RX_HIP(hipEventRecord(e1, st));
-	for (const auto& s : subs) rxgpu::launch_bm25_count_adds(p, s, static_cast<uint32_t*>(h->d_blocks.ptr), st);
-	rxgpu::launch_bm25_scan_blocks(static_cast<uint32_t*>(h->d_blocks.ptr), nblocks, static_cast<uint32_t*>(h->d_total.ptr), st);
-	for (const auto& s : subs) rxgpu::launch_bm25_emit(p, s, static_cast<const uint32_t*>(h->d_blocks.ptr), st);
 	RX_HIP(hipGetLastError());
-	uint32_t distinct = 0;
-	RX_HIP(hipMemcpyAsync(&distinct, h->d_total.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	uint32_t tail[2] = {0, 0};
+	RX_HIP(hipMemcpyAsync(&tail[0], d_num_docs + launch, 4, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipMemcpyAsync(&tail[1], d_error, 4, hipMemcpyDeviceToHost, st));
 	RX_HIP(hipStreamSynchronize(st));
 	float ms = 0.f;
 	(void)hipEventElapsedTime(&ms, e0, e1);
@@ -286,11 +334,12 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 	(void)hipEventDestroy(e1);
 	h->stat_postings += total;
 	h->stat_ms += ms;
-	const uint64_t n = std::min<uint64_t>(distinct, max_merged);
+	RX_CHECK(tail[1] == 0, RXGPU_ERR_DEVICE, "rxgpu_ft_merge_simple_raw: ordered look-back timed out on the device");
+	const uint64_t n = tail[0];
 	if (n) {
-		RX_HIP(hipMemcpy(out_doc, p.out_doc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-		RX_HIP(hipMemcpy(out_proc, p.out_proc, n * sizeof(float), hipMemcpyDeviceToHost));
-		RX_HIP(hipMemcpy(out_field, p.out_field, n, hipMemcpyDeviceToHost));
+		RX_HIP(hipMemcpy(out_doc, slots.doc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+		RX_HIP(hipMemcpy(out_proc, slots.proc, n * sizeof(float), hipMemcpyDeviceToHost));
+		RX_HIP(hipMemcpy(out_field, slots.field, n, hipMemcpyDeviceToHost));
 	}
 	*out_n = n;
 	return RXGPU_OK;
@@ -361,19 +410,7 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 			RX_CHECK(w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_terms_raw: the word was uploaded without positions (rxgpu_ft_set_word_positions)");
 			RX_CHECK(s == sub_off[t] || procs[s] <= procs[s - 1], RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: sub-terms must be sorted by proc, descending (SortSubterms)");
 			rxgpu::FtPosSubterm& ft = subs[s];
-			ft.n = w.n;
-			ft.doc = w.doc;
-			ft.ent_off = w.ent_off;
-			ft.ent_field = w.ent_field;
-			ft.ent_tf = w.ent_tf;
-			ft.ent_first_pos = w.ent_first_pos;
-			ft.pos_off = w.pos_off;
-			ft.fpos = w.fpos;
-			const double td = double(N - 1), md = double(w.n);   // Bm25Rx::IDF (bm25.h:19-26), "first doc is always empty"
-			double f = w.n ? std::log((td - md + 1) / md) / std::log(1 + td) : 0.2;
-			if (f < 0.2) f = 0.2;
-			ft.idf = f;
-			ft.proc = procs[s];
+			fill_subterm(w, N, procs[s], ft);
 			ft.gp_base = gp;
 			gp += w.n;
 		}
@@ -519,33 +556,8 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	// ---- mergeTerm for every term that is not a NOT
 	if (int rc = h->d_slot_of.ensure(N * 4); rc) return rc;
 	RX_HIP(hipMemsetAsync(h->d_slot_of.ptr, 0xFF, N * 4, st));
-	const size_t M = size_t(max_merged);
-	// slot state, 8-byte members first: last_ptr, next_ptr | doc, proc, rank, last_cnt, next_cnt | switched, counted, counter | field
-	const size_t slots_bytes = M * (8 + 8 + 4 * 5 + 2 * 3 + 1) + 64;
-	if (int rc = h->d_slots.ensure(slots_bytes); rc) return rc;
-	char* sp = static_cast<char*>(h->d_slots.ptr);
 	rxgpu::FtSlots slots{};
-	slots.last_ptr = reinterpret_cast<const uint64_t**>(sp);
-	sp += M * 8;
-	slots.next_ptr = reinterpret_cast<const uint64_t**>(sp);
-	sp += M * 8;
-	slots.doc = reinterpret_cast<uint32_t*>(sp);
-	sp += M * 4;
-	slots.proc = reinterpret_cast<float*>(sp);
-	sp += M * 4;
-	slots.rank = reinterpret_cast<float*>(sp);
-	sp += M * 4;
-	slots.last_cnt = reinterpret_cast<uint32_t*>(sp);
-	sp += M * 4;
-	slots.next_cnt = reinterpret_cast<uint32_t*>(sp);
-	sp += M * 4;
-	slots.switched_term = reinterpret_cast<uint16_t*>(sp);
-	sp += M * 2;
-	slots.last_counted = reinterpret_cast<uint16_t*>(sp);
-	sp += M * 2;
-	slots.terms_counter = reinterpret_cast<uint16_t*>(sp);
-	sp += M * 2;
-	slots.field = reinterpret_cast<uint8_t*>(sp);
+	if (int rc = carve_slots(h, size_t(max_merged), slots); rc) return rc;
 
 	hipEvent_t e0, e1;
 	RX_HIP(hipEventCreate(&e0));

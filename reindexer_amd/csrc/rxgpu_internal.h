@@ -61,46 +61,7 @@ void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool g
 struct HnswStream;
 void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, uint32_t batch, int mode, bool lds, hipStream_t st);
 
-// BM25 merge (bm25.hip)
-struct FtSubterm {
-	uint64_t n;               // postings
-	const uint32_t* doc;
-	const uint32_t* ent_off;  // [n + 1]
-	const uint8_t* ent_field;
-	const uint32_t* ent_tf;
-	const uint32_t* ent_first_pos;
-	double idf;               // Bm25Rx::IDF(totalDocs - 1, n), evaluated on the host
-	float proc;               // SubtermResults::Proc()
-	uint64_t gp_base;         // sequence position of posting 0 in the concatenated (sub-term, posting) order
-	uint32_t block_base;      // first scan block of this sub-term
-};
-struct FtMergeParams {
-	uint32_t num_fields;
-	const float* words;       // [total_docs][num_fields]
-	const float* avg_words;   // [num_fields]
-	const uint8_t* removed;   // [total_docs] or null
-	const uint8_t* excluded;  // [total_docs] or null
-	double k1, b, summation_ratio;
-	float opts_boost, term_len_boost_in;
-	const float* field_boost;      // [num_fields] FtDslFieldOpts::boost
-	const uint8_t* need_sum_rank;  // [num_fields]
-	const float *bm25_boost, *bm25_weight, *term_len_boost, *term_len_weight, *position_boost, *position_weight;   // FTFieldConfig as floats
-	unsigned long long* best;      // [total_docs] rank bits << 32 | ~sequence position
-	uint32_t* first;               // [total_docs] first valid sequence position
-	uint8_t* pfield;               // [total postings] winning field of each posting, 0xFF = not valid
-	uint32_t max_merged;
-	uint32_t* out_doc;
-	float* out_proc;
-	uint8_t* out_field;
-};
-void launch_bm25_score(const FtMergeParams& p, const FtSubterm& s, hipStream_t st);
-void launch_bm25_score_fused(const FtMergeParams& p, const FtSubterm* d_subs, uint32_t nsub, uint64_t total, hipStream_t st);
-uint32_t bm25_scan_blocks_for(uint64_t n);
-void launch_bm25_count_adds(const FtMergeParams& p, const FtSubterm& s, uint32_t* block_counts, hipStream_t st);
-void launch_bm25_scan_blocks(uint32_t* block_counts, uint32_t nblocks, uint32_t* total, hipStream_t st);
-void launch_bm25_emit(const FtMergeParams& p, const FtSubterm& s, const uint32_t* block_offsets, hipStream_t st);
-
-// Multi-term merge (ft_terms.hip): Merger::mergeTerm + restricting bitmask + preselect
+// ft_fast merge (ft_terms.hip): Merger::mergeSimple / mergeTerm + restricting bitmask + preselect
 struct FtPosSubterm {
 	uint64_t n;
 	const uint32_t* doc;
@@ -146,6 +107,7 @@ struct FtTermPass {
 	uint32_t* slot_of;         // idoffsets_: [total_docs], 0xFFFFFFFF = not added
 	uint32_t max_merged;
 	uint16_t qp_idx;
+	uint16_t simple;           // 1: Merger::mergeSimple (one term): existing documents keep max(proc, rank), first maximum wins; no positions
 	float distance_weight, distance_boost;
 	const uint32_t* num_docs_in;   // numDocs() before this sub-term
 	uint32_t* num_docs_out;        // ... and after it

@@ -199,7 +199,13 @@ void GpuFtMerger::postProcess(const FtConfig& cfg, MergeData& out, RankSortType 
 		md.proc = md.normalizedProc;
 	}
 	if (rankSortType == RankSortType::RankOnly || rankSortType == RankSortType::IDAndPositions) {
-		std::stable_sort(out.begin(), out.end(), [](const MergeInfo& l, const MergeInfo& r) { return l.normalizedProc > r.normalizedProc; });
+		// the key is one byte: a stable counting sort (descending) gives exactly what a stable comparison sort would, in O(n)
+		size_t start[257] = {0};
+		for (const MergeInfo& md : out) ++start[255 - md.normalizedProc + 1];
+		for (int b = 0; b < 256; ++b) start[b + 1] += start[b];
+		MergeData sorted(out.size());
+		for (const MergeInfo& md : out) sorted[start[255 - md.normalizedProc]++] = md;
+		out.swap(sorted);
 	}
 }
 

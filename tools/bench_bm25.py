@@ -174,11 +174,12 @@ def main():
 
     out = {"workload": f"ft_fast single-term BM25 merge, {args.docs} vdocs, sub-term df fractions {fracs}, 1 field, mergeLimit 20000",
            "postings_per_query": npost / args.queries,
-           "gpu": {"merges_per_sec": args.queries / gpu_s, "ms_per_merge": gpu_s / args.queries * 1e3, "score_kernel_ms_per_merge": kernel_ms / args.queries,
+           "gpu": {"merges_per_sec": args.queries / gpu_s, "ms_per_merge": gpu_s / args.queries * 1e3, "term_pass_ms_per_merge": kernel_ms / args.queries,
                    "postings_per_sec_kernel": npost / (kernel_ms / 1e3),
-                   "roofline": {"bound": "hbm", "achieved": npost * 20 / (kernel_ms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                                "frac": npost * 20 / (kernel_ms / 1e3) / 1e9 / 8000.0, "bytes_per_posting": 20,
-                                "note": "4 doc + 4 entry offset + 9 entry streamed, 4 words-in-field gathered, 8+4 B atomics"}}}
+                   "roofline": {"bound": "hbm", "achieved": npost * 29 / (kernel_ms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                "frac": npost * 29 / (kernel_ms / 1e3) / 1e9 / 8000.0, "bytes_per_posting": 29,
+                                "note": "4 doc + 8 entry offsets + 9 entry streamed; 4 words-in-field + 4 slot index gathered (+ the mask bit); SURVEY 8d's 20 B "
+                                        "layout + the slot index that replaces the per-document score word"}}}
     try:
         from oracle.pyoracle import FtOracle, Oracle
         ft = FtOracle(Oracle())
