@@ -67,9 +67,24 @@ def build_host(force: bool = False) -> Path | None:
     return out
 
 
+def build_cpp_tests(force: bool = False) -> list[Path]:
+    """tests/cpp/*.cc: reference-style engine tests written against the Map classes (run by pytest -m gpu)."""
+    outs = []
+    tdir = ROOT / "tests" / "cpp"
+    for src in sorted(tdir.glob("*_test.cc")):
+        out = src.with_suffix("")
+        deps = [src, PKG / "librxgpu_host.so"] + sorted(HOST.glob("*.h"))
+        if force or _stale(out, deps):
+            _run(["g++", "-O2", "-std=c++17", "-Wall", f"-I{INCLUDE}", f"-I{HOST}", src, "-o", out, f"-L{PKG}", "-lrxgpu_host", "-lrxgpu",
+                  "-Wl,-rpath,$ORIGIN/../../reindexer_amd", "-lpthread"])
+        outs.append(out)
+    return outs
+
+
 def build_all(force: bool = False) -> None:
     build_device(force)
     build_host(force)
+    build_cpp_tests(force)
 
 
 if __name__ == "__main__":
