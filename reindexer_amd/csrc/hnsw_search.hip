@@ -89,11 +89,20 @@ __device__ __forceinline__ void batch_distances(const HnswParams& p, const float
 
 // dim == 64*NB: the query fragment lives in registers and the NB 16-byte loads of EIGHT rows (two per 16-lane group) are
 // issued before the first reduction — one HBM round trip per 8 neighbours instead of three per 4.
-template <int kMetric, int NB>
-__device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const float4 (&q)[NB], const uint32_t* ids, int cnt, float* dists,
-													  int lane) {
+// kQLds: the query fragment is re-read from LDS (ds_read_b128) instead of living in NB*4 VGPRs — 48 fewer registers at D = 768, which is
+// what lets four of these wavefronts (instead of two) share a SIMD: the search is latency-bound, occupancy is throughput.
+template <int kMetric, int NB, bool kQLds>
+__device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const float4 (&q)[kQLds ? 1 : NB], const float4* qlds, const uint32_t* ids,
+													  int cnt, float* dists, int lane) {
 	const int m = lane & 15, g = lane >> 4;
-	for (int base = 0; base < cnt; base += 2 * kRowsPerWave) {
+	auto Q = [&](int t) -> float4 {
+		if constexpr (kQLds) {
+			return qlds[16 * t + m];
+		} else {
+			return q[t];
+		}
+	};
+	for (int base = 0; base < cnt; base += (NB <= 8 ? 2 : 1) * kRowsPerWave) {
 		const int ia = base + g, ib = base + kRowsPerWave + g;
 		const bool oka = ia < cnt, okb = ib < cnt;
 		const uint64_t ra = ids[oka ? ia : base], rb = ids[okb ? ib : base];
@@ -102,7 +111,7 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 		float4 xa[NB], xb[NB];
 #pragma unroll
 		for (int t = 0; t < NB; ++t) xa[t] = pa[16 * t];
-		const bool second = base + kRowsPerWave < cnt;   // wave-uniform
+		const bool second = NB <= 8 && base + kRowsPerWave < cnt;   // wave-uniform; at D = 768 one row set per trip keeps the kernel at 4 waves per SIMD
 		if (second) {
 #pragma unroll
 			for (int t = 0; t < NB; ++t) xb[t] = pb[16 * t];
@@ -110,13 +119,13 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 		__builtin_amdgcn_sched_barrier(0);
 		float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-		for (int t = 0; t < NB; ++t) chain_step<kMetric>(acc, q[t], xa[t]);
+		for (int t = 0; t < NB; ++t) chain_step<kMetric>(acc, Q(t), xa[t]);
 		const float da = 1.0f * metric_epilogue<kMetric>(fold_chains<false>(acc, nullptr, nullptr, 0, m) + 0.0f, p.inv_norms, ra);
 		if (oka && m == 0) dists[ia] = da;
 		if (second) {
 			acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-			for (int t = 0; t < NB; ++t) chain_step<kMetric>(acc, q[t], xb[t]);
+			for (int t = 0; t < NB; ++t) chain_step<kMetric>(acc, Q(t), xb[t]);
 			const float db = 1.0f * metric_epilogue<kMetric>(fold_chains<false>(acc, nullptr, nullptr, 0, m) + 0.0f, p.inv_norms, rb);
 			if (okb && m == 0) dists[ib] = db;
 		}
@@ -132,6 +141,8 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	uint32_t* top_i = reinterpret_cast<uint32_t*>(top_d + p.ef_cap);
 	float* lcand_d = reinterpret_cast<float*>(top_i + p.ef_cap);
 	uint32_t* lcand_i = reinterpret_cast<uint32_t*>(lcand_d + (kGlobalCand ? 0 : p.lds_cand_cap));
+	constexpr bool kQLds = NB > 0;   // fixed dims: query fragment in LDS behind the heaps (16-byte aligned: every part is a multiple of 64 entries)
+	float4* q_s = reinterpret_cast<float4*>(lcand_i + (kGlobalCand ? 0 : p.lds_cand_cap));
 	__shared__ uint32_t nb_id[kHnswMaxNeighbors];
 	__shared__ float nb_d[kHnswMaxNeighbors];
 	__shared__ uint8_t nb_del[kHnswMaxNeighbors];
@@ -147,15 +158,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	uint32_t* cand_i = kGlobalCand ? p.gcand_i + size_t(slot) * p.gcand_cap : lcand_i;
 	const uint64_t cand_cap = kGlobalCand ? p.gcand_cap : uint64_t(p.lds_cand_cap);
 	unsigned long long ndist = 0, hops = 0;
-	float4 qreg[NB > 0 ? NB : 1];
+	float4 qreg[1];
 	if constexpr (NB > 0) {
-		const float4* qp = reinterpret_cast<const float4*>(q) + (lane & 15);
-#pragma unroll
-		for (int t = 0; t < NB; ++t) qreg[t] = qp[16 * t];
+		const float4* qp = reinterpret_cast<const float4*>(q);
+		for (int i = lane; i < NB * 16; i += 64) q_s[i] = qp[i];
+		__syncthreads();
 	}
 	auto distances = [&](const uint32_t* ids, int cnt, float* dists) {
 		if constexpr (NB > 0) {
-			batch_distances_fixed<kMetric, NB>(p, qreg, ids, cnt, dists, lane);
+			batch_distances_fixed<kMetric, NB, kQLds>(p, qreg, q_s, ids, cnt, dists, lane);
 		} else {
 			batch_distances<kMetric>(p, q, ids, cnt, dists, lane);
 		}
@@ -300,7 +311,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 
 template <bool kGlobalCand, int NB>
 static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
-	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8;
+	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8 + size_t(NB) * 256;   // heaps + the query fragment (NB*16 float4)
 	switch (metric) {
 		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;
 		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;

@@ -247,16 +247,19 @@ __global__ __launch_bounds__(64) void knn_query_stats(const float* queries, uint
 	if (lane == 0) {
 		q_sq[qi] = s;
 		const float u = 5.9604645e-08f;   // 2^-24
-		float gamma = 1.1f * float(dim + 64) * u;   // covers both summation trees (D-chain vs 64-chain + fold), 10% slack
-		if constexpr (kBf16) gamma = gamma * 1.004f + 1.01f * 0.00390625f;   // rne_bf16 on q and x: (1+2^-9)^2 - 1 <= 2^-8 (1 + 2^-10)
+		const float gamma = 1.1f * float(dim + 64) * u;   // f32 accumulation: covers both summation trees (D-chain vs 64-chain + fold), 10% slack
+		// rne_bf16 on q and x: |q~.x~ - q.x| <= ((1+2^-9)^2 - 1) sum|q_i x_i| <= 2^-8 (1 + 2^-10) |q||x|   (only the inner product is affected:
+		// |q|^2 and |x|^2 of the L2 form come from the f32 data)
+		const float gb = kBf16 ? 1.01f * 0.00390625f : 0.0f;
 		const float xmax2 = __uint_as_float(stats[0]);
 		float eps;
 		if constexpr (kMetric == kL2) {
-			eps = 2.0f * gamma * (s + xmax2);   // 2*gamma*|q||x| <= gamma*(qq+xx), plus the roundings of qq, xx and of the reference's own sum
+			// d = (qq + xx) - 2 ip: 2*gamma*|q||x| <= gamma*(qq+xx), plus the roundings of qq, xx and of the reference's own sum; bf16 adds 2*gb*|q||x|
+			eps = 2.0f * gamma * (s + xmax2) + 2.0f * gb * sqrtf(s) * sqrtf(xmax2);
 		} else if constexpr (kMetric == kIP) {
-			eps = gamma * sqrtf(s) * sqrtf(xmax2);
+			eps = (gamma + gb) * sqrtf(s) * sqrtf(xmax2);
 		} else {
-			eps = (gamma + 4.0f * u) * sqrtf(s) * sqrtf(__uint_as_float(stats[1]));
+			eps = (gamma + gb + 4.0f * u) * sqrtf(s) * sqrtf(__uint_as_float(stats[1]));
 		}
 		// bf16 MFMA may flush subnormal inputs: at most dim * 2^-126 * (|q| + max|x|), far below the 1e-30 floor added here
 		margin[qi] = 2.0f * eps * 1.01f + (kBf16 ? 1e-30f : 1e-37f);

@@ -933,8 +933,11 @@ int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, ui
 	if (int rc = c->d_out_dist.ensure(size_t(n) * sizeof(float)); rc) return rc;
 	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, query, h->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
 	RX_HIP(hipMemcpyAsync(c->d_out_row.ptr, rows, size_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-	rxgpu::launch_distances(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr), h->stride, h->dim,
+	{
+		ProfileScope ps(h, "distances", c->stream);
+		rxgpu::launch_distances(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr), h->stride, h->dim,
 							static_cast<const uint32_t*>(c->d_out_row.ptr), n, static_cast<float*>(c->d_out_dist.ptr), c->stream);
+	}
 	RX_HIP(hipGetLastError());
 	RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(n) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipStreamSynchronize(c->stream));
@@ -1050,7 +1053,8 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 	p.out_count = static_cast<uint32_t*>(c->d_out_count.ptr);
 	p.stats = h->d_hnsw_stats;
 	p.ef_cap = (ef + 63u) & ~63u;
-	p.lds_cand_cap = ef <= 256 ? 1024u : uint32_t(rxgpu::kHnswCandLds);   // typical candidate heaps stay within a few x ef
+	// typical candidate heaps stay within a few x ef; a smaller LDS footprint keeps more searches resident per CU (overflow -> global-heap re-run)
+	p.lds_cand_cap = ef <= 128 ? 512u : ef <= 256 ? 1024u : uint32_t(rxgpu::kHnswCandLds);
 	if (const char* e = getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // test hook: force the global-heap re-run
 		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, atoi(e))));
 	}
