@@ -1053,8 +1053,9 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 	p.out_count = static_cast<uint32_t*>(c->d_out_count.ptr);
 	p.stats = h->d_hnsw_stats;
 	p.ef_cap = (ef + 63u) & ~63u;
-	// typical candidate heaps stay within a few x ef; a smaller LDS footprint keeps more searches resident per CU (overflow -> global-heap re-run)
-	p.lds_cand_cap = ef <= 128 ? 512u : ef <= 256 ? 1024u : uint32_t(rxgpu::kHnswCandLds);
+	// typical candidate heaps stay within a few x ef.  Measured at 1M x 768, ef = 128: 512 entries overflow for a handful of queries and the
+	// global-heap re-run costs more than the extra occupancy brings (1.07 M q/s at 1024 against 0.43 M at 512 and 0.86 M at 768)
+	p.lds_cand_cap = ef <= 256 ? 1024u : uint32_t(rxgpu::kHnswCandLds);
 	if (const char* e = getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // test hook: force the global-heap re-run
 		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, atoi(e))));
 	}

@@ -73,6 +73,24 @@ struct DevGuard {
 		if (prev >= 0) (void)hipSetDevice(prev);
 	}
 };
+// HIP event pair that cannot leak on an early error return
+struct EventPair {
+	hipEvent_t a = nullptr, b = nullptr;
+	int create() {
+		RX_HIP(hipEventCreate(&a));
+		RX_HIP(hipEventCreate(&b));
+		return RXGPU_OK;
+	}
+	float elapsed_ms() const {
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, a, b);
+		return ms;
+	}
+	~EventPair() {
+		if (a) (void)hipEventDestroy(a);
+		if (b) (void)hipEventDestroy(b);
+	}
+};
 template <typename T>
 int upload(T*& dst, const T* src, size_t count) {
 	if (dst) (void)hipFree(dst);
@@ -280,10 +298,9 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 	rxgpu::FtSlots slots{};
 	if (int rc = carve_slots(h, size_t(max_merged), slots); rc) return rc;
 
-	hipEvent_t e0, e1;
-	RX_HIP(hipEventCreate(&e0));
-	RX_HIP(hipEventCreate(&e1));
-	RX_HIP(hipEventRecord(e0, st));
+	EventPair ev;
+	if (int rc = ev.create(); rc) return rc;
+	RX_HIP(hipEventRecord(ev.a, st));
 	uint32_t launch = 0;
 	uint64_t lb_used = 0;
 	for (uint32_t s = 0; s < nsub; ++s) {   // sub-terms in SortSubterms order; documents are unique inside one: a launch is race free
@@ -322,16 +339,13 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 		lb_used += rxgpu::ft_pass_blocks(subs[s].n);
 		++launch;
 	}
-	RX_HIP(hipEventRecord(e1, st));
+	RX_HIP(hipEventRecord(ev.b, st));
 	RX_HIP(hipGetLastError());
 	uint32_t tail[2] = {0, 0};
 	RX_HIP(hipMemcpyAsync(&tail[0], d_num_docs + launch, 4, hipMemcpyDeviceToHost, st));
 	RX_HIP(hipMemcpyAsync(&tail[1], d_error, 4, hipMemcpyDeviceToHost, st));
 	RX_HIP(hipStreamSynchronize(st));
-	float ms = 0.f;
-	(void)hipEventElapsedTime(&ms, e0, e1);
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
+	const float ms = ev.elapsed_ms();
 	h->stat_postings += total;
 	h->stat_ms += ms;
 	RX_CHECK(tail[1] == 0, RXGPU_ERR_DEVICE, "rxgpu_ft_merge_simple_raw: ordered look-back timed out on the device");
@@ -559,10 +573,9 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	rxgpu::FtSlots slots{};
 	if (int rc = carve_slots(h, size_t(max_merged), slots); rc) return rc;
 
-	hipEvent_t e0, e1;
-	RX_HIP(hipEventCreate(&e0));
-	RX_HIP(hipEventCreate(&e1));
-	RX_HIP(hipEventRecord(e0, st));
+	EventPair ev;
+	if (int rc = ev.create(); rc) return rc;
+	RX_HIP(hipEventRecord(ev.a, st));
 	uint32_t launch = 0;
 	uint64_t lb_used = 0, merged_postings = 0;
 	uint16_t qp = 0;
@@ -608,16 +621,13 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 			++launch;
 		}
 	}
-	RX_HIP(hipEventRecord(e1, st));
+	RX_HIP(hipEventRecord(ev.b, st));
 	RX_HIP(hipGetLastError());
 	uint32_t tail[2] = {0, 0};   // numDocs, error flag
 	RX_HIP(hipMemcpyAsync(&tail[0], d_num_docs + launch, 4, hipMemcpyDeviceToHost, st));
 	RX_HIP(hipMemcpyAsync(&tail[1], d_error, 4, hipMemcpyDeviceToHost, st));
 	RX_HIP(hipStreamSynchronize(st));
-	float ms = 0.f;
-	(void)hipEventElapsedTime(&ms, e0, e1);
-	(void)hipEventDestroy(e0);
-	(void)hipEventDestroy(e1);
+	const float ms = ev.elapsed_ms();
 	h->stat_postings += merged_postings;
 	h->stat_ms += ms;
 	RX_CHECK(tail[1] == 0, RXGPU_ERR_DEVICE, "rxgpu_ft_merge_terms_raw: ordered look-back timed out on the device");
