@@ -91,7 +91,7 @@ __device__ __forceinline__ void batch_distances(const HnswParams& p, const float
 // issued before the first reduction — one HBM round trip per 8 neighbours instead of three per 4.
 // kQLds: the query fragment is re-read from LDS (ds_read_b128) instead of living in NB*4 VGPRs — 48 fewer registers at D = 768, which is
 // what lets four of these wavefronts (instead of two) share a SIMD: the search is latency-bound, occupancy is throughput.
-template <int kMetric, int NB, bool kQLds>
+template <int kMetric, int NB, bool kQLds, bool kTwoSets>
 __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const float4 (&q)[kQLds ? 1 : NB], const float4* qlds, const uint32_t* ids,
 													  int cnt, float* dists, int lane) {
 	const int m = lane & 15, g = lane >> 4;
@@ -102,7 +102,7 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 			return q[t];
 		}
 	};
-	for (int base = 0; base < cnt; base += (NB <= 8 ? 2 : 1) * kRowsPerWave) {
+	for (int base = 0; base < cnt; base += (kTwoSets ? 2 : 1) * kRowsPerWave) {
 		const int ia = base + g, ib = base + kRowsPerWave + g;
 		const bool oka = ia < cnt, okb = ib < cnt;
 		const uint64_t ra = ids[oka ? ia : base], rb = ids[okb ? ib : base];
@@ -111,7 +111,7 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 		float4 xa[NB], xb[NB];
 #pragma unroll
 		for (int t = 0; t < NB; ++t) xa[t] = pa[16 * t];
-		const bool second = NB <= 8 && base + kRowsPerWave < cnt;   // wave-uniform; at D = 768 one row set per trip keeps the kernel at 4 waves per SIMD
+		const bool second = kTwoSets && base + kRowsPerWave < cnt;   // wave-uniform; one row set per trip keeps the D = 768 kernel at 4+ waves per SIMD
 		if (second) {
 #pragma unroll
 			for (int t = 0; t < NB; ++t) xb[t] = pb[16 * t];
@@ -132,7 +132,9 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 	}
 }
 
-template <int kMetric, bool kGlobalCand, int NB>
+// kLatency: few queries in flight -> two row sets per distance trip (fewer dependent round trips per hop, 172 VGPRs at D = 768);
+// otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
+template <int kMetric, bool kGlobalCand, int NB, bool kLatency>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	}
 	auto distances = [&](const uint32_t* ids, int cnt, float* dists) {
 		if constexpr (NB > 0) {
-			batch_distances_fixed<kMetric, NB, kQLds>(p, qreg, q_s, ids, cnt, dists, lane);
+			batch_distances_fixed<kMetric, NB, kQLds, (kLatency || NB <= 8)>(p, qreg, q_s, ids, cnt, dists, lane);
 		} else {
 			batch_distances<kMetric>(p, q, ids, cnt, dists, lane);
 		}
@@ -312,11 +314,22 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 template <bool kGlobalCand, int NB>
 static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
 	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8 + size_t(NB) * 256;   // heaps + the query fragment (NB*16 float4)
+	constexpr bool kHasLatencyVariant = NB > 8;
+	const bool latency = kHasLatencyVariant && blocks < 2048;   // fewer searches than the GPU holds anyway: spend registers on fewer round trips
+#define RX_HNSW(M)                                                                                                        \
+	do {                                                                                                                  \
+		if (latency) {                                                                                                    \
+			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, kHasLatencyVariant>), dim3(blocks), dim3(64), lds, s, p); \
+		} else {                                                                                                          \
+			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, false>), dim3(blocks), dim3(64), lds, s, p);          \
+		}                                                                                                                 \
+	} while (0)
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;
-		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;
-		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kL2: RX_HNSW(kL2); break;
+		case kIP: RX_HNSW(kIP); break;
+		default: RX_HNSW(kCos); break;
 	}
+#undef RX_HNSW
 }
 
 template <bool kGlobalCand>
