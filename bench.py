@@ -195,7 +195,7 @@ def batched_leg(args, ix, queries: torch.Tensor, device, kk: int):
     same_rows = bool(torch.equal(srow[:nchk], orow[:nchk]))
     same_bits = bool(torch.equal(sd[:nchk].view(torch.int32), od[:nchk].view(torch.int32)))
     per_batch = (t1 - t0) / args.batch_iters
-    bf16_min = int(os.environ.get("RXGPU_BATCH_BF16_MIN", "65"))
+    bf16_min = int(os.environ.get("RXGPU_BATCH_BF16_MIN", "2"))
     bf16 = bf16_min > 0 and B >= bf16_min
     mt = 256 if bf16 else (32 if B <= 32 else 64 if B <= 64 else 128 if B <= 128 else 256)
     kpad = (args.dim + 63) // 64 * 64 if bf16 else args.dim

@@ -228,7 +228,12 @@ int ensure_bf16_shadow(rxgpu_index* h, hipStream_t s) {
 		if (h->d_rows_bf16) (void)hipFree(h->d_rows_bf16);
 		h->d_rows_bf16 = nullptr;
 		h->bf16_capacity = 0;
-		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_rows_bf16), need * ld * sizeof(uint16_t)));
+		if (hipMalloc(reinterpret_cast<void**>(&h->d_rows_bf16), need * ld * sizeof(uint16_t)) != hipSuccess) {
+			(void)hipGetLastError();   // not an error of the search: the caller falls back to the f32 rows
+			h->d_rows_bf16 = nullptr;
+			h->bf16_unavailable = true;
+			return RXGPU_ERR_NOMEM;
+		}
 		h->bf16_capacity = need;
 	}
 	rxgpu::launch_to_bf16(h->d_rows, h->count, h->stride, h->dim, h->d_rows_bf16, ld, h->cus, s);
@@ -238,15 +243,12 @@ int ensure_bf16_shadow(rxgpu_index* h, hipStream_t s) {
 	return RXGPU_OK;
 }
 
-static int batch_bf16_min_queries() {
-	static const int v = [] {
-		const char* e = getenv("RXGPU_BATCH_BF16_MIN");   // 0 disables the bf16 nomination path
-		return e ? atoi(e) : 65;
-	}();
-	return v;
+static int batch_bf16_min_queries() {   // read per call (tests and A/B runs switch it)
+	const char* e = getenv("RXGPU_BATCH_BF16_MIN");   // 0 disables the bf16 nomination path
+	return e ? atoi(e) : 2;   // measured at 10M x 768: 4.8-5.0 ms per batch for 8..256 queries against 6.2-10.6 ms on the f32 rows
 }
 
-// Batches of more than 64 queries: nomination on the bf16 MFMA pipe over the bf16 shadow (knn_batched_bf16.hip), then the same exact tail.
+// Every batch (2..256 queries at a time): nomination on the bf16 MFMA pipe over the bf16 shadow (knn_batched_bf16.hip), then the same exact tail.
 int enqueue_knn_batched_bf16(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t q0, uint32_t cq, uint32_t kk,
 							 float* d_out_dist, uint32_t* d_out_row, uint32_t* d_out_count) {
 	if (int rc = ensure_bf16_shadow(h, c->stream); rc) return rc;
@@ -349,9 +351,10 @@ int enqueue_knn_batched(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_quer
 	const uint32_t cap = uint32_t((cap64 + 63) & ~63ull);
 	for (uint32_t q0 = 0; q0 < nq; q0 += 256) {
 		const uint32_t cq = std::min<uint32_t>(256, nq - q0);
-		if (batch_bf16_min_queries() > 0 && int(cq) >= batch_bf16_min_queries()) {
-			if (int rc = enqueue_knn_batched_bf16(h, c, d_queries, q0, cq, kk, d_out_dist, d_out_row, d_out_count); rc) return rc;
-			continue;
+		if (batch_bf16_min_queries() > 0 && int(cq) >= batch_bf16_min_queries() && !h->bf16_unavailable) {
+			const int rc = enqueue_knn_batched_bf16(h, c, d_queries, q0, cq, kk, d_out_dist, d_out_row, d_out_count);
+			if (rc == RXGPU_OK) continue;
+			if (!(rc == RXGPU_ERR_NOMEM && h->bf16_unavailable)) return rc;   // no room for the shadow: f32 nomination below
 		}
 		const int mt = cq <= 32 ? 32 : cq <= 64 ? 64 : cq <= 128 ? 128 : 256;
 		if (int rc = c->d_qpad.ensure(size_t(mt) * q_stride * sizeof(float)); rc) return rc;
@@ -531,8 +534,9 @@ int enqueue_knn_pruned(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queri
 
 int enqueue_knn(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
 				uint32_t* d_out_row, uint32_t* d_out_count) {
-	if (scan_bf16_enabled() && nq <= kPrunedMaxQueries && rxgpu::scan_bf16_supported((h->dim + 63u) & ~63u)) {
-		return enqueue_knn_pruned(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
+	if (scan_bf16_enabled() && nq <= kPrunedMaxQueries && !h->bf16_unavailable && rxgpu::scan_bf16_supported((h->dim + 63u) & ~63u)) {
+		const int rc = enqueue_knn_pruned(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
+		if (!(rc == RXGPU_ERR_NOMEM && h->bf16_unavailable)) return rc;
 	}
 	if (int(nq) >= batch_min_queries() && nq >= 2) return enqueue_knn_batched(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);
 	return enqueue_knn_fused(h, c, d_queries, nq, kk, d_out_dist, d_out_row, d_out_count);

@@ -194,6 +194,7 @@ struct rxgpu_index {
 	uint16_t* d_rows_bf16 = nullptr;   // bf16 shadow of the rows for the nomination GEMM (built lazily with the row statistics)
 	uint64_t bf16_capacity = 0;
 	bool bf16_valid = false;
+	bool bf16_unavailable = false;     // the shadow did not fit in HBM: nominate on the f32 rows instead (still exact, still on the GPU)
 
 	// HNSW graph mirror (rxgpu_hnsw_attach_graph)
 	uint32_t* d_links0 = nullptr;

@@ -24,9 +24,18 @@ def check_batch(ix, oracle, metric, rows, inv, queries, kk):
         assert np.array_equal(bits(dist[qi, :c]), bits(wd))
 
 
+@pytest.fixture(params=["bf16", "f32"])
+def nomination(request, monkeypatch):
+    """Both nomination GEMMs: bf16 matrix cores over the shadow (default for every batch) and f32-input MFMA over the rows (what a GPU
+    without room for the shadow falls back to)."""
+    if request.param == "f32":
+        monkeypatch.setenv("RXGPU_BATCH_BF16_MIN", "0")
+    return request.param
+
+
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("d", [24, 100, 128, 768])
-def test_batched_equals_sequential(rxgpu, oracle, metric, d):
+def test_batched_equals_sequential(rxgpu, oracle, nomination, metric, d):
     n = 40_000 if d <= 128 else 12_000
     rows = make_corpus(d, n, d)
     inv = oracle.l2_modules(rows) if metric == 2 else None
