@@ -11,9 +11,10 @@
 // by ~2 ms of HBM (15.4 GB shadow) / ~1.6 ms of MFMA (3.93 TFLOP at 2.5 PFLOP/s) instead of 25 ms of f32-input MFMA.
 //
 // Tile: 256 corpus rows x 256 queries per workgroup (512 threads = 8 waves as 4 row-pairs x 2 query halves; each wave owns
-// 2 x 4 blocks of 32x32 -> 128 accumulator VGPRs), K staged 64 bf16 (one 128-byte line per row) per step through LDS, double
-// buffered, one barrier per step.  Both MFMA operands want 8 k-contiguous bf16 per lane = one ds_read_b128 from a row-major LDS
-// image; rows are pitched 144 B so the 16 lanes of a read phase hit 16 distinct 16-byte bank groups.
+// 2 x 4 blocks of 32x32 -> 128 accumulator VGPRs).  Both MFMA operands want 8 k-contiguous bf16 per lane = one ds_read_b128 from a
+// row-major LDS image.  A first version staged the operands through registers (8.1 -> 7.3 ms per 256 queries once its loads were made
+// unconditional and pinned ahead of the MFMAs); HBM latency (~2 us) is several times what one K-stage takes to multiply, so the kernel
+// below keeps three stages in flight by LDS-DMA instead (4.8 ms).
 #include <cstdlib>
 
 #include "knn_kernels.hip.h"
@@ -28,9 +29,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBfThreads = 512;
 constexpr int kBfRows = 256;       // corpus rows per tile
 constexpr int kBfQueries = 256;    // queries per tile (batches are padded to 256)
-constexpr int kBfKS = 32;          // bf16 elements of the dimension per stage (64 B per row)
-constexpr int kBfPitch = 40;       // LDS row pitch in bf16 elements (80 B): 5r mod 16 is a bijection on every ds_read_b128 lane group
-constexpr int kBfStageElems = kBfRows * kBfPitch;
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 	uint32_t u = __float_as_uint(f);
@@ -54,158 +52,6 @@ __global__ __launch_bounds__(256) void knn_to_bf16(const float* src, uint64_t n,
 			w[j] = uint32_t(f32_to_bf16_rne(a)) | (uint32_t(f32_to_bf16_rne(b)) << 16);
 		}
 		*reinterpret_cast<uint4*>(dst + row * ld + k) = make_uint4(w[0], w[1], w[2], w[3]);
-	}
-}
-
-template <int kMetric, int kMode>
-__global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16(GemmBf16Params p) {
-	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];
-	uint16_t* x_s = reinterpret_cast<uint16_t*>(bf_lds);            // [2][256][pitch]
-	uint16_t* q_s = x_s + 2 * kBfStageElems;                        // [2][256][pitch]
-	float* thr_s = reinterpret_cast<float*>(q_s + 2 * kBfStageElems);   // [256]
-	float* aux_s = thr_s + kBfQueries;                              // [256] |q|^2 (L2)
-
-	const int tid = threadIdx.x, lane = tid & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const int rp = wave & 3;    // rows [64 rp, +64) of the tile
-	const int qh = wave >> 2;   // queries [128 qh, +128)
-	const uint32_t stages = p.ld / kBfKS;
-	const uint64_t ntiles = (p.n + kBfRows - 1) / kBfRows;
-	for (int i = tid; i < kBfQueries; i += kBfThreads) {
-		thr_s[i] = kMode == kGemmFilter ? p.thr[i] : 0.f;
-		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
-	}
-
-	for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-		const uint64_t row0 = tile * kBfRows;
-		f32x16 acc[2][4];
-#pragma unroll
-		for (int a = 0; a < 2; ++a) {
-#pragma unroll
-			for (int b = 0; b < 4; ++b) {
-#pragma unroll
-				for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-			}
-		}
-		constexpr int kLoads = kBfRows * kBfKS * 2 / 16 / kBfThreads;   // 16-byte chunks per thread per operand per stage
-		constexpr int kChunks = kBfKS / 8;                              // chunks per row
-		// Per-thread staging addresses: chunk idx = tid + i*512 -> row idx / kChunks, 16-byte chunk idx % kChunks.  Rows past the end are
-		// clamped, not zeroed (their scores are discarded by row_ok in the epilogue); every load is unconditional so that the loads of a
-		// stage stay in flight together behind the MFMAs of the previous one.
-		const uint16_t* xsrc[kLoads];
-		const uint16_t* qsrc[kLoads];
-		uint32_t soff[kLoads];
-#pragma unroll
-		for (int i = 0; i < kLoads; ++i) {
-			const int idx = tid + i * kBfThreads;
-			const uint32_t r = idx / kChunks, c = (idx % kChunks) << 3;
-			const uint64_t row = (row0 + r < p.n ? row0 + r : p.n - 1) * p.row_step;
-			xsrc[i] = p.rows + row * p.ld + c;
-			qsrc[i] = p.queries + size_t(r) * p.ld + c;
-			soff[i] = r * kBfPitch + c;
-		}
-		u32x4 xr[kLoads], qr[kLoads];
-#pragma unroll
-		for (int i = 0; i < kLoads; ++i) {
-			xr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i]));
-			qr[i] = *reinterpret_cast<const u32x4*>(qsrc[i]);
-		}
-		for (uint32_t s = 0; s < stages; ++s) {
-			const int buf = s & 1;
-			// stage s: registers -> LDS buffer `buf` (last read two barriers ago), then everyone may read it
-#pragma unroll
-			for (int i = 0; i < kLoads; ++i) {
-				*reinterpret_cast<u32x4*>(x_s + buf * kBfStageElems + soff[i]) = xr[i];
-				*reinterpret_cast<u32x4*>(q_s + buf * kBfStageElems + soff[i]) = qr[i];
-			}
-			__syncthreads();
-			// stage s+1 (wrapping to 0 at the end: a harmless reload) travels while stage s is multiplied
-			const uint32_t kn = (s + 1 < stages ? s + 1 : 0) * kBfKS;
-#pragma unroll
-			for (int i = 0; i < kLoads; ++i) {
-				xr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(xsrc[i] + kn));
-				qr[i] = *reinterpret_cast<const u32x4*>(qsrc[i] + kn);
-			}
-			__builtin_amdgcn_sched_barrier(0);   // keep the loads issued HERE: the scheduler otherwise sinks them below the MFMAs, next to their use
-			const uint16_t* xb = x_s + buf * kBfStageElems + (64 * rp + (lane & 31)) * kBfPitch + 8 * (lane >> 5);
-			const uint16_t* qb = q_s + buf * kBfStageElems + (128 * qh + (lane & 31)) * kBfPitch + 8 * (lane >> 5);
-#pragma unroll
-			for (int t = 0; t < kBfKS / 16; ++t) {
-				bf16x8 bfrag[2], afrag[4];
-#pragma unroll
-				for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + a * 32 * kBfPitch + 16 * t));
-#pragma unroll
-				for (int b = 0; b < 4; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + b * 32 * kBfPitch + 16 * t));
-#pragma unroll
-				for (int a = 0; a < 2; ++a) {
-#pragma unroll
-					for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
-				}
-			}
-		}
-		__syncthreads();   // the last stage's fragment reads are done before the next tile overwrites buffer 0
-
-		// epilogue: element (query i, row j) of block (a, b): j = lane&31, i = (r&3) + 8(r>>2) + 4(lane>>5)
-#pragma unroll
-		for (int a = 0; a < 2; ++a) {
-			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
-			const bool row_ok = row < p.n;
-			const uint64_t rowc = (row_ok ? row : p.n - 1) * p.row_step;
-			float row_term = 0.f;
-			if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];
-			if constexpr (kMetric == kCos) row_term = p.inv_norms[rowc];
-			const int qlane = 4 * (lane >> 5) + 128 * qh;
-			if constexpr (kMode == kGemmDense) {
-				float* dp = p.dense + size_t(qlane) * p.n + row;
-				const size_t n1 = p.n, n5 = 5 * p.n;
-#pragma unroll
-				for (int b = 0; b < 4; ++b) {
-#pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
-						float d;
-						if constexpr (kMetric == kL2) {
-							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
-						} else if constexpr (kMetric == kIP) {
-							d = -acc[a][b][r];
-						} else {
-							d = -acc[a][b][r] * row_term;
-						}
-						if (row_ok) *dp = d;
-						dp += ((r & 3) == 3) ? n5 : n1;
-						asm volatile("" : "+v"(dp));
-					}
-				}
-			} else {
-#pragma unroll
-				for (int b = 0; b < 4; ++b) {
-					uint32_t mask = 0;
-#pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
-						float d;
-						if constexpr (kMetric == kL2) {
-							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
-						} else if constexpr (kMetric == kIP) {
-							d = -acc[a][b][r];
-						} else {
-							d = -acc[a][b][r] * row_term;
-						}
-						mask |= (d <= thr_s[qo + qlane]) ? (1u << r) : 0u;   // padded queries carry thr = -inf
-					}
-					if (!row_ok) mask = 0;
-					if (__ballot(mask != 0)) {
-						while (mask) {
-							const int r = __builtin_ctz(mask);
-							mask &= mask - 1;
-							const uint32_t qi = 32 * b + (r & 3) + 8 * (r >> 2) + qlane;
-							const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
-							if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(row);
-						}
-					}
-				}
-			}
-		}
 	}
 }
 
@@ -409,55 +255,18 @@ static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, h
 	return hipGetLastError();
 }
 
-static bool bf16_use_glds() {
-	static const bool v = [] {
-		const char* e = getenv("RXGPU_BF16_GLDS");
-		return e ? atoi(e) != 0 : true;
-	}();
-	return v;
-}
-
-size_t gemm_bf16_lds_bytes() { return size_t(4) * kBfStageElems * sizeof(uint16_t) + 2 * kBfQueries * sizeof(float); }
-
-template <int kMetric, int kMode>
-static hipError_t launch_bf16_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
-	const size_t lds = gemm_bf16_lds_bytes();
-	static bool attr_set = false;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm_bf16<kMetric, kMode>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-		if (e != hipSuccess) return e;
-		attr_set = true;
-	}
-	hipLaunchKernelGGL((knn_gemm_bf16<kMetric, kMode>), dim3(grid), dim3(kBfThreads), lds, s, p);
-	return hipGetLastError();
-}
-
 hipError_t launch_gemm_bf16(int metric, int mode, const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
-	if (bf16_use_glds()) {
-		if (mode == kGemmDense) {
-			switch (metric) {
-				case kL2: return launch_bf16_glds_one<kL2, kGemmDense>(p, grid, s);
-				case kIP: return launch_bf16_glds_one<kIP, kGemmDense>(p, grid, s);
-				default: return launch_bf16_glds_one<kCos, kGemmDense>(p, grid, s);
-			}
-		}
-		switch (metric) {
-			case kL2: return launch_bf16_glds_one<kL2, kGemmFilter>(p, grid, s);
-			case kIP: return launch_bf16_glds_one<kIP, kGemmFilter>(p, grid, s);
-			default: return launch_bf16_glds_one<kCos, kGemmFilter>(p, grid, s);
-		}
-	}
 	if (mode == kGemmDense) {
 		switch (metric) {
-			case kL2: return launch_bf16_one<kL2, kGemmDense>(p, grid, s);
-			case kIP: return launch_bf16_one<kIP, kGemmDense>(p, grid, s);
-			default: return launch_bf16_one<kCos, kGemmDense>(p, grid, s);
+			case kL2: return launch_bf16_glds_one<kL2, kGemmDense>(p, grid, s);
+			case kIP: return launch_bf16_glds_one<kIP, kGemmDense>(p, grid, s);
+			default: return launch_bf16_glds_one<kCos, kGemmDense>(p, grid, s);
 		}
 	}
 	switch (metric) {
-		case kL2: return launch_bf16_one<kL2, kGemmFilter>(p, grid, s);
-		case kIP: return launch_bf16_one<kIP, kGemmFilter>(p, grid, s);
-		default: return launch_bf16_one<kCos, kGemmFilter>(p, grid, s);
+		case kL2: return launch_bf16_glds_one<kL2, kGemmFilter>(p, grid, s);
+		case kIP: return launch_bf16_glds_one<kIP, kGemmFilter>(p, grid, s);
+		default: return launch_bf16_glds_one<kCos, kGemmFilter>(p, grid, s);
 	}
 }
 
