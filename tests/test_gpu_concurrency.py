@@ -1,0 +1,97 @@
+"""-m gpu: the reference's threading contract for reads — any number of query threads search one index concurrently under the namespace's
+shared lock (SURVEY §8b "Threading"; the reference test helper runs 4 threads x 20 queries, gtests/tests/unit/float_vector_index.cc:258-294).
+Every engine entry must be re-entrant: results of concurrent calls equal the sequential ones, bit for bit."""
+import threading
+
+import numpy as np
+import pytest
+
+from .conftest import make_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_threads(n_threads, fn):
+    errs, out = [], [None] * n_threads
+
+    def work(t):
+        try:
+            out[t] = fn(t)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    return out
+
+
+@pytest.mark.parametrize("pruned", [False, True])
+def test_concurrent_bruteforce_searches(rxgpu, oracle, monkeypatch, pruned):
+    if pruned:
+        monkeypatch.setenv("RXGPU_SCAN_BF16", "1")
+    n, d, k = 60_000, 128, 10
+    rows = make_corpus(51, n, d)
+    queries = make_corpus(52, 64, d)
+    with rxgpu.VectorIndex("l2", d, n) as ix:
+        ix.upload_rows(0, rows)
+        want = [ix.search_knn(queries[i:i + 1], k) for i in range(64)]                 # sequential, batch 1
+        want_b = ix.search_knn(queries, k)                                             # sequential, one batch
+
+        def fn(t):
+            res = []
+            for j in range(20):
+                i = (t * 7 + j) % 64
+                res.append((i, ix.search_knn(queries[i:i + 1], k)))
+            res.append(("batch", ix.search_knn(queries, k)))                           # batched path from several threads at once
+            return res
+
+        for res in _run_threads(8, fn):
+            for i, (dist, row, cnt) in res:
+                wd, wr, wc = want_b if i == "batch" else want[i]
+                assert np.array_equal(row, wr) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32)) and np.array_equal(cnt, wc)
+
+
+def test_concurrent_map_hnsw_and_ft(rxgpu, oracle):
+    from reindexer_amd import hostapi
+    from .test_bm25_oracle import _multi_case
+    n, d = 4000, 64
+    rows = make_corpus(53, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    queries = make_corpus(54, 32, d)
+    bf = hostapi.GpuBruteforceMap(0, d, n)
+    bf.add(rows, labels)
+    hn = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=100)
+    hn.add(rows, labels)
+    _, words, avg, removed, excluded, terms, store = _multi_case(3, 3, 3000, 20000, (2, 1), False, None)
+    ft = hostapi.GpuFtMerger(3)
+    ft.set_docs(words, avg, removed)
+    for s in store:
+        ft.set_word_fpos(s["word"], s)
+    cfg = hostapi.default_ft_config(3)
+    gterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    want_bf = [bf.search_knn(q, 10) for q in queries]
+    want_hn = [hn.search_knn(q, 10, 64) for q in queries]
+    want_ft = ft.merge_query(cfg, gterms, excluded, sort_by_rank=False)
+
+    def fn(t):
+        ok = True
+        for j in range(12):
+            i = (t * 5 + j) % 32
+            a, b = bf.search_knn(queries[i], 10), hn.search_knn(queries[i], 10, 64)
+            ok &= all(np.array_equal(x, y) for x, y in zip(a, want_bf[i])) and all(np.array_equal(x, y) for x, y in zip(b, want_hn[i]))
+            if j % 4 == 0:
+                f = ft.merge_query(cfg, gterms, excluded, sort_by_rank=False)
+                ok &= all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(f[:4], want_ft[:4]))
+            if j % 6 == 0:   # a streaming session of its own per thread
+                s = hn.stream(queries[i], 16)
+                got = [s.next(5)[1] for _ in range(3)]
+                s.close()
+                ok &= len(np.unique(np.concatenate(got))) == sum(len(g) for g in got)
+        return ok
+
+    assert all(_run_threads(6, fn))
+    bf.close()
+    hn.close()
+    ft.close()
