@@ -20,6 +20,12 @@ def test_bruteforce_fuzz_short(rxgpu):
     assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_hnsw_fuzz_short(rxgpu):
+    out = subprocess.run([sys.executable, str(ROOT / "tools" / "fuzz_hnsw.py"), "--seconds", "10", "--seed", "5"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "hnsw fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_bm25_multi_term_fuzz_short(rxgpu, oracle):
     from reindexer_amd import hostapi
     ft = FtOracle(oracle)
