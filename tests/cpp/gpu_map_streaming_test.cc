@@ -113,6 +113,6 @@ int main() {
 		std::fprintf(stderr, "%d check(s) failed\n", g_failures);
 		return 1;
 	}
-	std::puts("HnswStreamingSearchTest: all checks passed");
+	std::puts("GpuMapStreamingTest: all checks passed");
 	return 0;
 }
