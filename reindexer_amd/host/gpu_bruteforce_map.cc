@@ -201,6 +201,77 @@ void GpuBruteforceMap::syncDevice() const {
 //   * a row with dist < d_k is always admitted and never evicted;
 //   * while fewer than k rows with dist <= d_k have been seen the worst is > d_k, so such rows are admitted;
 //   * afterwards ties are rejected and every better row evicts the tie with the LARGEST LABEL.
+struct GpuBruteforceMap::PendingQuery {
+	const float* query;
+	uint32_t kk;
+	float* dist;
+	uint32_t* row;
+	uint32_t* count;
+	bool done = false;
+	int rc = 0;
+	std::string error;
+};
+
+// One device round trip for every query of the batch; each caller gets the first kk_i entries of its exact top-kk_max list.
+void GpuBruteforceMap::runBatch(std::vector<PendingQuery*>& batch) const {
+	if (batch.size() == 1) {
+		PendingQuery& p = *batch[0];
+		p.rc = rxgpu_search_knn(dev_, p.query, 1, p.kk, p.dist, p.row, p.count);
+		if (p.rc != RXGPU_OK) p.error = rxgpu_last_error();
+		return;
+	}
+	uint32_t kkMax = 0;
+	for (const PendingQuery* p : batch) kkMax = std::max(kkMax, p->kk);
+	const size_t nq = batch.size();
+	std::vector<float> queries(nq * dim_), dist(nq * kkMax);
+	std::vector<uint32_t> row(nq * kkMax), count(nq);
+	for (size_t i = 0; i < nq; ++i) std::copy(batch[i]->query, batch[i]->query + dim_, queries.begin() + i * dim_);
+	const int rc = rxgpu_search_knn(dev_, queries.data(), uint32_t(nq), kkMax, dist.data(), row.data(), count.data());
+	const std::string error = rc != RXGPU_OK ? rxgpu_last_error() : "";
+	for (size_t i = 0; i < nq; ++i) {
+		PendingQuery& p = *batch[i];
+		p.rc = rc;
+		p.error = error;
+		if (rc != RXGPU_OK) continue;
+		const uint32_t n = std::min(p.kk, count[i]);
+		std::copy(dist.begin() + i * kkMax, dist.begin() + i * kkMax + n, p.dist);
+		std::copy(row.begin() + i * kkMax, row.begin() + i * kkMax + n, p.row);
+		*p.count = n;
+	}
+}
+
+void GpuBruteforceMap::fetchTopK(const float* query, uint32_t kk, float* dist, uint32_t* row, uint32_t* count) const {
+	PendingQuery p{query, kk, dist, row, count, false, 0, {}};
+	if (!coalesce_) {
+		std::vector<PendingQuery*> one{&p};
+		runBatch(one);
+	} else {
+		std::unique_lock<std::mutex> lk(coMtx_);
+		coQueue_.push_back(&p);
+		while (!p.done) {
+			if (coLeader_) {
+				coCv_.wait(lk);
+				continue;
+			}
+			coLeader_ = true;   // the device is idle: run everything that is queued right now (our own query included unless > 256 are ahead)
+			std::vector<PendingQuery*> batch;
+			while (!coQueue_.empty() && batch.size() < 256) {
+				batch.push_back(coQueue_.front());
+				coQueue_.pop_front();
+			}
+			lk.unlock();
+			runBatch(batch);
+			lk.lock();
+			for (PendingQuery* q : batch) q->done = true;
+			++coBatches_;
+			coQueries_ += batch.size();
+			coLeader_ = false;
+			coCv_.notify_all();
+		}
+	}
+	if (p.rc != RXGPU_OK) throw std::runtime_error("SearchKnn: " + p.error);
+}
+
 SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optional<float>, size_t k, size_t) const {
 	SearchResultQueue result;
 	if (curElementCount_ == 0 || k == 0) return result;
@@ -210,7 +281,7 @@ SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optio
 	std::vector<float> dist(kk);
 	std::vector<uint32_t> row(kk);
 	uint32_t count = 0;
-	if (rxgpu_search_knn(dev_, queryData, 1, kk, dist.data(), row.data(), &count) != RXGPU_OK) throwDevice("SearchKnn");
+	fetchTopK(queryData, kk, dist.data(), row.data(), &count);
 	result.reserve(k);
 	const bool tieAcross = count > k && !(dist[k - 1] < dist[k]);
 	if (!tieAcross) {

@@ -10,6 +10,8 @@
 #pragma once
 
 #include <memory>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <optional>
 #include <unordered_map>
@@ -57,9 +59,21 @@ public:
 	// statistics for tests: how many searches needed the tie replay
 	size_t TieReplays() const noexcept { return tieReplays_; }
 
+	// Query coalescing (on by default).  The reference's concurrency model is T planner threads each running its own SearchKnn over the shared
+	// index (SURVEY §8b "Threading"); on a GPU a single scan already uses the whole HBM bandwidth, so concurrent scans would just queue.
+	// Instead, calls that arrive while the device is busy are merged into ONE batched search (rxgpu_search_knn, nq <= 256): the thread
+	// that finds the device idle runs the batch for everybody, the others sleep until their rows are back.  No waiting window is added:
+	// a lone caller goes straight through.  Results are the batch-1 results, bit for bit.
+	void EnableQueryCoalescing(bool on) noexcept { coalesce_ = on; }
+	size_t CoalescedBatches() const noexcept { return coBatches_; }
+	size_t CoalescedQueries() const noexcept { return coQueries_; }
+
 private:
 	void syncDevice() const;
 	void markDirty(size_t idx);
+	struct PendingQuery;
+	void fetchTopK(const float* query, uint32_t kk, float* dist, uint32_t* row, uint32_t* count) const;
+	void runBatch(std::vector<PendingQuery*>& batch) const;
 
 	const VectorMetric metric_;
 	const size_t dim_;
@@ -79,6 +93,13 @@ private:
 	mutable bool dirtyAll_ = false;
 	mutable bool needSync_ = false;
 	mutable size_t tieReplays_ = 0;
+
+	bool coalesce_ = true;
+	mutable std::mutex coMtx_;
+	mutable std::condition_variable coCv_;
+	mutable std::deque<PendingQuery*> coQueue_;
+	mutable bool coLeader_ = false;
+	mutable size_t coBatches_ = 0, coQueries_ = 0;
 };
 
 }  // namespace rxgpu::host

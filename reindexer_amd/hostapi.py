@@ -89,6 +89,17 @@ class GpuBruteforceMap:
         if not self.h:
             _raise()
 
+    def enable_coalescing(self, on: bool) -> None:
+        lib().rxhost_bf_enable_coalescing.argtypes = [_vp, _i]
+        lib().rxhost_bf_enable_coalescing(self.h, int(on))
+
+    def coalescing_stats(self):
+        """(device batches run, queries served) by the query coalescer."""
+        lib().rxhost_bf_coalescing_stats.argtypes = [_vp, _vp, _vp]
+        a, b = _u64(0), _u64(0)
+        lib().rxhost_bf_coalescing_stats(self.h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
     def clone(self, new_max_elements: int) -> "GpuBruteforceMap":
         h = lib().rxhost_bf_clone(self.h, new_max_elements)
         if not h:

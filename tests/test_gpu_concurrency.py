@@ -95,3 +95,34 @@ def test_concurrent_map_hnsw_and_ft(rxgpu, oracle):
     bf.close()
     hn.close()
     ft.close()
+
+
+def test_map_query_coalescing_is_transparent(rxgpu, oracle):
+    """T threads call GpuBruteforceMap::SearchKnn at once with different k: calls arriving while the device is busy are served by ONE
+    batched search; every caller still gets exactly its batch-1 result (ties at the k-th distance included)."""
+    from reindexer_amd import hostapi
+    rng = np.random.default_rng(8)
+    n, d = 30_000, 64
+    rows = rng.integers(-2, 3, (n, d)).astype(np.float32)                 # quantised: plenty of exact ties across the k-th boundary
+    labels = (rng.permutation(n).astype(np.uint64) << np.uint64(32))
+    queries = rng.integers(-2, 3, (48, d)).astype(np.float32)
+    m = hostapi.GpuBruteforceMap(0, d, n)
+    m.add(rows, labels)
+    m.enable_coalescing(False)
+    ks = [1, 5, 10, 33]
+    want = {(i, k): m.search_knn(queries[i], k) for i in range(48) for k in ks}
+    m.enable_coalescing(True)
+    b0, q0 = m.coalescing_stats()
+
+    def fn(t):
+        ok = True
+        for j in range(24):
+            i, k = (t * 11 + j) % 48, ks[(t + j) % 4]
+            got = m.search_knn(queries[i], k)
+            ok &= all(np.array_equal(x, y) for x, y in zip(got, want[(i, k)]))
+        return ok
+
+    assert all(_run_threads(12, fn))
+    b1, q1 = m.coalescing_stats()
+    assert q1 - q0 == 12 * 24 and b1 - b0 < q1 - q0        # fewer device round trips than queries: batches did form
+    m.close()
