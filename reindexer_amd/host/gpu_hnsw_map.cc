@@ -81,6 +81,76 @@ void GpuHnswMap::syncDevice() const {
 	deletedDirty_ = false;
 }
 
+struct GpuHnswMap::PendingQuery {
+	const float* query;
+	uint32_t k, ef;
+	float* dist;
+	uint32_t* row;
+	uint32_t* count;
+	bool done;
+	int rc;
+	std::string error;
+};
+
+void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* dist, uint32_t* row, uint32_t* count) const {
+	PendingQuery p{query, k, ef, dist, row, count, false, 0, {}};
+	if (!coalesce_) {
+		p.rc = rxgpu_hnsw_search_knn(dev_, query, 1, k, ef, dist, row, count);
+		if (p.rc != RXGPU_OK) p.error = rxgpu_last_error();
+	} else {
+		std::unique_lock<std::mutex> lk(coMtx_);
+		coQueue_.push_back(&p);
+		while (!p.done) {
+			if (coLeader_) {
+				coCv_.wait(lk);
+				continue;
+			}
+			coLeader_ = true;   // device idle: serve the queue head and everything queued with the same (k, ef)
+			std::vector<PendingQuery*> batch;
+			const uint32_t bk = coQueue_.front()->k, bef = coQueue_.front()->ef;
+			for (auto it = coQueue_.begin(); it != coQueue_.end() && batch.size() < 4096;) {
+				if ((*it)->k == bk && (*it)->ef == bef) {
+					batch.push_back(*it);
+					it = coQueue_.erase(it);
+				} else {
+					++it;
+				}
+			}
+			lk.unlock();
+			const size_t nq = batch.size(), dim = graph_.Dim();
+			int rc;
+			std::string error;
+			if (nq == 1) {
+				PendingQuery& q = *batch[0];
+				rc = rxgpu_hnsw_search_knn(dev_, q.query, 1, bk, bef, q.dist, q.row, q.count);
+			} else {
+				std::vector<float> queries(nq * dim), d(nq * bk);
+				std::vector<uint32_t> r(nq * bk), c(nq);
+				for (size_t i = 0; i < nq; ++i) std::copy(batch[i]->query, batch[i]->query + dim, queries.begin() + i * dim);
+				rc = rxgpu_hnsw_search_knn(dev_, queries.data(), uint32_t(nq), bk, bef, d.data(), r.data(), c.data());
+				if (rc == RXGPU_OK) {
+					for (size_t i = 0; i < nq; ++i) {
+						std::copy(d.begin() + i * bk, d.begin() + i * bk + c[i], batch[i]->dist);
+						std::copy(r.begin() + i * bk, r.begin() + i * bk + c[i], batch[i]->row);
+						*batch[i]->count = c[i];
+					}
+				}
+			}
+			if (rc != RXGPU_OK) error = rxgpu_last_error();
+			lk.lock();
+			for (PendingQuery* q : batch) {
+				q->rc = rc;
+				q->error = error;
+				q->done = true;
+			}
+			++coBatches_;
+			coLeader_ = false;
+			coCv_.notify_all();
+		}
+	}
+	if (p.rc != RXGPU_OK) throw std::runtime_error("SearchKnn: " + p.error);
+}
+
 // hnswalg.h:1988-2012
 SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional<float>, size_t k, size_t ef) const {
 	SearchResultQueue result;
@@ -91,9 +161,7 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 	std::vector<float> dist(k);
 	std::vector<uint32_t> row(k);
 	uint32_t count = 0;
-	if (rxgpu_hnsw_search_knn(dev_, queryDataRaw, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) {
-		throwDevice("SearchKnn");
-	}
+	fetchKnn(queryDataRaw, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count);
 	result.reserve(count);
 	for (uint32_t i = 0; i < count; ++i) result.emplace(dist[i], graph_.Label(row[i]));
 	return result;

@@ -4,6 +4,8 @@
 //   search : MI355X, rxgpu_hnsw_search_knn (hnsw_search.hip) — same traversal as the reference, no CPU search path
 #pragma once
 
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <optional>
@@ -68,6 +70,11 @@ public:
 	StreamingSearchSession BeginStreamingSearch(const float* queryDataRaw, std::optional<float> queryDataNorm, StreamingSearchOptions opts) const;
 	StreamingBatch ContinueStreamingSearch(StreamingSearchSession& session, size_t batchSize) const;
 
+	// Query coalescing, as in GpuBruteforceMap: one-shot searches that arrive while the device is busy and ask for the same (k, ef) share
+	// one launch of the batched search kernel (a wavefront per query) instead of one single-wavefront launch each.
+	void EnableQueryCoalescing(bool on) noexcept { coalesce_ = on; }
+	size_t CoalescedBatches() const noexcept { return coBatches_; }
+
 	bool IsQuantized() const noexcept { return false; }
 	bool QuantizationAvailable() const noexcept { return false; }
 
@@ -77,6 +84,8 @@ public:
 
 private:
 	void syncDevice() const;
+	struct PendingQuery;
+	void fetchKnn(const float* query, uint32_t k, uint32_t ef, float* dist, uint32_t* row, uint32_t* count) const;
 
 	HnswGraph graph_;
 	const int device_;
@@ -85,6 +94,13 @@ private:
 	mutable size_t syncedRows_ = 0;
 	mutable bool graphDirty_ = true;
 	mutable bool deletedDirty_ = false;
+
+	bool coalesce_ = true;
+	mutable std::mutex coMtx_;
+	mutable std::condition_variable coCv_;
+	mutable std::deque<PendingQuery*> coQueue_;
+	mutable bool coLeader_ = false;
+	mutable size_t coBatches_ = 0;
 };
 
 }  // namespace rxgpu::host

@@ -28,6 +28,35 @@ def run(m, queries, threads, per_thread, k):
     return threads * per_thread / (time.perf_counter() - t0)
 
 
+def main_hnsw(args):
+    rng = np.random.default_rng(4)
+    centres = rng.normal(0, 0.25, (500, args.dim)).astype(np.float32)
+    rows = (centres[rng.integers(0, 500, args.rows)] + rng.normal(0, 0.08, (args.rows, args.dim))).astype(np.float32)
+    queries = (centres[rng.integers(0, 500, 1024)] + rng.normal(0, 0.08, (1024, args.dim))).astype(np.float32)
+    queries = np.stack([hostapi.normalize_copy(q)[0] for q in queries])
+    m = hostapi.GpuHnswMap(2, args.dim, args.rows, M=16, ef_construction=200)
+    m.add(rows, np.arange(args.rows, dtype=np.uint64) << np.uint64(32))
+
+    class Wrap:   # run() calls search_knn(q, k)
+        def search_knn(self, q, k):
+            return m.search_knn(q, k, 128)
+    w = Wrap()
+    w.search_knn(queries[0], args.k)
+    out = {"workload": f"{args.threads} threads x {args.per_thread} single-query SearchKnn(k={args.k}, ef=128) calls on one GpuHnswMap, {args.rows} x {args.dim} cosine"}
+    t0 = time.perf_counter()
+    for i in range(50):
+        w.search_knn(queries[i], args.k)
+    out["single_thread_qps"] = 50 / (time.perf_counter() - t0)
+    L = hostapi.lib()
+    import ctypes as C
+    L.rxhost_hnsw_enable_coalescing.argtypes = [C.c_void_p, C.c_int]
+    L.rxhost_hnsw_enable_coalescing(m.h, 0)
+    out["threads_no_coalescing_qps"] = run(w, queries, args.threads, args.per_thread, args.k)
+    L.rxhost_hnsw_enable_coalescing(m.h, 1)
+    out["threads_coalescing_qps"] = run(w, queries, args.threads, args.per_thread, args.k)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=2_000_000)
@@ -35,7 +64,10 @@ def main():
     ap.add_argument("--threads", type=int, default=64)
     ap.add_argument("--per-thread", type=int, default=40)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--hnsw", action="store_true", help="the same experiment on GpuHnswMap (cosine, M=16, efC=200, ef=128); use --rows 50000")
     args = ap.parse_args()
+    if args.hnsw:
+        return main_hnsw(args)
     rng = np.random.default_rng(3)
     rows = rng.normal(0, 0.25, (args.rows, args.dim)).astype(np.float32)
     queries = rng.normal(0, 0.25, (1024, args.dim)).astype(np.float32)
