@@ -234,6 +234,11 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_simple_raw: rxgpu_ft_set_docs was not called");
 	if (nsub == 0) return RXGPU_OK;
 	RX_CHECK(word_ids && procs && opts->field_boost && opts->need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: null argument");
+	{
+		uint32_t nsum = 0;
+		for (uint32_t f = 0; f < h->num_fields; ++f) nsum += opts->need_sum_rank[f] ? 1 : 0;
+		RX_CHECK(nsum <= 8, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: more than 8 fields with needSumRank (GPU engine limit)");
+	}
 	std::lock_guard<std::mutex> lk(h->mtx);
 	DevGuard dg(h->device);
 	const uint32_t nf = h->num_fields;
@@ -452,6 +457,9 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	std::vector<uint8_t> need_sum(size_t(nterms) * nf);
 	for (uint32_t t = 0; t < nterms; ++t) {
 		RX_CHECK(opts[t].field_boost && opts[t].need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: null term options");
+		uint32_t nsum = 0;
+		for (uint32_t f = 0; f < nf; ++f) nsum += opts[t].need_sum_rank[f] ? 1 : 0;
+		RX_CHECK(nsum <= 8, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: more than 8 fields with needSumRank (GPU engine limit)");
 		for (uint32_t f = 0; f < nf; ++f) {
 			fcfg[size_t(6 + t) * nf + f] = opts[t].field_boost[f];
 			need_sum[size_t(t) * nf + f] = opts[t].need_sum_rank[f];

@@ -104,3 +104,20 @@ def test_gpu_merge_large_posting_lists(hostapi, ft):
     postings, ms = m.read_stats()
     assert postings == 108_000 and ms > 0
     m.close()
+
+
+def test_more_than_eight_summed_fields_is_refused_loudly(hostapi):
+    """The GPU engine keeps at most 8 per-field ranks for summationRanksByFieldsRatio: more is an error, never a silent truncation."""
+    nf = 10
+    m = hostapi.GpuFtMerger(nf)
+    total = 50
+    words = np.ones((total, nf), np.float32)
+    m.set_docs(words, np.ones(nf, np.float32))
+    rng = np.random.default_rng(1)
+    m.set_word_flat(0, make_postings(rng, total, nf, 20))
+    cfg = hostapi.default_ft_config(nf, summation_ratio=0.5)
+    with pytest.raises(Exception):
+        m.merge(cfg, hostapi.default_ft_opts(nf, need_sum_rank=[1] * nf), [(0, 100.0)])
+    ok = m.merge(cfg, hostapi.default_ft_opts(nf, need_sum_rank=[1] * 8 + [0, 0]), [(0, 100.0)])
+    assert len(ok[0]) > 0
+    m.close()
