@@ -76,7 +76,10 @@ inline void Finish(std::vector<IdRank>& merged, bool desc, HybridResult& out) {
 inline HybridResult MergeRankedRRF(const RerankerRRF& rr, HybridMergeType type, bool desc, VectorMetric metric, const std::vector<int32_t>& knnIds,
 								   const std::vector<float>& knnRanks, const std::vector<int32_t>& ftIds, const std::vector<size_t>& ftPositions) {
 	std::vector<detail::IdRank> merged;
-	std::unordered_set<int32_t> seen;   // Merged<desc> is keyed by id: the first emplace of an id wins
+	// Merged<desc> is keyed by id: the first emplace of an id wins.  Only the (few) KNN ids can repeat: ftIds are unique, and an FT id that
+	// also came through the KNN list is marked in ftAdded — so the FT tail needs no hashing.
+	std::unordered_set<int32_t> seen;
+	merged.reserve(knnIds.size() + (type == HybridMergeType::Union ? ftIds.size() : 0));
 	std::vector<bool> ftAdded(type == HybridMergeType::Union ? ftIds.size() : 0, false);
 	if (!knnIds.empty()) {
 		float last = knnRanks.front();
@@ -99,7 +102,7 @@ inline HybridResult MergeRankedRRF(const RerankerRRF& rr, HybridMergeType type, 
 	}
 	if (type == HybridMergeType::Union) {
 		for (size_t i = 0; i < ftIds.size(); ++i) {
-			if (!ftAdded[i] && seen.insert(ftIds[i]).second) merged.push_back({ftIds[i], rr.CalculateSingle(ftPositions[i])});
+			if (!ftAdded[i]) merged.push_back({ftIds[i], rr.CalculateSingle(ftPositions[i])});
 		}
 	}
 	HybridResult out;
@@ -125,7 +128,7 @@ inline HybridResult MergeRankedLinear(const RerankerLinear& rr, HybridMergeType 
 	}
 	if (type == HybridMergeType::Union) {
 		for (size_t i = 0; i < ftIds.size(); ++i) {
-			if (!ftAdded[i] && seen.insert(ftIds[i]).second) merged.push_back({ftIds[i], rr.CalculateJustFt(ftRanks[i])});
+			if (!ftAdded[i]) merged.push_back({ftIds[i], rr.CalculateJustFt(ftRanks[i])});   // unique ids, not in the KNN list: no hashing needed
 		}
 	}
 	HybridResult out;
