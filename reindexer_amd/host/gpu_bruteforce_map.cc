@@ -260,7 +260,14 @@ void GpuBruteforceMap::fetchTopK(const float* query, uint32_t kk, float* dist, u
 				coQueue_.pop_front();
 			}
 			lk.unlock();
-			runBatch(batch);
+			try {
+				runBatch(batch);
+			} catch (const std::exception& e) {   // e.g. bad_alloc while staging: every caller of the batch gets the error, leadership is released
+				for (PendingQuery* q : batch) {
+					q->rc = RXGPU_ERR_NOMEM;
+					q->error = e.what();
+				}
+			}
 			lk.lock();
 			for (PendingQuery* q : batch) q->done = true;
 			++coBatches_;

@@ -118,25 +118,30 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 			}
 			lk.unlock();
 			const size_t nq = batch.size(), dim = graph_.Dim();
-			int rc;
+			int rc = RXGPU_OK;
 			std::string error;
-			if (nq == 1) {
-				PendingQuery& q = *batch[0];
-				rc = rxgpu_hnsw_search_knn(dev_, q.query, 1, bk, bef, q.dist, q.row, q.count);
-			} else {
-				std::vector<float> queries(nq * dim), d(nq * bk);
-				std::vector<uint32_t> r(nq * bk), c(nq);
-				for (size_t i = 0; i < nq; ++i) std::copy(batch[i]->query, batch[i]->query + dim, queries.begin() + i * dim);
-				rc = rxgpu_hnsw_search_knn(dev_, queries.data(), uint32_t(nq), bk, bef, d.data(), r.data(), c.data());
-				if (rc == RXGPU_OK) {
-					for (size_t i = 0; i < nq; ++i) {
-						std::copy(d.begin() + i * bk, d.begin() + i * bk + c[i], batch[i]->dist);
-						std::copy(r.begin() + i * bk, r.begin() + i * bk + c[i], batch[i]->row);
-						*batch[i]->count = c[i];
+			try {
+				if (nq == 1) {
+					PendingQuery& q = *batch[0];
+					rc = rxgpu_hnsw_search_knn(dev_, q.query, 1, bk, bef, q.dist, q.row, q.count);
+				} else {
+					std::vector<float> queries(nq * dim), d(nq * bk);
+					std::vector<uint32_t> r(nq * bk), c(nq);
+					for (size_t i = 0; i < nq; ++i) std::copy(batch[i]->query, batch[i]->query + dim, queries.begin() + i * dim);
+					rc = rxgpu_hnsw_search_knn(dev_, queries.data(), uint32_t(nq), bk, bef, d.data(), r.data(), c.data());
+					if (rc == RXGPU_OK) {
+						for (size_t i = 0; i < nq; ++i) {
+							std::copy(d.begin() + i * bk, d.begin() + i * bk + c[i], batch[i]->dist);
+							std::copy(r.begin() + i * bk, r.begin() + i * bk + c[i], batch[i]->row);
+							*batch[i]->count = c[i];
+						}
 					}
 				}
+				if (rc != RXGPU_OK) error = rxgpu_last_error();
+			} catch (const std::exception& e) {   // e.g. bad_alloc while staging: every caller of the batch gets the error, leadership is released
+				rc = RXGPU_ERR_NOMEM;
+				error = e.what();
 			}
-			if (rc != RXGPU_OK) error = rxgpu_last_error();
 			lk.lock();
 			for (PendingQuery* q : batch) {
 				q->rc = rc;
