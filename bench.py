@@ -197,7 +197,7 @@ def batched_leg(args, ix, queries: torch.Tensor, device, kk: int):
     per_batch = (t1 - t0) / args.batch_iters
     bf16_min = int(os.environ.get("RXGPU_BATCH_BF16_MIN", "2"))
     bf16 = bf16_min > 0 and B >= bf16_min
-    mt = 256 if bf16 else (32 if B <= 32 else 64 if B <= 64 else 128 if B <= 128 else 256)
+    mt = (128 if B <= 128 else 256) if bf16 else (32 if B <= 32 else 64 if B <= 64 else 128 if B <= 128 else 256)
     kpad = (args.dim + 63) // 64 * 64 if bf16 else args.dim
     flops = 2.0 * mt * args.rows * kpad       # flops actually issued on the matrix cores (padded to the tile)
     gemm_ms = ms_gemm / max(n_gemm, 1)

@@ -28,7 +28,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBfThreads = 512;
 constexpr int kBfRows = 256;       // corpus rows per tile
-constexpr int kBfQueries = 256;    // queries per tile (batches are padded to 256)
 
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 	uint32_t u = __float_as_uint(f);
@@ -63,17 +62,24 @@ __global__ __launch_bounds__(256) void knn_to_bf16(const float* src, uint64_t n,
 // wave per SIMD nothing overlaps its fragment reads with its MFMAs.)  The DMA writes a lane-linear image (wave base + lane x 16 B), so the bank swizzle is applied on
 // the SOURCE side: LDS slot p = 4 r + cs holds chunk c = cs ^ ((r >> 2) & 3) of row r; a ds_read_b128 lane group (16 rows, one chunk) then
 // covers 16 distinct 16-byte slots.  One raw s_barrier per stage with counted vmcnt (a __syncthreads would drain the DMA queue).
-constexpr int kGlBufs = 4;
-constexpr int kGlAhead = 3;
-constexpr int kGlPartElems = kBfRows * 32;   // one operand of one stage: 256 rows x 32 bf16
+constexpr int kGlXElems = kBfRows * 32;   // the row operand of one stage: 256 rows x 32 bf16 (16 KB)
+// QT = queries per tile.  256: 32 KB per stage, 4 buffers, 3 stages in flight.  128 (batches <= 128 queries): 24 KB per stage, 6 buffers,
+// 5 stages in flight — the kernel waits on HBM latency, so the bytes in flight per CU are what the narrower query block buys.
+constexpr int gl_bufs(int qt) { return qt == 256 ? 4 : 6; }
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int kMetric, int kMode>
+template <int kMetric, int kMode, int QT>
 __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params p) {
+	constexpr int kBufs = gl_bufs(QT), kAhead = kBufs - 1;
+	constexpr int kQElems = QT * 32;                 // the query operand of one stage
+	constexpr int kStageElems = kGlXElems + kQElems;
+	constexpr int QB = QT / 64;                      // 32-query blocks per wave (two query halves)
+	constexpr int kQDma = QT * 4 / kBfThreads;       // DMA instructions per thread for the query part (2 or 1)
+	constexpr int kIps = 2 + kQDma;                  // DMA instructions per stage per wave
 	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];   // the ONLY shared object (a second one de-pipelines the DMA waits)
-	uint16_t* stage_s = reinterpret_cast<uint16_t*>(bf_lds);                                  // [4][x: 256 x 32 | q: 256 x 32]
-	float* thr_s = reinterpret_cast<float*>(bf_lds + size_t(kGlBufs) * 2 * kGlPartElems * 2);   // [256]
-	float* aux_s = thr_s + kBfQueries;
+	uint16_t* stage_s = reinterpret_cast<uint16_t*>(bf_lds);                            // [kBufs][x: 256 x 32 | q: QT x 32]
+	float* thr_s = reinterpret_cast<float*>(bf_lds + size_t(kBufs) * kStageElems * 2);   // [QT]
+	float* aux_s = thr_s + QT;
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 	const uint64_t ntiles = (p.n + kBfRows - 1) / kBfRows;
 	const uint64_t my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
 	const uint64_t total = my_tiles * stages;
-	for (int i = tid; i < kBfQueries; i += kBfThreads) {
+	for (int i = tid; i < QT; i += kBfThreads) {
 		thr_s[i] = kMode == kGemmFilter ? p.thr[i] : 0.f;
 		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
 	}
@@ -109,12 +115,12 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 			}
 		}
 		const uint32_t k0 = iss_stage * 32;
-		uint16_t* buf = stage_s + size_t(iss_g % kGlBufs) * 2 * kGlPartElems;
+		uint16_t* buf = stage_s + size_t(iss_g % kBufs) * kStageElems;
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
 			uint16_t* dx = buf + (j * kBfThreads + wave * 64) * 8;                 // wave-uniform base; the DMA adds lane x 16 B
 			__builtin_amdgcn_global_load_lds(xsrc[j] + k0, (lds_void*)(dx), 16, 0, 0);
-			__builtin_amdgcn_global_load_lds(p.queries + size_t(src_r[j]) * p.ld + src_c[j] + k0, (lds_void*)(dx + kGlPartElems), 16, 0, 0);
+			if (j < kQDma) __builtin_amdgcn_global_load_lds(p.queries + size_t(src_r[j]) * p.ld + src_c[j] + k0, (lds_void*)(dx + kGlXElems), 16, 0, 0);
 		}
 		++iss_g;
 		if (++iss_stage == stages) {
@@ -122,52 +128,52 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 			iss_tile += gridDim.x;
 		}
 	};
-	for (int a = 0; a < kGlAhead; ++a) {
+	for (int a = 0; a < kAhead; ++a) {
 		if (iss_g < total) issue();
 	}
 
 	// fragment addressing: row R of the part, chunk c -> slot 4 R + (c ^ ((R >> 2) & 3)); both rows (lane & 31) + 32 a keep (R >> 2) & 3 = (lane >> 2) & 3
 	const uint32_t half = lane >> 5;
 	const uint32_t swz = (lane >> 2) & 3;
-	const uint32_t xrow = 64 * rp + (lane & 31), qrow = 128 * qh + (lane & 31);
+	const uint32_t xrow = 64 * rp + (lane & 31), qrow = (QT / 2) * qh + (lane & 31);
 
 	uint64_t tile = blockIdx.x;
 	uint32_t s = 0;
-	f32x16 acc[2][4];
+	f32x16 acc[2][QB];
 #pragma unroll
 	for (int a = 0; a < 2; ++a) {
 #pragma unroll
-		for (int b = 0; b < 4; ++b) {
+		for (int b = 0; b < QB; ++b) {
 #pragma unroll
 			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 		}
 	}
 	for (uint64_t g = 0; g < total; ++g) {
-		// stage g has landed for THIS wave once at most the younger stages' DMAs (4 per stage) are outstanding
+		// stage g has landed for THIS wave once at most the younger stages' DMAs (kIps per stage) are outstanding
 		const uint64_t younger = iss_g - g - 1;
-		if (younger >= 2) {
-			asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-		} else if (younger == 1) {
-			asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-		} else {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		switch (younger < uint64_t(kAhead - 1) ? int(younger) : kAhead - 1) {
+			case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+			case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kIps) : "memory"); break;
+			case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kIps) : "memory"); break;
+			case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kIps) : "memory"); break;
+			default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * kIps) : "memory"); break;
 		}
 		__builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading the buffer the next DMA overwrites
 		asm volatile("" ::: "memory");
 		if (iss_g < total) issue();
-		const uint16_t* buf = stage_s + size_t(g % kGlBufs) * 2 * kGlPartElems;
+		const uint16_t* buf = stage_s + size_t(g % kBufs) * kStageElems;
 #pragma unroll
 		for (int t = 0; t < 2; ++t) {
 			const uint32_t cs = ((2 * t + half) ^ swz) << 3;
-			bf16x8 bfrag[2], afrag[4];
+			bf16x8 bfrag[2], afrag[QB];
 #pragma unroll
 			for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + (xrow + 32 * a) * 32 + cs));
 #pragma unroll
-			for (int b = 0; b < 4; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + kGlPartElems + (qrow + 32 * b) * 32 + cs));
+			for (int b = 0; b < QB; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(buf + kGlXElems + (qrow + 32 * b) * 32 + cs));
 #pragma unroll
 			for (int a = 0; a < 2; ++a) {
 #pragma unroll
-				for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
+				for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
 			}
 		}
 		if (++s < stages) continue;
@@ -183,12 +189,12 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 			float row_term = 0.f;
 			if constexpr (kMetric == kL2) row_term = p.row_sq[rowc];
 			if constexpr (kMetric == kCos) row_term = p.inv_norms[rowc];
-			const int qlane = 4 * (lane >> 5) + 128 * qh;
+			const int qlane = 4 * (lane >> 5) + (QT / 2) * qh;
 			if constexpr (kMode == kGemmDense) {
 				float* dp = p.dense + size_t(qlane) * p.n + row;
 				const size_t n1 = p.n, n5 = 5 * p.n;
 #pragma unroll
-				for (int b = 0; b < 4; ++b) {
+				for (int b = 0; b < QB; ++b) {
 #pragma unroll
 					for (int r = 0; r < 16; ++r) {
 						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 				}
 			} else {
 #pragma unroll
-				for (int b = 0; b < 4; ++b) {
+				for (int b = 0; b < QB; ++b) {
 					uint32_t mask = 0;
 #pragma unroll
 					for (int r = 0; r < 16; ++r) {
@@ -240,33 +246,39 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 	}
 }
 
-size_t gemm_bf16_glds_lds_bytes() { return size_t(kGlBufs) * 2 * kGlPartElems * sizeof(uint16_t) + 2 * kBfQueries * sizeof(float); }
+size_t gemm_bf16_glds_lds_bytes(int qt) { return size_t(gl_bufs(qt)) * (kGlXElems + qt * 32) * sizeof(uint16_t) + 2 * size_t(qt) * sizeof(float); }
 
-template <int kMetric, int kMode>
+template <int kMetric, int kMode, int QT>
 static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
-	const size_t lds = gemm_bf16_glds_lds_bytes();
+	const size_t lds = gemm_bf16_glds_lds_bytes(QT);
 	static bool attr_set = false;
 	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm_bf16_glds<kMetric, kMode>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm_bf16_glds<kMetric, kMode, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
 		if (e != hipSuccess) return e;
 		attr_set = true;
 	}
-	hipLaunchKernelGGL((knn_gemm_bf16_glds<kMetric, kMode>), dim3(grid), dim3(kBfThreads), lds, s, p);
+	hipLaunchKernelGGL((knn_gemm_bf16_glds<kMetric, kMode, QT>), dim3(grid), dim3(kBfThreads), lds, s, p);
 	return hipGetLastError();
 }
 
-hipError_t launch_gemm_bf16(int metric, int mode, const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
+template <int kMetric, int kMode>
+static hipError_t launch_bf16_glds_qt(int qt, const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
+	return qt == 128 ? launch_bf16_glds_one<kMetric, kMode, 128>(p, grid, s) : launch_bf16_glds_one<kMetric, kMode, 256>(p, grid, s);
+}
+
+// qt: query-tile width, 128 or 256 (the query block and the threshold arrays hold qt rows)
+hipError_t launch_gemm_bf16(int metric, int mode, int qt, const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
 	if (mode == kGemmDense) {
 		switch (metric) {
-			case kL2: return launch_bf16_glds_one<kL2, kGemmDense>(p, grid, s);
-			case kIP: return launch_bf16_glds_one<kIP, kGemmDense>(p, grid, s);
-			default: return launch_bf16_glds_one<kCos, kGemmDense>(p, grid, s);
+			case kL2: return launch_bf16_glds_qt<kL2, kGemmDense>(qt, p, grid, s);
+			case kIP: return launch_bf16_glds_qt<kIP, kGemmDense>(qt, p, grid, s);
+			default: return launch_bf16_glds_qt<kCos, kGemmDense>(qt, p, grid, s);
 		}
 	}
 	switch (metric) {
-		case kL2: return launch_bf16_glds_one<kL2, kGemmFilter>(p, grid, s);
-		case kIP: return launch_bf16_glds_one<kIP, kGemmFilter>(p, grid, s);
-		default: return launch_bf16_glds_one<kCos, kGemmFilter>(p, grid, s);
+		case kL2: return launch_bf16_glds_qt<kL2, kGemmFilter>(qt, p, grid, s);
+		case kIP: return launch_bf16_glds_qt<kIP, kGemmFilter>(qt, p, grid, s);
+		default: return launch_bf16_glds_qt<kCos, kGemmFilter>(qt, p, grid, s);
 	}
 }
 

@@ -252,7 +252,7 @@ static int batch_bf16_min_queries() {   // read per call (tests and A/B runs swi
 int enqueue_knn_batched_bf16(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t q0, uint32_t cq, uint32_t kk,
 							 float* d_out_dist, uint32_t* d_out_row, uint32_t* d_out_count) {
 	if (int rc = ensure_bf16_shadow(h, c->stream); rc) return rc;
-	constexpr uint32_t mt = 256;
+	const uint32_t mt = cq <= 128 ? 128 : 256;   // query-tile width of the nomination kernel
 	const uint32_t ld = (h->dim + 63u) & ~63u;
 	const uint32_t q_stride = ld;   // the f32 copy for the exact re-score shares the padded stride
 	const uint64_t ns = std::min<uint64_t>(h->count, kBatchSampleRowsBf16);
@@ -293,7 +293,7 @@ int enqueue_knn_batched_bf16(rxgpu_index* h, rxgpu_search_ctx* c, const float* d
 	g.dense = static_cast<float*>(c->d_dense.ptr);
 	{
 		ProfileScope ps(h, "gemm_sample", c->stream);
-		RX_HIP(rxgpu::launch_gemm_bf16(h->metric, rxgpu::kGemmDense, g, grid_for(ns), c->stream));
+		RX_HIP(rxgpu::launch_gemm_bf16(h->metric, rxgpu::kGemmDense, int(mt), g, grid_for(ns), c->stream));
 	}
 	rxgpu::launch_sample_threshold(g.dense, ns, cq, mt, kk, margin, thr, c->stream);
 	g.n = h->count;
@@ -305,7 +305,7 @@ int enqueue_knn_batched_bf16(rxgpu_index* h, rxgpu_search_ctx* c, const float* d
 	g.cap = cap;
 	{
 		ProfileScope ps(h, "gemm", c->stream);
-		RX_HIP(rxgpu::launch_gemm_bf16(h->metric, rxgpu::kGemmFilter, g, grid_for(h->count), c->stream));
+		RX_HIP(rxgpu::launch_gemm_bf16(h->metric, rxgpu::kGemmFilter, int(mt), g, grid_for(h->count), c->stream));
 	}
 	{
 		ProfileScope ps(h, "rescore", c->stream);

@@ -47,7 +47,7 @@ void launch_row_stats(const float* rows, const float* inv_norms, uint64_t n, uin
 void launch_query_stats(int metric, const float* queries, uint32_t nq, uint32_t mt, uint32_t q_stride, uint32_t dim, const unsigned int* stats,
 						float* q_sq, float* margin, bool bf16, hipStream_t s);
 struct GemmBf16Params;
-hipError_t launch_gemm_bf16(int metric, int mode, const GemmBf16Params& p, uint32_t grid, hipStream_t s);
+hipError_t launch_gemm_bf16(int metric, int mode, int qt, const GemmBf16Params& p, uint32_t grid, hipStream_t s);
 void launch_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, int cus, hipStream_t s);
 void launch_sample_threshold(const float* dense, uint64_t ns, uint32_t nq, uint32_t mt, uint32_t kk, const float* margin, float* thr,
 							 hipStream_t s);
