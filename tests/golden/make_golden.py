@@ -23,6 +23,9 @@ OUT = Path(__file__).resolve().parent
 DIMS = [1, 7, 16, 33, 64, 100, 128, 200, 512, 768, 1000]
 
 
+STREAM_PLANS = [(0, [10, 10, 10]), (16, [5, 40, 1, 300]), (3, [1, 1, 2, 2000])]   # (ef, batch sizes); shared with tests/test_golden.py
+
+
 def main():
     ref = Ref()
     assert ref.simd_level == 3, "golden vectors must be generated with the AVX-512 dispatch"
@@ -100,6 +103,17 @@ def main():
                 dd, ll = h.search_knn(qn, k, ef)
                 hz[f"p{phase}_q{qi}_k{k}_ef{ef}_dist"] = dd
                 hz[f"p{phase}_q{qi}_k{k}_ef{ef}_label"] = ll
+        # streaming sessions of the real engine (BeginStreamingSearch / ContinueStreamingSearch): every batch, sorted by (dist, label)
+        for qi in range(4):
+            qn, _ = ref.normalize_copy(queries[qi])
+            for si, (sef, plan) in enumerate(STREAM_PLANS):
+                sess = h.stream(qn, sef)
+                for bi, b in enumerate(plan):
+                    dd, ll, ex = sess.next(b)
+                    o = np.lexsort((ll, dd))
+                    hz[f"s{phase}_q{qi}_p{si}_b{bi}_dist"], hz[f"s{phase}_q{qi}_p{si}_b{bi}_label"] = dd[o], ll[o]
+                    hz[f"s{phase}_q{qi}_p{si}_b{bi}_exhausted"] = np.bool_(ex)
+                sess.close()
     h.close()
     np.savez_compressed(OUT / "hnsw.npz", **hz)
     make_ft_goldens()

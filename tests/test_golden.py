@@ -137,3 +137,24 @@ def test_oracle_hnsw_search_matches_golden(oracle, phase):
             gd, gl = oracle_hnsw_search_knn(oracle, g, qn, k, ef, inv)
             assert np.array_equal(gl, z[f"p{phase}_q{qi}_k{k}_ef{ef}_label"]), (phase, qi, k, ef)
             assert np.array_equal(bits(gd), bits(z[f"p{phase}_q{qi}_k{k}_ef{ef}_dist"]))
+
+
+@pytest.mark.parametrize("phase", [0, 1])
+def test_oracle_hnsw_streaming_matches_golden(oracle, phase):
+    """Streaming sessions recorded from the REAL engine (tests/golden/make_golden.py): the restatement must hand out the same batches and
+    flip `exhausted` at the same call — pins oracle_hnsw.c's streaming half where oracle/_ref is absent."""
+    from oracle.pyoracle import OracleHnswStream
+    plans = [(0, [10, 10, 10]), (16, [5, 40, 1, 300]), (3, [1, 1, 2, 2000])]
+    z, g = golden_hnsw_graph(oracle, phase)
+    inv = oracle.l2_modules(g["vectors"])
+    for qi in range(4):
+        qn, _ = oracle.normalize_copy(z["queries"][qi])
+        for si, (sef, plan) in enumerate(plans):
+            s = OracleHnswStream(oracle, g, qn, sef, inv)
+            for bi, b in enumerate(plan):
+                dd, ll, ex = s.next(b)
+                o = np.lexsort((ll, dd))
+                assert np.array_equal(ll[o], z[f"s{phase}_q{qi}_p{si}_b{bi}_label"]), (phase, qi, si, bi)
+                assert np.array_equal(bits(dd[o]), bits(z[f"s{phase}_q{qi}_p{si}_b{bi}_dist"]))
+                assert ex == bool(z[f"s{phase}_q{qi}_p{si}_b{bi}_exhausted"])
+            s.close()
