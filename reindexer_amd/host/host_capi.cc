@@ -479,15 +479,22 @@ long rxhost_merge_ranked(int kind, const double* params, int isUnion, int desc, 
 		HybridResult res;
 		const auto type = isUnion ? HybridMergeType::Union : HybridMergeType::Intersection;
 		if (kind == 0) {
-			// FT positions follow the FT result order (rank-sorted), then are re-indexed by ascending id like ftIds_
-			std::vector<size_t> order(nFt);
-			for (size_t i = 0; i < nFt; ++i) order[i] = i;
-			std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return fr[a] > fr[b]; });
+			// FT positions follow the FT result order (rank-sorted, ties in the given order), then are re-indexed by ascending id like ftIds_.
+			// Stable descending sort through one 64-bit key per entry: inverted order-preserving image of the rank, then the index.
+			std::vector<uint64_t> keys(nFt);
+			for (size_t i = 0; i < nFt; ++i) {
+				uint32_t u;
+				const float r = fr[i] + 0.0f;
+				std::memcpy(&u, &r, sizeof(u));
+				u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+				keys[i] = (uint64_t(~u) << 32) | uint32_t(i);
+			}
+			std::sort(keys.begin(), keys.end());
 			std::vector<float> sorted(nFt);
-			for (size_t i = 0; i < nFt; ++i) sorted[i] = fr[order[i]];
+			for (size_t i = 0; i < nFt; ++i) sorted[i] = fr[uint32_t(keys[i])];
 			auto posSorted = InitRRFPositions(sorted);
 			std::vector<size_t> pos(nFt);
-			for (size_t i = 0; i < nFt; ++i) pos[order[i]] = posSorted[i];
+			for (size_t i = 0; i < nFt; ++i) pos[uint32_t(keys[i])] = posSorted[i];
 			res = MergeRankedRRF(RerankerRRF{params[0]}, type, desc != 0, VectorMetric(metric), ki, kr, fi, pos);
 		} else {
 			res = MergeRankedLinear(RerankerLinear{params[0], params[1], params[2], params[3], params[4]}, type, desc != 0, ki, kr, fi, fr);

@@ -8,6 +8,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstring>
 #include <cstdint>
 #include <unordered_set>
 #include <vector>
@@ -56,17 +57,28 @@ struct IdRank {
 	int32_t id;
 	float rank;
 };
+// IdRank<desc>::operator< (selectiteratorcontainer.cc:1260-1281): by rank (descending when desc), ties by ascending id.  Sorted through one
+// 64-bit key per entry (order-preserving image of the float in the high word, id in the low word): same order, no comparator calls.
 inline void Finish(std::vector<IdRank>& merged, bool desc, HybridResult& out) {
-	std::sort(merged.begin(), merged.end(), [desc](const IdRank& l, const IdRank& r) {   // IdRank<desc>::operator< (:1260-1281)
-		if (desc ? l.rank > r.rank : l.rank < r.rank) return true;
-		if (desc ? l.rank < r.rank : l.rank > r.rank) return false;
-		return l.id < r.id;
-	});
-	out.ids.reserve(merged.size());
-	out.ranks.reserve(merged.size());
-	for (const IdRank& m : merged) {
-		out.ids.push_back(m.id);
-		out.ranks.push_back(m.rank);
+	struct Key {
+		uint64_t key;
+		uint32_t idx;
+	};
+	std::vector<Key> keys(merged.size());
+	for (size_t i = 0; i < merged.size(); ++i) {
+		uint32_t u;
+		const float r = merged[i].rank + 0.0f;   // -0 and +0 compare equal
+		std::memcpy(&u, &r, sizeof(u));
+		u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending float order == ascending unsigned order
+		if (desc) u = ~u;
+		keys[i] = Key{(uint64_t(u) << 32) | uint32_t(merged[i].id), uint32_t(i)};   // ids are non-negative (IdType) and unique
+	}
+	std::sort(keys.begin(), keys.end(), [](const Key& l, const Key& r) { return l.key < r.key; });
+	out.ids.resize(keys.size());
+	out.ranks.resize(keys.size());
+	for (size_t i = 0; i < keys.size(); ++i) {
+		out.ids[i] = merged[keys[i].idx].id;
+		out.ranks[i] = merged[keys[i].idx].rank;
 	}
 }
 }  // namespace detail
