@@ -210,6 +210,69 @@ struct WaveTopK {
 	__device__ __forceinline__ bool admits(float d, uint32_t idx) const { return filled < kk || pair_lt(d, idx, thr_d, thr_i); }
 };
 
+// Two entries per lane: the fused scan for 64 < kk <= 128 (e.g. hybrid queries with k = 100).  Lane i holds entries i (slot 0) and 64 + i (slot 1)
+// of the sorted list; the interface is WaveTopK's, so the scan kernels are templated on the list type and the kk <= 64 code is untouched.
+struct WaveTopK2 {
+	float d0, d1;
+	uint32_t i0, i1;
+	float thr_d;
+	uint32_t thr_i;
+	uint32_t filled;
+	uint32_t kk;
+
+	__device__ __forceinline__ void init(uint32_t kk_) {
+		d0 = d1 = __builtin_inff();
+		i0 = i1 = kInvalidRow;
+		thr_d = __builtin_inff();
+		thr_i = kInvalidRow;
+		filled = 0;
+		kk = kk_;
+	}
+	// (d, idx) must be wave-uniform.
+	__device__ __forceinline__ void insert(float d, uint32_t idx, int lane) {
+		const uint32_t p0 = __popcll(__ballot(pair_lt(d0, i0, d, idx)));
+		const float up1_d = __shfl_up(d1, 1);
+		const uint32_t up1_i = __shfl_up(i1, 1);
+		if (p0 < 64) {   // lands in slot 0: its last entry carries over to the head of slot 1
+			const float carry_d = __shfl(d0, 63);
+			const uint32_t carry_i = __shfl(i0, 63);
+			const float up_d = __shfl_up(d0, 1);
+			const uint32_t up_i = __shfl_up(i0, 1);
+			if (lane == int(p0)) {
+				d0 = d;
+				i0 = idx;
+			} else if (lane > int(p0)) {
+				d0 = up_d;
+				i0 = up_i;
+			}
+			if (lane == 0) {
+				d1 = carry_d;
+				i1 = carry_i;
+			} else {
+				d1 = up1_d;
+				i1 = up1_i;
+			}
+		} else {
+			const uint32_t p1 = __popcll(__ballot(pair_lt(d1, i1, d, idx)));
+			if (lane == int(p1)) {
+				d1 = d;
+				i1 = idx;
+			} else if (lane > int(p1)) {
+				d1 = up1_d;
+				i1 = up1_i;
+			}
+		}
+		if (filled < kk) ++filled;
+		if (filled == kk) {
+			const int e = int(kk) - 1;
+			thr_d = e < 64 ? __shfl(d0, e) : __shfl(d1, e - 64);
+			thr_i = e < 64 ? __shfl(i0, e) : __shfl(i1, e - 64);
+		}
+	}
+	__device__ __forceinline__ bool admits(float d, uint32_t idx) const { return filled < kk || pair_lt(d, idx, thr_d, thr_i); }
+};
+constexpr int kMaxFusedK2 = 128;
+
 // Fold of the 64 chains; every lane of the group ends with the row's sum.  `acc` holds chains 4m..4m+3.
 template <bool kIpTail>
 __device__ __forceinline__ float fold_chains(float4 acc, const float* __restrict__ row, const float* __restrict__ q, uint32_t dim,

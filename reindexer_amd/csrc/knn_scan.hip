@@ -46,8 +46,38 @@ __device__ __forceinline__ void block_merge_and_store(WaveTopK& top, const ScanP
 	}
 }
 
+// the same for the two-entries-per-lane list (64 < kk <= 128)
+__device__ __forceinline__ void block_merge_and_store(WaveTopK2& top, const ScanParams& p, int lane, int wave) {
+	__shared__ float s_d[kScanWaves][kMaxFusedK2];
+	__shared__ uint32_t s_i[kScanWaves][kMaxFusedK2];
+	s_d[wave][lane] = top.d0;
+	s_i[wave][lane] = top.i0;
+	s_d[wave][64 + lane] = top.d1;
+	s_i[wave][64 + lane] = top.i1;
+	__syncthreads();
+	if (wave != 0) return;
+	for (int w = 1; w < kScanWaves; ++w) {
+		for (uint32_t e = 0; e < top.kk; ++e) {   // sorted: once one entry is rejected the rest of that list is too
+			const float d = s_d[w][e];
+			const uint32_t i = s_i[w][e];
+			if (i == kInvalidRow || !top.admits(d, i)) break;
+			top.insert(d, i, lane);
+		}
+	}
+	const size_t o = (size_t(blockIdx.y) * gridDim.x + blockIdx.x) * top.kk;
+	if (lane < int(top.kk)) {
+		p.part_dist[o + lane] = top.d0;
+		p.part_row[o + lane] = top.i0;
+	}
+	if (64 + lane < int(top.kk)) {
+		p.part_dist[o + 64 + lane] = top.d1;
+		p.part_row[o + 64 + lane] = top.i1;
+	}
+}
+
 // Rows of this wave's step -> candidate insertion.  `dist` is replicated over each 16-lane group.
-__device__ __forceinline__ void consider_quad(WaveTopK& top, float dist, uint32_t row, bool valid, int lane) {
+template <typename TK>
+__device__ __forceinline__ void consider_quad(TK& top, float dist, uint32_t row, bool valid, int lane) {
 	// Rows arrive in increasing index order within a wave, so a tie with the current worst never enters:
 	// strict `<` is exactly the reference's admission test (bruteforce.cc:121).
 	const bool pass = valid && (top.filled < top.kk || dist < top.thr_d);
@@ -65,7 +95,7 @@ __device__ __forceinline__ void consider_quad(WaveTopK& top, float dist, uint32_
 //   kQLds     : query fragment read from LDS each step (frees NB*4 VGPRs) instead of living in registers
 //   kPrefetch : the loads of step i+1 are in flight while step i is reduced (double-buffered registers)
 //   kNT       : non-temporal row loads
-template <int kMetric, int NB, bool kQLds, bool kPrefetch, bool kNT>
+template <int kMetric, int NB, bool kQLds, bool kPrefetch, bool kNT, typename TK = WaveTopK>
 __global__ __launch_bounds__(kScanThreads) void knn_scan_fixed(ScanParams p) {
 	__shared__ float4 s_q[kQLds ? NB * 16 : 1];
 	if (p.gate_cnt && p.gate_cnt[blockIdx.y] <= p.gate_cap) return;
@@ -81,7 +111,7 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan_fixed(ScanParams p) {
 		for (int t = 0; t < NB; ++t) q[t] = qg[16 * t + m];
 	}
 
-	WaveTopK top;
+	TK top;
 	top.init(p.kk);
 
 	const uint64_t nquads = (p.n + kRowsPerWave - 1) / kRowsPerWave;
@@ -141,13 +171,13 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan_fixed(ScanParams p) {
 }
 
 // Any dim (tails included); query read through the caches.
-template <int kMetric>
+template <int kMetric, typename TK = WaveTopK>
 __global__ __launch_bounds__(kScanThreads) void knn_scan_generic(ScanParams p) {
 	if (p.gate_cnt && p.gate_cnt[blockIdx.y] <= p.gate_cap) return;
 	const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const float* q = p.queries + size_t(blockIdx.y) * p.dim;
-	WaveTopK top;
+	TK top;
 	top.init(p.kk);
 	const uint64_t nquads = (p.n + kRowsPerWave - 1) / kRowsPerWave;
 	const uint64_t nwaves = uint64_t(gridDim.x) * kScanWaves;
@@ -333,6 +363,58 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge(const float* part_dis
 	if (lane == 0 && out_count) out_count[blockIdx.x] = top.filled;
 }
 
+// knn_merge for 64 < kk <= 128 (two entries per lane)
+__global__ __launch_bounds__(kMergeThreads) void knn_merge_wide(const float* part_dist, const uint32_t* part_row, uint32_t total, uint32_t kk,
+																 float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	__shared__ float s_d[kMergeWaves][kMaxFusedK2];
+	__shared__ uint32_t s_i[kMergeWaves][kMaxFusedK2];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const size_t base = size_t(blockIdx.x) * total;
+	WaveTopK2 top;
+	top.init(kk);
+	for (uint32_t c0 = wave * kWave; c0 < total; c0 += kMergeThreads) {
+		const uint32_t c = c0 + lane;
+		float cd = __builtin_inff();
+		uint32_t ci = kInvalidRow;
+		if (c < total) {
+			cd = part_dist[base + c];
+			ci = part_row[base + c];
+		}
+		uint64_t pm = __ballot(ci != kInvalidRow && top.admits(cd, ci));
+		while (pm) {
+			const int src = __builtin_ctzll(pm);
+			pm &= pm - 1;
+			const float d = __shfl(cd, src);
+			const uint32_t i = __shfl(ci, src);
+			if (top.admits(d, i)) top.insert(d, i, lane);
+		}
+	}
+	s_d[wave][lane] = top.d0;
+	s_i[wave][lane] = top.i0;
+	s_d[wave][64 + lane] = top.d1;
+	s_i[wave][64 + lane] = top.i1;
+	__syncthreads();
+	if (wave != 0) return;
+	for (int w = 1; w < kMergeWaves; ++w) {
+		for (uint32_t e = 0; e < kk; ++e) {
+			const float d = s_d[w][e];
+			const uint32_t i = s_i[w][e];
+			if (i == kInvalidRow || !top.admits(d, i)) break;
+			top.insert(d, i, lane);
+		}
+	}
+	const size_t o = size_t(blockIdx.x) * kk;
+	if (lane < int(kk)) {
+		out_dist[o + lane] = top.d0;
+		out_row[o + lane] = top.i0;
+	}
+	if (64 + lane < int(kk)) {
+		out_dist[o + 64 + lane] = top.d1;
+		out_row[o + 64 + lane] = top.i1;
+	}
+	if (lane == 0 && out_count) out_count[blockIdx.x] = top.filled;
+}
+
 // Multi-GPU: fold the all-gathered per-shard lists of one query batch into the global top-kk.
 // gathered: [world][2][nq][kk] 32-bit words — per shard the [nq][kk] distances followed by the [nq][kk] shard-local rows (what
 // the scan writes when d_out_row == d_out_dist + nq*kk).  Global row = shard * shard_rows + local row; order = (dist, global row).
@@ -462,7 +544,24 @@ static void launch_scan_fixed(const ScanParams& p, dim3 grid, hipStream_t s) {
 }
 
 template <int kMetric>
+static void launch_scan_metric_wide(const ScanParams& p, dim3 grid, hipStream_t s) {
+	const dim3 blk(kScanThreads);
+	switch (p.dim) {
+		case 128: hipLaunchKernelGGL((knn_scan_fixed<kMetric, 2, true, true, true, WaveTopK2>), grid, blk, 0, s, p); return;
+		case 256: hipLaunchKernelGGL((knn_scan_fixed<kMetric, 4, true, true, true, WaveTopK2>), grid, blk, 0, s, p); return;
+		case 512: hipLaunchKernelGGL((knn_scan_fixed<kMetric, 8, true, true, true, WaveTopK2>), grid, blk, 0, s, p); return;
+		case 768: hipLaunchKernelGGL((knn_scan_fixed<kMetric, 12, true, true, true, WaveTopK2>), grid, blk, 0, s, p); return;
+		case 1024: hipLaunchKernelGGL((knn_scan_fixed<kMetric, 16, true, true, true, WaveTopK2>), grid, blk, 0, s, p); return;
+		default: hipLaunchKernelGGL((knn_scan_generic<kMetric, WaveTopK2>), grid, blk, 0, s, p);
+	}
+}
+
+template <int kMetric>
 static void launch_scan_metric(const ScanParams& p, dim3 grid, hipStream_t s) {
+	if (p.kk > uint32_t(kMaxFusedK)) {
+		launch_scan_metric_wide<kMetric>(p, grid, s);
+		return;
+	}
 	switch (p.dim) {
 		case 64: launch_scan_fixed<kMetric, 1>(p, grid, s); return;
 		case 128: launch_scan_fixed<kMetric, 2>(p, grid, s); return;
@@ -523,6 +622,10 @@ void launch_filter_approx(const float* approx, uint64_t n, const float* top_dist
 
 void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t total_per_query, uint32_t kk, uint32_t nq, float* out_dist,
 				  uint32_t* out_row, uint32_t* out_count, const uint32_t* gate_cnt, uint32_t gate_cap, hipStream_t s) {
+	if (kk > uint32_t(kMaxFusedK)) {   // 64 < kk <= 128: never gated (the batched / pruned paths keep kk <= 64)
+		hipLaunchKernelGGL(knn_merge_wide, dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, total_per_query, kk, out_dist, out_row, out_count);
+		return;
+	}
 	hipLaunchKernelGGL(knn_merge, dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, total_per_query, kk, out_dist, out_row, out_count,
 					   gate_cnt, gate_cap);
 }

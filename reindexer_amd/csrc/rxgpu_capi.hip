@@ -800,12 +800,14 @@ int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t
 	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
 	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, qbytes, hipMemcpyHostToDevice, c->stream));
 
-	if (eff <= uint32_t(rxgpu::kMaxFusedK)) {
+	if (eff <= uint32_t(rxgpu::kMaxFusedK2)) {
 		if (int rc = c->d_out_dist.ensure(size_t(nq) * eff * sizeof(float)); rc) return rc;
 		if (int rc = c->d_out_row.ensure(size_t(nq) * eff * sizeof(uint32_t)); rc) return rc;
 		if (int rc = c->d_out_count.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
-		if (int rc = enqueue_knn(h, c, static_cast<const float*>(c->d_queries.ptr), nq, eff, static_cast<float*>(c->d_out_dist.ptr),
-								 static_cast<uint32_t*>(c->d_out_row.ptr), static_cast<uint32_t*>(c->d_out_count.ptr));
+		// kk <= 64: fused / batched / pruned dispatch; 64 < kk <= 128 (e.g. hybrid k = 100): the fused scan with two list entries per lane
+		auto* run = eff <= uint32_t(rxgpu::kMaxFusedK) ? enqueue_knn : enqueue_knn_fused;
+		if (int rc = run(h, c, static_cast<const float*>(c->d_queries.ptr), nq, eff, static_cast<float*>(c->d_out_dist.ptr),
+						 static_cast<uint32_t*>(c->d_out_row.ptr), static_cast<uint32_t*>(c->d_out_count.ptr));
 			rc)
 			return rc;
 		if (eff == kk) {

@@ -261,3 +261,32 @@ def test_device_shard_merge_equals_single_index(rxgpu, oracle, nq):
         assert np.array_equal(bits(od[qi].cpu().numpy()), bits(wd))
     for ix in shards:
         ix.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("d,n", [(768, 20_000), (128, 60_000), (100, 9_000), (64, 90)])
+def test_fused_scan_with_two_entries_per_lane(rxgpu, oracle, metric, d, n):
+    """64 < k <= 128 (a hybrid query asks for k = 100): the fused scan keeps two list entries per lane instead of falling to the radix-select
+    path.  Same contract: exact rows and distance bits, ties by row — checked on gaussian and on quantised (massively tied) data."""
+    from .conftest import lex_topk
+    rng = np.random.default_rng(d + metric)
+    for style in ("gauss", "quant"):
+        rows = make_corpus(d + 3, n, d) if style == "gauss" else rng.integers(-1, 2, (n, d)).astype(np.float32)
+        if metric == 2:
+            rows[np.all(rows == 0, axis=1)] = 1.0
+        inv = oracle.l2_modules(rows) if metric == 2 else None
+        queries = make_corpus(4000 + d, 3, d) if style == "gauss" else rng.integers(-1, 2, (3, d)).astype(np.float32)
+        if metric == 2:
+            queries[np.all(queries == 0, axis=1)] = 1.0
+            queries = np.stack([oracle.normalize_copy(q)[0] for q in queries])
+        with rxgpu.VectorIndex(metric, d, n) as ix:
+            ix.upload_rows(0, rows, inv)
+            for k in (65, 100, 101, 128, 129):
+                for nq in (1, 3):
+                    dist, row, cnt = ix.search_knn(queries[:nq], k)
+                    c = min(k, n)
+                    for qi in range(nq):
+                        wd, wr = lex_topk(oracle.dist_many(metric, queries[qi], rows, inv), c)
+                        assert int(cnt[qi]) == c
+                        assert np.array_equal(row[qi, :c], wr), (metric, d, style, k, qi)
+                        assert np.array_equal(dist[qi, :c].view(np.uint32), wd.view(np.uint32))
