@@ -152,8 +152,19 @@ HnswGraph::Heap HnswGraph::searchBaseLayer(tableint ep, tableint self, int layer
 		frontier.pop();
 		const uint32_t* ll = list(cur.second, layer);
 		const size_t size = ll[0];
+		if (size) {   // the reference prefetches the same way (hnswalg.h:674-716): stamp + head of the vector of the neighbour that comes next
+			__builtin_prefetch(&visitStamp_[ll[1]]);
+			__builtin_prefetch(Vector(ll[1]));
+		}
 		for (size_t j = 0; j < size; ++j) {
 			const tableint cand = ll[1 + j];
+			if (j + 1 < size) {
+				const tableint next = ll[2 + j];
+				__builtin_prefetch(&visitStamp_[next]);
+				const char* nv = reinterpret_cast<const char*>(Vector(next));
+				__builtin_prefetch(nv);
+				__builtin_prefetch(nv + 64);
+			}
 			if (visitStamp_[cand] == stamp) continue;
 			visitStamp_[cand] = stamp;
 			const float d = distIds(self, cand);
