@@ -97,13 +97,39 @@ uint64_t rxgpu_index_device_bytes(const rxgpu_index* h);
  * queries: host [nq][dim] (cosine: already normalised by the caller, hnsw_index.cc:166-171).
  * out_dist/out_row: host [nq][kk]; out_count[q] = min(kk, count).
  * The GPU Map asks for kk = k+1 so it can detect a distance tie straddling the k-th boundary and replay the
- * reference's admission rule (strict `dist < worst`, bruteforce.cc:121) with rxgpu_search_collect_le(). */
+ * reference's admission rule (strict `dist < worst`, bruteforce.cc:121) with rxgpu_search_range(inclusive = 1). */
 int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, float* out_dist, uint32_t* out_row,
 					 uint32_t* out_count);
 
 /* Same, device-resident in/out on `stream` (hipStream_t); d_out_count may be NULL.  No synchronisation. */
 int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, void* d_out_dist, void* d_out_row,
 							void* d_out_count, void* stream);
+
+/* ---- Pre-filtered brute force: the caller side of `WHERE cond AND KNN(...)` -------------------
+ * The reference evaluates such a query by taking the KNN result and filtering it on the host (selectLoop,
+ * nsselecter.cc:841-875); only HNSW can stream more candidates (knn_streaming_index_iterator.cc).  Here the rows that
+ * passed `cond` are handed to the scan, which then reads ONLY those rows: the result is exactly what
+ * BruteforceSearch::SearchKnn (bruteforce.cc:103-127) returns over an index that holds just the allowed rows —
+ * same distance bits, same (dist, row) order — and HBM traffic shrinks with the selectivity of the filter.
+ *
+ * rxgpu_search_knn_subset: row_ids = host [n_ids], strictly increasing internal rows (the shape of the selector's
+ *   sorted IdSet, core/idset.h); best for selective filters (4 bytes per allowed row on the wire).
+ * rxgpu_search_knn_bitmap: allowed_words = host [n_words >= ceil(count / 32)], bit (r % 32) of word r / 32 set = row r
+ *   allowed (bits at and above `count` are ignored); expanded to the row list on the device; best for dense filters
+ *   (count / 8 bytes on the wire).  *out_allowed (optional) = number of allowed rows.
+ * Output layout as rxgpu_search_knn: host [nq][kk], out_count[q] = min(kk, allowed rows); any kk.
+ * Errors: RXGPU_ERR_PARAMS for an unsorted / out-of-range list or a short bitmap. */
+int rxgpu_search_knn_subset(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* row_ids, uint64_t n_ids,
+							float* out_dist, uint32_t* out_row, uint32_t* out_count);
+int rxgpu_search_knn_bitmap(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* allowed_words,
+							uint64_t n_words, float* out_dist, uint32_t* out_row, uint32_t* out_count, uint64_t* out_allowed);
+
+/* Device-resident variant on `stream` (no synchronisation): d_row_ids = device [n_ids] uint32, 1 <= n_ids <= count,
+ * kk in [1, 128]; d_out_count may be NULL.  The list is TRUSTED (strictly increasing, below count): an id beyond the
+ * index would fault the device.  rxgpu_check_row_list_device() verifies a device list (synchronises `stream`). */
+int rxgpu_search_knn_subset_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, const void* d_row_ids,
+								   uint64_t n_ids, void* d_out_dist, void* d_out_row, void* d_out_count, void* stream);
+int rxgpu_check_row_list_device(rxgpu_index* h, const void* d_row_ids, uint64_t n_ids, void* stream, int32_t* out_ok);
 
 /* Multi-GPU merge step (no reference counterpart: the reference has no device notion).  d_gathered = the all-gather of every
  * rank's search output for one query batch: [world][2][nq][kk] 32-bit words — per rank the [nq][kk] distances followed by the

@@ -49,6 +49,10 @@ _SIGNATURES = {
     "rxgpu_index_device_bytes": (_u64, [_vp]),
     "rxgpu_search_knn": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_search_knn_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "rxgpu_search_knn_subset": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
+    "rxgpu_search_knn_bitmap": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "rxgpu_search_knn_subset_device": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _vp]),
+    "rxgpu_check_row_list_device": (_i, [_vp, _vp, _u64, _vp, C.POINTER(C.c_int32)]),
     "rxgpu_merge_shards_device": (_i, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_search_range": (_i, [_vp, _vp, _f, _i, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_distances": (_i, [_vp, _vp, _vp, _u32, _vp]),
@@ -213,6 +217,42 @@ class VectorIndex:
     def search_knn_device(self, d_queries_ptr: int, nq: int, kk: int, d_out_dist_ptr: int, d_out_row_ptr: int,
                           d_out_count_ptr: int | None, stream_ptr: int) -> None:
         _check(lib().rxgpu_search_knn_device(self._h, d_queries_ptr, nq, kk, d_out_dist_ptr, d_out_row_ptr, d_out_count_ptr, stream_ptr))
+
+    # ---- pre-filtered search (`WHERE cond AND KNN(...)`)
+    def search_knn_subset(self, queries, kk: int, row_ids):
+        """Exact top-kk among the listed rows only (strictly increasing uint32 internal rows) -> (dist, row, count)."""
+        q = _f32c(queries).reshape(-1, self.dim)
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint32).reshape(-1)
+        nq = q.shape[0]
+        dist = np.full((nq, max(kk, 1)), np.inf, np.float32)
+        row = np.full((nq, max(kk, 1)), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        _check(lib().rxgpu_search_knn_subset(self._h, q.ctypes.data, nq, kk, ids.ctypes.data if ids.size else None, ids.size,
+                                             dist.ctypes.data, row.ctypes.data, cnt.ctypes.data))
+        return dist[:, :kk], row[:, :kk], cnt
+
+    def search_knn_bitmap(self, queries, kk: int, allowed_words):
+        """Same, the allowed rows given as a bitmap (uint32 words, bit r % 32 of word r // 32) -> (dist, row, count, n_allowed)."""
+        q = _f32c(queries).reshape(-1, self.dim)
+        words = np.ascontiguousarray(allowed_words, dtype=np.uint32).reshape(-1)
+        nq = q.shape[0]
+        dist = np.full((nq, max(kk, 1)), np.inf, np.float32)
+        row = np.full((nq, max(kk, 1)), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        allowed = _u64(0)
+        _check(lib().rxgpu_search_knn_bitmap(self._h, q.ctypes.data, nq, kk, words.ctypes.data, words.size, dist.ctypes.data, row.ctypes.data,
+                                             cnt.ctypes.data, C.byref(allowed)))
+        return dist[:, :kk], row[:, :kk], cnt, int(allowed.value)
+
+    def search_knn_subset_device(self, d_queries_ptr: int, nq: int, kk: int, d_row_ids_ptr: int, n_ids: int, d_out_dist_ptr: int,
+                                 d_out_row_ptr: int, d_out_count_ptr: int | None, stream_ptr: int) -> None:
+        _check(lib().rxgpu_search_knn_subset_device(self._h, d_queries_ptr, nq, kk, d_row_ids_ptr, n_ids, d_out_dist_ptr, d_out_row_ptr,
+                                                    d_out_count_ptr, stream_ptr))
+
+    def check_row_list_device(self, d_row_ids_ptr: int, n_ids: int, stream_ptr: int) -> bool:
+        ok = C.c_int32(0)
+        _check(lib().rxgpu_check_row_list_device(self._h, d_row_ids_ptr, n_ids, stream_ptr, C.byref(ok)))
+        return bool(ok.value)
 
     def search_range(self, query, radius: float, inclusive: bool = False, cap: int = 1 << 16):
         q = _f32c(query).reshape(self.dim)

@@ -2,6 +2,7 @@
 // See knn_kernels.hip.h for the arithmetic contract.  Reference being replaced:
 // cpp_src/core/index/float_vector/hnswlib/bruteforce.cc:103-143.
 #include <algorithm>
+#include <type_traits>
 
 #include "knn_kernels.hip.h"
 #include "rxgpu_internal.h"
@@ -188,6 +189,100 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan_generic(ScanParams p) {
 		const float sum = group_distance_generic<kMetric>(p.rows + rowc * p.stride, q, p.dim, m);
 		const float dist = metric_epilogue<kMetric>(sum, p.inv_norms, rowc);
 		consider_quad(top, dist, uint32_t(row), valid, lane);
+	}
+	block_merge_and_store(top, p, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pre-filtered scan: only the rows listed in `ids` (strictly increasing internal row numbers, p.n of them) compete.  This is the
+// caller side of `WHERE cond AND KNN(...)` (the reference post-filters on the host, nsselecter.cc:841-875): HBM traffic is
+// ids (4 B) + one row per ALLOWED row, so a 5 % filter reads 5 % of the corpus.  Distances are the same per-row arithmetic as
+// knn_scan_fixed and the (dist,row) list order is unchanged, hence the result is the unfiltered engine's result over the sub-corpus.
+//
+// A wavefront owns chunks of 64 consecutive list entries (chunk c of wave w = first + c * nwaves): ONE coalesced 256-byte load brings the
+// ids of 16 steps (lane l: step l / 4, group l % 4; a step's id is fetched with a cross-lane read), so the dependent id -> row address
+// hop is off the per-step path and the row loads keep the double-buffered issue order of knn_scan_fixed across chunk boundaries.
+template <int kMetric, int NB, typename TK = WaveTopK>
+__global__ __launch_bounds__(kScanThreads) void knn_scan_subset(ScanParams p, const uint32_t* __restrict__ ids) {
+	__shared__ float4 s_q[NB * 16];
+	const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const float4* qg = reinterpret_cast<const float4*>(p.queries + size_t(blockIdx.y) * p.dim);
+	for (int i = threadIdx.x; i < NB * 16; i += kScanThreads) s_q[i] = qg[i];
+	__syncthreads();
+
+	TK top;
+	top.init(p.kk);
+
+	constexpr int kChunk = 64, kSteps = kChunk / kRowsPerWave;
+	const uint64_t nchunks = (p.n + kChunk - 1) / kChunk;
+	const uint64_t nwaves = uint64_t(gridDim.x) * kScanWaves;
+	const uint64_t first = uint64_t(blockIdx.x) * kScanWaves + wave;
+
+	auto load_ids = [&](uint64_t chunk) -> uint32_t {   // clamped: reading past the list re-reads its last entry
+		const uint64_t cc = chunk < nchunks ? chunk : nchunks - 1;
+		const uint64_t item = cc * kChunk + lane;
+		return ids[item < p.n ? item : p.n - 1];
+	};
+	auto issue = [&](float4 (&x)[NB], uint32_t row) {
+		const float4* rp = reinterpret_cast<const float4*>(p.rows + uint64_t(row) * p.stride) + m;
+#pragma unroll
+		for (int t = 0; t < NB; ++t) x[t] = load_row4<true>(rp + 16 * t);
+	};
+	auto reduce = [&](const float4 (&x)[NB], uint64_t item, uint32_t row) {
+		float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+		for (int t = 0; t < NB; ++t) chain_step<kMetric>(acc, s_q[16 * t + m], x[t]);
+		const float sum = fold_chains<false>(acc, nullptr, nullptr, 0, m) + 0.0f;
+		const float dist = metric_epilogue<kMetric>(sum, p.inv_norms, row);
+		consider_quad(top, dist, row, item < p.n, lane);
+	};
+
+	if (first < nchunks) {
+		float4 xa[NB], xb[NB];
+		uint32_t idc = load_ids(first);
+		issue(xa, __shfl(idc, g));
+		for (uint64_t chunk = first; chunk < nchunks; chunk += nwaves) {
+			const uint32_t idn = load_ids(chunk + nwaves);   // in flight while this chunk's 16 steps run
+			const uint64_t base = chunk * kChunk + g;
+#pragma unroll 1
+			for (int t = 0; t < kSteps; t += 2) {
+				const uint32_t ra = __shfl(idc, t * kRowsPerWave + g);
+				const uint32_t rb = __shfl(idc, (t + 1) * kRowsPerWave + g);
+				issue(xb, rb);
+				__builtin_amdgcn_sched_barrier(0);
+				reduce(xa, base + uint64_t(t) * kRowsPerWave, ra);
+				__builtin_amdgcn_sched_barrier(0);
+				// step t + 2 of this chunk, or step 0 of this wave's next chunk (harmless re-read after the last one)
+				const uint32_t rn = t + 2 < kSteps ? __shfl(idc, (t + 2) * kRowsPerWave + g) : __shfl(idn, g);
+				issue(xa, rn);
+				__builtin_amdgcn_sched_barrier(0);
+				reduce(xb, base + uint64_t(t + 1) * kRowsPerWave, rb);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			idc = idn;
+		}
+	}
+	block_merge_and_store(top, p, lane, wave);
+}
+
+// Any dim: one list entry per 16-lane group and step.
+template <int kMetric, typename TK = WaveTopK>
+__global__ __launch_bounds__(kScanThreads) void knn_scan_subset_generic(ScanParams p, const uint32_t* __restrict__ ids) {
+	const int lane = threadIdx.x & 63, m = lane & 15, g = lane >> 4;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const float* q = p.queries + size_t(blockIdx.y) * p.dim;
+	TK top;
+	top.init(p.kk);
+	const uint64_t nquads = (p.n + kRowsPerWave - 1) / kRowsPerWave;
+	const uint64_t nwaves = uint64_t(gridDim.x) * kScanWaves;
+	for (uint64_t quad = uint64_t(blockIdx.x) * kScanWaves + wave; quad < nquads; quad += nwaves) {
+		const uint64_t item = quad * kRowsPerWave + g;
+		const bool valid = item < p.n;
+		const uint32_t row = ids[valid ? item : p.n - 1];
+		const float sum = group_distance_generic<kMetric>(p.rows + uint64_t(row) * p.stride, q, p.dim, m);
+		const float dist = metric_epilogue<kMetric>(sum, p.inv_norms, row);
+		consider_quad(top, dist, row, valid, lane);
 	}
 	block_merge_and_store(top, p, lane, wave);
 }
@@ -587,6 +682,60 @@ void launch_scan(int metric, const ScanParams& p, uint32_t nq, uint32_t gridx, h
 		case kL2: launch_scan_metric<kL2>(p, grid, s); break;
 		case kIP: launch_scan_metric<kIP>(p, grid, s); break;
 		default: launch_scan_metric<kCos>(p, grid, s); break;
+	}
+}
+
+// ---- pre-filtered scan ----
+constexpr uint64_t kSubsetChunk = 64;   // list entries per wavefront chunk of knn_scan_subset
+
+static bool subset_fixed_dim(uint32_t dim, uint32_t kk) {
+	if (kk > uint32_t(kMaxFusedK)) return dim == 512 || dim == 768;
+	return dim == 128 || dim == 256 || dim == 512 || dim == 768 || dim == 1024;
+}
+// short lists go to the one-quad-per-step kernel (16x more wavefronts in flight); long ones to the chunked, double-buffered one
+static bool subset_use_chunked(uint64_t n_ids, uint32_t dim, uint32_t kk, int cus) {
+	const uint64_t waves = uint64_t(cus) * tuning().wg_per_cu * kScanWaves;
+	return subset_fixed_dim(dim, kk) && n_ids >= 2 * waves * kSubsetChunk;
+}
+uint32_t subset_grid_x(uint64_t n_ids, uint32_t dim, uint32_t kk, int cus) {
+	if (!subset_use_chunked(n_ids, dim, kk, cus)) return scan_grid_x(n_ids, cus);
+	const uint64_t nchunks = (n_ids + kSubsetChunk - 1) / kSubsetChunk;
+	const uint64_t want = (nchunks + kScanWaves - 1) / kScanWaves;
+	const uint64_t cap = uint64_t(cus) * tuning().wg_per_cu;
+	return uint32_t(want < cap ? want : cap);
+}
+
+template <int kMetric, typename TK>
+static void launch_scan_subset_tk(const ScanParams& p, const uint32_t* ids, bool chunked, dim3 grid, hipStream_t s) {
+	const dim3 blk(kScanThreads);
+	if (chunked) {
+		switch (p.dim) {
+			case 128: if constexpr (std::is_same_v<TK, WaveTopK>) { hipLaunchKernelGGL((knn_scan_subset<kMetric, 2, TK>), grid, blk, 0, s, p, ids); return; } break;
+			case 256: if constexpr (std::is_same_v<TK, WaveTopK>) { hipLaunchKernelGGL((knn_scan_subset<kMetric, 4, TK>), grid, blk, 0, s, p, ids); return; } break;
+			case 512: hipLaunchKernelGGL((knn_scan_subset<kMetric, 8, TK>), grid, blk, 0, s, p, ids); return;
+			case 768: hipLaunchKernelGGL((knn_scan_subset<kMetric, 12, TK>), grid, blk, 0, s, p, ids); return;
+			case 1024: if constexpr (std::is_same_v<TK, WaveTopK>) { hipLaunchKernelGGL((knn_scan_subset<kMetric, 16, TK>), grid, blk, 0, s, p, ids); return; } break;
+			default: break;
+		}
+	}
+	hipLaunchKernelGGL((knn_scan_subset_generic<kMetric, TK>), grid, blk, 0, s, p, ids);
+}
+template <int kMetric>
+static void launch_scan_subset_metric(const ScanParams& p, const uint32_t* ids, bool chunked, dim3 grid, hipStream_t s) {
+	if (p.kk > uint32_t(kMaxFusedK)) {
+		launch_scan_subset_tk<kMetric, WaveTopK2>(p, ids, chunked, grid, s);
+	} else {
+		launch_scan_subset_tk<kMetric, WaveTopK>(p, ids, chunked, grid, s);
+	}
+}
+// p.n = number of list entries; gridx MUST come from subset_grid_x (it selects the kernel together with this function)
+void launch_scan_subset(int metric, const ScanParams& p, const uint32_t* ids, uint32_t nq, uint32_t gridx, int cus, hipStream_t s) {
+	const dim3 grid(gridx, nq);
+	const bool chunked = subset_use_chunked(p.n, p.dim, p.kk, cus);
+	switch (metric) {
+		case kL2: launch_scan_subset_metric<kL2>(p, ids, chunked, grid, s); break;
+		case kIP: launch_scan_subset_metric<kIP>(p, ids, chunked, grid, s); break;
+		default: launch_scan_subset_metric<kCos>(p, ids, chunked, grid, s); break;
 	}
 }
 

@@ -79,6 +79,9 @@ void rxgpu_search_ctx::release() {
 	d_gcand_i.release();
 	d_redo.release();
 	d_top.release();
+	d_subset.release();
+	d_bitmap.release();
+	d_tiles.release();
 	if (h_pinned) (void)hipHostFree(h_pinned);
 	h_pinned = nullptr;
 	if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -532,6 +535,93 @@ int enqueue_knn_pruned(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queri
 	return RXGPU_OK;
 }
 
+// Pre-filtered search, kk <= kMaxFusedK2: gather-scan over the row list + the usual merge (rows in the lists are real rows, so the
+// merge and everything downstream is unchanged).
+int enqueue_knn_subset(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, const uint32_t* d_ids,
+					   uint64_t n_ids, float* d_out_dist, uint32_t* d_out_row, uint32_t* d_out_count) {
+	const uint32_t gridx = rxgpu::subset_grid_x(n_ids, h->dim, kk, h->cus);
+	const size_t part = size_t(nq) * gridx * kk;
+	if (int rc = c->d_part_dist.ensure(part * sizeof(float)); rc) return rc;
+	if (int rc = c->d_part_row.ensure(part * sizeof(uint32_t)); rc) return rc;
+	rxgpu::ScanParams p{};
+	p.rows = h->d_rows;
+	p.inv_norms = h->d_inv_norms;
+	p.queries = d_queries;
+	p.n = n_ids;
+	p.stride = h->stride;
+	p.dim = h->dim;
+	p.kk = kk;
+	p.part_dist = static_cast<float*>(c->d_part_dist.ptr);
+	p.part_row = static_cast<uint32_t*>(c->d_part_row.ptr);
+	{
+		ProfileScope ps(h, "scan_subset", c->stream);
+		rxgpu::launch_scan_subset(h->metric, p, d_ids, nq, gridx, h->cus, c->stream);
+	}
+	{
+		ProfileScope ps(h, "merge", c->stream);
+		rxgpu::launch_merge(p.part_dist, p.part_row, gridx * kk, kk, nq, d_out_dist, d_out_row, d_out_count, nullptr, 0, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	return RXGPU_OK;
+}
+
+// Host-facing tail shared by rxgpu_search_knn_subset / _bitmap: queries on the host, the row list already in HBM.
+int search_subset_host(rxgpu_index* h, rxgpu_search_ctx* c, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* d_ids,
+					   uint64_t n_ids, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	const uint32_t eff = uint32_t(std::min<uint64_t>(kk, n_ids));
+	const size_t qbytes = size_t(nq) * h->dim * sizeof(float);
+	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, qbytes, hipMemcpyHostToDevice, c->stream));
+	if (eff <= uint32_t(rxgpu::kMaxFusedK2)) {
+		if (int rc = c->d_out_dist.ensure(size_t(nq) * eff * sizeof(float)); rc) return rc;
+		if (int rc = c->d_out_row.ensure(size_t(nq) * eff * sizeof(uint32_t)); rc) return rc;
+		if (int rc = c->d_out_count.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
+		if (int rc = enqueue_knn_subset(h, c, static_cast<const float*>(c->d_queries.ptr), nq, eff, d_ids, n_ids,
+										static_cast<float*>(c->d_out_dist.ptr), static_cast<uint32_t*>(c->d_out_row.ptr),
+										static_cast<uint32_t*>(c->d_out_count.ptr));
+			rc)
+			return rc;
+		RX_HIP(hipMemcpy2DAsync(out_dist, kk * sizeof(float), c->d_out_dist.ptr, eff * sizeof(float), eff * sizeof(float), nq,
+								hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpy2DAsync(out_row, kk * sizeof(uint32_t), c->d_out_row.ptr, eff * sizeof(uint32_t), eff * sizeof(uint32_t), nq,
+								hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));
+		return RXGPU_OK;
+	}
+	// large k: distances of the listed rows + radix select over (dist, position); positions -> rows; final sort of eff entries on the host
+	RX_CHECK(n_ids <= (1ull << 28), RXGPU_ERR_PARAMS, "pre-filtered search with k > 128: the row list must not exceed 2^28 entries");
+	if (int rc = c->d_misc.ensure(n_ids * sizeof(float)); rc) return rc;
+	if (int rc = c->d_select.ensure(rxgpu::select_scratch_bytes(n_ids)); rc) return rc;
+	if (int rc = c->d_out_dist.ensure(size_t(eff) * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(size_t(eff) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_part_row.ensure(size_t(eff) * sizeof(uint32_t)); rc) return rc;
+	std::vector<float> hd(eff);
+	std::vector<uint32_t> hr(eff), order(eff);
+	for (uint32_t q = 0; q < nq; ++q) {
+		{
+			ProfileScope ps(h, "scan_subset", c->stream);
+			rxgpu::launch_distances(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr) + size_t(q) * h->dim,
+									h->stride, h->dim, d_ids, uint32_t(n_ids), static_cast<float*>(c->d_misc.ptr), c->stream);
+		}
+		rxgpu::launch_select_smallest(static_cast<const float*>(c->d_misc.ptr), n_ids, eff, c->d_select.ptr, static_cast<float*>(c->d_out_dist.ptr),
+									  static_cast<uint32_t*>(c->d_out_row.ptr), c->stream);
+		rxgpu::launch_gather_u32(d_ids, static_cast<const uint32_t*>(c->d_out_row.ptr), eff, static_cast<uint32_t*>(c->d_part_row.ptr), c->stream);
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipMemcpyAsync(hd.data(), c->d_out_dist.ptr, size_t(eff) * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(hr.data(), c->d_part_row.ptr, size_t(eff) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));
+		std::iota(order.begin(), order.end(), 0u);
+		std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hd[a] < hd[b] || (!(hd[b] < hd[a]) && hr[a] < hr[b]); });
+		for (uint32_t i = 0; i < eff; ++i) {
+			out_dist[size_t(q) * kk + i] = hd[order[i]];
+			out_row[size_t(q) * kk + i] = hr[order[i]];
+		}
+		out_count[q] = eff;
+	}
+	return RXGPU_OK;
+}
+
 int enqueue_knn(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queries, uint32_t nq, uint32_t kk, float* d_out_dist,
 				uint32_t* d_out_row, uint32_t* d_out_count) {
 	if (scan_bf16_enabled() && nq <= kPrunedMaxQueries && !h->bf16_unavailable && rxgpu::scan_bf16_supported((h->dim + 63u) & ~63u)) {
@@ -857,6 +947,110 @@ int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t
 		}
 		out_count[q] = eff;
 	}
+	return RXGPU_OK;
+}
+
+int rxgpu_search_knn_subset(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* row_ids, uint64_t n_ids,
+							float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(queries && out_dist && out_row && out_count && (n_ids == 0 || row_ids), RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset: null argument");
+	if (nq == 0) return RXGPU_OK;
+	for (uint64_t i = 0; i < n_ids; ++i) {
+		RX_CHECK(row_ids[i] < h->count && (i == 0 || row_ids[i - 1] < row_ids[i]), RXGPU_ERR_PARAMS,
+				 "rxgpu_search_knn_subset: row_ids must be strictly increasing and below the row count");
+	}
+	if (n_ids == 0 || kk == 0) {
+		std::fill(out_count, out_count + nq, 0u);
+		return RXGPU_OK;
+	}
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	if (int rc = c->d_subset.ensure(n_ids * sizeof(uint32_t)); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_subset.ptr, row_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	return search_subset_host(h, c, queries, nq, kk, static_cast<const uint32_t*>(c->d_subset.ptr), n_ids, out_dist, out_row, out_count);
+}
+
+int rxgpu_search_knn_bitmap(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* allowed_words, uint64_t n_words,
+							float* out_dist, uint32_t* out_row, uint32_t* out_count, uint64_t* out_allowed) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(queries && out_dist && out_row && out_count && allowed_words, RXGPU_ERR_PARAMS, "rxgpu_search_knn_bitmap: null argument");
+	const uint64_t need_words = (h->count + 31) / 32;
+	RX_CHECK(n_words >= need_words, RXGPU_ERR_PARAMS, "rxgpu_search_knn_bitmap: the bitmap must cover every row (ceil(count / 32) words)");
+	if (out_allowed) *out_allowed = 0;
+	if (nq == 0) return RXGPU_OK;
+	if (h->count == 0) {
+		std::fill(out_count, out_count + nq, 0u);
+		return RXGPU_OK;
+	}
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	const uint32_t tiles = rxgpu::bitmap_tiles(h->count);
+	if (int rc = c->d_bitmap.ensure(need_words * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_tiles.ensure(size_t(2) * tiles * sizeof(uint32_t) + sizeof(unsigned long long)); rc) return rc;
+	uint32_t* tile_scratch = static_cast<uint32_t*>(c->d_tiles.ptr);
+	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(tile_scratch + size_t(2) * tiles);   // 8-byte aligned: 2 * tiles words
+	RX_HIP(hipMemcpyAsync(c->d_bitmap.ptr, allowed_words, need_words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	{
+		ProfileScope ps(h, "bitmap", c->stream);
+		rxgpu::launch_bitmap_count(static_cast<const uint32_t*>(c->d_bitmap.ptr), h->count, tile_scratch, d_total, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	unsigned long long total = 0;
+	RX_HIP(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	if (out_allowed) *out_allowed = total;
+	if (total == 0 || kk == 0) {
+		std::fill(out_count, out_count + nq, 0u);
+		return RXGPU_OK;
+	}
+	if (int rc = c->d_subset.ensure(total * sizeof(uint32_t)); rc) return rc;
+	{
+		ProfileScope ps(h, "bitmap", c->stream);
+		rxgpu::launch_bitmap_expand(static_cast<const uint32_t*>(c->d_bitmap.ptr), h->count, tile_scratch, static_cast<uint32_t*>(c->d_subset.ptr),
+									total, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	return search_subset_host(h, c, queries, nq, kk, static_cast<const uint32_t*>(c->d_subset.ptr), total, out_dist, out_row, out_count);
+}
+
+int rxgpu_search_knn_subset_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, const void* d_row_ids, uint64_t n_ids,
+								   void* d_out_dist, void* d_out_row, void* d_out_count, void* stream) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(nq > 0 && d_queries && d_row_ids && d_out_dist && d_out_row, RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset_device: null argument");
+	RX_CHECK(kk > 0 && kk <= uint32_t(rxgpu::kMaxFusedK2), RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset_device: kk must be in [1, 128]");
+	RX_CHECK(n_ids > 0 && n_ids <= h->count, RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset_device: the row list must hold 1..count entries");
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = stream_ctx(h, stream);
+	return enqueue_knn_subset(h, c, static_cast<const float*>(d_queries), nq, kk, static_cast<const uint32_t*>(d_row_ids), n_ids,
+							  static_cast<float*>(d_out_dist), static_cast<uint32_t*>(d_out_row), static_cast<uint32_t*>(d_out_count));
+}
+
+int rxgpu_check_row_list_device(rxgpu_index* h, const void* d_row_ids, uint64_t n_ids, void* stream, int32_t* out_ok) {
+	RX_CHECK(h && out_ok && (n_ids == 0 || d_row_ids), RXGPU_ERR_PARAMS, "rxgpu_check_row_list_device: null argument");
+	*out_ok = 1;
+	if (n_ids == 0) return RXGPU_OK;
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = stream_ctx(h, stream);
+	if (int rc = c->d_tiles.ensure(sizeof(uint32_t)); rc) return rc;
+	RX_HIP(hipMemsetAsync(c->d_tiles.ptr, 0, sizeof(uint32_t), c->stream));
+	rxgpu::launch_check_row_list(static_cast<const uint32_t*>(d_row_ids), n_ids, h->count, static_cast<uint32_t*>(c->d_tiles.ptr), h->cus, c->stream);
+	RX_HIP(hipGetLastError());
+	uint32_t bad = 0;
+	RX_HIP(hipMemcpyAsync(&bad, c->d_tiles.ptr, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	*out_ok = bad ? 0 : 1;
 	return RXGPU_OK;
 }
 

@@ -30,6 +30,15 @@ void launch_range(int metric, const float* rows, const float* inv_norms, const f
 void launch_distances(int metric, const float* rows, const float* inv_norms, const float* query, uint32_t stride, uint32_t dim,
 					  const uint32_t* ids, uint32_t n, float* out, hipStream_t s);
 
+// Pre-filtered search (knn_scan.hip: knn_scan_subset; knn_subset.hip: bitmap -> row list)
+uint32_t subset_grid_x(uint64_t n_ids, uint32_t dim, uint32_t kk, int cus);
+void launch_scan_subset(int metric, const ScanParams& p, const uint32_t* ids, uint32_t nq, uint32_t gridx, int cus, hipStream_t s);
+uint32_t bitmap_tiles(uint64_t n_rows);
+void launch_bitmap_count(const uint32_t* words, uint64_t n_rows, uint32_t* tile_scratch, unsigned long long* total, hipStream_t s);
+void launch_bitmap_expand(const uint32_t* words, uint64_t n_rows, const uint32_t* tile_scratch, uint32_t* out_rows, uint64_t cap, hipStream_t s);
+void launch_gather_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s);
+void launch_check_row_list(const uint32_t* ids, uint64_t n, uint64_t limit, uint32_t* bad, int cus, hipStream_t s);
+
 // Large-k path (k+1 > 64): distance pass + radix select (knn_select.hip).
 void launch_all_distances(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride,
 						  uint32_t dim, float* out_dist, uint32_t gridx, hipStream_t s);
@@ -162,6 +171,7 @@ struct rxgpu_search_ctx {
 	rxgpu_devbuf d_qpad, d_qstats, d_dense, d_cand_row, d_cand_dist, d_cand_cnt;   // batched path
 	rxgpu_devbuf d_visited, d_gcand_d, d_gcand_i, d_redo;                          // HNSW
 	rxgpu_devbuf d_top;                                                            // bf16-pruned scan: approximate top lists
+	rxgpu_devbuf d_subset, d_bitmap, d_tiles;                                      // pre-filtered search: row list, allowed-rows bitmap, tile sums
 	void* h_pinned = nullptr;
 	size_t h_pinned_bytes = 0;
 	int ensure_pinned(size_t need);

@@ -295,12 +295,18 @@ SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optio
 		for (size_t i = 0; i < std::min<size_t>(k, count); ++i) result.emplace(dist[i], labels_[row[i]]);
 		return result;
 	}
-	// ---- tie replay
+	return replayTies(queryData, k, dist[k - 1], nullptr);
+}
+
+// The tie replay of SearchKnn / SearchKnnFiltered: every row with dist <= dk (restricted to `allowedRows` when given, sorted), walked in
+// scan order through the reference's admission rule.
+SearchResultQueue GpuBruteforceMap::replayTies(const float* queryData, size_t k, float dk, const std::vector<uint32_t>* allowedRows) const {
+	SearchResultQueue result;
+	result.reserve(k);
 	{
 		std::lock_guard<std::mutex> lk(syncMtx_);
 		++tieReplays_;
 	}
-	const float dk = dist[k - 1];
 	std::vector<float> rd(std::max<size_t>(4 * k, 256));
 	std::vector<uint32_t> rr(rd.size());
 	uint64_t total = 0;
@@ -311,8 +317,11 @@ SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optio
 		rd.resize(total);
 		rr.resize(total);
 	}
-	std::vector<uint32_t> order(total);
-	for (uint64_t i = 0; i < total; ++i) order[i] = uint32_t(i);
+	std::vector<uint32_t> order;
+	order.reserve(total);
+	for (uint64_t i = 0; i < total; ++i) {
+		if (!allowedRows || std::binary_search(allowedRows->begin(), allowedRows->end(), rr[i])) order.push_back(uint32_t(i));
+	}
 	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rr[a] < rr[b]; });   // scan order
 	std::vector<std::pair<float, labeltype>> better;   // dist < dk: permanent members
 	std::priority_queue<labeltype> ties;               // dist == dk members, largest label on top
@@ -337,6 +346,44 @@ SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optio
 		result.emplace(dk, ties.top());
 		ties.pop();
 	}
+	return result;
+}
+
+// Pre-filtered search — the caller side of `WHERE cond AND KNN(...)` (the reference post-filters the k hits on the host,
+// nsselecter.cc:841-875).  Result == BruteforceSearch::SearchKnn (bruteforce.cc:103-127) over an index that holds only the points whose
+// labels are in `allowed`, inserted in the same relative order.  Unknown labels are ignored.  The scan reads the allowed rows only.
+SearchResultQueue GpuBruteforceMap::SearchKnnFiltered(const float* queryData, std::optional<float>, size_t k, const labeltype* allowed,
+													   size_t nAllowed) const {
+	SearchResultQueue result;
+	if (curElementCount_ == 0 || k == 0 || nAllowed == 0) return result;
+	syncDevice();
+	std::vector<uint32_t> rows;
+	rows.reserve(nAllowed);
+	for (size_t i = 0; i < nAllowed; ++i) {
+		const auto it = dictExternalToInternal_.find(allowed[i]);
+		if (it != dictExternalToInternal_.end()) rows.push_back(uint32_t(it->second));
+	}
+	std::sort(rows.begin(), rows.end());
+	rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+	if (rows.empty()) return result;
+	k = std::min(k, rows.size());
+	const uint32_t kk = uint32_t(std::min(k + 1, rows.size()));
+	std::vector<float> dist(kk);
+	std::vector<uint32_t> row(kk);
+	uint32_t count = 0;
+	int rc;
+	if (rows.size() * 32 >= curElementCount_) {   // dense filter: count / 8 bytes on the wire instead of 4 per allowed row
+		std::vector<uint32_t> words((curElementCount_ + 31) / 32, 0u);
+		for (uint32_t r : rows) words[r >> 5] |= 1u << (r & 31);
+		rc = rxgpu_search_knn_bitmap(dev_, queryData, 1, kk, words.data(), words.size(), dist.data(), row.data(), &count, nullptr);
+	} else {
+		rc = rxgpu_search_knn_subset(dev_, queryData, 1, kk, rows.data(), rows.size(), dist.data(), row.data(), &count);
+	}
+	if (rc != RXGPU_OK) throwDevice("SearchKnnFiltered");
+	const bool tieAcross = count > k && !(dist[k - 1] < dist[k]);
+	if (tieAcross) return replayTies(queryData, k, dist[k - 1], &rows);
+	result.reserve(k);
+	for (size_t i = 0; i < std::min<size_t>(k, count); ++i) result.emplace(dist[i], labels_[row[i]]);
 	return result;
 }
 

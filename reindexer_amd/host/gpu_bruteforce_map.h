@@ -49,6 +49,10 @@ public:
 
 	SearchResultQueue SearchKnn(const float* queryData, std::optional<float> queryDataNorm, size_t k, size_t ef = 0) const;
 	SearchResultQueue SearchRange(const float* queryData, std::optional<float> queryDataNorm, float radius, size_t ef) const;
+	// Extension (`WHERE cond AND KNN(...)`): the k nearest among the points whose labels are listed — what SearchKnn returns
+	// over an index holding only those points.  The device scan reads the allowed rows only (rxgpu_search_knn_subset / _bitmap).
+	SearchResultQueue SearchKnnFiltered(const float* queryData, std::optional<float> queryDataNorm, size_t k, const labeltype* allowed,
+										size_t nAllowed) const;
 
 	bool IsQuantized() const noexcept { return false; }
 	bool QuantizationAvailable() const noexcept { return false; }
@@ -74,6 +78,7 @@ private:
 	struct PendingQuery;
 	void fetchTopK(const float* query, uint32_t kk, float* dist, uint32_t* row, uint32_t* count) const;
 	void runBatch(std::vector<PendingQuery*>& batch) const;
+	SearchResultQueue replayTies(const float* queryData, size_t k, float dk, const std::vector<uint32_t>* allowedRows) const;
 
 	const VectorMetric metric_;
 	const size_t dim_;

@@ -92,6 +92,15 @@ long rxhost_bf_search_knn(void* h, const float* q, size_t k, float* outDist, uin
 	});
 	return n;
 }
+long rxhost_bf_search_knn_filtered(void* h, const float* q, size_t k, const uint64_t* allowed, size_t nAllowed, float* outDist,
+								   uint64_t* outLabel) {
+	long n = -1;
+	guarded([&] {
+		auto res = static_cast<const GpuBruteforceMap*>(h)->SearchKnnFiltered(q, std::nullopt, k, allowed, nAllowed);
+		n = long(drain(res, outDist, outLabel, k));
+	});
+	return n;
+}
 long rxhost_bf_search_range(void* h, const float* q, float radius, float* outDist, uint64_t* outLabel, size_t cap) {
 	long n = -1;
 	guarded([&] {

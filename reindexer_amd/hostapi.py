@@ -52,6 +52,8 @@ def lib() -> C.CDLL:
         L.rxhost_bf_vector_by_label.argtypes = [_vp, _u64, _vp]
         L.rxhost_bf_search_knn.restype = _l
         L.rxhost_bf_search_knn.argtypes = [_vp, _vp, _sz, _vp, _vp]
+        L.rxhost_bf_search_knn_filtered.restype = _l
+        L.rxhost_bf_search_knn_filtered.argtypes = [_vp, _vp, _sz, _vp, _sz, _vp, _vp]
         L.rxhost_bf_search_range.restype = _l
         L.rxhost_bf_search_range.argtypes = [_vp, _vp, _f, _vp, _vp, _sz]
         L.rxhost_bf_select.restype = _l
@@ -156,6 +158,17 @@ class GpuBruteforceMap:
         q = _f32(q)
         od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
         n = lib().rxhost_bf_search_knn(self.h, q.ctypes.data, k, od.ctypes.data, ol.ctypes.data)
+        if n < 0:
+            _raise()
+        return od[:n].copy(), ol[:n].copy()
+
+    def search_knn_filtered(self, q, k, allowed_labels):
+        """SearchKnnFiltered: the k nearest among the points whose labels are listed (`WHERE cond AND KNN(...)`)."""
+        q = _f32(q)
+        al = np.ascontiguousarray(allowed_labels, dtype=np.uint64).reshape(-1)
+        od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+        n = lib().rxhost_bf_search_knn_filtered(self.h, q.ctypes.data, k, al.ctypes.data if al.size else None, al.size, od.ctypes.data,
+                                                ol.ctypes.data)
         if n < 0:
             _raise()
         return od[:n].copy(), ol[:n].copy()
