@@ -491,23 +491,46 @@ long rxhost_merge_ranked(int kind, const double* params, int isUnion, int desc, 
 			// FT positions follow the FT result order (rank-sorted, ties in the given order), then are re-indexed by ascending id like ftIds_.
 			// Stable descending sort through one 64-bit key per entry: inverted order-preserving image of the rank, then the index.
 			std::vector<uint64_t> keys(nFt);
+			std::vector<uint32_t> idx(nFt);
 			for (size_t i = 0; i < nFt; ++i) {
-				uint32_t u;
-				const float r = fr[i] + 0.0f;
-				std::memcpy(&u, &r, sizeof(u));
-				u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-				keys[i] = (uint64_t(~u) << 32) | uint32_t(i);
+				keys[i] = (uint64_t(~detail::SortableBits(fr[i])) << 32) | uint32_t(i);
+				idx[i] = uint32_t(i);
 			}
-			std::sort(keys.begin(), keys.end());
+			detail::RadixSortPairs(keys, idx);
 			std::vector<float> sorted(nFt);
-			for (size_t i = 0; i < nFt; ++i) sorted[i] = fr[uint32_t(keys[i])];
+			for (size_t i = 0; i < nFt; ++i) sorted[i] = fr[idx[i]];
 			auto posSorted = InitRRFPositions(sorted);
 			std::vector<size_t> pos(nFt);
-			for (size_t i = 0; i < nFt; ++i) pos[uint32_t(keys[i])] = posSorted[i];
+			for (size_t i = 0; i < nFt; ++i) pos[idx[i]] = posSorted[i];
 			res = MergeRankedRRF(RerankerRRF{params[0]}, type, desc != 0, VectorMetric(metric), ki, kr, fi, pos);
 		} else {
 			res = MergeRankedLinear(RerankerLinear{params[0], params[1], params[2], params[3], params[4]}, type, desc != 0, ki, kr, fi, fr);
 		}
+		n = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
+			outIds[i] = res.ids[i];
+			outRanks[i] = res.ranks[i];
+		}
+	});
+	return n;
+}
+
+// The same fusion fed with the FT result exactly as the engine returns it (FT result order, best rank first): the id-ascending view and the
+// RRF positions are derived here (PrepareFtById), so the caller needs no sort of its own.
+long rxhost_merge_ranked_ft_order(int kind, const double* params, int isUnion, int desc, int metric, const int32_t* knnIds, const float* knnRanks,
+								  size_t nKnn, const int32_t* ftIds, const float* ftRanks, size_t nFt, int32_t* outIds, float* outRanks, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		std::vector<int32_t> ki(knnIds, knnIds + nKnn), fi(ftIds, ftIds + nFt);
+		std::vector<float> kr(knnRanks, knnRanks + nKnn), fr(ftRanks, ftRanks + nFt);
+		const FtById ft = PrepareFtById(fi, fr);
+		for (size_t i = 1; i < ft.ids.size(); ++i) {
+			if (ft.ids[i - 1] == ft.ids[i]) throw std::invalid_argument("merge_ranked: duplicate id in the FT result");
+		}
+		const auto type = isUnion ? HybridMergeType::Union : HybridMergeType::Intersection;
+		HybridResult res = kind == 0 ? MergeRankedRRF(RerankerRRF{params[0]}, type, desc != 0, VectorMetric(metric), ki, kr, ft.ids, ft.positions)
+									 : MergeRankedLinear(RerankerLinear{params[0], params[1], params[2], params[3], params[4]}, type, desc != 0, ki, kr,
+														 ft.ids, ft.ranks);
 		n = long(res.ids.size());
 		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
 			outIds[i] = res.ids[i];

@@ -57,31 +57,141 @@ struct IdRank {
 	int32_t id;
 	float rank;
 };
-// IdRank<desc>::operator< (selectiteratorcontainer.cc:1260-1281): by rank (descending when desc), ties by ascending id.  Sorted through one
-// 64-bit key per entry (order-preserving image of the float in the high word, id in the low word): same order, no comparator calls.
-inline void Finish(std::vector<IdRank>& merged, bool desc, HybridResult& out) {
-	struct Key {
-		uint64_t key;
-		uint32_t idx;
-	};
-	std::vector<Key> keys(merged.size());
-	for (size_t i = 0; i < merged.size(); ++i) {
-		uint32_t u;
-		const float r = merged[i].rank + 0.0f;   // -0 and +0 compare equal
-		std::memcpy(&u, &r, sizeof(u));
-		u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending float order == ascending unsigned order
-		if (desc) u = ~u;
-		keys[i] = Key{(uint64_t(u) << 32) | uint32_t(merged[i].id), uint32_t(i)};   // ids are non-negative (IdType) and unique
+// order-preserving image of a float in an unsigned word (ascending float order == ascending unsigned order; -0 and +0 share one image)
+inline uint32_t SortableBits(float v) noexcept {
+	uint32_t u;
+	const float r = v + 0.0f;
+	std::memcpy(&u, &r, sizeof(u));
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// Stable LSD radix sort of (key, value) pairs by key: 11-bit digits, digits on which all keys agree are skipped (ranks are a few hundred
+// distinct values, ids fit 23 bits — 3-4 passes of ~n steps each instead of n log n comparator calls).
+template <typename K>
+inline void RadixSortPairs(std::vector<K>& keys, std::vector<uint32_t>& vals) {
+	const size_t n = keys.size();
+	if (n < 2) return;
+	constexpr int kBits = 11, kBuckets = 1 << kBits, kPasses = (int(sizeof(K)) * 8 + kBits - 1) / kBits;
+	std::vector<uint32_t> hist(size_t(kPasses) * kBuckets, 0u);
+	for (size_t i = 0; i < n; ++i) {
+		const K k = keys[i];
+		for (int p = 0; p < kPasses; ++p) ++hist[size_t(p) * kBuckets + ((k >> (p * kBits)) & (kBuckets - 1))];
 	}
-	std::sort(keys.begin(), keys.end(), [](const Key& l, const Key& r) { return l.key < r.key; });
-	out.ids.resize(keys.size());
-	out.ranks.resize(keys.size());
-	for (size_t i = 0; i < keys.size(); ++i) {
-		out.ids[i] = merged[keys[i].idx].id;
-		out.ranks[i] = merged[keys[i].idx].rank;
+	std::vector<K> keys2(n);
+	std::vector<uint32_t> vals2(n);
+	K* ka = keys.data();
+	K* kb = keys2.data();
+	uint32_t* va = vals.data();
+	uint32_t* vb = vals2.data();
+	for (int p = 0; p < kPasses; ++p) {
+		uint32_t* h = hist.data() + size_t(p) * kBuckets;
+		if (h[(ka[0] >> (p * kBits)) & (kBuckets - 1)] == n) continue;   // every key has this digit
+		uint32_t sum = 0;
+		for (int b = 0; b < kBuckets; ++b) {
+			const uint32_t c = h[b];
+			h[b] = sum;
+			sum += c;
+		}
+		for (size_t i = 0; i < n; ++i) {
+			const uint32_t dst = h[(ka[i] >> (p * kBits)) & (kBuckets - 1)]++;
+			kb[dst] = ka[i];
+			vb[dst] = va[i];
+		}
+		std::swap(ka, kb);
+		std::swap(va, vb);
+	}
+	if (ka != keys.data()) {
+		keys.swap(keys2);
+		vals.swap(vals2);
+	}
+}
+// IdRank<desc>::operator< (selectiteratorcontainer.cc:1260-1281): by rank (descending when desc), ties by ascending id.
+// merged[0, tailStart) are the (few) entries that came through the KNN list, in no particular order; merged[tailStart, n) is the FT-only
+// tail, which is already in ascending id order — a STABLE sort of the tail by rank alone therefore yields its final order (32-bit radix keys,
+// order-preserving image of the float), the head is sorted by comparison, and one linear merge by (rank key, id) finishes.
+inline void Finish(std::vector<IdRank>& merged, size_t tailStart, bool desc, HybridResult& out) {
+	const size_t n = merged.size();
+	auto rankKey = [desc](float r) noexcept {
+		const uint32_t u = SortableBits(r);
+		return desc ? ~u : u;
+	};
+	std::vector<uint32_t> tkey(n - tailStart), tidx(n - tailStart);
+	for (size_t i = tailStart; i < n; ++i) {
+		tkey[i - tailStart] = rankKey(merged[i].rank);
+		tidx[i - tailStart] = uint32_t(i);
+	}
+	RadixSortPairs(tkey, tidx);
+	std::vector<uint64_t> hkey(tailStart);
+	for (size_t i = 0; i < tailStart; ++i) hkey[i] = (uint64_t(rankKey(merged[i].rank)) << 32) | (uint64_t(i) & 0xFFFFFFFFull);
+	std::sort(hkey.begin(), hkey.end(), [&](uint64_t l, uint64_t r) {   // ids are non-negative (IdType) and unique
+		const uint32_t lk = uint32_t(l >> 32), rk = uint32_t(r >> 32);
+		return lk != rk ? lk < rk : merged[uint32_t(l)].id < merged[uint32_t(r)].id;
+	});
+	out.ids.resize(n);
+	out.ranks.resize(n);
+	size_t h = 0, t = 0, o = 0;
+	while (h < hkey.size() || t < tkey.size()) {
+		bool takeHead;
+		if (h == hkey.size()) {
+			takeHead = false;
+		} else if (t == tkey.size()) {
+			takeHead = true;
+		} else {
+			const uint32_t hk = uint32_t(hkey[h] >> 32);
+			takeHead = hk != tkey[t] ? hk < tkey[t] : merged[uint32_t(hkey[h])].id < merged[tidx[t]].id;
+		}
+		const IdRank& e = takeHead ? merged[uint32_t(hkey[h++])] : merged[tidx[t++]];
+		out.ids[o] = e.id;
+		out.ranks[o] = e.rank;
+		++o;
 	}
 }
 }  // namespace detail
+
+// What the FT engine hands back is in FT result order (best rank first; ft::Merger / GpuFtMerger with sortByRank).  The fusion wants the id
+// set ascending (ftIds_) with, for RRF, each document's position in the rank order (RanksHolder::InitRRFPositions).  One pass each: the
+// positions come straight from the given order when it is rank-descending (else a stable rank sort restores it), the id order from a
+// radix sort of (id, index).
+struct FtById {
+	std::vector<int32_t> ids;        // ascending
+	std::vector<float> ranks;        // aligned with ids
+	std::vector<size_t> positions;   // aligned with ids (RRF)
+};
+inline FtById PrepareFtById(const std::vector<int32_t>& ftIdsFtOrder, const std::vector<float>& ftRanksFtOrder) {
+	const size_t n = ftIdsFtOrder.size();
+	FtById out;
+	std::vector<size_t> posFtOrder;
+	if (std::is_sorted(ftRanksFtOrder.begin(), ftRanksFtOrder.end(), [](float a, float b) { return a > b; })) {
+		posFtOrder = InitRRFPositions(ftRanksFtOrder);
+	} else {
+		std::vector<uint64_t> keys(n);
+		std::vector<uint32_t> idx(n);
+		for (size_t i = 0; i < n; ++i) {
+			keys[i] = uint64_t(~detail::SortableBits(ftRanksFtOrder[i])) << 32 | uint32_t(i);
+			idx[i] = uint32_t(i);
+		}
+		detail::RadixSortPairs(keys, idx);
+		std::vector<float> sorted(n);
+		for (size_t i = 0; i < n; ++i) sorted[i] = ftRanksFtOrder[idx[i]];
+		const auto posSorted = InitRRFPositions(sorted);
+		posFtOrder.resize(n);
+		for (size_t i = 0; i < n; ++i) posFtOrder[idx[i]] = posSorted[i];
+	}
+	std::vector<uint32_t> keys(n), idx(n);
+	for (size_t i = 0; i < n; ++i) {
+		keys[i] = uint32_t(ftIdsFtOrder[i]);
+		idx[i] = uint32_t(i);
+	}
+	detail::RadixSortPairs(keys, idx);
+	out.ids.resize(n);
+	out.ranks.resize(n);
+	out.positions.resize(n);
+	for (size_t i = 0; i < n; ++i) {
+		out.ids[i] = ftIdsFtOrder[idx[i]];
+		out.ranks[i] = ftRanksFtOrder[idx[i]];
+		out.positions[i] = posFtOrder[idx[i]];
+	}
+	return out;
+}
 
 // RRF: knnIds/knnRanks best-first as returned by KnnSelectRaw (L2: ascending distance; IP / cosine: descending similarity);
 // ftIds ascending with ftPositions from InitRRFPositions over the FT ranks in FT result order.
@@ -112,13 +222,14 @@ inline HybridResult MergeRankedRRF(const RerankerRRF& rr, HybridMergeType type, 
 			}
 		}
 	}
+	const size_t tailStart = merged.size();
 	if (type == HybridMergeType::Union) {
 		for (size_t i = 0; i < ftIds.size(); ++i) {
 			if (!ftAdded[i]) merged.push_back({ftIds[i], rr.CalculateSingle(ftPositions[i])});
 		}
 	}
 	HybridResult out;
-	detail::Finish(merged, desc, out);
+	detail::Finish(merged, tailStart, desc, out);
 	return out;
 }
 
@@ -138,13 +249,14 @@ inline HybridResult MergeRankedLinear(const RerankerLinear& rr, HybridMergeType 
 			if (seen.insert(id).second) merged.push_back({id, rr.CalculateJustKnn(double(knnRanks[i]))});
 		}
 	}
+	const size_t tailStart = merged.size();
 	if (type == HybridMergeType::Union) {
 		for (size_t i = 0; i < ftIds.size(); ++i) {
 			if (!ftAdded[i]) merged.push_back({ftIds[i], rr.CalculateJustFt(ftRanks[i])});   // unique ids, not in the KNN list: no hashing needed
 		}
 	}
 	HybridResult out;
-	detail::Finish(merged, desc, out);
+	detail::Finish(merged, tailStart, desc, out);
 	return out;
 }
 

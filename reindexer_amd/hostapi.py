@@ -594,19 +594,21 @@ def default_ft_opts(num_fields=1, **kw):
     return o
 
 
-def merge_ranked(kind: str, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=False, desc=True, metric=1):
+def merge_ranked(kind: str, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=False, desc=True, metric=1, ft_order="id"):
     """Hybrid FT+KNN rank fusion (hybrid_rerank.h). kind: 'rrf' (params=[rank_const]) or 'linear' (params=[kKnn, knnDefault, kFt, ftDefault, c]).
-    knn_* best-first as KnnSelectRaw returns them; ft_ids ascending with ft_ranks aligned."""
+    knn_* best-first as KnnSelectRaw returns them.  ft_order='id': ft_ids ascending with ft_ranks aligned (the selector's ftIds_ view);
+    ft_order='rank': the FT result as the merger returns it (best rank first) — the id view is derived inside, no sort needed by the caller."""
     L = lib()
-    L.rxhost_merge_ranked.restype = _l
-    L.rxhost_merge_ranked.argtypes = [_i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz]
+    fn = L.rxhost_merge_ranked if ft_order == "id" else L.rxhost_merge_ranked_ft_order
+    fn.restype = _l
+    fn.argtypes = [_i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz]
     p = np.ascontiguousarray(params, np.float64)
     ki, kr = np.ascontiguousarray(knn_ids, np.int32), _f32(knn_ranks)
     fi, fr = np.ascontiguousarray(ft_ids, np.int32), _f32(ft_ranks)
     cap = ki.shape[0] + fi.shape[0] + 1
-    oi, orr = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
-    n = L.rxhost_merge_ranked(0 if kind == "rrf" else 1, p.ctypes.data, int(union), int(desc), metric, ki.ctypes.data, kr.ctypes.data, ki.shape[0],
-                              fi.ctypes.data, fr.ctypes.data, fi.shape[0], oi.ctypes.data, orr.ctypes.data, cap)
+    oi, orr = np.empty(cap, np.int32), np.empty(cap, np.float32)
+    n = fn(0 if kind == "rrf" else 1, p.ctypes.data, int(union), int(desc), metric, ki.ctypes.data, kr.ctypes.data, ki.shape[0],
+           fi.ctypes.data, fr.ctypes.data, fi.shape[0], oi.ctypes.data, orr.ctypes.data, cap)
     if n < 0:
         _raise()
     return oi[:n].copy(), orr[:n].copy()

@@ -74,3 +74,38 @@ def test_merge_ranked_matches_restatement(kind, params, union, metric):
             wi, wr = restated(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union, desc, metric)
             gi, gr = hostapi.merge_ranked(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=union, desc=desc, metric=metric)
             assert np.array_equal(gi, wi) and np.array_equal(gr.view(np.uint32), wr.view(np.uint32))
+
+
+@pytest.mark.parametrize("kind,params", [("rrf", [60.0]), ("linear", [0.7, 0.1, -0.3, 5.0, 2.0]), ("linear", [1.0, 0.0, 1.0, 0.0, 0.0])])
+@pytest.mark.parametrize("union", [False, True])
+def test_merge_ranked_large_and_ft_order_entry(kind, params, union):
+    """Sizes of BASELINE configs[4] (thousands of FT hits, ids up to 5M, k = 100): the radix-sorted paths against the restatement, and the
+    entry that takes the FT result as the merger returns it (best rank first; also an arbitrary order) against the id-ordered entry."""
+    from reindexer_amd import hostapi
+    rng = np.random.default_rng(11)
+    for nf in (0, 1, 3000, 20000):
+        nk = 100
+        ft_ids = np.sort(rng.choice(5_000_000, nf, replace=False)).astype(np.int32)
+        ft_ranks = rng.integers(1, 256, nf).astype(np.float32)
+        knn_ids = rng.choice(5_000_000, nk, replace=False).astype(np.int32)
+        if nf:
+            knn_ids[:40] = ft_ids[rng.choice(nf, 40, replace=nf < 40)]
+            knn_ids = np.unique(knn_ids)[: nk]
+            rng.shuffle(knn_ids)
+        knn_ranks = np.sort(rng.random(knn_ids.size).astype(np.float32))[::-1].copy()
+        for desc in (True, False):
+            wi, wr = restated(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union, desc, 1)
+            gi, gr = hostapi.merge_ranked(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=union, desc=desc, metric=1)
+            assert np.array_equal(gi, wi) and np.array_equal(gr.view(np.uint32), wr.view(np.uint32))
+            by_rank = np.argsort(-ft_ranks, kind="stable")
+            for order in (by_rank, rng.permutation(nf)):
+                oi, orr = hostapi.merge_ranked(kind, params, knn_ids, knn_ranks, ft_ids[order], ft_ranks[order], union=union, desc=desc,
+                                               metric=1, ft_order="rank")
+                assert np.array_equal(oi, wi) and np.array_equal(orr.view(np.uint32), wr.view(np.uint32))
+
+
+def test_merge_ranked_ft_order_rejects_duplicate_ids():
+    from reindexer_amd import hostapi
+    with pytest.raises(Exception):
+        hostapi.merge_ranked("rrf", [60.0], np.array([1], np.int32), np.array([1.0], np.float32), np.array([5, 5], np.int32),
+                             np.array([9.0, 3.0], np.float32), union=True, ft_order="rank")

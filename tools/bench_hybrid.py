@@ -85,8 +85,8 @@ def main():
         t.append(time.perf_counter())
         kid, krank = vm.select(keys[q], k=args.k, need_sort=False)
         t.append(time.perf_counter())
-        o = np.argsort(fid, kind="stable")
-        ids, ranks = hostapi.merge_ranked("rrf", [60.0], kid, krank, fid[o].astype(np.int32), fproc[o], union=True, desc=True, metric=2)
+        # the FT result goes in as the merger returns it (best rank first): id view + RRF positions are derived inside the fusion
+        ids, ranks = hostapi.merge_ranked("rrf", [60.0], kid, krank, fid, fproc, union=True, desc=True, metric=2, ft_order="rank")
         t.append(time.perf_counter())
         return (fid, fproc, kid, krank, ids, ranks), np.diff(t)
 
@@ -147,7 +147,13 @@ def main():
             cpu_knn_s = (time.perf_counter() - t0) / nq * (total / pre.shape[0])
         out["cpu_baseline"] = {"kind": "port (ft merge) + " + knn_kind + " (knn scan)", "cores": 1, "unit": "queries/s", "value": 1.0 / (cpu_ft_s + cpu_knn_s), "ms_ft_merge": cpu_ft_s * 1e3,
                                "ms_knn_scan_scaled": cpu_knn_s * 1e3, "sample": f"{nq} queries; KNN scan timed on a {pre.shape[0]}-row prefix and scaled"}
-        out["parity"] = {"ft_identical_frac": same_ft / nq, "checked": nq,
+        same_fusion = 0
+        for q in range(nq):   # the fused list against the id-ordered entry fed with an explicitly sorted FT result
+            fid, fproc, kid, krank, ids, ranks = results[q]
+            o = np.argsort(fid, kind="stable")
+            wi, wr = hostapi.merge_ranked("rrf", [60.0], kid, krank, fid[o].astype(np.int32), fproc[o], union=True, desc=True, metric=2)
+            same_fusion += int(np.array_equal(wi, ids) and np.array_equal(wr.view(np.uint32), ranks.view(np.uint32)))
+        out["parity"] = {"ft_identical_frac": same_ft / nq, "checked": nq, "fusion_identical_frac": same_fusion / nq,
                          "knn": "ids and ranks of GpuBruteforceMap::select are covered bit-exact by tests/test_gpu_hybrid.py and the brute-force suites"}
     except Exception as e:
         out["cpu_baseline"] = {"error": repr(e)}
