@@ -14,15 +14,17 @@ namespace {
 [[noreturn]] void throwDevice(const char* what) { throw std::runtime_error(std::string(what) + ": " + rxgpu_last_error()); }
 }  // namespace
 
-GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device)
-	: graph_(metric, dim, maxElements, M, efConstruction), device_(device) {
+GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device,
+					   Synchronization synchronization)
+	: graph_(metric, dim, maxElements, M, efConstruction), device_(device), synchronization_(synchronization) {
 	if (2 * graph_.M() > 128) throw std::logic_error("GpuHnswMap: the GPU engine supports M <= 64");
 	if (rxgpu_index_create(int(metric), uint32_t(dim), maxElements, device_, &dev_) != RXGPU_OK) {
 		throwDevice("GpuHnswMap: device index creation failed");
 	}
 }
 
-GpuHnswMap::GpuHnswMap(const GpuHnswMap& other, size_t newCapacity) : graph_(other.graph_, newCapacity), device_(other.device_) {
+GpuHnswMap::GpuHnswMap(const GpuHnswMap& other, size_t newCapacity)
+	: graph_(other.graph_, newCapacity), device_(other.device_), synchronization_(other.synchronization_) {
 	if (rxgpu_index_create(int(graph_.Metric()), uint32_t(graph_.Dim()), graph_.MaxElements(), device_, &dev_) != RXGPU_OK) {
 		throwDevice("GpuHnswMap: device index creation failed");
 	}
@@ -37,8 +39,12 @@ void GpuHnswMap::AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id) {
 	graphDirty_ = true;
 }
 
-void GpuHnswMap::AddPointConcurrent(ConstFloatVectorView, FloatVectorId) {
-	throw std::logic_error("This HNSW index does not support concurrent insertions");   // hnswalg.h:1393-1399 (Synchronization::None)
+void GpuHnswMap::AddPointConcurrent(ConstFloatVectorView vect, FloatVectorId id) {
+	if (synchronization_ == Synchronization::None) {
+		throw std::logic_error("This HNSW index does not support concurrent insertions");   // hnswalg.h:1393-1399 (Synchronization::None)
+	}
+	graph_.AddPointConcurrent(vect.Data(), id.AsNumber());
+	graphDirty_ = true;
 }
 
 void GpuHnswMap::MarkDelete(FloatVectorId id) {

@@ -4,6 +4,7 @@
 //   search : MI355X, rxgpu_hnsw_search_knn (hnsw_search.hip) — same traversal as the reference, no CPU search path
 #pragma once
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -40,9 +41,14 @@ private:
 	const void* graph_ = nullptr;   // the Map that began the session (hnswalg.h:1953-1956: a foreign session is reported exhausted)
 };
 
+// hnswlib::Synchronization (hnswlib.h): None = HierarchicalNSWST (AddPointConcurrent throws), OnInsertions = HierarchicalNSWMT (the index
+// type the reference builds from several upsert threads, hnsw_index.cc:18-19, 105-116, 566-573)
+enum class Synchronization { None, OnInsertions };
+
 class GpuHnswMap {
 public:
-	GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device = 0);
+	GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device = 0,
+			   Synchronization synchronization = Synchronization::None);
 	GpuHnswMap(const GpuHnswMap& other, size_t newCapacity);
 	~GpuHnswMap();
 	GpuHnswMap& operator=(const GpuHnswMap&) = delete;
@@ -60,7 +66,7 @@ public:
 
 	void MarkDelete(FloatVectorId id);
 	void AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id);
-	[[noreturn]] void AddPointConcurrent(ConstFloatVectorView, FloatVectorId);
+	void AddPointConcurrent(ConstFloatVectorView vect, FloatVectorId id);   // Synchronization::None: throws, like the reference's ST map
 	void ResizeIndex(size_t newMaxElements);
 
 	SearchResultQueue SearchKnn(const float* queryDataRaw, std::optional<float> queryDataNorm, size_t k, size_t ef = 0) const;
@@ -92,7 +98,8 @@ private:
 	mutable std::mutex syncMtx_;
 	mutable rxgpu_index* dev_ = nullptr;
 	mutable size_t syncedRows_ = 0;
-	mutable bool graphDirty_ = true;
+	const Synchronization synchronization_;
+	mutable std::atomic<bool> graphDirty_{true};
 	mutable bool deletedDirty_ = false;
 
 	bool coalesce_ = true;

@@ -6,6 +6,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <thread>
 
 #include "distance_cpu.h"
 #include "gpu_bruteforce_map.h"   // CalculateL2Module
@@ -14,7 +15,31 @@ namespace rxgpu::host {
 
 namespace {
 constexpr tableint kNoEntry = std::numeric_limits<tableint>::max();
-}
+
+// One-byte test-and-test-and-set lock per element (a std::mutex per element would cost 40 B x 10M); waits are short except behind an
+// element that is still being inserted, hence the yield.
+class NodeLock {
+public:
+	explicit NodeLock(std::atomic<uint8_t>& f) noexcept : f_(f) {
+		unsigned spins = 0;
+		while (f_.exchange(1, std::memory_order_acquire)) {
+			while (f_.load(std::memory_order_relaxed)) {
+				if (++spins > 128) {
+					std::this_thread::yield();
+				} else {
+					__builtin_ia32_pause();
+				}
+			}
+		}
+	}
+	~NodeLock() { f_.store(0, std::memory_order_release); }
+	NodeLock(const NodeLock&) = delete;
+	NodeLock& operator=(const NodeLock&) = delete;
+
+private:
+	std::atomic<uint8_t>& f_;
+};
+}  // namespace
 
 HnswGraph::HnswGraph(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, size_t randomSeed)
 	: metric_(metric),
@@ -33,7 +58,7 @@ HnswGraph::HnswGraph(VectorMetric metric, size_t dim, size_t maxElements, size_t
 		levels_.assign(maxElements_, 0);
 		labels_.assign(maxElements_, 0);
 		deleted_.assign(maxElements_, 0);
-		visitStamp_.assign(maxElements_, 0);
+		visited_.stamp.assign(maxElements_, 0);
 	} catch (const std::bad_alloc&) {
 		throw std::runtime_error("Not enough memory: HNSW constructor failed to allocate level0");
 	}
@@ -60,8 +85,8 @@ HnswGraph::HnswGraph(const HnswGraph& o, size_t newMaxElements)
 	  labels_(o.labels_),
 	  deleted_(o.deleted_),
 	  labelLookup_(o.labelLookup_),
-	  levelGenerator_(o.levelGenerator_),
-	  visitStamp_(o.visitStamp_.size(), 0) {
+	  levelGenerator_(o.levelGenerator_) {
+	visited_.stamp.assign(o.visited_.stamp.size(), 0);
 	if (maxElements_ != o.maxElements_) {
 		const size_t keep = maxElements_;
 		maxElements_ = o.maxElements_;
@@ -79,8 +104,11 @@ void HnswGraph::Resize(size_t newMaxElements) {
 		levels_.resize(newMaxElements, 0);
 		labels_.resize(newMaxElements, 0);
 		deleted_.resize(newMaxElements, 0);
-		visitStamp_.assign(newMaxElements, 0);
-		curStamp_ = 0;
+		visited_.stamp.assign(newMaxElements, 0);
+		visited_.cur = 0;
+		visitedPool_.clear();
+		nodeLocks_.reset();
+		nodeLocksSize_ = 0;
 	} catch (const std::bad_alloc&) {
 		throw std::runtime_error("Not enough memory: resizeIndex failed to allocate base layer");
 	}
@@ -126,15 +154,21 @@ int HnswGraph::randomLevel() {
 }
 
 // Best-first search on one layer with beam efConstruction; returns the beam as a max-heap on distance.
-HnswGraph::Heap HnswGraph::searchBaseLayer(tableint ep, tableint self, int layer) {
-	if (++curStamp_ == 0) {   // stamp wrap-around: clear and restart at 1
-		std::fill(visitStamp_.begin(), visitStamp_.end(), uint16_t(0));
-		curStamp_ = 1;
+// kMT: a node's list is snapshotted under its lock (the reference keeps the lock over the distance evaluations, hnswalg.h:672-676; the
+// snapshot sees the same list and does not hold other inserters up).
+template <bool kMT>
+HnswGraph::Heap HnswGraph::searchBaseLayer(tableint ep, tableint self, int layer, Visited& vis) {
+	if (++vis.cur == 0) {   // stamp wrap-around: clear and restart at 1
+		std::fill(vis.stamp.begin(), vis.stamp.end(), uint16_t(0));
+		vis.cur = 1;
 	}
-	const uint16_t stamp = curStamp_;
+	const uint16_t stamp = vis.cur;
+	uint16_t* const visitStamp = vis.stamp.data();
 	Heap beam, frontier;   // beam: worst on top; frontier: keyed by -dist so the closest is on top
 	beam.reserve(256);
 	frontier.reserve(256);
+	std::vector<uint32_t> snapshot;
+	if constexpr (kMT) snapshot.resize(1 + maxM0_);
 	float bound;
 	if (!IsDeleted(ep)) {
 		const float d = distIds(self, ep);
@@ -145,28 +179,36 @@ HnswGraph::Heap HnswGraph::searchBaseLayer(tableint ep, tableint self, int layer
 		bound = std::numeric_limits<float>::max();
 		frontier.emplace(-bound, ep);
 	}
-	visitStamp_[ep] = stamp;
+	visitStamp[ep] = stamp;
 	while (!frontier.empty()) {
 		const Pair cur = frontier.top();
 		if (-cur.first > bound && beam.size() == efConstruction_) break;
 		frontier.pop();
-		const uint32_t* ll = list(cur.second, layer);
+		const uint32_t* ll;
+		if constexpr (kMT) {
+			NodeLock lk(nodeLocks_[cur.second]);
+			const uint32_t* src = list(cur.second, layer);
+			std::memcpy(snapshot.data(), src, (1 + size_t(src[0])) * sizeof(uint32_t));
+			ll = snapshot.data();
+		} else {
+			ll = list(cur.second, layer);
+		}
 		const size_t size = ll[0];
 		if (size) {   // the reference prefetches the same way (hnswalg.h:674-716): stamp + head of the vector of the neighbour that comes next
-			__builtin_prefetch(&visitStamp_[ll[1]]);
+			__builtin_prefetch(&visitStamp[ll[1]]);
 			__builtin_prefetch(Vector(ll[1]));
 		}
 		for (size_t j = 0; j < size; ++j) {
 			const tableint cand = ll[1 + j];
 			if (j + 1 < size) {
 				const tableint next = ll[2 + j];
-				__builtin_prefetch(&visitStamp_[next]);
+				__builtin_prefetch(&visitStamp[next]);
 				const char* nv = reinterpret_cast<const char*>(Vector(next));
 				__builtin_prefetch(nv);
 				__builtin_prefetch(nv + 64);
 			}
-			if (visitStamp_[cand] == stamp) continue;
-			visitStamp_[cand] = stamp;
+			if (visitStamp[cand] == stamp) continue;
+			visitStamp[cand] = stamp;
 			const float d = distIds(self, cand);
 			if (beam.size() < efConstruction_ || bound > d) {
 				frontier.emplace(-d, cand);
@@ -212,6 +254,9 @@ void HnswGraph::selectNeighbors(Heap& candidates, size_t M) const {
 }
 
 // Link `cur` on `level` to the selected neighbours and back; returns the entry point for the next (lower) level.
+// kMT: cur's own lists are covered by the lock its inserter holds for the whole insertion; every other list is rewritten under its lock
+// (mutuallyConnectNewElement, hnswalg.h:1086-1095).
+template <bool kMT>
 tableint HnswGraph::connect(tableint cur, Heap& candidates, int level) {
 	const size_t mCurMax = level ? M_ : maxM0_;
 	selectNeighbors(candidates, M_);
@@ -233,6 +278,8 @@ tableint HnswGraph::connect(tableint cur, Heap& candidates, int level) {
 		}
 	}
 	for (const tableint other : selected) {
+		[[maybe_unused]] std::unique_ptr<NodeLock> lk;
+		if constexpr (kMT) lk = std::make_unique<NodeLock>(nodeLocks_[other]);
 		uint32_t* lo = list(other, level);
 		const size_t sz = lo[0];
 		if (sz > mCurMax) throw std::runtime_error("Bad value of sz_link_list_other");
@@ -259,21 +306,52 @@ tableint HnswGraph::connect(tableint cur, Heap& candidates, int level) {
 	return nextEntry;
 }
 
-tableint HnswGraph::AddPoint(const float* data, labeltype label) {
-	if (labelLookup_.count(label)) {
-		// the reference routes this to updatePoint (hnswalg.h:1709-1724), a path its own comment marks as never exercised
-		throw std::logic_error("HnswGraph::AddPoint: label already present (in-place vector update is not supported)");
+template <bool kMT>
+tableint HnswGraph::addPoint(const float* data, labeltype label) {
+	tableint cur;
+	{
+		[[maybe_unused]] std::unique_lock<std::mutex> lockTable;
+		if constexpr (kMT) lockTable = std::unique_lock<std::mutex>(labelMtx_);
+		if (labelLookup_.count(label)) {
+			// the reference routes this to updatePoint (hnswalg.h:1709-1724), a path its own comment marks as never exercised
+			throw std::logic_error("HnswGraph::AddPoint: label already present (in-place vector update is not supported)");
+		}
+		if (count_ >= maxElements_) throw std::runtime_error("The number of elements exceeds the specified limit");
+		cur = tableint(count_);
+		count_++;
+		labelLookup_[label] = cur;
+		if (metric_ == VectorMetric::Cosine) invNorms_[cur] = CalculateL2Module(data, int32_t(dim_));
 	}
-	if (count_ >= maxElements_) throw std::runtime_error("The number of elements exceeds the specified limit");
-	const tableint cur = tableint(count_);
-	count_++;
-	labelLookup_[label] = cur;
-	if (metric_ == VectorMetric::Cosine) invNorms_[cur] = CalculateL2Module(data, int32_t(dim_));
 
-	const int curLevel = randomLevel();
+	int curLevel;
+	if constexpr (kMT) {
+		std::lock_guard<std::mutex> lk(generatorMtx_);
+		curLevel = randomLevel();
+	} else {
+		curLevel = randomLevel();
+	}
+
+	// `global` stays locked only while this element creates a new top level; the element's own lock is held to the end
+	[[maybe_unused]] std::unique_lock<std::mutex> tempLock;
+	[[maybe_unused]] std::unique_ptr<NodeLock> lockEl;
+	std::unique_ptr<Visited> pooled;
+	if constexpr (kMT) {
+		tempLock = std::unique_lock<std::mutex>(globalMtx_);
+		lockEl = std::make_unique<NodeLock>(nodeLocks_[cur]);
+	}
 	levels_[cur] = curLevel;
-	const int maxLevelCopy = maxLevel_;
-	tableint currObj = entryPoint_;
+	int maxLevelCopy;
+	tableint enterCopy;
+	if constexpr (kMT) {
+		std::lock_guard<std::mutex> lk(entryMtx_);
+		maxLevelCopy = maxLevel_;
+		enterCopy = entryPoint_;
+		if (curLevel <= maxLevelCopy && enterCopy != kNoEntry) tempLock.unlock();
+	} else {
+		maxLevelCopy = maxLevel_;
+		enterCopy = entryPoint_;
+	}
+	tableint currObj = enterCopy;
 
 	std::memset(list(cur, 0), 0, (1 + maxM0_) * sizeof(uint32_t));
 	labels_[cur] = label;
@@ -284,11 +362,21 @@ tableint HnswGraph::AddPoint(const float* data, labeltype label) {
 	if (currObj != kNoEntry) {
 		if (curLevel < maxLevelCopy) {
 			float curDist = distIds(cur, currObj);
+			std::vector<uint32_t> snapshot;
+			if constexpr (kMT) snapshot.resize(1 + M_);
 			for (int level = maxLevelCopy; level > curLevel; --level) {
 				bool changed = true;
 				while (changed) {
 					changed = false;
-					const uint32_t* ll = list(currObj, level);
+					const uint32_t* ll;
+					if constexpr (kMT) {
+						NodeLock lk(nodeLocks_[currObj]);
+						const uint32_t* src = list(currObj, level);
+						std::memcpy(snapshot.data(), src, (1 + size_t(src[0])) * sizeof(uint32_t));
+						ll = snapshot.data();
+					} else {
+						ll = list(currObj, level);
+					}
 					const int size = int(ll[0]);
 					for (int i = 0; i < size; ++i) {
 						const tableint cand = ll[1 + i];
@@ -303,9 +391,13 @@ tableint HnswGraph::AddPoint(const float* data, labeltype label) {
 				}
 			}
 		}
-		const tableint enterCopy = entryPoint_;
+		Visited* vis = &visited_;
+		if constexpr (kMT) {
+			pooled = acquireVisited();
+			vis = pooled.get();
+		}
 		for (int level = std::min(curLevel, maxLevelCopy); level >= 0; --level) {
-			Heap top = searchBaseLayer(currObj, cur, level);
+			Heap top = searchBaseLayer<kMT>(currObj, cur, level, *vis);
 			if (IsDeleted(enterCopy)) {   // hnswalg.h:1819-1828: a deleted entry point is still offered as a neighbour
 				const float d = distIds(cur, enterCopy);
 				if (top.size() < efConstruction_) {
@@ -314,17 +406,91 @@ tableint HnswGraph::AddPoint(const float* data, labeltype label) {
 					top.replace_top(Pair(d, enterCopy));
 				}
 			}
-			currObj = connect(cur, top, level);
+			currObj = connect<kMT>(cur, top, level);
 		}
+		if constexpr (kMT) releaseVisited(std::move(pooled));
 		if (curLevel > maxLevelCopy) {
+			[[maybe_unused]] std::unique_lock<std::mutex> lk;
+			if constexpr (kMT) lk = std::unique_lock<std::mutex>(entryMtx_);
 			entryPoint_ = cur;
 			maxLevel_ = curLevel;
 		}
 	} else {
+		[[maybe_unused]] std::unique_lock<std::mutex> lk;
+		if constexpr (kMT) lk = std::unique_lock<std::mutex>(entryMtx_);
 		maxLevel_ = curLevel;   // first element (hnswalg.h:1839-1848)
 		entryPoint_ = curLevel > maxLevelCopy ? cur : 0;
 	}
 	return cur;
+}
+
+tableint HnswGraph::AddPoint(const float* data, labeltype label) { return addPoint<false>(data, label); }
+
+void HnswGraph::enableConcurrentInserts() {
+	std::lock_guard<std::mutex> lk(visitedPoolMtx_);
+	if (nodeLocksSize_ == maxElements_ && nodeLocks_) return;
+	nodeLocks_.reset(new std::atomic<uint8_t>[maxElements_]);
+	for (size_t i = 0; i < maxElements_; ++i) nodeLocks_[i].store(0, std::memory_order_relaxed);
+	nodeLocksSize_ = maxElements_;
+}
+
+std::unique_ptr<HnswGraph::Visited> HnswGraph::acquireVisited() {
+	{
+		std::lock_guard<std::mutex> lk(visitedPoolMtx_);
+		if (!visitedPool_.empty()) {
+			auto v = std::move(visitedPool_.back());
+			visitedPool_.pop_back();
+			return v;
+		}
+	}
+	auto v = std::make_unique<Visited>();
+	v->stamp.assign(maxElements_, 0);
+	return v;
+}
+
+void HnswGraph::releaseVisited(std::unique_ptr<Visited> v) {
+	std::lock_guard<std::mutex> lk(visitedPoolMtx_);
+	visitedPool_.push_back(std::move(v));
+}
+
+tableint HnswGraph::AddPointConcurrent(const float* data, labeltype label) {
+	if (!nodeLocks_ || nodeLocksSize_ != maxElements_) enableConcurrentInserts();
+	return addPoint<true>(data, label);
+}
+
+void HnswGraph::AddPoints(const float* data, const labeltype* labels, size_t n, unsigned threads) {
+	if (n == 0) return;
+	if (threads <= 1) {
+		for (size_t i = 0; i < n; ++i) AddPoint(data + i * dim_, labels[i]);
+		return;
+	}
+	enableConcurrentInserts();
+	size_t first = 0;
+	if (count_ == 0) {   // the element that creates the entry point goes in alone
+		addPoint<true>(data, labels[0]);
+		first = 1;
+	}
+	std::atomic<size_t> next{first};
+	std::mutex errMtx;
+	std::string error;
+	auto worker = [&] {
+		try {
+			for (;;) {
+				const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+				if (i >= n) break;
+				addPoint<true>(data + i * dim_, labels[i]);
+			}
+		} catch (const std::exception& e) {
+			next.store(n, std::memory_order_relaxed);
+			std::lock_guard<std::mutex> lk(errMtx);
+			if (error.empty()) error = e.what();
+		}
+	};
+	std::vector<std::thread> pool;
+	pool.reserve(threads);
+	for (unsigned t = 0; t < threads; ++t) pool.emplace_back(worker);
+	for (auto& t : pool) t.join();
+	if (!error.empty()) throw std::runtime_error(error);
 }
 
 void HnswGraph::MarkDelete(labeltype label) {

@@ -10,12 +10,21 @@
 // Same algorithm, same RNG stream, same distance bits (distance_cpu.h), same heap tie mechanics (ResultHeap, rx_types.h) =>
 // for sequential inserts the graph equals the reference's link for link (tests/test_hnsw_builder.py).
 //
+// Concurrent construction (HierarchicalNSWMT = Synchronization::OnInsertions, hnsw.h:60-91; the reference's multithreaded index build):
+// AddPointConcurrent follows addPoint<RegularLocker> lock for lock — label table mutex, level generator mutex, `global` held only while
+// a new top level is being created, the new element's link-list lock held for the whole insertion, every other list locked while it is read
+// or rewritten (hnswalg.h:1694-1852, 644-749, 1042-1180).  Like the reference's, such a graph depends on thread timing; inserted from
+// ONE thread it equals the sequential graph link for link (tests/test_hnsw_builder.py).
+//
 // Deliberate difference: slots of deleted elements are not recycled by later inserts (the reference's
 // allow_replace_deleted path, updatePoint :1472-1690, picks the slot from a hash-set iteration order); new points are
 // always appended.  Search semantics with deleted nodes (traversed, never returned) are identical.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <random>
 #include <unordered_map>
 #include <vector>
@@ -31,6 +40,10 @@ public:
 
 	// addPoint<DummyLocker, ExpectConcurrentUpdates::No>(data, label, -1); returns the internal id
 	tableint AddPoint(const float* data, labeltype label);
+	// addPoint<RegularLocker, ExpectConcurrentUpdates::No>: callable from many threads at once (never together with AddPoint / Resize /
+	// MarkDelete).  AddPoints() is the driver the tools use: the first element goes in alone, the rest from `threads` workers.
+	tableint AddPointConcurrent(const float* data, labeltype label);
+	void AddPoints(const float* data, const labeltype* labels, size_t n, unsigned threads);
 	void MarkDelete(labeltype label);
 	void Resize(size_t newMaxElements);
 
@@ -74,9 +87,21 @@ private:
 	uint32_t* list(tableint id, int level) noexcept;
 	const uint32_t* list(tableint id, int level) const noexcept;
 	int randomLevel();
-	Heap searchBaseLayer(tableint ep, tableint self, int layer);
+	// construction scratch: visit stamps (VisitedListPool, visited_list_pool.h:13-36); one per inserting thread
+	struct Visited {
+		std::vector<uint16_t> stamp;
+		uint16_t cur = 0;
+	};
+	template <bool kMT>
+	Heap searchBaseLayer(tableint ep, tableint self, int layer, Visited& vis);
 	void selectNeighbors(Heap& candidates, size_t M) const;
+	template <bool kMT>
 	tableint connect(tableint cur, Heap& candidates, int level);
+	template <bool kMT>
+	tableint addPoint(const float* data, labeltype label);
+	void enableConcurrentInserts();
+	std::unique_ptr<Visited> acquireVisited();
+	void releaseVisited(std::unique_ptr<Visited> v);
 
 	const VectorMetric metric_;
 	const size_t dim_;
@@ -97,9 +122,13 @@ private:
 	std::unordered_map<labeltype, tableint> labelLookup_;
 	std::default_random_engine levelGenerator_;
 
-	// construction scratch: visit stamps (VisitedListPool, visited_list_pool.h:13-36)
-	std::vector<uint16_t> visitStamp_;
-	uint16_t curStamp_ = 0;
+	Visited visited_;   // the sequential builder's scratch
+
+	// concurrent construction only
+	std::unique_ptr<std::atomic<uint8_t>[]> nodeLocks_;   // link_list_locks_: one byte spin lock per element
+	size_t nodeLocksSize_ = 0;
+	std::mutex labelMtx_, generatorMtx_, globalMtx_, entryMtx_, visitedPoolMtx_;
+	std::vector<std::unique_ptr<Visited>> visitedPool_;
 };
 
 }  // namespace rxgpu::host

@@ -1,6 +1,9 @@
 // Flat C entry points over the C++ host layer so that pytest (ctypes) can drive GpuBruteforceMap / KnnSelect the way
 // the reference's own engine-level tests drive BruteforceSearch (gtests/tests/unit/hnsw_streaming_search_test.cc).
 // Exceptions become return codes + thread-local text, like the Reindexer API boundary turns them into Error values.
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <string>
 
@@ -147,6 +150,18 @@ int rxhost_graph_add_many(void* h, const float* vecs, size_t n, size_t dim, cons
 		for (size_t i = 0; i < n; ++i) g->AddPoint(vecs + i * dim, labels[i]);
 	});
 }
+// threads >= 2: HnswGraph::AddPoints (concurrent construction); threads == 1: every point through AddPointConcurrent from this one thread
+// (the concurrent code path, deterministic — tests compare it with the sequential graph)
+int rxhost_graph_add_many_mt(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels, unsigned threads) {
+	return guarded([&] {
+		auto* g = static_cast<HnswGraph*>(h);
+		if (threads >= 2) {
+			g->AddPoints(vecs, labels, n, threads);
+		} else {
+			for (size_t i = 0; i < n; ++i) g->AddPointConcurrent(vecs + i * dim, labels[i]);
+		}
+	});
+}
 int rxhost_graph_mark_delete(void* h, uint64_t label) {
 	return guarded([&] { static_cast<HnswGraph*>(h)->MarkDelete(label); });
 }
@@ -188,6 +203,43 @@ void* rxhost_hnsw_create(int metric, size_t dim, size_t maxElements, size_t M, s
 	GpuHnswMap* m = nullptr;
 	guarded([&] { m = new GpuHnswMap(VectorMetric(metric), dim, maxElements, M, efConstruction, device); });
 	return m;
+}
+// HierarchicalNSWMT: the Map the reference instantiates for multithreaded index builds (hnsw_index.cc:566-573)
+void* rxhost_hnsw_create_mt(int metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device) {
+	GpuHnswMap* m = nullptr;
+	guarded([&] { m = new GpuHnswMap(VectorMetric(metric), dim, maxElements, M, efConstruction, device, Synchronization::OnInsertions); });
+	return m;
+}
+// `threads` upsert threads calling AddPointConcurrent, as HnswIndexBase<HierarchicalNSWMT>::upsertConcurrent does (hnsw_index.cc:105-116)
+int rxhost_hnsw_add_many_mt(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels, unsigned threads) {
+	return guarded([&] {
+		auto* m = static_cast<GpuHnswMap*>(h);
+		size_t first = 0;
+		if (n && m->CurrentElementCount() == 0) {
+			m->AddPointConcurrent(ConstFloatVectorView(vecs, dim), FloatVectorId::FromNumber(labels[0]));
+			first = 1;
+		}
+		std::atomic<size_t> next{first};
+		std::mutex errMtx;
+		std::string error;
+		auto worker = [&] {
+			try {
+				for (;;) {
+					const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+					if (i >= n) break;
+					m->AddPointConcurrent(ConstFloatVectorView(vecs + i * dim, dim), FloatVectorId::FromNumber(labels[i]));
+				}
+			} catch (const std::exception& e) {
+				next.store(n, std::memory_order_relaxed);
+				std::lock_guard<std::mutex> lk(errMtx);
+				if (error.empty()) error = e.what();
+			}
+		};
+		std::vector<std::thread> pool;
+		for (unsigned t = 0; t < std::max(1u, threads); ++t) pool.emplace_back(worker);
+		for (auto& t : pool) t.join();
+		if (!error.empty()) throw std::logic_error(error);
+	});
 }
 void* rxhost_hnsw_clone(void* h, size_t newCapacity) {
 	GpuHnswMap* m = nullptr;

@@ -203,6 +203,7 @@ class HnswGraph:
             L.rxhost_graph_create.argtypes = [_i, _sz, _sz, _sz, _sz]
             L.rxhost_graph_destroy.argtypes = [_vp]
             L.rxhost_graph_add_many.argtypes = [_vp, _vp, _sz, _sz, _vp]
+            L.rxhost_graph_add_many_mt.argtypes = [_vp, _vp, _sz, _sz, _vp, C.c_uint]
             L.rxhost_graph_mark_delete.argtypes = [_vp, _u64]
             L.rxhost_graph_info.argtypes = [_vp, _vp]
             L.rxhost_graph_export.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
@@ -227,10 +228,16 @@ class HnswGraph:
         except Exception:
             pass
 
-    def add(self, vecs, labels):
+    def add(self, vecs, labels, threads: int = 0):
+        """threads == 0: sequential AddPoint (the reference's single-threaded graph, link for link); threads >= 2: concurrent construction
+        (AddPointConcurrent from `threads` workers, like the reference's multithreaded index build); threads == 1: the concurrent code
+        path driven from one thread."""
         vecs = _f32(vecs).reshape(-1, self.dim)
         labels = np.ascontiguousarray(labels, np.uint64).reshape(-1)
-        rc = lib().rxhost_graph_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data)
+        if threads:
+            rc = lib().rxhost_graph_add_many_mt(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data, threads)
+        else:
+            rc = lib().rxhost_graph_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data)
         if rc:
             _raise(rc)
 
@@ -324,13 +331,18 @@ class _KnnStream:
 
 
 class GpuHnswMap:
-    """rxgpu::host::GpuHnswMap (drop-in for hnswlib::HierarchicalNSW<Synchronization::None>)."""
+    """rxgpu::host::GpuHnswMap (drop-in for hnswlib::HierarchicalNSW<Synchronization::None>; multithread=True: <OnInsertions>, the Map of
+    the reference's multithreaded index build — add(..., threads=T) then inserts from T threads through AddPointConcurrent)."""
 
-    def __init__(self, metric: int, dim: int, max_elements: int, M: int = 16, ef_construction: int = 200, device: int = 0, _handle=None):
+    def __init__(self, metric: int, dim: int, max_elements: int, M: int = 16, ef_construction: int = 200, device: int = 0, _handle=None,
+                 multithread: bool = False):
         L = lib()
         if not hasattr(L, "_hnsw_bound"):
             L.rxhost_hnsw_create.restype = _vp
             L.rxhost_hnsw_create.argtypes = [_i, _sz, _sz, _sz, _sz, _i]
+            L.rxhost_hnsw_create_mt.restype = _vp
+            L.rxhost_hnsw_create_mt.argtypes = [_i, _sz, _sz, _sz, _sz, _i]
+            L.rxhost_hnsw_add_many_mt.argtypes = [_vp, _vp, _sz, _sz, _vp, C.c_uint]
             L.rxhost_hnsw_clone.restype = _vp
             L.rxhost_hnsw_clone.argtypes = [_vp, _sz]
             L.rxhost_hnsw_destroy.argtypes = [_vp]
@@ -352,7 +364,8 @@ class GpuHnswMap:
             L.rxhost_hnsw_select.argtypes = [_vp, _vp, _sz, _l, _sz, _i, _f, _i, _i, _vp, _vp, _sz]
             L._hnsw_bound = True
         self.dim, self.metric = dim, metric
-        self.h = _handle if _handle is not None else L.rxhost_hnsw_create(metric, dim, max_elements, M, ef_construction, device)
+        create = L.rxhost_hnsw_create_mt if multithread else L.rxhost_hnsw_create
+        self.h = _handle if _handle is not None else create(metric, dim, max_elements, M, ef_construction, device)
         if not self.h:
             _raise()
 
@@ -373,10 +386,13 @@ class GpuHnswMap:
         except Exception:
             pass
 
-    def add(self, vecs, labels):
+    def add(self, vecs, labels, threads: int = 0):
         vecs = _f32(vecs).reshape(-1, self.dim)
         labels = np.ascontiguousarray(labels, np.uint64).reshape(-1)
-        rc = lib().rxhost_hnsw_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data)
+        if threads:
+            rc = lib().rxhost_hnsw_add_many_mt(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data, threads)
+        else:
+            rc = lib().rxhost_hnsw_add_many(self.h, vecs.ctypes.data, vecs.shape[0], self.dim, labels.ctypes.data)
         if rc:
             _raise(rc)
 

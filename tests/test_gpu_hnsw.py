@@ -274,3 +274,44 @@ def test_index_level_streaming_best_first_with_user_ranks(rxgpu, oracle, metric)
     ks.close()
     os_.close()
     m.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_multithread_map_build_and_search(rxgpu, oracle, metric):
+    """GpuHnswMap<Synchronization::OnInsertions> (the reference's HierarchicalNSWMT): built from 6 upsert threads through AddPointConcurrent;
+    whatever graph the timing produced, the GPU search over it equals the restated engine on the exported graph, and recall holds.
+    The single-thread Map refuses AddPointConcurrent like the reference's ST map."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    from reindexer_amd import hostapi
+    n, d, k = 10000, 64, 10
+    rows = make_corpus(43, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    st = hostapi.GpuHnswMap(metric, d, 16, M=8, ef_construction=40)
+    with pytest.raises(hostapi.HostError, match="does not support concurrent insertions"):
+        st.add_concurrent(rows[0], labels[0])
+    st.close()
+    m = hostapi.GpuHnswMap(metric, d, n, M=16, ef_construction=200, multithread=True)
+    m.add(rows[:6000], labels[:6000], threads=6)
+    m.add(rows[6000:], labels[6000:], threads=6)   # a second wave into the populated graph
+    assert m.count == n
+    g = m.export_graph()
+    assert np.array_equal(np.sort(g["labels"][:n]), labels)
+    order = (g["labels"][:n] >> np.uint64(32)).astype(np.int64)   # internal id -> original row
+    vec = rows[order]
+    g["vectors"] = vec
+    inv = oracle.l2_modules(vec) if metric == 2 else None
+    hits = 0
+    for qi in range(40):
+        q = make_corpus(950 + qi, 1, d)[0]
+        if metric == 2:
+            q, _ = oracle.normalize_copy(q)
+        for ef in (128, 16):
+            wd, wl = oracle_hnsw_search_knn(oracle, g, q, k, ef, inv)
+            gd, gl = m.search_knn(q, k, ef)
+            assert np.array_equal(gl, wl), (metric, qi, ef)
+            assert np.array_equal(bits(gd), bits(wd))
+        alld = oracle.dist_many(metric, q, vec, inv)
+        truth = set(g["labels"][:n][np.argsort(alld, kind="stable")[:k]].tolist())
+        hits += len(truth & set(m.search_knn(q, k, 128)[1].tolist()))
+    assert hits / (40 * k) >= 0.85, hits / (40 * k)
+    m.close()

@@ -70,3 +70,97 @@ def test_builder_errors():
     with pytest.raises(hostapi.HostError, match="Label not found"):
         g.mark_delete(1)   # label removed from the lookup on delete (allow_replace_deleted semantics)
     g.close()
+
+
+# ------------------------------------------------------------------------------------------------ concurrent construction
+def exact_topk(rows, q, k, metric):
+    if metric == 0:
+        d = ((rows - q) ** 2).sum(axis=1)
+    else:
+        d = -(rows @ q)
+        if metric == 2:
+            d = d / np.linalg.norm(rows, axis=1)
+    return np.argsort(d, kind="stable")[:k]
+
+
+def graph_invariants(e, n, M):
+    links0, levels = e["links0"], e["levels"]
+    assert e["n"] == n and links0.shape == (n, 1 + 2 * M)
+    cnt = links0[:, 0]
+    assert cnt.max() <= 2 * M
+    for i in range(n):
+        ll = links0[i, 1:1 + cnt[i]]
+        assert ll.size == np.unique(ll).size and i not in ll and (ll < n).all(), i
+    off, upper = e["upper_off"], e["upper"].reshape(-1, 1 + M)
+    for i in np.flatnonzero(levels > 0):
+        for lv in range(1, levels[i] + 1):
+            blk = upper[off[i] + lv - 1]
+            ll = blk[1:1 + blk[0]]
+            assert blk[0] <= M and ll.size == np.unique(ll).size and i not in ll, (i, lv)
+            assert (levels[ll] >= lv).all(), (i, lv)
+    assert levels[e["entry"]] == e["maxlevel"] == levels.max()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_concurrent_path_from_one_thread_equals_sequential_graph(metric):
+    """AddPointConcurrent (addPoint<RegularLocker>) driven from ONE thread takes every lock of the multithreaded build and must still produce the
+    sequential graph link for link — the concurrent code is the same algorithm."""
+    from reindexer_amd import hostapi
+    n, d, M, efc = 3000, 48, 12, 100
+    rows = make_corpus(77, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    a = hostapi.HnswGraph(metric, d, n, M=M, ef_construction=efc)
+    a.add(rows, labels)
+    b = hostapi.HnswGraph(metric, d, n, M=M, ef_construction=efc)
+    b.add(rows, labels, threads=1)
+    graphs_equal(a.export(), b.export())
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_concurrent_build_is_a_valid_graph_with_the_sequential_recall(oracle, metric):
+    """8 inserting threads (the reference's HierarchicalNSWMT build): the graph depends on timing, so the checks are structural (degree bounds,
+    no self / duplicate / dangling links, links only to nodes that own the level, entry point on the top level, the same multiset of levels —
+    the level RNG stream is shared) plus recall@10 of the restated search, which must match the sequential graph's within 0.02."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    from reindexer_amd import hostapi
+    n, d, M, efc = 12000, 32, 16, 200
+    rows = make_corpus(5, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    graphs = {}
+    for name, threads in (("seq", 0), ("mt", 8)):
+        g = hostapi.HnswGraph(metric, d, n, M=M, ef_construction=efc)
+        g.add(rows, labels, threads=threads)
+        graphs[name] = g.export()
+        graphs[name]["vectors"] = rows
+        g.close()
+    graph_invariants(graphs["mt"], n, M)
+    assert np.array_equal(np.sort(graphs["mt"]["levels"]), np.sort(graphs["seq"]["levels"]))
+    assert np.array_equal(np.sort(graphs["mt"]["labels"][:n]), labels)
+    queries = make_corpus(6, 60, d)
+    recall = {}
+    for name, g in graphs.items():
+        # internal ids differ between the two builds (insertion order), labels do not: compare through labels
+        lab2row = {int(l): i for i, l in enumerate(labels)}
+        vec = np.stack([rows[lab2row[int(l)]] for l in g["labels"][:n]])
+        g["vectors"] = vec
+        ginv = oracle.l2_modules(vec) if metric == 2 else None
+        hit = 0
+        for q in queries:
+            qq = oracle.normalize_copy(q)[0] if metric == 2 else q
+            _, got = oracle_hnsw_search_knn(oracle, g, qq, 10, 64, ginv)
+            want = labels[exact_topk(rows, qq, 10, metric)]
+            hit += len(set(int(x) for x in got) & set(int(x) for x in want))
+        recall[name] = hit / (10 * len(queries))
+    assert recall["mt"] >= 0.9 and abs(recall["mt"] - recall["seq"]) <= 0.02, recall
+
+
+def test_concurrent_build_errors_propagate():
+    from reindexer_amd import hostapi
+    g = hostapi.HnswGraph(0, 8, 10, M=4, ef_construction=10)
+    rows = make_corpus(1, 12, 8)
+    with pytest.raises(hostapi.HostError, match="exceeds the specified limit"):
+        g.add(rows, np.arange(12, dtype=np.uint64), threads=4)
+    g.close()

@@ -41,6 +41,9 @@ def main():
                     help="synthetic corpus = cluster centre + noise (embedding-like: low intrinsic dimension); 0 = i.i.d. gaussian, "
                          "the reference tests' distribution, on which ANY graph index has poor recall at 768 dims")
     ap.add_argument("--graph", default=None, help="graph saved by tools/build_hnsw_graph.py (same corpus seed): skip the host build")
+    ap.add_argument("--build-threads", type=int, default=0,
+                    help="build the graph here with this many inserting threads (GpuHnswMap<OnInsertions>, the reference's multithreaded build); "
+                         "the CPU baseline is then the restated engine on the same graph")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     metric = capi.METRICS[args.metric]
@@ -65,13 +68,19 @@ def main():
     m = None
     if saved is None:
         t0 = time.perf_counter()
-        m = hostapi.GpuHnswMap(metric, args.dim, args.rows, M=args.M, ef_construction=args.efc)
-        m.add(rows, labels)
+        m = hostapi.GpuHnswMap(metric, args.dim, args.rows, M=args.M, ef_construction=args.efc, multithread=args.build_threads > 0)
+        m.add(rows, labels, threads=args.build_threads)
         build_s = time.perf_counter() - t0
         g = m.export_graph()
+        if args.build_threads:   # internal ids follow arrival order: bring the corpus into the graph's order (label i << 32 = original row i)
+            order = (g["labels"][:args.rows] >> np.uint64(32)).astype(np.int64)
+            rows, labels = rows[order], labels[order]
     else:
         meta = saved["meta"]
         build_s = float(saved["build_seconds"])
+        if "labels" in saved:   # a concurrently built graph: internal ids follow arrival order
+            order = (saved["labels"][:args.rows] >> np.uint64(32)).astype(np.int64)
+            rows, labels = rows[order], labels[order]
         g = dict(metric=metric, n=args.rows, dim=args.dim, M=args.M, maxM0=int(meta[4]), maxlevel=int(meta[5]), entry=int(meta[6]),
                  num_deleted=int(meta[7]), links0=saved["links0"], upper_off=saved["upper_off"], upper=saved["upper"], levels=saved["levels"],
                  labels=labels, deleted=saved["deleted"])
@@ -123,7 +132,7 @@ def main():
     out = {
         "workload": f"HNSW {args.metric} M={args.M} efC={args.efc} ef={args.ef} k={args.k}, {args.rows} x {args.dim} (scaled from BASELINE configs[2]), "
                     + (f"{args.clusters} gaussian clusters" if args.clusters else "i.i.d. gaussian"),
-        "build_seconds_host_1thread": build_s,
+        "build_seconds_host": build_s, "build_threads": max(args.build_threads, 1),
         "gpu": {"queries": args.queries, "queries_per_sec": args.queries / gpu_s, "kernel_ms_total": kernel_ms, "launches": launches,
                 "queries_per_sec_kernel_only": args.queries / ((kernel_ms + redo_ms) / 1e3) if kernel_ms else None,
                 "redo_launches": redo_launches, "redo_ms": redo_ms,
@@ -134,7 +143,7 @@ def main():
         "recall_at_k_vs_exact": recall,
         "streaming_session": stream,
     }
-    if saved is not None:   # CPU baseline on the SAME prebuilt graph: the restated engine (pinned equal to the reference's), 1 thread
+    if saved is not None or args.build_threads:   # CPU baseline on the SAME graph: the restated engine (pinned equal to the reference's), 1 thread
         try:
             from oracle.pyoracle import Oracle, oracle_hnsw_search_knn
             orc = Oracle()

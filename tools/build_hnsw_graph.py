@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--M", type=int, default=16)
     ap.add_argument("--efc", type=int, default=200)
     ap.add_argument("--metric", default="cosine")
+    ap.add_argument("--threads", type=int, default=0, help="concurrent construction with this many inserting threads (0: the sequential graph)")
     ap.add_argument("--out", required=True)
     args = ap.parse_args()
     metric = capi.METRICS[args.metric]
@@ -49,13 +50,15 @@ def main():
     t0 = time.perf_counter()
     step = 20000
     for a in range(0, args.rows, step):
-        g.add(rows[a:a + step], labels[a:a + step])
+        g.add(rows[a:a + step], labels[a:a + step], threads=args.threads)
         el = time.perf_counter() - t0
         print(f"{a + step}/{args.rows} rows, {el:.0f} s, {el / (a + step) * 1e3:.2f} ms/insert", flush=True)
     build_s = time.perf_counter() - t0
     e = g.export()
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
-    np.savez(args.out, links0=e["links0"], upper_off=e["upper_off"], upper=e["upper"], levels=e["levels"], deleted=e["deleted"],
+    if args.threads:
+        print("note: a concurrent build assigns internal ids in arrival order; `labels` (row << 32) is saved with the graph")
+    np.savez(args.out, labels=e["labels"], links0=e["links0"], upper_off=e["upper_off"], upper=e["upper"], levels=e["levels"], deleted=e["deleted"],
              meta=np.array([e["metric"], e["n"], e["dim"], e["M"], e["maxM0"], e["maxlevel"], e["entry"], e["num_deleted"], args.clusters, args.efc], np.int64),
              build_seconds=np.float64(build_s))
     print("saved", args.out, f"{build_s:.0f} s")
