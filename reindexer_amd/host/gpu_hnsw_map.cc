@@ -18,6 +18,7 @@ GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size
 					   Synchronization synchronization)
 	: graph_(metric, dim, maxElements, M, efConstruction), device_(device), synchronization_(synchronization) {
 	if (2 * graph_.M() > 128) throw std::logic_error("GpuHnswMap: the GPU engine supports M <= 64");
+	if (synchronization_ == Synchronization::OnInsertions) graph_.EnableConcurrentInserts();
 	if (rxgpu_index_create(int(metric), uint32_t(dim), maxElements, device_, &dev_) != RXGPU_OK) {
 		throwDevice("GpuHnswMap: device index creation failed");
 	}
@@ -25,6 +26,7 @@ GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size
 
 GpuHnswMap::GpuHnswMap(const GpuHnswMap& other, size_t newCapacity)
 	: graph_(other.graph_, newCapacity), device_(other.device_), synchronization_(other.synchronization_) {
+	if (synchronization_ == Synchronization::OnInsertions) graph_.EnableConcurrentInserts();
 	if (rxgpu_index_create(int(graph_.Metric()), uint32_t(graph_.Dim()), graph_.MaxElements(), device_, &dev_) != RXGPU_OK) {
 		throwDevice("GpuHnswMap: device index creation failed");
 	}

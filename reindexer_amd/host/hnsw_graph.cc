@@ -113,6 +113,7 @@ void HnswGraph::Resize(size_t newMaxElements) {
 		throw std::runtime_error("Not enough memory: resizeIndex failed to allocate base layer");
 	}
 	maxElements_ = newMaxElements;
+	if (concurrent_) EnableConcurrentInserts();
 }
 
 tableint HnswGraph::InternalId(labeltype label) const {
@@ -426,12 +427,14 @@ tableint HnswGraph::addPoint(const float* data, labeltype label) {
 
 tableint HnswGraph::AddPoint(const float* data, labeltype label) { return addPoint<false>(data, label); }
 
-void HnswGraph::enableConcurrentInserts() {
+void HnswGraph::EnableConcurrentInserts() {
 	std::lock_guard<std::mutex> lk(visitedPoolMtx_);
 	if (nodeLocksSize_ == maxElements_ && nodeLocks_) return;
 	nodeLocks_.reset(new std::atomic<uint8_t>[maxElements_]);
 	for (size_t i = 0; i < maxElements_; ++i) nodeLocks_[i].store(0, std::memory_order_relaxed);
 	nodeLocksSize_ = maxElements_;
+	labelLookup_.reserve(maxElements_);
+	concurrent_ = true;
 }
 
 std::unique_ptr<HnswGraph::Visited> HnswGraph::acquireVisited() {
@@ -454,7 +457,7 @@ void HnswGraph::releaseVisited(std::unique_ptr<Visited> v) {
 }
 
 tableint HnswGraph::AddPointConcurrent(const float* data, labeltype label) {
-	if (!nodeLocks_ || nodeLocksSize_ != maxElements_) enableConcurrentInserts();
+	if (!nodeLocks_ || nodeLocksSize_ != maxElements_) EnableConcurrentInserts();
 	return addPoint<true>(data, label);
 }
 
@@ -464,7 +467,7 @@ void HnswGraph::AddPoints(const float* data, const labeltype* labels, size_t n, 
 		for (size_t i = 0; i < n; ++i) AddPoint(data + i * dim_, labels[i]);
 		return;
 	}
-	enableConcurrentInserts();
+	EnableConcurrentInserts();
 	size_t first = 0;
 	if (count_ == 0) {   // the element that creates the entry point goes in alone
 		addPoint<true>(data, labels[0]);

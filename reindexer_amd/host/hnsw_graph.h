@@ -43,6 +43,9 @@ public:
 	// addPoint<RegularLocker, ExpectConcurrentUpdates::No>: callable from many threads at once (never together with AddPoint / Resize /
 	// MarkDelete).  AddPoints() is the driver the tools use: the first element goes in alone, the rest from `threads` workers.
 	tableint AddPointConcurrent(const float* data, labeltype label);
+	// allocates the per-element locks and reserves the label table (no rehash under the table mutex); call it before the first concurrent
+	// insert when several threads may race to be first (AddPointConcurrent does it lazily otherwise).  Survives Resize().
+	void EnableConcurrentInserts();
 	void AddPoints(const float* data, const labeltype* labels, size_t n, unsigned threads);
 	void MarkDelete(labeltype label);
 	void Resize(size_t newMaxElements);
@@ -99,7 +102,6 @@ private:
 	tableint connect(tableint cur, Heap& candidates, int level);
 	template <bool kMT>
 	tableint addPoint(const float* data, labeltype label);
-	void enableConcurrentInserts();
 	std::unique_ptr<Visited> acquireVisited();
 	void releaseVisited(std::unique_ptr<Visited> v);
 
@@ -127,6 +129,7 @@ private:
 	// concurrent construction only
 	std::unique_ptr<std::atomic<uint8_t>[]> nodeLocks_;   // link_list_locks_: one byte spin lock per element
 	size_t nodeLocksSize_ = 0;
+	bool concurrent_ = false;
 	std::mutex labelMtx_, generatorMtx_, globalMtx_, entryMtx_, visitedPoolMtx_;
 	std::vector<std::unique_ptr<Visited>> visitedPool_;
 };
