@@ -263,6 +263,56 @@ def pruned_leg(args, ix, queries: torch.Tensor, device, kk: int):
             "checked_queries": nq}
 
 
+def prefilter_leg(args, ix, queries: torch.Tensor, device, kk: int):
+    """Pre-filtered scan (`WHERE cond AND KNN(...)`): only the rows of a sorted row list compete and only they are read.
+    Row lists resident in HBM; per density the device time per query and the rate on the bytes that have to move (allowed x (D*4 + 4)).
+    Density 1.0 must reproduce the unfiltered search bit for bit.  Not the headline."""
+    stream = torch.cuda.current_stream(device).cuda_stream
+    nq = min(8, queries.shape[0])
+    sd = torch.empty((nq, kk), dtype=torch.float32, device=device)
+    srow = torch.empty((nq, kk), dtype=torch.int32, device=device)
+    for i in range(nq):
+        ix.search_knn_device(queries.data_ptr() + i * args.dim * 4, 1, kk, sd.data_ptr() + i * kk * 4, srow.data_ptr() + i * kk * 4, None, stream)
+    od, orow = torch.empty_like(sd), torch.empty_like(srow)
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    out = []
+    for dens in (0.01, 0.1, 1.0):
+        if dens >= 1.0:
+            ids = torch.arange(args.rows, dtype=torch.int32, device=device)
+        else:
+            ids = (torch.rand(args.rows, device=device, generator=g) < dens).nonzero().flatten().to(torch.int32)
+        n_ids = int(ids.numel())
+        if n_ids == 0:
+            continue
+
+        def run(i):
+            ix.search_knn_subset_device(queries.data_ptr() + i * args.dim * 4, 1, kk, ids.data_ptr(), n_ids, od.data_ptr() + i * kk * 4,
+                                        orow.data_ptr() + i * kk * 4, None, stream)
+        run(0)
+        torch.cuda.synchronize(device)
+        ix.profile_enable(True)
+        for i in range(nq):
+            run(i)
+        torch.cuda.synchronize(device)
+        n_scan, ms_scan = ix.profile_read("scan_subset")
+        ix.profile_enable(False)
+        ms = ms_scan / max(n_scan, 1)
+        moved = float(n_ids) * (args.dim * 4 + 4)
+        member = torch.zeros(args.rows, dtype=torch.bool, device=device)
+        member[ids.long()] = True
+        entry = {"density": dens, "allowed_rows": n_ids, "kernel": "knn_scan_subset", "avg_ms": ms, "launches": n_scan,
+                 "bytes_per_launch": moved, "achieved": moved / (ms / 1e3) / 1e9 if n_scan else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": moved / (ms / 1e3) / 1e9 / HBM_PEAK_GBS if n_scan else None,
+                 "rows_all_allowed": bool(member[orow.long().flatten()].all())}
+        if dens >= 1.0:
+            entry["equals_unfiltered_rows"] = bool(torch.equal(orow, srow))
+            entry["equals_unfiltered_dist_bits"] = bool(torch.equal(od.view(torch.int32), sd.view(torch.int32)))
+        out.append(entry)
+        del ids, member
+    return {"k": args.k, "queries": nq, "densities": out}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -367,6 +417,10 @@ def main():
                 result["pruned_scan"] = pruned_leg(args, ix, queries, device, kk)
             except Exception as e:
                 result["pruned_scan"] = {"error": repr(e)}
+            try:
+                result["prefilter"] = prefilter_leg(args, ix, queries, device, kk)
+            except Exception as e:
+                result["prefilter"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu:
             try:
                 base, parity = cpu_baseline_and_parity(args, corpus, queries, metric_id)
