@@ -131,6 +131,13 @@ int rxgpu_search_knn_subset_device(rxgpu_index* h, const void* d_queries, uint32
 								   uint64_t n_ids, void* d_out_dist, void* d_out_row, void* d_out_count, void* stream);
 int rxgpu_check_row_list_device(rxgpu_index* h, const void* d_row_ids, uint64_t n_ids, void* stream, int32_t* out_ok);
 
+/* SearchRange over a row list (same list contract as rxgpu_search_knn_subset): every listed row with dist < radius (<= when
+ * `inclusive`), sorted by (dist, row); *out_total = number of hits; RXGPU_ERR_OVERFLOW when it exceeds `cap` (call again with
+ * cap >= *out_total).  Stands in for the list scan of faiss::IndexIVFFlat::range_search as the reference's IvfIndex calls it
+ * (ivf_index.cc:212-272) — the probed inverted lists are the row list. */
+int rxgpu_search_range_subset(rxgpu_index* h, const float* query, float radius, int inclusive, const uint32_t* row_ids, uint64_t n_ids,
+							  float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total);
+
 /* Multi-GPU merge step (no reference counterpart: the reference has no device notion).  d_gathered = the all-gather of every
  * rank's search output for one query batch: [world][2][nq][kk] 32-bit words — per rank the [nq][kk] distances followed by the
  * [nq][kk] shard-local rows (what rxgpu_search_knn_device writes when d_out_row == d_out_dist + nq*kk words).

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "rxgpu_search_knn_bitmap": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
     "rxgpu_search_knn_subset_device": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _vp]),
     "rxgpu_check_row_list_device": (_i, [_vp, _vp, _u64, _vp, C.POINTER(C.c_int32)]),
+    "rxgpu_search_range_subset": (_i, [_vp, _vp, _f, _i, _vp, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_merge_shards_device": (_i, [_vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_search_range": (_i, [_vp, _vp, _f, _i, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_distances": (_i, [_vp, _vp, _vp, _u32, _vp]),
@@ -253,6 +254,22 @@ class VectorIndex:
         ok = C.c_int32(0)
         _check(lib().rxgpu_check_row_list_device(self._h, d_row_ids_ptr, n_ids, stream_ptr, C.byref(ok)))
         return bool(ok.value)
+
+    def search_range_subset(self, query, radius: float, row_ids, inclusive: bool = False, cap: int = 1 << 16):
+        """SearchRange over the listed rows only -> (dist, row) sorted by (dist, row)."""
+        q = _f32c(query).reshape(self.dim)
+        ids = np.ascontiguousarray(row_ids, dtype=np.uint32).reshape(-1)
+        while True:
+            dist = np.empty(max(cap, 1), np.float32)
+            row = np.empty(max(cap, 1), np.uint32)
+            total = _u64(0)
+            rc = lib().rxgpu_search_range_subset(self._h, q.ctypes.data, radius, int(inclusive), ids.ctypes.data if ids.size else None, ids.size,
+                                                 dist.ctypes.data, row.ctypes.data, cap, C.byref(total))
+            if rc == RXGPU_ERR_OVERFLOW:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            return dist[:total.value].copy(), row[:total.value].copy()
 
     def search_range(self, query, radius: float, inclusive: bool = False, cap: int = 1 << 16):
         q = _f32c(query).reshape(self.dim)

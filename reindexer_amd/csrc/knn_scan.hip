@@ -588,6 +588,35 @@ __global__ __launch_bounds__(kScanThreads) void knn_range(RangeParams p) {
 	}
 }
 
+// SearchRange restricted to a row list (the list scan of an IVF range query, ivf_index.cc:212-272; p.n = list entries)
+template <int kMetric>
+__global__ __launch_bounds__(kScanThreads) void knn_range_subset(RangeParams p, const uint32_t* __restrict__ ids) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
+	const uint64_t nquads = (p.n + kRowsPerWave - 1) / kRowsPerWave;
+	const uint64_t nwaves = uint64_t(gridDim.x) * kScanWaves;
+	for (uint64_t quad = uint64_t(blockIdx.x) * kScanWaves + wave; quad < nquads; quad += nwaves) {
+		const uint64_t item = quad * kRowsPerWave + g;
+		const bool valid = item < p.n;
+		const uint64_t row = ids[valid ? item : p.n - 1];
+		const float sum = group_distance_generic<kMetric>(p.rows + row * p.stride, p.query, p.dim, m);
+		const float dist = metric_epilogue<kMetric>(sum, p.inv_norms, row);
+		const bool hit = valid && m == 0 && (p.inclusive ? dist <= p.radius : dist < p.radius);
+		const uint64_t hm = __ballot(hit);
+		if (hm) {
+			unsigned long long basePos = 0;
+			if (lane == 0) basePos = atomicAdd(p.counter, (unsigned long long)__popcll(hm));
+			basePos = __shfl(basePos, 0);
+			if (hit) {
+				const uint64_t pos = basePos + __popcll(hm & ((1ull << lane) - 1));
+				if (pos < p.cap) {
+					p.out_dist[pos] = dist;
+					p.out_row[pos] = uint32_t(row);
+				}
+			}
+		}
+	}
+}
+
 // DistCalculator::operator()(q,row,id) for an explicit row list: one 16-lane group per row.
 template <int kMetric>
 __global__ __launch_bounds__(256) void knn_distances(const float* rows, const float* inv_norms, const float* query, uint32_t stride,
@@ -792,6 +821,17 @@ void launch_range(int metric, const float* rows, const float* inv_norms, const f
 		case kL2: hipLaunchKernelGGL((knn_range<kL2>), dim3(gridx), dim3(kScanThreads), 0, s, p); break;
 		case kIP: hipLaunchKernelGGL((knn_range<kIP>), dim3(gridx), dim3(kScanThreads), 0, s, p); break;
 		default: hipLaunchKernelGGL((knn_range<kCos>), dim3(gridx), dim3(kScanThreads), 0, s, p); break;
+	}
+}
+
+void launch_range_subset(int metric, const float* rows, const float* inv_norms, const float* query, const uint32_t* ids, uint64_t n_ids,
+						 uint32_t stride, uint32_t dim, float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap,
+						 unsigned long long* counter, uint32_t gridx, hipStream_t s) {
+	RangeParams p{rows, inv_norms, query, n_ids, stride, dim, radius, inclusive, out_dist, out_row, cap, counter};
+	switch (metric) {
+		case kL2: hipLaunchKernelGGL((knn_range_subset<kL2>), dim3(gridx), dim3(kScanThreads), 0, s, p, ids); break;
+		case kIP: hipLaunchKernelGGL((knn_range_subset<kIP>), dim3(gridx), dim3(kScanThreads), 0, s, p, ids); break;
+		default: hipLaunchKernelGGL((knn_range_subset<kCos>), dim3(gridx), dim3(kScanThreads), 0, s, p, ids); break;
 	}
 }
 

@@ -1115,6 +1115,64 @@ int rxgpu_search_range(rxgpu_index* h, const float* query, float radius, int inc
 	return RXGPU_OK;
 }
 
+int rxgpu_search_range_subset(rxgpu_index* h, const float* query, float radius, int inclusive, const uint32_t* row_ids, uint64_t n_ids,
+							  float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(query && out_total && (cap == 0 || (out_dist && out_row)) && (n_ids == 0 || row_ids), RXGPU_ERR_PARAMS,
+			 "rxgpu_search_range_subset: null argument");
+	*out_total = 0;
+	for (uint64_t i = 0; i < n_ids; ++i) {
+		RX_CHECK(row_ids[i] < h->count && (i == 0 || row_ids[i - 1] < row_ids[i]), RXGPU_ERR_PARAMS,
+				 "rxgpu_search_range_subset: row_ids must be strictly increasing and below the row count");
+	}
+	if (n_ids == 0) return RXGPU_OK;
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	const uint64_t dcap = std::min<uint64_t>(cap, n_ids);
+	if (int rc = c->d_queries.ensure(h->dim * sizeof(float)); rc) return rc;
+	if (int rc = c->d_subset.ensure(n_ids * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_out_dist.ensure(std::max<uint64_t>(dcap, 1) * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(std::max<uint64_t>(dcap, 1) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_out_count.ensure(sizeof(unsigned long long)); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, query, h->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
+	RX_HIP(hipMemcpyAsync(c->d_subset.ptr, row_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	RX_HIP(hipMemsetAsync(c->d_out_count.ptr, 0, sizeof(unsigned long long), c->stream));
+	{
+		ProfileScope ps(h, "range_subset", c->stream);
+		rxgpu::launch_range_subset(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr),
+								   static_cast<const uint32_t*>(c->d_subset.ptr), n_ids, h->stride, h->dim, radius, inclusive,
+								   static_cast<float*>(c->d_out_dist.ptr), static_cast<uint32_t*>(c->d_out_row.ptr), dcap,
+								   static_cast<unsigned long long*>(c->d_out_count.ptr), rxgpu::scan_grid_x(n_ids, h->cus), c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	unsigned long long total = 0;
+	RX_HIP(hipMemcpyAsync(&total, c->d_out_count.ptr, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	*out_total = total;
+	if (total > cap) {
+		set_error("rxgpu_search_range_subset: output buffer too small");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	if (total == 0) return RXGPU_OK;
+	std::vector<float> hd(total);
+	std::vector<uint32_t> hr(total), order(total);
+	RX_HIP(hipMemcpy(hd.data(), c->d_out_dist.ptr, total * sizeof(float), hipMemcpyDeviceToHost));
+	RX_HIP(hipMemcpy(hr.data(), c->d_out_row.ptr, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	std::iota(order.begin(), order.end(), 0u);
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hd[a] < hd[b] || (!(hd[b] < hd[a]) && hr[a] < hr[b]); });
+	for (uint64_t i = 0; i < total; ++i) {
+		out_dist[i] = hd[order[i]];
+		out_row[i] = hr[order[i]];
+	}
+	return RXGPU_OK;
+}
+
 int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(query && (n == 0 || (rows && out_dist)), RXGPU_ERR_PARAMS, "rxgpu_distances: null argument");

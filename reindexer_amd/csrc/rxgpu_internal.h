@@ -27,6 +27,9 @@ void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, 
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,
 				  float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap, unsigned long long* counter,
 				  uint32_t gridx, hipStream_t s);
+void launch_range_subset(int metric, const float* rows, const float* inv_norms, const float* query, const uint32_t* ids, uint64_t n_ids,
+						 uint32_t stride, uint32_t dim, float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap,
+						 unsigned long long* counter, uint32_t gridx, hipStream_t s);
 void launch_distances(int metric, const float* rows, const float* inv_norms, const float* query, uint32_t stride, uint32_t dim,
 					  const uint32_t* ids, uint32_t n, float* out, hipStream_t s);
 

@@ -1,0 +1,98 @@
+// GpuIvfFlat — IVF-Flat on the GPU engines (first cut).  Stands in for the pair the reference's IvfIndex drives
+// (cpp_src/core/index/float_vector/ivf_index.cc): faiss::IndexFlat `space_` while fewer than 39 * nCentroids vectors are indexed
+// (ivf_index.h:62, ivf_index.cc:88-108) and faiss::IndexIVFFlat `map_` afterwards — train / add_with_ids / remove_ids / search / range_search
+// with faiss::IVFSearchParameters::nprobe (ivf_index.cc:355-372, 143-272, 469-487).
+//
+// FAISS itself is a patched vendored copy in the reference (cpp_src/vendor_subdirs/faiss, needs BLAS: not buildable here), so parity is
+// UNPINNED: this file restates the published algorithm as the reference configures it —
+//   Level1Quantizer::train_q1 / Clustering::train   k-means, niter = 10 (IndexIVF.cpp:48), <= 256 points per centroid (subsampled),
+//                                                   random initial centroids, spherical (unit centroids) for inner product / cosine
+//                                                   (IndexIVF.cpp:179-182), empty clusters split off the big ones with the +-1/1024 perturbation
+//   IndexIVF::add_with_ids                          vector -> list of its nearest centroid (cosine: on the normalised vector, IndexIVF.cpp:195-215)
+//   IndexIVF::search / range_search                 nprobe nearest lists by the coarse quantiser, exact scan of those lists
+// — and tests hold it to the definition (result == exact search over the probed lists, bit-exact in the engine's own distance arithmetic)
+// and to recall against the exact search.  Centroids differ from FAISS's (its RNG stream is not reproduced), as they do between FAISS builds.
+//
+// MI355X mapping: both halves are the brute-force engine.  The coarse quantiser is a KNN over the nlist centroids (training assigns 256
+// points per call: the matrix-core batch path); the list scan is knn_scan_subset / knn_range_subset over the row list of the probed
+// inverted lists, so a query reads nprobe / nlist of the corpus.  Lists live on the host as sorted row numbers (next: CSR in HBM and the
+// concatenation on the device, which removes the second host round trip).
+#pragma once
+
+#include <cstdint>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "rx_types.h"
+
+struct rxgpu_index;
+
+namespace rxgpu::host {
+
+class GpuIvfFlat {
+public:
+	using idx_t = int64_t;   // faiss::idx_t
+
+	GpuIvfFlat(VectorMetric metric, size_t dim, size_t nlist, int device = 0);
+	~GpuIvfFlat();
+	GpuIvfFlat(const GpuIvfFlat&) = delete;
+	GpuIvfFlat& operator=(const GpuIvfFlat&) = delete;
+
+	static constexpr size_t TrainingSize(size_t nCentroids) noexcept { return nCentroids * 39; }   // ivf_index.h:62
+
+	bool IsTrained() const noexcept { return trained_; }
+	size_t NTotal() const noexcept { return count_; }
+	size_t NList() const noexcept { return nlist_; }
+	size_t Dim() const noexcept { return dim_; }
+	VectorMetric Metric() const noexcept { return metric_; }
+	size_t ListSize(size_t list) const { return lists_.at(list).size(); }
+	const std::vector<float>& Centroids() const noexcept { return centroids_; }
+
+	// IndexIVF::train over the vectors ALREADY added (the reference trains on space_'s content, ivf_index.cc:96-108) and moves every
+	// vector into its list.  seed: Clustering::seed (1234).
+	void Train(int seed = 1234);
+	// add_with_ids: before training the vectors only join the flat storage (the reference's `space_` phase); ids must be unique
+	void AddWithIds(size_t n, const float* x, const idx_t* ids);
+	// remove_ids(IDSelectorArray): returns how many were present
+	size_t RemoveIds(const idx_t* ids, size_t n);
+	void Reset();
+
+	// search(1, x, k, distances, labels, nprobe): best first; L2: squared distance ascending, inner product / cosine: similarity descending;
+	// labels[i] = -1 past the last hit (FAISS convention).  Untrained: exact search over everything (IndexFlat).
+	void Search(const float* x, size_t k, size_t nprobe, float* distances, idx_t* labels) const;
+	// range_search: L2: dist < radius; inner product / cosine: similarity > radius; sorted best first
+	void RangeSearch(const float* x, float radius, size_t nprobe, std::vector<float>& distances, std::vector<idx_t>& labels) const;
+
+	// the rows of the `nprobe` nearest lists for x (ascending) — what the list scan is run over; exposed for tests / tools
+	std::vector<uint32_t> ProbedRows(const float* x, size_t nprobe) const;
+
+private:
+	void prepareQuery(const float* x, std::vector<float>& q) const;
+	void coarse(const float* q, size_t nprobe, std::vector<uint32_t>& lists) const;
+	void assign(const float* xPrepared, size_t n, std::vector<uint32_t>& out) const;   // nearest centroid per (prepared) vector, GPU
+	void uploadCentroids() const;
+	void reserveRows(size_t need);
+	void listInsert(uint32_t list, uint32_t row);
+	void listErase(uint32_t list, uint32_t row);
+	float toFaiss(float internal) const noexcept { return metric_ == VectorMetric::L2 ? internal : -internal; }
+
+	const VectorMetric metric_;
+	const size_t dim_, nlist_;
+	const int device_;
+	bool trained_ = false;
+	size_t count_ = 0, capacity_ = 0;
+
+	std::vector<float> rows_;        // host master copy [count][dim] (raw vectors)
+	std::vector<float> invNorms_;    // cosine: 1 / |row|
+	std::vector<idx_t> ids_;         // [count]
+	std::vector<uint32_t> listOf_;   // [count], valid once trained
+	std::unordered_map<idx_t, uint32_t> idToRow_;   // DirectMap::Hashtable (ivf_index.cc:470)
+	std::vector<std::vector<uint32_t>> lists_;      // per centroid: its rows, ascending
+	std::vector<float> centroids_;   // [nlist][dim]
+
+	mutable rxgpu_index* dev_ = nullptr;        // the vectors
+	mutable rxgpu_index* devCentroids_ = nullptr;
+};
+
+}  // namespace rxgpu::host

@@ -593,3 +593,78 @@ long rxhost_merge_ranked_ft_order(int kind, const double* params, int isUnion, i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------- GpuIvfFlat
+#include "gpu_ivf_flat.h"
+
+extern "C" {
+
+void* rxhost_ivf_create(int metric, size_t dim, size_t nlist, int device) {
+	GpuIvfFlat* m = nullptr;
+	guarded([&] { m = new GpuIvfFlat(VectorMetric(metric), dim, nlist, device); });
+	return m;
+}
+void rxhost_ivf_destroy(void* h) { delete static_cast<GpuIvfFlat*>(h); }
+int rxhost_ivf_add(void* h, const float* x, size_t n, const int64_t* ids) {
+	return guarded([&] { static_cast<GpuIvfFlat*>(h)->AddWithIds(n, x, ids); });
+}
+int rxhost_ivf_train(void* h, int seed) {
+	return guarded([&] { static_cast<GpuIvfFlat*>(h)->Train(seed); });
+}
+long rxhost_ivf_remove(void* h, const int64_t* ids, size_t n) {
+	long removed = -1;
+	guarded([&] { removed = long(static_cast<GpuIvfFlat*>(h)->RemoveIds(ids, n)); });
+	return removed;
+}
+int rxhost_ivf_reset(void* h) {
+	return guarded([&] { static_cast<GpuIvfFlat*>(h)->Reset(); });
+}
+int rxhost_ivf_search(void* h, const float* x, size_t k, size_t nprobe, float* dist, int64_t* labels) {
+	return guarded([&] { static_cast<const GpuIvfFlat*>(h)->Search(x, k, nprobe, dist, labels); });
+}
+// returns the number of hits (the first min(hits, cap) are written), or -1
+long rxhost_ivf_range(void* h, const float* x, float radius, size_t nprobe, float* dist, int64_t* labels, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		std::vector<float> d;
+		std::vector<int64_t> l;
+		static_cast<const GpuIvfFlat*>(h)->RangeSearch(x, radius, nprobe, d, l);
+		n = long(d.size());
+		for (size_t i = 0; i < d.size() && i < cap; ++i) {
+			dist[i] = d[i];
+			labels[i] = l[i];
+		}
+	});
+	return n;
+}
+long rxhost_ivf_probed_rows(void* h, const float* x, size_t nprobe, uint32_t* out, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		const auto rows = static_cast<const GpuIvfFlat*>(h)->ProbedRows(x, nprobe);
+		n = long(rows.size());
+		for (size_t i = 0; i < rows.size() && i < cap; ++i) out[i] = rows[i];
+	});
+	return n;
+}
+// info[0] = ntotal, [1] = trained, [2] = nlist, [3] = dim
+void rxhost_ivf_info(void* h, int64_t* info) {
+	const auto* m = static_cast<const GpuIvfFlat*>(h);
+	info[0] = int64_t(m->NTotal());
+	info[1] = m->IsTrained() ? 1 : 0;
+	info[2] = int64_t(m->NList());
+	info[3] = int64_t(m->Dim());
+}
+int rxhost_ivf_list_sizes(void* h, uint32_t* out) {
+	return guarded([&] {
+		const auto* m = static_cast<const GpuIvfFlat*>(h);
+		for (size_t i = 0; i < m->NList(); ++i) out[i] = uint32_t(m->ListSize(i));
+	});
+}
+int rxhost_ivf_centroids(void* h, float* out) {
+	return guarded([&] {
+		const auto& c = static_cast<const GpuIvfFlat*>(h)->Centroids();
+		std::memcpy(out, c.data(), c.size() * sizeof(float));
+	});
+}
+
+}  // extern "C"

@@ -628,3 +628,119 @@ def merge_ranked(kind: str, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=
     if n < 0:
         _raise()
     return oi[:n].copy(), orr[:n].copy()
+
+
+class GpuIvfFlat:
+    """rxgpu::host::GpuIvfFlat — IVF-Flat on the GPU engines (the faiss::IndexFlat -> faiss::IndexIVFFlat pair of the reference's IvfIndex).
+    Distances follow FAISS: L2 squared distance ascending, inner product / cosine similarity descending; labels are -1 past the last hit."""
+
+    def __init__(self, metric: int, dim: int, nlist: int, device: int = 0):
+        L = lib()
+        if not hasattr(L, "_ivf_bound"):
+            L.rxhost_ivf_create.restype = _vp
+            L.rxhost_ivf_create.argtypes = [_i, _sz, _sz, _i]
+            L.rxhost_ivf_destroy.argtypes = [_vp]
+            L.rxhost_ivf_add.argtypes = [_vp, _vp, _sz, _vp]
+            L.rxhost_ivf_train.argtypes = [_vp, _i]
+            L.rxhost_ivf_remove.restype = _l
+            L.rxhost_ivf_remove.argtypes = [_vp, _vp, _sz]
+            L.rxhost_ivf_reset.argtypes = [_vp]
+            L.rxhost_ivf_search.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+            L.rxhost_ivf_range.restype = _l
+            L.rxhost_ivf_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
+            L.rxhost_ivf_probed_rows.restype = _l
+            L.rxhost_ivf_probed_rows.argtypes = [_vp, _vp, _sz, _vp, _sz]
+            L.rxhost_ivf_info.argtypes = [_vp, _vp]
+            L.rxhost_ivf_list_sizes.argtypes = [_vp, _vp]
+            L.rxhost_ivf_centroids.argtypes = [_vp, _vp]
+            L._ivf_bound = True
+        self.dim, self.metric, self.nlist = dim, metric, nlist
+        self.h = L.rxhost_ivf_create(metric, dim, nlist, device)
+        if not self.h:
+            _raise()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().rxhost_ivf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _info(self):
+        info = np.zeros(4, np.int64)
+        lib().rxhost_ivf_info(self.h, info.ctypes.data)
+        return info
+
+    ntotal = property(lambda self: int(self._info()[0]))
+    is_trained = property(lambda self: bool(self._info()[1]))
+
+    def add_with_ids(self, x, ids):
+        x = _f32(x).reshape(-1, self.dim)
+        ids = np.ascontiguousarray(ids, np.int64).reshape(-1)
+        assert ids.shape[0] == x.shape[0]
+        rc = lib().rxhost_ivf_add(self.h, x.ctypes.data, x.shape[0], ids.ctypes.data)
+        if rc:
+            _raise(rc)
+
+    def train(self, seed: int = 1234):
+        rc = lib().rxhost_ivf_train(self.h, seed)
+        if rc:
+            _raise(rc)
+
+    def remove_ids(self, ids) -> int:
+        ids = np.ascontiguousarray(ids, np.int64).reshape(-1)
+        n = lib().rxhost_ivf_remove(self.h, ids.ctypes.data, ids.shape[0])
+        if n < 0:
+            _raise()
+        return int(n)
+
+    def reset(self):
+        rc = lib().rxhost_ivf_reset(self.h)
+        if rc:
+            _raise(rc)
+
+    def search(self, x, k: int, nprobe: int = 1):
+        x = _f32(x)
+        d, l = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.int64)
+        rc = lib().rxhost_ivf_search(self.h, x.ctypes.data, k, nprobe, d.ctypes.data, l.ctypes.data)
+        if rc:
+            _raise(rc)
+        return d[:k], l[:k]
+
+    def range_search(self, x, radius: float, nprobe: int = 1, cap: int = 1 << 16):
+        x = _f32(x)
+        while True:
+            d, l = np.empty(cap, np.float32), np.empty(cap, np.int64)
+            n = lib().rxhost_ivf_range(self.h, x.ctypes.data, radius, nprobe, d.ctypes.data, l.ctypes.data, cap)
+            if n < 0:
+                _raise()
+            if n <= cap:
+                return d[:n].copy(), l[:n].copy()
+            cap = int(n)
+
+    def probed_rows(self, x, nprobe: int):
+        x = _f32(x)
+        cap = max(self.ntotal, 1)
+        out = np.empty(cap, np.uint32)
+        n = lib().rxhost_ivf_probed_rows(self.h, x.ctypes.data, nprobe, out.ctypes.data, cap)
+        if n < 0:
+            _raise()
+        return out[:n].copy()
+
+    def list_sizes(self):
+        out = np.zeros(self.nlist, np.uint32)
+        rc = lib().rxhost_ivf_list_sizes(self.h, out.ctypes.data)
+        if rc:
+            _raise(rc)
+        return out
+
+    def centroids(self):
+        out = np.zeros((self.nlist, self.dim), np.float32)
+        rc = lib().rxhost_ivf_centroids(self.h, out.ctypes.data)
+        if rc:
+            _raise(rc)
+        return out
