@@ -88,6 +88,21 @@ class ShardedBruteforce:
     def search(self, queries: torch.Tensor, kk: int):
         """-> (dist[nq,kk] f32, global_row[nq,kk] i64) identical on every rank."""
         d, r = self.local_search(queries, kk)
+        return self._exchange(d, r, kk)
+
+    def search_subset(self, queries: torch.Tensor, kk: int, global_rows, local_search_subset):
+        """Pre-filtered form (`WHERE cond AND KNN(...)` over a sharded index): `global_rows` = sorted global row numbers allowed to compete,
+        the same on every rank.  Each rank keeps the part that falls into its shard and scans only those rows
+        (local_search_subset(queries, kk, local_rows) -> (dist, row) padded with +inf / 0xFFFFFFFF past the allowed rows); the exchange and the
+        merge are the ones of search().  Equals the pre-filtered search over one index holding the whole corpus."""
+        import numpy as np
+        rows = np.ascontiguousarray(global_rows, dtype=np.int64)
+        lo = self.rank * self.shard_rows
+        a, b = np.searchsorted(rows, [lo, lo + self.shard_rows])
+        d, r = local_search_subset(queries, kk, (rows[a:b] - lo).astype(np.uint32))
+        return self._exchange(d, r, kk)
+
+    def _exchange(self, d: torch.Tensor, r: torch.Tensor, kk: int):
         packed = pack_topk(d, r)                                  # [nq, kk]
         if self.world > 1:
             gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
@@ -109,6 +124,24 @@ def rxgpu_local_search(index, device):
         stream = torch.cuda.current_stream(device)
         index.search_knn_device(q.data_ptr(), nq, kk, d.data_ptr(), r.data_ptr(), None, stream.cuda_stream)
         return d, r
+    return run
+
+
+def rxgpu_local_search_subset(index, device=None):
+    """Adapter: the pre-filtered scan of an rxgpu VectorIndex shard (rxgpu_search_knn_subset) as the local_search_subset of
+    ShardedBruteforce.search_subset; entries past the number of allowed rows come back as (+inf, invalid row)."""
+    import numpy as np
+
+    def run(queries: torch.Tensor, kk: int, local_rows):
+        q = queries.detach().to("cpu", torch.float32).contiguous().numpy()
+        dist, row, cnt = index.search_knn_subset(q, kk, local_rows)
+        d = np.full((q.shape[0], kk), np.inf, np.float32)
+        r = np.full((q.shape[0], kk), 0xFFFFFFFF, np.int64)
+        for i in range(q.shape[0]):
+            c = int(cnt[i])
+            d[i, :c], r[i, :c] = dist[i, :c], row[i, :c]
+        dt, rt = torch.from_numpy(d), torch.from_numpy(r)
+        return (dt.to(device), rt.to(device)) if device is not None else (dt, rt)
     return run
 
 

@@ -149,3 +149,58 @@ def test_two_rank_hnsw_shards_merge(oracle):
         assert np.all(np.diff(dd) >= 0)
         hits += len(set(rr.tolist()) & set(lex_topk(alld, kk)[1].tolist()))
     assert hits / (nq * kk) >= 0.9
+
+
+def _subset_worker(rank, world, port, n, d, kk, nq, dens, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import Oracle
+    from reindexer_amd.sharded import ShardedBruteforce
+    orc = Oracle()
+    rows = make_corpus(1, n, d)
+    shard = n // world
+    mine = rows[rank * shard:(rank + 1) * shard]
+
+    def local_subset(queries, k, local_rows):
+        ds, rs = [], []
+        for q in queries.numpy():
+            alld = orc.dist_many(0, q, mine[local_rows]) if local_rows.size else np.empty(0, np.float32)
+            dd, pos = lex_topk(alld, k)
+            pad = k - dd.shape[0]
+            ds.append(np.concatenate([dd, np.full(pad, np.inf, np.float32)]))
+            rs.append(np.concatenate([local_rows[pos].astype(np.int64), np.full(pad, 0xFFFFFFFF, np.int64)]))
+        return torch.from_numpy(np.stack(ds)), torch.from_numpy(np.stack(rs))
+
+    allowed = np.flatnonzero(np.random.default_rng(3).random(n) < dens)
+    sb = ShardedBruteforce(None, shard)
+    dd, rr = sb.search_subset(torch.from_numpy(make_corpus(2, nq, d)), kk, allowed, local_subset)
+    out_q.put((rank, dd.numpy().copy(), rr.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dens", [0.3, 0.002])
+def test_two_rank_prefiltered_search_equals_single_index(oracle, dens):
+    """The pre-filtered search over two shards == the pre-filtered search over one index: every rank scans only the allowed rows of its own
+    shard (one shard may hold fewer than kk, or none), the exchange and the merge are the unfiltered ones."""
+    world, n, d, kk, nq = 2, 4000, 32, 7, 5
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subset_worker, args=(r, world, port, n, d, kk, nq, dens, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, queries = make_corpus(1, n, d), make_corpus(2, nq, d)
+    allowed = np.flatnonzero(np.random.default_rng(3).random(n) < dens)
+    for rank, dd, rr in results:
+        for qi in range(nq):
+            wd, pos = lex_topk(oracle.dist_many(0, queries[qi], rows[allowed]), kk)
+            m = wd.shape[0]
+            assert np.array_equal(rr[qi, :m], allowed[pos].astype(np.int64)), (rank, qi)
+            assert np.array_equal(dd[qi, :m].view(np.uint32), wd.view(np.uint32))
+            assert np.all(rr[qi, m:] == -1)
