@@ -11,6 +11,7 @@
 
 #include "gpu_bruteforce_map.h"   // CalculateL2Module / NormalizeCopyVector
 #include "rxgpu.h"
+#include "sorted_union.h"
 
 namespace rxgpu::host {
 
@@ -21,27 +22,6 @@ constexpr size_t kMaxPointsPerCentroid = 256; // Clustering.h:45
 constexpr int kIterations = 10;               // Level1Quantizer: cp.niter = 10 (IndexIVF.cpp:48)
 constexpr float kSplitEps = 1.0f / 1024.0f;   // Clustering.cpp: EPS of split_clusters
 
-// k sorted runs -> one sorted vector, by rounds of pairwise merges
-std::vector<uint32_t> mergeSorted(std::vector<const std::vector<uint32_t>*> runs) {
-	std::vector<std::vector<uint32_t>> cur;
-	cur.reserve(runs.size());
-	for (const auto* r : runs) {
-		if (!r->empty()) cur.push_back(*r);
-	}
-	if (cur.empty()) return {};
-	while (cur.size() > 1) {
-		std::vector<std::vector<uint32_t>> next;
-		next.reserve((cur.size() + 1) / 2);
-		for (size_t i = 0; i + 1 < cur.size(); i += 2) {
-			std::vector<uint32_t> m(cur[i].size() + cur[i + 1].size());
-			std::merge(cur[i].begin(), cur[i].end(), cur[i + 1].begin(), cur[i + 1].end(), m.begin());
-			next.push_back(std::move(m));
-		}
-		if (cur.size() & 1) next.push_back(std::move(cur.back()));
-		cur.swap(next);
-	}
-	return std::move(cur.front());
-}
 }  // namespace
 
 GpuIvfFlat::GpuIvfFlat(VectorMetric metric, size_t dim, size_t nlist, int device)
@@ -323,7 +303,7 @@ std::vector<uint32_t> GpuIvfFlat::ProbedRows(const float* x, size_t nprobe) cons
 	std::vector<const std::vector<uint32_t>*> runs;
 	runs.reserve(probe.size());
 	for (uint32_t l : probe) runs.push_back(&lists_[l]);
-	return mergeSorted(std::move(runs));
+	return SortedUnion(runs, count_);
 }
 
 void GpuIvfFlat::Search(const float* x, size_t k, size_t nprobe, float* distances, idx_t* labels) const {
@@ -344,7 +324,7 @@ void GpuIvfFlat::Search(const float* x, size_t k, size_t nprobe, float* distance
 		std::vector<const std::vector<uint32_t>*> runs;
 		runs.reserve(probe.size());
 		for (uint32_t l : probe) runs.push_back(&lists_[l]);
-		const std::vector<uint32_t> rows = mergeSorted(std::move(runs));
+		const std::vector<uint32_t> rows = SortedUnion(runs, count_);
 		if (rows.empty()) return;
 		if (rxgpu_search_knn_subset(dev_, q.data(), 1, uint32_t(k), rows.data(), rows.size(), dist.data(), row.data(), &cnt) != RXGPU_OK) {
 			throwDevice("GpuIvfFlat::Search");
@@ -369,7 +349,7 @@ void GpuIvfFlat::RangeSearch(const float* x, float radius, size_t nprobe, std::v
 		coarse(q.data(), nprobe, probe);
 		std::vector<const std::vector<uint32_t>*> runs;
 		for (uint32_t l : probe) runs.push_back(&lists_[l]);
-		rows = mergeSorted(std::move(runs));
+		rows = SortedUnion(runs, count_);
 		if (rows.empty()) return;
 	}
 	std::vector<float> dist(1024);

@@ -668,3 +668,23 @@ int rxhost_ivf_centroids(void* h, float* out) {
 }
 
 }  // extern "C"
+
+// test hook for sorted_union.h: runs given as one concatenated array + offsets; strategy 0 = cost model, 1 = merge, 2 = bitmap
+#include "sorted_union.h"
+extern "C" long rxhost_sorted_union(const uint32_t* rows, const uint64_t* off, size_t nruns, size_t universe, int strategy, uint32_t* out, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		std::vector<std::vector<uint32_t>> runs(nruns);
+		std::vector<const std::vector<uint32_t>*> ptrs;
+		size_t total = 0;
+		for (size_t i = 0; i < nruns; ++i) {
+			runs[i].assign(rows + off[i], rows + off[i + 1]);
+			ptrs.push_back(&runs[i]);
+			total += runs[i].size();
+		}
+		const auto u = strategy == 1 ? SortedUnionByMerge(ptrs) : strategy == 2 ? SortedUnionByBitmap(ptrs, universe, total) : SortedUnion(ptrs, universe);
+		n = long(u.size());
+		for (size_t i = 0; i < u.size() && i < cap; ++i) out[i] = u[i];
+	});
+	return n;
+}
