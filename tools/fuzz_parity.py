@@ -5,7 +5,8 @@
 
 Every round draws a metric, a dimension (tails included), a corpus size, value scales (incl. quantised data with massive ties), a k, a batch
 size (so the fused scan, the radix-select path, the f32 and bf16 nomination paths and — with RXGPU_SCAN_BF16=1 — the pruned scan all get
-hit), applies a few random upserts / swap-deletes, and compares every query with the oracle."""
+hit), applies a few random upserts / swap-deletes, and compares every query with the oracle; each round also runs the pre-filtered entries
+(row list, bitmap, range over the list) over a random subset of the rows against the oracle on the sub-corpus."""
 import argparse
 import os
 import sys
@@ -35,7 +36,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     orc = Oracle()
     t_end = time.time() + args.seconds
-    rounds = checked = 0
+    rounds = checked = checked_subset = 0
     while time.time() < t_end:
         metric = int(rng.integers(0, 3))
         d = int(rng.choice([1, 3, 16, 24, 63, 64, 65, 100, 128, 130, 192, 256, 300, 384, 512, 768, 1000, 1024]))
@@ -111,8 +112,36 @@ def main():
                         print(" first diffs at", bad, row[qi, bad], wr[bad], dist[qi, bad], wd[bad], flush=True)
                         sys.exit(1)
                     checked += 1
+                # pre-filtered entries over a random row subset of the current corpus: list, bitmap and range-over-list
+                m = cur.shape[0]
+                dens = float(rng.choice([0.0, 0.01, 0.2, 0.9, 1.0]))
+                ids = np.flatnonzero(rng.random(m) < dens).astype(np.uint32) if dens < 1.0 else np.arange(m, dtype=np.uint32)
+                qs = queries[: min(nq, 4)]
+                sd, sr, sc = ix.search_knn_subset(qs, k, ids)
+                words = np.zeros((m + 31) // 32, np.uint32)
+                np.bitwise_or.at(words, ids.astype(np.int64) >> 5, np.uint32(1) << (ids & 31))
+                bd, br, bc, allowed = ix.search_knn_bitmap(qs, k, words)
+                c = min(k, ids.size)
+                for qi in range(qs.shape[0]):
+                    want = orc.dist_many(metric, qs[qi], cur[ids], cur_inv[ids] if cur_inv is not None else None) if ids.size else np.empty(0, np.float32)
+                    wd, wpos = lex_topk(want, c)
+                    wr = ids[wpos]
+                    ok = (int(sc[qi]) == c and int(bc[qi]) == c and allowed == ids.size
+                          and np.array_equal(sr[qi, :c], wr) and np.array_equal(sd[qi, :c].view(np.uint32), wd.view(np.uint32))
+                          and np.array_equal(br[qi, :c], wr) and np.array_equal(bd[qi, :c].view(np.uint32), wd.view(np.uint32)))
+                    if ok and ids.size:
+                        radius = float(np.sort(want)[min(int(rng.integers(0, 40)), want.size - 1)])
+                        keep = want < radius
+                        rd, rr = ix.search_range_subset(qs[qi], radius, ids, cap=16)
+                        gd, gpos = lex_topk(np.where(keep, want, np.inf), int(keep.sum()))
+                        ok = np.array_equal(rr, ids[gpos]) and np.array_equal(rd.view(np.uint32), gd.view(np.uint32))
+                    if not ok:
+                        print("MISMATCH (pre-filter)", dict(metric=metric, d=d, n=m, style=str(style), k=k, phase=phase, qi=qi, dens=dens,
+                                                            listed=int(ids.size), seed=args.seed, round=rounds), flush=True)
+                        sys.exit(1)
+                    checked_subset += 1
         rounds += 1
-    print(f"fuzz ok: {rounds} rounds, {checked} queries checked, seed {args.seed}")
+    print(f"fuzz ok: {rounds} rounds, {checked} queries checked, {checked_subset} pre-filtered queries (list + bitmap + range) checked, seed {args.seed}")
 
 
 if __name__ == "__main__":
