@@ -84,6 +84,20 @@ def make_corpus(rows: int, dim: int, seed: int, device) -> torch.Tensor:
     return out
 
 
+def host_cpu_info() -> dict:
+    """CPU model / hardware threads of the box the baseline ran on, and the reference's SIMD level."""
+    info = {"hardware_threads": os.cpu_count(), "RX_TARGET_INSTRUCTIONS": os.environ.get("RX_TARGET_INSTRUCTIONS", "avx512")}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    info["model"] = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return info
+
+
 def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, metric_id: int):
     from oracle import pyoracle  # checker / baseline only
     s_rows = min(args.cpu_sample_rows, corpus.shape[0])
@@ -135,6 +149,7 @@ def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, m
                   f"scaled by {s_rows}/{corpus.shape[0]} rows (linear scan); SIMD=avx512" ,
         "all_cores": {"value": qps_all * scale, "cores": threads, "measured_on_sample": qps_all},
         "gbps_per_core": qps_1 * s_rows * args.dim * 4 / 1e9,
+        "host": host_cpu_info(),
     }
 
     # parity on the same sample: GPU through the C-ABI vs the CPU result
