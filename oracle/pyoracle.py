@@ -713,3 +713,105 @@ def ref_ft_or_none(num_fields: int):
         return RefFt(num_fields)
     except (FileNotFoundError, OSError):
         return None
+
+
+# ---------------------------------------------------------------------------------------------------- SQ8 (uint8) distance path
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class _Sq8Base:
+    """Same method names over the restatement (oracle_sq8.c) and over the real reference (ref_shim.cc): codes are uint8 arrays, `corr` the
+    corrective offset Quantizer::quantize returns, distances follow DistCalculator<uint8_t> (smaller = closer for every metric)."""
+    prefix = ""
+
+    def _bind(self, L):
+        p = self.prefix
+        for name in ("l2sqr_u8", "ip_u8"):
+            fn = getattr(L, p + name)
+            fn.restype = _f
+            fn.argtypes = [_vp, _vp, _sz]
+        getattr(L, p + "sq8_params").argtypes = [_f, _f, _sz, _vp, _vp, _vp]
+
+    def l2sqr_u8(self, a, b):
+        a, b = _u8(a), _u8(b)
+        return np.float32(getattr(self.L, self.prefix + "l2sqr_u8")(a.ctypes.data, b.ctypes.data, a.shape[0]))
+
+    def ip_u8(self, a, b):
+        a, b = _u8(a), _u8(b)
+        return np.float32(getattr(self.L, self.prefix + "ip_u8")(a.ctypes.data, b.ctypes.data, a.shape[0]))
+
+    def params(self, min_q, max_q, dim):
+        out = np.zeros(3, np.float32)
+        getattr(self.L, self.prefix + "sq8_params")(min_q, max_q, dim, out[0:].ctypes.data, out[1:].ctypes.data, out[2:].ctypes.data)
+        return dict(min_q=np.float32(min_q), max_q=np.float32(max_q), alpha=out[0], alpha_2=out[1], delta=out[2])
+
+
+class Sq8Oracle(_Sq8Base):
+    prefix = "orc_"
+
+    def __init__(self, orc: Oracle):
+        self.L = orc.L
+        self._bind(self.L)
+        self.L.orc_sq8_quantize.restype = _f
+        self.L.orc_sq8_quantize.argtypes = [_i, _sz, _f, _f, _f, _vp, _f, _vp]
+        self.L.orc_sq8_dist.restype = _f
+        self.L.orc_sq8_dist.argtypes = [_i, _sz, _f, _vp, _f, _f, _vp, _f, _f]
+        self.L.orc_sq8_dist_query.restype = _f
+        self.L.orc_sq8_dist_query.argtypes = [_i, _sz, _f, _vp, _f, _vp, _f, _f]
+        self.L.orc_sq8_dist_query_many.argtypes = [_i, _sz, _f, _vp, _f, _vp, _vp, _vp, _sz, _vp]
+
+    def quantize(self, metric, p, vec, scale=1.0):
+        vec = _f32(vec)
+        to = np.empty(vec.shape[0], np.uint8)
+        corr = self.L.orc_sq8_quantize(metric, vec.shape[0], p["min_q"], p["alpha"], p["delta"], vec.ctypes.data, scale, to.ctypes.data)
+        return to, np.float32(corr)
+
+    def dist_pair(self, metric, p, a, corr_a, fa, b, corr_b, fb, orc: Oracle):
+        a, b = _u8(a), _u8(b)
+        na = orc.l2_module(fa) if metric == 2 else 1.0
+        nb = orc.l2_module(fb) if metric == 2 else 1.0
+        return np.float32(self.L.orc_sq8_dist(metric, a.shape[0], p["alpha_2"], a.ctypes.data, corr_a, na, b.ctypes.data, corr_b, nb))
+
+    def dist_query(self, metric, p, q, corr_q, row, corr_row, frow, orc: Oracle):
+        q, row = _u8(q), _u8(row)
+        n = orc.l2_module(frow) if metric == 2 else 1.0
+        return np.float32(self.L.orc_sq8_dist_query(metric, q.shape[0], p["alpha_2"], q.ctypes.data, corr_q, row.ctypes.data, corr_row, n))
+
+    def dist_query_many(self, metric, p, q, corr_q, rows, corr, inv_norms=None):
+        q, rows, corr = _u8(q), _u8(rows), _f32(corr)
+        out = np.empty(rows.shape[0], np.float32)
+        inv = _f32(inv_norms) if inv_norms is not None else None
+        self.L.orc_sq8_dist_query_many(metric, rows.shape[1], p["alpha_2"], q.ctypes.data, corr_q, rows.ctypes.data, corr.ctypes.data,
+                                       inv.ctypes.data if inv is not None else None, rows.shape[0], out.ctypes.data)
+        return out
+
+
+class Sq8Ref(_Sq8Base):
+    prefix = "ref_"
+
+    def __init__(self, ref: Ref):
+        self.L = ref.L
+        self._bind(self.L)   # AttributeError on a libref_oracle.so built before the SQ8 shims existed
+        self.L.ref_sq8_quantize.restype = _f
+        self.L.ref_sq8_quantize.argtypes = [_i, _sz, _f, _f, _vp, _f, _vp]
+        self.L.ref_sq8_dist_pair.restype = _f
+        self.L.ref_sq8_dist_pair.argtypes = [_i, _sz, _f, _vp, _f, _vp, _vp, _f, _vp]
+        self.L.ref_sq8_dist_query.restype = _f
+        self.L.ref_sq8_dist_query.argtypes = [_i, _sz, _f, _vp, _f, _vp, _f, _vp]
+
+    def quantize(self, metric, p, vec, scale=1.0):
+        vec = _f32(vec)
+        to = np.empty(vec.shape[0], np.uint8)
+        corr = self.L.ref_sq8_quantize(metric, vec.shape[0], p["min_q"], p["max_q"], vec.ctypes.data, scale, to.ctypes.data)
+        return to, np.float32(corr)
+
+    def dist_pair(self, metric, p, a, corr_a, fa, b, corr_b, fb, orc=None):
+        a, b, fa, fb = _u8(a), _u8(b), _f32(fa), _f32(fb)
+        return np.float32(self.L.ref_sq8_dist_pair(metric, a.shape[0], p["alpha_2"], a.ctypes.data, corr_a, fa.ctypes.data, b.ctypes.data, corr_b,
+                                                   fb.ctypes.data))
+
+    def dist_query(self, metric, p, q, corr_q, row, corr_row, frow, orc=None):
+        q, row, frow = _u8(q), _u8(row), _f32(frow)
+        return np.float32(self.L.ref_sq8_dist_query(metric, q.shape[0], p["alpha_2"], q.ctypes.data, corr_q, row.ctypes.data, corr_row,
+                                                    frow.ctypes.data))

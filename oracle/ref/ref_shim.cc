@@ -12,9 +12,11 @@
 //     (constructed exactly like HierarchicalNSW<>::Impl::Impl, hnsw.cc:74-78: seed 100, ReplaceDeleted_True)
 // The same usage pattern as the reference's own engine-level test
 // gtests/tests/unit/hnsw_streaming_search_test.cc:22-25,38,53,161-162.
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <ranges>
 #include <span>
 #include <string>
 #include <vector>
@@ -237,6 +239,57 @@ size_t ref_hnsw_export_upper(void* h, uint64_t* upperOff, uint32_t* upper) {
 	}
 	if (upperOff) upperOff[n] = blocks;
 	return blocks;
+}
+
+// ---------------------------------------------------------------------------------------------------- SQ8 (uint8) distance path
+//   vector_dists::L2SqrDistance<uint8_t> / InnerProductDistance<uint8_t>   tools/distances/l2_dist.cc:168-199, ip_dist.cc:163-192
+//   hnswlib::QuantizingParams / Quantizer::Quantize                       scalar_quantization/quantization_params.h:46-63, quantizer.h:31-124
+//   hnswlib::DistCalculator<uint8_t>                                      hnswlib/hnswlib.h:28-259
+float ref_l2sqr_u8(const uint8_t* a, const uint8_t* b, size_t d) { return reindexer::vector_dists::L2SqrDistance(a, b, d); }
+float ref_ip_u8(const uint8_t* a, const uint8_t* b, size_t d) { return reindexer::vector_dists::InnerProductDistance(a, b, d); }
+
+static hnswlib::QuantizingParams sq8Params(float minQ, float maxQ, size_t dim) {
+	hnswlib::QuantizingParams p;   // the arithmetic of QuantizingParams(hnsw, conf) after minQ / maxQ are known (quantization_params.h:60-63)
+	p.minQ = minQ;
+	p.maxQ = maxQ;
+	p.alpha = (p.maxQ - p.minQ) / hnswlib::kSq8Range;
+	p.alpha_2 = std::pow(p.alpha, 2.f);
+	p.delta = 0.5 * std::pow(p.minQ, 2.f) * dim;
+	return p;
+}
+void ref_sq8_params(float minQ, float maxQ, size_t dim, float* alpha, float* alpha2, float* delta) {
+	const auto p = sq8Params(minQ, maxQ, dim);
+	*alpha = p.alpha;
+	*alpha2 = p.alpha_2;
+	*delta = p.delta;
+}
+// Quantizer::Quantize of one vector (scale != 1: the `norm * val` view prepareData feeds it, hnswalg.h:527); returns the corrective offset
+float ref_sq8_quantize(int metric, size_t dim, float minQ, float maxQ, const float* from, float scale, uint8_t* to) {
+	hnswlib::Quantizer q(dim, toMetric(metric), sq8Params(minQ, maxQ, dim), []() noexcept { return size_t(0); });
+	std::span<const float> src(from, dim);
+	std::span<uint8_t> dst(to, dim);
+	if (scale == 1.f) return q.Quantize(src, dst);
+	return q.Quantize(src | std::views::transform([scale](float v) { return scale * v; }), dst);
+}
+// DistCalculator<uint8_t>::operator()(v1, id1, v2, id2); fa / fb = the original float vectors (AddNorm, cosine only)
+float ref_sq8_dist_pair(int metric, size_t dim, float alpha2, const uint8_t* a, float corrA, const float* fa, const uint8_t* b, float corrB,
+						const float* fb) {
+	hnswlib::DistCalculator<uint8_t> dc(toMetric(metric), dim, 2, alpha2);
+	dc.Sq8CorrectiveOffsets()[0] = corrA;
+	dc.Sq8CorrectiveOffsets()[1] = corrB;
+	dc.AddNorm(fa, 0);
+	dc.AddNorm(fb, 1);
+	return dc(a, 0u, b, 1u);
+}
+// DistCalculator<uint8_t>::operator()(query, row, id): the query's corrective offset sits behind its codes (hnswlib.h:251-258)
+float ref_sq8_dist_query(int metric, size_t dim, float alpha2, const uint8_t* q, float corrQ, const uint8_t* row, float corrRow, const float* frow) {
+	hnswlib::DistCalculator<uint8_t> dc(toMetric(metric), dim, 1, alpha2);
+	dc.Sq8CorrectiveOffsets()[0] = corrRow;
+	dc.AddNorm(frow, 0);
+	std::vector<uint8_t> qbuf(dim + sizeof(float));
+	std::memcpy(qbuf.data(), q, dim);
+	std::memcpy(qbuf.data() + dim, &corrQ, sizeof(float));
+	return dc(qbuf.data(), row, 0u);
 }
 
 }  // extern "C"

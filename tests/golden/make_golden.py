@@ -159,5 +159,52 @@ def make_ft_goldens():
     np.savez_compressed(OUT / "ft.npz", **z)
 
 
+SQ8_DIMS = [1, 5, 63, 64, 65, 100, 128, 768, 1000, 1536]
+
+
+def make_sq8_goldens():
+    """SQ8 (uint8) distance path from the REAL reference (ref_shim.cc: L2SqrDistance<uint8_t> / InnerProductDistance<uint8_t>,
+    Quantizer::Quantize, DistCalculator<uint8_t>): pins oracle/oracle_sq8.c where /root/reference does not exist."""
+    from oracle.pyoracle import Sq8Ref
+    sr = Sq8Ref(Ref())
+    rng = np.random.default_rng(2026)
+    z = {}
+    for d in SQ8_DIMS:
+        a = rng.integers(0, 256, (24, d)).astype(np.uint8)
+        b = rng.integers(0, 256, (24, d)).astype(np.uint8)
+        a[0], b[0] = 255, 0   # the largest lane sums: the float reduction rounds
+        z[f"u8_a_{d}"], z[f"u8_b_{d}"] = a, b
+        z[f"u8_l2_{d}"] = np.array([sr.l2sqr_u8(x, y) for x, y in zip(a, b)], np.float32)
+        z[f"u8_ip_{d}"] = np.array([sr.ip_u8(x, y) for x, y in zip(a, b)], np.float32)
+    for metric in (0, 1, 2):
+        for d in (8, 100, 768):
+            v = rng.normal(0, 0.25, (16, d)).astype(np.float32)
+            v[0, : min(4, d)] = [3.0, -3.0, 0.0, 1e-3][: min(4, d)]   # outliers beyond [minQ, maxQ]: the clamp
+            min_q, max_q = float(np.quantile(v, 0.02)), float(np.quantile(v, 0.98))
+            p = sr.params(min_q, max_q, d)
+            key = f"q_m{metric}_d{d}"
+            z[key + "_vec"], z[key + "_minmax"] = v, np.array([min_q, max_q], np.float32)
+            z[key + "_params"] = np.array([p["alpha"], p["alpha_2"], p["delta"]], np.float32)
+            codes, corr, qcodes, qcorr = [], [], [], []
+            for x in v:
+                c, o = sr.quantize(metric, p, x)
+                codes.append(c)
+                corr.append(o)
+                c, o = sr.quantize(metric, p, x, 1.25)   # the scaled view prepareData feeds for a query
+                qcodes.append(c)
+                qcorr.append(o)
+            z[key + "_codes"], z[key + "_corr"] = np.stack(codes), np.array(corr, np.float32)
+            z[key + "_qcodes"], z[key + "_qcorr"] = np.stack(qcodes), np.array(qcorr, np.float32)
+            z[key + "_pair"] = np.array([sr.dist_pair(metric, p, codes[i], corr[i], v[i], codes[i + 1], corr[i + 1], v[i + 1])
+                                         for i in range(15)], np.float32)
+            z[key + "_query"] = np.array([sr.dist_query(metric, p, qcodes[i], qcorr[i], codes[i + 1], corr[i + 1], v[i + 1])
+                                          for i in range(15)], np.float32)
+    np.savez_compressed(OUT / "sq8.npz", **z)
+
+
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["sq8"]:
+        make_sq8_goldens()
+    else:
+        main()
+        make_sq8_goldens()

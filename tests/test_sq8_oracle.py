@@ -1,0 +1,114 @@
+"""CPU: the SQ8 (scalar-quantised uint8) distance path of the reference — oracle/oracle_sq8.c against the REAL reference code
+compiled in place (oracle/_ref: L2SqrDistance<uint8_t>, InnerProductDistance<uint8_t>, Quantizer::Quantize, DistCalculator<uint8_t>) and
+against tests/golden/sq8.npz generated from it.  No GPU kernel reads uint8 vectors yet: this pins the checker for that next row.
+The uint8 kernels are NOT order-free: the 16 int32 lane sums are added as floats, which rounds beyond 2^24."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+G = Path(__file__).resolve().parent / "golden"
+DIMS = [1, 2, 31, 32, 63, 64, 65, 100, 127, 128, 129, 256, 768, 1000, 1024, 1536, 4096]
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def sq8(oracle):
+    from oracle.pyoracle import Sq8Oracle
+    return Sq8Oracle(oracle)
+
+
+@pytest.fixture(scope="module")
+def sq8ref(ref):
+    from oracle.pyoracle import Sq8Ref
+    try:
+        return Sq8Ref(ref)
+    except AttributeError:
+        pytest.skip("oracle/_ref/libref_oracle.so predates the SQ8 shims")
+
+
+@pytest.mark.parametrize("d", DIMS)
+def test_u8_distances_match_reference_bits(sq8, sq8ref, d):
+    rng = np.random.default_rng(d)
+    for style in ("uniform", "extreme", "narrow"):
+        for _ in range(60):
+            if style == "uniform":
+                a, b = rng.integers(0, 256, d), rng.integers(0, 256, d)
+            elif style == "extreme":
+                a, b = rng.choice([0, 255], d), rng.choice([0, 255], d)
+            else:
+                a, b = rng.integers(100, 140, d), rng.integers(100, 140, d)
+            a, b = a.astype(np.uint8), b.astype(np.uint8)
+            assert bits(sq8.l2sqr_u8(a, b)) == bits(sq8ref.l2sqr_u8(a, b)), (style, d)
+            assert bits(sq8.ip_u8(a, b)) == bits(sq8ref.ip_u8(a, b)), (style, d)
+
+
+def test_float_reduction_really_rounds(sq8):
+    """255^2 * 1536 = 9.99e7 > 2^24: the sequential float sum of the 16 lane sums is neither the exact integer (99 766 420) nor its
+    correctly rounded float (99 766 416) — the lane assignment and the order of that sum are part of the contract."""
+    d = 1536
+    a, b = np.full(d, 255, np.uint8), np.zeros(d, np.uint8)
+    a[::7] = 254
+    exact = int(((a.astype(np.int64) - b) ** 2).sum())
+    got = float(sq8.l2sqr_u8(a, b))
+    assert exact == 99_766_420 and got == 99_766_408.0 and got != float(np.float32(exact))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("d", [1, 8, 64, 100, 768, 1024])
+def test_quantize_and_distcalculator_match_reference(oracle, sq8, sq8ref, metric, d):
+    rng = np.random.default_rng(100 * metric + d)
+    v = rng.normal(0, 0.25, (40, d)).astype(np.float32)
+    v[0] = 10.0     # clamps to 255
+    v[1] = -10.0    # clamps to 0
+    for lo, hi in ((0.02, 0.98), (0.0, 1.0)):
+        min_q, max_q = float(np.quantile(v[2:], lo)), float(np.quantile(v[2:], hi))
+        p, pr = sq8.params(min_q, max_q, d), sq8ref.params(min_q, max_q, d)
+        assert all(bits(p[k]) == bits(pr[k]) for k in ("alpha", "alpha_2", "delta"))
+        stored = []
+        for x in v:
+            for scale in (1.0, 0.8, 3.5):
+                c, o = sq8.quantize(metric, p, x, scale)
+                rc, ro = sq8ref.quantize(metric, p, x, scale)
+                assert np.array_equal(c, rc) and bits(o) == bits(ro), (metric, d, scale)
+            stored.append(sq8.quantize(metric, p, x))
+        for i in range(len(v) - 1):
+            (a, ca), (b, cb) = stored[i], stored[i + 1]
+            assert bits(sq8.dist_pair(metric, p, a, ca, v[i], b, cb, v[i + 1], oracle)) == bits(sq8ref.dist_pair(metric, p, a, ca, v[i], b, cb, v[i + 1]))
+            qc, qo = sq8.quantize(metric, p, v[i], 1.25)
+            assert bits(sq8.dist_query(metric, p, qc, qo, b, cb, v[i + 1], oracle)) == bits(sq8ref.dist_query(metric, p, qc, qo, b, cb, v[i + 1]))
+
+
+def test_sq8_oracle_matches_golden_fixture(oracle, sq8):
+    """The same pins on machines without /root/reference: values produced by the real reference, committed."""
+    z = np.load(G / "sq8.npz")
+    from .golden.make_golden import SQ8_DIMS
+    for d in SQ8_DIMS:
+        a, b = z[f"u8_a_{d}"], z[f"u8_b_{d}"]
+        assert np.array_equal(bits([sq8.l2sqr_u8(x, y) for x, y in zip(a, b)]), bits(z[f"u8_l2_{d}"])), d
+        assert np.array_equal(bits([sq8.ip_u8(x, y) for x, y in zip(a, b)]), bits(z[f"u8_ip_{d}"])), d
+    for metric in (0, 1, 2):
+        for d in (8, 100, 768):
+            key = f"q_m{metric}_d{d}"
+            v, (min_q, max_q) = z[key + "_vec"], z[key + "_minmax"]
+            p = sq8.params(float(min_q), float(max_q), d)
+            assert np.array_equal(bits([p["alpha"], p["alpha_2"], p["delta"]]), bits(z[key + "_params"]))
+            codes, corr = z[key + "_codes"], z[key + "_corr"]
+            for i, x in enumerate(v):
+                c, o = sq8.quantize(metric, p, x)
+                assert np.array_equal(c, codes[i]) and bits(o) == bits(corr[i])
+                c, o = sq8.quantize(metric, p, x, 1.25)
+                assert np.array_equal(c, z[key + "_qcodes"][i]) and bits(o) == bits(z[key + "_qcorr"][i])
+            pair = [sq8.dist_pair(metric, p, codes[i], corr[i], v[i], codes[i + 1], corr[i + 1], v[i + 1], oracle) for i in range(15)]
+            assert np.array_equal(bits(pair), bits(z[key + "_pair"]))
+            query = [sq8.dist_query(metric, p, z[key + "_qcodes"][i], z[key + "_qcorr"][i], codes[i + 1], corr[i + 1], v[i + 1], oracle)
+                     for i in range(15)]
+            assert np.array_equal(bits(query), bits(z[key + "_query"]))
+            # the row-batch form equals the scalar form
+            inv = oracle.l2_modules(v) if metric == 2 else None
+            many = sq8.dist_query_many(metric, p, z[key + "_qcodes"][0], z[key + "_qcorr"][0], codes, corr, inv)
+            one = [sq8.dist_query(metric, p, z[key + "_qcodes"][0], z[key + "_qcorr"][0], codes[i], corr[i], v[i], oracle) for i in range(len(v))]
+            assert np.array_equal(bits(many), bits(one))
