@@ -105,9 +105,25 @@ typedef struct {
 	const uint8_t* deleted;
 	const float* vectors;
 	const float* inv_norms;
+	/* SQ8 graph (HierarchicalNSWImpl<uint8_t>): codes instead of vectors, the stored corrective offsets, alpha_2; the query travels as codes +
+	 * offset (prepareData, hnswalg.h:510-529) and every distance is scaled by normcoef (queryNormCoef, :1855-1863) */
+	const uint8_t* codes;
+	const float* corr;
+	float alpha_2;
+	const uint8_t* qcodes;
+	float qcorr;
+	float normcoef;
 } orc_hnsw_graph;
 
+float orc_sq8_dist_query(int metric, size_t dim, float alpha_2, const uint8_t* q, float corr_q, const uint8_t* row, float corr_row,
+						 float inv_norm_row);
+float orc_sq8_quantize(int metric, size_t dim, float min_q, float alpha, float delta, const float* from, float scale, uint8_t* to);
+
 static float gdist(const orc_hnsw_graph* g, const float* q, uint32_t id) {
+	if (g->codes) {
+		return g->normcoef * orc_sq8_dist_query(g->metric, g->dim, g->alpha_2, g->qcodes, g->qcorr, g->codes + (size_t)id * g->dim, g->corr[id],
+												 g->inv_norms ? g->inv_norms[id] : 1.0f);
+	}
 	/* normCoef == 1 for the unquantized graph (queryNormCoef, hnswalg.h:1855-1863) */
 	return 1.0f * orc_dist(g->metric, q, g->vectors + (size_t)id * g->dim, g->dim, g->inv_norms ? g->inv_norms[id] : 1.0f);
 }
@@ -150,13 +166,13 @@ void orc_hnsw_last_stats(long* ndist, long* hops) {
 }
 
 /* SearchKnn (hnswalg.h:1988-2012). Returns count; out[0] is the best hit (drained like hnsw_index.cc:258-273). */
-size_t orc_hnsw_search_knn(int metric, size_t n, size_t dim, size_t M, size_t maxM0, int maxlevel, uint32_t entry, size_t num_deleted,
-						   const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, const int32_t* levels,
-						   const uint64_t* labels, const uint8_t* deleted, const float* vectors, const float* inv_norms, const float* q,
-						   size_t k, size_t ef, float* out_dist, uint64_t* out_label) {
+static size_t search_knn_impl(const orc_hnsw_graph* gp, const float* q, size_t k, size_t ef, float* out_dist, uint64_t* out_label) {
+	const orc_hnsw_graph g = *gp;
+	const size_t n = g.n, maxM0 = g.maxM0, num_deleted = g.num_deleted;
+	const uint32_t* links0 = g.links0;
+	const uint64_t* labels = g.labels;
+	const uint8_t* deleted = g.deleted;
 	if (n == 0) return 0;
-	const orc_hnsw_graph g = {metric, n,     dim,      M,     maxM0,  maxlevel, entry,   num_deleted,
-							  links0, upper_off, upper, levels, labels, deleted,  vectors, inv_norms};
 	if (k > n) k = n;
 	if (!ef) ef = k * 3 / 2;
 	long ndist = 0, hops = 0;
@@ -237,6 +253,33 @@ size_t orc_hnsw_search_knn(int metric, size_t n, size_t dim, size_t M, size_t ma
 	return total;
 }
 
+size_t orc_hnsw_search_knn(int metric, size_t n, size_t dim, size_t M, size_t maxM0, int maxlevel, uint32_t entry, size_t num_deleted,
+						   const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, const int32_t* levels,
+						   const uint64_t* labels, const uint8_t* deleted, const float* vectors, const float* inv_norms, const float* q,
+						   size_t k, size_t ef, float* out_dist, uint64_t* out_label) {
+	const orc_hnsw_graph g = {metric, n,     dim,      M,     maxM0,  maxlevel, entry,   num_deleted, links0, upper_off, upper,
+							  levels, labels, deleted,  vectors, inv_norms, NULL,  NULL,    1.0f,        NULL,   0.0f,      1.0f};
+	return search_knn_impl(&g, q, k, ef, out_dist, out_label);
+}
+
+/* SearchKnn over the SQ8 graph (HierarchicalNSWImpl<uint8_t>, hnswalg.h:1977-2012): same traversal, distances from the codes.
+ * q = the query as the caller hands it to SearchKnn (normalised for cosine), has_qnorm / qnorm = query_data_norm. */
+size_t orc_hnsw_search_knn_sq8(int metric, size_t n, size_t dim, size_t M, size_t maxM0, int maxlevel, uint32_t entry, size_t num_deleted,
+							   const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, const int32_t* levels,
+							   const uint64_t* labels, const uint8_t* deleted, const uint8_t* codes, const float* corr, const float* inv_norms,
+							   float min_q, float alpha, float alpha_2, float delta, const float* q, int has_qnorm, float qnorm, size_t k, size_t ef,
+							   float* out_dist, uint64_t* out_label) {
+	if (n == 0) return 0;
+	const float normcoef = (metric == ORC_METRIC_COSINE && has_qnorm) ? 1.f / qnorm : 1.f; /* queryNormCoef */
+	uint8_t* qcodes = (uint8_t*)malloc(dim ? dim : 1);
+	const float qcorr = orc_sq8_quantize(metric, dim, min_q, alpha, delta, q, 1.f / normcoef, qcodes); /* prepareData: norm = 1.f / norm */
+	const orc_hnsw_graph g = {metric, n,     dim,     M,    maxM0,     maxlevel, entry, num_deleted, links0, upper_off, upper,
+							  levels, labels, deleted, NULL, inv_norms, codes,    corr,  alpha_2,     qcodes, qcorr,     normcoef};
+	const size_t r = search_knn_impl(&g, q, k, ef, out_dist, out_label);
+	free(qcodes);
+	return r;
+}
+
 /* ================================================================================================================
  * Streaming (batched) KNN: BeginStreamingSearch / ContinueStreamingSearch (hnswalg.h:1865-1975) with the streaming branches of
  * initLayer0SearchState (:846-850), layer0ShouldStopBeforePop (:865-868) and runLayer0Step (:882-893, 939-940),
@@ -257,8 +300,8 @@ void* orc_hnsw_stream_begin(int metric, size_t n, size_t dim, size_t M, size_t m
 							 const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, const int32_t* levels,
 							 const uint64_t* labels, const uint8_t* deleted, const float* vectors, const float* inv_norms, const float* q, size_t ef) {
 	orc_hnsw_stream* s = (orc_hnsw_stream*)calloc(1, sizeof(*s));
-	const orc_hnsw_graph g = {metric, n,     dim,      M,     maxM0,  maxlevel, entry,   num_deleted,
-							  links0, upper_off, upper, levels, labels, deleted,  vectors, inv_norms};
+	const orc_hnsw_graph g = {metric, n,     dim,      M,     maxM0,  maxlevel, entry,   num_deleted, links0, upper_off, upper,
+							  levels, labels, deleted,  vectors, inv_norms, NULL,  NULL,    1.0f,        NULL,   0.0f,      1.0f};
 	s->g = g;
 	s->empty_graph = n == 0;
 	if (n == 0) return s;

@@ -815,3 +815,61 @@ class Sq8Ref(_Sq8Base):
         q, row, frow = _u8(q), _u8(row), _f32(frow)
         return np.float32(self.L.ref_sq8_dist_query(metric, q.shape[0], p["alpha_2"], q.ctypes.data, corr_q, row.ctypes.data, corr_row,
                                                     frow.ctypes.data))
+
+
+class RefHnswQ:
+    """The reference's quantised engine (HierarchicalNSWImpl<uint8_t>) built from a RefHnsw by the copy constructor its own Quantize() uses."""
+
+    def __init__(self, float_graph: "RefHnsw", sample_size: int = 20000, quantile: float = 0.0):
+        L = self.L = float_graph.ref.L
+        L.ref_hnsw_quantize.restype = _vp
+        L.ref_hnsw_quantize.argtypes = [_vp, _sz, _f]
+        L.ref_hnswq_destroy.argtypes = [_vp]
+        L.ref_hnswq_export.argtypes = [_vp, _vp, _vp, _vp]
+        L.ref_hnswq_search_knn.restype = C.c_long
+        L.ref_hnswq_search_knn.argtypes = [_vp, _vp, _i, _f, _sz, _sz, _vp, _vp]
+        self.dim, self.n = float_graph.dim, float_graph.count
+        self.h = L.ref_hnsw_quantize(float_graph.h, sample_size, quantile)
+        if not self.h:
+            raise RuntimeError(L.ref_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.ref_hnswq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def export(self) -> dict:
+        params = np.zeros(5, np.float32)
+        codes = np.zeros((self.n, self.dim), np.uint8)
+        corr = np.zeros(self.n, np.float32)
+        self.L.ref_hnswq_export(self.h, params.ctypes.data, codes.ctypes.data, corr.ctypes.data)
+        return dict(min_q=params[0], max_q=params[1], alpha=params[2], alpha_2=params[3], delta=params[4], codes=codes, corr=corr)
+
+    def search_knn(self, q, k, ef=0, norm=None):
+        q = _f32(q)
+        od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+        c = self.L.ref_hnswq_search_knn(self.h, q.ctypes.data, int(norm is not None), 0.0 if norm is None else norm, k, ef, od.ctypes.data, ol.ctypes.data)
+        if c < 0:
+            raise RuntimeError(self.L.ref_last_error().decode())
+        return od[:c].copy(), ol[:c].copy()
+
+
+def oracle_hnsw_search_knn_sq8(orc: Oracle, g: dict, sq: dict, q, k: int, ef: int = 0, inv_norms=None, qnorm=None):
+    """Restated SearchKnn over an SQ8 graph: g = the flat graph (links of the float graph), sq = RefHnswQ.export()-shaped dict."""
+    L = orc.L
+    L.orc_hnsw_search_knn_sq8.restype = _sz
+    L.orc_hnsw_search_knn_sq8.argtypes = [_i, _sz, _sz, _sz, _sz, _i, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _f, _f, _f, _f, _vp, _i, _f, _sz, _sz, _vp, _vp]
+    q = _f32(q)
+    od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+    inv = _f32(inv_norms) if inv_norms is not None else None
+    codes, corr = _u8(sq["codes"]), _f32(sq["corr"])
+    c = L.orc_hnsw_search_knn_sq8(g["metric"], g["n"], g["dim"], g["M"], g["maxM0"], g["maxlevel"], g["entry"], g["num_deleted"],
+                                  g["links0"].ctypes.data, g["upper_off"].ctypes.data, g["upper"].ctypes.data, g["levels"].ctypes.data,
+                                  g["labels"].ctypes.data, g["deleted"].ctypes.data, codes.ctypes.data, corr.ctypes.data,
+                                  inv.ctypes.data if inv is not None else None, sq["min_q"], sq["alpha"], sq["alpha_2"], sq["delta"],
+                                  q.ctypes.data, int(qnorm is not None), 0.0 if qnorm is None else qnorm, k, ef, od.ctypes.data, ol.ctypes.data)
+    return od[:c].copy(), ol[:c].copy()

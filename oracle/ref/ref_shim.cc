@@ -292,4 +292,47 @@ float ref_sq8_dist_query(int metric, size_t dim, float alpha2, const uint8_t* q,
 	return dc(qbuf.data(), row, 0u);
 }
 
+// The quantised engine: HierarchicalNSWImpl<uint8_t> built from the float graph by the copy constructor the reference's
+// HierarchicalNSW<>::Impl::Quantize uses (hnsw.cc:132-150, hnswalg.h:411-500) — the links are copied, every vector goes through
+// Quantizer::Quantize with parameters sampled from the float graph (QuantizingParams(hnsw, conf), quantization_params.h:48-63).
+using QHnswT = hnswlib::HierarchicalNSWImpl<uint8_t, hnswlib::Synchronization::None>;
+void* ref_hnsw_quantize(void* h, size_t sampleSize, float quantile) {
+	try {
+		auto* g = static_cast<HnswT*>(h);
+		hnswlib::QuantizationConfig conf;
+		conf.sampleSize = sampleSize;
+		if (quantile > 0.f) conf.quantile = quantile;
+		return new QHnswT(*g, g->max_elements_, std::optional<hnswlib::QuantizationConfig>(conf));
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+void ref_hnswq_destroy(void* h) { delete static_cast<QHnswT*>(h); }
+// params[0..4] = minQ, maxQ, alpha, alpha_2, delta; codes [count][dim] u8; corr [count] f32
+void ref_hnswq_export(void* h, float* params, uint8_t* codes, float* corr) {
+	auto* g = static_cast<QHnswT*>(h);
+	const auto& p = g->quantizer_->Params();
+	params[0] = p.minQ;
+	params[1] = p.maxQ;
+	params[2] = p.alpha;
+	params[3] = p.alpha_2;
+	params[4] = p.delta;
+	const size_t n = g->cur_element_count.load(), dim = g->fstdistfunc_.Dim();
+	for (size_t i = 0; i < n; ++i) {
+		std::memcpy(codes + i * dim, g->getDataByInternalId(hnswlib::tableint(i)), dim);
+		corr[i] = g->fstdistfunc_.Sq8CorrectiveOffsets()[i];
+	}
+}
+// SearchKnn(query, query_data_norm, k, ef) of the quantised engine (hnswalg.h:1987-2012); hasNorm == 0 passes std::nullopt
+long ref_hnswq_search_knn(void* h, const float* q, int hasNorm, float norm, size_t k, size_t ef, float* outDist, uint64_t* outLabel) {
+	try {
+		auto res = static_cast<const QHnswT*>(h)->SearchKnn(q, hasNorm ? std::optional<float>(norm) : std::nullopt, k, ef);
+		return long(drain(res, outDist, outLabel, k));
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+
 }  // extern "C"

@@ -199,6 +199,42 @@ def make_sq8_goldens():
                                          for i in range(15)], np.float32)
             z[key + "_query"] = np.array([sr.dist_query(metric, p, qcodes[i], qcorr[i], codes[i + 1], corr[i + 1], v[i + 1])
                                           for i in range(15)], np.float32)
+    # the quantised engine end to end: float graph -> HierarchicalNSWImpl<uint8_t> (the copy constructor Quantize() uses) -> SearchKnn
+    from oracle.pyoracle import RefHnswQ
+    n, d = 1200, 32
+    for metric in (0, 2):
+        rows = rng.normal(0, 0.25, (n, d)).astype(np.float32)
+        labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+        h = RefHnsw(Ref(), metric, d, n, M=8, ef_construction=60)
+        h.add(rows, labels)
+        for lab in labels[rng.choice(n, 40, replace=False)]:
+            h.mark_delete(lab)
+        g = h.export(with_vectors=False)
+        hq = RefHnswQ(h, sample_size=1000)
+        sq = hq.export()
+        key = f"hq_m{metric}"
+        z[key + "_rows"], z[key + "_labels"] = rows, labels
+        for k in ("links0", "upper_off", "upper", "levels", "deleted"):
+            z[f"{key}_{k}"] = g[k]
+        z[key + "_meta"] = np.array([g["n"], g["dim"], g["M"], g["maxM0"], g["maxlevel"], g["entry"], g["num_deleted"]], np.int64)
+        z[key + "_params"] = np.array([sq["min_q"], sq["max_q"], sq["alpha"], sq["alpha_2"], sq["delta"]], np.float32)
+        z[key + "_codes"], z[key + "_corr"] = sq["codes"], sq["corr"]
+        queries = rng.normal(0, 0.25, (12, d)).astype(np.float32)
+        norms = np.zeros(12, np.float32)
+        if metric == 2:
+            ref = Ref()
+            for i in range(12):
+                queries[i], k_ = ref.normalize_copy(queries[i])
+                norms[i] = np.float32(1.0) / np.float32(k_)
+        z[key + "_queries"], z[key + "_qnorms"] = queries, norms
+        res_d, res_l = [], []
+        for i in range(12):
+            wd, wl = hq.search_knn(queries[i], 10, 32, float(norms[i]) if metric == 2 else None)
+            res_d.append(wd)
+            res_l.append(wl)
+        z[key + "_res_dist"], z[key + "_res_label"] = np.stack(res_d), np.stack(res_l)
+        hq.close()
+        h.close()
     np.savez_compressed(OUT / "sq8.npz", **z)
 
 

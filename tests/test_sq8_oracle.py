@@ -112,3 +112,65 @@ def test_sq8_oracle_matches_golden_fixture(oracle, sq8):
             many = sq8.dist_query_many(metric, p, z[key + "_qcodes"][0], z[key + "_qcorr"][0], codes, corr, inv)
             one = [sq8.dist_query(metric, p, z[key + "_qcodes"][0], z[key + "_qcorr"][0], codes[i], corr[i], v[i], oracle) for i in range(len(v))]
             assert np.array_equal(bits(many), bits(one))
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_quantised_hnsw_engine_is_reproduced(oracle, ref, sq8, sq8ref, metric):
+    """The whole SQ8 search path against the REAL quantised engine (HierarchicalNSWImpl<uint8_t> built from a float graph the way
+    HierarchicalNSW::Quantize does): with the engine's sampled (minQ, maxQ) the restatement reproduces every code, every corrective offset and
+    the derived parameters, and SearchKnn over the codes returns the engine's labels and distance bits, deleted nodes included."""
+    from oracle.pyoracle import RefHnsw, RefHnswQ, oracle_hnsw_search_knn_sq8
+    from .conftest import make_corpus
+    n, d = 3000, 64
+    rows = make_corpus(61, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    h = RefHnsw(ref, metric, d, n, M=16, ef_construction=100)
+    h.add(rows, labels)
+    for lab in labels[np.random.default_rng(4).choice(n, 100, replace=False)]:
+        h.mark_delete(lab)
+    g = h.export(with_vectors=False)
+    hq = RefHnswQ(h, sample_size=2000)
+    sq = hq.export()
+    p = sq8.params(float(sq["min_q"]), float(sq["max_q"]), d)
+    assert all(bits(p[k]) == bits(sq[k]) for k in ("alpha", "alpha_2", "delta"))
+    for i in range(0, n, 7):
+        c, o = sq8.quantize(metric, p, rows[i])
+        assert np.array_equal(c, sq["codes"][i]) and bits(o) == bits(sq["corr"][i]), i
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    for qi in range(40):
+        q = make_corpus(700 + qi, 1, d)[0]
+        norm = None
+        if metric == 2:
+            q, k_ = oracle.normalize_copy(q)
+            norm = float(np.float32(1.0) / np.float32(k_))   # hnsw_index.cc:168: normL2 = 1.f / NormalizeCopyVector(...)
+        for k, ef in ((10, 64), (1, 10), (50, 0)):
+            wd, wl = hq.search_knn(q, k, ef, norm)
+            gd, gl = oracle_hnsw_search_knn_sq8(oracle, g, sq, q, k, ef, inv, norm)
+            assert np.array_equal(gl, wl), (metric, qi, k, ef)
+            assert np.array_equal(bits(gd), bits(wd))
+    hq.close()
+    h.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_quantised_hnsw_search_matches_golden_engine_results(oracle, sq8, metric):
+    """The end-to-end pin without /root/reference: a quantised graph exported from the real engine and its SearchKnn results."""
+    from oracle.pyoracle import oracle_hnsw_search_knn_sq8
+    z = np.load(G / "sq8.npz")
+    key = f"hq_m{metric}"
+    n, dim, M, maxM0, maxlevel, entry, num_deleted = (int(x) for x in z[key + "_meta"])
+    g = dict(metric=metric, n=n, dim=dim, M=M, maxM0=maxM0, maxlevel=maxlevel, entry=entry, num_deleted=num_deleted,
+             links0=z[key + "_links0"], upper_off=z[key + "_upper_off"], upper=z[key + "_upper"], levels=z[key + "_levels"],
+             labels=z[key + "_labels"], deleted=z[key + "_deleted"])
+    min_q, max_q, alpha, alpha_2, delta = z[key + "_params"]
+    sq = dict(min_q=min_q, max_q=max_q, alpha=alpha, alpha_2=alpha_2, delta=delta, codes=z[key + "_codes"], corr=z[key + "_corr"])
+    rows = z[key + "_rows"]
+    p = sq8.params(float(min_q), float(max_q), dim)
+    assert bits(p["alpha"]) == bits(alpha) and bits(p["alpha_2"]) == bits(alpha_2) and bits(p["delta"]) == bits(delta)
+    for i in range(0, n, 5):
+        c, o = sq8.quantize(metric, p, rows[i])
+        assert np.array_equal(c, sq["codes"][i]) and bits(o) == bits(sq["corr"][i])
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    for i, q in enumerate(z[key + "_queries"]):
+        gd, gl = oracle_hnsw_search_knn_sq8(oracle, g, sq, q, 10, 32, inv, float(z[key + "_qnorms"][i]) if metric == 2 else None)
+        assert np.array_equal(gl, z[key + "_res_label"][i]) and np.array_equal(bits(gd), bits(z[key + "_res_dist"][i])), i
