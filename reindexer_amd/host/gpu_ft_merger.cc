@@ -115,6 +115,7 @@ void GpuFtMerger::ReadStats(uint64_t& postings, double& kernelMs) const {
 MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 							 RankSortType rankSortType) const {
 	MergeData out;
+	if (cfg.bm25Type != FtConfig::Bm25Type::Rx) throw std::logic_error("GpuFtMerger: only Bm25Rx is evaluated on the device (see Supports())");
 	if (subterms.empty() || totalDocs_ == 0) return out;   // mergerimpl.h:472-474
 	if (cfg.fieldsCfg.size() != numFields_ || termOpts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
 	// TermResults::SortSubterms (querymergedata.h:62-66): by proc, descending
@@ -217,6 +218,7 @@ MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> te
 								  bool* preselected) const {
 	if (preselected) *preselected = false;
 	MergeData out;
+	if (cfg.bm25Type != FtConfig::Bm25Type::Rx) throw std::logic_error("GpuFtMerger: only Bm25Rx is evaluated on the device (see Supports())");
 	// QueryMergeData::Empty() (querymergedata.h:208) / mergerimpl.h:472-474
 	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return out;
 	if (terms.size() == 1) return Merge(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType);   // Simple()

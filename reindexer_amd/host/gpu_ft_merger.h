@@ -32,6 +32,10 @@ struct FtConfig {
 	uint32_t mergeLimit = 20000;
 	double distanceBoost = 1.0, distanceWeight = 0.5;
 	double bm25k1 = 2.0, bm25b = 0.75;
+	// FTConfig::Bm25Config::Bm25Type (ftconfig.h:199-206).  The GPU merger evaluates Bm25Rx (the default); Classic and wordCount stay on the
+	// reference's CPU merger: Supports(cfg, ...) is false for them and Merge / MergeQuery refuse loudly.
+	enum class Bm25Type { Classic, Rx, WordCount };
+	Bm25Type bm25Type = Bm25Type::Rx;
 	double summationRanksByFieldsRatio = 0.0;
 	double fullMatchBoost = 1.1;
 	int minRank = 5;
@@ -110,6 +114,9 @@ public:
 	void SetWord(uint32_t wordId, const PositionPostings& postings);   // usable by Merge and MergeQuery
 
 	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept { return numQueryParts >= 1 && !hasPhrases && !hasSynonyms; }
+	static bool Supports(const FtConfig& cfg, size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept {
+		return cfg.bm25Type == FtConfig::Bm25Type::Rx && Supports(numQueryParts, hasPhrases, hasSynonyms);
+	}
 
 	// Merger::Merge<Bm25Rx> for a Simple() query
 	MergeData Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
