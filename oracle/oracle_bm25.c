@@ -38,6 +38,7 @@ typedef struct {
 	const double* term_len_weight;
 	const double* position_boost;
 	const double* position_weight;
+	int bm25_type;                /* FTConfig::Bm25Config::bm25Type (ftconfig.h:200-203): 0 = rx (default), 1 = classic, 2 = wordCount */
 } orc_ft_config;
 
 typedef struct {
@@ -66,6 +67,18 @@ double orc_bm25rx_idf(double total_docs, double matched_docs) {
 /* bm25.h:13-16 (TF = termCountInDoc) */
 double orc_bm25rx_get(double idf, double k1, double b, double term_count, double words_in_doc, double avg_doc_len) {
 	const double tf = term_count;
+	return idf * tf * (k1 + 1.0) / (tf + k1 * (1.0 - b + b * words_in_doc / avg_doc_len));
+}
+/* The three calculators behind Bm25Calculator<BM> (bm25.h:8-68), selected like the selecter does from bm25Config.bm25Type:
+ * rx: IDF saturated at 0.2, TF = count; classic: IDF = ln(N / (M + 1)) + 1, TF = count / wordsInDoc; wordCount: the count itself, IDF 0 */
+double orc_bm25_idf(int type, double total_docs, double matched_docs) {
+	if (type == 1) return log(total_docs / (matched_docs + 1)) + 1;
+	if (type == 2) return 0.0;
+	return orc_bm25rx_idf(total_docs, matched_docs);
+}
+double orc_bm25_get(int type, double idf, double k1, double b, double term_count, double words_in_doc, double avg_doc_len) {
+	if (type == 2) return term_count;
+	const double tf = type == 1 ? term_count / words_in_doc : term_count;
 	return idf * tf * (k1 + 1.0) / (tf + k1 * (1.0 - b + b * words_in_doc / avg_doc_len));
 }
 /* ftconfig.h:127-144 */
@@ -99,7 +112,7 @@ float orc_calc_term_rank(const orc_ft_config* cfg, const orc_ft_term_opts* opts,
 	for (uint32_t e = 0; e < nent; ++e) {
 		const unsigned f = ent_field[e];
 		if (opts->field_boost[f] == 0.0f) continue;
-		const float bm25 = (float)orc_bm25rx_get(idf, cfg->k1, cfg->b, (double)ent_tf[e], (double)words_in_field[f], (double)avg_words[f]);
+		const float bm25 = (float)orc_bm25_get(cfg->bm25_type, idf, cfg->k1, cfg->b, (double)ent_tf[e], (double)words_in_field[f], (double)avg_words[f]);
 		const float norm_bm25 = orc_bound(bm25, (float)cfg->bm25_weight[f], (float)cfg->bm25_boost[f]);
 		prank = orc_bound(orc_pos2rank(ent_first_pos[e]), (float)cfg->position_weight[f], (float)cfg->position_boost[f]);
 		tlb = orc_bound(opts->term_len_boost, (float)cfg->term_len_weight[f], (float)cfg->term_len_boost[f]);
@@ -194,7 +207,7 @@ size_t orc_ft_merge_simple(const orc_ft_config* cfg, const orc_ft_term_opts* opt
 	size_t n = 0;
 	for (uint32_t s = 0; s < nsub; ++s) {
 		const orc_ft_postings* p = &subs[s];
-		const double idf = orc_bm25rx_idf((double)(total_docs - 1), (double)p->n);   /* "first doc is always empty" */
+		const double idf = orc_bm25_idf(cfg->bm25_type, (double)(total_docs - 1), (double)p->n);   /* "first doc is always empty" */
 		for (uint64_t i = 0; i < p->n; ++i) {
 			const uint32_t d = p->doc[i];
 			if ((excluded && excluded[d]) || (removed && removed[d])) continue;
@@ -480,7 +493,7 @@ size_t orc_ft_merge_query(const orc_ft_config* cfg, double distance_boost, doubl
 		}
 		for (uint32_t s = 0; s < terms[t].nsub; ++s) {
 			const orc_ft_ppostings* p = &terms[t].subs[s];
-			const double idf = orc_bm25rx_idf((double)(total_docs - 1), (double)p->n);
+			const double idf = orc_bm25_idf(cfg->bm25_type, (double)(total_docs - 1), (double)p->n);
 			for (uint64_t i = 0; i < p->n; ++i) {
 				const uint32_t d = p->doc[i];
 				if (!mask[d]) continue;

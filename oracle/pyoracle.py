@@ -410,7 +410,7 @@ class _FtConfig(C.Structure):
     _fields_ = [("k1", C.c_double), ("b", C.c_double), ("summation_ratio", C.c_double), ("full_match_boost", C.c_double),
                 ("min_rank", C.c_int), ("merge_limit", C.c_uint32), ("num_fields", C.c_uint32),
                 ("bm25_boost", _vp), ("bm25_weight", _vp), ("term_len_boost", _vp), ("term_len_weight", _vp),
-                ("position_boost", _vp), ("position_weight", _vp)]
+                ("position_boost", _vp), ("position_weight", _vp), ("bm25_type", C.c_int)]
 
 
 class _FtTermOpts(C.Structure):
@@ -469,7 +469,7 @@ class FtOracle:
         keep = [np.ascontiguousarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
                                                                    "position_boost", "position_weight")]
         c = _FtConfig(cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg["min_rank"], cfg["merge_limit"],
-                      cfg["num_fields"], *[a.ctypes.data for a in keep])
+                      cfg["num_fields"], *[a.ctypes.data for a in keep], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")])
         return c, keep
 
     def _opts(self, opts):
@@ -682,6 +682,13 @@ class RefFt:
         fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
                                                                "position_boost", "position_weight")], axis=1).copy()
         self.L.ref_ft_set_config(self.h, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data)
+        bm25_type = cfg.get("bm25_type", "rx")
+        fn = getattr(self.L, "ref_ft_set_bm25_type", None)   # absent in a libref_ft.so built before the switch existed
+        if fn is not None:
+            fn.argtypes = [_vp, _i]
+            fn(self.h, {"rx": 0, "classic": 1, "word_count": 2}[bm25_type])
+        elif bm25_type != "rx":
+            raise RuntimeError("oracle/_ref/libref_ft.so predates the bm25Type switch: rebuild with `make -C oracle ref`")
 
     def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16):
         """terms: list of dict(op, opts (FtOracle.default_opts-like), subs=[(word_id, proc), ...])."""

@@ -98,6 +98,12 @@ void ref_ft_set_config(void* h, const double* cfgD, const int* cfgI, const doubl
 	}
 }
 
+// FTConfig::Bm25Config::bm25Type: 0 = rx, 1 = classic, 2 = wordCount (ftconfig.h:200-203)
+void ref_ft_set_bm25_type(void* h, int type) {
+	using T = FTConfig::Bm25Config::Bm25Type;
+	static_cast<FtRef*>(h)->cfg.bm25Config.bm25Type = type == 1 ? T::classic : type == 2 ? T::wordCount : T::rx;
+}
+
 // Query = nTerms terms.  Per term t: op (1 OR, 2 AND, 3 NOT), boost, termLenBoost, fieldBoost[nf], needSum[nf], and the sub-term
 // slice [subOff[t], subOff[t+1]) of (wordId, proc).  excluded: docsExcluded bitmap (bytes) or null.
 // rankSortType: 0 RankOnly, 1 RankAndID, 3 IDOnly, 4 IDAndPositions.  Returns the result count (<= cap written).
@@ -137,7 +143,15 @@ long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, c
 		RdxContext ctx;
 		ft::Merger<IdRelVec, ft::MergeData, uint32_t> merger(f->totalDocs, &f->cfg, st, f->nf, 0, /*inTransaction*/ true, ctx);
 		Stats stats{f->words.data(), f->nf, f->avg.data(), f->hasRemoved ? f->removed.data() : nullptr};
-		ft::MergeData md = merger.Merge<Bm25Rx>(q, RankSortType(rankSortType), stats);
+		auto run = [&]() -> ft::MergeData {   // the selecter's dispatch on bm25Type (selecterimpl.h:615-624)
+			switch (f->cfg.bm25Config.bm25Type) {
+				case FTConfig::Bm25Config::Bm25Type::classic: return merger.Merge<Bm25Classic>(q, RankSortType(rankSortType), stats);
+				case FTConfig::Bm25Config::Bm25Type::wordCount: return merger.Merge<TermCount>(q, RankSortType(rankSortType), stats);
+				case FTConfig::Bm25Config::Bm25Type::rx: break;
+			}
+			return merger.Merge<Bm25Rx>(q, RankSortType(rankSortType), stats);
+		};
+		ft::MergeData md = run();
 		for (size_t i = 0; i < md.size() && i < cap; ++i) {
 			outId[i] = md[i].id.ToNumber();
 			outProc[i] = md[i].proc;

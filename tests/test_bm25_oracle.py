@@ -335,3 +335,57 @@ def test_restated_multi_term_merge_equals_reference_golden(ft, case):
     gd, gp, gf, gn, _ = ft.merge_query(cfg, terms, total, words, avg, removed, excluded, sort_by_rank=False)
     assert np.array_equal(gd.astype(np.int32), z[f"merge{seed}_doc"]) and np.array_equal(gn, z[f"merge{seed}_norm"])
     assert np.array_equal(gf, z[f"merge{seed}_field"]) and np.array_equal(gp.view(np.uint32), z[f"merge{seed}_proc"].view(np.uint32))
+
+
+# ------------------------------------------------------------------------------------------- the other Bm25Calculator variants
+@pytest.mark.parametrize("bm25_type", ["classic", "word_count"])
+def test_restated_merges_with_bm25_classic_and_word_count_equal_real_merger(ft, bm25_type):
+    """FTConfig::Bm25Config::bm25Type = classic / wordCount (bm25.h:38-68, dispatch selecterimpl.h:615-624): the restatement against the real
+    Merger::Merge<Bm25Classic> / Merge<TermCount>, single-term (mergeSimple) and multi-term (mergeTerm + preselect).  The GPU merger evaluates
+    Bm25Rx only and refuses these types (GpuFtMerger::Supports) — this pins the checker for extending it."""
+    from oracle.pyoracle import ref_ft_or_none
+    nf = 3
+    real = ref_ft_or_none(nf)
+    if real is None:
+        pytest.skip("oracle/_ref/libref_ft.so not available")
+    if not hasattr(real.L, "ref_ft_set_bm25_type"):
+        pytest.skip("oracle/_ref/libref_ft.so predates the bm25Type switch")
+    rng = np.random.default_rng(7 if bm25_type == "classic" else 8)
+    total = 2500
+    words = rng.integers(1, 40, (total, nf)).astype(np.float32)
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    removed = np.zeros(total, np.uint8)
+    removed[rng.choice(total, 60, replace=False)] = 1
+    real.set_docs(words, avg, removed)
+    subs = []
+    for wid, proc in enumerate((100.0, 88.0, 61.5)):
+        s = make_postings(rng, total, nf, int(rng.integers(200, 900)))
+        s["proc"] = proc
+        subs.append(s)
+        real.set_word_flat(wid, s)
+    for limit in (20000, 150):
+        cfg = ft.default_config(nf, merge_limit=limit, bm25_type=bm25_type)
+        opts = ft.default_opts(nf, field_boost=[1.0, 0.7, 1.3], boost=1.2, term_len_boost=0.9)
+        real.set_config(cfg)
+        wd, wp, wf, wn = real.merge([dict(op=real.OP_OR, opts=opts, subs=[(i, s["proc"]) for i, s in enumerate(subs)])], None, rank_sort_type=1)
+        gd, gp, gf, gn = ft.merge_simple(cfg, opts, total, words, avg, removed, None, subs, sort_by_rank=False)
+        assert np.array_equal(gd.astype(np.int32), wd) and np.array_equal(gn, wn) and np.array_equal(gf, wf)
+        assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+    real.close()
+    # multi-term: two of the standing cases, re-run with the other calculator
+    for case in (MULTI_CASES[0], MULTI_CASES[3]):
+        seed, nf2, total2, limit, ops, arr, fbs = case
+        ref_ft, words, avg, removed, excluded, terms, store = _multi_case(seed, nf2, total2, limit, ops, arr, fbs)
+        real = ref_ft(nf2)
+        real.set_docs(words, avg, removed)
+        for s in store:
+            real.set_word_fpos(s["word"], s)
+        cfg = ft.default_config(nf2, merge_limit=limit, bm25_type=bm25_type)
+        real.set_config(cfg)
+        rterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+        wd, wp, wf, wn = real.merge(rterms, excluded, rank_sort_type=1)
+        gd, gp, gf, gn, _ = ft.merge_query(cfg, terms, total2, words, avg, removed, excluded, sort_by_rank=False)
+        assert np.array_equal(gd.astype(np.int32), wd), (bm25_type, seed)
+        assert np.array_equal(gn, wn) and np.array_equal(gf, wf) and np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+        real.close()
