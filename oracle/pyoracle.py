@@ -880,3 +880,80 @@ def oracle_hnsw_search_knn_sq8(orc: Oracle, g: dict, sq: dict, q, k: int, ef: in
                                   inv.ctypes.data if inv is not None else None, sq["min_q"], sq["alpha"], sq["alpha_2"], sq["delta"],
                                   q.ctypes.data, int(qnorm is not None), 0.0 if qnorm is None else qnorm, k, ef, od.ctypes.data, ol.ctypes.data)
     return od[:c].copy(), ol[:c].copy()
+
+
+# ---------------------------------------------------------------------------------------------------- the reference's IVF backend (FAISS)
+REF_IVF_SO = HERE / "_ref" / "libref_ivf.so"
+
+
+class RefIvf:
+    """The patched FAISS vendored in the reference, compiled in place (oracle/ref/ref_ivf_shim.cc), driven like IvfIndex drives it: a flat
+    index trained on and drained into an IndexIVFFlat.  Distances follow FAISS (L2 ascending, similarity descending)."""
+
+    def __init__(self, metric: int, dim: int, nlist: int, x, ids):
+        if not REF_IVF_SO.exists():
+            raise FileNotFoundError(REF_IVF_SO)
+        L = self.L = C.CDLL(str(REF_IVF_SO))
+        L.ref_ivf_build.restype = _vp
+        L.ref_ivf_build.argtypes = [_i, _sz, _sz, _sz, _vp, _vp]
+        L.ref_ivf_destroy.argtypes = [_vp]
+        L.ref_ivf_search.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+        L.ref_ivf_range.restype = C.c_long
+        L.ref_ivf_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
+        L.ref_ivf_export.argtypes = [_vp, _vp, _vp]
+        L.ref_ivf_list_ids.argtypes = [_vp, _sz, _vp]
+        L.ref_ivf_remove.restype = C.c_long
+        L.ref_ivf_remove.argtypes = [_vp, _vp, _sz]
+        L.ref_ivf_last_error.restype = C.c_char_p
+        x = _f32(x).reshape(-1, dim)
+        ids = np.ascontiguousarray(ids, np.int64)
+        self.metric, self.dim, self.nlist = metric, dim, nlist
+        self.h = L.ref_ivf_build(metric, dim, nlist, x.shape[0], x.ctypes.data, ids.ctypes.data)
+        if not self.h:
+            raise RuntimeError(L.ref_ivf_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ref_ivf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def search(self, q, k, nprobe):
+        q = _f32(q)
+        d, l = np.empty(k, np.float32), np.empty(k, np.int64)
+        if self.L.ref_ivf_search(self.h, q.ctypes.data, k, nprobe, d.ctypes.data, l.ctypes.data):
+            raise RuntimeError(self.L.ref_ivf_last_error().decode())
+        return d, l
+
+    def range_search(self, q, radius, nprobe, cap=1 << 16):
+        q = _f32(q)
+        while True:
+            d, l = np.empty(cap, np.float32), np.empty(cap, np.int64)
+            n = self.L.ref_ivf_range(self.h, q.ctypes.data, radius, nprobe, d.ctypes.data, l.ctypes.data, cap)
+            if n < 0:
+                raise RuntimeError(self.L.ref_ivf_last_error().decode())
+            if n <= cap:
+                return d[:n].copy(), l[:n].copy()
+            cap = int(n)
+
+    def export(self):
+        cent = np.zeros((self.nlist, self.dim), np.float32)
+        sizes = np.zeros(self.nlist, np.uint64)
+        self.L.ref_ivf_export(self.h, cent.ctypes.data, sizes.ctypes.data)
+        lists = []
+        for i in range(self.nlist):
+            ids = np.zeros(int(sizes[i]), np.int64)
+            if ids.size:
+                self.L.ref_ivf_list_ids(self.h, i, ids.ctypes.data)
+            lists.append(ids)
+        return cent, lists
+
+    def remove_ids(self, ids):
+        ids = np.ascontiguousarray(ids, np.int64)
+        return int(self.L.ref_ivf_remove(self.h, ids.ctypes.data, ids.shape[0]))
+
+
+def ref_ivf_available() -> bool:
+    return REF_IVF_SO.exists()

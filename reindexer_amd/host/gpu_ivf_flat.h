@@ -3,15 +3,21 @@
 // (ivf_index.h:62, ivf_index.cc:88-108) and faiss::IndexIVFFlat `map_` afterwards — train / add_with_ids / remove_ids / search / range_search
 // with faiss::IVFSearchParameters::nprobe (ivf_index.cc:355-372, 143-272, 469-487).
 //
-// FAISS itself is a patched vendored copy in the reference (cpp_src/vendor_subdirs/faiss, needs BLAS: not buildable here), so parity is
-// UNPINNED: this file restates the published algorithm as the reference configures it —
-//   Level1Quantizer::train_q1 / Clustering::train   k-means, niter = 10 (IndexIVF.cpp:48), <= 256 points per centroid (subsampled),
-//                                                   random initial centroids, spherical (unit centroids) for inner product / cosine
-//                                                   (IndexIVF.cpp:179-182), empty clusters split off the big ones with the +-1/1024 perturbation
-//   IndexIVF::add_with_ids                          vector -> list of its nearest centroid (cosine: on the normalised vector, IndexIVF.cpp:195-215)
-//   IndexIVF::search / range_search                 nprobe nearest lists by the coarse quantiser, exact scan of those lists
-// — and tests hold it to the definition (result == exact search over the probed lists, bit-exact in the engine's own distance arithmetic)
-// and to recall against the exact search.  Centroids differ from FAISS's (its RNG stream is not reproduced), as they do between FAISS builds.
+// FAISS is a patched copy vendored in the reference (cpp_src/vendor_subdirs/faiss; its fvec_L2sqr / fvec_inner_product call the reference's
+// own vector_dists functions).  Parity status:
+//   * SEARCH is pinned: the definition the tests hold this class to — the exact (dist,row)-ordered search, in the engine's distance arithmetic,
+//     over the rows of the nprobe nearest lists; cosine through the stored 1/|row| — returns the real FAISS's labels and distance bits for
+//     search / range_search / remove_ids given FAISS's trained state (tests/test_ivf_oracle.py; FAISS compiled in place into
+//     oracle/_ref/libref_ivf.so with a triple-loop sgemm standing in for BLAS).  tests/test_gpu_ivf.py checks the GPU index against that
+//     definition on its own centroids.
+//   * TRAINING is not pinned: this file restates the published algorithm as the reference configures it —
+//       Level1Quantizer::train_q1 / Clustering::train   k-means, niter = 10 (IndexIVF.cpp:48), <= 256 points per centroid (subsampled),
+//                                                       random initial centroids, spherical (unit centroids) for inner product / cosine
+//                                                       (IndexIVF.cpp:179-182), empty clusters split off the big ones with +-1/1024
+//       IndexIVF::add_with_ids                          vector -> list of its nearest centroid (cosine: on the normalised vector)
+//     — but FAISS's random stream is not reproduced, so the centroids differ (as they do between FAISS builds); recall against the exact
+//     search is what is asserted.  One deliberate simplification: the cosine coarse quantiser ranks unit centroids by inner product, where
+//     FAISS multiplies by the stored 1/|centroid| (identical up to the rounding of the normalisation).
 //
 // MI355X mapping: both halves are the brute-force engine.  The coarse quantiser is a KNN over the nlist centroids (training assigns 256
 // points per call: the matrix-core batch path); the list scan is knn_scan_subset / knn_range_subset over the row list of the probed

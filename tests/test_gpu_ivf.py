@@ -1,8 +1,8 @@
 """-m gpu: GpuIvfFlat and the range scan over a row list.
-FAISS (the reference's IVF backend, a patched vendored copy that needs BLAS) cannot be built here, so parity is UNPINNED; the tests hold the
-index to the DEFINITION of IVF-Flat in the engine's own arithmetic — the result of a query is the exact search over the rows of the nprobe
-nearest lists, distances bit-identical to the brute-force oracle — and to recall against the exact search, which is what the reference's own
-IVF tests assert (gtests/tests/unit/float_vector_index.cc compares IVF results with brute force by recall)."""
+The index is held to the DEFINITION of IVF-Flat in the engine's own arithmetic — the result of a query is the exact (dist,row)-ordered search
+over the rows of the nprobe nearest lists, distances bit-identical to the brute-force oracle — and to recall against the exact search (what the
+reference's own IVF tests assert).  That definition itself is pinned bit for bit against the reference's vendored FAISS, given FAISS's trained
+state, in tests/test_ivf_oracle.py (CPU); training is not pinned (FAISS's random stream is not reproduced)."""
 import numpy as np
 import pytest
 
