@@ -36,6 +36,8 @@ struct rxgpu_index;
 
 namespace rxgpu::host {
 
+// Threading: Search / RangeSearch / ProbedRows are const and may run concurrently (every call checks out its own device scratch); Train,
+// AddWithIds, RemoveIds and Reset need exclusive access — the reference serialises them the same way under the namespace lock.
 class GpuIvfFlat {
 public:
 	using idx_t = int64_t;   // faiss::idx_t
