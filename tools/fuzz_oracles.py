@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Randomised differential runs of the CPU checkers against the REAL reference code compiled in place (oracle/_ref) — no GPU involved.
+
+    RX_TARGET_INSTRUCTIONS=avx512 python tools/fuzz_oracles.py --seconds 60 [--only sq8_dist,sq8_quantize,sq8_hnsw,ivf,bm25,builder]
+
+  sq8_dist      oracle_sq8.c uint8 L2 / IP            vs vector_dists::L2SqrDistance<uint8_t> / InnerProductDistance<uint8_t>
+  sq8_quantize  Quantizer::quantize + DistCalculator   vs the reference's Quantizer / DistCalculator<uint8_t>
+  sq8_hnsw      SearchKnn over an SQ8 graph            vs HierarchicalNSWImpl<uint8_t> built from a float graph like Quantize() does
+  ivf           the IVF search definition              vs the reference's vendored FAISS (IndexIVFFlat), given its trained state
+  bm25          the merger restatement (3 calculators) vs ft::Merger::Merge<Bm25Rx / Bm25Classic / TermCount>
+  builder       the PRODUCT's host HNSW builder        vs the real engine's graph, link for link (sequential and one-thread concurrent path)
+Needs /root/reference (to build oracle/_ref) and an AVX-512 host."""
+import argparse
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
+
+from oracle.pyoracle import (FtOracle, Oracle, Ref, RefHnsw, RefHnswQ, RefIvf, Sq8Oracle, Sq8Ref, oracle_hnsw_search_knn_sq8)  # noqa: E402
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def lex_topk(d, k):
+    order = np.lexsort((np.arange(d.shape[0]), d))[:k]
+    return d[order], order
+
+
+def fuzz_sq8_dist(orc, ref, rng, seconds):
+    so, sr = Sq8Oracle(orc), Sq8Ref(ref)
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        d = int(rng.integers(1, 2049))
+        style = rng.integers(0, 3)
+        if style == 0:
+            a, b = rng.integers(0, 256, d), rng.integers(0, 256, d)
+        elif style == 1:
+            a, b = rng.choice([0, 255], d), rng.choice([0, 1, 254, 255], d)
+        else:
+            c = int(rng.integers(0, 200))
+            a, b = rng.integers(c, c + 56, d), rng.integers(c, c + 56, d)
+        a, b = a.astype(np.uint8), b.astype(np.uint8)
+        bad += int(bits(so.l2sqr_u8(a, b)) != bits(sr.l2sqr_u8(a, b)) or bits(so.ip_u8(a, b)) != bits(sr.ip_u8(a, b)))
+        n += 1
+    return n, bad
+
+
+def fuzz_sq8_quantize(orc, ref, rng, seconds):
+    so, sr = Sq8Oracle(orc), Sq8Ref(ref)
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        metric, d = int(rng.integers(0, 3)), int(rng.integers(1, 1100))
+        v = rng.normal(0, rng.choice([0.01, 0.25, 3.0]), (6, d)).astype(np.float32)
+        lo, hi = sorted(rng.normal(0, 0.5, 2).tolist())
+        hi = max(hi, lo + 0.1)
+        p, pr = so.params(lo, hi, d), sr.params(lo, hi, d)
+        bad += int(any(bits(p[k]) != bits(pr[k]) for k in ("alpha", "alpha_2", "delta")))
+        codes = []
+        for x in v:
+            sc = float(rng.choice([1.0, 0.37, 2.5]))
+            c, o = so.quantize(metric, p, x, sc)
+            rc, ro = sr.quantize(metric, p, x, sc)
+            bad += int(not np.array_equal(c, rc) or bits(o) != bits(ro))
+            codes.append(so.quantize(metric, p, x))
+            n += 1
+        for i in range(5):
+            (a, ca), (b, cb) = codes[i], codes[i + 1]
+            bad += int(bits(so.dist_pair(metric, p, a, ca, v[i], b, cb, v[i + 1], orc)) != bits(sr.dist_pair(metric, p, a, ca, v[i], b, cb, v[i + 1])))
+            bad += int(bits(so.dist_query(metric, p, a, ca, b, cb, v[i + 1], orc)) != bits(sr.dist_query(metric, p, a, ca, b, cb, v[i + 1])))
+    return n, bad
+
+
+def fuzz_sq8_hnsw(orc, ref, rng, seconds):
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        metric, d, cnt, M = int(rng.integers(0, 3)), int(rng.choice([8, 33, 64, 100, 128])), int(rng.integers(300, 2500)), int(rng.choice([4, 8, 16]))
+        rows = rng.normal(0, 0.25, (cnt, d)).astype(np.float32)
+        labels = (rng.permutation(cnt).astype(np.uint64) << np.uint64(32)) | np.uint64(1)
+        h = RefHnsw(ref, metric, d, cnt, M=M, ef_construction=int(rng.choice([20, 100])))
+        h.add(rows, labels)
+        for lab in labels[rng.choice(cnt, int(rng.integers(0, cnt // 10 + 1)), replace=False)]:
+            h.mark_delete(lab)
+        g = h.export(with_vectors=False)
+        hq = RefHnswQ(h, sample_size=int(rng.choice([200, 1000, 20000])), quantile=float(rng.choice([0.0, 0.97, 1.0])))
+        sq = hq.export()
+        inv = orc.l2_modules(rows) if metric == 2 else None
+        for _ in range(20):
+            q = (rows[rng.integers(0, cnt)] + rng.normal(0, 0.1, d)).astype(np.float32)
+            norm = None
+            if metric == 2:
+                q, k_ = orc.normalize_copy(q)
+                norm = float(np.float32(1.0) / np.float32(k_))
+            k, ef = int(rng.choice([1, 5, 10, 64])), int(rng.choice([0, 8, 40, 200]))
+            wd, wl = hq.search_knn(q, k, ef, norm)
+            gd, gl = oracle_hnsw_search_knn_sq8(orc, g, sq, q, k, ef, inv, norm)
+            bad += int(not (np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd))))
+            n += 1
+        hq.close()
+        h.close()
+    return n, bad
+
+
+def fuzz_ivf(orc, ref, rng, seconds):
+    sys.path.insert(0, str(ROOT / "tests"))
+    from tests.test_ivf_oracle import restated_ivf
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        metric, d, nlist = int(rng.integers(0, 3)), int(rng.choice([5, 16, 33, 64, 100, 128, 130])), int(rng.choice([4, 8, 16, 40]))
+        cnt = int(rng.integers(nlist * 40, nlist * 40 + 4000))
+        cent = rng.normal(0, 0.25, (max(2, nlist // 2), d)).astype(np.float32)
+        rows = (cent[rng.integers(0, cent.shape[0], cnt)] + rng.normal(0, 0.06, (cnt, d))).astype(np.float32)
+        ids = rng.permutation(cnt * 3)[:cnt].astype(np.int64)
+        f = RefIvf(metric, d, nlist, rows, ids)
+        c, lists = f.export()
+        row_of = {int(l): i for i, l in enumerate(ids)}
+        lr = [np.array([row_of[int(x)] for x in l], np.int64) for l in lists]
+        inv = orc.l2_modules(rows) if metric == 2 else None
+        sign = 1.0 if metric == 0 else -1.0
+        for _ in range(6):
+            q = (rows[rng.integers(0, cnt)] + rng.normal(0, 0.05, d)).astype(np.float32)
+            if metric == 2:
+                q, _ = orc.normalize_copy(q)
+            nprobe, k = int(rng.integers(1, nlist + 1)), int(rng.choice([1, 7, 40, 200]))
+            dist, cand = restated_ivf(orc, metric, q, c, lr, rows, inv, nprobe)
+            fd, fl = f.search(q, k, nprobe)
+            m = min(k, cand.size)
+            wd, wpos = lex_topk(dist, m)
+            got, want = np.lexsort((fl[:m], fd[:m] * sign)), np.lexsort((ids[cand[wpos]], wd))
+            ok = np.array_equal(fl[:m][got], ids[cand[wpos]][want]) and np.array_equal(bits((fd[:m] * sign)[got]), bits(wd[want])) and np.all(fl[m:] == -1)
+            bad += int(not ok)
+            n += 1
+        f.close()
+    return n, bad
+
+
+def fuzz_bm25(orc, ref, rng, seconds):
+    from tests.test_bm25_oracle import _multi_case
+    ft = FtOracle(orc)
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        seed, nf, total = int(rng.integers(10_000, 1_000_000)), int(rng.integers(1, 5)), int(rng.choice([1500, 4000]))
+        limit, nterms = int(rng.choice([20000, 20000, 90, 400])), int(rng.integers(2, 5))
+        ops = [int(rng.choice([1, 1, 2, 3])) for _ in range(nterms)]
+        if all(o == 3 for o in ops):
+            ops[0] = 1
+        bt = str(rng.choice(["rx", "classic", "word_count"]))
+        ref_ft, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, bool(rng.integers(0, 2)), None)
+        real = ref_ft(nf)
+        if real is None:
+            raise SystemExit("oracle/_ref/libref_ft.so not available")
+        real.set_docs(words, avg, removed)
+        for s in store:
+            real.set_word_fpos(s["word"], s)
+        cfg = ft.default_config(nf, merge_limit=limit, bm25_type=bt, min_rank=int(rng.choice([5, 0, 40])))
+        db, dw = float(rng.choice([1.0, 1.7, 0.0])), float(rng.choice([0.5, 0.8, 1.0]))
+        real.set_config(cfg, distance_boost=db, distance_weight=dw)
+        rterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+        exc = excluded if rng.integers(0, 2) else None
+        wd, wp, wf, wn = real.merge(rterms, exc, rank_sort_type=1)
+        gd, gp, gf, gn, _ = ft.merge_query(cfg, terms, total, words, avg, removed, exc, sort_by_rank=False, distance_boost=db, distance_weight=dw)
+        bad += int(not (np.array_equal(gd.astype(np.int32), wd) and np.array_equal(gn, wn) and np.array_equal(gf, wf) and np.array_equal(bits(gp), bits(wp))))
+        n += 1
+        real.close()
+    return n, bad
+
+
+def fuzz_builder(orc, ref, rng, seconds):
+    os.environ.setdefault("RXGPU_NO_TORCH", "1")
+    from reindexer_amd import hostapi
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        metric, d, cnt = int(rng.integers(0, 3)), int(rng.choice([3, 16, 33, 64, 100, 130])), int(rng.integers(50, 2500))
+        M, efc = int(rng.choice([2, 4, 8, 16, 24])), int(rng.choice([10, 40, 200]))
+        style = rng.integers(0, 3)
+        if style == 0:
+            rows = rng.normal(0, 0.25, (cnt, d)).astype(np.float32)
+        elif style == 1:
+            rows = rng.integers(-2, 3, (cnt, d)).astype(np.float32)
+        else:
+            base = rng.normal(0, 1, (max(1, cnt // 30), d)).astype(np.float32)
+            rows = base[rng.integers(0, base.shape[0], cnt)].copy()
+        rows[np.all(rows == 0, axis=1)] = 1.0
+        labels = (rng.permutation(cnt).astype(np.uint64) << np.uint64(32)) | np.uint64(rng.integers(0, 3))
+        r = RefHnsw(ref, metric, d, cnt, M=M, ef_construction=efc)
+        g = hostapi.HnswGraph(metric, d, cnt, M=M, ef_construction=efc)
+        r.add(rows, labels)
+        g.add(rows, labels, threads=int(rng.choice([0, 1])))   # 1: the concurrent code path driven from one thread
+        for lab in labels[rng.choice(cnt, int(rng.integers(0, cnt // 8 + 1)), replace=False)]:
+            r.mark_delete(lab)
+            g.mark_delete(lab)
+        a, b = r.export(with_vectors=False), g.export()
+        ok = all(a[k] == b[k] for k in ("n", "M", "maxM0", "maxlevel", "entry", "num_deleted"))
+        ok = ok and all(np.array_equal(a[k], b[k]) for k in ("levels", "labels", "deleted", "links0", "upper_off"))
+        blocks = int(a["upper_off"][-1])
+        bad += int(not (ok and np.array_equal(a["upper"][:blocks], b["upper"][:blocks])))
+        n += 1
+        r.close()
+        g.close()
+    return n, bad
+
+
+FUZZERS = {"sq8_dist": fuzz_sq8_dist, "sq8_quantize": fuzz_sq8_quantize, "sq8_hnsw": fuzz_sq8_hnsw, "ivf": fuzz_ivf, "bm25": fuzz_bm25,
+           "builder": fuzz_builder}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=30, help="per fuzzer")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--only", default=",".join(FUZZERS))
+    args = ap.parse_args()
+    orc, ref = Oracle(), Ref()
+    if ref.simd_level != 3:
+        raise SystemExit("the host lacks AVX-512: the reference dispatches to a different summation order")
+    failed = False
+    for name in args.only.split(","):
+        n, bad = FUZZERS[name](orc, ref, np.random.default_rng(args.seed), args.seconds)
+        print(f"{name}: {n} cases, {bad} mismatches", flush=True)
+        failed |= bad != 0
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()
