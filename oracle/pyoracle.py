@@ -197,6 +197,15 @@ class Ref:
         L.ref_hnsw_export_level0.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
         L.ref_hnsw_export_upper.restype = _sz
         L.ref_hnsw_export_upper.argtypes = [_vp, _vp, _vp]
+        if hasattr(L, "ref_bf_search_knn_mt"):   # timed multi-thread baselines + graph import (bench.py legs)
+            L.ref_bf_search_knn_mt.restype = C.c_double
+            L.ref_bf_search_knn_mt.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _sz, C.c_double, _vp, _vp]
+            L.ref_hnsw_search_knn_mt.restype = C.c_double
+            L.ref_hnsw_search_knn_mt.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _sz, C.c_double, _vp, _vp]
+            L.ref_hnsw_search_knn_many.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, _vp, _vp, _vp]
+            L.ref_hnsw_import_graph.restype = _i
+            L.ref_hnsw_import_graph.argtypes = [_vp, _sz, _i, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
+            L.ref_last_error.restype = C.c_char_p
 
     @property
     def simd_level(self) -> int:
@@ -261,6 +270,15 @@ class RefBruteforce:
         assert c <= cap
         return od[:c].copy(), ol[:c].copy()
 
+    def search_knn_mt(self, queries, k, threads, per_thread, deadline_s=0.0):
+        """T threads x per_thread searches over the shared index, clock from the common start flag to the last finish (threads are
+        created before the clock starts).  Returns (seconds, searches completed)."""
+        queries = _f32(queries).reshape(-1, self.dim)
+        done, chk = C.c_size_t(0), C.c_uint64(0)
+        s = self.ref.L.ref_bf_search_knn_mt(self.h, queries.ctypes.data, queries.shape[0], self.dim, k, threads, per_thread, float(deadline_s),
+                                            C.byref(done), C.byref(chk))
+        return float(s), int(done.value)
+
 
 def ref_or_none() -> Ref | None:
     try:
@@ -313,6 +331,38 @@ class RefHnsw:
     def stream(self, q, ef=0):
         """BeginStreamingSearch: returns a session object with .next(batch) -> (dist, label, exhausted) and .close()."""
         return _RefStream(self, _f32(q), ef)
+
+    def search_knn_many(self, queries, k, ef=0):
+        queries = _f32(queries).reshape(-1, self.dim)
+        nq = queries.shape[0]
+        od, ol, cnt = np.zeros((nq, k), np.float32), np.zeros((nq, k), np.uint64), np.zeros(nq, np.uint32)
+        self.ref.L.ref_hnsw_search_knn_many(self.h, queries.ctypes.data, nq, self.dim, k, ef, od.ctypes.data, ol.ctypes.data, cnt.ctypes.data)
+        return od, ol, cnt
+
+    def search_knn_mt(self, queries, k, ef, threads, per_thread, deadline_s=0.0):
+        """Timed like RefBruteforce.search_knn_mt.  Returns (seconds, searches completed)."""
+        queries = _f32(queries).reshape(-1, self.dim)
+        done, chk = C.c_size_t(0), C.c_uint64(0)
+        s = self.ref.L.ref_hnsw_search_knn_mt(self.h, queries.ctypes.data, queries.shape[0], self.dim, k, ef, threads, per_thread,
+                                              float(deadline_s), C.byref(done), C.byref(chk))
+        return float(s), int(done.value)
+
+    def import_graph(self, g: dict, vectors=None):
+        """Writes a flat graph (the export() layout; e.g. one built by the product's HnswGraph) INTO this (empty) engine, so that the
+        reference's own SearchKnn runs on it."""
+        vec = _f32(g["vectors"] if vectors is None else vectors)
+        n = int(g["n"])
+        links0 = np.ascontiguousarray(g["links0"], np.uint32)
+        levels = np.ascontiguousarray(g["levels"], np.int32)
+        labels = np.ascontiguousarray(g["labels"], np.uint64)
+        deleted = np.ascontiguousarray(g["deleted"], np.uint8)
+        upper_off = np.ascontiguousarray(g["upper_off"], np.uint64)
+        upper = np.ascontiguousarray(g["upper"], np.uint32)
+        assert links0.shape[0] >= n and vec.shape[0] >= n
+        rc = self.ref.L.ref_hnsw_import_graph(self.h, n, int(g["maxlevel"]), int(g["entry"]) & 0xFFFFFFFF, links0.ctypes.data, levels.ctypes.data,
+                                              labels.ctypes.data, deleted.ctypes.data, vec.ctypes.data, upper_off.ctypes.data, upper.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(self.ref.L.ref_last_error().decode())
 
     def export(self, with_vectors=True) -> dict:
         """Flat graph in the layout shared by the oracle restatement and the GPU engine."""
@@ -957,3 +1007,57 @@ class RefIvf:
 
 def ref_ivf_available() -> bool:
     return REF_IVF_SO.exists()
+
+
+# ------------------------------------------------------------------------------------------------ the REAL hybrid rank fusion (_ref)
+REF_RANK_SO = HERE / "_ref" / "libref_rank.so"
+
+
+class RefRank:
+    """SelectIteratorContainer::MergerRankedImpl + the drain of mergeRanked + RanksHolder::InitRRFPositions of the reference
+    (oracle/ref/ref_rank_shim.cc: selectiteratorcontainer.cc compiled in place)."""
+
+    def __init__(self):
+        if not REF_RANK_SO.exists():
+            raise FileNotFoundError(REF_RANK_SO)
+        L = self.L = C.CDLL(str(REF_RANK_SO))
+        L.ref_rank_uses_pmr.restype = _i
+        L.ref_rank_init_rrf_positions.argtypes = [_vp, _sz, _vp]
+        L.ref_rank_merge_rrf.restype = C.c_long
+        L.ref_rank_merge_rrf.argtypes = [C.c_double, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _sz]
+        L.ref_rank_merge_linear.restype = C.c_long
+        L.ref_rank_merge_linear.argtypes = [C.c_double] * 5 + [_i, _i, _i, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz]
+
+    @property
+    def uses_pmr(self) -> bool:
+        return bool(self.L.ref_rank_uses_pmr())
+
+    def rrf_positions(self, ranks_ft_order):
+        r = _f32(ranks_ft_order)
+        out = np.zeros(r.shape[0], np.uint64)
+        self.L.ref_rank_init_rrf_positions(r.ctypes.data, r.shape[0], out.ctypes.data)
+        return out
+
+    def merge(self, kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=False, desc=True, metric=1, ft_positions=None):
+        """ft_ids ascending with ft_ranks (and, for RRF, ft_positions) aligned — the selector's view (selectiteratorcontainer.cc:1494)."""
+        ki, kr = np.ascontiguousarray(knn_ids, np.int32), _f32(knn_ranks)
+        fi, fr = np.ascontiguousarray(ft_ids, np.int32), _f32(ft_ranks)
+        cap = ki.shape[0] + fi.shape[0] + 1
+        oi, orr = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        if kind == "rrf":
+            fp = np.ascontiguousarray(ft_positions, np.uint64)
+            assert fp.shape[0] == fi.shape[0]
+            n = self.L.ref_rank_merge_rrf(float(params[0]), int(union), int(desc), metric, ki.ctypes.data, kr.ctypes.data, ki.shape[0],
+                                          fi.ctypes.data, fr.ctypes.data, fp.ctypes.data, fi.shape[0], oi.ctypes.data, orr.ctypes.data, cap)
+        else:
+            n = self.L.ref_rank_merge_linear(*[float(x) for x in params], int(union), int(desc), metric, ki.ctypes.data, kr.ctypes.data,
+                                             ki.shape[0], fi.ctypes.data, fr.ctypes.data, fi.shape[0], oi.ctypes.data, orr.ctypes.data, cap)
+        assert 0 <= n <= cap
+        return oi[:n].copy(), orr[:n].copy()
+
+
+def ref_rank_or_none():
+    try:
+        return RefRank()
+    except (FileNotFoundError, OSError):
+        return None

@@ -12,6 +12,8 @@
 //     (constructed exactly like HierarchicalNSW<>::Impl::Impl, hnsw.cc:74-78: seed 100, ReplaceDeleted_True)
 // The same usage pattern as the reference's own engine-level test
 // gtests/tests/unit/hnsw_streaming_search_test.cc:22-25,38,53,161-162.
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -19,6 +21,7 @@
 #include <ranges>
 #include <span>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "core/index/float_vector/hnswlib/bruteforce.h"
@@ -52,6 +55,38 @@ size_t drain(hnswlib::SearchResultQueue& q, float* outDist, uint64_t* outLabel, 
 		}
 	}
 	return n;
+}
+template <typename SearchFn>
+static double timedThreads(size_t threads, size_t perThread, double deadlineSec, size_t* done, SearchFn&& fn) {
+	std::atomic<int> go{0};
+	std::atomic<size_t> ready{0}, total{0};
+	std::vector<std::thread> pool;
+	std::vector<double> finish(threads, 0.0);
+	using clk = std::chrono::steady_clock;
+	clk::time_point t0;
+	pool.reserve(threads);
+	for (size_t t = 0; t < threads; ++t) {
+		pool.emplace_back([&, t] {
+			ready.fetch_add(1);
+			while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+			size_t n = 0;
+			for (size_t j = 0; j < perThread; ++j) {
+				fn(t, j);
+				++n;
+				if (deadlineSec > 0 && std::chrono::duration<double>(clk::now() - t0).count() > deadlineSec) break;
+			}
+			finish[t] = std::chrono::duration<double>(clk::now() - t0).count();
+			total.fetch_add(n);
+		});
+	}
+	while (ready.load() < threads) std::this_thread::yield();
+	t0 = clk::now();
+	go.store(1, std::memory_order_release);
+	for (auto& th : pool) th.join();
+	double last = 0;
+	for (double f : finish) last = std::max(last, f);
+	*done = total.load();
+	return last;
 }
 }  // namespace
 
@@ -239,6 +274,102 @@ size_t ref_hnsw_export_upper(void* h, uint64_t* upperOff, uint32_t* upper) {
 	}
 	if (upperOff) upperOff[n] = blocks;
 	return blocks;
+}
+
+// ---------------------------------------------------------------- timed multi-thread baselines (bench.py cpu_baseline legs)
+// The reference's concurrency model: T planner threads, each with its own query over the shared index
+// (gtests/tests/unit/float_vector_index.cc:258-294).  Threads are created first and parked on a flag; the clock runs from
+// the release of that flag to the last thread's finish, so thread start-up is outside the timed region.  Thread t runs
+// queries (t * perThread + j) % nq, j = 0..perThread-1.  Results of the first `nq` (thread, j) slots are not returned: the
+// parity check uses the single-thread entry points; a checksum keeps the searches from being elided.
+// returns seconds; *done = searches completed (threads * perThread unless the deadline cut the run short)
+double ref_bf_search_knn_mt(void* h, const float* queries, size_t nq, size_t dim, size_t k, size_t threads, size_t perThread, double deadlineSec,
+							size_t* done, uint64_t* checksum) {
+	auto* bf = static_cast<const hnswlib::BruteforceSearch*>(h);
+	std::atomic<uint64_t> sum{0};
+	const double s = timedThreads(threads, perThread, deadlineSec, done, [&](size_t t, size_t j) {
+		auto res = bf->SearchKnn(queries + ((t * perThread + j) % nq) * dim, std::nullopt, k, 0);
+		uint64_t x = 0;
+		for (; !res.empty(); res.pop()) x += res.top().second;
+		sum.fetch_add(x, std::memory_order_relaxed);
+	});
+	*checksum = sum.load();
+	return s;
+}
+double ref_hnsw_search_knn_mt(void* h, const float* queries, size_t nq, size_t dim, size_t k, size_t ef, size_t threads, size_t perThread,
+							  double deadlineSec, size_t* done, uint64_t* checksum) {
+	auto* g = static_cast<const HnswT*>(h);
+	std::atomic<uint64_t> sum{0};
+	const double s = timedThreads(threads, perThread, deadlineSec, done, [&](size_t t, size_t j) {
+		auto res = g->SearchKnn(queries + ((t * perThread + j) % nq) * dim, std::nullopt, k, ef);
+		uint64_t x = 0;
+		for (; !res.empty(); res.pop()) x += res.top().second;
+		sum.fetch_add(x, std::memory_order_relaxed);
+	});
+	*checksum = sum.load();
+	return s;
+}
+// many queries, one thread, results returned ([nq][k], best first; cnt[i] = hits of query i)
+void ref_hnsw_search_knn_many(void* h, const float* queries, size_t nq, size_t dim, size_t k, size_t ef, float* outDist, uint64_t* outLabel,
+							  uint32_t* cnt) {
+	auto* g = static_cast<const HnswT*>(h);
+	for (size_t i = 0; i < nq; ++i) {
+		auto res = g->SearchKnn(queries + i * dim, std::nullopt, k, ef);
+		cnt[i] = uint32_t(drain(res, outDist + i * k, outLabel + i * k, k));
+	}
+}
+
+// Graph import: the flat export format of ref_hnsw_export_level0 / _upper written INTO the real engine, so that the reference's own
+// SearchKnn can be timed and compared on a graph somebody else built (the product's concurrent builder; a 10M-node graph takes the
+// reference's single-threaded AddPoint hours).  Fills exactly what HierarchicalNSWImpl(IReader&, ...) fills (hnswalg.h:290-410):
+// level-0 blocks [size word | maxM0 ids | vector | label | hash], the delete mark (markDeletedInternal :1323-1332), the stored norms
+// (DistCalculator::AddNorm), then initTree (:1265-1281) for label_lookup_ / deleted_elements / element_levels_ / linkLists_.
+int ref_hnsw_import_graph(void* h, size_t n, int maxlevel, uint32_t entry, const uint32_t* links0, const int32_t* levels, const uint64_t* labels,
+						  const uint8_t* deleted, const float* vectors, const uint64_t* upperOff, const uint32_t* upper) {
+	try {
+		auto* g = static_cast<HnswT*>(h);
+		if (g->cur_element_count.load() != 0) throw std::runtime_error("import into a non-empty graph");
+		if (n > g->max_elements_) throw std::runtime_error("import: graph larger than max_elements");
+		const size_t stride = 1 + g->maxM0_, ustride = 1 + g->M_, dim = g->fstdistfunc_.Dim();
+		for (size_t i = 0; i < n; ++i) {
+			auto* ll = g->get_linklist0(hnswlib::tableint(i));
+			std::memset(ll, 0, g->offsetData_);
+			const uint32_t cnt = links0[i * stride];
+			if (cnt > g->maxM0_) throw std::runtime_error("import: level-0 list longer than maxM0");
+			g->setListCount(ll, cnt);
+			std::memcpy(reinterpret_cast<char*>(ll) + sizeof(hnswlib::linklistsizeint), links0 + i * stride + 1, cnt * sizeof(uint32_t));
+			if (deleted[i]) *(reinterpret_cast<unsigned char*>(ll) + 2) |= HnswT::DELETE_MARK;
+			float* dst = g->getDataByInternalId(hnswlib::tableint(i));
+			std::memcpy(dst, vectors + i * dim, dim * sizeof(float));
+			g->fstdistfunc_.AddNorm(dst, i);
+			g->setExternalLabel(hnswlib::tableint(i), labels[i]);
+			g->setHashByInternalId(hnswlib::tableint(i), deleted[i] ? HnswT::emptyVectorHash() : g->CalcHash(dst));
+		}
+		g->cur_element_count.store(n);
+		g->maxlevel_ = maxlevel;
+		g->enterpoint_node_ = entry;
+		g->initTree([&](size_t i) -> size_t {
+			const size_t bytes = size_t(levels[i]) * g->size_links_per_element_;
+			if (!bytes) {
+				g->linkLists_[i] = nullptr;
+				return 0;
+			}
+			g->linkLists_[i] = static_cast<char*>(malloc(bytes));
+			if (!g->linkLists_[i]) throw std::runtime_error("import: out of memory");
+			std::memset(g->linkLists_[i], 0, bytes);
+			for (int l = 1; l <= levels[i]; ++l) {
+				auto* ul = g->get_linklist(hnswlib::tableint(i), l);
+				const uint32_t* src = upper + (upperOff[i] + size_t(l - 1)) * ustride;
+				g->setListCount(ul, src[0]);
+				std::memcpy(reinterpret_cast<char*>(ul) + sizeof(hnswlib::linklistsizeint), src + 1, size_t(src[0]) * sizeof(uint32_t));
+			}
+			return bytes;
+		});
+		return 0;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------------- SQ8 (uint8) distance path

@@ -10,6 +10,7 @@
 
 #include "distance_cpu.h"
 #include "gpu_bruteforce_map.h"   // CalculateL2Module
+#include "numa_policy.h"
 
 namespace rxgpu::host {
 
@@ -51,6 +52,7 @@ HnswGraph::HnswGraph(VectorMetric metric, size_t dim, size_t maxElements, size_t
 	  mult_(1.0 / std::log(1.0 * double(M_))) {
 	if (dim_ == 0) throw std::logic_error("HnswGraph: zero dimension");
 	try {
+		ScopedInterleave pages(maxElements_ * dim_ * sizeof(float));   // rows + link lists spread over every socket's DRAM (numa_policy.h)
 		vectors_.resize(maxElements_ * dim_);
 		if (metric_ == VectorMetric::Cosine) invNorms_.resize(maxElements_);
 		links0_.assign(maxElements_ * (1 + maxM0_), 0u);
@@ -97,6 +99,7 @@ HnswGraph::HnswGraph(const HnswGraph& o, size_t newMaxElements)
 void HnswGraph::Resize(size_t newMaxElements) {
 	if (newMaxElements < count_) throw std::runtime_error("Cannot resize, max element is less than the current number of elements");
 	try {
+		ScopedInterleave pages(newMaxElements * dim_ * sizeof(float));
 		vectors_.resize(newMaxElements * dim_);
 		if (metric_ == VectorMetric::Cosine) invNorms_.resize(newMaxElements);
 		links0_.resize(newMaxElements * (1 + maxM0_), 0u);

@@ -162,6 +162,9 @@ int rxhost_graph_add_many_mt(void* h, const float* vecs, size_t n, size_t dim, c
 		}
 	});
 }
+// borrowed views of the builder's own storage, in internal-id order (valid until the next insert that resizes / the graph's destruction)
+const float* rxhost_graph_vectors(void* h) { return static_cast<HnswGraph*>(h)->Vectors(); }
+const float* rxhost_graph_inv_norms(void* h) { return static_cast<HnswGraph*>(h)->InvNorms(); }
 int rxhost_graph_mark_delete(void* h, uint64_t label) {
 	return guarded([&] { static_cast<HnswGraph*>(h)->MarkDelete(label); });
 }

@@ -10,7 +10,6 @@
 #include <algorithm>
 #include <cstring>
 #include <cstdint>
-#include <unordered_set>
 #include <vector>
 
 #include "rx_types.h"
@@ -104,30 +103,42 @@ inline void RadixSortPairs(std::vector<K>& keys, std::vector<uint32_t>& vals) {
 		vals.swap(vals2);
 	}
 }
-// IdRank<desc>::operator< (selectiteratorcontainer.cc:1260-1281): by rank (descending when desc), ties by ascending id.
+// IdRank<desc>::operator< (selectiteratorcontainer.cc:1258-1278): desc == false: rank ascending, ties by ASCENDING id; desc == true (the
+// normal RRF / rank() ordering): rank descending, ties by DESCENDING id.  The container mirrored is the default (gcc) build's
+// Merged<desc> = std::pmr::set<IdRank<desc>> (tools/use_pmr.h, selectiteratorcontainer.cc:1280-1283): its key is the (rank, id) PAIR, so a
+// row id that reaches the merger twice (two vectors of one array row in the KNN list) stays twice unless both ranks are equal too.
 // merged[0, tailStart) are the (few) entries that came through the KNN list, in no particular order; merged[tailStart, n) is the FT-only
-// tail, which is already in ascending id order — a STABLE sort of the tail by rank alone therefore yields its final order (32-bit radix keys,
-// order-preserving image of the float), the head is sorted by comparison, and one linear merge by (rank key, id) finishes.
+// tail in ascending id order, disjoint from the head (an FT id that is in the KNN list is marked in ftAdded).  A STABLE sort of the tail
+// by rank alone — fed in reverse for desc, so equal ranks come out in descending id order — yields its final order (32-bit radix keys,
+// order-preserving image of the float); the head is sorted by comparison and stripped of exact (rank, id) repeats; one linear merge by
+// (rank key, id) finishes.
 inline void Finish(std::vector<IdRank>& merged, size_t tailStart, bool desc, HybridResult& out) {
 	const size_t n = merged.size();
 	auto rankKey = [desc](float r) noexcept {
 		const uint32_t u = SortableBits(r);
 		return desc ? ~u : u;
 	};
-	std::vector<uint32_t> tkey(n - tailStart), tidx(n - tailStart);
-	for (size_t i = tailStart; i < n; ++i) {
-		tkey[i - tailStart] = rankKey(merged[i].rank);
-		tidx[i - tailStart] = uint32_t(i);
+	auto idBefore = [desc](int32_t l, int32_t r) noexcept { return desc ? l > r : l < r; };
+	const size_t nTail = n - tailStart;
+	std::vector<uint32_t> tkey(nTail), tidx(nTail);
+	for (size_t j = 0; j < nTail; ++j) {
+		const size_t i = desc ? n - 1 - j : tailStart + j;
+		tkey[j] = rankKey(merged[i].rank);
+		tidx[j] = uint32_t(i);
 	}
 	RadixSortPairs(tkey, tidx);
 	std::vector<uint64_t> hkey(tailStart);
 	for (size_t i = 0; i < tailStart; ++i) hkey[i] = (uint64_t(rankKey(merged[i].rank)) << 32) | (uint64_t(i) & 0xFFFFFFFFull);
-	std::sort(hkey.begin(), hkey.end(), [&](uint64_t l, uint64_t r) {   // ids are non-negative (IdType) and unique
+	std::sort(hkey.begin(), hkey.end(), [&](uint64_t l, uint64_t r) {
 		const uint32_t lk = uint32_t(l >> 32), rk = uint32_t(r >> 32);
-		return lk != rk ? lk < rk : merged[uint32_t(l)].id < merged[uint32_t(r)].id;
+		return lk != rk ? lk < rk : idBefore(merged[uint32_t(l)].id, merged[uint32_t(r)].id);
 	});
-	out.ids.resize(n);
-	out.ranks.resize(n);
+	hkey.erase(std::unique(hkey.begin(), hkey.end(),
+						   [&](uint64_t l, uint64_t r) { return uint32_t(l >> 32) == uint32_t(r >> 32) && merged[uint32_t(l)].id == merged[uint32_t(r)].id; }),
+			   hkey.end());
+	const size_t total = hkey.size() + nTail;
+	out.ids.resize(total);
+	out.ranks.resize(total);
 	size_t h = 0, t = 0, o = 0;
 	while (h < hkey.size() || t < tkey.size()) {
 		bool takeHead;
@@ -137,7 +148,7 @@ inline void Finish(std::vector<IdRank>& merged, size_t tailStart, bool desc, Hyb
 			takeHead = true;
 		} else {
 			const uint32_t hk = uint32_t(hkey[h] >> 32);
-			takeHead = hk != tkey[t] ? hk < tkey[t] : merged[uint32_t(hkey[h])].id < merged[tidx[t]].id;
+			takeHead = hk != tkey[t] ? hk < tkey[t] : idBefore(merged[uint32_t(hkey[h])].id, merged[tidx[t]].id);
 		}
 		const IdRank& e = takeHead ? merged[uint32_t(hkey[h++])] : merged[tidx[t++]];
 		out.ids[o] = e.id;
@@ -198,9 +209,8 @@ inline FtById PrepareFtById(const std::vector<int32_t>& ftIdsFtOrder, const std:
 inline HybridResult MergeRankedRRF(const RerankerRRF& rr, HybridMergeType type, bool desc, VectorMetric metric, const std::vector<int32_t>& knnIds,
 								   const std::vector<float>& knnRanks, const std::vector<int32_t>& ftIds, const std::vector<size_t>& ftPositions) {
 	std::vector<detail::IdRank> merged;
-	// Merged<desc> is keyed by id: the first emplace of an id wins.  Only the (few) KNN ids can repeat: ftIds are unique, and an FT id that
-	// also came through the KNN list is marked in ftAdded — so the FT tail needs no hashing.
-	std::unordered_set<int32_t> seen;
+	// Merged<desc> (std::pmr::set) is keyed by the (rank, id) pair: only the (few) KNN ids can repeat, and such repeats are resolved by
+	// detail::Finish; ftIds are unique, and an FT id that also came through the KNN list is marked in ftAdded.
 	merged.reserve(knnIds.size() + (type == HybridMergeType::Union ? ftIds.size() : 0));
 	std::vector<bool> ftAdded(type == HybridMergeType::Union ? ftIds.size() : 0, false);
 	if (!knnIds.empty()) {
@@ -215,10 +225,10 @@ inline HybridResult MergeRankedRRF(const RerankerRRF& rr, HybridMergeType type, 
 			auto it = std::lower_bound(ftIds.begin(), ftIds.end(), id);
 			if (it != ftIds.end() && *it == id) {
 				const size_t n = size_t(it - ftIds.begin());
-				if (seen.insert(id).second) merged.push_back({id, rr.Calculate(knnPos, ftPositions[n])});
+				merged.push_back({id, rr.Calculate(knnPos, ftPositions[n])});
 				if (type == HybridMergeType::Union) ftAdded[n] = true;
 			} else if (type == HybridMergeType::Union) {
-				if (seen.insert(id).second) merged.push_back({id, rr.CalculateSingle(knnPos)});
+				merged.push_back({id, rr.CalculateSingle(knnPos)});
 			}
 		}
 	}
@@ -236,17 +246,16 @@ inline HybridResult MergeRankedRRF(const RerankerRRF& rr, HybridMergeType type, 
 inline HybridResult MergeRankedLinear(const RerankerLinear& rr, HybridMergeType type, bool desc, const std::vector<int32_t>& knnIds,
 									  const std::vector<float>& knnRanks, const std::vector<int32_t>& ftIds, const std::vector<float>& ftRanks) {
 	std::vector<detail::IdRank> merged;
-	std::unordered_set<int32_t> seen;
 	std::vector<bool> ftAdded(type == HybridMergeType::Union ? ftIds.size() : 0, false);
 	for (size_t i = 0; i < knnIds.size(); ++i) {
 		const int32_t id = knnIds[i];
 		auto it = std::lower_bound(ftIds.begin(), ftIds.end(), id);
 		if (it != ftIds.end() && *it == id) {
 			const size_t n = size_t(it - ftIds.begin());
-			if (seen.insert(id).second) merged.push_back({id, rr.Calculate(double(knnRanks[i]), ftRanks[n])});
+			merged.push_back({id, rr.Calculate(double(knnRanks[i]), ftRanks[n])});
 			if (type == HybridMergeType::Union) ftAdded[n] = true;
 		} else if (type == HybridMergeType::Union) {
-			if (seen.insert(id).second) merged.push_back({id, rr.CalculateJustKnn(double(knnRanks[i]))});
+			merged.push_back({id, rr.CalculateJustKnn(double(knnRanks[i]))});
 		}
 	}
 	const size_t tailStart = merged.size();

@@ -207,6 +207,10 @@ class HnswGraph:
             L.rxhost_graph_mark_delete.argtypes = [_vp, _u64]
             L.rxhost_graph_info.argtypes = [_vp, _vp]
             L.rxhost_graph_export.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp]
+            L.rxhost_graph_vectors.restype = C.POINTER(C.c_float)
+            L.rxhost_graph_vectors.argtypes = [_vp]
+            L.rxhost_graph_inv_norms.restype = C.POINTER(C.c_float)
+            L.rxhost_graph_inv_norms.argtypes = [_vp]
             L._graph_bound = True
         return L
 
@@ -260,6 +264,16 @@ class HnswGraph:
                                   upper_off.ctypes.data, upper.ctypes.data)
         return dict(metric=self.metric, n=n, dim=self.dim, M=M, maxM0=maxM0, maxlevel=maxlevel, entry=entry & 0xFFFFFFFF, num_deleted=ndel,
                     links0=links0, upper_off=upper_off, upper=upper, levels=levels, labels=labels, deleted=deleted)
+
+    def vector_views(self, n: int):
+        """Zero-copy numpy views of the builder's vectors [n][dim] and (cosine) stored 1/|v| [n], in internal-id order — the order a
+        concurrently built graph's ids refer to.  Valid while the graph lives and is not resized."""
+        L = lib()
+        vp = L.rxhost_graph_vectors(self.h)
+        vec = np.ctypeslib.as_array(vp, shape=(n, self.dim))
+        ip = L.rxhost_graph_inv_norms(self.h)
+        inv = np.ctypeslib.as_array(ip, shape=(n,)) if ip else None
+        return vec, inv
 
 
 class _HnswStream:
@@ -415,13 +429,17 @@ class GpuHnswMap:
     count = property(lambda self: lib().rxhost_hnsw_count(self.h))
     deleted_count = property(lambda self: lib().rxhost_hnsw_deleted_count(self.h))
 
-    def export_graph(self) -> dict:
-        """Flat graph of the host builder (borrowed HnswGraph handle)."""
+    def export_graph(self, with_views: bool = False) -> dict:
+        """Flat graph of the host builder (borrowed HnswGraph handle).  with_views: adds 'vectors' / 'inv_norms' = zero-copy views of
+        the builder's storage in internal-id order (valid while this Map lives and is not resized)."""
         HnswGraph._bind()
         g = HnswGraph.__new__(HnswGraph)
         g.dim, g.metric, g.h = self.dim, self.metric, lib().rxhost_hnsw_graph(self.h)
         try:
-            return g.export()
+            e = g.export()
+            if with_views:
+                e["vectors"], e["inv_norms"] = g.vector_views(e["n"])
+            return e
         finally:
             g.h = None   # borrowed: owned by the Map
 

@@ -1,9 +1,20 @@
-"""CPU: hybrid FT + KNN rank fusion (reindexer_amd/host/hybrid_rerank.h) vs a direct restatement of the reference's
-MergerRankedImpl (cpp_src/core/nsselecter/selectiteratorcontainer.cc:1343-1423), RanksHolder::InitRRFPositions
-(ranks_holder.h:61-76) and the rerankers (core/sorting/reranker.h:11-39) — the reference's own hybrid tests
-(gtests/tests/unit/hybrid.cc:119-143) check orderings by recomputing these formulas from separate FT and KNN queries."""
+"""CPU: hybrid FT + KNN rank fusion (reindexer_amd/host/hybrid_rerank.h) vs
+  * the REAL reference merger where oracle/_ref/libref_rank.so exists: SelectIteratorContainer::MergerRankedImpl, the drain of mergeRanked and
+    RanksHolder::InitRRFPositions compiled in place from cpp_src/core/nsselecter/selectiteratorcontainer.cc:1250-1552 (oracle/ref/ref_rank_shim.cc);
+  * a Python restatement of the same code (pinned against that library below), so the suite still means something where the library is absent
+— the reference's own hybrid tests (gtests/tests/unit/hybrid.cc:119-143) check orderings by recomputing these formulas from separate FT and
+KNN queries."""
 import numpy as np
 import pytest
+
+
+@pytest.fixture(scope="module")
+def refrank():
+    from oracle.pyoracle import ref_rank_or_none
+    r = ref_rank_or_none()
+    if r is None:
+        pytest.skip("oracle/_ref/libref_rank.so not built (needs /root/reference)")
+    return r
 
 
 def rrf_positions(ranks_desc):
@@ -17,7 +28,11 @@ def rrf_positions(ranks_desc):
 
 def restated(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union, desc, metric):
     f32 = np.float32
-    merged = {}
+
+    class _Set(set):   # Merged<desc> = std::pmr::set<IdRank<desc>>: keyed by the (rank, id) pair
+        def setdefault(self, id_, rank):
+            self.add((id_, float(rank)))
+    merged = _Set()
     ft_index = {int(i): n for n, i in enumerate(ft_ids)}
     if kind == "rrf":
         c = params[0]
@@ -53,7 +68,8 @@ def restated(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union, desc, me
             for n, id_ in enumerate(ft_ids):
                 if n not in added:
                     merged.setdefault(int(id_), f32(kk * kd + kf * float(ft_ranks[n]) + c))
-    items = sorted(merged.items(), key=lambda t: ((-t[1] if desc else t[1]), t[0]))
+    # IdRank<desc>::operator< (selectiteratorcontainer.cc:1258-1278): desc: rank descending, ties by DESCENDING id; else both ascending
+    items = sorted(merged, key=lambda t: ((-t[1], -t[0]) if desc else (t[1], t[0])))
     return np.array([i for i, _ in items], np.int32), np.array([r for _, r in items], np.float32)
 
 
@@ -109,3 +125,59 @@ def test_merge_ranked_ft_order_rejects_duplicate_ids():
     with pytest.raises(Exception):
         hostapi.merge_ranked("rrf", [60.0], np.array([1], np.int32), np.array([1.0], np.float32), np.array([5, 5], np.int32),
                              np.array([9.0, 3.0], np.float32), union=True, ft_order="rank")
+
+
+def _positions_by_id(ft_ranks):
+    """RRF positions aligned with the id-ascending FT view: InitRRFPositions over the rank-sorted result (indextext.cc:596-603)."""
+    order = np.argsort(-ft_ranks, kind="stable")
+    ps = rrf_positions([ft_ranks[i] for i in order])
+    out = np.zeros(len(ft_ranks), np.uint64)
+    out[order] = ps
+    return out
+
+
+@pytest.mark.parametrize("kind,params", [("rrf", [60.0]), ("rrf", [1.0]), ("linear", [0.7, 0.1, 0.3, 5.0, 2.0]), ("linear", [1.0, 0.0, -1.0, 0.0, 0.0])])
+@pytest.mark.parametrize("union", [False, True])
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_merge_ranked_matches_reference_merger(refrank, kind, params, union, metric):
+    """Pinned: product == the reference's own MergerRankedImpl (and so is the restatement), incl. massive rank ties (uint8-quantised FT
+    ranks), both sort directions, and a row id that reaches the merger twice through the KNN list (array field)."""
+    from reindexer_amd import hostapi
+    rng = np.random.default_rng(abs(hash((kind, union, metric, len(params)))) % 10007)
+    assert refrank.uses_pmr
+    for it in range(40):
+        nk, nf = int(rng.integers(0, 60)), int(rng.integers(0, 300))
+        knn_ids = rng.choice(500, nk, replace=False).astype(np.int32)
+        if it % 3 == 0 and nk > 4:   # duplicates in the KNN list
+            knn_ids[rng.integers(0, nk, 3)] = knn_ids[rng.integers(0, nk, 3)]
+        kr = np.sort(rng.integers(0, 12, nk).astype(np.float32))
+        knn_ranks = kr if metric == 0 else kr[::-1].copy()
+        ft_ids = np.sort(rng.choice(500, nf, replace=False)).astype(np.int32)
+        ft_ranks = rng.integers(5, 20 if it % 2 else 256, nf).astype(np.float32)
+        pos = _positions_by_id(ft_ranks)
+        if nf:
+            assert np.array_equal(refrank.rrf_positions(np.sort(ft_ranks)[::-1]), np.array(rrf_positions(list(np.sort(ft_ranks)[::-1])), np.uint64))
+        for desc in (True, False):
+            ri, rr = refrank.merge(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=union, desc=desc, metric=metric, ft_positions=pos)
+            wi, wr = restated(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union, desc, metric)
+            assert np.array_equal(wi, ri) and np.array_equal(wr.view(np.uint32), rr.view(np.uint32)), "restatement != reference"
+            gi, gr = hostapi.merge_ranked(kind, params, knn_ids, knn_ranks, ft_ids, ft_ranks, union=union, desc=desc, metric=metric)
+            assert np.array_equal(gi, ri) and np.array_equal(gr.view(np.uint32), rr.view(np.uint32)), "product != reference"
+
+
+def test_merge_ranked_reference_at_hybrid_size(refrank):
+    """configs[4] sizes: 20 000 FT hits with uint8 ranks, ids up to 5M, k = 100, union, RRF desc."""
+    from reindexer_amd import hostapi
+    rng = np.random.default_rng(5)
+    ft_ids = np.sort(rng.choice(5_000_000, 20000, replace=False)).astype(np.int32)
+    ft_ranks = rng.integers(1, 256, 20000).astype(np.float32)
+    knn_ids = np.concatenate([ft_ids[rng.choice(20000, 40, replace=False)], rng.choice(5_000_000, 60, replace=False).astype(np.int32)])
+    rng.shuffle(knn_ids)
+    knn_ranks = np.sort(rng.random(100).astype(np.float32))[::-1].copy()
+    pos = _positions_by_id(ft_ranks)
+    for desc in (True, False):
+        ri, rr = refrank.merge("rrf", [60.0], knn_ids, knn_ranks, ft_ids, ft_ranks, union=True, desc=desc, metric=2, ft_positions=pos)
+        by_rank = np.argsort(-ft_ranks, kind="stable")
+        gi, gr = hostapi.merge_ranked("rrf", [60.0], knn_ids, knn_ranks, ft_ids[by_rank], ft_ranks[by_rank], union=True, desc=desc, metric=2,
+                                      ft_order="rank")
+        assert np.array_equal(gi, ri) and np.array_equal(gr.view(np.uint32), rr.view(np.uint32))

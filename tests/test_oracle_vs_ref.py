@@ -181,3 +181,76 @@ def test_hnsw_streaming_restatement_matches_reference(oracle, ref, metric):
             rs.close()
             os_.close()
     h.close()
+
+
+# ---------------------------------------------------------------- bench.py infrastructure: graph import + timed multi-thread baselines
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_ref_graph_import_roundtrip(ref, metric):
+    """A graph written INTO the real engine by ref_hnsw_import_graph searches exactly like the engine that built it (labels + distance
+    bits, deleted nodes included) and exports the same flat graph; a graph built by the product's concurrent builder imports too."""
+    from oracle.pyoracle import RefHnsw
+    from reindexer_amd import hostapi
+    n, d, M, efc = 1500, 48, 8, 60
+    rows = make_corpus(77 + metric, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    a = RefHnsw(ref, metric, d, n, M=M, ef_construction=efc)
+    a.add(rows, labels)
+    for lab in labels[np.random.default_rng(2).choice(n, 40, replace=False)]:
+        a.mark_delete(lab)
+    g = a.export()
+    b = RefHnsw(ref, metric, d, n + 10, M=M, ef_construction=efc)
+    b.import_graph(g)
+    g2 = b.export()
+    for key in ("n", "maxlevel", "entry", "num_deleted"):
+        assert g[key] == g2[key], key
+    for key in ("links0", "levels", "labels", "deleted", "upper_off", "vectors"):
+        assert np.array_equal(g[key], g2[key]), key
+    assert np.array_equal(g["upper"][: int(g["upper_off"][-1])], g2["upper"][: int(g["upper_off"][-1])])
+    qs = make_corpus(5, 24, d)
+    od, ol, cnt = b.search_knn_many(qs, 10, 50)
+    for i, q in enumerate(qs):
+        wd, wl = a.search_knn(q, 10, 50)
+        assert cnt[i] == len(wl) and np.array_equal(ol[i, : cnt[i]], wl) and np.array_equal(od[i, : cnt[i]].view(np.uint32), wd.view(np.uint32))
+    # inserting after an import keeps working (label table, deleted-slot set, levels, norms are in place): the engine is constructed with
+    # ReplaceDeleted_True, so the 5 new points take 5 of the 40 vacated slots (hnswalg.h:1410-1421) exactly as in the engine that built it
+    extra = make_corpus(9, 5, d)
+    # (WHICH slots is the iteration order of a hash set filled in a different order by initTree — also true of the reference's own LoadIndex)
+    b.add(extra, np.arange(5, dtype=np.uint64) + np.uint64(7))
+    gb = b.export()
+    assert b.count == n and gb["num_deleted"] == 35
+    for i in range(5):
+        _, wl = b.search_knn(extra[i], 1, 50)
+        assert wl[0] == 7 + i
+    # the product's multithreaded builder -> import -> the reference's SearchKnn runs on it
+    hg = hostapi.HnswGraph(metric, d, n, M=M, ef_construction=efc)
+    hg.add(rows, labels, threads=4)
+    e = hg.export()
+    e["vectors"] = rows
+    c = RefHnsw(ref, metric, d, n, M=M, ef_construction=efc)
+    c.import_graph(e)
+    from oracle.pyoracle import Oracle, oracle_hnsw_search_knn
+    orc = Oracle()
+    inv = orc.l2_modules(rows) if metric == 2 else None
+    for q in qs[:8]:
+        if metric == 2:
+            q, _ = orc.normalize_copy(q)
+        wd, wl = oracle_hnsw_search_knn(orc, e, q, 10, 50, inv_norms=inv)
+        rd, rl = c.search_knn(q, 10, 50)
+        assert np.array_equal(np.sort(rl), np.sort(wl)) and np.array_equal(np.sort(rd).view(np.uint32), np.sort(wd).view(np.uint32))
+    secs, done = c.search_knn_mt(qs, 10, 50, threads=3, per_thread=5)
+    assert done == 15 and secs > 0
+    for x in (a, b, c):
+        x.close()
+    hg.close()
+
+
+def test_ref_bruteforce_timed_threads(ref):
+    from oracle.pyoracle import RefBruteforce
+    rows = make_corpus(3, 4000, 64)
+    bf = RefBruteforce(ref, 1, 64, 4000)
+    bf.add(rows, np.arange(4000, dtype=np.uint64))
+    secs, done = bf.search_knn_mt(make_corpus(4, 6, 64), 10, threads=4, per_thread=8)
+    assert done == 32 and 0 < secs < 30
+    secs, done = bf.search_knn_mt(make_corpus(4, 6, 64), 10, threads=2, per_thread=1_000_000, deadline_s=0.05)
+    assert 2 <= done < 2_000_000
+    bf.close()

@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
-"""HNSW leg (BASELINE configs[2], scaled): cosine, M=16, ef_construction=200, ef=128, k=10 on N x 768.
+"""HNSW leg (BASELINE configs[2]): cosine, M=16, ef_construction=200, ef=128, k=10 on N x 768.
 
-    python tools/bench_hnsw.py --rows 100000 --queries 4096 [--out profiles/r1_hnsw.json]
+    python tools/bench_hnsw.py --rows 1000000 --queries 16384 [--out profiles/r2_hnsw_1m.json]
+    python tools/bench_hnsw.py --rows 10000000 --no-map-legs --out profiles/r2_hnsw_10m.json      # configs[2] at its true size
 
-The full 10M x 768 graph takes hours to build on any CPU (the reference's build is CPU-only too), so this leg runs a scaled
-corpus: graph built on the host by the product's builder, searched (a) on the MI355X through GpuHnswMap / rxgpu_hnsw_search_knn
-and (b) by the reference engine itself (oracle/_ref, AVX-512) on the SAME graph where that library loads — reporting
-queries/s, achieved HBM GB/s from the kernel's own counters (distance evaluations x D x 4 + hops x (1+2M) x 4), the fraction
-of queries whose result equals the reference's, and recall@10 vs exact brute force (computed on the GPU by the exact scan).
+Also imported by bench.py (`run(opts)`), which puts the same leg into the driver-run bench line.
+
+The graph is built ON THIS BOX by the product's host builder from `--build-threads` inserting threads (GpuHnswMap<OnInsertions> =
+the reference's multithreaded index build, AddPointConcurrent), then
+  (a) searched on the MI355X through the C-ABI (rxgpu_hnsw_search_knn, all queries in one batched call; the Map's SearchKnn is the
+      nq = 1 case of the same entry point), with the kernel's own counters giving distance evaluations / hops -> algorithmic bytes
+      (evals x D x 4 + hops x (1 + 2M) x 4) against the HBM roofline;
+  (b) written INTO the reference's own engine (oracle/_ref, ref_hnsw_import_graph: HierarchicalNSWImpl<float> of the reference,
+      AVX-512 distances) and searched by ITS SearchKnn on the same graph: single-thread and all-core queries/s
+      (cpu_baseline.kind == "reference") and the fraction of queries whose result set equals the GPU's (labels + distance bits);
+  (c) recall@k of the GPU result vs exact brute force (the exact scan of the same index on the GPU).
+Without oracle/_ref the CPU side falls back to the plain-C restatement (kind "port").
 """
 import argparse
 import json
 import os
 import sys
-import threading
 import time
 from pathlib import Path
+from types import SimpleNamespace
 
 import numpy as np
 
@@ -25,176 +33,184 @@ os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
 
 from reindexer_amd import capi, hostapi  # noqa: E402
 
+DEFAULTS = dict(rows=1_000_000, dim=768, queries=16384, k=10, ef=128, M=16, efc=200, metric="cosine", cpu_queries=256, clusters=2000,
+                graph=None, save_graph=None, build_threads=0, cpu_threads=0, cpu_per_thread=64, map_legs=True, device=0, out=None, seed=20260924)
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--rows", type=int, default=100_000)
-    ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--ef", type=int, default=128)
-    ap.add_argument("--M", type=int, default=16)
-    ap.add_argument("--efc", type=int, default=200)
-    ap.add_argument("--metric", default="cosine")
-    ap.add_argument("--cpu-queries", type=int, default=256)
-    ap.add_argument("--clusters", type=int, default=2000,
-                    help="synthetic corpus = cluster centre + noise (embedding-like: low intrinsic dimension); 0 = i.i.d. gaussian, "
-                         "the reference tests' distribution, on which ANY graph index has poor recall at 768 dims")
-    ap.add_argument("--graph", default=None, help="graph saved by tools/build_hnsw_graph.py (same corpus seed): skip the host build")
-    ap.add_argument("--build-threads", type=int, default=0,
-                    help="build the graph here with this many inserting threads (GpuHnswMap<OnInsertions>, the reference's multithreaded build); "
-                         "the CPU baseline is then the restated engine on the same graph")
-    ap.add_argument("--out", default=None)
-    args = ap.parse_args()
-    metric = capi.METRICS[args.metric]
-    saved = None
-    if args.graph:
-        saved = np.load(args.graph)
-        meta = saved["meta"]
-        args.rows, args.dim, args.M, args.clusters, args.efc = int(meta[1]), int(meta[2]), int(meta[3]), int(meta[8]), int(meta[9])
-        assert int(meta[0]) == metric
-    rng = np.random.default_rng(20260924)
-    if args.clusters:
-        centres = rng.normal(0, 0.25, (args.clusters, args.dim)).astype(np.float32)
-        rows = (centres[rng.integers(0, args.clusters, args.rows)] + rng.normal(0, 0.08, (args.rows, args.dim))).astype(np.float32)
-        queries = (centres[rng.integers(0, args.clusters, args.queries)] + rng.normal(0, 0.08, (args.queries, args.dim))).astype(np.float32)
-    else:
-        rows = rng.normal(0, 0.25, (args.rows, args.dim)).astype(np.float32)
-        queries = rng.normal(0, 0.25, (args.queries, args.dim)).astype(np.float32)
-    labels = np.arange(args.rows, dtype=np.uint64) << np.uint64(32)
+
+def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
+    """Synthetic corpus = cluster centre + noise (embedding-like: low intrinsic dimension); clusters == 0: i.i.d. N(0, 0.25^2), the
+    distribution of the reference's tests (gtests/tools.h:121-129), on which ANY graph index has poor recall at 768 dims.
+    Generated on the GPU (a 10M x 768 corpus takes numpy minutes), returned as a host array; deterministic per (seed, device type)."""
+    import torch
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    centres = torch.empty((max(clusters, 1), dim), dtype=torch.float32, device=dev).normal_(0.0, 0.25, generator=g)
+    out = np.empty((rows, dim), np.float32)
+    chunk = 1 << 19
+    for a in range(0, rows, chunk):
+        n = min(chunk, rows - a)
+        if clusters:
+            pick = torch.randint(0, clusters, (n,), device=dev, generator=g)
+            x = centres[pick] + torch.empty((n, dim), dtype=torch.float32, device=dev).normal_(0.0, 0.08, generator=g)
+        else:
+            x = torch.empty((n, dim), dtype=torch.float32, device=dev).normal_(0.0, 0.25, generator=g)
+        out[a:a + n] = x.cpu().numpy()
+    return out
+
+
+def run(o) -> dict:
+    o = SimpleNamespace(**{**DEFAULTS, **(vars(o) if not isinstance(o, dict) else o)})
+    metric = capi.METRICS[o.metric]
+    ncpu = os.cpu_count() or 1
+    build_threads = o.build_threads or ncpu
+    t_all = time.perf_counter()
+    corpus = make_clustered(o.rows + o.queries, o.dim, o.clusters, o.seed, o.device)
+    rows, queries = corpus[:o.rows], corpus[o.rows:]
+    labels = np.arange(o.rows, dtype=np.uint64) << np.uint64(32)
     if metric == 2:
         queries = np.stack([hostapi.normalize_copy(q)[0] for q in queries])
+    gen_s = time.perf_counter() - t_all
 
     m = None
-    if saved is None:
-        t0 = time.perf_counter()
-        m = hostapi.GpuHnswMap(metric, args.dim, args.rows, M=args.M, ef_construction=args.efc, multithread=args.build_threads > 0)
-        m.add(rows, labels, threads=args.build_threads)
-        build_s = time.perf_counter() - t0
-        g = m.export_graph()
-        if args.build_threads:   # internal ids follow arrival order: bring the corpus into the graph's order (label i << 32 = original row i)
-            order = (g["labels"][:args.rows] >> np.uint64(32)).astype(np.int64)
-            rows, labels = rows[order], labels[order]
+    if o.graph:   # a graph saved by --save-graph on the same corpus (same seed): skip the host build (rocprof passes)
+        z = np.load(o.graph)
+        meta = z["meta"]
+        assert int(meta[0]) == metric and int(meta[1]) == o.rows and int(meta[2]) == o.dim, "graph file is for another corpus"
+        order = (z["labels"] >> np.uint64(32)).astype(np.int64)   # internal ids follow arrival order
+        vec = rows[order]
+        inv = np.array([hostapi.l2_module(r) for r in vec], np.float32) if metric == 2 else None
+        g = dict(metric=metric, n=o.rows, dim=o.dim, M=int(meta[3]), maxM0=int(meta[4]), maxlevel=int(meta[5]), entry=int(meta[6]), num_deleted=0,
+                 links0=z["links0"], upper_off=z["upper_off"], upper=z["upper"], levels=z["levels"], labels=z["labels"], deleted=z["deleted"],
+                 vectors=vec, inv_norms=inv)
+        build_s = float(z["build_seconds"])
+        build_threads = int(meta[7])
     else:
-        meta = saved["meta"]
-        build_s = float(saved["build_seconds"])
-        if "labels" in saved:   # a concurrently built graph: internal ids follow arrival order
-            order = (saved["labels"][:args.rows] >> np.uint64(32)).astype(np.int64)
-            rows, labels = rows[order], labels[order]
-        g = dict(metric=metric, n=args.rows, dim=args.dim, M=args.M, maxM0=int(meta[4]), maxlevel=int(meta[5]), entry=int(meta[6]),
-                 num_deleted=int(meta[7]), links0=saved["links0"], upper_off=saved["upper_off"], upper=saved["upper"], levels=saved["levels"],
-                 labels=labels, deleted=saved["deleted"])
+        t0 = time.perf_counter()
+        m = hostapi.GpuHnswMap(metric, o.dim, o.rows, M=o.M, ef_construction=o.efc, multithread=build_threads > 1, device=o.device)
+        m.add(rows, labels, threads=build_threads if build_threads > 1 else 0)
+        build_s = time.perf_counter() - t0
+        g = m.export_graph(with_views=True)   # vectors / 1/|v| in internal-id (= arrival) order, zero-copy views of the builder's storage
+        if o.save_graph:
+            np.savez(o.save_graph, meta=np.array([metric, o.rows, o.dim, g["M"], g["maxM0"], g["maxlevel"], g["entry"], build_threads], np.int64),
+                     links0=g["links0"], upper_off=g["upper_off"], upper=g["upper"], levels=g["levels"], labels=g["labels"], deleted=g["deleted"],
+                     build_seconds=np.float64(build_s))
+    glabels = g["labels"]
+    del corpus, rows
 
-    # GPU search through the C-ABI in one batched call (the Map's SearchKnn is the nq = 1 case of the same entry point)
-    inv = np.array([hostapi.l2_module(r) for r in rows], np.float32) if metric == 2 else None
-    ix = capi.VectorIndex(metric, args.dim, args.rows)
-    ix.upload_rows(0, rows, inv)
+    # ---- (a) GPU search through the C-ABI
+    ix = capi.VectorIndex(metric, o.dim, o.rows, device=o.device)
+    ix.upload_rows(0, g["vectors"], g["inv_norms"])
     ix.hnsw_attach_graph(g)
-    ix.hnsw_search_knn(queries[:64], args.k, args.ef)   # warmup
+    ix.hnsw_search_knn(queries[:64], o.k, o.ef)   # warm-up
     ix.hnsw_read_stats()
     ix.profile_enable(True)
     t0 = time.perf_counter()
-    dist, row, cnt = ix.hnsw_search_knn(queries, args.k, args.ef)
+    dist, row, cnt = ix.hnsw_search_knn(queries, o.k, o.ef)
     gpu_s = time.perf_counter() - t0
     launches, kernel_ms = ix.profile_read("hnsw")
     redo_launches, redo_ms = ix.profile_read("hnsw_redo")
     ix.profile_enable(False)
     evals, hops = ix.hnsw_read_stats()
-    bytes_algo = evals * args.dim * 4 + hops * (1 + 2 * args.M) * 4
-    # single-query latency (through the Map when it was built here, else the nq = 1 case of the same C-ABI entry)
-    t0 = time.perf_counter()
-    for q in queries[:32]:
-        if m is not None:
-            m.search_knn(q, args.k, args.ef)
-        else:
-            ix.hnsw_search_knn(q[None, :], args.k, args.ef)
-    lat_ms = (time.perf_counter() - t0) / 32 * 1e3
-    ix.hnsw_read_stats()
+    bytes_algo = evals * o.dim * 4 + hops * (1 + 2 * g["M"]) * 4
+    busy_ms = kernel_ms + redo_ms
 
-    stream = None
-    if m is not None:   # a15: one streaming session, 10 batches of 10 (the planner's post-filter pattern), per-call latency
-        sess = m.stream(queries[0], args.ef)
+    # ---- (c) exact ground truth: the exact scan of the SAME index
+    tq = min(o.queries, 512)
+    _, trow, _ = ix.search_knn(queries[:tq], o.k)
+    recall = float(np.mean([len(set(trow[i].tolist()) & set(row[i, :int(cnt[i])].tolist())) / o.k for i in range(tq)]))
+
+    out = {
+        "workload": f"HNSW {o.metric} M={g['M']} efC={o.efc} ef={o.ef} k={o.k}, {o.rows} x {o.dim} (BASELINE configs[2]"
+                    + ("" if o.rows == 10_000_000 else f" scaled to {o.rows} rows") + "), "
+                    + (f"{o.clusters} gaussian clusters" if o.clusters else "i.i.d. gaussian"),
+        "corpus_bytes": o.rows * o.dim * 4,
+        "build": {"seconds": build_s, "threads": build_threads, "inserts_per_sec": o.rows / build_s if build_s else None,
+                  "builder": "rxgpu::host::HnswGraph::AddPointConcurrent (host, the reference's HierarchicalNSWMT build)", "corpus_gen_seconds": gen_s},
+        "gpu": {"queries": o.queries, "queries_per_sec": o.queries / gpu_s, "kernel_ms_total": kernel_ms, "launches": launches,
+                "queries_per_sec_kernel_only": o.queries / (busy_ms / 1e3) if busy_ms else None,
+                "redo_launches": redo_launches, "redo_ms": redo_ms,
+                "distance_evals_per_query": evals / o.queries, "hops_per_query": hops / o.queries,
+                "roofline": {"bound": "hbm", "kernel": "hnsw_search_kernel", "achieved": bytes_algo / (busy_ms / 1e3) / 1e9 if busy_ms else None,
+                             "peak": 8000.0, "unit": "GB/s", "frac": bytes_algo / (busy_ms / 1e3) / 1e9 / 8000.0 if busy_ms else None,
+                             "algorithmic_bytes": bytes_algo, "avg_ms": busy_ms / max(launches, 1),
+                             "note": "dependent random 3 KB row gathers; bytes = evals*D*4 + hops*(1+2M)*4 from the kernel's own counters"}},
+        "recall_at_k_vs_exact": recall, "recall_queries": tq,
+    }
+
+    if m is not None and o.map_legs:
+        t0 = time.perf_counter()
+        for q in queries[:32]:
+            m.search_knn(q, o.k, o.ef)
+        out["gpu"]["map_single_query_latency_ms"] = (time.perf_counter() - t0) / 32 * 1e3
+        sess = m.stream(queries[0], o.ef)   # a15: one streaming session, 10 batches of 10 (the planner's post-filter pattern)
         t0 = time.perf_counter()
         got = 0
         for _ in range(10):
             d_, l_, ex_ = sess.next(10)
             got += len(d_)
-        stream = {"batches": 10, "batch": 10, "ef": args.ef, "returned": got, "ms_per_continue": (time.perf_counter() - t0) / 10 * 1e3}
+        out["streaming_session"] = {"batches": 10, "batch": 10, "ef": o.ef, "returned": got, "ms_per_continue": (time.perf_counter() - t0) / 10 * 1e3}
         sess.close()
 
-    # exact ground truth on the GPU (fused scan / batched path)
-    bf = capi.VectorIndex(metric, args.dim, args.rows)
-    bf.upload_rows(0, rows, inv)
-    tq = min(args.queries, 512)
-    _, trow, _ = bf.search_knn(queries[:tq], args.k)
-    recall = float(np.mean([len(set(trow[i].tolist()) & set(row[i, :int(cnt[i])].tolist())) / args.k for i in range(tq)]))
-
-    out = {
-        "workload": f"HNSW {args.metric} M={args.M} efC={args.efc} ef={args.ef} k={args.k}, {args.rows} x {args.dim} (scaled from BASELINE configs[2]), "
-                    + (f"{args.clusters} gaussian clusters" if args.clusters else "i.i.d. gaussian"),
-        "build_seconds_host": build_s, "build_threads": max(args.build_threads, 1),
-        "gpu": {"queries": args.queries, "queries_per_sec": args.queries / gpu_s, "kernel_ms_total": kernel_ms, "launches": launches,
-                "queries_per_sec_kernel_only": args.queries / ((kernel_ms + redo_ms) / 1e3) if kernel_ms else None,
-                "redo_launches": redo_launches, "redo_ms": redo_ms,
-                "map_single_query_latency_ms": lat_ms, "distance_evals_per_query": evals / args.queries, "hops_per_query": hops / args.queries,
-                "roofline": {"bound": "hbm", "achieved": bytes_algo / (kernel_ms / 1e3) / 1e9 if kernel_ms else None, "peak": 8000.0, "unit": "GB/s",
-                             "frac": bytes_algo / (kernel_ms / 1e3) / 1e9 / 8000.0 if kernel_ms else None,
-                             "algorithmic_bytes": bytes_algo, "note": "random 3 KB row gathers; bytes = evals*D*4 + hops*(1+2M)*4"}},
-        "recall_at_k_vs_exact": recall,
-        "streaming_session": stream,
-    }
-    if saved is not None or args.build_threads:   # CPU baseline on the SAME graph: the restated engine (pinned equal to the reference's), 1 thread
-        try:
-            from oracle.pyoracle import Oracle, oracle_hnsw_search_knn
-            orc = Oracle()
-            g2 = dict(g)
-            g2["vectors"] = rows
-            nq = min(args.cpu_queries, args.queries)
-            t0 = time.perf_counter()
-            res = [oracle_hnsw_search_knn(orc, g2, queries[i], args.k, args.ef, inv) for i in range(nq)]
-            cpu_s = time.perf_counter() - t0
-            same = sum(int(np.array_equal(np.sort(labels[row[i, :int(cnt[i])]]), np.sort(res[i][1]))) for i in range(nq))
-            out["cpu_baseline"] = {"kind": "port", "value": nq / cpu_s, "unit": "queries/s", "cores": 1, "sample": f"{nq} queries, same graph"}
-            out["equal_to_reference_frac"] = same / nq
-        except Exception as e:
-            out["cpu_baseline"] = {"error": repr(e)}
-        text = json.dumps(out)
-        print(text)
-        if args.out:
-            Path(args.out).write_text(text + "\n")
-        return
+    # ---- (b) the reference's engine on the SAME graph
+    nq = min(o.cpu_queries, o.queries)
     try:
         from oracle import pyoracle
         ref = pyoracle.ref_or_none()
-        if ref is not None and ref.simd_level == 3:
-            r = pyoracle.RefHnsw(ref, metric, args.dim, args.rows, M=args.M, ef_construction=args.efc)
+        if ref is not None and ref.simd_level == 3 and hasattr(ref.L, "ref_hnsw_import_graph"):
+            r = pyoracle.RefHnsw(ref, metric, o.dim, o.rows, M=g["M"], ef_construction=o.efc)
             t0 = time.perf_counter()
-            r.add(rows, labels)
-            ref_build = time.perf_counter() - t0
-            nq = min(args.cpu_queries, args.queries)
+            r.import_graph(g)
+            import_s = time.perf_counter() - t0
             t0 = time.perf_counter()
-            res = [r.search_knn(queries[i], args.k, args.ef) for i in range(nq)]
+            rd, rl, rc = r.search_knn_many(queries[:nq], o.k, o.ef)
             cpu_s = time.perf_counter() - t0
             same = 0
             for i in range(nq):
                 c = int(cnt[i])
-                gl = np.sort(labels[row[i, :c]])
-                same += int(np.array_equal(gl, np.sort(res[i][1])))
-            threads = min(os.cpu_count() or 1, 64)
-            def worker(t):
-                for j in range(8):
-                    r.search_knn(queries[(t * 8 + j) % args.queries], args.k, args.ef)
-            ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
-            t0 = time.perf_counter()
-            [t.start() for t in ths]
-            [t.join() for t in ths]
-            cpu_all_s = time.perf_counter() - t0
-            out["cpu_baseline"] = {"kind": "reference", "value": nq / cpu_s, "unit": "queries/s", "cores": 1, "sample": f"{nq} queries, same graph",
-                                   "all_cores": {"value": threads * 8 / cpu_all_s, "cores": threads}, "build_seconds": ref_build}
+                a = np.lexsort((glabels[row[i, :c]], dist[i, :c]))
+                b = np.lexsort((rl[i, :int(rc[i])], rd[i, :int(rc[i])]))
+                same += int(c == int(rc[i]) and np.array_equal(glabels[row[i, :c]][a], rl[i, :c][b])
+                            and np.array_equal(dist[i, :c][a].view(np.uint32), rd[i, :c][b].view(np.uint32)))
+            threads = o.cpu_threads or ncpu
+            secs, done = r.search_knn_mt(queries, o.k, o.ef, threads, o.cpu_per_thread, deadline_s=30.0)
+            out["cpu_baseline"] = {"kind": "reference", "value": nq / cpu_s, "unit": "queries/s", "cores": 1,
+                                   "sample": f"{nq} queries, measured; the reference's HierarchicalNSWImpl<float>::SearchKnn (AVX-512) on the SAME graph "
+                                             f"(written into the engine by ref_hnsw_import_graph in {import_s:.1f} s)",
+                                   "all_cores": {"value": done / secs, "cores": threads, "queries": done,
+                                                 "note": "T threads, one query each at a time over the shared index; thread start outside the timed region"}}
             out["equal_to_reference_frac"] = same / nq
+            out["equal_to_reference_checked"] = nq
             r.close()
+        else:
+            from oracle.pyoracle import Oracle, oracle_hnsw_search_knn
+            orc = Oracle()
+            t0 = time.perf_counter()
+            res = [oracle_hnsw_search_knn(orc, g, queries[i], o.k, o.ef, g["inv_norms"]) for i in range(nq)]
+            cpu_s = time.perf_counter() - t0
+            same = sum(int(np.array_equal(np.sort(glabels[row[i, :int(cnt[i])]]), np.sort(res[i][1]))) for i in range(nq))
+            out["cpu_baseline"] = {"kind": "port", "value": nq / cpu_s, "unit": "queries/s", "cores": 1, "sample": f"{nq} queries, same graph"}
+            out["equal_to_reference_frac"] = same / nq
     except Exception as e:  # the GPU numbers are still reported
         out["cpu_baseline"] = {"error": repr(e)}
+    out["leg_seconds"] = time.perf_counter() - t_all
+    ix.close()
+    if m is not None:
+        m.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    for k, v in DEFAULTS.items():
+        if k == "map_legs":
+            ap.add_argument("--no-map-legs", dest="map_legs", action="store_false")
+        elif v is None or isinstance(v, str):
+            ap.add_argument("--" + k.replace("_", "-"), default=v)
+        else:
+            ap.add_argument("--" + k.replace("_", "-"), type=type(v), default=v)
+    args = ap.parse_args()
+    out = run(args)
     text = json.dumps(out)
     print(text)
     if args.out:
