@@ -10,19 +10,25 @@ whole HBM-resident corpus through the C-ABI (rxgpu_search_knn_device), results l
 holds its own 10M-row shard (weak scaling = BASELINE configs[3]: 80M rows on 8 GPUs); each step then also does the
 per-shard top-k all-gather over RCCL and the k-way merge.  Rank 0 prints ONE JSON line.
 
-Extra legs (rank 0, N = 1 only, outside the timed region):
+Extra legs (rank 0, N = 1 only, outside the timed region; each leg is skipped — and says so — once --time-budget is used up):
   roofline      HIP events recorded by the library around every scan-kernel launch on the launch stream
-  cpu_baseline  the reference's own BruteforceSearch (oracle/_ref, AVX-512 path) — or the plain-C port when the
-                reference build is absent — timed on the host cores on a bounded row-prefix sample
-  parity        GPU result vs that CPU result on the same sample (ids must be identical, distance bits too)
+  batched / pruned_scan / prefilter   the other brute-force kernels at the same 10M x 768 shape
+  cpu_baseline  the reference's own BruteforceSearch (oracle/_ref, AVX-512 path) built over the FULL corpus on the host: measured,
+                un-scaled, 1 thread and all hardware threads (thread start outside the timed region)
+  parity        GPU result vs that CPU result on the same FULL corpus (ids must be identical, distance bits too)
+  hnsw          BASELINE configs[2] (scaled to --hnsw-rows): graph built here by the product's concurrent builder, searched on the GPU and by
+                the reference's own engine on the same graph (tools/bench_hnsw.py)
+  hybrid        BASELINE configs[4]: BM25 merge + KNN + RRF fusion on the GPU vs the reference's merger / brute force / rank merger
+                (tools/bench_hybrid.py)
+--scaling strong (or RXGPU_BENCH_SCALING=strong): BASELINE configs[3] with the corpus FIXED at --total-rows (80M) and split over the ranks.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
-import threading
 import time
 from pathlib import Path
 
@@ -31,6 +37,7 @@ import torch
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tools"))
 
 from reindexer_amd import capi  # noqa: E402  (no fallback: raises if librxgpu.so is missing)
 from reindexer_amd.sharded import ShardedBruteforceGpu  # noqa: E402
@@ -64,8 +71,17 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="ip", choices=["l2", "ip", "cosine"])
-    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-queries", type=int, default=16)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="only for the plain-C port fallback (no oracle/_ref): row-prefix sample")
+    ap.add_argument("--cpu-queries", type=int, default=8, help="queries of the 1-thread CPU leg = queries of the full-size parity check")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = every hardware thread)")
+    ap.add_argument("--cpu-per-thread", type=int, default=8)
+    ap.add_argument("--cpu-deadline", type=float, default=40.0, help="all-core CPU leg: threads stop STARTING searches after this many seconds")
+    ap.add_argument("--scaling", default=os.environ.get("RXGPU_BENCH_SCALING", "weak"), choices=["weak", "strong"])
+    ap.add_argument("--total-rows", type=int, default=80_000_000, help="--scaling strong: the fixed corpus, split over the ranks")
+    ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="hnsw leg: graph size (0 = skip)")
+    ap.add_argument("--hnsw-queries", type=int, default=16384)
+    ap.add_argument("--hybrid-docs", type=int, default=5_000_000, help="hybrid leg: documents = vectors (0 = skip)")
+    ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock after which remaining extra legs are skipped")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--batch", type=int, default=256, help="extra leg (N=1, untimed region): batched queries on the MFMA path; 0 = skip")
     ap.add_argument("--batch-iters", type=int, default=3)
@@ -98,82 +114,106 @@ def host_cpu_info() -> dict:
     return info
 
 
-def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, metric_id: int):
+def _numa_interleave(on: bool) -> bool:
+    """set_mempolicy(MPOL_INTERLEAVE over every allowed node) for pages this thread touches from now on / back to the default policy.
+    The reference allocates its row array with malloc and fills it from one thread; on a two-socket host first-touch would put all 30.8 GB
+    on one socket and halve what the all-core baseline can read.  Raw syscalls (no libnuma in the image); best effort."""
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        if not on:
+            return libc.syscall(ctypes.c_long(238), ctypes.c_long(0), None, ctypes.c_ulong(0)) == 0
+        mask = (ctypes.c_ulong * 16)()
+        if libc.syscall(ctypes.c_long(239), None, mask, ctypes.c_ulong(1024), None, ctypes.c_ulong(4)) != 0:   # get_mempolicy(MPOL_F_MEMS_ALLOWED)
+            return False
+        if sum(bin(w).count("1") for w in mask) < 2:
+            return False
+        return libc.syscall(ctypes.c_long(238), ctypes.c_long(3), mask, ctypes.c_ulong(1024)) == 0   # set_mempolicy(MPOL_INTERLEAVE)
+    except Exception:
+        return False
+
+
+def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, metric_id: int, ix):
+    """Full-size CPU leg: the reference's BruteforceSearch over ALL rows of the corpus (bruteforce.cc:103-127), measured — nothing is scaled."""
     from oracle import pyoracle  # checker / baseline only
+    ref = pyoracle.ref_or_none()
+    if ref is None or ref.simd_level != 3 or not hasattr(ref.L, "ref_bf_search_knn_mt"):
+        return cpu_baseline_port_sample(args, corpus, queries, metric_id)
+    rows = corpus.shape[0]
+    nq = min(args.cpu_queries, queries.shape[0])
+    ncores = os.cpu_count() or 1
+    orc = pyoracle.Oracle()
+    host_q = queries[:max(nq, 64)].cpu().numpy()
+    if metric_id == 2:
+        host_q = np.stack([orc.normalize_copy(q)[0] for q in host_q])
+    t0 = time.perf_counter()
+    interleaved = _numa_interleave(True)
+    bf = pyoracle.RefBruteforce(ref, metric_id, args.dim, rows)
+    chunk = 1 << 20
+    for a in range(0, rows, chunk):
+        b = min(rows, a + chunk)
+        bf.add(corpus[a:b].cpu().numpy(), np.arange(a, b, dtype=np.uint64) << np.uint64(32))
+    _numa_interleave(False)
+    load_s = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    cpu_res = [bf.search_knn(host_q[i], args.k) for i in range(nq)]
+    qps_1 = nq / (time.perf_counter() - t0)
+    threads = args.cpu_threads or ncores
+    secs, done = bf.search_knn_mt(host_q, args.k, threads, args.cpu_per_thread, deadline_s=args.cpu_deadline)
+    qps_all = done / secs
+    bf.close()
+    row_bytes = rows * args.dim * 4
+    baseline = {
+        "value": qps_1, "unit": "queries/s", "cores": 1, "kind": "reference",
+        "sample": f"measured, un-scaled: the reference's hnswlib::BruteforceSearch (AVX-512) over all {rows} rows, {nq} queries, k={args.k}, one thread",
+        "gbps_per_core": qps_1 * row_bytes / 1e9,
+        "all_cores": {"value": qps_all, "cores": threads, "queries": done, "seconds": secs, "gbps": qps_all * row_bytes / 1e9,
+                      "per_thread_target": args.cpu_per_thread, "deadline_s": args.cpu_deadline,
+                      "note": "T threads, each scanning the shared index for its own query (the reference's concurrency model, "
+                              "gtests/tests/unit/float_vector_index.cc:258-294); threads are created before the clock starts"},
+        "numa_interleaved": interleaved, "index_load_seconds": load_s, "host": host_cpu_info(),
+    }
+    # parity on the FULL corpus: GPU through the C-ABI vs the reference engine
+    labels_of = lambda r: r.astype(np.uint64) << np.uint64(32)  # noqa: E731
+    dist, row, cnt = ix.search_knn(host_q[:nq], args.k + 1)
+    ids_equal, max_ulps, rec = 0, 0, 0.0
+    for i in range(nq):
+        wd, wl = cpu_res[i]
+        gl = labels_of(row[i, :args.k])
+        ids_equal += int(np.array_equal(gl, wl))
+        ulps = np.abs(dist[i, :args.k].view(np.int32).astype(np.int64) - wd.view(np.int32).astype(np.int64))
+        max_ulps = max(max_ulps, int(ulps.max()))
+        rec += len(set(gl.tolist()) & set(wl.tolist())) / args.k
+    parity = {"ids_equal_frac": ids_equal / nq, "max_ulps_dist": max_ulps, "queries": nq, "rows": rows, "recall_at_k": rec / nq,
+              "against": "reference BruteforceSearch over the full corpus"}
+    return baseline, parity
+
+
+def cpu_baseline_port_sample(args, corpus: torch.Tensor, queries: torch.Tensor, metric_id: int):
+    """Fallback when oracle/_ref is absent: the plain-C port on a row-prefix sample, scaled (linear scan) — labelled as such."""
+    from oracle import pyoracle
     s_rows = min(args.cpu_sample_rows, corpus.shape[0])
     nq = min(args.cpu_queries, queries.shape[0])
     host_rows = corpus[:s_rows].cpu().numpy()
     host_q = queries[:nq].cpu().numpy()
     labels = np.arange(s_rows, dtype=np.uint64) << np.uint64(32)
     orc = pyoracle.Oracle()
-    ref = pyoracle.ref_or_none()
-    use_ref = ref is not None and ref.simd_level == 3
     inv = orc.l2_modules(host_rows) if metric_id == 2 else None
     if metric_id == 2:
         host_q = np.stack([orc.normalize_copy(q)[0] for q in host_q])
-    ncores = os.cpu_count() or 1
-
-    if use_ref:
-        bf = pyoracle.RefBruteforce(ref, metric_id, args.dim, s_rows)
-        bf.add(host_rows, labels)
-        search = lambda q: bf.search_knn(q, args.k)  # noqa: E731
-        kind = "reference"
-    else:
-        search = lambda q: orc.bf_search_knn(metric_id, host_rows, labels, inv, q, args.k)  # noqa: E731
-        kind = "port"
-
     t0 = time.perf_counter()
-    cpu_res = [search(host_q[i]) for i in range(nq)]
-    t1 = time.perf_counter()
-    qps_1 = nq / (t1 - t0)
-
-    # all host cores: T concurrent query threads over one shared index (the reference's own concurrency model)
-    threads = min(ncores, 64)
-    per_thread = 2
-    def worker(t):
-        for j in range(per_thread):
-            search(host_q[(t + j) % nq])
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
-    t2 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    t3 = time.perf_counter()
-    qps_all = threads * per_thread / (t3 - t2)
-
-    scale = s_rows / corpus.shape[0]  # linear scan: time is proportional to rows
-    baseline = {
-        "value": qps_1 * scale, "unit": "queries/s", "cores": 1, "kind": kind,
-        "sample": f"{s_rows}-row prefix of the same corpus, {nq} queries, k={args.k}; measured {qps_1:.3f} q/s on the sample, "
-                  f"scaled by {s_rows}/{corpus.shape[0]} rows (linear scan); SIMD=avx512" ,
-        "all_cores": {"value": qps_all * scale, "cores": threads, "measured_on_sample": qps_all},
-        "gbps_per_core": qps_1 * s_rows * args.dim * 4 / 1e9,
-        "host": host_cpu_info(),
-    }
-
-    # parity on the same sample: GPU through the C-ABI vs the CPU result
-    with capi.VectorIndex(metric_id, args.dim) as ix:
-        d_inv = None
-        if metric_id == 2:
-            d_inv = torch.from_numpy(inv).to(corpus.device)
-        ix.adopt_device_rows(corpus.data_ptr(), s_rows, corpus.shape[1], d_inv.data_ptr() if d_inv is not None else None,
-                             keepalive=(corpus, d_inv))
-        dist, row, cnt = ix.search_knn(host_q, args.k + 1)
-    ids_equal, max_ulps = 0, 0
-    for i in range(nq):
-        wd, wl = cpu_res[i]
-        gl = labels[row[i, :args.k]]
-        ids_equal += int(np.array_equal(gl, wl))
-        ulps = np.abs(dist[i, :args.k].view(np.int32).astype(np.int64) - wd.view(np.int32).astype(np.int64))
-        max_ulps = max(max_ulps, int(ulps.max()))
-    parity = {"ids_equal_frac": ids_equal / nq, "max_ulps_dist": max_ulps, "queries": nq, "rows": s_rows,
-              "recall_at_k": ids_equal / nq if ids_equal == nq else None}
-    if parity["recall_at_k"] is None:
-        rec = 0.0
-        for i in range(nq):
-            rec += len(set(labels[row[i, :args.k]].tolist()) & set(cpu_res[i][1].tolist())) / args.k
-        parity["recall_at_k"] = rec / nq
+    cpu_res = [orc.bf_search_knn(metric_id, host_rows, labels, inv, host_q[i], args.k) for i in range(nq)]
+    qps_1 = nq / (time.perf_counter() - t0)
+    scale = s_rows / corpus.shape[0]
+    baseline = {"value": qps_1 * scale, "unit": "queries/s", "cores": 1, "kind": "port",
+                "sample": f"{s_rows}-row prefix, {nq} queries; measured {qps_1:.3f} q/s on the sample, SCALED by {s_rows}/{corpus.shape[0]} rows "
+                          "(oracle/_ref absent: plain-C port)", "host": host_cpu_info()}
+    with capi.VectorIndex(metric_id, args.dim) as sx:
+        d_inv = torch.from_numpy(inv).to(corpus.device) if metric_id == 2 else None
+        sx.adopt_device_rows(corpus.data_ptr(), s_rows, corpus.shape[1], d_inv.data_ptr() if d_inv is not None else None, keepalive=(corpus, d_inv))
+        dist, row, cnt = sx.search_knn(host_q, args.k + 1)
+    ids_equal = sum(int(np.array_equal(labels[row[i, :args.k]], cpu_res[i][1])) for i in range(nq))
+    parity = {"ids_equal_frac": ids_equal / nq, "queries": nq, "rows": s_rows, "against": "plain-C port on a row prefix"}
     return baseline, parity
 
 
@@ -329,6 +369,7 @@ def prefilter_leg(args, ix, queries: torch.Tensor, device, kk: int):
 
 
 def main():
+    t_start = time.perf_counter()
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -350,6 +391,11 @@ def main():
 
     metric_id = capi.METRICS[args.metric]
     kk = args.k + 1  # the Map asks for k+1 to detect a distance tie straddling the k-th boundary
+    strong = args.scaling == "strong"
+    if strong:   # BASELINE configs[3]: the corpus is FIXED (80M rows) and split into row ranges, one per rank
+        if args.total_rows % world:
+            raise SystemExit("--total-rows must be divisible by the number of ranks")
+        args.rows = args.total_rows // world
     corpus = make_corpus(args.rows, args.dim, 20260924 + rank, device)
     total_q = args.steps + args.warmup
     gq = torch.Generator(device=device)
@@ -399,23 +445,31 @@ def main():
     ix.profile_enable(False)
 
     qps_global = args.steps / elapsed            # queries/s over the whole (N x rows) corpus
-    value = qps_global * world                   # aggregate in 10M-row-shard scans/s (== queries/s at N = 1)
+    # weak: aggregate in rows-per-GPU-shard scans/s (== queries/s at N = 1); strong: queries/s over the fixed corpus
+    value = qps_global if strong else qps_global * world
     algo_bytes = args.rows * args.dim * 4        # N*D*4 per query (labels/norms excluded)
     avg_scan_s = (scan_ms / 1e3) / max(launches, 1)
     achieved = algo_bytes / avg_scan_s / 1e9 if launches else 0.0
 
     if rank == 0:
         traffic = pmc_traffic(algo_bytes)
+        if strong:
+            workload = (f"brute-force KNN, {args.total_rows} x {args.dim} fp32 FIXED corpus row-sharded over {world} GPU(s) ({args.rows} rows each), "
+                        f"metric={args.metric}, k={args.k}, batch=1 (BASELINE configs[3], strong scaling)")
+        else:
+            workload = (f"brute-force KNN, {args.rows} x {args.dim} fp32 per GPU, metric={args.metric}, k={args.k}, batch=1 "
+                        f"(BASELINE configs[1]{'; x' + str(world) + ' row-sharded = configs[3]' if world > 1 else ''})")
         result = {
             "metric": "knn_queries_per_sec", "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"brute-force KNN, {args.rows} x {args.dim} fp32 per GPU, metric={args.metric}, k={args.k}, batch=1 "
-                            f"(BASELINE configs[1]{'; x' + str(world) + ' row-sharded = configs[3]' if world > 1 else ''})",
+                "workload": workload,
                 "rows_per_gpu": args.rows, "total_rows": args.rows * world, "dim": args.dim, "k": args.k, "batch": 1,
-                "sharding": "row-range shards, RCCL all-gather of per-shard top-k + merge" if world > 1 else "none",
-                "value_definition": "queries/s over the full corpus x n_gpus (each query scans one rows_per_gpu shard per GPU)",
+                "sharding": "row-range shards, RCCL all-gather of per-shard top-k + merge" if dist_on else "none",
+                "rccl_ranks": (dist.get_world_size() if dist_on else 0),
+                "value_definition": ("queries/s over the fixed corpus" if strong else
+                                     "queries/s over the full corpus x n_gpus (each query scans one rows_per_gpu shard per GPU)"),
                 "qps_over_full_corpus": qps_global, "arch": capi.device_arch(local_rank),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -423,28 +477,51 @@ def main():
                          "kernel": "knn_scan_fixed", "launches": launches, "avg_ms": avg_scan_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
-        if world == 1 and args.batch > 1:
+
+        def budget_left() -> float:
+            return args.time_budget - (time.perf_counter() - t_start)
+
+        def leg(name: str, need_s: float, fn):
+            """Extra legs never take the bench line down: an exception or an exhausted time budget is recorded in place of the result."""
+            if budget_left() < need_s:
+                return {"skipped": f"time budget: {budget_left():.0f} s left, leg needs ~{need_s:.0f} s (--time-budget)"}
+            t0 = time.perf_counter()
             try:
-                result["batched"] = batched_leg(args, ix, queries, device, kk)
+                out = fn()
             except Exception as e:
-                result["batched"] = {"error": repr(e)}
-            try:
-                result["pruned_scan"] = pruned_leg(args, ix, queries, device, kk)
-            except Exception as e:
-                result["pruned_scan"] = {"error": repr(e)}
-            try:
-                result["prefilter"] = prefilter_leg(args, ix, queries, device, kk)
-            except Exception as e:
-                result["prefilter"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu:
-            try:
-                base, parity = cpu_baseline_and_parity(args, corpus, queries, metric_id)
-                result["cpu_baseline"] = base
-                result["parity"] = parity
-            except Exception as e:  # the bench line must still be printed
-                result["cpu_baseline"] = {"value": None, "error": repr(e)}
+                out = {"error": repr(e)}
+            if isinstance(out, dict):
+                out.setdefault("leg_seconds", time.perf_counter() - t0)
+            return out
+
+        extra = world == 1 and not strong
+        if extra and args.batch > 1:
+            result["batched"] = leg("batched", 5, lambda: batched_leg(args, ix, queries, device, kk))
+            result["pruned_scan"] = leg("pruned_scan", 5, lambda: pruned_leg(args, ix, queries, device, kk))
+            result["prefilter"] = leg("prefilter", 5, lambda: prefilter_leg(args, ix, queries, device, kk))
+        if extra and not args.no_cpu:
+            out = leg("cpu_baseline", 60, lambda: cpu_baseline_and_parity(args, corpus, queries, metric_id, ix))
+            if isinstance(out, tuple):
+                result["cpu_baseline"], result["parity"] = out
+            else:
+                result["cpu_baseline"] = {"value": None, **out}
+        if extra and (args.hnsw_rows or args.hybrid_docs):
+            # the other configs need the HBM the headline corpus holds only partly, but host RAM and time are shared: release first
+            ix.close()
+            ix = None
+            corpus = None
+            torch.cuda.empty_cache()
+        if extra and args.hnsw_rows:
+            import bench_hnsw
+            need = 25 + 130 * args.hnsw_rows / 1e6
+            result["hnsw"] = leg("hnsw", need, lambda: bench_hnsw.run(dict(rows=args.hnsw_rows, queries=args.hnsw_queries, device=local_rank)))
+        if extra and args.hybrid_docs:
+            import bench_hybrid
+            result["hybrid"] = leg("hybrid", 20 + 14 * args.hybrid_docs / 1e6, lambda: bench_hybrid.run(dict(docs=args.hybrid_docs, device=local_rank)))
+        result["bench_wall_seconds"] = time.perf_counter() - t_start
         print(json.dumps(result), flush=True)
-    ix.close()
+    if ix is not None:
+        ix.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

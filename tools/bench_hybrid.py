@@ -2,18 +2,24 @@
 """BASELINE configs[4]: hybrid query = ft_fast BM25 merge over a 5M-document inverted index + cosine KNN over 5M x 512 vectors (k = 100),
 fused with RRF (rank_const 60) — the pipeline of hybrid.md's `ORDER BY RRF()` on one MI355X.
 
-    python tools/bench_hybrid.py --docs 5000000 --dim 512 --queries 20 [--out profiles/r1_hybrid_5m.json]
+    python tools/bench_hybrid.py --docs 5000000 --dim 512 --queries 20 [--out profiles/r2_hybrid_5m.json]
+
+Also imported by bench.py (`run(opts)`), which puts the same leg into the driver-run bench line.
 
 Per query: 1-3 query words (each with an exact and a stem variant, document frequencies 10 % / 3 % / 1 % / 0.3 %), one query vector.
-GPU: GpuFtMerger (single-term: mergeSimple, multi-term: OR terms through mergeTerm) + GpuBruteforceMap::select (k = 100 takes the exact
-radix-select path) + host rank fusion.  CPU: the same pipeline from the restated checkers on a sample of the queries, and parity of both
-halves (documents + ranks of the FT merge, ids of the KNN)."""
+GPU: GpuFtMerger (single-term: mergeSimple, multi-term: OR terms through mergeTerm) + GpuBruteforceMap::select (k = 100) + host rank
+fusion (hybrid_rerank.h).
+CPU baseline (cpu_baseline.kind "reference" when oracle/_ref is there): the SAME pipeline from the reference's own code compiled in
+place — ft::Merger (libref_ft.so), hnswlib::BruteforceSearch over the FULL corpus (libref_oracle.so, AVX-512) and
+SelectIteratorContainer::MergerRankedImpl (libref_rank.so) — one core, `cpu_queries` queries, measured (no scaling).
+Parity on those queries: FT documents + ranks, KNN ids + distance bits, fused ids + rank bits, each half against the reference's."""
 import argparse
 import json
 import os
 import sys
 import time
 from pathlib import Path
+from types import SimpleNamespace
 
 import numpy as np
 
@@ -25,23 +31,20 @@ os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
 from bench_bm25 import pos_postings  # noqa: E402
 from reindexer_amd import hostapi  # noqa: E402
 
+DEFAULTS = dict(docs=5_000_000, dim=512, queries=20, k=100, cpu_queries=8, device=0, out=None)
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--docs", type=int, default=5_000_000)
-    ap.add_argument("--dim", type=int, default=512)
-    ap.add_argument("--queries", type=int, default=20)
-    ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--cpu-queries", type=int, default=2)
-    ap.add_argument("--out", default=None)
-    args = ap.parse_args()
+
+def run(o) -> dict:
+    import torch
+    o = SimpleNamespace(**{**DEFAULTS, **(vars(o) if not isinstance(o, dict) else o)})
+    t_all = time.perf_counter()
     rng = np.random.default_rng(20260926)
-    total = args.docs + 1   # vdoc 0 = the empty sentinel; vdoc i <-> vector row i
+    total = o.docs + 1   # vdoc 0 = the empty sentinel; vdoc i <-> vector row i
     # ---- full-text side
     words = rng.integers(20, 61, (total, 1)).astype(np.float32)
     words[0] = 0
     avg = words[1:].mean(axis=0).astype(np.float32)
-    ftm = hostapi.GpuFtMerger(1)
+    ftm = hostapi.GpuFtMerger(1, device=o.device)
     ftm.set_docs(words, avg)
     vocab = []   # (exact sub-term, stem sub-term) per query word
     wid = 0
@@ -53,24 +56,27 @@ def main():
             pair.append((wid, s))
             wid += 1
         vocab.append(pair)
-    # ---- vector side
+    # ---- vector side: generated on the GPU, handed to the Map in chunks (host mirror + HBM upload, like upserts)
     t0 = time.perf_counter()
-    vm = hostapi.GpuBruteforceMap(2, args.dim, total)
-    step = 250_000
-    rows_sample = None
+    dev = torch.device("cuda", o.device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(20260926)
+    vm = hostapi.GpuBruteforceMap(2, o.dim, total, device=o.device)
+    labels = np.arange(total, dtype=np.uint64) << np.uint64(32)
+    rows_host = np.empty((total, o.dim), np.float32)
+    step = 500_000
     for a in range(0, total, step):
         b = min(total, a + step)
-        chunk = rng.normal(0, 0.25, (b - a, args.dim)).astype(np.float32)
+        chunk = torch.empty((b - a, o.dim), dtype=torch.float32, device=dev).normal_(0.0, 0.25, generator=g).cpu().numpy()
         if a == 0:
             chunk[0] = 1.0
-        vm.add(chunk, np.arange(a, b, dtype=np.uint64) << np.uint64(32))
-        if rows_sample is None:
-            rows_sample = chunk
+        rows_host[a:b] = chunk
+        vm.add(chunk, labels[a:b])
     load_s = time.perf_counter() - t0
-    keys = rng.normal(0, 0.25, (args.queries, args.dim)).astype(np.float32)
+    keys = torch.empty((o.queries, o.dim), dtype=torch.float32, device=dev).normal_(0.0, 0.25, generator=g).cpu().numpy()
     cfg, opts = hostapi.default_ft_config(1), hostapi.default_ft_opts(1)
     plans = []
-    for q in range(args.queries):
+    for q in range(o.queries):
         nw = int(rng.integers(1, 4))
         plans.append([int(x) for x in rng.choice(len(vocab), nw, replace=False)])
 
@@ -83,7 +89,7 @@ def main():
             terms = [dict(op=1, opts=opts, subs=[(w, s["proc"]) for w, s in vocab[p]]) for p in plan]
             fid, fproc, _, _, _ = ftm.merge_query(cfg, terms, sort_by_rank=True)
         t.append(time.perf_counter())
-        kid, krank = vm.select(keys[q], k=args.k, need_sort=False)
+        kid, krank = vm.select(keys[q], k=o.k, need_sort=False)
         t.append(time.perf_counter())
         # the FT result goes in as the merger returns it (best rank first): id view + RRF positions are derived inside the fusion
         ids, ranks = hostapi.merge_ranked("rrf", [60.0], kid, krank, fid, fproc, union=True, desc=True, metric=2, ft_order="rank")
@@ -94,69 +100,93 @@ def main():
     t0 = time.perf_counter()
     parts = np.zeros(3)
     results = []
-    for q in range(args.queries):
+    for q in range(o.queries):
         r, dt = run_gpu(q)
         results.append(r)
         parts += dt
     gpu_s = time.perf_counter() - t0
-    out = {"workload": f"hybrid RRF: ft_fast BM25 (1-3 OR terms x 2 sub-terms) over {args.docs} vdocs + cosine KNN k={args.k} over {args.docs} x {args.dim}, union fusion",
+    out = {"workload": f"hybrid RRF: ft_fast BM25 (1-3 OR terms x 2 sub-terms) over {o.docs} vdocs + cosine KNN k={o.k} over {o.docs} x {o.dim}, union fusion "
+                       "(BASELINE configs[4])",
            "load_seconds": load_s,
-           "gpu": {"queries_per_sec": args.queries / gpu_s, "ms_per_query": gpu_s / args.queries * 1e3,
-                   "ms_ft_merge": parts[0] / args.queries * 1e3, "ms_knn_select": parts[1] / args.queries * 1e3, "ms_fusion": parts[2] / args.queries * 1e3,
+           "gpu": {"queries": o.queries, "queries_per_sec": o.queries / gpu_s, "ms_per_query": gpu_s / o.queries * 1e3,
+                   "ms_ft_merge": parts[0] / o.queries * 1e3, "ms_knn_select": parts[1] / o.queries * 1e3, "ms_fusion": parts[2] / o.queries * 1e3,
                    "fused_results_avg": float(np.mean([len(r[4]) for r in results]))}}
-    try:   # CPU side on a sample: restated merger + exact CPU scan over the first rows (the KNN parity is checked on that prefix)
-        from oracle.pyoracle import FtOracle, Oracle
-        orc = Oracle()
-        ft = FtOracle(orc)
-        nq = min(args.cpu_queries, args.queries)
-        t0 = time.perf_counter()
-        same_ft = 0
-        for q in range(nq):
-            plan = plans[q]
-            if len(plan) == 1:
-                from oracle.pyoracle import positions_to_entries
-                subs = [dict(positions_to_entries(s), proc=s["proc"]) for _, s in vocab[plan[0]]]
-                wid_, wproc, _, _ = ft.merge_simple(cfg, opts, total, words, avg, None, None, subs, sort_by_rank=True)
-            else:
-                terms = [dict(op=1, opts=opts, subs=[s for _, s in vocab[p]]) for p in plan]
-                wid_, wproc, _, _, _ = ft.merge_query(cfg, terms, total, words, avg, None, None, sort_by_rank=True)
-            g = results[q]
-            a, b = np.argsort(g[0], kind="stable"), np.argsort(wid_, kind="stable")
-            same_ft += int(np.array_equal(g[0][a].astype(np.uint32), wid_[b].astype(np.uint32)) and np.array_equal(g[1][a], wproc[b]))
-        cpu_ft_s = (time.perf_counter() - t0) / nq
-        # KNN: time the CPU engine's scan on the resident prefix, scale to the corpus (linear scan); the real reference engine (AVX-512) if present
-        pre = rows_sample
+    nq = min(o.cpu_queries, o.queries)
+    try:
         from oracle import pyoracle
         ref = pyoracle.ref_or_none()
-        knn_kind = "port"
-        if ref is not None and ref.simd_level == 3:
-            rb = pyoracle.RefBruteforce(ref, 2, args.dim, pre.shape[0])
-            rb.add(pre, np.arange(pre.shape[0], dtype=np.uint64) << np.uint64(32))
+        rft = pyoracle.ref_ft_or_none(1)
+        rrank = pyoracle.ref_rank_or_none()
+        if ref is None or ref.simd_level != 3 or rft is None or rrank is None:
+            raise RuntimeError("oracle/_ref incomplete (needs libref_oracle.so with AVX-512, libref_ft.so, libref_rank.so)")
+        rft.set_docs(words, avg, None)
+        for pair in vocab:
+            for w, s in pair:
+                rft.set_word_fpos(w, s)
+        rft.set_config(cfg)
+        rb = pyoracle.RefBruteforce(ref, 2, o.dim, total)
+        rb.add(rows_host, labels)
+        orc = pyoracle.Oracle()
+        t_ft = t_knn = t_fuse = 0.0
+        same_ft = same_knn = same_fused = 0
+        for q in range(nq):
+            plan = plans[q]
+            terms = [dict(op=1, opts=opts, subs=[(w, s["proc"]) for w, s in vocab[p]]) for p in plan]
             t0 = time.perf_counter()
-            for q in range(nq):
-                rb.search_knn(keys[q], args.k)
-            cpu_knn_s = (time.perf_counter() - t0) / nq * (total / pre.shape[0])
-            knn_kind = "reference"
-            rb.close()
-        else:
-            inv = orc.l2_modules(pre)
-            t0 = time.perf_counter()
-            for q in range(nq):
-                qn, _ = orc.normalize_copy(keys[q])
-                orc.dist_many(2, qn, pre, inv)
-            cpu_knn_s = (time.perf_counter() - t0) / nq * (total / pre.shape[0])
-        out["cpu_baseline"] = {"kind": "port (ft merge) + " + knn_kind + " (knn scan)", "cores": 1, "unit": "queries/s", "value": 1.0 / (cpu_ft_s + cpu_knn_s), "ms_ft_merge": cpu_ft_s * 1e3,
-                               "ms_knn_scan_scaled": cpu_knn_s * 1e3, "sample": f"{nq} queries; KNN scan timed on a {pre.shape[0]}-row prefix and scaled"}
-        same_fusion = 0
-        for q in range(nq):   # the fused list against the id-ordered entry fed with an explicitly sorted FT result
+            rd, rp, rf, rn = rft.merge(terms, None, rank_sort_type=1, cap=1 << 17)
+            t1 = time.perf_counter()
+            qn, _ = orc.normalize_copy(keys[q])      # HnswIndexBase::search normalises the key for cosine (hnsw_index.cc:166-173)
+            kd, kl = rb.search_knn(qn, o.k)
+            t2 = time.perf_counter()
             fid, fproc, kid, krank, ids, ranks = results[q]
-            o = np.argsort(fid, kind="stable")
-            wi, wr = hostapi.merge_ranked("rrf", [60.0], kid, krank, fid[o].astype(np.int32), fproc[o], union=True, desc=True, metric=2)
-            same_fusion += int(np.array_equal(wi, ids) and np.array_equal(wr.view(np.uint32), ranks.view(np.uint32)))
-        out["parity"] = {"ft_identical_frac": same_ft / nq, "checked": nq, "fusion_identical_frac": same_fusion / nq,
-                         "knn": "ids and ranks of GpuBruteforceMap::select are covered bit-exact by tests/test_gpu_hybrid.py and the brute-force suites"}
+            # FT half: same documents with the same uint8 ranks
+            a, b = np.argsort(fid, kind="stable"), np.argsort(rd, kind="stable")
+            ft_ok = np.array_equal(fid[a].astype(np.uint32), rd[b].astype(np.uint32)) and np.array_equal(fproc[a].astype(np.float32), rn[b].astype(np.float32))
+            # KNN half: row ids best-first; ranks = -distance for cosine (selectRaw, hnsw_index.cc:205-222)
+            knn_ok = np.array_equal(kid.astype(np.int64), (kl >> np.uint64(32)).astype(np.int64)) and np.array_equal(
+                krank.astype(np.float32).view(np.uint32), (-kd).astype(np.float32).view(np.uint32))
+            # fusion by the reference's merger, fed with the reference's two halves
+            t3 = time.perf_counter()
+            by_id = np.argsort(rd, kind="stable")
+            order = np.argsort(-rn.astype(np.float32), kind="stable")
+            pos = np.zeros(rd.shape[0], np.uint64)
+            pos[order] = rrank.rrf_positions(rn.astype(np.float32)[order])
+            wi, wr = rrank.merge("rrf", [60.0], (kl >> np.uint64(32)).astype(np.int32), (-kd).astype(np.float32), rd[by_id].astype(np.int32),
+                                 rn[by_id].astype(np.float32), union=True, desc=True, metric=2, ft_positions=pos[by_id])
+            t4 = time.perf_counter()
+            fused_ok = np.array_equal(wi, ids) and np.array_equal(wr.view(np.uint32), ranks.view(np.uint32))
+            same_ft += int(ft_ok)
+            same_knn += int(knn_ok)
+            same_fused += int(fused_ok)
+            t_ft += t1 - t0
+            t_knn += t2 - t1
+            t_fuse += t4 - t3
+        per_q = (t_ft + t_knn + t_fuse) / nq
+        out["cpu_baseline"] = {"kind": "reference", "cores": 1, "unit": "queries/s", "value": 1.0 / per_q, "ms_ft_merge": t_ft / nq * 1e3,
+                               "ms_knn_scan": t_knn / nq * 1e3, "ms_fusion": t_fuse / nq * 1e3,
+                               "sample": f"{nq} of the same queries, measured (full {o.docs}-row corpus, no scaling): reference ft::Merger + "
+                                         "BruteforceSearch (AVX-512) + MergerRankedImpl, compiled in place (oracle/_ref)"}
+        out["parity"] = {"checked": nq, "ft_identical_frac": same_ft / nq, "knn_identical_frac": same_knn / nq, "fused_identical_frac": same_fused / nq,
+                         "against": "reference ft::Merger / BruteforceSearch / MergerRankedImpl"}
+        rb.close()
+        rft.close()
     except Exception as e:
         out["cpu_baseline"] = {"error": repr(e)}
+    out["leg_seconds"] = time.perf_counter() - t_all
+    ftm.close()
+    vm.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    for k, v in DEFAULTS.items():
+        if v is None:
+            ap.add_argument("--" + k.replace("_", "-"), default=None)
+        else:
+            ap.add_argument("--" + k.replace("_", "-"), type=type(v), default=v)
+    args = ap.parse_args()
+    out = run(args)
     text = json.dumps(out)
     print(text)
     if args.out:
