@@ -1,0 +1,620 @@
+// ft_fast merge on gfx950: Merger::Merge (cpp_src/core/ft/ft_fast/mergerimpl.h:466-566) for queries made of terms — mergeSimple (:194-250)
+// for a Simple() query, buildRestrictingBitmask (:326-384) + the 2-phase gate / preselectMostRelevantDocs (:386-464, 486-490) + mergeTerm
+// (:107-192) otherwise.  Phrases and multi-word synonyms stay on the CPU merger.
+//
+// The reference walks (term, sub-term, posting) sequentially and is order dependent in three places.  Round 1 reproduced that order with
+// one launch per sub-term (9 + 9 launches and as many fills for a 3 x 3 query: launch-latency bound, 5-11 % of HBM).  Here the same
+// RESULT is derived order-free, so a whole query is a fixed number of launches, each over ALL postings of the query:
+//
+//  * pre-score (calcTermScores :289-324): inside a term the FIRST sub-term containing a document contributes its proc16, across terms the
+//    contributions add with saturation.  `first` = atomicMax of (4095 - sub-term ordinal) << 16 | proc16 per (term, document); a saturating
+//    sum of non-negative values does not depend on the order  ->  ft_scan + ft_score.
+//  * admission (addDoc until maxMergedDocs, merger.h:161-180): a document is added by its first posting (in global posting order) that is
+//    eligible and has a non-zero rank; it gets the next merge slot if fewer than maxMergedDocs documents were added before it, and once the
+//    limit is hit nothing is added any more.  `first posting` = atomicMin of the global posting index per document; `slot` = ORDERED prefix
+//    count over those postings (ticket-ordered workgroups, decoupled look-back), cut at maxMergedDocs  ->  ft_rank_all + ft_assign_slots.
+//  * per-document state (`proc -= rank; proc += finalRank` on every strict improvement, switchToNextWord between terms, termsCounter):
+//    a document meets at most one posting per sub-term, so its postings are scattered into a per-slot row indexed by sub-term
+//    (ft_scatter: unique cells, no atomics) and ONE thread per merged document replays its row in sub-term order with the reference's
+//    float operations (ft_replay)  ->  same bits.
+//  * preselect ties at the threshold score are kept in document order: ordered prefix again (ft_preselect_apply).
+//
+// Launch train of a multi-term query: ft_init, [ft_scan, ft_combine, [ft_score, ft_preselect_pick, ft_preselect_apply]], ft_rank_all,
+// ft_assign_slots, ft_scatter, ft_replay; the 2-phase gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result
+// leaves in one packed buffer.  A Simple() query: ft_init, ft_rank_all, ft_assign_slots, ft_scatter, ft_replay.
+//
+// Bound: HBM gathers: per posting 4 B doc + 8 B entry offsets + 9 B per (field, tf, firstPos) entry streamed, 4 B
+// words-in-field + the mask word gathered, 5 B rank/field written and read back, 4 B atomicMin on the first-posting table.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "rxgpu_internal.h"
+#include "ft_rank.hip.h"
+
+namespace rxgpu {
+
+namespace {
+
+constexpr unsigned long long kLbPrefix = 1ull << 63;
+constexpr unsigned long long kLbAggregate = 1ull << 62;
+constexpr uint32_t kNoPosting = 0xFFFFFFFFu;
+constexpr uint32_t kBestPresent = 1u << 31;
+
+__device__ __forceinline__ bool mask_bit(const uint32_t* m, uint32_t d) { return (m[d >> 5] >> (d & 31)) & 1u; }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t o = __shfl_up(v, off, 64);
+		if (lane >= off) v += o;
+	}
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+// Exclusive prefix of `count` over ALL threads of ALL workgroups in ticket order (256 threads per workgroup).
+// lookback[] is zeroed before the launch; *grand_incl = inclusive total up to and including this workgroup.
+__device__ uint32_t ordered_prefix(uint32_t count, uint32_t ticket, unsigned long long* lookback, uint32_t* error_flag, uint32_t* grand_incl) {
+	__shared__ uint32_t s_wave_tot[4];
+	__shared__ uint32_t s_block_excl;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const uint32_t incl = wave_inclusive_scan(count, lane);
+	if (lane == 63) s_wave_tot[wave] = incl;
+	__syncthreads();
+	uint32_t before = 0;
+	for (int w = 0; w < wave; ++w) before += s_wave_tot[w];
+	const uint32_t block_total = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
+	if (wave == 0) {
+		if (lane == 0) {
+			__hip_atomic_store(&lookback[ticket], (ticket == 0 ? kLbPrefix : kLbAggregate) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		uint32_t excl = 0;
+		long long j = (long long)ticket - 1;   // nearest predecessor
+		while (j >= 0) {
+			const long long idx = j - lane;
+			unsigned long long st = 0;
+			if (idx >= 0) {
+				uint32_t spins = 0;
+				do {
+					st = __hip_atomic_load(&lookback[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (st) break;
+					__builtin_amdgcn_s_sleep(1);
+					if ((++spins & 1023u) == 0 &&
+						(spins > (1u << 24) || __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+						__hip_atomic_store(error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // never hang the GPU: bail out, the host reports it
+						st = kLbPrefix;
+						break;
+					}
+				} while (true);
+			}
+			const unsigned long long pm = __ballot(idx >= 0 && (st & kLbPrefix));
+			const int first = pm ? __ffsll((long long)pm) - 1 : 63;
+			excl += wave_sum((idx >= 0 && lane <= first) ? uint32_t(st & 0xFFFFFFFFull) : 0u);
+			if (pm) break;
+			j -= 64;
+		}
+		if (lane == 0) {
+			if (ticket != 0) __hip_atomic_store(&lookback[ticket], kLbPrefix | (unsigned long long)(excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			s_block_excl = excl;
+		}
+	}
+	__syncthreads();
+	const uint32_t be = s_block_excl;
+	*grand_incl = be + block_total;
+	__syncthreads();   // the shared words are reused by the caller's next call
+	return be + before + (incl - count);
+}
+
+__device__ __forceinline__ uint32_t grab_ticket(uint32_t* ticket) {
+	__shared__ uint32_t s_ticket;
+	if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
+	__syncthreads();
+	return s_ticket;
+}
+
+// block of a posting-side grid -> its sub-term (every entry owns at least one block; entries ascend by block_base)
+__device__ __forceinline__ FtGridEntry grid_entry(const FtGridEntry* g, uint32_t n, uint32_t block) {
+	uint32_t lo = 0, hi = n - 1;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi + 1) >> 1;
+		if (g[mid].block_base <= block) {
+			lo = mid;
+		} else {
+			hi = mid - 1;
+		}
+	}
+	return g[lo];
+}
+
+// The doc ids of a thread's kFtPassItems consecutive postings (one 16-byte load away from the tail)
+__device__ __forceinline__ void load_docs(const FtPosSubterm& s, uint64_t i0, uint32_t (&docs)[kFtPassItems], bool (&live)[kFtPassItems]) {
+	static_assert(kFtPassItems == 4, "the vector load reads four document ids");
+	if (i0 + kFtPassItems <= s.n) {
+		const uint4 v = *reinterpret_cast<const uint4*>(s.doc + i0);   // i0 % 4 == 0 and the list is 256-byte aligned
+		docs[0] = v.x;
+		docs[1] = v.y;
+		docs[2] = v.z;
+		docs[3] = v.w;
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) live[k] = true;
+	} else {
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) {
+			live[k] = i0 + k < s.n;
+			docs[k] = live[k] ? s.doc[i0 + k] : 0u;
+		}
+	}
+}
+
+__device__ __forceinline__ void fill_words(uint32_t* ptr, uint64_t n, uint32_t value, uint64_t gtid, uint64_t gsize) {
+	if (!ptr || !n) return;
+	const uint64_t n4 = n / 4;
+	uint4* p4 = reinterpret_cast<uint4*>(ptr);   // every scratch region starts on a 256-byte boundary
+	const uint4 v = make_uint4(value, value, value, value);
+	for (uint64_t i = gtid; i < n4; i += gsize) p4[i] = v;
+	for (uint64_t i = n4 * 4 + gtid; i < n; i += gsize) ptr[i] = value;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- per-merge scratch state
+// restrictingMask_ = ~docsExcluded_ (mergerimpl.h:328-330; bits past total_docs stay 0 so that a popcount is exact) + every table the
+// merge reads before it writes: AND / NOT bit arrays, pre-score words, histogram, first-posting table, entry rows, synchronisation words.
+__global__ __launch_bounds__(256) void ft_init(FtPlan p) {
+	const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, gsize = uint64_t(gridDim.x) * blockDim.x;
+	for (uint64_t w = gtid; w < p.nwords; w += gsize) {
+		const uint64_t d0 = w * 32;
+		uint32_t bits = 0;
+		const uint32_t cnt = uint32_t(p.total_docs - d0 < 32 ? p.total_docs - d0 : 32);
+		if (!p.excluded) {
+			bits = cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
+		} else {
+			for (uint32_t b = 0; b < cnt; ++b) bits |= (p.excluded[d0 + b] ? 0u : 1u) << b;
+		}
+		p.mask[w] = bits;
+	}
+	fill_words(p.and_masks, uint64_t(p.n_and) * p.nwords, 0u, gtid, gsize);
+	fill_words(p.not_mask, p.not_mask ? p.nwords : 0, 0u, gtid, gsize);
+	if (p.prescore) {
+		fill_words(p.best, uint64_t(p.n_best) * p.total_docs, 0u, gtid, gsize);
+		fill_words(p.hist, 65536, 0u, gtid, gsize);
+		fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 255) / 256) * 2, 0u, gtid, gsize);
+	}
+	fill_words(p.first, p.total_docs, kNoPosting, gtid, gsize);
+	fill_words(reinterpret_cast<uint32_t*>(p.e_rank), uint64_t(p.n_rows) * p.max_merged, 0u, gtid, gsize);
+	fill_words(reinterpret_cast<uint32_t*>(p.lookback_slots), uint64_t(p.merge_blocks) * 2, 0u, gtid, gsize);
+	fill_words(p.sync, kFtSyncWords, 0u, gtid, gsize);
+}
+
+// ---------------------------------------------------------------------------------------------- restricting bitmask + pre-scores
+// One pass over the postings of every term that needs one:
+//   AND term  calcTermBitmask (mergerimpl.h:252-274): any occurrence with a relevant field (checkFieldsRelevance, phrasemergerimpl.h:93-125)
+//   NOT term  excludeTermFromBitmask (:276-287)
+//   pre-score calcTermScores (:289-324) for every term that is not a NOT, when the host half of the 2-phase gate held
+__global__ __launch_bounds__(256) void ft_scan(FtPlan p) {
+	const FtGridEntry ge = grid_entry(p.scan_grid, p.n_scan_entries, blockIdx.x);
+	const FtPosSubterm& s = p.subs[ge.sub];
+	const FtTermCfg& t = p.terms[s.term];
+	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	if (i0 >= s.n) return;
+	uint32_t docs[kFtPassItems];
+	bool live[kFtPassItems];
+	load_docs(s, i0, docs, live);
+	const int op = t.op;
+	const bool want_score = p.prescore && op != 3;
+	const bool need_entries = (op == 2 && !t.all_pos_boost) || (want_score && !t.same_boost);
+	const uint32_t ord_key = kBestPresent | ((4095u - uint32_t(s.ord_in_term)) << 16);
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) {
+		if (!live[k]) continue;
+		const uint32_t d = docs[k];
+		if (op == 3) {
+			atomicOr(&p.not_mask[d >> 5], 1u << (d & 31));
+			continue;
+		}
+		bool rel = t.all_pos_boost;
+		float mb = t.field_boost[0];
+		if (need_entries) {   // maxFieldsBoost (phrasemergerimpl.h:127-160) / relevance of the occurrence
+			mb = 0.0f;
+			rel = false;
+			for (uint32_t e = s.ent_off[i0 + k], e1 = s.ent_off[i0 + k + 1]; e < e1; ++e) {
+				const float fb = t.field_boost[s.ent_field[e]];
+				mb = fmaxf(mb, fb);
+				rel = rel || fb != 0.0f;
+			}
+			if (t.same_boost) mb = t.field_boost[0];
+			if (t.all_pos_boost) rel = true;
+		}
+		if (op == 2 && rel) atomicOr(&p.and_masks[uint64_t(t.and_idx) * p.nwords + (d >> 5)], 1u << (d & 31));
+		if (want_score && mb > 0.0f) {
+			const float proc = s.proc * mb * t.opts_boost;
+			uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
+			p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
+			atomicMax(&p.best[uint64_t(t.best_idx) * p.total_docs + d], ord_key | p16);
+		}
+	}
+}
+
+// restrictingMask_ &= termMask for every AND term, minus the NOT terms (buildRestrictingBitmask); popcount for the 2-phase gate
+__global__ __launch_bounds__(256) void ft_combine(FtPlan p) {
+	uint32_t c = 0;
+	for (uint64_t w = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; w < p.nwords; w += uint64_t(gridDim.x) * blockDim.x) {
+		uint32_t m = p.mask[w];
+		for (uint32_t a = 0; a < p.n_and; ++a) m &= p.and_masks[uint64_t(a) * p.nwords + w];
+		if (p.not_mask) m &= ~p.not_mask[w];
+		p.mask[w] = m;
+		c += __popc(m);
+	}
+	c = wave_sum(c);
+	if ((threadIdx.x & 63) == 0 && c) atomicAdd(&p.sync[kFtSyncPop], c);
+}
+
+// ---------------------------------------------------------------------------------------------- preselect
+__device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerimpl.h:486-490, the half only the device knows
+	return p.prescore && __hip_atomic_load(&p.sync[kFtSyncPop], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > p.merge_limit;
+}
+
+// docsScore[d] = saturating sum over the terms of the first sub-term's proc16; masked-out / removed documents score 0 (mergerimpl.h:416-423);
+// histogram of the rest.  Scores take few distinct values, so the counts are aggregated per wave, then per workgroup in a small LDS table,
+// and only then added to the global histogram.
+__global__ __launch_bounds__(256) void ft_score(FtPlan p) {
+	if (!ft_preselect_on(p)) return;
+	__shared__ uint32_t keys[256];
+	__shared__ uint32_t cnts[256];
+	keys[threadIdx.x] = 0;   // a score of 0 is never inserted
+	cnts[threadIdx.x] = 0;
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	for (uint64_t base = uint64_t(blockIdx.x) * 256; base < p.total_docs; base += uint64_t(gridDim.x) * 256) {
+		const uint64_t d = base + threadIdx.x;
+		uint32_t sc = 0;
+		if (d < p.total_docs) {
+			for (uint32_t t = 0; t < p.n_best; ++t) {
+				const uint32_t key = p.best[uint64_t(t) * p.total_docs + d];
+				sc += (key & kBestPresent) ? (key & 0xFFFFu) : 0u;
+			}
+			sc = sc < 65535u ? sc : 65535u;
+			if (sc && (!mask_bit(p.mask, uint32_t(d)) || (p.removed && p.removed[d]))) sc = 0;
+			p.score[d] = uint16_t(sc);
+		}
+		unsigned long long todo = __ballot(sc != 0);
+		while (todo) {
+			const int leader = __ffsll((long long)todo) - 1;
+			const uint32_t v = __shfl(sc, leader, 64);
+			const unsigned long long same = __ballot(sc == v);
+			if (lane == leader) {
+				const uint32_t c = uint32_t(__popcll(same));
+				uint32_t h = (v * 2654435761u) >> 24;
+				int probes = 0;
+				for (; probes < 256; ++probes, h = (h + 1) & 255u) {
+					const uint32_t old = atomicCAS(&keys[h], 0u, v);
+					if (old == 0u || old == v) {
+						atomicAdd(&cnts[h], c);
+						break;
+					}
+				}
+				if (probes == 256) atomicAdd(&p.hist[v], c);   // more than 256 distinct scores in one workgroup
+			}
+			todo &= ~same;
+		}
+	}
+	__syncthreads();
+	if (keys[threadIdx.x]) atomicAdd(&p.hist[keys[threadIdx.x]], cnts[threadIdx.x]);
+}
+
+// mergerimpl.h:433-446: walk the scores downwards until maxMergedDocs documents are covered
+__global__ __launch_bounds__(1024) void ft_preselect_pick(FtPlan p) {
+	if (!ft_preselect_on(p)) return;
+	__shared__ unsigned long long suffix[1024];
+	__shared__ uint32_t s_min;
+	const int t = threadIdx.x;
+	unsigned long long chunk = 0;
+	for (int b = 0; b < 64; ++b) chunk += p.hist[t * 64 + b];
+	suffix[t] = chunk;
+	if (t == 0) s_min = 0xFFFFFFFFu;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) {   // inclusive suffix sums
+		const unsigned long long v = t + off < 1024 ? suffix[t + off] : 0;
+		__syncthreads();
+		suffix[t] += v;
+		__syncthreads();
+	}
+	unsigned long long above = suffix[t] - chunk;   // documents with a score in a higher chunk
+	// a score sc is visited iff the documents strictly above it are fewer than maxMergedDocs; minScore = lowest visited score >= 1
+	uint32_t lowest = 0xFFFFFFFFu;
+	unsigned long long lowest_above = 0;
+	for (int b = 63; b >= 0; --b) {
+		const uint32_t sc = uint32_t(t * 64 + b);
+		if (sc >= 1 && above < p.max_merged) {
+			lowest = sc;
+			lowest_above = above;
+		}
+		above += p.hist[sc];
+	}
+	if (lowest != 0xFFFFFFFFu) atomicMin(&s_min, lowest);
+	__syncthreads();
+	uint32_t* pick = p.sync + kFtSyncPick;
+	if (s_min == 0xFFFFFFFFu) {
+		if (t == 0) {
+			pick[0] = 65535u;
+			pick[1] = 0;
+		}
+	} else if (lowest == s_min) {
+		pick[0] = lowest;
+		pick[1] = uint32_t(p.max_merged - lowest_above);
+	}
+}
+
+// mergerimpl.h:448-462: one thread per mask word; ties at minScore are kept in document order up to minScoreDocs
+__global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
+	if (!ft_preselect_on(p)) return;
+	const uint32_t ticket = grab_ticket(p.sync + kFtSyncPreTicket);
+	const uint64_t w = uint64_t(ticket) * 256 + threadIdx.x;
+	const uint32_t min_score = p.sync[kFtSyncPick], min_docs = p.sync[kFtSyncPick + 1];
+	uint32_t bits = 0, gt = 0, tie = 0;
+	if (w < p.nwords) {
+		bits = p.mask[w];
+		const uint64_t d0 = w * 32;
+		for (uint32_t b = 0; b < 32; ++b) {
+			if (!((bits >> b) & 1u)) continue;   // only masked-in documents are inspected; d0 + b < total_docs by construction
+			const uint32_t sc = p.score[d0 + b];
+			gt |= uint32_t(sc > min_score) << b;
+			tie |= uint32_t(sc == min_score) << b;
+		}
+	}
+	uint32_t grand;
+	const uint32_t excl = ordered_prefix(__popc(tie), ticket, p.lookback_pre, p.sync + kFtSyncError, &grand);
+	if (w < p.nwords) {
+		uint32_t allowed = min_docs > excl ? min_docs - excl : 0;
+		uint32_t keep = gt;
+		while (tie && allowed) {
+			const uint32_t low = tie & (0u - tie);
+			keep |= low;
+			tie ^= low;
+			--allowed;
+		}
+		if (keep != bits) p.mask[w] = keep;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------- mergeTerm / mergeSimple
+// calcTermRank of every eligible posting of the query (restrictingMask_, DocRemoved) and the first-posting table.
+// The gathers of one posting form a dependent chain (doc -> mask word -> removed flag -> entries -> words in field); the four postings
+// of a thread are independent, so each stage is issued for all four before anything is consumed.
+__global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
+	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
+	const FtPosSubterm& s = p.subs[ge.sub];
+	const FtTermCfg& t = p.terms[s.term];
+	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const uint64_t gp0 = uint64_t(blockIdx.x) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	uint32_t docs[kFtPassItems];
+	bool live[kFtPassItems];
+	if (i0 < s.n) {
+		load_docs(s, i0, docs, live);
+	} else {
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) live[k] = false;
+	}
+	{
+		uint32_t mw[kFtPassItems];
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) mw[k] = live[k] ? p.mask[docs[k] >> 5] : 0u;
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) live[k] = live[k] && ((mw[k] >> (docs[k] & 31)) & 1u);   // restrictingMask_
+	}
+	if (p.removed && p.check_removed && !ft_preselect_on(p)) {   // needToCheckRemoved_ is false once the preselect has run (mergerimpl.h:463)
+		uint8_t rm[kFtPassItems];
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) rm[k] = live[k] ? p.removed[docs[k]] : uint8_t(0);
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) live[k] = live[k] && !rm[k];
+	}
+	float ranks[kFtPassItems];
+	uint8_t fields[kFtPassItems];
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) {
+		ranks[k] = 0.f;
+		fields[k] = 0;
+		if (!live[k]) continue;
+		const uint64_t i = i0 + k;
+		ranks[k] = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], docs[k], &fields[k]);
+		if (ranks[k] != 0.0f) atomicMin(&p.first[docs[k]], uint32_t(gp0 + k));
+	}
+	*reinterpret_cast<float4*>(p.p_rank + gp0) = make_float4(ranks[0], ranks[1], ranks[2], ranks[3]);
+	*reinterpret_cast<uchar4*>(p.p_field + gp0) = make_uchar4(fields[0], fields[1], fields[2], fields[3]);
+}
+
+// addDoc order (merger.h:161-180): the postings that add a document take consecutive merge slots in global posting order, cut at maxMergedDocs
+__global__ __launch_bounds__(256) void ft_assign_slots(FtPlan p) {
+	const uint32_t ticket = grab_ticket(p.sync + kFtSyncSlotTicket);
+	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, ticket);
+	const FtPosSubterm& s = p.subs[ge.sub];
+	const uint64_t i0 = uint64_t(ticket - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const uint64_t gp0 = uint64_t(ticket) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const float4 rk = *reinterpret_cast<const float4*>(p.p_rank + gp0);
+	const float ranks[kFtPassItems] = {rk.x, rk.y, rk.z, rk.w};
+	uint32_t docs[kFtPassItems];
+	uint32_t c_mask = 0;
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) {
+		docs[k] = 0;
+		if (ranks[k] == 0.0f) continue;   // includes every posting past the end of the list
+		docs[k] = s.doc[i0 + k];
+		if (p.first[docs[k]] == uint32_t(gp0 + k)) c_mask |= 1u << k;
+	}
+	uint32_t grand;
+	uint32_t slot = ordered_prefix(__popc(c_mask), ticket, p.lookback_slots, p.sync + kFtSyncError, &grand);
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) {
+		if (!((c_mask >> k) & 1u)) continue;
+		if (slot < p.max_merged) {
+			p.out_doc[slot] = docs[k];
+			p.slot_of[docs[k]] = slot;
+		}
+		++slot;
+	}
+	if (ticket == gridDim.x - 1 && threadIdx.x == 0) p.sync[kFtSyncNumDocs] = grand < p.max_merged ? grand : p.max_merged;
+}
+
+// every posting of a merged document drops (rank, field, posting index) into the document's row, column = its sub-term
+__global__ __launch_bounds__(256) void ft_scatter(FtPlan p) {
+	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
+	const FtPosSubterm& s = p.subs[ge.sub];
+	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const uint64_t gp0 = uint64_t(blockIdx.x) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const float4 rk = *reinterpret_cast<const float4*>(p.p_rank + gp0);
+	const float ranks[kFtPassItems] = {rk.x, rk.y, rk.z, rk.w};
+	const uint32_t num_docs = p.sync[kFtSyncNumDocs];
+	uint32_t docs[kFtPassItems], slots[kFtPassItems];
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) docs[k] = ranks[k] != 0.0f ? s.doc[i0 + k] : 0u;
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) slots[k] = ranks[k] != 0.0f ? p.slot_of[docs[k]] : kNoPosting;
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) {
+		if (ranks[k] == 0.0f) continue;
+		const uint32_t sl = slots[k];
+		if (sl >= num_docs || p.out_doc[sl] != docs[k]) continue;   // sparse-set test: slot_of[] is never cleared
+		const uint64_t cell = uint64_t(s.row) * p.max_merged + sl;
+		p.e_rank[cell] = ranks[k];
+		p.e_idx[cell] = uint32_t(i0 + k);
+		p.e_field[cell] = p.p_field[gp0 + k];
+	}
+}
+
+// mergerimpl.h:20-37; fullPos()/fullField() truncate the 64-bit PosType to uint32_t exactly like the reference's accessors
+__device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb) {
+	unsigned res = 0xFFFFFFFFu;
+	uint32_t i = 0, j = 0;
+	while (i < na && j < nb) {
+		const uint64_t pa = a[i], pb = b[j];
+		const uint32_t fa = uint32_t(pa), fb = uint32_t(pb);
+		const bool sign = fa > fb;
+		if (uint32_t(pa >> 28) == uint32_t(pb >> 28)) {
+			const unsigned dst = sign ? fa - fb : fb - fa;
+			if (dst < res) {
+				res = dst;
+				if (res <= 1) break;
+			}
+		}
+		if (sign) {
+			++j;
+		} else {
+			++i;
+		}
+	}
+	return res == 0xFFFFFFFFu ? 0 : res;
+}
+
+// One thread per merged document: its row replayed in sub-term order = the order mergeTerm / mergeSimple met its postings.
+__global__ __launch_bounds__(256) void ft_replay(FtPlan p) {
+	const uint32_t num_docs = p.sync[kFtSyncNumDocs];
+	const uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
+	if (sl == 0) {
+		p.out_header[0] = num_docs;
+		p.out_header[1] = p.sync[kFtSyncError];
+		p.out_header[2] = ft_preselect_on(p) ? 1u : 0u;
+		p.out_header[3] = 0;
+	}
+	if (sl >= num_docs) return;
+	bool created = false;
+	float proc = 0.f, rank = 0.f;
+	uint8_t field = 0;
+	const uint64_t* last_ptr = nullptr;
+	const uint64_t* next_ptr = nullptr;
+	uint32_t last_cnt = 0, next_cnt = 0;
+	uint16_t switched_term = 0, last_counted = 0, terms_counter = 0;
+	for (uint32_t row = 0; row < p.n_rows; ++row) {
+		const uint64_t cell = uint64_t(row) * p.max_merged + sl;
+		const float r = p.e_rank[cell];
+		if (r == 0.0f) continue;
+		const uint8_t fld = p.e_field[cell];
+		if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
+			if (!created) {
+				created = true;
+				proc = r;
+				field = fld;
+			} else if (proc < r) {
+				proc = r;
+				field = fld;
+			}
+			continue;
+		}
+		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
+		const uint32_t i = p.e_idx[cell];
+		const uint64_t* pos = s.fpos + s.pos_off[i];
+		const uint32_t npos = s.pos_off[i + 1] - s.pos_off[i];
+		const uint16_t qp = s.qp;
+		if (!created) {   // addDoc (mergerimpl.h:160-164)
+			created = true;
+			proc = r;
+			field = fld;
+			rank = r;
+			next_ptr = pos;
+			next_cnt = npos;
+			switched_term = qp;
+			last_counted = qp;
+			terms_counter = 1;
+			continue;
+		}
+		// ---- document already merged: mergerimpl.h:165-189
+		if (switched_term < qp) {   // switchToNextWord (merger.h:218-226) ran before every term since: idempotent after the first time
+			if (next_cnt) {
+				last_ptr = next_ptr;
+				last_cnt = next_cnt;
+				next_cnt = 0;
+				rank = 0.f;
+			}
+			switched_term = qp;
+		}
+		if (last_counted < qp) {   // InreaseTermsCounter
+			terms_counter = uint16_t(terms_counter + 1);
+			last_counted = qp;
+		}
+		unsigned dist = ft_positions_distance(last_ptr, last_cnt, pos, npos);
+		dist = dist > 1u ? dist : 1u;
+		const float norm_dist = ft_bound(float(1.0 / double(float(dist))), p.distance_weight, p.distance_boost);
+		const float final_rank = norm_dist * r;
+		if (final_rank > rank) {
+			proc -= rank;
+			proc += final_rank;
+			next_ptr = pos;
+			next_cnt = npos;
+			rank = final_rank;
+		}
+	}
+	p.out_proc[sl] = proc;
+	p.out_field[sl] = field;
+	p.out_terms_counter[sl] = terms_counter;
+}
+
+// ---------------------------------------------------------------------------------------------- launch train
+void launch_ft_merge(const FtPlan& p, hipStream_t st) {
+	const uint32_t doc_blocks = uint32_t(std::min<uint64_t>((p.total_docs + 255) / 256, 2048));
+	hipLaunchKernelGGL(ft_init, dim3(2048), dim3(256), 0, st, p);
+	if (!p.simple) {
+		if (p.scan_blocks) hipLaunchKernelGGL(ft_scan, dim3(p.scan_blocks), dim3(256), 0, st, p);
+		if (p.n_and || p.not_mask || p.prescore) {
+			hipLaunchKernelGGL(ft_combine, dim3(uint32_t(std::min<uint64_t>((p.nwords + 255) / 256, 1024))), dim3(256), 0, st, p);
+		}
+		if (p.prescore) {
+			hipLaunchKernelGGL(ft_score, dim3(doc_blocks), dim3(256), 0, st, p);
+			hipLaunchKernelGGL(ft_preselect_pick, dim3(1), dim3(1024), 0, st, p);
+			hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 255) / 256)), dim3(256), 0, st, p);
+		}
+	}
+	if (p.merge_blocks) {
+		hipLaunchKernelGGL(ft_rank_all, dim3(p.merge_blocks), dim3(256), 0, st, p);
+		hipLaunchKernelGGL(ft_assign_slots, dim3(p.merge_blocks), dim3(256), 0, st, p);
+		hipLaunchKernelGGL(ft_scatter, dim3(p.merge_blocks), dim3(256), 0, st, p);
+	}
+	hipLaunchKernelGGL(ft_replay, dim3((p.max_merged + 255) / 256), dim3(256), 0, st, p);
+}
+
+}  // namespace rxgpu

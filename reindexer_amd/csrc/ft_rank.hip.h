@@ -1,11 +1,15 @@
-// Device-side calcTermRankImpl (cpp_src/core/ft/ft_fast/phrasemergerimpl.h:13-81) with Bm25Rx (core/ft/bm25.h:8-36) and the
-// FTFieldConfig helpers (core/ft/config/ftconfig.h:127-148), used by the single-term and multi-term merge kernels (ft_terms.hip)
-// merge kernels.  P supplies the term / field configuration (FtMergeParams or FtTermCfg member names), S the posting arrays.
+// Device-side calcTermRankImpl (cpp_src/core/ft/ft_fast/phrasemergerimpl.h:13-81) with the three calculators behind Bm25Calculator<BM>
+// (core/ft/bm25.h:8-68: Bm25Rx, Bm25Classic, TermCount — selected per merge like the selecter does from bm25Config.bm25Type,
+// selecterimpl.h:615-624) and the FTFieldConfig helpers (core/ft/config/ftconfig.h:127-148), used by the merge kernels (ft_merge.hip).
+// P supplies the term / field configuration (FtTermCfg member names), S the posting arrays (FtPosSubterm; s.idf is the calculator's
+// IDF, computed on the host per sub-term).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace rxgpu {
+
+constexpr int kFtBm25Rx = 0, kFtBm25Classic = 1, kFtBm25WordCount = 2;   // rxgpu_ft_config::bm25_type
 
 __device__ __forceinline__ float ft_pos2rank(unsigned pos) {   // ftconfig.h:127-144
 	if (pos <= 10) return float(1.0 - (pos / 100.0));
@@ -32,8 +36,14 @@ __device__ __forceinline__ float ft_term_rank(const P& p, const S& s, uint32_t e
 		const unsigned f = s.ent_field[e];
 		const float fb = p.field_boost[f];
 		if (fb == 0.0f) continue;
-		const double tf = double(s.ent_tf[e]);
-		const double bm = s.idf * tf * (p.k1 + 1.0) / (tf + p.k1 * (1.0 - p.b + p.b * double(w[f]) / double(p.avg_words[f])));
+		const double cnt = double(s.ent_tf[e]), wif = double(w[f]);
+		double bm;
+		if (p.bm25_type == kFtBm25WordCount) {   // TermCount::Get (bm25.h:58-68)
+			bm = cnt;
+		} else {                                  // Bm25Rx::Get / Bm25Classic::Get: same expression, TF = count (rx) or count / wordsInDoc (classic)
+			const double tf = p.bm25_type == kFtBm25Classic ? cnt / wif : cnt;
+			bm = s.idf * tf * (p.k1 + 1.0) / (tf + p.k1 * (1.0 - p.b + p.b * wif / double(p.avg_words[f])));
+		}
 		const float bm25 = float(bm);
 		const float norm = ft_bound(bm25, p.bm25_weight[f], p.bm25_boost[f]);
 		const float prank = ft_bound(ft_pos2rank(s.ent_first_pos[e]), p.position_weight[f], p.position_boost[f]);

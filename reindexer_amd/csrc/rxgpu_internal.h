@@ -72,7 +72,8 @@ void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool g
 struct HnswStream;
 void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, uint32_t batch, int mode, bool lds, hipStream_t st);
 
-// ft_fast merge (ft_terms.hip): Merger::mergeSimple / mergeTerm + restricting bitmask + preselect
+// ft_fast merge (ft_merge.hip): Merger::mergeSimple / mergeTerm + restricting bitmask + preselect, restated ORDER-FREE so that a whole
+// query is a fixed number of launches (see the header of ft_merge.hip)
 struct FtPosSubterm {
 	uint64_t n;
 	const uint32_t* doc;
@@ -80,14 +81,18 @@ struct FtPosSubterm {
 	const uint8_t* ent_field;
 	const uint32_t* ent_tf;
 	const uint32_t* ent_first_pos;
-	const uint32_t* pos_off;   // [n + 1]
+	const uint32_t* pos_off;   // [n + 1]; null for words uploaded without positions (single-term merge only)
 	const uint64_t* fpos;      // PosType words (idrelset.h:14-32): pos | arrayIdx << 28 | field << 56
-	double idf;
+	double idf;                // the calculator's IDF for this sub-term (bm25.h), computed on the host
 	float proc;
-	uint64_t gp_base;          // used by the fused mask kernels only
+	uint32_t term;             // query term index -> FtPlan::terms
+	uint16_t qp;               // 1-based index among the terms that are not NOT (mergeTerm's qpIdx); 0 for a NOT term
+	uint16_t ord_in_term;      // position inside its term (SortSubterms order)
+	uint32_t row;              // row of the per-slot entry table = index among the merged (non-NOT, non-empty) sub-terms
 };
 struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslOpts of ONE query term
 	uint32_t num_fields;
+	int32_t bm25_type;         // kFtBm25Rx / Classic / WordCount (ft_rank.hip.h)
 	const float* words;
 	const float* avg_words;
 	double k1, b, summation_ratio;
@@ -95,64 +100,63 @@ struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslO
 	const float* field_boost;
 	const uint8_t* need_sum_rank;
 	const float *bm25_boost, *bm25_weight, *term_len_boost, *term_len_weight, *position_boost, *position_weight;
+	int32_t op;                // 1 OR, 2 AND, 3 NOT
+	uint32_t and_idx;          // AND terms: which of the per-term bit arrays
+	uint32_t best_idx;         // terms that are not NOT: which of the per-term pre-score arrays
+	uint8_t same_boost;        // every field has the same boost (calcTermScores' shortcut)
+	uint8_t all_pos_boost;     // every field has a non-zero boost (calcTermBitmask's shortcut)
 };
-struct FtSlots {               // MergeInfo + MergerDocumentData (merger.h:11-34) of the admitted documents, SoA by merge slot
-	uint32_t* doc;
-	float* proc;
-	uint8_t* field;
-	float* rank;               // MergerDocumentData::rank
-	const uint64_t** last_ptr; // lastTermPositions / nextTermPositions as views into the resident posting positions
-	uint32_t* last_cnt;
-	const uint64_t** next_ptr;
-	uint32_t* next_cnt;
-	uint16_t* switched_term;   // lazy switchToNextWord: last term index this slot was switched for
-	uint16_t* last_counted;    // lastTermCounted
-	uint16_t* terms_counter;
+struct FtGridEntry {           // block range of one sub-term in a posting-side grid (blocks of kFtBlockPostings postings)
+	uint32_t block_base;
+	uint32_t sub;              // index into FtPlan::subs
 };
-struct FtTermPass {
-	FtTermCfg cfg;
-	FtPosSubterm sub;
-	FtSlots slots;
-	const uint32_t* mask;      // restrictingMask_ bit words
-	const uint8_t* removed;    // null when needToCheckRemoved_ == false (after preselect) or nothing is removed
-	uint32_t* slot_of;         // idoffsets_: [total_docs], 0xFFFFFFFF = not added
-	uint32_t max_merged;
-	uint16_t qp_idx;
-	uint16_t simple;           // 1: Merger::mergeSimple (one term): existing documents keep max(proc, rank), first maximum wins; no positions
+constexpr int kFtPassItems = 4;            // postings per thread in the posting-side kernels
+constexpr int kFtBlockPostings = 256 * kFtPassItems;
+inline uint32_t ft_pass_blocks(uint64_t n) { return uint32_t((n + kFtBlockPostings - 1) / kFtBlockPostings); }
+
+// Everything one merge needs on the device.  Pointers into per-index scratch; scalar members by value (the struct travels as a kernel argument).
+struct FtPlan {
+	const FtPosSubterm* subs;
+	const FtTermCfg* terms;
+	const FtGridEntry* merge_grid;   // merged sub-terms in (term, sub-term) order
+	const FtGridEntry* scan_grid;    // sub-terms the bitmask / pre-score scan walks
+	uint32_t n_merge_entries, n_scan_entries, merge_blocks, scan_blocks;
+	uint32_t nterms, n_and, n_best, n_rows;
+	uint64_t total_docs, nwords;
+	uint32_t max_merged, merge_limit;
+	uint8_t simple;            // Merger::mergeSimple (one term): max over sub-terms, first maximum wins; no positions
+	uint8_t prescore;          // the host-side half of the 2-phase gate held: pre-scores are collected, the device decides on popcount
+	uint8_t check_removed;
 	float distance_weight, distance_boost;
-	const uint32_t* num_docs_in;   // numDocs() before this sub-term
-	uint32_t* num_docs_out;        // ... and after it
-	unsigned long long* lookback;  // [blocks] decoupled look-back words, zeroed
-	uint32_t* ticket;              // dynamic block id, zeroed
-	uint32_t* error_flag;
-};
-struct FtPreselect {
-	const uint32_t* mask_in;
-	uint32_t* mask;
-	uint32_t* term_mask;
-	uint16_t* score;
-	uint32_t* hist;            // [65536]
-	uint32_t* pick;            // [2]: minScore, minScoreDocs
-	uint64_t total_docs;
 	const uint8_t* removed;
-	uint32_t max_merged;
-	unsigned long long* lookback;
-	uint32_t* ticket;
-	uint32_t* error_flag;
+	const uint8_t* excluded;
+	uint32_t* mask;            // restrictingMask_ [nwords]
+	uint32_t* and_masks;       // [n_and][nwords]
+	uint32_t* not_mask;        // [nwords]
+	uint32_t* best;            // [n_best][total_docs]: presence bit | (4095 - sub-term ordinal) << 16 | proc16
+	uint16_t* score;           // [total_docs]
+	uint32_t* hist;            // [65536]
+	uint32_t* first;           // [total_docs]: smallest global posting index with a non-zero rank (the posting that adds the document)
+	uint32_t* slot_of;         // [total_docs]: sparse-set back pointer, valid iff slot_doc[slot_of[d]] == d
+	float* p_rank;             // [merge_blocks * kFtBlockPostings] rank of every posting (0 = not eligible)
+	uint8_t* p_field;
+	float* e_rank;             // per-slot entry table [n_rows][max_merged]: 0 = the document has no posting in that sub-term
+	uint32_t* e_idx;
+	uint8_t* e_field;
+	uint32_t* sync;            // kFtSync* words (zeroed by ft_init)
+	unsigned long long* lookback_slots;   // [merge_blocks]
+	unsigned long long* lookback_pre;     // [ceil(nwords / 256)]
+	// packed result: header (4 x u32: numDocs, error flag, preselected, 0) then doc[max_merged] u32, proc[max_merged] f32,
+	// terms_counter[max_merged] u16, field[max_merged] u8 — one D2H copy
+	uint32_t* out_header;
+	uint32_t* out_doc;
+	float* out_proc;
+	uint16_t* out_terms_counter;
+	uint8_t* out_field;
 };
-constexpr int kFtPassItems = 4;            // postings per thread in ft_term_pass
-constexpr int kFtPassBlock = 256 * kFtPassItems;
-inline uint32_t ft_pass_blocks(uint64_t n) { return uint32_t((n + kFtPassBlock - 1) / kFtPassBlock); }
-void launch_ft_mask_init(uint32_t* mask, const uint8_t* excluded, uint64_t total_docs, hipStream_t st);
-void launch_ft_term_mask(const FtPosSubterm* d_subs, uint32_t nsub, uint64_t total, const float* field_boost, uint32_t num_fields, uint32_t* term_mask,
-						 hipStream_t st);
-void launch_ft_mask_and(uint32_t* mask, const uint32_t* term_mask, uint64_t nwords, hipStream_t st);
-void launch_ft_mask_exclude(const FtPosSubterm* d_subs, uint32_t nsub, uint64_t total, uint32_t* mask, hipStream_t st);
-void launch_ft_mask_popcount(const uint32_t* mask, uint64_t nwords, uint32_t* out, hipStream_t st);
-void launch_ft_prescore(const FtPosSubterm& sub, const uint32_t* mask, uint32_t* term_mask, uint16_t* score, const float* field_boost, uint32_t num_fields,
-						 bool same_boost, float opts_boost, hipStream_t st);
-void launch_ft_preselect(const FtPreselect& p, hipStream_t st);
-void launch_ft_term_pass(const FtTermPass& p, hipStream_t st);
+enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPick = 2 /* +1 */, kFtSyncPreTicket = 4, kFtSyncSlotTicket = 5, kFtSyncNumDocs = 6,
+				  kFtSyncPreselected = 7, kFtSyncWords = 8 };
+void launch_ft_merge(const FtPlan& plan, hipStream_t st);
 
 void set_error(const std::string& msg);
 
