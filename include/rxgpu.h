@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RXGPU_ABI_VERSION 1
+#define RXGPU_ABI_VERSION 2
 
 typedef enum rxgpu_status {
 	RXGPU_OK = 0,
@@ -209,9 +209,11 @@ typedef struct rxgpu_ft_config {
 	uint32_t num_fields;
 	const double *bm25_boost, *bm25_weight, *term_len_boost, *term_len_weight, *position_boost, *position_weight;
 	double distance_boost, distance_weight;    /* 1.0, 0.5 (ftconfig.h:180-181); read by the multi-term merge only */
+	int32_t bm25_type;                         /* FTConfig::Bm25Config::bm25Type (ftconfig.h:199-206; calculators in core/ft/bm25.h:8-68):
+	                                              0 = rx (the default), 1 = classic, 2 = wordCount.  ABI 2. */
 } rxgpu_ft_config;
 
-/* FtDslOpts of the query term (cpp_src/core/ft/ftdsl.h:13-35). */
+/* FtDslOpts of the query term (cpp_src/core/ft/ftdsl.h:13-35).  At most 4096 sub-terms per term on the GPU engine. */
 typedef struct rxgpu_ft_term_opts {
 	float boost, term_len_boost;
 	const float* field_boost;       /* FtDslFieldOpts::boost per field */

@@ -9,6 +9,7 @@
 
 #include "../../include/rxgpu.h"
 #include "rxgpu_internal.h"
+#include "ft_rank.hip.h"
 
 using rxgpu::set_error;
 
@@ -56,8 +57,23 @@ struct rxgpu_ft_index {
 	std::unordered_map<uint32_t, rxgpu_ft_word> words;
 	std::mutex mtx;
 	hipStream_t stream = nullptr;
-	rxgpu_devbuf d_excluded, d_cfg, d_subs;
-	rxgpu_devbuf d_mask, d_tmask, d_score, d_hist, d_slot_of, d_slots, d_sync;   // multi-term merge
+	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
+	void* h_pinned = nullptr;     // staging: plan upload / result download
+	size_t h_pinned_bytes = 0;
+	hipEvent_t ev_a = nullptr, ev_b = nullptr;
+	int ensure_pinned(size_t need) {
+		if (need <= h_pinned_bytes) return RXGPU_OK;
+		if (h_pinned) (void)hipHostFree(h_pinned);
+		h_pinned = nullptr;
+		h_pinned_bytes = 0;
+		const size_t want = need + need / 2 + 4096;
+		if (hipHostMalloc(&h_pinned, want, hipHostMallocDefault) != hipSuccess) {
+			set_error("hipHostMalloc failed");
+			return RXGPU_ERR_NOMEM;
+		}
+		h_pinned_bytes = want;
+		return RXGPU_OK;
+	}
 	uint64_t stat_postings = 0;
 	double stat_ms = 0.0;
 };
@@ -131,10 +147,10 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
 		if (p) (void)hipFree(p);
 	}
-	for (rxgpu_devbuf* b : {&h->d_excluded, &h->d_cfg, &h->d_subs, &h->d_mask, &h->d_tmask, &h->d_score, &h->d_hist, &h->d_slot_of, &h->d_slots,
-							&h->d_sync}) {
-		b->release();
-	}
+	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out}) b->release();
+	if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+	if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+	if (h->ev_b) (void)hipEventDestroy(h->ev_b);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -178,52 +194,302 @@ int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uin
 	return RXGPU_OK;
 }
 
-// Shared by both merges: slot state of the admitted documents (MergeInfo + MergerDocumentData), SoA, 8-byte members first
-static int carve_slots(rxgpu_ft_index* h, size_t M, rxgpu::FtSlots& slots) {
-	const size_t slots_bytes = M * (8 + 8 + 4 * 5 + 2 * 3 + 1) + 64;
-	if (int rc = h->d_slots.ensure(slots_bytes); rc) return rc;
-	char* sp = static_cast<char*>(h->d_slots.ptr);
-	slots.last_ptr = reinterpret_cast<const uint64_t**>(sp);
-	sp += M * 8;
-	slots.next_ptr = reinterpret_cast<const uint64_t**>(sp);
-	sp += M * 8;
-	slots.doc = reinterpret_cast<uint32_t*>(sp);
-	sp += M * 4;
-	slots.proc = reinterpret_cast<float*>(sp);
-	sp += M * 4;
-	slots.rank = reinterpret_cast<float*>(sp);
-	sp += M * 4;
-	slots.last_cnt = reinterpret_cast<uint32_t*>(sp);
-	sp += M * 4;
-	slots.next_cnt = reinterpret_cast<uint32_t*>(sp);
-	sp += M * 4;
-	slots.switched_term = reinterpret_cast<uint16_t*>(sp);
-	sp += M * 2;
-	slots.last_counted = reinterpret_cast<uint16_t*>(sp);
-	sp += M * 2;
-	slots.terms_counter = reinterpret_cast<uint16_t*>(sp);
-	sp += M * 2;
-	slots.field = reinterpret_cast<uint8_t*>(sp);
+// ---------------------------------------------------------------------------------------------------- one merge = one launch train
+namespace {
+
+struct QueryTermIn {
+	int32_t op;
+	const rxgpu_ft_term_opts* opts;
+	uint32_t sub_begin, sub_end;
+};
+
+// the calculator's IDF per sub-term (bm25.h): totalDocCount = totalNumDocs - 1 ("first doc is always empty"), matchedDocCount = |postings|
+double subterm_idf(int bm25_type, uint64_t total_docs, uint64_t n) {
+	const double td = double(total_docs - 1), md = double(n);
+	if (bm25_type == rxgpu::kFtBm25WordCount) return 0.0;                            // TermCount::GetIDF
+	if (bm25_type == rxgpu::kFtBm25Classic) return std::log(td / (md + 1)) + 1;      // Bm25Classic::IDF
+	double f = n ? std::log((td - md + 1) / md) / std::log(1 + td) : 0.2;            // Bm25Rx::IDF, saturated at 0.2
+	if (f < 0.2) f = 0.2;
+	return f;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
+
+// Carves `bytes` out of one growable device buffer; every region starts on a 256-byte boundary
+struct Carver {
+	size_t off = 0;
+	size_t take(size_t bytes) {
+		const size_t at = off;
+		off = align256(off + bytes);
+		return at;
+	}
+};
+
+// Shared implementation of rxgpu_ft_merge_simple_raw / rxgpu_ft_merge_terms_raw.  out_terms_counter may be null (simple).
+int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
+			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
+			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who) {
+	const uint32_t nf = h->num_fields;
+	const uint64_t N = h->total_docs;
+	const uint32_t nterms = uint32_t(terms.size());
+	const int bm25_type = cfg->bm25_type;
+	RX_CHECK(bm25_type >= 0 && bm25_type <= 2, RXGPU_ERR_PARAMS, std::string(who) + ": bm25_type must be 0 (rx), 1 (classic) or 2 (wordCount)");
+
+	// ---- the plan: sub-terms, per-term configuration, the two posting-side grids
+	std::vector<rxgpu::FtPosSubterm> subs;
+	std::vector<rxgpu::FtTermCfg> tcfg(nterms);
+	std::vector<rxgpu::FtGridEntry> merge_grid, scan_grid;
+	std::vector<uint64_t> term_postings(nterms, 0);
+	uint64_t total_vids = 0, merged_postings = 0, merge_blocks = 0, scan_blocks = 0;
+	uint32_t n_and = 0, n_best = 0, n_not = 0;
+	uint16_t qp = 0;
+	// 2-phase gate, host half (estimateNumDocsInMerge, merger.h:239-267; mergerimpl.h:486-490)
+	uint64_t est_or = 0, est_and = UINT64_MAX;
+	for (uint32_t t = 0; t < nterms; ++t) {
+		const QueryTermIn& qt = terms[t];
+		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
+			auto it = h->words.find(word_ids[si]);
+			RX_CHECK(it != h->words.end(), RXGPU_ERR_NOTFOUND, std::string(who) + ": unknown word id");
+			term_postings[t] += it->second.n;
+		}
+		total_vids += term_postings[t];   // totalORVids: MaxVDocs of every term, whatever its operator (selecterimpl.h:546)
+		if (qt.op == 3) continue;
+		if (qt.op == 2) {
+			est_and = std::min(est_and, term_postings[t]);
+		} else {
+			est_or += term_postings[t];
+		}
+	}
+	RX_CHECK(total_vids < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^32 postings in one merge");
+	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, total_vids);   // Merge(): min(mergeLimit, totalORVids)
+	if (max_merged == 0) return RXGPU_OK;
+	RX_CHECK(cap >= max_merged && out_doc && out_proc && out_field && (simple || out_terms_counter), RXGPU_ERR_OVERFLOW,
+			 std::string(who) + ": output buffers too small");
+	const bool prescore = !simple && std::min(std::min(est_or, est_and), N) > cfg->merge_limit && N > cfg->merge_limit;
+
+	for (uint32_t t = 0; t < nterms; ++t) {
+		const QueryTermIn& qt = terms[t];
+		RX_CHECK(qt.opts->field_boost && qt.opts->need_sum_rank, RXGPU_ERR_PARAMS, std::string(who) + ": null term options");
+		uint32_t nsum = 0;
+		bool same = true, all_pos = true;
+		for (uint32_t f = 0; f < nf; ++f) {
+			nsum += qt.opts->need_sum_rank[f] ? 1 : 0;
+			same = same && qt.opts->field_boost[f] == qt.opts->field_boost[0];
+			all_pos = all_pos && qt.opts->field_boost[f] != 0.0f;
+		}
+		RX_CHECK(nsum <= 8, RXGPU_ERR_PARAMS, std::string(who) + ": more than 8 fields with needSumRank (GPU engine limit)");
+		RX_CHECK(qt.sub_end - qt.sub_begin <= 4096, RXGPU_ERR_PARAMS, std::string(who) + ": more than 4096 sub-terms in one term (GPU engine limit)");
+		rxgpu::FtTermCfg& tc = tcfg[t];
+		tc.num_fields = nf;
+		tc.bm25_type = bm25_type;
+		tc.words = h->d_words;
+		tc.avg_words = h->d_avg;
+		tc.k1 = cfg->bm25_k1;
+		tc.b = cfg->bm25_b;
+		tc.summation_ratio = cfg->summation_ranks_by_fields_ratio;
+		tc.opts_boost = qt.opts->boost;
+		tc.term_len_boost_in = qt.opts->term_len_boost;
+		tc.op = qt.op;
+		tc.and_idx = qt.op == 2 ? n_and++ : 0;
+		tc.best_idx = qt.op != 3 ? n_best++ : 0;
+		tc.same_boost = same ? 1 : 0;
+		tc.all_pos_boost = all_pos ? 1 : 0;
+		if (qt.op == 3) {
+			++n_not;
+		} else {
+			++qp;
+		}
+		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
+			const rxgpu_ft_word& w = h->words.find(word_ids[si])->second;
+			RX_CHECK(simple || w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
+			RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
+					 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
+			if (!w.n) continue;
+			rxgpu::FtPosSubterm ft{};
+			ft.n = w.n;
+			ft.doc = w.doc;
+			ft.ent_off = w.ent_off;
+			ft.ent_field = w.ent_field;
+			ft.ent_tf = w.ent_tf;
+			ft.ent_first_pos = w.ent_first_pos;
+			ft.pos_off = w.pos_off;
+			ft.fpos = w.fpos;
+			ft.idf = subterm_idf(bm25_type, N, w.n);
+			ft.proc = procs[si];
+			ft.term = t;
+			ft.qp = qt.op == 3 ? 0 : qp;
+			ft.ord_in_term = uint16_t(si - qt.sub_begin);
+			ft.row = 0;
+			const uint32_t blocks = rxgpu::ft_pass_blocks(w.n);
+			const uint32_t sub_index = uint32_t(subs.size());
+			if (qt.op != 3) {
+				ft.row = uint32_t(merge_grid.size());
+				merge_grid.push_back({uint32_t(merge_blocks), sub_index});
+				merge_blocks += blocks;
+				merged_postings += w.n;
+			}
+			if (!simple && (qt.op != 1 || prescore)) {
+				scan_grid.push_back({uint32_t(scan_blocks), sub_index});
+				scan_blocks += blocks;
+			}
+			subs.push_back(ft);
+		}
+	}
+	RX_CHECK(merge_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull && scan_blocks < 0x7FFFFFFFull, RXGPU_ERR_PARAMS,
+			 std::string(who) + ": more than 2^32 (padded) postings in one merge");
+	const uint32_t n_rows = uint32_t(merge_grid.size());
+	const uint64_t nwords = (N + 31) / 32;
+	const size_t M = size_t(max_merged);
+	const uint64_t padded = merge_blocks * rxgpu::kFtBlockPostings;
+
+	// ---- device scratch (one buffer each for the state and for the packed result)
+	Carver cv;
+	const size_t o_plan_subs = cv.take(std::max<size_t>(1, subs.size()) * sizeof(rxgpu::FtPosSubterm));
+	const size_t o_plan_terms = cv.take(size_t(nterms) * sizeof(rxgpu::FtTermCfg));
+	const size_t o_plan_mgrid = cv.take(std::max<size_t>(1, merge_grid.size()) * sizeof(rxgpu::FtGridEntry));
+	const size_t o_plan_sgrid = cv.take(std::max<size_t>(1, scan_grid.size()) * sizeof(rxgpu::FtGridEntry));
+	const size_t cfg_floats = size_t(6) * nf + size_t(nterms) * nf;
+	const size_t o_plan_fc = cv.take(cfg_floats * sizeof(float) + size_t(nterms) * nf);
+	const size_t plan_bytes = cv.off;   // everything above is uploaded in one copy
+	const size_t o_mask = cv.take(nwords * 4);
+	const size_t o_and = cv.take(size_t(n_and) * nwords * 4);
+	const size_t o_not = cv.take(n_not ? nwords * 4 : 0);
+	const size_t o_best = cv.take(prescore ? size_t(n_best) * N * 4 : 0);
+	const size_t o_score = cv.take(prescore ? N * 2 : 0);
+	const size_t o_hist = cv.take(prescore ? 65536 * 4 : 0);
+	const size_t o_lb_pre = cv.take(prescore ? ((nwords + 255) / 256) * 8 : 0);
+	const size_t o_first = cv.take(N * 4);
+	const size_t o_slot_of = cv.take(N * 4);
+	const size_t o_prank = cv.take(padded * 4);
+	const size_t o_pfield = cv.take(padded);
+	const size_t o_erank = cv.take(size_t(n_rows) * M * 4);
+	const size_t o_eidx = cv.take(size_t(n_rows) * M * 4);
+	const size_t o_efield = cv.take(size_t(n_rows) * M);
+	const size_t o_sync = cv.take(rxgpu::kFtSyncWords * 4);
+	const size_t o_lb_slots = cv.take(size_t(merge_blocks) * 8);
+	const size_t o_excl = cv.take(excluded ? N : 0);
+	if (int rc = h->d_state.ensure(cv.off); rc) return rc;
+	char* base = static_cast<char*>(h->d_state.ptr);
+	const size_t out_need = align256(16) + align256(M * 4) * 2 + align256(M * 2) + align256(M);
+	if (int rc = h->d_out.ensure(out_need); rc) return rc;
+	char* ob = static_cast<char*>(h->d_out.ptr);
+
+	// ---- host staging of the plan (pinned), one upload
+	if (int rc = h->ensure_pinned(std::max(plan_bytes, out_need)); rc) return rc;
+	char* hp = static_cast<char*>(h->h_pinned);
+	std::memset(hp, 0, plan_bytes);
+	float* fc = reinterpret_cast<float*>(hp + o_plan_fc);
+	const float* d_fc = reinterpret_cast<const float*>(base + o_plan_fc);
+	const uint8_t* d_need_sum = reinterpret_cast<const uint8_t*>(d_fc + cfg_floats);
+	uint8_t* need_sum = reinterpret_cast<uint8_t*>(fc + cfg_floats);
+	for (uint32_t f = 0; f < nf; ++f) {   // per-field parameters as floats (bound() takes float arguments)
+		fc[0 * nf + f] = float(cfg->bm25_boost[f]);
+		fc[1 * nf + f] = float(cfg->bm25_weight[f]);
+		fc[2 * nf + f] = float(cfg->term_len_boost[f]);
+		fc[3 * nf + f] = float(cfg->term_len_weight[f]);
+		fc[4 * nf + f] = float(cfg->position_boost[f]);
+		fc[5 * nf + f] = float(cfg->position_weight[f]);
+	}
+	for (uint32_t t = 0; t < nterms; ++t) {
+		for (uint32_t f = 0; f < nf; ++f) {
+			fc[size_t(6 + t) * nf + f] = terms[t].opts->field_boost[f];
+			need_sum[size_t(t) * nf + f] = terms[t].opts->need_sum_rank[f];
+		}
+		rxgpu::FtTermCfg& tc = tcfg[t];
+		tc.field_boost = d_fc + size_t(6 + t) * nf;
+		tc.need_sum_rank = d_need_sum + size_t(t) * nf;
+		tc.bm25_boost = d_fc + 0 * nf;
+		tc.bm25_weight = d_fc + 1 * nf;
+		tc.term_len_boost = d_fc + 2 * nf;
+		tc.term_len_weight = d_fc + 3 * nf;
+		tc.position_boost = d_fc + 4 * nf;
+		tc.position_weight = d_fc + 5 * nf;
+	}
+	if (!subs.empty()) std::memcpy(hp + o_plan_subs, subs.data(), subs.size() * sizeof(rxgpu::FtPosSubterm));
+	std::memcpy(hp + o_plan_terms, tcfg.data(), tcfg.size() * sizeof(rxgpu::FtTermCfg));
+	if (!merge_grid.empty()) std::memcpy(hp + o_plan_mgrid, merge_grid.data(), merge_grid.size() * sizeof(rxgpu::FtGridEntry));
+	if (!scan_grid.empty()) std::memcpy(hp + o_plan_sgrid, scan_grid.data(), scan_grid.size() * sizeof(rxgpu::FtGridEntry));
+
+	hipStream_t st = h->stream;
+	RX_HIP(hipMemcpyAsync(base, hp, plan_bytes, hipMemcpyHostToDevice, st));
+	if (excluded) RX_HIP(hipMemcpyAsync(base + o_excl, excluded, N, hipMemcpyHostToDevice, st));
+
+	rxgpu::FtPlan p{};
+	p.subs = reinterpret_cast<const rxgpu::FtPosSubterm*>(base + o_plan_subs);
+	p.terms = reinterpret_cast<const rxgpu::FtTermCfg*>(base + o_plan_terms);
+	p.merge_grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_plan_mgrid);
+	p.scan_grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_plan_sgrid);
+	p.n_merge_entries = uint32_t(merge_grid.size());
+	p.n_scan_entries = uint32_t(scan_grid.size());
+	p.merge_blocks = uint32_t(merge_blocks);
+	p.scan_blocks = uint32_t(scan_blocks);
+	p.nterms = nterms;
+	p.n_and = n_and;
+	p.n_best = prescore ? n_best : 0;
+	p.n_rows = n_rows;
+	p.total_docs = N;
+	p.nwords = nwords;
+	p.max_merged = uint32_t(max_merged);
+	p.merge_limit = cfg->merge_limit;
+	p.simple = simple ? 1 : 0;
+	p.prescore = prescore ? 1 : 0;
+	p.check_removed = 1;
+	p.distance_weight = float(cfg->distance_weight);
+	p.distance_boost = float(cfg->distance_boost);
+	p.removed = h->d_removed;
+	p.excluded = excluded ? reinterpret_cast<const uint8_t*>(base + o_excl) : nullptr;
+	p.mask = reinterpret_cast<uint32_t*>(base + o_mask);
+	p.and_masks = n_and ? reinterpret_cast<uint32_t*>(base + o_and) : nullptr;
+	p.not_mask = n_not ? reinterpret_cast<uint32_t*>(base + o_not) : nullptr;
+	p.best = prescore ? reinterpret_cast<uint32_t*>(base + o_best) : nullptr;
+	p.score = prescore ? reinterpret_cast<uint16_t*>(base + o_score) : nullptr;
+	p.hist = prescore ? reinterpret_cast<uint32_t*>(base + o_hist) : nullptr;
+	p.lookback_pre = prescore ? reinterpret_cast<unsigned long long*>(base + o_lb_pre) : nullptr;
+	p.first = reinterpret_cast<uint32_t*>(base + o_first);
+	p.slot_of = reinterpret_cast<uint32_t*>(base + o_slot_of);
+	p.p_rank = reinterpret_cast<float*>(base + o_prank);
+	p.p_field = reinterpret_cast<uint8_t*>(base + o_pfield);
+	p.e_rank = reinterpret_cast<float*>(base + o_erank);
+	p.e_idx = reinterpret_cast<uint32_t*>(base + o_eidx);
+	p.e_field = reinterpret_cast<uint8_t*>(base + o_efield);
+	p.sync = reinterpret_cast<uint32_t*>(base + o_sync);
+	p.lookback_slots = reinterpret_cast<unsigned long long*>(base + o_lb_slots);
+	p.out_header = reinterpret_cast<uint32_t*>(ob);
+	p.out_doc = reinterpret_cast<uint32_t*>(ob + align256(16));
+	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));
+	p.out_terms_counter = reinterpret_cast<uint16_t*>(ob + align256(16) + 2 * align256(M * 4));
+	p.out_field = reinterpret_cast<uint8_t*>(ob + align256(16) + 2 * align256(M * 4) + align256(M * 2));
+
+	if (!h->ev_a) {
+		RX_HIP(hipEventCreate(&h->ev_a));
+		RX_HIP(hipEventCreate(&h->ev_b));
+	}
+	RX_HIP(hipEventRecord(h->ev_a, st));
+	rxgpu::launch_ft_merge(p, st);
+	RX_HIP(hipEventRecord(h->ev_b, st));
+	RX_HIP(hipGetLastError());
+	RX_HIP(hipMemcpyAsync(hp, ob, out_need, hipMemcpyDeviceToHost, st));   // header + the four result arrays in one copy
+	RX_HIP(hipStreamSynchronize(st));
+	float ms = 0.f;
+	(void)hipEventElapsedTime(&ms, h->ev_a, h->ev_b);
+	h->stat_postings += merged_postings;
+	h->stat_ms += ms;
+	const uint32_t* hdr = reinterpret_cast<const uint32_t*>(hp);
+	RX_CHECK(hdr[1] == 0, RXGPU_ERR_DEVICE, std::string(who) + ": ordered look-back timed out on the device");
+	const uint64_t n = hdr[0];
+	RX_CHECK(n <= max_merged, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt result header");
+	if (n) {
+		std::memcpy(out_doc, hp + align256(16), n * 4);
+		std::memcpy(out_proc, hp + align256(16) + align256(M * 4), n * 4);
+		if (out_terms_counter) std::memcpy(out_terms_counter, hp + align256(16) + 2 * align256(M * 4), n * 2);
+		std::memcpy(out_field, hp + align256(16) + 2 * align256(M * 4) + align256(M * 2), n);
+	}
+	*out_n = n;
+	if (out_preselected) *out_preselected = hdr[2] ? 1 : 0;
 	return RXGPU_OK;
 }
 
-static void fill_subterm(const rxgpu_ft_word& w, uint64_t total_docs, float proc, rxgpu::FtPosSubterm& ft) {
-	ft.n = w.n;
-	ft.doc = w.doc;
-	ft.ent_off = w.ent_off;
-	ft.ent_field = w.ent_field;
-	ft.ent_tf = w.ent_tf;
-	ft.ent_first_pos = w.ent_first_pos;
-	ft.pos_off = w.pos_off;
-	ft.fpos = w.fpos;
-	// Bm25Rx::IDF(totalDocCount = totalNumDocs - 1, matchedDocCount = |postings|)  (bm25.h:19-26, mergerimpl.h:123-124, 203-205)
-	const double td = double(total_docs - 1), md = double(w.n);
-	double f = w.n ? std::log((td - md + 1) / md) / std::log(1 + td) : 0.2;
-	if (f < 0.2) f = 0.2;
-	ft.idf = f;
-	ft.proc = proc;
-	ft.gp_base = 0;
-}
+}  // namespace
 
 int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
 							  const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc,
@@ -234,134 +500,11 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_simple_raw: rxgpu_ft_set_docs was not called");
 	if (nsub == 0) return RXGPU_OK;
 	RX_CHECK(word_ids && procs && opts->field_boost && opts->need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: null argument");
-	{
-		uint32_t nsum = 0;
-		for (uint32_t f = 0; f < h->num_fields; ++f) nsum += opts->need_sum_rank[f] ? 1 : 0;
-		RX_CHECK(nsum <= 8, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: more than 8 fields with needSumRank (GPU engine limit)");
-	}
 	std::lock_guard<std::mutex> lk(h->mtx);
 	DevGuard dg(h->device);
-	const uint32_t nf = h->num_fields;
-	const uint64_t N = h->total_docs;
-	std::vector<rxgpu::FtPosSubterm> subs(nsub);
-	uint64_t total = 0, lookback_words = 0;
-	uint32_t launches = 0;
-	for (uint32_t s = 0; s < nsub; ++s) {
-		auto it = h->words.find(word_ids[s]);
-		RX_CHECK(it != h->words.end(), RXGPU_ERR_NOTFOUND, "rxgpu_ft_merge_simple_raw: unknown word id");
-		fill_subterm(it->second, N, procs[s], subs[s]);
-		total += subs[s].n;
-		if (subs[s].n) {
-			++launches;
-			lookback_words += rxgpu::ft_pass_blocks(subs[s].n);
-		}
-	}
-	RX_CHECK(total < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: more than 2^32 postings in one merge");
-	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, total);   // Merge(): min(mergeLimit, totalORVids)
-	if (max_merged == 0) return RXGPU_OK;
-	RX_CHECK(cap >= max_merged && out_doc && out_proc && out_field, RXGPU_ERR_OVERFLOW, "rxgpu_ft_merge_simple_raw: output buffers too small");
-
-	hipStream_t st = h->stream;
-	// per-field parameters as floats (bound() takes float arguments), packed in one upload
-	std::vector<float> fcfg(size_t(7) * nf);
-	for (uint32_t f = 0; f < nf; ++f) {
-		fcfg[0 * nf + f] = opts->field_boost[f];
-		fcfg[1 * nf + f] = float(cfg->bm25_boost[f]);
-		fcfg[2 * nf + f] = float(cfg->bm25_weight[f]);
-		fcfg[3 * nf + f] = float(cfg->term_len_boost[f]);
-		fcfg[4 * nf + f] = float(cfg->term_len_weight[f]);
-		fcfg[5 * nf + f] = float(cfg->position_boost[f]);
-		fcfg[6 * nf + f] = float(cfg->position_weight[f]);
-	}
-	if (int rc = h->d_cfg.ensure(fcfg.size() * sizeof(float) + nf); rc) return rc;
-	RX_HIP(hipMemcpyAsync(h->d_cfg.ptr, fcfg.data(), fcfg.size() * sizeof(float), hipMemcpyHostToDevice, st));
-	RX_HIP(hipMemcpyAsync(static_cast<char*>(h->d_cfg.ptr) + fcfg.size() * sizeof(float), opts->need_sum_rank, nf, hipMemcpyHostToDevice, st));
-	const float* fc = static_cast<const float*>(h->d_cfg.ptr);
-
-	// docsExcluded_ as the restricting mask (mergeSimple tests docsExcluded_[docId] || DocRemoved(docId), mergerimpl.h:209)
-	const uint64_t nwords = (N + 31) / 32;
-	if (int rc = h->d_mask.ensure(nwords * 4); rc) return rc;
-	const uint8_t* d_excl = nullptr;
-	if (excluded) {
-		if (int rc = h->d_excluded.ensure(N); rc) return rc;
-		RX_HIP(hipMemcpyAsync(h->d_excluded.ptr, excluded, N, hipMemcpyHostToDevice, st));
-		d_excl = static_cast<const uint8_t*>(h->d_excluded.ptr);
-	}
-	rxgpu::launch_ft_mask_init(static_cast<uint32_t*>(h->d_mask.ptr), d_excl, N, st);
-
-	const size_t sync_u32 = 8 + size_t(launches + 1) * 2;
-	const size_t sync_bytes = ((sync_u32 * 4 + 7) & ~size_t(7)) + lookback_words * 8;
-	if (int rc = h->d_sync.ensure(sync_bytes); rc) return rc;
-	RX_HIP(hipMemsetAsync(h->d_sync.ptr, 0, sync_bytes, st));
-	uint32_t* d_sync = static_cast<uint32_t*>(h->d_sync.ptr);
-	uint32_t* d_error = d_sync;
-	uint32_t* d_tickets = d_sync + 8;
-	uint32_t* d_num_docs = d_tickets + launches + 1;
-	unsigned long long* d_lookback = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->d_sync.ptr) + ((sync_u32 * 4 + 7) & ~size_t(7)));
-	if (int rc = h->d_slot_of.ensure(N * 4); rc) return rc;
-	RX_HIP(hipMemsetAsync(h->d_slot_of.ptr, 0xFF, N * 4, st));
-	rxgpu::FtSlots slots{};
-	if (int rc = carve_slots(h, size_t(max_merged), slots); rc) return rc;
-
-	EventPair ev;
-	if (int rc = ev.create(); rc) return rc;
-	RX_HIP(hipEventRecord(ev.a, st));
-	uint32_t launch = 0;
-	uint64_t lb_used = 0;
-	for (uint32_t s = 0; s < nsub; ++s) {   // sub-terms in SortSubterms order; documents are unique inside one: a launch is race free
-		if (!subs[s].n) continue;
-		rxgpu::FtTermPass p{};
-		p.cfg.num_fields = nf;
-		p.cfg.words = h->d_words;
-		p.cfg.avg_words = h->d_avg;
-		p.cfg.k1 = cfg->bm25_k1;
-		p.cfg.b = cfg->bm25_b;
-		p.cfg.summation_ratio = cfg->summation_ranks_by_fields_ratio;
-		p.cfg.opts_boost = opts->boost;
-		p.cfg.term_len_boost_in = opts->term_len_boost;
-		p.cfg.field_boost = fc + 0 * nf;
-		p.cfg.bm25_boost = fc + 1 * nf;
-		p.cfg.bm25_weight = fc + 2 * nf;
-		p.cfg.term_len_boost = fc + 3 * nf;
-		p.cfg.term_len_weight = fc + 4 * nf;
-		p.cfg.position_boost = fc + 5 * nf;
-		p.cfg.position_weight = fc + 6 * nf;
-		p.cfg.need_sum_rank = reinterpret_cast<const uint8_t*>(fc + 7 * nf);
-		p.sub = subs[s];
-		p.slots = slots;
-		p.mask = static_cast<const uint32_t*>(h->d_mask.ptr);
-		p.removed = h->d_removed;
-		p.slot_of = static_cast<uint32_t*>(h->d_slot_of.ptr);
-		p.max_merged = uint32_t(max_merged);
-		p.qp_idx = 1;
-		p.simple = 1;
-		p.num_docs_in = d_num_docs + launch;
-		p.num_docs_out = d_num_docs + launch + 1;
-		p.lookback = d_lookback + lb_used;
-		p.ticket = d_tickets + launch;
-		p.error_flag = d_error;
-		rxgpu::launch_ft_term_pass(p, st);
-		lb_used += rxgpu::ft_pass_blocks(subs[s].n);
-		++launch;
-	}
-	RX_HIP(hipEventRecord(ev.b, st));
-	RX_HIP(hipGetLastError());
-	uint32_t tail[2] = {0, 0};
-	RX_HIP(hipMemcpyAsync(&tail[0], d_num_docs + launch, 4, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipMemcpyAsync(&tail[1], d_error, 4, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipStreamSynchronize(st));
-	const float ms = ev.elapsed_ms();
-	h->stat_postings += total;
-	h->stat_ms += ms;
-	RX_CHECK(tail[1] == 0, RXGPU_ERR_DEVICE, "rxgpu_ft_merge_simple_raw: ordered look-back timed out on the device");
-	const uint64_t n = tail[0];
-	if (n) {
-		RX_HIP(hipMemcpy(out_doc, slots.doc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-		RX_HIP(hipMemcpy(out_proc, slots.proc, n * sizeof(float), hipMemcpyDeviceToHost));
-		RX_HIP(hipMemcpy(out_field, slots.field, n, hipMemcpyDeviceToHost));
-	}
-	*out_n = n;
-	return RXGPU_OK;
+	std::vector<QueryTermIn> terms{QueryTermIn{1, opts, 0, nsub}};
+	return run_merge(h, cfg, true, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, nullptr, cap, out_n, nullptr,
+					 "rxgpu_ft_merge_simple_raw");
 }
 
 int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uint32_t* doc, const uint32_t* pos_off, const uint64_t* fpos) {
@@ -410,245 +553,13 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	if (nterms == 1 && ops[0] == 3) return RXGPU_OK;
 	RX_CHECK(nterms >= 2, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: a single-term query is Simple(): use rxgpu_ft_merge_simple_raw");
 	RX_CHECK(nterms < 0xFFFF, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: too many terms");
-	const uint32_t nsub_total = sub_off[nterms];
-	RX_CHECK(nsub_total == 0 || (word_ids && procs), RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: null argument");
-
+	RX_CHECK(sub_off[nterms] == 0 || (word_ids && procs), RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
 	DevGuard dg(h->device);
-	const uint32_t nf = h->num_fields;
-	const uint64_t N = h->total_docs;
-	std::vector<rxgpu::FtPosSubterm> subs(nsub_total);
-	std::vector<uint64_t> term_postings(nterms, 0);
-	uint64_t total_vids = 0;
-	for (uint32_t t = 0; t < nterms; ++t) {
-		uint64_t gp = 0;
-		for (uint32_t s = sub_off[t]; s < sub_off[t + 1]; ++s) {
-			auto it = h->words.find(word_ids[s]);
-			RX_CHECK(it != h->words.end(), RXGPU_ERR_NOTFOUND, "rxgpu_ft_merge_terms_raw: unknown word id");
-			const rxgpu_ft_word& w = it->second;
-			RX_CHECK(w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_terms_raw: the word was uploaded without positions (rxgpu_ft_set_word_positions)");
-			RX_CHECK(s == sub_off[t] || procs[s] <= procs[s - 1], RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: sub-terms must be sorted by proc, descending (SortSubterms)");
-			rxgpu::FtPosSubterm& ft = subs[s];
-			fill_subterm(w, N, procs[s], ft);
-			ft.gp_base = gp;
-			gp += w.n;
-		}
-		term_postings[t] = gp;
-		total_vids += gp;   // totalORVids: MaxVDocs of every term (selecterimpl.h:546)
-	}
-	RX_CHECK(total_vids < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: more than 2^32 postings in one merge");
-	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, total_vids);
-	if (max_merged == 0) return RXGPU_OK;
-	RX_CHECK(cap >= max_merged && out_doc && out_proc && out_field && out_terms_counter, RXGPU_ERR_OVERFLOW,
-			 "rxgpu_ft_merge_terms_raw: output buffers too small");
-
-	hipStream_t st = h->stream;
-	// ---- configuration: 6 FTFieldConfig rows shared by all terms + per term (fieldBoost floats, needSumRank bytes)
-	const size_t cfg_floats = size_t(6) * nf + size_t(nterms) * nf;
-	std::vector<float> fcfg(cfg_floats);
-	for (uint32_t f = 0; f < nf; ++f) {
-		fcfg[0 * nf + f] = float(cfg->bm25_boost[f]);
-		fcfg[1 * nf + f] = float(cfg->bm25_weight[f]);
-		fcfg[2 * nf + f] = float(cfg->term_len_boost[f]);
-		fcfg[3 * nf + f] = float(cfg->term_len_weight[f]);
-		fcfg[4 * nf + f] = float(cfg->position_boost[f]);
-		fcfg[5 * nf + f] = float(cfg->position_weight[f]);
-	}
-	std::vector<uint8_t> need_sum(size_t(nterms) * nf);
-	for (uint32_t t = 0; t < nterms; ++t) {
-		RX_CHECK(opts[t].field_boost && opts[t].need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: null term options");
-		uint32_t nsum = 0;
-		for (uint32_t f = 0; f < nf; ++f) nsum += opts[t].need_sum_rank[f] ? 1 : 0;
-		RX_CHECK(nsum <= 8, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: more than 8 fields with needSumRank (GPU engine limit)");
-		for (uint32_t f = 0; f < nf; ++f) {
-			fcfg[size_t(6 + t) * nf + f] = opts[t].field_boost[f];
-			need_sum[size_t(t) * nf + f] = opts[t].need_sum_rank[f];
-		}
-	}
-	if (int rc = h->d_cfg.ensure(cfg_floats * sizeof(float) + need_sum.size()); rc) return rc;
-	RX_HIP(hipMemcpyAsync(h->d_cfg.ptr, fcfg.data(), cfg_floats * sizeof(float), hipMemcpyHostToDevice, st));
-	RX_HIP(hipMemcpyAsync(static_cast<char*>(h->d_cfg.ptr) + cfg_floats * sizeof(float), need_sum.data(), need_sum.size(), hipMemcpyHostToDevice, st));
-	const float* d_fc = static_cast<const float*>(h->d_cfg.ptr);
-	const uint8_t* d_need_sum = reinterpret_cast<const uint8_t*>(d_fc + cfg_floats);
-	if (int rc = h->d_subs.ensure(std::max<size_t>(1, subs.size()) * sizeof(rxgpu::FtPosSubterm)); rc) return rc;
-	if (!subs.empty()) RX_HIP(hipMemcpyAsync(h->d_subs.ptr, subs.data(), subs.size() * sizeof(rxgpu::FtPosSubterm), hipMemcpyHostToDevice, st));
-	const rxgpu::FtPosSubterm* d_subs = static_cast<const rxgpu::FtPosSubterm*>(h->d_subs.ptr);
-
-	// ---- buildRestrictingBitmask
-	const uint64_t nwords = (N + 31) / 32;
-	if (int rc = h->d_mask.ensure(nwords * 4); rc) return rc;
-	if (int rc = h->d_tmask.ensure(nwords * 4); rc) return rc;
-	uint32_t* d_mask = static_cast<uint32_t*>(h->d_mask.ptr);
-	uint32_t* d_tmask = static_cast<uint32_t*>(h->d_tmask.ptr);
-	const uint8_t* d_excl = nullptr;
-	if (excluded) {
-		if (int rc = h->d_excluded.ensure(N); rc) return rc;
-		RX_HIP(hipMemcpyAsync(h->d_excluded.ptr, excluded, N, hipMemcpyHostToDevice, st));
-		d_excl = static_cast<const uint8_t*>(h->d_excluded.ptr);
-	}
-	rxgpu::launch_ft_mask_init(d_mask, d_excl, N, st);
-	for (uint32_t t = 0; t < nterms; ++t) {
-		if (ops[t] != 2) continue;
-		RX_HIP(hipMemsetAsync(d_tmask, 0, nwords * 4, st));
-		rxgpu::launch_ft_term_mask(d_subs + sub_off[t], sub_off[t + 1] - sub_off[t], term_postings[t], d_fc + size_t(6 + t) * nf, nf, d_tmask, st);
-		rxgpu::launch_ft_mask_and(d_mask, d_tmask, nwords, st);
-	}
-	for (uint32_t t = 0; t < nterms; ++t) {
-		if (ops[t] != 3) continue;
-		rxgpu::launch_ft_mask_exclude(d_subs + sub_off[t], sub_off[t + 1] - sub_off[t], term_postings[t], d_mask, st);
-	}
-
-	// ---- synchronisation words: [0] error flag, [1] popcount, [2..3] preselect pick, then per launch: ticket + numDocs chain + look-back words
-	uint32_t merge_launches = 0;
-	uint64_t lookback_words = 0;
-	for (uint32_t t = 0; t < nterms; ++t) {
-		if (ops[t] == 3) continue;
-		for (uint32_t s = sub_off[t]; s < sub_off[t + 1]; ++s) {
-			if (!subs[s].n) continue;
-			++merge_launches;
-			lookback_words += rxgpu::ft_pass_blocks(subs[s].n);
-		}
-	}
-	const uint64_t pre_blocks = (nwords + 255) / 256;
-	const size_t sync_u32 = 8 + size_t(merge_launches + 1) * 2 + 2;   // header, (ticket, numDocs) per launch (+1), preselect ticket
-	const size_t sync_bytes = ((sync_u32 * 4 + 7) & ~size_t(7)) + (lookback_words + pre_blocks) * 8;
-	if (int rc = h->d_sync.ensure(sync_bytes); rc) return rc;
-	RX_HIP(hipMemsetAsync(h->d_sync.ptr, 0, sync_bytes, st));
-	uint32_t* d_sync = static_cast<uint32_t*>(h->d_sync.ptr);
-	uint32_t* d_error = d_sync + 0;
-	uint32_t* d_pop = d_sync + 1;
-	uint32_t* d_pick = d_sync + 2;
-	uint32_t* d_pre_ticket = d_sync + 4;
-	uint32_t* d_tickets = d_sync + 8;                        // [merge_launches]
-	uint32_t* d_num_docs = d_tickets + merge_launches + 1;   // [merge_launches + 1]
-	unsigned long long* d_lookback = reinterpret_cast<unsigned long long*>(static_cast<char*>(h->d_sync.ptr) + ((sync_u32 * 4 + 7) & ~size_t(7)));
-
-	// ---- estimateNumDocsInMerge (merger.h:239-267) and the 2-phase gate (mergerimpl.h:486-490)
-	bool preselected = false;
-	{
-		uint64_t est_or = 0, est_and = UINT64_MAX;
-		for (uint32_t t = 0; t < nterms; ++t) {
-			if (ops[t] == 3) continue;
-			if (ops[t] == 2) {
-				est_and = std::min(est_and, term_postings[t]);
-			} else {
-				est_or += term_postings[t];
-			}
-		}
-		const uint64_t est = std::min(std::min(est_or, est_and), N);
-		if (est > cfg->merge_limit && N > cfg->merge_limit) {
-			rxgpu::launch_ft_mask_popcount(d_mask, nwords, d_pop, st);
-			uint32_t pop = 0;
-			RX_HIP(hipMemcpyAsync(&pop, d_pop, 4, hipMemcpyDeviceToHost, st));
-			RX_HIP(hipStreamSynchronize(st));
-			preselected = pop > cfg->merge_limit;
-		}
-	}
-	if (preselected) {   // preselectMostRelevantDocs (mergerimpl.h:386-464)
-		if (int rc = h->d_score.ensure(N * 2); rc) return rc;
-		if (int rc = h->d_hist.ensure(65536 * 4); rc) return rc;
-		RX_HIP(hipMemsetAsync(h->d_score.ptr, 0, N * 2, st));
-		RX_HIP(hipMemsetAsync(h->d_hist.ptr, 0, 65536 * 4, st));
-		uint16_t* d_score = static_cast<uint16_t*>(h->d_score.ptr);
-		for (uint32_t t = 0; t < nterms; ++t) {
-			if (ops[t] == 3) continue;
-			RX_HIP(hipMemsetAsync(d_tmask, 0, nwords * 4, st));
-			bool same = true;
-			for (uint32_t f = 0; f < nf; ++f) same = same && opts[t].field_boost[f] == opts[t].field_boost[0];
-			for (uint32_t s = sub_off[t]; s < sub_off[t + 1]; ++s) {
-				rxgpu::launch_ft_prescore(subs[s], d_mask, d_tmask, d_score, d_fc + size_t(6 + t) * nf, nf, same, opts[t].boost, st);
-			}
-		}
-		rxgpu::FtPreselect ps{};
-		ps.mask_in = d_mask;
-		ps.mask = d_mask;
-		ps.term_mask = d_tmask;
-		ps.score = d_score;
-		ps.hist = static_cast<uint32_t*>(h->d_hist.ptr);
-		ps.pick = d_pick;
-		ps.total_docs = N;
-		ps.removed = h->d_removed;
-		ps.max_merged = uint32_t(max_merged);
-		ps.lookback = d_lookback + lookback_words;
-		ps.ticket = d_pre_ticket;
-		ps.error_flag = d_error;
-		rxgpu::launch_ft_preselect(ps, st);
-	}
-
-	// ---- mergeTerm for every term that is not a NOT
-	if (int rc = h->d_slot_of.ensure(N * 4); rc) return rc;
-	RX_HIP(hipMemsetAsync(h->d_slot_of.ptr, 0xFF, N * 4, st));
-	rxgpu::FtSlots slots{};
-	if (int rc = carve_slots(h, size_t(max_merged), slots); rc) return rc;
-
-	EventPair ev;
-	if (int rc = ev.create(); rc) return rc;
-	RX_HIP(hipEventRecord(ev.a, st));
-	uint32_t launch = 0;
-	uint64_t lb_used = 0, merged_postings = 0;
-	uint16_t qp = 0;
-	for (uint32_t t = 0; t < nterms; ++t) {
-		if (ops[t] == 3) continue;
-		++qp;
-		for (uint32_t s = sub_off[t]; s < sub_off[t + 1]; ++s) {
-			if (!subs[s].n) continue;
-			rxgpu::FtTermPass p{};
-			p.cfg.num_fields = nf;
-			p.cfg.words = h->d_words;
-			p.cfg.avg_words = h->d_avg;
-			p.cfg.k1 = cfg->bm25_k1;
-			p.cfg.b = cfg->bm25_b;
-			p.cfg.summation_ratio = cfg->summation_ranks_by_fields_ratio;
-			p.cfg.opts_boost = opts[t].boost;
-			p.cfg.term_len_boost_in = opts[t].term_len_boost;
-			p.cfg.field_boost = d_fc + size_t(6 + t) * nf;
-			p.cfg.need_sum_rank = d_need_sum + size_t(t) * nf;
-			p.cfg.bm25_boost = d_fc + 0 * nf;
-			p.cfg.bm25_weight = d_fc + 1 * nf;
-			p.cfg.term_len_boost = d_fc + 2 * nf;
-			p.cfg.term_len_weight = d_fc + 3 * nf;
-			p.cfg.position_boost = d_fc + 4 * nf;
-			p.cfg.position_weight = d_fc + 5 * nf;
-			p.sub = subs[s];
-			p.slots = slots;
-			p.mask = d_mask;
-			p.removed = preselected ? nullptr : h->d_removed;   // needToCheckRemoved_ = false after the preselect
-			p.slot_of = static_cast<uint32_t*>(h->d_slot_of.ptr);
-			p.max_merged = uint32_t(max_merged);
-			p.qp_idx = qp;
-			p.distance_weight = float(cfg->distance_weight);
-			p.distance_boost = float(cfg->distance_boost);
-			p.num_docs_in = d_num_docs + launch;
-			p.num_docs_out = d_num_docs + launch + 1;
-			p.lookback = d_lookback + lb_used;
-			p.ticket = d_tickets + launch;
-			p.error_flag = d_error;
-			rxgpu::launch_ft_term_pass(p, st);
-			lb_used += rxgpu::ft_pass_blocks(subs[s].n);
-			merged_postings += subs[s].n;
-			++launch;
-		}
-	}
-	RX_HIP(hipEventRecord(ev.b, st));
-	RX_HIP(hipGetLastError());
-	uint32_t tail[2] = {0, 0};   // numDocs, error flag
-	RX_HIP(hipMemcpyAsync(&tail[0], d_num_docs + launch, 4, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipMemcpyAsync(&tail[1], d_error, 4, hipMemcpyDeviceToHost, st));
-	RX_HIP(hipStreamSynchronize(st));
-	const float ms = ev.elapsed_ms();
-	h->stat_postings += merged_postings;
-	h->stat_ms += ms;
-	RX_CHECK(tail[1] == 0, RXGPU_ERR_DEVICE, "rxgpu_ft_merge_terms_raw: ordered look-back timed out on the device");
-	const uint64_t n = tail[0];
-	if (n) {
-		RX_HIP(hipMemcpy(out_doc, slots.doc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-		RX_HIP(hipMemcpy(out_proc, slots.proc, n * sizeof(float), hipMemcpyDeviceToHost));
-		RX_HIP(hipMemcpy(out_field, slots.field, n, hipMemcpyDeviceToHost));
-		RX_HIP(hipMemcpy(out_terms_counter, slots.terms_counter, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
-	}
-	*out_n = n;
-	if (out_preselected) *out_preselected = preselected ? 1 : 0;
-	return RXGPU_OK;
+	std::vector<QueryTermIn> terms(nterms);
+	for (uint32_t t = 0; t < nterms; ++t) terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1]};
+	return run_merge(h, cfg, false, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected,
+					 "rxgpu_ft_merge_terms_raw");
 }
 
 int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms) {

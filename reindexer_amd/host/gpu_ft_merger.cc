@@ -115,7 +115,6 @@ void GpuFtMerger::ReadStats(uint64_t& postings, double& kernelMs) const {
 MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 							 RankSortType rankSortType) const {
 	MergeData out;
-	if (cfg.bm25Type != FtConfig::Bm25Type::Rx) throw std::logic_error("GpuFtMerger: only Bm25Rx is evaluated on the device (see Supports())");
 	if (subterms.empty() || totalDocs_ == 0) return out;   // mergerimpl.h:472-474
 	if (cfg.fieldsCfg.size() != numFields_ || termOpts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
 	// TermResults::SortSubterms (querymergedata.h:62-66): by proc, descending
@@ -135,6 +134,7 @@ MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std
 		needSum[f] = termOpts.fieldsOpts[f].needSumRank ? 1 : 0;
 	}
 	rxgpu_ft_config c{};
+	c.bm25_type = cfg.bm25Type == FtConfig::Bm25Type::Rx ? 0 : (cfg.bm25Type == FtConfig::Bm25Type::Classic ? 1 : 2);
 	c.bm25_k1 = cfg.bm25k1;
 	c.bm25_b = cfg.bm25b;
 	c.summation_ranks_by_fields_ratio = cfg.summationRanksByFieldsRatio;
@@ -218,7 +218,6 @@ MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> te
 								  bool* preselected) const {
 	if (preselected) *preselected = false;
 	MergeData out;
-	if (cfg.bm25Type != FtConfig::Bm25Type::Rx) throw std::logic_error("GpuFtMerger: only Bm25Rx is evaluated on the device (see Supports())");
 	// QueryMergeData::Empty() (querymergedata.h:208) / mergerimpl.h:472-474
 	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return out;
 	if (terms.size() == 1) return Merge(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType);   // Simple()
@@ -235,6 +234,7 @@ MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> te
 		posWeight[f] = cfg.fieldsCfg[f].positionWeight;
 	}
 	rxgpu_ft_config c{};
+	c.bm25_type = cfg.bm25Type == FtConfig::Bm25Type::Rx ? 0 : (cfg.bm25Type == FtConfig::Bm25Type::Classic ? 1 : 2);
 	c.bm25_k1 = cfg.bm25k1;
 	c.bm25_b = cfg.bm25b;
 	c.summation_ranks_by_fields_ratio = cfg.summationRanksByFieldsRatio;

@@ -32,8 +32,8 @@ struct FtConfig {
 	uint32_t mergeLimit = 20000;
 	double distanceBoost = 1.0, distanceWeight = 0.5;
 	double bm25k1 = 2.0, bm25b = 0.75;
-	// FTConfig::Bm25Config::Bm25Type (ftconfig.h:199-206).  The GPU merger evaluates Bm25Rx (the default); Classic and wordCount stay on the
-	// reference's CPU merger: Supports(cfg, ...) is false for them and Merge / MergeQuery refuse loudly.
+	// FTConfig::Bm25Config::Bm25Type (ftconfig.h:199-206): the calculator behind Bm25Calculator<BM> (bm25.h:8-68, dispatch selecterimpl.h:615-624);
+	// all three are evaluated on the device (ft_rank.hip.h).
 	enum class Bm25Type { Classic, Rx, WordCount };
 	Bm25Type bm25Type = Bm25Type::Rx;
 	double summationRanksByFieldsRatio = 0.0;
@@ -115,14 +115,15 @@ public:
 
 	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept { return numQueryParts >= 1 && !hasPhrases && !hasSynonyms; }
 	static bool Supports(const FtConfig& cfg, size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept {
-		return cfg.bm25Type == FtConfig::Bm25Type::Rx && Supports(numQueryParts, hasPhrases, hasSynonyms);
+		(void)cfg;   // every Bm25Type is evaluated on the device
+		return Supports(numQueryParts, hasPhrases, hasSynonyms);
 	}
 
-	// Merger::Merge<Bm25Rx> for a Simple() query
+	// Merger::Merge<Bm25T> for a Simple() query (Bm25T from cfg.bm25Type)
 	MergeData Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 					RankSortType rankSortType) const;
 
-	// Merger::Merge<Bm25Rx> for any query made of terms (queryParts without phrases, no synonyms); one OR/AND term -> Merge()
+	// Merger::Merge<Bm25T> for any query made of terms (queryParts without phrases, no synonyms); one OR/AND term -> Merge()
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
 

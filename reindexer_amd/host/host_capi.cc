@@ -406,6 +406,7 @@ long rxhost_ft_merge(void* h, size_t nf, const double* cfgD, const int* cfgI, co
 		cfg.fullMatchBoost = cfgD[3];
 		cfg.minRank = cfgI[0];
 		cfg.mergeLimit = uint32_t(cfgI[1]);
+		cfg.bm25Type = cfgI[2] == 1 ? FtConfig::Bm25Type::Classic : (cfgI[2] == 2 ? FtConfig::Bm25Type::WordCount : FtConfig::Bm25Type::Rx);
 		FtDslOpts opts;
 		opts.boost = boost;
 		opts.termLenBoost = termLenBoost;
@@ -473,6 +474,7 @@ extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, co
 		cfg.distanceWeight = cfgD[5];
 		cfg.minRank = cfgI[0];
 		cfg.mergeLimit = uint32_t(cfgI[1]);
+		cfg.bm25Type = cfgI[2] == 1 ? FtConfig::Bm25Type::Classic : (cfgI[2] == 2 ? FtConfig::Bm25Type::WordCount : FtConfig::Bm25Type::Rx);
 		for (size_t f = 0; f < nf; ++f) {
 			cfg.fieldsCfg[f] = FtFieldConfig{fieldCfg[f * 6 + 0], fieldCfg[f * 6 + 1], fieldCfg[f * 6 + 2], fieldCfg[f * 6 + 3], fieldCfg[f * 6 + 4], fieldCfg[f * 6 + 5]};
 		}

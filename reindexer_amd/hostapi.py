@@ -537,7 +537,7 @@ class GpuFtMerger:
         """cfg/opts: dicts as built by default_ft_config()/default_ft_opts(); subterms: [(word_id, proc), ...]."""
         nf = self.nf
         cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"]], np.float64)
-        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"]], np.int32)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")]], np.int32)
         fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
                                                                "position_boost", "position_weight")], axis=1).copy()
         fb = _f32(opts["field_boost"])
@@ -578,7 +578,7 @@ class GpuFtMerger:
         nf = self.nf
         cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
                           cfg.get("distance_weight", 0.5)], np.float64)
-        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"]], np.int32)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")]], np.int32)
         fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
                                                                "position_boost", "position_weight")], axis=1).copy()
         ops = np.array([t["op"] for t in terms], np.int32)

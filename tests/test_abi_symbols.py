@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(str(capi.LIB_PATH))
     for name in header_symbols():
         assert hasattr(lib, name), f"librxgpu.so does not export {name}"
-    assert lib.rxgpu_abi_version() == 1
+    assert lib.rxgpu_abi_version() == 2
 
 
 def test_product_never_imports_oracle():

@@ -1,4 +1,4 @@
-"""-m gpu: ft_fast BM25 merge on the GPU (bm25.hip through rxgpu_ft_* and GpuFtMerger) vs the CPU restatement that is pinned
+"""-m gpu: ft_fast BM25 merge on the GPU (ft_merge.hip through rxgpu_ft_* and GpuFtMerger) vs the CPU restatement that is pinned
 by the reference's golden debug_rank strings.  Bar: id set equal, uint8 rank equal — here the raw float ranks are
 bit-identical as well, because the kernel keeps the reference's fp64/fp32 types operation for operation."""
 import numpy as np
@@ -120,4 +120,32 @@ def test_more_than_eight_summed_fields_is_refused_loudly(hostapi):
         m.merge(cfg, hostapi.default_ft_opts(nf, need_sum_rank=[1] * nf), [(0, 100.0)])
     ok = m.merge(cfg, hostapi.default_ft_opts(nf, need_sum_rank=[1] * 8 + [0, 0]), [(0, 100.0)])
     assert len(ok[0]) > 0
+    m.close()
+
+
+@pytest.mark.parametrize("bm25_type", ["classic", "word_count"])
+@pytest.mark.parametrize("nf,limit", [(1, 20000), (3, 150)])
+def test_gpu_merge_bm25_classic_and_word_count(hostapi, ft, bm25_type, nf, limit):
+    """FTConfig::Bm25Config::bm25Type = classic / wordCount (bm25.h:38-68) evaluated ON THE DEVICE: same documents, order, raw-rank bits and
+    uint8 ranks as the restatement, which tests/test_bm25_oracle.py pins against the real Merge<Bm25Classic> / Merge<TermCount>."""
+    rng = np.random.default_rng(nf * 7 + limit + len(bm25_type))
+    total = 2500
+    words = rng.integers(1, 40, (total, nf)).astype(np.float32)
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg)
+    subs = []
+    for wid, proc in enumerate((100.0, 88.5, 61.0)):
+        s = make_postings(rng, total, nf, int(rng.integers(200, 1200)))
+        s["proc"] = proc
+        subs.append(s)
+        m.set_word_flat(wid, s)
+    cfg = ft.default_config(nf, merge_limit=limit, bm25_type=bm25_type)
+    opts = ft.default_opts(nf, field_boost=[1.0, 0.7, 1.3][:nf], term_len_boost=0.8)
+    for sort_by_rank in (False, True):
+        wd, wp, wf, wn = ft.merge_simple(cfg, opts, total, words, avg, None, None, subs, sort_by_rank=sort_by_rank)
+        gd, gp, gf, gn = m.merge(cfg, opts, [(i, s["proc"]) for i, s in enumerate(subs)], sort_by_rank=sort_by_rank)
+        assert np.array_equal(gd.astype(np.uint32), wd) and np.array_equal(gn, wn) and np.array_equal(gf, wf)
+        assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
     m.close()

@@ -1,4 +1,4 @@
-"""-m gpu: ft_fast MULTI-TERM merge on the GPU (ft_terms.hip through rxgpu_ft_merge_terms_raw and GpuFtMerger::MergeQuery) vs the
+"""-m gpu: ft_fast MULTI-TERM merge on the GPU (ft_merge.hip through rxgpu_ft_merge_terms_raw and GpuFtMerger::MergeQuery) vs the
 CPU restatement of Merger::Merge, which tests/test_bm25_oracle.py pins bit-exact against the real reference merger.
 Bar: the same documents in the same merge order, the same raw-rank bits, fields and uint8 ranks — for AND / OR / NOT terms, zero field
 boosts, array positions, the mergeLimit cut inside mergeTerm and the preselect phase."""
@@ -23,7 +23,8 @@ def hostapi(rxgpu):
     return h
 
 
-def _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, expect_pre=None, variants=((1.0, 0.5), (1.7, 0.8), (0.0, 1.0))):
+def _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, expect_pre=None, variants=((1.0, 0.5), (1.7, 0.8), (0.0, 1.0)),
+           bm25_type="rx"):
     m = hostapi.GpuFtMerger(nf)
     m.set_docs(words, avg, removed)
     for s in store:
@@ -31,7 +32,7 @@ def _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, 
     gterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
     saw_pre = False
     for variant, (dboost, dweight) in enumerate(variants):
-        cfg = ft.default_config(nf, merge_limit=limit, min_rank=5 if variant != 1 else 60)
+        cfg = ft.default_config(nf, merge_limit=limit, min_rank=5 if variant != 1 else 60, bm25_type=bm25_type)
         cfg["distance_boost"], cfg["distance_weight"] = dboost, dweight
         for exc in (None, excluded):
             wd, wp, wf, wn, wpre = ft.merge_query(cfg, terms, total, words, avg, removed, exc, sort_by_rank=False, distance_boost=dboost,
@@ -56,6 +57,15 @@ def _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, 
 def test_gpu_multi_term_merge_equals_restated_merger(hostapi, ft, seed, nf, total, limit, ops, arr, fbs):
     _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, fbs)
     _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, expect_pre=(limit < 1000 and 1 in ops))
+
+
+@pytest.mark.parametrize("bm25_type", ["classic", "word_count"])
+@pytest.mark.parametrize("case", [0, 3, len(MULTI_CASES) - 1])
+def test_gpu_multi_term_merge_classic_and_word_count(hostapi, ft, bm25_type, case):
+    """The other two calculators of Bm25Calculator<BM> (bm25.h:38-68) through the multi-term merge."""
+    seed, nf, total, limit, ops, arr, fbs = MULTI_CASES[case]
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, fbs)
+    _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, variants=((1.0, 0.5),), bm25_type=bm25_type)
 
 
 @pytest.mark.parametrize("limit,ops", [(20000, (1, 1)), (3000, (1, 1, 1)), (2500, (2, 1)), (700, (2, 2)), (20000, (1, 3, 2))])
