@@ -289,7 +289,7 @@ SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optio
 	std::vector<uint32_t> row(kk);
 	uint32_t count = 0;
 	fetchTopK(queryData, kk, dist.data(), row.data(), &count);
-	result.reserve(k);
+	ReserveQueue(result, k);
 	const bool tieAcross = count > k && !(dist[k - 1] < dist[k]);
 	if (!tieAcross) {
 		for (size_t i = 0; i < std::min<size_t>(k, count); ++i) result.emplace(dist[i], labels_[row[i]]);
@@ -302,7 +302,7 @@ SearchResultQueue GpuBruteforceMap::SearchKnn(const float* queryData, std::optio
 // scan order through the reference's admission rule.
 SearchResultQueue GpuBruteforceMap::replayTies(const float* queryData, size_t k, float dk, const std::vector<uint32_t>* allowedRows) const {
 	SearchResultQueue result;
-	result.reserve(k);
+	ReserveQueue(result, k);
 	{
 		std::lock_guard<std::mutex> lk(syncMtx_);
 		++tieReplays_;
@@ -382,7 +382,7 @@ SearchResultQueue GpuBruteforceMap::SearchKnnFiltered(const float* queryData, st
 	if (rc != RXGPU_OK) throwDevice("SearchKnnFiltered");
 	const bool tieAcross = count > k && !(dist[k - 1] < dist[k]);
 	if (tieAcross) return replayTies(queryData, k, dist[k - 1], &rows);
-	result.reserve(k);
+	ReserveQueue(result, k);
 	for (size_t i = 0; i < std::min<size_t>(k, count); ++i) result.emplace(dist[i], labels_[row[i]]);
 	return result;
 }
@@ -402,7 +402,7 @@ SearchResultQueue GpuBruteforceMap::SearchRange(const float* queryData, std::opt
 		rd.resize(total);
 		rr.resize(total);
 	}
-	result.reserve(total);
+	ReserveQueue(result, total);
 	for (uint64_t i = 0; i < total; ++i) result.emplace(rd[i], labels_[rr[i]]);
 	return result;
 }

@@ -175,7 +175,7 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 	std::vector<uint32_t> row(k);
 	uint32_t count = 0;
 	fetchKnn(queryDataRaw, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count);
-	result.reserve(count);
+	ReserveQueue(result, count);
 	for (uint32_t i = 0; i < count; ++i) result.emplace(dist[i], graph_.Label(row[i]));
 	return result;
 }
@@ -218,7 +218,7 @@ StreamingBatch GpuHnswMap::ContinueStreamingSearch(StreamingSearchSession& sessi
 	if (rxgpu_hnsw_stream_continue(session.impl_, uint32_t(std::min<size_t>(batchSize, 0xFFFFFFFFu)), dist.data(), row.data(), &count, &exhausted) != RXGPU_OK) {
 		throwDevice("ContinueStreamingSearch");
 	}
-	batch.results.reserve(count);
+	ReserveQueue(batch.results, count);
 	for (uint32_t i = 0; i < count; ++i) batch.results.emplace(dist[i], graph_.Label(row[i]));   // emitStreamingBatch: (dist, ExternalLabel)
 	batch.exhausted = exhausted != 0;
 	return batch;

@@ -20,9 +20,14 @@ struct rxgpu_hnsw_stream;
 namespace rxgpu::host {
 
 // hnsw_interface.h:18-45
+#if defined(RXGPU_IN_TREE)
+using hnswlib::StreamingSearchOptions;
+using hnswlib::Synchronization;
+#else
 struct StreamingSearchOptions {
 	size_t ef = 0;
 };
+#endif
 struct StreamingBatch {
 	SearchResultQueue results;
 	bool exhausted = false;
@@ -43,7 +48,9 @@ private:
 
 // hnswlib::Synchronization (hnswlib.h): None = HierarchicalNSWST (AddPointConcurrent throws), OnInsertions = HierarchicalNSWMT (the index
 // type the reference builds from several upsert threads, hnsw_index.cc:18-19, 105-116, 566-573)
+#if !defined(RXGPU_IN_TREE)
 enum class Synchronization { None, OnInsertions };
+#endif
 
 class GpuHnswMap {
 public:

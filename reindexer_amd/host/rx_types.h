@@ -6,6 +6,10 @@
 //   ConstFloatVectorView    cpp_src/core/keyvalue/float_vector.h:12-72               (pointer + dimension)
 //   SearchResultQueue       cpp_src/core/index/float_vector/hnswlib/hnsw_interface.h:14 +
 //                           priority_queue.h:7-152  (max-heap of (dist,label), std::less<pair> => lexicographic)
+//
+// RXGPU_IN_TREE (the engine compiled inside cpp_src): the aliases below ARE the reference's own types — the Maps then
+// compile against reindexer::FloatVectorId / ConstFloatVectorView / hnswlib::SearchResultQueue unchanged, which is what
+// tests/test_seam_compile.py builds (HnswIndexBase<GpuBruteforceMap> / <GpuHnswMapT<...>> instantiated from the reference's hnsw_index.cc).
 #pragma once
 
 #include <cstddef>
@@ -14,7 +18,26 @@
 #include <utility>
 #include <vector>
 
+#if defined(RXGPU_IN_TREE)
+#include "core/enums.h"
+#include "core/index/float_vector/float_vector_id.h"
+#include "core/index/float_vector/hnswlib/hnsw_interface.h"
+#include "core/index/float_vector/hnswlib/type_consts.h"
+#include "core/keyvalue/float_vector.h"
+#endif
+
 namespace rxgpu::host {
+
+#if defined(RXGPU_IN_TREE)
+using reindexer::VectorMetric;
+using reindexer::FloatVectorId;
+using reindexer::ConstFloatVectorView;
+using hnswlib::labeltype;
+using hnswlib::tableint;
+using hnswlib::SearchResultQueue;
+template <class Q>
+inline void ReserveQueue(Q&, size_t) noexcept {}   // hnswlib::PriorityQueue has no reserve()
+#else
 
 enum class VectorMetric { L2 = 0, InnerProduct = 1, Cosine = 2 };
 
@@ -49,6 +72,7 @@ private:
 	const float* data_ = nullptr;
 	size_t dim_ = 0;
 };
+#endif   // RXGPU_IN_TREE
 
 // Binary max-heap with the interface the reference's result consumers use (top/pop/size/empty/emplace/push,
 // replace_top).  Ordering is supplied by Compare exactly like std::priority_queue.
@@ -110,6 +134,10 @@ private:
 	Compare cmp_{};
 };
 
+#if !defined(RXGPU_IN_TREE)
 using SearchResultQueue = ResultHeap<std::pair<float, labeltype>>;
+template <class Q>
+inline void ReserveQueue(Q& q, size_t n) { q.reserve(n); }
+#endif
 
 }  // namespace rxgpu::host
