@@ -73,7 +73,8 @@ def parse_args():
     ap.add_argument("--metric", default="ip", choices=["l2", "ip", "cosine"])
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="only for the plain-C port fallback (no oracle/_ref): row-prefix sample")
     ap.add_argument("--cpu-queries", type=int, default=8, help="queries of the 1-thread CPU leg = queries of the full-size parity check")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = every hardware thread)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = every CPU the container may use: "
+                                                               "min(affinity, cgroup quota), tools/cpu_scaling.py)")
     ap.add_argument("--cpu-per-thread", type=int, default=8)
     ap.add_argument("--cpu-deadline", type=float, default=40.0, help="all-core CPU leg: threads stop STARTING searches after this many seconds")
     ap.add_argument("--scaling", default=os.environ.get("RXGPU_BENCH_SCALING", "weak"), choices=["weak", "strong"])
@@ -102,7 +103,10 @@ def make_corpus(rows: int, dim: int, seed: int, device) -> torch.Tensor:
 
 def host_cpu_info() -> dict:
     """CPU model / hardware threads of the box the baseline ran on, and the reference's SIMD level."""
-    info = {"hardware_threads": os.cpu_count(), "RX_TARGET_INSTRUCTIONS": os.environ.get("RX_TARGET_INSTRUCTIONS", "avx512")}
+    from cpu_scaling import effective_cpus, host_limits
+    lim = host_limits()
+    info = {"hardware_threads": os.cpu_count(), "usable_cpus": effective_cpus(), "cgroup_cpu_max": lim.get("cgroup_v2_cpu_max"),
+            "numa_nodes": lim.get("numa_online"), "RX_TARGET_INSTRUCTIONS": os.environ.get("RX_TARGET_INSTRUCTIONS", "avx512")}
     try:
         with open("/proc/cpuinfo") as f:
             for line in f:
@@ -140,7 +144,8 @@ def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, m
         return cpu_baseline_port_sample(args, corpus, queries, metric_id)
     rows = corpus.shape[0]
     nq = min(args.cpu_queries, queries.shape[0])
-    ncores = os.cpu_count() or 1
+    from cpu_scaling import effective_cpus
+    ncores = effective_cpus()   # what the container may really use: min(affinity, cgroup CPU quota) — NOT os.cpu_count()
     orc = pyoracle.Oracle()
     host_q = queries[:max(nq, 64)].cpu().numpy()
     if metric_id == 2:
@@ -170,7 +175,8 @@ def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, m
         "all_cores": {"value": qps_all, "cores": threads, "queries": done, "seconds": secs, "gbps": qps_all * row_bytes / 1e9,
                       "per_thread_target": args.cpu_per_thread, "deadline_s": args.cpu_deadline,
                       "note": "T threads, each scanning the shared index for its own query (the reference's concurrency model, "
-                              "gtests/tests/unit/float_vector_index.cc:258-294); threads are created before the clock starts"},
+                              "gtests/tests/unit/float_vector_index.cc:258-294); threads are created before the clock starts; T = the CPUs "
+                              "the container may use (cgroup quota, see host) — more threads only add throttling (profiles/r2b_cpu_scaling.json)"},
         "numa_interleaved": interleaved, "index_load_seconds": load_s, "host": host_cpu_info(),
     }
     # parity on the FULL corpus: GPU through the C-ABI vs the reference engine

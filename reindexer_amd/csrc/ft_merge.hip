@@ -308,16 +308,23 @@ __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 	if (keys[threadIdx.x]) atomicAdd(&p.hist[keys[threadIdx.x]], cnts[threadIdx.x]);
 }
 
-// mergerimpl.h:433-446: walk the scores downwards until maxMergedDocs documents are covered
+// mergerimpl.h:433-446: walk the scores downwards until maxMergedDocs documents are covered.  A score sc is visited iff the documents
+// strictly above it are fewer than maxMergedDocs; minScore = the lowest visited score >= 1, minScoreDocs = maxMergedDocs - (documents above
+// it).  `above` is monotone, so the boundary falls inside ONE 64-score chunk: chunk sums by coalesced loads + wave reductions, a suffix
+// scan over the 1024 chunks, then one wavefront resolves the boundary chunk.
 __global__ __launch_bounds__(1024) void ft_preselect_pick(FtPlan p) {
 	if (!ft_preselect_on(p)) return;
-	__shared__ unsigned long long suffix[1024];
-	__shared__ uint32_t s_min;
-	const int t = threadIdx.x;
-	unsigned long long chunk = 0;
-	for (int b = 0; b < 64; ++b) chunk += p.hist[t * 64 + b];
-	suffix[t] = chunk;
-	if (t == 0) s_min = 0xFFFFFFFFu;
+	__shared__ unsigned long long suffix[1024];   // documents in this chunk and every higher one
+	__shared__ uint32_t chunk_sum[1024];
+	__shared__ int s_chunk;
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	for (int i = 0; i < 64; ++i) {   // the wave reads 64 consecutive scores = chunk i * 16 + wave
+		const uint32_t c = wave_sum(p.hist[i * 1024 + t]);
+		if (lane == 0) chunk_sum[i * 16 + wave] = c;
+	}
+	if (t == 0) s_chunk = -1;
+	__syncthreads();
+	suffix[t] = chunk_sum[t];
 	__syncthreads();
 	for (int off = 1; off < 1024; off <<= 1) {   // inclusive suffix sums
 		const unsigned long long v = t + off < 1024 ? suffix[t + off] : 0;
@@ -325,29 +332,44 @@ __global__ __launch_bounds__(1024) void ft_preselect_pick(FtPlan p) {
 		suffix[t] += v;
 		__syncthreads();
 	}
-	unsigned long long above = suffix[t] - chunk;   // documents with a score in a higher chunk
-	// a score sc is visited iff the documents strictly above it are fewer than maxMergedDocs; minScore = lowest visited score >= 1
-	uint32_t lowest = 0xFFFFFFFFu;
-	unsigned long long lowest_above = 0;
-	for (int b = 63; b >= 0; --b) {
-		const uint32_t sc = uint32_t(t * 64 + b);
-		if (sc >= 1 && above < p.max_merged) {
-			lowest = sc;
-			lowest_above = above;
-		}
-		above += p.hist[sc];
-	}
-	if (lowest != 0xFFFFFFFFu) atomicMin(&s_min, lowest);
+	// the lowest chunk whose TOP score is visited (documents in higher chunks < maxMergedDocs); chunk 0 only counts through scores >= 1
+	const unsigned long long above_chunk = suffix[t] - chunk_sum[t];
+	const bool top_visited = above_chunk < p.max_merged;
+	const bool below_visited = t > 0 && suffix[t] < p.max_merged;   // would the top of chunk t - 1 be visited too?
+	if (top_visited && !below_visited) s_chunk = t;   // exactly one thread: `above` is monotone
 	__syncthreads();
 	uint32_t* pick = p.sync + kFtSyncPick;
-	if (s_min == 0xFFFFFFFFu) {
+	const int c = s_chunk;
+	if (c < 0) {   // unreachable (the top chunk has nothing above it), kept as the reference's initial values
 		if (t == 0) {
 			pick[0] = 65535u;
 			pick[1] = 0;
 		}
-	} else if (lowest == s_min) {
-		pick[0] = lowest;
-		pick[1] = uint32_t(p.max_merged - lowest_above);
+		return;
+	}
+	if (wave != 0) return;
+	const uint32_t sc = uint32_t(c * 64 + lane);
+	const uint32_t h = p.hist[sc];
+	uint32_t incl = h;   // inclusive suffix over the lanes: documents with a score in [sc, top of the chunk]
+#pragma unroll
+	for (int off = 1; off < 64; off <<= 1) {
+		const uint32_t o = __shfl_down(incl, off, 64);
+		if (lane + off < 64) incl += o;
+	}
+	const unsigned long long above = (suffix[c] - chunk_sum[c]) + (incl - h);
+	const bool visited = sc >= 1 && above < p.max_merged;
+	const unsigned long long vis = __ballot(visited);
+	if (!vis) {   // only score 0 of chunk 0 left: nothing with a positive score
+		if (lane == 0) {
+			pick[0] = 65535u;
+			pick[1] = 0;
+		}
+		return;
+	}
+	const int low = __ffsll((long long)vis) - 1;   // visited lanes form a suffix of the wave: the lowest one is minScore
+	if (lane == low) {
+		pick[0] = sc;
+		pick[1] = uint32_t(p.max_merged - above);
 	}
 }
 

@@ -62,8 +62,10 @@ def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
 def run(o) -> dict:
     o = SimpleNamespace(**{**DEFAULTS, **(vars(o) if not isinstance(o, dict) else o)})
     metric = capi.METRICS[o.metric]
-    ncpu = os.cpu_count() or 1
-    build_threads = o.build_threads or ncpu
+    sys.path.insert(0, str(ROOT / "tools"))
+    from cpu_scaling import effective_cpus
+    ncpu = effective_cpus()   # min(affinity, cgroup CPU quota): what the container may really use
+    build_threads = o.build_threads or 2 * ncpu
     t_all = time.perf_counter()
     corpus = make_clustered(o.rows + o.queries, o.dim, o.clusters, o.seed, o.device)
     rows, queries = corpus[:o.rows], corpus[o.rows:]
@@ -102,7 +104,7 @@ def run(o) -> dict:
     ix = capi.VectorIndex(metric, o.dim, o.rows, device=o.device)
     ix.upload_rows(0, g["vectors"], g["inv_norms"])
     ix.hnsw_attach_graph(g)
-    ix.hnsw_search_knn(queries[:64], o.k, o.ef)   # warm-up
+    ix.hnsw_search_knn(queries, o.k, o.ef)   # warm-up at full size (scratch buffers, visited bitsets)
     ix.hnsw_read_stats()
     ix.profile_enable(True)
     t0 = time.perf_counter()
