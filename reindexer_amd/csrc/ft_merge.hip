@@ -12,16 +12,17 @@
 //  * admission (addDoc until maxMergedDocs, merger.h:161-180): a document is added by its first posting (in global posting order) that is
 //    eligible and has a non-zero rank; it gets the next merge slot if fewer than maxMergedDocs documents were added before it, and once the
 //    limit is hit nothing is added any more.  `first posting` = atomicMin of the global posting index per document; `slot` = ORDERED prefix
-//    count over those postings (ticket-ordered workgroups, decoupled look-back), cut at maxMergedDocs  ->  ft_rank_all + ft_assign_slots.
+//    count over those postings (per-workgroup counts, then every workgroup sums its predecessors), cut at maxMergedDocs
+//    ->  ft_rank_all + ft_count_adders + ft_assign_slots.
 //  * per-document state (`proc -= rank; proc += finalRank` on every strict improvement, switchToNextWord between terms, termsCounter):
 //    a document meets at most one posting per sub-term, so its postings are scattered into a per-slot row indexed by sub-term
 //    (ft_scatter: unique cells, no atomics) and ONE thread per merged document replays its row in sub-term order with the reference's
 //    float operations (ft_replay)  ->  same bits.
 //  * preselect ties at the threshold score are kept in document order: ordered prefix again (ft_preselect_apply).
 //
-// Launch train of a multi-term query: ft_init, [ft_scan, ft_combine, [ft_score, ft_preselect_pick, ft_preselect_apply]], ft_rank_all,
-// ft_assign_slots, ft_scatter, ft_replay; the 2-phase gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result
-// leaves in one packed buffer.  A Simple() query: ft_init, ft_rank_all, ft_assign_slots, ft_scatter, ft_replay.
+// Launch train of a multi-term query: ft_init, [ft_scan x (up to) 3 levels, ft_combine, [ft_score, ft_preselect_pick, ft_preselect_apply]],
+// ft_rank_all, ft_count_adders, ft_assign_slots, ft_scatter, ft_replay; the 2-phase gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result
+// leaves in one packed buffer.  A Simple() query: ft_init, ft_rank_all, ft_count_adders, ft_assign_slots, ft_scatter, ft_replay.
 //
 // Bound: HBM gathers: per posting 4 B doc + 8 B entry offsets + 9 B per (field, tf, firstPos) entry streamed, 4 B
 // words-in-field + the mask word gathered, 5 B rank/field written and read back, 4 B atomicMin on the first-posting table.
@@ -41,8 +42,7 @@ constexpr unsigned long long kLbPrefix = 1ull << 63;
 constexpr unsigned long long kLbAggregate = 1ull << 62;
 constexpr uint32_t kNoPosting = 0xFFFFFFFFu;
 constexpr uint32_t kBestPresent = 1u << 31;
-
-__device__ __forceinline__ bool mask_bit(const uint32_t* m, uint32_t d) { return (m[d >> 5] >> (d & 31)) & 1u; }
+constexpr int kFtApplyWords = 4;   // mask words per thread in ft_preselect_apply
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -182,26 +182,30 @@ __global__ __launch_bounds__(256) void ft_init(FtPlan p) {
 	fill_words(p.and_masks, uint64_t(p.n_and) * p.nwords, 0u, gtid, gsize);
 	fill_words(p.not_mask, p.not_mask ? p.nwords : 0, 0u, gtid, gsize);
 	if (p.prescore) {
-		fill_words(p.best, uint64_t(p.n_best) * p.total_docs, 0u, gtid, gsize);
+		fill_words(p.best, uint64_t(p.n_best) * p.best_stride, 0u, gtid, gsize);
 		fill_words(p.hist, 65536, 0u, gtid, gsize);
-		fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 255) / 256) * 2, 0u, gtid, gsize);
+		fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)) * 2, 0u, gtid, gsize);
 	}
 	fill_words(p.first, p.total_docs, kNoPosting, gtid, gsize);
 	fill_words(reinterpret_cast<uint32_t*>(p.e_rank), uint64_t(p.n_rows) * p.max_merged, 0u, gtid, gsize);
-	fill_words(reinterpret_cast<uint32_t*>(p.lookback_slots), uint64_t(p.merge_blocks) * 2, 0u, gtid, gsize);
 	fill_words(p.sync, kFtSyncWords, 0u, gtid, gsize);
 }
 
 // ---------------------------------------------------------------------------------------------- restricting bitmask + pre-scores
-// One pass over the postings of every term that needs one:
+// The postings of every term that needs a pass:
 //   AND term  calcTermBitmask (mergerimpl.h:252-274): any occurrence with a relevant field (checkFieldsRelevance, phrasemergerimpl.h:93-125)
 //   NOT term  excludeTermFromBitmask (:276-287)
 //   pre-score calcTermScores (:289-324) for every term that is not a NOT, when the host half of the 2-phase gate held
-__global__ __launch_bounds__(256) void ft_scan(FtPlan p) {
-	const FtGridEntry ge = grid_entry(p.scan_grid, p.n_scan_entries, blockIdx.x);
+// Device-scope atomics on random addresses run at ~28 G/s on this part (they resolve at the memory side, past the per-XCD L2s) — 140 us
+// for the 3.9 M postings of a 3 x 3 query — so the "first sub-term wins" rule is resolved by LAUNCH ORDER instead: level 0 = the first
+// sub-term of every term (plain stores: documents are unique inside a sub-term and every term has its own array), level 1 = the second
+// sub-terms (store only where nothing is recorded yet), level 2 = all further sub-terms together (atomicMax on the few cells still open).
+__global__ __launch_bounds__(256) void ft_scan(FtPlan p, uint32_t level) {
+	const uint32_t block = blockIdx.x + p.scan_level_base[level];
+	const FtGridEntry ge = grid_entry(p.scan_grid, p.n_scan_entries, block);
 	const FtPosSubterm& s = p.subs[ge.sub];
 	const FtTermCfg& t = p.terms[s.term];
-	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const uint64_t i0 = uint64_t(block - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
 	if (i0 >= s.n) return;
 	uint32_t docs[kFtPassItems];
 	bool live[kFtPassItems];
@@ -210,6 +214,10 @@ __global__ __launch_bounds__(256) void ft_scan(FtPlan p) {
 	const bool want_score = p.prescore && op != 3;
 	const bool need_entries = (op == 2 && !t.all_pos_boost) || (want_score && !t.same_boost);
 	const uint32_t ord_key = kBestPresent | ((4095u - uint32_t(s.ord_in_term)) << 16);
+	uint32_t* best = want_score ? p.best + uint64_t(t.best_idx) * p.best_stride : nullptr;
+	uint32_t cur[kFtPassItems];
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) cur[k] = (want_score && level > 0 && live[k]) ? best[docs[k]] : 0u;
 #pragma unroll
 	for (int k = 0; k < kFtPassItems; ++k) {
 		if (!live[k]) continue;
@@ -236,13 +244,21 @@ __global__ __launch_bounds__(256) void ft_scan(FtPlan p) {
 			const float proc = s.proc * mb * t.opts_boost;
 			uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
 			p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
-			atomicMax(&p.best[uint64_t(t.best_idx) * p.total_docs + d], ord_key | p16);
+			const uint32_t key = ord_key | p16;
+			if (level == 0) {
+				best[d] = key;
+			} else if (level == 1) {
+				if (!(cur[k] & kBestPresent)) best[d] = key;
+			} else if (cur[k] < key) {
+				atomicMax(&best[d], key);
+			}
 		}
 	}
 }
 
 // restrictingMask_ &= termMask for every AND term, minus the NOT terms (buildRestrictingBitmask); popcount for the 2-phase gate
 __global__ __launch_bounds__(256) void ft_combine(FtPlan p) {
+	__shared__ uint32_t s_part[4];
 	uint32_t c = 0;
 	for (uint64_t w = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; w < p.nwords; w += uint64_t(gridDim.x) * blockDim.x) {
 		uint32_t m = p.mask[w];
@@ -252,7 +268,12 @@ __global__ __launch_bounds__(256) void ft_combine(FtPlan p) {
 		c += __popc(m);
 	}
 	c = wave_sum(c);
-	if ((threadIdx.x & 63) == 0 && c) atomicAdd(&p.sync[kFtSyncPop], c);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) {   // one atomic per workgroup: thousands of them on one word cost more than the whole pass
+		const uint32_t tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+		if (tot) atomicAdd(&p.sync[kFtSyncPop], tot);
+	}
 }
 
 // ---------------------------------------------------------------------------------------------- preselect
@@ -261,8 +282,9 @@ __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerim
 }
 
 // docsScore[d] = saturating sum over the terms of the first sub-term's proc16; masked-out / removed documents score 0 (mergerimpl.h:416-423);
-// histogram of the rest.  Scores take few distinct values, so the counts are aggregated per wave, then per workgroup in a small LDS table,
-// and only then added to the global histogram.
+// histogram of the rest.  Four documents per thread (16-byte loads, every term's load in flight before the first use: the pass is
+// latency-bound otherwise).  Scores take few distinct values, so the counts are aggregated per wave, then per workgroup in a small LDS
+// table, and only then added to the global histogram.
 __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 	if (!ft_preselect_on(p)) return;
 	__shared__ uint32_t keys[256];
@@ -271,37 +293,64 @@ __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 	cnts[threadIdx.x] = 0;
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
-	for (uint64_t base = uint64_t(blockIdx.x) * 256; base < p.total_docs; base += uint64_t(gridDim.x) * 256) {
-		const uint64_t d = base + threadIdx.x;
-		uint32_t sc = 0;
-		if (d < p.total_docs) {
-			for (uint32_t t = 0; t < p.n_best; ++t) {
-				const uint32_t key = p.best[uint64_t(t) * p.total_docs + d];
-				sc += (key & kBestPresent) ? (key & 0xFFFFu) : 0u;
-			}
-			sc = sc < 65535u ? sc : 65535u;
-			if (sc && (!mask_bit(p.mask, uint32_t(d)) || (p.removed && p.removed[d]))) sc = 0;
-			p.score[d] = uint16_t(sc);
-		}
-		unsigned long long todo = __ballot(sc != 0);
-		while (todo) {
-			const int leader = __ffsll((long long)todo) - 1;
-			const uint32_t v = __shfl(sc, leader, 64);
-			const unsigned long long same = __ballot(sc == v);
-			if (lane == leader) {
-				const uint32_t c = uint32_t(__popcll(same));
-				uint32_t h = (v * 2654435761u) >> 24;
-				int probes = 0;
-				for (; probes < 256; ++probes, h = (h + 1) & 255u) {
-					const uint32_t old = atomicCAS(&keys[h], 0u, v);
-					if (old == 0u || old == v) {
-						atomicAdd(&cnts[h], c);
-						break;
-					}
+	const uint64_t quads = (p.total_docs + 3) / 4;
+	for (uint64_t q = uint64_t(blockIdx.x) * 256 + threadIdx.x; q < quads + 255; q += uint64_t(gridDim.x) * 256) {   // whole waves stay in the loop
+		const uint64_t d0 = q * 4;
+		uint32_t sc[4] = {0, 0, 0, 0};
+		if (q < quads) {
+			constexpr uint32_t kChunk = 4;
+			for (uint32_t t0 = 0; t0 < p.n_best; t0 += kChunk) {
+				uint4 key[kChunk];
+#pragma unroll
+				for (uint32_t j = 0; j < kChunk; ++j) {
+					key[j] = t0 + j < p.n_best ? *reinterpret_cast<const uint4*>(p.best + uint64_t(t0 + j) * p.best_stride + d0) : make_uint4(0, 0, 0, 0);
 				}
-				if (probes == 256) atomicAdd(&p.hist[v], c);   // more than 256 distinct scores in one workgroup
+#pragma unroll
+				for (uint32_t j = 0; j < kChunk; ++j) {
+					sc[0] += (key[j].x & kBestPresent) ? (key[j].x & 0xFFFFu) : 0u;
+					sc[1] += (key[j].y & kBestPresent) ? (key[j].y & 0xFFFFu) : 0u;
+					sc[2] += (key[j].z & kBestPresent) ? (key[j].z & 0xFFFFu) : 0u;
+					sc[3] += (key[j].w & kBestPresent) ? (key[j].w & 0xFFFFu) : 0u;
+				}
 			}
-			todo &= ~same;
+			const uint32_t mw = p.mask[d0 >> 5];
+			uint32_t rm = 0;
+			if (p.removed) rm = *reinterpret_cast<const uint32_t*>(p.removed + d0);   // 4 flags; the array is padded to a multiple of 4
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				sc[k] = sc[k] < 65535u ? sc[k] : 65535u;
+				const bool in = d0 + k < p.total_docs && ((mw >> ((d0 + k) & 31)) & 1u) && !((rm >> (8 * k)) & 0xFFu);
+				if (!in) sc[k] = 0;
+			}
+			if (d0 + 3 < p.total_docs) {
+				*reinterpret_cast<uint2*>(p.score + d0) = make_uint2(sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16));
+			} else {
+				for (int k = 0; k < 4 && d0 + k < p.total_docs; ++k) p.score[d0 + k] = uint16_t(sc[k]);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t v0 = sc[k];
+			unsigned long long todo = __ballot(v0 != 0);
+			while (todo) {
+				const int leader = __ffsll((long long)todo) - 1;
+				const uint32_t v = __shfl(v0, leader, 64);
+				const unsigned long long same = __ballot(v0 == v);
+				if (lane == leader) {
+					const uint32_t c = uint32_t(__popcll(same));
+					uint32_t h = (v * 2654435761u) >> 24;
+					int probes = 0;
+					for (; probes < 256; ++probes, h = (h + 1) & 255u) {
+						const uint32_t old = atomicCAS(&keys[h], 0u, v);
+						if (old == 0u || old == v) {
+							atomicAdd(&cnts[h], c);
+							break;
+						}
+					}
+					if (probes == 256) atomicAdd(&p.hist[v], c);   // more than 256 distinct scores in one workgroup
+				}
+				todo &= ~same;
+			}
 		}
 	}
 	__syncthreads();
@@ -318,9 +367,15 @@ __global__ __launch_bounds__(1024) void ft_preselect_pick(FtPlan p) {
 	__shared__ uint32_t chunk_sum[1024];
 	__shared__ int s_chunk;
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	for (int i = 0; i < 64; ++i) {   // the wave reads 64 consecutive scores = chunk i * 16 + wave
-		const uint32_t c = wave_sum(p.hist[i * 1024 + t]);
-		if (lane == 0) chunk_sum[i * 16 + wave] = c;
+	{   // thread t sums chunk t = scores [64 t, 64 t + 64): sixteen independent 16-byte loads in flight
+		const uint4* h4 = reinterpret_cast<const uint4*>(p.hist) + size_t(t) * 16;
+		uint4 v[16];
+#pragma unroll
+		for (int i = 0; i < 16; ++i) v[i] = h4[i];
+		uint32_t c = 0;
+#pragma unroll
+		for (int i = 0; i < 16; ++i) c += v[i].x + v[i].y + v[i].z + v[i].w;
+		chunk_sum[t] = c;
 	}
 	if (t == 0) s_chunk = -1;
 	__syncthreads();
@@ -373,35 +428,46 @@ __global__ __launch_bounds__(1024) void ft_preselect_pick(FtPlan p) {
 	}
 }
 
-// mergerimpl.h:448-462: one thread per mask word; ties at minScore are kept in document order up to minScoreDocs
+// mergerimpl.h:448-462: kFtApplyWords mask words per thread (the ordered prefix chain is as long as the grid: fewer, fatter workgroups);
+// ties at minScore are kept in document order up to minScoreDocs
 __global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
 	if (!ft_preselect_on(p)) return;
 	const uint32_t ticket = grab_ticket(p.sync + kFtSyncPreTicket);
-	const uint64_t w = uint64_t(ticket) * 256 + threadIdx.x;
+	const uint64_t w0 = (uint64_t(ticket) * 256 + threadIdx.x) * kFtApplyWords;
 	const uint32_t min_score = p.sync[kFtSyncPick], min_docs = p.sync[kFtSyncPick + 1];
-	uint32_t bits = 0, gt = 0, tie = 0;
-	if (w < p.nwords) {
-		bits = p.mask[w];
+	uint32_t bits[kFtApplyWords], gt[kFtApplyWords], tie[kFtApplyWords];
+	uint32_t ties = 0;
+#pragma unroll
+	for (int j = 0; j < kFtApplyWords; ++j) {
+		bits[j] = gt[j] = tie[j] = 0;
+		const uint64_t w = w0 + j;
+		if (w >= p.nwords) continue;
+		bits[j] = p.mask[w];
 		const uint64_t d0 = w * 32;
-		for (uint32_t b = 0; b < 32; ++b) {
-			if (!((bits >> b) & 1u)) continue;   // only masked-in documents are inspected; d0 + b < total_docs by construction
+		uint32_t todo = bits[j];
+		while (todo) {   // only masked-in documents are inspected; d0 + b < total_docs by construction
+			const uint32_t b = __ffs(todo) - 1;
+			todo &= todo - 1;
 			const uint32_t sc = p.score[d0 + b];
-			gt |= uint32_t(sc > min_score) << b;
-			tie |= uint32_t(sc == min_score) << b;
+			gt[j] |= uint32_t(sc > min_score) << b;
+			tie[j] |= uint32_t(sc == min_score) << b;
 		}
+		ties += __popc(tie[j]);
 	}
 	uint32_t grand;
-	const uint32_t excl = ordered_prefix(__popc(tie), ticket, p.lookback_pre, p.sync + kFtSyncError, &grand);
-	if (w < p.nwords) {
-		uint32_t allowed = min_docs > excl ? min_docs - excl : 0;
-		uint32_t keep = gt;
-		while (tie && allowed) {
-			const uint32_t low = tie & (0u - tie);
+	const uint32_t excl = ordered_prefix(ties, ticket, p.lookback_pre, p.sync + kFtSyncError, &grand);
+	uint32_t allowed = min_docs > excl ? min_docs - excl : 0;
+#pragma unroll
+	for (int j = 0; j < kFtApplyWords; ++j) {
+		if (w0 + j >= p.nwords) continue;
+		uint32_t keep = gt[j], tj = tie[j];
+		while (tj && allowed) {
+			const uint32_t low = tj & (0u - tj);
 			keep |= low;
-			tie ^= low;
+			tj ^= low;
 			--allowed;
 		}
-		if (keep != bits) p.mask[w] = keep;
+		if (keep != bits[j]) p.mask[w0 + j] = keep;
 	}
 }
 
@@ -452,36 +518,64 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 	*reinterpret_cast<uchar4*>(p.p_field + gp0) = make_uchar4(fields[0], fields[1], fields[2], fields[3]);
 }
 
-// addDoc order (merger.h:161-180): the postings that add a document take consecutive merge slots in global posting order, cut at maxMergedDocs
-__global__ __launch_bounds__(256) void ft_assign_slots(FtPlan p) {
-	const uint32_t ticket = grab_ticket(p.sync + kFtSyncSlotTicket);
-	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, ticket);
+// addDoc order (merger.h:161-180): the postings that add a document take consecutive merge slots in global posting order, cut at
+// maxMergedDocs.  Two passes without any inter-workgroup waiting (a decoupled look-back over ~3800 workgroups took 70 us here):
+// ft_count_adders marks the adding postings and counts them per workgroup; ft_assign_slots sums the counts of the workgroups before it
+// (a few KB, L2-resident) and scans its own.
+__global__ __launch_bounds__(256) void ft_count_adders(FtPlan p) {
+	__shared__ uint32_t s_part[4];
+	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
 	const FtPosSubterm& s = p.subs[ge.sub];
-	const uint64_t i0 = uint64_t(ticket - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	const uint64_t gp0 = uint64_t(ticket) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+	const uint64_t gp0 = uint64_t(blockIdx.x) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
 	const float4 rk = *reinterpret_cast<const float4*>(p.p_rank + gp0);
 	const float ranks[kFtPassItems] = {rk.x, rk.y, rk.z, rk.w};
-	uint32_t docs[kFtPassItems];
+	uint32_t docs[kFtPassItems], firsts[kFtPassItems];
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) docs[k] = ranks[k] != 0.0f ? s.doc[i0 + k] : 0u;   // rank 0 includes every posting past the end of the list
+#pragma unroll
+	for (int k = 0; k < kFtPassItems; ++k) firsts[k] = ranks[k] != 0.0f ? p.first[docs[k]] : kNoPosting;
 	uint32_t c_mask = 0;
 #pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) {
-		docs[k] = 0;
-		if (ranks[k] == 0.0f) continue;   // includes every posting past the end of the list
-		docs[k] = s.doc[i0 + k];
-		if (p.first[docs[k]] == uint32_t(gp0 + k)) c_mask |= 1u << k;
+	for (int k = 0; k < kFtPassItems; ++k) c_mask |= uint32_t(ranks[k] != 0.0f && firsts[k] == uint32_t(gp0 + k)) << k;
+	p.p_adder[uint64_t(blockIdx.x) * 256 + threadIdx.x] = uint8_t(c_mask);
+	const uint32_t c = wave_sum(__popc(c_mask));
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) p.block_counts[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(256) void ft_assign_slots(FtPlan p) {
+	__shared__ uint32_t s_part[4], s_wave_tot[4];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t before = 0;   // adders in the workgroups before this one
+	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) before += p.block_counts[b];
+	before = wave_sum(before);
+	const uint32_t c_mask = p.p_adder[uint64_t(blockIdx.x) * 256 + threadIdx.x];
+	const uint32_t incl = wave_inclusive_scan(__popc(c_mask), lane);
+	if (lane == 0) s_part[wave] = before;
+	if (lane == 63) s_wave_tot[wave] = incl;
+	__syncthreads();
+	uint32_t slot = s_part[0] + s_part[1] + s_part[2] + s_part[3] + (incl - __popc(c_mask));
+	for (int w = 0; w < wave; ++w) slot += s_wave_tot[w];
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
+		const uint32_t total = slot + __popc(c_mask);
+		p.sync[kFtSyncNumDocs] = total < p.max_merged ? total : p.max_merged;
 	}
-	uint32_t grand;
-	uint32_t slot = ordered_prefix(__popc(c_mask), ticket, p.lookback_slots, p.sync + kFtSyncError, &grand);
+	if (!c_mask) return;
+	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
+	const FtPosSubterm& s = p.subs[ge.sub];
+	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
 #pragma unroll
 	for (int k = 0; k < kFtPassItems; ++k) {
 		if (!((c_mask >> k) & 1u)) continue;
 		if (slot < p.max_merged) {
-			p.out_doc[slot] = docs[k];
-			p.slot_of[docs[k]] = slot;
+			const uint32_t d = s.doc[i0 + k];
+			p.out_doc[slot] = d;
+			p.slot_of[d] = slot;
 		}
 		++slot;
 	}
-	if (ticket == gridDim.x - 1 && threadIdx.x == 0) p.sync[kFtSyncNumDocs] = grand < p.max_merged ? grand : p.max_merged;
 }
 
 // every posting of a merged document drops (rank, field, posting index) into the document's row, column = its sub-term
@@ -618,21 +712,25 @@ __global__ __launch_bounds__(256) void ft_replay(FtPlan p) {
 
 // ---------------------------------------------------------------------------------------------- launch train
 void launch_ft_merge(const FtPlan& p, hipStream_t st) {
-	const uint32_t doc_blocks = uint32_t(std::min<uint64_t>((p.total_docs + 255) / 256, 2048));
+	const uint32_t doc_blocks = uint32_t(std::min<uint64_t>(((p.total_docs + 3) / 4 + 255) / 256, 2048));
 	hipLaunchKernelGGL(ft_init, dim3(2048), dim3(256), 0, st, p);
 	if (!p.simple) {
-		if (p.scan_blocks) hipLaunchKernelGGL(ft_scan, dim3(p.scan_blocks), dim3(256), 0, st, p);
+		for (uint32_t level = 0; level < 3; ++level) {
+			const uint32_t blocks = p.scan_level_base[level + 1] - p.scan_level_base[level];
+			if (blocks) hipLaunchKernelGGL(ft_scan, dim3(blocks), dim3(256), 0, st, p, level);
+		}
 		if (p.n_and || p.not_mask || p.prescore) {
-			hipLaunchKernelGGL(ft_combine, dim3(uint32_t(std::min<uint64_t>((p.nwords + 255) / 256, 1024))), dim3(256), 0, st, p);
+			hipLaunchKernelGGL(ft_combine, dim3(uint32_t(std::min<uint64_t>((p.nwords + 255) / 256, 128))), dim3(256), 0, st, p);
 		}
 		if (p.prescore) {
 			hipLaunchKernelGGL(ft_score, dim3(doc_blocks), dim3(256), 0, st, p);
 			hipLaunchKernelGGL(ft_preselect_pick, dim3(1), dim3(1024), 0, st, p);
-			hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 255) / 256)), dim3(256), 0, st, p);
+			hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
 		}
 	}
 	if (p.merge_blocks) {
 		hipLaunchKernelGGL(ft_rank_all, dim3(p.merge_blocks), dim3(256), 0, st, p);
+		hipLaunchKernelGGL(ft_count_adders, dim3(p.merge_blocks), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_assign_slots, dim3(p.merge_blocks), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_scatter, dim3(p.merge_blocks), dim3(256), 0, st, p);
 	}

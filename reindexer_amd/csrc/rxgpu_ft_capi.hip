@@ -239,6 +239,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	std::vector<rxgpu::FtPosSubterm> subs;
 	std::vector<rxgpu::FtTermCfg> tcfg(nterms);
 	std::vector<rxgpu::FtGridEntry> merge_grid, scan_grid;
+	std::vector<uint32_t> scan_subs;
 	std::vector<uint64_t> term_postings(nterms, 0);
 	uint64_t total_vids = 0, merged_postings = 0, merge_blocks = 0, scan_blocks = 0;
 	uint32_t n_and = 0, n_best = 0, n_not = 0;
@@ -328,13 +329,23 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 				merge_blocks += blocks;
 				merged_postings += w.n;
 			}
-			if (!simple && (qt.op != 1 || prescore)) {
-				scan_grid.push_back({uint32_t(scan_blocks), sub_index});
-				scan_blocks += blocks;
-			}
+			if (!simple && (qt.op != 1 || prescore)) scan_subs.push_back(sub_index);
 			subs.push_back(ft);
 		}
 	}
+	// the scan grid ordered by level: first sub-terms of their terms, second sub-terms, all further ones (ft_scan resolves "the first sub-term
+	// containing the document wins" by launch order instead of atomics)
+	uint32_t scan_level_base[4] = {0, 0, 0, 0};
+	for (uint32_t level = 0; level < 3; ++level) {
+		scan_level_base[level] = uint32_t(scan_blocks);
+		for (uint32_t si : scan_subs) {
+			const uint32_t lv = std::min<uint32_t>(subs[si].ord_in_term, 2);
+			if (lv != level) continue;
+			scan_grid.push_back({uint32_t(scan_blocks), si});
+			scan_blocks += rxgpu::ft_pass_blocks(subs[si].n);
+		}
+	}
+	scan_level_base[3] = uint32_t(scan_blocks);
 	RX_CHECK(merge_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull && scan_blocks < 0x7FFFFFFFull, RXGPU_ERR_PARAMS,
 			 std::string(who) + ": more than 2^32 (padded) postings in one merge");
 	const uint32_t n_rows = uint32_t(merge_grid.size());
@@ -354,19 +365,21 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t o_mask = cv.take(nwords * 4);
 	const size_t o_and = cv.take(size_t(n_and) * nwords * 4);
 	const size_t o_not = cv.take(n_not ? nwords * 4 : 0);
-	const size_t o_best = cv.take(prescore ? size_t(n_best) * N * 4 : 0);
+	const uint64_t best_stride = (N + 3) & ~uint64_t(3);
+	const size_t o_best = cv.take(prescore ? size_t(n_best) * best_stride * 4 : 0);
 	const size_t o_score = cv.take(prescore ? N * 2 : 0);
 	const size_t o_hist = cv.take(prescore ? 65536 * 4 : 0);
-	const size_t o_lb_pre = cv.take(prescore ? ((nwords + 255) / 256) * 8 : 0);
+	const size_t o_lb_pre = cv.take(prescore ? ((nwords + 1023) / 1024) * 8 : 0);
 	const size_t o_first = cv.take(N * 4);
 	const size_t o_slot_of = cv.take(N * 4);
 	const size_t o_prank = cv.take(padded * 4);
 	const size_t o_pfield = cv.take(padded);
+	const size_t o_padder = cv.take(size_t(merge_blocks) * 256);
+	const size_t o_bcounts = cv.take(size_t(merge_blocks) * 4);
 	const size_t o_erank = cv.take(size_t(n_rows) * M * 4);
 	const size_t o_eidx = cv.take(size_t(n_rows) * M * 4);
 	const size_t o_efield = cv.take(size_t(n_rows) * M);
 	const size_t o_sync = cv.take(rxgpu::kFtSyncWords * 4);
-	const size_t o_lb_slots = cv.take(size_t(merge_blocks) * 8);
 	const size_t o_excl = cv.take(excluded ? N : 0);
 	if (int rc = h->d_state.ensure(cv.off); rc) return rc;
 	char* base = static_cast<char*>(h->d_state.ptr);
@@ -423,6 +436,8 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.n_scan_entries = uint32_t(scan_grid.size());
 	p.merge_blocks = uint32_t(merge_blocks);
 	p.scan_blocks = uint32_t(scan_blocks);
+	for (int i = 0; i < 4; ++i) p.scan_level_base[i] = scan_level_base[i];
+	p.best_stride = best_stride;
 	p.nterms = nterms;
 	p.n_and = n_and;
 	p.n_best = prescore ? n_best : 0;
@@ -449,11 +464,12 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.slot_of = reinterpret_cast<uint32_t*>(base + o_slot_of);
 	p.p_rank = reinterpret_cast<float*>(base + o_prank);
 	p.p_field = reinterpret_cast<uint8_t*>(base + o_pfield);
+	p.p_adder = reinterpret_cast<uint8_t*>(base + o_padder);
+	p.block_counts = reinterpret_cast<uint32_t*>(base + o_bcounts);
 	p.e_rank = reinterpret_cast<float*>(base + o_erank);
 	p.e_idx = reinterpret_cast<uint32_t*>(base + o_eidx);
 	p.e_field = reinterpret_cast<uint8_t*>(base + o_efield);
 	p.sync = reinterpret_cast<uint32_t*>(base + o_sync);
-	p.lookback_slots = reinterpret_cast<unsigned long long*>(base + o_lb_slots);
 	p.out_header = reinterpret_cast<uint32_t*>(ob);
 	p.out_doc = reinterpret_cast<uint32_t*>(ob + align256(16));
 	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));

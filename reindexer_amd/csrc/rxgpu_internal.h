@@ -121,6 +121,7 @@ struct FtPlan {
 	const FtGridEntry* merge_grid;   // merged sub-terms in (term, sub-term) order
 	const FtGridEntry* scan_grid;    // sub-terms the bitmask / pre-score scan walks
 	uint32_t n_merge_entries, n_scan_entries, merge_blocks, scan_blocks;
+	uint32_t scan_level_base[4];     // scan_grid is ordered by level (first / second / further sub-terms of their term): block ranges
 	uint32_t nterms, n_and, n_best, n_rows;
 	uint64_t total_docs, nwords;
 	uint32_t max_merged, merge_limit;
@@ -133,19 +134,21 @@ struct FtPlan {
 	uint32_t* mask;            // restrictingMask_ [nwords]
 	uint32_t* and_masks;       // [n_and][nwords]
 	uint32_t* not_mask;        // [nwords]
-	uint32_t* best;            // [n_best][total_docs]: presence bit | (4095 - sub-term ordinal) << 16 | proc16
+	uint32_t* best;            // [n_best][best_stride]: presence bit | (4095 - sub-term ordinal) << 16 | proc16
+	uint64_t best_stride;      // total_docs rounded up to 4 (16-byte loads)
 	uint16_t* score;           // [total_docs]
 	uint32_t* hist;            // [65536]
 	uint32_t* first;           // [total_docs]: smallest global posting index with a non-zero rank (the posting that adds the document)
 	uint32_t* slot_of;         // [total_docs]: sparse-set back pointer, valid iff slot_doc[slot_of[d]] == d
 	float* p_rank;             // [merge_blocks * kFtBlockPostings] rank of every posting (0 = not eligible)
 	uint8_t* p_field;
+	uint8_t* p_adder;          // [merge_blocks * 256]: per thread, which of its postings add a document
+	uint32_t* block_counts;    // [merge_blocks] adding postings per workgroup
 	float* e_rank;             // per-slot entry table [n_rows][max_merged]: 0 = the document has no posting in that sub-term
 	uint32_t* e_idx;
 	uint8_t* e_field;
 	uint32_t* sync;            // kFtSync* words (zeroed by ft_init)
-	unsigned long long* lookback_slots;   // [merge_blocks]
-	unsigned long long* lookback_pre;     // [ceil(nwords / 256)]
+	unsigned long long* lookback_pre;     // [ceil(nwords / (256 * 4))]
 	// packed result: header (4 x u32: numDocs, error flag, preselected, 0) then doc[max_merged] u32, proc[max_merged] f32,
 	// terms_counter[max_merged] u16, field[max_merged] u8 — one D2H copy
 	uint32_t* out_header;
@@ -154,7 +157,7 @@ struct FtPlan {
 	uint16_t* out_terms_counter;
 	uint8_t* out_field;
 };
-enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPick = 2 /* +1 */, kFtSyncPreTicket = 4, kFtSyncSlotTicket = 5, kFtSyncNumDocs = 6,
+enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPick = 2 /* +1 */, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6,
 				  kFtSyncPreselected = 7, kFtSyncWords = 8 };
 void launch_ft_merge(const FtPlan& plan, hipStream_t st);
 
