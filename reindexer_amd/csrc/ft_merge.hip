@@ -302,15 +302,17 @@ __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 			for (uint32_t t0 = 0; t0 < p.n_best; t0 += kChunk) {
 				uint4 key[kChunk];
 #pragma unroll
-				for (uint32_t j = 0; j < kChunk; ++j) {
-					key[j] = t0 + j < p.n_best ? *reinterpret_cast<const uint4*>(p.best + uint64_t(t0 + j) * p.best_stride + d0) : make_uint4(0, 0, 0, 0);
+				for (uint32_t j = 0; j < kChunk; ++j) {   // unconditional loads (a clamped row for j past the last term): all four in flight at once
+					const uint32_t tt = t0 + j < p.n_best ? t0 + j : p.n_best - 1;
+					key[j] = *reinterpret_cast<const uint4*>(p.best + uint64_t(tt) * p.best_stride + d0);
 				}
 #pragma unroll
 				for (uint32_t j = 0; j < kChunk; ++j) {
-					sc[0] += (key[j].x & kBestPresent) ? (key[j].x & 0xFFFFu) : 0u;
-					sc[1] += (key[j].y & kBestPresent) ? (key[j].y & 0xFFFFu) : 0u;
-					sc[2] += (key[j].z & kBestPresent) ? (key[j].z & 0xFFFFu) : 0u;
-					sc[3] += (key[j].w & kBestPresent) ? (key[j].w & 0xFFFFu) : 0u;
+					const uint32_t on = t0 + j < p.n_best ? kBestPresent : 0u;
+					sc[0] += (key[j].x & on) ? (key[j].x & 0xFFFFu) : 0u;
+					sc[1] += (key[j].y & on) ? (key[j].y & 0xFFFFu) : 0u;
+					sc[2] += (key[j].z & on) ? (key[j].z & 0xFFFFu) : 0u;
+					sc[3] += (key[j].w & on) ? (key[j].w & 0xFFFFu) : 0u;
 				}
 			}
 			const uint32_t mw = p.mask[d0 >> 5];
@@ -341,7 +343,8 @@ __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 					uint32_t h = (v * 2654435761u) >> 24;
 					int probes = 0;
 					for (; probes < 256; ++probes, h = (h + 1) & 255u) {
-						const uint32_t old = atomicCAS(&keys[h], 0u, v);
+						uint32_t old = keys[h];   // the usual case after the first few documents: the value already owns its slot
+						if (old != v) old = atomicCAS(&keys[h], 0u, v);
 						if (old == 0u || old == v) {
 							atomicAdd(&cnts[h], c);
 							break;
@@ -443,15 +446,21 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
 		const uint64_t w = w0 + j;
 		if (w >= p.nwords) continue;
 		bits[j] = p.mask[w];
-		const uint64_t d0 = w * 32;
-		uint32_t todo = bits[j];
-		while (todo) {   // only masked-in documents are inspected; d0 + b < total_docs by construction
-			const uint32_t b = __ffs(todo) - 1;
-			todo &= todo - 1;
-			const uint32_t sc = p.score[d0 + b];
-			gt[j] |= uint32_t(sc > min_score) << b;
-			tie[j] |= uint32_t(sc == min_score) << b;
+		// the 32 scores of the word as four 16-byte loads (the score array is padded to a whole word); only masked-in documents count
+		const uint4* s4 = reinterpret_cast<const uint4*>(p.score + w * 32);
+		uint4 v[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) v[q] = s4[q];
+		const uint32_t half[16] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w,
+								   v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+#pragma unroll
+		for (int q = 0; q < 16; ++q) {
+			const uint32_t lo = half[q] & 0xFFFFu, hi = half[q] >> 16;
+			gt[j] |= (uint32_t(lo > min_score) << (2 * q)) | (uint32_t(hi > min_score) << (2 * q + 1));
+			tie[j] |= (uint32_t(lo == min_score) << (2 * q)) | (uint32_t(hi == min_score) << (2 * q + 1));
 		}
+		gt[j] &= bits[j];
+		tie[j] &= bits[j];
 		ties += __popc(tie[j]);
 	}
 	uint32_t grand;
@@ -646,9 +655,17 @@ __global__ __launch_bounds__(256) void ft_replay(FtPlan p) {
 	const uint64_t* next_ptr = nullptr;
 	uint32_t last_cnt = 0, next_cnt = 0;
 	uint16_t switched_term = 0, last_counted = 0, terms_counter = 0;
+	constexpr uint32_t kRowChunk = 8;   // the document's cells of eight sub-terms are fetched together: the walk below is latency-bound
+	float rank_ahead[kRowChunk];
 	for (uint32_t row = 0; row < p.n_rows; ++row) {
 		const uint64_t cell = uint64_t(row) * p.max_merged + sl;
-		const float r = p.e_rank[cell];
+		if (row % kRowChunk == 0) {
+#pragma unroll
+			for (uint32_t j = 0; j < kRowChunk; ++j) rank_ahead[j] = row + j < p.n_rows ? p.e_rank[cell + uint64_t(j) * p.max_merged] : 0.0f;
+		}
+		float r = 0.0f;
+#pragma unroll
+		for (uint32_t j = 0; j < kRowChunk; ++j) r = (row % kRowChunk == j) ? rank_ahead[j] : r;
 		if (r == 0.0f) continue;
 		const uint8_t fld = p.e_field[cell];
 		if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins

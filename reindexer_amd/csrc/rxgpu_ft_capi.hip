@@ -367,7 +367,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t o_not = cv.take(n_not ? nwords * 4 : 0);
 	const uint64_t best_stride = (N + 3) & ~uint64_t(3);
 	const size_t o_best = cv.take(prescore ? size_t(n_best) * best_stride * 4 : 0);
-	const size_t o_score = cv.take(prescore ? N * 2 : 0);
+	const size_t o_score = cv.take(prescore ? nwords * 32 * 2 : 0);   // padded to whole mask words (ft_preselect_apply reads 32 scores at a time)
 	const size_t o_hist = cv.take(prescore ? 65536 * 4 : 0);
 	const size_t o_lb_pre = cv.take(prescore ? ((nwords + 1023) / 1024) * 8 : 0);
 	const size_t o_first = cv.take(N * 4);
