@@ -283,8 +283,8 @@ __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerim
 
 // docsScore[d] = saturating sum over the terms of the first sub-term's proc16; masked-out / removed documents score 0 (mergerimpl.h:416-423);
 // histogram of the rest.  Four documents per thread (16-byte loads, every term's load in flight before the first use: the pass is
-// latency-bound otherwise).  Scores take few distinct values, so the counts are aggregated per wave, then per workgroup in a small LDS
-// table, and only then added to the global histogram.
+// latency-bound otherwise).  Scores take few distinct values, so the counts are aggregated per workgroup in a small LDS hash table
+// (lanes insert independently; a leader-per-value loop over the wave cost 25 us more) and only then added to the global histogram.
 __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 	if (!ft_preselect_on(p)) return;
 	__shared__ uint32_t keys[256];
@@ -292,12 +292,11 @@ __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 	keys[threadIdx.x] = 0;   // a score of 0 is never inserted
 	cnts[threadIdx.x] = 0;
 	__syncthreads();
-	const int lane = threadIdx.x & 63;
 	const uint64_t quads = (p.total_docs + 3) / 4;
-	for (uint64_t q = uint64_t(blockIdx.x) * 256 + threadIdx.x; q < quads + 255; q += uint64_t(gridDim.x) * 256) {   // whole waves stay in the loop
+	for (uint64_t q = uint64_t(blockIdx.x) * 256 + threadIdx.x; q < quads; q += uint64_t(gridDim.x) * 256) {
 		const uint64_t d0 = q * 4;
 		uint32_t sc[4] = {0, 0, 0, 0};
-		if (q < quads) {
+		{
 			constexpr uint32_t kChunk = 4;
 			for (uint32_t t0 = 0; t0 < p.n_best; t0 += kChunk) {
 				uint4 key[kChunk];
@@ -331,29 +330,22 @@ __global__ __launch_bounds__(256) void ft_score(FtPlan p) {
 			}
 		}
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const uint32_t v0 = sc[k];
-			unsigned long long todo = __ballot(v0 != 0);
-			while (todo) {
-				const int leader = __ffsll((long long)todo) - 1;
-				const uint32_t v = __shfl(v0, leader, 64);
-				const unsigned long long same = __ballot(v0 == v);
-				if (lane == leader) {
-					const uint32_t c = uint32_t(__popcll(same));
-					uint32_t h = (v * 2654435761u) >> 24;
-					int probes = 0;
-					for (; probes < 256; ++probes, h = (h + 1) & 255u) {
-						uint32_t old = keys[h];   // the usual case after the first few documents: the value already owns its slot
-						if (old != v) old = atomicCAS(&keys[h], 0u, v);
-						if (old == 0u || old == v) {
-							atomicAdd(&cnts[h], c);
-							break;
-						}
-					}
-					if (probes == 256) atomicAdd(&p.hist[v], c);   // more than 256 distinct scores in one workgroup
+		for (int k = 0; k < 4; ++k) {   // every lane files its own score: one LDS read + one LDS add once the value owns a slot
+			const uint32_t v = sc[k];
+			if (!v) continue;
+			uint32_t h = (v * 2654435761u) >> 24;
+			int probes = 0;
+			for (; probes < 256; ++probes, h = (h + 1) & 255u) {
+				uint32_t cur = keys[h];
+				if (cur != v) {
+					if (cur != 0u) continue;
+					cur = atomicCAS(&keys[h], 0u, v);
+					if (cur != 0u && cur != v) continue;
 				}
-				todo &= ~same;
+				atomicAdd(&cnts[h], 1u);
+				break;
 			}
+			if (probes == 256) atomicAdd(&p.hist[v], 1u);   // more than 256 distinct scores in one workgroup
 		}
 	}
 	__syncthreads();
@@ -638,7 +630,18 @@ __device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uin
 }
 
 // One thread per merged document: its row replayed in sub-term order = the order mergeTerm / mergeSimple met its postings.
-__global__ __launch_bounds__(256) void ft_replay(FtPlan p) {
+constexpr uint32_t kFtReplayRows = 128;   // sub-term descriptors staged in LDS (queries with more merged sub-terms read the plan from HBM)
+__global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
+	__shared__ const uint64_t* s_fpos[kFtReplayRows];
+	__shared__ const uint32_t* s_pos_off[kFtReplayRows];
+	__shared__ uint16_t s_qp[kFtReplayRows];
+	for (uint32_t row = threadIdx.x; row < p.n_rows && row < kFtReplayRows; row += blockDim.x) {   // two dependent loads per row, once per workgroup
+		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
+		s_fpos[row] = s.fpos;
+		s_pos_off[row] = s.pos_off;
+		s_qp[row] = s.qp;
+	}
+	__syncthreads();
 	const uint32_t num_docs = p.sync[kFtSyncNumDocs];
 	const uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
 	if (sl == 0) {
@@ -679,11 +682,23 @@ __global__ __launch_bounds__(256) void ft_replay(FtPlan p) {
 			}
 			continue;
 		}
-		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
 		const uint32_t i = p.e_idx[cell];
-		const uint64_t* pos = s.fpos + s.pos_off[i];
-		const uint32_t npos = s.pos_off[i + 1] - s.pos_off[i];
-		const uint16_t qp = s.qp;
+		const uint64_t* fpos;
+		const uint32_t* pos_off;
+		uint16_t qp;
+		if (row < kFtReplayRows) {
+			fpos = s_fpos[row];
+			pos_off = s_pos_off[row];
+			qp = s_qp[row];
+		} else {
+			const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
+			fpos = s.fpos;
+			pos_off = s.pos_off;
+			qp = s.qp;
+		}
+		const uint32_t po0 = pos_off[i], po1 = pos_off[i + 1];
+		const uint64_t* pos = fpos + po0;
+		const uint32_t npos = po1 - po0;
 		if (!created) {   // addDoc (mergerimpl.h:160-164)
 			created = true;
 			proc = r;
@@ -751,7 +766,7 @@ void launch_ft_merge(const FtPlan& p, hipStream_t st) {
 		hipLaunchKernelGGL(ft_assign_slots, dim3(p.merge_blocks), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_scatter, dim3(p.merge_blocks), dim3(256), 0, st, p);
 	}
-	hipLaunchKernelGGL(ft_replay, dim3((p.max_merged + 255) / 256), dim3(256), 0, st, p);
+	hipLaunchKernelGGL(ft_replay, dim3((p.max_merged + 63) / 64), dim3(64), 0, st, p);
 }
 
 }  // namespace rxgpu

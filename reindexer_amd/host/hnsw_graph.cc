@@ -89,6 +89,7 @@ HnswGraph::HnswGraph(const HnswGraph& o, size_t newMaxElements)
 	  labelLookup_(o.labelLookup_),
 	  levelGenerator_(o.levelGenerator_) {
 	visited_.stamp.assign(o.visited_.stamp.size(), 0);
+	rebuildDeletedSet();   // the reference's copy constructor refills deleted_elements through initTree, in index order (hnswalg.h:492, 1265-1281)
 	if (maxElements_ != o.maxElements_) {
 		const size_t keep = maxElements_;
 		maxElements_ = o.maxElements_;
@@ -261,7 +262,7 @@ void HnswGraph::selectNeighbors(Heap& candidates, size_t M) const {
 // kMT: cur's own lists are covered by the lock its inserter holds for the whole insertion; every other list is rewritten under its lock
 // (mutuallyConnectNewElement, hnswalg.h:1086-1095).
 template <bool kMT>
-tableint HnswGraph::connect(tableint cur, Heap& candidates, int level) {
+tableint HnswGraph::connect(tableint cur, Heap& candidates, int level, bool isUpdate) {
 	const size_t mCurMax = level ? M_ : maxM0_;
 	selectNeighbors(candidates, M_);
 	if (candidates.size() > M_) throw std::runtime_error("Should be not be more than M_ candidates returned by the heuristic");
@@ -274,12 +275,13 @@ tableint HnswGraph::connect(tableint cur, Heap& candidates, int level) {
 	const tableint nextEntry = selected.back();
 	{
 		uint32_t* ll = list(cur, level);
-		if (ll[0] != 0) throw std::runtime_error("The newly inserted element should have blank link list");
+		if (ll[0] != 0 && !isUpdate) throw std::runtime_error("The newly inserted element should have blank link list");
 		ll[0] = uint32_t(selected.size());
 		for (size_t i = 0; i < selected.size(); ++i) {
 			if (level > levels_[selected[i]]) throw std::runtime_error("Trying to make a link on a non-existent level");
 			ll[1 + i] = selected[i];
 		}
+		for (size_t i = selected.size(); i < mCurMax; ++i) ll[1 + i] = 0;   // canonical unused slots (an updated element's list may shrink)
 	}
 	for (const tableint other : selected) {
 		[[maybe_unused]] std::unique_ptr<NodeLock> lk;
@@ -288,6 +290,11 @@ tableint HnswGraph::connect(tableint cur, Heap& candidates, int level) {
 		const size_t sz = lo[0];
 		if (sz > mCurMax) throw std::runtime_error("Bad value of sz_link_list_other");
 		if (other == cur) throw std::runtime_error("Trying to connect an element to itself");
+		if (isUpdate) {   // hnswalg.h:1119-1131: an updated element may already be among the neighbour's links — then nothing changes there
+			bool present = false;
+			for (size_t j = 0; j < sz && !present; ++j) present = lo[1 + j] == cur;
+			if (present) continue;
+		}
 		if (sz < mCurMax) {
 			lo[1 + sz] = cur;
 			lo[0] = uint32_t(sz + 1);
@@ -316,9 +323,16 @@ tableint HnswGraph::addPoint(const float* data, labeltype label) {
 	{
 		[[maybe_unused]] std::unique_lock<std::mutex> lockTable;
 		if constexpr (kMT) lockTable = std::unique_lock<std::mutex>(labelMtx_);
-		if (labelLookup_.count(label)) {
-			// the reference routes this to updatePoint (hnswalg.h:1709-1724), a path its own comment marks as never exercised
-			throw std::logic_error("HnswGraph::AddPoint: label already present (in-place vector update is not supported)");
+		if (auto found = labelLookup_.find(label); found != labelLookup_.end()) {
+			// hnswalg.h:1709-1724: the label exists -> the element is updated in place instead of a new one being created
+			const tableint existing = found->second;
+			if (IsDeleted(existing)) throw std::runtime_error("Can't use addPoint to update deleted elements if replacement of deleted elements is enabled.");
+			if constexpr (kMT) {
+				throw std::logic_error("HnswGraph::AddPointConcurrent: in-place update of an existing label needs the graph exclusively (use AddPoint)");
+			} else {
+				updatePoint(data, existing);
+				return existing;
+			}
 		}
 		if (count_ >= maxElements_) throw std::runtime_error("The number of elements exceeds the specified limit");
 		cur = tableint(count_);
@@ -428,7 +442,118 @@ tableint HnswGraph::addPoint(const float* data, labeltype label) {
 	return cur;
 }
 
-tableint HnswGraph::AddPoint(const float* data, labeltype label) { return addPoint<false>(data, label); }
+// addPoint<LockerT>(data_point, label), hnswalg.h:1401-1470 (allow_replace_deleted_ is always on: hnsw.h:72): a vacated slot is recycled first
+tableint HnswGraph::AddPoint(const float* data, labeltype label) {
+	if (deletedElements_.empty()) return addPoint<false>(data, label);
+	const tableint id = deletedElements_.pop_front();
+	numDeleted_ -= 1;
+	labels_[id] = label;
+	labelLookup_[label] = id;
+	updatePoint(data, id);
+	return id;
+}
+
+void HnswGraph::rebuildDeletedSet() {
+	deletedElements_ = DeletedIdSet();
+	for (size_t i = 0; i < count_; ++i) {
+		if (deleted_[i]) deletedElements_.insert(tableint(i));
+	}
+}
+
+// updatePoint<LockerT>(dataPointRaw, internalId, 1.0), hnswalg.h:1472-1587
+void HnswGraph::updatePoint(const float* data, tableint id) {
+	std::memcpy(vectors_.data() + size_t(id) * dim_, data, dim_ * sizeof(float));
+	if (metric_ == VectorMetric::Cosine) invNorms_[id] = CalculateL2Module(data, int32_t(dim_));   // AddNorm
+	if (deleted_[id]) {   // unmarkDeletedInternal :1342-1361
+		deleted_[id] = 0;
+		if (deletedElements_.erase(id)) numDeleted_ -= 1;
+	}
+	const int maxLevelCopy = maxLevel_;
+	const tableint entryPointCopy = entryPoint_;
+	if (entryPointCopy == id && count_ == 1) return;   // the graph is this single element
+	const int elemLevel = levels_[id];
+	for (int layer = 0; layer <= elemLevel; ++layer) {
+		CandidateIdSet sCand, sNeigh;   // reindexer::fast_hash_set<tableint>: walked in the reference's hash order
+		const uint32_t* l1 = list(id, layer);
+		const std::vector<tableint> listOneHop(l1 + 1, l1 + 1 + l1[0]);
+		if (listOneHop.empty()) continue;
+		sCand.insert(id);
+		for (const tableint elOneHop : listOneHop) {
+			sCand.insert(elOneHop);
+			sNeigh.insert(elOneHop);   // updateNeighborProbability == 1.0: every one-hop neighbour is re-selected
+			const uint32_t* l2 = list(elOneHop, layer);
+			for (uint32_t j = 0; j < l2[0]; ++j) sCand.insert(l2[1 + j]);
+		}
+		const size_t mLayer = layer == 0 ? maxM0_ : M_;
+		sNeigh.for_each([&](tableint neigh) {
+			Heap candidates;
+			const size_t size = sCand.count(neigh) ? sCand.size() - 1 : sCand.size();
+			const size_t elementsToKeep = std::min(efConstruction_, size);
+			sCand.for_each([&](tableint cand) {
+				if (cand == neigh) return;
+				const float distance = distIds(neigh, cand);
+				if (candidates.size() < elementsToKeep) {
+					candidates.emplace(distance, cand);
+				} else if (distance < candidates.top().first) {
+					candidates.pop();
+					candidates.emplace(distance, cand);
+				}
+			});
+			selectNeighbors(candidates, mLayer);
+			uint32_t* ll = list(neigh, layer);
+			const size_t candSize = candidates.size();
+			ll[0] = uint32_t(candSize);
+			for (size_t idx = 0; idx < candSize; ++idx) {
+				ll[1 + idx] = candidates.top().second;
+				candidates.pop();
+			}
+			for (size_t idx = candSize; idx < mLayer; ++idx) ll[1 + idx] = 0;
+		});
+	}
+	repairConnectionsForUpdate(id, entryPointCopy, elemLevel, maxLevelCopy);
+}
+
+// hnswalg.h:1589-1680
+void HnswGraph::repairConnectionsForUpdate(tableint id, tableint entryPoint, int level, int maxLevel) {
+	tableint currObj = entryPoint;
+	if (level < maxLevel) {
+		float curDist = distIds(id, currObj);
+		for (int l = maxLevel; l > level; --l) {
+			bool changed = true;
+			while (changed) {
+				changed = false;
+				const uint32_t* ll = list(currObj, l);
+				const int size = int(ll[0]);
+				for (int i = 0; i < size; ++i) {
+					const tableint cand = ll[1 + i];
+					const float d = distIds(id, cand);
+					if (d < curDist) {
+						curDist = d;
+						currObj = cand;
+						changed = true;
+					}
+				}
+			}
+		}
+	}
+	if (level > maxLevel) throw std::runtime_error("Level of item to be updated cannot be bigger than max level");
+	for (int l = level; l >= 0; --l) {
+		Heap top = searchBaseLayer<false>(currObj, id, l, visited_);
+		Heap filtered;   // the element itself is dropped (pushed in pop order, like the reference does)
+		while (top.size() > 0) {
+			if (top.top().second != id) filtered.push(top.top());
+			top.pop();
+		}
+		// element_levels_ is used to get the level, so `top` may hold nothing but the element itself: then the level stays as it is
+		if (filtered.size() > 0) {
+			if (IsDeleted(entryPoint)) {
+				filtered.emplace(distIds(id, entryPoint), entryPoint);
+				if (filtered.size() > efConstruction_) filtered.pop();
+			}
+			currObj = connect<false>(id, filtered, l, true);
+		}
+	}
+}
 
 void HnswGraph::EnableConcurrentInserts() {
 	std::lock_guard<std::mutex> lk(visitedPoolMtx_);
@@ -461,7 +586,31 @@ void HnswGraph::releaseVisited(std::unique_ptr<Visited> v) {
 
 tableint HnswGraph::AddPointConcurrent(const float* data, labeltype label) {
 	if (!nodeLocks_ || nodeLocksSize_ != maxElements_) EnableConcurrentInserts();
-	return addPoint<true>(data, label);
+	// A vacated slot is recycled first, as in the reference (hnswalg.h:1410-1421).  The reference then runs updatePoint next to other inserts
+	// behind per-element data locks (ExpectConcurrentUpdates::Yes); here the recycling insert takes the graph exclusively instead: same
+	// graph invariants, and slot reuse is the rare case of a bulk build.
+	bool vacant = false;
+	tableint id = 0;
+	{
+		std::lock_guard<std::mutex> lk(deletedMtx_);
+		if (!deletedElements_.empty()) {
+			vacant = true;
+			id = deletedElements_.pop_front();
+			numDeleted_ -= 1;
+		}
+	}
+	if (!vacant) {
+		std::shared_lock<std::shared_mutex> shared(updateMtx_);
+		return addPoint<true>(data, label);
+	}
+	std::unique_lock<std::shared_mutex> exclusive(updateMtx_);
+	labels_[id] = label;
+	{
+		std::lock_guard<std::mutex> lk(labelMtx_);
+		labelLookup_[label] = id;
+	}
+	updatePoint(data, id);
+	return id;
 }
 
 void HnswGraph::AddPoints(const float* data, const labeltype* labels, size_t n, unsigned threads) {
@@ -473,7 +622,7 @@ void HnswGraph::AddPoints(const float* data, const labeltype* labels, size_t n, 
 	EnableConcurrentInserts();
 	size_t first = 0;
 	if (count_ == 0) {   // the element that creates the entry point goes in alone
-		addPoint<true>(data, labels[0]);
+		AddPointConcurrent(data, labels[0]);
 		first = 1;
 	}
 	std::atomic<size_t> next{first};
@@ -484,7 +633,7 @@ void HnswGraph::AddPoints(const float* data, const labeltype* labels, size_t n, 
 			for (;;) {
 				const size_t i = next.fetch_add(1, std::memory_order_relaxed);
 				if (i >= n) break;
-				addPoint<true>(data + i * dim_, labels[i]);
+				AddPointConcurrent(data + i * dim_, labels[i]);
 			}
 		} catch (const std::exception& e) {
 			next.store(n, std::memory_order_relaxed);
@@ -506,7 +655,8 @@ void HnswGraph::MarkDelete(labeltype label) {
 	if (deleted_[id]) throw std::runtime_error("The requested to delete element is already deleted");
 	deleted_[id] = 1;
 	numDeleted_ += 1;
-	labelLookup_.erase(it);   // allow_replace_deleted_ == true in the reference's construction (hnsw.h:72)
+	deletedElements_.insert(id);   // markDeletedInternal :1323-1338 (allow_replace_deleted_)
+	labelLookup_.erase(it);        // allow_replace_deleted_ == true in the reference's construction (hnsw.h:72)
 }
 
 void HnswGraph::ExportUpper(std::vector<uint64_t>& off, std::vector<uint32_t>& blocks) const {

@@ -16,9 +16,13 @@
 // or rewritten (hnswalg.h:1694-1852, 644-749, 1042-1180).  Like the reference's, such a graph depends on thread timing; inserted from
 // ONE thread it equals the sequential graph link for link (tests/test_hnsw_builder.py).
 //
-// Deliberate difference: slots of deleted elements are not recycled by later inserts (the reference's
-// allow_replace_deleted path, updatePoint :1472-1690, picks the slot from a hash-set iteration order); new points are
-// always appended.  Search semantics with deleted nodes (traversed, never returned) are identical.
+//   slot reuse            addPoint<LockerT>(data, label) :1401-1470: a new point takes `*deleted_elements.begin()` when a deleted slot exists
+//                         (the reference's Maps are built with ReplaceDeleted_True, hnsw.h:72); the hash set's iteration order is restated in
+//                         hopscotch_set.h, so the SAME slot is recycled
+//   in-place update       updatePoint :1472-1587 (one- / two-hop neighbourhood re-selected per neighbour, sets walked in the reference's hash
+//                         order), repairConnectionsForUpdate :1589-1680, mutuallyConnectNewElement(isUpdate = true) :1042-1180
+// A delete + upsert sequence therefore yields the reference's graph link for link and the capacity does not leak
+// (tests/test_hnsw_builder.py: delete / re-insert cycles against the real engine).
 #pragma once
 
 #include <atomic>
@@ -26,9 +30,11 @@
 #include <memory>
 #include <mutex>
 #include <random>
+#include <shared_mutex>
 #include <unordered_map>
 #include <vector>
 
+#include "hopscotch_set.h"
 #include "rx_types.h"
 
 namespace rxgpu::host {
@@ -99,9 +105,12 @@ private:
 	Heap searchBaseLayer(tableint ep, tableint self, int layer, Visited& vis);
 	void selectNeighbors(Heap& candidates, size_t M) const;
 	template <bool kMT>
-	tableint connect(tableint cur, Heap& candidates, int level);
+	tableint connect(tableint cur, Heap& candidates, int level, bool isUpdate = false);
 	template <bool kMT>
 	tableint addPoint(const float* data, labeltype label);
+	void updatePoint(const float* data, tableint id);                                   // hnswalg.h:1472-1587 (callers hold the graph exclusively)
+	void repairConnectionsForUpdate(tableint id, tableint entryPoint, int level, int maxLevel);
+	void rebuildDeletedSet();
 	std::unique_ptr<Visited> acquireVisited();
 	void releaseVisited(std::unique_ptr<Visited> v);
 
@@ -123,6 +132,7 @@ private:
 	std::vector<uint8_t> deleted_;
 	std::unordered_map<labeltype, tableint> labelLookup_;
 	std::default_random_engine levelGenerator_;
+	DeletedIdSet deletedElements_;   // HierarchicalNSWImpl::deleted_elements (allow_replace_deleted_): ids in the reference's hash-set order
 
 	Visited visited_;   // the sequential builder's scratch
 
@@ -130,7 +140,8 @@ private:
 	std::unique_ptr<std::atomic<uint8_t>[]> nodeLocks_;   // link_list_locks_: one byte spin lock per element
 	size_t nodeLocksSize_ = 0;
 	bool concurrent_ = false;
-	std::mutex labelMtx_, generatorMtx_, globalMtx_, entryMtx_, visitedPoolMtx_;
+	std::mutex labelMtx_, generatorMtx_, globalMtx_, entryMtx_, visitedPoolMtx_, deletedMtx_;
+	std::shared_mutex updateMtx_;   // concurrent inserts share it; an insert that recycles a slot (updatePoint) holds it exclusively
 	std::vector<std::unique_ptr<Visited>> visitedPool_;
 };
 

@@ -164,3 +164,70 @@ def test_concurrent_build_errors_propagate():
     with pytest.raises(hostapi.HostError, match="exceeds the specified limit"):
         g.add(rows, np.arange(12, dtype=np.uint64), threads=4)
     g.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(900, 24, 8, 60), (500, 64, 16, 200), (1500, 16, 4, 30)])
+def test_builder_delete_upsert_cycles_equal_reference_graph(ref, metric, shape):
+    """updatePoint + deleted-slot reuse (hnswalg.h:1401-1587, 1589-1680): after rounds of deletes and inserts — the new points take the
+    vacated slots in the order of the reference's hash set (*deleted_elements.begin()), their one- / two-hop neighbourhoods are re-selected
+    and the element is re-linked — the graph equals the real engine's link for link, and the element count does not grow."""
+    from oracle.pyoracle import RefHnsw
+    from reindexer_amd import hostapi
+    n, d, M, efc = shape
+    rng = np.random.default_rng(n + metric)
+    rows = make_corpus(5 + n, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    r = RefHnsw(ref, metric, d, n + 40, M=M, ef_construction=efc)
+    g = hostapi.HnswGraph(metric, d, n + 40, M=M, ef_construction=efc)
+    for x in (r, g):
+        x.add(rows, labels)
+    live = list(labels)
+    next_label = n
+    for rnd in range(6):
+        # delete a batch (enough of them, in later rounds, to take the hash set through a rehash: > 15 elements)
+        k = [3, 10, 25, 40, 7, 60][rnd]
+        pick = rng.choice(len(live), k, replace=False)
+        for idx in sorted(pick.tolist(), reverse=True):
+            lab = live.pop(idx)
+            r.mark_delete(lab)
+            g.mark_delete(lab)
+        graphs_equal(r.export(with_vectors=False), g.export())
+        # insert fewer / as many / more points than were deleted: slots are recycled first, the rest is appended
+        m = [3, 6, 30, 40, 2, 75][rnd]
+        new_rows = make_corpus(1000 + rnd + n, m, d)
+        if rnd == 2:
+            new_rows[:5] = rows[:5]   # exact duplicates of live vectors: zero / tied distances in the re-selection
+        new_labels = ((np.arange(next_label, next_label + m, dtype=np.uint64)) << np.uint64(32)) | np.uint64(2)
+        next_label += m
+        for i in range(m):
+            r.add(new_rows[i:i + 1], new_labels[i:i + 1])
+            g.add(new_rows[i:i + 1], new_labels[i:i + 1])
+        live.extend(new_labels.tolist())
+        e_ref, e_got = r.export(with_vectors=False), g.export()
+        graphs_equal(e_ref, e_got)
+    assert r.count == g.export()["n"] <= n + 40
+    r.close()
+    g.close()
+
+
+def test_builder_update_existing_label_in_place(ref):
+    """addPoint with a label that is already present updates the element in place (hnswalg.h:1709-1724) — same graph as the reference's."""
+    from oracle.pyoracle import RefHnsw
+    from reindexer_amd import hostapi
+    n, d = 400, 20
+    rows = make_corpus(77, n, d)
+    labels = np.arange(n, dtype=np.uint64) + np.uint64(10)
+    r = RefHnsw(ref, 0, d, n, M=8, ef_construction=40)
+    g = hostapi.HnswGraph(0, d, n, M=8, ef_construction=40)
+    for x in (r, g):
+        x.add(rows, labels)
+    upd = make_corpus(78, 12, d)
+    for i in range(12):
+        lab = labels[i * 17:i * 17 + 1]
+        r.add(upd[i:i + 1], lab)
+        g.add(upd[i:i + 1], lab)
+    graphs_equal(r.export(with_vectors=False), g.export())
+    assert g.export()["n"] == n
+    r.close()
+    g.close()
