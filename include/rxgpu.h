@@ -170,6 +170,14 @@ int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, ui
  * Limits of the GPU engine: max_m0 <= 128 (M <= 64). */
 int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, uint64_t upper_blocks,
 							const uint8_t* deleted, uint32_t M, uint32_t max_m0, int32_t maxlevel, uint32_t entry, uint64_t num_deleted);
+/* In-place mirror of a host-side insert or update (addPoint / updatePoint, hnswalg.h:1472-1852, touch the new element and a few dozen
+ * neighbours): instead of re-uploading the whole graph, the nodes whose lists changed are scattered into the resident arrays.  Call after
+ * rxgpu_index_upload_rows for the new rows.  dirty_ids [n_dirty]: every node with a changed level-0 list, upper list or delete flag; new
+ * nodes (id >= the attached node count) all listed, ascending; links0_rows [n_dirty][1 + max_m0]; deleted_flags [n_dirty]; levels [n_dirty]
+ * = the node's level (upper blocks); upper_rows = those blocks concatenated in dirty order, (1 + M) words each.
+ * RXGPU_ERR_OVERFLOW: the arrays allocated by the last attach cannot take the growth — attach the graph again. */
+int rxgpu_hnsw_patch_graph(rxgpu_index* h, uint32_t n_dirty, const uint32_t* dirty_ids, const uint32_t* links0_rows, const uint8_t* deleted_flags,
+						   const int32_t* levels, const uint32_t* upper_rows, int32_t maxlevel, uint32_t entry, uint64_t num_deleted);
 /* MarkDelete mirror (hnswalg.h:1303-1339): refresh only the flags. */
 int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t num_deleted);
 

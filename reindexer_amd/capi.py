@@ -59,6 +59,7 @@ _SIGNATURES = {
     "rxgpu_distances": (_i, [_vp, _vp, _vp, _u32, _vp]),
     "rxgpu_hnsw_attach_graph": (_i, [_vp, _vp, _vp, _vp, _u64, _vp, _u32, _u32, C.c_int32, _u32, _u64]),
     "rxgpu_hnsw_update_deleted": (_i, [_vp, _vp, _u64]),
+    "rxgpu_hnsw_patch_graph": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.c_int32, _u32, _u64]),
     "rxgpu_hnsw_search_knn": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_hnsw_stream_begin": (_i, [_vp, _vp, _u32, C.POINTER(_vp)]),

@@ -350,4 +350,27 @@ void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool g
 	}
 }
 
+
+// rxgpu_hnsw_patch_graph: a host insert (addPoint / updatePoint, hnswalg.h:1472-1852) rewrites the lists of the new element and of a few
+// dozen neighbours; their staged copies are scattered into the resident graph instead of re-uploading all of it.
+__global__ __launch_bounds__(64) void hnsw_patch_kernel(HnswPatch p) {
+	const uint32_t j = blockIdx.x, lane = threadIdx.x;
+	const uint32_t id = p.ids[j];
+	const uint32_t stride0 = 1 + p.maxM0, stride = 1 + p.M;
+	for (uint32_t w = lane; w < stride0; w += 64) p.links0[uint64_t(id) * stride0 + w] = p.src_links0[uint64_t(j) * stride0 + w];
+	uint64_t at = p.upper_at[j];
+	if (at == ~uint64_t(0)) {
+		at = p.upper_off[id];
+	} else if (lane == 0) {
+		p.upper_off[id] = at;
+	}
+	const uint32_t words = uint32_t(p.levels[j]) * stride;
+	for (uint32_t w = lane; w < words; w += 64) p.upper[at * stride + w] = p.src_upper[uint64_t(p.upper_src[j]) * stride + w];
+	if (lane == 0) p.deleted[id] = p.src_deleted[j];
+}
+
+void launch_hnsw_patch(const HnswPatch& p, uint32_t n_dirty, hipStream_t s) {
+	if (n_dirty) hipLaunchKernelGGL(hnsw_patch_kernel, dim3(n_dirty), dim3(64), 0, s, p);
+}
+
 }  // namespace rxgpu

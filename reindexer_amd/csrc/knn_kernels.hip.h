@@ -124,6 +124,22 @@ struct HnswParams {
 	uint32_t ef_cap;             // result-heap capacity in LDS: ef rounded up to 64
 };
 
+// In-place graph update (rxgpu_hnsw_patch_graph): one workgroup per touched node scatters its staged lists into the resident arrays
+struct HnswPatch {
+	const uint32_t* ids;          // [n_dirty] node ids
+	const uint64_t* upper_at;     // [n_dirty] first upper block of the node in `upper` (new nodes: assigned by the host; old nodes: ~0 = keep)
+	const uint32_t* upper_src;    // [n_dirty] first staged upper block of the node in src_upper
+	const int32_t* levels;        // [n_dirty] upper levels of the node (= its block count)
+	const uint32_t* src_links0;   // [n_dirty][1 + maxM0]
+	const uint32_t* src_upper;    // staged upper blocks, (1 + M) words each
+	const uint8_t* src_deleted;   // [n_dirty]
+	uint32_t* links0;
+	uint64_t* upper_off;
+	uint32_t* upper;
+	uint8_t* deleted;
+	uint32_t M, maxM0;
+};
+
 // Streaming session (hnsw_stream.hip): Layer0SearchState (hnswalg.h:741-777) resident in device memory between calls
 constexpr int kStreamBegin = 0, kStreamContinue = 1, kStreamResume = 2;
 constexpr uint32_t kStreamOk = 0, kStreamNeedGlobal = 1, kStreamError = 2;

@@ -1215,23 +1215,27 @@ int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64
 	RX_CHECK(n == 0 || entry < n, RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_graph: entry point out of range");
 	DeviceGuard dg(h->device);
 	RX_HIP(hipDeviceSynchronize());
-	auto replace = [&](auto*& dst, const void* src, size_t bytes) -> int {
+	// allocated for the index CAPACITY (and with headroom for upper-level blocks), so that rxgpu_hnsw_patch_graph can grow the graph in place
+	auto replace = [&](auto*& dst, const void* src, size_t bytes, size_t cap_bytes) -> int {
 		if (dst) (void)hipFree(dst);
 		dst = nullptr;
-		if (bytes == 0) return RXGPU_OK;
-		RX_HIP(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
-		RX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+		if (cap_bytes == 0) return RXGPU_OK;
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&dst), cap_bytes));
+		if (bytes) RX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
 		return RXGPU_OK;
 	};
 	h->graph_attached = false;
-	if (int rc = replace(h->d_links0, links0, n * (1 + size_t(max_m0)) * sizeof(uint32_t)); rc) return rc;
-	if (int rc = replace(h->d_upper_off, upper_off, (n + 1) * sizeof(uint64_t)); rc) return rc;
-	static const uint32_t kZero[2] = {0, 0};
-	if (int rc = replace(h->d_upper, upper_blocks ? static_cast<const void*>(upper) : static_cast<const void*>(kZero),
-						 upper_blocks ? upper_blocks * (1 + size_t(M)) * sizeof(uint32_t) : sizeof(kZero));
-		rc)
-		return rc;
-	if (int rc = replace(h->d_deleted, deleted, std::max<uint64_t>(n, 1)); rc) return rc;
+	const uint64_t rows_cap = std::max<uint64_t>(std::max<uint64_t>(h->capacity, n), 1);
+	// expected upper blocks of a full index: sum over levels of cap / M^level = cap / (M - 1); twice that (and at least what is there) as headroom
+	const uint64_t upper_cap = std::max<uint64_t>(2 * upper_blocks + 64, 2 * rows_cap / std::max<uint32_t>(M - 1, 1) + 64);
+	const size_t row_bytes = (1 + size_t(max_m0)) * sizeof(uint32_t), blk_bytes = (1 + size_t(M)) * sizeof(uint32_t);
+	if (int rc = replace(h->d_links0, links0, n * row_bytes, rows_cap * row_bytes); rc) return rc;
+	if (int rc = replace(h->d_upper_off, upper_off, n ? (n + 1) * sizeof(uint64_t) : 0, (rows_cap + 1) * sizeof(uint64_t)); rc) return rc;
+	if (int rc = replace(h->d_upper, upper, upper_blocks * blk_bytes, upper_cap * blk_bytes); rc) return rc;
+	if (int rc = replace(h->d_deleted, deleted, n, rows_cap); rc) return rc;
+	h->graph_rows_cap = rows_cap;
+	h->graph_upper_cap = upper_cap;
+	h->graph_upper_used = upper_blocks;
 	if (!h->d_hnsw_stats) {
 		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_hnsw_stats), 2 * sizeof(unsigned long long)));
 		RX_HIP(hipMemset(h->d_hnsw_stats, 0, 2 * sizeof(unsigned long long)));
@@ -1243,6 +1247,94 @@ int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64
 	h->graph_entry = entry;
 	h->graph_deleted = num_deleted;
 	h->graph_attached = true;
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_patch_graph(rxgpu_index* h, uint32_t n_dirty, const uint32_t* dirty_ids, const uint32_t* links0_rows, const uint8_t* deleted_flags,
+						   const int32_t* levels, const uint32_t* upper_rows, int32_t maxlevel, uint32_t entry, uint64_t num_deleted) {
+	RX_CHECK(h && h->graph_attached, RXGPU_ERR_LOGIC, "rxgpu_hnsw_patch_graph: no graph attached");
+	RX_CHECK(n_dirty == 0 || (dirty_ids && links0_rows && deleted_flags && levels), RXGPU_ERR_PARAMS, "rxgpu_hnsw_patch_graph: null argument");
+	const uint64_t n_new = h->count;   // the rows were uploaded first (rxgpu_index_upload_rows)
+	RX_CHECK(n_new >= h->graph_n, RXGPU_ERR_LOGIC, "rxgpu_hnsw_patch_graph: the index shrank under the graph");
+	RX_CHECK(n_new == 0 || entry < n_new, RXGPU_ERR_PARAMS, "rxgpu_hnsw_patch_graph: entry point out of range");
+	if (n_new > h->graph_rows_cap) {
+		set_error("rxgpu_hnsw_patch_graph: the graph arrays were allocated for fewer rows (re-attach the graph)");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	// staging: ids, per-node upper placement, lists — one buffer, one upload, one scatter launch
+	const uint32_t M = h->graph_M, max_m0 = h->graph_maxM0;
+	const size_t stride0 = 1 + size_t(max_m0), stride = 1 + size_t(M);
+	std::vector<uint64_t> upper_at(n_dirty);
+	std::vector<uint32_t> upper_src(n_dirty);
+	uint64_t used = h->graph_upper_used, staged_blocks = 0, next_new = h->graph_n;
+	for (uint32_t j = 0; j < n_dirty; ++j) {
+		RX_CHECK(dirty_ids[j] < n_new && levels[j] >= 0, RXGPU_ERR_PARAMS, "rxgpu_hnsw_patch_graph: node id / level out of range");
+		upper_src[j] = uint32_t(staged_blocks);
+		staged_blocks += uint64_t(levels[j]);
+		if (dirty_ids[j] >= h->graph_n) {   // a new node: ids ascending, every one of them listed (its blocks are appended in id order)
+			RX_CHECK(dirty_ids[j] == next_new, RXGPU_ERR_PARAMS, "rxgpu_hnsw_patch_graph: new nodes must be listed in ascending id order, none skipped");
+			++next_new;
+			upper_at[j] = used;
+			used += uint64_t(levels[j]);
+		} else {
+			upper_at[j] = ~uint64_t(0);
+		}
+	}
+	RX_CHECK(next_new == n_new, RXGPU_ERR_PARAMS, "rxgpu_hnsw_patch_graph: every new node must be listed");
+	RX_CHECK(staged_blocks == 0 || upper_rows, RXGPU_ERR_PARAMS, "rxgpu_hnsw_patch_graph: upper_rows is null");
+	if (used > h->graph_upper_cap) {
+		set_error("rxgpu_hnsw_patch_graph: upper-level storage exhausted (re-attach the graph)");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	RX_HIP(hipDeviceSynchronize());   // no search may be reading the lists while they change (the Map calls this under its writer lock)
+	auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+	const size_t o_ids = 0, o_at = al(o_ids + size_t(n_dirty) * 4), o_src = al(o_at + size_t(n_dirty) * 8), o_lv = al(o_src + size_t(n_dirty) * 4),
+				 o_l0 = al(o_lv + size_t(n_dirty) * 4), o_up = al(o_l0 + size_t(n_dirty) * stride0 * 4), o_del = al(o_up + staged_blocks * stride * 4),
+				 total = al(o_del + n_dirty);
+	if (n_dirty) {
+		if (int rc = c->d_misc.ensure(total); rc) return rc;
+		if (int rc = c->ensure_pinned(total); rc) return rc;
+		char* hp = static_cast<char*>(c->h_pinned);
+		std::memcpy(hp + o_ids, dirty_ids, size_t(n_dirty) * 4);
+		std::memcpy(hp + o_at, upper_at.data(), size_t(n_dirty) * 8);
+		std::memcpy(hp + o_src, upper_src.data(), size_t(n_dirty) * 4);
+		std::memcpy(hp + o_lv, levels, size_t(n_dirty) * 4);
+		std::memcpy(hp + o_l0, links0_rows, size_t(n_dirty) * stride0 * 4);
+		if (staged_blocks) std::memcpy(hp + o_up, upper_rows, staged_blocks * stride * 4);
+		std::memcpy(hp + o_del, deleted_flags, n_dirty);
+		char* db = static_cast<char*>(c->d_misc.ptr);
+		RX_HIP(hipMemcpyAsync(db, hp, total, hipMemcpyHostToDevice, c->stream));
+		rxgpu::HnswPatch p{};
+		p.ids = reinterpret_cast<const uint32_t*>(db + o_ids);
+		p.upper_at = reinterpret_cast<const uint64_t*>(db + o_at);
+		p.upper_src = reinterpret_cast<const uint32_t*>(db + o_src);
+		p.levels = reinterpret_cast<const int32_t*>(db + o_lv);
+		p.src_links0 = reinterpret_cast<const uint32_t*>(db + o_l0);
+		p.src_upper = reinterpret_cast<const uint32_t*>(db + o_up);
+		p.src_deleted = reinterpret_cast<const uint8_t*>(db + o_del);
+		p.links0 = h->d_links0;
+		p.upper_off = h->d_upper_off;
+		p.upper = h->d_upper;
+		p.deleted = h->d_deleted;
+		p.M = M;
+		p.maxM0 = max_m0;
+		rxgpu::launch_hnsw_patch(p, n_dirty, c->stream);
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipStreamSynchronize(c->stream));
+	}
+	h->graph_upper_used = used;
+	h->graph_n = n_new;
+	h->graph_maxlevel = maxlevel;
+	h->graph_entry = entry;
+	h->graph_deleted = num_deleted;
 	return RXGPU_OK;
 }
 

@@ -69,6 +69,8 @@ void launch_rescore(int metric, const float* rows, const float* inv_norms, const
 // HNSW search (hnsw_search.hip)
 struct HnswParams;
 void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s);
+struct HnswPatch;
+void launch_hnsw_patch(const HnswPatch& p, uint32_t n_dirty, hipStream_t s);
 struct HnswStream;
 void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, uint32_t batch, int mode, bool lds, hipStream_t st);
 
@@ -221,6 +223,7 @@ struct rxgpu_index {
 	uint32_t* d_upper = nullptr;
 	uint8_t* d_deleted = nullptr;
 	uint64_t graph_n = 0, graph_deleted = 0;
+	uint64_t graph_rows_cap = 0, graph_upper_cap = 0, graph_upper_used = 0;   // allocated level-0 rows / upper blocks (rxgpu_hnsw_patch_graph grows in place)
 	uint32_t graph_M = 0, graph_maxM0 = 0;
 	int graph_maxlevel = -1;
 	uint32_t graph_entry = 0;

@@ -1,5 +1,7 @@
 #include "gpu_hnsw_map.h"
 
+#include <cstring>
+
 #include <algorithm>
 #include <queue>
 #include <stdexcept>
@@ -67,20 +69,64 @@ void GpuHnswMap::syncDevice() const {
 		if (rxgpu_index_capacity(dev_) < graph_.MaxElements()) {
 			if (rxgpu_index_reserve(dev_, graph_.MaxElements()) != RXGPU_OK) throwDevice("Not enough memory: resizeIndex failed to allocate base layer");
 		}
-		if (n > syncedRows_) {   // rows never change once inserted: ship only the new ones
-			const float* norms = graph_.InvNorms();
-			if (rxgpu_index_upload_rows(dev_, syncedRows_, n - syncedRows_, graph_.Vectors() + syncedRows_ * graph_.Dim(),
-										norms ? norms + syncedRows_ : nullptr) != RXGPU_OK) {
-				throwDevice("row upload failed");
+		// What changed since the last sync: a handful of nodes after an upsert (the new element, the neighbours it was linked to; an
+		// in-place update also its one-hop neighbourhood) — their vectors and lists are patched in place; a bulk build re-sends everything.
+		std::vector<tableint> dirty;
+		const bool incremental = graph_.TakeDirty(dirty) && graphOnDevice_;
+		const float* norms = graph_.InvNorms();
+		bool patched = false;
+		if (incremental) {
+			// vectors: new rows as one run, updated rows (recycled slots / in-place updates) one by one
+			for (const tableint id : dirty) {
+				if (id >= syncedRows_) break;   // ids ascend; the rest are new rows
+				if (rxgpu_index_upload_rows(dev_, id, 1, graph_.Vector(id), norms ? norms + id : nullptr) != RXGPU_OK) throwDevice("row upload failed");
+			}
+			if (n > syncedRows_) {
+				if (rxgpu_index_upload_rows(dev_, syncedRows_, n - syncedRows_, graph_.Vectors() + syncedRows_ * graph_.Dim(),
+											norms ? norms + syncedRows_ : nullptr) != RXGPU_OK) {
+					throwDevice("row upload failed");
+				}
+			}
+			const size_t stride0 = 1 + graph_.MaxM0();
+			std::vector<uint32_t> rows0(dirty.size() * stride0), upperRows;
+			std::vector<uint8_t> del(dirty.size());
+			std::vector<int32_t> levels(dirty.size());
+			for (size_t j = 0; j < dirty.size(); ++j) {
+				const tableint id = dirty[j];
+				std::memcpy(rows0.data() + j * stride0, graph_.Links0() + size_t(id) * stride0, stride0 * sizeof(uint32_t));
+				del[j] = graph_.Deleted()[id];
+				levels[j] = graph_.Levels()[id];
+				graph_.AppendUpper(id, upperRows);
+			}
+			const int rc = rxgpu_hnsw_patch_graph(dev_, uint32_t(dirty.size()), dirty.data(), rows0.data(), del.data(), levels.data(),
+												  upperRows.empty() ? nullptr : upperRows.data(), graph_.MaxLevel(), n ? graph_.EntryPoint() : 0,
+												  graph_.DeletedCount());
+			if (rc == RXGPU_OK) {
+				patched = true;
+			} else if (rc != RXGPU_ERR_OVERFLOW) {
+				throwDevice("graph patch failed");
 			}
 			syncedRows_ = n;
 		}
-		std::vector<uint64_t> off;
-		std::vector<uint32_t> upper;
-		graph_.ExportUpper(off, upper);
-		if (rxgpu_hnsw_attach_graph(dev_, graph_.Links0(), off.data(), upper.data(), off.empty() ? 0 : off[n], graph_.Deleted(), uint32_t(graph_.M()),
-									uint32_t(graph_.MaxM0()), graph_.MaxLevel(), n ? graph_.EntryPoint() : 0, graph_.DeletedCount()) != RXGPU_OK) {
-			throwDevice("graph upload failed");
+		if (!patched) {
+			if (!incremental) {   // the vectors of recycled slots may have changed too: the tracker lost them, re-send all rows
+				syncedRows_ = 0;
+			}
+			if (n > syncedRows_) {
+				if (rxgpu_index_upload_rows(dev_, syncedRows_, n - syncedRows_, graph_.Vectors() + syncedRows_ * graph_.Dim(),
+											norms ? norms + syncedRows_ : nullptr) != RXGPU_OK) {
+					throwDevice("row upload failed");
+				}
+				syncedRows_ = n;
+			}
+			std::vector<uint64_t> off;
+			std::vector<uint32_t> upper;
+			graph_.ExportUpper(off, upper);
+			if (rxgpu_hnsw_attach_graph(dev_, graph_.Links0(), off.data(), upper.data(), off.empty() ? 0 : off[n], graph_.Deleted(), uint32_t(graph_.M()),
+										uint32_t(graph_.MaxM0()), graph_.MaxLevel(), n ? graph_.EntryPoint() : 0, graph_.DeletedCount()) != RXGPU_OK) {
+				throwDevice("graph upload failed");
+			}
+			graphOnDevice_ = true;
 		}
 	} else if (deletedDirty_) {
 		if (rxgpu_hnsw_update_deleted(dev_, graph_.Deleted(), graph_.DeletedCount()) != RXGPU_OK) throwDevice("delete-mark upload failed");

@@ -100,11 +100,12 @@ private:
 	struct PendingQuery;
 	void fetchKnn(const float* query, uint32_t k, uint32_t ef, float* dist, uint32_t* row, uint32_t* count) const;
 
-	HnswGraph graph_;
+	mutable HnswGraph graph_;   // mutable: syncDevice() (const, under syncMtx_) drains the graph's change tracker
 	const int device_;
 	mutable std::mutex syncMtx_;
 	mutable rxgpu_index* dev_ = nullptr;
 	mutable size_t syncedRows_ = 0;
+	mutable bool graphOnDevice_ = false;   // a full attach happened: later changes can be patched in place (rxgpu_hnsw_patch_graph)
 	const Synchronization synchronization_;
 	mutable std::atomic<bool> graphDirty_{true};
 	mutable bool deletedDirty_ = false;

@@ -117,7 +117,32 @@ void HnswGraph::Resize(size_t newMaxElements) {
 		throw std::runtime_error("Not enough memory: resizeIndex failed to allocate base layer");
 	}
 	maxElements_ = newMaxElements;
+	dirtyAll_.store(true, std::memory_order_relaxed);
 	if (concurrent_) EnableConcurrentInserts();
+}
+
+void HnswGraph::markDirty(tableint id) {
+	if (dirtyAll_.load(std::memory_order_relaxed)) return;
+	std::lock_guard<std::mutex> lk(dirtyMtx_);
+	if (dirty_.size() > std::max<size_t>(count_ / 4, 4096)) {
+		dirty_.clear();
+		dirtyAll_.store(true, std::memory_order_relaxed);
+		return;
+	}
+	dirty_.push_back(id);
+}
+
+bool HnswGraph::TakeDirty(std::vector<tableint>& out) {
+	std::lock_guard<std::mutex> lk(dirtyMtx_);
+	out.clear();
+	const bool all = dirtyAll_.exchange(false, std::memory_order_relaxed);
+	if (!all) {
+		std::sort(dirty_.begin(), dirty_.end());
+		dirty_.erase(std::unique(dirty_.begin(), dirty_.end()), dirty_.end());
+		out.swap(dirty_);
+	}
+	dirty_.clear();
+	return !all;
 }
 
 tableint HnswGraph::InternalId(labeltype label) const {
@@ -282,6 +307,7 @@ tableint HnswGraph::connect(tableint cur, Heap& candidates, int level, bool isUp
 			ll[1 + i] = selected[i];
 		}
 		for (size_t i = selected.size(); i < mCurMax; ++i) ll[1 + i] = 0;   // canonical unused slots (an updated element's list may shrink)
+		markDirty(cur);
 	}
 	for (const tableint other : selected) {
 		[[maybe_unused]] std::unique_ptr<NodeLock> lk;
@@ -295,6 +321,7 @@ tableint HnswGraph::connect(tableint cur, Heap& candidates, int level, bool isUp
 			for (size_t j = 0; j < sz && !present; ++j) present = lo[1 + j] == cur;
 			if (present) continue;
 		}
+		markDirty(other);
 		if (sz < mCurMax) {
 			lo[1 + sz] = cur;
 			lo[0] = uint32_t(sz + 1);
@@ -372,6 +399,7 @@ tableint HnswGraph::addPoint(const float* data, labeltype label) {
 	tableint currObj = enterCopy;
 
 	std::memset(list(cur, 0), 0, (1 + maxM0_) * sizeof(uint32_t));
+	markDirty(cur);
 	labels_[cur] = label;
 	deleted_[cur] = 0;
 	std::memcpy(vectors_.data() + size_t(cur) * dim_, data, dim_ * sizeof(float));
@@ -463,6 +491,7 @@ void HnswGraph::rebuildDeletedSet() {
 // updatePoint<LockerT>(dataPointRaw, internalId, 1.0), hnswalg.h:1472-1587
 void HnswGraph::updatePoint(const float* data, tableint id) {
 	std::memcpy(vectors_.data() + size_t(id) * dim_, data, dim_ * sizeof(float));
+	markDirty(id);
 	if (metric_ == VectorMetric::Cosine) invNorms_[id] = CalculateL2Module(data, int32_t(dim_));   // AddNorm
 	if (deleted_[id]) {   // unmarkDeletedInternal :1342-1361
 		deleted_[id] = 0;
@@ -508,6 +537,7 @@ void HnswGraph::updatePoint(const float* data, tableint id) {
 				candidates.pop();
 			}
 			for (size_t idx = candSize; idx < mLayer; ++idx) ll[1 + idx] = 0;
+			markDirty(neigh);
 		});
 	}
 	repairConnectionsForUpdate(id, entryPointCopy, elemLevel, maxLevelCopy);

@@ -82,8 +82,13 @@ public:
 	const labeltype* Labels() const noexcept { return labels_.data(); }
 	// upper levels as CSR blocks of (1 + M) u32: node i owns levels[i] consecutive blocks starting at off[i]
 	void ExportUpper(std::vector<uint64_t>& off, std::vector<uint32_t>& blocks) const;
+	void AppendUpper(tableint id, std::vector<uint32_t>& blocks) const { blocks.insert(blocks.end(), upper_[id].begin(), upper_[id].end()); }
 
 	size_t AllocatedMemSize() const noexcept;
+
+	// Change tracking for the device mirror: the nodes whose lists / vector changed since the last TakeDirty().  Returns false when the
+	// tracker gave up (more than a quarter of the graph touched, e.g. a bulk build): everything has to be re-sent.
+	bool TakeDirty(std::vector<tableint>& out);
 
 private:
 	using Pair = std::pair<float, tableint>;
@@ -111,6 +116,7 @@ private:
 	void updatePoint(const float* data, tableint id);                                   // hnswalg.h:1472-1587 (callers hold the graph exclusively)
 	void repairConnectionsForUpdate(tableint id, tableint entryPoint, int level, int maxLevel);
 	void rebuildDeletedSet();
+	void markDirty(tableint id);
 	std::unique_ptr<Visited> acquireVisited();
 	void releaseVisited(std::unique_ptr<Visited> v);
 
@@ -135,6 +141,10 @@ private:
 	DeletedIdSet deletedElements_;   // HierarchicalNSWImpl::deleted_elements (allow_replace_deleted_): ids in the reference's hash-set order
 
 	Visited visited_;   // the sequential builder's scratch
+
+	std::vector<tableint> dirty_;
+	std::atomic<bool> dirtyAll_{true};   // nothing has been mirrored yet
+	std::mutex dirtyMtx_;
 
 	// concurrent construction only
 	std::unique_ptr<std::atomic<uint8_t>[]> nodeLocks_;   // link_list_locks_: one byte spin lock per element
