@@ -6,9 +6,12 @@
 // one launch per sub-term (9 + 9 launches and as many fills for a 3 x 3 query: launch-latency bound, 5-11 % of HBM).  Here the same
 // RESULT is derived order-free, so a whole query is a fixed number of launches, each over ALL postings of the query:
 //
-//  * pre-score (calcTermScores :289-324): inside a term the FIRST sub-term containing a document contributes its proc16, across terms the
-//    contributions add with saturation.  `first` = atomicMax of (4095 - sub-term ordinal) << 16 | proc16 per (term, document); a saturating
-//    sum of non-negative values does not depend on the order  ->  ft_scan + ft_score.
+//  * restricting bitmask and pre-score (buildRestrictingBitmask :326-384, calcTermScores :289-324): both are per-DOCUMENT facts (is the
+//    document in every AND term / in no NOT term; per term the FIRST sub-term holding it contributes its proc16, saturating sum over the
+//    terms).  Posting lists are sorted by document, so a workgroup that owns a RANGE of 8192 documents finds its segment of every list in
+//    a per-word range index and resolves everything in LDS — bit arrays for the masks, a 16-bit score per document, sub-terms in order
+//    behind workgroup barriers — without one global atomic  ->  ft_ranges.  (The first cut scattered postings into per-term arrays with
+//    device-scope atomics: 140 us for a 3 x 3 query; atomics on random addresses resolve past the per-XCD L2s at ~28 G/s.)
 //  * admission (addDoc until maxMergedDocs, merger.h:161-180): a document is added by its first posting (in global posting order) that is
 //    eligible and has a non-zero rank; it gets the next merge slot if fewer than maxMergedDocs documents were added before it, and once the
 //    limit is hit nothing is added any more.  `first posting` = atomicMin of the global posting index per document; `slot` = ORDERED prefix
@@ -20,9 +23,9 @@
 //    float operations (ft_replay)  ->  same bits.
 //  * preselect ties at the threshold score are kept in document order: ordered prefix again (ft_preselect_apply).
 //
-// Launch train of a multi-term query: ft_init, [ft_scan x (up to) 3 levels, ft_combine, [ft_score, ft_preselect_pick, ft_preselect_apply]],
-// ft_rank_all, ft_count_adders, ft_assign_slots, ft_scatter, ft_replay; the 2-phase gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result
-// leaves in one packed buffer.  A Simple() query: ft_init, ft_rank_all, ft_count_adders, ft_assign_slots, ft_scatter, ft_replay.
+// Launch train of a multi-term query: ft_init, ft_ranges, [ft_preselect_pick, ft_preselect_apply], ft_rank_all, ft_count_adders,
+// ft_assign_slots, ft_scatter, ft_replay; the 2-phase gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result
+// leaves in one packed buffer.  A Simple() query: ft_init, ft_ranges (mask only), ft_rank_all, ft_count_adders, ft_assign_slots, ft_scatter, ft_replay.
 //
 // Bound: HBM gathers: per posting 4 B doc + 8 B entry offsets + 9 B per (field, tf, firstPos) entry streamed, 4 B
 // words-in-field + the mask word gathered, 5 B rank/field written and read back, 4 B atomicMin on the first-posting table.
@@ -41,7 +44,6 @@ namespace {
 constexpr unsigned long long kLbPrefix = 1ull << 63;
 constexpr unsigned long long kLbAggregate = 1ull << 62;
 constexpr uint32_t kNoPosting = 0xFFFFFFFFu;
-constexpr uint32_t kBestPresent = 1u << 31;
 constexpr int kFtApplyWords = 4;   // mask words per thread in ft_preselect_apply
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
@@ -164,25 +166,10 @@ __device__ __forceinline__ void fill_words(uint32_t* ptr, uint64_t n, uint32_t v
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- per-merge scratch state
-// restrictingMask_ = ~docsExcluded_ (mergerimpl.h:328-330; bits past total_docs stay 0 so that a popcount is exact) + every table the
-// merge reads before it writes: AND / NOT bit arrays, pre-score words, histogram, first-posting table, entry rows, synchronisation words.
+// Every table the merge reads before it writes: histogram, first-posting table, entry rows, synchronisation words.
 __global__ __launch_bounds__(256) void ft_init(FtPlan p) {
 	const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, gsize = uint64_t(gridDim.x) * blockDim.x;
-	for (uint64_t w = gtid; w < p.nwords; w += gsize) {
-		const uint64_t d0 = w * 32;
-		uint32_t bits = 0;
-		const uint32_t cnt = uint32_t(p.total_docs - d0 < 32 ? p.total_docs - d0 : 32);
-		if (!p.excluded) {
-			bits = cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
-		} else {
-			for (uint32_t b = 0; b < cnt; ++b) bits |= (p.excluded[d0 + b] ? 0u : 1u) << b;
-		}
-		p.mask[w] = bits;
-	}
-	fill_words(p.and_masks, uint64_t(p.n_and) * p.nwords, 0u, gtid, gsize);
-	fill_words(p.not_mask, p.not_mask ? p.nwords : 0, 0u, gtid, gsize);
 	if (p.prescore) {
-		fill_words(p.best, uint64_t(p.n_best) * p.best_stride, 0u, gtid, gsize);
 		fill_words(p.hist, 65536, 0u, gtid, gsize);
 		fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)) * 2, 0u, gtid, gsize);
 	}
@@ -192,164 +179,152 @@ __global__ __launch_bounds__(256) void ft_init(FtPlan p) {
 }
 
 // ---------------------------------------------------------------------------------------------- restricting bitmask + pre-scores
-// The postings of every term that needs a pass:
-//   AND term  calcTermBitmask (mergerimpl.h:252-274): any occurrence with a relevant field (checkFieldsRelevance, phrasemergerimpl.h:93-125)
-//   NOT term  excludeTermFromBitmask (:276-287)
-//   pre-score calcTermScores (:289-324) for every term that is not a NOT, when the host half of the 2-phase gate held
-// Device-scope atomics on random addresses run at ~28 G/s on this part (they resolve at the memory side, past the per-XCD L2s) — 140 us
-// for the 3.9 M postings of a 3 x 3 query — so the "first sub-term wins" rule is resolved by LAUNCH ORDER instead: level 0 = the first
-// sub-term of every term (plain stores: documents are unique inside a sub-term and every term has its own array), level 1 = the second
-// sub-terms (store only where nothing is recorded yet), level 2 = all further sub-terms together (atomicMax on the few cells still open).
-__global__ __launch_bounds__(256) void ft_scan(FtPlan p, uint32_t level) {
-	const uint32_t block = blockIdx.x + p.scan_level_base[level];
-	const FtGridEntry ge = grid_entry(p.scan_grid, p.n_scan_entries, block);
-	const FtPosSubterm& s = p.subs[ge.sub];
-	const FtTermCfg& t = p.terms[s.term];
-	const uint64_t i0 = uint64_t(block - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	if (i0 >= s.n) return;
-	uint32_t docs[kFtPassItems];
-	bool live[kFtPassItems];
-	load_docs(s, i0, docs, live);
-	const int op = t.op;
-	const bool want_score = p.prescore && op != 3;
-	const bool need_entries = (op == 2 && !t.all_pos_boost) || (want_score && !t.same_boost);
-	const uint32_t ord_key = kBestPresent | ((4095u - uint32_t(s.ord_in_term)) << 16);
-	uint32_t* best = want_score ? p.best + uint64_t(t.best_idx) * p.best_stride : nullptr;
-	uint32_t cur[kFtPassItems];
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) cur[k] = (want_score && level > 0 && live[k]) ? best[docs[k]] : 0u;
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) {
-		if (!live[k]) continue;
-		const uint32_t d = docs[k];
-		if (op == 3) {
-			atomicOr(&p.not_mask[d >> 5], 1u << (d & 31));
-			continue;
-		}
-		bool rel = t.all_pos_boost;
-		float mb = t.field_boost[0];
-		if (need_entries) {   // maxFieldsBoost (phrasemergerimpl.h:127-160) / relevance of the occurrence
-			mb = 0.0f;
-			rel = false;
-			for (uint32_t e = s.ent_off[i0 + k], e1 = s.ent_off[i0 + k + 1]; e < e1; ++e) {
-				const float fb = t.field_boost[s.ent_field[e]];
-				mb = fmaxf(mb, fb);
-				rel = rel || fb != 0.0f;
-			}
-			if (t.same_boost) mb = t.field_boost[0];
-			if (t.all_pos_boost) rel = true;
-		}
-		if (op == 2 && rel) atomicOr(&p.and_masks[uint64_t(t.and_idx) * p.nwords + (d >> 5)], 1u << (d & 31));
-		if (want_score && mb > 0.0f) {
-			const float proc = s.proc * mb * t.opts_boost;
-			uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
-			p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
-			const uint32_t key = ord_key | p16;
-			if (level == 0) {
-				best[d] = key;
-			} else if (level == 1) {
-				if (!(cur[k] & kBestPresent)) best[d] = key;
-			} else if (cur[k] < key) {
-				atomicMax(&best[d], key);
-			}
-		}
-	}
-}
-
-// restrictingMask_ &= termMask for every AND term, minus the NOT terms (buildRestrictingBitmask); popcount for the 2-phase gate
-__global__ __launch_bounds__(256) void ft_combine(FtPlan p) {
-	__shared__ uint32_t s_part[4];
-	uint32_t c = 0;
-	for (uint64_t w = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; w < p.nwords; w += uint64_t(gridDim.x) * blockDim.x) {
-		uint32_t m = p.mask[w];
-		for (uint32_t a = 0; a < p.n_and; ++a) m &= p.and_masks[uint64_t(a) * p.nwords + w];
-		if (p.not_mask) m &= ~p.not_mask[w];
-		p.mask[w] = m;
-		c += __popc(m);
-	}
-	c = wave_sum(c);
-	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
-	__syncthreads();
-	if (threadIdx.x == 0) {   // one atomic per workgroup: thousands of them on one word cost more than the whole pass
-		const uint32_t tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-		if (tot) atomicAdd(&p.sync[kFtSyncPop], tot);
-	}
-}
-
-// ---------------------------------------------------------------------------------------------- preselect
 __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerimpl.h:486-490, the half only the device knows
 	return p.prescore && __hip_atomic_load(&p.sync[kFtSyncPop], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > p.merge_limit;
 }
 
-// docsScore[d] = saturating sum over the terms of the first sub-term's proc16; masked-out / removed documents score 0 (mergerimpl.h:416-423);
-// histogram of the rest.  Four documents per thread (16-byte loads, every term's load in flight before the first use: the pass is
-// latency-bound otherwise).  Scores take few distinct values, so the counts are aggregated per workgroup in a small LDS hash table
-// (lanes insert independently; a leader-per-value loop over the wave cost 25 us more) and only then added to the global histogram.
-__global__ __launch_bounds__(256) void ft_score(FtPlan p) {
-	if (!ft_preselect_on(p)) return;
-	__shared__ uint32_t keys[256];
-	__shared__ uint32_t cnts[256];
-	keys[threadIdx.x] = 0;   // a score of 0 is never inserted
-	cnts[threadIdx.x] = 0;
-	__syncthreads();
-	const uint64_t quads = (p.total_docs + 3) / 4;
-	for (uint64_t q = uint64_t(blockIdx.x) * 256 + threadIdx.x; q < quads; q += uint64_t(gridDim.x) * 256) {
-		const uint64_t d0 = q * 4;
-		uint32_t sc[4] = {0, 0, 0, 0};
-		{
-			constexpr uint32_t kChunk = 4;
-			for (uint32_t t0 = 0; t0 < p.n_best; t0 += kChunk) {
-				uint4 key[kChunk];
-#pragma unroll
-				for (uint32_t j = 0; j < kChunk; ++j) {   // unconditional loads (a clamped row for j past the last term): all four in flight at once
-					const uint32_t tt = t0 + j < p.n_best ? t0 + j : p.n_best - 1;
-					key[j] = *reinterpret_cast<const uint4*>(p.best + uint64_t(tt) * p.best_stride + d0);
-				}
-#pragma unroll
-				for (uint32_t j = 0; j < kChunk; ++j) {
-					const uint32_t on = t0 + j < p.n_best ? kBestPresent : 0u;
-					sc[0] += (key[j].x & on) ? (key[j].x & 0xFFFFu) : 0u;
-					sc[1] += (key[j].y & on) ? (key[j].y & 0xFFFFu) : 0u;
-					sc[2] += (key[j].z & on) ? (key[j].z & 0xFFFFu) : 0u;
-					sc[3] += (key[j].w & on) ? (key[j].w & 0xFFFFu) : 0u;
-				}
-			}
-			const uint32_t mw = p.mask[d0 >> 5];
-			uint32_t rm = 0;
-			if (p.removed) rm = *reinterpret_cast<const uint32_t*>(p.removed + d0);   // 4 flags; the array is padded to a multiple of 4
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				sc[k] = sc[k] < 65535u ? sc[k] : 65535u;
-				const bool in = d0 + k < p.total_docs && ((mw >> ((d0 + k) & 31)) & 1u) && !((rm >> (8 * k)) & 0xFFu);
-				if (!in) sc[k] = 0;
-			}
-			if (d0 + 3 < p.total_docs) {
-				*reinterpret_cast<uint2*>(p.score + d0) = make_uint2(sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16));
+// One workgroup per range of kFtRangeDocs documents; everything below lives in LDS until the range's mask words / scores are written.
+//   restrictingMask_ = ~docsExcluded_ (mergerimpl.h:328-330; bits past total_docs stay 0 so that the popcount is exact)
+//   AND term   calcTermBitmask (:252-274): any occurrence with a relevant field (checkFieldsRelevance, phrasemergerimpl.h:93-125); mask &= it
+//   NOT term   excludeTermFromBitmask (:276-287)
+//   pre-score  calcTermScores (:289-324) for every term that is not a NOT, when the host half of the 2-phase gate held: the first sub-term
+//              (SortSubterms order) with a positive field boost adds min(proc16, 65535 / 4), saturating at 65535; then (:416-423) documents
+//              outside the mask / removed score 0 and the rest is histogrammed
+__global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
+	constexpr uint32_t kWords = kFtRangeDocs / 32;
+	__shared__ uint32_t s_mask[kWords], s_term[kWords], s_seen[kWords];
+	__shared__ uint16_t s_score[kFtRangeDocs];
+	__shared__ uint32_t s_keys[256], s_cnts[256], s_part[4];
+	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	const uint64_t d_begin = uint64_t(range) * kFtRangeDocs;
+	const uint32_t docs_here = uint32_t(p.total_docs - d_begin < kFtRangeDocs ? p.total_docs - d_begin : kFtRangeDocs);
+	for (uint32_t w = tid; w < kWords; w += 256) {
+		const uint32_t d0 = w * 32;
+		uint32_t bits = 0;
+		if (d0 < docs_here) {
+			const uint32_t cnt = docs_here - d0 < 32 ? docs_here - d0 : 32;
+			if (!p.excluded) {
+				bits = cnt == 32 ? 0xFFFFFFFFu : ((1u << cnt) - 1u);
 			} else {
-				for (int k = 0; k < 4 && d0 + k < p.total_docs; ++k) p.score[d0 + k] = uint16_t(sc[k]);
+				for (uint32_t b = 0; b < cnt; ++b) bits |= (p.excluded[d_begin + d0 + b] ? 0u : 1u) << b;
 			}
 		}
+		s_mask[w] = bits;
+	}
+	if (p.prescore) {
+		for (uint32_t i = tid; i < kFtRangeDocs; i += 256) s_score[i] = 0;
+		s_keys[tid] = 0;   // a score of 0 is never inserted
+		s_cnts[tid] = 0;
+	}
+	__syncthreads();
+	for (uint32_t t = 0; t < (p.simple ? 0u : p.nterms); ++t) {
+		const FtTermCfg& term = p.terms[t];
+		const int op = term.op;
+		const bool want_score = p.prescore && op != 3;
+		if (op == 1 && !want_score) continue;   // an OR term only matters to the pre-score
+		for (uint32_t w = tid; w < kWords; w += 256) {
+			s_term[w] = 0;
+			s_seen[w] = 0;
+		}
+		__syncthreads();
+		const bool need_entries = (op == 2 && !term.all_pos_boost) || (want_score && !term.same_boost);
+		for (uint32_t si = term.sub_begin; si < term.sub_end; ++si) {
+			const FtPosSubterm& s = p.subs[si];
+			const uint32_t lo = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
+			const uint32_t hi = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+			for (uint32_t i = lo + tid; i < hi; i += 256) {
+				const uint32_t local = uint32_t(s.doc[i] - d_begin);
+				const uint32_t bit = 1u << (local & 31);
+				if (op == 3) {
+					atomicAnd(&s_mask[local >> 5], ~bit);
+					continue;
+				}
+				bool rel = term.all_pos_boost;
+				float mb = term.field_boost[0];
+				if (need_entries) {   // maxFieldsBoost (phrasemergerimpl.h:127-160) / relevance of the occurrence
+					mb = 0.0f;
+					rel = false;
+					for (uint32_t e = s.ent_off[i], e1 = s.ent_off[i + 1]; e < e1; ++e) {
+						const float fb = term.field_boost[s.ent_field[e]];
+						mb = fmaxf(mb, fb);
+						rel = rel || fb != 0.0f;
+					}
+					if (term.same_boost) mb = term.field_boost[0];
+					if (term.all_pos_boost) rel = true;
+				}
+				if (op == 2 && rel) atomicOr(&s_term[local >> 5], bit);
+				if (want_score && mb > 0.0f) {
+					// termMask: documents are unique inside a sub-term and earlier sub-terms are behind a barrier, so the first one wins
+					const uint32_t old = atomicOr(&s_seen[local >> 5], bit);
+					if (!(old & bit)) {
+						const float proc = s.proc * mb * term.opts_boost;
+						uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
+						p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
+						const uint32_t cur = s_score[local];
+						p16 = p16 < 65535u - cur ? p16 : 65535u - cur;
+						s_score[local] = uint16_t(cur + p16);
+					}
+				}
+			}
+			__syncthreads();   // the next sub-term of the term sees this one's documents
+		}
+		if (op == 2) {   // restrictingMask_ &= termMask (an AND term without postings empties the range)
+			for (uint32_t w = tid; w < kWords; w += 256) s_mask[w] &= s_term[w];
+			__syncthreads();
+		}
+	}
+	// ---- the range's mask words + their popcount (the device half of the 2-phase gate)
+	uint32_t c = 0;
+	for (uint32_t w = tid; w < kWords; w += 256) {
+		const uint64_t gw = d_begin / 32 + w;
+		if (gw < p.nwords) {
+			p.mask[gw] = s_mask[w];
+			c += __popc(s_mask[w]);
+		}
+	}
+	c = wave_sum(c);
+	if ((tid & 63) == 0) s_part[tid >> 6] = c;
+	__syncthreads();
+	if (tid == 0) {
+		const uint32_t tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+		if (tot) atomicAdd(&p.sync[kFtSyncPop], tot);
+	}
+	if (!p.prescore) return;
+	// ---- scores: masked-out / removed documents score 0 (mergerimpl.h:416-423); histogram of the rest through a small LDS hash table
+	for (uint32_t q = tid; q < kFtRangeDocs / 4; q += 256) {
+		const uint32_t l0 = q * 4;
+		if (l0 >= docs_here) break;
+		const uint32_t mw = s_mask[l0 >> 5];
+		uint32_t rm = 0;
+		if (p.removed) rm = *reinterpret_cast<const uint32_t*>(p.removed + d_begin + l0);   // 4 flags; reads past the end stay inside the allocation
+		uint32_t sc[4];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {   // every lane files its own score: one LDS read + one LDS add once the value owns a slot
+		for (int k = 0; k < 4; ++k) {
+			const bool in = l0 + k < docs_here && ((mw >> ((l0 + k) & 31)) & 1u) && !((rm >> (8 * k)) & 0xFFu);
+			sc[k] = in ? uint32_t(s_score[l0 + k]) : 0u;
+		}
+		*reinterpret_cast<uint2*>(p.score + d_begin + l0) = make_uint2(sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16));   // the array is padded to whole mask words
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
 			const uint32_t v = sc[k];
 			if (!v) continue;
 			uint32_t h = (v * 2654435761u) >> 24;
 			int probes = 0;
 			for (; probes < 256; ++probes, h = (h + 1) & 255u) {
-				uint32_t cur = keys[h];
+				uint32_t cur = s_keys[h];
 				if (cur != v) {
 					if (cur != 0u) continue;
-					cur = atomicCAS(&keys[h], 0u, v);
+					cur = atomicCAS(&s_keys[h], 0u, v);
 					if (cur != 0u && cur != v) continue;
 				}
-				atomicAdd(&cnts[h], 1u);
+				atomicAdd(&s_cnts[h], 1u);
 				break;
 			}
-			if (probes == 256) atomicAdd(&p.hist[v], 1u);   // more than 256 distinct scores in one workgroup
+			if (probes == 256) atomicAdd(&p.hist[v], 1u);   // more than 256 distinct scores in one range
 		}
 	}
 	__syncthreads();
-	if (keys[threadIdx.x]) atomicAdd(&p.hist[keys[threadIdx.x]], cnts[threadIdx.x]);
+	if (s_keys[tid]) atomicAdd(&p.hist[s_keys[tid]], s_cnts[tid]);
 }
 
 // mergerimpl.h:433-446: walk the scores downwards until maxMergedDocs documents are covered.  A score sc is visited iff the documents
@@ -744,21 +719,11 @@ __global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
 
 // ---------------------------------------------------------------------------------------------- launch train
 void launch_ft_merge(const FtPlan& p, hipStream_t st) {
-	const uint32_t doc_blocks = uint32_t(std::min<uint64_t>(((p.total_docs + 3) / 4 + 255) / 256, 2048));
-	hipLaunchKernelGGL(ft_init, dim3(2048), dim3(256), 0, st, p);
-	if (!p.simple) {
-		for (uint32_t level = 0; level < 3; ++level) {
-			const uint32_t blocks = p.scan_level_base[level + 1] - p.scan_level_base[level];
-			if (blocks) hipLaunchKernelGGL(ft_scan, dim3(blocks), dim3(256), 0, st, p, level);
-		}
-		if (p.n_and || p.not_mask || p.prescore) {
-			hipLaunchKernelGGL(ft_combine, dim3(uint32_t(std::min<uint64_t>((p.nwords + 255) / 256, 128))), dim3(256), 0, st, p);
-		}
-		if (p.prescore) {
-			hipLaunchKernelGGL(ft_score, dim3(doc_blocks), dim3(256), 0, st, p);
-			hipLaunchKernelGGL(ft_preselect_pick, dim3(1), dim3(1024), 0, st, p);
-			hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
-		}
+	hipLaunchKernelGGL(ft_init, dim3(1024), dim3(256), 0, st, p);
+	hipLaunchKernelGGL(ft_ranges, dim3(uint32_t((p.total_docs + kFtRangeDocs - 1) / kFtRangeDocs)), dim3(256), 0, st, p);
+	if (!p.simple && p.prescore) {
+		hipLaunchKernelGGL(ft_preselect_pick, dim3(1), dim3(1024), 0, st, p);
+		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
 	}
 	if (p.merge_blocks) {
 		hipLaunchKernelGGL(ft_rank_all, dim3(p.merge_blocks), dim3(256), 0, st, p);

@@ -37,10 +37,12 @@ struct rxgpu_ft_word {
 	uint32_t* ent_tf = nullptr;
 	uint32_t* ent_first_pos = nullptr;
 	uint32_t* pos_off = nullptr;   // only for words uploaded with their positions (multi-term merge)
+	uint32_t* range_off = nullptr; // [n_ranges]: first posting with doc >= k * kFtRangeDocs (ft_ranges finds its segment of the list here)
+	uint32_t n_ranges = 0;
 	uint64_t* fpos = nullptr;
 	void release() {
 		for (void* p : {static_cast<void*>(doc), static_cast<void*>(ent_off), static_cast<void*>(ent_field), static_cast<void*>(ent_tf),
-						static_cast<void*>(ent_first_pos), static_cast<void*>(pos_off), static_cast<void*>(fpos)}) {
+						static_cast<void*>(ent_first_pos), static_cast<void*>(pos_off), static_cast<void*>(fpos), static_cast<void*>(range_off)}) {
 			if (p) (void)hipFree(p);
 		}
 		*this = rxgpu_ft_word{};
@@ -189,6 +191,23 @@ int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uin
 	if (int rc = upload(w.ent_field, ent_field, nent); rc) return rc;
 	if (int rc = upload(w.ent_tf, ent_tf, nent); rc) return rc;
 	if (int rc = upload(w.ent_first_pos, ent_first_pos, nent); rc) return rc;
+	{   // range index over the (ascending) document ids: range k starts at the first posting with doc >= k * kFtRangeDocs; the last entry is n
+		RX_CHECK(n < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_set_word: posting list too long");
+		const uint32_t n_ranges = uint32_t(doc[n - 1] / rxgpu::kFtRangeDocs) + 2;
+		std::vector<uint32_t> ro(n_ranges);
+		uint64_t i = 0;
+		for (uint32_t k = 0; k < n_ranges; ++k) {
+			const uint64_t first_doc = uint64_t(k) * rxgpu::kFtRangeDocs;
+			while (i < n && doc[i] < first_doc) {
+				RX_CHECK(i == 0 || doc[i] > doc[i - 1], RXGPU_ERR_PARAMS, "rxgpu_ft_set_word: document ids must ascend strictly");
+				++i;
+			}
+			ro[k] = uint32_t(i);
+		}
+		for (; i < n; ++i) RX_CHECK(i == 0 || doc[i] > doc[i - 1], RXGPU_ERR_PARAMS, "rxgpu_ft_set_word: document ids must ascend strictly");
+		if (int rc = upload(w.range_off, ro.data(), ro.size()); rc) return rc;
+		w.n_ranges = n_ranges;
+	}
 	w.n = n;
 	w.nent = nent;
 	return RXGPU_OK;
@@ -238,11 +257,9 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	// ---- the plan: sub-terms, per-term configuration, the two posting-side grids
 	std::vector<rxgpu::FtPosSubterm> subs;
 	std::vector<rxgpu::FtTermCfg> tcfg(nterms);
-	std::vector<rxgpu::FtGridEntry> merge_grid, scan_grid;
-	std::vector<uint32_t> scan_subs;
+	std::vector<rxgpu::FtGridEntry> merge_grid;
 	std::vector<uint64_t> term_postings(nterms, 0);
-	uint64_t total_vids = 0, merged_postings = 0, merge_blocks = 0, scan_blocks = 0;
-	uint32_t n_and = 0, n_best = 0, n_not = 0;
+	uint64_t total_vids = 0, merged_postings = 0, merge_blocks = 0;
 	uint16_t qp = 0;
 	// 2-phase gate, host half (estimateNumDocsInMerge, merger.h:239-267; mergerimpl.h:486-490)
 	uint64_t est_or = 0, est_and = UINT64_MAX;
@@ -291,15 +308,10 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		tc.opts_boost = qt.opts->boost;
 		tc.term_len_boost_in = qt.opts->term_len_boost;
 		tc.op = qt.op;
-		tc.and_idx = qt.op == 2 ? n_and++ : 0;
-		tc.best_idx = qt.op != 3 ? n_best++ : 0;
 		tc.same_boost = same ? 1 : 0;
 		tc.all_pos_boost = all_pos ? 1 : 0;
-		if (qt.op == 3) {
-			++n_not;
-		} else {
-			++qp;
-		}
+		tc.sub_begin = uint32_t(subs.size());
+		if (qt.op != 3) ++qp;
 		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
 			const rxgpu_ft_word& w = h->words.find(word_ids[si])->second;
 			RX_CHECK(simple || w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
@@ -321,6 +333,8 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 			ft.qp = qt.op == 3 ? 0 : qp;
 			ft.ord_in_term = uint16_t(si - qt.sub_begin);
 			ft.row = 0;
+			ft.range_off = w.range_off;
+			ft.n_ranges = w.n_ranges;
 			const uint32_t blocks = rxgpu::ft_pass_blocks(w.n);
 			const uint32_t sub_index = uint32_t(subs.size());
 			if (qt.op != 3) {
@@ -329,24 +343,11 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 				merge_blocks += blocks;
 				merged_postings += w.n;
 			}
-			if (!simple && (qt.op != 1 || prescore)) scan_subs.push_back(sub_index);
 			subs.push_back(ft);
 		}
+		tc.sub_end = uint32_t(subs.size());
 	}
-	// the scan grid ordered by level: first sub-terms of their terms, second sub-terms, all further ones (ft_scan resolves "the first sub-term
-	// containing the document wins" by launch order instead of atomics)
-	uint32_t scan_level_base[4] = {0, 0, 0, 0};
-	for (uint32_t level = 0; level < 3; ++level) {
-		scan_level_base[level] = uint32_t(scan_blocks);
-		for (uint32_t si : scan_subs) {
-			const uint32_t lv = std::min<uint32_t>(subs[si].ord_in_term, 2);
-			if (lv != level) continue;
-			scan_grid.push_back({uint32_t(scan_blocks), si});
-			scan_blocks += rxgpu::ft_pass_blocks(subs[si].n);
-		}
-	}
-	scan_level_base[3] = uint32_t(scan_blocks);
-	RX_CHECK(merge_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull && scan_blocks < 0x7FFFFFFFull, RXGPU_ERR_PARAMS,
+	RX_CHECK(merge_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull, RXGPU_ERR_PARAMS,
 			 std::string(who) + ": more than 2^32 (padded) postings in one merge");
 	const uint32_t n_rows = uint32_t(merge_grid.size());
 	const uint64_t nwords = (N + 31) / 32;
@@ -358,15 +359,10 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t o_plan_subs = cv.take(std::max<size_t>(1, subs.size()) * sizeof(rxgpu::FtPosSubterm));
 	const size_t o_plan_terms = cv.take(size_t(nterms) * sizeof(rxgpu::FtTermCfg));
 	const size_t o_plan_mgrid = cv.take(std::max<size_t>(1, merge_grid.size()) * sizeof(rxgpu::FtGridEntry));
-	const size_t o_plan_sgrid = cv.take(std::max<size_t>(1, scan_grid.size()) * sizeof(rxgpu::FtGridEntry));
 	const size_t cfg_floats = size_t(6) * nf + size_t(nterms) * nf;
 	const size_t o_plan_fc = cv.take(cfg_floats * sizeof(float) + size_t(nterms) * nf);
 	const size_t plan_bytes = cv.off;   // everything above is uploaded in one copy
 	const size_t o_mask = cv.take(nwords * 4);
-	const size_t o_and = cv.take(size_t(n_and) * nwords * 4);
-	const size_t o_not = cv.take(n_not ? nwords * 4 : 0);
-	const uint64_t best_stride = (N + 3) & ~uint64_t(3);
-	const size_t o_best = cv.take(prescore ? size_t(n_best) * best_stride * 4 : 0);
 	const size_t o_score = cv.take(prescore ? nwords * 32 * 2 : 0);   // padded to whole mask words (ft_preselect_apply reads 32 scores at a time)
 	const size_t o_hist = cv.take(prescore ? 65536 * 4 : 0);
 	const size_t o_lb_pre = cv.take(prescore ? ((nwords + 1023) / 1024) * 8 : 0);
@@ -421,7 +417,6 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	if (!subs.empty()) std::memcpy(hp + o_plan_subs, subs.data(), subs.size() * sizeof(rxgpu::FtPosSubterm));
 	std::memcpy(hp + o_plan_terms, tcfg.data(), tcfg.size() * sizeof(rxgpu::FtTermCfg));
 	if (!merge_grid.empty()) std::memcpy(hp + o_plan_mgrid, merge_grid.data(), merge_grid.size() * sizeof(rxgpu::FtGridEntry));
-	if (!scan_grid.empty()) std::memcpy(hp + o_plan_sgrid, scan_grid.data(), scan_grid.size() * sizeof(rxgpu::FtGridEntry));
 
 	hipStream_t st = h->stream;
 	RX_HIP(hipMemcpyAsync(base, hp, plan_bytes, hipMemcpyHostToDevice, st));
@@ -431,16 +426,9 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.subs = reinterpret_cast<const rxgpu::FtPosSubterm*>(base + o_plan_subs);
 	p.terms = reinterpret_cast<const rxgpu::FtTermCfg*>(base + o_plan_terms);
 	p.merge_grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_plan_mgrid);
-	p.scan_grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_plan_sgrid);
 	p.n_merge_entries = uint32_t(merge_grid.size());
-	p.n_scan_entries = uint32_t(scan_grid.size());
 	p.merge_blocks = uint32_t(merge_blocks);
-	p.scan_blocks = uint32_t(scan_blocks);
-	for (int i = 0; i < 4; ++i) p.scan_level_base[i] = scan_level_base[i];
-	p.best_stride = best_stride;
 	p.nterms = nterms;
-	p.n_and = n_and;
-	p.n_best = prescore ? n_best : 0;
 	p.n_rows = n_rows;
 	p.total_docs = N;
 	p.nwords = nwords;
@@ -454,9 +442,6 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.removed = h->d_removed;
 	p.excluded = excluded ? reinterpret_cast<const uint8_t*>(base + o_excl) : nullptr;
 	p.mask = reinterpret_cast<uint32_t*>(base + o_mask);
-	p.and_masks = n_and ? reinterpret_cast<uint32_t*>(base + o_and) : nullptr;
-	p.not_mask = n_not ? reinterpret_cast<uint32_t*>(base + o_not) : nullptr;
-	p.best = prescore ? reinterpret_cast<uint32_t*>(base + o_best) : nullptr;
 	p.score = prescore ? reinterpret_cast<uint16_t*>(base + o_score) : nullptr;
 	p.hist = prescore ? reinterpret_cast<uint32_t*>(base + o_hist) : nullptr;
 	p.lookback_pre = prescore ? reinterpret_cast<unsigned long long*>(base + o_lb_pre) : nullptr;

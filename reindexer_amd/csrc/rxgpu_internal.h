@@ -91,6 +91,8 @@ struct FtPosSubterm {
 	uint16_t qp;               // 1-based index among the terms that are not NOT (mergeTerm's qpIdx); 0 for a NOT term
 	uint16_t ord_in_term;      // position inside its term (SortSubterms order)
 	uint32_t row;              // row of the per-slot entry table = index among the merged (non-NOT, non-empty) sub-terms
+	const uint32_t* range_off; // [n_ranges + 1]: first posting with doc >= k * kFtRangeDocs (built when the word is uploaded)
+	uint32_t n_ranges;
 };
 struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslOpts of ONE query term
 	uint32_t num_fields;
@@ -103,8 +105,7 @@ struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslO
 	const uint8_t* need_sum_rank;
 	const float *bm25_boost, *bm25_weight, *term_len_boost, *term_len_weight, *position_boost, *position_weight;
 	int32_t op;                // 1 OR, 2 AND, 3 NOT
-	uint32_t and_idx;          // AND terms: which of the per-term bit arrays
-	uint32_t best_idx;         // terms that are not NOT: which of the per-term pre-score arrays
+	uint32_t sub_begin, sub_end; // the term's (non-empty) sub-terms in FtPlan::subs, in SortSubterms order
 	uint8_t same_boost;        // every field has the same boost (calcTermScores' shortcut)
 	uint8_t all_pos_boost;     // every field has a non-zero boost (calcTermBitmask's shortcut)
 };
@@ -113,6 +114,7 @@ struct FtGridEntry {           // block range of one sub-term in a posting-side 
 	uint32_t sub;              // index into FtPlan::subs
 };
 constexpr int kFtPassItems = 4;            // postings per thread in the posting-side kernels
+constexpr uint32_t kFtRangeDocs = 8192;    // documents per workgroup of the document-range kernel (ft_ranges); multiple of 32
 constexpr int kFtBlockPostings = 256 * kFtPassItems;
 inline uint32_t ft_pass_blocks(uint64_t n) { return uint32_t((n + kFtBlockPostings - 1) / kFtBlockPostings); }
 
@@ -121,10 +123,8 @@ struct FtPlan {
 	const FtPosSubterm* subs;
 	const FtTermCfg* terms;
 	const FtGridEntry* merge_grid;   // merged sub-terms in (term, sub-term) order
-	const FtGridEntry* scan_grid;    // sub-terms the bitmask / pre-score scan walks
-	uint32_t n_merge_entries, n_scan_entries, merge_blocks, scan_blocks;
-	uint32_t scan_level_base[4];     // scan_grid is ordered by level (first / second / further sub-terms of their term): block ranges
-	uint32_t nterms, n_and, n_best, n_rows;
+	uint32_t n_merge_entries, merge_blocks;
+	uint32_t nterms, n_rows;
 	uint64_t total_docs, nwords;
 	uint32_t max_merged, merge_limit;
 	uint8_t simple;            // Merger::mergeSimple (one term): max over sub-terms, first maximum wins; no positions
@@ -134,10 +134,6 @@ struct FtPlan {
 	const uint8_t* removed;
 	const uint8_t* excluded;
 	uint32_t* mask;            // restrictingMask_ [nwords]
-	uint32_t* and_masks;       // [n_and][nwords]
-	uint32_t* not_mask;        // [nwords]
-	uint32_t* best;            // [n_best][best_stride]: presence bit | (4095 - sub-term ordinal) << 16 | proc16
-	uint64_t best_stride;      // total_docs rounded up to 4 (16-byte loads)
 	uint16_t* score;           // [total_docs]
 	uint32_t* hist;            // [65536]
 	uint32_t* first;           // [total_docs]: smallest global posting index with a non-zero rank (the posting that adds the document)

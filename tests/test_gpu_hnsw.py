@@ -315,3 +315,54 @@ def test_multithread_map_build_and_search(rxgpu, oracle, metric):
         hits += len(truth & set(m.search_knn(q, k, 128)[1].tolist()))
     assert hits / (40 * k) >= 0.85, hits / (40 * k)
     m.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_interleaved_upserts_patch_the_device_graph_in_place(rxgpu, oracle, metric):
+    """Insert / delete / re-insert (slot reuse, updatePoint) interleaved with searches: after the first full attach the Map mirrors every
+    change through rxgpu_hnsw_patch_graph (only the touched nodes travel); each search must equal the restated engine on the host graph
+    as it is at that moment — new elements, recycled slots with new vectors and labels, rewritten neighbour lists, upper levels."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    from reindexer_amd import hostapi
+    n0, d, k = 1500, 48, 10
+    rng = np.random.default_rng(3 + metric)
+    rows = make_corpus(71, n0 + 400, d)
+    labels = (np.arange(n0 + 400, dtype=np.uint64) << np.uint64(32)) | np.uint64(1)
+    m = hostapi.GpuHnswMap(metric, d, n0 + 200, M=8, ef_construction=60)
+    m.add(rows[:n0], labels[:n0])
+    live = list(range(n0))
+    nxt = n0
+
+    def check(tag):
+        g = m.export_graph(with_views=True)
+        vec = np.array(g["vectors"])
+        inv = np.array(g["inv_norms"]) if g["inv_norms"] is not None else None
+        g = dict(g, vectors=vec)
+        for qi in range(6):
+            q = make_corpus(500 + qi, 1, d)[0]
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            wd, wl = oracle_hnsw_search_knn(oracle, g, q, k, 64, inv)
+            gd, gl = m.search_knn(q, k, 64)
+            assert np.array_equal(gl, wl), (tag, qi)
+            assert np.array_equal(bits(gd), bits(wd)), (tag, qi)
+
+    check("attach")
+    for step in range(40):
+        op = step % 4
+        if op in (0, 1):     # plain insert (appended, or into a vacated slot if one exists)
+            m.add(rows[nxt:nxt + 1], labels[nxt:nxt + 1])
+            live.append(nxt)
+            nxt += 1
+        elif op == 2:        # delete two
+            for _ in range(2):
+                victim = live.pop(int(rng.integers(0, len(live))))
+                m.mark_delete(labels[victim])
+        else:                # a burst: several inserts before the next search (one of them recycles a slot)
+            for _ in range(3):
+                m.add(rows[nxt:nxt + 1], labels[nxt:nxt + 1])
+                live.append(nxt)
+                nxt += 1
+        check(step)
+    assert m.count <= n0 + 200
+    m.close()
