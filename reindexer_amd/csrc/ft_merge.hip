@@ -232,12 +232,12 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 			const FtPosSubterm& s = p.subs[si];
 			const uint32_t lo = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
 			const uint32_t hi = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
-			for (uint32_t i = lo + tid; i < hi; i += 256) {
-				const uint32_t local = uint32_t(s.doc[i] - d_begin);
+			auto visit = [&](uint32_t i, uint32_t d) {
+				const uint32_t local = uint32_t(d - d_begin);
 				const uint32_t bit = 1u << (local & 31);
 				if (op == 3) {
 					atomicAnd(&s_mask[local >> 5], ~bit);
-					continue;
+					return;
 				}
 				bool rel = term.all_pos_boost;
 				float mb = term.field_boost[0];
@@ -264,6 +264,18 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 						p16 = p16 < 65535u - cur ? p16 : 65535u - cur;
 						s_score[local] = uint16_t(cur + p16);
 					}
+				}
+			};
+			for (uint32_t base = lo; base < hi; base += 4 * 256) {   // four independent document loads in flight per thread
+				uint32_t idx[4], dd[4];
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					idx[j] = base + uint32_t(j) * 256 + tid;
+					dd[j] = idx[j] < hi ? s.doc[idx[j]] : 0u;
+				}
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					if (idx[j] < hi) visit(idx[j], dd[j]);
 				}
 			}
 			__syncthreads();   // the next sub-term of the term sees this one's documents
@@ -449,49 +461,81 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
 
 // ---------------------------------------------------------------------------------------------- mergeTerm / mergeSimple
 // calcTermRank of every eligible posting of the query (restrictingMask_, DocRemoved) and the first-posting table.
-// The gathers of one posting form a dependent chain (doc -> mask word -> removed flag -> entries -> words in field); the four postings
-// of a thread are independent, so each stage is issued for all four before anything is consumed.
+// The gathers of one posting form a dependent chain (doc -> mask word -> removed flag -> entries -> words in field).  A workgroup takes
+// kFtRankGroups consecutive 1024-posting tiles (4 postings per thread each), every stage issued for all sixteen postings of the thread
+// before anything is consumed.  After a preselect ~1 % of the postings survive the mask, yet nearly every wavefront holds one and pays the
+// rank chain: fewer, fatter workgroups keep the whole grid resident so that the chain is paid once, not per round of workgroups.
+constexpr int kFtRankGroups = 4;
 __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
-	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
-	const FtPosSubterm& s = p.subs[ge.sub];
-	const FtTermCfg& t = p.terms[s.term];
-	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	const uint64_t gp0 = uint64_t(blockIdx.x) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	uint32_t docs[kFtPassItems];
-	bool live[kFtPassItems];
-	if (i0 < s.n) {
-		load_docs(s, i0, docs, live);
-	} else {
+	uint32_t sub_of[kFtRankGroups];
+	uint64_t i0[kFtRankGroups], gp0[kFtRankGroups];
+	uint32_t docs[kFtRankGroups][kFtPassItems];
+	bool live[kFtRankGroups][kFtPassItems];
+	bool tile_on[kFtRankGroups];
 #pragma unroll
-		for (int k = 0; k < kFtPassItems; ++k) live[k] = false;
+	for (int g = 0; g < kFtRankGroups; ++g) {
+		const uint32_t tile = blockIdx.x * kFtRankGroups + g;
+		tile_on[g] = tile < p.merge_blocks;
+		sub_of[g] = 0;
+		i0[g] = gp0[g] = 0;
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) {
+			live[g][k] = false;
+			docs[g][k] = 0;
+		}
+		if (!tile_on[g]) continue;
+		const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, tile);
+		sub_of[g] = ge.sub;
+		i0[g] = uint64_t(tile - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+		gp0[g] = uint64_t(tile) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+		const FtPosSubterm& s = p.subs[ge.sub];
+		if (i0[g] < s.n) load_docs(s, i0[g], docs[g], live[g]);
 	}
 	{
-		uint32_t mw[kFtPassItems];
+		uint32_t mw[kFtRankGroups][kFtPassItems];
 #pragma unroll
-		for (int k = 0; k < kFtPassItems; ++k) mw[k] = live[k] ? p.mask[docs[k] >> 5] : 0u;
+		for (int g = 0; g < kFtRankGroups; ++g) {
 #pragma unroll
-		for (int k = 0; k < kFtPassItems; ++k) live[k] = live[k] && ((mw[k] >> (docs[k] & 31)) & 1u);   // restrictingMask_
+			for (int k = 0; k < kFtPassItems; ++k) mw[g][k] = live[g][k] ? p.mask[docs[g][k] >> 5] : 0u;
+		}
+#pragma unroll
+		for (int g = 0; g < kFtRankGroups; ++g) {
+#pragma unroll
+			for (int k = 0; k < kFtPassItems; ++k) live[g][k] = live[g][k] && ((mw[g][k] >> (docs[g][k] & 31)) & 1u);   // restrictingMask_
+		}
 	}
 	if (p.removed && p.check_removed && !ft_preselect_on(p)) {   // needToCheckRemoved_ is false once the preselect has run (mergerimpl.h:463)
-		uint8_t rm[kFtPassItems];
+		uint8_t rm[kFtRankGroups][kFtPassItems];
 #pragma unroll
-		for (int k = 0; k < kFtPassItems; ++k) rm[k] = live[k] ? p.removed[docs[k]] : uint8_t(0);
+		for (int g = 0; g < kFtRankGroups; ++g) {
 #pragma unroll
-		for (int k = 0; k < kFtPassItems; ++k) live[k] = live[k] && !rm[k];
+			for (int k = 0; k < kFtPassItems; ++k) rm[g][k] = live[g][k] ? p.removed[docs[g][k]] : uint8_t(0);
+		}
+#pragma unroll
+		for (int g = 0; g < kFtRankGroups; ++g) {
+#pragma unroll
+			for (int k = 0; k < kFtPassItems; ++k) live[g][k] = live[g][k] && !rm[g][k];
+		}
 	}
-	float ranks[kFtPassItems];
-	uint8_t fields[kFtPassItems];
 #pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) {
-		ranks[k] = 0.f;
-		fields[k] = 0;
-		if (!live[k]) continue;
-		const uint64_t i = i0 + k;
-		ranks[k] = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], docs[k], &fields[k]);
-		if (ranks[k] != 0.0f) atomicMin(&p.first[docs[k]], uint32_t(gp0 + k));
+	for (int g = 0; g < kFtRankGroups; ++g) {
+		if (!tile_on[g]) continue;
+		const FtPosSubterm& s = p.subs[sub_of[g]];
+		const FtTermCfg& t = p.terms[s.term];
+		float ranks[kFtPassItems];
+		uint8_t fields[kFtPassItems];
+#pragma unroll
+		for (int k = 0; k < kFtPassItems; ++k) {
+			ranks[k] = 0.f;
+			fields[k] = 0;
+			if (!live[g][k]) continue;
+			const uint64_t i = i0[g] + k;
+			ranks[k] = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], docs[g][k], &fields[k]);
+			if (ranks[k] != 0.0f) atomicMin(&p.first[docs[g][k]], uint32_t(gp0[g] + k));
+		}
+		*reinterpret_cast<float4*>(p.p_rank + gp0[g]) = make_float4(ranks[0], ranks[1], ranks[2], ranks[3]);
+		*reinterpret_cast<uchar4*>(p.p_field + gp0[g]) = make_uchar4(fields[0], fields[1], fields[2], fields[3]);
 	}
-	*reinterpret_cast<float4*>(p.p_rank + gp0) = make_float4(ranks[0], ranks[1], ranks[2], ranks[3]);
-	*reinterpret_cast<uchar4*>(p.p_field + gp0) = make_uchar4(fields[0], fields[1], fields[2], fields[3]);
 }
 
 // addDoc order (merger.h:161-180): the postings that add a document take consecutive merge slots in global posting order, cut at
@@ -726,7 +770,7 @@ void launch_ft_merge(const FtPlan& p, hipStream_t st) {
 		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
 	}
 	if (p.merge_blocks) {
-		hipLaunchKernelGGL(ft_rank_all, dim3(p.merge_blocks), dim3(256), 0, st, p);
+		hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankGroups - 1) / kFtRankGroups), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_count_adders, dim3(p.merge_blocks), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_assign_slots, dim3(p.merge_blocks), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_scatter, dim3(p.merge_blocks), dim3(256), 0, st, p);

@@ -1,6 +1,9 @@
 // C-ABI of the BM25 merge (include/rxgpu.h, rxgpu_ft_*): device mirror of the ft_fast posting lists + the scoring launch.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <cstdint>
 #include <mutex>
@@ -78,6 +81,7 @@ struct rxgpu_ft_index {
 	}
 	uint64_t stat_postings = 0;
 	double stat_ms = 0.0;
+	double trace_us[6] = {0, 0, 0, 0, 0, 0};   // RXGPU_FT_TRACE: plan build, staging + upload, launches, wait + download, unpack, merges
 };
 
 namespace {
@@ -248,6 +252,9 @@ struct Carver {
 int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
 			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who) {
+	using clk = std::chrono::steady_clock;
+	const auto t_begin = clk::now();
+	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
 	const uint32_t nf = h->num_fields;
 	const uint64_t N = h->total_docs;
 	const uint32_t nterms = uint32_t(terms.size());
@@ -354,6 +361,8 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t M = size_t(max_merged);
 	const uint64_t padded = merge_blocks * rxgpu::kFtBlockPostings;
 
+	h->trace_us[0] += since(t_begin);
+	const auto t_stage = clk::now();
 	// ---- device scratch (one buffer each for the state and for the packed result)
 	Carver cv;
 	const size_t o_plan_subs = cv.take(std::max<size_t>(1, subs.size()) * sizeof(rxgpu::FtPosSubterm));
@@ -461,6 +470,8 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.out_terms_counter = reinterpret_cast<uint16_t*>(ob + align256(16) + 2 * align256(M * 4));
 	p.out_field = reinterpret_cast<uint8_t*>(ob + align256(16) + 2 * align256(M * 4) + align256(M * 2));
 
+	h->trace_us[1] += since(t_stage);
+	const auto t_launch = clk::now();
 	if (!h->ev_a) {
 		RX_HIP(hipEventCreate(&h->ev_a));
 		RX_HIP(hipEventCreate(&h->ev_b));
@@ -469,8 +480,12 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	rxgpu::launch_ft_merge(p, st);
 	RX_HIP(hipEventRecord(h->ev_b, st));
 	RX_HIP(hipGetLastError());
+	h->trace_us[2] += since(t_launch);
+	const auto t_wait = clk::now();
 	RX_HIP(hipMemcpyAsync(hp, ob, out_need, hipMemcpyDeviceToHost, st));   // header + the four result arrays in one copy
 	RX_HIP(hipStreamSynchronize(st));
+	h->trace_us[3] += since(t_wait);
+	const auto t_unpack = clk::now();
 	float ms = 0.f;
 	(void)hipEventElapsedTime(&ms, h->ev_a, h->ev_b);
 	h->stat_postings += merged_postings;
@@ -487,6 +502,8 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	}
 	*out_n = n;
 	if (out_preselected) *out_preselected = hdr[2] ? 1 : 0;
+	h->trace_us[4] += since(t_unpack);
+	h->trace_us[5] += 1;
 	return RXGPU_OK;
 }
 
@@ -568,6 +585,12 @@ int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms
 	std::lock_guard<std::mutex> lk(h->mtx);
 	*postings = h->stat_postings;
 	*kernel_ms = h->stat_ms;
+	if (const char* e = std::getenv("RXGPU_FT_TRACE"); e && e[0] == '1' && h->trace_us[5] > 0) {
+		const double m = h->trace_us[5];
+		std::fprintf(stderr, "[rxgpu ft trace] per merge (us): plan %.1f  stage+upload %.1f  launches %.1f  wait+download %.1f  unpack %.1f  (kernels %.1f)\n",
+					 h->trace_us[0] / m, h->trace_us[1] / m, h->trace_us[2] / m, h->trace_us[3] / m, h->trace_us[4] / m, h->stat_ms * 1e3 / m);
+		for (double& v : h->trace_us) v = 0;
+	}
 	h->stat_postings = 0;
 	h->stat_ms = 0.0;
 	return RXGPU_OK;

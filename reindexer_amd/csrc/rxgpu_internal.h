@@ -114,7 +114,7 @@ struct FtGridEntry {           // block range of one sub-term in a posting-side 
 	uint32_t sub;              // index into FtPlan::subs
 };
 constexpr int kFtPassItems = 4;            // postings per thread in the posting-side kernels
-constexpr uint32_t kFtRangeDocs = 8192;    // documents per workgroup of the document-range kernel (ft_ranges); multiple of 32
+constexpr uint32_t kFtRangeDocs = 4096;    // documents per workgroup of the document-range kernel (ft_ranges); multiple of 32
 constexpr int kFtBlockPostings = 256 * kFtPassItems;
 inline uint32_t ft_pass_blocks(uint64_t n) { return uint32_t((n + kFtBlockPostings - 1) / kFtBlockPostings); }
 
