@@ -211,7 +211,7 @@ typedef struct rxgpu_ft_index rxgpu_ft_index; /* device mirror of one ft_fast Da
 typedef struct rxgpu_ft_config {
 	double bm25_k1, bm25_b;                    /* Bm25Config: 2.0, 0.75 */
 	double summation_ranks_by_fields_ratio;    /* 0.0 */
-	double full_match_boost;                   /* 1.1 (applied by the host merger, carried here for completeness) */
+	double full_match_boost;                   /* 1.1; addFullMatchBoost (merger.h:100-109) is applied on the device (the word counts are resident) */
 	int32_t min_rank;                          /* 5   (host) */
 	uint32_t merge_limit;                      /* 20000 */
 	uint32_t num_fields;
@@ -240,8 +240,8 @@ int rxgpu_ft_set_docs(rxgpu_ft_index* h, uint64_t total_docs, const float* words
 int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uint32_t* doc, const uint32_t* ent_off, const uint8_t* ent_field,
 					  const uint32_t* ent_tf, const uint32_t* ent_first_pos);
 /* Device half of Merger::mergeSimple for a Simple() query: nsub sub-terms (word_ids[], procs[], caller-sorted by proc desc like
- * SortSubterms), docsExcluded bitmap or NULL.  Writes the admitted documents IN MERGE ORDER with their raw rank and field
- * (before addFullMatchBoost / postProcessResults, merger.h:100-155, which the host merger applies to these <= merge_limit rows). */
+ * SortSubterms), docsExcluded bitmap or NULL.  Writes the admitted documents IN MERGE ORDER with their rank (addFullMatchBoost applied,
+ * merger.h:100-109) and field — before postProcessResults (merger.h:111-155), which the host merger applies to these <= merge_limit rows. */
 int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
 							  const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc,
 							  uint8_t* out_field, uint64_t cap, uint64_t* out_n);
@@ -254,8 +254,8 @@ int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n,
  * buildRestrictingBitmask (:326-384), the 2-phase gate + preselectMostRelevantDocs (:386-464, 486-490) and mergeTerm (:107-192) for
  * every term that is not a NOT.  ops[t]: OpType 1 OR / 2 AND / 3 NOT (core/type_consts.h); opts[t]: the term's FtDslOpts; the
  * sub-terms of term t are word_ids/procs[sub_off[t] .. sub_off[t+1]) sorted by proc descending (SortSubterms).
- * Writes the merged documents IN MERGE ORDER with raw proc, field and MergerDocumentData::termsCounter (merger.h:24) — the host
- * merger derives canBeBoostedByFullMatch (:527-531) from it and applies addFullMatchBoost / postProcessResults (merger.h:100-155).
+ * Writes the merged documents IN MERGE ORDER with proc (addFullMatchBoost applied: canBeBoostedByFullMatch :527-531, merger.h:100-109),
+ * field and MergerDocumentData::termsCounter (merger.h:24); the host merger applies postProcessResults (merger.h:111-155).
  * *out_preselected = 1 if the preselect phase ran.  cap >= min(merge_limit, total postings). */
 int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
 							 const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc,

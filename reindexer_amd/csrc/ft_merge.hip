@@ -190,11 +190,13 @@ __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerim
 //   pre-score  calcTermScores (:289-324) for every term that is not a NOT, when the host half of the 2-phase gate held: the first sub-term
 //              (SortSubterms order) with a positive field boost adds min(proc16, 65535 / 4), saturating at 65535; then (:416-423) documents
 //              outside the mask / removed score 0 and the rest is histogrammed
+constexpr uint32_t kFtRangeSubs = 512;   // segments staged in LDS (queries with more sub-terms read the range index from HBM)
 __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 	constexpr uint32_t kWords = kFtRangeDocs / 32;
 	__shared__ uint32_t s_mask[kWords], s_term[kWords], s_seen[kWords];
 	__shared__ uint16_t s_score[kFtRangeDocs];
 	__shared__ uint32_t s_keys[256], s_cnts[256], s_part[4];
+	__shared__ uint32_t s_lo[kFtRangeSubs], s_hi[kFtRangeSubs];
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
 	const uint64_t d_begin = uint64_t(range) * kFtRangeDocs;
 	const uint32_t docs_here = uint32_t(p.total_docs - d_begin < kFtRangeDocs ? p.total_docs - d_begin : kFtRangeDocs);
@@ -216,6 +218,13 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 		s_keys[tid] = 0;   // a score of 0 is never inserted
 		s_cnts[tid] = 0;
 	}
+	// this range's segment [lo, hi) of every posting list, fetched up front (two dependent loads each, all in flight together)
+	const uint32_t n_subs = p.simple ? 0u : p.n_subs;
+	for (uint32_t si = tid; si < n_subs && si < kFtRangeSubs; si += 256) {
+		const FtPosSubterm& s = p.subs[si];
+		s_lo[si] = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
+		s_hi[si] = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+	}
 	__syncthreads();
 	for (uint32_t t = 0; t < (p.simple ? 0u : p.nterms); ++t) {
 		const FtTermCfg& term = p.terms[t];
@@ -228,57 +237,92 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 		}
 		__syncthreads();
 		const bool need_entries = (op == 2 && !term.all_pos_boost) || (want_score && !term.same_boost);
-		for (uint32_t si = term.sub_begin; si < term.sub_end; ++si) {
-			const FtPosSubterm& s = p.subs[si];
-			const uint32_t lo = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
-			const uint32_t hi = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
-			auto visit = [&](uint32_t i, uint32_t d) {
-				const uint32_t local = uint32_t(d - d_begin);
-				const uint32_t bit = 1u << (local & 31);
-				if (op == 3) {
-					atomicAnd(&s_mask[local >> 5], ~bit);
-					return;
+		auto visit = [&](const FtPosSubterm& s, uint32_t i, uint32_t d) {
+			const uint32_t local = uint32_t(d - d_begin);
+			const uint32_t bit = 1u << (local & 31);
+			if (op == 3) {
+				atomicAnd(&s_mask[local >> 5], ~bit);
+				return;
+			}
+			bool rel = term.all_pos_boost;
+			float mb = term.field_boost[0];
+			if (need_entries) {   // maxFieldsBoost (phrasemergerimpl.h:127-160) / relevance of the occurrence
+				mb = 0.0f;
+				rel = false;
+				for (uint32_t e = s.ent_off[i], e1 = s.ent_off[i + 1]; e < e1; ++e) {
+					const float fb = term.field_boost[s.ent_field[e]];
+					mb = fmaxf(mb, fb);
+					rel = rel || fb != 0.0f;
 				}
-				bool rel = term.all_pos_boost;
-				float mb = term.field_boost[0];
-				if (need_entries) {   // maxFieldsBoost (phrasemergerimpl.h:127-160) / relevance of the occurrence
-					mb = 0.0f;
-					rel = false;
-					for (uint32_t e = s.ent_off[i], e1 = s.ent_off[i + 1]; e < e1; ++e) {
-						const float fb = term.field_boost[s.ent_field[e]];
-						mb = fmaxf(mb, fb);
-						rel = rel || fb != 0.0f;
-					}
-					if (term.same_boost) mb = term.field_boost[0];
-					if (term.all_pos_boost) rel = true;
-				}
-				if (op == 2 && rel) atomicOr(&s_term[local >> 5], bit);
-				if (want_score && mb > 0.0f) {
-					// termMask: documents are unique inside a sub-term and earlier sub-terms are behind a barrier, so the first one wins
-					const uint32_t old = atomicOr(&s_seen[local >> 5], bit);
-					if (!(old & bit)) {
-						const float proc = s.proc * mb * term.opts_boost;
-						uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
-						p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
-						const uint32_t cur = s_score[local];
-						p16 = p16 < 65535u - cur ? p16 : 65535u - cur;
-						s_score[local] = uint16_t(cur + p16);
-					}
-				}
-			};
-			for (uint32_t base = lo; base < hi; base += 4 * 256) {   // four independent document loads in flight per thread
-				uint32_t idx[4], dd[4];
-#pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					idx[j] = base + uint32_t(j) * 256 + tid;
-					dd[j] = idx[j] < hi ? s.doc[idx[j]] : 0u;
-				}
-#pragma unroll
-				for (int j = 0; j < 4; ++j) {
-					if (idx[j] < hi) visit(idx[j], dd[j]);
+				if (term.same_boost) mb = term.field_boost[0];
+				if (term.all_pos_boost) rel = true;
+			}
+			if (op == 2 && rel) atomicOr(&s_term[local >> 5], bit);
+			if (want_score && mb > 0.0f) {
+				// termMask: documents are unique inside a sub-term and earlier sub-terms are behind a barrier, so the first one wins
+				const uint32_t old = atomicOr(&s_seen[local >> 5], bit);
+				if (!(old & bit)) {
+					const float proc = s.proc * mb * term.opts_boost;
+					uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
+					p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
+					const uint32_t cur = s_score[local];
+					p16 = p16 < 65535u - cur ? p16 : 65535u - cur;
+					s_score[local] = uint16_t(cur + p16);
 				}
 			}
-			__syncthreads();   // the next sub-term of the term sees this one's documents
+		};
+		// Sub-terms go in SortSubterms order behind barriers ("the first one holding the document wins"), but their document ids do not depend
+		// on each other: the first 1024 postings of up to four sub-terms are fetched together — one load latency per group, not per sub-term.
+		constexpr int kGroup = 4;
+		for (uint32_t g0 = term.sub_begin; g0 < term.sub_end; g0 += kGroup) {
+			uint32_t lo[kGroup], hi[kGroup], dd[kGroup][4];
+#pragma unroll
+			for (int j = 0; j < kGroup; ++j) {
+				const uint32_t si = g0 + j;
+				lo[j] = hi[j] = 0;
+				if (si < term.sub_end) {
+					if (si < kFtRangeSubs) {
+						lo[j] = s_lo[si];
+						hi[j] = s_hi[si];
+					} else {
+						const FtPosSubterm& s = p.subs[si];
+						lo[j] = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
+						hi[j] = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+					}
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < kGroup; ++j) {
+				const uint32_t* doc = g0 + j < term.sub_end ? p.subs[g0 + j].doc : nullptr;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const uint32_t idx = lo[j] + uint32_t(q) * 256 + tid;
+					dd[j][q] = idx < hi[j] ? doc[idx] : 0u;
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < kGroup; ++j) {
+				if (g0 + j >= term.sub_end) break;   // uniform
+				const FtPosSubterm& s = p.subs[g0 + j];
+#pragma unroll
+				for (int q = 0; q < 4; ++q) {
+					const uint32_t idx = lo[j] + uint32_t(q) * 256 + tid;
+					if (idx < hi[j]) visit(s, idx, dd[j][q]);
+				}
+				for (uint32_t base = lo[j] + 4 * 256; base < hi[j]; base += 4 * 256) {   // the rest of a long segment
+					uint32_t idx[4], d4[4];
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						idx[q] = base + uint32_t(q) * 256 + tid;
+						d4[q] = idx[q] < hi[j] ? s.doc[idx[q]] : 0u;
+					}
+#pragma unroll
+					for (int q = 0; q < 4; ++q) {
+						if (idx[q] < hi[j]) visit(s, idx[q], d4[q]);
+					}
+				}
+				__syncthreads();   // the next sub-term of the term sees this one's documents
+			}
 		}
 		if (op == 2) {   // restrictingMask_ &= termMask (an AND term without postings empties the range)
 			for (uint32_t w = tid; w < kWords; w += 256) s_mask[w] &= s_term[w];
@@ -461,80 +505,101 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
 
 // ---------------------------------------------------------------------------------------------- mergeTerm / mergeSimple
 // calcTermRank of every eligible posting of the query (restrictingMask_, DocRemoved) and the first-posting table.
-// The gathers of one posting form a dependent chain (doc -> mask word -> removed flag -> entries -> words in field).  A workgroup takes
-// kFtRankGroups consecutive 1024-posting tiles (4 postings per thread each), every stage issued for all sixteen postings of the thread
-// before anything is consumed.  After a preselect ~1 % of the postings survive the mask, yet nearly every wavefront holds one and pays the
-// rank chain: fewer, fatter workgroups keep the whole grid resident so that the chain is paid once, not per round of workgroups.
-constexpr int kFtRankGroups = 4;
+// The gathers of one posting form a dependent chain (doc -> mask word -> removed flag | entries -> words in field).  The cheap half
+// (document, mask bit, removed flag) is streamed for kFtRankTiles x 1024 postings per workgroup, four postings per thread and tile with
+// every stage issued for all of them before anything is consumed; the survivors are COMPACTED in LDS and the expensive half
+// (calcTermRank, five dependent gathers) then runs once over the compact list, one posting per lane.  After a preselect ~1 % of the
+// postings survive: evaluated in place, nearly every wavefront held one and paid the chain up to four times in a row (once per
+// item slot) — 38 us for 3.9 M postings; a first attempt with fatter threads made that 64 us.
+constexpr int kFtRankTiles = 2;
 __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
-	uint32_t sub_of[kFtRankGroups];
-	uint64_t i0[kFtRankGroups], gp0[kFtRankGroups];
-	uint32_t docs[kFtRankGroups][kFtPassItems];
-	bool live[kFtRankGroups][kFtPassItems];
-	bool tile_on[kFtRankGroups];
+	__shared__ uint32_t s_cnt;
+	__shared__ uint16_t s_item[kFtRankTiles * kFtBlockPostings];   // tile << 10 | thread << 2 | slot
+	__shared__ uint32_t s_doc[kFtRankTiles * kFtBlockPostings];
+	__shared__ uint32_t s_sub[kFtRankTiles], s_base[kFtRankTiles];
+	if (threadIdx.x == 0) s_cnt = 0;
+	if (threadIdx.x < kFtRankTiles) {
+		const uint32_t tile = blockIdx.x * kFtRankTiles + threadIdx.x;
+		if (tile < p.merge_blocks) {
+			const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, tile);
+			s_sub[threadIdx.x] = ge.sub;
+			s_base[threadIdx.x] = ge.block_base;
+		}
+	}
+	__syncthreads();
+	uint32_t docs[kFtRankTiles][kFtPassItems];
+	bool live[kFtRankTiles][kFtPassItems];
 #pragma unroll
-	for (int g = 0; g < kFtRankGroups; ++g) {
-		const uint32_t tile = blockIdx.x * kFtRankGroups + g;
-		tile_on[g] = tile < p.merge_blocks;
-		sub_of[g] = 0;
-		i0[g] = gp0[g] = 0;
+	for (int g = 0; g < kFtRankTiles; ++g) {
+		const uint32_t tile = blockIdx.x * kFtRankTiles + g;
 #pragma unroll
 		for (int k = 0; k < kFtPassItems; ++k) {
 			live[g][k] = false;
 			docs[g][k] = 0;
 		}
-		if (!tile_on[g]) continue;
-		const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, tile);
-		sub_of[g] = ge.sub;
-		i0[g] = uint64_t(tile - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-		gp0[g] = uint64_t(tile) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-		const FtPosSubterm& s = p.subs[ge.sub];
-		if (i0[g] < s.n) load_docs(s, i0[g], docs[g], live[g]);
+		if (tile >= p.merge_blocks) continue;
+		const FtPosSubterm& s = p.subs[s_sub[g]];
+		const uint64_t i0 = uint64_t(tile - s_base[g]) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+		if (i0 < s.n) load_docs(s, i0, docs[g], live[g]);
 	}
 	{
-		uint32_t mw[kFtRankGroups][kFtPassItems];
+		uint32_t mw[kFtRankTiles][kFtPassItems];
 #pragma unroll
-		for (int g = 0; g < kFtRankGroups; ++g) {
+		for (int g = 0; g < kFtRankTiles; ++g) {
 #pragma unroll
 			for (int k = 0; k < kFtPassItems; ++k) mw[g][k] = live[g][k] ? p.mask[docs[g][k] >> 5] : 0u;
 		}
 #pragma unroll
-		for (int g = 0; g < kFtRankGroups; ++g) {
+		for (int g = 0; g < kFtRankTiles; ++g) {
 #pragma unroll
 			for (int k = 0; k < kFtPassItems; ++k) live[g][k] = live[g][k] && ((mw[g][k] >> (docs[g][k] & 31)) & 1u);   // restrictingMask_
 		}
 	}
 	if (p.removed && p.check_removed && !ft_preselect_on(p)) {   // needToCheckRemoved_ is false once the preselect has run (mergerimpl.h:463)
-		uint8_t rm[kFtRankGroups][kFtPassItems];
+		uint8_t rm[kFtRankTiles][kFtPassItems];
 #pragma unroll
-		for (int g = 0; g < kFtRankGroups; ++g) {
+		for (int g = 0; g < kFtRankTiles; ++g) {
 #pragma unroll
 			for (int k = 0; k < kFtPassItems; ++k) rm[g][k] = live[g][k] ? p.removed[docs[g][k]] : uint8_t(0);
 		}
 #pragma unroll
-		for (int g = 0; g < kFtRankGroups; ++g) {
+		for (int g = 0; g < kFtRankTiles; ++g) {
 #pragma unroll
 			for (int k = 0; k < kFtPassItems; ++k) live[g][k] = live[g][k] && !rm[g][k];
 		}
 	}
 #pragma unroll
-	for (int g = 0; g < kFtRankGroups; ++g) {
-		if (!tile_on[g]) continue;
-		const FtPosSubterm& s = p.subs[sub_of[g]];
-		const FtTermCfg& t = p.terms[s.term];
-		float ranks[kFtPassItems];
-		uint8_t fields[kFtPassItems];
+	for (int g = 0; g < kFtRankTiles; ++g) {
+		const uint32_t tile = blockIdx.x * kFtRankTiles + g;
+		if (tile >= p.merge_blocks) continue;
+		const uint64_t gp0 = uint64_t(tile) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
+		*reinterpret_cast<float4*>(p.p_rank + gp0) = make_float4(0.f, 0.f, 0.f, 0.f);   // rank 0 = not eligible; survivors overwrite theirs below
+		*reinterpret_cast<uchar4*>(p.p_field + gp0) = make_uchar4(0, 0, 0, 0);
 #pragma unroll
 		for (int k = 0; k < kFtPassItems; ++k) {
-			ranks[k] = 0.f;
-			fields[k] = 0;
 			if (!live[g][k]) continue;
-			const uint64_t i = i0[g] + k;
-			ranks[k] = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], docs[g][k], &fields[k]);
-			if (ranks[k] != 0.0f) atomicMin(&p.first[docs[g][k]], uint32_t(gp0[g] + k));
+			const uint32_t at = atomicAdd(&s_cnt, 1u);
+			s_item[at] = uint16_t((uint32_t(g) << 10) | (threadIdx.x << 2) | uint32_t(k));
+			s_doc[at] = docs[g][k];
 		}
-		*reinterpret_cast<float4*>(p.p_rank + gp0[g]) = make_float4(ranks[0], ranks[1], ranks[2], ranks[3]);
-		*reinterpret_cast<uchar4*>(p.p_field + gp0[g]) = make_uchar4(fields[0], fields[1], fields[2], fields[3]);
+	}
+	__syncthreads();   // also orders the zero fill above before the survivors' stores below (same workgroup)
+	const uint32_t cnt = s_cnt;
+	for (uint32_t e = threadIdx.x; e < cnt; e += 256) {
+		const uint32_t item = s_item[e], g = item >> 10, local = item & 1023u;
+		const uint32_t tile = blockIdx.x * kFtRankTiles + g;
+		const FtPosSubterm& s = p.subs[s_sub[g]];
+		const FtTermCfg& t = p.terms[s.term];
+		const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
+		const uint64_t gp = uint64_t(tile) * kFtBlockPostings + local;
+		const uint32_t d = s_doc[e];
+		uint8_t field = 0;
+		const float rank = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d, &field);
+		if (rank != 0.0f) {
+			p.p_rank[gp] = rank;
+			p.p_field[gp] = field;
+			atomicMin(&p.first[d], uint32_t(gp));
+		}
 	}
 }
 
@@ -756,6 +821,15 @@ __global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
 			rank = final_rank;
 		}
 	}
+	// addFullMatchBoost (merger.h:100-109): a document whose best field holds exactly as many words as the query has parts — and, for a
+	// multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts
+	// are resident: on the host it was one cache miss per merged document.
+	{
+		const FtTermCfg& t0 = p.terms[0];
+		const float words = t0.words[size_t(p.out_doc[sl]) * t0.num_fields + field];
+		const bool full = p.simple ? words == 1.0f : (terms_counter == p.nterms && words == float(p.nterms));
+		if (full) proc = float(double(proc) * p.full_match_boost);
+	}
 	p.out_proc[sl] = proc;
 	p.out_field[sl] = field;
 	p.out_terms_counter[sl] = terms_counter;
@@ -770,7 +844,7 @@ void launch_ft_merge(const FtPlan& p, hipStream_t st) {
 		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
 	}
 	if (p.merge_blocks) {
-		hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankGroups - 1) / kFtRankGroups), dim3(256), 0, st, p);
+		hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankTiles - 1) / kFtRankTiles), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_count_adders, dim3(p.merge_blocks), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_assign_slots, dim3(p.merge_blocks), dim3(256), 0, st, p);
 		hipLaunchKernelGGL(ft_scatter, dim3(p.merge_blocks), dim3(256), 0, st, p);

@@ -439,6 +439,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.merge_blocks = uint32_t(merge_blocks);
 	p.nterms = nterms;
 	p.n_rows = n_rows;
+	p.n_subs = uint32_t(subs.size());
 	p.total_docs = N;
 	p.nwords = nwords;
 	p.max_merged = uint32_t(max_merged);
@@ -448,6 +449,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.check_removed = 1;
 	p.distance_weight = float(cfg->distance_weight);
 	p.distance_boost = float(cfg->distance_boost);
+	p.full_match_boost = cfg->full_match_boost;
 	p.removed = h->d_removed;
 	p.excluded = excluded ? reinterpret_cast<const uint8_t*>(base + o_excl) : nullptr;
 	p.mask = reinterpret_cast<uint32_t*>(base + o_mask);

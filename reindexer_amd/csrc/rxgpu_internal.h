@@ -114,7 +114,7 @@ struct FtGridEntry {           // block range of one sub-term in a posting-side 
 	uint32_t sub;              // index into FtPlan::subs
 };
 constexpr int kFtPassItems = 4;            // postings per thread in the posting-side kernels
-constexpr uint32_t kFtRangeDocs = 4096;    // documents per workgroup of the document-range kernel (ft_ranges); multiple of 32
+constexpr uint32_t kFtRangeDocs = 8192;    // documents per workgroup of the document-range kernel (ft_ranges); multiple of 32
 constexpr int kFtBlockPostings = 256 * kFtPassItems;
 inline uint32_t ft_pass_blocks(uint64_t n) { return uint32_t((n + kFtBlockPostings - 1) / kFtBlockPostings); }
 
@@ -124,13 +124,14 @@ struct FtPlan {
 	const FtTermCfg* terms;
 	const FtGridEntry* merge_grid;   // merged sub-terms in (term, sub-term) order
 	uint32_t n_merge_entries, merge_blocks;
-	uint32_t nterms, n_rows;
+	uint32_t nterms, n_rows, n_subs;
 	uint64_t total_docs, nwords;
 	uint32_t max_merged, merge_limit;
 	uint8_t simple;            // Merger::mergeSimple (one term): max over sub-terms, first maximum wins; no positions
 	uint8_t prescore;          // the host-side half of the 2-phase gate held: pre-scores are collected, the device decides on popcount
 	uint8_t check_removed;
 	float distance_weight, distance_boost;
+	double full_match_boost;   // FTConfig::fullMatchBoost, applied by ft_replay (addFullMatchBoost)
 	const uint8_t* removed;
 	const uint8_t* excluded;
 	uint32_t* mask;            // restrictingMask_ [nwords]

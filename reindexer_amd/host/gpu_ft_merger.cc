@@ -171,10 +171,7 @@ MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std
 		out[i].proc = proc[i];
 		out[i].field = field[i];
 	}
-	// addFullMatchBoost(numTerms = 1) — merger.h:100-109 (mergeDataExtended_ is empty for Simple() queries)
-	for (MergeInfo& md : out) {
-		if (words_[size_t(md.id) * numFields_ + md.field] == float(size_t(1))) md.proc = float(double(md.proc) * cfg.fullMatchBoost);
-	}
+	// addFullMatchBoost(numTerms = 1) — merger.h:100-109 — was applied on the device (ft_replay)
 	postProcess(cfg, out, rankSortType);
 	return out;
 }
@@ -287,12 +284,11 @@ MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> te
 	}
 	if (preselected) *preselected = pre != 0;
 	out.resize(n);
-	// canBeBoostedByFullMatch: termsCounter == queryParts.size() (mergerimpl.h:527-531); addFullMatchBoost(QueryLength) (merger.h:100-109)
+	// canBeBoostedByFullMatch / addFullMatchBoost(QueryLength) (mergerimpl.h:527-531, merger.h:100-109) were applied on the device (ft_replay)
 	for (uint64_t i = 0; i < n; ++i) {
 		out[i].id = int32_t(doc[i]);
 		out[i].proc = proc[i];
 		out[i].field = field[i];
-		if (termsCounter[i] == nt && words_[size_t(doc[i]) * numFields_ + field[i]] == float(nt)) out[i].proc = float(double(proc[i]) * cfg.fullMatchBoost);
 	}
 	postProcess(cfg, out, rankSortType);
 	return out;
