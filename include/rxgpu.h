@@ -61,6 +61,20 @@ int rxgpu_device_arch(int device, char* name, size_t cap);
 int rxgpu_index_create(int metric, uint32_t dim, uint64_t capacity, int device, rxgpu_index** out);
 void rxgpu_index_destroy(rxgpu_index* h);
 
+/* The same index row-range SHARDED over several GPUs of this process (BASELINE configs[3]: the Map owns a device list; `devices` may
+ * repeat a device — several shards on one GPU).  Shard s holds the global rows [s * shard_rows, (s + 1) * shard_rows), shard_rows =
+ * ceil(capacity / n_devices) rounded up to 32.  The handle is used like any other with rxgpu_index_upload_rows (no holes: first_row <= count)
+ * / move_row / truncate / count / capacity / device_bytes, rxgpu_search_knn, rxgpu_search_knn_subset, rxgpu_search_range,
+ * rxgpu_search_range_subset and rxgpu_distances: rows in and out are GLOBAL rows, results are the single-device results bit for bit
+ * (per-shard exact lists merged under (dist, global row), i.e. BruteforceSearch's scan order, bruteforce.cc:103-127), every shard's
+ * kernels run concurrently on their own device.  The capacity is fixed (create a new index to grow); device-pointer entry points,
+ * bitmap filters, HNSW and profiling are single-device only and return RXGPU_ERR_LOGIC here. */
+int rxgpu_index_create_sharded(int metric, uint32_t dim, uint64_t capacity, uint32_t n_devices, const int* devices, rxgpu_index** out);
+uint32_t rxgpu_index_shard_count(const rxgpu_index* h);   /* 0 for an unsharded index */
+uint64_t rxgpu_index_shard_rows(const rxgpu_index* h);
+/* One row back to the host (and its 1/|row| for cosine; out_inv_norm may be NULL): the cross-device half of a sharded swap-delete. */
+int rxgpu_index_download_row(rxgpu_index* h, uint64_t row, float* out_row, float* out_inv_norm);
+
 /* BruteforceSearch::ResizeIndex  bruteforce.cc:88-101 (contents preserved; shrinking below count is an error). */
 int rxgpu_index_reserve(rxgpu_index* h, uint64_t capacity);
 

@@ -35,6 +35,10 @@ _SIGNATURES = {
     "rxgpu_device_arch": (_i, [_i, C.c_char_p, C.c_size_t]),
     "rxgpu_index_create": (_i, [_i, _u32, _u64, _i, C.POINTER(_vp)]),
     "rxgpu_index_destroy": (None, [_vp]),
+    "rxgpu_index_create_sharded": (_i, [_i, _u32, _u64, _u32, _vp, C.POINTER(_vp)]),
+    "rxgpu_index_shard_count": (_u32, [_vp]),
+    "rxgpu_index_shard_rows": (_u64, [_vp]),
+    "rxgpu_index_download_row": (_i, [_vp, _u64, _vp, _vp]),
     "rxgpu_index_reserve": (_i, [_vp, _u64]),
     "rxgpu_index_upload_rows": (_i, [_vp, _u64, _u64, _vp, _vp]),
     "rxgpu_index_adopt_device_rows": (_i, [_vp, _vp, _u64, _u32, _vp]),

@@ -742,18 +742,25 @@ __global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
 	const uint64_t* next_ptr = nullptr;
 	uint32_t last_cnt = 0, next_cnt = 0;
 	uint16_t switched_term = 0, last_counted = 0, terms_counter = 0;
-	constexpr uint32_t kRowChunk = 8;   // the document's cells of eight sub-terms are fetched together: the walk below is latency-bound
-	float rank_ahead[kRowChunk];
-	for (uint32_t row = 0; row < p.n_rows; ++row) {
-		const uint64_t cell = uint64_t(row) * p.max_merged + sl;
-		if (row % kRowChunk == 0) {
+	// Most documents meet ONE sub-term, a few two or three, out of many: walking the rows in lock step would make every wavefront pay the
+	// per-row gather chain once per row (19 us for 20 000 documents x 9 rows).  Instead each lane first collects WHICH of its rows are
+	// occupied (coalesced rank loads, 64 rows per mask word) and then walks only those: the wavefront iterates as often as its busiest lane
+	// has entries.  The order inside a lane is still row order = the order mergeTerm met the postings.
+	for (uint32_t row0 = 0; row0 < p.n_rows; row0 += 64) {
+		unsigned long long occupied = 0;
+		const uint32_t rows_here = p.n_rows - row0 < 64 ? p.n_rows - row0 : 64;
+		for (uint32_t j0 = 0; j0 < rows_here; j0 += 8) {
+			float ahead[8];
 #pragma unroll
-			for (uint32_t j = 0; j < kRowChunk; ++j) rank_ahead[j] = row + j < p.n_rows ? p.e_rank[cell + uint64_t(j) * p.max_merged] : 0.0f;
+			for (uint32_t j = 0; j < 8; ++j) ahead[j] = j0 + j < rows_here ? p.e_rank[uint64_t(row0 + j0 + j) * p.max_merged + sl] : 0.0f;
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j) occupied |= (unsigned long long)(ahead[j] != 0.0f) << (j0 + j);
 		}
-		float r = 0.0f;
-#pragma unroll
-		for (uint32_t j = 0; j < kRowChunk; ++j) r = (row % kRowChunk == j) ? rank_ahead[j] : r;
-		if (r == 0.0f) continue;
+	while (occupied) {
+		const uint32_t row = row0 + uint32_t(__ffsll((long long)occupied) - 1);
+		occupied &= occupied - 1;
+		const uint64_t cell = uint64_t(row) * p.max_merged + sl;
+		const float r = p.e_rank[cell];
 		const uint8_t fld = p.e_field[cell];
 		if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
 			if (!created) {
@@ -820,6 +827,7 @@ __global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
 			next_cnt = npos;
 			rank = final_rank;
 		}
+	}
 	}
 	// addFullMatchBoost (merger.h:100-109): a document whose best field holds exactly as many words as the query has parts — and, for a
 	// multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts

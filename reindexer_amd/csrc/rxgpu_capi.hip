@@ -686,6 +686,11 @@ int rxgpu_index_create(int metric, uint32_t dim, uint64_t capacity, int device, 
 
 void rxgpu_index_destroy(rxgpu_index* h) {
 	if (!h) return;
+	if (h->shard_set) {
+		rxgpu::sharded_destroy(h);
+		delete h;
+		return;
+	}
 	DeviceGuard dg(h->device);
 	(void)hipDeviceSynchronize();
 	for (auto* c : h->free_ctx) {
@@ -719,6 +724,11 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 
 int rxgpu_index_reserve(rxgpu_index* h, uint64_t capacity) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		if (capacity == h->capacity) return RXGPU_OK;
+		set_error("rxgpu_index_reserve: the capacity of a sharded index is fixed (create a new one)");
+		return RXGPU_ERR_LOGIC;
+	}
 	RX_CHECK(!h->adopted, RXGPU_ERR_LOGIC, "rxgpu_index_reserve: storage is adopted (caller-owned)");
 	RX_CHECK(capacity >= h->count, RXGPU_ERR_PARAMS, "Cannot resize, max element is less than the current number of elements");
 	RX_CHECK(capacity < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "capacity must fit 32-bit rows");
@@ -751,6 +761,7 @@ int rxgpu_index_reserve(rxgpu_index* h, uint64_t capacity) {
 
 int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, const float* rows, const float* inv_norms) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) return rxgpu::sharded_upload_rows(h, first_row, n, rows, inv_norms);
 	RX_CHECK(!h->adopted, RXGPU_ERR_LOGIC, "rxgpu_index_upload_rows: storage is adopted (caller-owned)");
 	if (n == 0) return RXGPU_OK;
 	RX_CHECK(rows, RXGPU_ERR_PARAMS, "rxgpu_index_upload_rows: rows is null");
@@ -793,6 +804,10 @@ int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, cons
 
 int rxgpu_index_adopt_device_rows(rxgpu_index* h, const void* d_rows, uint64_t n, uint32_t row_stride, const void* d_inv_norms) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_index_adopt_device_rows: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
 	RX_CHECK(d_rows || n == 0, RXGPU_ERR_PARAMS, "rxgpu_index_adopt_device_rows: d_rows is null");
 	RX_CHECK(row_stride >= h->dim && row_stride % 4 == 0, RXGPU_ERR_PARAMS, "row_stride must be >= dim and a multiple of 4 floats");
 	RX_CHECK((reinterpret_cast<uintptr_t>(d_rows) & 15) == 0, RXGPU_ERR_PARAMS, "d_rows must be 16-byte aligned");
@@ -816,6 +831,7 @@ int rxgpu_index_adopt_device_rows(rxgpu_index* h, const void* d_rows, uint64_t n
 
 int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) return rxgpu::sharded_move_row(h, from, to);
 	RX_CHECK(!h->adopted, RXGPU_ERR_LOGIC, "rxgpu_index_move_row: storage is adopted (caller-owned)");
 	RX_CHECK(from < h->count && to < h->count, RXGPU_ERR_PARAMS, "rxgpu_index_move_row: row out of range");
 	if (from == to) return RXGPU_OK;
@@ -833,8 +849,22 @@ int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
 	return RXGPU_OK;
 }
 
+int rxgpu_index_download_row(rxgpu_index* h, uint64_t row, float* out_row, float* out_inv_norm) {
+	RX_CHECK(h && out_row, RXGPU_ERR_PARAMS, "rxgpu_index_download_row: null argument");
+	RX_CHECK(!h->shard_set, RXGPU_ERR_LOGIC, "rxgpu_index_download_row: single-device indexes only");
+	RX_CHECK(row < h->count, RXGPU_ERR_PARAMS, "rxgpu_index_download_row: row out of range");
+	DeviceGuard dg(h->device);
+	RX_HIP(hipMemcpy(out_row, h->d_rows + row * h->stride, h->dim * sizeof(float), hipMemcpyDeviceToHost));
+	if (out_inv_norm) {
+		*out_inv_norm = 1.0f;
+		if (h->d_inv_norms) RX_HIP(hipMemcpy(out_inv_norm, h->d_inv_norms + row, sizeof(float), hipMemcpyDeviceToHost));
+	}
+	return RXGPU_OK;
+}
+
 int rxgpu_index_truncate(rxgpu_index* h, uint64_t count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) return rxgpu::sharded_truncate(h, count);
 	RX_CHECK(count <= h->capacity, RXGPU_ERR_PARAMS, "rxgpu_index_truncate: count exceeds capacity");
 	// shrinking keeps the statistics (upper bounds stay upper bounds) and the shadow (rows past count are never read)
 	if (count > h->count) {
@@ -853,12 +883,17 @@ int rxgpu_index_metric(const rxgpu_index* h) { return h ? h->metric : -1; }
 int rxgpu_index_device(const rxgpu_index* h) { return h ? h->device : -1; }
 uint64_t rxgpu_index_device_bytes(const rxgpu_index* h) {
 	if (!h) return 0;
+	if (h->shard_set) return rxgpu::sharded_device_bytes(h);
 	return h->capacity * h->stride * sizeof(float) + (h->d_inv_norms ? h->capacity * sizeof(float) : 0);
 }
 
 int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, void* d_out_dist, void* d_out_row,
 							void* d_out_count, void* stream) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_search_knn_device: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
 	RX_CHECK(nq > 0 && d_queries && d_out_dist && d_out_row, RXGPU_ERR_PARAMS, "rxgpu_search_knn_device: null argument");
 	RX_CHECK(kk > 0 && kk <= uint32_t(rxgpu::kMaxFusedK), RXGPU_ERR_PARAMS, "rxgpu_search_knn_device: kk must be in [1, 64]");
 	RX_CHECK(h->count > 0, RXGPU_ERR_PARAMS, "rxgpu_search_knn_device: index is empty");
@@ -872,6 +907,11 @@ int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t
 					 uint32_t* out_count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(queries && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_search_knn: null argument");
+	if (h->shard_set) {
+		if (nq == 0) return RXGPU_OK;
+		RX_CHECK(kk >= 1, RXGPU_ERR_PARAMS, "rxgpu_search_knn: kk must be >= 1");
+		return rxgpu::sharded_search_knn_impl(h, queries, nq, kk, nullptr, 0, out_dist, out_row, out_count);
+	}
 	if (nq == 0) return RXGPU_OK;
 	if (h->count == 0 || kk == 0) {   // bruteforce.cc:106-108
 		std::fill(out_count, out_count + nq, 0u);
@@ -954,6 +994,15 @@ int rxgpu_search_knn_subset(rxgpu_index* h, const float* queries, uint32_t nq, u
 							float* out_dist, uint32_t* out_row, uint32_t* out_count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(queries && out_dist && out_row && out_count && (n_ids == 0 || row_ids), RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset: null argument");
+	if (h->shard_set) {
+		if (nq == 0) return RXGPU_OK;
+		RX_CHECK(kk >= 1, RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset: kk must be >= 1");
+		if (n_ids == 0) {
+			std::fill(out_count, out_count + nq, 0u);
+			return RXGPU_OK;
+		}
+		return rxgpu::sharded_search_knn_impl(h, queries, nq, kk, row_ids, n_ids, out_dist, out_row, out_count);
+	}
 	if (nq == 0) return RXGPU_OK;
 	for (uint64_t i = 0; i < n_ids; ++i) {
 		RX_CHECK(row_ids[i] < h->count && (i == 0 || row_ids[i - 1] < row_ids[i]), RXGPU_ERR_PARAMS,
@@ -979,6 +1028,10 @@ int rxgpu_search_knn_subset(rxgpu_index* h, const float* queries, uint32_t nq, u
 int rxgpu_search_knn_bitmap(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* allowed_words, uint64_t n_words,
 							float* out_dist, uint32_t* out_row, uint32_t* out_count, uint64_t* out_allowed) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_search_knn_bitmap: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
 	RX_CHECK(queries && out_dist && out_row && out_count && allowed_words, RXGPU_ERR_PARAMS, "rxgpu_search_knn_bitmap: null argument");
 	const uint64_t need_words = (h->count + 31) / 32;
 	RX_CHECK(n_words >= need_words, RXGPU_ERR_PARAMS, "rxgpu_search_knn_bitmap: the bitmap must cover every row (ceil(count / 32) words)");
@@ -1028,6 +1081,10 @@ int rxgpu_search_knn_bitmap(rxgpu_index* h, const float* queries, uint32_t nq, u
 int rxgpu_search_knn_subset_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, const void* d_row_ids, uint64_t n_ids,
 								   void* d_out_dist, void* d_out_row, void* d_out_count, void* stream) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_search_knn_subset_device: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
 	RX_CHECK(nq > 0 && d_queries && d_row_ids && d_out_dist && d_out_row, RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset_device: null argument");
 	RX_CHECK(kk > 0 && kk <= uint32_t(rxgpu::kMaxFusedK2), RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset_device: kk must be in [1, 128]");
 	RX_CHECK(n_ids > 0 && n_ids <= h->count, RXGPU_ERR_PARAMS, "rxgpu_search_knn_subset_device: the row list must hold 1..count entries");
@@ -1069,6 +1126,10 @@ int rxgpu_search_range(rxgpu_index* h, const float* query, float radius, int inc
 					   uint64_t* out_total) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(query && out_total && (cap == 0 || (out_dist && out_row)), RXGPU_ERR_PARAMS, "rxgpu_search_range: null argument");
+	if (h->shard_set) {
+		*out_total = 0;
+		return rxgpu::sharded_search_range_impl(h, query, radius, inclusive, nullptr, 0, out_dist, out_row, cap, out_total);
+	}
 	*out_total = 0;
 	if (h->count == 0) return RXGPU_OK;   // bruteforce.cc:132-134
 	DeviceGuard dg(h->device);
@@ -1120,6 +1181,11 @@ int rxgpu_search_range_subset(rxgpu_index* h, const float* query, float radius, 
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(query && out_total && (cap == 0 || (out_dist && out_row)) && (n_ids == 0 || row_ids), RXGPU_ERR_PARAMS,
 			 "rxgpu_search_range_subset: null argument");
+	if (h->shard_set) {
+		*out_total = 0;
+		if (n_ids == 0) return RXGPU_OK;
+		return rxgpu::sharded_search_range_impl(h, query, radius, inclusive, row_ids, n_ids, out_dist, out_row, cap, out_total);
+	}
 	*out_total = 0;
 	for (uint64_t i = 0; i < n_ids; ++i) {
 		RX_CHECK(row_ids[i] < h->count && (i == 0 || row_ids[i - 1] < row_ids[i]), RXGPU_ERR_PARAMS,
@@ -1177,6 +1243,7 @@ int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, ui
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(query && (n == 0 || (rows && out_dist)), RXGPU_ERR_PARAMS, "rxgpu_distances: null argument");
 	if (n == 0) return RXGPU_OK;
+	if (h->shard_set) return rxgpu::sharded_distances(h, query, rows, n, out_dist);
 	for (uint32_t i = 0; i < n; ++i) RX_CHECK(rows[i] < h->count, RXGPU_ERR_PARAMS, "rxgpu_distances: row out of range");
 	DeviceGuard dg(h->device);
 	rxgpu_search_ctx* c = acquire_ctx(h);
@@ -1207,6 +1274,10 @@ int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, ui
 int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64_t* upper_off, const uint32_t* upper, uint64_t upper_blocks,
 							const uint8_t* deleted, uint32_t M, uint32_t max_m0, int32_t maxlevel, uint32_t entry, uint64_t num_deleted) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_hnsw_attach_graph: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
 	const uint64_t n = h->count;
 	RX_CHECK(n == 0 || (links0 && upper_off && deleted), RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_graph: null argument");
 	RX_CHECK(upper_blocks == 0 || upper, RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_graph: upper is null");
@@ -1351,6 +1422,10 @@ int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t n
 int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 						  uint32_t* out_count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_hnsw_search_knn: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
 	RX_CHECK(queries && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
 	if (nq == 0) return RXGPU_OK;
 	if (h->count == 0 || k == 0) {   // hnswalg.h:1989-1991
@@ -1630,6 +1705,14 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 
 int rxgpu_profile_enable(rxgpu_index* h, int on) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_profile_enable: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	if (h->shard_set) {
+		set_error("rxgpu_hnsw_stream_begin: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
 	std::lock_guard<std::mutex> lk(h->mtx);
 	for (auto& kv : h->profile) {
 		for (auto& ev : kv.second.events) {

@@ -191,7 +191,23 @@ struct rxgpu_profile_slot {
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 };
 
+struct rxgpu_index;
+namespace rxgpu {
+struct ShardSet;
+void sharded_destroy(struct ::rxgpu_index* h);
+uint64_t sharded_device_bytes(const struct ::rxgpu_index* h);
+int sharded_upload_rows(struct ::rxgpu_index* h, uint64_t first_row, uint64_t n, const float* rows, const float* inv_norms);
+int sharded_truncate(struct ::rxgpu_index* h, uint64_t count);
+int sharded_move_row(struct ::rxgpu_index* h, uint64_t from, uint64_t to);
+int sharded_search_knn_impl(struct ::rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* row_ids, uint64_t n_ids, float* out_dist,
+							uint32_t* out_row, uint32_t* out_count);
+int sharded_search_range_impl(struct ::rxgpu_index* h, const float* query, float radius, int inclusive, const uint32_t* row_ids, uint64_t n_ids,
+							  float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total);
+int sharded_distances(struct ::rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist);
+}  // namespace rxgpu
+
 struct rxgpu_index {
+	rxgpu::ShardSet* shard_set = nullptr;   // non-null: a row-range sharded index (rxgpu_sharded.hip); the fields below describe the whole
 	int metric = 0;
 	uint32_t dim = 0;
 	uint32_t stride = 0;     // floats per row in HBM

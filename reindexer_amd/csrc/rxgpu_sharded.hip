@@ -1,0 +1,383 @@
+// Row-range sharding of one float_vector index over several GPUs of THIS process (BASELINE configs[3] behind the C++ seam: the Map owns a
+// device list).  No device code here: every shard is an ordinary rxgpu_index on its own device, driven by its own worker thread; a search
+// fans the query out, every shard runs the kernels of rxgpu_search_* on its rows, and the per-shard answers (kk x 8 B per query) are merged
+// on the host under the reference's order — (dist, GLOBAL row), global row = shard * shard_rows + local row, which is the scan order of
+// BruteforceSearch::SearchKnn (bruteforce.cc:103-127) because shard s holds the rows [s * shard_rows, (s + 1) * shard_rows).
+// The one-process-per-GPU deployment (torch.distributed / RCCL all-gather of the same per-shard lists) is reindexer_amd/sharded.py.
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rxgpu.h"
+#include "rxgpu_internal.h"
+
+using rxgpu::set_error;
+
+namespace rxgpu {
+
+// One worker thread per shard: the shard's device stays current on it, calls into the single-device entry points are serialised per shard
+// and run concurrently across shards.
+struct ShardWorker {
+	std::thread thread;
+	std::mutex mtx;
+	std::condition_variable cv;
+	std::function<void()> job;
+	bool has_job = false, stop = false, done = false;
+
+	void run() {
+		std::unique_lock<std::mutex> lk(mtx);
+		for (;;) {
+			cv.wait(lk, [&] { return has_job || stop; });
+			if (stop) return;
+			auto fn = std::move(job);
+			lk.unlock();
+			fn();
+			lk.lock();
+			has_job = false;
+			done = true;
+			cv.notify_all();
+		}
+	}
+	void start(std::function<void()> fn) {
+		std::lock_guard<std::mutex> lk(mtx);
+		job = std::move(fn);
+		done = false;
+		has_job = true;
+		cv.notify_all();
+	}
+	void wait() {
+		std::unique_lock<std::mutex> lk(mtx);
+		cv.wait(lk, [&] { return done; });
+	}
+};
+
+struct ShardSet {
+	std::vector<rxgpu_index*> shards;
+	std::vector<ShardWorker*> workers;
+	uint64_t shard_rows = 0;
+	std::mutex call_mtx;   // one fan-out at a time (the Maps coalesce concurrent queries into batches above this layer)
+};
+
+namespace {
+
+// runs fn(s) for every shard concurrently; returns the first non-OK code (the message of that shard is kept)
+int for_each_shard(ShardSet* ss, const std::function<int(size_t)>& fn) {
+	const size_t n = ss->shards.size();
+	std::vector<int> rc(n, RXGPU_OK);
+	std::vector<std::string> err(n);
+	for (size_t s = 0; s < n; ++s) {
+		ss->workers[s]->start([&, s] {
+			rc[s] = fn(s);
+			if (rc[s] != RXGPU_OK) err[s] = rxgpu_last_error();   // thread-local on the worker: carry it over
+		});
+	}
+	for (size_t s = 0; s < n; ++s) ss->workers[s]->wait();
+	for (size_t s = 0; s < n; ++s) {
+		if (rc[s] != RXGPU_OK) {
+			set_error("shard " + std::to_string(s) + ": " + err[s]);
+			return rc[s];
+		}
+	}
+	return RXGPU_OK;
+}
+
+uint64_t local_count(const ShardSet* ss, size_t s, uint64_t count) {
+	const uint64_t lo = uint64_t(s) * ss->shard_rows;
+	return count > lo ? std::min<uint64_t>(count - lo, ss->shard_rows) : 0;
+}
+
+}  // namespace
+
+void sharded_destroy(rxgpu_index* h) {
+	ShardSet* ss = h->shard_set;
+	if (!ss) return;
+	for (ShardWorker* w : ss->workers) {
+		{
+			std::lock_guard<std::mutex> lk(w->mtx);
+			w->stop = true;
+			w->cv.notify_all();
+		}
+		if (w->thread.joinable()) w->thread.join();
+		delete w;
+	}
+	for (rxgpu_index* s : ss->shards) rxgpu_index_destroy(s);
+	delete ss;
+	h->shard_set = nullptr;
+}
+
+uint64_t sharded_device_bytes(const rxgpu_index* h) {
+	uint64_t b = 0;
+	for (const rxgpu_index* s : h->shard_set->shards) b += rxgpu_index_device_bytes(s);
+	return b;
+}
+
+int sharded_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, const float* rows, const float* inv_norms) {
+	ShardSet* ss = h->shard_set;
+	if (n == 0) return RXGPU_OK;
+	if (!rows) {
+		set_error("rxgpu_index_upload_rows: rows is null");
+		return RXGPU_ERR_PARAMS;
+	}
+	if (first_row > h->count || first_row + n > h->capacity) {
+		set_error(first_row > h->count ? "rxgpu_index_upload_rows: a sharded index is filled without holes (first_row <= count)"
+									   : "The number of elements exceeds the specified limit");
+		return RXGPU_ERR_PARAMS;
+	}
+	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	const int rc = for_each_shard(ss, [&](size_t s) -> int {
+		const uint64_t lo = uint64_t(s) * ss->shard_rows, hi = lo + ss->shard_rows;
+		const uint64_t a = std::max(first_row, lo), b = std::min(first_row + n, hi);
+		if (a >= b) return RXGPU_OK;
+		return rxgpu_index_upload_rows(ss->shards[s], a - lo, b - a, rows + (a - first_row) * h->dim, inv_norms ? inv_norms + (a - first_row) : nullptr);
+	});
+	if (rc == RXGPU_OK) h->count = std::max(h->count, first_row + n);
+	return rc;
+}
+
+int sharded_truncate(rxgpu_index* h, uint64_t count) {
+	ShardSet* ss = h->shard_set;
+	if (count > h->count) {
+		set_error("rxgpu_index_truncate: count exceeds the number of rows");
+		return RXGPU_ERR_PARAMS;
+	}
+	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	const int rc = for_each_shard(ss, [&](size_t s) -> int { return rxgpu_index_truncate(ss->shards[s], local_count(ss, s, count)); });
+	if (rc == RXGPU_OK) h->count = count;
+	return rc;
+}
+
+// exact top-kk of every query under (dist, global row): per-shard exact top-kk lists merged on the host
+int sharded_search_knn_impl(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* row_ids, uint64_t n_ids, float* out_dist,
+							uint32_t* out_row, uint32_t* out_count) {
+	ShardSet* ss = h->shard_set;
+	const size_t ns = ss->shards.size();
+	std::vector<std::vector<float>> sd(ns);
+	std::vector<std::vector<uint32_t>> sr(ns), sc(ns);
+	// a row list (pre-filtered search) is split at the shard boundaries; local ids = global - shard base
+	std::vector<std::vector<uint32_t>> local_ids(ns);
+	if (row_ids) {
+		for (uint64_t i = 0; i < n_ids; ++i) {
+			if (i && row_ids[i] <= row_ids[i - 1]) {
+				set_error("rxgpu_search_knn_subset: row ids must be strictly increasing");
+				return RXGPU_ERR_PARAMS;
+			}
+			if (row_ids[i] >= h->count) {
+				set_error("rxgpu_search_knn_subset: row id out of range");
+				return RXGPU_ERR_PARAMS;
+			}
+			const size_t s = size_t(row_ids[i] / ss->shard_rows);
+			local_ids[s].push_back(uint32_t(row_ids[i] - s * ss->shard_rows));
+		}
+	}
+	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	const int rc = for_each_shard(ss, [&](size_t s) -> int {
+		sd[s].assign(size_t(nq) * kk, 0.f);
+		sr[s].assign(size_t(nq) * kk, 0u);
+		sc[s].assign(nq, 0u);
+		if (row_ids) {
+			if (local_ids[s].empty()) return RXGPU_OK;
+			return rxgpu_search_knn_subset(ss->shards[s], queries, nq, kk, local_ids[s].data(), local_ids[s].size(), sd[s].data(), sr[s].data(), sc[s].data());
+		}
+		if (rxgpu_index_count(ss->shards[s]) == 0) return RXGPU_OK;
+		return rxgpu_search_knn(ss->shards[s], queries, nq, kk, sd[s].data(), sr[s].data(), sc[s].data());
+	});
+	if (rc != RXGPU_OK) return rc;
+	std::vector<std::pair<float, uint32_t>> all;
+	for (uint32_t q = 0; q < nq; ++q) {
+		all.clear();
+		for (size_t s = 0; s < ns; ++s) {
+			for (uint32_t j = 0; j < sc[s][q]; ++j) all.emplace_back(sd[s][size_t(q) * kk + j], uint32_t(sr[s][size_t(q) * kk + j] + s * ss->shard_rows));
+		}
+		const size_t take = std::min<size_t>(kk, all.size());
+		std::partial_sort(all.begin(), all.begin() + take, all.end());   // lexicographic (dist, global row): the single-device order
+		for (size_t j = 0; j < take; ++j) {
+			out_dist[size_t(q) * kk + j] = all[j].first;
+			out_row[size_t(q) * kk + j] = all[j].second;
+		}
+		out_count[q] = uint32_t(take);
+	}
+	return RXGPU_OK;
+}
+
+int sharded_search_range_impl(rxgpu_index* h, const float* query, float radius, int inclusive, const uint32_t* row_ids, uint64_t n_ids, float* out_dist,
+							  uint32_t* out_row, uint64_t cap, uint64_t* out_total) {
+	ShardSet* ss = h->shard_set;
+	const size_t ns = ss->shards.size();
+	std::vector<std::vector<float>> sd(ns);
+	std::vector<std::vector<uint32_t>> sr(ns), local_ids(ns);
+	std::vector<uint64_t> st(ns, 0);
+	if (row_ids) {
+		for (uint64_t i = 0; i < n_ids; ++i) {
+			if ((i && row_ids[i] <= row_ids[i - 1]) || row_ids[i] >= h->count) {
+				set_error("rxgpu_search_range_subset: row ids must be strictly increasing and below count");
+				return RXGPU_ERR_PARAMS;
+			}
+			const size_t s = size_t(row_ids[i] / ss->shard_rows);
+			local_ids[s].push_back(uint32_t(row_ids[i] - s * ss->shard_rows));
+		}
+	}
+	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	const int rc = for_each_shard(ss, [&](size_t s) -> int {
+		uint64_t want = std::max<uint64_t>(cap, 64);
+		for (int attempt = 0; attempt < 2; ++attempt) {   // a shard that overflows its buffer is asked again with the size it reported
+			sd[s].resize(want);
+			sr[s].resize(want);
+			int r;
+			if (row_ids) {
+				if (local_ids[s].empty()) {
+					st[s] = 0;
+					return RXGPU_OK;
+				}
+				r = rxgpu_search_range_subset(ss->shards[s], query, radius, inclusive, local_ids[s].data(), local_ids[s].size(), sd[s].data(), sr[s].data(), want, &st[s]);
+			} else {
+				if (rxgpu_index_count(ss->shards[s]) == 0) {
+					st[s] = 0;
+					return RXGPU_OK;
+				}
+				r = rxgpu_search_range(ss->shards[s], query, radius, inclusive, sd[s].data(), sr[s].data(), want, &st[s]);
+			}
+			if (r != RXGPU_ERR_OVERFLOW) return r;
+			want = st[s];
+		}
+		return RXGPU_ERR_OVERFLOW;
+	});
+	if (rc != RXGPU_OK) return rc;
+	std::vector<std::pair<float, uint32_t>> all;
+	for (size_t s = 0; s < ns; ++s) {
+		for (uint64_t j = 0; j < st[s]; ++j) all.emplace_back(sd[s][j], uint32_t(sr[s][j] + s * ss->shard_rows));
+	}
+	std::sort(all.begin(), all.end());
+	*out_total = all.size();
+	for (size_t j = 0; j < all.size() && j < cap; ++j) {
+		out_dist[j] = all[j].first;
+		out_row[j] = all[j].second;
+	}
+	if (all.size() > cap) {
+		set_error("rxgpu_search_range: more hits than the output buffer holds");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	return RXGPU_OK;
+}
+
+int sharded_distances(rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist) {
+	ShardSet* ss = h->shard_set;
+	const size_t ns = ss->shards.size();
+	std::vector<std::vector<uint32_t>> local(ns), where(ns);
+	for (uint32_t i = 0; i < n; ++i) {
+		if (rows[i] >= h->count) {
+			set_error("rxgpu_distances: row out of range");
+			return RXGPU_ERR_PARAMS;
+		}
+		const size_t s = size_t(rows[i] / ss->shard_rows);
+		local[s].push_back(uint32_t(rows[i] - s * ss->shard_rows));
+		where[s].push_back(i);
+	}
+	std::vector<std::vector<float>> sd(ns);
+	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	const int rc = for_each_shard(ss, [&](size_t s) -> int {
+		if (local[s].empty()) return RXGPU_OK;
+		sd[s].resize(local[s].size());
+		return rxgpu_distances(ss->shards[s], query, local[s].data(), uint32_t(local[s].size()), sd[s].data());
+	});
+	if (rc != RXGPU_OK) return rc;
+	for (size_t s = 0; s < ns; ++s) {
+		for (size_t j = 0; j < where[s].size(); ++j) out_dist[where[s][j]] = sd[s][j];
+	}
+	return RXGPU_OK;
+}
+
+// RemovePoint's swap-with-last across shards: the row travels through the host (two devices may be involved)
+int sharded_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
+	ShardSet* ss = h->shard_set;
+	if (from >= h->count || to >= h->count) {
+		set_error("rxgpu_index_move_row: row out of range");
+		return RXGPU_ERR_PARAMS;
+	}
+	if (from == to) return RXGPU_OK;
+	const size_t sf = size_t(from / ss->shard_rows), st = size_t(to / ss->shard_rows);
+	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	if (sf == st) {
+		int rc = RXGPU_OK;
+		std::string err;
+		ss->workers[sf]->start([&] {
+			rc = rxgpu_index_move_row(ss->shards[sf], from - sf * ss->shard_rows, to - sf * ss->shard_rows);
+			if (rc != RXGPU_OK) err = rxgpu_last_error();
+		});
+		ss->workers[sf]->wait();
+		if (rc != RXGPU_OK) set_error(err);
+		return rc;
+	}
+	std::vector<float> row(h->dim);
+	float norm = 0.f;
+	int rc = RXGPU_OK;
+	std::string err;
+	ss->workers[sf]->start([&] {
+		rc = rxgpu_index_download_row(ss->shards[sf], from - sf * ss->shard_rows, row.data(), &norm);
+		if (rc != RXGPU_OK) err = rxgpu_last_error();
+	});
+	ss->workers[sf]->wait();
+	if (rc == RXGPU_OK) {
+		ss->workers[st]->start([&] {
+			rc = rxgpu_index_upload_rows(ss->shards[st], to - st * ss->shard_rows, 1, row.data(), h->metric == RXGPU_METRIC_COSINE ? &norm : nullptr);
+			if (rc != RXGPU_OK) err = rxgpu_last_error();
+		});
+		ss->workers[st]->wait();
+	}
+	if (rc != RXGPU_OK) set_error(err);
+	return rc;
+}
+
+}  // namespace rxgpu
+
+extern "C" {
+
+int rxgpu_index_create_sharded(int metric, uint32_t dim, uint64_t capacity, uint32_t n_devices, const int* devices, rxgpu_index** out) {
+	if (!out || !devices || n_devices == 0 || n_devices > 64) {
+		set_error("rxgpu_index_create_sharded: bad arguments (1..64 devices)");
+		return RXGPU_ERR_PARAMS;
+	}
+	if (capacity == 0 || capacity >= 0xFFFFFFFFull) {
+		set_error("rxgpu_index_create_sharded: capacity must be in [1, 2^32)");
+		return RXGPU_ERR_PARAMS;
+	}
+	*out = nullptr;
+	auto* ss = new rxgpu::ShardSet();
+	ss->shard_rows = ((capacity + n_devices - 1) / n_devices + 31) & ~uint64_t(31);   // whole bitmap words per shard
+	auto* h = new rxgpu_index();
+	h->metric = metric;
+	h->dim = dim;
+	h->stride = (dim + 3u) & ~3u;
+	h->device = devices[0];
+	h->capacity = capacity;
+	h->shard_set = ss;
+	for (uint32_t s = 0; s < n_devices; ++s) {
+		rxgpu_index* sh = nullptr;
+		const uint64_t lo = uint64_t(s) * ss->shard_rows;
+		const uint64_t cap = capacity > lo ? std::min<uint64_t>(capacity - lo, ss->shard_rows) : 0;
+		const int rc = rxgpu_index_create(metric, dim, std::max<uint64_t>(cap, 1), devices[s], &sh);
+		if (rc != RXGPU_OK) {
+			rxgpu::sharded_destroy(h);
+			delete h;
+			return rc;
+		}
+		ss->shards.push_back(sh);
+		auto* w = new rxgpu::ShardWorker();
+		w->thread = std::thread([w, dev = devices[s]] {
+			(void)hipSetDevice(dev);
+			w->run();
+		});
+		ss->workers.push_back(w);
+	}
+	*out = h;
+	return RXGPU_OK;
+}
+
+uint32_t rxgpu_index_shard_count(const rxgpu_index* h) { return h && h->shard_set ? uint32_t(h->shard_set->shards.size()) : 0; }
+uint64_t rxgpu_index_shard_rows(const rxgpu_index* h) { return h && h->shard_set ? h->shard_set->shard_rows : 0; }
+
+}  // extern "C"

@@ -33,7 +33,20 @@ float NormalizeCopyVector(const float* x, int32_t d, float* out) noexcept {
 }
 
 GpuBruteforceMap::GpuBruteforceMap(VectorMetric metric, size_t dim, size_t maxElements, int device)
-	: metric_(metric), dim_(dim), device_(device), maxElements_(maxElements) {
+	: GpuBruteforceMap(metric, dim, maxElements, std::vector<int>{device}) {}
+
+void GpuBruteforceMap::createDeviceIndex() {
+	if (dev_) rxgpu_index_destroy(dev_);
+	dev_ = nullptr;
+	const int rc = devices_.size() > 1 ? rxgpu_index_create_sharded(int(metric_), uint32_t(dim_), std::max<size_t>(maxElements_, 1), uint32_t(devices_.size()),
+																	devices_.data(), &dev_)
+									   : rxgpu_index_create(int(metric_), uint32_t(dim_), maxElements_, device_, &dev_);
+	if (rc != RXGPU_OK) throwDevice("GpuBruteforceMap: device index creation failed");
+}
+
+GpuBruteforceMap::GpuBruteforceMap(VectorMetric metric, size_t dim, size_t maxElements, std::vector<int> devices)
+	: metric_(metric), dim_(dim), device_(devices.empty() ? 0 : devices[0]), devices_(std::move(devices)), maxElements_(maxElements) {
+	if (devices_.empty()) throw std::logic_error("GpuBruteforceMap: empty device list");
 	if (dim_ == 0 || dim_ > 65535) throw std::logic_error("GpuBruteforceMap: dimension must be in [1, 65535]");
 	try {
 		rows_.resize(maxElements_ * dim_);
@@ -42,15 +55,14 @@ GpuBruteforceMap::GpuBruteforceMap(VectorMetric metric, size_t dim, size_t maxEl
 	} catch (const std::bad_alloc&) {
 		throw std::runtime_error("Not enough memory: BruteforceSearch failed to allocate data");
 	}
-	if (rxgpu_index_create(int(metric_), uint32_t(dim_), maxElements_, device_, &dev_) != RXGPU_OK) {
-		throwDevice("GpuBruteforceMap: device index creation failed");
-	}
+	createDeviceIndex();
 }
 
 GpuBruteforceMap::GpuBruteforceMap(const GpuBruteforceMap& other, size_t newMaxElements)
 	: metric_(other.metric_),
 	  dim_(other.dim_),
 	  device_(other.device_),
+	  devices_(other.devices_),
 	  maxElements_(std::max(other.maxElements_, newMaxElements)),
 	  curElementCount_(other.curElementCount_),
 	  dictExternalToInternal_(other.dictExternalToInternal_) {
@@ -64,9 +76,7 @@ GpuBruteforceMap::GpuBruteforceMap(const GpuBruteforceMap& other, size_t newMaxE
 	std::memcpy(rows_.data(), other.rows_.data(), curElementCount_ * dim_ * sizeof(float));
 	std::memcpy(labels_.data(), other.labels_.data(), curElementCount_ * sizeof(labeltype));
 	if (!invNorms_.empty()) std::memcpy(invNorms_.data(), other.invNorms_.data(), curElementCount_ * sizeof(float));
-	if (rxgpu_index_create(int(metric_), uint32_t(dim_), maxElements_, device_, &dev_) != RXGPU_OK) {
-		throwDevice("GpuBruteforceMap: device index creation failed");
-	}
+	createDeviceIndex();
 	dirtyAll_ = true;
 	needSync_ = true;
 }
@@ -160,7 +170,11 @@ void GpuBruteforceMap::ResizeIndex(size_t newMaxElements) {
 void GpuBruteforceMap::syncDevice() const {
 	std::lock_guard<std::mutex> lk(syncMtx_);
 	if (!needSync_) return;
-	if (rxgpu_index_capacity(dev_) != maxElements_) {
+	if (devices_.size() > 1 && rxgpu_index_capacity(dev_) != std::max<size_t>(maxElements_, 1)) {
+		// the shard boundaries follow the capacity: a resized sharded mirror is rebuilt from the host master copy
+		const_cast<GpuBruteforceMap*>(this)->createDeviceIndex();
+		dirtyAll_ = true;
+	} else if (devices_.size() == 1 && rxgpu_index_capacity(dev_) != maxElements_) {
 		// keep the live prefix on the device when growing; shrinking below the device count needs a truncate first
 		if (rxgpu_index_count(dev_) > curElementCount_) {
 			if (rxgpu_index_truncate(dev_, curElementCount_) != RXGPU_OK) throwDevice("truncate");
@@ -372,7 +386,7 @@ SearchResultQueue GpuBruteforceMap::SearchKnnFiltered(const float* queryData, st
 	std::vector<uint32_t> row(kk);
 	uint32_t count = 0;
 	int rc;
-	if (rows.size() * 32 >= curElementCount_) {   // dense filter: count / 8 bytes on the wire instead of 4 per allowed row
+	if (devices_.size() == 1 && rows.size() * 32 >= curElementCount_) {   // dense filter: count / 8 bytes on the wire instead of 4 per allowed row
 		std::vector<uint32_t> words((curElementCount_ + 31) / 32, 0u);
 		for (uint32_t r : rows) words[r >> 5] |= 1u << (r & 31);
 		rc = rxgpu_search_knn_bitmap(dev_, queryData, 1, kk, words.data(), words.size(), dist.data(), row.data(), &count, nullptr);

@@ -30,6 +30,10 @@ float NormalizeCopyVector(const float* x, int32_t d, float* out) noexcept;
 class GpuBruteforceMap {
 public:
 	GpuBruteforceMap(VectorMetric metric, size_t dim, size_t maxElements, int device = 0);
+	// BASELINE configs[3]: the same Map over a DEVICE LIST — the rows are range-sharded over the listed GPUs (rxgpu_index_create_sharded; a
+	// device may be listed more than once), every search runs on all of them at once and the per-shard top-k lists are merged under the
+	// reference's (dist, row) order, so results — including the k-th-boundary tie replay by label — are those of the single-device Map.
+	GpuBruteforceMap(VectorMetric metric, size_t dim, size_t maxElements, std::vector<int> devices);
 	GpuBruteforceMap(const GpuBruteforceMap& other, size_t newMaxElements);   // copy-on-write tx clone (hnsw_index.cc:68-70)
 	~GpuBruteforceMap();
 	GpuBruteforceMap& operator=(const GpuBruteforceMap&) = delete;
@@ -83,6 +87,8 @@ private:
 	const VectorMetric metric_;
 	const size_t dim_;
 	const int device_;
+	const std::vector<int> devices_;   // more than one entry: a sharded device mirror
+	void createDeviceIndex();
 	size_t maxElements_;
 	size_t curElementCount_ = 0;
 

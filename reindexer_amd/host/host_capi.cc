@@ -52,6 +52,12 @@ void* rxhost_bf_create(int metric, size_t dim, size_t maxElements, int device) {
 	guarded([&] { m = new GpuBruteforceMap(VectorMetric(metric), dim, maxElements, device); });
 	return m;
 }
+// the Map over a device list (row-range shards, BASELINE configs[3]); a device may be listed more than once
+void* rxhost_bf_create_sharded(int metric, size_t dim, size_t maxElements, const int* devices, size_t nDevices) {
+	GpuBruteforceMap* m = nullptr;
+	guarded([&] { m = new GpuBruteforceMap(VectorMetric(metric), dim, maxElements, std::vector<int>(devices, devices + nDevices)); });
+	return m;
+}
 void* rxhost_bf_clone(void* h, size_t newMaxElements) {
 	GpuBruteforceMap* m = nullptr;
 	guarded([&] { m = new GpuBruteforceMap(*static_cast<GpuBruteforceMap*>(h), newMaxElements); });

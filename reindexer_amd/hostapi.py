@@ -85,8 +85,17 @@ def normalize_copy(x):
 class GpuBruteforceMap:
     """rxgpu::host::GpuBruteforceMap (drop-in for hnswlib::BruteforceSearch)."""
 
-    def __init__(self, metric: int, dim: int, max_elements: int, device: int = 0, _handle=None):
+    def __init__(self, metric: int, dim: int, max_elements: int, device: int = 0, _handle=None, devices=None):
+        """devices=[d0, d1, ...]: the Map over a device list (row-range shards; a device may be listed more than once)."""
         self.dim = dim
+        if _handle is None and devices is not None:
+            L = lib()
+            L.rxhost_bf_create_sharded.restype = _vp
+            L.rxhost_bf_create_sharded.argtypes = [_i, _sz, _sz, _vp, _sz]
+            dv = np.ascontiguousarray(devices, np.int32)
+            _handle = L.rxhost_bf_create_sharded(metric, dim, max_elements, dv.ctypes.data, dv.shape[0])
+            if not _handle:
+                _raise()
         self.h = _handle if _handle is not None else lib().rxhost_bf_create(metric, dim, max_elements, device)
         if not self.h:
             _raise()

@@ -102,6 +102,84 @@ class ShardedBruteforce:
         d, r = local_search_subset(queries, kk, (rows[a:b] - lo).astype(np.uint32))
         return self._exchange(d, r, kk)
 
+    def search_knn_labels(self, queries: torch.Tensor, k: int, local_labels, local_range):
+        """SearchKnn with the reference's (dist, LABEL) semantics over the sharded corpus (bruteforce.cc:103-127): -> per query a list of
+        (dist f32, label u64) best first, identical on every rank and identical to hnswlib::BruteforceSearch over the whole corpus.
+
+        The merge order (dist, global row) equals the reference's result unless an exact distance tie straddles the k-th boundary: the
+        reference then keeps the tied rows its heap keeps — admission is strict (`dist < worst`), eviction removes the largest (dist, label).
+        Exactly as the single-device Map does (gpu_bruteforce_map.cc, replayTies) the rule is then replayed over every row with
+        dist <= d_k: each rank fetches those rows of its shard (local_range(query, d_k) -> (dist, local rows), inclusive) with their labels
+        (local_labels: this shard's labels, indexable by local row), the lists travel in one more all-gather, and every rank replays the scan
+        in global row order.  local_labels / local_range are injected like local_search."""
+        import numpy as np
+        kk = k + 1
+        d, r = self.search(queries, kk)
+        d_np, r_np = d.cpu().numpy(), r.cpu().numpy()
+        nq = d_np.shape[0]
+        lo = self.rank * self.shard_rows
+        need = [qi for qi in range(nq) if r_np[qi, k] >= 0 and not (d_np[qi, k - 1] < d_np[qi, k])] if k >= 1 else []
+        # labels of the merged rows: every rank contributes the labels of the rows it owns (one small all-reduce-by-gather)
+        lab = np.zeros((nq, kk), np.int64)
+        own = (r_np >= lo) & (r_np < lo + self.shard_rows)
+        lab[own] = np.asarray(local_labels)[(r_np[own] - lo).astype(np.int64)].astype(np.uint64).view(np.int64)
+        lab_t = torch.from_numpy(lab).to(queries.device if queries.is_cuda else "cpu")
+        if self.world > 1:
+            self._dist.all_reduce(lab_t, op=self._dist.ReduceOp.SUM, group=self.group)   # exactly one rank owns each row: the sum is its label
+        lab = lab_t.cpu().numpy().view(np.uint64)
+        out = []
+        replay = {}
+        if need:
+            # (dist, global row, label) of every row with dist <= d_k on this shard, for all queries that need it, in one padded exchange
+            mine = []
+            for qi in need:
+                rd, rr = local_range(queries[qi], float(d_np[qi, k - 1]))
+                rd = np.asarray(rd, np.float32)
+                rr = np.asarray(rr, np.int64)
+                ll = np.asarray(local_labels)[rr].astype(np.uint64).view(np.int64)
+                mine.append(np.stack([rd.view(np.int32).astype(np.int64), rr + lo, ll], axis=1))
+            counts = torch.tensor([m.shape[0] for m in mine], dtype=torch.int64)
+            all_counts = [torch.zeros_like(counts) for _ in range(self.world)]
+            if self.world > 1:
+                self._dist.all_gather(all_counts, counts, group=self.group)
+            else:
+                all_counts = [counts]
+            width = int(max(int(c.max()) for c in all_counts)) if need else 0
+            buf = torch.zeros((len(need), max(width, 1), 3), dtype=torch.int64)
+            for j, m in enumerate(mine):
+                buf[j, : m.shape[0]] = torch.from_numpy(m)
+            bufs = [torch.zeros_like(buf) for _ in range(self.world)]
+            if self.world > 1:
+                self._dist.all_gather(bufs, buf, group=self.group)
+            else:
+                bufs = [buf]
+            for j, qi in enumerate(need):
+                rows = np.concatenate([bufs[w][j, : int(all_counts[w][j])].numpy() for w in range(self.world)], axis=0)
+                rows = rows[np.argsort(rows[:, 1], kind="stable")]                       # scan order = global row order
+                dk = d_np[qi, k - 1]
+                better, ties = [], []                                                     # ties: labels, the largest is evicted first
+                for bits, _, label in rows:
+                    dist_v = np.array([bits], np.int64).astype(np.int32).view(np.float32)[0]
+                    is_tie = not (dist_v < dk)
+                    ulabel = int(np.array([label], np.int64).view(np.uint64)[0])
+                    if len(better) + len(ties) < k:
+                        (ties if is_tie else better).append(ulabel if is_tie else (dist_v, ulabel))
+                    elif not is_tie:
+                        ties.remove(max(ties))
+                        better.append((dist_v, ulabel))
+                res = better + [(dk, t) for t in ties]
+                res.sort(key=lambda p: (p[0], p[1]))
+                replay[qi] = res
+        for qi in range(nq):
+            if qi in replay:
+                out.append(replay[qi])
+            else:
+                n = int((r_np[qi, :k] >= 0).sum())
+                res = [(d_np[qi, j], int(lab[qi, j])) for j in range(n)]
+                res.sort(key=lambda p: (p[0], p[1]))
+                out.append(res)
+        return out
+
     def _exchange(self, d: torch.Tensor, r: torch.Tensor, kk: int):
         packed = pack_topk(d, r)                                  # [nq, kk]
         if self.world > 1:

@@ -204,3 +204,70 @@ def test_two_rank_prefiltered_search_equals_single_index(oracle, dens):
             assert np.array_equal(rr[qi, :m], allowed[pos].astype(np.int64)), (rank, qi)
             assert np.array_equal(dd[qi, :m].view(np.uint32), wd.view(np.uint32))
             assert np.all(rr[qi, m:] == -1)
+
+
+def _labels_worker(rank, world, port, n, d, k, nq, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import Oracle
+    from reindexer_amd.sharded import ShardedBruteforce
+    orc = Oracle()
+    rows, labels = _corpus(n, d, True), _perm_labels(n)
+    shard = n // world
+    mine, mine_labels = rows[rank * shard:(rank + 1) * shard], labels[rank * shard:(rank + 1) * shard]
+
+    def local_search(queries, kk):
+        ds, rs = [], []
+        for q in queries.numpy():
+            dd, rr = lex_topk(orc.dist_many(0, q, mine), kk)
+            pad = kk - dd.shape[0]
+            ds.append(np.concatenate([dd, np.full(pad, np.inf, np.float32)]))
+            rs.append(np.concatenate([rr.astype(np.int64), np.full(pad, 0xFFFFFFFF, np.int64)]))
+        return torch.from_numpy(np.stack(ds)), torch.from_numpy(np.stack(rs))
+
+    def local_range(q, radius):
+        alld = orc.dist_many(0, q.numpy(), mine)
+        hit = np.flatnonzero(alld <= radius)
+        return alld[hit], hit
+
+    sb = ShardedBruteforce(local_search, shard)
+    res = sb.search_knn_labels(torch.from_numpy(_queries(nq, d, True)), k, mine_labels, local_range)
+    out_q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _perm_labels(n):
+    return (np.random.default_rng(9).permutation(n).astype(np.uint64) << np.uint64(32)) | np.uint64(1)
+
+
+@pytest.mark.parametrize("k", [7, 40])
+def test_two_rank_label_search_replays_cross_shard_ties(oracle, k):
+    """The (dist, label) semantics of BruteforceSearch::SearchKnn over a 2-rank sharded corpus with massive exact ties and labels that are
+    not in row order: the k-th boundary cuts through a group of equal distances spread over both shards; every rank must return what the
+    restated engine (pinned to the real one) returns over the whole corpus."""
+    world, n, d, nq = 2, 3000, 8, 8
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_labels_worker, args=(r, world, port, n, d, k, nq, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows, labels, queries = _corpus(n, d, True), _perm_labels(n), _queries(nq, d, True)
+    ties_seen = 0
+    for rank, res in results:
+        for qi in range(nq):
+            wd, wl = oracle.bf_search_knn(0, rows, labels, None, queries[qi], k)
+            got_d = np.array([p[0] for p in res[qi]], np.float32)
+            got_l = np.array([p[1] for p in res[qi]], np.uint64)
+            order = np.lexsort((wl, wd))
+            assert np.array_equal(got_l, wl[order]), (rank, qi)
+            assert np.array_equal(got_d.view(np.uint32), wd[order].view(np.uint32))
+            alld = np.sort(oracle.dist_many(0, queries[qi], rows))
+            ties_seen += int(alld[k - 1] == alld[k])
+    assert ties_seen > 0
