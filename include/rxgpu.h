@@ -201,6 +201,21 @@ int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t n
  * The traversal replays the reference's heaps step for step, so on the same graph the sets are identical. */
 int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 						  uint32_t* out_count);
+
+/* SQ8 graphs — HierarchicalNSWImpl<uint8_t> after HnswIndexBase::Quantize (hnsw_index.cc:626-660, hnswalg.h:353-420): the level-0 payload
+ * is one byte per component plus the row's corrective offset, distances are DistCalculator<uint8_t>::operator() (hnswlib.h:147-165) over
+ * L2SqrDistance<uint8_t> / InnerProductDistance<uint8_t> (tools/distances/l2_dist.cc:168-199, ip_dist.cc:163-192):
+ *   alpha_2 * sum + corr(query) + corr(row)   (negated for IP / cosine, times 1/|row| for cosine), times the query's normCoef.
+ * The summation order of the reference's AVX-512 form is part of the contract and is reproduced on the device (v_dot4_u32_u8 partial
+ * sums re-associated into the 16 zmm lanes), so results are bit-identical to the quantised engine on the same graph.
+ * codes [count][dim] u8, corr [count] (Quantizer::Quantize + CorrectiveOffsets, quantizer.h:93-124); count == the index row count.
+ * Attach after rxgpu_hnsw_attach_graph / upload; the float rows of the index are not read by the SQ8 search. */
+int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* corr, uint64_t count, float alpha_2);
+/* SearchKnn on the SQ8 graph.  The caller quantises the queries the way prepareData does (hnswalg.h:510-529): query_codes [nq][dim],
+ * query_corr [nq], query_norm_coef [nq] (1 for L2 / IP, queryNormCoef for cosine, hnswalg.h:1855-1863).  Same outputs as
+ * rxgpu_hnsw_search_knn. */
+int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const float* query_corr, const float* query_norm_coef, uint32_t nq,
+							  uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count);
 /* Counters accumulated since the last call (for the roofline accounting: bytes = evals*dim*4 + hops*(1+2M)*4). */
 int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops);
 

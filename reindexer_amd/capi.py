@@ -65,6 +65,8 @@ _SIGNATURES = {
     "rxgpu_hnsw_update_deleted": (_i, [_vp, _vp, _u64]),
     "rxgpu_hnsw_patch_graph": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.c_int32, _u32, _u64]),
     "rxgpu_hnsw_search_knn": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "rxgpu_hnsw_attach_sq8": (_i, [_vp, _vp, _vp, _u64, _f]),
+    "rxgpu_hnsw_search_knn_sq8": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_hnsw_stream_begin": (_i, [_vp, _vp, _u32, C.POINTER(_vp)]),
     "rxgpu_hnsw_stream_continue": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i)]),
@@ -318,6 +320,28 @@ class VectorIndex:
         row = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
         cnt = np.zeros(nq, np.uint32)
         _check(lib().rxgpu_hnsw_search_knn(self._h, q.ctypes.data, nq, k, ef, dist.ctypes.data, row.ctypes.data, cnt.ctypes.data))
+        return dist[:, :k], row[:, :k], cnt
+
+    def hnsw_attach_sq8(self, codes, corr, alpha_2: float) -> None:
+        """SQ8 copy of the rows (Quantizer::Quantize, quantizer.h:93-124): codes [count][dim] u8, corr [count] f32."""
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(-1, self.dim)
+        corr = _f32c(corr).reshape(-1)
+        if codes.shape[0] != corr.shape[0]:
+            raise ValueError("one corrective offset per code row")
+        _check(lib().rxgpu_hnsw_attach_sq8(self._h, codes.ctypes.data, corr.ctypes.data, codes.shape[0], float(alpha_2)))
+
+    def hnsw_search_knn_sq8(self, qcodes, qcorr, qnorm, k: int, ef: int = 0):
+        qc = np.ascontiguousarray(qcodes, np.uint8).reshape(-1, self.dim)
+        nq = qc.shape[0]
+        qcorr = _f32c(qcorr).reshape(-1)
+        qnorm = _f32c(qnorm).reshape(-1)
+        if qcorr.shape[0] != nq or qnorm.shape[0] != nq:
+            raise ValueError("one corrective offset and one normCoef per query")
+        dist = np.full((nq, max(k, 1)), np.inf, np.float32)
+        row = np.full((nq, max(k, 1)), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(nq, np.uint32)
+        _check(lib().rxgpu_hnsw_search_knn_sq8(self._h, qc.ctypes.data, qcorr.ctypes.data, qnorm.ctypes.data, nq, k, ef, dist.ctypes.data,
+                                               row.ctypes.data, cnt.ctypes.data))
         return dist[:, :k], row[:, :k], cnt
 
     def hnsw_read_stats(self):

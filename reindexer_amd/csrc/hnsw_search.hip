@@ -87,6 +87,79 @@ __device__ __forceinline__ void batch_distances(const HnswParams& p, const float
 	}
 }
 
+// SQ8: DistCalculator<uint8_t>::operator()(query, row, id) (hnswlib.h:147-165) over vector_dists::L2SqrDistance<uint8_t> /
+// InnerProductDistance<uint8_t> (tools/distances/l2_dist.cc:168-199, ip_dist.cc:163-192, AVX-512 form).  The integer part is exact; the
+// contract is in the REDUCTION: per 64-byte block the reference's zmm lane j collects elements {2j, 2j+1} and {32+2j, 33+2j}, the 16 lane
+// sums are converted to float and added one after another (rounds past 2^24), then the scalar tail (an int) is added as a float.
+// A 16-lane group owns a row: lane m reads the 4 bytes [4m, 4m+4) of every block with one 32-bit load and feeds reference lanes
+// 2(m & 7) and 2(m & 7) + 1 (low half for m < 8, high half above) through v_dot4_u32_u8 on the masked halves of the word; an xor-8
+// exchange completes the 16 reference sums, which every lane then adds in the reference's order.  A row is D bytes instead of 4 D:
+// the search is bound by exactly these gathers.
+template <int kMetric>
+__device__ __forceinline__ void batch_distances_sq8(const HnswParams& p, const uint8_t* q, float qcorr, float qnorm, const uint32_t* ids, int cnt,
+													float* dists, int lane) {
+	const int m = lane & 15, g = lane >> 4;
+	const uint32_t nblk = p.dim / 64, tail0 = nblk * 64;
+	const bool words_ok = (p.dim & 3u) == 0;   // every row (and the query) then starts on a 4-byte boundary
+	for (int base = 0; base < cnt; base += kRowsPerWave) {
+		const int idx = base + g;
+		const bool ok = idx < cnt;
+		const uint64_t row = ids[ok ? idx : base];
+		const uint8_t* r8 = p.codes + row * p.dim;
+		uint32_t s0 = 0, s1 = 0;
+		for (uint32_t t = 0; t < nblk; ++t) {
+			uint32_t a, b;
+			if (words_ok) {
+				a = reinterpret_cast<const uint32_t*>(r8)[16 * t + m];
+				b = reinterpret_cast<const uint32_t*>(q)[16 * t + m];
+			} else {
+				const uint8_t* pa = r8 + 64 * t + 4 * m;
+				const uint8_t* pb = q + 64 * t + 4 * m;
+				a = uint32_t(pa[0]) | (uint32_t(pa[1]) << 8) | (uint32_t(pa[2]) << 16) | (uint32_t(pa[3]) << 24);
+				b = uint32_t(pb[0]) | (uint32_t(pb[1]) << 8) | (uint32_t(pb[2]) << 16) | (uint32_t(pb[3]) << 24);
+			}
+			const uint32_t alo = a & 0xFFFFu, ahi = a >> 16, blo = b & 0xFFFFu, bhi = b >> 16;
+			if constexpr (kMetric == kL2) {   // (a - b)^2 = a^2 + b^2 - 2ab, exact in uint32 (the reference's madd_epi16 of the differences)
+				s0 += __builtin_amdgcn_udot4(alo, alo, 0u, false) + __builtin_amdgcn_udot4(blo, blo, 0u, false) - 2u * __builtin_amdgcn_udot4(alo, blo, 0u, false);
+				s1 += __builtin_amdgcn_udot4(ahi, ahi, 0u, false) + __builtin_amdgcn_udot4(bhi, bhi, 0u, false) - 2u * __builtin_amdgcn_udot4(ahi, bhi, 0u, false);
+			} else {
+				s0 = __builtin_amdgcn_udot4(alo, blo, s0, false);
+				s1 = __builtin_amdgcn_udot4(ahi, bhi, s1, false);
+			}
+		}
+		s0 += __shfl_xor(s0, 8, 64);   // low half (lanes 0-7) + high half (lanes 8-15) of the same reference lanes
+		s1 += __shfl_xor(s1, 8, 64);
+		float result = 0.f;
+		const int group_base = lane & ~15;
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {   // result += (float)lane[j], j = 0 .. 15
+			result += float(__shfl(s0, group_base + t, 64));
+			result += float(__shfl(s1, group_base + t, 64));
+		}
+		int tail = 0;   // the scalar tail: an int accumulator
+		for (uint32_t i = tail0 + m; i < p.dim; i += 16) {
+			if constexpr (kMetric == kL2) {
+				const int df = int(r8[i]) - int(q[i]);
+				tail += df * df;
+			} else {
+				tail += int(r8[i]) * int(q[i]);
+			}
+		}
+#pragma unroll
+		for (int off = 1; off < 16; off <<= 1) tail += __shfl_xor(tail, off, 64);
+		result = result + float(tail);
+		float dist;
+		if constexpr (kMetric == kL2) {
+			dist = p.alpha2 * result + qcorr + p.corr[row];
+		} else {
+			dist = -(p.alpha2 * result + qcorr + p.corr[row]);
+			if constexpr (kMetric == kCos) dist *= p.inv_norms[row];
+		}
+		dist = qnorm * dist;
+		if (ok && m == 0) dists[idx] = dist;
+	}
+}
+
 // dim == 64*NB: the query fragment lives in registers and the NB 16-byte loads of EIGHT rows (two per 16-lane group) are
 // issued before the first reduction — one HBM round trip per 8 neighbours instead of three per 4.
 // kQLds: the query fragment is re-read from LDS (ds_read_b128) instead of living in NB*4 VGPRs — 48 fewer registers at D = 768, which is
@@ -134,7 +207,7 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 
 // kLatency: few queries in flight -> two row sets per distance trip (fewer dependent round trips per hop, 172 VGPRs at D = 768);
 // otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
-template <int kMetric, bool kGlobalCand, int NB, bool kLatency>
+template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false>
 __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
@@ -167,7 +240,9 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 		__syncthreads();
 	}
 	auto distances = [&](const uint32_t* ids, int cnt, float* dists) {
-		if constexpr (NB > 0) {
+		if constexpr (kSq8) {
+			batch_distances_sq8<kMetric>(p, p.qcodes + size_t(qi) * p.dim, p.qcorr[qi], p.qnorm[qi], ids, cnt, dists, lane);
+		} else if constexpr (NB > 0) {
 			batch_distances_fixed<kMetric, NB, kQLds, (kLatency || NB <= 8)>(p, qreg, q_s, ids, cnt, dists, lane);
 		} else {
 			batch_distances<kMetric>(p, q, ids, cnt, dists, lane);
@@ -342,7 +417,25 @@ static void launch_hnsw_mode(int metric, const HnswParams& p, uint32_t blocks, h
 	}
 }
 
+template <bool kGlobalCand>
+static void launch_hnsw_sq8(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
+	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8;
+	switch (metric) {
+		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, 0, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, 0, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, 0, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+	}
+}
+
 void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s) {
+	if (p.codes) {   // SQ8 graph
+		if (global_cand) {
+			launch_hnsw_sq8<true>(metric, p, blocks, s);
+		} else {
+			launch_hnsw_sq8<false>(metric, p, blocks, s);
+		}
+		return;
+	}
 	if (global_cand) {
 		launch_hnsw_mode<true>(metric, p, blocks, s);
 	} else {

@@ -122,6 +122,14 @@ struct HnswParams {
 	unsigned long long* stats;   // optional [2]: distance evaluations, hops
 	uint32_t lds_cand_cap;       // <= kHnswCandLds (tests shrink it to force the global-heap re-run)
 	uint32_t ef_cap;             // result-heap capacity in LDS: ef rounded up to 64
+	// SQ8 graph (HierarchicalNSWImpl<uint8_t>): codes instead of vectors, stored corrective offsets, alpha^2; the queries travel as codes +
+	// corrective offset (prepareData, hnswalg.h:510-529) and every distance is scaled by the query's normCoef (queryNormCoef :1855-1863)
+	const uint8_t* codes;        // [n][dim]
+	const float* corr;           // [n]
+	float alpha2;
+	const uint8_t* qcodes;       // [nq][dim]
+	const float* qcorr;          // [nq]
+	const float* qnorm;          // [nq]
 };
 
 // In-place graph update (rxgpu_hnsw_patch_graph): one workgroup per touched node scatters its staged lists into the resident arrays

@@ -718,6 +718,8 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 	if (h->d_upper_off) (void)hipFree(h->d_upper_off);
 	if (h->d_upper) (void)hipFree(h->d_upper);
 	if (h->d_deleted) (void)hipFree(h->d_deleted);
+	if (h->d_codes) (void)hipFree(h->d_codes);
+	if (h->d_corr) (void)hipFree(h->d_corr);
 	if (h->d_hnsw_stats) (void)hipFree(h->d_hnsw_stats);
 	delete h;
 }
@@ -1419,8 +1421,55 @@ int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t n
 	return RXGPU_OK;
 }
 
+int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* corr, uint64_t count, float alpha_2) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_hnsw_attach_sq8: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	RX_CHECK(count == h->count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_sq8: one code row per index row");
+	RX_CHECK(count == 0 || (codes && corr), RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_sq8: null argument");
+	DeviceGuard dg(h->device);
+	RX_HIP(hipDeviceSynchronize());
+	if (h->d_codes) (void)hipFree(h->d_codes);
+	if (h->d_corr) (void)hipFree(h->d_corr);
+	h->d_codes = nullptr;
+	h->d_corr = nullptr;
+	h->sq8_n = 0;
+	if (count) {
+		// + 4 bytes: the word loads of the last row's last block stay inside the allocation whatever dim % 4 is
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_codes), size_t(count) * h->dim + 4));
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_corr), size_t(count) * sizeof(float)));
+		RX_HIP(hipMemcpy(h->d_codes, codes, size_t(count) * h->dim, hipMemcpyHostToDevice));
+		RX_HIP(hipMemcpy(h->d_corr, corr, size_t(count) * sizeof(float), hipMemcpyHostToDevice));
+	}
+	h->sq8_alpha2 = alpha_2;
+	h->sq8_n = count;
+	return RXGPU_OK;
+}
+
+// One body for both row formats: `queries` are float rows (qcorr == nullptr) or SQ8 codes with their corrective offsets and normCoefs.
+static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef,
+							float* out_dist, uint32_t* out_row, uint32_t* out_count);
+
 int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 						  uint32_t* out_count) {
+	RX_CHECK(queries, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
+	return hnsw_search_impl(h, queries, nullptr, nullptr, nq, k, ef, out_dist, out_row, out_count);
+}
+
+int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const float* query_corr, const float* query_norm_coef, uint32_t nq,
+							  uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(query_codes && query_corr && query_norm_coef, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn_sq8: null argument");
+	RX_CHECK(h->count == 0 || (h->d_codes && h->sq8_n == h->count), RXGPU_ERR_LOGIC,
+			 "rxgpu_hnsw_search_knn_sq8: SQ8 codes are not attached / out of date");
+	return hnsw_search_impl(h, query_codes, query_corr, query_norm_coef, nq, k, ef, out_dist, out_row, out_count);
+}
+
+static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef,
+							float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	const bool sq8 = qcorr != nullptr;
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	if (h->shard_set) {
 		set_error("rxgpu_hnsw_search_knn: not available on a sharded index");
@@ -1448,13 +1497,27 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 	const uint64_t words = (h->count + 31) / 32;
 	// visited bitsets are the memory hog: bound one launch to ~2 GiB of them
 	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(8192, (2ull << 30) / (words * 4)));
-	const size_t qbytes = size_t(nq) * h->dim * sizeof(float);
-	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
+	// SQ8 queries: [codes, padded to 4 bytes][corr][normCoef] in the one query buffer
+	const size_t qelem = sq8 ? sizeof(uint8_t) : sizeof(float);
+	const size_t qbytes = size_t(nq) * h->dim * qelem;
+	const size_t o_qcorr = (qbytes + 255) & ~size_t(255), o_qnorm = o_qcorr + ((size_t(nq) * 4 + 255) & ~size_t(255));
+	if (int rc = c->d_queries.ensure(sq8 ? o_qnorm + size_t(nq) * 4 : qbytes); rc) return rc;
 	if (int rc = c->d_out_dist.ensure(size_t(nq) * k * sizeof(float)); rc) return rc;
 	if (int rc = c->d_out_row.ensure(size_t(nq) * k * sizeof(uint32_t)); rc) return rc;
 	if (int rc = c->d_out_count.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
 	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, qbytes, hipMemcpyHostToDevice, c->stream));
 	rxgpu::HnswParams p{};
+	if (sq8) {
+		char* qb = static_cast<char*>(c->d_queries.ptr);
+		RX_HIP(hipMemcpyAsync(qb + o_qcorr, qcorr, size_t(nq) * 4, hipMemcpyHostToDevice, c->stream));
+		RX_HIP(hipMemcpyAsync(qb + o_qnorm, qnorm, size_t(nq) * 4, hipMemcpyHostToDevice, c->stream));
+		p.codes = h->d_codes;
+		p.corr = h->d_corr;
+		p.alpha2 = h->sq8_alpha2;
+		p.qcodes = reinterpret_cast<const uint8_t*>(qb);
+		p.qcorr = reinterpret_cast<const float*>(qb + o_qcorr);
+		p.qnorm = reinterpret_cast<const float*>(qb + o_qnorm);
+	}
 	p.rows = h->d_rows;
 	p.inv_norms = h->d_inv_norms;
 	p.links0 = h->d_links0;
@@ -1490,6 +1553,11 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 		RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
 		rxgpu::HnswParams pc = p;
 		pc.queries = static_cast<const float*>(c->d_queries.ptr) + size_t(q0) * h->dim;
+		if (sq8) {
+			pc.qcodes = p.qcodes + size_t(q0) * h->dim;
+			pc.qcorr = p.qcorr + q0;
+			pc.qnorm = p.qnorm + q0;
+		}
 		pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
 		pc.out_dist = p.out_dist + size_t(q0) * k;
 		pc.out_row = p.out_row + size_t(q0) * k;

@@ -235,6 +235,11 @@ struct rxgpu_index {
 	uint64_t* d_upper_off = nullptr;
 	uint32_t* d_upper = nullptr;
 	uint8_t* d_deleted = nullptr;
+	// SQ8 copy of the rows (rxgpu_hnsw_attach_sq8): codes [sq8_n][dim], stored corrective offsets, alpha^2
+	uint8_t* d_codes = nullptr;
+	float* d_corr = nullptr;
+	float sq8_alpha2 = 0.f;
+	uint64_t sq8_n = 0;
 	uint64_t graph_n = 0, graph_deleted = 0;
 	uint64_t graph_rows_cap = 0, graph_upper_cap = 0, graph_upper_used = 0;   // allocated level-0 rows / upper blocks (rxgpu_hnsw_patch_graph grows in place)
 	uint32_t graph_M = 0, graph_maxM0 = 0;

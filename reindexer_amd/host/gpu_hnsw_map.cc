@@ -131,8 +131,28 @@ void GpuHnswMap::syncDevice() const {
 	} else if (deletedDirty_) {
 		if (rxgpu_hnsw_update_deleted(dev_, graph_.Deleted(), graph_.DeletedCount()) != RXGPU_OK) throwDevice("delete-mark upload failed");
 	}
+	if (quantized_ && (graphDirty_ || codesDirty_)) attachCodes();
 	graphDirty_ = false;
 	deletedDirty_ = false;
+}
+
+// hnswalg.h:443-470 (the quantising copy) and :1480-1495 (points added to a quantised graph): codes + corrective offsets of every stored
+// vector under the Map's parameters.  The whole code table is re-sent after a mutation — D bytes a row, a quarter of the float rows.
+void GpuHnswMap::attachCodes() const {
+	const size_t n = graph_.Count(), dim = graph_.Dim();
+	std::vector<uint8_t> codes(n * dim);
+	std::vector<float> corr(n);
+	for (size_t i = 0; i < n; ++i) corr[i] = Sq8Quantize(graph_.Metric(), sq8_, graph_.Vector(tableint(i)), dim, 1.f, codes.data() + i * dim);
+	if (rxgpu_hnsw_attach_sq8(dev_, codes.data(), corr.data(), n, sq8_.alpha_2) != RXGPU_OK) throwDevice("SQ8 code upload failed");
+	codesDirty_ = false;
+}
+
+void GpuHnswMap::Quantize(float minQ, float maxQ) {
+	if (!(maxQ > minQ)) throw std::runtime_error("Quantize: empty quantisation range");
+	sq8_ = Sq8Params::FromRange(minQ, maxQ, graph_.Dim());
+	quantized_ = true;
+	codesDirty_ = true;
+	graphDirty_ = true;
 }
 
 struct GpuHnswMap::PendingQuery {
@@ -211,7 +231,7 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 }
 
 // hnswalg.h:1988-2012
-SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional<float>, size_t k, size_t ef) const {
+SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional<float> queryDataNorm, size_t k, size_t ef) const {
 	SearchResultQueue result;
 	const size_t n = graph_.Count();
 	if (n == 0 || k == 0) return result;
@@ -220,7 +240,23 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 	std::vector<float> dist(k);
 	std::vector<uint32_t> row(k);
 	uint32_t count = 0;
-	fetchKnn(queryDataRaw, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count);
+	if (quantized_) {
+		// queryNormCoef (hnswalg.h:1855-1863) and prepareData (:510-529): the query is scaled back to its original length, quantised, and
+		// every distance is multiplied by 1 / |q|
+		const bool cosine = graph_.Metric() == VectorMetric::Cosine;
+		if (cosine && !queryDataNorm) {
+			throw std::runtime_error("Norm is required for Cosine-metric during corrective offsets calculation in quantized graph");
+		}
+		const float normCoef = cosine ? 1.f / *queryDataNorm : 1.f;
+		std::vector<uint8_t> qcodes(graph_.Dim());
+		const float qcorr = Sq8Quantize(graph_.Metric(), sq8_, queryDataRaw, graph_.Dim(), 1.f / normCoef, qcodes.data());
+		if (rxgpu_hnsw_search_knn_sq8(dev_, qcodes.data(), &qcorr, &normCoef, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) !=
+			RXGPU_OK) {
+			throwDevice("SearchKnn");
+		}
+	} else {
+		fetchKnn(queryDataRaw, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count);
+	}
 	ReserveQueue(result, count);
 	for (uint32_t i = 0; i < count; ++i) result.emplace(dist[i], graph_.Label(row[i]));
 	return result;
@@ -241,6 +277,7 @@ StreamingSearchSession& StreamingSearchSession::operator=(StreamingSearchSession
 
 // hnswalg.h:1865-1891
 StreamingSearchSession GpuHnswMap::BeginStreamingSearch(const float* queryDataRaw, std::optional<float>, StreamingSearchOptions opts) const {
+	if (quantized_) throw std::runtime_error("BeginStreamingSearch: not implemented for a quantised GPU graph");
 	StreamingSearchSession session;
 	session.graph_ = this;
 	syncDevice();
@@ -277,6 +314,7 @@ SearchResultQueue GpuHnswMap::SearchRange(const float* queryDataRaw, std::option
 	SearchResultQueue result;
 	const size_t n = graph_.Count();
 	if (n == 0) return result;
+	if (quantized_) throw std::runtime_error("SearchRange: not implemented for a quantised GPU graph");
 	syncDevice();
 	const size_t efEff = std::max<size_t>(1, std::min<size_t>(ef ? ef : 1, 1024));
 	const size_t kk = std::min(efEff, n);

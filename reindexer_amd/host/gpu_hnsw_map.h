@@ -13,6 +13,7 @@
 
 #include "hnsw_graph.h"
 #include "rx_types.h"
+#include "sq8_quantizer.h"
 
 struct rxgpu_index;
 struct rxgpu_hnsw_stream;
@@ -88,8 +89,15 @@ public:
 	void EnableQueryCoalescing(bool on) noexcept { coalesce_ = on; }
 	size_t CoalescedBatches() const noexcept { return coBatches_; }
 
-	bool IsQuantized() const noexcept { return false; }
-	bool QuantizationAvailable() const noexcept { return false; }
+	// SQ8 (HierarchicalNSW::Quantize, hnsw.h:104-118; hnswalg.h:411-470): from here on SearchKnn runs over one byte per component on the
+	// device (rxgpu_hnsw_search_knn_sq8) and returns what HierarchicalNSWImpl<uint8_t> returns on the same graph, bit for bit.  The range
+	// [minQ, maxQ] is what QuantizingParams derives from its sample (quantization_params.h:48-63); the caller supplies it (in-tree:
+	// QuantizingParams over the Map's rows).  Points added later are quantised with the same parameters at the next sync
+	// (addPoint, hnswalg.h:1480-1495).  Streaming and range searches of a quantised Map are not implemented: they throw.
+	void Quantize(float minQ, float maxQ);
+	bool IsQuantized() const noexcept { return quantized_; }
+	bool QuantizationAvailable() const noexcept { return !quantized_; }
+	const Sq8Params& QuantizingParams() const noexcept { return sq8_; }
 
 	VectorMetric Metric() const noexcept { return graph_.Metric(); }
 	size_t Dim() const noexcept { return graph_.Dim(); }
@@ -109,6 +117,10 @@ private:
 	const Synchronization synchronization_;
 	mutable std::atomic<bool> graphDirty_{true};
 	mutable bool deletedDirty_ = false;
+	bool quantized_ = false;
+	Sq8Params sq8_;
+	mutable bool codesDirty_ = false;
+	void attachCodes() const;
 
 	bool coalesce_ = true;
 	mutable std::mutex coMtx_;

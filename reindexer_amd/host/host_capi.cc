@@ -282,6 +282,45 @@ long rxhost_hnsw_search_knn(void* h, const float* q, size_t k, size_t ef, float*
 	});
 	return n;
 }
+// the quantised Map: Quantize(minQ, maxQ), SearchKnn with query_data_norm (hnsw_index.cc:168: normL2 = 1.f / NormalizeCopyVector(...))
+int rxhost_hnsw_quantize(void* h, float minQ, float maxQ) {
+	return guarded([&] { static_cast<GpuHnswMap*>(h)->Quantize(minQ, maxQ); });
+}
+int rxhost_hnsw_is_quantized(void* h) { return static_cast<GpuHnswMap*>(h)->IsQuantized() ? 1 : 0; }
+long rxhost_hnsw_search_knn_norm(void* h, const float* q, int hasNorm, float norm, size_t k, size_t ef, float* outDist, uint64_t* outLabel) {
+	long n = -1;
+	guarded([&] {
+		auto res = static_cast<const GpuHnswMap*>(h)->SearchKnn(q, hasNorm ? std::optional<float>(norm) : std::nullopt, k, ef);
+		n = long(drain(res, outDist, outLabel, k));
+	});
+	return n;
+}
+// Sq8Quantize / Sq8Params (sq8_quantizer.h) for the CPU parity tests against Quantizer::Quantize
+float rxhost_sq8_quantize(int metric, float minQ, float maxQ, size_t dim, const float* from, float scale, uint8_t* to, float* params3) {
+	const Sq8Params p = Sq8Params::FromRange(minQ, maxQ, dim);
+	if (params3) {
+		params3[0] = p.alpha;
+		params3[1] = p.alpha_2;
+		params3[2] = p.delta;
+	}
+	return Sq8Quantize(VectorMetric(metric), p, from, dim, scale, to);
+}
+// n vectors at once (rows of a corpus, or a query batch with one scale per query), split over `threads` host threads
+void rxhost_sq8_quantize_many(int metric, float minQ, float maxQ, size_t dim, const float* from, size_t n, const float* scales, uint8_t* to,
+							  float* corr, unsigned threads) {
+	const Sq8Params p = Sq8Params::FromRange(minQ, maxQ, dim);
+	threads = std::max(1u, std::min<unsigned>(threads ? threads : 1u, unsigned(std::max<size_t>(n / 64, 1))));
+	auto work = [&](size_t a, size_t b) {
+		for (size_t i = a; i < b; ++i) corr[i] = Sq8Quantize(VectorMetric(metric), p, from + i * dim, dim, scales ? scales[i] : 1.f, to + i * dim);
+	};
+	std::vector<std::thread> pool;
+	const size_t per = (n + threads - 1) / threads;
+	for (unsigned t = 1; t < threads; ++t) {
+		if (t * per < n) pool.emplace_back(work, t * per, std::min(n, (t + 1) * per));
+	}
+	work(0, std::min(n, per));
+	for (auto& th : pool) th.join();
+}
 // streaming session, driven like HnswIndexBase<Map>::beginStreaming / continueStreaming (hnsw_index.cc:318-351)
 void* rxhost_hnsw_stream_begin(void* h, const float* q, size_t ef) {
 	StreamingSearchSession* s = nullptr;

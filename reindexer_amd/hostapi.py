@@ -353,6 +353,33 @@ class _KnnStream:
             pass
 
 
+def sq8_quantize(metric: int, min_q: float, max_q: float, vec, scale: float = 1.0):
+    """Sq8Quantize of the host library (sq8_quantizer.h): (codes, corrective offset, (alpha, alpha_2, delta))."""
+    L = lib()
+    L.rxhost_sq8_quantize.restype = _f
+    L.rxhost_sq8_quantize.argtypes = [_i, _f, _f, _sz, _vp, _f, _vp, _vp]
+    v = _f32(vec)
+    to = np.empty(v.shape[0], np.uint8)
+    params = np.zeros(3, np.float32)
+    corr = L.rxhost_sq8_quantize(metric, float(min_q), float(max_q), v.shape[0], v.ctypes.data, float(scale), to.ctypes.data, params.ctypes.data)
+    return to, np.float32(corr), params
+
+
+def sq8_quantize_many(metric: int, min_q: float, max_q: float, vecs, scales=None, threads: int = 0):
+    """(codes [n][dim], corr [n]) of n vectors; scales: one multiplier per vector (the 1 / normCoef of cosine queries)."""
+    import os
+    L = lib()
+    L.rxhost_sq8_quantize_many.restype = None
+    L.rxhost_sq8_quantize_many.argtypes = [_i, _f, _f, _sz, _vp, _sz, _vp, _vp, _vp, C.c_uint]
+    v = np.ascontiguousarray(vecs, np.float32)
+    n, dim = v.shape
+    codes, corr = np.empty((n, dim), np.uint8), np.empty(n, np.float32)
+    sc = None if scales is None else np.ascontiguousarray(scales, np.float32)
+    L.rxhost_sq8_quantize_many(metric, float(min_q), float(max_q), dim, v.ctypes.data, n, None if sc is None else sc.ctypes.data, codes.ctypes.data,
+                               corr.ctypes.data, threads or len(os.sched_getaffinity(0)))
+    return codes, corr
+
+
 class GpuHnswMap:
     """rxgpu::host::GpuHnswMap (drop-in for hnswlib::HierarchicalNSW<Synchronization::None>; multithread=True: <OnInsertions>, the Map of
     the reference's multithreaded index build — add(..., threads=T) then inserts from T threads through AddPointConcurrent)."""
@@ -381,6 +408,10 @@ class GpuHnswMap:
             L.rxhost_hnsw_graph.argtypes = [_vp]
             L.rxhost_hnsw_search_knn.restype = _l
             L.rxhost_hnsw_search_knn.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+            L.rxhost_hnsw_quantize.argtypes = [_vp, _f, _f]
+            L.rxhost_hnsw_is_quantized.argtypes = [_vp]
+            L.rxhost_hnsw_search_knn_norm.restype = _l
+            L.rxhost_hnsw_search_knn_norm.argtypes = [_vp, _vp, _i, _f, _sz, _sz, _vp, _vp]
             L.rxhost_hnsw_search_range.restype = _l
             L.rxhost_hnsw_search_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
             L.rxhost_hnsw_select.restype = _l
@@ -456,6 +487,26 @@ class GpuHnswMap:
         q = _f32(q)
         od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
         n = lib().rxhost_hnsw_search_knn(self.h, q.ctypes.data, k, ef, od.ctypes.data, ol.ctypes.data)
+        if n < 0:
+            _raise()
+        return od[:n].copy(), ol[:n].copy()
+
+    def quantize(self, min_q: float, max_q: float) -> None:
+        """Quantize: from here on searches run over SQ8 codes on the device (HierarchicalNSWImpl<uint8_t>)."""
+        rc = lib().rxhost_hnsw_quantize(self.h, float(min_q), float(max_q))
+        if rc:
+            _raise(rc)
+
+    @property
+    def is_quantized(self) -> bool:
+        return bool(lib().rxhost_hnsw_is_quantized(self.h))
+
+    def search_knn_norm(self, q, k, ef=0, norm=None):
+        """SearchKnn(query, query_data_norm, k, ef): the norm is required by a quantised cosine graph."""
+        q = _f32(q)
+        od, ol = np.empty(max(k, 1), np.float32), np.empty(max(k, 1), np.uint64)
+        n = lib().rxhost_hnsw_search_knn_norm(self.h, q.ctypes.data, int(norm is not None), 0.0 if norm is None else float(norm), k, ef,
+                                              od.ctypes.data, ol.ctypes.data)
         if n < 0:
             _raise()
         return od[:n].copy(), ol[:n].copy()

@@ -174,3 +174,37 @@ def test_quantised_hnsw_search_matches_golden_engine_results(oracle, sq8, metric
     for i, q in enumerate(z[key + "_queries"]):
         gd, gl = oracle_hnsw_search_knn_sq8(oracle, g, sq, q, 10, 32, inv, float(z[key + "_qnorms"][i]) if metric == 2 else None)
         assert np.array_equal(gl, z[key + "_res_label"][i]) and np.array_equal(bits(gd), bits(z[key + "_res_dist"][i])), i
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_host_quantiser_matches_golden_reference_codes(metric):
+    """The PRODUCT quantiser (reindexer_amd/host/sq8_quantizer.h, used by GpuHnswMap::Quantize and for the queries of a quantised Map)
+    against codes, offsets and parameters produced by the real Quantizer (tests/golden/sq8.npz)."""
+    from reindexer_amd.hostapi import sq8_quantize
+    z = np.load(G / "sq8.npz")
+    for d in (8, 100, 768):
+        key = f"q_m{metric}_d{d}"
+        v, (min_q, max_q) = z[key + "_vec"], z[key + "_minmax"]
+        for i, x in enumerate(v):
+            c, o, params = sq8_quantize(metric, float(min_q), float(max_q), x)
+            assert np.array_equal(bits(params), bits(z[key + "_params"]))
+            assert np.array_equal(c, z[key + "_codes"][i]) and bits(o) == bits(z[key + "_corr"][i])
+            c, o, _ = sq8_quantize(metric, float(min_q), float(max_q), x, 1.25)
+            assert np.array_equal(c, z[key + "_qcodes"][i]) and bits(o) == bits(z[key + "_qcorr"][i])
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_host_quantiser_matches_reference_quantizer(sq8ref, metric):
+    from reindexer_amd.hostapi import sq8_quantize
+    rng = np.random.default_rng(metric)
+    for d in (1, 33, 128, 1000):
+        v = rng.normal(0, 0.3, (30, d)).astype(np.float32)
+        v[0], v[1] = 9.0, -9.0
+        min_q, max_q = float(np.quantile(v[2:], 0.01)), float(np.quantile(v[2:], 0.99))
+        pr = sq8ref.params(min_q, max_q, d)
+        for x in v:
+            for scale in (1.0, 0.7, 2.5):
+                c, o, params = sq8_quantize(metric, min_q, max_q, x, scale)
+                rc, ro = sq8ref.quantize(metric, pr, x, scale)
+                assert np.array_equal(c, rc) and bits(o) == bits(ro)
+                assert np.array_equal(bits(params), bits([pr["alpha"], pr["alpha_2"], pr["delta"]]))

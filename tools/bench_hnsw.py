@@ -34,7 +34,7 @@ os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
 from reindexer_amd import capi, hostapi  # noqa: E402
 
 DEFAULTS = dict(rows=1_000_000, dim=768, queries=16384, k=10, ef=128, M=16, efc=200, metric="cosine", cpu_queries=256, clusters=2000,
-                graph=None, save_graph=None, build_threads=0, cpu_threads=0, cpu_per_thread=64, map_legs=True, device=0, out=None, seed=20260924)
+                graph=None, save_graph=None, sq8=True, gpu_only=False, build_threads=0, cpu_threads=0, cpu_per_thread=64, map_legs=True, device=0, out=None, seed=20260924)
 
 
 def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
@@ -59,6 +59,56 @@ def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
     return out
 
 
+def sq8_leg(o, ix, metric, g, queries, qnorms, trow, tq, nq, ncpu, ref_float) -> dict:
+    """the same graph with SQ8 rows.  The reference's own Quantize() (HierarchicalNSWImpl<uint8_t> copy-built from the float
+    engine, sampled minQ / maxQ) produces the codes; the device searches THOSE codes (rxgpu_hnsw_search_knn_sq8) and is compared, labels and
+    distance bits, with the quantised engine's SearchKnn; the queries are quantised by the product's host quantiser."""
+    from oracle import pyoracle
+    t0 = time.perf_counter()
+    hq = pyoracle.RefHnswQ(ref_float, sample_size=20000)
+    sq = hq.export()
+    quant_s = time.perf_counter() - t0
+    glabels = g["labels"]
+    ix.hnsw_attach_sq8(sq["codes"], sq["corr"], float(sq["alpha_2"]))
+    coef = (np.float32(1.0) / qnorms).astype(np.float32) if metric == 2 else np.ones(len(queries), np.float32)
+    scales = (np.float32(1.0) / coef).astype(np.float32)   # prepareData: norm = 1.f / normCoef
+    qcodes, qcorr = hostapi.sq8_quantize_many(metric, float(sq["min_q"]), float(sq["max_q"]), queries, scales if metric == 2 else None)
+    ix.hnsw_search_knn_sq8(qcodes, qcorr, coef, o.k, o.ef)
+    ix.hnsw_read_stats()
+    ix.profile_enable(True)
+    t0 = time.perf_counter()
+    dist, row, cnt = ix.hnsw_search_knn_sq8(qcodes, qcorr, coef, o.k, o.ef)
+    gpu_s = time.perf_counter() - t0
+    launches, kernel_ms = ix.profile_read("hnsw")
+    _, redo_ms = ix.profile_read("hnsw_redo")
+    ix.profile_enable(False)
+    evals, hops = ix.hnsw_read_stats()
+    busy_ms = kernel_ms + redo_ms
+    bytes_algo = evals * (o.dim + 4) + hops * (1 + 2 * g["M"]) * 4
+    recall = float(np.mean([len(set(trow[i].tolist()) & set(row[i, :int(cnt[i])].tolist())) / o.k for i in range(tq)]))
+    t0 = time.perf_counter()
+    same = 0
+    for i in range(nq):
+        wd, wl = hq.search_knn(queries[i], o.k, o.ef, float(qnorms[i]) if metric == 2 else None)
+        c = int(cnt[i])
+        a = np.lexsort((glabels[row[i, :c]], dist[i, :c]))
+        b = np.lexsort((wl, wd))
+        same += int(c == len(wl) and np.array_equal(glabels[row[i, :c]][a], wl[b]) and np.array_equal(dist[i, :c][a].view(np.uint32), wd[b].view(np.uint32)))
+    cpu_s = time.perf_counter() - t0
+    hq.close()
+    return {"gpu": {"queries": len(queries), "queries_per_sec": len(queries) / gpu_s, "kernel_ms_total": kernel_ms, "redo_ms": redo_ms,
+                    "queries_per_sec_kernel_only": len(queries) / (busy_ms / 1e3) if busy_ms else None,
+                    "distance_evals_per_query": evals / len(queries), "hops_per_query": hops / len(queries),
+                    "roofline": {"bound": "hbm", "kernel": "hnsw_search_kernel<sq8>", "achieved": bytes_algo / (busy_ms / 1e3) / 1e9 if busy_ms else None,
+                                 "peak": 8000.0, "unit": "GB/s", "frac": bytes_algo / (busy_ms / 1e3) / 1e9 / 8000.0 if busy_ms else None,
+                                 "algorithmic_bytes": bytes_algo, "note": "bytes = evals*(D+4) + hops*(1+2M)*4"}},
+            "recall_at_k_vs_exact_float": recall,
+            "cpu_baseline": {"kind": "reference", "value": nq / cpu_s, "unit": "queries/s", "cores": 1,
+                             "sample": f"{nq} queries through the reference's quantised engine (python call per query included)"},
+            "equal_to_reference_frac": same / nq, "equal_to_reference_checked": nq,
+            "quantize_seconds_reference": quant_s, "params": {k: float(sq[k]) for k in ("min_q", "max_q", "alpha", "alpha_2", "delta")}}
+
+
 def run(o) -> dict:
     o = SimpleNamespace(**{**DEFAULTS, **(vars(o) if not isinstance(o, dict) else o)})
     metric = capi.METRICS[o.metric]
@@ -70,8 +120,11 @@ def run(o) -> dict:
     corpus = make_clustered(o.rows + o.queries, o.dim, o.clusters, o.seed, o.device)
     rows, queries = corpus[:o.rows], corpus[o.rows:]
     labels = np.arange(o.rows, dtype=np.uint64) << np.uint64(32)
+    qnorms = np.ones(o.queries, np.float32)   # query_data_norm of the Map's SearchKnn (hnsw_index.cc:168): 1.f / NormalizeCopyVector(...)
     if metric == 2:
-        queries = np.stack([hostapi.normalize_copy(q)[0] for q in queries])
+        pairs = [hostapi.normalize_copy(q) for q in queries]
+        queries = np.stack([a for a, _ in pairs])
+        qnorms = (np.float32(1.0) / np.array([b for _, b in pairs], np.float32)).astype(np.float32)
     gen_s = time.perf_counter() - t_all
 
     m = None
@@ -140,6 +193,11 @@ def run(o) -> dict:
         "recall_at_k_vs_exact": recall, "recall_queries": tq,
     }
 
+    if o.gpu_only:
+        out["leg_seconds"] = time.perf_counter() - t_all
+        ix.close()
+        return out
+
     if m is not None and o.map_legs:
         t0 = time.perf_counter()
         for q in queries[:32]:
@@ -183,6 +241,8 @@ def run(o) -> dict:
                                                  "note": "T threads, one query each at a time over the shared index; thread start outside the timed region"}}
             out["equal_to_reference_frac"] = same / nq
             out["equal_to_reference_checked"] = nq
+            if o.sq8:
+                out["sq8"] = sq8_leg(o, ix, metric, g, queries, qnorms, trow, tq, nq, ncpu, ref_float=r)
             r.close()
         else:
             from oracle.pyoracle import Oracle, oracle_hnsw_search_knn
@@ -207,6 +267,10 @@ def main():
     for k, v in DEFAULTS.items():
         if k == "map_legs":
             ap.add_argument("--no-map-legs", dest="map_legs", action="store_false")
+        elif k == "gpu_only":
+            ap.add_argument("--gpu-only", dest="gpu_only", action="store_true", help="stop after the GPU search (rocprof passes)")
+        elif k == "sq8":
+            ap.add_argument("--no-sq8", dest="sq8", action="store_false")
         elif v is None or isinstance(v, str):
             ap.add_argument("--" + k.replace("_", "-"), default=v)
         else:
