@@ -195,7 +195,8 @@ int rxgpu_hnsw_patch_graph(rxgpu_index* h, uint32_t n_dirty, const uint32_t* dir
 /* MarkDelete mirror (hnswalg.h:1303-1339): refresh only the flags. */
 int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t num_deleted);
 
-/* SearchKnn for nq queries (host in/out).  ef == 0 means k*3/2 like the engine (hnswalg.h:1995); ef <= 1024.
+/* SearchKnn for nq queries (host in/out).  ef == 0 means k*3/2 like the engine (hnswalg.h:1995); ef <= 4096
+ * (RXGPU_ERR_PARAMS above that; from ef = 1025 on the candidate heap lives in global scratch instead of LDS).
  * Writes, per query, the members of the reference's top_candidates after trimming to k (UNORDERED: the Map pushes them into the
  * (dist,label) result heap exactly as hnswalg.h:2002-2010 does): out_dist/out_row [nq][k], out_count[q] <= k.
  * The traversal replays the reference's heaps step for step, so on the same graph the sets are identical. */

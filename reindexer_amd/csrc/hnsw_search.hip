@@ -160,6 +160,78 @@ __device__ __forceinline__ void batch_distances_sq8(const HnswParams& p, const u
 	}
 }
 
+// dim == 64*NB, SQ8: 16-byte loads.  Lane m of the row's 16-lane group reads bytes [256 i + 16 m, + 16) of load i: block 4 i + (m >> 2),
+// bytes 16 (m & 3) .. + 16 of it, i.e. the element pairs of reference lanes j = 8 (m & 1) + p, p = 0 .. 7 (pair p = halfword p of the 16
+// bytes) — in the low half of the block for (m & 3) < 2, in the high half above; both halves feed the same reference lane.  Eight integer
+// accumulators a lane, over all blocks (the reference's lanes accumulate over all blocks too); a transpose-reduction over the eight lanes
+// of equal parity (xor 2, 4, 8: 7 exchanges) leaves reference lane j's sum on lane (j >> 3) + 2 ((j >> 2) & 1) + 4 ((j >> 1) & 1) + 8 (j & 1),
+// and the 16 sums are then added as floats in the reference's order j = 0 .. 15.  L2: (a - b)^2 = a^2 - 2ab + b^2 per pair, exact in
+// uint32; the query's b^2 share (qq) is computed once a search.  The query words and qq live in registers for the whole search.
+template <int kMetric, int NB>
+__device__ __forceinline__ void batch_distances_sq8_fixed(const HnswParams& p, const uint4 (&qw)[(NB + 3) / 4], const uint32_t (&qq)[8], float qcorr,
+														  float qnorm, const uint32_t* ids, int cnt, float* dists, int lane) {
+	constexpr int L = (NB + 3) / 4;
+	const int m = lane & 15, g = lane >> 4;
+	const int group_base = lane & ~15;
+	for (int base = 0; base < cnt; base += kRowsPerWave) {
+		const int idx = base + g;
+		const bool ok = idx < cnt;
+		const uint64_t row = ids[ok ? idx : base];
+		const uint4* r = reinterpret_cast<const uint4*>(p.codes + row * uint64_t(64 * NB));
+		uint4 a[L];
+#pragma unroll
+		for (int i = 0; i < L; ++i) {
+			if (256 * i + 256 <= 64 * NB || 256 * i + 16 * m < 64 * NB) {
+				a[i] = r[16 * i + m];
+			} else {
+				a[i] = make_uint4(0u, 0u, 0u, 0u);
+			}
+		}
+		uint32_t ab[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}, aa[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+		for (int i = 0; i < L; ++i) {
+			const uint32_t aw[4] = {a[i].x, a[i].y, a[i].z, a[i].w};
+			const uint32_t bw[4] = {qw[i].x, qw[i].y, qw[i].z, qw[i].w};
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				const uint32_t lo = aw[c] & 0x0000FFFFu, hi = aw[c] & 0xFFFF0000u;
+				ab[2 * c] = __builtin_amdgcn_udot4(lo, bw[c], ab[2 * c], false);
+				ab[2 * c + 1] = __builtin_amdgcn_udot4(hi, bw[c], ab[2 * c + 1], false);
+				if constexpr (kMetric == kL2) {
+					aa[2 * c] = __builtin_amdgcn_udot4(lo, aw[c], aa[2 * c], false);
+					aa[2 * c + 1] = __builtin_amdgcn_udot4(hi, aw[c], aa[2 * c + 1], false);
+				}
+			}
+		}
+		uint32_t s8[8];
+#pragma unroll
+		for (int q = 0; q < 8; ++q) s8[q] = kMetric == kL2 ? aa[q] + qq[q] - 2u * ab[q] : ab[q];
+		const bool up1 = (m & 2) != 0, up2 = (m & 4) != 0, up3 = (m & 8) != 0;
+		uint32_t t4[4], t2[2];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) t4[q] = (up1 ? s8[q + 4] : s8[q]) + uint32_t(__shfl_xor(int(up1 ? s8[q] : s8[q + 4]), 2, 64));
+#pragma unroll
+		for (int q = 0; q < 2; ++q) t2[q] = (up2 ? t4[q + 2] : t4[q]) + uint32_t(__shfl_xor(int(up2 ? t4[q] : t4[q + 2]), 4, 64));
+		const uint32_t mine = (up3 ? t2[1] : t2[0]) + uint32_t(__shfl_xor(int(up3 ? t2[0] : t2[1]), 8, 64));
+		float result = 0.f;
+#pragma unroll
+		for (int j = 0; j < 16; ++j) {   // result += (float)lane[j], j = 0 .. 15
+			const int holder = (j >> 3) + 2 * ((j >> 2) & 1) + 4 * ((j >> 1) & 1) + 8 * (j & 1);
+			result += float(uint32_t(__shfl(int(mine), group_base + holder, 64)));
+		}
+		result = result + 0.f;   // + (float)tail, tail == 0: dim is a multiple of 64 (x + 0.f == x for every x the sum can take)
+		float dist;
+		if constexpr (kMetric == kL2) {
+			dist = p.alpha2 * result + qcorr + p.corr[row];
+		} else {
+			dist = -(p.alpha2 * result + qcorr + p.corr[row]);
+			if constexpr (kMetric == kCos) dist *= p.inv_norms[row];
+		}
+		dist = qnorm * dist;
+		if (ok && m == 0) dists[idx] = dist;
+	}
+}
+
 // dim == 64*NB: the query fragment lives in registers and the NB 16-byte loads of EIGHT rows (two per 16-lane group) are
 // issued before the first reduction — one HBM round trip per 8 neighbours instead of three per 4.
 // kQLds: the query fragment is re-read from LDS (ds_read_b128) instead of living in NB*4 VGPRs — 48 fewer registers at D = 768, which is
@@ -216,7 +288,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	uint32_t* top_i = reinterpret_cast<uint32_t*>(top_d + p.ef_cap);
 	float* lcand_d = reinterpret_cast<float*>(top_i + p.ef_cap);
 	uint32_t* lcand_i = reinterpret_cast<uint32_t*>(lcand_d + (kGlobalCand ? 0 : p.lds_cand_cap));
-	constexpr bool kQLds = NB > 0;   // fixed dims: query fragment in LDS behind the heaps (16-byte aligned: every part is a multiple of 64 entries)
+	constexpr bool kQLds = NB > 0 && !kSq8;   // fixed dims: query fragment in LDS behind the heaps (16-byte aligned: every part is a multiple of 64 entries)
 	float4* q_s = reinterpret_cast<float4*>(lcand_i + (kGlobalCand ? 0 : p.lds_cand_cap));
 	__shared__ uint32_t nb_id[kHnswMaxNeighbors];
 	__shared__ float nb_d[kHnswMaxNeighbors];
@@ -234,13 +306,34 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	const uint64_t cand_cap = kGlobalCand ? p.gcand_cap : uint64_t(p.lds_cand_cap);
 	unsigned long long ndist = 0, hops = 0;
 	float4 qreg[1];
-	if constexpr (NB > 0) {
+	constexpr int kSqL = (kSq8 && NB > 0) ? (NB + 3) / 4 : 1;
+	uint4 sq_q[kSqL];
+	uint32_t sq_qq[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	if constexpr (kSq8 && NB > 0) {
+		const uint4* qp = reinterpret_cast<const uint4*>(p.qcodes + size_t(qi) * p.dim);
+		const int m = lane & 15;
+#pragma unroll
+		for (int i = 0; i < kSqL; ++i) {
+			sq_q[i] = (256 * i + 16 * m < 64 * NB) ? qp[16 * i + m] : make_uint4(0u, 0u, 0u, 0u);
+			if constexpr (kMetric == kL2) {
+				const uint32_t bw[4] = {sq_q[i].x, sq_q[i].y, sq_q[i].z, sq_q[i].w};
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					sq_qq[2 * c] = __builtin_amdgcn_udot4(bw[c] & 0x0000FFFFu, bw[c], sq_qq[2 * c], false);
+					sq_qq[2 * c + 1] = __builtin_amdgcn_udot4(bw[c] & 0xFFFF0000u, bw[c], sq_qq[2 * c + 1], false);
+				}
+			}
+		}
+	}
+	if constexpr (NB > 0 && !kSq8) {
 		const float4* qp = reinterpret_cast<const float4*>(q);
 		for (int i = lane; i < NB * 16; i += 64) q_s[i] = qp[i];
 		__syncthreads();
 	}
 	auto distances = [&](const uint32_t* ids, int cnt, float* dists) {
-		if constexpr (kSq8) {
+		if constexpr (kSq8 && NB > 0) {
+			batch_distances_sq8_fixed<kMetric, NB>(p, sq_q, sq_qq, p.qcorr[qi], p.qnorm[qi], ids, cnt, dists, lane);
+		} else if constexpr (kSq8) {
 			batch_distances_sq8<kMetric>(p, p.qcodes + size_t(qi) * p.dim, p.qcorr[qi], p.qnorm[qi], ids, cnt, dists, lane);
 		} else if constexpr (NB > 0) {
 			batch_distances_fixed<kMetric, NB, kQLds, (kLatency || NB <= 8)>(p, qreg, q_s, ids, cnt, dists, lane);
@@ -417,13 +510,26 @@ static void launch_hnsw_mode(int metric, const HnswParams& p, uint32_t blocks, h
 	}
 }
 
-template <bool kGlobalCand>
-static void launch_hnsw_sq8(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
+template <bool kGlobalCand, int NB>
+static void launch_hnsw_sq8_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
 	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8;
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, 0, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
-		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, 0, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
-		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, 0, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+	}
+}
+
+template <bool kGlobalCand>
+static void launch_hnsw_sq8(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
+	switch (p.dim) {   // the embedding sizes in use get the 16-byte-load form; any other dim the generic one
+		case 128: launch_hnsw_sq8_nb<kGlobalCand, 2>(metric, p, blocks, s); break;
+		case 384: launch_hnsw_sq8_nb<kGlobalCand, 6>(metric, p, blocks, s); break;
+		case 512: launch_hnsw_sq8_nb<kGlobalCand, 8>(metric, p, blocks, s); break;
+		case 768: launch_hnsw_sq8_nb<kGlobalCand, 12>(metric, p, blocks, s); break;
+		case 1024: launch_hnsw_sq8_nb<kGlobalCand, 16>(metric, p, blocks, s); break;
+		case 1536: launch_hnsw_sq8_nb<kGlobalCand, 24>(metric, p, blocks, s); break;
+		default: launch_hnsw_sq8_nb<kGlobalCand, 0>(metric, p, blocks, s); break;
 	}
 }
 

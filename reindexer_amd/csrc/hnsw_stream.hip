@@ -384,12 +384,8 @@ void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, ui
 	const size_t lds_bytes = lds ? size_t(2 * kStreamLdsTop + 2 * kStreamLdsExt + kStreamLdsCand) * 8 : 0;
 #define RX_STREAM(M, L)                                                                                                      \
 	do {                                                                                                                     \
-		static bool attr_set = false;                                                                                        \
-		if (L && !attr_set) {                                                                                                \
-			(void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hnsw_stream_kernel<M, L>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-									  int(lds_bytes));                                                                       \
-			attr_set = true;                                                                                                 \
-		}                                                                                                                    \
+		static std::atomic<uint64_t> raised{0};                                                                              \
+		if (L) (void)raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&hnsw_stream_kernel<M, L>), lds_bytes);     \
 		hipLaunchKernelGGL((hnsw_stream_kernel<M, L>), dim3(1), dim3(64), lds_bytes, st, p, s, batch, mode);                  \
 	} while (0)
 	if (lds) {

@@ -344,13 +344,8 @@ template <int kMetric, int MT, int kMode>
 static hipError_t launch_gemm_one(const GemmParams& p, uint32_t grid, hipStream_t s) {
 	constexpr int QS = MT >= 128 ? 2 : 1;
 	const size_t lds = gemm_lds_bytes(MT);
-	static bool attr_set = false;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm<kMetric, MT, kMode, QS>),
-										   hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-		if (e != hipSuccess) return e;
-		attr_set = true;
-	}
+	static std::atomic<uint64_t> raised{0};
+	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&knn_gemm<kMetric, MT, kMode, QS>), lds); e != hipSuccess) return e;
 	hipLaunchKernelGGL((knn_gemm<kMetric, MT, kMode, QS>), dim3(grid), dim3(kGemmThreads * QS), lds, s, p);
 	return hipGetLastError();
 }

@@ -251,11 +251,9 @@ size_t gemm_bf16_glds_lds_bytes(int qt) { return size_t(gl_bufs(qt)) * (kGlXElem
 template <int kMetric, int kMode, int QT>
 static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
 	const size_t lds = gemm_bf16_glds_lds_bytes(QT);
-	static bool attr_set = false;
-	if (!attr_set) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_gemm_bf16_glds<kMetric, kMode, QT>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-		if (e != hipSuccess) return e;
-		attr_set = true;
+	static std::atomic<uint64_t> raised{0};
+	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&knn_gemm_bf16_glds<kMetric, kMode, QT>), lds); e != hipSuccess) {
+		return e;
 	}
 	hipLaunchKernelGGL((knn_gemm_bf16_glds<kMetric, kMode, QT>), dim3(grid), dim3(kBfThreads), lds, s, p);
 	return hipGetLastError();

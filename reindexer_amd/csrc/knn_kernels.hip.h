@@ -18,7 +18,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace rxgpu {
+
+// hipFuncSetAttribute acts on the CURRENT device, and launch helpers are entered from several host threads (sharded indexes run one worker
+// per device): the "already raised" flag is one bit per device ordinal, set only after the call succeeded.
+inline hipError_t raise_dynamic_lds_once(std::atomic<uint64_t>& done_mask, const void* kernel, size_t bytes) {
+	int dev = 0;
+	if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+	const uint64_t bit = 1ull << (unsigned(dev) & 63u);
+	if (done_mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+	if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes)); e != hipSuccess) return e;
+	done_mask.fetch_or(bit, std::memory_order_release);
+	return hipSuccess;
+}
 
 constexpr int kWave = 64;
 constexpr int kGroup = 16;            // lanes per row
@@ -91,7 +105,8 @@ struct GemmBf16Params {
 	uint32_t cap;
 };
 
-constexpr int kHnswMaxEf = 1024;        // result-heap capacity in LDS
+constexpr int kHnswMaxEf = 4096;        // result-heap capacity in LDS (above kHnswLdsCandEf the candidate heap lives in global scratch)
+constexpr int kHnswLdsCandEf = 1024;    // largest ef whose candidate heap is tried in LDS first
 constexpr int kHnswCandLds = 2048;      // candidate-heap capacity in LDS
 constexpr int kHnswMaxNeighbors = 128;  // 2*M <= 128
 constexpr uint32_t kHnswOverflow = 0xFFFFFFFFu;

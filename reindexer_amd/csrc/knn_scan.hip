@@ -622,7 +622,7 @@ template <int kMetric>
 __global__ __launch_bounds__(256) void knn_distances(const float* rows, const float* inv_norms, const float* query, uint32_t stride,
 													uint32_t dim, const uint32_t* ids, uint32_t n, float* out) {
 	const int lane = threadIdx.x & 63, m = lane & 15;
-	const uint32_t item = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+	const uint32_t item = blockIdx.x * (256u / kGroup) + (threadIdx.x >> 4);   // 16 rows a block: no 32-bit thread-index product (n up to 2^32 - 1)
 	const uint32_t itemc = item < n ? item : n - 1;
 	const uint64_t row = ids[itemc];
 	const float sum = group_distance_generic<kMetric>(rows + row * stride, query, dim, m);
@@ -837,7 +837,7 @@ void launch_range_subset(int metric, const float* rows, const float* inv_norms, 
 
 void launch_distances(int metric, const float* rows, const float* inv_norms, const float* query, uint32_t stride, uint32_t dim,
 					  const uint32_t* ids, uint32_t n, float* out, hipStream_t s) {
-	const uint32_t blocks = (n * kGroup + 255) / 256;
+	const uint32_t blocks = uint32_t((uint64_t(n) * kGroup + 255) / 256);   // 64-bit product: n * 16 wraps from 2^28 rows on
 	switch (metric) {
 		case kL2: hipLaunchKernelGGL((knn_distances<kL2>), dim3(blocks), dim3(256), 0, s, rows, inv_norms, query, stride, dim, ids, n, out); break;
 		case kIP: hipLaunchKernelGGL((knn_distances<kIP>), dim3(blocks), dim3(256), 0, s, rows, inv_norms, query, stride, dim, ids, n, out); break;

@@ -1485,7 +1485,9 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	k = uint32_t(std::min<uint64_t>(k, h->count));
 	if (!ef) ef = k * 3 / 2;                                        // hnswalg.h:1995
 	if (!ef) ef = 1;
-	RX_CHECK(ef <= uint32_t(rxgpu::kHnswMaxEf), RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: ef must be <= 1024 on the GPU engine");
+	RX_CHECK(ef <= uint32_t(rxgpu::kHnswMaxEf), RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: ef must be <= 4096 on the GPU engine");
+	// ef > 1024: the result heap alone takes the LDS budget of a search — the candidate heap goes to global scratch from the start
+	const bool big_ef = ef > uint32_t(rxgpu::kHnswLdsCandEf);
 	DeviceGuard dg(h->device);
 	rxgpu_search_ctx* c = acquire_ctx(h);
 	if (!c) return RXGPU_ERR_DEVICE;
@@ -1547,31 +1549,36 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	if (const char* e = getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // test hook: force the global-heap re-run
 		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, atoi(e))));
 	}
-	for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(max_slots)) {
-		const uint32_t cq = uint32_t(std::min<uint64_t>(max_slots, nq - q0));
-		if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
-		RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
-		rxgpu::HnswParams pc = p;
-		pc.queries = static_cast<const float*>(c->d_queries.ptr) + size_t(q0) * h->dim;
-		if (sq8) {
-			pc.qcodes = p.qcodes + size_t(q0) * h->dim;
-			pc.qcorr = p.qcorr + q0;
-			pc.qnorm = p.qnorm + q0;
-		}
-		pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
-		pc.out_dist = p.out_dist + size_t(q0) * k;
-		pc.out_row = p.out_row + size_t(q0) * k;
-		pc.out_count = p.out_count + q0;
-		ProfileScope ps(h, "hnsw", c->stream);
-		rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
-	}
-	RX_HIP(hipGetLastError());
-	RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-	RX_HIP(hipStreamSynchronize(c->stream));
-	// queries whose candidate heap outgrew LDS: re-run with the heap in global scratch (bounded by one entry per node)
 	std::vector<uint32_t> redo;
-	for (uint32_t q = 0; q < nq; ++q) {
-		if (out_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
+	if (big_ef) {
+		redo.resize(nq);
+		for (uint32_t q = 0; q < nq; ++q) redo[q] = q;
+	} else {
+		for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(max_slots)) {
+			const uint32_t cq = uint32_t(std::min<uint64_t>(max_slots, nq - q0));
+			if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
+			RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+			rxgpu::HnswParams pc = p;
+			pc.queries = static_cast<const float*>(c->d_queries.ptr) + size_t(q0) * h->dim;
+			if (sq8) {
+				pc.qcodes = p.qcodes + size_t(q0) * h->dim;
+				pc.qcorr = p.qcorr + q0;
+				pc.qnorm = p.qnorm + q0;
+			}
+			pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
+			pc.out_dist = p.out_dist + size_t(q0) * k;
+			pc.out_row = p.out_row + size_t(q0) * k;
+			pc.out_count = p.out_count + q0;
+			ProfileScope ps(h, "hnsw", c->stream);
+			rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
+		}
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));
+		// queries whose candidate heap outgrew LDS: re-run with the heap in global scratch (bounded by one entry per node)
+		for (uint32_t q = 0; q < nq; ++q) {
+			if (out_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
+		}
 	}
 	if (!redo.empty()) {
 		const uint64_t gcap = h->count + 1;

@@ -316,7 +316,7 @@ SearchResultQueue GpuHnswMap::SearchRange(const float* queryDataRaw, std::option
 	if (n == 0) return result;
 	if (quantized_) throw std::runtime_error("SearchRange: not implemented for a quantised GPU graph");
 	syncDevice();
-	const size_t efEff = std::max<size_t>(1, std::min<size_t>(ef ? ef : 1, 1024));
+	const size_t efEff = ef ? ef : 1;   // no clamp: an ef beyond the device engine's limit (4096) is an error from the C-ABI, never a silently smaller search
 	const size_t kk = std::min(efEff, n);
 	std::vector<float> dist(kk);
 	std::vector<uint32_t> row(kk);

@@ -366,3 +366,28 @@ def test_interleaved_upserts_patch_the_device_graph_in_place(rxgpu, oracle, metr
         check(step)
     assert m.count <= n0 + 200
     m.close()
+
+
+def test_large_ef_runs_with_global_candidate_heap(rxgpu, oracle):
+    """1024 < ef <= 4096: the result heap takes the LDS, the candidate heap lives in global scratch from the start — same answers as the
+    restated engine; beyond 4096 the C-ABI refuses (no silent clamp anywhere, SearchRange included)."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    from reindexer_amd import hostapi
+    n, d = 6000, 48
+    rows = make_corpus(47, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    m = hostapi.GpuHnswMap(0, d, n, M=12, ef_construction=100)
+    m.add(rows, labels)
+    g = m.export_graph()
+    g["vectors"] = rows
+    for qi in range(6):
+        q = make_corpus(800 + qi, 1, d)[0]
+        for k, ef in ((10, 1025), (1500, 3000), (100, 4096)):
+            wd, wl = oracle_hnsw_search_knn(oracle, g, q, k, ef)
+            gd, gl = m.search_knn(q, k, ef)
+            assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd)), (qi, k, ef)
+    with pytest.raises(RuntimeError, match="4096"):
+        m.search_knn(rows[0], 10, 5000)
+    with pytest.raises(RuntimeError):
+        m.search_range(rows[0], 1.0, 5000)
+    m.close()

@@ -72,7 +72,7 @@ def _clique(n, M=16):
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])
-@pytest.mark.parametrize("d", [1, 2, 3, 31, 63, 64, 65, 100, 127, 128, 130, 257, 768, 1000, 1536, 4096])
+@pytest.mark.parametrize("d", [1, 2, 3, 31, 63, 64, 65, 100, 127, 128, 130, 257, 384, 512, 768, 1000, 1024, 1536, 4096])
 def test_sq8_distance_bits_all_dims(rxgpu, oracle, sq8, metric, d):
     """Every distance of the device equals DistCalculator<uint8_t>::operator()(query, row, id) bit for bit — ragged dims (tails, rows that
     do not start on a word boundary), saturated codes (sums beyond 2^24, where the float reduction order shows) and narrow ranges."""
