@@ -282,7 +282,9 @@ static int cmp_i32(const void* a, const void* b) {
  *   NeedSort: ids inside runs of exactly equal rank are sorted ascending (:239-257, 274-276);
  *   IsArray: duplicates of a rowId are dropped keeping the first = best (float_vector_index.h:140-160);
  *   k AND radius both given: truncate to k (removeOverK, :193-203).
- * Returns the number of (id, rank) pairs written. */
+ * Returns the number of (id, rank) pairs written.
+ * PARITY PINNED: tests/test_select_pin.py runs it against the reference's HnswIndexBase<BruteforceSearch>::select compiled in place
+ * (oracle/_ref/libref_select.so, oracle/ref/ref_select_shim.cc). */
 size_t orc_select_postprocess(int metric, const float* dist, const uint64_t* label, size_t n, int need_sort, int is_array,
 							  int has_k, size_t k, int has_radius, int32_t* out_ids, float* out_ranks) {
 	if (n == 0) return 0;

@@ -1061,3 +1061,60 @@ def ref_rank_or_none():
         return RefRank()
     except (FileNotFoundError, OSError):
         return None
+
+
+# ---------------------------------------------------------------------------------------------------- the reference's select post-processing
+REF_SELECT_SO = HERE / "_ref" / "libref_select.so"
+
+
+class RefSelect:
+    """_ref/libref_select.so (oracle/ref/ref_select_shim.cc): HnswIndexBase<BruteforceSearch>::select / selectRaw of the reference over its own
+    brute-force map."""
+
+    def __init__(self, metric: int, dim: int, max_elements: int, is_array: bool = False, index_radius=None):
+        if not REF_SELECT_SO.exists():
+            raise FileNotFoundError(REF_SELECT_SO)
+        L = self.L = C.CDLL(str(REF_SELECT_SO))
+        L.ref_select_create.restype = _vp
+        L.ref_select_create.argtypes = [_i, _sz, _sz, _i, _i, _f]
+        L.ref_select_destroy.argtypes = [_vp]
+        L.ref_select_add.argtypes = [_vp, _vp, _sz, _vp]
+        L.ref_select.restype = C.c_long
+        L.ref_select.argtypes = [_vp, _vp, C.c_long, _i, _f, _i, _vp, _vp, _sz]
+        L.ref_select_raw.restype = C.c_long
+        L.ref_select_raw.argtypes = [_vp, _vp, C.c_long, _i, _f, _vp, _vp, _sz]
+        self.dim = dim
+        self.h = L.ref_select_create(metric, dim, max_elements, int(is_array), int(index_radius is not None),
+                                     0.0 if index_radius is None else index_radius)
+
+    def close(self):
+        if self.h:
+            self.L.ref_select_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def add(self, vecs, labels):
+        v, lab = _f32(vecs), np.ascontiguousarray(labels, np.uint64)
+        self.L.ref_select_add(self.h, v.ctypes.data, v.shape[0], lab.ctypes.data)
+
+    def select(self, key, k=None, radius=None, need_sort=True, cap=1 << 20):
+        key = _f32(key)
+        ids, ranks = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        n = self.L.ref_select(self.h, key.ctypes.data, -1 if k is None else k, int(radius is not None), 0.0 if radius is None else radius,
+                              int(need_sort), ids.ctypes.data, ranks.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError("ref_select: ids / ranks size mismatch")
+        return ids[:n].copy(), ranks[:n].copy()
+
+    def select_raw(self, key, k=None, radius=None, cap=1 << 20):
+        key = _f32(key)
+        ids, ranks = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        n = self.L.ref_select_raw(self.h, key.ctypes.data, -1 if k is None else k, int(radius is not None), 0.0 if radius is None else radius,
+                                  ids.ctypes.data, ranks.ctypes.data, cap)
+        return ids[:n].copy(), ranks[:n].copy()
+
+
+def ref_select_available() -> bool:
+    return REF_SELECT_SO.exists()

@@ -119,6 +119,46 @@ long rxhost_bf_search_range(void* h, const float* q, float radius, float* outDis
 	return n;
 }
 // HnswIndexBase::select through the Map: k < 0 => no k, has_radius == 0 => no radius.  Returns count or -1.
+// KnnSelect over a GIVEN search result (what the Map's SearchKnn / SearchRange returned): the host post-processing alone, so that it can be
+// checked on CPU against the reference's HnswIndexBase::select (tests/test_select_pin.py)
+namespace {
+struct FixedResultMap {
+	VectorMetric metric;
+	size_t dim;
+	const float* dist;
+	const uint64_t* label;
+	size_t n;
+	VectorMetric Metric() const noexcept { return metric; }
+	size_t Dim() const noexcept { return dim; }
+	SearchResultQueue fill() const {
+		SearchResultQueue q;
+		for (size_t i = 0; i < n; ++i) q.emplace(dist[i], label[i]);
+		return q;
+	}
+	SearchResultQueue SearchKnn(const float*, std::optional<float>, size_t, size_t) const { return fill(); }
+	SearchResultQueue SearchRange(const float*, std::optional<float>, float, size_t) const { return fill(); }
+};
+}  // namespace
+long rxhost_select_postprocess(int metric, const float* dist, const uint64_t* label, size_t n, long k, int has_radius, int need_sort, int is_array,
+							   int raw, int32_t* outIds, float* outRanks) {
+	long cnt = -1;
+	guarded([&] {
+		const FixedResultMap map{VectorMetric(metric), 1, dist, label, n};
+		KnnSearchParams p;
+		if (k >= 0) p.k = size_t(k);
+		if (has_radius) p.radius = 0.f;   // only its presence matters after the search (removeOverK)
+		const float key = 1.f;
+		auto res = raw ? KnnSelectRaw(map, ConstFloatVectorView(&key, 1), p, is_array != 0)
+					   : KnnSelect(map, ConstFloatVectorView(&key, 1), p, need_sort != 0, is_array != 0);
+		cnt = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size(); ++i) {
+			outIds[i] = res.ids[i];
+			outRanks[i] = res.ranks[i];
+		}
+	});
+	return cnt;
+}
+
 long rxhost_bf_select(void* h, const float* key, size_t dim, long k, int has_radius, float radius, int need_sort, int is_array,
 					  int32_t* outIds, float* outRanks, size_t cap) {
 	long n = -1;

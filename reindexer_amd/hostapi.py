@@ -353,6 +353,21 @@ class _KnnStream:
             pass
 
 
+def select_postprocess(metric: int, dist, label, k=None, has_radius=False, need_sort=True, is_array=False, raw=False):
+    """KnnSelect / KnnSelectRaw (host/knn_select.h) applied to a given Map search result: (ids, ranks)."""
+    L = lib()
+    L.rxhost_select_postprocess.restype = _l
+    L.rxhost_select_postprocess.argtypes = [_i, _vp, _vp, _sz, _l, _i, _i, _i, _i, _vp, _vp]
+    d = _f32(dist)
+    lab = np.ascontiguousarray(label, np.uint64)
+    ids, ranks = np.empty(max(d.shape[0], 1), np.int32), np.empty(max(d.shape[0], 1), np.float32)
+    n = L.rxhost_select_postprocess(metric, d.ctypes.data, lab.ctypes.data, d.shape[0], -1 if k is None else k, int(has_radius), int(need_sort),
+                                    int(is_array), int(raw), ids.ctypes.data, ranks.ctypes.data)
+    if n < 0:
+        _raise()
+    return ids[:n].copy(), ranks[:n].copy()
+
+
 def sq8_quantize(metric: int, min_q: float, max_q: float, vec, scale: float = 1.0):
     """Sq8Quantize of the host library (sq8_quantizer.h): (codes, corrective offset, (alpha, alpha_2, delta))."""
     L = lib()
