@@ -14,27 +14,34 @@
 //    device-scope atomics: 140 us for a 3 x 3 query; atomics on random addresses resolve past the per-XCD L2s at ~28 G/s.)
 //  * admission (addDoc until maxMergedDocs, merger.h:161-180): a document is added by its first posting (in global posting order) that is
 //    eligible and has a non-zero rank; it gets the next merge slot if fewer than maxMergedDocs documents were added before it, and once the
-//    limit is hit nothing is added any more.  `first posting` = atomicMin of the global posting index per document; `slot` = ORDERED prefix
-//    count over those postings (per-workgroup counts, then every workgroup sums its predecessors), cut at maxMergedDocs
-//    ->  ft_rank_all + ft_count_adders + ft_assign_slots.
+//    limit is hit nothing is added any more.  Global posting order is (sub-term row, document) — every list ascends by document — so the
+//    slot of a document is  #documents first met in an earlier row  +  #documents first met in the same row with a smaller id.
+//    ft_rank_all ranks every eligible posting (calcTermRank) and drops the survivors (rank != 0; ~1 % after a preselect) into per-document-
+//    range buckets; ft_adders, one workgroup per range of 8192 documents, finds every document's first row (16-bit minimum in LDS) and
+//    counts them per (row, range); the last workgroup turns that small table into its exclusive prefix in row-major order = the slot bases.
+//    (The first cuts ran this posting-side: an atomicMin table over all documents plus three passes over ALL postings — count, ordered
+//    prefix, scatter — 45 us of a 128 us merge, each pass bound by its dependent gathers, not by bytes.)
 //  * per-document state (`proc -= rank; proc += finalRank` on every strict improvement, switchToNextWord between terms, termsCounter):
-//    a document meets at most one posting per sub-term, so its postings are scattered into a per-slot row indexed by sub-term
-//    (ft_scatter: unique cells, no atomics) and ONE thread per merged document replays its row in sub-term order with the reference's
-//    float operations (ft_replay)  ->  same bits.
-//  * preselect ties at the threshold score are kept in document order: ordered prefix again (ft_preselect_apply).
+//    a document meets at most one posting per sub-term and all its postings sit in ONE bucket, so ft_finish — again one workgroup per
+//    range — sorts the range's first postings by (row, document) in LDS, adds the slot bases, drops the range's survivors into a per-slot
+//    row indexed by sub-term and, behind a workgroup barrier, replays each of its documents in sub-term order with the reference's float
+//    operations  ->  same bits.
+//  * preselect ties at the threshold score are kept in document order: ordered prefix (ft_preselect_apply).
 //
-// Launch train of a multi-term query: ft_init, ft_ranges, [ft_preselect_pick, ft_preselect_apply], ft_rank_all, ft_count_adders,
-// ft_assign_slots, ft_scatter, ft_replay; the 2-phase gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result
-// leaves in one packed buffer.  A Simple() query: ft_init, ft_ranges (mask only), ft_rank_all, ft_count_adders, ft_assign_slots, ft_scatter, ft_replay.
+// Launch train of a multi-term query: ft_ranges, [ft_preselect_pick, ft_preselect_apply], ft_rank_all, ft_adders, ft_finish; the 2-phase
+// gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result leaves in one packed buffer.  A Simple() query:
+// ft_ranges (mask only), ft_rank_all, ft_adders, ft_finish.  No fill kernel: the tables a merge reads before it writes (histogram,
+// bucket counters, look-back and synchronisation words) are handed back ZEROED by the merge that used them (ft_adders / ft_finish).
 //
 // Bound: HBM gathers: per posting 4 B doc + 8 B entry offsets + 9 B per (field, tf, firstPos) entry streamed, 4 B
-// words-in-field + the mask word gathered, 5 B rank/field written and read back, 4 B atomicMin on the first-posting table.
+// words-in-field + the mask word gathered; 16 B per surviving posting written and read back.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <algorithm>
 
 #include "rxgpu_internal.h"
+#include "knn_kernels.hip.h"
 #include "ft_rank.hip.h"
 
 namespace rxgpu {
@@ -43,7 +50,6 @@ namespace {
 
 constexpr unsigned long long kLbPrefix = 1ull << 63;
 constexpr unsigned long long kLbAggregate = 1ull << 62;
-constexpr uint32_t kNoPosting = 0xFFFFFFFFu;
 constexpr int kFtApplyWords = 4;   // mask words per thread in ft_preselect_apply
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
@@ -165,19 +171,6 @@ __device__ __forceinline__ void fill_words(uint32_t* ptr, uint64_t n, uint32_t v
 
 }  // namespace
 
-// ---------------------------------------------------------------------------------------------- per-merge scratch state
-// Every table the merge reads before it writes: histogram, first-posting table, entry rows, synchronisation words.
-__global__ __launch_bounds__(256) void ft_init(FtPlan p) {
-	const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, gsize = uint64_t(gridDim.x) * blockDim.x;
-	if (p.prescore) {
-		fill_words(p.hist, 65536, 0u, gtid, gsize);
-		fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)) * 2, 0u, gtid, gsize);
-	}
-	fill_words(p.first, p.total_docs, kNoPosting, gtid, gsize);
-	fill_words(reinterpret_cast<uint32_t*>(p.e_rank), uint64_t(p.n_rows) * p.max_merged, 0u, gtid, gsize);
-	fill_words(p.sync, kFtSyncWords, 0u, gtid, gsize);
-}
-
 // ---------------------------------------------------------------------------------------------- restricting bitmask + pre-scores
 __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerimpl.h:486-490, the half only the device knows
 	return p.prescore && __hip_atomic_load(&p.sync[kFtSyncPop], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > p.merge_limit;
@@ -218,14 +211,23 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 		s_keys[tid] = 0;   // a score of 0 is never inserted
 		s_cnts[tid] = 0;
 	}
-	// this range's segment [lo, hi) of every posting list, fetched up front (two dependent loads each, all in flight together)
-	const uint32_t n_subs = p.simple ? 0u : p.n_subs;
-	for (uint32_t si = tid; si < n_subs && si < kFtRangeSubs; si += 256) {
+	// this range's segment [lo, hi) of every posting list, fetched up front (two dependent loads each, all in flight together); the merged
+	// postings in front of the range = where its bucket of surviving postings starts (ft_rank_all)
+	uint32_t before = 0;
+	for (uint32_t si = tid; si < p.n_subs; si += 256) {
 		const FtPosSubterm& s = p.subs[si];
-		s_lo[si] = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
-		s_hi[si] = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+		const uint32_t lo = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
+		if (si < kFtRangeSubs) {
+			s_lo[si] = lo;
+			s_hi[si] = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+		}
+		if (s.qp != 0) before += lo;   // NOT terms are not merged
 	}
+	before = wave_sum(before);
+	if ((tid & 63) == 0) s_part[tid >> 6] = before;
 	__syncthreads();
+	if (tid == 0) p.bucket_off[range] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+	__syncthreads();   // s_part is reused for the popcount below
 	for (uint32_t t = 0; t < (p.simple ? 0u : p.nterms); ++t) {
 		const FtTermCfg& term = p.terms[t];
 		const int op = term.op;
@@ -504,7 +506,8 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
 }
 
 // ---------------------------------------------------------------------------------------------- mergeTerm / mergeSimple
-// calcTermRank of every eligible posting of the query (restrictingMask_, DocRemoved) and the first-posting table.
+// calcTermRank of every eligible posting of the query (restrictingMask_, DocRemoved); the postings that rank non-zero leave as 16-byte
+// records in the bucket of their document range.
 // The gathers of one posting form a dependent chain (doc -> mask word -> removed flag | entries -> words in field).  The cheap half
 // (document, mask bit, removed flag) is streamed for kFtRankTiles x 1024 postings per workgroup, four postings per thread and tile with
 // every stage issued for all of them before anything is consumed; the survivors are COMPACTED in LDS and the expensive half
@@ -570,11 +573,6 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 	}
 #pragma unroll
 	for (int g = 0; g < kFtRankTiles; ++g) {
-		const uint32_t tile = blockIdx.x * kFtRankTiles + g;
-		if (tile >= p.merge_blocks) continue;
-		const uint64_t gp0 = uint64_t(tile) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-		*reinterpret_cast<float4*>(p.p_rank + gp0) = make_float4(0.f, 0.f, 0.f, 0.f);   // rank 0 = not eligible; survivors overwrite theirs below
-		*reinterpret_cast<uchar4*>(p.p_field + gp0) = make_uchar4(0, 0, 0, 0);
 #pragma unroll
 		for (int k = 0; k < kFtPassItems; ++k) {
 			if (!live[g][k]) continue;
@@ -583,110 +581,138 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 			s_doc[at] = docs[g][k];
 		}
 	}
-	__syncthreads();   // also orders the zero fill above before the survivors' stores below (same workgroup)
+	__syncthreads();
 	const uint32_t cnt = s_cnt;
-	for (uint32_t e = threadIdx.x; e < cnt; e += 256) {
-		const uint32_t item = s_item[e], g = item >> 10, local = item & 1023u;
-		const uint32_t tile = blockIdx.x * kFtRankTiles + g;
-		const FtPosSubterm& s = p.subs[s_sub[g]];
-		const FtTermCfg& t = p.terms[s.term];
-		const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
-		const uint64_t gp = uint64_t(tile) * kFtBlockPostings + local;
-		const uint32_t d = s_doc[e];
+	const int lane = threadIdx.x & 63;
+	for (uint32_t e0 = 0; e0 < cnt; e0 += 256) {   // uniform trip count: the wavefront votes below
+		const uint32_t e = e0 + threadIdx.x;
+		bool want = false;
+		uint32_t d = 0, row = 0, idx = 0;
+		float rank = 0.0f;
 		uint8_t field = 0;
-		const float rank = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d, &field);
-		if (rank != 0.0f) {
-			p.p_rank[gp] = rank;
-			p.p_field[gp] = field;
-			atomicMin(&p.first[d], uint32_t(gp));
+		if (e < cnt) {
+			const uint32_t item = s_item[e], g = item >> 10, local = item & 1023u;
+			const uint32_t tile = blockIdx.x * kFtRankTiles + g;
+			const FtPosSubterm& s = p.subs[s_sub[g]];
+			const FtTermCfg& t = p.terms[s.term];
+			const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
+			d = s_doc[e];
+			rank = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d, &field);
+			want = rank != 0.0f;
+			row = s.row;
+			idx = uint32_t(i);
+		}
+		// one device atomic per (wavefront, document range): neighbouring postings share a range, whole-corpus merges would otherwise
+		// hammer a few hundred counters with millions of same-address atomics
+		const uint32_t rg = d >> kFtRangeShift;
+		unsigned long long pending = __ballot(want);
+		while (pending) {
+			const int leader = __ffsll((long long)pending) - 1;
+			const uint32_t lrg = uint32_t(__shfl(int(rg), leader, 64));
+			const bool mine = want && rg == lrg;
+			const unsigned long long same = __ballot(mine);
+			uint32_t base = 0;
+			if (lane == leader) base = atomicAdd(&p.bucket_cnt[lrg], uint32_t(__popcll(same)));
+			base = uint32_t(__shfl(int(base), leader, 64));
+			if (mine) {
+				const uint32_t pos = base + uint32_t(__popcll(same & ((1ull << lane) - 1ull)));
+				p.b_rec[uint64_t(p.bucket_off[lrg]) + pos] = make_uint4(d, idx, __float_as_uint(rank), row | (uint32_t(field) << 16));
+				want = false;
+			}
+			pending &= ~same;
 		}
 	}
 }
 
-// addDoc order (merger.h:161-180): the postings that add a document take consecutive merge slots in global posting order, cut at
-// maxMergedDocs.  Two passes without any inter-workgroup waiting (a decoupled look-back over ~3800 workgroups took 70 us here):
-// ft_count_adders marks the adding postings and counts them per workgroup; ft_assign_slots sums the counts of the workgroups before it
-// (a few KB, L2-resident) and scans its own.
-__global__ __launch_bounds__(256) void ft_count_adders(FtPlan p) {
+// 16-bit minimum in an LDS table of packed halves (there are no 16-bit LDS atomics; contention is one posting per (document, sub-term))
+__device__ __forceinline__ void lds_min_u16(uint32_t* words, uint32_t idx, uint32_t v) {
+	uint32_t* w = words + (idx >> 1);
+	const uint32_t sh = (idx & 1u) * 16u;
+	uint32_t old = *w;
+	while (((old >> sh) & 0xFFFFu) > v) {
+		const uint32_t nw = (old & ~(0xFFFFu << sh)) | (v << sh);
+		const uint32_t prev = atomicCAS(w, old, nw);
+		if (prev == old) break;
+		old = prev;
+	}
+}
+__device__ __forceinline__ uint32_t lds_get_u16(const uint32_t* words, uint32_t idx) { return (words[idx >> 1] >> ((idx & 1u) * 16u)) & 0xFFFFu; }
+__device__ __forceinline__ void lds_set_u16(uint32_t* words, uint32_t idx, uint32_t v) {   // plain store of one half (ds_write_b16)
+	reinterpret_cast<uint16_t*>(words)[idx] = uint16_t(v);
+}
+
+// addDoc order (merger.h:161-180), document side.  One workgroup per range: the row (sub-term) of every document's first surviving
+// posting, counted per (row, range); the LAST workgroup to finish replaces the table by its exclusive prefix in row-major order — the merge
+// slot of the first document of every (row, range) — and publishes the number of merged documents.  Also hands the next kernels / the next
+// merge their zeroed tables (entry rows, histogram, look-back words).
+constexpr uint32_t kFtAdderRowsLds = 1024;
+__global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
+	__shared__ uint32_t s_tab[kFtRangeDocs / 2];   // first row of every document of the range, 16 bits each
+	__shared__ uint32_t s_rowcnt[kFtAdderRowsLds];
 	__shared__ uint32_t s_part[4];
-	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
-	const FtPosSubterm& s = p.subs[ge.sub];
-	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	const uint64_t gp0 = uint64_t(blockIdx.x) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	const float4 rk = *reinterpret_cast<const float4*>(p.p_rank + gp0);
-	const float ranks[kFtPassItems] = {rk.x, rk.y, rk.z, rk.w};
-	uint32_t docs[kFtPassItems], firsts[kFtPassItems];
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) docs[k] = ranks[k] != 0.0f ? s.doc[i0 + k] : 0u;   // rank 0 includes every posting past the end of the list
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) firsts[k] = ranks[k] != 0.0f ? p.first[docs[k]] : kNoPosting;
-	uint32_t c_mask = 0;
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) c_mask |= uint32_t(ranks[k] != 0.0f && firsts[k] == uint32_t(gp0 + k)) << k;
-	p.p_adder[uint64_t(blockIdx.x) * 256 + threadIdx.x] = uint8_t(c_mask);
-	const uint32_t c = wave_sum(__popc(c_mask));
-	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
-	__syncthreads();
-	if (threadIdx.x == 0) p.block_counts[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-}
-
-__global__ __launch_bounds__(256) void ft_assign_slots(FtPlan p) {
-	__shared__ uint32_t s_part[4], s_wave_tot[4];
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	uint32_t before = 0;   // adders in the workgroups before this one
-	for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) before += p.block_counts[b];
-	before = wave_sum(before);
-	const uint32_t c_mask = p.p_adder[uint64_t(blockIdx.x) * 256 + threadIdx.x];
-	const uint32_t incl = wave_inclusive_scan(__popc(c_mask), lane);
-	if (lane == 0) s_part[wave] = before;
-	if (lane == 63) s_wave_tot[wave] = incl;
-	__syncthreads();
-	uint32_t slot = s_part[0] + s_part[1] + s_part[2] + s_part[3] + (incl - __popc(c_mask));
-	for (int w = 0; w < wave; ++w) slot += s_wave_tot[w];
-	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
-		const uint32_t total = slot + __popc(c_mask);
-		p.sync[kFtSyncNumDocs] = total < p.max_merged ? total : p.max_merged;
-	}
-	if (!c_mask) return;
-	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
-	const FtPosSubterm& s = p.subs[ge.sub];
-	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) {
-		if (!((c_mask >> k) & 1u)) continue;
-		if (slot < p.max_merged) {
-			const uint32_t d = s.doc[i0 + k];
-			p.out_doc[slot] = d;
-			p.slot_of[d] = slot;
+	__shared__ uint32_t s_last;
+	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	{
+		const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + tid, gsize = uint64_t(gridDim.x) * blockDim.x;
+		fill_words(reinterpret_cast<uint32_t*>(p.e_rank), uint64_t(p.n_rows) * p.max_merged, 0u, gtid, gsize);
+		if (p.prescore) {   // ft_preselect_apply was their last reader
+			fill_words(p.hist, 65536, 0u, gtid, gsize);
+			fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)) * 2, 0u, gtid, gsize);
 		}
-		++slot;
 	}
-}
-
-// every posting of a merged document drops (rank, field, posting index) into the document's row, column = its sub-term
-__global__ __launch_bounds__(256) void ft_scatter(FtPlan p) {
-	const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, blockIdx.x);
-	const FtPosSubterm& s = p.subs[ge.sub];
-	const uint64_t i0 = uint64_t(blockIdx.x - ge.block_base) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	const uint64_t gp0 = uint64_t(blockIdx.x) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
-	const float4 rk = *reinterpret_cast<const float4*>(p.p_rank + gp0);
-	const float ranks[kFtPassItems] = {rk.x, rk.y, rk.z, rk.w};
-	const uint32_t num_docs = p.sync[kFtSyncNumDocs];
-	uint32_t docs[kFtPassItems], slots[kFtPassItems];
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) docs[k] = ranks[k] != 0.0f ? s.doc[i0 + k] : 0u;
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) slots[k] = ranks[k] != 0.0f ? p.slot_of[docs[k]] : kNoPosting;
-#pragma unroll
-	for (int k = 0; k < kFtPassItems; ++k) {
-		if (ranks[k] == 0.0f) continue;
-		const uint32_t sl = slots[k];
-		if (sl >= num_docs || p.out_doc[sl] != docs[k]) continue;   // sparse-set test: slot_of[] is never cleared
-		const uint64_t cell = uint64_t(s.row) * p.max_merged + sl;
-		p.e_rank[cell] = ranks[k];
-		p.e_idx[cell] = uint32_t(i0 + k);
-		p.e_field[cell] = p.p_field[gp0 + k];
+	const uint32_t n = p.bucket_cnt[range];
+	const bool lds_rows = p.n_rows <= kFtAdderRowsLds;
+	for (uint32_t w = tid; w < kFtRangeDocs / 2; w += 256) s_tab[w] = 0xFFFFFFFFu;
+	for (uint32_t r = tid; r < p.n_rows; r += 256) {
+		if (lds_rows) {
+			s_rowcnt[r] = 0;
+		} else {
+			p.adders[uint64_t(r) * p.n_ranges + range] = 0;   // this workgroup owns the column
+		}
 	}
+	__syncthreads();
+	const uint4* rec = p.b_rec + p.bucket_off[range];
+	for (uint32_t e = tid; e < n; e += 256) {
+		const uint4 r = rec[e];
+		lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
+	}
+	__syncthreads();
+	for (uint32_t e = tid; e < n; e += 256) {
+		const uint4 r = rec[e];
+		const uint32_t row = r.w & 0xFFFFu;
+		if (lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1)) != row) continue;   // one posting per (document, row): exactly one record adds the document
+		if (lds_rows) {
+			atomicAdd(&s_rowcnt[row], 1u);
+		} else {
+			atomicAdd(&p.adders[uint64_t(row) * p.n_ranges + range], 1u);
+		}
+	}
+	__syncthreads();
+	if (lds_rows) {
+		for (uint32_t r = tid; r < p.n_rows; r += 256) p.adders[uint64_t(r) * p.n_ranges + range] = s_rowcnt[r];
+	}
+	// ---- the last workgroup scans the table
+	__threadfence();
+	__syncthreads();
+	if (tid == 0) s_last = atomicAdd(&p.sync[kFtSyncDoneAdders], 1u) == gridDim.x - 1 ? 1u : 0u;
+	__syncthreads();
+	if (!s_last) return;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' counts (their release: the fence before the counter)
+	const uint64_t total = uint64_t(p.n_rows) * p.n_ranges, per = (total + 255) / 256;
+	const uint64_t a = std::min<uint64_t>(total, uint64_t(tid) * per), b = std::min<uint64_t>(total, a + per);
+	uint32_t local = 0;
+	for (uint64_t j = a; j < b; ++j) local += p.adders[j];
+	const uint32_t incl = wave_inclusive_scan(local, int(tid & 63));
+	if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+	__syncthreads();
+	uint32_t running = incl - local;
+	for (uint32_t w = 0; w < (tid >> 6); ++w) running += s_part[w];
+	for (uint64_t j = a; j < b; ++j) {
+		const uint32_t v = p.adders[j];
+		p.adders[j] = running;
+		running += v;
+	}
+	if (tid == 255) p.sync[kFtSyncNumDocs] = running < p.max_merged ? running : p.max_merged;   // the last thread ends on the grand total
 }
 
 // mergerimpl.h:20-37; fullPos()/fullField() truncate the 64-bit PosType to uint32_t exactly like the reference's accessors
@@ -713,28 +739,10 @@ __device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uin
 	return res == 0xFFFFFFFFu ? 0 : res;
 }
 
-// One thread per merged document: its row replayed in sub-term order = the order mergeTerm / mergeSimple met its postings.
+// One merged document: its row of the entry table replayed in sub-term order = the order mergeTerm / mergeSimple met its postings.
 constexpr uint32_t kFtReplayRows = 128;   // sub-term descriptors staged in LDS (queries with more merged sub-terms read the plan from HBM)
-__global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
-	__shared__ const uint64_t* s_fpos[kFtReplayRows];
-	__shared__ const uint32_t* s_pos_off[kFtReplayRows];
-	__shared__ uint16_t s_qp[kFtReplayRows];
-	for (uint32_t row = threadIdx.x; row < p.n_rows && row < kFtReplayRows; row += blockDim.x) {   // two dependent loads per row, once per workgroup
-		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
-		s_fpos[row] = s.fpos;
-		s_pos_off[row] = s.pos_off;
-		s_qp[row] = s.qp;
-	}
-	__syncthreads();
-	const uint32_t num_docs = p.sync[kFtSyncNumDocs];
-	const uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
-	if (sl == 0) {
-		p.out_header[0] = num_docs;
-		p.out_header[1] = p.sync[kFtSyncError];
-		p.out_header[2] = ft_preselect_on(p) ? 1u : 0u;
-		p.out_header[3] = 0;
-	}
-	if (sl >= num_docs) return;
+__device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint32_t doc, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
+											  const uint16_t* s_qp) {
 	bool created = false;
 	float proc = 0.f, rank = 0.f;
 	uint8_t field = 0;
@@ -742,10 +750,8 @@ __global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
 	const uint64_t* next_ptr = nullptr;
 	uint32_t last_cnt = 0, next_cnt = 0;
 	uint16_t switched_term = 0, last_counted = 0, terms_counter = 0;
-	// Most documents meet ONE sub-term, a few two or three, out of many: walking the rows in lock step would make every wavefront pay the
-	// per-row gather chain once per row (19 us for 20 000 documents x 9 rows).  Instead each lane first collects WHICH of its rows are
-	// occupied (coalesced rank loads, 64 rows per mask word) and then walks only those: the wavefront iterates as often as its busiest lane
-	// has entries.  The order inside a lane is still row order = the order mergeTerm met the postings.
+	// Most documents meet ONE sub-term, a few two or three, out of many: each lane first collects WHICH of its rows are occupied (rank
+	// loads, 64 rows per mask word) and then walks only those, in row order = the order mergeTerm met the postings.
 	for (uint32_t row0 = 0; row0 < p.n_rows; row0 += 64) {
 		unsigned long long occupied = 0;
 		const uint32_t rows_here = p.n_rows - row0 < 64 ? p.n_rows - row0 : 64;
@@ -756,85 +762,85 @@ __global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
 #pragma unroll
 			for (uint32_t j = 0; j < 8; ++j) occupied |= (unsigned long long)(ahead[j] != 0.0f) << (j0 + j);
 		}
-	while (occupied) {
-		const uint32_t row = row0 + uint32_t(__ffsll((long long)occupied) - 1);
-		occupied &= occupied - 1;
-		const uint64_t cell = uint64_t(row) * p.max_merged + sl;
-		const float r = p.e_rank[cell];
-		const uint8_t fld = p.e_field[cell];
-		if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
-			if (!created) {
+		while (occupied) {
+			const uint32_t row = row0 + uint32_t(__ffsll((long long)occupied) - 1);
+			occupied &= occupied - 1;
+			const uint64_t cell = uint64_t(row) * p.max_merged + sl;
+			const float r = p.e_rank[cell];
+			const uint8_t fld = p.e_field[cell];
+			if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
+				if (!created) {
+					created = true;
+					proc = r;
+					field = fld;
+				} else if (proc < r) {
+					proc = r;
+					field = fld;
+				}
+				continue;
+			}
+			const uint32_t i = p.e_idx[cell];
+			const uint64_t* fpos;
+			const uint32_t* pos_off;
+			uint16_t qp;
+			if (row < kFtReplayRows) {
+				fpos = s_fpos[row];
+				pos_off = s_pos_off[row];
+				qp = s_qp[row];
+			} else {
+				const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
+				fpos = s.fpos;
+				pos_off = s.pos_off;
+				qp = s.qp;
+			}
+			const uint32_t po0 = pos_off[i], po1 = pos_off[i + 1];
+			const uint64_t* pos = fpos + po0;
+			const uint32_t npos = po1 - po0;
+			if (!created) {   // addDoc (mergerimpl.h:160-164)
 				created = true;
 				proc = r;
 				field = fld;
-			} else if (proc < r) {
-				proc = r;
-				field = fld;
+				rank = r;
+				next_ptr = pos;
+				next_cnt = npos;
+				switched_term = qp;
+				last_counted = qp;
+				terms_counter = 1;
+				continue;
 			}
-			continue;
-		}
-		const uint32_t i = p.e_idx[cell];
-		const uint64_t* fpos;
-		const uint32_t* pos_off;
-		uint16_t qp;
-		if (row < kFtReplayRows) {
-			fpos = s_fpos[row];
-			pos_off = s_pos_off[row];
-			qp = s_qp[row];
-		} else {
-			const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
-			fpos = s.fpos;
-			pos_off = s.pos_off;
-			qp = s.qp;
-		}
-		const uint32_t po0 = pos_off[i], po1 = pos_off[i + 1];
-		const uint64_t* pos = fpos + po0;
-		const uint32_t npos = po1 - po0;
-		if (!created) {   // addDoc (mergerimpl.h:160-164)
-			created = true;
-			proc = r;
-			field = fld;
-			rank = r;
-			next_ptr = pos;
-			next_cnt = npos;
-			switched_term = qp;
-			last_counted = qp;
-			terms_counter = 1;
-			continue;
-		}
-		// ---- document already merged: mergerimpl.h:165-189
-		if (switched_term < qp) {   // switchToNextWord (merger.h:218-226) ran before every term since: idempotent after the first time
-			if (next_cnt) {
-				last_ptr = next_ptr;
-				last_cnt = next_cnt;
-				next_cnt = 0;
-				rank = 0.f;
+			// ---- document already merged: mergerimpl.h:165-189
+			if (switched_term < qp) {   // switchToNextWord (merger.h:218-226) ran before every term since: idempotent after the first time
+				if (next_cnt) {
+					last_ptr = next_ptr;
+					last_cnt = next_cnt;
+					next_cnt = 0;
+					rank = 0.f;
+				}
+				switched_term = qp;
 			}
-			switched_term = qp;
+			if (last_counted < qp) {   // InreaseTermsCounter
+				terms_counter = uint16_t(terms_counter + 1);
+				last_counted = qp;
+			}
+			unsigned dist = ft_positions_distance(last_ptr, last_cnt, pos, npos);
+			dist = dist > 1u ? dist : 1u;
+			const float norm_dist = ft_bound(float(1.0 / double(float(dist))), p.distance_weight, p.distance_boost);
+			const float final_rank = norm_dist * r;
+			if (final_rank > rank) {
+				proc -= rank;
+				proc += final_rank;
+				next_ptr = pos;
+				next_cnt = npos;
+				rank = final_rank;
+			}
 		}
-		if (last_counted < qp) {   // InreaseTermsCounter
-			terms_counter = uint16_t(terms_counter + 1);
-			last_counted = qp;
-		}
-		unsigned dist = ft_positions_distance(last_ptr, last_cnt, pos, npos);
-		dist = dist > 1u ? dist : 1u;
-		const float norm_dist = ft_bound(float(1.0 / double(float(dist))), p.distance_weight, p.distance_boost);
-		const float final_rank = norm_dist * r;
-		if (final_rank > rank) {
-			proc -= rank;
-			proc += final_rank;
-			next_ptr = pos;
-			next_cnt = npos;
-			rank = final_rank;
-		}
-	}
 	}
 	// addFullMatchBoost (merger.h:100-109): a document whose best field holds exactly as many words as the query has parts — and, for a
 	// multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts
 	// are resident: on the host it was one cache miss per merged document.
 	{
 		const FtTermCfg& t0 = p.terms[0];
-		const float words = t0.words[size_t(p.out_doc[sl]) * t0.num_fields + field];
+		const float words = t0.words[size_t(doc) * t0.num_fields + field];
 		const bool full = p.simple ? words == 1.0f : (terms_counter == p.nterms && words == float(p.nterms));
 		if (full) proc = float(double(proc) * p.full_match_boost);
 	}
@@ -843,21 +849,135 @@ __global__ __launch_bounds__(64) void ft_replay(FtPlan p) {
 	p.out_terms_counter[sl] = terms_counter;
 }
 
+// Slots, entry rows and the per-document replay of one document range.  Dynamic LDS: the 16-bit document table (first row, then the
+// position in the sorted key list) followed by the key list of the range's first postings ((row << 13 | document), then the slot).
+__global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
+	extern __shared__ uint32_t ft_finish_lds[];
+	uint32_t* s_tab = ft_finish_lds;                       // [kFtRangeDocs / 2]
+	uint32_t* s_keys = ft_finish_lds + kFtRangeDocs / 2;   // [kFtRangeDocs]
+	__shared__ const uint64_t* s_fpos[kFtReplayRows];
+	__shared__ const uint32_t* s_pos_off[kFtReplayRows];
+	__shared__ uint16_t s_qp[kFtReplayRows];
+	__shared__ uint32_t s_nadd, s_last;
+	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	const uint32_t n = p.bucket_cnt[range];
+	if (n) {
+		for (uint32_t row = tid; row < p.n_rows && row < kFtReplayRows; row += 256) {   // two dependent loads per row, once per workgroup
+			const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
+			s_fpos[row] = s.fpos;
+			s_pos_off[row] = s.pos_off;
+			s_qp[row] = s.qp;
+		}
+		for (uint32_t w = tid; w < kFtRangeDocs / 2; w += 256) s_tab[w] = 0xFFFFFFFFu;
+		if (tid == 0) s_nadd = 0;
+		__syncthreads();
+		uint4* rec = p.b_rec + p.bucket_off[range];
+		for (uint32_t e = tid; e < n; e += 256) {
+			const uint4 r = rec[e];
+			lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
+		}
+		__syncthreads();
+		for (uint32_t e = tid; e < n; e += 256) {   // the range's first postings: key (row, document); the record remembers that it adds
+			const uint4 r = rec[e];
+			const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
+			if (lds_get_u16(s_tab, dl) != row) continue;
+			s_keys[atomicAdd(&s_nadd, 1u)] = (row << kFtRangeShift) | dl;
+			rec[e].w = r.w | 0x80000000u;
+		}
+		__syncthreads();
+		const uint32_t A = s_nadd;   // <= kFtRangeDocs: one per document
+		uint32_t N = 2;
+		while (N < A) N <<= 1;
+		for (uint32_t q = A + tid; q < N; q += 256) s_keys[q] = 0xFFFFFFFFu;
+		__syncthreads();
+		for (uint32_t k = 2; k <= N; k <<= 1) {   // bitonic sort, ascending
+			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+				for (uint32_t t = tid; t < N / 2; t += 256) {
+					const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+					const uint32_t x = s_keys[i], y = s_keys[l];
+					if ((x > y) == ((i & k) == 0)) {
+						s_keys[i] = y;
+						s_keys[l] = x;
+					}
+				}
+				__syncthreads();
+			}
+		}
+		// rank inside the row = position - first position of the row (binary search); parked in the document table, whose first-row
+		// entries are no longer needed
+		for (uint32_t q = tid; q < A; q += 256) {
+			const uint32_t key = s_keys[q], first_of_row = key & ~(kFtRangeDocs - 1);
+			uint32_t lo = 0, hi = q;   // lower bound of first_of_row in [0, q]
+			while (lo < hi) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_keys[mid] < first_of_row) {
+					lo = mid + 1;
+				} else {
+					hi = mid;
+				}
+			}
+			lds_set_u16(s_tab, key & (kFtRangeDocs - 1), q - lo);
+		}
+		__syncthreads();
+		const uint32_t d_begin = range << kFtRangeShift;
+		for (uint32_t q = tid; q < A; q += 256) {   // key -> slot; document -> its position in the list
+			const uint32_t key = s_keys[q], row = key >> kFtRangeShift, dl = key & (kFtRangeDocs - 1);
+			const uint32_t slot = p.adders[uint64_t(row) * p.n_ranges + range] + lds_get_u16(s_tab, dl);
+			s_keys[q] = slot;
+			lds_set_u16(s_tab, dl, q);
+			if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
+		}
+		__syncthreads();
+		for (uint32_t e = tid; e < n; e += 256) {   // every posting of a merged document into the document's row, column = its sub-term
+			const uint4 r = rec[e];
+			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
+			if (sl >= p.max_merged) continue;   // met after the limit was hit: never added
+			const uint64_t cell = uint64_t(r.w & 0xFFFFu) * p.max_merged + sl;
+			p.e_rank[cell] = __uint_as_float(r.z);
+			p.e_idx[cell] = r.y;
+			p.e_field[cell] = uint8_t((r.w >> 16) & 0xFFu);
+		}
+		__syncthreads();   // the rows are read back by this workgroup only
+		for (uint32_t e = tid; e < n; e += 256) {
+			const uint4 r = rec[e];
+			if (!(r.w >> 31)) continue;
+			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
+			if (sl < p.max_merged) ft_replay_doc(p, sl, r.x, s_fpos, s_pos_off, s_qp);
+		}
+	}
+	// ---- leave the shared tables clean for the next merge; the last workgroup writes the result header
+	__syncthreads();
+	if (tid == 0) {
+		if (n) p.bucket_cnt[range] = 0;
+		__threadfence();
+		s_last = atomicAdd(&p.sync[kFtSyncDoneFinish], 1u) == gridDim.x - 1 ? 1u : 0u;
+	}
+	__syncthreads();
+	if (!s_last) return;
+	if (tid == 0) {
+		p.out_header[0] = p.sync[kFtSyncNumDocs];
+		p.out_header[1] = p.sync[kFtSyncError];
+		p.out_header[2] = ft_preselect_on(p) ? 1u : 0u;
+		p.out_header[3] = 0;
+	}
+	__syncthreads();
+	if (tid < kFtSyncWords) p.sync[tid] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------- launch train
-void launch_ft_merge(const FtPlan& p, hipStream_t st) {
-	hipLaunchKernelGGL(ft_init, dim3(1024), dim3(256), 0, st, p);
-	hipLaunchKernelGGL(ft_ranges, dim3(uint32_t((p.total_docs + kFtRangeDocs - 1) / kFtRangeDocs)), dim3(256), 0, st, p);
+hipError_t launch_ft_merge(const FtPlan& p, hipStream_t st) {
+	constexpr size_t kFinishLds = (kFtRangeDocs / 2 + kFtRangeDocs) * sizeof(uint32_t);
+	static std::atomic<uint64_t> raised{0};
+	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&ft_finish), kFinishLds); e != hipSuccess) return e;
+	hipLaunchKernelGGL(ft_ranges, dim3(p.n_ranges), dim3(256), 0, st, p);
 	if (!p.simple && p.prescore) {
 		hipLaunchKernelGGL(ft_preselect_pick, dim3(1), dim3(1024), 0, st, p);
 		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
 	}
-	if (p.merge_blocks) {
-		hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankTiles - 1) / kFtRankTiles), dim3(256), 0, st, p);
-		hipLaunchKernelGGL(ft_count_adders, dim3(p.merge_blocks), dim3(256), 0, st, p);
-		hipLaunchKernelGGL(ft_assign_slots, dim3(p.merge_blocks), dim3(256), 0, st, p);
-		hipLaunchKernelGGL(ft_scatter, dim3(p.merge_blocks), dim3(256), 0, st, p);
-	}
-	hipLaunchKernelGGL(ft_replay, dim3((p.max_merged + 63) / 64), dim3(64), 0, st, p);
+	if (p.merge_blocks) hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankTiles - 1) / kFtRankTiles), dim3(256), 0, st, p);
+	hipLaunchKernelGGL(ft_adders, dim3(p.n_ranges), dim3(256), 0, st, p);
+	hipLaunchKernelGGL(ft_finish, dim3(p.n_ranges), dim3(256), kFinishLds, st, p);
+	return hipGetLastError();
 }
 
 }  // namespace rxgpu

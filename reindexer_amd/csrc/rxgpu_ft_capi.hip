@@ -63,6 +63,11 @@ struct rxgpu_ft_index {
 	std::mutex mtx;
 	hipStream_t stream = nullptr;
 	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
+	// tables every merge finds ZEROED and leaves zeroed (ft_adders / ft_finish clear what the merge used): pre-score histogram, look-back
+	// words of the preselect, bucket counters, synchronisation words.  Cleared by the host only when (re)allocated or after a failed merge.
+	rxgpu_devbuf d_clean;
+	uint64_t clean_docs = 0;
+	bool clean_dirty = true;
 	void* h_pinned = nullptr;     // staging: plan upload / result download
 	size_t h_pinned_bytes = 0;
 	hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -153,7 +158,7 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
 		if (p) (void)hipFree(p);
 	}
-	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out}) b->release();
+	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean}) b->release();
 	if (h->h_pinned) (void)hipHostFree(h->h_pinned);
 	if (h->ev_a) (void)hipEventDestroy(h->ev_a);
 	if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -357,9 +362,9 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_CHECK(merge_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull, RXGPU_ERR_PARAMS,
 			 std::string(who) + ": more than 2^32 (padded) postings in one merge");
 	const uint32_t n_rows = uint32_t(merge_grid.size());
+	RX_CHECK(n_rows < 0xFFFFu, RXGPU_ERR_PARAMS, std::string(who) + ": more than 65534 merged sub-terms in one query (GPU engine limit)");
 	const uint64_t nwords = (N + 31) / 32;
 	const size_t M = size_t(max_merged);
-	const uint64_t padded = merge_blocks * rxgpu::kFtBlockPostings;
 
 	h->trace_us[0] += since(t_begin);
 	const auto t_stage = clk::now();
@@ -373,21 +378,28 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t plan_bytes = cv.off;   // everything above is uploaded in one copy
 	const size_t o_mask = cv.take(nwords * 4);
 	const size_t o_score = cv.take(prescore ? nwords * 32 * 2 : 0);   // padded to whole mask words (ft_preselect_apply reads 32 scores at a time)
-	const size_t o_hist = cv.take(prescore ? 65536 * 4 : 0);
-	const size_t o_lb_pre = cv.take(prescore ? ((nwords + 1023) / 1024) * 8 : 0);
-	const size_t o_first = cv.take(N * 4);
-	const size_t o_slot_of = cv.take(N * 4);
-	const size_t o_prank = cv.take(padded * 4);
-	const size_t o_pfield = cv.take(padded);
-	const size_t o_padder = cv.take(size_t(merge_blocks) * 256);
-	const size_t o_bcounts = cv.take(size_t(merge_blocks) * 4);
+	const uint32_t n_ranges = uint32_t((N + rxgpu::kFtRangeDocs - 1) / rxgpu::kFtRangeDocs);
+	const size_t o_brec = cv.take(size_t(merged_postings) * sizeof(uint4));
+	const size_t o_boff = cv.take(size_t(n_ranges) * 4);
+	const size_t o_adders = cv.take(std::max<size_t>(1, size_t(n_rows) * n_ranges) * 4);
 	const size_t o_erank = cv.take(size_t(n_rows) * M * 4);
 	const size_t o_eidx = cv.take(size_t(n_rows) * M * 4);
 	const size_t o_efield = cv.take(size_t(n_rows) * M);
-	const size_t o_sync = cv.take(rxgpu::kFtSyncWords * 4);
 	const size_t o_excl = cv.take(excluded ? N : 0);
 	if (int rc = h->d_state.ensure(cv.off); rc) return rc;
 	char* base = static_cast<char*>(h->d_state.ptr);
+	// the kept-clean tables: sized by the corpus only, so that they stay where they are from merge to merge
+	Carver cc;
+	const size_t o_hist = cc.take(65536 * 4);
+	const size_t o_lb_pre = cc.take(((nwords + 1023) / 1024) * 8);
+	const size_t o_bcnt = cc.take(size_t(n_ranges) * 4);
+	const size_t o_sync = cc.take(rxgpu::kFtSyncWords * 4);
+	if (h->clean_docs != N || h->d_clean.bytes < cc.off) {
+		if (int rc = h->d_clean.ensure(cc.off); rc) return rc;
+		h->clean_docs = N;
+		h->clean_dirty = true;
+	}
+	char* cbase = static_cast<char*>(h->d_clean.ptr);
 	const size_t out_need = align256(16) + align256(M * 4) * 2 + align256(M * 2) + align256(M);
 	if (int rc = h->d_out.ensure(out_need); rc) return rc;
 	char* ob = static_cast<char*>(h->d_out.ptr);
@@ -428,6 +440,10 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	if (!merge_grid.empty()) std::memcpy(hp + o_plan_mgrid, merge_grid.data(), merge_grid.size() * sizeof(rxgpu::FtGridEntry));
 
 	hipStream_t st = h->stream;
+	if (h->clean_dirty) {
+		RX_HIP(hipMemsetAsync(cbase, 0, cc.off, st));
+		h->clean_dirty = false;
+	}
 	RX_HIP(hipMemcpyAsync(base, hp, plan_bytes, hipMemcpyHostToDevice, st));
 	if (excluded) RX_HIP(hipMemcpyAsync(base + o_excl, excluded, N, hipMemcpyHostToDevice, st));
 
@@ -454,18 +470,17 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.excluded = excluded ? reinterpret_cast<const uint8_t*>(base + o_excl) : nullptr;
 	p.mask = reinterpret_cast<uint32_t*>(base + o_mask);
 	p.score = prescore ? reinterpret_cast<uint16_t*>(base + o_score) : nullptr;
-	p.hist = prescore ? reinterpret_cast<uint32_t*>(base + o_hist) : nullptr;
-	p.lookback_pre = prescore ? reinterpret_cast<unsigned long long*>(base + o_lb_pre) : nullptr;
-	p.first = reinterpret_cast<uint32_t*>(base + o_first);
-	p.slot_of = reinterpret_cast<uint32_t*>(base + o_slot_of);
-	p.p_rank = reinterpret_cast<float*>(base + o_prank);
-	p.p_field = reinterpret_cast<uint8_t*>(base + o_pfield);
-	p.p_adder = reinterpret_cast<uint8_t*>(base + o_padder);
-	p.block_counts = reinterpret_cast<uint32_t*>(base + o_bcounts);
+	p.hist = prescore ? reinterpret_cast<uint32_t*>(cbase + o_hist) : nullptr;
+	p.lookback_pre = prescore ? reinterpret_cast<unsigned long long*>(cbase + o_lb_pre) : nullptr;
+	p.b_rec = reinterpret_cast<uint4*>(base + o_brec);
+	p.bucket_off = reinterpret_cast<uint32_t*>(base + o_boff);
+	p.bucket_cnt = reinterpret_cast<uint32_t*>(cbase + o_bcnt);
+	p.adders = reinterpret_cast<uint32_t*>(base + o_adders);
+	p.n_ranges = n_ranges;
 	p.e_rank = reinterpret_cast<float*>(base + o_erank);
 	p.e_idx = reinterpret_cast<uint32_t*>(base + o_eidx);
 	p.e_field = reinterpret_cast<uint8_t*>(base + o_efield);
-	p.sync = reinterpret_cast<uint32_t*>(base + o_sync);
+	p.sync = reinterpret_cast<uint32_t*>(cbase + o_sync);
 	p.out_header = reinterpret_cast<uint32_t*>(ob);
 	p.out_doc = reinterpret_cast<uint32_t*>(ob + align256(16));
 	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));
@@ -478,10 +493,11 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		RX_HIP(hipEventCreate(&h->ev_a));
 		RX_HIP(hipEventCreate(&h->ev_b));
 	}
+	// from here on an error return leaves the kept-clean tables in an unknown state: the next merge clears them first
+	h->clean_dirty = true;
 	RX_HIP(hipEventRecord(h->ev_a, st));
-	rxgpu::launch_ft_merge(p, st);
+	RX_HIP(rxgpu::launch_ft_merge(p, st));
 	RX_HIP(hipEventRecord(h->ev_b, st));
-	RX_HIP(hipGetLastError());
 	h->trace_us[2] += since(t_launch);
 	const auto t_wait = clk::now();
 	RX_HIP(hipMemcpyAsync(hp, ob, out_need, hipMemcpyDeviceToHost, st));   // header + the four result arrays in one copy
@@ -496,6 +512,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_CHECK(hdr[1] == 0, RXGPU_ERR_DEVICE, std::string(who) + ": ordered look-back timed out on the device");
 	const uint64_t n = hdr[0];
 	RX_CHECK(n <= max_merged, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt result header");
+	h->clean_dirty = false;   // the merge ran to its end: ft_adders / ft_finish handed the tables back zeroed
 	if (n) {
 		std::memcpy(out_doc, hp + align256(16), n * 4);
 		std::memcpy(out_proc, hp + align256(16) + align256(M * 4), n * 4);

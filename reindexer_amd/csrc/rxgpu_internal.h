@@ -137,16 +137,16 @@ struct FtPlan {
 	uint32_t* mask;            // restrictingMask_ [nwords]
 	uint16_t* score;           // [total_docs]
 	uint32_t* hist;            // [65536]
-	uint32_t* first;           // [total_docs]: smallest global posting index with a non-zero rank (the posting that adds the document)
-	uint32_t* slot_of;         // [total_docs]: sparse-set back pointer, valid iff slot_doc[slot_of[d]] == d
-	float* p_rank;             // [merge_blocks * kFtBlockPostings] rank of every posting (0 = not eligible)
-	uint8_t* p_field;
-	uint8_t* p_adder;          // [merge_blocks * 256]: per thread, which of its postings add a document
-	uint32_t* block_counts;    // [merge_blocks] adding postings per workgroup
+	// admission (ft_rank_all -> ft_adders -> ft_finish): the eligible postings with a non-zero rank, bucketed by document range
+	uint4* b_rec;              // [merged postings] records {doc, posting index, rank bits, row | field << 16}; bucket r starts at bucket_off[r]
+	uint32_t* bucket_off;      // [n_ranges] = merged postings in front of the range (sum of the sub-terms' range offsets), written by ft_ranges
+	uint32_t* bucket_cnt;      // [n_ranges] records in the bucket; kept zero between merges (ft_finish clears its own)
+	uint32_t* adders;          // [n_rows][n_ranges]: documents first met in (sub-term row, range); then its exclusive prefix in place = slot bases
+	uint32_t n_ranges;
 	float* e_rank;             // per-slot entry table [n_rows][max_merged]: 0 = the document has no posting in that sub-term
 	uint32_t* e_idx;
 	uint8_t* e_field;
-	uint32_t* sync;            // kFtSync* words (zeroed by ft_init)
+	uint32_t* sync;            // kFtSync* words; kept zero between merges (the last workgroup of ft_finish clears them)
 	unsigned long long* lookback_pre;     // [ceil(nwords / (256 * 4))]
 	// packed result: header (4 x u32: numDocs, error flag, preselected, 0) then doc[max_merged] u32, proc[max_merged] f32,
 	// terms_counter[max_merged] u16, field[max_merged] u8 — one D2H copy
@@ -157,8 +157,10 @@ struct FtPlan {
 	uint8_t* out_field;
 };
 enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPick = 2 /* +1 */, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6,
-				  kFtSyncPreselected = 7, kFtSyncWords = 8 };
-void launch_ft_merge(const FtPlan& plan, hipStream_t st);
+				  kFtSyncPreselected = 7, kFtSyncDoneAdders = 8, kFtSyncDoneFinish = 9, kFtSyncWords = 16 };
+constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
+static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
+hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);
 
 void set_error(const std::string& msg);
 
