@@ -28,10 +28,10 @@
 //    operations  ->  same bits.
 //  * preselect ties at the threshold score are kept in document order: ordered prefix (ft_preselect_apply).
 //
-// Launch train of a multi-term query: ft_ranges, [ft_preselect_pick, ft_preselect_apply], ft_rank_all, ft_adders, ft_finish; the 2-phase
+// Launch train of a multi-term query: ft_ranges, [ft_preselect_apply], ft_rank_all, ft_adders, ft_slot_bases, ft_finish; the 2-phase
 // gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result leaves in one packed buffer.  A Simple() query:
-// ft_ranges (mask only), ft_rank_all, ft_adders, ft_finish.  No fill kernel: the tables a merge reads before it writes (histogram,
-// bucket counters, look-back and synchronisation words) are handed back ZEROED by the merge that used them (ft_adders / ft_finish).
+// ft_ranges (mask only), ft_rank_all, ft_adders, ft_slot_bases, ft_finish.  No fill kernel: the tables a merge reads before it writes (histogram,
+// entry-row occupancy, bucket counters, look-back and synchronisation words) are handed back ZEROED by the kernel that read them last.
 //
 // Bound: HBM gathers: per posting 4 B doc + 8 B entry offsets + 9 B per (field, tf, firstPos) entry streamed, 4 B
 // words-in-field + the mask word gathered; 16 B per surviving posting written and read back.
@@ -47,6 +47,12 @@
 namespace rxgpu {
 
 namespace {
+
+// phase stamps of one workgroup (100 MHz wall clock), see rxgpu_ft_read_stats
+#define FT_STAMP(p, k)                                                                                    \
+	do {                                                                                                  \
+		if ((p).dbg && blockIdx.x == (p).dbg_block && threadIdx.x == 0) (p).dbg[k] = wall_clock64();      \
+	} while (0)
 
 constexpr unsigned long long kLbPrefix = 1ull << 63;
 constexpr unsigned long long kLbAggregate = 1ull << 62;
@@ -183,14 +189,20 @@ __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerim
 //   pre-score  calcTermScores (:289-324) for every term that is not a NOT, when the host half of the 2-phase gate held: the first sub-term
 //              (SortSubterms order) with a positive field boost adds min(proc16, 65535 / 4), saturating at 65535; then (:416-423) documents
 //              outside the mask / removed score 0 and the rest is histogrammed
-constexpr uint32_t kFtRangeSubs = 512;   // segments staged in LDS (queries with more sub-terms read the range index from HBM)
+constexpr uint32_t kFtRangeSubs = 512;   // sub-terms whose segment, list pointer and proc are staged in LDS (more: read from HBM)
+constexpr uint32_t kFtStage = 8192;      // postings of the range prefetched into LDS (16-bit local document ids)
 __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 	constexpr uint32_t kWords = kFtRangeDocs / 32;
 	__shared__ uint32_t s_mask[kWords], s_term[kWords], s_seen[kWords];
 	__shared__ uint16_t s_score[kFtRangeDocs];
-	__shared__ uint32_t s_keys[256], s_cnts[256], s_part[4];
-	__shared__ uint32_t s_lo[kFtRangeSubs], s_hi[kFtRangeSubs];
+	__shared__ uint32_t s_keys[256], s_part[4];
+	__shared__ uint32_t s_lo[kFtRangeSubs], s_hi[kFtRangeSubs], s_start[kFtRangeSubs + 1];
+	__shared__ const uint32_t* s_docptr[kFtRangeSubs];
+	__shared__ const uint32_t* s_elem0[kFtRangeSubs];   // &doc[lo] - start: the element at flat position f is s_elem0[si][f]
+	__shared__ float s_proc[kFtRangeSubs];
+	__shared__ __attribute__((aligned(16))) uint16_t s_stage[kFtStage];
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	FT_STAMP(p, 0);
 	const uint64_t d_begin = uint64_t(range) * kFtRangeDocs;
 	const uint32_t docs_here = uint32_t(p.total_docs - d_begin < kFtRangeDocs ? p.total_docs - d_begin : kFtRangeDocs);
 	for (uint32_t w = tid; w < kWords; w += 256) {
@@ -207,9 +219,8 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 		s_mask[w] = bits;
 	}
 	if (p.prescore) {
-		for (uint32_t i = tid; i < kFtRangeDocs; i += 256) s_score[i] = 0;
+		for (uint32_t i = tid; i < kFtRangeDocs / 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
 		s_keys[tid] = 0;   // a score of 0 is never inserted
-		s_cnts[tid] = 0;
 	}
 	// this range's segment [lo, hi) of every posting list, fetched up front (two dependent loads each, all in flight together); the merged
 	// postings in front of the range = where its bucket of surviving postings starts (ft_rank_all)
@@ -220,6 +231,8 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 		if (si < kFtRangeSubs) {
 			s_lo[si] = lo;
 			s_hi[si] = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+			s_docptr[si] = s.doc;
+			s_proc[si] = s.proc;
 		}
 		if (s.qp != 0) before += lo;   // NOT terms are not merged
 	}
@@ -227,8 +240,82 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 	if ((tid & 63) == 0) s_part[tid >> 6] = before;
 	__syncthreads();
 	if (tid == 0) p.bucket_off[range] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-	__syncthreads();   // s_part is reused for the popcount below
-	for (uint32_t t = 0; t < (p.simple ? 0u : p.nterms); ++t) {
+	__syncthreads();   // s_part is reused below
+	FT_STAMP(p, 1);
+	const uint32_t nterms = p.simple ? 0u : p.nterms;
+	const uint32_t ns = nterms ? (p.n_subs < kFtRangeSubs ? p.n_subs : kFtRangeSubs) : 0u;
+	// ---- all staged segments laid end to end; the first kFtStage postings of that layout are fetched NOW, every load independent of the
+	// others: the terms below then run out of LDS.  (Walking the sub-terms one after the other, each behind its own load round trips —
+	// list pointer, document ids, a second round for segments over 1024 postings — took 23 us of this kernel's 40 for a 3 x 3 query.)
+	if (ns) {
+		const uint32_t a = 2 * tid, b = 2 * tid + 1;
+		const uint32_t la = a < ns ? s_hi[a] - s_lo[a] : 0u, lb = b < ns ? s_hi[b] - s_lo[b] : 0u;
+		const uint32_t incl = wave_inclusive_scan(la + lb, int(tid & 63));
+		if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+		__syncthreads();
+		uint32_t excl = incl - (la + lb);
+		for (uint32_t w = 0; w < (tid >> 6); ++w) excl += s_part[w];
+		if (a < ns) s_start[a] = excl;
+		if (b < ns) s_start[b] = excl + la;
+		if (a < ns) s_elem0[a] = s_docptr[a] + s_lo[a] - excl;
+		if (b < ns) s_elem0[b] = s_docptr[b] + s_lo[b] - (excl + la);
+		if (b + 1 == ns) {   // the thread that holds the last staged sub-term also writes the end marker
+			s_start[ns] = excl + la + lb;
+		} else if (a + 1 == ns) {
+			s_start[ns] = excl + la;
+		}
+		__syncthreads();
+	}
+	FT_STAMP(p, 7);
+	const uint32_t total_staged = ns ? s_start[ns] : 0u;
+	const uint32_t n_stage = total_staged < kFtStage ? total_staged : kFtStage;
+	{
+		// 32 postings per thread.  Which sub-term holds flat position f: a branch-free binary search that advances all 32 positions of the
+		// thread one level at a time (the LDS reads of a level are independent; 32 separate search loops cost 9 us in LDS round trips),
+		// then every global load is issued before the first one is consumed.
+		constexpr int kPer = kFtStage / 256;
+		uint32_t pos[kPer], dd[kPer];
+#pragma unroll
+		for (int q = 0; q < kPer; ++q) pos[q] = 0;
+		if (ns <= 16) {   // the usual query: the slice starts in registers, position = how many starts lie at or before f
+			uint32_t st[16];
+#pragma unroll
+			for (int j = 1; j < 16; ++j) st[j] = s_start[uint32_t(j) < ns ? uint32_t(j) : ns];   // padding = the total: beyond every staged f
+#pragma unroll
+			for (int q = 0; q < kPer; ++q) {
+				const uint32_t f = uint32_t(q) * 256 + tid;
+#pragma unroll
+				for (int j = 1; j < 16; ++j) pos[q] += uint32_t(j) < ns && st[j] <= f ? 1u : 0u;
+			}
+		} else {
+			uint32_t top = 1;
+			while (top * 2 < ns) top *= 2;   // uniform
+			for (uint32_t step = top; step; step >>= 1) {
+#pragma unroll
+				for (int q = 0; q < kPer; ++q) {
+					const uint32_t cand = pos[q] + step;
+					const uint32_t start = s_start[cand < ns ? cand : ns];   // s_start[ns] = the total: past every staged position
+					if (cand < ns && start <= uint32_t(q) * 256 + tid) pos[q] = cand;
+				}
+			}
+		}
+		FT_STAMP(p, 8);
+#pragma unroll
+		for (int q = 0; q < kPer; ++q) {
+			const uint32_t f = uint32_t(q) * 256 + tid;
+			dd[q] = f < n_stage ? s_elem0[pos[q]][f] : 0u;
+		}
+		FT_STAMP(p, 9);
+#pragma unroll
+		for (int q = 0; q < kPer; ++q) {
+			const uint32_t f = uint32_t(q) * 256 + tid;
+			if (f < n_stage) s_stage[f] = uint16_t(dd[q] - uint32_t(d_begin));
+		}
+		FT_STAMP(p, 10);
+	}
+	__syncthreads();
+	FT_STAMP(p, 6);
+	for (uint32_t t = 0; t < nterms; ++t) {
 		const FtTermCfg& term = p.terms[t];
 		const int op = term.op;
 		const bool want_score = p.prescore && op != 3;
@@ -238,16 +325,18 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 			s_seen[w] = 0;
 		}
 		__syncthreads();
-		const bool need_entries = (op == 2 && !term.all_pos_boost) || (want_score && !term.same_boost);
-		auto visit = [&](const FtPosSubterm& s, uint32_t i, uint32_t d) {
-			const uint32_t local = uint32_t(d - d_begin);
+		// the term's configuration in registers: `term` lives in global memory, and a load per posting sat on the critical path
+		const bool all_pos_boost = term.all_pos_boost != 0, same_boost = term.same_boost != 0;
+		const float boost0 = term.field_boost[0], opts_boost = term.opts_boost;
+		const bool need_entries = (op == 2 && !all_pos_boost) || (want_score && !same_boost);
+		auto visit = [&](const FtPosSubterm& s, float sproc, uint32_t i, uint32_t local) {
 			const uint32_t bit = 1u << (local & 31);
 			if (op == 3) {
 				atomicAnd(&s_mask[local >> 5], ~bit);
 				return;
 			}
-			bool rel = term.all_pos_boost;
-			float mb = term.field_boost[0];
+			bool rel = all_pos_boost;
+			float mb = boost0;
 			if (need_entries) {   // maxFieldsBoost (phrasemergerimpl.h:127-160) / relevance of the occurrence
 				mb = 0.0f;
 				rel = false;
@@ -256,15 +345,15 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 					mb = fmaxf(mb, fb);
 					rel = rel || fb != 0.0f;
 				}
-				if (term.same_boost) mb = term.field_boost[0];
-				if (term.all_pos_boost) rel = true;
+				if (same_boost) mb = boost0;
+				if (all_pos_boost) rel = true;
 			}
 			if (op == 2 && rel) atomicOr(&s_term[local >> 5], bit);
 			if (want_score && mb > 0.0f) {
 				// termMask: documents are unique inside a sub-term and earlier sub-terms are behind a barrier, so the first one wins
 				const uint32_t old = atomicOr(&s_seen[local >> 5], bit);
 				if (!(old & bit)) {
-					const float proc = s.proc * mb * term.opts_boost;
+					const float proc = sproc * mb * opts_boost;
 					uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
 					p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
 					const uint32_t cur = s_score[local];
@@ -273,72 +362,88 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 				}
 			}
 		};
-		// Sub-terms go in SortSubterms order behind barriers ("the first one holding the document wins"), but their document ids do not depend
-		// on each other: the first 1024 postings of up to four sub-terms are fetched together — one load latency per group, not per sub-term.
-		constexpr int kGroup = 4;
-		for (uint32_t g0 = term.sub_begin; g0 < term.sub_end; g0 += kGroup) {
-			uint32_t lo[kGroup], hi[kGroup], dd[kGroup][4];
+		// sub-terms in SortSubterms order behind barriers ("the first one holding the document wins")
+		const uint32_t sub_begin = term.sub_begin, sub_end = term.sub_end;
+		for (uint32_t si = sub_begin; si < sub_end; ++si) {
+			const FtPosSubterm& s = p.subs[si];
+			uint32_t lo, hi, from_global;
+			float sproc;
+			if (si < ns) {
+				lo = s_lo[si];
+				hi = s_hi[si];
+				sproc = s_proc[si];
+				const uint32_t f_begin = s_start[si], f_end = s_start[si + 1];
+				const uint32_t staged_end = f_end < n_stage ? f_end : n_stage;
+				if (op == 3 || need_entries) {
+					for (uint32_t f = f_begin + tid; f < staged_end; f += 256) visit(s, sproc, lo + (f - f_begin), s_stage[f]);
+				} else {
+					// the common case (no per-entry field test), four postings per thread and step: their LDS reads and atomics are
+					// independent, so the four chains (stage -> seen bit -> score) overlap instead of running one after the other
+					const float proc = sproc * boost0 * opts_boost;
+					uint32_t p16c = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
+					p16c = p16c < 65535u / 4 ? p16c : 65535u / 4;
+					const bool scoring = want_score && boost0 > 0.0f;
+					for (uint32_t f0 = f_begin; f0 < staged_end; f0 += 4 * 256) {
+						uint32_t loc[4], old[4];
+						bool ok[4];
 #pragma unroll
-			for (int j = 0; j < kGroup; ++j) {
-				const uint32_t si = g0 + j;
-				lo[j] = hi[j] = 0;
-				if (si < term.sub_end) {
-					if (si < kFtRangeSubs) {
-						lo[j] = s_lo[si];
-						hi[j] = s_hi[si];
-					} else {
-						const FtPosSubterm& s = p.subs[si];
-						lo[j] = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
-						hi[j] = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+						for (int q = 0; q < 4; ++q) {
+							const uint32_t f = f0 + uint32_t(q) * 256 + tid;
+							ok[q] = f < staged_end;
+							loc[q] = ok[q] ? uint32_t(s_stage[f]) : 0u;
+						}
+						if (op == 2) {   // all_pos_boost: every occurrence is relevant
+#pragma unroll
+							for (int q = 0; q < 4; ++q) {
+								if (ok[q]) atomicOr(&s_term[loc[q] >> 5], 1u << (loc[q] & 31));
+							}
+						}
+						if (scoring) {
+#pragma unroll
+							for (int q = 0; q < 4; ++q) old[q] = ok[q] ? atomicOr(&s_seen[loc[q] >> 5], 1u << (loc[q] & 31)) : 0xFFFFFFFFu;
+#pragma unroll
+							for (int q = 0; q < 4; ++q) {
+								if ((old[q] >> (loc[q] & 31)) & 1u) continue;   // an earlier sub-term of the term holds the document
+								const uint32_t cur = s_score[loc[q]];
+								const uint32_t add = p16c < 65535u - cur ? p16c : 65535u - cur;
+								s_score[loc[q]] = uint16_t(cur + add);
+							}
+						}
 					}
 				}
+				from_global = lo + (staged_end > f_begin ? staged_end - f_begin : 0u);   // what did not fit the stage
+			} else {
+				lo = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
+				hi = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
+				sproc = s.proc;
+				from_global = lo;
 			}
-#pragma unroll
-			for (int j = 0; j < kGroup; ++j) {
-				const uint32_t* doc = g0 + j < term.sub_end ? p.subs[g0 + j].doc : nullptr;
+			for (uint32_t base = from_global; base < hi; base += 4 * 256) {
+				uint32_t idx[4], d4[4];
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
-					const uint32_t idx = lo[j] + uint32_t(q) * 256 + tid;
-					dd[j][q] = idx < hi[j] ? doc[idx] : 0u;
+					idx[q] = base + uint32_t(q) * 256 + tid;
+					d4[q] = idx[q] < hi ? s.doc[idx[q]] : 0u;
 				}
-			}
-#pragma unroll
-			for (int j = 0; j < kGroup; ++j) {
-				if (g0 + j >= term.sub_end) break;   // uniform
-				const FtPosSubterm& s = p.subs[g0 + j];
 #pragma unroll
 				for (int q = 0; q < 4; ++q) {
-					const uint32_t idx = lo[j] + uint32_t(q) * 256 + tid;
-					if (idx < hi[j]) visit(s, idx, dd[j][q]);
+					if (idx[q] < hi) visit(s, sproc, idx[q], uint32_t(d4[q] - d_begin));
 				}
-				for (uint32_t base = lo[j] + 4 * 256; base < hi[j]; base += 4 * 256) {   // the rest of a long segment
-					uint32_t idx[4], d4[4];
-#pragma unroll
-					for (int q = 0; q < 4; ++q) {
-						idx[q] = base + uint32_t(q) * 256 + tid;
-						d4[q] = idx[q] < hi[j] ? s.doc[idx[q]] : 0u;
-					}
-#pragma unroll
-					for (int q = 0; q < 4; ++q) {
-						if (idx[q] < hi[j]) visit(s, idx[q], d4[q]);
-					}
-				}
-				__syncthreads();   // the next sub-term of the term sees this one's documents
 			}
+			__syncthreads();   // the next sub-term of the term sees this one's documents
 		}
 		if (op == 2) {   // restrictingMask_ &= termMask (an AND term without postings empties the range)
 			for (uint32_t w = tid; w < kWords; w += 256) s_mask[w] &= s_term[w];
 			__syncthreads();
 		}
+		FT_STAMP(p, 11 + (t < 4 ? t : 4));
 	}
-	// ---- the range's mask words + their popcount (the device half of the 2-phase gate)
+	FT_STAMP(p, 2);
+	// ---- the range's mask words + their popcount (the device half of the 2-phase gate).  The global stores come last: a barrier behind
+	// them would wait for their acknowledgement
 	uint32_t c = 0;
 	for (uint32_t w = tid; w < kWords; w += 256) {
-		const uint64_t gw = d_begin / 32 + w;
-		if (gw < p.nwords) {
-			p.mask[gw] = s_mask[w];
-			c += __popc(s_mask[w]);
-		}
+		if (d_begin / 32 + w < p.nwords) c += __popc(s_mask[w]);
 	}
 	c = wave_sum(c);
 	if ((tid & 63) == 0) s_part[tid >> 6] = c;
@@ -347,14 +452,32 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 		const uint32_t tot = s_part[0] + s_part[1] + s_part[2] + s_part[3];
 		if (tot) atomicAdd(&p.sync[kFtSyncPop], tot);
 	}
+	for (uint32_t w = tid; w < kWords; w += 256) {
+		const uint64_t gw = d_begin / 32 + w;
+		if (gw < p.nwords) p.mask[gw] = s_mask[w];
+	}
+	FT_STAMP(p, 3);
 	if (!p.prescore) return;
-	// ---- scores: masked-out / removed documents score 0 (mergerimpl.h:416-423); histogram of the rest through a small LDS hash table
-	for (uint32_t q = tid; q < kFtRangeDocs / 4; q += 256) {
-		const uint32_t l0 = q * 4;
+	// ---- scores: masked-out / removed documents score 0 (mergerimpl.h:416-423); histogram of the rest through a small LDS hash table.
+	// Few distinct scores occur (a handful of proc values and their sums), so plain counters would take 64-way same-address atomics from
+	// every wavefront: each key gets 16 counters on 16 different banks (the posting stage is free by now), lane l adds to counter l % 16
+	uint32_t* s_rep = reinterpret_cast<uint32_t*>(s_stage);   // [256 keys][16]
+	uint32_t* hist_copy = p.hist + size_t(range % kFtHistCopies) * kFtHistStride;
+	static_assert(kFtStage * sizeof(uint16_t) >= 256 * 16 * sizeof(uint32_t), "the posting stage holds the replicated counters");
+	for (uint32_t i = tid; i < 256 * 16; i += 256) s_rep[i] = 0;
+	__syncthreads();
+	uint32_t rm8[kFtRangeDocs / 4 / 256];   // the removed flags of the thread's documents (4 per word), fetched together
+#pragma unroll
+	for (uint32_t j = 0; j < kFtRangeDocs / 4 / 256; ++j) {
+		const uint32_t l0 = (j * 256 + tid) * 4;
+		rm8[j] = (p.removed && l0 < docs_here) ? *reinterpret_cast<const uint32_t*>(p.removed + d_begin + l0) : 0u;   // reads past the end stay inside the allocation
+	}
+#pragma unroll
+	for (uint32_t j = 0; j < kFtRangeDocs / 4 / 256; ++j) {
+		const uint32_t l0 = (j * 256 + tid) * 4;
 		if (l0 >= docs_here) break;
 		const uint32_t mw = s_mask[l0 >> 5];
-		uint32_t rm = 0;
-		if (p.removed) rm = *reinterpret_cast<const uint32_t*>(p.removed + d_begin + l0);   // 4 flags; reads past the end stay inside the allocation
+		const uint32_t rm = rm8[j];
 		uint32_t sc[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
@@ -375,85 +498,123 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 					cur = atomicCAS(&s_keys[h], 0u, v);
 					if (cur != 0u && cur != v) continue;
 				}
-				atomicAdd(&s_cnts[h], 1u);
+				atomicAdd(&s_rep[h * 16 + (tid & 15)], 1u);
 				break;
 			}
 			if (probes == 256) atomicAdd(&p.hist[v], 1u);   // more than 256 distinct scores in one range
 		}
 	}
 	__syncthreads();
-	if (s_keys[tid]) atomicAdd(&p.hist[s_keys[tid]], s_cnts[tid]);
+	FT_STAMP(p, 4);
+	const uint32_t key = s_keys[tid];
+	uint32_t total = 0;
+	if (key) {
+#pragma unroll
+		for (int r = 0; r < 16; ++r) total += s_rep[tid * 16 + r];
+		atomicAdd(&hist_copy[key], total);
+	}
+	// the chunk totals: the keys of one chunk are combined inside the workgroup first — every workgroup holds the same few scores, and
+	// same-address device atomics from 600 workgroups on two or three chunk counters took 24 us when each key added on its own
+	__syncthreads();   // the replicated counters have been read: their space becomes the chunk table
+	uint32_t* s_ck = s_rep;          // [256] chunk + 1 (0 = free)
+	uint32_t* s_cc = s_rep + 256;    // [256] documents
+	s_ck[tid] = 0;
+	s_cc[tid] = 0;
+	__syncthreads();
+	if (key) {
+		const uint32_t ck = (key >> 6) + 1;
+		uint32_t h = (ck * 2654435761u) >> 24;
+		for (int probes = 0; probes < 256; ++probes, h = (h + 1) & 255u) {   // at most 256 keys: a free slot always turns up
+			uint32_t cur = s_ck[h];
+			if (cur != ck) {
+				if (cur != 0u) continue;
+				cur = atomicCAS(&s_ck[h], 0u, ck);
+				if (cur != 0u && cur != ck) continue;
+			}
+			atomicAdd(&s_cc[h], total);
+			break;
+		}
+	}
+	__syncthreads();
+	if (s_ck[tid]) atomicAdd(&hist_copy[65536 + s_ck[tid] - 1], s_cc[tid]);
+	FT_STAMP(p, 5);
 }
 
 // mergerimpl.h:433-446: walk the scores downwards until maxMergedDocs documents are covered.  A score sc is visited iff the documents
 // strictly above it are fewer than maxMergedDocs; minScore = the lowest visited score >= 1, minScoreDocs = maxMergedDocs - (documents above
-// it).  `above` is monotone, so the boundary falls inside ONE 64-score chunk: chunk sums by coalesced loads + wave reductions, a suffix
-// scan over the 1024 chunks, then one wavefront resolves the boundary chunk.
-__global__ __launch_bounds__(1024) void ft_preselect_pick(FtPlan p) {
-	if (!ft_preselect_on(p)) return;
-	__shared__ unsigned long long suffix[1024];   // documents in this chunk and every higher one
-	__shared__ uint32_t chunk_sum[1024];
-	__shared__ int s_chunk;
+// it).  `above` is monotone, so the boundary falls inside ONE chunk of 64 scores: ft_ranges also keeps the 1024 chunk totals
+// (behind the fine counters of every histogram copy), every workgroup of ft_preselect_apply finds the boundary chunk from those (one 16-byte load per thread, a suffix scan)
+// and one wavefront resolves it on the chunk's 64 fine counters — 4 KB + 256 B read per workgroup instead of a kernel of its own
+// (a single workgroup summing the 256 KB histogram: 11 us).
+__device__ void ft_pick_threshold(const FtPlan& p, uint32_t* out_score, uint32_t* out_docs) {
+	__shared__ uint32_t s_wave_tot[4], s_found[2], s_res[2];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	{   // thread t sums chunk t = scores [64 t, 64 t + 64): sixteen independent 16-byte loads in flight
-		const uint4* h4 = reinterpret_cast<const uint4*>(p.hist) + size_t(t) * 16;
-		uint4 v[16];
+	uint32_t c[4] = {0u, 0u, 0u, 0u};   // chunks 4 t .. 4 t + 3, summed over the copies
 #pragma unroll
-		for (int i = 0; i < 16; ++i) v[i] = h4[i];
-		uint32_t c = 0;
-#pragma unroll
-		for (int i = 0; i < 16; ++i) c += v[i].x + v[i].y + v[i].z + v[i].w;
-		chunk_sum[t] = c;
+	for (uint32_t k = 0; k < kFtHistCopies; ++k) {
+		const uint4 c4 = reinterpret_cast<const uint4*>(p.hist + size_t(k) * kFtHistStride + 65536)[t];
+		c[0] += c4.x;
+		c[1] += c4.y;
+		c[2] += c4.z;
+		c[3] += c4.w;
 	}
-	if (t == 0) s_chunk = -1;
-	__syncthreads();
-	suffix[t] = chunk_sum[t];
-	__syncthreads();
-	for (int off = 1; off < 1024; off <<= 1) {   // inclusive suffix sums
-		const unsigned long long v = t + off < 1024 ? suffix[t + off] : 0;
-		__syncthreads();
-		suffix[t] += v;
-		__syncthreads();
-	}
-	// the lowest chunk whose TOP score is visited (documents in higher chunks < maxMergedDocs); chunk 0 only counts through scores >= 1
-	const unsigned long long above_chunk = suffix[t] - chunk_sum[t];
-	const bool top_visited = above_chunk < p.max_merged;
-	const bool below_visited = t > 0 && suffix[t] < p.max_merged;   // would the top of chunk t - 1 be visited too?
-	if (top_visited && !below_visited) s_chunk = t;   // exactly one thread: `above` is monotone
-	__syncthreads();
-	uint32_t* pick = p.sync + kFtSyncPick;
-	const int c = s_chunk;
-	if (c < 0) {   // unreachable (the top chunk has nothing above it), kept as the reference's initial values
-		if (t == 0) {
-			pick[0] = 65535u;
-			pick[1] = 0;
-		}
-		return;
-	}
-	if (wave != 0) return;
-	const uint32_t sc = uint32_t(c * 64 + lane);
-	const uint32_t h = p.hist[sc];
-	uint32_t incl = h;   // inclusive suffix over the lanes: documents with a score in [sc, top of the chunk]
+	const uint32_t mine = c[0] + c[1] + c[2] + c[3];   // every document is counted once: the sums stay below 2^32
+	uint32_t incl = mine;   // inclusive suffix over the lanes
 #pragma unroll
 	for (int off = 1; off < 64; off <<= 1) {
 		const uint32_t o = __shfl_down(incl, off, 64);
 		if (lane + off < 64) incl += o;
 	}
-	const unsigned long long above = (suffix[c] - chunk_sum[c]) + (incl - h);
-	const bool visited = sc >= 1 && above < p.max_merged;
-	const unsigned long long vis = __ballot(visited);
-	if (!vis) {   // only score 0 of chunk 0 left: nothing with a positive score
-		if (lane == 0) {
-			pick[0] = 65535u;
-			pick[1] = 0;
+	if (lane == 0) s_wave_tot[wave] = incl;
+	if (t == 0) s_found[0] = 0xFFFFFFFFu;
+	__syncthreads();
+	uint32_t above = incl - mine;   // documents in the chunks above this thread's four
+	for (int w = wave + 1; w < 4; ++w) above += s_wave_tot[w];
+#pragma unroll
+	for (int k = 3; k >= 0; --k) {
+		const uint32_t g = uint32_t(4 * t + k);
+		// the lowest chunk whose TOP score is visited (documents in higher chunks < maxMergedDocs); chunk 0 only counts through scores >= 1
+		const bool top_visited = above < p.max_merged;
+		const bool below_visited = g > 0 && above + c[k] < p.max_merged;   // would the top of chunk g - 1 be visited too?
+		if (top_visited && !below_visited) {   // exactly one (thread, k): `above` is monotone
+			s_found[0] = g;
+			s_found[1] = above;
 		}
-		return;
+		above += c[k];
 	}
-	const int low = __ffsll((long long)vis) - 1;   // visited lanes form a suffix of the wave: the lowest one is minScore
-	if (lane == low) {
-		pick[0] = sc;
-		pick[1] = uint32_t(p.max_merged - above);
+	__syncthreads();
+	const uint32_t g = s_found[0];
+	if (wave == 0) {
+		uint32_t res_score = 65535u, res_docs = 0;   // the reference's initial values (unreachable for g: the top chunk has nothing above it)
+		if (g != 0xFFFFFFFFu) {
+			const uint32_t sc = g * 64 + uint32_t(lane);
+			uint32_t h = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < kFtHistCopies; ++k) h += p.hist[size_t(k) * kFtHistStride + sc];
+			uint32_t fine = h;   // inclusive suffix over the lanes: documents with a score in [sc, top of the chunk]
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const uint32_t o = __shfl_down(fine, off, 64);
+				if (lane + off < 64) fine += o;
+			}
+			const uint32_t above_sc = s_found[1] + (fine - h);
+			const bool visited = sc >= 1 && above_sc < p.max_merged;
+			const unsigned long long vis = __ballot(visited);
+			if (vis) {   // visited lanes form a suffix of the wave: the lowest one is minScore; none: only score 0 of chunk 0 is left
+				const int low = __ffsll((long long)vis) - 1;
+				res_score = uint32_t(__shfl(int(sc), low, 64));
+				res_docs = p.max_merged - uint32_t(__shfl(int(above_sc), low, 64));
+			}
+		}
+		if (lane == 0) {
+			s_res[0] = res_score;
+			s_res[1] = res_docs;
+		}
 	}
+	__syncthreads();
+	*out_score = s_res[0];
+	*out_docs = s_res[1];
+	__syncthreads();   // the shared words may be reused by the caller's next shared-memory helper
 }
 
 // mergerimpl.h:448-462: kFtApplyWords mask words per thread (the ordered prefix chain is as long as the grid: fewer, fatter workgroups);
@@ -462,7 +623,8 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
 	if (!ft_preselect_on(p)) return;
 	const uint32_t ticket = grab_ticket(p.sync + kFtSyncPreTicket);
 	const uint64_t w0 = (uint64_t(ticket) * 256 + threadIdx.x) * kFtApplyWords;
-	const uint32_t min_score = p.sync[kFtSyncPick], min_docs = p.sync[kFtSyncPick + 1];
+	uint32_t min_score, min_docs;
+	ft_pick_threshold(p, &min_score, &min_docs);
 	uint32_t bits[kFtApplyWords], gt[kFtApplyWords], tie[kFtApplyWords];
 	uint32_t ties = 0;
 #pragma unroll
@@ -520,6 +682,7 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 	__shared__ uint16_t s_item[kFtRankTiles * kFtBlockPostings];   // tile << 10 | thread << 2 | slot
 	__shared__ uint32_t s_doc[kFtRankTiles * kFtBlockPostings];
 	__shared__ uint32_t s_sub[kFtRankTiles], s_base[kFtRankTiles];
+	FT_STAMP(p, 16);
 	if (threadIdx.x == 0) s_cnt = 0;
 	if (threadIdx.x < kFtRankTiles) {
 		const uint32_t tile = blockIdx.x * kFtRankTiles + threadIdx.x;
@@ -582,6 +745,7 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 		}
 	}
 	__syncthreads();
+	FT_STAMP(p, 17);
 	const uint32_t cnt = s_cnt;
 	const int lane = threadIdx.x & 63;
 	for (uint32_t e0 = 0; e0 < cnt; e0 += 256) {   // uniform trip count: the wavefront votes below
@@ -622,6 +786,7 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 			pending &= ~same;
 		}
 	}
+	FT_STAMP(p, 18);
 }
 
 // 16-bit minimum in an LDS table of packed halves (there are no 16-bit LDS atomics; contention is one posting per (document, sub-term))
@@ -649,16 +814,12 @@ constexpr uint32_t kFtAdderRowsLds = 1024;
 __global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
 	__shared__ uint32_t s_tab[kFtRangeDocs / 2];   // first row of every document of the range, 16 bits each
 	__shared__ uint32_t s_rowcnt[kFtAdderRowsLds];
-	__shared__ uint32_t s_part[4];
-	__shared__ uint32_t s_last;
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
-	{
+	FT_STAMP(p, 24);
+	if (p.prescore) {   // ft_preselect_apply was the last reader of the histograms and of the look-back words
 		const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + tid, gsize = uint64_t(gridDim.x) * blockDim.x;
-		fill_words(reinterpret_cast<uint32_t*>(p.e_rank), uint64_t(p.n_rows) * p.max_merged, 0u, gtid, gsize);
-		if (p.prescore) {   // ft_preselect_apply was their last reader
-			fill_words(p.hist, 65536, 0u, gtid, gsize);
-			fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)) * 2, 0u, gtid, gsize);
-		}
+		fill_words(p.hist, uint64_t(kFtHistCopies) * kFtHistStride, 0u, gtid, gsize);
+		fill_words(reinterpret_cast<uint32_t*>(p.lookback_pre), ((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)) * 2, 0u, gtid, gsize);
 	}
 	const uint32_t n = p.bucket_cnt[range];
 	const bool lds_rows = p.n_rows <= kFtAdderRowsLds;
@@ -671,12 +832,14 @@ __global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
 		}
 	}
 	__syncthreads();
+	FT_STAMP(p, 25);
 	const uint4* rec = p.b_rec + p.bucket_off[range];
 	for (uint32_t e = tid; e < n; e += 256) {
 		const uint4 r = rec[e];
 		lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
 	}
 	__syncthreads();
+	FT_STAMP(p, 26);
 	for (uint32_t e = tid; e < n; e += 256) {
 		const uint4 r = rec[e];
 		const uint32_t row = r.w & 0xFFFFu;
@@ -691,34 +854,73 @@ __global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
 	if (lds_rows) {
 		for (uint32_t r = tid; r < p.n_rows; r += 256) p.adders[uint64_t(r) * p.n_ranges + range] = s_rowcnt[r];
 	}
-	// ---- the last workgroup scans the table
-	__threadfence();
-	__syncthreads();
-	if (tid == 0) s_last = atomicAdd(&p.sync[kFtSyncDoneAdders], 1u) == gridDim.x - 1 ? 1u : 0u;
-	__syncthreads();
-	if (!s_last) return;
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' counts (their release: the fence before the counter)
-	const uint64_t total = uint64_t(p.n_rows) * p.n_ranges, per = (total + 255) / 256;
-	const uint64_t a = std::min<uint64_t>(total, uint64_t(tid) * per), b = std::min<uint64_t>(total, a + per);
-	uint32_t local = 0;
-	for (uint64_t j = a; j < b; ++j) local += p.adders[j];
-	const uint32_t incl = wave_inclusive_scan(local, int(tid & 63));
-	if ((tid & 63) == 63) s_part[tid >> 6] = incl;
-	__syncthreads();
-	uint32_t running = incl - local;
-	for (uint32_t w = 0; w < (tid >> 6); ++w) running += s_part[w];
-	for (uint64_t j = a; j < b; ++j) {
-		const uint32_t v = p.adders[j];
-		p.adders[j] = running;
-		running += v;
+	FT_STAMP(p, 27);
+}
+
+// The table of ft_adders -> its exclusive prefix in row-major order = the merge slot of the first document of every (row, range), and the
+// number of merged documents.  One workgroup, behind a kernel boundary: an in-kernel hand-over (every workgroup releasing at agent scope
+// before an arrival counter) cost 29 us — each release writes back the dirty lines of its XCD's L2.
+// Tiles of 2048 entries: eight consecutive loads per thread in flight, one workgroup scan, eight stores.
+__global__ __launch_bounds__(256) void ft_slot_bases(FtPlan p) {
+	__shared__ uint32_t s_part[4];
+	const uint32_t tid = threadIdx.x;
+	const uint64_t total = uint64_t(p.n_rows) * p.n_ranges;
+	uint32_t carry = 0;
+	for (uint64_t base = 0; base < total; base += 256 * 8) {
+		const uint64_t j0 = base + uint64_t(tid) * 8;
+		uint32_t v[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) v[k] = j0 + k < total ? p.adders[j0 + k] : 0u;
+		uint32_t local = 0;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) local += v[k];
+		const uint32_t incl = wave_inclusive_scan(local, int(tid & 63));
+		if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+		__syncthreads();
+		uint32_t running = carry + incl - local;
+		for (uint32_t w = 0; w < (tid >> 6); ++w) running += s_part[w];
+		carry += s_part[0] + s_part[1] + s_part[2] + s_part[3];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			if (j0 + k < total) p.adders[j0 + k] = running;
+			running += v[k];
+		}
+		__syncthreads();   // s_part is rewritten by the next tile
 	}
-	if (tid == 255) p.sync[kFtSyncNumDocs] = running < p.max_merged ? running : p.max_merged;   // the last thread ends on the grand total
+	if (tid == 0) p.sync[kFtSyncNumDocs] = carry < p.max_merged ? carry : p.max_merged;
 }
 
 // mergerimpl.h:20-37; fullPos()/fullField() truncate the 64-bit PosType to uint32_t exactly like the reference's accessors
 __device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb) {
 	unsigned res = 0xFFFFFFFFu;
 	uint32_t i = 0, j = 0;
+	if (na <= 4 && nb <= 4) {   // the usual case: both lists fetched at once (eight independent loads), the walk runs on registers
+		uint64_t ra[4], rb[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			ra[k] = k < na ? a[k] : 0ull;
+			rb[k] = k < nb ? b[k] : 0ull;
+		}
+		while (i < na && j < nb) {
+			const uint64_t pa = i == 0 ? ra[0] : i == 1 ? ra[1] : i == 2 ? ra[2] : ra[3];
+			const uint64_t pb = j == 0 ? rb[0] : j == 1 ? rb[1] : j == 2 ? rb[2] : rb[3];
+			const uint32_t fa = uint32_t(pa), fb = uint32_t(pb);
+			const bool sign = fa > fb;
+			if (uint32_t(pa >> 28) == uint32_t(pb >> 28)) {
+				const unsigned dst = sign ? fa - fb : fb - fa;
+				if (dst < res) {
+					res = dst;
+					if (res <= 1) break;
+				}
+			}
+			if (sign) {
+				++j;
+			} else {
+				++i;
+			}
+		}
+		return res == 0xFFFFFFFFu ? 0 : res;
+	}
 	while (i < na && j < nb) {
 		const uint64_t pa = a[i], pb = b[j];
 		const uint32_t fa = uint32_t(pa), fb = uint32_t(pb);
@@ -860,6 +1062,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 	__shared__ uint16_t s_qp[kFtReplayRows];
 	__shared__ uint32_t s_nadd, s_last;
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	FT_STAMP(p, 32);
 	const uint32_t n = p.bucket_cnt[range];
 	if (n) {
 		for (uint32_t row = tid; row < p.n_rows && row < kFtReplayRows; row += 256) {   // two dependent loads per row, once per workgroup
@@ -871,12 +1074,14 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		for (uint32_t w = tid; w < kFtRangeDocs / 2; w += 256) s_tab[w] = 0xFFFFFFFFu;
 		if (tid == 0) s_nadd = 0;
 		__syncthreads();
+		FT_STAMP(p, 33);
 		uint4* rec = p.b_rec + p.bucket_off[range];
 		for (uint32_t e = tid; e < n; e += 256) {
 			const uint4 r = rec[e];
 			lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
 		}
 		__syncthreads();
+		FT_STAMP(p, 34);
 		for (uint32_t e = tid; e < n; e += 256) {   // the range's first postings: key (row, document); the record remembers that it adds
 			const uint4 r = rec[e];
 			const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
@@ -885,6 +1090,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			rec[e].w = r.w | 0x80000000u;
 		}
 		__syncthreads();
+		FT_STAMP(p, 35);
 		const uint32_t A = s_nadd;   // <= kFtRangeDocs: one per document
 		uint32_t N = 2;
 		while (N < A) N <<= 1;
@@ -903,6 +1109,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 				__syncthreads();
 			}
 		}
+		FT_STAMP(p, 36);
 		// rank inside the row = position - first position of the row (binary search); parked in the document table, whose first-row
 		// entries are no longer needed
 		for (uint32_t q = tid; q < A; q += 256) {
@@ -919,6 +1126,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			lds_set_u16(s_tab, key & (kFtRangeDocs - 1), q - lo);
 		}
 		__syncthreads();
+		FT_STAMP(p, 37);
 		const uint32_t d_begin = range << kFtRangeShift;
 		for (uint32_t q = tid; q < A; q += 256) {   // key -> slot; document -> its position in the list
 			const uint32_t key = s_keys[q], row = key >> kFtRangeShift, dl = key & (kFtRangeDocs - 1);
@@ -928,6 +1136,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
 		}
 		__syncthreads();
+		FT_STAMP(p, 38);
 		for (uint32_t e = tid; e < n; e += 256) {   // every posting of a merged document into the document's row, column = its sub-term
 			const uint4 r = rec[e];
 			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
@@ -938,21 +1147,30 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			p.e_field[cell] = uint8_t((r.w >> 16) & 0xFFu);
 		}
 		__syncthreads();   // the rows are read back by this workgroup only
+		FT_STAMP(p, 39);
 		for (uint32_t e = tid; e < n; e += 256) {
 			const uint4 r = rec[e];
 			if (!(r.w >> 31)) continue;
 			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
 			if (sl < p.max_merged) ft_replay_doc(p, sl, r.x, s_fpos, s_pos_off, s_qp);
 		}
+		__syncthreads();
+		for (uint32_t e = tid; e < n; e += 256) {   // the entry rows go back ZEROED: the occupancy test of the next merge relies on it
+			const uint4 r = rec[e];
+			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
+			if (sl < p.max_merged) p.e_rank[uint64_t(r.w & 0xFFFFu) * p.max_merged + sl] = 0.0f;
+		}
 	}
 	// ---- leave the shared tables clean for the next merge; the last workgroup writes the result header
 	__syncthreads();
+	FT_STAMP(p, 40);
 	if (tid == 0) {
 		if (n) p.bucket_cnt[range] = 0;
-		__threadfence();
+		// no release: the last workgroup reads nothing the others wrote in this kernel (header values come from the kernels before)
 		s_last = atomicAdd(&p.sync[kFtSyncDoneFinish], 1u) == gridDim.x - 1 ? 1u : 0u;
 	}
 	__syncthreads();
+	FT_STAMP(p, 41);
 	if (!s_last) return;
 	if (tid == 0) {
 		p.out_header[0] = p.sync[kFtSyncNumDocs];
@@ -971,11 +1189,11 @@ hipError_t launch_ft_merge(const FtPlan& p, hipStream_t st) {
 	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&ft_finish), kFinishLds); e != hipSuccess) return e;
 	hipLaunchKernelGGL(ft_ranges, dim3(p.n_ranges), dim3(256), 0, st, p);
 	if (!p.simple && p.prescore) {
-		hipLaunchKernelGGL(ft_preselect_pick, dim3(1), dim3(1024), 0, st, p);
 		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
 	}
 	if (p.merge_blocks) hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankTiles - 1) / kFtRankTiles), dim3(256), 0, st, p);
 	hipLaunchKernelGGL(ft_adders, dim3(p.n_ranges), dim3(256), 0, st, p);
+	hipLaunchKernelGGL(ft_slot_bases, dim3(1), dim3(256), 0, st, p);
 	hipLaunchKernelGGL(ft_finish, dim3(p.n_ranges), dim3(256), kFinishLds, st, p);
 	return hipGetLastError();
 }

@@ -63,8 +63,8 @@ struct rxgpu_ft_index {
 	std::mutex mtx;
 	hipStream_t stream = nullptr;
 	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
-	// tables every merge finds ZEROED and leaves zeroed (ft_adders / ft_finish clear what the merge used): pre-score histogram, look-back
-	// words of the preselect, bucket counters, synchronisation words.  Cleared by the host only when (re)allocated or after a failed merge.
+	// tables every merge finds ZEROED and leaves zeroed (the kernel that reads one last clears it): pre-score histogram, look-back words of
+	// the preselect, bucket counters, synchronisation words, the occupancy (rank) plane of the entry rows.  Cleared by the host only when (re)allocated or after a failed merge.
 	rxgpu_devbuf d_clean;
 	uint64_t clean_docs = 0;
 	bool clean_dirty = true;
@@ -86,6 +86,7 @@ struct rxgpu_ft_index {
 	}
 	uint64_t stat_postings = 0;
 	double stat_ms = 0.0;
+	double stamps[64] = {};   // RXGPU_FT_STAMPS: summed phase stamps (relative to the workgroup's first), see rxgpu_ft_read_stats
 	double trace_us[6] = {0, 0, 0, 0, 0, 0};   // RXGPU_FT_TRACE: plan build, staging + upload, launches, wait + download, unpack, merges
 };
 
@@ -382,7 +383,6 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t o_brec = cv.take(size_t(merged_postings) * sizeof(uint4));
 	const size_t o_boff = cv.take(size_t(n_ranges) * 4);
 	const size_t o_adders = cv.take(std::max<size_t>(1, size_t(n_rows) * n_ranges) * 4);
-	const size_t o_erank = cv.take(size_t(n_rows) * M * 4);
 	const size_t o_eidx = cv.take(size_t(n_rows) * M * 4);
 	const size_t o_efield = cv.take(size_t(n_rows) * M);
 	const size_t o_excl = cv.take(excluded ? N : 0);
@@ -390,10 +390,12 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	char* base = static_cast<char*>(h->d_state.ptr);
 	// the kept-clean tables: sized by the corpus only, so that they stay where they are from merge to merge
 	Carver cc;
-	const size_t o_hist = cc.take(65536 * 4);
+	const size_t o_hist = cc.take(size_t(rxgpu::kFtHistCopies) * rxgpu::kFtHistStride * 4);   // copies of (fine + coarse)
 	const size_t o_lb_pre = cc.take(((nwords + 1023) / 1024) * 8);
 	const size_t o_bcnt = cc.take(size_t(n_ranges) * 4);
 	const size_t o_sync = cc.take(rxgpu::kFtSyncWords * 4);
+	const size_t o_dbg = cc.take(64 * 8);
+	const size_t o_erank = cc.take(size_t(n_rows) * M * 4);   // last: the regions before it never move when a query needs more rows
 	if (h->clean_docs != N || h->d_clean.bytes < cc.off) {
 		if (int rc = h->d_clean.ensure(cc.off); rc) return rc;
 		h->clean_docs = N;
@@ -441,7 +443,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 
 	hipStream_t st = h->stream;
 	if (h->clean_dirty) {
-		RX_HIP(hipMemsetAsync(cbase, 0, cc.off, st));
+		RX_HIP(hipMemsetAsync(cbase, 0, h->d_clean.bytes, st));
 		h->clean_dirty = false;
 	}
 	RX_HIP(hipMemcpyAsync(base, hp, plan_bytes, hipMemcpyHostToDevice, st));
@@ -477,10 +479,13 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.bucket_cnt = reinterpret_cast<uint32_t*>(cbase + o_bcnt);
 	p.adders = reinterpret_cast<uint32_t*>(base + o_adders);
 	p.n_ranges = n_ranges;
-	p.e_rank = reinterpret_cast<float*>(base + o_erank);
+	p.e_rank = reinterpret_cast<float*>(cbase + o_erank);
 	p.e_idx = reinterpret_cast<uint32_t*>(base + o_eidx);
 	p.e_field = reinterpret_cast<uint8_t*>(base + o_efield);
 	p.sync = reinterpret_cast<uint32_t*>(cbase + o_sync);
+	const char* stamps_env = std::getenv("RXGPU_FT_STAMPS");
+	p.dbg = stamps_env ? reinterpret_cast<unsigned long long*>(cbase + o_dbg) : nullptr;
+	p.dbg_block = stamps_env ? uint32_t(std::atoi(stamps_env)) : 0;
 	p.out_header = reinterpret_cast<uint32_t*>(ob);
 	p.out_doc = reinterpret_cast<uint32_t*>(ob + align256(16));
 	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));
@@ -502,6 +507,17 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const auto t_wait = clk::now();
 	RX_HIP(hipMemcpyAsync(hp, ob, out_need, hipMemcpyDeviceToHost, st));   // header + the four result arrays in one copy
 	RX_HIP(hipStreamSynchronize(st));
+	if (p.dbg) {
+		unsigned long long raw[64];
+		RX_HIP(hipMemcpy(raw, p.dbg, sizeof(raw), hipMemcpyDeviceToHost));
+		RX_HIP(hipMemset(p.dbg, 0, sizeof(raw)));
+		const int groups[][2] = {{0, 16}, {16, 24}, {24, 32}, {32, 48}};
+		for (const auto& g : groups) {
+			for (int k = g[0]; k < g[1]; ++k) {
+				if (raw[k] && raw[g[0]]) h->stamps[k] += double(raw[k] - raw[g[0]]) * 0.01;   // 100 MHz -> us
+			}
+		}
+	}
 	h->trace_us[3] += since(t_wait);
 	const auto t_unpack = clk::now();
 	float ms = 0.f;
@@ -608,6 +624,18 @@ int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms
 		const double m = h->trace_us[5];
 		std::fprintf(stderr, "[rxgpu ft trace] per merge (us): plan %.1f  stage+upload %.1f  launches %.1f  wait+download %.1f  unpack %.1f  (kernels %.1f)\n",
 					 h->trace_us[0] / m, h->trace_us[1] / m, h->trace_us[2] / m, h->trace_us[3] / m, h->trace_us[4] / m, h->stat_ms * 1e3 / m);
+		if (std::getenv("RXGPU_FT_STAMPS")) {
+			auto line = [&](const char* name, int a, int b) {
+				std::fprintf(stderr, "[rxgpu ft stamps] %-12s", name);
+				for (int k = a; k < b; ++k) std::fprintf(stderr, " %d:%.1f", k, h->stamps[k] / m);
+				std::fprintf(stderr, "\n");
+			};
+			line("ft_ranges", 0, 16);
+			line("ft_rank_all", 16, 19);
+			line("ft_adders", 24, 32);
+			line("ft_finish", 32, 42);
+			for (double& v : h->stamps) v = 0;
+		}
 		for (double& v : h->trace_us) v = 0;
 	}
 	h->stat_postings = 0;

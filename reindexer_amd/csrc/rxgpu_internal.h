@@ -136,7 +136,10 @@ struct FtPlan {
 	const uint8_t* excluded;
 	uint32_t* mask;            // restrictingMask_ [nwords]
 	uint16_t* score;           // [total_docs]
-	uint32_t* hist;            // [65536]
+	// pre-score histogram in kFtHistCopies interleaved copies (workgroup b of ft_ranges adds to copy b % kFtHistCopies; the reader sums them):
+	// every workgroup holds the same handful of scores, and same-address device atomics are served one at a time.
+	// Copy c = hist + c * kFtHistStride: [65536] documents per pre-score, then [1024] documents per chunk of 64 scores.
+	uint32_t* hist;
 	// admission (ft_rank_all -> ft_adders -> ft_finish): the eligible postings with a non-zero rank, bucketed by document range
 	uint4* b_rec;              // [merged postings] records {doc, posting index, rank bits, row | field << 16}; bucket r starts at bucket_off[r]
 	uint32_t* bucket_off;      // [n_ranges] = merged postings in front of the range (sum of the sub-terms' range offsets), written by ft_ranges
@@ -146,6 +149,8 @@ struct FtPlan {
 	float* e_rank;             // per-slot entry table [n_rows][max_merged]: 0 = the document has no posting in that sub-term
 	uint32_t* e_idx;
 	uint8_t* e_field;
+	unsigned long long* dbg;   // RXGPU_FT_STAMPS=<workgroup>: wall-clock stamps of that workgroup's phases (null otherwise)
+	uint32_t dbg_block;
 	uint32_t* sync;            // kFtSync* words; kept zero between merges (the last workgroup of ft_finish clears them)
 	unsigned long long* lookback_pre;     // [ceil(nwords / (256 * 4))]
 	// packed result: header (4 x u32: numDocs, error flag, preselected, 0) then doc[max_merged] u32, proc[max_merged] f32,
@@ -158,6 +163,7 @@ struct FtPlan {
 };
 enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPick = 2 /* +1 */, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6,
 				  kFtSyncPreselected = 7, kFtSyncDoneAdders = 8, kFtSyncDoneFinish = 9, kFtSyncWords = 16 };
+constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
 hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" && mkdir -p gpurun_out && export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_bm25.py tests/test_gpu_ft_terms.py tests/test_gpu_hybrid.py -x -q > gpurun_out/${TAG}_tests.log 2>&1
 tail -8 gpurun_out/${TAG}_tests.log
-RXGPU_FT_TRACE=1 timeout 600 python tools/bench_bm25.py --ops 1,1,1 --docs 5000000 --queries 30 --out gpurun_out/${TAG}_bm25_terms_1_1_1.json > gpurun_out/${TAG}_bm25_terms.log 2>&1
+RXGPU_FT_TRACE=1 RXGPU_FT_STAMPS=${STAMP_BLOCK:-300} timeout 600 python tools/bench_bm25.py --ops 1,1,1 --docs 5000000 --queries 30 --out gpurun_out/${TAG}_bm25_terms_1_1_1.json > gpurun_out/${TAG}_bm25_terms.log 2>&1
 tail -c 1800 gpurun_out/${TAG}_bm25_terms.log
 timeout 600 python tools/bench_bm25.py --docs 5000000 --queries 20 --out gpurun_out/${TAG}_bm25_single.json > gpurun_out/${TAG}_bm25_single.log 2>&1
 tail -c 600 gpurun_out/${TAG}_bm25_single.log
