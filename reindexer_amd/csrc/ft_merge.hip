@@ -682,14 +682,28 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 	__shared__ uint16_t s_item[kFtRankTiles * kFtBlockPostings];   // tile << 10 | thread << 2 | slot
 	__shared__ uint32_t s_doc[kFtRankTiles * kFtBlockPostings];
 	__shared__ uint32_t s_sub[kFtRankTiles], s_base[kFtRankTiles];
+	// the tiles' sub-term and term descriptors, copied once: calcTermRank reads a dozen of their fields per posting, and from global
+	// memory every first touch was one more round trip in front of the entry gathers
+	__shared__ FtPosSubterm s_subd[kFtRankTiles];
+	__shared__ FtTermCfg s_termd[kFtRankTiles];
+	static_assert(sizeof(FtPosSubterm) % 4 == 0 && sizeof(FtTermCfg) % 4 == 0, "descriptors are copied word by word");
 	FT_STAMP(p, 16);
 	if (threadIdx.x == 0) s_cnt = 0;
-	if (threadIdx.x < kFtRankTiles) {
-		const uint32_t tile = blockIdx.x * kFtRankTiles + threadIdx.x;
+	{
+		const uint32_t g = threadIdx.x >> 7, l = threadIdx.x & 127;   // 128 threads per tile: binary search by all (broadcast loads), copy by words
+		static_assert(kFtRankTiles == 2, "two tiles, 128 threads each");
+		const uint32_t tile = blockIdx.x * kFtRankTiles + g;
 		if (tile < p.merge_blocks) {
 			const FtGridEntry ge = grid_entry(p.merge_grid, p.n_merge_entries, tile);
-			s_sub[threadIdx.x] = ge.sub;
-			s_base[threadIdx.x] = ge.block_base;
+			if (l == 0) {
+				s_sub[g] = ge.sub;
+				s_base[g] = ge.block_base;
+			}
+			const uint32_t* src_s = reinterpret_cast<const uint32_t*>(p.subs + ge.sub);
+			if (l < sizeof(FtPosSubterm) / 4) reinterpret_cast<uint32_t*>(&s_subd[g])[l] = src_s[l];
+			const uint32_t term = p.subs[ge.sub].term;
+			const uint32_t* src_t = reinterpret_cast<const uint32_t*>(p.terms + term);
+			if (l < sizeof(FtTermCfg) / 4) reinterpret_cast<uint32_t*>(&s_termd[g])[l] = src_t[l];
 		}
 	}
 	__syncthreads();
@@ -704,7 +718,7 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 			docs[g][k] = 0;
 		}
 		if (tile >= p.merge_blocks) continue;
-		const FtPosSubterm& s = p.subs[s_sub[g]];
+		const FtPosSubterm& s = s_subd[g];
 		const uint64_t i0 = uint64_t(tile - s_base[g]) * kFtBlockPostings + uint64_t(threadIdx.x) * kFtPassItems;
 		if (i0 < s.n) load_docs(s, i0, docs[g], live[g]);
 	}
@@ -757,8 +771,8 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 		if (e < cnt) {
 			const uint32_t item = s_item[e], g = item >> 10, local = item & 1023u;
 			const uint32_t tile = blockIdx.x * kFtRankTiles + g;
-			const FtPosSubterm& s = p.subs[s_sub[g]];
-			const FtTermCfg& t = p.terms[s.term];
+			const FtPosSubterm& s = s_subd[g];
+			const FtTermCfg& t = s_termd[g];
 			const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
 			d = s_doc[e];
 			rank = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d, &field);
@@ -1051,6 +1065,12 @@ __device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint
 	p.out_terms_counter[sl] = terms_counter;
 }
 
+// The merge slot of the first document of (row, range) = the entries of ft_adders' table in front of it, in row-major order.  Up to
+// kFtFinishRows merged sub-terms (and 8192 entries) the table is small and every workgroup of ft_finish adds up its own bases (one pass, all
+// rows at once); larger queries run ft_slot_bases, which turns the table into its prefix.
+constexpr uint32_t kFtFinishRows = 16;
+__host__ __device__ inline bool ft_own_bases(const FtPlan& p) { return p.n_rows <= kFtFinishRows && uint64_t(p.n_rows) * p.n_ranges <= kFtRangeDocs; }
+
 // Slots, entry rows and the per-document replay of one document range.  Dynamic LDS: the 16-bit document table (first row, then the
 // position in the sorted key list) followed by the key list of the range's first postings ((row << 13 | document), then the slot).
 __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
@@ -1061,21 +1081,68 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 	__shared__ const uint32_t* s_pos_off[kFtReplayRows];
 	__shared__ uint16_t s_qp[kFtReplayRows];
 	__shared__ uint32_t s_nadd, s_last;
+	__shared__ uint32_t s_red[4][kFtFinishRows], s_rowbase[kFtFinishRows];
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	const bool own_bases = ft_own_bases(p);   // the table is small: every workgroup sums what lies in front of its own entries
 	FT_STAMP(p, 32);
+	// everything the workgroup fetches unconditionally is issued together: record count and bucket offset, the replay descriptors, and
+	// (own_bases) the whole table of ft_adders — pulled into the key area of the LDS, which is idle until the first postings are keyed.
+	// base(row) = every entry of the rows before it + this row's entries left of the range: one wavefront per row adds up (row total,
+	// part left of the range).  (Loops that consumed each load before issuing the next paid a memory round trip per row or per column
+	// chunk: 7-10 us; testing every entry against every row's position in registers: 9 us of VALU work.)
 	const uint32_t n = p.bucket_cnt[range];
+	const uint32_t bucket_off = p.bucket_off[range];
+	uint32_t tv[kFtRangeDocs / 256];
+	if (own_bases) {
+		const uint32_t total = p.n_rows * p.n_ranges;
+#pragma unroll
+		for (uint32_t k = 0; k < kFtRangeDocs / 256; ++k) tv[k] = k * 256 + tid < total ? p.adders[k * 256 + tid] : 0u;
+	}
+	for (uint32_t row = tid; row < p.n_rows && row < kFtReplayRows; row += 256) {   // two dependent loads per row, once per workgroup
+		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
+		s_fpos[row] = s.fpos;
+		s_pos_off[row] = s.pos_off;
+		s_qp[row] = s.qp;
+	}
 	if (n) {
-		for (uint32_t row = tid; row < p.n_rows && row < kFtReplayRows; row += 256) {   // two dependent loads per row, once per workgroup
-			const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
-			s_fpos[row] = s.fpos;
-			s_pos_off[row] = s.pos_off;
-			s_qp[row] = s.qp;
-		}
 		for (uint32_t w = tid; w < kFtRangeDocs / 2; w += 256) s_tab[w] = 0xFFFFFFFFu;
 		if (tid == 0) s_nadd = 0;
+		if (own_bases) {
+			const uint32_t total = p.n_rows * p.n_ranges;
+#pragma unroll
+			for (uint32_t k = 0; k < kFtRangeDocs / 256; ++k) {
+				if (k * 256 + tid < total) s_keys[k * 256 + tid] = tv[k];
+			}
+		}
+		__syncthreads();
+		if (own_bases) {
+			const uint32_t lane = tid & 63;
+			for (uint32_t r = tid >> 6; r < p.n_rows; r += 4) {
+				uint32_t rs = 0, ps = 0;
+				for (uint32_t c = lane; c < p.n_ranges; c += 64) {
+					const uint32_t x = s_keys[r * p.n_ranges + c];
+					rs += x;
+					ps += c < range ? x : 0u;
+				}
+				rs = wave_sum(rs);
+				ps = wave_sum(ps);
+				if (lane == 0) {
+					s_red[0][r] = rs;
+					s_red[1][r] = ps;
+				}
+			}
+		}
+		__syncthreads();
+		if (own_bases && tid == 0) {
+			uint32_t before_rows = 0;
+			for (uint32_t r = 0; r < p.n_rows; ++r) {
+				s_rowbase[r] = before_rows + s_red[1][r];
+				before_rows += s_red[0][r];
+			}
+		}
 		__syncthreads();
 		FT_STAMP(p, 33);
-		uint4* rec = p.b_rec + p.bucket_off[range];
+		uint4* rec = p.b_rec + bucket_off;
 		for (uint32_t e = tid; e < n; e += 256) {
 			const uint4 r = rec[e];
 			lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
@@ -1130,7 +1197,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		const uint32_t d_begin = range << kFtRangeShift;
 		for (uint32_t q = tid; q < A; q += 256) {   // key -> slot; document -> its position in the list
 			const uint32_t key = s_keys[q], row = key >> kFtRangeShift, dl = key & (kFtRangeDocs - 1);
-			const uint32_t slot = p.adders[uint64_t(row) * p.n_ranges + range] + lds_get_u16(s_tab, dl);
+			const uint32_t slot = (own_bases ? s_rowbase[row] : p.adders[uint64_t(row) * p.n_ranges + range]) + lds_get_u16(s_tab, dl);
 			s_keys[q] = slot;
 			lds_set_u16(s_tab, dl, q);
 			if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
@@ -1172,6 +1239,18 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 	__syncthreads();
 	FT_STAMP(p, 41);
 	if (!s_last) return;
+	if (own_bases) {   // the number of merged documents = the whole table, cut at maxMergedDocs (ft_slot_bases did not run)
+		const uint64_t total = uint64_t(p.n_rows) * p.n_ranges;
+		uint32_t sum = 0;
+		for (uint64_t j = tid; j < total; j += 256) sum += p.adders[j];
+		sum = wave_sum(sum);
+		if ((tid & 63) == 0) s_red[tid >> 6][0] = sum;
+		__syncthreads();
+		if (tid == 0) {
+			const uint32_t all = s_red[0][0] + s_red[1][0] + s_red[2][0] + s_red[3][0];
+			p.sync[kFtSyncNumDocs] = all < p.max_merged ? all : p.max_merged;
+		}
+	}
 	if (tid == 0) {
 		p.out_header[0] = p.sync[kFtSyncNumDocs];
 		p.out_header[1] = p.sync[kFtSyncError];
@@ -1180,6 +1259,37 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 	}
 	__syncthreads();
 	if (tid < kFtSyncWords) p.sync[tid] = 0;
+}
+
+// The packed result (header + four arrays, ~11 B per merged document) leaves through a copy kernel writing 16-byte words straight into
+// the caller's pinned host buffer: a hipMemcpyAsync of the same 220 KB took ~40 us from enqueue to completion (copy-engine start-up),
+// a third of the merge.  Only the header and the first numDocs entries of every array are written.
+__global__ __launch_bounds__(256) void ft_export(FtPlan p) {
+	const uint32_t n = p.out_header[0] < p.max_merged ? p.out_header[0] : p.max_merged;
+	const uint4* src = reinterpret_cast<const uint4*>(p.out_header);
+	uint4* dst = reinterpret_cast<uint4*>(p.host_out);
+	// region r of the packed layout: [start, start + bytes actually used), in 16-byte words
+	const size_t a16 = 16, m4 = (size_t(p.max_merged) * 4 + 255) & ~size_t(255), m2 = (size_t(p.max_merged) * 2 + 255) & ~size_t(255);
+	const size_t starts[5] = {0, 256, 256 + m4, 256 + 2 * m4, 256 + 2 * m4 + m2};
+	const size_t used[5] = {a16, size_t(n) * 4, size_t(n) * 4, size_t(n) * 2, size_t(n)};
+	const size_t gtid = size_t(blockIdx.x) * blockDim.x + threadIdx.x, gsize = size_t(gridDim.x) * blockDim.x;
+#pragma unroll
+	for (int r = 0; r < 5; ++r) {
+		const size_t w0 = starts[r] / 16, w1 = (starts[r] + used[r] + 15) / 16;
+		for (size_t w = w0 + gtid; w < w1; w += gsize) dst[w] = src[w];
+	}
+}
+
+// The plan (sub-term and term descriptors, grid entries, per-field parameters: a few KB) comes in the same way: one small workgroup
+// reads it from the pinned staging buffer and writes it where the kernels expect it — no copy-engine transfer in front of the train.
+__global__ __launch_bounds__(256) void ft_import(const uint4* host_plan, uint4* dev_plan, uint32_t n16) {
+	for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n16; w += gridDim.x * blockDim.x) dev_plan[w] = host_plan[w];
+}
+hipError_t launch_ft_import(const void* host_plan, void* dev_plan, size_t bytes, hipStream_t st) {
+	const uint32_t n16 = uint32_t((bytes + 15) / 16);
+	hipLaunchKernelGGL(ft_import, dim3((n16 + 255) / 256 < 16 ? (n16 + 255) / 256 : 16), dim3(256), 0, st, reinterpret_cast<const uint4*>(host_plan),
+					   reinterpret_cast<uint4*>(dev_plan), n16);
+	return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------- launch train
@@ -1193,8 +1303,9 @@ hipError_t launch_ft_merge(const FtPlan& p, hipStream_t st) {
 	}
 	if (p.merge_blocks) hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankTiles - 1) / kFtRankTiles), dim3(256), 0, st, p);
 	hipLaunchKernelGGL(ft_adders, dim3(p.n_ranges), dim3(256), 0, st, p);
-	hipLaunchKernelGGL(ft_slot_bases, dim3(1), dim3(256), 0, st, p);
+	if (!ft_own_bases(p)) hipLaunchKernelGGL(ft_slot_bases, dim3(1), dim3(256), 0, st, p);
 	hipLaunchKernelGGL(ft_finish, dim3(p.n_ranges), dim3(256), kFinishLds, st, p);
+	if (p.host_out) hipLaunchKernelGGL(ft_export, dim3(64), dim3(256), 0, st, p);
 	return hipGetLastError();
 }
 

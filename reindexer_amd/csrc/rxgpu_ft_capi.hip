@@ -446,7 +446,9 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		RX_HIP(hipMemsetAsync(cbase, 0, h->d_clean.bytes, st));
 		h->clean_dirty = false;
 	}
-	RX_HIP(hipMemcpyAsync(base, hp, plan_bytes, hipMemcpyHostToDevice, st));
+	void* hp_dev = nullptr;   // the pinned staging buffer as the device sees it
+	RX_HIP(hipHostGetDevicePointer(&hp_dev, hp, 0));
+	RX_HIP(rxgpu::launch_ft_import(hp_dev, base, plan_bytes, st));   // plan_bytes is a multiple of 256
 	if (excluded) RX_HIP(hipMemcpyAsync(base + o_excl, excluded, N, hipMemcpyHostToDevice, st));
 
 	rxgpu::FtPlan p{};
@@ -487,6 +489,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.dbg = stamps_env ? reinterpret_cast<unsigned long long*>(cbase + o_dbg) : nullptr;
 	p.dbg_block = stamps_env ? uint32_t(std::atoi(stamps_env)) : 0;
 	p.out_header = reinterpret_cast<uint32_t*>(ob);
+	p.host_out = hp_dev;
 	p.out_doc = reinterpret_cast<uint32_t*>(ob + align256(16));
 	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));
 	p.out_terms_counter = reinterpret_cast<uint16_t*>(ob + align256(16) + 2 * align256(M * 4));
@@ -505,8 +508,19 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_HIP(hipEventRecord(h->ev_b, st));
 	h->trace_us[2] += since(t_launch);
 	const auto t_wait = clk::now();
-	RX_HIP(hipMemcpyAsync(hp, ob, out_need, hipMemcpyDeviceToHost, st));   // header + the four result arrays in one copy
-	RX_HIP(hipStreamSynchronize(st));
+	// (the result is already on its way: ft_export, the last kernel of the train, writes it into the pinned staging buffer)
+	{
+		// a merge is ~0.1 ms of device time: poll for its end instead of sleeping in hipStreamSynchronize (the wake-up alone is tens of
+		// microseconds); anything that takes longer than a few milliseconds falls back to the blocking wait
+		const auto t_poll = clk::now();
+		hipError_t q = hipStreamQuery(st);
+		while (q == hipErrorNotReady && since(t_poll) < 3000.0) q = hipStreamQuery(st);
+		if (q == hipErrorNotReady) {
+			RX_HIP(hipStreamSynchronize(st));
+		} else {
+			RX_HIP(q);
+		}
+	}
 	if (p.dbg) {
 		unsigned long long raw[64];
 		RX_HIP(hipMemcpy(raw, p.dbg, sizeof(raw), hipMemcpyDeviceToHost));

@@ -156,6 +156,7 @@ struct FtPlan {
 	// packed result: header (4 x u32: numDocs, error flag, preselected, 0) then doc[max_merged] u32, proc[max_merged] f32,
 	// terms_counter[max_merged] u16, field[max_merged] u8 — one D2H copy
 	uint32_t* out_header;
+	void* host_out;            // device-visible address of the caller's pinned staging buffer: ft_export copies the used part of the result there
 	uint32_t* out_doc;
 	float* out_proc;
 	uint16_t* out_terms_counter;
@@ -167,6 +168,7 @@ constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
 hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);
+hipError_t launch_ft_import(const void* host_plan_device_view, void* dev_plan, size_t bytes, hipStream_t st);
 
 void set_error(const std::string& msg);
 

@@ -1,5 +1,6 @@
 #include "gpu_ft_merger.h"
 
+#include <chrono>
 #include <algorithm>
 #include <stdexcept>
 
@@ -112,8 +113,21 @@ void GpuFtMerger::ReadStats(uint64_t& postings, double& kernelMs) const {
 	if (rxgpu_ft_read_stats(dev_, &postings, &kernelMs) != RXGPU_OK) throwDevice("ReadStats");
 }
 
+namespace {
+struct CallTimer {
+	std::atomic<uint64_t>& calls;
+	std::atomic<uint64_t>& ns;
+	const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	~CallTimer() {
+		ns += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+		++calls;
+	}
+};
+}  // namespace
+
 MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 							 RankSortType rankSortType) const {
+	CallTimer timer{timedCalls_, timedNs_};
 	MergeData out;
 	if (subterms.empty() || totalDocs_ == 0) return out;   // mergerimpl.h:472-474
 	if (cfg.fieldsCfg.size() != numFields_ || termOpts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
@@ -211,8 +225,18 @@ void GpuFtMerger::SetWord(uint32_t wordId, const PositionPostings& p) {
 	if (rxgpu_ft_set_word_positions(dev_, wordId, p.doc.size(), p.doc.data(), p.posOff.data(), p.fpos.data()) != RXGPU_OK) throwDevice("SetWord");
 }
 
+void GpuFtMerger::ReadTiming(uint64_t& calls, double& totalMs) const {
+	calls = timedCalls_.exchange(0);
+	totalMs = double(timedNs_.exchange(0)) * 1e-6;
+}
+
 MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 								  bool* preselected) const {
+	if (terms.size() == 1 && terms[0].op != OpType::Not && totalDocs_ != 0) {   // Simple(): timed by Merge
+		if (preselected) *preselected = false;
+		return Merge(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType);
+	}
+	CallTimer timer{timedCalls_, timedNs_};
 	if (preselected) *preselected = false;
 	MergeData out;
 	// QueryMergeData::Empty() (querymergedata.h:208) / mergerimpl.h:472-474

@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <atomic>
 #include <vector>
 
 struct rxgpu_ft_index;
@@ -129,6 +130,9 @@ public:
 
 	size_t TotalDocs() const noexcept { return totalDocs_; }
 	void ReadStats(uint64_t& postings, double& kernelMs) const;
+	// wall time spent inside Merge / MergeQuery since the last call (everything behind the Merger boundary: plan, launches, the wait,
+	// unpacking, postProcessResults) and the number of calls; resets both
+	void ReadTiming(uint64_t& calls, double& totalMs) const;
 
 private:
 	void postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const;
@@ -136,6 +140,7 @@ private:
 	size_t totalDocs_ = 0;
 	std::vector<float> words_;   // host copy for addFullMatchBoost
 	rxgpu_ft_index* dev_ = nullptr;
+	mutable std::atomic<uint64_t> timedCalls_{0}, timedNs_{0};
 };
 
 }  // namespace rxgpu::host

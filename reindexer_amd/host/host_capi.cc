@@ -544,6 +544,8 @@ extern "C" int rxhost_ft_set_word_fpos(void* h, uint32_t wordId, size_t n, const
 }
 // cfgD: [k1, b, summationRatio, fullMatchBoost, distanceBoost, distanceWeight]; per term: op, boost, termLenBoost, fieldBoost[nf],
 // needSum[nf], sub-term slice [subOff[t], subOff[t+1]) of (wordId, proc).  Returns the result count, -1 on error.
+extern "C" void rxhost_ft_read_timing(void* h, uint64_t* calls, double* totalMs) { static_cast<const GpuFtMerger*>(h)->ReadTiming(*calls, *totalMs); }
+
 extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, const int* ops,
 									  const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
 									  const uint32_t* subOff, const uint32_t* wordIds, const float* procs, const uint8_t* excluded, int sortByRank,

@@ -681,6 +681,16 @@ class GpuFtMerger:
             _raise()
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
 
+    def read_timing(self):
+        """(calls, total ms) spent inside the C++ Merger since the last call — the end-to-end time of the drop-in boundary, without this
+        Python wrapper's argument marshalling."""
+        L = lib()
+        L.rxhost_ft_read_timing.restype = None
+        L.rxhost_ft_read_timing.argtypes = [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]
+        calls, ms = _u64(0), C.c_double(0.0)
+        L.rxhost_ft_read_timing(self.h, C.byref(calls), C.byref(ms))
+        return int(calls.value), float(ms.value)
+
     def read_stats(self):
         a, b = _u64(0), C.c_double(0.0)
         lib().rxhost_ft_read_stats(self.h, C.byref(a), C.byref(b))

@@ -194,7 +194,7 @@ def make_pos_postings(rng, total, nf, n, proc, array_fields=False, max_pos=40):
     return dict(doc=doc, pos_off=np.cumsum(pos_off).astype(np.uint32), fpos=w.astype(np.uint64), proc=proc)
 
 
-def _multi_case(seed, nf, total, limit, ops, array_fields=False, field_boosts=None, sizes=(150, 900)):
+def _multi_case(seed, nf, total, limit, ops, array_fields=False, field_boosts=None, sizes=(150, 900), nsub_range=(1, 4)):
     from oracle.pyoracle import ref_ft_or_none
     rng = np.random.default_rng(seed)
     words = rng.integers(1, 6, (total, nf)).astype(np.float32)
@@ -206,7 +206,7 @@ def _multi_case(seed, nf, total, limit, ops, array_fields=False, field_boosts=No
     excluded[rng.choice(total, total // 30, replace=False)] = 1
     terms, wid, word_store = [], 0, []
     for ti, op in enumerate(ops):
-        nsub = int(rng.integers(1, 4))
+        nsub = int(rng.integers(*nsub_range))
         procs = sorted((float(rng.choice([100.0, 85.0, 70.5, 55.0, 40.0])) for _ in range(nsub)), reverse=True)
         subs = []
         for pr in procs:

@@ -76,6 +76,17 @@ def test_gpu_multi_term_many_workgroups(hostapi, ft, limit, ops):
     _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, variants=((1.0, 0.5),))
 
 
+@pytest.mark.parametrize("limit,ops,nsub", [(20000, (1, 1, 2, 1), (30, 50)), (400, (1, 1, 1), (40, 60)), (20000, (2, 1), (9, 12)), (150, (1, 3, 1), (20, 30))])
+def test_gpu_multi_term_wide_queries(hostapi, ft, limit, ops, nsub):
+    """Dozens of sub-terms per term (typo / stem variants): more merged sub-terms than ft_finish sums slot bases for on its own
+    (ft_slot_bases path), more than its staged replay descriptors, several document ranges."""
+    nf, total = 2, 30_000
+    _, words, avg, removed, excluded, terms, store = _multi_case(2000 + limit + len(ops), nf, total, limit, ops, False, None, sizes=(150, 900),
+                                                                 nsub_range=nsub)
+    assert sum(len(t["subs"]) for t in terms if t["op"] != 3) > 16
+    _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, variants=((1.0, 0.5),))
+
+
 def test_gpu_multi_term_edge_cases(hostapi, ft):
     nf, total = 2, 500
     rng = np.random.default_rng(5)

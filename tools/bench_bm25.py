@@ -76,17 +76,22 @@ def run_multi(args):
     cfg = hostapi.default_ft_config(1)
     m.merge_query(cfg, terms_g)
     m.read_stats()
+    m.read_timing()
     t0 = time.perf_counter()
     for _ in range(args.queries):
         res = m.merge_query(cfg, terms_g, sort_by_rank=False)
     gpu_s = time.perf_counter() - t0
     npost, kernel_ms = m.read_stats()
+    host_calls, host_ms = m.read_timing()
     npos = sum(int(s["pos_off"][-1]) for t in terms_o if t["op"] != 3 for s in t["subs"])
     nposting = sum(int(s["doc"].shape[0]) for t in terms_o if t["op"] != 3 for s in t["subs"])
     bytes_per_merge = nposting * (4 + 8 + 9 + 8 + 4 + 4 + 4) + npos * 8   # doc, entry offs, entry, pos offs, words gather, slot gather, mask ; positions
     out = {"workload": f"ft_fast multi-term merge ops={ops}, {args.docs} vdocs, sub-term df fractions {fracs}, 1 field, mergeLimit 20000",
            "postings_per_query": npost / args.queries, "preselected": bool(res[4]), "results": int(res[0].shape[0]),
            "gpu": {"merges_per_sec": args.queries / gpu_s, "ms_per_merge": gpu_s / args.queries * 1e3, "term_pass_ms_per_merge": kernel_ms / args.queries,
+                   "ms_per_merge_cpp_boundary": host_ms / max(host_calls, 1),
+                   "note_e2e": "ms_per_merge = through this Python harness (ctypes marshalling of the query included); ms_per_merge_cpp_boundary = "
+                               "inside GpuFtMerger::MergeQuery, the drop-in boundary (plan, launches, wait, unpack, postProcessResults)",
                    "postings_per_sec_kernel": npost / (kernel_ms / 1e3),
                    "roofline": {"bound": "hbm", "achieved": bytes_per_merge / (kernel_ms / args.queries / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                 "frac": bytes_per_merge / (kernel_ms / args.queries / 1e3) / 1e9 / 8000.0,
@@ -164,6 +169,7 @@ def main():
     cfg, opts = hostapi.default_ft_config(1), hostapi.default_ft_opts(1)
     m.merge(cfg, opts, [(wid, s["proc"]) for wid, s in subs_of[0]])   # warmup
     m.read_stats()
+    m.read_timing()
     t0 = time.perf_counter()
     results = []
     for q in range(args.queries):
@@ -171,10 +177,14 @@ def main():
         results.append(m.merge(cfg, opts, [(wid, s["proc"]) for wid, s in subs]))
     gpu_s = time.perf_counter() - t0
     npost, kernel_ms = m.read_stats()
+    host_calls, host_ms = m.read_timing()
 
     out = {"workload": f"ft_fast single-term BM25 merge, {args.docs} vdocs, sub-term df fractions {fracs}, 1 field, mergeLimit 20000",
            "postings_per_query": npost / args.queries,
            "gpu": {"merges_per_sec": args.queries / gpu_s, "ms_per_merge": gpu_s / args.queries * 1e3, "term_pass_ms_per_merge": kernel_ms / args.queries,
+                   "ms_per_merge_cpp_boundary": host_ms / max(host_calls, 1),
+                   "note_e2e": "ms_per_merge = through this Python harness (ctypes marshalling of the query included); ms_per_merge_cpp_boundary = "
+                               "inside GpuFtMerger::MergeQuery, the drop-in boundary (plan, launches, wait, unpack, postProcessResults)",
                    "postings_per_sec_kernel": npost / (kernel_ms / 1e3),
                    "roofline": {"bound": "hbm", "achieved": npost * 29 / (kernel_ms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                 "frac": npost * 29 / (kernel_ms / 1e3) / 1e9 / 8000.0, "bytes_per_posting": 29,
