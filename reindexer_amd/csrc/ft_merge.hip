@@ -1141,15 +1141,23 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			}
 		}
 		__syncthreads();
+		// the mergeLimit cut (addDoc until maxMergedDocs): slots ascend with (row, range), so when even the first slot of every row of this
+		// range lies at or beyond the limit none of its documents is merged — a whole-corpus single-term merge adds its 20 000 documents in
+		// the first dozen ranges, and the other six hundred have nothing to sort, scatter or replay
+		bool reaches = false;
+		for (uint32_t r = tid; r < p.n_rows; r += 256) {
+			reaches = reaches || (own_bases ? s_rowbase[r] : p.adders[uint64_t(r) * p.n_ranges + range]) < p.max_merged;
+		}
+		const uint32_t nw = __syncthreads_or(reaches ? 1 : 0) ? n : 0u;
 		FT_STAMP(p, 33);
 		uint4* rec = p.b_rec + bucket_off;
-		for (uint32_t e = tid; e < n; e += 256) {
+		for (uint32_t e = tid; e < nw; e += 256) {
 			const uint4 r = rec[e];
 			lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
 		}
 		__syncthreads();
 		FT_STAMP(p, 34);
-		for (uint32_t e = tid; e < n; e += 256) {   // the range's first postings: key (row, document); the record remembers that it adds
+		for (uint32_t e = tid; e < nw; e += 256) {   // the range's first postings: key (row, document); the record remembers that it adds
 			const uint4 r = rec[e];
 			const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
 			if (lds_get_u16(s_tab, dl) != row) continue;
@@ -1204,7 +1212,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		}
 		__syncthreads();
 		FT_STAMP(p, 38);
-		for (uint32_t e = tid; e < n; e += 256) {   // every posting of a merged document into the document's row, column = its sub-term
+		for (uint32_t e = tid; e < nw; e += 256) {   // every posting of a merged document into the document's row, column = its sub-term
 			const uint4 r = rec[e];
 			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
 			if (sl >= p.max_merged) continue;   // met after the limit was hit: never added
@@ -1215,14 +1223,14 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		}
 		__syncthreads();   // the rows are read back by this workgroup only
 		FT_STAMP(p, 39);
-		for (uint32_t e = tid; e < n; e += 256) {
+		for (uint32_t e = tid; e < nw; e += 256) {
 			const uint4 r = rec[e];
 			if (!(r.w >> 31)) continue;
 			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
 			if (sl < p.max_merged) ft_replay_doc(p, sl, r.x, s_fpos, s_pos_off, s_qp);
 		}
 		__syncthreads();
-		for (uint32_t e = tid; e < n; e += 256) {   // the entry rows go back ZEROED: the occupancy test of the next merge relies on it
+		for (uint32_t e = tid; e < nw; e += 256) {   // the entry rows go back ZEROED: the occupancy test of the next merge relies on it
 			const uint4 r = rec[e];
 			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
 			if (sl < p.max_merged) p.e_rank[uint64_t(r.w & 0xFFFFu) * p.max_merged + sl] = 0.0f;
