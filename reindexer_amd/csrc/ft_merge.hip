@@ -277,7 +277,9 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 		uint32_t pos[kPer], dd[kPer];
 #pragma unroll
 		for (int q = 0; q < kPer; ++q) pos[q] = 0;
-		if (ns <= 16) {   // the usual query: the slice starts in registers, position = how many starts lie at or before f
+		if (ns == 0) {
+			// a Simple() query: no term pass, nothing to stage
+		} else if (ns <= 16) {   // the usual query: the slice starts in registers, position = how many starts lie at or before f
 			uint32_t st[16];
 #pragma unroll
 			for (int j = 1; j < 16; ++j) st[j] = s_start[uint32_t(j) < ns ? uint32_t(j) : ns];   // padding = the total: beyond every staged f
@@ -762,42 +764,51 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 	FT_STAMP(p, 17);
 	const uint32_t cnt = s_cnt;
 	const int lane = threadIdx.x & 63;
-	for (uint32_t e0 = 0; e0 < cnt; e0 += 256) {   // uniform trip count: the wavefront votes below
-		const uint32_t e = e0 + threadIdx.x;
-		bool want = false;
-		uint32_t d = 0, row = 0, idx = 0;
-		float rank = 0.0f;
-		uint8_t field = 0;
-		if (e < cnt) {
-			const uint32_t item = s_item[e], g = item >> 10, local = item & 1023u;
-			const uint32_t tile = blockIdx.x * kFtRankTiles + g;
-			const FtPosSubterm& s = s_subd[g];
-			const FtTermCfg& t = s_termd[g];
-			const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
-			d = s_doc[e];
-			rank = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d, &field);
-			want = rank != 0.0f;
-			row = s.row;
-			idx = uint32_t(i);
+	// Two postings per thread and step when more than one step is due (dense merges rank every posting of the tile): the two
+	// calcTermRank gather chains are independent and overlap.  Uniform trip count: the wavefront votes below.
+	const uint32_t per_step = cnt > 256 ? 512u : 256u;
+	for (uint32_t e0 = 0; e0 < cnt; e0 += per_step) {
+		bool want[2] = {false, false};
+		uint32_t d[2] = {0, 0}, row[2] = {0, 0}, idx[2] = {0, 0};
+		float rank[2] = {0.0f, 0.0f};
+		uint8_t field[2] = {0, 0};
+#pragma unroll
+		for (int u = 0; u < 2; ++u) {
+			const uint32_t e = e0 + uint32_t(u) * 256 + threadIdx.x;
+			if ((u == 0 || per_step == 512) && e < cnt) {
+				const uint32_t item = s_item[e], g = item >> 10, local = item & 1023u;
+				const uint32_t tile = blockIdx.x * kFtRankTiles + g;
+				const FtPosSubterm& s = s_subd[g];
+				const FtTermCfg& t = s_termd[g];
+				const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
+				d[u] = s_doc[e];
+				rank[u] = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d[u], &field[u]);
+				want[u] = rank[u] != 0.0f;
+				row[u] = s.row;
+				idx[u] = uint32_t(i);
+			}
 		}
 		// one device atomic per (wavefront, document range): neighbouring postings share a range, whole-corpus merges would otherwise
 		// hammer a few hundred counters with millions of same-address atomics
-		const uint32_t rg = d >> kFtRangeShift;
-		unsigned long long pending = __ballot(want);
-		while (pending) {
-			const int leader = __ffsll((long long)pending) - 1;
-			const uint32_t lrg = uint32_t(__shfl(int(rg), leader, 64));
-			const bool mine = want && rg == lrg;
-			const unsigned long long same = __ballot(mine);
-			uint32_t base = 0;
-			if (lane == leader) base = atomicAdd(&p.bucket_cnt[lrg], uint32_t(__popcll(same)));
-			base = uint32_t(__shfl(int(base), leader, 64));
-			if (mine) {
-				const uint32_t pos = base + uint32_t(__popcll(same & ((1ull << lane) - 1ull)));
-				p.b_rec[uint64_t(p.bucket_off[lrg]) + pos] = make_uint4(d, idx, __float_as_uint(rank), row | (uint32_t(field) << 16));
-				want = false;
+#pragma unroll
+		for (int u = 0; u < 2; ++u) {
+			const uint32_t rg = d[u] >> kFtRangeShift;
+			unsigned long long pending = __ballot(want[u]);
+			while (pending) {
+				const int leader = __ffsll((long long)pending) - 1;
+				const uint32_t lrg = uint32_t(__shfl(int(rg), leader, 64));
+				const bool mine = want[u] && rg == lrg;
+				const unsigned long long same = __ballot(mine);
+				uint32_t base = 0;
+				if (lane == leader) base = atomicAdd(&p.bucket_cnt[lrg], uint32_t(__popcll(same)));
+				base = uint32_t(__shfl(int(base), leader, 64));
+				if (mine) {
+					const uint32_t pos = base + uint32_t(__popcll(same & ((1ull << lane) - 1ull)));
+					p.b_rec[uint64_t(p.bucket_off[lrg]) + pos] = make_uint4(d[u], idx[u], __float_as_uint(rank[u]), row[u] | (uint32_t(field[u]) << 16));
+					want[u] = false;
+				}
+				pending &= ~same;
 			}
-			pending &= ~same;
 		}
 	}
 	FT_STAMP(p, 18);
@@ -1069,6 +1080,7 @@ __device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint
 // kFtFinishRows merged sub-terms (and 8192 entries) the table is small and every workgroup of ft_finish adds up its own bases (one pass, all
 // rows at once); larger queries run ft_slot_bases, which turns the table into its prefix.
 constexpr uint32_t kFtFinishRows = 16;
+constexpr uint32_t kFtBitmapRows = 8;   // up to this many merged sub-terms ft_finish ranks the first postings with per-row bitmaps instead of a sort
 __host__ __device__ inline bool ft_own_bases(const FtPlan& p) { return p.n_rows <= kFtFinishRows && uint64_t(p.n_rows) * p.n_ranges <= kFtRangeDocs; }
 
 // Slots, entry rows and the per-document replay of one document range.  Dynamic LDS: the 16-bit document table (first row, then the
@@ -1105,7 +1117,6 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		s_qp[row] = s.qp;
 	}
 	if (n) {
-		for (uint32_t w = tid; w < kFtRangeDocs / 2; w += 256) s_tab[w] = 0xFFFFFFFFu;
 		if (tid == 0) s_nadd = 0;
 		if (own_bases) {
 			const uint32_t total = p.n_rows * p.n_ranges;
@@ -1149,72 +1160,134 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			reaches = reaches || (own_bases ? s_rowbase[r] : p.adders[uint64_t(r) * p.n_ranges + range]) < p.max_merged;
 		}
 		const uint32_t nw = __syncthreads_or(reaches ? 1 : 0) ? n : 0u;
-		FT_STAMP(p, 33);
 		uint4* rec = p.b_rec + bucket_off;
-		for (uint32_t e = tid; e < nw; e += 256) {
-			const uint4 r = rec[e];
-			lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
-		}
-		__syncthreads();
-		FT_STAMP(p, 34);
-		for (uint32_t e = tid; e < nw; e += 256) {   // the range's first postings: key (row, document); the record remembers that it adds
-			const uint4 r = rec[e];
-			const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
-			if (lds_get_u16(s_tab, dl) != row) continue;
-			s_keys[atomicAdd(&s_nadd, 1u)] = (row << kFtRangeShift) | dl;
-			rec[e].w = r.w | 0x80000000u;
-		}
-		__syncthreads();
-		FT_STAMP(p, 35);
-		const uint32_t A = s_nadd;   // <= kFtRangeDocs: one per document
-		uint32_t N = 2;
-		while (N < A) N <<= 1;
-		for (uint32_t q = A + tid; q < N; q += 256) s_keys[q] = 0xFFFFFFFFu;
-		__syncthreads();
-		for (uint32_t k = 2; k <= N; k <<= 1) {   // bitonic sort, ascending
-			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-				for (uint32_t t = tid; t < N / 2; t += 256) {
-					const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-					const uint32_t x = s_keys[i], y = s_keys[l];
-					if ((x > y) == ((i & k) == 0)) {
-						s_keys[i] = y;
-						s_keys[l] = x;
-					}
+		const uint32_t d_begin = range << kFtRangeShift;
+		const bool few_rows = p.n_rows <= kFtBitmapRows;
+		if (few_rows) {
+			// ---- up to kFtBitmapRows merged sub-terms: no sort.  s_slot[doc] = first row, then the slot; one bitmap of the range's documents
+			// per row marks the first postings, a prefix over the bitmap words gives every one its rank inside (row, range)
+			uint32_t* s_slot = ft_finish_lds;                                  // [kFtRangeDocs]
+			uint32_t* s_bits = ft_finish_lds + kFtRangeDocs;                   // [kFtBitmapRows][256]
+			uint32_t* s_pref = s_bits + kFtBitmapRows * (kFtRangeDocs / 32);   // [kFtBitmapRows][256]
+			for (uint32_t w = tid; w < kFtRangeDocs; w += 256) s_slot[w] = 0xFFFFFFFFu;
+			for (uint32_t w = tid; w < kFtBitmapRows * (kFtRangeDocs / 32); w += 256) s_bits[w] = 0;
+			__syncthreads();
+			FT_STAMP(p, 33);
+			for (uint32_t e = tid; e < nw; e += 256) {
+				const uint4 r = rec[e];
+				atomicMin(&s_slot[r.x & (kFtRangeDocs - 1)], r.w & 0xFFFFu);
+			}
+			__syncthreads();
+			FT_STAMP(p, 34);
+			for (uint32_t e = tid; e < nw; e += 256) {   // the range's first postings; the record remembers that it adds its document
+				const uint4 r = rec[e];
+				const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
+				if (s_slot[dl] != row) continue;
+				atomicOr(&s_bits[row * (kFtRangeDocs / 32) + (dl >> 5)], 1u << (dl & 31));
+				rec[e].w = r.w | 0x80000000u;
+			}
+			__syncthreads();
+			FT_STAMP(p, 35);
+			{   // exclusive prefix of the popcounts along every bitmap: thread t owns word t
+				uint32_t cnt[kFtBitmapRows], incl[kFtBitmapRows];
+#pragma unroll
+				for (uint32_t r = 0; r < kFtBitmapRows; ++r) {
+					cnt[r] = r < p.n_rows ? __popc(s_bits[r * (kFtRangeDocs / 32) + tid]) : 0u;
+					incl[r] = wave_inclusive_scan(cnt[r], int(tid & 63));
+					if ((tid & 63) == 63) s_red[tid >> 6][r] = incl[r];
 				}
 				__syncthreads();
-			}
-		}
-		FT_STAMP(p, 36);
-		// rank inside the row = position - first position of the row (binary search); parked in the document table, whose first-row
-		// entries are no longer needed
-		for (uint32_t q = tid; q < A; q += 256) {
-			const uint32_t key = s_keys[q], first_of_row = key & ~(kFtRangeDocs - 1);
-			uint32_t lo = 0, hi = q;   // lower bound of first_of_row in [0, q]
-			while (lo < hi) {
-				const uint32_t mid = (lo + hi) >> 1;
-				if (s_keys[mid] < first_of_row) {
-					lo = mid + 1;
-				} else {
-					hi = mid;
+#pragma unroll
+				for (uint32_t r = 0; r < kFtBitmapRows; ++r) {
+					uint32_t excl = incl[r] - cnt[r];
+					for (uint32_t w = 0; w < (tid >> 6); ++w) excl += s_red[w][r];
+					s_pref[r * (kFtRangeDocs / 32) + tid] = excl;
 				}
 			}
-			lds_set_u16(s_tab, key & (kFtRangeDocs - 1), q - lo);
+			__syncthreads();
+			FT_STAMP(p, 36);
+			for (uint32_t e = tid; e < nw; e += 256) {   // first posting -> slot of its document
+				const uint4 r = rec[e];
+				if (!(r.w >> 31)) continue;
+				const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
+				const uint32_t word = row * (kFtRangeDocs / 32) + (dl >> 5);
+				const uint32_t rank = s_pref[word] + __popc(s_bits[word] & ((1u << (dl & 31)) - 1u));
+				const uint32_t slot = (own_bases ? s_rowbase[row] : p.adders[uint64_t(row) * p.n_ranges + range]) + rank;
+				s_slot[dl] = slot;   // every document with a record has exactly one first posting: no first-row value is left behind
+				if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
+			}
+			__syncthreads();
+			FT_STAMP(p, 37);
+		} else {
+			// ---- many sub-terms: 16-bit document table + a sorted list of (row, document) keys
+			for (uint32_t w = tid; w < kFtRangeDocs / 2; w += 256) s_tab[w] = 0xFFFFFFFFu;
+			__syncthreads();
+			FT_STAMP(p, 33);
+			for (uint32_t e = tid; e < nw; e += 256) {
+				const uint4 r = rec[e];
+				lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
+			}
+			__syncthreads();
+			FT_STAMP(p, 34);
+			for (uint32_t e = tid; e < nw; e += 256) {   // the range's first postings: key (row, document); the record remembers that it adds
+				const uint4 r = rec[e];
+				const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
+				if (lds_get_u16(s_tab, dl) != row) continue;
+				s_keys[atomicAdd(&s_nadd, 1u)] = (row << kFtRangeShift) | dl;
+				rec[e].w = r.w | 0x80000000u;
+			}
+			__syncthreads();
+			FT_STAMP(p, 35);
+			const uint32_t A = s_nadd;   // <= kFtRangeDocs: one per document
+			uint32_t N = 2;
+			while (N < A) N <<= 1;
+			for (uint32_t q = A + tid; q < N; q += 256) s_keys[q] = 0xFFFFFFFFu;
+			__syncthreads();
+			for (uint32_t k = 2; k <= N; k <<= 1) {   // bitonic sort, ascending
+				for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+					for (uint32_t t = tid; t < N / 2; t += 256) {
+						const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+						const uint32_t x = s_keys[i], y = s_keys[l];
+						if ((x > y) == ((i & k) == 0)) {
+							s_keys[i] = y;
+							s_keys[l] = x;
+						}
+					}
+					__syncthreads();
+				}
+			}
+			FT_STAMP(p, 36);
+			// rank inside the row = position - first position of the row (binary search); parked in the document table, whose first-row
+			// entries are no longer needed
+			for (uint32_t q = tid; q < A; q += 256) {
+				const uint32_t key = s_keys[q], first_of_row = key & ~(kFtRangeDocs - 1);
+				uint32_t lo = 0, hi = q;   // lower bound of first_of_row in [0, q]
+				while (lo < hi) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (s_keys[mid] < first_of_row) {
+						lo = mid + 1;
+					} else {
+						hi = mid;
+					}
+				}
+				lds_set_u16(s_tab, key & (kFtRangeDocs - 1), q - lo);
+			}
+			__syncthreads();
+			FT_STAMP(p, 37);
+			for (uint32_t q = tid; q < A; q += 256) {   // key -> slot; document -> its position in the list
+				const uint32_t key = s_keys[q], row = key >> kFtRangeShift, dl = key & (kFtRangeDocs - 1);
+				const uint32_t slot = (own_bases ? s_rowbase[row] : p.adders[uint64_t(row) * p.n_ranges + range]) + lds_get_u16(s_tab, dl);
+				s_keys[q] = slot;
+				lds_set_u16(s_tab, dl, q);
+				if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
+			}
+			__syncthreads();
 		}
-		__syncthreads();
-		FT_STAMP(p, 37);
-		const uint32_t d_begin = range << kFtRangeShift;
-		for (uint32_t q = tid; q < A; q += 256) {   // key -> slot; document -> its position in the list
-			const uint32_t key = s_keys[q], row = key >> kFtRangeShift, dl = key & (kFtRangeDocs - 1);
-			const uint32_t slot = (own_bases ? s_rowbase[row] : p.adders[uint64_t(row) * p.n_ranges + range]) + lds_get_u16(s_tab, dl);
-			s_keys[q] = slot;
-			lds_set_u16(s_tab, dl, q);
-			if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
-		}
-		__syncthreads();
+		auto slot_of = [&](uint32_t dl) -> uint32_t { return few_rows ? ft_finish_lds[dl] : s_keys[lds_get_u16(s_tab, dl)]; };
 		FT_STAMP(p, 38);
 		for (uint32_t e = tid; e < nw; e += 256) {   // every posting of a merged document into the document's row, column = its sub-term
 			const uint4 r = rec[e];
-			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
+			const uint32_t sl = slot_of(r.x & (kFtRangeDocs - 1));
 			if (sl >= p.max_merged) continue;   // met after the limit was hit: never added
 			const uint64_t cell = uint64_t(r.w & 0xFFFFu) * p.max_merged + sl;
 			p.e_rank[cell] = __uint_as_float(r.z);
@@ -1226,13 +1299,13 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		for (uint32_t e = tid; e < nw; e += 256) {
 			const uint4 r = rec[e];
 			if (!(r.w >> 31)) continue;
-			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
+			const uint32_t sl = slot_of(r.x & (kFtRangeDocs - 1));
 			if (sl < p.max_merged) ft_replay_doc(p, sl, r.x, s_fpos, s_pos_off, s_qp);
 		}
 		__syncthreads();
 		for (uint32_t e = tid; e < nw; e += 256) {   // the entry rows go back ZEROED: the occupancy test of the next merge relies on it
 			const uint4 r = rec[e];
-			const uint32_t sl = s_keys[lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1))];
+			const uint32_t sl = slot_of(r.x & (kFtRangeDocs - 1));
 			if (sl < p.max_merged) p.e_rank[uint64_t(r.w & 0xFFFFu) * p.max_merged + sl] = 0.0f;
 		}
 	}
