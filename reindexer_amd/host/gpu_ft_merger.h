@@ -7,7 +7,7 @@
 // Device: per-posting BM25 ranks, max per document, mergeLimit admission (bm25.hip via rxgpu_ft_merge_simple_raw).
 // Host:   the O(mergeLimit) tail of the merger — addFullMatchBoost (merger.h:100-109) and postProcessResults (:111-155).
 // Multi-term queries (AND / OR / NOT terms: restricting bitmask, preselect, mergeTerm with position distances,
-// mergerimpl.h:107-192, 252-464) go through MergeQuery (ft_terms.hip via rxgpu_ft_merge_terms_raw).
+// mergerimpl.h:107-192, 252-464) go through MergeQuery (ft_merge.hip via rxgpu_ft_merge_terms_raw).
 // Phrases and multi-word synonyms stay on the reference's CPU merger; Supports() tells the caller which way to go.
 #pragma once
 

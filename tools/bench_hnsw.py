@@ -199,8 +199,9 @@ def run(o) -> dict:
         return out
 
     if m is not None and o.map_legs:
+        m.search_knn(queries[0], o.k, o.ef)   # the first search of a Map mirrors the graph into HBM (3 GB at 1M x 768): not a query latency
         t0 = time.perf_counter()
-        for q in queries[:32]:
+        for q in queries[1:33]:
             m.search_knn(q, o.k, o.ef)
         out["gpu"]["map_single_query_latency_ms"] = (time.perf_counter() - t0) / 32 * 1e3
         sess = m.stream(queries[0], o.ef)   # a15: one streaming session, 10 batches of 10 (the planner's post-filter pattern)
