@@ -87,6 +87,40 @@ def test_gpu_multi_term_wide_queries(hostapi, ft, limit, ops, nsub):
     _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, variants=((1.0, 0.5),))
 
 
+def test_gpu_one_merger_many_query_shapes(hostapi, ft):
+    """The tables a merge finds zeroed and hands back zeroed (histogram copies, bucket counters, entry-row occupancy, sync words) live
+    across merges: ONE merger instance runs wide, narrow, simple, AND-only, preselected and cut queries in turn — different numbers of
+    sub-term rows and different mergeLimits reshape the entry rows between merges — and every result must still be the oracle's."""
+    nf, total = 2, 40_000
+    rng = np.random.default_rng(77)
+    _, words, avg, removed, excluded, terms_all, store = _multi_case(4242, nf, total, 20000, (1, 1, 2, 1, 3, 1), False, None, sizes=(200, 3000),
+                                                                     nsub_range=(2, 14))
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg, removed)
+    for s_ in store:
+        m.set_word_fpos(s_["word"], s_)
+
+    def gq(ts):
+        return [dict(op=t["op"], opts=t["opts"], subs=[(x["word"], x["proc"]) for x in t["subs"]]) for t in ts]
+
+    shapes = [([0, 1, 2, 3, 4, 5], 20000), ([0], 20000), ([2, 3], 300), ([0, 1], 150), ([5], 50), ([0, 1, 2, 3, 4, 5], 700), ([1, 3, 5], 20000),
+              ([2], 20000), ([0, 2, 4], 97), ([0, 1, 2, 3, 4, 5], 20000)]
+    for rnd in range(2):
+        for pick, limit in shapes:
+            ts = [terms_all[i] for i in pick]
+            if all(t["op"] == 3 for t in ts):
+                continue
+            cfg = ft.default_config(nf, merge_limit=limit, min_rank=5)
+            exc = excluded if (rnd + len(pick)) % 2 else None
+            wd, wp, wf, wn, wpre = ft.merge_query(cfg, ts, total, words, avg, removed, exc, sort_by_rank=False)
+            gd, gp, gf, gn, gpre = m.merge_query(cfg, gq(ts), exc, sort_by_rank=False)
+            assert gpre == wpre, (pick, limit)
+            assert np.array_equal(gd, wd.astype(np.int32)), (pick, limit, len(gd), len(wd))
+            assert np.array_equal(gn, wn) and np.array_equal(gf, wf)
+            assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+    m.close()
+
+
 def test_gpu_multi_term_edge_cases(hostapi, ft):
     nf, total = 2, 500
     rng = np.random.default_rng(5)
