@@ -1497,8 +1497,12 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		~Rel() { release_ctx(h, c); }
 	} rel{h, c};
 	const uint64_t words = (h->count + 31) / 32;
-	// visited bitsets are the memory hog: bound one launch to ~2 GiB of them
-	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(8192, (2ull << 30) / (words * 4)));
+	// visited bitsets are the memory hog (N / 8 bytes per resident search): a launch gets an eighth of the free HBM for them, between 2 and
+	// 16 GiB.  (A fixed 2 GiB held a 10M-node index to 1717 searches per launch — fewer than the chip keeps resident.)
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+	const uint64_t visited_budget = std::min<uint64_t>(16ull << 30, std::max<uint64_t>(2ull << 30, (uint64_t(free_b) + c->d_visited.bytes) / 8));
+	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(8192, visited_budget / (words * 4)));
 	// SQ8 queries: [codes, padded to 4 bytes][corr][normCoef] in the one query buffer
 	const size_t qelem = sq8 ? sizeof(uint8_t) : sizeof(float);
 	const size_t qbytes = size_t(nq) * h->dim * qelem;
@@ -1580,8 +1584,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			if (out_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
 		}
 	}
-	if (!redo.empty()) {
-		const uint64_t gcap = h->count + 1;
+	// Re-runs with the candidate heap in global scratch, in two tiers: 64 K entries first (0.5 MB per search: hundreds of re-runs share one
+	// launch), one entry per node — the bound that cannot overflow — only for what outgrows that.  (With the full bound from the start a
+	// 10M-node index allows 13 searches per launch: 39 overflowing queries out of 16 384 cost a quarter of the whole batch.)
+	uint64_t tier_cap[2] = {std::min<uint64_t>(h->count + 1, 65536), h->count + 1};
+	if (const char* e = getenv("RXGPU_HNSW_GCAND_CAP")) tier_cap[0] = std::min<uint64_t>(h->count + 1, uint64_t(std::max(1, atoi(e))));   // test hook
+	for (int tier = 0; tier < 2 && !redo.empty(); ++tier) {
+		if (tier == 1 && tier_cap[1] == tier_cap[0]) break;
+		const uint64_t gcap = tier_cap[tier];
 		const uint64_t redo_slots = std::max<uint64_t>(1, std::min<uint64_t>(max_slots, (1ull << 30) / (gcap * 8)));
 		if (int rc = c->d_redo.ensure(redo.size() * sizeof(uint32_t)); rc) return rc;
 		RX_HIP(hipMemcpyAsync(c->d_redo.ptr, redo.data(), redo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -1603,7 +1613,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		}
 		RX_HIP(hipGetLastError());
 		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));
+		std::vector<uint32_t> again;
+		for (const uint32_t q : redo) {
+			if (out_count[q] == rxgpu::kHnswOverflow) again.push_back(q);
+		}
+		redo.swap(again);
 	}
+	RX_CHECK(redo.empty(), RXGPU_ERR_DEVICE, "rxgpu_hnsw_search_knn: a candidate heap of one entry per node overflowed");
 	RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipStreamSynchronize(c->stream));

@@ -94,11 +94,14 @@ def test_candidate_heap_overflow_is_rerun_on_gpu(rxgpu, oracle, monkeypatch):
     g = m.export_graph()
     g["vectors"] = rows
     monkeypatch.setenv("RXGPU_HNSW_LDS_CAND_CAP", "4")
-    for qi in range(10):
-        q = make_corpus(700 + qi, 1, d)[0]
-        wd, wl = oracle_hnsw_search_knn(oracle, g, q, 10, 64)
-        gd, gl = m.search_knn(q, 10, 64)
-        assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd))
+    for tier0 in (None, "8"):   # "8": the first global tier overflows too, the one-entry-per-node tier answers
+        if tier0:
+            monkeypatch.setenv("RXGPU_HNSW_GCAND_CAP", tier0)
+        for qi in range(10):
+            q = make_corpus(700 + qi, 1, d)[0]
+            wd, wl = oracle_hnsw_search_knn(oracle, g, q, 10, 64)
+            gd, gl = m.search_knn(q, 10, 64)
+            assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd))
     m.close()
 
 
