@@ -940,10 +940,13 @@ class RefIvf:
     """The patched FAISS vendored in the reference, compiled in place (oracle/ref/ref_ivf_shim.cc), driven like IvfIndex drives it: a flat
     index trained on and drained into an IndexIVFFlat.  Distances follow FAISS (L2 ascending, similarity descending)."""
 
-    def __init__(self, metric: int, dim: int, nlist: int, x, ids):
+    def __init__(self, metric: int, dim: int, nlist: int, x, ids, exact_assignment: bool = False):
+        """exact_assignment: train with FAISS's BLAS shortcut off (distance_compute_blas_threshold = INT_MAX): the k-means assignment then
+        uses the reference's exact per-pair distance functions instead of |x|^2 + |y|^2 - 2 x.y through sgemm."""
         if not REF_IVF_SO.exists():
             raise FileNotFoundError(REF_IVF_SO)
         L = self.L = C.CDLL(str(REF_IVF_SO))
+        old = L.ref_ivf_set_blas_threshold(0x7FFFFFFF) if exact_assignment else None
         L.ref_ivf_build.restype = _vp
         L.ref_ivf_build.argtypes = [_i, _sz, _sz, _sz, _vp, _vp]
         L.ref_ivf_destroy.argtypes = [_vp]
@@ -959,6 +962,8 @@ class RefIvf:
         ids = np.ascontiguousarray(ids, np.int64)
         self.metric, self.dim, self.nlist = metric, dim, nlist
         self.h = L.ref_ivf_build(metric, dim, nlist, x.shape[0], x.ctypes.data, ids.ctypes.data)
+        if old is not None:
+            L.ref_ivf_set_blas_threshold(old)
         if not self.h:
             raise RuntimeError(L.ref_ivf_last_error().decode())
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "faiss/IndexFlat.h"
+#include "faiss/utils/distances.h"
 #include "faiss/IndexIVFFlat.h"
 #include "faiss/impl/AuxIndexStructures.h"
 #include "faiss/invlists/InvertedLists.h"
@@ -62,6 +63,15 @@ std::unique_ptr<faiss::IndexFlat> newSpace(size_t dim, int metric) {
 extern "C" {
 
 const char* ref_ivf_last_error() { return g_err.c_str(); }
+
+// faiss::distance_compute_blas_threshold (utils/distances.cpp:630): batches of at least this many queries go through sgemm
+// (|x|^2 + |y|^2 - 2 x.y); INT_MAX keeps every search — the k-means assignment of training included — on the exact per-pair functions
+// (the reference's own L2 / inner-product kernels).  Returns the previous value.
+int ref_ivf_set_blas_threshold(int v) {
+	const int old = faiss::distance_compute_blas_threshold;
+	faiss::distance_compute_blas_threshold = v;
+	return old;
+}
 
 // The state IvfIndex reaches once more than 39 * nCentroids vectors were upserted: the flat `space_` holding them is trained on and drained
 // into the IVF index (ivf_index.cc:96-108).

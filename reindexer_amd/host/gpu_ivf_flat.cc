@@ -28,7 +28,8 @@ GpuIvfFlat::GpuIvfFlat(VectorMetric metric, size_t dim, size_t nlist, int device
 	: metric_(metric), dim_(dim), nlist_(nlist), device_(device), lists_(nlist) {
 	if (dim_ == 0 || nlist_ == 0) throw std::logic_error("GpuIvfFlat: zero dimension or zero centroids");
 	if (rxgpu_index_create(int(metric_), uint32_t(dim_), 0, device_, &dev_) != RXGPU_OK) throwDevice("GpuIvfFlat: device index creation failed");
-	const int coarseMetric = metric_ == VectorMetric::L2 ? RXGPU_METRIC_L2 : RXGPU_METRIC_IP;
+	// the coarse quantiser is the flat index of the same metric (IndexFlatCosine ranks by inner product x the stored 1 / |centroid|)
+	const int coarseMetric = int(metric_);
 	if (rxgpu_index_create(coarseMetric, uint32_t(dim_), nlist_, device_, &devCentroids_) != RXGPU_OK) {
 		rxgpu_index_destroy(dev_);
 		dev_ = nullptr;
@@ -72,7 +73,14 @@ void GpuIvfFlat::prepareQuery(const float* x, std::vector<float>& q) const {
 }
 
 void GpuIvfFlat::uploadCentroids() const {
-	if (rxgpu_index_upload_rows(devCentroids_, 0, nlist_, centroids_.data(), nullptr) != RXGPU_OK) throwDevice("GpuIvfFlat: centroid upload failed");
+	std::vector<float> coefs;
+	if (metric_ == VectorMetric::Cosine) {   // IndexFlatCodes::add (IndexFlatCodes.cpp:33-40): norm_coefs = NormalizeVector's coefficient
+		coefs.resize(nlist_);
+		for (size_t c = 0; c < nlist_; ++c) coefs[c] = CalculateL2Module(centroids_.data() + c * dim_, int32_t(dim_));
+	}
+	if (rxgpu_index_upload_rows(devCentroids_, 0, nlist_, centroids_.data(), coefs.empty() ? nullptr : coefs.data()) != RXGPU_OK) {
+		throwDevice("GpuIvfFlat: centroid upload failed");
+	}
 }
 
 void GpuIvfFlat::assign(const float* xPrepared, size_t n, std::vector<uint32_t>& out) const {
@@ -99,91 +107,127 @@ void GpuIvfFlat::listErase(uint32_t list, uint32_t row) {
 	l.erase(it);
 }
 
+namespace {
+// faiss::RandomGenerator (utils/random.cpp:35-51): std::mt19937 seeded with the low 32 bits; rand_int(max) = mt() % max,
+// rand_float() = mt() / float(mt.max())
+struct FaissRng {
+	std::mt19937 mt;
+	explicit FaissRng(int64_t seed) : mt(static_cast<unsigned int>(seed)) {}
+	int rand_int(int max) { return int(mt() % static_cast<std::mt19937::result_type>(max)); }
+	float rand_float() { return float(mt()) / float(mt.max()); }
+};
+// faiss::rand_perm (utils/random.cpp:184-194)
+std::vector<int> faissRandPerm(size_t n, int64_t seed) {
+	std::vector<int> perm(n);
+	for (size_t i = 0; i < n; ++i) perm[i] = int(i);
+	FaissRng rng(seed);
+	for (size_t i = 0; i + 1 < n; ++i) {
+		const int i2 = int(i) + rng.rand_int(int(n - i));
+		std::swap(perm[i], perm[size_t(i2)]);
+	}
+	return perm;
+}
+}  // namespace
+
+// faiss::Clustering::train_encoded as Level1Quantizer::train_q1 configures it for IndexIVFFlat (IndexIVF.cpp:43-49, 76-88; Clustering.cpp:
+// 330-560): niter = 10, nredo = 1, seed 1234, <= 256 points per centroid (rand_perm subsample beyond that), initial centroids = the first
+// nlist points of rand_perm(seed + 1), spherical (renormalised centroids) for inner product / cosine, compute_centroids in single-precision
+// sums in data order, split_clusters with its own RandomGenerator(1234) per call.  The assignment of every iteration is the exact k = 1
+// search of the coarse quantiser on the device — FAISS's own search with its BLAS shortcut off (distance_compute_blas_threshold above nx);
+// with the shortcut on, the reference's result depends on the BLAS library it finds at run time.  tests/test_gpu_ivf.py holds the
+// centroids to the bits of the vendored FAISS built in place (oracle/_ref/libref_ivf.so).
 void GpuIvfFlat::Train(int seed) {
 	if (count_ < nlist_) throw std::runtime_error("Number of training points should be at least as large as number of clusters");
-	std::mt19937 rng{uint32_t(seed)};
-	// the training set: every vector, or nlist * 256 of them picked at random (Clustering::train_encoded subsampling)
-	std::vector<uint32_t> pick(count_);
-	std::iota(pick.begin(), pick.end(), 0u);
-	const size_t ns = std::min(count_, nlist_ * kMaxPointsPerCentroid);
-	if (ns < count_) {
-		std::shuffle(pick.begin(), pick.end(), rng);
+	// IndexIVFFlat::train (IndexIVFFlat.cpp:54-75): cosine trains on x * (1 / |x|)
+	size_t ns = count_;
+	std::vector<int> pick;
+	if (ns > nlist_ * kMaxPointsPerCentroid) {   // subsample_training_set (Clustering.cpp:83-137)
+		pick = faissRandPerm(ns, seed);
+		ns = nlist_ * kMaxPointsPerCentroid;
 		pick.resize(ns);
 	}
 	std::vector<float> pts(ns * dim_);
 	for (size_t i = 0; i < ns; ++i) {
-		const float* src = rows_.data() + size_t(pick[i]) * dim_;
+		const size_t srcRow = pick.empty() ? i : size_t(pick[i]);
+		const float* src = rows_.data() + srcRow * dim_;
 		float* dst = pts.data() + i * dim_;
 		if (metric_ == VectorMetric::Cosine) {
-			NormalizeCopyVector(src, int32_t(dim_), dst);
+			const float k = invNorms_[srcRow];
+			for (size_t j = 0; j < dim_; ++j) dst[j] = src[j] * k;
 		} else {
 			std::memcpy(dst, src, dim_ * sizeof(float));
 		}
 	}
-	const bool spherical = metric_ != VectorMetric::L2;   // IndexIVF.cpp:179-182
-	auto normalise = [&](float* c) {
-		double s = 0;
-		for (size_t j = 0; j < dim_; ++j) s += double(c[j]) * double(c[j]);
-		if (s > 0) {
-			const float k = float(1.0 / std::sqrt(s));
-			for (size_t j = 0; j < dim_; ++j) c[j] *= k;
+	const bool spherical = metric_ != VectorMetric::L2;   // IndexIVF.cpp:179-182 (cosine is METRIC_INNER_PRODUCT + is_cosine)
+	// fvec_renorm_L2 (utils/distances.cpp:77-86) over fvec_norm_L2sqr (utils/distances_simd.cpp:216-235): in the AVX-512 build (the SIMD level
+	// every parity claim here is pinned to) the sum of squares is ONE sequential chain of fused multiply-adds
+	auto renorm = [&](float* c) {
+		float nr = 0.f;
+		for (size_t j = 0; j < dim_; ++j) nr = std::fmaf(c[j], c[j], nr);
+		if (nr > 0) {
+			const float inv = float(1.0 / double(std::sqrt(nr)));
+			for (size_t j = 0; j < dim_; ++j) c[j] *= inv;
 		}
 	};
-	// initial centroids: nlist distinct training points
-	std::vector<uint32_t> perm(ns);
-	std::iota(perm.begin(), perm.end(), 0u);
-	std::shuffle(perm.begin(), perm.end(), rng);
 	centroids_.assign(nlist_ * dim_, 0.f);
-	for (size_t c = 0; c < nlist_; ++c) {
-		std::memcpy(centroids_.data() + c * dim_, pts.data() + size_t(perm[c]) * dim_, dim_ * sizeof(float));
-		if (spherical) normalise(centroids_.data() + c * dim_);
-	}
-	std::vector<uint32_t> a;
-	std::vector<double> sum(nlist_ * dim_);
-	std::vector<size_t> hassign(nlist_);
-	std::uniform_real_distribution<float> uni(0.f, 1.f);
-	for (int it = 0; it < kIterations; ++it) {
-		uploadCentroids();
-		assign(pts.data(), ns, a);
-		std::fill(sum.begin(), sum.end(), 0.0);
-		std::fill(hassign.begin(), hassign.end(), size_t(0));
-		for (size_t i = 0; i < ns; ++i) {
-			const float* p = pts.data() + i * dim_;
-			double* s = sum.data() + size_t(a[i]) * dim_;
-			for (size_t j = 0; j < dim_; ++j) s[j] += double(p[j]);
-			++hassign[a[i]];
-		}
+	if (ns == nlist_) {   // corner case: the training set is the centroid table (no post-processing, Clustering.cpp:365-383)
+		std::memcpy(centroids_.data(), pts.data(), nlist_ * dim_ * sizeof(float));
+	} else {
+		const std::vector<int> perm = faissRandPerm(ns, int64_t(seed) + 1);
 		for (size_t c = 0; c < nlist_; ++c) {
-			if (!hassign[c]) continue;
-			float* dst = centroids_.data() + c * dim_;
-			const double inv = 1.0 / double(hassign[c]);
-			for (size_t j = 0; j < dim_; ++j) dst[j] = float(sum[c * dim_ + j] * inv);
-		}
-		// split_clusters: an empty cluster takes half of a big one, both nudged apart by +-1/1024
-		for (size_t ci = 0; ci < nlist_ && ns > nlist_; ++ci) {
-			if (hassign[ci]) continue;
-			size_t cj = 0;
-			for (;; cj = (cj + 1) % nlist_) {
-				const float p = (float(hassign[cj]) - 1.0f) / float(ns - nlist_);
-				if (uni(rng) < p) break;
-			}
-			float* ni = centroids_.data() + ci * dim_;
-			float* nj = centroids_.data() + cj * dim_;
-			std::memcpy(ni, nj, dim_ * sizeof(float));
-			for (size_t j = 0; j < dim_; ++j) {
-				if (j % 2 == 0) {
-					ni[j] *= 1 + kSplitEps;
-					nj[j] *= 1 - kSplitEps;
-				} else {
-					ni[j] *= 1 - kSplitEps;
-					nj[j] *= 1 + kSplitEps;
-				}
-			}
-			hassign[ci] = hassign[cj] / 2;
-			hassign[cj] -= hassign[ci];
+			std::memcpy(centroids_.data() + c * dim_, pts.data() + size_t(perm[c]) * dim_, dim_ * sizeof(float));
 		}
 		if (spherical) {
-			for (size_t c = 0; c < nlist_; ++c) normalise(centroids_.data() + c * dim_);
+			for (size_t c = 0; c < nlist_; ++c) renorm(centroids_.data() + c * dim_);
+		}
+		std::vector<uint32_t> a;
+		std::vector<float> hassign(nlist_);
+		for (int it = 0; it < kIterations; ++it) {
+			uploadCentroids();
+			assign(pts.data(), ns, a);
+			// compute_centroids (Clustering.cpp:153-230)
+			std::fill(centroids_.begin(), centroids_.end(), 0.f);
+			std::fill(hassign.begin(), hassign.end(), 0.f);
+			for (size_t i = 0; i < ns; ++i) {
+				const float* x = pts.data() + i * dim_;
+				float* c = centroids_.data() + size_t(a[i]) * dim_;
+				hassign[a[i]] += 1.0f;
+				for (size_t j = 0; j < dim_; ++j) c[j] += x[j];
+			}
+			for (size_t ci = 0; ci < nlist_; ++ci) {
+				if (hassign[ci] == 0) continue;
+				const float norm = 1 / hassign[ci];
+				float* c = centroids_.data() + ci * dim_;
+				for (size_t j = 0; j < dim_; ++j) c[j] *= norm;
+			}
+			// split_clusters (Clustering.cpp:243-290): an empty cluster takes half of a big one, both nudged apart by +-1/1024
+			FaissRng rng(1234);
+			for (size_t ci = 0; ci < nlist_; ++ci) {
+				if (hassign[ci] != 0) continue;
+				size_t cj = 0;
+				for (;; cj = (cj + 1) % nlist_) {
+					const float p = float((double(hassign[cj]) - 1.0) / double(float(ns - nlist_)));
+					const float r = rng.rand_float();
+					if (r < p) break;
+				}
+				float* ni = centroids_.data() + ci * dim_;
+				float* nj = centroids_.data() + cj * dim_;
+				std::memcpy(ni, nj, dim_ * sizeof(float));
+				for (size_t j = 0; j < dim_; ++j) {
+					if (j % 2 == 0) {
+						ni[j] = float(double(ni[j]) * (1 + double(kSplitEps)));
+						nj[j] = float(double(nj[j]) * (1 - double(kSplitEps)));
+					} else {
+						ni[j] = float(double(ni[j]) * (1 - double(kSplitEps)));
+						nj[j] = float(double(nj[j]) * (1 + double(kSplitEps)));
+					}
+				}
+				hassign[ci] = hassign[cj] / 2;
+				hassign[cj] -= hassign[ci];
+			}
+			if (spherical) {   // post_process_centroids
+				for (size_t c = 0; c < nlist_; ++c) renorm(centroids_.data() + c * dim_);
+			}
 		}
 	}
 	uploadCentroids();

@@ -10,14 +10,20 @@
 //     search / range_search / remove_ids given FAISS's trained state (tests/test_ivf_oracle.py; FAISS compiled in place into
 //     oracle/_ref/libref_ivf.so with a triple-loop sgemm standing in for BLAS).  tests/test_gpu_ivf.py checks the GPU index against that
 //     definition on its own centroids.
-//   * TRAINING is not pinned: this file restates the published algorithm as the reference configures it —
-//       Level1Quantizer::train_q1 / Clustering::train   k-means, niter = 10 (IndexIVF.cpp:48), <= 256 points per centroid (subsampled),
-//                                                       random initial centroids, spherical (unit centroids) for inner product / cosine
-//                                                       (IndexIVF.cpp:179-182), empty clusters split off the big ones with +-1/1024
-//       IndexIVF::add_with_ids                          vector -> list of its nearest centroid (cosine: on the normalised vector)
-//     — but FAISS's random stream is not reproduced, so the centroids differ (as they do between FAISS builds); recall against the exact
-//     search is what is asserted.  One deliberate simplification: the cosine coarse quantiser ranks unit centroids by inner product, where
-//     FAISS multiplies by the stored 1/|centroid| (identical up to the rounding of the normalisation).
+//   * TRAINING is pinned too: Train() restates faiss::Clustering::train_encoded as Level1Quantizer::train_q1 configures it for
+//     IndexIVFFlat (IndexIVF.cpp:43-49, 76-88; Clustering.cpp:83-137, 153-290, 330-560) —
+//       subsample        more than 256 points per centroid: the first nlist * 256 of rand_perm(n, seed 1234)
+//       initial centroids the first nlist points of rand_perm(n, seed + 1) (faiss::RandomGenerator = std::mt19937, rand_int = mt() % max)
+//       10 iterations     k = 1 search of the coarse quantiser per point -> compute_centroids (single-precision sums in data order, x 1/count)
+//                         -> split_clusters (its own RandomGenerator(1234) every call, +-1/1024) -> spherical renormalisation for
+//                         inner product / cosine (fvec_renorm_L2: a sequential fmaf chain of squares in the AVX-512 build, 1.0 / sqrtf)
+//       add_with_ids      vector -> list of its nearest centroid (cosine: x * 1/|x|; the coarse quantiser is IndexFlatCosine:
+//                         inner product x the stored 1/|centroid|)
+//     and tests/test_gpu_ivf.py holds centroids and inverted lists to the BITS of the vendored FAISS built in place, L2 / IP / cosine, incl.
+//     the subsample and the empty-cluster split.  One qualification: the k-means assignment is the exact k = 1 search on the device (the
+//     reference's own distance functions); FAISS takes its BLAS shortcut (|x|^2 + |y|^2 - 2 x.y through sgemm) for batches of 20+ queries,
+//     whose rounding depends on the BLAS library the reference finds at run time — the pin is against FAISS with that shortcut off
+//     (faiss::distance_compute_blas_threshold = INT_MAX), the form that is a function of the reference's code alone.
 //
 // MI355X mapping: both halves are the brute-force engine.  The coarse quantiser is a KNN over the nlist centroids (training assigns 256
 // points per call: the matrix-core batch path); the list scan is knn_scan_subset / knn_range_subset over the row list of the probed
@@ -55,6 +61,11 @@ public:
 	size_t Dim() const noexcept { return dim_; }
 	VectorMetric Metric() const noexcept { return metric_; }
 	size_t ListSize(size_t list) const { return lists_.at(list).size(); }
+	// the ids held by an inverted list, in row order (tests: compared with faiss::InvertedLists::get_ids)
+	void ListIds(size_t list, idx_t* out) const {
+		const auto& l = lists_.at(list);
+		for (size_t i = 0; i < l.size(); ++i) out[i] = ids_[l[i]];
+	}
 	const std::vector<float>& Centroids() const noexcept { return centroids_; }
 
 	// IndexIVF::train over the vectors ALREADY added (the reference trains on space_'s content, ivf_index.cc:96-108) and moves every

@@ -752,6 +752,9 @@ int rxhost_ivf_list_sizes(void* h, uint32_t* out) {
 		for (size_t i = 0; i < m->NList(); ++i) out[i] = uint32_t(m->ListSize(i));
 	});
 }
+int rxhost_ivf_list_ids(void* h, size_t list, int64_t* out) {
+	return guarded([&] { static_cast<const GpuIvfFlat*>(h)->ListIds(list, out); });
+}
 int rxhost_ivf_centroids(void* h, float* out) {
 	return guarded([&] {
 		const auto& c = static_cast<const GpuIvfFlat*>(h)->Centroids();

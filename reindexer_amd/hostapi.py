@@ -841,6 +841,16 @@ class GpuIvfFlat:
             _raise(rc)
         return out
 
+    def list_ids(self, lst: int):
+        L = lib()
+        L.rxhost_ivf_list_ids.argtypes = [_vp, _sz, _vp]
+        out = np.zeros(int(self.list_sizes()[lst]), np.int64)
+        if out.size:
+            rc = L.rxhost_ivf_list_ids(self.h, lst, out.ctypes.data)
+            if rc:
+                _raise(rc)
+        return out
+
     def centroids(self):
         out = np.zeros((self.nlist, self.dim), np.float32)
         rc = lib().rxhost_ivf_centroids(self.h, out.ctypes.data)

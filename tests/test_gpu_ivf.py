@@ -2,7 +2,8 @@
 The index is held to the DEFINITION of IVF-Flat in the engine's own arithmetic — the result of a query is the exact (dist,row)-ordered search
 over the rows of the nprobe nearest lists, distances bit-identical to the brute-force oracle — and to recall against the exact search (what the
 reference's own IVF tests assert).  That definition itself is pinned bit for bit against the reference's vendored FAISS, given FAISS's trained
-state, in tests/test_ivf_oracle.py (CPU); training is not pinned (FAISS's random stream is not reproduced)."""
+state, in tests/test_ivf_oracle.py (CPU).  TRAINING is pinned here: centroids and inverted lists equal, bit for bit, those of the vendored FAISS
+built in place (oracle/_ref/libref_ivf.so) with its k-means assignment on the exact distance functions."""
 import numpy as np
 import pytest
 
@@ -142,3 +143,36 @@ def test_ivf_errors(hostapi):
     d, l = ivf.search(np.zeros(8, np.float32), 3, nprobe=2)
     assert np.all(l == -1) and np.all(np.isinf(d))
     ivf.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+@pytest.mark.parametrize("n,d,nlist,clusters", [(2500, 32, 16, 16), (9000, 48, 32, 200), (700, 24, 16, 3), (3000, 40, 8, 64)])
+def test_training_equals_vendored_faiss_bit_for_bit(hostapi, metric, n, d, nlist, clusters):
+    """IvfIndex's trained state (ivf_index.cc:96-108, 469-487): IndexIVFFlat::train -> Level1Quantizer::train_q1 -> Clustering::train_encoded
+    (rand_perm initialisation with seed 1234 + 1, 10 iterations, single-precision centroid sums in data order, split_clusters with its own
+    RandomGenerator(1234), spherical renormalisation for inner product / cosine; (9000, 32 lists) exceeds 256 points per centroid: the
+    rand_perm subsample; (700, 16 lists, 3 clusters) leaves clusters empty: split_clusters runs) and add_with_ids.  The product's centroids
+    and lists must be FAISS's, bit for bit."""
+    from oracle.pyoracle import RefIvf, ref_ivf_available
+    if not ref_ivf_available():
+        pytest.skip("oracle/_ref/libref_ivf.so not built")
+    rows = clustered(50 + metric, n, d, clusters)
+    ids = (np.arange(n, dtype=np.int64) * 7 + 3)
+    ref = RefIvf(metric, d, nlist, rows, ids, exact_assignment=True)
+    cent_ref, lists_ref = ref.export()
+    g = hostapi.GpuIvfFlat(metric, d, nlist)
+    g.add_with_ids(rows, ids)
+    g.train()
+    cent = g.centroids()
+    assert np.array_equal(bits(cent), bits(cent_ref)), (metric, int((bits(cent) != bits(cent_ref)).sum()))
+    for c in range(nlist):
+        assert np.array_equal(np.sort(g.list_ids(c)), np.sort(lists_ref[c])), (metric, c)
+    # searches then agree label for label (the search definition is pinned separately)
+    q = clustered(99, 1, d, clusters)[0]
+    qref = hostapi.normalize_copy(q)[0] if metric == 2 else q   # IvfIndex normalises a cosine query before it reaches FAISS
+    for nprobe in (1, 4):
+        gd, gl = g.search(q, 10, nprobe)
+        rd, rl = ref.search(qref, 10, nprobe)
+        assert np.array_equal(gl, rl) and np.array_equal(bits(gd), bits(rd))
+    g.close()
+    ref.close()
