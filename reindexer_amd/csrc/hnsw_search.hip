@@ -18,59 +18,54 @@
 
 namespace rxgpu {
 
-// --- PriorityQueue<pair<float,tableint>, vector, CompareByFirst> restated on raw arrays (executed by ONE lane) ---
-__device__ __forceinline__ void hp_sift_up(float* d, uint32_t* id, int child) {
-	const float vd = d[child];
-	const uint32_t vi = id[child];
+// --- PriorityQueue<pair<float,tableint>, vector, CompareByFirst> restated on an array of (dist bits, id) pairs (executed by ONE lane) ---
+// One 8-byte entry per element: a sift level is ONE dependent LDS round trip (both children, each one ds_read_b64, issued together)
+// instead of three (two distances, then the winner's id) — the heap updates of lane 0 are the longest stretch of a hop.
+__device__ __forceinline__ float hp_dist(uint2 e) { return __uint_as_float(e.x); }
+__device__ __forceinline__ void hp_sift_up(uint2* h, int child) {
+	const uint2 v = h[child];
 	while (child > 0) {
 		const int parent = (child - 1) / 2;
-		if (!(d[parent] < vd)) break;
-		d[child] = d[parent];
-		id[child] = id[parent];
+		const uint2 pe = h[parent];
+		if (!(hp_dist(pe) < hp_dist(v))) break;
+		h[child] = pe;
 		child = parent;
 	}
-	d[child] = vd;
-	id[child] = vi;
+	h[child] = v;
 }
-__device__ __forceinline__ void hp_sift_down(float* d, uint32_t* id, int parent, int size) {
-	const float vd = d[parent];
-	const uint32_t vi = id[parent];
+__device__ __forceinline__ void hp_sift_down(uint2* h, int parent, int size) {
+	const uint2 v = h[parent];
 	for (;;) {
 		const int left = parent * 2 + 1;
 		if (left >= size) break;
-		int best = left;
 		const int right = left + 1;
-		if (right < size && d[left] < d[right]) best = right;
-		if (!(vd < d[best])) break;
-		d[parent] = d[best];
-		id[parent] = id[best];
-		parent = best;
+		const uint2 le = h[left];
+		const uint2 re = h[right < size ? right : left];
+		const bool take_right = right < size && hp_dist(le) < hp_dist(re);
+		const uint2 be = take_right ? re : le;
+		if (!(hp_dist(v) < hp_dist(be))) break;
+		h[parent] = be;
+		parent = take_right ? right : left;
 	}
-	d[parent] = vd;
-	id[parent] = vi;
+	h[parent] = v;
 }
-__device__ __forceinline__ void hp_emplace(float* d, uint32_t* id, int& n, float vd, uint32_t vi) {
-	d[n] = vd;
-	id[n] = vi;
+__device__ __forceinline__ void hp_emplace(uint2* h, int& n, float vd, uint32_t vi) {
+	h[n] = make_uint2(__float_as_uint(vd), vi);
 	++n;
-	if (n >= 2) hp_sift_up(d, id, n - 1);
+	if (n >= 2) hp_sift_up(h, n - 1);
 }
-__device__ __forceinline__ void hp_pop(float* d, uint32_t* id, int& n) {
+__device__ __forceinline__ void hp_pop(uint2* h, int& n) {
 	if (n >= 2) {
-		const float td = d[0];
-		const uint32_t ti = id[0];
-		d[0] = d[n - 1];
-		id[0] = id[n - 1];
-		d[n - 1] = td;
-		id[n - 1] = ti;
-		if (n > 2) hp_sift_down(d, id, 0, n - 1);
+		const uint2 t = h[0];
+		h[0] = h[n - 1];
+		h[n - 1] = t;
+		if (n > 2) hp_sift_down(h, 0, n - 1);
 	}
 	--n;
 }
-__device__ __forceinline__ void hp_replace_top(float* d, uint32_t* id, int n, float vd, uint32_t vi) {
-	d[0] = vd;
-	id[0] = vi;
-	hp_sift_down(d, id, 0, n);
+__device__ __forceinline__ void hp_replace_top(uint2* h, int n, float vd, uint32_t vi) {
+	h[0] = make_uint2(__float_as_uint(vd), vi);
+	hp_sift_down(h, 0, n);
 }
 
 // Distances of `cnt` rows (ids in LDS) to the query, 4 rows per step; every lane participates in every step.
@@ -284,12 +279,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
 	extern __shared__ __attribute__((aligned(16))) unsigned char hnsw_lds[];
-	float* top_d = reinterpret_cast<float*>(hnsw_lds);
-	uint32_t* top_i = reinterpret_cast<uint32_t*>(top_d + p.ef_cap);
-	float* lcand_d = reinterpret_cast<float*>(top_i + p.ef_cap);
-	uint32_t* lcand_i = reinterpret_cast<uint32_t*>(lcand_d + (kGlobalCand ? 0 : p.lds_cand_cap));
+	uint2* top = reinterpret_cast<uint2*>(hnsw_lds);   // (dist bits, id) entries
+	uint2* lcand = top + p.ef_cap;
 	constexpr bool kQLds = NB > 0 && !kSq8;   // fixed dims: query fragment in LDS behind the heaps (16-byte aligned: every part is a multiple of 64 entries)
-	float4* q_s = reinterpret_cast<float4*>(lcand_i + (kGlobalCand ? 0 : p.lds_cand_cap));
+	float4* q_s = reinterpret_cast<float4*>(lcand + (kGlobalCand ? 0 : p.lds_cand_cap));
 	__shared__ uint32_t nb_id[kHnswMaxNeighbors];
 	__shared__ float nb_d[kHnswMaxNeighbors];
 	__shared__ uint8_t nb_del[kHnswMaxNeighbors];
@@ -301,8 +294,7 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	const uint32_t qi = p.only ? p.only[slot] : slot;
 	const float* q = p.queries + size_t(qi) * p.dim;
 	uint32_t* visited = p.visited + size_t(slot) * p.visited_words;
-	float* cand_d = kGlobalCand ? p.gcand_d + size_t(slot) * p.gcand_cap : lcand_d;
-	uint32_t* cand_i = kGlobalCand ? p.gcand_i + size_t(slot) * p.gcand_cap : lcand_i;
+	uint2* cand = kGlobalCand ? p.gcand + size_t(slot) * p.gcand_cap : lcand;
 	const uint64_t cand_cap = kGlobalCand ? p.gcand_cap : uint64_t(p.lds_cand_cap);
 	unsigned long long ndist = 0, hops = 0;
 	float4 qreg[1];
@@ -381,10 +373,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 		const bool ep_ok = p.bare || !p.deleted[cur];
 		if (lane == 0) {
 			if (ep_ok) {
-				hp_emplace(top_d, top_i, top_n, curdist, cur);
-				hp_emplace(cand_d, cand_i, cand_n, -curdist, cur);
+				hp_emplace(top, top_n, curdist, cur);
+				hp_emplace(cand, cand_n, -curdist, cur);
 			} else {
-				hp_emplace(cand_d, cand_i, cand_n, -3.402823466e+38f, cur);
+				hp_emplace(cand, cand_n, -3.402823466e+38f, cur);
 			}
 			atomicOr(&visited[cur >> 5], 1u << (cur & 31));
 		}
@@ -399,12 +391,13 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 			if (cand_n == 0 || overflow) {
 				flag = 1;
 			} else {
-				const float cdist = -cand_d[0];
+				const uint2 best = cand[0];
+				const float cdist = -hp_dist(best);
 				if (p.bare ? (cdist > lower) : (cdist > lower && top_n >= int(p.ef))) {
 					flag = 1;
 				} else {
-					s_cur = cand_i[0];
-					hp_pop(cand_d, cand_i, cand_n);
+					s_cur = best.y;
+					hp_pop(cand, cand_n);
 				}
 			}
 			s_flag = flag;
@@ -413,21 +406,24 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 		if (s_flag) break;
 		const uint32_t node = s_cur;
 		hops += 1;
-		// neighbours: one per lane; atomicOr = visited test + mark
+		// neighbours: the whole list block (count word + up to 2M ids) is fetched in ONE round — lane L reads word L of the block, so the
+		// count arrives together with the ids instead of in front of them; atomicOr = visited test + mark
 		const uint32_t* ll = p.links0 + size_t(node) * (1 + p.maxM0);
-		const int cnt = int(ll[0]);
 		int nfresh = 0;
-		for (int base = 0; base < cnt; base += 64) {
-			const int j = base + lane;
+		int cnt = 0;
+		for (int base = 0; base <= int(p.maxM0); base += 64) {
+			const int w = base + lane;   // word of the block; neighbour index j = w - 1
+			const uint32_t word = w <= int(p.maxM0) ? ll[w] : 0u;
+			if (base == 0) cnt = int(__builtin_amdgcn_readfirstlane(word));
+			if (base > cnt) break;   // uniform
+			const int j = w - 1;
 			bool fresh = false;
-			uint32_t id = 0;
-			if (j < cnt) {
-				id = ll[1 + j];
-				const uint32_t bit = 1u << (id & 31);
-				fresh = !(atomicOr(&visited[id >> 5], bit) & bit);
+			if (j >= 0 && j < cnt) {
+				const uint32_t bit = 1u << (word & 31);
+				fresh = !(atomicOr(&visited[word >> 5], bit) & bit);
 			}
 			const uint64_t fm = __ballot(fresh);
-			if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = id;
+			if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
 			nfresh += __popcll(fm);
 		}
 		__syncthreads();
@@ -446,15 +442,15 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 						overflow = true;
 						break;
 					}
-					hp_emplace(cand_d, cand_i, cand_n, -d, id);
+					hp_emplace(cand, cand_n, -d, id);
 					if (p.bare || !nb_del[i]) {
 						if (top_n < int(p.ef)) {
-							hp_emplace(top_d, top_i, top_n, d, id);
+							hp_emplace(top, top_n, d, id);
 						} else {
-							hp_replace_top(top_d, top_i, top_n, d, id);
+							hp_replace_top(top, top_n, d, id);
 						}
 					}
-					if (top_n) lower = top_d[0];
+					if (top_n) lower = hp_dist(top[0]);
 				}
 			}
 		}
@@ -465,10 +461,10 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 		if (overflow) {
 			p.out_count[qi] = kHnswOverflow;
 		} else {
-			while (top_n > int(p.k)) hp_pop(top_d, top_i, top_n);   // SearchKnn :1998-2000
+			while (top_n > int(p.k)) hp_pop(top, top_n);   // SearchKnn :1998-2000
 			for (int i = 0; i < top_n; ++i) {
-				p.out_dist[size_t(qi) * p.k + i] = top_d[i];
-				p.out_row[size_t(qi) * p.k + i] = top_i[i];
+				p.out_dist[size_t(qi) * p.k + i] = hp_dist(top[i]);
+				p.out_row[size_t(qi) * p.k + i] = top[i].y;
 			}
 			p.out_count[qi] = uint32_t(top_n);
 		}

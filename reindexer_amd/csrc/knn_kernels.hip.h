@@ -131,8 +131,7 @@ struct HnswParams {
 	uint32_t* out_row;
 	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode)
 	const uint32_t* only;     // optional: list of query indices to process (blockIdx.x indexes this list)
-	float* gcand_d;           // global-mode candidate heap storage [slots][gcand_cap]
-	uint32_t* gcand_i;
+	uint2* gcand;             // global-mode candidate heap storage [slots][gcand_cap] of (dist bits, id)
 	uint64_t gcand_cap;
 	unsigned long long* stats;   // optional [2]: distance evaluations, hops
 	uint32_t lds_cand_cap;       // <= kHnswCandLds (tests shrink it to force the global-heap re-run)

@@ -1502,7 +1502,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	size_t free_b = 0, total_b = 0;
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
 	const uint64_t visited_budget = std::min<uint64_t>(16ull << 30, std::max<uint64_t>(2ull << 30, (uint64_t(free_b) + c->d_visited.bytes) / 8));
-	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(8192, visited_budget / (words * 4)));
+	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(32768, visited_budget / (words * 4)));
 	// SQ8 queries: [codes, padded to 4 bytes][corr][normCoef] in the one query buffer
 	const size_t qelem = sq8 ? sizeof(uint8_t) : sizeof(float);
 	const size_t qbytes = size_t(nq) * h->dim * qelem;
@@ -1598,15 +1598,13 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		for (size_t r0 = 0; r0 < redo.size(); r0 += redo_slots) {
 			const uint32_t cq = uint32_t(std::min<uint64_t>(redo_slots, redo.size() - r0));
 			if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
-			if (int rc = c->d_gcand_d.ensure(size_t(cq) * gcap * sizeof(float)); rc) return rc;
-			if (int rc = c->d_gcand_i.ensure(size_t(cq) * gcap * sizeof(uint32_t)); rc) return rc;
+			if (int rc = c->d_gcand_d.ensure(size_t(cq) * gcap * sizeof(uint2)); rc) return rc;
 			RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
 			rxgpu::HnswParams pc = p;
 			pc.queries = static_cast<const float*>(c->d_queries.ptr);
 			pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
 			pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;
-			pc.gcand_d = static_cast<float*>(c->d_gcand_d.ptr);
-			pc.gcand_i = static_cast<uint32_t*>(c->d_gcand_i.ptr);
+			pc.gcand = static_cast<uint2*>(c->d_gcand_d.ptr);
 			pc.gcand_cap = gcap;
 			ProfileScope ps(h, "hnsw_redo", c->stream);
 			rxgpu::launch_hnsw_search(h->metric, pc, cq, true, c->stream);
