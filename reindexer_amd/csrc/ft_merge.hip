@@ -190,17 +190,28 @@ __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerim
 //              (SortSubterms order) with a positive field boost adds min(proc16, 65535 / 4), saturating at 65535; then (:416-423) documents
 //              outside the mask / removed score 0 and the rest is histogrammed
 constexpr uint32_t kFtRangeSubs = 512;   // sub-terms whose segment, list pointer and proc are staged in LDS (more: read from HBM)
-constexpr uint32_t kFtStage = 8192;      // postings of the range prefetched into LDS (16-bit local document ids)
-__global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
+constexpr uint32_t kFtStageBlocks = 32;  // 256-posting blocks of the range prefetched into registers (one posting per thread and block)
+__global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 	constexpr uint32_t kWords = kFtRangeDocs / 32;
-	__shared__ uint32_t s_mask[kWords], s_term[kWords], s_seen[kWords];
+	__shared__ uint32_t s_mask[kWords], s_term[kWords];
 	__shared__ uint16_t s_score[kFtRangeDocs];
 	__shared__ uint32_t s_keys[256], s_part[4];
-	__shared__ uint32_t s_lo[kFtRangeSubs], s_hi[kFtRangeSubs], s_start[kFtRangeSubs + 1];
+	__shared__ uint32_t s_lo[kFtRangeSubs], s_hi[kFtRangeSubs], s_blk0[kFtRangeSubs + 1];
 	__shared__ const uint32_t* s_docptr[kFtRangeSubs];
-	__shared__ const uint32_t* s_elem0[kFtRangeSubs];   // &doc[lo] - start: the element at flat position f is s_elem0[si][f]
 	__shared__ float s_proc[kFtRangeSubs];
-	__shared__ __attribute__((aligned(16))) uint16_t s_stage[kFtStage];
+	struct BlockInfo {            // one 256-posting block of a staged sub-term's segment
+		const uint32_t* first;    // &doc[lo + 256 k]
+		uint32_t count;           // postings in the block (1..256)
+		uint32_t pad;
+	};
+	__shared__ __attribute__((aligned(16))) BlockInfo s_binfo[kFtStageBlocks];
+	__shared__ __attribute__((aligned(16))) uint32_t s_rep[256 * 16];   // score histogram: 16 counters per key (after the term pass)
+	// During the term pass the same space holds one byte per document: the number (+1) of the last term that scored it.  "Already scored in
+	// this term" is then a plain byte compare — documents are unique inside a sub-term and sub-terms sit behind barriers, so no two threads
+	// touch one byte — where a bit set took an LDS atomic with return per posting: at 6400 postings per range and three ranges per CU the
+	// atomics alone were ~10 us of this kernel.
+	uint8_t* s_scored = reinterpret_cast<uint8_t*>(s_rep);   // [kFtRangeDocs]
+	static_assert(sizeof(s_rep) >= kFtRangeDocs, "one byte per document fits the counter space");
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
 	FT_STAMP(p, 0);
 	const uint64_t d_begin = uint64_t(range) * kFtRangeDocs;
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 	}
 	if (p.prescore) {
 		for (uint32_t i = tid; i < kFtRangeDocs / 2; i += 256) reinterpret_cast<uint32_t*>(s_score)[i] = 0;
+		for (uint32_t i = tid; i < kFtRangeDocs / 4; i += 256) reinterpret_cast<uint32_t*>(s_scored)[i] = 0;
 		s_keys[tid] = 0;   // a score of 0 is never inserted
 	}
 	// this range's segment [lo, hi) of every posting list, fetched up front (two dependent loads each, all in flight together); the merged
@@ -244,87 +256,63 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 	FT_STAMP(p, 1);
 	const uint32_t nterms = p.simple ? 0u : p.nterms;
 	const uint32_t ns = nterms ? (p.n_subs < kFtRangeSubs ? p.n_subs : kFtRangeSubs) : 0u;
-	// ---- all staged segments laid end to end; the first kFtStage postings of that layout are fetched NOW, every load independent of the
-	// others: the terms below then run out of LDS.  (Walking the sub-terms one after the other, each behind its own load round trips —
-	// list pointer, document ids, a second round for segments over 1024 postings — took 23 us of this kernel's 40 for a 3 x 3 query.)
+	// ---- the staged segments cut into blocks of 256 postings (a block never spans two sub-terms); the first kFtStageBlocks blocks are
+	// fetched NOW into registers — one posting per thread and block, every load independent of the others — and the terms below run out
+	// of registers.  Which sub-term a block belongs to is a wave-uniform fact: the term loop tests it with scalar compares.  (History:
+	// walking the sub-terms one after the other, each behind its own load round trips, took 23 us of this kernel's 40 for a 3 x 3 query;
+	// a flat layout with a per-posting owner search spent 6 us in VALU compares — a wave64 operation costs four cycles — plus an LDS stage.)
 	if (ns) {
 		const uint32_t a = 2 * tid, b = 2 * tid + 1;
-		const uint32_t la = a < ns ? s_hi[a] - s_lo[a] : 0u, lb = b < ns ? s_hi[b] - s_lo[b] : 0u;
-		const uint32_t incl = wave_inclusive_scan(la + lb, int(tid & 63));
+		const uint32_t na = a < ns ? (s_hi[a] - s_lo[a] + 255) / 256 : 0u, nb = b < ns ? (s_hi[b] - s_lo[b] + 255) / 256 : 0u;
+		const uint32_t incl = wave_inclusive_scan(na + nb, int(tid & 63));
 		if ((tid & 63) == 63) s_part[tid >> 6] = incl;
 		__syncthreads();
-		uint32_t excl = incl - (la + lb);
+		uint32_t excl = incl - (na + nb);
 		for (uint32_t w = 0; w < (tid >> 6); ++w) excl += s_part[w];
-		if (a < ns) s_start[a] = excl;
-		if (b < ns) s_start[b] = excl + la;
-		if (a < ns) s_elem0[a] = s_docptr[a] + s_lo[a] - excl;
-		if (b < ns) s_elem0[b] = s_docptr[b] + s_lo[b] - (excl + la);
+		if (a < ns) s_blk0[a] = excl;
+		if (b < ns) s_blk0[b] = excl + na;
 		if (b + 1 == ns) {   // the thread that holds the last staged sub-term also writes the end marker
-			s_start[ns] = excl + la + lb;
+			s_blk0[ns] = excl + na + nb;
 		} else if (a + 1 == ns) {
-			s_start[ns] = excl + la;
+			s_blk0[ns] = excl + na;
+		}
+		for (uint32_t which = 0; which < 2; ++which) {   // block descriptors of this thread's two sub-terms
+			const uint32_t si = which ? b : a, nblk = which ? nb : na, b0 = which ? excl + na : excl;
+			if (si >= ns) continue;
+			for (uint32_t k = 0; k < nblk && b0 + k < kFtStageBlocks; ++k) {
+				const uint32_t first = s_lo[si] + 256 * k;
+				s_binfo[b0 + k] = BlockInfo{s_docptr[si] + first, s_hi[si] - first < 256u ? s_hi[si] - first : 256u, 0u};
+			}
 		}
 		__syncthreads();
 	}
 	FT_STAMP(p, 7);
-	const uint32_t total_staged = ns ? s_start[ns] : 0u;
-	const uint32_t n_stage = total_staged < kFtStage ? total_staged : kFtStage;
+	const uint32_t total_blocks = ns ? s_blk0[ns] : 0u;
+	const uint32_t n_staged = total_blocks < kFtStageBlocks ? total_blocks : kFtStageBlocks;
+	uint32_t dd[kFtStageBlocks];   // local document id of the thread's posting in block q, or 0xFFFFFFFF
 	{
-		// 32 postings per thread.  Which sub-term holds flat position f: a branch-free binary search that advances all 32 positions of the
-		// thread one level at a time (the LDS reads of a level are independent; 32 separate search loops cost 9 us in LDS round trips),
-		// then every global load is issued before the first one is consumed.
-		constexpr int kPer = kFtStage / 256;
-		uint32_t pos[kPer], dd[kPer];
+		uint32_t raw[kFtStageBlocks];
+		bool have[kFtStageBlocks];
 #pragma unroll
-		for (int q = 0; q < kPer; ++q) pos[q] = 0;
-		if (ns == 0) {
-			// a Simple() query: no term pass, nothing to stage
-		} else if (ns <= 16) {   // the usual query: the slice starts in registers, position = how many starts lie at or before f
-			uint32_t st[16];
-#pragma unroll
-			for (int j = 1; j < 16; ++j) st[j] = s_start[uint32_t(j) < ns ? uint32_t(j) : ns];   // padding = the total: beyond every staged f
-#pragma unroll
-			for (int q = 0; q < kPer; ++q) {
-				const uint32_t f = uint32_t(q) * 256 + tid;
-#pragma unroll
-				for (int j = 1; j < 16; ++j) pos[q] += uint32_t(j) < ns && st[j] <= f ? 1u : 0u;
-			}
-		} else {
-			uint32_t top = 1;
-			while (top * 2 < ns) top *= 2;   // uniform
-			for (uint32_t step = top; step; step >>= 1) {
-#pragma unroll
-				for (int q = 0; q < kPer; ++q) {
-					const uint32_t cand = pos[q] + step;
-					const uint32_t start = s_start[cand < ns ? cand : ns];   // s_start[ns] = the total: past every staged position
-					if (cand < ns && start <= uint32_t(q) * 256 + tid) pos[q] = cand;
-				}
-			}
+		for (uint32_t q = 0; q < kFtStageBlocks; ++q) {
+			const uint4 info = *reinterpret_cast<const uint4*>(&s_binfo[q]);   // uniform address: one broadcast read, all 32 of them independent
+			const uint32_t* first = reinterpret_cast<const uint32_t*>((uint64_t(info.y) << 32) | info.x);
+			have[q] = q < n_staged && tid < info.z;
+			raw[q] = have[q] ? first[tid] : 0u;
 		}
-		FT_STAMP(p, 8);
 #pragma unroll
-		for (int q = 0; q < kPer; ++q) {
-			const uint32_t f = uint32_t(q) * 256 + tid;
-			dd[q] = f < n_stage ? s_elem0[pos[q]][f] : 0u;
-		}
-		FT_STAMP(p, 9);
-#pragma unroll
-		for (int q = 0; q < kPer; ++q) {
-			const uint32_t f = uint32_t(q) * 256 + tid;
-			if (f < n_stage) s_stage[f] = uint16_t(dd[q] - uint32_t(d_begin));
-		}
-		FT_STAMP(p, 10);
+		for (uint32_t q = 0; q < kFtStageBlocks; ++q) dd[q] = have[q] ? raw[q] - uint32_t(d_begin) : 0xFFFFFFFFu;
 	}
-	__syncthreads();
 	FT_STAMP(p, 6);
 	for (uint32_t t = 0; t < nterms; ++t) {
 		const FtTermCfg& term = p.terms[t];
 		const int op = term.op;
 		const bool want_score = p.prescore && op != 3;
 		if (op == 1 && !want_score) continue;   // an OR term only matters to the pre-score
-		for (uint32_t w = tid; w < kWords; w += 256) {
-			s_term[w] = 0;
-			s_seen[w] = 0;
+		for (uint32_t w = tid; w < kWords; w += 256) s_term[w] = 0;
+		const uint32_t epoch = (t % 255u) + 1u;   // byte tag of this term (the bytes start at 0: set with the scores above)
+		if (t && t % 255u == 0) {   // the tags wrap: no stale one may survive
+			for (uint32_t w = tid; w < kFtRangeDocs / 4; w += 256) reinterpret_cast<uint32_t*>(s_scored)[w] = 0;
 		}
 		__syncthreads();
 		// the term's configuration in registers: `term` lives in global memory, and a load per posting sat on the critical path
@@ -353,8 +341,8 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 			if (op == 2 && rel) atomicOr(&s_term[local >> 5], bit);
 			if (want_score && mb > 0.0f) {
 				// termMask: documents are unique inside a sub-term and earlier sub-terms are behind a barrier, so the first one wins
-				const uint32_t old = atomicOr(&s_seen[local >> 5], bit);
-				if (!(old & bit)) {
+				if (s_scored[local] != epoch) {
+					s_scored[local] = uint8_t(epoch);
 					const float proc = sproc * mb * opts_boost;
 					uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
 					p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
@@ -374,46 +362,53 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 				lo = s_lo[si];
 				hi = s_hi[si];
 				sproc = s_proc[si];
-				const uint32_t f_begin = s_start[si], f_end = s_start[si + 1];
-				const uint32_t staged_end = f_end < n_stage ? f_end : n_stage;
-				if (op == 3 || need_entries) {
-					for (uint32_t f = f_begin + tid; f < staged_end; f += 256) visit(s, sproc, lo + (f - f_begin), s_stage[f]);
-				} else {
-					// the common case (no per-entry field test), four postings per thread and step: their LDS reads and atomics are
-					// independent, so the four chains (stage -> seen bit -> score) overlap instead of running one after the other
-					const float proc = sproc * boost0 * opts_boost;
-					uint32_t p16c = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
-					p16c = p16c < 65535u / 4 ? p16c : 65535u / 4;
-					const bool scoring = want_score && boost0 > 0.0f;
-					for (uint32_t f0 = f_begin; f0 < staged_end; f0 += 4 * 256) {
-						uint32_t loc[4], old[4];
-						bool ok[4];
+				const uint32_t b0 = s_blk0[si], b1raw = s_blk0[si + 1];
+				const uint32_t b1 = b1raw < n_staged ? b1raw : n_staged;   // staged blocks of this sub-term: [b0, b1)
+				const bool fast = !(op == 3 || need_entries);
+				const float proc = sproc * boost0 * opts_boost;
+				uint32_t p16c = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
+				p16c = p16c < 65535u / 4 ? p16c : 65535u / 4;
+				const bool scoring = want_score && boost0 > 0.0f;
 #pragma unroll
-						for (int q = 0; q < 4; ++q) {
-							const uint32_t f = f0 + uint32_t(q) * 256 + tid;
-							ok[q] = f < staged_end;
-							loc[q] = ok[q] ? uint32_t(s_stage[f]) : 0u;
+				for (uint32_t g = 0; g < kFtStageBlocks; g += 4) {
+					if (g + 4 <= b0 || g >= b1) continue;   // uniform: none of the four blocks is this sub-term's
+					bool ok[4];
+					uint32_t loc[4], tag[4];
+#pragma unroll
+					for (uint32_t q = 0; q < 4; ++q) {
+						ok[q] = g + q >= b0 && g + q < b1 && dd[g + q] != 0xFFFFFFFFu;
+						loc[q] = ok[q] ? dd[g + q] : 0u;
+					}
+					if (!fast) {
+#pragma unroll
+						for (uint32_t q = 0; q < 4; ++q) {
+							if (ok[q]) visit(s, sproc, lo + 256 * (g + q - b0) + tid, loc[q]);
 						}
-						if (op == 2) {   // all_pos_boost: every occurrence is relevant
+						continue;
+					}
+					// the common case (no per-entry field test), four postings per thread: their LDS atomics and score updates are
+					// independent chains that overlap
+					if (op == 2) {   // all_pos_boost: every occurrence is relevant
 #pragma unroll
-							for (int q = 0; q < 4; ++q) {
-								if (ok[q]) atomicOr(&s_term[loc[q] >> 5], 1u << (loc[q] & 31));
-							}
+						for (uint32_t q = 0; q < 4; ++q) {
+							if (ok[q]) atomicOr(&s_term[loc[q] >> 5], 1u << (loc[q] & 31));
 						}
-						if (scoring) {
+					}
+					if (scoring) {
 #pragma unroll
-							for (int q = 0; q < 4; ++q) old[q] = ok[q] ? atomicOr(&s_seen[loc[q] >> 5], 1u << (loc[q] & 31)) : 0xFFFFFFFFu;
+						for (uint32_t q = 0; q < 4; ++q) tag[q] = ok[q] ? uint32_t(s_scored[loc[q]]) : epoch;
 #pragma unroll
-							for (int q = 0; q < 4; ++q) {
-								if ((old[q] >> (loc[q] & 31)) & 1u) continue;   // an earlier sub-term of the term holds the document
-								const uint32_t cur = s_score[loc[q]];
-								const uint32_t add = p16c < 65535u - cur ? p16c : 65535u - cur;
-								s_score[loc[q]] = uint16_t(cur + add);
-							}
+						for (uint32_t q = 0; q < 4; ++q) {
+							if (tag[q] == epoch) continue;   // an earlier sub-term of the term holds the document
+							s_scored[loc[q]] = uint8_t(epoch);
+							const uint32_t cur = s_score[loc[q]];
+							const uint32_t add = p16c < 65535u - cur ? p16c : 65535u - cur;
+							s_score[loc[q]] = uint16_t(cur + add);
 						}
 					}
 				}
-				from_global = lo + (staged_end > f_begin ? staged_end - f_begin : 0u);   // what did not fit the stage
+				from_global = lo + 256 * (b1 > b0 ? b1 - b0 : 0u);   // what did not fit the stage
+				if (from_global > hi) from_global = hi;
 			} else {
 				lo = range < s.n_ranges ? s.range_off[range] : uint32_t(s.n);
 				hi = range + 1 < s.n_ranges ? s.range_off[range + 1] : uint32_t(s.n);
@@ -463,47 +458,66 @@ __global__ __launch_bounds__(256) void ft_ranges(FtPlan p) {
 	// ---- scores: masked-out / removed documents score 0 (mergerimpl.h:416-423); histogram of the rest through a small LDS hash table.
 	// Few distinct scores occur (a handful of proc values and their sums), so plain counters would take 64-way same-address atomics from
 	// every wavefront: each key gets 16 counters on 16 different banks (the posting stage is free by now), lane l adds to counter l % 16
-	uint32_t* s_rep = reinterpret_cast<uint32_t*>(s_stage);   // [256 keys][16]
 	uint32_t* hist_copy = p.hist + size_t(range % kFtHistCopies) * kFtHistStride;
-	static_assert(kFtStage * sizeof(uint16_t) >= 256 * 16 * sizeof(uint32_t), "the posting stage holds the replicated counters");
 	for (uint32_t i = tid; i < 256 * 16; i += 256) s_rep[i] = 0;
-	__syncthreads();
-	uint32_t rm8[kFtRangeDocs / 4 / 256];   // the removed flags of the thread's documents (4 per word), fetched together
+	constexpr uint32_t kSteps = kFtRangeDocs / 4 / 256;   // 8 steps of four documents per thread
+	uint32_t rm8[kSteps];   // the removed flags of the thread's documents (4 per word), fetched together
 #pragma unroll
-	for (uint32_t j = 0; j < kFtRangeDocs / 4 / 256; ++j) {
+	for (uint32_t j = 0; j < kSteps; ++j) {
 		const uint32_t l0 = (j * 256 + tid) * 4;
 		rm8[j] = (p.removed && l0 < docs_here) ? *reinterpret_cast<const uint32_t*>(p.removed + d_begin + l0) : 0u;   // reads past the end stay inside the allocation
 	}
+	__syncthreads();
+	// scores first (eight 8-byte LDS reads and the global stores), then every hash probe, then the counters: each phase's LDS accesses are
+	// independent of one another, so their latencies overlap instead of queueing per document
+	uint32_t sc[kSteps][4];
 #pragma unroll
-	for (uint32_t j = 0; j < kFtRangeDocs / 4 / 256; ++j) {
+	for (uint32_t j = 0; j < kSteps; ++j) {
 		const uint32_t l0 = (j * 256 + tid) * 4;
-		if (l0 >= docs_here) break;
-		const uint32_t mw = s_mask[l0 >> 5];
-		const uint32_t rm = rm8[j];
-		uint32_t sc[4];
+		const uint32_t mw = s_mask[(l0 >> 5) & (kWords - 1)];
+		const uint2 four = *reinterpret_cast<const uint2*>(&s_score[l0]);
+		const uint32_t raw[4] = {four.x & 0xFFFFu, four.x >> 16, four.y & 0xFFFFu, four.y >> 16};
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const bool in = l0 + k < docs_here && ((mw >> ((l0 + k) & 31)) & 1u) && !((rm >> (8 * k)) & 0xFFu);
-			sc[k] = in ? uint32_t(s_score[l0 + k]) : 0u;
+			const bool in = l0 + k < docs_here && ((mw >> ((l0 + k) & 31)) & 1u) && !((rm8[j] >> (8 * k)) & 0xFFu);
+			sc[j][k] = in ? raw[k] : 0u;
 		}
-		*reinterpret_cast<uint2*>(p.score + d_begin + l0) = make_uint2(sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16));   // the array is padded to whole mask words
+		if (l0 < docs_here) {
+			*reinterpret_cast<uint2*>(p.score + d_begin + l0) = make_uint2(sc[j][0] | (sc[j][1] << 16), sc[j][2] | (sc[j][3] << 16));   // the array is padded to whole mask words
+		}
+	}
+#pragma unroll
+	for (uint32_t j = 0; j < kSteps; ++j) {
+		uint32_t h[4], cur[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const uint32_t v = sc[k];
+			h[k] = (sc[j][k] * 2654435761u) >> 24;
+			cur[k] = sc[j][k] ? s_keys[h[k]] : 0u;
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const uint32_t v = sc[j][k];
 			if (!v) continue;
-			uint32_t h = (v * 2654435761u) >> 24;
+			if (cur[k] == v) {   // the key is there already (after the first few documents of the range it always is)
+				atomicAdd(&s_rep[h[k] * 16 + (tid & 15)], 1u);
+				continue;
+			}
+			uint32_t hh = h[k];
 			int probes = 0;
-			for (; probes < 256; ++probes, h = (h + 1) & 255u) {
-				uint32_t cur = s_keys[h];
-				if (cur != v) {
-					if (cur != 0u) continue;
-					cur = atomicCAS(&s_keys[h], 0u, v);
-					if (cur != 0u && cur != v) continue;
+			for (; probes < 256; ++probes, hh = (hh + 1) & 255u) {
+				uint32_t c = s_keys[hh];
+				if (c != v) {
+					if (c != 0u) continue;
+					c = atomicCAS(&s_keys[hh], 0u, v);
+					if (c != 0u && c != v) continue;
 				}
-				atomicAdd(&s_rep[h * 16 + (tid & 15)], 1u);
+				atomicAdd(&s_rep[hh * 16 + (tid & 15)], 1u);
 				break;
 			}
-			if (probes == 256) atomicAdd(&p.hist[v], 1u);   // more than 256 distinct scores in one range
+			if (probes == 256) {   // more than 256 distinct scores in one range (a register-side count of the common values was slower: 15 us)
+				atomicAdd(&hist_copy[v], 1u);
+				atomicAdd(&hist_copy[65536 + (v >> 6)], 1u);
+			}
 		}
 	}
 	__syncthreads();
