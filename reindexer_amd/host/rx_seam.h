@@ -43,8 +43,11 @@ public:
 	size_t GetHash(FloatVectorId id) const {
 		return ConstFloatVectorView{std::span<const float>{FloatPtrByExternalLabel(id.AsNumber()), Dim()}}.Hash();
 	}
-	// The ANN disk cache and SQ8 are not provided by the GPU engine: the index type is registered as non-cacheable (like brute force) and
-	// QuantizationAvailable() is false, so these are never reached through HnswIndexBase; they fail loudly if somebody calls them directly.
+	// The ANN disk cache is not provided by the GPU engine: the index type is registered as non-cacheable (like brute force).  SQ8: the Map
+	// itself quantises (GpuHnswMap::Quantize(minQ, maxQ) + the device search over codes), but HnswIndexBase::Quantize() derives the range by
+	// sampling the reference's own graph storage (QuantizingParams over an HNSWView, quantization_params.h:48-63), which this adapter does
+	// not expose yet — so through the seam QuantizationAvailable() stays false and these are never reached; they fail loudly if called.
+	bool QuantizationAvailable() const noexcept { return false; }
 	void SaveIndex(hnswlib::IWriter&, const std::atomic_int32_t&) const { throw std::logic_error("GpuHnswMap: the ANN disk cache is not supported"); }
 	void LoadIndex(hnswlib::IReader&) { throw std::logic_error("GpuHnswMap: the ANN disk cache is not supported"); }
 	void Quantize(const hnswlib::QuantizationConfig&) { throw std::logic_error("GpuHnswMap: quantization is not supported"); }
