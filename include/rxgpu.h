@@ -138,6 +138,18 @@ int rxgpu_search_knn_subset(rxgpu_index* h, const float* queries, uint32_t nq, u
 int rxgpu_search_knn_bitmap(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, const uint32_t* allowed_words,
 							uint64_t n_words, float* out_dist, uint32_t* out_row, uint32_t* out_count, uint64_t* out_allowed);
 
+/* ---- IVF-Flat: faiss::IndexIVFFlat::search as IvfIndex drives it (ivf_index.cc:355-372) in ONE call ----------
+ * rxgpu_index_set_lists: the inverted lists over this index's rows as CSR — list_off [nlist + 1] (list_off[0] = 0), list_rows
+ *   [list_off[nlist]] internal rows (lists are disjoint); uploaded and kept until the next call.  Set them again after the rows change.
+ * rxgpu_search_knn_lists: `coarse` = a flat index of the nlist centroids (same metric family, same device).  The nprobe nearest centroids
+ *   are found on the device, their lists are marked in an allowed-rows bitmap, expanded to the ascending row list and scanned
+ *   (rxgpu_search_knn_subset's kernels) without a host round trip in between: same result as rxgpu_search_knn_subset over the union of
+ *   the probed lists.  query = host [dim], already prepared for the metric (cosine: normalised).  nprobe <= 64; *out_scanned (optional)
+ *   = rows in the probed lists.  Output as rxgpu_search_knn for nq = 1. */
+int rxgpu_index_set_lists(rxgpu_index* h, uint32_t nlist, const uint64_t* list_off, const uint32_t* list_rows);
+int rxgpu_search_knn_lists(rxgpu_index* h, rxgpu_index* coarse, const float* query, uint32_t nprobe, uint32_t kk, float* out_dist,
+						   uint32_t* out_row, uint32_t* out_count, uint64_t* out_scanned);
+
 /* Device-resident variant on `stream` (no synchronisation): d_row_ids = device [n_ids] uint32, 1 <= n_ids <= count,
  * kk in [1, 128]; d_out_count may be NULL.  The list is TRUSTED (strictly increasing, below count): an id beyond the
  * index would fault the device.  rxgpu_check_row_list_device() verifies a device list (synchronises `stream`). */

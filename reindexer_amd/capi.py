@@ -55,6 +55,8 @@ _SIGNATURES = {
     "rxgpu_search_knn_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_search_knn_subset": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "rxgpu_search_knn_bitmap": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "rxgpu_index_set_lists": (_i, [_vp, _u32, _vp, _vp]),
+    "rxgpu_search_knn_lists": (_i, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u64)]),
     "rxgpu_search_knn_subset_device": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _vp]),
     "rxgpu_check_row_list_device": (_i, [_vp, _vp, _u64, _vp, C.POINTER(C.c_int32)]),
     "rxgpu_search_range_subset": (_i, [_vp, _vp, _f, _i, _vp, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),

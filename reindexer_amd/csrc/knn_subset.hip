@@ -138,6 +138,23 @@ void launch_bitmap_expand(const uint32_t* words, uint64_t n_rows, const uint32_t
 	hipLaunchKernelGGL(bitmap_expand, dim3(tiles), dim3(kTileThreads), 0, s, words, nwords, n_rows, tile_scratch + tiles, out_rows, cap);
 }
 
+// IVF: the rows of the probed inverted lists marked in the allowed-rows bitmap (lists are disjoint: every bit is set once; the bitmap ->
+// row-list kernels above then produce the ascending list the subset scan wants).  One workgroup per probed list; the list numbers and
+// their count are on the device (the coarse search's output), nothing goes through the host.
+__global__ __launch_bounds__(256) void ivf_mark_lists(const uint32_t* probe, const uint32_t* probe_cnt, const uint64_t* list_off, const uint32_t* list_rows,
+													   uint32_t* bitmap) {
+	if (blockIdx.x >= *probe_cnt) return;
+	const uint32_t l = probe[blockIdx.x];
+	for (uint64_t i = list_off[l] + threadIdx.x, e = list_off[l + 1]; i < e; i += 256) {
+		const uint32_t r = list_rows[i];
+		atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+	}
+}
+void launch_ivf_mark_lists(const uint32_t* probe, const uint32_t* probe_cnt, uint32_t nprobe, const uint64_t* list_off, const uint32_t* list_rows,
+						   uint32_t* bitmap, hipStream_t s) {
+	hipLaunchKernelGGL(ivf_mark_lists, dim3(nprobe), dim3(256), 0, s, probe, probe_cnt, list_off, list_rows, bitmap);
+}
+
 void launch_gather_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s) {
 	hipLaunchKernelGGL(gather_u32, dim3((n + 255) / 256), dim3(256), 0, s, src, idx, n, out);
 }

@@ -75,6 +75,7 @@ void rxgpu_search_ctx::release() {
 	d_cand_dist.release();
 	d_cand_cnt.release();
 	d_visited.release();
+	d_ivf.release();
 	d_gcand_d.release();
 	d_gcand_i.release();
 	d_redo.release();
@@ -719,6 +720,8 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 	if (h->d_upper) (void)hipFree(h->d_upper);
 	if (h->d_deleted) (void)hipFree(h->d_deleted);
 	if (h->d_codes) (void)hipFree(h->d_codes);
+	if (h->d_list_off) (void)hipFree(h->d_list_off);
+	if (h->d_list_rows) (void)hipFree(h->d_list_rows);
 	if (h->d_corr) (void)hipFree(h->d_corr);
 	if (h->d_hnsw_stats) (void)hipFree(h->d_hnsw_stats);
 	delete h;
@@ -1078,6 +1081,98 @@ int rxgpu_search_knn_bitmap(rxgpu_index* h, const float* queries, uint32_t nq, u
 	}
 	RX_HIP(hipGetLastError());
 	return search_subset_host(h, c, queries, nq, kk, static_cast<const uint32_t*>(c->d_subset.ptr), total, out_dist, out_row, out_count);
+}
+
+int rxgpu_index_set_lists(rxgpu_index* h, uint32_t nlist, const uint64_t* list_off, const uint32_t* list_rows) {
+	RX_CHECK(h && list_off && nlist > 0, RXGPU_ERR_PARAMS, "rxgpu_index_set_lists: null argument");
+	if (h->shard_set) {
+		set_error("rxgpu_index_set_lists: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	RX_CHECK(list_off[0] == 0, RXGPU_ERR_PARAMS, "rxgpu_index_set_lists: offsets start at 0");
+	for (uint32_t l = 0; l < nlist; ++l) RX_CHECK(list_off[l] <= list_off[l + 1], RXGPU_ERR_PARAMS, "rxgpu_index_set_lists: offsets must not decrease");
+	const uint64_t total = list_off[nlist];
+	RX_CHECK(total <= h->count && (total == 0 || list_rows), RXGPU_ERR_PARAMS, "rxgpu_index_set_lists: more listed rows than the index holds");
+	for (uint64_t i = 0; i < total; ++i) RX_CHECK(list_rows[i] < h->count, RXGPU_ERR_PARAMS, "rxgpu_index_set_lists: row out of range");
+	DeviceGuard dg(h->device);
+	RX_HIP(hipDeviceSynchronize());
+	if (h->d_list_off) (void)hipFree(h->d_list_off);
+	if (h->d_list_rows) (void)hipFree(h->d_list_rows);
+	h->d_list_off = nullptr;
+	h->d_list_rows = nullptr;
+	h->nlist = 0;
+	RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_list_off), (size_t(nlist) + 1) * sizeof(uint64_t)));
+	RX_HIP(hipMemcpy(h->d_list_off, list_off, (size_t(nlist) + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+	if (total) {
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_list_rows), total * sizeof(uint32_t)));
+		RX_HIP(hipMemcpy(h->d_list_rows, list_rows, total * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
+	h->nlist = nlist;
+	h->lists_rows = total;
+	h->lists_count = h->count;
+	return RXGPU_OK;
+}
+
+int rxgpu_search_knn_lists(rxgpu_index* h, rxgpu_index* coarse, const float* query, uint32_t nprobe, uint32_t kk, float* out_dist,
+						   uint32_t* out_row, uint32_t* out_count, uint64_t* out_scanned) {
+	RX_CHECK(h && coarse && query && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_search_knn_lists: null argument");
+	if (h->shard_set || coarse->shard_set) {
+		set_error("rxgpu_search_knn_lists: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	RX_CHECK(h->nlist > 0 && h->lists_count == h->count, RXGPU_ERR_LOGIC, "rxgpu_search_knn_lists: inverted lists are not set / out of date");
+	RX_CHECK(coarse->count == h->nlist && coarse->dim == h->dim && coarse->device == h->device, RXGPU_ERR_PARAMS,
+			 "rxgpu_search_knn_lists: the coarse index must hold one centroid per list, same dimension, same device");
+	if (out_scanned) *out_scanned = 0;
+	*out_count = 0;
+	if (h->count == 0 || kk == 0) return RXGPU_OK;
+	nprobe = std::max<uint32_t>(1, std::min<uint32_t>(nprobe, h->nlist));
+	RX_CHECK(nprobe <= uint32_t(rxgpu::kMaxFusedK), RXGPU_ERR_PARAMS, "rxgpu_search_knn_lists: nprobe must be <= 64 (wider probes: rxgpu_search_knn_subset over the lists' union)");
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	// 1. the coarse quantiser: nprobe nearest centroids, result left on the device
+	const size_t qbytes = size_t(h->dim) * sizeof(float);
+	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, query, qbytes, hipMemcpyHostToDevice, c->stream));
+	const size_t o_lists = 0, o_dist = size_t(nprobe) * 4, o_cnt = o_dist + size_t(nprobe) * 4;
+	if (int rc = c->d_ivf.ensure(o_cnt + 256); rc) return rc;
+	char* ivf = static_cast<char*>(c->d_ivf.ptr);
+	if (int rc = rxgpu_search_knn_device(coarse, c->d_queries.ptr, 1, nprobe, ivf + o_dist, ivf + o_lists, ivf + o_cnt, c->stream); rc) return rc;
+	// 2. probed lists -> allowed-rows bitmap -> ascending row list, all on the device
+	const uint64_t need_words = (h->count + 31) / 32;
+	const uint32_t tiles = rxgpu::bitmap_tiles(h->count);
+	if (int rc = c->d_bitmap.ensure(need_words * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_tiles.ensure(size_t(2) * tiles * sizeof(uint32_t) + sizeof(unsigned long long)); rc) return rc;
+	uint32_t* tile_scratch = static_cast<uint32_t*>(c->d_tiles.ptr);
+	unsigned long long* d_total = reinterpret_cast<unsigned long long*>(tile_scratch + size_t(2) * tiles);
+	RX_HIP(hipMemsetAsync(c->d_bitmap.ptr, 0, need_words * sizeof(uint32_t), c->stream));
+	{
+		ProfileScope ps(h, "ivf_lists", c->stream);
+		rxgpu::launch_ivf_mark_lists(reinterpret_cast<const uint32_t*>(ivf + o_lists), reinterpret_cast<const uint32_t*>(ivf + o_cnt), nprobe, h->d_list_off,
+									 h->d_list_rows, static_cast<uint32_t*>(c->d_bitmap.ptr), c->stream);
+		rxgpu::launch_bitmap_count(static_cast<const uint32_t*>(c->d_bitmap.ptr), h->count, tile_scratch, d_total, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	unsigned long long total = 0;
+	RX_HIP(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	if (out_scanned) *out_scanned = total;
+	if (total == 0) return RXGPU_OK;
+	if (int rc = c->d_subset.ensure(total * sizeof(uint32_t)); rc) return rc;
+	{
+		ProfileScope ps(h, "ivf_lists", c->stream);
+		rxgpu::launch_bitmap_expand(static_cast<const uint32_t*>(c->d_bitmap.ptr), h->count, tile_scratch, static_cast<uint32_t*>(c->d_subset.ptr),
+									total, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	// 3. the list scan
+	return search_subset_host(h, c, query, 1, kk, static_cast<const uint32_t*>(c->d_subset.ptr), total, out_dist, out_row, out_count);
 }
 
 int rxgpu_search_knn_subset_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, const void* d_row_ids, uint64_t n_ids,

@@ -39,6 +39,8 @@ void launch_scan_subset(int metric, const ScanParams& p, const uint32_t* ids, ui
 uint32_t bitmap_tiles(uint64_t n_rows);
 void launch_bitmap_count(const uint32_t* words, uint64_t n_rows, uint32_t* tile_scratch, unsigned long long* total, hipStream_t s);
 void launch_bitmap_expand(const uint32_t* words, uint64_t n_rows, const uint32_t* tile_scratch, uint32_t* out_rows, uint64_t cap, hipStream_t s);
+void launch_ivf_mark_lists(const uint32_t* probe, const uint32_t* probe_cnt, uint32_t nprobe, const uint64_t* list_off, const uint32_t* list_rows,
+						   uint32_t* bitmap, hipStream_t s);
 void launch_gather_u32(const uint32_t* src, const uint32_t* idx, uint32_t n, uint32_t* out, hipStream_t s);
 void launch_check_row_list(const uint32_t* ids, uint64_t n, uint64_t limit, uint32_t* bad, int cus, hipStream_t s);
 
@@ -190,6 +192,7 @@ struct rxgpu_search_ctx {
 	rxgpu_devbuf d_qpad, d_qstats, d_dense, d_cand_row, d_cand_dist, d_cand_cnt;   // batched path
 	rxgpu_devbuf d_visited, d_gcand_d, d_gcand_i, d_redo;                          // HNSW
 	rxgpu_devbuf d_top;                                                            // bf16-pruned scan: approximate top lists
+	rxgpu_devbuf d_ivf;                                                            // IVF: the coarse search's lists, distances, count
 	rxgpu_devbuf d_subset, d_bitmap, d_tiles;                                      // pre-filtered search: row list, allowed-rows bitmap, tile sums
 	void* h_pinned = nullptr;
 	size_t h_pinned_bytes = 0;
@@ -245,6 +248,11 @@ struct rxgpu_index {
 	uint64_t* d_upper_off = nullptr;
 	uint32_t* d_upper = nullptr;
 	uint8_t* d_deleted = nullptr;
+	// IVF: inverted lists over this index's rows as CSR (rxgpu_index_set_lists)
+	uint64_t* d_list_off = nullptr;   // [nlist + 1]
+	uint32_t* d_list_rows = nullptr;  // [lists_rows]
+	uint32_t nlist = 0;
+	uint64_t lists_rows = 0, lists_count = 0;   // rows listed; the index row count the lists were built for
 	// SQ8 copy of the rows (rxgpu_hnsw_attach_sq8): codes [sq8_n][dim], stored corrective offsets, alpha^2
 	uint8_t* d_codes = nullptr;
 	float* d_corr = nullptr;

@@ -52,6 +52,7 @@ void GpuIvfFlat::Reset() {
 	centroids_.clear();
 	count_ = 0;
 	trained_ = false;
+	listsDirty_ = true;
 	if (rxgpu_index_truncate(dev_, 0) != RXGPU_OK) throwDevice("GpuIvfFlat::Reset");
 }
 
@@ -96,11 +97,13 @@ void GpuIvfFlat::assign(const float* xPrepared, size_t n, std::vector<uint32_t>&
 }
 
 void GpuIvfFlat::listInsert(uint32_t list, uint32_t row) {
+	listsDirty_ = true;
 	auto& l = lists_[list];
 	l.insert(std::lower_bound(l.begin(), l.end(), row), row);
 }
 
 void GpuIvfFlat::listErase(uint32_t list, uint32_t row) {
+	listsDirty_ = true;
 	auto& l = lists_[list];
 	const auto it = std::lower_bound(l.begin(), l.end(), row);
 	if (it == l.end() || *it != row) throw std::logic_error("GpuIvfFlat: inverted list out of sync");
@@ -232,6 +235,7 @@ void GpuIvfFlat::Train(int seed) {
 	}
 	uploadCentroids();
 	trained_ = true;
+	listsDirty_ = true;
 	// add_with_ids of everything that sat in the flat phase (ivf_index.cc:101-103)
 	for (auto& l : lists_) l.clear();
 	listOf_.assign(count_, 0u);
@@ -292,6 +296,7 @@ void GpuIvfFlat::AddWithIds(size_t n, const float* x, const idx_t* ids) {
 		for (size_t i = 0; i < n; ++i) {
 			listOf_[count_ + i] = a[i];
 			lists_[a[i]].push_back(uint32_t(count_ + i));
+			listsDirty_ = true;
 		}
 	}
 	count_ += n;
@@ -329,6 +334,17 @@ size_t GpuIvfFlat::RemoveIds(const idx_t* ids, size_t n) {
 	return removed;
 }
 
+void GpuIvfFlat::syncLists() const {
+	if (!listsDirty_) return;
+	std::vector<uint64_t> off(nlist_ + 1, 0);
+	for (size_t l = 0; l < nlist_; ++l) off[l + 1] = off[l] + lists_[l].size();
+	std::vector<uint32_t> rows;
+	rows.reserve(off[nlist_]);
+	for (const auto& l : lists_) rows.insert(rows.end(), l.begin(), l.end());
+	if (rxgpu_index_set_lists(dev_, uint32_t(nlist_), off.data(), rows.data()) != RXGPU_OK) throwDevice("GpuIvfFlat: list upload failed");
+	listsDirty_ = false;
+}
+
 void GpuIvfFlat::coarse(const float* q, size_t nprobe, std::vector<uint32_t>& lists) const {
 	const uint32_t np = uint32_t(std::min(std::max<size_t>(nprobe, 1), nlist_));
 	std::vector<float> dist(np);
@@ -363,15 +379,22 @@ void GpuIvfFlat::Search(const float* x, size_t k, size_t nprobe, float* distance
 	if (!trained_) {   // the flat phase: IndexFlat::search
 		if (rxgpu_search_knn(dev_, q.data(), 1, uint32_t(k), dist.data(), row.data(), &cnt) != RXGPU_OK) throwDevice("GpuIvfFlat::Search");
 	} else {
-		std::vector<uint32_t> probe;
-		coarse(q.data(), nprobe, probe);
-		std::vector<const std::vector<uint32_t>*> runs;
-		runs.reserve(probe.size());
-		for (uint32_t l : probe) runs.push_back(&lists_[l]);
-		const std::vector<uint32_t> rows = SortedUnion(runs, count_);
-		if (rows.empty()) return;
-		if (rxgpu_search_knn_subset(dev_, q.data(), 1, uint32_t(k), rows.data(), rows.size(), dist.data(), row.data(), &cnt) != RXGPU_OK) {
-			throwDevice("GpuIvfFlat::Search");
+		if (std::min(std::max<size_t>(nprobe, 1), nlist_) <= 64) {   // everything on the device: no list ids, no row list through the host
+			syncLists();
+			if (rxgpu_search_knn_lists(dev_, devCentroids_, q.data(), uint32_t(nprobe), uint32_t(k), dist.data(), row.data(), &cnt, nullptr) != RXGPU_OK) {
+				throwDevice("GpuIvfFlat::Search");
+			}
+		} else {
+			std::vector<uint32_t> probe;
+			coarse(q.data(), nprobe, probe);
+			std::vector<const std::vector<uint32_t>*> runs;
+			runs.reserve(probe.size());
+			for (uint32_t l : probe) runs.push_back(&lists_[l]);
+			const std::vector<uint32_t> rows = SortedUnion(runs, count_);
+			if (rows.empty()) return;
+			if (rxgpu_search_knn_subset(dev_, q.data(), 1, uint32_t(k), rows.data(), rows.size(), dist.data(), row.data(), &cnt) != RXGPU_OK) {
+				throwDevice("GpuIvfFlat::Search");
+			}
 		}
 	}
 	for (uint32_t i = 0; i < cnt; ++i) {

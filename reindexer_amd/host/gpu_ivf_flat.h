@@ -27,8 +27,9 @@
 //
 // MI355X mapping: both halves are the brute-force engine.  The coarse quantiser is a KNN over the nlist centroids (training assigns 256
 // points per call: the matrix-core batch path); the list scan is knn_scan_subset / knn_range_subset over the row list of the probed
-// inverted lists, so a query reads nprobe / nlist of the corpus.  Lists live on the host as sorted row numbers (next: CSR in HBM and the
-// concatenation on the device, which removes the second host round trip).
+// inverted lists, so a query reads nprobe / nlist of the corpus.  The lists are mirrored into HBM as CSR (rebuilt after a mutation) and a
+// search with nprobe <= 64 is ONE C-ABI call (rxgpu_search_knn_lists): coarse search, list union (bitmap), row list and scan all on the
+// device; the host copy of the lists serves mutations, range search and wider probes.
 #pragma once
 
 #include <cstdint>
@@ -110,6 +111,8 @@ private:
 	std::vector<std::vector<uint32_t>> lists_;      // per centroid: its rows, ascending
 	std::vector<float> centroids_;   // [nlist][dim]
 
+	void syncLists() const;                     // CSR mirror of lists_ in HBM (rxgpu_index_set_lists), rebuilt after a mutation
+	mutable bool listsDirty_ = true;
 	mutable rxgpu_index* dev_ = nullptr;        // the vectors
 	mutable rxgpu_index* devCentroids_ = nullptr;
 };
