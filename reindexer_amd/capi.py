@@ -301,6 +301,26 @@ class VectorIndex:
         return out
 
     # ---- HNSW
+    # ---- IVF: device-resident inverted lists
+    def set_lists(self, lists) -> None:
+        """lists: sequence of row arrays (disjoint) -> CSR in HBM (rxgpu_index_set_lists)."""
+        off = np.zeros(len(lists) + 1, np.uint64)
+        off[1:] = np.cumsum([len(l) for l in lists])
+        rows = np.ascontiguousarray(np.concatenate([np.asarray(l, np.uint32) for l in lists]) if len(lists) else np.empty(0, np.uint32), np.uint32)
+        _check(lib().rxgpu_index_set_lists(self._h, len(lists), off.ctypes.data, rows.ctypes.data if rows.size else None))
+
+    def search_knn_lists(self, coarse: "VectorIndex", query, nprobe: int, k: int):
+        """IndexIVFFlat::search in one call: (dist[k'], row[k'], rows scanned)."""
+        q = _f32c(query).reshape(self.dim)
+        dist = np.full(max(k, 1), np.inf, np.float32)
+        row = np.full(max(k, 1), 0xFFFFFFFF, np.uint32)
+        cnt = np.zeros(1, np.uint32)
+        scanned = _u64(0)
+        _check(lib().rxgpu_search_knn_lists(self._h, coarse._h, q.ctypes.data, nprobe, k, dist.ctypes.data, row.ctypes.data, cnt.ctypes.data,
+                                            C.byref(scanned)))
+        c = int(cnt[0])
+        return dist[:c], row[:c], int(scanned.value)
+
     def hnsw_attach_graph(self, g: dict) -> None:
         """g: flat graph dict (links0, upper_off, upper, deleted, M, maxM0, maxlevel, entry, num_deleted)."""
         links0 = np.ascontiguousarray(g["links0"], np.uint32)

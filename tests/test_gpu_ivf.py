@@ -176,3 +176,47 @@ def test_training_equals_vendored_faiss_bit_for_bit(hostapi, metric, n, d, nlist
         assert np.array_equal(gl, rl) and np.array_equal(bits(gd), bits(rd))
     g.close()
     ref.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_c_abi_list_search_equals_subset_search_over_the_probed_lists(rxgpu, oracle, metric):
+    """rxgpu_search_knn_lists (coarse search -> bitmap of the probed lists -> row list -> scan, one call) == rxgpu_search_knn_subset over the
+    union of the lists of the nprobe nearest centroids; error behaviour of the two entries."""
+    n, d, nlist = 6000, 40, 24
+    rng = np.random.default_rng(200 + metric)
+    rows = clustered(7, n, d, 30)
+    cents = clustered(8, nlist, d, 30)
+    owner = rng.integers(0, nlist, n)
+    lists = [np.flatnonzero(owner == l).astype(np.uint32) for l in range(nlist)]
+    lists[5] = np.empty(0, np.uint32)   # an empty list
+    kept = np.concatenate(lists)
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    cinv = oracle.l2_modules(cents) if metric == 2 else None
+    with rxgpu.VectorIndex(metric, d, n) as ix, rxgpu.VectorIndex(metric, d, nlist) as cx:
+        ix.upload_rows(0, rows, inv)
+        cx.upload_rows(0, cents, cinv)
+        with pytest.raises(rxgpu.RxGpuError):   # no lists yet
+            ix.search_knn_lists(cx, rows[0], 4, 10)
+        ix.set_lists(lists)
+        for qi in range(12):
+            q = clustered(300 + qi, 1, d, 30)[0]
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            for nprobe, k in ((1, 10), (4, 10), (7, 100), (24, 33), (64, 5)):
+                _, crow, ccnt = cx.search_knn(q, min(nprobe, nlist))
+                probed = crow[0, :int(ccnt[0])]
+                want_rows = np.sort(np.concatenate([lists[int(l)] for l in probed]))
+                gd, gr, scanned = ix.search_knn_lists(cx, q, nprobe, k)
+                assert scanned == want_rows.size
+                if want_rows.size == 0:
+                    assert gd.size == 0
+                    continue
+                wd, wr, wc = ix.search_knn_subset(q, k, want_rows)
+                c = int(wc[0])
+                assert np.array_equal(gr, wr[0, :c]) and np.array_equal(bits(gd), bits(wd[0, :c])), (metric, qi, nprobe, k)
+        # (nprobe is clamped to the number of lists first; the 64-list limit of the device entry only matters above that)
+        with pytest.raises(rxgpu.RxGpuError):   # a row that the index does not hold
+            ix.set_lists([np.array([n], np.uint32)])
+        ix.upload_rows(n - 1, rows[-1:], inv[-1:] if inv is not None else None)   # same count: lists stay valid
+        ix.search_knn_lists(cx, rows[0] if metric != 2 else oracle.normalize_copy(rows[0])[0], 2, 3)
+    assert kept.size <= n
