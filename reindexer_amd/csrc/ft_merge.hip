@@ -9,28 +9,31 @@
 //  * restricting bitmask and pre-score (buildRestrictingBitmask :326-384, calcTermScores :289-324): both are per-DOCUMENT facts (is the
 //    document in every AND term / in no NOT term; per term the FIRST sub-term holding it contributes its proc16, saturating sum over the
 //    terms).  Posting lists are sorted by document, so a workgroup that owns a RANGE of 8192 documents finds its segment of every list in
-//    a per-word range index and resolves everything in LDS — bit arrays for the masks, a 16-bit score per document, sub-terms in order
-//    behind workgroup barriers — without one global atomic  ->  ft_ranges.  (The first cut scattered postings into per-term arrays with
-//    device-scope atomics: 140 us for a 3 x 3 query; atomics on random addresses resolve past the per-XCD L2s at ~28 G/s.)
+//    a per-word range index, pulls the range's postings into registers in one round (256-posting blocks, every load independent) and
+//    resolves everything in LDS — bit arrays for the masks, a 16-bit score and a "scored in this term" byte per document, sub-terms in
+//    order behind workgroup barriers — without one global atomic  ->  ft_ranges.  (The first cut scattered postings into per-term arrays
+//    with device-scope atomics: 140 us for a 3 x 3 query; atomics on random addresses resolve past the per-XCD L2s at ~28 G/s.)
 //  * admission (addDoc until maxMergedDocs, merger.h:161-180): a document is added by its first posting (in global posting order) that is
 //    eligible and has a non-zero rank; it gets the next merge slot if fewer than maxMergedDocs documents were added before it, and once the
 //    limit is hit nothing is added any more.  Global posting order is (sub-term row, document) — every list ascends by document — so the
 //    slot of a document is  #documents first met in an earlier row  +  #documents first met in the same row with a smaller id.
 //    ft_rank_all ranks every eligible posting (calcTermRank) and drops the survivors (rank != 0; ~1 % after a preselect) into per-document-
 //    range buckets; ft_adders, one workgroup per range of 8192 documents, finds every document's first row (16-bit minimum in LDS) and
-//    counts them per (row, range); the last workgroup turns that small table into its exclusive prefix in row-major order = the slot bases.
+//    counts them per (row, range); the exclusive prefix of that small table in row-major order = the slot bases (summed by every workgroup
+//    of ft_finish for itself when the table is small, by ft_slot_bases otherwise).
 //    (The first cuts ran this posting-side: an atomicMin table over all documents plus three passes over ALL postings — count, ordered
 //    prefix, scatter — 45 us of a 128 us merge, each pass bound by its dependent gathers, not by bytes.)
 //  * per-document state (`proc -= rank; proc += finalRank` on every strict improvement, switchToNextWord between terms, termsCounter):
 //    a document meets at most one posting per sub-term and all its postings sit in ONE bucket, so ft_finish — again one workgroup per
-//    range — sorts the range's first postings by (row, document) in LDS, adds the slot bases, drops the range's survivors into a per-slot
-//    row indexed by sub-term and, behind a workgroup barrier, replays each of its documents in sub-term order with the reference's float
-//    operations  ->  same bits.
+//    range — ranks the range's first postings inside (row, range) (per-row bitmaps + popcount prefix up to 8 sub-terms, an LDS sort of
+//    (row, document) keys beyond), adds the slot bases, drops the range's survivors into a per-slot row indexed by sub-term and, behind a
+//    workgroup barrier, replays each of its documents in sub-term order with the reference's float operations  ->  same bits.
 //  * preselect ties at the threshold score are kept in document order: ordered prefix (ft_preselect_apply).
 //
-// Launch train of a multi-term query: ft_ranges, [ft_preselect_apply], ft_rank_all, ft_adders, ft_slot_bases, ft_finish; the 2-phase
+// Launch train of a multi-term query: ft_ranges, [ft_preselect_apply], ft_rank_all, ft_adders, [ft_slot_bases], ft_finish (+ ft_import in
+// front and ft_export behind: plan and result travel through one pinned staging buffer by copy kernels); the 2-phase
 // gate's popcount test is evaluated ON THE DEVICE (no host round trip), the result leaves in one packed buffer.  A Simple() query:
-// ft_ranges (mask only), ft_rank_all, ft_adders, ft_slot_bases, ft_finish.  No fill kernel: the tables a merge reads before it writes (histogram,
+// ft_ranges (mask only), ft_rank_all, ft_adders, [ft_slot_bases], ft_finish.  No fill kernel: the tables a merge reads before it writes (histogram,
 // entry-row occupancy, bucket counters, look-back and synchronisation words) are handed back ZEROED by the kernel that read them last.
 //
 // Bound: HBM gathers: per posting 4 B doc + 8 B entry offsets + 9 B per (field, tf, firstPos) entry streamed, 4 B

@@ -77,7 +77,6 @@ void rxgpu_search_ctx::release() {
 	d_visited.release();
 	d_ivf.release();
 	d_gcand_d.release();
-	d_gcand_i.release();
 	d_redo.release();
 	d_top.release();
 	d_subset.release();

@@ -164,8 +164,7 @@ struct FtPlan {
 	uint16_t* out_terms_counter;
 	uint8_t* out_field;
 };
-enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPick = 2 /* +1 */, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6,
-				  kFtSyncPreselected = 7, kFtSyncDoneAdders = 8, kFtSyncDoneFinish = 9, kFtSyncWords = 16 };
+enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6, kFtSyncDoneFinish = 9, kFtSyncWords = 16 };
 constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
@@ -191,7 +190,7 @@ struct rxgpu_search_ctx {
 	bool own_stream = false;
 	rxgpu_devbuf d_queries, d_part_dist, d_part_row, d_out_dist, d_out_row, d_out_count, d_misc, d_select;
 	rxgpu_devbuf d_qpad, d_qstats, d_dense, d_cand_row, d_cand_dist, d_cand_cnt;   // batched path
-	rxgpu_devbuf d_visited, d_gcand_d, d_gcand_i, d_redo;                          // HNSW
+	rxgpu_devbuf d_visited, d_gcand_d, d_redo;                                     // HNSW (d_gcand_d: (dist bits, id) entries)
 	rxgpu_devbuf d_top;                                                            // bf16-pruned scan: approximate top lists
 	rxgpu_devbuf d_ivf;                                                            // IVF: the coarse search's lists, distances, count
 	rxgpu_devbuf d_subset, d_bitmap, d_tiles;                                      // pre-filtered search: row list, allowed-rows bitmap, tile sums
