@@ -985,8 +985,7 @@ __device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uin
 
 // One merged document: its row of the entry table replayed in sub-term order = the order mergeTerm / mergeSimple met its postings.
 constexpr uint32_t kFtReplayRows = 128;   // sub-term descriptors staged in LDS (queries with more merged sub-terms read the plan from HBM)
-__device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint32_t doc, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
-											  const uint16_t* s_qp) {
+struct FtReplayState {
 	bool created = false;
 	float proc = 0.f, rank = 0.f;
 	uint8_t field = 0;
@@ -994,6 +993,104 @@ __device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint
 	const uint64_t* next_ptr = nullptr;
 	uint32_t last_cnt = 0, next_cnt = 0;
 	uint16_t switched_term = 0, last_counted = 0, terms_counter = 0;
+};
+// one posting of the document, met in sub-term order: (rank r, field fld, posting index i) of sub-term row `row`
+// the positions of posting i of sub-term row `row`, and the query position of its term
+__device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, uint32_t i, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
+												 const uint16_t* s_qp, uint16_t& qp, const uint64_t*& pos, uint32_t& npos) {
+	const uint64_t* fpos;
+	const uint32_t* pos_off;
+	if (row < kFtReplayRows) {
+		fpos = s_fpos[row];
+		pos_off = s_pos_off[row];
+		qp = s_qp[row];
+	} else {
+		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
+		fpos = s.fpos;
+		pos_off = s.pos_off;
+		qp = s.qp;
+	}
+	const uint32_t po0 = pos_off[i], po1 = pos_off[i + 1];
+	pos = fpos + po0;
+	npos = po1 - po0;
+}
+// one posting of the document, met in sub-term order: rank r in field fld, positions [pos, pos + npos) (not read for a simple merge)
+__device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayState& st, float r, uint8_t fld, uint16_t qp, const uint64_t* pos, uint32_t npos) {
+	if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
+		if (!st.created) {
+			st.created = true;
+			st.proc = r;
+			st.field = fld;
+		} else if (st.proc < r) {
+			st.proc = r;
+			st.field = fld;
+		}
+		return;
+	}
+	if (!st.created) {   // addDoc (mergerimpl.h:160-164)
+		st.created = true;
+		st.proc = r;
+		st.field = fld;
+		st.rank = r;
+		st.next_ptr = pos;
+		st.next_cnt = npos;
+		st.switched_term = qp;
+		st.last_counted = qp;
+		st.terms_counter = 1;
+		return;
+	}
+	// ---- document already merged: mergerimpl.h:165-189
+	if (st.switched_term < qp) {   // switchToNextWord (merger.h:218-226) ran before every term since: idempotent after the first time
+		if (st.next_cnt) {
+			st.last_ptr = st.next_ptr;
+			st.last_cnt = st.next_cnt;
+			st.next_cnt = 0;
+			st.rank = 0.f;
+		}
+		st.switched_term = qp;
+	}
+	if (st.last_counted < qp) {   // InreaseTermsCounter
+		st.terms_counter = uint16_t(st.terms_counter + 1);
+		st.last_counted = qp;
+	}
+	unsigned dist = ft_positions_distance(st.last_ptr, st.last_cnt, pos, npos);
+	dist = dist > 1u ? dist : 1u;
+	const float norm_dist = ft_bound(float(1.0 / double(float(dist))), p.distance_weight, p.distance_boost);
+	const float final_rank = norm_dist * r;
+	if (final_rank > st.rank) {
+		st.proc -= st.rank;
+		st.proc += final_rank;
+		st.next_ptr = pos;
+		st.next_cnt = npos;
+		st.rank = final_rank;
+	}
+}
+__device__ __forceinline__ void ft_replay_step(const FtPlan& p, FtReplayState& st, uint32_t row, float r, uint8_t fld, uint32_t i, const uint64_t* const* s_fpos,
+											   const uint32_t* const* s_pos_off, const uint16_t* s_qp) {
+	uint16_t qp = 0;
+	const uint64_t* pos = nullptr;
+	uint32_t npos = 0;
+	if (!p.simple) ft_replay_locate(p, row, i, s_fpos, s_pos_off, s_qp, qp, pos, npos);
+	ft_replay_apply(p, st, r, fld, qp, pos, npos);
+}
+// addFullMatchBoost (merger.h:100-109): a document whose best field holds exactly as many words as the query has parts — and, for a
+// multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts
+// are resident: on the host it was one cache miss per merged document.
+__device__ __forceinline__ void ft_replay_finish(const FtPlan& p, const FtReplayState& st, uint32_t sl, uint32_t doc, bool have_words = false,
+												 float words0 = 0.f) {
+	float proc = st.proc;
+	const FtTermCfg& t0 = p.terms[0];
+	const float words = have_words ? words0 : t0.words[size_t(doc) * t0.num_fields + st.field];
+	const bool full = p.simple ? words == 1.0f : (st.terms_counter == p.nterms && words == float(p.nterms));
+	if (full) proc = float(double(proc) * p.full_match_boost);
+	p.out_proc[sl] = proc;
+	p.out_field[sl] = st.field;
+	p.out_terms_counter[sl] = st.terms_counter;
+}
+// the document's row of the entry table, walked in sub-term order
+__device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint32_t doc, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
+											  const uint16_t* s_qp) {
+	FtReplayState st;
 	// Most documents meet ONE sub-term, a few two or three, out of many: each lane first collects WHICH of its rows are occupied (rank
 	// loads, 64 rows per mask word) and then walks only those, in row order = the order mergeTerm met the postings.
 	for (uint32_t row0 = 0; row0 < p.n_rows; row0 += 64) {
@@ -1010,93 +1107,18 @@ __device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint
 			const uint32_t row = row0 + uint32_t(__ffsll((long long)occupied) - 1);
 			occupied &= occupied - 1;
 			const uint64_t cell = uint64_t(row) * p.max_merged + sl;
-			const float r = p.e_rank[cell];
-			const uint8_t fld = p.e_field[cell];
-			if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
-				if (!created) {
-					created = true;
-					proc = r;
-					field = fld;
-				} else if (proc < r) {
-					proc = r;
-					field = fld;
-				}
-				continue;
-			}
-			const uint32_t i = p.e_idx[cell];
-			const uint64_t* fpos;
-			const uint32_t* pos_off;
-			uint16_t qp;
-			if (row < kFtReplayRows) {
-				fpos = s_fpos[row];
-				pos_off = s_pos_off[row];
-				qp = s_qp[row];
-			} else {
-				const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
-				fpos = s.fpos;
-				pos_off = s.pos_off;
-				qp = s.qp;
-			}
-			const uint32_t po0 = pos_off[i], po1 = pos_off[i + 1];
-			const uint64_t* pos = fpos + po0;
-			const uint32_t npos = po1 - po0;
-			if (!created) {   // addDoc (mergerimpl.h:160-164)
-				created = true;
-				proc = r;
-				field = fld;
-				rank = r;
-				next_ptr = pos;
-				next_cnt = npos;
-				switched_term = qp;
-				last_counted = qp;
-				terms_counter = 1;
-				continue;
-			}
-			// ---- document already merged: mergerimpl.h:165-189
-			if (switched_term < qp) {   // switchToNextWord (merger.h:218-226) ran before every term since: idempotent after the first time
-				if (next_cnt) {
-					last_ptr = next_ptr;
-					last_cnt = next_cnt;
-					next_cnt = 0;
-					rank = 0.f;
-				}
-				switched_term = qp;
-			}
-			if (last_counted < qp) {   // InreaseTermsCounter
-				terms_counter = uint16_t(terms_counter + 1);
-				last_counted = qp;
-			}
-			unsigned dist = ft_positions_distance(last_ptr, last_cnt, pos, npos);
-			dist = dist > 1u ? dist : 1u;
-			const float norm_dist = ft_bound(float(1.0 / double(float(dist))), p.distance_weight, p.distance_boost);
-			const float final_rank = norm_dist * r;
-			if (final_rank > rank) {
-				proc -= rank;
-				proc += final_rank;
-				next_ptr = pos;
-				next_cnt = npos;
-				rank = final_rank;
-			}
+			ft_replay_step(p, st, row, p.e_rank[cell], p.e_field[cell], p.simple ? 0u : p.e_idx[cell], s_fpos, s_pos_off, s_qp);
 		}
 	}
-	// addFullMatchBoost (merger.h:100-109): a document whose best field holds exactly as many words as the query has parts — and, for a
-	// multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts
-	// are resident: on the host it was one cache miss per merged document.
-	{
-		const FtTermCfg& t0 = p.terms[0];
-		const float words = t0.words[size_t(doc) * t0.num_fields + field];
-		const bool full = p.simple ? words == 1.0f : (terms_counter == p.nterms && words == float(p.nterms));
-		if (full) proc = float(double(proc) * p.full_match_boost);
-	}
-	p.out_proc[sl] = proc;
-	p.out_field[sl] = field;
-	p.out_terms_counter[sl] = terms_counter;
+	ft_replay_finish(p, st, sl, doc);
 }
 
 // The merge slot of the first document of (row, range) = the entries of ft_adders' table in front of it, in row-major order.  Up to
 // kFtFinishRows merged sub-terms (and 8192 entries) the table is small and every workgroup of ft_finish adds up its own bases (one pass, all
 // rows at once); larger queries run ft_slot_bases, which turns the table into its prefix.
 constexpr uint32_t kFtFinishRows = 16;
+constexpr uint32_t kFtSparseRecords = 768;   // buckets up to this size are replayed from an LDS copy of their records
+constexpr uint32_t kFtSparsePostings = 6;   // ... if no document of theirs has more postings than this
 constexpr uint32_t kFtBitmapRows = 8;   // up to this many merged sub-terms ft_finish ranks the first postings with per-row bitmaps instead of a sort
 __host__ __device__ inline bool ft_own_bases(const FtPlan& p) { return p.n_rows <= kFtFinishRows && uint64_t(p.n_rows) * p.n_ranges <= kFtRangeDocs; }
 
@@ -1301,6 +1323,97 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			__syncthreads();
 		}
 		auto slot_of = [&](uint32_t dl) -> uint32_t { return few_rows ? ft_finish_lds[dl] : s_keys[lds_get_u16(s_tab, dl)]; };
+		// ---- a sparse bucket (the usual one after a preselect: a few hundred records): the records go into LDS and the thread of every
+		// first posting collects its document's other postings from there — no entry rows in global memory, i.e. no scatter, no gather
+		// chain in front of the position loads, nothing to hand back zeroed.  A document with more than kFtSparsePostings postings
+		// sends the whole range down the general path.
+		bool sparse = nw <= kFtSparseRecords;
+		if (sparse) {
+			// behind the slots of the bitmap layout; in the sorted layout the list of slots is no longer than the bucket, i.e. ends in front
+			uint4* s_rec = reinterpret_cast<uint4*>(ft_finish_lds + kFtRangeDocs);   // [kFtSparseRecords]; .x = document in the range | next record << 13
+			uint32_t* s_head = ft_finish_lds + kFtRangeDocs + kFtSparseRecords * 4;   // [kHeads] first record of the documents with these low bits
+			constexpr uint32_t kHeads = 512, kNil = 1023;
+			uint16_t* s_todo = reinterpret_cast<uint16_t*>(s_head + kHeads);   // [kFtSparseRecords] the first postings of the documents to replay
+			static_assert(kFtSparseRecords <= kNil && kFtSparseRecords * 4 + kHeads + kFtSparseRecords / 2 <= kFtRangeDocs / 2, "LDS layout of the sparse replay");
+			for (uint32_t w = tid; w < kHeads; w += 256) s_head[w] = kNil;
+			if (tid == 0) s_nadd = 0;
+			__syncthreads();
+			for (uint32_t e = tid; e < nw; e += 256) {   // the documents' records chained through the copy; one thread per document to replay
+				uint4 r = rec[e];
+				const uint32_t dl = r.x & (kFtRangeDocs - 1);
+				r.x = dl | (atomicExch(&s_head[dl & (kHeads - 1)], e) << kFtRangeShift);
+				s_rec[e] = r;
+				if ((r.w >> 31) && slot_of(dl) < p.max_merged) s_todo[atomicAdd(&s_nadd, 1u)] = uint16_t(e);
+			}
+			__syncthreads();
+			FT_STAMP(p, 38);
+			const uint32_t todo = s_nadd;
+			const FtTermCfg& t0 = p.terms[0];
+			const bool one_field = t0.num_fields == 1;
+			int over = 0;
+			for (uint32_t q = tid; q < todo; q += 256) {
+				const uint32_t dl = s_rec[s_todo[q]].x & (kFtRangeDocs - 1);
+				float words0 = 0.f;
+				if (one_field) words0 = t0.words[d_begin + dl];   // in flight during the walk
+				// the document's postings: keys (sub-term row, record) collected along the chain, ordered by a sorting network
+				uint32_t key[kFtSparsePostings];
+#pragma unroll
+				for (uint32_t k = 0; k < kFtSparsePostings; ++k) key[k] = 0xFFFFFFFFu;
+				uint32_t cnt = 0;
+				for (uint32_t j = s_head[dl & (kHeads - 1)]; j != kNil;) {
+					const uint4 o = s_rec[j];
+					if ((o.x & (kFtRangeDocs - 1)) == dl) {
+						const uint32_t v = ((o.w & 0xFFFFu) << 16) | j;
+#pragma unroll
+						for (uint32_t k = 0; k < kFtSparsePostings; ++k) key[k] = cnt == k ? v : key[k];
+						++cnt;
+					}
+					j = o.x >> kFtRangeShift;
+				}
+				if (cnt > kFtSparsePostings) {
+					over = 1;
+					continue;
+				}
+#define RX_CSWAP(a, b)                                \
+	{                                                 \
+		const uint32_t lo = key[a] < key[b] ? key[a] : key[b]; \
+		const uint32_t hi = key[a] < key[b] ? key[b] : key[a]; \
+		key[a] = lo;                                  \
+		key[b] = hi;                                  \
+	}
+				static_assert(kFtSparsePostings == 6, "the network below orders six keys");
+				RX_CSWAP(0, 5) RX_CSWAP(1, 3) RX_CSWAP(2, 4) RX_CSWAP(1, 2) RX_CSWAP(3, 4) RX_CSWAP(0, 3) RX_CSWAP(2, 5) RX_CSWAP(0, 1) RX_CSWAP(2, 3)
+				RX_CSWAP(4, 5) RX_CSWAP(1, 2) RX_CSWAP(3, 4)
+#undef RX_CSWAP
+				// everything the walk will read is requested first: the position ranges of all the postings are in flight together
+				float pr[kFtSparsePostings];
+				uint8_t pf[kFtSparsePostings];
+				uint16_t pq[kFtSparsePostings];
+				const uint64_t* pp[kFtSparsePostings];
+				uint32_t pn[kFtSparsePostings];
+#pragma unroll
+				for (uint32_t k = 0; k < kFtSparsePostings; ++k) {   // in sub-term order = the order mergeTerm met the postings
+					pr[k] = 0.f;
+					pf[k] = 0;
+					pq[k] = 0;
+					pp[k] = nullptr;
+					pn[k] = 0;
+					if (k >= cnt) continue;
+					const uint4 o = s_rec[key[k] & 0xFFFFu];
+					pr[k] = __uint_as_float(o.z);
+					pf[k] = uint8_t((o.w >> 16) & 0xFFu);
+					if (!p.simple) ft_replay_locate(p, key[k] >> 16, o.y, s_fpos, s_pos_off, s_qp, pq[k], pp[k], pn[k]);
+				}
+				FtReplayState st;
+#pragma unroll
+				for (uint32_t k = 0; k < kFtSparsePostings; ++k) {
+					if (k < cnt) ft_replay_apply(p, st, pr[k], pf[k], pq[k], pp[k], pn[k]);
+				}
+				ft_replay_finish(p, st, slot_of(dl), d_begin + dl, one_field, words0);
+			}
+			sparse = !__syncthreads_or(over);   // a document with more postings than the network orders: the general path redoes the range
+		}
+		if (!sparse) {
 		FT_STAMP(p, 38);
 		for (uint32_t e = tid; e < nw; e += 256) {   // every posting of a merged document into the document's row, column = its sub-term
 			const uint4 r = rec[e];
@@ -1324,6 +1437,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			const uint4 r = rec[e];
 			const uint32_t sl = slot_of(r.x & (kFtRangeDocs - 1));
 			if (sl < p.max_merged) p.e_rank[uint64_t(r.w & 0xFFFFu) * p.max_merged + sl] = 0.0f;
+		}
 		}
 	}
 	// ---- leave the shared tables clean for the next merge; the last workgroup writes the result header

@@ -87,6 +87,25 @@ def test_gpu_multi_term_wide_queries(hostapi, ft, limit, ops, nsub):
     _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, variants=((1.0, 0.5),))
 
 
+@pytest.mark.parametrize("limit,ops,nsub,total,sizes", [
+    (20000, (1, 1, 1), (1, 4), 20_000, (40, 120)),      # a few hundred records per document range, 1-3 postings per document
+    (20000, (2, 1, 1), (2, 4), 20_000, (60, 200)),
+    (60, (1, 1, 1), (2, 4), 20_000, (100, 250)),        # ... and the mergeLimit cut inside the sparse ranges
+    (20000, (1, 1, 1), (6, 8), 600, (15, 40)),          # up to ~6 postings per document, still ordered in registers
+    (20000, (1, 1, 2, 1), (9, 11), 200, (10, 20)),      # ~40 sub-terms over 200 documents: documents with more postings than the
+    (20000, (1, 1, 1), (12, 14), 150, (8, 16)),         # sparse replay orders in registers => the range falls back to the entry rows
+    (30, (1, 1, 1), (12, 14), 150, (8, 16)),
+])
+def test_gpu_multi_term_sparse_ranges(hostapi, ft, limit, ops, nsub, total, sizes):
+    """Document ranges with no more than a few hundred surviving records take ft_finish's sparse replay (records chained per document in
+    LDS, one thread per merged document); a document with more postings than its sorting network holds sends the range down the general
+    path.  Both must give the merger's result."""
+    nf = 2
+    _, words, avg, removed, excluded, terms, store = _multi_case(3000 + limit + total + len(ops), nf, total, limit, ops, False, None, sizes=sizes,
+                                                                 nsub_range=nsub)
+    _check(hostapi, ft, nf, total, limit, words, avg, removed, excluded, terms, store, variants=((1.0, 0.5), (1.7, 0.8)))
+
+
 def test_gpu_one_merger_many_query_shapes(hostapi, ft):
     """The tables a merge finds zeroed and hands back zeroed (histogram copies, bucket counters, entry-row occupancy, sync words) live
     across merges: ONE merger instance runs wide, narrow, simple, AND-only, preselected and cut queries in turn — different numbers of
