@@ -933,9 +933,30 @@ __global__ __launch_bounds__(256) void ft_slot_bases(FtPlan p) {
 }
 
 // mergerimpl.h:20-37; fullPos()/fullField() truncate the 64-bit PosType to uint32_t exactly like the reference's accessors
-__device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb) {
+__device__ __forceinline__ unsigned ft_positions_distance_regs(const uint64_t (&ra)[4], uint32_t na, const uint64_t (&rb)[4], uint32_t nb) {
 	unsigned res = 0xFFFFFFFFu;
 	uint32_t i = 0, j = 0;
+	while (i < na && j < nb) {
+		const uint64_t pa = i == 0 ? ra[0] : i == 1 ? ra[1] : i == 2 ? ra[2] : ra[3];
+		const uint64_t pb = j == 0 ? rb[0] : j == 1 ? rb[1] : j == 2 ? rb[2] : rb[3];
+		const uint32_t fa = uint32_t(pa), fb = uint32_t(pb);
+		const bool sign = fa > fb;
+		if (uint32_t(pa >> 28) == uint32_t(pb >> 28)) {
+			const unsigned dst = sign ? fa - fb : fb - fa;
+			if (dst < res) {
+				res = dst;
+				if (res <= 1) break;
+			}
+		}
+		if (sign) {
+			++j;
+		} else {
+			++i;
+		}
+	}
+	return res == 0xFFFFFFFFu ? 0 : res;
+}
+__device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uint32_t na, const uint64_t* b, uint32_t nb) {
 	if (na <= 4 && nb <= 4) {   // the usual case: both lists fetched at once (eight independent loads), the walk runs on registers
 		uint64_t ra[4], rb[4];
 #pragma unroll
@@ -943,26 +964,10 @@ __device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uin
 			ra[k] = k < na ? a[k] : 0ull;
 			rb[k] = k < nb ? b[k] : 0ull;
 		}
-		while (i < na && j < nb) {
-			const uint64_t pa = i == 0 ? ra[0] : i == 1 ? ra[1] : i == 2 ? ra[2] : ra[3];
-			const uint64_t pb = j == 0 ? rb[0] : j == 1 ? rb[1] : j == 2 ? rb[2] : rb[3];
-			const uint32_t fa = uint32_t(pa), fb = uint32_t(pb);
-			const bool sign = fa > fb;
-			if (uint32_t(pa >> 28) == uint32_t(pb >> 28)) {
-				const unsigned dst = sign ? fa - fb : fb - fa;
-				if (dst < res) {
-					res = dst;
-					if (res <= 1) break;
-				}
-			}
-			if (sign) {
-				++j;
-			} else {
-				++i;
-			}
-		}
-		return res == 0xFFFFFFFFu ? 0 : res;
+		return ft_positions_distance_regs(ra, na, rb, nb);
 	}
+	unsigned res = 0xFFFFFFFFu;
+	uint32_t i = 0, j = 0;
 	while (i < na && j < nb) {
 		const uint64_t pa = a[i], pb = b[j];
 		const uint32_t fa = uint32_t(pa), fb = uint32_t(pb);
@@ -985,15 +990,25 @@ __device__ __forceinline__ unsigned ft_positions_distance(const uint64_t* a, uin
 
 // One merged document: its row of the entry table replayed in sub-term order = the order mergeTerm / mergeSimple met its postings.
 constexpr uint32_t kFtReplayRows = 128;   // sub-term descriptors staged in LDS (queries with more merged sub-terms read the plan from HBM)
-struct FtReplayState {
+struct FtPosList {   // a posting's positions where the index keeps them
+	const uint64_t* ptr = nullptr;
+	uint32_t n = 0;
+};
+struct FtPosRegs {   // ... fetched ahead (n <= 4)
+	uint64_t v[4] = {0, 0, 0, 0};
+	uint32_t n = 0;
+};
+__device__ __forceinline__ unsigned ft_positions_distance(const FtPosList& a, const FtPosList& b) { return ft_positions_distance(a.ptr, a.n, b.ptr, b.n); }
+__device__ __forceinline__ unsigned ft_positions_distance(const FtPosRegs& a, const FtPosRegs& b) { return ft_positions_distance_regs(a.v, a.n, b.v, b.n); }
+template <typename Pos>
+struct FtReplayStateT {
 	bool created = false;
 	float proc = 0.f, rank = 0.f;
 	uint8_t field = 0;
-	const uint64_t* last_ptr = nullptr;
-	const uint64_t* next_ptr = nullptr;
-	uint32_t last_cnt = 0, next_cnt = 0;
+	Pos last, next;
 	uint16_t switched_term = 0, last_counted = 0, terms_counter = 0;
 };
+using FtReplayState = FtReplayStateT<FtPosList>;
 // one posting of the document, met in sub-term order: (rank r, field fld, posting index i) of sub-term row `row`
 // the positions of posting i of sub-term row `row`, and the query position of its term
 __device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, uint32_t i, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
@@ -1014,8 +1029,9 @@ __device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, 
 	pos = fpos + po0;
 	npos = po1 - po0;
 }
-// one posting of the document, met in sub-term order: rank r in field fld, positions [pos, pos + npos) (not read for a simple merge)
-__device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayState& st, float r, uint8_t fld, uint16_t qp, const uint64_t* pos, uint32_t npos) {
+// one posting of the document, met in sub-term order: rank r in field fld, positions `pos` (not read for a simple merge)
+template <typename Pos>
+__device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<Pos>& st, float r, uint8_t fld, uint16_t qp, const Pos& pos) {
 	if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
 		if (!st.created) {
 			st.created = true;
@@ -1032,8 +1048,7 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayState& 
 		st.proc = r;
 		st.field = fld;
 		st.rank = r;
-		st.next_ptr = pos;
-		st.next_cnt = npos;
+		st.next = pos;
 		st.switched_term = qp;
 		st.last_counted = qp;
 		st.terms_counter = 1;
@@ -1041,10 +1056,9 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayState& 
 	}
 	// ---- document already merged: mergerimpl.h:165-189
 	if (st.switched_term < qp) {   // switchToNextWord (merger.h:218-226) ran before every term since: idempotent after the first time
-		if (st.next_cnt) {
-			st.last_ptr = st.next_ptr;
-			st.last_cnt = st.next_cnt;
-			st.next_cnt = 0;
+		if (st.next.n) {
+			st.last = st.next;
+			st.next.n = 0;
 			st.rank = 0.f;
 		}
 		st.switched_term = qp;
@@ -1053,30 +1067,29 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayState& 
 		st.terms_counter = uint16_t(st.terms_counter + 1);
 		st.last_counted = qp;
 	}
-	unsigned dist = ft_positions_distance(st.last_ptr, st.last_cnt, pos, npos);
+	unsigned dist = ft_positions_distance(st.last, pos);
 	dist = dist > 1u ? dist : 1u;
 	const float norm_dist = ft_bound(float(1.0 / double(float(dist))), p.distance_weight, p.distance_boost);
 	const float final_rank = norm_dist * r;
 	if (final_rank > st.rank) {
 		st.proc -= st.rank;
 		st.proc += final_rank;
-		st.next_ptr = pos;
-		st.next_cnt = npos;
+		st.next = pos;
 		st.rank = final_rank;
 	}
 }
 __device__ __forceinline__ void ft_replay_step(const FtPlan& p, FtReplayState& st, uint32_t row, float r, uint8_t fld, uint32_t i, const uint64_t* const* s_fpos,
 											   const uint32_t* const* s_pos_off, const uint16_t* s_qp) {
 	uint16_t qp = 0;
-	const uint64_t* pos = nullptr;
-	uint32_t npos = 0;
-	if (!p.simple) ft_replay_locate(p, row, i, s_fpos, s_pos_off, s_qp, qp, pos, npos);
-	ft_replay_apply(p, st, r, fld, qp, pos, npos);
+	FtPosList pos;
+	if (!p.simple) ft_replay_locate(p, row, i, s_fpos, s_pos_off, s_qp, qp, pos.ptr, pos.n);
+	ft_replay_apply(p, st, r, fld, qp, pos);
 }
 // addFullMatchBoost (merger.h:100-109): a document whose best field holds exactly as many words as the query has parts — and, for a
 // multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts
 // are resident: on the host it was one cache miss per merged document.
-__device__ __forceinline__ void ft_replay_finish(const FtPlan& p, const FtReplayState& st, uint32_t sl, uint32_t doc, bool have_words = false,
+template <typename Pos>
+__device__ __forceinline__ void ft_replay_finish(const FtPlan& p, const FtReplayStateT<Pos>& st, uint32_t sl, uint32_t doc, bool have_words = false,
 												 float words0 = 0.f) {
 	float proc = st.proc;
 	const FtTermCfg& t0 = p.terms[0];
@@ -1404,12 +1417,36 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 					pf[k] = uint8_t((o.w >> 16) & 0xFFu);
 					if (!p.simple) ft_replay_locate(p, key[k] >> 16, o.y, s_fpos, s_pos_off, s_qp, pq[k], pp[k], pn[k]);
 				}
-				FtReplayState st;
+				uint32_t longest = 0;
 #pragma unroll
-				for (uint32_t k = 0; k < kFtSparsePostings; ++k) {
-					if (k < cnt) ft_replay_apply(p, st, pr[k], pf[k], pq[k], pp[k], pn[k]);
+				for (uint32_t k = 0; k < kFtSparsePostings; ++k) longest = pn[k] > longest ? pn[k] : longest;
+				if (cnt > 1 && longest <= 4) {
+					// ... and so are the positions (up to four per posting, the usual case): the walk, which compares the lists of two
+					// consecutive terms at a time, then runs on registers instead of paying one memory round trip per posting
+					FtPosRegs lists[kFtSparsePostings];
+#pragma unroll
+					for (uint32_t k = 0; k < kFtSparsePostings; ++k) {
+						lists[k].n = pn[k];
+#pragma unroll
+						for (uint32_t i = 0; i < 4; ++i) lists[k].v[i] = i < pn[k] ? pp[k][i] : 0ull;
+					}
+					FtReplayStateT<FtPosRegs> st;
+#pragma unroll
+					for (uint32_t k = 0; k < kFtSparsePostings; ++k) {
+						if (k < cnt) ft_replay_apply(p, st, pr[k], pf[k], pq[k], lists[k]);
+					}
+					ft_replay_finish(p, st, slot_of(dl), d_begin + dl, one_field, words0);
+				} else {
+					FtReplayState st;
+#pragma unroll
+					for (uint32_t k = 0; k < kFtSparsePostings; ++k) {
+						FtPosList pos;
+						pos.ptr = pp[k];
+						pos.n = pn[k];
+						if (k < cnt) ft_replay_apply(p, st, pr[k], pf[k], pq[k], pos);
+					}
+					ft_replay_finish(p, st, slot_of(dl), d_begin + dl, one_field, words0);
 				}
-				ft_replay_finish(p, st, slot_of(dl), d_begin + dl, one_field, words0);
 			}
 			sparse = !__syncthreads_or(over);   // a document with more postings than the network orders: the general path redoes the range
 		}
