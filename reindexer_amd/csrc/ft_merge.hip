@@ -307,6 +307,14 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 		for (uint32_t q = 0; q < kFtStageBlocks; ++q) dd[q] = have[q] ? raw[q] - uint32_t(d_begin) : 0xFFFFFFFFu;
 	}
 	FT_STAMP(p, 6);
+	// the removed flags of the thread's documents (four per word), wanted after the terms: requested now, in flight behind the term pass
+	constexpr uint32_t kSteps = kFtRangeDocs / 4 / 256;   // 8 steps of four documents per thread
+	uint32_t rm8[kSteps];
+#pragma unroll
+	for (uint32_t j = 0; j < kSteps; ++j) {
+		const uint32_t l0 = (j * 256 + tid) * 4;
+		rm8[j] = (p.prescore && p.removed && l0 < docs_here) ? *reinterpret_cast<const uint32_t*>(p.removed + d_begin + l0) : 0u;   // reads past the end stay inside the allocation
+	}
 	for (uint32_t t = 0; t < nterms; ++t) {
 		const FtTermCfg& term = p.terms[t];
 		const int op = term.op;
@@ -463,49 +471,52 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 	// every wavefront: each key gets 16 counters on 16 different banks (the posting stage is free by now), lane l adds to counter l % 16
 	uint32_t* hist_copy = p.hist + size_t(range % kFtHistCopies) * kFtHistStride;
 	for (uint32_t i = tid; i < 256 * 16; i += 256) s_rep[i] = 0;
-	constexpr uint32_t kSteps = kFtRangeDocs / 4 / 256;   // 8 steps of four documents per thread
-	uint32_t rm8[kSteps];   // the removed flags of the thread's documents (4 per word), fetched together
-#pragma unroll
-	for (uint32_t j = 0; j < kSteps; ++j) {
-		const uint32_t l0 = (j * 256 + tid) * 4;
-		rm8[j] = (p.removed && l0 < docs_here) ? *reinterpret_cast<const uint32_t*>(p.removed + d_begin + l0) : 0u;   // reads past the end stay inside the allocation
-	}
 	__syncthreads();
-	// scores first (eight 8-byte LDS reads and the global stores), then every hash probe, then the counters: each phase's LDS accesses are
-	// independent of one another, so their latencies overlap instead of queueing per document
-	uint32_t sc[kSteps][4];
+	// masked scores first (eight 8-byte LDS reads, the global stores; the masked value goes back into the LDS copy), then the counting
+	// loop — deliberately NOT unrolled: with the probe loop inlined 32 times this phase was 8400 instructions and, at three wavefronts
+	// per SIMD, took 6 us on instruction issue alone
 #pragma unroll
 	for (uint32_t j = 0; j < kSteps; ++j) {
 		const uint32_t l0 = (j * 256 + tid) * 4;
 		const uint32_t mw = s_mask[(l0 >> 5) & (kWords - 1)];
 		const uint2 four = *reinterpret_cast<const uint2*>(&s_score[l0]);
 		const uint32_t raw[4] = {four.x & 0xFFFFu, four.x >> 16, four.y & 0xFFFFu, four.y >> 16};
+		uint32_t sc[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
 			const bool in = l0 + k < docs_here && ((mw >> ((l0 + k) & 31)) & 1u) && !((rm8[j] >> (8 * k)) & 0xFFu);
-			sc[j][k] = in ? raw[k] : 0u;
+			sc[k] = in ? raw[k] : 0u;
 		}
-		if (l0 < docs_here) {
-			*reinterpret_cast<uint2*>(p.score + d_begin + l0) = make_uint2(sc[j][0] | (sc[j][1] << 16), sc[j][2] | (sc[j][3] << 16));   // the array is padded to whole mask words
-		}
+		const uint2 packed = make_uint2(sc[0] | (sc[1] << 16), sc[2] | (sc[3] << 16));
+		*reinterpret_cast<uint2*>(&s_score[l0]) = packed;   // this thread's own four documents
+		if (l0 < docs_here) *reinterpret_cast<uint2*>(p.score + d_begin + l0) = packed;   // the array is padded to whole mask words
 	}
-#pragma unroll
+#pragma unroll 1
 	for (uint32_t j = 0; j < kSteps; ++j) {
+		const uint32_t l0 = (j * 256 + tid) * 4;
+		const uint2 four = *reinterpret_cast<const uint2*>(&s_score[l0]);
+		const uint32_t sc[4] = {four.x & 0xFFFFu, four.x >> 16, four.y & 0xFFFFu, four.y >> 16};
 		uint32_t h[4], cur[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			h[k] = (sc[j][k] * 2654435761u) >> 24;
-			cur[k] = sc[j][k] ? s_keys[h[k]] : 0u;
+			h[k] = (sc[k] * 2654435761u) >> 24;
+			cur[k] = sc[k] ? s_keys[h[k]] : 0u;
 		}
+		uint32_t slow = 0;
 #pragma unroll
 		for (int k = 0; k < 4; ++k) {
-			const uint32_t v = sc[j][k];
-			if (!v) continue;
-			if (cur[k] == v) {   // the key is there already (after the first few documents of the range it always is)
+			if (!sc[k]) continue;
+			if (cur[k] == sc[k]) {   // the key is there already (after the first few documents of the range it always is)
 				atomicAdd(&s_rep[h[k] * 16 + (tid & 15)], 1u);
-				continue;
+			} else {
+				slow |= 1u << k;
 			}
-			uint32_t hh = h[k];
+		}
+		while (slow) {   // a new key, or a slot taken by another one: probe
+			const int k = __ffs(int(slow)) - 1;
+			slow &= slow - 1;
+			const uint32_t v = k == 0 ? sc[0] : k == 1 ? sc[1] : k == 2 ? sc[2] : sc[3];
+			uint32_t hh = k == 0 ? h[0] : k == 1 ? h[1] : k == 2 ? h[2] : h[3];
 			int probes = 0;
 			for (; probes < 256; ++probes, hh = (hh + 1) & 255u) {
 				uint32_t c = s_keys[hh];
