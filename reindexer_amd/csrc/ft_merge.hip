@@ -406,15 +406,21 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 						}
 					}
 					if (scoring) {
+						// Reads without a condition (a lane without a posting reads document 0 and drops the result): under `if (ok)` each
+						// of them became its own exec-masked block with its own lgkmcnt(0), i.e. eight LDS round trips in a row per
+						// group instead of two.  The four documents of a thread are distinct, and so are those of different threads
+						// (one sub-term), so every read may precede every write.
+						uint32_t cur[4];
 #pragma unroll
-						for (uint32_t q = 0; q < 4; ++q) tag[q] = ok[q] ? uint32_t(s_scored[loc[q]]) : epoch;
+						for (uint32_t q = 0; q < 4; ++q) tag[q] = s_scored[loc[q]];
+#pragma unroll
+						for (uint32_t q = 0; q < 4; ++q) cur[q] = s_score[loc[q]];
 #pragma unroll
 						for (uint32_t q = 0; q < 4; ++q) {
-							if (tag[q] == epoch) continue;   // an earlier sub-term of the term holds the document
+							if (!ok[q] || tag[q] == epoch) continue;   // (an earlier sub-term of the term holds the document)
+							const uint32_t add = p16c < 65535u - cur[q] ? p16c : 65535u - cur[q];
 							s_scored[loc[q]] = uint8_t(epoch);
-							const uint32_t cur = s_score[loc[q]];
-							const uint32_t add = p16c < 65535u - cur ? p16c : 65535u - cur;
-							s_score[loc[q]] = uint16_t(cur + add);
+							s_score[loc[q]] = uint16_t(cur[q] + add);
 						}
 					}
 				}
