@@ -292,6 +292,19 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
  * (cpp_src/core/ft/idrelset.h:14-32: pos | arrayIdx << 28 | field << 56), ascending like IdRelType::SortAndUnique leaves them.
  * The (field, tf, first position) entries of rxgpu_ft_set_word are derived from them, so the word serves both merges. */
 int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uint32_t* doc, const uint32_t* pos_off, const uint64_t* fpos);
+/* Posting lists in the reference's own storage format, decoded ON THE DEVICE: `bytes` holds the PackedIdRelVec streams of
+ * nwords dictionary words back to back (cpp_src/core/ft/idrelset.h:155-280; IdRelType::pack / unpack, idrelset.cc:8-139; varints
+ * tools/varint.h:122-176), word w = bytes[byte_off[w] .. byte_off[w + 1]); array_found_pos[w] = PackedIdRelVec's offset (relative to the
+ * word's first byte) from which elements carry array indexes (>= the stream length if none do).  Replaces, for these words, the host-side
+ * flattening + rxgpu_ft_set_word_positions: documents, positions (PosType words), the (field, tf, first position) entries of
+ * calcTermRankImpl (phrasemergerimpl.h:24-49) and the range index are produced by a kernel (one thread per word) into one device
+ * allocation per call.  A malformed stream (truncated varint, ids not ascending, field >= num_fields) is RXGPU_ERR_PARAMS naming the word. */
+int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t* word_ids, const uint64_t* byte_off, const uint8_t* bytes,
+							  const uint64_t* array_found_pos);
+/* Reads a word's device arrays back (tests, diagnostics).  Sizes first (array pointers null), then the arrays the caller wants. */
+int rxgpu_ft_get_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t* n, uint64_t* npos, uint64_t* nent, uint32_t* doc, uint32_t* pos_off, uint64_t* fpos,
+					  uint32_t* ent_off, uint8_t* ent_field, uint32_t* ent_tf, uint32_t* ent_first_pos, uint32_t* n_ranges, uint32_t* range_off);
+
 /* Device half of Merger::Merge for a query of nterms >= 2 terms without phrases / multi-word synonyms (mergerimpl.h:466-566):
  * buildRestrictingBitmask (:326-384), the 2-phase gate + preselectMostRelevantDocs (:386-464, 486-490) and mergeTerm (:107-192) for
  * every term that is not a NOT.  ops[t]: OpType 1 OR / 2 AND / 3 NOT (core/type_consts.h); opts[t]: the term's FtDslOpts; the

@@ -78,6 +78,13 @@ def build_cpp_tests(force: bool = False) -> list[Path]:
             _run(["g++", "-O2", "-std=c++17", "-Wall", f"-I{INCLUDE}", f"-I{HOST}", src, "-o", out, f"-L{PKG}", "-lrxgpu_host", "-lrxgpu",
                   "-Wl,-rpath,$ORIGIN/../../reindexer_amd", "-lpthread"])
         outs.append(out)
+    # the device decoder of packed postings compiled for the host (CPU check of the code the kernel runs)
+    src = tdir / "ft_packed_decode_cpu.cc"
+    if src.exists():
+        out = tdir / "libft_packed_decode_cpu.so"
+        if force or _stale(out, [src, CSRC / "ft_packed_decode.h"]):
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", f"-I{CSRC}", src, "-o", out])
+        outs.append(out)
     return outs
 
 

@@ -6,7 +6,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdint>
+#include <memory>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -43,10 +45,13 @@ struct rxgpu_ft_word {
 	uint32_t* range_off = nullptr; // [n_ranges]: first posting with doc >= k * kFtRangeDocs (ft_ranges finds its segment of the list here)
 	uint32_t n_ranges = 0;
 	uint64_t* fpos = nullptr;
+	std::shared_ptr<void> pool;    // set for words decoded on the device (rxgpu_ft_set_words_packed): the arrays are slices of one allocation
 	void release() {
-		for (void* p : {static_cast<void*>(doc), static_cast<void*>(ent_off), static_cast<void*>(ent_field), static_cast<void*>(ent_tf),
-						static_cast<void*>(ent_first_pos), static_cast<void*>(pos_off), static_cast<void*>(fpos), static_cast<void*>(range_off)}) {
-			if (p) (void)hipFree(p);
+		if (!pool) {
+			for (void* p : {static_cast<void*>(doc), static_cast<void*>(ent_off), static_cast<void*>(ent_field), static_cast<void*>(ent_tf),
+							static_cast<void*>(ent_first_pos), static_cast<void*>(pos_off), static_cast<void*>(fpos), static_cast<void*>(range_off)}) {
+				if (p) (void)hipFree(p);
+			}
 		}
 		*this = rxgpu_ft_word{};
 	}
@@ -603,6 +608,178 @@ int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n,
 	rxgpu_ft_word& w = h->words[word_id];
 	if (int rc = upload(w.pos_off, pos_off, n + 1); rc) return rc;
 	if (int rc = upload(w.fpos, fpos, size_t(pos_off[n])); rc) return rc;
+	return RXGPU_OK;
+}
+
+int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t* word_ids, const uint64_t* byte_off, const uint8_t* bytes,
+							  const uint64_t* array_found_pos) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null ft index");
+	if (nwords == 0) return RXGPU_OK;
+	RX_CHECK(word_ids && byte_off && array_found_pos, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: null argument");
+	RX_CHECK(byte_off[0] == 0, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: byte_off[0] must be 0");
+	for (uint32_t w = 0; w < nwords; ++w) RX_CHECK(byte_off[w + 1] >= byte_off[w], RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: byte_off must not descend");
+	const uint64_t total_bytes = byte_off[nwords];
+	RX_CHECK(total_bytes == 0 || bytes, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: null argument");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	RX_HIP(hipStreamSynchronize(h->stream));
+	// wavefronts of similar work: the words go to the threads longest first (a wavefront lasts as long as its longest stream)
+	std::vector<uint32_t> order(nwords);
+	for (uint32_t w = 0; w < nwords; ++w) order[w] = w;
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return byte_off[a + 1] - byte_off[a] > byte_off[b + 1] - byte_off[b]; });
+	// staging: the streams in launch order, their offsets and array_found_pos
+	std::vector<uint64_t> off(nwords + 1), afp(nwords);
+	off[0] = 0;
+	for (uint32_t k = 0; k < nwords; ++k) {
+		const uint32_t w = order[k];
+		off[k + 1] = off[k] + (byte_off[w + 1] - byte_off[w]);
+		afp[k] = array_found_pos[w];
+	}
+	struct Scratch {
+		void* p = nullptr;
+		~Scratch() {
+			if (p) (void)hipFree(p);
+		}
+	} d_in, d_cnt, d_outs;
+	const size_t in_bytes = align256(size_t(total_bytes) + 16) + align256((nwords + 1) * 8) + align256(size_t(nwords) * 8);
+	RX_HIP(hipMalloc(&d_in.p, in_bytes));
+	uint8_t* d_bytes = static_cast<uint8_t*>(d_in.p);
+	uint64_t* d_off = reinterpret_cast<uint64_t*>(d_bytes + align256(size_t(total_bytes) + 16));
+	uint64_t* d_afp = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(d_off) + align256((nwords + 1) * 8));
+	{
+		std::vector<uint8_t> packed(total_bytes);
+		for (uint32_t k = 0; k < nwords; ++k) {
+			const uint32_t w = order[k];
+			if (off[k + 1] > off[k]) std::memcpy(packed.data() + off[k], bytes + byte_off[w], size_t(off[k + 1] - off[k]));
+		}
+		if (total_bytes) RX_HIP(hipMemcpyAsync(d_bytes, packed.data(), total_bytes, hipMemcpyHostToDevice, h->stream));
+		RX_HIP(hipMemcpyAsync(d_off, off.data(), (nwords + 1) * 8, hipMemcpyHostToDevice, h->stream));
+		RX_HIP(hipMemcpyAsync(d_afp, afp.data(), size_t(nwords) * 8, hipMemcpyHostToDevice, h->stream));
+		RX_HIP(hipStreamSynchronize(h->stream));   // `packed` goes out of scope
+	}
+	RX_HIP(hipMalloc(&d_cnt.p, size_t(nwords) * sizeof(rxgpu::FtPackedCounts)));
+	rxgpu::FtPackedCounts* d_counts = static_cast<rxgpu::FtPackedCounts*>(d_cnt.p);
+	RX_HIP(rxgpu::launch_ft_packed_count(d_bytes, d_off, d_afp, nwords, h->num_fields, d_counts, h->stream));
+	std::vector<rxgpu::FtPackedCounts> counts(nwords);
+	RX_HIP(hipMemcpyAsync(counts.data(), d_counts, size_t(nwords) * sizeof(rxgpu::FtPackedCounts), hipMemcpyDeviceToHost, h->stream));
+	RX_HIP(hipStreamSynchronize(h->stream));
+	auto status_text = [](uint32_t st) {
+		switch (st) {
+			case rxgpu::kFtPackedTruncated: return "truncated varint stream";
+			case rxgpu::kFtPackedDocOrder: return "document ids must ascend strictly";
+			case rxgpu::kFtPackedField: return "field out of range";
+			default: return "posting list too long";
+		}
+	};
+	for (uint32_t k = 0; k < nwords; ++k) {
+		RX_CHECK(counts[k].status == rxgpu::kFtPackedOk, RXGPU_ERR_PARAMS,
+				 std::string("rxgpu_ft_set_words_packed: word ") + std::to_string(word_ids[order[k]]) + ": " + status_text(counts[k].status));
+	}
+	// one pool for the whole batch, every array of every word on a 256-byte boundary (the kernels read document ids 16 bytes at a time)
+	Carver cv;
+	std::vector<rxgpu::FtPackedOut> outs(nwords);
+	struct Slices {
+		size_t doc, pos_off, fpos, ent_off, ent_field, ent_tf, ent_first, range_off;
+	};
+	std::vector<Slices> sl(nwords);
+	for (uint32_t k = 0; k < nwords; ++k) {
+		const rxgpu::FtPackedCounts& c = counts[k];
+		if (!c.n) continue;
+		sl[k].doc = cv.take(size_t(c.n) * 4);
+		sl[k].pos_off = cv.take((size_t(c.n) + 1) * 4);
+		sl[k].fpos = cv.take(size_t(c.npos) * 8);
+		sl[k].ent_off = cv.take((size_t(c.n) + 1) * 4);
+		sl[k].ent_field = cv.take(size_t(c.nent));
+		sl[k].ent_tf = cv.take(size_t(c.nent) * 4);
+		sl[k].ent_first = cv.take(size_t(c.nent) * 4);
+		outs[k].n_ranges = c.last_doc / rxgpu::kFtRangeDocs + 2;
+		sl[k].range_off = cv.take(size_t(outs[k].n_ranges) * 4);
+	}
+	std::shared_ptr<void> pool;
+	char* base = nullptr;
+	if (cv.off) {
+		void* raw = nullptr;
+		RX_HIP(hipMalloc(&raw, cv.off));
+		const int device = h->device;
+		pool = std::shared_ptr<void>(raw, [device](void* q) {
+			DevGuard g(device);
+			(void)hipFree(q);
+		});
+		base = static_cast<char*>(raw);
+	}
+	for (uint32_t k = 0; k < nwords; ++k) {
+		if (!counts[k].n) continue;
+		outs[k].doc = reinterpret_cast<uint32_t*>(base + sl[k].doc);
+		outs[k].pos_off = reinterpret_cast<uint32_t*>(base + sl[k].pos_off);
+		outs[k].fpos = reinterpret_cast<uint64_t*>(base + sl[k].fpos);
+		outs[k].ent_off = reinterpret_cast<uint32_t*>(base + sl[k].ent_off);
+		outs[k].ent_field = reinterpret_cast<uint8_t*>(base + sl[k].ent_field);
+		outs[k].ent_tf = reinterpret_cast<uint32_t*>(base + sl[k].ent_tf);
+		outs[k].ent_first_pos = reinterpret_cast<uint32_t*>(base + sl[k].ent_first);
+		outs[k].range_off = reinterpret_cast<uint32_t*>(base + sl[k].range_off);
+	}
+	RX_HIP(hipMalloc(&d_outs.p, size_t(nwords) * sizeof(rxgpu::FtPackedOut)));
+	RX_HIP(hipMemcpyAsync(d_outs.p, outs.data(), size_t(nwords) * sizeof(rxgpu::FtPackedOut), hipMemcpyHostToDevice, h->stream));
+	RX_HIP(rxgpu::launch_ft_packed_write(d_bytes, d_off, d_afp, nwords, h->num_fields, static_cast<const rxgpu::FtPackedOut*>(d_outs.p), d_counts, h->stream));
+	std::vector<rxgpu::FtPackedCounts> again(nwords);
+	RX_HIP(hipMemcpyAsync(again.data(), d_counts, size_t(nwords) * sizeof(rxgpu::FtPackedCounts), hipMemcpyDeviceToHost, h->stream));
+	RX_HIP(hipStreamSynchronize(h->stream));
+	for (uint32_t k = 0; k < nwords; ++k) {
+		RX_CHECK(again[k].status == rxgpu::kFtPackedOk && again[k].n == counts[k].n && again[k].npos == counts[k].npos && again[k].nent == counts[k].nent,
+				 RXGPU_ERR_DEVICE, "rxgpu_ft_set_words_packed: the write pass disagrees with the counting pass");
+	}
+	for (uint32_t k = 0; k < nwords; ++k) {
+		rxgpu_ft_word& w = h->words[word_ids[order[k]]];
+		w.release();
+		const rxgpu::FtPackedCounts& c = counts[k];
+		if (!c.n) continue;
+		w.n = c.n;
+		w.nent = c.nent;
+		w.doc = outs[k].doc;
+		w.ent_off = outs[k].ent_off;
+		w.ent_field = outs[k].ent_field;
+		w.ent_tf = outs[k].ent_tf;
+		w.ent_first_pos = outs[k].ent_first_pos;
+		w.pos_off = outs[k].pos_off;
+		w.fpos = outs[k].fpos;
+		w.range_off = outs[k].range_off;
+		w.n_ranges = outs[k].n_ranges;
+		w.pool = pool;
+	}
+	return RXGPU_OK;
+}
+
+int rxgpu_ft_get_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t* n, uint64_t* npos, uint64_t* nent, uint32_t* doc, uint32_t* pos_off, uint64_t* fpos,
+					  uint32_t* ent_off, uint8_t* ent_field, uint32_t* ent_tf, uint32_t* ent_first_pos, uint32_t* n_ranges, uint32_t* range_off) {
+	RX_CHECK(h && n && npos && nent && n_ranges, RXGPU_ERR_PARAMS, "rxgpu_ft_get_word: null argument");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	RX_HIP(hipStreamSynchronize(h->stream));
+	const auto it = h->words.find(word_id);
+	RX_CHECK(it != h->words.end(), RXGPU_ERR_PARAMS, "rxgpu_ft_get_word: unknown word");
+	const rxgpu_ft_word& w = it->second;
+	*n = w.n;
+	*nent = w.nent;
+	*n_ranges = w.n_ranges;
+	*npos = 0;
+	if (!w.n) return RXGPU_OK;
+	if (w.pos_off) {
+		uint32_t last = 0;
+		RX_HIP(hipMemcpy(&last, w.pos_off + w.n, 4, hipMemcpyDeviceToHost));
+		*npos = last;
+	}
+	auto down = [](void* dst, const void* src, size_t bytes) -> int {
+		if (dst && src && bytes) RX_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+		return RXGPU_OK;
+	};
+	if (int rc = down(doc, w.doc, w.n * 4); rc) return rc;
+	if (int rc = down(pos_off, w.pos_off, (w.n + 1) * 4); rc) return rc;
+	if (int rc = down(fpos, w.fpos, size_t(*npos) * 8); rc) return rc;
+	if (int rc = down(ent_off, w.ent_off, (w.n + 1) * 4); rc) return rc;
+	if (int rc = down(ent_field, w.ent_field, w.nent); rc) return rc;
+	if (int rc = down(ent_tf, w.ent_tf, w.nent * 4); rc) return rc;
+	if (int rc = down(ent_first_pos, w.ent_first_pos, w.nent * 4); rc) return rc;
+	if (int rc = down(range_off, w.range_off, size_t(w.n_ranges) * 4); rc) return rc;
 	return RXGPU_OK;
 }
 

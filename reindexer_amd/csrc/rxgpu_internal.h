@@ -8,6 +8,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include "ft_packed_decode.h"
 
 namespace rxgpu {
 
@@ -171,6 +172,11 @@ static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers
 hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);
 hipError_t launch_ft_export(const FtPlan& plan, hipStream_t st);
 hipError_t launch_ft_import(const void* host_plan_device_view, void* dev_plan, size_t bytes, hipStream_t st);
+// ft_packed.hip: PackedIdRelVec streams -> flat posting arrays, one thread per word (counting pass, then writing pass)
+hipError_t launch_ft_packed_count(const uint8_t* bytes, const uint64_t* byte_off, const uint64_t* array_found_pos, uint32_t nwords, uint32_t num_fields,
+								   FtPackedCounts* counts, hipStream_t st);
+hipError_t launch_ft_packed_write(const uint8_t* bytes, const uint64_t* byte_off, const uint64_t* array_found_pos, uint32_t nwords, uint32_t num_fields,
+								   const FtPackedOut* outs, FtPackedCounts* counts, hipStream_t st);
 
 void set_error(const std::string& msg);
 

@@ -225,6 +225,50 @@ void GpuFtMerger::SetWord(uint32_t wordId, const PositionPostings& p) {
 	if (rxgpu_ft_set_word_positions(dev_, wordId, p.doc.size(), p.doc.data(), p.posOff.data(), p.fpos.data()) != RXGPU_OK) throwDevice("SetWord");
 }
 
+void GpuFtMerger::SetWordsPacked(const std::vector<PackedWord>& words, size_t hostDecodeFromBytes) {
+	std::vector<uint32_t> ids;
+	std::vector<uint64_t> off{0}, afp;
+	std::vector<uint8_t> bytes;
+	for (const PackedWord& w : words) {
+		if (w.len >= hostDecodeFromBytes) {
+			PositionPostings pp;
+			pp.AppendPacked(w.data, w.len, w.arrayFoundPos);
+			SetWord(w.wordId, pp);
+			continue;
+		}
+		ids.push_back(w.wordId);
+		bytes.insert(bytes.end(), w.data, w.data + w.len);
+		off.push_back(bytes.size());
+		afp.push_back(w.arrayFoundPos);
+	}
+	if (ids.empty()) return;
+	if (rxgpu_ft_set_words_packed(dev_, uint32_t(ids.size()), ids.data(), off.data(), bytes.data(), afp.data()) != RXGPU_OK) throwDevice("SetWordsPacked");
+}
+
+void GpuFtMerger::GetWord(uint32_t wordId, PositionPostings& positions, FlatPostings& entries, std::vector<uint32_t>& rangeOff) const {
+	uint64_t n = 0, npos = 0, nent = 0;
+	uint32_t nRanges = 0;
+	if (rxgpu_ft_get_word(dev_, wordId, &n, &npos, &nent, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &nRanges, nullptr) != RXGPU_OK) {
+		throwDevice("GetWord");
+	}
+	positions.doc.assign(n, 0);
+	positions.posOff.assign(n + 1, 0);
+	positions.fpos.assign(npos, 0);
+	entries.doc.assign(n, 0);
+	entries.entOff.assign(n + 1, 0);
+	entries.entField.assign(nent, 0);
+	entries.entTf.assign(nent, 0);
+	entries.entFirstPos.assign(nent, 0);
+	rangeOff.assign(nRanges, 0);
+	if (!n) return;
+	if (rxgpu_ft_get_word(dev_, wordId, &n, &npos, &nent, positions.doc.data(), npos ? positions.posOff.data() : nullptr, positions.fpos.data(),
+						  entries.entOff.data(), entries.entField.data(), entries.entTf.data(), entries.entFirstPos.data(), &nRanges,
+						  rangeOff.data()) != RXGPU_OK) {
+		throwDevice("GetWord");
+	}
+	entries.doc = positions.doc;
+}
+
 void GpuFtMerger::ReadTiming(uint64_t& calls, double& totalMs) const {
 	calls = timedCalls_.exchange(0);
 	totalMs = double(timedNs_.exchange(0)) * 1e-6;

@@ -113,6 +113,18 @@ public:
 	void SetWord(uint32_t wordId, const FlatPostings& postings);
 
 	void SetWord(uint32_t wordId, const PositionPostings& postings);   // usable by Merge and MergeQuery
+	// IndexText side, bulk: the dictionary's posting lists as the reference stores them (PackedIdRelVec byte streams, idrelset.h:155-280)
+	// are uploaded in one piece and decoded ON THE DEVICE (ft_packed.hip, one thread per word) into everything Merge / MergeQuery read.
+	// A single stream is serial work (no sync points in the format), so streams of `hostDecodeFromBytes` bytes or more are decoded by
+	// AppendPacked on the host and uploaded as before; the rest — the bulk of a dictionary — never touch the host decoder.
+	struct PackedWord {
+		uint32_t wordId;
+		const uint8_t* data;
+		size_t len, arrayFoundPos;   // PackedIdRelVec::arrayFoundPos_ (>= len: no element carries array indexes)
+	};
+	void SetWordsPacked(const std::vector<PackedWord>& words, size_t hostDecodeFromBytes = size_t(1) << 18);
+	// reads a word's device arrays back (tests, diagnostics)
+	void GetWord(uint32_t wordId, PositionPostings& positions, FlatPostings& entries, std::vector<uint32_t>& rangeOff) const;
 
 	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept { return numQueryParts >= 1 && !hasPhrases && !hasSynonyms; }
 	static bool Supports(const FtConfig& cfg, size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept {

@@ -612,6 +612,39 @@ extern "C" int rxhost_ft_set_word_packed(void* h, uint32_t wordId, const uint8_t
 	});
 }
 
+// bulk: nwords PackedIdRelVec streams back to back, decoded on the device (streams of hostFromBytes bytes or more: on the host)
+extern "C" int rxhost_ft_set_words_packed(void* h, uint32_t nwords, const uint32_t* wordIds, const uint64_t* byteOff, const uint8_t* bytes,
+										  const uint64_t* arrayFoundPos, size_t hostFromBytes) {
+	return guarded([&] {
+		std::vector<GpuFtMerger::PackedWord> ws(nwords);
+		for (uint32_t i = 0; i < nwords; ++i) ws[i] = {wordIds[i], bytes + byteOff[i], size_t(byteOff[i + 1] - byteOff[i]), size_t(arrayFoundPos[i])};
+		static_cast<GpuFtMerger*>(h)->SetWordsPacked(ws, hostFromBytes);
+	});
+}
+// a word's device arrays; sizes[4] = {n, npos, nent, nRanges}; with null arrays only the sizes
+extern "C" int rxhost_ft_get_word(void* h, uint32_t wordId, uint64_t* sizes, uint32_t* doc, uint32_t* posOff, uint64_t* fpos, uint32_t* entOff,
+								  uint8_t* entField, uint32_t* entTf, uint32_t* entFirstPos, uint32_t* rangeOff) {
+	return guarded([&] {
+		PositionPostings pp;
+		FlatPostings fp;
+		std::vector<uint32_t> ro;
+		static_cast<const GpuFtMerger*>(h)->GetWord(wordId, pp, fp, ro);
+		sizes[0] = pp.doc.size();
+		sizes[1] = pp.fpos.size();
+		sizes[2] = fp.entField.size();
+		sizes[3] = ro.size();
+		if (!doc) return;
+		std::copy(pp.doc.begin(), pp.doc.end(), doc);
+		std::copy(pp.posOff.begin(), pp.posOff.end(), posOff);
+		std::copy(pp.fpos.begin(), pp.fpos.end(), fpos);
+		std::copy(fp.entOff.begin(), fp.entOff.end(), entOff);
+		std::copy(fp.entField.begin(), fp.entField.end(), entField);
+		std::copy(fp.entTf.begin(), fp.entTf.end(), entTf);
+		std::copy(fp.entFirstPos.begin(), fp.entFirstPos.end(), entFirstPos);
+		std::copy(ro.begin(), ro.end(), rangeOff);
+	});
+}
+
 // ---------------------------------------------------------------------------------------------- hybrid rank fusion
 #include "hybrid_rerank.h"
 

@@ -642,6 +642,40 @@ class GpuFtMerger:
         if rc:
             _raise(rc)
 
+    def set_words_packed(self, words, host_from_bytes=1 << 18):
+        """words: [(word_id, bytes (uint8 array: a PackedIdRelVec stream), array_found_pos), ...] — uploaded in one piece and decoded on the
+        device (GpuFtMerger::SetWordsPacked); streams of host_from_bytes bytes or more are decoded on the host."""
+        L = lib()
+        L.rxhost_ft_set_words_packed.argtypes = [_vp, C.c_uint32, _vp, _vp, _vp, _vp, _sz]
+        ids = np.array([w[0] for w in words], np.uint32)
+        datas = [np.ascontiguousarray(w[1], np.uint8) for w in words]
+        off = np.zeros(len(words) + 1, np.uint64)
+        off[1:] = np.cumsum([d.shape[0] for d in datas])
+        blob = np.concatenate(datas) if datas else np.zeros(0, np.uint8)
+        blob = np.ascontiguousarray(np.append(blob, np.zeros(1, np.uint8)))   # never a null pointer
+        afp = np.array([min(int(w[2]), 1 << 62) for w in words], np.uint64)
+        rc = L.rxhost_ft_set_words_packed(self.h, len(words), ids.ctypes.data, off.ctypes.data, blob.ctypes.data, afp.ctypes.data, host_from_bytes)
+        if rc:
+            _raise(rc)
+
+    def get_word(self, word_id):
+        """The word's device arrays read back: dict(doc, pos_off, fpos, ent_off, ent_field, ent_tf, ent_first, range_off)."""
+        L = lib()
+        L.rxhost_ft_get_word.argtypes = [_vp, C.c_uint32] + [_vp] * 9
+        sizes = np.zeros(4, np.uint64)
+        rc = L.rxhost_ft_get_word(self.h, word_id, sizes.ctypes.data, None, None, None, None, None, None, None, None)
+        if rc:
+            _raise(rc)
+        n, npos, nent, nr = (int(x) for x in sizes)
+        out = dict(doc=np.zeros(n, np.uint32), pos_off=np.zeros(n + 1, np.uint32), fpos=np.zeros(npos, np.uint64), ent_off=np.zeros(n + 1, np.uint32),
+                   ent_field=np.zeros(nent, np.uint8), ent_tf=np.zeros(nent, np.uint32), ent_first=np.zeros(nent, np.uint32),
+                   range_off=np.zeros(nr, np.uint32))
+        rc = L.rxhost_ft_get_word(self.h, word_id, sizes.ctypes.data, *(out[k].ctypes.data for k in
+                                  ("doc", "pos_off", "fpos", "ent_off", "ent_field", "ent_tf", "ent_first", "range_off")))
+        if rc:
+            _raise(rc)
+        return out
+
     OP_OR, OP_AND, OP_NOT = 1, 2, 3
 
     def merge_query(self, cfg: dict, terms, excluded=None, sort_by_rank=True):

@@ -1,0 +1,73 @@
+"""Commit-time side of the ft half: a dictionary's posting lists arrive as PackedIdRelVec byte streams.  Times
+  device : GpuFtMerger::SetWordsPacked — one upload of the bytes, decode on the GPU (ft_packed.hip), one pool allocation
+  host   : the previous path — PositionPostings::AppendPacked per word on the host + rxgpu_ft_set_word_positions (eight uploads per word)
+for a Zipf-shaped dictionary built by repeating a few hundred distinct streams under different word ids.  Usage:
+  python tools/bench_ft_packed.py [--words 100000] [--out file.json]"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--words", type=int, default=100_000)
+    ap.add_argument("--host-words", type=int, default=5_000, help="words timed through the per-word host path (it is slow)")
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+    from reindexer_amd import hostapi
+    from tests.ft_pack import pack_postings
+    from tests.test_bm25_oracle import make_pos_postings
+    hostapi.lib()
+    nf, total = 3, 5_000_000
+    rng = np.random.default_rng(3)
+    lens = np.unique(np.minimum(20_000, np.maximum(1, (3000.0 / np.arange(1, 301) ** 1.1).astype(int))))   # distinct list lengths, Zipf-ish
+    distinct = []
+    for n in lens:
+        s = make_pos_postings(rng, total, nf, int(n), 1.0, array_fields=False, max_pos=4000)
+        data, afp = pack_postings(s["doc"], s["pos_off"], s["fpos"])
+        distinct.append((data, afp, int(n), int(s["pos_off"][-1])))
+    # word w takes one of the distinct streams by a heavy-tailed draw: distinct[] ascends in length, most words get short lists
+    idx = np.clip((rng.pareto(1.2, args.words) * 3).astype(int), 0, len(distinct) - 1)
+    words = [(w, distinct[idx[w]][0], distinct[idx[w]][1]) for w in range(args.words)]
+    nbytes = sum(int(w[1].shape[0]) for w in words)
+    npost = sum(distinct[i][2] for i in idx)
+    npos = sum(distinct[i][3] for i in idx)
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(np.ones((total, nf), np.float32), np.ones(nf, np.float32), np.zeros(total, np.uint8))
+    m.set_words_packed(words[:1000])   # warm-up (module load, allocator)
+    t0 = time.perf_counter()
+    m.set_words_packed(words, host_from_bytes=1 << 40)
+    dev_s = time.perf_counter() - t0
+    chk = m.get_word(args.words - 1)
+    m.close()
+    m2 = hostapi.GpuFtMerger(nf)
+    m2.set_docs(np.ones((total, nf), np.float32), np.ones(nf, np.float32), np.zeros(total, np.uint8))
+    hw = words[:args.host_words]
+    t0 = time.perf_counter()
+    m2.set_words_packed(hw, host_from_bytes=0)   # every stream through AppendPacked + rxgpu_ft_set_word_positions
+    host_s = time.perf_counter() - t0
+    chk2 = m2.get_word(args.host_words - 1)
+    m2.close()
+    hbytes = sum(int(w[1].shape[0]) for w in hw)
+    out_bytes = npost * (4 + 4 + 4) + npos * 8 + npost * 9   # doc, pos_off, ent_off, positions, ~1 entry per posting
+    res = {"workload": f"{args.words} dictionary words as PackedIdRelVec streams, {nbytes / 1e6:.1f} MB packed, {npost} postings, {npos} positions",
+           "device": {"seconds": dev_s, "words_per_sec": args.words / dev_s, "packed_MB_per_sec": nbytes / 1e6 / dev_s,
+                      "postings_per_sec": npost / dev_s, "flat_bytes_written": out_bytes},
+           "host_path": {"words": args.host_words, "seconds": host_s, "words_per_sec": args.host_words / host_s,
+                         "packed_MB_per_sec": hbytes / 1e6 / host_s},
+           "speedup_words_per_sec": (args.words / dev_s) / (args.host_words / host_s),
+           "last_word_postings": int(chk["doc"].shape[0]), "host_last_word_postings": int(chk2["doc"].shape[0])}
+    print(json.dumps(res))
+    if args.out:
+        Path(args.out).write_text(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
