@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised differential runs of the CPU checkers against the REAL reference code compiled in place (oracle/_ref) — no GPU involved.
 
-    RX_TARGET_INSTRUCTIONS=avx512 python tools/fuzz_oracles.py --seconds 60 [--only sq8_dist,sq8_quantize,sq8_hnsw,ivf,bm25,builder]
+    RX_TARGET_INSTRUCTIONS=avx512 python tools/fuzz_oracles.py --seconds 60 [--only packed,sq8_dist,sq8_quantize,sq8_hnsw,ivf,bm25,builder]
 
+  packed        PackedIdRelVec streams of the reference's packer -> the device kernel's decoder (host build), the host decoder, the test packer
   sq8_dist      oracle_sq8.c uint8 L2 / IP            vs vector_dists::L2SqrDistance<uint8_t> / InnerProductDistance<uint8_t>
   sq8_quantize  Quantizer::quantize + DistCalculator   vs the reference's Quantizer / DistCalculator<uint8_t>
   sq8_hnsw      SearchKnn over an SQ8 graph            vs HierarchicalNSWImpl<uint8_t> built from a float graph like Quantize() does
@@ -207,7 +208,45 @@ def fuzz_builder(orc, ref, rng, seconds):
     return n, bad
 
 
-FUZZERS = {"sq8_dist": fuzz_sq8_dist, "sq8_quantize": fuzz_sq8_quantize, "sq8_hnsw": fuzz_sq8_hnsw, "ivf": fuzz_ivf, "bm25": fuzz_bm25,
+def fuzz_packed(orc, ref, rng, seconds):
+    """PackedIdRelVec: random posting lists through the reference's own packer (PackedIdRelVec::insert_back) -> (a) the decoder the device
+    kernel runs, compiled for the host, (b) the host decoder AppendPacked, (c) the test-side packer, byte for byte."""
+    import ctypes as C
+    from oracle.pyoracle import ref_ft_or_none
+    from tests.ft_pack import flat_entries, pack_postings
+    from tests.test_bm25_oracle import _unpack, make_pos_postings
+    from tests.test_ft_packed_decode import LIB, decode
+    L = C.CDLL(str(LIB))
+    L.ftpk_count.restype = C.c_uint32
+    L.ftpk_count.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.ftpk_write.restype = C.c_uint32
+    L.ftpk_write.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32] + [C.c_void_p] * 8 + [C.c_uint32, C.c_void_p]
+    real = ref_ft_or_none(6)
+    if real is None:
+        raise SystemExit("oracle/_ref/libref_ft.so not available")
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        nf = int(rng.integers(1, 7))
+        s = make_pos_postings(rng, int(rng.choice([3000, 200_000, 50_000_000])), nf, int(rng.integers(1, 1500)), 1.0,
+                              array_fields=bool(rng.integers(0, 2)), max_pos=int(rng.choice([8, 300, 1 << 20, (1 << 28) - 1])))
+        data, afp = real.pack(s)
+        mine, mine_afp = pack_postings(s["doc"], s["pos_off"], s["fpos"])
+        ok = np.array_equal(mine, data) and (mine_afp == afp or (afp >= len(data) and mine_afp == len(data)))
+        hd, hp, hf = _unpack(data, afp)
+        ok &= np.array_equal(hd, s["doc"]) and np.array_equal(hp, s["pos_off"]) and np.array_equal(hf, s["fpos"])
+        st, got = decode(L, data, min(int(afp), 1 << 62), nf)
+        ok &= st == 0
+        if st == 0:
+            eo, ef, et, e1, ro = flat_entries(s["doc"], s["pos_off"], s["fpos"])
+            ok &= all(np.array_equal(got[k], v) for k, v in (("doc", s["doc"]), ("pos_off", s["pos_off"]), ("fpos", s["fpos"]), ("ent_off", eo),
+                                                            ("ent_field", ef), ("ent_tf", et), ("ent_first", e1), ("range_off", ro)))
+        bad += int(not ok)
+        n += 1
+    real.close()
+    return n, bad
+
+
+FUZZERS = {"packed": fuzz_packed, "sq8_dist": fuzz_sq8_dist, "sq8_quantize": fuzz_sq8_quantize, "sq8_hnsw": fuzz_sq8_hnsw, "ivf": fuzz_ivf, "bm25": fuzz_bm25,
            "builder": fuzz_builder}
 
 
