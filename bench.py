@@ -20,6 +20,8 @@ Extra legs (rank 0, N = 1 only, outside the timed region; each leg is skipped â€
                 the reference's own engine on the same graph (tools/bench_hnsw.py)
   hybrid        BASELINE configs[4]: BM25 merge + KNN + RRF fusion on the GPU vs the reference's merger / brute force / rank merger
                 (tools/bench_hybrid.py)
+  ft_packed     index-commit side of the ft half: a dictionary's PackedIdRelVec posting streams decoded on the device vs the per-word host path
+                (tools/bench_ft_packed.py)
 --scaling strong (or RXGPU_BENCH_SCALING=strong): BASELINE configs[3] with the corpus FIXED at --total-rows (80M) and split over the ranks.
 """
 from __future__ import annotations
@@ -82,6 +84,8 @@ def parse_args():
     ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="hnsw leg: graph size (0 = skip)")
     ap.add_argument("--hnsw-queries", type=int, default=16384)
     ap.add_argument("--hybrid-docs", type=int, default=5_000_000, help="hybrid leg: documents = vectors (0 = skip)")
+    ap.add_argument("--ft-packed-words", type=int, default=100_000, help="ft_packed leg: dictionary words whose PackedIdRelVec streams are decoded "
+                                                                         "on the device (0 = skip)")
     ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock after which remaining extra legs are skipped")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--batch", type=int, default=256, help="extra leg (N=1, untimed region): batched queries on the MFMA path; 0 = skip")
@@ -524,6 +528,9 @@ def main():
         if extra and args.hybrid_docs:
             import bench_hybrid
             result["hybrid"] = leg("hybrid", 20 + 14 * args.hybrid_docs / 1e6, lambda: bench_hybrid.run(dict(docs=args.hybrid_docs, device=local_rank)))
+        if extra and args.ft_packed_words:
+            import bench_ft_packed
+            result["ft_packed"] = leg("ft_packed", 15, lambda: bench_ft_packed.run(dict(words=args.ft_packed_words)))
         result["bench_wall_seconds"] = time.perf_counter() - t_start
         print(json.dumps(result), flush=True)
     if ix is not None:

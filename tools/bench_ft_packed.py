@@ -15,12 +15,13 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--words", type=int, default=100_000)
-    ap.add_argument("--host-words", type=int, default=5_000, help="words timed through the per-word host path (it is slow)")
-    ap.add_argument("--out", default="")
-    args = ap.parse_args()
+def run(opts: dict) -> dict:
+    class A:
+        pass
+    args = A()
+    args.words = int(opts.get("words", 100_000))
+    args.host_words = int(opts.get("host_words", 5_000))
+    args.out = opts.get("out", "")
     from reindexer_amd import hostapi
     from tests.ft_pack import pack_postings
     from tests.test_bm25_oracle import make_pos_postings
@@ -64,9 +65,18 @@ def main():
                          "packed_MB_per_sec": hbytes / 1e6 / host_s},
            "speedup_words_per_sec": (args.words / dev_s) / (args.host_words / host_s),
            "last_word_postings": int(chk["doc"].shape[0]), "host_last_word_postings": int(chk2["doc"].shape[0])}
-    print(json.dumps(res))
     if args.out:
         Path(args.out).write_text(json.dumps(res, indent=1))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--words", type=int, default=100_000)
+    ap.add_argument("--host-words", type=int, default=5_000, help="words timed through the per-word host path (it is slow)")
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    print(json.dumps(run(dict(words=a.words, host_words=a.host_words, out=a.out))))
 
 
 if __name__ == "__main__":
