@@ -25,7 +25,7 @@ constexpr float kSplitEps = 1.0f / 1024.0f;   // Clustering.cpp: EPS of split_cl
 }  // namespace
 
 GpuIvfFlat::GpuIvfFlat(VectorMetric metric, size_t dim, size_t nlist, int device)
-	: metric_(metric), dim_(dim), nlist_(nlist), device_(device), lists_(nlist) {
+	: metric_(metric), dim_(dim), nlist_(nlist), device_(device), lists_(nlist), scan_(nlist) {
 	if (dim_ == 0 || nlist_ == 0) throw std::logic_error("GpuIvfFlat: zero dimension or zero centroids");
 	if (rxgpu_index_create(int(metric_), uint32_t(dim_), 0, device_, &dev_) != RXGPU_OK) throwDevice("GpuIvfFlat: device index creation failed");
 	// the coarse quantiser is the flat index of the same metric (IndexFlatCosine ranks by inner product x the stored 1 / |centroid|)
@@ -49,6 +49,8 @@ void GpuIvfFlat::Reset() {
 	listOf_.clear();
 	idToRow_.clear();
 	for (auto& l : lists_) l.clear();
+	for (auto& l : scan_) l.clear();
+	scanPos_.clear();
 	centroids_.clear();
 	count_ = 0;
 	trained_ = false;
@@ -102,12 +104,36 @@ void GpuIvfFlat::listInsert(uint32_t list, uint32_t row) {
 	l.insert(std::lower_bound(l.begin(), l.end(), row), row);
 }
 
+void GpuIvfFlat::scanAppend(uint32_t list, uint32_t row) {
+	if (scanPos_.size() <= row) scanPos_.resize(size_t(row) + 1);
+	scanPos_[row] = uint32_t(scan_[list].size());
+	scan_[list].push_back(row);
+}
+
 void GpuIvfFlat::listErase(uint32_t list, uint32_t row) {
 	listsDirty_ = true;
 	auto& l = lists_[list];
 	const auto it = std::lower_bound(l.begin(), l.end(), row);
 	if (it == l.end() || *it != row) throw std::logic_error("GpuIvfFlat: inverted list out of sync");
 	l.erase(it);
+	// DirectMap::remove_ids (Hashtable): the list's last entry takes the place of the removed one
+	auto& sc = scan_[list];
+	const uint32_t pos = scanPos_[row], moved = sc.back();
+	sc[pos] = moved;
+	scanPos_[moved] = pos;
+	sc.pop_back();
+}
+
+void GpuIvfFlat::listRename(uint32_t list, uint32_t from, uint32_t to) {
+	listsDirty_ = true;
+	auto& l = lists_[list];
+	const auto it = std::lower_bound(l.begin(), l.end(), from);
+	if (it == l.end() || *it != from) throw std::logic_error("GpuIvfFlat: inverted list out of sync");
+	l.erase(it);
+	l.insert(std::lower_bound(l.begin(), l.end(), to), to);
+	if (scanPos_.size() <= to) scanPos_.resize(size_t(to) + 1);
+	scan_[list][scanPos_[from]] = to;   // the entry keeps its place in the list: only the row number behind it changed
+	scanPos_[to] = scanPos_[from];
 }
 
 namespace {
@@ -238,6 +264,8 @@ void GpuIvfFlat::Train(int seed) {
 	listsDirty_ = true;
 	// add_with_ids of everything that sat in the flat phase (ivf_index.cc:101-103)
 	for (auto& l : lists_) l.clear();
+	for (auto& l : scan_) l.clear();
+	scanPos_.assign(count_, 0u);
 	listOf_.assign(count_, 0u);
 	std::vector<float> prepared;
 	std::vector<uint32_t> chunkAssign;
@@ -254,6 +282,7 @@ void GpuIvfFlat::Train(int seed) {
 		for (size_t i = 0; i < n; ++i) {
 			listOf_[first + i] = chunkAssign[i];
 			lists_[chunkAssign[i]].push_back(uint32_t(first + i));   // rows ascend: every list stays sorted
+			scanAppend(chunkAssign[i], uint32_t(first + i));
 		}
 	}
 }
@@ -296,6 +325,7 @@ void GpuIvfFlat::AddWithIds(size_t n, const float* x, const idx_t* ids) {
 		for (size_t i = 0; i < n; ++i) {
 			listOf_[count_ + i] = a[i];
 			lists_[a[i]].push_back(uint32_t(count_ + i));
+			scanAppend(a[i], uint32_t(count_ + i));
 			listsDirty_ = true;
 		}
 	}
@@ -317,8 +347,7 @@ size_t GpuIvfFlat::RemoveIds(const idx_t* ids, size_t n) {
 			if (metric_ == VectorMetric::Cosine) invNorms_[row] = invNorms_[last];
 			idToRow_[ids_[row]] = row;
 			if (trained_) {
-				listErase(listOf_[last], last);
-				listInsert(listOf_[last], row);
+				listRename(listOf_[last], last, row);
 				listOf_[row] = listOf_[last];
 			}
 			if (rxgpu_index_move_row(dev_, last, row) != RXGPU_OK) throwDevice("GpuIvfFlat: row move failed");
@@ -327,7 +356,10 @@ size_t GpuIvfFlat::RemoveIds(const idx_t* ids, size_t n) {
 		rows_.resize(count_ * dim_);
 		ids_.resize(count_);
 		if (metric_ == VectorMetric::Cosine) invNorms_.resize(count_);
-		if (trained_) listOf_.resize(count_);
+		if (trained_) {
+			listOf_.resize(count_);
+			scanPos_.resize(count_);
+		}
 		if (rxgpu_index_truncate(dev_, count_) != RXGPU_OK) throwDevice("GpuIvfFlat: truncate failed");
 		++removed;
 	}
@@ -373,15 +405,17 @@ void GpuIvfFlat::Search(const float* x, size_t k, size_t nprobe, float* distance
 	if (k == 0 || count_ == 0) return;
 	std::vector<float> q;
 	prepareQuery(x, q);
-	std::vector<float> dist(k);
-	std::vector<uint32_t> row(k);
+	// one candidate more than asked for: equal distances at the k-th place are decided the way faiss's scanner decides them (below)
+	const size_t kk = trained_ ? k + 1 : k;
+	std::vector<float> dist(kk);
+	std::vector<uint32_t> row(kk);
 	uint32_t cnt = 0;
 	if (!trained_) {   // the flat phase: IndexFlat::search
 		if (rxgpu_search_knn(dev_, q.data(), 1, uint32_t(k), dist.data(), row.data(), &cnt) != RXGPU_OK) throwDevice("GpuIvfFlat::Search");
 	} else {
 		if (std::min(std::max<size_t>(nprobe, 1), nlist_) <= 64) {   // everything on the device: no list ids, no row list through the host
 			syncLists();
-			if (rxgpu_search_knn_lists(dev_, devCentroids_, q.data(), uint32_t(nprobe), uint32_t(k), dist.data(), row.data(), &cnt, nullptr) != RXGPU_OK) {
+			if (rxgpu_search_knn_lists(dev_, devCentroids_, q.data(), uint32_t(nprobe), uint32_t(kk), dist.data(), row.data(), &cnt, nullptr) != RXGPU_OK) {
 				throwDevice("GpuIvfFlat::Search");
 			}
 		} else {
@@ -392,14 +426,98 @@ void GpuIvfFlat::Search(const float* x, size_t k, size_t nprobe, float* distance
 			for (uint32_t l : probe) runs.push_back(&lists_[l]);
 			const std::vector<uint32_t> rows = SortedUnion(runs, count_);
 			if (rows.empty()) return;
-			if (rxgpu_search_knn_subset(dev_, q.data(), 1, uint32_t(k), rows.data(), rows.size(), dist.data(), row.data(), &cnt) != RXGPU_OK) {
+			if (rxgpu_search_knn_subset(dev_, q.data(), 1, uint32_t(kk), rows.data(), rows.size(), dist.data(), row.data(), &cnt) != RXGPU_OK) {
 				throwDevice("GpuIvfFlat::Search");
 			}
 		}
 	}
-	for (uint32_t i = 0; i < cnt; ++i) {
+	if (trained_ && cnt > k && dist[k] == dist[k - 1]) {   // more candidates at the k-th distance than places: the scanner's order decides
+		replayTies(q.data(), k, nprobe, dist[k - 1], distances, labels);
+		return;
+	}
+	const uint32_t n = uint32_t(std::min<size_t>(cnt, k));
+	for (uint32_t i = 0; i < n; ++i) {
 		distances[i] = toFaiss(dist[i]);
 		labels[i] = ids_[row[i]];
+	}
+	if (trained_) orderTies(n, distances, labels);
+}
+
+// Equal distances inside a result: heap_reorder (utils/Heap.h) pops the heap top into the last free place.  The top of the CMax heap (L2)
+// is the maximum by (distance, id) => ties end up by id ascending; the top of the CMin heap (inner product / cosine) is the minimum by
+// (similarity, id) => ties end up by id DESCENDING.
+void GpuIvfFlat::orderTies(size_t n, float* distances, idx_t* labels) const {
+	for (size_t a = 0; a < n;) {
+		size_t b = a + 1;
+		while (b < n && distances[b] == distances[a]) ++b;
+		if (b - a > 1) {
+			if (metric_ == VectorMetric::L2) {
+				std::sort(labels + a, labels + b);
+			} else {
+				std::sort(labels + a, labels + b, std::greater<idx_t>());
+			}
+		}
+		a = b;
+	}
+}
+
+// IndexIVFFlat's scanner (IndexIVFFlat.cpp, scan_codes) walks the probed lists in coarse order and every list in storage order and takes
+// a vector only if it is STRICTLY better than the heap top; the top is the worst entry by (distance, id) (L2) resp. by (similarity, id)
+// (inner product / cosine: among equal similarities the SMALLEST id is evicted first) — heap_replace_top compares with cmp2.  With ties
+// at the k-th place the result therefore depends on the scan order.  Only the candidates at or below the k-th distance can be in the
+// result or influence it, so: all of them from the device (range search over the probed rows, bound = the next float after `worst`),
+// put into scan order, and the scanner's rule replayed over them.
+void GpuIvfFlat::replayTies(const float* q, size_t k, size_t nprobe, float worst, float* distances, idx_t* labels) const {
+	std::vector<uint32_t> probe;
+	coarse(q, nprobe, probe);
+	std::vector<const std::vector<uint32_t>*> runs;
+	for (uint32_t l : probe) runs.push_back(&lists_[l]);
+	const std::vector<uint32_t> rows = SortedUnion(runs, count_);
+	const float bound = std::nextafter(worst, std::numeric_limits<float>::infinity());
+	std::vector<float> dist(k + 64);
+	std::vector<uint32_t> row(k + 64);
+	uint64_t total = 0;
+	for (;;) {
+		const int rc = rxgpu_search_range_subset(dev_, q, bound, 0, rows.data(), rows.size(), dist.data(), row.data(), dist.size(), &total);
+		if (rc == RXGPU_OK) break;
+		if (rc != RXGPU_ERR_OVERFLOW) throwDevice("GpuIvfFlat::Search (ties)");
+		dist.resize(total);
+		row.resize(total);
+	}
+	// scan order: (position of the row's list in the probe order, position inside the list)
+	std::vector<uint32_t> probeRank(nlist_, 0xFFFFFFFFu);
+	for (size_t i = 0; i < probe.size(); ++i) probeRank[probe[i]] = uint32_t(i);
+	struct Cand {
+		uint64_t order;
+		float dist;
+		idx_t id;
+	};
+	std::vector<Cand> cands(total);
+	for (uint64_t i = 0; i < total; ++i) {
+		const uint32_t r = row[i];
+		cands[i] = {(uint64_t(probeRank[listOf_[r]]) << 32) | scanPos_[r], dist[i], ids_[r]};
+	}
+	std::sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b) { return a.order < b.order; });
+	const bool l2 = metric_ == VectorMetric::L2;
+	// "worse" = closer to the heap top: larger internal distance; among equals the larger id (L2) resp. the smaller id (similarities)
+	auto worse = [l2](const Cand& a, const Cand& b) { return a.dist != b.dist ? a.dist > b.dist : (l2 ? a.id > b.id : a.id < b.id); };
+	auto heapLess = [&](const Cand& a, const Cand& b) { return worse(b, a); };   // std heap: the "largest" (= worst) on top
+	std::vector<Cand> heap;
+	heap.reserve(k);
+	for (const Cand& c : cands) {
+		if (heap.size() < k) {
+			heap.push_back(c);
+			std::push_heap(heap.begin(), heap.end(), heapLess);
+		} else if (heap.front().dist > c.dist) {
+			std::pop_heap(heap.begin(), heap.end(), heapLess);
+			heap.back() = c;
+			std::push_heap(heap.begin(), heap.end(), heapLess);
+		}
+	}
+	std::sort(heap.begin(), heap.end(), [&](const Cand& a, const Cand& b) { return worse(b, a); });   // best first; ties as heap_reorder leaves them
+	for (size_t i = 0; i < heap.size(); ++i) {
+		distances[i] = toFaiss(heap[i].dist);
+		labels[i] = heap[i].id;
 	}
 }
 

@@ -95,6 +95,11 @@ private:
 	void reserveRows(size_t need);
 	void listInsert(uint32_t list, uint32_t row);
 	void listErase(uint32_t list, uint32_t row);
+	void listRename(uint32_t list, uint32_t from, uint32_t to);   // a row number changes (swap-delete of the flat storage)
+	void scanAppend(uint32_t list, uint32_t row);
+	// faiss tie semantics over the candidates with internal distance <= worst (see Search)
+	void replayTies(const float* q, size_t k, size_t nprobe, float worst, float* distances, idx_t* labels) const;
+	void orderTies(size_t n, float* distances, idx_t* labels) const;
 	float toFaiss(float internal) const noexcept { return metric_ == VectorMetric::L2 ? internal : -internal; }
 
 	const VectorMetric metric_;
@@ -109,6 +114,11 @@ private:
 	std::vector<uint32_t> listOf_;   // [count], valid once trained
 	std::unordered_map<idx_t, uint32_t> idToRow_;   // DirectMap::Hashtable (ivf_index.cc:470)
 	std::vector<std::vector<uint32_t>> lists_;      // per centroid: its rows, ascending
+	// the same lists in faiss::ArrayInvertedLists order — append on add, the list's last entry moves into the hole on remove
+	// (DirectMap::remove_ids, Hashtable type) — and every row's position there.  Only exact ties in a search read it: the scanner keeps
+	// the first-scanned of equal distances at the k-th place (IndexIVFFlat.cpp scan_codes: `if (C::cmp(simi[0], dis))` is strict).
+	std::vector<std::vector<uint32_t>> scan_;
+	std::vector<uint32_t> scanPos_;                 // [count]
 	std::vector<float> centroids_;   // [nlist][dim]
 
 	void syncLists() const;                     // CSR mirror of lists_ in HBM (rxgpu_index_set_lists), rebuilt after a mutation

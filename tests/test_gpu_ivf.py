@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 from .conftest import lex_topk, make_corpus
+from .test_ivf_oracle import check_topk_whatever_the_tie_rule
 
 pytestmark = pytest.mark.gpu
 
@@ -92,17 +93,15 @@ def test_ivf_equals_exact_search_over_the_probed_lists(hostapi, oracle, metric):
         for nprobe in (1, 4, 16, nlist):
             cand = ivf.probed_rows(q, nprobe)
             assert np.all(np.diff(cand.astype(np.int64)) > 0)
+            full = oracle.dist_many(metric, qp, rows[cand], inv_all[cand] if inv_all is not None else None)
             for k in (1, 10, 100, 300):
                 gd, gl = ivf.search(q, k, nprobe=nprobe)
-                wd, wr = exact(qp, cand, k)
-                m = wr.size
-                assert np.array_equal(gl[:m], ids[wr]), (metric, nprobe, k)
-                assert np.array_equal(bits(gd[:m] * sign), bits(wd))
-                assert np.all(gl[m:] == -1)
+                # (which of several vectors AT the k-th distance are kept, and the order of equal distances, follow FAISS's scanner:
+                # test_ties_follow_the_faiss_scanner; here the answer is checked without assuming a tie rule)
+                check_topk_whatever_the_tie_rule(gd * sign, gl, full, ids[cand], k)
             if nprobe == nlist:
                 assert cand.size == n   # every list probed == exact search
             # range search over the same lists
-            full = oracle.dist_many(metric, qp, rows[cand], inv_all[cand] if inv_all is not None else None)
             radius_internal = float(np.sort(full)[min(25, full.size - 1)])
             gd, gl = ivf.range_search(q, radius_internal * sign, nprobe=nprobe, cap=4)
             keep = full < radius_internal
@@ -126,8 +125,8 @@ def test_ivf_equals_exact_search_over_the_probed_lists(hostapi, oracle, metric):
     for q in queries[:10]:
         qp = oracle.normalize_copy(q)[0] if metric == 2 else q
         gd, gl = ivf.search(q, 20, nprobe=nlist)   # all lists probed: must equal the exact search over the survivors
-        wd, wr = exact(qp, alive_rows, 20)
-        assert np.array_equal(np.sort(gl), np.sort(ids[wr])) and np.array_equal(bits(np.sort(gd * sign)), bits(np.sort(wd)))
+        full = oracle.dist_many(metric, qp, rows[alive_rows], inv_all[alive_rows] if inv_all is not None else None)
+        check_topk_whatever_the_tie_rule(gd * sign, gl, full, ids[alive_rows], 20)
         assert not (set(gl.tolist()) & set(ids[victims].tolist()))
     with pytest.raises(hostapi.HostError, match="already present"):
         ivf.add_with_ids(rows[:1], ids[alive_rows[:1]])
@@ -174,6 +173,45 @@ def test_training_equals_vendored_faiss_bit_for_bit(hostapi, metric, n, d, nlist
         gd, gl = g.search(q, 10, nprobe)
         rd, rl = ref.search(qref, 10, nprobe)
         assert np.array_equal(gl, rl) and np.array_equal(bits(gd), bits(rd))
+    g.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_ties_follow_the_faiss_scanner(hostapi, metric):
+    """Exact copies among the vectors: equal distances inside a result and at its k-th place.  FAISS's scanner keeps the first-scanned of
+    equal distances at the boundary and evicts by (distance, id) resp. (similarity, id); GpuIvfFlat replays that over the tied candidates
+    (scan order = probed lists in coarse order, every list in ArrayInvertedLists order, which remove_ids reshuffles).  Labels AND their
+    order must be the vendored FAISS's, before and after removals, through the device list search (nprobe <= 64)."""
+    from oracle.pyoracle import RefIvf, ref_ivf_available
+    if not ref_ivf_available():
+        pytest.skip("oracle/_ref/libref_ivf.so not built")
+    rng = np.random.default_rng(60 + metric)
+    n, d, nlist = 4000, 12, 16
+    base = clustered(80 + metric, n, d, 12)
+    rows = np.where((rng.random(n) < 0.35)[:, None], base[rng.integers(0, n, n)], base).astype(np.float32)
+    ids = rng.permutation(n * 3)[:n].astype(np.int64)
+    ref = RefIvf(metric, d, nlist, rows, ids, exact_assignment=True)
+    g = hostapi.GpuIvfFlat(metric, d, nlist)
+    g.add_with_ids(rows, ids)
+    g.train()
+    alive = np.ones(n, bool)
+    boundary_ties = 0
+    for round_ in range(3):
+        for _ in range(30):
+            q = (rows[rng.integers(0, n)] + rng.normal(0, 0.02, d)).astype(np.float32)
+            qref = hostapi.normalize_copy(q)[0] if metric == 2 else q
+            nprobe, k = int(rng.integers(1, nlist + 1)), int(rng.choice([1, 3, 10, 50]))
+            gd, gl = g.search(q, k, nprobe)
+            rd, rl = ref.search(qref, k, nprobe)
+            assert np.array_equal(gl, rl), (metric, round_, nprobe, k, gl[:12], rl[:12])
+            assert np.array_equal(bits(gd[rl >= 0]), bits(rd[rl >= 0]))
+            rd1, _ = ref.search(qref, k + 1, nprobe)
+            boundary_ties += int(k < len(rd1) and rd1[k] == rd1[k - 1] and np.isfinite(rd1[k]))
+        victims = ids[rng.choice(np.flatnonzero(alive), 500, replace=False)]
+        assert ref.remove_ids(victims) == 500 and g.remove_ids(victims) == 500
+        alive &= ~np.isin(ids, victims)
+    assert boundary_ties > 5
     g.close()
     ref.close()
 

@@ -46,6 +46,106 @@ def restated_ivf(oracle, metric, q, cent, lists_rows, rows, inv, nprobe):
     return oracle.dist_many(metric, q, rows[cand], inv[cand] if inv is not None else None), cand
 
 
+def check_topk_whatever_the_tie_rule(got_dist, got_labels, cand_dist, cand_ids, k):
+    """A top-k answer checked without assuming how equal distances are ordered or which of several candidates AT the k-th distance were
+    kept (FAISS decides both by scan order and id; a (distance, row) order decides them differently): the distance bits, place by place;
+    every label's own distance at its place; no label twice; everything strictly better than the k-th distance present; -1 behind the
+    last hit.  got_dist / cand_dist are internal distances (smaller = closer)."""
+    cand_dist = np.asarray(cand_dist, np.float32)
+    cand_ids = np.asarray(cand_ids)
+    m = min(k, cand_dist.size)
+    want = np.sort(cand_dist, kind="stable")[:m]
+    assert np.array_equal(np.asarray(got_dist[:m], np.float32).view(np.uint32), want.view(np.uint32))
+    assert np.all(np.asarray(got_labels[m:]) == -1)
+    got = [int(x) for x in got_labels[:m]]
+    assert len(set(got)) == m
+    where = {int(i): j for j, i in enumerate(cand_ids.tolist())}
+    for j, lab in enumerate(got):
+        assert lab in where and cand_dist[where[lab]].view(np.uint32) == want[j].view(np.uint32), (j, lab)
+    if m:
+        assert set(cand_ids[cand_dist < want[m - 1]].tolist()) <= set(got)
+
+
+def test_tie_agnostic_checker_accepts_both_rules_and_rejects_wrong_answers():
+    rng = np.random.default_rng(0)
+    dist = rng.integers(0, 12, 200).astype(np.float32) / 4         # many ties
+    ids = rng.permutation(1000)[:200].astype(np.int64)
+    for k in (1, 7, 50, 200, 300):
+        for l2 in (True, False):
+            d, l = faiss_topk(dist, ids, k, l2)
+            pad = max(0, k - len(l))
+            check_topk_whatever_the_tie_rule(np.concatenate([d, np.full(pad, np.inf, np.float32)]), np.concatenate([l, np.full(pad, -1)]), dist, ids, k)
+        o = np.lexsort((ids, dist))[:k]                              # the (distance, id) order
+        pad = max(0, k - len(o))
+        check_topk_whatever_the_tie_rule(np.concatenate([dist[o], np.full(pad, np.inf, np.float32)]), np.concatenate([ids[o], np.full(pad, -1)]), dist, ids, k)
+    d, l = faiss_topk(dist, ids, 7, True)
+    bad = l.copy()
+    bad[0] = ids[np.argmax(dist)]                                    # a label whose distance is not the one reported
+    with pytest.raises(AssertionError):
+        check_topk_whatever_the_tie_rule(d, bad, dist, ids, 7)
+    with pytest.raises(AssertionError):
+        check_topk_whatever_the_tie_rule(d, np.concatenate([l[:6], l[:1]]), dist, ids, 7)   # a label twice
+    with pytest.raises(AssertionError):
+        check_topk_whatever_the_tie_rule(d + 1, l, dist, ids, 7)     # wrong distances
+
+
+def faiss_topk(dist, ids, k, l2):
+    """What IndexIVFFlat's scanner leaves in its heap when it meets the candidates in THIS order (the probed lists in coarse order, every
+    list in storage order): a candidate enters only if it is strictly better than the heap top (IndexIVFFlat.cpp scan_codes,
+    `if (C::cmp(simi[0], dis))`), the top is the worst entry by (distance, id) for L2 (CMax) resp. by (similarity, id) for inner product /
+    cosine (CMin: among equal similarities the smallest id leaves first) — heap_replace_top orders with cmp2 (utils/Heap.h:112-150) — and
+    heap_reorder lists ties by id ascending (L2) resp. descending.  `dist` are internal distances (smaller = closer)."""
+    import heapq
+    sg = 1 if l2 else -1
+    heap = []          # (-dist, -sg * id): heapq's minimum is the FAISS heap top
+    for d, i in zip(np.asarray(dist, np.float32).tolist(), np.asarray(ids).tolist()):
+        if len(heap) < k:
+            heapq.heappush(heap, (-d, -sg * i))
+        elif -heap[0][0] > d:
+            heapq.heapreplace(heap, (-d, -sg * i))
+    out = sorted((-a, -b) for a, b in heap)
+    return np.array([o[0] for o in out], np.float32), np.array([sg * o[1] for o in out], np.int64)
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_faiss_tie_rule_on_duplicate_heavy_data(oracle, faiss_ready, metric):
+    """A third of the vectors are exact copies of others: equal distances everywhere, at the k-th place in particular.  The restated
+    definition with the scanner's tie rule must give FAISS's labels in FAISS's order, also after remove_ids reshuffled the lists (the last
+    entry of a list moves into the hole)."""
+    rng = np.random.default_rng(40 + metric)
+    n, d, nlist = 3000, 12, 16
+    base = clustered(31 + metric, n, d)
+    rows = np.where((rng.random(n) < 0.35)[:, None], base[rng.integers(0, n, n)], base).astype(np.float32)
+    ids = rng.permutation(n * 3)[:n].astype(np.int64)
+    f = faiss_ready.RefIvf(metric, d, nlist, rows, ids)
+    sign = 1.0 if metric == 0 else -1.0
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    alive = np.ones(n, bool)
+    boundary_ties = 0
+    for round_ in range(2):
+        cent, lists = f.export()
+        row_of = {int(l): i for i, l in enumerate(ids)}
+        lists_rows = [np.array([row_of[int(x)] for x in l], np.int64) for l in lists]
+        for _ in range(40):
+            q = (rows[rng.integers(0, n)] + rng.normal(0, 0.02, d)).astype(np.float32)
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            nprobe, k = int(rng.integers(1, nlist + 1)), int(rng.choice([1, 3, 10, 50]))
+            dist, cand = restated_ivf(oracle, metric, q, cent, lists_rows, rows, inv, nprobe)
+            wd, wl = faiss_topk(dist, ids[cand], k, metric == 0)
+            fd, fl = f.search(q, k, nprobe)
+            m = min(k, cand.size)
+            assert np.array_equal(fl[:m], wl[:m]), (metric, round_, nprobe, k)
+            assert np.array_equal(bits(fd[:m] * sign), bits(wd[:m])) and np.all(fl[m:] == -1)
+            sd = np.sort(dist)
+            boundary_ties += int(cand.size > k and sd[k - 1] == sd[k])
+        victims = ids[rng.choice(np.flatnonzero(alive), 400, replace=False)]
+        assert f.remove_ids(victims) == 400
+        alive &= ~np.isin(ids, victims)
+    assert boundary_ties > 10
+    f.close()
+
+
 @pytest.mark.parametrize("metric", [0, 1, 2])
 def test_ivf_search_definition_equals_real_faiss(oracle, faiss_ready, metric):
     n, d, nlist = 9000, 48, 32
