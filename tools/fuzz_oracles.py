@@ -229,7 +229,9 @@ def fuzz_packed(orc, ref, rng, seconds):
     while time.time() - t0 < seconds:
         nf = int(rng.integers(1, 7))
         s = make_pos_postings(rng, int(rng.choice([3000, 200_000, 50_000_000])), nf, int(rng.integers(1, 1500)), 1.0,
-                              array_fields=bool(rng.integers(0, 2)), max_pos=int(rng.choice([8, 300, 1 << 20, (1 << 28) - 1])))
+                              array_fields=bool(rng.integers(0, 2)), max_pos=int(rng.choice([8, 300, 1 << 14, 1 << 20])))
+        # (positions near 2^28 overrun IdRelType::maxpackedsize() in the reference's own insert_back — its assertion, idrelset.h:258 —
+        # so the live packer is not fed with them; the test-side packer covers that range in tests/test_ft_packed_decode.py)
         data, afp = real.pack(s)
         mine, mine_afp = pack_postings(s["doc"], s["pos_off"], s["fpos"])
         ok = np.array_equal(mine, data) and (mine_afp == afp or (afp >= len(data) and mine_afp == len(data)))
