@@ -15,7 +15,8 @@ Extra legs (rank 0, N = 1 only, outside the timed region; each leg is skipped â€
   batched / pruned_scan / prefilter   the other brute-force kernels at the same 10M x 768 shape
   cpu_baseline  the reference's own BruteforceSearch (oracle/_ref, AVX-512 path) built over the FULL corpus on the host: measured,
                 un-scaled, 1 thread and all hardware threads (thread start outside the timed region)
-  parity        GPU result vs that CPU result on the same FULL corpus (ids must be identical, distance bits too)
+  parity        GPU result vs that CPU result on the same FULL corpus (ids must be identical, distance bits too): every query through
+                the timed batch-1 kernel, then in one batched call; ip / l2 / cosine each against a reference index of that metric
   hnsw          BASELINE configs[2] (scaled to --hnsw-rows): graph built here by the product's concurrent builder, searched on the GPU and by
                 the reference's own engine on the same graph (tools/bench_hnsw.py)
   hybrid        BASELINE configs[4]: BM25 merge + KNN + RRF fusion on the GPU vs the reference's merger / brute force / rank merger
@@ -73,11 +74,16 @@ def parse_args():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="ip", choices=["l2", "ip", "cosine"])
-    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="only for the plain-C port fallback (no oracle/_ref): row-prefix sample")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000, help="only used when oracle/_ref is absent (never on the driver's box: "
+                                                                            "the prebuilt reference library travels with the repo)")
     ap.add_argument("--cpu-queries", type=int, default=8, help="queries of the 1-thread CPU leg = queries of the full-size parity check")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-core CPU leg (0 = every CPU the container may use: "
                                                                "min(affinity, cgroup quota), tools/cpu_scaling.py)")
     ap.add_argument("--cpu-per-thread", type=int, default=8)
+    ap.add_argument("--parity-other-queries", type=int, default=2, help="full-size parity of the two metrics that are not --metric: queries each "
+                                                                         "(a reference index per metric is built over all rows; 0 = skip)")
+    ap.add_argument("--parity-deadline", type=float, default=150.0, help="no further per-metric reference index is built once the CPU leg "
+                                                                          "has run this many seconds")
     ap.add_argument("--cpu-deadline", type=float, default=40.0, help="all-core CPU leg: threads stop STARTING searches after this many seconds")
     ap.add_argument("--scaling", default=os.environ.get("RXGPU_BENCH_SCALING", "weak"), choices=["weak", "strong"])
     ap.add_argument("--total-rows", type=int, default=80_000_000, help="--scaling strong: the fixed corpus, split over the ranks")
@@ -143,6 +149,7 @@ def _numa_interleave(on: bool) -> bool:
 def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, metric_id: int, ix):
     """Full-size CPU leg: the reference's BruteforceSearch over ALL rows of the corpus (bruteforce.cc:103-127), measured â€” nothing is scaled."""
     from oracle import pyoracle  # checker / baseline only
+    t_leg = time.perf_counter()
     ref = pyoracle.ref_or_none()
     if ref is None or ref.simd_level != 3 or not hasattr(ref.L, "ref_bf_search_knn_mt"):
         return cpu_baseline_port_sample(args, corpus, queries, metric_id)
@@ -183,20 +190,74 @@ def cpu_baseline_and_parity(args, corpus: torch.Tensor, queries: torch.Tensor, m
                               "the container may use (cgroup quota, see host) â€” more threads only add throttling (profiles/r2b_cpu_scaling.json)"},
         "numa_interleaved": interleaved, "index_load_seconds": load_s, "host": host_cpu_info(),
     }
-    # parity on the FULL corpus: GPU through the C-ABI vs the reference engine
+    # parity on the FULL corpus: GPU through the C-ABI vs the reference engine.  The kernel that `value` times is the batch-1 scan
+    # (knn_scan_fixed): the queries go through it one call each (nq = 1); the same queries in ONE call (nq = 8: bf16 nomination +
+    # exact re-score) are the second check.  Then the other two metrics over the same resident rows, each against a reference index
+    # of that metric built over all rows.
+    parity = _compare_with_reference(ix, host_q[:nq], cpu_res, args.k)
+    parity.update({"rows": rows, "path": "batch1", "metric": args.metric,
+                   "against": "reference BruteforceSearch over the full corpus; every query through the timed batch-1 kernel (nq = 1 per call)"})
+    parity["batched_call"] = _compare_with_reference(ix, host_q[:nq], cpu_res, args.k, one_call=True)
+    per_metric = {args.metric: {k_: parity[k_] for k_ in ("ids_equal_frac", "max_ulps_dist", "queries")}}
+    nq_other = min(args.parity_other_queries, nq)
+    for other in ("ip", "l2", "cosine"):
+        if other == args.metric or nq_other == 0:
+            continue
+        if time.perf_counter() - t_leg > args.parity_deadline:
+            per_metric[other] = {"skipped": "parity deadline (--parity-deadline)"}
+            continue
+        per_metric[other] = _parity_other_metric(args, corpus, queries, capi.METRICS[other], nq_other, ref, ncores)
+    parity["per_metric"] = per_metric
+    return baseline, parity
+
+
+def _compare_with_reference(ix, host_q, cpu_res, k, one_call=False):
     labels_of = lambda r: r.astype(np.uint64) << np.uint64(32)  # noqa: E731
-    dist, row, cnt = ix.search_knn(host_q[:nq], args.k + 1)
+    nq = host_q.shape[0]
+    if one_call:
+        dist, row, cnt = ix.search_knn(host_q, k + 1)
+    else:
+        parts = [ix.search_knn(host_q[i:i + 1], k + 1) for i in range(nq)]
+        dist, row = np.concatenate([p_[0] for p_ in parts]), np.concatenate([p_[1] for p_ in parts])
     ids_equal, max_ulps, rec = 0, 0, 0.0
     for i in range(nq):
         wd, wl = cpu_res[i]
-        gl = labels_of(row[i, :args.k])
+        gl = labels_of(row[i, :k])
         ids_equal += int(np.array_equal(gl, wl))
-        ulps = np.abs(dist[i, :args.k].view(np.int32).astype(np.int64) - wd.view(np.int32).astype(np.int64))
+        ulps = np.abs(dist[i, :k].view(np.int32).astype(np.int64) - wd.view(np.int32).astype(np.int64))
         max_ulps = max(max_ulps, int(ulps.max()))
-        rec += len(set(gl.tolist()) & set(wl.tolist())) / args.k
-    parity = {"ids_equal_frac": ids_equal / nq, "max_ulps_dist": max_ulps, "queries": nq, "rows": rows, "recall_at_k": rec / nq,
-              "against": "reference BruteforceSearch over the full corpus"}
-    return baseline, parity
+        rec += len(set(gl.tolist()) & set(wl.tolist())) / k
+    return {"ids_equal_frac": ids_equal / nq, "max_ulps_dist": max_ulps, "queries": nq, "recall_at_k": rec / nq,
+            "path": "nq=%d in one call (bf16 nomination + exact re-score)" % nq if one_call else "batch1"}
+
+
+def _parity_other_metric(args, corpus, queries, metric_id, nq, ref, threads):
+    """The same resident rows under another metric: a reference index of that metric over ALL rows vs the batch-1 scan of that metric.
+    Cosine: the query is normalised on the host and 1/|row| comes from the product's own AddNorm arithmetic (hostapi)."""
+    from oracle import pyoracle
+    from reindexer_amd import hostapi
+    rows = corpus.shape[0]
+    host_q = queries[:nq].cpu().numpy()
+    if metric_id == 2:
+        host_q = np.stack([hostapi.normalize_copy(q)[0] for q in host_q])
+    inv = np.empty(rows, np.float32) if metric_id == 2 else None
+    _numa_interleave(True)
+    bf = pyoracle.RefBruteforce(ref, metric_id, args.dim, rows)
+    chunk = 1 << 20
+    for a in range(0, rows, chunk):
+        b = min(rows, a + chunk)
+        blk = corpus[a:b].cpu().numpy()
+        bf.add(blk, np.arange(a, b, dtype=np.uint64) << np.uint64(32))
+        if inv is not None:
+            inv[a:b] = hostapi.l2_modules_many(blk, threads)
+    _numa_interleave(False)
+    cpu_res = [bf.search_knn(host_q[i], args.k) for i in range(nq)]
+    bf.close()
+    d_inv = torch.from_numpy(inv).to(corpus.device) if inv is not None else None
+    with capi.VectorIndex(metric_id, args.dim, device=corpus.device.index or 0) as mx:
+        mx.adopt_device_rows(corpus.data_ptr(), rows, args.dim, d_inv.data_ptr() if d_inv is not None else None, keepalive=(corpus, d_inv))
+        out = _compare_with_reference(mx, host_q, cpu_res, args.k)
+    return {k_: out[k_] for k_ in ("ids_equal_frac", "max_ulps_dist", "queries")}
 
 
 def cpu_baseline_port_sample(args, corpus: torch.Tensor, queries: torch.Tensor, metric_id: int):
@@ -510,7 +571,7 @@ def main():
             result["pruned_scan"] = leg("pruned_scan", 5, lambda: pruned_leg(args, ix, queries, device, kk))
             result["prefilter"] = leg("prefilter", 5, lambda: prefilter_leg(args, ix, queries, device, kk))
         if extra and not args.no_cpu:
-            out = leg("cpu_baseline", 60, lambda: cpu_baseline_and_parity(args, corpus, queries, metric_id, ix))
+            out = leg("cpu_baseline", 90, lambda: cpu_baseline_and_parity(args, corpus, queries, metric_id, ix))
             if isinstance(out, tuple):
                 result["cpu_baseline"], result["parity"] = out
             else:

@@ -48,11 +48,26 @@ def _run(cmd: list[str]) -> None:
 
 
 def build_device(force: bool = False) -> Path:
+    """One object per .hip translation unit (compiled in parallel, only the stale ones), then one link.  No relocatable device code:
+    no kernel calls device code of another unit."""
+    from concurrent.futures import ThreadPoolExecutor
     out = PKG / "librxgpu.so"
+    objdir = PKG / "build" / "obj"
+    objdir.mkdir(parents=True, exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip"))
-    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(INCLUDE.glob("*.h"))
-    if force or _stale(out, deps):
-        _run([HIPCC, *HIP_FLAGS, *srcs, "-o", out, "-Wl,-rpath,/opt/rocm/lib"])
+    headers = sorted(CSRC.glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    flags = [f for f in HIP_FLAGS if f != "-shared"]
+    todo = []
+    for src in srcs:
+        obj = objdir / (src.stem + ".o")
+        if force or _stale(obj, [src] + headers):
+            todo.append((src, obj))
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(lambda so: _run([HIPCC, *flags, "-c", so[0], "-o", so[1]]), todo))
+    objs = [objdir / (src.stem + ".o") for src in srcs]
+    if force or todo or _stale(out, objs):
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-Wl,-rpath,/opt/rocm/lib"])
     return out
 
 

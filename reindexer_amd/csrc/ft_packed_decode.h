@@ -98,6 +98,10 @@ RX_HD inline FtPackedCounts ft_decode_packed(const uint8_t* data, uint64_t len, 
 		}
 		if (ok && !size_is_1) {
 			ok = ft_packed_varint(p, end, size);
+			if (ok && size == 0xFFFFFFFFu) {   // size - 1 is stored: this one would wrap to a posting without positions
+				c.status = kFtPackedTooLong;
+				break;
+			}
 			size += 1;
 		}
 		if (!ok) {

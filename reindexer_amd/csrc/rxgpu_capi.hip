@@ -913,7 +913,10 @@ int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t
 	RX_CHECK(queries && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_search_knn: null argument");
 	if (h->shard_set) {
 		if (nq == 0) return RXGPU_OK;
-		RX_CHECK(kk >= 1, RXGPU_ERR_PARAMS, "rxgpu_search_knn: kk must be >= 1");
+		if (h->count == 0 || kk == 0) {   // bruteforce.cc:106-108, as on a single device
+			std::fill(out_count, out_count + nq, 0u);
+			return RXGPU_OK;
+		}
 		return rxgpu::sharded_search_knn_impl(h, queries, nq, kk, nullptr, 0, out_dist, out_row, out_count);
 	}
 	if (nq == 0) return RXGPU_OK;

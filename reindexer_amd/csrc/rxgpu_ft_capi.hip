@@ -44,6 +44,7 @@ struct rxgpu_ft_word {
 	uint32_t* pos_off = nullptr;   // only for words uploaded with their positions (multi-term merge)
 	uint32_t* range_off = nullptr; // [n_ranges]: first posting with doc >= k * kFtRangeDocs (ft_ranges finds its segment of the list here)
 	uint32_t n_ranges = 0;
+	uint32_t last_doc = 0;         // largest document id of the list: checked against total_docs when a merge uses the word
 	uint64_t* fpos = nullptr;
 	std::shared_ptr<void> pool;    // set for words decoded on the device (rxgpu_ft_set_words_packed): the arrays are slices of one allocation
 	void release() {
@@ -225,6 +226,7 @@ int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uin
 	}
 	w.n = n;
 	w.nent = nent;
+	w.last_doc = doc[n - 1];
 	return RXGPU_OK;
 }
 
@@ -286,6 +288,10 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
 			auto it = h->words.find(word_ids[si]);
 			RX_CHECK(it != h->words.end(), RXGPU_ERR_NOTFOUND, std::string(who) + ": unknown word id");
+			// the kernels index words_in_field[doc * fields + f] and an (N + 31) / 32-word mask by document: a list reaching past the
+			// documents rxgpu_ft_set_docs described would read and write out of bounds (set_docs may follow the words, so it is checked here)
+			RX_CHECK(it->second.n == 0 || it->second.last_doc < N, RXGPU_ERR_PARAMS,
+					 std::string(who) + ": a posting list holds a document id >= total_docs (rxgpu_ft_set_docs)");
 			term_postings[t] += it->second.n;
 		}
 		total_vids += term_postings[t];   // totalORVids: MaxVDocs of every term, whatever its operator (selecterimpl.h:546)
@@ -735,6 +741,7 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 		if (!c.n) continue;
 		w.n = c.n;
 		w.nent = c.nent;
+		w.last_doc = c.last_doc;
 		w.doc = outs[k].doc;
 		w.ent_off = outs[k].ent_off;
 		w.ent_field = outs[k].ent_field;

@@ -7,8 +7,11 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <exception>
 #include <functional>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,39 +23,36 @@ using rxgpu::set_error;
 
 namespace rxgpu {
 
-// One worker thread per shard: the shard's device stays current on it, calls into the single-device entry points are serialised per shard
-// and run concurrently across shards.
+// A small pool of worker threads per shard (the shard's device stays current on them) behind one job queue: fan-outs of concurrent
+// callers queue up per shard and overlap — the single-device entry points are re-entrant (a search context and stream per call) — so
+// no lock is held across a fan-out.  Searches share `call_mtx`, mutations take it exclusively (the reference's namespace lock above us
+// does the same; this one only protects direct C-ABI callers).
 struct ShardWorker {
-	std::thread thread;
+	static constexpr unsigned kThreads = 4;
+	std::vector<std::thread> threads;
 	std::mutex mtx;
 	std::condition_variable cv;
-	std::function<void()> job;
-	bool has_job = false, stop = false, done = false;
+	std::deque<std::function<void()>> jobs;
+	bool stop = false;
 
 	void run() {
 		std::unique_lock<std::mutex> lk(mtx);
 		for (;;) {
-			cv.wait(lk, [&] { return has_job || stop; });
-			if (stop) return;
-			auto fn = std::move(job);
+			cv.wait(lk, [&] { return !jobs.empty() || stop; });
+			if (jobs.empty()) return;   // stop requested and nothing left
+			auto fn = std::move(jobs.front());
+			jobs.pop_front();
 			lk.unlock();
 			fn();
 			lk.lock();
-			has_job = false;
-			done = true;
-			cv.notify_all();
 		}
 	}
-	void start(std::function<void()> fn) {
-		std::lock_guard<std::mutex> lk(mtx);
-		job = std::move(fn);
-		done = false;
-		has_job = true;
-		cv.notify_all();
-	}
-	void wait() {
-		std::unique_lock<std::mutex> lk(mtx);
-		cv.wait(lk, [&] { return done; });
+	void post(std::function<void()> fn) {
+		{
+			std::lock_guard<std::mutex> lk(mtx);
+			jobs.push_back(std::move(fn));
+		}
+		cv.notify_one();
 	}
 };
 
@@ -60,23 +60,64 @@ struct ShardSet {
 	std::vector<rxgpu_index*> shards;
 	std::vector<ShardWorker*> workers;
 	uint64_t shard_rows = 0;
-	std::mutex call_mtx;   // one fan-out at a time (the Maps coalesce concurrent queries into batches above this layer)
+	std::shared_mutex call_mtx;   // shared: searches (any number of fan-outs in flight); exclusive: uploads, moves, truncation
 };
 
 namespace {
+
+// completion latch of one fan-out (lives on the caller's stack)
+struct FanOut {
+	std::mutex m;
+	std::condition_variable cv;
+	size_t left;
+	explicit FanOut(size_t n) : left(n) {}
+	void arrive() {
+		std::lock_guard<std::mutex> lk(m);
+		if (--left == 0) cv.notify_all();
+	}
+	void wait() {
+		std::unique_lock<std::mutex> lk(m);
+		cv.wait(lk, [&] { return left == 0; });
+	}
+};
+
+// runs fn on the worker pool of shard s and waits; an exception inside (bad_alloc while staging) becomes RXGPU_ERR_NOMEM
+int run_on_shard(ShardSet* ss, size_t s, const std::function<int()>& fn, std::string& err) {
+	int rc = RXGPU_OK;
+	FanOut done(1);
+	ss->workers[s]->post([&] {
+		try {
+			rc = fn();
+			if (rc != RXGPU_OK) err = rxgpu_last_error();   // thread-local on the worker: carry it over
+		} catch (const std::exception& e) {
+			rc = RXGPU_ERR_NOMEM;
+			err = e.what();
+		}
+		done.arrive();
+	});
+	done.wait();
+	return rc;
+}
 
 // runs fn(s) for every shard concurrently; returns the first non-OK code (the message of that shard is kept)
 int for_each_shard(ShardSet* ss, const std::function<int(size_t)>& fn) {
 	const size_t n = ss->shards.size();
 	std::vector<int> rc(n, RXGPU_OK);
 	std::vector<std::string> err(n);
+	FanOut done(n);
 	for (size_t s = 0; s < n; ++s) {
-		ss->workers[s]->start([&, s] {
-			rc[s] = fn(s);
-			if (rc[s] != RXGPU_OK) err[s] = rxgpu_last_error();   // thread-local on the worker: carry it over
+		ss->workers[s]->post([&, s] {
+			try {
+				rc[s] = fn(s);
+				if (rc[s] != RXGPU_OK) err[s] = rxgpu_last_error();
+			} catch (const std::exception& e) {
+				rc[s] = RXGPU_ERR_NOMEM;
+				err[s] = e.what();
+			}
+			done.arrive();
 		});
 	}
-	for (size_t s = 0; s < n; ++s) ss->workers[s]->wait();
+	done.wait();
 	for (size_t s = 0; s < n; ++s) {
 		if (rc[s] != RXGPU_OK) {
 			set_error("shard " + std::to_string(s) + ": " + err[s]);
@@ -84,6 +125,14 @@ int for_each_shard(ShardSet* ss, const std::function<int(size_t)>& fn) {
 		}
 	}
 	return RXGPU_OK;
+}
+
+// (dist, global row) as a strict weak order even when a distance is NaN (NaN sorts last): the comparator of the large-k path
+inline bool dist_row_less(const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
+	const bool an = a.first != a.first, bn = b.first != b.first;
+	if (an != bn) return bn;
+	if (!an && a.first != b.first) return a.first < b.first;
+	return a.second < b.second;
 }
 
 uint64_t local_count(const ShardSet* ss, size_t s, uint64_t count) {
@@ -102,7 +151,9 @@ void sharded_destroy(rxgpu_index* h) {
 			w->stop = true;
 			w->cv.notify_all();
 		}
-		if (w->thread.joinable()) w->thread.join();
+		for (std::thread& t : w->threads) {
+			if (t.joinable()) t.join();
+		}
 		delete w;
 	}
 	for (rxgpu_index* s : ss->shards) rxgpu_index_destroy(s);
@@ -128,7 +179,7 @@ int sharded_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, const fl
 									   : "The number of elements exceeds the specified limit");
 		return RXGPU_ERR_PARAMS;
 	}
-	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	std::unique_lock<std::shared_mutex> lk(ss->call_mtx);
 	const int rc = for_each_shard(ss, [&](size_t s) -> int {
 		const uint64_t lo = uint64_t(s) * ss->shard_rows, hi = lo + ss->shard_rows;
 		const uint64_t a = std::max(first_row, lo), b = std::min(first_row + n, hi);
@@ -145,7 +196,7 @@ int sharded_truncate(rxgpu_index* h, uint64_t count) {
 		set_error("rxgpu_index_truncate: count exceeds the number of rows");
 		return RXGPU_ERR_PARAMS;
 	}
-	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	std::unique_lock<std::shared_mutex> lk(ss->call_mtx);
 	const int rc = for_each_shard(ss, [&](size_t s) -> int { return rxgpu_index_truncate(ss->shards[s], local_count(ss, s, count)); });
 	if (rc == RXGPU_OK) h->count = count;
 	return rc;
@@ -174,7 +225,7 @@ int sharded_search_knn_impl(rxgpu_index* h, const float* queries, uint32_t nq, u
 			local_ids[s].push_back(uint32_t(row_ids[i] - s * ss->shard_rows));
 		}
 	}
-	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	std::shared_lock<std::shared_mutex> lk(ss->call_mtx);
 	const int rc = for_each_shard(ss, [&](size_t s) -> int {
 		sd[s].assign(size_t(nq) * kk, 0.f);
 		sr[s].assign(size_t(nq) * kk, 0u);
@@ -194,7 +245,7 @@ int sharded_search_knn_impl(rxgpu_index* h, const float* queries, uint32_t nq, u
 			for (uint32_t j = 0; j < sc[s][q]; ++j) all.emplace_back(sd[s][size_t(q) * kk + j], uint32_t(sr[s][size_t(q) * kk + j] + s * ss->shard_rows));
 		}
 		const size_t take = std::min<size_t>(kk, all.size());
-		std::partial_sort(all.begin(), all.begin() + take, all.end());   // lexicographic (dist, global row): the single-device order
+		std::partial_sort(all.begin(), all.begin() + take, all.end(), dist_row_less);   // lexicographic (dist, global row): the single-device order
 		for (size_t j = 0; j < take; ++j) {
 			out_dist[size_t(q) * kk + j] = all[j].first;
 			out_row[size_t(q) * kk + j] = all[j].second;
@@ -221,7 +272,7 @@ int sharded_search_range_impl(rxgpu_index* h, const float* query, float radius, 
 			local_ids[s].push_back(uint32_t(row_ids[i] - s * ss->shard_rows));
 		}
 	}
-	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	std::shared_lock<std::shared_mutex> lk(ss->call_mtx);
 	const int rc = for_each_shard(ss, [&](size_t s) -> int {
 		uint64_t want = std::max<uint64_t>(cap, 64);
 		for (int attempt = 0; attempt < 2; ++attempt) {   // a shard that overflows its buffer is asked again with the size it reported
@@ -251,7 +302,7 @@ int sharded_search_range_impl(rxgpu_index* h, const float* query, float radius, 
 	for (size_t s = 0; s < ns; ++s) {
 		for (uint64_t j = 0; j < st[s]; ++j) all.emplace_back(sd[s][j], uint32_t(sr[s][j] + s * ss->shard_rows));
 	}
-	std::sort(all.begin(), all.end());
+	std::sort(all.begin(), all.end(), dist_row_less);
 	*out_total = all.size();
 	for (size_t j = 0; j < all.size() && j < cap; ++j) {
 		out_dist[j] = all[j].first;
@@ -278,7 +329,7 @@ int sharded_distances(rxgpu_index* h, const float* query, const uint32_t* rows, 
 		where[s].push_back(i);
 	}
 	std::vector<std::vector<float>> sd(ns);
-	std::lock_guard<std::mutex> lk(ss->call_mtx);
+	std::shared_lock<std::shared_mutex> lk(ss->call_mtx);
 	const int rc = for_each_shard(ss, [&](size_t s) -> int {
 		if (local[s].empty()) return RXGPU_OK;
 		sd[s].resize(local[s].size());
@@ -300,33 +351,20 @@ int sharded_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
 	}
 	if (from == to) return RXGPU_OK;
 	const size_t sf = size_t(from / ss->shard_rows), st = size_t(to / ss->shard_rows);
-	std::lock_guard<std::mutex> lk(ss->call_mtx);
-	if (sf == st) {
-		int rc = RXGPU_OK;
-		std::string err;
-		ss->workers[sf]->start([&] {
-			rc = rxgpu_index_move_row(ss->shards[sf], from - sf * ss->shard_rows, to - sf * ss->shard_rows);
-			if (rc != RXGPU_OK) err = rxgpu_last_error();
-		});
-		ss->workers[sf]->wait();
-		if (rc != RXGPU_OK) set_error(err);
-		return rc;
-	}
-	std::vector<float> row(h->dim);
-	float norm = 0.f;
-	int rc = RXGPU_OK;
+	std::unique_lock<std::shared_mutex> lk(ss->call_mtx);
 	std::string err;
-	ss->workers[sf]->start([&] {
-		rc = rxgpu_index_download_row(ss->shards[sf], from - sf * ss->shard_rows, row.data(), &norm);
-		if (rc != RXGPU_OK) err = rxgpu_last_error();
-	});
-	ss->workers[sf]->wait();
-	if (rc == RXGPU_OK) {
-		ss->workers[st]->start([&] {
-			rc = rxgpu_index_upload_rows(ss->shards[st], to - st * ss->shard_rows, 1, row.data(), h->metric == RXGPU_METRIC_COSINE ? &norm : nullptr);
-			if (rc != RXGPU_OK) err = rxgpu_last_error();
-		});
-		ss->workers[st]->wait();
+	int rc;
+	if (sf == st) {
+		rc = run_on_shard(ss, sf, [&] { return rxgpu_index_move_row(ss->shards[sf], from - sf * ss->shard_rows, to - sf * ss->shard_rows); }, err);
+	} else {
+		std::vector<float> row(h->dim);
+		float norm = 0.f;
+		rc = run_on_shard(ss, sf, [&] { return rxgpu_index_download_row(ss->shards[sf], from - sf * ss->shard_rows, row.data(), &norm); }, err);
+		if (rc == RXGPU_OK) {
+			rc = run_on_shard(ss, st, [&] {
+				return rxgpu_index_upload_rows(ss->shards[st], to - st * ss->shard_rows, 1, row.data(), h->metric == RXGPU_METRIC_COSINE ? &norm : nullptr);
+			}, err);
+		}
 	}
 	if (rc != RXGPU_OK) set_error(err);
 	return rc;
@@ -367,10 +405,12 @@ int rxgpu_index_create_sharded(int metric, uint32_t dim, uint64_t capacity, uint
 		}
 		ss->shards.push_back(sh);
 		auto* w = new rxgpu::ShardWorker();
-		w->thread = std::thread([w, dev = devices[s]] {
-			(void)hipSetDevice(dev);
-			w->run();
-		});
+		for (unsigned t = 0; t < rxgpu::ShardWorker::kThreads; ++t) {
+			w->threads.emplace_back([w, dev = devices[s]] {
+				(void)hipSetDevice(dev);
+				w->run();
+			});
+		}
 		ss->workers.push_back(w);
 	}
 	*out = h;

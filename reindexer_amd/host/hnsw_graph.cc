@@ -687,6 +687,7 @@ void HnswGraph::MarkDelete(labeltype label) {
 	numDeleted_ += 1;
 	deletedElements_.insert(id);   // markDeletedInternal :1323-1338 (allow_replace_deleted_)
 	labelLookup_.erase(it);        // allow_replace_deleted_ == true in the reference's construction (hnsw.h:72)
+	markDirty(id);                 // the flag travels with the next incremental patch of the device mirror (GpuHnswMap::syncDevice)
 }
 
 void HnswGraph::ExportUpper(std::vector<uint64_t>& off, std::vector<uint32_t>& blocks) const {

@@ -46,6 +46,20 @@ const char* rxhost_last_error() { return g_err.c_str(); }
 
 float rxhost_l2_module(const float* x, int32_t d) { return CalculateL2Module(x, d); }
 float rxhost_normalize_copy(const float* x, int32_t d, float* out) { return NormalizeCopyVector(x, d, out); }
+// AddNorm over a block of rows (hnswlib.h:80-92): the 1/|row| table a cosine index stores, the product's own host arithmetic
+void rxhost_l2_modules_many(const float* rows, size_t n, int32_t d, float* out, unsigned threads) {
+	threads = std::max(1u, std::min<unsigned>(threads ? threads : 1u, unsigned(std::max<size_t>(n / 1024, 1))));
+	auto work = [&](size_t a, size_t b) {
+		for (size_t i = a; i < b; ++i) out[i] = CalculateL2Module(rows + i * size_t(d), d);
+	};
+	std::vector<std::thread> pool;
+	const size_t per = (n + threads - 1) / threads;
+	for (unsigned t = 1; t < threads; ++t) {
+		if (t * per < n) pool.emplace_back(work, t * per, std::min(n, (t + 1) * per));
+	}
+	work(0, std::min(n, per));
+	for (auto& th : pool) th.join();
+}
 
 void* rxhost_bf_create(int metric, size_t dim, size_t maxElements, int device) {
 	GpuBruteforceMap* m = nullptr;

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -73,6 +74,17 @@ def _f32(a):
 def l2_module(x) -> np.float32:
     x = _f32(x)
     return np.float32(lib().rxhost_l2_module(x.ctypes.data, x.shape[0]))
+
+
+def l2_modules_many(rows, threads: int = 0) -> np.ndarray:
+    """1/|row| of every row as a cosine index stores it (AddNorm, hnswlib.h:80-92), on `threads` host threads."""
+    rows = _f32(rows)
+    out = np.empty(rows.shape[0], np.float32)
+    L = lib()
+    L.rxhost_l2_modules_many.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_uint]
+    L.rxhost_l2_modules_many.restype = None
+    L.rxhost_l2_modules_many(rows.ctypes.data, rows.shape[0], rows.shape[1], out.ctypes.data, max(1, threads or (os.cpu_count() or 1)))
+    return out
 
 
 def normalize_copy(x):

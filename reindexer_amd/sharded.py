@@ -138,7 +138,9 @@ class ShardedBruteforce:
                 rr = np.asarray(rr, np.int64)
                 ll = np.asarray(local_labels)[rr].astype(np.uint64).view(np.int64)
                 mine.append(np.stack([rd.view(np.int32).astype(np.int64), rr + lo, ll], axis=1))
-            counts = torch.tensor([m.shape[0] for m in mine], dtype=torch.int64)
+            # the exchange tensors live where the group's backend wants them: RCCL rejects CPU tensors, gloo takes either
+            xdev = lab_t.device
+            counts = torch.tensor([m.shape[0] for m in mine], dtype=torch.int64, device=xdev)
             all_counts = [torch.zeros_like(counts) for _ in range(self.world)]
             if self.world > 1:
                 self._dist.all_gather(all_counts, counts, group=self.group)
@@ -148,11 +150,14 @@ class ShardedBruteforce:
             buf = torch.zeros((len(need), max(width, 1), 3), dtype=torch.int64)
             for j, m in enumerate(mine):
                 buf[j, : m.shape[0]] = torch.from_numpy(m)
+            buf = buf.to(xdev)
             bufs = [torch.zeros_like(buf) for _ in range(self.world)]
             if self.world > 1:
                 self._dist.all_gather(bufs, buf, group=self.group)
             else:
                 bufs = [buf]
+            bufs = [b.cpu() for b in bufs]
+            all_counts = [c.cpu() for c in all_counts]
             for j, qi in enumerate(need):
                 rows = np.concatenate([bufs[w][j, : int(all_counts[w][j])].numpy() for w in range(self.world)], axis=0)
                 rows = rows[np.argsort(rows[:, 1], kind="stable")]                       # scan order = global row order

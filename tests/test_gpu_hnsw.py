@@ -371,6 +371,40 @@ def test_interleaved_upserts_patch_the_device_graph_in_place(rxgpu, oracle, metr
     m.close()
 
 
+def test_delete_marks_travel_with_an_incremental_patch(rxgpu, oracle):
+    """A MarkDelete followed by an insert BEFORE the next search: both the graph and the delete flags are dirty at sync time and the
+    incremental patch succeeds — the flags of deleted nodes that are not otherwise touched must still reach the device (they are on
+    the dirty list since MarkDelete marks its node).  Sequences: add with no vacant slot then delete; delete two then add one (one slot
+    recycled, the other only flagged)."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    from reindexer_amd import hostapi
+    n0, d, k = 800, 32, 10
+    rows = make_corpus(91, n0 + 50, d)
+    labels = np.arange(n0 + 50, dtype=np.uint64) << np.uint64(32)
+    m = hostapi.GpuHnswMap(0, d, n0 + 50, M=8, ef_construction=60)
+    m.add(rows[:n0], labels[:n0])
+
+    def check(tag, gone):
+        g = m.export_graph(with_views=True)
+        g = dict(g, vectors=np.array(g["vectors"]))
+        for victim in gone:                        # query AT the deleted point: it would be the 1-NN if its flag were stale
+            q = rows[victim]
+            wd, wl = oracle_hnsw_search_knn(oracle, g, q, k, 64)
+            gd, gl = m.search_knn(q, k, 64)
+            assert labels[victim] not in gl, (tag, victim)
+            assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd)), (tag, victim)
+
+    check("attach", [])                           # full attach
+    m.add(rows[n0:n0 + 1], labels[n0:n0 + 1])     # no vacant slot: appended
+    m.mark_delete(labels[17])
+    check("add-then-delete", [17])
+    m.mark_delete(labels[100])
+    m.mark_delete(labels[200])
+    m.add(rows[n0 + 1:n0 + 2], labels[n0 + 1:n0 + 2])   # recycles one of the two slots
+    check("two-deletes-one-add", [17, 100, 200])
+    m.close()
+
+
 def test_large_ef_runs_with_global_candidate_heap(rxgpu, oracle):
     """1024 < ef <= 4096: the result heap takes the LDS, the candidate heap lives in global scratch from the start — same answers as the
     restated engine; beyond 4096 the C-ABI refuses (no silent clamp anywhere, SearchRange included)."""
