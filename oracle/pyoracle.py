@@ -765,6 +765,104 @@ class RefFt:
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
 
 
+REF_FT_SEAM_SO = HERE / "_ref" / "libref_ft_seam.so"
+
+
+class RefFtSeam(RefFt):
+    """The FT half of the drop-in boundary, executed over the reference's own types (oracle/ref/ref_ft_seam_shim.cc): one word table held
+    as PackedWordEntry<PackedIdRelVec> and <IdRelVec>, merged by the reference's ft::Merger (gpu=False) or by the adapter the patched
+    Selector::mergeResults calls first (gpu=True: rx_ft_seam.h -> GpuFtMerger -> kernels)."""
+
+    def __init__(self, num_fields: int):
+        if not REF_FT_SEAM_SO.exists():
+            raise FileNotFoundError(REF_FT_SEAM_SO)
+        L = self.L = C.CDLL(str(REF_FT_SEAM_SO))
+        L.ref_seam_create.restype = _vp
+        L.ref_seam_create.argtypes = [_sz]
+        L.ref_seam_destroy.argtypes = [_vp]
+        L.ref_seam_last_error.restype = C.c_char_p
+        L.ref_seam_last_error.argtypes = [_vp]
+        L.ref_seam_set_docs.argtypes = [_vp, _sz, _vp, _vp, _vp]
+        L.ref_seam_set_word.argtypes = [_vp, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp]
+        L.ref_seam_set_config.argtypes = [_vp, _vp, _vp, _vp, _i]
+        L.ref_seam_commit.restype = C.c_long
+        L.ref_seam_commit.argtypes = [_vp, _i]
+        L.ref_seam_merge.restype = C.c_long
+        L.ref_seam_merge.argtypes = [_vp, _i, _i, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz]
+        self.nf = num_fields
+        self.h = L.ref_seam_create(num_fields)
+
+    def close(self):
+        if self.h:
+            self.L.ref_seam_destroy(self.h)
+            self.h = None
+
+    def set_docs(self, words, avg, removed=None):
+        words = _f32(words).reshape(-1, self.nf)
+        avg = _f32(avg)
+        rem = np.ascontiguousarray(removed, np.uint8) if removed is not None else None
+        self.total = words.shape[0]
+        self.L.ref_seam_set_docs(self.h, words.shape[0], words.ctypes.data, avg.ctypes.data, rem.ctypes.data if rem is not None else None)
+
+    def set_word_fpos(self, word_id, s):
+        fp = np.asarray(s["fpos"], np.uint64)
+        doc = np.ascontiguousarray(s["doc"], np.uint32)
+        po = np.ascontiguousarray(s["pos_off"], np.uint32)
+        pf = (fp >> np.uint64(56)).astype(np.uint32)
+        pp = (fp & np.uint64((1 << 28) - 1)).astype(np.uint32)
+        pa = ((fp >> np.uint64(28)) & np.uint64((1 << 28) - 1)).astype(np.uint32)
+        self.L.ref_seam_set_word(self.h, word_id, doc.shape[0], doc.ctypes.data, po.ctypes.data, pf.ctypes.data, pp.ctypes.data, pa.ctypes.data)
+
+    def set_config(self, cfg: dict, distance_boost=1.0, distance_weight=0.5):
+        cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], distance_boost, distance_weight], np.float64)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"]], np.int32)
+        fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                               "position_boost", "position_weight")], axis=1).copy()
+        self.L.ref_seam_set_config(self.h, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data,
+                                   {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")])
+
+    def commit(self, device: int = 0) -> int:
+        """The end of IndexText::commitFulltextImpl in the patched tree: statistics + changed words go to the device mirrors."""
+        n = self.L.ref_seam_commit(self.h, device)
+        if n < 0:
+            raise RuntimeError(self.L.ref_seam_last_error(self.h).decode(errors="replace"))
+        return n
+
+    def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16, packed=True, gpu=False):
+        nf = self.nf
+        ops = np.array([t["op"] for t in terms], np.int32)
+        boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+        tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+        fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+        ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+        sub_off, sw, sp = [0], [], []
+        for t in terms:
+            for w, p in t["subs"]:
+                sw.append(w)
+                sp.append(p)
+            sub_off.append(len(sw))
+        sub_off, sw, sp = np.array(sub_off, np.uint32), np.array(sw, np.uint32), np.array(sp, np.float32)
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        n = self.L.ref_seam_merge(self.h, int(packed), int(gpu), len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data,
+                                  ns.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
+                                  rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
+        if n == -2:
+            return None   # the GPU branch declined: the CPU merger would run
+        if n < 0:
+            raise RuntimeError(self.L.ref_seam_last_error(self.h).decode(errors="replace"))
+        assert n <= cap, n
+        return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
+
+
+def ref_ft_seam_or_none(num_fields: int):
+    try:
+        return RefFtSeam(num_fields)
+    except (FileNotFoundError, OSError):
+        return None
+
+
 def ref_ft_or_none(num_fields: int):
     try:
         return RefFt(num_fields)

@@ -1,0 +1,245 @@
+// In-tree adapter (RXGPU_IN_TREE only) between the reference's ft_fast selector and GpuFtMerger: the FT half of the drop-in boundary.
+//
+//   Selector<IdCont>::mergeResults (cpp_src/core/ft/ft_fast/selecterimpl.h:608-628) constructs ft::Merger and calls Merge<Bm25T>;
+//   integration/patches/0003-ft-fast-gpu-merger.patch puts `rxgpu::host::TryMergeOnGpu(...)` in front of it.  Everything that call needs is
+//   converted here from the reference's OWN types:
+//     FTConfig (core/ft/config/ftconfig.h:118-220)                         -> FtConfig            (ToGpuCfg)
+//     FtDslOpts (core/ft/ftdsl.h:13-35)                                    -> FtDslOpts           (ToGpuOpts)
+//     ft::QueryMergeData<IdCont> (core/ft/ft_fast/querymergedata.h:14-242) -> std::vector<QueryTerm>  (ToGpuTerms; word id = WordIdType::b.id,
+//                                                                           the index of DataHolder<IdCont>::words_, dataholder.h:186-207)
+//     FtMergeStatuses::Statuses (core/index/ft_preselect.h:10-17)          -> one byte per vdoc, or nothing when no bit is set
+//     MergeData (ours) -> ft::MergeData (phrasemerger.h:57-78)             (ToRxMergeData)
+//   and the posting lists are handed over at commit time (IndexText::commitFulltextImpl, core/index/indextext/indextext.cc:817-885):
+//     DataHolder<PackedIdRelVec>::words_ — the raw varint streams, decoded ON THE DEVICE (GpuFtMerger::SetWordsPacked); needs the three
+//                                          accessors the patch adds to PackedIdRelVec (RawData / RawSize / ArrayFoundPos)
+//     DataHolder<IdRelVec>::words_       — IdRelType by IdRelType through PositionPostings::Add
+//     vdoc statistics                    — the duck-typed DocsStatsGetter (indextext.h:245-258): DocRemoved / NumWordsInField / AvgWordsCount
+//   Only the words whose list changed since the last commit travel again (fingerprint: byte size + FNV-1a of the stream / (size, last id)).
+//
+// What still goes to the reference's CPU merger (TryMergeOnGpu returns false): phrases, multi-word synonyms, MergeDataAreas (highlight /
+// snippet) — GpuFtMerger::Supports.
+#pragma once
+#if !defined(RXGPU_IN_TREE)
+#error "rx_ft_seam.h is for the build inside cpp_src (define RXGPU_IN_TREE)"
+#endif
+
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "core/enums.h"
+#include "core/ft/config/ftconfig.h"
+#include "core/ft/ft_fast/dataholder.h"
+#include "core/ft/ft_fast/phrasemerger.h"
+#include "core/ft/ft_fast/querymergedata.h"
+#include "core/ft/ftdsl.h"
+#include "core/ft/idrelset.h"
+#include "core/index/ft_preselect.h"
+#include "gpu_ft_merger.h"
+
+namespace rxgpu::host {
+
+// RX_GPU_FT_INDEXES=<device> routes the merge step of `text` (ft_fast) indexes to the MI355X engine (unset / empty: the CPU merger).
+inline int GpuFtDeviceFromEnv() noexcept {
+	const char* e = std::getenv("RX_GPU_FT_INDEXES");
+	return (e && *e) ? std::atoi(e) : -1;
+}
+
+inline FtConfig ToGpuCfg(const reindexer::FTConfig& c) {
+	FtConfig g(c.fieldsCfg.size());
+	g.mergeLimit = c.mergeLimit;
+	g.distanceBoost = c.distanceBoost;
+	g.distanceWeight = c.distanceWeight;
+	g.bm25k1 = c.bm25Config.bm25k1;
+	g.bm25b = c.bm25Config.bm25b;
+	using RT = reindexer::FTConfig::Bm25Config::Bm25Type;
+	g.bm25Type = c.bm25Config.bm25Type == RT::rx ? FtConfig::Bm25Type::Rx
+											   : (c.bm25Config.bm25Type == RT::classic ? FtConfig::Bm25Type::Classic : FtConfig::Bm25Type::WordCount);
+	g.summationRanksByFieldsRatio = c.summationRanksByFieldsRatio;
+	g.fullMatchBoost = c.fullMatchBoost;
+	g.minRank = c.minRank;
+	for (size_t f = 0; f < c.fieldsCfg.size(); ++f) {
+		const reindexer::FTFieldConfig& s = c.fieldsCfg[f];
+		g.fieldsCfg[f] = FtFieldConfig{s.bm25Boost, s.bm25Weight, s.termLenBoost, s.termLenWeight, s.positionBoost, s.positionWeight};
+	}
+	return g;
+}
+
+inline FtDslOpts ToGpuOpts(const reindexer::FtDslOpts& o) {
+	FtDslOpts g;
+	g.boost = o.boost;
+	g.termLenBoost = o.termLenBoost;
+	g.fieldsOpts.resize(o.fieldsOpts.size());
+	for (size_t f = 0; f < o.fieldsOpts.size(); ++f) g.fieldsOpts[f] = FtDslFieldOpts{o.fieldsOpts[f].boost, o.fieldsOpts[f].needSumRank};
+	return g;
+}
+
+inline bool ToGpuSortType(reindexer::RankSortType t, RankSortType& out) noexcept {
+	switch (t) {
+		case reindexer::RankSortType::RankOnly: out = RankSortType::RankOnly; return true;
+		case reindexer::RankSortType::RankAndID: out = RankSortType::RankAndID; return true;
+		case reindexer::RankSortType::IDOnly: out = RankSortType::IDOnly; return true;
+		case reindexer::RankSortType::IDAndPositions: out = RankSortType::IDAndPositions; return true;
+		case reindexer::RankSortType::ExternalExpression: return false;   // merger.h:151: the CPU merger throws errLogic — let it
+	}
+	return false;
+}
+
+// The query as the merger walks it: queryParts in order, sub-terms in SortSubterms() order (the caller has sorted them, mergerimpl.h:479).
+// False when the query holds something the GPU merger does not evaluate (phrases, synonyms).
+template <typename IdCont>
+bool ToGpuTerms(const reindexer::ft::QueryMergeData<IdCont>& q, std::vector<QueryTerm>& terms) {
+	if (!q.synonyms.empty()) return false;
+	terms.clear();
+	terms.reserve(q.queryParts.size());
+	for (const auto& qp : q.queryParts) {
+		if (!qp.IsTerm() || !qp.SynonymsIds().empty()) return false;
+		const auto& t = qp.Term();
+		QueryTerm g;
+		switch (t.Op()) {
+			case OpOr: g.op = OpType::Or; break;
+			case OpAnd: g.op = OpType::And; break;
+			case OpNot: g.op = OpType::Not; break;
+			default: return false;
+		}
+		g.opts = ToGpuOpts(t.Opts());
+		g.subterms.reserve(t.NumSubterms());
+		for (const auto& st : t) g.subterms.push_back(SubtermRef{uint32_t(st.PatternID().b.id), st.Proc()});
+		terms.push_back(std::move(g));
+	}
+	return true;
+}
+
+inline void ToRxMergeData(const MergeData& in, reindexer::ft::MergeData& out) {
+	out.resize(in.size());
+	for (size_t i = 0; i < in.size(); ++i) {
+		reindexer::ft::MergeInfo& o = out[i];
+		o.id = reindexer::IdType::FromNumber(in[i].id);
+		o.proc = in[i].proc;
+		o.field = in[i].field;
+		o.normalizedProc = in[i].normalizedProc;
+	}
+}
+
+// The device mirror of one ft_fast index: owned by the DataHolder (the patch adds `std::shared_ptr<GpuFtMirror> gpuMirror_` to IDataHolder),
+// refreshed by SyncGpuFtMirror at the end of every commit, read by TryMergeOnGpu under the index's shared lock.
+class GpuFtMirror {
+public:
+	GpuFtMirror(size_t numFields, int device) : merger_(numFields, device), numFields_(numFields) {}
+
+	const GpuFtMerger& Merger() const noexcept { return merger_; }
+	size_t SyncedWords() const noexcept { return prints_.size(); }
+	size_t SyncedDocs() const noexcept { return merger_.TotalDocs(); }
+
+	// vdoc statistics (b7) from the reference's DocsStatsGetter; vdoc 0 is the empty sentinel like everywhere in ft_fast
+	template <typename DocsStatsGetter>
+	void SyncDocs(size_t totalDocs, const DocsStatsGetter& stats) {
+		std::vector<float> words(totalDocs * numFields_), avg(numFields_);
+		std::vector<uint8_t> removed(totalDocs);
+		for (size_t d = 0; d < totalDocs; ++d) {
+			removed[d] = stats.DocRemoved(uint32_t(d)) ? 1 : 0;
+			// the merger reads size_t NumWordsInField() (indextext.h:249-253: the float count truncated) — hand over the same number
+			if (!removed[d]) {
+				for (size_t f = 0; f < numFields_; ++f) words[d * numFields_ + f] = float(stats.NumWordsInField(uint32_t(d), uint32_t(f)));
+			}
+		}
+		for (size_t f = 0; f < numFields_; ++f) avg[f] = stats.AvgWordsCount(uint32_t(f));
+		merger_.SetDocs(totalDocs, words.data(), avg.data(), removed.data());
+	}
+
+	// Optimization::Memory: the packed streams travel as they are and are decoded on the device
+	void SyncWords(const std::vector<reindexer::PackedWordEntry<reindexer::PackedIdRelVec>>& words) {
+		std::vector<GpuFtMerger::PackedWord> changed;
+		prints_.resize(words.size());
+		for (size_t w = 0; w < words.size(); ++w) {
+			const reindexer::PackedIdRelVec& v = words[w].vids;
+			const Print p{v.RawSize(), fnv1a(v.RawData(), v.RawSize())};
+			if (p == prints_[w]) continue;
+			prints_[w] = p;
+			changed.push_back(GpuFtMerger::PackedWord{uint32_t(w), v.RawData(), v.RawSize(), v.ArrayFoundPos()});
+		}
+		if (!changed.empty()) merger_.SetWordsPacked(changed);
+	}
+
+	// Optimization::CPU: plain vectors of IdRelType
+	void SyncWords(const std::vector<reindexer::PackedWordEntry<reindexer::IdRelVec>>& words) {
+		prints_.resize(words.size());
+		std::vector<uint64_t> fpos;
+		for (size_t w = 0; w < words.size(); ++w) {
+			const reindexer::IdRelVec& v = words[w].vids;
+			const Print p{v.size(), v.empty() ? 0 : (uint64_t(v.back().Id()) << 32) ^ v.back().Pos().size()};
+			if (p == prints_[w]) continue;
+			prints_[w] = p;
+			PositionPostings pp;
+			for (const reindexer::IdRelType& e : v) {
+				fpos.clear();
+				for (const reindexer::PosType& pos : e.Pos()) fpos.push_back(PositionPostings::Pos(pos.pos(), pos.field(), pos.arrayIdx()));
+				pp.Add(e.Id(), fpos.data(), fpos.size());
+			}
+			merger_.SetWord(uint32_t(w), pp);
+		}
+	}
+
+private:
+	struct Print {
+		uint64_t size = ~uint64_t(0), hash = 0;
+		bool operator==(const Print& o) const noexcept { return size == o.size && hash == o.hash; }
+	};
+	static uint64_t fnv1a(const uint8_t* p, size_t n) noexcept {
+		uint64_t h = 1469598103934665603ull;
+		for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+		return h;
+	}
+	GpuFtMerger merger_;
+	const size_t numFields_;
+	std::vector<Print> prints_;
+};
+
+// End of IndexText::commitFulltextImpl: (re)creates the mirror when the engine is switched on and brings it up to date.
+template <typename IdCont, typename DocsStatsGetter>
+void SyncGpuFtMirror(reindexer::DataHolder<IdCont>& holder, std::shared_ptr<GpuFtMirror>& mirror, size_t totalDocs, size_t numFields,
+					 const DocsStatsGetter& stats) {
+	const int device = GpuFtDeviceFromEnv();
+	if (device < 0) {
+		mirror.reset();
+		return;
+	}
+	if (!mirror || holder.status_ == reindexer::FullRebuild) mirror = std::make_shared<GpuFtMirror>(numFields, device);
+	mirror->SyncDocs(totalDocs, stats);
+	mirror->SyncWords(holder.GetWords());   // DataHolder<IdCont>::words_ (dataholder.h:186-207)
+}
+
+// Selector<IdCont>::mergeResults, GPU branch.  Returns false — and leaves everything untouched — when the CPU merger has to run.
+template <typename IdCont, typename MergedDataType>
+bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, size_t totalNumDocs, reindexer::ft::QueryMergeData<IdCont>& q,
+				   reindexer::RankSortType rankSortType, const reindexer::FtMergeStatuses::Statuses& docsExcluded, bool inTransaction,
+				   MergedDataType& result) {
+	if constexpr (!std::is_same_v<MergedDataType, reindexer::ft::MergeData>) {
+		return false;   // areas (highlight / snippet) are built by the CPU merger
+	} else {
+		(void)inTransaction;   // only gates ThrowOnCancel checkpoints in the CPU merger (mergerimpl.h:118, 200); one GPU merge is a fraction of a millisecond
+		if (!mirror || mirror->SyncedDocs() != totalNumDocs) return false;
+		RankSortType sortType;
+		if (!ToGpuSortType(rankSortType, sortType)) return false;
+		if (q.Empty()) return false;   // the CPU merger returns its empty result
+		q.SortSubterms();   // Merge() does it before anything reads the sub-terms (mergerimpl.h:479)
+		std::vector<QueryTerm> terms;
+		if (!ToGpuTerms(q, terms)) return false;
+		size_t hasPhrases = 0;
+		if (!GpuFtMerger::Supports(terms.size(), hasPhrases != 0, !q.synonyms.empty())) return false;
+		std::vector<uint8_t> excluded;
+		const uint8_t* excludedPtr = nullptr;
+		if (docsExcluded.PopCount() != 0) {
+			excluded.resize(totalNumDocs);
+			for (size_t d = 0; d < totalNumDocs && d < docsExcluded.size(); ++d) excluded[d] = docsExcluded[d] ? 1 : 0;
+			excludedPtr = excluded.data();
+		}
+		const MergeData merged = mirror->Merger().MergeQuery(ToGpuCfg(cfg), std::move(terms), excludedPtr, sortType);
+		ToRxMergeData(merged, result);
+		return true;
+	}
+}
+
+}  // namespace rxgpu::host

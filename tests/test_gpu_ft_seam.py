@@ -1,0 +1,123 @@
+"""The FT half of the drop-in boundary, EXECUTED over the reference's own types.
+
+oracle/_ref/libref_ft_seam.so (built here from the reference tree by oracle/Makefile, travels to the GPU box) is a TU compiled INSIDE a
+scratch copy of the reference's ft headers with integration/patches/0003-ft-fast-gpu-merger.patch applied: it holds a word table of
+PackedWordEntry<PackedIdRelVec> / <IdRelVec> as DataHolder<IdCont>::words_ does, builds ft::QueryMergeData<IdCont> / FTConfig / FtDslOpts /
+FtMergeStatuses::Statuses as Selector<IdCont> does, and merges it
+  * with the reference's ft::Merger<IdCont, ft::MergeData, uint32_t>::Merge<Bm25T>   (what mergeResults runs today), and
+  * with rxgpu::host::TryMergeOnGpu (reindexer_amd/host/rx_ft_seam.h)                 (what the patched mergeResults runs first):
+    ToGpuCfg / ToGpuOpts / ToGpuTerms, the commit-time hand-over GpuFtMirror::SyncDocs / SyncWords (packed streams decoded on the device),
+    GpuFtMerger::MergeQuery, ToRxMergeData.
+Bar: the two ft::MergeData are identical — documents in merge order, rank bits, fields, uint8 ranks."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FtOracle, ref_ft_seam_or_none
+from .test_bm25_oracle import MULTI_CASES, _multi_case, make_pos_postings
+
+
+@pytest.fixture(scope="module")
+def ft(oracle):
+    return FtOracle(oracle)
+
+
+def _seam(nf, words, avg, removed, store):
+    seam = ref_ft_seam_or_none(nf)
+    if seam is None:
+        pytest.skip("oracle/_ref/libref_ft_seam.so not available (built where /root/reference exists)")
+    seam.set_docs(words, avg, removed)
+    for s in store:
+        seam.set_word_fpos(s["word"], s)
+    return seam
+
+
+def _same(a, b, tag):
+    assert a is not None and b is not None, tag
+    assert np.array_equal(a[0], b[0]), (tag, len(a[0]), len(b[0]))
+    assert np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)), tag
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]), tag
+
+
+@pytest.mark.parametrize("case", [0, 4, 5, 8])
+def test_reference_merger_over_packed_lists_equals_plain_lists(ft, case):
+    """CPU: the shim's two word tables hold the same postings — the reference's merger must not care which container it walks (and the
+    library, which links the product's host layer, loads without a GPU)."""
+    seed, nf, total, limit, ops, arr, fbs = MULTI_CASES[case]
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, fbs)
+    seam = _seam(nf, words, avg, removed, store)
+    seam.set_config(ft.default_config(nf, merge_limit=limit))
+    rterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    for exc in (None, excluded):
+        _same(seam.merge(rterms, exc, packed=True), seam.merge(rterms, exc, packed=False), case)
+    seam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,nf,total,limit,ops,arr,fbs", MULTI_CASES)
+def test_patched_merge_results_branch_equals_reference_merger(rxgpu, ft, seed, nf, total, limit, ops, arr, fbs):
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, fbs)
+    seam = _seam(nf, words, avg, removed, store)
+    assert seam.commit(0) == len(store)
+    rterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    for variant, (dboost, dweight) in enumerate([(1.0, 0.5), (1.7, 0.8)]):
+        seam.set_config(ft.default_config(nf, merge_limit=limit, min_rank=5 if variant == 0 else 60), distance_boost=dboost, distance_weight=dweight)
+        for exc in (None, excluded):
+            for packed in (True, False):
+                want = seam.merge(rterms, exc, rank_sort_type=1, packed=packed, gpu=False)
+                got = seam.merge(rterms, exc, rank_sort_type=1, packed=packed, gpu=True)
+                _same(got, want, (variant, packed))
+                # RankOnly: sorted by uint8 rank, ties unspecified in the reference (pdqsort) — same (doc -> rank, field) map, non-increasing
+                ws = seam.merge(rterms, exc, rank_sort_type=0, packed=packed, gpu=False)
+                gs = seam.merge(rterms, exc, rank_sort_type=0, packed=packed, gpu=True)
+                assert np.all(np.diff(gs[3].astype(int)) <= 0)
+                o1, o2 = np.argsort(ws[0], kind="stable"), np.argsort(gs[0], kind="stable")
+                assert np.array_equal(ws[0][o1], gs[0][o2]) and np.array_equal(ws[3][o1], gs[3][o2]) and np.array_equal(ws[2][o1], gs[2][o2])
+    seam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bm25_type", ["rx", "classic", "word_count"])
+def test_seam_simple_queries_recommit_and_calculators(rxgpu, ft, bm25_type):
+    """Simple() queries (one OR term, several sub-terms) for all three calculators; then a second commit that appends documents to some
+    words and adds new words: only the changed lists travel again (fingerprints) and the merges follow."""
+    nf, total = 2, 4000
+    rng = np.random.default_rng(5)
+    words = rng.integers(1, 6, (total, nf)).astype(np.float32)
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    store = []
+    for w in range(6):
+        s = make_pos_postings(rng, total // 2, nf, int(rng.integers(100, 600)), 100.0 - 7 * w, w % 2 == 1)   # documents of the first half
+        s["word"] = w
+        store.append(s)
+    seam = _seam(nf, words, avg, None, store)
+    cfg = ft.default_config(nf, merge_limit=300, bm25_type=bm25_type)
+    seam.set_config(cfg)
+    assert seam.commit(0) == 6
+    opts = dict(boost=1.2, term_len_boost=0.9, field_boost=[1.0, 0.5], need_sum_rank=[0, 1])
+    simple = [dict(op=1, opts=opts, subs=[(w, store[w]["proc"]) for w in (0, 2, 3)])]
+    two = [dict(op=1, opts=opts, subs=[(0, 100.0), (1, 93.0)]), dict(op=2, opts=opts, subs=[(4, 72.0), (5, 65.0)])]
+    for q in (simple, two):
+        for packed in (True, False):
+            _same(seam.merge(q, packed=packed, gpu=True), seam.merge(q, packed=packed, gpu=False), (bm25_type, packed))
+    # second commit: words 0 and 4 get documents of the second half appended, word 6 is new
+    for w in (0, 4, 6):
+        extra = make_pos_postings(rng, total // 2, nf, 300, 100.0 - 7 * w, False)
+        extra["doc"] = (np.asarray(extra["doc"], np.uint32) + np.uint32(total // 2 - 1)).astype(np.uint32)
+        if w < 6:
+            old = store[w]
+            merged = dict(doc=np.concatenate([old["doc"], extra["doc"]]),
+                          pos_off=np.concatenate([np.asarray(old["pos_off"], np.uint32), np.asarray(extra["pos_off"][1:], np.uint32) + np.uint32(old["pos_off"][-1])]),
+                          fpos=np.concatenate([old["fpos"], extra["fpos"]]), proc=old["proc"], word=w)
+            assert np.all(np.diff(merged["doc"].astype(np.int64)) > 0)
+            store[w] = merged
+        else:
+            extra["word"] = w
+            store.append(extra)
+        seam.set_word_fpos(w, store[w])
+    assert seam.commit(0) == 7
+    wide = [dict(op=1, opts=opts, subs=[(0, 100.0), (6, 58.0)]), dict(op=1, opts=opts, subs=[(4, 72.0)]), dict(op=3, opts=opts, subs=[(2, 86.0)])]
+    for q in (simple, two, wide):
+        for packed in (True, False):
+            _same(seam.merge(q, packed=packed, gpu=True), seam.merge(q, packed=packed, gpu=False), ("recommit", bm25_type, packed))
+    seam.close()

@@ -9,7 +9,9 @@ cpp_src/core/index/float_vector/hnsw_index.cc (HnswIndexBase<Map>: ctor :47-70, 
      the reference's OWN FloatVectorId / ConstFloatVectorView / hnswlib::SearchResultQueue / StreamingSearchOptions,
   3. compiles the patched hnsw_index.cc, which instantiates HnswIndexBase<GpuBruteforceMapInTree>, <GpuHnswMapT<None>> and
      <GpuHnswMapT<OnInsertions>> (every virtual of FloatVectorIndex), and checks that the object file defines them.
--c only: linking the full core needs the reference's CMake build (LevelDB / Snappy are fetched from the network)."""
+  4. the same for the ft_fast half (patch 0003: Selector<IdCont>::mergeResults, IndexText::commitFulltextImpl, rx_ft_seam.h).
+-c only: linking the full core needs the reference's CMake build (LevelDB / Snappy are fetched from the network); the FT adapter is
+additionally EXECUTED against the reference's merger in tests/test_gpu_ft_seam.py (oracle/_ref/libref_ft_seam.so)."""
 import shutil
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -27,15 +29,34 @@ FLAGS = ["-std=c++20", "-O0", "-fPIC", "-w", "-DWITH_RXGPU=1", "-DRXGPU_IN_TREE=
 
 
 def _patched_tree(tmp: Path) -> Path:
-    """a/cpp_src/... layout holding copies of exactly the files the patches name, patched with `patch -p1`."""
+    """a/cpp_src/... layout: a mirror of every directory that holds a patched file (symlinks to the reference's files — so that headers which
+    include a patched header by its bare name, from the same directory, find the patched one), the patched files themselves materialised as
+    copies and patched with `patch -p1`."""
+    targets = []
     for patch in sorted(PATCHES.glob("*.patch")):
         for line in patch.read_text().splitlines():
             if line.startswith("+++ b/"):
-                rel = line[len("+++ b/"):].split("\t")[0]
-                dst = tmp / rel
-                if not dst.exists():
-                    dst.parent.mkdir(parents=True, exist_ok=True)
-                    shutil.copy(Path("/root/reference") / rel, dst)
+                targets.append(line[len("+++ b/"):].split("\t")[0])
+    for rel in targets:
+        src_dir, dst_dir = (Path("/root/reference") / rel).parent, (tmp / rel).parent
+        if src_dir.name == "cpp_src":   # CMakeLists.txt: the file alone
+            dst_dir.mkdir(parents=True, exist_ok=True)
+            continue
+        # mirror the directory tree below the patched file's directory (ft/ holds config/, stopwords/, ... that headers name relatively)
+        for f in src_dir.rglob("*"):
+            d = dst_dir / f.relative_to(src_dir)
+            if f.is_dir():
+                d.mkdir(parents=True, exist_ok=True)
+            elif not d.exists():
+                d.parent.mkdir(parents=True, exist_ok=True)
+                d.symlink_to(f)
+    for rel in targets:
+        dst = tmp / rel
+        if dst.is_symlink() or not dst.exists():
+            if dst.is_symlink():
+                dst.unlink()
+            shutil.copy(Path("/root/reference") / rel, dst)
+    for patch in sorted(PATCHES.glob("*.patch")):
         r = subprocess.run(["patch", "-p1", "--no-backup-if-mismatch", "-i", str(patch)], cwd=tmp, capture_output=True, text=True)
         assert r.returncode == 0, f"{patch.name} does not apply:\n{r.stdout}\n{r.stderr}"
     return tmp
@@ -74,7 +95,41 @@ def test_gpu_maps_instantiate_hnsw_index_base_against_reference_headers(tmp_path
 
 
 @pytest.mark.skipif(not REF.exists(), reason="needs the reference tree (/root/reference)")
+def test_gpu_ft_merger_branch_compiles_inside_selecter_and_indextext(tmp_path):
+    """The FT half: with integration/patches/0003 applied, the reference's own indextext.cc — which instantiates
+    Selector<PackedIdRelVec / IdRelVec>::Process -> mergeResults for ft::MergeData and both MergeDataAreas flavours, and
+    IndexText<key_string / PayloadValue>::commitFulltextImpl — compiles with the GPU branch (rx_ft_seam.h: TryMergeOnGpu over
+    ft::QueryMergeData / FTConfig / FtDslOpts / FtMergeStatuses::Statuses, SyncGpuFtMirror over DataHolder<IdCont>::words_ and the index as
+    DocsStatsGetter), and gpu_ft_merger.cc compiles beside it with the core's flags."""
+    tree = _patched_tree(tmp_path)
+    patched = tree / "cpp_src/core/index/indextext/indextext.cc"
+    assert "SyncGpuFtMirror" in patched.read_text()
+    assert "TryMergeOnGpu" in (tree / "cpp_src/core/ft/ft_fast/selecterimpl.h").read_text()
+    flags = [f"-I{tree}/cpp_src"] + FLAGS   # the patched headers shadow the reference's
+    jobs = {"indextext": patched, "gpu_ft_merger": ROOT / "reindexer_amd" / "host" / "gpu_ft_merger.cc"}
+
+    def compile_one(item):
+        name, src = item
+        obj = tmp_path / f"{name}.o"
+        return name, obj, subprocess.run(["g++", *flags, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        results = list(ex.map(compile_one, jobs.items()))
+    for name, obj, r in results:
+        assert r.returncode == 0, f"{name} does not compile inside cpp_src:\n{r.stderr[-4000:]}"
+    syms = subprocess.run(["nm", "-C", "--defined-only", str(tmp_path / "indextext.o")], capture_output=True, text=True, check=True).stdout
+    for cont in ("reindexer::PackedIdRelVec", "reindexer::IdRelVec"):
+        assert f"bool rxgpu::host::TryMergeOnGpu<{cont}, reindexer::ft::MergeData>(" in syms, cont
+        assert f"bool rxgpu::host::ToGpuTerms<{cont}>(" in syms, cont
+        assert f"rxgpu::host::GpuFtMirror::SyncWords(std::vector<reindexer::PackedWordEntry<{cont}>" in syms, cont
+        assert f"reindexer::Selector<{cont}>::mergeResults<" in syms.replace("unsigned short, ", "").replace("unsigned int, ", "") or \
+            f"Selector<{cont}>" in syms, cont
+    for store in ("reindexer::key_string", "reindexer::PayloadValue"):
+        assert f"void rxgpu::host::GpuFtMirror::SyncDocs<reindexer::IndexText<{store}> >(" in syms, store
+
+
+@pytest.mark.skipif(not REF.exists(), reason="needs the reference tree (/root/reference)")
 def test_patches_apply_cleanly(tmp_path):
     _patched_tree(tmp_path)
     cm = (tmp_path / "cpp_src/CMakeLists.txt").read_text()
-    assert "WITH_RXGPU" in cm and "RXGPU_IN_TREE" in cm
+    assert "WITH_RXGPU" in cm and "RXGPU_IN_TREE" in cm and "gpu_ft_merger.cc" in cm
