@@ -115,6 +115,17 @@ uint64_t rxgpu_index_device_bytes(const rxgpu_index* h);
 int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, float* out_dist, uint32_t* out_row,
 					 uint32_t* out_count);
 
+/* internal row -> row id (label >> 32, FloatVectorId::RowId) table kept beside the rows for consumers on the device: the hybrid fusion
+ * translates the scan's rows there.  Rows [first_row, first_row + n); the table is sized by the index capacity.  The device pointer
+ * (int32 [capacity]) or NULL when nothing was uploaded. */
+int rxgpu_index_upload_row_ids(rxgpu_index* h, uint64_t first_row, uint64_t n, const int32_t* row_ids);
+const void* rxgpu_index_row_ids_device(const rxgpu_index* h);
+/* One host query searched with the result LEFT IN HBM (the hybrid query's KNN half): the search is enqueued on a stream of the
+ * index and the call returns without waiting; *d_dist / *d_row ((dist, row) best first, *entries of them) and *d_count (device uint32)
+ * are buffers of the index that hold this result until the next resident search on it; *stream is the stream it runs on — a consumer
+ * (rxgpu_hybrid_fuse_resident) orders itself behind it on the device.  kk in [1, 128]. */
+int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, void** d_dist, void** d_row, void** d_count, void** stream,
+							  uint32_t* entries);
 /* Same, device-resident in/out on `stream` (hipStream_t); d_out_count may be NULL.  No synchronisation. */
 int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, void* d_out_dist, void* d_out_row,
 							void* d_out_count, void* stream);
@@ -315,6 +326,42 @@ int rxgpu_ft_get_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t* n, uint64_t
 int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
 							 const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc,
 							 float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n, int32_t* out_preselected);
+/* ---------------------------------------------------------------------------------------------------------
+ * Hybrid rank fusion on the device: MergerRankedImpl + mergeRanked (cpp_src/core/nsselecter/selectiteratorcontainer.cc:
+ * 1343-1423, 1454-1559), RanksHolder::InitRRFPositions (ranks_holder.h:61-76), RerankerRRF / RerankerLinear (core/sorting/reranker.h:11-39),
+ * the Merged<desc> order (selectiteratorcontainer.cc:1258-1283: desc = rank descending, ties by DESCENDING id).
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct rxgpu_hybrid_params {
+	int32_t kind;       /* 0 = RRF: params[0] = rank_const; 1 = linear: params = kKnn, knnDefault, kFt, ftDefault, c */
+	int32_t is_union;   /* the two ranked conditions joined by OR (union) / AND (intersection), selectiteratorcontainer.cc:1473-1480 */
+	int32_t desc;       /* 1: the normal rank() / RRF() ordering */
+	int32_t reserved;
+	double params[5];
+} rxgpu_hybrid_params;
+/* The merge of rxgpu_ft_merge_simple_raw / _terms_raw, but the result STAYS IN HBM (ft_finish's output; no export, no wait, the call
+ * returns as soon as the train is enqueued) for rxgpu_hybrid_fuse_resident to read. */
+int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
+								   const uint32_t* word_ids, const float* procs, const uint8_t* excluded);
+int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
+								  const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded);
+/* Fuses the resident merge of `h` (postProcessResults — merger.h:111-140: proc < min_rank dropped, scaled to 0..255, uint8 — is applied on
+ * the device) with a KNN result that lies in HBM as rxgpu_search_knn_device left it: d_knn_dist / d_knn_row best first, d_knn_count (device
+ * uint32, or NULL) of knn_n entries valid, the first k taking part (ranks as the planner sees them: the distance for L2, its negation for
+ * inner product / cosine, hnsw_index.cc:261-270).  knn_stream: the stream that search was enqueued on (the fusion waits for it on the
+ * device) or NULL.  d_row_of_doc: int32 [total_docs], vdoc -> row id when texts and rows correspond 1:1 otherwise than by number, or NULL;
+ * d_rowid_of_row: int32 [rows], internal row -> row id (label >> 32), or NULL = identity.  One list of (row id, fused rank) comes back,
+ * ordered like Merged<desc>.  *out_flags bit 0: the k-th and (k+1)-th KNN distances are equal — the boundary tie is decided by labels on
+ * the host (GpuBruteforceMap replays it), the caller should take that path.  cap >= merge_limit + k. */
+int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_knn_dist,
+							   const void* d_knn_row, const void* d_knn_count, uint32_t knn_n, uint32_t k, void* knn_stream, const void* d_row_of_doc,
+							   const void* d_rowid_of_row, int32_t* out_ids, float* out_ranks, uint64_t cap, uint64_t* out_n, uint32_t* out_flags);
+/* Fusions run by rxgpu_hybrid_fuse_resident and the device time of their kernel (HIP events on the merger's stream) since the last call. */
+int rxgpu_hybrid_read_stats(rxgpu_ft_index* h, uint64_t* calls, double* kernel_ms);
+/* The same kernel on host arrays: knn_ids / knn_ranks best first (at most 1024), ft_ids (unique, any order) with their uint8 ranks
+ * (MergeInfo::normalizedProc).  cap >= n_knn + n_ft. */
+int rxgpu_hybrid_fuse(int device, const rxgpu_hybrid_params* params, int metric, const int32_t* knn_ids, const float* knn_ranks, uint32_t n_knn,
+					  const int32_t* ft_ids, const uint8_t* ft_ranks, uint32_t n_ft, int32_t* out_ids, float* out_ranks, uint64_t cap, uint64_t* out_n);
+
 /* Postings scored / kernel milliseconds since the last call (roofline accounting: 20 B per posting). */
 int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms);
 

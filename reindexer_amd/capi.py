@@ -52,6 +52,9 @@ _SIGNATURES = {
     "rxgpu_index_device": (_i, [_vp]),
     "rxgpu_index_device_bytes": (_u64, [_vp]),
     "rxgpu_search_knn": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "rxgpu_index_upload_row_ids": (_i, [_vp, _u64, _u64, _vp]),
+    "rxgpu_index_row_ids_device": (_vp, [_vp]),
+    "rxgpu_search_knn_resident": (_i, [_vp, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u32)]),
     "rxgpu_search_knn_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_search_knn_subset": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "rxgpu_search_knn_bitmap": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
@@ -83,6 +86,12 @@ _SIGNATURES = {
     "rxgpu_ft_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
     "rxgpu_ft_set_words_packed": (_i, [_vp, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_ft_get_word": (_i, [_vp, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u32), _vp]),
+    "rxgpu_ft_merge_simple_resident": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp]),
+    "rxgpu_ft_merge_terms_resident": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rxgpu_hybrid_fuse_resident": (_i, [_vp, C.c_int32, _vp, _i, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64),
+                                        C.POINTER(_u32)]),
+    "rxgpu_hybrid_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "rxgpu_hybrid_fuse": (_i, [_i, _vp, _i, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_profile_enable": (_i, [_vp, _i]),
     "rxgpu_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
 }
@@ -386,6 +395,29 @@ class VectorIndex:
 def merge_shards_device(d_gathered_ptr: int, world: int, nq: int, kk: int, shard_rows: int, d_out_dist_ptr: int, d_out_row_ptr: int,
                         d_out_count_ptr: int | None, stream_ptr: int) -> None:
     _check(lib().rxgpu_merge_shards_device(d_gathered_ptr, world, nq, kk, shard_rows, d_out_dist_ptr, d_out_row_ptr, d_out_count_ptr, stream_ptr))
+
+
+class HybridParams(C.Structure):
+    """rxgpu_hybrid_params"""
+    _fields_ = [("kind", C.c_int32), ("is_union", C.c_int32), ("desc", C.c_int32), ("reserved", C.c_int32), ("params", C.c_double * 5)]
+
+
+def hybrid_fuse(kind: str, params, knn_ids, knn_ranks, ft_ids, ft_ranks_u8, union=True, desc=True, metric=METRIC_IP, device: int = 0):
+    """rxgpu_hybrid_fuse: the device rank fusion on host arrays.  knn_* best first (the planner's ranks), ft_ids unique in any order with
+    their uint8 ranks.  Returns (ids, ranks) in Merged<desc> order."""
+    hp = HybridParams()
+    hp.kind = 0 if kind == "rrf" else 1
+    hp.is_union, hp.desc = int(union), int(desc)
+    for i, v in enumerate(params):
+        hp.params[i] = float(v)
+    ki, kr = np.ascontiguousarray(knn_ids, np.int32), _f32c(knn_ranks)
+    fi, fr = np.ascontiguousarray(ft_ids, np.int32), np.ascontiguousarray(ft_ranks_u8, np.uint8)
+    cap = ki.shape[0] + fi.shape[0] + 1
+    oi, orank = np.empty(cap, np.int32), np.empty(cap, np.float32)
+    n = _u64(0)
+    _check(lib().rxgpu_hybrid_fuse(device, C.addressof(hp), metric, ki.ctypes.data, kr.ctypes.data, ki.shape[0], fi.ctypes.data, fr.ctypes.data,
+                                   fi.shape[0], oi.ctypes.data, orank.ctypes.data, cap, C.byref(n)))
+    return oi[:n.value].copy(), orank[:n.value].copy()
 
 
 def gpu_available() -> bool:

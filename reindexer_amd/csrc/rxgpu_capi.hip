@@ -205,7 +205,8 @@ int ensure_row_stats(rxgpu_index* h, hipStream_t s) {
 	if (h->stats_valid) return RXGPU_OK;
 	if (!h->d_stats) RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stats), 2 * sizeof(unsigned int)));
 	if (h->metric == RXGPU_METRIC_L2 && h->row_sq_capacity < h->count) {
-		if (h->d_row_sq) (void)hipFree(h->d_row_sq);
+		if (h->d_row_ids) (void)hipFree(h->d_row_ids);
+	if (h->d_row_sq) (void)hipFree(h->d_row_sq);
 		h->d_row_sq = nullptr;
 		h->row_sq_capacity = 0;
 		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_row_sq), std::max<uint64_t>(h->capacity, h->count) * sizeof(float)));
@@ -693,6 +694,7 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 	}
 	DeviceGuard dg(h->device);
 	(void)hipDeviceSynchronize();
+	if (h->resident_ctx) h->free_ctx.push_back(h->resident_ctx);
 	for (auto* c : h->free_ctx) {
 		c->release();
 		delete c;
@@ -905,6 +907,71 @@ int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, 
 	rxgpu_search_ctx* c = stream_ctx(h, stream);
 	return enqueue_knn(h, c, static_cast<const float*>(d_queries), nq, kk, static_cast<float*>(d_out_dist),
 					   static_cast<uint32_t*>(d_out_row), static_cast<uint32_t*>(d_out_count));
+}
+
+// internal row -> row id table for consumers on the device (the hybrid fusion maps the scan's rows to the planner's row ids there)
+int rxgpu_index_upload_row_ids(rxgpu_index* h, uint64_t first_row, uint64_t n, const int32_t* row_ids) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_index_upload_row_ids: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	if (n == 0) return RXGPU_OK;
+	RX_CHECK(row_ids && first_row + n <= h->capacity, RXGPU_ERR_PARAMS, "rxgpu_index_upload_row_ids: rows out of range");
+	DeviceGuard dg(h->device);
+	if (h->row_ids_cap < h->capacity) {
+		int32_t* grown = nullptr;
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&grown), h->capacity * sizeof(int32_t)));
+		if (h->d_row_ids) {
+			(void)hipMemcpy(grown, h->d_row_ids, h->row_ids_cap * sizeof(int32_t), hipMemcpyDeviceToDevice);
+			(void)hipFree(h->d_row_ids);
+		}
+		h->d_row_ids = grown;
+		h->row_ids_cap = h->capacity;
+	}
+	RX_HIP(hipMemcpy(h->d_row_ids + first_row, row_ids, n * sizeof(int32_t), hipMemcpyHostToDevice));
+	return RXGPU_OK;
+}
+const void* rxgpu_index_row_ids_device(const rxgpu_index* h) { return h && !h->shard_set ? h->d_row_ids : nullptr; }
+
+// One query, the result LEFT IN HBM: enqueued on the index's resident stream, nothing waited for.  The buffers belong to the index and
+// hold this result until the next resident search on it; a consumer on another stream orders itself behind *stream.
+int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, void** d_dist, void** d_row, void** d_count, void** stream,
+							  uint32_t* entries) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(query && d_dist && d_row && d_count && stream && entries, RXGPU_ERR_PARAMS, "rxgpu_search_knn_resident: null argument");
+	if (h->shard_set) {
+		set_error("rxgpu_search_knn_resident: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	RX_CHECK(kk >= 1 && kk <= uint32_t(rxgpu::kMaxFusedK2), RXGPU_ERR_PARAMS, "rxgpu_search_knn_resident: kk must be in [1, 128]");
+	RX_CHECK(h->count > 0, RXGPU_ERR_PARAMS, "rxgpu_search_knn_resident: index is empty");
+	DeviceGuard dg(h->device);
+	std::lock_guard<std::mutex> lk(h->resident_mtx);
+	if (!h->resident_ctx) h->resident_ctx = acquire_ctx(h);
+	rxgpu_search_ctx* c = h->resident_ctx;
+	if (!c) return RXGPU_ERR_DEVICE;
+	const uint32_t eff = uint32_t(std::min<uint64_t>(kk, h->count));
+	const size_t qbytes = size_t(h->dim) * sizeof(float);
+	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
+	if (int rc = c->ensure_pinned(qbytes); rc) return rc;
+	RX_HIP(hipStreamSynchronize(c->stream));   // the staging copy of the query before this one has been read (normally long ago)
+	std::memcpy(c->h_pinned, query, qbytes);
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, c->h_pinned, qbytes, hipMemcpyHostToDevice, c->stream));
+	if (int rc = c->d_out_dist.ensure(size_t(eff) * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(size_t(eff) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_out_count.ensure(sizeof(uint32_t)); rc) return rc;
+	auto* run = eff <= uint32_t(rxgpu::kMaxFusedK) ? enqueue_knn : enqueue_knn_fused;
+	if (int rc = run(h, c, static_cast<const float*>(c->d_queries.ptr), 1, eff, static_cast<float*>(c->d_out_dist.ptr),
+					 static_cast<uint32_t*>(c->d_out_row.ptr), static_cast<uint32_t*>(c->d_out_count.ptr));
+		rc)
+		return rc;
+	*d_dist = c->d_out_dist.ptr;
+	*d_row = c->d_out_row.ptr;
+	*d_count = c->d_out_count.ptr;
+	*stream = c->stream;
+	*entries = eff;
+	return RXGPU_OK;
 }
 
 int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, float* out_dist, uint32_t* out_row,

@@ -90,6 +90,14 @@ struct rxgpu_ft_index {
 		h_pinned_bytes = want;
 		return RXGPU_OK;
 	}
+	// a merge left in HBM for the hybrid fusion (rxgpu_ft_merge_*_resident): no export, no wait; checked by finish_pending()
+	bool res_pending = false;
+	uint32_t res_cap = 0;          // max_merged of that merge (the packed layout of d_out depends on it)
+	rxgpu_devbuf d_fuse;           // fusion scratch: radix ping-pong keys / classes
+	hipEvent_t ev_knn = nullptr;   // orders the fusion behind the KNN search's stream
+	hipEvent_t ev_fa = nullptr, ev_fb = nullptr;   // around the fusion kernel (rxgpu_hybrid_read_stats)
+	uint64_t fuse_calls = 0;
+	double fuse_ms = 0.0;
 	uint64_t stat_postings = 0;
 	double stat_ms = 0.0;
 	double stamps[64] = {};   // RXGPU_FT_STAMPS: summed phase stamps (relative to the workgroup's first), see rxgpu_ft_read_stats
@@ -165,7 +173,10 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
 		if (p) (void)hipFree(p);
 	}
-	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean}) b->release();
+	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse}) b->release();
+	for (hipEvent_t e : {h->ev_knn, h->ev_fa, h->ev_fb}) {
+		if (e) (void)hipEventDestroy(e);
+	}
 	if (h->h_pinned) (void)hipHostFree(h->h_pinned);
 	if (h->ev_a) (void)hipEventDestroy(h->ev_a);
 	if (h->ev_b) (void)hipEventDestroy(h->ev_b);
@@ -261,11 +272,26 @@ struct Carver {
 	}
 };
 
+// A resident merge was enqueued and nobody looked at its header yet: wait for it, check the look-back word, settle the kept-clean state.
+int finish_pending(rxgpu_ft_index* h, const char* who) {
+	if (!h->res_pending) return RXGPU_OK;
+	h->res_pending = false;
+	RX_HIP(hipStreamSynchronize(h->stream));
+	uint32_t hdr[4] = {0, 0, 0, 0};
+	RX_HIP(hipMemcpy(hdr, h->d_out.ptr, sizeof(hdr), hipMemcpyDeviceToHost));
+	float ms = 0.f;
+	if (h->ev_a && hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) h->stat_ms += ms;
+	RX_CHECK(hdr[1] == 0, RXGPU_ERR_DEVICE, std::string(who) + ": ordered look-back timed out on the device");
+	h->clean_dirty = false;
+	return RXGPU_OK;
+}
+
 // Shared implementation of rxgpu_ft_merge_simple_raw / rxgpu_ft_merge_terms_raw.  out_terms_counter may be null (simple).
 int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
-			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who) {
+			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false) {
 	using clk = std::chrono::steady_clock;
+	if (int rc = finish_pending(h, who); rc) return rc;
 	const auto t_begin = clk::now();
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
 	const uint32_t nf = h->num_fields;
@@ -305,7 +331,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_CHECK(total_vids < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^32 postings in one merge");
 	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, total_vids);   // Merge(): min(mergeLimit, totalORVids)
 	if (max_merged == 0) return RXGPU_OK;
-	RX_CHECK(cap >= max_merged && out_doc && out_proc && out_field && (simple || out_terms_counter), RXGPU_ERR_OVERFLOW,
+	RX_CHECK(resident || (cap >= max_merged && out_doc && out_proc && out_field && (simple || out_terms_counter)), RXGPU_ERR_OVERFLOW,
 			 std::string(who) + ": output buffers too small");
 	const bool prescore = !simple && std::min(std::min(est_or, est_and), N) > cfg->merge_limit && N > cfg->merge_limit;
 
@@ -517,6 +543,14 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_HIP(hipEventRecord(h->ev_a, st));
 	RX_HIP(rxgpu::launch_ft_merge(p, st));
 	RX_HIP(hipEventRecord(h->ev_b, st));
+	if (resident) {   // the result stays where ft_finish wrote it (d_out): the fusion kernel reads it there, nothing travels
+		h->res_pending = true;
+		h->res_cap = uint32_t(max_merged);
+		h->stat_postings += merged_postings;
+		h->trace_us[2] += since(t_launch);
+		h->trace_us[5] += 1;
+		return RXGPU_OK;
+	}
 	RX_HIP(rxgpu::launch_ft_export(p, st));
 	h->trace_us[2] += since(t_launch);
 	const auto t_wait = clk::now();
@@ -812,6 +846,224 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	for (uint32_t t = 0; t < nterms; ++t) terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1]};
 	return run_merge(h, cfg, false, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected,
 					 "rxgpu_ft_merge_terms_raw");
+}
+
+// ---------------------------------------------------------------------------------------------------- hybrid: merges that stay in HBM + the fusion
+int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
+								   const uint32_t* word_ids, const float* procs, const uint8_t* excluded) {
+	RX_CHECK(h && cfg && opts, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_resident: null argument");
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_resident: field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_simple_resident: rxgpu_ft_set_docs was not called");
+	RX_CHECK(nsub > 0 && word_ids && procs && opts->field_boost && opts->need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_resident: null argument");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	std::vector<QueryTermIn> terms{QueryTermIn{1, opts, 0, nsub}};
+	uint64_t n = 0;
+	h->res_cap = 0;
+	return run_merge(h, cfg, true, terms, word_ids, procs, excluded, nullptr, nullptr, nullptr, nullptr, 0, &n, nullptr, "rxgpu_ft_merge_simple_resident", true);
+}
+
+int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
+								  const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded) {
+	RX_CHECK(h && cfg && ops && opts && sub_off, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: null argument");
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_terms_resident: rxgpu_ft_set_docs was not called");
+	RX_CHECK(nterms >= 2 && nterms < 0xFFFF, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: 2 or more terms (one term: rxgpu_ft_merge_simple_resident)");
+	for (uint32_t t = 0; t < nterms; ++t) RX_CHECK(ops[t] >= 1 && ops[t] <= 3, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: op must be 1 (OR), 2 (AND) or 3 (NOT)");
+	RX_CHECK(sub_off[nterms] == 0 || (word_ids && procs), RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: null argument");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	std::vector<QueryTermIn> terms(nterms);
+	for (uint32_t t = 0; t < nterms; ++t) terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1]};
+	uint64_t n = 0;
+	h->res_cap = 0;
+	return run_merge(h, cfg, false, terms, word_ids, procs, excluded, nullptr, nullptr, nullptr, nullptr, 0, &n, nullptr, "rxgpu_ft_merge_terms_resident", true);
+}
+
+namespace {
+int check_hybrid_params(const rxgpu_hybrid_params* p, const char* who) {
+	RX_CHECK(p, RXGPU_ERR_PARAMS, std::string(who) + ": null parameters");
+	RX_CHECK(p->kind == 0 || p->kind == 1, RXGPU_ERR_PARAMS, std::string(who) + ": kind must be 0 (RRF) or 1 (linear)");
+	return RXGPU_OK;
+}
+void fill_reranker(rxgpu::HybridFuseArgs& a, const rxgpu_hybrid_params* p, int metric) {
+	a.kind = p->kind;
+	a.is_union = p->is_union ? 1 : 0;
+	a.desc = p->desc ? 1 : 0;
+	for (int i = 0; i < 5; ++i) a.params[i] = p->params[i];
+	a.metric_l2 = metric == RXGPU_METRIC_L2 ? 1 : 0;
+}
+}  // namespace
+
+int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_knn_dist,
+							   const void* d_knn_row, const void* d_knn_count, uint32_t knn_n, uint32_t k, void* knn_stream, const void* d_row_of_doc,
+							   const void* d_rowid_of_row, int32_t* out_ids, float* out_ranks, uint64_t cap, uint64_t* out_n, uint32_t* out_flags) {
+	RX_CHECK(h && out_n, RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse_resident: null argument");
+	*out_n = 0;
+	if (out_flags) *out_flags = 0;
+	if (int rc = check_hybrid_params(params, "rxgpu_hybrid_fuse_resident"); rc) return rc;
+	RX_CHECK(k <= uint32_t(rxgpu::kMaxFuseKnn) && k <= knn_n, RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse_resident: k must be <= 1024 and <= the entries of the KNN list");
+	RX_CHECK(knn_n == 0 || (d_knn_dist && d_knn_row), RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse_resident: null KNN list");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	const uint32_t M = h->res_pending ? h->res_cap : 0;   // no resident merge: an empty FT side (the merge found nothing to do)
+	const size_t out_cap = size_t(M) + k;
+	RX_CHECK(cap >= out_cap && (out_cap == 0 || (out_ids && out_ranks)), RXGPU_ERR_OVERFLOW, "rxgpu_hybrid_fuse_resident: output buffers too small");
+	const size_t key_bytes = align256(size_t(2) * std::max<uint32_t>(M, 1) * 4), cls_bytes = align256(size_t(2) * std::max<uint32_t>(M, 1) * 2);
+	if (int rc = h->d_fuse.ensure(key_bytes + cls_bytes + 256); rc) return rc;
+	// the result leaves through the pinned staging buffer: the kernel's stores go straight to host memory, no copy-engine start-up
+	const size_t o_ids = 256, o_ranks = o_ids + align256(out_cap * 4), stage = o_ranks + align256(out_cap * 4);
+	if (int rc = h->ensure_pinned(stage); rc) return rc;
+	char* hp = static_cast<char*>(h->h_pinned);
+	void* hp_dev = nullptr;
+	RX_HIP(hipHostGetDevicePointer(&hp_dev, hp, 0));
+	char* hd = static_cast<char*>(hp_dev);
+	hipStream_t st = h->stream;
+	if (knn_stream) {   // the KNN search ran on the caller's stream: the fusion waits for it on the device, the host does not
+		if (!h->ev_knn) RX_HIP(hipEventCreateWithFlags(&h->ev_knn, hipEventDisableTiming));
+		RX_HIP(hipEventRecord(h->ev_knn, static_cast<hipStream_t>(knn_stream)));
+		RX_HIP(hipStreamWaitEvent(st, h->ev_knn, 0));
+	}
+	rxgpu::HybridFuseArgs a{};
+	char* ob = static_cast<char*>(h->d_out.ptr);
+	if (M) {   // the packed layout run_merge gave d_out for max_merged = M
+		a.ft_count_ptr = reinterpret_cast<const uint32_t*>(ob);
+		a.ft_doc = reinterpret_cast<const uint32_t*>(ob + align256(16));
+		a.ft_proc = reinterpret_cast<const float*>(ob + align256(16) + align256(size_t(M) * 4));
+	}
+	a.ft_n = 0;
+	a.ft_cap = M;
+	a.min_rank = float(min_rank);
+	a.row_of_doc = static_cast<const int32_t*>(d_row_of_doc);
+	a.knn_dist = static_cast<const float*>(d_knn_dist);
+	a.knn_row = static_cast<const uint32_t*>(d_knn_row);
+	a.knn_count_ptr = static_cast<const uint32_t*>(d_knn_count);
+	a.knn_n = knn_n;
+	a.k = k;
+	a.knn_negate = metric == RXGPU_METRIC_L2 ? 0 : 1;
+	a.rowid_of_row = static_cast<const int32_t*>(d_rowid_of_row);
+	fill_reranker(a, params, metric);
+	a.out_header = reinterpret_cast<uint32_t*>(hd);
+	a.out_ids = reinterpret_cast<int32_t*>(hd + o_ids);
+	a.out_ranks = reinterpret_cast<float*>(hd + o_ranks);
+	a.scratch_key = static_cast<uint32_t*>(h->d_fuse.ptr);
+	a.scratch_cls = reinterpret_cast<uint16_t*>(static_cast<char*>(h->d_fuse.ptr) + key_bytes);
+	if (!h->ev_fa) {
+		RX_HIP(hipEventCreate(&h->ev_fa));
+		RX_HIP(hipEventCreate(&h->ev_fb));
+	}
+	RX_HIP(hipEventRecord(h->ev_fa, st));
+	RX_HIP(rxgpu::launch_hybrid_fuse(a, st));
+	RX_HIP(hipEventRecord(h->ev_fb, st));
+	{
+		using clk = std::chrono::steady_clock;
+		const auto t_poll = clk::now();
+		hipError_t q = hipStreamQuery(st);
+		while (q == hipErrorNotReady && std::chrono::duration<double, std::micro>(clk::now() - t_poll).count() < 3000.0) q = hipStreamQuery(st);
+		if (q == hipErrorNotReady) {
+			RX_HIP(hipStreamSynchronize(st));
+		} else {
+			RX_HIP(q);
+		}
+	}
+	if (h->res_pending) {   // the merge in front of the fusion has ended too: settle its state without another wait
+		h->res_pending = false;
+		uint32_t mh[4] = {0, 0, 0, 0};
+		RX_HIP(hipMemcpy(mh, h->d_out.ptr, sizeof(mh), hipMemcpyDeviceToHost));
+		float ms = 0.f;
+		if (h->ev_a && hipEventElapsedTime(&ms, h->ev_a, h->ev_b) == hipSuccess) h->stat_ms += ms;
+		RX_CHECK(mh[1] == 0, RXGPU_ERR_DEVICE, "rxgpu_hybrid_fuse_resident: ordered look-back timed out on the device");
+		h->clean_dirty = false;
+	}
+	{
+		float fms = 0.f;
+		if (hipEventElapsedTime(&fms, h->ev_fa, h->ev_fb) == hipSuccess) {
+			h->fuse_ms += fms;
+			h->fuse_calls += 1;
+		}
+	}
+	const uint32_t* hdr = reinterpret_cast<const uint32_t*>(hp);
+	const uint64_t n = hdr[0];
+	RX_CHECK(n <= out_cap, RXGPU_ERR_DEVICE, "rxgpu_hybrid_fuse_resident: corrupt result header");
+	if (n) {
+		std::memcpy(out_ids, hp + o_ids, n * 4);
+		std::memcpy(out_ranks, hp + o_ranks, n * 4);
+	}
+	*out_n = n;
+	if (out_flags) *out_flags = hdr[1];
+	return RXGPU_OK;
+}
+
+int rxgpu_hybrid_read_stats(rxgpu_ft_index* h, uint64_t* calls, double* kernel_ms) {
+	RX_CHECK(h && calls && kernel_ms, RXGPU_ERR_PARAMS, "rxgpu_hybrid_read_stats: null argument");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	*calls = h->fuse_calls;
+	*kernel_ms = h->fuse_ms;
+	h->fuse_calls = 0;
+	h->fuse_ms = 0.0;
+	return RXGPU_OK;
+}
+
+// The same kernel on host arrays (tests, callers whose two halves are already on the host): everything is staged, fused, brought back.
+int rxgpu_hybrid_fuse(int device, const rxgpu_hybrid_params* params, int metric, const int32_t* knn_ids, const float* knn_ranks, uint32_t n_knn,
+					  const int32_t* ft_ids, const uint8_t* ft_ranks, uint32_t n_ft, int32_t* out_ids, float* out_ranks, uint64_t cap, uint64_t* out_n) {
+	RX_CHECK(out_n, RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse: null argument");
+	*out_n = 0;
+	if (int rc = check_hybrid_params(params, "rxgpu_hybrid_fuse"); rc) return rc;
+	RX_CHECK(n_knn <= uint32_t(rxgpu::kMaxFuseKnn), RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse: at most 1024 KNN entries");
+	RX_CHECK((n_knn == 0 || (knn_ids && knn_ranks)) && (n_ft == 0 || (ft_ids && ft_ranks)), RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse: null argument");
+	RX_CHECK(cap >= uint64_t(n_knn) + n_ft && (cap == 0 || (out_ids && out_ranks)), RXGPU_ERR_OVERFLOW, "rxgpu_hybrid_fuse: output buffers too small");
+	int ndev = 0;
+	RX_HIP(hipGetDeviceCount(&ndev));
+	RX_CHECK(device >= 0 && device < ndev, RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse: no such device");
+	DevGuard dg(device);
+	const size_t nf = std::max<uint32_t>(n_ft, 1), nk = std::max<uint32_t>(n_knn, 1), no = size_t(n_ft) + n_knn + 1;
+	Carver cv;
+	const size_t o_fid = cv.take(nf * 4), o_fr = cv.take(nf), o_kid = cv.take(nk * 4), o_kr = cv.take(nk * 4), o_key = cv.take(2 * nf * 4),
+				 o_cls = cv.take(2 * nf * 2), o_hdr = cv.take(16), o_oid = cv.take(no * 4), o_or = cv.take(no * 4);
+	rxgpu_devbuf buf;
+	if (int rc = buf.ensure(cv.off); rc) return rc;
+	struct Rel {
+		rxgpu_devbuf& b;
+		~Rel() { b.release(); }
+	} rel{buf};
+	char* d = static_cast<char*>(buf.ptr);
+	if (n_ft) {
+		RX_HIP(hipMemcpy(d + o_fid, ft_ids, size_t(n_ft) * 4, hipMemcpyHostToDevice));
+		RX_HIP(hipMemcpy(d + o_fr, ft_ranks, n_ft, hipMemcpyHostToDevice));
+	}
+	if (n_knn) {
+		RX_HIP(hipMemcpy(d + o_kid, knn_ids, size_t(n_knn) * 4, hipMemcpyHostToDevice));
+		RX_HIP(hipMemcpy(d + o_kr, knn_ranks, size_t(n_knn) * 4, hipMemcpyHostToDevice));
+	}
+	rxgpu::HybridFuseArgs a{};
+	a.ft_doc = reinterpret_cast<const uint32_t*>(d + o_fid);
+	a.ft_rank_u8 = reinterpret_cast<const uint8_t*>(d + o_fr);
+	a.ft_n = n_ft;
+	a.ft_cap = uint32_t(nf);
+	a.knn_dist = reinterpret_cast<const float*>(d + o_kr);   // ranks as the planner holds them: no sign change
+	a.knn_row = reinterpret_cast<const uint32_t*>(d + o_kid);
+	a.knn_n = n_knn;
+	a.k = n_knn;
+	a.knn_negate = 0;
+	fill_reranker(a, params, metric);
+	a.out_header = reinterpret_cast<uint32_t*>(d + o_hdr);
+	a.out_ids = reinterpret_cast<int32_t*>(d + o_oid);
+	a.out_ranks = reinterpret_cast<float*>(d + o_or);
+	a.scratch_key = reinterpret_cast<uint32_t*>(d + o_key);
+	a.scratch_cls = reinterpret_cast<uint16_t*>(d + o_cls);
+	RX_HIP(rxgpu::launch_hybrid_fuse(a, nullptr));
+	RX_HIP(hipDeviceSynchronize());
+	uint32_t hdr[4];
+	RX_HIP(hipMemcpy(hdr, d + o_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
+	const uint64_t n = hdr[0];
+	RX_CHECK(n <= uint64_t(n_knn) + n_ft, RXGPU_ERR_DEVICE, "rxgpu_hybrid_fuse: corrupt result header");
+	if (n) {
+		RX_HIP(hipMemcpy(out_ids, d + o_oid, n * 4, hipMemcpyDeviceToHost));
+		RX_HIP(hipMemcpy(out_ranks, d + o_or, n * 4, hipMemcpyDeviceToHost));
+	}
+	*out_n = n;
+	return RXGPU_OK;
 }
 
 int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms) {

@@ -77,6 +77,37 @@ void launch_hnsw_patch(const HnswPatch& p, uint32_t n_dirty, hipStream_t s);
 struct HnswStream;
 void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, uint32_t batch, int mode, bool lds, hipStream_t st);
 
+// Hybrid FT + KNN rank fusion on the device (hybrid_fuse.hip)
+constexpr int kMaxFuseKnn = 1024;      // KNN entries one fusion takes (k of the KNN condition)
+struct HybridFuseArgs {
+	// FT side.  Either the merge train's raw output (ft_doc + ft_proc: postProcessResults is applied here with min_rank) or documents with
+	// their uint8 ranks (ft_doc + ft_rank_u8).  Ids unique, any order.  ft_count_ptr (device) overrides ft_n when set.
+	const uint32_t* ft_doc;
+	const float* ft_proc;
+	const uint8_t* ft_rank_u8;
+	const uint32_t* ft_count_ptr;
+	uint32_t ft_n, ft_cap;             // ft_cap: what the scratch arrays hold
+	float min_rank;
+	const int32_t* row_of_doc;         // vdoc -> row id (1:1), or null: the document number is the row id
+	// KNN side: the search's (dist, row) list, best first
+	const float* knn_dist;
+	const uint32_t* knn_row;
+	const uint32_t* knn_count_ptr;     // device count of valid entries, or null: knn_n
+	uint32_t knn_n, k;                 // entries present / entries that take part (the list holds k + 1 when the caller checks boundary ties)
+	int32_t knn_negate;                // IP / cosine: the planner's rank is -distance (hnsw_index.cc:261-270)
+	int32_t metric_l2;                 // runs of equal KNN ranks: L2 ascends, IP / cosine descend
+	const int32_t* rowid_of_row;       // internal row -> row id, or null: identity
+	// reranker: kind 0 RRF (params[0] = rank_const), 1 linear (kKnn, knnDefault, kFt, ftDefault, c)
+	int32_t kind, is_union, desc;
+	double params[5];
+	int32_t* out_ids;
+	float* out_ranks;
+	uint32_t* out_header;              // [0] count, [1] flags (1: distance tie at the k-th place), [2] head size, [3] tail size
+	uint32_t* scratch_key;             // [2 * ft_cap]
+	uint16_t* scratch_cls;             // [2 * ft_cap]
+};
+hipError_t launch_hybrid_fuse(const HybridFuseArgs& a, hipStream_t st);
+
 // ft_fast merge (ft_merge.hip): Merger::mergeSimple / mergeTerm + restricting bitmask + preselect, restated ORDER-FREE so that a whole
 // query is a fixed number of launches (see the header of ft_merge.hip)
 struct FtPosSubterm {
@@ -275,6 +306,10 @@ struct rxgpu_index {
 	std::mutex mtx;  // guards ctx pool + profile state
 	std::vector<rxgpu_search_ctx*> free_ctx;
 	std::map<void*, rxgpu_search_ctx*> stream_ctx;
+	int32_t* d_row_ids = nullptr;   // internal row -> row id (label >> 32) for consumers on the device (hybrid fusion); null until uploaded
+	uint64_t row_ids_cap = 0;
+	rxgpu_search_ctx* resident_ctx = nullptr;   // rxgpu_search_knn_resident: the result stays in its buffers for a consumer on the device
+	std::mutex resident_mtx;
 
 	bool profiling = false;
 	std::map<std::string, rxgpu_profile_slot> profile;

@@ -76,6 +76,7 @@ GpuBruteforceMap::GpuBruteforceMap(const GpuBruteforceMap& other, size_t newMaxE
 	std::memcpy(rows_.data(), other.rows_.data(), curElementCount_ * dim_ * sizeof(float));
 	std::memcpy(labels_.data(), other.labels_.data(), curElementCount_ * sizeof(labeltype));
 	if (!invNorms_.empty()) std::memcpy(invNorms_.data(), other.invNorms_.data(), curElementCount_ * sizeof(float));
+	labelsIdentity_ = other.labelsIdentity_;
 	createDeviceIndex();
 	dirtyAll_ = true;
 	needSync_ = true;
@@ -125,6 +126,7 @@ void GpuBruteforceMap::AddPointNoLock(ConstFloatVectorView vect, FloatVectorId i
 	if (metric_ == VectorMetric::Cosine) invNorms_[idx] = CalculateL2Module(vect.Data(), int32_t(dim_));   // AddNorm
 	std::memcpy(rows_.data() + idx * dim_, vect.Data(), dim_ * sizeof(float));
 	labels_[idx] = label;
+	if (label != (labeltype(idx) << 32)) labelsIdentity_ = false;
 	markDirty(idx);
 }
 
@@ -143,6 +145,7 @@ void GpuBruteforceMap::RemovePoint(labeltype curExternal) {
 		dictExternalToInternal_[labels_[last]] = cur;
 		std::memcpy(rows_.data() + cur * dim_, rows_.data() + last * dim_, dim_ * sizeof(float));
 		labels_[cur] = labels_[last];
+		labelsIdentity_ = false;
 		if (!invNorms_.empty()) invNorms_[cur] = invNorms_[last];   // MoveNorm
 		markDirty(cur);
 	}
@@ -182,12 +185,25 @@ void GpuBruteforceMap::syncDevice() const {
 		if (rxgpu_index_reserve(dev_, maxElements_) != RXGPU_OK) throwDevice("Not enough memory: resizeIndex failed to allocate data");
 	}
 	const float* norms = invNorms_.empty() ? nullptr : invNorms_.data();
+	// the row-id table of the hybrid fusion travels with the rows once a label is not (row << 32) any more (single-device mirror only)
+	const bool withIds = !labelsIdentity_ && devices_.size() == 1;
+	std::vector<int32_t> ids;
+	auto uploadIds = [&](size_t first, size_t n) {
+		ids.resize(n);
+		for (size_t i = 0; i < n; ++i) ids[i] = int32_t(labels_[first + i] >> 32);
+		if (rxgpu_index_upload_row_ids(dev_, first, n, ids.data()) != RXGPU_OK) throwDevice("row id upload failed");
+	};
 	auto upload = [&](size_t first, size_t n) {
 		if (n == 0) return;
 		if (rxgpu_index_upload_rows(dev_, first, n, rows_.data() + first * dim_, norms ? norms + first : nullptr) != RXGPU_OK) {
 			throwDevice("row upload failed");
 		}
+		if (withIds && rowIdsOnDevice_) uploadIds(first, n);
 	};
+	if (withIds && !rowIdsOnDevice_) {
+		if (curElementCount_) uploadIds(0, curElementCount_);
+		rowIdsOnDevice_ = true;
+	}
 	if (dirtyAll_) {
 		upload(0, curElementCount_);
 	} else if (!dirtyRows_.empty()) {
@@ -206,6 +222,22 @@ void GpuBruteforceMap::syncDevice() const {
 	dirtyRows_.clear();
 	dirtyAll_ = false;
 	needSync_ = false;
+}
+
+GpuBruteforceMap::ResidentKnn GpuBruteforceMap::SearchKnnResident(const float* queryData, size_t k) const {
+	if (devices_.size() > 1) throw std::logic_error("SearchKnnResident: not available on a sharded mirror");
+	if (curElementCount_ == 0 || k == 0) return ResidentKnn{};
+	syncDevice();
+	ResidentKnn r;
+	void *dd = nullptr, *dr = nullptr, *dc = nullptr;
+	if (rxgpu_search_knn_resident(dev_, queryData, uint32_t(std::min<size_t>(k + 1, curElementCount_)), &dd, &dr, &dc, &r.stream, &r.entries) != RXGPU_OK) {
+		throwDevice("SearchKnnResident");
+	}
+	r.dDist = dd;
+	r.dRow = dr;
+	r.dCount = dc;
+	r.dRowIds = labelsIdentity_ ? nullptr : rxgpu_index_row_ids_device(dev_);
+	return r;
 }
 
 // bruteforce.cc:103-127.  The kernels return the exact top-(k+1) under the (dist,row) order; the reference keeps a

@@ -58,6 +58,21 @@ public:
 	SearchResultQueue SearchKnnFiltered(const float* queryData, std::optional<float> queryDataNorm, size_t k, const labeltype* allowed,
 										size_t nAllowed) const;
 
+	// Hybrid query, KNN half: ONE query's search enqueued, its exact top-(k + 1) (dist, internal row) list LEFT IN HBM for the
+	// rank fusion on the device (GpuFtMerger::FuseResident) — nothing is waited for, nothing comes back.  The extra entry lets the consumer
+	// see a distance tie straddling the k-th place (which only the label-aware replay of SearchKnn can decide).  rowIds: device table
+	// internal row -> row id (label >> 32), null while every label is (row << 32) (the fusion then takes the row as the id).
+	struct ResidentKnn {
+		const void* dDist = nullptr;
+		const void* dRow = nullptr;
+		const void* dCount = nullptr;
+		void* stream = nullptr;
+		uint32_t entries = 0;
+		const void* dRowIds = nullptr;
+	};
+	ResidentKnn SearchKnnResident(const float* queryData, size_t k) const;
+	rxgpu_index* DeviceIndex() const noexcept { return dev_; }
+
 	bool IsQuantized() const noexcept { return false; }
 	bool QuantizationAvailable() const noexcept { return false; }
 
@@ -104,6 +119,8 @@ private:
 	mutable bool dirtyAll_ = false;
 	mutable bool needSync_ = false;
 	mutable size_t tieReplays_ = 0;
+	bool labelsIdentity_ = true;            // every label is (internal row << 32): the device needs no row-id table
+	mutable bool rowIdsOnDevice_ = false;   // the table has been uploaded in full once
 
 	bool coalesce_ = true;
 	mutable std::mutex coMtx_;

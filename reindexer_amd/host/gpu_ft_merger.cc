@@ -113,6 +113,10 @@ void GpuFtMerger::ReadStats(uint64_t& postings, double& kernelMs) const {
 	if (rxgpu_ft_read_stats(dev_, &postings, &kernelMs) != RXGPU_OK) throwDevice("ReadStats");
 }
 
+void GpuFtMerger::ReadFuseStats(uint64_t& calls, double& kernelMs) const {
+	if (rxgpu_hybrid_read_stats(dev_, &calls, &kernelMs) != RXGPU_OK) throwDevice("ReadFuseStats");
+}
+
 namespace {
 struct CallTimer {
 	std::atomic<uint64_t>& calls;
@@ -127,6 +131,11 @@ struct CallTimer {
 
 MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 							 RankSortType rankSortType) const {
+	return mergeImpl(cfg, termOpts, std::move(subterms), docsExcluded, rankSortType, false);
+}
+
+MergeData GpuFtMerger::mergeImpl(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
+								 RankSortType rankSortType, bool resident) const {
 	CallTimer timer{timedCalls_, timedNs_};
 	MergeData out;
 	if (subterms.empty() || totalDocs_ == 0) return out;   // mergerimpl.h:472-474
@@ -169,6 +178,12 @@ MergeData GpuFtMerger::Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std
 	for (size_t i = 0; i < subterms.size(); ++i) {
 		wordIds[i] = subterms[i].wordId;
 		procs[i] = subterms[i].proc;
+	}
+	if (resident) {   // the result stays in HBM for FuseResident
+		if (rxgpu_ft_merge_simple_resident(dev_, &c, &o, uint32_t(subterms.size()), wordIds.data(), procs.data(), docsExcluded) != RXGPU_OK) {
+			throwDevice("MergeQueryResident");
+		}
+		return out;
 	}
 	const size_t cap = cfg.mergeLimit;
 	std::vector<uint32_t> doc(cap);
@@ -276,16 +291,56 @@ void GpuFtMerger::ReadTiming(uint64_t& calls, double& totalMs) const {
 
 MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 								  bool* preselected) const {
+	return mergeQueryImpl(cfg, std::move(terms), docsExcluded, rankSortType, preselected, false);
+}
+
+bool GpuFtMerger::MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded) const {
+	// what Merge() returns empty without touching a posting (mergerimpl.h:472-474; a sub-term-less query merges nothing): no resident result
+	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return false;
+	size_t subs = 0;
+	for (const QueryTerm& t : terms) subs += t.subterms.size();
+	if (subs == 0) return false;
+	if (terms.size() == 1 && terms[0].subterms.empty()) return false;
+	(void)mergeQueryImpl(cfg, std::move(terms), docsExcluded, RankSortType::RankAndID, nullptr, true);
+	return true;
+}
+
+HybridFused GpuFtMerger::FuseResident(const FtConfig& cfg, const HybridFuseParams& hp, int metric, const void* dKnnDist, const void* dKnnRow,
+									  const void* dKnnCount, uint32_t knnEntries, uint32_t k, void* knnStream, const void* dRowOfDoc,
+									  const void* dRowIdOfRow) const {
+	HybridFused out;
+	const size_t cap = size_t(cfg.mergeLimit) + k;
+	out.ids.resize(cap);
+	out.ranks.resize(cap);
+	rxgpu_hybrid_params p{};
+	p.kind = hp.linear ? 1 : 0;
+	p.is_union = hp.isUnion ? 1 : 0;
+	p.desc = hp.desc ? 1 : 0;
+	for (int i = 0; i < 5; ++i) p.params[i] = hp.params[i];
+	uint64_t n = 0;
+	uint32_t flags = 0;
+	if (rxgpu_hybrid_fuse_resident(dev_, cfg.minRank, &p, metric, dKnnDist, dKnnRow, dKnnCount, knnEntries, k, knnStream, dRowOfDoc, dRowIdOfRow,
+								   out.ids.data(), out.ranks.data(), cap, &n, &flags) != RXGPU_OK) {
+		throwDevice("FuseResident");
+	}
+	out.ids.resize(n);
+	out.ranks.resize(n);
+	out.knnBoundaryTie = (flags & 1u) != 0;
+	return out;
+}
+
+MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
+									  bool* preselected, bool resident) const {
 	if (terms.size() == 1 && terms[0].op != OpType::Not && totalDocs_ != 0) {   // Simple(): timed by Merge
 		if (preselected) *preselected = false;
-		return Merge(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType);
+		return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);
 	}
 	CallTimer timer{timedCalls_, timedNs_};
 	if (preselected) *preselected = false;
 	MergeData out;
 	// QueryMergeData::Empty() (querymergedata.h:208) / mergerimpl.h:472-474
 	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return out;
-	if (terms.size() == 1) return Merge(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType);   // Simple()
+	if (terms.size() == 1) return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);   // Simple()
 	if (cfg.fieldsCfg.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
 
 	const size_t nt = terms.size();
@@ -338,6 +393,13 @@ MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> te
 			procs.push_back(sr.proc);
 		}
 		subOff[t + 1] = uint32_t(wordIds.size());
+	}
+	if (resident) {
+		if (rxgpu_ft_merge_terms_resident(dev_, &c, uint32_t(nt), ops.data(), opts.data(), subOff.data(), wordIds.data(), procs.data(), docsExcluded) !=
+			RXGPU_OK) {
+			throwDevice("MergeQueryResident");
+		}
+		return out;
 	}
 	const size_t cap = cfg.mergeLimit;
 	std::vector<uint32_t> doc(cap);

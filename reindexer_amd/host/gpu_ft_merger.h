@@ -102,6 +102,19 @@ struct QueryTerm {
 	std::vector<SubtermRef> subterms;
 };
 
+// The hybrid rank fusion on the device (hybrid_fuse.hip): reranker + join type, as MergerRankedImpl gets them (selectiteratorcontainer.cc:1305-1341)
+struct HybridFuseParams {
+	bool linear = false;   // false: RRF, params[0] = rank_const (60); true: RerankerLinear, params = kKnn, knnDefault, kFt, ftDefault, c
+	bool isUnion = true;   // OR between the two ranked conditions (AND: intersection)
+	bool desc = true;
+	double params[5] = {60.0, 0.0, 0.0, 0.0, 0.0};
+};
+struct HybridFused {
+	std::vector<int32_t> ids;    // row ids in Merged<desc> order
+	std::vector<float> ranks;
+	bool knnBoundaryTie = false;   // the k-th and (k+1)-th KNN distances are equal: the Map's label-aware replay has to decide the k-th place
+};
+
 class GpuFtMerger {
 public:
 	GpuFtMerger(size_t numFields, int device = 0);
@@ -140,13 +153,26 @@ public:
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
 
+	// Hybrid query, FT half: the same merge, but the result STAYS IN HBM (no export, no wait).  False when the query merges nothing
+	// (Empty(), no sub-terms) — there is then no resident result and FuseResident sees an empty FT side.
+	bool MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded) const;
+	// ... and the fusion: postProcessResults + MergerRankedImpl on the device over the resident merge and a KNN result that lies in HBM
+	// as rxgpu_search_knn_device left it ((dist, row) best first; the first k take part; knnStream = the stream of that search).
+	HybridFused FuseResident(const FtConfig& cfg, const HybridFuseParams& hp, int metric, const void* dKnnDist, const void* dKnnRow, const void* dKnnCount,
+							 uint32_t knnEntries, uint32_t k, void* knnStream, const void* dRowOfDoc = nullptr, const void* dRowIdOfRow = nullptr) const;
+
 	size_t TotalDocs() const noexcept { return totalDocs_; }
 	void ReadStats(uint64_t& postings, double& kernelMs) const;
+	void ReadFuseStats(uint64_t& calls, double& kernelMs) const;   // FuseResident: fusions and the device time of their kernel since the last call
 	// wall time spent inside Merge / MergeQuery since the last call (everything behind the Merger boundary: plan, launches, the wait,
 	// unpacking, postProcessResults) and the number of calls; resets both
 	void ReadTiming(uint64_t& calls, double& totalMs) const;
 
 private:
+	MergeData mergeImpl(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
+						RankSortType rankSortType, bool resident) const;
+	MergeData mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType, bool* preselected,
+							 bool resident) const;
 	void postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const;
 	const size_t numFields_;
 	size_t totalDocs_ = 0;

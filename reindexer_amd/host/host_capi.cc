@@ -558,7 +558,40 @@ extern "C" int rxhost_ft_set_word_fpos(void* h, uint32_t wordId, size_t n, const
 }
 // cfgD: [k1, b, summationRatio, fullMatchBoost, distanceBoost, distanceWeight]; per term: op, boost, termLenBoost, fieldBoost[nf],
 // needSum[nf], sub-term slice [subOff[t], subOff[t+1]) of (wordId, proc).  Returns the result count, -1 on error.
+extern "C" void rxhost_ft_read_fuse_stats(void* h, uint64_t* calls, double* kernelMs) { static_cast<const GpuFtMerger*>(h)->ReadFuseStats(*calls, *kernelMs); }
 extern "C" void rxhost_ft_read_timing(void* h, uint64_t* calls, double* totalMs) { static_cast<const GpuFtMerger*>(h)->ReadTiming(*calls, *totalMs); }
+
+namespace {
+FtConfig parseFtConfig(size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg) {
+	FtConfig cfg(nf);
+	cfg.bm25k1 = cfgD[0];
+	cfg.bm25b = cfgD[1];
+	cfg.summationRanksByFieldsRatio = cfgD[2];
+	cfg.fullMatchBoost = cfgD[3];
+	cfg.distanceBoost = cfgD[4];
+	cfg.distanceWeight = cfgD[5];
+	cfg.minRank = cfgI[0];
+	cfg.mergeLimit = uint32_t(cfgI[1]);
+	cfg.bm25Type = cfgI[2] == 1 ? FtConfig::Bm25Type::Classic : (cfgI[2] == 2 ? FtConfig::Bm25Type::WordCount : FtConfig::Bm25Type::Rx);
+	for (size_t f = 0; f < nf; ++f) {
+		cfg.fieldsCfg[f] = FtFieldConfig{fieldCfg[f * 6 + 0], fieldCfg[f * 6 + 1], fieldCfg[f * 6 + 2], fieldCfg[f * 6 + 3], fieldCfg[f * 6 + 4], fieldCfg[f * 6 + 5]};
+	}
+	return cfg;
+}
+std::vector<QueryTerm> parseFtTerms(size_t nf, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+									const uint8_t* needSum, const uint32_t* subOff, const uint32_t* wordIds, const float* procs) {
+	std::vector<QueryTerm> terms(nTerms);
+	for (size_t t = 0; t < nTerms; ++t) {
+		terms[t].op = OpType(ops[t]);
+		terms[t].opts.boost = boosts[t];
+		terms[t].opts.termLenBoost = termLenBoosts[t];
+		terms[t].opts.fieldsOpts.resize(nf);
+		for (size_t f = 0; f < nf; ++f) terms[t].opts.fieldsOpts[f] = FtDslFieldOpts{fieldBoost[t * nf + f], needSum[t * nf + f] != 0};
+		for (uint32_t s = subOff[t]; s < subOff[t + 1]; ++s) terms[t].subterms.push_back(SubtermRef{wordIds[s], procs[s]});
+	}
+	return terms;
+}
+}  // namespace
 
 extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, const int* ops,
 									  const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
@@ -566,28 +599,8 @@ extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, co
 									  int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap, int* outPreselected) {
 	long n = -1;
 	guarded([&] {
-		FtConfig cfg(nf);
-		cfg.bm25k1 = cfgD[0];
-		cfg.bm25b = cfgD[1];
-		cfg.summationRanksByFieldsRatio = cfgD[2];
-		cfg.fullMatchBoost = cfgD[3];
-		cfg.distanceBoost = cfgD[4];
-		cfg.distanceWeight = cfgD[5];
-		cfg.minRank = cfgI[0];
-		cfg.mergeLimit = uint32_t(cfgI[1]);
-		cfg.bm25Type = cfgI[2] == 1 ? FtConfig::Bm25Type::Classic : (cfgI[2] == 2 ? FtConfig::Bm25Type::WordCount : FtConfig::Bm25Type::Rx);
-		for (size_t f = 0; f < nf; ++f) {
-			cfg.fieldsCfg[f] = FtFieldConfig{fieldCfg[f * 6 + 0], fieldCfg[f * 6 + 1], fieldCfg[f * 6 + 2], fieldCfg[f * 6 + 3], fieldCfg[f * 6 + 4], fieldCfg[f * 6 + 5]};
-		}
-		std::vector<QueryTerm> terms(nTerms);
-		for (size_t t = 0; t < nTerms; ++t) {
-			terms[t].op = OpType(ops[t]);
-			terms[t].opts.boost = boosts[t];
-			terms[t].opts.termLenBoost = termLenBoosts[t];
-			terms[t].opts.fieldsOpts.resize(nf);
-			for (size_t f = 0; f < nf; ++f) terms[t].opts.fieldsOpts[f] = FtDslFieldOpts{fieldBoost[t * nf + f], needSum[t * nf + f] != 0};
-			for (uint32_t s = subOff[t]; s < subOff[t + 1]; ++s) terms[t].subterms.push_back(SubtermRef{wordIds[s], procs[s]});
-		}
+		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
+		std::vector<QueryTerm> terms = parseFtTerms(nf, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
 		bool pre = false;
 		auto res = static_cast<const GpuFtMerger*>(h)->MergeQuery(cfg, std::move(terms), excluded, sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID, &pre);
 		if (outPreselected) *outPreselected = pre ? 1 : 0;
@@ -597,6 +610,66 @@ extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, co
 			outProc[i] = res[i].proc;
 			outField[i] = res[i].field;
 			outNorm[i] = res[i].normalizedProc;
+		}
+	});
+	return n;
+}
+
+// Hybrid query through the Merger class: the FT merge stays in HBM (MergeQueryResident), then the fusion with a KNN result that lies in
+// HBM (FuseResident).  dKnn*: device pointers ((dist, row) best first as rxgpu_search_knn_device left them), knnStream: that search's stream.
+// hybrid: kind (0 RRF / 1 linear), isUnion, desc; params[5].  Returns the fused count (-1 on error); *outTie = boundary-tie flag.
+extern "C" long rxhost_ft_hybrid_query(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, const int* ops,
+									   const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
+									   const uint32_t* subOff, const uint32_t* wordIds, const float* procs, const uint8_t* excluded, const int* hybrid,
+									   const double* params, int metric, const void* dKnnDist, const void* dKnnRow, const void* dKnnCount, uint32_t knnEntries,
+									   uint32_t k, void* knnStream, const void* dRowOfDoc, const void* dRowIdOfRow, int32_t* outId, float* outRank, size_t cap,
+									   int* outTie) {
+	long n = -1;
+	guarded([&] {
+		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
+		std::vector<QueryTerm> terms = parseFtTerms(nf, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
+		const auto* m = static_cast<const GpuFtMerger*>(h);
+		m->MergeQueryResident(cfg, std::move(terms), excluded);
+		HybridFuseParams hp;
+		hp.linear = hybrid[0] == 1;
+		hp.isUnion = hybrid[1] != 0;
+		hp.desc = hybrid[2] != 0;
+		for (int i = 0; i < 5; ++i) hp.params[i] = params[i];
+		const HybridFused res = m->FuseResident(cfg, hp, metric, dKnnDist, dKnnRow, dKnnCount, knnEntries, k, knnStream, dRowOfDoc, dRowIdOfRow);
+		if (outTie) *outTie = res.knnBoundaryTie ? 1 : 0;
+		n = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
+			outId[i] = res.ids[i];
+			outRank[i] = res.ranks[i];
+		}
+	});
+	return n;
+}
+
+// The whole hybrid query through the two engines' classes (hybrid_query.h): KNN half + FT half left in HBM, fused there, one list back.
+// key: the query vector as the user gave it (normalised inside for cosine).  Returns the fused count (-1 on error).
+#include "hybrid_query.h"
+extern "C" long rxhost_hybrid_query_resident(void* mapHandle, void* ftHandle, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg,
+											 size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+											 const uint8_t* needSum, const uint32_t* subOff, const uint32_t* wordIds, const float* procs, const uint8_t* excluded,
+											 const int* hybrid, const double* params, const float* key, size_t k, const void* dRowOfDoc,
+											 const int32_t* hostRowOfDoc, int32_t* outId, float* outRank, size_t cap, int* outTie) {
+	long n = -1;
+	guarded([&] {
+		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
+		const std::vector<QueryTerm> terms = parseFtTerms(nf, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
+		HybridFuseParams hp;
+		hp.linear = hybrid[0] == 1;
+		hp.isUnion = hybrid[1] != 0;
+		hp.desc = hybrid[2] != 0;
+		for (int i = 0; i < 5; ++i) hp.params[i] = params[i];
+		const HybridFused res = HybridQueryResident(*static_cast<const GpuBruteforceMap*>(mapHandle), *static_cast<const GpuFtMerger*>(ftHandle), cfg, terms,
+													excluded, key, k, hp, dRowOfDoc, hostRowOfDoc);
+		if (outTie) *outTie = res.knnBoundaryTie ? 1 : 0;
+		n = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
+			outId[i] = res.ids[i];
+			outRank[i] = res.ranks[i];
 		}
 	});
 	return n;

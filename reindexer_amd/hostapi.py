@@ -727,6 +727,58 @@ class GpuFtMerger:
             _raise()
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
 
+    def hybrid_query(self, cfg: dict, terms, knn_dist_ptr: int, knn_row_ptr: int, knn_entries: int, k: int, metric: int, kind="rrf", params=(60.0,),
+                     union=True, desc=True, excluded=None, knn_count_ptr: int = 0, knn_stream: int = 0, row_of_doc_ptr: int = 0, rowid_of_row_ptr: int = 0):
+        """Hybrid query with everything resident: the FT merge stays in HBM (GpuFtMerger::MergeQueryResident), the KNN result lies in HBM
+        ((dist, row) best first at the given device pointers, e.g. from VectorIndex.search_knn_device), the fusion kernel applies
+        postProcessResults + MergerRankedImpl and ONE list of (row id, fused rank) comes back.  Returns (ids, ranks, boundary_tie)."""
+        L = lib()
+        L.rxhost_ft_hybrid_query.restype = _l
+        L.rxhost_ft_hybrid_query.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                             C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]
+        nf = self.nf
+        cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
+                          cfg.get("distance_weight", 0.5)], np.float64)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")]], np.int32)
+        fc = np.stack([np.asarray(cfg[k_], np.float64) for k_ in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                                 "position_boost", "position_weight")], axis=1).copy()
+        ops = np.array([t["op"] for t in terms], np.int32)
+        boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+        tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+        fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+        ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+        sub_off, wid, pr = [0], [], []
+        for t in terms:
+            for w, p_ in t["subs"]:
+                wid.append(w)
+                pr.append(p_)
+            sub_off.append(len(wid))
+        sub_off, wid, pr = np.array(sub_off, np.uint32), np.array(wid, np.uint32), np.array(pr, np.float32)
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        hyb = np.array([0 if kind == "rrf" else 1, int(union), int(desc)], np.int32)
+        par = np.zeros(5, np.float64)
+        par[:len(params)] = params
+        cap = int(cfg["merge_limit"]) + int(k)
+        oid, orank = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        tie = C.c_int(0)
+        n = L.rxhost_ft_hybrid_query(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, len(terms), ops.ctypes.data, boosts.ctypes.data,
+                                     tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data,
+                                     exc.ctypes.data if exc is not None else None, hyb.ctypes.data, par.ctypes.data, metric, knn_dist_ptr, knn_row_ptr,
+                                     knn_count_ptr or None, knn_entries, k, knn_stream or None, row_of_doc_ptr or None, rowid_of_row_ptr or None,
+                                     oid.ctypes.data, orank.ctypes.data, cap, C.byref(tie))
+        if n < 0:
+            _raise()
+        return oid[:n].copy(), orank[:n].copy(), bool(tie.value)
+
+    def read_fuse_stats(self):
+        """(fusions, device ms of the fusion kernel) since the last call."""
+        L = lib()
+        L.rxhost_ft_read_fuse_stats.restype = None
+        L.rxhost_ft_read_fuse_stats.argtypes = [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]
+        calls, ms = _u64(0), C.c_double(0)
+        L.rxhost_ft_read_fuse_stats(self.h, C.byref(calls), C.byref(ms))
+        return int(calls.value), float(ms.value)
+
     def read_timing(self):
         """(calls, total ms) spent inside the C++ Merger since the last call — the end-to-end time of the drop-in boundary, without this
         Python wrapper's argument marshalling."""
@@ -741,6 +793,51 @@ class GpuFtMerger:
         a, b = _u64(0), C.c_double(0.0)
         lib().rxhost_ft_read_stats(self.h, C.byref(a), C.byref(b))
         return int(a.value), float(b.value)
+
+
+def hybrid_query_resident(vmap: "GpuBruteforceMap", ftm: "GpuFtMerger", cfg: dict, terms, key, k: int, kind="rrf", params=(60.0,), union=True,
+                          desc=True, excluded=None, row_of_doc_ptr: int = 0, host_row_of_doc=None):
+    """rxgpu::host::HybridQueryResident (hybrid_query.h): the hybrid query through the Map and the Merger with both halves left in HBM and
+    fused there.  key: the query vector as given by the user.  Returns (row ids, fused ranks, boundary_tie_redone_on_host)."""
+    L = lib()
+    L.rxhost_hybrid_query_resident.restype = _l
+    L.rxhost_hybrid_query_resident.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp,
+                                               _vp, _vp, _sz, _vp]
+    nf = ftm.nf
+    cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
+                      cfg.get("distance_weight", 0.5)], np.float64)
+    cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")]], np.int32)
+    fc = np.stack([np.asarray(cfg[k_], np.float64) for k_ in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                             "position_boost", "position_weight")], axis=1).copy()
+    ops = np.array([t["op"] for t in terms], np.int32)
+    boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+    tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+    fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+    ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+    sub_off, wid, pr = [0], [], []
+    for t in terms:
+        for w, p_ in t["subs"]:
+            wid.append(w)
+            pr.append(p_)
+        sub_off.append(len(wid))
+    sub_off, wid, pr = np.array(sub_off, np.uint32), np.array(wid, np.uint32), np.array(pr, np.float32)
+    exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+    hyb = np.array([0 if kind == "rrf" else 1, int(union), int(desc)], np.int32)
+    par = np.zeros(5, np.float64)
+    par[:len(params)] = params
+    keyf = _f32(key)
+    hmap = np.ascontiguousarray(host_row_of_doc, np.int32) if host_row_of_doc is not None else None
+    cap = int(cfg["merge_limit"]) + int(k)
+    oid, orank = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+    tie = C.c_int(0)
+    n = L.rxhost_hybrid_query_resident(vmap.h, ftm.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, len(terms), ops.ctypes.data,
+                                       boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, sub_off.ctypes.data, wid.ctypes.data,
+                                       pr.ctypes.data, exc.ctypes.data if exc is not None else None, hyb.ctypes.data, par.ctypes.data, keyf.ctypes.data, k,
+                                       row_of_doc_ptr or None, hmap.ctypes.data if hmap is not None else None, oid.ctypes.data, orank.ctypes.data, cap,
+                                       C.byref(tie))
+    if n < 0:
+        _raise()
+    return oid[:n].copy(), orank[:n].copy(), bool(tie.value)
 
 
 def default_ft_config(num_fields=1, **kw):

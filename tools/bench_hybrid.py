@@ -7,8 +7,10 @@ fused with RRF (rank_const 60) — the pipeline of hybrid.md's `ORDER BY RRF()` 
 Also imported by bench.py (`run(opts)`), which puts the same leg into the driver-run bench line.
 
 Per query: 1-3 query words (each with an exact and a stem variant, document frequencies 10 % / 3 % / 1 % / 0.3 %), one query vector.
-GPU: GpuFtMerger (single-term: mergeSimple, multi-term: OR terms through mergeTerm) + GpuBruteforceMap::select (k = 100) + host rank
-fusion (hybrid_rerank.h).
+GPU: rxgpu::host::HybridQueryResident (hybrid_query.h) — the Map's search and the Merger's merge run on their own streams with their
+results LEFT IN HBM, one kernel applies postProcessResults + the rank fusion there (hybrid_fuse.hip), one list of (row id, rank) comes
+back.  The same queries also run through the separate product calls (GpuFtMerger::MergeQuery, GpuBruteforceMap::select, host fusion
+hybrid_rerank.h) — the round-2 path — for the per-half parity against the reference's engines and as the comparison figure.
 CPU baseline (cpu_baseline.kind "reference" when oracle/_ref is there): the SAME pipeline from the reference's own code compiled in
 place — ft::Merger (libref_ft.so), hnswlib::BruteforceSearch over the FULL corpus (libref_oracle.so, AVX-512) and
 SelectIteratorContainer::MergerRankedImpl (libref_rank.so) — one core, `cpu_queries` queries, measured (no scaling).
@@ -31,7 +33,7 @@ os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
 from bench_bm25 import pos_postings  # noqa: E402
 from reindexer_amd import hostapi  # noqa: E402
 
-DEFAULTS = dict(docs=5_000_000, dim=512, queries=20, k=100, cpu_queries=8, device=0, out=None)
+DEFAULTS = dict(docs=5_000_000, dim=512, queries=64, k=100, cpu_queries=64, device=0, out=None)
 
 
 def run(o) -> dict:
@@ -80,37 +82,58 @@ def run(o) -> dict:
         nw = int(rng.integers(1, 4))
         plans.append([int(x) for x in rng.choice(len(vocab), nw, replace=False)])
 
-    def run_gpu(q):
+    def terms_of(q):
+        return [dict(op=1, opts=opts, subs=[(w, s["proc"]) for w, s in vocab[p]]) for p in plans[q]]
+
+    def run_split(q):
+        """the separate product calls: FT result and KNN result come to the host, fused there"""
         plan = plans[q]
         t = [time.perf_counter()]
         if len(plan) == 1:
             fid, fproc, _, _ = ftm.merge(cfg, opts, [(w, s["proc"]) for w, s in vocab[plan[0]]], sort_by_rank=True)
         else:
-            terms = [dict(op=1, opts=opts, subs=[(w, s["proc"]) for w, s in vocab[p]]) for p in plan]
-            fid, fproc, _, _, _ = ftm.merge_query(cfg, terms, sort_by_rank=True)
+            fid, fproc, _, _, _ = ftm.merge_query(cfg, terms_of(q), sort_by_rank=True)
         t.append(time.perf_counter())
         kid, krank = vm.select(keys[q], k=o.k, need_sort=False)
         t.append(time.perf_counter())
-        # the FT result goes in as the merger returns it (best rank first): id view + RRF positions are derived inside the fusion
         ids, ranks = hostapi.merge_ranked("rrf", [60.0], kid, krank, fid, fproc, union=True, desc=True, metric=2, ft_order="rank")
         t.append(time.perf_counter())
         return (fid, fproc, kid, krank, ids, ranks), np.diff(t)
 
-    run_gpu(0)   # warm-up (device sync of the Map, buffers)
+    def run_resident(q):
+        return hostapi.hybrid_query_resident(vm, ftm, cfg, terms_of(q), keys[q], o.k, kind="rrf", params=[60.0], union=True, desc=True)
+
+    run_split(0)   # warm-up (device sync of the Map, buffers)
+    run_resident(0)
     t0 = time.perf_counter()
     parts = np.zeros(3)
     results = []
     for q in range(o.queries):
-        r, dt = run_gpu(q)
+        r, dt = run_split(q)
         results.append(r)
         parts += dt
+    split_s = time.perf_counter() - t0
+    ftm.read_stats()
+    ftm.read_fuse_stats()
+    t0 = time.perf_counter()
+    fused = [run_resident(q) for q in range(o.queries)]
     gpu_s = time.perf_counter() - t0
+    ft_postings, ft_kernel_ms = ftm.read_stats()
+    fuse_calls, fuse_kernel_ms = ftm.read_fuse_stats()
+    same_as_split = sum(int(np.array_equal(f[0], r[4]) and np.array_equal(f[1].view(np.uint32), r[5].view(np.uint32))) for f, r in zip(fused, results))
     out = {"workload": f"hybrid RRF: ft_fast BM25 (1-3 OR terms x 2 sub-terms) over {o.docs} vdocs + cosine KNN k={o.k} over {o.docs} x {o.dim}, union fusion "
                        "(BASELINE configs[4])",
            "load_seconds": load_s,
-           "gpu": {"queries": o.queries, "queries_per_sec": o.queries / gpu_s, "ms_per_query": gpu_s / o.queries * 1e3,
-                   "ms_ft_merge": parts[0] / o.queries * 1e3, "ms_knn_select": parts[1] / o.queries * 1e3, "ms_fusion": parts[2] / o.queries * 1e3,
-                   "fused_results_avg": float(np.mean([len(r[4]) for r in results]))}}
+           "gpu": {"path": "resident: KNN list and FT merge left in HBM, postProcessResults + rank fusion on the device (hybrid_fuse.hip), one download",
+                   "queries": o.queries, "queries_per_sec": o.queries / gpu_s, "ms_per_query": gpu_s / o.queries * 1e3,
+                   "ms_fusion": fuse_kernel_ms / max(fuse_calls, 1), "fusion_kernel_launches": fuse_calls,
+                   "ms_ft_kernels": ft_kernel_ms / o.queries, "ft_postings_per_query": ft_postings / o.queries,
+                   "boundary_ties_redone_on_host": int(sum(int(f[2]) for f in fused)),
+                   "fused_results_avg": float(np.mean([len(f[0]) for f in fused])),
+                   "identical_to_split_path_frac": same_as_split / o.queries},
+           "gpu_split": {"path": "round-2 path: both halves downloaded, fused on the host (hybrid_rerank.h)", "queries_per_sec": o.queries / split_s,
+                         "ms_per_query": split_s / o.queries * 1e3, "ms_ft_merge": parts[0] / o.queries * 1e3, "ms_knn_select": parts[1] / o.queries * 1e3,
+                         "ms_fusion": parts[2] / o.queries * 1e3}}
     nq = min(o.cpu_queries, o.queries)
     try:
         from oracle import pyoracle
@@ -154,7 +177,7 @@ def run(o) -> dict:
             wi, wr = rrank.merge("rrf", [60.0], (kl >> np.uint64(32)).astype(np.int32), (-kd).astype(np.float32), rd[by_id].astype(np.int32),
                                  rn[by_id].astype(np.float32), union=True, desc=True, metric=2, ft_positions=pos[by_id])
             t4 = time.perf_counter()
-            fused_ok = np.array_equal(wi, ids) and np.array_equal(wr.view(np.uint32), ranks.view(np.uint32))
+            fused_ok = np.array_equal(wi, fused[q][0]) and np.array_equal(wr.view(np.uint32), fused[q][1].view(np.uint32))   # the RESIDENT path's list
             same_ft += int(ft_ok)
             same_knn += int(knn_ok)
             same_fused += int(fused_ok)
@@ -167,7 +190,8 @@ def run(o) -> dict:
                                "sample": f"{nq} of the same queries, measured (full {o.docs}-row corpus, no scaling): reference ft::Merger + "
                                          "BruteforceSearch (AVX-512) + MergerRankedImpl, compiled in place (oracle/_ref)"}
         out["parity"] = {"checked": nq, "ft_identical_frac": same_ft / nq, "knn_identical_frac": same_knn / nq, "fused_identical_frac": same_fused / nq,
-                         "against": "reference ft::Merger / BruteforceSearch / MergerRankedImpl"}
+                         "against": "reference ft::Merger / BruteforceSearch / MergerRankedImpl; the fused list checked is the device fusion's "
+                                    "(resident path), the two halves are the split path's"}
         rb.close()
         rft.close()
     except Exception as e:
