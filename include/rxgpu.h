@@ -344,6 +344,11 @@ int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg
 								   const uint32_t* word_ids, const float* procs, const uint8_t* excluded);
 int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
 								  const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded);
+/* The FT-only half of the fusion (postProcessResults, the documents' order among themselves, the rank-class tables), enqueued behind the
+ * resident merge: it needs nothing from the KNN side, so a caller that enqueues it BEFORE it starts the KNN search has it run while the
+ * scan streams the corpus, and only the short join is left on the query's critical path.  Optional — rxgpu_hybrid_fuse_resident
+ * enqueues it itself when it was not called with the same min_rank / params / d_row_of_doc. */
+int rxgpu_hybrid_prepare_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_row_of_doc);
 /* Fuses the resident merge of `h` (postProcessResults — merger.h:111-140: proc < min_rank dropped, scaled to 0..255, uint8 — is applied on
  * the device) with a KNN result that lies in HBM as rxgpu_search_knn_device left it: d_knn_dist / d_knn_row best first, d_knn_count (device
  * uint32, or NULL) of knn_n entries valid, the first k taking part (ranks as the planner sees them: the distance for L2, its negation for
@@ -355,8 +360,9 @@ int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_knn_dist,
 							   const void* d_knn_row, const void* d_knn_count, uint32_t knn_n, uint32_t k, void* knn_stream, const void* d_row_of_doc,
 							   const void* d_rowid_of_row, int32_t* out_ids, float* out_ranks, uint64_t cap, uint64_t* out_n, uint32_t* out_flags);
-/* Fusions run by rxgpu_hybrid_fuse_resident and the device time of their kernel (HIP events on the merger's stream) since the last call. */
-int rxgpu_hybrid_read_stats(rxgpu_ft_index* h, uint64_t* calls, double* kernel_ms);
+/* Fusions run by rxgpu_hybrid_fuse_resident and the device time of their JOIN kernel — what is left on the critical path once both
+ * halves are there (HIP events on the merger's stream) — since the last call. */
+int rxgpu_hybrid_read_stats(rxgpu_ft_index* h, uint64_t* calls, double* kernel_ms, double* prepare_ms /* the overlapped FT-only kernel; may be NULL */);
 /* The same kernel on host arrays: knn_ids / knn_ranks best first (at most 1024), ft_ids (unique, any order) with their uint8 ranks
  * (MergeInfo::normalizedProc).  cap >= n_knn + n_ft. */
 int rxgpu_hybrid_fuse(int device, const rxgpu_hybrid_params* params, int metric, const int32_t* knn_ids, const float* knn_ranks, uint32_t n_knn,

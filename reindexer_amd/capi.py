@@ -88,9 +88,10 @@ _SIGNATURES = {
     "rxgpu_ft_get_word": (_i, [_vp, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u32), _vp]),
     "rxgpu_ft_merge_simple_resident": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp]),
     "rxgpu_ft_merge_terms_resident": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rxgpu_hybrid_prepare_resident": (_i, [_vp, C.c_int32, _vp, _i, _vp]),
     "rxgpu_hybrid_fuse_resident": (_i, [_vp, C.c_int32, _vp, _i, _vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64),
                                         C.POINTER(_u32)]),
-    "rxgpu_hybrid_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "rxgpu_hybrid_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rxgpu_hybrid_fuse": (_i, [_i, _vp, _i, _vp, _vp, _u32, _vp, _vp, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_profile_enable": (_i, [_vp, _i]),
     "rxgpu_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(_u64), C.POINTER(C.c_double)]),
@@ -240,6 +241,15 @@ class VectorIndex:
         _check(lib().rxgpu_search_knn_device(self._h, d_queries_ptr, nq, kk, d_out_dist_ptr, d_out_row_ptr, d_out_count_ptr, stream_ptr))
 
     # ---- pre-filtered search (`WHERE cond AND KNN(...)`)
+    def search_knn_resident(self, query, kk: int):
+        """rxgpu_search_knn_resident: one host query, the (dist, row) list left in the index's device buffers.
+        Returns (d_dist_ptr, d_row_ptr, d_count_ptr, stream_ptr, entries)."""
+        q = _f32c(query)
+        dd, dr, dc, st = _vp(), _vp(), _vp(), _vp()
+        n = _u32(0)
+        _check(lib().rxgpu_search_knn_resident(self._h, q.ctypes.data, kk, C.byref(dd), C.byref(dr), C.byref(dc), C.byref(st), C.byref(n)))
+        return dd.value, dr.value, dc.value, st.value, int(n.value)
+
     def search_knn_subset(self, queries, kk: int, row_ids):
         """Exact top-kk among the listed rows only (strictly increasing uint32 internal rows) -> (dist, row, count)."""
         q = _f32c(queries).reshape(-1, self.dim)

@@ -93,11 +93,17 @@ struct rxgpu_ft_index {
 	// a merge left in HBM for the hybrid fusion (rxgpu_ft_merge_*_resident): no export, no wait; checked by finish_pending()
 	bool res_pending = false;
 	uint32_t res_cap = 0;          // max_merged of that merge (the packed layout of d_out depends on it)
+	bool prep_done = false;        // hybrid_prepare_kernel has been enqueued behind that merge (with prep_sig's reranker / min_rank)
+	double prep_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	rxgpu_devbuf d_fuse;           // fusion scratch: radix ping-pong keys / classes
 	hipEvent_t ev_knn = nullptr;   // orders the fusion behind the KNN search's stream
-	hipEvent_t ev_fa = nullptr, ev_fb = nullptr;   // around the fusion kernel (rxgpu_hybrid_read_stats)
+	hipEvent_t ev_fa = nullptr, ev_fb = nullptr;   // around the join kernel (rxgpu_hybrid_read_stats)
+	hipEvent_t ev_pa = nullptr, ev_pb = nullptr;   // around the prepare kernel
+	bool prep_timed = false;
+	double prep_ms = 0.0;
 	uint64_t fuse_calls = 0;
 	double fuse_ms = 0.0;
+	double fuse_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // RXGPU_FUSE_STAMPS: summed phase stamps of the fusion kernel (us since its first)
 	uint64_t stat_postings = 0;
 	double stat_ms = 0.0;
 	double stamps[64] = {};   // RXGPU_FT_STAMPS: summed phase stamps (relative to the workgroup's first), see rxgpu_ft_read_stats
@@ -174,7 +180,7 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 		if (p) (void)hipFree(p);
 	}
 	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse}) b->release();
-	for (hipEvent_t e : {h->ev_knn, h->ev_fa, h->ev_fb}) {
+	for (hipEvent_t e : {h->ev_knn, h->ev_fa, h->ev_fb, h->ev_pa, h->ev_pb}) {
 		if (e) (void)hipEventDestroy(e);
 	}
 	if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -545,6 +551,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_HIP(hipEventRecord(h->ev_b, st));
 	if (resident) {   // the result stays where ft_finish wrote it (d_out): the fusion kernel reads it there, nothing travels
 		h->res_pending = true;
+		h->prep_done = false;
 		h->res_cap = uint32_t(max_merged);
 		h->stat_postings += merged_postings;
 		h->trace_us[2] += since(t_launch);
@@ -860,6 +867,7 @@ int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg
 	std::vector<QueryTermIn> terms{QueryTermIn{1, opts, 0, nsub}};
 	uint64_t n = 0;
 	h->res_cap = 0;
+	h->prep_done = false;
 	return run_merge(h, cfg, true, terms, word_ids, procs, excluded, nullptr, nullptr, nullptr, nullptr, 0, &n, nullptr, "rxgpu_ft_merge_simple_resident", true);
 }
 
@@ -877,6 +885,7 @@ int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 	for (uint32_t t = 0; t < nterms; ++t) terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1]};
 	uint64_t n = 0;
 	h->res_cap = 0;
+	h->prep_done = false;
 	return run_merge(h, cfg, false, terms, word_ids, procs, excluded, nullptr, nullptr, nullptr, nullptr, 0, &n, nullptr, "rxgpu_ft_merge_terms_resident", true);
 }
 
@@ -895,6 +904,62 @@ void fill_reranker(rxgpu::HybridFuseArgs& a, const rxgpu_hybrid_params* p, int m
 }
 }  // namespace
 
+namespace {
+// the FT-side arguments of the two fusion kernels for the resident merge of `h` (M = its max_merged; 0: no resident merge)
+int fuse_ft_args(rxgpu_ft_index* h, uint32_t M, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_row_of_doc,
+				 rxgpu::HybridFuseArgs& a) {
+	const size_t key_bytes = align256(size_t(2) * std::max<uint32_t>(M, 1) * 4), cls_bytes = align256(size_t(2) * std::max<uint32_t>(M, 1) * 2);
+	if (int rc = h->d_fuse.ensure(key_bytes + cls_bytes + align256(sizeof(rxgpu::HybridFuseState))); rc) return rc;
+	char* ob = static_cast<char*>(h->d_out.ptr);
+	if (M) {   // the packed layout run_merge gave d_out for max_merged = M
+		a.ft_count_ptr = reinterpret_cast<const uint32_t*>(ob);
+		a.ft_doc = reinterpret_cast<const uint32_t*>(ob + align256(16));
+		a.ft_proc = reinterpret_cast<const float*>(ob + align256(16) + align256(size_t(M) * 4));
+	}
+	a.ft_n = 0;
+	a.ft_cap = M;
+	a.min_rank = float(min_rank);
+	a.row_of_doc = static_cast<const int32_t*>(d_row_of_doc);
+	fill_reranker(a, params, metric);
+	a.scratch_key = static_cast<uint32_t*>(h->d_fuse.ptr);
+	a.scratch_cls = reinterpret_cast<uint16_t*>(static_cast<char*>(h->d_fuse.ptr) + key_bytes);
+	a.state = reinterpret_cast<rxgpu::HybridFuseState*>(static_cast<char*>(h->d_fuse.ptr) + key_bytes + cls_bytes);
+	return RXGPU_OK;
+}
+void prep_signature(int32_t min_rank, const rxgpu_hybrid_params* p, const void* d_row_of_doc, double sig[8]) {
+	sig[0] = min_rank;
+	sig[1] = p->kind * 4 + (p->desc ? 2 : 0);
+	for (int i = 0; i < 5; ++i) sig[2 + i] = p->params[i];
+	sig[7] = double(reinterpret_cast<uintptr_t>(d_row_of_doc));
+}
+int enqueue_prepare(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_row_of_doc) {
+	const uint32_t M = h->res_pending ? h->res_cap : 0;
+	rxgpu::HybridFuseArgs a{};
+	if (int rc = fuse_ft_args(h, M, min_rank, params, metric, d_row_of_doc, a); rc) return rc;
+	if (!h->ev_pa) {
+		RX_HIP(hipEventCreate(&h->ev_pa));
+		RX_HIP(hipEventCreate(&h->ev_pb));
+	}
+	RX_HIP(hipEventRecord(h->ev_pa, h->stream));
+	RX_HIP(rxgpu::launch_hybrid_prepare(a, h->stream));
+	RX_HIP(hipEventRecord(h->ev_pb, h->stream));
+	h->prep_timed = true;
+	prep_signature(min_rank, params, d_row_of_doc, h->prep_sig);
+	h->prep_done = true;
+	return RXGPU_OK;
+}
+}  // namespace
+
+// The FT-only half of the fusion (postProcessResults, id order, class / group tables), enqueued behind the resident merge so that it
+// runs while the KNN search is still streaming the corpus.  Optional: rxgpu_hybrid_fuse_resident enqueues it itself when it was not.
+int rxgpu_hybrid_prepare_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_row_of_doc) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "rxgpu_hybrid_prepare_resident: null argument");
+	if (int rc = check_hybrid_params(params, "rxgpu_hybrid_prepare_resident"); rc) return rc;
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	return enqueue_prepare(h, min_rank, params, metric, d_row_of_doc);
+}
+
 int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_knn_dist,
 							   const void* d_knn_row, const void* d_knn_count, uint32_t knn_n, uint32_t k, void* knn_stream, const void* d_row_of_doc,
 							   const void* d_rowid_of_row, int32_t* out_ids, float* out_ranks, uint64_t cap, uint64_t* out_n, uint32_t* out_flags) {
@@ -909,8 +974,13 @@ int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_
 	const uint32_t M = h->res_pending ? h->res_cap : 0;   // no resident merge: an empty FT side (the merge found nothing to do)
 	const size_t out_cap = size_t(M) + k;
 	RX_CHECK(cap >= out_cap && (out_cap == 0 || (out_ids && out_ranks)), RXGPU_ERR_OVERFLOW, "rxgpu_hybrid_fuse_resident: output buffers too small");
-	const size_t key_bytes = align256(size_t(2) * std::max<uint32_t>(M, 1) * 4), cls_bytes = align256(size_t(2) * std::max<uint32_t>(M, 1) * 2);
-	if (int rc = h->d_fuse.ensure(key_bytes + cls_bytes + 256); rc) return rc;
+	{   // the FT-only half, unless the caller had it enqueued already (for exactly these parameters)
+		double sig[8];
+		prep_signature(min_rank, params, d_row_of_doc, sig);
+		if (!h->prep_done || std::memcmp(sig, h->prep_sig, sizeof(sig)) != 0) {
+			if (int rc = enqueue_prepare(h, min_rank, params, metric, d_row_of_doc); rc) return rc;
+		}
+	}
 	// the result leaves through the pinned staging buffer: the kernel's stores go straight to host memory, no copy-engine start-up
 	const size_t o_ids = 256, o_ranks = o_ids + align256(out_cap * 4), stage = o_ranks + align256(out_cap * 4);
 	if (int rc = h->ensure_pinned(stage); rc) return rc;
@@ -919,22 +989,13 @@ int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_
 	RX_HIP(hipHostGetDevicePointer(&hp_dev, hp, 0));
 	char* hd = static_cast<char*>(hp_dev);
 	hipStream_t st = h->stream;
-	if (knn_stream) {   // the KNN search ran on the caller's stream: the fusion waits for it on the device, the host does not
+	if (knn_stream) {   // the KNN search ran on the caller's stream: the join waits for it on the device, the host does not
 		if (!h->ev_knn) RX_HIP(hipEventCreateWithFlags(&h->ev_knn, hipEventDisableTiming));
 		RX_HIP(hipEventRecord(h->ev_knn, static_cast<hipStream_t>(knn_stream)));
 		RX_HIP(hipStreamWaitEvent(st, h->ev_knn, 0));
 	}
 	rxgpu::HybridFuseArgs a{};
-	char* ob = static_cast<char*>(h->d_out.ptr);
-	if (M) {   // the packed layout run_merge gave d_out for max_merged = M
-		a.ft_count_ptr = reinterpret_cast<const uint32_t*>(ob);
-		a.ft_doc = reinterpret_cast<const uint32_t*>(ob + align256(16));
-		a.ft_proc = reinterpret_cast<const float*>(ob + align256(16) + align256(size_t(M) * 4));
-	}
-	a.ft_n = 0;
-	a.ft_cap = M;
-	a.min_rank = float(min_rank);
-	a.row_of_doc = static_cast<const int32_t*>(d_row_of_doc);
+	if (int rc = fuse_ft_args(h, M, min_rank, params, metric, d_row_of_doc, a); rc) return rc;
 	a.knn_dist = static_cast<const float*>(d_knn_dist);
 	a.knn_row = static_cast<const uint32_t*>(d_knn_row);
 	a.knn_count_ptr = static_cast<const uint32_t*>(d_knn_count);
@@ -942,19 +1003,19 @@ int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_
 	a.k = k;
 	a.knn_negate = metric == RXGPU_METRIC_L2 ? 0 : 1;
 	a.rowid_of_row = static_cast<const int32_t*>(d_rowid_of_row);
-	fill_reranker(a, params, metric);
 	a.out_header = reinterpret_cast<uint32_t*>(hd);
 	a.out_ids = reinterpret_cast<int32_t*>(hd + o_ids);
 	a.out_ranks = reinterpret_cast<float*>(hd + o_ranks);
-	a.scratch_key = static_cast<uint32_t*>(h->d_fuse.ptr);
-	a.scratch_cls = reinterpret_cast<uint16_t*>(static_cast<char*>(h->d_fuse.ptr) + key_bytes);
+	static const bool stamps = std::getenv("RXGPU_FUSE_STAMPS") != nullptr;
+	if (stamps) a.dbg = reinterpret_cast<unsigned long long*>(hd + 64);   // inside the 256-byte header region of the staging buffer
 	if (!h->ev_fa) {
 		RX_HIP(hipEventCreate(&h->ev_fa));
 		RX_HIP(hipEventCreate(&h->ev_fb));
 	}
 	RX_HIP(hipEventRecord(h->ev_fa, st));
-	RX_HIP(rxgpu::launch_hybrid_fuse(a, st));
+	RX_HIP(rxgpu::launch_hybrid_join(a, st));
 	RX_HIP(hipEventRecord(h->ev_fb, st));
+	h->prep_done = false;
 	{
 		using clk = std::chrono::steady_clock;
 		const auto t_poll = clk::now();
@@ -981,6 +1042,12 @@ int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_
 			h->fuse_ms += fms;
 			h->fuse_calls += 1;
 		}
+		if (h->prep_timed && hipEventElapsedTime(&fms, h->ev_pa, h->ev_pb) == hipSuccess) h->prep_ms += fms;
+		h->prep_timed = false;
+	}
+	if (stamps) {
+		const unsigned long long* raw = reinterpret_cast<const unsigned long long*>(hp + 64);
+		for (int k2 = 1; k2 < 8; ++k2) h->fuse_stamps[k2] += raw[k2] >= raw[0] ? double(raw[k2] - raw[0]) * 0.01 : 0.0;   // 100 MHz -> us
 	}
 	const uint32_t* hdr = reinterpret_cast<const uint32_t*>(hp);
 	const uint64_t n = hdr[0];
@@ -994,11 +1061,21 @@ int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_
 	return RXGPU_OK;
 }
 
-int rxgpu_hybrid_read_stats(rxgpu_ft_index* h, uint64_t* calls, double* kernel_ms) {
+int rxgpu_hybrid_read_stats(rxgpu_ft_index* h, uint64_t* calls, double* kernel_ms, double* prepare_ms) {
 	RX_CHECK(h && calls && kernel_ms, RXGPU_ERR_PARAMS, "rxgpu_hybrid_read_stats: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
 	*calls = h->fuse_calls;
 	*kernel_ms = h->fuse_ms;
+	if (prepare_ms) *prepare_ms = h->prep_ms;
+	h->prep_ms = 0.0;
+	if (std::getenv("RXGPU_FUSE_STAMPS") && h->fuse_calls) {
+		std::fprintf(stderr, "[rxgpu fuse stamps] us since kernel start:");
+		for (int k = 1; k < 8; ++k) {
+			std::fprintf(stderr, " %d:%.1f", k, h->fuse_stamps[k] / double(h->fuse_calls));
+			h->fuse_stamps[k] = 0;
+		}
+		std::fprintf(stderr, "\n");
+	}
 	h->fuse_calls = 0;
 	h->fuse_ms = 0.0;
 	return RXGPU_OK;
@@ -1020,7 +1097,8 @@ int rxgpu_hybrid_fuse(int device, const rxgpu_hybrid_params* params, int metric,
 	const size_t nf = std::max<uint32_t>(n_ft, 1), nk = std::max<uint32_t>(n_knn, 1), no = size_t(n_ft) + n_knn + 1;
 	Carver cv;
 	const size_t o_fid = cv.take(nf * 4), o_fr = cv.take(nf), o_kid = cv.take(nk * 4), o_kr = cv.take(nk * 4), o_key = cv.take(2 * nf * 4),
-				 o_cls = cv.take(2 * nf * 2), o_hdr = cv.take(16), o_oid = cv.take(no * 4), o_or = cv.take(no * 4);
+				 o_cls = cv.take(2 * nf * 2), o_hdr = cv.take(16), o_oid = cv.take(no * 4), o_or = cv.take(no * 4),
+				 o_state = cv.take(sizeof(rxgpu::HybridFuseState));
 	rxgpu_devbuf buf;
 	if (int rc = buf.ensure(cv.off); rc) return rc;
 	struct Rel {
@@ -1052,7 +1130,9 @@ int rxgpu_hybrid_fuse(int device, const rxgpu_hybrid_params* params, int metric,
 	a.out_ranks = reinterpret_cast<float*>(d + o_or);
 	a.scratch_key = reinterpret_cast<uint32_t*>(d + o_key);
 	a.scratch_cls = reinterpret_cast<uint16_t*>(d + o_cls);
-	RX_HIP(rxgpu::launch_hybrid_fuse(a, nullptr));
+	a.state = reinterpret_cast<rxgpu::HybridFuseState*>(d + o_state);
+	RX_HIP(rxgpu::launch_hybrid_prepare(a, nullptr));
+	RX_HIP(rxgpu::launch_hybrid_join(a, nullptr));
 	RX_HIP(hipDeviceSynchronize());
 	uint32_t hdr[4];
 	RX_HIP(hipMemcpy(hdr, d + o_hdr, sizeof(hdr), hipMemcpyDeviceToHost));

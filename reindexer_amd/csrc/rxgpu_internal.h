@@ -79,6 +79,19 @@ void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, ui
 
 // Hybrid FT + KNN rank fusion on the device (hybrid_fuse.hip)
 constexpr int kMaxFuseKnn = 1024;      // KNN entries one fusion takes (k of the KNN condition)
+// what hybrid_prepare_kernel leaves in HBM for hybrid_join_kernel, next to the FT documents in their final mutual order
+struct HybridFuseState {
+	uint32_t n_valid;            // documents that passed postProcessResults = entries of the prepared list
+	uint32_t max_id;
+	uint32_t result_in_second;   // which half of the scratch arrays holds the prepared list
+	uint32_t pad;
+	uint32_t cls_pos[256];       // RRF position of a rank class
+	uint32_t cls_key[256];       // fused rank of an FT-only document of the class, as an order key (smaller = earlier)
+	float cls_rank[256];         // ... and as the float that is returned
+	uint32_t cls_group[256];     // classes with equal fused ranks share a group
+	uint32_t grp_key[256];       // key of group g (0xFFFFFFFF: unused)
+	uint32_t grp_start[260];     // first prepared position of group g; [256] = n_valid
+};
 struct HybridFuseArgs {
 	// FT side.  Either the merge train's raw output (ft_doc + ft_proc: postProcessResults is applied here with min_rank) or documents with
 	// their uint8 ranks (ft_doc + ft_rank_u8).  Ids unique, any order.  ft_count_ptr (device) overrides ft_n when set.
@@ -103,10 +116,13 @@ struct HybridFuseArgs {
 	int32_t* out_ids;
 	float* out_ranks;
 	uint32_t* out_header;              // [0] count, [1] flags (1: distance tie at the k-th place), [2] head size, [3] tail size
+	unsigned long long* dbg;           // phase stamps of the join kernel (100 MHz wall clock), 8 words, or null
+	HybridFuseState* state;
 	uint32_t* scratch_key;             // [2 * ft_cap]
 	uint16_t* scratch_cls;             // [2 * ft_cap]
 };
-hipError_t launch_hybrid_fuse(const HybridFuseArgs& a, hipStream_t st);
+hipError_t launch_hybrid_prepare(const HybridFuseArgs& a, hipStream_t st);   // FT only: may run while the KNN search is still going
+hipError_t launch_hybrid_join(const HybridFuseArgs& a, hipStream_t st);      // needs both halves
 
 // ft_fast merge (ft_merge.hip): Merger::mergeSimple / mergeTerm + restricting bitmask + preselect, restated ORDER-FREE so that a whole
 // query is a fixed number of launches (see the header of ft_merge.hip)

@@ -113,8 +113,8 @@ void GpuFtMerger::ReadStats(uint64_t& postings, double& kernelMs) const {
 	if (rxgpu_ft_read_stats(dev_, &postings, &kernelMs) != RXGPU_OK) throwDevice("ReadStats");
 }
 
-void GpuFtMerger::ReadFuseStats(uint64_t& calls, double& kernelMs) const {
-	if (rxgpu_hybrid_read_stats(dev_, &calls, &kernelMs) != RXGPU_OK) throwDevice("ReadFuseStats");
+void GpuFtMerger::ReadFuseStats(uint64_t& calls, double& kernelMs, double* prepareMs) const {
+	if (rxgpu_hybrid_read_stats(dev_, &calls, &kernelMs, prepareMs) != RXGPU_OK) throwDevice("ReadFuseStats");
 }
 
 namespace {
@@ -305,6 +305,22 @@ bool GpuFtMerger::MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm>
 	return true;
 }
 
+namespace {
+rxgpu_hybrid_params toAbi(const HybridFuseParams& hp) {
+	rxgpu_hybrid_params p{};
+	p.kind = hp.linear ? 1 : 0;
+	p.is_union = hp.isUnion ? 1 : 0;
+	p.desc = hp.desc ? 1 : 0;
+	for (int i = 0; i < 5; ++i) p.params[i] = hp.params[i];
+	return p;
+}
+}  // namespace
+
+void GpuFtMerger::PrepareResident(const FtConfig& cfg, const HybridFuseParams& hp, int metric, const void* dRowOfDoc) const {
+	const rxgpu_hybrid_params p = toAbi(hp);
+	if (rxgpu_hybrid_prepare_resident(dev_, cfg.minRank, &p, metric, dRowOfDoc) != RXGPU_OK) throwDevice("PrepareResident");
+}
+
 HybridFused GpuFtMerger::FuseResident(const FtConfig& cfg, const HybridFuseParams& hp, int metric, const void* dKnnDist, const void* dKnnRow,
 									  const void* dKnnCount, uint32_t knnEntries, uint32_t k, void* knnStream, const void* dRowOfDoc,
 									  const void* dRowIdOfRow) const {
@@ -312,11 +328,7 @@ HybridFused GpuFtMerger::FuseResident(const FtConfig& cfg, const HybridFuseParam
 	const size_t cap = size_t(cfg.mergeLimit) + k;
 	out.ids.resize(cap);
 	out.ranks.resize(cap);
-	rxgpu_hybrid_params p{};
-	p.kind = hp.linear ? 1 : 0;
-	p.is_union = hp.isUnion ? 1 : 0;
-	p.desc = hp.desc ? 1 : 0;
-	for (int i = 0; i < 5; ++i) p.params[i] = hp.params[i];
+	const rxgpu_hybrid_params p = toAbi(hp);
 	uint64_t n = 0;
 	uint32_t flags = 0;
 	if (rxgpu_hybrid_fuse_resident(dev_, cfg.minRank, &p, metric, dKnnDist, dKnnRow, dKnnCount, knnEntries, k, knnStream, dRowOfDoc, dRowIdOfRow,

@@ -156,6 +156,9 @@ public:
 	// Hybrid query, FT half: the same merge, but the result STAYS IN HBM (no export, no wait).  False when the query merges nothing
 	// (Empty(), no sub-terms) — there is then no resident result and FuseResident sees an empty FT side.
 	bool MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded) const;
+	// ... the FT-only half of the fusion (postProcessResults, the documents' mutual order, rank-class tables) enqueued behind that merge:
+	// called BEFORE the KNN search is started it runs while the scan streams the corpus (optional: FuseResident does it when it was not) ...
+	void PrepareResident(const FtConfig& cfg, const HybridFuseParams& hp, int metric, const void* dRowOfDoc = nullptr) const;
 	// ... and the fusion: postProcessResults + MergerRankedImpl on the device over the resident merge and a KNN result that lies in HBM
 	// as rxgpu_search_knn_device left it ((dist, row) best first; the first k take part; knnStream = the stream of that search).
 	HybridFused FuseResident(const FtConfig& cfg, const HybridFuseParams& hp, int metric, const void* dKnnDist, const void* dKnnRow, const void* dKnnCount,
@@ -163,7 +166,8 @@ public:
 
 	size_t TotalDocs() const noexcept { return totalDocs_; }
 	void ReadStats(uint64_t& postings, double& kernelMs) const;
-	void ReadFuseStats(uint64_t& calls, double& kernelMs) const;   // FuseResident: fusions and the device time of their kernel since the last call
+	// FuseResident: fusions, the device time of their join kernel (critical path) and of the overlapped prepare kernel since the last call
+	void ReadFuseStats(uint64_t& calls, double& kernelMs, double* prepareMs = nullptr) const;
 	// wall time spent inside Merge / MergeQuery since the last call (everything behind the Merger boundary: plan, launches, the wait,
 	// unpacking, postProcessResults) and the number of calls; resets both
 	void ReadTiming(uint64_t& calls, double& totalMs) const;

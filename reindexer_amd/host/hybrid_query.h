@@ -2,7 +2,9 @@
 // NOTHING leaving HBM between the engines:
 //   KNN half   GpuBruteforceMap::SearchKnnResident    the scan's exact top-(k + 1) (dist, row) list stays in the index's device buffers
 //   FT half    GpuFtMerger::MergeQueryResident        ft_finish's (document, proc) list stays in the merger's device buffer
-//   fusion     GpuFtMerger::FuseResident              postProcessResults + MergerRankedImpl / mergeRanked on the device (hybrid_fuse.hip),
+//   fusion     GpuFtMerger::PrepareResident           the FT-only part (postProcessResults, order of the documents among themselves, rank
+//                                                     classes) right behind the merge — overlapped with the scan
+//              GpuFtMerger::FuseResident              the join (MergerRankedImpl / mergeRanked) once both halves are there (hybrid_fuse.hip);
 //                                                     the two halves run on their own streams and meet through an event
 // One list of (row id, fused rank) in Merged<desc> order comes back.  Mirrors what the planner does with the two SelectKeyResults in
 // SelectIteratorContainer (cpp_src/core/nsselecter/selectiteratorcontainer.cc:1305-1559); hybrid_rerank.h is the same fusion on the host.
@@ -32,8 +34,11 @@ inline HybridFused HybridQueryResident(const GpuBruteforceMap& map, const GpuFtM
 		NormalizeCopyVector(key, int32_t(map.Dim()), normalized.data());
 		q = normalized.data();
 	}
+	// FT half first: the merge train and the FT-only part of the fusion (postProcessResults, the sort by id, the class tables) are on the
+	// merger's stream before the scan's persistent workgroups fill the chip; they run while the scan — ten times longer — streams the corpus
+	ft.MergeQueryResident(cfg, terms, docsExcluded);
+	ft.PrepareResident(cfg, hp, int(map.Metric()), dRowOfDoc);
 	const GpuBruteforceMap::ResidentKnn knn = map.SearchKnnResident(q, k);            // enqueued on the index's stream
-	ft.MergeQueryResident(cfg, terms, docsExcluded);                                  // enqueued on the merger's stream: both halves overlap
 	HybridFused fused = ft.FuseResident(cfg, hp, int(map.Metric()), knn.dDist, knn.dRow, knn.dCount, knn.entries, uint32_t(std::min<size_t>(k, knn.entries)),
 										knn.stream, dRowOfDoc, knn.dRowIds);
 	if (!fused.knnBoundaryTie) return fused;

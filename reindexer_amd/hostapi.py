@@ -771,13 +771,14 @@ class GpuFtMerger:
         return oid[:n].copy(), orank[:n].copy(), bool(tie.value)
 
     def read_fuse_stats(self):
-        """(fusions, device ms of the fusion kernel) since the last call."""
+        """(fusions, device ms of the join kernel — the part on the critical path —, device ms of the overlapped FT-only prepare kernel)
+        since the last call."""
         L = lib()
         L.rxhost_ft_read_fuse_stats.restype = None
-        L.rxhost_ft_read_fuse_stats.argtypes = [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]
-        calls, ms = _u64(0), C.c_double(0)
-        L.rxhost_ft_read_fuse_stats(self.h, C.byref(calls), C.byref(ms))
-        return int(calls.value), float(ms.value)
+        L.rxhost_ft_read_fuse_stats.argtypes = [_vp, C.POINTER(_u64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        calls, ms, pms = _u64(0), C.c_double(0), C.c_double(0)
+        L.rxhost_ft_read_fuse_stats(self.h, C.byref(calls), C.byref(ms), C.byref(pms))
+        return int(calls.value), float(ms.value), float(pms.value)
 
     def read_timing(self):
         """(calls, total ms) spent inside the C++ Merger since the last call — the end-to-end time of the drop-in boundary, without this

@@ -139,26 +139,23 @@ def test_resident_hybrid_query_equals_assembled_pipeline(rxgpu, oracle, metric):
         "or_or": [dict(op=1, opts=opts, subs=[(0, 100.0), (1, 85.0)]), dict(op=1, opts=opts, subs=[(2, 100.0), (3, 70.0)])],
         "and": [dict(op=1, opts=opts, subs=[(0, 100.0)]), dict(op=2, opts=opts, subs=[(2, 100.0)])],
     }
-    stream = torch.cuda.current_stream(dev).cuda_stream
     for qname, terms in queries.items():
         for min_rank, limit in ((5, 20000), (90, 20000), (5, 700)):
             cfg = hostapi.default_ft_config(nf, min_rank=min_rank, merge_limit=limit)
             key = make_corpus(50 + len(qname), 1, d)[0]
             if metric == 2:
                 key, _ = oracle.normalize_copy(key)
-            d_key = torch.from_numpy(key).to(dev)
-            od = torch.empty(k + 1, dtype=torch.float32, device=dev)
-            orow = torch.empty(k + 1, dtype=torch.int32, device=dev)
-            ix.search_knn_device(d_key.data_ptr(), 1, k + 1, od.data_ptr(), orow.data_ptr(), None, stream)
             for kind, params in (("rrf", [60.0]), ("linear", [0.7, 0.1, 0.3, 5.0, 2.0])):
                 for union in (True, False):
-                    gi, gr, tie = m.hybrid_query(cfg, terms, od.data_ptr(), orow.data_ptr(), k + 1, k, metric, kind=kind, params=params, union=union,
-                                                 knn_stream=stream, row_of_doc_ptr=d_map.data_ptr())
+                    p_dist, p_row, p_cnt, p_stream, entries = ix.search_knn_resident(key, k + 1)      # enqueued, left in HBM
+                    assert entries == k + 1
+                    gi, gr, tie = m.hybrid_query(cfg, terms, p_dist, p_row, entries, k, metric, kind=kind, params=params, union=union,
+                                                 knn_count_ptr=p_cnt, knn_stream=p_stream, row_of_doc_ptr=d_map.data_ptr())
                     assert not tie
                     # the assembled pipeline
                     fid, fproc, _, fnorm, _ = m.merge_query(cfg, terms, sort_by_rank=False)
-                    torch.cuda.synchronize(dev)
-                    kd, kr_ = od.cpu().numpy()[:k], orow.cpu().numpy()[:k].astype(np.int32)
+                    hd, hr, _ = ix.search_knn(key[None, :], k + 1)
+                    kd, kr_ = hd[0, :k], hr[0, :k].astype(np.int32)
                     ranks = kd if metric == 0 else -kd
                     ft_rows = row_of_doc[fid]
                     o = np.argsort(ft_rows, kind="stable")

@@ -119,7 +119,7 @@ def run(o) -> dict:
     fused = [run_resident(q) for q in range(o.queries)]
     gpu_s = time.perf_counter() - t0
     ft_postings, ft_kernel_ms = ftm.read_stats()
-    fuse_calls, fuse_kernel_ms = ftm.read_fuse_stats()
+    fuse_calls, fuse_kernel_ms, prep_kernel_ms = ftm.read_fuse_stats()
     same_as_split = sum(int(np.array_equal(f[0], r[4]) and np.array_equal(f[1].view(np.uint32), r[5].view(np.uint32))) for f, r in zip(fused, results))
     out = {"workload": f"hybrid RRF: ft_fast BM25 (1-3 OR terms x 2 sub-terms) over {o.docs} vdocs + cosine KNN k={o.k} over {o.docs} x {o.dim}, union fusion "
                        "(BASELINE configs[4])",
@@ -127,6 +127,10 @@ def run(o) -> dict:
            "gpu": {"path": "resident: KNN list and FT merge left in HBM, postProcessResults + rank fusion on the device (hybrid_fuse.hip), one download",
                    "queries": o.queries, "queries_per_sec": o.queries / gpu_s, "ms_per_query": gpu_s / o.queries * 1e3,
                    "ms_fusion": fuse_kernel_ms / max(fuse_calls, 1), "fusion_kernel_launches": fuse_calls,
+                   "ms_fusion_note": "hybrid_join_kernel: what is left to do once both halves are there (critical path)",
+                   "ms_fusion_prepare_overlapped": prep_kernel_ms / max(fuse_calls, 1),
+                   "ms_fusion_prepare_note": "hybrid_prepare_kernel (FT only: postProcessResults, id sort, rank classes): enqueued behind the merge, runs "
+                                             "while the KNN scan streams the corpus",
                    "ms_ft_kernels": ft_kernel_ms / o.queries, "ft_postings_per_query": ft_postings / o.queries,
                    "boundary_ties_redone_on_host": int(sum(int(f[2]) for f in fused)),
                    "fused_results_avg": float(np.mean([len(f[0]) for f in fused])),
