@@ -231,6 +231,9 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 						acc[a][b][r] = 0.0f;
 					}
 					if (!row_ok) mask = 0;
+					// block after block: hoisting the next block's threshold / query-norm reads above this block's compares only adds live
+					// registers (the L2 form, two LDS operands per compare, spilled 61 VGPRs into the K loop without this)
+					__builtin_amdgcn_sched_barrier(0);
 					if (__ballot(mask != 0)) {
 						while (mask) {
 							const int r = __builtin_ctz(mask);
