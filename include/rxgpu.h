@@ -312,6 +312,9 @@ int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n,
  * allocation per call.  A malformed stream (truncated varint, ids not ascending, field >= num_fields) is RXGPU_ERR_PARAMS naming the word. */
 int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t* word_ids, const uint64_t* byte_off, const uint8_t* bytes,
 							  const uint64_t* array_found_pos);
+/* Device time of the two decode kernels of rxgpu_ft_set_words_packed (count pass, write pass), the stream bytes they read (each pass)
+ * and the bytes of the arrays they produced (256-byte aligned slices included), since the last call. */
+int rxgpu_ft_read_packed_stats(rxgpu_ft_index* h, double* count_ms, double* write_ms, uint64_t* bytes_in, uint64_t* bytes_out);
 /* Reads a word's device arrays back (tests, diagnostics).  Sizes first (array pointers null), then the arrays the caller wants. */
 int rxgpu_ft_get_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t* n, uint64_t* npos, uint64_t* nent, uint32_t* doc, uint32_t* pos_off, uint64_t* fpos,
 					  uint32_t* ent_off, uint8_t* ent_field, uint32_t* ent_tf, uint32_t* ent_first_pos, uint32_t* n_ranges, uint32_t* range_off);

@@ -51,6 +51,16 @@ struct FtPackedOut {   // all null for the counting pass
 	uint32_t n_ranges = 0;           // last_doc / range_docs + 2
 };
 
+// A point of a stream where an element starts, with the decoder state in front of it (ft_packed_wave: the counting pass leaves one per
+// kFtPackedSegBytes of stream, the writing pass decodes the pieces between them with one wavefront each).
+constexpr uint32_t kFtPackedSegBytes = 1024;
+struct FtPackedCheckpoint {
+	uint64_t byte_off;   // ~0: no element starts inside this piece (one element spans it)
+	uint32_t last_id, last_field;
+	uint32_t n, npos, nent;
+	uint32_t next_range;   // unclamped: largest (document / range_docs + 1) seen so far
+};
+
 RX_HD inline bool ft_packed_varint(const uint8_t*& p, const uint8_t* end, uint32_t& v) {
 	v = 0;
 	for (unsigned i = 0; i < 5; ++i) {

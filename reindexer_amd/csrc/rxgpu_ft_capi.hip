@@ -104,6 +104,8 @@ struct rxgpu_ft_index {
 	uint64_t fuse_calls = 0;
 	double fuse_ms = 0.0;
 	double fuse_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // RXGPU_FUSE_STAMPS: summed phase stamps of the fusion kernel (us since its first)
+	double packed_count_ms = 0.0, packed_write_ms = 0.0;   // rxgpu_ft_set_words_packed: device time of the two decode kernels ...
+	uint64_t packed_bytes_in = 0, packed_bytes_out = 0;    // ... the stream bytes they read and the array bytes they wrote
 	uint64_t stat_postings = 0;
 	double stat_ms = 0.0;
 	double stamps[64] = {};   // RXGPU_FT_STAMPS: summed phase stamps (relative to the workgroup's first), see rxgpu_ft_read_stats
@@ -687,7 +689,7 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 		~Scratch() {
 			if (p) (void)hipFree(p);
 		}
-	} d_in, d_cnt, d_outs;
+	} d_in, d_cnt, d_outs, d_segs;
 	const size_t in_bytes = align256(size_t(total_bytes) + 16) + align256((nwords + 1) * 8) + align256(size_t(nwords) * 8);
 	RX_HIP(hipMalloc(&d_in.p, in_bytes));
 	uint8_t* d_bytes = static_cast<uint8_t*>(d_in.p);
@@ -706,7 +708,41 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 	}
 	RX_HIP(hipMalloc(&d_cnt.p, size_t(nwords) * sizeof(rxgpu::FtPackedCounts)));
 	rxgpu::FtPackedCounts* d_counts = static_cast<rxgpu::FtPackedCounts*>(d_cnt.p);
-	RX_HIP(rxgpu::launch_ft_packed_count(d_bytes, d_off, d_afp, nwords, h->num_fields, d_counts, h->stream));
+	// one wavefront per word (ft_packed_wave); RXGPU_FT_PACKED_THREAD=1: the one-thread-per-word kernels of round 2 (cross-check, comparison)
+	const bool wave = std::getenv("RXGPU_FT_PACKED_THREAD") == nullptr;
+	// pieces of kFtPackedSegBytes: the counting pass leaves a checkpoint in each, the writing pass runs one wavefront per piece
+	rxgpu::FtPackedSegs segs{};
+	if (wave) {
+		std::vector<uint32_t> seg_first(nwords + 1), seg_word;
+		seg_first[0] = 0;
+		for (uint32_t k = 0; k < nwords; ++k) {
+			const uint64_t len = off[k + 1] - off[k];
+			const uint64_t pieces = std::max<uint64_t>(1, (len + rxgpu::kFtPackedSegBytes - 1) / rxgpu::kFtPackedSegBytes);
+			RX_CHECK(seg_first[k] + pieces < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: too many stream bytes in one call");
+			seg_first[k + 1] = uint32_t(seg_first[k] + pieces);
+		}
+		const uint32_t nsegs = seg_first[nwords];
+		seg_word.resize(nsegs);
+		for (uint32_t k = 0; k < nwords; ++k) std::fill(seg_word.begin() + seg_first[k], seg_word.begin() + seg_first[k + 1], k);
+		const size_t o_sw = 0, o_sf = align256(size_t(nsegs) * 4), o_cp = o_sf + align256((size_t(nwords) + 1) * 4);
+		const size_t seg_bytes = o_cp + size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint);
+		RX_HIP(hipMalloc(&d_segs.p, seg_bytes));
+		char* sb = static_cast<char*>(d_segs.p);
+		RX_HIP(hipMemcpyAsync(sb + o_sw, seg_word.data(), size_t(nsegs) * 4, hipMemcpyHostToDevice, h->stream));
+		RX_HIP(hipMemcpyAsync(sb + o_sf, seg_first.data(), (size_t(nwords) + 1) * 4, hipMemcpyHostToDevice, h->stream));
+		RX_HIP(hipMemsetAsync(sb + o_cp, 0xFF, size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint), h->stream));
+		RX_HIP(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
+		segs.seg_word = reinterpret_cast<const uint32_t*>(sb + o_sw);
+		segs.seg_first = reinterpret_cast<const uint32_t*>(sb + o_sf);
+		segs.cps = reinterpret_cast<rxgpu::FtPackedCheckpoint*>(sb + o_cp);
+		segs.nsegs = nsegs;
+	}
+	EventPair ev_count, ev_write;
+	if (int rc = ev_count.create(); rc) return rc;
+	if (int rc = ev_write.create(); rc) return rc;
+	RX_HIP(hipEventRecord(ev_count.a, h->stream));
+	RX_HIP(rxgpu::launch_ft_packed_count(d_bytes, d_off, d_afp, nwords, h->num_fields, d_counts, wave ? &segs : nullptr, h->stream));
+	RX_HIP(hipEventRecord(ev_count.b, h->stream));
 	std::vector<rxgpu::FtPackedCounts> counts(nwords);
 	RX_HIP(hipMemcpyAsync(counts.data(), d_counts, size_t(nwords) * sizeof(rxgpu::FtPackedCounts), hipMemcpyDeviceToHost, h->stream));
 	RX_HIP(hipStreamSynchronize(h->stream));
@@ -767,7 +803,9 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 	}
 	RX_HIP(hipMalloc(&d_outs.p, size_t(nwords) * sizeof(rxgpu::FtPackedOut)));
 	RX_HIP(hipMemcpyAsync(d_outs.p, outs.data(), size_t(nwords) * sizeof(rxgpu::FtPackedOut), hipMemcpyHostToDevice, h->stream));
-	RX_HIP(rxgpu::launch_ft_packed_write(d_bytes, d_off, d_afp, nwords, h->num_fields, static_cast<const rxgpu::FtPackedOut*>(d_outs.p), d_counts, h->stream));
+	RX_HIP(hipEventRecord(ev_write.a, h->stream));
+	RX_HIP(rxgpu::launch_ft_packed_write(d_bytes, d_off, d_afp, nwords, h->num_fields, static_cast<const rxgpu::FtPackedOut*>(d_outs.p), d_counts, wave ? &segs : nullptr, h->stream));
+	RX_HIP(hipEventRecord(ev_write.b, h->stream));
 	std::vector<rxgpu::FtPackedCounts> again(nwords);
 	RX_HIP(hipMemcpyAsync(again.data(), d_counts, size_t(nwords) * sizeof(rxgpu::FtPackedCounts), hipMemcpyDeviceToHost, h->stream));
 	RX_HIP(hipStreamSynchronize(h->stream));
@@ -775,6 +813,10 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 		RX_CHECK(again[k].status == rxgpu::kFtPackedOk && again[k].n == counts[k].n && again[k].npos == counts[k].npos && again[k].nent == counts[k].nent,
 				 RXGPU_ERR_DEVICE, "rxgpu_ft_set_words_packed: the write pass disagrees with the counting pass");
 	}
+	h->packed_count_ms += ev_count.elapsed_ms();
+	h->packed_write_ms += ev_write.elapsed_ms();
+	h->packed_bytes_in += total_bytes;
+	h->packed_bytes_out += cv.off;
 	for (uint32_t k = 0; k < nwords; ++k) {
 		rxgpu_ft_word& w = h->words[word_ids[order[k]]];
 		w.release();
@@ -794,6 +836,18 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 		w.n_ranges = outs[k].n_ranges;
 		w.pool = pool;
 	}
+	return RXGPU_OK;
+}
+
+int rxgpu_ft_read_packed_stats(rxgpu_ft_index* h, double* count_ms, double* write_ms, uint64_t* bytes_in, uint64_t* bytes_out) {
+	RX_CHECK(h && count_ms && write_ms && bytes_in && bytes_out, RXGPU_ERR_PARAMS, "rxgpu_ft_read_packed_stats: null argument");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	*count_ms = h->packed_count_ms;
+	*write_ms = h->packed_write_ms;
+	*bytes_in = h->packed_bytes_in;
+	*bytes_out = h->packed_bytes_out;
+	h->packed_count_ms = h->packed_write_ms = 0.0;
+	h->packed_bytes_in = h->packed_bytes_out = 0;
 	return RXGPU_OK;
 }
 

@@ -220,10 +220,17 @@ hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);
 hipError_t launch_ft_export(const FtPlan& plan, hipStream_t st);
 hipError_t launch_ft_import(const void* host_plan_device_view, void* dev_plan, size_t bytes, hipStream_t st);
 // ft_packed.hip: PackedIdRelVec streams -> flat posting arrays, one thread per word (counting pass, then writing pass)
+// pieces of the packed streams for the wavefront decoder (null: the one-thread-per-word kernels)
+struct FtPackedSegs {
+	const uint32_t* seg_word;    // [nsegs] word (launch order) of a piece
+	const uint32_t* seg_first;   // [nwords + 1] first piece of a word
+	FtPackedCheckpoint* cps;     // [nsegs], byte_off preset to ~0
+	uint32_t nsegs;
+};
 hipError_t launch_ft_packed_count(const uint8_t* bytes, const uint64_t* byte_off, const uint64_t* array_found_pos, uint32_t nwords, uint32_t num_fields,
-								   FtPackedCounts* counts, hipStream_t st);
+								   FtPackedCounts* counts, const FtPackedSegs* segs, hipStream_t st);
 hipError_t launch_ft_packed_write(const uint8_t* bytes, const uint64_t* byte_off, const uint64_t* array_found_pos, uint32_t nwords, uint32_t num_fields,
-								   const FtPackedOut* outs, FtPackedCounts* counts, hipStream_t st);
+								   const FtPackedOut* outs, FtPackedCounts* counts, const FtPackedSegs* segs, hipStream_t st);
 
 void set_error(const std::string& msg);
 

@@ -113,6 +113,10 @@ void GpuFtMerger::ReadStats(uint64_t& postings, double& kernelMs) const {
 	if (rxgpu_ft_read_stats(dev_, &postings, &kernelMs) != RXGPU_OK) throwDevice("ReadStats");
 }
 
+void GpuFtMerger::ReadPackedStats(double& countMs, double& writeMs, uint64_t& bytesIn, uint64_t& bytesOut) const {
+	if (rxgpu_ft_read_packed_stats(dev_, &countMs, &writeMs, &bytesIn, &bytesOut) != RXGPU_OK) throwDevice("ReadPackedStats");
+}
+
 void GpuFtMerger::ReadFuseStats(uint64_t& calls, double& kernelMs, double* prepareMs) const {
 	if (rxgpu_hybrid_read_stats(dev_, &calls, &kernelMs, prepareMs) != RXGPU_OK) throwDevice("ReadFuseStats");
 }

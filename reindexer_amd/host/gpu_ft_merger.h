@@ -166,6 +166,8 @@ public:
 
 	size_t TotalDocs() const noexcept { return totalDocs_; }
 	void ReadStats(uint64_t& postings, double& kernelMs) const;
+	// SetWordsPacked: device time of the two decode kernels, stream bytes read per pass, array bytes produced, since the last call
+	void ReadPackedStats(double& countMs, double& writeMs, uint64_t& bytesIn, uint64_t& bytesOut) const;
 	// FuseResident: fusions, the device time of their join kernel (critical path) and of the overlapped prepare kernel since the last call
 	void ReadFuseStats(uint64_t& calls, double& kernelMs, double* prepareMs = nullptr) const;
 	// wall time spent inside Merge / MergeQuery since the last call (everything behind the Merger boundary: plan, launches, the wait,

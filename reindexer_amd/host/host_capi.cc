@@ -558,6 +558,9 @@ extern "C" int rxhost_ft_set_word_fpos(void* h, uint32_t wordId, size_t n, const
 }
 // cfgD: [k1, b, summationRatio, fullMatchBoost, distanceBoost, distanceWeight]; per term: op, boost, termLenBoost, fieldBoost[nf],
 // needSum[nf], sub-term slice [subOff[t], subOff[t+1]) of (wordId, proc).  Returns the result count, -1 on error.
+extern "C" void rxhost_ft_read_packed_stats(void* h, double* countMs, double* writeMs, uint64_t* bytesIn, uint64_t* bytesOut) {
+	static_cast<const GpuFtMerger*>(h)->ReadPackedStats(*countMs, *writeMs, *bytesIn, *bytesOut);
+}
 extern "C" void rxhost_ft_read_fuse_stats(void* h, uint64_t* calls, double* kernelMs, double* prepareMs) {
 	static_cast<const GpuFtMerger*>(h)->ReadFuseStats(*calls, *kernelMs, prepareMs);
 }

@@ -770,6 +770,15 @@ class GpuFtMerger:
             _raise()
         return oid[:n].copy(), orank[:n].copy(), bool(tie.value)
 
+    def read_packed_stats(self):
+        """set_words_packed since the last call: (count kernel ms, write kernel ms, stream bytes read per pass, array bytes produced)."""
+        L = lib()
+        L.rxhost_ft_read_packed_stats.restype = None
+        L.rxhost_ft_read_packed_stats.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_u64), C.POINTER(_u64)]
+        a, b, c, d = C.c_double(0), C.c_double(0), _u64(0), _u64(0)
+        L.rxhost_ft_read_packed_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return float(a.value), float(b.value), int(c.value), int(d.value)
+
     def read_fuse_stats(self):
         """(fusions, device ms of the join kernel — the part on the critical path —, device ms of the overlapped FT-only prepare kernel)
         since the last call."""
@@ -839,6 +848,23 @@ def hybrid_query_resident(vmap: "GpuBruteforceMap", ftm: "GpuFtMerger", cfg: dic
     if n < 0:
         _raise()
     return oid[:n].copy(), orank[:n].copy(), bool(tie.value)
+
+
+def ft_unpack(data, array_found_pos: int) -> dict:
+    """PositionPostings::AppendPacked on the host (the product's host decoder of a PackedIdRelVec stream): dict(doc, pos_off, fpos)."""
+    L = lib()
+    L.rxhost_ft_unpack.restype = _l
+    L.rxhost_ft_unpack.argtypes = [_vp, _sz, _sz, _vp, _vp, _vp, _vp]
+    data = np.ascontiguousarray(data, np.uint8)
+    afp = min(int(array_found_pos), 1 << 62)
+    npos = _sz(0)
+    n = L.rxhost_ft_unpack(data.ctypes.data, data.shape[0], afp, None, None, None, C.byref(npos))
+    if n < 0:
+        _raise()
+    doc, po, fp = np.zeros(n, np.uint32), np.zeros(n + 1, np.uint32), np.zeros(int(npos.value), np.uint64)
+    if L.rxhost_ft_unpack(data.ctypes.data, data.shape[0], afp, doc.ctypes.data, po.ctypes.data, fp.ctypes.data, None) != n:
+        _raise()
+    return dict(doc=doc, pos_off=po, fpos=fp)
 
 
 def default_ft_config(num_fields=1, **kw):

@@ -26,10 +26,13 @@ def _same(got, want):
     assert np.array_equal(got["ent_first"], e1) and np.array_equal(got["range_off"], ro)
 
 
-@pytest.mark.parametrize("host_from", [1 << 30, 2000])
-def test_device_decode_equals_host_upload(hostapi, host_from):
+@pytest.mark.parametrize("host_from,thread_kernels", [(1 << 30, False), (2000, False), (1 << 30, True)])
+def test_device_decode_equals_host_upload(hostapi, monkeypatch, host_from, thread_kernels):
     """A batch of words: the reference packer's committed streams (both element layouts), random lists of 1..3000 postings (some with array
-    indexes from some element on), an empty word.  host_from = 2000 sends the longer streams through the host decoder: same arrays."""
+    indexes from some element on), an empty word.  host_from = 2000 sends the longer streams through the host decoder: same arrays.
+    thread_kernels: the one-thread-per-word kernels of round 2 instead of the wavefront-per-word ones (both stay checked)."""
+    if thread_kernels:
+        monkeypatch.setenv("RXGPU_FT_PACKED_THREAD", "1")
     nf = 4
     z = np.load(FT_GOLDEN)
     rng = np.random.default_rng(21)
@@ -92,6 +95,34 @@ def test_merges_over_device_decoded_words(hostapi, oracle, case):
     m.close()
 
 
+def test_long_lists_through_the_wave_decoder(hostapi):
+    """Lists of 40 000 .. 250 000 postings (0.2 .. 1.5 MB of stream: thousands of 256-byte windows, every staging buffer flushed thousands of
+    times, range indexes of hundreds of entries), positions up to 2^28 - 1 (5-byte varints across window borders), array indexes starting
+    mid-stream, plus a list of ONE posting with 3000 positions (an element spanning a dozen windows)."""
+    nf = 3
+    rng = np.random.default_rng(77)
+    m = hostapi.GpuFtMerger(nf)
+    total = 3_000_001
+    m.set_docs(np.ones((total, nf), np.float32), np.ones(nf, np.float32), np.zeros(total, np.uint8))
+    want, words = {}, []
+    for wid, (n, arrays, max_pos) in enumerate([(40_000, False, 40), (120_000, True, (1 << 28) - 1), (250_000, False, 1 << 14)]):
+        s = make_pos_postings(rng, total, nf, n, 1.0, array_fields=arrays, max_pos=max_pos)
+        data, afp = pack_postings(s["doc"], s["pos_off"], s["fpos"])
+        words.append((wid, data, afp))
+        want[wid] = s
+    from oracle.pyoracle import make_fpos
+    pos = np.sort(rng.choice(1 << 20, 3000, replace=False))
+    one = dict(doc=np.array([123456], np.uint32), pos_off=np.array([0, 3000], np.uint32),
+               fpos=np.sort(make_fpos(pos, rng.integers(0, nf, 3000), np.zeros(3000, np.int64))).astype(np.uint64))
+    data, afp = pack_postings(one["doc"], one["pos_off"], one["fpos"])
+    words.append((3, data, afp))
+    want[3] = one
+    m.set_words_packed(words, host_from_bytes=1 << 40)
+    for wid, s in want.items():
+        _same(m.get_word(wid), s)
+    m.close()
+
+
 def test_malformed_streams_are_refused_loudly(hostapi):
     nf = 2
     m = hostapi.GpuFtMerger(nf)
@@ -105,6 +136,9 @@ def test_malformed_streams_are_refused_loudly(hostapi):
     dup, afp3 = pack_postings([5, 5], [0, 1, 2], [3, 4])
     with pytest.raises(Exception, match="ascend"):
         m.set_words_packed([(9, dup, afp3)])
+    sixbytes = np.array([0x81, 0x80, 0x80, 0x80, 0x80, 0x80, 0x01, 0x04], np.uint8)   # a "varint" of seven bytes
+    with pytest.raises(Exception, match="word 11"):
+        m.set_words_packed([(11, sixbytes, 1 << 40)])
     m.set_words_packed([(3, good, afp)])
     assert m.get_word(3)["doc"].tolist() == [1, 9, 300]
     m.close()

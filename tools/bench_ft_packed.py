@@ -43,28 +43,69 @@ def run(opts: dict) -> dict:
     m = hostapi.GpuFtMerger(nf)
     m.set_docs(np.ones((total, nf), np.float32), np.ones(nf, np.float32), np.zeros(total, np.uint8))
     m.set_words_packed(words[:1000])   # warm-up (module load, allocator)
+    m.read_packed_stats()
     t0 = time.perf_counter()
     m.set_words_packed(words, host_from_bytes=1 << 40)
     dev_s = time.perf_counter() - t0
+    count_ms, write_ms, bytes_in, bytes_out = m.read_packed_stats()
+    # parity inside the bench: a sample of words (every distinct stream is hit) against the arrays the host decoder derives
+    from tests.ft_pack import flat_entries
+    checked = same = 0
+    for w in list(range(0, args.words, max(1, args.words // 200))) + [args.words - 1]:
+        got = m.get_word(w)
+        data, afp = words[w][1], words[w][2]
+        host = hostapi.ft_unpack(data, afp)
+        eo, ef, et, e1, ro = flat_entries(host["doc"], host["pos_off"], host["fpos"])
+        ok = (np.array_equal(got["doc"], host["doc"]) and np.array_equal(got["pos_off"], host["pos_off"]) and np.array_equal(got["fpos"], host["fpos"])
+              and np.array_equal(got["ent_off"], eo) and np.array_equal(got["ent_field"], ef) and np.array_equal(got["ent_tf"], et)
+              and np.array_equal(got["ent_first"], e1) and np.array_equal(got["range_off"], ro))
+        checked += 1
+        same += int(ok)
     chk = m.get_word(args.words - 1)
     m.close()
+    # the thread-per-word kernels of round 2 on the same dictionary (device time only), for the record
+    import os
+    os.environ["RXGPU_FT_PACKED_THREAD"] = "1"
+    try:
+        mt = hostapi.GpuFtMerger(nf)
+        mt.set_docs(np.ones((total, nf), np.float32), np.ones(nf, np.float32), np.zeros(total, np.uint8))
+        mt.set_words_packed(words[:1000])
+        mt.read_packed_stats()
+        mt.set_words_packed(words, host_from_bytes=1 << 40)
+        t_count_ms, t_write_ms, _, _ = mt.read_packed_stats()
+        mt.close()
+    finally:
+        os.environ.pop("RXGPU_FT_PACKED_THREAD", None)
     m2 = hostapi.GpuFtMerger(nf)
     m2.set_docs(np.ones((total, nf), np.float32), np.ones(nf, np.float32), np.zeros(total, np.uint8))
     hw = words[:args.host_words]
     t0 = time.perf_counter()
     m2.set_words_packed(hw, host_from_bytes=0)   # every stream through AppendPacked + rxgpu_ft_set_word_positions
     host_s = time.perf_counter() - t0
-    chk2 = m2.get_word(args.host_words - 1)
+    chk2 = m2.get_word(args.words - 1) if args.host_words >= args.words else None
     m2.close()
     hbytes = sum(int(w[1].shape[0]) for w in hw)
     out_bytes = npost * (4 + 4 + 4) + npos * 8 + npost * 9   # doc, pos_off, ent_off, positions, ~1 entry per posting
     res = {"workload": f"{args.words} dictionary words as PackedIdRelVec streams, {nbytes / 1e6:.1f} MB packed, {npost} postings, {npos} positions",
            "device": {"seconds": dev_s, "words_per_sec": args.words / dev_s, "packed_MB_per_sec": nbytes / 1e6 / dev_s,
-                      "postings_per_sec": npost / dev_s, "flat_bytes_written": out_bytes},
+                      "postings_per_sec": npost / dev_s, "flat_bytes_written": out_bytes,
+                      "kernels": {"form": "ft_packed_wave: one wavefront per word (256-byte windows, ballot varint ends, wave-uniform walk, LDS-staged "
+                                          "coalesced output)",
+                                  "count_ms": count_ms, "write_ms": write_ms, "stream_bytes_per_pass": bytes_in, "array_bytes_written": bytes_out,
+                                  "thread_per_word_count_ms": t_count_ms, "thread_per_word_write_ms": t_write_ms,
+                                  "speedup_vs_thread_per_word": (t_count_ms + t_write_ms) / max(count_ms + write_ms, 1e-9)},
+                      "roofline": {"bound": "hbm", "kernel": "ft_packed_wave<write>", "unit": "GB/s", "peak": 8000.0,
+                                   "bytes_per_launch": bytes_in + bytes_out, "avg_ms": write_ms,
+                                   "achieved": (bytes_in + bytes_out) / max(write_ms, 1e-9) / 1e6,
+                                   "frac": (bytes_in + bytes_out) / max(write_ms, 1e-9) / 1e6 / 8000.0,
+                                   "flat_output_GBps_both_passes": bytes_out / max(count_ms + write_ms, 1e-9) / 1e6,
+                                   "note": "bytes = packed streams read + flat arrays written by the write pass (the count pass reads the streams once more)"},
+                      "parity": {"words_checked": checked, "identical_to_host_decoder_frac": same / max(checked, 1),
+                                 "against": "PositionPostings::AppendPacked (pinned to the reference's packer) + the entry / range derivation of the tests"}},
            "host_path": {"words": args.host_words, "seconds": host_s, "words_per_sec": args.host_words / host_s,
                          "packed_MB_per_sec": hbytes / 1e6 / host_s},
            "speedup_words_per_sec": (args.words / dev_s) / (args.host_words / host_s),
-           "last_word_postings": int(chk["doc"].shape[0]), "host_last_word_postings": int(chk2["doc"].shape[0])}
+           "last_word_postings": int(chk["doc"].shape[0])}
     if args.out:
         Path(args.out).write_text(json.dumps(res, indent=1))
     return res
