@@ -243,6 +243,15 @@ int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const 
 /* Counters accumulated since the last call (for the roofline accounting: bytes = evals*dim*4 + hops*(1+2M)*4). */
 int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops);
 
+/* HierarchicalNSW::SearchRange (hnswalg.h:2015-2070) with BOTH halves on the device: the ef-search, then the closure of its hits over the
+ * level-0 links while dist < radius (a fresh visited set in which only the ef hits are marked; deleted neighbours skipped) in ONE launch.
+ * Hits come back unordered ((dist, row), dist as the engine reports it: negated similarity for inner product / cosine).  cap too small:
+ * RXGPU_ERR_OVERFLOW with *out_total = the hits counted so far (a lower bound) — retry with more room.  The _sq8 form runs over the
+ * attached codes with the query as prepareData leaves it. */
+int rxgpu_hnsw_search_range(rxgpu_index* h, const float* query, float radius, uint32_t ef, float* out_dist, uint32_t* out_row, uint64_t cap,
+							uint64_t* out_total);
+int rxgpu_hnsw_search_range_sq8(rxgpu_index* h, const uint8_t* query_codes, float query_corr, float query_norm_coef, float radius, uint32_t ef,
+								float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total);
 /* Streaming (batched) KNN over the attached graph: HierarchicalNSWImpl::BeginStreamingSearch / ContinueStreamingSearch
  * (cpp_src/core/index/float_vector/hnswlib/hnswalg.h:1865-1975; interface hnsw_interface.h:18-45, 99-102).  The session owns its
  * Layer0SearchState (candidate_set, top_candidates, top_candidates_extras, visited set) in device memory.  query: [dim] floats, already
@@ -251,6 +260,9 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
  * session (the reference requires an external read lock for the same reason). */
 typedef struct rxgpu_hnsw_stream rxgpu_hnsw_stream;
 int rxgpu_hnsw_stream_begin(rxgpu_index* h, const float* query, uint32_t ef, rxgpu_hnsw_stream** out);
+/* The same session over the attached SQ8 codes (HierarchicalNSWImpl<uint8_t>): query codes + corrective offset + normCoef as for
+ * rxgpu_hnsw_search_knn_sq8; rxgpu_hnsw_stream_continue / _end as above. */
+int rxgpu_hnsw_stream_begin_sq8(rxgpu_index* h, const uint8_t* query_codes, float query_corr, float query_norm_coef, uint32_t ef, rxgpu_hnsw_stream** out);
 int rxgpu_hnsw_stream_continue(rxgpu_hnsw_stream* s, uint32_t batch, float* out_dist, uint32_t* out_row, uint32_t* out_count, int32_t* exhausted);
 void rxgpu_hnsw_stream_end(rxgpu_hnsw_stream* s);
 

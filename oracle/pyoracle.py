@@ -1012,6 +1012,56 @@ class RefHnswQ:
         return od[:c].copy(), ol[:c].copy()
 
 
+    def search_range(self, q, radius, ef, norm=None, cap=1 << 20):
+        L = self.L
+        L.ref_hnswq_search_range.restype = C.c_long
+        L.ref_hnswq_search_range.argtypes = [_vp, _vp, _i, _f, _f, _sz, _vp, _vp, _sz]
+        q = _f32(q)
+        od, ol = np.empty(cap, np.float32), np.empty(cap, np.uint64)
+        c = L.ref_hnswq_search_range(self.h, q.ctypes.data, int(norm is not None), 0.0 if norm is None else norm, radius, ef, od.ctypes.data, ol.ctypes.data, cap)
+        if c < 0:
+            raise RuntimeError(L.ref_last_error().decode())
+        assert c <= cap
+        return od[:c].copy(), ol[:c].copy()
+
+    def stream(self, q, ef=0, norm=None):
+        return _RefStreamQ(self, q, ef, norm)
+
+
+class _RefStreamQ:
+    """BeginStreamingSearch / ContinueStreamingSearch of the quantised engine; next(batch) -> (dist, label, exhausted), worst first."""
+
+    def __init__(self, owner: "RefHnswQ", q, ef, norm):
+        L = self.L = owner.L
+        L.ref_hnswq_stream_begin.restype = _vp
+        L.ref_hnswq_stream_begin.argtypes = [_vp, _vp, _sz, _i, _f, _sz]
+        L.ref_hnswq_stream_continue.restype = C.c_long
+        L.ref_hnswq_stream_continue.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp]
+        L.ref_hnsw_stream_end.argtypes = [_vp]
+        self.owner = owner
+        q = _f32(q)
+        self.s = L.ref_hnswq_stream_begin(owner.h, q.ctypes.data, owner.dim, int(norm is not None), 0.0 if norm is None else norm, ef)
+        if not self.s:
+            raise RuntimeError(L.ref_last_error().decode())
+
+    def next(self, batch):
+        cap = max(1, min(batch, self.owner.n + 1))
+        od, ol = np.empty(cap, np.float32), np.empty(cap, np.uint64)
+        ex = C.c_int(0)
+        c = self.L.ref_hnswq_stream_continue(self.owner.h, self.s, batch, od.ctypes.data, ol.ctypes.data, C.byref(ex))
+        if c < 0:
+            raise RuntimeError(self.L.ref_last_error().decode())
+        return od[:c].copy(), ol[:c].copy(), bool(ex.value)
+
+    def close(self):
+        if self.s:
+            self.L.ref_hnsw_stream_end(self.s)
+            self.s = None
+
+    def __del__(self):
+        self.close()
+
+
 def oracle_hnsw_search_knn_sq8(orc: Oracle, g: dict, sq: dict, q, k: int, ef: int = 0, inv_norms=None, qnorm=None):
     """Restated SearchKnn over an SQ8 graph: g = the flat graph (links of the float graph), sq = RefHnswQ.export()-shaped dict."""
     L = orc.L

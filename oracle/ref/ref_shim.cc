@@ -466,4 +466,46 @@ long ref_hnswq_search_knn(void* h, const float* q, int hasNorm, float norm, size
 	}
 }
 
+// SearchRange / streaming of the quantised engine (hnswalg.h:2015-2070, 1865-1975 instantiated for uint8_t)
+long ref_hnswq_search_range(void* h, const float* q, int hasNorm, float norm, float radius, size_t ef, float* outDist, uint64_t* outLabel, size_t cap) {
+	try {
+		auto res = static_cast<const QHnswT*>(h)->SearchRange(q, hasNorm ? std::optional<float>(norm) : std::nullopt, radius, ef);
+		const size_t n = res.size();
+		drain(res, outDist, outLabel, cap);
+		return long(n);
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+void* ref_hnswq_stream_begin(void* h, const float* q, size_t dim, int hasNorm, float norm, size_t ef) {
+	try {
+		auto* s = new RefStream();
+		s->q.assign(q, q + dim);
+		s->session = std::make_unique<hnswlib::StreamingSearchSession>(static_cast<const QHnswT*>(h)->BeginStreamingSearch(
+			s->q.data(), hasNorm ? std::optional<float>(norm) : std::nullopt, hnswlib::StreamingSearchOptions{.ef = ef}));
+		return s;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+long ref_hnswq_stream_continue(void* h, void* session, size_t batch, float* outDist, uint64_t* outLabel, int* exhausted) {
+	try {
+		auto* s = static_cast<RefStream*>(session);
+		auto b = static_cast<const QHnswT*>(h)->ContinueStreamingSearch(*s->session, batch);
+		*exhausted = b.exhausted ? 1 : 0;
+		long n = 0;
+		for (; !b.results.empty(); b.results.pop()) {
+			outDist[n] = b.results.top().first;
+			outLabel[n] = b.results.top().second;
+			++n;
+		}
+		return n;
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+
 }  // extern "C"

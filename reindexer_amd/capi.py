@@ -73,6 +73,9 @@ _SIGNATURES = {
     "rxgpu_hnsw_attach_sq8": (_i, [_vp, _vp, _vp, _u64, _f]),
     "rxgpu_hnsw_search_knn_sq8": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rxgpu_hnsw_search_range": (_i, [_vp, _vp, _f, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "rxgpu_hnsw_search_range_sq8": (_i, [_vp, _vp, _f, _f, _f, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
+    "rxgpu_hnsw_stream_begin_sq8": (_i, [_vp, _vp, _f, _f, _u32, C.POINTER(_vp)]),
     "rxgpu_hnsw_stream_begin": (_i, [_vp, _vp, _u32, C.POINTER(_vp)]),
     "rxgpu_hnsw_stream_continue": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i)]),
     "rxgpu_hnsw_stream_end": (None, [_vp]),

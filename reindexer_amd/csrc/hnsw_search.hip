@@ -82,79 +82,6 @@ __device__ __forceinline__ void batch_distances(const HnswParams& p, const float
 	}
 }
 
-// SQ8: DistCalculator<uint8_t>::operator()(query, row, id) (hnswlib.h:147-165) over vector_dists::L2SqrDistance<uint8_t> /
-// InnerProductDistance<uint8_t> (tools/distances/l2_dist.cc:168-199, ip_dist.cc:163-192, AVX-512 form).  The integer part is exact; the
-// contract is in the REDUCTION: per 64-byte block the reference's zmm lane j collects elements {2j, 2j+1} and {32+2j, 33+2j}, the 16 lane
-// sums are converted to float and added one after another (rounds past 2^24), then the scalar tail (an int) is added as a float.
-// A 16-lane group owns a row: lane m reads the 4 bytes [4m, 4m+4) of every block with one 32-bit load and feeds reference lanes
-// 2(m & 7) and 2(m & 7) + 1 (low half for m < 8, high half above) through v_dot4_u32_u8 on the masked halves of the word; an xor-8
-// exchange completes the 16 reference sums, which every lane then adds in the reference's order.  A row is D bytes instead of 4 D:
-// the search is bound by exactly these gathers.
-template <int kMetric>
-__device__ __forceinline__ void batch_distances_sq8(const HnswParams& p, const uint8_t* q, float qcorr, float qnorm, const uint32_t* ids, int cnt,
-													float* dists, int lane) {
-	const int m = lane & 15, g = lane >> 4;
-	const uint32_t nblk = p.dim / 64, tail0 = nblk * 64;
-	const bool words_ok = (p.dim & 3u) == 0;   // every row (and the query) then starts on a 4-byte boundary
-	for (int base = 0; base < cnt; base += kRowsPerWave) {
-		const int idx = base + g;
-		const bool ok = idx < cnt;
-		const uint64_t row = ids[ok ? idx : base];
-		const uint8_t* r8 = p.codes + row * p.dim;
-		uint32_t s0 = 0, s1 = 0;
-		for (uint32_t t = 0; t < nblk; ++t) {
-			uint32_t a, b;
-			if (words_ok) {
-				a = reinterpret_cast<const uint32_t*>(r8)[16 * t + m];
-				b = reinterpret_cast<const uint32_t*>(q)[16 * t + m];
-			} else {
-				const uint8_t* pa = r8 + 64 * t + 4 * m;
-				const uint8_t* pb = q + 64 * t + 4 * m;
-				a = uint32_t(pa[0]) | (uint32_t(pa[1]) << 8) | (uint32_t(pa[2]) << 16) | (uint32_t(pa[3]) << 24);
-				b = uint32_t(pb[0]) | (uint32_t(pb[1]) << 8) | (uint32_t(pb[2]) << 16) | (uint32_t(pb[3]) << 24);
-			}
-			const uint32_t alo = a & 0xFFFFu, ahi = a >> 16, blo = b & 0xFFFFu, bhi = b >> 16;
-			if constexpr (kMetric == kL2) {   // (a - b)^2 = a^2 + b^2 - 2ab, exact in uint32 (the reference's madd_epi16 of the differences)
-				s0 += __builtin_amdgcn_udot4(alo, alo, 0u, false) + __builtin_amdgcn_udot4(blo, blo, 0u, false) - 2u * __builtin_amdgcn_udot4(alo, blo, 0u, false);
-				s1 += __builtin_amdgcn_udot4(ahi, ahi, 0u, false) + __builtin_amdgcn_udot4(bhi, bhi, 0u, false) - 2u * __builtin_amdgcn_udot4(ahi, bhi, 0u, false);
-			} else {
-				s0 = __builtin_amdgcn_udot4(alo, blo, s0, false);
-				s1 = __builtin_amdgcn_udot4(ahi, bhi, s1, false);
-			}
-		}
-		s0 += __shfl_xor(s0, 8, 64);   // low half (lanes 0-7) + high half (lanes 8-15) of the same reference lanes
-		s1 += __shfl_xor(s1, 8, 64);
-		float result = 0.f;
-		const int group_base = lane & ~15;
-#pragma unroll
-		for (int t = 0; t < 8; ++t) {   // result += (float)lane[j], j = 0 .. 15
-			result += float(__shfl(s0, group_base + t, 64));
-			result += float(__shfl(s1, group_base + t, 64));
-		}
-		int tail = 0;   // the scalar tail: an int accumulator
-		for (uint32_t i = tail0 + m; i < p.dim; i += 16) {
-			if constexpr (kMetric == kL2) {
-				const int df = int(r8[i]) - int(q[i]);
-				tail += df * df;
-			} else {
-				tail += int(r8[i]) * int(q[i]);
-			}
-		}
-#pragma unroll
-		for (int off = 1; off < 16; off <<= 1) tail += __shfl_xor(tail, off, 64);
-		result = result + float(tail);
-		float dist;
-		if constexpr (kMetric == kL2) {
-			dist = p.alpha2 * result + qcorr + p.corr[row];
-		} else {
-			dist = -(p.alpha2 * result + qcorr + p.corr[row]);
-			if constexpr (kMetric == kCos) dist *= p.inv_norms[row];
-		}
-		dist = qnorm * dist;
-		if (ok && m == 0) dists[idx] = dist;
-	}
-}
-
 // dim == 64*NB, SQ8: 16-byte loads.  Lane m of the row's 16-lane group reads bytes [256 i + 16 m, + 16) of load i: block 4 i + (m >> 2),
 // bytes 16 (m & 3) .. + 16 of it, i.e. the element pairs of reference lanes j = 8 (m & 1) + p, p = 0 .. 7 (pair p = halfword p of the 16
 // bytes) — in the low half of the block for (m & 3) < 2, in the high half above; both halves feed the same reference lane.  Eight integer
@@ -545,6 +472,105 @@ void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool g
 	}
 }
 
+
+// SearchRange's second half on the device (hnswalg.h:2030-2064): the closure of the ef-search's hits under "neighbour on level 0, not
+// deleted, dist < radius".  The result is a SET (the reference's radius_queue order does not change it), so the expansion runs level by
+// level: one workgroup of 16 wavefronts, every wavefront takes frontier nodes — the node's list block in one round, test-and-mark on a
+// fresh visited bitset (atomicOr; the reference starts a new visited list too: only the ef hits are marked), distances of the fresh
+// neighbours 4 rows per step — and appends what lies inside the radius to the result and to the next frontier.
+constexpr int kRangeThreads = 1024;
+constexpr int kRangeWaves = kRangeThreads / 64;
+
+template <int kMetric>
+__global__ __launch_bounds__(kRangeThreads) void hnsw_range_kernel(HnswParams p, HnswRange r) {
+	__shared__ uint32_t nb_id[kRangeWaves][kHnswMaxNeighbors];
+	__shared__ float nb_d[kRangeWaves][kHnswMaxNeighbors];
+	__shared__ uint32_t s_na, s_nb;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const bool sq8 = p.codes != nullptr;
+	uint32_t* fa = r.frontier;
+	uint32_t* fb = r.frontier + r.cap;
+	if (tid == 0) {
+		s_na = 0;
+		s_nb = 0;
+	}
+	__syncthreads();
+	// the ef hits: all marked visited, those inside the radius are results and the first frontier
+	for (uint32_t i = tid; i < r.seed_n; i += kRangeThreads) {
+		const uint32_t id = r.seed_row[i];
+		const float d = r.seed_dist[i];
+		atomicOr(&r.visited[id >> 5], 1u << (id & 31));
+		if (d < r.radius) {
+			const unsigned long long pos = atomicAdd(r.total, 1ull);
+			if (pos < r.cap) {
+				r.out_dist[pos] = d;
+				r.out_row[pos] = id;
+				fa[atomicAdd(&s_na, 1u)] = id;
+			}
+		}
+	}
+	__syncthreads();
+	for (;;) {
+		const uint32_t na = s_na;
+		if (na == 0) break;
+		for (uint32_t i = wave; i < na; i += kRangeWaves) {
+			const uint32_t node = fa[i];
+			const uint32_t* ll = p.links0 + size_t(node) * (1 + p.maxM0);
+			int nfresh = 0, cnt = 0;
+			for (int base = 0; base <= int(p.maxM0); base += 64) {
+				const int w = base + lane;
+				const uint32_t word = w <= int(p.maxM0) ? ll[w] : 0u;
+				if (base == 0) cnt = int(__builtin_amdgcn_readfirstlane(word));
+				if (base > cnt) break;   // uniform
+				const int j = w - 1;
+				bool fresh = false;
+				if (j >= 0 && j < cnt && (p.bare || !p.deleted[word])) {   // IsMarkedDeleted first: a deleted neighbour is not even marked
+					const uint32_t bit = 1u << (word & 31);
+					fresh = !(atomicOr(&r.visited[word >> 5], bit) & bit);
+				}
+				const uint64_t fm = __ballot(fresh);
+				if (fresh) nb_id[wave][nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
+				nfresh += __popcll(fm);
+			}
+			__builtin_amdgcn_wave_barrier();
+			if (sq8) {
+				batch_distances_sq8<kMetric>(p, p.qcodes, p.qcorr[0], p.qnorm[0], nb_id[wave], nfresh, nb_d[wave], lane);
+			} else {
+				batch_distances<kMetric>(p, p.queries, nb_id[wave], nfresh, nb_d[wave], lane);
+			}
+			__builtin_amdgcn_wave_barrier();
+			for (int j = lane; j < nfresh; j += 64) {
+				const float d = nb_d[wave][j];
+				if (d < r.radius) {
+					const unsigned long long pos = atomicAdd(r.total, 1ull);
+					if (pos < r.cap) {
+						r.out_dist[pos] = d;
+						r.out_row[pos] = nb_id[wave][j];
+						fb[atomicAdd(&s_nb, 1u)] = nb_id[wave][j];   // at most cap entries ever enter a frontier: one per stored result
+					}
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+		__syncthreads();
+		if (tid == 0) {
+			s_na = s_nb;
+			s_nb = 0;
+		}
+		uint32_t* t = fa;
+		fa = fb;
+		fb = t;
+		__syncthreads();
+	}
+}
+
+void launch_hnsw_range(int metric, const HnswParams& p, const HnswRange& r, hipStream_t s) {
+	switch (metric) {
+		case kL2: hipLaunchKernelGGL(hnsw_range_kernel<kL2>, dim3(1), dim3(kRangeThreads), 0, s, p, r); break;
+		case kIP: hipLaunchKernelGGL(hnsw_range_kernel<kIP>, dim3(1), dim3(kRangeThreads), 0, s, p, r); break;
+		default: hipLaunchKernelGGL(hnsw_range_kernel<kCos>, dim3(1), dim3(kRangeThreads), 0, s, p, r); break;
+	}
+}
 
 // rxgpu_hnsw_patch_graph: a host insert (addPoint / updatePoint, hnswalg.h:1472-1852) rewrites the lists of the new element and of a few
 // dozen neighbours; their staged copies are scattered into the resident graph instead of re-uploading all of it.

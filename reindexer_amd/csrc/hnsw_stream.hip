@@ -78,7 +78,12 @@ __device__ __forceinline__ void sh_replace_top(Heap& h, float vd, uint32_t vi) {
 }
 
 template <int kMetric>
-__device__ __forceinline__ void stream_distances(const HnswParams& p, const float* q, const uint32_t* ids, int cnt, float* dists, int lane) {
+__device__ __forceinline__ void stream_distances(const HnswParams& p, const HnswStream& s, const float* q, const uint32_t* ids, int cnt, float* dists,
+												 int lane) {
+	if (p.codes) {   // quantised graph (HierarchicalNSWImpl<uint8_t>): the same session over codes — wave-uniform branch
+		batch_distances_sq8<kMetric>(p, s.qcodes, s.qcorr, s.qnorm, ids, cnt, dists, lane);
+		return;
+	}
 	const int m = lane & 15, g = lane >> 4;
 	for (int base = 0; base < cnt; base += kRowsPerWave) {
 		const int idx = base + g;
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(64) void hnsw_stream_kernel(HnswParams p, HnswStrea
 		uint32_t cur = p.entry;
 		if (lane == 0) nb_id[0] = cur;
 		__syncthreads();
-		stream_distances<kMetric>(p, q, nb_id, 1, nb_d, lane);
+		stream_distances<kMetric>(p, s, q, nb_id, 1, nb_d, lane);
 		__syncthreads();
 		float curdist = nb_d[0];
 		for (int level = p.maxlevel; level > 0; --level) {
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(64) void hnsw_stream_kernel(HnswParams p, HnswStrea
 				const int cnt = int(ll[0]);
 				for (int j = lane; j < cnt; j += 64) nb_id[j] = ll[1 + j];
 				__syncthreads();
-				stream_distances<kMetric>(p, q, nb_id, cnt, nb_d, lane);
+				stream_distances<kMetric>(p, s, q, nb_id, cnt, nb_d, lane);
 				__syncthreads();
 				changed = false;
 				for (int i = 0; i < cnt; ++i) {
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(64) void hnsw_stream_kernel(HnswParams p, HnswStrea
 				nfresh += __popcll(fm);
 			}
 			__syncthreads();
-			stream_distances<kMetric>(p, q, nb_id, nfresh, nb_d, lane);
+			stream_distances<kMetric>(p, s, q, nb_id, nfresh, nb_d, lane);
 			__syncthreads();
 			if (lane == 0) {
 				for (int i = 0; i < nfresh; ++i) sh_emplace(cand, -nb_d[i], nb_id[i]);   // streaming: every evaluated node (hnswalg.h:939-940)

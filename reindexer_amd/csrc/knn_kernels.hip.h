@@ -176,6 +176,8 @@ struct HnswStreamState {
 };
 struct HnswStream {
 	const float* query;      // [dim], normalised by the host for cosine
+	const uint8_t* qcodes;   // SQ8 graph: the query as codes (prepareData, hnswalg.h:510-529) + its corrective offset and normCoef; else null
+	float qcorr, qnorm;
 	uint32_t* visited;       // [ceil(n/32)]
 	float* cand_d;           // [cap]
 	uint32_t* cand_i;
@@ -400,5 +402,93 @@ __device__ __forceinline__ float group_distance_generic(const float* __restrict_
 	}
 	return folded + tail;
 }
+
+// the closure step of SearchRange on the device (hnsw_range_kernel)
+struct HnswRange {
+	const float* seed_dist;     // the ef-search's hits
+	const uint32_t* seed_row;
+	uint32_t seed_n;
+	float radius;
+	uint32_t* visited;          // [ceil(n / 32)], zeroed
+	uint32_t* frontier;         // [2][cap]
+	float* out_dist;            // [cap]
+	uint32_t* out_row;
+	unsigned long long* total;  // hits found (may exceed cap: then the expansion is incomplete and the caller retries with more room)
+	uint64_t cap;
+};
+
+// SQ8: DistCalculator<uint8_t>::operator()(query, row, id) (hnswlib.h:147-165) over vector_dists::L2SqrDistance<uint8_t> /
+// InnerProductDistance<uint8_t> (tools/distances/l2_dist.cc:168-199, ip_dist.cc:163-192, AVX-512 form).  The integer part is exact; the
+// contract is in the REDUCTION: per 64-byte block the reference's zmm lane j collects elements {2j, 2j+1} and {32+2j, 33+2j}, the 16 lane
+// sums are converted to float and added one after another (rounds past 2^24), then the scalar tail (an int) is added as a float.
+// A 16-lane group owns a row: lane m reads the 4 bytes [4m, 4m+4) of every block with one 32-bit load and feeds reference lanes
+// 2(m & 7) and 2(m & 7) + 1 (low half for m < 8, high half above) through v_dot4_u32_u8 on the masked halves of the word; an xor-8
+// exchange completes the 16 reference sums, which every lane then adds in the reference's order.  A row is D bytes instead of 4 D:
+// the search is bound by exactly these gathers.
+template <int kMetric>
+__device__ __forceinline__ void batch_distances_sq8(const HnswParams& p, const uint8_t* q, float qcorr, float qnorm, const uint32_t* ids, int cnt,
+													float* dists, int lane) {
+	const int m = lane & 15, g = lane >> 4;
+	const uint32_t nblk = p.dim / 64, tail0 = nblk * 64;
+	const bool words_ok = (p.dim & 3u) == 0;   // every row (and the query) then starts on a 4-byte boundary
+	for (int base = 0; base < cnt; base += kRowsPerWave) {
+		const int idx = base + g;
+		const bool ok = idx < cnt;
+		const uint64_t row = ids[ok ? idx : base];
+		const uint8_t* r8 = p.codes + row * p.dim;
+		uint32_t s0 = 0, s1 = 0;
+		for (uint32_t t = 0; t < nblk; ++t) {
+			uint32_t a, b;
+			if (words_ok) {
+				a = reinterpret_cast<const uint32_t*>(r8)[16 * t + m];
+				b = reinterpret_cast<const uint32_t*>(q)[16 * t + m];
+			} else {
+				const uint8_t* pa = r8 + 64 * t + 4 * m;
+				const uint8_t* pb = q + 64 * t + 4 * m;
+				a = uint32_t(pa[0]) | (uint32_t(pa[1]) << 8) | (uint32_t(pa[2]) << 16) | (uint32_t(pa[3]) << 24);
+				b = uint32_t(pb[0]) | (uint32_t(pb[1]) << 8) | (uint32_t(pb[2]) << 16) | (uint32_t(pb[3]) << 24);
+			}
+			const uint32_t alo = a & 0xFFFFu, ahi = a >> 16, blo = b & 0xFFFFu, bhi = b >> 16;
+			if constexpr (kMetric == kL2) {   // (a - b)^2 = a^2 + b^2 - 2ab, exact in uint32 (the reference's madd_epi16 of the differences)
+				s0 += __builtin_amdgcn_udot4(alo, alo, 0u, false) + __builtin_amdgcn_udot4(blo, blo, 0u, false) - 2u * __builtin_amdgcn_udot4(alo, blo, 0u, false);
+				s1 += __builtin_amdgcn_udot4(ahi, ahi, 0u, false) + __builtin_amdgcn_udot4(bhi, bhi, 0u, false) - 2u * __builtin_amdgcn_udot4(ahi, bhi, 0u, false);
+			} else {
+				s0 = __builtin_amdgcn_udot4(alo, blo, s0, false);
+				s1 = __builtin_amdgcn_udot4(ahi, bhi, s1, false);
+			}
+		}
+		s0 += __shfl_xor(s0, 8, 64);   // low half (lanes 0-7) + high half (lanes 8-15) of the same reference lanes
+		s1 += __shfl_xor(s1, 8, 64);
+		float result = 0.f;
+		const int group_base = lane & ~15;
+#pragma unroll
+		for (int t = 0; t < 8; ++t) {   // result += (float)lane[j], j = 0 .. 15
+			result += float(__shfl(s0, group_base + t, 64));
+			result += float(__shfl(s1, group_base + t, 64));
+		}
+		int tail = 0;   // the scalar tail: an int accumulator
+		for (uint32_t i = tail0 + m; i < p.dim; i += 16) {
+			if constexpr (kMetric == kL2) {
+				const int df = int(r8[i]) - int(q[i]);
+				tail += df * df;
+			} else {
+				tail += int(r8[i]) * int(q[i]);
+			}
+		}
+#pragma unroll
+		for (int off = 1; off < 16; off <<= 1) tail += __shfl_xor(tail, off, 64);
+		result = result + float(tail);
+		float dist;
+		if constexpr (kMetric == kL2) {
+			dist = p.alpha2 * result + qcorr + p.corr[row];
+		} else {
+			dist = -(p.alpha2 * result + qcorr + p.corr[row]);
+			if constexpr (kMetric == kCos) dist *= p.inv_norms[row];
+		}
+		dist = qnorm * dist;
+		if (ok && m == 0) dists[idx] = dist;
+	}
+}
+
 
 }  // namespace rxgpu

@@ -1789,6 +1789,126 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	return RXGPU_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- SearchRange, expansion on the device
+// hnswalg.h:2015-2070: ef-search (the kernels above), then the closure over level-0 links while dist < radius — hnsw_range_kernel, one
+// launch whatever the depth of the expansion.  cap too small: RXGPU_ERR_OVERFLOW with *out_total = hits counted so far (a lower bound: the
+// expansion stops growing where it cannot store) — the caller retries with more room.
+static int hnsw_range_impl(rxgpu_index* h, const void* query, const float* qcorr, const float* qnorm, float radius, uint32_t ef, float* out_dist,
+						   uint32_t* out_row, uint64_t cap, uint64_t* out_total) {
+	const bool sq8 = qcorr != nullptr;
+	RX_CHECK(h && query && out_total, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_range: null argument");
+	*out_total = 0;
+	RX_CHECK(cap == 0 || (out_dist && out_row), RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_range: null argument");
+	if (h->count == 0) return RXGPU_OK;
+	const uint32_t ef_eff = ef ? ef : 1;
+	const uint32_t kk = uint32_t(std::min<uint64_t>(ef_eff, h->count));
+	std::vector<float> sd(kk);
+	std::vector<uint32_t> sr(kk);
+	uint32_t sc = 0;
+	if (int rc = hnsw_search_impl(h, query, qcorr, qnorm, 1, kk, ef_eff, sd.data(), sr.data(), &sc); rc) return rc;
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	const uint64_t words = (h->count + 31) / 32;
+	const uint64_t room = std::max<uint64_t>(cap, 1);
+	const size_t qelem = sq8 ? 1 : 4;
+	size_t carve = 0;
+	auto take = [&carve](size_t bytes) {
+		const size_t at = carve;
+		carve = (carve + bytes + 255) & ~size_t(255);
+		return at;
+	};
+	const size_t o_q = take(size_t(h->dim) * qelem + 16), o_qc = take(8), o_sd = take(size_t(kk) * 4), o_sr = take(size_t(kk) * 4),
+				 o_front = take(size_t(2) * room * 4), o_total = take(8);
+	if (int rc = c->d_misc.ensure(carve); rc) return rc;
+	if (int rc = c->d_visited.ensure(words * 4); rc) return rc;
+	if (int rc = c->d_out_dist.ensure(room * 4); rc) return rc;
+	if (int rc = c->d_out_row.ensure(room * 4); rc) return rc;
+	char* mb = static_cast<char*>(c->d_misc.ptr);
+	RX_HIP(hipMemcpyAsync(mb + o_q, query, size_t(h->dim) * qelem, hipMemcpyHostToDevice, c->stream));
+	if (sq8) {
+		const float qc[2] = {*qcorr, *qnorm};
+		RX_HIP(hipMemcpyAsync(mb + o_qc, qc, 8, hipMemcpyHostToDevice, c->stream));
+	}
+	if (sc) {
+		RX_HIP(hipMemcpyAsync(mb + o_sd, sd.data(), size_t(sc) * 4, hipMemcpyHostToDevice, c->stream));
+		RX_HIP(hipMemcpyAsync(mb + o_sr, sr.data(), size_t(sc) * 4, hipMemcpyHostToDevice, c->stream));
+	}
+	RX_HIP(hipMemsetAsync(mb + o_total, 0, 8, c->stream));
+	RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, words * 4, c->stream));
+	rxgpu::HnswParams p{};
+	p.rows = h->d_rows;
+	p.inv_norms = h->d_inv_norms;
+	p.links0 = h->d_links0;
+	p.deleted = h->d_deleted;
+	p.n = h->count;
+	p.stride = h->stride;
+	p.dim = h->dim;
+	p.M = h->graph_M;
+	p.maxM0 = h->graph_maxM0;
+	p.bare = h->graph_deleted == 0;
+	p.queries = reinterpret_cast<const float*>(mb + o_q);
+	if (sq8) {
+		p.codes = h->d_codes;
+		p.corr = h->d_corr;
+		p.alpha2 = h->sq8_alpha2;
+		p.qcodes = reinterpret_cast<const uint8_t*>(mb + o_q);
+		p.qcorr = reinterpret_cast<const float*>(mb + o_qc);
+		p.qnorm = reinterpret_cast<const float*>(mb + o_qc) + 1;
+	}
+	rxgpu::HnswRange r{};
+	r.seed_dist = reinterpret_cast<const float*>(mb + o_sd);
+	r.seed_row = reinterpret_cast<const uint32_t*>(mb + o_sr);
+	r.seed_n = sc;
+	r.radius = radius;
+	r.visited = static_cast<uint32_t*>(c->d_visited.ptr);
+	r.frontier = reinterpret_cast<uint32_t*>(mb + o_front);
+	r.out_dist = static_cast<float*>(c->d_out_dist.ptr);
+	r.out_row = static_cast<uint32_t*>(c->d_out_row.ptr);
+	r.total = reinterpret_cast<unsigned long long*>(mb + o_total);
+	r.cap = cap;
+	{
+		ProfileScope ps(h, "hnsw_range", c->stream);
+		rxgpu::launch_hnsw_range(h->metric, p, r, c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	unsigned long long total = 0;
+	RX_HIP(hipMemcpyAsync(&total, mb + o_total, 8, hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	*out_total = total;
+	const uint64_t have = std::min<uint64_t>(total, cap);
+	if (have) {
+		RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, have * 4, hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, have * 4, hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));
+	}
+	if (total > cap) {
+		set_error("rxgpu_hnsw_search_range: more hits than the output buffer holds");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_search_range(rxgpu_index* h, const float* query, float radius, uint32_t ef, float* out_dist, uint32_t* out_row, uint64_t cap,
+							uint64_t* out_total) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(h->count == 0 || (h->graph_attached && h->graph_n == h->count), RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_range: graph is not attached / out of date");
+	return hnsw_range_impl(h, query, nullptr, nullptr, radius, ef, out_dist, out_row, cap, out_total);
+}
+
+int rxgpu_hnsw_search_range_sq8(rxgpu_index* h, const uint8_t* query_codes, float query_corr, float query_norm_coef, float radius, uint32_t ef,
+								float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(h->count == 0 || (h->graph_attached && h->graph_n == h->count), RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_range_sq8: graph is not attached / out of date");
+	RX_CHECK(h->count == 0 || (h->d_codes && h->sq8_n == h->count), RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_range_sq8: SQ8 codes are not attached / out of date");
+	return hnsw_range_impl(h, query_codes, &query_corr, &query_norm_coef, radius, ef, out_dist, out_row, cap, out_total);
+}
+
 // ---------------------------------------------------------------------------------------------- streaming KNN sessions
 struct rxgpu_hnsw_stream {
 	rxgpu_index* owner = nullptr;
@@ -1799,6 +1919,8 @@ struct rxgpu_hnsw_stream {
 	uint32_t out_cap = 0;
 	rxgpu::HnswStreamState host_state{};
 	bool empty_graph = false;
+	bool sq8 = false;          // the session runs over the SQ8 codes: d_query holds the query's codes
+	float qcorr = 0.f, qnorm = 1.f;
 };
 
 static void fill_hnsw_params(const rxgpu_index* h, rxgpu::HnswParams& p) {
@@ -1818,9 +1940,19 @@ static void fill_hnsw_params(const rxgpu_index* h, rxgpu::HnswParams& p) {
 	p.bare = h->graph_deleted == 0;
 }
 
+static void fill_sq8_params(const rxgpu_index* h, const rxgpu_hnsw_stream* s, rxgpu::HnswParams& p) {
+	if (!s->sq8) return;
+	p.codes = h->d_codes;
+	p.corr = h->d_corr;
+	p.alpha2 = h->sq8_alpha2;
+}
+
 static void fill_stream(const rxgpu_hnsw_stream* s, rxgpu::HnswStream& d) {
 	const uint64_t cap = s->graph_n;
 	d.query = static_cast<const float*>(s->d_query.ptr);
+	d.qcodes = s->sq8 ? static_cast<const uint8_t*>(s->d_query.ptr) : nullptr;
+	d.qcorr = s->qcorr;
+	d.qnorm = s->qnorm;
 	d.visited = static_cast<uint32_t*>(s->d_visited.ptr);
 	d.cand_d = static_cast<float*>(s->d_cand.ptr);
 	d.cand_i = reinterpret_cast<uint32_t*>(d.cand_d + cap);
@@ -1846,13 +1978,18 @@ void rxgpu_hnsw_stream_end(rxgpu_hnsw_stream* s) {
 	delete s;
 }
 
-int rxgpu_hnsw_stream_begin(rxgpu_index* h, const float* query, uint32_t ef, rxgpu_hnsw_stream** out) {
+static int hnsw_stream_begin_impl(rxgpu_index* h, const void* query, bool sq8, float qcorr, float qnorm, uint32_t ef, rxgpu_hnsw_stream** out) {
 	RX_CHECK(h && query && out, RXGPU_ERR_PARAMS, "rxgpu_hnsw_stream_begin: null argument");
 	*out = nullptr;
+	RX_CHECK(!sq8 || h->count == 0 || (h->d_codes && h->sq8_n == h->count), RXGPU_ERR_LOGIC,
+			 "rxgpu_hnsw_stream_begin_sq8: SQ8 codes are not attached / out of date");
 	DeviceGuard dg(h->device);
 	auto* s = new rxgpu_hnsw_stream();
 	s->owner = h;
 	s->ef = ef ? ef : 100;   // kDefaultStreamingEf (hnswalg.h:1867)
+	s->sq8 = sq8;
+	s->qcorr = qcorr;
+	s->qnorm = qnorm;
 	s->graph_n = h->count;
 	if (h->count == 0) {     // hnswalg.h:1880-1882: an empty graph yields a session that is exhausted at once
 		s->empty_graph = true;
@@ -1868,16 +2005,18 @@ int rxgpu_hnsw_stream_begin(rxgpu_index* h, const float* query, uint32_t ef, rxg
 	RX_CHECK(h->graph_attached && h->graph_n == h->count, RXGPU_ERR_LOGIC, "rxgpu_hnsw_stream_begin: graph is not attached / out of date");
 	RX_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
 	const uint64_t cap = h->count, words = (h->count + 31) / 32;
+	const size_t qbytes = size_t(h->dim) * (sq8 ? 1 : 4);
 	if (int rc = s->d_query.ensure(size_t(h->dim) * 4); rc) return rc;
 	if (int rc = s->d_visited.ensure(words * 4); rc) return rc;
 	if (int rc = s->d_cand.ensure(cap * 8); rc) return rc;
 	if (int rc = s->d_top.ensure(cap * 16); rc) return rc;
 	if (int rc = s->d_ext.ensure(cap * 16); rc) return rc;
 	if (int rc = s->d_state.ensure(sizeof(rxgpu::HnswStreamState)); rc) return rc;
-	RX_HIP(hipMemcpyAsync(s->d_query.ptr, query, size_t(h->dim) * 4, hipMemcpyHostToDevice, s->stream));
+	RX_HIP(hipMemcpyAsync(s->d_query.ptr, query, qbytes, hipMemcpyHostToDevice, s->stream));
 	RX_HIP(hipMemsetAsync(s->d_visited.ptr, 0, words * 4, s->stream));
 	rxgpu::HnswParams p{};
 	fill_hnsw_params(h, p);
+	fill_sq8_params(h, s, p);
 	rxgpu::HnswStream d{};
 	fill_stream(s, d);
 	rxgpu::launch_hnsw_stream(h->metric, p, d, 0, rxgpu::kStreamBegin, false, s->stream);
@@ -1887,6 +2026,16 @@ int rxgpu_hnsw_stream_begin(rxgpu_index* h, const float* query, uint32_t ef, rxg
 	guard.s = nullptr;
 	*out = s;
 	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_stream_begin(rxgpu_index* h, const float* query, uint32_t ef, rxgpu_hnsw_stream** out) {
+	return hnsw_stream_begin_impl(h, query, false, 0.f, 1.f, ef, out);
+}
+
+// The same session over a quantised graph (HierarchicalNSWImpl<uint8_t>): the query as prepareData leaves it (codes + corrective offset),
+// every distance scaled by its normCoef — BeginStreamingSearch / ContinueStreamingSearch (hnswalg.h:1865-1975) instantiated for uint8_t.
+int rxgpu_hnsw_stream_begin_sq8(rxgpu_index* h, const uint8_t* query_codes, float query_corr, float query_norm_coef, uint32_t ef, rxgpu_hnsw_stream** out) {
+	return hnsw_stream_begin_impl(h, query_codes, true, query_corr, query_norm_coef, ef, out);
 }
 
 int rxgpu_hnsw_stream_continue(rxgpu_hnsw_stream* s, uint32_t batch, float* out_dist, uint32_t* out_row, uint32_t* out_count, int32_t* exhausted) {
@@ -1911,6 +2060,7 @@ int rxgpu_hnsw_stream_continue(rxgpu_hnsw_stream* s, uint32_t batch, float* out_
 	}
 	rxgpu::HnswParams p{};
 	fill_hnsw_params(h, p);
+	fill_sq8_params(h, s, p);
 	rxgpu::HnswStream d{};
 	fill_stream(s, d);
 	const rxgpu::HnswStreamState& hs = s->host_state;

@@ -76,6 +76,8 @@ struct HnswPatch;
 void launch_hnsw_patch(const HnswPatch& p, uint32_t n_dirty, hipStream_t s);
 struct HnswStream;
 void launch_hnsw_stream(int metric, const HnswParams& p, const HnswStream& s, uint32_t batch, int mode, bool lds, hipStream_t st);
+struct HnswRange;
+void launch_hnsw_range(int metric, const HnswParams& p, const HnswRange& r, hipStream_t s);
 
 // Hybrid FT + KNN rank fusion on the device (hybrid_fuse.hip)
 constexpr int kMaxFuseKnn = 1024;      // KNN entries one fusion takes (k of the KNN condition)

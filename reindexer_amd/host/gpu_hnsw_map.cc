@@ -230,6 +230,18 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 	if (p.rc != RXGPU_OK) throw std::runtime_error("SearchKnn: " + p.error);
 }
 
+// queryNormCoef (hnswalg.h:1855-1863) and prepareData (:510-529): the query is scaled back to its original length, quantised, and every
+// distance is multiplied by 1 / |q|.  Returns the query's corrective offset.
+float GpuHnswMap::quantizeQuery(const float* queryDataRaw, std::optional<float> queryDataNorm, std::vector<uint8_t>& qcodes, float& normCoef) const {
+	const bool cosine = graph_.Metric() == VectorMetric::Cosine;
+	if (cosine && !queryDataNorm) {
+		throw std::runtime_error("Norm is required for Cosine-metric during corrective offsets calculation in quantized graph");
+	}
+	normCoef = cosine ? 1.f / *queryDataNorm : 1.f;
+	qcodes.resize(graph_.Dim());
+	return Sq8Quantize(graph_.Metric(), sq8_, queryDataRaw, graph_.Dim(), 1.f / normCoef, qcodes.data());
+}
+
 // hnswalg.h:1988-2012
 SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional<float> queryDataNorm, size_t k, size_t ef) const {
 	SearchResultQueue result;
@@ -241,15 +253,9 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 	std::vector<uint32_t> row(k);
 	uint32_t count = 0;
 	if (quantized_) {
-		// queryNormCoef (hnswalg.h:1855-1863) and prepareData (:510-529): the query is scaled back to its original length, quantised, and
-		// every distance is multiplied by 1 / |q|
-		const bool cosine = graph_.Metric() == VectorMetric::Cosine;
-		if (cosine && !queryDataNorm) {
-			throw std::runtime_error("Norm is required for Cosine-metric during corrective offsets calculation in quantized graph");
-		}
-		const float normCoef = cosine ? 1.f / *queryDataNorm : 1.f;
-		std::vector<uint8_t> qcodes(graph_.Dim());
-		const float qcorr = Sq8Quantize(graph_.Metric(), sq8_, queryDataRaw, graph_.Dim(), 1.f / normCoef, qcodes.data());
+		float normCoef = 1.f;
+		std::vector<uint8_t> qcodes;
+		const float qcorr = quantizeQuery(queryDataRaw, queryDataNorm, qcodes, normCoef);
 		if (rxgpu_hnsw_search_knn_sq8(dev_, qcodes.data(), &qcorr, &normCoef, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) !=
 			RXGPU_OK) {
 			throwDevice("SearchKnn");
@@ -276,11 +282,19 @@ StreamingSearchSession& StreamingSearchSession::operator=(StreamingSearchSession
 }
 
 // hnswalg.h:1865-1891
-StreamingSearchSession GpuHnswMap::BeginStreamingSearch(const float* queryDataRaw, std::optional<float>, StreamingSearchOptions opts) const {
-	if (quantized_) throw std::runtime_error("BeginStreamingSearch: not implemented for a quantised GPU graph");
+StreamingSearchSession GpuHnswMap::BeginStreamingSearch(const float* queryDataRaw, std::optional<float> queryDataNorm, StreamingSearchOptions opts) const {
 	StreamingSearchSession session;
 	session.graph_ = this;
 	syncDevice();
+	if (quantized_) {   // HierarchicalNSWImpl<uint8_t>: the session runs over the codes, the query prepared as in SearchKnn (hnswalg.h:1872-1878)
+		float normCoef = 1.f;
+		std::vector<uint8_t> qcodes;
+		const float qcorr = quantizeQuery(queryDataRaw, queryDataNorm, qcodes, normCoef);
+		if (rxgpu_hnsw_stream_begin_sq8(dev_, qcodes.data(), qcorr, normCoef, uint32_t(opts.ef), &session.impl_) != RXGPU_OK) {
+			throwDevice("BeginStreamingSearch");
+		}
+		return session;
+	}
 	if (rxgpu_hnsw_stream_begin(dev_, queryDataRaw, uint32_t(opts.ef), &session.impl_) != RXGPU_OK) throwDevice("BeginStreamingSearch");
 	return session;
 }
@@ -307,58 +321,31 @@ StreamingBatch GpuHnswMap::ContinueStreamingSearch(StreamingSearchSession& sessi
 	return batch;
 }
 
-// hnswalg.h:2015-2070: ef-search, then breadth-first expansion over level-0 links while dist < radius.
-// The expansion is a closure (its result set does not depend on visiting order); the host walks the frontier and the
-// GPU computes every distance (rxgpu_distances), so no search arithmetic runs on the CPU.
-SearchResultQueue GpuHnswMap::SearchRange(const float* queryDataRaw, std::optional<float>, float radius, size_t ef) const {
+// hnswalg.h:2015-2070: ef-search, then the closure over level-0 links while dist < radius — both on the device (rxgpu_hnsw_search_range:
+// the expansion is one launch of hnsw_range_kernel whatever its depth; the result is a set, its order does not depend on the walk).
+SearchResultQueue GpuHnswMap::SearchRange(const float* queryDataRaw, std::optional<float> queryDataNorm, float radius, size_t ef) const {
 	SearchResultQueue result;
 	const size_t n = graph_.Count();
 	if (n == 0) return result;
-	if (quantized_) throw std::runtime_error("SearchRange: not implemented for a quantised GPU graph");
 	syncDevice();
 	const size_t efEff = ef ? ef : 1;   // no clamp: an ef beyond the device engine's limit (4096) is an error from the C-ABI, never a silently smaller search
-	const size_t kk = std::min(efEff, n);
-	std::vector<float> dist(kk);
-	std::vector<uint32_t> row(kk);
-	uint32_t count = 0;
-	if (rxgpu_hnsw_search_knn(dev_, queryDataRaw, 1, uint32_t(kk), uint32_t(efEff), dist.data(), row.data(), &count) != RXGPU_OK) {
-		throwDevice("SearchRange");
+	float normCoef = 1.f, qcorr = 0.f;
+	std::vector<uint8_t> qcodes;
+	if (quantized_) qcorr = quantizeQuery(queryDataRaw, queryDataNorm, qcodes, normCoef);
+	std::vector<float> dist;
+	std::vector<uint32_t> row;
+	uint64_t total = 0;
+	for (size_t cap = std::max<size_t>(4 * efEff, 1024);; cap = std::min<size_t>(n, std::max<size_t>(2 * cap, size_t(total)))) {
+		cap = std::min(cap, n);
+		dist.resize(cap);
+		row.resize(cap);
+		const int rc = quantized_ ? rxgpu_hnsw_search_range_sq8(dev_, qcodes.data(), qcorr, normCoef, radius, uint32_t(efEff), dist.data(), row.data(), cap, &total)
+								  : rxgpu_hnsw_search_range(dev_, queryDataRaw, radius, uint32_t(efEff), dist.data(), row.data(), cap, &total);
+		if (rc == RXGPU_OK) break;
+		if (rc != RXGPU_ERR_OVERFLOW || cap >= n) throwDevice("SearchRange");
 	}
-	std::vector<uint8_t> visited(n, 0);
-	std::vector<uint32_t> frontier, next, fresh;
-	for (uint32_t i = 0; i < count; ++i) {
-		visited[row[i]] = 1;
-		if (dist[i] < radius) {
-			frontier.push_back(row[i]);
-			result.emplace(dist[i], graph_.Label(row[i]));
-		}
-	}
-	const size_t stride = 1 + graph_.MaxM0();
-	std::vector<float> fd;
-	while (!frontier.empty()) {
-		fresh.clear();
-		for (uint32_t cur : frontier) {
-			const uint32_t* ll = graph_.Links0() + size_t(cur) * stride;
-			for (uint32_t j = 0; j < ll[0]; ++j) {
-				const uint32_t cand = ll[1 + j];
-				if (graph_.IsDeleted(cand) || visited[cand]) continue;
-				visited[cand] = 1;
-				fresh.push_back(cand);
-			}
-		}
-		next.clear();
-		if (!fresh.empty()) {
-			fd.resize(fresh.size());
-			if (rxgpu_distances(dev_, queryDataRaw, fresh.data(), uint32_t(fresh.size()), fd.data()) != RXGPU_OK) throwDevice("SearchRange");
-			for (size_t i = 0; i < fresh.size(); ++i) {
-				if (fd[i] < radius) {
-					next.push_back(fresh[i]);
-					result.emplace(fd[i], graph_.Label(fresh[i]));
-				}
-			}
-		}
-		frontier.swap(next);
-	}
+	ReserveQueue(result, size_t(total));
+	for (uint64_t i = 0; i < total; ++i) result.emplace(dist[i], graph_.Label(row[i]));
 	return result;
 }
 

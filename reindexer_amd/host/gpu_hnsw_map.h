@@ -121,6 +121,7 @@ private:
 	Sq8Params sq8_;
 	mutable bool codesDirty_ = false;
 	void attachCodes() const;
+	float quantizeQuery(const float* queryDataRaw, std::optional<float> queryDataNorm, std::vector<uint8_t>& qcodes, float& normCoef) const;
 
 	bool coalesce_ = true;
 	mutable std::mutex coMtx_;

@@ -381,6 +381,23 @@ void* rxhost_hnsw_stream_begin(void* h, const float* q, size_t ef) {
 	guarded([&] { s = new StreamingSearchSession(static_cast<const GpuHnswMap*>(h)->BeginStreamingSearch(q, std::nullopt, StreamingSearchOptions{ef})); });
 	return s;
 }
+// with the query's norm (a quantised cosine graph needs it: queryNormCoef, hnswalg.h:1855-1863)
+void* rxhost_hnsw_stream_begin_norm(void* h, const float* q, int hasNorm, float norm, size_t ef) {
+	StreamingSearchSession* s = nullptr;
+	guarded([&] {
+		s = new StreamingSearchSession(static_cast<const GpuHnswMap*>(h)->BeginStreamingSearch(q, hasNorm ? std::optional<float>(norm) : std::nullopt,
+																								   StreamingSearchOptions{ef}));
+	});
+	return s;
+}
+long rxhost_hnsw_search_range_norm(void* h, const float* q, int hasNorm, float norm, float radius, size_t ef, float* outDist, uint64_t* outLabel, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		auto res = static_cast<const GpuHnswMap*>(h)->SearchRange(q, hasNorm ? std::optional<float>(norm) : std::nullopt, radius, ef);
+		n = long(drain(res, outDist, outLabel, cap));
+	});
+	return n;
+}
 // pops the batch's result queue: worst first under (dist, label).  Returns the count, -1 on error.
 long rxhost_hnsw_stream_continue(void* h, void* session, size_t batch, float* outDist, uint64_t* outLabel, int* exhausted) {
 	long n = -1;

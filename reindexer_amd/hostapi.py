@@ -298,15 +298,20 @@ class HnswGraph:
 
 
 class _HnswStream:
-    def __init__(self, owner, q, ef):
+    def __init__(self, owner, q, ef, norm=None):
         L = lib()
         L.rxhost_hnsw_stream_begin.restype = _vp
         L.rxhost_hnsw_stream_begin.argtypes = [_vp, _vp, _sz]
+        L.rxhost_hnsw_stream_begin_norm.restype = _vp
+        L.rxhost_hnsw_stream_begin_norm.argtypes = [_vp, _vp, _i, _f, _sz]
         L.rxhost_hnsw_stream_continue.restype = _l
         L.rxhost_hnsw_stream_continue.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp]
         L.rxhost_hnsw_stream_end.argtypes = [_vp]
         self.owner, self.q = owner, q
-        self.s = L.rxhost_hnsw_stream_begin(owner.h, q.ctypes.data, ef)
+        if norm is None:
+            self.s = L.rxhost_hnsw_stream_begin(owner.h, q.ctypes.data, ef)
+        else:
+            self.s = L.rxhost_hnsw_stream_begin_norm(owner.h, q.ctypes.data, 1, float(norm), ef)
         if not self.s:
             _raise()
 
@@ -538,19 +543,26 @@ class GpuHnswMap:
             _raise()
         return od[:n].copy(), ol[:n].copy()
 
-    def stream(self, q, ef=0):
-        """BeginStreamingSearch: session with .next(batch) -> (dist, label, exhausted) (worst first) and .close()."""
-        return _HnswStream(self, _f32(q), ef)
+    def stream(self, q, ef=0, norm=None):
+        """BeginStreamingSearch: session with .next(batch) -> (dist, label, exhausted) (worst first) and .close().  norm: the query's
+        norm as HnswIndexBase::search passes it (needed by a quantised cosine graph)."""
+        return _HnswStream(self, _f32(q), ef, norm)
 
     def knn_stream(self, key, ef=0):
         """Index-level streaming (HnswIndexBase<Map>::beginStreaming / continueStreaming): raw key in; .next(batch) -> (row ids,
         user-visible ranks, exhausted), best first."""
         return _KnnStream(self, _f32(key), ef)
 
-    def search_range(self, q, radius, ef, cap=1 << 20):
+    def search_range(self, q, radius, ef, cap=1 << 20, norm=None):
         q = _f32(q)
         od, ol = np.empty(cap, np.float32), np.empty(cap, np.uint64)
-        n = lib().rxhost_hnsw_search_range(self.h, q.ctypes.data, radius, ef, od.ctypes.data, ol.ctypes.data, cap)
+        L = lib()
+        if norm is None:
+            n = L.rxhost_hnsw_search_range(self.h, q.ctypes.data, radius, ef, od.ctypes.data, ol.ctypes.data, cap)
+        else:
+            L.rxhost_hnsw_search_range_norm.restype = _l
+            L.rxhost_hnsw_search_range_norm.argtypes = [_vp, _vp, _i, _f, _f, _sz, _vp, _vp, _sz]
+            n = L.rxhost_hnsw_search_range_norm(self.h, q.ctypes.data, 1, float(norm), radius, ef, od.ctypes.data, ol.ctypes.data, cap)
         if n < 0:
             _raise()
         return od[:n].copy(), ol[:n].copy()

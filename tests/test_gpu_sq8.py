@@ -149,6 +149,61 @@ def test_quantised_map_equals_restated_quantised_engine(rxgpu, oracle, sq8, metr
     if metric == 2:
         with pytest.raises(RuntimeError, match="Norm is required"):
             m.search_knn_norm(rows[0], 5, 10, None)
-    with pytest.raises(RuntimeError, match="not implemented"):
-        m.search_range(rows[0], 1.0, 10)
+    m.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_quantised_map_range_and_streaming_equal_the_reference_quantised_engine(rxgpu, ref, oracle, metric):
+    """After Quantize() the Map answers EVERYTHING the reference's quantised engine does (HierarchicalNSWImpl<uint8_t>): SearchRange — the
+    ef-search and the closure over codes, both on the device — and whole streaming sessions over codes, compared with the REAL engine built
+    from the same inserts (the host builder is link-for-link the reference's; the quantisation range is the one the reference sampled)."""
+    from oracle.pyoracle import RefHnsw, RefHnswQ
+    from reindexer_amd import hostapi
+    n, d = 4000, 64
+    rows = make_corpus(83 + metric, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(2)
+    rf = RefHnsw(ref, metric, d, n, M=12, ef_construction=80)
+    rf.add(rows, labels)
+    m = hostapi.GpuHnswMap(metric, d, n, M=12, ef_construction=80)
+    m.add(rows, labels)
+    dead = labels[np.random.default_rng(4).choice(n, 120, replace=False)]
+    for lab in dead:
+        rf.mark_delete(lab)
+        m.mark_delete(lab)
+    rq = RefHnswQ(rf, sample_size=n)
+    prm = rq.export()
+    m.quantize(float(prm["min_q"]), float(prm["max_q"]))
+
+    def pairs(dist, lab):
+        o = np.lexsort((lab, dist))
+        return dist[o], lab[o]
+
+    for qi in range(12):
+        q = make_corpus(2300 + qi, 1, d)[0]
+        norm = None
+        if metric == 2:
+            q, k_ = oracle.normalize_copy(q)
+            norm = float(np.float32(1.0) / np.float32(k_))
+        wd, wl = rq.search_knn(q, 40, 64, norm)
+        gd, gl = m.search_knn_norm(q, 40, 64, norm)
+        assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd)), (metric, qi, "knn")      # same graph, same codes
+        # radii around the 10th / 40th hit: a handful .. a few hundred results, expansion several levels deep
+        for radius in (float(wd[9]), float(wd[39]), float(wd[39]) + abs(float(wd[39])) * 0.05 + 0.02):
+            for ef in (16, 64):
+                rd, rl = rq.search_range(q, radius, ef, norm)
+                sd, sl = m.search_range(q, radius, ef, norm=norm)
+                a, b = pairs(sd, sl), pairs(rd, rl)
+                assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])), (metric, qi, radius, ef, len(sd), len(rd))
+        # streaming sessions over the codes: batch for batch, exhausted at the same call
+        for ef, plan in ((0, [10] * 5), (32, [7, 60, 1, 200])):
+            gs, ws = m.stream(q, ef, norm=norm), rq.stream(q, ef, norm)
+            for bsz in plan:
+                g1, w1 = gs.next(bsz), ws.next(bsz)
+                assert g1[2] == w1[2] and len(g1[0]) == len(w1[0]), (metric, qi, ef, bsz)
+                a, b = pairs(g1[0], g1[1]), pairs(w1[0], w1[1])
+                assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])), (metric, qi, ef, bsz)
+            gs.close()
+            ws.close()
+    rq.close()
+    rf.close()
     m.close()
