@@ -341,6 +341,20 @@ int rxgpu_ft_get_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t* n, uint64_t
 int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
 							 const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded, uint32_t* out_doc,
 							 float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n, int32_t* out_preselected);
+/* Device half of Merger::Merge for ANY query made of terms and phrases (QueryMergeData::queryParts, querymergedata.h:191-242; the
+ * selecter builds them in selecterimpl.h:482-572): the arguments of rxgpu_ft_merge_terms_raw plus, per term, FtDslOpts::phraseNum and
+ * FtDslOpts::distance (ftdsl.h:13-35) — consecutive terms with the same phrase_num >= 0 form one phrase (PhraseResults; its operator is
+ * its first term's), phrase_num < 0 is a plain term; both arrays may be NULL (no phrases).  Every phrase goes through PhraseMerger::Merge
+ * on the device first (phrasemergerimpl.h:161-329: preselectDocsContainingAllTerms, mergePhraseTerm with MergePositionsWithDist /
+ * SwitchPositions, phrasemerger.h:24-55, 107-140), then the query parts are merged: mergeTerm for terms, mergePhrase (mergerimpl.h:39-90)
+ * for phrases, the restricting bitmask / pre-scores with GetMergedDocsBitmask / ExcludeMergedDocsFromBitmask / GetMergedDocsScore
+ * (phrasemerger.h:309-333).  A single plain term is the Simple() merge; an Empty() query writes nothing.  Multi-word synonyms
+ * (QueryMergeData::synonyms) are not covered: such queries stay on the CPU merger.  Outputs as rxgpu_ft_merge_terms_raw;
+ * cap >= min(merge_limit, total postings of all terms). */
+int rxgpu_ft_merge_query_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
+							 const int32_t* phrase_num, const int32_t* distance, const uint32_t* sub_off, const uint32_t* word_ids, const float* procs,
+							 const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap,
+							 uint64_t* out_n, int32_t* out_preselected);
 /* ---------------------------------------------------------------------------------------------------------
  * Hybrid rank fusion on the device: MergerRankedImpl + mergeRanked (cpp_src/core/nsselecter/selectiteratorcontainer.cc:
  * 1343-1423, 1454-1559), RanksHolder::InitRRFPositions (ranks_holder.h:61-76), RerankerRRF / RerankerLinear (core/sorting/reranker.h:11-39),
@@ -359,6 +373,11 @@ int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg
 								   const uint32_t* word_ids, const float* procs, const uint8_t* excluded);
 int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
 								  const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, const uint8_t* excluded);
+/* ... the same for rxgpu_ft_merge_query_raw's queries (phrases included).  *out_enqueued = 0 when the query is Empty(): there is then no
+ * resident result and the fusion sees an empty FT side. */
+int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
+								  const int32_t* phrase_num, const int32_t* distance, const uint32_t* sub_off, const uint32_t* word_ids, const float* procs,
+								  const uint8_t* excluded, int32_t* out_enqueued);
 /* The FT-only half of the fusion (postProcessResults, the documents' order among themselves, the rank-class tables), enqueued behind the
  * resident merge: it needs nothing from the KNN side, so a caller that enqueues it BEFORE it starts the KNN search has it run while the
  * scan streams the corpus, and only the short join is left on the query's critical path.  Optional — rxgpu_hybrid_fuse_resident

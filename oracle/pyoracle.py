@@ -741,8 +741,11 @@ class RefFt:
             raise RuntimeError("oracle/_ref/libref_ft.so predates the bm25Type switch: rebuild with `make -C oracle ref`")
 
     def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16):
-        """terms: list of dict(op, opts (FtOracle.default_opts-like), subs=[(word_id, proc), ...])."""
+        """terms: list of dict(op, opts (FtOracle.default_opts-like), subs=[(word_id, proc), ...][, phrase=<phraseNum>, distance=<d>]);
+        consecutive terms with the same phrase number >= 0 form one phrase (the shim groups them like Selector::Process)."""
         nf = self.nf
+        phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
+        dst = np.array([t.get("distance", 1) for t in terms], np.int32)
         ops = np.array([t["op"] for t in terms], np.int32)
         boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
         tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
@@ -758,9 +761,19 @@ class RefFt:
         exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
         oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
         of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
-        n = self.L.ref_ft_merge(self.h, len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data,
-                                sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
-                                rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
+        fn = getattr(self.L, "ref_ft_merge_phrases", None)
+        if fn is None:
+            if (phr >= 0).any():
+                raise RuntimeError("oracle/_ref/libref_ft.so predates phrases: rebuild with `make -C oracle ref`")
+            n = self.L.ref_ft_merge(self.h, len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data,
+                                    sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
+                                    rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
+        else:
+            fn.restype = C.c_long
+            fn.argtypes = [_vp, _sz] + [_vp] * 11 + [_i, _vp, _vp, _vp, _vp, _sz]
+            n = fn(self.h, len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, phr.ctypes.data,
+                   dst.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
+                   rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
         assert 0 <= n <= cap, n
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
 

@@ -107,14 +107,26 @@ void ref_ft_set_bm25_type(void* h, int type) {
 // Query = nTerms terms.  Per term t: op (1 OR, 2 AND, 3 NOT), boost, termLenBoost, fieldBoost[nf], needSum[nf], and the sub-term
 // slice [subOff[t], subOff[t+1]) of (wordId, proc).  excluded: docsExcluded bitmap (bytes) or null.
 // rankSortType: 0 RankOnly, 1 RankAndID, 3 IDOnly, 4 IDAndPositions.  Returns the result count (<= cap written).
-long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
-				  const uint8_t* needSum, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
-				  int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
+// phraseNum / distance: FtDslOpts::phraseNum (-1: a plain term) and FtDslOpts::distance per term, or null.  The query parts are put
+// together the way Selector::Process does (selecterimpl.h:482-572): consecutive terms with the same phraseNum >= 0 become one PhraseResults.
+long ref_ft_merge_phrases(void* h, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+						  const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord,
+						  const float* subProc, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField,
+						  uint8_t* outNorm, size_t cap) {
 	auto* f = static_cast<FtRef*>(h);
 	try {
 		ft::QueryMergeData<IdRelVec> q;
+		int curPhraseNum = -1;
+		ft::PhraseResults<IdRelVec> nextPhrase;
 		for (size_t t = 0; t < nTerms; ++t) {
 			FtDslOpts o;
+			o.phraseNum = phraseNum ? phraseNum[t] : -1;
+			o.distance = distance ? distance[t] : 1;
+			const bool phraseTerm = o.phraseNum != -1;
+			if (!phraseTerm && nextPhrase.NumTerms()) {
+				q.queryParts.emplace_back(std::move(nextPhrase));
+				nextPhrase.clear();
+			}
 			o.op = OpType(ops[t]);
 			o.boost = boosts[t];
 			o.termLenBoost = termLenBoosts[t];
@@ -131,7 +143,20 @@ long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, c
 				tr.AddSubterm(*f->postings.at(subWord[s]), std::string_view("w"), wid, subProc[s]);
 			}
 			q.totalORVids += tr.MaxVDocs();   // selecterimpl.h:546: every term, whatever its operator
-			q.queryParts.emplace_back(std::move(tr));
+			if (phraseTerm) {
+				if (nextPhrase.NumTerms() && curPhraseNum != o.phraseNum) {
+					q.queryParts.emplace_back(std::move(nextPhrase));
+					nextPhrase.clear();
+				}
+				curPhraseNum = o.phraseNum;
+				nextPhrase.Add(std::move(tr));
+			} else {
+				q.queryParts.emplace_back(std::move(tr));
+			}
+		}
+		if (nextPhrase.NumTerms()) {
+			q.queryParts.emplace_back(std::move(nextPhrase));
+			nextPhrase.clear();
 		}
 		FtMergeStatuses::Statuses st;
 		st.resize(f->totalDocs, false);
@@ -162,6 +187,13 @@ long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, c
 	} catch (const std::exception&) {
 		return -1;
 	}
+}
+
+long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+				  const uint8_t* needSum, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
+				  int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
+	return ref_ft_merge_phrases(h, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, nullptr, nullptr, subOff, subWord, subProc, excluded, rankSortType,
+								outId, outProc, outField, outNorm, cap);
 }
 
 // The REAL packer: PackedIdRelVec::insert_back (idrelset.h:229-261) over IdRelType::pack / packWithoutArrayIdxs (idrelset.cc:8-68,

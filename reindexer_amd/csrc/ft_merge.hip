@@ -46,6 +46,7 @@
 #include "rxgpu_internal.h"
 #include "knn_kernels.hip.h"
 #include "ft_rank.hip.h"
+#include "ft_scan.hip.h"
 
 namespace rxgpu {
 
@@ -57,97 +58,7 @@ namespace {
 		if ((p).dbg && blockIdx.x == (p).dbg_block && threadIdx.x == 0) (p).dbg[k] = wall_clock64();      \
 	} while (0)
 
-constexpr unsigned long long kLbPrefix = 1ull << 63;
-constexpr unsigned long long kLbAggregate = 1ull << 62;
 constexpr int kFtApplyWords = 4;   // mask words per thread in ft_preselect_apply
-
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) {
-#pragma unroll
-	for (int off = 1; off < 64; off <<= 1) {
-		const uint32_t o = __shfl_up(v, off, 64);
-		if (lane >= off) v += o;
-	}
-	return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
-}
-
-// Exclusive prefix of `count` over ALL threads of ALL workgroups in ticket order (256 threads per workgroup).
-// lookback[] is zeroed before the launch; *grand_incl = inclusive total up to and including this workgroup.
-__device__ uint32_t ordered_prefix(uint32_t count, uint32_t ticket, unsigned long long* lookback, uint32_t* error_flag, uint32_t* grand_incl) {
-	__shared__ uint32_t s_wave_tot[4];
-	__shared__ uint32_t s_block_excl;
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t incl = wave_inclusive_scan(count, lane);
-	if (lane == 63) s_wave_tot[wave] = incl;
-	__syncthreads();
-	uint32_t before = 0;
-	for (int w = 0; w < wave; ++w) before += s_wave_tot[w];
-	const uint32_t block_total = s_wave_tot[0] + s_wave_tot[1] + s_wave_tot[2] + s_wave_tot[3];
-	if (wave == 0) {
-		if (lane == 0) {
-			__hip_atomic_store(&lookback[ticket], (ticket == 0 ? kLbPrefix : kLbAggregate) | block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		uint32_t excl = 0;
-		long long j = (long long)ticket - 1;   // nearest predecessor
-		while (j >= 0) {
-			const long long idx = j - lane;
-			unsigned long long st = 0;
-			if (idx >= 0) {
-				uint32_t spins = 0;
-				do {
-					st = __hip_atomic_load(&lookback[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					if (st) break;
-					__builtin_amdgcn_s_sleep(1);
-					if ((++spins & 1023u) == 0 &&
-						(spins > (1u << 24) || __hip_atomic_load(error_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-						__hip_atomic_store(error_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // never hang the GPU: bail out, the host reports it
-						st = kLbPrefix;
-						break;
-					}
-				} while (true);
-			}
-			const unsigned long long pm = __ballot(idx >= 0 && (st & kLbPrefix));
-			const int first = pm ? __ffsll((long long)pm) - 1 : 63;
-			excl += wave_sum((idx >= 0 && lane <= first) ? uint32_t(st & 0xFFFFFFFFull) : 0u);
-			if (pm) break;
-			j -= 64;
-		}
-		if (lane == 0) {
-			if (ticket != 0) __hip_atomic_store(&lookback[ticket], kLbPrefix | (unsigned long long)(excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			s_block_excl = excl;
-		}
-	}
-	__syncthreads();
-	const uint32_t be = s_block_excl;
-	*grand_incl = be + block_total;
-	__syncthreads();   // the shared words are reused by the caller's next call
-	return be + before + (incl - count);
-}
-
-__device__ __forceinline__ uint32_t grab_ticket(uint32_t* ticket) {
-	__shared__ uint32_t s_ticket;
-	if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1u);
-	__syncthreads();
-	return s_ticket;
-}
-
-// block of a posting-side grid -> its sub-term (every entry owns at least one block; entries ascend by block_base)
-__device__ __forceinline__ FtGridEntry grid_entry(const FtGridEntry* g, uint32_t n, uint32_t block) {
-	uint32_t lo = 0, hi = n - 1;
-	while (lo < hi) {
-		const uint32_t mid = (lo + hi + 1) >> 1;
-		if (g[mid].block_base <= block) {
-			lo = mid;
-		} else {
-			hi = mid - 1;
-		}
-	}
-	return g[lo];
-}
 
 // The doc ids of a thread's kFtPassItems consecutive postings (one 16-byte load away from the tail)
 __device__ __forceinline__ void load_docs(const FtPosSubterm& s, uint64_t i0, uint32_t (&docs)[kFtPassItems], bool (&live)[kFtPassItems]) {
@@ -329,6 +240,10 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 		// the term's configuration in registers: `term` lives in global memory, and a load per posting sat on the critical path
 		const bool all_pos_boost = term.all_pos_boost != 0, same_boost = term.same_boost != 0;
 		const float boost0 = term.field_boost[0], opts_boost = term.opts_boost;
+		// a phrase part (its rows come from ft_phrase.hip): every document counts (GetMergedDocsBitmask, phrasemerger.h:309-317) and scores
+		// CalcProc16 without the 65535 / 4 cap of a term (GetMergedDocsScore, :326-333)
+		const bool is_phrase = term.phrase != 0;
+		const uint32_t phrase16 = term.phrase_proc16;
 		const bool need_entries = (op == 2 && !all_pos_boost) || (want_score && !same_boost);
 		auto visit = [&](const FtPosSubterm& s, float sproc, uint32_t i, uint32_t local) {
 			const uint32_t bit = 1u << (local & 31);
@@ -357,6 +272,7 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 					const float proc = sproc * mb * opts_boost;
 					uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
 					p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
+					if (is_phrase) p16 = phrase16;
 					const uint32_t cur = s_score[local];
 					p16 = p16 < 65535u - cur ? p16 : 65535u - cur;
 					s_score[local] = uint16_t(cur + p16);
@@ -379,6 +295,7 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 				const float proc = sproc * boost0 * opts_boost;
 				uint32_t p16c = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
 				p16c = p16c < 65535u / 4 ? p16c : 65535u / 4;
+				if (is_phrase) p16c = phrase16;
 				const bool scoring = want_score && boost0 > 0.0f;
 #pragma unroll
 				for (uint32_t g = 0; g < kFtStageBlocks; g += 4) {
@@ -816,7 +733,12 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 				const FtTermCfg& t = s_termd[g];
 				const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
 				d[u] = s_doc[e];
-				rank[u] = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d[u], &field[u]);
+				if (s.pre_rank) {   // a phrase row: mergePhrase takes the PhraseMerger's rank and field as they are (mergerimpl.h:46-62)
+					rank[u] = s.pre_rank[i];
+					field[u] = s.pre_field[i];
+				} else {
+					rank[u] = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], d[u], &field[u]);
+				}
 				want[u] = rank[u] != 0.0f;
 				row[u] = s.row;
 				idx[u] = uint32_t(i);
@@ -1029,7 +951,7 @@ using FtReplayState = FtReplayStateT<FtPosList>;
 // one posting of the document, met in sub-term order: (rank r, field fld, posting index i) of sub-term row `row`
 // the positions of posting i of sub-term row `row`, and the query position of its term
 __device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, uint32_t i, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
-												 const uint16_t* s_qp, uint16_t& qp, const uint64_t*& pos, uint32_t& npos) {
+												 const uint32_t* s_qp, uint32_t& qp, const uint64_t*& pos, uint32_t& npos) {
 	const uint64_t* fpos;
 	const uint32_t* pos_off;
 	if (row < kFtReplayRows) {
@@ -1040,15 +962,17 @@ __device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, 
 		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
 		fpos = s.fpos;
 		pos_off = s.pos_off;
-		qp = s.qp;
+		qp = ft_row_qpw(s);
 	}
 	const uint32_t po0 = pos_off[i], po1 = pos_off[i + 1];
 	pos = fpos + po0;
 	npos = po1 - po0;
 }
 // one posting of the document, met in sub-term order: rank r in field fld, positions `pos` (not read for a simple merge)
+// (qpw = ft_row_qpw of the posting's row: the query position, whether the row is a phrase's, the last plain term in front of that phrase)
 template <typename Pos>
-__device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<Pos>& st, float r, uint8_t fld, uint16_t qp, const Pos& pos) {
+__device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<Pos>& st, float r, uint8_t fld, uint32_t qpw, const Pos& pos) {
+	const uint16_t qp = uint16_t(qpw & 0x7FFFu);
 	if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
 		if (!st.created) {
 			st.created = true;
@@ -1058,6 +982,38 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<
 			st.proc = r;
 			st.field = fld;
 		}
+		return;
+	}
+	if (qpw & 0x8000u) {   // ---- mergePhrase (mergerimpl.h:39-90): the document's phrase rank, no distance, no switchToNextWord of its own
+		if (!st.created) {   // :60-73: MergerDocumentData(rank = the PhraseMerger's rank, 0 after its last term), lastTermPositions = the phrase's
+			st.created = true;
+			st.proc = r;
+			st.field = fld;
+			st.rank = 0.f;
+			st.last = pos;
+			st.next.n = 0;
+			st.switched_term = qp;
+			st.last_counted = qp;
+			st.terms_counter = 1;
+			return;
+		}
+		// the switchToNextWord calls of the plain terms between the document's last posting and this phrase (merger.h:218-226) come first
+		const uint16_t prev_term = uint16_t(qpw >> 16);
+		if (st.switched_term < prev_term) {
+			if (st.next.n) {
+				st.last = st.next;
+				st.next.n = 0;
+				st.rank = 0.f;
+			}
+			st.switched_term = prev_term;
+		}
+		if (st.last_counted < qp) {
+			st.terms_counter = uint16_t(st.terms_counter + 1);
+			st.last_counted = qp;
+		}
+		st.proc += r;          // :77-80 (nextTermPositions stays: the next plain term's switchToNextWord swaps it in over the phrase's)
+		st.last = pos;
+		st.rank = 0.f;
 		return;
 	}
 	if (!st.created) {   // addDoc (mergerimpl.h:160-164)
@@ -1096,8 +1052,8 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<
 	}
 }
 __device__ __forceinline__ void ft_replay_step(const FtPlan& p, FtReplayState& st, uint32_t row, float r, uint8_t fld, uint32_t i, const uint64_t* const* s_fpos,
-											   const uint32_t* const* s_pos_off, const uint16_t* s_qp) {
-	uint16_t qp = 0;
+											   const uint32_t* const* s_pos_off, const uint32_t* s_qp) {
+	uint32_t qp = 0;
 	FtPosList pos;
 	if (!p.simple) ft_replay_locate(p, row, i, s_fpos, s_pos_off, s_qp, qp, pos.ptr, pos.n);
 	ft_replay_apply(p, st, r, fld, qp, pos);
@@ -1111,7 +1067,7 @@ __device__ __forceinline__ void ft_replay_finish(const FtPlan& p, const FtReplay
 	float proc = st.proc;
 	const FtTermCfg& t0 = p.terms[0];
 	const float words = have_words ? words0 : t0.words[size_t(doc) * t0.num_fields + st.field];
-	const bool full = p.simple ? words == 1.0f : (st.terms_counter == p.nterms && words == float(p.nterms));
+	const bool full = p.simple ? words == 1.0f : (st.terms_counter == p.nterms && words == float(p.query_len));
 	if (full) proc = float(double(proc) * p.full_match_boost);
 	p.out_proc[sl] = proc;
 	p.out_field[sl] = st.field;
@@ -1119,7 +1075,7 @@ __device__ __forceinline__ void ft_replay_finish(const FtPlan& p, const FtReplay
 }
 // the document's row of the entry table, walked in sub-term order
 __device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint32_t doc, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
-											  const uint16_t* s_qp) {
+											  const uint32_t* s_qp) {
 	FtReplayState st;
 	// Most documents meet ONE sub-term, a few two or three, out of many: each lane first collects WHICH of its rows are occupied (rank
 	// loads, 64 rows per mask word) and then walks only those, in row order = the order mergeTerm met the postings.
@@ -1160,7 +1116,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 	uint32_t* s_keys = ft_finish_lds + kFtRangeDocs / 2;   // [kFtRangeDocs]
 	__shared__ const uint64_t* s_fpos[kFtReplayRows];
 	__shared__ const uint32_t* s_pos_off[kFtReplayRows];
-	__shared__ uint16_t s_qp[kFtReplayRows];
+	__shared__ uint32_t s_qp[kFtReplayRows];   // ft_row_qpw
 	__shared__ uint32_t s_nadd, s_last;
 	__shared__ uint32_t s_red[4][kFtFinishRows], s_rowbase[kFtFinishRows];
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
@@ -1183,7 +1139,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		const FtPosSubterm& s = p.subs[p.merge_grid[row].sub];
 		s_fpos[row] = s.fpos;
 		s_pos_off[row] = s.pos_off;
-		s_qp[row] = s.qp;
+		s_qp[row] = ft_row_qpw(s);
 	}
 	if (n) {
 		if (tid == 0) s_nadd = 0;
@@ -1418,7 +1374,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 				// everything the walk will read is requested first: the position ranges of all the postings are in flight together
 				float pr[kFtSparsePostings];
 				uint8_t pf[kFtSparsePostings];
-				uint16_t pq[kFtSparsePostings];
+				uint32_t pq[kFtSparsePostings];
 				const uint64_t* pp[kFtSparsePostings];
 				uint32_t pn[kFtSparsePostings];
 #pragma unroll

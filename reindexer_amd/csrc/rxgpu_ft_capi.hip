@@ -69,6 +69,9 @@ struct rxgpu_ft_index {
 	std::mutex mtx;
 	hipStream_t stream = nullptr;
 	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
+	rxgpu_devbuf d_excl;           // docsExcluded of the running merge
+	std::vector<rxgpu_devbuf> d_phrase_a, d_phrase_b;   // per phrase of a query: plan + admission slots, workspace + the packed rows
+	hipEvent_t ev_pha = nullptr, ev_phb = nullptr;      // around the phrase kernels
 	// tables every merge finds ZEROED and leaves zeroed (the kernel that reads one last clears it): pre-score histogram, look-back words of
 	// the preselect, bucket counters, synchronisation words, the occupancy (rank) plane of the entry rows.  Cleared by the host only when (re)allocated or after a failed merge.
 	rxgpu_devbuf d_clean;
@@ -181,8 +184,10 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
 		if (p) (void)hipFree(p);
 	}
-	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse}) b->release();
-	for (hipEvent_t e : {h->ev_knn, h->ev_fa, h->ev_fb, h->ev_pa, h->ev_pb}) {
+	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse, &h->d_excl}) b->release();
+	for (rxgpu_devbuf& b : h->d_phrase_a) b.release();
+	for (rxgpu_devbuf& b : h->d_phrase_b) b.release();
+	for (hipEvent_t e : {h->ev_knn, h->ev_fa, h->ev_fb, h->ev_pa, h->ev_pb, h->ev_pha, h->ev_phb}) {
 		if (e) (void)hipEventDestroy(e);
 	}
 	if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -256,6 +261,13 @@ struct QueryTermIn {
 	int32_t op;
 	const rxgpu_ft_term_opts* opts;
 	uint32_t sub_begin, sub_end;
+	int32_t phrase_num = -1;   // FtDslOpts::phraseNum: consecutive terms with the same number >= 0 are one phrase (selecterimpl.h:482-572)
+	int32_t distance = 1;      // FtDslOpts::distance (the phrase's terms)
+};
+// a query part (PhraseOrTerm, querymergedata.h:145-176): one plain term or the terms [t_begin, t_end) of one phrase
+struct QueryPartIn {
+	bool phrase;
+	uint32_t t_begin, t_end;
 };
 
 // the calculator's IDF per sub-term (bm25.h): totalDocCount = totalNumDocs - 1 ("first doc is always empty"), matchedDocCount = |postings|
@@ -279,6 +291,269 @@ struct Carver {
 		return at;
 	}
 };
+
+// FtDslOpts of a term as the kernels want it
+int check_term_opts(const QueryTermIn& qt, uint32_t nf, const char* who, bool& same, bool& all_pos) {
+	RX_CHECK(qt.opts->field_boost && qt.opts->need_sum_rank, RXGPU_ERR_PARAMS, std::string(who) + ": null term options");
+	uint32_t nsum = 0;
+	same = true;
+	all_pos = true;
+	for (uint32_t f = 0; f < nf; ++f) {
+		nsum += qt.opts->need_sum_rank[f] ? 1 : 0;
+		same = same && qt.opts->field_boost[f] == qt.opts->field_boost[0];
+		all_pos = all_pos && qt.opts->field_boost[f] != 0.0f;
+	}
+	RX_CHECK(nsum <= 8, RXGPU_ERR_PARAMS, std::string(who) + ": more than 8 fields with needSumRank (GPU engine limit)");
+	RX_CHECK(qt.sub_end - qt.sub_begin <= 4096, RXGPU_ERR_PARAMS, std::string(who) + ": more than 4096 sub-terms in one term (GPU engine limit)");
+	return RXGPU_OK;
+}
+void fill_term_cfg(rxgpu::FtTermCfg& tc, const rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const QueryTermIn& qt, bool same, bool all_pos) {
+	tc.num_fields = h->num_fields;
+	tc.bm25_type = cfg->bm25_type;
+	tc.words = h->d_words;
+	tc.avg_words = h->d_avg;
+	tc.k1 = cfg->bm25_k1;
+	tc.b = cfg->bm25_b;
+	tc.summation_ratio = cfg->summation_ranks_by_fields_ratio;
+	tc.opts_boost = qt.opts->boost;
+	tc.term_len_boost_in = qt.opts->term_len_boost;
+	tc.op = qt.op;
+	tc.same_boost = same ? 1 : 0;
+	tc.all_pos_boost = all_pos ? 1 : 0;
+}
+// the per-field FTConfig parameters as floats (bound() takes float arguments): 6 x nf
+void stage_field_cfg(float* fc, const rxgpu_ft_config* cfg, uint32_t nf) {
+	for (uint32_t f = 0; f < nf; ++f) {
+		fc[0 * nf + f] = float(cfg->bm25_boost[f]);
+		fc[1 * nf + f] = float(cfg->bm25_weight[f]);
+		fc[2 * nf + f] = float(cfg->term_len_boost[f]);
+		fc[3 * nf + f] = float(cfg->term_len_weight[f]);
+		fc[4 * nf + f] = float(cfg->position_boost[f]);
+		fc[5 * nf + f] = float(cfg->position_weight[f]);
+	}
+}
+void point_term_cfg(rxgpu::FtTermCfg& tc, const float* d_fc, const float* d_field_boost, const uint8_t* d_need_sum, uint32_t nf) {
+	tc.field_boost = d_field_boost;
+	tc.need_sum_rank = d_need_sum;
+	tc.bm25_boost = d_fc + 0 * nf;
+	tc.bm25_weight = d_fc + 1 * nf;
+	tc.term_len_boost = d_fc + 2 * nf;
+	tc.term_len_weight = d_fc + 3 * nf;
+	tc.position_boost = d_fc + 4 * nf;
+	tc.position_weight = d_fc + 5 * nf;
+}
+rxgpu::FtPosSubterm word_subterm(const rxgpu_ft_word& w, int bm25_type, uint64_t N, float proc) {
+	rxgpu::FtPosSubterm ft{};
+	ft.n = w.n;
+	ft.doc = w.doc;
+	ft.ent_off = w.ent_off;
+	ft.ent_field = w.ent_field;
+	ft.ent_tf = w.ent_tf;
+	ft.ent_first_pos = w.ent_first_pos;
+	ft.pos_off = w.pos_off;
+	ft.fpos = w.fpos;
+	ft.idf = subterm_idf(bm25_type, N, w.n);
+	ft.proc = proc;
+	ft.range_off = w.range_off;
+	ft.n_ranges = w.n_ranges;
+	return ft;
+}
+
+// One phrase through ft_phrase.hip: the rows the main merge reads instead of words
+struct PhraseRows {
+	std::vector<rxgpu::FtPosSubterm> rows;   // non-empty rows, first-term sub-term order; device arrays live in the handle's phrase buffers
+	uint32_t admitted = 0;                   // PhraseMerger::NumDocsMerged()
+	uint32_t proc16 = 0;                     // PhraseResults::CalcProc16
+	uint64_t postings = 0;                   // postings of the phrase's words (statistics)
+};
+int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<QueryTermIn>& terms, const QueryPartIn& part, const uint32_t* word_ids,
+			   const float* procs, const uint8_t* d_excluded, size_t phrase_index, PhraseRows& out, const char* who) {
+	const uint32_t nf = h->num_fields, T = part.t_end - part.t_begin;
+	const uint64_t N = h->total_docs;
+	const int bm25_type = cfg->bm25_type;
+	std::vector<rxgpu::FtPosSubterm> subs;
+	std::vector<rxgpu::FtTermCfg> tcfg(T);
+	std::vector<int32_t> distance(T);
+	std::vector<rxgpu::FtGridEntry> grid;
+	std::vector<uint32_t> row_sub;   // first term: position of the row's sub-term in the caller's list
+	uint64_t grid_blocks = 0, term0_vdocs = 0;
+	long long sum_proc = 0;
+	for (uint32_t k = 0; k < T; ++k) {
+		const QueryTermIn& qt = terms[part.t_begin + k];
+		bool same, all_pos;
+		if (int rc = check_term_opts(qt, nf, who, same, all_pos); rc) return rc;
+		fill_term_cfg(tcfg[k], h, cfg, qt, same, all_pos);
+		distance[k] = qt.distance;
+		tcfg[k].sub_begin = uint32_t(subs.size());
+		if (qt.sub_end > qt.sub_begin) sum_proc = (long long)(float(sum_proc) + procs[qt.sub_begin]);   // CalcProc16: long long += float, term by term
+		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
+			const rxgpu_ft_word& w = h->words.find(word_ids[si])->second;
+			RX_CHECK(w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
+			RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
+					 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
+			if (k == 0) term0_vdocs += w.n;
+			out.postings += w.n;
+			if (!w.n) continue;
+			rxgpu::FtPosSubterm ft = word_subterm(w, bm25_type, N, procs[si]);
+			ft.term = k;
+			ft.ord_in_term = uint16_t(si - qt.sub_begin);
+			if (k == 0) {
+				grid.push_back({uint32_t(grid_blocks), uint32_t(subs.size())});
+				grid_blocks += rxgpu::ft_pass_blocks(w.n);
+				row_sub.push_back(si);
+			}
+			subs.push_back(ft);
+		}
+		tcfg[k].sub_end = uint32_t(subs.size());
+	}
+	RX_CHECK(sum_proc >= 0 && sum_proc < 65535, RXGPU_ERR_PARAMS, std::string(who) + ": the procs of a phrase's terms add up to 65535 or more");
+	out.proc16 = uint32_t(sum_proc);
+	const uint32_t n_rows0 = uint32_t(grid.size());
+	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, term0_vdocs);   // phrasemerger.h:341
+	if (!n_rows0 || !max_merged) return RXGPU_OK;   // the first term matched nothing: no document holds the phrase
+	RX_CHECK(grid_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^32 (padded) postings in one phrase term");
+	const uint32_t n_ranges = uint32_t((N + rxgpu::kFtRangeDocs - 1) / rxgpu::kFtRangeDocs);
+	const size_t M = size_t(max_merged);
+
+	if (h->d_phrase_a.size() <= phrase_index) {
+		h->d_phrase_a.resize(phrase_index + 1);
+		h->d_phrase_b.resize(phrase_index + 1);
+	}
+	Carver ca;
+	const size_t o_subs = ca.take(subs.size() * sizeof(rxgpu::FtPosSubterm));
+	const size_t o_terms = ca.take(size_t(T) * sizeof(rxgpu::FtTermCfg));
+	const size_t o_dist = ca.take(size_t(T) * 4);
+	const size_t o_grid = ca.take(grid.size() * sizeof(rxgpu::FtGridEntry));
+	const size_t cfg_floats = size_t(6) * nf + size_t(T) * nf;
+	const size_t o_fc = ca.take(cfg_floats * 4 + size_t(T) * nf);
+	const size_t plan_bytes = ca.off;
+	const size_t o_zero = ca.off;
+	const size_t o_lb = ca.take(size_t(grid_blocks) * 8);
+	const size_t o_sync = ca.take(8 * 4);
+	const size_t zero_bytes = ca.off - o_zero;
+	const size_t o_sdoc = ca.take(M * 4), o_srow = ca.take(M * 4), o_scap = ca.take(M * 4), o_sproc = ca.take(M * 4), o_sfield = ca.take(M);
+	const size_t o_spos = ca.take(M * 8), o_snpos = ca.take(M * 4);
+	rxgpu_devbuf& da = h->d_phrase_a[phrase_index];
+	if (int rc = da.ensure(ca.off); rc) return rc;
+	char* base = static_cast<char*>(da.ptr);
+	if (int rc = h->ensure_pinned(std::max<size_t>(plan_bytes, (size_t(8) + n_rows0) * 4 + 256)); rc) return rc;
+	char* hp = static_cast<char*>(h->h_pinned);
+	std::memset(hp, 0, plan_bytes);
+	float* fc = reinterpret_cast<float*>(hp + o_fc);
+	uint8_t* need_sum = reinterpret_cast<uint8_t*>(fc + cfg_floats);
+	const float* d_fc = reinterpret_cast<const float*>(base + o_fc);
+	const uint8_t* d_need_sum = reinterpret_cast<const uint8_t*>(d_fc + cfg_floats);
+	stage_field_cfg(fc, cfg, nf);
+	for (uint32_t k = 0; k < T; ++k) {
+		const QueryTermIn& qt = terms[part.t_begin + k];
+		for (uint32_t f = 0; f < nf; ++f) {
+			fc[size_t(6 + k) * nf + f] = qt.opts->field_boost[f];
+			need_sum[size_t(k) * nf + f] = qt.opts->need_sum_rank[f];
+		}
+		point_term_cfg(tcfg[k], d_fc, d_fc + size_t(6 + k) * nf, d_need_sum + size_t(k) * nf, nf);
+	}
+	std::memcpy(hp + o_subs, subs.data(), subs.size() * sizeof(rxgpu::FtPosSubterm));
+	std::memcpy(hp + o_terms, tcfg.data(), tcfg.size() * sizeof(rxgpu::FtTermCfg));
+	std::memcpy(hp + o_dist, distance.data(), distance.size() * 4);
+	std::memcpy(hp + o_grid, grid.data(), grid.size() * sizeof(rxgpu::FtGridEntry));
+	hipStream_t st = h->stream;
+	RX_HIP(hipMemcpyAsync(base, hp, plan_bytes, hipMemcpyHostToDevice, st));
+	RX_HIP(hipMemsetAsync(base + o_zero, 0, zero_bytes, st));
+
+	rxgpu::FtPhrasePlan p{};
+	p.subs = reinterpret_cast<const rxgpu::FtPosSubterm*>(base + o_subs);
+	p.terms = reinterpret_cast<const rxgpu::FtTermCfg*>(base + o_terms);
+	p.distance = reinterpret_cast<const int32_t*>(base + o_dist);
+	p.grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_grid);
+	p.nterms = T;
+	p.n_grid = n_rows0;
+	p.grid_blocks = uint32_t(grid_blocks);
+	p.n_rows0 = n_rows0;
+	p.max_merged = uint32_t(max_merged);
+	p.n_ranges = n_ranges;
+	p.total_docs = N;
+	p.distance_weight = float(cfg->distance_weight);
+	p.distance_boost = float(cfg->distance_boost);
+	p.removed = h->d_removed;
+	p.excluded = d_excluded;
+	p.lookback = reinterpret_cast<unsigned long long*>(base + o_lb);
+	p.sync = reinterpret_cast<uint32_t*>(base + o_sync);
+	p.slot_doc = reinterpret_cast<uint32_t*>(base + o_sdoc);
+	p.slot_row = reinterpret_cast<uint32_t*>(base + o_srow);
+	p.slot_cap = reinterpret_cast<uint32_t*>(base + o_scap);
+	p.slot_proc = reinterpret_cast<float*>(base + o_sproc);
+	p.slot_field = reinterpret_cast<uint8_t*>(base + o_sfield);
+	p.slot_pos = reinterpret_cast<uint64_t*>(base + o_spos);
+	p.slot_npos = reinterpret_cast<uint32_t*>(base + o_snpos);
+	if (!h->ev_pha) {
+		RX_HIP(hipEventCreate(&h->ev_pha));
+		RX_HIP(hipEventCreate(&h->ev_phb));
+	}
+	RX_HIP(hipEventRecord(h->ev_pha, st));
+	RX_HIP(rxgpu::launch_ft_phrase_admit(p, st));
+	RX_HIP(hipMemcpyAsync(hp, p.sync, 8 * 4, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipStreamSynchronize(st));
+	const uint32_t* sy = reinterpret_cast<const uint32_t*>(hp);
+	RX_CHECK(sy[1] == 0, RXGPU_ERR_DEVICE, std::string(who) + ": ordered look-back timed out on the device (phrase admission)");
+	const uint32_t admitted = sy[2];
+	const uint64_t sum_caps = uint64_t(sy[4]) | (uint64_t(sy[5]) << 32);
+	RX_CHECK(admitted <= max_merged, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt phrase admission count");
+	RX_CHECK(sum_caps < (1ull << 31), RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^31 positions in the documents of one phrase (GPU engine limit)");
+	out.admitted = admitted;
+
+	// ---- workspace + packed rows, sized by what the admission found
+	const size_t pad = rxgpu::kFtPhraseRowPad;
+	const size_t cap_entries = size_t(admitted) + (size_t(n_rows0) + 1) * pad;
+	Carver cb;
+	const size_t o_ws = cb.take(std::max<uint64_t>(1, 2 * sum_caps) * 8);
+	const size_t o_rcnt = cb.take(size_t(n_rows0) * 4), o_rbase = cb.take(size_t(n_rows0) * 4);
+	const size_t o_odoc = cb.take(cap_entries * 4), o_orank = cb.take(cap_entries * 4), o_ofield = cb.take(cap_entries), o_opoff = cb.take(cap_entries * 4);
+	const size_t o_ofpos = cb.take(std::max<uint64_t>(1, sum_caps) * 8);
+	const size_t o_orange = cb.take(size_t(n_rows0) * (n_ranges + 1) * 4);
+	const size_t o_hdr = cb.take((size_t(4) + n_rows0) * 4);
+	rxgpu_devbuf& db = h->d_phrase_b[phrase_index];
+	if (int rc = db.ensure(cb.off); rc) return rc;
+	char* bb = static_cast<char*>(db.ptr);
+	p.ws = reinterpret_cast<uint64_t*>(bb + o_ws);
+	p.row_cnt = reinterpret_cast<uint32_t*>(bb + o_rcnt);
+	p.row_base = reinterpret_cast<uint32_t*>(bb + o_rbase);
+	p.out_doc = reinterpret_cast<uint32_t*>(bb + o_odoc);
+	p.out_rank = reinterpret_cast<float*>(bb + o_orank);
+	p.out_field = reinterpret_cast<uint8_t*>(bb + o_ofield);
+	p.out_pos_off = reinterpret_cast<uint32_t*>(bb + o_opoff);
+	p.out_fpos = reinterpret_cast<uint64_t*>(bb + o_ofpos);
+	p.out_range_off = reinterpret_cast<uint32_t*>(bb + o_orange);
+	p.out_header = reinterpret_cast<uint32_t*>(bb + o_hdr);
+	RX_HIP(rxgpu::launch_ft_phrase_docs(p, admitted, st));
+	RX_HIP(rxgpu::launch_ft_phrase_pack(p, st));
+	RX_HIP(hipEventRecord(h->ev_phb, st));
+	RX_HIP(hipMemcpyAsync(hp, p.out_header, (size_t(4) + n_rows0) * 4, hipMemcpyDeviceToHost, st));
+	RX_HIP(hipStreamSynchronize(st));
+	float ms = 0.f;
+	if (hipEventElapsedTime(&ms, h->ev_pha, h->ev_phb) == hipSuccess) h->stat_ms += ms;
+	const uint32_t* hdr = reinterpret_cast<const uint32_t*>(hp);
+	RX_CHECK(hdr[0] == admitted && hdr[2] <= admitted, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt phrase header");
+	size_t row_base = 0;
+	for (uint32_t r = 0; r < n_rows0; ++r) {
+		const uint32_t cnt = hdr[4 + r];
+		if (cnt) {
+			rxgpu::FtPosSubterm row{};
+			row.n = cnt;
+			row.doc = p.out_doc + row_base;
+			row.pos_off = p.out_pos_off + row_base;
+			row.fpos = p.out_fpos;
+			row.pre_rank = p.out_rank + row_base;
+			row.pre_field = p.out_field + row_base;
+			row.proc = procs[row_sub[r]];
+			row.range_off = p.out_range_off + size_t(r) * (n_ranges + 1);
+			row.n_ranges = n_ranges;
+			row.phrase = 1;
+			out.rows.push_back(row);
+		}
+		row_base += (size_t(cnt) + 1 + pad - 1) / pad * pad;
+	}
+	return RXGPU_OK;
+}
 
 // A resident merge was enqueued and nobody looked at its header yet: wait for it, check the look-back word, settle the kept-clean state.
 int finish_pending(rxgpu_ft_index* h, const char* who) {
@@ -308,15 +583,29 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const int bm25_type = cfg->bm25_type;
 	RX_CHECK(bm25_type >= 0 && bm25_type <= 2, RXGPU_ERR_PARAMS, std::string(who) + ": bm25_type must be 0 (rx), 1 (classic) or 2 (wordCount)");
 
-	// ---- the plan: sub-terms, per-term configuration, the two posting-side grids
+	// ---- the query parts (selecterimpl.h:482-572): consecutive terms with the same phraseNum >= 0 are one phrase
+	std::vector<QueryPartIn> parts;
+	for (uint32_t t = 0; t < nterms;) {
+		if (terms[t].phrase_num < 0) {
+			parts.push_back({false, t, t + 1});
+			++t;
+			continue;
+		}
+		uint32_t e = t + 1;
+		while (e < nterms && terms[e].phrase_num == terms[t].phrase_num) ++e;
+		parts.push_back({true, t, e});
+		t = e;
+	}
+	const uint32_t nparts = uint32_t(parts.size());
+	RX_CHECK(nparts < 0x7FFF, RXGPU_ERR_PARAMS, std::string(who) + ": too many query parts");
+	RX_CHECK(!simple || (nparts == 1 && !parts[0].phrase), RXGPU_ERR_LOGIC, std::string(who) + ": a phrase is not a Simple() query");
+
+	// ---- the plan: sub-terms, per-part configuration, the posting-side grid
 	std::vector<rxgpu::FtPosSubterm> subs;
-	std::vector<rxgpu::FtTermCfg> tcfg(nterms);
+	std::vector<rxgpu::FtTermCfg> tcfg(nparts);
 	std::vector<rxgpu::FtGridEntry> merge_grid;
 	std::vector<uint64_t> term_postings(nterms, 0);
 	uint64_t total_vids = 0, merged_postings = 0, merge_blocks = 0;
-	uint16_t qp = 0;
-	// 2-phase gate, host half (estimateNumDocsInMerge, merger.h:239-267; mergerimpl.h:486-490)
-	uint64_t est_or = 0, est_and = UINT64_MAX;
 	for (uint32_t t = 0; t < nterms; ++t) {
 		const QueryTermIn& qt = terms[t];
 		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
@@ -328,71 +617,93 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 					 std::string(who) + ": a posting list holds a document id >= total_docs (rxgpu_ft_set_docs)");
 			term_postings[t] += it->second.n;
 		}
-		total_vids += term_postings[t];   // totalORVids: MaxVDocs of every term, whatever its operator (selecterimpl.h:546)
-		if (qt.op == 3) continue;
-		if (qt.op == 2) {
-			est_and = std::min(est_and, term_postings[t]);
-		} else {
-			est_or += term_postings[t];
-		}
+		total_vids += term_postings[t];   // totalORVids: MaxVDocs of every term, whatever its operator and inside phrases too (selecterimpl.h:546)
 	}
 	RX_CHECK(total_vids < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^32 postings in one merge");
 	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, total_vids);   // Merge(): min(mergeLimit, totalORVids)
 	if (max_merged == 0) return RXGPU_OK;
 	RX_CHECK(resident || (cap >= max_merged && out_doc && out_proc && out_field && (simple || out_terms_counter)), RXGPU_ERR_OVERFLOW,
 			 std::string(who) + ": output buffers too small");
+
+	hipStream_t st = h->stream;
+	const uint8_t* d_excluded = nullptr;
+	if (excluded) {
+		if (int rc = h->d_excl.ensure(N); rc) return rc;
+		RX_HIP(hipMemcpyAsync(h->d_excl.ptr, excluded, N, hipMemcpyHostToDevice, st));
+		d_excluded = static_cast<const uint8_t*>(h->d_excl.ptr);
+	}
+	// ---- phrases first (Merger::init, merger.h:73-81): every PhraseMerger runs before the query parts are looked at
+	std::vector<PhraseRows> phrase_rows(nparts);
+	size_t n_phrases = 0;
+	for (uint32_t pi = 0; pi < nparts; ++pi) {
+		if (!parts[pi].phrase) continue;
+		if (int rc = run_phrase(h, cfg, terms, parts[pi], word_ids, procs, d_excluded, n_phrases++, phrase_rows[pi], who); rc) return rc;
+	}
+
+	// 2-phase gate, host half (estimateNumDocsInMerge, merger.h:239-267; mergerimpl.h:486-490)
+	uint64_t est_or = 0, est_and = UINT64_MAX;
+	uint32_t query_len = 0;
+	for (uint32_t pi = 0; pi < nparts; ++pi) {
+		const QueryPartIn& part = parts[pi];
+		query_len += part.t_end - part.t_begin;
+		const int32_t op = terms[part.t_begin].op;   // PhraseResults::Op(): its first term's
+		if (op == 3) continue;
+		const uint64_t num_docs = part.phrase ? phrase_rows[pi].admitted : term_postings[part.t_begin];
+		if (op == 2) {
+			est_and = std::min(est_and, num_docs);
+		} else {
+			est_or += num_docs;
+		}
+	}
 	const bool prescore = !simple && std::min(std::min(est_or, est_and), N) > cfg->merge_limit && N > cfg->merge_limit;
 
-	for (uint32_t t = 0; t < nterms; ++t) {
-		const QueryTermIn& qt = terms[t];
-		RX_CHECK(qt.opts->field_boost && qt.opts->need_sum_rank, RXGPU_ERR_PARAMS, std::string(who) + ": null term options");
-		uint32_t nsum = 0;
-		bool same = true, all_pos = true;
-		for (uint32_t f = 0; f < nf; ++f) {
-			nsum += qt.opts->need_sum_rank[f] ? 1 : 0;
-			same = same && qt.opts->field_boost[f] == qt.opts->field_boost[0];
-			all_pos = all_pos && qt.opts->field_boost[f] != 0.0f;
+	uint16_t qp = 0, last_term_qp = 0;
+	for (uint32_t pi = 0; pi < nparts; ++pi) {
+		const QueryPartIn& part = parts[pi];
+		const QueryTermIn& qt = terms[part.t_begin];
+		rxgpu::FtTermCfg& tc = tcfg[pi];
+		if (part.phrase) {
+			// the phrase as one part: its rows carry rank and field, every document counts for the masks, the pre-score adds CalcProc16
+			fill_term_cfg(tc, h, cfg, qt, true, true);
+			tc.opts_boost = 1.0f;
+			tc.phrase = 1;
+			tc.phrase_proc16 = phrase_rows[pi].proc16;
+			tc.sub_begin = uint32_t(subs.size());
+			if (qt.op != 3) ++qp;
+			for (rxgpu::FtPosSubterm ft : phrase_rows[pi].rows) {
+				ft.term = pi;
+				ft.qp = qt.op == 3 ? 0 : qp;
+				ft.prev_term_qp = last_term_qp;
+				ft.ord_in_term = uint16_t(subs.size() - tc.sub_begin);
+				const uint32_t sub_index = uint32_t(subs.size());
+				if (qt.op != 3) {
+					ft.row = uint32_t(merge_grid.size());
+					merge_grid.push_back({uint32_t(merge_blocks), sub_index});
+					merge_blocks += rxgpu::ft_pass_blocks(ft.n);
+					merged_postings += ft.n;
+				}
+				subs.push_back(ft);
+			}
+			tc.sub_end = uint32_t(subs.size());
+			h->stat_postings += phrase_rows[pi].postings;
+			continue;
 		}
-		RX_CHECK(nsum <= 8, RXGPU_ERR_PARAMS, std::string(who) + ": more than 8 fields with needSumRank (GPU engine limit)");
-		RX_CHECK(qt.sub_end - qt.sub_begin <= 4096, RXGPU_ERR_PARAMS, std::string(who) + ": more than 4096 sub-terms in one term (GPU engine limit)");
-		rxgpu::FtTermCfg& tc = tcfg[t];
-		tc.num_fields = nf;
-		tc.bm25_type = bm25_type;
-		tc.words = h->d_words;
-		tc.avg_words = h->d_avg;
-		tc.k1 = cfg->bm25_k1;
-		tc.b = cfg->bm25_b;
-		tc.summation_ratio = cfg->summation_ranks_by_fields_ratio;
-		tc.opts_boost = qt.opts->boost;
-		tc.term_len_boost_in = qt.opts->term_len_boost;
-		tc.op = qt.op;
-		tc.same_boost = same ? 1 : 0;
-		tc.all_pos_boost = all_pos ? 1 : 0;
+		bool same, all_pos;
+		if (int rc = check_term_opts(qt, nf, who, same, all_pos); rc) return rc;
+		fill_term_cfg(tc, h, cfg, qt, same, all_pos);
 		tc.sub_begin = uint32_t(subs.size());
-		if (qt.op != 3) ++qp;
+		if (qt.op != 3) last_term_qp = ++qp;
 		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
 			const rxgpu_ft_word& w = h->words.find(word_ids[si])->second;
 			RX_CHECK(simple || w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
 			RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
 					 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
 			if (!w.n) continue;
-			rxgpu::FtPosSubterm ft{};
-			ft.n = w.n;
-			ft.doc = w.doc;
-			ft.ent_off = w.ent_off;
-			ft.ent_field = w.ent_field;
-			ft.ent_tf = w.ent_tf;
-			ft.ent_first_pos = w.ent_first_pos;
-			ft.pos_off = w.pos_off;
-			ft.fpos = w.fpos;
-			ft.idf = subterm_idf(bm25_type, N, w.n);
-			ft.proc = procs[si];
-			ft.term = t;
+			rxgpu::FtPosSubterm ft = word_subterm(w, bm25_type, N, procs[si]);
+			ft.term = pi;
 			ft.qp = qt.op == 3 ? 0 : qp;
 			ft.ord_in_term = uint16_t(si - qt.sub_begin);
 			ft.row = 0;
-			ft.range_off = w.range_off;
-			ft.n_ranges = w.n_ranges;
 			const uint32_t blocks = rxgpu::ft_pass_blocks(w.n);
 			const uint32_t sub_index = uint32_t(subs.size());
 			if (qt.op != 3) {
@@ -417,10 +728,10 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	// ---- device scratch (one buffer each for the state and for the packed result)
 	Carver cv;
 	const size_t o_plan_subs = cv.take(std::max<size_t>(1, subs.size()) * sizeof(rxgpu::FtPosSubterm));
-	const size_t o_plan_terms = cv.take(size_t(nterms) * sizeof(rxgpu::FtTermCfg));
+	const size_t o_plan_terms = cv.take(size_t(nparts) * sizeof(rxgpu::FtTermCfg));
 	const size_t o_plan_mgrid = cv.take(std::max<size_t>(1, merge_grid.size()) * sizeof(rxgpu::FtGridEntry));
-	const size_t cfg_floats = size_t(6) * nf + size_t(nterms) * nf;
-	const size_t o_plan_fc = cv.take(cfg_floats * sizeof(float) + size_t(nterms) * nf);
+	const size_t cfg_floats = size_t(6) * nf + size_t(nparts) * nf;
+	const size_t o_plan_fc = cv.take(cfg_floats * sizeof(float) + size_t(nparts) * nf);
 	const size_t plan_bytes = cv.off;   // everything above is uploaded in one copy
 	const size_t o_mask = cv.take(nwords * 4);
 	const size_t o_score = cv.take(prescore ? nwords * 32 * 2 : 0);   // padded to whole mask words (ft_preselect_apply reads 32 scores at a time)
@@ -430,7 +741,6 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t o_adders = cv.take(std::max<size_t>(1, size_t(n_rows) * n_ranges) * 4);
 	const size_t o_eidx = cv.take(size_t(n_rows) * M * 4);
 	const size_t o_efield = cv.take(size_t(n_rows) * M);
-	const size_t o_excl = cv.take(excluded ? N : 0);
 	if (int rc = h->d_state.ensure(cv.off); rc) return rc;
 	char* base = static_cast<char*>(h->d_state.ptr);
 	// the kept-clean tables: sized by the corpus only, so that they stay where they are from merge to merge
@@ -459,34 +769,19 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const float* d_fc = reinterpret_cast<const float*>(base + o_plan_fc);
 	const uint8_t* d_need_sum = reinterpret_cast<const uint8_t*>(d_fc + cfg_floats);
 	uint8_t* need_sum = reinterpret_cast<uint8_t*>(fc + cfg_floats);
-	for (uint32_t f = 0; f < nf; ++f) {   // per-field parameters as floats (bound() takes float arguments)
-		fc[0 * nf + f] = float(cfg->bm25_boost[f]);
-		fc[1 * nf + f] = float(cfg->bm25_weight[f]);
-		fc[2 * nf + f] = float(cfg->term_len_boost[f]);
-		fc[3 * nf + f] = float(cfg->term_len_weight[f]);
-		fc[4 * nf + f] = float(cfg->position_boost[f]);
-		fc[5 * nf + f] = float(cfg->position_weight[f]);
-	}
-	for (uint32_t t = 0; t < nterms; ++t) {
-		for (uint32_t f = 0; f < nf; ++f) {
-			fc[size_t(6 + t) * nf + f] = terms[t].opts->field_boost[f];
-			need_sum[size_t(t) * nf + f] = terms[t].opts->need_sum_rank[f];
+	stage_field_cfg(fc, cfg, nf);
+	for (uint32_t pi = 0; pi < nparts; ++pi) {
+		const QueryTermIn& qt = terms[parts[pi].t_begin];
+		for (uint32_t f = 0; f < nf; ++f) {   // a phrase part: ones (its rows are ranked already; ft_ranges reads field_boost[0] > 0)
+			fc[size_t(6 + pi) * nf + f] = parts[pi].phrase ? 1.0f : qt.opts->field_boost[f];
+			need_sum[size_t(pi) * nf + f] = parts[pi].phrase ? uint8_t(0) : qt.opts->need_sum_rank[f];
 		}
-		rxgpu::FtTermCfg& tc = tcfg[t];
-		tc.field_boost = d_fc + size_t(6 + t) * nf;
-		tc.need_sum_rank = d_need_sum + size_t(t) * nf;
-		tc.bm25_boost = d_fc + 0 * nf;
-		tc.bm25_weight = d_fc + 1 * nf;
-		tc.term_len_boost = d_fc + 2 * nf;
-		tc.term_len_weight = d_fc + 3 * nf;
-		tc.position_boost = d_fc + 4 * nf;
-		tc.position_weight = d_fc + 5 * nf;
+		point_term_cfg(tcfg[pi], d_fc, d_fc + size_t(6 + pi) * nf, d_need_sum + size_t(pi) * nf, nf);
 	}
 	if (!subs.empty()) std::memcpy(hp + o_plan_subs, subs.data(), subs.size() * sizeof(rxgpu::FtPosSubterm));
 	std::memcpy(hp + o_plan_terms, tcfg.data(), tcfg.size() * sizeof(rxgpu::FtTermCfg));
 	if (!merge_grid.empty()) std::memcpy(hp + o_plan_mgrid, merge_grid.data(), merge_grid.size() * sizeof(rxgpu::FtGridEntry));
 
-	hipStream_t st = h->stream;
 	if (h->clean_dirty) {
 		RX_HIP(hipMemsetAsync(cbase, 0, h->d_clean.bytes, st));
 		h->clean_dirty = false;
@@ -494,7 +789,6 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	void* hp_dev = nullptr;   // the pinned staging buffer as the device sees it
 	RX_HIP(hipHostGetDevicePointer(&hp_dev, hp, 0));
 	RX_HIP(rxgpu::launch_ft_import(hp_dev, base, plan_bytes, st));   // plan_bytes is a multiple of 256
-	if (excluded) RX_HIP(hipMemcpyAsync(base + o_excl, excluded, N, hipMemcpyHostToDevice, st));
 
 	rxgpu::FtPlan p{};
 	p.subs = reinterpret_cast<const rxgpu::FtPosSubterm*>(base + o_plan_subs);
@@ -502,7 +796,8 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.merge_grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_plan_mgrid);
 	p.n_merge_entries = uint32_t(merge_grid.size());
 	p.merge_blocks = uint32_t(merge_blocks);
-	p.nterms = nterms;
+	p.nterms = nparts;
+	p.query_len = query_len;
 	p.n_rows = n_rows;
 	p.n_subs = uint32_t(subs.size());
 	p.total_docs = N;
@@ -516,7 +811,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.distance_boost = float(cfg->distance_boost);
 	p.full_match_boost = cfg->full_match_boost;
 	p.removed = h->d_removed;
-	p.excluded = excluded ? reinterpret_cast<const uint8_t*>(base + o_excl) : nullptr;
+	p.excluded = d_excluded;
 	p.mask = reinterpret_cast<uint32_t*>(base + o_mask);
 	p.score = prescore ? reinterpret_cast<uint16_t*>(base + o_score) : nullptr;
 	p.hist = prescore ? reinterpret_cast<uint32_t*>(cbase + o_hist) : nullptr;
@@ -907,6 +1202,70 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	for (uint32_t t = 0; t < nterms; ++t) terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1]};
 	return run_merge(h, cfg, false, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected,
 					 "rxgpu_ft_merge_terms_raw");
+}
+
+namespace {
+// the checks shared by rxgpu_ft_merge_query_raw / _resident; *empty: QueryMergeData::Empty() (querymergedata.h:208)
+int query_terms(const char* who, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts, const int32_t* phrase_num, const int32_t* distance,
+				const uint32_t* sub_off, const uint32_t* word_ids, const float* procs, std::vector<QueryTermIn>& terms, bool* empty, bool* simple) {
+	*empty = true;
+	*simple = false;
+	if (nterms == 0) return RXGPU_OK;
+	RX_CHECK(ops && opts && sub_off, RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	RX_CHECK(nterms < 0x7FFF, RXGPU_ERR_PARAMS, std::string(who) + ": too many terms");
+	RX_CHECK(sub_off[nterms] == 0 || (word_ids && procs), RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	terms.resize(nterms);
+	uint32_t nparts = 0;
+	for (uint32_t t = 0; t < nterms; ++t) {
+		RX_CHECK(ops[t] >= 1 && ops[t] <= 3, RXGPU_ERR_PARAMS, std::string(who) + ": op must be 1 (OR), 2 (AND) or 3 (NOT)");
+		terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1], phrase_num ? phrase_num[t] : -1, distance ? distance[t] : 1};
+		if (terms[t].phrase_num < 0 || t == 0 || terms[t - 1].phrase_num != terms[t].phrase_num) ++nparts;
+	}
+	*empty = nparts == 1 && ops[0] == 3;
+	*simple = nparts == 1 && ops[0] != 3 && terms[0].phrase_num < 0;
+	return RXGPU_OK;
+}
+}  // namespace
+
+int rxgpu_ft_merge_query_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
+							 const int32_t* phrase_num, const int32_t* distance, const uint32_t* sub_off, const uint32_t* word_ids, const float* procs,
+							 const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap,
+							 uint64_t* out_n, int32_t* out_preselected) {
+	const char* who = "rxgpu_ft_merge_query_raw";
+	RX_CHECK(h && cfg && out_n, RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	*out_n = 0;
+	if (out_preselected) *out_preselected = 0;
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, std::string(who) + ": field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
+	std::vector<QueryTermIn> terms;
+	bool empty = false, simple = false;
+	if (int rc = query_terms(who, nterms, ops, opts, phrase_num, distance, sub_off, word_ids, procs, terms, &empty, &simple); rc) return rc;
+	if (empty) return RXGPU_OK;
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	return run_merge(h, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who);
+}
+
+int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
+								  const int32_t* phrase_num, const int32_t* distance, const uint32_t* sub_off, const uint32_t* word_ids, const float* procs,
+								  const uint8_t* excluded, int32_t* out_enqueued) {
+	const char* who = "rxgpu_ft_merge_query_resident";
+	RX_CHECK(h && cfg && out_enqueued, RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	*out_enqueued = 0;
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, std::string(who) + ": field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
+	std::vector<QueryTermIn> terms;
+	bool empty = false, simple = false;
+	if (int rc = query_terms(who, nterms, ops, opts, phrase_num, distance, sub_off, word_ids, procs, terms, &empty, &simple); rc) return rc;
+	std::lock_guard<std::mutex> lk(h->mtx);
+	DevGuard dg(h->device);
+	h->res_cap = 0;
+	h->prep_done = false;
+	if (empty) return finish_pending(h, who);   // nothing is merged: the fusion sees an empty FT side
+	uint64_t n = 0;
+	if (int rc = run_merge(h, cfg, simple, terms, word_ids, procs, excluded, nullptr, nullptr, nullptr, nullptr, 0, &n, nullptr, who, true); rc) return rc;
+	*out_enqueued = h->res_pending ? 1 : 0;
+	return RXGPU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------- hybrid: merges that stay in HBM + the fusion

@@ -145,7 +145,15 @@ struct FtPosSubterm {
 	uint32_t row;              // row of the per-slot entry table = index among the merged (non-NOT, non-empty) sub-terms
 	const uint32_t* range_off; // [n_ranges + 1]: first posting with doc >= k * kFtRangeDocs (built when the word is uploaded)
 	uint32_t n_ranges;
+	// A row of a merged PHRASE (ft_phrase.hip): the documents one sub-term of the phrase's first term added to the PhraseMerger, with their
+	// phrase rank / field (what mergePhrase reads, mergerimpl.h:39-90) instead of entries; fpos = lastPhrasePositions.  Null for a word.
+	const float* pre_rank;
+	const uint8_t* pre_field;
+	uint16_t prev_term_qp;     // phrase row: qp of the last plain term in front of the phrase (0: none) — the last switchToNextWord before it
+	uint16_t phrase;           // 1: phrase row
 };
+// (qp, phrase flag, prev_term_qp) of a row as the replay carries it
+__host__ __device__ inline uint32_t ft_row_qpw(const FtPosSubterm& s) { return uint32_t(s.qp) | (uint32_t(s.phrase) << 15) | (uint32_t(s.prev_term_qp) << 16); }
 struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslOpts of ONE query term
 	uint32_t num_fields;
 	int32_t bm25_type;         // kFtBm25Rx / Classic / WordCount (ft_rank.hip.h)
@@ -160,6 +168,9 @@ struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslO
 	uint32_t sub_begin, sub_end; // the term's (non-empty) sub-terms in FtPlan::subs, in SortSubterms order
 	uint8_t same_boost;        // every field has the same boost (calcTermScores' shortcut)
 	uint8_t all_pos_boost;     // every field has a non-zero boost (calcTermBitmask's shortcut)
+	uint8_t phrase;            // the part is a phrase: its sub-terms are the rows ft_phrase.hip produced; field_boost = ones
+	uint8_t pad0;
+	uint32_t phrase_proc16;    // PhraseResults::CalcProc16 (querymergedata.h:117-127): what GetMergedDocsScore adds (phrasemerger.h:326-333)
 };
 struct FtGridEntry {           // block range of one sub-term in a posting-side grid (blocks of kFtBlockPostings postings)
 	uint32_t block_base;
@@ -176,7 +187,8 @@ struct FtPlan {
 	const FtTermCfg* terms;
 	const FtGridEntry* merge_grid;   // merged sub-terms in (term, sub-term) order
 	uint32_t n_merge_entries, merge_blocks;
-	uint32_t nterms, n_rows, n_subs;
+	uint32_t nterms, n_rows, n_subs;   // nterms = queryParts.size() (a phrase is one part)
+	uint32_t query_len;                // QueryMergeData::QueryLength(): the terms inside phrases counted one by one (addFullMatchBoost)
 	uint64_t total_docs, nwords;
 	uint32_t max_merged, merge_limit;
 	uint8_t simple;            // Merger::mergeSimple (one term): max over sub-terms, first maximum wins; no positions
@@ -219,6 +231,47 @@ constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
 hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);
+
+// PhraseMerger::Merge (phrasemergerimpl.h:161-329) for ONE phrase, ft_phrase.hip.  Three launches: admission over the first term's
+// postings (ordered prefix = mergeData_ order), one thread per admitted document through the terms, packing of the documents with a
+// non-zero rank into one posting list per sub-term of the first term (the rows the main merge then treats like words).
+struct FtPhrasePlan {
+	const FtPosSubterm* subs;      // the sub-terms of the phrase's terms, term after term, SortSubterms order
+	const FtTermCfg* terms;        // [nterms]: calcTermRank configuration, sub_begin / sub_end into subs
+	const int32_t* distance;       // [nterms] FtDslOpts::distance of the term (MergeWithDist's dist)
+	const FtGridEntry* grid;       // the first term's sub-terms in blocks of kFtBlockPostings postings
+	uint32_t nterms, n_grid, grid_blocks, n_rows0;   // n_rows0: sub-terms of the first term
+	uint32_t max_merged;           // min(mergeLimit, Term(0).MaxVDocs()) (phrasemerger.h:341-342)
+	uint32_t n_ranges;
+	uint64_t total_docs;
+	float distance_weight, distance_boost;
+	const uint8_t* removed;
+	const uint8_t* excluded;
+	unsigned long long* lookback;  // [grid_blocks], zero
+	uint32_t* sync;                // [8], zero: 0 ticket, 1 error, 2 admitted, 3 alive, 4-5 sum of caps (u64), 6-7 workspace top (u64)
+	uint32_t* slot_doc;            // [max_merged] per admitted document, mergeData_ order
+	uint32_t* slot_row;            // sub-term of the first term that added it
+	uint32_t* slot_cap;            // positions the document can carry from one term to the next
+	float* slot_proc;
+	uint8_t* slot_field;
+	uint64_t* slot_pos;            // offset of lastPhrasePositions in the workspace
+	uint32_t* slot_npos;
+	uint64_t* ws;                  // position workspace (2 x sum of caps)
+	// packed rows: row r = [row_base[r], row_base[r] + row_cnt[r]) of the arrays below; pos_off holds row_cnt + 1 entries per row
+	uint32_t* row_cnt;             // [n_rows0]
+	uint32_t* row_base;            // [n_rows0]
+	uint32_t* out_doc;
+	float* out_rank;
+	uint8_t* out_field;
+	uint32_t* out_pos_off;
+	uint64_t* out_fpos;
+	uint32_t* out_range_off;       // [n_rows0][n_ranges + 1]
+	uint32_t* out_header;          // [4 + n_rows0] (pinned, device view): admitted, error, alive, positions, then row_cnt
+};
+constexpr uint32_t kFtPhraseRowPad = 64;   // entries: every packed row starts on a 256-byte boundary
+hipError_t launch_ft_phrase_admit(const FtPhrasePlan& p, hipStream_t st);
+hipError_t launch_ft_phrase_docs(const FtPhrasePlan& p, uint32_t admitted, hipStream_t st);
+hipError_t launch_ft_phrase_pack(const FtPhrasePlan& p, hipStream_t st);
 hipError_t launch_ft_export(const FtPlan& plan, hipStream_t st);
 hipError_t launch_ft_import(const void* host_plan_device_view, void* dev_plan, size_t bytes, hipStream_t st);
 // ft_packed.hip: PackedIdRelVec streams -> flat posting arrays, one thread per word (counting pass, then writing pass)

@@ -305,6 +305,7 @@ bool GpuFtMerger::MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm>
 	for (const QueryTerm& t : terms) subs += t.subterms.size();
 	if (subs == 0) return false;
 	if (terms.size() == 1 && terms[0].subterms.empty()) return false;
+	if (terms.front().phraseNum >= 0 && terms.front().op == OpType::Not && terms.front().phraseNum == terms.back().phraseNum) return false;   // one NOT phrase: Empty()
 	(void)mergeQueryImpl(cfg, std::move(terms), docsExcluded, RankSortType::RankAndID, nullptr, true);
 	return true;
 }
@@ -347,7 +348,7 @@ HybridFused GpuFtMerger::FuseResident(const FtConfig& cfg, const HybridFuseParam
 
 MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 									  bool* preselected, bool resident) const {
-	if (terms.size() == 1 && terms[0].op != OpType::Not && totalDocs_ != 0) {   // Simple(): timed by Merge
+	if (terms.size() == 1 && terms[0].op != OpType::Not && terms[0].phraseNum < 0 && totalDocs_ != 0) {   // Simple(): timed by Merge
 		if (preselected) *preselected = false;
 		return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);
 	}
@@ -356,7 +357,9 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 	MergeData out;
 	// QueryMergeData::Empty() (querymergedata.h:208) / mergerimpl.h:472-474
 	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return out;
-	if (terms.size() == 1) return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);   // Simple()
+	bool anyPhrase = false;
+	for (const QueryTerm& t : terms) anyPhrase = anyPhrase || t.phraseNum >= 0;
+	if (terms.size() == 1 && !anyPhrase) return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);   // Simple()
 	if (cfg.fieldsCfg.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
 
 	const size_t nt = terms.size();
@@ -387,7 +390,7 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 	c.distance_boost = cfg.distanceBoost;
 	c.distance_weight = cfg.distanceWeight;
 
-	std::vector<int32_t> ops(nt);
+	std::vector<int32_t> ops(nt), phraseNum(nt), distance(nt);
 	std::vector<float> fieldBoost(nt * numFields_);
 	std::vector<uint8_t> needSum(nt * numFields_);
 	std::vector<rxgpu_ft_term_opts> opts(nt);
@@ -397,6 +400,8 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 		QueryTerm& qt = terms[t];
 		if (qt.opts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
 		ops[t] = int32_t(qt.op);
+		phraseNum[t] = qt.phraseNum;
+		distance[t] = qt.distance;
 		for (size_t f = 0; f < numFields_; ++f) {
 			fieldBoost[t * numFields_ + f] = qt.opts.fieldsOpts[f].boost;
 			needSum[t * numFields_ + f] = qt.opts.fieldsOpts[f].needSumRank ? 1 : 0;
@@ -409,6 +414,14 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 			procs.push_back(sr.proc);
 		}
 		subOff[t + 1] = uint32_t(wordIds.size());
+	}
+	if (resident && anyPhrase) {
+		int32_t enqueued = 0;
+		if (rxgpu_ft_merge_query_resident(dev_, &c, uint32_t(nt), ops.data(), opts.data(), phraseNum.data(), distance.data(), subOff.data(), wordIds.data(),
+										  procs.data(), docsExcluded, &enqueued) != RXGPU_OK) {
+			throwDevice("MergeQueryResident");
+		}
+		return out;
 	}
 	if (resident) {
 		if (rxgpu_ft_merge_terms_resident(dev_, &c, uint32_t(nt), ops.data(), opts.data(), subOff.data(), wordIds.data(), procs.data(), docsExcluded) !=
@@ -424,10 +437,12 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 	std::vector<uint16_t> termsCounter(cap);
 	uint64_t n = 0;
 	int32_t pre = 0;
-	if (rxgpu_ft_merge_terms_raw(dev_, &c, uint32_t(nt), ops.data(), opts.data(), subOff.data(), wordIds.data(), procs.data(), docsExcluded, doc.data(),
-								 proc.data(), field.data(), termsCounter.data(), cap, &n, &pre) != RXGPU_OK) {
-		throwDevice("MergeQuery");
-	}
+	const int rc = anyPhrase ? rxgpu_ft_merge_query_raw(dev_, &c, uint32_t(nt), ops.data(), opts.data(), phraseNum.data(), distance.data(), subOff.data(),
+														wordIds.data(), procs.data(), docsExcluded, doc.data(), proc.data(), field.data(),
+														termsCounter.data(), cap, &n, &pre)
+							 : rxgpu_ft_merge_terms_raw(dev_, &c, uint32_t(nt), ops.data(), opts.data(), subOff.data(), wordIds.data(), procs.data(), docsExcluded,
+														doc.data(), proc.data(), field.data(), termsCounter.data(), cap, &n, &pre);
+	if (rc != RXGPU_OK) throwDevice("MergeQuery");
 	if (preselected) *preselected = pre != 0;
 	out.resize(n);
 	// canBeBoostedByFullMatch / addFullMatchBoost(QueryLength) (mergerimpl.h:527-531, merger.h:100-109) were applied on the device (ft_replay)

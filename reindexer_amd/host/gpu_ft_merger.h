@@ -8,7 +8,9 @@
 // Host:   the O(mergeLimit) tail of the merger — addFullMatchBoost (merger.h:100-109) and postProcessResults (:111-155).
 // Multi-term queries (AND / OR / NOT terms: restricting bitmask, preselect, mergeTerm with position distances,
 // mergerimpl.h:107-192, 252-464) go through MergeQuery (ft_merge.hip via rxgpu_ft_merge_terms_raw).
-// Phrases and multi-word synonyms stay on the reference's CPU merger; Supports() tells the caller which way to go.
+// Phrases run through PhraseMerger::Merge on the device first (ft_phrase.hip via rxgpu_ft_merge_query_raw) and join the merge as query parts
+// (mergePhrase, mergerimpl.h:39-90).  Multi-word synonyms and MergeDataAreas (highlight / snippet) stay on the reference's CPU merger;
+// Supports() tells the caller which way to go.
 #pragma once
 
 #include <cstdint>
@@ -100,6 +102,10 @@ struct QueryTerm {
 	OpType op = OpType::Or;
 	FtDslOpts opts;
 	std::vector<SubtermRef> subterms;
+	// FtDslOpts::phraseNum / distance (ftdsl.h:13-35): consecutive terms with the same phraseNum >= 0 are one phrase (PhraseResults,
+	// querymergedata.h:100-142; built in selecterimpl.h:482-572), merged by PhraseMerger on the device (ft_phrase.hip)
+	int phraseNum = -1;
+	int distance = 1;
 };
 
 // The hybrid rank fusion on the device (hybrid_fuse.hip): reranker + join type, as MergerRankedImpl gets them (selectiteratorcontainer.cc:1305-1341)
@@ -139,7 +145,10 @@ public:
 	// reads a word's device arrays back (tests, diagnostics)
 	void GetWord(uint32_t wordId, PositionPostings& positions, FlatPostings& entries, std::vector<uint32_t>& rangeOff) const;
 
-	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept { return numQueryParts >= 1 && !hasPhrases && !hasSynonyms; }
+	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept {
+		(void)hasPhrases;   // PhraseMerger runs on the device
+		return numQueryParts >= 1 && !hasSynonyms;
+	}
 	static bool Supports(const FtConfig& cfg, size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept {
 		(void)cfg;   // every Bm25Type is evaluated on the device
 		return Supports(numQueryParts, hasPhrases, hasSynonyms);
@@ -149,7 +158,7 @@ public:
 	MergeData Merge(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 					RankSortType rankSortType) const;
 
-	// Merger::Merge<Bm25T> for any query made of terms (queryParts without phrases, no synonyms); one OR/AND term -> Merge()
+	// Merger::Merge<Bm25T> for any query made of terms and phrases (no multi-word synonyms); one OR/AND term -> Merge()
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
 

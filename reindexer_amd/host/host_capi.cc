@@ -615,14 +615,20 @@ std::vector<QueryTerm> parseFtTerms(size_t nf, size_t nTerms, const int* ops, co
 }
 }  // namespace
 
-extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, const int* ops,
-									  const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
-									  const uint32_t* subOff, const uint32_t* wordIds, const float* procs, const uint8_t* excluded, int sortByRank,
-									  int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap, int* outPreselected) {
+// phraseNum / distance: FtDslOpts::phraseNum (-1: a plain term) and FtDslOpts::distance per term, or null (no phrases)
+extern "C" long rxhost_ft_merge_query_phrases(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, const int* ops,
+											  const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
+											  const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* wordIds, const float* procs,
+											  const uint8_t* excluded, int sortByRank, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm,
+											  size_t cap, int* outPreselected) {
 	long n = -1;
 	guarded([&] {
 		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
 		std::vector<QueryTerm> terms = parseFtTerms(nf, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
+		for (size_t t = 0; t < nTerms; ++t) {
+			if (phraseNum) terms[t].phraseNum = phraseNum[t];
+			if (distance) terms[t].distance = distance[t];
+		}
 		bool pre = false;
 		auto res = static_cast<const GpuFtMerger*>(h)->MergeQuery(cfg, std::move(terms), excluded, sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID, &pre);
 		if (outPreselected) *outPreselected = pre ? 1 : 0;
@@ -635,6 +641,13 @@ extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, co
 		}
 	});
 	return n;
+}
+extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, const int* ops,
+									  const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
+									  const uint32_t* subOff, const uint32_t* wordIds, const float* procs, const uint8_t* excluded, int sortByRank,
+									  int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap, int* outPreselected) {
+	return rxhost_ft_merge_query_phrases(h, nf, cfgD, cfgI, fieldCfg, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, nullptr, nullptr, subOff, wordIds,
+										 procs, excluded, sortByRank, outId, outProc, outField, outNorm, cap, outPreselected);
 }
 
 // Hybrid query through the Merger class: the FT merge stays in HBM (MergeQueryResident), then the fusion with a KNN result that lies in

@@ -703,11 +703,13 @@ class GpuFtMerger:
     OP_OR, OP_AND, OP_NOT = 1, 2, 3
 
     def merge_query(self, cfg: dict, terms, excluded=None, sort_by_rank=True):
-        """Multi-term Merger::Merge.  terms: [dict(op, opts, subs=[(word_id, proc), ...]), ...].
+        """Multi-term Merger::Merge.  terms: [dict(op, opts, subs=[(word_id, proc), ...][, phrase=<phraseNum>, distance=<d>]), ...];
+        consecutive terms with the same phrase number >= 0 are one phrase (FtDslOpts::phraseNum / distance).
         Returns (ids, proc, field, norm, preselected)."""
         L = lib()
-        L.rxhost_ft_merge_query.restype = _l
-        L.rxhost_ft_merge_query.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]
+        L.rxhost_ft_merge_query_phrases.restype = _l
+        L.rxhost_ft_merge_query_phrases.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                                    _vp, _sz, _vp]
         nf = self.nf
         cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
                           cfg.get("distance_weight", 0.5)], np.float64)
@@ -719,6 +721,8 @@ class GpuFtMerger:
         tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
         fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
         ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+        phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
+        dst = np.array([t.get("distance", 1) for t in terms], np.int32)
         sub_off, wid, pr = [0], [], []
         for t in terms:
             for w, p in t["subs"]:
@@ -731,10 +735,10 @@ class GpuFtMerger:
         oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
         of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
         pre = C.c_int(0)
-        n = L.rxhost_ft_merge_query(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, len(terms), ops.ctypes.data, boosts.ctypes.data,
-                                    tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data,
-                                    exc.ctypes.data if exc is not None else None, int(sort_by_rank), oid.ctypes.data, op.ctypes.data,
-                                    of.ctypes.data, on.ctypes.data, cap, C.byref(pre))
+        n = L.rxhost_ft_merge_query_phrases(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, len(terms), ops.ctypes.data,
+                                            boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, phr.ctypes.data, dst.ctypes.data,
+                                            sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data, exc.ctypes.data if exc is not None else None,
+                                            int(sort_by_rank), oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap, C.byref(pre))
         if n < 0:
             _raise()
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
