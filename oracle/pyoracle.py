@@ -858,9 +858,14 @@ class RefFtSeam(RefFt):
         exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
         oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
         of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
-        n = self.L.ref_seam_merge(self.h, int(packed), int(gpu), len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data,
-                                  ns.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
-                                  rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
+        phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
+        dst = np.array([t.get("distance", 1) for t in terms], np.int32)
+        fn = self.L.ref_seam_merge_phrases
+        fn.restype = C.c_long
+        fn.argtypes = [_vp, _i, _i, _sz] + [_vp] * 11 + [_i, _vp, _vp, _vp, _vp, _sz]
+        n = fn(self.h, int(packed), int(gpu), len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data,
+               phr.ctypes.data, dst.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
+               rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
         if n == -2:
             return None   # the GPU branch declined: the CPU merger would run
         if n < 0:

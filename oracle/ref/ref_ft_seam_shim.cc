@@ -56,12 +56,22 @@ const std::vector<PackedWordEntry<IdCont>>& wordsOf(const SeamRef& f) {
 
 template <typename IdCont>
 long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
-			   const uint8_t* needSum, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
+			   const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
 			   int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
 	const auto& words = wordsOf<IdCont>(*f);
 	ft::QueryMergeData<IdCont> q;
+	// query parts as Selector::Process puts them together (selecterimpl.h:482-572): terms with the same phraseNum >= 0 -> one PhraseResults
+	int curPhraseNum = -1;
+	ft::PhraseResults<IdCont> nextPhrase;
 	for (size_t t = 0; t < nTerms; ++t) {
 		FtDslOpts o;
+		o.phraseNum = phraseNum ? phraseNum[t] : -1;
+		o.distance = distance ? distance[t] : 1;
+		const bool phraseTerm = o.phraseNum != -1;
+		if (!phraseTerm && nextPhrase.NumTerms()) {
+			q.queryParts.emplace_back(std::move(nextPhrase));
+			nextPhrase.clear();
+		}
 		o.op = OpType(ops[t]);
 		o.boost = boosts[t];
 		o.termLenBoost = termLenBoosts[t];
@@ -79,7 +89,20 @@ long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float*
 			tr.AddSubterm(words.at(subWord[s]).vids, std::string_view("w"), wid, subProc[s]);
 		}
 		q.totalORVids += tr.MaxVDocs();   // selecterimpl.h:546
-		q.queryParts.emplace_back(std::move(tr));
+		if (phraseTerm) {
+			if (nextPhrase.NumTerms() && curPhraseNum != o.phraseNum) {
+				q.queryParts.emplace_back(std::move(nextPhrase));
+				nextPhrase.clear();
+			}
+			curPhraseNum = o.phraseNum;
+			nextPhrase.Add(std::move(tr));
+		} else {
+			q.queryParts.emplace_back(std::move(tr));
+		}
+	}
+	if (nextPhrase.NumTerms()) {
+		q.queryParts.emplace_back(std::move(nextPhrase));
+		nextPhrase.clear();
 	}
 	FtMergeStatuses::Statuses st;
 	st.resize(f->totalDocs, false);
@@ -204,21 +227,29 @@ long ref_seam_commit(void* h, int device) {
 
 // packed: 1 = QueryMergeData<PackedIdRelVec>, 0 = <IdRelVec>; gpu: 1 = TryMergeOnGpu, 0 = the reference's ft::Merger.
 // Returns the result count, -1 on an exception, -2 when the GPU branch declined the query (the CPU merger would run).
-long ref_seam_merge(void* h, int packed, int gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts,
-					const float* fieldBoost, const uint8_t* needSum, const uint32_t* subOff, const uint32_t* subWord, const float* subProc,
-					const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
+// phraseNum / distance: FtDslOpts::phraseNum (-1: a plain term) / FtDslOpts::distance per term, or null.
+long ref_seam_merge_phrases(void* h, int packed, int gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts,
+							const float* fieldBoost, const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff,
+							const uint32_t* subWord, const float* subProc, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc,
+							uint8_t* outField, uint8_t* outNorm, size_t cap) {
 	auto* f = static_cast<SeamRef*>(h);
 	try {
 		if (packed) {
-			return mergeImpl<PackedIdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, subWord, subProc, excluded,
-											 rankSortType, outId, outProc, outField, outNorm, cap);
+			return mergeImpl<PackedIdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord,
+											 subProc, excluded, rankSortType, outId, outProc, outField, outNorm, cap);
 		}
-		return mergeImpl<IdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, subWord, subProc, excluded, rankSortType,
-								   outId, outProc, outField, outNorm, cap);
+		return mergeImpl<IdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord, subProc,
+								   excluded, rankSortType, outId, outProc, outField, outNorm, cap);
 	} catch (const std::exception& e) {
 		f->error = e.what();
 		return -1;
 	}
+}
+long ref_seam_merge(void* h, int packed, int gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts,
+					const float* fieldBoost, const uint8_t* needSum, const uint32_t* subOff, const uint32_t* subWord, const float* subProc,
+					const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
+	return ref_seam_merge_phrases(h, packed, gpu, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, nullptr, nullptr, subOff, subWord, subProc,
+								  excluded, rankSortType, outId, outProc, outField, outNorm, cap);
 }
 
 }  // extern "C"

@@ -16,8 +16,8 @@
 //     vdoc statistics                    — the duck-typed DocsStatsGetter (indextext.h:245-258): DocRemoved / NumWordsInField / AvgWordsCount
 //   Only the words whose list changed since the last commit travel again (fingerprint: byte size + FNV-1a of the stream / (size, last id)).
 //
-// What still goes to the reference's CPU merger (TryMergeOnGpu returns false): phrases, multi-word synonyms, MergeDataAreas (highlight /
-// snippet) — GpuFtMerger::Supports.
+// What still goes to the reference's CPU merger (TryMergeOnGpu returns false): multi-word synonyms, MergeDataAreas (highlight / snippet)
+// — GpuFtMerger::Supports.  Phrases go to the device (PhraseMerger as kernels, ft_phrase.hip).
 #pragma once
 #if !defined(RXGPU_IN_TREE)
 #error "rx_ft_seam.h is for the build inside cpp_src (define RXGPU_IN_TREE)"
@@ -88,26 +88,46 @@ inline bool ToGpuSortType(reindexer::RankSortType t, RankSortType& out) noexcept
 }
 
 // The query as the merger walks it: queryParts in order, sub-terms in SortSubterms() order (the caller has sorted them, mergerimpl.h:479).
-// False when the query holds something the GPU merger does not evaluate (phrases, synonyms).
+// A phrase part (PhraseResults, querymergedata.h:100-142) travels as its terms, marked with one phrase number and each with its
+// FtDslOpts::distance — what GpuFtMerger::MergeQuery groups again (PhraseMerger on the device).
+// False when the query holds something the GPU merger does not evaluate (multi-word synonyms).
 template <typename IdCont>
-bool ToGpuTerms(const reindexer::ft::QueryMergeData<IdCont>& q, std::vector<QueryTerm>& terms) {
+bool ToGpuTerm(const reindexer::ft::TermResults<IdCont>& t, int phraseNum, std::vector<QueryTerm>& terms) {
+	QueryTerm g;
+	switch (t.Op()) {
+		case OpOr: g.op = OpType::Or; break;
+		case OpAnd: g.op = OpType::And; break;
+		case OpNot: g.op = OpType::Not; break;
+		default: return false;
+	}
+	g.opts = ToGpuOpts(t.Opts());
+	g.phraseNum = phraseNum;
+	g.distance = t.Distance();
+	g.subterms.reserve(t.NumSubterms());
+	for (const auto& st : t) g.subterms.push_back(SubtermRef{uint32_t(st.PatternID().b.id), st.Proc()});
+	terms.push_back(std::move(g));
+	return true;
+}
+template <typename IdCont>
+bool ToGpuTerms(reindexer::ft::QueryMergeData<IdCont>& q, std::vector<QueryTerm>& terms, bool* hasPhrases = nullptr) {
+	if (hasPhrases) *hasPhrases = false;
 	if (!q.synonyms.empty()) return false;
 	terms.clear();
 	terms.reserve(q.queryParts.size());
-	for (const auto& qp : q.queryParts) {
-		if (!qp.IsTerm() || !qp.SynonymsIds().empty()) return false;
-		const auto& t = qp.Term();
-		QueryTerm g;
-		switch (t.Op()) {
-			case OpOr: g.op = OpType::Or; break;
-			case OpAnd: g.op = OpType::And; break;
-			case OpNot: g.op = OpType::Not; break;
-			default: return false;
+	int phraseNum = 0;
+	for (auto& qp : q.queryParts) {
+		if (!qp.SynonymsIds().empty()) return false;
+		if (qp.IsTerm()) {
+			if (!ToGpuTerm(qp.Term(), -1, terms)) return false;
+			continue;
 		}
-		g.opts = ToGpuOpts(t.Opts());
-		g.subterms.reserve(t.NumSubterms());
-		for (const auto& st : t) g.subterms.push_back(SubtermRef{uint32_t(st.PatternID().b.id), st.Proc()});
-		terms.push_back(std::move(g));
+		auto& ph = qp.Phrase();   // (PhraseResults::Term has no const overload)
+		if (ph.NumTerms() < 2) return false;   // FtDSLQuery::closeGroup (ftdsl.cc:87-101) marks groups of two or more terms only
+		for (size_t i = 0; i < ph.NumTerms(); ++i) {
+			if (!ToGpuTerm(ph.Term(i), phraseNum, terms)) return false;
+		}
+		++phraseNum;
+		if (hasPhrases) *hasPhrases = true;
 	}
 	return true;
 }
@@ -226,9 +246,9 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		if (q.Empty()) return false;   // the CPU merger returns its empty result
 		q.SortSubterms();   // Merge() does it before anything reads the sub-terms (mergerimpl.h:479)
 		std::vector<QueryTerm> terms;
-		if (!ToGpuTerms(q, terms)) return false;
-		size_t hasPhrases = 0;
-		if (!GpuFtMerger::Supports(terms.size(), hasPhrases != 0, !q.synonyms.empty())) return false;
+		bool hasPhrases = false;
+		if (!ToGpuTerms(q, terms, &hasPhrases)) return false;
+		if (!GpuFtMerger::Supports(terms.size(), hasPhrases, !q.synonyms.empty())) return false;
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
 		if (docsExcluded.PopCount() != 0) {

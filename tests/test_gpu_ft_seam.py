@@ -121,3 +121,51 @@ def test_seam_simple_queries_recommit_and_calculators(rxgpu, ft, bm25_type):
         for packed in (True, False):
             _same(seam.merge(q, packed=packed, gpu=True), seam.merge(q, packed=packed, gpu=False), ("recommit", bm25_type, packed))
     seam.close()
+
+
+def _phrase_terms(terms, phrases, distances):
+    return [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]], phrase=int(ph), distance=int(d))
+            for t, ph, d in zip(terms, phrases, distances)]
+
+
+PHRASE_SHAPES = [((1, 1, 1), (0, 0, -1), (1, 12, 1)), ((2, 2, 1, 1), (0, 0, -1, -1), (1, 20, 1, 1)), ((1, 1, 1, 1), (-1, 0, 0, 0), (1, 1, 15, 15))]
+
+
+@pytest.mark.parametrize("ops,phrases,distances", PHRASE_SHAPES)
+def test_reference_phrase_merger_over_packed_lists_equals_plain_lists(ft, ops, phrases, distances):
+    """CPU: PhraseResults built by the shim like Selector::Process builds them; PhraseMerger walks PackedIdRelVec (occurrences moved out of
+    the iterator) and IdRelVec (by reference) to the same result."""
+    nf, total = 2, 3000
+    _, words, avg, removed, excluded, terms, store = _multi_case(500 + len(ops), nf, total, 20000, ops, False, None, sizes=(400, 1500), nsub_range=(2, 4))
+    seam = _seam(nf, words, avg, removed, store)
+    seam.set_config(ft.default_config(nf, merge_limit=20000))
+    q = _phrase_terms(terms, phrases, distances)
+    plain = [dict(t, phrase=-1) for t in q]
+    for exc in (None, excluded):
+        a, b = seam.merge(q, exc, packed=True), seam.merge(q, exc, packed=False)
+        _same(a, b, ops)
+        assert len(a[0]) > 0
+        c = seam.merge(plain, exc, packed=False)
+        assert len(c[0]) != len(a[0]) or not np.array_equal(c[1], a[1])   # the phrase is not the same query as its terms
+    seam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ops,phrases,distances", PHRASE_SHAPES)
+def test_patched_merge_results_branch_takes_phrases(rxgpu, ft, ops, phrases, distances):
+    """Phrase queries through the patched Selector::mergeResults branch: ToGpuTerms hands the PhraseResults over term by term with a
+    phrase number and FtDslOpts::distance, the PhraseMerger runs on the device — result identical to the reference's merger."""
+    nf, total = 2, 3000
+    _, words, avg, removed, excluded, terms, store = _multi_case(500 + len(ops), nf, total, 20000, ops, False, None, sizes=(400, 1500), nsub_range=(2, 4))
+    seam = _seam(nf, words, avg, removed, store)
+    assert seam.commit(0) == len(store)
+    q = _phrase_terms(terms, phrases, distances)
+    for limit in (20000, 80):
+        seam.set_config(ft.default_config(nf, merge_limit=limit))
+        for exc in (None, excluded):
+            for packed in (True, False):
+                want = seam.merge(q, exc, rank_sort_type=1, packed=packed, gpu=False)
+                got = seam.merge(q, exc, rank_sort_type=1, packed=packed, gpu=True)
+                _same(got, want, (limit, packed))
+                assert len(want[0]) > 0
+    seam.close()
