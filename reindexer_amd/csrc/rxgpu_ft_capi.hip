@@ -7,7 +7,9 @@
 #include <cstring>
 #include <cstdint>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -67,6 +69,15 @@ struct rxgpu_ft_index {
 	uint8_t* d_removed = nullptr;
 	std::unordered_map<uint32_t, rxgpu_ft_word> words;
 	std::mutex mtx;
+	// Concurrent merges (several planner threads query one index at a time): extra LANES — own stream, scratch, staging, events — behind
+	// the same dictionary.  A lane is a rxgpu_ft_index whose `root` points at the handle that owns words and statistics; the handle
+	// itself is lane 0 and the only one the resident / hybrid calls use.  Merges hold dict_mtx shared, dictionary updates exclusively.
+	rxgpu_ft_index* root = nullptr;
+	std::vector<std::unique_ptr<rxgpu_ft_index>> lanes;
+	std::mutex lanes_mtx;
+	std::shared_mutex dict_mtx;
+	std::atomic<uint32_t> next_lane{0};
+	const std::unordered_map<uint32_t, rxgpu_ft_word>& dict() const { return root ? root->words : words; }
 	hipStream_t stream = nullptr;
 	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
 	rxgpu_devbuf d_excl;           // docsExcluded of the running merge
@@ -176,14 +187,8 @@ int rxgpu_ft_create(uint32_t num_fields, int device, rxgpu_ft_index** out) {
 	return RXGPU_OK;
 }
 
-void rxgpu_ft_destroy(rxgpu_ft_index* h) {
-	if (!h) return;
-	DevGuard dg(h->device);
-	(void)hipDeviceSynchronize();
-	for (auto& kv : h->words) kv.second.release();
-	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
-		if (p) (void)hipFree(p);
-	}
+namespace {
+void release_lane(rxgpu_ft_index* h) {   // what a lane owns: stream, scratch, staging, events
 	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse, &h->d_excl}) b->release();
 	for (rxgpu_devbuf& b : h->d_phrase_a) b.release();
 	for (rxgpu_devbuf& b : h->d_phrase_b) b.release();
@@ -194,6 +199,92 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	if (h->ev_a) (void)hipEventDestroy(h->ev_a);
 	if (h->ev_b) (void)hipEventDestroy(h->ev_b);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+constexpr uint32_t kFtMaxLanes = 16;
+uint32_t ft_lane_limit() {
+	static const uint32_t v = [] {
+		const char* e = std::getenv("RXGPU_FT_LANES");
+		const long n = e && *e ? std::atol(e) : 4;
+		return uint32_t(n < 1 ? 1 : (n > long(kFtMaxLanes) ? long(kFtMaxLanes) : n));
+	}();
+	return v;
+}
+
+// A free lane for one merge, locked; then the dictionary, shared.  The first free one of: the handle itself, the lanes made so far, a new
+// lane (up to RXGPU_FT_LANES, default 4); all busy: wait for one in turn.
+struct LaneLock {
+	rxgpu_ft_index* lane = nullptr;
+	std::unique_lock<std::mutex> lk;
+	std::shared_lock<std::shared_mutex> dict;
+};
+int checkout_lane(rxgpu_ft_index* h, LaneLock& out) {
+	auto take = [&](rxgpu_ft_index* l, std::unique_lock<std::mutex>&& lk) {
+		out.lane = l;
+		out.lk = std::move(lk);
+		out.dict = std::shared_lock<std::shared_mutex>(h->dict_mtx);
+		if (l != h) {   // what a merge reads of the statistics
+			l->total_docs = h->total_docs;
+			l->d_words = h->d_words;
+			l->d_avg = h->d_avg;
+			l->d_removed = h->d_removed;
+		}
+	};
+	{
+		std::unique_lock<std::mutex> lk(h->mtx, std::try_to_lock);
+		if (lk.owns_lock()) {
+			take(h, std::move(lk));
+			return RXGPU_OK;
+		}
+	}
+	std::vector<rxgpu_ft_index*> have;
+	{
+		std::lock_guard<std::mutex> g(h->lanes_mtx);
+		for (auto& l : h->lanes) have.push_back(l.get());
+	}
+	for (rxgpu_ft_index* l : have) {
+		std::unique_lock<std::mutex> lk(l->mtx, std::try_to_lock);
+		if (lk.owns_lock()) {
+			take(l, std::move(lk));
+			return RXGPU_OK;
+		}
+	}
+	if (have.size() + 1 < ft_lane_limit()) {
+		auto lane = std::make_unique<rxgpu_ft_index>();
+		lane->device = h->device;
+		lane->num_fields = h->num_fields;
+		lane->root = h;
+		DevGuard dg(h->device);
+		if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) {
+			set_error("hipStreamCreateWithFlags failed");
+			return RXGPU_ERR_DEVICE;
+		}
+		rxgpu_ft_index* l = lane.get();
+		std::unique_lock<std::mutex> lk(l->mtx);
+		{
+			std::lock_guard<std::mutex> g(h->lanes_mtx);
+			h->lanes.push_back(std::move(lane));
+		}
+		take(l, std::move(lk));
+		return RXGPU_OK;
+	}
+	const uint32_t turn = h->next_lane.fetch_add(1) % uint32_t(have.size() + 1);
+	rxgpu_ft_index* l = turn == 0 ? h : have[turn - 1];
+	take(l, std::unique_lock<std::mutex>(l->mtx));
+	return RXGPU_OK;
+}
+}  // namespace
+
+void rxgpu_ft_destroy(rxgpu_ft_index* h) {
+	if (!h) return;
+	DevGuard dg(h->device);
+	(void)hipDeviceSynchronize();
+	for (auto& kv : h->words) kv.second.release();
+	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
+		if (p) (void)hipFree(p);
+	}
+	for (auto& l : h->lanes) release_lane(l.get());
+	release_lane(h);
 	delete h;
 }
 
@@ -201,6 +292,7 @@ int rxgpu_ft_set_docs(rxgpu_ft_index* h, uint64_t total_docs, const float* words
 	RX_CHECK(h && words_in_field && avg_words, RXGPU_ERR_PARAMS, "rxgpu_ft_set_docs: null argument");
 	RX_CHECK(total_docs >= 1 && total_docs < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_set_docs: total_docs out of range");
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::shared_mutex> dict_lk(h->dict_mtx);   // no merge on any lane reads the dictionary meanwhile
 	DevGuard dg(h->device);
 	RX_HIP(hipStreamSynchronize(h->stream));
 	if (int rc = upload(h->d_words, words_in_field, total_docs * h->num_fields); rc) return rc;
@@ -220,6 +312,7 @@ int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uin
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null ft index");
 	RX_CHECK(n == 0 || (doc && ent_off && ent_field && ent_tf && ent_first_pos), RXGPU_ERR_PARAMS, "rxgpu_ft_set_word: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::shared_mutex> dict_lk(h->dict_mtx);   // no merge on any lane reads the dictionary meanwhile
 	DevGuard dg(h->device);
 	RX_HIP(hipStreamSynchronize(h->stream));
 	rxgpu_ft_word& w = h->words[word_id];
@@ -387,7 +480,7 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 		tcfg[k].sub_begin = uint32_t(subs.size());
 		if (qt.sub_end > qt.sub_begin) sum_proc = (long long)(float(sum_proc) + procs[qt.sub_begin]);   // CalcProc16: long long += float, term by term
 		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
-			const rxgpu_ft_word& w = h->words.find(word_ids[si])->second;
+			const rxgpu_ft_word& w = h->dict().find(word_ids[si])->second;
 			RX_CHECK(w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
 			RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
 					 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
@@ -609,8 +702,8 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	for (uint32_t t = 0; t < nterms; ++t) {
 		const QueryTermIn& qt = terms[t];
 		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
-			auto it = h->words.find(word_ids[si]);
-			RX_CHECK(it != h->words.end(), RXGPU_ERR_NOTFOUND, std::string(who) + ": unknown word id");
+			auto it = h->dict().find(word_ids[si]);
+			RX_CHECK(it != h->dict().end(), RXGPU_ERR_NOTFOUND, std::string(who) + ": unknown word id");
 			// the kernels index words_in_field[doc * fields + f] and an (N + 31) / 32-word mask by document: a list reaching past the
 			// documents rxgpu_ft_set_docs described would read and write out of bounds (set_docs may follow the words, so it is checked here)
 			RX_CHECK(it->second.n == 0 || it->second.last_doc < N, RXGPU_ERR_PARAMS,
@@ -694,7 +787,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		tc.sub_begin = uint32_t(subs.size());
 		if (qt.op != 3) last_term_qp = ++qp;
 		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
-			const rxgpu_ft_word& w = h->words.find(word_ids[si])->second;
+			const rxgpu_ft_word& w = h->dict().find(word_ids[si])->second;
 			RX_CHECK(simple || w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
 			RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
 					 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
@@ -917,10 +1010,11 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_simple_raw: rxgpu_ft_set_docs was not called");
 	if (nsub == 0) return RXGPU_OK;
 	RX_CHECK(word_ids && procs && opts->field_boost && opts->need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_raw: null argument");
-	std::lock_guard<std::mutex> lk(h->mtx);
+	LaneLock ll;
+	if (int rc = checkout_lane(h, ll); rc) return rc;
 	DevGuard dg(h->device);
 	std::vector<QueryTermIn> terms{QueryTermIn{1, opts, 0, nsub}};
-	return run_merge(h, cfg, true, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, nullptr, cap, out_n, nullptr,
+	return run_merge(ll.lane, cfg, true, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, nullptr, cap, out_n, nullptr,
 					 "rxgpu_ft_merge_simple_raw");
 }
 
@@ -948,6 +1042,7 @@ int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n,
 	if (int rc = rxgpu_ft_set_word(h, word_id, n, doc, ent_off.data(), ent_field.data(), ent_tf.data(), ent_first.data()); rc) return rc;
 	if (n == 0) return RXGPU_OK;
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	rxgpu_ft_word& w = h->words[word_id];
 	if (int rc = upload(w.pos_off, pos_off, n + 1); rc) return rc;
@@ -965,6 +1060,7 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 	const uint64_t total_bytes = byte_off[nwords];
 	RX_CHECK(total_bytes == 0 || bytes, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::shared_mutex> dict_lk(h->dict_mtx);   // no merge on any lane reads the dictionary meanwhile
 	DevGuard dg(h->device);
 	RX_HIP(hipStreamSynchronize(h->stream));
 	// wavefronts of similar work: the words go to the threads longest first (a wavefront lasts as long as its longest stream)
@@ -1150,6 +1246,7 @@ int rxgpu_ft_get_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t* n, uint64_t
 					  uint32_t* ent_off, uint8_t* ent_field, uint32_t* ent_tf, uint32_t* ent_first_pos, uint32_t* n_ranges, uint32_t* range_off) {
 	RX_CHECK(h && n && npos && nent && n_ranges, RXGPU_ERR_PARAMS, "rxgpu_ft_get_word: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	RX_HIP(hipStreamSynchronize(h->stream));
 	const auto it = h->words.find(word_id);
@@ -1196,11 +1293,12 @@ int rxgpu_ft_merge_terms_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	RX_CHECK(nterms >= 2, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: a single-term query is Simple(): use rxgpu_ft_merge_simple_raw");
 	RX_CHECK(nterms < 0xFFFF, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: too many terms");
 	RX_CHECK(sub_off[nterms] == 0 || (word_ids && procs), RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_raw: null argument");
-	std::lock_guard<std::mutex> lk(h->mtx);
+	LaneLock ll;
+	if (int rc = checkout_lane(h, ll); rc) return rc;
 	DevGuard dg(h->device);
 	std::vector<QueryTermIn> terms(nterms);
 	for (uint32_t t = 0; t < nterms; ++t) terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1]};
-	return run_merge(h, cfg, false, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected,
+	return run_merge(ll.lane, cfg, false, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected,
 					 "rxgpu_ft_merge_terms_raw");
 }
 
@@ -1241,9 +1339,10 @@ int rxgpu_ft_merge_query_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	bool empty = false, simple = false;
 	if (int rc = query_terms(who, nterms, ops, opts, phrase_num, distance, sub_off, word_ids, procs, terms, &empty, &simple); rc) return rc;
 	if (empty) return RXGPU_OK;
-	std::lock_guard<std::mutex> lk(h->mtx);
+	LaneLock ll;
+	if (int rc = checkout_lane(h, ll); rc) return rc;
 	DevGuard dg(h->device);
-	return run_merge(h, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who);
+	return run_merge(ll.lane, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who);
 }
 
 int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
@@ -1258,6 +1357,7 @@ int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 	bool empty = false, simple = false;
 	if (int rc = query_terms(who, nterms, ops, opts, phrase_num, distance, sub_off, word_ids, procs, terms, &empty, &simple); rc) return rc;
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	h->res_cap = 0;
 	h->prep_done = false;
@@ -1276,6 +1376,7 @@ int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg
 	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_simple_resident: rxgpu_ft_set_docs was not called");
 	RX_CHECK(nsub > 0 && word_ids && procs && opts->field_boost && opts->need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_resident: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	std::vector<QueryTermIn> terms{QueryTermIn{1, opts, 0, nsub}};
 	uint64_t n = 0;
@@ -1293,6 +1394,7 @@ int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 	for (uint32_t t = 0; t < nterms; ++t) RX_CHECK(ops[t] >= 1 && ops[t] <= 3, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: op must be 1 (OR), 2 (AND) or 3 (NOT)");
 	RX_CHECK(sub_off[nterms] == 0 || (word_ids && procs), RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
+	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	std::vector<QueryTermIn> terms(nterms);
 	for (uint32_t t = 0; t < nterms; ++t) terms[t] = QueryTermIn{ops[t], &opts[t], sub_off[t], sub_off[t + 1]};
@@ -1562,6 +1664,24 @@ int rxgpu_hybrid_fuse(int device, const rxgpu_hybrid_params* params, int metric,
 int rxgpu_ft_read_stats(rxgpu_ft_index* h, uint64_t* postings, double* kernel_ms) {
 	RX_CHECK(h && postings && kernel_ms, RXGPU_ERR_PARAMS, "rxgpu_ft_read_stats: null argument");
 	std::lock_guard<std::mutex> lk(h->mtx);
+	{   // the lanes' merges count too
+		std::vector<rxgpu_ft_index*> have;
+		{
+			std::lock_guard<std::mutex> g(h->lanes_mtx);
+			for (auto& l : h->lanes) have.push_back(l.get());
+		}
+		for (rxgpu_ft_index* l : have) {
+			std::lock_guard<std::mutex> ll(l->mtx);
+			h->stat_postings += l->stat_postings;
+			h->stat_ms += l->stat_ms;
+			for (int k = 0; k < 6; ++k) h->trace_us[k] += l->trace_us[k];
+			for (int k = 0; k < 64; ++k) h->stamps[k] += l->stamps[k];
+			l->stat_postings = 0;
+			l->stat_ms = 0.0;
+			for (double& v : l->trace_us) v = 0;
+			for (double& v : l->stamps) v = 0;
+		}
+	}
 	*postings = h->stat_postings;
 	*kernel_ms = h->stat_ms;
 	if (const char* e = std::getenv("RXGPU_FT_TRACE"); e && e[0] == '1' && h->trace_us[5] > 0) {

@@ -2,6 +2,8 @@
 // the reference's own engine-level tests drive BruteforceSearch (gtests/tests/unit/hnsw_streaming_search_test.cc).
 // Exceptions become return codes + thread-local text, like the Reindexer API boundary turns them into Error values.
 #include <atomic>
+#include <chrono>
+#include <stdexcept>
 #include <mutex>
 #include <thread>
 #include <cstring>
@@ -648,6 +650,48 @@ extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, co
 									  int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap, int* outPreselected) {
 	return rxhost_ft_merge_query_phrases(h, nf, cfgD, cfgI, fieldCfg, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, nullptr, nullptr, subOff, wordIds,
 										 procs, excluded, sortByRank, outId, outProc, outField, outNorm, cap, outPreselected);
+}
+
+// `threads` callers issue the same query `repeats` times each against ONE merger (what several planner threads of a server do to one text
+// index): wall time of the whole run in *wallMs, the callers' merges spread over the handle's lanes.  Returns the result count of a merge
+// (every one is checked against the first: same count, same ids), -1 on error.
+extern "C" long rxhost_ft_merge_query_concurrent(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms,
+												 const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+												 const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff,
+												 const uint32_t* wordIds, const float* procs, const uint8_t* excluded, int threads, int repeats, double* wallMs) {
+	long n = -1;
+	guarded([&] {
+		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
+		std::vector<QueryTerm> terms = parseFtTerms(nf, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
+		for (size_t t = 0; t < nTerms; ++t) {
+			if (phraseNum) terms[t].phraseNum = phraseNum[t];
+			if (distance) terms[t].distance = distance[t];
+		}
+		const auto* m = static_cast<const GpuFtMerger*>(h);
+		const MergeData first = m->MergeQuery(cfg, terms, excluded, RankSortType::RankAndID);
+		std::atomic<int> bad{0};
+		std::vector<std::thread> pool;
+		const auto t0 = std::chrono::steady_clock::now();
+		for (int t = 0; t < threads; ++t) {
+			pool.emplace_back([&] {
+				try {
+					for (int r = 0; r < repeats; ++r) {
+						const MergeData res = m->MergeQuery(cfg, terms, excluded, RankSortType::RankAndID);
+						bool same = res.size() == first.size();
+						for (size_t i = 0; same && i < res.size(); ++i) same = res[i].id == first[i].id && res[i].normalizedProc == first[i].normalizedProc;
+						if (!same) bad.fetch_add(1);
+					}
+				} catch (...) {
+					bad.fetch_add(1);
+				}
+			});
+		}
+		for (auto& th : pool) th.join();
+		if (wallMs) *wallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		if (bad.load()) throw std::runtime_error("rxhost_ft_merge_query_concurrent: a concurrent merge differs from the first one");
+		n = long(first.size());
+	});
+	return n;
 }
 
 // Hybrid query through the Merger class: the FT merge stays in HBM (MergeQueryResident), then the fusion with a KNN result that lies in

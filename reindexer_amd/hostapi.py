@@ -743,6 +743,43 @@ class GpuFtMerger:
             _raise()
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
 
+    def merge_query_concurrent(self, cfg: dict, terms, threads: int, repeats: int, excluded=None):
+        """`threads` native threads issue the same query `repeats` times each against this merger (GpuFtMerger::MergeQuery is what several
+        planner threads call at once; the merges spread over the handle's lanes).  Every result is checked against the first.
+        Returns (results per merge, wall ms of the whole run)."""
+        L = lib()
+        L.rxhost_ft_merge_query_concurrent.restype = _l
+        L.rxhost_ft_merge_query_concurrent.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz] + [_vp] * 11 + [_i, _i, _vp]
+        nf = self.nf
+        cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
+                          cfg.get("distance_weight", 0.5)], np.float64)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")]], np.int32)
+        fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                               "position_boost", "position_weight")], axis=1).copy()
+        ops = np.array([t["op"] for t in terms], np.int32)
+        boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+        tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+        fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+        ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+        phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
+        dst = np.array([t.get("distance", 1) for t in terms], np.int32)
+        sub_off, wid, pr = [0], [], []
+        for t in terms:
+            for w, p in t["subs"]:
+                wid.append(w)
+                pr.append(p)
+            sub_off.append(len(wid))
+        sub_off, wid, pr = np.array(sub_off, np.uint32), np.array(wid, np.uint32), np.array(pr, np.float32)
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        wall = C.c_double(0.0)
+        n = L.rxhost_ft_merge_query_concurrent(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, len(terms), ops.ctypes.data,
+                                               boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, phr.ctypes.data, dst.ctypes.data,
+                                               sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data, exc.ctypes.data if exc is not None else None,
+                                               int(threads), int(repeats), C.byref(wall))
+        if n < 0:
+            _raise()
+        return int(n), float(wall.value)
+
     def hybrid_query(self, cfg: dict, terms, knn_dist_ptr: int, knn_row_ptr: int, knn_entries: int, k: int, metric: int, kind="rrf", params=(60.0,),
                      union=True, desc=True, excluded=None, knn_count_ptr: int = 0, knn_stream: int = 0, row_of_doc_ptr: int = 0, rowid_of_row_ptr: int = 0):
         """Hybrid query with everything resident: the FT merge stays in HBM (GpuFtMerger::MergeQueryResident), the KNN result lies in HBM

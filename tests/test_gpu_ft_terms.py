@@ -172,3 +172,53 @@ def test_gpu_multi_term_edge_cases(hostapi, ft):
     with pytest.raises(Exception):
         m.merge_query(cfg, [dict(op=1, opts=o, subs=[(2, 100.0)]), dict(op=1, opts=o, subs=[(1, 100.0)])])
     m.close()
+
+
+def test_gpu_concurrent_callers_share_one_index(hostapi, ft):
+    """Several planner threads query ONE text index at a time: every caller gets its own lane of the handle (stream, scratch, staging,
+    kept-clean tables) behind the shared dictionary.  Different query shapes in flight together, each result the oracle's; then the same
+    query from 6 native threads x 8 (checked inside the driver against a merge made alone)."""
+    import threading
+    nf, total = 2, 60_000
+    _, words, avg, removed, excluded, terms_all, store = _multi_case(5151, nf, total, 20000, (1, 1, 2, 1, 3, 1), False, None, sizes=(500, 6000),
+                                                                     nsub_range=(2, 6))
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg, removed)
+    for s_ in store:
+        m.set_word_fpos(s_["word"], s_)
+
+    def gq(ts):
+        return [dict(op=t["op"], opts=t["opts"], subs=[(x["word"], x["proc"]) for x in t["subs"]]) for t in ts]
+
+    shapes = [([0, 1, 2, 3, 4, 5], 20000), ([0], 20000), ([2, 3], 300), ([0, 1], 150), ([1, 3, 5], 20000), ([0, 2, 4], 97)]
+    want = []
+    for pick, limit in shapes:
+        cfg = ft.default_config(nf, merge_limit=limit, min_rank=5)
+        ts = [terms_all[i] for i in pick]
+        want.append((cfg, ts, ft.merge_query(cfg, ts, total, words, avg, removed, excluded, sort_by_rank=False)))
+    errors = []
+
+    def worker(k):
+        try:
+            for rnd in range(6):
+                cfg, ts, (wd, wp, wf, wn, wpre) = want[(k + rnd) % len(want)]
+                gd, gp, gf, gn, gpre = m.merge_query(cfg, gq(ts), excluded, sort_by_rank=False)
+                assert gpre == wpre and np.array_equal(gd, wd.astype(np.int32)) and np.array_equal(gn, wn) and np.array_equal(gf, wf)
+                assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    cfg, ts, (wd, *_rest) = want[0]
+    n, wall_ms = m.merge_query_concurrent(cfg, gq(ts), threads=6, repeats=8, excluded=excluded)
+    assert n == len(wd) and wall_ms > 0
+    # a dictionary update while nobody merges, then merges again (the lanes keep their scratch, the statistics are re-read)
+    m.set_docs(words, avg, removed)
+    gd, *_ = m.merge_query(cfg, gq(ts), excluded, sort_by_rank=False)
+    assert np.array_equal(gd, wd.astype(np.int32))
+    m.close()

@@ -96,6 +96,22 @@ def run_multi(args):
                    "roofline": {"bound": "hbm", "achieved": bytes_per_merge / (kernel_ms / args.queries / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                 "frac": bytes_per_merge / (kernel_ms / args.queries / 1e3) / 1e9 / 8000.0,
                                 "note": "per posting 41 B (doc, entry offsets, entry, position offsets, words/slot/mask gathers) + 8 B per position"}}}
+    if args.threads:
+        # several planner threads against one index: the merges of concurrent callers run on the handle's lanes (own stream + scratch each)
+        conc = []
+        for th in [int(x) for x in args.threads.split(",")]:
+            m.merge_query_concurrent(cfg, terms_g, th, 2)   # warm-up: the lanes' scratch
+            m.read_stats()
+            reps = max(4, args.queries)
+            n_res, wall_ms = m.merge_query_concurrent(cfg, terms_g, th, reps)
+            cp, ck = m.read_stats()
+            merges = th * reps + 1   # (+ the reference merge of the driver)
+            conc.append({"threads": th, "merges": merges, "merges_per_sec": th * reps / (wall_ms / 1e3), "ms_per_merge_wall": wall_ms / (th * reps),
+                         "kernel_ms_per_merge_in_lane": ck / merges,
+                         "roofline_wall": {"bound": "hbm", "achieved": bytes_per_merge * th * reps / (wall_ms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                           "frac": bytes_per_merge * th * reps / (wall_ms / 1e3) / 1e9 / 8000.0,
+                                           "note": "same byte model as gpu.roofline, over the WALL time of the whole concurrent run (host work included)"}})
+        out["concurrent"] = conc
     try:
         from oracle.pyoracle import FtOracle, Oracle, ref_ft_or_none
         ft = FtOracle(Oracle())
@@ -135,6 +151,7 @@ def main():
     ap.add_argument("--queries", type=int, default=20)
     ap.add_argument("--fracs", default="0.2,0.05,0.01")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--threads", default=None, help="multi-term mode: comma list of concurrent caller counts (e.g. 1,2,4,8)")
     args = ap.parse_args()
     if args.ops:
         return run_multi(args)
