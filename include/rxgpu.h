@@ -155,11 +155,17 @@ int rxgpu_search_knn_bitmap(rxgpu_index* h, const float* queries, uint32_t nq, u
  * rxgpu_search_knn_lists: `coarse` = a flat index of the nlist centroids (same metric family, same device).  The nprobe nearest centroids
  *   are found on the device, their lists are marked in an allowed-rows bitmap, expanded to the ascending row list and scanned
  *   (rxgpu_search_knn_subset's kernels) without a host round trip in between: same result as rxgpu_search_knn_subset over the union of
- *   the probed lists.  query = host [dim], already prepared for the metric (cosine: normalised).  nprobe <= 64; *out_scanned (optional)
- *   = rows in the probed lists.  Output as rxgpu_search_knn for nq = 1. */
+ *   the probed lists.  query = host [dim], already prepared for the metric (cosine: normalised).  Any nprobe (clamped to nlist): up to
+ *   128 lists the coarse result never leaves HBM, wider probes fetch the nprobe list ids and send them back.  *out_scanned (optional)
+ *   = rows in the probed lists.  Output as rxgpu_search_knn for nq = 1.
+ * rxgpu_search_range_lists: IndexIVFFlat::range_search (ivf_index.cc:212-272 drives it) over the same device lists — probed lists ->
+ *   row list on the device -> the range kernel of rxgpu_search_range_subset; output, overflow protocol and ordering as
+ *   rxgpu_search_range_subset. */
 int rxgpu_index_set_lists(rxgpu_index* h, uint32_t nlist, const uint64_t* list_off, const uint32_t* list_rows);
 int rxgpu_search_knn_lists(rxgpu_index* h, rxgpu_index* coarse, const float* query, uint32_t nprobe, uint32_t kk, float* out_dist,
 						   uint32_t* out_row, uint32_t* out_count, uint64_t* out_scanned);
+int rxgpu_search_range_lists(rxgpu_index* h, rxgpu_index* coarse, const float* query, uint32_t nprobe, float radius, int inclusive, float* out_dist,
+							 uint32_t* out_row, uint64_t cap, uint64_t* out_total, uint64_t* out_scanned);
 
 /* Device-resident variant on `stream` (no synchronisation): d_row_ids = device [n_ids] uint32, 1 <= n_ids <= count,
  * kk in [1, 128]; d_out_count may be NULL.  The list is TRUSTED (strictly increasing, below count): an id beyond the

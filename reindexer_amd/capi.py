@@ -60,6 +60,7 @@ _SIGNATURES = {
     "rxgpu_search_knn_bitmap": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),
     "rxgpu_index_set_lists": (_i, [_vp, _u32, _vp, _vp]),
     "rxgpu_search_knn_lists": (_i, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, C.POINTER(_u64)]),
+    "rxgpu_search_range_lists": (_i, [_vp, _vp, _vp, _u32, C.c_float, _i, _vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_search_knn_subset_device": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, _vp]),
     "rxgpu_check_row_list_device": (_i, [_vp, _vp, _u64, _vp, C.POINTER(C.c_int32)]),
     "rxgpu_search_range_subset": (_i, [_vp, _vp, _f, _i, _vp, _u64, _vp, _vp, _u64, C.POINTER(_u64)]),
@@ -347,6 +348,21 @@ class VectorIndex:
                                             C.byref(scanned)))
         c = int(cnt[0])
         return dist[:c], row[:c], int(scanned.value)
+
+    def search_range_lists(self, coarse: "VectorIndex", query, nprobe: int, radius: float, inclusive: bool = False, cap: int = 1 << 14):
+        """IndexIVFFlat::range_search over the device lists in one call: (dist[n], row[n], rows scanned), ascending by (dist, row)."""
+        q = _f32c(query).reshape(self.dim)
+        while True:
+            dist, row = np.empty(max(cap, 1), np.float32), np.empty(max(cap, 1), np.uint32)
+            total, scanned = _u64(0), _u64(0)
+            rc = lib().rxgpu_search_range_lists(self._h, coarse._h, q.ctypes.data, nprobe, float(radius), int(inclusive), dist.ctypes.data, row.ctypes.data,
+                                                cap, C.byref(total), C.byref(scanned))
+            if rc == RXGPU_ERR_OVERFLOW:
+                cap = int(total.value)
+                continue
+            _check(rc)
+            n = int(total.value)
+            return dist[:n].copy(), row[:n].copy(), int(scanned.value)
 
     def hnsw_attach_graph(self, g: dict) -> None:
         """g: flat graph dict (links0, upper_off, upper, deleted, M, maxM0, maxlevel, entry, num_deleted)."""

@@ -1182,38 +1182,33 @@ int rxgpu_index_set_lists(rxgpu_index* h, uint32_t nlist, const uint64_t* list_o
 	return RXGPU_OK;
 }
 
-int rxgpu_search_knn_lists(rxgpu_index* h, rxgpu_index* coarse, const float* query, uint32_t nprobe, uint32_t kk, float* out_dist,
-						   uint32_t* out_row, uint32_t* out_count, uint64_t* out_scanned) {
-	RX_CHECK(h && coarse && query && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_search_knn_lists: null argument");
-	if (h->shard_set || coarse->shard_set) {
-		set_error("rxgpu_search_knn_lists: not available on a sharded index");
-		return RXGPU_ERR_LOGIC;
-	}
-	RX_CHECK(h->nlist > 0 && h->lists_count == h->count, RXGPU_ERR_LOGIC, "rxgpu_search_knn_lists: inverted lists are not set / out of date");
-	RX_CHECK(coarse->count == h->nlist && coarse->dim == h->dim && coarse->device == h->device, RXGPU_ERR_PARAMS,
-			 "rxgpu_search_knn_lists: the coarse index must hold one centroid per list, same dimension, same device");
-	if (out_scanned) *out_scanned = 0;
-	*out_count = 0;
-	if (h->count == 0 || kk == 0) return RXGPU_OK;
-	nprobe = std::max<uint32_t>(1, std::min<uint32_t>(nprobe, h->nlist));
-	RX_CHECK(nprobe <= uint32_t(rxgpu::kMaxFusedK), RXGPU_ERR_PARAMS, "rxgpu_search_knn_lists: nprobe must be <= 64 (wider probes: rxgpu_search_knn_subset over the lists' union)");
-	DeviceGuard dg(h->device);
-	rxgpu_search_ctx* c = acquire_ctx(h);
-	if (!c) return RXGPU_ERR_DEVICE;
-	struct Rel {
-		rxgpu_index* h;
-		rxgpu_search_ctx* c;
-		~Rel() { release_ctx(h, c); }
-	} rel{h, c};
-	// 1. the coarse quantiser: nprobe nearest centroids, result left on the device
+namespace {
+// The probed lists of one query as an ascending row list in c->d_subset, everything on the device: nprobe nearest centroids (the coarse
+// quantiser's search; up to 128 lists its result never leaves HBM, wider probes fetch the list ids — nprobe words — and send them back),
+// lists -> allowed-rows bitmap -> row list.  *total = rows to scan.
+int ivf_probe_rows(rxgpu_index* h, rxgpu_index* coarse, rxgpu_search_ctx* c, const float* query, uint32_t nprobe, unsigned long long* total, const char* who) {
 	const size_t qbytes = size_t(h->dim) * sizeof(float);
 	if (int rc = c->d_queries.ensure(qbytes); rc) return rc;
 	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, query, qbytes, hipMemcpyHostToDevice, c->stream));
 	const size_t o_lists = 0, o_dist = size_t(nprobe) * 4, o_cnt = o_dist + size_t(nprobe) * 4;
 	if (int rc = c->d_ivf.ensure(o_cnt + 256); rc) return rc;
 	char* ivf = static_cast<char*>(c->d_ivf.ptr);
-	if (int rc = rxgpu_search_knn_device(coarse, c->d_queries.ptr, 1, nprobe, ivf + o_dist, ivf + o_lists, ivf + o_cnt, c->stream); rc) return rc;
-	// 2. probed lists -> allowed-rows bitmap -> ascending row list, all on the device
+	if (nprobe <= uint32_t(rxgpu::kMaxFusedK2)) {
+		rxgpu_search_ctx* cc = stream_ctx(coarse, c->stream);
+		auto* run = nprobe <= uint32_t(rxgpu::kMaxFusedK) ? enqueue_knn : enqueue_knn_fused;
+		if (int rc = run(coarse, cc, static_cast<const float*>(c->d_queries.ptr), 1, nprobe, reinterpret_cast<float*>(ivf + o_dist),
+						 reinterpret_cast<uint32_t*>(ivf + o_lists), reinterpret_cast<uint32_t*>(ivf + o_cnt));
+			rc)
+			return rc;
+	} else {
+		std::vector<float> cd(nprobe);
+		std::vector<uint32_t> cl(nprobe);
+		uint32_t cnt = 0;
+		if (int rc = rxgpu_search_knn(coarse, query, 1, nprobe, cd.data(), cl.data(), &cnt); rc) return rc;
+		RX_HIP(hipMemcpyAsync(ivf + o_lists, cl.data(), size_t(cnt) * 4, hipMemcpyHostToDevice, c->stream));
+		RX_HIP(hipMemcpyAsync(ivf + o_cnt, &cnt, 4, hipMemcpyHostToDevice, c->stream));
+		RX_HIP(hipStreamSynchronize(c->stream));   // cl / cnt live on this frame
+	}
 	const uint64_t need_words = (h->count + 31) / 32;
 	const uint32_t tiles = rxgpu::bitmap_tiles(h->count);
 	if (int rc = c->d_bitmap.ensure(need_words * sizeof(uint32_t)); rc) return rc;
@@ -1228,20 +1223,116 @@ int rxgpu_search_knn_lists(rxgpu_index* h, rxgpu_index* coarse, const float* que
 		rxgpu::launch_bitmap_count(static_cast<const uint32_t*>(c->d_bitmap.ptr), h->count, tile_scratch, d_total, c->stream);
 	}
 	RX_HIP(hipGetLastError());
-	unsigned long long total = 0;
-	RX_HIP(hipMemcpyAsync(&total, d_total, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+	*total = 0;
+	RX_HIP(hipMemcpyAsync(total, d_total, sizeof(*total), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipStreamSynchronize(c->stream));
-	if (out_scanned) *out_scanned = total;
-	if (total == 0) return RXGPU_OK;
-	if (int rc = c->d_subset.ensure(total * sizeof(uint32_t)); rc) return rc;
+	if (*total == 0) return RXGPU_OK;
+	if (int rc = c->d_subset.ensure(*total * sizeof(uint32_t)); rc) return rc;
 	{
 		ProfileScope ps(h, "ivf_lists", c->stream);
-		rxgpu::launch_bitmap_expand(static_cast<const uint32_t*>(c->d_bitmap.ptr), h->count, tile_scratch, static_cast<uint32_t*>(c->d_subset.ptr),
-									total, c->stream);
+		rxgpu::launch_bitmap_expand(static_cast<const uint32_t*>(c->d_bitmap.ptr), h->count, tile_scratch, static_cast<uint32_t*>(c->d_subset.ptr), *total,
+									c->stream);
 	}
 	RX_HIP(hipGetLastError());
-	// 3. the list scan
+	(void)who;
+	return RXGPU_OK;
+}
+int ivf_check(rxgpu_index* h, rxgpu_index* coarse, const char* who) {
+	if (h->shard_set || coarse->shard_set) {
+		set_error(std::string(who) + ": not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	RX_CHECK(h->nlist > 0 && h->lists_count == h->count, RXGPU_ERR_LOGIC, std::string(who) + ": inverted lists are not set / out of date");
+	RX_CHECK(coarse->count == h->nlist && coarse->dim == h->dim && coarse->device == h->device, RXGPU_ERR_PARAMS,
+			 std::string(who) + ": the coarse index must hold one centroid per list, same dimension, same device");
+	return RXGPU_OK;
+}
+}  // namespace
+
+int rxgpu_search_knn_lists(rxgpu_index* h, rxgpu_index* coarse, const float* query, uint32_t nprobe, uint32_t kk, float* out_dist,
+						   uint32_t* out_row, uint32_t* out_count, uint64_t* out_scanned) {
+	RX_CHECK(h && coarse && query && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_search_knn_lists: null argument");
+	if (int rc = ivf_check(h, coarse, "rxgpu_search_knn_lists"); rc) return rc;
+	if (out_scanned) *out_scanned = 0;
+	*out_count = 0;
+	if (h->count == 0 || kk == 0) return RXGPU_OK;
+	nprobe = std::max<uint32_t>(1, std::min<uint32_t>(nprobe, h->nlist));
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	unsigned long long total = 0;
+	if (int rc = ivf_probe_rows(h, coarse, c, query, nprobe, &total, "rxgpu_search_knn_lists"); rc) return rc;
+	if (out_scanned) *out_scanned = total;
+	if (total == 0) return RXGPU_OK;
 	return search_subset_host(h, c, query, 1, kk, static_cast<const uint32_t*>(c->d_subset.ptr), total, out_dist, out_row, out_count);
+}
+
+namespace {
+// range search over a row list that lies in c->d_subset (query in c->d_queries): the tail of rxgpu_search_range_subset
+int range_subset_on_device(rxgpu_index* h, rxgpu_search_ctx* c, uint64_t n_ids, float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap,
+						   uint64_t* out_total, const char* who) {
+	const uint64_t dcap = std::min<uint64_t>(cap, n_ids);
+	if (int rc = c->d_out_dist.ensure(std::max<uint64_t>(dcap, 1) * sizeof(float)); rc) return rc;
+	if (int rc = c->d_out_row.ensure(std::max<uint64_t>(dcap, 1) * sizeof(uint32_t)); rc) return rc;
+	if (int rc = c->d_out_count.ensure(sizeof(unsigned long long)); rc) return rc;
+	RX_HIP(hipMemsetAsync(c->d_out_count.ptr, 0, sizeof(unsigned long long), c->stream));
+	{
+		ProfileScope ps(h, "range_subset", c->stream);
+		rxgpu::launch_range_subset(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr),
+								   static_cast<const uint32_t*>(c->d_subset.ptr), n_ids, h->stride, h->dim, radius, inclusive,
+								   static_cast<float*>(c->d_out_dist.ptr), static_cast<uint32_t*>(c->d_out_row.ptr), dcap,
+								   static_cast<unsigned long long*>(c->d_out_count.ptr), rxgpu::scan_grid_x(n_ids, h->cus), c->stream);
+	}
+	RX_HIP(hipGetLastError());
+	unsigned long long total = 0;
+	RX_HIP(hipMemcpyAsync(&total, c->d_out_count.ptr, sizeof(total), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipStreamSynchronize(c->stream));
+	*out_total = total;
+	if (total > cap) {
+		set_error(std::string(who) + ": output buffer too small");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	if (total == 0) return RXGPU_OK;
+	std::vector<float> hd(total);
+	std::vector<uint32_t> hr(total), order(total);
+	RX_HIP(hipMemcpy(hd.data(), c->d_out_dist.ptr, total * sizeof(float), hipMemcpyDeviceToHost));
+	RX_HIP(hipMemcpy(hr.data(), c->d_out_row.ptr, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	std::iota(order.begin(), order.end(), 0u);
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hd[a] < hd[b] || (!(hd[b] < hd[a]) && hr[a] < hr[b]); });
+	for (uint64_t i = 0; i < total; ++i) {
+		out_dist[i] = hd[order[i]];
+		out_row[i] = hr[order[i]];
+	}
+	return RXGPU_OK;
+}
+}  // namespace
+
+int rxgpu_search_range_lists(rxgpu_index* h, rxgpu_index* coarse, const float* query, uint32_t nprobe, float radius, int inclusive, float* out_dist,
+							 uint32_t* out_row, uint64_t cap, uint64_t* out_total, uint64_t* out_scanned) {
+	RX_CHECK(h && coarse && query && out_total && (cap == 0 || (out_dist && out_row)), RXGPU_ERR_PARAMS, "rxgpu_search_range_lists: null argument");
+	if (int rc = ivf_check(h, coarse, "rxgpu_search_range_lists"); rc) return rc;
+	if (out_scanned) *out_scanned = 0;
+	*out_total = 0;
+	if (h->count == 0) return RXGPU_OK;
+	nprobe = std::max<uint32_t>(1, std::min<uint32_t>(nprobe, h->nlist));
+	DeviceGuard dg(h->device);
+	rxgpu_search_ctx* c = acquire_ctx(h);
+	if (!c) return RXGPU_ERR_DEVICE;
+	struct Rel {
+		rxgpu_index* h;
+		rxgpu_search_ctx* c;
+		~Rel() { release_ctx(h, c); }
+	} rel{h, c};
+	unsigned long long total = 0;
+	if (int rc = ivf_probe_rows(h, coarse, c, query, nprobe, &total, "rxgpu_search_range_lists"); rc) return rc;
+	if (out_scanned) *out_scanned = total;
+	if (total == 0) return RXGPU_OK;
+	return range_subset_on_device(h, c, total, radius, inclusive, out_dist, out_row, cap, out_total, "rxgpu_search_range_lists");
 }
 
 int rxgpu_search_knn_subset_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, const void* d_row_ids, uint64_t n_ids,
@@ -1366,43 +1457,11 @@ int rxgpu_search_range_subset(rxgpu_index* h, const float* query, float radius, 
 		rxgpu_search_ctx* c;
 		~Rel() { release_ctx(h, c); }
 	} rel{h, c};
-	const uint64_t dcap = std::min<uint64_t>(cap, n_ids);
 	if (int rc = c->d_queries.ensure(h->dim * sizeof(float)); rc) return rc;
 	if (int rc = c->d_subset.ensure(n_ids * sizeof(uint32_t)); rc) return rc;
-	if (int rc = c->d_out_dist.ensure(std::max<uint64_t>(dcap, 1) * sizeof(float)); rc) return rc;
-	if (int rc = c->d_out_row.ensure(std::max<uint64_t>(dcap, 1) * sizeof(uint32_t)); rc) return rc;
-	if (int rc = c->d_out_count.ensure(sizeof(unsigned long long)); rc) return rc;
 	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, query, h->dim * sizeof(float), hipMemcpyHostToDevice, c->stream));
 	RX_HIP(hipMemcpyAsync(c->d_subset.ptr, row_ids, n_ids * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-	RX_HIP(hipMemsetAsync(c->d_out_count.ptr, 0, sizeof(unsigned long long), c->stream));
-	{
-		ProfileScope ps(h, "range_subset", c->stream);
-		rxgpu::launch_range_subset(h->metric, h->d_rows, h->d_inv_norms, static_cast<const float*>(c->d_queries.ptr),
-								   static_cast<const uint32_t*>(c->d_subset.ptr), n_ids, h->stride, h->dim, radius, inclusive,
-								   static_cast<float*>(c->d_out_dist.ptr), static_cast<uint32_t*>(c->d_out_row.ptr), dcap,
-								   static_cast<unsigned long long*>(c->d_out_count.ptr), rxgpu::scan_grid_x(n_ids, h->cus), c->stream);
-	}
-	RX_HIP(hipGetLastError());
-	unsigned long long total = 0;
-	RX_HIP(hipMemcpyAsync(&total, c->d_out_count.ptr, sizeof(total), hipMemcpyDeviceToHost, c->stream));
-	RX_HIP(hipStreamSynchronize(c->stream));
-	*out_total = total;
-	if (total > cap) {
-		set_error("rxgpu_search_range_subset: output buffer too small");
-		return RXGPU_ERR_OVERFLOW;
-	}
-	if (total == 0) return RXGPU_OK;
-	std::vector<float> hd(total);
-	std::vector<uint32_t> hr(total), order(total);
-	RX_HIP(hipMemcpy(hd.data(), c->d_out_dist.ptr, total * sizeof(float), hipMemcpyDeviceToHost));
-	RX_HIP(hipMemcpy(hr.data(), c->d_out_row.ptr, total * sizeof(uint32_t), hipMemcpyDeviceToHost));
-	std::iota(order.begin(), order.end(), 0u);
-	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hd[a] < hd[b] || (!(hd[b] < hd[a]) && hr[a] < hr[b]); });
-	for (uint64_t i = 0; i < total; ++i) {
-		out_dist[i] = hd[order[i]];
-		out_row[i] = hr[order[i]];
-	}
-	return RXGPU_OK;
+	return range_subset_on_device(h, c, n_ids, radius, inclusive, out_dist, out_row, cap, out_total, "rxgpu_search_range_subset");
 }
 
 int rxgpu_distances(rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist) {

@@ -1,6 +1,10 @@
 #include "gpu_ivf_flat.h"
 
 #include <algorithm>
+#include <atomic>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -367,6 +371,7 @@ size_t GpuIvfFlat::RemoveIds(const idx_t* ids, size_t n) {
 }
 
 void GpuIvfFlat::syncLists() const {
+	std::lock_guard<std::mutex> lk(listsMtx_);
 	if (!listsDirty_) return;
 	std::vector<uint64_t> off(nlist_ + 1, 0);
 	for (size_t l = 0; l < nlist_; ++l) off[l + 1] = off[l] + lists_[l].size();
@@ -413,22 +418,11 @@ void GpuIvfFlat::Search(const float* x, size_t k, size_t nprobe, float* distance
 	if (!trained_) {   // the flat phase: IndexFlat::search
 		if (rxgpu_search_knn(dev_, q.data(), 1, uint32_t(k), dist.data(), row.data(), &cnt) != RXGPU_OK) throwDevice("GpuIvfFlat::Search");
 	} else {
-		if (std::min(std::max<size_t>(nprobe, 1), nlist_) <= 64) {   // everything on the device: no list ids, no row list through the host
-			syncLists();
-			if (rxgpu_search_knn_lists(dev_, devCentroids_, q.data(), uint32_t(nprobe), uint32_t(kk), dist.data(), row.data(), &cnt, nullptr) != RXGPU_OK) {
-				throwDevice("GpuIvfFlat::Search");
-			}
-		} else {
-			std::vector<uint32_t> probe;
-			coarse(q.data(), nprobe, probe);
-			std::vector<const std::vector<uint32_t>*> runs;
-			runs.reserve(probe.size());
-			for (uint32_t l : probe) runs.push_back(&lists_[l]);
-			const std::vector<uint32_t> rows = SortedUnion(runs, count_);
-			if (rows.empty()) return;
-			if (rxgpu_search_knn_subset(dev_, q.data(), 1, uint32_t(kk), rows.data(), rows.size(), dist.data(), row.data(), &cnt) != RXGPU_OK) {
-				throwDevice("GpuIvfFlat::Search");
-			}
+		// everything on the device, whatever nprobe: no row list through the host (up to 128 probed lists not even their ids)
+		syncLists();
+		if (rxgpu_search_knn_lists(dev_, devCentroids_, q.data(), uint32_t(std::min<size_t>(nprobe, nlist_)), uint32_t(kk), dist.data(), row.data(), &cnt,
+								   nullptr) != RXGPU_OK) {
+			throwDevice("GpuIvfFlat::Search");
 		}
 	}
 	if (trained_ && cnt > k && dist[k] == dist[k - 1]) {   // more candidates at the k-th distance than places: the scanner's order decides
@@ -441,6 +435,34 @@ void GpuIvfFlat::Search(const float* x, size_t k, size_t nprobe, float* distance
 		labels[i] = ids_[row[i]];
 	}
 	if (trained_) orderTies(n, distances, labels);
+}
+
+// n queries (IndexIVFFlat::search's n; ivf_index.cc:355-372 passes 1, SelectKnn callers with several keys more): the queries are independent
+// launch trains, so a few host threads drive them side by side — every Search checks out its own device scratch and stream.
+void GpuIvfFlat::SearchBatch(size_t n, const float* x, size_t k, size_t nprobe, float* distances, idx_t* labels) const {
+	if (n == 0) return;
+	const size_t workers = std::min<size_t>(n, 4);
+	if (workers <= 1) {
+		Search(x, k, nprobe, distances, labels);
+		return;
+	}
+	if (trained_) syncLists();   // once, before the threads (it mutates the cached device lists)
+	std::atomic<size_t> next{0};
+	std::exception_ptr failure;
+	std::mutex failMtx;
+	std::vector<std::thread> pool;
+	for (size_t w = 0; w < workers; ++w) {
+		pool.emplace_back([&] {
+			try {
+				for (size_t q = next.fetch_add(1); q < n; q = next.fetch_add(1)) Search(x + q * dim_, k, nprobe, distances + q * k, labels + q * k);
+			} catch (...) {
+				std::lock_guard<std::mutex> lk(failMtx);
+				if (!failure) failure = std::current_exception();
+			}
+		});
+	}
+	for (auto& t : pool) t.join();
+	if (failure) std::rethrow_exception(failure);
 }
 
 // Equal distances inside a result: heap_reorder (utils/Heap.h) pops the heap top into the last free place.  The top of the CMax heap (L2)
@@ -528,20 +550,13 @@ void GpuIvfFlat::RangeSearch(const float* x, float radius, size_t nprobe, std::v
 	std::vector<float> q;
 	prepareQuery(x, q);
 	const float internal = metric_ == VectorMetric::L2 ? radius : -radius;   // similarity > radius <=> -similarity < -radius
-	std::vector<uint32_t> rows;
-	if (trained_) {
-		std::vector<uint32_t> probe;
-		coarse(q.data(), nprobe, probe);
-		std::vector<const std::vector<uint32_t>*> runs;
-		for (uint32_t l : probe) runs.push_back(&lists_[l]);
-		rows = SortedUnion(runs, count_);
-		if (rows.empty()) return;
-	}
+	if (trained_) syncLists();
 	std::vector<float> dist(1024);
 	std::vector<uint32_t> row(1024);
 	uint64_t total = 0;
-	for (;;) {
-		const int rc = trained_ ? rxgpu_search_range_subset(dev_, q.data(), internal, 0, rows.data(), rows.size(), dist.data(), row.data(), dist.size(), &total)
+	for (;;) {   // trained: the probed lists are found, united and scanned on the device (rxgpu_search_range_lists)
+		const int rc = trained_ ? rxgpu_search_range_lists(dev_, devCentroids_, q.data(), uint32_t(std::min<size_t>(std::max<size_t>(nprobe, 1), nlist_)), internal,
+														   0, dist.data(), row.data(), dist.size(), &total, nullptr)
 								: rxgpu_search_range(dev_, q.data(), internal, 0, dist.data(), row.data(), dist.size(), &total);
 		if (rc == RXGPU_OK) break;
 		if (rc != RXGPU_ERR_OVERFLOW) throwDevice("GpuIvfFlat::RangeSearch");

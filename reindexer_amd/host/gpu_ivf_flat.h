@@ -81,6 +81,8 @@ public:
 	// search(1, x, k, distances, labels, nprobe): best first; L2: squared distance ascending, inner product / cosine: similarity descending;
 	// labels[i] = -1 past the last hit (FAISS convention).  Untrained: exact search over everything (IndexFlat).
 	void Search(const float* x, size_t k, size_t nprobe, float* distances, idx_t* labels) const;
+	// n queries, x [n][dim] -> distances / labels [n][k]: the searches run side by side on a few streams
+	void SearchBatch(size_t n, const float* x, size_t k, size_t nprobe, float* distances, idx_t* labels) const;
 	// range_search: L2: dist < radius; inner product / cosine: similarity > radius; sorted best first
 	void RangeSearch(const float* x, float radius, size_t nprobe, std::vector<float>& distances, std::vector<idx_t>& labels) const;
 
@@ -123,6 +125,7 @@ private:
 
 	void syncLists() const;                     // CSR mirror of lists_ in HBM (rxgpu_index_set_lists), rebuilt after a mutation
 	mutable bool listsDirty_ = true;
+	mutable std::mutex listsMtx_;               // concurrent searches: one of them uploads the lists
 	mutable rxgpu_index* dev_ = nullptr;        // the vectors
 	mutable rxgpu_index* devCentroids_ = nullptr;
 };

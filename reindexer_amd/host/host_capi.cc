@@ -913,6 +913,9 @@ int rxhost_ivf_reset(void* h) {
 int rxhost_ivf_search(void* h, const float* x, size_t k, size_t nprobe, float* dist, int64_t* labels) {
 	return guarded([&] { static_cast<const GpuIvfFlat*>(h)->Search(x, k, nprobe, dist, labels); });
 }
+int rxhost_ivf_search_batch(void* h, size_t n, const float* x, size_t k, size_t nprobe, float* dist, int64_t* labels) {
+	return guarded([&] { static_cast<const GpuIvfFlat*>(h)->SearchBatch(n, x, k, nprobe, dist, labels); });
+}
 // returns the number of hits (the first min(hits, cap) are written), or -1
 long rxhost_ivf_range(void* h, const float* x, float radius, size_t nprobe, float* dist, int64_t* labels, size_t cap) {
 	long n = -1;

@@ -972,6 +972,7 @@ class GpuIvfFlat:
             L.rxhost_ivf_remove.argtypes = [_vp, _vp, _sz]
             L.rxhost_ivf_reset.argtypes = [_vp]
             L.rxhost_ivf_search.argtypes = [_vp, _vp, _sz, _sz, _vp, _vp]
+            L.rxhost_ivf_search_batch.argtypes = [_vp, _sz, _vp, _sz, _sz, _vp, _vp]
             L.rxhost_ivf_range.restype = _l
             L.rxhost_ivf_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
             L.rxhost_ivf_probed_rows.restype = _l
@@ -1036,6 +1037,16 @@ class GpuIvfFlat:
         if rc:
             _raise(rc)
         return d[:k], l[:k]
+
+    def search_batch(self, x, k: int, nprobe: int = 1):
+        """x [n][dim] -> (distances [n][k], labels [n][k]): GpuIvfFlat::SearchBatch, the queries side by side on a few streams."""
+        x = _f32(x).reshape(-1, self.dim)
+        n = x.shape[0]
+        d, l = np.empty((n, max(k, 1)), np.float32), np.empty((n, max(k, 1)), np.int64)
+        rc = lib().rxhost_ivf_search_batch(self.h, n, x.ctypes.data, k, nprobe, d.ctypes.data, l.ctypes.data)
+        if rc:
+            _raise(rc)
+        return d[:, :k], l[:, :k]
 
     def range_search(self, x, radius: float, nprobe: int = 1, cap: int = 1 << 16):
         x = _f32(x)

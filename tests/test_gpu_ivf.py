@@ -258,3 +258,75 @@ def test_c_abi_list_search_equals_subset_search_over_the_probed_lists(rxgpu, ora
         ix.upload_rows(n - 1, rows[-1:], inv[-1:] if inv is not None else None)   # same count: lists stay valid
         ix.search_knn_lists(cx, rows[0] if metric != 2 else oracle.normalize_copy(rows[0])[0], 2, 3)
     assert kept.size <= n
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_c_abi_wide_probes_and_range_over_device_lists(rxgpu, oracle, metric):
+    """More lists than the resident coarse search returns (nprobe 65..128: the wide fused select; above: list ids through the host, the
+    lists themselves stay in HBM), and rxgpu_search_range_lists == rxgpu_search_range_subset over the union of the probed lists."""
+    n, d, nlist = 9000, 24, 300
+    rng = np.random.default_rng(400 + metric)
+    rows = clustered(17, n, d, 40)
+    cents = clustered(18, nlist, d, 40)
+    owner = rng.integers(0, nlist, n)
+    lists = [np.flatnonzero(owner == l).astype(np.uint32) for l in range(nlist)]
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    cinv = oracle.l2_modules(cents) if metric == 2 else None
+    with rxgpu.VectorIndex(metric, d, n) as ix, rxgpu.VectorIndex(metric, d, nlist) as cx:
+        ix.upload_rows(0, rows, inv)
+        cx.upload_rows(0, cents, cinv)
+        ix.set_lists(lists)
+        for qi in range(6):
+            q = clustered(500 + qi, 1, d, 40)[0]
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            for nprobe, k in ((3, 10), (64, 10), (65, 20), (100, 7), (128, 128), (129, 10), (250, 50), (300, 10), (1000, 10)):
+                np_eff = min(nprobe, nlist)
+                _, crow, ccnt = cx.search_knn(q, np_eff)
+                probed = crow[0, :int(ccnt[0])]
+                want_rows = np.sort(np.concatenate([lists[int(l)] for l in probed]))
+                gd, gr, scanned = ix.search_knn_lists(cx, q, nprobe, k)
+                assert scanned == want_rows.size, (nprobe, scanned, want_rows.size)
+                wd, wr, wc = ix.search_knn_subset(q, k, want_rows)
+                c = int(wc[0])
+                assert np.array_equal(gr, wr[0, :c]) and np.array_equal(bits(gd), bits(wd[0, :c])), (metric, qi, nprobe, k)
+                # range: a radius that takes the k best of the probed rows
+                if c >= 2 and wd[0, c - 1] > wd[0, 0]:
+                    radius = float(wd[0, c - 1])
+                    rd, rr, rscanned = ix.search_range_lists(cx, q, nprobe, radius, inclusive=False, cap=4)   # cap 4: the overflow protocol too
+                    sd, sr = ix.search_range_subset(q, radius, want_rows, inclusive=False)
+                    assert rscanned == want_rows.size
+                    assert np.array_equal(rr, sr) and np.array_equal(bits(rd), bits(sd)), (metric, qi, nprobe)
+                    assert rr.size >= 1 and np.all(rd < radius)
+                    rd2, rr2, _ = ix.search_range_lists(cx, q, nprobe, radius, inclusive=True)
+                    assert rr2.size > rr.size
+
+
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_ivf_batch_and_wide_probe_searches_equal_single_searches(hostapi, oracle, metric):
+    """GpuIvfFlat::SearchBatch (queries side by side on several streams) == the same queries one by one; nprobe beyond 64 / 128 lists
+    and RangeSearch go through the device lists and still equal the exact search over ProbedRows."""
+    n, d, nlist = 8000, 32, 200
+    rows = clustered(27, n, d, 25)
+    ivf = hostapi.GpuIvfFlat(metric, d, nlist)
+    ivf.add_with_ids(rows, np.arange(n, dtype=np.int64) * 3 + 1)
+    ivf.train()
+    qs = clustered(28, 24, d, 25)
+    for nprobe in (4, 100, 180):
+        bd, bl = ivf.search_batch(qs, 10, nprobe=nprobe)
+        for i in range(qs.shape[0]):
+            sd, sl = ivf.search(qs[i], 10, nprobe=nprobe)
+            assert np.array_equal(bl[i], sl) and np.array_equal(bits(bd[i]), bits(sd)), (metric, nprobe, i)
+        # the range search over the same probe equals a filter of a wide KNN over the probed rows
+        q = qs[0]
+        cand = ivf.probed_rows(q, nprobe)
+        kd, kl = ivf.search(q, 40, nprobe=nprobe)
+        valid = kl >= 0
+        kd, kl = kd[valid], kl[valid]
+        if kd.size >= 12 and kd[10] != kd[11]:
+            radius = float(kd[11])
+            rd, rl = ivf.range_search(q, radius, nprobe=nprobe)
+            inside = kd < radius if metric == 0 else kd > radius
+            assert set(rl.tolist()) == set(kl[inside].tolist()), (metric, nprobe, rd.size, int(inside.sum()))
+        assert cand.size > 0
+    ivf.close()
