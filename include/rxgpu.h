@@ -361,6 +361,33 @@ int rxgpu_ft_merge_query_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 							 const int32_t* phrase_num, const int32_t* distance, const uint32_t* sub_off, const uint32_t* word_ids, const float* procs,
 							 const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap,
 							 uint64_t* out_n, int32_t* out_preselected);
+/* The whole QueryMergeData (querymergedata.h:191-242) in one description: query parts (terms, phrases) AND multi-word synonyms.
+ * Terms [0, nterms) make up the query parts exactly as in rxgpu_ft_merge_query_raw; terms [nterms, nterms + nsyn_terms) are the terms of the
+ * nsyn multi-word synonyms (Synonym::Terms(), querymergedata.h:178-192), synonym s owning terms nterms + syn_term_off[s] .. nterms +
+ * syn_term_off[s + 1]; every per-term array has nterms + nsyn_terms entries (phrase_num / distance of a synonym's term are ignored).
+ * part_syn_off [nparts + 1] / part_syn: PhraseOrTerm::SynonymsIds() of every query part (nparts = the number of parts the terms form).
+ * suppressed (may be NULL): SubtermResults::Suppressed() per sub-term — what QueryMergeData::SupressDuplicatesInSynonyms (:221-241) set.
+ * The merge: buildRestrictingBitmask with the synonyms' masks (mergerimpl.h:347-361), their terms in the pre-scores (:393-397) and in the
+ * 2-phase estimate (merger.h:251-255), mergeTerm for every synonym term behind the query parts with the term counting, the
+ * containsFullMultiWordSynonym rule and the removal of documents that hold only parts of a synonym (:509-555).  A query without
+ * synonyms is rxgpu_ft_merge_query_raw's. */
+typedef struct rxgpu_ft_query {
+	uint32_t nterms, nsyn_terms;
+	const int32_t* ops;
+	const rxgpu_ft_term_opts* opts;
+	const int32_t* phrase_num;      /* may be NULL */
+	const int32_t* distance;        /* may be NULL */
+	const uint32_t* sub_off;        /* [nterms + nsyn_terms + 1] */
+	const uint32_t* word_ids;
+	const float* procs;
+	const uint8_t* suppressed;      /* per sub-term, may be NULL */
+	uint32_t nsyn;
+	const uint32_t* syn_term_off;   /* [nsyn + 1] */
+	const uint32_t* part_syn_off;   /* [nparts + 1], may be NULL when nsyn == 0 */
+	const uint32_t* part_syn;
+} rxgpu_ft_query;
+int rxgpu_ft_merge_query2_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* query, const uint8_t* excluded, uint32_t* out_doc,
+							  float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n, int32_t* out_preselected);
 /* ---------------------------------------------------------------------------------------------------------
  * Hybrid rank fusion on the device: MergerRankedImpl + mergeRanked (cpp_src/core/nsselecter/selectiteratorcontainer.cc:
  * 1343-1423, 1454-1559), RanksHolder::InitRRFPositions (ranks_holder.h:61-76), RerankerRRF / RerankerLinear (core/sorting/reranker.h:11-39),

@@ -740,10 +740,18 @@ class RefFt:
         elif bm25_type != "rx":
             raise RuntimeError("oracle/_ref/libref_ft.so predates the bm25Type switch: rebuild with `make -C oracle ref`")
 
-    def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16):
+    def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16, synonyms=None, part_synonyms=None):
         """terms: list of dict(op, opts (FtOracle.default_opts-like), subs=[(word_id, proc), ...][, phrase=<phraseNum>, distance=<d>]);
-        consecutive terms with the same phrase number >= 0 form one phrase (the shim groups them like Selector::Process)."""
+        consecutive terms with the same phrase number >= 0 form one phrase (the shim groups them like Selector::Process).
+        synonyms: [[term, ...], ...] multi-word synonyms (Synonym::Terms()); part_synonyms[i]: ids of the synonyms of query part i."""
         nf = self.nf
+        n_part_terms = len(terms)
+        syn_off = [0]
+        if synonyms:
+            terms = list(terms)
+            for syn in synonyms:
+                terms.extend(syn)
+                syn_off.append(len(terms) - n_part_terms)
         phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
         dst = np.array([t.get("distance", 1) for t in terms], np.int32)
         ops = np.array([t["op"] for t in terms], np.int32)
@@ -761,6 +769,22 @@ class RefFt:
         exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
         oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
         of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        if synonyms:
+            nparts = sum(1 for i in range(n_part_terms) if phr[i] < 0 or i == 0 or phr[i - 1] != phr[i])
+            ps_off, ps = [0], []
+            for pi in range(nparts):
+                ps.extend(part_synonyms[pi] if part_synonyms and pi < len(part_synonyms) else [])
+                ps_off.append(len(ps))
+            syn_off_a, ps_off_a, ps_a = np.array(syn_off, np.uint32), np.array(ps_off, np.uint32), np.array(ps + [0], np.uint32)
+            fn = self.L.ref_ft_merge_full
+            fn.restype = C.c_long
+            fn.argtypes = [_vp, _sz, _sz] + [_vp] * 10 + [_sz] + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _sz]
+            n = fn(self.h, n_part_terms, len(terms) - n_part_terms, ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data,
+                   phr.ctypes.data, dst.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, len(synonyms), syn_off_a.ctypes.data,
+                   ps_off_a.ctypes.data, ps_a.ctypes.data, exc.ctypes.data if exc is not None else None, rank_sort_type, oid.ctypes.data, op.ctypes.data,
+                   of.ctypes.data, on.ctypes.data, cap)
+            assert 0 <= n <= cap, n
+            return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy()
         fn = getattr(self.L, "ref_ft_merge_phrases", None)
         if fn is None:
             if (phr >= 0).any():

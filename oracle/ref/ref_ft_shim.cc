@@ -109,13 +109,37 @@ void ref_ft_set_bm25_type(void* h, int type) {
 // rankSortType: 0 RankOnly, 1 RankAndID, 3 IDOnly, 4 IDAndPositions.  Returns the result count (<= cap written).
 // phraseNum / distance: FtDslOpts::phraseNum (-1: a plain term) and FtDslOpts::distance per term, or null.  The query parts are put
 // together the way Selector::Process does (selecterimpl.h:482-572): consecutive terms with the same phraseNum >= 0 become one PhraseResults.
-long ref_ft_merge_phrases(void* h, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
-						  const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord,
-						  const float* subProc, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField,
-						  uint8_t* outNorm, size_t cap) {
+// ... plus multi-word synonyms: the per-term arrays hold nTerms + nSynTerms entries, synonym s owns the terms nTerms + synTermOff[s] ..
+// nTerms + synTermOff[s + 1]; partSynOff [parts + 1] / partSyn: PhraseOrTerm::SynonymsIds of every query part.  The selecter's
+// SupressDuplicatesInSynonyms (selecterimpl.h:606) is called before the merge, like Selector::Process does.
+long ref_ft_merge_full(void* h, size_t nTerms, size_t nSynTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+					   const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord,
+					   const float* subProc, size_t nSyn, const uint32_t* synTermOff, const uint32_t* partSynOff, const uint32_t* partSyn,
+					   const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
 	auto* f = static_cast<FtRef*>(h);
 	try {
 		ft::QueryMergeData<IdRelVec> q;
+		auto makeTerm = [&](size_t t, int phrase, int dist) {
+			FtDslOpts o;
+			o.phraseNum = phrase;
+			o.distance = dist;
+			o.op = OpType(ops[t]);
+			o.boost = boosts[t];
+			o.termLenBoost = termLenBoosts[t];
+			o.fieldsOpts.resize(f->nf);
+			for (size_t i = 0; i < f->nf; ++i) {
+				o.fieldsOpts[i].boost = fieldBoost[t * f->nf + i];
+				o.fieldsOpts[i].needSumRank = needSum[t * f->nf + i] != 0;
+			}
+			ft::TermResults<IdRelVec> tr{FtDSLEntry(std::wstring(L"t") + std::to_wstring(t), o)};
+			for (uint32_t s = subOff[t]; s < subOff[t + 1]; ++s) {
+				WordIdType wid;
+				wid.data = 0;
+				wid.SetID(int32_t(subWord[s]));
+				tr.AddSubterm(*f->postings.at(subWord[s]), std::string_view("w"), wid, subProc[s]);
+			}
+			return tr;
+		};
 		int curPhraseNum = -1;
 		ft::PhraseResults<IdRelVec> nextPhrase;
 		for (size_t t = 0; t < nTerms; ++t) {
@@ -158,6 +182,21 @@ long ref_ft_merge_phrases(void* h, size_t nTerms, const int* ops, const float* b
 			q.queryParts.emplace_back(std::move(nextPhrase));
 			nextPhrase.clear();
 		}
+		for (size_t sy = 0; sy < nSyn; ++sy) {
+			ft::Synonym<IdRelVec> syn;
+			for (uint32_t k = synTermOff[sy]; k < synTermOff[sy + 1]; ++k) {
+				auto tr = makeTerm(nTerms + k, -1, 1);
+				q.totalORVids += tr.MaxVDocs();   // selecterimpl.h:443, 462, 595
+				syn.AddTerm(std::move(tr));
+			}
+			q.synonyms.emplace_back(std::move(syn));
+		}
+		if (nSyn) {
+			for (size_t pi = 0; pi < q.queryParts.size(); ++pi) {
+				for (uint32_t k = partSynOff[pi]; k < partSynOff[pi + 1]; ++k) q.queryParts[pi].AddSynonymId(partSyn[k]);
+			}
+			q.SupressDuplicatesInSynonyms();
+		}
 		FtMergeStatuses::Statuses st;
 		st.resize(f->totalDocs, false);
 		if (excluded) {
@@ -189,6 +228,13 @@ long ref_ft_merge_phrases(void* h, size_t nTerms, const int* ops, const float* b
 	}
 }
 
+long ref_ft_merge_phrases(void* h, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+						  const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord,
+						  const float* subProc, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField,
+						  uint8_t* outNorm, size_t cap) {
+	return ref_ft_merge_full(h, nTerms, 0, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord, subProc, 0, nullptr, nullptr,
+							 nullptr, excluded, rankSortType, outId, outProc, outField, outNorm, cap);
+}
 long ref_ft_merge(void* h, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
 				  const uint8_t* needSum, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
 				  int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {

@@ -364,7 +364,11 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 			__syncthreads();   // the next sub-term of the term sees this one's documents
 		}
 		if (op == 2) {   // restrictingMask_ &= termMask (an AND term without postings empties the range)
-			for (uint32_t w = tid; w < kWords; w += 256) s_mask[w] &= s_term[w];
+			const uint32_t* syn_mask = term.syn_mask;   // termMask |= synMask of the part's multi-word synonyms (mergerimpl.h:347-361), ft_syn_masks
+			for (uint32_t w = tid; w < kWords; w += 256) {
+				const uint64_t gw = d_begin / 32 + w;
+				s_mask[w] &= s_term[w] | ((syn_mask && gw < p.nwords) ? syn_mask[gw] : 0u);
+			}
 			__syncthreads();
 		}
 		FT_STAMP(p, 11 + (t < 4 ? t : 4));
@@ -733,7 +737,10 @@ __global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
 				const FtTermCfg& t = s_termd[g];
 				const uint64_t i = uint64_t(tile - s_base[g]) * kFtBlockPostings + local;
 				d[u] = s_doc[e];
-				if (s.pre_rank) {   // a phrase row: mergePhrase takes the PhraseMerger's rank and field as they are (mergerimpl.h:46-62)
+				if (s.suppressed) {   // mergerimpl.h:144-151: no rank; the record only counts the term for a document that is merged already
+					rank[u] = __uint_as_float(kFtSuppressedRank);
+					field[u] = 0;
+				} else if (s.pre_rank) {   // a phrase row: mergePhrase takes the PhraseMerger's rank and field as they are (mergerimpl.h:46-62)
 					rank[u] = s.pre_rank[i];
 					field[u] = s.pre_field[i];
 				} else {
@@ -817,6 +824,7 @@ __global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
 	const uint4* rec = p.b_rec + p.bucket_off[range];
 	for (uint32_t e = tid; e < n; e += 256) {
 		const uint4 r = rec[e];
+		if (r.z == kFtSuppressedRank) continue;   // a suppressed sub-term never adds a document
 		lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
 	}
 	__syncthreads();
@@ -824,6 +832,7 @@ __global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
 	for (uint32_t e = tid; e < n; e += 256) {
 		const uint4 r = rec[e];
 		const uint32_t row = r.w & 0xFFFFu;
+		if (r.z == kFtSuppressedRank) continue;
 		if (lds_get_u16(s_tab, r.x & (kFtRangeDocs - 1)) != row) continue;   // one posting per (document, row): exactly one record adds the document
 		if (lds_rows) {
 			atomicAdd(&s_rowcnt[row], 1u);
@@ -946,7 +955,26 @@ struct FtReplayStateT {
 	uint8_t field = 0;
 	Pos last, next;
 	uint16_t switched_term = 0, last_counted = 0, terms_counter = 0;
+	// multi-word synonyms (mergerimpl.h:509-555): the qp the document was created at, the synonyms whose end has been applied to it,
+	// MergerDocumentData::containsFullMultiWordSynonym
+	uint16_t created_qp = 0, syn_done = 0;
+	bool contains_full = false;
 };
+// The loop behind every synonym's terms (mergerimpl.h:516-523), applied lazily: a document created by a synonym's term keeps its term count
+// only if it met every term of the synonym that just ended.  Called with the qp of the posting about to be applied (or past the last).
+template <typename Pos>
+__device__ __forceinline__ void ft_replay_synonym_ends(const FtPlan& p, FtReplayStateT<Pos>& st, uint32_t qp) {
+	while (st.syn_done < p.n_syn && p.syns[st.syn_done].end_qp < qp) {
+		if (st.created && st.created_qp > p.n_part_qp) {
+			if (st.terms_counter < p.syns[st.syn_done].nterms) {
+				st.terms_counter = 0;
+			} else {
+				st.contains_full = true;
+			}
+		}
+		st.syn_done = uint16_t(st.syn_done + 1);
+	}
+}
 using FtReplayState = FtReplayStateT<FtPosList>;
 // one posting of the document, met in sub-term order: (rank r, field fld, posting index i) of sub-term row `row`
 // the positions of posting i of sub-term row `row`, and the query position of its term
@@ -973,6 +1001,14 @@ __device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, 
 template <typename Pos>
 __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<Pos>& st, float r, uint8_t fld, uint32_t qpw, const Pos& pos) {
 	const uint16_t qp = uint16_t(qpw & 0x7FFFu);
+	if (p.n_syn) ft_replay_synonym_ends(p, st, qp);
+	if (__float_as_uint(r) == kFtSuppressedRank) {   // mergerimpl.h:144-151: a merged document counts the term, nothing else
+		if (st.created && st.last_counted < qp) {
+			st.terms_counter = uint16_t(st.terms_counter + 1);
+			st.last_counted = qp;
+		}
+		return;
+	}
 	if (p.simple) {   // mergeSimple, mergerimpl.h:232-240: strict <, so the first maximum (and its field) wins
 		if (!st.created) {
 			st.created = true;
@@ -995,6 +1031,7 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<
 			st.switched_term = qp;
 			st.last_counted = qp;
 			st.terms_counter = 1;
+			st.created_qp = qp;
 			return;
 		}
 		// the switchToNextWord calls of the plain terms between the document's last posting and this phrase (merger.h:218-226) come first
@@ -1025,6 +1062,7 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<
 		st.switched_term = qp;
 		st.last_counted = qp;
 		st.terms_counter = 1;
+		st.created_qp = qp;
 		return;
 	}
 	// ---- document already merged: mergerimpl.h:165-189
@@ -1062,12 +1100,21 @@ __device__ __forceinline__ void ft_replay_step(const FtPlan& p, FtReplayState& s
 // multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts
 // are resident: on the host it was one cache miss per merged document.
 template <typename Pos>
-__device__ __forceinline__ void ft_replay_finish(const FtPlan& p, const FtReplayStateT<Pos>& st, uint32_t sl, uint32_t doc, bool have_words = false,
+__device__ __forceinline__ void ft_replay_finish(const FtPlan& p, FtReplayStateT<Pos>& st, uint32_t sl, uint32_t doc, bool have_words = false,
 												 float words0 = 0.f) {
+	if (p.n_syn) {
+		ft_replay_synonym_ends(p, st, 0xFFFFFFFFu);
+		if (st.created_qp > p.n_part_qp && !st.contains_full) {   // only parts of a multi-word synonym: removed (mergerimpl.h:533-555; the host compacts)
+			p.out_proc[sl] = 0.f;
+			p.out_field[sl] = st.field;
+			p.out_terms_counter[sl] = 0xFFFFu;
+			return;
+		}
+	}
 	float proc = st.proc;
 	const FtTermCfg& t0 = p.terms[0];
 	const float words = have_words ? words0 : t0.words[size_t(doc) * t0.num_fields + st.field];
-	const bool full = p.simple ? words == 1.0f : (st.terms_counter == p.nterms && words == float(p.query_len));
+	const bool full = p.simple ? words == 1.0f : (st.terms_counter == p.n_parts && words == float(p.query_len));
 	if (full) proc = float(double(proc) * p.full_match_boost);
 	p.out_proc[sl] = proc;
 	p.out_field[sl] = st.field;
@@ -1200,14 +1247,14 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			FT_STAMP(p, 33);
 			for (uint32_t e = tid; e < nw; e += 256) {
 				const uint4 r = rec[e];
-				atomicMin(&s_slot[r.x & (kFtRangeDocs - 1)], r.w & 0xFFFFu);
+				if (r.z != kFtSuppressedRank) atomicMin(&s_slot[r.x & (kFtRangeDocs - 1)], r.w & 0xFFFFu);
 			}
 			__syncthreads();
 			FT_STAMP(p, 34);
 			for (uint32_t e = tid; e < nw; e += 256) {   // the range's first postings; the record remembers that it adds its document
 				const uint4 r = rec[e];
 				const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
-				if (s_slot[dl] != row) continue;
+				if (s_slot[dl] != row || r.z == kFtSuppressedRank) continue;
 				atomicOr(&s_bits[row * (kFtRangeDocs / 32) + (dl >> 5)], 1u << (dl & 31));
 				rec[e].w = r.w | 0x80000000u;
 			}
@@ -1238,7 +1285,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 				const uint32_t word = row * (kFtRangeDocs / 32) + (dl >> 5);
 				const uint32_t rank = s_pref[word] + __popc(s_bits[word] & ((1u << (dl & 31)) - 1u));
 				const uint32_t slot = (own_bases ? s_rowbase[row] : p.adders[uint64_t(row) * p.n_ranges + range]) + rank;
-				s_slot[dl] = slot;   // every document with a record has exactly one first posting: no first-row value is left behind
+				s_slot[dl] = slot;   // every document with an unsuppressed record has exactly one first posting (the others keep 0xFFFFFFFF: never merged)
 				if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
 			}
 			__syncthreads();
@@ -1250,14 +1297,14 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			FT_STAMP(p, 33);
 			for (uint32_t e = tid; e < nw; e += 256) {
 				const uint4 r = rec[e];
-				lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
+				if (r.z != kFtSuppressedRank) lds_min_u16(s_tab, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
 			}
 			__syncthreads();
 			FT_STAMP(p, 34);
 			for (uint32_t e = tid; e < nw; e += 256) {   // the range's first postings: key (row, document); the record remembers that it adds
 				const uint4 r = rec[e];
 				const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
-				if (lds_get_u16(s_tab, dl) != row) continue;
+				if (lds_get_u16(s_tab, dl) != row || r.z == kFtSuppressedRank) continue;
 				s_keys[atomicAdd(&s_nadd, 1u)] = (row << kFtRangeShift) | dl;
 				rec[e].w = r.w | 0x80000000u;
 			}
@@ -1308,7 +1355,12 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			}
 			__syncthreads();
 		}
-		auto slot_of = [&](uint32_t dl) -> uint32_t { return few_rows ? ft_finish_lds[dl] : s_keys[lds_get_u16(s_tab, dl)]; };
+		// (a document whose only records are a suppressed sub-term's has no first posting: slot 0xFFFFFFFF = never merged)
+		auto slot_of = [&](uint32_t dl) -> uint32_t {
+			if (few_rows) return ft_finish_lds[dl];
+			const uint32_t at = lds_get_u16(s_tab, dl);
+			return at == 0xFFFFu ? 0xFFFFFFFFu : s_keys[at];
+		};
 		// ---- a sparse bucket (the usual one after a preselect: a few hundred records): the records go into LDS and the thread of every
 		// first posting collects its document's other postings from there — no entry rows in global memory, i.e. no scatter, no gather
 		// chain in front of the position loads, nothing to hand back zeroed.  A document with more than kFtSparsePostings postings
@@ -1515,10 +1567,62 @@ hipError_t launch_ft_import(const void* host_plan, void* dev_plan, size_t bytes,
 }
 
 // ---------------------------------------------------------------------------------------------- launch train
+// buildRestrictingBitmask's synonym half (mergerimpl.h:347-361): for every AND part with multi-word synonyms, the documents that hold EVERY
+// term of ONE of its synonyms (calcTermBitmask per term :252-274: any occurrence with a relevant field; AccumulateAnd over the synonym's
+// terms; OR over the part's synonyms).  One workgroup per range of kFtRangeDocs documents, bitmaps in LDS; runs in front of ft_ranges only
+// when the query has such parts.
+__global__ __launch_bounds__(256) void ft_syn_masks(FtPlan p) {
+	constexpr uint32_t kWords = kFtRangeDocs / 32;
+	__shared__ uint32_t s_or[kWords], s_and[kWords], s_tmp[kWords];
+	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	const uint64_t d_begin = uint64_t(range) * kFtRangeDocs;
+	for (uint32_t j = 0; j < p.n_syn_jobs; ++j) {
+		const FtSynMaskJob job = p.syn_jobs[j];
+		for (uint32_t w = tid; w < kWords; w += 256) s_or[w] = 0;
+		for (uint32_t k = job.syn_begin; k < job.syn_end; ++k) {
+			const FtSynonym syn = p.syns[p.job_syns[k]];
+			for (uint32_t w = tid; w < kWords; w += 256) s_and[w] = 0xFFFFFFFFu;
+			for (uint32_t t = syn.term_begin; t < syn.term_end; ++t) {
+				const FtTermCfg& term = p.terms[t];
+				for (uint32_t w = tid; w < kWords; w += 256) s_tmp[w] = 0;
+				__syncthreads();
+				for (uint32_t si = term.sub_begin; si < term.sub_end; ++si) {
+					const FtPosSubterm& sub = p.subs[si];
+					const uint32_t lo = range < sub.n_ranges ? sub.range_off[range] : uint32_t(sub.n);
+					const uint32_t hi = range + 1 < sub.n_ranges ? sub.range_off[range + 1] : uint32_t(sub.n);
+					for (uint32_t i = lo + tid; i < hi; i += 256) {
+						bool rel = term.all_pos_boost != 0;
+						if (!rel) {   // checkFieldsRelevance (phrasemergerimpl.h:93-125)
+							for (uint32_t e = sub.ent_off[i], e1 = sub.ent_off[i + 1]; e < e1 && !rel; ++e) rel = term.field_boost[sub.ent_field[e]] != 0.0f;
+						}
+						if (rel) {
+							const uint32_t local = uint32_t(sub.doc[i] - d_begin);
+							atomicOr(&s_tmp[local >> 5], 1u << (local & 31));
+						}
+					}
+				}
+				__syncthreads();
+				for (uint32_t w = tid; w < kWords; w += 256) s_and[w] &= s_tmp[w];
+			}
+			__syncthreads();
+			if (syn.term_end > syn.term_begin) {   // (AccumulateAnd over no term leaves an empty mask: nothing to OR)
+				for (uint32_t w = tid; w < kWords; w += 256) s_or[w] |= s_and[w];
+			}
+			__syncthreads();
+		}
+		for (uint32_t w = tid; w < kWords; w += 256) {
+			const uint64_t gw = d_begin / 32 + w;
+			if (gw < p.nwords) job.out[gw] = s_or[w];
+		}
+		__syncthreads();
+	}
+}
+
 hipError_t launch_ft_merge(const FtPlan& p, hipStream_t st) {
 	constexpr size_t kFinishLds = (kFtRangeDocs / 2 + kFtRangeDocs) * sizeof(uint32_t);
 	static std::atomic<uint64_t> raised{0};
 	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&ft_finish), kFinishLds); e != hipSuccess) return e;
+	if (p.n_syn_jobs) hipLaunchKernelGGL(ft_syn_masks, dim3(p.n_ranges), dim3(256), 0, st, p);
 	hipLaunchKernelGGL(ft_ranges, dim3(p.n_ranges), dim3(256), 0, st, p);
 	if (!p.simple && p.prescore) {
 		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);

@@ -357,6 +357,14 @@ struct QueryTermIn {
 	int32_t phrase_num = -1;   // FtDslOpts::phraseNum: consecutive terms with the same number >= 0 are one phrase (selecterimpl.h:482-572)
 	int32_t distance = 1;      // FtDslOpts::distance (the phrase's terms)
 };
+// multi-word synonyms of a query (rxgpu_ft_query): their terms are terms[first_term ..] of run_merge's list
+struct SynonymsIn {
+	uint32_t nsyn = 0, first_term = 0;
+	const uint32_t* syn_term_off = nullptr;   // [nsyn + 1], relative to first_term
+	const uint32_t* part_syn_off = nullptr;   // [nparts + 1]
+	const uint32_t* part_syn = nullptr;
+	const uint8_t* suppressed = nullptr;      // per sub-term
+};
 // a query part (PhraseOrTerm, querymergedata.h:145-176): one plain term or the terms [t_begin, t_end) of one phrase
 struct QueryPartIn {
 	bool phrase;
@@ -665,37 +673,49 @@ int finish_pending(rxgpu_ft_index* h, const char* who) {
 // Shared implementation of rxgpu_ft_merge_simple_raw / rxgpu_ft_merge_terms_raw.  out_terms_counter may be null (simple).
 int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
-			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false) {
+			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false, const SynonymsIn* synonyms = nullptr) {
 	using clk = std::chrono::steady_clock;
 	if (int rc = finish_pending(h, who); rc) return rc;
 	const auto t_begin = clk::now();
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
 	const uint32_t nf = h->num_fields;
 	const uint64_t N = h->total_docs;
-	const uint32_t nterms = uint32_t(terms.size());
+	const uint32_t nterms = uint32_t(terms.size());   // the query parts' terms, then the synonyms' terms
+	const uint32_t nsyn = synonyms ? synonyms->nsyn : 0;
+	const uint32_t npart_terms = nsyn ? synonyms->first_term : nterms;
+	const uint32_t nsyn_terms = nterms - npart_terms;
 	const int bm25_type = cfg->bm25_type;
 	RX_CHECK(bm25_type >= 0 && bm25_type <= 2, RXGPU_ERR_PARAMS, std::string(who) + ": bm25_type must be 0 (rx), 1 (classic) or 2 (wordCount)");
+	RX_CHECK(!nsyn || !resident, RXGPU_ERR_LOGIC, std::string(who) + ": a query with multi-word synonyms has no resident form (the removed documents are compacted on the host)");
 
 	// ---- the query parts (selecterimpl.h:482-572): consecutive terms with the same phraseNum >= 0 are one phrase
 	std::vector<QueryPartIn> parts;
-	for (uint32_t t = 0; t < nterms;) {
+	for (uint32_t t = 0; t < npart_terms;) {
 		if (terms[t].phrase_num < 0) {
 			parts.push_back({false, t, t + 1});
 			++t;
 			continue;
 		}
 		uint32_t e = t + 1;
-		while (e < nterms && terms[e].phrase_num == terms[t].phrase_num) ++e;
+		while (e < npart_terms && terms[e].phrase_num == terms[t].phrase_num) ++e;
 		parts.push_back({true, t, e});
 		t = e;
 	}
 	const uint32_t nparts = uint32_t(parts.size());
 	RX_CHECK(nparts < 0x7FFF, RXGPU_ERR_PARAMS, std::string(who) + ": too many query parts");
-	RX_CHECK(!simple || (nparts == 1 && !parts[0].phrase), RXGPU_ERR_LOGIC, std::string(who) + ": a phrase is not a Simple() query");
+	RX_CHECK(!simple || (nparts == 1 && !parts[0].phrase && !nsyn), RXGPU_ERR_LOGIC, std::string(who) + ": a phrase is not a Simple() query");
+	if (nsyn) {
+		RX_CHECK(synonyms->syn_term_off && synonyms->part_syn_off && synonyms->syn_term_off[0] == 0 && synonyms->syn_term_off[nsyn] == nsyn_terms &&
+					 synonyms->part_syn_off[0] == 0,
+				 RXGPU_ERR_PARAMS, std::string(who) + ": inconsistent synonym tables");
+		for (uint32_t k = 0; k < synonyms->part_syn_off[nparts]; ++k) {
+			RX_CHECK(synonyms->part_syn && synonyms->part_syn[k] < nsyn, RXGPU_ERR_PARAMS, std::string(who) + ": synonym id out of range");
+		}
+	}
 
 	// ---- the plan: sub-terms, per-part configuration, the posting-side grid
 	std::vector<rxgpu::FtPosSubterm> subs;
-	std::vector<rxgpu::FtTermCfg> tcfg(nparts);
+	std::vector<rxgpu::FtTermCfg> tcfg(nparts + nsyn_terms);
 	std::vector<rxgpu::FtGridEntry> merge_grid;
 	std::vector<uint64_t> term_postings(nterms, 0);
 	uint64_t total_vids = 0, merged_postings = 0, merge_blocks = 0;
@@ -741,7 +761,13 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		query_len += part.t_end - part.t_begin;
 		const int32_t op = terms[part.t_begin].op;   // PhraseResults::Op(): its first term's
 		if (op == 3) continue;
-		const uint64_t num_docs = part.phrase ? phrase_rows[pi].admitted : term_postings[part.t_begin];
+		uint64_t num_docs = part.phrase ? phrase_rows[pi].admitted : term_postings[part.t_begin];
+		if (nsyn) {   // + the first term of every synonym of the part (merger.h:251-255)
+			for (uint32_t k = synonyms->part_syn_off[pi]; k < synonyms->part_syn_off[pi + 1]; ++k) {
+				const uint32_t sy = synonyms->part_syn[k];
+				if (synonyms->syn_term_off[sy + 1] > synonyms->syn_term_off[sy]) num_docs += term_postings[npart_terms + synonyms->syn_term_off[sy]];
+			}
+		}
 		if (op == 2) {
 			est_and = std::min(est_and, num_docs);
 		} else {
@@ -809,6 +835,59 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		}
 		tc.sub_end = uint32_t(subs.size());
 	}
+	// ---- the multi-word synonyms' terms behind the parts (mergerimpl.h:509-514): plain mergeTerm calls, every term takes a qp
+	const uint32_t n_part_qp = qp;
+	std::vector<rxgpu::FtSynonym> syns(nsyn);
+	for (uint32_t sy = 0; sy < nsyn; ++sy) {
+		syns[sy].term_begin = nparts + synonyms->syn_term_off[sy];
+		syns[sy].term_end = nparts + synonyms->syn_term_off[sy + 1];
+		syns[sy].nterms = synonyms->syn_term_off[sy + 1] - synonyms->syn_term_off[sy];
+		for (uint32_t k = synonyms->syn_term_off[sy]; k < synonyms->syn_term_off[sy + 1]; ++k) {
+			const QueryTermIn& qt = terms[npart_terms + k];
+			rxgpu::FtTermCfg& tc = tcfg[nparts + k];
+			bool same, all_pos;
+			if (int rc = check_term_opts(qt, nf, who, same, all_pos); rc) return rc;
+			fill_term_cfg(tc, h, cfg, qt, same, all_pos);
+			tc.op = 1;   // for ft_ranges: scored like any term (calcTermScores, mergerimpl.h:393-397), never a restriction of its own
+			tc.sub_begin = uint32_t(subs.size());
+			RX_CHECK(qp < 0x7FFE, RXGPU_ERR_PARAMS, std::string(who) + ": too many query terms");
+			++qp;
+			for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
+				const rxgpu_ft_word& w = h->dict().find(word_ids[si])->second;
+				RX_CHECK(w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
+				RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
+						 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
+				if (!w.n) continue;
+				rxgpu::FtPosSubterm ft = word_subterm(w, bm25_type, N, procs[si]);
+				ft.term = nparts + k;
+				ft.qp = qt.op == 3 ? 0 : qp;
+				ft.ord_in_term = uint16_t(si - qt.sub_begin);
+				ft.suppressed = synonyms->suppressed && synonyms->suppressed[si] ? 1 : 0;
+				const uint32_t sub_index = uint32_t(subs.size());
+				if (qt.op != 3) {   // mergeTerm returns at once for a NOT term (mergerimpl.h:110-112)
+					ft.row = uint32_t(merge_grid.size());
+					merge_grid.push_back({uint32_t(merge_blocks), sub_index});
+					merge_blocks += rxgpu::ft_pass_blocks(w.n);
+					merged_postings += w.n;
+				}
+				subs.push_back(ft);
+			}
+			tc.sub_end = uint32_t(subs.size());
+		}
+		syns[sy].end_qp = qp;
+	}
+	// the AND parts whose term mask takes their synonyms' masks in (ft_syn_masks)
+	std::vector<rxgpu::FtSynMaskJob> syn_jobs;
+	std::vector<uint32_t> job_syns, job_part;
+	for (uint32_t pi = 0; pi < nparts && nsyn; ++pi) {
+		if (terms[parts[pi].t_begin].op != 2 || synonyms->part_syn_off[pi + 1] == synonyms->part_syn_off[pi]) continue;
+		rxgpu::FtSynMaskJob job{};
+		job.syn_begin = uint32_t(job_syns.size());
+		for (uint32_t k = synonyms->part_syn_off[pi]; k < synonyms->part_syn_off[pi + 1]; ++k) job_syns.push_back(synonyms->part_syn[k]);
+		job.syn_end = uint32_t(job_syns.size());
+		syn_jobs.push_back(job);
+		job_part.push_back(pi);
+	}
 	RX_CHECK(merge_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull, RXGPU_ERR_PARAMS,
 			 std::string(who) + ": more than 2^32 (padded) postings in one merge");
 	const uint32_t n_rows = uint32_t(merge_grid.size());
@@ -821,12 +900,17 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	// ---- device scratch (one buffer each for the state and for the packed result)
 	Carver cv;
 	const size_t o_plan_subs = cv.take(std::max<size_t>(1, subs.size()) * sizeof(rxgpu::FtPosSubterm));
-	const size_t o_plan_terms = cv.take(size_t(nparts) * sizeof(rxgpu::FtTermCfg));
+	const uint32_t nplan_terms = nparts + nsyn_terms;
+	const size_t o_plan_terms = cv.take(size_t(nplan_terms) * sizeof(rxgpu::FtTermCfg));
 	const size_t o_plan_mgrid = cv.take(std::max<size_t>(1, merge_grid.size()) * sizeof(rxgpu::FtGridEntry));
-	const size_t cfg_floats = size_t(6) * nf + size_t(nparts) * nf;
-	const size_t o_plan_fc = cv.take(cfg_floats * sizeof(float) + size_t(nparts) * nf);
+	const size_t cfg_floats = size_t(6) * nf + size_t(nplan_terms) * nf;
+	const size_t o_plan_fc = cv.take(cfg_floats * sizeof(float) + size_t(nplan_terms) * nf);
+	const size_t o_plan_syns = cv.take(std::max<size_t>(1, syns.size()) * sizeof(rxgpu::FtSynonym));
+	const size_t o_plan_jobs = cv.take(std::max<size_t>(1, syn_jobs.size()) * sizeof(rxgpu::FtSynMaskJob));
+	const size_t o_plan_jsyn = cv.take(std::max<size_t>(1, job_syns.size()) * 4);
 	const size_t plan_bytes = cv.off;   // everything above is uploaded in one copy
 	const size_t o_mask = cv.take(nwords * 4);
+	const size_t o_synmask = cv.take(syn_jobs.size() * nwords * 4);
 	const size_t o_score = cv.take(prescore ? nwords * 32 * 2 : 0);   // padded to whole mask words (ft_preselect_apply reads 32 scores at a time)
 	const uint32_t n_ranges = uint32_t((N + rxgpu::kFtRangeDocs - 1) / rxgpu::kFtRangeDocs);
 	const size_t o_brec = cv.take(size_t(merged_postings) * sizeof(uint4));
@@ -871,6 +955,22 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		}
 		point_term_cfg(tcfg[pi], d_fc, d_fc + size_t(6 + pi) * nf, d_need_sum + size_t(pi) * nf, nf);
 	}
+	for (uint32_t k = 0; k < nsyn_terms; ++k) {
+		const QueryTermIn& qt = terms[npart_terms + k];
+		const uint32_t ti = nparts + k;
+		for (uint32_t f = 0; f < nf; ++f) {
+			fc[size_t(6 + ti) * nf + f] = qt.opts->field_boost[f];
+			need_sum[size_t(ti) * nf + f] = qt.opts->need_sum_rank[f];
+		}
+		point_term_cfg(tcfg[ti], d_fc, d_fc + size_t(6 + ti) * nf, d_need_sum + size_t(ti) * nf, nf);
+	}
+	for (size_t j = 0; j < syn_jobs.size(); ++j) {
+		syn_jobs[j].out = reinterpret_cast<uint32_t*>(base + o_synmask) + j * nwords;
+		tcfg[job_part[j]].syn_mask = syn_jobs[j].out;
+	}
+	if (!syns.empty()) std::memcpy(hp + o_plan_syns, syns.data(), syns.size() * sizeof(rxgpu::FtSynonym));
+	if (!syn_jobs.empty()) std::memcpy(hp + o_plan_jobs, syn_jobs.data(), syn_jobs.size() * sizeof(rxgpu::FtSynMaskJob));
+	if (!job_syns.empty()) std::memcpy(hp + o_plan_jsyn, job_syns.data(), job_syns.size() * 4);
 	if (!subs.empty()) std::memcpy(hp + o_plan_subs, subs.data(), subs.size() * sizeof(rxgpu::FtPosSubterm));
 	std::memcpy(hp + o_plan_terms, tcfg.data(), tcfg.size() * sizeof(rxgpu::FtTermCfg));
 	if (!merge_grid.empty()) std::memcpy(hp + o_plan_mgrid, merge_grid.data(), merge_grid.size() * sizeof(rxgpu::FtGridEntry));
@@ -889,7 +989,14 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.merge_grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_plan_mgrid);
 	p.n_merge_entries = uint32_t(merge_grid.size());
 	p.merge_blocks = uint32_t(merge_blocks);
-	p.nterms = nparts;
+	p.nterms = nplan_terms;
+	p.n_parts = nparts;
+	p.n_part_qp = n_part_qp;
+	p.syns = reinterpret_cast<const rxgpu::FtSynonym*>(base + o_plan_syns);
+	p.n_syn = nsyn;
+	p.syn_jobs = reinterpret_cast<const rxgpu::FtSynMaskJob*>(base + o_plan_jobs);
+	p.job_syns = reinterpret_cast<const uint32_t*>(base + o_plan_jsyn);
+	p.n_syn_jobs = uint32_t(syn_jobs.size());
 	p.query_len = query_len;
 	p.n_rows = n_rows;
 	p.n_subs = uint32_t(subs.size());
@@ -986,13 +1093,28 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const uint64_t n = hdr[0];
 	RX_CHECK(n <= max_merged, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt result header");
 	h->clean_dirty = false;   // the merge ran to its end: ft_adders / ft_finish handed the tables back zeroed
-	if (n) {
+	uint64_t kept = n;
+	if (n && nsyn) {   // the documents that hold only parts of a multi-word synonym go (mergerimpl.h:533-555): the rest keeps its order
+		const uint32_t* sd = reinterpret_cast<const uint32_t*>(hp + align256(16));
+		const float* sp = reinterpret_cast<const float*>(hp + align256(16) + align256(M * 4));
+		const uint16_t* st_ = reinterpret_cast<const uint16_t*>(hp + align256(16) + 2 * align256(M * 4));
+		const uint8_t* sf = reinterpret_cast<const uint8_t*>(hp + align256(16) + 2 * align256(M * 4) + align256(M * 2));
+		kept = 0;
+		for (uint64_t i = 0; i < n; ++i) {
+			if (st_[i] == 0xFFFFu) continue;
+			out_doc[kept] = sd[i];
+			out_proc[kept] = sp[i];
+			if (out_terms_counter) out_terms_counter[kept] = st_[i];
+			out_field[kept] = sf[i];
+			++kept;
+		}
+	} else if (n) {
 		std::memcpy(out_doc, hp + align256(16), n * 4);
 		std::memcpy(out_proc, hp + align256(16) + align256(M * 4), n * 4);
 		if (out_terms_counter) std::memcpy(out_terms_counter, hp + align256(16) + 2 * align256(M * 4), n * 2);
 		std::memcpy(out_field, hp + align256(16) + 2 * align256(M * 4) + align256(M * 2), n);
 	}
-	*out_n = n;
+	*out_n = kept;
 	if (out_preselected) *out_preselected = hdr[2] ? 1 : 0;
 	h->trace_us[4] += since(t_unpack);
 	h->trace_us[5] += 1;
@@ -1343,6 +1465,42 @@ int rxgpu_ft_merge_query_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 	if (int rc = checkout_lane(h, ll); rc) return rc;
 	DevGuard dg(h->device);
 	return run_merge(ll.lane, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who);
+}
+
+int rxgpu_ft_merge_query2_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* q, const uint8_t* excluded, uint32_t* out_doc, float* out_proc,
+							  uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n, int32_t* out_preselected) {
+	const char* who = "rxgpu_ft_merge_query2_raw";
+	RX_CHECK(h && cfg && q && out_n, RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	*out_n = 0;
+	if (out_preselected) *out_preselected = 0;
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, std::string(who) + ": field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
+	RX_CHECK(q->nsyn > 0 || q->nsyn_terms == 0, RXGPU_ERR_PARAMS, std::string(who) + ": synonym terms without synonyms");
+	std::vector<QueryTermIn> terms;
+	bool empty = false, simple = false;
+	if (int rc = query_terms(who, q->nterms, q->ops, q->opts, q->phrase_num, q->distance, q->sub_off, q->word_ids, q->procs, terms, &empty, &simple); rc) return rc;
+	if (empty) return RXGPU_OK;   // QueryMergeData::Empty() looks at the query parts only
+	SynonymsIn syn;
+	if (q->nsyn) {
+		RX_CHECK(q->syn_term_off && q->part_syn_off, RXGPU_ERR_PARAMS, std::string(who) + ": null synonym tables");
+		for (uint32_t k = 0; k < q->nsyn_terms; ++k) {
+			const uint32_t t = q->nterms + k;
+			RX_CHECK(q->ops[t] >= 1 && q->ops[t] <= 3, RXGPU_ERR_PARAMS, std::string(who) + ": op must be 1 (OR), 2 (AND) or 3 (NOT)");
+			terms.push_back(QueryTermIn{q->ops[t], &q->opts[t], q->sub_off[t], q->sub_off[t + 1], -1, 1});
+		}
+		syn.nsyn = q->nsyn;
+		syn.first_term = q->nterms;
+		syn.syn_term_off = q->syn_term_off;
+		syn.part_syn_off = q->part_syn_off;
+		syn.part_syn = q->part_syn;
+		syn.suppressed = q->suppressed;
+		simple = false;
+	}
+	LaneLock ll;
+	if (int rc = checkout_lane(h, ll); rc) return rc;
+	DevGuard dg(h->device);
+	return run_merge(ll.lane, cfg, simple, terms, q->word_ids, q->procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who,
+					 false, q->nsyn ? &syn : nullptr);
 }
 
 int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,

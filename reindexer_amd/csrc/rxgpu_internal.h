@@ -150,8 +150,11 @@ struct FtPosSubterm {
 	const float* pre_rank;
 	const uint8_t* pre_field;
 	uint16_t prev_term_qp;     // phrase row: qp of the last plain term in front of the phrase (0: none) — the last switchToNextWord before it
-	uint16_t phrase;           // 1: phrase row
+	uint8_t phrase;            // 1: phrase row
+	uint8_t suppressed;        // SubtermResults::Suppressed() (querymergedata.h:32, set by SupressDuplicatesInSynonyms :221-241): the sub-term of a
+	                           // multi-word synonym is a word the query's own terms found already — its postings only count terms (mergerimpl.h:144-151)
 };
+constexpr uint32_t kFtSuppressedRank = 0x7FC00001u;   // rank bits of a suppressed sub-term's record (a NaN: never a rank, never 0)
 // (qp, phrase flag, prev_term_qp) of a row as the replay carries it
 __host__ __device__ inline uint32_t ft_row_qpw(const FtPosSubterm& s) { return uint32_t(s.qp) | (uint32_t(s.phrase) << 15) | (uint32_t(s.prev_term_qp) << 16); }
 struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslOpts of ONE query term
@@ -171,6 +174,20 @@ struct FtTermCfg {             // what calcTermRank reads: FTConfig + the FtDslO
 	uint8_t phrase;            // the part is a phrase: its sub-terms are the rows ft_phrase.hip produced; field_boost = ones
 	uint8_t pad0;
 	uint32_t phrase_proc16;    // PhraseResults::CalcProc16 (querymergedata.h:117-127): what GetMergedDocsScore adds (phrasemerger.h:326-333)
+	// an AND part with multi-word synonyms (PhraseOrTerm::SynonymsIds): the documents that hold EVERY term of one of them, as a bitmap over
+	// the documents — OR-ed into the part's term mask before it restricts (buildRestrictingBitmask, mergerimpl.h:347-361); ft_syn_masks
+	const uint32_t* syn_mask;
+};
+// Multi-word synonyms (QueryMergeData::synonyms, querymergedata.h:178-192): their terms follow the query parts in FtPlan::terms (op = OR for
+// the pre-score pass: calcTermScores counts them like any term, mergerimpl.h:393-397, and they never restrict on their own)
+struct FtSynonym {
+	uint32_t term_begin, term_end;   // its terms in FtPlan::terms
+	uint32_t end_qp;                 // qp of its last term (every term takes a qp, NOT terms too: mergerimpl.h:511-514)
+	uint32_t nterms;                 // Synonym::NumTerms()
+};
+struct FtSynMaskJob {                // one AND part's synonym mask
+	uint32_t syn_begin, syn_end;     // into FtPlan::job_syns
+	uint32_t* out;                   // [nwords]
 };
 struct FtGridEntry {           // block range of one sub-term in a posting-side grid (blocks of kFtBlockPostings postings)
 	uint32_t block_base;
@@ -187,7 +204,14 @@ struct FtPlan {
 	const FtTermCfg* terms;
 	const FtGridEntry* merge_grid;   // merged sub-terms in (term, sub-term) order
 	uint32_t n_merge_entries, merge_blocks;
-	uint32_t nterms, n_rows, n_subs;   // nterms = queryParts.size() (a phrase is one part)
+	uint32_t nterms, n_rows, n_subs;   // nterms = entries of `terms`: the query parts (a phrase is one part), then the synonyms' terms
+	uint32_t n_parts;                  // queryParts.size()
+	uint32_t n_part_qp;                // qp of the last merged query part: documents created behind it are the synonyms' (mergerimpl.h:510)
+	const FtSynonym* syns;             // [n_syn]
+	uint32_t n_syn;
+	const FtSynMaskJob* syn_jobs;      // [n_syn_jobs] -> ft_syn_masks
+	const uint32_t* job_syns;
+	uint32_t n_syn_jobs;
 	uint32_t query_len;                // QueryMergeData::QueryLength(): the terms inside phrases counted one by one (addFullMatchBoost)
 	uint64_t total_docs, nwords;
 	uint32_t max_merged, merge_limit;

@@ -346,9 +346,15 @@ HybridFused GpuFtMerger::FuseResident(const FtConfig& cfg, const HybridFuseParam
 	return out;
 }
 
+MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, QuerySynonyms synonyms, const uint8_t* docsExcluded,
+								  RankSortType rankSortType, bool* preselected) const {
+	return mergeQueryImpl(cfg, std::move(terms), docsExcluded, rankSortType, preselected, false, synonyms.Empty() ? nullptr : &synonyms);
+}
+
 MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
-									  bool* preselected, bool resident) const {
-	if (terms.size() == 1 && terms[0].op != OpType::Not && terms[0].phraseNum < 0 && totalDocs_ != 0) {   // Simple(): timed by Merge
+									  bool* preselected, bool resident, QuerySynonyms* synonyms) const {
+	if (synonyms && resident) throw std::logic_error("GpuFtMerger: a query with multi-word synonyms has no resident form");
+	if (!synonyms && terms.size() == 1 && terms[0].op != OpType::Not && terms[0].phraseNum < 0 && totalDocs_ != 0) {   // Simple(): timed by Merge
 		if (preselected) *preselected = false;
 		return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);
 	}
@@ -359,9 +365,17 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return out;
 	bool anyPhrase = false;
 	for (const QueryTerm& t : terms) anyPhrase = anyPhrase || t.phraseNum >= 0;
-	if (terms.size() == 1 && !anyPhrase) return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);   // Simple()
+	if (terms.size() == 1 && !anyPhrase && !synonyms) return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);   // Simple()
 	if (cfg.fieldsCfg.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
 
+	const size_t npartTerms = terms.size();
+	std::vector<uint32_t> synTermOff{0};
+	if (synonyms) {   // the synonyms' terms behind the parts' terms
+		for (auto& syn : synonyms->synonyms) {
+			for (auto& t : syn) terms.push_back(std::move(t));
+			synTermOff.push_back(uint32_t(terms.size() - npartTerms));
+		}
+	}
 	const size_t nt = terms.size();
 	std::vector<double> bm25Boost(numFields_), bm25Weight(numFields_), tlBoost(numFields_), tlWeight(numFields_), posBoost(numFields_), posWeight(numFields_);
 	for (size_t f = 0; f < numFields_; ++f) {
@@ -396,6 +410,7 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 	std::vector<rxgpu_ft_term_opts> opts(nt);
 	std::vector<uint32_t> subOff(nt + 1, 0), wordIds;
 	std::vector<float> procs;
+	std::vector<uint8_t> suppressed;
 	for (size_t t = 0; t < nt; ++t) {
 		QueryTerm& qt = terms[t];
 		if (qt.opts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
@@ -412,8 +427,60 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 		for (const SubtermRef& sr : qt.subterms) {
 			wordIds.push_back(sr.wordId);
 			procs.push_back(sr.proc);
+			suppressed.push_back(sr.suppressed ? 1 : 0);
 		}
 		subOff[t + 1] = uint32_t(wordIds.size());
+	}
+	if (synonyms) {
+		// parts as the engine forms them: a plain term, or the consecutive terms of one phrase number
+		uint32_t nparts = 0;
+		for (size_t t = 0; t < npartTerms; ++t) {
+			if (terms[t].phraseNum < 0 || t == 0 || terms[t - 1].phraseNum != terms[t].phraseNum) ++nparts;
+		}
+		std::vector<uint32_t> partSynOff(nparts + 1, 0), partSyn;
+		for (uint32_t pi = 0; pi < nparts; ++pi) {
+			if (pi < synonyms->partSynonyms.size()) {
+				for (uint32_t id : synonyms->partSynonyms[pi]) {
+					if (id >= synonyms->synonyms.size()) throw std::logic_error("GpuFtMerger: synonym id out of range");
+					partSyn.push_back(id);
+				}
+			}
+			partSynOff[pi + 1] = uint32_t(partSyn.size());
+		}
+		rxgpu_ft_query q{};
+		q.nterms = uint32_t(npartTerms);
+		q.nsyn_terms = uint32_t(nt - npartTerms);
+		q.ops = ops.data();
+		q.opts = opts.data();
+		q.phrase_num = phraseNum.data();
+		q.distance = distance.data();
+		q.sub_off = subOff.data();
+		q.word_ids = wordIds.data();
+		q.procs = procs.data();
+		q.suppressed = suppressed.data();
+		q.nsyn = uint32_t(synonyms->synonyms.size());
+		q.syn_term_off = synTermOff.data();
+		q.part_syn_off = partSynOff.data();
+		q.part_syn = partSyn.data();
+		const size_t cap = cfg.mergeLimit;
+		std::vector<uint32_t> doc(cap);
+		std::vector<float> proc(cap);
+		std::vector<uint8_t> field(cap);
+		std::vector<uint16_t> termsCounter(cap);
+		uint64_t n = 0;
+		int32_t pre = 0;
+		if (rxgpu_ft_merge_query2_raw(dev_, &c, &q, docsExcluded, doc.data(), proc.data(), field.data(), termsCounter.data(), cap, &n, &pre) != RXGPU_OK) {
+			throwDevice("MergeQuery (synonyms)");
+		}
+		if (preselected) *preselected = pre != 0;
+		out.resize(n);
+		for (uint64_t i = 0; i < n; ++i) {
+			out[i].id = int32_t(doc[i]);
+			out[i].proc = proc[i];
+			out[i].field = field[i];
+		}
+		postProcess(cfg, out, rankSortType);
+		return out;
 	}
 	if (resident && anyPhrase) {
 		int32_t enqueued = 0;

@@ -9,8 +9,8 @@
 // Multi-term queries (AND / OR / NOT terms: restricting bitmask, preselect, mergeTerm with position distances,
 // mergerimpl.h:107-192, 252-464) go through MergeQuery (ft_merge.hip via rxgpu_ft_merge_terms_raw).
 // Phrases run through PhraseMerger::Merge on the device first (ft_phrase.hip via rxgpu_ft_merge_query_raw) and join the merge as query parts
-// (mergePhrase, mergerimpl.h:39-90).  Multi-word synonyms and MergeDataAreas (highlight / snippet) stay on the reference's CPU merger;
-// Supports() tells the caller which way to go.
+// (mergePhrase, mergerimpl.h:39-90); multi-word synonyms ride behind the parts (rxgpu_ft_merge_query2_raw).  MergeDataAreas (highlight /
+// snippet) stays on the reference's CPU merger; Supports() tells the caller which way to go.
 #pragma once
 
 #include <cstdint>
@@ -58,7 +58,11 @@ struct FtDslOpts {
 struct SubtermRef {
 	uint32_t wordId;
 	float proc;
+	bool suppressed = false;   // SubtermResults::Suppressed() (set by QueryMergeData::SupressDuplicatesInSynonyms, querymergedata.h:221-241)
 };
+// Synonym<IdCont> (querymergedata.h:178-192): a multi-word synonym = the terms every one of which a document has to hold
+struct QueryTerm;
+struct QuerySynonyms;
 enum class RankSortType { RankOnly, RankAndID, IDOnly, IDAndPositions };   // core/ft/ft_fast/...: how the caller consumes the result
 // phrasemerger.h:57-62
 struct MergeInfo {
@@ -108,6 +112,13 @@ struct QueryTerm {
 	int distance = 1;
 };
 
+// QueryMergeData::synonyms + PhraseOrTerm::SynonymsIds (querymergedata.h:145-176, 191-193)
+struct QuerySynonyms {
+	std::vector<std::vector<QueryTerm>> synonyms;      // synonym -> its terms (Synonym::Terms())
+	std::vector<std::vector<uint32_t>> partSynonyms;   // query part (a term or a whole phrase) -> ids of its synonyms; may be shorter than the parts
+	bool Empty() const noexcept { return synonyms.empty(); }
+};
+
 // The hybrid rank fusion on the device (hybrid_fuse.hip): reranker + join type, as MergerRankedImpl gets them (selectiteratorcontainer.cc:1305-1341)
 struct HybridFuseParams {
 	bool linear = false;   // false: RRF, params[0] = rank_const (60); true: RerankerLinear, params = kKnn, knnDefault, kFt, ftDefault, c
@@ -146,8 +157,9 @@ public:
 	void GetWord(uint32_t wordId, PositionPostings& positions, FlatPostings& entries, std::vector<uint32_t>& rangeOff) const;
 
 	static bool Supports(size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept {
-		(void)hasPhrases;   // PhraseMerger runs on the device
-		return numQueryParts >= 1 && !hasSynonyms;
+		(void)hasPhrases;    // PhraseMerger runs on the device
+		(void)hasSynonyms;   // multi-word synonyms too (MergeQuery with QuerySynonyms)
+		return numQueryParts >= 1;
 	}
 	static bool Supports(const FtConfig& cfg, size_t numQueryParts, bool hasPhrases, bool hasSynonyms) noexcept {
 		(void)cfg;   // every Bm25Type is evaluated on the device
@@ -160,6 +172,9 @@ public:
 
 	// Merger::Merge<Bm25T> for any query made of terms and phrases (no multi-word synonyms); one OR/AND term -> Merge()
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
+						 bool* preselected = nullptr) const;
+	// ... with multi-word synonyms (mergerimpl.h:347-361, 393-397, 509-555).  No resident form: hybrid queries with synonyms fuse on the host.
+	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, QuerySynonyms synonyms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
 
 	// Hybrid query, FT half: the same merge, but the result STAYS IN HBM (no export, no wait).  False when the query merges nothing
@@ -187,7 +202,7 @@ private:
 	MergeData mergeImpl(const FtConfig& cfg, const FtDslOpts& termOpts, std::vector<SubtermRef> subterms, const uint8_t* docsExcluded,
 						RankSortType rankSortType, bool resident) const;
 	MergeData mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType, bool* preselected,
-							 bool resident) const;
+							 bool resident, QuerySynonyms* synonyms = nullptr) const;
 	void postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const;
 	const size_t numFields_;
 	size_t totalDocs_ = 0;

@@ -1,6 +1,7 @@
 // Flat C entry points over the C++ host layer so that pytest (ctypes) can drive GpuBruteforceMap / KnnSelect the way
 // the reference's own engine-level tests drive BruteforceSearch (gtests/tests/unit/hnsw_streaming_search_test.cc).
 // Exceptions become return codes + thread-local text, like the Reindexer API boundary turns them into Error values.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <stdexcept>
@@ -633,6 +634,55 @@ extern "C" long rxhost_ft_merge_query_phrases(void* h, size_t nf, const double* 
 		}
 		bool pre = false;
 		auto res = static_cast<const GpuFtMerger*>(h)->MergeQuery(cfg, std::move(terms), excluded, sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID, &pre);
+		if (outPreselected) *outPreselected = pre ? 1 : 0;
+		n = long(res.size());
+		for (size_t i = 0; i < res.size() && i < cap; ++i) {
+			outId[i] = res[i].id;
+			outProc[i] = res[i].proc;
+			outField[i] = res[i].field;
+			outNorm[i] = res[i].normalizedProc;
+		}
+	});
+	return n;
+}
+// ... plus multi-word synonyms: per-term arrays hold nTerms + nSynTerms entries; synonym s = terms nTerms + synTermOff[s] .. nTerms + synTermOff[s + 1];
+// partSynOff [nParts + 1] / partSyn: the synonyms of every query part.  Sub-terms of the synonyms whose word the query's own plain terms found
+// are marked suppressed here, like QueryMergeData::SupressDuplicatesInSynonyms does in front of the reference's merge (selecterimpl.h:606).
+extern "C" long rxhost_ft_merge_query_full(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, size_t nSynTerms,
+										   const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
+										   const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* wordIds, const float* procs,
+										   size_t nSyn, const uint32_t* synTermOff, size_t nParts, const uint32_t* partSynOff, const uint32_t* partSyn,
+										   const uint8_t* excluded, int sortByRank, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm,
+										   size_t cap, int* outPreselected) {
+	long n = -1;
+	guarded([&] {
+		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
+		std::vector<QueryTerm> all = parseFtTerms(nf, nTerms + nSynTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
+		for (size_t t = 0; t < nTerms; ++t) {
+			if (phraseNum) all[t].phraseNum = phraseNum[t];
+			if (distance) all[t].distance = distance[t];
+		}
+		std::vector<QueryTerm> terms(all.begin(), all.begin() + nTerms);
+		QuerySynonyms syn;
+		std::vector<uint32_t> found;   // words of the plain (non-phrase) query terms
+		for (const QueryTerm& t : terms) {
+			if (t.phraseNum < 0) {
+				for (const SubtermRef& s : t.subterms) found.push_back(s.wordId);
+			}
+		}
+		std::sort(found.begin(), found.end());
+		for (size_t sy = 0; sy < nSyn; ++sy) {
+			syn.synonyms.emplace_back();
+			for (uint32_t k = synTermOff[sy]; k < synTermOff[sy + 1]; ++k) {
+				QueryTerm t = all[nTerms + k];
+				for (SubtermRef& s : t.subterms) s.suppressed = std::binary_search(found.begin(), found.end(), s.wordId);
+				syn.synonyms.back().push_back(std::move(t));
+			}
+		}
+		for (size_t pi = 0; pi < nParts; ++pi) syn.partSynonyms.emplace_back(partSyn + partSynOff[pi], partSyn + partSynOff[pi + 1]);
+		bool pre = false;
+		auto res = static_cast<const GpuFtMerger*>(h)->MergeQuery(cfg, std::move(terms), std::move(syn), excluded,
+																  sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID, &pre);
 		if (outPreselected) *outPreselected = pre ? 1 : 0;
 		n = long(res.size());
 		for (size_t i = 0; i < res.size() && i < cap; ++i) {

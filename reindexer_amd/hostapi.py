@@ -702,11 +702,20 @@ class GpuFtMerger:
 
     OP_OR, OP_AND, OP_NOT = 1, 2, 3
 
-    def merge_query(self, cfg: dict, terms, excluded=None, sort_by_rank=True):
-        """Multi-term Merger::Merge.  terms: [dict(op, opts, subs=[(word_id, proc), ...][, phrase=<phraseNum>, distance=<d>]), ...];
+    def merge_query(self, cfg: dict, terms, excluded=None, sort_by_rank=True, synonyms=None, part_synonyms=None):
+        """synonyms: [[term, ...], ...] multi-word synonyms (Synonym::Terms()), part_synonyms[i]: ids of the synonyms of query part i
+        (PhraseOrTerm::SynonymsIds) -> GpuFtMerger::MergeQuery with QuerySynonyms.
+        Multi-term Merger::Merge.  terms: [dict(op, opts, subs=[(word_id, proc), ...][, phrase=<phraseNum>, distance=<d>]), ...];
         consecutive terms with the same phrase number >= 0 are one phrase (FtDslOpts::phraseNum / distance).
         Returns (ids, proc, field, norm, preselected)."""
         L = lib()
+        n_part_terms = len(terms)
+        syn_off = [0]
+        if synonyms:
+            terms = list(terms)
+            for syn in synonyms:
+                terms.extend(syn)
+                syn_off.append(len(terms) - n_part_terms)
         L.rxhost_ft_merge_query_phrases.restype = _l
         L.rxhost_ft_merge_query_phrases.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                                                     _vp, _sz, _vp]
@@ -735,6 +744,23 @@ class GpuFtMerger:
         oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
         of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
         pre = C.c_int(0)
+        if synonyms:
+            nparts = sum(1 for i in range(n_part_terms) if phr[i] < 0 or i == 0 or phr[i - 1] != phr[i])
+            ps_off, ps = [0], []
+            for pi in range(nparts):
+                ps.extend(part_synonyms[pi] if part_synonyms and pi < len(part_synonyms) else [])
+                ps_off.append(len(ps))
+            syn_off_a, ps_off_a, ps_a = np.array(syn_off, np.uint32), np.array(ps_off, np.uint32), np.array(ps + [0], np.uint32)
+            L.rxhost_ft_merge_query_full.restype = _l
+            L.rxhost_ft_merge_query_full.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz, _sz] + [_vp] * 10 + [_sz, _vp, _sz, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]
+            n = L.rxhost_ft_merge_query_full(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, n_part_terms, len(terms) - n_part_terms,
+                                             ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, phr.ctypes.data,
+                                             dst.ctypes.data, sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data, len(synonyms), syn_off_a.ctypes.data,
+                                             nparts, ps_off_a.ctypes.data, ps_a.ctypes.data, exc.ctypes.data if exc is not None else None,
+                                             int(sort_by_rank), oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap, C.byref(pre))
+            if n < 0:
+                _raise()
+            return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
         n = L.rxhost_ft_merge_query_phrases(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, len(terms), ops.ctypes.data,
                                             boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, phr.ctypes.data, dst.ctypes.data,
                                             sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data, exc.ctypes.data if exc is not None else None,
