@@ -865,8 +865,15 @@ class RefFtSeam(RefFt):
             raise RuntimeError(self.L.ref_seam_last_error(self.h).decode(errors="replace"))
         return n
 
-    def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16, packed=True, gpu=False):
+    def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16, packed=True, gpu=False, synonyms=None, part_synonyms=None):
         nf = self.nf
+        n_part_terms = len(terms)
+        syn_off = [0]
+        if synonyms:
+            terms = list(terms)
+            for syn in synonyms:
+                terms.extend(syn)
+                syn_off.append(len(terms) - n_part_terms)
         ops = np.array([t["op"] for t in terms], np.int32)
         boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
         tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
@@ -884,12 +891,19 @@ class RefFtSeam(RefFt):
         of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
         phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
         dst = np.array([t.get("distance", 1) for t in terms], np.int32)
-        fn = self.L.ref_seam_merge_phrases
+        nparts = sum(1 for i in range(n_part_terms) if phr[i] < 0 or i == 0 or phr[i - 1] != phr[i])
+        ps_off, ps = [0], []
+        for pi in range(nparts):
+            ps.extend(part_synonyms[pi] if part_synonyms and pi < len(part_synonyms) else [])
+            ps_off.append(len(ps))
+        syn_off_a, ps_off_a, ps_a = np.array(syn_off, np.uint32), np.array(ps_off, np.uint32), np.array(ps + [0], np.uint32)
+        fn = self.L.ref_seam_merge_full
         fn.restype = C.c_long
-        fn.argtypes = [_vp, _i, _i, _sz] + [_vp] * 11 + [_i, _vp, _vp, _vp, _vp, _sz]
-        n = fn(self.h, int(packed), int(gpu), len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data,
-               phr.ctypes.data, dst.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
-               rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
+        fn.argtypes = [_vp, _i, _i, _sz, _sz] + [_vp] * 10 + [_sz] + [_vp] * 4 + [_i, _vp, _vp, _vp, _vp, _sz]
+        n = fn(self.h, int(packed), int(gpu), n_part_terms, len(terms) - n_part_terms, ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data,
+               ns.ctypes.data, phr.ctypes.data, dst.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, len(synonyms) if synonyms else 0,
+               syn_off_a.ctypes.data, ps_off_a.ctypes.data, ps_a.ctypes.data, exc.ctypes.data if exc is not None else None, rank_sort_type,
+               oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap)
         if n == -2:
             return None   # the GPU branch declined: the CPU merger would run
         if n < 0:

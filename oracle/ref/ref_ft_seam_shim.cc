@@ -56,7 +56,8 @@ const std::vector<PackedWordEntry<IdCont>>& wordsOf(const SeamRef& f) {
 
 template <typename IdCont>
 long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
-			   const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
+			   const uint8_t* needSum, const int* phraseNum, const int* distance, size_t nSynTerms, size_t nSyn, const uint32_t* synTermOff,
+			   const uint32_t* partSynOff, const uint32_t* partSyn, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
 			   int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
 	const auto& words = wordsOf<IdCont>(*f);
 	ft::QueryMergeData<IdCont> q;
@@ -104,6 +105,40 @@ long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float*
 		q.queryParts.emplace_back(std::move(nextPhrase));
 		nextPhrase.clear();
 	}
+	// multi-word synonyms (selecterimpl.h:427-466, 576-603), then what Selector::Process does in front of mergeResults (:606)
+	for (size_t sy = 0; sy < nSyn; ++sy) {
+		ft::Synonym<IdCont> syn;
+		for (uint32_t k = synTermOff[sy]; k < synTermOff[sy + 1]; ++k) {
+			const size_t t = nTerms + k;
+			FtDslOpts o;
+			o.op = OpType(ops[t]);
+			o.boost = boosts[t];
+			o.termLenBoost = termLenBoosts[t];
+			o.fieldsOpts.resize(f->nf);
+			for (size_t i = 0; i < f->nf; ++i) {
+				o.fieldsOpts[i].boost = fieldBoost[t * f->nf + i];
+				o.fieldsOpts[i].needSumRank = needSum[t * f->nf + i] != 0;
+			}
+			ft::TermResults<IdCont> tr{FtDSLEntry(std::wstring(L"s") + std::to_wstring(t), o)};
+			for (uint32_t s = subOff[t]; s < subOff[t + 1]; ++s) {
+				WordIdType wid;
+				wid.data = 0;
+				wid.b.step_num = 1;
+				wid.SetID(int32_t(subWord[s]));
+				tr.AddSubterm(words.at(subWord[s]).vids, std::string_view("w"), wid, subProc[s]);
+			}
+			q.totalORVids += tr.MaxVDocs();
+			syn.AddTerm(std::move(tr));
+		}
+		q.synonyms.emplace_back(std::move(syn));
+	}
+	if (nSyn) {
+		for (size_t pi = 0; pi < q.queryParts.size(); ++pi) {
+			for (uint32_t k = partSynOff[pi]; k < partSynOff[pi + 1]; ++k) q.queryParts[pi].AddSynonymId(partSyn[k]);
+		}
+		q.SupressDuplicatesInSynonyms();
+	}
+	(void)nSynTerms;
 	FtMergeStatuses::Statuses st;
 	st.resize(f->totalDocs, false);
 	if (excluded) {
@@ -227,23 +262,32 @@ long ref_seam_commit(void* h, int device) {
 
 // packed: 1 = QueryMergeData<PackedIdRelVec>, 0 = <IdRelVec>; gpu: 1 = TryMergeOnGpu, 0 = the reference's ft::Merger.
 // Returns the result count, -1 on an exception, -2 when the GPU branch declined the query (the CPU merger would run).
-// phraseNum / distance: FtDslOpts::phraseNum (-1: a plain term) / FtDslOpts::distance per term, or null.
-long ref_seam_merge_phrases(void* h, int packed, int gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts,
-							const float* fieldBoost, const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff,
-							const uint32_t* subWord, const float* subProc, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc,
-							uint8_t* outField, uint8_t* outNorm, size_t cap) {
+// phraseNum / distance: FtDslOpts::phraseNum (-1: a plain term) / FtDslOpts::distance per term, or null; synonyms as in ref_ft_merge_full
+// (ref_ft_shim.cc): per-term arrays hold nTerms + nSynTerms entries.
+long ref_seam_merge_full(void* h, int packed, int gpu, size_t nTerms, size_t nSynTerms, const int* ops, const float* boosts, const float* termLenBoosts,
+						 const float* fieldBoost, const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff,
+						 const uint32_t* subWord, const float* subProc, size_t nSyn, const uint32_t* synTermOff, const uint32_t* partSynOff,
+						 const uint32_t* partSyn, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField,
+						 uint8_t* outNorm, size_t cap) {
 	auto* f = static_cast<SeamRef*>(h);
 	try {
 		if (packed) {
-			return mergeImpl<PackedIdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord,
-											 subProc, excluded, rankSortType, outId, outProc, outField, outNorm, cap);
+			return mergeImpl<PackedIdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, nSynTerms, nSyn, synTermOff,
+											 partSynOff, partSyn, subOff, subWord, subProc, excluded, rankSortType, outId, outProc, outField, outNorm, cap);
 		}
-		return mergeImpl<IdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord, subProc,
-								   excluded, rankSortType, outId, outProc, outField, outNorm, cap);
+		return mergeImpl<IdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, nSynTerms, nSyn, synTermOff, partSynOff,
+								   partSyn, subOff, subWord, subProc, excluded, rankSortType, outId, outProc, outField, outNorm, cap);
 	} catch (const std::exception& e) {
 		f->error = e.what();
 		return -1;
 	}
+}
+long ref_seam_merge_phrases(void* h, int packed, int gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts,
+							const float* fieldBoost, const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff,
+							const uint32_t* subWord, const float* subProc, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc,
+							uint8_t* outField, uint8_t* outNorm, size_t cap) {
+	return ref_seam_merge_full(h, packed, gpu, nTerms, 0, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord, subProc, 0, nullptr,
+							   nullptr, nullptr, excluded, rankSortType, outId, outProc, outField, outNorm, cap);
 }
 long ref_seam_merge(void* h, int packed, int gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts,
 					const float* fieldBoost, const uint8_t* needSum, const uint32_t* subOff, const uint32_t* subWord, const float* subProc,

@@ -16,8 +16,8 @@
 //     vdoc statistics                    — the duck-typed DocsStatsGetter (indextext.h:245-258): DocRemoved / NumWordsInField / AvgWordsCount
 //   Only the words whose list changed since the last commit travel again (fingerprint: byte size + FNV-1a of the stream / (size, last id)).
 //
-// What still goes to the reference's CPU merger (TryMergeOnGpu returns false): multi-word synonyms, MergeDataAreas (highlight / snippet)
-// — GpuFtMerger::Supports.  Phrases go to the device (PhraseMerger as kernels, ft_phrase.hip).
+// What still goes to the reference's CPU merger (TryMergeOnGpu returns false): MergeDataAreas (highlight / snippet) — the patched
+// mergeResults only branches for plain ft::MergeData.  Phrases (PhraseMerger as kernels, ft_phrase.hip) and multi-word synonyms go to the device.
 #pragma once
 #if !defined(RXGPU_IN_TREE)
 #error "rx_ft_seam.h is for the build inside cpp_src (define RXGPU_IN_TREE)"
@@ -104,19 +104,35 @@ bool ToGpuTerm(const reindexer::ft::TermResults<IdCont>& t, int phraseNum, std::
 	g.phraseNum = phraseNum;
 	g.distance = t.Distance();
 	g.subterms.reserve(t.NumSubterms());
-	for (const auto& st : t) g.subterms.push_back(SubtermRef{uint32_t(st.PatternID().b.id), st.Proc()});
+	for (const auto& st : t) g.subterms.push_back(SubtermRef{uint32_t(st.PatternID().b.id), st.Proc(), st.Suppressed()});
 	terms.push_back(std::move(g));
 	return true;
 }
+// Multi-word synonyms (QueryMergeData::synonyms, PhraseOrTerm::SynonymsIds) -> QuerySynonyms; the Suppressed() marks of
+// SupressDuplicatesInSynonyms (the selecter has called it, selecterimpl.h:606) travel with the sub-terms.
 template <typename IdCont>
-bool ToGpuTerms(reindexer::ft::QueryMergeData<IdCont>& q, std::vector<QueryTerm>& terms, bool* hasPhrases = nullptr) {
+bool ToGpuTerms(reindexer::ft::QueryMergeData<IdCont>& q, std::vector<QueryTerm>& terms, bool* hasPhrases = nullptr, QuerySynonyms* synonyms = nullptr) {
 	if (hasPhrases) *hasPhrases = false;
-	if (!q.synonyms.empty()) return false;
+	if (!q.synonyms.empty() && !synonyms) return false;
+	if (synonyms) {
+		synonyms->synonyms.clear();
+		synonyms->partSynonyms.clear();
+		for (auto& syn : q.synonyms) {
+			synonyms->synonyms.emplace_back();
+			for (const auto& t : syn.Terms()) {
+				if (!ToGpuTerm(t, -1, synonyms->synonyms.back())) return false;
+			}
+		}
+	}
 	terms.clear();
 	terms.reserve(q.queryParts.size());
 	int phraseNum = 0;
 	for (auto& qp : q.queryParts) {
-		if (!qp.SynonymsIds().empty()) return false;
+		if (!qp.SynonymsIds().empty() && !synonyms) return false;
+		if (synonyms) {
+			synonyms->partSynonyms.emplace_back();
+			for (size_t id : qp.SynonymsIds()) synonyms->partSynonyms.back().push_back(uint32_t(id));
+		}
 		if (qp.IsTerm()) {
 			if (!ToGpuTerm(qp.Term(), -1, terms)) return false;
 			continue;
@@ -247,7 +263,8 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		q.SortSubterms();   // Merge() does it before anything reads the sub-terms (mergerimpl.h:479)
 		std::vector<QueryTerm> terms;
 		bool hasPhrases = false;
-		if (!ToGpuTerms(q, terms, &hasPhrases)) return false;
+		QuerySynonyms synonyms;
+		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
 		if (!GpuFtMerger::Supports(terms.size(), hasPhrases, !q.synonyms.empty())) return false;
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
@@ -256,7 +273,8 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 			for (size_t d = 0; d < totalNumDocs && d < docsExcluded.size(); ++d) excluded[d] = docsExcluded[d] ? 1 : 0;
 			excludedPtr = excluded.data();
 		}
-		const MergeData merged = mirror->Merger().MergeQuery(ToGpuCfg(cfg), std::move(terms), excludedPtr, sortType);
+		const MergeData merged = synonyms.Empty() ? mirror->Merger().MergeQuery(ToGpuCfg(cfg), std::move(terms), excludedPtr, sortType)
+												  : mirror->Merger().MergeQuery(ToGpuCfg(cfg), std::move(terms), std::move(synonyms), excludedPtr, sortType);
 		ToRxMergeData(merged, result);
 		return true;
 	}

@@ -169,3 +169,58 @@ def test_patched_merge_results_branch_takes_phrases(rxgpu, ft, ops, phrases, dis
                 _same(got, want, (limit, packed))
                 assert len(want[0]) > 0
     seam.close()
+
+
+def _syn_query(seed, nf, total, ops, syn_sizes, part_syn):
+    n_syn_terms = sum(syn_sizes)
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, 20000, tuple(ops) + (1,) * n_syn_terms, False, None, sizes=(300, 1200),
+                                                                 nsub_range=(1, 4))
+    def cv(t, op=None):
+        return dict(op=t["op"] if op is None else op, opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]])
+    parts = [cv(t) for t in terms[:len(ops)]]
+    owner_op = {sid: parts[pi]["op"] for pi, ids in enumerate(part_syn) for sid in ids}
+    synonyms, at = [], len(ops)
+    for sid, k in enumerate(syn_sizes):
+        synonyms.append([cv(t, owner_op.get(sid, 1)) for t in terms[at:at + k]])
+        at += k
+    # a duplicate: the first synonym term also finds a word of the first query term (SupressDuplicatesInSynonyms marks it)
+    synonyms[0][0]["subs"] = sorted(synonyms[0][0]["subs"] + [(parts[0]["subs"][0][0], 21.0)], key=lambda x: -x[1])
+    return words, avg, removed, excluded, store, parts, synonyms
+
+
+SYN_SHAPES = [((1, 1), [2], [[0], []]), ((2, 1), [2, 2], [[0, 1], []]), ((1, 2, 1), [3], [[], [0], []])]
+
+
+@pytest.mark.parametrize("ops,syn_sizes,part_syn", SYN_SHAPES)
+def test_reference_synonym_merge_over_packed_lists_equals_plain_lists(ft, ops, syn_sizes, part_syn):
+    nf, total = 2, 3000
+    words, avg, removed, excluded, store, parts, synonyms = _syn_query(600 + len(ops), nf, total, ops, syn_sizes, part_syn)
+    seam = _seam(nf, words, avg, removed, store)
+    seam.set_config(ft.default_config(nf, merge_limit=20000))
+    for exc in (None, excluded):
+        a = seam.merge(parts, exc, packed=True, synonyms=synonyms, part_synonyms=part_syn)
+        b = seam.merge(parts, exc, packed=False, synonyms=synonyms, part_synonyms=part_syn)
+        _same(a, b, ops)
+        c = seam.merge(parts, exc, packed=False)
+        assert len(a[0]) > 0 and (len(c[0]) != len(a[0]) or not np.array_equal(c[1], a[1]))   # the synonyms change the result
+    seam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ops,syn_sizes,part_syn", SYN_SHAPES)
+def test_patched_merge_results_branch_takes_multi_word_synonyms(rxgpu, ft, ops, syn_sizes, part_syn):
+    """QueryMergeData::synonyms through the patched Selector::mergeResults branch: ToGpuTerms hands the synonyms, the parts' SynonymsIds and
+    the Suppressed() marks over, the device merges — identical to the reference's merger for both containers."""
+    nf, total = 2, 3000
+    words, avg, removed, excluded, store, parts, synonyms = _syn_query(600 + len(ops), nf, total, ops, syn_sizes, part_syn)
+    seam = _seam(nf, words, avg, removed, store)
+    assert seam.commit(0) == len(store)
+    for limit in (20000, 70):
+        seam.set_config(ft.default_config(nf, merge_limit=limit))
+        for exc in (None, excluded):
+            for packed in (True, False):
+                want = seam.merge(parts, exc, rank_sort_type=1, packed=packed, gpu=False, synonyms=synonyms, part_synonyms=part_syn)
+                got = seam.merge(parts, exc, rank_sort_type=1, packed=packed, gpu=True, synonyms=synonyms, part_synonyms=part_syn)
+                _same(got, want, (limit, packed))
+                assert len(want[0]) > 0
+    seam.close()
