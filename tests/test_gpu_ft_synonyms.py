@@ -142,3 +142,75 @@ def test_gpu_synonyms_long_lists(hostapi, ft):
     finally:
         real.close()
         m.close()
+
+
+def test_gpu_random_query_shapes_equal_real_merger(hostapi, ft):
+    """Randomised differential run: 60 queries of random shape over one corpus — 1-5 parts (terms and phrases, OR / AND / NOT), 0-3 multi-word
+    synonyms of 1-3 terms hung on random parts (some sharing words with the query's own terms), zero field boosts, merge limits from 30
+    to 20000, docsExcluded on and off — each against the real merger."""
+    nf, total = 3, 6000
+    rng = np.random.default_rng(777)
+    _, words, avg, removed, excluded, pool, store = _multi_case(778, nf, total, 20000, (1,) * 18, True, None, sizes=(200, 2500), nsub_range=(1, 5))
+    real, m = _engines(hostapi, nf, words, avg, removed, store)
+    boosts = [[1.0, 1.0, 1.0], [1.0, 0.0, 2.0], [0.0, 1.0, 0.5], [1.0, 1.0, 0.0]]
+    try:
+        checked = nonempty = 0
+        for qi in range(60):
+            order = rng.permutation(len(pool))
+            take = iter(order)
+            parts, nparts = [], int(rng.integers(1, 6))
+            part_ops = []
+            for pi in range(nparts):
+                op = int(rng.choice([1, 1, 1, 2, 2, 3]))
+                part_ops.append(op)
+                if rng.random() < 0.3:   # a phrase of 2-3 terms
+                    k = int(rng.integers(2, 4))
+                    dist = int(rng.choice([1, 3, 10, 40]))
+                    for j in range(k):
+                        t = pool[next(take)]
+                        parts.append(dict(_t(t, op=op), phrase=pi, distance=1 if j == 0 else dist))
+                else:
+                    parts.append(_t(pool[next(take)], op=op))
+            if all(o == 3 for o in part_ops):
+                parts[0]["op"] = 1
+                part_ops[0] = 1
+                if parts[0]["phrase"] >= 0:
+                    for p_ in parts:
+                        if p_["phrase"] == parts[0]["phrase"]:
+                            p_["op"] = 1
+            for p_ in parts:
+                fb = boosts[int(rng.integers(0, len(boosts)))] if rng.random() < 0.3 else [1.0] * nf
+                p_["opts"] = dict(p_["opts"], field_boost=fb)
+            nsyn = int(rng.integers(0, 4))
+            synonyms, part_syn = [], [[] for _ in range(nparts)]
+            for sid in range(nsyn):
+                owner = int(rng.integers(0, nparts))
+                syn = []
+                for _ in range(int(rng.integers(1, 4))):
+                    st = _t(pool[next(take)], op=part_ops[owner] if part_ops[owner] != 3 else 1)
+                    if rng.random() < 0.4:   # shares a word with one of the query's own terms
+                        src = parts[int(rng.integers(0, len(parts)))]
+                        if src["subs"]:
+                            st["subs"] = sorted(st["subs"] + [(src["subs"][0][0], float(rng.choice([15.0, 33.0, 61.0])))], key=lambda x: -x[1])
+                    syn.append(st)
+                synonyms.append(syn)
+                part_syn[owner].append(sid)
+            limit = int(rng.choice([30, 150, 1000, 20000]))
+            cfg = ft.default_config(nf, merge_limit=limit, min_rank=int(rng.choice([0, 5, 40])))
+            dboost, dweight = (1.0, 0.5) if qi % 3 else (1.7, 0.8)
+            cfg["distance_boost"], cfg["distance_weight"] = dboost, dweight
+            real.set_config(cfg, distance_boost=dboost, distance_weight=dweight)
+            exc = excluded if qi % 2 else None
+            kw = dict(synonyms=synonyms, part_synonyms=part_syn) if synonyms else {}
+            wd, wp, wf, wn = real.merge(parts, exc, rank_sort_type=1, **kw)
+            gd, gp, gf, gn, _ = m.merge_query(cfg, parts, exc, sort_by_rank=False, **kw)
+            tag = (qi, part_ops, [p_["phrase"] for p_ in parts], part_syn, limit)
+            assert np.array_equal(gd, wd), (tag, len(gd), len(wd), gd[:6], wd[:6])
+            assert np.array_equal(gp.view(np.uint32), wp.view(np.uint32)), tag
+            assert np.array_equal(gn, wn) and np.array_equal(gf, wf), tag
+            checked += 1
+            nonempty += len(wd) > 0
+        assert checked == 60 and nonempty >= 30, (checked, nonempty)
+    finally:
+        real.close()
+        m.close()
