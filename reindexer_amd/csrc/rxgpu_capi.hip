@@ -205,8 +205,7 @@ int ensure_row_stats(rxgpu_index* h, hipStream_t s) {
 	if (h->stats_valid) return RXGPU_OK;
 	if (!h->d_stats) RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_stats), 2 * sizeof(unsigned int)));
 	if (h->metric == RXGPU_METRIC_L2 && h->row_sq_capacity < h->count) {
-		if (h->d_row_ids) (void)hipFree(h->d_row_ids);
-	if (h->d_row_sq) (void)hipFree(h->d_row_sq);
+		if (h->d_row_sq) (void)hipFree(h->d_row_sq);
 		h->d_row_sq = nullptr;
 		h->row_sq_capacity = 0;
 		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_row_sq), std::max<uint64_t>(h->capacity, h->count) * sizeof(float)));
@@ -714,6 +713,7 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 		if (h->d_inv_norms) (void)hipFree(h->d_inv_norms);
 	}
 	if (h->d_row_sq) (void)hipFree(h->d_row_sq);
+	if (h->d_row_ids) (void)hipFree(h->d_row_ids);
 	if (h->d_rows_bf16) (void)hipFree(h->d_rows_bf16);
 	if (h->d_stats) (void)hipFree(h->d_stats);
 	if (h->d_links0) (void)hipFree(h->d_links0);
