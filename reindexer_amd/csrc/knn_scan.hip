@@ -17,6 +17,7 @@ constexpr int kScanThreads = 256;                    // 4 wavefronts per workgro
 constexpr int kScanWaves = kScanThreads / kWave;
 constexpr int kMergeThreads = 512;
 constexpr int kMergeWaves = kMergeThreads / kWave;
+constexpr int kMergeAhead = 8;                       // candidate chunks whose loads a merge wavefront keeps in flight
 
 // Workgroup epilogue shared by both scan kernels: fold the per-wave lists into one and store it.
 __device__ __forceinline__ void block_merge_and_store(WaveTopK& top, const ScanParams& p, int lane, int wave) {
@@ -417,21 +418,31 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge(const float* part_dis
 	const size_t base = size_t(blockIdx.x) * total;
 	WaveTopK top;
 	top.init(kk);
-	for (uint32_t c0 = wave * kWave; c0 < total; c0 += kMergeThreads) {
-		const uint32_t c = c0 + lane;
-		float cd = __builtin_inff();
-		uint32_t ci = kInvalidRow;
-		if (c < total) {
-			cd = part_dist[base + c];
-			ci = part_row[base + c];
+	// kMergeAhead chunks of 64 candidates per trip, all their loads issued together: one chunk per trip left every trip behind its own
+	// memory round trip (~2 us each: 0.27 ms for the 512 x 101 partial entries of a k = 100 search, against 0.03 ms of list work)
+	for (uint32_t c0 = wave * kWave; c0 < total; c0 += kMergeThreads * kMergeAhead) {
+		float cd[kMergeAhead];
+		uint32_t ci[kMergeAhead];
+#pragma unroll
+		for (int u = 0; u < kMergeAhead; ++u) {
+			const uint32_t c = c0 + uint32_t(u) * kMergeThreads + lane;
+			cd[u] = __builtin_inff();
+			ci[u] = kInvalidRow;
+			if (c < total) {
+				cd[u] = part_dist[base + c];
+				ci[u] = part_row[base + c];
+			}
 		}
-		uint64_t pm = __ballot(ci != kInvalidRow && top.admits(cd, ci));
-		while (pm) {
-			const int src = __builtin_ctzll(pm);
-			pm &= pm - 1;
-			const float d = __shfl(cd, src);
-			const uint32_t i = __shfl(ci, src);
-			if (top.admits(d, i)) top.insert(d, i, lane);
+#pragma unroll
+		for (int u = 0; u < kMergeAhead; ++u) {
+			uint64_t pm = __ballot(ci[u] != kInvalidRow && top.admits(cd[u], ci[u]));
+			while (pm) {
+				const int src = __builtin_ctzll(pm);
+				pm &= pm - 1;
+				const float d = __shfl(cd[u], src);
+				const uint32_t i = __shfl(ci[u], src);
+				if (top.admits(d, i)) top.insert(d, i, lane);
+			}
 		}
 	}
 	s_d[wave][lane] = top.bd;
@@ -467,21 +478,31 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_wide(const float* par
 	const size_t base = size_t(blockIdx.x) * total;
 	WaveTopK2 top;
 	top.init(kk);
-	for (uint32_t c0 = wave * kWave; c0 < total; c0 += kMergeThreads) {
-		const uint32_t c = c0 + lane;
-		float cd = __builtin_inff();
-		uint32_t ci = kInvalidRow;
-		if (c < total) {
-			cd = part_dist[base + c];
-			ci = part_row[base + c];
+	// kMergeAhead chunks of 64 candidates per trip, all their loads issued together: one chunk per trip left every trip behind its own
+	// memory round trip (~2 us each: 0.27 ms for the 512 x 101 partial entries of a k = 100 search, against 0.03 ms of list work)
+	for (uint32_t c0 = wave * kWave; c0 < total; c0 += kMergeThreads * kMergeAhead) {
+		float cd[kMergeAhead];
+		uint32_t ci[kMergeAhead];
+#pragma unroll
+		for (int u = 0; u < kMergeAhead; ++u) {
+			const uint32_t c = c0 + uint32_t(u) * kMergeThreads + lane;
+			cd[u] = __builtin_inff();
+			ci[u] = kInvalidRow;
+			if (c < total) {
+				cd[u] = part_dist[base + c];
+				ci[u] = part_row[base + c];
+			}
 		}
-		uint64_t pm = __ballot(ci != kInvalidRow && top.admits(cd, ci));
-		while (pm) {
-			const int src = __builtin_ctzll(pm);
-			pm &= pm - 1;
-			const float d = __shfl(cd, src);
-			const uint32_t i = __shfl(ci, src);
-			if (top.admits(d, i)) top.insert(d, i, lane);
+#pragma unroll
+		for (int u = 0; u < kMergeAhead; ++u) {
+			uint64_t pm = __ballot(ci[u] != kInvalidRow && top.admits(cd[u], ci[u]));
+			while (pm) {
+				const int src = __builtin_ctzll(pm);
+				pm &= pm - 1;
+				const float d = __shfl(cd[u], src);
+				const uint32_t i = __shfl(ci[u], src);
+				if (top.admits(d, i)) top.insert(d, i, lane);
+			}
 		}
 	}
 	s_d[wave][lane] = top.d0;
@@ -506,6 +527,180 @@ __global__ __launch_bounds__(kMergeThreads) void knn_merge_wide(const float* par
 	if (64 + lane < int(kk)) {
 		out_dist[o + 64 + lane] = top.d1;
 		out_row[o + 64 + lane] = top.i1;
+	}
+	if (lane == 0 && out_count) out_count[blockIdx.x] = top.filled;
+}
+
+// ---- merge of SORTED partial lists (what the scans leave: gridDim.x lists of kk entries per query), without serial insertions.
+// Folding ~500 lists through a wavefront-wide sorted list costs an insertion (a chain of cross-lane operations, ~0.4 us) for every
+// candidate that beats the running kk-th — ~650 of them at k = 100: 0.25 ms behind a 1.5 ms scan.  The lists are sorted, so:
+//   1. the kk-th smallest list HEAD bounds the kk-th best overall (the heads are kk real candidates at or below it);
+//   2. only entries at or below that bound can be in the result: every list is walked from its head while it stays below — for rows
+//      spread evenly over the partitions that is ~1.1 kk entries in total;
+//   3. those candidates are sorted in LDS (bitonic, (distance, row) keys) and the first kk written.
+// Exact for any data; when the bound lets more than kMergeCandMax entries through (masses of equal distances) or there are fewer lists
+// than kk, the insertion merge runs instead (same kernel, workgroup-uniform branch).
+constexpr uint32_t kMergeHeadsMax = 4096, kMergeCandMax = 2048;
+__device__ __forceinline__ unsigned long long merge_pair_key(float d, uint32_t row) {
+	uint32_t b = __float_as_uint(d);
+	if (b == 0x80000000u) b = 0;   // -0.0 == +0.0 for pair_lt: the row decides
+	b ^= (b >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+	return (static_cast<unsigned long long>(b) << 32) | row;
+}
+// ascending bitonic sort of n = 2^m (key, payload) pairs in LDS by all kMergeThreads threads
+__device__ __forceinline__ void merge_bitonic(unsigned long long* key, float* val, uint32_t n) {
+	for (uint32_t k = 2; k <= n; k <<= 1) {
+		for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+			for (uint32_t t = threadIdx.x; t < n / 2; t += kMergeThreads) {
+				const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+				const unsigned long long x = key[i], y = key[l];
+				if ((x > y) == ((i & k) == 0)) {
+					key[i] = y;
+					key[l] = x;
+					const float vx = val[i];
+					val[i] = val[l];
+					val[l] = vx;
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+template <typename TK>
+__device__ void merge_by_insertion(const float* part_dist, const uint32_t* part_row, size_t base, uint32_t total, uint32_t kk, float* out_dist,
+								   uint32_t* out_row, uint32_t* out_count, float* s_d, uint32_t* s_i);
+
+template <typename TK>
+__global__ __launch_bounds__(kMergeThreads) void knn_merge_lists(const float* part_dist, const uint32_t* part_row, uint32_t nlists, uint32_t kk,
+																  float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	__shared__ unsigned long long s_key[kMergeHeadsMax];
+	__shared__ float s_val[kMergeHeadsMax];
+	__shared__ uint32_t s_n;
+	const uint32_t tid = threadIdx.x, total = nlists * kk;
+	const size_t base = size_t(blockIdx.x) * total;
+	bool serial = nlists < kk || nlists > kMergeHeadsMax;
+	if (!serial) {
+		uint32_t n1 = 64;
+		while (n1 < nlists) n1 <<= 1;
+		for (uint32_t l = tid; l < n1; l += kMergeThreads) {
+			unsigned long long k = ~0ull;
+			if (l < nlists) {
+				const uint32_t r = part_row[base + size_t(l) * kk];
+				if (r != kInvalidRow) k = merge_pair_key(part_dist[base + size_t(l) * kk], r);
+			}
+			s_key[l] = k;
+			s_val[l] = 0.f;
+		}
+		if (tid == 0) s_n = 0;
+		__syncthreads();
+		merge_bitonic(s_key, s_val, n1);
+		const unsigned long long bound = s_key[kk - 1];   // ~0: fewer than kk non-empty lists — everything valid is a candidate
+		__syncthreads();
+		// (the candidates overwrite the heads: every thread has read the bound)
+		for (uint32_t l = tid; l < nlists; l += kMergeThreads) {
+			const size_t at = base + size_t(l) * kk;
+			for (uint32_t e = 0; e < kk; ++e) {
+				const uint32_t r = part_row[at + e];
+				if (r == kInvalidRow) break;
+				const float d = part_dist[at + e];
+				const unsigned long long k = merge_pair_key(d, r);
+				if (k > bound) break;
+				const uint32_t pos = atomicAdd(&s_n, 1u);
+				if (pos < kMergeCandMax) {
+					s_key[pos] = k;
+					s_val[pos] = d;
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t n = s_n;
+		serial = n > kMergeCandMax;
+		if (!serial) {
+			uint32_t n2 = 64;
+			while (n2 < n) n2 <<= 1;
+			for (uint32_t q = n + tid; q < n2; q += kMergeThreads) {
+				s_key[q] = ~0ull;
+				s_val[q] = 0.f;
+			}
+			__syncthreads();
+			merge_bitonic(s_key, s_val, n2);
+			const uint32_t cnt = n < kk ? n : kk;
+			for (uint32_t q = tid; q < kk; q += kMergeThreads) {
+				out_dist[size_t(blockIdx.x) * kk + q] = q < cnt ? s_val[q] : __builtin_inff();
+				out_row[size_t(blockIdx.x) * kk + q] = q < cnt ? uint32_t(s_key[q]) : kInvalidRow;
+			}
+			if (tid == 0 && out_count) out_count[blockIdx.x] = cnt;
+			return;
+		}
+		__syncthreads();
+	}
+	// the insertion merge over the same lists (LDS reused for the wavefronts' lists)
+	merge_by_insertion<TK>(part_dist, part_row, base, total, kk, out_dist, out_row, out_count, s_val, reinterpret_cast<uint32_t*>(s_key));
+}
+
+__device__ __forceinline__ void merge_store_list(const WaveTopK& t, float* d, uint32_t* i, int lane) {
+	d[lane] = t.bd;
+	i[lane] = t.bi;
+	d[64 + lane] = __builtin_inff();
+	i[64 + lane] = kInvalidRow;
+}
+__device__ __forceinline__ void merge_store_list(const WaveTopK2& t, float* d, uint32_t* i, int lane) {
+	d[lane] = t.d0;
+	i[lane] = t.i0;
+	d[64 + lane] = t.d1;
+	i[64 + lane] = t.i1;
+}
+template <typename TK>
+__device__ void merge_by_insertion(const float* part_dist, const uint32_t* part_row, size_t base, uint32_t total, uint32_t kk, float* out_dist,
+								   uint32_t* out_row, uint32_t* out_count, float* s_d, uint32_t* s_i) {
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	TK top;
+	top.init(kk);
+	for (uint32_t c0 = wave * kWave; c0 < total; c0 += kMergeThreads * kMergeAhead) {
+		float cd[kMergeAhead];
+		uint32_t ci[kMergeAhead];
+#pragma unroll
+		for (int u = 0; u < kMergeAhead; ++u) {
+			const uint32_t c = c0 + uint32_t(u) * kMergeThreads + lane;
+			cd[u] = __builtin_inff();
+			ci[u] = kInvalidRow;
+			if (c < total) {
+				cd[u] = part_dist[base + c];
+				ci[u] = part_row[base + c];
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < kMergeAhead; ++u) {
+			uint64_t pm = __ballot(ci[u] != kInvalidRow && top.admits(cd[u], ci[u]));
+			while (pm) {
+				const int src = __builtin_ctzll(pm);
+				pm &= pm - 1;
+				const float d = __shfl(cd[u], src);
+				const uint32_t i = __shfl(ci[u], src);
+				if (top.admits(d, i)) top.insert(d, i, lane);
+			}
+		}
+	}
+	merge_store_list(top, s_d + wave * kMaxFusedK2, s_i + wave * kMaxFusedK2, lane);
+	__syncthreads();
+	if (wave != 0) return;
+	for (int w = 1; w < kMergeWaves; ++w) {
+		for (uint32_t e = 0; e < kk; ++e) {   // sorted: once one entry is rejected the rest of that list is too
+			const float d = s_d[w * kMaxFusedK2 + e];
+			const uint32_t i = s_i[w * kMaxFusedK2 + e];
+			if (i == kInvalidRow || !top.admits(d, i)) break;
+			top.insert(d, i, lane);
+		}
+	}
+	merge_store_list(top, s_d, s_i, lane);   // wave 0 only, its own slice
+	const size_t o = size_t(blockIdx.x) * kk;
+	if (lane < int(kk)) {
+		out_dist[o + lane] = s_d[lane];
+		out_row[o + lane] = s_i[lane];
+	}
+	if (64 + lane < int(kk)) {
+		out_dist[o + 64 + lane] = s_d[64 + lane];
+		out_row[o + 64 + lane] = s_i[64 + lane];
 	}
 	if (lane == 0 && out_count) out_count[blockIdx.x] = top.filled;
 }
@@ -806,6 +1001,16 @@ void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t tot
 	}
 	hipLaunchKernelGGL(knn_merge, dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, total_per_query, kk, out_dist, out_row, out_count,
 					   gate_cnt, gate_cap);
+}
+
+// the partial results are SORTED lists of kk entries (nlists per query): knn_merge_lists
+void launch_merge_lists(const float* part_dist, const uint32_t* part_row, uint32_t nlists, uint32_t kk, uint32_t nq, float* out_dist, uint32_t* out_row,
+						uint32_t* out_count, hipStream_t s) {
+	if (kk > uint32_t(kMaxFusedK)) {
+		hipLaunchKernelGGL((knn_merge_lists<WaveTopK2>), dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, nlists, kk, out_dist, out_row, out_count);
+	} else {
+		hipLaunchKernelGGL((knn_merge_lists<WaveTopK>), dim3(nq), dim3(kMergeThreads), 0, s, part_dist, part_row, nlists, kk, out_dist, out_row, out_count);
+	}
 }
 
 void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,

@@ -181,7 +181,7 @@ int enqueue_knn_fused(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_querie
 	}
 	{
 		ProfileScope ps(h, "merge", c->stream);
-		rxgpu::launch_merge(p.part_dist, p.part_row, gridx * kk, kk, nq, d_out_dist, d_out_row, d_out_count, nullptr, 0, c->stream);
+		rxgpu::launch_merge_lists(p.part_dist, p.part_row, gridx, kk, nq, d_out_dist, d_out_row, d_out_count, c->stream);
 	}
 	RX_HIP(hipGetLastError());
 	return RXGPU_OK;
@@ -559,7 +559,7 @@ int enqueue_knn_subset(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queri
 	}
 	{
 		ProfileScope ps(h, "merge", c->stream);
-		rxgpu::launch_merge(p.part_dist, p.part_row, gridx * kk, kk, nq, d_out_dist, d_out_row, d_out_count, nullptr, 0, c->stream);
+		rxgpu::launch_merge_lists(p.part_dist, p.part_row, gridx, kk, nq, d_out_dist, d_out_row, d_out_count, c->stream);
 	}
 	RX_HIP(hipGetLastError());
 	return RXGPU_OK;

@@ -23,6 +23,8 @@ void launch_filter_approx(const float* approx, uint64_t n, const float* top_dist
 						  uint32_t* cand_row, uint32_t* cand_cnt, uint32_t cap, uint32_t nq, int cus, hipStream_t s);
 void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t total_per_query, uint32_t kk, uint32_t nq, float* out_dist,
 				  uint32_t* out_row, uint32_t* out_count, const uint32_t* gate_cnt, uint32_t gate_cap, hipStream_t s);
+void launch_merge_lists(const float* part_dist, const uint32_t* part_row, uint32_t nlists, uint32_t kk, uint32_t nq, float* out_dist, uint32_t* out_row,
+						uint32_t* out_count, hipStream_t s);   // the partial results are sorted lists of kk entries: no serial insertions
 void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
 						 uint32_t* out_row, uint32_t* out_count, hipStream_t s);
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,
