@@ -105,6 +105,7 @@ def run(o) -> dict:
 
     run_split(0)   # warm-up (device sync of the Map, buffers)
     run_resident(0)
+    ftm.read_stats()
     t0 = time.perf_counter()
     parts = np.zeros(3)
     results = []
@@ -113,7 +114,7 @@ def run(o) -> dict:
         results.append(r)
         parts += dt
     split_s = time.perf_counter() - t0
-    ftm.read_stats()
+    split_postings, split_ft_ms = ftm.read_stats()   # the merges of the split leg ran alone on the device: their kernel time is the FT half's own
     ftm.read_fuse_stats()
     t0 = time.perf_counter()
     fused = [run_resident(q) for q in range(o.queries)]
@@ -135,6 +136,16 @@ def run(o) -> dict:
                    "boundary_ties_redone_on_host": int(sum(int(f[2]) for f in fused)),
                    "fused_results_avg": float(np.mean([len(f[0]) for f in fused])),
                    "identical_to_split_path_frac": same_as_split / o.queries},
+           "ft_half": {"kernel": "ft_ranges / ft_rank_all / ft_adders / ft_finish (+ ft_preselect_apply) train, alone on the device (split leg)",
+                       "ms_kernels_per_merge": split_ft_ms / o.queries, "postings_per_merge": split_postings / o.queries,
+                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
+                                    "achieved": split_postings * 20 / (split_ft_ms / 1e3) / 1e9 if split_ft_ms else None,
+                                    "frac": split_postings * 20 / (split_ft_ms / 1e3) / 1e9 / 8000.0 if split_ft_ms else None,
+                                    "bytes_per_posting": 20,
+                                    "note": "SURVEY 8d's 20 B per posting; the PMC passes of the 3 x 3 merge (profiles/rd3b_bm25_rocprof.json, FETCH_SIZE with the "
+                                            "gfx950 x2 correction) count 89 MB fetched + 16 MB written for 3.9 M postings = 27 B per posting = 1.34 x this model; "
+                                            "in the resident leg the same kernels share the device with the KNN scan (ms_ft_kernels there is their "
+                                            "stretched elapsed time, not their cost)"}},
            "gpu_split": {"path": "round-2 path: both halves downloaded, fused on the host (hybrid_rerank.h)", "queries_per_sec": o.queries / split_s,
                          "ms_per_query": split_s / o.queries * 1e3, "ms_ft_merge": parts[0] / o.queries * 1e3, "ms_knn_select": parts[1] / o.queries * 1e3,
                          "ms_fusion": parts[2] / o.queries * 1e3}}
