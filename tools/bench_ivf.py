@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--queries", type=int, default=200)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="cosine")
-    ap.add_argument("--nprobe", default="1,4,16,64")
+    ap.add_argument("--nprobe", default="1,4,16,64,128,256")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     metric = capi.METRICS[args.metric]
@@ -67,6 +67,24 @@ def main():
     for q in queries[:32]:
         ivf.search(q, args.k, nprobe=args.nlist)
     out["all_lists_ms_per_query"] = (time.perf_counter() - t0) / 32 * 1e3
+    # the queries of one call side by side (GpuIvfFlat::SearchBatch: a few host threads, every search on its own stream) and the range form
+    ivf.search_batch(queries[:8], args.k, nprobe=16)
+    t0 = time.perf_counter()
+    bd, bl = ivf.search_batch(queries, args.k, nprobe=16)
+    dt = (time.perf_counter() - t0) / args.queries
+    one = [ivf.search(q, args.k, nprobe=16) for q in queries]
+    out["batch_nprobe16"] = {"ms_per_query": dt * 1e3, "queries_per_sec": 1.0 / dt,
+                             "identical_to_single_searches": bool(all(np.array_equal(bl[i], one[i][1]) and
+                                                                      np.array_equal(bd[i].view(np.uint32), one[i][0].view(np.uint32)) for i in range(args.queries)))}
+    kd, _ = ivf.search(queries[0], 50, nprobe=16)
+    t0 = time.perf_counter()
+    hits = 0
+    for q in queries[:64]:
+        kd, _ = ivf.search(q, 50, nprobe=16)
+        rd, _ = ivf.range_search(q, float(kd[40]), nprobe=16)
+        hits += rd.size
+    out["range_nprobe16"] = {"ms_per_knn50_plus_range_query": (time.perf_counter() - t0) / 64 * 1e3, "hits_avg": hits / 64,
+                             "note": "radius = the 41st best distance of the same probe: the device lists are scanned by rxgpu_search_range_lists"}
     ivf.close()
     text = json.dumps(out)
     print(text)

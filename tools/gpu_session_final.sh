@@ -20,6 +20,8 @@ cd "$R"
 find gpurun_out/prof -name "*.csv" | head; tail -2 /tmp/p1.log
 # flatten rocprofv3's per-host subdirectories for tools/summarize_prof.py
 for d in trace pmc_fetch pmc_write; do for f in $(find gpurun_out/prof/$d -name "${TAG}_*.csv"); do cp "$f" gpurun_out/prof/$d/ 2>/dev/null; done; done
-python tools/summarize_prof.py gpurun_out/prof $TAG 2>&1 | tail -40
-# keep only what is small
-find gpurun_out/prof -name "*.csv" -size +2M -delete
+python tools/summarize_prof.py gpurun_out/prof $TAG > gpurun_out/${TAG}_summarize.log 2>&1; tail -5 gpurun_out/${TAG}_summarize.log
+cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_rocprof_summary.json gpurun_out/ 2>/dev/null   # profiles/ does not travel back, gpurun_out/ does
+# keep only what is small: of the counter files only this library's kernels
+for f in $(find gpurun_out/prof -name "*counter_collection.csv"); do (head -1 "$f"; grep rxgpu "$f") > "$f.rx" && mv "$f.rx" "$f"; done
+find gpurun_out/prof -name "*.csv" -size +4M -delete
