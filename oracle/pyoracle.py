@@ -290,10 +290,36 @@ def ref_or_none() -> Ref | None:
 class RefHnsw:
     """hnswlib::HierarchicalNSWImpl<float, None> of the reference (seed 100, ReplaceDeleted_True — hnsw.cc:74-78)."""
 
-    def __init__(self, ref: Ref, metric: int, dim: int, capacity: int, M: int = 16, ef_construction: int = 200):
+    def __init__(self, ref: Ref, metric: int, dim: int, capacity: int, M: int = 16, ef_construction: int = 200, _handle=None):
         self.ref, self.dim, self.metric = ref, dim, metric
-        self.h = ref.L.ref_hnsw_create(metric, dim, capacity, M, ef_construction)
+        self.h = _handle if _handle is not None else ref.L.ref_hnsw_create(metric, dim, capacity, M, ef_construction)
         assert self.h
+
+    def save_index(self) -> bytes:
+        """HierarchicalNSW::SaveIndex behind the float flag (hnsw.cc:56-62, hnswalg.h:1213-1263) through an in-memory IWriter."""
+        L = self.ref.L
+        L.ref_hnsw_save_index.restype = C.c_long
+        L.ref_hnsw_save_index.argtypes = [_vp, _vp, _sz]
+        n = L.ref_hnsw_save_index(self.h, None, 0)
+        if n < 0:
+            raise RuntimeError(L.ref_last_error().decode())
+        buf = np.empty(max(n, 1), np.uint8)
+        assert L.ref_hnsw_save_index(self.h, buf.ctypes.data, n) == n
+        return buf[:n].tobytes()
+
+    @classmethod
+    def load_index(cls, ref: Ref, data: bytes, metric: int, dim: int, labels, vectors) -> "RefHnsw":
+        """The reference's reader constructor (hnswalg.h:297-409) on an in-memory IReader whose primary keys resolve to (labels, vectors)."""
+        L = ref.L
+        L.ref_hnsw_load_index.restype = _vp
+        L.ref_hnsw_load_index.argtypes = [_vp, _sz, _i, _sz, _vp, _vp, _sz]
+        raw = np.frombuffer(data, np.uint8)
+        labels = np.ascontiguousarray(labels, np.uint64).reshape(-1)
+        vectors = _f32(vectors).reshape(-1, dim)
+        h = L.ref_hnsw_load_index(raw.ctypes.data if raw.size else None, raw.size, metric, dim, labels.ctypes.data, vectors.ctypes.data, labels.shape[0])
+        if not h:
+            raise RuntimeError(L.ref_last_error().decode())
+        return cls(ref, metric, dim, 0, _handle=h)
 
     def close(self):
         if self.h:

@@ -90,6 +90,73 @@ static double timedThreads(size_t threads, size_t perThread, double deadlineSec,
 }
 }  // namespace
 
+// ---- the ANN disk cache (HierarchicalNSW::SaveIndex / LoadIndex, hnsw.cc:41-53, over HierarchicalNSWImpl::SaveIndex hnswalg.h:1213-1263 and the reader
+// constructor :297-409) through memory: hnswlib::IWriter / IReader (hnsw_interface.h:47-70) implemented with fixed-width little-endian fields — 8 bytes per
+// var-int, u64 length + bytes per string, 4 bytes per float, the 8-byte label for a primary key.  reindexer_amd/host/host_capi.cc encodes the same way.
+namespace {
+class MemWriter final : public hnswlib::IWriter {
+public:
+	std::vector<uint8_t> buf;
+	void put(const void* p, size_t n) { buf.insert(buf.end(), static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n); }
+	void PutVarUInt(uint64_t v) override { put(&v, 8); }
+	void PutVarUInt(uint32_t v) override { PutVarUInt(uint64_t(v)); }
+	void PutVarInt(int64_t v) override { put(&v, 8); }
+	void PutVarInt(int32_t v) override { PutVarInt(int64_t(v)); }
+	void PutVString(std::string_view v) override {
+		const uint64_t n = v.size();
+		put(&n, 8);
+		put(v.data(), v.size());
+	}
+	void PutFloat(float v) override { put(&v, 4); }
+	void AppendPKByID(hnswlib::labeltype l) override {
+		const uint64_t v = l;
+		put(&v, 8);
+	}
+};
+class MemReader final : public hnswlib::IReader {
+public:
+	MemReader(const uint8_t* d, size_t n, size_t dim, const uint64_t* labels, const float* vectors, size_t rows) : d_(d), n_(n), dim_(dim), labels_(labels), vectors_(vectors), rows_(rows) {}
+	size_t Remaining() const noexcept { return n_ - at_; }
+	uint64_t GetVarUInt() override { return get<uint64_t>(); }
+	int64_t GetVarInt() override { return get<int64_t>(); }
+	float GetFloat() override { return get<float>(); }
+	std::string_view GetVString() override {
+		const uint64_t n = get<uint64_t>();
+		if (n_ - at_ < n) throw std::runtime_error("ANN cache: truncated stream");
+		std::string_view v(reinterpret_cast<const char*>(d_ + at_), n);
+		at_ += n;
+		return v;
+	}
+	hnswlib::labeltype ReadPkEncodedData(float* dest) override {
+		const uint64_t label = get<uint64_t>();
+		for (size_t i = 0; i < rows_; ++i) {
+			if (labels_[i] == label) {
+				std::memcpy(dest, vectors_ + i * dim_, dim_ * sizeof(float));
+				return label;
+			}
+		}
+		throw std::runtime_error("ANN cache: no row with the stored key");
+	}
+	bool WithQuantizer() const override { return false; }
+
+private:
+	template <typename T>
+	T get() {
+		if (n_ - at_ < sizeof(T)) throw std::runtime_error("ANN cache: truncated stream");
+		T v;
+		std::memcpy(&v, d_ + at_, sizeof(T));
+		at_ += sizeof(T);
+		return v;
+	}
+	const uint8_t* d_;
+	size_t n_, at_ = 0, dim_;
+	const uint64_t* labels_;
+	const float* vectors_;
+	size_t rows_;
+};
+}  // namespace
+
+
 extern "C" {
 
 const char* ref_last_error() { return g_err.c_str(); }
@@ -324,6 +391,34 @@ void ref_hnsw_search_knn_many(void* h, const float* queries, size_t nq, size_t d
 // reference's single-threaded AddPoint hours).  Fills exactly what HierarchicalNSWImpl(IReader&, ...) fills (hnswalg.h:290-410):
 // level-0 blocks [size word | maxM0 ids | vector | label | hash], the delete mark (markDeletedInternal :1323-1332), the stored norms
 // (DistCalculator::AddNorm), then initTree (:1265-1281) for label_lookup_ / deleted_elements / element_levels_ / linkLists_.
+// serializeQuantizingParams' flag for a float graph (hnsw.cc:56-62), then the engine's own SaveIndex.  Returns the byte count (copied when it fits).
+long ref_hnsw_save_index(void* h, uint8_t* out, size_t cap) {
+	try {
+		MemWriter w;
+		w.PutVarUInt(uint32_t(0));
+		const std::atomic_int32_t cancel{0};
+		static_cast<HnswT*>(h)->SaveIndex(w, cancel);
+		if (w.buf.size() <= cap) std::memcpy(out, w.buf.data(), w.buf.size());
+		return long(w.buf.size());
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return -1;
+	}
+}
+// HierarchicalNSW::LoadIndex's float branch (hnsw.cc:46-53, 85-100): the flag, then the reader constructor with the engine's construction constants
+void* ref_hnsw_load_index(const uint8_t* data, size_t len, int metric, size_t dim, const uint64_t* labels, const float* vectors, size_t rows) {
+	try {
+		MemReader r(data, len, dim, labels, vectors, rows);
+		if (r.GetVarUInt() != 0) throw std::runtime_error("quantization parameters in the stream");
+		auto g = std::make_unique<HnswT>(r, toMetric(metric), dim, 100, reindexer::ReplaceDeleted_True, std::nullopt);
+		if (r.Remaining()) throw std::runtime_error("unparsed data behind the graph");
+		return g.release();
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+
 int ref_hnsw_import_graph(void* h, size_t n, int maxlevel, uint32_t entry, const uint32_t* links0, const int32_t* levels, const uint64_t* labels,
 						  const uint8_t* deleted, const float* vectors, const uint64_t* upperOff, const uint32_t* upper) {
 	try {

@@ -61,6 +61,30 @@ void GpuHnswMap::ResizeIndex(size_t newMaxElements) {
 	graphDirty_ = true;
 }
 
+void GpuHnswMap::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const {
+	writer.PutVarUInt(uint32_t(0));   // serializeQuantizingParams: the cache holds links and keys, never codes — a float graph (hnsw.cc:56-62)
+	graph_.SaveIndex(writer, cancel);
+}
+
+void GpuHnswMap::LoadIndex(AnnCacheReader& reader) {
+	if (reader.GetVarUInt() != 0) {
+		throw std::runtime_error("GpuHnswMap::LoadIndex: the cache carries quantization parameters (read them with the reference's QuantizingParams and call LoadGraph)");
+	}
+	LoadGraph(reader);
+}
+
+void GpuHnswMap::Clear() {
+	graph_.Clear();
+	graphDirty_ = true;
+	deletedDirty_ = true;
+}
+
+void GpuHnswMap::LoadGraph(AnnCacheReader& reader) {
+	graph_.LoadIndex(reader);
+	graphDirty_ = true;
+	deletedDirty_ = true;
+}
+
 void GpuHnswMap::syncDevice() const {
 	std::lock_guard<std::mutex> lk(syncMtx_);
 	if (!graphDirty_ && !deletedDirty_) return;

@@ -105,6 +105,16 @@ public:
 
 private:
 	void syncDevice() const;
+public:
+	// The ANN disk cache (ann_cache.h): HierarchicalNSW::SaveIndex / LoadIndex (hnswlib/hnsw.cc:41-53).  The stream starts with the
+	// "quantised" flag (+ QuantizingParams when set); a float graph writes 0.  LoadIndex takes a stream whose flag is 0; a caller that
+	// holds the reference's QuantizingParams type (rx_seam.h) reads the flag and the parameters itself and calls LoadGraph for the rest.
+	// The Map must be empty; the next search uploads the whole graph to the device.
+	void SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const;
+	void LoadIndex(AnnCacheReader& reader);
+	void LoadGraph(AnnCacheReader& reader);
+	void Clear();   // an empty Map again (HnswIndexBase::clearMap)
+private:
 	struct PendingQuery;
 	void fetchKnn(const float* query, uint32_t k, uint32_t ef, float* dist, uint32_t* row, uint32_t* count) const;
 

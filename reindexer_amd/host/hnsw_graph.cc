@@ -65,6 +65,7 @@ HnswGraph::HnswGraph(VectorMetric metric, size_t dim, size_t maxElements, size_t
 		throw std::runtime_error("Not enough memory: HNSW constructor failed to allocate level0");
 	}
 	levelGenerator_.seed(uint32_t(randomSeed));
+	randomSeed_ = randomSeed;
 }
 
 HnswGraph::HnswGraph(const HnswGraph& o, size_t newMaxElements)
@@ -688,6 +689,150 @@ void HnswGraph::MarkDelete(labeltype label) {
 	deletedElements_.insert(id);   // markDeletedInternal :1323-1338 (allow_replace_deleted_)
 	labelLookup_.erase(it);        // allow_replace_deleted_ == true in the reference's construction (hnsw.h:72)
 	markDirty(id);                 // the flag travels with the next incremental patch of the device mirror (GpuHnswMap::syncDevice)
+}
+
+// ---------------------------------------------------------------------------------------------------- ANN disk cache
+void HnswGraph::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const {
+	constexpr size_t kCancelPeriod = 0x3FFFFF;
+	writer.PutVarUInt(uint64_t(maxElements_));
+	writer.PutVarUInt(uint64_t(count_));
+	writer.PutVarInt(int32_t(maxLevel_));
+	writer.PutVarUInt(uint32_t(entryPoint_));
+	writer.PutVarUInt(uint32_t(M_));
+	writer.PutVarUInt(uint32_t(efConstruction_));
+	for (size_t i = 0; i < count_; ++i) {
+		if (((i & kCancelPeriod) == kCancelPeriod) && cancel.load(std::memory_order_relaxed)) throw std::runtime_error("HNSW index saving was canceled");
+		const uint32_t* l0 = list(tableint(i), 0);
+		const uint32_t n = l0[0] & 0xFFFFu;   // getListCount: the low 16 bits; the delete mark is bit 0 of byte 2 (hnswalg.h:204, 1366-1374)
+		writer.PutVarUInt(uint32_t(n | (deleted_[i] ? 0x10000u : 0u)));
+		for (uint32_t j = 1; j <= n; ++j) writer.PutVarUInt(uint32_t(l0[j]));
+		if (deleted_[i]) {   // "We have to store full vector for the deleted items"
+			writer.PutVString(std::string_view(reinterpret_cast<const char*>(Vector(tableint(i))), dim_ * sizeof(float)));
+		} else {
+			writer.AppendPKByID(labels_[i]);
+		}
+	}
+	std::vector<uint32_t> block;
+	for (size_t i = 0; i < count_; ++i) {
+		if (((i & kCancelPeriod) == kCancelPeriod) && cancel.load(std::memory_order_relaxed)) throw std::runtime_error("HNSW index saving was canceled");
+		// the reference writes the raw block (:1259-1261), slots past each list's count included; those carry no meaning (every reader
+		// stops at the count), so this writer zeroes them: one graph, one byte string
+		const size_t words = levels_[i] > 0 ? size_t(levels_[i]) * (1 + M_) : 0;
+		block.assign(upper_[i].begin(), upper_[i].begin() + ptrdiff_t(words));
+		for (size_t lv = 0; lv < size_t(std::max(levels_[i], 0)); ++lv) {
+			uint32_t* ll = block.data() + lv * (1 + M_);
+			for (size_t j = 1 + (ll[0] & 0xFFFFu); j <= M_; ++j) ll[j] = 0;
+		}
+		writer.PutVString(std::string_view(reinterpret_cast<const char*>(block.data()), words * sizeof(uint32_t)));
+	}
+}
+
+void HnswGraph::LoadIndex(AnnCacheReader& reader) {
+	if (count_ != 0) throw std::logic_error("HnswGraph::LoadIndex: the graph is not empty");
+	try {
+		loadIndex(reader);
+	} catch (...) {
+		Clear();   // a half-read cache leaves nothing behind
+		throw;
+	}
+}
+
+void HnswGraph::loadIndex(AnnCacheReader& reader) {
+	const uint64_t maxElements = reader.GetVarUInt();
+	const uint64_t cnt = reader.GetVarUInt();
+	if (cnt > maxElements) throw std::runtime_error("Current elements count is larger than max elements count");
+	const int64_t maxLevel = reader.GetVarInt();
+	const uint64_t entry = reader.GetVarUInt();
+	if (cnt) {
+		if (entry >= cnt) throw std::runtime_error("Incorrect entrypoint node ID");
+	} else if (entry != 0xFFFFFFFFull) {
+		throw std::runtime_error("Unexpected entrypoint node ID for empty HNSW");
+	}
+	const uint64_t M = reader.GetVarUInt(), efC = reader.GetVarUInt();
+	if (M != M_ || efC != efConstruction_) {
+		throw std::runtime_error("HnswGraph::LoadIndex: the cache was written with M = " + std::to_string(M) + ", efConstruction = " + std::to_string(efC) +
+								 ", the index is defined with " + std::to_string(M_) + " / " + std::to_string(efConstruction_));
+	}
+	if (maxElements >= 0xFFFFFFFFull) throw std::runtime_error("HnswGraph::LoadIndex: max elements out of range");
+	if (maxElements > maxElements_) Resize(size_t(maxElements));
+	const size_t levelBytes = (1 + M_) * sizeof(uint32_t);
+	size_t deletedCount = 0;
+	for (size_t i = 0; i < cnt; ++i) {
+		uint32_t* l0 = list(tableint(i), 0);
+		const uint64_t marked = reader.GetVarUInt();
+		const uint32_t n = uint32_t(marked) & 0xFFFFu;
+		if (n > maxM0_) throw std::runtime_error("HnswGraph::LoadIndex: a level-0 list is longer than maxM0");
+		const bool isDeleted = ((marked >> 16) & 1u) != 0;
+		l0[0] = n;
+		for (uint32_t j = 1; j <= n; ++j) {
+			const uint64_t link = reader.GetVarUInt();
+			if (link >= cnt) throw std::runtime_error("HnswGraph::LoadIndex: a link points past the element count");
+			l0[j] = uint32_t(link);
+		}
+		float* dest = vectors_.data() + i * dim_;
+		labeltype label = std::numeric_limits<labeltype>::max();
+		if (isDeleted) {
+			const std::string_view vec = reader.GetVString();
+			if (vec.size() != dim_ * sizeof(float)) throw std::runtime_error("HnswGraph::LoadIndex: a deleted element's vector has the wrong size");
+			std::memcpy(dest, vec.data(), vec.size());
+		} else {
+			label = reader.ReadPkEncodedData(dest);
+		}
+		if (metric_ == VectorMetric::Cosine) invNorms_[i] = CalculateL2Module(dest, int32_t(dim_));   // AddNorm
+		labels_[i] = label;
+		deleted_[i] = isDeleted ? 1 : 0;
+		deletedCount += isDeleted ? 1 : 0;
+	}
+	count_ = size_t(cnt);
+	// initTree (hnswalg.h:1264-1281): deleted slots into the reuse set in id order, live labels into the lookup, levels from the list sizes
+	numDeleted_ = 0;
+	for (size_t i = 0; i < cnt; ++i) {
+		if (deleted_[i]) {
+			numDeleted_ += 1;
+			deletedElements_.insert(tableint(i));
+		} else {
+			labelLookup_[labels_[i]] = tableint(i);
+		}
+		const std::string_view lists = reader.GetVString();
+		if (lists.size() % levelBytes != 0) throw std::runtime_error("HnswGraph::LoadIndex: an upper-level block has a broken size");
+		levels_[i] = int32_t(lists.size() / levelBytes);
+		upper_[i].resize(lists.size() / sizeof(uint32_t));
+		if (!lists.empty()) std::memcpy(upper_[i].data(), lists.data(), lists.size());
+		for (int lv = 1; lv <= levels_[i]; ++lv) {
+			const uint32_t* ll = list(tableint(i), lv);
+			const uint32_t n = ll[0] & 0xFFFFu;
+			if (n > M_) throw std::runtime_error("HnswGraph::LoadIndex: an upper-level list is longer than M");
+			for (uint32_t j = 1; j <= n; ++j) {
+				if (ll[j] >= cnt) throw std::runtime_error("HnswGraph::LoadIndex: a link points past the element count");
+			}
+			for (size_t j = size_t(n) + 1; j <= M_; ++j) list(tableint(i), lv)[j] = 0;   // stale slots of the writer's raw block
+		}
+	}
+	if (numDeleted_ != deletedCount) throw std::logic_error("HnswGraph::LoadIndex: delete marks out of step");
+	maxLevel_ = int(maxLevel);
+	entryPoint_ = tableint(entry);
+	if (cnt && levels_[entryPoint_] != maxLevel_) throw std::runtime_error("HnswGraph::LoadIndex: the entry point is not on the top level");
+	dirty_.clear();
+	dirtyAll_.store(true, std::memory_order_relaxed);   // the device mirror takes the whole graph
+}
+
+void HnswGraph::Clear() {
+	count_ = 0;
+	numDeleted_ = 0;
+	maxLevel_ = -1;
+	entryPoint_ = 0xFFFFFFFFu;
+	std::fill(links0_.begin(), links0_.end(), 0u);
+	for (auto& u : upper_) u.clear();
+	std::fill(levels_.begin(), levels_.end(), 0);
+	std::fill(labels_.begin(), labels_.end(), labeltype(0));
+	std::fill(deleted_.begin(), deleted_.end(), uint8_t(0));
+	labelLookup_.clear();
+	deletedElements_ = DeletedIdSet();
+	levelGenerator_.seed(uint32_t(randomSeed_));
+	std::fill(visited_.stamp.begin(), visited_.stamp.end(), uint16_t(0));
+	visited_.cur = 0;
+	dirty_.clear();
+	dirtyAll_.store(true, std::memory_order_relaxed);
 }
 
 void HnswGraph::ExportUpper(std::vector<uint64_t>& off, std::vector<uint32_t>& blocks) const {

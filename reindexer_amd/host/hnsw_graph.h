@@ -34,6 +34,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "ann_cache.h"
 #include "hopscotch_set.h"
 #include "rx_types.h"
 
@@ -86,6 +87,17 @@ public:
 
 	size_t AllocatedMemSize() const noexcept;
 
+	// The ANN disk cache (ann_cache.h): HierarchicalNSWImpl::SaveIndex (hnswalg.h:1213-1263) and its reader constructor + initTree
+	// (:297-409, 1264-1281), field for field — header (max elements, count, max level, entry point, M, efConstruction), per element the
+	// level-0 list (size word with the delete mark, links) and either the vector (deleted) or the row's primary key, then per element the raw
+	// upper-level lists.  LoadIndex needs an EMPTY graph built with the cache's M / efConstruction (anything else throws: the caller then
+	// rebuilds the index, exactly what HnswIndexBase::LoadIndexCache's error path leads to).
+	void SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const;
+	void LoadIndex(AnnCacheReader& reader);
+	// back to the freshly constructed state (same capacity, same parameters, level generator reseeded): what HnswIndexBase::clearMap
+	// (hnsw_index.cc:72-83) does with `map_ = Map(...)` after a cache load failed half way
+	void Clear();
+
 	// Change tracking for the device mirror: the nodes whose lists / vector changed since the last TakeDirty().  Returns false when the
 	// tracker gave up (more than a quarter of the graph touched, e.g. a bulk build): everything has to be re-sent.
 	bool TakeDirty(std::vector<tableint>& out);
@@ -98,6 +110,7 @@ private:
 	using Heap = ResultHeap<Pair, ByFirst>;
 
 	float distIds(tableint a, tableint b) const noexcept;               // DistCalculator(v1,id1,v2,id2) hnswlib.h:123-145
+	void loadIndex(AnnCacheReader& reader);
 	uint32_t* list(tableint id, int level) noexcept;
 	const uint32_t* list(tableint id, int level) const noexcept;
 	int randomLevel();
@@ -138,6 +151,7 @@ private:
 	std::vector<uint8_t> deleted_;
 	std::unordered_map<labeltype, tableint> labelLookup_;
 	std::default_random_engine levelGenerator_;
+	size_t randomSeed_ = 100;
 	DeletedIdSet deletedElements_;   // HierarchicalNSWImpl::deleted_elements (allow_replace_deleted_): ids in the reference's hash-set order
 
 	Visited visited_;   // the sequential builder's scratch

@@ -7,6 +7,8 @@
 #include <stdexcept>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
+#include <vector>
 #include <cstring>
 #include <string>
 
@@ -199,6 +201,72 @@ long rxhost_bf_select(void* h, const float* key, size_t dim, long k, int has_rad
 // ---------------------------------------------------------------------------------------------- HNSW graph builder
 #include "hnsw_graph.h"
 
+// ---- the ANN disk cache through plain memory (tests, tools): fixed-width little-endian fields — 8 bytes per var-int, u64 length + bytes per
+// string, 4 bytes per float, the 8-byte label for a primary key (the reader resolves it against the (labels, vectors) table it was given).
+// oracle/ref/ref_shim.cc implements hnswlib::IWriter / IReader with the SAME encoding around the reference engine, so the two sides exchange
+// caches byte for byte.
+namespace {
+class MemAnnWriter final : public rxgpu::host::AnnCacheWriter {
+public:
+	std::vector<uint8_t> buf;
+	void put(const void* p, size_t n) { buf.insert(buf.end(), static_cast<const uint8_t*>(p), static_cast<const uint8_t*>(p) + n); }
+	void PutVarUInt(uint64_t v) override { put(&v, 8); }
+	void PutVarUInt(uint32_t v) override { PutVarUInt(uint64_t(v)); }
+	void PutVarInt(int64_t v) override { put(&v, 8); }
+	void PutVarInt(int32_t v) override { PutVarInt(int64_t(v)); }
+	void PutVString(std::string_view v) override {
+		const uint64_t n = v.size();
+		put(&n, 8);
+		put(v.data(), v.size());
+	}
+	void PutFloat(float v) override { put(&v, 4); }
+	void AppendPKByID(labeltype l) override { put(&l, 8); }
+};
+class MemAnnReader final : public rxgpu::host::AnnCacheReader {
+public:
+	MemAnnReader(const uint8_t* d, size_t n, size_t dim, const uint64_t* labels, const float* vectors, size_t rows) : d_(d), n_(n), dim_(dim), vectors_(vectors) {
+		for (size_t i = 0; i < rows; ++i) rowOf_[labels[i]] = i;
+	}
+	size_t Remaining() const noexcept { return n_ - at_; }
+	uint64_t GetVarUInt() override { return get<uint64_t>(); }
+	int64_t GetVarInt() override { return get<int64_t>(); }
+	float GetFloat() override { return get<float>(); }
+	std::string_view GetVString() override {
+		const uint64_t n = get<uint64_t>();
+		need(n);
+		std::string_view v(reinterpret_cast<const char*>(d_ + at_), n);
+		at_ += n;
+		return v;
+	}
+	labeltype ReadPkEncodedData(float* dest) override {
+		const uint64_t label = get<uint64_t>();
+		const auto it = rowOf_.find(label);
+		if (it == rowOf_.end()) throw std::runtime_error("ANN cache: no row with the stored key");
+		std::memcpy(dest, vectors_ + it->second * dim_, dim_ * sizeof(float));
+		return label;
+	}
+	bool WithQuantizer() const override { return false; }
+
+private:
+	void need(size_t n) const {
+		if (n_ - at_ < n) throw std::runtime_error("ANN cache: truncated stream");
+	}
+	template <typename T>
+	T get() {
+		need(sizeof(T));
+		T v;
+		std::memcpy(&v, d_ + at_, sizeof(T));
+		at_ += sizeof(T);
+		return v;
+	}
+	const uint8_t* d_;
+	size_t n_, at_ = 0, dim_;
+	const float* vectors_;
+	std::unordered_map<uint64_t, size_t> rowOf_;
+};
+}  // namespace
+
+
 extern "C" {
 
 void* rxhost_graph_create(int metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction) {
@@ -232,6 +300,31 @@ int rxhost_graph_mark_delete(void* h, uint64_t label) {
 	return guarded([&] { static_cast<HnswGraph*>(h)->MarkDelete(label); });
 }
 // info[0]=count [1]=M [2]=maxM0 [3]=maxlevel [4]=entry [5]=numDeleted [6]=upper blocks
+// HnswGraph::SaveIndex behind the "not quantised" flag of HierarchicalNSW::SaveIndex (hnsw.cc:41-44).  Returns the byte count (copied when it fits cap).
+long rxhost_graph_save_index(void* h, uint8_t* out, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		MemAnnWriter w;
+		w.PutVarUInt(uint32_t(0));
+		const std::atomic_int32_t cancel{0};
+		static_cast<const HnswGraph*>(h)->SaveIndex(w, cancel);
+		if (w.buf.size() <= cap) std::memcpy(out, w.buf.data(), w.buf.size());
+		n = long(w.buf.size());
+	});
+	return n;
+}
+// ... and LoadIndex into an EMPTY graph; (labels, vectors): the namespace's rows the primary keys of the cache resolve to
+int rxhost_graph_load_index(void* h, const uint8_t* data, size_t len, const uint64_t* labels, const float* vectors, size_t rows) {
+	return guarded([&] {
+		auto* g = static_cast<HnswGraph*>(h);
+		MemAnnReader r(data, len, g->Dim(), labels, vectors, rows);
+		if (r.GetVarUInt() != 0) throw std::runtime_error("ANN cache: quantization parameters in the stream");
+		g->LoadIndex(r);
+		if (r.Remaining()) throw std::runtime_error("ANN cache: unparsed data behind the graph");
+	});
+}
+void rxhost_graph_clear(void* h) { static_cast<HnswGraph*>(h)->Clear(); }
+
 void rxhost_graph_info(void* h, int64_t* info) {
 	auto* g = static_cast<HnswGraph*>(h);
 	info[0] = int64_t(g->Count());
@@ -331,6 +424,31 @@ int rxhost_hnsw_resize(void* h, size_t n) {
 size_t rxhost_hnsw_count(void* h) { return static_cast<GpuHnswMap*>(h)->CurrentElementCount(); }
 size_t rxhost_hnsw_deleted_count(void* h) { return static_cast<GpuHnswMap*>(h)->DeletedCountUnsafe(); }
 void* rxhost_hnsw_graph(void* h) { return const_cast<HnswGraph*>(&static_cast<GpuHnswMap*>(h)->Graph()); }
+// the Map's ANN disk cache through memory (same encoding as rxhost_graph_save_index / _load_index)
+long rxhost_hnsw_save_index(void* h, uint8_t* out, size_t cap) {
+	long n = -1;
+	guarded([&] {
+		MemAnnWriter w;
+		const std::atomic_int32_t cancel{0};
+		static_cast<const GpuHnswMap*>(h)->SaveIndex(w, cancel);
+		if (w.buf.size() <= cap) std::memcpy(out, w.buf.data(), w.buf.size());
+		n = long(w.buf.size());
+	});
+	return n;
+}
+int rxhost_hnsw_load_index(void* h, const uint8_t* data, size_t len, const uint64_t* labels, const float* vectors, size_t rows) {
+	return guarded([&] {
+		auto* m = static_cast<GpuHnswMap*>(h);
+		MemAnnReader r(data, len, m->Dim(), labels, vectors, rows);
+		try {
+			m->LoadIndex(r);
+			if (r.Remaining()) throw std::runtime_error("ANN cache: unparsed data behind the graph");
+		} catch (...) {
+			m->Clear();   // HnswIndexBase::LoadIndexCache's error path (clearMap)
+			throw;
+		}
+	});
+}
 long rxhost_hnsw_search_knn(void* h, const float* q, size_t k, size_t ef, float* outDist, uint64_t* outLabel) {
 	long n = -1;
 	guarded([&] {

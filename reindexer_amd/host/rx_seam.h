@@ -43,13 +43,45 @@ public:
 	size_t GetHash(FloatVectorId id) const {
 		return ConstFloatVectorView{std::span<const float>{FloatPtrByExternalLabel(id.AsNumber()), Dim()}}.Hash();
 	}
-	// The ANN disk cache is not provided by the GPU engine: the index type is registered as non-cacheable (like brute force).  SQ8: the Map
-	// itself quantises (GpuHnswMap::Quantize(minQ, maxQ) + the device search over codes), but HnswIndexBase::Quantize() derives the range by
-	// sampling the reference's own graph storage (QuantizingParams over an HNSWView, quantization_params.h:48-63), which this adapter does
-	// not expose yet — so through the seam QuantizationAvailable() stays false and these are never reached; they fail loudly if called.
+	// The ANN disk cache (HnswIndexBase::WriteIndexCache / LoadIndexCache, hnsw_index.cc:388-507): the reference's writer / reader objects
+	// forwarded to the Map's own interfaces (ann_cache.h) — the stream is the CPU engine's, field for field, so a cache written by either
+	// engine loads into the other.  A cache the CPU engine wrote from a QUANTISED graph carries QuantizingParams in front: read past with
+	// the reference's own type; the links are the same graph and the Map rebuilds float rows from the primary keys.
+	void SaveIndex(hnswlib::IWriter& writer, const std::atomic_int32_t& cancel) const {
+		struct W final : AnnCacheWriter {
+			hnswlib::IWriter& w;
+			explicit W(hnswlib::IWriter& w_) : w(w_) {}
+			void PutVarUInt(uint64_t v) override { w.PutVarUInt(v); }
+			void PutVarUInt(uint32_t v) override { w.PutVarUInt(v); }
+			void PutVarInt(int64_t v) override { w.PutVarInt(v); }
+			void PutVarInt(int32_t v) override { w.PutVarInt(v); }
+			void PutVString(std::string_view v) override { w.PutVString(v); }
+			void PutFloat(float v) override { w.PutFloat(v); }
+			void AppendPKByID(labeltype l) override { w.AppendPKByID(l); }
+		} fw(writer);
+		GpuHnswMap::SaveIndex(fw, cancel);
+	}
+	void LoadIndex(hnswlib::IReader& reader) {
+		struct R final : AnnCacheReader {
+			hnswlib::IReader& r;
+			explicit R(hnswlib::IReader& r_) : r(r_) {}
+			uint64_t GetVarUInt() override { return r.GetVarUInt(); }
+			int64_t GetVarInt() override { return r.GetVarInt(); }
+			std::string_view GetVString() override { return r.GetVString(); }
+			float GetFloat() override { return r.GetFloat(); }
+			labeltype ReadPkEncodedData(float* dest) override { return r.ReadPkEncodedData(dest); }
+			bool WithQuantizer() const override { return r.WithQuantizer(); }
+		} fr(reader);
+		if (reader.GetVarUInt() != 0) {   // deserializeQuantizingParams (hnsw.cc:64-72)
+			hnswlib::QuantizingParams params;
+			params.Deserialize(reader);
+		}
+		GpuHnswMap::LoadGraph(fr);
+	}
+	// SQ8: the Map itself quantises (GpuHnswMap::Quantize(minQ, maxQ) + the device search over codes), but HnswIndexBase::Quantize() derives
+	// the range by sampling the reference's own graph storage (QuantizingParams over an HNSWView, quantization_params.h:48-63), which this
+	// adapter does not expose yet — so through the seam QuantizationAvailable() stays false and the two below are never reached.
 	bool QuantizationAvailable() const noexcept { return false; }
-	void SaveIndex(hnswlib::IWriter&, const std::atomic_int32_t&) const { throw std::logic_error("GpuHnswMap: the ANN disk cache is not supported"); }
-	void LoadIndex(hnswlib::IReader&) { throw std::logic_error("GpuHnswMap: the ANN disk cache is not supported"); }
 	void Quantize(const hnswlib::QuantizationConfig&) { throw std::logic_error("GpuHnswMap: quantization is not supported"); }
 	void SwitchMapOnQuantized() { throw std::logic_error("GpuHnswMap: quantization is not supported"); }
 };

@@ -71,6 +71,26 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _save_bytes(fn, h) -> bytes:
+    n = fn(h, None, 0)
+    if n < 0:
+        _raise()
+    buf = np.empty(max(n, 1), np.uint8)
+    if fn(h, buf.ctypes.data, n) != n:
+        _raise()
+    return buf[:n].tobytes()
+
+
+def _load_bytes(fn, h, data: bytes, labels, vectors, dim: int):
+    raw = np.frombuffer(data, np.uint8)
+    labels = np.ascontiguousarray(labels, np.uint64).reshape(-1)
+    vectors = _f32(vectors).reshape(-1, dim)
+    assert vectors.shape[0] == labels.shape[0]
+    rc = fn(h, raw.ctypes.data if raw.size else None, raw.size, labels.ctypes.data, vectors.ctypes.data, labels.shape[0])
+    if rc:
+        _raise(rc)
+
+
 def l2_module(x) -> np.float32:
     x = _f32(x)
     return np.float32(lib().rxhost_l2_module(x.ctypes.data, x.shape[0]))
@@ -232,6 +252,10 @@ class HnswGraph:
             L.rxhost_graph_vectors.argtypes = [_vp]
             L.rxhost_graph_inv_norms.restype = C.POINTER(C.c_float)
             L.rxhost_graph_inv_norms.argtypes = [_vp]
+            L.rxhost_graph_save_index.restype = _l
+            L.rxhost_graph_save_index.argtypes = [_vp, _vp, _sz]
+            L.rxhost_graph_load_index.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
+            L.rxhost_graph_clear.argtypes = [_vp]
             L._graph_bound = True
         return L
 
@@ -285,6 +309,18 @@ class HnswGraph:
                                   upper_off.ctypes.data, upper.ctypes.data)
         return dict(metric=self.metric, n=n, dim=self.dim, M=M, maxM0=maxM0, maxlevel=maxlevel, entry=entry & 0xFFFFFFFF, num_deleted=ndel,
                     links0=links0, upper_off=upper_off, upper=upper, levels=levels, labels=labels, deleted=deleted)
+
+    def save_index(self) -> bytes:
+        """The reference's ANN disk cache of this graph (hnswalg.h:1213-1263 behind the float flag of hnsw.cc:56-62), in the test
+        encoding of the in-memory writer: 8 bytes per var-int, u64 length + bytes per string, 8-byte label per primary key."""
+        return _save_bytes(lib().rxhost_graph_save_index, self.h)
+
+    def load_index(self, data: bytes, labels, vectors):
+        """LoadIndex into this EMPTY graph; (labels, vectors) are the namespace's rows the cache's primary keys resolve to."""
+        _load_bytes(lib().rxhost_graph_load_index, self.h, data, labels, vectors, self.dim)
+
+    def clear(self):
+        lib().rxhost_graph_clear(self.h)
 
     def vector_views(self, n: int):
         """Zero-copy numpy views of the builder's vectors [n][dim] and (cosine) stored 1/|v| [n], in internal-id order — the order a
@@ -448,6 +484,9 @@ class GpuHnswMap:
             L.rxhost_hnsw_search_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
             L.rxhost_hnsw_select.restype = _l
             L.rxhost_hnsw_select.argtypes = [_vp, _vp, _sz, _l, _sz, _i, _f, _i, _i, _vp, _vp, _sz]
+            L.rxhost_hnsw_save_index.restype = _l
+            L.rxhost_hnsw_save_index.argtypes = [_vp, _vp, _sz]
+            L.rxhost_hnsw_load_index.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
             L._hnsw_bound = True
         self.dim, self.metric = dim, metric
         create = L.rxhost_hnsw_create_mt if multithread else L.rxhost_hnsw_create
@@ -497,6 +536,14 @@ class GpuHnswMap:
         rc = lib().rxhost_hnsw_resize(self.h, n)
         if rc:
             _raise(rc)
+
+    def save_index(self) -> bytes:
+        """HnswIndexBase::WriteIndexCache's Map part (hnsw_index.cc:388-437 -> hnsw.cc:56-62): quantisation flag + the graph."""
+        return _save_bytes(lib().rxhost_hnsw_save_index, self.h)
+
+    def load_index(self, data: bytes, labels, vectors):
+        """LoadIndexCache's Map part (hnsw_index.cc:439-507) into an empty Map; on any error the Map is cleared, as clearMap() does."""
+        _load_bytes(lib().rxhost_hnsw_load_index, self.h, data, labels, vectors, self.dim)
 
     count = property(lambda self: lib().rxhost_hnsw_count(self.h))
     deleted_count = property(lambda self: lib().rxhost_hnsw_deleted_count(self.h))
