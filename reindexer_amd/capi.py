@@ -74,6 +74,7 @@ _SIGNATURES = {
     "rxgpu_hnsw_attach_sq8": (_i, [_vp, _vp, _vp, _u64, _f]),
     "rxgpu_hnsw_search_knn_sq8": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rxgpu_hnsw_read_tie_reruns": (_i, [_vp, C.POINTER(_u64)]),
     "rxgpu_hnsw_search_range": (_i, [_vp, _vp, _f, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_hnsw_search_range_sq8": (_i, [_vp, _vp, _f, _f, _f, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_hnsw_stream_begin_sq8": (_i, [_vp, _vp, _f, _f, _u32, C.POINTER(_vp)]),
@@ -414,6 +415,11 @@ class VectorIndex:
         a, b = _u64(0), _u64(0)
         _check(lib().rxgpu_hnsw_read_stats(self._h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
+
+    def hnsw_read_tie_reruns(self) -> int:
+        a = _u64(0)
+        _check(lib().rxgpu_hnsw_read_tie_reruns(self._h, C.byref(a)))
+        return int(a.value)
 
     # ---- instrumentation
     def profile_enable(self, on: bool = True) -> None:

@@ -68,6 +68,162 @@ __device__ __forceinline__ void hp_replace_top(uint2* h, int n, float vd, uint32
 	hp_sift_down(h, 0, n);
 }
 
+// --- The fast path of a search over a graph without deleted nodes: BOTH queues as one sorted list spread over the lanes ---
+// In a bare-bone search (hnswalg.h:873-876, 932-960) every candidate is pushed into top_candidates together with its push into
+// candidate_set, so the live part of candidate_set is "the members of top_candidates that were not expanded yet": what top_candidates
+// evicted lies at or above lowerBound for good, and popping it ends the search like an empty candidate_set does (at: see below).  One list of <= ef
+// entries sorted by distance plus one "expanded" bit per entry therefore carries the whole Layer0SearchState: entry 64 s + l lives in
+// slot s of lane l, an insertion is one ballot + one lane shift (wave_shr DPP) instead of two binary-heap sifts by one lane, the pop is a
+// scalar find-first-zero.
+// Equal distances.  With CompareByFirst heaps the reference's choice among EQUAL keys is whatever libstdc++'s sift loops leave on top,
+// which a sorted list cannot know.  Where that choice cannot matter the list goes on; where it can, the query is flagged — kHnswTie —
+// and the launcher re-runs it on the heap kernel below:
+//   * the popped candidate's key d equals the next unexpanded one's (which of the two the reference expands first is its heap's
+//     secret) AND lowerBound has come down to d by the time every candidate with a key <= d is expanded.  While lowerBound stays above
+//     d the order is immaterial: each node of key <= d that gets evaluated is admitted (key < lowerBound) and expanded before anything
+//     farther, so both orders expand the same closure — "evaluated nodes of key <= d, and what their lists reach" —, top_candidates
+//     is the ef smallest keys of the same evaluated set, and lowerBound in the other order is never below its value at the end of this
+//     one (fewer keys seen, larger ef-th smallest).  The check is made when the first key > d is popped, or when the list runs dry;
+//   * the popped key, or lowerBound when the list runs dry, equals the key of the last node that went OUTSIDE the list with a key equal
+//     to lowerBound — evicted next to an equal maximum, or refused admission at dist == lowerBound: an evicted entry is still in the
+//     reference's candidate_set, alive (dist > lowerBound is false) and due for expansion, and in another order of equal pops a refused
+//     node is one that got in.  (Keys outside the list never lie below lowerBound, and lowerBound only falls: the last such key is the
+//     only one that can still equal it.)
+//   * entries k - 1 and k of the final list are equal (SearchKnn's trim to k pops one of them);
+//   * a key is not finite.
+// Everything else depends on keys alone: top_candidates is the multiset of the ef smallest keys seen, an eviction among equal maxima
+// changes neither lowerBound nor candidate_set, and an equal key met in the middle of the list has no consequence until one of the
+// events above.  (Flagging every equal key met on insertion re-ran 31 % of the queries of a 1M x 768 corpus: with 128 keys in a narrow
+// band of float32 values a search of ~400 insertions meets one more often than not.)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {   // lane l <- lane l - 1 (lane 0 keeps its value)
+	return uint32_t(__builtin_amdgcn_update_dpp(int(x), int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_value(float v, int l) { return __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(v)), l))); }
+template <int S>
+struct HnswSortedList {
+	float d[S];
+	uint32_t id[S];
+	uint64_t done[S];   // wave-uniform: bit l of word s = entry 64 s + l is expanded (or empty)
+	int n;
+	float lower;        // lowerBound: the largest key while the list is filling, entry ef - 1 afterwards
+	float outside;      // key of the last node evicted, or refused at dist == lowerBound (NaN before the first: equal to nothing)
+	float pend;         // largest key at which a pop met an equal unexpanded key and the verdict is still open
+	bool pending;
+	bool tie;
+	bool dpp;
+
+	__device__ __forceinline__ void init(bool use_dpp) {
+		dpp = use_dpp;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			d[s] = __builtin_inff();
+			id[s] = 0u;
+			done[s] = ~0ull;
+		}
+		n = 0;
+		lower = 3.402823466e+38f;
+		outside = __builtin_nanf("");
+		pend = 0.f;
+		pending = false;
+		tie = false;
+	}
+	// every candidate of key <= pend is expanded now: the order among the equal ones was immaterial iff lowerBound is still above pend
+	// (a list that is not full admits everything, whatever lowerBound says)
+	__device__ __forceinline__ void settle(int ef) {
+		if (pending && n == ef && !(lower > pend)) tie = true;
+		pending = false;
+	}
+	// key of entry e (wave-uniform e)
+	__device__ __forceinline__ float key_at(int e) const {
+		float v = d[0];
+#pragma unroll
+		for (int s = 1; s < S; ++s) v = (e >> 6) == s ? d[s] : v;
+		return lane_value(v, e & 63);
+	}
+	// (nd, nid) wave-uniform; the caller has checked n < ef || lower > nd
+	__device__ __forceinline__ void insert(float nd, uint32_t nid, int ef, int lane) {
+		int pos = 0;
+#pragma unroll
+		for (int s = 0; s < S; ++s) pos += __popcll(__ballot(d[s] < nd));
+		tie = tie || !(nd < __builtin_inff());
+		if (n == ef) outside = lower;   // the list is full: its last entry leaves
+#pragma unroll
+		for (int s = S - 1; s >= 0; --s) {
+			if (pos >= 64 * (s + 1)) continue;   // uniform: the slot lies below the insertion point
+			const int g = 64 * s + lane;
+			float up_d;
+			uint32_t up_i;
+			if (dpp) {
+				up_d = __uint_as_float(wave_shr1(__float_as_uint(d[s])));
+				up_i = wave_shr1(id[s]);
+			} else {   // RXGPU_HNSW_SORTED=2: the same shift through the LDS crossbar (ds_bpermute)
+				up_d = __shfl_up(d[s], 1, 64);
+				up_i = __shfl_up(id[s], 1, 64);
+			}
+			if (s > 0) {
+				const float carry_d = lane_value(d[s > 0 ? s - 1 : 0], 63);
+				const uint32_t carry_i = uint32_t(__builtin_amdgcn_readlane(int(id[s > 0 ? s - 1 : 0]), 63));
+				if (lane == 0) {
+					up_d = carry_d;
+					up_i = carry_i;
+				}
+			}
+			d[s] = g < pos ? d[s] : (g == pos ? nd : up_d);
+			id[s] = g < pos ? id[s] : (g == pos ? nid : up_i);
+			if (pos < 64 * s) {
+				done[s] = (done[s] << 1) | (done[s > 0 ? s - 1 : 0] >> 63);
+			} else {
+				const uint64_t below = (1ull << (pos - 64 * s)) - 1ull;
+				done[s] = (done[s] & below) | ((done[s] & ~below) << 1);   // bit pos: 0 = not expanded
+			}
+		}
+		if (n < ef) {
+			++n;
+		} else {
+#pragma unroll
+			for (int s = 0; s < S; ++s) {   // the evicted maximum sits at index ef now (if the registers reach that far): an empty entry again
+				const bool here = (ef >> 6) == s;
+				d[s] = (here && lane == (ef & 63)) ? __builtin_inff() : d[s];
+				done[s] |= here ? 1ull << (ef & 63) : 0ull;
+			}
+		}
+		lower = key_at(n - 1);
+	}
+	// first entry that was not expanded yet, -1 if none (selects over static slot numbers, no early exit: the arrays must stay in registers)
+	__device__ __forceinline__ int first_open() const {
+		int e = -1;
+#pragma unroll
+		for (int s = S - 1; s >= 0; --s) {
+			const uint64_t o = ~done[s];
+			e = o ? 64 * s + __builtin_ctzll(o) : e;
+		}
+		return e;
+	}
+	// candidate_set.top() + pop(): the nearest entry that was not expanded yet
+	__device__ __forceinline__ bool pop(uint32_t& node, float& dist, int ef) {
+		const int e = first_open();
+		if (e < 0) {
+			settle(ef);
+			return false;
+		}
+		uint32_t iv = id[0];
+#pragma unroll
+		for (int s = 1; s < S; ++s) iv = (e >> 6) == s ? id[s] : iv;
+		dist = key_at(e);
+		node = uint32_t(__builtin_amdgcn_readlane(int(iv), e & 63));
+		if (pending && dist > pend) settle(ef);
+#pragma unroll
+		for (int s = 0; s < S; ++s) done[s] |= (e >> 6) == s ? 1ull << (e & 63) : 0ull;
+		const int next = first_open();
+		tie = tie || dist == outside;
+		if (next >= 0 && key_at(next) == dist) {
+			pend = pending ? fmaxf(pend, dist) : dist;
+			pending = true;
+		}
+		return true;
+	}
+};
+
 // Distances of `cnt` rows (ids in LDS) to the query, 4 rows per step; every lane participates in every step.
 template <int kMetric>
 __device__ __forceinline__ void batch_distances(const HnswParams& p, const float* q, const uint32_t* ids, int cnt, float* dists, int lane) {
@@ -201,8 +357,10 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 
 // kLatency: few queries in flight -> two row sets per distance trip (fewer dependent round trips per hop, 172 VGPRs at D = 768);
 // otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
-template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false>
-__global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
+// kSorted: 0 = the reference's two heaps, replayed by lane 0; S > 0 = HnswSortedList<S> (ef <= 64 S, no deleted nodes, heaps not in LDS at all)
+template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0>
+__global__ __launch_bounds__(64, (kSorted > 0 && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
+	static_assert(kSorted == 0 || !kGlobalCand, "the sorted list has no candidate heap to spill");
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
 	extern __shared__ __attribute__((aligned(16))) unsigned char hnsw_lds[];
@@ -290,6 +448,88 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 				}
 			}
 		}
+	}
+
+	if constexpr (kSorted > 0) {
+		// ---- layer 0 on the sorted list (bare-bone search only: the launcher keeps graphs with deleted nodes on the heap path)
+		HnswSortedList<kSorted> list;
+		list.init(p.sorted == 1);
+		const int ef = int(p.ef);
+		list.insert(curdist, cur, ef, lane);
+		if (lane == 0) atomicOr(&visited[cur >> 5], 1u << (cur & 31));
+		ndist += 1;   // the reference recomputes the entry distance here (same value)
+		for (;;) {
+			uint32_t node;
+			float cdist;
+			if (!list.pop(node, cdist, ef)) {   // candidate_set empty, or only evicted entries left in it ...
+				list.tie = list.tie || (list.n == ef && list.lower == list.outside);   // ... of which the last one is still alive in the reference's
+				break;
+			}
+			if (list.tie) break;                 // the rest of this search belongs to the heap kernel
+			if (cdist > list.lower) break;       // layer0ShouldStopBeforePop (never true for a member of the list; kept for the form)
+			hops += 1;
+			const uint32_t* ll = p.links0 + size_t(node) * (1 + p.maxM0);
+			int nfresh = 0;
+			int cnt = 0;
+			for (int base = 0; base <= int(p.maxM0); base += 64) {
+				const int w = base + lane;
+				const uint32_t word = w <= int(p.maxM0) ? ll[w] : 0u;
+				if (base == 0) cnt = int(__builtin_amdgcn_readfirstlane(word));
+				if (base > cnt) break;   // uniform
+				const int j = w - 1;
+				bool fresh = false;
+				if (j >= 0 && j < cnt) {
+					const uint32_t bit = 1u << (word & 31);
+					fresh = !(atomicOr(&visited[word >> 5], bit) & bit);
+				}
+				const uint64_t fm = __ballot(fresh);
+				if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
+				nfresh += __popcll(fm);
+			}
+			__syncthreads();
+			distances(nb_id, nfresh, nb_d);
+			ndist += nfresh;
+			__syncthreads();
+			for (int base = 0; base < nfresh; base += 64) {   // runLayer0Step :932-960 in neighbour order; lane j carries neighbour base + j
+				const int j = base + lane;
+				const float dj = j < nfresh ? nb_d[j] : __builtin_inff();
+				const uint32_t idj = j < nfresh ? nb_id[j] : 0u;
+				// lowerBound only falls while the list is full: what fails the test now fails it later in the loop as well
+				uint64_t m = __ballot(j < nfresh && (list.n < ef || list.lower > dj));
+				if (list.n == ef && __ballot(j < nfresh && dj == list.lower)) list.outside = list.lower;   // refused at dist == lowerBound
+				while (m) {
+					const int b = __builtin_ctzll(m);
+					m &= m - 1;
+					const float nd = lane_value(dj, b);
+					if (list.n < ef || list.lower > nd) {
+						list.insert(nd, uint32_t(__builtin_amdgcn_readlane(int(idj), b)), ef, lane);
+					} else if (nd == list.lower) {
+						list.outside = nd;
+					}
+				}
+			}
+			__syncthreads();
+		}
+		const int keep = list.n < int(p.k) ? list.n : int(p.k);   // SearchKnn :1998-2000: the k nearest of top_candidates
+		if (!list.tie && list.n > keep && list.key_at(keep - 1) == list.key_at(keep)) list.tie = true;   // the trim pops one of two equal keys
+		if (list.tie) {
+			if (lane == 0) p.out_count[qi] = kHnswTie;
+		} else {
+#pragma unroll
+			for (int s = 0; s < kSorted; ++s) {
+				const int g = 64 * s + lane;
+				if (g < keep) {
+					p.out_dist[size_t(qi) * p.k + g] = list.d[s];
+					p.out_row[size_t(qi) * p.k + g] = list.id[s];
+				}
+			}
+			if (lane == 0) p.out_count[qi] = uint32_t(keep);
+		}
+		if (lane == 0 && p.stats && !list.tie) {   // a re-run counts itself
+			atomicAdd(&p.stats[0], ndist);
+			atomicAdd(&p.stats[1], hops);
+		}
+		return;
 	}
 
 	// ---- layer 0: initLayer0SearchState
@@ -402,18 +642,18 @@ __global__ __launch_bounds__(64) void hnsw_search_kernel(HnswParams p) {
 	}
 }
 
-template <bool kGlobalCand, int NB>
+template <bool kGlobalCand, int NB, int kSorted = 0>
 static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
 	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8 + size_t(NB) * 256;   // heaps + the query fragment (NB*16 float4)
 	constexpr bool kHasLatencyVariant = NB > 8;
-	const bool latency = kHasLatencyVariant && blocks < 2048;   // fewer searches than the GPU holds anyway: spend registers on fewer round trips
-#define RX_HNSW(M)                                                                                                        \
-	do {                                                                                                                  \
-		if (latency) {                                                                                                    \
-			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, kHasLatencyVariant>), dim3(blocks), dim3(64), lds, s, p); \
-		} else {                                                                                                          \
-			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, false>), dim3(blocks), dim3(64), lds, s, p);          \
-		}                                                                                                                 \
+	const bool latency = kHasLatencyVariant && blocks <= 3072;   // no more searches than the chip holds of this form (3 per SIMD): spend registers on fewer round trips
+#define RX_HNSW(M)                                                                                                                         \
+	do {                                                                                                                                   \
+		if (latency) {                                                                                                                     \
+			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, kHasLatencyVariant, false, kSorted>), dim3(blocks), dim3(64), lds, s, p); \
+		} else {                                                                                                                           \
+			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, false, false, kSorted>), dim3(blocks), dim3(64), lds, s, p);          \
+		}                                                                                                                                  \
 	} while (0)
 	switch (metric) {
 		case kL2: RX_HNSW(kL2); break;
@@ -421,6 +661,16 @@ static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hip
 		default: RX_HNSW(kCos); break;
 	}
 #undef RX_HNSW
+}
+
+template <int kSorted>
+static void launch_hnsw_sorted(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
+	switch (p.dim) {
+		case 128: launch_hnsw_nb<false, 2, kSorted>(metric, p, blocks, s); break;
+		case 512: launch_hnsw_nb<false, 8, kSorted>(metric, p, blocks, s); break;
+		case 768: launch_hnsw_nb<false, 12, kSorted>(metric, p, blocks, s); break;
+		default: launch_hnsw_nb<false, 0, kSorted>(metric, p, blocks, s); break;
+	}
 }
 
 template <bool kGlobalCand>
@@ -433,13 +683,26 @@ static void launch_hnsw_mode(int metric, const HnswParams& p, uint32_t blocks, h
 	}
 }
 
-template <bool kGlobalCand, int NB>
+template <bool kGlobalCand, int NB, int kSorted = 0>
 static void launch_hnsw_sq8_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
 	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8;
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
-		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
-		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB, false, true>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB, false, true, kSorted>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB, false, true, kSorted>), dim3(blocks), dim3(64), lds, s, p); break;
+		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB, false, true, kSorted>), dim3(blocks), dim3(64), lds, s, p); break;
+	}
+}
+
+template <int kSorted>
+static void launch_hnsw_sq8_sorted(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
+	switch (p.dim) {
+		case 128: launch_hnsw_sq8_nb<false, 2, kSorted>(metric, p, blocks, s); break;
+		case 384: launch_hnsw_sq8_nb<false, 6, kSorted>(metric, p, blocks, s); break;
+		case 512: launch_hnsw_sq8_nb<false, 8, kSorted>(metric, p, blocks, s); break;
+		case 768: launch_hnsw_sq8_nb<false, 12, kSorted>(metric, p, blocks, s); break;
+		case 1024: launch_hnsw_sq8_nb<false, 16, kSorted>(metric, p, blocks, s); break;
+		case 1536: launch_hnsw_sq8_nb<false, 24, kSorted>(metric, p, blocks, s); break;
+		default: launch_hnsw_sq8_nb<false, 0, kSorted>(metric, p, blocks, s); break;
 	}
 }
 
@@ -457,6 +720,20 @@ static void launch_hnsw_sq8(int metric, const HnswParams& p, uint32_t blocks, hi
 }
 
 void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s) {
+	if (p.sorted && !global_cand) {   // both queues as one sorted list in registers: 2 entries a lane up to ef = 128, 4 up to 256
+		if (p.codes) {
+			if (p.ef <= 128) {
+				launch_hnsw_sq8_sorted<2>(metric, p, blocks, s);
+			} else {
+				launch_hnsw_sq8_sorted<4>(metric, p, blocks, s);
+			}
+		} else if (p.ef <= 128) {
+			launch_hnsw_sorted<2>(metric, p, blocks, s);
+		} else {
+			launch_hnsw_sorted<4>(metric, p, blocks, s);
+		}
+		return;
+	}
 	if (p.codes) {   // SQ8 graph
 		if (global_cand) {
 			launch_hnsw_sq8<true>(metric, p, blocks, s);

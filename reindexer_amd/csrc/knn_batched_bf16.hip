@@ -66,6 +66,10 @@ constexpr int kGlXElems = kBfRows * 32;   // the row operand of one stage: 256 r
 // QT = queries per tile.  256: 32 KB per stage, 4 buffers, 3 stages in flight.  128 (batches <= 128 queries): 24 KB per stage, 6 buffers,
 // 5 stages in flight — the kernel waits on HBM latency, so the bytes in flight per CU are what the narrower query block buys.
 constexpr int gl_bufs(int qt) { return qt == 256 ? 4 : 6; }
+// Nominations of the filter pass are collected in LDS, one list per wavefront, and reach the global per-query lists in batches: a returning
+// global atomic in the stream of LDS-DMAs makes its wave wait for every DMA issued before it (vmcnt counts in order), i.e. drains the
+// stages in flight — with ~3 nominations per wave and tile that happened in nearly every epilogue.  LDS atomics count on lgkmcnt instead.
+constexpr int kGlHitCap = 192;   // entries (query << 32 | row) per wavefront
 typedef __attribute__((address_space(3))) void lds_void;
 
 template <int kMetric, int kMode, int QT>
@@ -80,6 +84,8 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 	uint16_t* stage_s = reinterpret_cast<uint16_t*>(bf_lds);                            // [kBufs][x: 256 x 32 | q: QT x 32]
 	float* thr_s = reinterpret_cast<float*>(bf_lds + size_t(kBufs) * kStageElems * 2);   // [QT]
 	float* aux_s = thr_s + QT;
+	uint32_t* hit_n = reinterpret_cast<uint32_t*>(aux_s + QT);                            // [8]: one counter per wavefront
+	unsigned long long* hit_all = reinterpret_cast<unsigned long long*>(hit_n + 8);       // [8][kGlHitCap]
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +98,20 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 		thr_s[i] = kMode == kGemmFilter ? p.thr[i] : 0.f;
 		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
 	}
+	if (tid < 8) hit_n[tid] = 0;
 	__syncthreads();
+	unsigned long long* hit_s = hit_all + size_t(wave) * kGlHitCap;
+	uint32_t* my_n = hit_n + wave;
+	auto flush_hits = [&]() {   // this wave's list -> the global per-query lists (only this wave reads or writes its list: no barrier)
+		const uint32_t cnt = min(*my_n, uint32_t(kGlHitCap));
+		for (uint32_t e = lane; e < cnt; e += 64) {
+			const unsigned long long h = hit_s[e];
+			const uint32_t qi = uint32_t(h >> 32);
+			const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+			if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(h);
+		}
+		if (lane == 0) *my_n = 0;
+	};
 
 	// DMA source addressing of this thread: instruction j covers LDS slots [512 j, 512 j + 512) of an operand part
 	uint32_t src_r[2], src_c[2];
@@ -239,17 +258,28 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 							const int r = __builtin_ctz(mask);
 							mask &= mask - 1;
 							const uint32_t qi = 32 * b + (r & 3) + 8 * (r >> 2) + qlane;
-							const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
-							if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(row);
+							const uint32_t at = atomicAdd(my_n, 1u);
+							if (at < uint32_t(kGlHitCap)) {
+								hit_s[at] = (static_cast<unsigned long long>(qi) << 32) | uint32_t(row);
+							} else {   // list full (rows next to many queries): straight to the global lists
+								const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+								if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(row);
+							}
 						}
 					}
 				}
 			}
 		}
+		if constexpr (kMode == kGemmFilter) {
+			if (*my_n >= uint32_t(kGlHitCap / 2)) flush_hits();   // wave-uniform: only this wave writes its counter
+		}
 	}
+	if constexpr (kMode == kGemmFilter) flush_hits();
 }
 
-size_t gemm_bf16_glds_lds_bytes(int qt) { return size_t(gl_bufs(qt)) * (kGlXElems + qt * 32) * sizeof(uint16_t) + 2 * size_t(qt) * sizeof(float); }
+size_t gemm_bf16_glds_lds_bytes(int qt) {
+	return size_t(gl_bufs(qt)) * (kGlXElems + qt * 32) * sizeof(uint16_t) + 2 * size_t(qt) * sizeof(float) + 8 * sizeof(uint32_t) + size_t(8) * kGlHitCap * 8;
+}
 
 template <int kMetric, int kMode, int QT>
 static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {

@@ -110,6 +110,8 @@ constexpr int kHnswLdsCandEf = 1024;    // largest ef whose candidate heap is tr
 constexpr int kHnswCandLds = 2048;      // candidate-heap capacity in LDS
 constexpr int kHnswMaxNeighbors = 128;  // 2*M <= 128
 constexpr uint32_t kHnswOverflow = 0xFFFFFFFFu;
+constexpr uint32_t kHnswTie = 0xFFFFFFFEu;        // sorted-list search met equal keys: re-run on the heap kernel
+constexpr int kHnswSortedMaxEf = 256;            // largest ef the sorted-list search holds in registers (4 entries a lane)
 
 struct HnswParams {
 	const float* rows;
@@ -129,13 +131,14 @@ struct HnswParams {
 	uint64_t visited_words;
 	float* out_dist;          // [nq][k]
 	uint32_t* out_row;
-	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode)
+	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode), kHnswTie = re-run on the heaps
 	const uint32_t* only;     // optional: list of query indices to process (blockIdx.x indexes this list)
 	uint2* gcand;             // global-mode candidate heap storage [slots][gcand_cap] of (dist bits, id)
 	uint64_t gcand_cap;
 	unsigned long long* stats;   // optional [2]: distance evaluations, hops
 	uint32_t lds_cand_cap;       // <= kHnswCandLds (tests shrink it to force the global-heap re-run)
 	uint32_t ef_cap;             // result-heap capacity in LDS: ef rounded up to 64
+	uint32_t sorted;             // 0 = heap kernel; else the sorted-list search (bare graphs, ef <= kHnswSortedMaxEf; ef_cap = lds_cand_cap = 0)
 	// SQ8 graph (HierarchicalNSWImpl<uint8_t>): codes instead of vectors, stored corrective offsets, alpha^2; the queries travel as codes +
 	// corrective offset (prepareData, hnswalg.h:510-529) and every distance is scaled by the query's normCoef (queryNormCoef :1855-1863)
 	const uint8_t* codes;        // [n][dim]

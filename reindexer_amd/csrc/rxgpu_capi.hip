@@ -1776,6 +1776,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	if (const char* e = getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // test hook: force the global-heap re-run
 		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, atoi(e))));
 	}
+	// Graphs without deleted nodes, ef <= 256: both queues as one sorted list in registers (hnsw_search.hip).  A query that meets equal
+	// distances there comes back as kHnswTie and takes the heap kernel, whose sift order is the reference's.
+	bool use_sorted = p.bare && ef <= uint32_t(rxgpu::kHnswSortedMaxEf);
+	uint32_t sorted_mode = 1;
+	if (const char* e = getenv("RXGPU_HNSW_SORTED")) {   // A/B and test hook: 0 = heaps only, 2 = list shifts through ds_bpermute instead of DPP
+		sorted_mode = uint32_t(std::max(0, atoi(e)));
+		use_sorted = use_sorted && sorted_mode != 0;
+	}
 	std::vector<uint32_t> redo;
 	if (big_ef) {
 		redo.resize(nq);
@@ -1796,12 +1804,40 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			pc.out_dist = p.out_dist + size_t(q0) * k;
 			pc.out_row = p.out_row + size_t(q0) * k;
 			pc.out_count = p.out_count + q0;
+			if (use_sorted) {
+				pc.sorted = sorted_mode;
+				pc.ef_cap = 0;   // no heaps in LDS
+				pc.lds_cand_cap = 0;
+			}
 			ProfileScope ps(h, "hnsw", c->stream);
 			rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 		}
 		RX_HIP(hipGetLastError());
 		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		RX_HIP(hipStreamSynchronize(c->stream));
+		std::vector<uint32_t> ties;
+		for (uint32_t q = 0; q < nq; ++q) {
+			if (out_count[q] == rxgpu::kHnswTie) ties.push_back(q);
+		}
+		if (!ties.empty()) {   // equal keys met in the sorted list: the same queries through the reference's heaps (candidate heap in LDS)
+			h->hnsw_tie_reruns += ties.size();
+			if (int rc = c->d_redo.ensure(ties.size() * sizeof(uint32_t)); rc) return rc;
+			RX_HIP(hipMemcpyAsync(c->d_redo.ptr, ties.data(), ties.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+			for (size_t r0 = 0; r0 < ties.size(); r0 += max_slots) {
+				const uint32_t cq = uint32_t(std::min<uint64_t>(max_slots, ties.size() - r0));
+				if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
+				RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+				rxgpu::HnswParams pc = p;
+				pc.queries = static_cast<const float*>(c->d_queries.ptr);
+				pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
+				pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;
+				ProfileScope ps(h, "hnsw_ties", c->stream);
+				rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
+			}
+			RX_HIP(hipGetLastError());
+			RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipStreamSynchronize(c->stream));
+		}
 		// queries whose candidate heap outgrew LDS: re-run with the heap in global scratch (bounded by one entry per node)
 		for (uint32_t q = 0; q < nq; ++q) {
 			if (out_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
@@ -2163,6 +2199,12 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 	RX_HIP(hipMemset(h->d_hnsw_stats, 0, sizeof(v)));
 	*distance_evals = v[0];
 	*hops = v[1];
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_read_tie_reruns(rxgpu_index* h, uint64_t* reruns) {
+	RX_CHECK(h && reruns, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_tie_reruns: null argument");
+	*reruns = h->hnsw_tie_reruns.exchange(0);
 	return RXGPU_OK;
 }
 

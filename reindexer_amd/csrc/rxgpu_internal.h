@@ -1,6 +1,7 @@
 // Internal declarations shared by the C-ABI implementation and the kernel translation units.
 #pragma once
 
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -406,6 +407,7 @@ struct rxgpu_index {
 	uint32_t graph_entry = 0;
 	bool graph_attached = false;
 	unsigned long long* d_hnsw_stats = nullptr;
+	std::atomic<uint64_t> hnsw_tie_reruns{0};   // queries the sorted-list search handed to the heap kernel (equal distances met)
 
 	std::mutex mtx;  // guards ctx pool + profile state
 	std::vector<rxgpu_search_ctx*> free_ctx;

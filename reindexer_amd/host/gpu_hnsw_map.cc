@@ -292,6 +292,12 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 	return result;
 }
 
+uint64_t GpuHnswMap::TieReruns() const {
+	uint64_t n = 0;
+	if (rxgpu_hnsw_read_tie_reruns(dev_, &n) != RXGPU_OK) throwDevice("TieReruns");
+	return n;
+}
+
 StreamingSearchSession::~StreamingSearchSession() {
 	if (impl_) rxgpu_hnsw_stream_end(impl_);
 }

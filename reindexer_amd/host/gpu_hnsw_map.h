@@ -88,6 +88,8 @@ public:
 	// one launch of the batched search kernel (a wavefront per query) instead of one single-wavefront launch each.
 	void EnableQueryCoalescing(bool on) noexcept { coalesce_ = on; }
 	size_t CoalescedBatches() const noexcept { return coBatches_; }
+	// searches the device re-ran on its heap kernel because the sorted-list search met equal distances (rxgpu_hnsw_read_tie_reruns); resets
+	uint64_t TieReruns() const;
 
 	// SQ8 (HierarchicalNSW::Quantize, hnsw.h:104-118; hnswalg.h:411-470): from here on SearchKnn runs over one byte per component on the
 	// device (rxgpu_hnsw_search_knn_sq8) and returns what HierarchicalNSWImpl<uint8_t> returns on the same graph, bit for bit.  The range

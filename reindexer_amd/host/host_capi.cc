@@ -423,6 +423,11 @@ int rxhost_hnsw_resize(void* h, size_t n) {
 }
 size_t rxhost_hnsw_count(void* h) { return static_cast<GpuHnswMap*>(h)->CurrentElementCount(); }
 size_t rxhost_hnsw_deleted_count(void* h) { return static_cast<GpuHnswMap*>(h)->DeletedCountUnsafe(); }
+long rxhost_hnsw_tie_reruns(void* h) {
+	long n = -1;
+	guarded([&] { n = long(static_cast<const GpuHnswMap*>(h)->TieReruns()); });
+	return n;
+}
 void* rxhost_hnsw_graph(void* h) { return const_cast<HnswGraph*>(&static_cast<GpuHnswMap*>(h)->Graph()); }
 // the Map's ANN disk cache through memory (same encoding as rxhost_graph_save_index / _load_index)
 long rxhost_hnsw_save_index(void* h, uint8_t* out, size_t cap) {

@@ -484,6 +484,8 @@ class GpuHnswMap:
             L.rxhost_hnsw_search_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
             L.rxhost_hnsw_select.restype = _l
             L.rxhost_hnsw_select.argtypes = [_vp, _vp, _sz, _l, _sz, _i, _f, _i, _i, _vp, _vp, _sz]
+            L.rxhost_hnsw_tie_reruns.restype = _l
+            L.rxhost_hnsw_tie_reruns.argtypes = [_vp]
             L.rxhost_hnsw_save_index.restype = _l
             L.rxhost_hnsw_save_index.argtypes = [_vp, _vp, _sz]
             L.rxhost_hnsw_load_index.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
@@ -544,6 +546,13 @@ class GpuHnswMap:
     def load_index(self, data: bytes, labels, vectors):
         """LoadIndexCache's Map part (hnsw_index.cc:439-507) into an empty Map; on any error the Map is cleared, as clearMap() does."""
         _load_bytes(lib().rxhost_hnsw_load_index, self.h, data, labels, vectors, self.dim)
+
+    def tie_reruns(self) -> int:
+        """Searches re-run on the heap kernel since the last call (the sorted-list search met equal distances)."""
+        n = lib().rxhost_hnsw_tie_reruns(self.h)
+        if n < 0:
+            _raise()
+        return n
 
     count = property(lambda self: lib().rxhost_hnsw_count(self.h))
     deleted_count = property(lambda self: lib().rxhost_hnsw_deleted_count(self.h))

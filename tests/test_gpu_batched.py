@@ -114,7 +114,7 @@ def test_batched_device_api_matches_host_api(rxgpu, oracle):
 
 # ---------------------------------------------------------------------------------------------- bf16 nomination path (batches > 64 queries)
 @pytest.mark.parametrize("metric", [0, 1, 2])
-@pytest.mark.parametrize("d,n", [(100, 30_000), (768, 20_000), (130, 9_000), (64, 300)])
+@pytest.mark.parametrize("d,n", [(100, 30_000), (768, 20_000), (130, 9_000), (64, 300), (512, 6_000), (250, 5_000), (768, 33)])
 def test_bf16_nomination_is_exact(rxgpu, oracle, metric, d, n):
     """Batches of 65..256 queries are nominated by the bf16 matrix-core GEMM over the bf16 shadow of the rows (knn_batched_bf16.hip) under a
     rigorous rounding bound; the exact kernels re-score.  Rows and distance bits must equal per-query exact search."""

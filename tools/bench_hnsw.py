@@ -81,9 +81,11 @@ def sq8_leg(o, ix, metric, g, queries, qnorms, trow, tq, nq, ncpu, ref_float) ->
     gpu_s = time.perf_counter() - t0
     launches, kernel_ms = ix.profile_read("hnsw")
     _, redo_ms = ix.profile_read("hnsw_redo")
+    _, ties_ms = ix.profile_read("hnsw_ties")
     ix.profile_enable(False)
     evals, hops = ix.hnsw_read_stats()
-    busy_ms = kernel_ms + redo_ms
+    tie_reruns = ix.hnsw_read_tie_reruns()
+    busy_ms = kernel_ms + redo_ms + ties_ms
     bytes_algo = evals * (o.dim + 4) + hops * (1 + 2 * g["M"]) * 4
     recall = float(np.mean([len(set(trow[i].tolist()) & set(row[i, :int(cnt[i])].tolist())) / o.k for i in range(tq)]))
     t0 = time.perf_counter()
@@ -97,6 +99,7 @@ def sq8_leg(o, ix, metric, g, queries, qnorms, trow, tq, nq, ncpu, ref_float) ->
     cpu_s = time.perf_counter() - t0
     hq.close()
     return {"gpu": {"queries": len(queries), "queries_per_sec": len(queries) / gpu_s, "kernel_ms_total": kernel_ms, "redo_ms": redo_ms,
+                    "tie_reruns": tie_reruns, "tie_rerun_ms": ties_ms,
                     "queries_per_sec_kernel_only": len(queries) / (busy_ms / 1e3) if busy_ms else None,
                     "distance_evals_per_query": evals / len(queries), "hops_per_query": hops / len(queries),
                     "roofline": {"bound": "hbm", "kernel": "hnsw_search_kernel<sq8>", "achieved": bytes_algo / (busy_ms / 1e3) / 1e9 if busy_ms else None,
@@ -165,10 +168,32 @@ def run(o) -> dict:
     gpu_s = time.perf_counter() - t0
     launches, kernel_ms = ix.profile_read("hnsw")
     redo_launches, redo_ms = ix.profile_read("hnsw_redo")
+    _, ties_ms = ix.profile_read("hnsw_ties")
     ix.profile_enable(False)
     evals, hops = ix.hnsw_read_stats()
+    tie_reruns = ix.hnsw_read_tie_reruns()
     bytes_algo = evals * o.dim * 4 + hops * (1 + 2 * g["M"]) * 4
-    busy_ms = kernel_ms + redo_ms
+    busy_ms = kernel_ms + redo_ms + ties_ms
+    heap_leg = None
+    if not o.gpu_only and os.environ.get("RXGPU_HNSW_SORTED", "1") != "0":
+        # the same batch on the kernel that replays the reference's binary heaps (what every search used before the sorted list)
+        os.environ["RXGPU_HNSW_SORTED"] = "0"
+        ix.hnsw_search_knn(queries, o.k, o.ef)
+        ix.profile_enable(True)
+        t0 = time.perf_counter()
+        hd, hr, hc = ix.hnsw_search_knn(queries, o.k, o.ef)
+        heap_s = time.perf_counter() - t0
+        _, hk_ms = ix.profile_read("hnsw")
+        _, hr_ms = ix.profile_read("hnsw_redo")
+        ix.profile_enable(False)
+        ix.hnsw_read_stats()
+        del os.environ["RXGPU_HNSW_SORTED"]
+        same = 0
+        for i in range(o.queries):
+            c = int(cnt[i])
+            a, b = np.lexsort((row[i, :c], dist[i, :c])), np.lexsort((hr[i, :c], hd[i, :c]))
+            same += int(c == int(hc[i]) and np.array_equal(row[i, :c][a], hr[i, :c][b]) and np.array_equal(dist[i, :c][a].view(np.uint32), hd[i, :c][b].view(np.uint32)))
+        heap_leg = {"queries_per_sec": o.queries / heap_s, "kernel_ms_total": hk_ms + hr_ms, "equal_to_sorted_list_frac": same / o.queries}
 
     # ---- (c) exact ground truth: the exact scan of the SAME index
     tq = min(o.queries, 512)
@@ -184,7 +209,7 @@ def run(o) -> dict:
                   "builder": "rxgpu::host::HnswGraph::AddPointConcurrent (host, the reference's HierarchicalNSWMT build)", "corpus_gen_seconds": gen_s},
         "gpu": {"queries": o.queries, "queries_per_sec": o.queries / gpu_s, "kernel_ms_total": kernel_ms, "launches": launches,
                 "queries_per_sec_kernel_only": o.queries / (busy_ms / 1e3) if busy_ms else None,
-                "redo_launches": redo_launches, "redo_ms": redo_ms,
+                "redo_launches": redo_launches, "redo_ms": redo_ms, "tie_reruns": tie_reruns, "tie_rerun_ms": ties_ms, "heap_kernel": heap_leg,
                 "distance_evals_per_query": evals / o.queries, "hops_per_query": hops / o.queries,
                 "roofline": {"bound": "hbm", "kernel": "hnsw_search_kernel", "achieved": bytes_algo / (busy_ms / 1e3) / 1e9 if busy_ms else None,
                              "peak": 8000.0, "unit": "GB/s", "frac": bytes_algo / (busy_ms / 1e3) / 1e9 / 8000.0 if busy_ms else None,
