@@ -1813,12 +1813,18 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 		}
 		RX_HIP(hipGetLastError());
+		// counts and results travel together: a batch without re-runs (the common case for a handful of queries) is done after ONE wait
 		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		RX_HIP(hipStreamSynchronize(c->stream));
 		std::vector<uint32_t> ties;
+		bool clean = true;
 		for (uint32_t q = 0; q < nq; ++q) {
 			if (out_count[q] == rxgpu::kHnswTie) ties.push_back(q);
+			clean = clean && out_count[q] != rxgpu::kHnswTie && out_count[q] != rxgpu::kHnswOverflow;
 		}
+		if (clean) return RXGPU_OK;
 		if (!ties.empty()) {   // equal keys met in the sorted list: the same queries through the reference's heaps (candidate heap in LDS)
 			h->hnsw_tie_reruns += ties.size();
 			if (int rc = c->d_redo.ensure(ties.size() * sizeof(uint32_t)); rc) return rc;
