@@ -86,6 +86,8 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 	float* aux_s = thr_s + QT;
 	uint32_t* hit_n = reinterpret_cast<uint32_t*>(aux_s + QT);                            // [8]: one counter per wavefront
 	unsigned long long* hit_all = reinterpret_cast<unsigned long long*>(hit_n + 8);       // [8][kGlHitCap]
+	float* gmax_s = reinterpret_cast<float*>(hit_all + size_t(8) * kGlHitCap);           // [QT / 16] loosest threshold of a lane's 16 queries
+	float* gmin_s = gmax_s + QT / 16;                                                     // [QT / 16] smallest |q|^2 of them (L2)
 
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,6 +101,20 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
 	}
 	if (tid < 8) hit_n[tid] = 0;
+	__syncthreads();
+	// block-level test of the filter epilogue: group gi = (qh * QB + b) * 2 + (lane >> 5) holds the 16 queries one lane compares in block b
+	if (kMode == kGemmFilter && tid < QT / 16) {
+		const int half = tid & 1, bb = (tid >> 1) % QB, hh = (tid >> 1) / QB;
+		float tmax = -__builtin_inff(), amin = __builtin_inff();
+		for (int r = 0; r < 16; ++r) {
+			const int qi = 32 * bb + (r & 3) + 8 * (r >> 2) + 4 * half + (QT / 2) * hh;
+			tmax = fmaxf(tmax, thr_s[qi]);
+			amin = fminf(amin, aux_s[qi]);
+			if (thr_s[qi] != thr_s[qi]) tmax = __builtin_inff();   // a NaN threshold admits nothing per element; never let it hide the others
+		}
+		gmax_s[tid] = tmax;
+		gmin_s[tid] = amin;
+	}
 	__syncthreads();
 	unsigned long long* hit_s = hit_all + size_t(wave) * kGlHitCap;
 	uint32_t* my_n = hit_n + wave;
@@ -234,21 +250,39 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 			} else {
 #pragma unroll
 				for (int b = 0; b < QB; ++b) {
-					uint32_t mask = 0;
+					// Block-level test first: the best of the lane's 16 products against the loosest of their 16 thresholds, by the same
+					// formula (every step of it is monotone in the product, rounding included, so no nomination can hide behind it); only
+					// when some lane of the wave passes do the 16 compares and their 16 (L2: 32) LDS reads run.
+					float best = acc[a][b][0];
 #pragma unroll
-					for (int r = 0; r < 16; ++r) {
-						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
-						float d;
-						if constexpr (kMetric == kL2) {
-							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
-						} else if constexpr (kMetric == kIP) {
-							d = -acc[a][b][r];
-						} else {
-							d = -acc[a][b][r] * row_term;
-						}
-						mask |= (d <= thr_s[qo + qlane]) ? (1u << r) : 0u;
-						acc[a][b][r] = 0.0f;
+					for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[a][b][r]);
+					const int gi = (qh * QB + b) * 2 + (lane >> 5);
+					float dbest;
+					if constexpr (kMetric == kL2) {
+						dbest = (gmin_s[gi] + row_term) - 2.0f * best;
+					} else if constexpr (kMetric == kIP) {
+						dbest = -best;
+					} else {
+						dbest = -best * row_term;
 					}
+					uint32_t mask = 0;
+					if (__ballot(row_ok && !(dbest > gmax_s[gi]))) {
+#pragma unroll
+						for (int r = 0; r < 16; ++r) {
+							const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+							float d;
+							if constexpr (kMetric == kL2) {
+								d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+							} else if constexpr (kMetric == kIP) {
+								d = -acc[a][b][r];
+							} else {
+								d = -acc[a][b][r] * row_term;
+							}
+							mask |= (d <= thr_s[qo + qlane]) ? (1u << r) : 0u;
+						}
+					}
+#pragma unroll
+					for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 					if (!row_ok) mask = 0;
 					// block after block: hoisting the next block's threshold / query-norm reads above this block's compares only adds live
 					// registers (the L2 form, two LDS operands per compare, spilled 61 VGPRs into the K loop without this)
@@ -278,7 +312,8 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 }
 
 size_t gemm_bf16_glds_lds_bytes(int qt) {
-	return size_t(gl_bufs(qt)) * (kGlXElems + qt * 32) * sizeof(uint16_t) + 2 * size_t(qt) * sizeof(float) + 8 * sizeof(uint32_t) + size_t(8) * kGlHitCap * 8;
+	return size_t(gl_bufs(qt)) * (kGlXElems + qt * 32) * sizeof(uint16_t) + 2 * size_t(qt) * sizeof(float) + 8 * sizeof(uint32_t) + size_t(8) * kGlHitCap * 8 +
+		   2 * size_t(qt / 16) * sizeof(float);
 }
 
 template <int kMetric, int kMode, int QT>
