@@ -359,8 +359,8 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 // otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
 // kSorted: 0 = the reference's two heaps, replayed by lane 0; S > 0 = HnswSortedList<S> (ef <= 64 S, no deleted nodes, heaps not in LDS at all)
 template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0>
-__global__ __launch_bounds__(64, (kSorted > 0 && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
-	static_assert(kSorted == 0 || !kGlobalCand, "the sorted list has no candidate heap to spill");
+__global__ __launch_bounds__(64, (kSorted == 2 && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
+	static_assert(kSorted == 0 || !kGlobalCand, "the sorted-list search starts in LDS; its re-runs with a global heap are heap-kernel launches");
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
 	extern __shared__ __attribute__((aligned(16))) unsigned char hnsw_lds[];
@@ -450,6 +450,7 @@ __global__ __launch_bounds__(64, (kSorted > 0 && !kLatency && !kSq8 && NB == 12)
 		}
 	}
 
+	const unsigned long long ndist_upper = ndist;
 	if constexpr (kSorted > 0) {
 		// ---- layer 0 on the sorted list (bare-bone search only: the launcher keeps graphs with deleted nodes on the heap path)
 		HnswSortedList<kSorted> list;
@@ -512,9 +513,7 @@ __global__ __launch_bounds__(64, (kSorted > 0 && !kLatency && !kSq8 && NB == 12)
 		}
 		const int keep = list.n < int(p.k) ? list.n : int(p.k);   // SearchKnn :1998-2000: the k nearest of top_candidates
 		if (!list.tie && list.n > keep && list.key_at(keep - 1) == list.key_at(keep)) list.tie = true;   // the trim pops one of two equal keys
-		if (list.tie) {
-			if (lane == 0) p.out_count[qi] = kHnswTie;
-		} else {
+		if (!list.tie) {
 #pragma unroll
 			for (int s = 0; s < kSorted; ++s) {
 				const int g = 64 * s + lane;
@@ -523,13 +522,29 @@ __global__ __launch_bounds__(64, (kSorted > 0 && !kLatency && !kSq8 && NB == 12)
 					p.out_row[size_t(qi) * p.k + g] = list.id[s];
 				}
 			}
-			if (lane == 0) p.out_count[qi] = uint32_t(keep);
+			if (lane == 0) {
+				p.out_count[qi] = uint32_t(keep);
+				if (p.stats) {
+					atomicAdd(&p.stats[0], ndist);
+					atomicAdd(&p.stats[1], hops);
+				}
+			}
+			return;
 		}
-		if (lane == 0 && p.stats && !list.tie) {   // a re-run counts itself
-			atomicAdd(&p.stats[0], ndist);
-			atomicAdd(&p.stats[1], hops);
+		// Equal keys that matter: this search starts over on the reference's heaps, here and now — while the rest of the batch keeps the
+		// chip busy — instead of in a launch of its own after the batch (whose whole duration is the tail of ONE heap search).  The
+		// launcher gives every workgroup a small heap area for that (lds_cand_cap entries; a search that outgrows it is flagged
+		// kHnswOverflow and re-run with the global heap like any other); without one the query goes back to the host as kHnswTie.
+		if (p.lds_cand_cap == 0) {
+			if (lane == 0) p.out_count[qi] = kHnswTie;
+			return;
 		}
-		return;
+		for (uint64_t w = lane; w < p.visited_words; w += 64) visited[w] = 0u;
+		__threadfence();
+		__syncthreads();
+		if (lane == 0 && p.stats) atomicAdd(&p.stats[2], 1ull);
+		ndist = ndist_upper;
+		hops = 0;
 	}
 
 	// ---- layer 0: initLayer0SearchState

@@ -1533,8 +1533,8 @@ int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64
 	h->graph_upper_cap = upper_cap;
 	h->graph_upper_used = upper_blocks;
 	if (!h->d_hnsw_stats) {
-		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_hnsw_stats), 2 * sizeof(unsigned long long)));
-		RX_HIP(hipMemset(h->d_hnsw_stats, 0, 2 * sizeof(unsigned long long)));
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_hnsw_stats), 4 * sizeof(unsigned long long)));   // evals, hops, in-kernel restarts, spare
+		RX_HIP(hipMemset(h->d_hnsw_stats, 0, 4 * sizeof(unsigned long long)));
 	}
 	h->graph_n = n;
 	h->graph_M = M;
@@ -1780,6 +1780,12 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// distances there comes back as kHnswTie and takes the heap kernel, whose sift order is the reference's.
 	bool use_sorted = p.bare && ef <= uint32_t(rxgpu::kHnswSortedMaxEf);
 	uint32_t sorted_mode = 1;
+	// candidate-heap entries a restarted search gets in LDS.  Measured at 1M x 768, ef = 128, 16 384 queries, ~90 restarts (profiles/
+	// rd3p_restart_caps.txt, one graph, one box): 384 entries (8 KB per workgroup, 19 per CU) -> one restart overflows and the global-heap
+	// launch it needs costs 2.9 ms; 600 (10 KB, 16 per CU) 11.96 ms in all; 780 12.10; 1024 12.25; no in-kernel restart (0: the tie queries
+	// come back to this function and get a launch of their own) 9.92 + 2.53 = 12.46 ms.
+	uint32_t sorted_restart_cap = 600;
+	if (const char* e = getenv("RXGPU_HNSW_RESTART_CAND")) sorted_restart_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(0, atoi(e))));
 	if (const char* e = getenv("RXGPU_HNSW_SORTED")) {   // A/B and test hook: 0 = heaps only, 2 = list shifts through ds_bpermute instead of DPP
 		sorted_mode = uint32_t(std::max(0, atoi(e)));
 		use_sorted = use_sorted && sorted_mode != 0;
@@ -1804,10 +1810,10 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			pc.out_dist = p.out_dist + size_t(q0) * k;
 			pc.out_row = p.out_row + size_t(q0) * k;
 			pc.out_count = p.out_count + q0;
-			if (use_sorted) {
+			if (use_sorted) {   // the list lives in registers; LDS holds only the heap area of a search that starts over (equal keys that matter)
 				pc.sorted = sorted_mode;
-				pc.ef_cap = 0;   // no heaps in LDS
-				pc.lds_cand_cap = 0;
+				pc.lds_cand_cap = sorted_restart_cap;
+				if (sorted_restart_cap == 0) pc.ef_cap = 0;
 			}
 			ProfileScope ps(h, "hnsw", c->stream);
 			rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
@@ -2210,7 +2216,15 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 
 int rxgpu_hnsw_read_tie_reruns(rxgpu_index* h, uint64_t* reruns) {
 	RX_CHECK(h && reruns, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_tie_reruns: null argument");
-	*reruns = h->hnsw_tie_reruns.exchange(0);
+	*reruns = h->hnsw_tie_reruns.exchange(0);   // queries this library re-ran in a launch of their own ...
+	if (h->d_hnsw_stats) {                      // ... and searches that started over on the heaps inside the sorted-list kernel
+		DeviceGuard dg(h->device);
+		unsigned long long v = 0;
+		RX_HIP(hipDeviceSynchronize());
+		RX_HIP(hipMemcpy(&v, h->d_hnsw_stats + 2, sizeof(v), hipMemcpyDeviceToHost));
+		RX_HIP(hipMemset(h->d_hnsw_stats + 2, 0, sizeof(v)));
+		*reruns += v;
+	}
 	return RXGPU_OK;
 }
 

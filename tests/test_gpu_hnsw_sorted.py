@@ -90,11 +90,16 @@ def test_sorted_list_batches_through_the_c_abi(rxgpu, oracle, monkeypatch):
     m.close()
 
 
+@pytest.mark.parametrize("restart", [None, "0", "6"])
 @pytest.mark.parametrize("metric", [0, 1, 2])
-def test_equal_distances_are_rerun_on_the_heaps(rxgpu, oracle, metric):
+def test_equal_distances_are_rerun_on_the_heaps(rxgpu, oracle, monkeypatch, metric, restart):
     """Rows on a small integer grid, every row four times: most searches meet equal keys.  The answers must still be the restated
-    engine's (its heaps decide the order among equal keys), and the counter must show that the heap kernel served them."""
+    engine's (its heaps decide the order among equal keys), and the counter must show that the heaps served them — restarted inside the
+    sorted-list kernel (default), sent back to the host for a launch of their own (RXGPU_HNSW_RESTART_CAND=0), or restarted with a heap
+    area so small that the restart overflows into the global-heap tier (6 entries)."""
     from oracle.pyoracle import oracle_hnsw_search_knn
+    if restart is not None:
+        monkeypatch.setenv("RXGPU_HNSW_RESTART_CAND", restart)
     n, d = 6000, 32
     rng = np.random.default_rng(71)
     base = rng.integers(-3, 4, size=(n // 4, d)).astype(np.float32)
