@@ -13,6 +13,8 @@
 // Per query state: candidate heap + result heap in LDS (heap updates by lane 0 in neighbour order), visited bitset in HBM
 // (one atomicOr per neighbour is both the test and the mark).  A query whose candidate heap outgrows LDS is flagged and
 // re-run with the heap in a global scratch (still on the GPU) — never on the CPU.
+// Graphs without deleted nodes, ef <= 256, start differently: both queues as ONE sorted list in registers (HnswSortedList below), and
+// only a search in which equal distances could change what the reference's heaps do starts over on the heaps, inside the same kernel.
 #include "knn_kernels.hip.h"
 #include "rxgpu_internal.h"
 
@@ -76,8 +78,9 @@ __device__ __forceinline__ void hp_replace_top(uint2* h, int n, float vd, uint32
 // slot s of lane l, an insertion is one ballot + one lane shift (wave_shr DPP) instead of two binary-heap sifts by one lane, the pop is a
 // scalar find-first-zero.
 // Equal distances.  With CompareByFirst heaps the reference's choice among EQUAL keys is whatever libstdc++'s sift loops leave on top,
-// which a sorted list cannot know.  Where that choice cannot matter the list goes on; where it can, the query is flagged — kHnswTie —
-// and the launcher re-runs it on the heap kernel below:
+// which a sorted list cannot know.  Where that choice cannot matter the list goes on; where it can, the search is flagged and starts
+// over on the heaps (the code below the list's branch in hnsw_search_kernel; kHnswTie and a launch of its own if the launcher gave the
+// workgroup no heap area):
 //   * the popped candidate's key d equals the next unexpanded one's (which of the two the reference expands first is its heap's
 //     secret) AND lowerBound has come down to d by the time every candidate with a key <= d is expanded.  While lowerBound stays above
 //     d the order is immaterial: each node of key <= d that gets evaluated is admitted (key < lowerBound) and expanded before anything
