@@ -22,8 +22,8 @@
 // What bounded the thread-per-word form: every byte of a list was a dependent global load of ONE lane (~0.4 us per byte:
 // 13.6 ms for the 33 KB lists of the first wavefront), 64 lists of a wavefront in 64 different decoder states, single-lane 4-byte stores.
 // Here a list costs ~50 scalar cycles per varint whatever its neighbours do, and the chip runs 4096 lists at a time.
-// Still serial per list: a 1 MB list takes ~20 ms on its wavefront — lists beyond kFtPackedDeviceMaxBytes go to the host decoder
-// (GpuFtMerger::SetWordsPacked; rxgpu_ft_set_words_packed refuses nothing, the split is the caller's).
+// The COUNT walk stays serial per list: a 1 MB list takes ~20 ms on its wavefront.  The C-ABI entry decodes whatever it is given on the
+// device; a caller that wants very long lists decoded on the host says so itself (GpuFtMerger::SetWordsPacked's hostDecodeFromBytes).
 #include "ft_packed_decode.h"
 #include "rxgpu_internal.h"
 
