@@ -15,6 +15,8 @@
 // re-run with the heap in a global scratch (still on the GPU) — never on the CPU.
 // Graphs without deleted nodes, ef <= 256, start differently: both queues as ONE sorted list in registers (HnswSortedList below), and
 // only a search in which equal distances could change what the reference's heaps do starts over on the heaps, inside the same kernel.
+#include <type_traits>
+
 #include "knn_kernels.hip.h"
 #include "rxgpu_internal.h"
 
@@ -102,11 +104,61 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t x) {   // lane l <- lane 
 	return uint32_t(__builtin_amdgcn_update_dpp(int(x), int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
 }
 __device__ __forceinline__ float lane_value(float v, int l) { return __uint_as_float(uint32_t(__builtin_amdgcn_readlane(int(__float_as_uint(v)), l))); }
+// The per-slot state of a list as VECTOR values, not arrays: an array member keeps the whole struct in scratch memory as soon as a loop
+// over it is not unrolled before LLVM's SROA pass runs (seen for S = 3 and 4: 100 bytes of scratch per lane, every access a memory op).
+template <int S>
+struct HnswVec {
+	typedef float f __attribute__((ext_vector_type(S)));
+	typedef uint32_t u __attribute__((ext_vector_type(S)));
+	typedef uint64_t m __attribute__((ext_vector_type(S)));
+};
+// entries >= pos move up by one (the last one falls off the registers), (nd, nid) lands at pos
+template <int S>
+__device__ __forceinline__ void sorted_shift_in(typename HnswVec<S>::f& d, typename HnswVec<S>::u& id, int pos, float nd, uint32_t nid, bool dpp, int lane) {
+#pragma unroll
+	for (int s = S - 1; s >= 0; --s) {
+		if (pos >= 64 * (s + 1)) continue;   // uniform: the slot lies below the insertion point
+		const int g = 64 * s + lane;
+		float up_d;
+		uint32_t up_i;
+		if (dpp) {
+			up_d = __uint_as_float(wave_shr1(__float_as_uint(d[s])));
+			up_i = wave_shr1(id[s]);
+		} else {   // RXGPU_HNSW_SORTED=2: the same shift through the LDS crossbar (ds_bpermute)
+			up_d = __shfl_up(d[s], 1, 64);
+			up_i = __shfl_up(id[s], 1, 64);
+		}
+		if (s > 0) {
+			const float carry_d = lane_value(d[s > 0 ? s - 1 : 0], 63);
+			const uint32_t carry_i = uint32_t(__builtin_amdgcn_readlane(int(id[s > 0 ? s - 1 : 0]), 63));
+			if (lane == 0) {
+				up_d = carry_d;
+				up_i = carry_i;
+			}
+		}
+		d[s] = g < pos ? d[s] : (g == pos ? nd : up_d);
+		id[s] = g < pos ? id[s] : (g == pos ? nid : up_i);
+	}
+}
+// the same for a wave-uniform bit per entry
+template <int S>
+__device__ __forceinline__ void mask_shift_in(typename HnswVec<S>::m& m, int pos, bool bit) {
+#pragma unroll
+	for (int s = S - 1; s >= 0; --s) {
+		if (pos >= 64 * (s + 1)) continue;
+		if (pos < 64 * s) {
+			m[s] = (m[s] << 1) | (m[s > 0 ? s - 1 : 0] >> 63);
+		} else {
+			const uint64_t below = (1ull << (pos - 64 * s)) - 1ull;
+			m[s] = (m[s] & below) | ((m[s] & ~below) << 1) | (uint64_t(bit) << (pos - 64 * s));
+		}
+	}
+}
 template <int S>
 struct HnswSortedList {
-	float d[S];
-	uint32_t id[S];
-	uint64_t done[S];   // wave-uniform: bit l of word s = entry 64 s + l is expanded (or empty)
+	typename HnswVec<S>::f d;
+	typename HnswVec<S>::u id;
+	typename HnswVec<S>::m done;   // wave-uniform: bit l of word s = entry 64 s + l is expanded (or empty)
 	int n;
 	float lower;        // lowerBound: the largest key while the list is filling, entry ef - 1 afterwards
 	float outside;      // key of the last node evicted, or refused at dist == lowerBound (NaN before the first: equal to nothing)
@@ -150,36 +202,8 @@ struct HnswSortedList {
 		for (int s = 0; s < S; ++s) pos += __popcll(__ballot(d[s] < nd));
 		tie = tie || !(nd < __builtin_inff());
 		if (n == ef) outside = lower;   // the list is full: its last entry leaves
-#pragma unroll
-		for (int s = S - 1; s >= 0; --s) {
-			if (pos >= 64 * (s + 1)) continue;   // uniform: the slot lies below the insertion point
-			const int g = 64 * s + lane;
-			float up_d;
-			uint32_t up_i;
-			if (dpp) {
-				up_d = __uint_as_float(wave_shr1(__float_as_uint(d[s])));
-				up_i = wave_shr1(id[s]);
-			} else {   // RXGPU_HNSW_SORTED=2: the same shift through the LDS crossbar (ds_bpermute)
-				up_d = __shfl_up(d[s], 1, 64);
-				up_i = __shfl_up(id[s], 1, 64);
-			}
-			if (s > 0) {
-				const float carry_d = lane_value(d[s > 0 ? s - 1 : 0], 63);
-				const uint32_t carry_i = uint32_t(__builtin_amdgcn_readlane(int(id[s > 0 ? s - 1 : 0]), 63));
-				if (lane == 0) {
-					up_d = carry_d;
-					up_i = carry_i;
-				}
-			}
-			d[s] = g < pos ? d[s] : (g == pos ? nd : up_d);
-			id[s] = g < pos ? id[s] : (g == pos ? nid : up_i);
-			if (pos < 64 * s) {
-				done[s] = (done[s] << 1) | (done[s > 0 ? s - 1 : 0] >> 63);
-			} else {
-				const uint64_t below = (1ull << (pos - 64 * s)) - 1ull;
-				done[s] = (done[s] & below) | ((done[s] & ~below) << 1);   // bit pos: 0 = not expanded
-			}
-		}
+		sorted_shift_in<S>(d, id, pos, nd, nid, dpp, lane);
+		mask_shift_in<S>(done, pos, false);   // bit pos: 0 = not expanded
 		if (n < ef) {
 			++n;
 		} else {
@@ -192,6 +216,9 @@ struct HnswSortedList {
 		}
 		lower = key_at(n - 1);
 	}
+	// the interface the kernel shares with HnswSortedListDel: members of top_candidates held, insertion with a delete mark (none here)
+	__device__ __forceinline__ int held() const { return n; }
+	__device__ __forceinline__ void insert(float nd, uint32_t nid, bool, int ef, int lane) { insert(nd, nid, ef, lane); }
 	// first entry that was not expanded yet, -1 if none (selects over static slot numbers, no early exit: the arrays must stay in registers)
 	__device__ __forceinline__ int first_open() const {
 		int e = -1;
@@ -224,6 +251,159 @@ struct HnswSortedList {
 			pending = true;
 		}
 		return true;
+	}
+};
+
+// The same list for a graph WITH deleted nodes (hnswalg.h:882-893, 943-957): a deleted node is a candidate like any other but never a
+// member of top_candidates, lowerBound follows the LIVE entries only, the search stops on a far candidate only once ef live entries are
+// held, and a deleted entry point enters candidate_set at FLT_MAX (initLayer0SearchState :853-856).  The list holds live and deleted
+// entries in one order; `del` marks the deleted ones, `live` counts the others.  Once ef live entries are held everything behind the
+// last of them is dead — deleted entries above lowerBound, the live entry a new one evicts — and leaves the list; `outside` takes the
+// smallest key that leaves.  The equal-key rules are the bare list's, with "full" meaning live == ef; a list that runs out of registers
+// (many deleted nodes in reach) flags the search like an equal key does.  tests/test_hnsw_sorted_model.py holds the Python restatement
+// of both lists and runs it against the two-heap oracle.
+template <int S>
+struct HnswSortedListDel {
+	static constexpr int kCap = 64 * S;
+	typename HnswVec<S>::f d;
+	typename HnswVec<S>::u id;
+	typename HnswVec<S>::m done;   // wave-uniform: expanded (or empty)
+	typename HnswVec<S>::m del;    // wave-uniform: the entry is a deleted node (0 for empty slots)
+	int n, live;
+	float lower, outside, pend;
+	bool pending, tie, dpp;
+
+	__device__ __forceinline__ void init(bool use_dpp) {
+		dpp = use_dpp;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			d[s] = __builtin_inff();
+			id[s] = 0u;
+			done[s] = ~0ull;
+			del[s] = 0ull;
+		}
+		n = live = 0;
+		lower = 3.402823466e+38f;
+		outside = __builtin_nanf("");
+		pend = 0.f;
+		pending = false;
+		tie = false;
+	}
+	__device__ __forceinline__ float key_at(int e) const {
+		float v = d[0];
+#pragma unroll
+		for (int s = 1; s < S; ++s) v = (e >> 6) == s ? d[s] : v;
+		return lane_value(v, e & 63);
+	}
+	// bits of word s that belong to entries < count
+	static __device__ __forceinline__ uint64_t below_count(int s, int count) {
+		const int c = count - 64 * s;
+		return c <= 0 ? 0ull : (c >= 64 ? ~0ull : ((1ull << c) - 1ull));
+	}
+	__device__ __forceinline__ int last_live() const {
+		int e = -1;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			const uint64_t m = ~del[s] & below_count(s, n);
+			e = m ? 64 * s + 63 - __builtin_clzll(m) : e;
+		}
+		return e;
+	}
+	__device__ __forceinline__ int held() const { return live; }
+	__device__ __forceinline__ void settle(int ef) {
+		if (pending && live == ef && !(lower > pend)) tie = true;
+		pending = false;
+	}
+	// (nd, nid, isdel) wave-uniform; the caller has checked live < ef || lower > nd
+	__device__ __forceinline__ void insert(float nd, uint32_t nid, bool isdel, int ef, int lane) {
+		tie = tie || !(nd < __builtin_inff());
+		const bool full = live == ef;
+		if (n == kCap && !(full && !isdel)) {   // no register left for one more entry: the heaps take the search over
+			tie = true;
+			return;
+		}
+		int pos = 0;
+#pragma unroll
+		for (int s = 0; s < S; ++s) pos += __popcll(__ballot(d[s] < nd));
+		const float old_lower = lower;
+		sorted_shift_in<S>(d, id, pos, nd, nid, dpp, lane);
+		mask_shift_in<S>(done, pos, false);
+		mask_shift_in<S>(del, pos, isdel);
+		const bool fell_off = n == kCap;   // only with a full top and a live newcomer: the entry that fell off was the largest live one
+		if (!fell_off) ++n;
+		if (!isdel) {
+			if (!full) {
+				++live;
+			} else if (fell_off) {
+				outside = old_lower;
+			} else {   // the largest live entry leaves top_candidates: from here on it is one of the dead behind the last live entry
+				const int gone = last_live();
+				outside = key_at(gone);
+#pragma unroll
+				for (int s = 0; s < S; ++s) del[s] |= (gone >> 6) == s ? 1ull << (gone & 63) : 0ull;
+			}
+			if (live == ef) {   // everything behind the last live entry is dead now
+				const int keep = last_live() + 1;
+				if (keep < n) {
+					outside = key_at(keep);   // the smallest key that leaves
+#pragma unroll
+					for (int s = 0; s < S; ++s) {
+						const uint64_t stay = below_count(s, keep);
+						d[s] = (64 * s + lane) >= keep ? __builtin_inff() : d[s];
+						done[s] |= ~stay;
+						del[s] &= stay;
+					}
+					n = keep;
+				}
+			}
+		}
+		if (live > 0) lower = key_at(last_live());
+	}
+	__device__ __forceinline__ int first_open() const {
+		int e = -1;
+#pragma unroll
+		for (int s = S - 1; s >= 0; --s) {
+			const uint64_t o = ~done[s];
+			e = o ? 64 * s + __builtin_ctzll(o) : e;
+		}
+		return e;
+	}
+	__device__ __forceinline__ bool pop(uint32_t& node, float& dist, int ef) {
+		const int e = first_open();
+		if (e < 0) {
+			settle(ef);
+			return false;
+		}
+		uint32_t iv = id[0];
+#pragma unroll
+		for (int s = 1; s < S; ++s) iv = (e >> 6) == s ? id[s] : iv;
+		dist = key_at(e);
+		node = uint32_t(__builtin_amdgcn_readlane(int(iv), e & 63));
+		if (pending && dist > pend) settle(ef);
+#pragma unroll
+		for (int s = 0; s < S; ++s) done[s] |= (e >> 6) == s ? 1ull << (e & 63) : 0ull;
+		const int next = first_open();
+		tie = tie || dist == outside;
+		if (next >= 0 && key_at(next) == dist) {
+			pend = pending ? fmaxf(pend, dist) : dist;
+			pending = true;
+		}
+		return true;
+	}
+	// index of the r-th live entry (r < live)
+	__device__ __forceinline__ int live_at(int r) const {
+		int e = -1, seen = 0;
+#pragma unroll
+		for (int s = 0; s < S; ++s) {
+			uint64_t m = ~del[s] & below_count(s, n);
+			const int c = __popcll(m);
+			if (e < 0 && r < seen + c) {
+				for (int i = seen; i < r; ++i) m &= m - 1;   // drop the r - seen lowest set bits (wave-uniform loop)
+				e = 64 * s + __builtin_ctzll(m);
+			}
+			seen += c;
+		}
+		return e;
 	}
 };
 
@@ -361,8 +541,9 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 // kLatency: few queries in flight -> two row sets per distance trip (fewer dependent round trips per hop, 172 VGPRs at D = 768);
 // otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
 // kSorted: 0 = the reference's two heaps, replayed by lane 0; S > 0 = HnswSortedList<S> (ef <= 64 S, no deleted nodes, heaps not in LDS at all)
-template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0>
-__global__ __launch_bounds__(64, (kSorted == 2 && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
+// kDel (with kSorted): the graph has deleted nodes — HnswSortedListDel
+template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0, bool kDel = false>
+__global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
 	static_assert(kSorted == 0 || !kGlobalCand, "the sorted-list search starts in LDS; its re-runs with a global heap are heap-kernel launches");
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
@@ -455,22 +636,27 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kLatency && !kSq8 && NB == 12
 
 	const unsigned long long ndist_upper = ndist;
 	if constexpr (kSorted > 0) {
-		// ---- layer 0 on the sorted list (bare-bone search only: the launcher keeps graphs with deleted nodes on the heap path)
-		HnswSortedList<kSorted> list;
+		// ---- layer 0 on the sorted list
+		using List = typename std::conditional<kDel, HnswSortedListDel<kSorted>, HnswSortedList<kSorted>>::type;
+		List list;
 		list.init(p.sorted == 1);
 		const int ef = int(p.ef);
-		list.insert(curdist, cur, ef, lane);
+		if (!kDel || !p.deleted[cur]) {
+			list.insert(curdist, cur, false, ef, lane);
+			ndist += 1;   // the reference recomputes the entry distance here (same value)
+		} else {
+			list.insert(3.402823466e+38f, cur, true, ef, lane);   // a deleted entry point: candidate at FLT_MAX, lowerBound = FLT_MAX (:853-856)
+		}
 		if (lane == 0) atomicOr(&visited[cur >> 5], 1u << (cur & 31));
-		ndist += 1;   // the reference recomputes the entry distance here (same value)
 		for (;;) {
 			uint32_t node;
 			float cdist;
-			if (!list.pop(node, cdist, ef)) {   // candidate_set empty, or only evicted entries left in it ...
-				list.tie = list.tie || (list.n == ef && list.lower == list.outside);   // ... of which the last one is still alive in the reference's
+			if (!list.pop(node, cdist, ef)) {   // candidate_set empty, or only dead entries left in it ...
+				list.tie = list.tie || (list.held() == ef && list.lower == list.outside);   // ... of which the last one is still alive in the reference's
 				break;
 			}
-			if (list.tie) break;                 // the rest of this search belongs to the heap kernel
-			if (cdist > list.lower) break;       // layer0ShouldStopBeforePop (never true for a member of the list; kept for the form)
+			if (list.tie) break;                 // the rest of this search belongs to the heaps
+			if (cdist > list.lower && (!kDel || list.held() == ef)) break;   // layer0ShouldStopBeforePop (never true for a member of a full list; kept for the form)
 			hops += 1;
 			const uint32_t* ll = p.links0 + size_t(node) * (1 + p.maxM0);
 			int nfresh = 0;
@@ -491,22 +677,26 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kLatency && !kSq8 && NB == 12
 				nfresh += __popcll(fm);
 			}
 			__syncthreads();
+			if constexpr (kDel) {   // the delete marks travel while the distances are computed
+				for (int j = lane; j < nfresh; j += 64) nb_del[j] = p.deleted[nb_id[j]];
+			}
 			distances(nb_id, nfresh, nb_d);
 			ndist += nfresh;
 			__syncthreads();
-			for (int base = 0; base < nfresh; base += 64) {   // runLayer0Step :932-960 in neighbour order; lane j carries neighbour base + j
+			for (int base = 0; base < nfresh && !list.tie; base += 64) {   // runLayer0Step :932-960 in neighbour order; lane j carries neighbour base + j
 				const int j = base + lane;
 				const float dj = j < nfresh ? nb_d[j] : __builtin_inff();
 				const uint32_t idj = j < nfresh ? nb_id[j] : 0u;
+				const uint64_t delm = kDel ? __ballot(j < nfresh && nb_del[j] != 0) : 0ull;
 				// lowerBound only falls while the list is full: what fails the test now fails it later in the loop as well
-				uint64_t m = __ballot(j < nfresh && (list.n < ef || list.lower > dj));
-				if (list.n == ef && __ballot(j < nfresh && dj == list.lower)) list.outside = list.lower;   // refused at dist == lowerBound
-				while (m) {
+				uint64_t m = __ballot(j < nfresh && (list.held() < ef || list.lower > dj));
+				if (list.held() == ef && __ballot(j < nfresh && dj == list.lower)) list.outside = list.lower;   // refused at dist == lowerBound
+				while (m && !list.tie) {
 					const int b = __builtin_ctzll(m);
 					m &= m - 1;
 					const float nd = lane_value(dj, b);
-					if (list.n < ef || list.lower > nd) {
-						list.insert(nd, uint32_t(__builtin_amdgcn_readlane(int(idj), b)), ef, lane);
+					if (list.held() < ef || list.lower > nd) {
+						list.insert(nd, uint32_t(__builtin_amdgcn_readlane(int(idj), b)), ((delm >> b) & 1ull) != 0, ef, lane);
 					} else if (nd == list.lower) {
 						list.outside = nd;
 					}
@@ -514,15 +704,34 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kLatency && !kSq8 && NB == 12
 			}
 			__syncthreads();
 		}
-		const int keep = list.n < int(p.k) ? list.n : int(p.k);   // SearchKnn :1998-2000: the k nearest of top_candidates
-		if (!list.tie && list.n > keep && list.key_at(keep - 1) == list.key_at(keep)) list.tie = true;   // the trim pops one of two equal keys
+		const int total = list.held();
+		const int keep = total < int(p.k) ? total : int(p.k);   // SearchKnn :1998-2000: the k nearest of top_candidates
+		if constexpr (!kDel) {
+			if (!list.tie && total > keep && list.key_at(keep - 1) == list.key_at(keep)) list.tie = true;   // the trim pops one of two equal keys
+		} else {
+			if (!list.tie && total > keep && keep > 0 && list.key_at(list.live_at(keep - 1)) == list.key_at(list.live_at(keep))) list.tie = true;
+		}
 		if (!list.tie) {
+			if constexpr (!kDel) {
 #pragma unroll
-			for (int s = 0; s < kSorted; ++s) {
-				const int g = 64 * s + lane;
-				if (g < keep) {
-					p.out_dist[size_t(qi) * p.k + g] = list.d[s];
-					p.out_row[size_t(qi) * p.k + g] = list.id[s];
+				for (int s = 0; s < kSorted; ++s) {
+					const int g = 64 * s + lane;
+					if (g < keep) {
+						p.out_dist[size_t(qi) * p.k + g] = list.d[s];
+						p.out_row[size_t(qi) * p.k + g] = list.id[s];
+					}
+				}
+			} else {
+				int before = 0;   // live entries in the slots below
+#pragma unroll
+				for (int s = 0; s < kSorted; ++s) {
+					const uint64_t lm = ~list.del[s] & List::below_count(s, list.n);
+					const int r = before + __popcll(lm & ((1ull << lane) - 1ull));
+					if (((lm >> lane) & 1ull) && r < keep) {
+						p.out_dist[size_t(qi) * p.k + r] = list.d[s];
+						p.out_row[size_t(qi) * p.k + r] = list.id[s];
+					}
+					before += __popcll(lm);
 				}
 			}
 			if (lane == 0) {
@@ -660,7 +869,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kLatency && !kSq8 && NB == 12
 	}
 }
 
-template <bool kGlobalCand, int NB, int kSorted = 0>
+template <bool kGlobalCand, int NB, int kSorted = 0, bool kDel = false>
 static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
 	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8 + size_t(NB) * 256;   // heaps + the query fragment (NB*16 float4)
 	constexpr bool kHasLatencyVariant = NB > 8;
@@ -668,9 +877,9 @@ static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hip
 #define RX_HNSW(M)                                                                                                                         \
 	do {                                                                                                                                   \
 		if (latency) {                                                                                                                     \
-			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, kHasLatencyVariant, false, kSorted>), dim3(blocks), dim3(64), lds, s, p); \
+			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, kHasLatencyVariant, false, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, p); \
 		} else {                                                                                                                           \
-			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, false, false, kSorted>), dim3(blocks), dim3(64), lds, s, p);          \
+			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, false, false, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, p);    \
 		}                                                                                                                                  \
 	} while (0)
 	switch (metric) {
@@ -681,13 +890,13 @@ static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hip
 #undef RX_HNSW
 }
 
-template <int kSorted>
+template <int kSorted, bool kDel>
 static void launch_hnsw_sorted(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
 	switch (p.dim) {
-		case 128: launch_hnsw_nb<false, 2, kSorted>(metric, p, blocks, s); break;
-		case 512: launch_hnsw_nb<false, 8, kSorted>(metric, p, blocks, s); break;
-		case 768: launch_hnsw_nb<false, 12, kSorted>(metric, p, blocks, s); break;
-		default: launch_hnsw_nb<false, 0, kSorted>(metric, p, blocks, s); break;
+		case 128: launch_hnsw_nb<false, 2, kSorted, kDel>(metric, p, blocks, s); break;
+		case 512: launch_hnsw_nb<false, 8, kSorted, kDel>(metric, p, blocks, s); break;
+		case 768: launch_hnsw_nb<false, 12, kSorted, kDel>(metric, p, blocks, s); break;
+		default: launch_hnsw_nb<false, 0, kSorted, kDel>(metric, p, blocks, s); break;
 	}
 }
 
@@ -701,26 +910,34 @@ static void launch_hnsw_mode(int metric, const HnswParams& p, uint32_t blocks, h
 	}
 }
 
-template <bool kGlobalCand, int NB, int kSorted = 0>
+template <bool kGlobalCand, int NB, int kSorted = 0, bool kDel = false>
 static void launch_hnsw_sq8_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
 	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8;
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB, false, true, kSorted>), dim3(blocks), dim3(64), lds, s, p); break;
-		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB, false, true, kSorted>), dim3(blocks), dim3(64), lds, s, p); break;
-		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB, false, true, kSorted>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kL2: hipLaunchKernelGGL((hnsw_search_kernel<kL2, kGlobalCand, NB, false, true, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, p); break;
+		case kIP: hipLaunchKernelGGL((hnsw_search_kernel<kIP, kGlobalCand, NB, false, true, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, p); break;
+		default: hipLaunchKernelGGL((hnsw_search_kernel<kCos, kGlobalCand, NB, false, true, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, p); break;
 	}
 }
 
-template <int kSorted>
+template <int kSorted, bool kDel>
 static void launch_hnsw_sq8_sorted(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
-	switch (p.dim) {
-		case 128: launch_hnsw_sq8_nb<false, 2, kSorted>(metric, p, blocks, s); break;
-		case 384: launch_hnsw_sq8_nb<false, 6, kSorted>(metric, p, blocks, s); break;
-		case 512: launch_hnsw_sq8_nb<false, 8, kSorted>(metric, p, blocks, s); break;
-		case 768: launch_hnsw_sq8_nb<false, 12, kSorted>(metric, p, blocks, s); break;
-		case 1024: launch_hnsw_sq8_nb<false, 16, kSorted>(metric, p, blocks, s); break;
-		case 1536: launch_hnsw_sq8_nb<false, 24, kSorted>(metric, p, blocks, s); break;
-		default: launch_hnsw_sq8_nb<false, 0, kSorted>(metric, p, blocks, s); break;
+	if constexpr (kDel) {   // graphs with deleted nodes: two embedding sizes get the 16-byte-load form, the rest the generic one
+		switch (p.dim) {
+			case 128: launch_hnsw_sq8_nb<false, 2, kSorted, true>(metric, p, blocks, s); break;
+			case 768: launch_hnsw_sq8_nb<false, 12, kSorted, true>(metric, p, blocks, s); break;
+			default: launch_hnsw_sq8_nb<false, 0, kSorted, true>(metric, p, blocks, s); break;
+		}
+	} else {
+		switch (p.dim) {
+			case 128: launch_hnsw_sq8_nb<false, 2, kSorted>(metric, p, blocks, s); break;
+			case 384: launch_hnsw_sq8_nb<false, 6, kSorted>(metric, p, blocks, s); break;
+			case 512: launch_hnsw_sq8_nb<false, 8, kSorted>(metric, p, blocks, s); break;
+			case 768: launch_hnsw_sq8_nb<false, 12, kSorted>(metric, p, blocks, s); break;
+			case 1024: launch_hnsw_sq8_nb<false, 16, kSorted>(metric, p, blocks, s); break;
+			case 1536: launch_hnsw_sq8_nb<false, 24, kSorted>(metric, p, blocks, s); break;
+			default: launch_hnsw_sq8_nb<false, 0, kSorted>(metric, p, blocks, s); break;
+		}
 	}
 }
 
@@ -738,17 +955,25 @@ static void launch_hnsw_sq8(int metric, const HnswParams& p, uint32_t blocks, hi
 }
 
 void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s) {
-	if (p.sorted && !global_cand) {   // both queues as one sorted list in registers: 2 entries a lane up to ef = 128, 4 up to 256
-		if (p.codes) {
-			if (p.ef <= 128) {
-				launch_hnsw_sq8_sorted<2>(metric, p, blocks, s);
+	if (p.sorted && !global_cand) {
+		// both queues as one sorted list in registers.  Without deleted nodes: 2 entries a lane up to ef = 128, 4 up to 256; with deleted
+		// nodes the list also holds the deleted candidates in reach: 2 entries a lane up to ef = 96, 3 up to 160, 4 up to 224 (kHnswSortedMaxEfDel)
+		if (p.bare) {
+			const bool four = p.ef > 128;
+			if (p.codes) {
+				four ? launch_hnsw_sq8_sorted<4, false>(metric, p, blocks, s) : launch_hnsw_sq8_sorted<2, false>(metric, p, blocks, s);
 			} else {
-				launch_hnsw_sq8_sorted<4>(metric, p, blocks, s);
+				four ? launch_hnsw_sorted<4, false>(metric, p, blocks, s) : launch_hnsw_sorted<2, false>(metric, p, blocks, s);
 			}
-		} else if (p.ef <= 128) {
-			launch_hnsw_sorted<2>(metric, p, blocks, s);
 		} else {
-			launch_hnsw_sorted<4>(metric, p, blocks, s);
+			const int slots = p.ef <= 96 ? 2 : p.ef <= 160 ? 3 : 4;
+			if (p.codes) {
+				slots == 2 ? launch_hnsw_sq8_sorted<2, true>(metric, p, blocks, s)
+						   : slots == 3 ? launch_hnsw_sq8_sorted<3, true>(metric, p, blocks, s) : launch_hnsw_sq8_sorted<4, true>(metric, p, blocks, s);
+			} else {
+				slots == 2 ? launch_hnsw_sorted<2, true>(metric, p, blocks, s)
+						   : slots == 3 ? launch_hnsw_sorted<3, true>(metric, p, blocks, s) : launch_hnsw_sorted<4, true>(metric, p, blocks, s);
+			}
 		}
 		return;
 	}

@@ -112,6 +112,7 @@ constexpr int kHnswMaxNeighbors = 128;  // 2*M <= 128
 constexpr uint32_t kHnswOverflow = 0xFFFFFFFFu;
 constexpr uint32_t kHnswTie = 0xFFFFFFFEu;        // sorted-list search met equal keys: re-run on the heap kernel
 constexpr int kHnswSortedMaxEf = 256;            // largest ef the sorted-list search holds in registers (4 entries a lane)
+constexpr int kHnswSortedMaxEfDel = 224;         // ... for a graph with deleted nodes: 32 entries of room for the deleted candidates in reach
 
 struct HnswParams {
 	const float* rows;

@@ -1778,7 +1778,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	}
 	// Graphs without deleted nodes, ef <= 256: both queues as one sorted list in registers (hnsw_search.hip).  A query that meets equal
 	// distances there comes back as kHnswTie and takes the heap kernel, whose sift order is the reference's.
-	bool use_sorted = p.bare && ef <= uint32_t(rxgpu::kHnswSortedMaxEf);
+	bool use_sorted = ef <= uint32_t(p.bare ? rxgpu::kHnswSortedMaxEf : rxgpu::kHnswSortedMaxEfDel);
 	uint32_t sorted_mode = 1;
 	// candidate-heap entries a restarted search gets in LDS.  Measured at 1M x 768, ef = 128, 16 384 queries, ~90 restarts (profiles/
 	// rd3p_restart_caps.txt, one graph, one box): 384 entries (8 KB per workgroup, 19 per CU) -> one restart overflows and the global-heap

@@ -199,3 +199,44 @@ def test_range_search_and_tiny_graphs_on_the_sorted_list(rxgpu, oracle, monkeypa
         assert np.array_equal(a[1], b[1]) and np.array_equal(bits(a[0]), bits(b[0])), n
         monkeypatch.delenv("RXGPU_HNSW_SORTED")
         m.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("del_frac", [0.03, 0.4])
+def test_graphs_with_deleted_nodes_on_the_sorted_list(rxgpu, oracle, monkeypatch, metric, del_frac):
+    """HnswSortedListDel: deleted nodes are candidates, never results; 2 / 3 / 4 entries a lane by ef (96 / 160 / 224), heaps above.
+    Against the heap kernel on every query and against the restated engine; the entry point is deleted in the second round."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    n, d = 7000, 128
+    m, rows, labels = build(metric, n, d, M=12, efc=80, seed=131)
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    rng = np.random.default_rng(9)
+    plans = ((10, 64), (10, 96), (20, 97), (10, 128), (40, 160), (10, 161), (64, 224), (10, 225), (5, 0), (1, 1))
+    for phase in range(2):
+        victims = labels[rng.choice(n, int(n * del_frac / 2), replace=False)]
+        g = m.export_graph()
+        if phase:
+            victims = np.unique(np.concatenate([victims, labels[[int(g["entry"])]]]))
+        for lab in victims:
+            try:
+                m.mark_delete(lab)
+            except Exception:
+                pass   # already deleted in the first round
+        g = m.export_graph()
+        g["vectors"] = rows
+        assert g["num_deleted"] > 0
+        for qi in range(10):
+            q = make_corpus(3100 + qi, 1, d)[0]
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            for k, ef in plans:
+                monkeypatch.setenv("RXGPU_HNSW_SORTED", "1")
+                gd, gl = m.search_knn(q, k, ef)
+                monkeypatch.setenv("RXGPU_HNSW_SORTED", "0")
+                hd, hl = m.search_knn(q, k, ef)
+                assert np.array_equal(gl, hl) and np.array_equal(bits(gd), bits(hd)), (metric, phase, qi, k, ef)
+                if qi < 4:
+                    wd, wl = oracle_hnsw_search_knn(oracle, g, q, k, ef, inv)
+                    assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd)), (metric, phase, qi, k, ef)
+    monkeypatch.delenv("RXGPU_HNSW_SORTED")
+    m.close()
