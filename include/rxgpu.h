@@ -248,10 +248,10 @@ int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const 
 							  uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count);
 /* Counters accumulated since the last call (for the roofline accounting: bytes = evals*dim*4 + hops*(1+2M)*4). */
 int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* hops);
-/* Searches over a graph without deleted nodes and ef <= 256 keep top_candidates + candidate_set (hnswalg.h:741-777) as one sorted list in
- * registers; a query that meets two EQUAL distances in it is re-run on the kernel that replays the reference's binary heaps, where the
- * order among equal keys is the reference's (CompareByFirst, hnswalg.h:581-585).  Reads and resets the number of such re-runs.
- * RXGPU_HNSW_SORTED=0 in the environment keeps every search on the heap kernel. */
+/* Searches with ef <= 256 (<= 224 when the graph has deleted nodes) keep top_candidates + candidate_set (hnswalg.h:741-777) as one sorted
+ * list in registers; a search in which EQUAL distances could change what the reference's binary heaps do (CompareByFirst,
+ * hnswalg.h:581-585), or whose list runs out of registers, starts over on the kernel that replays those heaps.  Reads and resets the
+ * number of such restarts.  RXGPU_HNSW_SORTED=0 in the environment keeps every search on the heap kernel. */
 int rxgpu_hnsw_read_tie_reruns(rxgpu_index* h, uint64_t* reruns);
 
 /* HierarchicalNSW::SearchRange (hnswalg.h:2015-2070) with BOTH halves on the device: the ef-search, then the closure of its hits over the

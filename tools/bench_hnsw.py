@@ -34,7 +34,7 @@ os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
 from reindexer_amd import capi, hostapi  # noqa: E402
 
 DEFAULTS = dict(rows=1_000_000, dim=768, queries=16384, k=10, ef=128, M=16, efc=200, metric="cosine", cpu_queries=256, clusters=2000,
-                graph=None, save_graph=None, sq8=True, gpu_only=False, build_threads=0, cpu_threads=0, cpu_per_thread=64, map_legs=True, device=0, out=None, seed=20260924)
+                graph=None, save_graph=None, sq8=True, gpu_only=False, build_threads=0, cpu_threads=0, cpu_per_thread=64, map_legs=True, device=0, out=None, seed=20260924, delete_frac=0.0)
 
 
 def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
@@ -155,6 +155,11 @@ def run(o) -> dict:
                      build_seconds=np.float64(build_s))
     glabels = g["labels"]
     del corpus, rows
+    if o.delete_frac > 0:   # MarkDelete on a random subset (flags only, like hnswalg.h:1303-1339): the search then runs its non-bare form
+        dele = np.random.default_rng(o.seed + 1).random(o.rows) < o.delete_frac
+        g["deleted"] = np.ascontiguousarray(dele.astype(np.uint8))
+        g["num_deleted"] = int(dele.sum())
+        o.map_legs = False   # the Map built above knows nothing of these marks (it stays alive: g's vectors are views of its storage)
 
     # ---- (a) GPU search through the C-ABI
     ix = capi.VectorIndex(metric, o.dim, o.rows, device=o.device)
@@ -201,6 +206,7 @@ def run(o) -> dict:
     recall = float(np.mean([len(set(trow[i].tolist()) & set(row[i, :int(cnt[i])].tolist())) / o.k for i in range(tq)]))
 
     out = {
+        "deleted_nodes": int(g.get("num_deleted", 0)),
         "workload": f"HNSW {o.metric} M={g['M']} efC={o.efc} ef={o.ef} k={o.k}, {o.rows} x {o.dim} (BASELINE configs[2]"
                     + ("" if o.rows == 10_000_000 else f" scaled to {o.rows} rows") + "), "
                     + (f"{o.clusters} gaussian clusters" if o.clusters else "i.i.d. gaussian"),
