@@ -51,3 +51,50 @@ def test_hybrid_fusion_kernels_fit(tmp_path):
     join = next(v for k, v in usage.items() if "hybrid_join_kernel" in k)
     assert prep["VGPRs"] <= 128 and prep["VGPRs Spill"] == 0 and prep["ScratchSize"] == 0, prep
     assert join["VGPRs Spill"] == 0 and join["ScratchSize"] == 0, join
+
+
+# ---------------------------------------------------------------------------------------------- HNSW search kernels, from the built object
+LLVM_BIN = Path("/opt/rocm/lib/llvm/bin")
+
+
+def built_kernel_metadata(obj: Path, tmp: Path) -> dict:
+    """Per-kernel metadata of the gfx950 code object embedded in a built .o (the note hipcc writes: what the loader will allocate).
+    A recompile with -Rpass-analysis of hnsw_search.hip takes 90 s (220 instantiations); this takes one."""
+    fat, dev = tmp / "fat.bin", tmp / "dev.co"
+    subprocess.run([str(LLVM_BIN / "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", str(obj)], check=True, capture_output=True)
+    subprocess.run([str(LLVM_BIN / "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    f"--input={fat}", f"--output={dev}"], check=True, capture_output=True)
+    notes = subprocess.run([str(LLVM_BIN / "llvm-readelf"), "--notes", str(dev)], check=True, capture_output=True, text=True).stdout
+    out, block = {}, {}
+    for line in notes.splitlines():   # the kernel's fields come in alphabetical order, .name among them: close a block at ".args:" / "- .agpr_count"
+        m = re.match(r"\s+(?:- )?\.(\w+):\s+(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2)
+        if key in ("args", "agpr_count") and line.lstrip().startswith("- "):
+            if "name" in block:
+                out[block["name"]] = block
+            block = {}
+        if key in ("name", "symbol", "vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"):
+            block[key] = val if key in ("name", "symbol") else int(val)
+    if "name" in block:
+        out[block["name"]] = block
+    return {k: v for k, v in out.items() if k == v.get("symbol", "").removesuffix(".kd") or "symbol" not in v}
+
+
+@pytest.mark.skipif(not (LLVM_BIN / "llvm-readelf").exists(), reason="needs the ROCm llvm tools")
+def test_hnsw_search_kernels_stay_in_registers(tmp_path):
+    """The sorted-list searches keep their lists in registers (per-slot state as vector values): no instantiation may use scratch memory
+    or spill VGPRs, and the throughput form of the headline shape (cosine / ip / l2, D = 768, two entries a lane, no deleted nodes) must
+    fit five wavefronts per SIMD (<= 96 VGPRs) — what its __launch_bounds__ asks for."""
+    obj = ROOT / "reindexer_amd" / "build" / "obj" / "hnsw_search.o"
+    if not obj.exists():
+        from reindexer_amd import build
+        build.build_device()
+    meta = built_kernel_metadata(obj, tmp_path)
+    search = {k: v for k, v in meta.items() if "hnsw_search_kernel" in k}
+    assert len(search) >= 200, len(search)
+    for name, v in search.items():
+        assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, (name, v)
+    headline = [v for k, v in search.items() if re.search(r"ILi[012]ELb0ELi12ELb0ELb0ELi2ELb0EE", k)]
+    assert len(headline) == 3 and all(v["vgpr_count"] <= 96 for v in headline), headline
