@@ -116,8 +116,35 @@ def main():
                 sess.close()
     h.close()
     np.savez_compressed(OUT / "hnsw.npz", **hz)
+    make_ann_cache_golden()
     make_ft_goldens()
     print("wrote", [p.name for p in OUT.glob("*.npz")])
+
+
+def make_ann_cache_golden():
+    """The reference's ANN disk cache of a small graph, written by the REAL engine (HierarchicalNSW::SaveIndex behind hnsw.cc:56-62's flag,
+    through the in-memory IWriter of oracle/ref/ref_shim.cc): the stream, the rows it refers to, and the graph the engine holds after
+    re-loading it — for tests/test_ann_cache.py::test_loader_reads_the_golden_reference_cache on machines without the reference tree."""
+    from tests.conftest import make_corpus
+    ref = Ref()
+    z = {}
+    for metric in (0, 2):
+        n, d, M, efc = 700, 20, 8, 60
+        rows = make_corpus(4242 + metric, n, d)
+        labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(11)
+        r = RefHnsw(ref, metric, d, n, M=M, ef_construction=efc)
+        r.add(rows, labels)
+        for lab in labels[np.random.default_rng(3).choice(n, 35, replace=False)]:
+            r.mark_delete(lab)
+        blob = np.frombuffer(r.save_index(), np.uint8)
+        e = r.export(with_vectors=False)
+        z[f"m{metric}_cache"], z[f"m{metric}_rows"], z[f"m{metric}_labels"] = blob, rows, labels
+        z[f"m{metric}_meta"] = np.array([metric, n, d, M, efc, e["maxlevel"], e["entry"], e["num_deleted"]], np.int64)
+        for key in ("links0", "levels", "deleted", "upper_off"):
+            z[f"m{metric}_{key}"] = e[key]
+        z[f"m{metric}_upper"] = e["upper"][:int(e["upper_off"][-1])]
+        r.close()
+    np.savez_compressed(OUT / "ann_cache.npz", **z)
 
 
 def make_ft_goldens():

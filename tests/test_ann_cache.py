@@ -66,6 +66,41 @@ def test_writers_agree_and_caches_cross_load(ref, metric, shape):
         x.close()
 
 
+def test_loader_reads_the_golden_reference_cache():
+    """No reference needed: a cache written by the real engine is committed (tests/golden/ann_cache.npz, make_golden.py) with the graph the
+    engine holds; the product's loader must rebuild that graph from the stream, write a stream of the same length back, and read its own
+    stream to the same graph again."""
+    from pathlib import Path
+    from reindexer_amd import hostapi
+    z = np.load(Path(__file__).resolve().parent / "golden" / "ann_cache.npz")
+    for metric in (0, 2):
+        meta = z[f"m{metric}_meta"]
+        _, n, d, M, efc, maxlevel, entry, ndel = (int(x) for x in meta)
+        cache, rows, labels = z[f"m{metric}_cache"].tobytes(), z[f"m{metric}_rows"], z[f"m{metric}_labels"]
+        g = hostapi.HnswGraph(metric, d, n, M=M, ef_construction=efc)
+        g.load_index(cache, labels, rows)
+        e = g.export()
+        assert (e["n"], e["maxlevel"], e["entry"], e["num_deleted"]) == (n, maxlevel, entry, ndel)
+        for key in ("links0", "levels", "deleted", "upper_off"):
+            assert np.array_equal(e[key], z[f"m{metric}_{key}"]), key
+        blocks = int(e["upper_off"][-1])
+        count = e["upper"][:blocks, 0].astype(np.int64)
+        live = np.arange(e["upper"].shape[1] - 1)[None, :] < count[:, None]   # the slots below each list's count: the rest is the writer's stale data
+        assert np.array_equal(e["upper"][:blocks, 0], z[f"m{metric}_upper"][:, 0])
+        assert np.array_equal(np.where(live, e["upper"][:blocks, 1:], 0), np.where(live, z[f"m{metric}_upper"][:, 1:], 0))
+        alive = e["deleted"] == 0
+        assert np.array_equal(e["labels"][alive], labels[alive])
+        vec, _ = g.vector_views(n)
+        assert np.array_equal(vec[alive], rows[alive])
+        mine = g.save_index()
+        assert len(mine) == len(cache)
+        g2 = hostapi.HnswGraph(metric, d, n, M=M, ef_construction=efc)
+        g2.load_index(mine, labels, rows)
+        assert g2.save_index() == mine
+        g.close()
+        g2.close()
+
+
 def test_loaded_graph_keeps_building_like_the_reference(ref):
     """After LoadIndex both engines continue from the same state: the level generator restarts from its seed in the reader constructor
     (hnswalg.h:301-303) and the slots of deleted elements are reusable (allow_replace_deleted).  The reference sizes the loaded graph
