@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential runs of the CPU checkers against the REAL reference code compiled in place (oracle/_ref) — no GPU involved.
 
-    RX_TARGET_INSTRUCTIONS=avx512 python tools/fuzz_oracles.py --seconds 60 [--only packed,sq8_dist,sq8_quantize,sq8_hnsw,ivf,bm25,builder]
+    RX_TARGET_INSTRUCTIONS=avx512 python tools/fuzz_oracles.py --seconds 60 [--only packed,sq8_dist,sq8_quantize,sq8_hnsw,ivf,bm25,builder,ann_cache,sorted_list]
 
   packed        PackedIdRelVec streams of the reference's packer -> the device kernel's decoder (host build), the host decoder, the test packer
   sq8_dist      oracle_sq8.c uint8 L2 / IP            vs vector_dists::L2SqrDistance<uint8_t> / InnerProductDistance<uint8_t>
@@ -10,6 +10,8 @@
   ivf           the IVF search definition              vs the reference's vendored FAISS (IndexIVFFlat), given its trained state
   bm25          the merger restatement (3 calculators) vs ft::Merger::Merge<Bm25Rx / Bm25Classic / TermCount>
   builder       the PRODUCT's host HNSW builder        vs the real engine's graph, link for link (sequential and one-thread concurrent path)
+  ann_cache     the PRODUCT's ANN-cache writer/reader  vs the real engine's SaveIndex / reader constructor, both directions, then more inserts
+  sorted_list   the rules of the device's sorted-list HNSW search (Python restatement, tests/test_hnsw_sorted_model.py) vs the two-heap restatement
 Needs /root/reference (to build oracle/_ref) and an AVX-512 host."""
 import argparse
 import os
@@ -209,6 +211,85 @@ def fuzz_builder(orc, ref, rng, seconds):
     return n, bad
 
 
+def fuzz_ann_cache(orc, ref, rng, seconds):
+    """Random graphs with deleted nodes: the reference's cache into the product's graph and back, the product's cache into the reference's
+    engine; graphs equal, re-saved streams equal, and both keep building the same way into the slots of the deleted nodes."""
+    os.environ.setdefault("RXGPU_NO_TORCH", "1")
+    from reindexer_amd import hostapi
+    keys = ("n", "M", "maxM0", "maxlevel", "entry", "num_deleted")
+
+    def same(a, b):
+        if any(a[k] != b[k] for k in keys):
+            return False
+        lab_a, lab_b = np.where(a["deleted"] != 0, 0, a["labels"]), np.where(b["deleted"] != 0, 0, b["labels"])
+        blocks = int(a["upper_off"][-1])
+        cnt = a["upper"][:blocks, 0].astype(np.int64)
+        live = np.arange(a["upper"].shape[1] - 1)[None, :] < cnt[:, None]
+        return (all(np.array_equal(a[k], b[k]) for k in ("levels", "deleted", "links0", "upper_off")) and np.array_equal(lab_a, lab_b)
+                and np.array_equal(a["upper"][:blocks, 0], b["upper"][:blocks, 0])
+                and np.array_equal(np.where(live, a["upper"][:blocks, 1:], 0), np.where(live, b["upper"][:blocks, 1:], 0)))
+
+    t0, n, bad = time.time(), 0, 0
+    while time.time() - t0 < seconds:
+        metric, d, cnt = int(rng.integers(0, 3)), int(rng.choice([3, 16, 33, 100])), int(rng.integers(1, 1500))
+        M, efc = int(rng.choice([2, 4, 8, 16])), int(rng.choice([10, 40, 200]))
+        rows = rng.normal(0, 0.25, (cnt, d)).astype(np.float32)
+        rows[np.all(rows == 0, axis=1)] = 1.0
+        labels = (rng.permutation(cnt).astype(np.uint64) << np.uint64(32)) | np.uint64(5)
+        r = RefHnsw(ref, metric, d, cnt, M=M, ef_construction=efc)
+        g = hostapi.HnswGraph(metric, d, cnt, M=M, ef_construction=efc)
+        r.add(rows, labels)
+        g.add(rows, labels)
+        ndel = int(rng.integers(0, cnt // 4 + 1))
+        for lab in labels[rng.choice(cnt, ndel, replace=False)]:
+            r.mark_delete(lab)
+            g.mark_delete(lab)
+        theirs, ours = r.save_index(), g.save_index()
+        g2 = hostapi.HnswGraph(metric, d, cnt, M=M, ef_construction=efc)
+        g2.load_index(theirs, labels, rows)
+        r2 = RefHnsw.load_index(ref, ours, metric, d, labels, rows)
+        ok = len(theirs) == len(ours) and g2.save_index() == ours and same(g.export(), g2.export()) and same(r.export(with_vectors=False), r2.export(with_vectors=False))
+        if ok and ndel:   # the loaded graphs go on like the built ones
+            more = rng.normal(0, 0.25, (ndel, d)).astype(np.float32)
+            more_labels = ((np.arange(cnt, cnt + ndel).astype(np.uint64)) << np.uint64(32)) | np.uint64(5)
+            for x in (r2, g2):
+                x.add(more, more_labels)
+            ok = same(r2.export(with_vectors=False), g2.export())
+        bad += int(not ok)
+        n += 1
+        for x in (r, r2, g, g2):
+            x.close()
+    return n, bad
+
+
+def fuzz_sorted_list(orc, ref, rng, seconds):
+    """The tie rules of HnswSortedList / HnswSortedListDel: every search the Python restatement does not flag must equal the two-heap
+    restatement (results and hops) — corpora from tie-free to tie-saturated, with and without deleted nodes.  A mismatch raises."""
+    os.environ.setdefault("RXGPU_NO_TORCH", "1")
+    sys.path.insert(0, str(ROOT))
+    from tests.test_hnsw_sorted_model import run_deleted_model_against_oracle, run_model_against_oracle
+    t0, n, bad, seed = time.time(), 0, 0, 0
+    while time.time() - t0 < seconds:
+        metric = int(rng.integers(0, 3))
+        cnt, d, M = int(rng.integers(50, 2500)), int(rng.integers(2, 20)), int(rng.choice([2, 4, 6, 8, 12, 16]))
+        scale = float(rng.choice([1, 2, 4, 8, 16, 64, 4096]))
+        rows = (np.round(rng.standard_normal((cnt, d)) * scale) / scale).astype(np.float32)
+        rows[np.all(rows == 0, axis=1)] = 1 / scale
+        queries = [(np.round(rng.standard_normal(d) * scale) / scale).astype(np.float32) for _ in range(20)]
+        queries = [q if np.any(q) else np.full(d, 1 / scale, np.float32) for q in queries]
+        plans = tuple((int(rng.integers(1, 60)), int(rng.choice([0, 1, 5, 10, 32, 64, 96, 97, 128, 160, 161, 224]))) for _ in range(5))
+        try:
+            _, t1 = run_model_against_oracle(orc, metric, rows, queries, M, int(rng.choice([10, 60])), plans)
+            _, t2 = run_deleted_model_against_oracle(orc, metric, rows, queries, M, int(rng.choice([10, 60])), plans,
+                                                     float(rng.choice([0.01, 0.1, 0.4, 0.9])), seed)
+            n += t1 + t2
+        except AssertionError as e:
+            print("sorted_list mismatch:", e, flush=True)
+            bad += 1
+        seed += 1
+    return n, bad
+
+
 def fuzz_packed(orc, ref, rng, seconds):
     """PackedIdRelVec: random posting lists through the reference's own packer (PackedIdRelVec::insert_back) -> (a) the decoder the device
     kernel runs, compiled for the host, (b) the host decoder AppendPacked, (c) the test-side packer, byte for byte."""
@@ -250,7 +331,7 @@ def fuzz_packed(orc, ref, rng, seconds):
 
 
 FUZZERS = {"packed": fuzz_packed, "sq8_dist": fuzz_sq8_dist, "sq8_quantize": fuzz_sq8_quantize, "sq8_hnsw": fuzz_sq8_hnsw, "ivf": fuzz_ivf, "bm25": fuzz_bm25,
-           "builder": fuzz_builder}
+           "builder": fuzz_builder, "ann_cache": fuzz_ann_cache, "sorted_list": fuzz_sorted_list}
 
 
 def main():
