@@ -72,6 +72,18 @@ void rxgpu_index_destroy(rxgpu_index* h);
 int rxgpu_index_create_sharded(int metric, uint32_t dim, uint64_t capacity, uint32_t n_devices, const int* devices, rxgpu_index** out);
 uint32_t rxgpu_index_shard_count(const rxgpu_index* h);   /* 0 for an unsharded index */
 uint64_t rxgpu_index_shard_rows(const rxgpu_index* h);
+/* How SearchKnn's per-shard lists meet (north_star: "RCCL all-gather of per-shard top-k over xGMI"): 1 = on the devices — the index owns one
+ * RCCL communicator over its distinct devices (ncclCommInitAll at creation), each search is the shards' scans, ONE ncclAllGather of
+ * kk x 8 B x nq per shard on the shards' streams, the (dist, global row) merge kernel on the first device and one D2H copy; 0 = on the host
+ * (RXGPU_SHARD_MERGE=host in the environment at creation: D2H per shard + host merge — also what range searches, pre-filtered searches and
+ * kk > 64 use in either mode); -1 = not a sharded index.  Creation FAILS if the communicator cannot be built and host mode was not asked for. */
+int rxgpu_index_shard_merge_mode(const rxgpu_index* h);
+uint32_t rxgpu_index_shard_ranks(const rxgpu_index* h);         /* RCCL ranks = distinct devices of the shard list (0 in host mode) */
+uint64_t rxgpu_index_shard_collectives(const rxgpu_index* h);   /* all-gathers issued so far (tests / bench assert the path that ran) */
+/* Shard s as an ordinary single-device index, for filling it in place (rxgpu_index_adopt_device_rows with memory of THAT device; the
+ * sharded handle then takes the row counts over with rxgpu_index_shard_sync_count: full shards, then at most one partial, then empty). */
+rxgpu_index* rxgpu_index_shard(rxgpu_index* h, uint32_t s);
+int rxgpu_index_shard_sync_count(rxgpu_index* h);
 /* One row back to the host (and its 1/|row| for cosine; out_inv_norm may be NULL): the cross-device half of a sharded swap-delete. */
 int rxgpu_index_download_row(rxgpu_index* h, uint64_t row, float* out_row, float* out_inv_norm);
 

@@ -38,6 +38,11 @@ _SIGNATURES = {
     "rxgpu_index_create_sharded": (_i, [_i, _u32, _u64, _u32, _vp, C.POINTER(_vp)]),
     "rxgpu_index_shard_count": (_u32, [_vp]),
     "rxgpu_index_shard_rows": (_u64, [_vp]),
+    "rxgpu_index_shard_merge_mode": (_i, [_vp]),
+    "rxgpu_index_shard_ranks": (_u32, [_vp]),
+    "rxgpu_index_shard_collectives": (_u64, [_vp]),
+    "rxgpu_index_shard": (_vp, [_vp, _u32]),
+    "rxgpu_index_shard_sync_count": (_i, [_vp]),
     "rxgpu_index_download_row": (_i, [_vp, _u64, _vp, _vp]),
     "rxgpu_index_reserve": (_i, [_vp, _u64]),
     "rxgpu_index_upload_rows": (_i, [_vp, _u64, _u64, _vp, _vp]),
@@ -429,6 +434,62 @@ class VectorIndex:
         n, ms = _u64(0), C.c_double(0.0)
         _check(lib().rxgpu_profile_read(self._h, name.encode(), C.byref(n), C.byref(ms)))
         return int(n.value), float(ms.value)
+
+
+class ShardedVectorIndex(VectorIndex):
+    """rxgpu_index_create_sharded: the same index row-range sharded over a device list of THIS process (a device may repeat).  Rows in and out
+    are global rows; SearchKnn's per-shard lists meet in one RCCL all-gather on the devices (merge_mode == 1) unless RXGPU_SHARD_MERGE=host
+    was set when the index was created."""
+
+    def __init__(self, metric: int | str, dim: int, capacity: int, devices):
+        if isinstance(metric, str):
+            metric = METRICS[metric.lower()]
+        self.metric, self.dim = int(metric), int(dim)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = _vp()
+        _check(lib().rxgpu_index_create_sharded(self.metric, self.dim, capacity, len(devices), devs, C.byref(h)))
+        self._h = h
+        self._keepalive = None
+
+    @property
+    def merge_mode(self) -> str:
+        return {1: "rccl", 0: "host"}[lib().rxgpu_index_shard_merge_mode(self._h)]
+
+    @property
+    def ranks(self) -> int:
+        return lib().rxgpu_index_shard_ranks(self._h)
+
+    @property
+    def collectives(self) -> int:
+        return lib().rxgpu_index_shard_collectives(self._h)
+
+    @property
+    def shard_count(self) -> int:
+        return lib().rxgpu_index_shard_count(self._h)
+
+    @property
+    def shard_rows(self) -> int:
+        return lib().rxgpu_index_shard_rows(self._h)
+
+    def shard(self, s: int) -> "VectorIndex":
+        """Shard s as a NON-owning single-device view (adopt_device_rows / profile_enable / profile_read on it)."""
+        hs = lib().rxgpu_index_shard(self._h, s)
+        if not hs:
+            raise RxGpuError("no such shard")
+        return _ShardView(self.metric, self.dim, _vp(hs))
+
+    def sync_count(self) -> None:
+        _check(lib().rxgpu_index_shard_sync_count(self._h))
+
+
+class _ShardView(VectorIndex):
+    def __init__(self, metric: int, dim: int, handle):
+        self.metric, self.dim, self._keepalive = metric, dim, None
+        self._h = handle
+
+    def close(self) -> None:   # owned by the sharded index
+        self._h = None
+        self._keepalive = None
 
 
 def merge_shards_device(d_gathered_ptr: int, world: int, nq: int, kk: int, shard_rows: int, d_out_dist_ptr: int, d_out_row_ptr: int,

@@ -708,20 +708,24 @@ __device__ void merge_by_insertion(const float* part_dist, const uint32_t* part_
 // Multi-GPU: fold the all-gathered per-shard lists of one query batch into the global top-kk.
 // gathered: [world][2][nq][kk] 32-bit words — per shard the [nq][kk] distances followed by the [nq][kk] shard-local rows (what
 // the scan writes when d_out_row == d_out_dist + nq*kk).  Global row = shard * shard_rows + local row; order = (dist, global row).
+// slot_base (in-process RCCL path, rxgpu_sharded.hip): the global row base of every gathered position (rank-major, several shards per
+// device, padded positions = kInvalidRow and skipped); null: position w is shard w.
 __global__ __launch_bounds__(64) void knn_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows,
-														float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+														const uint32_t* slot_base, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
 	const int lane = threadIdx.x;
 	const uint32_t q = blockIdx.x;
 	WaveTopK top;
 	top.init(kk);
 	for (uint32_t w = 0; w < world; ++w) {
 		const uint32_t* rec = gathered + size_t(w) * 2 * nq * kk + size_t(q) * kk;
+		const uint32_t base = slot_base ? slot_base[w] : w * shard_rows;
+		if (base == kInvalidRow) continue;
 		float cd = __builtin_inff();
 		uint32_t ci = kInvalidRow;
 		if (lane < int(kk)) {
 			cd = __uint_as_float(rec[lane]);
 			const uint32_t local = rec[size_t(nq) * kk + lane];
-			if (local != kInvalidRow) ci = w * shard_rows + local;
+			if (local != kInvalidRow) ci = base + local;
 		}
 		uint64_t pm = __ballot(ci != kInvalidRow);
 		while (pm) {
@@ -1014,8 +1018,8 @@ void launch_merge_lists(const float* part_dist, const uint32_t* part_row, uint32
 }
 
 void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
-						 uint32_t* out_row, uint32_t* out_count, hipStream_t s) {
-	hipLaunchKernelGGL(knn_merge_shards, dim3(nq), dim3(64), 0, s, gathered, world, nq, kk, shard_rows, out_dist, out_row, out_count);
+						 uint32_t* out_row, uint32_t* out_count, hipStream_t s, const uint32_t* slot_base) {
+	hipLaunchKernelGGL(knn_merge_shards, dim3(nq), dim3(64), 0, s, gathered, world, nq, kk, shard_rows, slot_base, out_dist, out_row, out_count);
 }
 
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,

@@ -27,7 +27,7 @@ void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t tot
 void launch_merge_lists(const float* part_dist, const uint32_t* part_row, uint32_t nlists, uint32_t kk, uint32_t nq, float* out_dist, uint32_t* out_row,
 						uint32_t* out_count, hipStream_t s);   // the partial results are sorted lists of kk entries: no serial insertions
 void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
-						 uint32_t* out_row, uint32_t* out_count, hipStream_t s);
+						 uint32_t* out_row, uint32_t* out_count, hipStream_t s, const uint32_t* slot_base = nullptr);
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,
 				  float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap, unsigned long long* counter,
 				  uint32_t gridx, hipStream_t s);

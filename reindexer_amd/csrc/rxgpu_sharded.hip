@@ -1,11 +1,19 @@
 // Row-range sharding of one float_vector index over several GPUs of THIS process (BASELINE configs[3] behind the C++ seam: the Map owns a
-// device list).  No device code here: every shard is an ordinary rxgpu_index on its own device, driven by its own worker thread; a search
-// fans the query out, every shard runs the kernels of rxgpu_search_* on its rows, and the per-shard answers (kk x 8 B per query) are merged
-// on the host under the reference's order — (dist, GLOBAL row), global row = shard * shard_rows + local row, which is the scan order of
-// BruteforceSearch::SearchKnn (bruteforce.cc:103-127) because shard s holds the rows [s * shard_rows, (s + 1) * shard_rows).
-// The one-process-per-GPU deployment (torch.distributed / RCCL all-gather of the same per-shard lists) is reindexer_amd/sharded.py.
+// device list).  Every shard is an ordinary rxgpu_index on its own device; a search fans the query out, every shard runs the kernels of
+// rxgpu_search_* on its rows, and the per-shard answers (kk x 8 B per query) are merged under the reference's order — (dist, GLOBAL row),
+// global row = shard * shard_rows + local row, which is the scan order of BruteforceSearch::SearchKnn (bruteforce.cc:103-127) because shard
+// s holds the rows [s * shard_rows, (s + 1) * shard_rows).
+//
+// SearchKnn (kk <= 64, the planner's case) exchanges the lists over RCCL: the index keeps ONE communicator over its distinct devices
+// (ncclCommInitAll), every device's scans write their sorted lists straight into that device's send buffer, one ncclAllGather per query
+// batch (inside ncclGroupStart/End, on the shards' streams: kk x 8 B x nq per shard over xGMI), knn_merge_shards on device 0, ONE D2H copy.
+// One host thread enqueues everything; nothing is merged on the host.  RXGPU_SHARD_MERGE=host keeps the former path (a worker thread per
+// shard, D2H per shard, host merge), which also serves range searches, pre-filtered searches, kk > 64 and shards holding fewer than kk rows.
+// The one-process-per-GPU deployment (torch.distributed over the same RCCL) is reindexer_amd/sharded.py.
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <exception>
@@ -16,7 +24,11 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
 #include "../../include/rxgpu.h"
+#include "knn_kernels.hip.h"
 #include "rxgpu_internal.h"
 
 using rxgpu::set_error;
@@ -56,11 +68,35 @@ struct ShardWorker {
 	}
 };
 
+// Buffers and streams of one exchange in flight (per distinct device = RCCL rank); lanes are pooled so that concurrent callers overlap.
+struct ExchangeLane {
+	std::vector<hipStream_t> stream;
+	std::vector<rxgpu_devbuf> d_queries, d_local, d_gathered;
+	rxgpu_devbuf d_out;            // rank 0: [nq][kk] distances | [nq][kk] global rows | [nq] counts
+	void* h_pinned = nullptr;      // queries on the way in, the merged lists on the way out
+	size_t h_pinned_bytes = 0;
+};
+
+// The RCCL side of a sharded index: one rank per DISTINCT device; a device that holds several shards (the 1-GPU test box lists the same
+// device several times) sends them as `slots` consecutive lists, devices with fewer shards pad (slot base = kInvalidRow, skipped by the merge).
+struct ShardExchange {
+	uint32_t nranks = 0, slots = 0;
+	std::vector<int> rank_dev;
+	std::vector<ncclComm_t> comms;
+	std::vector<uint32_t> shard_rank, shard_slot;
+	uint32_t* d_slot_base = nullptr;   // on rank_dev[0]: global row base of every gathered position
+	std::mutex mtx;                    // lane pool
+	std::vector<ExchangeLane*> free_lanes;
+	std::mutex coll_mtx;               // collectives of one communicator are enqueued in one order
+	std::atomic<uint64_t> collectives{0};
+};
+
 struct ShardSet {
 	std::vector<rxgpu_index*> shards;
 	std::vector<ShardWorker*> workers;
 	uint64_t shard_rows = 0;
 	std::shared_mutex call_mtx;   // shared: searches (any number of fan-outs in flight); exclusive: uploads, moves, truncation
+	ShardExchange* xch = nullptr; // null: RXGPU_SHARD_MERGE=host
 };
 
 namespace {
@@ -142,9 +178,198 @@ uint64_t local_count(const ShardSet* ss, size_t s, uint64_t count) {
 
 }  // namespace
 
+
+#define SH_HIP(expr)                                                                       \
+	do {                                                                                   \
+		hipError_t e__ = (expr);                                                           \
+		if (e__ != hipSuccess) {                                                           \
+			set_error(std::string(#expr) + ": " + hipGetErrorString(e__));                 \
+			return e__ == hipErrorOutOfMemory ? RXGPU_ERR_NOMEM : RXGPU_ERR_DEVICE;        \
+		}                                                                                  \
+	} while (0)
+#define SH_NCCL(expr)                                                                      \
+	do {                                                                                   \
+		ncclResult_t r__ = (expr);                                                         \
+		if (r__ != ncclSuccess) {                                                          \
+			set_error(std::string(#expr) + ": " + ncclGetErrorString(r__));                \
+			return RXGPU_ERR_DEVICE;                                                       \
+		}                                                                                  \
+	} while (0)
+
+namespace {
+
+struct CurrentDevice {   // restores the caller's device
+	int prev = -1;
+	CurrentDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+	~CurrentDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void free_lane(ShardExchange* x, ExchangeLane* l) {
+	for (uint32_t r = 0; r < x->nranks; ++r) {
+		(void)hipSetDevice(x->rank_dev[r]);
+		if (r < l->stream.size() && l->stream[r]) {
+			(void)hipStreamSynchronize(l->stream[r]);
+			(void)hipStreamDestroy(l->stream[r]);
+		}
+		if (r < l->d_queries.size()) l->d_queries[r].release();
+		if (r < l->d_local.size()) l->d_local[r].release();
+		if (r < l->d_gathered.size()) l->d_gathered[r].release();
+	}
+	(void)hipSetDevice(x->rank_dev[0]);
+	l->d_out.release();
+	if (l->h_pinned) (void)hipHostFree(l->h_pinned);
+	delete l;
+}
+
+int new_lane(ShardExchange* x, ExchangeLane** out) {
+	auto* l = new ExchangeLane();
+	l->stream.assign(x->nranks, nullptr);
+	l->d_queries.resize(x->nranks);
+	l->d_local.resize(x->nranks);
+	l->d_gathered.resize(x->nranks);
+	for (uint32_t r = 0; r < x->nranks; ++r) {
+		hipError_t e = hipSetDevice(x->rank_dev[r]);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&l->stream[r], hipStreamNonBlocking);
+		if (e != hipSuccess) {
+			set_error(std::string("sharded exchange: stream on device ") + std::to_string(x->rank_dev[r]) + ": " + hipGetErrorString(e));
+			free_lane(x, l);
+			return RXGPU_ERR_DEVICE;
+		}
+	}
+	*out = l;
+	return RXGPU_OK;
+}
+
+void exchange_destroy(ShardExchange* x) {
+	if (!x) return;
+	CurrentDevice cd;
+	for (ExchangeLane* l : x->free_lanes) free_lane(x, l);
+	for (ncclComm_t c : x->comms) {
+		if (c) (void)ncclCommDestroy(c);
+	}
+	if (x->d_slot_base) {
+		(void)hipSetDevice(x->rank_dev[0]);
+		(void)hipFree(x->d_slot_base);
+	}
+	delete x;
+}
+
+// One communicator over the distinct devices of the shard list, and the position -> global row base table of the merge kernel.
+int exchange_create(ShardSet* ss, uint32_t n_devices, const int* devices, ShardExchange** out) {
+	auto* x = new ShardExchange();
+	x->shard_rank.resize(n_devices);
+	x->shard_slot.resize(n_devices);
+	std::vector<uint32_t> per_rank;
+	for (uint32_t s = 0; s < n_devices; ++s) {
+		uint32_t r = 0;
+		while (r < x->rank_dev.size() && x->rank_dev[r] != devices[s]) ++r;
+		if (r == x->rank_dev.size()) {
+			x->rank_dev.push_back(devices[s]);
+			per_rank.push_back(0);
+		}
+		x->shard_rank[s] = r;
+		x->shard_slot[s] = per_rank[r]++;
+	}
+	x->nranks = uint32_t(x->rank_dev.size());
+	x->slots = *std::max_element(per_rank.begin(), per_rank.end());
+	CurrentDevice cd;
+	x->comms.assign(x->nranks, nullptr);
+	const ncclResult_t nr = ncclCommInitAll(x->comms.data(), int(x->nranks), x->rank_dev.data());
+	if (nr != ncclSuccess) {
+		set_error(std::string("rxgpu_index_create_sharded: ncclCommInitAll over ") + std::to_string(x->nranks) + " device(s): " + ncclGetErrorString(nr) +
+				  " (RXGPU_SHARD_MERGE=host selects the host-merge path)");
+		x->comms.clear();
+		exchange_destroy(x);
+		return RXGPU_ERR_DEVICE;
+	}
+	std::vector<uint32_t> base(size_t(x->nranks) * x->slots, kInvalidRow);
+	for (uint32_t s = 0; s < n_devices; ++s) base[size_t(x->shard_rank[s]) * x->slots + x->shard_slot[s]] = uint32_t(s * ss->shard_rows);
+	hipError_t e = hipSetDevice(x->rank_dev[0]);
+	if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&x->d_slot_base), base.size() * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMemcpy(x->d_slot_base, base.data(), base.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		set_error(std::string("rxgpu_index_create_sharded: slot table: ") + hipGetErrorString(e));
+		exchange_destroy(x);
+		return RXGPU_ERR_DEVICE;
+	}
+	*out = x;
+	return RXGPU_OK;
+}
+
+// SearchKnn over every shard with the exchange on the devices.  The caller holds call_mtx shared and has checked the shape
+// (kk <= kMaxFusedK, every non-empty shard holds >= kk rows).
+int exchange_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const float* queries, uint32_t nq, uint32_t kk, float* out_dist,
+						uint32_t* out_row, uint32_t* out_count) {
+	ShardExchange* x = ss->xch;
+	const size_t qbytes = size_t(nq) * h->dim * sizeof(float);
+	const size_t list_words = size_t(2) * nq * kk;                 // one shard: [nq][kk] distances | [nq][kk] local rows
+	const size_t local_bytes = list_words * x->slots * sizeof(uint32_t);
+	const size_t out_bytes = (size_t(2) * nq * kk + nq) * sizeof(uint32_t);
+	const size_t pin = std::max(qbytes, out_bytes);
+	if (l->h_pinned_bytes < pin) {
+		if (l->h_pinned) (void)hipHostFree(l->h_pinned);
+		l->h_pinned = nullptr;
+		l->h_pinned_bytes = 0;
+		SH_HIP(hipHostMalloc(&l->h_pinned, pin, hipHostMallocDefault));
+		l->h_pinned_bytes = pin;
+	}
+	std::memcpy(l->h_pinned, queries, qbytes);
+	bool hole = x->slots * x->nranks != ss->shards.size();   // padded positions are skipped by their base; EMPTY shards need invalid lists
+	std::vector<uint64_t> lc(ss->shards.size());
+	for (size_t s = 0; s < ss->shards.size(); ++s) {
+		lc[s] = rxgpu_index_count(ss->shards[s]);
+		hole = hole || lc[s] == 0;
+	}
+	for (uint32_t r = 0; r < x->nranks; ++r) {
+		SH_HIP(hipSetDevice(x->rank_dev[r]));
+		if (int rc = l->d_queries[r].ensure(qbytes); rc) return rc;
+		if (int rc = l->d_local[r].ensure(local_bytes); rc) return rc;
+		if (int rc = l->d_gathered[r].ensure(local_bytes * x->nranks); rc) return rc;
+		SH_HIP(hipMemcpyAsync(l->d_queries[r].ptr, l->h_pinned, qbytes, hipMemcpyHostToDevice, l->stream[r]));
+		if (hole) SH_HIP(hipMemsetAsync(l->d_local[r].ptr, 0xFF, local_bytes, l->stream[r]));   // rows = kInvalidRow
+		for (size_t s = 0; s < ss->shards.size(); ++s) {
+			if (x->shard_rank[s] != r || lc[s] == 0) continue;
+			uint32_t* dst = static_cast<uint32_t*>(l->d_local[r].ptr) + list_words * x->shard_slot[s];
+			if (int rc = rxgpu_search_knn_device(ss->shards[s], l->d_queries[r].ptr, nq, kk, dst, dst + size_t(nq) * kk, nullptr, l->stream[r]); rc) return rc;
+		}
+	}
+	{
+		std::lock_guard<std::mutex> lk(x->coll_mtx);
+		SH_NCCL(ncclGroupStart());
+		for (uint32_t r = 0; r < x->nranks; ++r) {
+			const ncclResult_t nr = ncclAllGather(l->d_local[r].ptr, l->d_gathered[r].ptr, list_words * x->slots, ncclUint32, x->comms[r], l->stream[r]);
+			if (nr != ncclSuccess) {
+				(void)ncclGroupEnd();
+				set_error(std::string("ncclAllGather: ") + ncclGetErrorString(nr));
+				return RXGPU_ERR_DEVICE;
+			}
+		}
+		SH_NCCL(ncclGroupEnd());
+		x->collectives.fetch_add(1, std::memory_order_relaxed);
+	}
+	SH_HIP(hipSetDevice(x->rank_dev[0]));
+	if (int rc = l->d_out.ensure(out_bytes); rc) return rc;
+	float* d_od = static_cast<float*>(l->d_out.ptr);
+	uint32_t* d_or = static_cast<uint32_t*>(l->d_out.ptr) + size_t(nq) * kk;
+	uint32_t* d_oc = d_or + size_t(nq) * kk;
+	launch_merge_shards(static_cast<const uint32_t*>(l->d_gathered[0].ptr), x->nranks * x->slots, nq, kk, 0, d_od, d_or, d_oc, l->stream[0], x->d_slot_base);
+	SH_HIP(hipGetLastError());
+	SH_HIP(hipMemcpyAsync(l->h_pinned, l->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, l->stream[0]));
+	for (uint32_t r = 0; r < x->nranks; ++r) SH_HIP(hipStreamSynchronize(l->stream[r]));
+	const auto* hp = static_cast<const uint32_t*>(l->h_pinned);
+	std::memcpy(out_dist, hp, size_t(nq) * kk * sizeof(float));
+	std::memcpy(out_row, hp + size_t(nq) * kk, size_t(nq) * kk * sizeof(uint32_t));
+	std::memcpy(out_count, hp + size_t(2) * nq * kk, size_t(nq) * sizeof(uint32_t));
+	return RXGPU_OK;
+}
+
+}  // namespace
+
 void sharded_destroy(rxgpu_index* h) {
 	ShardSet* ss = h->shard_set;
 	if (!ss) return;
+	exchange_destroy(ss->xch);
+	ss->xch = nullptr;
 	for (ShardWorker* w : ss->workers) {
 		{
 			std::lock_guard<std::mutex> lk(w->mtx);
@@ -226,6 +451,38 @@ int sharded_search_knn_impl(rxgpu_index* h, const float* queries, uint32_t nq, u
 		}
 	}
 	std::shared_lock<std::shared_mutex> lk(ss->call_mtx);
+	if (ss->xch && !row_ids && kk <= uint32_t(kMaxFusedK)) {
+		bool fits = true;   // a shard with fewer rows than kk returns a shorter list: the host path pads it
+		for (rxgpu_index* sh : ss->shards) {
+			const uint64_t c = rxgpu_index_count(sh);
+			fits = fits && (c == 0 || c >= kk);
+		}
+		if (fits) {
+			ShardExchange* x = ss->xch;
+			CurrentDevice cd;
+			ExchangeLane* lane = nullptr;
+			{
+				std::lock_guard<std::mutex> pl(x->mtx);
+				if (!x->free_lanes.empty()) {
+					lane = x->free_lanes.back();
+					x->free_lanes.pop_back();
+				}
+			}
+			if (!lane) {
+				if (int rc = new_lane(x, &lane); rc) return rc;
+			}
+			const int rc = exchange_search_knn(h, ss, lane, queries, nq, kk, out_dist, out_row, out_count);
+			if (rc != RXGPU_OK) {   // streams may hold half an exchange: drain before the lane is reused
+				for (uint32_t r = 0; r < x->nranks; ++r) {
+					(void)hipSetDevice(x->rank_dev[r]);
+					(void)hipStreamSynchronize(lane->stream[r]);
+				}
+			}
+			std::lock_guard<std::mutex> pl(x->mtx);
+			x->free_lanes.push_back(lane);
+			return rc;
+		}
+	}
 	const int rc = for_each_shard(ss, [&](size_t s) -> int {
 		sd[s].assign(size_t(nq) * kk, 0.f);
 		sr[s].assign(size_t(nq) * kk, 0u);
@@ -413,7 +670,47 @@ int rxgpu_index_create_sharded(int metric, uint32_t dim, uint64_t capacity, uint
 		}
 		ss->workers.push_back(w);
 	}
+	const char* mode = getenv("RXGPU_SHARD_MERGE");
+	if (!(mode && std::strcmp(mode, "host") == 0)) {
+		if (const int rc = rxgpu::exchange_create(ss, n_devices, devices, &ss->xch); rc != RXGPU_OK) {
+			rxgpu::sharded_destroy(h);
+			delete h;
+			return rc;
+		}
+	}
 	*out = h;
+	return RXGPU_OK;
+}
+
+int rxgpu_index_shard_merge_mode(const rxgpu_index* h) { return h && h->shard_set ? (h->shard_set->xch ? 1 : 0) : -1; }
+uint32_t rxgpu_index_shard_ranks(const rxgpu_index* h) { return h && h->shard_set && h->shard_set->xch ? h->shard_set->xch->nranks : 0; }
+uint64_t rxgpu_index_shard_collectives(const rxgpu_index* h) {
+	return h && h->shard_set && h->shard_set->xch ? h->shard_set->xch->collectives.load(std::memory_order_relaxed) : 0;
+}
+rxgpu_index* rxgpu_index_shard(rxgpu_index* h, uint32_t s) {
+	return h && h->shard_set && s < h->shard_set->shards.size() ? h->shard_set->shards[s] : nullptr;
+}
+/* After the caller filled shards directly (rxgpu_index_adopt_device_rows on rxgpu_index_shard handles): count = rows held, which must
+ * form a prefix of the global row space (every shard before the last non-empty one full). */
+int rxgpu_index_shard_sync_count(rxgpu_index* h) {
+	if (!h || !h->shard_set) {
+		set_error("rxgpu_index_shard_sync_count: not a sharded index");
+		return RXGPU_ERR_PARAMS;
+	}
+	rxgpu::ShardSet* ss = h->shard_set;
+	std::unique_lock<std::shared_mutex> lk(ss->call_mtx);
+	uint64_t total = 0;
+	bool ended = false;
+	for (rxgpu_index* sh : ss->shards) {
+		const uint64_t c = rxgpu_index_count(sh);
+		if (c > ss->shard_rows || (ended && c)) {
+			set_error("rxgpu_index_shard_sync_count: shards must hold a prefix of the global rows (full shards, then at most one partial)");
+			return RXGPU_ERR_PARAMS;
+		}
+		ended = ended || c < ss->shard_rows;
+		total += c;
+	}
+	h->count = total;
 	return RXGPU_OK;
 }
 

@@ -119,3 +119,92 @@ def test_sharded_c_abi_contract(rxgpu):
         assert np.array_equal(out.view(np.uint32), ix.distances(q[0], pick).view(np.uint32))
     assert L.rxgpu_search_knn_device(h, None, 1, 1, None, None, None, None) != 0
     L.rxgpu_index_destroy(h)
+
+
+@pytest.mark.parametrize("mode", ["rccl", "host"])
+def test_knn_lists_meet_in_one_rccl_all_gather_behind_the_c_abi(rxgpu, oracle, monkeypatch, mode):
+    """the per-shard top-k lists travel in ONE all-gather inside librxgpu.so (the path the C++ Map reaches), the merge runs on
+    the first device; RXGPU_SHARD_MERGE=host keeps the host merge.  Both equal the single-device index bit for bit — batch 1 and a batch,
+    k + 1 = 11 and 64, partially filled last shard, an EMPTY last shard, equal distances straddling shard boundaries."""
+    from reindexer_amd import capi
+    if mode == "host":
+        monkeypatch.setenv("RXGPU_SHARD_MERGE", "host")
+    else:
+        monkeypatch.delenv("RXGPU_SHARD_MERGE", raising=False)
+    n, d = 3000, 48
+    rows = make_corpus(21, n, d)
+    rows[1500] = rows[10]            # exact ties across shards: (dist, global row) decides
+    rows[2900] = rows[10]
+    for metric in (0, 1, 2):
+        inv = oracle.l2_modules(rows) if metric == 2 else None
+        for shards, fill in ((2, n), (3, n), (5, 2000), (4, 700)):
+            with capi.ShardedVectorIndex(metric, d, n, [0] * shards) as sx, capi.VectorIndex(metric, d, n) as one:
+                assert sx.merge_mode == mode and sx.ranks == (1 if mode == "rccl" else 0)
+                sx.upload_rows(0, rows[:fill], inv[:fill] if inv is not None else None)
+                one.upload_rows(0, rows[:fill], inv[:fill] if inv is not None else None)
+                q = make_corpus(40 + metric, 9, d)
+                q[0] = rows[10]
+                if metric == 2:
+                    q = np.stack([oracle.normalize_copy(v)[0] for v in q])
+                before = sx.collectives
+                calls = 0
+                for kk in (1, 11, 64):
+                    for qs in (q[:1], q):
+                        ad, ar, ac = one.search_knn(qs, kk)
+                        bd, br, bc = sx.search_knn(qs, kk)
+                        calls += 1
+                        assert np.array_equal(br, ar) and np.array_equal(bits(bd), bits(ad)) and np.array_equal(bc, ac), (metric, shards, fill, kk)
+                # every shard non-empty holds >= 64 rows here, so every call above went through the exchange
+                assert sx.collectives - before == (calls if mode == "rccl" else 0)
+                ad, ar, ac = one.search_knn(q, 100)     # kk > 64: host merge in either mode
+                bd, br, bc = sx.search_knn(q, 100)
+                assert np.array_equal(br, ar) and np.array_equal(bits(bd), bits(ad))
+
+
+def test_rccl_exchange_with_concurrent_callers(rxgpu):
+    """Several planner threads on one sharded index: every fan-out takes its own lane (streams + buffers), the collectives of the one
+    communicator are enqueued under a lock — results stay those of the single-device index."""
+    import threading
+    from reindexer_amd import capi
+    n, d = 4000, 64
+    rows = make_corpus(5, n, d)
+    q = make_corpus(6, 32, d)
+    with capi.ShardedVectorIndex(1, d, n, [0, 0, 0]) as sx, capi.VectorIndex(1, d, n) as one:
+        assert sx.merge_mode == "rccl"
+        sx.upload_rows(0, rows)
+        one.upload_rows(0, rows)
+        want = one.search_knn(q, 11)
+        bad = []
+
+        def worker(t):
+            for it in range(20):
+                i = (t * 7 + it) % 32
+                gd, gr, gc = sx.search_knn(q[i:i + 1], 11)
+                if not (np.array_equal(gr[0], want[1][i]) and np.array_equal(bits(gd[0]), bits(want[0][i]))):
+                    bad.append((t, it))
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not bad
+        assert sx.collectives >= 120
+
+
+def test_shards_filled_in_place_from_device_memory(rxgpu):
+    """bench.py --in-process: every shard adopts rows generated on ITS device; the sharded handle takes the counts over."""
+    import torch
+    from reindexer_amd import capi
+    n_per, d = 2048, 32
+    with capi.ShardedVectorIndex(1, d, 3 * n_per, [0, 0, 0]) as sx, capi.VectorIndex(1, d, 3 * n_per) as one:
+        parts = [torch.randn((n_per, d), device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(s)) * 0.25 for s in range(3)]
+        for s, p in enumerate(parts):
+            sx.shard(s).adopt_device_rows(p.data_ptr(), n_per, d)
+        sx.sync_count()
+        assert sx.count == 3 * n_per
+        one.upload_rows(0, torch.cat(parts).cpu().numpy())
+        q = make_corpus(9, 5, d)
+        ad, ar, ac = one.search_knn(q, 11)
+        bd, br, bc = sx.search_knn(q, 11)
+        assert np.array_equal(br, ar) and np.array_equal(bits(bd), bits(ad))
+        del parts
