@@ -134,7 +134,8 @@ int rxgpu_index_upload_row_ids(rxgpu_index* h, uint64_t first_row, uint64_t n, c
 const void* rxgpu_index_row_ids_device(const rxgpu_index* h);
 /* One host query searched with the result LEFT IN HBM (the hybrid query's KNN half): the search is enqueued on a stream of the
  * index and the call returns without waiting; *d_dist / *d_row ((dist, row) best first, *entries of them) and *d_count (device uint32)
- * are buffers of the index that hold this result until the next resident search on it; *stream is the stream it runs on — a consumer
+ * are buffers of the index that hold this result until the CALLING THREAD's next resident search on it (every thread has buffers and a
+ * stream of its own there); *stream is the stream it runs on — a consumer
  * (rxgpu_hybrid_fuse_resident) orders itself behind it on the device.  kk in [1, 128]. */
 int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, void** d_dist, void** d_row, void** d_count, void** stream,
 							  uint32_t* entries);
@@ -405,6 +406,18 @@ typedef struct rxgpu_ft_query {
 } rxgpu_ft_query;
 int rxgpu_ft_merge_query2_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* query, const uint8_t* excluded, uint32_t* out_doc,
 							  float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n, int32_t* out_preselected);
+/* nq queries (each as in rxgpu_ft_merge_query2_raw) over one index in ONE launch train: the kernels of the merge run with the query as the
+ * second grid dimension, so the per-launch floors and the ramp of every grid are paid once per train and the device works on all the
+ * queries' document ranges at a time — the form for a caller with several Merge() calls in hand (the hybrid path's query batch, T planner
+ * threads behind one combiner).  Per query i: excluded[i] (the array or any entry may be NULL), the output arrays out_*[i] of `cap` entries
+ * each, out_n[i], out_preselected[i] (may be NULL).  Results are those of nq single calls, bit for bit.  Queries with phrases or
+ * multi-word synonyms (kernels of their own in front of the train) are run one by one inside the call; at most 64 queries share a train
+ * (longer batches are cut). */
+int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nq, const rxgpu_ft_query* queries, const uint8_t* const* excluded,
+							 uint32_t* const* out_doc, float* const* out_proc, uint8_t* const* out_field, uint16_t* const* out_terms_counter, uint64_t cap,
+							 uint64_t* out_n, int32_t* out_preselected);
+/* Launch trains run by rxgpu_ft_merge_batch_raw and the merges they carried, since the index was created. */
+int rxgpu_ft_read_batch_stats(rxgpu_ft_index* h, uint64_t* trains, uint64_t* merges);
 /* ---------------------------------------------------------------------------------------------------------
  * Hybrid rank fusion on the device: MergerRankedImpl + mergeRanked (cpp_src/core/nsselecter/selectiteratorcontainer.cc:
  * 1343-1423, 1454-1559), RanksHolder::InitRRFPositions (ranks_holder.h:61-76), RerankerRRF / RerankerLinear (core/sorting/reranker.h:11-39),
@@ -418,7 +431,11 @@ typedef struct rxgpu_hybrid_params {
 	double params[5];
 } rxgpu_hybrid_params;
 /* The merge of rxgpu_ft_merge_simple_raw / _terms_raw, but the result STAYS IN HBM (ft_finish's output; no export, no wait, the call
- * returns as soon as the train is enqueued) for rxgpu_hybrid_fuse_resident to read. */
+ * returns as soon as the train is enqueued) for rxgpu_hybrid_fuse_resident to read.
+ * A resident merge opens a SESSION on the index that belongs to the calling thread and ends with that thread's rxgpu_hybrid_fuse_resident:
+ * ordinary merges of other threads run on the handle's other lanes meanwhile, another thread's resident merge (or session-less fusion)
+ * WAITS for the session to end.  A session that is not fused within 2 s is taken over; its owner's prepare / fuse then fail with
+ * RXGPU_ERR_LOGIC — a resident result is never silently replaced by an empty or a foreign one. */
 int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
 								   const uint32_t* word_ids, const float* procs, const uint8_t* excluded);
 int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,

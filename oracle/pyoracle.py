@@ -839,6 +839,10 @@ class RefFtSeam(RefFt):
     def __init__(self, num_fields: int):
         if not REF_FT_SEAM_SO.exists():
             raise FileNotFoundError(REF_FT_SEAM_SO)
+        # this checker library links the product (librxgpu_host.so -> librxgpu.so -> HIP / RCCL): the product's loader goes first, so that the
+        # process ends up with ONE HIP runtime whatever test runs first (reindexer_amd.capi.lib: torch's bundled runtime wins when torch is installed)
+        from reindexer_amd import hostapi as _product
+        _product.lib()
         L = self.L = C.CDLL(str(REF_FT_SEAM_SO))
         L.ref_seam_create.restype = _vp
         L.ref_seam_create.argtypes = [_sz]

@@ -50,6 +50,14 @@
 
 namespace rxgpu {
 
+// Every kernel of the train takes the plans of a BATCH of Q merges over one index (grid.y = query; a single merge is a batch of one).  The
+// plans lie in HBM — uploaded with the rest of the plan by the import kernel — and are read through the constant address space: uniform
+// scalar loads on demand, exactly what a by-value kernel argument compiles to, so one merge costs what it cost when the plan travelled as
+// the argument, and Q merges share the launch floors (~1.5-2 us of boundary plus the ramp of a 600-workgroup grid per kernel, five
+// kernels: a 400 k-posting merge is latency from end to end) and fill the device together.
+typedef const FtPlan __attribute__((address_space(4))) FtPlanK;
+#define FT_PLAN_OF_QUERY(plans) (*(FtPlanK*)((plans) + blockIdx.y))
+
 namespace {
 
 // phase stamps of one workgroup (100 MHz wall clock), see rxgpu_ft_read_stats
@@ -92,7 +100,7 @@ __device__ __forceinline__ void fill_words(uint32_t* ptr, uint64_t n, uint32_t v
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- restricting bitmask + pre-scores
-__device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerimpl.h:486-490, the half only the device knows
+__device__ __forceinline__ bool ft_preselect_on(FtPlanK& p) {   // mergerimpl.h:486-490, the half only the device knows
 	return p.prescore && __hip_atomic_load(&p.sync[kFtSyncPop], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > p.merge_limit;
 }
 
@@ -103,9 +111,14 @@ __device__ __forceinline__ bool ft_preselect_on(const FtPlan& p) {   // mergerim
 //   pre-score  calcTermScores (:289-324) for every term that is not a NOT, when the host half of the 2-phase gate held: the first sub-term
 //              (SortSubterms order) with a positive field boost adds min(proc16, 65535 / 4), saturating at 65535; then (:416-423) documents
 //              outside the mask / removed score 0 and the rest is histogrammed
-constexpr uint32_t kFtRangeSubs = 512;   // sub-terms whose segment, list pointer and proc are staged in LDS (more: read from HBM)
+constexpr uint32_t kFtRangeSubs = 128;   // sub-terms whose segment, list pointer and proc are staged in LDS (more: read from HBM)
+constexpr uint32_t kFtHistRep = 8;       // counters per key of the LDS score histogram (on distinct banks)
+// LDS per workgroup ~30 KB -> 5 workgroups per CU.  The kernel is a chain of dependent phases (range index, posting stage, terms behind
+// barriers, mask, scores, histogram): with Q queries in one grid its throughput is the number of workgroups a CU holds.  (512 staged
+// sub-terms and 16 counters per key cost 48.6 KB = 3 per CU; queries with more than 128 sub-terms read the rest of their plan from HBM.)
 constexpr uint32_t kFtStageBlocks = 32;  // 256-posting blocks of the range prefetched into registers (one posting per thread and block)
-__global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
+__global__ __launch_bounds__(256, 5) void ft_ranges(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	constexpr uint32_t kWords = kFtRangeDocs / 32;
 	__shared__ uint32_t s_mask[kWords], s_term[kWords];
 	__shared__ uint16_t s_score[kFtRangeDocs];
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 		uint32_t pad;
 	};
 	__shared__ __attribute__((aligned(16))) BlockInfo s_binfo[kFtStageBlocks];
-	__shared__ __attribute__((aligned(16))) uint32_t s_rep[256 * 16];   // score histogram: 16 counters per key (after the term pass)
+	__shared__ __attribute__((aligned(16))) uint32_t s_rep[256 * kFtHistRep];   // score histogram: kFtHistRep counters per key (after the term pass)
 	// During the term pass the same space holds one byte per document: the number (+1) of the last term that scored it.  "Already scored in
 	// this term" is then a plain byte compare — documents are unique inside a sub-term and sub-terms sit behind barriers, so no two threads
 	// touch one byte — where a bit set took an LDS atomic with return per posting: at 6400 postings per range and three ranges per CU the
@@ -395,9 +408,9 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 	if (!p.prescore) return;
 	// ---- scores: masked-out / removed documents score 0 (mergerimpl.h:416-423); histogram of the rest through a small LDS hash table.
 	// Few distinct scores occur (a handful of proc values and their sums), so plain counters would take 64-way same-address atomics from
-	// every wavefront: each key gets 16 counters on 16 different banks (the posting stage is free by now), lane l adds to counter l % 16
+	// every wavefront: each key gets kFtHistRep counters on different banks (the posting stage is free by now), lane l adds to counter l % kFtHistRep
 	uint32_t* hist_copy = p.hist + size_t(range % kFtHistCopies) * kFtHistStride;
-	for (uint32_t i = tid; i < 256 * 16; i += 256) s_rep[i] = 0;
+	for (uint32_t i = tid; i < 256 * kFtHistRep; i += 256) s_rep[i] = 0;
 	__syncthreads();
 	// masked scores first (eight 8-byte LDS reads, the global stores; the masked value goes back into the LDS copy), then the counting
 	// loop — deliberately NOT unrolled: with the probe loop inlined 32 times this phase was 8400 instructions and, at three wavefronts
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 		for (int k = 0; k < 4; ++k) {
 			if (!sc[k]) continue;
 			if (cur[k] == sc[k]) {   // the key is there already (after the first few documents of the range it always is)
-				atomicAdd(&s_rep[h[k] * 16 + (tid & 15)], 1u);
+				atomicAdd(&s_rep[h[k] * kFtHistRep + (tid & (kFtHistRep - 1))], 1u);
 			} else {
 				slow |= 1u << k;
 			}
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 					c = atomicCAS(&s_keys[hh], 0u, v);
 					if (c != 0u && c != v) continue;
 				}
-				atomicAdd(&s_rep[hh * 16 + (tid & 15)], 1u);
+				atomicAdd(&s_rep[hh * kFtHistRep + (tid & (kFtHistRep - 1))], 1u);
 				break;
 			}
 			if (probes == 256) {   // more than 256 distinct scores in one range (a register-side count of the common values was slower: 15 us)
@@ -467,7 +480,7 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 	uint32_t total = 0;
 	if (key) {
 #pragma unroll
-		for (int r = 0; r < 16; ++r) total += s_rep[tid * 16 + r];
+		for (uint32_t r = 0; r < kFtHistRep; ++r) total += s_rep[tid * kFtHistRep + r];
 		atomicAdd(&hist_copy[key], total);
 	}
 	// the chunk totals: the keys of one chunk are combined inside the workgroup first — every workgroup holds the same few scores, and
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256, 3) void ft_ranges(FtPlan p) {
 // (behind the fine counters of every histogram copy), every workgroup of ft_preselect_apply finds the boundary chunk from those (one 16-byte load per thread, a suffix scan)
 // and one wavefront resolves it on the chunk's 64 fine counters — 4 KB + 256 B read per workgroup instead of a kernel of its own
 // (a single workgroup summing the 256 KB histogram: 11 us).
-__device__ void ft_pick_threshold(const FtPlan& p, uint32_t* out_score, uint32_t* out_docs) {
+__device__ void ft_pick_threshold(FtPlanK& p, uint32_t* out_score, uint32_t* out_docs) {
 	__shared__ uint32_t s_wave_tot[4], s_found[2], s_res[2];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	uint32_t c[4] = {0u, 0u, 0u, 0u};   // chunks 4 t .. 4 t + 3, summed over the copies
@@ -576,7 +589,8 @@ __device__ void ft_pick_threshold(const FtPlan& p, uint32_t* out_score, uint32_t
 
 // mergerimpl.h:448-462: kFtApplyWords mask words per thread (the ordered prefix chain is as long as the grid: fewer, fatter workgroups);
 // ties at minScore are kept in document order up to minScoreDocs
-__global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
+__global__ __launch_bounds__(256) void ft_preselect_apply(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	if (!ft_preselect_on(p)) return;
 	const uint32_t ticket = grab_ticket(p.sync + kFtSyncPreTicket);
 	const uint64_t w0 = (uint64_t(ticket) * 256 + threadIdx.x) * kFtApplyWords;
@@ -634,7 +648,9 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(FtPlan p) {
 // postings survive: evaluated in place, nearly every wavefront held one and paid the chain up to four times in a row (once per
 // item slot) — 38 us for 3.9 M postings; a first attempt with fatter threads made that 64 us.
 constexpr int kFtRankTiles = 2;
-__global__ __launch_bounds__(256) void ft_rank_all(FtPlan p) {
+__global__ __launch_bounds__(256) void ft_rank_all(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	if (blockIdx.x * kFtRankTiles >= p.merge_blocks) return;   // the grid is the widest query's
 	__shared__ uint32_t s_cnt;
 	__shared__ uint16_t s_item[kFtRankTiles * kFtBlockPostings];   // tile << 10 | thread << 2 | slot
 	__shared__ uint32_t s_doc[kFtRankTiles * kFtBlockPostings];
@@ -799,7 +815,8 @@ __device__ __forceinline__ void lds_set_u16(uint32_t* words, uint32_t idx, uint3
 // slot of the first document of every (row, range) — and publishes the number of merged documents.  Also hands the next kernels / the next
 // merge their zeroed tables (entry rows, histogram, look-back words).
 constexpr uint32_t kFtAdderRowsLds = 1024;
-__global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
+__global__ __launch_bounds__(256) void ft_adders(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	__shared__ uint32_t s_tab[kFtRangeDocs / 2];   // first row of every document of the range, 16 bits each
 	__shared__ uint32_t s_rowcnt[kFtAdderRowsLds];
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
@@ -847,11 +864,23 @@ __global__ __launch_bounds__(256) void ft_adders(FtPlan p) {
 	FT_STAMP(p, 27);
 }
 
+// The merge slot of the first document of (row, range) = the entries of ft_adders' table in front of it, in row-major order.  Up to
+// kFtFinishRows merged sub-terms (and 8192 entries) the table is small and every workgroup of ft_finish adds up its own bases (one pass, all
+// rows at once); larger queries run ft_slot_bases, which turns the table into its prefix.
+constexpr uint32_t kFtFinishRows = 16;
+constexpr uint32_t kFtSparseRecords = 768;   // buckets up to this size are replayed from an LDS copy of their records
+constexpr uint32_t kFtSparsePostings = 6;   // ... if no document of theirs has more postings than this
+constexpr uint32_t kFtBitmapRows = 8;   // up to this many merged sub-terms ft_finish ranks the first postings with per-row bitmaps instead of a sort
+template <typename Plan>
+__host__ __device__ inline bool ft_own_bases(const Plan& p) { return p.n_rows <= kFtFinishRows && uint64_t(p.n_rows) * p.n_ranges <= kFtRangeDocs; }
+
 // The table of ft_adders -> its exclusive prefix in row-major order = the merge slot of the first document of every (row, range), and the
 // number of merged documents.  One workgroup, behind a kernel boundary: an in-kernel hand-over (every workgroup releasing at agent scope
 // before an arrival counter) cost 29 us — each release writes back the dirty lines of its XCD's L2.
 // Tiles of 2048 entries: eight consecutive loads per thread in flight, one workgroup scan, eight stores.
-__global__ __launch_bounds__(256) void ft_slot_bases(FtPlan p) {
+__global__ __launch_bounds__(256) void ft_slot_bases(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	if (ft_own_bases(p)) return;   // this query's ft_finish sums the small table itself
 	__shared__ uint32_t s_part[4];
 	const uint32_t tid = threadIdx.x;
 	const uint64_t total = uint64_t(p.n_rows) * p.n_ranges;
@@ -963,7 +992,7 @@ struct FtReplayStateT {
 // The loop behind every synonym's terms (mergerimpl.h:516-523), applied lazily: a document created by a synonym's term keeps its term count
 // only if it met every term of the synonym that just ended.  Called with the qp of the posting about to be applied (or past the last).
 template <typename Pos>
-__device__ __forceinline__ void ft_replay_synonym_ends(const FtPlan& p, FtReplayStateT<Pos>& st, uint32_t qp) {
+__device__ __forceinline__ void ft_replay_synonym_ends(FtPlanK& p, FtReplayStateT<Pos>& st, uint32_t qp) {
 	while (st.syn_done < p.n_syn && p.syns[st.syn_done].end_qp < qp) {
 		if (st.created && st.created_qp > p.n_part_qp) {
 			if (st.terms_counter < p.syns[st.syn_done].nterms) {
@@ -978,7 +1007,7 @@ __device__ __forceinline__ void ft_replay_synonym_ends(const FtPlan& p, FtReplay
 using FtReplayState = FtReplayStateT<FtPosList>;
 // one posting of the document, met in sub-term order: (rank r, field fld, posting index i) of sub-term row `row`
 // the positions of posting i of sub-term row `row`, and the query position of its term
-__device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, uint32_t i, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
+__device__ __forceinline__ void ft_replay_locate(FtPlanK& p, uint32_t row, uint32_t i, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
 												 const uint32_t* s_qp, uint32_t& qp, const uint64_t*& pos, uint32_t& npos) {
 	const uint64_t* fpos;
 	const uint32_t* pos_off;
@@ -999,7 +1028,7 @@ __device__ __forceinline__ void ft_replay_locate(const FtPlan& p, uint32_t row, 
 // one posting of the document, met in sub-term order: rank r in field fld, positions `pos` (not read for a simple merge)
 // (qpw = ft_row_qpw of the posting's row: the query position, whether the row is a phrase's, the last plain term in front of that phrase)
 template <typename Pos>
-__device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<Pos>& st, float r, uint8_t fld, uint32_t qpw, const Pos& pos) {
+__device__ __forceinline__ void ft_replay_apply(FtPlanK& p, FtReplayStateT<Pos>& st, float r, uint8_t fld, uint32_t qpw, const Pos& pos) {
 	const uint16_t qp = uint16_t(qpw & 0x7FFFu);
 	if (p.n_syn) ft_replay_synonym_ends(p, st, qp);
 	if (__float_as_uint(r) == kFtSuppressedRank) {   // mergerimpl.h:144-151: a merged document counts the term, nothing else
@@ -1089,7 +1118,7 @@ __device__ __forceinline__ void ft_replay_apply(const FtPlan& p, FtReplayStateT<
 		st.rank = final_rank;
 	}
 }
-__device__ __forceinline__ void ft_replay_step(const FtPlan& p, FtReplayState& st, uint32_t row, float r, uint8_t fld, uint32_t i, const uint64_t* const* s_fpos,
+__device__ __forceinline__ void ft_replay_step(FtPlanK& p, FtReplayState& st, uint32_t row, float r, uint8_t fld, uint32_t i, const uint64_t* const* s_fpos,
 											   const uint32_t* const* s_pos_off, const uint32_t* s_qp) {
 	uint32_t qp = 0;
 	FtPosList pos;
@@ -1100,7 +1129,7 @@ __device__ __forceinline__ void ft_replay_step(const FtPlan& p, FtReplayState& s
 // multi-term query, that met every part (canBeBoostedByFullMatch, mergerimpl.h:527-531) — is boosted.  Done here because the word counts
 // are resident: on the host it was one cache miss per merged document.
 template <typename Pos>
-__device__ __forceinline__ void ft_replay_finish(const FtPlan& p, FtReplayStateT<Pos>& st, uint32_t sl, uint32_t doc, bool have_words = false,
+__device__ __forceinline__ void ft_replay_finish(FtPlanK& p, FtReplayStateT<Pos>& st, uint32_t sl, uint32_t doc, bool have_words = false,
 												 float words0 = 0.f) {
 	if (p.n_syn) {
 		ft_replay_synonym_ends(p, st, 0xFFFFFFFFu);
@@ -1121,7 +1150,7 @@ __device__ __forceinline__ void ft_replay_finish(const FtPlan& p, FtReplayStateT
 	p.out_terms_counter[sl] = st.terms_counter;
 }
 // the document's row of the entry table, walked in sub-term order
-__device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint32_t doc, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
+__device__ __forceinline__ void ft_replay_doc(FtPlanK& p, uint32_t sl, uint32_t doc, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
 											  const uint32_t* s_qp) {
 	FtReplayState st;
 	// Most documents meet ONE sub-term, a few two or three, out of many: each lane first collects WHICH of its rows are occupied (rank
@@ -1146,18 +1175,10 @@ __device__ __forceinline__ void ft_replay_doc(const FtPlan& p, uint32_t sl, uint
 	ft_replay_finish(p, st, sl, doc);
 }
 
-// The merge slot of the first document of (row, range) = the entries of ft_adders' table in front of it, in row-major order.  Up to
-// kFtFinishRows merged sub-terms (and 8192 entries) the table is small and every workgroup of ft_finish adds up its own bases (one pass, all
-// rows at once); larger queries run ft_slot_bases, which turns the table into its prefix.
-constexpr uint32_t kFtFinishRows = 16;
-constexpr uint32_t kFtSparseRecords = 768;   // buckets up to this size are replayed from an LDS copy of their records
-constexpr uint32_t kFtSparsePostings = 6;   // ... if no document of theirs has more postings than this
-constexpr uint32_t kFtBitmapRows = 8;   // up to this many merged sub-terms ft_finish ranks the first postings with per-row bitmaps instead of a sort
-__host__ __device__ inline bool ft_own_bases(const FtPlan& p) { return p.n_rows <= kFtFinishRows && uint64_t(p.n_rows) * p.n_ranges <= kFtRangeDocs; }
-
 // Slots, entry rows and the per-document replay of one document range.  Dynamic LDS: the 16-bit document table (first row, then the
 // position in the sorted key list) followed by the key list of the range's first postings ((row << 13 | document), then the slot).
-__global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
+__global__ __launch_bounds__(256) void ft_finish(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	extern __shared__ uint32_t ft_finish_lds[];
 	uint32_t* s_tab = ft_finish_lds;                       // [kFtRangeDocs / 2]
 	uint32_t* s_keys = ft_finish_lds + kFtRangeDocs / 2;   // [kFtRangeDocs]
@@ -1188,13 +1209,16 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		s_pos_off[row] = s.pos_off;
 		s_qp[row] = ft_row_qpw(s);
 	}
+	// up to kFtBitmapRows merged sub-terms (and mergeLimit below 65535): the compact layout — 16-bit slots, 32 KB of LDS, 4 workgroups per CU
+	const bool few_rows = p.n_rows <= kFtBitmapRows && p.max_merged < 0xFFFFu;
+	uint32_t* s_table = few_rows ? ft_finish_lds : s_keys;   // ft_adders' table while the bases are summed (the slots are set up afterwards)
 	if (n) {
 		if (tid == 0) s_nadd = 0;
 		if (own_bases) {
 			const uint32_t total = p.n_rows * p.n_ranges;
 #pragma unroll
 			for (uint32_t k = 0; k < kFtRangeDocs / 256; ++k) {
-				if (k * 256 + tid < total) s_keys[k * 256 + tid] = tv[k];
+				if (k * 256 + tid < total) s_table[k * 256 + tid] = tv[k];
 			}
 		}
 		__syncthreads();
@@ -1203,7 +1227,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 			for (uint32_t r = tid >> 6; r < p.n_rows; r += 4) {
 				uint32_t rs = 0, ps = 0;
 				for (uint32_t c = lane; c < p.n_ranges; c += 64) {
-					const uint32_t x = s_keys[r * p.n_ranges + c];
+					const uint32_t x = s_table[r * p.n_ranges + c];
 					rs += x;
 					ps += c < range ? x : 0u;
 				}
@@ -1234,27 +1258,28 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		const uint32_t nw = __syncthreads_or(reaches ? 1 : 0) ? n : 0u;
 		uint4* rec = p.b_rec + bucket_off;
 		const uint32_t d_begin = range << kFtRangeShift;
-		const bool few_rows = p.n_rows <= kFtBitmapRows;
 		if (few_rows) {
-			// ---- up to kFtBitmapRows merged sub-terms: no sort.  s_slot[doc] = first row, then the slot; one bitmap of the range's documents
-			// per row marks the first postings, a prefix over the bitmap words gives every one its rank inside (row, range)
-			uint32_t* s_slot = ft_finish_lds;                                  // [kFtRangeDocs]
-			uint32_t* s_bits = ft_finish_lds + kFtRangeDocs;                   // [kFtBitmapRows][256]
+			// ---- up to kFtBitmapRows merged sub-terms: no sort.  s_slot[doc] = first row, then the slot (16 bits: max_merged < 65535, a slot at
+			// or beyond it means "never merged" and is stored as 0xFFFF); one bitmap of the range's documents per row marks the first
+			// postings, a prefix over the bitmap words gives every one its rank inside (row, range)
+			uint32_t* s_slot = ft_finish_lds;                                  // [kFtRangeDocs] halves
+			uint32_t* s_bits = ft_finish_lds + kFtRangeDocs / 2;               // [kFtBitmapRows][256]
 			uint32_t* s_pref = s_bits + kFtBitmapRows * (kFtRangeDocs / 32);   // [kFtBitmapRows][256]
-			for (uint32_t w = tid; w < kFtRangeDocs; w += 256) s_slot[w] = 0xFFFFFFFFu;
+			// (the table of ft_adders lay here: dead since the barrier behind the row bases)
+			for (uint32_t w = tid; w < kFtRangeDocs / 2; w += 256) s_slot[w] = 0xFFFFFFFFu;
 			for (uint32_t w = tid; w < kFtBitmapRows * (kFtRangeDocs / 32); w += 256) s_bits[w] = 0;
 			__syncthreads();
 			FT_STAMP(p, 33);
 			for (uint32_t e = tid; e < nw; e += 256) {
 				const uint4 r = rec[e];
-				if (r.z != kFtSuppressedRank) atomicMin(&s_slot[r.x & (kFtRangeDocs - 1)], r.w & 0xFFFFu);
+				if (r.z != kFtSuppressedRank) lds_min_u16(s_slot, r.x & (kFtRangeDocs - 1), r.w & 0xFFFFu);
 			}
 			__syncthreads();
 			FT_STAMP(p, 34);
 			for (uint32_t e = tid; e < nw; e += 256) {   // the range's first postings; the record remembers that it adds its document
 				const uint4 r = rec[e];
 				const uint32_t row = r.w & 0xFFFFu, dl = r.x & (kFtRangeDocs - 1);
-				if (s_slot[dl] != row || r.z == kFtSuppressedRank) continue;
+				if (lds_get_u16(s_slot, dl) != row || r.z == kFtSuppressedRank) continue;
 				atomicOr(&s_bits[row * (kFtRangeDocs / 32) + (dl >> 5)], 1u << (dl & 31));
 				rec[e].w = r.w | 0x80000000u;
 			}
@@ -1285,7 +1310,7 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 				const uint32_t word = row * (kFtRangeDocs / 32) + (dl >> 5);
 				const uint32_t rank = s_pref[word] + __popc(s_bits[word] & ((1u << (dl & 31)) - 1u));
 				const uint32_t slot = (own_bases ? s_rowbase[row] : p.adders[uint64_t(row) * p.n_ranges + range]) + rank;
-				s_slot[dl] = slot;   // every document with an unsuppressed record has exactly one first posting (the others keep 0xFFFFFFFF: never merged)
+				lds_set_u16(s_slot, dl, slot < 0xFFFFu ? slot : 0xFFFFu);   // every document with an unsuppressed record has exactly one first posting (the others keep 0xFFFF: never merged)
 				if (slot < p.max_merged) p.out_doc[slot] = d_begin + dl;
 			}
 			__syncthreads();
@@ -1357,7 +1382,10 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		}
 		// (a document whose only records are a suppressed sub-term's has no first posting: slot 0xFFFFFFFF = never merged)
 		auto slot_of = [&](uint32_t dl) -> uint32_t {
-			if (few_rows) return ft_finish_lds[dl];
+			if (few_rows) {
+				const uint32_t v = lds_get_u16(ft_finish_lds, dl);
+				return v == 0xFFFFu ? 0xFFFFFFFFu : v;
+			}
 			const uint32_t at = lds_get_u16(s_tab, dl);
 			return at == 0xFFFFu ? 0xFFFFFFFFu : s_keys[at];
 		};
@@ -1368,8 +1396,9 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 		bool sparse = nw <= kFtSparseRecords;
 		if (sparse) {
 			// behind the slots of the bitmap layout; in the sorted layout the list of slots is no longer than the bucket, i.e. ends in front
-			uint4* s_rec = reinterpret_cast<uint4*>(ft_finish_lds + kFtRangeDocs);   // [kFtSparseRecords]; .x = document in the range | next record << 13
-			uint32_t* s_head = ft_finish_lds + kFtRangeDocs + kFtSparseRecords * 4;   // [kHeads] first record of the documents with these low bits
+			uint32_t* sparse_base = ft_finish_lds + (few_rows ? kFtRangeDocs / 2 : kFtRangeDocs);   // behind the 16-bit slots / inside the idle tail of the key list
+			uint4* s_rec = reinterpret_cast<uint4*>(sparse_base);   // [kFtSparseRecords]; .x = document in the range | next record << 13
+			uint32_t* s_head = sparse_base + kFtSparseRecords * 4;   // [kHeads] first record of the documents with these low bits
 			constexpr uint32_t kHeads = 512, kNil = 1023;
 			uint16_t* s_todo = reinterpret_cast<uint16_t*>(s_head + kHeads);   // [kFtSparseRecords] the first postings of the documents to replay
 			static_assert(kFtSparseRecords <= kNil && kFtSparseRecords * 4 + kHeads + kFtSparseRecords / 2 <= kFtRangeDocs / 2, "LDS layout of the sparse replay");
@@ -1538,7 +1567,9 @@ __global__ __launch_bounds__(256) void ft_finish(FtPlan p) {
 // The packed result (header + four arrays, ~11 B per merged document) leaves through a copy kernel writing 16-byte words straight into
 // the caller's pinned host buffer: a hipMemcpyAsync of the same 220 KB took ~40 us from enqueue to completion (copy-engine start-up),
 // a third of the merge.  Only the header and the first numDocs entries of every array are written.
-__global__ __launch_bounds__(256) void ft_export(FtPlan p) {
+__global__ __launch_bounds__(256) void ft_export(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	if (!p.host_out) return;
 	const uint32_t n = p.out_header[0] < p.max_merged ? p.out_header[0] : p.max_merged;
 	const uint4* src = reinterpret_cast<const uint4*>(p.out_header);
 	uint4* dst = reinterpret_cast<uint4*>(p.host_out);
@@ -1559,6 +1590,17 @@ __global__ __launch_bounds__(256) void ft_export(FtPlan p) {
 __global__ __launch_bounds__(256) void ft_import(const uint4* host_plan, uint4* dev_plan, uint32_t n16) {
 	for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < n16; w += gridDim.x * blockDim.x) dev_plan[w] = host_plan[w];
 }
+// the plans of a batch (and the FtPlan array itself) from their pinned staging buffers into HBM in ONE launch: blockIdx.y = piece
+__global__ __launch_bounds__(256) void ft_import_pieces(FtImportBatch b) {
+	const uint32_t j = blockIdx.y;
+	const uint4* src = reinterpret_cast<const uint4*>(b.src[j]);
+	uint4* dst = reinterpret_cast<uint4*>(b.dst[j]);
+	for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < b.n16[j]; w += gridDim.x * blockDim.x) dst[w] = src[w];
+}
+hipError_t launch_ft_import_batch(const FtImportBatch& b, hipStream_t st) {
+	if (b.n) hipLaunchKernelGGL(ft_import_pieces, dim3(4, b.n), dim3(256), 0, st, b);
+	return hipGetLastError();
+}
 hipError_t launch_ft_import(const void* host_plan, void* dev_plan, size_t bytes, hipStream_t st) {
 	const uint32_t n16 = uint32_t((bytes + 15) / 16);
 	hipLaunchKernelGGL(ft_import, dim3((n16 + 255) / 256 < 16 ? (n16 + 255) / 256 : 16), dim3(256), 0, st, reinterpret_cast<const uint4*>(host_plan),
@@ -1571,7 +1613,8 @@ hipError_t launch_ft_import(const void* host_plan, void* dev_plan, size_t bytes,
 // term of ONE of its synonyms (calcTermBitmask per term :252-274: any occurrence with a relevant field; AccumulateAnd over the synonym's
 // terms; OR over the part's synonyms).  One workgroup per range of kFtRangeDocs documents, bitmaps in LDS; runs in front of ft_ranges only
 // when the query has such parts.
-__global__ __launch_bounds__(256) void ft_syn_masks(FtPlan p) {
+__global__ __launch_bounds__(256) void ft_syn_masks(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	constexpr uint32_t kWords = kFtRangeDocs / 32;
 	__shared__ uint32_t s_or[kWords], s_and[kWords], s_tmp[kWords];
 	const uint32_t tid = threadIdx.x, range = blockIdx.x;
@@ -1618,25 +1661,40 @@ __global__ __launch_bounds__(256) void ft_syn_masks(FtPlan p) {
 	}
 }
 
-hipError_t launch_ft_merge(const FtPlan& p, hipStream_t st) {
-	constexpr size_t kFinishLds = (kFtRangeDocs / 2 + kFtRangeDocs) * sizeof(uint32_t);
+// plans: the Q plans in HBM; host_plans: the same on the host (grid sizes).  All Q merges run over ONE index (same documents, so the same
+// document ranges and mask words).  Queries with multi-word synonyms run alone (ft_syn_masks in front); phrases ran before (ft_phrase.hip).
+hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st) {
+	constexpr size_t kFinishLds = (kFtRangeDocs / 2 + kFtRangeDocs) * sizeof(uint32_t), kFinishLdsFew = kFtRangeDocs * sizeof(uint32_t);
 	static std::atomic<uint64_t> raised{0};
 	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&ft_finish), kFinishLds); e != hipSuccess) return e;
-	if (p.n_syn_jobs) hipLaunchKernelGGL(ft_syn_masks, dim3(p.n_ranges), dim3(256), 0, st, p);
-	hipLaunchKernelGGL(ft_ranges, dim3(p.n_ranges), dim3(256), 0, st, p);
-	if (!p.simple && p.prescore) {
-		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords))), dim3(256), 0, st, p);
+	if (!nq) return hipSuccess;
+	uint32_t rank_blocks = 0;
+	bool any_pre = false, any_bases = false, any_many_rows = false;
+	for (uint32_t q = 0; q < nq; ++q) {
+		const FtPlan& p = host_plans[q];
+		any_many_rows = any_many_rows || !(p.n_rows <= kFtBitmapRows && p.max_merged < 0xFFFFu);   // ft_finish's compact layout: 32 KB instead of 48
+		rank_blocks = std::max(rank_blocks, (p.merge_blocks + kFtRankTiles - 1) / kFtRankTiles);
+		any_pre = any_pre || (!p.simple && p.prescore);
+		any_bases = any_bases || !ft_own_bases(p);
 	}
-	if (p.merge_blocks) hipLaunchKernelGGL(ft_rank_all, dim3((p.merge_blocks + kFtRankTiles - 1) / kFtRankTiles), dim3(256), 0, st, p);
-	hipLaunchKernelGGL(ft_adders, dim3(p.n_ranges), dim3(256), 0, st, p);
-	if (!ft_own_bases(p)) hipLaunchKernelGGL(ft_slot_bases, dim3(1), dim3(256), 0, st, p);
-	hipLaunchKernelGGL(ft_finish, dim3(p.n_ranges), dim3(256), kFinishLds, st, p);
+	const FtPlan& p0 = host_plans[0];
+	if (p0.n_syn_jobs) hipLaunchKernelGGL(ft_syn_masks, dim3(p0.n_ranges, 1), dim3(256), 0, st, plans);   // (nq == 1: the caller's rule)
+	hipLaunchKernelGGL(ft_ranges, dim3(p0.n_ranges, nq), dim3(256), 0, st, plans);
+	if (any_pre) {
+		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p0.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)), nq), dim3(256), 0, st, plans);
+	}
+	if (rank_blocks) hipLaunchKernelGGL(ft_rank_all, dim3(rank_blocks, nq), dim3(256), 0, st, plans);
+	hipLaunchKernelGGL(ft_adders, dim3(p0.n_ranges, nq), dim3(256), 0, st, plans);
+	if (any_bases) hipLaunchKernelGGL(ft_slot_bases, dim3(1, nq), dim3(256), 0, st, plans);
+	hipLaunchKernelGGL(ft_finish, dim3(p0.n_ranges, nq), dim3(256), any_many_rows ? kFinishLds : kFinishLdsFew, st, plans);
 	return hipGetLastError();
 }
 
-// the result's way out (after the merge's timing bracket: the roofline of the merge kernels does not include the transfer)
-hipError_t launch_ft_export(const FtPlan& p, hipStream_t st) {
-	if (p.host_out) hipLaunchKernelGGL(ft_export, dim3(64), dim3(256), 0, st, p);
+// the results' way out (after the merge's timing bracket: the roofline of the merge kernels does not include the transfer)
+hipError_t launch_ft_export(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st) {
+	bool any = false;
+	for (uint32_t q = 0; q < nq; ++q) any = any || host_plans[q].host_out;
+	if (any) hipLaunchKernelGGL(ft_export, dim3(nq > 4 ? 16 : 64, nq), dim3(256), 0, st, plans);
 	return hipGetLastError();
 }
 

@@ -538,6 +538,39 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 	}
 }
 
+// The node of the nearest entry that is not expanded yet (what pop() would return next if nothing nearer is inserted before), or
+// 0xFFFFFFFF: the search prefetches that node's link block while the current hop's distances are computed.
+template <typename List, int S>
+__device__ __forceinline__ uint32_t hnsw_peek_open(const List& list) {
+	const int e = list.first_open();
+	if (e < 0) return 0xFFFFFFFFu;
+	uint32_t iv = list.id[0];
+#pragma unroll
+	for (int s = 1; s < S; ++s) iv = (e >> 6) == s ? list.id[s] : iv;
+	return uint32_t(__builtin_amdgcn_readlane(int(iv), e & 63));
+}
+
+typedef __attribute__((address_space(3))) void hnsw_lds_void;
+// "Seen before?" of the reference's visited list (vl_type tags, hnswalg.h:904-931), as test-and-set.  Bitset: one atomicOr.  Hash set
+// (HnswParams::vis_hash_log2): linear probing with compare-and-swap on node + 1; the neighbours a wavefront tests together are distinct
+// nodes, two lanes can only meet on an EMPTY slot and the CAS settles that.  The table is at most half full (the callers check), so a probe
+// sequence ends.  Its 32 KB stay in the L2 / Infinity Cache for the life of the search, where a bitset over 10M nodes (1.25 MB per
+// search, 6 GB for the searches in flight) sends every test to HBM.
+__device__ __forceinline__ bool hnsw_visit(uint32_t* visited, uint32_t hash_log2, uint32_t id) {
+	if (hash_log2 == 0) {
+		const uint32_t bit = 1u << (id & 31);
+		return !(atomicOr(&visited[id >> 5], bit) & bit);
+	}
+	const uint32_t mask = (1u << hash_log2) - 1u, key = id + 1u;
+	uint32_t h = (id * 2654435761u) >> (32u - hash_log2);
+	for (;;) {
+		const uint32_t old = atomicCAS(&visited[h], 0u, key);
+		if (old == 0u) return true;
+		if (old == key) return false;
+		h = (h + 1u) & mask;
+	}
+}
+
 // kLatency: few queries in flight -> two row sets per distance trip (fewer dependent round trips per hop, 172 VGPRs at D = 768);
 // otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
 // kSorted: 0 = the reference's two heaps, replayed by lane 0; S > 0 = HnswSortedList<S> (ef <= 64 S, no deleted nodes, heaps not in LDS at all)
@@ -557,6 +590,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 	__shared__ uint8_t nb_del[kHnswMaxNeighbors];
 	__shared__ uint32_t s_cur;
 	__shared__ int s_flag;
+	__shared__ uint32_t s_pre[64];   // sorted-list search: the link block of the candidate next in line, fetched one hop ahead by LDS-DMA
 
 	const int lane = threadIdx.x;
 	const uint32_t slot = blockIdx.x;
@@ -603,6 +637,12 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 		}
 	};
 
+	const uint32_t vis_hash = p.vis_hash_log2;
+	const unsigned long long vis_limit = vis_hash ? (1ull << (vis_hash - 1)) : ~0ull;   // entries the hash set may hold
+	if (vis_hash) {   // the search zeroes its own (small) set: 16-byte stores, in flight during the descent through the upper levels
+		uint4* v4 = reinterpret_cast<uint4*>(visited);
+		for (uint32_t w = lane; w < (1u << vis_hash) / 4; w += 64) v4[w] = make_uint4(0u, 0u, 0u, 0u);
+	}
 	// ---- upper levels: greedy descent (getLayer0EntryPoint)
 	uint32_t cur = p.entry;
 	if (lane == 0) nb_id[0] = cur;
@@ -647,8 +687,20 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 		} else {
 			list.insert(3.402823466e+38f, cur, true, ef, lane);   // a deleted entry point: candidate at FLT_MAX, lowerBound = FLT_MAX (:853-856)
 		}
-		if (lane == 0) atomicOr(&visited[cur >> 5], 1u << (cur & 31));
+		if (vis_hash) {   // the zeroing stores have landed before the first test-and-set
+			__threadfence();
+			__syncthreads();
+		}
+		if (lane == 0) (void)hnsw_visit(visited, vis_hash, cur);
+		// the link block of the candidate that is next in line, requested one hop ahead: it arrives while this hop's visited tests and row
+		// gathers are in flight, and saves the next hop its first dependent round trip whenever no nearer candidate turned up meanwhile
+		// (LDS-DMA: the block goes straight into s_pre, no register lives across the hop — the D = 768 kernel sits at its 96-VGPR budget)
+		uint32_t pre_node = 0xFFFFFFFFu;
 		for (;;) {
+			if (ndist - ndist_upper + p.maxM0 > vis_limit) {   // the hash set would pass half full: this search goes to the bitset re-run
+				if (lane == 0) p.out_count[qi] = kHnswOverflow;
+				return;
+			}
 			uint32_t node;
 			float cdist;
 			if (!list.pop(node, cdist, ef)) {   // candidate_set empty, or only dead entries left in it ...
@@ -659,19 +711,30 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			if (cdist > list.lower && (!kDel || list.held() == ef)) break;   // layer0ShouldStopBeforePop (never true for a member of a full list; kept for the form)
 			hops += 1;
 			const uint32_t* ll = p.links0 + size_t(node) * (1 + p.maxM0);
+			uint32_t first_word;
+			if (node == pre_node) {   // uniform: the block was requested a hop ago and has landed (every load issued since has been waited for)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				first_word = s_pre[lane];
+			} else {
+				first_word = lane <= int(p.maxM0) ? ll[lane] : 0u;
+			}
 			int nfresh = 0;
 			int cnt = 0;
 			for (int base = 0; base <= int(p.maxM0); base += 64) {
 				const int w = base + lane;
-				const uint32_t word = w <= int(p.maxM0) ? ll[w] : 0u;
-				if (base == 0) cnt = int(__builtin_amdgcn_readfirstlane(word));
+				const uint32_t word = base == 0 ? first_word : (w <= int(p.maxM0) ? ll[w] : 0u);
+				if (base == 0) {
+					cnt = int(__builtin_amdgcn_readfirstlane(word));   // (s_pre has been read: the next request may overwrite it)
+					pre_node = p.prefetch_links ? hnsw_peek_open<List, kSorted>(list) : 0xFFFFFFFFu;
+					if (pre_node != 0xFFFFFFFFu) {
+						const uint32_t* src = p.links0 + size_t(pre_node) * (1 + p.maxM0) + (lane <= int(p.maxM0) ? lane : int(p.maxM0));
+						__builtin_amdgcn_global_load_lds(src, (hnsw_lds_void*)s_pre, 4, 0, 0);
+					}
+				}
 				if (base > cnt) break;   // uniform
 				const int j = w - 1;
 				bool fresh = false;
-				if (j >= 0 && j < cnt) {
-					const uint32_t bit = 1u << (word & 31);
-					fresh = !(atomicOr(&visited[word >> 5], bit) & bit);
-				}
+				if (j >= 0 && j < cnt) fresh = hnsw_visit(visited, vis_hash, word);
 				const uint64_t fm = __ballot(fresh);
 				if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
 				nfresh += __popcll(fm);
@@ -763,6 +826,10 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 	int top_n = 0, cand_n = 0;
 	float lower;
 	bool overflow = false;
+	if (vis_hash) {   // the zeroing stores (kernel start, or the restart above) have landed before the first test-and-set
+		__threadfence();
+		__syncthreads();
+	}
 	{
 		const bool ep_ok = p.bare || !p.deleted[cur];
 		if (lane == 0) {
@@ -772,7 +839,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			} else {
 				hp_emplace(cand, cand_n, -3.402823466e+38f, cur);
 			}
-			atomicOr(&visited[cur >> 5], 1u << (cur & 31));
+			(void)hnsw_visit(visited, vis_hash, cur);
 		}
 		lower = ep_ok ? curdist : 3.402823466e+38f;
 		if (ep_ok) ndist += 1;   // the reference recomputes the entry distance here (same value)
@@ -780,8 +847,10 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 
 	for (;;) {
 		// layer0ShouldStopBeforePop + pop (lane 0), broadcast through LDS
+		const bool vis_full = ndist - ndist_upper + p.maxM0 > vis_limit;   // uniform: the hash set would pass half full
 		if (lane == 0) {
 			int flag = 0;
+			if (vis_full) overflow = true;
 			if (cand_n == 0 || overflow) {
 				flag = 1;
 			} else {
@@ -812,10 +881,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			if (base > cnt) break;   // uniform
 			const int j = w - 1;
 			bool fresh = false;
-			if (j >= 0 && j < cnt) {
-				const uint32_t bit = 1u << (word & 31);
-				fresh = !(atomicOr(&visited[word >> 5], bit) & bit);
-			}
+			if (j >= 0 && j < cnt) fresh = hnsw_visit(visited, vis_hash, word);
 			const uint64_t fm = __ballot(fresh);
 			if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
 			nfresh += __popcll(fm);

@@ -128,8 +128,13 @@ struct HnswParams {
 	uint32_t entry;
 	int bare;                 // num_deleted == 0 (hnswalg.h:1982)
 	uint32_t nq, k, ef;
-	uint32_t* visited;        // [slots][visited_words], zeroed by the launcher
+	uint32_t* visited;        // [slots][visited_words]: a bitset over the nodes zeroed by the launcher, or (vis_hash_log2 > 0) a hash set
 	uint64_t visited_words;
+	// > 0: the visited set of a search is an open-addressing hash set of 2^vis_hash_log2 words (= visited_words) holding node + 1, zeroed by
+	// the search itself — its size follows ef, not the number of nodes.  A search that fills half of it leaves as kHnswOverflow and is re-run
+	// on a bitset.  0: one bit per node (N / 8 bytes per search in flight, zeroed by a memset in front of the launch).
+	uint32_t vis_hash_log2;
+	uint32_t prefetch_links;     // sorted-list search: fetch the link block of the candidate next in line one hop ahead (LDS-DMA)
 	float* out_dist;          // [nq][k]
 	uint32_t* out_row;
 	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode), kHnswTie = re-run on the heaps

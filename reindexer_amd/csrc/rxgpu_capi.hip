@@ -693,7 +693,7 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 	}
 	DeviceGuard dg(h->device);
 	(void)hipDeviceSynchronize();
-	if (h->resident_ctx) h->free_ctx.push_back(h->resident_ctx);
+	for (auto& kv : h->resident_ctx) h->free_ctx.push_back(kv.second);
 	for (auto* c : h->free_ctx) {
 		c->release();
 		delete c;
@@ -934,8 +934,9 @@ int rxgpu_index_upload_row_ids(rxgpu_index* h, uint64_t first_row, uint64_t n, c
 }
 const void* rxgpu_index_row_ids_device(const rxgpu_index* h) { return h && !h->shard_set ? h->d_row_ids : nullptr; }
 
-// One query, the result LEFT IN HBM: enqueued on the index's resident stream, nothing waited for.  The buffers belong to the index and
-// hold this result until the next resident search on it; a consumer on another stream orders itself behind *stream.
+// One query, the result LEFT IN HBM: enqueued on the calling thread's resident stream, nothing waited for.  The buffers belong to the index
+// and hold this result until the SAME THREAD's next resident search on it (other threads have buffers of their own); a consumer on another
+// stream orders itself behind *stream.
 int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, void** d_dist, void** d_row, void** d_count, void** stream,
 							  uint32_t* entries) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
@@ -947,9 +948,13 @@ int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, v
 	RX_CHECK(kk >= 1 && kk <= uint32_t(rxgpu::kMaxFusedK2), RXGPU_ERR_PARAMS, "rxgpu_search_knn_resident: kk must be in [1, 128]");
 	RX_CHECK(h->count > 0, RXGPU_ERR_PARAMS, "rxgpu_search_knn_resident: index is empty");
 	DeviceGuard dg(h->device);
-	std::lock_guard<std::mutex> lk(h->resident_mtx);
-	if (!h->resident_ctx) h->resident_ctx = acquire_ctx(h);
-	rxgpu_search_ctx* c = h->resident_ctx;
+	rxgpu_search_ctx* c = nullptr;
+	{   // this thread's resident context (created on its first resident search; searches of one thread are sequential)
+		std::lock_guard<std::mutex> lk(h->resident_mtx);
+		rxgpu_search_ctx*& slot = h->resident_ctx[std::this_thread::get_id()];
+		if (!slot) slot = acquire_ctx(h);
+		c = slot;
+	}
 	if (!c) return RXGPU_ERR_DEVICE;
 	const uint32_t eff = uint32_t(std::min<uint64_t>(kk, h->count));
 	const size_t qbytes = size_t(h->dim) * sizeof(float);
@@ -1726,6 +1731,21 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
 	const uint64_t visited_budget = std::min<uint64_t>(16ull << 30, std::max<uint64_t>(2ull << 30, (uint64_t(free_b) + c->d_visited.bytes) / 8));
 	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(32768, visited_budget / (words * 4)));
+	// The visited set of the first pass (and of the tie re-runs) is a HASH SET sized by ef, zeroed by the search itself — not a bitset over
+	// the nodes zeroed by a memset: 2^k words >= 64 ef (8192 words = 32 KB at ef = 128; a search may fill half: 4096 nodes, against the
+	// 850 - 2300 it tests at 1M - 10M rows) instead of N / 8 bytes (1.25 MB per search at 10M rows: 20 GB of memset in front of a 16 384-query
+	// launch).  Searches that would outgrow it come back as kHnswOverflow and take the global-heap re-run, which keeps the bitset.
+	// Graphs so small that the bitset is the smaller of the two keep it.  RXGPU_HNSW_VISITED=bitset: the former path (A/B, tests).
+	uint32_t vis_hash_log2 = 12;
+	while ((1ull << vis_hash_log2) < 64ull * ef && vis_hash_log2 < 18) ++vis_hash_log2;
+	if (const char* e = getenv("RXGPU_HNSW_VISITED_LOG2")) vis_hash_log2 = uint32_t(std::min(20, std::max(6, atoi(e))));   // test hook: force overflows
+	{
+		const char* e = getenv("RXGPU_HNSW_VISITED");   // "bitset" / "hash": force one of the two (A/B, tests on small graphs)
+		const bool force_hash = e && std::strcmp(e, "hash") == 0;
+		if ((e && std::strcmp(e, "bitset") == 0) || (!force_hash && (1ull << vis_hash_log2) >= words)) vis_hash_log2 = 0;
+	}
+	const uint64_t vis_words = vis_hash_log2 ? (1ull << vis_hash_log2) : words;   // per search of the first pass
+	const uint64_t vis_slots = vis_hash_log2 ? std::max<uint64_t>(1, std::min<uint64_t>(32768, visited_budget / (vis_words * 4))) : max_slots;
 	// SQ8 queries: [codes, padded to 4 bytes][corr][normCoef] in the one query buffer
 	const size_t qelem = sq8 ? sizeof(uint8_t) : sizeof(float);
 	const size_t qbytes = size_t(nq) * h->dim * qelem;
@@ -1765,6 +1785,8 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	p.k = k;
 	p.ef = ef;
 	p.visited_words = words;
+	p.prefetch_links = 1;
+	if (const char* e = getenv("RXGPU_HNSW_PREFETCH")) p.prefetch_links = atoi(e) ? 1u : 0u;   // A/B hook
 	p.out_dist = static_cast<float*>(c->d_out_dist.ptr);
 	p.out_row = static_cast<uint32_t*>(c->d_out_row.ptr);
 	p.out_count = static_cast<uint32_t*>(c->d_out_count.ptr);
@@ -1795,11 +1817,13 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		redo.resize(nq);
 		for (uint32_t q = 0; q < nq; ++q) redo[q] = q;
 	} else {
-		for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(max_slots)) {
-			const uint32_t cq = uint32_t(std::min<uint64_t>(max_slots, nq - q0));
-			if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
-			RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+		for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(vis_slots)) {
+			const uint32_t cq = uint32_t(std::min<uint64_t>(vis_slots, nq - q0));
+			if (int rc = c->d_visited.ensure(size_t(cq) * vis_words * 4); rc) return rc;
+			if (!vis_hash_log2) RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
 			rxgpu::HnswParams pc = p;
+			pc.vis_hash_log2 = vis_hash_log2;
+			pc.visited_words = vis_words;
 			pc.queries = static_cast<const float*>(c->d_queries.ptr) + size_t(q0) * h->dim;
 			if (sq8) {
 				pc.qcodes = p.qcodes + size_t(q0) * h->dim;
@@ -1835,11 +1859,13 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			h->hnsw_tie_reruns += ties.size();
 			if (int rc = c->d_redo.ensure(ties.size() * sizeof(uint32_t)); rc) return rc;
 			RX_HIP(hipMemcpyAsync(c->d_redo.ptr, ties.data(), ties.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-			for (size_t r0 = 0; r0 < ties.size(); r0 += max_slots) {
-				const uint32_t cq = uint32_t(std::min<uint64_t>(max_slots, ties.size() - r0));
-				if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
-				RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+			for (size_t r0 = 0; r0 < ties.size(); r0 += vis_slots) {
+				const uint32_t cq = uint32_t(std::min<uint64_t>(vis_slots, ties.size() - r0));
+				if (int rc = c->d_visited.ensure(size_t(cq) * vis_words * 4); rc) return rc;
+				if (!vis_hash_log2) RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
 				rxgpu::HnswParams pc = p;
+				pc.vis_hash_log2 = vis_hash_log2;
+				pc.visited_words = vis_words;
 				pc.queries = static_cast<const float*>(c->d_queries.ptr);
 				pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
 				pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;

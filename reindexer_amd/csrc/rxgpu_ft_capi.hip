@@ -1,6 +1,7 @@
 // C-ABI of the BM25 merge (include/rxgpu.h, rxgpu_ft_*): device mirror of the ft_fast posting lists + the scoring launch.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -77,6 +79,15 @@ struct rxgpu_ft_index {
 	std::mutex lanes_mtx;
 	std::shared_mutex dict_mtx;
 	std::atomic<uint32_t> next_lane{0};
+	// Q merges in ONE launch train (rxgpu_ft_merge_batch_raw): a scratch set per query of the batch (lanes without a stream of their own: the
+	// whole train runs on batch_stream), the Q FtPlan structs back to back in HBM + their pinned staging, events around the train
+	std::vector<std::unique_ptr<rxgpu_ft_index>> batch_lanes;
+	std::mutex batch_mtx;
+	hipStream_t batch_stream = nullptr;
+	rxgpu_devbuf d_batch_plans;
+	void* h_batch_plans = nullptr;
+	hipEvent_t ev_ba = nullptr, ev_bb = nullptr;
+	uint64_t batch_trains = 0, batch_merges = 0;
 	const std::unordered_map<uint32_t, rxgpu_ft_word>& dict() const { return root ? root->words : words; }
 	hipStream_t stream = nullptr;
 	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
@@ -105,6 +116,14 @@ struct rxgpu_ft_index {
 		return RXGPU_OK;
 	}
 	// a merge left in HBM for the hybrid fusion (rxgpu_ft_merge_*_resident): no export, no wait; checked by finish_pending()
+	// The steps of one hybrid query (resident merge, prepare, fuse) each take `mtx` on their own, so the result is guarded by a SESSION: opened
+	// by the resident merge for the calling thread, closed by that thread's fusion.  While it is open ordinary merges keep off this lane
+	// (checkout_lane), other threads' resident merges wait on res_cv; a session nobody fuses is taken over after kResidentPatience and its
+	// owner's later calls fail with RXGPU_ERR_LOGIC (generation mismatch) instead of reading another query's result.
+	bool res_session = false;
+	std::thread::id res_owner;
+	uint64_t res_generation = 0;
+	std::condition_variable res_cv;
 	bool res_pending = false;
 	uint32_t res_cap = 0;          // max_merged of that merge (the packed layout of d_out depends on it)
 	bool prep_done = false;        // hybrid_prepare_kernel has been enqueued behind that merge (with prep_sig's reranker / min_rank)
@@ -232,7 +251,7 @@ int checkout_lane(rxgpu_ft_index* h, LaneLock& out) {
 	};
 	{
 		std::unique_lock<std::mutex> lk(h->mtx, std::try_to_lock);
-		if (lk.owns_lock()) {
+		if (lk.owns_lock() && !h->res_session) {   // (a resident merge parked on the handle: ordinary merges take the other lanes)
 			take(h, std::move(lk));
 			return RXGPU_OK;
 		}
@@ -249,7 +268,7 @@ int checkout_lane(rxgpu_ft_index* h, LaneLock& out) {
 			return RXGPU_OK;
 		}
 	}
-	if (have.size() + 1 < ft_lane_limit()) {
+	if (have.size() + 1 < std::max<uint32_t>(ft_lane_limit(), 2)) {   // (at least one lane besides the handle: a parked resident merge keeps the handle busy)
 		auto lane = std::make_unique<rxgpu_ft_index>();
 		lane->device = h->device;
 		lane->num_fields = h->num_fields;
@@ -268,8 +287,16 @@ int checkout_lane(rxgpu_ft_index* h, LaneLock& out) {
 		take(l, std::move(lk));
 		return RXGPU_OK;
 	}
-	const uint32_t turn = h->next_lane.fetch_add(1) % uint32_t(have.size() + 1);
-	rxgpu_ft_index* l = turn == 0 ? h : have[turn - 1];
+	uint32_t turn = h->next_lane.fetch_add(1) % uint32_t(have.size() + 1);
+	if (turn == 0) {
+		std::unique_lock<std::mutex> lk(h->mtx);
+		if (!h->res_session) {
+			take(h, std::move(lk));
+			return RXGPU_OK;
+		}
+		turn = 1;   // (have is not empty: the branch above makes a second lane before anyone queues)
+	}
+	rxgpu_ft_index* l = have[turn - 1];
 	take(l, std::unique_lock<std::mutex>(l->mtx));
 	return RXGPU_OK;
 }
@@ -284,6 +311,12 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 		if (p) (void)hipFree(p);
 	}
 	for (auto& l : h->lanes) release_lane(l.get());
+	for (auto& l : h->batch_lanes) release_lane(l.get());
+	h->d_batch_plans.release();
+	if (h->h_batch_plans) (void)hipHostFree(h->h_batch_plans);
+	if (h->ev_ba) (void)hipEventDestroy(h->ev_ba);
+	if (h->ev_bb) (void)hipEventDestroy(h->ev_bb);
+	if (h->batch_stream) (void)hipStreamDestroy(h->batch_stream);
 	release_lane(h);
 	delete h;
 }
@@ -656,6 +689,63 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 	return RXGPU_OK;
 }
 
+constexpr std::chrono::milliseconds kResidentPatience{2000};
+// what THIS thread believes about its resident session (one text index at a time per thread: HybridQueryResident runs its steps in a row)
+thread_local const rxgpu_ft_index* tl_res_handle = nullptr;
+thread_local uint64_t tl_res_generation = 0;
+
+// `lk` holds h->mtx.  Waits until no OTHER thread's session is open (bounded), then opens one for the caller.
+void open_resident_session(rxgpu_ft_index* h, std::unique_lock<std::mutex>& lk) {
+	const auto me = std::this_thread::get_id();
+	if (h->res_session && h->res_owner != me) {
+		(void)h->res_cv.wait_for(lk, kResidentPatience, [&] { return !h->res_session; });   // timed out: the session is taken over below
+	}
+	h->res_session = true;
+	h->res_owner = me;
+	h->res_generation += 1;
+	tl_res_handle = h;
+	tl_res_generation = h->res_generation;
+}
+// `lk` holds h->mtx.  RXGPU_OK when the caller may use the lane for the prepare / fuse step: it owns the open session, or it never opened one
+// (a query whose FT side merged nothing) and nobody else's is open (waited for, bounded).
+int check_resident_session(rxgpu_ft_index* h, std::unique_lock<std::mutex>& lk, const char* who) {
+	const auto me = std::this_thread::get_id();
+	if (tl_res_handle == h && tl_res_generation != 0) {
+		if (!(h->res_session && h->res_owner == me && h->res_generation == tl_res_generation)) {
+			tl_res_generation = 0;
+			set_error(std::string(who) + ": this thread's resident merge was replaced by another caller's (its session was not fused within 2 s)");
+			return RXGPU_ERR_LOGIC;
+		}
+		return RXGPU_OK;
+	}
+	if (h->res_session && h->res_owner != me) {
+		if (!h->res_cv.wait_for(lk, kResidentPatience, [&] { return !h->res_session; })) {
+			set_error(std::string(who) + ": another caller's resident merge is parked on this index");
+			return RXGPU_ERR_LOGIC;
+		}
+	}
+	// a fusion without a resident merge in front (the query's FT side merged nothing): a session of its own with an empty FT side, so that
+	// nobody else's prepare lands between this caller's prepare and its fuse
+	if (!h->res_session) {
+		h->res_pending = false;
+		h->res_cap = 0;
+		h->prep_done = false;
+	}
+	h->res_session = true;
+	h->res_owner = me;
+	h->res_generation += 1;
+	tl_res_handle = h;
+	tl_res_generation = h->res_generation;
+	return RXGPU_OK;
+}
+void close_resident_session(rxgpu_ft_index* h) {
+	if (h->res_session && h->res_owner == std::this_thread::get_id()) {
+		h->res_session = false;
+		h->res_cv.notify_all();
+	}
+	if (tl_res_handle == h) tl_res_generation = 0;
+}
+
 // A resident merge was enqueued and nobody looked at its header yet: wait for it, check the look-back word, settle the kept-clean state.
 int finish_pending(rxgpu_ft_index* h, const char* who) {
 	if (!h->res_pending) return RXGPU_OK;
@@ -670,12 +760,25 @@ int finish_pending(rxgpu_ft_index* h, const char* who) {
 	return RXGPU_OK;
 }
 
-// Shared implementation of rxgpu_ft_merge_simple_raw / rxgpu_ft_merge_terms_raw.  out_terms_counter may be null (simple).
-int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
-			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
-			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false, const SynonymsIn* synonyms = nullptr) {
+// One merge between the building of its plan and the unpacking of its result.
+struct MergeJob {
+	rxgpu::FtPlan p{};
+	const rxgpu::FtPlan* d_plan = nullptr;   // the plan where the kernels read it (HBM, behind the rest of the plan)
+	void* dev_base = nullptr;                // where the staged plan goes (the lane's state buffer)
+	uint64_t max_merged = 0, merged_postings = 0;
+	size_t plan_bytes = 0;
+	void* hp_dev = nullptr;                  // the lane's pinned staging buffer as the device sees it
+	uint32_t nsyn = 0;
+	bool empty = false;                      // min(mergeLimit, totalORVids) == 0: nothing is merged
+};
+
+// First half of a merge: the plan (sub-terms, per-part configuration, posting-side grid), the lane's scratch, the plan staged in the lane's
+// pinned buffer — FtPlan included, behind the tables it points into — and (import_now) the copy kernel that takes it to HBM.  Everything is
+// enqueued on `st`: the lane's own stream for a single merge, the batch stream when Q lanes' merges go into one train.
+int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
+				  const float* procs, const uint8_t* excluded, bool have_outs, uint64_t cap, const char* who, bool resident, const SynonymsIn* synonyms,
+				  MergeJob& job, bool import_now) {
 	using clk = std::chrono::steady_clock;
-	if (int rc = finish_pending(h, who); rc) return rc;
 	const auto t_begin = clk::now();
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
 	const uint32_t nf = h->num_fields;
@@ -734,11 +837,12 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	}
 	RX_CHECK(total_vids < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^32 postings in one merge");
 	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, total_vids);   // Merge(): min(mergeLimit, totalORVids)
-	if (max_merged == 0) return RXGPU_OK;
-	RX_CHECK(resident || (cap >= max_merged && out_doc && out_proc && out_field && (simple || out_terms_counter)), RXGPU_ERR_OVERFLOW,
-			 std::string(who) + ": output buffers too small");
+	if (max_merged == 0) {
+		job.empty = true;
+		return RXGPU_OK;
+	}
+	RX_CHECK(resident || (cap >= max_merged && have_outs), RXGPU_ERR_OVERFLOW, std::string(who) + ": output buffers too small");
 
-	hipStream_t st = h->stream;
 	const uint8_t* d_excluded = nullptr;
 	if (excluded) {
 		if (int rc = h->d_excl.ensure(N); rc) return rc;
@@ -908,6 +1012,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	const size_t o_plan_syns = cv.take(std::max<size_t>(1, syns.size()) * sizeof(rxgpu::FtSynonym));
 	const size_t o_plan_jobs = cv.take(std::max<size_t>(1, syn_jobs.size()) * sizeof(rxgpu::FtSynMaskJob));
 	const size_t o_plan_jsyn = cv.take(std::max<size_t>(1, job_syns.size()) * 4);
+	const size_t o_plan_self = cv.take(sizeof(rxgpu::FtPlan));   // the FtPlan itself: the kernels read it from HBM (a batch of one)
 	const size_t plan_bytes = cv.off;   // everything above is uploaded in one copy
 	const size_t o_mask = cv.take(nwords * 4);
 	const size_t o_synmask = cv.take(syn_jobs.size() * nwords * 4);
@@ -981,9 +1086,9 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	}
 	void* hp_dev = nullptr;   // the pinned staging buffer as the device sees it
 	RX_HIP(hipHostGetDevicePointer(&hp_dev, hp, 0));
-	RX_HIP(rxgpu::launch_ft_import(hp_dev, base, plan_bytes, st));   // plan_bytes is a multiple of 256
 
-	rxgpu::FtPlan p{};
+	rxgpu::FtPlan& p = job.p;
+	p = rxgpu::FtPlan{};
 	p.subs = reinterpret_cast<const rxgpu::FtPosSubterm*>(base + o_plan_subs);
 	p.terms = reinterpret_cast<const rxgpu::FtTermCfg*>(base + o_plan_terms);
 	p.merge_grid = reinterpret_cast<const rxgpu::FtGridEntry*>(base + o_plan_mgrid);
@@ -1035,7 +1140,71 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	p.out_terms_counter = reinterpret_cast<uint16_t*>(ob + align256(16) + 2 * align256(M * 4));
 	p.out_field = reinterpret_cast<uint8_t*>(ob + align256(16) + 2 * align256(M * 4) + align256(M * 2));
 
+	std::memcpy(hp + o_plan_self, &p, sizeof(p));
+	job.d_plan = reinterpret_cast<const rxgpu::FtPlan*>(base + o_plan_self);
+	job.dev_base = base;
+	job.max_merged = max_merged;
+	job.merged_postings = merged_postings;
+	job.plan_bytes = plan_bytes;
+	job.hp_dev = hp_dev;
+	job.nsyn = nsyn;
+	if (import_now) RX_HIP(rxgpu::launch_ft_import(hp_dev, base, plan_bytes, st));   // plan_bytes is a multiple of 256
 	h->trace_us[1] += since(t_stage);
+	return RXGPU_OK;
+}
+
+// Second half: the merged documents out of the lane's pinned staging buffer (ft_export wrote them there; the stream has been waited for).
+int collect_merge(rxgpu_ft_index* h, const MergeJob& job, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t* out_n,
+				  int32_t* out_preselected, const char* who) {
+	const char* hp = static_cast<const char*>(h->h_pinned);
+	const size_t M = size_t(job.max_merged);
+	const uint32_t* hdr = reinterpret_cast<const uint32_t*>(hp);
+	RX_CHECK(hdr[1] == 0, RXGPU_ERR_DEVICE, std::string(who) + ": ordered look-back timed out on the device");
+	const uint64_t n = hdr[0];
+	RX_CHECK(n <= job.max_merged, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt result header");
+	h->clean_dirty = false;   // the merge ran to its end: ft_adders / ft_finish handed the tables back zeroed
+	uint64_t kept = n;
+	if (n && job.nsyn) {   // the documents that hold only parts of a multi-word synonym go (mergerimpl.h:533-555): the rest keeps its order
+		const uint32_t* sd = reinterpret_cast<const uint32_t*>(hp + align256(16));
+		const float* sp = reinterpret_cast<const float*>(hp + align256(16) + align256(M * 4));
+		const uint16_t* st_ = reinterpret_cast<const uint16_t*>(hp + align256(16) + 2 * align256(M * 4));
+		const uint8_t* sf = reinterpret_cast<const uint8_t*>(hp + align256(16) + 2 * align256(M * 4) + align256(M * 2));
+		kept = 0;
+		for (uint64_t i = 0; i < n; ++i) {
+			if (st_[i] == 0xFFFFu) continue;
+			out_doc[kept] = sd[i];
+			out_proc[kept] = sp[i];
+			if (out_terms_counter) out_terms_counter[kept] = st_[i];
+			out_field[kept] = sf[i];
+			++kept;
+		}
+	} else if (n) {
+		std::memcpy(out_doc, hp + align256(16), n * 4);
+		std::memcpy(out_proc, hp + align256(16) + align256(M * 4), n * 4);
+		if (out_terms_counter) std::memcpy(out_terms_counter, hp + align256(16) + 2 * align256(M * 4), n * 2);
+		std::memcpy(out_field, hp + align256(16) + 2 * align256(M * 4) + align256(M * 2), n);
+	}
+	*out_n = kept;
+	if (out_preselected) *out_preselected = hdr[2] ? 1 : 0;
+	return RXGPU_OK;
+}
+
+// Shared implementation of rxgpu_ft_merge_simple_raw / rxgpu_ft_merge_terms_raw.  out_terms_counter may be null (simple).
+int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
+			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
+			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false, const SynonymsIn* synonyms = nullptr) {
+	using clk = std::chrono::steady_clock;
+	if (int rc = finish_pending(h, who); rc) return rc;
+	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
+	hipStream_t st = h->stream;
+	MergeJob job;
+	if (int rc = prepare_merge(h, st, cfg, simple, terms, word_ids, procs, excluded, out_doc && out_proc && out_field && (simple || out_terms_counter), cap, who,
+							   resident, synonyms, job, true);
+		rc)
+		return rc;
+	if (job.empty) return RXGPU_OK;
+	const rxgpu::FtPlan& p = job.p;
+	const uint64_t max_merged = job.max_merged, merged_postings = job.merged_postings;
 	const auto t_launch = clk::now();
 	if (!h->ev_a) {
 		RX_HIP(hipEventCreate(&h->ev_a));
@@ -1044,7 +1213,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	// from here on an error return leaves the kept-clean tables in an unknown state: the next merge clears them first
 	h->clean_dirty = true;
 	RX_HIP(hipEventRecord(h->ev_a, st));
-	RX_HIP(rxgpu::launch_ft_merge(p, st));
+	RX_HIP(rxgpu::launch_ft_merge(job.d_plan, &job.p, 1, st));
 	RX_HIP(hipEventRecord(h->ev_b, st));
 	if (resident) {   // the result stays where ft_finish wrote it (d_out): the fusion kernel reads it there, nothing travels
 		h->res_pending = true;
@@ -1055,7 +1224,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		h->trace_us[5] += 1;
 		return RXGPU_OK;
 	}
-	RX_HIP(rxgpu::launch_ft_export(p, st));
+	RX_HIP(rxgpu::launch_ft_export(job.d_plan, &job.p, 1, st));
 	h->trace_us[2] += since(t_launch);
 	const auto t_wait = clk::now();
 	// (the result is already on its way: ft_export, the last kernel of the train, writes it into the pinned staging buffer)
@@ -1088,34 +1257,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	(void)hipEventElapsedTime(&ms, h->ev_a, h->ev_b);
 	h->stat_postings += merged_postings;
 	h->stat_ms += ms;
-	const uint32_t* hdr = reinterpret_cast<const uint32_t*>(hp);
-	RX_CHECK(hdr[1] == 0, RXGPU_ERR_DEVICE, std::string(who) + ": ordered look-back timed out on the device");
-	const uint64_t n = hdr[0];
-	RX_CHECK(n <= max_merged, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt result header");
-	h->clean_dirty = false;   // the merge ran to its end: ft_adders / ft_finish handed the tables back zeroed
-	uint64_t kept = n;
-	if (n && nsyn) {   // the documents that hold only parts of a multi-word synonym go (mergerimpl.h:533-555): the rest keeps its order
-		const uint32_t* sd = reinterpret_cast<const uint32_t*>(hp + align256(16));
-		const float* sp = reinterpret_cast<const float*>(hp + align256(16) + align256(M * 4));
-		const uint16_t* st_ = reinterpret_cast<const uint16_t*>(hp + align256(16) + 2 * align256(M * 4));
-		const uint8_t* sf = reinterpret_cast<const uint8_t*>(hp + align256(16) + 2 * align256(M * 4) + align256(M * 2));
-		kept = 0;
-		for (uint64_t i = 0; i < n; ++i) {
-			if (st_[i] == 0xFFFFu) continue;
-			out_doc[kept] = sd[i];
-			out_proc[kept] = sp[i];
-			if (out_terms_counter) out_terms_counter[kept] = st_[i];
-			out_field[kept] = sf[i];
-			++kept;
-		}
-	} else if (n) {
-		std::memcpy(out_doc, hp + align256(16), n * 4);
-		std::memcpy(out_proc, hp + align256(16) + align256(M * 4), n * 4);
-		if (out_terms_counter) std::memcpy(out_terms_counter, hp + align256(16) + 2 * align256(M * 4), n * 2);
-		std::memcpy(out_field, hp + align256(16) + 2 * align256(M * 4) + align256(M * 2), n);
-	}
-	*out_n = kept;
-	if (out_preselected) *out_preselected = hdr[2] ? 1 : 0;
+	if (int rc = collect_merge(h, job, out_doc, out_proc, out_field, out_terms_counter, out_n, out_preselected, who); rc) return rc;
 	h->trace_us[4] += since(t_unpack);
 	h->trace_us[5] += 1;
 	return RXGPU_OK;
@@ -1503,6 +1645,142 @@ int rxgpu_ft_merge_query2_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 					 false, q->nsyn ? &syn : nullptr);
 }
 
+// Q queries over one index in ONE launch train (ft_merge.hip: grid.y = query).  The launch floors and the ramp of every kernel's grid are
+// paid once per train instead of once per merge, and the device sees Q x the work at a time: what a planner with several FT queries in
+// hand (or the hybrid path with its batch of queries) calls instead of Q single merges.
+int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nq, const rxgpu_ft_query* queries, const uint8_t* const* excluded,
+							 uint32_t* const* out_doc, float* const* out_proc, uint8_t* const* out_field, uint16_t* const* out_terms_counter, uint64_t cap,
+							 uint64_t* out_n, int32_t* out_preselected) {
+	const char* who = "rxgpu_ft_merge_batch_raw";
+	RX_CHECK(h && cfg && out_n && (nq == 0 || (queries && out_doc && out_proc && out_field && out_terms_counter)), RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	for (uint32_t i = 0; i < nq; ++i) {
+		out_n[i] = 0;
+		if (out_preselected) out_preselected[i] = 0;
+	}
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, std::string(who) + ": field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
+	// queries with phrases or multi-word synonyms have kernels of their own in front of the train (ft_phrase.hip, ft_syn_masks): one by one
+	std::vector<uint32_t> batched;
+	for (uint32_t i = 0; i < nq; ++i) {
+		const rxgpu_ft_query& q = queries[i];
+		bool plain = q.nsyn == 0 && q.nsyn_terms == 0;
+		for (uint32_t t = 0; plain && q.phrase_num && t < q.nterms; ++t) plain = q.phrase_num[t] < 0;
+		if (plain) {
+			batched.push_back(i);
+			continue;
+		}
+		if (int rc = rxgpu_ft_merge_query2_raw(h, cfg, &q, excluded ? excluded[i] : nullptr, out_doc[i], out_proc[i], out_field[i], out_terms_counter[i], cap, &out_n[i],
+											   out_preselected ? &out_preselected[i] : nullptr);
+			rc)
+			return rc;
+	}
+	if (batched.empty()) return RXGPU_OK;
+	std::lock_guard<std::mutex> batch_lk(h->batch_mtx);
+	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
+	DevGuard dg(h->device);
+	if (!h->batch_stream) RX_HIP(hipStreamCreateWithFlags(&h->batch_stream, hipStreamNonBlocking));
+	if (!h->ev_ba) {
+		RX_HIP(hipEventCreate(&h->ev_ba));
+		RX_HIP(hipEventCreate(&h->ev_bb));
+	}
+	constexpr size_t kPlansBytes = (size_t(rxgpu::kFtBatchMax) * sizeof(rxgpu::FtPlan) + 255) & ~size_t(255);
+	if (!h->h_batch_plans) RX_HIP(hipHostMalloc(&h->h_batch_plans, kPlansBytes, hipHostMallocDefault));
+	if (int rc = h->d_batch_plans.ensure(kPlansBytes); rc) return rc;
+	void* plans_dev_view = nullptr;
+	RX_HIP(hipHostGetDevicePointer(&plans_dev_view, h->h_batch_plans, 0));
+	hipStream_t st = h->batch_stream;
+	using clk = std::chrono::steady_clock;
+	for (size_t c0 = 0; c0 < batched.size(); c0 += rxgpu::kFtBatchMax) {
+		const size_t c1 = std::min(batched.size(), c0 + rxgpu::kFtBatchMax);
+		std::vector<MergeJob> jobs;
+		std::vector<rxgpu_ft_index*> job_lane;
+		std::vector<uint32_t> job_query;
+		std::vector<rxgpu::FtPlan> host_plans;
+		rxgpu::FtImportBatch pieces{};
+		uint64_t postings = 0;
+		for (size_t c = c0; c < c1; ++c) {
+			const uint32_t i = batched[c];
+			const rxgpu_ft_query& q = queries[i];
+			std::vector<QueryTermIn> terms;
+			bool empty = false, simple = false;
+			if (int rc = query_terms(who, q.nterms, q.ops, q.opts, q.phrase_num, q.distance, q.sub_off, q.word_ids, q.procs, terms, &empty, &simple); rc) return rc;
+			if (empty) continue;
+			const size_t k = jobs.size();
+			while (h->batch_lanes.size() <= k) {
+				auto lane = std::make_unique<rxgpu_ft_index>();
+				lane->device = h->device;
+				lane->num_fields = h->num_fields;
+				lane->root = h;
+				h->batch_lanes.push_back(std::move(lane));
+			}
+			rxgpu_ft_index* lane = h->batch_lanes[k].get();
+			lane->total_docs = h->total_docs;
+			lane->d_words = h->d_words;
+			lane->d_avg = h->d_avg;
+			lane->d_removed = h->d_removed;
+			MergeJob job;
+			if (int rc = prepare_merge(lane, st, cfg, simple, terms, q.word_ids, q.procs, excluded ? excluded[i] : nullptr,
+									   out_doc[i] && out_proc[i] && out_field[i] && (simple || out_terms_counter[i]), cap, who, false, nullptr, job, false);
+				rc)
+				return rc;
+			if (job.empty) continue;
+			pieces.src[k] = job.hp_dev;
+			pieces.dst[k] = job.dev_base;
+			pieces.n16[k] = uint32_t(job.plan_bytes / 16);
+			postings += job.merged_postings;
+			host_plans.push_back(job.p);
+			jobs.push_back(job);
+			job_lane.push_back(lane);
+			job_query.push_back(i);
+		}
+		const uint32_t B = uint32_t(jobs.size());
+		if (!B) continue;
+		std::memcpy(h->h_batch_plans, host_plans.data(), size_t(B) * sizeof(rxgpu::FtPlan));
+		pieces.src[B] = plans_dev_view;
+		pieces.dst[B] = h->d_batch_plans.ptr;
+		pieces.n16[B] = uint32_t((size_t(B) * sizeof(rxgpu::FtPlan) + 15) / 16);
+		pieces.n = B + 1;
+		const rxgpu::FtPlan* d_plans = static_cast<const rxgpu::FtPlan*>(h->d_batch_plans.ptr);
+		for (rxgpu_ft_index* lane : job_lane) lane->clean_dirty = true;   // until the train has run to its end
+		RX_HIP(rxgpu::launch_ft_import_batch(pieces, st));
+		RX_HIP(hipEventRecord(h->ev_ba, st));
+		RX_HIP(rxgpu::launch_ft_merge(d_plans, host_plans.data(), B, st));
+		RX_HIP(hipEventRecord(h->ev_bb, st));
+		RX_HIP(rxgpu::launch_ft_export(d_plans, host_plans.data(), B, st));
+		{
+			const auto t_poll = clk::now();
+			hipError_t qs = hipStreamQuery(st);
+			while (qs == hipErrorNotReady && std::chrono::duration<double, std::micro>(clk::now() - t_poll).count() < 3000.0) qs = hipStreamQuery(st);
+			if (qs == hipErrorNotReady) {
+				RX_HIP(hipStreamSynchronize(st));
+			} else {
+				RX_HIP(qs);
+			}
+		}
+		float ms = 0.f;
+		(void)hipEventElapsedTime(&ms, h->ev_ba, h->ev_bb);
+		h->stat_postings += postings;
+		h->stat_ms += ms;
+		h->batch_trains += 1;
+		h->batch_merges += B;
+		for (uint32_t k = 0; k < B; ++k) {
+			const uint32_t i = job_query[k];
+			if (int rc = collect_merge(job_lane[k], jobs[k], out_doc[i], out_proc[i], out_field[i], out_terms_counter[i], &out_n[i],
+									   out_preselected ? &out_preselected[i] : nullptr, who);
+				rc)
+				return rc;
+		}
+	}
+	return RXGPU_OK;
+}
+int rxgpu_ft_read_batch_stats(rxgpu_ft_index* h, uint64_t* trains, uint64_t* merges) {
+	RX_CHECK(h && trains && merges, RXGPU_ERR_PARAMS, "rxgpu_ft_read_batch_stats: null argument");
+	std::lock_guard<std::mutex> lk(h->batch_mtx);
+	*trains = h->batch_trains;
+	*merges = h->batch_merges;
+	return RXGPU_OK;
+}
+
 int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
 								  const int32_t* phrase_num, const int32_t* distance, const uint32_t* sub_off, const uint32_t* word_ids, const float* procs,
 								  const uint8_t* excluded, int32_t* out_enqueued) {
@@ -1514,7 +1792,8 @@ int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 	std::vector<QueryTermIn> terms;
 	bool empty = false, simple = false;
 	if (int rc = query_terms(who, nterms, ops, opts, phrase_num, distance, sub_off, word_ids, procs, terms, &empty, &simple); rc) return rc;
-	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::mutex> lk(h->mtx);
+	open_resident_session(h, lk);
 	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	h->res_cap = 0;
@@ -1533,7 +1812,8 @@ int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg
 	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_resident: field count mismatch");
 	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, "rxgpu_ft_merge_simple_resident: rxgpu_ft_set_docs was not called");
 	RX_CHECK(nsub > 0 && word_ids && procs && opts->field_boost && opts->need_sum_rank, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_simple_resident: null argument");
-	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::mutex> lk(h->mtx);
+	open_resident_session(h, lk);
 	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	std::vector<QueryTermIn> terms{QueryTermIn{1, opts, 0, nsub}};
@@ -1551,7 +1831,8 @@ int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 	RX_CHECK(nterms >= 2 && nterms < 0xFFFF, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: 2 or more terms (one term: rxgpu_ft_merge_simple_resident)");
 	for (uint32_t t = 0; t < nterms; ++t) RX_CHECK(ops[t] >= 1 && ops[t] <= 3, RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: op must be 1 (OR), 2 (AND) or 3 (NOT)");
 	RX_CHECK(sub_off[nterms] == 0 || (word_ids && procs), RXGPU_ERR_PARAMS, "rxgpu_ft_merge_terms_resident: null argument");
-	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::mutex> lk(h->mtx);
+	open_resident_session(h, lk);
 	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
 	DevGuard dg(h->device);
 	std::vector<QueryTermIn> terms(nterms);
@@ -1628,7 +1909,8 @@ int enqueue_prepare(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_para
 int rxgpu_hybrid_prepare_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_hybrid_params* params, int metric, const void* d_row_of_doc) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "rxgpu_hybrid_prepare_resident: null argument");
 	if (int rc = check_hybrid_params(params, "rxgpu_hybrid_prepare_resident"); rc) return rc;
-	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::mutex> lk(h->mtx);
+	if (int rc = check_resident_session(h, lk, "rxgpu_hybrid_prepare_resident"); rc) return rc;
 	DevGuard dg(h->device);
 	return enqueue_prepare(h, min_rank, params, metric, d_row_of_doc);
 }
@@ -1642,7 +1924,12 @@ int rxgpu_hybrid_fuse_resident(rxgpu_ft_index* h, int32_t min_rank, const rxgpu_
 	if (int rc = check_hybrid_params(params, "rxgpu_hybrid_fuse_resident"); rc) return rc;
 	RX_CHECK(k <= uint32_t(rxgpu::kMaxFuseKnn) && k <= knn_n, RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse_resident: k must be <= 1024 and <= the entries of the KNN list");
 	RX_CHECK(knn_n == 0 || (d_knn_dist && d_knn_row), RXGPU_ERR_PARAMS, "rxgpu_hybrid_fuse_resident: null KNN list");
-	std::lock_guard<std::mutex> lk(h->mtx);
+	std::unique_lock<std::mutex> lk(h->mtx);
+	if (int rc = check_resident_session(h, lk, "rxgpu_hybrid_fuse_resident"); rc) return rc;
+	struct SessionEnd {   // whatever happens below, this thread's session ends with its fusion
+		rxgpu_ft_index* h;
+		~SessionEnd() { close_resident_session(h); }
+	} session_end{h};
 	DevGuard dg(h->device);
 	const uint32_t M = h->res_pending ? h->res_cap : 0;   // no resident merge: an empty FT side (the merge found nothing to do)
 	const size_t out_cap = size_t(M) + k;

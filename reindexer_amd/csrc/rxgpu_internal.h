@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <thread>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -257,7 +258,16 @@ enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPreTicket = 4, kFtSyn
 constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
-hipError_t launch_ft_merge(const FtPlan& plan, hipStream_t st);
+// Q merges over one index in ONE train (grid.y = query; a single merge is a batch of one): the plans in HBM + their host copy
+hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st);
+constexpr uint32_t kFtBatchMax = 64;
+struct FtImportBatch {             // pieces of one batched upload (pinned staging -> HBM), 16-byte words
+	const void* src[kFtBatchMax + 1];
+	void* dst[kFtBatchMax + 1];
+	uint32_t n16[kFtBatchMax + 1];
+	uint32_t n;
+};
+hipError_t launch_ft_import_batch(const FtImportBatch& b, hipStream_t st);
 
 // PhraseMerger::Merge (phrasemergerimpl.h:161-329) for ONE phrase, ft_phrase.hip.  Three launches: admission over the first term's
 // postings (ordered prefix = mergeData_ order), one thread per admitted document through the terms, packing of the documents with a
@@ -299,7 +309,7 @@ constexpr uint32_t kFtPhraseRowPad = 64;   // entries: every packed row starts o
 hipError_t launch_ft_phrase_admit(const FtPhrasePlan& p, hipStream_t st);
 hipError_t launch_ft_phrase_docs(const FtPhrasePlan& p, uint32_t admitted, hipStream_t st);
 hipError_t launch_ft_phrase_pack(const FtPhrasePlan& p, hipStream_t st);
-hipError_t launch_ft_export(const FtPlan& plan, hipStream_t st);
+hipError_t launch_ft_export(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st);
 hipError_t launch_ft_import(const void* host_plan_device_view, void* dev_plan, size_t bytes, hipStream_t st);
 // ft_packed.hip: PackedIdRelVec streams -> flat posting arrays, one thread per word (counting pass, then writing pass)
 // pieces of the packed streams for the wavefront decoder (null: the one-thread-per-word kernels)
@@ -414,7 +424,9 @@ struct rxgpu_index {
 	std::map<void*, rxgpu_search_ctx*> stream_ctx;
 	int32_t* d_row_ids = nullptr;   // internal row -> row id (label >> 32) for consumers on the device (hybrid fusion); null until uploaded
 	uint64_t row_ids_cap = 0;
-	rxgpu_search_ctx* resident_ctx = nullptr;   // rxgpu_search_knn_resident: the result stays in its buffers for a consumer on the device
+	// rxgpu_search_knn_resident: the result stays in the context's buffers for a consumer on the device.  One context per CALLING THREAD:
+	// the list a thread left in HBM lives until that thread's next resident search, whatever other threads search meanwhile.
+	std::map<std::thread::id, rxgpu_search_ctx*> resident_ctx;
 	std::mutex resident_mtx;
 
 	bool profiling = false;

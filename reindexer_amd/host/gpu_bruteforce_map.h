@@ -77,6 +77,7 @@ public:
 	bool QuantizationAvailable() const noexcept { return false; }
 
 	VectorMetric Metric() const noexcept { return metric_; }
+	bool Sharded() const noexcept { return devices_.size() > 1; }   // the device mirror is row-range sharded over a device list
 	size_t Dim() const noexcept { return dim_; }
 	labeltype LabelByIdx(size_t idx) const noexcept { return labels_[idx]; }
 	// statistics for tests: how many searches needed the tie replay

@@ -522,4 +522,126 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 	return out;
 }
 
+std::vector<MergeData> GpuFtMerger::MergeQueryBatch(const FtConfig& cfg, std::vector<std::vector<QueryTerm>> queries, const std::vector<const uint8_t*>& docsExcluded,
+													RankSortType rankSortType, std::vector<uint8_t>* preselected) const {
+	CallTimer timer{timedCalls_, timedNs_};
+	const size_t nq = queries.size();
+	std::vector<MergeData> out(nq);
+	if (preselected) preselected->assign(nq, 0);
+	if (!nq || totalDocs_ == 0) return out;
+	if (cfg.fieldsCfg.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
+	if (!docsExcluded.empty() && docsExcluded.size() != nq) throw std::logic_error("GpuFtMerger::MergeQueryBatch: one docsExcluded per query (or none)");
+	std::vector<double> bm25Boost(numFields_), bm25Weight(numFields_), tlBoost(numFields_), tlWeight(numFields_), posBoost(numFields_), posWeight(numFields_);
+	for (size_t f = 0; f < numFields_; ++f) {
+		bm25Boost[f] = cfg.fieldsCfg[f].bm25Boost;
+		bm25Weight[f] = cfg.fieldsCfg[f].bm25Weight;
+		tlBoost[f] = cfg.fieldsCfg[f].termLenBoost;
+		tlWeight[f] = cfg.fieldsCfg[f].termLenWeight;
+		posBoost[f] = cfg.fieldsCfg[f].positionBoost;
+		posWeight[f] = cfg.fieldsCfg[f].positionWeight;
+	}
+	rxgpu_ft_config c{};
+	c.bm25_type = cfg.bm25Type == FtConfig::Bm25Type::Rx ? 0 : (cfg.bm25Type == FtConfig::Bm25Type::Classic ? 1 : 2);
+	c.bm25_k1 = cfg.bm25k1;
+	c.bm25_b = cfg.bm25b;
+	c.summation_ranks_by_fields_ratio = cfg.summationRanksByFieldsRatio;
+	c.full_match_boost = cfg.fullMatchBoost;
+	c.min_rank = cfg.minRank;
+	c.merge_limit = cfg.mergeLimit;
+	c.num_fields = uint32_t(numFields_);
+	c.bm25_boost = bm25Boost.data();
+	c.bm25_weight = bm25Weight.data();
+	c.term_len_boost = tlBoost.data();
+	c.term_len_weight = tlWeight.data();
+	c.position_boost = posBoost.data();
+	c.position_weight = posWeight.data();
+	c.distance_boost = cfg.distanceBoost;
+	c.distance_weight = cfg.distanceWeight;
+
+	// one query's arrays as the C-ABI wants them; the vectors own what rxgpu_ft_query points at
+	struct AbiQuery {
+		std::vector<int32_t> ops, phraseNum, distance;
+		std::vector<float> fieldBoost, procs;
+		std::vector<uint8_t> needSum;
+		std::vector<rxgpu_ft_term_opts> opts;
+		std::vector<uint32_t> subOff, wordIds;
+	};
+	std::vector<AbiQuery> abi(nq);
+	std::vector<rxgpu_ft_query> qs(nq);
+	for (size_t i = 0; i < nq; ++i) {
+		std::vector<QueryTerm>& terms = queries[i];
+		AbiQuery& a = abi[i];
+		const size_t nt = terms.size();
+		a.ops.resize(nt);
+		a.phraseNum.resize(nt);
+		a.distance.resize(nt);
+		a.fieldBoost.resize(nt * numFields_);
+		a.needSum.resize(nt * numFields_);
+		a.opts.resize(nt);
+		a.subOff.assign(nt + 1, 0);
+		for (size_t t = 0; t < nt; ++t) {
+			QueryTerm& qt = terms[t];
+			if (qt.opts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
+			a.ops[t] = int32_t(qt.op);
+			a.phraseNum[t] = qt.phraseNum;
+			a.distance[t] = qt.distance;
+			for (size_t f = 0; f < numFields_; ++f) {
+				a.fieldBoost[t * numFields_ + f] = qt.opts.fieldsOpts[f].boost;
+				a.needSum[t * numFields_ + f] = qt.opts.fieldsOpts[f].needSumRank ? 1 : 0;
+			}
+			a.opts[t] = rxgpu_ft_term_opts{qt.opts.boost, qt.opts.termLenBoost, a.fieldBoost.data() + t * numFields_, a.needSum.data() + t * numFields_};
+			// QueryMergeData::SortSubterms (querymergedata.h:196-206)
+			std::stable_sort(qt.subterms.begin(), qt.subterms.end(), [](const SubtermRef& l, const SubtermRef& r) { return l.proc > r.proc; });
+			for (const SubtermRef& sr : qt.subterms) {
+				a.wordIds.push_back(sr.wordId);
+				a.procs.push_back(sr.proc);
+			}
+			a.subOff[t + 1] = uint32_t(a.wordIds.size());
+		}
+		rxgpu_ft_query& q = qs[i];
+		q = rxgpu_ft_query{};
+		q.nterms = uint32_t(nt);
+		q.ops = a.ops.data();
+		q.opts = a.opts.data();
+		q.phrase_num = a.phraseNum.data();
+		q.distance = a.distance.data();
+		q.sub_off = a.subOff.data();
+		q.word_ids = a.wordIds.data();
+		q.procs = a.procs.data();
+	}
+	const size_t cap = cfg.mergeLimit;
+	std::vector<uint32_t> doc(nq * cap);
+	std::vector<float> proc(nq * cap);
+	std::vector<uint8_t> field(nq * cap);
+	std::vector<uint16_t> termsCounter(nq * cap);
+	std::vector<uint32_t*> pDoc(nq);
+	std::vector<float*> pProc(nq);
+	std::vector<uint8_t*> pField(nq);
+	std::vector<uint16_t*> pTc(nq);
+	for (size_t i = 0; i < nq; ++i) {
+		pDoc[i] = doc.data() + i * cap;
+		pProc[i] = proc.data() + i * cap;
+		pField[i] = field.data() + i * cap;
+		pTc[i] = termsCounter.data() + i * cap;
+	}
+	std::vector<uint64_t> n(nq, 0);
+	std::vector<int32_t> pre(nq, 0);
+	if (rxgpu_ft_merge_batch_raw(dev_, &c, uint32_t(nq), qs.data(), docsExcluded.empty() ? nullptr : docsExcluded.data(), pDoc.data(), pProc.data(), pField.data(),
+								 pTc.data(), cap, n.data(), pre.data()) != RXGPU_OK) {
+		throwDevice("MergeQueryBatch");
+	}
+	for (size_t i = 0; i < nq; ++i) {
+		if (preselected) (*preselected)[i] = pre[i] ? 1 : 0;
+		MergeData& md = out[i];
+		md.resize(n[i]);
+		for (uint64_t j = 0; j < n[i]; ++j) {
+			md[j].id = int32_t(pDoc[i][j]);
+			md[j].proc = pProc[i][j];
+			md[j].field = pField[i][j];
+		}
+		postProcess(cfg, md, rankSortType);
+	}
+	return out;
+}
+
 }  // namespace rxgpu::host

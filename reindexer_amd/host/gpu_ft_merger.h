@@ -177,6 +177,12 @@ public:
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, QuerySynonyms synonyms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
 
+	// Several queries in hand (the hybrid path's batch, a combiner in front of T planner threads): ONE launch train on the device for all of
+	// them (rxgpu_ft_merge_batch_raw: the merge kernels run with the query as the second grid dimension) — the result of query i is what
+	// MergeQuery(cfg, queries[i], ...) returns, bit for bit.  docsExcluded: per query, or empty (none); preselected: per query, may be null.
+	std::vector<MergeData> MergeQueryBatch(const FtConfig& cfg, std::vector<std::vector<QueryTerm>> queries, const std::vector<const uint8_t*>& docsExcluded,
+										   RankSortType rankSortType, std::vector<uint8_t>* preselected = nullptr) const;
+
 	// Hybrid query, FT half: the same merge, but the result STAYS IN HBM (no export, no wait).  False when the query merges nothing
 	// (Empty(), no sub-terms) — there is then no resident result and FuseResident sees an empty FT side.
 	bool MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded) const;

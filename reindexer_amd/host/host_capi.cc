@@ -825,6 +825,41 @@ extern "C" long rxhost_ft_merge_query(void* h, size_t nf, const double* cfgD, co
 										 procs, excluded, sortByRank, outId, outProc, outField, outNorm, cap, outPreselected);
 }
 
+// Q queries in ONE launch train (GpuFtMerger::MergeQueryBatch).  The queries' terms back to back: query i = terms [termOff[i], termOff[i + 1]);
+// the per-term arrays and subOff ([all terms + 1], into wordIds / procs) cover all of them.  Outputs: row i of [nQueries][cap] arrays, outN[i].
+extern "C" int rxhost_ft_merge_query_batch(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nQueries, const uint32_t* termOff,
+										   const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
+										   const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* wordIds, const float* procs,
+										   int sortByRank, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap, long* outN,
+										   int* outPreselected) {
+	int rc = -1;
+	guarded([&] {
+		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
+		const size_t nTerms = termOff[nQueries];
+		std::vector<QueryTerm> all = parseFtTerms(nf, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
+		for (size_t t = 0; t < nTerms; ++t) {
+			if (phraseNum) all[t].phraseNum = phraseNum[t];
+			if (distance) all[t].distance = distance[t];
+		}
+		std::vector<std::vector<QueryTerm>> queries(nQueries);
+		for (size_t i = 0; i < nQueries; ++i) queries[i].assign(all.begin() + termOff[i], all.begin() + termOff[i + 1]);
+		std::vector<uint8_t> pre;
+		const auto res = static_cast<const GpuFtMerger*>(h)->MergeQueryBatch(cfg, std::move(queries), {}, sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID, &pre);
+		for (size_t i = 0; i < nQueries; ++i) {
+			outN[i] = long(res[i].size());
+			if (outPreselected) outPreselected[i] = pre[i];
+			for (size_t j = 0; j < res[i].size() && j < cap; ++j) {
+				outId[i * cap + j] = res[i][j].id;
+				outProc[i * cap + j] = res[i][j].proc;
+				outField[i * cap + j] = res[i][j].field;
+				outNorm[i * cap + j] = res[i][j].normalizedProc;
+			}
+		}
+		rc = 0;
+	});
+	return rc;
+}
+
 // `threads` callers issue the same query `repeats` times each against ONE merger (what several planner threads of a server do to one text
 // index): wall time of the whole run in *wallMs, the callers' merges spread over the handle's lanes.  Returns the result count of a merge
 // (every one is checked against the first: same count, same ids), -1 on error.

@@ -34,14 +34,20 @@ inline HybridFused HybridQueryResident(const GpuBruteforceMap& map, const GpuFtM
 		NormalizeCopyVector(key, int32_t(map.Dim()), normalized.data());
 		q = normalized.data();
 	}
+	// The resident KNN list holds at most 128 entries (k + 1 <= 128) and lives on ONE device: a wider k or a sharded mirror takes the host-side
+	// pieces below straight away (same result; the fusion kernel itself takes k <= 1024)
+	const bool residentFits = k + 1 <= 128 && !map.Sharded();
+	HybridFused fused;
+	if (residentFits) {
 	// FT half first: the merge train and the FT-only part of the fusion (postProcessResults, the sort by id, the class tables) are on the
 	// merger's stream before the scan's persistent workgroups fill the chip; they run while the scan — ten times longer — streams the corpus
 	ft.MergeQueryResident(cfg, terms, docsExcluded);
 	ft.PrepareResident(cfg, hp, int(map.Metric()), dRowOfDoc);
 	const GpuBruteforceMap::ResidentKnn knn = map.SearchKnnResident(q, k);            // enqueued on the index's stream
-	HybridFused fused = ft.FuseResident(cfg, hp, int(map.Metric()), knn.dDist, knn.dRow, knn.dCount, knn.entries, uint32_t(std::min<size_t>(k, knn.entries)),
-										knn.stream, dRowOfDoc, knn.dRowIds);
+	fused = ft.FuseResident(cfg, hp, int(map.Metric()), knn.dDist, knn.dRow, knn.dCount, knn.entries, uint32_t(std::min<size_t>(k, knn.entries)),
+							knn.stream, dRowOfDoc, knn.dRowIds);
 	if (!fused.knnBoundaryTie) return fused;
+	}
 	// the k-th place is a distance tie: the Map's label-aware replay decides it; assemble this query from the host-side pieces
 	KnnSearchParams params;
 	params.k = k;
@@ -66,7 +72,7 @@ inline HybridFused HybridQueryResident(const GpuBruteforceMap& map, const GpuFtM
 	HybridFused out;
 	out.ids = res.ids;
 	out.ranks = res.ranks;
-	out.knnBoundaryTie = true;
+	out.knnBoundaryTie = residentFits;   // (set when the resident path handed the query over because of a tie at the k-th place)
 	return out;
 }
 

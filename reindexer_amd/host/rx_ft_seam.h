@@ -205,7 +205,15 @@ public:
 		std::vector<uint64_t> fpos;
 		for (size_t w = 0; w < words.size(); ++w) {
 			const reindexer::IdRelVec& v = words[w].vids;
-			const Print p{v.size(), v.empty() ? 0 : (uint64_t(v.back().Id()) << 32) ^ v.back().Pos().size()};
+			// The whole list is hashed, as for the packed streams: a re-commit erases the last step's words and rebuilds them at the same
+			// indices (dataholder.cc:116), so a DIFFERENT word — or the same word with changed earlier documents, positions or fields — can
+			// land on index w with the same length and the same last entry.
+			uint64_t hsh = kFnvBasis;
+			for (const reindexer::IdRelType& e : v) {
+				hsh = mix(hsh, uint64_t(e.Id()) | (uint64_t(e.Pos().size()) << 32));
+				for (const reindexer::PosType& pos : e.Pos()) hsh = mix(hsh, PositionPostings::Pos(pos.pos(), pos.field(), pos.arrayIdx()));
+			}
+			const Print p{v.size(), hsh};
 			if (p == prints_[w]) continue;
 			prints_[w] = p;
 			PositionPostings pp;
@@ -223,8 +231,13 @@ private:
 		uint64_t size = ~uint64_t(0), hash = 0;
 		bool operator==(const Print& o) const noexcept { return size == o.size && hash == o.hash; }
 	};
+	static constexpr uint64_t kFnvBasis = 1469598103934665603ull;
+	static uint64_t mix(uint64_t h, uint64_t x) noexcept {   // FNV-1a over 64-bit words, folded once more so that the high bits take part
+		h = (h ^ x) * 1099511628211ull;
+		return h ^ (h >> 29);
+	}
 	static uint64_t fnv1a(const uint8_t* p, size_t n) noexcept {
-		uint64_t h = 1469598103934665603ull;
+		uint64_t h = kFnvBasis;
 		for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
 		return h;
 	}

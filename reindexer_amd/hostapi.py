@@ -825,6 +825,48 @@ class GpuFtMerger:
             _raise()
         return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), bool(pre.value)
 
+    def merge_query_batch(self, cfg: dict, queries, sort_by_rank=True):
+        """GpuFtMerger::MergeQueryBatch: `queries` = a list of term lists as merge_query takes them (no synonyms), merged in ONE launch train.
+        Returns a list of (ids, proc, field, norm, preselected) — what merge_query returns per query."""
+        L = lib()
+        L.rxhost_ft_merge_query_batch.restype = _i
+        L.rxhost_ft_merge_query_batch.argtypes = [_vp, _sz, _vp, _vp, _vp, _sz] + [_vp] * 11 + [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp]
+        nf = self.nf
+        cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
+                          cfg.get("distance_weight", 0.5)], np.float64)
+        cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")]], np.int32)
+        fc = np.stack([np.asarray(cfg[k], np.float64) for k in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                               "position_boost", "position_weight")], axis=1).copy()
+        terms = [t for q in queries for t in q]
+        term_off = np.zeros(len(queries) + 1, np.uint32)
+        term_off[1:] = np.cumsum([len(q) for q in queries])
+        nt = max(len(terms), 1)
+        ops = np.array([t["op"] for t in terms] or [1], np.int32)
+        boosts = np.array([t["opts"]["boost"] for t in terms] or [1.0], np.float32)
+        tlb = np.array([t["opts"]["term_len_boost"] for t in terms] or [1.0], np.float32)
+        fb = np.array([t["opts"]["field_boost"] for t in terms] or [[1.0] * nf], np.float32).reshape(nt, nf).copy()
+        ns = np.array([t["opts"]["need_sum_rank"] for t in terms] or [[0] * nf], np.uint8).reshape(nt, nf).copy()
+        phr = np.array([t.get("phrase", -1) for t in terms] or [-1], np.int32)
+        dst = np.array([t.get("distance", 1) for t in terms] or [1], np.int32)
+        sub_off, wid, pr = [0], [], []
+        for t in terms:
+            for w, p in t["subs"]:
+                wid.append(w)
+                pr.append(p)
+            sub_off.append(len(wid))
+        sub_off, wid, pr = np.array(sub_off, np.uint32), np.array(wid + [0], np.uint32), np.array(pr + [0.0], np.float32)
+        cap, nq = int(cfg["merge_limit"]), len(queries)
+        oid, op = np.zeros((nq, cap), np.int32), np.zeros((nq, cap), np.float32)
+        of, on = np.zeros((nq, cap), np.uint8), np.zeros((nq, cap), np.uint8)
+        cnt, pre = np.zeros(nq, np.int64), np.zeros(nq, np.int32)
+        rc = L.rxhost_ft_merge_query_batch(self.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, nq, term_off.ctypes.data, ops.ctypes.data,
+                                           boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, phr.ctypes.data, dst.ctypes.data,
+                                           sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data, int(sort_by_rank), oid.ctypes.data, op.ctypes.data,
+                                           of.ctypes.data, on.ctypes.data, cap, cnt.ctypes.data, pre.ctypes.data)
+        if rc:
+            _raise()
+        return [(oid[i, :cnt[i]].copy(), op[i, :cnt[i]].copy(), of[i, :cnt[i]].copy(), on[i, :cnt[i]].copy(), bool(pre[i])) for i in range(nq)]
+
     def merge_query_concurrent(self, cfg: dict, terms, threads: int, repeats: int, excluded=None):
         """`threads` native threads issue the same query `repeats` times each against this merger (GpuFtMerger::MergeQuery is what several
         planner threads call at once; the merges spread over the handle's lanes).  Every result is checked against the first.

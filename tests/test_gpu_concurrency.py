@@ -126,3 +126,49 @@ def test_map_query_coalescing_is_transparent(rxgpu, oracle):
     b1, q1 = m.coalescing_stats()
     assert q1 - q0 == 12 * 24 and b1 - b0 < q1 - q0        # fewer device round trips than queries: batches did form
     m.close()
+
+
+def test_concurrent_hybrid_queries_and_plain_merges_on_one_text_index(rxgpu, oracle):
+    """Several planner threads run HYBRID queries (resident FT merge -> prepare -> resident KNN search -> fusion: four C-ABI calls each)
+    on one text index + one vector index while other threads run ordinary FT merges on the same text index.  A resident merge is a session
+    of its thread until that thread's fusion (ordinary merges take the handle's other lanes, another thread's resident merge waits), and every
+    thread has its own resident KNN buffers: each fused list must be the one the same query gives when it runs alone."""
+    from reindexer_amd import hostapi
+    from .test_bm25_oracle import _multi_case
+    n_docs, d = 6000, 48
+    total = n_docs + 1
+    _, words, avg, removed, excluded, terms_all, store = _multi_case(91, 1, total, 20000, (1, 1, 1, 1), False, None, sizes=(300, 2000), nsub_range=(1, 3))
+    ftm = hostapi.GpuFtMerger(1)
+    ftm.set_docs(words, avg, None)
+    for s in store:
+        ftm.set_word_fpos(s["word"], s)
+    rows = make_corpus(92, total, d)
+    vm = hostapi.GpuBruteforceMap(2, d, total)
+    vm.add(rows, np.arange(total, dtype=np.uint64) << np.uint64(32))
+    keys = make_corpus(93, 12, d)
+    cfg = hostapi.default_ft_config(1)
+    gterms = [dict(op=1, opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms_all]
+    queries = [[gterms[i % 4]] if i % 3 == 0 else [gterms[i % 4], gterms[(i + 1) % 4]] for i in range(12)]
+
+    def hybrid(i):
+        return hostapi.hybrid_query_resident(vm, ftm, cfg, queries[i], keys[i], 20, kind="rrf", params=[60.0], union=True, desc=True)
+
+    want_h = [hybrid(i) for i in range(12)]
+    want_m = [ftm.merge_query(cfg, queries[i], None, sort_by_rank=False) for i in range(12)]
+    assert all(len(w[0]) > 20 for w in want_h)
+
+    def fn(t):
+        ok = True
+        for j in range(10):
+            i = (t * 5 + j) % 12
+            if t < 4:   # hybrid callers
+                got = hybrid(i)
+                ok &= np.array_equal(got[0], want_h[i][0]) and np.array_equal(got[1].view(np.uint32), want_h[i][1].view(np.uint32))
+            else:       # plain merges on the same text index meanwhile
+                got = ftm.merge_query(cfg, queries[i], None, sort_by_rank=False)
+                ok &= all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(got[:4], want_m[i][:4]))
+        return ok
+
+    assert all(_run_threads(7, fn))
+    vm.close()
+    ftm.close()

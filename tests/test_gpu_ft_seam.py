@@ -120,6 +120,19 @@ def test_seam_simple_queries_recommit_and_calculators(rxgpu, ft, bm25_type):
     for q in (simple, two, wide):
         for packed in (True, False):
             _same(seam.merge(q, packed=packed, gpu=True), seam.merge(q, packed=packed, gpu=False), ("recommit", bm25_type, packed))
+    # third commit: word 2 is replaced by a list of the SAME length with the SAME last entry but other earlier documents — what lands on an index
+    # when the last step's words are erased and rebuilt (dataholder.cc:116).  The mirror hashes whole lists (packed and plain alike), so it travels.
+    old = store[2]
+    n = len(old["doc"])
+    docs = np.asarray(old["doc"], np.uint32).copy()
+    docs[: n - 1] = np.sort(rng.choice(np.arange(1, int(docs[-1])), n - 1, replace=False)).astype(np.uint32)
+    assert not np.array_equal(docs, old["doc"]) and docs[-1] == old["doc"][-1] and np.all(np.diff(docs.astype(np.int64)) > 0)
+    store[2] = dict(old, doc=docs)
+    seam.set_word_fpos(2, store[2])
+    assert seam.commit(0) == 7
+    for q in (simple, wide):
+        for packed in (True, False):
+            _same(seam.merge(q, packed=packed, gpu=True), seam.merge(q, packed=packed, gpu=False), ("same-length replacement", bm25_type, packed))
     seam.close()
 
 

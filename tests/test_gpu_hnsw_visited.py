@@ -1,0 +1,109 @@
+"""-m gpu: the visited set of an HNSW search as a HASH SET sized by ef (hnsw_visit in hnsw_search.hip; the reference's visited list is a
+tag array over all nodes, visited_list_pool.h:13-36 — the semantics are "seen before", hnswalg.h:904-931) instead of a bitset over the
+nodes zeroed by a memset in front of every launch.  Bar: the same answers as the bitset path, bit for bit, the same number of distance
+evaluations and hops (= the same traversal); a search that would fill the set leaves as an overflow and is re-run on the bitset; the
+sorted-list search, its in-kernel restart on the heaps, the heap kernel, graphs with deleted nodes and quantised graphs all go through it."""
+import numpy as np
+import pytest
+
+from .conftest import make_corpus
+from .test_gpu_hnsw_sorted import as_sorted_pairs, bits, build
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(ix, queries, k, ef):
+    ix.hnsw_read_stats()
+    dist, row, cnt = ix.hnsw_search_knn(queries, k, ef)
+    return dist.copy(), row.copy(), cnt.copy(), ix.hnsw_read_stats()
+
+
+def _same_batches(a, b, nq):
+    assert np.array_equal(a[2], b[2])
+    for qi in range(nq):
+        c = int(a[2][qi])
+        x, y = as_sorted_pairs(a[0][qi, :c], a[1][qi, :c]), as_sorted_pairs(b[0][qi, :c], b[1][qi, :c])
+        assert np.array_equal(x[1], y[1]) and np.array_equal(bits(x[0]), bits(y[0])), qi
+
+
+@pytest.mark.parametrize("metric,d", [(0, 128), (2, 768), (1, 96)])
+def test_hash_set_equals_bitset(rxgpu, oracle, monkeypatch, metric, d):
+    n, nq = 20_000, 600
+    m, rows, labels = build(metric, n, d, M=12, efc=60, seed=31 + d)
+    g = m.export_graph()
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    queries = make_corpus(33, nq, d)
+    if metric == 2:
+        queries = np.stack([oracle.normalize_copy(q)[0] for q in queries])
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, rows, inv)
+        ix.hnsw_attach_graph(g)
+        for sorted_mode in ("1", "0"):                      # the list in registers / the reference's heaps
+            monkeypatch.setenv("RXGPU_HNSW_SORTED", sorted_mode)
+            for k, ef in ((10, 128), (10, 16), (100, 256), (300, 300)):
+                monkeypatch.setenv("RXGPU_HNSW_VISITED", "bitset")
+                want = _batch(ix, queries, k, ef)
+                monkeypatch.setenv("RXGPU_HNSW_VISITED", "hash")
+                got = _batch(ix, queries, k, ef)
+                _same_batches(got, want, nq)
+                assert got[3] == want[3], (sorted_mode, k, ef, got[3], want[3])   # evaluations and hops: the same traversal
+    m.close()
+
+
+def test_a_search_that_fills_the_set_is_rerun_on_the_bitset(rxgpu, oracle, monkeypatch):
+    """2^7 = 128 words: a search may hold 64 nodes — every ef = 128 search overflows and comes back through the global-heap tier (bitset),
+    small-ef searches stay; the answers do not change."""
+    n, d, nq = 12_000, 64, 200
+    m, rows, labels = build(0, n, d, M=8, efc=60, seed=77)
+    g = m.export_graph()
+    queries = make_corpus(78, nq, d)
+    with rxgpu.VectorIndex(0, d, n) as ix:
+        ix.upload_rows(0, rows)
+        ix.hnsw_attach_graph(g)
+        for k, ef in ((10, 128), (3, 4)):
+            monkeypatch.setenv("RXGPU_HNSW_VISITED", "bitset")
+            monkeypatch.delenv("RXGPU_HNSW_VISITED_LOG2", raising=False)
+            want = _batch(ix, queries, k, ef)
+            monkeypatch.setenv("RXGPU_HNSW_VISITED", "hash")
+            monkeypatch.setenv("RXGPU_HNSW_VISITED_LOG2", "7")
+            got = _batch(ix, queries, k, ef)
+            _same_batches(got, want, nq)
+    m.close()
+
+
+def test_equal_keys_restart_and_deleted_nodes_with_the_hash_set(rxgpu, oracle, monkeypatch):
+    """Rows on an integer grid, every row four times (most searches meet equal keys and start over on the heaps INSIDE the kernel: the set is
+    zeroed and refilled), then a third of the nodes marked deleted (HnswSortedListDel / heaps with delete marks): vs the restated engine."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    monkeypatch.setenv("RXGPU_HNSW_VISITED", "hash")
+    n, d = 6000, 32
+    rng = np.random.default_rng(5)
+    base = rng.integers(-3, 4, size=(n // 4, d)).astype(np.float32)
+    base[np.all(base == 0, axis=1)] = 1.0
+    rows = np.ascontiguousarray(np.repeat(base, 4, axis=0)[rng.permutation(n)])
+    m, rows, labels = build(0, n, d, M=8, efc=60, rows=rows)
+    g = m.export_graph()
+    g["vectors"] = rows
+    m.tie_reruns()
+    for qi in range(16):
+        q = rng.integers(-3, 4, size=d).astype(np.float32)
+        for k, ef in ((10, 64), (100, 200)):
+            wd, wl = oracle_hnsw_search_knn(oracle, g, q, k, ef, None)
+            gd, gl = m.search_knn(q, k, ef)
+            assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd)), (qi, k, ef)
+    assert m.tie_reruns() > 0
+    m.close()
+    # deleted nodes
+    m, rows, labels = build(2, 8000, 48, M=10, efc=80, seed=91)
+    victims = rng.choice(8000, 2500, replace=False)
+    for v in victims:
+        m.mark_delete(int(labels[v]))
+    queries = make_corpus(92, 12, 48)
+    for q in queries:
+        for k, ef in ((10, 96), (20, 200)):
+            monkeypatch.setenv("RXGPU_HNSW_VISITED", "bitset")
+            wd, wl = m.search_knn(q, k, ef)
+            monkeypatch.setenv("RXGPU_HNSW_VISITED", "hash")
+            gd, gl = m.search_knn(q, k, ef)
+            assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd))
+    m.close()

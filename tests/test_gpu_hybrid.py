@@ -54,3 +54,39 @@ def test_hybrid_rrf_pipeline(rxgpu, oracle):
         assert (len(gi) > 0) if union else True
     m.close()
     vm.close()
+
+
+def test_hybrid_resident_wide_k_and_sharded_mirror_take_the_host_pieces(rxgpu, oracle):
+    """HybridQueryResident with k + 1 > 128 (the resident KNN list holds 128 entries) or over a sharded mirror: no exception — the query is
+    assembled from the host-side pieces (KnnSelectRaw + MergeQuery + MergeRanked), the list a narrow-k resident query gives for the same
+    inputs when k fits."""
+    from reindexer_amd import hostapi
+    from .test_bm25_oracle import _multi_case
+    n_docs, d = 5000, 32
+    total = n_docs + 1
+    _, words, avg, removed, excluded, terms_all, store = _multi_case(17, 1, total, 20000, (1, 1), False, None, sizes=(300, 1500), nsub_range=(1, 3))
+    ftm = hostapi.GpuFtMerger(1)
+    ftm.set_docs(words, avg, None)
+    for s in store:
+        ftm.set_word_fpos(s["word"], s)
+    rows = make_corpus(18, total, d)
+    labels = np.arange(total, dtype=np.uint64) << np.uint64(32)
+    cfg = hostapi.default_ft_config(1)
+    terms = [dict(op=1, opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms_all]
+    key = make_corpus(19, 1, d)[0]
+    one = hostapi.GpuBruteforceMap(2, d, total)
+    one.add(rows, labels)
+    many = hostapi.GpuBruteforceMap(2, d, total, devices=[0, 0])
+    many.add(rows, labels)
+    narrow = hostapi.hybrid_query_resident(one, ftm, cfg, terms, key, 50, kind="rrf", params=[60.0], union=True, desc=True)
+    sharded = hostapi.hybrid_query_resident(many, ftm, cfg, terms, key, 50, kind="rrf", params=[60.0], union=True, desc=True)
+    assert np.array_equal(narrow[0], sharded[0]) and np.array_equal(narrow[1].view(np.uint32), sharded[1].view(np.uint32))
+    for k in (127, 128, 300):
+        wide = hostapi.hybrid_query_resident(one, ftm, cfg, terms, key, k, kind="rrf", params=[60.0], union=True, desc=True)
+        # the same fusion from the separate product calls
+        fid, fproc, _, _, _ = ftm.merge_query(cfg, terms, None, sort_by_rank=True)
+        kid, krank = one.select(key, k=k, need_sort=False)
+        ids, ranks = hostapi.merge_ranked("rrf", [60.0], kid, krank, fid, fproc, union=True, desc=True, metric=2, ft_order="rank")
+        assert np.array_equal(wide[0], ids) and np.array_equal(wide[1].view(np.uint32), ranks.view(np.uint32)), k
+    for m in (one, many, ftm):
+        m.close()

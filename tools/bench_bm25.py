@@ -74,6 +74,13 @@ def run_multi(args):
         terms_o.append(dict(op=op, opts=o, subs=subs_o))
         terms_g.append(dict(op=op, opts=o, subs=subs_g))
     cfg = hostapi.default_ft_config(1)
+    if args.batch_only:   # profiling runs: nothing but trains of Q queries (a single merge is the same kernels with grid.y = 1)
+        Q = int(args.batch.split(",")[0])
+        for _ in range(max(2, args.queries // Q) + 1):
+            m.merge_query_batch(cfg, [terms_g] * Q, sort_by_rank=False)
+        npost, kernel_ms = m.read_stats()
+        print(json.dumps({"batch_only": Q, "postings": npost, "kernel_ms": kernel_ms}))
+        return
     m.merge_query(cfg, terms_g)
     m.read_stats()
     m.read_timing()
@@ -96,6 +103,25 @@ def run_multi(args):
                    "roofline": {"bound": "hbm", "achieved": bytes_per_merge / (kernel_ms / args.queries / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                 "frac": bytes_per_merge / (kernel_ms / args.queries / 1e3) / 1e9 / 8000.0,
                                 "note": "per posting 41 B (doc, entry offsets, entry, position offsets, words/slot/mask gathers) + 8 B per position"}}}
+    if args.batch:
+        # Q merges in ONE launch train (GpuFtMerger::MergeQueryBatch): the same query Q times — every one must equal the single merge
+        trains = []
+        for Q in [int(x) for x in args.batch.split(",")]:
+            m.merge_query_batch(cfg, [terms_g] * Q, sort_by_rank=False)   # warm-up: the batch lanes' scratch
+            m.read_stats()
+            reps = max(2, args.queries // Q)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                bres = m.merge_query_batch(cfg, [terms_g] * Q, sort_by_rank=False)
+            wall = time.perf_counter() - t0
+            bp, bk = m.read_stats()
+            same = all(np.array_equal(b[0], res[0]) and np.array_equal(b[1].view(np.uint32), res[1].view(np.uint32)) and np.array_equal(b[3], res[3]) for b in bres)
+            trains.append({"queries_per_train": Q, "trains": reps, "kernel_ms_per_merge": bk / (reps * Q), "kernel_ms_per_train": bk / reps,
+                           "merges_per_sec_wall": reps * Q / wall, "identical_to_single_merge": bool(same),
+                           "roofline": {"bound": "hbm", "achieved": bytes_per_merge / (bk / (reps * Q) / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                        "frac": bytes_per_merge / (bk / (reps * Q) / 1e3) / 1e9 / 8000.0,
+                                        "frac_20B_per_posting": nposting * 20 / (bk / (reps * Q) / 1e3) / 1e9 / 8000.0}})
+        out["batched_trains"] = trains
     if args.threads:
         # several planner threads against one index: the merges of concurrent callers run on the handle's lanes (own stream + scratch each)
         conc = []
@@ -152,6 +178,8 @@ def main():
     ap.add_argument("--fracs", default="0.2,0.05,0.01")
     ap.add_argument("--out", default=None)
     ap.add_argument("--threads", default=None, help="multi-term mode: comma list of concurrent caller counts (e.g. 1,2,4,8)")
+    ap.add_argument("--batch-only", action="store_true", help="with --batch Q: run nothing but trains of Q queries (for rocprofv3)")
+    ap.add_argument("--batch", default=None, help="multi-term mode: comma list of queries per launch train (MergeQueryBatch), e.g. 2,8,32")
     args = ap.parse_args()
     if args.ops:
         return run_multi(args)

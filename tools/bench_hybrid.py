@@ -115,6 +115,15 @@ def run(o) -> dict:
         parts += dt
     split_s = time.perf_counter() - t0
     split_postings, split_ft_ms = ftm.read_stats()   # the merges of the split leg ran alone on the device: their kernel time is the FT half's own
+    # the same FT merges as ONE launch train (GpuFtMerger::MergeQueryBatch: the query is the kernels' second grid dimension)
+    all_terms = [terms_of(q) for q in range(o.queries)]
+    ftm.merge_query_batch(cfg, all_terms, sort_by_rank=True)   # warm-up: the batch lanes' scratch
+    ftm.read_stats()
+    t0 = time.perf_counter()
+    batch_res = ftm.merge_query_batch(cfg, all_terms, sort_by_rank=True)
+    batch_wall = time.perf_counter() - t0
+    batch_postings, batch_ms = ftm.read_stats()
+    batch_same = sum(int(np.array_equal(b[0], r[0]) and np.array_equal(b[1], r[1])) for b, r in zip(batch_res, results))
     ftm.read_fuse_stats()
     t0 = time.perf_counter()
     fused = [run_resident(q) for q in range(o.queries)]
@@ -136,11 +145,17 @@ def run(o) -> dict:
                    "boundary_ties_redone_on_host": int(sum(int(f[2]) for f in fused)),
                    "fused_results_avg": float(np.mean([len(f[0]) for f in fused])),
                    "identical_to_split_path_frac": same_as_split / o.queries},
-           "ft_half": {"kernel": "ft_ranges / ft_rank_all / ft_adders / ft_finish (+ ft_preselect_apply) train, alone on the device (split leg)",
-                       "ms_kernels_per_merge": split_ft_ms / o.queries, "postings_per_merge": split_postings / o.queries,
+           "ft_half": {"kernel": "ft_ranges / ft_rank_all / ft_adders / ft_finish (+ ft_preselect_apply): the train of ALL the leg's queries at once "
+                                 "(MergeQueryBatch: grid.y = query), alone on the device",
+                       "queries_per_train": o.queries, "ms_kernels_per_train": batch_ms, "ms_kernels_per_merge": batch_ms / o.queries,
+                       "ms_wall_per_merge": batch_wall / o.queries * 1e3, "postings_per_merge": batch_postings / o.queries,
+                       "identical_to_single_merges_frac": batch_same / o.queries,
+                       "single_merge": {"ms_kernels_per_merge": split_ft_ms / o.queries,
+                                        "frac": split_postings * 20 / (split_ft_ms / 1e3) / 1e9 / 8000.0 if split_ft_ms else None,
+                                        "what": "the same merges one train each (the split leg)"},
                        "roofline": {"bound": "hbm", "unit": "GB/s", "peak": 8000.0,
-                                    "achieved": split_postings * 20 / (split_ft_ms / 1e3) / 1e9 if split_ft_ms else None,
-                                    "frac": split_postings * 20 / (split_ft_ms / 1e3) / 1e9 / 8000.0 if split_ft_ms else None,
+                                    "achieved": batch_postings * 20 / (batch_ms / 1e3) / 1e9 if batch_ms else None,
+                                    "frac": batch_postings * 20 / (batch_ms / 1e3) / 1e9 / 8000.0 if batch_ms else None,
                                     "bytes_per_posting": 20,
                                     "note": "SURVEY 8d's 20 B per posting; the PMC passes of the 3 x 3 merge (profiles/rd3b_bm25_rocprof.json, FETCH_SIZE with the "
                                             "gfx950 x2 correction) count 89 MB fetched + 16 MB written for 3.9 M postings = 27 B per posting = 1.34 x this model; "
