@@ -1742,7 +1742,11 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	{
 		const char* e = getenv("RXGPU_HNSW_VISITED");   // "bitset" / "hash": force one of the two (A/B, tests on small graphs)
 		const bool force_hash = e && std::strcmp(e, "hash") == 0;
-		if ((e && std::strcmp(e, "bitset") == 0) || (!force_hash && (1ull << vis_hash_log2) >= words)) vis_hash_log2 = 0;
+		// Which one by default: the hash set costs a second dependent trip on the hops where a lane's first slot is taken (measured at 1M x 768,
+		// ef = 128, same box and graph: 1.28 - 1.33 M q/s against 1.43 - 1.46 M on the bitset, profiles/rd4f_hnsw_visited_ab.txt); the bitset
+		// costs its memset (N / 8 bytes per query) and, once the bitsets of the searches in flight outgrow the Infinity Cache, an HBM round trip per
+		// test.  The hash set takes over where one search's bitset is 16 x its hash set or more (4.2 M nodes at ef = 128).
+		if ((e && std::strcmp(e, "bitset") == 0) || (!force_hash && (16ull << vis_hash_log2) > words)) vis_hash_log2 = 0;
 	}
 	const uint64_t vis_words = vis_hash_log2 ? (1ull << vis_hash_log2) : words;   // per search of the first pass
 	const uint64_t vis_slots = vis_hash_log2 ? std::max<uint64_t>(1, std::min<uint64_t>(32768, visited_budget / (vis_words * 4))) : max_slots;
