@@ -254,6 +254,10 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
  * codes [count][dim] u8, corr [count] (Quantizer::Quantize + CorrectiveOffsets, quantizer.h:93-124); count == the index row count.
  * Attach after rxgpu_hnsw_attach_graph / upload; the float rows of the index are not read by the SQ8 search. */
 int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* corr, uint64_t count, float alpha_2);
+/* Rows [first_row, first_row + n) of the code table (first_row <= rows that have codes; first_row + n <= count): the device side of a point
+ * added to or updated in a quantised graph (addPoint with a quantizer, hnswalg.h:1480-1495) — D + 4 bytes per row instead of the whole
+ * table again.  The table is sized by the index capacity. */
+int rxgpu_hnsw_upload_sq8_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, const uint8_t* codes, const float* corr, float alpha_2);
 /* SearchKnn on the SQ8 graph.  The caller quantises the queries the way prepareData does (hnswalg.h:510-529): query_codes [nq][dim],
  * query_corr [nq], query_norm_coef [nq] (1 for L2 / IP, queryNormCoef for cosine, hnswalg.h:1855-1863).  Same outputs as
  * rxgpu_hnsw_search_knn. */

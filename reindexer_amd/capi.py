@@ -77,6 +77,7 @@ _SIGNATURES = {
     "rxgpu_hnsw_patch_graph": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.c_int32, _u32, _u64]),
     "rxgpu_hnsw_search_knn": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_attach_sq8": (_i, [_vp, _vp, _vp, _u64, _f]),
+    "rxgpu_hnsw_upload_sq8_rows": (_i, [_vp, _u64, _u64, _vp, _vp, _f]),
     "rxgpu_hnsw_search_knn_sq8": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_hnsw_read_tie_reruns": (_i, [_vp, C.POINTER(_u64)]),

@@ -1649,6 +1649,47 @@ int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t n
 	return RXGPU_OK;
 }
 
+// Rows [first_row, first_row + n) of the code table: the device side of a point added to / updated in a quantised graph (addPoint with a
+// quantizer, hnswalg.h:1480-1495).  The table is allocated for the index CAPACITY (like the rows), so an upsert is a copy of its own D + 4
+// bytes, not a re-upload of the table.
+int rxgpu_hnsw_upload_sq8_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, const uint8_t* codes, const float* corr, float alpha_2) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) {
+		set_error("rxgpu_hnsw_upload_sq8_rows: not available on a sharded index");
+		return RXGPU_ERR_LOGIC;
+	}
+	if (n == 0) return RXGPU_OK;
+	RX_CHECK(codes && corr, RXGPU_ERR_PARAMS, "rxgpu_hnsw_upload_sq8_rows: null argument");
+	RX_CHECK(first_row <= h->sq8_n && first_row + n <= h->count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_upload_sq8_rows: rows follow the table without a hole and stay below count");
+	DeviceGuard dg(h->device);
+	const uint64_t cap = std::max<uint64_t>(h->capacity, h->count);
+	if (h->sq8_cap < first_row + n) {   // first rows, or the index was reserved larger since: a new table, the old rows copied over
+		RX_HIP(hipDeviceSynchronize());
+		uint8_t* nc = nullptr;
+		float* nr = nullptr;
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&nc), size_t(cap) * h->dim + 4));
+		if (hipMalloc(reinterpret_cast<void**>(&nr), size_t(cap) * sizeof(float)) != hipSuccess) {
+			(void)hipFree(nc);
+			set_error("rxgpu_hnsw_upload_sq8_rows: not enough memory for the corrective offsets");
+			return RXGPU_ERR_NOMEM;
+		}
+		if (h->sq8_n) {
+			RX_HIP(hipMemcpy(nc, h->d_codes, size_t(h->sq8_n) * h->dim, hipMemcpyDeviceToDevice));
+			RX_HIP(hipMemcpy(nr, h->d_corr, size_t(h->sq8_n) * sizeof(float), hipMemcpyDeviceToDevice));
+		}
+		if (h->d_codes) (void)hipFree(h->d_codes);
+		if (h->d_corr) (void)hipFree(h->d_corr);
+		h->d_codes = nc;
+		h->d_corr = nr;
+		h->sq8_cap = cap;
+	}
+	RX_HIP(hipMemcpy(h->d_codes + size_t(first_row) * h->dim, codes, size_t(n) * h->dim, hipMemcpyHostToDevice));
+	RX_HIP(hipMemcpy(h->d_corr + first_row, corr, size_t(n) * sizeof(float), hipMemcpyHostToDevice));
+	h->sq8_alpha2 = alpha_2;
+	h->sq8_n = std::max<uint64_t>(h->sq8_n, first_row + n);
+	return RXGPU_OK;
+}
+
 int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* corr, uint64_t count, float alpha_2) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	if (h->shard_set) {
@@ -1664,10 +1705,14 @@ int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* cor
 	h->d_codes = nullptr;
 	h->d_corr = nullptr;
 	h->sq8_n = 0;
+	h->sq8_cap = 0;
 	if (count) {
+		// sized by the index capacity: rows added later are patched in (rxgpu_hnsw_upload_sq8_rows)
 		// + 4 bytes: the word loads of the last row's last block stay inside the allocation whatever dim % 4 is
-		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_codes), size_t(count) * h->dim + 4));
-		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_corr), size_t(count) * sizeof(float)));
+		const uint64_t cap = std::max<uint64_t>(h->capacity, count);
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_codes), size_t(cap) * h->dim + 4));
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_corr), size_t(cap) * sizeof(float)));
+		h->sq8_cap = cap;
 		RX_HIP(hipMemcpy(h->d_codes, codes, size_t(count) * h->dim, hipMemcpyHostToDevice));
 		RX_HIP(hipMemcpy(h->d_corr, corr, size_t(count) * sizeof(float), hipMemcpyHostToDevice));
 	}

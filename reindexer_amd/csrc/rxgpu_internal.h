@@ -409,7 +409,7 @@ struct rxgpu_index {
 	uint8_t* d_codes = nullptr;
 	float* d_corr = nullptr;
 	float sq8_alpha2 = 0.f;
-	uint64_t sq8_n = 0;
+	uint64_t sq8_n = 0, sq8_cap = 0;   // rows with codes / rows the tables are allocated for
 	uint64_t graph_n = 0, graph_deleted = 0;
 	uint64_t graph_rows_cap = 0, graph_upper_cap = 0, graph_upper_used = 0;   // allocated level-0 rows / upper blocks (rxgpu_hnsw_patch_graph grows in place)
 	uint32_t graph_M = 0, graph_maxM0 = 0;

@@ -62,15 +62,54 @@ void GpuHnswMap::ResizeIndex(size_t newMaxElements) {
 }
 
 void GpuHnswMap::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const {
-	writer.PutVarUInt(uint32_t(0));   // serializeQuantizingParams: the cache holds links and keys, never codes — a float graph (hnsw.cc:56-62)
+	// serializeQuantizingParams (hnsw.cc:56-62) + QuantizingParams::Serialize (quantization_params.h:83-96)
+	writer.PutVarUInt(uint32_t(quantized_ ? 1 : 0));
+	if (quantized_) {
+		writer.PutVarUInt(uint64_t(kAnnCacheQuantizationParamsVersion));
+		writer.PutVarInt(int32_t(0));                                   // QuantizationType::ScalarQuantization8bit
+		writer.PutFloat(sq8Config_.quantile ? *sq8Config_.quantile : 0.f);
+		writer.PutVarUInt(uint64_t(sq8Config_.sampleSize));
+		writer.PutVarUInt(uint64_t(sq8Config_.quantizationThreshold));
+		writer.PutFloat(sq8_.minQ);
+		writer.PutFloat(sq8_.maxQ);
+		writer.PutFloat(sq8_.alpha);
+		writer.PutFloat(sq8_.alpha_2);
+		writer.PutFloat(sq8_.delta);
+	}
 	graph_.SaveIndex(writer, cancel);
 }
 
 void GpuHnswMap::LoadIndex(AnnCacheReader& reader) {
-	if (reader.GetVarUInt() != 0) {
-		throw std::runtime_error("GpuHnswMap::LoadIndex: the cache carries quantization parameters (read them with the reference's QuantizingParams and call LoadGraph)");
+	std::optional<Sq8Params> stored;
+	Sq8QuantizationConfig cfg;
+	if (reader.GetVarUInt() != 0) {   // deserializeQuantizingParams (hnsw.cc:64-72)
+		if (reader.GetVarUInt() != kAnnCacheQuantizationParamsVersion) throw std::runtime_error("Invalid quantization parameters version during deserialization");
+		if (reader.GetVarInt() != 0) throw std::runtime_error("Unsupported quantization type");
+		const float q = reader.GetFloat();   // QuantizationConfig::Deserialize (quantization_config.cc:30-41)
+		if (q >= 0.95f && q <= 1.f) {
+			cfg.quantile = q;
+		} else if (q != 0.f) {
+			throw std::runtime_error("Incorrect deserialized quantile value: must be within [0.95; 1.0]");
+		}
+		cfg.sampleSize = size_t(reader.GetVarUInt());
+		cfg.quantizationThreshold = size_t(reader.GetVarUInt());
+		Sq8Params p;
+		p.minQ = reader.GetFloat();
+		p.maxQ = reader.GetFloat();
+		p.alpha = reader.GetFloat();
+		p.alpha_2 = reader.GetFloat();
+		p.delta = reader.GetFloat();
+		stored = p;
 	}
 	LoadGraph(reader);
+	quantized_ = false;
+	pendingSq8_.reset();
+	if (stored && reader.WithQuantizer()) {   // hnsw.cc:47-53: Load<QuantizedHnswT> only then; else the float graph
+		sq8_ = *stored;
+		sq8Config_ = cfg;
+		quantized_ = true;
+		codesDirty_ = true;
+	}
 }
 
 void GpuHnswMap::Clear() {
@@ -97,6 +136,8 @@ void GpuHnswMap::syncDevice() const {
 		// in-place update also its one-hop neighbourhood) — their vectors and lists are patched in place; a bulk build re-sends everything.
 		std::vector<tableint> dirty;
 		const bool incremental = graph_.TakeDirty(dirty) && graphOnDevice_;
+		codesIncremental_ = incremental;
+		if (incremental) codesDirtyRows_ = dirty;
 		const float* norms = graph_.InvNorms();
 		bool patched = false;
 		if (incremental) {
@@ -155,7 +196,17 @@ void GpuHnswMap::syncDevice() const {
 	} else if (deletedDirty_) {
 		if (rxgpu_hnsw_update_deleted(dev_, graph_.Deleted(), graph_.DeletedCount()) != RXGPU_OK) throwDevice("delete-mark upload failed");
 	}
-	if (quantized_ && (graphDirty_ || codesDirty_)) attachCodes();
+	if (quantized_ && (graphDirty_ || codesDirty_)) {
+		// points added to (or updated in) a quantised graph are quantised with the same parameters (addPoint, hnswalg.h:1480-1495): only their
+		// codes travel when the change tracker knows what changed; a bulk change (or a fresh quantisation) sends the whole table
+		if (!codesDirty_ && codesIncremental_ && syncedCodes_ <= n) {
+			patchCodes(codesDirtyRows_, n);
+		} else {
+			attachCodes();
+		}
+	}
+	codesDirtyRows_.clear();
+	codesIncremental_ = false;
 	graphDirty_ = false;
 	deletedDirty_ = false;
 }
@@ -169,11 +220,48 @@ void GpuHnswMap::attachCodes() const {
 	for (size_t i = 0; i < n; ++i) corr[i] = Sq8Quantize(graph_.Metric(), sq8_, graph_.Vector(tableint(i)), dim, 1.f, codes.data() + i * dim);
 	if (rxgpu_hnsw_attach_sq8(dev_, codes.data(), corr.data(), n, sq8_.alpha_2) != RXGPU_OK) throwDevice("SQ8 code upload failed");
 	codesDirty_ = false;
+	syncedCodes_ = n;
+}
+
+void GpuHnswMap::patchCodes(const std::vector<tableint>& dirty, size_t n) const {
+	const size_t dim = graph_.Dim();
+	std::vector<uint8_t> code(dim);
+	for (const tableint id : dirty) {   // updated rows (recycled slots, in-place updates; neighbours whose links changed cost a row each, a handful)
+		if (id >= syncedCodes_) break;   // ids ascend; the rest are new rows
+		const float corr = Sq8Quantize(graph_.Metric(), sq8_, graph_.Vector(id), dim, 1.f, code.data());
+		if (rxgpu_hnsw_upload_sq8_rows(dev_, id, 1, code.data(), &corr, sq8_.alpha_2) != RXGPU_OK) throwDevice("SQ8 code upload failed");
+	}
+	if (n > syncedCodes_) {
+		const size_t add = n - syncedCodes_;
+		std::vector<uint8_t> codes(add * dim);
+		std::vector<float> corr(add);
+		for (size_t i = 0; i < add; ++i) corr[i] = Sq8Quantize(graph_.Metric(), sq8_, graph_.Vector(tableint(syncedCodes_ + i)), dim, 1.f, codes.data() + i * dim);
+		if (rxgpu_hnsw_upload_sq8_rows(dev_, syncedCodes_, add, codes.data(), corr.data(), sq8_.alpha_2) != RXGPU_OK) throwDevice("SQ8 code upload failed");
+	}
+	syncedCodes_ = n;
 }
 
 void GpuHnswMap::Quantize(float minQ, float maxQ) {
 	if (!(maxQ > minQ)) throw std::runtime_error("Quantize: empty quantisation range");
 	sq8_ = Sq8Params::FromRange(minQ, maxQ, graph_.Dim());
+	pendingSq8_.reset();
+	quantized_ = true;
+	codesDirty_ = true;
+	graphDirty_ = true;
+}
+
+void GpuHnswMap::Quantize(const Sq8QuantizationConfig& config) {
+	if (quantized_ || pendingSq8_) throw std::logic_error("Quantize: the Map is quantised already");
+	const Sq8Params p = Sq8SampleParams(graph_.Count(), graph_.Dim(), config, [this](uint32_t id) { return graph_.Vector(tableint(id)); });
+	if (!(p.maxQ > p.minQ)) throw std::runtime_error("Quantize: empty quantisation range");
+	sq8Config_ = config;
+	pendingSq8_ = p;
+}
+
+void GpuHnswMap::SwitchMapOnQuantized() {
+	if (!pendingSq8_) return;   // Impl::get(): nothing pending, nothing to swap in
+	sq8_ = *pendingSq8_;
+	pendingSq8_.reset();
 	quantized_ = true;
 	codesDirty_ = true;
 	graphDirty_ = true;

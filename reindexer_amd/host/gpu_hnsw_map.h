@@ -97,8 +97,15 @@ public:
 	// QuantizingParams over the Map's rows).  Points added later are quantised with the same parameters at the next sync
 	// (addPoint, hnswalg.h:1480-1495).  Streaming and range searches of a quantised Map are not implemented: they throw.
 	void Quantize(float minQ, float maxQ);
+	// HierarchicalNSW::Quantize(config) + SwitchMapOnQuantized() (hnsw.h:61-62, hnsw.cc:131-137, Impl::get :108-114) as HnswIndexBase drives them
+	// (hnsw_index.cc:532-551): Quantize derives the parameters from a sample of the stored rows exactly as QuantizingParams does
+	// (quantization_params.h:48-66: reservoir sample by std::rand, batches of 20 rows, n-th min / max per batch, means) and keeps them PENDING —
+	// searches go on over the float rows, like the reference's readers on ptr_ while quantizedPtr_ is built — until SwitchMapOnQuantized()
+	// (under the namespace write lock) makes the Map a quantised one.
+	void Quantize(const Sq8QuantizationConfig& config);
+	void SwitchMapOnQuantized();
 	bool IsQuantized() const noexcept { return quantized_; }
-	bool QuantizationAvailable() const noexcept { return !quantized_; }
+	bool QuantizationAvailable() const noexcept { return !quantized_ && !pendingSq8_; }
 	const Sq8Params& QuantizingParams() const noexcept { return sq8_; }
 
 	VectorMetric Metric() const noexcept { return graph_.Metric(); }
@@ -108,10 +115,11 @@ public:
 private:
 	void syncDevice() const;
 public:
-	// The ANN disk cache (ann_cache.h): HierarchicalNSW::SaveIndex / LoadIndex (hnswlib/hnsw.cc:41-53).  The stream starts with the
-	// "quantised" flag (+ QuantizingParams when set); a float graph writes 0.  LoadIndex takes a stream whose flag is 0; a caller that
-	// holds the reference's QuantizingParams type (rx_seam.h) reads the flag and the parameters itself and calls LoadGraph for the rest.
-	// The Map must be empty; the next search uploads the whole graph to the device.
+	// The ANN disk cache (ann_cache.h): HierarchicalNSW::SaveIndex / LoadIndex (hnswlib/hnsw.cc:41-72).  The stream starts with the
+	// "quantised" flag; a quantised Map writes 1 + its QuantizingParams (version, QuantizationConfig, minQ, maxQ, alpha, alpha_2, delta:
+	// quantization_params.h:83-96, quantization_config.cc:44-49), a float graph 0.  LoadIndex reads them back: parameters in the stream and
+	// reader.WithQuantizer() -> the Map comes back QUANTISED with exactly those parameters (the codes are rebuilt from the rows: the cache holds
+	// links and keys); otherwise a float graph (hnsw.cc:47-53).  The Map must be empty; the next search uploads the whole graph to the device.
 	void SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const;
 	void LoadIndex(AnnCacheReader& reader);
 	void LoadGraph(AnnCacheReader& reader);
@@ -131,8 +139,14 @@ private:
 	mutable bool deletedDirty_ = false;
 	bool quantized_ = false;
 	Sq8Params sq8_;
-	mutable bool codesDirty_ = false;
+	Sq8QuantizationConfig sq8Config_;               // what the parameters were sampled under (travels with them in the ANN cache)
+	std::optional<Sq8Params> pendingSq8_;           // Quantize(config) ran, SwitchMapOnQuantized() has not yet
+	mutable bool codesDirty_ = false;               // the whole code table has to be (re)built and sent
+	mutable size_t syncedCodes_ = 0;                // rows whose codes are on the device
+	mutable std::vector<tableint> codesDirtyRows_;  // what the graph's change tracker named at this sync (when it could)
+	mutable bool codesIncremental_ = false;
 	void attachCodes() const;
+	void patchCodes(const std::vector<tableint>& dirty, size_t n) const;   // codes of the changed / new rows only
 	float quantizeQuery(const float* queryDataRaw, std::optional<float> queryDataNorm, std::vector<uint8_t>& qcodes, float& normCoef) const;
 
 	bool coalesce_ = true;

@@ -815,6 +815,18 @@ void HnswGraph::loadIndex(AnnCacheReader& reader) {
 		}
 	}
 	if (numDeleted_ != deletedCount) throw std::logic_error("HnswGraph::LoadIndex: delete marks out of step");
+	// third pass, once every element's level is known: a link on level lv must lead to an element that HAS a level-lv list (search, insert and
+	// the device export index upper_[target] by the level they arrived on), and nothing may stand above the stored top level
+	for (size_t i = 0; i < cnt; ++i) {
+		if (levels_[i] > int(maxLevel)) throw std::runtime_error("HnswGraph::LoadIndex: an element stands above the stored top level");
+		for (int lv = 1; lv <= levels_[i]; ++lv) {
+			const uint32_t* ll = list(tableint(i), lv);
+			const uint32_t n = ll[0] & 0xFFFFu;
+			for (uint32_t j = 1; j <= n; ++j) {
+				if (levels_[ll[j]] < lv) throw std::runtime_error("HnswGraph::LoadIndex: an upper-level link leads to an element without that level");
+			}
+		}
+	}
 	maxLevel_ = int(maxLevel);
 	entryPoint_ = tableint(entry);
 	if (cnt && levels_[entryPoint_] != maxLevel_) throw std::runtime_error("HnswGraph::LoadIndex: the entry point is not on the top level");

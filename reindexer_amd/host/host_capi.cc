@@ -245,7 +245,8 @@ public:
 		std::memcpy(dest, vectors_ + it->second * dim_, dim_ * sizeof(float));
 		return label;
 	}
-	bool WithQuantizer() const override { return false; }
+	bool WithQuantizer() const override { return withQuantizer; }
+	bool withQuantizer = false;   // LoadWithQuantizer of HnswIndexBase::LoadIndexCache (hnsw_index.cc:452-484)
 
 private:
 	void need(size_t n) const {
@@ -441,10 +442,11 @@ long rxhost_hnsw_save_index(void* h, uint8_t* out, size_t cap) {
 	});
 	return n;
 }
-int rxhost_hnsw_load_index(void* h, const uint8_t* data, size_t len, const uint64_t* labels, const float* vectors, size_t rows) {
+static int hnswLoadIndex(void* h, const uint8_t* data, size_t len, const uint64_t* labels, const float* vectors, size_t rows, bool withQuantizer) {
 	return guarded([&] {
 		auto* m = static_cast<GpuHnswMap*>(h);
 		MemAnnReader r(data, len, m->Dim(), labels, vectors, rows);
+		r.withQuantizer = withQuantizer;
 		try {
 			m->LoadIndex(r);
 			if (r.Remaining()) throw std::runtime_error("ANN cache: unparsed data behind the graph");
@@ -453,6 +455,13 @@ int rxhost_hnsw_load_index(void* h, const uint8_t* data, size_t len, const uint6
 			throw;
 		}
 	});
+}
+int rxhost_hnsw_load_index(void* h, const uint8_t* data, size_t len, const uint64_t* labels, const float* vectors, size_t rows) {
+	return hnswLoadIndex(h, data, len, labels, vectors, rows, false);
+}
+// ... with LoadWithQuantizer_True: a cache that carries QuantizingParams brings the Map back quantised
+int rxhost_hnsw_load_index_quantized(void* h, const uint8_t* data, size_t len, const uint64_t* labels, const float* vectors, size_t rows) {
+	return hnswLoadIndex(h, data, len, labels, vectors, rows, true);
 }
 long rxhost_hnsw_search_knn(void* h, const float* q, size_t k, size_t ef, float* outDist, uint64_t* outLabel) {
 	long n = -1;
@@ -467,6 +476,64 @@ int rxhost_hnsw_quantize(void* h, float minQ, float maxQ) {
 	return guarded([&] { static_cast<GpuHnswMap*>(h)->Quantize(minQ, maxQ); });
 }
 int rxhost_hnsw_is_quantized(void* h) { return static_cast<GpuHnswMap*>(h)->IsQuantized() ? 1 : 0; }
+// HnswIndexBase::Quantize() / SwitchMapOnQuantized() (hnsw_index.cc:532-551) through the Map: the parameters are sampled from the stored rows
+// like QuantizingParams does (quantile <= 0: the default of the dimension); params5 (may be null) = minQ, maxQ, alpha, alpha_2, delta
+int rxhost_hnsw_quantize_config(void* h, size_t sampleSize, float quantile, int switchOn, float* params5) {
+	return guarded([&] {
+		auto* m = static_cast<GpuHnswMap*>(h);
+		rxgpu::host::Sq8QuantizationConfig cfg;
+		cfg.sampleSize = sampleSize;
+		if (quantile > 0.f) cfg.quantile = quantile;
+		m->Quantize(cfg);
+		if (m->QuantizationAvailable()) throw std::logic_error("QuantizationAvailable() after Quantize(config)");
+		if (m->IsQuantized()) throw std::logic_error("IsQuantized() before SwitchMapOnQuantized()");
+		if (switchOn) m->SwitchMapOnQuantized();
+		if (params5 && switchOn) {
+			const auto& p = m->QuantizingParams();
+			params5[0] = p.minQ;
+			params5[1] = p.maxQ;
+			params5[2] = p.alpha;
+			params5[3] = p.alpha_2;
+			params5[4] = p.delta;
+		}
+	});
+}
+int rxhost_hnsw_switch_on_quantized(void* h) {
+	return guarded([&] { static_cast<GpuHnswMap*>(h)->SwitchMapOnQuantized(); });
+}
+void rxhost_hnsw_quantizing_params(void* h, float* params5) {
+	const auto& p = static_cast<GpuHnswMap*>(h)->QuantizingParams();
+	params5[0] = p.minQ;
+	params5[1] = p.maxQ;
+	params5[2] = p.alpha;
+	params5[3] = p.alpha_2;
+	params5[4] = p.delta;
+}
+// Sq8FindNthMinMax / Sq8SampleIndexes (sq8_quantizer.h) for the CPU parity tests against the reference's sampler
+void rxhost_sq8_find_nth_min_max(const float* v, size_t count, size_t dataSize, float quantile, float* out2) {
+	const auto mm = rxgpu::host::Sq8FindNthMinMax(v, count, dataSize, quantile);
+	out2[0] = mm.first;
+	out2[1] = mm.second;
+}
+size_t rxhost_sq8_sample_indexes(size_t sampleSize, size_t size, uint32_t* out) {
+	const auto ids = rxgpu::host::Sq8SampleIndexes(sampleSize, size);
+	std::copy(ids.begin(), ids.end(), out);
+	return ids.size();
+}
+// QuantizingParams(hnsw, config) over plain rows [n][dim] (Sq8SampleParams): minQ, maxQ, alpha, alpha_2, delta
+int rxhost_sq8_sample_params(const float* rows, size_t n, size_t dim, size_t sampleSize, float quantile, float* params5) {
+	return guarded([&] {
+		rxgpu::host::Sq8QuantizationConfig cfg;
+		cfg.sampleSize = sampleSize;
+		if (quantile > 0.f) cfg.quantile = quantile;
+		const auto p = rxgpu::host::Sq8SampleParams(n, dim, cfg, [&](uint32_t id) { return rows + size_t(id) * dim; });
+		params5[0] = p.minQ;
+		params5[1] = p.maxQ;
+		params5[2] = p.alpha;
+		params5[3] = p.alpha_2;
+		params5[4] = p.delta;
+	});
+}
 long rxhost_hnsw_search_knn_norm(void* h, const float* q, int hasNorm, float norm, size_t k, size_t ef, float* outDist, uint64_t* outLabel) {
 	long n = -1;
 	guarded([&] {

@@ -45,8 +45,7 @@ public:
 	}
 	// The ANN disk cache (HnswIndexBase::WriteIndexCache / LoadIndexCache, hnsw_index.cc:388-507): the reference's writer / reader objects
 	// forwarded to the Map's own interfaces (ann_cache.h) — the stream is the CPU engine's, field for field, so a cache written by either
-	// engine loads into the other.  A cache the CPU engine wrote from a QUANTISED graph carries QuantizingParams in front: read past with
-	// the reference's own type; the links are the same graph and the Map rebuilds float rows from the primary keys.
+	// engine loads into the other, QuantizingParams of a quantised graph included (the Map comes back quantised when the reader asks for it).
 	void SaveIndex(hnswlib::IWriter& writer, const std::atomic_int32_t& cancel) const {
 		struct W final : AnnCacheWriter {
 			hnswlib::IWriter& w;
@@ -72,18 +71,17 @@ public:
 			labeltype ReadPkEncodedData(float* dest) override { return r.ReadPkEncodedData(dest); }
 			bool WithQuantizer() const override { return r.WithQuantizer(); }
 		} fr(reader);
-		if (reader.GetVarUInt() != 0) {   // deserializeQuantizingParams (hnsw.cc:64-72)
-			hnswlib::QuantizingParams params;
-			params.Deserialize(reader);
-		}
-		GpuHnswMap::LoadGraph(fr);
+		GpuHnswMap::LoadIndex(fr);   // reads the "quantised" flag and QuantizingParams itself (the reference's stream, field for field)
 	}
-	// SQ8: the Map itself quantises (GpuHnswMap::Quantize(minQ, maxQ) + the device search over codes), but HnswIndexBase::Quantize() derives
-	// the range by sampling the reference's own graph storage (QuantizingParams over an HNSWView, quantization_params.h:48-63), which this
-	// adapter does not expose yet — so through the seam QuantizationAvailable() stays false and the two below are never reached.
-	bool QuantizationAvailable() const noexcept { return false; }
-	void Quantize(const hnswlib::QuantizationConfig&) { throw std::logic_error("GpuHnswMap: quantization is not supported"); }
-	void SwitchMapOnQuantized() { throw std::logic_error("GpuHnswMap: quantization is not supported"); }
+	// SQ8 through the seam (HnswIndexBase::Quantize / SwitchMapOnQuantized, hnsw_index.cc:532-551): the Map samples its own rows like
+	// QuantizingParams does (quantization_params.h:48-66) and keeps the parameters pending until the switch.
+	void Quantize(const hnswlib::QuantizationConfig& c) {
+		Sq8QuantizationConfig cfg;
+		cfg.quantile = c.quantile;
+		cfg.sampleSize = c.sampleSize;
+		cfg.quantizationThreshold = c.quantizationThreshold;
+		GpuHnswMap::Quantize(cfg);
+	}
 };
 using GpuHnswMapST = GpuHnswMapT<Synchronization::None>;
 using GpuHnswMapMT = GpuHnswMapT<Synchronization::OnInsertions>;

@@ -543,9 +543,10 @@ class GpuHnswMap:
         """HnswIndexBase::WriteIndexCache's Map part (hnsw_index.cc:388-437 -> hnsw.cc:56-62): quantisation flag + the graph."""
         return _save_bytes(lib().rxhost_hnsw_save_index, self.h)
 
-    def load_index(self, data: bytes, labels, vectors):
-        """LoadIndexCache's Map part (hnsw_index.cc:439-507) into an empty Map; on any error the Map is cleared, as clearMap() does."""
-        _load_bytes(lib().rxhost_hnsw_load_index, self.h, data, labels, vectors, self.dim)
+    def load_index(self, data: bytes, labels, vectors, with_quantizer: bool = False):
+        """LoadIndexCache's Map part (hnsw_index.cc:439-507) into an empty Map; on any error the Map is cleared, as clearMap() does.
+        with_quantizer = LoadWithQuantizer: a cache written from a quantised Map brings it back quantised (same parameters)."""
+        _load_bytes(lib().rxhost_hnsw_load_index_quantized if with_quantizer else lib().rxhost_hnsw_load_index, self.h, data, labels, vectors, self.dim)
 
     def tie_reruns(self) -> int:
         """Searches re-run on the heap kernel since the last call (the sorted-list search met equal distances)."""
@@ -584,6 +585,30 @@ class GpuHnswMap:
         rc = lib().rxhost_hnsw_quantize(self.h, float(min_q), float(max_q))
         if rc:
             _raise(rc)
+
+    def quantize_config(self, sample_size: int = 20000, quantile: float = 0.0, switch: bool = True):
+        """HnswIndexBase::Quantize() (+ SwitchMapOnQuantized()): the parameters are sampled from the Map's rows the way QuantizingParams does
+        (std::rand reservoir sample, batches of 20 rows, n-th min / max, means).  -> (minQ, maxQ, alpha, alpha_2, delta) when switched on."""
+        L = lib()
+        L.rxhost_hnsw_quantize_config.argtypes = [_vp, _sz, _f, _i, _vp]
+        p = np.zeros(5, np.float32)
+        rc = L.rxhost_hnsw_quantize_config(self.h, sample_size, float(quantile), int(switch), p.ctypes.data)
+        if rc:
+            _raise(rc)
+        return p
+
+    def switch_on_quantized(self) -> None:
+        rc = lib().rxhost_hnsw_switch_on_quantized(self.h)
+        if rc:
+            _raise(rc)
+
+    @property
+    def quantizing_params(self):
+        L = lib()
+        L.rxhost_hnsw_quantizing_params.argtypes = [_vp, _vp]
+        p = np.zeros(5, np.float32)
+        L.rxhost_hnsw_quantizing_params(self.h, p.ctypes.data)
+        return p
 
     @property
     def is_quantized(self) -> bool:
@@ -1215,3 +1240,35 @@ class GpuIvfFlat:
         if rc:
             _raise(rc)
         return out
+
+
+def sq8_find_nth_min_max(values, data_size: int, quantile: float):
+    """Sq8FindNthMinMax (FindNthMinMax, quantization_params.h:12-44) -> (min, max)"""
+    L = lib()
+    L.rxhost_sq8_find_nth_min_max.argtypes = [_vp, _sz, _sz, _f, _vp]
+    v = _f32(values).reshape(-1)
+    out = np.zeros(2, np.float32)
+    L.rxhost_sq8_find_nth_min_max(v.ctypes.data, v.shape[0], data_size, float(quantile), out.ctypes.data)
+    return float(out[0]), float(out[1])
+
+
+def sq8_sample_indexes(sample_size: int, size: int):
+    """Sq8SampleIndexes (HNSWView::GetSampleIndexes): consumes the C library's rand() like the reference"""
+    L = lib()
+    L.rxhost_sq8_sample_indexes.restype = _sz
+    L.rxhost_sq8_sample_indexes.argtypes = [_sz, _sz, _vp]
+    out = np.zeros(min(sample_size, size), np.uint32)
+    n = L.rxhost_sq8_sample_indexes(sample_size, size, out.ctypes.data)
+    return out[:n]
+
+
+def sq8_sample_params(rows, sample_size: int = 20000, quantile: float = 0.0):
+    """Sq8SampleParams (QuantizingParams(hnsw, config)) over plain rows -> (minQ, maxQ, alpha, alpha_2, delta)"""
+    L = lib()
+    L.rxhost_sq8_sample_params.argtypes = [_vp, _sz, _sz, _sz, _f, _vp]
+    r = _f32(rows)
+    p = np.zeros(5, np.float32)
+    rc = L.rxhost_sq8_sample_params(r.ctypes.data, r.shape[0], r.shape[1], sample_size, float(quantile), p.ctypes.data)
+    if rc:
+        _raise(rc)
+    return p

@@ -161,6 +161,21 @@ def test_load_errors(ref):
     with pytest.raises(hostapi.HostError, match="no row"):
         fresh.load_index(cache, labels[keep], rows[keep])
     assert fresh.export()["n"] == 0
+    # an upper-level link that leads to an element WITHOUT that level (a corrupt cache): refused at load time — search, insert and the device
+    # export would index that element's upper lists out of bounds
+    ex = g.export()
+    tall = int(np.flatnonzero(ex["levels"] >= 1)[0])
+    flat = int(np.flatnonzero(ex["levels"] == 0)[0])
+    blk = np.asarray(ex["upper"], np.uint32)[int(ex["upper_off"][tall])].copy()   # the element's level-1 block: count + M links
+    assert blk[0] >= 1
+    at = cache.find(blk.tobytes())
+    assert at > 0 and cache.find(blk.tobytes(), at + 1) < 0
+    bad = blk.copy()
+    bad[1] = flat
+    fresh.clear()
+    with pytest.raises(hostapi.HostError, match="without that level"):
+        fresh.load_index(cache[:at] + bad.tobytes() + cache[at + blk.nbytes:], labels, rows)
+    assert fresh.export()["n"] == 0
     # too small a graph for the cache
     small = hostapi.HnswGraph(metric, d, n // 2, M=M, ef_construction=efc)
     small.load_index(cache, labels, rows)   # the stored max_elements wins, as in the reader constructor

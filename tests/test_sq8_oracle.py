@@ -208,3 +208,54 @@ def test_host_quantiser_matches_reference_quantizer(sq8ref, metric):
                 rc, ro = sq8ref.quantize(metric, pr, x, scale)
                 assert np.array_equal(c, rc) and bits(o) == bits(ro)
                 assert np.array_equal(bits(params), bits([pr["alpha"], pr["alpha_2"], pr["delta"]]))
+
+
+def _srand(seed):
+    import ctypes
+    ctypes.CDLL(None).srand(int(seed))
+
+
+@pytest.mark.parametrize("metric,n,d,sample,quantile", [(0, 2500, 32, 20000, 0.0), (2, 3000, 24, 700, 0.0), (1, 2010, 48, 1000, 0.97), (0, 400, 128, 100, 0.0),
+                                                         (2, 61, 768, 20000, 0.0), (0, 1203, 16, 1203, 1.0)])
+def test_sampled_quantisation_parameters_equal_the_reference(ref, metric, n, d, sample, quantile):
+    """QuantizingParams(hnsw, config) (quantization_params.h:48-66) — reservoir sample by std::rand (hnsw_view_iterator.h:99-113), batches of 20
+    rows with a shorter last one, FindNthMinMax per batch (:12-44), means — restated on the host (sq8_quantizer.h: Sq8SampleParams, what
+    GpuHnswMap::Quantize(config) runs) against the reference's own constructor over its own float graph, from the same srand() state:
+    minQ, maxQ, alpha, alpha_2 and delta bit for bit.  Rows with repeated components (equal minima / maxima: the FIRST occurrence leaves)."""
+    from oracle.pyoracle import RefHnsw, RefHnswQ
+    from reindexer_amd import hostapi
+    rng = np.random.default_rng(n + d)
+    rows = rng.normal(0.0, 0.25, (n, d)).astype(np.float32)
+    rows[::7] = np.round(rows[::7], 1)            # ties among the extremes
+    rows[5] = rows[5].max()
+    if metric == 2:
+        rows /= np.linalg.norm(rows, axis=1, keepdims=True)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    g = RefHnsw(ref, metric, d, n, M=8, ef_construction=40)
+    g.add(rows, labels)
+    _srand(4242 + n)
+    q = RefHnswQ(g, sample_size=sample, quantile=quantile)
+    want = q.export()
+    q.close()
+    _srand(4242 + n)
+    got = hostapi.sq8_sample_params(rows, sample_size=sample, quantile=quantile)
+    wantp = np.array([want["min_q"], want["max_q"], want["alpha"], want["alpha_2"], want["delta"]], np.float32)
+    assert np.array_equal(bits(got), bits(wantp)), (got, wantp)
+    # the sample itself: the same ids from the same generator state
+    _srand(99)
+    a = hostapi.sq8_sample_indexes(sample, n)
+    _srand(99)
+    b = hostapi.sq8_sample_indexes(sample, n)
+    assert np.array_equal(a, b) and len(a) == min(sample, n) and np.all(np.diff(a.astype(np.int64)) > 0)
+    g.close()
+
+
+def test_find_nth_min_max_walk():
+    """FindNthMinMax by hand: n = trunc(0.5 (1 - q) dataSize) passes, each removes the current minimum and maximum (first occurrence)."""
+    from reindexer_amd import hostapi
+    v = np.array([5, 1, 9, 1, 7, 9, 3, 4], np.float32)
+    assert hostapi.sq8_find_nth_min_max(v, 8, 1.0) == (1.0, 9.0)          # n = 0: one pass, nothing removed
+    assert hostapi.sq8_find_nth_min_max(v, 8, 0.75) == (1.0, 9.0)         # n = 1
+    assert hostapi.sq8_find_nth_min_max(v, 8, 0.5) == (1.0, 9.0)          # n = 2: the second 1 and the second 9
+    assert hostapi.sq8_find_nth_min_max(v, 8, 0.25) == (3.0, 7.0)         # n = 3
+    assert hostapi.sq8_find_nth_min_max(v, 16, 0.5) == (4.0, 5.0)         # dataSize is what the caller claims: n = 4 on 8 values
