@@ -352,6 +352,12 @@ int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n,
  * allocation per call.  A malformed stream (truncated varint, ids not ascending, field >= num_fields) is RXGPU_ERR_PARAMS naming the word. */
 int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t* word_ids, const uint64_t* byte_off, const uint8_t* bytes,
 							  const uint64_t* array_found_pos);
+/* The same with word w's stream at data[w] (len[w] bytes) — PackedIdRelVec::RawData() of every dictionary entry, where the engine keeps it:
+ * the streams are gathered once, in launch order, into pinned staging memory and travel in one asynchronous copy. */
+int rxgpu_ft_set_words_packed_ptrs(rxgpu_ft_index* h, uint32_t nwords, const uint32_t* word_ids, const uint8_t* const* data, const uint64_t* len,
+								   const uint64_t* array_found_pos);
+/* Wall time spent inside rxgpu_ft_set_words_packed / _ptrs since the last call (the commit-side cost at the C-ABI boundary). */
+int rxgpu_ft_read_packed_wall(rxgpu_ft_index* h, double* wall_ms);
 /* Device time of the two decode kernels of rxgpu_ft_set_words_packed (count pass, write pass), the stream bytes they read (each pass)
  * and the bytes of the arrays they produced (256-byte aligned slices included), since the last call. */
 int rxgpu_ft_read_packed_stats(rxgpu_ft_index* h, double* count_ms, double* write_ms, uint64_t* bytes_in, uint64_t* bytes_out);

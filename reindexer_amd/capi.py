@@ -101,6 +101,8 @@ _SIGNATURES = {
     "rxgpu_ft_merge_query_resident": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "rxgpu_ft_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
     "rxgpu_ft_set_words_packed": (_i, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    "rxgpu_ft_set_words_packed_ptrs": (_i, [_vp, _u32, _vp, _vp, _vp, _vp]),
+    "rxgpu_ft_read_packed_wall": (_i, [_vp, C.POINTER(C.c_double)]),
     "rxgpu_ft_read_packed_stats": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_ft_get_word": (_i, [_vp, _u32, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u32), _vp]),
     "rxgpu_ft_merge_simple_resident": (_i, [_vp, _vp, _vp, _u32, _vp, _vp, _vp]),

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ft_packed_count(const uint8_t* bytes, con
 														 uint32_t num_fields, FtPackedCounts* counts) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= nwords) return;
-	const uint64_t b0 = byte_off[w], b1 = byte_off[w + 1];
+	const uint64_t b0 = byte_off[2 * w], b1 = byte_off[2 * w + 1];   // (start, end) of the word's stream: the streams lie where the caller packed them
 	counts[w] = ft_decode_packed(bytes + b0, b1 - b0, array_found_pos[w], num_fields, kFtRangeDocs, FtPackedOut{});
 }
 
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void ft_packed_write(const uint8_t* bytes, con
 														 uint32_t num_fields, const FtPackedOut* outs, FtPackedCounts* counts) {
 	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= nwords) return;
-	const uint64_t b0 = byte_off[w], b1 = byte_off[w + 1];
+	const uint64_t b0 = byte_off[2 * w], b1 = byte_off[2 * w + 1];   // (start, end) of the word's stream: the streams lie where the caller packed them
 	if (!outs[w].doc) return;   // an empty word
 	counts[w] = ft_decode_packed(bytes + b0, b1 - b0, array_found_pos[w], num_fields, kFtRangeDocs, outs[w]);
 }
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void ft_packed_wave(const uint8_t* __restrict__
 	if (w >= nwords) return;
 	const int lane = threadIdx.x;
 	const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-	const uint64_t b0 = byte_off[w], full_len = byte_off[w + 1] - b0;
+	const uint64_t b0 = byte_off[2 * w], full_len = byte_off[2 * w + 1] - b0;   // (start, end) pairs in launch order
 	const uint8_t* __restrict__ data = bytes + b0;
 	const uint64_t afp = array_found_pos[w];
 	const uint32_t cp0 = seg_first[w], ncp = seg_first[w + 1] - cp0;   // the word's pieces

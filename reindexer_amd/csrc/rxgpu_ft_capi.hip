@@ -92,6 +92,7 @@ struct rxgpu_ft_index {
 	hipStream_t stream = nullptr;
 	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
 	rxgpu_devbuf d_excl;           // docsExcluded of the running merge
+	rxgpu_devbuf d_pk_in, d_pk_cnt, d_pk_segs, d_pk_outs;   // rxgpu_ft_set_words_packed: streams + offsets, counts, pieces, slices (kept and grown)
 	std::vector<rxgpu_devbuf> d_phrase_a, d_phrase_b;   // per phrase of a query: plan + admission slots, workspace + the packed rows
 	hipEvent_t ev_pha = nullptr, ev_phb = nullptr;      // around the phrase kernels
 	// tables every merge finds ZEROED and leaves zeroed (the kernel that reads one last clears it): pre-score histogram, look-back words of
@@ -137,6 +138,7 @@ struct rxgpu_ft_index {
 	uint64_t fuse_calls = 0;
 	double fuse_ms = 0.0;
 	double fuse_stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // RXGPU_FUSE_STAMPS: summed phase stamps of the fusion kernel (us since its first)
+	double packed_wall_ms = 0.0;                            // rxgpu_ft_set_words_packed*: wall time inside the calls (rxgpu_ft_read_packed_wall)
 	double packed_count_ms = 0.0, packed_write_ms = 0.0;   // rxgpu_ft_set_words_packed: device time of the two decode kernels ...
 	uint64_t packed_bytes_in = 0, packed_bytes_out = 0;    // ... the stream bytes they read and the array bytes they wrote
 	uint64_t stat_postings = 0;
@@ -208,7 +210,7 @@ int rxgpu_ft_create(uint32_t num_fields, int device, rxgpu_ft_index** out) {
 
 namespace {
 void release_lane(rxgpu_ft_index* h) {   // what a lane owns: stream, scratch, staging, events
-	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse, &h->d_excl}) b->release();
+	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse, &h->d_excl, &h->d_pk_in, &h->d_pk_cnt, &h->d_pk_segs, &h->d_pk_outs}) b->release();
 	for (rxgpu_devbuf& b : h->d_phrase_a) b.release();
 	for (rxgpu_devbuf& b : h->d_phrase_b) b.release();
 	for (hipEvent_t e : {h->ev_knn, h->ev_fa, h->ev_fb, h->ev_pa, h->ev_pb, h->ev_pha, h->ev_phb}) {
@@ -1321,48 +1323,97 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 	RX_CHECK(word_ids && byte_off && array_found_pos, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: null argument");
 	RX_CHECK(byte_off[0] == 0, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: byte_off[0] must be 0");
 	for (uint32_t w = 0; w < nwords; ++w) RX_CHECK(byte_off[w + 1] >= byte_off[w], RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: byte_off must not descend");
-	const uint64_t total_bytes = byte_off[nwords];
-	RX_CHECK(total_bytes == 0 || bytes, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: null argument");
+	RX_CHECK(byte_off[nwords] == 0 || bytes, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: null argument");
+	std::vector<const uint8_t*> data(nwords);
+	std::vector<uint64_t> len(nwords);
+	for (uint32_t w = 0; w < nwords; ++w) {
+		data[w] = bytes + byte_off[w];
+		len[w] = byte_off[w + 1] - byte_off[w];
+	}
+	return rxgpu_ft_set_words_packed_ptrs(h, nwords, word_ids, data.data(), len.data(), array_found_pos);
+}
+
+// The same with every word's stream where the caller keeps it (PackedIdRelVec::RawData() of each dictionary entry — separate allocations):
+// the streams are gathered ONCE, in launch order, straight into the pinned staging buffer, and travel in one asynchronous copy.
+int rxgpu_ft_set_words_packed_ptrs(rxgpu_ft_index* h, uint32_t nwords, const uint32_t* word_ids, const uint8_t* const* data, const uint64_t* len,
+								   const uint64_t* array_found_pos) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null ft index");
+	if (nwords == 0) return RXGPU_OK;
+	RX_CHECK(word_ids && data && len && array_found_pos, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed_ptrs: null argument");
+	const auto t_call = std::chrono::steady_clock::now();
+	struct WallClock {
+		rxgpu_ft_index* h;
+		std::chrono::steady_clock::time_point t0;
+		~WallClock() { h->packed_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+	};
+	uint64_t total_bytes = 0;
+	for (uint32_t w = 0; w < nwords; ++w) {
+		RX_CHECK(len[w] == 0 || data[w], RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed_ptrs: null stream");
+		total_bytes += len[w];
+	}
 	std::lock_guard<std::mutex> lk(h->mtx);
+	WallClock wall{h, t_call};
 	std::unique_lock<std::shared_mutex> dict_lk(h->dict_mtx);   // no merge on any lane reads the dictionary meanwhile
 	DevGuard dg(h->device);
 	RX_HIP(hipStreamSynchronize(h->stream));
-	// wavefronts of similar work: the words go to the threads longest first (a wavefront lasts as long as its longest stream)
+	// wavefronts of similar work: the words are launched longest first (a wavefront lasts as long as its longest stream).  A bucket sort by
+	// the length's power of two is enough for that — O(n); a comparison sort of a 100 000-word dictionary cost 8 ms of this call.
 	std::vector<uint32_t> order(nwords);
-	for (uint32_t w = 0; w < nwords; ++w) order[w] = w;
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return byte_off[a + 1] - byte_off[a] > byte_off[b + 1] - byte_off[b]; });
-	// staging: the streams in launch order, their offsets and array_found_pos
-	std::vector<uint64_t> off(nwords + 1), afp(nwords);
-	off[0] = 0;
-	for (uint32_t k = 0; k < nwords; ++k) {
-		const uint32_t w = order[k];
-		off[k + 1] = off[k] + (byte_off[w + 1] - byte_off[w]);
-		afp[k] = array_found_pos[w];
-	}
-	struct Scratch {
-		void* p = nullptr;
-		~Scratch() {
-			if (p) (void)hipFree(p);
-		}
-	} d_in, d_cnt, d_outs, d_segs;
-	const size_t in_bytes = align256(size_t(total_bytes) + 16) + align256((nwords + 1) * 8) + align256(size_t(nwords) * 8);
-	RX_HIP(hipMalloc(&d_in.p, in_bytes));
-	uint8_t* d_bytes = static_cast<uint8_t*>(d_in.p);
-	uint64_t* d_off = reinterpret_cast<uint64_t*>(d_bytes + align256(size_t(total_bytes) + 16));
-	uint64_t* d_afp = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(d_off) + align256((nwords + 1) * 8));
 	{
-		std::vector<uint8_t> packed(total_bytes);
+		uint32_t bucket_n[65] = {0};
+		auto bucket_of = [&](uint32_t w) {
+			const uint64_t l = len[w];
+			return l ? 64 - uint32_t(__builtin_clzll(l)) : 0u;   // 0 .. 64
+		};
+		for (uint32_t w = 0; w < nwords; ++w) bucket_n[bucket_of(w)] += 1;
+		uint32_t start[65];
+		uint32_t at = 0;
+		for (int b = 64; b >= 0; --b) {
+			start[b] = at;
+			at += bucket_n[b];
+		}
+		for (uint32_t w = 0; w < nwords; ++w) order[start[bucket_of(w)]++] = w;
+	}
+	// (start, end) of every stream in the staging buffer, launch order; scratch of the call (streams, offsets, counts, pieces, slices) lives
+	// in buffers the index keeps and grows: no hipMalloc / hipFree pair — each a device synchronisation — per call
+	std::vector<uint64_t> off(size_t(nwords) * 2), afp(nwords);
+	{
+		uint64_t at = 0;
 		for (uint32_t k = 0; k < nwords; ++k) {
 			const uint32_t w = order[k];
-			if (off[k + 1] > off[k]) std::memcpy(packed.data() + off[k], bytes + byte_off[w], size_t(off[k + 1] - off[k]));
+			off[2 * size_t(k)] = at;
+			at += len[w];
+			off[2 * size_t(k) + 1] = at;
+			afp[k] = array_found_pos[w];
 		}
-		if (total_bytes) RX_HIP(hipMemcpyAsync(d_bytes, packed.data(), total_bytes, hipMemcpyHostToDevice, h->stream));
-		RX_HIP(hipMemcpyAsync(d_off, off.data(), (nwords + 1) * 8, hipMemcpyHostToDevice, h->stream));
-		RX_HIP(hipMemcpyAsync(d_afp, afp.data(), size_t(nwords) * 8, hipMemcpyHostToDevice, h->stream));
-		RX_HIP(hipStreamSynchronize(h->stream));   // `packed` goes out of scope
 	}
-	RX_HIP(hipMalloc(&d_cnt.p, size_t(nwords) * sizeof(rxgpu::FtPackedCounts)));
-	rxgpu::FtPackedCounts* d_counts = static_cast<rxgpu::FtPackedCounts*>(d_cnt.p);
+	auto len_of = [&](uint32_t k) { return off[2 * size_t(k) + 1] - off[2 * size_t(k)]; };
+	const size_t o_off = align256(size_t(total_bytes) + 16), o_afp = o_off + align256(size_t(nwords) * 16), in_bytes = o_afp + align256(size_t(nwords) * 8);
+	if (int rc = h->d_pk_in.ensure(in_bytes); rc) return rc;
+	if (int rc = h->ensure_pinned(in_bytes); rc) return rc;
+	uint8_t* hp = static_cast<uint8_t*>(h->h_pinned);
+	{   // the gather: one pass over the streams, a few threads (100 000 pieces of a few hundred bytes: one thread moves ~7 GB/s of them)
+		const unsigned nthr = total_bytes > (8u << 20) ? 4u : 1u;
+		auto work = [&](unsigned t) {
+			for (uint32_t k = uint32_t(uint64_t(nwords) * t / nthr), e = uint32_t(uint64_t(nwords) * (t + 1) / nthr); k < e; ++k) {
+				const uint64_t n = len_of(k);
+				if (n) std::memcpy(hp + off[2 * size_t(k)], data[order[k]], size_t(n));
+			}
+		};
+		std::vector<std::thread> pool;
+		for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work, t);
+		work(0);
+		for (std::thread& t : pool) t.join();
+	}
+	std::memset(hp + total_bytes, 0, 16);
+	std::memcpy(hp + o_off, off.data(), size_t(nwords) * 16);
+	std::memcpy(hp + o_afp, afp.data(), size_t(nwords) * 8);
+	uint8_t* d_bytes = static_cast<uint8_t*>(h->d_pk_in.ptr);
+	uint64_t* d_off = reinterpret_cast<uint64_t*>(d_bytes + o_off);
+	uint64_t* d_afp = reinterpret_cast<uint64_t*>(d_bytes + o_afp);
+	RX_HIP(hipMemcpyAsync(d_bytes, hp, in_bytes, hipMemcpyHostToDevice, h->stream));   // one copy from pinned memory: streams, offsets, array_found_pos
+	if (int rc = h->d_pk_cnt.ensure(size_t(nwords) * sizeof(rxgpu::FtPackedCounts)); rc) return rc;
+	rxgpu::FtPackedCounts* d_counts = static_cast<rxgpu::FtPackedCounts*>(h->d_pk_cnt.ptr);
 	// one wavefront per word (ft_packed_wave); RXGPU_FT_PACKED_THREAD=1: the one-thread-per-word kernels of round 2 (cross-check, comparison)
 	const bool wave = std::getenv("RXGPU_FT_PACKED_THREAD") == nullptr;
 	// pieces of kFtPackedSegBytes: the counting pass leaves a checkpoint in each, the writing pass runs one wavefront per piece
@@ -1371,7 +1422,7 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 		std::vector<uint32_t> seg_first(nwords + 1), seg_word;
 		seg_first[0] = 0;
 		for (uint32_t k = 0; k < nwords; ++k) {
-			const uint64_t len = off[k + 1] - off[k];
+			const uint64_t len = len_of(k);
 			const uint64_t pieces = std::max<uint64_t>(1, (len + rxgpu::kFtPackedSegBytes - 1) / rxgpu::kFtPackedSegBytes);
 			RX_CHECK(seg_first[k] + pieces < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: too many stream bytes in one call");
 			seg_first[k + 1] = uint32_t(seg_first[k] + pieces);
@@ -1381,8 +1432,8 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 		for (uint32_t k = 0; k < nwords; ++k) std::fill(seg_word.begin() + seg_first[k], seg_word.begin() + seg_first[k + 1], k);
 		const size_t o_sw = 0, o_sf = align256(size_t(nsegs) * 4), o_cp = o_sf + align256((size_t(nwords) + 1) * 4);
 		const size_t seg_bytes = o_cp + size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint);
-		RX_HIP(hipMalloc(&d_segs.p, seg_bytes));
-		char* sb = static_cast<char*>(d_segs.p);
+		if (int rc = h->d_pk_segs.ensure(seg_bytes); rc) return rc;
+		char* sb = static_cast<char*>(h->d_pk_segs.ptr);
 		RX_HIP(hipMemcpyAsync(sb + o_sw, seg_word.data(), size_t(nsegs) * 4, hipMemcpyHostToDevice, h->stream));
 		RX_HIP(hipMemcpyAsync(sb + o_sf, seg_first.data(), (size_t(nwords) + 1) * 4, hipMemcpyHostToDevice, h->stream));
 		RX_HIP(hipMemsetAsync(sb + o_cp, 0xFF, size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint), h->stream));
@@ -1456,10 +1507,10 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 		outs[k].ent_first_pos = reinterpret_cast<uint32_t*>(base + sl[k].ent_first);
 		outs[k].range_off = reinterpret_cast<uint32_t*>(base + sl[k].range_off);
 	}
-	RX_HIP(hipMalloc(&d_outs.p, size_t(nwords) * sizeof(rxgpu::FtPackedOut)));
-	RX_HIP(hipMemcpyAsync(d_outs.p, outs.data(), size_t(nwords) * sizeof(rxgpu::FtPackedOut), hipMemcpyHostToDevice, h->stream));
+	if (int rc = h->d_pk_outs.ensure(size_t(nwords) * sizeof(rxgpu::FtPackedOut)); rc) return rc;
+	RX_HIP(hipMemcpyAsync(h->d_pk_outs.ptr, outs.data(), size_t(nwords) * sizeof(rxgpu::FtPackedOut), hipMemcpyHostToDevice, h->stream));
 	RX_HIP(hipEventRecord(ev_write.a, h->stream));
-	RX_HIP(rxgpu::launch_ft_packed_write(d_bytes, d_off, d_afp, nwords, h->num_fields, static_cast<const rxgpu::FtPackedOut*>(d_outs.p), d_counts, wave ? &segs : nullptr, h->stream));
+	RX_HIP(rxgpu::launch_ft_packed_write(d_bytes, d_off, d_afp, nwords, h->num_fields, static_cast<const rxgpu::FtPackedOut*>(h->d_pk_outs.ptr), d_counts, wave ? &segs : nullptr, h->stream));
 	RX_HIP(hipEventRecord(ev_write.b, h->stream));
 	std::vector<rxgpu::FtPackedCounts> again(nwords);
 	RX_HIP(hipMemcpyAsync(again.data(), d_counts, size_t(nwords) * sizeof(rxgpu::FtPackedCounts), hipMemcpyDeviceToHost, h->stream));
@@ -1472,6 +1523,7 @@ int rxgpu_ft_set_words_packed(rxgpu_ft_index* h, uint32_t nwords, const uint32_t
 	h->packed_write_ms += ev_write.elapsed_ms();
 	h->packed_bytes_in += total_bytes;
 	h->packed_bytes_out += cv.off;
+	h->words.reserve(h->words.size() + nwords);
 	for (uint32_t k = 0; k < nwords; ++k) {
 		rxgpu_ft_word& w = h->words[word_ids[order[k]]];
 		w.release();
@@ -1503,6 +1555,14 @@ int rxgpu_ft_read_packed_stats(rxgpu_ft_index* h, double* count_ms, double* writ
 	*bytes_out = h->packed_bytes_out;
 	h->packed_count_ms = h->packed_write_ms = 0.0;
 	h->packed_bytes_in = h->packed_bytes_out = 0;
+	return RXGPU_OK;
+}
+
+int rxgpu_ft_read_packed_wall(rxgpu_ft_index* h, double* wall_ms) {
+	RX_CHECK(h && wall_ms, RXGPU_ERR_PARAMS, "rxgpu_ft_read_packed_wall: null argument");
+	std::lock_guard<std::mutex> lk(h->mtx);
+	*wall_ms = h->packed_wall_ms;
+	h->packed_wall_ms = 0.0;
 	return RXGPU_OK;
 }
 

@@ -246,8 +246,8 @@ void GpuFtMerger::SetWord(uint32_t wordId, const PositionPostings& p) {
 
 void GpuFtMerger::SetWordsPacked(const std::vector<PackedWord>& words, size_t hostDecodeFromBytes) {
 	std::vector<uint32_t> ids;
-	std::vector<uint64_t> off{0}, afp;
-	std::vector<uint8_t> bytes;
+	std::vector<const uint8_t*> data;
+	std::vector<uint64_t> len, afp;
 	for (const PackedWord& w : words) {
 		if (w.len >= hostDecodeFromBytes) {
 			PositionPostings pp;
@@ -256,12 +256,17 @@ void GpuFtMerger::SetWordsPacked(const std::vector<PackedWord>& words, size_t ho
 			continue;
 		}
 		ids.push_back(w.wordId);
-		bytes.insert(bytes.end(), w.data, w.data + w.len);
-		off.push_back(bytes.size());
+		data.push_back(w.data);
+		len.push_back(w.len);
 		afp.push_back(w.arrayFoundPos);
 	}
 	if (ids.empty()) return;
-	if (rxgpu_ft_set_words_packed(dev_, uint32_t(ids.size()), ids.data(), off.data(), bytes.data(), afp.data()) != RXGPU_OK) throwDevice("SetWordsPacked");
+	// the streams stay where the dictionary keeps them: the library gathers them once, straight into pinned staging memory
+	if (rxgpu_ft_set_words_packed_ptrs(dev_, uint32_t(ids.size()), ids.data(), data.data(), len.data(), afp.data()) != RXGPU_OK) throwDevice("SetWordsPacked");
+}
+
+void GpuFtMerger::ReadPackedWall(double& wallMs) const {
+	if (rxgpu_ft_read_packed_wall(dev_, &wallMs) != RXGPU_OK) throwDevice("ReadPackedWall");
 }
 
 void GpuFtMerger::GetWord(uint32_t wordId, PositionPostings& positions, FlatPostings& entries, std::vector<uint32_t>& rangeOff) const {

@@ -198,6 +198,8 @@ public:
 	void ReadStats(uint64_t& postings, double& kernelMs) const;
 	// SetWordsPacked: device time of the two decode kernels, stream bytes read per pass, array bytes produced, since the last call
 	void ReadPackedStats(double& countMs, double& writeMs, uint64_t& bytesIn, uint64_t& bytesOut) const;
+	// ... and the wall time spent inside the library's packed-upload calls (gather, upload, both passes, the dictionary entries), since the last call
+	void ReadPackedWall(double& wallMs) const;
 	// FuseResident: fusions, the device time of their join kernel (critical path) and of the overlapped prepare kernel since the last call
 	void ReadFuseStats(uint64_t& calls, double& kernelMs, double* prepareMs = nullptr) const;
 	// wall time spent inside Merge / MergeQuery since the last call (everything behind the Merger boundary: plan, launches, the wait,

@@ -1062,6 +1062,11 @@ extern "C" int rxhost_ft_set_words_packed(void* h, uint32_t nwords, const uint32
 		static_cast<GpuFtMerger*>(h)->SetWordsPacked(ws, hostFromBytes);
 	});
 }
+extern "C" double rxhost_ft_read_packed_wall(void* h) {
+	double ms = -1.0;
+	guarded([&] { static_cast<const GpuFtMerger*>(h)->ReadPackedWall(ms); });
+	return ms;
+}
 // a word's device arrays; sizes[4] = {n, npos, nent, nRanges}; with null arrays only the sizes
 extern "C" int rxhost_ft_get_word(void* h, uint32_t wordId, uint64_t* sizes, uint32_t* doc, uint32_t* posOff, uint64_t* fpos, uint32_t* entOff,
 								  uint8_t* entField, uint32_t* entTf, uint32_t* entFirstPos, uint32_t* rangeOff) {

@@ -489,6 +489,7 @@ class GpuHnswMap:
             L.rxhost_hnsw_save_index.restype = _l
             L.rxhost_hnsw_save_index.argtypes = [_vp, _vp, _sz]
             L.rxhost_hnsw_load_index.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
+            L.rxhost_hnsw_load_index_quantized.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
             L._hnsw_bound = True
         self.dim, self.metric = dim, metric
         create = L.rxhost_hnsw_create_mt if multithread else L.rxhost_hnsw_create
@@ -598,6 +599,7 @@ class GpuHnswMap:
         return p
 
     def switch_on_quantized(self) -> None:
+        lib().rxhost_hnsw_switch_on_quantized.argtypes = [_vp]
         rc = lib().rxhost_hnsw_switch_on_quantized(self.h)
         if rc:
             _raise(rc)
@@ -762,6 +764,13 @@ class GpuFtMerger:
         rc = L.rxhost_ft_set_words_packed(self.h, len(words), ids.ctypes.data, off.ctypes.data, blob.ctypes.data, afp.ctypes.data, host_from_bytes)
         if rc:
             _raise(rc)
+
+    def read_packed_wall(self) -> float:
+        """ms spent inside the library's packed-upload calls since the last call (the commit-side cost at the C-ABI boundary)"""
+        L = lib()
+        L.rxhost_ft_read_packed_wall.restype = C.c_double
+        L.rxhost_ft_read_packed_wall.argtypes = [_vp]
+        return float(L.rxhost_ft_read_packed_wall(self.h))
 
     def get_word(self, word_id):
         """The word's device arrays read back: dict(doc, pos_off, fpos, ent_off, ent_field, ent_tf, ent_first, range_off)."""
