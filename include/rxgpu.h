@@ -416,6 +416,16 @@ typedef struct rxgpu_ft_query {
 } rxgpu_ft_query;
 int rxgpu_ft_merge_query2_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* query, const uint8_t* excluded, uint32_t* out_doc,
 							  float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n, int32_t* out_preselected);
+/* Merger<IdCont, MergeDataAreas<Area>, ..>::Merge — the merge behind highlight() / snippet() (merger.h:36-57 with kWithRegularAreas; addAreas
+ * :196-204; AreasInDocument / AreasInField::Insert / Area::Concat, core/ft/areaholder.h:9-37, 56-155): the result of rxgpu_ft_merge_query2_raw
+ * plus, per merged document i (merge order, like out_doc) and field f, the areas its postings left: out_area_cnt[i * num_fields + f] entries
+ * of {start, end, arrayIdx} at out_areas[((i * num_fields + f) * max_areas_in_doc + j) * 3], in the order AreasInField::data_ holds them
+ * BEFORE Commit() (the engine sorts and joins them when they are read).  max_areas_in_doc = FTConfig::maxAreasInDoc (default 5), >= 1.
+ * out_area_cnt: cap * num_fields words; out_areas: cap * num_fields * max_areas_in_doc * 3 words.  Queries of plain terms (Simple() included;
+ * the words need their positions); phrases, multi-word synonyms and MergeDataAreas<AreaDebug> return RXGPU_ERR_LOGIC: the CPU merger. */
+int rxgpu_ft_merge_query_areas_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* query, const uint8_t* excluded, uint32_t max_areas_in_doc,
+								   uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n,
+								   int32_t* out_preselected, uint32_t* out_area_cnt, uint32_t* out_areas);
 /* nq queries (each as in rxgpu_ft_merge_query2_raw) over one index in ONE launch train: the kernels of the merge run with the query as the
  * second grid dimension, so the per-launch floors and the ramp of every grid are paid once per train and the device works on all the
  * queries' document ranges at a time — the form for a caller with several Merge() calls in hand (the hybrid path's query batch, T planner

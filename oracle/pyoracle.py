@@ -895,6 +895,47 @@ class RefFtSeam(RefFt):
             raise RuntimeError(self.L.ref_seam_last_error(self.h).decode(errors="replace"))
         return n
 
+    def merge_areas(self, terms, max_areas=5, excluded=None, rank_sort_type=1, cap=1 << 16, packed=True, gpu=False, area_cap=1 << 20):
+        """The merge behind highlight() / snippet(): MergedDataType = MergeDataAreas<Area>, through the reference's ft::Merger (gpu=False) or the
+        adapter the patched mergeResults calls first (gpu=True; None when it declines).  -> (ids, proc, field, norm, raw, committed): raw /
+        committed = per merged document a list over the fields of (k, 3) uint32 arrays {start, end, arrayIdx} — AreasInField::data_ as the merge
+        left it / after Commit()."""
+        nf = self.nf
+        ops = np.array([t["op"] for t in terms], np.int32)
+        boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+        tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+        fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+        ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+        phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
+        dst = np.array([t.get("distance", 1) for t in terms], np.int32)
+        sub_off, sw, sp = [0], [], []
+        for t in terms:
+            for w, p in t["subs"]:
+                sw.append(w)
+                sp.append(p)
+            sub_off.append(len(sw))
+        sub_off, sw, sp = np.array(sub_off, np.uint32), np.array(sw + [0], np.uint32), np.array(sp + [0.0], np.float32)
+        exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+        oid, op = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        of, on = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        roff, coff = np.zeros(cap * nf + 1, np.uint32), np.zeros(cap * nf + 1, np.uint32)
+        ra, ca = np.zeros((area_cap, 3), np.uint32), np.zeros((area_cap, 3), np.uint32)
+        fn = self.L.ref_seam_merge_areas
+        fn.restype = C.c_long
+        fn.argtypes = [_vp, _i, _i, _i, _sz] + [_vp] * 11 + [_i, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz]
+        n = fn(self.h, int(packed), int(gpu), int(max_areas), len(terms), ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data,
+               phr.ctypes.data, dst.ctypes.data, sub_off.ctypes.data, sw.ctypes.data, sp.ctypes.data, exc.ctypes.data if exc is not None else None,
+               rank_sort_type, oid.ctypes.data, op.ctypes.data, of.ctypes.data, on.ctypes.data, cap, roff.ctypes.data, ra.ctypes.data, coff.ctypes.data,
+               ca.ctypes.data, area_cap)
+        if n == -2:
+            return None
+        if n < 0:
+            raise RuntimeError(self.L.ref_seam_last_error(self.h).decode(errors="replace"))
+        assert n <= cap
+        raw = [[ra[roff[i * nf + f]:roff[i * nf + f + 1]].copy() for f in range(nf)] for i in range(n)]
+        com = [[ca[coff[i * nf + f]:coff[i * nf + f + 1]].copy() for f in range(nf)] for i in range(n)]
+        return oid[:n].copy(), op[:n].copy(), of[:n].copy(), on[:n].copy(), raw, com
+
     def merge(self, terms, excluded=None, rank_sort_type=1, cap=1 << 16, packed=True, gpu=False, synonyms=None, part_synonyms=None):
         nf = self.nf
         n_part_terms = len(terms)

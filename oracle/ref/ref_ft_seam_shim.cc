@@ -54,11 +54,12 @@ const std::vector<PackedWordEntry<IdCont>>& wordsOf(const SeamRef& f) {
 	}
 }
 
-template <typename IdCont>
-long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+// the query as Selector::Process hands it to mergeResults + the docsExcluded statuses, then fn(query, statuses)
+template <typename IdCont, typename Fn>
+long withQuery(SeamRef* f, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
 			   const uint8_t* needSum, const int* phraseNum, const int* distance, size_t nSynTerms, size_t nSyn, const uint32_t* synTermOff,
 			   const uint32_t* partSynOff, const uint32_t* partSyn, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
-			   int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
+			   Fn&& fn) {
 	const auto& words = wordsOf<IdCont>(*f);
 	ft::QueryMergeData<IdCont> q;
 	// query parts as Selector::Process puts them together (selecterimpl.h:482-572): terms with the same phraseNum >= 0 -> one PhraseResults
@@ -146,6 +147,16 @@ long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float*
 			if (excluded[i]) st.set(i);
 		}
 	}
+	return fn(q, st);
+}
+
+template <typename IdCont>
+long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+			   const uint8_t* needSum, const int* phraseNum, const int* distance, size_t nSynTerms, size_t nSyn, const uint32_t* synTermOff,
+			   const uint32_t* partSynOff, const uint32_t* partSyn, const uint32_t* subOff, const uint32_t* subWord, const float* subProc, const uint8_t* excluded,
+			   int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap) {
+	return withQuery<IdCont>(f, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, nSynTerms, nSyn, synTermOff, partSynOff, partSyn, subOff,
+							 subWord, subProc, excluded, [&](ft::QueryMergeData<IdCont>& q, FtMergeStatuses::Statuses& st) -> long {
 	bool declined = false;
 	auto run = [&]() -> ft::MergeData {
 		ft::MergeData out;
@@ -173,6 +184,76 @@ long mergeImpl(SeamRef* f, bool gpu, size_t nTerms, const int* ops, const float*
 		outNorm[i] = md[i].normalizedProc;
 	}
 	return long(md.size());
+	});
+}
+
+// The merge behind highlight() / snippet(): MergedDataType = MergeDataAreas<Area> (selecterimpl.h:611-628 with that instantiation).  gpu: the
+// adapter the patched mergeResults calls first; else the reference's ft::Merger.  Per merged document i and field fld the areas come back twice:
+// raw (AreasInField::data_ as the merge left it, GetAreasRaw) and committed (GetAreas: sorted by start, neighbours joined — what the engine
+// reads): areaOff [2][n * nf + 1] into areas [..][3] = start, end, arrayIdx.
+template <typename IdCont>
+long mergeAreasImpl(SeamRef* f, bool gpu, int maxAreasInDoc, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost,
+					const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord, const float* subProc,
+					const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm, size_t cap,
+					uint32_t* rawOff, uint32_t* rawAreas, uint32_t* comOff, uint32_t* comAreas, size_t areaCap) {
+	return withQuery<IdCont>(f, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, 0, 0, nullptr, nullptr, nullptr, subOff, subWord, subProc,
+							 excluded, [&](ft::QueryMergeData<IdCont>& q, FtMergeStatuses::Statuses& st) -> long {
+		using MD = ft::MergeDataAreas<Area>;
+		bool declined = false;
+		auto run = [&]() -> MD {
+			if (gpu) {
+				MD out;
+				const auto& mirror = std::is_same_v<IdCont, PackedIdRelVec> ? f->packedMirror : f->plainMirror;
+				declined = !rxgpu::host::TryMergeOnGpu(mirror.get(), f->cfg, f->totalDocs, q, RankSortType(rankSortType), st, /*inTransaction*/ false, out, maxAreasInDoc);
+				return out;
+			}
+			RdxContext ctx;
+			ft::Merger<IdCont, MD, uint32_t> merger(f->totalDocs, &f->cfg, st, f->nf, maxAreasInDoc, /*inTransaction*/ true, ctx);
+			const Stats stats = f->stats();
+			switch (f->cfg.bm25Config.bm25Type) {
+				case FTConfig::Bm25Config::Bm25Type::classic: return merger.template Merge<Bm25Classic>(q, RankSortType(rankSortType), stats);
+				case FTConfig::Bm25Config::Bm25Type::wordCount: return merger.template Merge<TermCount>(q, RankSortType(rankSortType), stats);
+				case FTConfig::Bm25Config::Bm25Type::rx: break;
+			}
+			return merger.template Merge<Bm25Rx>(q, RankSortType(rankSortType), stats);
+		};
+		MD md = run();
+		if (declined) return -2;
+		size_t nRaw = 0, nCom = 0;
+		rawOff[0] = comOff[0] = 0;
+		for (size_t i = 0; i < md.size() && i < cap; ++i) {
+			outId[i] = md[i].id.ToNumber();
+			outProc[i] = md[i].proc;
+			outField[i] = md[i].field;
+			outNorm[i] = md[i].normalizedProc;
+			auto& doc = md.vectorAreas.at(md[i].areaIndex);
+			for (size_t fld = 0; fld < f->nf; ++fld) {
+				if (const auto* raw = doc.GetAreasRaw(unsigned(fld))) {
+					for (const Area& a : raw->GetData()) {
+						if (nRaw >= areaCap) throw std::runtime_error("area buffer too small");
+						rawAreas[nRaw * 3] = a.start;
+						rawAreas[nRaw * 3 + 1] = a.end;
+						rawAreas[nRaw * 3 + 2] = a.arrayIdx;
+						++nRaw;
+					}
+				}
+				rawOff[i * f->nf + fld + 1] = uint32_t(nRaw);
+			}
+			for (size_t fld = 0; fld < f->nf; ++fld) {
+				if (const auto* com = doc.GetAreas(unsigned(fld))) {   // commits
+					for (const Area& a : com->GetData()) {
+						if (nCom >= areaCap) throw std::runtime_error("area buffer too small");
+						comAreas[nCom * 3] = a.start;
+						comAreas[nCom * 3 + 1] = a.end;
+						comAreas[nCom * 3 + 2] = a.arrayIdx;
+						++nCom;
+					}
+				}
+				comOff[i * f->nf + fld + 1] = uint32_t(nCom);
+			}
+		}
+		return long(md.size());
+	});
 }
 
 }  // namespace
@@ -277,6 +358,23 @@ long ref_seam_merge_full(void* h, int packed, int gpu, size_t nTerms, size_t nSy
 		}
 		return mergeImpl<IdRelVec>(f, gpu != 0, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, nSynTerms, nSyn, synTermOff, partSynOff,
 								   partSyn, subOff, subWord, subProc, excluded, rankSortType, outId, outProc, outField, outNorm, cap);
+	} catch (const std::exception& e) {
+		f->error = e.what();
+		return -1;
+	}
+}
+long ref_seam_merge_areas(void* h, int packed, int gpu, int maxAreasInDoc, size_t nTerms, const int* ops, const float* boosts, const float* termLenBoosts,
+						  const float* fieldBoost, const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* subWord,
+						  const float* subProc, const uint8_t* excluded, int rankSortType, int32_t* outId, float* outProc, uint8_t* outField, uint8_t* outNorm,
+						  size_t cap, uint32_t* rawOff, uint32_t* rawAreas, uint32_t* comOff, uint32_t* comAreas, size_t areaCap) {
+	auto* f = static_cast<SeamRef*>(h);
+	try {
+		if (packed) {
+			return mergeAreasImpl<PackedIdRelVec>(f, gpu != 0, maxAreasInDoc, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord,
+												  subProc, excluded, rankSortType, outId, outProc, outField, outNorm, cap, rawOff, rawAreas, comOff, comAreas, areaCap);
+		}
+		return mergeAreasImpl<IdRelVec>(f, gpu != 0, maxAreasInDoc, nTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, phraseNum, distance, subOff, subWord, subProc,
+										excluded, rankSortType, outId, outProc, outField, outNorm, cap, rawOff, rawAreas, comOff, comAreas, areaCap);
 	} catch (const std::exception& e) {
 		f->error = e.what();
 		return -1;

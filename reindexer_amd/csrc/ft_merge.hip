@@ -1025,6 +1025,57 @@ __device__ __forceinline__ void ft_replay_locate(FtPlanK& p, uint32_t row, uint3
 	pos = fpos + po0;
 	npos = po1 - po0;
 }
+// addAreas (merger.h:196-204) for one posting of merged document `sl`: every position -> AreasInDocument::AddWord(Area(pos, pos + 1, arrayIdx),
+// field, rank, maxAreasInDoc) until one is refused, then UpdateRank(rank) (areaholder.h:125-132, 76-95).  AreasInField::Insert: the new word
+// joins the area inserted last when Area::Concat says so (same array index, touching or overlapping, :14-29); otherwise it is appended while
+// fewer than maxAreasInDoc areas are held, and once they are it overwrites the oldest in turn — only for a term rank above the best the
+// document has seen (maxTermRank_), else the word is refused and the rest of the posting skipped.  The areas of a (document, field) are
+// the thread's own words in HBM: one thread replays one document.
+__device__ __forceinline__ void ft_areas_of_posting(FtPlanK& p, uint32_t sl, const uint64_t* pos, uint32_t npos, float rank, float& max_term_rank) {
+	const uint32_t nf = p.area_fields, cap = p.max_areas;
+	for (uint32_t i = 0; i < npos; ++i) {
+		const uint64_t w = pos[i];
+		const uint32_t wpos = uint32_t(w) & 0x0FFFFFFFu, arr = uint32_t(w >> 28) & 0x0FFFFFFFu, field = uint32_t(w >> 56);
+		if (field >= nf) break;   // (cannot happen: the upload checks fields)
+		uint32_t* hdr = p.area_hdr + (size_t(sl) * nf + field) * 2;
+		uint32_t* areas = p.out_areas + (size_t(sl) * nf + field) * cap * 3;
+		const uint32_t held = hdr[0], index = hdr[1];
+		const uint32_t a_start = wpos, a_end = wpos + 1;
+		bool ok = false;
+		if (index > 0) {   // Concat with the area inserted last
+			uint32_t* prev = areas + size_t((index - 1) % cap) * 3;
+			const uint32_t ps = prev[0], pe = prev[1];
+			if (prev[2] == arr && ((a_start <= pe && a_start >= ps) || (a_end <= pe && a_end >= ps) || (ps > a_start && pe < a_end))) {
+				if (ps > a_start) prev[0] = a_start;
+				if (pe < a_end) prev[1] = a_end;
+				ok = true;
+			}
+		}
+		if (!ok) {
+			if (held == cap) {
+				if (rank > max_term_rank) {
+					uint32_t* slot = areas + size_t(index % cap) * 3;
+					slot[0] = a_start;
+					slot[1] = a_end;
+					slot[2] = arr;
+					hdr[1] = index + 1;
+					ok = true;
+				}
+			} else {
+				uint32_t* slot = areas + size_t(held) * 3;
+				slot[0] = a_start;
+				slot[1] = a_end;
+				slot[2] = arr;
+				hdr[0] = held + 1;
+				hdr[1] = index + 1;
+				ok = true;
+			}
+		}
+		if (!ok) break;
+	}
+	if (rank > max_term_rank) max_term_rank = rank;
+}
+
 // one posting of the document, met in sub-term order: rank r in field fld, positions `pos` (not read for a simple merge)
 // (qpw = ft_row_qpw of the posting's row: the query position, whether the row is a phrase's, the last plain term in front of that phrase)
 template <typename Pos>
@@ -1119,10 +1170,11 @@ __device__ __forceinline__ void ft_replay_apply(FtPlanK& p, FtReplayStateT<Pos>&
 	}
 }
 __device__ __forceinline__ void ft_replay_step(FtPlanK& p, FtReplayState& st, uint32_t row, float r, uint8_t fld, uint32_t i, const uint64_t* const* s_fpos,
-											   const uint32_t* const* s_pos_off, const uint32_t* s_qp) {
+											   const uint32_t* const* s_pos_off, const uint32_t* s_qp, uint32_t sl, float& max_term_rank) {
 	uint32_t qp = 0;
 	FtPosList pos;
-	if (!p.simple) ft_replay_locate(p, row, i, s_fpos, s_pos_off, s_qp, qp, pos.ptr, pos.n);
+	if (!p.simple || p.max_areas) ft_replay_locate(p, row, i, s_fpos, s_pos_off, s_qp, qp, pos.ptr, pos.n);
+	if (p.max_areas && __float_as_uint(r) != kFtSuppressedRank) ft_areas_of_posting(p, sl, pos.ptr, pos.n, r, max_term_rank);
 	ft_replay_apply(p, st, r, fld, qp, pos);
 }
 // addFullMatchBoost (merger.h:100-109): a document whose best field holds exactly as many words as the query has parts — and, for a
@@ -1153,6 +1205,7 @@ __device__ __forceinline__ void ft_replay_finish(FtPlanK& p, FtReplayStateT<Pos>
 __device__ __forceinline__ void ft_replay_doc(FtPlanK& p, uint32_t sl, uint32_t doc, const uint64_t* const* s_fpos, const uint32_t* const* s_pos_off,
 											  const uint32_t* s_qp) {
 	FtReplayState st;
+	float max_term_rank = 0.f;   // AreasInDocument::maxTermRank_
 	// Most documents meet ONE sub-term, a few two or three, out of many: each lane first collects WHICH of its rows are occupied (rank
 	// loads, 64 rows per mask word) and then walks only those, in row order = the order mergeTerm met the postings.
 	for (uint32_t row0 = 0; row0 < p.n_rows; row0 += 64) {
@@ -1169,7 +1222,7 @@ __device__ __forceinline__ void ft_replay_doc(FtPlanK& p, uint32_t sl, uint32_t 
 			const uint32_t row = row0 + uint32_t(__ffsll((long long)occupied) - 1);
 			occupied &= occupied - 1;
 			const uint64_t cell = uint64_t(row) * p.max_merged + sl;
-			ft_replay_step(p, st, row, p.e_rank[cell], p.e_field[cell], p.simple ? 0u : p.e_idx[cell], s_fpos, s_pos_off, s_qp);
+			ft_replay_step(p, st, row, p.e_rank[cell], p.e_field[cell], (p.simple && !p.max_areas) ? 0u : p.e_idx[cell], s_fpos, s_pos_off, s_qp, sl, max_term_rank);
 		}
 	}
 	ft_replay_finish(p, st, sl, doc);
@@ -1469,7 +1522,15 @@ __global__ __launch_bounds__(256) void ft_finish(const FtPlan* plans) {
 					const uint4 o = s_rec[key[k] & 0xFFFFu];
 					pr[k] = __uint_as_float(o.z);
 					pf[k] = uint8_t((o.w >> 16) & 0xFFu);
-					if (!p.simple) ft_replay_locate(p, key[k] >> 16, o.y, s_fpos, s_pos_off, s_qp, pq[k], pp[k], pn[k]);
+					if (!p.simple || p.max_areas) ft_replay_locate(p, key[k] >> 16, o.y, s_fpos, s_pos_off, s_qp, pq[k], pp[k], pn[k]);
+				}
+				if (p.max_areas) {   // MergeDataAreas: the document's areas from its postings in merge order (before the ranks: independent of them)
+					float max_term_rank = 0.f;
+					const uint32_t sl_a = slot_of(dl);
+#pragma unroll
+					for (uint32_t k = 0; k < kFtSparsePostings; ++k) {
+						if (k < cnt && __float_as_uint(pr[k]) != kFtSuppressedRank) ft_areas_of_posting(p, sl_a, pp[k], pn[k], pr[k], max_term_rank);
+					}
 				}
 				uint32_t longest = 0;
 #pragma unroll

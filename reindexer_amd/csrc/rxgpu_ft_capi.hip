@@ -92,6 +92,7 @@ struct rxgpu_ft_index {
 	hipStream_t stream = nullptr;
 	rxgpu_devbuf d_state, d_out;   // per-merge scratch (plan + tables) and the packed result
 	rxgpu_devbuf d_excl;           // docsExcluded of the running merge
+	rxgpu_devbuf d_areas;          // MergeDataAreas: per merged document and field {held, insertions} + the areas themselves
 	rxgpu_devbuf d_pk_in, d_pk_cnt, d_pk_segs, d_pk_outs;   // rxgpu_ft_set_words_packed: streams + offsets, counts, pieces, slices (kept and grown)
 	std::vector<rxgpu_devbuf> d_phrase_a, d_phrase_b;   // per phrase of a query: plan + admission slots, workspace + the packed rows
 	hipEvent_t ev_pha = nullptr, ev_phb = nullptr;      // around the phrase kernels
@@ -210,7 +211,7 @@ int rxgpu_ft_create(uint32_t num_fields, int device, rxgpu_ft_index** out) {
 
 namespace {
 void release_lane(rxgpu_ft_index* h) {   // what a lane owns: stream, scratch, staging, events
-	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse, &h->d_excl, &h->d_pk_in, &h->d_pk_cnt, &h->d_pk_segs, &h->d_pk_outs}) b->release();
+	for (rxgpu_devbuf* b : {&h->d_state, &h->d_out, &h->d_clean, &h->d_fuse, &h->d_excl, &h->d_areas, &h->d_pk_in, &h->d_pk_cnt, &h->d_pk_segs, &h->d_pk_outs}) b->release();
 	for (rxgpu_devbuf& b : h->d_phrase_a) b.release();
 	for (rxgpu_devbuf& b : h->d_phrase_b) b.release();
 	for (hipEvent_t e : {h->ev_knn, h->ev_fa, h->ev_fb, h->ev_pa, h->ev_pb, h->ev_pha, h->ev_phb}) {
@@ -762,6 +763,13 @@ int finish_pending(rxgpu_ft_index* h, const char* who) {
 	return RXGPU_OK;
 }
 
+// MergeDataAreas<Area>: what the caller wants back besides the merged documents (rxgpu_ft_merge_query_areas_raw)
+struct AreasOut {
+	uint32_t max_areas = 0;      // FTConfig::maxAreasInDoc
+	uint32_t* cnt = nullptr;     // [cap][num_fields]
+	uint32_t* areas = nullptr;   // [cap][num_fields][max_areas][3]
+};
+
 // One merge between the building of its plan and the unpacking of its result.
 struct MergeJob {
 	rxgpu::FtPlan p{};
@@ -772,6 +780,7 @@ struct MergeJob {
 	void* hp_dev = nullptr;                  // the lane's pinned staging buffer as the device sees it
 	uint32_t nsyn = 0;
 	bool empty = false;                      // min(mergeLimit, totalORVids) == 0: nothing is merged
+	size_t area_hdr_bytes = 0, area_bytes = 0;   // MergeDataAreas: the two regions of the lane's d_areas
 };
 
 // First half of a merge: the plan (sub-terms, per-part configuration, posting-side grid), the lane's scratch, the plan staged in the lane's
@@ -779,7 +788,7 @@ struct MergeJob {
 // enqueued on `st`: the lane's own stream for a single merge, the batch stream when Q lanes' merges go into one train.
 int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 				  const float* procs, const uint8_t* excluded, bool have_outs, uint64_t cap, const char* who, bool resident, const SynonymsIn* synonyms,
-				  MergeJob& job, bool import_now) {
+				  MergeJob& job, bool import_now, uint32_t max_areas = 0) {
 	using clk = std::chrono::steady_clock;
 	const auto t_begin = clk::now();
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
@@ -1001,6 +1010,13 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	const uint64_t nwords = (N + 31) / 32;
 	const size_t M = size_t(max_merged);
 
+	if (max_areas) {   // MergeDataAreas<Area>: plain terms only (a phrase's areas come out of the PhraseMerger's position chains, phrasemerger.h:147-181)
+		RX_CHECK(!resident && !nsyn, RXGPU_ERR_LOGIC, std::string(who) + ": areas are built for queries of plain terms (no multi-word synonyms, no resident form)");
+		for (const QueryPartIn& part : parts) RX_CHECK(!part.phrase, RXGPU_ERR_LOGIC, std::string(who) + ": a phrase's areas stay on the CPU merger");
+		for (const rxgpu::FtPosSubterm& ft : subs) {
+			RX_CHECK(ft.n == 0 || ft.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": areas need the words' positions (rxgpu_ft_set_word_positions)");
+		}
+	}
 	h->trace_us[0] += since(t_begin);
 	const auto t_stage = clk::now();
 	// ---- device scratch (one buffer each for the state and for the packed result)
@@ -1141,6 +1157,16 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));
 	p.out_terms_counter = reinterpret_cast<uint16_t*>(ob + align256(16) + 2 * align256(M * 4));
 	p.out_field = reinterpret_cast<uint8_t*>(ob + align256(16) + 2 * align256(M * 4) + align256(M * 2));
+	if (max_areas) {
+		job.area_hdr_bytes = align256(M * nf * 2 * sizeof(uint32_t));
+		job.area_bytes = M * nf * size_t(max_areas) * 3 * sizeof(uint32_t);
+		if (int rc = h->d_areas.ensure(job.area_hdr_bytes + job.area_bytes); rc) return rc;
+		RX_HIP(hipMemsetAsync(h->d_areas.ptr, 0, job.area_hdr_bytes, st));
+		p.max_areas = max_areas;
+		p.area_fields = nf;
+		p.area_hdr = static_cast<uint32_t*>(h->d_areas.ptr);
+		p.out_areas = reinterpret_cast<uint32_t*>(static_cast<char*>(h->d_areas.ptr) + job.area_hdr_bytes);
+	}
 
 	std::memcpy(hp + o_plan_self, &p, sizeof(p));
 	job.d_plan = reinterpret_cast<const rxgpu::FtPlan*>(base + o_plan_self);
@@ -1194,14 +1220,15 @@ int collect_merge(rxgpu_ft_index* h, const MergeJob& job, uint32_t* out_doc, flo
 // Shared implementation of rxgpu_ft_merge_simple_raw / rxgpu_ft_merge_terms_raw.  out_terms_counter may be null (simple).
 int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
-			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false, const SynonymsIn* synonyms = nullptr) {
+			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false, const SynonymsIn* synonyms = nullptr,
+			  const AreasOut* areas = nullptr) {
 	using clk = std::chrono::steady_clock;
 	if (int rc = finish_pending(h, who); rc) return rc;
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
 	hipStream_t st = h->stream;
 	MergeJob job;
 	if (int rc = prepare_merge(h, st, cfg, simple, terms, word_ids, procs, excluded, out_doc && out_proc && out_field && (simple || out_terms_counter), cap, who,
-							   resident, synonyms, job, true);
+							   resident, synonyms, job, true, areas ? areas->max_areas : 0u);
 		rc)
 		return rc;
 	if (job.empty) return RXGPU_OK;
@@ -1227,6 +1254,12 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		return RXGPU_OK;
 	}
 	RX_HIP(rxgpu::launch_ft_export(job.d_plan, &job.p, 1, st));
+	std::vector<uint32_t> area_hdr;
+	if (areas) {   // {held, insertions} per (document, field) and the areas, as the replay left them (the wait below covers the copies)
+		area_hdr.resize(size_t(max_merged) * h->num_fields * 2);
+		RX_HIP(hipMemcpyAsync(area_hdr.data(), job.p.area_hdr, area_hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		RX_HIP(hipMemcpyAsync(areas->areas, job.p.out_areas, job.area_bytes, hipMemcpyDeviceToHost, st));
+	}
 	h->trace_us[2] += since(t_launch);
 	const auto t_wait = clk::now();
 	// (the result is already on its way: ft_export, the last kernel of the train, writes it into the pinned staging buffer)
@@ -1260,6 +1293,13 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	h->stat_postings += merged_postings;
 	h->stat_ms += ms;
 	if (int rc = collect_merge(h, job, out_doc, out_proc, out_field, out_terms_counter, out_n, out_preselected, who); rc) return rc;
+	if (areas) {
+		RX_HIP(hipStreamSynchronize(st));   // (the polling above may have ended on the export kernel: the two copies behind it too, now)
+		const size_t nf = h->num_fields;
+		for (uint64_t i = 0; i < *out_n; ++i) {
+			for (size_t f = 0; f < nf; ++f) areas->cnt[i * nf + f] = area_hdr[(i * nf + f) * 2];
+		}
+	}
 	h->trace_us[4] += since(t_unpack);
 	h->trace_us[5] += 1;
 	return RXGPU_OK;
@@ -1703,6 +1743,34 @@ int rxgpu_ft_merge_query2_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 	DevGuard dg(h->device);
 	return run_merge(ll.lane, cfg, simple, terms, q->word_ids, q->procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who,
 					 false, q->nsyn ? &syn : nullptr);
+}
+
+// Merger<IdCont, MergeDataAreas<Area>, ...>::Merge (merger.h:36-57 with kWithRegularAreas): the merge of rxgpu_ft_merge_query2_raw plus, per merged
+// document and field, the areas its postings left — what highlight() / snippet() read.
+int rxgpu_ft_merge_query_areas_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* q, const uint8_t* excluded, uint32_t max_areas_in_doc,
+								   uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter, uint64_t cap, uint64_t* out_n,
+								   int32_t* out_preselected, uint32_t* out_area_cnt, uint32_t* out_areas) {
+	const char* who = "rxgpu_ft_merge_query_areas_raw";
+	RX_CHECK(h && cfg && q && out_n && out_area_cnt && out_areas, RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	*out_n = 0;
+	if (out_preselected) *out_preselected = 0;
+	RX_CHECK(max_areas_in_doc >= 1 && max_areas_in_doc <= 4096, RXGPU_ERR_PARAMS, std::string(who) + ": max_areas_in_doc must be in [1, 4096] (FTConfig::maxAreasInDoc; unlimited areas stay on the CPU merger)");
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, std::string(who) + ": field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
+	RX_CHECK(q->nsyn == 0 && q->nsyn_terms == 0, RXGPU_ERR_LOGIC, std::string(who) + ": areas are built for queries without multi-word synonyms");
+	std::vector<QueryTermIn> terms;
+	bool empty = false, simple = false;
+	if (int rc = query_terms(who, q->nterms, q->ops, q->opts, q->phrase_num, q->distance, q->sub_off, q->word_ids, q->procs, terms, &empty, &simple); rc) return rc;
+	if (empty) return RXGPU_OK;
+	LaneLock ll;
+	if (int rc = checkout_lane(h, ll); rc) return rc;
+	DevGuard dg(h->device);
+	AreasOut ao;
+	ao.max_areas = max_areas_in_doc;
+	ao.cnt = out_area_cnt;
+	ao.areas = out_areas;
+	return run_merge(ll.lane, cfg, simple, terms, q->word_ids, q->procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who,
+					 false, nullptr, &ao);
 }
 
 // Q queries over one index in ONE launch train (ft_merge.hip: grid.y = query).  The launch floors and the ramp of every kernel's grid are

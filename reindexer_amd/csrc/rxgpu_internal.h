@@ -253,6 +253,13 @@ struct FtPlan {
 	float* out_proc;
 	uint16_t* out_terms_counter;
 	uint8_t* out_field;
+	// MergeDataAreas<Area> (merger.h:39-41, 182-204; areaholder.h:56-155): the highlight / snippet areas of every merged document, built by the
+	// replay from the positions of the document's postings in merge order.  max_areas = FTConfig::maxAreasInDoc (> 0), 0: no areas.
+	// area_hdr [max_merged][area_fields][2] = {entries held (AreasInField::data_.size()), insertions so far (index_)}, zeroed by the host in
+	// front of the train; out_areas [max_merged][area_fields][max_areas][3] = {start, end, arrayIdx} in data_ order.
+	uint32_t max_areas, area_fields;
+	uint32_t* area_hdr;
+	uint32_t* out_areas;
 };
 enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6, kFtSyncDoneFinish = 9, kFtSyncWords = 16 };
 constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;

@@ -209,10 +209,13 @@ MergeData GpuFtMerger::mergeImpl(const FtConfig& cfg, const FtDslOpts& termOpts,
 	return out;
 }
 
-void GpuFtMerger::postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const {
-	// postProcessResults — merger.h:111-155
+namespace {
+// postProcessResults — merger.h:111-155 (the same for MergeInfo and MergeInfoAreas: the areas stay where they are, areaIndex travels)
+template <typename Vec>
+void postProcessImpl(const FtConfig& cfg, Vec& out, RankSortType rankSortType) {
+	using Info = typename Vec::value_type;
 	float maxProc = 0.0f;
-	for (const MergeInfo& md : out) maxProc = std::max(maxProc, md.proc);
+	for (const Info& md : out) maxProc = std::max(maxProc, md.proc);
 	const float scalingFactor = float(maxProc > 255 ? 255.0 / double(maxProc) : 1.0);
 	const float minProc = float(cfg.minRank);
 	size_t passed = out.size();
@@ -225,20 +228,25 @@ void GpuFtMerger::postProcess(const FtConfig& cfg, MergeData& out, RankSortType 
 		}
 	}
 	out.resize(passed);
-	for (MergeInfo& md : out) {
+	for (Info& md : out) {
 		md.normalizedProc = uint8_t(md.proc * scalingFactor);
 		md.proc = md.normalizedProc;
 	}
 	if (rankSortType == RankSortType::RankOnly || rankSortType == RankSortType::IDAndPositions) {
 		// the key is one byte: a stable counting sort (descending) gives exactly what a stable comparison sort would, in O(n)
 		size_t start[257] = {0};
-		for (const MergeInfo& md : out) ++start[255 - md.normalizedProc + 1];
+		for (const Info& md : out) ++start[255 - md.normalizedProc + 1];
 		for (int b = 0; b < 256; ++b) start[b + 1] += start[b];
-		MergeData sorted(out.size());
-		for (const MergeInfo& md : out) sorted[start[255 - md.normalizedProc]++] = md;
-		out.swap(sorted);
+		std::vector<Info> sorted(out.size());
+		for (const Info& md : out) sorted[start[255 - md.normalizedProc]++] = md;
+		std::copy(sorted.begin(), sorted.end(), out.begin());
 	}
 }
+}  // namespace
+
+void GpuFtMerger::postProcess(const FtConfig& cfg, MergeDataAreas& out, RankSortType rankSortType) const { postProcessImpl(cfg, out, rankSortType); }
+
+void GpuFtMerger::postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const { postProcessImpl(cfg, out, rankSortType); }
 
 void GpuFtMerger::SetWord(uint32_t wordId, const PositionPostings& p) {
 	if (rxgpu_ft_set_word_positions(dev_, wordId, p.doc.size(), p.doc.data(), p.posOff.data(), p.fpos.data()) != RXGPU_OK) throwDevice("SetWord");
@@ -646,6 +654,103 @@ std::vector<MergeData> GpuFtMerger::MergeQueryBatch(const FtConfig& cfg, std::ve
 		}
 		postProcess(cfg, md, rankSortType);
 	}
+	return out;
+}
+
+MergeDataAreas GpuFtMerger::MergeQueryAreas(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
+											int maxAreasInDoc, bool* preselected) const {
+	CallTimer timer{timedCalls_, timedNs_};
+	if (preselected) *preselected = false;
+	MergeDataAreas out;
+	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return out;   // Empty() / mergerimpl.h:472-474
+	if (cfg.fieldsCfg.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
+	bool anyPhrase = false;
+	for (const QueryTerm& t : terms) anyPhrase = anyPhrase || t.phraseNum >= 0;
+	if (!SupportsAreas(terms.size(), anyPhrase, false, maxAreasInDoc)) throw std::logic_error("GpuFtMerger::MergeQueryAreas: this query's areas are built by the CPU merger (SupportsAreas)");
+	const size_t nt = terms.size();
+	std::vector<double> bm25Boost(numFields_), bm25Weight(numFields_), tlBoost(numFields_), tlWeight(numFields_), posBoost(numFields_), posWeight(numFields_);
+	for (size_t f = 0; f < numFields_; ++f) {
+		bm25Boost[f] = cfg.fieldsCfg[f].bm25Boost;
+		bm25Weight[f] = cfg.fieldsCfg[f].bm25Weight;
+		tlBoost[f] = cfg.fieldsCfg[f].termLenBoost;
+		tlWeight[f] = cfg.fieldsCfg[f].termLenWeight;
+		posBoost[f] = cfg.fieldsCfg[f].positionBoost;
+		posWeight[f] = cfg.fieldsCfg[f].positionWeight;
+	}
+	rxgpu_ft_config c{};
+	c.bm25_type = cfg.bm25Type == FtConfig::Bm25Type::Rx ? 0 : (cfg.bm25Type == FtConfig::Bm25Type::Classic ? 1 : 2);
+	c.bm25_k1 = cfg.bm25k1;
+	c.bm25_b = cfg.bm25b;
+	c.summation_ranks_by_fields_ratio = cfg.summationRanksByFieldsRatio;
+	c.full_match_boost = cfg.fullMatchBoost;
+	c.min_rank = cfg.minRank;
+	c.merge_limit = cfg.mergeLimit;
+	c.num_fields = uint32_t(numFields_);
+	c.bm25_boost = bm25Boost.data();
+	c.bm25_weight = bm25Weight.data();
+	c.term_len_boost = tlBoost.data();
+	c.term_len_weight = tlWeight.data();
+	c.position_boost = posBoost.data();
+	c.position_weight = posWeight.data();
+	c.distance_boost = cfg.distanceBoost;
+	c.distance_weight = cfg.distanceWeight;
+	std::vector<int32_t> ops(nt);
+	std::vector<float> fieldBoost(nt * numFields_), procs;
+	std::vector<uint8_t> needSum(nt * numFields_);
+	std::vector<rxgpu_ft_term_opts> opts(nt);
+	std::vector<uint32_t> subOff(nt + 1, 0), wordIds;
+	for (size_t t = 0; t < nt; ++t) {
+		QueryTerm& qt = terms[t];
+		if (qt.opts.fieldsOpts.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
+		ops[t] = int32_t(qt.op);
+		for (size_t f = 0; f < numFields_; ++f) {
+			fieldBoost[t * numFields_ + f] = qt.opts.fieldsOpts[f].boost;
+			needSum[t * numFields_ + f] = qt.opts.fieldsOpts[f].needSumRank ? 1 : 0;
+		}
+		opts[t] = rxgpu_ft_term_opts{qt.opts.boost, qt.opts.termLenBoost, fieldBoost.data() + t * numFields_, needSum.data() + t * numFields_};
+		std::stable_sort(qt.subterms.begin(), qt.subterms.end(), [](const SubtermRef& l, const SubtermRef& r) { return l.proc > r.proc; });   // SortSubterms
+		for (const SubtermRef& sr : qt.subterms) {
+			wordIds.push_back(sr.wordId);
+			procs.push_back(sr.proc);
+		}
+		subOff[t + 1] = uint32_t(wordIds.size());
+	}
+	rxgpu_ft_query q{};
+	q.nterms = uint32_t(nt);
+	q.ops = ops.data();
+	q.opts = opts.data();
+	q.sub_off = subOff.data();
+	q.word_ids = wordIds.data();
+	q.procs = procs.data();
+	const size_t cap = cfg.mergeLimit, nf = numFields_, maxA = size_t(maxAreasInDoc);
+	std::vector<uint32_t> doc(cap), areaCnt(cap * nf), areas(cap * nf * maxA * 3);
+	std::vector<float> proc(cap);
+	std::vector<uint8_t> field(cap);
+	std::vector<uint16_t> termsCounter(cap);
+	uint64_t n = 0;
+	int32_t pre = 0;
+	if (rxgpu_ft_merge_query_areas_raw(dev_, &c, &q, docsExcluded, uint32_t(maxAreasInDoc), doc.data(), proc.data(), field.data(), termsCounter.data(), cap, &n, &pre,
+									   areaCnt.data(), areas.data()) != RXGPU_OK) {
+		throwDevice("MergeQueryAreas");
+	}
+	if (preselected) *preselected = pre != 0;
+	out.resize(n);
+	out.vectorAreas.resize(n);
+	for (uint64_t i = 0; i < n; ++i) {
+		out[i].id = int32_t(doc[i]);
+		out[i].proc = proc[i];
+		out[i].field = field[i];
+		out[i].areaIndex = uint32_t(i);
+		auto& fields = out.vectorAreas[i];
+		fields.resize(nf);   // AreasInDocument::ReserveField(fieldSize_) (merger.h:165-166)
+		for (size_t f = 0; f < nf; ++f) {
+			const uint32_t cnt = areaCnt[i * nf + f];
+			const uint32_t* a = areas.data() + (i * nf + f) * maxA * 3;
+			fields[f].data.resize(cnt);
+			for (uint32_t j = 0; j < cnt; ++j) fields[f].data[j] = Area{a[j * 3], a[j * 3 + 1], a[j * 3 + 2]};
+		}
+	}
+	postProcess(cfg, out, rankSortType);
 	return out;
 }
 

@@ -73,6 +73,25 @@ struct MergeInfo {
 };
 using MergeData = std::vector<MergeInfo>;
 
+// MergeDataAreas<Area> (phrasemerger.h:64-89; core/ft/areaholder.h:9-37, 56-155): what highlight() / snippet() read.  Per merged document an
+// entry of vectorAreas (MergeInfoAreas::areaIndex), per field the areas in the order AreasInField::data_ holds them BEFORE Commit().
+struct Area {
+	uint32_t start = 0, end = 0, arrayIdx = 0;
+};
+struct FieldAreas {
+	std::vector<Area> data;
+};
+struct MergeInfoAreas {
+	int32_t id = 0;
+	float proc = 0;
+	uint32_t areaIndex = 0xFFFFFFFFu;
+	uint8_t field = 0;
+	uint8_t normalizedProc = 0;
+};
+struct MergeDataAreas : std::vector<MergeInfoAreas> {
+	std::vector<std::vector<FieldAreas>> vectorAreas;   // [areaIndex][field]
+};
+
 // One flattened posting list (IdRelVec of one dictionary word)
 struct FlatPostings {
 	std::vector<uint32_t> doc, entOff{0};
@@ -177,6 +196,15 @@ public:
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, QuerySynonyms synonyms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
 
+	// Merger<IdCont, MergeDataAreas<Area>, ..>::Merge (merger.h:36-57, addAreas :196-204): the merge behind highlight() / snippet() on the device
+	// (rxgpu_ft_merge_query_areas_raw) for queries of plain terms, Simple() included; maxAreasInDoc = FTConfig::maxAreasInDoc >= 1.
+	// Phrases (their areas come out of the PhraseMerger's position chains), multi-word synonyms and AreaDebug: the CPU merger (SupportsAreas).
+	static bool SupportsAreas(size_t numQueryParts, bool hasPhrases, bool hasSynonyms, int maxAreasInDoc) noexcept {
+		return numQueryParts >= 1 && !hasPhrases && !hasSynonyms && maxAreasInDoc >= 1 && maxAreasInDoc <= 4096;
+	}
+	MergeDataAreas MergeQueryAreas(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType, int maxAreasInDoc,
+								   bool* preselected = nullptr) const;
+
 	// Several queries in hand (the hybrid path's batch, a combiner in front of T planner threads): ONE launch train on the device for all of
 	// them (rxgpu_ft_merge_batch_raw: the merge kernels run with the query as the second grid dimension) — the result of query i is what
 	// MergeQuery(cfg, queries[i], ...) returns, bit for bit.  docsExcluded: per query, or empty (none); preselected: per query, may be null.
@@ -212,6 +240,7 @@ private:
 	MergeData mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType, bool* preselected,
 							 bool resident, QuerySynonyms* synonyms = nullptr) const;
 	void postProcess(const FtConfig& cfg, MergeData& out, RankSortType rankSortType) const;
+	void postProcess(const FtConfig& cfg, MergeDataAreas& out, RankSortType rankSortType) const;
 	const size_t numFields_;
 	size_t totalDocs_ = 0;
 	std::vector<float> words_;   // host copy for addFullMatchBoost

@@ -168,6 +168,7 @@ public:
 	const GpuFtMerger& Merger() const noexcept { return merger_; }
 	size_t SyncedWords() const noexcept { return prints_.size(); }
 	size_t SyncedDocs() const noexcept { return merger_.TotalDocs(); }
+	size_t NumFields() const noexcept { return numFields_; }
 
 	// vdoc statistics (b7) from the reference's DocsStatsGetter; vdoc 0 is the empty sentinel like everywhere in ft_fast
 	template <typename DocsStatsGetter>
@@ -261,13 +262,65 @@ void SyncGpuFtMirror(reindexer::DataHolder<IdCont>& holder, std::shared_ptr<GpuF
 }
 
 // Selector<IdCont>::mergeResults, GPU branch.  Returns false — and leaves everything untouched — when the CPU merger has to run.
+// MergeDataAreas<Area> back in the reference's types: MergeInfoAreas + one AreasInDocument per merged document, every field's areas adopted as
+// the merge left them (AreasInField::AdoptRaw, patch 0003: data_ in insertion order, not committed — GetAreas() sorts and joins them on first use)
+inline void ToRxMergeDataAreas(MergeDataAreas&& in, size_t fieldSize, reindexer::ft::MergeDataAreas<reindexer::Area>& out) {
+	out.resize(in.size());
+	for (size_t i = 0; i < in.size(); ++i) {
+		reindexer::ft::MergeInfoAreas& o = out[i];
+		o.id = reindexer::IdType::FromNumber(in[i].id);
+		o.proc = in[i].proc;
+		o.field = in[i].field;
+		o.normalizedProc = in[i].normalizedProc;
+		o.areaIndex = in[i].areaIndex;
+	}
+	out.vectorAreas.resize(in.vectorAreas.size());
+	for (size_t d = 0; d < in.vectorAreas.size(); ++d) {
+		reindexer::AreasInDocument<reindexer::Area>& doc = out.vectorAreas[d];
+		doc.ReserveField(int(fieldSize));   // addDoc (merger.h:165-166)
+		for (size_t f = 0; f < in.vectorAreas[d].size() && f < fieldSize; ++f) {
+			const std::vector<Area>& src = in.vectorAreas[d][f].data;
+			if (src.empty()) continue;
+			reindexer::h_vector<reindexer::Area, 2> data;
+			data.reserve(src.size());
+			for (const Area& a : src) data.emplace_back(a.start, a.end, a.arrayIdx);
+			doc.GetAreasRaw(unsigned(f))->AdoptRaw(std::move(data), int(src.size()));
+		}
+	}
+}
+
 template <typename IdCont, typename MergedDataType>
 bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, size_t totalNumDocs, reindexer::ft::QueryMergeData<IdCont>& q,
 				   reindexer::RankSortType rankSortType, const reindexer::FtMergeStatuses::Statuses& docsExcluded, bool inTransaction,
-				   MergedDataType& result) {
-	if constexpr (!std::is_same_v<MergedDataType, reindexer::ft::MergeData>) {
-		return false;   // areas (highlight / snippet) are built by the CPU merger
+				   MergedDataType& result, int maxAreasInDoc = 0) {
+	if constexpr (std::is_same_v<MergedDataType, reindexer::ft::MergeDataAreas<reindexer::Area>>) {
+		// highlight() / snippet(): queries of plain terms run on the device (GpuFtMerger::MergeQueryAreas); phrases, multi-word synonyms and an
+		// unlimited maxAreasInDoc go to the CPU merger
+		(void)inTransaction;
+		if (!mirror || mirror->SyncedDocs() != totalNumDocs) return false;
+		RankSortType sortType;
+		if (!ToGpuSortType(rankSortType, sortType)) return false;
+		if (q.Empty()) return false;
+		q.SortSubterms();
+		std::vector<QueryTerm> terms;
+		bool hasPhrases = false;
+		QuerySynonyms synonyms;
+		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
+		if (!GpuFtMerger::SupportsAreas(terms.size(), hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;
+		std::vector<uint8_t> excluded;
+		const uint8_t* excludedPtr = nullptr;
+		if (docsExcluded.PopCount() != 0) {
+			excluded.resize(totalNumDocs);
+			for (size_t d = 0; d < totalNumDocs && d < docsExcluded.size(); ++d) excluded[d] = docsExcluded[d] ? 1 : 0;
+			excludedPtr = excluded.data();
+		}
+		MergeDataAreas merged = mirror->Merger().MergeQueryAreas(ToGpuCfg(cfg), std::move(terms), excludedPtr, sortType, maxAreasInDoc);
+		ToRxMergeDataAreas(std::move(merged), mirror->NumFields(), result);
+		return true;
+	} else if constexpr (!std::is_same_v<MergedDataType, reindexer::ft::MergeData>) {
+		return false;   // MergeDataAreas<AreaDebug> (debug_rank strings) is built by the CPU merger
 	} else {
+		(void)maxAreasInDoc;
 		(void)inTransaction;   // only gates ThrowOnCancel checkpoints in the CPU merger (mergerimpl.h:118, 200); one GPU merge is a fraction of a millisecond
 		if (!mirror || mirror->SyncedDocs() != totalNumDocs) return false;
 		RankSortType sortType;
