@@ -74,9 +74,9 @@ __global__ __launch_bounds__(64) void ft_packed_wave(const uint8_t* __restrict__
 													  const uint64_t* __restrict__ array_found_pos, uint32_t nwords, uint32_t num_fields,
 													  const FtPackedOut* __restrict__ outs, FtPackedCounts* __restrict__ counts,
 													  const uint32_t* __restrict__ seg_word, const uint32_t* __restrict__ seg_first,
-													  FtPackedCheckpoint* __restrict__ cps, uint32_t nsegs) {
+													  FtPackedCheckpoint* __restrict__ cps, uint32_t first_word) {
 	__shared__ PwShared s;
-	const uint32_t w = WRITE ? seg_word[blockIdx.x] : blockIdx.x;
+	const uint32_t w = WRITE ? seg_word[blockIdx.x] : blockIdx.x + first_word;   // the count pass may be launched chunk by chunk (behind each chunk's upload)
 	if (w >= nwords) return;
 	const int lane = threadIdx.x;
 	const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
@@ -103,7 +103,6 @@ __global__ __launch_bounds__(64) void ft_packed_wave(const uint8_t* __restrict__
 			}
 		}
 	}
-	(void)nsegs;
 
 	// walk state (wave-uniform)
 	uint32_t status = kFtPackedOk;
@@ -459,11 +458,12 @@ __global__ __launch_bounds__(64) void ft_packed_wave(const uint8_t* __restrict__
 }
 
 hipError_t launch_ft_packed_count(const uint8_t* bytes, const uint64_t* byte_off, const uint64_t* array_found_pos, uint32_t nwords, uint32_t num_fields,
-								   FtPackedCounts* counts, const FtPackedSegs* segs, hipStream_t st) {
+								   FtPackedCounts* counts, const FtPackedSegs* segs, hipStream_t st, uint32_t first_word, uint32_t word_count) {
 	if (!nwords) return hipSuccess;
-	if (segs) {
-		hipLaunchKernelGGL(ft_packed_wave<false>, dim3(nwords), dim3(64), 0, st, bytes, byte_off, array_found_pos, nwords, num_fields, nullptr, counts,
-						   segs->seg_word, segs->seg_first, segs->cps, segs->nsegs);
+	if (segs) {   // words [first_word, first_word + word_count) of the nwords the arrays describe
+		if (!word_count) return hipSuccess;
+		hipLaunchKernelGGL(ft_packed_wave<false>, dim3(word_count), dim3(64), 0, st, bytes, byte_off, array_found_pos, nwords, num_fields, nullptr, counts,
+						   segs->seg_word, segs->seg_first, segs->cps, first_word);
 	} else {
 		hipLaunchKernelGGL(ft_packed_count, dim3((nwords + 255) / 256), dim3(256), 0, st, bytes, byte_off, array_found_pos, nwords, num_fields, counts);
 	}
@@ -475,7 +475,7 @@ hipError_t launch_ft_packed_write(const uint8_t* bytes, const uint64_t* byte_off
 	if (!nwords) return hipSuccess;
 	if (segs) {
 		hipLaunchKernelGGL(ft_packed_wave<true>, dim3(segs->nsegs), dim3(64), 0, st, bytes, byte_off, array_found_pos, nwords, num_fields, outs, counts,
-						   segs->seg_word, segs->seg_first, segs->cps, segs->nsegs);
+						   segs->seg_word, segs->seg_first, segs->cps, 0u);
 	} else {
 		hipLaunchKernelGGL(ft_packed_write, dim3((nwords + 255) / 256), dim3(256), 0, st, bytes, byte_off, array_found_pos, nwords, num_fields, outs, counts);
 	}

@@ -1428,38 +1428,13 @@ int rxgpu_ft_set_words_packed_ptrs(rxgpu_ft_index* h, uint32_t nwords, const uin
 		}
 	}
 	auto len_of = [&](uint32_t k) { return off[2 * size_t(k) + 1] - off[2 * size_t(k)]; };
-	const size_t o_off = align256(size_t(total_bytes) + 16), o_afp = o_off + align256(size_t(nwords) * 16), in_bytes = o_afp + align256(size_t(nwords) * 8);
-	if (int rc = h->d_pk_in.ensure(in_bytes); rc) return rc;
-	if (int rc = h->ensure_pinned(in_bytes); rc) return rc;
-	uint8_t* hp = static_cast<uint8_t*>(h->h_pinned);
-	{   // the gather: one pass over the streams, a few threads (100 000 pieces of a few hundred bytes: one thread moves ~7 GB/s of them)
-		const unsigned nthr = total_bytes > (8u << 20) ? 4u : 1u;
-		auto work = [&](unsigned t) {
-			for (uint32_t k = uint32_t(uint64_t(nwords) * t / nthr), e = uint32_t(uint64_t(nwords) * (t + 1) / nthr); k < e; ++k) {
-				const uint64_t n = len_of(k);
-				if (n) std::memcpy(hp + off[2 * size_t(k)], data[order[k]], size_t(n));
-			}
-		};
-		std::vector<std::thread> pool;
-		for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(work, t);
-		work(0);
-		for (std::thread& t : pool) t.join();
-	}
-	std::memset(hp + total_bytes, 0, 16);
-	std::memcpy(hp + o_off, off.data(), size_t(nwords) * 16);
-	std::memcpy(hp + o_afp, afp.data(), size_t(nwords) * 8);
-	uint8_t* d_bytes = static_cast<uint8_t*>(h->d_pk_in.ptr);
-	uint64_t* d_off = reinterpret_cast<uint64_t*>(d_bytes + o_off);
-	uint64_t* d_afp = reinterpret_cast<uint64_t*>(d_bytes + o_afp);
-	RX_HIP(hipMemcpyAsync(d_bytes, hp, in_bytes, hipMemcpyHostToDevice, h->stream));   // one copy from pinned memory: streams, offsets, array_found_pos
-	if (int rc = h->d_pk_cnt.ensure(size_t(nwords) * sizeof(rxgpu::FtPackedCounts)); rc) return rc;
-	rxgpu::FtPackedCounts* d_counts = static_cast<rxgpu::FtPackedCounts*>(h->d_pk_cnt.ptr);
 	// one wavefront per word (ft_packed_wave); RXGPU_FT_PACKED_THREAD=1: the one-thread-per-word kernels of round 2 (cross-check, comparison)
 	const bool wave = std::getenv("RXGPU_FT_PACKED_THREAD") == nullptr;
 	// pieces of kFtPackedSegBytes: the counting pass leaves a checkpoint in each, the writing pass runs one wavefront per piece
-	rxgpu::FtPackedSegs segs{};
+	uint32_t nsegs = 0;
+	std::vector<uint32_t> seg_first;
 	if (wave) {
-		std::vector<uint32_t> seg_first(nwords + 1), seg_word;
+		seg_first.resize(size_t(nwords) + 1);
 		seg_first[0] = 0;
 		for (uint32_t k = 0; k < nwords; ++k) {
 			const uint64_t len = len_of(k);
@@ -1467,28 +1442,103 @@ int rxgpu_ft_set_words_packed_ptrs(rxgpu_ft_index* h, uint32_t nwords, const uin
 			RX_CHECK(seg_first[k] + pieces < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_set_words_packed: too many stream bytes in one call");
 			seg_first[k + 1] = uint32_t(seg_first[k] + pieces);
 		}
-		const uint32_t nsegs = seg_first[nwords];
-		seg_word.resize(nsegs);
-		for (uint32_t k = 0; k < nwords; ++k) std::fill(seg_word.begin() + seg_first[k], seg_word.begin() + seg_first[k + 1], k);
-		const size_t o_sw = 0, o_sf = align256(size_t(nsegs) * 4), o_cp = o_sf + align256((size_t(nwords) + 1) * 4);
-		const size_t seg_bytes = o_cp + size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint);
-		if (int rc = h->d_pk_segs.ensure(seg_bytes); rc) return rc;
-		char* sb = static_cast<char*>(h->d_pk_segs.ptr);
-		RX_HIP(hipMemcpyAsync(sb + o_sw, seg_word.data(), size_t(nsegs) * 4, hipMemcpyHostToDevice, h->stream));
-		RX_HIP(hipMemcpyAsync(sb + o_sf, seg_first.data(), (size_t(nwords) + 1) * 4, hipMemcpyHostToDevice, h->stream));
-		RX_HIP(hipMemsetAsync(sb + o_cp, 0xFF, size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint), h->stream));
-		RX_HIP(hipStreamSynchronize(h->stream));   // the staging vectors go out of scope
-		segs.seg_word = reinterpret_cast<const uint32_t*>(sb + o_sw);
-		segs.seg_first = reinterpret_cast<const uint32_t*>(sb + o_sf);
-		segs.cps = reinterpret_cast<rxgpu::FtPackedCheckpoint*>(sb + o_cp);
+		nsegs = seg_first[nwords];
+	}
+	// pinned staging: [streams | (start, end) pairs | array_found_pos | piece -> word | first piece of a word]; everything but the streams
+	// travels first (one copy), the streams follow in chunks so that the gather of the next chunk, the copy of this one and the counting
+	// pass of the previous one overlap
+	const size_t o_off = align256(size_t(total_bytes) + 16), o_afp = o_off + align256(size_t(nwords) * 16), o_sw = o_afp + align256(size_t(nwords) * 8);
+	const size_t o_sf = o_sw + align256(size_t(nsegs) * 4), in_bytes = o_sf + align256((size_t(nwords) + 1) * 4);
+	if (int rc = h->d_pk_in.ensure(in_bytes); rc) return rc;
+	if (int rc = h->ensure_pinned(in_bytes); rc) return rc;
+	uint8_t* hp = static_cast<uint8_t*>(h->h_pinned);
+	std::memcpy(hp + o_off, off.data(), size_t(nwords) * 16);
+	std::memcpy(hp + o_afp, afp.data(), size_t(nwords) * 8);
+	if (wave) {
+		uint32_t* sw = reinterpret_cast<uint32_t*>(hp + o_sw);
+		for (uint32_t k = 0; k < nwords; ++k) std::fill(sw + seg_first[k], sw + seg_first[k + 1], k);
+		std::memcpy(hp + o_sf, seg_first.data(), (size_t(nwords) + 1) * 4);
+	}
+	uint8_t* d_bytes = static_cast<uint8_t*>(h->d_pk_in.ptr);
+	uint64_t* d_off = reinterpret_cast<uint64_t*>(d_bytes + o_off);
+	uint64_t* d_afp = reinterpret_cast<uint64_t*>(d_bytes + o_afp);
+	RX_HIP(hipMemcpyAsync(d_bytes + o_off, hp + o_off, in_bytes - o_off, hipMemcpyHostToDevice, h->stream));
+	if (int rc = h->d_pk_cnt.ensure(size_t(nwords) * sizeof(rxgpu::FtPackedCounts)); rc) return rc;
+	rxgpu::FtPackedCounts* d_counts = static_cast<rxgpu::FtPackedCounts*>(h->d_pk_cnt.ptr);
+	rxgpu::FtPackedSegs segs{};
+	if (wave) {
+		if (int rc = h->d_pk_segs.ensure(size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint)); rc) return rc;
+		RX_HIP(hipMemsetAsync(h->d_pk_segs.ptr, 0xFF, size_t(nsegs) * sizeof(rxgpu::FtPackedCheckpoint), h->stream));
+		segs.seg_word = reinterpret_cast<const uint32_t*>(d_bytes + o_sw);
+		segs.seg_first = reinterpret_cast<const uint32_t*>(d_bytes + o_sf);
+		segs.cps = static_cast<rxgpu::FtPackedCheckpoint*>(h->d_pk_segs.ptr);
 		segs.nsegs = nsegs;
 	}
-	EventPair ev_count, ev_write;
-	if (int rc = ev_count.create(); rc) return rc;
+	// chunks of ~8 MB of streams, whole words each (launch order: the longest words travel first)
+	std::vector<uint32_t> chunk_first{0u};
+	{
+		const uint64_t target = 8ull << 20;
+		uint64_t acc = 0;
+		for (uint32_t k = 0; k < nwords; ++k) {
+			acc += len_of(k);
+			if (acc >= target && k + 1 < nwords) {
+				chunk_first.push_back(k + 1);
+				acc = 0;
+			}
+		}
+		chunk_first.push_back(nwords);
+	}
+	const uint32_t nchunks = uint32_t(chunk_first.size() - 1);
+	// the gather: one pass over the streams by a few threads (100 000 pieces of a few hundred bytes: one thread moves ~7 GB/s of them), chunk
+	// by chunk; the calling thread sends a chunk on its way as soon as every worker is through with it
+	const unsigned nthr = total_bytes > (8u << 20) ? 4u : 1u;
+	std::vector<std::atomic<uint32_t>> chunk_done(nchunks);
+	for (auto& c : chunk_done) c.store(0, std::memory_order_relaxed);
+	auto gather = [&](unsigned t) {
+		for (uint32_t c = 0; c < nchunks; ++c) {
+			const uint32_t k0 = chunk_first[c], kn = chunk_first[c + 1] - k0;
+			for (uint32_t k = k0 + uint32_t(uint64_t(kn) * t / nthr), e = k0 + uint32_t(uint64_t(kn) * (t + 1) / nthr); k < e; ++k) {
+				const uint64_t n = len_of(k);
+				if (n) std::memcpy(hp + off[2 * size_t(k)], data[order[k]], size_t(n));
+			}
+			chunk_done[c].fetch_add(1, std::memory_order_release);
+		}
+	};
+	std::memset(hp + total_bytes, 0, 16);
+	std::vector<std::thread> gatherers;
+	struct Joiner {
+		std::vector<std::thread>& threads;
+		~Joiner() {
+			for (std::thread& t : threads) t.join();
+		}
+	} joiner{gatherers};
+	if (nthr > 1) {
+		for (unsigned t = 0; t < nthr; ++t) gatherers.emplace_back(gather, t);
+	}
+	std::vector<std::unique_ptr<EventPair>> ev_count(nchunks);
+	EventPair ev_write;
 	if (int rc = ev_write.create(); rc) return rc;
-	RX_HIP(hipEventRecord(ev_count.a, h->stream));
-	RX_HIP(rxgpu::launch_ft_packed_count(d_bytes, d_off, d_afp, nwords, h->num_fields, d_counts, wave ? &segs : nullptr, h->stream));
-	RX_HIP(hipEventRecord(ev_count.b, h->stream));
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		ev_count[c] = std::make_unique<EventPair>();
+		if (int rc = ev_count[c]->create(); rc) return rc;
+	}
+	for (uint32_t c = 0; c < nchunks; ++c) {
+		if (nthr > 1) {
+			while (chunk_done[c].load(std::memory_order_acquire) < nthr) std::this_thread::yield();
+		} else if (c == 0) {
+			gather(0);   // small calls: everything at once on this thread
+		}
+		const uint32_t k0 = chunk_first[c], k1 = chunk_first[c + 1];
+		const uint64_t b0 = off[2 * size_t(k0)], b1 = off[2 * size_t(k1 - 1) + 1] + (c + 1 == nchunks ? 16 : 0);
+		if (b1 > b0) RX_HIP(hipMemcpyAsync(d_bytes + b0, hp + b0, size_t(b1 - b0), hipMemcpyHostToDevice, h->stream));
+		RX_HIP(hipEventRecord(ev_count[c]->a, h->stream));
+		if (wave) {
+			RX_HIP(rxgpu::launch_ft_packed_count(d_bytes, d_off, d_afp, nwords, h->num_fields, d_counts, &segs, h->stream, k0, k1 - k0));
+		} else if (c + 1 == nchunks) {   // the thread-per-word kernels: one launch over all words
+			RX_HIP(rxgpu::launch_ft_packed_count(d_bytes, d_off, d_afp, nwords, h->num_fields, d_counts, nullptr, h->stream, 0, nwords));
+		}
+		RX_HIP(hipEventRecord(ev_count[c]->b, h->stream));
+	}
 	std::vector<rxgpu::FtPackedCounts> counts(nwords);
 	RX_HIP(hipMemcpyAsync(counts.data(), d_counts, size_t(nwords) * sizeof(rxgpu::FtPackedCounts), hipMemcpyDeviceToHost, h->stream));
 	RX_HIP(hipStreamSynchronize(h->stream));
@@ -1554,15 +1604,8 @@ int rxgpu_ft_set_words_packed_ptrs(rxgpu_ft_index* h, uint32_t nwords, const uin
 	RX_HIP(hipEventRecord(ev_write.b, h->stream));
 	std::vector<rxgpu::FtPackedCounts> again(nwords);
 	RX_HIP(hipMemcpyAsync(again.data(), d_counts, size_t(nwords) * sizeof(rxgpu::FtPackedCounts), hipMemcpyDeviceToHost, h->stream));
-	RX_HIP(hipStreamSynchronize(h->stream));
-	for (uint32_t k = 0; k < nwords; ++k) {
-		RX_CHECK(again[k].status == rxgpu::kFtPackedOk && again[k].n == counts[k].n && again[k].npos == counts[k].npos && again[k].nent == counts[k].nent,
-				 RXGPU_ERR_DEVICE, "rxgpu_ft_set_words_packed: the write pass disagrees with the counting pass");
-	}
-	h->packed_count_ms += ev_count.elapsed_ms();
-	h->packed_write_ms += ev_write.elapsed_ms();
-	h->packed_bytes_in += total_bytes;
-	h->packed_bytes_out += cv.off;
+	// the dictionary entries while the write pass runs (100 000 map insertions are a fifth of this call); should the pass disagree with the
+	// counting pass below — an internal error — the words of the call are left empty
 	h->words.reserve(h->words.size() + nwords);
 	for (uint32_t k = 0; k < nwords; ++k) {
 		rxgpu_ft_word& w = h->words[word_ids[order[k]]];
@@ -1583,6 +1626,20 @@ int rxgpu_ft_set_words_packed_ptrs(rxgpu_ft_index* h, uint32_t nwords, const uin
 		w.n_ranges = outs[k].n_ranges;
 		w.pool = pool;
 	}
+	const hipError_t waited = hipStreamSynchronize(h->stream);
+	bool agree = waited == hipSuccess;
+	for (uint32_t k = 0; k < nwords && agree; ++k) {
+		agree = again[k].status == rxgpu::kFtPackedOk && again[k].n == counts[k].n && again[k].npos == counts[k].npos && again[k].nent == counts[k].nent;
+	}
+	if (!agree) {
+		for (uint32_t k = 0; k < nwords; ++k) h->words[word_ids[order[k]]].release();
+		RX_HIP(waited);
+		RX_CHECK(false, RXGPU_ERR_DEVICE, "rxgpu_ft_set_words_packed: the write pass disagrees with the counting pass");
+	}
+	for (const auto& e : ev_count) h->packed_count_ms += e->elapsed_ms();
+	h->packed_write_ms += ev_write.elapsed_ms();
+	h->packed_bytes_in += total_bytes;
+	h->packed_bytes_out += cv.off;
 	return RXGPU_OK;
 }
 

@@ -327,7 +327,7 @@ struct FtPackedSegs {
 	uint32_t nsegs;
 };
 hipError_t launch_ft_packed_count(const uint8_t* bytes, const uint64_t* byte_off, const uint64_t* array_found_pos, uint32_t nwords, uint32_t num_fields,
-								   FtPackedCounts* counts, const FtPackedSegs* segs, hipStream_t st);
+								   FtPackedCounts* counts, const FtPackedSegs* segs, hipStream_t st, uint32_t first_word, uint32_t word_count);
 hipError_t launch_ft_packed_write(const uint8_t* bytes, const uint64_t* byte_off, const uint64_t* array_found_pos, uint32_t nwords, uint32_t num_fields,
 								   const FtPackedOut* outs, FtPackedCounts* counts, const FtPackedSegs* segs, hipStream_t st);
 
