@@ -270,6 +270,10 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
  * hnswalg.h:581-585), or whose list runs out of registers, starts over on the kernel that replays those heaps.  Reads and resets the
  * number of such restarts.  RXGPU_HNSW_SORTED=0 in the environment keeps every search on the heap kernel. */
 int rxgpu_hnsw_read_tie_reruns(rxgpu_index* h, uint64_t* reruns);
+/* A search whose candidate_set (hnswalg.h:741-777, unbounded in the reference) outgrows the LDS area of its first pass is run again on the
+ * heap kernel with the largest LDS heap (2048 entries) before the global-scratch tiers are tried.  Reads and resets the number of such
+ * re-runs. */
+int rxgpu_hnsw_read_lds_reruns(rxgpu_index* h, uint64_t* reruns);
 
 /* HierarchicalNSW::SearchRange (hnswalg.h:2015-2070) with BOTH halves on the device: the ef-search, then the closure of its hits over the
  * level-0 links while dist < radius (a fresh visited set in which only the ef hits are marked; deleted neighbours skipped) in ONE launch.

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "rxgpu_hnsw_search_knn_sq8": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_hnsw_read_tie_reruns": (_i, [_vp, C.POINTER(_u64)]),
+    "rxgpu_hnsw_read_lds_reruns": (_i, [_vp, C.POINTER(_u64)]),
     "rxgpu_hnsw_search_range": (_i, [_vp, _vp, _f, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_hnsw_search_range_sq8": (_i, [_vp, _vp, _f, _f, _f, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "rxgpu_hnsw_stream_begin_sq8": (_i, [_vp, _vp, _f, _f, _u32, C.POINTER(_vp)]),
@@ -430,6 +431,11 @@ class VectorIndex:
     def hnsw_read_tie_reruns(self) -> int:
         a = _u64(0)
         _check(lib().rxgpu_hnsw_read_tie_reruns(self._h, C.byref(a)))
+        return int(a.value)
+
+    def hnsw_read_lds_reruns(self) -> int:
+        a = _u64(0)
+        _check(lib().rxgpu_hnsw_read_lds_reruns(self._h, C.byref(a)))
         return int(a.value)
 
     # ---- instrumentation

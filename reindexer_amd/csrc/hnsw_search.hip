@@ -571,6 +571,26 @@ __device__ __forceinline__ bool hnsw_visit(uint32_t* visited, uint32_t hash_log2
 	}
 }
 
+// the latency form may keep the hash set in LDS (HnswParams::vis_lds): same probing, a ds_cmpst_rtn instead of a global atomic.  (Its own
+// function, without the bitset branch: sharing hnsw_visit let the compiler merge the two bitset paths into ONE flat_atomic_or.)
+__device__ __forceinline__ bool hnsw_visit_lds(uint32_t* table, uint32_t hash_log2, uint32_t id) {
+	const uint32_t mask = (1u << hash_log2) - 1u, key = id + 1u;
+	uint32_t h = (id * 2654435761u) >> (32u - hash_log2);
+	for (;;) {
+		const uint32_t old = atomicCAS(&table[h], 0u, key);
+		if (old == 0u) return true;
+		if (old == key) return false;
+		h = (h + 1u) & mask;
+	}
+}
+template <bool kLds>
+__device__ __forceinline__ bool hnsw_visit_sel(uint32_t* visited, uint32_t* lds_vis, bool use_lds, uint32_t hash_log2, uint32_t id) {
+	if constexpr (kLds) {
+		if (use_lds) return hnsw_visit_lds(lds_vis, hash_log2, id);
+	}
+	return hnsw_visit(visited, hash_log2, id);
+}
+
 // kLatency: few queries in flight -> two row sets per distance trip (fewer dependent round trips per hop, 172 VGPRs at D = 768);
 // otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
 // kSorted: 0 = the reference's two heaps, replayed by lane 0; S > 0 = HnswSortedList<S> (ef <= 64 S, no deleted nodes, heaps not in LDS at all)
@@ -585,6 +605,8 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 	uint2* lcand = top + p.ef_cap;
 	constexpr bool kQLds = NB > 0 && !kSq8;   // fixed dims: query fragment in LDS behind the heaps (16-byte aligned: every part is a multiple of 64 entries)
 	float4* q_s = reinterpret_cast<float4*>(lcand + (kGlobalCand ? 0 : p.lds_cand_cap));
+	uint32_t* lds_vis = reinterpret_cast<uint32_t*>(q_s + (kQLds ? NB * 16 : 0));   // [1 << vis_hash_log2] when p.vis_lds (latency form only)
+	const bool vis_in_lds = kLatency && p.vis_lds != 0;
 	__shared__ uint32_t nb_id[kHnswMaxNeighbors];
 	__shared__ float nb_d[kHnswMaxNeighbors];
 	__shared__ uint8_t nb_del[kHnswMaxNeighbors];
@@ -640,8 +662,13 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 	const uint32_t vis_hash = p.vis_hash_log2;
 	const unsigned long long vis_limit = vis_hash ? (1ull << (vis_hash - 1)) : ~0ull;   // entries the hash set may hold
 	if (vis_hash) {   // the search zeroes its own (small) set: 16-byte stores, in flight during the descent through the upper levels
-		uint4* v4 = reinterpret_cast<uint4*>(visited);
-		for (uint32_t w = lane; w < (1u << vis_hash) / 4; w += 64) v4[w] = make_uint4(0u, 0u, 0u, 0u);
+		if (vis_in_lds) {
+			uint4* v4 = reinterpret_cast<uint4*>(lds_vis);
+			for (uint32_t w = lane; w < (1u << vis_hash) / 4; w += 64) v4[w] = make_uint4(0u, 0u, 0u, 0u);
+		} else {
+			uint4* v4 = reinterpret_cast<uint4*>(visited);
+			for (uint32_t w = lane; w < (1u << vis_hash) / 4; w += 64) v4[w] = make_uint4(0u, 0u, 0u, 0u);
+		}
 	}
 	// ---- upper levels: greedy descent (getLayer0EntryPoint)
 	uint32_t cur = p.entry;
@@ -691,7 +718,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			__threadfence();
 			__syncthreads();
 		}
-		if (lane == 0) (void)hnsw_visit(visited, vis_hash, cur);
+		if (lane == 0) (void)hnsw_visit_sel<kLatency>(visited, lds_vis, vis_in_lds, vis_hash, cur);
 		// the link block of the candidate that is next in line, requested one hop ahead: it arrives while this hop's visited tests and row
 		// gathers are in flight, and saves the next hop its first dependent round trip whenever no nearer candidate turned up meanwhile
 		// (LDS-DMA: the block goes straight into s_pre, no register lives across the hop — the D = 768 kernel sits at its 96-VGPR budget)
@@ -734,7 +761,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 				if (base > cnt) break;   // uniform
 				const int j = w - 1;
 				bool fresh = false;
-				if (j >= 0 && j < cnt) fresh = hnsw_visit(visited, vis_hash, word);
+				if (j >= 0 && j < cnt) fresh = hnsw_visit_sel<kLatency>(visited, lds_vis, vis_in_lds, vis_hash, word);
 				const uint64_t fm = __ballot(fresh);
 				if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
 				nfresh += __popcll(fm);
@@ -814,7 +841,11 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			if (lane == 0) p.out_count[qi] = kHnswTie;
 			return;
 		}
-		for (uint64_t w = lane; w < p.visited_words; w += 64) visited[w] = 0u;
+		if (vis_in_lds) {
+			for (uint32_t w = lane; w < (1u << vis_hash); w += 64) lds_vis[w] = 0u;
+		} else {
+			for (uint64_t w = lane; w < p.visited_words; w += 64) visited[w] = 0u;
+		}
 		__threadfence();
 		__syncthreads();
 		if (lane == 0 && p.stats) atomicAdd(&p.stats[2], 1ull);
@@ -839,7 +870,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			} else {
 				hp_emplace(cand, cand_n, -3.402823466e+38f, cur);
 			}
-			(void)hnsw_visit(visited, vis_hash, cur);
+			(void)hnsw_visit_sel<kLatency>(visited, lds_vis, vis_in_lds, vis_hash, cur);
 		}
 		lower = ep_ok ? curdist : 3.402823466e+38f;
 		if (ep_ok) ndist += 1;   // the reference recomputes the entry distance here (same value)
@@ -881,7 +912,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			if (base > cnt) break;   // uniform
 			const int j = w - 1;
 			bool fresh = false;
-			if (j >= 0 && j < cnt) fresh = hnsw_visit(visited, vis_hash, word);
+			if (j >= 0 && j < cnt) fresh = hnsw_visit_sel<kLatency>(visited, lds_vis, vis_in_lds, vis_hash, word);
 			const uint64_t fm = __ballot(fresh);
 			if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
 			nfresh += __popcll(fm);
@@ -937,13 +968,21 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 
 template <bool kGlobalCand, int NB, int kSorted = 0, bool kDel = false>
 static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hipStream_t s) {
-	const size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8 + size_t(NB) * 256;   // heaps + the query fragment (NB*16 float4)
+	size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8 + size_t(NB) * 256;   // heaps + the query fragment (NB*16 float4)
 	constexpr bool kHasLatencyVariant = NB > 8;
 	const bool latency = kHasLatencyVariant && blocks <= 3072;   // no more searches than the chip holds of this form (3 per SIMD): spend registers on fewer round trips
+	// at most two searches per CU and a set of up to 32 KB: the visited set moves into LDS (dynamic LDS stays under the 64 KB a launch gets
+	// without an attribute)
+	HnswParams pl = p;
+	if (latency && !kGlobalCand && p.vis_lds_log2 && blocks <= 512 && (size_t(4) << p.vis_lds_log2) <= (32u << 10) && lds + (size_t(4) << p.vis_lds_log2) <= (60u << 10)) {
+		pl.vis_lds = 1;
+		pl.vis_hash_log2 = p.vis_lds_log2;
+		lds += size_t(4) << p.vis_lds_log2;
+	}
 #define RX_HNSW(M)                                                                                                                         \
 	do {                                                                                                                                   \
 		if (latency) {                                                                                                                     \
-			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, kHasLatencyVariant, false, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, p); \
+			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, kHasLatencyVariant, false, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, pl); \
 		} else {                                                                                                                           \
 			hipLaunchKernelGGL((hnsw_search_kernel<M, kGlobalCand, NB, false, false, kSorted, kDel>), dim3(blocks), dim3(64), lds, s, p);    \
 		}                                                                                                                                  \

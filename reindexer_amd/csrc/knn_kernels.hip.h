@@ -134,6 +134,11 @@ struct HnswParams {
 	// the search itself — its size follows ef, not the number of nodes.  A search that fills half of it leaves as kHnswOverflow and is re-run
 	// on a bitset.  0: one bit per node (N / 8 bytes per search in flight, zeroed by a memset in front of the launch).
 	uint32_t vis_hash_log2;
+	// Few searches in flight (the latency form of the kernel, at most two workgroups per CU): the hash set lives in the workgroup's LDS
+	// behind the heaps — the test-and-set of a hop is an LDS atomic instead of a round trip to L2.  vis_lds_log2 is what the caller allows
+	// (0: never); the launcher turns vis_lds on when the launch qualifies and then overrides vis_hash_log2 with it.
+	uint32_t vis_lds_log2;
+	uint32_t vis_lds;
 	uint32_t prefetch_links;     // sorted-list search: fetch the link block of the candidate next in line one hop ahead (LDS-DMA)
 	float* out_dist;          // [nq][k]
 	uint32_t* out_row;

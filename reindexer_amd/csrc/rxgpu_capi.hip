@@ -1784,6 +1784,13 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	uint32_t vis_hash_log2 = 12;
 	while ((1ull << vis_hash_log2) < 64ull * ef && vis_hash_log2 < 18) ++vis_hash_log2;
 	if (const char* e = getenv("RXGPU_HNSW_VISITED_LOG2")) vis_hash_log2 = uint32_t(std::min(20, std::max(6, atoi(e))));   // test hook: force overflows
+	// a handful of searches (the latency form of the kernel, at most two workgroups per CU): the same hash set in LDS, whatever the rule
+	// below picks for batches — the launcher decides (launch_hnsw_nb).  RXGPU_HNSW_VISITED_LDS=0: off (A/B)
+	uint32_t vis_lds_log2 = vis_hash_log2;
+	if (const char* e = getenv("RXGPU_HNSW_VISITED_LDS")) {
+		if (!atoi(e)) vis_lds_log2 = 0;
+	}
+	if (getenv("RXGPU_HNSW_VISITED")) vis_lds_log2 = 0;   // an explicit choice of the global form (A/B, tests) stands for every launch
 	{
 		const char* e = getenv("RXGPU_HNSW_VISITED");   // "bitset" / "hash": force one of the two (A/B, tests on small graphs)
 		const bool force_hash = e && std::strcmp(e, "hash") == 0;
@@ -1834,6 +1841,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	p.k = k;
 	p.ef = ef;
 	p.visited_words = words;
+	p.vis_lds_log2 = vis_lds_log2;
 	p.prefetch_links = 1;
 	if (const char* e = getenv("RXGPU_HNSW_PREFETCH")) p.prefetch_links = atoi(e) ? 1u : 0u;   // A/B hook
 	p.out_dist = static_cast<float*>(c->d_out_dist.ptr);
@@ -1925,8 +1933,38 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 			RX_HIP(hipStreamSynchronize(c->stream));
 		}
-		// queries whose candidate heap outgrew LDS: re-run with the heap in global scratch (bounded by one entry per node)
+		// Queries whose candidate heap outgrew its LDS area — 600 entries for a search that started over inside the sorted-list kernel, 1024 for
+		// the heap kernel's first pass: once more on the heap kernel with the largest LDS heap there is and a bitset (a search that filled
+		// its hash set lands here too), before the global-heap tiers.  A search with its heap in global scratch takes 5 - 7 ms at 10M x 768
+		// (profiles/rd4i_hnsw_10m_*.json: ONE such query was a fifth of a 16 384-query batch), one in LDS about 1 ms.
+		std::vector<uint32_t> over;
 		for (uint32_t q = 0; q < nq; ++q) {
+			if (out_count[q] == rxgpu::kHnswOverflow) over.push_back(q);
+		}
+		const uint32_t first_cap = use_sorted ? sorted_restart_cap : p.lds_cand_cap;
+		if (!over.empty() && first_cap < uint32_t(rxgpu::kHnswCandLds) && !getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // (the hook forces the global tiers)
+			if (int rc = c->d_redo.ensure(over.size() * sizeof(uint32_t)); rc) return rc;
+			RX_HIP(hipMemcpyAsync(c->d_redo.ptr, over.data(), over.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+			for (size_t r0 = 0; r0 < over.size(); r0 += max_slots) {
+				const uint32_t cq = uint32_t(std::min<uint64_t>(max_slots, over.size() - r0));
+				if (int rc = c->d_visited.ensure(size_t(cq) * words * 4); rc) return rc;
+				RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+				rxgpu::HnswParams pc = p;
+				pc.lds_cand_cap = uint32_t(rxgpu::kHnswCandLds);
+				pc.vis_lds_log2 = 0;   // (a search that filled its hash set is among these)
+				pc.queries = static_cast<const float*>(c->d_queries.ptr);
+				pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
+				pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;
+				ProfileScope ps(h, "hnsw_redo", c->stream);
+				rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
+			}
+			RX_HIP(hipGetLastError());
+			RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipStreamSynchronize(c->stream));
+			h->hnsw_lds_reruns += over.size();
+		}
+		// ... and what still does not fit: re-run with the heap in global scratch (bounded by one entry per node)
+		for (const uint32_t q : over) {
 			if (out_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
 		}
 	}
@@ -2286,6 +2324,12 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 	RX_HIP(hipMemset(h->d_hnsw_stats, 0, sizeof(v)));
 	*distance_evals = v[0];
 	*hops = v[1];
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_read_lds_reruns(rxgpu_index* h, uint64_t* reruns) {
+	RX_CHECK(h && reruns, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_lds_reruns: null argument");
+	*reruns = h->hnsw_lds_reruns.exchange(0);
 	return RXGPU_OK;
 }
 

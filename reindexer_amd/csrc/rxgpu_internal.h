@@ -424,6 +424,7 @@ struct rxgpu_index {
 	uint32_t graph_entry = 0;
 	bool graph_attached = false;
 	unsigned long long* d_hnsw_stats = nullptr;
+	std::atomic<uint64_t> hnsw_lds_reruns{0};   // searches whose candidate heap outgrew its first LDS area and were re-run with the largest one
 	std::atomic<uint64_t> hnsw_tie_reruns{0};   // queries the sorted-list search handed to the heap kernel (equal distances met)
 
 	std::mutex mtx;  // guards ctx pool + profile state

@@ -386,6 +386,12 @@ uint64_t GpuHnswMap::TieReruns() const {
 	return n;
 }
 
+uint64_t GpuHnswMap::LdsReruns() const {
+	uint64_t n = 0;
+	if (rxgpu_hnsw_read_lds_reruns(dev_, &n) != RXGPU_OK) throwDevice("LdsReruns");
+	return n;
+}
+
 StreamingSearchSession::~StreamingSearchSession() {
 	if (impl_) rxgpu_hnsw_stream_end(impl_);
 }

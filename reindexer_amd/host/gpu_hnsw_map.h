@@ -90,6 +90,8 @@ public:
 	size_t CoalescedBatches() const noexcept { return coBatches_; }
 	// searches the device re-ran on its heap kernel because the sorted-list search met equal distances (rxgpu_hnsw_read_tie_reruns); resets
 	uint64_t TieReruns() const;
+	// searches whose candidate heap outgrew the LDS area of their first pass and ran again with the largest one (rxgpu_hnsw_read_lds_reruns); resets
+	uint64_t LdsReruns() const;
 
 	// SQ8 (HierarchicalNSW::Quantize, hnsw.h:104-118; hnswalg.h:411-470): from here on SearchKnn runs over one byte per component on the
 	// device (rxgpu_hnsw_search_knn_sq8) and returns what HierarchicalNSWImpl<uint8_t> returns on the same graph, bit for bit.  The range

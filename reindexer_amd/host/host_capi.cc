@@ -429,6 +429,11 @@ long rxhost_hnsw_tie_reruns(void* h) {
 	guarded([&] { n = long(static_cast<const GpuHnswMap*>(h)->TieReruns()); });
 	return n;
 }
+long rxhost_hnsw_lds_reruns(void* h) {
+	long n = -1;
+	guarded([&] { n = long(static_cast<const GpuHnswMap*>(h)->LdsReruns()); });
+	return n;
+}
 void* rxhost_hnsw_graph(void* h) { return const_cast<HnswGraph*>(&static_cast<GpuHnswMap*>(h)->Graph()); }
 // the Map's ANN disk cache through memory (same encoding as rxhost_graph_save_index / _load_index)
 long rxhost_hnsw_save_index(void* h, uint8_t* out, size_t cap) {

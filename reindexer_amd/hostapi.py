@@ -486,6 +486,8 @@ class GpuHnswMap:
             L.rxhost_hnsw_select.argtypes = [_vp, _vp, _sz, _l, _sz, _i, _f, _i, _i, _vp, _vp, _sz]
             L.rxhost_hnsw_tie_reruns.restype = _l
             L.rxhost_hnsw_tie_reruns.argtypes = [_vp]
+            L.rxhost_hnsw_lds_reruns.restype = _l
+            L.rxhost_hnsw_lds_reruns.argtypes = [_vp]
             L.rxhost_hnsw_save_index.restype = _l
             L.rxhost_hnsw_save_index.argtypes = [_vp, _vp, _sz]
             L.rxhost_hnsw_load_index.argtypes = [_vp, _vp, _sz, _vp, _vp, _sz]
@@ -548,6 +550,13 @@ class GpuHnswMap:
         """LoadIndexCache's Map part (hnsw_index.cc:439-507) into an empty Map; on any error the Map is cleared, as clearMap() does.
         with_quantizer = LoadWithQuantizer: a cache written from a quantised Map brings it back quantised (same parameters)."""
         _load_bytes(lib().rxhost_hnsw_load_index_quantized if with_quantizer else lib().rxhost_hnsw_load_index, self.h, data, labels, vectors, self.dim)
+
+    def lds_reruns(self) -> int:
+        """Searches re-run with the largest LDS candidate heap since the last call (their first heap area overflowed)."""
+        n = lib().rxhost_hnsw_lds_reruns(self.h)
+        if n < 0:
+            _raise()
+        return n
 
     def tie_reruns(self) -> int:
         """Searches re-run on the heap kernel since the last call (the sorted-list search met equal distances)."""

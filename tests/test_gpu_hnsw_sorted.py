@@ -96,7 +96,8 @@ def test_equal_distances_are_rerun_on_the_heaps(rxgpu, oracle, monkeypatch, metr
     """Rows on a small integer grid, every row four times: most searches meet equal keys.  The answers must still be the restated
     engine's (its heaps decide the order among equal keys), and the counter must show that the heaps served them — restarted inside the
     sorted-list kernel (default), sent back to the host for a launch of their own (RXGPU_HNSW_RESTART_CAND=0), or restarted with a heap
-    area so small that the restart overflows into the global-heap tier (6 entries)."""
+    area so small (6 entries) that the restart overflows: those run once more on the heap kernel with the largest LDS heap, in front of the
+    global-heap tiers (which tests/test_gpu_hnsw.py forces)."""
     from oracle.pyoracle import oracle_hnsw_search_knn
     if restart is not None:
         monkeypatch.setenv("RXGPU_HNSW_RESTART_CAND", restart)
@@ -110,6 +111,7 @@ def test_equal_distances_are_rerun_on_the_heaps(rxgpu, oracle, monkeypatch, metr
     g["vectors"] = rows
     inv = oracle.l2_modules(rows) if metric == 2 else None
     m.tie_reruns()
+    m.lds_reruns()
     searches = 0
     for qi in range(24):
         q = rng.integers(-3, 4, size=d).astype(np.float32) if qi % 2 else rows[rng.integers(n)].copy()
@@ -123,6 +125,8 @@ def test_equal_distances_are_rerun_on_the_heaps(rxgpu, oracle, monkeypatch, metr
     reruns = m.tie_reruns()
     assert 0 < reruns <= searches, reruns
     assert m.tie_reruns() == 0   # reading resets
+    lds = m.lds_reruns()
+    assert lds <= searches and (lds > 0 or restart != "6"), (restart, lds)
     m.close()
 
 

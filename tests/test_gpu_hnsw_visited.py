@@ -107,3 +107,46 @@ def test_equal_keys_restart_and_deleted_nodes_with_the_hash_set(rxgpu, oracle, m
             gd, gl = m.search_knn(q, k, ef)
             assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd))
     m.close()
+
+
+@pytest.mark.parametrize("grid_rows", [False, True])
+def test_small_batches_keep_the_set_in_lds(rxgpu, oracle, monkeypatch, grid_rows):
+    """D = 768, at most 512 searches in a launch, ef <= 128: the latency form of the kernel keeps the hash set in the workgroup's LDS
+    (HnswParams::vis_lds).  Same answers and the same traversal as the bitset; rows on an integer grid make most searches start over on the
+    heaps inside the kernel (the LDS set is zeroed and refilled); a set of 2^7 words overflows and the search comes back through the re-run
+    with the largest LDS heap (a bitset)."""
+    n, d = 6000, 768
+    rng = np.random.default_rng(17)
+    if grid_rows:
+        base = rng.integers(-2, 3, size=(n // 4, d)).astype(np.float32)
+        rows = np.ascontiguousarray(np.repeat(base, 4, axis=0)[rng.permutation(n)])
+        m, rows, labels = build(0, n, d, M=8, efc=40, rows=rows)
+    else:
+        m, rows, labels = build(2, n, d, M=12, efc=60, seed=19)
+    metric = 0 if grid_rows else 2
+    g = m.export_graph()
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, rows, inv)
+        ix.hnsw_attach_graph(g)
+        for nq in (1, 7, 300):
+            if grid_rows:
+                queries = rng.integers(-2, 3, size=(nq, d)).astype(np.float32)
+            else:
+                queries = np.stack([oracle.normalize_copy(q)[0] for q in make_corpus(40 + nq, nq, d)])
+            for k, ef in ((10, 128), (5, 16), (50, 200)):   # ef = 200: the set would take 64 KB and stays in global memory
+                monkeypatch.delenv("RXGPU_HNSW_VISITED_LOG2", raising=False)
+                monkeypatch.setenv("RXGPU_HNSW_VISITED", "bitset")
+                want = _batch(ix, queries, k, ef)
+                monkeypatch.delenv("RXGPU_HNSW_VISITED")
+                ix.hnsw_read_lds_reruns()
+                got = _batch(ix, queries, k, ef)
+                _same_batches(got, want, nq)
+                assert got[3] == want[3], (nq, k, ef, got[3], want[3])
+                assert ix.hnsw_read_lds_reruns() == 0 or grid_rows
+                if ef == 128:
+                    monkeypatch.setenv("RXGPU_HNSW_VISITED_LOG2", "7")
+                    small = _batch(ix, queries, k, ef)
+                    _same_batches(small, want, nq)
+                    assert ix.hnsw_read_lds_reruns() > 0
+    m.close()
