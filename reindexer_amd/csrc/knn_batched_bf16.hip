@@ -311,13 +311,323 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 	if constexpr (kMode == kGemmFilter) flush_hits();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// split-ring variant.  What bounds the kernel above is the number of HBM bytes a CU has in flight: a stage is 16 KB of rows (HBM, ~2-3 us
+// under load) + 16 KB of queries (the 393 KB query block sits in L2), both in one ring of four 32 KB buffers -> three stages = 48 KB of
+// rows in flight per CU, 12 MB over the chip, against the ~16-24 MB that 8 TB/s x 2-3 us ask for (the 128-query tile, with five 24 KB
+// stages in flight, streams the shadow at 4.5 TB/s; this one at 3.2).  The two operands cannot simply get rings of different depth:
+// vmcnt retires in order, so a wave that waits for a query stage issued two iterations ago also waits for every row stage it issued
+// before that.  Hence the loaders are split by WAVE: waves 0-3 issue only row stages into a ring of RB buffers (RB - 1 in flight), waves
+// 4-7 only query stages into a ring of three (two in flight); each wave waits for its own stream, the per-stage barrier publishes both.
+// All eight waves multiply as before.  The per-row terms of the epilogue (|x|^2, 1/|x|) travel by LDS-DMA in front of their tile's
+// first row stage: a global load in the epilogue would wait for every DMA in flight.
+constexpr int gl_row_bufs(int qt) { return qt == 256 ? 6 : 7; }
+constexpr int gl_query_bufs(int) { return 3; }
+constexpr int kGlHitCapSplit = 160;
+
+template <int kMetric, int kMode, int QT, int RB = gl_row_bufs(QT), int QBUFS = gl_query_bufs(QT)>
+__global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params p) {
+	static_assert(RB >= 3 && RB <= 7 && QBUFS >= 2 && QBUFS <= 3, "the vmcnt switches below cover these ring depths");
+	constexpr int kQElems = QT * 32;                 // the query operand of one stage
+	constexpr int QB = QT / 64;                      // 32-query blocks per wave (two query halves)
+	constexpr int kQIps = QT * 4 / 256;              // DMA instructions per query-loader wave and stage (4 or 2)
+	constexpr bool kTerms = kMetric != kIP;          // the epilogue needs one float per row
+	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];   // the ONLY shared object (a second one de-pipelines the DMA waits)
+	uint16_t* rows_s = reinterpret_cast<uint16_t*>(bf_lds);                                    // [RB][256 x 32]
+	uint16_t* qry_s = rows_s + size_t(RB) * kGlXElems;                                         // [QBUFS][QT x 32]
+	float* term_s = reinterpret_cast<float*>(qry_s + size_t(QBUFS) * kQElems);                 // [2][256] row terms of the tile in flight / the next one
+	float* thr_s = term_s + 2 * kBfRows;                                                       // [QT]
+	float* aux_s = thr_s + QT;
+	uint32_t* hit_n = reinterpret_cast<uint32_t*>(aux_s + QT);                                 // [8]: one counter per wavefront
+	unsigned long long* hit_all = reinterpret_cast<unsigned long long*>(hit_n + 8);            // [8][kGlHitCapSplit]
+	float* gmax_s = reinterpret_cast<float*>(hit_all + size_t(8) * kGlHitCapSplit);            // [QT / 16] loosest threshold of a lane's 16 queries
+	float* gmin_s = gmax_s + QT / 16;                                                          // [QT / 16] smallest |q|^2 of them (L2)
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int rp = wave & 3, qh = wave >> 2;
+	const bool row_loader = wave < 4;                // wave-uniform role in the DMA streams
+	const uint32_t stages = p.ld / 32;
+	const uint64_t ntiles = (p.n + kBfRows - 1) / kBfRows;
+	const uint64_t my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+	const uint64_t total = my_tiles * stages;
+	for (int i = tid; i < QT; i += kBfThreads) {
+		thr_s[i] = kMode == kGemmFilter ? p.thr[i] : 0.f;
+		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
+	}
+	if (tid < 8) hit_n[tid] = 0;
+	__syncthreads();
+	if (kMode == kGemmFilter && tid < QT / 16) {   // block-level test of the filter epilogue, as in the kernel above
+		const int half = tid & 1, bb = (tid >> 1) % QB, hh = (tid >> 1) / QB;
+		float tmax = -__builtin_inff(), amin = __builtin_inff();
+		for (int r = 0; r < 16; ++r) {
+			const int qi = 32 * bb + (r & 3) + 8 * (r >> 2) + 4 * half + (QT / 2) * hh;
+			tmax = fmaxf(tmax, thr_s[qi]);
+			amin = fminf(amin, aux_s[qi]);
+			if (thr_s[qi] != thr_s[qi]) tmax = __builtin_inff();
+		}
+		gmax_s[tid] = tmax;
+		gmin_s[tid] = amin;
+	}
+	__syncthreads();
+	unsigned long long* hit_s = hit_all + size_t(wave) * kGlHitCapSplit;
+	uint32_t* my_n = hit_n + wave;
+	auto flush_hits = [&]() {
+		const uint32_t cnt = min(*my_n, uint32_t(kGlHitCapSplit));
+		for (uint32_t e = lane; e < cnt; e += 64) {
+			const unsigned long long h = hit_s[e];
+			const uint32_t qi = uint32_t(h >> 32);
+			const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+			if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(h);
+		}
+		if (lane == 0) *my_n = 0;
+	};
+
+	// DMA addressing of this thread inside its 4-wave loader group: instruction j covers LDS slots [256 j, 256 j + 256) of the operand
+	// (slot p = 4 r + cs holds chunk c = cs ^ ((r >> 2) & 3) of row r, the swizzle of the kernel above)
+	uint32_t src_r[4], src_c[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const uint32_t slot = j * 256 + rp * 64 + lane;
+		src_r[j] = slot >> 2;
+		src_c[j] = ((slot & 3) ^ ((src_r[j] >> 2) & 3)) << 3;
+	}
+	const uint16_t* src[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) src[j] = p.queries + size_t(src_r[j] % QT) * p.ld + src_c[j];   // query loaders: fixed; row loaders: set per tile
+	uint64_t iss_tile = blockIdx.x;   // tile / stage of the NEXT stage this wave issues
+	uint32_t iss_stage = 0;
+	uint64_t iss_g = 0;
+	uint32_t iss_buf = 0;             // ring position of the next stage (rows: mod RB, queries: mod QBUFS)
+	uint32_t iss_par = 0;             // which half of term_s the next tile's row terms go to
+	auto issue = [&]() {
+		const uint32_t k0 = iss_stage * 32;
+		if (row_loader) {
+			if (iss_stage == 0) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const uint64_t row = iss_tile * kBfRows + src_r[j];
+					src[j] = p.rows + (row < p.n ? row : p.n - 1) * p.row_step * p.ld + src_c[j];   // clamped: discarded by row_ok in the epilogue
+				}
+				if constexpr (kTerms) {   // this wave's 64 row terms, in front of the tile's first rows (in-order retirement: there when they are)
+					const uint64_t row = iss_tile * kBfRows + 64 * rp + lane;
+					const uint64_t rowc = (row < p.n ? row : p.n - 1) * p.row_step;
+					const float* tsrc = (kMetric == kL2 ? p.row_sq : p.inv_norms) + rowc;
+					float* tdst = term_s + iss_par * kBfRows + 64 * rp;
+					__builtin_amdgcn_global_load_lds(tsrc, (lds_void*)(tdst), 4, 0, 0);
+				}
+				iss_par ^= 1u;
+			}
+			uint16_t* buf = rows_s + size_t(iss_buf) * kGlXElems;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(src[j] + k0, (lds_void*)(buf + (j * 256 + rp * 64) * 8), 16, 0, 0);
+			iss_buf = iss_buf + 1 == uint32_t(RB) ? 0u : iss_buf + 1;
+		} else {
+			uint16_t* buf = qry_s + size_t(iss_buf) * kQElems;
+#pragma unroll
+			for (int j = 0; j < kQIps; ++j) __builtin_amdgcn_global_load_lds(src[j] + k0, (lds_void*)(buf + (j * 256 + rp * 64) * 8), 16, 0, 0);
+			iss_buf = iss_buf + 1 == uint32_t(QBUFS) ? 0u : iss_buf + 1;
+		}
+		++iss_g;
+		if (++iss_stage == stages) {
+			iss_stage = 0;
+			iss_tile += gridDim.x;
+		}
+	};
+	const int ahead = row_loader ? RB - 1 : QBUFS - 1;
+	for (int a = 0; a < ahead; ++a) {
+		if (iss_g < total) issue();
+	}
+
+	const uint32_t half = lane >> 5;
+	const uint32_t swz = (lane >> 2) & 3;
+	const uint32_t xrow = 64 * rp + (lane & 31), qrow = (QT / 2) * qh + (lane & 31);
+
+	uint64_t tile = blockIdx.x;
+	uint32_t s = 0, rbuf = 0, qbuf = 0, tpar = 0;
+	f32x16 acc[2][QB];
+#pragma unroll
+	for (int a = 0; a < 2; ++a) {
+#pragma unroll
+		for (int b = 0; b < QB; ++b) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+		}
+	}
+	for (uint64_t g = 0; g < total; ++g) {
+		// stage g of THIS wave's stream has landed once at most the younger stages' DMAs are outstanding (4 resp. kQIps per stage; a tile's
+		// row terms ride in front of its first stage, so counting them out only ever waits for one instruction more than needed)
+		const uint64_t younger = iss_g - g - 1;
+		if (row_loader) {
+			switch (younger < uint64_t(RB - 2) ? int(younger) : RB - 2) {
+				case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+				case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+				case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+				case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+				case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+				default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+			}
+		} else {
+			switch (younger < uint64_t(QBUFS - 2) ? int(younger) : QBUFS - 2) {
+				case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+				default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQIps) : "memory"); break;
+			}
+		}
+		__builtin_amdgcn_s_barrier();   // ... and for every wave; also: everyone is done reading the buffers the next DMAs overwrite
+		asm volatile("" ::: "memory");
+		if (iss_g < total) issue();
+		const uint16_t* xb = rows_s + size_t(rbuf) * kGlXElems;
+		const uint16_t* qb = qry_s + size_t(qbuf) * kQElems;
+		rbuf = rbuf + 1 == uint32_t(RB) ? 0u : rbuf + 1;
+		qbuf = qbuf + 1 == uint32_t(QBUFS) ? 0u : qbuf + 1;
+#pragma unroll
+		for (int t = 0; t < 2; ++t) {
+			const uint32_t cs = ((2 * t + half) ^ swz) << 3;
+			bf16x8 bfrag[2], afrag[QB];
+#pragma unroll
+			for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + (xrow + 32 * a) * 32 + cs));
+#pragma unroll
+			for (int b = 0; b < QB; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (qrow + 32 * b) * 32 + cs));
+#pragma unroll
+			for (int a = 0; a < 2; ++a) {
+#pragma unroll
+				for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
+			}
+		}
+		if (++s < stages) continue;
+		s = 0;
+		// ---- tile epilogue (same element mapping as the kernel above; row terms from LDS)
+		const uint64_t row0 = tile * kBfRows;
+		tile += gridDim.x;
+		const float* terms = term_s + tpar * kBfRows;
+		tpar ^= 1u;
+#pragma unroll
+		for (int a = 0; a < 2; ++a) {
+			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
+			const bool row_ok = row < p.n;
+			float row_term = 0.f;
+			if constexpr (kTerms) row_term = terms[64 * rp + 32 * a + (lane & 31)];
+			const int qlane = 4 * (lane >> 5) + (QT / 2) * qh;
+			if constexpr (kMode == kGemmDense) {
+				float* dp = p.dense + size_t(qlane) * p.n + row;
+				const size_t n1 = p.n, n5 = 5 * p.n;
+#pragma unroll
+				for (int b = 0; b < QB; ++b) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+						float d;
+						if constexpr (kMetric == kL2) {
+							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+						} else if constexpr (kMetric == kIP) {
+							d = -acc[a][b][r];
+						} else {
+							d = -acc[a][b][r] * row_term;
+						}
+						if (row_ok) *dp = d;
+						dp += ((r & 3) == 3) ? n5 : n1;
+						asm volatile("" : "+v"(dp));
+						acc[a][b][r] = 0.0f;
+					}
+				}
+			} else {
+#pragma unroll
+				for (int b = 0; b < QB; ++b) {
+					float best = acc[a][b][0];
+#pragma unroll
+					for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[a][b][r]);
+					const int gi = (qh * QB + b) * 2 + (lane >> 5);
+					float dbest;
+					if constexpr (kMetric == kL2) {
+						dbest = (gmin_s[gi] + row_term) - 2.0f * best;
+					} else if constexpr (kMetric == kIP) {
+						dbest = -best;
+					} else {
+						dbest = -best * row_term;
+					}
+					uint32_t mask = 0;
+					if (__ballot(row_ok && !(dbest > gmax_s[gi]))) {
+#pragma unroll
+						for (int r = 0; r < 16; ++r) {
+							const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+							float d;
+							if constexpr (kMetric == kL2) {
+								d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+							} else if constexpr (kMetric == kIP) {
+								d = -acc[a][b][r];
+							} else {
+								d = -acc[a][b][r] * row_term;
+							}
+							mask |= (d <= thr_s[qo + qlane]) ? (1u << r) : 0u;
+						}
+					}
+#pragma unroll
+					for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+					if (!row_ok) mask = 0;
+					__builtin_amdgcn_sched_barrier(0);
+					if (__ballot(mask != 0)) {
+						while (mask) {
+							const int r = __builtin_ctz(mask);
+							mask &= mask - 1;
+							const uint32_t qi = 32 * b + (r & 3) + 8 * (r >> 2) + qlane;
+							const uint32_t at = atomicAdd(my_n, 1u);
+							if (at < uint32_t(kGlHitCapSplit)) {
+								hit_s[at] = (static_cast<unsigned long long>(qi) << 32) | uint32_t(row);
+							} else {   // list full (rows next to many queries): straight to the global lists
+								const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+								if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(row);
+							}
+						}
+					}
+				}
+			}
+		}
+		if constexpr (kMode == kGemmFilter) {
+			if (*my_n >= uint32_t(kGlHitCapSplit / 2)) flush_hits();   // wave-uniform: only this wave writes its counter
+		}
+	}
+	if constexpr (kMode == kGemmFilter) flush_hits();
+}
+
+size_t gemm_bf16_split_lds_bytes(int qt, int rb, int qbufs) {
+	return (size_t(rb) * kGlXElems + size_t(qbufs) * qt * 32) * sizeof(uint16_t) + 2 * size_t(kBfRows) * sizeof(float) +
+		   2 * size_t(qt) * sizeof(float) + 8 * sizeof(uint32_t) + size_t(8) * kGlHitCapSplit * 8 + 2 * size_t(qt / 16) * sizeof(float);
+}
+
 size_t gemm_bf16_glds_lds_bytes(int qt) {
 	return size_t(gl_bufs(qt)) * (kGlXElems + qt * 32) * sizeof(uint16_t) + 2 * size_t(qt) * sizeof(float) + 8 * sizeof(uint32_t) + size_t(8) * kGlHitCap * 8 +
 		   2 * size_t(qt / 16) * sizeof(float);
 }
 
+// RXGPU_GEMM_SPLIT=0 / 1: the single-ring kernel / the split-ring one (A/B in one process: read at every launch)
+static bool gemm_split_rings() {
+	const char* e = std::getenv("RXGPU_GEMM_SPLIT");
+	return e ? std::atoi(e) != 0 : true;
+}
+
 template <int kMetric, int kMode, int QT>
 static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
+	if (gemm_split_rings()) {
+		if constexpr (QT == 256) {   // RXGPU_GEMM_RINGS=72: seven row buffers + two query buffers instead of six + three (A/B)
+			const char* e = std::getenv("RXGPU_GEMM_RINGS");
+			if (e && std::atoi(e) == 72) {
+				const size_t lds = gemm_bf16_split_lds_bytes(QT, 7, 2);
+				static std::atomic<uint64_t> raised_72{0};
+				if (hipError_t er = raise_dynamic_lds_once(raised_72, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT, 7, 2>), lds); er != hipSuccess) {
+					return er;
+				}
+				hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT, 7, 2>), dim3(grid), dim3(kBfThreads), lds, s, p);
+				return hipGetLastError();
+			}
+		}
+		const size_t lds = gemm_bf16_split_lds_bytes(QT, gl_row_bufs(QT), gl_query_bufs(QT));
+		static std::atomic<uint64_t> raised_split{0};
+		if (hipError_t e = raise_dynamic_lds_once(raised_split, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT>), lds); e != hipSuccess) {
+			return e;
+		}
+		hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT>), dim3(grid), dim3(kBfThreads), lds, s, p);
+		return hipGetLastError();
+	}
 	const size_t lds = gemm_bf16_glds_lds_bytes(QT);
 	static std::atomic<uint64_t> raised{0};
 	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&knn_gemm_bf16_glds<kMetric, kMode, QT>), lds); e != hipSuccess) {

@@ -59,7 +59,19 @@ int rxgpu_search_ctx::ensure_pinned(size_t need) {
 	h_pinned_bytes = want;
 	return RXGPU_OK;
 }
+int rxgpu_search_ctx::ensure_aux() {
+	if (aux_stream) return RXGPU_OK;
+	RX_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+	RX_HIP(hipEventCreateWithFlags(&aux_done, hipEventDisableTiming));
+	RX_HIP(hipEventCreateWithFlags(&main_done, hipEventDisableTiming));
+	return RXGPU_OK;
+}
 void rxgpu_search_ctx::release() {
+	if (aux_done) (void)hipEventDestroy(aux_done);
+	if (main_done) (void)hipEventDestroy(main_done);
+	if (aux_stream) (void)hipStreamDestroy(aux_stream);
+	aux_done = main_done = nullptr;
+	aux_stream = nullptr;
 	d_queries.release();
 	d_part_dist.release();
 	d_part_row.release();
@@ -1810,6 +1822,21 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	if (int rc = c->d_out_dist.ensure(size_t(nq) * k * sizeof(float)); rc) return rc;
 	if (int rc = c->d_out_row.ensure(size_t(nq) * k * sizeof(uint32_t)); rc) return rc;
 	if (int rc = c->d_out_count.ensure(size_t(nq) * sizeof(uint32_t)); rc) return rc;
+	// the bitsets of the first launch (N / 8 bytes per search: 2 GB for 16 384 searches over 1M nodes) are zeroed on a second stream and
+	// enqueued BEFORE the upload of the query block (a copy from pageable memory keeps this thread until it is staged): the two overlap,
+	// the launch waits for both
+	bool first_zeroed = false;
+	if (!big_ef && !vis_hash_log2) {
+		const uint32_t cq = uint32_t(std::min<uint64_t>(vis_slots, nq));
+		const size_t zero_bytes = size_t(cq) * words * 4;
+		if (zero_bytes >= (size_t(8) << 20)) {
+			if (int rc = c->d_visited.ensure(zero_bytes); rc) return rc;
+			if (int rc = c->ensure_aux(); rc) return rc;
+			RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, zero_bytes, c->aux_stream));
+			RX_HIP(hipEventRecord(c->aux_done, c->aux_stream));
+			first_zeroed = true;
+		}
+	}
 	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, qbytes, hipMemcpyHostToDevice, c->stream));
 	rxgpu::HnswParams p{};
 	if (sq8) {
@@ -1877,7 +1904,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(vis_slots)) {
 			const uint32_t cq = uint32_t(std::min<uint64_t>(vis_slots, nq - q0));
 			if (int rc = c->d_visited.ensure(size_t(cq) * vis_words * 4); rc) return rc;
-			if (!vis_hash_log2) RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
+			if (!vis_hash_log2) {
+				const size_t zero_bytes = size_t(cq) * words * 4;
+				if (q0 == 0 && first_zeroed) {
+					RX_HIP(hipStreamWaitEvent(c->stream, c->aux_done, 0));
+				} else {   // (a later chunk of the same call reuses the buffer behind the chunk before it)
+					RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, zero_bytes, c->stream));
+				}
+			}
 			rxgpu::HnswParams pc = p;
 			pc.vis_hash_log2 = vis_hash_log2;
 			pc.visited_words = vis_words;

@@ -355,6 +355,11 @@ struct rxgpu_search_ctx {
 	rxgpu_devbuf d_subset, d_bitmap, d_tiles;                                      // pre-filtered search: row list, allowed-rows bitmap, tile sums
 	void* h_pinned = nullptr;
 	size_t h_pinned_bytes = 0;
+	// second stream + events (created on first use): work that does not depend on the query upload — zeroing the visited bitsets of an
+	// HNSW launch — runs beside it
+	hipStream_t aux_stream = nullptr;
+	hipEvent_t aux_done = nullptr, main_done = nullptr;
+	int ensure_aux();
 	int ensure_pinned(size_t need);
 	void release();
 };

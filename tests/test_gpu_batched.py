@@ -24,12 +24,21 @@ def check_batch(ix, oracle, metric, rows, inv, queries, kk):
         assert np.array_equal(bits(dist[qi, :c]), bits(wd))
 
 
-@pytest.fixture(params=["bf16", "f32"])
+@pytest.fixture(params=["bf16", "bf16_single_ring", "f32"])
 def nomination(request, monkeypatch):
-    """Both nomination GEMMs: bf16 matrix cores over the shadow (default for every batch) and f32-input MFMA over the rows (what a GPU
-    without room for the shadow falls back to)."""
+    """The nomination GEMMs: bf16 matrix cores over the shadow (default for every batch; the split-ring kernel, and the single-ring one it
+    replaced: RXGPU_GEMM_SPLIT=0) and f32-input MFMA over the rows (what a GPU without room for the shadow falls back to)."""
     if request.param == "f32":
         monkeypatch.setenv("RXGPU_BATCH_BF16_MIN", "0")
+    if request.param == "bf16_single_ring":
+        monkeypatch.setenv("RXGPU_GEMM_SPLIT", "0")
+    return request.param
+
+
+@pytest.fixture(params=["split_ring", "single_ring"])
+def gemm_ring(request, monkeypatch):
+    if request.param == "single_ring":
+        monkeypatch.setenv("RXGPU_GEMM_SPLIT", "0")
     return request.param
 
 
@@ -115,7 +124,7 @@ def test_batched_device_api_matches_host_api(rxgpu, oracle):
 # ---------------------------------------------------------------------------------------------- bf16 nomination path (batches > 64 queries)
 @pytest.mark.parametrize("metric", [0, 1, 2])
 @pytest.mark.parametrize("d,n", [(100, 30_000), (768, 20_000), (130, 9_000), (64, 300), (512, 6_000), (250, 5_000), (768, 33)])
-def test_bf16_nomination_is_exact(rxgpu, oracle, metric, d, n):
+def test_bf16_nomination_is_exact(rxgpu, oracle, gemm_ring, metric, d, n):
     """Batches of 65..256 queries are nominated by the bf16 matrix-core GEMM over the bf16 shadow of the rows (knn_batched_bf16.hip) under a
     rigorous rounding bound; the exact kernels re-score.  Rows and distance bits must equal per-query exact search."""
     rows = make_corpus(d + 7, n, d)

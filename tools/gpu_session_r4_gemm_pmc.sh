@@ -1,0 +1,14 @@
+#!/bin/bash
+# counters of the two bf16 nomination kernels on the headline corpus (one counter set per pass; kernel trace beside each)
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/gemm_pmc; export TMPDIR=/tmp
+CMD="python $R/tools/bench_gemm_ab.py --metrics ip --rounds 1 --iters 2"
+cd /tmp
+i=0
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "FETCH_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  timeout 400 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/gemm_pmc/pass$i -o g -- $CMD > /tmp/gp$i.log 2>&1; echo "pass $i rc=$?"; tail -2 /tmp/gp$i.log
+done
+cd $R
+for f in $(find gpurun_out/gemm_pmc -name "*counter_collection.csv" -o -name "*kernel_trace.csv"); do (head -1 "$f"; grep knn_gemm_bf16 "$f") > "$f.rx" && mv "$f.rx" "$f"; done
+find gpurun_out/gemm_pmc -name "*.csv" -size +2M -delete
+python tools/summarize_gemm_pmc.py gpurun_out/gemm_pmc gpurun_out/rd4_gemm_pmc.json
