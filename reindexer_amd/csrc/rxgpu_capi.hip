@@ -1811,6 +1811,9 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		// costs its memset (N / 8 bytes per query) and, once the bitsets of the searches in flight outgrow the Infinity Cache, an HBM round trip per
 		// test.  The hash set takes over where one search's bitset is 16 x its hash set or more (4.2 M nodes at ef = 128).
 		if ((e && std::strcmp(e, "bitset") == 0) || (!force_hash && (16ull << vis_hash_log2) > words)) vis_hash_log2 = 0;
+		// in HBM the set gets twice the words (a quarter full at most): fewer second probes — 10M x 768, one graph and box, 16 384 queries:
+		// 2^13 words 469 k q/s kernels only, 2^14 498 k, 2^15 497 k, 2^16 483 k, bitset 472 k (profiles/rd4j_hnsw_10m_*.json)
+		if (vis_hash_log2 && !getenv("RXGPU_HNSW_VISITED_LOG2") && vis_hash_log2 < 18) vis_hash_log2 += 1;
 	}
 	const uint64_t vis_words = vis_hash_log2 ? (1ull << vis_hash_log2) : words;   // per search of the first pass
 	const uint64_t vis_slots = vis_hash_log2 ? std::max<uint64_t>(1, std::min<uint64_t>(32768, visited_budget / (vis_words * 4))) : max_slots;

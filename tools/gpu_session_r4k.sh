@@ -1,7 +1,8 @@
 #!/bin/bash
 # round 4, session k: the split-ring bf16 nomination kernel — parity tests of both kernels, then the A/B on the headline corpus
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_batched.py -q -m gpu -x 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_batched.py tests/test_gpu_ft_packed.py -q -m gpu -x 2>&1 | tail -4
+timeout 300 python tools/bench_ft_packed.py --out gpurun_out/r4k_ft_packed.json > /tmp/pk.log 2>&1; echo "packed rc=$?"; python -c "import json; d=json.load(open('gpurun_out/r4k_ft_packed.json'))['device']; print('packed wall', d['seconds'], 'count', d['kernels']['count_ms'], 'write', d['kernels']['write_ms'])"
 timeout 900 python tools/bench_gemm_ab.py --out gpurun_out/r4k_gemm_ab.json 2>&1 | tail -8
 timeout 300 python tools/bench_gemm_ab.py --batch 128 --metrics ip --out gpurun_out/r4k_gemm_ab_b128.json 2>&1 | tail -3
 # HNSW 1M: heap area of an in-kernel restart (LDS per workgroup decides how many searches a CU holds: 600 entries -> 15, 320 -> 20) now that an
