@@ -595,8 +595,20 @@ __device__ __forceinline__ bool hnsw_visit_sel(uint32_t* visited, uint32_t* lds_
 // otherwise one set (92 VGPRs: twice the resident searches).  D <= 512 always affords two.
 // kSorted: 0 = the reference's two heaps, replayed by lane 0; S > 0 = HnswSortedList<S> (ef <= 64 S, no deleted nodes, heaps not in LDS at all)
 // kDel (with kSorted): the graph has deleted nodes — HnswSortedListDel
+// A search that leaves as kHnswOverflow also goes into the launch's overflow queue when there is one: a few helper workgroups launched
+// beside the batch (hnsw_helper_kernel) pick it up and run it with the largest LDS heap WHILE the batch is still running — after the batch
+// such a search is pure tail (one of 16 384 queries took 5 - 7 ms of a 32 ms batch at 10M x 768).
+__device__ __forceinline__ void hnsw_enqueue_overflow(const HnswParams& p, uint32_t qi) {   // lane 0, behind the out_count store
+	if (!p.helper_n) return;
+	__threadfence();
+	const uint32_t at = atomicAdd(p.helper_n, 1u);
+	if (at < p.helper_cap) __hip_atomic_store(&p.helper_ids[at], p.q_base + qi + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One search by one wavefront: slot = its scratch (visited set, global heap), qi = the query.  hnsw_search_kernel runs it once per
+// workgroup, hnsw_helper_kernel in a loop over the overflow queue.
 template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0, bool kDel = false>
-__global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
+__device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint32_t slot, const uint32_t qi) {
 	static_assert(kSorted == 0 || !kGlobalCand, "the sorted-list search starts in LDS; its re-runs with a global heap are heap-kernel launches");
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
@@ -615,8 +627,6 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 	__shared__ uint32_t s_pre[64];   // sorted-list search: the link block of the candidate next in line, fetched one hop ahead by LDS-DMA
 
 	const int lane = threadIdx.x;
-	const uint32_t slot = blockIdx.x;
-	const uint32_t qi = p.only ? p.only[slot] : slot;
 	const float* q = p.queries + size_t(qi) * p.dim;
 	uint32_t* visited = p.visited + size_t(slot) * p.visited_words;
 	uint2* cand = kGlobalCand ? p.gcand + size_t(slot) * p.gcand_cap : lcand;
@@ -725,7 +735,10 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 		uint32_t pre_node = 0xFFFFFFFFu;
 		for (;;) {
 			if (ndist - ndist_upper + p.maxM0 > vis_limit) {   // the hash set would pass half full: this search goes to the bitset re-run
-				if (lane == 0) p.out_count[qi] = kHnswOverflow;
+				if (lane == 0) {
+					p.out_count[qi] = kHnswOverflow;
+					hnsw_enqueue_overflow(p, qi);
+				}
 				return;
 			}
 			uint32_t node;
@@ -951,6 +964,7 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 	if (lane == 0) {
 		if (overflow) {
 			p.out_count[qi] = kHnswOverflow;
+			if constexpr (!kGlobalCand) hnsw_enqueue_overflow(p, qi);
 		} else {
 			while (top_n > int(p.k)) hp_pop(top, top_n);   // SearchKnn :1998-2000
 			for (int i = 0; i < top_n; ++i) {
@@ -963,6 +977,45 @@ __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 &&
 			atomicAdd(&p.stats[0], ndist);
 			atomicAdd(&p.stats[1], hops);
 		}
+	}
+}
+
+template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0, bool kDel = false>
+__global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
+	const uint32_t slot = blockIdx.x;
+	hnsw_search_one<kMetric, kGlobalCand, NB, kLatency, kSq8, kSorted, kDel>(p, slot, p.only ? p.only[slot] : slot);
+}
+
+// Helper workgroups of a batch: workgroup w serves entries w, w + G, ... of the overflow queue until the stop word is set (a 4-byte memset
+// behind the batch's last launch) and its next entry does not exist.  Every search runs on the heap kernel's code with the largest LDS heap
+// and the workgroup's own bitset (zeroed here); a search that overflows again keeps kHnswOverflow for the host's global-heap tiers.  A
+// wall-clock limit ends a helper that was never told to stop.
+template <int kMetric, int NB, bool kSq8>
+__global__ __launch_bounds__(64) void hnsw_helper_kernel(HnswParams p, HnswHelper hq) {
+	const uint32_t w = blockIdx.x, G = gridDim.x;
+	const int lane = threadIdx.x;
+	const unsigned long long t0 = wall_clock64();
+	uint4* bits = reinterpret_cast<uint4*>(p.visited + size_t(w) * p.visited_words);
+	for (uint32_t s = w; s < hq.cap; s += G) {
+		uint32_t id1 = 0;
+		for (;;) {
+			id1 = __hip_atomic_load(&hq.ids[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			if (id1) break;
+			if (__hip_atomic_load(hq.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {   // the batch is over: the queue is final
+				const uint32_t n = __hip_atomic_load(hq.n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+				if (s >= n) return;
+				id1 = __hip_atomic_load(&hq.ids[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+				if (id1) break;
+			}
+			if (wall_clock64() - t0 > hq.ticks_limit) return;
+			__builtin_amdgcn_s_sleep(100);
+		}
+		id1 = uint32_t(__builtin_amdgcn_readfirstlane(int(id1)));
+		for (uint64_t i = lane; i < p.visited_words / 4; i += 64) bits[i] = make_uint4(0u, 0u, 0u, 0u);   // (visited_words is padded to 4)
+		__threadfence();
+		__syncthreads();
+		hnsw_search_one<kMetric, false, NB, (NB > 8 && !kSq8), kSq8, 0, false>(p, w, id1 - 1u);
+		__syncthreads();
 	}
 }
 
@@ -1097,6 +1150,34 @@ void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool g
 	}
 }
 
+
+template <int NB, bool kSq8>
+static void launch_hnsw_helper_nb(int metric, const HnswParams& p, const HnswHelper& hq, uint32_t groups, hipStream_t s) {
+	const size_t lds = (size_t(p.ef_cap) + p.lds_cand_cap) * 8 + (kSq8 ? 0 : size_t(NB) * 256);
+	switch (metric) {
+		case kL2: hipLaunchKernelGGL((hnsw_helper_kernel<kL2, NB, kSq8>), dim3(groups), dim3(64), lds, s, p, hq); break;
+		case kIP: hipLaunchKernelGGL((hnsw_helper_kernel<kIP, NB, kSq8>), dim3(groups), dim3(64), lds, s, p, hq); break;
+		default: hipLaunchKernelGGL((hnsw_helper_kernel<kCos, NB, kSq8>), dim3(groups), dim3(64), lds, s, p, hq); break;
+	}
+}
+
+// the helper workgroups of a batch (hnsw_helper_kernel): p = the batch's parameters with the helpers' own visited bitsets, the largest LDS
+// heap, no `only` list, no overflow queue of their own
+void launch_hnsw_helper(int metric, const HnswParams& p, const HnswHelper& hq, uint32_t groups, hipStream_t s) {
+	if (p.codes) {
+		switch (p.dim) {
+			case 128: launch_hnsw_helper_nb<2, true>(metric, p, hq, groups, s); break;
+			case 768: launch_hnsw_helper_nb<12, true>(metric, p, hq, groups, s); break;
+			default: launch_hnsw_helper_nb<0, true>(metric, p, hq, groups, s); break;
+		}
+		return;
+	}
+	switch (p.dim) {
+		case 128: launch_hnsw_helper_nb<2, false>(metric, p, hq, groups, s); break;
+		case 768: launch_hnsw_helper_nb<12, false>(metric, p, hq, groups, s); break;
+		default: launch_hnsw_helper_nb<0, false>(metric, p, hq, groups, s); break;
+	}
+}
 
 // SearchRange's second half on the device (hnswalg.h:2030-2064): the closure of the ef-search's hits under "neighbour on level 0, not
 // deleted, dist < radius".  The result is a SET (the reference's radius_queue order does not change it), so the expansion runs level by

@@ -144,6 +144,11 @@ struct HnswParams {
 	uint32_t* out_row;
 	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode), kHnswTie = re-run on the heaps
 	const uint32_t* only;     // optional: list of query indices to process (blockIdx.x indexes this list)
+	// overflow queue of the launch (null: none): a search that leaves as kHnswOverflow appends q_base + its query index + 1
+	uint32_t* helper_n;
+	uint32_t* helper_ids;
+	uint32_t helper_cap;
+	uint32_t q_base;          // index of this launch's query 0 in the whole batch (chunked launches)
 	uint2* gcand;             // global-mode candidate heap storage [slots][gcand_cap] of (dist bits, id)
 	uint64_t gcand_cap;
 	unsigned long long* stats;   // optional [2]: distance evaluations, hops
@@ -158,6 +163,15 @@ struct HnswParams {
 	const uint8_t* qcodes;       // [nq][dim]
 	const float* qcorr;          // [nq]
 	const float* qnorm;          // [nq]
+};
+
+// what the helper workgroups of a batch poll (hnsw_helper_kernel)
+struct HnswHelper {
+	const uint32_t* n;        // entries appended so far
+	const uint32_t* ids;      // [cap] query index + 1, 0 = not written yet
+	const uint32_t* stop;     // set behind the batch's last launch
+	uint32_t cap;
+	unsigned long long ticks_limit;   // wall_clock64 ticks (100 MHz) after which a helper gives up
 };
 
 // In-place graph update (rxgpu_hnsw_patch_graph): one workgroup per touched node scatters its staged lists into the resident arrays

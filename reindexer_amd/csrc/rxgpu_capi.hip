@@ -87,6 +87,8 @@ void rxgpu_search_ctx::release() {
 	d_cand_dist.release();
 	d_cand_cnt.release();
 	d_visited.release();
+	d_helper.release();
+	d_helper_bits.release();
 	d_ivf.release();
 	d_gcand_d.release();
 	d_redo.release();
@@ -1894,6 +1896,11 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// launch it needs costs 2.9 ms; 600 (10 KB, 16 per CU) 11.96 ms in all; 780 12.10; 1024 12.25; no in-kernel restart (0: the tie queries
 	// come back to this function and get a launch of their own) 9.92 + 2.53 = 12.46 ms.
 	uint32_t sorted_restart_cap = 600;
+	// Round 4: with helper workgroups beside the batch (below) an overflowing restart is no longer a launch behind the batch, and the area
+	// can shrink to what lets a CU hold 20 searches instead of 15 (LDS per workgroup 10.3 -> 7.6 KB): first pass of 16 384 queries at
+	// 1M x 768 11.9 -> 10.5 ms (profiles/rd4k_hnsw_1m_restart_caps.txt; without the helpers the one restart that overflows costs 2.5 ms).
+	const bool helper_wanted = nq >= 2048 && !big_ef && !(getenv("RXGPU_HNSW_HELPER") && atoi(getenv("RXGPU_HNSW_HELPER")) == 0);
+	if (helper_wanted && ef <= 128) sorted_restart_cap = 256;
 	if (const char* e = getenv("RXGPU_HNSW_RESTART_CAND")) sorted_restart_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(0, atoi(e))));
 	if (const char* e = getenv("RXGPU_HNSW_SORTED")) {   // A/B and test hook: 0 = heaps only, 2 = list shifts through ds_bpermute instead of DPP
 		sorted_mode = uint32_t(std::max(0, atoi(e)));
@@ -1904,6 +1911,32 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		redo.resize(nq);
 		for (uint32_t q = 0; q < nq; ++q) redo[q] = q;
 	} else {
+		// Helper workgroups beside a large batch (hnsw_helper_kernel, second stream): a search that overflows its LDS heap area is queued and
+		// runs with the largest LDS heap while the batch is still going, instead of as a launch of its own behind it.  RXGPU_HNSW_HELPER=0: off.
+		constexpr uint32_t kHelperGroups = 64, kHelperCap = 4096;
+		const bool use_helper = helper_wanted;
+		uint32_t* hq_words = nullptr;   // [0] entries appended, [1] stop, [16 ..] ids
+		uint32_t helper_n = 0;
+		if (use_helper) {
+			const uint64_t words4 = (words + 3) & ~uint64_t(3);
+			const size_t hq_bytes = (size_t(kHelperCap) + 16) * 4;
+			if (int rc = c->ensure_aux(); rc) return rc;
+			if (int rc = c->d_helper.ensure(hq_bytes); rc) return rc;
+			if (int rc = c->d_helper_bits.ensure(size_t(kHelperGroups) * words4 * 4); rc) return rc;
+			hq_words = static_cast<uint32_t*>(c->d_helper.ptr);
+			RX_HIP(hipMemsetAsync(hq_words, 0, hq_bytes, c->aux_stream));
+			rxgpu::HnswParams ph = p;
+			ph.queries = static_cast<const float*>(c->d_queries.ptr);
+			ph.visited = static_cast<uint32_t*>(c->d_helper_bits.ptr);
+			ph.visited_words = words4;
+			ph.vis_hash_log2 = 0;
+			ph.vis_lds_log2 = 0;
+			ph.lds_cand_cap = uint32_t(rxgpu::kHnswCandLds);
+			ph.sorted = 0;
+			rxgpu::HnswHelper hq{hq_words, hq_words + 16, hq_words + 1, kHelperCap, 300000000ull};   // gives up after 3 s
+			rxgpu::launch_hnsw_helper(h->metric, ph, hq, kHelperGroups, c->aux_stream);
+			RX_HIP(hipGetLastError());
+		}
 		for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(vis_slots)) {
 			const uint32_t cq = uint32_t(std::min<uint64_t>(vis_slots, nq - q0));
 			if (int rc = c->d_visited.ensure(size_t(cq) * vis_words * 4); rc) return rc;
@@ -1928,6 +1961,12 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			pc.out_dist = p.out_dist + size_t(q0) * k;
 			pc.out_row = p.out_row + size_t(q0) * k;
 			pc.out_count = p.out_count + q0;
+			if (use_helper) {
+				pc.helper_n = hq_words;
+				pc.helper_ids = hq_words + 16;
+				pc.helper_cap = kHelperCap;
+				pc.q_base = q0;
+			}
 			if (use_sorted) {   // the list lives in registers; LDS holds only the heap area of a search that starts over (equal keys that matter)
 				pc.sorted = sorted_mode;
 				pc.lds_cand_cap = sorted_restart_cap;
@@ -1937,11 +1976,18 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 		}
 		RX_HIP(hipGetLastError());
+		if (use_helper) {   // the batch is over: tell the helpers, take their results with the batch's
+			RX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(hq_words + 1), 1, 1, c->stream));
+			RX_HIP(hipEventRecord(c->aux_done, c->aux_stream));
+			RX_HIP(hipStreamWaitEvent(c->stream, c->aux_done, 0));
+			RX_HIP(hipMemcpyAsync(&helper_n, hq_words, sizeof(helper_n), hipMemcpyDeviceToHost, c->stream));
+		}
 		// counts and results travel together: a batch without re-runs (the common case for a handful of queries) is done after ONE wait
 		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 		RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		RX_HIP(hipStreamSynchronize(c->stream));
+		h->hnsw_lds_reruns += std::min<uint32_t>(helper_n, kHelperCap);
 		std::vector<uint32_t> ties;
 		bool clean = true;
 		for (uint32_t q = 0; q < nq; ++q) {

@@ -1479,10 +1479,17 @@ int rxgpu_ft_set_words_packed_ptrs(rxgpu_ft_index* h, uint32_t nwords, const uin
 		segs.cps = static_cast<rxgpu::FtPackedCheckpoint*>(h->d_pk_segs.ptr);
 		segs.nsegs = nsegs;
 	}
-	// chunks of ~8 MB of streams, whole words each (launch order: the longest words travel first)
+	// The streams may travel in chunks of whole words (launch order: the longest words first) so that the gather of chunk c + 1, the copy of
+	// chunk c and the counting pass over chunk c - 1 overlap.  Measured on the 100 000-word dictionary of tools/bench_ft_packed.py: 49.8 ms
+	// per call with 8 MB chunks against 34.6 ms in one piece (profiles/rd4k_ft_packed_chunked.json, rd4h_ft_packed.json) — a chunk's
+	// counting pass lasts as long as its longest stream, and the longest streams are what travels first.  One piece is the default;
+	// RXGPU_FT_PACKED_CHUNK_MB=<n> cuts.
 	std::vector<uint32_t> chunk_first{0u};
 	{
-		const uint64_t target = 8ull << 20;
+		uint64_t target = ~0ull;
+		if (const char* e = std::getenv("RXGPU_FT_PACKED_CHUNK_MB")) {
+			if (std::atol(e) > 0) target = uint64_t(std::atol(e)) << 20;
+		}
 		uint64_t acc = 0;
 		for (uint32_t k = 0; k < nwords; ++k) {
 			acc += len_of(k);

@@ -76,6 +76,8 @@ void launch_rescore(int metric, const float* rows, const float* inv_norms, const
 // HNSW search (hnsw_search.hip)
 struct HnswParams;
 void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s);
+struct HnswHelper;
+void launch_hnsw_helper(int metric, const HnswParams& p, const HnswHelper& hq, uint32_t groups, hipStream_t s);
 struct HnswPatch;
 void launch_hnsw_patch(const HnswPatch& p, uint32_t n_dirty, hipStream_t s);
 struct HnswStream;
@@ -350,6 +352,7 @@ struct rxgpu_search_ctx {
 	rxgpu_devbuf d_queries, d_part_dist, d_part_row, d_out_dist, d_out_row, d_out_count, d_misc, d_select;
 	rxgpu_devbuf d_qpad, d_qstats, d_dense, d_cand_row, d_cand_dist, d_cand_cnt;   // batched path
 	rxgpu_devbuf d_visited, d_gcand_d, d_redo;                                     // HNSW (d_gcand_d: (dist bits, id) entries)
+	rxgpu_devbuf d_helper, d_helper_bits;                                          // HNSW: overflow queue of a batch, bitsets of its helper workgroups
 	rxgpu_devbuf d_top;                                                            // bf16-pruned scan: approximate top lists
 	rxgpu_devbuf d_ivf;                                                            // IVF: the coarse search's lists, distances, count
 	rxgpu_devbuf d_subset, d_bitmap, d_tiles;                                      // pre-filtered search: row list, allowed-rows bitmap, tile sums

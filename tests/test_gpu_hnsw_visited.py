@@ -150,3 +150,35 @@ def test_small_batches_keep_the_set_in_lds(rxgpu, oracle, monkeypatch, grid_rows
                     _same_batches(small, want, nq)
                     assert ix.hnsw_read_lds_reruns() > 0
     m.close()
+
+
+@pytest.mark.parametrize("d", [32, 768])
+def test_overflowing_searches_of_a_batch_run_on_helper_workgroups(rxgpu, oracle, monkeypatch, d):
+    """Batches of >= 2048 queries get helper workgroups on a second stream (hnsw_helper_kernel): a search whose in-kernel restart outgrows
+    its LDS heap area is queued and runs with the largest LDS heap while the batch is still going.  Rows on an integer grid, every row four
+    times, make most searches restart; a restart area of 6 entries makes every restart overflow (more than the queue holds: the rest takes
+    the tiers behind the batch).  Bar: the answers of the same batch with the helpers switched off, and the counter says they ran."""
+    n, nq = 6000, 2300
+    rng = np.random.default_rng(23)
+    base = rng.integers(-2, 3, size=(n // 4, d)).astype(np.float32)
+    base[np.all(base == 0, axis=1)] = 1.0
+    rows = np.ascontiguousarray(np.repeat(base, 4, axis=0)[rng.permutation(n)])
+    m, rows, labels = build(0, n, d, M=8, efc=40, rows=rows)
+    g = m.export_graph()
+    queries = rng.integers(-2, 3, size=(nq, d)).astype(np.float32)
+    with rxgpu.VectorIndex(0, d, n) as ix:
+        ix.upload_rows(0, rows, None)
+        ix.hnsw_attach_graph(g)
+        for cap in (None, "6"):
+            if cap:
+                monkeypatch.setenv("RXGPU_HNSW_RESTART_CAND", cap)
+            for k, ef in ((10, 64), (5, 128)):
+                monkeypatch.setenv("RXGPU_HNSW_HELPER", "0")
+                want = _batch(ix, queries, k, ef)
+                monkeypatch.delenv("RXGPU_HNSW_HELPER")
+                ix.hnsw_read_lds_reruns()
+                got = _batch(ix, queries, k, ef)
+                _same_batches(got, want, nq)
+                if cap:
+                    assert ix.hnsw_read_lds_reruns() > 0
+    m.close()
