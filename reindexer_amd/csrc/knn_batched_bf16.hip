@@ -35,10 +35,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 	return uint16_t(u >> 16);
 }
 
-// rows [n][stride] f32 -> shadow [n][ld] bf16 (ld = dim rounded up to 64, zero padded); also used for the padded query block
-__global__ __launch_bounds__(256) void knn_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld) {
+// rows [n][stride] f32 -> bf16 rows of ld elements (ld = dim rounded up to 64, zero padded): the shadow of corpus rows first_row .. (in
+// its layout, knn_kernels.hip.h), or — blocked = 0, first_row = 0 — the padded query block
+__global__ __launch_bounds__(256) void knn_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, uint64_t first_row,
+													uint32_t blocked) {
 	const uint32_t chunks = ld / 8;   // 8 elements (16 B out) per thread
 	const uint64_t total = n * chunks;
+	const uint32_t step = shadow_stage_step(blocked != 0);
 	for (uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += uint64_t(gridDim.x) * blockDim.x) {
 		const uint64_t row = i / chunks;
 		const uint32_t k = uint32_t(i % chunks) * 8;
@@ -50,7 +53,16 @@ __global__ __launch_bounds__(256) void knn_to_bf16(const float* src, uint64_t n,
 			const float b = k + 2 * j + 1 < dim ? s[2 * j + 1] : 0.f;
 			w[j] = uint32_t(f32_to_bf16_rne(a)) | (uint32_t(f32_to_bf16_rne(b)) << 16);
 		}
-		*reinterpret_cast<uint4*>(dst + row * ld + k) = make_uint4(w[0], w[1], w[2], w[3]);
+		*reinterpret_cast<uint4*>(dst + shadow_elem_base(first_row + row, ld, blocked != 0) + uint64_t(k / 32) * step + k % 32) = make_uint4(w[0], w[1], w[2], w[3]);
+	}
+}
+
+// one row of the shadow onto another (swap-delete)
+__global__ __launch_bounds__(256) void knn_shadow_move(uint16_t* shadow, uint32_t ld, uint64_t from, uint64_t to, uint32_t blocked) {
+	const uint32_t step = shadow_stage_step(blocked != 0);
+	for (uint32_t k = threadIdx.x * 8; k < ld; k += 256 * 8) {
+		const uint64_t o = uint64_t(k / 32) * step + k % 32;
+		*reinterpret_cast<uint4*>(shadow + shadow_elem_base(to, ld, blocked != 0) + o) = *reinterpret_cast<const uint4*>(shadow + shadow_elem_base(from, ld, blocked != 0) + o);
 	}
 }
 
@@ -146,15 +158,16 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 #pragma unroll
 			for (int j = 0; j < 2; ++j) {
 				const uint64_t row = iss_tile * kBfRows + src_r[j];
-				xsrc[j] = p.rows + (row < p.n ? row : p.n - 1) * p.row_step * p.ld + src_c[j];   // clamped: discarded by row_ok in the epilogue
+				xsrc[j] = p.rows + shadow_elem_base((row < p.n ? row : p.n - 1) * p.row_step, p.ld, p.blocked != 0) + src_c[j];   // clamped: discarded by row_ok in the epilogue
 			}
 		}
 		const uint32_t k0 = iss_stage * 32;
+		const uint32_t kx = iss_stage * shadow_stage_step(p.blocked != 0);
 		uint16_t* buf = stage_s + size_t(iss_g % kBufs) * kStageElems;
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
 			uint16_t* dx = buf + (j * kBfThreads + wave * 64) * 8;                 // wave-uniform base; the DMA adds lane x 16 B
-			__builtin_amdgcn_global_load_lds(xsrc[j] + k0, (lds_void*)(dx), 16, 0, 0);
+			__builtin_amdgcn_global_load_lds(xsrc[j] + kx, (lds_void*)(dx), 16, 0, 0);
 			if (j < kQDma) __builtin_amdgcn_global_load_lds(p.queries + size_t(src_r[j]) * p.ld + src_c[j] + k0, (lds_void*)(dx + kGlXElems), 16, 0, 0);
 		}
 		++iss_g;
@@ -401,13 +414,13 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 	uint32_t iss_buf = 0;             // ring position of the next stage (rows: mod RB, queries: mod QBUFS)
 	uint32_t iss_par = 0;             // which half of term_s the next tile's row terms go to
 	auto issue = [&]() {
-		const uint32_t k0 = iss_stage * 32;
+		const uint32_t k0 = iss_stage * (row_loader ? shadow_stage_step(p.blocked != 0) : 32u);
 		if (row_loader) {
 			if (iss_stage == 0) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const uint64_t row = iss_tile * kBfRows + src_r[j];
-					src[j] = p.rows + (row < p.n ? row : p.n - 1) * p.row_step * p.ld + src_c[j];   // clamped: discarded by row_ok in the epilogue
+					src[j] = p.rows + shadow_elem_base((row < p.n ? row : p.n - 1) * p.row_step, p.ld, p.blocked != 0) + src_c[j];   // clamped: discarded by row_ok in the epilogue
 				}
 				if constexpr (kTerms) {   // this wave's 64 row terms, in front of the tile's first rows (in-order retirement: there when they are)
 					const uint64_t row = iss_tile * kBfRows + 64 * rp + lane;
@@ -658,11 +671,15 @@ hipError_t launch_gemm_bf16(int metric, int mode, int qt, const GemmBf16Params& 
 	}
 }
 
-void launch_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, int cus, hipStream_t s) {
+void launch_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, int cus, hipStream_t s, uint64_t first_row, bool blocked) {
 	if (!n) return;
 	const uint64_t total = n * (ld / 8);
 	const uint32_t blocks = uint32_t(std::max<uint64_t>(1, std::min<uint64_t>((total + 255) / 256, uint64_t(cus) * 16)));
-	hipLaunchKernelGGL(knn_to_bf16, dim3(blocks), dim3(256), 0, s, src, n, stride, dim, dst, ld);
+	hipLaunchKernelGGL(knn_to_bf16, dim3(blocks), dim3(256), 0, s, src, n, stride, dim, dst, ld, first_row, blocked ? 1u : 0u);
+}
+
+void launch_shadow_move(uint16_t* shadow, uint32_t ld, uint64_t from, uint64_t to, bool blocked, hipStream_t s) {
+	hipLaunchKernelGGL(knn_shadow_move, dim3(1), dim3(256), 0, s, shadow, ld, from, to, blocked ? 1u : 0u);
 }
 
 }  // namespace rxgpu

@@ -60,7 +60,8 @@ struct ScanParams {
 // bf16-pruned scan (knn_scan.hip: knn_scan_bf16 + knn_filter_approx): approximate distances from the bf16 shadow, exact tail
 struct ScanBf16Params {
 	ScanParams sp;            // kk, part_dist / part_row ([nq][gridDim.x][kk]); rows / stride / dim / queries unused here
-	const uint16_t* rows16;   // [n][ld] bf16 shadow
+	const uint16_t* rows16;   // bf16 shadow: [n][ld], or tile-blocked (shadow_elem_base)
+	uint32_t blocked;         // layout of the shadow
 	const float* queries32;   // [nq][ld] f32, zero padded
 	const float* row_sq;      // L2
 	const float* q_sq;        // L2: [nq]
@@ -89,8 +90,18 @@ struct GemmParams {
 };
 
 // bf16 nomination GEMM (knn_batched_bf16.hip): shadow rows / queries as bf16, ld = dim rounded up to 64 (zero padded)
+// Layout of the bf16 shadow.  Row-major [n][ld], or TILE-BLOCKED: [tile of 256 rows][k-block of 32 elements][row in tile][32] — one K-stage
+// of a nomination tile (256 rows x 32 elements) is then one contiguous 16 KB read instead of 256 pieces of 64 B at a row stride, and a row's
+// next k-block lies kShadowStageElems further on.  Element (row, k) = shadow_elem_base(row) + (k / 32) * stage step + k % 32.
+constexpr uint32_t kShadowTileRows = 256, kShadowStageElems = kShadowTileRows * 32;
+__host__ __device__ inline uint64_t shadow_elem_base(uint64_t row, uint32_t ld, bool blocked) {
+	return blocked ? (row / kShadowTileRows) * (uint64_t(kShadowTileRows) * ld) + (row % kShadowTileRows) * 32u : row * ld;
+}
+__host__ __device__ inline uint32_t shadow_stage_step(bool blocked) { return blocked ? kShadowStageElems : 32u; }
+
 struct GemmBf16Params {
-	const uint16_t* rows;     // [n][ld]
+	const uint16_t* rows;     // the shadow (layout: `blocked`)
+	uint32_t blocked;
 	const uint16_t* queries;  // [256][ld], rows >= nq are zero
 	const float* inv_norms;
 	const float* row_sq;

@@ -348,9 +348,13 @@ __global__ __launch_bounds__(kScanThreads) void knn_scan_bf16(ScanBf16Params p) 
 	auto issue = [&](u32x4 (&x)[NC], uint64_t quad) {
 		uint64_t row = quad * kRowsPerWave + g;
 		if (row >= n) row = n - 1;
-		const u32x4* src = reinterpret_cast<const u32x4*>(p.rows16 + row * p.ld) + m;
+		// chunk m + 16 t of the row = k-block (m >> 2) + 4 t, 16-byte piece m & 3 of it; in the tile-blocked shadow the four 16-lane groups
+		// of a wavefront (four consecutive rows) read 256 contiguous bytes per k-block, as they read 256 contiguous bytes per row otherwise
+		const bool blocked = p.blocked != 0;
+		const u32x4* src = reinterpret_cast<const u32x4*>(p.rows16 + shadow_elem_base(row, p.ld, blocked) + uint64_t(m >> 2) * shadow_stage_step(blocked) + (m & 3) * 8);
+		const uint32_t tstep = shadow_stage_step(blocked) / 2;   // four k-blocks further on, in 16-byte units
 #pragma unroll
-		for (int t = 0; t < NC; ++t) x[t] = __builtin_nontemporal_load(src + 16 * t);
+		for (int t = 0; t < NC; ++t) x[t] = __builtin_nontemporal_load(src + size_t(tstep) * t);
 	};
 	auto reduce = [&](const u32x4 (&x)[NC], uint64_t quad) {
 		if (quad >= nquads) return;

@@ -240,11 +240,13 @@ int ensure_bf16_shadow(rxgpu_index* h, hipStream_t s) {
 	std::lock_guard<std::mutex> lk(h->mtx);
 	if (h->bf16_valid) return RXGPU_OK;
 	const uint32_t ld = (h->dim + 63u) & ~63u;
-	const uint64_t need = std::max<uint64_t>(h->capacity, h->count);
+	const uint64_t need = (std::max<uint64_t>(h->capacity, h->count) + rxgpu::kShadowTileRows - 1) / rxgpu::kShadowTileRows * rxgpu::kShadowTileRows;   // whole tiles
 	if (h->bf16_capacity < need) {
 		if (h->d_rows_bf16) (void)hipFree(h->d_rows_bf16);
 		h->d_rows_bf16 = nullptr;
 		h->bf16_capacity = 0;
+		const char* e = getenv("RXGPU_SHADOW_BLOCKED");
+		h->bf16_blocked = !(e && atoi(e) == 0);
 		if (hipMalloc(reinterpret_cast<void**>(&h->d_rows_bf16), need * ld * sizeof(uint16_t)) != hipSuccess) {
 			(void)hipGetLastError();   // not an error of the search: the caller falls back to the f32 rows
 			h->d_rows_bf16 = nullptr;
@@ -253,7 +255,7 @@ int ensure_bf16_shadow(rxgpu_index* h, hipStream_t s) {
 		}
 		h->bf16_capacity = need;
 	}
-	rxgpu::launch_to_bf16(h->d_rows, h->count, h->stride, h->dim, h->d_rows_bf16, ld, h->cus, s);
+	rxgpu::launch_to_bf16(h->d_rows, h->count, h->stride, h->dim, h->d_rows_bf16, ld, h->cus, s, 0, h->bf16_blocked);
 	RX_HIP(hipGetLastError());
 	RX_HIP(hipStreamSynchronize(s));
 	h->bf16_valid = true;
@@ -298,6 +300,7 @@ int enqueue_knn_batched_bf16(rxgpu_index* h, rxgpu_search_ctx* c, const float* d
 
 	rxgpu::GemmBf16Params g{};
 	g.rows = h->d_rows_bf16;
+	g.blocked = h->bf16_blocked ? 1u : 0u;
 	g.queries = qbf;
 	g.inv_norms = h->d_inv_norms;
 	g.row_sq = h->d_row_sq;
@@ -506,6 +509,7 @@ int enqueue_knn_pruned(rxgpu_index* h, rxgpu_search_ctx* c, const float* d_queri
 	p.sp.part_dist = static_cast<float*>(c->d_part_dist.ptr);
 	p.sp.part_row = static_cast<uint32_t*>(c->d_part_row.ptr);
 	p.rows16 = h->d_rows_bf16;
+	p.blocked = h->bf16_blocked ? 1u : 0u;
 	p.queries32 = qpad;
 	p.row_sq = h->d_row_sq;
 	p.q_sq = q_sq;
@@ -814,7 +818,7 @@ int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, cons
 			h->bf16_valid = false;
 		} else {
 			const uint32_t ld = (h->dim + 63u) & ~63u;
-			rxgpu::launch_to_bf16(dst, n, h->stride, h->dim, h->d_rows_bf16 + first_row * ld, ld, h->cus, nullptr);
+			rxgpu::launch_to_bf16(dst, n, h->stride, h->dim, h->d_rows_bf16, ld, h->cus, nullptr, first_row, h->bf16_blocked);
 		}
 	}
 	RX_HIP(hipGetLastError());
@@ -864,7 +868,9 @@ int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
 	}
 	if (h->bf16_valid) {
 		const uint32_t ld = (h->dim + 63u) & ~63u;
-		RX_HIP(hipMemcpy(h->d_rows_bf16 + to * ld, h->d_rows_bf16 + from * ld, ld * sizeof(uint16_t), hipMemcpyDeviceToDevice));
+		rxgpu::launch_shadow_move(h->d_rows_bf16, ld, from, to, h->bf16_blocked, nullptr);
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipStreamSynchronize(nullptr));
 	}
 	return RXGPU_OK;
 }

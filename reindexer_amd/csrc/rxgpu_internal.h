@@ -67,7 +67,9 @@ void launch_query_stats(int metric, const float* queries, uint32_t nq, uint32_t 
 						float* q_sq, float* margin, bool bf16, hipStream_t s);
 struct GemmBf16Params;
 hipError_t launch_gemm_bf16(int metric, int mode, int qt, const GemmBf16Params& p, uint32_t grid, hipStream_t s);
-void launch_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, int cus, hipStream_t s);
+void launch_to_bf16(const float* src, uint64_t n, uint32_t stride, uint32_t dim, uint16_t* dst, uint32_t ld, int cus, hipStream_t s, uint64_t first_row = 0,
+					bool blocked = false);   // dst = the shadow's base when first_row / blocked are given
+void launch_shadow_move(uint16_t* shadow, uint32_t ld, uint64_t from, uint64_t to, bool blocked, hipStream_t s);
 void launch_sample_threshold(const float* dense, uint64_t ns, uint32_t nq, uint32_t mt, uint32_t kk, const float* margin, float* thr,
 							 hipStream_t s);
 void launch_rescore(int metric, const float* rows, const float* inv_norms, const float* queries, uint32_t q_stride, uint32_t stride,
@@ -407,6 +409,7 @@ struct rxgpu_index {
 	bool stats_valid = false;
 	uint16_t* d_rows_bf16 = nullptr;   // bf16 shadow of the rows for the nomination GEMM (built lazily with the row statistics)
 	uint64_t bf16_capacity = 0;
+	bool bf16_blocked = true;   // layout of the shadow (knn_kernels.hip.h); RXGPU_SHADOW_BLOCKED=0 when the shadow is first built: row-major (A/B)
 	bool bf16_valid = false;
 	bool bf16_unavailable = false;     // the shadow did not fit in HBM: nominate on the f32 rows instead (still exact, still on the GPU)
 

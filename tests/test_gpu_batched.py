@@ -35,10 +35,13 @@ def nomination(request, monkeypatch):
     return request.param
 
 
-@pytest.fixture(params=["split_ring", "single_ring"])
+@pytest.fixture(params=["split_ring", "single_ring", "rowmajor_shadow"])
 def gemm_ring(request, monkeypatch):
+    """Both nomination kernels over the tile-blocked bf16 shadow (default), and the split-ring one over the row-major shadow."""
     if request.param == "single_ring":
         monkeypatch.setenv("RXGPU_GEMM_SPLIT", "0")
+    if request.param == "rowmajor_shadow":
+        monkeypatch.setenv("RXGPU_SHADOW_BLOCKED", "0")
     return request.param
 
 
@@ -154,7 +157,7 @@ def test_bf16_nomination_adversarial_magnitudes(rxgpu, oracle, metric):
         check_batch(ix, oracle, metric, rows, None, queries, 11)
 
 
-def test_bf16_shadow_follows_mutations(rxgpu, oracle):
+def test_bf16_shadow_follows_mutations(rxgpu, oracle, gemm_ring):
     rng = np.random.default_rng(9)
     n, d = 5000, 80
     rows = make_corpus(3, n, d)

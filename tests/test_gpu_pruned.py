@@ -10,9 +10,12 @@ from .test_gpu_batched import bits, check_batch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def pruned(monkeypatch):
+@pytest.fixture(params=["blocked_shadow", "rowmajor_shadow"])
+def pruned(request, monkeypatch):
+    """The scan reads the same bf16 shadow as the nomination GEMM: tile-blocked by default, row-major with RXGPU_SHADOW_BLOCKED=0."""
     monkeypatch.setenv("RXGPU_SCAN_BF16", "1")
+    if request.param == "rowmajor_shadow":
+        monkeypatch.setenv("RXGPU_SHADOW_BLOCKED", "0")
 
 
 @pytest.mark.parametrize("metric", [0, 1, 2])

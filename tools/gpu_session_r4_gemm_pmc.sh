@@ -1,7 +1,7 @@
 #!/bin/bash
 # counters of the two bf16 nomination kernels on the headline corpus (one counter set per pass; kernel trace beside each)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R; mkdir -p gpurun_out/gemm_pmc; export TMPDIR=/tmp
-CMD="python $R/tools/bench_gemm_ab.py --metrics ip --rounds 1 --iters 2"
+CMD="python $R/tools/bench_gemm_ab.py --metrics ip --rounds 1 --iters 2 --modes split_ring_blocked_shadow,single_ring_blocked_shadow"
 cd /tmp
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "FETCH_SIZE" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"; do

@@ -45,7 +45,7 @@ def main():
         if "FETCH_SIZE" in e:
             e["hbm_read_GB_corrected"] = e["FETCH_SIZE"] * 1024.0 * 2.0 / 1e9
         res[k] = e
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc <one set per pass>, tools/bench_gemm_ab.py --metrics ip --rounds 1 --iters 2 (10M x 768, 256 queries)",
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc <one set per pass>, tools/bench_gemm_ab.py --metrics ip --rounds 1 --iters 2 --modes split_ring_blocked_shadow,single_ring_blocked_shadow (10M x 768, 256 queries; tile-blocked bf16 shadow)",
                "kernels": res}, open(out, "w"), indent=1)
     for k, e in res.items():
         print(k[:70], {x: (round(y, 4) if isinstance(y, float) else y) for x, y in e.items() if x != "launches_per_counter"})
