@@ -1906,7 +1906,11 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// can shrink to what lets a CU hold 20 searches instead of 15 (LDS per workgroup 10.3 -> 7.6 KB): first pass of 16 384 queries at
 	// 1M x 768 11.9 -> 10.5 ms (profiles/rd4k_hnsw_1m_restart_caps.txt; without the helpers the one restart that overflows costs 2.5 ms).
 	const bool helper_wanted = nq >= 2048 && !big_ef && !(getenv("RXGPU_HNSW_HELPER") && atoi(getenv("RXGPU_HNSW_HELPER")) == 0);
-	if (helper_wanted && ef <= 128) sorted_restart_cap = 256;
+	// ... where a batch lasts long against one heap search: the overflowing searches now run beside the batch, but one that is queued late
+	// still sticks out by its own length (2.5 ms at 1M x 768, where the whole batch takes 10: 1.29 M q/s with the copies at 600 entries
+	// against 1.16 - 1.22 M at 256 although the first pass alone runs at 1.57 - 1.70 M; at 10M x 768: 495 k -> 586 k q/s,
+	// profiles/rd4l_hnsw_*.json).  Same size rule as the hash set.
+	if (helper_wanted && ef <= 128 && (16ull << 13) <= words) sorted_restart_cap = 256;
 	if (const char* e = getenv("RXGPU_HNSW_RESTART_CAND")) sorted_restart_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(0, atoi(e))));
 	if (const char* e = getenv("RXGPU_HNSW_SORTED")) {   // A/B and test hook: 0 = heaps only, 2 = list shifts through ds_bpermute instead of DPP
 		sorted_mode = uint32_t(std::max(0, atoi(e)));
