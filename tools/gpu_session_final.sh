@@ -8,10 +8,10 @@ cd "$R" && mkdir -p gpurun_out/prof && export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; tail -4 gpurun_out/${TAG}_smoke.log
 timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest_gpu.log 2>&1
 tail -4 gpurun_out/${TAG}_pytest_gpu.log
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_full.json 2> gpurun_out/${TAG}_bench_full.err
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --full-json gpurun_out/${TAG}_bench_full.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_full.err
 tail -c 600 gpurun_out/${TAG}_bench_full.err
-head -c 1500 gpurun_out/${TAG}_bench_full.json
-PROF="python $R/bench.py --steps 30 --warmup 5 --no-cpu --batch 0 --hnsw-rows 0 --hybrid-docs 0"
+wc -c gpurun_out/${TAG}_bench_line.json; head -c 1500 gpurun_out/${TAG}_bench_line.json
+PROF="python $R/bench.py --steps 30 --warmup 5 --no-cpu --batch 0 --hnsw-rows 0 --hybrid-docs 0 --ft-packed-words 0 --full-json /tmp/prof_bench_full.json"
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/trace -o $TAG -- $PROF > /tmp/p1.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof/pmc_fetch -o $TAG -- $PROF > /tmp/p2.log 2>&1
