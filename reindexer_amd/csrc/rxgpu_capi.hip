@@ -1935,6 +1935,8 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			if (int rc = c->d_helper_bits.ensure(size_t(kHelperGroups) * words4 * 4); rc) return rc;
 			hq_words = static_cast<uint32_t*>(c->d_helper.ptr);
 			RX_HIP(hipMemsetAsync(hq_words, 0, hq_bytes, c->aux_stream));
+			RX_HIP(hipEventRecord(c->main_done, c->aux_stream));      // the queue is empty before the first search of the batch can append to it
+			RX_HIP(hipStreamWaitEvent(c->stream, c->main_done, 0));
 			rxgpu::HnswParams ph = p;
 			ph.queries = static_cast<const float*>(c->d_queries.ptr);
 			ph.visited = static_cast<uint32_t*>(c->d_helper_bits.ptr);
