@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kPrepThreads, 4) void hybrid_prepare_kernel(HybridF
 			for (int j = 0; j < kBatch; ++j) {
 				const uint32_t i = base + uint32_t(j) * kPrepThreads;
 				v[j] = a.ft_proc[i < n ? i : 0];
-				if (i >= n) v[j] = 0.0f;
+				if (i >= n || (a.ft_terms && a.ft_terms[i] == 0xFFFFu)) v[j] = 0.0f;
 			}
 #pragma unroll
 			for (int j = 0; j < kBatch; ++j) mx = fmaxf(mx, v[j]);
@@ -264,19 +264,22 @@ __global__ __launch_bounds__(kPrepThreads, 4) void hybrid_prepare_kernel(HybridF
 	for (uint32_t base = tid; base < n; base += kPrepThreads * kBatch) {
 		uint32_t doc[kBatch], r8[kBatch], id[kBatch];
 		float proc[kBatch];
+		bool gone[kBatch];   // removed with its partial synonym: as if it had not been merged
 #pragma unroll
 		for (int j = 0; j < kBatch; ++j) {
 			const uint32_t i = base + uint32_t(j) * kPrepThreads, ci = i < n ? i : 0;
 			doc[j] = a.ft_doc[ci];
 			proc[j] = a.ft_proc ? a.ft_proc[ci] : 0.0f;
 			r8[j] = a.ft_rank_u8 ? uint32_t(a.ft_rank_u8[ci]) : 0u;
+			gone[j] = a.ft_terms != nullptr && a.ft_terms[ci] == 0xFFFFu;
 		}
 #pragma unroll
 		for (int j = 0; j < kBatch; ++j) id[j] = a.row_of_doc ? uint32_t(a.row_of_doc[doc[j]]) : doc[j];   // the gathers, together
 #pragma unroll
 		for (int j = 0; j < kBatch; ++j) {
 			const uint32_t i = base + uint32_t(j) * kPrepThreads;
-			const uint32_t cls = a.ft_proc ? (proc[j] < a.min_rank ? uint32_t(kClsDropped) : uint32_t(uint8_t(proc[j] * scale))) : r8[j];
+			const uint32_t cls = gone[j] ? uint32_t(kClsDropped)
+									 : a.ft_proc ? (proc[j] < a.min_rank ? uint32_t(kClsDropped) : uint32_t(uint8_t(proc[j] * scale))) : r8[j];
 			const bool valid = i < n && cls != kClsDropped;
 			if (i < n) {
 				keyA[i] = id[j];

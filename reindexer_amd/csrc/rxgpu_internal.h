@@ -109,6 +109,8 @@ struct HybridFuseArgs {
 	const float* ft_proc;
 	const uint8_t* ft_rank_u8;
 	const uint32_t* ft_count_ptr;
+	const uint16_t* ft_terms;          // optional (raw merge output of a query with multi-word synonyms): 0xFFFF marks a document that holds only
+	                                   // parts of a synonym — removed before postProcessResults (mergerimpl.h:533-555), i.e. absent here
 	uint32_t ft_n, ft_cap;             // ft_cap: what the scratch arrays hold
 	float min_rank;
 	const int32_t* row_of_doc;         // vdoc -> row id (1:1), or null: the document number is the row id
