@@ -469,6 +469,10 @@ int rxgpu_ft_merge_terms_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint32_t nterms, const int32_t* ops, const rxgpu_ft_term_opts* opts,
 								  const int32_t* phrase_num, const int32_t* distance, const uint32_t* sub_off, const uint32_t* word_ids, const float* procs,
 								  const uint8_t* excluded, int32_t* out_enqueued);
+/* The resident form of rxgpu_ft_merge_query2_raw (terms, phrases AND multi-word synonyms, QueryMergeData::synonyms): Merger::Merge
+ * (mergerimpl.h:466-566) left in HBM for rxgpu_hybrid_prepare_resident / rxgpu_hybrid_fuse_resident.  The documents Merge() removes because
+ * they hold only parts of a synonym (mergerimpl.h:533-555) are skipped by the fusion kernels. */
+int rxgpu_ft_merge_query2_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* query, const uint8_t* excluded, int32_t* out_enqueued);
 /* The FT-only half of the fusion (postProcessResults, the documents' order among themselves, the rank-class tables), enqueued behind the
  * resident merge: it needs nothing from the KNN side, so a caller that enqueues it BEFORE it starts the KNN search has it run while the
  * scan streams the corpus, and only the short join is left on the query's critical path.  Optional — rxgpu_hybrid_fuse_resident

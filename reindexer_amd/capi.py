@@ -101,6 +101,7 @@ _SIGNATURES = {
     "rxgpu_ft_merge_batch_raw": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp]),
     "rxgpu_ft_read_batch_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_ft_merge_query_resident": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "rxgpu_ft_merge_query2_resident": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "rxgpu_ft_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),
     "rxgpu_ft_set_words_packed": (_i, [_vp, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_ft_set_words_packed_ptrs": (_i, [_vp, _u32, _vp, _vp, _vp, _vp]),

@@ -128,6 +128,7 @@ struct rxgpu_ft_index {
 	uint64_t res_generation = 0;
 	std::condition_variable res_cv;
 	bool res_pending = false;
+	bool res_has_syn = false;   // the resident merge had multi-word synonyms: its terms counters carry the 0xFFFF marks of the removed documents
 	uint32_t res_cap = 0;          // max_merged of that merge (the packed layout of d_out depends on it)
 	bool prep_done = false;        // hybrid_prepare_kernel has been enqueued behind that merge (with prep_sig's reranker / min_rank)
 	double prep_sig[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -805,7 +806,6 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	const uint32_t nsyn_terms = nterms - npart_terms;
 	const int bm25_type = cfg->bm25_type;
 	RX_CHECK(bm25_type >= 0 && bm25_type <= 2, RXGPU_ERR_PARAMS, std::string(who) + ": bm25_type must be 0 (rx), 1 (classic) or 2 (wordCount)");
-	RX_CHECK(!nsyn || !resident, RXGPU_ERR_LOGIC, std::string(who) + ": a query with multi-word synonyms has no resident form (the removed documents are compacted on the host)");
 
 	// ---- the query parts (selecterimpl.h:482-572): consecutive terms with the same phraseNum >= 0 are one phrase
 	std::vector<QueryPartIn> parts;
@@ -1251,6 +1251,7 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	RX_HIP(hipEventRecord(h->ev_b, st));
 	if (resident) {   // the result stays where ft_finish wrote it (d_out): the fusion kernel reads it there, nothing travels
 		h->res_pending = true;
+		h->res_has_syn = job.nsyn != 0;   // the fusion skips the documents ft_finish marked (they hold only parts of a synonym)
 		h->prep_done = false;
 		h->res_cap = uint32_t(max_merged);
 		h->stat_postings += merged_postings;
@@ -2026,6 +2027,49 @@ int rxgpu_ft_merge_query_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg,
 	return RXGPU_OK;
 }
 
+// ... and the resident form of rxgpu_ft_merge_query2_raw: multi-word synonyms included.  The documents that hold only parts of a synonym
+// stay in the result with their 0xFFFF mark; the fusion kernels treat them as absent (HybridFuseArgs::ft_terms).
+int rxgpu_ft_merge_query2_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_query* q, const uint8_t* excluded, int32_t* out_enqueued) {
+	const char* who = "rxgpu_ft_merge_query2_resident";
+	RX_CHECK(h && cfg && q && out_enqueued, RXGPU_ERR_PARAMS, std::string(who) + ": null argument");
+	*out_enqueued = 0;
+	RX_CHECK(cfg->num_fields == h->num_fields, RXGPU_ERR_PARAMS, std::string(who) + ": field count mismatch");
+	RX_CHECK(h->total_docs > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
+	RX_CHECK(q->nsyn > 0 || q->nsyn_terms == 0, RXGPU_ERR_PARAMS, std::string(who) + ": synonym terms without synonyms");
+	std::vector<QueryTermIn> terms;
+	bool empty = false, simple = false;
+	if (int rc = query_terms(who, q->nterms, q->ops, q->opts, q->phrase_num, q->distance, q->sub_off, q->word_ids, q->procs, terms, &empty, &simple); rc) return rc;
+	SynonymsIn syn;
+	if (!empty && q->nsyn) {
+		RX_CHECK(q->syn_term_off && q->part_syn_off, RXGPU_ERR_PARAMS, std::string(who) + ": null synonym tables");
+		for (uint32_t k = 0; k < q->nsyn_terms; ++k) {
+			const uint32_t t = q->nterms + k;
+			RX_CHECK(q->ops[t] >= 1 && q->ops[t] <= 3, RXGPU_ERR_PARAMS, std::string(who) + ": op must be 1 (OR), 2 (AND) or 3 (NOT)");
+			terms.push_back(QueryTermIn{q->ops[t], &q->opts[t], q->sub_off[t], q->sub_off[t + 1], -1, 1});
+		}
+		syn.nsyn = q->nsyn;
+		syn.first_term = q->nterms;
+		syn.syn_term_off = q->syn_term_off;
+		syn.part_syn_off = q->part_syn_off;
+		syn.part_syn = q->part_syn;
+		syn.suppressed = q->suppressed;
+		simple = false;
+	}
+	std::unique_lock<std::mutex> lk(h->mtx);
+	open_resident_session(h, lk);
+	std::shared_lock<std::shared_mutex> dict_lk(h->dict_mtx);
+	DevGuard dg(h->device);
+	h->res_cap = 0;
+	h->prep_done = false;
+	if (empty) return finish_pending(h, who);   // nothing is merged: the fusion sees an empty FT side
+	uint64_t n = 0;
+	if (int rc = run_merge(h, cfg, simple, terms, q->word_ids, q->procs, excluded, nullptr, nullptr, nullptr, nullptr, 0, &n, nullptr, who, true, q->nsyn ? &syn : nullptr); rc) {
+		return rc;
+	}
+	*out_enqueued = h->res_pending ? 1 : 0;
+	return RXGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------- hybrid: merges that stay in HBM + the fusion
 int rxgpu_ft_merge_simple_resident(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const rxgpu_ft_term_opts* opts, uint32_t nsub,
 								   const uint32_t* word_ids, const float* procs, const uint8_t* excluded) {
@@ -2090,6 +2134,7 @@ int fuse_ft_args(rxgpu_ft_index* h, uint32_t M, int32_t min_rank, const rxgpu_hy
 		a.ft_count_ptr = reinterpret_cast<const uint32_t*>(ob);
 		a.ft_doc = reinterpret_cast<const uint32_t*>(ob + align256(16));
 		a.ft_proc = reinterpret_cast<const float*>(ob + align256(16) + align256(size_t(M) * 4));
+		if (h->res_has_syn) a.ft_terms = reinterpret_cast<const uint16_t*>(ob + align256(16) + 2 * align256(size_t(M) * 4));
 	}
 	a.ft_n = 0;
 	a.ft_cap = M;

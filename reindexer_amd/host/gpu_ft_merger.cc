@@ -323,6 +323,15 @@ bool GpuFtMerger::MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm>
 	return true;
 }
 
+bool GpuFtMerger::MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm> terms, QuerySynonyms synonyms, const uint8_t* docsExcluded) const {
+	if (synonyms.Empty()) return MergeQueryResident(cfg, std::move(terms), docsExcluded);
+	// QueryMergeData::Empty() looks at the query parts only: the same early answers as above
+	if (terms.empty() || (terms.size() == 1 && terms[0].op == OpType::Not) || totalDocs_ == 0) return false;
+	if (terms.front().phraseNum >= 0 && terms.front().op == OpType::Not && terms.front().phraseNum == terms.back().phraseNum) return false;
+	(void)mergeQueryImpl(cfg, std::move(terms), docsExcluded, RankSortType::RankAndID, nullptr, true, &synonyms);
+	return true;
+}
+
 namespace {
 rxgpu_hybrid_params toAbi(const HybridFuseParams& hp) {
 	rxgpu_hybrid_params p{};
@@ -366,7 +375,6 @@ MergeData GpuFtMerger::MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> te
 
 MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 									  bool* preselected, bool resident, QuerySynonyms* synonyms) const {
-	if (synonyms && resident) throw std::logic_error("GpuFtMerger: a query with multi-word synonyms has no resident form");
 	if (!synonyms && terms.size() == 1 && terms[0].op != OpType::Not && terms[0].phraseNum < 0 && totalDocs_ != 0) {   // Simple(): timed by Merge
 		if (preselected) *preselected = false;
 		return mergeImpl(cfg, terms[0].opts, std::move(terms[0].subterms), docsExcluded, rankSortType, resident);
@@ -475,6 +483,11 @@ MergeData GpuFtMerger::mergeQueryImpl(const FtConfig& cfg, std::vector<QueryTerm
 		q.syn_term_off = synTermOff.data();
 		q.part_syn_off = partSynOff.data();
 		q.part_syn = partSyn.data();
+		if (resident) {   // left in HBM for FuseResident; the removed documents keep their mark there
+			int32_t enqueued = 0;
+			if (rxgpu_ft_merge_query2_resident(dev_, &c, &q, docsExcluded, &enqueued) != RXGPU_OK) throwDevice("MergeQueryResident (synonyms)");
+			return out;
+		}
 		const size_t cap = cfg.mergeLimit;
 		std::vector<uint32_t> doc(cap);
 		std::vector<float> proc(cap);

@@ -192,7 +192,7 @@ public:
 	// Merger::Merge<Bm25T> for any query made of terms and phrases (no multi-word synonyms); one OR/AND term -> Merge()
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
-	// ... with multi-word synonyms (mergerimpl.h:347-361, 393-397, 509-555).  No resident form: hybrid queries with synonyms fuse on the host.
+	// ... with multi-word synonyms (mergerimpl.h:347-361, 393-397, 509-555)
 	MergeData MergeQuery(const FtConfig& cfg, std::vector<QueryTerm> terms, QuerySynonyms synonyms, const uint8_t* docsExcluded, RankSortType rankSortType,
 						 bool* preselected = nullptr) const;
 
@@ -214,6 +214,8 @@ public:
 	// Hybrid query, FT half: the same merge, but the result STAYS IN HBM (no export, no wait).  False when the query merges nothing
 	// (Empty(), no sub-terms) — there is then no resident result and FuseResident sees an empty FT side.
 	bool MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm> terms, const uint8_t* docsExcluded) const;
+	// ... with multi-word synonyms (round 4): the documents Merge() removes with their partial synonym stay marked in HBM, the fusion skips them
+	bool MergeQueryResident(const FtConfig& cfg, std::vector<QueryTerm> terms, QuerySynonyms synonyms, const uint8_t* docsExcluded) const;
 	// ... the FT-only half of the fusion (postProcessResults, the documents' mutual order, rank-class tables) enqueued behind that merge:
 	// called BEFORE the KNN search is started it runs while the scan streams the corpus (optional: FuseResident does it when it was not) ...
 	void PrepareResident(const FtConfig& cfg, const HybridFuseParams& hp, int metric, const void* dRowOfDoc = nullptr) const;

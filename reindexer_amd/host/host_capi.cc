@@ -843,6 +843,34 @@ extern "C" long rxhost_ft_merge_query_phrases(void* h, size_t nf, const double* 
 // ... plus multi-word synonyms: per-term arrays hold nTerms + nSynTerms entries; synonym s = terms nTerms + synTermOff[s] .. nTerms + synTermOff[s + 1];
 // partSynOff [nParts + 1] / partSyn: the synonyms of every query part.  Sub-terms of the synonyms whose word the query's own plain terms found
 // are marked suppressed here, like QueryMergeData::SupressDuplicatesInSynonyms does in front of the reference's merge (selecterimpl.h:606).
+namespace {
+// the per-term arrays of a query with multi-word synonyms (rxhost_ft_merge_query_full's layout) -> the parts' terms + QuerySynonyms
+void splitSynonyms(std::vector<QueryTerm>& all, size_t nTerms, const int* phraseNum, const int* distance, size_t nSyn, const uint32_t* synTermOff, size_t nParts,
+				   const uint32_t* partSynOff, const uint32_t* partSyn, std::vector<QueryTerm>& terms, QuerySynonyms& syn) {
+	for (size_t t = 0; t < nTerms; ++t) {
+		if (phraseNum) all[t].phraseNum = phraseNum[t];
+		if (distance) all[t].distance = distance[t];
+	}
+	terms.assign(all.begin(), all.begin() + nTerms);
+	std::vector<uint32_t> found;   // words of the plain (non-phrase) query terms
+	for (const QueryTerm& t : terms) {
+		if (t.phraseNum < 0) {
+			for (const SubtermRef& s : t.subterms) found.push_back(s.wordId);
+		}
+	}
+	std::sort(found.begin(), found.end());
+	for (size_t sy = 0; sy < nSyn; ++sy) {
+		syn.synonyms.emplace_back();
+		for (uint32_t k = synTermOff[sy]; k < synTermOff[sy + 1]; ++k) {
+			QueryTerm t = all[nTerms + k];
+			for (SubtermRef& s : t.subterms) s.suppressed = std::binary_search(found.begin(), found.end(), s.wordId);
+			syn.synonyms.back().push_back(std::move(t));
+		}
+	}
+	for (size_t pi = 0; pi < nParts; ++pi) syn.partSynonyms.emplace_back(partSyn + partSynOff[pi], partSyn + partSynOff[pi + 1]);
+}
+}  // namespace
+
 extern "C" long rxhost_ft_merge_query_full(void* h, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg, size_t nTerms, size_t nSynTerms,
 										   const int* ops, const float* boosts, const float* termLenBoosts, const float* fieldBoost, const uint8_t* needSum,
 										   const int* phraseNum, const int* distance, const uint32_t* subOff, const uint32_t* wordIds, const float* procs,
@@ -853,28 +881,9 @@ extern "C" long rxhost_ft_merge_query_full(void* h, size_t nf, const double* cfg
 	guarded([&] {
 		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
 		std::vector<QueryTerm> all = parseFtTerms(nf, nTerms + nSynTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
-		for (size_t t = 0; t < nTerms; ++t) {
-			if (phraseNum) all[t].phraseNum = phraseNum[t];
-			if (distance) all[t].distance = distance[t];
-		}
-		std::vector<QueryTerm> terms(all.begin(), all.begin() + nTerms);
+		std::vector<QueryTerm> terms;
 		QuerySynonyms syn;
-		std::vector<uint32_t> found;   // words of the plain (non-phrase) query terms
-		for (const QueryTerm& t : terms) {
-			if (t.phraseNum < 0) {
-				for (const SubtermRef& s : t.subterms) found.push_back(s.wordId);
-			}
-		}
-		std::sort(found.begin(), found.end());
-		for (size_t sy = 0; sy < nSyn; ++sy) {
-			syn.synonyms.emplace_back();
-			for (uint32_t k = synTermOff[sy]; k < synTermOff[sy + 1]; ++k) {
-				QueryTerm t = all[nTerms + k];
-				for (SubtermRef& s : t.subterms) s.suppressed = std::binary_search(found.begin(), found.end(), s.wordId);
-				syn.synonyms.back().push_back(std::move(t));
-			}
-		}
-		for (size_t pi = 0; pi < nParts; ++pi) syn.partSynonyms.emplace_back(partSyn + partSynOff[pi], partSyn + partSynOff[pi + 1]);
+		splitSynonyms(all, nTerms, phraseNum, distance, nSyn, synTermOff, nParts, partSynOff, partSyn, terms, syn);
 		bool pre = false;
 		auto res = static_cast<const GpuFtMerger*>(h)->MergeQuery(cfg, std::move(terms), std::move(syn), excluded,
 																  sortByRank ? RankSortType::RankOnly : RankSortType::RankAndID, &pre);
@@ -1024,6 +1033,38 @@ extern "C" long rxhost_hybrid_query_resident(void* mapHandle, void* ftHandle, si
 		for (int i = 0; i < 5; ++i) hp.params[i] = params[i];
 		const HybridFused res = HybridQueryResident(*static_cast<const GpuBruteforceMap*>(mapHandle), *static_cast<const GpuFtMerger*>(ftHandle), cfg, terms,
 													excluded, key, k, hp, dRowOfDoc, hostRowOfDoc);
+		if (outTie) *outTie = res.knnBoundaryTie ? 1 : 0;
+		n = long(res.ids.size());
+		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {
+			outId[i] = res.ids[i];
+			outRank[i] = res.ranks[i];
+		}
+	});
+	return n;
+}
+
+// ... for a query with multi-word synonyms (per-term arrays as in rxhost_ft_merge_query_full)
+extern "C" long rxhost_hybrid_query_resident_full(void* mapHandle, void* ftHandle, size_t nf, const double* cfgD, const int* cfgI, const double* fieldCfg,
+												  size_t nTerms, size_t nSynTerms, const int* ops, const float* boosts, const float* termLenBoosts,
+												  const float* fieldBoost, const uint8_t* needSum, const int* phraseNum, const int* distance, const uint32_t* subOff,
+												  const uint32_t* wordIds, const float* procs, size_t nSyn, const uint32_t* synTermOff, size_t nParts,
+												  const uint32_t* partSynOff, const uint32_t* partSyn, const uint8_t* excluded, const int* hybrid, const double* params,
+												  const float* key, size_t k, const void* dRowOfDoc, const int32_t* hostRowOfDoc, int32_t* outId, float* outRank,
+												  size_t cap, int* outTie) {
+	long n = -1;
+	guarded([&] {
+		const FtConfig cfg = parseFtConfig(nf, cfgD, cfgI, fieldCfg);
+		std::vector<QueryTerm> all = parseFtTerms(nf, nTerms + nSynTerms, ops, boosts, termLenBoosts, fieldBoost, needSum, subOff, wordIds, procs);
+		std::vector<QueryTerm> terms;
+		QuerySynonyms syn;
+		splitSynonyms(all, nTerms, phraseNum, distance, nSyn, synTermOff, nParts, partSynOff, partSyn, terms, syn);
+		HybridFuseParams hp;
+		hp.linear = hybrid[0] == 1;
+		hp.isUnion = hybrid[1] != 0;
+		hp.desc = hybrid[2] != 0;
+		for (int i = 0; i < 5; ++i) hp.params[i] = params[i];
+		const HybridFused res = HybridQueryResident(*static_cast<const GpuBruteforceMap*>(mapHandle), *static_cast<const GpuFtMerger*>(ftHandle), cfg, terms,
+													excluded, key, k, hp, dRowOfDoc, hostRowOfDoc, &syn);
 		if (outTie) *outTie = res.knnBoundaryTie ? 1 : 0;
 		n = long(res.ids.size());
 		for (size_t i = 0; i < res.ids.size() && i < cap; ++i) {

@@ -25,7 +25,7 @@ namespace rxgpu::host {
 // dRowOfDoc: device int32 [totalDocs], vdoc -> row id, when the two do not coincide (IndexText's vdoc table, 1:1 texts); else null
 inline HybridFused HybridQueryResident(const GpuBruteforceMap& map, const GpuFtMerger& ft, const FtConfig& cfg, const std::vector<QueryTerm>& terms,
 									   const uint8_t* docsExcluded, const float* key, size_t k, const HybridFuseParams& hp, const void* dRowOfDoc = nullptr,
-									   const int32_t* hostRowOfDoc = nullptr) {
+									   const int32_t* hostRowOfDoc = nullptr, const QuerySynonyms* synonyms = nullptr) {
 	// HnswIndexBase::search normalises the key for cosine (hnsw_index.cc:166-173)
 	std::vector<float> normalized;
 	const float* q = key;
@@ -41,7 +41,11 @@ inline HybridFused HybridQueryResident(const GpuBruteforceMap& map, const GpuFtM
 	if (residentFits) {
 	// FT half first: the merge train and the FT-only part of the fusion (postProcessResults, the sort by id, the class tables) are on the
 	// merger's stream before the scan's persistent workgroups fill the chip; they run while the scan — ten times longer — streams the corpus
-	ft.MergeQueryResident(cfg, terms, docsExcluded);
+	if (synonyms && !synonyms->Empty()) {   // multi-word synonyms: the documents Merge() removes stay marked in HBM, the fusion skips them
+		ft.MergeQueryResident(cfg, terms, *synonyms, docsExcluded);
+	} else {
+		ft.MergeQueryResident(cfg, terms, docsExcluded);
+	}
 	ft.PrepareResident(cfg, hp, int(map.Metric()), dRowOfDoc);
 	const GpuBruteforceMap::ResidentKnn knn = map.SearchKnnResident(q, k);            // enqueued on the index's stream
 	fused = ft.FuseResident(cfg, hp, int(map.Metric()), knn.dDist, knn.dRow, knn.dCount, knn.entries, uint32_t(std::min<size_t>(k, knn.entries)),
@@ -57,7 +61,8 @@ inline HybridFused HybridQueryResident(const GpuBruteforceMap& map, const GpuFtM
 	const ConstFloatVectorView keyView{key, map.Dim()};
 #endif
 	const KnnSelectResult sel = KnnSelectRaw(map, keyView, params, /*isArray*/ false);
-	const MergeData md = ft.MergeQuery(cfg, terms, docsExcluded, RankSortType::RankAndID);
+	const MergeData md = synonyms && !synonyms->Empty() ? ft.MergeQuery(cfg, terms, *synonyms, docsExcluded, RankSortType::RankAndID)
+													   : ft.MergeQuery(cfg, terms, docsExcluded, RankSortType::RankAndID);
 	std::vector<int32_t> ftIds(md.size());
 	std::vector<float> ftRanks(md.size());
 	for (size_t i = 0; i < md.size(); ++i) {

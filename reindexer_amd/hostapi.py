@@ -1026,10 +1026,15 @@ class GpuFtMerger:
 
 
 def hybrid_query_resident(vmap: "GpuBruteforceMap", ftm: "GpuFtMerger", cfg: dict, terms, key, k: int, kind="rrf", params=(60.0,), union=True,
-                          desc=True, excluded=None, row_of_doc_ptr: int = 0, host_row_of_doc=None):
+                          desc=True, excluded=None, row_of_doc_ptr: int = 0, host_row_of_doc=None, synonyms=None, part_synonyms=None):
     """rxgpu::host::HybridQueryResident (hybrid_query.h): the hybrid query through the Map and the Merger with both halves left in HBM and
-    fused there.  key: the query vector as given by the user.  Returns (row ids, fused ranks, boundary_tie_redone_on_host)."""
+    fused there.  key: the query vector as given by the user.  synonyms / part_synonyms: as GpuFtMerger.merge_query takes them (multi-word
+    synonyms; the resident merge keeps the documents it removes marked, the fusion skips them).
+    Returns (row ids, fused ranks, boundary_tie_redone_on_host)."""
     L = lib()
+    if synonyms:
+        return _hybrid_query_resident_full(vmap, ftm, cfg, terms, key, k, kind, params, union, desc, excluded, row_of_doc_ptr, host_row_of_doc, synonyms,
+                                           part_synonyms)
     L.rxhost_hybrid_query_resident.restype = _l
     L.rxhost_hybrid_query_resident.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp,
                                                _vp, _vp, _sz, _vp]
@@ -1065,6 +1070,63 @@ def hybrid_query_resident(vmap: "GpuBruteforceMap", ftm: "GpuFtMerger", cfg: dic
                                        pr.ctypes.data, exc.ctypes.data if exc is not None else None, hyb.ctypes.data, par.ctypes.data, keyf.ctypes.data, k,
                                        row_of_doc_ptr or None, hmap.ctypes.data if hmap is not None else None, oid.ctypes.data, orank.ctypes.data, cap,
                                        C.byref(tie))
+    if n < 0:
+        _raise()
+    return oid[:n].copy(), orank[:n].copy(), bool(tie.value)
+
+
+def _hybrid_query_resident_full(vmap, ftm, cfg, terms, key, k, kind, params, union, desc, excluded, row_of_doc_ptr, host_row_of_doc, synonyms, part_synonyms):
+    L = lib()
+    L.rxhost_hybrid_query_resident_full.restype = _l
+    L.rxhost_hybrid_query_resident_full.argtypes = [_vp, _vp, _sz, _vp, _vp, _vp, _sz, _sz] + [_vp] * 10 + [_sz, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp,
+                                                                                                        _vp, _vp, _vp, _sz, _vp]
+    nf = ftm.nf
+    n_part_terms = len(terms)
+    terms = list(terms)
+    syn_off = [0]
+    for syn in synonyms:
+        terms.extend(syn)
+        syn_off.append(len(terms) - n_part_terms)
+    cfg_d = np.array([cfg["k1"], cfg["b"], cfg["summation_ratio"], cfg["full_match_boost"], cfg.get("distance_boost", 1.0),
+                      cfg.get("distance_weight", 0.5)], np.float64)
+    cfg_i = np.array([cfg["min_rank"], cfg["merge_limit"], {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")]], np.int32)
+    fc = np.stack([np.asarray(cfg[k_], np.float64) for k_ in ("bm25_boost", "bm25_weight", "term_len_boost", "term_len_weight",
+                                                             "position_boost", "position_weight")], axis=1).copy()
+    ops = np.array([t["op"] for t in terms], np.int32)
+    boosts = np.array([t["opts"]["boost"] for t in terms], np.float32)
+    tlb = np.array([t["opts"]["term_len_boost"] for t in terms], np.float32)
+    fb = np.array([t["opts"]["field_boost"] for t in terms], np.float32).reshape(len(terms), nf).copy()
+    ns = np.array([t["opts"]["need_sum_rank"] for t in terms], np.uint8).reshape(len(terms), nf).copy()
+    phr = np.array([t.get("phrase", -1) for t in terms], np.int32)
+    dst = np.array([t.get("distance", 1) for t in terms], np.int32)
+    sub_off, wid, pr = [0], [], []
+    for t in terms:
+        for w, p_ in t["subs"]:
+            wid.append(w)
+            pr.append(p_)
+        sub_off.append(len(wid))
+    sub_off, wid, pr = np.array(sub_off, np.uint32), np.array(wid, np.uint32), np.array(pr, np.float32)
+    nparts = sum(1 for i in range(n_part_terms) if phr[i] < 0 or i == 0 or phr[i - 1] != phr[i])
+    ps_off, ps = [0], []
+    for pi in range(nparts):
+        ps.extend(part_synonyms[pi] if part_synonyms and pi < len(part_synonyms) else [])
+        ps_off.append(len(ps))
+    syn_off_a, ps_off_a, ps_a = np.array(syn_off, np.uint32), np.array(ps_off, np.uint32), np.array(ps + [0], np.uint32)
+    exc = np.ascontiguousarray(excluded, np.uint8) if excluded is not None else None
+    hyb = np.array([0 if kind == "rrf" else 1, int(union), int(desc)], np.int32)
+    par = np.zeros(5, np.float64)
+    par[:len(params)] = params
+    keyf = _f32(key)
+    hmap = np.ascontiguousarray(host_row_of_doc, np.int32) if host_row_of_doc is not None else None
+    cap = int(cfg["merge_limit"]) + int(k)
+    oid, orank = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+    tie = C.c_int(0)
+    n = L.rxhost_hybrid_query_resident_full(vmap.h, ftm.h, nf, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data, n_part_terms, len(terms) - n_part_terms,
+                                            ops.ctypes.data, boosts.ctypes.data, tlb.ctypes.data, fb.ctypes.data, ns.ctypes.data, phr.ctypes.data, dst.ctypes.data,
+                                            sub_off.ctypes.data, wid.ctypes.data, pr.ctypes.data, len(synonyms), syn_off_a.ctypes.data, nparts,
+                                            ps_off_a.ctypes.data, ps_a.ctypes.data, exc.ctypes.data if exc is not None else None, hyb.ctypes.data,
+                                            par.ctypes.data, keyf.ctypes.data, k, row_of_doc_ptr or None, hmap.ctypes.data if hmap is not None else None,
+                                            oid.ctypes.data, orank.ctypes.data, cap, C.byref(tie))
     if n < 0:
         _raise()
     return oid[:n].copy(), orank[:n].copy(), bool(tie.value)

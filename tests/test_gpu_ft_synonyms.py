@@ -214,3 +214,50 @@ def test_gpu_random_query_shapes_equal_real_merger(hostapi, ft):
     finally:
         real.close()
         m.close()
+
+
+@pytest.mark.parametrize("seed,ops,syn_sizes,part_syn,limit", [(231, (1, 1), [2, 3], [[0], [1]], 20000), (232, (2, 1), [2], [[0], []], 20000),
+                                                               (233, (1, 1), [2, 2], [[0], [1]], 60)])
+def test_hybrid_query_with_synonyms_stays_resident(hostapi, ft, seed, ops, syn_sizes, part_syn, limit):
+    """A hybrid query whose FT half has multi-word synonyms (round 4: rxgpu_ft_merge_query2_resident): the merge stays in HBM with the
+    documents Merger::Merge removes (they hold only parts of a synonym, mergerimpl.h:533-555) still marked, the fusion kernels treat them
+    as absent — before postProcessResults, as the reference does.  Bar: the fusion of the separate product calls (MergeQuery with the
+    synonyms — itself pinned to the real merger above — + the Map's select + MergeRanked), RRF and linear, union and intersection."""
+    from .conftest import make_corpus
+    nf, total, d, k = 2, 3000, 32, 40
+    n_syn_terms = sum(syn_sizes)
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, tuple(ops) + (1,) * n_syn_terms, False, None, sizes=(300, 1200),
+                                                                 nsub_range=(1, 4))
+    parts = [_t(t) for t in terms[:len(ops)]]
+    synonyms, at = [], len(ops)
+    owner_op = {sid: parts[pi]["op"] for pi, ids in enumerate(part_syn) for sid in ids}
+    for sid, n_ in enumerate(syn_sizes):
+        synonyms.append([_t(t, op=owner_op.get(sid, 1)) for t in terms[at:at + n_]])
+        at += n_
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg, removed)
+    for s in store:
+        m.set_word_fpos(s["word"], s)
+    rows = make_corpus(seed, total, d)
+    vm = hostapi.GpuBruteforceMap(2, d, total)
+    vm.add(rows, np.arange(total, dtype=np.uint64) << np.uint64(32))
+    cfg = ft.default_config(nf, merge_limit=limit, min_rank=5)
+    try:
+        removed_some = False
+        for qi in range(4):
+            key = make_corpus(1000 * seed + qi, 1, d)[0]
+            fid, fproc, _, _, _ = m.merge_query(cfg, parts, None, sort_by_rank=True, synonyms=synonyms, part_synonyms=part_syn)
+            plain = m.merge_query(cfg, parts, None, sort_by_rank=True)[0]
+            removed_some = removed_some or len(fid) != len(plain)
+            kid, krank = vm.select(key, k=k, need_sort=False)
+            for kind, params in (("rrf", [60.0]), ("linear", [0.7, 0.3, 1.0, 0.0, 0.0])):
+                for union in (True, False):
+                    got = hostapi.hybrid_query_resident(vm, m, cfg, parts, key, k, kind=kind, params=params, union=union, desc=True, synonyms=synonyms,
+                                                        part_synonyms=part_syn)
+                    ids, ranks = hostapi.merge_ranked(kind, params, kid, krank, fid, fproc, union=union, desc=True, metric=2, ft_order="rank")
+                    assert np.array_equal(got[0], ids), (qi, kind, union, len(got[0]), len(ids))
+                    assert np.array_equal(got[1].view(np.uint32), ranks.view(np.uint32)), (qi, kind, union)
+        assert len(fid) > 0
+    finally:
+        m.close()
+        vm.close()
