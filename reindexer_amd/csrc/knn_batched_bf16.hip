@@ -158,11 +158,11 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 #pragma unroll
 			for (int j = 0; j < 2; ++j) {
 				const uint64_t row = iss_tile * kBfRows + src_r[j];
-				xsrc[j] = p.rows + shadow_elem_base((row < p.n ? row : p.n - 1) * p.row_step, p.ld, p.blocked != 0) + src_c[j];   // clamped: discarded by row_ok in the epilogue
+				xsrc[j] = p.rows + shadow_elem_base((row < p.n ? row : p.n - 1) * p.row_step, p.ld, (p.blocked & 1u) != 0) + src_c[j];   // clamped: discarded by row_ok in the epilogue
 			}
 		}
 		const uint32_t k0 = iss_stage * 32;
-		const uint32_t kx = iss_stage * shadow_stage_step(p.blocked != 0);
+		const uint32_t kx = iss_stage * shadow_stage_step((p.blocked & 1u) != 0);
 		uint16_t* buf = stage_s + size_t(iss_g % kBufs) * kStageElems;
 #pragma unroll
 		for (int j = 0; j < 2; ++j) {
@@ -414,13 +414,13 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 	uint32_t iss_buf = 0;             // ring position of the next stage (rows: mod RB, queries: mod QBUFS)
 	uint32_t iss_par = 0;             // which half of term_s the next tile's row terms go to
 	auto issue = [&]() {
-		const uint32_t k0 = iss_stage * (row_loader ? shadow_stage_step(p.blocked != 0) : 32u);
+		const uint32_t k0 = iss_stage * (row_loader ? shadow_stage_step((p.blocked & 1u) != 0) : 32u);
 		if (row_loader) {
 			if (iss_stage == 0) {
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const uint64_t row = iss_tile * kBfRows + src_r[j];
-					src[j] = p.rows + shadow_elem_base((row < p.n ? row : p.n - 1) * p.row_step, p.ld, p.blocked != 0) + src_c[j];   // clamped: discarded by row_ok in the epilogue
+					src[j] = p.rows + shadow_elem_base((row < p.n ? row : p.n - 1) * p.row_step, p.ld, (p.blocked & 1u) != 0) + src_c[j];   // clamped: discarded by row_ok in the epilogue
 				}
 				if constexpr (kTerms) {   // this wave's 64 row terms, in front of the tile's first rows (in-order retirement: there when they are)
 					const uint64_t row = iss_tile * kBfRows + 64 * rp + lane;
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 		const uint16_t* qb = qry_s + size_t(qbuf) * kQElems;
 		rbuf = rbuf + 1 == uint32_t(RB) ? 0u : rbuf + 1;
 		qbuf = qbuf + 1 == uint32_t(QBUFS) ? 0u : qbuf + 1;
+		if (p.blocked & 2u) __builtin_amdgcn_s_setprio(1);   // RXGPU_GEMM_PRIO=1 (A/B): the stage's fragment reads and MFMAs ahead of the other wave's epilogue / DMA issue
 #pragma unroll
 		for (int t = 0; t < 2; ++t) {
 			const uint32_t cs = ((2 * t + half) ^ swz) << 3;
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 				for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
 			}
 		}
+		if (p.blocked & 2u) __builtin_amdgcn_s_setprio(0);
 		if (++s < stages) continue;
 		s = 0;
 		// ---- tile epilogue (same element mapping as the kernel above; row terms from LDS)

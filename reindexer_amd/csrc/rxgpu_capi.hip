@@ -300,7 +300,7 @@ int enqueue_knn_batched_bf16(rxgpu_index* h, rxgpu_search_ctx* c, const float* d
 
 	rxgpu::GemmBf16Params g{};
 	g.rows = h->d_rows_bf16;
-	g.blocked = h->bf16_blocked ? 1u : 0u;
+	g.blocked = (h->bf16_blocked ? 1u : 0u) | ((getenv("RXGPU_GEMM_PRIO") && atoi(getenv("RXGPU_GEMM_PRIO"))) ? 2u : 0u);   // bit 1: s_setprio around the MFMA bursts (A/B)
 	g.queries = qbf;
 	g.inv_norms = h->d_inv_norms;
 	g.row_sq = h->d_row_sq;

@@ -53,7 +53,7 @@ def main():
             return ix_
 
         # (name, shadow layout, environment of the launch)
-        modes = [("split_ring_blocked_shadow", True, {"RXGPU_GEMM_SPLIT": "1"}), ("split_ring_rowmajor_shadow", False, {"RXGPU_GEMM_SPLIT": "1"}),
+        modes = [("split_ring_blocked_shadow", True, {"RXGPU_GEMM_SPLIT": "1"}), ("split_ring_blocked_shadow_setprio", True, {"RXGPU_GEMM_SPLIT": "1", "RXGPU_GEMM_PRIO": "1"}), ("split_ring_rowmajor_shadow", False, {"RXGPU_GEMM_SPLIT": "1"}),
                  ("single_ring_blocked_shadow", True, {"RXGPU_GEMM_SPLIT": "0"}), ("single_ring_rowmajor_shadow", False, {"RXGPU_GEMM_SPLIT": "0"})]
         if a.modes:
             modes = [m for m in modes if m[0] in a.modes.split(",")]
@@ -61,6 +61,7 @@ def main():
 
         def set_mode(env):
             os.environ.pop("RXGPU_GEMM_RINGS", None)
+            os.environ.pop("RXGPU_GEMM_PRIO", None)
             os.environ.update(env)
 
         od = {m: torch.empty((a.batch, kk), dtype=torch.float32, device=dev) for m, _, _ in modes}
@@ -116,6 +117,7 @@ def main():
         index.clear()
     os.environ.pop("RXGPU_GEMM_SPLIT", None)
     os.environ.pop("RXGPU_GEMM_RINGS", None)
+    os.environ.pop("RXGPU_GEMM_PRIO", None)
     if a.out:
         Path(a.out).parent.mkdir(parents=True, exist_ok=True)
         Path(a.out).write_text(json.dumps(result) + "\n")
