@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 // 4-7 only query stages into a ring of three (two in flight); each wave waits for its own stream, the per-stage barrier publishes both.
 // All eight waves multiply as before.  The per-row terms of the epilogue (|x|^2, 1/|x|) travel by LDS-DMA in front of their tile's
 // first row stage: a global load in the epilogue would wait for every DMA in flight.
-constexpr int gl_row_bufs(int qt) { return qt == 256 ? 6 : 7; }
+constexpr int gl_row_bufs(int qt) { return qt == 256 ? 6 : 7; }   // (seven row + two query buffers for the 256-query tile measured no better: 4.88 ms)
 constexpr int gl_query_bufs(int) { return 3; }
 constexpr int kGlHitCapSplit = 160;
 
@@ -623,18 +623,6 @@ static bool gemm_split_rings() {
 template <int kMetric, int kMode, int QT>
 static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
 	if (gemm_split_rings()) {
-		if constexpr (QT == 256) {   // RXGPU_GEMM_RINGS=72: seven row buffers + two query buffers instead of six + three (A/B)
-			const char* e = std::getenv("RXGPU_GEMM_RINGS");
-			if (e && std::atoi(e) == 72) {
-				const size_t lds = gemm_bf16_split_lds_bytes(QT, 7, 2);
-				static std::atomic<uint64_t> raised_72{0};
-				if (hipError_t er = raise_dynamic_lds_once(raised_72, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT, 7, 2>), lds); er != hipSuccess) {
-					return er;
-				}
-				hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT, 7, 2>), dim3(grid), dim3(kBfThreads), lds, s, p);
-				return hipGetLastError();
-			}
-		}
 		const size_t lds = gemm_bf16_split_lds_bytes(QT, gl_row_bufs(QT), gl_query_bufs(QT));
 		static std::atomic<uint64_t> raised_split{0};
 		if (hipError_t e = raise_dynamic_lds_once(raised_split, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT>), lds); e != hipSuccess) {

@@ -62,6 +62,8 @@ int rxgpu_search_ctx::ensure_pinned(size_t need) {
 int rxgpu_search_ctx::ensure_aux() {
 	if (aux_stream) return RXGPU_OK;
 	RX_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+	RX_HIP(hipStreamCreateWithFlags(&aux2_stream, hipStreamNonBlocking));
+	RX_HIP(hipEventCreateWithFlags(&split_done, hipEventDisableTiming));
 	RX_HIP(hipEventCreateWithFlags(&aux_done, hipEventDisableTiming));
 	RX_HIP(hipEventCreateWithFlags(&main_done, hipEventDisableTiming));
 	return RXGPU_OK;
@@ -69,9 +71,11 @@ int rxgpu_search_ctx::ensure_aux() {
 void rxgpu_search_ctx::release() {
 	if (aux_done) (void)hipEventDestroy(aux_done);
 	if (main_done) (void)hipEventDestroy(main_done);
+	if (split_done) (void)hipEventDestroy(split_done);
 	if (aux_stream) (void)hipStreamDestroy(aux_stream);
-	aux_done = main_done = nullptr;
-	aux_stream = nullptr;
+	if (aux2_stream) (void)hipStreamDestroy(aux2_stream);
+	aux_done = main_done = split_done = nullptr;
+	aux_stream = aux2_stream = nullptr;
 	d_queries.release();
 	d_part_dist.release();
 	d_part_row.release();
@@ -1848,7 +1852,16 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			first_zeroed = true;
 		}
 	}
-	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, qbytes, hipMemcpyHostToDevice, c->stream));
+	// A large batch in ONE launch is searched in two halves on two streams: the upload of the second half of the query block (a copy from
+	// pageable memory keeps this thread until it is staged) runs while the first half's searches have started; the halves overlap on the
+	// device like the workgroups of one launch.  RXGPU_HNSW_SPLIT_UPLOAD=0: one upload, one launch.
+	bool split_upload = !big_ef && nq >= 8192 && uint64_t(nq) <= vis_slots;
+	if (const char* e = getenv("RXGPU_HNSW_SPLIT_UPLOAD")) split_upload = split_upload && atoi(e) != 0;
+	const uint32_t first_half = split_upload ? nq / 2 : nq;
+	if (split_upload) {
+		if (int rc = c->ensure_aux(); rc) return rc;
+	}
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, size_t(first_half) * h->dim * qelem, hipMemcpyHostToDevice, c->stream));
 	rxgpu::HnswParams p{};
 	if (sq8) {
 		char* qb = static_cast<char*>(c->d_queries.ptr);
@@ -1960,32 +1973,49 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 					RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, zero_bytes, c->stream));
 				}
 			}
-			rxgpu::HnswParams pc = p;
-			pc.vis_hash_log2 = vis_hash_log2;
-			pc.visited_words = vis_words;
-			pc.queries = static_cast<const float*>(c->d_queries.ptr) + size_t(q0) * h->dim;
-			if (sq8) {
-				pc.qcodes = p.qcodes + size_t(q0) * h->dim;
-				pc.qcorr = p.qcorr + q0;
-				pc.qnorm = p.qnorm + q0;
+			// searches [qa, qa + cnt) of the batch on stream st (slot = index inside this launch's visited block)
+			auto launch_part = [&](uint32_t qa, uint32_t cnt, uint32_t slot0, hipStream_t st) {
+				rxgpu::HnswParams pc = p;
+				pc.vis_hash_log2 = vis_hash_log2;
+				pc.visited_words = vis_words;
+				pc.queries = reinterpret_cast<const float*>(static_cast<const char*>(c->d_queries.ptr) + size_t(qa) * h->dim * qelem);
+				if (sq8) {
+					pc.qcodes = p.qcodes + size_t(qa) * h->dim;
+					pc.qcorr = p.qcorr + qa;
+					pc.qnorm = p.qnorm + qa;
+				}
+				pc.visited = static_cast<uint32_t*>(c->d_visited.ptr) + size_t(slot0) * vis_words;
+				pc.out_dist = p.out_dist + size_t(qa) * k;
+				pc.out_row = p.out_row + size_t(qa) * k;
+				pc.out_count = p.out_count + qa;
+				if (use_helper) {
+					pc.helper_n = hq_words;
+					pc.helper_ids = hq_words + 16;
+					pc.helper_cap = kHelperCap;
+					pc.q_base = qa;
+				}
+				if (use_sorted) {   // the list lives in registers; LDS holds only the heap area of a search that starts over (equal keys that matter)
+					pc.sorted = sorted_mode;
+					pc.lds_cand_cap = sorted_restart_cap;
+					if (sorted_restart_cap == 0) pc.ef_cap = 0;
+				}
+				rxgpu::launch_hnsw_search(h->metric, pc, cnt, false, st);
+			};
+			ProfileScope ps(h, "hnsw", c->stream);   // (with two halves: until the main stream has waited for the second one)
+			if (split_upload) {
+				hipStream_t sb = c->aux2_stream;
+				// whatever the first half waits for — zeroed bitsets, the empty overflow queue, the SQ8 query terms — the second half waits for too
+				RX_HIP(hipEventRecord(c->split_done, c->stream));
+				RX_HIP(hipStreamWaitEvent(sb, c->split_done, 0));
+				launch_part(0, first_half, 0, c->stream);
+				const size_t off = size_t(first_half) * h->dim * qelem;
+				RX_HIP(hipMemcpyAsync(static_cast<char*>(c->d_queries.ptr) + off, static_cast<const char*>(queries) + off, qbytes - off, hipMemcpyHostToDevice, sb));
+				launch_part(first_half, nq - first_half, first_half, sb);
+				RX_HIP(hipEventRecord(c->split_done, sb));
+				RX_HIP(hipStreamWaitEvent(c->stream, c->split_done, 0));
+			} else {
+				launch_part(q0, cq, 0, c->stream);
 			}
-			pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
-			pc.out_dist = p.out_dist + size_t(q0) * k;
-			pc.out_row = p.out_row + size_t(q0) * k;
-			pc.out_count = p.out_count + q0;
-			if (use_helper) {
-				pc.helper_n = hq_words;
-				pc.helper_ids = hq_words + 16;
-				pc.helper_cap = kHelperCap;
-				pc.q_base = q0;
-			}
-			if (use_sorted) {   // the list lives in registers; LDS holds only the heap area of a search that starts over (equal keys that matter)
-				pc.sorted = sorted_mode;
-				pc.lds_cand_cap = sorted_restart_cap;
-				if (sorted_restart_cap == 0) pc.ef_cap = 0;
-			}
-			ProfileScope ps(h, "hnsw", c->stream);
-			rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 		}
 		RX_HIP(hipGetLastError());
 		if (use_helper) {   // the batch is over: tell the helpers, take their results with the batch's

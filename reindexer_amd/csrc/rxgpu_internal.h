@@ -365,6 +365,8 @@ struct rxgpu_search_ctx {
 	// second stream + events (created on first use): work that does not depend on the query upload — zeroing the visited bitsets of an
 	// HNSW launch — runs beside it
 	hipStream_t aux_stream = nullptr;
+	hipStream_t aux2_stream = nullptr;   // second half of a large HNSW batch: its upload runs beside the first half's searches
+	hipEvent_t split_done = nullptr;
 	hipEvent_t aux_done = nullptr, main_done = nullptr;
 	int ensure_aux();
 	int ensure_pinned(size_t need);

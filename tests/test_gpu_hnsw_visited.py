@@ -182,3 +182,29 @@ def test_overflowing_searches_of_a_batch_run_on_helper_workgroups(rxgpu, oracle,
                 if cap:
                     assert ix.hnsw_read_lds_reruns() > 0
     m.close()
+
+
+@pytest.mark.parametrize("metric,d", [(0, 32), (2, 768)])
+def test_large_batches_are_searched_in_two_halves(rxgpu, oracle, monkeypatch, metric, d):
+    """Batches of >= 8192 queries: the second half of the query block is uploaded on a second stream while the first half's searches run
+    (two launches on two streams, RXGPU_HNSW_SPLIT_UPLOAD=0: one upload, one launch).  Same answers — with the bitset, the hash set, SQ8-less
+    float graphs, an odd batch size."""
+    n, nq = 5000, 8193
+    m, rows, labels = build(metric, n, d, M=8, efc=40, seed=61 + d)
+    g = m.export_graph()
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    queries = make_corpus(62, nq, d)
+    if metric == 2:
+        queries = queries / np.linalg.norm(queries, axis=1, keepdims=True).astype(np.float32)
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, rows, inv)
+        ix.hnsw_attach_graph(g)
+        for visited in ("bitset", "hash"):
+            monkeypatch.setenv("RXGPU_HNSW_VISITED", visited)
+            monkeypatch.setenv("RXGPU_HNSW_SPLIT_UPLOAD", "0")
+            want = _batch(ix, queries, 10, 64)
+            monkeypatch.delenv("RXGPU_HNSW_SPLIT_UPLOAD")
+            got = _batch(ix, queries, 10, 64)
+            _same_batches(got, want, nq)
+            assert got[3] == want[3]
+    m.close()

@@ -60,7 +60,6 @@ def main():
         index = {}
 
         def set_mode(env):
-            os.environ.pop("RXGPU_GEMM_RINGS", None)
             os.environ.pop("RXGPU_GEMM_PRIO", None)
             os.environ.update(env)
 
@@ -116,7 +115,6 @@ def main():
         print(metric, json.dumps(entry), flush=True)
         index.clear()
     os.environ.pop("RXGPU_GEMM_SPLIT", None)
-    os.environ.pop("RXGPU_GEMM_RINGS", None)
     os.environ.pop("RXGPU_GEMM_PRIO", None)
     if a.out:
         Path(a.out).parent.mkdir(parents=True, exist_ok=True)

@@ -31,6 +31,7 @@ VARIANTS = [
     {"RXGPU_HNSW_RESTART_CAND": "0"},                                          # flagged searches go back to the host as ties
     {"RXGPU_HNSW_PREFETCH": "0"},
     {"RXGPU_HNSW_VISITED_LDS": "0"},
+    {"RXGPU_HNSW_SPLIT_UPLOAD": "0"},                                          # one upload, one launch for batches >= 8192
     {"RXGPU_HNSW_SORTED": "0"},                                                # heaps only
     {"RXGPU_HNSW_SORTED": "0", "RXGPU_HNSW_LDS_CAND_CAP": "8", "RXGPU_HNSW_GCAND_CAP": "64"},   # heap overflow -> both global tiers
 ]
@@ -87,7 +88,7 @@ def main():
         ix.upload_rows(0, np.array(g["vectors"]), inv)
         ix.hnsw_attach_graph(g)
         for _ in range(2):
-            nq = int(rng.choice([1, 17, 300, 2048, 2500]))
+            nq = int(rng.choice([1, 17, 300, 2048, 2500, 8200], p=[0.15, 0.15, 0.2, 0.2, 0.2, 0.1]))
             if grid:
                 queries = rng.integers(-2, 3, size=(nq, d)).astype(np.float32)
             else:
