@@ -336,11 +336,16 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_glds(GemmBf16Params 
 // first row stage: a global load in the epilogue would wait for every DMA in flight.
 constexpr int gl_row_bufs(int qt) { return qt == 256 ? 6 : 7; }   // (seven row + two query buffers for the 256-query tile measured no better: 4.88 ms)
 constexpr int gl_query_bufs(int) { return 3; }
-constexpr int kGlHitCapSplit = 160;
+constexpr int kGlHitCapSplit = 144;
+// Row terms of the tiles whose first row stage has been issued: the row loaders run RB - 1 stages ahead, i.e. up to
+// 1 + (RB - 2) / stages tiles beyond the one in its epilogue (stages >= 2: ld is a multiple of 64) -> at most 4 tiles with RB <= 7.
+// (A ring of two was overrun at ld = 64 / 128, where the loaders are 2-3 tiles ahead: ADVICE round 4.)
+constexpr int kGlTermRing = 4;
 
 template <int kMetric, int kMode, int QT, int RB = gl_row_bufs(QT), int QBUFS = gl_query_bufs(QT)>
 __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params p) {
 	static_assert(RB >= 3 && RB <= 7 && QBUFS >= 2 && QBUFS <= 3, "the vmcnt switches below cover these ring depths");
+	static_assert(2 + (RB - 2) / 2 <= kGlTermRing, "term ring shorter than the row loaders' lead in tiles at two stages per tile");
 	constexpr int kQElems = QT * 32;                 // the query operand of one stage
 	constexpr int QB = QT / 64;                      // 32-query blocks per wave (two query halves)
 	constexpr int kQIps = QT * 4 / 256;              // DMA instructions per query-loader wave and stage (4 or 2)
@@ -348,8 +353,8 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];   // the ONLY shared object (a second one de-pipelines the DMA waits)
 	uint16_t* rows_s = reinterpret_cast<uint16_t*>(bf_lds);                                    // [RB][256 x 32]
 	uint16_t* qry_s = rows_s + size_t(RB) * kGlXElems;                                         // [QBUFS][QT x 32]
-	float* term_s = reinterpret_cast<float*>(qry_s + size_t(QBUFS) * kQElems);                 // [2][256] row terms of the tile in flight / the next one
-	float* thr_s = term_s + 2 * kBfRows;                                                       // [QT]
+	float* term_s = reinterpret_cast<float*>(qry_s + size_t(QBUFS) * kQElems);                 // [kGlTermRing][256] row terms of the tiles in flight
+	float* thr_s = term_s + kGlTermRing * kBfRows;                                                       // [QT]
 	float* aux_s = thr_s + QT;
 	uint32_t* hit_n = reinterpret_cast<uint32_t*>(aux_s + QT);                                 // [8]: one counter per wavefront
 	unsigned long long* hit_all = reinterpret_cast<unsigned long long*>(hit_n + 8);            // [8][kGlHitCapSplit]
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 	uint32_t iss_stage = 0;
 	uint64_t iss_g = 0;
 	uint32_t iss_buf = 0;             // ring position of the next stage (rows: mod RB, queries: mod QBUFS)
-	uint32_t iss_par = 0;             // which half of term_s the next tile's row terms go to
+	uint32_t iss_par = 0;             // which slot of term_s the next tile's row terms go to (tile counter mod kGlTermRing)
 	auto issue = [&]() {
 		const uint32_t k0 = iss_stage * (row_loader ? shadow_stage_step((p.blocked & 1u) != 0) : 32u);
 		if (row_loader) {
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 					float* tdst = term_s + iss_par * kBfRows + 64 * rp;
 					__builtin_amdgcn_global_load_lds(tsrc, (lds_void*)(tdst), 4, 0, 0);
 				}
-				iss_par ^= 1u;
+				iss_par = (iss_par + 1u) % uint32_t(kGlTermRing);
 			}
 			uint16_t* buf = rows_s + size_t(iss_buf) * kGlXElems;
 #pragma unroll
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 		const uint64_t row0 = tile * kBfRows;
 		tile += gridDim.x;
 		const float* terms = term_s + tpar * kBfRows;
-		tpar ^= 1u;
+		tpar = (tpar + 1u) % uint32_t(kGlTermRing);
 #pragma unroll
 		for (int a = 0; a < 2; ++a) {
 			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 }
 
 size_t gemm_bf16_split_lds_bytes(int qt, int rb, int qbufs) {
-	return (size_t(rb) * kGlXElems + size_t(qbufs) * qt * 32) * sizeof(uint16_t) + 2 * size_t(kBfRows) * sizeof(float) +
+	return (size_t(rb) * kGlXElems + size_t(qbufs) * qt * 32) * sizeof(uint16_t) + size_t(kGlTermRing) * kBfRows * sizeof(float) +
 		   2 * size_t(qt) * sizeof(float) + 8 * sizeof(uint32_t) + size_t(8) * kGlHitCapSplit * 8 + 2 * size_t(qt / 16) * sizeof(float);
 }
 

@@ -60,6 +60,30 @@ def test_batched_equals_sequential(rxgpu, oracle, nomination, metric, d):
             check_batch(ix, oracle, metric, rows, inv, allq[:nq], kk)
 
 
+@pytest.mark.parametrize("metric", [0, 2])
+@pytest.mark.parametrize("d", [64, 128])
+def test_batched_many_tiles_per_block_at_small_ld(rxgpu, oracle, metric, d):
+    """ld = 64 / 128 (2 / 4 stages per tile) with > 2 tiles per workgroup: the split-ring kernel's row loaders run 2-3 TILES ahead, so the
+    per-row epilogue terms (|x|^2, 1/|x|) of several tiles are in LDS at once (a ring of two was overrun here).  Rows with
+    very different norms make a swapped term visible: a tile scored with its neighbour's norms drops true neighbours."""
+    n, nq, kk = 330_000, 256, 11
+    rng = np.random.default_rng(64 + d + metric)
+    rows = rng.normal(0, 0.25, (n, d)).astype(np.float32)
+    rows *= rng.uniform(0.2, 3.0, (n, 1)).astype(np.float32)   # norms vary tile to tile and row to row
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    queries = make_corpus(9000 + d, nq, d)
+    if metric == 2:
+        queries = np.stack([oracle.normalize_copy(q)[0] for q in queries])
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, rows, inv)
+        dist, row, cnt = ix.search_knn(queries, kk)
+        for qi in range(0, nq, 3):
+            wd, wr = lex_topk(oracle.dist_many(metric, queries[qi], rows, inv), kk)
+            assert int(cnt[qi]) == kk
+            assert np.array_equal(row[qi, :kk], wr), (metric, d, qi)
+            assert np.array_equal(bits(dist[qi, :kk]), bits(wd))
+
+
 def test_batched_more_than_256_queries(rxgpu, oracle):
     n, d = 30_000, 64
     rows = make_corpus(1, n, d)
