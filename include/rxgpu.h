@@ -68,7 +68,13 @@ void rxgpu_index_destroy(rxgpu_index* h);
  * rxgpu_search_range_subset and rxgpu_distances: rows in and out are GLOBAL rows, results are the single-device results bit for bit
  * (per-shard exact lists merged under (dist, global row), i.e. BruteforceSearch's scan order, bruteforce.cc:103-127), every shard's
  * kernels run concurrently on their own device.  The capacity is fixed (create a new index to grow); device-pointer entry points,
- * bitmap filters, HNSW and profiling are single-device only and return RXGPU_ERR_LOGIC here. */
+ * bitmap filters, SQ8, streaming sessions and profiling are single-device only and return RXGPU_ERR_LOGIC here.
+ * HNSW over shards (SURVEY 8e "HNSW": "per-shard independent graphs + the same all-gather merge"): every shard holds the graph of ITS rows —
+ * rows, graph, patches and delete marks go to the rxgpu_index_shard(h, s) handles (local row ids), each of which may hold any number of rows
+ * up to rxgpu_index_shard_rows — and rxgpu_hnsw_search_knn / rxgpu_hnsw_search_range / rxgpu_hnsw_read_* on the sharded handle fan out:
+ * every shard runs HierarchicalNSWImpl::SearchKnn (hnswalg.h:1988-2012) over its graph concurrently, the per-shard results stay in HBM and
+ * meet in the same ncclAllGather + (dist, global row) merge as brute force (k <= 64; host merge above that or in host mode).  The merged
+ * list of a query = the k best of the union of the per-shard results, sorted, rows GLOBAL (shard * shard_rows + local row). */
 int rxgpu_index_create_sharded(int metric, uint32_t dim, uint64_t capacity, uint32_t n_devices, const int* devices, rxgpu_index** out);
 uint32_t rxgpu_index_shard_count(const rxgpu_index* h);   /* 0 for an unsharded index */
 uint64_t rxgpu_index_shard_rows(const rxgpu_index* h);
@@ -76,8 +82,11 @@ uint64_t rxgpu_index_shard_rows(const rxgpu_index* h);
  * RCCL communicator over its distinct devices (ncclCommInitAll at creation), each search is the shards' scans, ONE ncclAllGather of
  * kk x 8 B x nq per shard on the shards' streams, the (dist, global row) merge kernel on the first device and one D2H copy; 0 = on the host
  * (RXGPU_SHARD_MERGE=host in the environment at creation: D2H per shard + host merge — also what range searches, pre-filtered searches and
- * kk > 64 use in either mode); -1 = not a sharded index.  Creation FAILS if the communicator cannot be built and host mode was not asked for. */
+ * kk > 64 use in either mode); -1 = not a sharded index.  RCCL is opened when the first sharded index asks for it (dlopen: a single-GPU
+ * deployment does not need the library); if it is missing or the communicator cannot be built (no peer access, no /dev/shm, ...) the index is
+ * still created, in host mode — one line on stderr, and rxgpu_index_shard_merge_note says why ("" in device mode). */
 int rxgpu_index_shard_merge_mode(const rxgpu_index* h);
+const char* rxgpu_index_shard_merge_note(const rxgpu_index* h);
 uint32_t rxgpu_index_shard_ranks(const rxgpu_index* h);         /* RCCL ranks = distinct devices of the shard list (0 in host mode) */
 uint64_t rxgpu_index_shard_collectives(const rxgpu_index* h);   /* all-gathers issued so far (tests / bench assert the path that ran) */
 /* Shard s as an ordinary single-device index, for filling it in place (rxgpu_index_adopt_device_rows with memory of THAT device; the

@@ -67,7 +67,7 @@ def build_device(force: bool = False) -> Path:
             list(ex.map(lambda so: _run([HIPCC, *flags, "-c", so[0], "-o", so[1]]), todo))
     objs = [objdir / (src.stem + ".o") for src in srcs]
     if force or todo or _stale(out, objs):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-ldl", "-Wl,-rpath,/opt/rocm/lib"])   # RCCL is dlopen'ed by the first sharded index (rxgpu_sharded.hip)
     return out
 
 

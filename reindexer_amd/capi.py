@@ -39,6 +39,7 @@ _SIGNATURES = {
     "rxgpu_index_shard_count": (_u32, [_vp]),
     "rxgpu_index_shard_rows": (_u64, [_vp]),
     "rxgpu_index_shard_merge_mode": (_i, [_vp]),
+    "rxgpu_index_shard_merge_note": (C.c_char_p, [_vp]),
     "rxgpu_index_shard_ranks": (_u32, [_vp]),
     "rxgpu_index_shard_collectives": (_u64, [_vp]),
     "rxgpu_index_shard": (_vp, [_vp, _u32]),
@@ -467,6 +468,11 @@ class ShardedVectorIndex(VectorIndex):
     @property
     def merge_mode(self) -> str:
         return {1: "rccl", 0: "host"}[lib().rxgpu_index_shard_merge_mode(self._h)]
+
+    @property
+    def merge_note(self) -> str:
+        """why the index merges on the host ("" in rccl mode)"""
+        return (lib().rxgpu_index_shard_merge_note(self._h) or b"").decode()
 
     @property
     def ranks(self) -> int:

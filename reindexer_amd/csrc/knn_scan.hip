@@ -817,8 +817,9 @@ __device__ void merge_by_insertion(const float* part_dist, const uint32_t* part_
 // the scan writes when d_out_row == d_out_dist + nq*kk).  Global row = shard * shard_rows + local row; order = (dist, global row).
 // slot_base (in-process RCCL path, rxgpu_sharded.hip): the global row base of every gathered position (rank-major, several shards per
 // device, padded positions = kInvalidRow and skipped); null: position w is shard w.
+// sorted = 0: the lists are UNORDERED sets (the per-shard HNSW results, members of top_candidates): every entry is offered.
 __global__ __launch_bounds__(64) void knn_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows,
-														const uint32_t* slot_base, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+														const uint32_t* slot_base, float* out_dist, uint32_t* out_row, uint32_t* out_count, uint32_t sorted) {
 	const int lane = threadIdx.x;
 	const uint32_t q = blockIdx.x;
 	WaveTopK top;
@@ -840,7 +841,10 @@ __global__ __launch_bounds__(64) void knn_merge_shards(const uint32_t* gathered,
 			pm &= pm - 1;
 			const float d = __shfl(cd, src);
 			const uint32_t i = __shfl(ci, src);
-			if (!top.admits(d, i)) break;   // each shard list is sorted
+			if (!top.admits(d, i)) {
+				if (sorted) break;   // each shard list is sorted
+				continue;
+			}
 			top.insert(d, i, lane);
 		}
 	}
@@ -849,6 +853,18 @@ __global__ __launch_bounds__(64) void knn_merge_shards(const uint32_t* gathered,
 		out_row[size_t(q) * kk + lane] = top.bi;
 	}
 	if (lane == 0 && out_count) out_count[q] = top.filled;
+}
+
+// Sharded HNSW: one shard's search result ([nq][k] distances, [nq][k] local rows, [nq] counts <= k) into its slot of the exchange's send
+// buffer — [nq][kk] distances | [nq][kk] rows, entries past a query's count = (+inf, kInvalidRow), which knn_merge_shards skips.
+__global__ __launch_bounds__(256) void knn_pack_lists(const float* dist, const uint32_t* row, const uint32_t* count, uint32_t nq, uint32_t k, uint32_t kk,
+													   uint32_t* dst_dist, uint32_t* dst_row) {
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= nq * kk) return;
+	const uint32_t q = i / kk, j = i % kk;
+	const bool have = j < k && j < count[q];
+	dst_dist[i] = have ? __float_as_uint(dist[size_t(q) * k + j]) : 0x7F800000u;
+	dst_row[i] = have ? row[size_t(q) * k + j] : kInvalidRow;
 }
 
 // BruteforceSearch::SearchRange (bruteforce.cc:129-143): compact every row with dist < radius (or <=).
@@ -1136,8 +1152,15 @@ void launch_merge_lists(const float* part_dist, const uint32_t* part_row, uint32
 }
 
 void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
-						 uint32_t* out_row, uint32_t* out_count, hipStream_t s, const uint32_t* slot_base) {
-	hipLaunchKernelGGL(knn_merge_shards, dim3(nq), dim3(64), 0, s, gathered, world, nq, kk, shard_rows, slot_base, out_dist, out_row, out_count);
+						 uint32_t* out_row, uint32_t* out_count, hipStream_t s, const uint32_t* slot_base, bool sorted) {
+	hipLaunchKernelGGL(knn_merge_shards, dim3(nq), dim3(64), 0, s, gathered, world, nq, kk, shard_rows, slot_base, out_dist, out_row, out_count, sorted ? 1u : 0u);
+}
+
+void launch_pack_lists(const float* dist, const uint32_t* row, const uint32_t* count, uint32_t nq, uint32_t k, uint32_t kk, uint32_t* dst_dist, uint32_t* dst_row,
+					   hipStream_t s) {
+	const uint32_t total = nq * kk;
+	if (!total) return;
+	hipLaunchKernelGGL(knn_pack_lists, dim3((total + 255) / 256), dim3(256), 0, s, dist, row, count, nq, k, kk, dst_dist, dst_row);
 }
 
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,

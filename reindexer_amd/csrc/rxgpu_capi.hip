@@ -1529,7 +1529,7 @@ int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64
 							const uint8_t* deleted, uint32_t M, uint32_t max_m0, int32_t maxlevel, uint32_t entry, uint64_t num_deleted) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	if (h->shard_set) {
-		set_error("rxgpu_hnsw_attach_graph: not available on a sharded index");
+		set_error("rxgpu_hnsw_attach_graph: a sharded index holds one graph per shard — attach to the rxgpu_index_shard(h, s) handles");
 		return RXGPU_ERR_LOGIC;
 	}
 	const uint64_t n = h->count;
@@ -1746,14 +1746,31 @@ int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* cor
 }
 
 // One body for both row formats: `queries` are float rows (qcorr == nullptr) or SQ8 codes with their corrective offsets and normCoefs.
+// sink (sharded HNSW, rxgpu_sharded.hip): the result lists stay in HBM — packed into the shard's slot of the exchange's send buffer
+// ([nq][kk] distances | [nq][kk] local rows, invalid entries past a query's count) instead of travelling to the host; only the counts
+// come back (the re-run tiers are driven by them).  The stream is drained before the call returns.
 static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef,
-							float* out_dist, uint32_t* out_row, uint32_t* out_count);
+							float* out_dist, uint32_t* out_row, uint32_t* out_count, const rxgpu::HnswSink* sink = nullptr);
 
 int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 						  uint32_t* out_count) {
+	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(queries, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
+	if (h->shard_set) {   // SURVEY 8(e) "HNSW": a graph per shard, the per-shard results meet in the same all-gather + merge as brute force
+		RX_CHECK(out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
+		return rxgpu::sharded_hnsw_search_knn(h, queries, nq, k, ef, out_dist, out_row, out_count);
+	}
 	return hnsw_search_impl(h, queries, nullptr, nullptr, nq, k, ef, out_dist, out_row, out_count);
 }
+
+extern "C++" {
+namespace rxgpu {
+int hnsw_search_to_sink(rxgpu_index* shard, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, const HnswSink& sink) {
+	std::vector<uint32_t> counts(nq);
+	return hnsw_search_impl(shard, queries, nullptr, nullptr, nq, k, ef, nullptr, nullptr, counts.data(), &sink);
+}
+}  // namespace rxgpu
+}  // extern "C++"
 
 int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const float* query_corr, const float* query_norm_coef, uint32_t nq,
 							  uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
@@ -1765,16 +1782,18 @@ int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const 
 }
 
 static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef,
-							float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+							float* out_dist, uint32_t* out_row, uint32_t* out_count, const rxgpu::HnswSink* sink) {
 	const bool sq8 = qcorr != nullptr;
+	const bool to_host = sink == nullptr;
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	if (h->shard_set) {
-		set_error("rxgpu_hnsw_search_knn: not available on a sharded index");
+		set_error("rxgpu_hnsw_search_knn_sq8: not available on a sharded index");
 		return RXGPU_ERR_LOGIC;
 	}
-	RX_CHECK(queries && out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
+	RX_CHECK(queries && out_count && (sink || (out_dist && out_row)), RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
 	if (nq == 0) return RXGPU_OK;
 	if (h->count == 0 || k == 0) {   // hnswalg.h:1989-1991
+		RX_CHECK(to_host, RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_knn: an empty shard has no list to send");
 		std::fill(out_count, out_count + nq, 0u);
 		return RXGPU_OK;
 	}
@@ -1900,6 +1919,12 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	p.out_count = static_cast<uint32_t*>(c->d_out_count.ptr);
 	p.stats = h->d_hnsw_stats;
 	p.ef_cap = (ef + 63u) & ~63u;
+	auto to_sink = [&]() -> int {   // the finished lists into the exchange's send buffer (sharded HNSW), on this search's stream, drained
+		rxgpu::launch_pack_lists(p.out_dist, p.out_row, p.out_count, nq, k, sink->kk, sink->d_dist, sink->d_row, c->stream);
+		RX_HIP(hipGetLastError());
+		RX_HIP(hipStreamSynchronize(c->stream));
+		return RXGPU_OK;
+	};
 	// typical candidate heaps stay within a few x ef.  Measured at 1M x 768, ef = 128: 512 entries overflow for a handful of queries and the
 	// global-heap re-run costs more than the extra occupancy brings (1.07 M q/s at 1024 against 0.43 M at 512 and 0.86 M at 768)
 	p.lds_cand_cap = ef <= 256 ? 1024u : uint32_t(rxgpu::kHnswCandLds);
@@ -1950,6 +1975,13 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			RX_HIP(hipMemsetAsync(hq_words, 0, hq_bytes, c->aux_stream));
 			RX_HIP(hipEventRecord(c->main_done, c->aux_stream));      // the queue is empty before the first search of the batch can append to it
 			RX_HIP(hipStreamWaitEvent(c->stream, c->main_done, 0));
+		}
+		// The helpers spin until the batch says stop, so they are enqueued BEHIND the batch's launches: HIP streams share a few
+		// hardware queues, and a helper that reached a queue in front of the batch kernel it waits for would hold that queue until its
+		// wall-clock bail-out.  Launched last, the worst case is the serial one — helpers behind the batch on one queue find the stop flag and
+		// only drain what was queued; on separate queues they run beside the batch as intended.
+		auto launch_helpers = [&]() -> int {
+			const uint64_t words4 = (words + 3) & ~uint64_t(3);
 			rxgpu::HnswParams ph = p;
 			ph.queries = static_cast<const float*>(c->d_queries.ptr);
 			ph.visited = static_cast<uint32_t*>(c->d_helper_bits.ptr);
@@ -1961,7 +1993,9 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			rxgpu::HnswHelper hq{hq_words, hq_words + 16, hq_words + 1, kHelperCap, 300000000ull};   // gives up after 3 s
 			rxgpu::launch_hnsw_helper(h->metric, ph, hq, kHelperGroups, c->aux_stream);
 			RX_HIP(hipGetLastError());
-		}
+			return RXGPU_OK;
+		};
+		bool helpers_launched = false;
 		for (uint32_t q0 = 0; q0 < nq; q0 += uint32_t(vis_slots)) {
 			const uint32_t cq = uint32_t(std::min<uint64_t>(vis_slots, nq - q0));
 			if (int rc = c->d_visited.ensure(size_t(cq) * vis_words * 4); rc) return rc;
@@ -2016,6 +2050,10 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			} else {
 				launch_part(q0, cq, 0, c->stream);
 			}
+			if (use_helper && !helpers_launched) {   // behind the first chunk's launches (all of them, for a batch that fits one chunk)
+				if (int rc = launch_helpers(); rc) return rc;
+				helpers_launched = true;
+			}
 		}
 		RX_HIP(hipGetLastError());
 		if (use_helper) {   // the batch is over: tell the helpers, take their results with the batch's
@@ -2026,17 +2064,20 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		}
 		// counts and results travel together: a batch without re-runs (the common case for a handful of queries) is done after ONE wait
 		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-		RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-		RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		if (to_host) {
+			RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		}
 		RX_HIP(hipStreamSynchronize(c->stream));
-		h->hnsw_lds_reruns += std::min<uint32_t>(helper_n, kHelperCap);
+		const uint32_t helper_queued = std::min<uint32_t>(helper_n, kHelperCap);
+		h->hnsw_lds_reruns += helper_queued;
 		std::vector<uint32_t> ties;
 		bool clean = true;
 		for (uint32_t q = 0; q < nq; ++q) {
 			if (out_count[q] == rxgpu::kHnswTie) ties.push_back(q);
 			clean = clean && out_count[q] != rxgpu::kHnswTie && out_count[q] != rxgpu::kHnswOverflow;
 		}
-		if (clean) return RXGPU_OK;
+		if (clean) return to_host ? RXGPU_OK : to_sink();
 		if (!ties.empty()) {   // equal keys met in the sorted list: the same queries through the reference's heaps (candidate heap in LDS)
 			h->hnsw_tie_reruns += ties.size();
 			if (int rc = c->d_redo.ensure(ties.size() * sizeof(uint32_t)); rc) return rc;
@@ -2086,7 +2127,8 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			RX_HIP(hipGetLastError());
 			RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 			RX_HIP(hipStreamSynchronize(c->stream));
-			h->hnsw_lds_reruns += over.size();
+			// searches the helpers had queued but not finished are in `over` again: counted once
+			h->hnsw_lds_reruns += over.size() > helper_queued ? over.size() - helper_queued : 0;
 		}
 		// ... and what still does not fit: re-run with the heap in global scratch (bounded by one entry per node)
 		for (const uint32_t q : over) {
@@ -2128,6 +2170,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		redo.swap(again);
 	}
 	RX_CHECK(redo.empty(), RXGPU_ERR_DEVICE, "rxgpu_hnsw_search_knn: a candidate heap of one entry per node overflowed");
+	if (!to_host) return to_sink();
 	RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipStreamSynchronize(c->stream));
@@ -2242,6 +2285,7 @@ static int hnsw_range_impl(rxgpu_index* h, const void* query, const float* qcorr
 int rxgpu_hnsw_search_range(rxgpu_index* h, const float* query, float radius, uint32_t ef, float* out_dist, uint32_t* out_row, uint64_t cap,
 							uint64_t* out_total) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	if (h->shard_set) return rxgpu::sharded_hnsw_search_range(h, query, radius, ef, out_dist, out_row, cap, out_total);
 	RX_CHECK(h->count == 0 || (h->graph_attached && h->graph_n == h->count), RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_range: graph is not attached / out of date");
 	return hnsw_range_impl(h, query, nullptr, nullptr, radius, ef, out_dist, out_row, cap, out_total);
 }
@@ -2249,6 +2293,7 @@ int rxgpu_hnsw_search_range(rxgpu_index* h, const float* query, float radius, ui
 int rxgpu_hnsw_search_range_sq8(rxgpu_index* h, const uint8_t* query_codes, float query_corr, float query_norm_coef, float radius, uint32_t ef,
 								float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
+	RX_CHECK(!h->shard_set, RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_range_sq8: not available on a sharded index");
 	RX_CHECK(h->count == 0 || (h->graph_attached && h->graph_n == h->count), RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_range_sq8: graph is not attached / out of date");
 	RX_CHECK(h->count == 0 || (h->d_codes && h->sq8_n == h->count), RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_range_sq8: SQ8 codes are not attached / out of date");
 	return hnsw_range_impl(h, query_codes, &query_corr, &query_norm_coef, radius, ef, out_dist, out_row, cap, out_total);
@@ -2326,6 +2371,7 @@ void rxgpu_hnsw_stream_end(rxgpu_hnsw_stream* s) {
 static int hnsw_stream_begin_impl(rxgpu_index* h, const void* query, bool sq8, float qcorr, float qnorm, uint32_t ef, rxgpu_hnsw_stream** out) {
 	RX_CHECK(h && query && out, RXGPU_ERR_PARAMS, "rxgpu_hnsw_stream_begin: null argument");
 	*out = nullptr;
+	RX_CHECK(!h->shard_set, RXGPU_ERR_LOGIC, "rxgpu_hnsw_stream_begin: streaming sessions are per graph — not available on a sharded index");
 	RX_CHECK(!sq8 || h->count == 0 || (h->d_codes && h->sq8_n == h->count), RXGPU_ERR_LOGIC,
 			 "rxgpu_hnsw_stream_begin_sq8: SQ8 codes are not attached / out of date");
 	DeviceGuard dg(h->device);
@@ -2441,6 +2487,15 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 	RX_CHECK(h && distance_evals && hops, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_stats: null argument");
 	*distance_evals = 0;
 	*hops = 0;
+	if (h->shard_set) {   // the sum over the shards' graphs
+		for (uint32_t s = 0; s < rxgpu_index_shard_count(h); ++s) {
+			uint64_t e = 0, hp = 0;
+			if (int rc = rxgpu_hnsw_read_stats(rxgpu_index_shard(h, s), &e, &hp); rc) return rc;
+			*distance_evals += e;
+			*hops += hp;
+		}
+		return RXGPU_OK;
+	}
 	if (!h->d_hnsw_stats) return RXGPU_OK;
 	DeviceGuard dg(h->device);
 	unsigned long long v[2] = {0, 0};
@@ -2454,12 +2509,30 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 
 int rxgpu_hnsw_read_lds_reruns(rxgpu_index* h, uint64_t* reruns) {
 	RX_CHECK(h && reruns, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_lds_reruns: null argument");
+	if (h->shard_set) {
+		*reruns = 0;
+		for (uint32_t s = 0; s < rxgpu_index_shard_count(h); ++s) {
+			uint64_t v = 0;
+			if (int rc = rxgpu_hnsw_read_lds_reruns(rxgpu_index_shard(h, s), &v); rc) return rc;
+			*reruns += v;
+		}
+		return RXGPU_OK;
+	}
 	*reruns = h->hnsw_lds_reruns.exchange(0);
 	return RXGPU_OK;
 }
 
 int rxgpu_hnsw_read_tie_reruns(rxgpu_index* h, uint64_t* reruns) {
 	RX_CHECK(h && reruns, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_tie_reruns: null argument");
+	if (h->shard_set) {
+		*reruns = 0;
+		for (uint32_t s = 0; s < rxgpu_index_shard_count(h); ++s) {
+			uint64_t v = 0;
+			if (int rc = rxgpu_hnsw_read_tie_reruns(rxgpu_index_shard(h, s), &v); rc) return rc;
+			*reruns += v;
+		}
+		return RXGPU_OK;
+	}
 	*reruns = h->hnsw_tie_reruns.exchange(0);   // queries this library re-ran in a launch of their own ...
 	if (h->d_hnsw_stats) {                      // ... and searches that started over on the heaps inside the sorted-list kernel
 		DeviceGuard dg(h->device);

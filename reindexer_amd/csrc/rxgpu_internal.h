@@ -28,7 +28,10 @@ void launch_merge(const float* part_dist, const uint32_t* part_row, uint32_t tot
 void launch_merge_lists(const float* part_dist, const uint32_t* part_row, uint32_t nlists, uint32_t kk, uint32_t nq, float* out_dist, uint32_t* out_row,
 						uint32_t* out_count, hipStream_t s);   // the partial results are sorted lists of kk entries: no serial insertions
 void launch_merge_shards(const uint32_t* gathered, uint32_t world, uint32_t nq, uint32_t kk, uint32_t shard_rows, float* out_dist,
-						 uint32_t* out_row, uint32_t* out_count, hipStream_t s, const uint32_t* slot_base = nullptr);
+						 uint32_t* out_row, uint32_t* out_count, hipStream_t s, const uint32_t* slot_base = nullptr, bool sorted = true);
+// one shard's HNSW result (unordered, counts <= k) into its [nq][kk] | [nq][kk] slot of the exchange's send buffer, padded with invalid entries
+void launch_pack_lists(const float* dist, const uint32_t* row, const uint32_t* count, uint32_t nq, uint32_t k, uint32_t kk, uint32_t* dst_dist, uint32_t* dst_row,
+					   hipStream_t s);
 void launch_range(int metric, const float* rows, const float* inv_norms, const float* query, uint64_t n, uint32_t stride, uint32_t dim,
 				  float radius, int inclusive, float* out_dist, uint32_t* out_row, uint64_t cap, unsigned long long* counter,
 				  uint32_t gridx, hipStream_t s);
@@ -390,6 +393,17 @@ int sharded_search_knn_impl(struct ::rxgpu_index* h, const float* queries, uint3
 int sharded_search_range_impl(struct ::rxgpu_index* h, const float* query, float radius, int inclusive, const uint32_t* row_ids, uint64_t n_ids,
 							  float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total);
 int sharded_distances(struct ::rxgpu_index* h, const float* query, const uint32_t* rows, uint32_t n, float* out_dist);
+// Sharded HNSW: a graph per shard (attached through rxgpu_index_shard handles), SearchKnn fans out and meets in the exchange
+struct HnswSink {
+	uint32_t* d_dist;   // [nq][kk] distance bits   (device memory of the shard's GPU)
+	uint32_t* d_row;    // [nq][kk] shard-local rows, kInvalidRow past a query's count
+	uint32_t kk;
+};
+int hnsw_search_to_sink(struct ::rxgpu_index* shard, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, const HnswSink& sink);
+int sharded_hnsw_search_knn(struct ::rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
+							uint32_t* out_count);
+int sharded_hnsw_search_range(struct ::rxgpu_index* h, const float* query, float radius, uint32_t ef, float* out_dist, uint32_t* out_row, uint64_t cap,
+							  uint64_t* out_total);
 }  // namespace rxgpu
 
 struct rxgpu_index {

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -24,8 +25,10 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is opened at the first sharded index (rccl_api below)
 
 #include "../../include/rxgpu.h"
 #include "knn_kernels.hip.h"
@@ -34,6 +37,56 @@
 using rxgpu::set_error;
 
 namespace rxgpu {
+
+// RCCL is opened lazily (dlopen) by the first sharded index that asks for the device-side exchange: a single-GPU deployment neither links
+// nor needs librccl.so, and a node where the library is missing or cannot initialise (no peer access, no /dev/shm in the container, ...)
+// keeps working on the host-merge path.  The entry points keep their nccl* names below.
+struct RcclApi {
+	decltype(&::ncclCommInitAll) ncclCommInitAll = nullptr;
+	decltype(&::ncclCommDestroy) ncclCommDestroy = nullptr;
+	decltype(&::ncclAllGather) ncclAllGather = nullptr;
+	decltype(&::ncclAllReduce) ncclAllReduce = nullptr;
+	decltype(&::ncclGroupStart) ncclGroupStart = nullptr;
+	decltype(&::ncclGroupEnd) ncclGroupEnd = nullptr;
+	decltype(&::ncclGetErrorString) ncclGetErrorString = nullptr;
+	std::string why;   // non-empty: not available, and why
+};
+
+const RcclApi& rccl_api() {
+	static RcclApi api;
+	static std::once_flag once;
+	std::call_once(once, [] {
+		void* lib = nullptr;
+		std::string tried;
+		const char* env = std::getenv("RXGPU_RCCL_LIB");   // an explicit path (tests use it to provoke the fallback)
+		const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+		for (const char* n : names) {
+			if (!n || !*n) continue;
+			lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+			if (lib) break;
+			const char* e = dlerror();
+			tried += std::string(tried.empty() ? "" : "; ") + n + ": " + (e ? e : "?");
+			if (n == env) break;   // an explicit choice is not second-guessed
+		}
+		if (!lib) {
+			api.why = "librccl.so could not be opened (" + tried + ")";
+			return;
+		}
+		auto sym = [&](const char* name) -> void* {
+			void* p = dlsym(lib, name);
+			if (!p && api.why.empty()) api.why = std::string("librccl.so lacks ") + name;
+			return p;
+		};
+		api.ncclCommInitAll = reinterpret_cast<decltype(api.ncclCommInitAll)>(sym("ncclCommInitAll"));
+		api.ncclCommDestroy = reinterpret_cast<decltype(api.ncclCommDestroy)>(sym("ncclCommDestroy"));
+		api.ncclAllGather = reinterpret_cast<decltype(api.ncclAllGather)>(sym("ncclAllGather"));
+		api.ncclAllReduce = reinterpret_cast<decltype(api.ncclAllReduce)>(sym("ncclAllReduce"));
+		api.ncclGroupStart = reinterpret_cast<decltype(api.ncclGroupStart)>(sym("ncclGroupStart"));
+		api.ncclGroupEnd = reinterpret_cast<decltype(api.ncclGroupEnd)>(sym("ncclGroupEnd"));
+		api.ncclGetErrorString = reinterpret_cast<decltype(api.ncclGetErrorString)>(sym("ncclGetErrorString"));
+	});
+	return api;
+}
 
 // A small pool of worker threads per shard (the shard's device stays current on them) behind one job queue: fan-outs of concurrent
 // callers queue up per shard and overlap — the single-device entry points are re-entrant (a search context and stream per call) — so
@@ -96,7 +149,8 @@ struct ShardSet {
 	std::vector<ShardWorker*> workers;
 	uint64_t shard_rows = 0;
 	std::shared_mutex call_mtx;   // shared: searches (any number of fan-outs in flight); exclusive: uploads, moves, truncation
-	ShardExchange* xch = nullptr; // null: RXGPU_SHARD_MERGE=host
+	ShardExchange* xch = nullptr; // null: the host-merge path (RXGPU_SHARD_MERGE=host, or RCCL is not available: merge_note says why)
+	std::string merge_note;
 };
 
 namespace {
@@ -191,7 +245,7 @@ uint64_t local_count(const ShardSet* ss, size_t s, uint64_t count) {
 	do {                                                                                   \
 		ncclResult_t r__ = (expr);                                                         \
 		if (r__ != ncclSuccess) {                                                          \
-			set_error(std::string(#expr) + ": " + ncclGetErrorString(r__));                \
+			set_error(std::string(#expr) + ": " + rccl_api().ncclGetErrorString(r__));     \
 			return RXGPU_ERR_DEVICE;                                                       \
 		}                                                                                  \
 	} while (0)
@@ -245,7 +299,7 @@ void exchange_destroy(ShardExchange* x) {
 	CurrentDevice cd;
 	for (ExchangeLane* l : x->free_lanes) free_lane(x, l);
 	for (ncclComm_t c : x->comms) {
-		if (c) (void)ncclCommDestroy(c);
+		if (c) (void)rccl_api().ncclCommDestroy(c);
 	}
 	if (x->d_slot_base) {
 		(void)hipSetDevice(x->rank_dev[0]);
@@ -273,11 +327,16 @@ int exchange_create(ShardSet* ss, uint32_t n_devices, const int* devices, ShardE
 	x->nranks = uint32_t(x->rank_dev.size());
 	x->slots = *std::max_element(per_rank.begin(), per_rank.end());
 	CurrentDevice cd;
+	const RcclApi& api = rccl_api();
+	if (!api.why.empty()) {
+		set_error("RCCL unavailable: " + api.why);
+		delete x;
+		return RXGPU_ERR_DEVICE;
+	}
 	x->comms.assign(x->nranks, nullptr);
-	const ncclResult_t nr = ncclCommInitAll(x->comms.data(), int(x->nranks), x->rank_dev.data());
+	const ncclResult_t nr = api.ncclCommInitAll(x->comms.data(), int(x->nranks), x->rank_dev.data());
 	if (nr != ncclSuccess) {
-		set_error(std::string("rxgpu_index_create_sharded: ncclCommInitAll over ") + std::to_string(x->nranks) + " device(s): " + ncclGetErrorString(nr) +
-				  " (RXGPU_SHARD_MERGE=host selects the host-merge path)");
+		set_error(std::string("ncclCommInitAll over ") + std::to_string(x->nranks) + " device(s): " + api.ncclGetErrorString(nr));
 		x->comms.clear();
 		exchange_destroy(x);
 		return RXGPU_ERR_DEVICE;
@@ -296,6 +355,54 @@ int exchange_create(ShardSet* ss, uint32_t n_devices, const int* devices, ShardE
 	return RXGPU_OK;
 }
 
+// The second half of every exchange: the per-shard lists sit in d_local of their rank's device (on that rank's lane stream) -> ONE
+// ncclAllGather per query batch -> knn_merge_shards on the first device -> one D2H copy of the merged lists.
+int exchange_gather_merge(ShardSet* ss, ExchangeLane* l, uint32_t nq, uint32_t kk, bool sorted, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	ShardExchange* x = ss->xch;
+	const size_t list_words = size_t(2) * nq * kk;
+	const size_t out_bytes = (size_t(2) * nq * kk + nq) * sizeof(uint32_t);
+	{
+		std::lock_guard<std::mutex> lk(x->coll_mtx);
+		const RcclApi& api = rccl_api();
+		SH_NCCL(api.ncclGroupStart());
+		for (uint32_t r = 0; r < x->nranks; ++r) {
+			const ncclResult_t nr = api.ncclAllGather(l->d_local[r].ptr, l->d_gathered[r].ptr, list_words * x->slots, ncclUint32, x->comms[r], l->stream[r]);
+			if (nr != ncclSuccess) {
+				(void)api.ncclGroupEnd();
+				set_error(std::string("ncclAllGather: ") + api.ncclGetErrorString(nr));
+				return RXGPU_ERR_DEVICE;
+			}
+		}
+		SH_NCCL(api.ncclGroupEnd());
+		x->collectives.fetch_add(1, std::memory_order_relaxed);
+	}
+	SH_HIP(hipSetDevice(x->rank_dev[0]));
+	if (int rc = l->d_out.ensure(out_bytes); rc) return rc;
+	float* d_od = static_cast<float*>(l->d_out.ptr);
+	uint32_t* d_or = static_cast<uint32_t*>(l->d_out.ptr) + size_t(nq) * kk;
+	uint32_t* d_oc = d_or + size_t(nq) * kk;
+	launch_merge_shards(static_cast<const uint32_t*>(l->d_gathered[0].ptr), x->nranks * x->slots, nq, kk, 0, d_od, d_or, d_oc, l->stream[0], x->d_slot_base, sorted);
+	SH_HIP(hipGetLastError());
+	SH_HIP(hipMemcpyAsync(l->h_pinned, l->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, l->stream[0]));
+	for (uint32_t r = 0; r < x->nranks; ++r) SH_HIP(hipStreamSynchronize(l->stream[r]));
+	const auto* hp = static_cast<const uint32_t*>(l->h_pinned);
+	std::memcpy(out_dist, hp, size_t(nq) * kk * sizeof(float));
+	std::memcpy(out_row, hp + size_t(nq) * kk, size_t(nq) * kk * sizeof(uint32_t));
+	std::memcpy(out_count, hp + size_t(2) * nq * kk, size_t(nq) * sizeof(uint32_t));
+	return RXGPU_OK;
+}
+
+int ensure_pinned(ExchangeLane* l, size_t pin) {
+	if (l->h_pinned_bytes < pin) {
+		if (l->h_pinned) (void)hipHostFree(l->h_pinned);
+		l->h_pinned = nullptr;
+		l->h_pinned_bytes = 0;
+		SH_HIP(hipHostMalloc(&l->h_pinned, pin, hipHostMallocDefault));
+		l->h_pinned_bytes = pin;
+	}
+	return RXGPU_OK;
+}
+
 // SearchKnn over every shard with the exchange on the devices.  The caller holds call_mtx shared and has checked the shape
 // (kk <= kMaxFusedK, every non-empty shard holds >= kk rows).
 int exchange_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const float* queries, uint32_t nq, uint32_t kk, float* out_dist,
@@ -305,14 +412,7 @@ int exchange_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const flo
 	const size_t list_words = size_t(2) * nq * kk;                 // one shard: [nq][kk] distances | [nq][kk] local rows
 	const size_t local_bytes = list_words * x->slots * sizeof(uint32_t);
 	const size_t out_bytes = (size_t(2) * nq * kk + nq) * sizeof(uint32_t);
-	const size_t pin = std::max(qbytes, out_bytes);
-	if (l->h_pinned_bytes < pin) {
-		if (l->h_pinned) (void)hipHostFree(l->h_pinned);
-		l->h_pinned = nullptr;
-		l->h_pinned_bytes = 0;
-		SH_HIP(hipHostMalloc(&l->h_pinned, pin, hipHostMallocDefault));
-		l->h_pinned_bytes = pin;
-	}
+	if (int rc = ensure_pinned(l, std::max(qbytes, out_bytes)); rc) return rc;
 	std::memcpy(l->h_pinned, queries, qbytes);
 	bool hole = x->slots * x->nranks != ss->shards.size();   // padded positions are skipped by their base; EMPTY shards need invalid lists
 	std::vector<uint64_t> lc(ss->shards.size());
@@ -333,34 +433,53 @@ int exchange_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const flo
 			if (int rc = rxgpu_search_knn_device(ss->shards[s], l->d_queries[r].ptr, nq, kk, dst, dst + size_t(nq) * kk, nullptr, l->stream[r]); rc) return rc;
 		}
 	}
-	{
-		std::lock_guard<std::mutex> lk(x->coll_mtx);
-		SH_NCCL(ncclGroupStart());
-		for (uint32_t r = 0; r < x->nranks; ++r) {
-			const ncclResult_t nr = ncclAllGather(l->d_local[r].ptr, l->d_gathered[r].ptr, list_words * x->slots, ncclUint32, x->comms[r], l->stream[r]);
-			if (nr != ncclSuccess) {
-				(void)ncclGroupEnd();
-				set_error(std::string("ncclAllGather: ") + ncclGetErrorString(nr));
-				return RXGPU_ERR_DEVICE;
-			}
-		}
-		SH_NCCL(ncclGroupEnd());
-		x->collectives.fetch_add(1, std::memory_order_relaxed);
+	return exchange_gather_merge(ss, l, nq, kk, true, out_dist, out_row, out_count);
+}
+
+// HNSW SearchKnn over every shard's own graph (SURVEY 8e "HNSW"): the searches run concurrently on the shards' worker threads — each is the
+// single-device search with its re-run tiers, driven from the host by the counts alone — and leave their lists in HBM, packed into the
+// shard's slot of the send buffer (HnswSink); then the same all-gather + merge as brute force (the lists are unordered sets: sorted = false).
+int exchange_hnsw_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist,
+							 uint32_t* out_row, uint32_t* out_count) {
+	(void)h;
+	ShardExchange* x = ss->xch;
+	const size_t list_words = size_t(2) * nq * k;
+	const size_t local_bytes = list_words * x->slots * sizeof(uint32_t);
+	const size_t out_bytes = (size_t(2) * nq * k + nq) * sizeof(uint32_t);
+	if (int rc = ensure_pinned(l, out_bytes); rc) return rc;
+	for (uint32_t r = 0; r < x->nranks; ++r) {
+		SH_HIP(hipSetDevice(x->rank_dev[r]));
+		if (int rc = l->d_local[r].ensure(local_bytes); rc) return rc;
+		if (int rc = l->d_gathered[r].ensure(local_bytes * x->nranks); rc) return rc;
+		SH_HIP(hipMemsetAsync(l->d_local[r].ptr, 0xFF, local_bytes, l->stream[r]));   // empty shards and padded slots: rows = kInvalidRow
+		SH_HIP(hipStreamSynchronize(l->stream[r]));                                    // the searches write from their own streams
 	}
-	SH_HIP(hipSetDevice(x->rank_dev[0]));
-	if (int rc = l->d_out.ensure(out_bytes); rc) return rc;
-	float* d_od = static_cast<float*>(l->d_out.ptr);
-	uint32_t* d_or = static_cast<uint32_t*>(l->d_out.ptr) + size_t(nq) * kk;
-	uint32_t* d_oc = d_or + size_t(nq) * kk;
-	launch_merge_shards(static_cast<const uint32_t*>(l->d_gathered[0].ptr), x->nranks * x->slots, nq, kk, 0, d_od, d_or, d_oc, l->stream[0], x->d_slot_base);
-	SH_HIP(hipGetLastError());
-	SH_HIP(hipMemcpyAsync(l->h_pinned, l->d_out.ptr, out_bytes, hipMemcpyDeviceToHost, l->stream[0]));
-	for (uint32_t r = 0; r < x->nranks; ++r) SH_HIP(hipStreamSynchronize(l->stream[r]));
-	const auto* hp = static_cast<const uint32_t*>(l->h_pinned);
-	std::memcpy(out_dist, hp, size_t(nq) * kk * sizeof(float));
-	std::memcpy(out_row, hp + size_t(nq) * kk, size_t(nq) * kk * sizeof(uint32_t));
-	std::memcpy(out_count, hp + size_t(2) * nq * kk, size_t(nq) * sizeof(uint32_t));
-	return RXGPU_OK;
+	const int rc = for_each_shard(ss, [&](size_t s) -> int {
+		if (rxgpu_index_count(ss->shards[s]) == 0) return RXGPU_OK;
+		uint32_t* dst = static_cast<uint32_t*>(l->d_local[x->shard_rank[s]].ptr) + list_words * x->shard_slot[s];
+		return hnsw_search_to_sink(ss->shards[s], queries, nq, k, ef, HnswSink{dst, dst + size_t(nq) * k, k});
+	});
+	if (rc != RXGPU_OK) return rc;
+	return exchange_gather_merge(ss, l, nq, k, false, out_dist, out_row, out_count);
+}
+
+ExchangeLane* take_lane(ShardExchange* x) {
+	std::lock_guard<std::mutex> pl(x->mtx);
+	if (x->free_lanes.empty()) return nullptr;
+	ExchangeLane* lane = x->free_lanes.back();
+	x->free_lanes.pop_back();
+	return lane;
+}
+
+void give_lane(ShardExchange* x, ExchangeLane* lane, int rc) {
+	if (rc != RXGPU_OK) {   // streams may hold half an exchange: drain before the lane is reused
+		for (uint32_t r = 0; r < x->nranks; ++r) {
+			(void)hipSetDevice(x->rank_dev[r]);
+			(void)hipStreamSynchronize(lane->stream[r]);
+		}
+	}
+	std::lock_guard<std::mutex> pl(x->mtx);
+	x->free_lanes.push_back(lane);
 }
 
 }  // namespace
@@ -460,26 +579,12 @@ int sharded_search_knn_impl(rxgpu_index* h, const float* queries, uint32_t nq, u
 		if (fits) {
 			ShardExchange* x = ss->xch;
 			CurrentDevice cd;
-			ExchangeLane* lane = nullptr;
-			{
-				std::lock_guard<std::mutex> pl(x->mtx);
-				if (!x->free_lanes.empty()) {
-					lane = x->free_lanes.back();
-					x->free_lanes.pop_back();
-				}
-			}
+			ExchangeLane* lane = take_lane(x);
 			if (!lane) {
 				if (int rc = new_lane(x, &lane); rc) return rc;
 			}
 			const int rc = exchange_search_knn(h, ss, lane, queries, nq, kk, out_dist, out_row, out_count);
-			if (rc != RXGPU_OK) {   // streams may hold half an exchange: drain before the lane is reused
-				for (uint32_t r = 0; r < x->nranks; ++r) {
-					(void)hipSetDevice(x->rank_dev[r]);
-					(void)hipStreamSynchronize(lane->stream[r]);
-				}
-			}
-			std::lock_guard<std::mutex> pl(x->mtx);
-			x->free_lanes.push_back(lane);
+			give_lane(x, lane, rc);
 			return rc;
 		}
 	}
@@ -567,6 +672,106 @@ int sharded_search_range_impl(rxgpu_index* h, const float* query, float radius, 
 	}
 	if (all.size() > cap) {
 		set_error("rxgpu_search_range: more hits than the output buffer holds");
+		return RXGPU_ERR_OVERFLOW;
+	}
+	return RXGPU_OK;
+}
+
+// rxgpu_hnsw_search_knn on a sharded handle: every shard searches its own graph (attached through rxgpu_index_shard(h, s)); the merged list
+// of a query = the k best of the union of the per-shard results under (dist, global row), global row = s * shard_rows + local row.
+// out_count[q] <= k entries, sorted (a superset of the single-device contract, which leaves them unordered).
+int sharded_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+	ShardSet* ss = h->shard_set;
+	const size_t ns = ss->shards.size();
+	if (nq == 0) return RXGPU_OK;
+	if (k == 0) {
+		std::fill(out_count, out_count + nq, 0u);
+		return RXGPU_OK;
+	}
+	std::shared_lock<std::shared_mutex> lk(ss->call_mtx);
+	bool any = false;
+	for (rxgpu_index* sh : ss->shards) any = any || rxgpu_index_count(sh) != 0;
+	if (!any) {
+		std::fill(out_count, out_count + nq, 0u);
+		return RXGPU_OK;
+	}
+	if (ss->xch && k <= uint32_t(kMaxFusedK)) {
+		ShardExchange* x = ss->xch;
+		CurrentDevice cd;
+		ExchangeLane* lane = take_lane(x);
+		if (!lane) {
+			if (int rc = new_lane(x, &lane); rc) return rc;
+		}
+		const int rc = exchange_hnsw_search_knn(h, ss, lane, queries, nq, k, ef, out_dist, out_row, out_count);
+		give_lane(x, lane, rc);
+		return rc;
+	}
+	std::vector<std::vector<float>> sd(ns);
+	std::vector<std::vector<uint32_t>> sr(ns), sc(ns);
+	const int rc = for_each_shard(ss, [&](size_t s) -> int {
+		sd[s].assign(size_t(nq) * k, 0.f);
+		sr[s].assign(size_t(nq) * k, 0u);
+		sc[s].assign(nq, 0u);
+		if (rxgpu_index_count(ss->shards[s]) == 0) return RXGPU_OK;
+		return rxgpu_hnsw_search_knn(ss->shards[s], queries, nq, k, ef, sd[s].data(), sr[s].data(), sc[s].data());
+	});
+	if (rc != RXGPU_OK) return rc;
+	std::vector<std::pair<float, uint32_t>> all;
+	for (uint32_t q = 0; q < nq; ++q) {
+		all.clear();
+		for (size_t s = 0; s < ns; ++s) {
+			for (uint32_t j = 0; j < sc[s][q]; ++j) all.emplace_back(sd[s][size_t(q) * k + j], uint32_t(sr[s][size_t(q) * k + j] + s * ss->shard_rows));
+		}
+		const size_t take = std::min<size_t>(k, all.size());
+		std::partial_sort(all.begin(), all.begin() + take, all.end(), dist_row_less);
+		for (size_t j = 0; j < take; ++j) {
+			out_dist[size_t(q) * k + j] = all[j].first;
+			out_row[size_t(q) * k + j] = all[j].second;
+		}
+		out_count[q] = uint32_t(take);
+	}
+	return RXGPU_OK;
+}
+
+// HierarchicalNSW::SearchRange over the shards' graphs: every shard's ef-search + closure (rxgpu_hnsw_search_range), hits concatenated with
+// global rows (unordered, like the single-device call).  Overflow protocol as there: *out_total = hits counted so far.
+int sharded_hnsw_search_range(rxgpu_index* h, const float* query, float radius, uint32_t ef, float* out_dist, uint32_t* out_row, uint64_t cap, uint64_t* out_total) {
+	ShardSet* ss = h->shard_set;
+	const size_t ns = ss->shards.size();
+	if (!query || !out_total || (cap && !(out_dist && out_row))) {
+		set_error("rxgpu_hnsw_search_range: null argument");
+		return RXGPU_ERR_PARAMS;
+	}
+	*out_total = 0;
+	std::vector<std::vector<float>> sd(ns);
+	std::vector<std::vector<uint32_t>> sr(ns);
+	std::vector<uint64_t> st(ns, 0);
+	std::shared_lock<std::shared_mutex> lk(ss->call_mtx);
+	const int rc = for_each_shard(ss, [&](size_t s) -> int {
+		if (rxgpu_index_count(ss->shards[s]) == 0) return RXGPU_OK;
+		uint64_t want = std::max<uint64_t>(cap, 256);
+		for (int attempt = 0; attempt < 8; ++attempt) {   // the count an overflow reports is a lower bound: grow until the closure fits
+			sd[s].resize(want);
+			sr[s].resize(want);
+			const int r = rxgpu_hnsw_search_range(ss->shards[s], query, radius, ef, sd[s].data(), sr[s].data(), want, &st[s]);
+			if (r != RXGPU_ERR_OVERFLOW) return r;
+			want = std::max<uint64_t>(want * 4, st[s] * 2);
+		}
+		return RXGPU_ERR_OVERFLOW;
+	});
+	if (rc != RXGPU_OK) return rc;
+	uint64_t total = 0;
+	for (size_t s = 0; s < ns; ++s) {
+		for (uint64_t j = 0; j < st[s]; ++j, ++total) {
+			if (total < cap) {
+				out_dist[total] = sd[s][j];
+				out_row[total] = uint32_t(sr[s][j] + s * ss->shard_rows);
+			}
+		}
+	}
+	*out_total = total;
+	if (total > cap) {
+		set_error("rxgpu_hnsw_search_range: more hits than the output buffer holds");
 		return RXGPU_ERR_OVERFLOW;
 	}
 	return RXGPU_OK;
@@ -671,18 +876,21 @@ int rxgpu_index_create_sharded(int metric, uint32_t dim, uint64_t capacity, uint
 		ss->workers.push_back(w);
 	}
 	const char* mode = getenv("RXGPU_SHARD_MERGE");
-	if (!(mode && std::strcmp(mode, "host") == 0)) {
-		if (const int rc = rxgpu::exchange_create(ss, n_devices, devices, &ss->xch); rc != RXGPU_OK) {
-			rxgpu::sharded_destroy(h);
-			delete h;
-			return rc;
-		}
+	if (mode && std::strcmp(mode, "host") == 0) {
+		ss->merge_note = "RXGPU_SHARD_MERGE=host";
+	} else if (rxgpu::exchange_create(ss, n_devices, devices, &ss->xch) != RXGPU_OK) {
+		// no device-side exchange on this node: the index works on the host-merge path (same results); said once per index, and kept for
+		// rxgpu_index_shard_merge_note
+		ss->xch = nullptr;
+		ss->merge_note = rxgpu_last_error();
+		fprintf(stderr, "rxgpu: sharded index over %u device slot(s): %s — per-shard lists are merged on the host\n", n_devices, ss->merge_note.c_str());
 	}
 	*out = h;
 	return RXGPU_OK;
 }
 
 int rxgpu_index_shard_merge_mode(const rxgpu_index* h) { return h && h->shard_set ? (h->shard_set->xch ? 1 : 0) : -1; }
+const char* rxgpu_index_shard_merge_note(const rxgpu_index* h) { return h && h->shard_set ? h->shard_set->merge_note.c_str() : ""; }
 uint32_t rxgpu_index_shard_ranks(const rxgpu_index* h) { return h && h->shard_set && h->shard_set->xch ? h->shard_set->xch->nranks : 0; }
 uint64_t rxgpu_index_shard_collectives(const rxgpu_index* h) {
 	return h && h->shard_set && h->shard_set->xch ? h->shard_set->xch->collectives.load(std::memory_order_relaxed) : 0;

@@ -26,8 +26,112 @@ GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size
 	}
 }
 
+// ------------------------------------------------------------------------------------------------ the Map over a device list
+struct GpuHnswMap::ShardedState {
+	std::vector<int> devices;
+	rxgpu_index* parent = nullptr;                    // rxgpu_index_create_sharded: owns the shards' device indexes
+	std::vector<std::unique_ptr<GpuHnswMap>> maps;    // shard s: a single-device Map over rxgpu_index_shard(parent, s)
+	size_t shardRows = 0;                             // capacity of every shard = the parent's shard_rows (global row = s * shardRows + local)
+	size_t maxElements = 0;                           // what the caller asked for (MaxElements())
+	size_t M = 0, efConstruction = 0;
+	std::mutex routeMtx;                              // label -> shard decisions (the insert itself runs outside it)
+	std::unordered_map<labeltype, uint32_t> shardOf;  // every label ever routed (a recycled slot leaves a harmless stale entry)
+	std::vector<size_t> routed;                       // new labels sent to shard s so far
+	~ShardedState() {
+		maps.clear();
+		if (parent) rxgpu_index_destroy(parent);
+	}
+};
+
+namespace {
+size_t shardRowsFor(size_t maxElements, size_t n) { return ((std::max<size_t>(maxElements, 1) + n - 1) / n + 31) & ~size_t(31); }
+}  // namespace
+
+void GpuHnswMap::shCreateParent(size_t shardRows) {
+	ShardedState& S = *sh_;
+	rxgpu_index* parent = nullptr;
+	const uint64_t cap = uint64_t(shardRows) * S.devices.size();   // shard_rows of the handle == shardRows (a multiple of 32)
+	if (rxgpu_index_create_sharded(int(graph_.Metric()), uint32_t(graph_.Dim()), cap, uint32_t(S.devices.size()), S.devices.data(), &parent) != RXGPU_OK) {
+		throwDevice("GpuHnswMap: sharded device index creation failed");
+	}
+	if (rxgpu_index_shard_rows(parent) != shardRows) {
+		rxgpu_index_destroy(parent);
+		throw std::logic_error("GpuHnswMap: unexpected shard size of the device index");
+	}
+	for (size_t s = 0; s < S.maps.size(); ++s) S.maps[s]->rebindDevice(rxgpu_index_shard(parent, uint32_t(s)));   // before the old handles go
+	if (S.parent) rxgpu_index_destroy(S.parent);
+	S.parent = parent;
+	S.shardRows = shardRows;
+}
+
+GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, std::vector<int> devices,
+					   Synchronization synchronization)
+	: graph_(metric, dim, 1, M, efConstruction), device_(devices.empty() ? 0 : devices[0]), synchronization_(synchronization), ownsDev_(false) {
+	if (devices.empty()) throw std::logic_error("GpuHnswMap: empty device list");
+	if (2 * graph_.M() > 128) throw std::logic_error("GpuHnswMap: the GPU engine supports M <= 64");
+	if (devices.size() == 1) {   // an ordinary single-device Map
+		ownsDev_ = true;
+		graph_.Resize(maxElements);
+		if (synchronization_ == Synchronization::OnInsertions) graph_.EnableConcurrentInserts();
+		if (rxgpu_index_create(int(metric), uint32_t(dim), maxElements, device_, &dev_) != RXGPU_OK) throwDevice("GpuHnswMap: device index creation failed");
+		return;
+	}
+	sh_ = std::make_unique<ShardedState>();
+	ShardedState& S = *sh_;
+	S.devices = std::move(devices);
+	S.maxElements = maxElements;
+	S.M = M;
+	S.efConstruction = efConstruction;
+	S.routed.assign(S.devices.size(), 0);
+	const size_t rows = shardRowsFor(maxElements, S.devices.size());
+	shCreateParent(rows);
+	for (size_t s = 0; s < S.devices.size(); ++s) {
+		S.maps.emplace_back(new GpuHnswMap(metric, dim, rows, M, efConstruction, S.devices[s], synchronization, rxgpu_index_shard(S.parent, uint32_t(s))));
+	}
+}
+
+GpuHnswMap::GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device, Synchronization synchronization,
+					   rxgpu_index* external)
+	: graph_(metric, dim, maxElements, M, efConstruction), device_(device), dev_(external), synchronization_(synchronization), ownsDev_(false) {
+	if (synchronization_ == Synchronization::OnInsertions) graph_.EnableConcurrentInserts();
+	coalesce_ = false;   // the fan-out above this shard batches nothing; a direct call to a shard stays a direct call
+}
+
+GpuHnswMap::GpuHnswMap(const GpuHnswMap& other, size_t newCapacity, rxgpu_index* external)
+	: graph_(other.graph_, newCapacity), device_(other.device_), dev_(external), synchronization_(other.synchronization_), ownsDev_(false) {
+	if (synchronization_ == Synchronization::OnInsertions) graph_.EnableConcurrentInserts();
+	coalesce_ = false;
+}
+
+void GpuHnswMap::rebindDevice(rxgpu_index* external) {
+	std::lock_guard<std::mutex> lk(syncMtx_);
+	dev_ = external;
+	syncedRows_ = 0;
+	syncedCodes_ = 0;
+	graphOnDevice_ = false;
+	graphDirty_ = true;
+	codesDirty_ = quantized_;
+}
+
 GpuHnswMap::GpuHnswMap(const GpuHnswMap& other, size_t newCapacity)
-	: graph_(other.graph_, newCapacity), device_(other.device_), synchronization_(other.synchronization_) {
+	: graph_(other.graph_, other.sh_ ? 1 : newCapacity), device_(other.device_), synchronization_(other.synchronization_), ownsDev_(!other.sh_) {
+	if (other.sh_) {   // copy-on-write tx clone of a Map over a device list: every shard cloned, a sharded handle of its own
+		const ShardedState& O = *other.sh_;
+		sh_ = std::make_unique<ShardedState>();
+		ShardedState& S = *sh_;
+		S.devices = O.devices;
+		S.maxElements = std::max(O.maxElements, newCapacity);
+		S.M = O.M;
+		S.efConstruction = O.efConstruction;
+		S.shardOf = O.shardOf;
+		S.routed = O.routed;
+		const size_t rows = std::max(O.shardRows, shardRowsFor(S.maxElements, S.devices.size()));
+		shCreateParent(rows);
+		for (size_t s = 0; s < O.maps.size(); ++s) {
+			S.maps.emplace_back(new GpuHnswMap(*O.maps[s], rows, rxgpu_index_shard(S.parent, uint32_t(s))));
+		}
+		return;
+	}
 	if (synchronization_ == Synchronization::OnInsertions) graph_.EnableConcurrentInserts();
 	if (rxgpu_index_create(int(graph_.Metric()), uint32_t(graph_.Dim()), graph_.MaxElements(), device_, &dev_) != RXGPU_OK) {
 		throwDevice("GpuHnswMap: device index creation failed");
@@ -35,10 +139,73 @@ GpuHnswMap::GpuHnswMap(const GpuHnswMap& other, size_t newCapacity)
 }
 
 GpuHnswMap::~GpuHnswMap() {
-	if (dev_) rxgpu_index_destroy(dev_);
+	sh_.reset();
+	if (dev_ && ownsDev_) rxgpu_index_destroy(dev_);
+}
+
+size_t GpuHnswMap::ShardCount() const noexcept { return sh_ ? sh_->maps.size() : 0; }
+size_t GpuHnswMap::ShardRows() const noexcept { return sh_ ? sh_->shardRows : 0; }
+const GpuHnswMap& GpuHnswMap::Shard(size_t s) const {
+	if (!sh_ || s >= sh_->maps.size()) throw std::logic_error("GpuHnswMap: no such shard");
+	return *sh_->maps[s];
+}
+rxgpu_index* GpuHnswMap::DeviceIndex() const noexcept { return sh_ ? sh_->parent : dev_; }
+size_t GpuHnswMap::shMaxElements() const noexcept { return sh_->maxElements; }
+size_t GpuHnswMap::shCount(bool deleted) const noexcept {
+	size_t n = 0;
+	for (const auto& m : sh_->maps) n += deleted ? m->graph_.DeletedCount() : m->graph_.Count();
+	return n;
+}
+size_t GpuHnswMap::shAllocated() const noexcept {
+	size_t n = sizeof(ShardedState) + sh_->shardOf.size() * (sizeof(labeltype) + sizeof(uint32_t) + 2 * sizeof(void*));
+	for (const auto& m : sh_->maps) n += m->graph_.AllocatedMemSize();
+	return n;
+}
+labeltype GpuHnswMap::shLabel(tableint id) const { return Shard(id / sh_->shardRows).graph_.Label(tableint(id % sh_->shardRows)); }
+bool GpuHnswMap::shIsDeleted(tableint id) const noexcept { return sh_->maps[id / sh_->shardRows]->graph_.IsDeleted(tableint(id % sh_->shardRows)); }
+const float* GpuHnswMap::shFloatPtr(labeltype label) const {
+	ShardedState& S = *sh_;
+	uint32_t s;
+	{
+		std::lock_guard<std::mutex> lk(S.routeMtx);
+		const auto it = S.shardOf.find(label);
+		if (it == S.shardOf.end()) throw std::runtime_error("Label not found");
+		s = it->second;
+	}
+	const HnswGraph& g = S.maps[s]->graph_;
+	return g.Vector(g.InternalId(label));
+}
+
+// Which shard takes the point: the one that holds the label already (an update in place, or a re-insert over its delete-marked slot), else
+// the first shard that still has room — shards fill in order, i.e. contiguous ranges of the insertion sequence ("row range").
+GpuHnswMap& GpuHnswMap::shRoute(labeltype label) {
+	ShardedState& S = *sh_;
+	std::lock_guard<std::mutex> lk(S.routeMtx);
+	if (const auto it = S.shardOf.find(label); it != S.shardOf.end()) return *S.maps[it->second];
+	for (size_t s = 0; s < S.maps.size(); ++s) {
+		if (S.routed[s] < S.shardRows) {
+			++S.routed[s];
+			S.shardOf.emplace(label, uint32_t(s));
+			return *S.maps[s];
+		}
+	}
+	for (size_t s = 0; s < S.maps.size(); ++s) {   // every range is full: a delete-marked slot is recycled (addPoint, hnswalg.h:1401-1470)
+		if (S.maps[s]->graph_.DeletedCount()) {
+			S.shardOf.emplace(label, uint32_t(s));
+			return *S.maps[s];
+		}
+	}
+	throw std::runtime_error("The number of elements exceeds the specified limit");   // hnswalg.h:1445
+}
+
+void GpuHnswMap::shSyncAll() const {
+	for (const auto& m : sh_->maps) {
+		if (m->graph_.Count()) m->syncDevice();
+	}
 }
 
 void GpuHnswMap::AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id) {
+	if (sh_) return shRoute(id.AsNumber()).AddPointNoLock(vect, id);
 	graph_.AddPoint(vect.Data(), id.AsNumber());
 	graphDirty_ = true;
 }
@@ -47,21 +214,45 @@ void GpuHnswMap::AddPointConcurrent(ConstFloatVectorView vect, FloatVectorId id)
 	if (synchronization_ == Synchronization::None) {
 		throw std::logic_error("This HNSW index does not support concurrent insertions");   // hnswalg.h:1393-1399 (Synchronization::None)
 	}
+	if (sh_) return shRoute(id.AsNumber()).AddPointConcurrent(vect, id);
 	graph_.AddPointConcurrent(vect.Data(), id.AsNumber());
 	graphDirty_ = true;
 }
 
 void GpuHnswMap::MarkDelete(FloatVectorId id) {
+	if (sh_) {
+		ShardedState& S = *sh_;
+		uint32_t s;
+		{
+			std::lock_guard<std::mutex> lk(S.routeMtx);
+			const auto it = S.shardOf.find(id.AsNumber());
+			if (it == S.shardOf.end()) throw std::runtime_error("Label not found");   // hnswalg.h:1310
+			s = it->second;
+		}
+		return S.maps[s]->MarkDelete(id);
+	}
 	graph_.MarkDelete(id.AsNumber());
 	deletedDirty_ = true;
 }
 
 void GpuHnswMap::ResizeIndex(size_t newMaxElements) {
+	if (sh_) {   // every range grows; the sharded device handle has a fixed shard size, so a new one takes over (the next search mirrors again)
+		ShardedState& S = *sh_;
+		if (newMaxElements < shCount(false)) throw std::runtime_error("Cannot resize, max element is less than the current number of elements");   // hnswalg.h:1187
+		S.maxElements = newMaxElements;
+		const size_t rows = shardRowsFor(newMaxElements, S.devices.size());
+		if (rows > S.shardRows) {
+			for (auto& m : S.maps) m->ResizeIndex(rows);
+			shCreateParent(rows);
+		}
+		return;
+	}
 	graph_.Resize(newMaxElements);
 	graphDirty_ = true;
 }
 
 void GpuHnswMap::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const {
+	if (sh_) throw std::logic_error("GpuHnswMap: the ANN cache stream holds ONE graph — not available for a Map over a device list");
 	// serializeQuantizingParams (hnsw.cc:56-62) + QuantizingParams::Serialize (quantization_params.h:83-96)
 	writer.PutVarUInt(uint32_t(quantized_ ? 1 : 0));
 	if (quantized_) {
@@ -80,6 +271,7 @@ void GpuHnswMap::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& ca
 }
 
 void GpuHnswMap::LoadIndex(AnnCacheReader& reader) {
+	if (sh_) throw std::logic_error("GpuHnswMap: the ANN cache stream holds ONE graph — not available for a Map over a device list");
 	std::optional<Sq8Params> stored;
 	Sq8QuantizationConfig cfg;
 	if (reader.GetVarUInt() != 0) {   // deserializeQuantizingParams (hnsw.cc:64-72)
@@ -113,12 +305,20 @@ void GpuHnswMap::LoadIndex(AnnCacheReader& reader) {
 }
 
 void GpuHnswMap::Clear() {
+	if (sh_) {
+		for (auto& m : sh_->maps) m->Clear();
+		std::lock_guard<std::mutex> lk(sh_->routeMtx);
+		sh_->shardOf.clear();
+		sh_->routed.assign(sh_->maps.size(), 0);
+		return;
+	}
 	graph_.Clear();
 	graphDirty_ = true;
 	deletedDirty_ = true;
 }
 
 void GpuHnswMap::LoadGraph(AnnCacheReader& reader) {
+	if (sh_) throw std::logic_error("GpuHnswMap: the ANN cache stream holds ONE graph — not available for a Map over a device list");
 	graph_.LoadIndex(reader);
 	graphDirty_ = true;
 	deletedDirty_ = true;
@@ -242,6 +442,7 @@ void GpuHnswMap::patchCodes(const std::vector<tableint>& dirty, size_t n) const 
 }
 
 void GpuHnswMap::Quantize(float minQ, float maxQ) {
+	if (sh_) throw std::logic_error("GpuHnswMap: SQ8 is not available for a Map over a device list");
 	if (!(maxQ > minQ)) throw std::runtime_error("Quantize: empty quantisation range");
 	sq8_ = Sq8Params::FromRange(minQ, maxQ, graph_.Dim());
 	pendingSq8_.reset();
@@ -251,6 +452,7 @@ void GpuHnswMap::Quantize(float minQ, float maxQ) {
 }
 
 void GpuHnswMap::Quantize(const Sq8QuantizationConfig& config) {
+	if (sh_) throw std::logic_error("GpuHnswMap: SQ8 is not available for a Map over a device list");
 	if (quantized_ || pendingSq8_) throw std::logic_error("Quantize: the Map is quantised already");
 	const Sq8Params p = Sq8SampleParams(graph_.Count(), graph_.Dim(), config, [this](uint32_t id) { return graph_.Vector(tableint(id)); });
 	if (!(p.maxQ > p.minQ)) throw std::runtime_error("Quantize: empty quantisation range");
@@ -357,6 +559,19 @@ float GpuHnswMap::quantizeQuery(const float* queryDataRaw, std::optional<float> 
 // hnswalg.h:1988-2012
 SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional<float> queryDataNorm, size_t k, size_t ef) const {
 	SearchResultQueue result;
+	if (sh_) {   // every shard's SearchKnn at once; the lists meet on the devices (rxgpu_hnsw_search_knn on the sharded handle)
+		const size_t total = shCount(false);
+		if (total == 0 || k == 0) return result;
+		shSyncAll();
+		k = std::min(k, total);
+		std::vector<float> dist(k);
+		std::vector<uint32_t> row(k);
+		uint32_t count = 0;
+		if (rxgpu_hnsw_search_knn(sh_->parent, queryDataRaw, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) throwDevice("SearchKnn");
+		ReserveQueue(result, count);
+		for (uint32_t i = 0; i < count; ++i) result.emplace(dist[i], shLabel(row[i]));
+		return result;
+	}
 	const size_t n = graph_.Count();
 	if (n == 0 || k == 0) return result;
 	syncDevice();
@@ -382,13 +597,13 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 
 uint64_t GpuHnswMap::TieReruns() const {
 	uint64_t n = 0;
-	if (rxgpu_hnsw_read_tie_reruns(dev_, &n) != RXGPU_OK) throwDevice("TieReruns");
+	if (rxgpu_hnsw_read_tie_reruns(DeviceIndex(), &n) != RXGPU_OK) throwDevice("TieReruns");
 	return n;
 }
 
 uint64_t GpuHnswMap::LdsReruns() const {
 	uint64_t n = 0;
-	if (rxgpu_hnsw_read_lds_reruns(dev_, &n) != RXGPU_OK) throwDevice("LdsReruns");
+	if (rxgpu_hnsw_read_lds_reruns(DeviceIndex(), &n) != RXGPU_OK) throwDevice("LdsReruns");
 	return n;
 }
 
@@ -407,6 +622,7 @@ StreamingSearchSession& StreamingSearchSession::operator=(StreamingSearchSession
 
 // hnswalg.h:1865-1891
 StreamingSearchSession GpuHnswMap::BeginStreamingSearch(const float* queryDataRaw, std::optional<float> queryDataNorm, StreamingSearchOptions opts) const {
+	if (sh_) throw std::logic_error("GpuHnswMap: streaming sessions walk ONE graph — not available for a Map over a device list");
 	StreamingSearchSession session;
 	session.graph_ = this;
 	syncDevice();
@@ -449,6 +665,26 @@ StreamingBatch GpuHnswMap::ContinueStreamingSearch(StreamingSearchSession& sessi
 // the expansion is one launch of hnsw_range_kernel whatever its depth; the result is a set, its order does not depend on the walk).
 SearchResultQueue GpuHnswMap::SearchRange(const float* queryDataRaw, std::optional<float> queryDataNorm, float radius, size_t ef) const {
 	SearchResultQueue result;
+	if (sh_) {   // every shard's ef-search + closure (rxgpu_hnsw_search_range on the sharded handle), hits concatenated
+		const size_t total = shCount(false);
+		if (total == 0) return result;
+		shSyncAll();
+		const size_t efEff = ef ? ef : 1;
+		std::vector<float> dist;
+		std::vector<uint32_t> row;
+		uint64_t hits = 0;
+		for (size_t cap = std::max<size_t>(4 * efEff * sh_->maps.size(), 1024);; cap = std::min<size_t>(total, std::max<size_t>(2 * cap, size_t(hits)))) {
+			cap = std::min(cap, total);
+			dist.resize(cap);
+			row.resize(cap);
+			const int rc = rxgpu_hnsw_search_range(sh_->parent, queryDataRaw, radius, uint32_t(efEff), dist.data(), row.data(), cap, &hits);
+			if (rc == RXGPU_OK) break;
+			if (rc != RXGPU_ERR_OVERFLOW || cap >= total) throwDevice("SearchRange");
+		}
+		ReserveQueue(result, size_t(hits));
+		for (uint64_t i = 0; i < hits; ++i) result.emplace(dist[i], shLabel(row[i]));
+		return result;
+	}
 	const size_t n = graph_.Count();
 	if (n == 0) return result;
 	syncDevice();

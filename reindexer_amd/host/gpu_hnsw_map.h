@@ -10,6 +10,8 @@
 #include <memory>
 #include <mutex>
 #include <optional>
+#include <unordered_map>
+#include <vector>
 
 #include "hnsw_graph.h"
 #include "rx_types.h"
@@ -57,20 +59,35 @@ class GpuHnswMap {
 public:
 	GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device = 0,
 			   Synchronization synchronization = Synchronization::None);
+	// SURVEY 8(e) "HNSW": the same Map over a DEVICE LIST (more than one entry; a device may repeat).  The points are split into row ranges in
+	// insertion order — shard s takes the points that arrive while shards 0 .. s - 1 are full (ceil(maxElements / N) each) — and every
+	// shard is a complete single-device Map of its own: its graph is what the reference builds over those points in that order, mirrored
+	// on that shard's GPU (one rxgpu_index_create_sharded handle owns the N device indexes).  SearchKnn runs every shard's search at once and
+	// the per-shard results meet in the same ncclAllGather + (dist, global row) merge as brute force (rxgpu_hnsw_search_knn on the sharded
+	// handle): the k best of the union of the per-shard engine results, recall >= the single graph's at equal ef.  Not available over a device
+	// list: SQ8, streaming sessions, the ANN disk cache (they throw / report "not available"; a single-device Map has them all).
+	GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, std::vector<int> devices,
+			   Synchronization synchronization = Synchronization::None);
 	GpuHnswMap(const GpuHnswMap& other, size_t newCapacity);
 	~GpuHnswMap();
 	GpuHnswMap& operator=(const GpuHnswMap&) = delete;
 
-	size_t MaxElements() const noexcept { return graph_.MaxElements(); }
-	size_t CurrentElementCount() const noexcept { return graph_.Count(); }
-	size_t DeletedCountUnsafe() const noexcept { return graph_.DeletedCount(); }
-	size_t AllocatedMemSize() const noexcept { return graph_.AllocatedMemSize(); }
+	size_t MaxElements() const noexcept { return sh_ ? shMaxElements() : graph_.MaxElements(); }
+	size_t CurrentElementCount() const noexcept { return sh_ ? shCount(false) : graph_.Count(); }
+	size_t DeletedCountUnsafe() const noexcept { return sh_ ? shCount(true) : graph_.DeletedCount(); }
+	size_t AllocatedMemSize() const noexcept { return sh_ ? shAllocated() : graph_.AllocatedMemSize(); }
 	// hnswalg.h:216-228: links0 + data + label + hash per element
 	size_t ElementSize() const noexcept { return (1 + graph_.MaxM0()) * sizeof(uint32_t) + graph_.Dim() * sizeof(float) + 16; }
 
-	labeltype ExternalLabel(tableint id) const { return graph_.Label(id); }
-	bool IsMarkedDeleted(tableint id) const noexcept { return graph_.IsDeleted(id); }
-	const float* FloatPtrByExternalLabel(labeltype label) const { return graph_.Vector(graph_.InternalId(label)); }
+	// internal ids of a Map over a device list are GLOBAL rows: shard * ShardRows() + the shard's internal id
+	labeltype ExternalLabel(tableint id) const { return sh_ ? shLabel(id) : graph_.Label(id); }
+	bool IsMarkedDeleted(tableint id) const noexcept { return sh_ ? shIsDeleted(id) : graph_.IsDeleted(id); }
+	const float* FloatPtrByExternalLabel(labeltype label) const { return sh_ ? shFloatPtr(label) : graph_.Vector(graph_.InternalId(label)); }
+	bool Sharded() const noexcept { return bool(sh_); }
+	size_t ShardCount() const noexcept;
+	size_t ShardRows() const noexcept;
+	const GpuHnswMap& Shard(size_t s) const;   // shard s as the single-device Map it is (tests pin each to the reference engine)
+	rxgpu_index* DeviceIndex() const noexcept;   // the device handle (sharded: the rxgpu_index_create_sharded handle)
 
 	void MarkDelete(FloatVectorId id);
 	void AddPointNoLock(ConstFloatVectorView vect, FloatVectorId id);
@@ -116,6 +133,21 @@ public:
 
 private:
 	void syncDevice() const;
+	// ---- the Map over a device list
+	struct ShardedState;
+	GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, int device, Synchronization synchronization,
+			   rxgpu_index* external);                                                     // a shard: the device index belongs to the sharded handle
+	GpuHnswMap(const GpuHnswMap& other, size_t newCapacity, rxgpu_index* external);
+	void rebindDevice(rxgpu_index* external);                                               // the sharded handle was re-created: mirror everything again
+	void shCreateParent(size_t shardRows);
+	size_t shMaxElements() const noexcept;
+	size_t shCount(bool deleted) const noexcept;
+	size_t shAllocated() const noexcept;
+	labeltype shLabel(tableint id) const;
+	bool shIsDeleted(tableint id) const noexcept;
+	const float* shFloatPtr(labeltype label) const;
+	GpuHnswMap& shRoute(labeltype label);
+	void shSyncAll() const;
 public:
 	// The ANN disk cache (ann_cache.h): HierarchicalNSW::SaveIndex / LoadIndex (hnswlib/hnsw.cc:41-72).  The stream starts with the
 	// "quantised" flag; a quantised Map writes 1 + its QuantizingParams (version, QuantizationConfig, minQ, maxQ, alpha, alpha_2, delta:
@@ -157,6 +189,8 @@ private:
 	mutable std::deque<PendingQuery*> coQueue_;
 	mutable bool coLeader_ = false;
 	mutable size_t coBatches_ = 0;
+	bool ownsDev_ = true;                 // false: a shard (the device index belongs to the sharded handle) or the Map over a device list itself
+	std::unique_ptr<ShardedState> sh_;    // non-null: the Map over a device list
 };
 
 }  // namespace rxgpu::host

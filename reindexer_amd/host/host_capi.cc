@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string>
 
+#include "device_list.h"
 #include "gpu_bruteforce_map.h"
 #include "knn_select.h"
 
@@ -77,6 +78,24 @@ void* rxhost_bf_create_sharded(int metric, size_t dim, size_t maxElements, const
 	guarded([&] { m = new GpuBruteforceMap(VectorMetric(metric), dim, maxElements, std::vector<int>(devices, devices + nDevices)); });
 	return m;
 }
+// The shape the in-tree adapter constructs (rx_seam.h GpuBruteforceMapInTree: `Map(metric, dim, maxElements)`, hnsw_index.cc:61-66): the
+// device list comes from RX_GPU_VECTOR_INDEXES (device_list.h); unset -> device 0.
+void* rxhost_bf_create_from_env(int metric, size_t dim, size_t maxElements) {
+	GpuBruteforceMap* m = nullptr;
+	guarded([&] {
+		std::vector<int> d = GpuDevicesFromEnv();
+		if (d.empty()) d.push_back(0);
+		m = new GpuBruteforceMap(VectorMetric(metric), dim, maxElements, std::move(d));
+	});
+	return m;
+}
+// device_list.h's parser: the list into out[0..cap), returns its length (0: no GPU engine)
+size_t rxhost_parse_device_list(const char* text, int* out, size_t cap) {
+	const std::vector<int> d = ParseDeviceList(text);
+	for (size_t i = 0; i < d.size() && i < cap; ++i) out[i] = d[i];
+	return d.size();
+}
+int rxhost_bf_is_sharded(void* h) { return static_cast<GpuBruteforceMap*>(h)->Sharded() ? 1 : 0; }
 void* rxhost_bf_clone(void* h, size_t newMaxElements) {
 	GpuBruteforceMap* m = nullptr;
 	guarded([&] { m = new GpuBruteforceMap(*static_cast<GpuBruteforceMap*>(h), newMaxElements); });
@@ -370,6 +389,29 @@ void* rxhost_hnsw_create_mt(int metric, size_t dim, size_t maxElements, size_t M
 	guarded([&] { m = new GpuHnswMap(VectorMetric(metric), dim, maxElements, M, efConstruction, device, Synchronization::OnInsertions); });
 	return m;
 }
+// The Map over a device list (SURVEY 8e "HNSW": a graph per shard, the per-shard results meet in the all-gather + merge of brute force);
+// nDevices == 0: the list comes from RX_GPU_VECTOR_INDEXES like the in-tree adapter's (rx_seam.h GpuHnswMapT), unset -> device 0
+void* rxhost_hnsw_create_sharded(int metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, const int* devices, size_t nDevices,
+								 int multithread) {
+	GpuHnswMap* m = nullptr;
+	guarded([&] {
+		std::vector<int> d = nDevices ? std::vector<int>(devices, devices + nDevices) : GpuDevicesFromEnv();
+		if (d.empty()) d.push_back(0);
+		m = new GpuHnswMap(VectorMetric(metric), dim, maxElements, M, efConstruction, std::move(d),
+						   multithread ? Synchronization::OnInsertions : Synchronization::None);
+	});
+	return m;
+}
+size_t rxhost_hnsw_shard_count(void* h) { return static_cast<GpuHnswMap*>(h)->ShardCount(); }
+size_t rxhost_hnsw_shard_rows(void* h) { return static_cast<GpuHnswMap*>(h)->ShardRows(); }
+// shard s as a borrowed single-device Map (owned by the sharded one): graph export, direct searches
+void* rxhost_hnsw_shard(void* h, size_t s) {
+	void* out = nullptr;
+	guarded([&] { out = const_cast<GpuHnswMap*>(&static_cast<GpuHnswMap*>(h)->Shard(s)); });
+	return out;
+}
+// the device handle of the Map (sharded: the rxgpu_index_create_sharded handle) — tests read its merge mode / collectives counter
+void* rxhost_hnsw_device_index(void* h) { return static_cast<GpuHnswMap*>(h)->DeviceIndex(); }
 // `threads` upsert threads calling AddPointConcurrent, as HnswIndexBase<HierarchicalNSWMT>::upsertConcurrent does (hnsw_index.cc:105-116)
 int rxhost_hnsw_add_many_mt(void* h, const float* vecs, size_t n, size_t dim, const uint64_t* labels, unsigned threads) {
 	return guarded([&] {

@@ -13,21 +13,30 @@
 
 #include "core/enums.h"
 #include "core/index/float_vector/scalar_quantization/quantization_params.h"
+#include "device_list.h"
 #include "gpu_bruteforce_map.h"
 #include "gpu_hnsw_map.h"
 
 namespace rxgpu::host {
 
-// RX_GPU_VECTOR_INDEXES=<device> routes `vec_bf` / `hnsw` index definitions to the MI355X engines (unset / empty: the CPU engines).
+// RX_GPU_VECTOR_INDEXES=<device list> (device_list.h: "3", "0,1,2,3", "0-7") routes `vec_bf` / `hnsw` index definitions to the MI355X
+// engines (unset / empty / malformed: the CPU engines).  More than one device: the brute-force Map range-shards its rows over the list
+// (rxgpu_index_create_sharded, one RCCL all-gather per query batch) — BruteForceVectorIndex_New (hnsw_index.cc:578-581) reaches BASELINE
+// configs[3] with no further change.
 inline int GpuDeviceFromEnv() noexcept {
-	const char* e = std::getenv("RX_GPU_VECTOR_INDEXES");
-	return (e && *e) ? std::atoi(e) : -1;
+	const std::vector<int> d = GpuDevicesFromEnv();
+	return d.empty() ? -1 : d[0];
+}
+inline std::vector<int> GpuDevicesOrDefault() {
+	std::vector<int> d = GpuDevicesFromEnv();
+	if (d.empty()) d.push_back(0);
+	return d;
 }
 
 // hnswlib::BruteforceSearch's shape: (metric, dim, maxElements) + copy-with-capacity (bruteforce.h:16-17)
 class GpuBruteforceMapInTree : public GpuBruteforceMap {
 public:
-	GpuBruteforceMapInTree(VectorMetric metric, size_t dim, size_t maxElements) : GpuBruteforceMap(metric, dim, maxElements, std::max(0, GpuDeviceFromEnv())) {}
+	GpuBruteforceMapInTree(VectorMetric metric, size_t dim, size_t maxElements) : GpuBruteforceMap(metric, dim, maxElements, GpuDevicesOrDefault()) {}
 	GpuBruteforceMapInTree(const GpuBruteforceMapInTree& other, size_t newMaxElements) : GpuBruteforceMap(other, newMaxElements) {}
 };
 
@@ -36,7 +45,7 @@ template <Synchronization synchronization>
 class GpuHnswMapT : public GpuHnswMap {
 public:
 	GpuHnswMapT(reindexer::IsArray, VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction)
-		: GpuHnswMap(metric, dim, maxElements, M, efConstruction, std::max(0, GpuDeviceFromEnv()), synchronization) {}
+		: GpuHnswMap(metric, dim, maxElements, M, efConstruction, GpuDevicesOrDefault(), synchronization) {}
 	GpuHnswMapT(const GpuHnswMapT& other, size_t newCapacity) : GpuHnswMap(other, newCapacity) {}
 
 	// hnsw.h:32 / hnswalg.h:586-592

@@ -114,6 +114,16 @@ def normalize_copy(x):
     return out, np.float32(k)
 
 
+def parse_device_list(text: str | None) -> list[int]:
+    """host/device_list.h: "3" | "0,1,2,3" | "0-7" | "0-3,6" -> device list; empty = no GPU engine."""
+    L = lib()
+    L.rxhost_parse_device_list.restype = _sz
+    L.rxhost_parse_device_list.argtypes = [C.c_char_p, _vp, _sz]
+    out = np.zeros(64, np.int32)
+    n = L.rxhost_parse_device_list(None if text is None else text.encode(), out.ctypes.data, 64)
+    return [int(x) for x in out[:n]]
+
+
 class GpuBruteforceMap:
     """rxgpu::host::GpuBruteforceMap (drop-in for hnswlib::BruteforceSearch)."""
 
@@ -131,6 +141,23 @@ class GpuBruteforceMap:
         self.h = _handle if _handle is not None else lib().rxhost_bf_create(metric, dim, max_elements, device)
         if not self.h:
             _raise()
+
+    @classmethod
+    def from_env(cls, metric: int, dim: int, max_elements: int) -> "GpuBruteforceMap":
+        """What the reference's factory constructs through the in-tree adapter (rx_seam.h): `Map(metric, dim, maxElements)`, the device
+        list taken from RX_GPU_VECTOR_INDEXES ("3", "0,1,2,3", "0-7"; unset: device 0)."""
+        L = lib()
+        L.rxhost_bf_create_from_env.restype = _vp
+        L.rxhost_bf_create_from_env.argtypes = [_i, _sz, _sz]
+        h = L.rxhost_bf_create_from_env(metric, dim, max_elements)
+        if not h:
+            _raise()
+        return cls(metric, dim, max_elements, _handle=h)
+
+    @property
+    def sharded(self) -> bool:
+        lib().rxhost_bf_is_sharded.argtypes = [_vp]
+        return bool(lib().rxhost_bf_is_sharded(self.h))
 
     def enable_coalescing(self, on: bool) -> None:
         lib().rxhost_bf_enable_coalescing.argtypes = [_vp, _i]
@@ -453,9 +480,22 @@ class GpuHnswMap:
     the reference's multithreaded index build — add(..., threads=T) then inserts from T threads through AddPointConcurrent)."""
 
     def __init__(self, metric: int, dim: int, max_elements: int, M: int = 16, ef_construction: int = 200, device: int = 0, _handle=None,
-                 multithread: bool = False):
+                 multithread: bool = False, devices=None, _borrowed: bool = False):
+        """devices=[d0, d1, ...]: the Map over a device list (a graph per shard; a device may be listed more than once); devices=[] takes
+        the list from RX_GPU_VECTOR_INDEXES like the in-tree adapter."""
         L = lib()
+        self._borrowed = _borrowed
         if not hasattr(L, "_hnsw_bound"):
+            L.rxhost_hnsw_create_sharded.restype = _vp
+            L.rxhost_hnsw_create_sharded.argtypes = [_i, _sz, _sz, _sz, _sz, _vp, _sz, _i]
+            L.rxhost_hnsw_shard_count.restype = _sz
+            L.rxhost_hnsw_shard_count.argtypes = [_vp]
+            L.rxhost_hnsw_shard_rows.restype = _sz
+            L.rxhost_hnsw_shard_rows.argtypes = [_vp]
+            L.rxhost_hnsw_shard.restype = _vp
+            L.rxhost_hnsw_shard.argtypes = [_vp, _sz]
+            L.rxhost_hnsw_device_index.restype = _vp
+            L.rxhost_hnsw_device_index.argtypes = [_vp]
             L.rxhost_hnsw_create.restype = _vp
             L.rxhost_hnsw_create.argtypes = [_i, _sz, _sz, _sz, _sz, _i]
             L.rxhost_hnsw_create_mt.restype = _vp
@@ -495,9 +535,30 @@ class GpuHnswMap:
             L._hnsw_bound = True
         self.dim, self.metric = dim, metric
         create = L.rxhost_hnsw_create_mt if multithread else L.rxhost_hnsw_create
-        self.h = _handle if _handle is not None else create(metric, dim, max_elements, M, ef_construction, device)
+        if _handle is not None:
+            self.h = _handle
+        elif devices is not None:
+            dv = np.ascontiguousarray(devices, np.int32)
+            self.h = L.rxhost_hnsw_create_sharded(metric, dim, max_elements, M, ef_construction, dv.ctypes.data, dv.shape[0], int(multithread))
+        else:
+            self.h = create(metric, dim, max_elements, M, ef_construction, device)
         if not self.h:
             _raise()
+
+    shard_count = property(lambda self: lib().rxhost_hnsw_shard_count(self.h))
+    shard_rows = property(lambda self: lib().rxhost_hnsw_shard_rows(self.h))
+
+    def shard(self, s: int) -> "GpuHnswMap":
+        """Shard s of a Map over a device list as the (borrowed) single-device Map it is."""
+        h = lib().rxhost_hnsw_shard(self.h, s)
+        if not h:
+            _raise()
+        return GpuHnswMap(self.metric, self.dim, 0, _handle=h, _borrowed=True)
+
+    @property
+    def device_index(self) -> int:
+        """rxgpu_index* of the Map's device mirror (sharded: the rxgpu_index_create_sharded handle)."""
+        return lib().rxhost_hnsw_device_index(self.h)
 
     def clone(self, new_capacity: int) -> "GpuHnswMap":
         h = lib().rxhost_hnsw_clone(self.h, new_capacity)
@@ -507,7 +568,8 @@ class GpuHnswMap:
 
     def close(self):
         if getattr(self, "h", None):
-            lib().rxhost_hnsw_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                lib().rxhost_hnsw_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,254 @@
+"""-m gpu: HNSW over a DEVICE LIST (SURVEY §8(e) "HNSW": per-shard independent graphs + the same all-gather merge as brute force).
+
+C-ABI: every shard of an rxgpu_index_create_sharded handle holds the graph of ITS rows (rows / graph attached through the
+rxgpu_index_shard(h, s) handles); rxgpu_hnsw_search_knn on the sharded handle runs every shard's search at once, the per-shard results stay in
+HBM and meet in one ncclAllGather + the (dist, global row) merge kernel.  Map: GpuHnswMap over a device list — the shape the reference's
+factory reaches with RX_GPU_VECTOR_INDEXES=0-7 (rx_seam.h).  The 1-GPU test box lists device 0 several times: the code path is the multi-GPU one.
+
+Bar: the merged result = the k best of the union of the per-shard ENGINE results — each shard pinned to the restated engine and, where
+oracle/_ref travels, to the reference's own HierarchicalNSW built over the shard's points — labels and distance bits; recall vs exact brute
+force >= the single graph's at equal ef."""
+import numpy as np
+import pytest
+
+from .conftest import make_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def hostapi(rxgpu):
+    from reindexer_amd import hostapi as h
+    h.lib()
+    return h
+
+
+def expected_merge(per_shard, k):
+    """per_shard: [(dist, global_row)] arrays of every shard -> the k best under (dist, global row)."""
+    d = np.concatenate([p[0] for p in per_shard])
+    r = np.concatenate([p[1] for p in per_shard])
+    order = np.lexsort((r, d))[:k]
+    return d[order], r[order]
+
+
+@pytest.mark.parametrize("mode", ["rccl", "host"])
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_c_abi_sharded_hnsw_is_the_merge_of_the_per_shard_engines(rxgpu, hostapi, oracle, monkeypatch, mode, metric):
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    if mode == "host":
+        monkeypatch.setenv("RXGPU_SHARD_MERGE", "host")
+    else:
+        monkeypatch.delenv("RXGPU_SHARD_MERGE", raising=False)
+    n, d = 5000, 48
+    rows = make_corpus(70 + metric, n, d)
+    for shards, fill in ((2, n), (3, n), (8, n), (4, 1400)):   # the last: shard 1 partial, shards 2 and 3 EMPTY
+        with rxgpu.ShardedVectorIndex(metric, d, n, [0] * shards) as sx:
+            assert sx.merge_mode == mode
+            sr = sx.shard_rows
+            graphs = []
+            for s in range(shards):
+                lo, hi = s * sr, min(fill, (s + 1) * sr)
+                if lo >= hi:
+                    graphs.append(None)
+                    continue
+                part = rows[lo:hi]
+                m = hostapi.GpuHnswMap(metric, d, hi - lo, M=8, ef_construction=80)
+                m.add(part, np.arange(lo, hi, dtype=np.uint64))   # label = GLOBAL row
+                g = m.export_graph()
+                g["vectors"] = part
+                m.close()
+                inv = oracle.l2_modules(part) if metric == 2 else None
+                view = sx.shard(s)
+                view.upload_rows(0, part, inv)
+                view.hnsw_attach_graph(g)
+                graphs.append((g, inv))
+            q = make_corpus(400 + metric, 7, d)
+            if metric == 2:
+                q = np.stack([oracle.normalize_copy(v)[0] for v in q])
+            before = sx.collectives
+            calls = 0
+            for k, ef in ((10, 64), (1, 0), (40, 40), (64, 100)):
+                for qs in (q[:1], q):
+                    gd, gr, gc = sx.hnsw_search_knn(qs, k, ef)
+                    calls += 1
+                    for qi in range(qs.shape[0]):
+                        per = []
+                        for g in graphs:
+                            if g is None:
+                                continue
+                            wd, wl = oracle_hnsw_search_knn(oracle, g[0], qs[qi], k, ef, g[1])
+                            per.append((wd, wl.astype(np.uint32)))
+                        wd, wr = expected_merge(per, k)
+                        c = int(gc[qi])
+                        assert c == wd.shape[0], (metric, shards, fill, k, ef, qi)
+                        assert np.array_equal(gr[qi, :c], wr) and np.array_equal(bits(gd[qi, :c]), bits(wd)), (metric, shards, fill, k, ef, qi)
+            assert sx.collectives - before == (calls if mode == "rccl" else 0)
+            # k > 64: host merge in either mode
+            gd, gr, gc = sx.hnsw_search_knn(q[:2], 100, 128)
+            for qi in range(2):
+                per = [(lambda r: (r[0], r[1].astype(np.uint32)))(oracle_hnsw_search_knn(oracle, g[0], q[qi], 100, 128, g[1])) for g in graphs if g]
+                wd, wr = expected_merge(per, 100)
+                c = int(gc[qi])
+                assert c == wd.shape[0] and np.array_equal(gr[qi, :c], wr) and np.array_equal(bits(gd[qi, :c]), bits(wd))
+            evals, hops = sx.hnsw_read_stats()
+            assert evals > 0 and hops > 0
+
+
+def test_sharded_handle_refuses_what_is_per_graph(rxgpu):
+    from reindexer_amd import capi
+    with rxgpu.ShardedVectorIndex(1, 16, 256, [0, 0]) as sx:
+        g = dict(links0=np.zeros((1, 17), np.uint32), upper_off=np.zeros(2, np.uint64), upper=np.zeros(0, np.uint32), deleted=np.zeros(1, np.uint8),
+                 M=8, maxM0=16, maxlevel=0, entry=0, num_deleted=0)
+        with pytest.raises(capi.RxGpuError, match="one graph per shard"):
+            sx.hnsw_attach_graph(g)
+        d, r, c = sx.hnsw_search_knn(np.zeros((2, 16), np.float32), 5, 10)    # every shard empty: no hits, no error
+        assert c.tolist() == [0, 0]
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_map_over_a_device_list_equals_the_per_shard_engines(hostapi, oracle, metric):
+    """GpuHnswMap(devices=[0, 0, 0]): points fill the shards in insertion order; every shard's graph is what the engine builds over its points
+    (restated engine on the exported shard graph); SearchKnn / SearchRange = the merge of the shard results; deletes and re-inserts route to the
+    shard that holds the label; recall >= the single graph's."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    n, d, k = 4500, 40, 10
+    rows = make_corpus(81 + metric, n, d)
+    rng = np.random.default_rng(metric)
+    labels = (rng.permutation(n).astype(np.uint64) << np.uint64(32)) | np.uint64(5)
+    many = hostapi.GpuHnswMap(metric, d, n, M=8, ef_construction=80, devices=[0, 0, 0])
+    one = hostapi.GpuHnswMap(metric, d, n, M=8, ef_construction=80)
+    assert many.shard_count == 3 and many.shard_rows == 1504
+    many.add(rows, labels)
+    one.add(rows, labels)
+    assert many.count == n and [many.shard(s).count for s in range(3)] == [1504, 1504, n - 3008]
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    for phase in range(3):
+        if phase == 1:
+            for lab in labels[rng.choice(n, 300, replace=False)]:
+                many.mark_delete(lab)
+                one.mark_delete(lab)
+            assert many.deleted_count == 300
+        if phase == 2:   # updates in place: the label stays in its shard
+            upd = rng.choice(n, 50, replace=False)
+            rows[upd] = make_corpus(999, 50, d)
+            many.add(rows[upd], labels[upd])
+            one.add(rows[upd], labels[upd])
+            inv = oracle.l2_modules(rows) if metric == 2 else None
+            assert many.count == n
+        graphs = []
+        for s in range(3):
+            g = many.shard(s).export_graph(with_views=True)
+            graphs.append(g)
+        hits_many = hits_one = total = 0
+        for qi in range(20):
+            q = make_corpus(700 + qi, 1, d)[0]
+            if metric == 2:
+                q, _ = oracle.normalize_copy(q)
+            for kk, ef in ((k, 64), (3, 0)):
+                per = [oracle_hnsw_search_knn(oracle, g, q, kk, ef, g["inv_norms"]) for g in graphs]
+                # the Map merges under (dist, global row); labels of one shard keep the shard's internal order only through the row — compare as sets
+                # of (dist bits, label), ties at the kk-th place excluded by the generic data
+                wd = np.concatenate([p[0] for p in per])
+                wl = np.concatenate([p[1] for p in per])
+                order = np.lexsort((wl, wd))[:kk]
+                gd, gl = many.search_knn(q, kk, ef)
+                o2 = np.lexsort((gl, gd))
+                assert np.array_equal(gl[o2], wl[order]) and np.array_equal(bits(gd[o2]), bits(wd[order])), (metric, phase, qi, kk, ef)
+            alld = oracle.dist_many(metric, q, rows, inv)
+            live = np.ones(n, bool)
+            for g in graphs:
+                dead = g["labels"][g["deleted"] != 0]
+                live[np.isin(labels, dead)] = False
+            alld[~live] = np.inf
+            truth = set(labels[np.argsort(alld, kind="stable")[:k]].tolist())
+            hits_many += len(truth & set(many.search_knn(q, k, 64)[1].tolist()))
+            hits_one += len(truth & set(one.search_knn(q, k, 64)[1].tolist()))
+            total += k
+            radius = float(np.sort(alld)[25])
+            gd, gl = many.search_range(q, radius, 32)
+            per = [many.shard(s).search_range(q, radius, 32) for s in range(3)]
+            wl = np.concatenate([p[1] for p in per])
+            assert sorted(gl.tolist()) == sorted(wl.tolist())
+        assert hits_many >= hits_one, (hits_many, hits_one, total)   # recall >= the single graph's at equal ef
+    # growth: every range grows, the device mirror is re-created, results stay
+    q = make_corpus(5, 1, d)[0]
+    if metric == 2:
+        q, _ = oracle.normalize_copy(q)
+    before = many.search_knn(q, k, 64)
+    many.resize(2 * n)
+    assert many.shard_rows == 3008
+    after = many.search_knn(q, k, 64)
+    assert np.array_equal(before[1], after[1]) and np.array_equal(bits(before[0]), bits(after[0]))
+    extra = make_corpus(6, 200, d)
+    many.add(extra, (np.arange(n, n + 200, dtype=np.uint64) << np.uint64(32)) | np.uint64(5))
+    assert many.count == n + 200 and many.shard(0).count == 1504 + 200   # the first range has room again
+    gd, gl = many.search_knn(extra[17], 1, 32)
+    assert gl[0] == ((n + 17) << 32 | 5)
+    # copy-on-write clone
+    c = many.clone(2 * n + 10)
+    cd, cl = c.search_knn(q, k, 64)
+    md, ml = many.search_knn(q, k, 64)
+    assert np.array_equal(cl, ml) and np.array_equal(bits(cd), bits(md))
+    c.close()
+    many.close()
+    one.close()
+
+
+def test_map_shards_equal_the_reference_engine_built_over_the_same_points(hostapi, ref, oracle):
+    """Each shard pinned to the reference's own HierarchicalNSW (oracle/_ref) over the shard's points in insertion order: the sharded Map's
+    answer = the (dist, label)-sorted union of what those engines return, cut at k."""
+    from oracle.pyoracle import RefHnsw
+    n, d, metric = 3000, 64, 1
+    rows = make_corpus(91, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(2)
+    many = hostapi.GpuHnswMap(metric, d, n, devices=[0, 0])
+    many.add(rows, labels)
+    sr = many.shard_rows
+    engines = []
+    for s in range(2):
+        lo, hi = s * sr, min(n, (s + 1) * sr)
+        r = RefHnsw(ref, metric, d, hi - lo)
+        r.add(rows[lo:hi], labels[lo:hi])
+        engines.append(r)
+    for qi in range(20):
+        q = make_corpus(300 + qi, 1, d)[0]
+        for k, ef in ((10, 128), (5, 5)):
+            per = [e.search_knn(q, k, ef) for e in engines]
+            wd = np.concatenate([p[0] for p in per])
+            wl = np.concatenate([p[1] for p in per])
+            order = np.lexsort((wl, wd))[:k]
+            gd, gl = many.search_knn(q, k, ef)
+            o2 = np.lexsort((gl, gd))
+            assert np.array_equal(gl[o2], wl[order]) and np.array_equal(bits(gd[o2]), bits(wd[order])), (qi, k, ef)
+    for e in engines:
+        e.close()
+    many.close()
+
+
+def test_in_tree_hnsw_shape_takes_its_device_list_from_the_environment(hostapi, monkeypatch):
+    """rx_seam.h GpuHnswMapT: `Map(IsArray, metric, dim, maxElements, M, efConstruction)` (hnsw_index.cc:47-58) with the device list from
+    RX_GPU_VECTOR_INDEXES."""
+    monkeypatch.setenv("RX_GPU_VECTOR_INDEXES", "0,0")
+    m = hostapi.GpuHnswMap(1, 16, 500, devices=[])
+    assert m.shard_count == 2
+    m.close()
+    monkeypatch.setenv("RX_GPU_VECTOR_INDEXES", "0")
+    m = hostapi.GpuHnswMap(1, 16, 500, devices=[])
+    assert m.shard_count == 0
+    m.close()
+
+
+def test_what_a_device_list_does_not_offer_says_so(hostapi):
+    m = hostapi.GpuHnswMap(1, 16, 500, devices=[0, 0])
+    m.add(make_corpus(1, 100, 16), np.arange(100, dtype=np.uint64) << np.uint64(32))
+    with pytest.raises(Exception, match="device list"):
+        m.quantize(-1.0, 1.0)
+    with pytest.raises(Exception, match="device list"):
+        m.stream(np.zeros(16, np.float32), 16)
+    with pytest.raises(Exception, match="device list"):
+        m.save_index()
+    m.close()

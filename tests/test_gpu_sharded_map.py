@@ -208,3 +208,29 @@ def test_shards_filled_in_place_from_device_memory(rxgpu):
         bd, br, bc = sx.search_knn(q, 11)
         assert np.array_equal(br, ar) and np.array_equal(bits(bd), bits(ad))
         del parts
+
+
+def test_in_tree_constructor_shape_takes_its_device_list_from_the_environment(hostapi, oracle, monkeypatch):
+    """§8(e) "Host topology" through the seam: the reference constructs `Map(metric, dim, maxElements)` (hnsw_index.cc:61-66) and the in-tree
+    adapter (rx_seam.h GpuBruteforceMapInTree) reads the device list from RX_GPU_VECTOR_INDEXES.  "0,0,0" builds the three-shard Map — the path
+    an 8-GPU node takes with "0-7" — and must answer like the single-device Map and the reference engine."""
+    n, d = 3000, 32
+    rows = make_corpus(77, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    monkeypatch.setenv("RX_GPU_VECTOR_INDEXES", "0,0,0")
+    many = hostapi.GpuBruteforceMap.from_env(1, d, n)
+    monkeypatch.setenv("RX_GPU_VECTOR_INDEXES", "0")
+    one = hostapi.GpuBruteforceMap.from_env(1, d, n)
+    monkeypatch.delenv("RX_GPU_VECTOR_INDEXES")
+    dflt = hostapi.GpuBruteforceMap.from_env(1, d, n)
+    assert many.sharded and not one.sharded and not dflt.sharded
+    for m in (one, many, dflt):
+        m.add(rows, labels)
+    for qi in range(8):
+        q = make_corpus(500 + qi, 1, d)[0]
+        wd, wl = oracle.bf_search_knn(1, rows, labels, None, q, 10)
+        for m in (one, many, dflt):
+            gd, gl = m.search_knn(q, 10)
+            assert np.array_equal(gl, wl) and np.array_equal(bits(gd), bits(wd))
+    for m in (one, many, dflt):
+        m.close()

@@ -87,6 +87,11 @@ def test_gpu_maps_instantiate_hnsw_index_base_against_reference_headers(tmp_path
                      "rxgpu::host::GpuHnswMapT<(hnswlib::Synchronization)1>"):
         for member in ("select(", "selectRaw(", "upsert(", "del(", "beginStreaming(", "continueStreaming(", "Clone(", "GetMemStat(", "GrowFor("):
             assert f"reindexer::HnswIndexBase<{map_type}>::{member}" in syms, (map_type, member)
+    # the brute-force Map the reference's factory constructs takes a DEVICE LIST (RX_GPU_VECTOR_INDEXES, device_list.h): the only constructor
+    # the patched translation unit references is the std::vector<int> one -> rxgpu_index_create_sharded on a multi-GPU node (§8e / configs[3])
+    usyms = subprocess.run(["nm", "-C", "-u", str(tmp_path / "hnsw_index.o")], capture_output=True, text=True, check=True).stdout
+    assert "rxgpu::host::GpuBruteforceMap::GpuBruteforceMap(reindexer::VectorMetric, unsigned long, unsigned long, std::vector<int" in usyms
+    assert "rxgpu::host::GpuBruteforceMap::GpuBruteforceMap(reindexer::VectorMetric, unsigned long, unsigned long, int)" not in usyms
     # what the Maps themselves export with the reference's types in their signatures
     msyms = subprocess.run(["nm", "-C", "--defined-only", str(tmp_path / "gpu_bruteforce_map.o")], capture_output=True, text=True, check=True).stdout
     assert "rxgpu::host::GpuBruteforceMap::AddPointNoLock(reindexer::ConstFloatVectorView, reindexer::FloatVectorId)" in msyms
