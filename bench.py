@@ -85,14 +85,19 @@ def parse_args():
     ap.add_argument("--parity-deadline", type=float, default=150.0, help="no further per-metric reference index is built once the CPU leg "
                                                                           "has run this many seconds")
     ap.add_argument("--cpu-deadline", type=float, default=40.0, help="all-core CPU leg: threads stop STARTING searches after this many seconds")
-    ap.add_argument("--scaling", default=os.environ.get("RXGPU_BENCH_SCALING", "weak"), choices=["weak", "strong"])
+    ap.add_argument("--scaling", default=os.environ.get("RXGPU_BENCH_SCALING"), choices=["weak", "strong"],
+                    help="default: weak at N = 1 (BASELINE configs[1], 10M rows); STRONG at N > 1 — BASELINE configs[3]: the 80M-row corpus FIXED and "
+                         "split over the ranks, value = queries/s over that whole corpus")
     ap.add_argument("--total-rows", type=int, default=80_000_000, help="--scaling strong: the fixed corpus, split over the ranks")
-    ap.add_argument("--hnsw-rows", type=int, default=1_000_000, help="hnsw leg: graph size (0 = skip)")
+    ap.add_argument("--hnsw-rows", type=int, default=10_000_000, help="hnsw leg: graph size — BASELINE configs[2] at its true size when the time budget "
+                                                                      "allows the host build, else --hnsw-fallback-rows (0 = skip)")
+    ap.add_argument("--hnsw-fallback-rows", type=int, default=1_000_000)
     ap.add_argument("--hnsw-queries", type=int, default=16384)
     ap.add_argument("--hybrid-docs", type=int, default=5_000_000, help="hybrid leg: documents = vectors (0 = skip)")
     ap.add_argument("--ft-packed-words", type=int, default=100_000, help="ft_packed leg: dictionary words whose PackedIdRelVec streams are decoded "
                                                                          "on the device (0 = skip)")
-    ap.add_argument("--time-budget", type=float, default=330.0, help="seconds of wall clock after which remaining extra legs are skipped")
+    ap.add_argument("--time-budget", type=float, default=1350.0, help="seconds of wall clock after which remaining extra legs are skipped "
+                                                                      "(the 10M-row HNSW host build alone takes 6 - 9 minutes; without it the run takes ~3)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline / parity leg")
     ap.add_argument("--batch", type=int, default=256, help="extra leg (N=1, untimed region): batched queries on the MFMA path; 0 = skip")
     ap.add_argument("--batch-iters", type=int, default=3)
@@ -500,6 +505,8 @@ def main_in_process(args, t_start: float) -> None:
     kk = args.k + 1
     devices = [g for g in range(args.gpus) for _ in range(args.shards_per_gpu)]
     nshards = len(devices)
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     strong = args.scaling == "strong"
     rows = args.total_rows // nshards if strong else args.rows // args.shards_per_gpu
     rows -= rows % 32   # shard_rows are whole bitmap words
@@ -547,7 +554,7 @@ def main_in_process(args, t_start: float) -> None:
     avg_scan_s = sum(ms for _, ms in per_shard) / 1e3 / max(launches, 1)
     achieved = algo_bytes / avg_scan_s / 1e9 if launches else 0.0
     result = {
-        "metric": "knn_queries_per_sec", "value": qps if strong else qps * args.gpus, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps,
+        "metric": "knn_queries_per_sec", "value": qps, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
@@ -556,7 +563,8 @@ def main_in_process(args, t_start: float) -> None:
             "rows_per_shard": rows, "total_rows": rows * nshards, "dim": args.dim, "k": args.k, "batch": 1,
             "sharding": "rxgpu_index_create_sharded: per-shard scans, ncclAllGather of kk x 8 B per shard inside librxgpu.so, merge kernel on device 0",
             "merge_mode": sx.merge_mode, "rccl_ranks": sx.ranks, "collectives_in_timed_region": collectives,
-            "merged_equals_per_shard_lists": bool(merged_ok), "qps_over_full_corpus": qps, "arch": capi.device_arch(0),
+            "merged_equals_per_shard_lists": bool(merged_ok), "qps_over_full_corpus": qps, "shard_scans_per_sec": qps * nshards,
+            "arch": capi.device_arch(0),
             "host_boundary": "queries enter as host pointers (3 KB H2D per step) and the merged list leaves by one D2H copy (88 B): both inside the timed region",
         },
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -567,6 +575,50 @@ def main_in_process(args, t_start: float) -> None:
     emit(result, args)
     sx.close()
     del keep
+
+
+def sharded_in_process_leg(args, ix, corpus, d_inv, queries, device, kk):
+    """BASELINE configs[3]'s code path on this one GPU (a driver SCALE run needs a multi-GPU node): the SAME resident corpus as two row-range
+    shards of one rxgpu_index_create_sharded handle — what the C++ Map builds from RX_GPU_VECTOR_INDEXES=0,0 — each step = host query in ->
+    both shards' scans -> ONE ncclAllGather of kk x 8 B per shard inside librxgpu.so (RCCL communicator of the index) -> knn_merge_shards ->
+    one D2H copy.  Asserted: merge mode 1 (device exchange), collectives == steps, and ids + distance bits identical to the unsharded index."""
+    n = args.rows
+    half = n // 2
+    if n % 64:
+        return {"skipped": "rows not a multiple of 64"}
+    metric_id = capi.METRICS[args.metric]
+    sx = capi.ShardedVectorIndex(metric_id, args.dim, n, [device.index, device.index])
+    try:
+        assert sx.shard_rows == half, (sx.shard_rows, half)
+        esz = 4
+        for s in range(2):
+            sx.shard(s).adopt_device_rows(corpus.data_ptr() + s * half * args.dim * esz, half, args.dim,
+                                          d_inv.data_ptr() + s * half * esz if d_inv is not None else None)
+        sx.sync_count()
+        steps = max(8, min(args.steps, 32))
+        hq = queries[:steps + 2].cpu().numpy()
+        for i in range(2):
+            sx.search_knn(hq[i:i + 1], kk)
+        c0 = sx.collectives
+        got = []
+        t0 = time.perf_counter()
+        for i in range(2, steps + 2):
+            got.append(sx.search_knn(hq[i:i + 1], kk))
+        elapsed = time.perf_counter() - t0
+        collectives = sx.collectives - c0
+        same = 0
+        for i, (d1, r1, c1) in enumerate(got):
+            d0, r0, c0_ = ix.search_knn(hq[i + 2:i + 3], kk)
+            same += int(np.array_equal(r0, r1) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and np.array_equal(c0_, c1))
+        return {"workload": f"the headline corpus ({n} x {args.dim}) as 2 row-range shards on device {device.index}, batch = 1, host query in / merged list out",
+                "shards": 2, "shard_merge_mode": 1 if sx.merge_mode == "rccl" else 0, "merge_note": sx.merge_note, "rccl_ranks": sx.ranks,
+                "steps": steps, "collectives": collectives, "collectives_equal_steps": collectives == steps,
+                "identical": same == steps and sx.merge_mode == "rccl" and collectives == steps, "identical_queries": same,
+                "ms_per_query": elapsed / steps * 1e3, "queries_per_sec": steps / elapsed,
+                "note": "both shards share one GPU here, so the scans run back to back: the figure prices the fan-out + RCCL + merge + copies around "
+                        "one full scan, not a speedup"}
+    finally:
+        sx.close()
 
 
 def main():
@@ -594,6 +646,8 @@ def main():
 
     metric_id = capi.METRICS[args.metric]
     kk = args.k + 1  # the Map asks for k+1 to detect a distance tie straddling the k-th boundary
+    if args.scaling is None:   # N > 1 is BASELINE configs[3]: the 80M corpus fixed, value = queries/s over ALL of it
+        args.scaling = "strong" if world > 1 else "weak"
     strong = args.scaling == "strong"
     if strong:   # BASELINE configs[3]: the corpus is FIXED (80M rows) and split into row ranges, one per rank
         if args.total_rows % world:
@@ -648,8 +702,24 @@ def main():
     ix.profile_enable(False)
 
     qps_global = args.steps / elapsed            # queries/s over the whole (N x rows) corpus
-    # weak: aggregate in rows-per-GPU-shard scans/s (== queries/s at N = 1); strong: queries/s over the fixed corpus
-    value = qps_global if strong else qps_global * world
+    # N > 1: value = queries/s over the WHOLE corpus (every query scans every shard) in either mode — the metric's unit; the aggregate of
+    # shard scans (rows_per_gpu-row scans/s, what "weak" used to report as value) is a side field.  N = 1: the two coincide.
+    value = qps_global
+    one_gpu = None
+    if world > 1:
+        # The same bytes on ONE GPU, measured here: rank 0 scans its shard `world` times back to back per query (what a single GPU holding the
+        # whole corpus does: HBM-bound, rows x world x dim x 4 bytes; the shard is 100x the caches, nothing is reused) -> queries/s of one GPU
+        # over a corpus of the full size, the denominator of the speedup.
+        reps = max(2, min(8, args.steps))
+        sync()
+        t0 = time.perf_counter()
+        if rank == 0:
+            for i in range(reps):
+                for _ in range(world):
+                    ix.search_knn_device(queries.data_ptr() + i * args.dim * esz, 1, kk, out_dist.data_ptr() + i * kk * esz,
+                                         out_row.data_ptr() + i * kk * esz, None, stream.cuda_stream)
+        sync()
+        one_gpu = reps / (time.perf_counter() - t0)
     algo_bytes = args.rows * args.dim * 4        # N*D*4 per query (labels/norms excluded)
     avg_scan_s = (scan_ms / 1e3) / max(launches, 1)
     achieved = algo_bytes / avg_scan_s / 1e9 if launches else 0.0
@@ -671,9 +741,12 @@ def main():
                 "rows_per_gpu": args.rows, "total_rows": args.rows * world, "dim": args.dim, "k": args.k, "batch": 1,
                 "sharding": "row-range shards, RCCL all-gather of per-shard top-k + merge" if dist_on else "none",
                 "rccl_ranks": (dist.get_world_size() if dist_on else 0),
-                "value_definition": ("queries/s over the fixed corpus" if strong else
-                                     "queries/s over the full corpus x n_gpus (each query scans one rows_per_gpu shard per GPU)"),
-                "qps_over_full_corpus": qps_global, "arch": capi.device_arch(local_rank),
+                "value_definition": "queries/s over the whole corpus (total_rows): every query scans every shard",
+                "qps_over_full_corpus": qps_global, "shard_scans_per_sec": qps_global * world,
+                "one_gpu_same_bytes_qps": one_gpu, "speedup_vs_one_gpu": (qps_global / one_gpu if one_gpu else None),
+                "one_gpu_note": ("rank 0 scanning its shard n_gpus times per query, measured in this run: what one GPU needs for the same corpus bytes"
+                                 if one_gpu else None),
+                "arch": capi.device_arch(local_rank),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None,
@@ -698,6 +771,8 @@ def main():
             return out
 
         extra = world == 1 and not strong
+        if extra:
+            result["sharded_in_process"] = leg("sharded_in_process", 5, lambda: sharded_in_process_leg(args, ix, corpus, d_inv, queries, device, kk))
         if extra and args.batch > 1:
             result["batched"] = leg("batched", 5, lambda: batched_leg(args, ix, queries, device, kk))
             result["pruned_scan"] = leg("pruned_scan", 5, lambda: pruned_leg(args, ix, queries, device, kk))
@@ -709,21 +784,35 @@ def main():
             else:
                 result["cpu_baseline"] = {"value": None, **out}
         if extra and (args.hnsw_rows or args.hybrid_docs):
+            d_inv = None
             # the other configs need the HBM the headline corpus holds only partly, but host RAM and time are shared: release first
             ix.close()
             ix = None
             corpus = None
             torch.cuda.empty_cache()
-        if extra and args.hnsw_rows:
-            import bench_hnsw
-            need = 25 + 130 * args.hnsw_rows / 1e6
-            result["hnsw"] = leg("hnsw", need, lambda: bench_hnsw.run(dict(rows=args.hnsw_rows, queries=args.hnsw_queries, device=local_rank)))
         if extra and args.hybrid_docs:
             import bench_hybrid
             result["hybrid"] = leg("hybrid", 20 + 14 * args.hybrid_docs / 1e6, lambda: bench_hybrid.run(dict(docs=args.hybrid_docs, device=local_rank)))
         if extra and args.ft_packed_words:
             import bench_ft_packed
             result["ft_packed"] = leg("ft_packed", 15, lambda: bench_ft_packed.run(dict(words=args.ft_packed_words)))
+        if extra and args.hnsw_rows:   # last: at its true size (BASELINE configs[2], 10M x 768) the host build alone takes minutes
+            import bench_hnsw
+            from cpu_scaling import effective_cpus
+            threads = 2 * effective_cpus()
+
+            def need_s(rows):   # host build (measured: 20.6 k inserts/s from 16 threads, 25.8 k from 32, at 768 dims) + corpus, mirrors, reference engine
+                return 40 + rows / (1290.0 * min(threads, 16) + 325.0 * max(0, min(threads, 32) - 16)) * 1.25 + 110 * rows / 1e7
+
+            rows = args.hnsw_rows
+            picked = None
+            if budget_left() < need_s(rows) and args.hnsw_fallback_rows and args.hnsw_fallback_rows < rows:
+                picked = (f"{rows} rows need ~{need_s(rows):.0f} s of the {budget_left():.0f} s left (--time-budget): "
+                          f"configs[2] scaled to {args.hnsw_fallback_rows} rows instead")
+                rows = args.hnsw_fallback_rows
+            result["hnsw"] = leg("hnsw", need_s(rows), lambda: bench_hnsw.run(dict(rows=rows, queries=args.hnsw_queries, device=local_rank)))
+            if picked and isinstance(result["hnsw"], dict):
+                result["hnsw"]["size_fallback"] = picked
         result["bench_wall_seconds"] = time.perf_counter() - t_start
         emit(result, args)
     if ix is not None:

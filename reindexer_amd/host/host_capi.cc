@@ -518,6 +518,46 @@ long rxhost_hnsw_search_knn(void* h, const float* q, size_t k, size_t ef, float*
 	});
 	return n;
 }
+// The reference's concurrency model on the GPU Map (SURVEY 8b "Threading", 8d): T planner threads, each running its own SearchKnn with ONE
+// query over the shared Map (cf. runMultithreadQueries, gtests/tests/unit/float_vector_index.cc:258-294) — native threads, started outside the
+// timed region; a thread stops STARTING searches once deadlineS has passed.  Thread t searches queries[(t * perThread + j) % nq].
+int rxhost_hnsw_search_knn_mt(void* h, const float* queries, size_t nq, size_t dim, size_t k, size_t ef, unsigned threads, size_t perThread,
+							  double deadlineS, double* outSeconds, size_t* outDone, size_t* outBatches) {
+	return guarded([&] {
+		const auto* m = static_cast<const GpuHnswMap*>(h);
+		std::atomic<int> gate{0};
+		std::atomic<size_t> done{0}, ready{0};
+		std::mutex errMtx;
+		std::string error;
+		std::chrono::steady_clock::time_point t0;
+		auto worker = [&](unsigned t) {
+			ready.fetch_add(1);
+			while (!gate.load(std::memory_order_acquire)) std::this_thread::yield();
+			try {
+				for (size_t j = 0; j < perThread; ++j) {
+					if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadlineS) break;
+					auto res = m->SearchKnn(queries + ((size_t(t) * perThread + j) % nq) * dim, std::nullopt, k, ef);
+					if (res.empty()) throw std::logic_error("empty SearchKnn result");
+					done.fetch_add(1, std::memory_order_relaxed);
+				}
+			} catch (const std::exception& e) {
+				std::lock_guard<std::mutex> lk(errMtx);
+				if (error.empty()) error = e.what();
+			}
+		};
+		const size_t b0 = m->CoalescedBatches();
+		std::vector<std::thread> pool;
+		for (unsigned t = 0; t < std::max(1u, threads); ++t) pool.emplace_back(worker, t);
+		while (ready.load() < pool.size()) std::this_thread::yield();
+		t0 = std::chrono::steady_clock::now();
+		gate.store(1, std::memory_order_release);
+		for (auto& th : pool) th.join();
+		*outSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		*outDone = done.load();
+		if (outBatches) *outBatches = m->CoalescedBatches() - b0;
+		if (!error.empty()) throw std::logic_error(error);
+	});
+}
 // the quantised Map: Quantize(minQ, maxQ), SearchKnn with query_data_norm (hnsw_index.cc:168: normL2 = 1.f / NormalizeCopyVector(...))
 int rxhost_hnsw_quantize(void* h, float minQ, float maxQ) {
 	return guarded([&] { static_cast<GpuHnswMap*>(h)->Quantize(minQ, maxQ); });

@@ -652,6 +652,19 @@ class GpuHnswMap:
             _raise()
         return od[:n].copy(), ol[:n].copy()
 
+    def search_knn_mt(self, queries, k: int, ef: int, threads: int, per_thread: int, deadline_s: float = 30.0):
+        """T native planner threads, one query per SearchKnn call each, over this shared Map (the reference's concurrency model).
+        -> (seconds, searches completed, device batches the coalescer ran)."""
+        L = lib()
+        L.rxhost_hnsw_search_knn_mt.argtypes = [_vp, _vp, _sz, _sz, _sz, _sz, C.c_uint, _sz, C.c_double, _vp, _vp, _vp]
+        q = _f32(queries).reshape(-1, self.dim)
+        secs, done, batches = C.c_double(0.0), C.c_size_t(0), C.c_size_t(0)
+        rc = L.rxhost_hnsw_search_knn_mt(self.h, q.ctypes.data, q.shape[0], self.dim, k, ef, threads, per_thread, float(deadline_s),
+                                         C.addressof(secs), C.addressof(done), C.addressof(batches))
+        if rc:
+            _raise(rc)
+        return float(secs.value), int(done.value), int(batches.value)
+
     def quantize(self, min_q: float, max_q: float) -> None:
         """Quantize: from here on searches run over SQ8 codes on the device (HierarchicalNSWImpl<uint8_t>)."""
         rc = lib().rxhost_hnsw_quantize(self.h, float(min_q), float(max_q))
