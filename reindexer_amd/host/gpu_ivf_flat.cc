@@ -41,6 +41,29 @@ GpuIvfFlat::GpuIvfFlat(VectorMetric metric, size_t dim, size_t nlist, int device
 	}
 }
 
+GpuIvfFlat::GpuIvfFlat(const GpuIvfFlat& o, int device)
+	: metric_(o.metric_), dim_(o.dim_), nlist_(o.nlist_), device_(device), trained_(o.trained_), count_(o.count_), rows_(o.rows_), invNorms_(o.invNorms_),
+	  ids_(o.ids_), listOf_(o.listOf_), idToRow_(o.idToRow_), lists_(o.lists_), scan_(o.scan_), scanPos_(o.scanPos_), centroids_(o.centroids_) {
+	if (rxgpu_index_create(int(metric_), uint32_t(dim_), std::max<size_t>(count_, 1), device_, &dev_) != RXGPU_OK) throwDevice("GpuIvfFlat: device index creation failed");
+	capacity_ = std::max<size_t>(count_, 1);
+	if (rxgpu_index_create(int(metric_), uint32_t(dim_), nlist_, device_, &devCentroids_) != RXGPU_OK) {
+		rxgpu_index_destroy(dev_);
+		dev_ = nullptr;
+		throwDevice("GpuIvfFlat: centroid index creation failed");
+	}
+	if (count_ && rxgpu_index_upload_rows(dev_, 0, count_, rows_.data(), metric_ == VectorMetric::Cosine ? invNorms_.data() : nullptr) != RXGPU_OK) {
+		throwDevice("GpuIvfFlat: row upload failed");
+	}
+	if (trained_) uploadCentroids();
+	listsDirty_ = true;
+}
+
+const float* GpuIvfFlat::VectorById(idx_t id) const {
+	const auto it = idToRow_.find(id);
+	if (it == idToRow_.end()) throw std::runtime_error("GpuIvfFlat: id not found");
+	return rows_.data() + size_t(it->second) * dim_;
+}
+
 GpuIvfFlat::~GpuIvfFlat() {
 	if (dev_) rxgpu_index_destroy(dev_);
 	if (devCentroids_) rxgpu_index_destroy(devCentroids_);

@@ -50,6 +50,9 @@ public:
 	using idx_t = int64_t;   // faiss::idx_t
 
 	GpuIvfFlat(VectorMetric metric, size_t dim, size_t nlist, int device = 0);
+	// a copy with a device mirror of its own (IvfIndex's copy-on-write clone, ivf_index.cc:72-79: faiss::clone_index): vectors, ids, centroids
+	// and inverted lists as they are — nothing is re-trained or re-assigned
+	GpuIvfFlat(const GpuIvfFlat& other, int device);
 	~GpuIvfFlat();
 	GpuIvfFlat(const GpuIvfFlat&) = delete;
 	GpuIvfFlat& operator=(const GpuIvfFlat&) = delete;
@@ -60,7 +63,10 @@ public:
 	size_t NTotal() const noexcept { return count_; }
 	size_t NList() const noexcept { return nlist_; }
 	size_t Dim() const noexcept { return dim_; }
+	int Device() const noexcept { return device_; }
 	VectorMetric Metric() const noexcept { return metric_; }
+	// the stored vector of an id (IvfIndex::reconstruct / getFloatVectorViewImpl, ivf_index.cc:455-467, 489-497); throws when absent
+	const float* VectorById(idx_t id) const;
 	size_t ListSize(size_t list) const { return lists_.at(list).size(); }
 	// the ids held by an inverted list, in row order (tests: compared with faiss::InvertedLists::get_ids)
 	void ListIds(size_t list, idx_t* out) const {

@@ -134,7 +134,60 @@ def test_gpu_ft_merger_branch_compiles_inside_selecter_and_indextext(tmp_path):
 
 
 @pytest.mark.skipif(not REF.exists(), reason="needs the reference tree (/root/reference)")
+def test_gpu_ivf_branch_compiles_inside_ivf_index(tmp_path):
+    """SURVEY §8f-3 bound into the reference: with integration/patches/0004 applied, the reference's ivf_index.cc — IvfIndex::upsert / del /
+    select / selectRaw / reconstruct / getFloatVectorViewImpl / RebuildCentroids / the cache hooks (:88-141, 143-425, 455-497, 625-678) —
+    compiles with the GPU branch: its own search helpers (templates over `map`) instantiated over rxgpu::host::GpuIvfInTree (rx_ivf_seam.h:
+    faiss::Index's search / range_search signatures on top of GpuIvfFlat), against the reference's vendored FAISS headers; gpu_ivf_flat.cc
+    compiles beside it with the core's flags."""
+    tree = _patched_tree(tmp_path)
+    patched = tree / "cpp_src/core/index/float_vector/ivf_index.cc"
+    assert "gpu_->Upsert" in patched.read_text() and "rx_ivf_seam.h" in (tree / "cpp_src/core/index/float_vector/ivf_index.h").read_text()
+    flags = [f"-I{tree}/cpp_src", f"-I{tree}/cpp_src/core/index/float_vector"] + FLAGS + ["-DRX_WITH_FAISS_ANN_INDEXES=1"]
+    jobs = {"ivf_index": patched, "gpu_ivf_flat": ROOT / "reindexer_amd" / "host" / "gpu_ivf_flat.cc"}
+
+    def compile_one(item):
+        name, src = item
+        obj = tmp_path / f"{name}.o"
+        return name, obj, subprocess.run(["g++", *flags, "-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        results = list(ex.map(compile_one, jobs.items()))
+    for name, obj, r in results:
+        assert r.returncode == 0, f"{name} does not compile inside cpp_src:\n{r.stderr[-4000:]}"
+    defined = subprocess.run(["nm", "-C", "--defined-only", str(tmp_path / "ivf_index.o")], capture_output=True, text=True, check=True).stdout
+    for member in ("upsert(", "del(", "select(", "selectRaw(", "RebuildCentroids(", "getFloatVectorViewImpl(", "WriteIndexCache(", "LoadIndexCache("):
+        assert f"reindexer::IvfIndex::{member}" in defined, member
+    # the reference's own search helpers instantiated over the GPU adapter (std::unique_ptr<GpuIvfInTree> as `map`)
+    assert "rxgpu::host::GpuIvfInTree" in defined
+    undefined = subprocess.run(["nm", "-C", "-u", str(tmp_path / "ivf_index.o")], capture_output=True, text=True, check=True).stdout
+    for sym in ("rxgpu::host::GpuIvfFlat::AddWithIds(", "rxgpu::host::GpuIvfFlat::Train(", "rxgpu::host::GpuIvfFlat::RemoveIds(",
+                "rxgpu::host::GpuIvfFlat::Search(", "rxgpu::host::GpuIvfFlat::RangeSearch(", "rxgpu::host::GpuIvfFlat::VectorById("):
+        assert sym in undefined, sym
+
+
+@pytest.mark.skipif(not REF.exists(), reason="needs the reference tree (/root/reference)")
+def test_gpu_hybrid_fusion_branch_compiles_inside_selectiteratorcontainer(tmp_path):
+    """SURVEY §8f-1 bound into the reference: with integration/patches/0005 applied, selectiteratorcontainer.cc — SelectIteratorContainer::
+    mergeRanked<desc> (:1454-1559) — compiles with the branch that hands both ranked conditions (KnnRawResult variant, the full-text flat id
+    set + RanksHolder ranks, the Reranker variant through the accessors the patch adds to reranker.h) to rxgpu_hybrid_fuse
+    (rx_hybrid_seam.h FuseRankedOnGpu)."""
+    tree = _patched_tree(tmp_path)
+    patched = tree / "cpp_src/core/nsselecter/selectiteratorcontainer.cc"
+    assert "FuseRankedOnGpu" in patched.read_text() and "RankConst()" in (tree / "cpp_src/core/sorting/reranker.h").read_text()
+    flags = [f"-I{tree}/cpp_src"] + FLAGS + ["-DRX_WITH_FAISS_ANN_INDEXES=1"]
+    obj = tmp_path / "selectiteratorcontainer.o"
+    r = subprocess.run(["g++", *flags, "-c", str(patched), "-o", str(obj)], capture_output=True, text=True)
+    assert r.returncode == 0, f"selectiteratorcontainer.cc does not compile with the GPU fusion branch:\n{r.stderr[-4000:]}"
+    defined = subprocess.run(["nm", "-C", "--defined-only", str(obj)], capture_output=True, text=True, check=True).stdout
+    assert "reindexer::SelectIteratorContainer::MergeRanked(" in defined
+    assert "bool rxgpu::host::FuseRankedOnGpu<" in defined
+    undefined = subprocess.run(["nm", "-u", str(obj)], capture_output=True, text=True, check=True).stdout
+    assert "rxgpu_hybrid_fuse" in undefined
+
+
+@pytest.mark.skipif(not REF.exists(), reason="needs the reference tree (/root/reference)")
 def test_patches_apply_cleanly(tmp_path):
     _patched_tree(tmp_path)
     cm = (tmp_path / "cpp_src/CMakeLists.txt").read_text()
-    assert "WITH_RXGPU" in cm and "RXGPU_IN_TREE" in cm and "gpu_ft_merger.cc" in cm
+    assert "WITH_RXGPU" in cm and "RXGPU_IN_TREE" in cm and "gpu_ft_merger.cc" in cm and "gpu_ivf_flat.cc" in cm
