@@ -342,7 +342,12 @@ constexpr int kGlHitCapSplit = 144;
 // (A ring of two was overrun at ld = 64 / 128, where the loaders are 2-3 tiles ahead: ADVICE round 4.)
 constexpr int kGlTermRing = 4;
 
-template <int kMetric, int kMode, int QT, int RB = gl_row_bufs(QT), int QBUFS = gl_query_bufs(QT)>
+// kPipe: the fragment reads of BOTH 16-element halves of a stage are issued in front of the stage's first MFMA (twice the fragment registers),
+// so the second half's ds_reads travel while the first half multiplies.  Without it the compiler reuses the fragment registers and every
+// half-stage is  6 x ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 8 x MFMA : behind the per-stage barrier all eight waves read at once (the LDS needs
+// ~380 cycles to serve them) and then all multiply (2 x 256 cycles per SIMD), twice per stage, nothing overlapping — the MFMA pipe sat idle
+// for the LDS's share: MFMA busy 0.45-0.47 of the cycles (profiles/rd4_gemm_pmc.json), which is 1024 / (1024 + 2 x 380) to the digit.
+template <int kMetric, int kMode, int QT, bool kPipe = true, int RB = gl_row_bufs(QT), int QBUFS = gl_query_bufs(QT)>
 __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params p) {
 	static_assert(RB >= 3 && RB <= 7 && QBUFS >= 2 && QBUFS <= 3, "the vmcnt switches below cover these ring depths");
 	static_assert(2 + (RB - 2) / 2 <= kGlTermRing, "term ring shorter than the row loaders' lead in tiles at two stages per tile");
@@ -499,18 +504,62 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 		rbuf = rbuf + 1 == uint32_t(RB) ? 0u : rbuf + 1;
 		qbuf = qbuf + 1 == uint32_t(QBUFS) ? 0u : qbuf + 1;
 		if (p.blocked & 2u) __builtin_amdgcn_s_setprio(1);   // RXGPU_GEMM_PRIO=1 (A/B): the stage's fragment reads and MFMAs ahead of the other wave's epilogue / DMA issue
+		if constexpr (kPipe) {
+			// Reads and waits are written out: with an LDS-DMA in flight (always, here) the compiler's wait-count pass treats the LGKM counter
+			// as out of order and puts s_waitcnt lgkmcnt(0) in front of the first MFMA whatever the order of the reads (global_load_lds is a
+			// FLAT-encoded instruction that "may access LDS").  ds_read returns are in order among themselves: with 2 x (2 + QB) reads issued,
+			// lgkmcnt(2 + QB) means the first half's fragments are there (a scalar load the compiler slipped in can only make that wait longer).
+			u32x4 bfr[2][2], afr[2][QB];
+			const uint32_t xbase = uint32_t(size_t((lds_void*)(xb + xrow * 32)));
+			const uint32_t qbase = uint32_t(size_t((lds_void*)(qb + qrow * 32)));
 #pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			const uint32_t cs = ((2 * t + half) ^ swz) << 3;
-			bf16x8 bfrag[2], afrag[QB];
+			for (int t = 0; t < 2; ++t) {
+				const uint32_t cs = (((2 * t + half) ^ swz) << 3) * 2;   // byte offset of the 16-byte chunk inside the row's 64-byte stage
+				const uint32_t xa = xbase + cs, qa = qbase + cs;
 #pragma unroll
-			for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + (xrow + 32 * a) * 32 + cs));
+				for (int a = 0; a < 2; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[t][a]) : "v"(xa), "n"(32 * 64 * a) : "memory");
 #pragma unroll
-			for (int b = 0; b < QB; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (qrow + 32 * b) * 32 + cs));
+				for (int b = 0; b < QB; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[t][b]) : "v"(qa), "n"(32 * 64 * b) : "memory");
+			}
+			if constexpr (QB == 4) {
+				asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[0][2]), "+v"(afr[0][3])::"memory");
+			} else {
+				asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(afr[0][0]), "+v"(afr[0][1])::"memory");
+			}
 #pragma unroll
 			for (int a = 0; a < 2; ++a) {
 #pragma unroll
-				for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
+				for (int b = 0; b < QB; ++b) {
+					acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[0][b]), __builtin_bit_cast(bf16x8, bfr[0][a]), acc[a][b], 0, 0, 0);
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);   // the first half's MFMAs stay in front of the second wait
+			if constexpr (QB == 4) {
+				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(afr[1][0]), "+v"(afr[1][1]), "+v"(afr[1][2]), "+v"(afr[1][3])::"memory");
+			} else {
+				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(afr[1][0]), "+v"(afr[1][1])::"memory");
+			}
+#pragma unroll
+			for (int a = 0; a < 2; ++a) {
+#pragma unroll
+				for (int b = 0; b < QB; ++b) {
+					acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[1][b]), __builtin_bit_cast(bf16x8, bfr[1][a]), acc[a][b], 0, 0, 0);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int t = 0; t < 2; ++t) {
+				const uint32_t cs = ((2 * t + half) ^ swz) << 3;
+				bf16x8 bfrag[2], afrag[QB];
+#pragma unroll
+				for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + (xrow + 32 * a) * 32 + cs));
+#pragma unroll
+				for (int b = 0; b < QB; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (qrow + 32 * b) * 32 + cs));
+#pragma unroll
+				for (int a = 0; a < 2; ++a) {
+#pragma unroll
+					for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
+				}
 			}
 		}
 		if (p.blocked & 2u) __builtin_amdgcn_s_setprio(0);
@@ -625,15 +674,31 @@ static bool gemm_split_rings() {
 	return e ? std::atoi(e) != 0 : true;
 }
 
+// RXGPU_GEMM_PIPE=0: the stage without the software pipeline (A/B)
+static bool gemm_pipe() {
+	const char* e = std::getenv("RXGPU_GEMM_PIPE");
+	return e ? std::atoi(e) != 0 : true;
+}
+
 template <int kMetric, int kMode, int QT>
 static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
 	if (gemm_split_rings()) {
 		const size_t lds = gemm_bf16_split_lds_bytes(QT, gl_row_bufs(QT), gl_query_bufs(QT));
+		if constexpr (kMode == kGemmFilter) {   // (the dense form runs over the 32 K-row sample only; its L2 epilogue would spill beside the second fragment set)
+		if (gemm_pipe()) {
+			static std::atomic<uint64_t> raised_pipe{0};
+			if (hipError_t e = raise_dynamic_lds_once(raised_pipe, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT, true>), lds); e != hipSuccess) {
+				return e;
+			}
+			hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT, true>), dim3(grid), dim3(kBfThreads), lds, s, p);
+			return hipGetLastError();
+		}
+		}
 		static std::atomic<uint64_t> raised_split{0};
-		if (hipError_t e = raise_dynamic_lds_once(raised_split, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT>), lds); e != hipSuccess) {
+		if (hipError_t e = raise_dynamic_lds_once(raised_split, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT, false>), lds); e != hipSuccess) {
 			return e;
 		}
-		hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT>), dim3(grid), dim3(kBfThreads), lds, s, p);
+		hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT, false>), dim3(grid), dim3(kBfThreads), lds, s, p);
 		return hipGetLastError();
 	}
 	const size_t lds = gemm_bf16_glds_lds_bytes(QT);

@@ -489,11 +489,15 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 		std::unique_lock<std::mutex> lk(coMtx_);
 		coQueue_.push_back(&p);
 		while (!p.done) {
-			if (coLeader_) {
+			// Up to kMaxLeaders batches in flight at once (round 5; it was one).  A search is a chain of ~140 dependent hops on ONE wavefront:
+			// a batch of 8 takes as long as a batch of 1 and leaves the chip empty, so with a single leader T planner threads saw
+			// T / (2 x latency) — 4.7 k q/s from 16 threads at 10M x 768 against 13.7 k for the reference's 16 cores.  Every leader's call has a
+			// stream and buffers of its own inside the library (the C-ABI is re-entrant), so the batches overlap on the device.
+			if (coLeaders_ >= kMaxLeaders || coQueue_.empty()) {
 				coCv_.wait(lk);
 				continue;
 			}
-			coLeader_ = true;   // device idle: serve the queue head and everything queued with the same (k, ef)
+			++coLeaders_;   // a free lane: serve the queue head and everything queued with the same (k, ef) — this thread's own query possibly later
 			std::vector<PendingQuery*> batch;
 			const uint32_t bk = coQueue_.front()->k, bef = coQueue_.front()->ef;
 			for (auto it = coQueue_.begin(); it != coQueue_.end() && batch.size() < 4096;) {
@@ -526,7 +530,7 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 					}
 				}
 				if (rc != RXGPU_OK) error = rxgpu_last_error();
-			} catch (const std::exception& e) {   // e.g. bad_alloc while staging: every caller of the batch gets the error, leadership is released
+			} catch (const std::exception& e) {   // e.g. bad_alloc while staging: every caller of the batch gets the error, the lane is released
 				rc = RXGPU_ERR_NOMEM;
 				error = e.what();
 			}
@@ -537,7 +541,7 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 				q->done = true;
 			}
 			++coBatches_;
-			coLeader_ = false;
+			--coLeaders_;
 			coCv_.notify_all();
 		}
 	}

@@ -187,7 +187,8 @@ private:
 	mutable std::mutex coMtx_;
 	mutable std::condition_variable coCv_;
 	mutable std::deque<PendingQuery*> coQueue_;
-	mutable bool coLeader_ = false;
+	static constexpr unsigned kMaxLeaders = 8;   // device batches of the coalescer in flight at once
+	mutable unsigned coLeaders_ = 0;
 	mutable size_t coBatches_ = 0;
 	bool ownsDev_ = true;                 // false: a shard (the device index belongs to the sharded handle) or the Map over a device list itself
 	std::unique_ptr<ShardedState> sh_;    // non-null: the Map over a device list

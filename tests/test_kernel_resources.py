@@ -38,7 +38,7 @@ def resource_usage(src: Path, tmp: Path) -> dict:
 def test_bf16_gemm_instantiations_do_not_spill(tmp_path):
     usage = resource_usage(CSRC / "knn_batched_bf16.hip", tmp_path)
     gemms = {k: v for k, v in usage.items() if "knn_gemm_bf16_glds" in k or "knn_gemm_bf16_split" in k}
-    assert len(gemms) == 24, sorted(gemms)   # (single ring + split rings) x 3 metrics x 2 modes x 2 query-tile widths
+    assert len(gemms) == 30, sorted(gemms)   # (single ring + split rings) x 3 metrics x 2 modes x 2 query-tile widths + the software-pipelined filter form x 3 x 2
     for name, u in gemms.items():
         assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (name, u)
         assert u["VGPRs"] <= 256, (name, u)
