@@ -90,6 +90,11 @@ _SIGNATURES = {
     "rxgpu_hnsw_stream_continue": (_i, [_vp, _u32, _vp, _vp, C.POINTER(_u32), C.POINTER(_i)]),
     "rxgpu_hnsw_stream_end": (None, [_vp]),
     "rxgpu_ft_create": (_i, [_u32, _i, C.POINTER(_vp)]),
+    "rxgpu_ft_create_sharded": (_i, [_u32, _u32, _vp, C.POINTER(_vp)]),
+    "rxgpu_ft_shard_count": (_u32, [_vp]),
+    "rxgpu_ft_shard_exchange_mode": (_i, [_vp]),
+    "rxgpu_ft_shard_collectives": (_u64, [_vp]),
+    "rxgpu_ft_shard_ranges": (_i, [_vp, _u32, _vp, _vp]),
     "rxgpu_ft_destroy": (None, [_vp]),
     "rxgpu_ft_set_docs": (_i, [_vp, _u64, _vp, _vp, _vp]),
     "rxgpu_ft_set_word": (_i, [_vp, _u32, _u64, _vp, _vp, _vp, _vp, _vp]),

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 5) void ft_ranges(const FtPlan* plans) {
 	// atomics alone were ~10 us of this kernel.
 	uint8_t* s_scored = reinterpret_cast<uint8_t*>(s_rep);   // [kFtRangeDocs]
 	static_assert(sizeof(s_rep) >= kFtRangeDocs, "one byte per document fits the counter space");
-	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	const uint32_t tid = threadIdx.x, range = blockIdx.x + p.range_begin;   // (a document-range shard runs its own ranges only)
 	FT_STAMP(p, 0);
 	const uint64_t d_begin = uint64_t(range) * kFtRangeDocs;
 	const uint32_t docs_here = uint32_t(p.total_docs - d_begin < kFtRangeDocs ? p.total_docs - d_begin : kFtRangeDocs);
@@ -593,16 +593,24 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(const FtPlan* plans) {
 	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	if (!ft_preselect_on(p)) return;
 	const uint32_t ticket = grab_ticket(p.sync + kFtSyncPreTicket);
-	const uint64_t w0 = (uint64_t(ticket) * 256 + threadIdx.x) * kFtApplyWords;
+	// a document-range shard walks its own mask words (tickets = document order inside the shard); nwords_end bounds the last workgroup
+	const uint64_t word_begin = uint64_t(p.range_begin) * (kFtRangeDocs / 32);
+	const uint64_t nwords_end = p.range_count ? min(p.nwords, word_begin + uint64_t(p.range_count) * (kFtRangeDocs / 32)) : p.nwords;
+	const uint64_t w0 = word_begin + (uint64_t(ticket) * 256 + threadIdx.x) * kFtApplyWords;
 	uint32_t min_score, min_docs;
 	ft_pick_threshold(p, &min_score, &min_docs);
+	if (p.shard_hist) {   // the ties the shards in front of this one keep at the threshold score (document order = shard order): taken off the quota
+		uint32_t used = 0;
+		for (uint32_t sh = 0; sh < p.shard_index; ++sh) used += p.shard_hist[size_t(p.shard_pos[sh]) * kFtFoldWords + min_score];
+		min_docs = min_docs > used ? min_docs - used : 0u;
+	}
 	uint32_t bits[kFtApplyWords], gt[kFtApplyWords], tie[kFtApplyWords];
 	uint32_t ties = 0;
 #pragma unroll
 	for (int j = 0; j < kFtApplyWords; ++j) {
 		bits[j] = gt[j] = tie[j] = 0;
 		const uint64_t w = w0 + j;
-		if (w >= p.nwords) continue;
+		if (w >= nwords_end) continue;
 		bits[j] = p.mask[w];
 		// the 32 scores of the word as four 16-byte loads (the score array is padded to a whole word); only masked-in documents count
 		const uint4* s4 = reinterpret_cast<const uint4*>(p.score + w * 32);
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(256) void ft_preselect_apply(const FtPlan* plans) {
 	uint32_t allowed = min_docs > excl ? min_docs - excl : 0;
 #pragma unroll
 	for (int j = 0; j < kFtApplyWords; ++j) {
-		if (w0 + j >= p.nwords) continue;
+		if (w0 + j >= nwords_end) continue;
 		uint32_t keep = gt[j], tj = tie[j];
 		while (tj && allowed) {
 			const uint32_t low = tj & (0u - tj);
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(256) void ft_adders(const FtPlan* plans) {
 	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	__shared__ uint32_t s_tab[kFtRangeDocs / 2];   // first row of every document of the range, 16 bits each
 	__shared__ uint32_t s_rowcnt[kFtAdderRowsLds];
-	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	const uint32_t tid = threadIdx.x, range = blockIdx.x + p.range_begin;
 	FT_STAMP(p, 24);
 	if (p.prescore) {   // ft_preselect_apply was the last reader of the histograms and of the look-back words
 		const uint64_t gtid = uint64_t(blockIdx.x) * blockDim.x + tid, gsize = uint64_t(gridDim.x) * blockDim.x;
@@ -1240,7 +1248,7 @@ __global__ __launch_bounds__(256) void ft_finish(const FtPlan* plans) {
 	__shared__ uint32_t s_qp[kFtReplayRows];   // ft_row_qpw
 	__shared__ uint32_t s_nadd, s_last;
 	__shared__ uint32_t s_red[4][kFtFinishRows], s_rowbase[kFtFinishRows];
-	const uint32_t tid = threadIdx.x, range = blockIdx.x;
+	const uint32_t tid = threadIdx.x, range = blockIdx.x + p.range_begin;
 	const bool own_bases = ft_own_bases(p);   // the table is small: every workgroup sums what lies in front of its own entries
 	FT_STAMP(p, 32);
 	// everything the workgroup fetches unconditionally is issued together: record count and bucket offset, the replay descriptors, and
@@ -1724,7 +1732,8 @@ __global__ __launch_bounds__(256) void ft_syn_masks(const FtPlan* plans) {
 
 // plans: the Q plans in HBM; host_plans: the same on the host (grid sizes).  All Q merges run over ONE index (same documents, so the same
 // document ranges and mask words).  Queries with multi-word synonyms run alone (ft_syn_masks in front); phrases ran before (ft_phrase.hip).
-hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st) {
+// phase < 0: the whole train; 0 / 1 / 2: the pieces a sharded merge exchanges between (rxgpu_internal.h)
+hipError_t launch_ft_merge_phase(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, int phase, hipStream_t st) {
 	constexpr size_t kFinishLds = (kFtRangeDocs / 2 + kFtRangeDocs) * sizeof(uint32_t), kFinishLdsFew = kFtRangeDocs * sizeof(uint32_t);
 	static std::atomic<uint64_t> raised{0};
 	if (hipError_t e = raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&ft_finish), kFinishLds); e != hipSuccess) return e;
@@ -1739,16 +1748,79 @@ hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32
 		any_bases = any_bases || !ft_own_bases(p);
 	}
 	const FtPlan& p0 = host_plans[0];
-	if (p0.n_syn_jobs) hipLaunchKernelGGL(ft_syn_masks, dim3(p0.n_ranges, 1), dim3(256), 0, st, plans);   // (nq == 1: the caller's rule)
-	hipLaunchKernelGGL(ft_ranges, dim3(p0.n_ranges, nq), dim3(256), 0, st, plans);
-	if (any_pre) {
-		hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((p0.nwords + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)), nq), dim3(256), 0, st, plans);
+	const uint32_t ranges = p0.range_count ? p0.range_count : p0.n_ranges;   // a document-range shard: its own ranges (nq == 1)
+	const uint64_t words = p0.range_count ? uint64_t(p0.range_count) * (kFtRangeDocs / 32) : p0.nwords;
+	if (phase < 0 || phase == 0) {
+		if (p0.n_syn_jobs) hipLaunchKernelGGL(ft_syn_masks, dim3(p0.n_ranges, 1), dim3(256), 0, st, plans);   // (nq == 1: the caller's rule)
+		hipLaunchKernelGGL(ft_ranges, dim3(ranges, nq), dim3(256), 0, st, plans);
 	}
-	if (rank_blocks) hipLaunchKernelGGL(ft_rank_all, dim3(rank_blocks, nq), dim3(256), 0, st, plans);
-	hipLaunchKernelGGL(ft_adders, dim3(p0.n_ranges, nq), dim3(256), 0, st, plans);
-	if (any_bases) hipLaunchKernelGGL(ft_slot_bases, dim3(1, nq), dim3(256), 0, st, plans);
-	hipLaunchKernelGGL(ft_finish, dim3(p0.n_ranges, nq), dim3(256), any_many_rows ? kFinishLds : kFinishLdsFew, st, plans);
+	if (phase < 0 || phase == 1) {
+		if (any_pre) {
+			hipLaunchKernelGGL(ft_preselect_apply, dim3(uint32_t((words + 256 * kFtApplyWords - 1) / (256 * kFtApplyWords)), nq), dim3(256), 0, st, plans);
+		}
+		if (rank_blocks) hipLaunchKernelGGL(ft_rank_all, dim3(rank_blocks, nq), dim3(256), 0, st, plans);
+		hipLaunchKernelGGL(ft_adders, dim3(ranges, nq), dim3(256), 0, st, plans);
+	}
+	if (phase < 0 || phase == 2) {
+		if (any_bases) hipLaunchKernelGGL(ft_slot_bases, dim3(1, nq), dim3(256), 0, st, plans);
+		hipLaunchKernelGGL(ft_finish, dim3(ranges, nq), dim3(256), any_many_rows ? kFinishLds : kFinishLdsFew, st, plans);
+	}
 	return hipGetLastError();
+}
+
+hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st) { return launch_ft_merge_phase(plans, host_plans, nq, -1, st); }
+
+// ---------------------------------------------------------------------------------------------- document-range shards: what travels between the kernels
+// One shard's pre-score histogram, its kFtHistCopies copies added up (fine counters, then the chunk counters), and the popcount of its
+// mask words behind them: what the all-gather carries.
+__global__ __launch_bounds__(256) void ft_shard_fold(const FtPlan* plans, uint32_t* dst) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < kFtFoldWords; i += gridDim.x * 256) {
+		uint32_t v = 0;
+		if (i < kFtHistStride) {
+			if (p.hist) {
+#pragma unroll
+				for (uint32_t k = 0; k < kFtHistCopies; ++k) v += p.hist[size_t(k) * kFtHistStride + i];
+			}
+		} else if (i == kFtHistStride) {
+			v = p.sync[kFtSyncPop];
+		}
+		dst[i] = v;
+	}
+}
+// ... and back: copy 0 of the histogram = the sum over the shards (the other copies zero), the popcount = the sum: ft_preselect_on and
+// ft_pick_threshold then decide on the WHOLE index, every shard alike.  pos[s] = where shard s lies in the gathered buffer.
+__global__ __launch_bounds__(256) void ft_shard_hist_combine(const FtPlan* plans, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= kFtHistStride; i += gridDim.x * 256) {
+		uint32_t v = 0;
+		for (uint32_t sh = 0; sh < n_shards; ++sh) v += gathered[size_t(pos[sh]) * kFtFoldWords + i];
+		if (i < kFtHistStride) {
+			if (p.hist) {
+				p.hist[i] = v;
+#pragma unroll
+				for (uint32_t k = 1; k < kFtHistCopies; ++k) p.hist[size_t(k) * kFtHistStride + i] = 0u;
+			}
+		} else {
+			p.sync[kFtSyncPop] = v;
+		}
+	}
+}
+// the table of ft_adders: every shard filled its own columns (the rest zero) — the sum is the table of the whole index
+__global__ __launch_bounds__(256) void ft_shard_table_sum(uint32_t* table, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards, uint64_t n, uint64_t stride) {
+	for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+		uint32_t v = 0;
+		for (uint32_t sh = 0; sh < n_shards; ++sh) v += gathered[size_t(pos[sh]) * stride + i];
+		table[i] = v;
+	}
+}
+void launch_ft_shard_fold(const FtPlan* plan, uint32_t* dst, hipStream_t st) { hipLaunchKernelGGL(ft_shard_fold, dim3(64), dim3(256), 0, st, plan, dst); }
+void launch_ft_shard_hist_combine(const FtPlan* plan, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards, hipStream_t st) {
+	hipLaunchKernelGGL(ft_shard_hist_combine, dim3(64), dim3(256), 0, st, plan, gathered, pos, n_shards);
+}
+void launch_ft_shard_table_sum(uint32_t* table, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards, uint64_t n, uint64_t stride, hipStream_t st) {
+	if (!n) return;
+	hipLaunchKernelGGL(ft_shard_table_sum, dim3(uint32_t(std::min<uint64_t>(256, (n + 255) / 256))), dim3(256), 0, st, table, gathered, pos, n_shards, n, stride);
 }
 
 // the results' way out (after the merge's timing bracket: the roofline of the merge kernels does not include the transfer)

@@ -342,12 +342,7 @@ constexpr int kGlHitCapSplit = 144;
 // (A ring of two was overrun at ld = 64 / 128, where the loaders are 2-3 tiles ahead: ADVICE round 4.)
 constexpr int kGlTermRing = 4;
 
-// kPipe: the fragment reads of BOTH 16-element halves of a stage are issued in front of the stage's first MFMA (twice the fragment registers),
-// so the second half's ds_reads travel while the first half multiplies.  Without it the compiler reuses the fragment registers and every
-// half-stage is  6 x ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 8 x MFMA : behind the per-stage barrier all eight waves read at once (the LDS needs
-// ~380 cycles to serve them) and then all multiply (2 x 256 cycles per SIMD), twice per stage, nothing overlapping — the MFMA pipe sat idle
-// for the LDS's share: MFMA busy 0.45-0.47 of the cycles (profiles/rd4_gemm_pmc.json), which is 1024 / (1024 + 2 x 380) to the digit.
-template <int kMetric, int kMode, int QT, bool kPipe = true, int RB = gl_row_bufs(QT), int QBUFS = gl_query_bufs(QT)>
+template <int kMetric, int kMode, int QT, int RB = gl_row_bufs(QT), int QBUFS = gl_query_bufs(QT)>
 __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params p) {
 	static_assert(RB >= 3 && RB <= 7 && QBUFS >= 2 && QBUFS <= 3, "the vmcnt switches below cover these ring depths");
 	static_assert(2 + (RB - 2) / 2 <= kGlTermRing, "term ring shorter than the row loaders' lead in tiles at two stages per tile");
@@ -504,62 +499,18 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 		rbuf = rbuf + 1 == uint32_t(RB) ? 0u : rbuf + 1;
 		qbuf = qbuf + 1 == uint32_t(QBUFS) ? 0u : qbuf + 1;
 		if (p.blocked & 2u) __builtin_amdgcn_s_setprio(1);   // RXGPU_GEMM_PRIO=1 (A/B): the stage's fragment reads and MFMAs ahead of the other wave's epilogue / DMA issue
-		if constexpr (kPipe) {
-			// Reads and waits are written out: with an LDS-DMA in flight (always, here) the compiler's wait-count pass treats the LGKM counter
-			// as out of order and puts s_waitcnt lgkmcnt(0) in front of the first MFMA whatever the order of the reads (global_load_lds is a
-			// FLAT-encoded instruction that "may access LDS").  ds_read returns are in order among themselves: with 2 x (2 + QB) reads issued,
-			// lgkmcnt(2 + QB) means the first half's fragments are there (a scalar load the compiler slipped in can only make that wait longer).
-			u32x4 bfr[2][2], afr[2][QB];
-			const uint32_t xbase = uint32_t(size_t((lds_void*)(xb + xrow * 32)));
-			const uint32_t qbase = uint32_t(size_t((lds_void*)(qb + qrow * 32)));
 #pragma unroll
-			for (int t = 0; t < 2; ++t) {
-				const uint32_t cs = (((2 * t + half) ^ swz) << 3) * 2;   // byte offset of the 16-byte chunk inside the row's 64-byte stage
-				const uint32_t xa = xbase + cs, qa = qbase + cs;
+		for (int t = 0; t < 2; ++t) {
+			const uint32_t cs = ((2 * t + half) ^ swz) << 3;
+			bf16x8 bfrag[2], afrag[QB];
 #pragma unroll
-				for (int a = 0; a < 2; ++a) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bfr[t][a]) : "v"(xa), "n"(32 * 64 * a) : "memory");
+			for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + (xrow + 32 * a) * 32 + cs));
 #pragma unroll
-				for (int b = 0; b < QB; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(afr[t][b]) : "v"(qa), "n"(32 * 64 * b) : "memory");
-			}
-			if constexpr (QB == 4) {
-				asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(afr[0][0]), "+v"(afr[0][1]), "+v"(afr[0][2]), "+v"(afr[0][3])::"memory");
-			} else {
-				asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bfr[0][0]), "+v"(bfr[0][1]), "+v"(afr[0][0]), "+v"(afr[0][1])::"memory");
-			}
+			for (int b = 0; b < QB; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (qrow + 32 * b) * 32 + cs));
 #pragma unroll
 			for (int a = 0; a < 2; ++a) {
 #pragma unroll
-				for (int b = 0; b < QB; ++b) {
-					acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[0][b]), __builtin_bit_cast(bf16x8, bfr[0][a]), acc[a][b], 0, 0, 0);
-				}
-			}
-			__builtin_amdgcn_sched_barrier(0);   // the first half's MFMAs stay in front of the second wait
-			if constexpr (QB == 4) {
-				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(afr[1][0]), "+v"(afr[1][1]), "+v"(afr[1][2]), "+v"(afr[1][3])::"memory");
-			} else {
-				asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bfr[1][0]), "+v"(bfr[1][1]), "+v"(afr[1][0]), "+v"(afr[1][1])::"memory");
-			}
-#pragma unroll
-			for (int a = 0; a < 2; ++a) {
-#pragma unroll
-				for (int b = 0; b < QB; ++b) {
-					acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[1][b]), __builtin_bit_cast(bf16x8, bfr[1][a]), acc[a][b], 0, 0, 0);
-				}
-			}
-		} else {
-#pragma unroll
-			for (int t = 0; t < 2; ++t) {
-				const uint32_t cs = ((2 * t + half) ^ swz) << 3;
-				bf16x8 bfrag[2], afrag[QB];
-#pragma unroll
-				for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + (xrow + 32 * a) * 32 + cs));
-#pragma unroll
-				for (int b = 0; b < QB; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (qrow + 32 * b) * 32 + cs));
-#pragma unroll
-				for (int a = 0; a < 2; ++a) {
-#pragma unroll
-					for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
-				}
+				for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
 			}
 		}
 		if (p.blocked & 2u) __builtin_amdgcn_s_setprio(0);
@@ -658,6 +609,295 @@ __global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_split(GemmBf16Params
 	if constexpr (kMode == kGemmFilter) flush_hits();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// qreg variant (filter pass): the query operand NOT through LDS-DMA.  What bounds the two kernels above is the fill rate of the LDS-DMA
+// path: a stage of 32 KB at 256 queries (16 KB rows + 16 KB queries) takes 1.26 us, 24 KB at 128 queries 0.93 us — 25.5 GB/s per CU either
+// way (the microarch guide's "ldsdma-fill" figure), with the MFMA pipe busy a third of the time and the LDS a quarter (a software-pipelined
+// stage — both halves' fragment reads in front of the first MFMA — changed nothing: 4.57 vs 4.61 ms, profiles/rd5b_gemm_ab.txt).  Half of
+// those bytes are the query block, re-streamed from L2 for every tile.  Here the four query-loader waves fetch their stage with plain
+// global loads into REGISTERS, two stages ahead, and store it into a two-slot query ring with ds_write_b128 — same LDS image, same
+// consumers — so the DMA path carries the rows alone (and the ring gets a seventh row slot for the LDS the third query slot held).
+// Measured (tools/bench_gemm_ab.py, 10M x 768, one box, profiles/rd5b_gemm_ab.txt): 256 queries 4.55 -> 4.33 ms (ip), 4.93 -> 4.62 (l2);
+// 128 queries 3.4 -> 2.96 ms.  The fill rate was a bound, not the only one: a stage still takes ~1.15 us where its MFMAs need 0.53.
+//   * Loads, waits and stores of that path are inline asm: with an LDS-DMA pending the compiler's wait-count pass answers every VGPR
+//     dependency on a VMEM load with vmcnt(0) (global_load_lds is FLAT-encoded, "may access LDS"), which would drain the ring each stage.
+//   * The registers are in flight ACROSS loop iterations, invisibly to the compiler, so nothing may make it copy them: the two roles run
+//     two separate loops (no merge points), the query loop is unrolled by two (stage parity = register set = slot; a tile has an even
+//     number of stages since ld is a multiple of 64) and its loads are unconditional (beyond the end they re-read stage 0 — never stored
+//     where anyone reads).  tests/test_kernel_resources.py checks the ISA for moves of the staging registers.
+template <int kMetric, int QT>
+__global__ __launch_bounds__(kBfThreads) void knn_gemm_bf16_qreg(GemmBf16Params p) {
+	constexpr int RB = 7;                            // row ring (six stages in flight)
+	constexpr int kQElems = QT * 32;                 // the query operand of one stage
+	constexpr int QB = QT / 64;                      // 32-query blocks per wave (two query halves)
+	constexpr int kQIps = QT * 4 / 256;              // 16-byte pieces per query-loader lane and stage (4 or 2)
+	constexpr bool kTerms = kMetric != kIP;          // the epilogue needs one float per row
+	extern __shared__ __attribute__((aligned(16))) unsigned char bf_lds[];   // the ONLY shared object
+	uint16_t* rows_s = reinterpret_cast<uint16_t*>(bf_lds);                                    // [RB][256 x 32]
+	uint16_t* qry_s = rows_s + size_t(RB) * kGlXElems;                                         // [2][QT x 32]
+	float* term_s = reinterpret_cast<float*>(qry_s + size_t(2) * kQElems);                     // [kGlTermRing][256]
+	float* thr_s = term_s + kGlTermRing * kBfRows;                                             // [QT]
+	float* aux_s = thr_s + QT;
+	uint32_t* hit_n = reinterpret_cast<uint32_t*>(aux_s + QT);                                 // [8]
+	unsigned long long* hit_all = reinterpret_cast<unsigned long long*>(hit_n + 8);            // [8][kGlHitCapSplit]
+	float* gmax_s = reinterpret_cast<float*>(hit_all + size_t(8) * kGlHitCapSplit);            // [QT / 16]
+	float* gmin_s = gmax_s + QT / 16;                                                          // [QT / 16]
+
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int rp = wave & 3, qh = wave >> 2;
+	const bool row_loader = wave < 4;
+	const uint32_t stages = p.ld / 32;
+	const uint64_t ntiles = (p.n + kBfRows - 1) / kBfRows;
+	const uint64_t my_tiles = blockIdx.x < ntiles ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+	const uint64_t total = my_tiles * stages;   // even
+	for (int i = tid; i < QT; i += kBfThreads) {
+		thr_s[i] = p.thr[i];
+		aux_s[i] = kMetric == kL2 ? p.q_sq[i] : 0.f;
+	}
+	if (tid < 8) hit_n[tid] = 0;
+	__syncthreads();
+	if (tid < QT / 16) {   // block-level test of the filter epilogue, as in the kernels above
+		const int half = tid & 1, bb = (tid >> 1) % QB, hh = (tid >> 1) / QB;
+		float tmax = -__builtin_inff(), amin = __builtin_inff();
+		for (int r = 0; r < 16; ++r) {
+			const int qi = 32 * bb + (r & 3) + 8 * (r >> 2) + 4 * half + (QT / 2) * hh;
+			tmax = fmaxf(tmax, thr_s[qi]);
+			amin = fminf(amin, aux_s[qi]);
+			if (thr_s[qi] != thr_s[qi]) tmax = __builtin_inff();
+		}
+		gmax_s[tid] = tmax;
+		gmin_s[tid] = amin;
+	}
+	__syncthreads();
+	if (total == 0) return;
+	unsigned long long* hit_s = hit_all + size_t(wave) * kGlHitCapSplit;
+	uint32_t* my_n = hit_n + wave;
+	auto flush_hits = [&]() {
+		const uint32_t cnt = min(*my_n, uint32_t(kGlHitCapSplit));
+		for (uint32_t e = lane; e < cnt; e += 64) {
+			const unsigned long long h = hit_s[e];
+			const uint32_t qi = uint32_t(h >> 32);
+			const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+			if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(h);
+		}
+		if (lane == 0) *my_n = 0;
+	};
+	// piece j of a loader lane covers LDS slots [256 j, 256 j + 256) of the operand: slot p = 4 r + cs holds chunk c = cs ^ ((r >> 2) & 3) of row r
+	uint32_t src_r[4], src_c[4];
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const uint32_t slot = j * 256 + rp * 64 + lane;
+		src_r[j] = slot >> 2;
+		src_c[j] = ((slot & 3) ^ ((src_r[j] >> 2) & 3)) << 3;
+	}
+	const uint32_t half = lane >> 5;
+	const uint32_t swz = (lane >> 2) & 3;
+	const uint32_t xrow = 64 * rp + (lane & 31), qrow = (QT / 2) * qh + (lane & 31);
+	f32x16 acc[2][QB];
+#pragma unroll
+	for (int a = 0; a < 2; ++a) {
+#pragma unroll
+		for (int b = 0; b < QB; ++b) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+		}
+	}
+	auto multiply = [&](const uint16_t* xb, const uint16_t* qb) {
+#pragma unroll
+		for (int t = 0; t < 2; ++t) {
+			const uint32_t cs = ((2 * t + half) ^ swz) << 3;
+			bf16x8 bfrag[2], afrag[QB];
+#pragma unroll
+			for (int a = 0; a < 2; ++a) bfrag[a] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xb + (xrow + 32 * a) * 32 + cs));
+#pragma unroll
+			for (int b = 0; b < QB; ++b) afrag[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(qb + (qrow + 32 * b) * 32 + cs));
+#pragma unroll
+			for (int a = 0; a < 2; ++a) {
+#pragma unroll
+				for (int b = 0; b < QB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[b], bfrag[a], acc[a][b], 0, 0, 0);
+			}
+		}
+	};
+	// the filter epilogue of one tile (element mapping and block test of the kernels above; row terms from LDS)
+	auto tile_end = [&](const uint64_t row0, const float* terms) {
+#pragma unroll
+		for (int a = 0; a < 2; ++a) {
+			const uint64_t row = row0 + 64 * rp + 32 * a + (lane & 31);
+			const bool row_ok = row < p.n;
+			float row_term = 0.f;
+			if constexpr (kTerms) row_term = terms[64 * rp + 32 * a + (lane & 31)];
+			const int qlane = 4 * (lane >> 5) + (QT / 2) * qh;
+#pragma unroll
+			for (int b = 0; b < QB; ++b) {
+				float best = acc[a][b][0];
+#pragma unroll
+				for (int r = 1; r < 16; ++r) best = fmaxf(best, acc[a][b][r]);
+				const int gi = (qh * QB + b) * 2 + (lane >> 5);
+				float dbest;
+				if constexpr (kMetric == kL2) {
+					dbest = (gmin_s[gi] + row_term) - 2.0f * best;
+				} else if constexpr (kMetric == kIP) {
+					dbest = -best;
+				} else {
+					dbest = -best * row_term;
+				}
+				uint32_t mask = 0;
+				if (__ballot(row_ok && !(dbest > gmax_s[gi]))) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						const int qo = 32 * b + (r & 3) + 8 * (r >> 2);
+						float d;
+						if constexpr (kMetric == kL2) {
+							d = (aux_s[qo + qlane] + row_term) - 2.0f * acc[a][b][r];
+						} else if constexpr (kMetric == kIP) {
+							d = -acc[a][b][r];
+						} else {
+							d = -acc[a][b][r] * row_term;
+						}
+						mask |= (d <= thr_s[qo + qlane]) ? (1u << r) : 0u;
+					}
+				}
+#pragma unroll
+				for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+				if (!row_ok) mask = 0;
+				__builtin_amdgcn_sched_barrier(0);
+				if (__ballot(mask != 0)) {
+					while (mask) {
+						const int r = __builtin_ctz(mask);
+						mask &= mask - 1;
+						const uint32_t qi = 32 * b + (r & 3) + 8 * (r >> 2) + qlane;
+						const uint32_t at = atomicAdd(my_n, 1u);
+						if (at < uint32_t(kGlHitCapSplit)) {
+							hit_s[at] = (static_cast<unsigned long long>(qi) << 32) | uint32_t(row);
+						} else {
+							const uint32_t pos = atomicAdd(&p.cand_cnt[qi], 1u);
+							if (pos < p.cap) p.cand_row[size_t(qi) * p.cap + pos] = uint32_t(row);
+						}
+					}
+				}
+			}
+		}
+		if (*my_n >= uint32_t(kGlHitCapSplit / 2)) flush_hits();
+	};
+
+	uint64_t tile = blockIdx.x;
+	uint32_t s = 0, rbuf = 0, tpar = 0;
+	if (row_loader) {
+		// ---- waves 0-3: the row stream by LDS-DMA, RB - 1 stages ahead (as in the split-ring kernel)
+		const uint16_t* src[4] = {nullptr, nullptr, nullptr, nullptr};
+		uint64_t iss_tile = blockIdx.x, iss_g = 0;
+		uint32_t iss_stage = 0, iss_buf = 0, iss_par = 0;
+		auto issue = [&]() {
+			const uint32_t k0 = iss_stage * shadow_stage_step((p.blocked & 1u) != 0);
+			if (iss_stage == 0) {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const uint64_t row = iss_tile * kBfRows + src_r[j];
+					src[j] = p.rows + shadow_elem_base((row < p.n ? row : p.n - 1) * p.row_step, p.ld, (p.blocked & 1u) != 0) + src_c[j];   // clamped: discarded by row_ok
+				}
+				if constexpr (kTerms) {
+					const uint64_t row = iss_tile * kBfRows + 64 * rp + lane;
+					const uint64_t rowc = (row < p.n ? row : p.n - 1) * p.row_step;
+					const float* tsrc = (kMetric == kL2 ? p.row_sq : p.inv_norms) + rowc;
+					float* tdst = term_s + iss_par * kBfRows + 64 * rp;
+					__builtin_amdgcn_global_load_lds(tsrc, (lds_void*)(tdst), 4, 0, 0);
+				}
+				iss_par = (iss_par + 1u) % uint32_t(kGlTermRing);
+			}
+			uint16_t* buf = rows_s + size_t(iss_buf) * kGlXElems;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) __builtin_amdgcn_global_load_lds(src[j] + k0, (lds_void*)(buf + (j * 256 + rp * 64) * 8), 16, 0, 0);
+			iss_buf = iss_buf + 1 == uint32_t(RB) ? 0u : iss_buf + 1;
+			++iss_g;
+			if (++iss_stage == stages) {
+				iss_stage = 0;
+				iss_tile += gridDim.x;
+			}
+		};
+		for (int a = 0; a < RB - 1; ++a) {
+			if (iss_g < total) issue();
+		}
+		for (uint64_t g = 0; g < total; ++g) {
+			const uint64_t younger = iss_g - g - 1;
+			switch (younger < uint64_t(RB - 2) ? int(younger) : RB - 2) {
+				case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+				case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+				case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+				case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+				case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+				default: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+			}
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+			if (iss_g < total) issue();
+			multiply(rows_s + size_t(rbuf) * kGlXElems, qry_s + size_t(g & 1) * kQElems);
+			rbuf = rbuf + 1 == uint32_t(RB) ? 0u : rbuf + 1;
+			if (++s < stages) continue;
+			s = 0;
+			tile_end(tile * kBfRows, term_s + tpar * kBfRows);
+			tile += gridDim.x;
+			tpar = (tpar + 1u) % uint32_t(kGlTermRing);
+		}
+	} else {
+		// ---- waves 4-7: the query stream through registers, two stages ahead; stage g -> register set g & 1 -> ring slot g & 1
+		const uint16_t* qsrc[kQIps];
+#pragma unroll
+		for (int j = 0; j < kQIps; ++j) qsrc[j] = p.queries + size_t(src_r[j] % QT) * p.ld + src_c[j];
+		const uint32_t st_base = uint32_t(size_t((lds_void*)(qry_s + (rp * 64 + lane) * 8)));
+		u32x4 qs0[kQIps], qs1[kQIps];
+		uint32_t qls = 0;   // stage (inside its tile) of the next load
+#define RX_Q_LOAD(SET)                                                                                                             \
+	do {                                                                                                                           \
+		const uint32_t k0__ = qls * 32u;                                                                                           \
+		_Pragma("unroll") for (int j = 0; j < kQIps; ++j)                                                                         \
+			asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(SET[j]) : "v"(qsrc[j] + k0__) : "memory");                       \
+		qls = qls + 1 == stages ? 0u : qls + 1;                                                                                    \
+	} while (0)
+#define RX_Q_STORE(SET, SLOT)                                                                                                      \
+	do {                                                                                                                           \
+		_Pragma("unroll") for (int j = 0; j < kQIps; ++j)                                                                         \
+			asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(st_base), "v"(SET[j]), "n"((SLOT) * kQElems * 2 + j * 256 * 16) : "memory"); \
+	} while (0)
+		// (Order inside a stage, measured at 10M x 768, 256 queries, ip: this wave loading FIRST and multiplying after — like its partner on the
+		// SIMD, the row loader, which issues its DMA pieces first — 4.33 ms; multiplying first and moving its query stage behind the MFMAs, so
+		// that one of the pair computes while the other loads, 4.52 ms: the shorter lead of the loads costs more than the overlap brings.)
+		RX_Q_LOAD(qs0);   // stage 0
+		RX_Q_LOAD(qs1);   // stage 1 (total >= 2)
+		asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQIps) : "memory");
+		RX_Q_STORE(qs0, 0);
+		for (uint64_t g = 0; g < total; g += 2) {
+			// ---- even stage g: set 0 is free (stage g sits in slot 0), stage g + 1 waits in set 1
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's stores of stage g are in the LDS
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+			RX_Q_LOAD(qs0);                                                   // stage g + 2 (beyond the end: a stage nobody reads)
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQIps) : "memory");      // ... stage g + 1 has landed (the older half of the queue)
+			RX_Q_STORE(qs1, 1);
+			multiply(rows_s + size_t(rbuf) * kGlXElems, qry_s);
+			rbuf = rbuf + 1 == uint32_t(RB) ? 0u : rbuf + 1;
+			// ---- odd stage g + 1
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+			RX_Q_LOAD(qs1);                                                   // stage g + 3
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kQIps) : "memory");      // stage g + 2 has landed
+			RX_Q_STORE(qs0, 0);
+			multiply(rows_s + size_t(rbuf) * kGlXElems, qry_s + kQElems);
+			rbuf = rbuf + 1 == uint32_t(RB) ? 0u : rbuf + 1;
+			s += 2;
+			if (s < stages) continue;
+			s = 0;
+			tile_end(tile * kBfRows, term_s + tpar * kBfRows);
+			tile += gridDim.x;
+			tpar = (tpar + 1u) % uint32_t(kGlTermRing);
+		}
+#undef RX_Q_LOAD
+#undef RX_Q_STORE
+	}
+	flush_hits();
+}
+
 size_t gemm_bf16_split_lds_bytes(int qt, int rb, int qbufs) {
 	return (size_t(rb) * kGlXElems + size_t(qbufs) * qt * 32) * sizeof(uint16_t) + size_t(kGlTermRing) * kBfRows * sizeof(float) +
 		   2 * size_t(qt) * sizeof(float) + 8 * sizeof(uint32_t) + size_t(8) * kGlHitCapSplit * 8 + 2 * size_t(qt / 16) * sizeof(float);
@@ -674,31 +914,30 @@ static bool gemm_split_rings() {
 	return e ? std::atoi(e) != 0 : true;
 }
 
-// RXGPU_GEMM_PIPE=0: the stage without the software pipeline (A/B)
-static bool gemm_pipe() {
-	const char* e = std::getenv("RXGPU_GEMM_PIPE");
+// RXGPU_GEMM_QREG=0: the query operand through LDS-DMA like the rows (the split-ring kernel; A/B)
+static bool gemm_qreg() {
+	const char* e = std::getenv("RXGPU_GEMM_QREG");
 	return e ? std::atoi(e) != 0 : true;
 }
 
 template <int kMetric, int kMode, int QT>
 static hipError_t launch_bf16_glds_one(const GemmBf16Params& p, uint32_t grid, hipStream_t s) {
-	if (gemm_split_rings()) {
-		const size_t lds = gemm_bf16_split_lds_bytes(QT, gl_row_bufs(QT), gl_query_bufs(QT));
-		if constexpr (kMode == kGemmFilter) {   // (the dense form runs over the 32 K-row sample only; its L2 epilogue would spill beside the second fragment set)
-		if (gemm_pipe()) {
-			static std::atomic<uint64_t> raised_pipe{0};
-			if (hipError_t e = raise_dynamic_lds_once(raised_pipe, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT, true>), lds); e != hipSuccess) {
-				return e;
-			}
-			hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT, true>), dim3(grid), dim3(kBfThreads), lds, s, p);
+	if constexpr (kMode == kGemmFilter) {   // (the dense form runs over the 32 K-row sample only)
+		if (gemm_split_rings() && gemm_qreg()) {
+			const size_t lds = gemm_bf16_split_lds_bytes(QT, 7, 2);
+			static std::atomic<uint64_t> raised_qreg{0};
+			if (hipError_t e = raise_dynamic_lds_once(raised_qreg, reinterpret_cast<const void*>(&knn_gemm_bf16_qreg<kMetric, QT>), lds); e != hipSuccess) return e;
+			hipLaunchKernelGGL((knn_gemm_bf16_qreg<kMetric, QT>), dim3(grid), dim3(kBfThreads), lds, s, p);
 			return hipGetLastError();
 		}
-		}
+	}
+	if (gemm_split_rings()) {
+		const size_t lds = gemm_bf16_split_lds_bytes(QT, gl_row_bufs(QT), gl_query_bufs(QT));
 		static std::atomic<uint64_t> raised_split{0};
-		if (hipError_t e = raise_dynamic_lds_once(raised_split, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT, false>), lds); e != hipSuccess) {
+		if (hipError_t e = raise_dynamic_lds_once(raised_split, reinterpret_cast<const void*>(&knn_gemm_bf16_split<kMetric, kMode, QT>), lds); e != hipSuccess) {
 			return e;
 		}
-		hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT, false>), dim3(grid), dim3(kBfThreads), lds, s, p);
+		hipLaunchKernelGGL((knn_gemm_bf16_split<kMetric, kMode, QT>), dim3(grid), dim3(kBfThreads), lds, s, p);
 		return hipGetLastError();
 	}
 	const size_t lds = gemm_bf16_glds_lds_bytes(QT);

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/rxgpu.h"
+#include "rccl_dyn.h"
 #include "rxgpu_internal.h"
 #include "ft_rank.hip.h"
 
@@ -49,6 +50,7 @@ struct rxgpu_ft_word {
 	uint32_t* range_off = nullptr; // [n_ranges]: first posting with doc >= k * kFtRangeDocs (ft_ranges finds its segment of the list here)
 	uint32_t n_ranges = 0;
 	uint32_t last_doc = 0;         // largest document id of the list: checked against total_docs when a merge uses the word
+	uint64_t df = 0;               // document-range shards: the word's document frequency over the WHOLE index (this list is a fragment); 0: n
 	uint64_t* fpos = nullptr;
 	std::shared_ptr<void> pool;    // set for words decoded on the device (rxgpu_ft_set_words_packed): the arrays are slices of one allocation
 	void release() {
@@ -62,10 +64,17 @@ struct rxgpu_ft_word {
 	}
 };
 
+struct rxgpu_ft_shard_set;
 struct rxgpu_ft_index {
 	int device = 0;
 	uint32_t num_fields = 0;
 	uint64_t total_docs = 0;
+	// Document-range shards (rxgpu_ft_create_sharded, SURVEY 8e "BM25").  The handle the caller holds owns the shards (shard_set); a shard is
+	// an ordinary index over the GLOBAL document space that merges its own ranges only (sh_*: set by the sharded layer around every merge).
+	rxgpu_ft_shard_set* shard_set = nullptr;
+	uint32_t sh_range_begin = 0, sh_range_count = 0, sh_index = 0, sh_total = 0;
+	const uint32_t* sh_hist = nullptr;   // every shard's folded histogram as gathered on this shard's device
+	const uint32_t* sh_pos = nullptr;    // shard -> position in the gathered buffers
 	float* d_words = nullptr;
 	float* d_avg = nullptr;
 	uint8_t* d_removed = nullptr;
@@ -150,6 +159,41 @@ struct rxgpu_ft_index {
 	double trace_us[6] = {0, 0, 0, 0, 0, 0};   // RXGPU_FT_TRACE: plan build, staging + upload, launches, wait + download, unpack, merges
 };
 
+// ---------------------------------------------------------------------------------------------- document-range shards (SURVEY 8e "BM25")
+// "Shard by doc-id range (each GPU holds the posting fragments of its docs; idf uses global N and df ...); exchange = ... the uint16 pre-score
+// histogram for the global threshold".  The index is cut into contiguous runs of 8192-document ranges, one run per listed device (a device
+// may repeat).  Every shard is an ordinary rxgpu_ft_index over the GLOBAL document space — the per-document statistics are replicated (a
+// few bytes per document), the posting lists, the bulk, are split: a shard holds the fragment of every list that falls into its documents,
+// with the whole list's length as document frequency — and runs the ordinary kernels over its own ranges.  The merge algorithm is
+// range-parallel with three per-query facts that span the ranges; between the kernels exactly those travel, over RCCL when the library is
+// there (one all-gather each; rccl_dyn.h), on the streams, without a host round trip:
+//   behind ft_ranges   every shard's folded pre-score histogram + the popcount of its mask words  (266 KB per shard)
+//                      -> the 2-phase gate and preselectMostRelevantDocs' threshold (mergerimpl.h:386-464, 486-490) are decided on the sums,
+//                         the ties kept at the threshold score are handed out in document order = shard order
+//   behind ft_adders   every shard's table of documents first met per (sub-term row, range)      (rows x ranges x 4 B per shard)
+//                      -> the sum is the table of the whole index: the merge slot of every document (addDoc order, merger.h:161-180) and the
+//                         cut at maxMergedDocs are the single index's
+// so every shard writes its documents at their GLOBAL merge slots, and the caller's list is the slot-wise union: the single handle's result,
+// bit for bit (tests/test_gpu_ft_sharded.py).  postProcessResults' maximum (merger.h:111-155) is taken by the host merger over that list.
+struct rxgpu_ft_shard_set {
+	std::vector<rxgpu_ft_index*> shards;
+	std::vector<int> devices;
+	uint32_t n_ranges = 0;                  // of the whole index; 0: rxgpu_ft_set_docs has not run
+	// the exchange: one RCCL rank per DISTINCT device, a device's shards are `slots` consecutive pieces of its rank's buffers
+	uint32_t nranks = 0, slots = 0;
+	std::vector<int> rank_dev;
+	std::vector<uint32_t> shard_rank, shard_slot, pos;   // pos[s] = rank * slots + slot: where shard s lies in a gathered buffer
+	std::vector<ncclComm_t> comms;          // empty: RCCL is not available (note says why) — the pieces then travel through the host
+	std::string note;
+	std::vector<hipStream_t> rstream;       // per rank
+	std::vector<hipEvent_t> ev_shard, ev_rank;
+	std::vector<uint32_t*> d_pos;           // per rank: pos[] on the device
+	std::vector<rxgpu_devbuf> d_send[2], d_recv[2];   // per rank; [0] histograms, [1] adder tables
+	uint64_t collectives = 0, merges = 0;
+	std::mutex coll_mtx;
+};
+
+
 namespace {
 struct DevGuard {
 	int prev = -1;
@@ -188,6 +232,7 @@ int upload(T*& dst, const T* src, size_t count) {
 	RX_HIP(hipMemcpy(dst, src, count * sizeof(T), hipMemcpyHostToDevice));
 	return RXGPU_OK;
 }
+inline uint64_t word_df(const rxgpu_ft_word& w) { return w.df ? w.df : w.n; }
 }  // namespace
 
 extern "C" {
@@ -208,6 +253,103 @@ int rxgpu_ft_create(uint32_t num_fields, int device, rxgpu_ft_index** out) {
 		return RXGPU_ERR_DEVICE;
 	}
 	*out = h;
+	return RXGPU_OK;
+}
+
+namespace {
+void ft_shards_destroy(rxgpu_ft_shard_set* ss);
+}
+
+int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* devices, rxgpu_ft_index** out) {
+	RX_CHECK(out && devices && n_devices >= 1 && n_devices <= 64, RXGPU_ERR_PARAMS, "rxgpu_ft_create_sharded: bad arguments (1..64 devices)");
+	*out = nullptr;
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	rxgpu_ft_index* h = nullptr;
+	if (int rc = rxgpu_ft_create(num_fields, devices[0], &h); rc) return rc;   // the handle the caller holds: no dictionary of its own
+	auto* ss = new rxgpu_ft_shard_set();
+	h->shard_set = ss;
+	auto fail = [&](int rc) {
+		const std::string msg = rxgpu_last_error();
+		rxgpu_ft_destroy(h);
+		if (prev >= 0) (void)hipSetDevice(prev);
+		set_error(msg);
+		return rc;
+	};
+	std::vector<uint32_t> per_rank;
+	for (uint32_t s = 0; s < n_devices; ++s) {
+		rxgpu_ft_index* sh = nullptr;
+		if (int rc = rxgpu_ft_create(num_fields, devices[s], &sh); rc) return fail(rc);
+		ss->shards.push_back(sh);
+		ss->devices.push_back(devices[s]);
+		uint32_t r = 0;
+		while (r < ss->rank_dev.size() && ss->rank_dev[r] != devices[s]) ++r;
+		if (r == ss->rank_dev.size()) {
+			ss->rank_dev.push_back(devices[s]);
+			per_rank.push_back(0);
+		}
+		ss->shard_rank.push_back(r);
+		ss->shard_slot.push_back(per_rank[r]++);
+	}
+	ss->nranks = uint32_t(ss->rank_dev.size());
+	ss->slots = *std::max_element(per_rank.begin(), per_rank.end());
+	for (uint32_t s = 0; s < n_devices; ++s) ss->pos.push_back(ss->shard_rank[s] * ss->slots + ss->shard_slot[s]);
+	ss->rstream.assign(ss->nranks, nullptr);
+	ss->ev_rank.assign(ss->nranks, nullptr);
+	ss->d_pos.assign(ss->nranks, nullptr);
+	ss->ev_shard.assign(n_devices, nullptr);
+	for (int k = 0; k < 2; ++k) {
+		ss->d_send[k].resize(ss->nranks);
+		ss->d_recv[k].resize(ss->nranks);
+	}
+	for (uint32_t r = 0; r < ss->nranks; ++r) {
+		hipError_t e = hipSetDevice(ss->rank_dev[r]);
+		if (e == hipSuccess) e = hipStreamCreateWithFlags(&ss->rstream[r], hipStreamNonBlocking);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&ss->ev_rank[r], hipEventDisableTiming);
+		if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ss->d_pos[r]), ss->pos.size() * sizeof(uint32_t));
+		if (e == hipSuccess) e = hipMemcpy(ss->d_pos[r], ss->pos.data(), ss->pos.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+		if (e != hipSuccess) {
+			set_error(std::string("rxgpu_ft_create_sharded: device ") + std::to_string(ss->rank_dev[r]) + ": " + hipGetErrorString(e));
+			return fail(RXGPU_ERR_DEVICE);
+		}
+	}
+	for (uint32_t s = 0; s < n_devices; ++s) {
+		hipError_t e = hipSetDevice(devices[s]);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&ss->ev_shard[s], hipEventDisableTiming);
+		if (e != hipSuccess) {
+			set_error(std::string("rxgpu_ft_create_sharded: ") + hipGetErrorString(e));
+			return fail(RXGPU_ERR_DEVICE);
+		}
+	}
+	// the communicator (RXGPU_SHARD_MERGE=host: the pieces travel through the host instead, as they do when RCCL is missing)
+	const char* mode = getenv("RXGPU_SHARD_MERGE");
+	if (mode && std::strcmp(mode, "host") == 0) {
+		ss->note = "RXGPU_SHARD_MERGE=host";
+	} else {
+		const rxgpu::RcclApi& api = rxgpu::rccl_api();
+		if (!api.why.empty()) {
+			ss->note = "RCCL unavailable: " + api.why;
+		} else {
+			ss->comms.assign(ss->nranks, nullptr);
+			const ncclResult_t nr = api.ncclCommInitAll(ss->comms.data(), int(ss->nranks), ss->rank_dev.data());
+			if (nr != ncclSuccess) {
+				ss->note = std::string("ncclCommInitAll over ") + std::to_string(ss->nranks) + " device(s): " + api.ncclGetErrorString(nr);
+				ss->comms.clear();
+			}
+		}
+		if (!ss->note.empty()) fprintf(stderr, "rxgpu: sharded ft index over %u device slot(s): %s — the shards' histograms and tables travel through the host\n", n_devices, ss->note.c_str());
+	}
+	if (prev >= 0) (void)hipSetDevice(prev);
+	*out = h;
+	return RXGPU_OK;
+}
+uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h) { return h && h->shard_set ? uint32_t(h->shard_set->shards.size()) : 0; }
+int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h) { return h && h->shard_set ? (h->shard_set->comms.empty() ? 0 : 1) : -1; }
+uint64_t rxgpu_ft_shard_collectives(const rxgpu_ft_index* h) { return h && h->shard_set ? h->shard_set->collectives : 0; }
+int rxgpu_ft_shard_ranges(const rxgpu_ft_index* h, uint32_t shard, uint32_t* range_begin, uint32_t* range_count) {
+	RX_CHECK(h && h->shard_set && shard < h->shard_set->shards.size() && range_begin && range_count, RXGPU_ERR_PARAMS, "rxgpu_ft_shard_ranges: bad arguments");
+	*range_begin = h->shard_set->shards[shard]->sh_range_begin;
+	*range_count = h->shard_set->shards[shard]->sh_range_count;
 	return RXGPU_OK;
 }
 
@@ -247,6 +389,12 @@ struct LaneLock {
 	std::shared_lock<std::shared_mutex> dict;
 };
 int checkout_lane(rxgpu_ft_index* h, LaneLock& out) {
+	if (h->shard_set) {   // a sharded index runs one merge at a time: every shard's handle is busy with it
+		out.lane = h;
+		out.lk = std::unique_lock<std::mutex>(h->mtx);
+		out.dict = std::shared_lock<std::shared_mutex>(h->dict_mtx);
+		return RXGPU_OK;
+	}
 	auto take = [&](rxgpu_ft_index* l, std::unique_lock<std::mutex>&& lk) {
 		out.lane = l;
 		out.lk = std::move(lk);
@@ -311,8 +459,72 @@ int checkout_lane(rxgpu_ft_index* h, LaneLock& out) {
 }
 }  // namespace
 
+// ---- the sharded handle's side of the dictionary calls (the merge itself: run_merge_sharded)
+static int ft_shards_set_docs(rxgpu_ft_index* h, uint64_t total_docs, const float* words_in_field, const float* avg_words, const uint8_t* removed) {
+	rxgpu_ft_shard_set* ss = h->shard_set;
+	std::lock_guard<std::mutex> lk(h->mtx);
+	const uint32_t S = uint32_t(ss->shards.size());
+	const uint32_t n_ranges = uint32_t((total_docs + rxgpu::kFtRangeDocs - 1) / rxgpu::kFtRangeDocs);
+	const uint32_t per = (n_ranges + S - 1) / S;
+	if (ss->n_ranges && ss->n_ranges != n_ranges) {   // the cut moves: the fragments the shards hold belong to the old one
+		for (rxgpu_ft_index* sh : ss->shards) {
+			RX_CHECK(sh->words.empty(), RXGPU_ERR_LOGIC,
+					 "rxgpu_ft_set_docs: the document ranges of a sharded ft index moved — create a new index (or upload every word again on a fresh one)");
+		}
+	}
+	for (uint32_t s = 0; s < S; ++s) {
+		rxgpu_ft_index* sh = ss->shards[s];
+		if (int rc = rxgpu_ft_set_docs(sh, total_docs, words_in_field, avg_words, removed); rc) return rc;   // replicated: a few bytes per document
+		sh->sh_index = s;
+		sh->sh_total = S;
+		sh->sh_range_begin = std::min(s * per, n_ranges);
+		sh->sh_range_count = std::min(per, n_ranges - sh->sh_range_begin);
+	}
+	ss->n_ranges = n_ranges;
+	h->total_docs = total_docs;
+	return RXGPU_OK;
+}
+
+// One dictionary word: every shard takes the postings of ITS documents (ids stay global) and the whole list's length as document frequency.
+// Either the flat form (ent_*) or the positions form (pos_off / fpos).
+static int ft_shards_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uint32_t* doc, const uint32_t* ent_off, const uint8_t* ent_field,
+							  const uint32_t* ent_tf, const uint32_t* ent_first_pos, const uint32_t* pos_off, const uint64_t* fpos) {
+	rxgpu_ft_shard_set* ss = h->shard_set;
+	std::lock_guard<std::mutex> lk(h->mtx);
+	RX_CHECK(ss->n_ranges > 0, RXGPU_ERR_LOGIC, "a sharded ft index cuts its posting lists at the document ranges: call rxgpu_ft_set_docs first");
+	for (uint64_t i = 1; i < n; ++i) RX_CHECK(doc[i] > doc[i - 1], RXGPU_ERR_PARAMS, "rxgpu_ft_set_word: document ids must ascend strictly");
+	RX_CHECK(n == 0 || doc[n - 1] < h->total_docs, RXGPU_ERR_PARAMS, "rxgpu_ft_set_word: a posting list holds a document id >= total_docs (rxgpu_ft_set_docs)");
+	for (rxgpu_ft_index* sh : ss->shards) {
+		const uint64_t d_lo = uint64_t(sh->sh_range_begin) * rxgpu::kFtRangeDocs, d_hi = d_lo + uint64_t(sh->sh_range_count) * rxgpu::kFtRangeDocs;
+		const uint64_t a = uint64_t(std::lower_bound(doc, doc + n, d_lo, [](uint32_t x, uint64_t v) { return uint64_t(x) < v; }) - doc);
+		const uint64_t b = uint64_t(std::lower_bound(doc, doc + n, d_hi, [](uint32_t x, uint64_t v) { return uint64_t(x) < v; }) - doc);
+		const uint64_t m = b - a;
+		int rc;
+		if (pos_off) {
+			std::vector<uint32_t> po(m + 1);
+			for (uint64_t i = 0; i <= m; ++i) po[i] = pos_off[a + i] - pos_off[a];
+			rc = rxgpu_ft_set_word_positions(sh, word_id, m, m ? doc + a : nullptr, po.data(), m ? fpos + pos_off[a] : nullptr);
+		} else {
+			std::vector<uint32_t> eo(m + 1);
+			for (uint64_t i = 0; i <= m; ++i) eo[i] = ent_off[a + i] - ent_off[a];
+			const uint32_t e0 = m ? ent_off[a] : 0;
+			rc = rxgpu_ft_set_word(sh, word_id, m, m ? doc + a : nullptr, eo.data(), ent_field + e0, ent_tf + e0, ent_first_pos + e0);
+		}
+		if (rc) return rc;
+		std::lock_guard<std::mutex> slk(sh->mtx);
+		std::unique_lock<std::shared_mutex> dict_lk(sh->dict_mtx);
+		sh->words[word_id].df = n;   // (an empty fragment keeps its entry: the word's row exists on every shard)
+	}
+	return RXGPU_OK;
+}
+
 void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	if (!h) return;
+	if (h->shard_set) {
+		DevGuard dgs(h->device);
+		ft_shards_destroy(h->shard_set);
+		h->shard_set = nullptr;
+	}
 	DevGuard dg(h->device);
 	(void)hipDeviceSynchronize();
 	for (auto& kv : h->words) kv.second.release();
@@ -333,6 +545,7 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 int rxgpu_ft_set_docs(rxgpu_ft_index* h, uint64_t total_docs, const float* words_in_field, const float* avg_words, const uint8_t* removed) {
 	RX_CHECK(h && words_in_field && avg_words, RXGPU_ERR_PARAMS, "rxgpu_ft_set_docs: null argument");
 	RX_CHECK(total_docs >= 1 && total_docs < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "rxgpu_ft_set_docs: total_docs out of range");
+	if (h->shard_set) return ft_shards_set_docs(h, total_docs, words_in_field, avg_words, removed);
 	std::lock_guard<std::mutex> lk(h->mtx);
 	std::unique_lock<std::shared_mutex> dict_lk(h->dict_mtx);   // no merge on any lane reads the dictionary meanwhile
 	DevGuard dg(h->device);
@@ -353,6 +566,7 @@ int rxgpu_ft_set_word(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uin
 					  const uint32_t* ent_tf, const uint32_t* ent_first_pos) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null ft index");
 	RX_CHECK(n == 0 || (doc && ent_off && ent_field && ent_tf && ent_first_pos), RXGPU_ERR_PARAMS, "rxgpu_ft_set_word: null argument");
+	if (h->shard_set) return ft_shards_set_word(h, word_id, n, doc, ent_off, ent_field, ent_tf, ent_first_pos, nullptr, nullptr);
 	std::lock_guard<std::mutex> lk(h->mtx);
 	std::unique_lock<std::shared_mutex> dict_lk(h->dict_mtx);   // no merge on any lane reads the dictionary meanwhile
 	DevGuard dg(h->device);
@@ -495,7 +709,7 @@ rxgpu::FtPosSubterm word_subterm(const rxgpu_ft_word& w, int bm25_type, uint64_t
 	ft.ent_first_pos = w.ent_first_pos;
 	ft.pos_off = w.pos_off;
 	ft.fpos = w.fpos;
-	ft.idf = subterm_idf(bm25_type, N, w.n);
+	ft.idf = subterm_idf(bm25_type, N, word_df(w));
 	ft.proc = proc;
 	ft.range_off = w.range_off;
 	ft.n_ranges = w.n_ranges;
@@ -847,7 +1061,7 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 			// documents rxgpu_ft_set_docs described would read and write out of bounds (set_docs may follow the words, so it is checked here)
 			RX_CHECK(it->second.n == 0 || it->second.last_doc < N, RXGPU_ERR_PARAMS,
 					 std::string(who) + ": a posting list holds a document id >= total_docs (rxgpu_ft_set_docs)");
-			term_postings[t] += it->second.n;
+			term_postings[t] += word_df(it->second);   // (a document-range shard: the whole index's count — limits and gates are global facts)
 		}
 		total_vids += term_postings[t];   // totalORVids: MaxVDocs of every term, whatever its operator and inside phrases too (selecterimpl.h:546)
 	}
@@ -937,7 +1151,7 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 			RX_CHECK(simple || w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
 			RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
 					 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
-			if (!w.n) continue;
+			if (!word_df(w)) continue;   // (a shard keeps the row of a word it holds no posting of: rows are numbered alike on every shard)
 			rxgpu::FtPosSubterm ft = word_subterm(w, bm25_type, N, procs[si]);
 			ft.term = pi;
 			ft.qp = qt.op == 3 ? 0 : qp;
@@ -977,7 +1191,7 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 				RX_CHECK(w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
 				RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
 						 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
-				if (!w.n) continue;
+				if (!word_df(w)) continue;
 				rxgpu::FtPosSubterm ft = word_subterm(w, bm25_type, N, procs[si]);
 				ft.term = nparts + k;
 				ft.qp = qt.op == 3 ? 0 : qp;
@@ -1162,6 +1376,18 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));
 	p.out_terms_counter = reinterpret_cast<uint16_t*>(ob + align256(16) + 2 * align256(M * 4));
 	p.out_field = reinterpret_cast<uint8_t*>(ob + align256(16) + 2 * align256(M * 4) + align256(M * 2));
+	if (h->sh_total > 1) {   // a document-range shard: its own ranges, the facts that span the shards arrive between the kernels
+		RX_CHECK(!resident && !nsyn && !max_areas && n_phrases == 0, RXGPU_ERR_LOGIC,
+				 std::string(who) + ": a sharded ft index merges plain terms (no phrases, multi-word synonyms, areas or resident results)");
+		p.range_begin = h->sh_range_begin;
+		p.range_count = h->sh_range_count;
+		p.shard_index = h->sh_index;
+		p.n_shards = h->sh_total;
+		p.shard_hist = prescore ? h->sh_hist : nullptr;
+		p.shard_pos = h->sh_pos;
+		RX_HIP(hipMemsetAsync(p.adders, 0, std::max<size_t>(1, size_t(n_rows) * n_ranges) * 4, st));   // the other shards' columns
+		RX_HIP(hipMemsetAsync(p.out_doc, 0xFF, M * 4, st));                                              // slots another shard fills stay marked
+	}
 	if (max_areas) {
 		job.area_hdr_bytes = align256(M * nf * 2 * sizeof(uint32_t));
 		job.area_bytes = M * nf * size_t(max_areas) * 3 * sizeof(uint32_t);
@@ -1222,12 +1448,252 @@ int collect_merge(rxgpu_ft_index* h, const MergeJob& job, uint32_t* out_doc, flo
 	return RXGPU_OK;
 }
 
+void ft_shards_destroy(rxgpu_ft_shard_set* ss) {
+	if (!ss) return;
+	for (rxgpu_ft_index* sh : ss->shards) rxgpu_ft_destroy(sh);
+	for (uint32_t r = 0; r < ss->nranks; ++r) {
+		(void)hipSetDevice(ss->rank_dev[r]);
+		if (r < ss->rstream.size() && ss->rstream[r]) (void)hipStreamDestroy(ss->rstream[r]);
+		if (r < ss->ev_rank.size() && ss->ev_rank[r]) (void)hipEventDestroy(ss->ev_rank[r]);
+		if (r < ss->d_pos.size() && ss->d_pos[r]) (void)hipFree(ss->d_pos[r]);
+		for (int k = 0; k < 2; ++k) {
+			if (r < ss->d_send[k].size()) ss->d_send[k][r].release();
+			if (r < ss->d_recv[k].size()) ss->d_recv[k][r].release();
+		}
+	}
+	for (size_t s = 0; s < ss->ev_shard.size(); ++s) {
+		if (ss->ev_shard[s]) {
+			(void)hipSetDevice(ss->devices[s]);
+			(void)hipEventDestroy(ss->ev_shard[s]);
+		}
+	}
+	for (ncclComm_t c : ss->comms) {
+		if (c) (void)rxgpu::rccl_api().ncclCommDestroy(c);
+	}
+	delete ss;
+}
+
+// Piece `k` (0 histograms, 1 tables) of every shard -> every rank's receive buffer.  Every shard's producer has been enqueued on its own
+// stream and wrote bytes (a multiple of 4) at send_ptr(k, s); consumers enqueued afterwards on the shards' streams read recv_ptr(k, s).
+int ft_shards_gather(rxgpu_ft_shard_set* ss, int k, size_t bytes) {
+	const size_t S = ss->shards.size();
+	for (size_t s = 0; s < S; ++s) {
+		RX_HIP(hipSetDevice(ss->devices[s]));
+		RX_HIP(hipEventRecord(ss->ev_shard[s], ss->shards[s]->stream));
+	}
+	for (uint32_t r = 0; r < ss->nranks; ++r) {
+		RX_HIP(hipSetDevice(ss->rank_dev[r]));
+		for (size_t s = 0; s < S; ++s) {
+			if (ss->shard_rank[s] == r) RX_HIP(hipStreamWaitEvent(ss->rstream[r], ss->ev_shard[s], 0));
+		}
+	}
+	if (!ss->comms.empty()) {
+		const rxgpu::RcclApi& api = rxgpu::rccl_api();
+		std::lock_guard<std::mutex> lk(ss->coll_mtx);
+		ncclResult_t nr = api.ncclGroupStart();
+		for (uint32_t r = 0; r < ss->nranks && nr == ncclSuccess; ++r) {
+			nr = api.ncclAllGather(ss->d_send[k][r].ptr, ss->d_recv[k][r].ptr, bytes / 4 * ss->slots, ncclUint32, ss->comms[r], ss->rstream[r]);
+		}
+		const ncclResult_t ne = api.ncclGroupEnd();
+		if (nr == ncclSuccess) nr = ne;
+		if (nr != ncclSuccess) {
+			set_error(std::string("sharded ft index: ncclAllGather: ") + api.ncclGetErrorString(nr));
+			return RXGPU_ERR_DEVICE;
+		}
+		++ss->collectives;
+	} else {   // no RCCL on this node: the same pieces through the host
+		std::vector<char> all(size_t(ss->nranks) * ss->slots * bytes);
+		for (uint32_t r = 0; r < ss->nranks; ++r) {
+			RX_HIP(hipSetDevice(ss->rank_dev[r]));
+			RX_HIP(hipMemcpyAsync(all.data() + size_t(r) * ss->slots * bytes, ss->d_send[k][r].ptr, ss->slots * bytes, hipMemcpyDeviceToHost, ss->rstream[r]));
+		}
+		for (uint32_t r = 0; r < ss->nranks; ++r) {
+			RX_HIP(hipSetDevice(ss->rank_dev[r]));
+			RX_HIP(hipStreamSynchronize(ss->rstream[r]));
+		}
+		for (uint32_t r = 0; r < ss->nranks; ++r) {
+			RX_HIP(hipSetDevice(ss->rank_dev[r]));
+			RX_HIP(hipMemcpyAsync(ss->d_recv[k][r].ptr, all.data(), all.size(), hipMemcpyHostToDevice, ss->rstream[r]));
+			RX_HIP(hipStreamSynchronize(ss->rstream[r]));   // (`all` goes out of scope)
+		}
+	}
+	for (uint32_t r = 0; r < ss->nranks; ++r) {
+		RX_HIP(hipSetDevice(ss->rank_dev[r]));
+		RX_HIP(hipEventRecord(ss->ev_rank[r], ss->rstream[r]));
+	}
+	for (size_t s = 0; s < S; ++s) {
+		RX_HIP(hipSetDevice(ss->devices[s]));
+		RX_HIP(hipStreamWaitEvent(ss->shards[s]->stream, ss->ev_rank[ss->shard_rank[s]], 0));
+	}
+	return RXGPU_OK;
+}
+
+int ft_shards_buffers(rxgpu_ft_shard_set* ss, int k, size_t bytes) {
+	for (uint32_t r = 0; r < ss->nranks; ++r) {
+		RX_HIP(hipSetDevice(ss->rank_dev[r]));
+		const bool grow = ss->d_send[k][r].bytes < bytes * ss->slots;
+		if (int rc = ss->d_send[k][r].ensure(bytes * ss->slots); rc) return rc;
+		if (int rc = ss->d_recv[k][r].ensure(bytes * ss->slots * ss->nranks); rc) return rc;
+		if (grow) RX_HIP(hipMemset(ss->d_send[k][r].ptr, 0, ss->d_send[k][r].bytes));   // padded slots (a device with fewer shards) stay zero
+	}
+	return RXGPU_OK;
+}
+inline char* ft_send_ptr(rxgpu_ft_shard_set* ss, int k, size_t s, size_t bytes) {
+	return static_cast<char*>(ss->d_send[k][ss->shard_rank[s]].ptr) + size_t(ss->shard_slot[s]) * bytes;
+}
+
+// One merge over all shards (the caller holds the sharded handle's mutex): the ordinary launch train in its three pieces, the two exchanges
+// between them, every shard's packed result, the slot-wise union.
+int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
+					  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
+					  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who) {
+	rxgpu_ft_shard_set* ss = parent->shard_set;
+	const size_t S = ss->shards.size();
+	RX_CHECK(ss->n_ranges > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
+	int prev_dev = -1;
+	(void)hipGetDevice(&prev_dev);
+	struct Restore {
+		int d;
+		~Restore() { if (d >= 0) (void)hipSetDevice(d); }
+	} restore{prev_dev};
+	// exchange buffers first: the plans carry pointers into them
+	const size_t fold_bytes = size_t(rxgpu::kFtFoldWords) * 4;
+	const size_t nsubs = terms.empty() ? 0 : terms.back().sub_end;
+	const size_t table_stride = std::max<size_t>(1, nsubs) * ss->n_ranges;   // >= rows x ranges of the plan (every sub-term is at most one row)
+	if (int rc = ft_shards_buffers(ss, 0, fold_bytes); rc) return rc;
+	if (int rc = ft_shards_buffers(ss, 1, table_stride * 4); rc) return rc;
+	std::vector<MergeJob> jobs(S);
+	std::vector<std::unique_lock<std::mutex>> locks;
+	std::vector<std::shared_lock<std::shared_mutex>> dicts;
+	std::vector<bool> active(S, false);
+	bool empty = false;
+	for (size_t s = 0; s < S; ++s) {
+		rxgpu_ft_index* sh = ss->shards[s];
+		locks.emplace_back(sh->mtx);
+		dicts.emplace_back(sh->dict_mtx);
+		RX_HIP(hipSetDevice(ss->devices[s]));
+		active[s] = sh->sh_range_count != 0;
+		sh->sh_hist = static_cast<const uint32_t*>(ss->d_recv[0][ss->shard_rank[s]].ptr);
+		sh->sh_pos = ss->d_pos[ss->shard_rank[s]];
+		if (int rc = prepare_merge(sh, sh->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, nullptr, jobs[s], true, 0); rc) return rc;
+		empty = empty || jobs[s].empty;
+		sh->clean_dirty = !jobs[s].empty;   // an error return from here on leaves the kept-clean tables in an unknown state
+	}
+	if (empty) return RXGPU_OK;   // min(mergeLimit, totalORVids) == 0 — decided on the whole index's counts, alike on every shard
+	const uint64_t M = jobs[0].max_merged;
+	RX_CHECK(cap >= M, RXGPU_ERR_OVERFLOW, std::string(who) + ": output buffers too small");
+	const bool prescore = jobs[0].p.prescore != 0;
+	auto phase = [&](int ph) -> int {
+		for (size_t s = 0; s < S; ++s) {
+			if (!active[s]) continue;
+			RX_HIP(hipSetDevice(ss->devices[s]));
+			RX_HIP(rxgpu::launch_ft_merge_phase(jobs[s].d_plan, &jobs[s].p, 1, ph, ss->shards[s]->stream));
+		}
+		return RXGPU_OK;
+	};
+	if (int rc = phase(0); rc) return rc;
+	if (prescore) {   // the histogram + popcount of every shard -> the sums; gate, threshold and tie quota are the whole index's
+		for (size_t s = 0; s < S; ++s) {
+			RX_HIP(hipSetDevice(ss->devices[s]));
+			uint32_t* dst = reinterpret_cast<uint32_t*>(ft_send_ptr(ss, 0, s, fold_bytes));
+			if (active[s]) {
+				rxgpu::launch_ft_shard_fold(jobs[s].d_plan, dst, ss->shards[s]->stream);
+			} else {
+				RX_HIP(hipMemsetAsync(dst, 0, fold_bytes, ss->shards[s]->stream));
+			}
+		}
+		if (int rc = ft_shards_gather(ss, 0, fold_bytes); rc) return rc;
+		for (size_t s = 0; s < S; ++s) {
+			if (!active[s]) continue;
+			RX_HIP(hipSetDevice(ss->devices[s]));
+			rxgpu::launch_ft_shard_hist_combine(jobs[s].d_plan, static_cast<const uint32_t*>(ss->d_recv[0][ss->shard_rank[s]].ptr), ss->d_pos[ss->shard_rank[s]],
+												uint32_t(S), ss->shards[s]->stream);
+		}
+	}
+	if (int rc = phase(1); rc) return rc;
+	{   // the adder tables: every shard's own columns -> the table of the whole index
+		const size_t n_table = size_t(jobs[0].p.n_rows) * jobs[0].p.n_ranges;
+		for (size_t s = 0; s < S; ++s) {
+			RX_HIP(hipSetDevice(ss->devices[s]));
+			char* dst = ft_send_ptr(ss, 1, s, table_stride * 4);
+			if (active[s] && n_table) {
+				RX_HIP(hipMemcpyAsync(dst, jobs[s].p.adders, n_table * 4, hipMemcpyDeviceToDevice, ss->shards[s]->stream));
+			} else {
+				RX_HIP(hipMemsetAsync(dst, 0, std::max<size_t>(4, n_table * 4), ss->shards[s]->stream));
+			}
+		}
+		if (int rc = ft_shards_gather(ss, 1, table_stride * 4); rc) return rc;
+		for (size_t s = 0; s < S; ++s) {
+			if (!active[s]) continue;
+			RX_HIP(hipSetDevice(ss->devices[s]));
+			rxgpu::launch_ft_shard_table_sum(jobs[s].p.adders, static_cast<const uint32_t*>(ss->d_recv[1][ss->shard_rank[s]].ptr), ss->d_pos[ss->shard_rank[s]], uint32_t(S),
+											 n_table, table_stride, ss->shards[s]->stream);
+		}
+	}
+	if (int rc = phase(2); rc) return rc;
+	for (size_t s = 0; s < S; ++s) {
+		if (!active[s]) continue;
+		RX_HIP(hipSetDevice(ss->devices[s]));
+		RX_HIP(rxgpu::launch_ft_export(jobs[s].d_plan, &jobs[s].p, 1, ss->shards[s]->stream));
+	}
+	for (size_t s = 0; s < S; ++s) {
+		RX_HIP(hipSetDevice(ss->devices[s]));
+		RX_HIP(hipStreamSynchronize(ss->shards[s]->stream));
+	}
+	++ss->merges;
+	// ---- the slot-wise union: every merge slot was written by exactly one shard (the others left their 0xFFFFFFFF mark)
+	uint64_t n = 0;
+	bool have_n = false;
+	int32_t presel = 0;
+	for (size_t s = 0; s < S; ++s) {
+		if (!active[s]) continue;
+		const uint32_t* hdr = static_cast<const uint32_t*>(ss->shards[s]->h_pinned);
+		RX_CHECK(hdr[1] == 0, RXGPU_ERR_DEVICE, std::string(who) + ": ordered look-back timed out on the device");
+		RX_CHECK(!have_n || hdr[0] == n, RXGPU_ERR_DEVICE, std::string(who) + ": the shards disagree on the number of merged documents");
+		n = hdr[0];
+		have_n = true;
+		presel = presel || hdr[2];
+		ss->shards[s]->clean_dirty = false;
+		ss->shards[s]->stat_postings += jobs[s].merged_postings;
+	}
+	RX_CHECK(n <= M, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt result header");
+	std::vector<uint8_t> filled(n, 0);
+	for (size_t s = 0; s < S; ++s) {
+		if (!active[s]) continue;
+		const char* hp = static_cast<const char*>(ss->shards[s]->h_pinned);
+		const uint32_t* sd = reinterpret_cast<const uint32_t*>(hp + align256(16));
+		const float* sp = reinterpret_cast<const float*>(hp + align256(16) + align256(M * 4));
+		const uint16_t* st_ = reinterpret_cast<const uint16_t*>(hp + align256(16) + 2 * align256(M * 4));
+		const uint8_t* sf = reinterpret_cast<const uint8_t*>(hp + align256(16) + 2 * align256(M * 4) + align256(M * 2));
+		for (uint64_t i = 0; i < n; ++i) {
+			if (sd[i] == 0xFFFFFFFFu) continue;
+			RX_CHECK(!filled[i], RXGPU_ERR_DEVICE, std::string(who) + ": two shards wrote one merge slot");
+			filled[i] = 1;
+			out_doc[i] = sd[i];
+			out_proc[i] = sp[i];
+			if (out_terms_counter) out_terms_counter[i] = st_[i];
+			out_field[i] = sf[i];
+		}
+	}
+	for (uint64_t i = 0; i < n; ++i) RX_CHECK(filled[i], RXGPU_ERR_DEVICE, std::string(who) + ": a merge slot no shard wrote");
+	*out_n = n;
+	if (out_preselected) *out_preselected = presel;
+	return RXGPU_OK;
+}
+
+
 // Shared implementation of rxgpu_ft_merge_simple_raw / rxgpu_ft_merge_terms_raw.  out_terms_counter may be null (simple).
 int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 			  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
 			  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, bool resident = false, const SynonymsIn* synonyms = nullptr,
 			  const AreasOut* areas = nullptr) {
 	using clk = std::chrono::steady_clock;
+	if (h->shard_set) {   // document-range shards: the same train on every shard, two exchanges between its pieces
+		RX_CHECK(!resident && !(synonyms && synonyms->nsyn) && !areas, RXGPU_ERR_LOGIC,
+				 std::string(who) + ": a sharded ft index merges plain terms (no multi-word synonyms, areas or resident results)");
+		RX_CHECK(out_doc && out_proc && out_field && (simple || out_terms_counter), RXGPU_ERR_OVERFLOW, std::string(who) + ": output buffers too small");
+		return run_merge_sharded(h, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who);
+	}
 	if (int rc = finish_pending(h, who); rc) return rc;
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
 	hipStream_t st = h->stream;
@@ -1333,6 +1799,7 @@ int rxgpu_ft_merge_simple_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 int rxgpu_ft_set_word_positions(rxgpu_ft_index* h, uint32_t word_id, uint64_t n, const uint32_t* doc, const uint32_t* pos_off, const uint64_t* fpos) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null ft index");
 	RX_CHECK(n == 0 || (doc && pos_off && fpos), RXGPU_ERR_PARAMS, "rxgpu_ft_set_word_positions: null argument");
+	if (h->shard_set) return ft_shards_set_word(h, word_id, n, doc, nullptr, nullptr, nullptr, nullptr, pos_off, fpos);
 	// derive the (field, tf, first position) entries calcTermRankImpl groups out of IdRelType::Pos() (phrasemergerimpl.h:24-49)
 	std::vector<uint32_t> ent_off(n + 1, 0), ent_tf, ent_first;
 	std::vector<uint8_t> ent_field;

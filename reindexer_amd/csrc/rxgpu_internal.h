@@ -269,13 +269,30 @@ struct FtPlan {
 	uint32_t max_areas, area_fields;
 	uint32_t* area_hdr;
 	uint32_t* out_areas;
+	// Document-range shards (SURVEY 8e "BM25", rxgpu_ft_sharded.hip): this handle merges the documents of the ranges [range_begin,
+	// range_begin + range_count) only — its posting lists hold just those documents' fragments (global ids; idf from the global N / df) — and
+	// the three per-query facts that span the shards travel between the kernels: the pre-score histogram + mask popcount (behind ft_ranges;
+	// shard_hist = every shard's folded histogram, [n_shards][kFtFoldWords]: the sum is the threshold's input, the entries of the shards in
+	// front give the tie quota already used at the threshold score), and the table of ft_adders (every shard fills its own columns, the
+	// sum is the global table the slot bases come from).  range_count == 0: the whole index (unsharded).
+	uint32_t range_begin, range_count;
+	uint32_t shard_index, n_shards;
+	const uint32_t* shard_hist;   // gathered layout: shard s at [shard_pos[s]][kFtFoldWords]
+	const uint32_t* shard_pos;    // [n_shards]
 };
+constexpr uint32_t kFtFoldWords = 65536 + 1024 + 64;   // one shard's folded histogram (fine + chunk counters), [65536 + 1024] = its mask popcount
 enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6, kFtSyncDoneFinish = 9, kFtSyncWords = 16 };
 constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
 // Q merges over one index in ONE train (grid.y = query; a single merge is a batch of one): the plans in HBM + their host copy
 hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st);
+// the same train in the three pieces a sharded merge exchanges between: 0 = [syn masks] + ft_ranges, 1 = [ft_preselect_apply] + ft_rank_all +
+// ft_adders, 2 = [ft_slot_bases] + ft_finish
+hipError_t launch_ft_merge_phase(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, int phase, hipStream_t st);
+void launch_ft_shard_fold(const FtPlan* plan, uint32_t* dst, hipStream_t st);                                            // hist copies + popcount -> dst [kFtFoldWords]
+void launch_ft_shard_hist_combine(const FtPlan* plan, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards, hipStream_t st);   // gathered [..][kFtFoldWords]
+void launch_ft_shard_table_sum(uint32_t* table, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards, uint64_t n, uint64_t stride, hipStream_t st);   // gathered [..][stride]
 constexpr uint32_t kFtBatchMax = 64;
 struct FtImportBatch {             // pieces of one batched upload (pinned staging -> HBM), 16-byte words
 	const void* src[kFtBatchMax + 1];

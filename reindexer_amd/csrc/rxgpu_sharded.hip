@@ -28,7 +28,7 @@
 #include <dlfcn.h>
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>   // types and prototypes only: the library is opened at the first sharded index (rccl_api below)
+#include "rccl_dyn.h"   // <rccl/rccl.h> for types and prototypes only: the library is opened at the first sharded index (rccl_api below)
 
 #include "../../include/rxgpu.h"
 #include "knn_kernels.hip.h"
@@ -37,20 +37,6 @@
 using rxgpu::set_error;
 
 namespace rxgpu {
-
-// RCCL is opened lazily (dlopen) by the first sharded index that asks for the device-side exchange: a single-GPU deployment neither links
-// nor needs librccl.so, and a node where the library is missing or cannot initialise (no peer access, no /dev/shm in the container, ...)
-// keeps working on the host-merge path.  The entry points keep their nccl* names below.
-struct RcclApi {
-	decltype(&::ncclCommInitAll) ncclCommInitAll = nullptr;
-	decltype(&::ncclCommDestroy) ncclCommDestroy = nullptr;
-	decltype(&::ncclAllGather) ncclAllGather = nullptr;
-	decltype(&::ncclAllReduce) ncclAllReduce = nullptr;
-	decltype(&::ncclGroupStart) ncclGroupStart = nullptr;
-	decltype(&::ncclGroupEnd) ncclGroupEnd = nullptr;
-	decltype(&::ncclGetErrorString) ncclGetErrorString = nullptr;
-	std::string why;   // non-empty: not available, and why
-};
 
 const RcclApi& rccl_api() {
 	static RcclApi api;

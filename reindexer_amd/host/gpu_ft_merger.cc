@@ -92,6 +92,18 @@ GpuFtMerger::GpuFtMerger(size_t numFields, int device) : numFields_(numFields) {
 	if (rxgpu_ft_create(uint32_t(numFields), device, &dev_) != RXGPU_OK) throwDevice("GpuFtMerger: device index creation failed");
 }
 
+GpuFtMerger::GpuFtMerger(size_t numFields, std::vector<int> devices) : numFields_(numFields) {
+	if (devices.empty()) throw std::logic_error("GpuFtMerger: empty device list");
+	if (devices.size() == 1) {
+		if (rxgpu_ft_create(uint32_t(numFields), devices[0], &dev_) != RXGPU_OK) throwDevice("GpuFtMerger: device index creation failed");
+		return;
+	}
+	if (rxgpu_ft_create_sharded(uint32_t(numFields), uint32_t(devices.size()), devices.data(), &dev_) != RXGPU_OK) {
+		throwDevice("GpuFtMerger: sharded device index creation failed");
+	}
+	sharded_ = true;
+}
+
 GpuFtMerger::~GpuFtMerger() {
 	if (dev_) rxgpu_ft_destroy(dev_);
 }
@@ -257,7 +269,7 @@ void GpuFtMerger::SetWordsPacked(const std::vector<PackedWord>& words, size_t ho
 	std::vector<const uint8_t*> data;
 	std::vector<uint64_t> len, afp;
 	for (const PackedWord& w : words) {
-		if (w.len >= hostDecodeFromBytes) {
+		if (sharded_ || w.len >= hostDecodeFromBytes) {   // (a sharded index cuts every list at its document ranges: decoded here, split by the library)
 			PositionPostings pp;
 			pp.AppendPacked(w.data, w.len, w.arrayFoundPos);
 			SetWord(w.wordId, pp);

@@ -154,7 +154,17 @@ struct HybridFused {
 class GpuFtMerger {
 public:
 	GpuFtMerger(size_t numFields, int device = 0);
+	// SURVEY 8(e) "BM25": the same merger over a DEVICE LIST — the index is cut into document-range shards (rxgpu_ft_create_sharded: every
+	// device holds the posting fragments of its documents, idf from the global N / df; the pre-score histograms and the admission table meet
+	// in one all-gather each) and every merge returns the single-device result bit for bit.  Queries of plain terms only: phrases,
+	// multi-word synonyms, areas, batches and resident (hybrid) merges need a single-device merger (ShardedSupports()).
+	GpuFtMerger(size_t numFields, std::vector<int> devices);
 	~GpuFtMerger();
+	bool Sharded() const noexcept { return sharded_; }
+	rxgpu_ft_index* DeviceIndex() const noexcept { return dev_; }
+	bool ShardedSupports(bool hasPhrases, bool hasSynonyms, int maxAreasInDoc = 0) const noexcept {
+		return !sharded_ || (!hasPhrases && !hasSynonyms && maxAreasInDoc == 0);
+	}
 	GpuFtMerger(const GpuFtMerger&) = delete;
 
 	// IndexText side (CommitFulltext): vdoc statistics and posting lists
@@ -247,6 +257,7 @@ private:
 	size_t totalDocs_ = 0;
 	std::vector<float> words_;   // host copy for addFullMatchBoost
 	rxgpu_ft_index* dev_ = nullptr;
+	bool sharded_ = false;
 	mutable std::atomic<uint64_t> timedCalls_{0}, timedNs_{0};
 };
 

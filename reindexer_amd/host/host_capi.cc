@@ -771,6 +771,13 @@ void* rxhost_ft_create(size_t numFields, int device) {
 	guarded([&] { m = new GpuFtMerger(numFields, device); });
 	return m;
 }
+// the merger over a device list: document-range shards (SURVEY 8e "BM25")
+void* rxhost_ft_create_sharded(size_t numFields, const int* devices, size_t nDevices) {
+	GpuFtMerger* m = nullptr;
+	guarded([&] { m = new GpuFtMerger(numFields, std::vector<int>(devices, devices + nDevices)); });
+	return m;
+}
+void* rxhost_ft_device_index(void* h) { return static_cast<GpuFtMerger*>(h)->DeviceIndex(); }
 void rxhost_ft_destroy(void* h) { delete static_cast<GpuFtMerger*>(h); }
 int rxhost_ft_set_docs(void* h, size_t totalDocs, const float* words, const float* avg, const uint8_t* removed) {
 	return guarded([&] { static_cast<GpuFtMerger*>(h)->SetDocs(totalDocs, words, avg, removed); });

@@ -37,14 +37,17 @@
 #include "core/ft/ftdsl.h"
 #include "core/ft/idrelset.h"
 #include "core/index/ft_preselect.h"
+#include "device_list.h"
 #include "gpu_ft_merger.h"
 
 namespace rxgpu::host {
 
-// RX_GPU_FT_INDEXES=<device> routes the merge step of `text` (ft_fast) indexes to the MI355X engine (unset / empty: the CPU merger).
+// RX_GPU_FT_INDEXES=<device list> (device_list.h: "3", "0,1,2,3", "0-7") routes the merge step of `text` (ft_fast) indexes to the MI355X
+// engine (unset / empty / malformed: the CPU merger).  More than one device: the index is cut into document-range shards (SURVEY 8e "BM25").
+inline std::vector<int> GpuFtDevicesFromEnv() { return GpuDevicesFromEnv("RX_GPU_FT_INDEXES"); }
 inline int GpuFtDeviceFromEnv() noexcept {
-	const char* e = std::getenv("RX_GPU_FT_INDEXES");
-	return (e && *e) ? std::atoi(e) : -1;
+	const std::vector<int> d = GpuFtDevicesFromEnv();
+	return d.empty() ? -1 : d[0];
 }
 
 inline FtConfig ToGpuCfg(const reindexer::FTConfig& c) {
@@ -164,6 +167,7 @@ inline void ToRxMergeData(const MergeData& in, reindexer::ft::MergeData& out) {
 class GpuFtMirror {
 public:
 	GpuFtMirror(size_t numFields, int device) : merger_(numFields, device), numFields_(numFields) {}
+	GpuFtMirror(size_t numFields, std::vector<int> devices) : merger_(numFields, std::move(devices)), numFields_(numFields) {}
 
 	const GpuFtMerger& Merger() const noexcept { return merger_; }
 	size_t SyncedWords() const noexcept { return prints_.size(); }
@@ -251,12 +255,12 @@ private:
 template <typename IdCont, typename DocsStatsGetter>
 void SyncGpuFtMirror(reindexer::DataHolder<IdCont>& holder, std::shared_ptr<GpuFtMirror>& mirror, size_t totalDocs, size_t numFields,
 					 const DocsStatsGetter& stats) {
-	const int device = GpuFtDeviceFromEnv();
-	if (device < 0) {
+	std::vector<int> devices = GpuFtDevicesFromEnv();
+	if (devices.empty()) {
 		mirror.reset();
 		return;
 	}
-	if (!mirror || holder.status_ == reindexer::FullRebuild) mirror = std::make_shared<GpuFtMirror>(numFields, device);
+	if (!mirror || holder.status_ == reindexer::FullRebuild) mirror = std::make_shared<GpuFtMirror>(numFields, std::move(devices));
 	mirror->SyncDocs(totalDocs, stats);
 	mirror->SyncWords(holder.GetWords());   // DataHolder<IdCont>::words_ (dataholder.h:186-207)
 }
@@ -307,6 +311,7 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		QuerySynonyms synonyms;
 		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
 		if (!GpuFtMerger::SupportsAreas(terms.size(), hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;
+		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;   // a device list: plain terms, no areas
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
 		if (docsExcluded.PopCount() != 0) {
@@ -332,6 +337,7 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		QuerySynonyms synonyms;
 		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
 		if (!GpuFtMerger::Supports(terms.size(), hasPhrases, !q.synonyms.empty())) return false;
+		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty())) return false;   // a device list: phrases and synonyms stay on the CPU merger
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
 		if (docsExcluded.PopCount() != 0) {

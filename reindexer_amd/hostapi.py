@@ -747,9 +747,14 @@ class GpuHnswMap:
 class GpuFtMerger:
     """rxgpu::host::GpuFtMerger — ft_fast single-term BM25 merge on the GPU (stand-in for ft::Merger::Merge<Bm25Rx>)."""
 
-    def __init__(self, num_fields: int, device: int = 0):
+    def __init__(self, num_fields: int, device: int = 0, devices=None):
+        """devices=[d0, d1, ...]: the merger over a device list — document-range shards (a device may be listed more than once)."""
         L = lib()
         if not hasattr(L, "_ft_bound"):
+            L.rxhost_ft_create_sharded.restype = _vp
+            L.rxhost_ft_create_sharded.argtypes = [_sz, _vp, _sz]
+            L.rxhost_ft_device_index.restype = _vp
+            L.rxhost_ft_device_index.argtypes = [_vp]
             L.rxhost_ft_create.restype = _vp
             L.rxhost_ft_create.argtypes = [_sz, _i]
             L.rxhost_ft_destroy.argtypes = [_vp]
@@ -760,9 +765,18 @@ class GpuFtMerger:
             L.rxhost_ft_read_stats.argtypes = [_vp, _vp, _vp]
             L._ft_bound = True
         self.nf = num_fields
-        self.h = L.rxhost_ft_create(num_fields, device)
+        if devices is not None:
+            dv = np.ascontiguousarray(devices, np.int32)
+            self.h = L.rxhost_ft_create_sharded(num_fields, dv.ctypes.data, dv.shape[0])
+        else:
+            self.h = L.rxhost_ft_create(num_fields, device)
         if not self.h:
             _raise()
+
+    @property
+    def device_index(self) -> int:
+        """rxgpu_ft_index* behind the merger (sharded: the rxgpu_ft_create_sharded handle)."""
+        return lib().rxhost_ft_device_index(self.h)
 
     def close(self):
         if getattr(self, "h", None):

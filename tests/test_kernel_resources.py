@@ -37,11 +37,70 @@ def resource_usage(src: Path, tmp: Path) -> dict:
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="needs hipcc")
 def test_bf16_gemm_instantiations_do_not_spill(tmp_path):
     usage = resource_usage(CSRC / "knn_batched_bf16.hip", tmp_path)
-    gemms = {k: v for k, v in usage.items() if "knn_gemm_bf16_glds" in k or "knn_gemm_bf16_split" in k}
-    assert len(gemms) == 30, sorted(gemms)   # (single ring + split rings) x 3 metrics x 2 modes x 2 query-tile widths + the software-pipelined filter form x 3 x 2
+    gemms = {k: v for k, v in usage.items() if "knn_gemm_bf16_glds" in k or "knn_gemm_bf16_split" in k or "knn_gemm_bf16_qreg" in k}
+    # (single ring + split rings) x 3 metrics x 2 modes x 2 query-tile widths + the register-staged-query filter kernel x 3 metrics x 2 widths
+    assert len(gemms) == 30, sorted(gemms)
     for name, u in gemms.items():
         assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (name, u)
         assert u["VGPRs"] <= 256, (name, u)
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="needs hipcc")
+def test_qreg_gemm_staging_registers_are_left_alone(tmp_path):
+    """knn_gemm_bf16_qreg keeps a query stage IN FLIGHT in registers across loop iterations behind the compiler's back (inline-asm
+    global_load_dwordx4 ... s_waitcnt ... ds_write_b128).  That is only sound while the compiler never touches those registers between the
+    load and the store: in every instantiation they may appear in the asm loads (destination / address), the asm stores (data) and the
+    address arithmetic in front of a load — nowhere else."""
+    from reindexer_amd.build import HIP_FLAGS
+    flags = [f for f in HIP_FLAGS if f not in ("-shared",)]
+    r = subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", str(CSRC / "knn_batched_bf16.hip"), "-o", str(tmp_path / "k.s")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    text = (tmp_path / "k.s").read_text()
+    kernels = re.findall(r"^(_ZN5rxgpu18knn_gemm_bf16_qreg\w+):.*?\n(.*?)^\s*\.end_amdhsa_kernel|^(_ZN5rxgpu18knn_gemm_bf16_qreg\w+):", text, re.S | re.M)
+    bodies = {}
+    for m in re.finditer(r"^(_ZN5rxgpu18knn_gemm_bf16_qreg\w+):\s*;.*?\n(.*?)s_endpgm", text, re.S | re.M):
+        bodies[m.group(1)] = m.group(2)
+    assert len(bodies) == 6, sorted(bodies)   # 3 metrics x 2 query-tile widths
+
+    def regs_of(tok):   # "v[128:131]" / "v155" -> set of register numbers
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    for name, body in bodies.items():
+        lines = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(";")]
+        # the query loaders' stage loop = the outermost loop (label ... last branch back to it) that holds the asm loads; the prologue's
+        # loads lie in front of it and may use any register
+        labels = {ln.split(":")[0]: i for i, ln in enumerate(lines) if re.match(r"\.LBB\d+_\d+:", ln)}
+        loops = {}
+        for i, ln in enumerate(lines):
+            m = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", ln)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops[m.group(1)] = max(loops.get(m.group(1), 0), i)
+        regions = [(labels[lab], end) for lab, end in loops.items()
+                   if any(x.startswith("global_load_dwordx4") for x in lines[labels[lab]:end]) and sum(x.startswith("s_barrier") for x in lines[labels[lab]:end]) >= 2
+                   and any(("atomic" in x or x.startswith("ds_add")) for x in lines[labels[lab]:end])]
+        assert regions, name
+        # two stages per iteration: two barriers; the tile epilogue (its atomics) is part of the loop; an enclosing region would hold the prologue too
+        lo, hi = min(regions, key=lambda r: r[1] - r[0])
+        region = lines[lo:hi + 1]
+        staging = set()
+        for ln in region:
+            if ln.startswith("global_load_dwordx4"):
+                staging |= regs_of(ln.split()[1].rstrip(","))
+        assert len(staging) in (8, 16, 32), (name, sorted(staging))
+        for ln in region:
+            toks = re.findall(r"v\[\d+:\d+\]|v\d+\b", ln)
+            used = set().union(*[regs_of(t) for t in toks]) if toks else set()
+            if not (used & staging):
+                continue
+            op = ln.split()[0]
+            assert op in ("global_load_dwordx4", "ds_write_b128", "v_lshl_add_u64", "v_mov_b64_e32", "v_mov_b32_e32"), (name, ln)
+            if op in ("v_lshl_add_u64", "v_mov_b64_e32", "v_mov_b32_e32"):   # address preparation: staging registers may only be WRITTEN by it
+                srcs = set().union(*[regs_of(t) for t in toks[1:]]) if len(toks) > 1 else set()
+                assert not (srcs & staging), (name, ln)
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="needs hipcc")
