@@ -344,13 +344,15 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h);
  * run the ordinary launch train on every shard at once and exchange, between its kernels, what spans the shards — every shard's pre-score
  * histogram + mask popcount (the 2-phase gate and preselectMostRelevantDocs' threshold, mergerimpl.h:386-464, with the ties at the threshold
  * handed out in document order) and every shard's table of first-met documents per (sub-term row, range) (the merge slots of addDoc,
- * merger.h:161-180, and the cut at maxMergedDocs) — one ncclAllGather each on the shards' streams (RCCL opened on demand; without it, or with
- * RXGPU_SHARD_MERGE=host at creation, the pieces travel through the host: rxgpu_ft_shard_exchange_mode 1 / 0).  The result is the single
+ * merger.h:161-180, and the cut at maxMergedDocs) — one all-gather each, stream-ordered between the shards' kernels with no host round trip:
+ * an ncclAllGather over the listed devices (RCCL opened on demand; one communicator per index), a plain device copy when every shard lives on
+ * one device; without RCCL on a multi-device node, or with RXGPU_SHARD_MERGE=host at creation, the pieces travel through the host
+ * (rxgpu_ft_shard_exchange_mode 1 = on the devices, 0 = through the host).  The result is the single
  * index's, bit for bit, in merge order.  Phrases, multi-word synonyms, areas, packed uploads, batches and resident (hybrid) merges are
  * single-device features: RXGPU_ERR_LOGIC here. */
 int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* devices, rxgpu_ft_index** out);
 uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h);           /* 0 for an unsharded index */
-int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h);        /* 1 RCCL, 0 host, -1 not sharded */
+int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h);        /* 1 on the devices, 0 through the host, -1 not sharded */
 uint64_t rxgpu_ft_shard_collectives(const rxgpu_ft_index* h);     /* all-gathers issued so far */
 int rxgpu_ft_shard_ranges(const rxgpu_ft_index* h, uint32_t shard, uint32_t* range_begin, uint32_t* range_count);   /* the shard's run of 8192-document ranges */
 /* The DocsStatsGetter of IndexText (cpp_src/core/index/indextext/indextext.h:245-258): total_docs counts the empty sentinel

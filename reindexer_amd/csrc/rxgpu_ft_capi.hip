@@ -183,7 +183,8 @@ struct rxgpu_ft_shard_set {
 	uint32_t nranks = 0, slots = 0;
 	std::vector<int> rank_dev;
 	std::vector<uint32_t> shard_rank, shard_slot, pos;   // pos[s] = rank * slots + slot: where shard s lies in a gathered buffer
-	std::vector<ncclComm_t> comms;          // empty: RCCL is not available (note says why) — the pieces then travel through the host
+	std::vector<ncclComm_t> comms;          // one per rank when the shards span several devices (RCCL); empty otherwise
+	bool host_exchange = false;             // RXGPU_SHARD_MERGE=host, or several devices without RCCL (note says why): the pieces travel through the host
 	std::string note;
 	std::vector<hipStream_t> rstream;       // per rank
 	std::vector<hipEvent_t> ev_shard, ev_rank;
@@ -321,11 +322,13 @@ int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* 
 			return fail(RXGPU_ERR_DEVICE);
 		}
 	}
-	// the communicator (RXGPU_SHARD_MERGE=host: the pieces travel through the host instead, as they do when RCCL is missing)
+	// the exchange: RXGPU_SHARD_MERGE=host -> through the host; one device -> copies on that device; several devices -> one RCCL
+	// communicator over them (opened on demand; missing / failing: through the host, one line on stderr)
 	const char* mode = getenv("RXGPU_SHARD_MERGE");
 	if (mode && std::strcmp(mode, "host") == 0) {
+		ss->host_exchange = true;
 		ss->note = "RXGPU_SHARD_MERGE=host";
-	} else {
+	} else if (ss->nranks > 1) {
 		const rxgpu::RcclApi& api = rxgpu::rccl_api();
 		if (!api.why.empty()) {
 			ss->note = "RCCL unavailable: " + api.why;
@@ -337,14 +340,17 @@ int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* 
 				ss->comms.clear();
 			}
 		}
-		if (!ss->note.empty()) fprintf(stderr, "rxgpu: sharded ft index over %u device slot(s): %s — the shards' histograms and tables travel through the host\n", n_devices, ss->note.c_str());
+		if (!ss->note.empty()) {
+			ss->host_exchange = true;
+			fprintf(stderr, "rxgpu: sharded ft index over %u device slot(s): %s — the shards' histograms and tables travel through the host\n", n_devices, ss->note.c_str());
+		}
 	}
 	if (prev >= 0) (void)hipSetDevice(prev);
 	*out = h;
 	return RXGPU_OK;
 }
 uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h) { return h && h->shard_set ? uint32_t(h->shard_set->shards.size()) : 0; }
-int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h) { return h && h->shard_set ? (h->shard_set->comms.empty() ? 0 : 1) : -1; }
+int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h) { return h && h->shard_set ? (h->shard_set->host_exchange ? 0 : 1) : -1; }
 uint64_t rxgpu_ft_shard_collectives(const rxgpu_ft_index* h) { return h && h->shard_set ? h->shard_set->collectives : 0; }
 int rxgpu_ft_shard_ranges(const rxgpu_ft_index* h, uint32_t shard, uint32_t* range_begin, uint32_t* range_count) {
 	RX_CHECK(h && h->shard_set && shard < h->shard_set->shards.size() && range_begin && range_count, RXGPU_ERR_PARAMS, "rxgpu_ft_shard_ranges: bad arguments");
@@ -1501,7 +1507,13 @@ int ft_shards_gather(rxgpu_ft_shard_set* ss, int k, size_t bytes) {
 			return RXGPU_ERR_DEVICE;
 		}
 		++ss->collectives;
-	} else {   // no RCCL on this node: the same pieces through the host
+	} else if (!ss->host_exchange && ss->nranks == 1) {
+		// every shard lives on ONE device: the all-gather of a single rank is a copy on that device's exchange stream (no communicator is made
+		// for one rank; with several devices the branch above runs — the same call pattern as the float_vector shards' exchange)
+		RX_HIP(hipSetDevice(ss->rank_dev[0]));
+		RX_HIP(hipMemcpyAsync(ss->d_recv[k][0].ptr, ss->d_send[k][0].ptr, bytes * ss->slots, hipMemcpyDeviceToDevice, ss->rstream[0]));
+		++ss->collectives;
+	} else {   // asked for, or no RCCL on this node: the same pieces through the host
 		std::vector<char> all(size_t(ss->nranks) * ss->slots * bytes);
 		for (uint32_t r = 0; r < ss->nranks; ++r) {
 			RX_HIP(hipSetDevice(ss->rank_dev[r]));

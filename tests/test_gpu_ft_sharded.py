@@ -1,0 +1,181 @@
+"""-m gpu: ft_fast merge over DOCUMENT-RANGE shards (SURVEY §8(e) "BM25": "shard by doc-id range — each GPU holds the posting fragments of
+its docs; idf uses global N and df ...; exchange = ... the uint16 pre-score histogram for the global threshold").
+
+rxgpu_ft_create_sharded / GpuFtMerger(devices=[...]): the index cut into runs of 8192-document ranges, one per listed device (the 1-GPU box
+lists device 0 several times: per-shard launch trains on their own streams, the pre-score histograms + mask popcounts and the table of
+first-met documents exchanged in one all-gather each between the kernels — a device copy here, where one device holds every shard; an
+ncclAllGather over the listed devices on a multi-GPU node — the merge slots global).
+
+Bar: the merged documents IN MERGE ORDER, raw rank bits, fields, terms counters, uint8 ranks and the preselect flag of the single-device
+merger — which tests/test_gpu_ft_terms.py holds to the restated Merger::Merge, itself pinned to the real ft::Merger — and of that restated
+merger directly: multi-term queries with AND / OR / NOT, Simple() queries, the preselect phase with ties at the threshold that straddle shard
+boundaries, the mergeLimit cut, excluded and removed documents, more shards than document ranges, one merger through many query shapes."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import FtOracle
+from .test_bm25_oracle import _multi_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ft(oracle):
+    return FtOracle(oracle)
+
+
+@pytest.fixture(scope="module")
+def hostapi(rxgpu):
+    from reindexer_amd import hostapi as h
+    h.lib()
+    return h
+
+
+def load(m, words, avg, removed, store):
+    m.set_docs(words, avg, removed)   # first: the cut of a sharded index follows the documents
+    for s in store:
+        m.set_word_fpos(s["word"], s)
+
+
+def same(a, b):
+    return (np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32)) and np.array_equal(a[2], b[2])
+            and np.array_equal(a[3], b[3]) and a[4] == b[4])
+
+
+def exchange_mode(rxgpu, m):
+    return rxgpu.lib().rxgpu_ft_shard_exchange_mode(m.device_index), rxgpu.lib().rxgpu_ft_shard_collectives(m.device_index)
+
+
+@pytest.mark.parametrize("mode", ["device", "host"])
+@pytest.mark.parametrize("shards", [2, 3, 4])
+@pytest.mark.parametrize("limit,ops,total,sizes", [
+    (20000, (1, 1), 60_000, (3000, 12_000)),          # no limit in reach: the union of the shards' documents in (row, document) order
+    (900, (1, 1, 1), 60_000, (3000, 12_000)),         # preselect: the threshold from the summed histograms, ties handed out across the shards
+    (2500, (2, 1), 60_000, (4000, 20_000)),           # AND + OR
+    (700, (2, 2), 50_000, (9000, 30_000)),
+    (20000, (1, 3, 2), 60_000, (3000, 12_000)),       # a NOT term
+    (150, (1, 3, 1), 30_000, (2000, 9000)),
+])
+def test_sharded_merge_equals_single_device_and_restated_merger(rxgpu, hostapi, ft, monkeypatch, mode, shards, limit, ops, total, sizes):
+    if mode == "host":
+        monkeypatch.setenv("RXGPU_SHARD_MERGE", "host")
+    else:
+        monkeypatch.delenv("RXGPU_SHARD_MERGE", raising=False)
+    nf = 2
+    _, words, avg, removed, excluded, terms, store = _multi_case(7000 + limit + shards + len(ops), nf, total, limit, ops, False, None, sizes=sizes)
+    one = hostapi.GpuFtMerger(nf)
+    many = hostapi.GpuFtMerger(nf, devices=[0] * shards)
+    assert rxgpu.lib().rxgpu_ft_shard_count(many.device_index) == shards
+    assert exchange_mode(rxgpu, many)[0] == (1 if mode == "device" else 0)
+    load(one, words, avg, removed, store)
+    load(many, words, avg, removed, store)
+    gterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    c0 = exchange_mode(rxgpu, many)[1]
+    merges = 0
+    for variant, (dboost, dweight) in enumerate(((1.0, 0.5), (1.7, 0.8))):
+        cfg = ft.default_config(nf, merge_limit=limit, min_rank=5 if variant == 0 else 60)
+        cfg["distance_boost"], cfg["distance_weight"] = dboost, dweight
+        for exc in (None, excluded):
+            a = one.merge_query(cfg, gterms, exc, sort_by_rank=False)
+            b = many.merge_query(cfg, gterms, exc, sort_by_rank=False)
+            merges += 1
+            assert same(a, b), (variant, exc is not None, len(a[0]), len(b[0]))
+            wd, wp, wf, wn, wpre = ft.merge_query(cfg, terms, total, words, avg, removed, exc, sort_by_rank=False, distance_boost=dboost, distance_weight=dweight)
+            assert np.array_equal(b[0], wd.astype(np.int32)) and np.array_equal(b[1].view(np.uint32), wp.view(np.uint32)) and b[4] == wpre
+            assert np.array_equal(b[2], wf) and np.array_equal(b[3], wn)
+    if mode == "device":   # one all-gather for the tables, one more for the histograms when the host half of the 2-phase gate held
+        got = exchange_mode(rxgpu, many)[1] - c0
+        assert merges <= got <= 2 * merges, (got, merges)
+    one.close()
+    many.close()
+
+
+def test_preselect_ties_at_the_threshold_cross_shard_boundaries(hostapi, ft):
+    """Every posting has the same pre-score (one sub-term per term, one proc): documents of both terms score 2 p, documents of one term p.
+    With mergeLimit between the two counts the threshold is p and only mergeLimit - (documents at 2 p) of its ~34 000 ties are kept, in
+    DOCUMENT order — shard 0's ties first, the quota that is left moves on to shard 1, 2, ...  A shard that did not take the ties of the
+    shards in front of it into account would keep too many."""
+    nf, total, limit = 1, 70_000, 26_900
+    rng = np.random.default_rng(11)
+    words = np.ones((total, nf), np.float32) * 5
+    words[0] = 0
+    avg = words[1:].mean(axis=0).astype(np.float32)
+    from oracle.pyoracle import make_fpos
+    store, terms, gterms = [], [], []
+    for t in range(2):
+        doc = np.sort(rng.choice(np.arange(1, total), 30_000, replace=False)).astype(np.uint32)
+        po = np.arange(doc.shape[0] + 1, dtype=np.uint32)
+        fp = make_fpos(rng.integers(0, 40, doc.shape[0]), np.zeros(doc.shape[0], np.int64)).astype(np.uint64)
+        s = dict(word=t, doc=doc, pos_off=po, fpos=fp, proc=100.0)
+        store.append(s)
+        o = hostapi.default_ft_opts(nf)
+        terms.append(dict(op=1, opts=o, subs=[s]))
+        gterms.append(dict(op=1, opts=o, subs=[(t, 100.0)]))
+    cfg = ft.default_config(nf, merge_limit=limit)
+    w = ft.merge_query(cfg, terms, total, words, avg, None, None, sort_by_rank=False)
+    for shards in (2, 5, 8):
+        many = hostapi.GpuFtMerger(nf, devices=[0] * shards)
+        load(many, words, avg, None, store)
+        b = many.merge_query(cfg, gterms, None, sort_by_rank=False)
+        assert b[4] and len(b[0]) == len(w[0]) <= limit
+        assert np.array_equal(b[0], w[0].astype(np.int32)) and np.array_equal(b[1].view(np.uint32), w[1].view(np.uint32)) and np.array_equal(b[3], w[3])
+        # the kept ties (documents of exactly one term) really straddle a shard boundary, and stop before the last shard
+        only_one = np.setxor1d(store[0]["doc"], store[1]["doc"])
+        kept = np.intersect1d(b[0].astype(np.uint32), only_one)
+        per = -(-9 // shards)   # 70 000 documents = 9 ranges of 8192
+        tie_shards = set((kept // 8192 // per).tolist())
+        assert (shards - 1) not in tie_shards and (len(tie_shards) > 1 or shards == 2), (shards, sorted(tie_shards), len(kept))   # (two shards: the first holds more ties than the quota)
+        many.close()
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_simple_query_and_merge_limit_cut_over_shards(hostapi, ft, shards):
+    """Merger::mergeSimple over shards: max over the sub-terms per document, the first mergeLimit documents in (sub-term row, document) order
+    — a cut that falls in the middle of the shards' documents."""
+    nf, total = 2, 50_000
+    _, words, avg, removed, excluded, terms, store = _multi_case(909, nf, total, 20000, (1,), False, None, sizes=(2000, 9000), nsub_range=(3, 6))
+    one, many = hostapi.GpuFtMerger(nf), hostapi.GpuFtMerger(nf, devices=[0] * shards)
+    load(one, words, avg, removed, store)
+    load(many, words, avg, removed, store)
+    gterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    for limit in (20000, 3000, 300):
+        cfg = ft.default_config(nf, merge_limit=limit)
+        for exc in (None, excluded):
+            a = one.merge_query(cfg, gterms, exc, sort_by_rank=False)
+            b = many.merge_query(cfg, gterms, exc, sort_by_rank=False)
+            assert same(a, b), (limit, len(a[0]), len(b[0]))
+            assert len(b[0]) <= limit
+    one.close()
+    many.close()
+
+
+def test_more_shards_than_document_ranges_and_one_merger_many_shapes(hostapi, ft):
+    """20 000 documents are three ranges: of five shards two hold nothing.  ONE sharded merger then runs wide, narrow, preselected and cut
+    queries in turn (the kept-clean tables of every shard live across merges)."""
+    nf, total = 2, 20_000
+    _, words, avg, removed, excluded, terms_all, store = _multi_case(4343, nf, total, 20000, (1, 1, 2, 1, 3, 1), False, None, sizes=(200, 3000), nsub_range=(2, 9))
+    one, many = hostapi.GpuFtMerger(nf), hostapi.GpuFtMerger(nf, devices=[0] * 5)
+    load(one, words, avg, removed, store)
+    load(many, words, avg, removed, store)
+    rng = np.random.default_rng(5)
+    for it in range(14):
+        pick = sorted(rng.choice(len(terms_all), int(rng.integers(2, len(terms_all) + 1)), replace=False).tolist())
+        terms = [terms_all[i] for i in pick]
+        if all(t["op"] == 3 for t in terms):
+            continue
+        gterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+        cfg = ft.default_config(nf, merge_limit=int(rng.choice([20000, 1500, 200, 40])))
+        exc = excluded if it % 3 == 0 else None
+        a = one.merge_query(cfg, gterms, exc, sort_by_rank=False)
+        b = many.merge_query(cfg, gterms, exc, sort_by_rank=False)
+        assert same(a, b), (it, pick, len(a[0]), len(b[0]))
+    one.close()
+    many.close()
+
+
+def test_what_a_sharded_ft_index_does_not_offer_says_so(rxgpu, hostapi, ft):
+    nf = 1
+    m = hostapi.GpuFtMerger(nf, devices=[0, 0])
+    with pytest.raises(Exception, match="rxgpu_ft_set_docs first"):
+        m.set_word_fpos(0, dict(doc=np.array([1], np.uint32), pos_off=np.array([0, 1], np.uint32), fpos=np.array([3], np.uint64), proc=1.0))
+    m.close()

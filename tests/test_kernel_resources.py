@@ -49,8 +49,8 @@ def test_bf16_gemm_instantiations_do_not_spill(tmp_path):
 def test_qreg_gemm_staging_registers_are_left_alone(tmp_path):
     """knn_gemm_bf16_qreg keeps a query stage IN FLIGHT in registers across loop iterations behind the compiler's back (inline-asm
     global_load_dwordx4 ... s_waitcnt ... ds_write_b128).  That is only sound while the compiler never touches those registers between the
-    load and the store: in every instantiation they may appear in the asm loads (destination / address), the asm stores (data) and the
-    address arithmetic in front of a load — nowhere else."""
+    load and the store: in every instantiation, walking the stage loop in program order, no instruction may name a register between the asm
+    load that targets it and the asm store that reads it."""
     from reindexer_amd.build import HIP_FLAGS
     flags = [f for f in HIP_FLAGS if f not in ("-shared",)]
     r = subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", str(CSRC / "knn_batched_bf16.hip"), "-o", str(tmp_path / "k.s")], capture_output=True, text=True)
@@ -86,21 +86,29 @@ def test_qreg_gemm_staging_registers_are_left_alone(tmp_path):
         # two stages per iteration: two barriers; the tile epilogue (its atomics) is part of the loop; an enclosing region would hold the prologue too
         lo, hi = min(regions, key=lambda r: r[1] - r[0])
         region = lines[lo:hi + 1]
-        staging = set()
-        for ln in region:
-            if ln.startswith("global_load_dwordx4"):
-                staging |= regs_of(ln.split()[1].rstrip(","))
-        assert len(staging) in (8, 16, 32), (name, sorted(staging))
-        for ln in region:
-            toks = re.findall(r"v\[\d+:\d+\]|v\d+\b", ln)
-            used = set().union(*[regs_of(t) for t in toks]) if toks else set()
-            if not (used & staging):
-                continue
-            op = ln.split()[0]
-            assert op in ("global_load_dwordx4", "ds_write_b128", "v_lshl_add_u64", "v_mov_b64_e32", "v_mov_b32_e32"), (name, ln)
-            if op in ("v_lshl_add_u64", "v_mov_b64_e32", "v_mov_b32_e32"):   # address preparation: staging registers may only be WRITTEN by it
-                srcs = set().union(*[regs_of(t) for t in toks[1:]]) if len(toks) > 1 else set()
-                assert not (srcs & staging), (name, ln)
+        # walk the loop in program order, twice (what is in flight at its end is in flight at its start): a register is IN FLIGHT from the asm
+        # load that targets it to the asm store that reads it; in between nothing else may name it
+        in_flight = set()
+        loads = stores = 0
+        for lap in range(2):
+            for ln in region:
+                toks = re.findall(r"v\[\d+:\d+\]|v\d+\b", ln)
+                op = ln.split()[0]
+                if op == "global_load_dwordx4":
+                    dst = regs_of(toks[0])
+                    addr = regs_of(toks[1]) if len(toks) > 1 else set()
+                    assert not ((dst | addr) & in_flight) or lap == 0, (name, ln)
+                    in_flight |= dst
+                    loads += lap
+                elif op == "ds_write_b128":
+                    data = regs_of(toks[1]) if len(toks) > 1 else set()
+                    assert not (regs_of(toks[0]) & in_flight), (name, ln)
+                    in_flight -= data
+                    stores += lap
+                elif toks:
+                    used = set().union(*[regs_of(t) for t in toks])
+                    assert lap == 0 or not (used & in_flight), (name, ln, sorted(used & in_flight))
+        assert loads in (4, 8) and stores == loads, (name, loads, stores)   # two stages per iteration, 2 or 4 pieces each
 
 
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="needs hipcc")
