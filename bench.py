@@ -714,7 +714,8 @@ def main():
         sync()
         t0 = time.perf_counter()
         if rank == 0:
-            for i in range(reps):
+            for j in range(reps):
+                i = j % total_q
                 for _ in range(world):
                     ix.search_knn_device(queries.data_ptr() + i * args.dim * esz, 1, kk, out_dist.data_ptr() + i * kk * esz,
                                          out_row.data_ptr() + i * kk * esz, None, stream.cuda_stream)
