@@ -148,6 +148,9 @@ const void* rxgpu_index_row_ids_device(const rxgpu_index* h);
  * (rxgpu_hybrid_fuse_resident) orders itself behind it on the device.  kk in [1, 128]. */
 int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, void** d_dist, void** d_row, void** d_count, void** stream,
 							  uint32_t* entries);
+/* Diagnostics: how many threads hold a resident context (stream + result buffers) on the index right now.  A thread that ends gives its
+ * context back to the index's pool, so the number follows the LIVE searching threads, not every thread that ever searched. */
+uint32_t rxgpu_index_resident_contexts(rxgpu_index* h);
 /* Same, device-resident in/out on `stream` (hipStream_t); d_out_count may be NULL.  No synchronisation. */
 int rxgpu_search_knn_device(rxgpu_index* h, const void* d_queries, uint32_t nq, uint32_t kk, void* d_out_dist, void* d_out_row,
 							void* d_out_count, void* stream);

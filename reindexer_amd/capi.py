@@ -61,6 +61,7 @@ _SIGNATURES = {
     "rxgpu_index_upload_row_ids": (_i, [_vp, _u64, _u64, _vp]),
     "rxgpu_index_row_ids_device": (_vp, [_vp]),
     "rxgpu_search_knn_resident": (_i, [_vp, _vp, _u32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_u32)]),
+    "rxgpu_index_resident_contexts": (_u32, [_vp]),
     "rxgpu_search_knn_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
     "rxgpu_search_knn_subset": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp]),
     "rxgpu_search_knn_bitmap": (_i, [_vp, _vp, _u32, _u32, _vp, _u64, _vp, _vp, _vp, C.POINTER(_u64)]),

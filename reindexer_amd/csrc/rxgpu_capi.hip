@@ -143,6 +143,42 @@ void release_ctx(rxgpu_index* h, rxgpu_search_ctx* c) {
 	std::lock_guard<std::mutex> lk(h->mtx);
 	h->free_ctx.push_back(c);
 }
+// Resident contexts are per calling thread (rxgpu_search_knn_resident).  Planner threads come and go: a thread that ends hands the contexts it
+// held back to the pools of the indexes that still exist — looked up by serial number, never through a pointer the thread kept — so short-lived
+// threads neither pile up streams + device buffers until rxgpu_index_destroy nor leave their context to a later thread that got the same id.
+std::mutex g_live_mtx;
+std::map<uint64_t, rxgpu_index*> g_live_indexes;
+std::atomic<uint64_t> g_index_serial{0};
+struct ResidentThread {
+	std::vector<uint64_t> used;
+	~ResidentThread() {
+		std::lock_guard<std::mutex> live(g_live_mtx);
+		for (uint64_t serial : used) {
+			auto it = g_live_indexes.find(serial);
+			if (it == g_live_indexes.end()) continue;
+			rxgpu_index* h = it->second;
+			rxgpu_search_ctx* c = nullptr;
+			{
+				std::lock_guard<std::mutex> lk(h->resident_mtx);
+				auto slot = h->resident_ctx.find(std::this_thread::get_id());
+				if (slot == h->resident_ctx.end()) continue;
+				c = slot->second;
+				h->resident_ctx.erase(slot);
+			}
+			if (c) release_ctx(h, c);   // its stream orders the next user's work behind whatever this thread left running
+		}
+	}
+};
+thread_local ResidentThread t_resident;
+void register_live_index(rxgpu_index* h) {
+	std::lock_guard<std::mutex> live(g_live_mtx);
+	h->serial = ++g_index_serial;
+	g_live_indexes[h->serial] = h;
+}
+void unregister_live_index(rxgpu_index* h) {
+	std::lock_guard<std::mutex> live(g_live_mtx);
+	g_live_indexes.erase(h->serial);
+}
 // Scratch bound to a caller-owned stream: stream order makes reuse safe without synchronising.
 rxgpu_search_ctx* stream_ctx(rxgpu_index* h, void* stream) {
 	std::lock_guard<std::mutex> lk(h->mtx);
@@ -703,6 +739,7 @@ int rxgpu_index_create(int metric, uint32_t dim, uint64_t capacity, int device, 
 			return rc;
 		}
 	}
+	register_live_index(h);
 	return RXGPU_OK;
 }
 
@@ -713,6 +750,7 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 		delete h;
 		return;
 	}
+	unregister_live_index(h);   // from here on an ending thread leaves this index alone
 	DeviceGuard dg(h->device);
 	(void)hipDeviceSynchronize();
 	for (auto& kv : h->resident_ctx) h->free_ctx.push_back(kv.second);
@@ -976,7 +1014,10 @@ int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, v
 	{   // this thread's resident context (created on its first resident search; searches of one thread are sequential)
 		std::lock_guard<std::mutex> lk(h->resident_mtx);
 		rxgpu_search_ctx*& slot = h->resident_ctx[std::this_thread::get_id()];
-		if (!slot) slot = acquire_ctx(h);
+		if (!slot) {
+			slot = acquire_ctx(h);
+			if (slot) t_resident.used.push_back(h->serial);
+		}
 		c = slot;
 	}
 	if (!c) return RXGPU_ERR_DEVICE;
@@ -1001,6 +1042,12 @@ int rxgpu_search_knn_resident(rxgpu_index* h, const float* query, uint32_t kk, v
 	*stream = c->stream;
 	*entries = eff;
 	return RXGPU_OK;
+}
+
+uint32_t rxgpu_index_resident_contexts(rxgpu_index* h) {
+	if (!h || h->shard_set) return 0;
+	std::lock_guard<std::mutex> lk(h->resident_mtx);
+	return uint32_t(h->resident_ctx.size());
 }
 
 int rxgpu_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t kk, float* out_dist, uint32_t* out_row,

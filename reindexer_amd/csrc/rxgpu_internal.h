@@ -480,8 +480,10 @@ struct rxgpu_index {
 	uint64_t row_ids_cap = 0;
 	// rxgpu_search_knn_resident: the result stays in the context's buffers for a consumer on the device.  One context per CALLING THREAD:
 	// the list a thread left in HBM lives until that thread's next resident search, whatever other threads search meanwhile.
+	// A thread that ends gives its context back to the pool (rxgpu_capi.hip: ResidentThread), found through `serial` in the table of live indexes.
 	std::map<std::thread::id, rxgpu_search_ctx*> resident_ctx;
 	std::mutex resident_mtx;
+	uint64_t serial = 0;
 
 	bool profiling = false;
 	std::map<std::string, rxgpu_profile_slot> profile;

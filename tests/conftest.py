@@ -17,6 +17,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_runtest_logreport(report):
+    """RXGPU_TEST_TIMES=<file>: one line per finished test (outcome, seconds, node id), flushed at once — what a run that is cut short
+    (a `timeout` around pytest on the GPU box) still leaves behind."""
+    path = os.environ.get("RXGPU_TEST_TIMES")
+    if path and report.when == "call":
+        with open(path, "a") as f:
+            f.write(f"{report.outcome} {report.duration:8.2f} {report.nodeid}\n")
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle.pyoracle import Oracle

@@ -172,3 +172,42 @@ def test_concurrent_hybrid_queries_and_plain_merges_on_one_text_index(rxgpu, ora
     assert all(_run_threads(7, fn))
     vm.close()
     ftm.close()
+
+
+def test_resident_contexts_follow_the_live_threads(rxgpu):
+    """rxgpu_search_knn_resident keeps a stream + result buffers per calling thread.  Planner threads are short-lived: a thread that ends
+    hands its context back to the index's pool, so 40 threads that searched one after another leave no context behind (and the pool did
+    not grow to 40 either: each newcomer takes over what its predecessor returned); threads that are alive at once each hold their own."""
+    import torch
+    n, d, k = 20_000, 64, 5
+    rows = make_corpus(91, n, d)
+    queries = make_corpus(92, 48, d)
+    lib = rxgpu.lib()
+    with rxgpu.VectorIndex("l2", d, n) as ix:
+        ix.upload_rows(0, rows)
+        want = [ix.search_knn(queries[i:i + 1], k) for i in range(48)]
+
+        def one(i):
+            dd, dr, dc, st, cnt = ix.search_knn_resident(queries[i], k)
+            torch.cuda.synchronize()   # the search was only enqueued
+            return cnt
+
+        for i in range(40):   # one after another, each in a thread of its own
+            assert _run_threads(1, lambda t, i=i: one(i))[0] == k
+            assert lib.rxgpu_index_resident_contexts(ix._h) == 0
+        assert one(40) == k and lib.rxgpu_index_resident_contexts(ix._h) == 1   # the calling thread stays alive and keeps its context
+        gate = threading.Barrier(8)
+
+        def alive(t):
+            one(t)
+            gate.wait()
+            held = lib.rxgpu_index_resident_contexts(ix._h)
+            gate.wait()
+            return held
+
+        assert all(h == 9 for h in _run_threads(8, alive))   # eight live threads + the main one
+        assert lib.rxgpu_index_resident_contexts(ix._h) == 1
+        # and the plain searches still give the sequential results out of the recycled contexts
+        for i in (0, 17, 47):
+            dist, row, cnt = ix.search_knn(queries[i:i + 1], k)
+            assert np.array_equal(row, want[i][1]) and np.array_equal(dist.view(np.uint32), want[i][0].view(np.uint32))
