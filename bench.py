@@ -386,7 +386,8 @@ def batched_leg(args, ix, queries: torch.Tensor, device, kk: int):
     peak = 2500.0 if bf16 else 157.3
     roof = {"bound": "mfma", "achieved": flops / (gemm_ms / 1e3) / 1e12 if n_gemm else None, "peak": peak, "unit": "TFLOP/s",
             "frac": flops / (gemm_ms / 1e3) / 1e12 / peak if n_gemm else None,
-            "kernel": ("knn_gemm_bf16_split<FILTER>" if os.environ.get("RXGPU_GEMM_SPLIT", "1") != "0" else "knn_gemm_bf16_glds<FILTER>") if bf16 else "knn_gemm<FILTER>", "avg_ms": gemm_ms, "launches": n_gemm,
+            "kernel": ("knn_gemm_bf16_qreg<FILTER>" if os.environ.get("RXGPU_GEMM_QREG", "1") != "0" and os.environ.get("RXGPU_GEMM_SPLIT", "1") != "0"
+                       else "knn_gemm_bf16_split<FILTER>" if os.environ.get("RXGPU_GEMM_SPLIT", "1") != "0" else "knn_gemm_bf16_glds<FILTER>") if bf16 else "knn_gemm<FILTER>", "avg_ms": gemm_ms, "launches": n_gemm,
             "dtype": "bf16 nomination (v_mfma_f32_32x32x16_bf16) + exact f32 re-score" if bf16 else "f32 (v_mfma_f32_32x32x2_f32)"}
     if bf16 and n_gemm:
         shadow = float(args.rows) * kpad * 2

@@ -2,7 +2,10 @@
 // document-range shards), resolved once by the first index that asks.
 #pragma once
 
+#include <memory>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include <rccl/rccl.h>   // types and prototypes only
 
@@ -23,5 +26,17 @@ struct RcclApi {
 };
 
 const RcclApi& rccl_api();   // rxgpu_sharded.hip
+
+// The communicators over one list of distinct devices, shared by every sharded index of the process over that list and kept until the
+// process ends: ncclCommInitAll costs hundreds of milliseconds, proxy threads and device buffers per communicator, and namespaces (and
+// tests) create and drop indexes all the time — an index takes the set that is there instead of building and tearing down its own.
+// Collectives of one communicator are enqueued in one order: `mtx` is held from ncclGroupStart to ncclGroupEnd (the enqueue, not the run).
+struct RcclCommSet {
+	std::vector<int> devices;
+	std::vector<ncclComm_t> comms;   // comms[r] on devices[r]
+	std::mutex mtx;
+};
+// nullptr + *why when RCCL is not there or ncclCommInitAll fails (the caller falls back to the host path)
+std::shared_ptr<RcclCommSet> rccl_comm_set(const std::vector<int>& devices, std::string* why);   // rxgpu_sharded.hip
 
 }  // namespace rxgpu

@@ -183,7 +183,7 @@ struct rxgpu_ft_shard_set {
 	uint32_t nranks = 0, slots = 0;
 	std::vector<int> rank_dev;
 	std::vector<uint32_t> shard_rank, shard_slot, pos;   // pos[s] = rank * slots + slot: where shard s lies in a gathered buffer
-	std::vector<ncclComm_t> comms;          // one per rank when the shards span several devices (RCCL); empty otherwise
+	std::shared_ptr<rxgpu::RcclCommSet> cs; // the process-wide communicators over rank_dev when the shards span several devices (rccl_dyn.h); else null
 	bool host_exchange = false;             // RXGPU_SHARD_MERGE=host, or several devices without RCCL (note says why): the pieces travel through the host
 	std::string note;
 	std::vector<hipStream_t> rstream;       // per rank
@@ -191,7 +191,6 @@ struct rxgpu_ft_shard_set {
 	std::vector<uint32_t*> d_pos;           // per rank: pos[] on the device
 	std::vector<rxgpu_devbuf> d_send[2], d_recv[2];   // per rank; [0] histograms, [1] adder tables
 	uint64_t collectives = 0, merges = 0;
-	std::mutex coll_mtx;
 };
 
 
@@ -329,18 +328,8 @@ int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* 
 		ss->host_exchange = true;
 		ss->note = "RXGPU_SHARD_MERGE=host";
 	} else if (ss->nranks > 1) {
-		const rxgpu::RcclApi& api = rxgpu::rccl_api();
-		if (!api.why.empty()) {
-			ss->note = "RCCL unavailable: " + api.why;
-		} else {
-			ss->comms.assign(ss->nranks, nullptr);
-			const ncclResult_t nr = api.ncclCommInitAll(ss->comms.data(), int(ss->nranks), ss->rank_dev.data());
-			if (nr != ncclSuccess) {
-				ss->note = std::string("ncclCommInitAll over ") + std::to_string(ss->nranks) + " device(s): " + api.ncclGetErrorString(nr);
-				ss->comms.clear();
-			}
-		}
-		if (!ss->note.empty()) {
+		ss->cs = rxgpu::rccl_comm_set(ss->rank_dev, &ss->note);
+		if (!ss->cs) {
 			ss->host_exchange = true;
 			fprintf(stderr, "rxgpu: sharded ft index over %u device slot(s): %s — the shards' histograms and tables travel through the host\n", n_devices, ss->note.c_str());
 		}
@@ -1473,9 +1462,6 @@ void ft_shards_destroy(rxgpu_ft_shard_set* ss) {
 			(void)hipEventDestroy(ss->ev_shard[s]);
 		}
 	}
-	for (ncclComm_t c : ss->comms) {
-		if (c) (void)rxgpu::rccl_api().ncclCommDestroy(c);
-	}
 	delete ss;
 }
 
@@ -1493,12 +1479,12 @@ int ft_shards_gather(rxgpu_ft_shard_set* ss, int k, size_t bytes) {
 			if (ss->shard_rank[s] == r) RX_HIP(hipStreamWaitEvent(ss->rstream[r], ss->ev_shard[s], 0));
 		}
 	}
-	if (!ss->comms.empty()) {
+	if (ss->cs) {
 		const rxgpu::RcclApi& api = rxgpu::rccl_api();
-		std::lock_guard<std::mutex> lk(ss->coll_mtx);
+		std::lock_guard<std::mutex> lk(ss->cs->mtx);
 		ncclResult_t nr = api.ncclGroupStart();
 		for (uint32_t r = 0; r < ss->nranks && nr == ncclSuccess; ++r) {
-			nr = api.ncclAllGather(ss->d_send[k][r].ptr, ss->d_recv[k][r].ptr, bytes / 4 * ss->slots, ncclUint32, ss->comms[r], ss->rstream[r]);
+			nr = api.ncclAllGather(ss->d_send[k][r].ptr, ss->d_recv[k][r].ptr, bytes / 4 * ss->slots, ncclUint32, ss->cs->comms[r], ss->rstream[r]);
 		}
 		const ncclResult_t ne = api.ncclGroupEnd();
 		if (nr == ncclSuccess) nr = ne;

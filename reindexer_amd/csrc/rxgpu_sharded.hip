@@ -74,6 +74,33 @@ const RcclApi& rccl_api() {
 	return api;
 }
 
+std::shared_ptr<RcclCommSet> rccl_comm_set(const std::vector<int>& devices, std::string* why) {
+	static std::mutex pool_mtx;
+	static std::vector<std::shared_ptr<RcclCommSet>>* pool = new std::vector<std::shared_ptr<RcclCommSet>>();   // never torn down: no RCCL calls at exit
+	const RcclApi& api = rccl_api();
+	if (!api.why.empty()) {
+		if (why) *why = "RCCL unavailable: " + api.why;
+		return nullptr;
+	}
+	std::lock_guard<std::mutex> lk(pool_mtx);
+	for (const auto& cs : *pool) {
+		if (cs->devices == devices) return cs;
+	}
+	auto cs = std::make_shared<RcclCommSet>();
+	cs->devices = devices;
+	cs->comms.assign(devices.size(), nullptr);
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	const ncclResult_t nr = api.ncclCommInitAll(cs->comms.data(), int(devices.size()), devices.data());
+	if (prev >= 0) (void)hipSetDevice(prev);
+	if (nr != ncclSuccess) {
+		if (why) *why = std::string("ncclCommInitAll over ") + std::to_string(devices.size()) + " device(s): " + api.ncclGetErrorString(nr);
+		return nullptr;
+	}
+	pool->push_back(cs);
+	return cs;
+}
+
 // A small pool of worker threads per shard (the shard's device stays current on them) behind one job queue: fan-outs of concurrent
 // callers queue up per shard and overlap — the single-device entry points are re-entrant (a search context and stream per call) — so
 // no lock is held across a fan-out.  Searches share `call_mtx`, mutations take it exclusively (the reference's namespace lock above us
@@ -121,12 +148,11 @@ struct ExchangeLane {
 struct ShardExchange {
 	uint32_t nranks = 0, slots = 0;
 	std::vector<int> rank_dev;
-	std::vector<ncclComm_t> comms;
+	std::shared_ptr<RcclCommSet> cs;   // the process-wide communicators over rank_dev (rccl_dyn.h)
 	std::vector<uint32_t> shard_rank, shard_slot;
 	uint32_t* d_slot_base = nullptr;   // on rank_dev[0]: global row base of every gathered position
 	std::mutex mtx;                    // lane pool
 	std::vector<ExchangeLane*> free_lanes;
-	std::mutex coll_mtx;               // collectives of one communicator are enqueued in one order
 	std::atomic<uint64_t> collectives{0};
 };
 
@@ -284,9 +310,6 @@ void exchange_destroy(ShardExchange* x) {
 	if (!x) return;
 	CurrentDevice cd;
 	for (ExchangeLane* l : x->free_lanes) free_lane(x, l);
-	for (ncclComm_t c : x->comms) {
-		if (c) (void)rccl_api().ncclCommDestroy(c);
-	}
 	if (x->d_slot_base) {
 		(void)hipSetDevice(x->rank_dev[0]);
 		(void)hipFree(x->d_slot_base);
@@ -313,18 +336,11 @@ int exchange_create(ShardSet* ss, uint32_t n_devices, const int* devices, ShardE
 	x->nranks = uint32_t(x->rank_dev.size());
 	x->slots = *std::max_element(per_rank.begin(), per_rank.end());
 	CurrentDevice cd;
-	const RcclApi& api = rccl_api();
-	if (!api.why.empty()) {
-		set_error("RCCL unavailable: " + api.why);
+	std::string why;
+	x->cs = rccl_comm_set(x->rank_dev, &why);
+	if (!x->cs) {
+		set_error(why);
 		delete x;
-		return RXGPU_ERR_DEVICE;
-	}
-	x->comms.assign(x->nranks, nullptr);
-	const ncclResult_t nr = api.ncclCommInitAll(x->comms.data(), int(x->nranks), x->rank_dev.data());
-	if (nr != ncclSuccess) {
-		set_error(std::string("ncclCommInitAll over ") + std::to_string(x->nranks) + " device(s): " + api.ncclGetErrorString(nr));
-		x->comms.clear();
-		exchange_destroy(x);
 		return RXGPU_ERR_DEVICE;
 	}
 	std::vector<uint32_t> base(size_t(x->nranks) * x->slots, kInvalidRow);
@@ -348,11 +364,11 @@ int exchange_gather_merge(ShardSet* ss, ExchangeLane* l, uint32_t nq, uint32_t k
 	const size_t list_words = size_t(2) * nq * kk;
 	const size_t out_bytes = (size_t(2) * nq * kk + nq) * sizeof(uint32_t);
 	{
-		std::lock_guard<std::mutex> lk(x->coll_mtx);
+		std::lock_guard<std::mutex> lk(x->cs->mtx);
 		const RcclApi& api = rccl_api();
 		SH_NCCL(api.ncclGroupStart());
 		for (uint32_t r = 0; r < x->nranks; ++r) {
-			const ncclResult_t nr = api.ncclAllGather(l->d_local[r].ptr, l->d_gathered[r].ptr, list_words * x->slots, ncclUint32, x->comms[r], l->stream[r]);
+			const ncclResult_t nr = api.ncclAllGather(l->d_local[r].ptr, l->d_gathered[r].ptr, list_words * x->slots, ncclUint32, x->cs->comms[r], l->stream[r]);
 			if (nr != ncclSuccess) {
 				(void)api.ncclGroupEnd();
 				set_error(std::string("ncclAllGather: ") + api.ncclGetErrorString(nr));
