@@ -3,7 +3,7 @@
 pass, 256-query tile) the average per-launch value of every counter collected, the kernel's average duration from the kernel trace of the
 same runs, and the derived fractions (matrix-core busy share of the SIMD cycles, wait share of the wave cycles, HBM bytes by the gfx950
 FETCH_SIZE rule: KB units, x2 for 16-byte-per-lane loads as in MI355X_MICROARCH.md).
-    python tools/summarize_gemm_pmc.py <dir with pass subdirs> <out.json>"""
+    python tools/summarize_gemm_pmc.py <dir with pass subdirs> <out.json> ["<source line>"]"""
 import collections
 import csv
 import glob
@@ -45,7 +45,8 @@ def main():
         if "FETCH_SIZE" in e:
             e["hbm_read_GB_corrected"] = e["FETCH_SIZE"] * 1024.0 * 2.0 / 1e9
         res[k] = e
-    json.dump({"source": "rocprofv3 --kernel-trace --pmc <one set per pass>, tools/bench_gemm_ab.py --metrics ip --rounds 1 --iters 2 --modes split_ring_blocked_shadow,single_ring_blocked_shadow (10M x 768, 256 queries; tile-blocked bf16 shadow)",
+    source = sys.argv[3] if len(sys.argv) > 3 else None
+    json.dump({"source": source or "rocprofv3 --kernel-trace --pmc <one set per pass>, tools/bench_gemm_ab.py --metrics ip --rounds 1 --iters 2 --modes split_ring_blocked_shadow,single_ring_blocked_shadow (10M x 768, 256 queries; tile-blocked bf16 shadow)",
                "kernels": res}, open(out, "w"), indent=1)
     for k, e in res.items():
         print(k[:70], {x: (round(y, 4) if isinstance(y, float) else y) for x, y in e.items() if x != "launches_per_counter"})
