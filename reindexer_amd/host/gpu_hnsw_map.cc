@@ -489,11 +489,13 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 		std::unique_lock<std::mutex> lk(coMtx_);
 		coQueue_.push_back(&p);
 		while (!p.done) {
-			// Up to kMaxLeaders batches in flight at once (round 5; it was one).  A search is a chain of ~140 dependent hops on ONE wavefront:
-			// a batch of 8 takes as long as a batch of 1 and leaves the chip empty, so with a single leader T planner threads saw
-			// T / (2 x latency) — 4.7 k q/s from 16 threads at 10M x 768 against 13.7 k for the reference's 16 cores.  Every leader's call has a
-			// stream and buffers of its own inside the library (the C-ABI is re-entrant), so the batches overlap on the device.
-			if (coLeaders_ >= kMaxLeaders || coQueue_.empty()) {
+			// How many batches at once?  Measured at 1M x 768 (tools/bench_hnsw_nq_sweep.py, profiles/rd5_hnsw_nq_sweep*.json): one call costs
+			// 0.60 ms for 1 query, 0.75 for 8, 1.25 for 128, 2.3 for 1024 — a search is a chain of ~140 dependent hops on one wavefront, so a
+			// batch is nearly free until the chip fills — but calls of different threads overlap only in part on the device.  T = 16 / 64 / 256
+			// planner threads: one lane 9 / 28 / 66-70 k q/s, FOUR 12 / 34-37 / 57-75 k, eight 8-9 / 15-23 / 37-55 k, sixteen 6 / 6 / 9 k (the
+			// reference's 16 cores on the same graph: 39 k).  A rule that made a long queue wait for an empty device so as to leave as one
+			// batch lost the overlap and measured worse than any fixed number.
+			if (coLeaders_ >= coLanes_ || coQueue_.empty()) {
 				coCv_.wait(lk);
 				continue;
 			}

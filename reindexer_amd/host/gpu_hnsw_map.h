@@ -105,6 +105,8 @@ public:
 	// one launch of the batched search kernel (a wavefront per query) instead of one single-wavefront launch each.
 	void EnableQueryCoalescing(bool on) noexcept { coalesce_ = on; }
 	size_t CoalescedBatches() const noexcept { return coBatches_; }
+	// device batches the coalescer keeps in flight at once (1 .. 64; default kMaxLeaders)
+	void SetCoalescerLanes(unsigned lanes) noexcept { coLanes_ = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes); }
 	// searches the device re-ran on its heap kernel because the sorted-list search met equal distances (rxgpu_hnsw_read_tie_reruns); resets
 	uint64_t TieReruns() const;
 	// searches whose candidate heap outgrew the LDS area of their first pass and ran again with the largest one (rxgpu_hnsw_read_lds_reruns); resets
@@ -187,7 +189,8 @@ private:
 	mutable std::mutex coMtx_;
 	mutable std::condition_variable coCv_;
 	mutable std::deque<PendingQuery*> coQueue_;
-	static constexpr unsigned kMaxLeaders = 8;   // device batches of the coalescer in flight at once
+	static constexpr unsigned kMaxLeaders = 4;   // device batches of the coalescer in flight at once (gpu_hnsw_map.cc: fetchKnn)
+	unsigned coLanes_ = kMaxLeaders;
 	mutable unsigned coLeaders_ = 0;
 	mutable size_t coBatches_ = 0;
 	bool ownsDev_ = true;                 // false: a shard (the device index belongs to the sharded handle) or the Map over a device list itself

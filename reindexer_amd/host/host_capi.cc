@@ -754,6 +754,7 @@ void rxhost_hnsw_knn_stream_end(void* h, void* session) {
 
 extern "C" {
 void rxhost_hnsw_enable_coalescing(void* h, int on) { static_cast<GpuHnswMap*>(h)->EnableQueryCoalescing(on != 0); }
+void rxhost_hnsw_set_coalescer_lanes(void* h, unsigned lanes) { static_cast<GpuHnswMap*>(h)->SetCoalescerLanes(lanes); }
 void rxhost_bf_enable_coalescing(void* h, int on) { static_cast<GpuBruteforceMap*>(h)->EnableQueryCoalescing(on != 0); }
 void rxhost_bf_coalescing_stats(void* h, uint64_t* batches, uint64_t* queries) {
 	*batches = static_cast<const GpuBruteforceMap*>(h)->CoalescedBatches();

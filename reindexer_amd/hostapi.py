@@ -652,6 +652,11 @@ class GpuHnswMap:
             _raise()
         return od[:n].copy(), ol[:n].copy()
 
+    def set_coalescer_lanes(self, lanes: int) -> None:
+        """Device batches the query coalescer keeps in flight at once (GpuHnswMap::SetCoalescerLanes)."""
+        lib().rxhost_hnsw_set_coalescer_lanes.argtypes = [_vp, C.c_uint]
+        lib().rxhost_hnsw_set_coalescer_lanes(self.h, int(lanes))
+
     def search_knn_mt(self, queries, k: int, ef: int, threads: int, per_thread: int, deadline_s: float = 30.0):
         """T native planner threads, one query per SearchKnn call each, over this shared Map (the reference's concurrency model).
         -> (seconds, searches completed, device batches the coalescer ran)."""
