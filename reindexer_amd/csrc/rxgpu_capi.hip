@@ -1927,12 +1927,50 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	if (split_upload) {
 		if (int rc = c->ensure_aux(); rc) return rc;
 	}
-	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, queries, size_t(first_half) * h->dim * qelem, hipMemcpyHostToDevice, c->stream));
+	// Small calls — the Map's single queries and its coalesced batches — move their queries and results through the context's PINNED buffer.
+	// A copy between pageable memory and the device goes through the runtime's own staging, one call after the other whatever their
+	// streams: T planner threads then queue up in the copies on both sides of a 0.5 ms kernel.  (Large batches keep the direct copies:
+	// they are the bandwidth case, and the two-halves upload overlaps them with the searches.)
+	const size_t up_bytes = (size_t(nq) * h->dim * qelem + 15) & ~size_t(15);
+	const size_t st_corr = up_bytes, st_norm = st_corr + size_t(nq) * 4, st_count = st_norm + size_t(nq) * 4, st_dist = st_count + size_t(nq) * 4,
+				 st_row = st_dist + size_t(nq) * k * 4, st_end = st_row + size_t(nq) * k * 4;
+	const bool staged = !split_upload && st_end <= (size_t(1) << 20);
+	const void* up_queries = queries;
+	const float *up_qcorr = qcorr, *up_qnorm = qnorm;
+	uint32_t* dl_count = out_count;
+	float* dl_dist = out_dist;
+	uint32_t* dl_row = out_row;
+	if (staged) {
+		if (int rc = c->ensure_pinned(st_end); rc) return rc;
+		char* hp = static_cast<char*>(c->h_pinned);
+		std::memcpy(hp, queries, size_t(nq) * h->dim * qelem);
+		up_queries = hp;
+		if (sq8) {
+			std::memcpy(hp + st_corr, qcorr, size_t(nq) * 4);
+			std::memcpy(hp + st_norm, qnorm, size_t(nq) * 4);
+			up_qcorr = reinterpret_cast<const float*>(hp + st_corr);
+			up_qnorm = reinterpret_cast<const float*>(hp + st_norm);
+		}
+		dl_count = reinterpret_cast<uint32_t*>(hp + st_count);
+		dl_dist = reinterpret_cast<float*>(hp + st_dist);
+		dl_row = reinterpret_cast<uint32_t*>(hp + st_row);
+	}
+	auto done_host = [&]() -> int {   // (behind the last hipStreamSynchronize) what was staged goes to the caller's arrays
+		if (staged) {
+			std::memcpy(out_count, dl_count, size_t(nq) * 4);
+			if (to_host) {
+				std::memcpy(out_dist, dl_dist, size_t(nq) * k * 4);
+				std::memcpy(out_row, dl_row, size_t(nq) * k * 4);
+			}
+		}
+		return RXGPU_OK;
+	};
+	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, up_queries, size_t(first_half) * h->dim * qelem, hipMemcpyHostToDevice, c->stream));
 	rxgpu::HnswParams p{};
 	if (sq8) {
 		char* qb = static_cast<char*>(c->d_queries.ptr);
-		RX_HIP(hipMemcpyAsync(qb + o_qcorr, qcorr, size_t(nq) * 4, hipMemcpyHostToDevice, c->stream));
-		RX_HIP(hipMemcpyAsync(qb + o_qnorm, qnorm, size_t(nq) * 4, hipMemcpyHostToDevice, c->stream));
+		RX_HIP(hipMemcpyAsync(qb + o_qcorr, up_qcorr, size_t(nq) * 4, hipMemcpyHostToDevice, c->stream));
+		RX_HIP(hipMemcpyAsync(qb + o_qnorm, up_qnorm, size_t(nq) * 4, hipMemcpyHostToDevice, c->stream));
 		p.codes = h->d_codes;
 		p.corr = h->d_corr;
 		p.alpha2 = h->sq8_alpha2;
@@ -1970,7 +2008,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		rxgpu::launch_pack_lists(p.out_dist, p.out_row, p.out_count, nq, k, sink->kk, sink->d_dist, sink->d_row, c->stream);
 		RX_HIP(hipGetLastError());
 		RX_HIP(hipStreamSynchronize(c->stream));
-		return RXGPU_OK;
+		return done_host();   // (the counts)
 	};
 	// typical candidate heaps stay within a few x ef.  Measured at 1M x 768, ef = 128: 512 entries overflow for a handful of queries and the
 	// global-heap re-run costs more than the extra occupancy brings (1.07 M q/s at 1024 against 0.43 M at 512 and 0.86 M at 768)
@@ -2110,10 +2148,10 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			RX_HIP(hipMemcpyAsync(&helper_n, hq_words, sizeof(helper_n), hipMemcpyDeviceToHost, c->stream));
 		}
 		// counts and results travel together: a batch without re-runs (the common case for a handful of queries) is done after ONE wait
-		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		if (to_host) {
-			RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-			RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpyAsync(dl_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpyAsync(dl_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		}
 		RX_HIP(hipStreamSynchronize(c->stream));
 		const uint32_t helper_queued = std::min<uint32_t>(helper_n, kHelperCap);
@@ -2121,10 +2159,10 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		std::vector<uint32_t> ties;
 		bool clean = true;
 		for (uint32_t q = 0; q < nq; ++q) {
-			if (out_count[q] == rxgpu::kHnswTie) ties.push_back(q);
-			clean = clean && out_count[q] != rxgpu::kHnswTie && out_count[q] != rxgpu::kHnswOverflow;
+			if (dl_count[q] == rxgpu::kHnswTie) ties.push_back(q);
+			clean = clean && dl_count[q] != rxgpu::kHnswTie && dl_count[q] != rxgpu::kHnswOverflow;
 		}
-		if (clean) return to_host ? RXGPU_OK : to_sink();
+		if (clean) return to_host ? done_host() : to_sink();
 		if (!ties.empty()) {   // equal keys met in the sorted list: the same queries through the reference's heaps (candidate heap in LDS)
 			h->hnsw_tie_reruns += ties.size();
 			if (int rc = c->d_redo.ensure(ties.size() * sizeof(uint32_t)); rc) return rc;
@@ -2143,7 +2181,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 				rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 			}
 			RX_HIP(hipGetLastError());
-			RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 			RX_HIP(hipStreamSynchronize(c->stream));
 		}
 		// Queries whose candidate heap outgrew its LDS area — 600 entries for a search that started over inside the sorted-list kernel, 1024 for
@@ -2152,7 +2190,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		// (profiles/rd4i_hnsw_10m_*.json: ONE such query was a fifth of a 16 384-query batch), one in LDS about 1 ms.
 		std::vector<uint32_t> over;
 		for (uint32_t q = 0; q < nq; ++q) {
-			if (out_count[q] == rxgpu::kHnswOverflow) over.push_back(q);
+			if (dl_count[q] == rxgpu::kHnswOverflow) over.push_back(q);
 		}
 		const uint32_t first_cap = use_sorted ? sorted_restart_cap : p.lds_cand_cap;
 		if (!over.empty() && first_cap < uint32_t(rxgpu::kHnswCandLds) && !getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // (the hook forces the global tiers)
@@ -2172,14 +2210,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 				rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 			}
 			RX_HIP(hipGetLastError());
-			RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 			RX_HIP(hipStreamSynchronize(c->stream));
 			// searches the helpers had queued but not finished are in `over` again: counted once
 			h->hnsw_lds_reruns += over.size() > helper_queued ? over.size() - helper_queued : 0;
 		}
 		// ... and what still does not fit: re-run with the heap in global scratch (bounded by one entry per node)
 		for (const uint32_t q : over) {
-			if (out_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
+			if (dl_count[q] == rxgpu::kHnswOverflow) redo.push_back(q);
 		}
 	}
 	// Re-runs with the candidate heap in global scratch, in two tiers: 64 K entries first (0.5 MB per search: hundreds of re-runs share one
@@ -2208,20 +2246,20 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			rxgpu::launch_hnsw_search(h->metric, pc, cq, true, c->stream);
 		}
 		RX_HIP(hipGetLastError());
-		RX_HIP(hipMemcpyAsync(out_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 		RX_HIP(hipStreamSynchronize(c->stream));
 		std::vector<uint32_t> again;
 		for (const uint32_t q : redo) {
-			if (out_count[q] == rxgpu::kHnswOverflow) again.push_back(q);
+			if (dl_count[q] == rxgpu::kHnswOverflow) again.push_back(q);
 		}
 		redo.swap(again);
 	}
 	RX_CHECK(redo.empty(), RXGPU_ERR_DEVICE, "rxgpu_hnsw_search_knn: a candidate heap of one entry per node overflowed");
 	if (!to_host) return to_sink();
-	RX_HIP(hipMemcpyAsync(out_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-	RX_HIP(hipMemcpyAsync(out_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipMemcpyAsync(dl_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+	RX_HIP(hipMemcpyAsync(dl_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 	RX_HIP(hipStreamSynchronize(c->stream));
-	return RXGPU_OK;
+	return done_host();
 }
 
 // ---------------------------------------------------------------------------------------------- SearchRange, expansion on the device
