@@ -27,8 +27,13 @@ def main():
     ap.add_argument("--lanes", default="1,2,3,4,8,16")
     ap.add_argument("--threads", default="16,64,256")
     ap.add_argument("--short", action="store_true", help="four call sizes only")
+    ap.add_argument("--blocking-sync", action="store_true", help="hipDeviceScheduleBlockingSync: host waits do not spin")
     ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "hnsw_nq_sweep.json"))
     a = ap.parse_args()
+    if a.blocking_sync:   # hipDeviceScheduleBlockingSync before the first HIP call of the process: waits sleep on an interrupt instead of spinning
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        print("hipSetDeviceFlags(hipDeviceScheduleBlockingSync) ->", hip.hipSetDeviceFlags(ctypes.c_uint(4)), flush=True)
     nqmax = 4096
     corpus = bench_hnsw.make_clustered(a.rows + nqmax, a.dim, 2000, 20260924, 0)
     rows, queries = corpus[:a.rows], corpus[a.rows:]
