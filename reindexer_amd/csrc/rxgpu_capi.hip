@@ -2047,7 +2047,24 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		// Helper workgroups beside a large batch (hnsw_helper_kernel, second stream): a search that overflows its LDS heap area is queued and
 		// runs with the largest LDS heap while the batch is still going, instead of as a launch of its own behind it.  RXGPU_HNSW_HELPER=0: off.
 		constexpr uint32_t kHelperGroups = 64, kHelperCap = 4096;
-		const bool use_helper = helper_wanted;
+		// ONE batch at a time has helpers, and only a batch that is one chunk.  A helper polls until ITS batch is over; HIP streams share a
+		// few hardware queues, so with two callers at it helper A can sit in front of batch B's kernels while helper B sits in front of
+		// batch A's — each waits for a batch that cannot start, until the helpers' wall-clock bail-out (seconds: four threads with 2300-query
+		// batches measured 3 s calls, tests/test_gpu_hnsw_visited.py).  With a single set of helpers in flight nothing that spins ever waits
+		// for work queued behind another spinner; the callers that come second run their overflowing searches behind their batch, as batches
+		// below 2048 queries always do.  (The same inside one call: the kernels of a second chunk would queue up behind its own helpers.)
+		static std::atomic<bool> helpers_in_flight{false};
+		struct HelperLease {
+			bool held = false;
+			~HelperLease() {
+				if (held) helpers_in_flight.store(false, std::memory_order_release);
+			}
+		} helper_lease;
+		if (helper_wanted && uint64_t(nq) <= vis_slots) {
+			bool expected = false;
+			helper_lease.held = helpers_in_flight.compare_exchange_strong(expected, true, std::memory_order_acq_rel);
+		}
+		const bool use_helper = helper_lease.held;
 		uint32_t* hq_words = nullptr;   // [0] entries appended, [1] stop, [16 ..] ids
 		uint32_t helper_n = 0;
 		if (use_helper) {

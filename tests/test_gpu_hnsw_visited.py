@@ -208,3 +208,46 @@ def test_large_batches_are_searched_in_two_halves(rxgpu, oracle, monkeypatch, me
             _same_batches(got, want, nq)
             assert got[3] == want[3]
     m.close()
+
+
+def test_concurrent_large_batches_with_helpers_do_not_wait_for_each_other(rxgpu, oracle, monkeypatch):
+    """Four searcher threads, each with batches of >= 2048 queries (the size from which helper workgroups are launched), on ONE index at
+    once.  A helper is a kernel that polls a queue until its batch says it is over: it is enqueued BEHIND the batch's own launches, so that
+    it can never sit in front of them on a hardware queue its stream shares with another caller's batch (where the batch would wait for the
+    helper's multi-second bail-out).  Bar: every thread's answers equal the sequential ones, and no call takes anywhere near a bail-out."""
+    import threading
+    import time
+    d, n, nq = 32, 6000, 2300
+    rng = np.random.default_rng(29)
+    base = rng.integers(-2, 3, size=(n // 4, d)).astype(np.float32)
+    base[np.all(base == 0, axis=1)] = 1.0
+    rows = np.ascontiguousarray(np.repeat(base, 4, axis=0)[rng.permutation(n)])
+    m, rows, labels = build(0, n, d, M=8, efc=40, rows=rows)
+    g = m.export_graph()
+    queries = [rng.integers(-2, 3, size=(nq, d)).astype(np.float32) for _ in range(4)]
+    monkeypatch.setenv("RXGPU_HNSW_RESTART_CAND", "6")   # every restart overflows: the helpers have work
+    with rxgpu.VectorIndex(0, d, n) as ix:
+        ix.upload_rows(0, rows, None)
+        ix.hnsw_attach_graph(g)
+        want = [ix.hnsw_search_knn(q, 10, 64) for q in queries]
+        want = [(a.copy(), b.copy(), c.copy()) for a, b, c in want]
+        ix.hnsw_read_lds_reruns()
+        errs, slowest = [], [0.0] * 4
+
+        def work(t):
+            try:
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    got = ix.hnsw_search_knn(queries[t], 10, 64)
+                    slowest[t] = max(slowest[t], time.perf_counter() - t0)
+                    _same_batches((got[0], got[1], got[2]), want[t], nq)
+            except Exception as e:  # noqa: BLE001
+                errs.append(repr(e))
+
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        assert not errs, errs
+        assert ix.hnsw_read_lds_reruns() > 0
+        assert max(slowest) < 1.5, slowest   # (a batch of 2300 searches over 6000 nodes takes milliseconds; the helpers' bail-out is 3 s)
+    m.close()
