@@ -16,9 +16,7 @@ namespace rxgpu {
 // keeps working on the host-merge path.  The entry points keep their nccl* names below.
 struct RcclApi {
 	decltype(&::ncclCommInitAll) ncclCommInitAll = nullptr;
-	decltype(&::ncclCommDestroy) ncclCommDestroy = nullptr;
 	decltype(&::ncclAllGather) ncclAllGather = nullptr;
-	decltype(&::ncclAllReduce) ncclAllReduce = nullptr;
 	decltype(&::ncclGroupStart) ncclGroupStart = nullptr;
 	decltype(&::ncclGroupEnd) ncclGroupEnd = nullptr;
 	decltype(&::ncclGetErrorString) ncclGetErrorString = nullptr;

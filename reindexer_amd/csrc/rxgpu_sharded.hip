@@ -64,9 +64,7 @@ const RcclApi& rccl_api() {
 			return p;
 		};
 		api.ncclCommInitAll = reinterpret_cast<decltype(api.ncclCommInitAll)>(sym("ncclCommInitAll"));
-		api.ncclCommDestroy = reinterpret_cast<decltype(api.ncclCommDestroy)>(sym("ncclCommDestroy"));
 		api.ncclAllGather = reinterpret_cast<decltype(api.ncclAllGather)>(sym("ncclAllGather"));
-		api.ncclAllReduce = reinterpret_cast<decltype(api.ncclAllReduce)>(sym("ncclAllReduce"));
 		api.ncclGroupStart = reinterpret_cast<decltype(api.ncclGroupStart)>(sym("ncclGroupStart"));
 		api.ncclGroupEnd = reinterpret_cast<decltype(api.ncclGroupEnd)>(sym("ncclGroupEnd"));
 		api.ncclGetErrorString = reinterpret_cast<decltype(api.ncclGetErrorString)>(sym("ncclGetErrorString"));
