@@ -473,6 +473,13 @@ int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 							 uint64_t* out_n, int32_t* out_preselected);
 /* Launch trains run by rxgpu_ft_merge_batch_raw and the merges they carried, since the index was created. */
 int rxgpu_ft_read_batch_stats(rxgpu_ft_index* h, uint64_t* trains, uint64_t* merges);
+/* Two launch trains produce the same merge: the dense one (a workgroup per 8192-document range, per-document arrays in HBM between its
+ * kernels) and the one for SPARSELY hit ranges (a wavefront per (query, range), bitmaps per sub-term in LDS, nothing per document in HBM;
+ * eligible: plain terms whose fields share one positive boost, <= 16 sub-terms, Bm25Rx / TermCount, weights below 1).  By default the host
+ * picks per query (eligible and postings on <= 30 % of the documents -> sparse).  mode: -1 that default, 0 always dense, 1 sparse whenever
+ * eligible.  Process-wide; RXGPU_FT_TRAIN=dense|sparse presets it.  rxgpu_ft_read_train_stats: merges run by either since the last call. */
+void rxgpu_ft_set_train_mode(int mode);
+int rxgpu_ft_read_train_stats(rxgpu_ft_index* h, uint64_t* dense_merges, uint64_t* sparse_merges);
 /* ---------------------------------------------------------------------------------------------------------
  * Hybrid rank fusion on the device: MergerRankedImpl + mergeRanked (cpp_src/core/nsselecter/selectiteratorcontainer.cc:
  * 1343-1423, 1454-1559), RanksHolder::InitRRFPositions (ranks_holder.h:61-76), RerankerRRF / RerankerLinear (core/sorting/reranker.h:11-39),

@@ -107,6 +107,8 @@ _SIGNATURES = {
     "rxgpu_ft_merge_query_areas_raw": (_i, [_vp, _vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _u64, C.POINTER(_u64), C.POINTER(_i), _vp, _vp]),
     "rxgpu_ft_merge_batch_raw": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _u64, _vp, _vp]),
     "rxgpu_ft_read_batch_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rxgpu_ft_set_train_mode": (None, [_i]),
+    "rxgpu_ft_read_train_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_ft_merge_query_resident": (_i, [_vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "rxgpu_ft_merge_query2_resident": (_i, [_vp, _vp, _vp, _vp, C.POINTER(_i)]),
     "rxgpu_ft_read_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(C.c_double)]),

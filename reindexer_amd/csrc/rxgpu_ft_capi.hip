@@ -78,6 +78,9 @@ struct rxgpu_ft_index {
 	float* d_words = nullptr;
 	float* d_avg = nullptr;
 	uint8_t* d_removed = nullptr;
+	uint32_t* d_removed_bits = nullptr;   // the same as one bit per document (the sparse train, ft_sparse.hip); null: no document is removed
+	std::vector<float> h_avg;             // avg_words as uploaded (the sparse train's eligibility test reads it)
+	std::atomic<uint64_t> trains_dense{0}, trains_sparse{0};   // merges by launch train (rxgpu_ft_read_train_stats)
 	std::unordered_map<uint32_t, rxgpu_ft_word> words;
 	std::mutex mtx;
 	// Concurrent merges (several planner threads query one index at a time): extra LANES — own stream, scratch, staging, events — behind
@@ -399,6 +402,8 @@ int checkout_lane(rxgpu_ft_index* h, LaneLock& out) {
 			l->d_words = h->d_words;
 			l->d_avg = h->d_avg;
 			l->d_removed = h->d_removed;
+			l->d_removed_bits = h->d_removed_bits;
+			l->h_avg = h->h_avg;
 		}
 	};
 	{
@@ -523,7 +528,7 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 	DevGuard dg(h->device);
 	(void)hipDeviceSynchronize();
 	for (auto& kv : h->words) kv.second.release();
-	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed)}) {
+	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed), static_cast<void*>(h->d_removed_bits)}) {
 		if (p) (void)hipFree(p);
 	}
 	for (auto& l : h->lanes) release_lane(l.get());
@@ -547,12 +552,28 @@ int rxgpu_ft_set_docs(rxgpu_ft_index* h, uint64_t total_docs, const float* words
 	RX_HIP(hipStreamSynchronize(h->stream));
 	if (int rc = upload(h->d_words, words_in_field, total_docs * h->num_fields); rc) return rc;
 	if (int rc = upload(h->d_avg, avg_words, h->num_fields); rc) return rc;
+	bool any_removed = false;
 	if (removed) {
 		if (int rc = upload(h->d_removed, removed, total_docs); rc) return rc;
+		std::vector<uint32_t> bits((total_docs + 31) / 32, 0u);
+		for (uint64_t d = 0; d < total_docs; ++d) {
+			if (removed[d]) {
+				bits[d >> 5] |= 1u << (d & 31);
+				any_removed = true;
+			}
+		}
+		if (any_removed) {
+			if (int rc = upload(h->d_removed_bits, bits.data(), bits.size()); rc) return rc;
+		}
 	} else {
 		if (h->d_removed) (void)hipFree(h->d_removed);
 		h->d_removed = nullptr;
 	}
+	if (!any_removed && h->d_removed_bits) {
+		(void)hipFree(h->d_removed_bits);
+		h->d_removed_bits = nullptr;
+	}
+	h->h_avg.assign(avg_words, avg_words + h->num_fields);
 	h->total_docs = total_docs;
 	return RXGPU_OK;
 }
@@ -998,6 +1019,64 @@ struct MergeJob {
 	size_t area_hdr_bytes = 0, area_bytes = 0;   // MergeDataAreas: the two regions of the lane's d_areas
 };
 
+// Which launch train runs a merge: -1 the host decides per query (ft_sparse_eligible + a density test), 0 always the dense train
+// (ft_merge.hip), 1 the sparse train (ft_sparse.hip) whenever the query is eligible.  RXGPU_FT_TRAIN=dense|sparse presets it, read once;
+// rxgpu_ft_set_train_mode changes it (tests, benchmarks).
+std::atomic<int>* ft_train_mode() {
+	static std::atomic<int> mode{[] {
+		const char* e = std::getenv("RXGPU_FT_TRAIN");
+		if (e && std::strcmp(e, "dense") == 0) return 0;
+		if (e && std::strcmp(e, "sparse") == 0) return 1;
+		return -1;
+	}()};
+	return &mode;
+}
+
+// The sparse train (ft_sparse.hip) derives every per-document fact from one bitmap per sub-term and ranks a document only once its merge slot
+// is known.  That is the reference's merge exactly when
+//   * the query is made of plain terms (no phrase rows, no multi-word synonyms, no areas) with at most kFtSparseSubs sub-terms,
+//   * every field of every merged term has the same positive boost — calcTermBitmask / calcTermScores then never look at an occurrence's
+//     fields (mergerimpl.h:252-324: allFieldsHaveSameBoost; checkFieldsRelevance is true for every occurrence),
+//   * calcTermRank cannot return 0 for any posting, so that "added by its first posting with a non-zero rank" (merger.h:161-180) is "added
+//     by its first posting": Bm25Rx / TermCount (positive, finite for avg_words > 0), every weight below 1 and every boost >= 0, which
+//     bounds each factor of phrasemergerimpl.h:51-63 from below by (1 - weight) > 0; the product's lower bound must stay a normal float.
+bool ft_sparse_eligible(const rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<QueryTermIn>& terms, const float* procs, size_t n_subs,
+						size_t n_phrases, uint32_t nsyn, uint32_t max_areas) {
+	if (h->sh_total > 1 || n_phrases || nsyn || max_areas) return false;
+	if (n_subs == 0 || n_subs > rxgpu::kFtSparseSubs || terms.size() > 32) return false;
+	if (cfg->bm25_type == rxgpu::kFtBm25Classic) return false;   // TF = count / wordsInDoc: a field without words makes the rank NaN, which is never admitted
+	if (!(cfg->bm25_k1 >= 0.0) || !(cfg->bm25_b >= 0.0 && cfg->bm25_b <= 1.0) || !(cfg->summation_ranks_by_fields_ratio >= 0.0)) return false;
+	const uint32_t nf = h->num_fields;
+	if (h->h_avg.size() != nf) return false;
+	double floor_fields = 1.0;   // lower bound of norm * termLenBoost * positionRank over the fields
+	for (uint32_t f = 0; f < nf; ++f) {
+		if (!(h->h_avg[f] > 0.0f) || !std::isfinite(h->h_avg[f])) return false;
+		const double w[3] = {cfg->bm25_weight[f], cfg->term_len_weight[f], cfg->position_weight[f]};
+		const double b[3] = {cfg->bm25_boost[f], cfg->term_len_boost[f], cfg->position_boost[f]};
+		double fl = 1.0;
+		for (int k = 0; k < 3; ++k) {
+			if (!(w[k] >= 0.0 && w[k] <= 0.999) || !(b[k] >= 0.0) || !std::isfinite(b[k])) return false;
+			fl *= 1.0 - w[k];
+		}
+		floor_fields = std::min(floor_fields, fl);
+	}
+	for (const QueryTermIn& qt : terms) {
+		if (qt.phrase_num >= 0) return false;
+		if (qt.op == 3) continue;   // a NOT term only clears mask bits, whatever its options (excludeTermFromBitmask, mergerimpl.h:276-287)
+		const float fb = qt.opts->field_boost[0];
+		if (!(fb > 0.0f) || !std::isfinite(fb)) return false;
+		for (uint32_t f = 1; f < nf; ++f) {
+			if (qt.opts->field_boost[f] != fb) return false;
+		}
+		if (!(qt.opts->boost > 0.0f) || !std::isfinite(qt.opts->boost) || !(qt.opts->term_len_boost >= 0.0f) || !std::isfinite(qt.opts->term_len_boost)) return false;
+		for (uint32_t si = qt.sub_begin; si < qt.sub_end; ++si) {
+			if (!(procs[si] > 0.0f) || !std::isfinite(procs[si])) return false;
+			if (double(fb) * floor_fields * double(qt.opts->boost) * double(procs[si]) < 1e-30) return false;
+		}
+	}
+	return true;
+}
+
 // First half of a merge: the plan (sub-terms, per-part configuration, posting-side grid), the lane's scratch, the plan staged in the lane's
 // pinned buffer — FtPlan included, behind the tables it points into — and (import_now) the copy kernel that takes it to HBM.  Everything is
 // enqueued on `st`: the lane's own stream for a single merge, the batch stream when Q lanes' merges go into one train.
@@ -1068,8 +1147,35 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	}
 	RX_CHECK(resident || (cap >= max_merged && have_outs), RXGPU_ERR_OVERFLOW, std::string(who) + ": output buffers too small");
 
+	bool any_phrase = false;
+	for (const QueryPartIn& part : parts) any_phrase = any_phrase || part.phrase;
+	// the launch train: the sparse one for eligible queries whose postings lie on a fraction of the documents (or on request)
+	bool sparse = false;
+	{
+		const int mode = ft_train_mode()->load(std::memory_order_relaxed);
+		size_t n_subs_all = 0;
+		uint64_t local_postings = 0;
+		for (uint32_t t = 0; t < nterms; ++t) {
+			for (uint32_t si = terms[t].sub_begin; si < terms[t].sub_end; ++si) {
+				const rxgpu_ft_word& w = h->dict().find(word_ids[si])->second;
+				if (!word_df(w)) continue;
+				++n_subs_all;
+				local_postings += w.n;
+			}
+		}
+		if (mode != 0 && ft_sparse_eligible(h, cfg, terms, procs, n_subs_all, any_phrase ? 1 : 0, nsyn, max_areas)) {
+			sparse = mode == 1 || local_postings * 10 <= N * 3;   // dense queries keep the dense train (posting-parallel ranking, per-range workgroups)
+		}
+	}
 	const uint8_t* d_excluded = nullptr;
-	if (excluded) {
+	const uint32_t* d_excluded_bits = nullptr;
+	if (excluded && sparse) {   // the sparse train reads docsExcluded as one bit per document
+		std::vector<uint32_t> bits((N + 31) / 32, 0u);
+		for (uint64_t d = 0; d < N; ++d) bits[d >> 5] |= (excluded[d] ? 1u : 0u) << (d & 31);
+		if (int rc = h->d_excl.ensure(bits.size() * 4); rc) return rc;
+		RX_HIP(hipMemcpyAsync(h->d_excl.ptr, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));   // (pageable source: the copy is staged before the call returns)
+		d_excluded_bits = static_cast<const uint32_t*>(h->d_excl.ptr);
+	} else if (excluded) {
 		if (int rc = h->d_excl.ensure(N); rc) return rc;
 		RX_HIP(hipMemcpyAsync(h->d_excl.ptr, excluded, N, hipMemcpyHostToDevice, st));
 		d_excluded = static_cast<const uint8_t*>(h->d_excl.ptr);
@@ -1246,15 +1352,17 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	const size_t o_plan_jsyn = cv.take(std::max<size_t>(1, job_syns.size()) * 4);
 	const size_t o_plan_self = cv.take(sizeof(rxgpu::FtPlan));   // the FtPlan itself: the kernels read it from HBM (a batch of one)
 	const size_t plan_bytes = cv.off;   // everything above is uploaded in one copy
-	const size_t o_mask = cv.take(nwords * 4);
+	// (a sparse merge keeps nothing per document or per posting in HBM: ft_sparse.hip)
+	const size_t o_mask = cv.take(sparse ? 0 : nwords * 4);
 	const size_t o_synmask = cv.take(syn_jobs.size() * nwords * 4);
-	const size_t o_score = cv.take(prescore ? nwords * 32 * 2 : 0);   // padded to whole mask words (ft_preselect_apply reads 32 scores at a time)
+	const size_t o_score = cv.take(prescore && !sparse ? nwords * 32 * 2 : 0);   // padded to whole mask words (ft_preselect_apply reads 32 scores at a time)
 	const uint32_t n_ranges = uint32_t((N + rxgpu::kFtRangeDocs - 1) / rxgpu::kFtRangeDocs);
-	const size_t o_brec = cv.take(size_t(merged_postings) * sizeof(uint4));
+	const size_t o_brec = cv.take(sparse ? 0 : size_t(merged_postings) * sizeof(uint4));
 	const size_t o_boff = cv.take(size_t(n_ranges) * 4);
 	const size_t o_adders = cv.take(std::max<size_t>(1, size_t(n_rows) * n_ranges) * 4);
-	const size_t o_eidx = cv.take(size_t(n_rows) * M * 4);
-	const size_t o_efield = cv.take(size_t(n_rows) * M);
+	const size_t o_eidx = cv.take(sparse ? 0 : size_t(n_rows) * M * 4);
+	const size_t o_efield = cv.take(sparse ? 0 : size_t(n_rows) * M);
+	const size_t o_allow = cv.take(sparse ? size_t(n_ranges) * 4 : 0);
 	if (int rc = h->d_state.ensure(cv.off); rc) return rc;
 	char* base = static_cast<char*>(h->d_state.ptr);
 	// the kept-clean tables: sized by the corpus only, so that they stay where they are from merge to merge
@@ -1264,7 +1372,8 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	const size_t o_bcnt = cc.take(size_t(n_ranges) * 4);
 	const size_t o_sync = cc.take(rxgpu::kFtSyncWords * 4);
 	const size_t o_dbg = cc.take(64 * 8);
-	const size_t o_erank = cc.take(size_t(n_rows) * M * 4);   // last: the regions before it never move when a query needs more rows
+	const size_t o_lb_units = cc.take(size_t(n_ranges) * 8);
+	const size_t o_erank = cc.take(sparse ? 0 : size_t(n_rows) * M * 4);   // last: the regions before it never move when a query needs more rows
 	if (h->clean_docs != N || h->d_clean.bytes < cc.off) {
 		if (int rc = h->d_clean.ensure(cc.off); rc) return rc;
 		h->clean_docs = N;
@@ -1371,6 +1480,11 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	p.out_proc = reinterpret_cast<float*>(ob + align256(16) + align256(M * 4));
 	p.out_terms_counter = reinterpret_cast<uint16_t*>(ob + align256(16) + 2 * align256(M * 4));
 	p.out_field = reinterpret_cast<uint8_t*>(ob + align256(16) + 2 * align256(M * 4) + align256(M * 2));
+	p.sparse = sparse ? 1 : 0;
+	p.removed_bits = h->d_removed_bits;
+	p.excluded_bits = d_excluded_bits;
+	p.unit_allow = sparse ? reinterpret_cast<uint32_t*>(base + o_allow) : nullptr;
+	p.lb_units = reinterpret_cast<unsigned long long*>(cbase + o_lb_units);
 	if (h->sh_total > 1) {   // a document-range shard: its own ranges, the facts that span the shards arrive between the kernels
 		RX_CHECK(!resident && !nsyn && !max_areas && n_phrases == 0, RXGPU_ERR_LOGIC,
 				 std::string(who) + ": a sharded ft index merges plain terms (no phrases, multi-word synonyms, areas or resident results)");
@@ -1711,8 +1825,14 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 	// from here on an error return leaves the kept-clean tables in an unknown state: the next merge clears them first
 	h->clean_dirty = true;
 	RX_HIP(hipEventRecord(h->ev_a, st));
-	RX_HIP(rxgpu::launch_ft_merge(job.d_plan, &job.p, 1, st));
+	if (job.p.sparse) {
+		RX_HIP(rxgpu::launch_ft_merge_sparse(job.d_plan, &job.p, 1, st));
+	} else {
+		RX_HIP(rxgpu::launch_ft_merge(job.d_plan, &job.p, 1, st));
+	}
 	RX_HIP(hipEventRecord(h->ev_b, st));
+	(h->root ? h->root : h)->trains_dense += job.p.sparse ? 0 : 1;
+	(h->root ? h->root : h)->trains_sparse += job.p.sparse ? 1 : 0;
 	if (resident) {   // the result stays where ft_finish wrote it (d_out): the fusion kernel reads it there, nothing travels
 		h->res_pending = true;
 		h->res_has_syn = job.nsyn != 0;   // the fusion skips the documents ft_finish marked (they hold only parts of a synonym)
@@ -2405,6 +2525,8 @@ int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 			lane->d_words = h->d_words;
 			lane->d_avg = h->d_avg;
 			lane->d_removed = h->d_removed;
+			lane->d_removed_bits = h->d_removed_bits;
+			lane->h_avg = h->h_avg;
 			MergeJob job;
 			if (int rc = prepare_merge(lane, st, cfg, simple, terms, q.word_ids, q.procs, excluded ? excluded[i] : nullptr,
 									   out_doc[i] && out_proc[i] && out_field[i] && (simple || out_terms_counter[i]), cap, who, false, nullptr, job, false);
@@ -2422,6 +2544,10 @@ int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 		}
 		const uint32_t B = uint32_t(jobs.size());
 		if (!B) continue;
+		// the sparse train's queries in front, the dense train's behind: each train is launched over its own run of plans
+		std::stable_partition(host_plans.begin(), host_plans.end(), [](const rxgpu::FtPlan& pl) { return pl.sparse != 0; });
+		uint32_t n_sparse = 0;
+		while (n_sparse < B && host_plans[n_sparse].sparse) ++n_sparse;
 		std::memcpy(h->h_batch_plans, host_plans.data(), size_t(B) * sizeof(rxgpu::FtPlan));
 		pieces.src[B] = plans_dev_view;
 		pieces.dst[B] = h->d_batch_plans.ptr;
@@ -2431,8 +2557,11 @@ int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 		for (rxgpu_ft_index* lane : job_lane) lane->clean_dirty = true;   // until the train has run to its end
 		RX_HIP(rxgpu::launch_ft_import_batch(pieces, st));
 		RX_HIP(hipEventRecord(h->ev_ba, st));
-		RX_HIP(rxgpu::launch_ft_merge(d_plans, host_plans.data(), B, st));
+		RX_HIP(rxgpu::launch_ft_merge_sparse(d_plans, host_plans.data(), n_sparse, st));
+		RX_HIP(rxgpu::launch_ft_merge(d_plans + n_sparse, host_plans.data() + n_sparse, B - n_sparse, st));
 		RX_HIP(hipEventRecord(h->ev_bb, st));
+		h->trains_sparse += n_sparse;
+		h->trains_dense += B - n_sparse;
 		RX_HIP(rxgpu::launch_ft_export(d_plans, host_plans.data(), B, st));
 		{
 			const auto t_poll = clk::now();
@@ -2458,6 +2587,13 @@ int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 				return rc;
 		}
 	}
+	return RXGPU_OK;
+}
+void rxgpu_ft_set_train_mode(int mode) { ft_train_mode()->store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
+int rxgpu_ft_read_train_stats(rxgpu_ft_index* h, uint64_t* dense_merges, uint64_t* sparse_merges) {
+	RX_CHECK(h && dense_merges && sparse_merges, RXGPU_ERR_PARAMS, "rxgpu_ft_read_train_stats: null argument");
+	*dense_merges = h->trains_dense.exchange(0);
+	*sparse_merges = h->trains_sparse.exchange(0);
 	return RXGPU_OK;
 }
 int rxgpu_ft_read_batch_stats(rxgpu_ft_index* h, uint64_t* trains, uint64_t* merges) {

@@ -279,9 +279,18 @@ struct FtPlan {
 	uint32_t shard_index, n_shards;
 	const uint32_t* shard_hist;   // gathered layout: shard s at [shard_pos[s]][kFtFoldWords]
 	const uint32_t* shard_pos;    // [n_shards]
+	// The train for SPARSELY hit document ranges (ft_sparse.hip): one wavefront per (query, range), bitmaps of the range's documents per
+	// sub-term in LDS, nothing per document in HBM.  sparse = 1: the host found the query eligible (ft_sparse_eligible, rxgpu_ft_capi.hip).
+	uint8_t sparse;
+	const uint32_t* removed_bits; // [nwords] DocRemoved as one bit per document (null: none removed); built by rxgpu_ft_set_docs
+	const uint32_t* excluded_bits;// [nwords] docsExcluded of this merge as bits (null: none)
+	uint32_t* unit_allow;         // [n_ranges] ties at the threshold score the range keeps (ft_sp_select -> ft_sp_finish)
+	unsigned long long* lb_units; // [n_ranges] look-back words of ft_sp_select's ordered tie count; kept zero between merges
 };
 constexpr uint32_t kFtFoldWords = 65536 + 1024 + 64;   // one shard's folded histogram (fine + chunk counters), [65536 + 1024] = its mask popcount
-enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6, kFtSyncDoneFinish = 9, kFtSyncWords = 16 };
+enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6, kFtSyncDoneFinish = 9,
+				  // the sparse train: threshold score / documents kept at it / flags (bit 0 preselect on, bit 1 every tie is kept), the ticket of ft_sp_select
+				  kFtSyncThrScore = 10, kFtSyncThrDocs = 11, kFtSyncThrFlags = 12, kFtSyncSpTicket = 13, kFtSyncWords = 16 };
 constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
@@ -290,6 +299,11 @@ hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32
 // the same train in the three pieces a sharded merge exchanges between: 0 = [syn masks] + ft_ranges, 1 = [ft_preselect_apply] + ft_rank_all +
 // ft_adders, 2 = [ft_slot_bases] + ft_finish
 hipError_t launch_ft_merge_phase(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, int phase, hipStream_t st);
+// the train for sparsely hit ranges (ft_sparse.hip) over nq plans that all have sparse = 1: ft_sp_scan, [ft_sp_threshold, ft_sp_select],
+// ft_slot_bases, ft_sp_finish
+hipError_t launch_ft_merge_sparse(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st);
+void launch_ft_slot_bases(const FtPlan* plans, uint32_t nq, hipStream_t st);   // ft_merge.hip
+constexpr uint32_t kFtSparseSubs = 16;   // sub-terms (NOT terms' included) a sparse merge holds bitmaps for
 void launch_ft_shard_fold(const FtPlan* plan, uint32_t* dst, hipStream_t st);                                            // hist copies + popcount -> dst [kFtFoldWords]
 void launch_ft_shard_hist_combine(const FtPlan* plan, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards, hipStream_t st);   // gathered [..][kFtFoldWords]
 void launch_ft_shard_table_sum(uint32_t* table, const uint32_t* gathered, const uint32_t* pos, uint32_t n_shards, uint64_t n, uint64_t stride, hipStream_t st);   // gathered [..][stride]

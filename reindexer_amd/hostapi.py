@@ -749,6 +749,12 @@ class GpuHnswMap:
         return ids[:n].copy(), ranks[:n].copy()
 
 
+def set_ft_train_mode(mode: int) -> None:
+    """rxgpu_ft_set_train_mode: -1 the host picks the launch train per query, 0 always the dense train, 1 the sparse train whenever eligible."""
+    from . import capi
+    capi.lib().rxgpu_ft_set_train_mode(int(mode))
+
+
 class GpuFtMerger:
     """rxgpu::host::GpuFtMerger — ft_fast single-term BM25 merge on the GPU (stand-in for ft::Merger::Merge<Bm25Rx>)."""
 
@@ -1102,6 +1108,13 @@ class GpuFtMerger:
         calls, ms, pms = _u64(0), C.c_double(0), C.c_double(0)
         L.rxhost_ft_read_fuse_stats(self.h, C.byref(calls), C.byref(ms), C.byref(pms))
         return int(calls.value), float(ms.value), float(pms.value)
+
+    def read_train_stats(self):
+        """(dense merges, sparse merges) since the last call: which launch train ran them (rxgpu_ft_read_train_stats)."""
+        from . import capi
+        a, b = _u64(0), _u64(0)
+        capi.lib().rxgpu_ft_read_train_stats(self.device_index, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
 
     def read_timing(self):
         """(calls, total ms) spent inside the C++ Merger since the last call — the end-to-end time of the drop-in boundary, without this
