@@ -6,7 +6,8 @@
 // between its kernels (16-bit pre-scores, the restricting mask, 16-byte records of every ranked posting).  A two-term query over 5M
 // documents touches 8 % of them: 650 postings per range, for which a workgroup walks ~20 us of dependent phases and the arrays move 4 x the
 // bytes of the postings (profiles/rd5_bm25_train64_sparse_rocprof.json).  Here the unit of work is ONE WAVEFRONT per (query, range), four to a
-// workgroup, no workgroup barrier inside a unit, and NOTHING per document or per posting is written to HBM:
+// workgroup, no workgroup barrier and no shared descriptor copy in a unit, and nothing per document or per posting is written to HBM except
+// one small task per MERGED document:
 //
 //  * every unit pulls the document ids of its range's postings (all sub-terms, one flat index space, eight independent loads per lane in
 //    flight) and sets one bit per (sub-term, document) in LDS: kS bitmaps of 8192 bits.  Every per-document fact of the merge is then a
@@ -17,18 +18,22 @@
 //      addDoc order (merger.h:161-180)                        a document is added by the first non-NOT sub-term holding it (every rank is
 //                                                             positive: checked on the host), so "first met in row r" = W[r] & ~seen-so-far;
 //                                                             its merge slot = documents first met in earlier rows + same row, smaller id
-//  * three global facts order the kernels: the pre-score histogram -> threshold (ft_sp_scan | ft_sp_threshold), the ties kept at the threshold
-//    in document order and the table of documents first met per (row, range) (ft_sp_select | ft_slot_bases), the slots (ft_sp_finish).
-//    Each unit kernel rebuilds its bitmaps from the postings (4 B per posting from L2 / HBM) instead of reading back what another wrote.
-//  * calcTermRank + the per-document replay (mergeTerm :107-192 / mergeSimple :194-250) run LAST, in ft_sp_finish, only for documents whose
-//    slot lies below maxMergedDocs: a whole-corpus single-term merge ranks its 20 000 merged documents, not its 600 000 postings.
+//      posting index of a document in a sub-term              segment start + set bits in front of it (popcount prefix along the bitmap)
+//  * the global facts order the kernels: the pre-score histogram -> threshold (ft_sp_scan | ft_sp_threshold), the ties kept at the threshold
+//    in document order (ft_sp_select's ordered count over the units) and the table of documents first met per (row, range) -> slot bases
+//    (ft_slot_bases).  Each unit kernel rebuilds its bitmaps from the postings (4 B per posting, L2-warm the second time).
+//  * calcTermRank + the per-document replay (mergeTerm :107-192 / mergeSimple :194-250) run LAST and document-parallel, in ft_sp_replay: one
+//    thread per merged document reads its task (document, slot or (row, rank in the range), posting index per sub-term row) — a
+//    whole-corpus single-term merge ranks its 20 000 merged documents, not its 600 000 postings, and no range is a straggler.
 //
-// Launch train: ft_sp_scan, [ft_sp_threshold, ft_sp_select — queries that may preselect], ft_slot_bases (ft_merge.hip), ft_sp_finish.
-// Results are the dense train's to the bit (same float operations per document, same slots): tests/test_gpu_ft_*.py run both.
+// Launch train: ft_sp_scan, [ft_sp_threshold, ft_sp_select — queries that may preselect: they come first in the batch], ft_slot_bases
+// (ft_merge.hip), [ft_sp_place — the others], ft_sp_replay.
+// Results are the dense train's to the bit (same float operations per document, same slots): tests/test_gpu_ft_sparse.py runs both.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "rxgpu_internal.h"
 #include "knn_kernels.hip.h"
@@ -41,49 +46,10 @@ namespace {
 
 constexpr uint32_t kSpWords = kFtRangeDocs / 32;   // mask words of one range
 constexpr uint32_t kSpUnits = 4;                   // units (wavefronts) per workgroup
-constexpr uint32_t kSpRing = 128;                  // documents waiting for a replay lane (ft_sp_finish)
 constexpr uint32_t kSpLoads = 8;                   // posting loads a lane keeps in flight while the bitmaps are built
 static_assert(kSpWords == 4 * 64, "a lane owns four words of every bitmap");
 
-// LDS of one workgroup (32-bit words): the query's sub-term and term descriptors (all four units serve the same query), one attribute
-// word per sub-term, then per unit the bitmaps, the segment starts and — ft_sp_finish — the popcount prefixes and the replay ring.
-struct SpLayout {
-	uint32_t subs, terms, attr, meta, unit0, unit_stride;   // word offsets
-	uint32_t u_bits, u_lo, u_prefix, u_ring;                // inside a unit
-	uint32_t total_words;
-};
-__host__ __device__ inline SpLayout sp_layout(uint32_t ks, uint32_t t_max, bool finish) {
-	SpLayout l{};
-	uint32_t o = 0;
-	l.subs = o;
-	o += ks * uint32_t(sizeof(FtPosSubterm) / 4);
-	l.terms = o;
-	o += t_max * uint32_t(sizeof(FtTermCfg) / 4);
-	l.attr = o;
-	o += kFtSparseSubs;
-	l.meta = o;
-	o += 4;
-	o = (o + 3u) & ~3u;
-	l.unit0 = o;
-	uint32_t u = 0;
-	l.u_bits = u;
-	u += ks * kSpWords;
-	l.u_lo = u;
-	u += kFtSparseSubs;
-	if (finish) {
-		l.u_prefix = u;
-		u += ks * kSpWords / 2;   // 16 bits per word
-		l.u_ring = u;
-		u += 2 * kSpRing;
-	}
-	u = (u + 3u) & ~3u;
-	l.unit_stride = u;
-	l.total_words = o + kSpUnits * u;
-	return l;
-}
-static_assert(sizeof(FtPosSubterm) % 8 == 0 && sizeof(FtTermCfg) % 8 == 0, "descriptors are copied word by word and hold 8-byte members");
-
-// sub-term attribute word: proc16 | first sub-term of its term << 16 | AND term << 17 | NOT term << 18 | merge row << 20
+// sub-term attribute word (FtPlan::SpSub::attr, built on the host)
 constexpr uint32_t kSpFirst = 1u << 16, kSpAnd = 1u << 17, kSpNot = 1u << 18;
 
 // LDS traffic between the lanes of ONE wavefront: the hardware executes a wavefront's LDS instructions in order, the fence keeps the compiler
@@ -93,86 +59,43 @@ __device__ __forceinline__ void sp_fence() {
 	__builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint32_t sp_readlane(uint32_t v, int lane) { return uint32_t(__builtin_amdgcn_readlane(int(v), lane)); }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) {
-		const uint32_t o = uint32_t(__shfl_xor(int(v), off, 64));
-		v = o < v ? o : v;
-	}
-	return v;
-}
-__device__ __forceinline__ uint32_t sp_lanes_below(unsigned long long m, int lane) { return uint32_t(__popcll(m & ((1ull << lane) - 1ull))); }
 
-// What every unit kernel knows about its query (uniform over the wavefront) and its range
+// What a unit knows about its query (uniform over the wavefront) and its range
 template <int kS>
 struct SpCtx {
-	const FtPosSubterm* subs;   // LDS copies
-	const FtTermCfg* terms;
 	uint32_t* bits;             // LDS [kS][kSpWords]
-	uint32_t* lo;               // LDS [kFtSparseSubs]: first posting of the range in sub-term si
 	uint32_t n_subs;
 	uint32_t attr;              // lane si: attribute word of sub-term si
+	uint32_t lo;                // lane si: first posting of the range in sub-term si
 	unsigned long long first_m, and_m, not_m;
 	uint32_t p16[kS];           // proc16 of sub-term si (uniform)
-	bool empty_and;             // an AND term without postings: no document passes (buildRestrictingBitmask)
+	bool empty_and;
 	uint32_t range, d_begin, docs_here;
 	uint32_t rm[4], ex[4];      // removed / excluded bits of the lane's four words
 };
 
-// The workgroup's share: descriptors into LDS, attribute words.  Ends with a workgroup barrier (the only one in front of the units).
+// The unit's bitmaps: one bit per (sub-term, document of the range).  Lane si reads sub-term si's entry of the plan and the range's segment
+// of its list; the postings of all sub-terms form one flat index space, a lane keeps kSpLoads document loads in flight.
 template <int kS>
-__device__ __forceinline__ void sp_setup(FtPlanK& p, uint32_t* lds, const SpLayout& L) {
-	const uint32_t tid = threadIdx.x;
-	uint32_t* d_subs = lds + L.subs;
-	uint32_t* d_terms = lds + L.terms;
-	const uint32_t ns_words = p.n_subs * uint32_t(sizeof(FtPosSubterm) / 4), nt_words = p.nterms * uint32_t(sizeof(FtTermCfg) / 4);
-	const uint32_t* src_s = reinterpret_cast<const uint32_t*>(p.subs);
-	const uint32_t* src_t = reinterpret_cast<const uint32_t*>(p.terms);
-	for (uint32_t w = tid; w < ns_words; w += 256) d_subs[w] = src_s[w];
-	for (uint32_t w = tid; w < nt_words; w += 256) d_terms[w] = src_t[w];
-	if (tid < 4) lds[L.meta + tid] = 0;
-	__syncthreads();
-	const FtPosSubterm* subs = reinterpret_cast<const FtPosSubterm*>(d_subs);
-	const FtTermCfg* terms = reinterpret_cast<const FtTermCfg*>(d_terms);
-	if (tid < p.n_subs) {
-		const FtPosSubterm& s = subs[tid];
-		const FtTermCfg& t = terms[s.term];
-		// calcTermScores (mergerimpl.h:312-315): every field has the same boost, so maxBoostFromFields is field 0's
-		const float proc = s.proc * t.field_boost[0] * t.opts_boost;
-		uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
-		p16 = p16 < 65535u / 4 ? p16 : 65535u / 4;
-		uint32_t a = p16 | (s.row << 20);
-		if (tid == t.sub_begin) a |= kSpFirst;
-		if (t.op == 2) a |= kSpAnd;
-		if (t.op == 3) a |= kSpNot;
-		lds[L.attr + tid] = a;
-	}
-	if (tid < p.nterms && !p.simple) {
-		const FtTermCfg& t = terms[tid];
-		if (t.op == 2 && t.sub_begin == t.sub_end) lds[L.meta] = 1;
-	}
-	__syncthreads();
-}
-
-template <int kS>
-__device__ __forceinline__ void sp_unit_ctx(FtPlanK& p, uint32_t* lds, const SpLayout& L, uint32_t unit_in_wg, uint32_t range, int lane, SpCtx<kS>& c) {
-	uint32_t* ub = lds + L.unit0 + unit_in_wg * L.unit_stride;
-	c.subs = reinterpret_cast<const FtPosSubterm*>(lds + L.subs);
-	c.terms = reinterpret_cast<const FtTermCfg*>(lds + L.terms);
-	c.bits = ub + L.u_bits;
-	c.lo = ub + L.u_lo;
+__device__ __forceinline__ void sp_open(FtPlanK& p, uint32_t* unit_lds, uint32_t range, int lane, SpCtx<kS>& c) {
+	c.bits = unit_lds;
 	c.n_subs = p.n_subs;
-	c.attr = uint32_t(lane) < p.n_subs ? lds[L.attr + lane] : 0u;
-	c.first_m = __ballot((c.attr & kSpFirst) != 0);
-	c.and_m = __ballot((c.attr & kSpAnd) != 0);
-	c.not_m = __ballot((c.attr & kSpNot) != 0);
-#pragma unroll
-	for (int si = 0; si < kS; ++si) c.p16[si] = sp_readlane(c.attr, si) & 0xFFFFu;
-	c.empty_and = lds[L.meta] != 0;
 	c.range = range;
 	c.d_begin = range << kFtRangeShift;
 	const uint64_t left = p.total_docs - uint64_t(c.d_begin);
 	c.docs_here = uint32_t(left < kFtRangeDocs ? left : kFtRangeDocs);
+	c.empty_and = p.sp_empty_and != 0;
+	const uint32_t* docp = nullptr;
+	uint32_t lo = 0, hi = 0;
+	c.attr = 0;
+	if (uint32_t(lane) < c.n_subs) {
+		const auto& s = p.sp_sub[lane];
+		docp = s.doc;
+		c.attr = s.attr;
+		lo = range < s.n_ranges ? s.range_off[range] : s.n;
+		hi = range + 1 < s.n_ranges ? s.range_off[range + 1] : s.n;
+	}
+	c.lo = lo;
 #pragma unroll
 	for (int j = 0; j < 4; ++j) {   // requested now, consumed behind the bitmaps
 		const uint64_t gw = uint64_t(c.d_begin) / 32 + uint32_t(64 * j + lane);
@@ -180,19 +103,11 @@ __device__ __forceinline__ void sp_unit_ctx(FtPlanK& p, uint32_t* lds, const SpL
 		c.rm[j] = (p.removed_bits && in) ? p.removed_bits[gw] : 0u;
 		c.ex[j] = (p.excluded_bits && in) ? p.excluded_bits[gw] : 0u;
 	}
-}
-
-// One bit per (sub-term, document of the range).  The postings of all sub-terms form one flat index space; a lane keeps kSpLoads document
-// loads in flight.
-template <int kS>
-__device__ __forceinline__ void sp_build(const SpCtx<kS>& c, int lane) {
-	uint32_t lo = 0, hi = 0;
-	if (uint32_t(lane) < c.n_subs) {
-		const FtPosSubterm& s = c.subs[lane];
-		lo = c.range < s.n_ranges ? s.range_off[c.range] : uint32_t(s.n);
-		hi = c.range + 1 < s.n_ranges ? s.range_off[c.range + 1] : uint32_t(s.n);
-		c.lo[lane] = lo;
-	}
+	c.first_m = __ballot((c.attr & kSpFirst) != 0);
+	c.and_m = __ballot((c.attr & kSpAnd) != 0);
+	c.not_m = __ballot((c.attr & kSpNot) != 0);
+#pragma unroll
+	for (int si = 0; si < kS; ++si) c.p16[si] = sp_readlane(c.attr, si) & 0xFFFFu;
 	uint4* b4 = reinterpret_cast<uint4*>(c.bits);
 	for (uint32_t k = uint32_t(lane); k < kS * kSpWords / 4; k += 64) b4[k] = make_uint4(0u, 0u, 0u, 0u);
 	const uint32_t len = hi - lo;
@@ -202,6 +117,8 @@ __device__ __forceinline__ void sp_build(const SpCtx<kS>& c, int lane) {
 	uint32_t cum_u[kS];
 #pragma unroll
 	for (int si = 0; si < kS; ++si) cum_u[si] = sp_readlane(cum, si);   // (lanes past the last sub-term: total)
+	const uint64_t doc_at = reinterpret_cast<uint64_t>(docp) + uint64_t(lo) * 4;   // lane si: address of the segment's first document id
+	const uint32_t doc_lo = uint32_t(doc_at), doc_hi = uint32_t(doc_at >> 32);
 	sp_fence();
 	for (uint32_t base = 0; base < total; base += 64 * kSpLoads) {
 		uint32_t d[kSpLoads], sub[kSpLoads];
@@ -218,8 +135,9 @@ __device__ __forceinline__ void sp_build(const SpCtx<kS>& c, int lane) {
 				cs = ge ? cum_u[si] : cs;
 			}
 			sub[k] = s;
+			const uint64_t a = (uint64_t(uint32_t(__shfl(int(doc_hi), int(s), 64))) << 32) | uint32_t(__shfl(int(doc_lo), int(s), 64));
 			d[k] = 0;
-			if (ok[k]) d[k] = c.subs[s].doc[c.lo[s] + (f - cs)];
+			if (ok[k]) d[k] = reinterpret_cast<const uint32_t*>(a)[f - cs];
 		}
 #pragma unroll
 		for (uint32_t k = 0; k < kSpLoads; ++k) {
@@ -347,22 +265,6 @@ __device__ __forceinline__ SpThreshold sp_threshold(FtPlanK& p) {
 	t.docs = p.sync[kFtSyncThrDocs];
 	return t;
 }
-
-// the documents of the lane's word above / at the threshold score
-template <int kS>
-__device__ __forceinline__ void sp_gt_tie(const SpCtx<kS>& c, const SpWord<kS>& w, uint32_t thr, uint32_t& gt, uint32_t& tie) {
-	uint32_t claim[kS];
-	sp_term_claims(c, w, claim);
-	gt = tie = 0;
-	uint32_t rem = w.cand;
-	while (rem) {
-		const uint32_t b = uint32_t(__ffs(int(rem)) - 1);
-		rem &= rem - 1;
-		const uint32_t sc = sp_score(c, claim, b);
-		gt |= uint32_t(sc > thr) << b;
-		tie |= uint32_t(sc == thr) << b;
-	}
-}
 __device__ __forceinline__ uint32_t sp_lowest_bits(uint32_t x, uint32_t n) {   // the n lowest set bits of x
 	uint32_t out = 0;
 	while (n && x) {
@@ -373,36 +275,48 @@ __device__ __forceinline__ uint32_t sp_lowest_bits(uint32_t x, uint32_t n) {   /
 	}
 	return out;
 }
-// the documents of word j the merge may add: everything (no preselect), or above the threshold + the first `allowed` ties of the unit
+
+// One task per merged document (FtPlan::t_doc / t_pos / t_idx): its posting index in every merged sub-term, from the lane's own words —
+// segment start + bits of the sub-term's bitmap in front of the document (pre[si]: in front of this word).
 template <int kS>
-__device__ __forceinline__ uint32_t sp_kept_word(const SpCtx<kS>& c, const SpWord<kS>& w, const SpThreshold& thr, uint32_t allowed, uint32_t& ties_before, int lane) {
-	if (!thr.on) return w.cand;
-	uint32_t gt, tie;
-	sp_gt_tie(c, w, thr.score, gt, tie);
-	if (thr.all_ties) return gt | tie;
-	const uint32_t cnt = uint32_t(__popc(tie));
-	const uint32_t incl = wave_inclusive_scan(cnt, lane);
-	const uint32_t before = ties_before + incl - cnt;   // ties of the unit in front of this word, in document order
-	ties_before += sp_readlane(incl, 63);
-	const uint32_t room = allowed > before ? allowed - before : 0u;
-	return gt | sp_lowest_bits(tie, room);
+__device__ __forceinline__ void sp_emit(FtPlanK& p, const SpCtx<kS>& c, const SpWord<kS>& w, const uint32_t (&pre)[kS], const uint32_t (&lo_u)[kS], uint32_t t,
+										uint32_t word, uint32_t b, uint32_t pos) {
+	p.t_doc[t] = c.d_begin + word * 32 + b;
+	p.t_pos[t] = pos;
+	uint32_t* row = p.t_idx + size_t(t) * p.n_rows;
+	const uint32_t below = (1u << b) - 1u;
+#pragma unroll
+	for (int si = 0; si < kS; ++si) {
+		if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
+		const uint32_t r = sp_readlane(c.attr, si) >> 20;
+		row[r] = ((w.W[si] >> b) & 1u) ? lo_u[si] + pre[si] + uint32_t(__popc(w.W[si] & below)) + 1u : 0u;
+	}
+}
+
+// the table of documents first met per (row, range): this unit's column, zeros included (the table is the merge's scratch)
+// (kPerLane: rows[] holds every lane's own count; otherwise the unit's totals, the same in every lane)
+template <int kS, bool kPerLane>
+__device__ __forceinline__ void sp_store_rows(FtPlanK& p, const SpCtx<kS>& c, const uint32_t (&rows)[kS], int lane) {
+#pragma unroll
+	for (int si = 0; si < kS; ++si) {
+		if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
+		const uint32_t tot = kPerLane ? wave_sum(rows[si]) : rows[si];
+		if (lane == 0) p.adders[uint64_t(sp_readlane(c.attr, si) >> 20) * p.n_ranges + c.range] = tot;
+	}
 }
 
 // ---------------------------------------------------------------------------------------------- ft_sp_scan
 // prescore: the restricting mask's popcount and the pre-score histogram of the unit's documents (the input of the 2-phase gate and of the
 // threshold).  Otherwise (Simple() queries, queries below mergeLimit): the documents first met per (row, range) — ft_adders' table — at once.
 template <int kS>
-__global__ __launch_bounds__(256) void ft_sp_scan(const FtPlan* plans, uint32_t t_max) {
+__global__ __launch_bounds__(256) void ft_sp_scan(const FtPlan* plans) {
 	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
-	const SpLayout L = sp_layout(kS, t_max, false);
-	sp_setup<kS>(p, sp_lds, L);
 	const int lane = threadIdx.x & 63;
 	const uint32_t unit = threadIdx.x >> 6, range = blockIdx.x * kSpUnits + unit;
 	if (range >= p.n_ranges) return;
 	SpCtx<kS> c;
-	sp_unit_ctx<kS>(p, sp_lds, L, unit, range, lane, c);
-	sp_build<kS>(c, lane);
+	sp_open<kS>(p, sp_lds + unit * (kS * kSpWords), range, lane, c);
 	uint32_t pop = 0;
 	uint32_t rows[kS];
 #pragma unroll
@@ -443,12 +357,7 @@ __global__ __launch_bounds__(256) void ft_sp_scan(const FtPlan* plans, uint32_t 
 		if (lane == 0 && pop) atomicAdd(&p.sync[kFtSyncPop], pop);
 		if (uint32_t(lane) < keys.n) overflow(keys.key, keys.cnt);
 	} else {
-#pragma unroll
-		for (int si = 0; si < kS; ++si) {
-			if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
-			const uint32_t tot = wave_sum(rows[si]);
-			if (lane == 0) p.adders[uint64_t(sp_readlane(c.attr, si) >> 20) * p.n_ranges + range] = tot;
-		}
+		sp_store_rows<kS, true>(p, c, rows, lane);
 	}
 }
 
@@ -506,26 +415,62 @@ __device__ inline uint32_t sp_lookback(uint32_t mine, uint32_t unit, unsigned lo
 	return excl;
 }
 
+// The documents of the unit in (word round j, lane) = document order, a sub-term at a time: per merged sub-term the exclusive prefix of its
+// bitmap's popcounts (posting indices) and of the documents first met in it (ranks inside (row, range)); `visit` gets the lane's first-met
+// documents of every (round, sub-term) that has any: (j, si, words, popcount prefixes, the lane's first-met bits, the rank of its first
+// one inside (row, range), documents of the round in front of the lane's, documents of the round).
+template <int kS, typename KeptOf, typename Visit>
+__device__ __forceinline__ void sp_walk(const SpCtx<kS>& c, int lane, uint32_t (&rows)[kS], KeptOf&& kept_of, Visit&& visit) {
+	uint32_t run[kS];
+#pragma unroll
+	for (int si = 0; si < kS; ++si) run[si] = rows[si] = 0;
+	for (int j = 0; j < 4; ++j) {
+		SpWord<kS> w;
+		sp_word<kS>(c, j, lane, w);
+		const uint32_t kept = kept_of(j, w);
+		uint32_t fm[kS], pre[kS];
+		sp_first_met(c, w, kept, fm);
+#pragma unroll
+		for (int si = 0; si < kS; ++si) {
+			pre[si] = 0;
+			if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
+			const uint32_t cnt = uint32_t(__popc(w.W[si]));
+			const uint32_t incl = wave_inclusive_scan(cnt, lane);
+			pre[si] = run[si] + incl - cnt;
+			run[si] += sp_readlane(incl, 63);
+		}
+#pragma unroll
+		for (int si = 0; si < kS; ++si) {
+			if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
+			const uint32_t cnt = uint32_t(__popc(fm[si]));
+			const uint32_t incl = wave_inclusive_scan(cnt, lane);
+			const uint32_t total = sp_readlane(incl, 63);
+			if (total) visit(j, si, w, pre, fm[si], rows[si] + incl - cnt, incl - cnt, total);
+			rows[si] += total;   // (uniform: documents of the unit first met in sub-term si so far)
+		}
+	}
+}
+
 // ---------------------------------------------------------------------------------------------- ft_sp_select
 // Queries whose 2-phase gate held on the host: which documents preselectMostRelevantDocs keeps (mergerimpl.h:448-462; the ties at the
-// threshold score in document order up to minScoreDocs: an ordered count over the units) and, over those, the table of documents first met
-// per (row, range).  Also hands the pre-score histogram back zeroed: every unit clears the counters of its own scores.
+// threshold score in document order up to minScoreDocs: an ordered count over the units), the table of documents first met per (row,
+// range) over those, and one task per kept document.  Also hands the pre-score histogram back zeroed: every unit clears the counters of
+// its own scores.
 template <int kS>
-__global__ __launch_bounds__(256) void ft_sp_select(const FtPlan* plans, uint32_t t_max) {
+__global__ __launch_bounds__(256) void ft_sp_select(const FtPlan* plans) {
 	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	if (!p.prescore) return;
 	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
-	const SpLayout L = sp_layout(kS, t_max, false);
 	const uint32_t ticket = grab_ticket(p.sync + kFtSyncSpTicket);
-	sp_setup<kS>(p, sp_lds, L);
 	const int lane = threadIdx.x & 63;
 	const uint32_t unit = threadIdx.x >> 6, range = ticket * kSpUnits + unit;
 	if (range >= p.n_ranges) return;
 	const SpThreshold thr = sp_threshold(p);
 	SpCtx<kS> c;
-	sp_unit_ctx<kS>(p, sp_lds, L, unit, range, lane, c);
-	sp_build<kS>(c, lane);
-	// pass 1: the unit's ties at the threshold; the distinct scores of its documents (their histogram counters are cleared)
+	uint32_t* unit_lds = sp_lds + unit * ((kS + 1) * kSpWords);
+	uint32_t* keptw = unit_lds + kS * kSpWords;   // [kSpWords] the kept documents of the unit, word by word
+	sp_open<kS>(p, unit_lds, range, lane, c);
+	// pass 1: the unit's documents above / at the threshold; the distinct scores of its documents (their histogram counters are cleared)
 	uint32_t* hist_copy = p.hist + size_t(range % kFtHistCopies) * kFtHistStride;
 	auto clear = [&](uint32_t v, uint32_t) {
 		hist_copy[v] = 0;
@@ -538,7 +483,7 @@ __global__ __launch_bounds__(256) void ft_sp_select(const FtPlan* plans, uint32_
 		sp_word<kS>(c, j, lane, w);
 		uint32_t claim[kS];
 		sp_term_claims(c, w, claim);
-		uint32_t rem = w.cand;
+		uint32_t rem = w.cand, g = 0, t = 0;
 		while (__ballot(rem != 0)) {
 			const bool have = rem != 0;
 			uint32_t sc = 0;
@@ -546,226 +491,254 @@ __global__ __launch_bounds__(256) void ft_sp_select(const FtPlan* plans, uint32_
 				const uint32_t b = uint32_t(__ffs(int(rem)) - 1);
 				rem &= rem - 1;
 				sc = sp_score(c, claim, b);
+				g |= uint32_t(sc > thr.score) << b;
+				t |= uint32_t(sc == thr.score) << b;
 			}
-			ties += (have && thr.on && sc == thr.score) ? 1u : 0u;
 			sp_keys_add(keys, have && sc != 0, sc, lane, clear);
 		}
+		if (!thr.on) {   // no preselect: every candidate stays
+			g = w.cand;
+			t = 0;
+		} else if (thr.all_ties) {
+			g |= t;
+			t = 0;
+		}
+		keptw[64 * j + lane] = g;   // above the threshold (or everything); the ties are found again once their quota is known
+		ties += uint32_t(__popc(t));
 	}
 	if (uint32_t(lane) < keys.n) clear(keys.key, keys.cnt);
-	uint32_t allowed = 0xFFFFFFFFu;
-	if (thr.on && !thr.all_ties) {
-		ties = wave_sum(ties);
-		const uint32_t before = sp_lookback(ties, range, p.lb_units, p.sync + kFtSyncError, lane);
-		allowed = thr.docs > before ? thr.docs - before : 0u;
-		if (lane == 0) p.unit_allow[range] = allowed;
+	if (thr.on && !thr.all_ties) {   // the ties this unit keeps: minScoreDocs minus those of the units in front, in document order
+		const uint32_t before = sp_lookback(wave_sum(ties), range, p.lb_units, p.sync + kFtSyncError, lane);
+		const uint32_t allowed = thr.docs > before ? thr.docs - before : 0u;
+		uint32_t ties_before = 0;
+		for (int j = 0; j < 4; ++j) {
+			SpWord<kS> w;
+			sp_word<kS>(c, j, lane, w);
+			uint32_t claim[kS];
+			sp_term_claims(c, w, claim);
+			uint32_t rem = w.cand & ~keptw[64 * j + lane], t = 0;   // not above the threshold: at it, or below
+			while (rem) {
+				const uint32_t b = uint32_t(__ffs(int(rem)) - 1);
+				rem &= rem - 1;
+				t |= uint32_t(sp_score(c, claim, b) == thr.score) << b;
+			}
+			const uint32_t cnt = uint32_t(__popc(t));
+			const uint32_t incl = wave_inclusive_scan(cnt, lane);
+			const uint32_t front = ties_before + incl - cnt;
+			ties_before += sp_readlane(incl, 63);
+			keptw[64 * j + lane] |= sp_lowest_bits(t, allowed > front ? allowed - front : 0u);
+		}
 	}
-	// pass 2: first met per (row, range) over the kept documents
+	sp_fence();
+	uint32_t kept_total = 0;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) kept_total += uint32_t(__popc(keptw[64 * j + lane]));
+	kept_total = wave_sum(kept_total);
+	uint32_t task0 = 0;
+	if (lane == 0 && kept_total) task0 = atomicAdd(&p.sync[kFtSyncTasks], kept_total);
+	task0 = sp_readlane(task0, 0);
 	uint32_t rows[kS];
+	if (task0 + kept_total > p.max_merged) {   // (cannot happen: preselectMostRelevantDocs keeps at most maxMergedDocs documents)
+		if (lane == 0) p.sync[kFtSyncError] = 1;
 #pragma unroll
-	for (int si = 0; si < kS; ++si) rows[si] = 0;
-	uint32_t ties_before = 0;
-	for (int j = 0; j < 4; ++j) {
-		SpWord<kS> w;
-		sp_word<kS>(c, j, lane, w);
-		const uint32_t kept = sp_kept_word(c, w, thr, allowed, ties_before, lane);
-		uint32_t fm[kS];
-		sp_first_met(c, w, kept, fm);
-#pragma unroll
-		for (int si = 0; si < kS; ++si) rows[si] += uint32_t(__popc(fm[si]));
+		for (int si = 0; si < kS; ++si) rows[si] = 0;
+		sp_store_rows<kS, false>(p, c, rows, lane);
+		return;
 	}
+	// pass 2: first met per (row, range) over the kept documents, one task each
+	uint32_t lo_u[kS];
+#pragma unroll
+	for (int si = 0; si < kS; ++si) lo_u[si] = sp_readlane(c.lo, si);
+	uint32_t emitted = 0;
+	sp_walk<kS>(
+		c, lane, rows, [&](int j, const SpWord<kS>&) { return keptw[64 * j + lane]; },
+		[&](int j, int si, const SpWord<kS>& w, const uint32_t (&pre)[kS], uint32_t fm, uint32_t rank0, uint32_t lanes_front, uint32_t total) {
+			const uint32_t row = sp_readlane(c.attr, si) >> 20;
+			const uint32_t t = task0 + emitted + lanes_front;
+			emitted += total;
+			uint32_t k = 0;
+			while (fm) {
+				const uint32_t b = uint32_t(__ffs(int(fm)) - 1);
+				fm &= fm - 1;
+				sp_emit<kS>(p, c, w, pre, lo_u, t + k, uint32_t(64 * j + lane), b, (row << 24) | (rank0 + k));
+				++k;
+			}
+		});
+	sp_store_rows<kS, false>(p, c, rows, lane);
+}
+
+// ---------------------------------------------------------------------------------------------- ft_sp_place
+// Queries without a preselect (Simple() ones, queries the host found below mergeLimit): the slots are known (ft_slot_bases ran over
+// ft_sp_scan's table), so only the documents below maxMergedDocs become tasks, at their slot.
+template <int kS>
+__global__ __launch_bounds__(256) void ft_sp_place(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	if (p.prescore) return;
+	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t unit = threadIdx.x >> 6, range = blockIdx.x * kSpUnits + unit;
+	if (range >= p.n_ranges) return;
+	// slot of the first document of (row, range): ft_slot_bases' prefix of the table, lane si holds sub-term si's
+	uint32_t base_v = 0xFFFFFFFFu;
+	if (uint32_t(lane) < p.n_subs) {
+		const uint32_t a = p.sp_sub[lane].attr;
+		if (!(a & kSpNot)) base_v = p.adders[uint64_t(a >> 20) * p.n_ranges + range];
+	}
+	uint32_t low = base_v;
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		const uint32_t o = uint32_t(__shfl_xor(int(low), off, 64));
+		low = o < low ? o : low;
+	}
+	if (low >= p.max_merged) return;   // slots ascend with (row, range): a range whose every row starts at or beyond the limit merges nothing
+	SpCtx<kS> c;
+	sp_open<kS>(p, sp_lds + unit * (kS * kSpWords), range, lane, c);
+	uint32_t lo_u[kS], base_u[kS], rows[kS];
 #pragma unroll
 	for (int si = 0; si < kS; ++si) {
-		if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
-		const uint32_t tot = wave_sum(rows[si]);
-		if (lane == 0) p.adders[uint64_t(sp_readlane(c.attr, si) >> 20) * p.n_ranges + range] = tot;
+		lo_u[si] = sp_readlane(c.lo, si);
+		base_u[si] = sp_readlane(base_v, si);
 	}
+	sp_walk<kS>(
+		c, lane, rows, [&](int, const SpWord<kS>& w) { return w.cand; },
+		[&](int j, int si, const SpWord<kS>& w, const uint32_t (&pre)[kS], uint32_t fm, uint32_t rank0, uint32_t, uint32_t) {
+			const uint32_t slot0 = base_u[si] + rank0;
+			uint32_t todo = sp_lowest_bits(fm, slot0 < p.max_merged ? p.max_merged - slot0 : 0u), k = 0;
+			while (todo) {
+				const uint32_t b = uint32_t(__ffs(int(todo)) - 1);
+				todo &= todo - 1;
+				sp_emit<kS>(p, c, w, pre, lo_u, slot0 + k, uint32_t(64 * j + lane), b, (slot0 + k) | 0x80000000u);
+				++k;
+			}
+		});
 }
 
-// ---------------------------------------------------------------------------------------------- ft_sp_finish
-// One document per lane: its postings in sub-term order = the order mergeTerm / mergeSimple met them (calcTermRank + replay), written at its slot
+// ---------------------------------------------------------------------------------------------- ft_sp_replay
+// One thread per merged document: its postings in sub-term order = the order mergeTerm / mergeSimple met them (calcTermRank + the replay of
+// ft_replay.hip.h), written at its slot.  The last workgroup writes the result header and hands the synchronisation words back zeroed.
 template <int kS>
-__device__ __forceinline__ void sp_replay_chunk(FtPlanK& p, const SpCtx<kS>& c, const uint16_t* prefix, bool have, uint32_t dl, uint32_t slot) {
-	uint32_t hits = 0;   // bit si: merged sub-term si holds the document
-	const uint32_t word = dl >> 5, bit = dl & 31u;
-	if (have) {
-#pragma unroll
-		for (int si = 0; si < kS; ++si) {
-			if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
-			hits |= ((c.bits[uint32_t(si) * kSpWords + word] >> bit) & 1u) << si;
-		}
-	}
-	const uint32_t doc = c.d_begin + dl;
-	FtReplayState st;
-	while (hits) {
-		const uint32_t si = uint32_t(__ffs(int(hits)) - 1);
-		hits &= hits - 1;
-		const FtPosSubterm& s = c.subs[si];
-		const FtTermCfg& t = c.terms[s.term];
-		const uint32_t wbits = c.bits[si * kSpWords + word];
-		const uint32_t i = c.lo[si] + prefix[si * kSpWords + word] + uint32_t(__popc(wbits & ((1u << bit) - 1u)));
-		uint8_t field = 0;
-		const float rank = ft_term_rank(t, s, s.ent_off[i], s.ent_off[i + 1], doc, &field);
-		FtPosList pos;
-		if (!p.simple) {
-			const uint32_t po0 = s.pos_off[i], po1 = s.pos_off[i + 1];
-			pos.ptr = s.fpos + po0;
-			pos.n = po1 - po0;
-		}
-		ft_replay_apply(p, st, rank, field, ft_row_qpw(s), pos);
-	}
-	if (have) {
-		p.out_doc[slot] = doc;
-		ft_replay_finish(p, st, slot, doc);
-	}
-}
-
-template <int kS>
-__global__ __launch_bounds__(256) void ft_sp_finish(const FtPlan* plans, uint32_t t_max) {
+__global__ __launch_bounds__(256) void ft_sp_replay(const FtPlan* plans) {
 	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
 	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
 	__shared__ uint32_t s_last;
-	const SpLayout L = sp_layout(kS, t_max, true);
-	sp_setup<kS>(p, sp_lds, L);
-	const int lane = threadIdx.x & 63;
-	const uint32_t unit = threadIdx.x >> 6, range = blockIdx.x * kSpUnits + unit;
-	if (range < p.n_ranges) {
-		const SpThreshold thr = sp_threshold(p);
-		SpCtx<kS> c;
-		sp_unit_ctx<kS>(p, sp_lds, L, unit, range, lane, c);
-		// slot of the first document of (row, range): ft_slot_bases' prefix of the table, lane si holds sub-term si's
-		uint32_t base_v = 0xFFFFFFFFu;
-		if (uint32_t(lane) < c.n_subs && !((c.not_m >> lane) & 1ull)) base_v = p.adders[uint64_t(c.attr >> 20) * p.n_ranges + range];
-		uint32_t allowed = 0xFFFFFFFFu;
-		if (thr.on && !thr.all_ties) allowed = p.unit_allow[range];
-		if (lane == 0 && p.lb_units) p.lb_units[range] = 0;   // (ft_sp_select is over: the look-back word goes back zeroed)
-		const uint32_t low = wave_min_u32(base_v);
-		if (low < p.max_merged) {   // slots ascend with (row, range): a range whose every row starts at or beyond the limit merges nothing
-			sp_build<kS>(c, lane);
-			uint32_t* ub = sp_lds + L.unit0 + unit * L.unit_stride;
-			uint16_t* prefix = reinterpret_cast<uint16_t*>(ub + L.u_prefix);   // [kS][kSpWords]: postings of the range in front of a word's
-			uint32_t* ring = ub + L.u_ring;                                     // [kSpRing] document in the range, [kSpRing] slot
-			{   // popcount prefix along every merged sub-term's bitmap: the posting index of a document = segment start + bits in front
-				uint32_t run[kS];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t n_docs = p.sync[kFtSyncNumDocs];   // ft_slot_bases: min(documents first met anywhere, maxMergedDocs)
+	if (blockIdx.x * 256 < n_docs) {
+		// the query's sub-term (by merge row) and term descriptors: calcTermRank reads a dozen of their fields per posting
+		const FtPosSubterm* subs = reinterpret_cast<const FtPosSubterm*>(sp_lds);
+		const FtTermCfg* terms = reinterpret_cast<const FtTermCfg*>(sp_lds + kS * (sizeof(FtPosSubterm) / 4));
+		{
+			const uint32_t sw = uint32_t(sizeof(FtPosSubterm) / 4), tw = uint32_t(sizeof(FtTermCfg) / 4);
+			for (uint32_t w = tid; w < p.n_rows * sw; w += 256) {
+				const uint32_t r = w / sw;
+				sp_lds[w] = reinterpret_cast<const uint32_t*>(p.subs + p.merge_grid[r].sub)[w - r * sw];
+			}
+			uint32_t* dt = sp_lds + kS * sw;
+			const uint32_t* src_t = reinterpret_cast<const uint32_t*>(p.terms);
+			for (uint32_t w = tid; w < p.nterms * tw; w += 256) dt[w] = src_t[w];
+		}
+		__syncthreads();
+		const uint32_t t = blockIdx.x * 256 + tid;
+		if (t < n_docs) {
+			const uint32_t doc = p.t_doc[t], pos = p.t_pos[t];
+			uint32_t slot;
+			if (pos >> 31) {
+				slot = pos & 0x7FFFFFFFu;
+			} else {   // ft_sp_select's task: the slot base of its (row, range) is known by now
+				slot = p.adders[uint64_t(pos >> 24) * p.n_ranges + (doc >> kFtRangeShift)] + (pos & 0xFFFFFFu);
+			}
+			uint32_t idx[kS];
+			const uint32_t* row = p.t_idx + size_t(t) * p.n_rows;
 #pragma unroll
-				for (int si = 0; si < kS; ++si) run[si] = 0;
-				for (int j = 0; j < 4; ++j) {
+			for (int r = 0; r < kS; ++r) idx[r] = uint32_t(r) < p.n_rows ? row[r] : 0u;
+			if (slot < p.max_merged) {
+				FtReplayState st;
 #pragma unroll
-					for (int si = 0; si < kS; ++si) {
-						if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
-						const uint32_t cnt = uint32_t(__popc(c.bits[uint32_t(si) * kSpWords + uint32_t(64 * j + lane)]));
-						const uint32_t incl = wave_inclusive_scan(cnt, lane);
-						prefix[uint32_t(si) * kSpWords + uint32_t(64 * j + lane)] = uint16_t(run[si] + incl - cnt);
-						run[si] += sp_readlane(incl, 63);
+				for (int r = 0; r < kS; ++r) {
+					if (!idx[r]) continue;
+					const uint32_t i = idx[r] - 1;
+					const FtPosSubterm& s = subs[r];
+					const FtTermCfg& tc = terms[s.term];
+					uint8_t field = 0;
+					const float rank = ft_term_rank(tc, s, s.ent_off[i], s.ent_off[i + 1], doc, &field);
+					FtPosList pl;
+					if (!p.simple) {
+						const uint32_t po0 = s.pos_off[i], po1 = s.pos_off[i + 1];
+						pl.ptr = s.fpos + po0;
+						pl.n = po1 - po0;
 					}
+					ft_replay_apply(p, st, rank, field, ft_row_qpw(s), pl);
 				}
+				p.out_doc[slot] = doc;
+				ft_replay_finish(p, st, slot, doc);
 			}
-			sp_fence();
-			uint32_t base_u[kS], met[kS];
-#pragma unroll
-			for (int si = 0; si < kS; ++si) {
-				base_u[si] = sp_readlane(base_v, si);
-				met[si] = 0;   // documents of the unit first met in row si so far
-			}
-			uint32_t head = 0, count = 0, ties_before = 0;
-			auto drain = [&](bool all) {
-				while (count >= 64 || (all && count)) {
-					const bool have = uint32_t(lane) < count;
-					const uint32_t at = (head + uint32_t(lane)) & (kSpRing - 1);
-					sp_replay_chunk<kS>(p, c, prefix, have, have ? ring[at] : 0u, have ? ring[kSpRing + at] : 0u);
-					const uint32_t took = count < 64 ? count : 64;
-					head = (head + took) & (kSpRing - 1);
-					count -= took;
-				}
-			};
-			for (int j = 0; j < 4; ++j) {
-				SpWord<kS> w;
-				sp_word<kS>(c, j, lane, w);
-				const uint32_t kept = sp_kept_word(c, w, thr, allowed, ties_before, lane);
-				uint32_t fm[kS];
-				sp_first_met(c, w, kept, fm);
-#pragma unroll
-				for (int si = 0; si < kS; ++si) {
-					if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
-					if (base_u[si] + met[si] >= p.max_merged) continue;   // the rest of this row lies beyond the limit
-					const uint32_t cnt = uint32_t(__popc(fm[si]));
-					const uint32_t incl = wave_inclusive_scan(cnt, lane);
-					const uint32_t first_slot = base_u[si] + met[si] + incl - cnt;
-					met[si] += sp_readlane(incl, 63);
-					uint32_t room = first_slot < p.max_merged ? p.max_merged - first_slot : 0u;
-					uint32_t todo = sp_lowest_bits(fm[si], room), k = 0;
-					while (__ballot(todo != 0)) {   // one document per lane and pass into the ring
-						const bool have = todo != 0;
-						const unsigned long long m = __ballot(have);
-						if (have) {
-							const uint32_t b = uint32_t(__ffs(int(todo)) - 1);
-							todo &= todo - 1;
-							const uint32_t at = (head + count + sp_lanes_below(m, lane)) & (kSpRing - 1);
-							ring[at] = uint32_t(64 * j + lane) * 32 + b;
-							ring[kSpRing + at] = first_slot + k;
-							++k;
-						}
-						count += uint32_t(__popcll(m));
-						sp_fence();
-						drain(false);
-					}
-				}
-			}
-			sp_fence();
-			drain(true);
 		}
 	}
-	// ---- the last workgroup writes the result header and hands the synchronisation words back zeroed
+	// the look-back words of ft_sp_select go back zeroed (every unit of that kernel is over)
+	if (p.prescore) {
+		for (uint32_t r = blockIdx.x * 256 + tid; r < p.n_ranges; r += gridDim.x * 256) p.lb_units[r] = 0;
+	}
 	__syncthreads();
-	if (threadIdx.x == 0) s_last = atomicAdd(&p.sync[kFtSyncDoneFinish], 1u) == gridDim.x - 1 ? 1u : 0u;
+	if (tid == 0) s_last = atomicAdd(&p.sync[kFtSyncDoneFinish], 1u) == gridDim.x - 1 ? 1u : 0u;
 	__syncthreads();
 	if (!s_last) return;
-	if (threadIdx.x == 0) {
-		p.out_header[0] = p.sync[kFtSyncNumDocs];
+	if (tid == 0) {
+		p.out_header[0] = n_docs;
 		p.out_header[1] = p.sync[kFtSyncError];
 		p.out_header[2] = p.prescore ? (p.sync[kFtSyncThrFlags] & 1u) : 0u;
 		p.out_header[3] = 0;
 	}
 	__syncthreads();
-	if (threadIdx.x < kFtSyncWords) p.sync[threadIdx.x] = 0;
+	if (tid < kFtSyncWords) p.sync[tid] = 0;
 }
 
 template <int kS>
-hipError_t sp_launch(const FtPlan* plans, uint32_t nq, uint32_t n_ranges, uint32_t t_max, bool any_pre, hipStream_t st) {
-	const size_t lds_scan = size_t(sp_layout(kS, t_max, false).total_words) * 4, lds_fin = size_t(sp_layout(kS, t_max, true).total_words) * 4;
-	static std::atomic<uint64_t> raised_a{0}, raised_b{0}, raised_c{0};
+hipError_t sp_launch(const FtPlan* plans, uint32_t nq, uint32_t n_pre, uint32_t n_ranges, uint32_t t_max, uint32_t m_max, hipStream_t st) {
 	constexpr uint32_t kTermsMax = 32;   // ft_sparse_eligible's bound on the query's terms
 	if (t_max > kTermsMax) return hipErrorInvalidValue;
-	const size_t max_scan = size_t(sp_layout(kS, kTermsMax, false).total_words) * 4, max_fin = size_t(sp_layout(kS, kTermsMax, true).total_words) * 4;
-	if (hipError_t e = raise_dynamic_lds_once(raised_a, reinterpret_cast<const void*>(&ft_sp_scan<kS>), max_scan); e != hipSuccess) return e;
-	if (hipError_t e = raise_dynamic_lds_once(raised_b, reinterpret_cast<const void*>(&ft_sp_select<kS>), max_scan); e != hipSuccess) return e;
-	if (hipError_t e = raise_dynamic_lds_once(raised_c, reinterpret_cast<const void*>(&ft_sp_finish<kS>), max_fin); e != hipSuccess) return e;
-	const dim3 grid((n_ranges + kSpUnits - 1) / kSpUnits, nq);
-	hipLaunchKernelGGL(ft_sp_scan<kS>, grid, dim3(256), lds_scan, st, plans, t_max);
-	if (any_pre) {
-		hipLaunchKernelGGL(ft_sp_threshold, dim3(1, nq), dim3(256), 0, st, plans);
-		hipLaunchKernelGGL(ft_sp_select<kS>, grid, dim3(256), lds_scan, st, plans, t_max);
+	const size_t lds_scan = size_t(kSpUnits) * kS * kSpWords * 4, lds_sel = size_t(kSpUnits) * (kS + 1) * kSpWords * 4;
+	const size_t lds_replay = size_t(kS) * sizeof(FtPosSubterm) + size_t(kTermsMax) * sizeof(FtTermCfg);
+	static std::atomic<uint64_t> raised_a{0}, raised_b{0}, raised_c{0}, raised_d{0};
+	if (hipError_t e = raise_dynamic_lds_once(raised_a, reinterpret_cast<const void*>(&ft_sp_scan<kS>), lds_scan); e != hipSuccess) return e;
+	if (hipError_t e = raise_dynamic_lds_once(raised_b, reinterpret_cast<const void*>(&ft_sp_select<kS>), lds_sel); e != hipSuccess) return e;
+	if (hipError_t e = raise_dynamic_lds_once(raised_c, reinterpret_cast<const void*>(&ft_sp_place<kS>), lds_scan); e != hipSuccess) return e;
+	if (hipError_t e = raise_dynamic_lds_once(raised_d, reinterpret_cast<const void*>(&ft_sp_replay<kS>), lds_replay); e != hipSuccess) return e;
+	const uint32_t gx = (n_ranges + kSpUnits - 1) / kSpUnits;
+	static const int stop = std::getenv("RXGPU_FT_SP_STOP") ? std::atoi(std::getenv("RXGPU_FT_SP_STOP")) : 0;   // debugging: leave the train after kernel <stop>
+	hipLaunchKernelGGL(ft_sp_scan<kS>, dim3(gx, nq), dim3(256), lds_scan, st, plans);
+	if (stop == 1) return hipGetLastError();
+	if (n_pre) {
+		hipLaunchKernelGGL(ft_sp_threshold, dim3(1, n_pre), dim3(256), 0, st, plans);
+		if (stop == 2) return hipGetLastError();
+		hipLaunchKernelGGL(ft_sp_select<kS>, dim3(gx, n_pre), dim3(256), lds_sel, st, plans);
 	}
+	if (stop == 3) return hipGetLastError();
 	launch_ft_slot_bases(plans, nq, st);
-	hipLaunchKernelGGL(ft_sp_finish<kS>, grid, dim3(256), lds_fin, st, plans, t_max);
+	if (stop == 4) return hipGetLastError();
+	if (nq > n_pre) hipLaunchKernelGGL(ft_sp_place<kS>, dim3(gx, nq - n_pre), dim3(256), lds_scan, st, plans + n_pre);
+	hipLaunchKernelGGL(ft_sp_replay<kS>, dim3((m_max + 255) / 256, nq), dim3(256), lds_replay, st, plans);
 	return hipGetLastError();
 }
 
 }  // namespace
 
-// plans: nq plans with sparse = 1 over ONE index, in HBM; host_plans: their host copies
+// plans: nq plans with sparse = 1 over ONE index, in HBM, those with prescore = 1 first; host_plans: their host copies
 hipError_t launch_ft_merge_sparse(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st) {
 	if (!nq) return hipSuccess;
-	uint32_t s_max = 1, t_max = 1;
-	bool any_pre = false;
+	uint32_t s_max = 1, t_max = 1, m_max = 1, n_pre = 0;
 	for (uint32_t q = 0; q < nq; ++q) {
 		s_max = std::max(s_max, host_plans[q].n_subs);
 		t_max = std::max(t_max, host_plans[q].nterms);
-		any_pre = any_pre || host_plans[q].prescore;
+		m_max = std::max(m_max, host_plans[q].max_merged);
+		if (host_plans[q].prescore) {
+			if (n_pre != q) return hipErrorInvalidValue;   // (the caller sorts them to the front)
+			++n_pre;
+		}
 	}
 	const uint32_t n_ranges = host_plans[0].n_ranges;
-	if (s_max <= 4) return sp_launch<4>(plans, nq, n_ranges, t_max, any_pre, st);
-	if (s_max <= 8) return sp_launch<8>(plans, nq, n_ranges, t_max, any_pre, st);
-	if (s_max <= kFtSparseSubs) return sp_launch<16>(plans, nq, n_ranges, t_max, any_pre, st);
+	if (s_max <= 4) return sp_launch<4>(plans, nq, n_pre, n_ranges, t_max, m_max, st);
+	if (s_max <= 8) return sp_launch<8>(plans, nq, n_pre, n_ranges, t_max, m_max, st);
+	if (s_max <= kFtSparseSubs) return sp_launch<16>(plans, nq, n_pre, n_ranges, t_max, m_max, st);
 	return hipErrorInvalidValue;
 }
 

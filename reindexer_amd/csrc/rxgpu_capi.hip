@@ -42,6 +42,12 @@ int rxgpu_devbuf::ensure(size_t need) {
 	const size_t want = std::max<size_t>(need, 4096);
 	RX_HIP(hipMalloc(&ptr, want));
 	bytes = want;
+	// RXGPU_DEBUG_FILL=<byte>: every fresh scratch buffer is filled with it (a read before the first write then shows, whatever the allocator returned)
+	static const int fill = [] {
+		const char* e = std::getenv("RXGPU_DEBUG_FILL");
+		return e ? int(std::strtol(e, nullptr, 0)) & 0xFF : -1;
+	}();
+	if (fill >= 0) RX_HIP(hipMemset(ptr, fill, want));
 	return RXGPU_OK;
 }
 void rxgpu_devbuf::release() {

@@ -1362,7 +1362,9 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	const size_t o_adders = cv.take(std::max<size_t>(1, size_t(n_rows) * n_ranges) * 4);
 	const size_t o_eidx = cv.take(sparse ? 0 : size_t(n_rows) * M * 4);
 	const size_t o_efield = cv.take(sparse ? 0 : size_t(n_rows) * M);
-	const size_t o_allow = cv.take(sparse ? size_t(n_ranges) * 4 : 0);
+	const size_t o_tdoc = cv.take(sparse ? M * 4 : 0);
+	const size_t o_tpos = cv.take(sparse ? M * 4 : 0);
+	const size_t o_tidx = cv.take(sparse ? M * std::max<size_t>(1, n_rows) * 4 : 0);
 	if (int rc = h->d_state.ensure(cv.off); rc) return rc;
 	char* base = static_cast<char*>(h->d_state.ptr);
 	// the kept-clean tables: sized by the corpus only, so that they stay where they are from merge to merge
@@ -1483,8 +1485,33 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	p.sparse = sparse ? 1 : 0;
 	p.removed_bits = h->d_removed_bits;
 	p.excluded_bits = d_excluded_bits;
-	p.unit_allow = sparse ? reinterpret_cast<uint32_t*>(base + o_allow) : nullptr;
 	p.lb_units = reinterpret_cast<unsigned long long*>(cbase + o_lb_units);
+	if (sparse) {
+		p.t_doc = reinterpret_cast<uint32_t*>(base + o_tdoc);
+		p.t_pos = reinterpret_cast<uint32_t*>(base + o_tpos);
+		p.t_idx = reinterpret_cast<uint32_t*>(base + o_tidx);
+		for (size_t si = 0; si < subs.size(); ++si) {   // what the unit kernels read of a sub-term, and its attribute word (ft_sparse.hip)
+			const rxgpu::FtPosSubterm& ft = subs[si];
+			const rxgpu::FtTermCfg& tc = tcfg[ft.term];
+			const QueryTermIn& qt = terms[parts[ft.term].t_begin];
+			// calcTermScores (mergerimpl.h:312-315): every field has the same boost, so maxBoostFromFields is field 0's
+			const float proc = ft.proc * qt.opts->field_boost[0] * tc.opts_boost;
+			uint32_t p16 = uint32_t(int32_t(proc)) & 0xFFFFu;   // static_cast<uint16_t>(float) as x86 evaluates it
+			p16 = std::min<uint32_t>(p16, 65535u / 4);
+			uint32_t attr = p16 | (ft.row << 20);
+			if (si == tc.sub_begin) attr |= 1u << 16;
+			if (tc.op == 2) attr |= 1u << 17;
+			if (tc.op == 3) attr |= 1u << 18;
+			p.sp_sub[si].doc = ft.doc;
+			p.sp_sub[si].range_off = ft.range_off;
+			p.sp_sub[si].n = uint32_t(ft.n);
+			p.sp_sub[si].n_ranges = ft.n_ranges;
+			p.sp_sub[si].attr = attr;
+		}
+		for (uint32_t pi = 0; pi < nparts && !simple; ++pi) {   // an AND term without postings empties the mask (buildRestrictingBitmask)
+			if (tcfg[pi].op == 2 && tcfg[pi].sub_begin == tcfg[pi].sub_end) p.sp_empty_and = 1;
+		}
+	}
 	if (h->sh_total > 1) {   // a document-range shard: its own ranges, the facts that span the shards arrive between the kernels
 		RX_CHECK(!resident && !nsyn && !max_areas && n_phrases == 0, RXGPU_ERR_LOGIC,
 				 std::string(who) + ": a sharded ft index merges plain terms (no phrases, multi-word synonyms, areas or resident results)");
@@ -1864,6 +1891,37 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 		} else {
 			RX_HIP(q);
 		}
+	}
+	if (job.p.sparse && std::getenv("RXGPU_FT_SP_STOP")) {   // debugging: what the sparse train left behind when it was cut short
+		RX_HIP(hipStreamSynchronize(st));
+		uint32_t sy[rxgpu::kFtSyncWords];
+		RX_HIP(hipMemcpy(sy, job.p.sync, sizeof(sy), hipMemcpyDeviceToHost));
+		std::fprintf(stderr, "[sp dbg] sync:");
+		for (uint32_t k = 0; k < rxgpu::kFtSyncWords; ++k) std::fprintf(stderr, " %u", sy[k]);
+		std::vector<uint32_t> ad(size_t(job.p.n_rows) * job.p.n_ranges);
+		RX_HIP(hipMemcpy(ad.data(), job.p.adders, ad.size() * 4, hipMemcpyDeviceToHost));
+		std::fprintf(stderr, "\n[sp dbg] adders (%u rows x %u ranges):", job.p.n_rows, job.p.n_ranges);
+		for (uint32_t r = 0; r < job.p.n_rows; ++r) {
+			std::fprintf(stderr, "\n   row %u:", r);
+			for (uint32_t c = 0; c < job.p.n_ranges; ++c) std::fprintf(stderr, " %u", ad[size_t(r) * job.p.n_ranges + c]);
+		}
+		if (job.p.hist) {
+			std::vector<uint32_t> hs(size_t(rxgpu::kFtHistCopies) * rxgpu::kFtHistStride);
+			RX_HIP(hipMemcpy(hs.data(), job.p.hist, hs.size() * 4, hipMemcpyDeviceToHost));
+			std::fprintf(stderr, "\n[sp dbg] hist:");
+			for (uint32_t v = 0; v < 65536; ++v) {
+				uint32_t c = 0;
+				for (uint32_t k = 0; k < rxgpu::kFtHistCopies; ++k) c += hs[size_t(k) * rxgpu::kFtHistStride + v];
+				if (c) std::fprintf(stderr, " %u:%u", v, c);
+			}
+		}
+		std::vector<unsigned long long> lb(job.p.n_ranges);
+		RX_HIP(hipMemcpy(lb.data(), job.p.lb_units, lb.size() * 8, hipMemcpyDeviceToHost));
+		std::fprintf(stderr, "\n[sp dbg] lookback:");
+		for (unsigned long long v : lb) std::fprintf(stderr, " %llx", v);
+		std::fprintf(stderr, "\n");
+		RX_HIP(hipMemset(h->d_clean.ptr, 0, h->d_clean.bytes));
+		return RXGPU_ERR_LOGIC;
 	}
 	if (p.dbg) {
 		unsigned long long raw[64];
@@ -2545,7 +2603,10 @@ int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 		const uint32_t B = uint32_t(jobs.size());
 		if (!B) continue;
 		// the sparse train's queries in front, the dense train's behind: each train is launched over its own run of plans
-		std::stable_partition(host_plans.begin(), host_plans.end(), [](const rxgpu::FtPlan& pl) { return pl.sparse != 0; });
+		std::stable_sort(host_plans.begin(), host_plans.end(), [](const rxgpu::FtPlan& a, const rxgpu::FtPlan& b) {
+			const int ka = a.sparse ? (a.prescore ? 0 : 1) : 2, kb = b.sparse ? (b.prescore ? 0 : 1) : 2;   // (the sparse train runs the preselecting queries as one run)
+			return ka < kb;
+		});
 		uint32_t n_sparse = 0;
 		while (n_sparse < B && host_plans[n_sparse].sparse) ++n_sparse;
 		std::memcpy(h->h_batch_plans, host_plans.data(), size_t(B) * sizeof(rxgpu::FtPlan));

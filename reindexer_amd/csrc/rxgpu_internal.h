@@ -282,15 +282,29 @@ struct FtPlan {
 	// The train for SPARSELY hit document ranges (ft_sparse.hip): one wavefront per (query, range), bitmaps of the range's documents per
 	// sub-term in LDS, nothing per document in HBM.  sparse = 1: the host found the query eligible (ft_sparse_eligible, rxgpu_ft_capi.hip).
 	uint8_t sparse;
+	uint8_t sp_empty_and;         // an AND term without postings: no document passes the mask
 	const uint32_t* removed_bits; // [nwords] DocRemoved as one bit per document (null: none removed); built by rxgpu_ft_set_docs
 	const uint32_t* excluded_bits;// [nwords] docsExcluded of this merge as bits (null: none)
-	uint32_t* unit_allow;         // [n_ranges] ties at the threshold score the range keeps (ft_sp_select -> ft_sp_finish)
 	unsigned long long* lb_units; // [n_ranges] look-back words of ft_sp_select's ordered tie count; kept zero between merges
+	// the merged documents as ft_sp_select / ft_sp_place found them, one task each, replayed by ft_sp_replay:
+	//   t_doc [max_merged] document; t_pos [max_merged] its slot | 1 << 31, or merge row << 24 | rank among the (row, range)'s documents;
+	//   t_idx [max_merged][n_rows] posting index + 1 of the document in sub-term row r, 0: none
+	uint32_t* t_doc;
+	uint32_t* t_pos;
+	uint32_t* t_idx;
+	struct SpSub {                // what the unit kernels read of sub-term si (lane si loads entry si)
+		const uint32_t* doc;
+		const uint32_t* range_off;
+		uint32_t n, n_ranges;
+		uint32_t attr;            // proc16 | first sub-term of its term << 16 | AND term << 17 | NOT term << 18 | merge row << 20
+		uint32_t pad;
+	} sp_sub[16];
 };
+static_assert(sizeof(FtPlan::SpSub) == 32, "one 32-byte entry per lane");
 constexpr uint32_t kFtFoldWords = 65536 + 1024 + 64;   // one shard's folded histogram (fine + chunk counters), [65536 + 1024] = its mask popcount
 enum : uint32_t { kFtSyncError = 0, kFtSyncPop = 1, kFtSyncPreTicket = 4, kFtSyncNumDocs = 6, kFtSyncDoneFinish = 9,
 				  // the sparse train: threshold score / documents kept at it / flags (bit 0 preselect on, bit 1 every tie is kept), the ticket of ft_sp_select
-				  kFtSyncThrScore = 10, kFtSyncThrDocs = 11, kFtSyncThrFlags = 12, kFtSyncSpTicket = 13, kFtSyncWords = 16 };
+				  kFtSyncThrScore = 10, kFtSyncThrDocs = 11, kFtSyncThrFlags = 12, kFtSyncSpTicket = 13, kFtSyncTasks = 14, kFtSyncWords = 16 };
 constexpr uint32_t kFtHistCopies = 8, kFtHistStride = 65536 + 1024;
 constexpr uint32_t kFtRangeShift = 13;     // log2(kFtRangeDocs)
 static_assert((1u << kFtRangeShift) == kFtRangeDocs, "document ranges are powers of two");
@@ -299,8 +313,8 @@ hipError_t launch_ft_merge(const FtPlan* plans, const FtPlan* host_plans, uint32
 // the same train in the three pieces a sharded merge exchanges between: 0 = [syn masks] + ft_ranges, 1 = [ft_preselect_apply] + ft_rank_all +
 // ft_adders, 2 = [ft_slot_bases] + ft_finish
 hipError_t launch_ft_merge_phase(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, int phase, hipStream_t st);
-// the train for sparsely hit ranges (ft_sparse.hip) over nq plans that all have sparse = 1: ft_sp_scan, [ft_sp_threshold, ft_sp_select],
-// ft_slot_bases, ft_sp_finish
+// the train for sparsely hit ranges (ft_sparse.hip) over nq plans that all have sparse = 1, those with prescore = 1 in front: ft_sp_scan,
+// [ft_sp_threshold, ft_sp_select], ft_slot_bases, [ft_sp_place], ft_sp_replay
 hipError_t launch_ft_merge_sparse(const FtPlan* plans, const FtPlan* host_plans, uint32_t nq, hipStream_t st);
 void launch_ft_slot_bases(const FtPlan* plans, uint32_t nq, hipStream_t st);   // ft_merge.hip
 constexpr uint32_t kFtSparseSubs = 16;   // sub-terms (NOT terms' included) a sparse merge holds bitmaps for

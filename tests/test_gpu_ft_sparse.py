@@ -34,22 +34,38 @@ def same(a, b):
             and np.array_equal(a[3], b[3]) and a[4] == b[4])
 
 
+class Pair:
+    """Two mergers over the same index: one only ever runs the dense train, the other the sparse one whenever the query is eligible — a train
+    never finds the other's result of the same query in its output buffers."""
+
+    def __init__(self, hostapi, nf, words, avg, removed, store):
+        self.ms = []
+        for _ in range(2):
+            m = hostapi.GpuFtMerger(nf)
+            m.set_docs(words, avg, removed)
+            for s in store:
+                m.set_word_fpos(s["word"], s)
+            self.ms.append(m)
+        self.dense, self.sparse = self.ms
+
+    def close(self):
+        for m in self.ms:
+            m.close()
+
+
 def load(hostapi, nf, words, avg, removed, store):
-    m = hostapi.GpuFtMerger(nf)
-    m.set_docs(words, avg, removed)
-    for s in store:
-        m.set_word_fpos(s["word"], s)
-    return m
+    return Pair(hostapi, nf, words, avg, removed, store)
 
 
 def both_trains(hostapi, m, cfg, gterms, exc, expect_sparse=True):
-    hostapi.set_ft_train_mode(0)
-    m.read_train_stats()
-    d = m.merge_query(cfg, gterms, exc, sort_by_rank=False)
-    assert m.read_train_stats() == (1, 0)
     hostapi.set_ft_train_mode(1)
-    s = m.merge_query(cfg, gterms, exc, sort_by_rank=False)
-    assert m.read_train_stats() == ((0, 1) if expect_sparse else (1, 0))
+    m.sparse.read_train_stats()
+    s = m.sparse.merge_query(cfg, gterms, exc, sort_by_rank=False)
+    assert m.sparse.read_train_stats() == ((0, 1) if expect_sparse else (1, 0))
+    hostapi.set_ft_train_mode(0)
+    m.dense.read_train_stats()
+    d = m.dense.merge_query(cfg, gterms, exc, sort_by_rank=False)
+    assert m.dense.read_train_stats() == (1, 0)
     return d, s
 
 
@@ -172,7 +188,10 @@ def test_batch_mixing_both_trains(hostapi, ft):
     wide = _multi_case(4243, nf, total, 700, (1, 1), False, None, sizes=(300, 900), nsub_range=(10, 12))
     for s in wide[6]:
         s["word"] += 1000
-    m = load(hostapi, nf, words, avg, removed, store + wide[6])
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg, removed)
+    for s_ in store + wide[6]:
+        m.set_word_fpos(s_["word"], s_)
     rng = np.random.default_rng(9)
     queries, oracle_terms = [], []
     for it in range(12):
@@ -203,7 +222,10 @@ def test_one_merger_many_shapes_auto_mode(hostapi, ft):
     synchronisation words, look-back words) are handed back clean by whichever ran."""
     nf, total = 2, 100_000
     _, words, avg, removed, excluded, terms_all, store = _multi_case(5151, nf, total, 20000, (1, 1, 2, 1, 3, 1), False, None, sizes=(800, 30_000), nsub_range=(2, 5))
-    m = load(hostapi, nf, words, avg, removed, store)
+    m = hostapi.GpuFtMerger(nf)
+    m.set_docs(words, avg, removed)
+    for s_ in store:
+        m.set_word_fpos(s_["word"], s_)
     rng = np.random.default_rng(5)
     hostapi.set_ft_train_mode(-1)
     m.read_train_stats()
