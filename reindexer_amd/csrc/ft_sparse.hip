@@ -33,7 +33,6 @@
 #include <stdint.h>
 
 #include <algorithm>
-#include <cstdlib>
 
 #include "rxgpu_internal.h"
 #include "knn_kernels.hip.h"
@@ -59,6 +58,18 @@ __device__ __forceinline__ void sp_fence() {
 	__builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ uint32_t sp_readlane(uint32_t v, int lane) { return uint32_t(__builtin_amdgcn_readlane(int(v), lane)); }
+// Inclusive prefix sum over the wavefront on the DPP path: four row_shr steps inside the rows of 16 lanes, then lane 15 of rows 0 / 2 into
+// rows 1 / 3 (row_bcast:15) and lane 31 into rows 2 and 3 (row_bcast:31) — twelve VALU instructions, no LDS crossbar (the unit kernels
+// are bound by instruction issue, and a ds_bpermute scan costs three times that).
+__device__ __forceinline__ uint32_t sp_scan(uint32_t v) {
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x111, 0xF, 0xF, true));   // row_shr:1
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x112, 0xF, 0xF, true));   // row_shr:2
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x114, 0xF, 0xF, true));   // row_shr:4
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x118, 0xF, 0xF, true));   // row_shr:8
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+	v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+	return v;
+}
 
 // What a unit knows about its query (uniform over the wavefront) and its range
 template <int kS>
@@ -111,7 +122,7 @@ __device__ __forceinline__ void sp_open(FtPlanK& p, uint32_t* unit_lds, uint32_t
 	uint4* b4 = reinterpret_cast<uint4*>(c.bits);
 	for (uint32_t k = uint32_t(lane); k < kS * kSpWords / 4; k += 64) b4[k] = make_uint4(0u, 0u, 0u, 0u);
 	const uint32_t len = hi - lo;
-	const uint32_t incl = wave_inclusive_scan(len, lane);
+	const uint32_t incl = sp_scan(len);
 	const uint32_t cum = incl - len;                     // lane si: postings of the range in front of sub-term si
 	const uint32_t total = sp_readlane(incl, 63);
 	uint32_t cum_u[kS];
@@ -221,19 +232,37 @@ __device__ __forceinline__ void sp_first_met(const SpCtx<kS>& c, const SpWord<kS
 	}
 }
 
+// A lane's own pre-score counts: four (score, count) pairs in registers, compared without a cross-lane operation per document (a query has
+// a handful of distinct scores: sums of its sub-terms' proc16); a fifth distinct score in one lane goes straight to HBM
+struct SpLaneKeys {
+	uint32_t k[4] = {0, 0, 0, 0}, c[4] = {0, 0, 0, 0};
+	template <typename Overflow>
+	__device__ __forceinline__ void add(uint32_t sc, Overflow&& overflow) {   // sc != 0
+		bool done = false;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const bool hit = !done && (k[i] == sc || c[i] == 0);
+			k[i] = hit ? sc : k[i];
+			c[i] += hit ? 1u : 0u;
+			done = done || hit;
+		}
+		if (!done) overflow(sc, 1u);
+	}
+};
 // The distinct pre-scores of a unit with their document counts, one (score, count) per lane; more than 64 distinct scores go straight to HBM
 struct SpKeys {
 	uint32_t key = 0, cnt = 0;
 	uint32_t n = 0;   // uniform
 };
 template <typename Overflow>
-__device__ __forceinline__ void sp_keys_add(SpKeys& t, bool have, uint32_t sc, int lane, Overflow&& overflow) {
+__device__ __forceinline__ void sp_keys_add(SpKeys& t, bool have, uint32_t sc, uint32_t weight, int lane, Overflow&& overflow) {
 	unsigned long long pending = __ballot(have);
 	while (pending) {
 		const int leader = __ffsll((long long)pending) - 1;
 		const uint32_t v = uint32_t(__shfl(int(sc), leader, 64));
-		const unsigned long long same = __ballot(have && sc == v);
-		const uint32_t c = uint32_t(__popcll(same));
+		const bool mine = have && sc == v;
+		const unsigned long long same = __ballot(mine);
+		const uint32_t c = wave_sum(mine ? weight : 0u);
 		const unsigned long long found = __ballot(uint32_t(lane) < t.n && t.key == v);
 		if (found) {
 			if (lane == __ffsll((long long)found) - 1) t.cnt += c;
@@ -309,24 +338,21 @@ __device__ __forceinline__ void sp_store_rows(FtPlanK& p, const SpCtx<kS>& c, co
 // prescore: the restricting mask's popcount and the pre-score histogram of the unit's documents (the input of the 2-phase gate and of the
 // threshold).  Otherwise (Simple() queries, queries below mergeLimit): the documents first met per (row, range) — ft_adders' table — at once.
 template <int kS>
-__global__ __launch_bounds__(256) void ft_sp_scan(const FtPlan* plans) {
-	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
-	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
-	const int lane = threadIdx.x & 63;
-	const uint32_t unit = threadIdx.x >> 6, range = blockIdx.x * kSpUnits + unit;
-	if (range >= p.n_ranges) return;
+__device__ __forceinline__ void sp_scan_unit(FtPlanK& p, uint32_t* unit_lds, uint32_t range, int lane) {
 	SpCtx<kS> c;
-	sp_open<kS>(p, sp_lds + unit * (kS * kSpWords), range, lane, c);
+	sp_open<kS>(p, unit_lds, range, lane, c);
 	uint32_t pop = 0;
 	uint32_t rows[kS];
 #pragma unroll
 	for (int si = 0; si < kS; ++si) rows[si] = 0;
-	SpKeys keys;
-	uint32_t* hist_copy = p.prescore ? p.hist + size_t(range % kFtHistCopies) * kFtHistStride : nullptr;
+	// (the sparse train counts into histogram copy 0 alone: a unit adds each of its few distinct scores once, and ft_sp_threshold, which
+	// clears what it has read, then has one copy to clear)
+	uint32_t* hist_copy = p.hist;
 	auto overflow = [&](uint32_t v, uint32_t n) {
 		atomicAdd(&hist_copy[v], n);
 		atomicAdd(&hist_copy[65536 + (v >> 6)], n);
 	};
+	SpLaneKeys mine;
 	for (int j = 0; j < 4; ++j) {
 		SpWord<kS> w;
 		sp_word<kS>(c, j, lane, w);
@@ -335,15 +361,11 @@ __global__ __launch_bounds__(256) void ft_sp_scan(const FtPlan* plans) {
 			uint32_t claim[kS];
 			sp_term_claims(c, w, claim);
 			uint32_t rem = w.cand;
-			while (__ballot(rem != 0)) {
-				const bool have = rem != 0;
-				uint32_t sc = 0;
-				if (have) {
-					const uint32_t b = uint32_t(__ffs(int(rem)) - 1);
-					rem &= rem - 1;
-					sc = sp_score(c, claim, b);
-				}
-				sp_keys_add(keys, have && sc != 0, sc, lane, overflow);   // (score 0 is not counted: mergerimpl.h:433 walks scores >= 1)
+			while (rem) {
+				const uint32_t b = uint32_t(__ffs(int(rem)) - 1);
+				rem &= rem - 1;
+				const uint32_t sc = sp_score(c, claim, b);
+				if (sc) mine.add(sc, overflow);   // (score 0 is not counted: mergerimpl.h:433 walks scores >= 1)
 			}
 		} else {
 			uint32_t fm[kS];
@@ -355,10 +377,35 @@ __global__ __launch_bounds__(256) void ft_sp_scan(const FtPlan* plans) {
 	if (p.prescore) {
 		pop = wave_sum(pop);
 		if (lane == 0 && pop) atomicAdd(&p.sync[kFtSyncPop], pop);
+		SpKeys keys;   // the lanes' tables folded into one per unit: one atomic per distinct score and unit
+#pragma unroll
+		for (int i = 0; i < 4; ++i) sp_keys_add(keys, mine.c[i] != 0, mine.k[i], mine.c[i], lane, overflow);
 		if (uint32_t(lane) < keys.n) overflow(keys.key, keys.cnt);
 	} else {
 		sp_store_rows<kS, true>(p, c, rows, lane);
 	}
+}
+// A batch is launched for its widest query (kMax bitmaps per unit in LDS); a unit of a narrower query runs the narrower code: the kernels
+// are bound by instruction issue, and most of their loops run over the sub-terms.
+#define SP_DISPATCH(kMax, n_subs, call4, call8, callmax) \
+	do {                                                 \
+		if (kMax > 4 && (n_subs) <= 4) {                 \
+			call4;                                       \
+		} else if (kMax > 8 && (n_subs) <= 8) {          \
+			call8;                                       \
+		} else {                                         \
+			callmax;                                     \
+		}                                                \
+	} while (0)
+template <int kMax>
+__global__ __launch_bounds__(256) void ft_sp_scan(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t unit = threadIdx.x >> 6, range = blockIdx.x * kSpUnits + unit;
+	if (range >= p.n_ranges) return;
+	uint32_t* unit_lds = sp_lds + unit * (kMax * kSpWords);
+	SP_DISPATCH(kMax, p.n_subs, sp_scan_unit<4>(p, unit_lds, range, lane), sp_scan_unit<8>(p, unit_lds, range, lane), sp_scan_unit<kMax>(p, unit_lds, range, lane));
 }
 
 // ---------------------------------------------------------------------------------------------- ft_sp_threshold
@@ -373,14 +420,16 @@ __global__ __launch_bounds__(256) void ft_sp_threshold(const FtPlan* plans) {
 	if (threadIdx.x == 0) {
 		uint32_t flags = on ? 1u : 0u;
 		if (on) {
-			uint32_t ties = 0;
-			for (uint32_t k = 0; k < kFtHistCopies; ++k) ties += p.hist[size_t(k) * kFtHistStride + score];
+			const uint32_t ties = p.hist[score];
 			if (ties <= docs) flags |= 2u;   // every document at the threshold score is kept: no order to respect
 		}
 		p.sync[kFtSyncThrScore] = score;
 		p.sync[kFtSyncThrDocs] = docs;
 		p.sync[kFtSyncThrFlags] = flags;
 	}
+	__syncthreads();   // the histogram has been read: it goes back zeroed (one copy, 266 KB, 65 16-byte stores per thread)
+	uint4* h4 = reinterpret_cast<uint4*>(p.hist);
+	for (uint32_t i = threadIdx.x; i < kFtHistStride / 4; i += 256) h4[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // exclusive prefix of `mine` over the units in front of `unit` (decoupled look-back, one word per unit; units start in ticket order, so
@@ -434,19 +483,26 @@ __device__ __forceinline__ void sp_walk(const SpCtx<kS>& c, int lane, uint32_t (
 		for (int si = 0; si < kS; ++si) {
 			pre[si] = 0;
 			if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
-			const uint32_t cnt = uint32_t(__popc(w.W[si]));
-			const uint32_t incl = wave_inclusive_scan(cnt, lane);
-			pre[si] = run[si] + incl - cnt;
-			run[si] += sp_readlane(incl, 63);
+			const uint32_t cnt_w = uint32_t(__popc(w.W[si]));
+			pre[si] = cnt_w | (uint32_t(__popc(fm[si])) << 16);   // two counts (<= 32 a lane, <= 2048 a round) share one scan
+		}
+		uint32_t first_rank[kS], lanes_front[kS], totals[kS];
+#pragma unroll
+		for (int si = 0; si < kS; ++si) {
+			first_rank[si] = lanes_front[si] = totals[si] = 0;
+			if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
+			const uint32_t both = pre[si], incl = sp_scan(both), last = sp_readlane(incl, 63);
+			pre[si] = run[si] + (incl & 0xFFFFu) - (both & 0xFFFFu);
+			run[si] += last & 0xFFFFu;
+			lanes_front[si] = (incl >> 16) - (both >> 16);
+			first_rank[si] = rows[si] + lanes_front[si];
+			totals[si] = last >> 16;
 		}
 #pragma unroll
 		for (int si = 0; si < kS; ++si) {
 			if (uint32_t(si) >= c.n_subs || ((c.not_m >> si) & 1ull)) continue;
-			const uint32_t cnt = uint32_t(__popc(fm[si]));
-			const uint32_t incl = wave_inclusive_scan(cnt, lane);
-			const uint32_t total = sp_readlane(incl, 63);
-			if (total) visit(j, si, w, pre, fm[si], rows[si] + incl - cnt, incl - cnt, total);
-			rows[si] += total;   // (uniform: documents of the unit first met in sub-term si so far)
+			if (totals[si]) visit(j, si, w, pre, fm[si], first_rank[si], lanes_front[si], totals[si]);
+			rows[si] += totals[si];   // (uniform: documents of the unit first met in sub-term si so far)
 		}
 	}
 }
@@ -454,79 +510,54 @@ __device__ __forceinline__ void sp_walk(const SpCtx<kS>& c, int lane, uint32_t (
 // ---------------------------------------------------------------------------------------------- ft_sp_select
 // Queries whose 2-phase gate held on the host: which documents preselectMostRelevantDocs keeps (mergerimpl.h:448-462; the ties at the
 // threshold score in document order up to minScoreDocs: an ordered count over the units), the table of documents first met per (row,
-// range) over those, and one task per kept document.  Also hands the pre-score histogram back zeroed: every unit clears the counters of
-// its own scores.
+// range) over those, and one task per kept document.
 template <int kS>
-__global__ __launch_bounds__(256) void ft_sp_select(const FtPlan* plans) {
-	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
-	if (!p.prescore) return;
-	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
-	const uint32_t ticket = grab_ticket(p.sync + kFtSyncSpTicket);
-	const int lane = threadIdx.x & 63;
-	const uint32_t unit = threadIdx.x >> 6, range = ticket * kSpUnits + unit;
-	if (range >= p.n_ranges) return;
+__device__ __forceinline__ void sp_select_unit(FtPlanK& p, uint32_t* unit_lds, uint32_t* keptw, uint32_t range, int lane) {
 	const SpThreshold thr = sp_threshold(p);
 	SpCtx<kS> c;
-	uint32_t* unit_lds = sp_lds + unit * ((kS + 1) * kSpWords);
-	uint32_t* keptw = unit_lds + kS * kSpWords;   // [kSpWords] the kept documents of the unit, word by word
 	sp_open<kS>(p, unit_lds, range, lane, c);
-	// pass 1: the unit's documents above / at the threshold; the distinct scores of its documents (their histogram counters are cleared)
-	uint32_t* hist_copy = p.hist + size_t(range % kFtHistCopies) * kFtHistStride;
-	auto clear = [&](uint32_t v, uint32_t) {
-		hist_copy[v] = 0;
-		hist_copy[65536 + (v >> 6)] = 0;
-	};
-	SpKeys keys;
-	uint32_t ties = 0;
+	// pass 1: the unit's documents above / at the threshold score
+	uint32_t gt[4], tie[4], ties = 0;
+#pragma unroll
 	for (int j = 0; j < 4; ++j) {
 		SpWord<kS> w;
 		sp_word<kS>(c, j, lane, w);
-		uint32_t claim[kS];
-		sp_term_claims(c, w, claim);
-		uint32_t rem = w.cand, g = 0, t = 0;
-		while (__ballot(rem != 0)) {
-			const bool have = rem != 0;
-			uint32_t sc = 0;
-			if (have) {
-				const uint32_t b = uint32_t(__ffs(int(rem)) - 1);
-				rem &= rem - 1;
-				sc = sp_score(c, claim, b);
-				g |= uint32_t(sc > thr.score) << b;
-				t |= uint32_t(sc == thr.score) << b;
-			}
-			sp_keys_add(keys, have && sc != 0, sc, lane, clear);
-		}
-		if (!thr.on) {   // no preselect: every candidate stays
-			g = w.cand;
-			t = 0;
-		} else if (thr.all_ties) {
-			g |= t;
-			t = 0;
-		}
-		keptw[64 * j + lane] = g;   // above the threshold (or everything); the ties are found again once their quota is known
-		ties += uint32_t(__popc(t));
-	}
-	if (uint32_t(lane) < keys.n) clear(keys.key, keys.cnt);
-	if (thr.on && !thr.all_ties) {   // the ties this unit keeps: minScoreDocs minus those of the units in front, in document order
-		const uint32_t before = sp_lookback(wave_sum(ties), range, p.lb_units, p.sync + kFtSyncError, lane);
-		const uint32_t allowed = thr.docs > before ? thr.docs - before : 0u;
-		uint32_t ties_before = 0;
-		for (int j = 0; j < 4; ++j) {
-			SpWord<kS> w;
-			sp_word<kS>(c, j, lane, w);
+		uint32_t g = w.cand, t = 0;   // no preselect: every candidate stays
+		if (thr.on) {
 			uint32_t claim[kS];
 			sp_term_claims(c, w, claim);
-			uint32_t rem = w.cand & ~keptw[64 * j + lane], t = 0;   // not above the threshold: at it, or below
+			uint32_t rem = w.cand;
+			g = 0;
 			while (rem) {
 				const uint32_t b = uint32_t(__ffs(int(rem)) - 1);
 				rem &= rem - 1;
-				t |= uint32_t(sp_score(c, claim, b) == thr.score) << b;
+				const uint32_t sc = sp_score(c, claim, b);
+				g |= uint32_t(sc > thr.score) << b;
+				t |= uint32_t(sc == thr.score) << b;
 			}
-			const uint32_t cnt = uint32_t(__popc(t));
-			const uint32_t incl = wave_inclusive_scan(cnt, lane);
+			if (thr.all_ties) {
+				g |= t;
+				t = 0;
+			}
+		}
+		gt[j] = g;
+		tie[j] = t;
+		ties += uint32_t(__popc(t));
+	}
+	{   // the ties this unit keeps: minScoreDocs minus those of the units in front, in document order
+		uint32_t allowed = 0;
+		if (thr.on && !thr.all_ties) {
+			const uint32_t before = sp_lookback(wave_sum(ties), range, p.lb_units, p.sync + kFtSyncError, lane);
+			allowed = thr.docs > before ? thr.docs - before : 0u;
+		}
+		uint32_t ties_before = 0;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const uint32_t cnt = uint32_t(__popc(tie[j]));
+			const uint32_t incl = sp_scan(cnt);
 			const uint32_t front = ties_before + incl - cnt;
 			ties_before += sp_readlane(incl, 63);
-			keptw[64 * j + lane] |= sp_lowest_bits(t, allowed > front ? allowed - front : 0u);
+			keptw[64 * j + lane] = gt[j] | sp_lowest_bits(tie[j], allowed > front ? allowed - front : 0u);
 		}
 	}
 	sp_fence();
@@ -566,18 +597,26 @@ __global__ __launch_bounds__(256) void ft_sp_select(const FtPlan* plans) {
 		});
 	sp_store_rows<kS, false>(p, c, rows, lane);
 }
+template <int kMax>
+__global__ __launch_bounds__(256) void ft_sp_select(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	if (!p.prescore) return;
+	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
+	const uint32_t ticket = grab_ticket(p.sync + kFtSyncSpTicket);
+	const int lane = threadIdx.x & 63;
+	const uint32_t unit = threadIdx.x >> 6, range = ticket * kSpUnits + unit;
+	if (range >= p.n_ranges) return;
+	uint32_t* unit_lds = sp_lds + unit * ((kMax + 1) * kSpWords);
+	uint32_t* keptw = unit_lds + kMax * kSpWords;   // [kSpWords] the kept documents of the unit, word by word
+	SP_DISPATCH(kMax, p.n_subs, sp_select_unit<4>(p, unit_lds, keptw, range, lane), sp_select_unit<8>(p, unit_lds, keptw, range, lane),
+				sp_select_unit<kMax>(p, unit_lds, keptw, range, lane));
+}
 
 // ---------------------------------------------------------------------------------------------- ft_sp_place
 // Queries without a preselect (Simple() ones, queries the host found below mergeLimit): the slots are known (ft_slot_bases ran over
 // ft_sp_scan's table), so only the documents below maxMergedDocs become tasks, at their slot.
 template <int kS>
-__global__ __launch_bounds__(256) void ft_sp_place(const FtPlan* plans) {
-	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
-	if (p.prescore) return;
-	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
-	const int lane = threadIdx.x & 63;
-	const uint32_t unit = threadIdx.x >> 6, range = blockIdx.x * kSpUnits + unit;
-	if (range >= p.n_ranges) return;
+__device__ __forceinline__ void sp_place_unit(FtPlanK& p, uint32_t* unit_lds, uint32_t range, int lane) {
 	// slot of the first document of (row, range): ft_slot_bases' prefix of the table, lane si holds sub-term si's
 	uint32_t base_v = 0xFFFFFFFFu;
 	if (uint32_t(lane) < p.n_subs) {
@@ -592,7 +631,7 @@ __global__ __launch_bounds__(256) void ft_sp_place(const FtPlan* plans) {
 	}
 	if (low >= p.max_merged) return;   // slots ascend with (row, range): a range whose every row starts at or beyond the limit merges nothing
 	SpCtx<kS> c;
-	sp_open<kS>(p, sp_lds + unit * (kS * kSpWords), range, lane, c);
+	sp_open<kS>(p, unit_lds, range, lane, c);
 	uint32_t lo_u[kS], base_u[kS], rows[kS];
 #pragma unroll
 	for (int si = 0; si < kS; ++si) {
@@ -611,6 +650,17 @@ __global__ __launch_bounds__(256) void ft_sp_place(const FtPlan* plans) {
 				++k;
 			}
 		});
+}
+template <int kMax>
+__global__ __launch_bounds__(256) void ft_sp_place(const FtPlan* plans) {
+	FtPlanK& p = FT_PLAN_OF_QUERY(plans);
+	if (p.prescore) return;
+	extern __shared__ __attribute__((aligned(16))) uint32_t sp_lds[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t unit = threadIdx.x >> 6, range = blockIdx.x * kSpUnits + unit;
+	if (range >= p.n_ranges) return;
+	uint32_t* unit_lds = sp_lds + unit * (kMax * kSpWords);
+	SP_DISPATCH(kMax, p.n_subs, sp_place_unit<4>(p, unit_lds, range, lane), sp_place_unit<8>(p, unit_lds, range, lane), sp_place_unit<kMax>(p, unit_lds, range, lane));
 }
 
 // ---------------------------------------------------------------------------------------------- ft_sp_replay
@@ -704,17 +754,12 @@ hipError_t sp_launch(const FtPlan* plans, uint32_t nq, uint32_t n_pre, uint32_t 
 	if (hipError_t e = raise_dynamic_lds_once(raised_c, reinterpret_cast<const void*>(&ft_sp_place<kS>), lds_scan); e != hipSuccess) return e;
 	if (hipError_t e = raise_dynamic_lds_once(raised_d, reinterpret_cast<const void*>(&ft_sp_replay<kS>), lds_replay); e != hipSuccess) return e;
 	const uint32_t gx = (n_ranges + kSpUnits - 1) / kSpUnits;
-	static const int stop = std::getenv("RXGPU_FT_SP_STOP") ? std::atoi(std::getenv("RXGPU_FT_SP_STOP")) : 0;   // debugging: leave the train after kernel <stop>
 	hipLaunchKernelGGL(ft_sp_scan<kS>, dim3(gx, nq), dim3(256), lds_scan, st, plans);
-	if (stop == 1) return hipGetLastError();
 	if (n_pre) {
 		hipLaunchKernelGGL(ft_sp_threshold, dim3(1, n_pre), dim3(256), 0, st, plans);
-		if (stop == 2) return hipGetLastError();
-		hipLaunchKernelGGL(ft_sp_select<kS>, dim3(gx, n_pre), dim3(256), lds_sel, st, plans);
+			hipLaunchKernelGGL(ft_sp_select<kS>, dim3(gx, n_pre), dim3(256), lds_sel, st, plans);
 	}
-	if (stop == 3) return hipGetLastError();
 	launch_ft_slot_bases(plans, nq, st);
-	if (stop == 4) return hipGetLastError();
 	if (nq > n_pre) hipLaunchKernelGGL(ft_sp_place<kS>, dim3(gx, nq - n_pre), dim3(256), lds_scan, st, plans + n_pre);
 	hipLaunchKernelGGL(ft_sp_replay<kS>, dim3((m_max + 255) / 256, nq), dim3(256), lds_replay, st, plans);
 	return hipGetLastError();

@@ -1892,37 +1892,6 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 			RX_HIP(q);
 		}
 	}
-	if (job.p.sparse && std::getenv("RXGPU_FT_SP_STOP")) {   // debugging: what the sparse train left behind when it was cut short
-		RX_HIP(hipStreamSynchronize(st));
-		uint32_t sy[rxgpu::kFtSyncWords];
-		RX_HIP(hipMemcpy(sy, job.p.sync, sizeof(sy), hipMemcpyDeviceToHost));
-		std::fprintf(stderr, "[sp dbg] sync:");
-		for (uint32_t k = 0; k < rxgpu::kFtSyncWords; ++k) std::fprintf(stderr, " %u", sy[k]);
-		std::vector<uint32_t> ad(size_t(job.p.n_rows) * job.p.n_ranges);
-		RX_HIP(hipMemcpy(ad.data(), job.p.adders, ad.size() * 4, hipMemcpyDeviceToHost));
-		std::fprintf(stderr, "\n[sp dbg] adders (%u rows x %u ranges):", job.p.n_rows, job.p.n_ranges);
-		for (uint32_t r = 0; r < job.p.n_rows; ++r) {
-			std::fprintf(stderr, "\n   row %u:", r);
-			for (uint32_t c = 0; c < job.p.n_ranges; ++c) std::fprintf(stderr, " %u", ad[size_t(r) * job.p.n_ranges + c]);
-		}
-		if (job.p.hist) {
-			std::vector<uint32_t> hs(size_t(rxgpu::kFtHistCopies) * rxgpu::kFtHistStride);
-			RX_HIP(hipMemcpy(hs.data(), job.p.hist, hs.size() * 4, hipMemcpyDeviceToHost));
-			std::fprintf(stderr, "\n[sp dbg] hist:");
-			for (uint32_t v = 0; v < 65536; ++v) {
-				uint32_t c = 0;
-				for (uint32_t k = 0; k < rxgpu::kFtHistCopies; ++k) c += hs[size_t(k) * rxgpu::kFtHistStride + v];
-				if (c) std::fprintf(stderr, " %u:%u", v, c);
-			}
-		}
-		std::vector<unsigned long long> lb(job.p.n_ranges);
-		RX_HIP(hipMemcpy(lb.data(), job.p.lb_units, lb.size() * 8, hipMemcpyDeviceToHost));
-		std::fprintf(stderr, "\n[sp dbg] lookback:");
-		for (unsigned long long v : lb) std::fprintf(stderr, " %llx", v);
-		std::fprintf(stderr, "\n");
-		RX_HIP(hipMemset(h->d_clean.ptr, 0, h->d_clean.bytes));
-		return RXGPU_ERR_LOGIC;
-	}
 	if (p.dbg) {
 		unsigned long long raw[64];
 		RX_HIP(hipMemcpy(raw, p.dbg, sizeof(raw), hipMemcpyDeviceToHost));
