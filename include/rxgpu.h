@@ -355,6 +355,10 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h);
  * single-device features: RXGPU_ERR_LOGIC here. */
 int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* devices, rxgpu_ft_index** out);
 uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h);           /* 0 for an unsharded index */
+/* The cut of a sharded index is fixed by the first rxgpu_ft_set_docs and kept while the shards hold words: an index that grows through
+ * step commits (a larger total_docs, only the changed words uploaded again) keeps its fragments, the new document ranges go to the last
+ * shard.  Ranges of the fullest shard / ranges of an even cut; 1.0 for an even cut or an unsharded index. */
+double rxgpu_ft_shard_imbalance(const rxgpu_ft_index* h);
 int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h);        /* 1 on the devices, 0 through the host, -1 not sharded */
 uint64_t rxgpu_ft_shard_collectives(const rxgpu_ft_index* h);     /* all-gathers issued so far */
 int rxgpu_ft_shard_ranges(const rxgpu_ft_index* h, uint32_t shard, uint32_t* range_begin, uint32_t* range_count);   /* the shard's run of 8192-document ranges */

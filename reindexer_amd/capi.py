@@ -93,6 +93,7 @@ _SIGNATURES = {
     "rxgpu_ft_create": (_i, [_u32, _i, C.POINTER(_vp)]),
     "rxgpu_ft_create_sharded": (_i, [_u32, _u32, _vp, C.POINTER(_vp)]),
     "rxgpu_ft_shard_count": (_u32, [_vp]),
+    "rxgpu_ft_shard_imbalance": (C.c_double, [_vp]),
     "rxgpu_ft_shard_exchange_mode": (_i, [_vp]),
     "rxgpu_ft_shard_collectives": (_u64, [_vp]),
     "rxgpu_ft_shard_ranges": (_i, [_vp, _u32, _vp, _vp]),

@@ -182,6 +182,7 @@ struct rxgpu_ft_shard_set {
 	std::vector<rxgpu_ft_index*> shards;
 	std::vector<int> devices;
 	uint32_t n_ranges = 0;                  // of the whole index; 0: rxgpu_ft_set_docs has not run
+	uint32_t per = 0;                       // ranges per shard of the current cut (the last shard also takes what lies behind S * per)
 	// the exchange: one RCCL rank per DISTINCT device, a device's shards are `slots` consecutive pieces of its rank's buffers
 	uint32_t nranks = 0, slots = 0;
 	std::vector<int> rank_dev;
@@ -342,6 +343,15 @@ int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* 
 	return RXGPU_OK;
 }
 uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h) { return h && h->shard_set ? uint32_t(h->shard_set->shards.size()) : 0; }
+// ranges of the fullest shard / ranges of an even cut (1.0: even; an index that grew by step commits piles its new ranges on the last shard)
+double rxgpu_ft_shard_imbalance(const rxgpu_ft_index* h) {
+	if (!h || !h->shard_set || !h->shard_set->n_ranges) return 1.0;
+	const rxgpu_ft_shard_set* ss = h->shard_set;
+	uint32_t most = 0;
+	for (const rxgpu_ft_index* sh : ss->shards) most = std::max(most, sh->sh_range_count);
+	const double even = double(ss->n_ranges) / double(ss->shards.size());
+	return even > 0 ? std::max(1.0, double(most) / std::max(1.0, even)) : 1.0;
+}
 int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h) { return h && h->shard_set ? (h->shard_set->host_exchange ? 0 : 1) : -1; }
 uint64_t rxgpu_ft_shard_collectives(const rxgpu_ft_index* h) { return h && h->shard_set ? h->shard_set->collectives : 0; }
 int rxgpu_ft_shard_ranges(const rxgpu_ft_index* h, uint32_t shard, uint32_t* range_begin, uint32_t* range_count) {
@@ -465,20 +475,21 @@ static int ft_shards_set_docs(rxgpu_ft_index* h, uint64_t total_docs, const floa
 	std::lock_guard<std::mutex> lk(h->mtx);
 	const uint32_t S = uint32_t(ss->shards.size());
 	const uint32_t n_ranges = uint32_t((total_docs + rxgpu::kFtRangeDocs - 1) / rxgpu::kFtRangeDocs);
-	const uint32_t per = (n_ranges + S - 1) / S;
-	if (ss->n_ranges && ss->n_ranges != n_ranges) {   // the cut moves: the fragments the shards hold belong to the old one
-		for (rxgpu_ft_index* sh : ss->shards) {
-			RX_CHECK(sh->words.empty(), RXGPU_ERR_LOGIC,
-					 "rxgpu_ft_set_docs: the document ranges of a sharded ft index moved — create a new index (or upload every word again on a fresh one)");
-		}
-	}
+	// The cut: shard s starts at range s * per.  It is fixed by the first rxgpu_ft_set_docs and KEPT while any shard holds words — the index
+	// grows through step commits (IndexText::commitFulltextImpl calls this with a larger totalDocs and re-uploads only the changed words),
+	// and the fragments already on the shards must stay where the cut put them: new ranges go to the last shard, an even cut comes back
+	// with the next index built from scratch (rxgpu_ft_shard_imbalance tells the caller when that is worth it).
+	bool holds_words = false;
+	for (rxgpu_ft_index* sh : ss->shards) holds_words = holds_words || !sh->words.empty();
+	if (!ss->per || !holds_words) ss->per = std::max<uint32_t>(1, (n_ranges + S - 1) / S);
+	const uint32_t per = ss->per;
 	for (uint32_t s = 0; s < S; ++s) {
 		rxgpu_ft_index* sh = ss->shards[s];
 		if (int rc = rxgpu_ft_set_docs(sh, total_docs, words_in_field, avg_words, removed); rc) return rc;   // replicated: a few bytes per document
 		sh->sh_index = s;
 		sh->sh_total = S;
 		sh->sh_range_begin = std::min(s * per, n_ranges);
-		sh->sh_range_count = std::min(per, n_ranges - sh->sh_range_begin);
+		sh->sh_range_count = s + 1 == S ? n_ranges - sh->sh_range_begin : std::min(per, n_ranges - sh->sh_range_begin);
 	}
 	ss->n_ranges = n_ranges;
 	h->total_docs = total_docs;

@@ -720,7 +720,9 @@ int sharded_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, u
 	for (uint32_t q = 0; q < nq; ++q) {
 		all.clear();
 		for (size_t s = 0; s < ns; ++s) {
-			for (uint32_t j = 0; j < sc[s][q]; ++j) all.emplace_back(sd[s][size_t(q) * k + j], uint32_t(sr[s][size_t(q) * k + j] + s * ss->shard_rows));
+			// a shard's search clamps k to the points it holds and writes its lists with THAT stride (hnsw_search_impl: p.k = min(k, count))
+			const size_t ks = std::min<uint64_t>(k, rxgpu_index_count(ss->shards[s]));
+			for (uint32_t j = 0; j < sc[s][q]; ++j) all.emplace_back(sd[s][size_t(q) * ks + j], uint32_t(sr[s][size_t(q) * ks + j] + s * ss->shard_rows));
 		}
 		const size_t take = std::min<size_t>(k, all.size());
 		std::partial_sort(all.begin(), all.begin() + take, all.end(), dist_row_less);

@@ -108,6 +108,8 @@ GpuFtMerger::~GpuFtMerger() {
 	if (dev_) rxgpu_ft_destroy(dev_);
 }
 
+double GpuFtMerger::ShardImbalance() const noexcept { return sharded_ ? rxgpu_ft_shard_imbalance(dev_) : 1.0; }
+
 void GpuFtMerger::SetDocs(size_t totalDocs, const float* wordsInField, const float* avgWords, const uint8_t* removed) {
 	if (rxgpu_ft_set_docs(dev_, totalDocs, wordsInField, avgWords, removed) != RXGPU_OK) throwDevice("SetDocs");
 	totalDocs_ = totalDocs;

@@ -161,6 +161,9 @@ public:
 	GpuFtMerger(size_t numFields, std::vector<int> devices);
 	~GpuFtMerger();
 	bool Sharded() const noexcept { return sharded_; }
+	// ranges of the fullest shard / ranges of an even cut: an index that grew through step commits keeps its cut, the new document ranges
+	// pile up on the last shard (rxgpu_ft_shard_imbalance).  1.0 for an unsharded merger.
+	double ShardImbalance() const noexcept;
 	rxgpu_ft_index* DeviceIndex() const noexcept { return dev_; }
 	bool ShardedSupports(bool hasPhrases, bool hasSynonyms, int maxAreasInDoc = 0) const noexcept {
 		return !sharded_ || (!hasPhrases && !hasSynonyms && maxAreasInDoc == 0);

@@ -181,7 +181,12 @@ const float* GpuHnswMap::shFloatPtr(labeltype label) const {
 GpuHnswMap& GpuHnswMap::shRoute(labeltype label) {
 	ShardedState& S = *sh_;
 	std::lock_guard<std::mutex> lk(S.routeMtx);
-	if (const auto it = S.shardOf.find(label); it != S.shardOf.end()) return *S.maps[it->second];
+	if (const auto it = S.shardOf.find(label); it != S.shardOf.end()) {
+		// the entry is only a hint: the label's slot may have been recycled by another label since (a delete-marked slot taken over,
+		// hnswalg.h:1401-1470) — then the label is new again and goes wherever there is room
+		if (S.maps[it->second]->graph_.HasLabelSync(label)) return *S.maps[it->second];
+		S.shardOf.erase(it);
+	}
 	for (size_t s = 0; s < S.maps.size(); ++s) {
 		if (S.routed[s] < S.shardRows) {
 			++S.routed[s];
@@ -191,7 +196,7 @@ GpuHnswMap& GpuHnswMap::shRoute(labeltype label) {
 	}
 	for (size_t s = 0; s < S.maps.size(); ++s) {   // every range is full: a delete-marked slot is recycled (addPoint, hnswalg.h:1401-1470)
 		if (S.maps[s]->graph_.DeletedCount()) {
-			S.shardOf.emplace(label, uint32_t(s));
+			S.shardOf[label] = uint32_t(s);
 			return *S.maps[s];
 		}
 	}
@@ -307,9 +312,14 @@ void GpuHnswMap::LoadIndex(AnnCacheReader& reader) {
 void GpuHnswMap::Clear() {
 	if (sh_) {
 		for (auto& m : sh_->maps) m->Clear();
-		std::lock_guard<std::mutex> lk(sh_->routeMtx);
-		sh_->shardOf.clear();
-		sh_->routed.assign(sh_->maps.size(), 0);
+		{
+			std::lock_guard<std::mutex> lk(sh_->routeMtx);
+			sh_->shardOf.clear();
+			sh_->routed.assign(sh_->maps.size(), 0);
+		}
+		// the shards' DEVICE indexes still hold the old rows and graphs, and shSyncAll() mirrors only shards that hold points: a fresh
+		// parent handle rebinds every shard to an empty device index (a search over a shard left empty then finds nothing there)
+		shCreateParent(sh_->shardRows);
 		return;
 	}
 	graph_.Clear();

@@ -68,6 +68,10 @@ public:
 	VectorMetric Metric() const noexcept { return metric_; }
 
 	bool HasLabel(labeltype label) const { return labelLookup_.count(label) != 0; }
+	bool HasLabelSync(labeltype label) const {   // ... while other threads may be inside AddPointConcurrent
+		std::lock_guard<std::mutex> lk(labelMtx_);
+		return labelLookup_.count(label) != 0;
+	}
 	tableint InternalId(labeltype label) const;   // throws std::runtime_error("Label not found")
 	labeltype Label(tableint id) const noexcept { return labels_[id]; }
 	bool IsDeleted(tableint id) const noexcept { return deleted_[id] != 0; }
@@ -164,7 +168,7 @@ private:
 	std::unique_ptr<std::atomic<uint8_t>[]> nodeLocks_;   // link_list_locks_: one byte spin lock per element
 	size_t nodeLocksSize_ = 0;
 	bool concurrent_ = false;
-	std::mutex labelMtx_, generatorMtx_, globalMtx_, entryMtx_, visitedPoolMtx_, deletedMtx_;
+	mutable std::mutex labelMtx_, generatorMtx_, globalMtx_, entryMtx_, visitedPoolMtx_, deletedMtx_;
 	std::shared_mutex updateMtx_;   // concurrent inserts share it; an insert that recycles a slot (updatePoint) holds it exclusively
 	std::vector<std::unique_ptr<Visited>> visitedPool_;
 };

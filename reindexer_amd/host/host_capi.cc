@@ -461,6 +461,9 @@ int rxhost_hnsw_add_concurrent(void* h, const float* vec, size_t dim, uint64_t l
 int rxhost_hnsw_mark_delete(void* h, uint64_t label) {
 	return guarded([&] { static_cast<GpuHnswMap*>(h)->MarkDelete(FloatVectorId::FromNumber(label)); });
 }
+int rxhost_hnsw_clear(void* h) {
+	return guarded([&] { static_cast<GpuHnswMap*>(h)->Clear(); });
+}
 int rxhost_hnsw_resize(void* h, size_t n) {
 	return guarded([&] { static_cast<GpuHnswMap*>(h)->ResizeIndex(n); });
 }

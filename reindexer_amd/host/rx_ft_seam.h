@@ -19,6 +19,7 @@
 // What still goes to the reference's CPU merger (TryMergeOnGpu returns false): MergeDataAreas (highlight / snippet) — the patched
 // mergeResults only branches for plain ft::MergeData.  Phrases (PhraseMerger as kernels, ft_phrase.hip) and multi-word synonyms go to the device.
 #pragma once
+#include <cstdio>
 #if !defined(RXGPU_IN_TREE)
 #error "rx_ft_seam.h is for the build inside cpp_src (define RXGPU_IN_TREE)"
 #endif
@@ -260,9 +261,18 @@ void SyncGpuFtMirror(reindexer::DataHolder<IdCont>& holder, std::shared_ptr<GpuF
 		mirror.reset();
 		return;
 	}
-	if (!mirror || holder.status_ == reindexer::FullRebuild) mirror = std::make_shared<GpuFtMirror>(numFields, std::move(devices));
-	mirror->SyncDocs(totalDocs, stats);
-	mirror->SyncWords(holder.GetWords());   // DataHolder<IdCont>::words_ (dataholder.h:186-207)
+	// A mirror over a device list keeps its document-range cut while the index grows through step commits: the new ranges pile up on the last
+	// shard.  Once that shard holds twice its share the mirror is built again (every word uploaded once more, an even cut).
+	const bool recut = mirror && mirror->Merger().ShardImbalance() > 2.0;
+	try {
+		if (!mirror || recut || holder.status_ == reindexer::FullRebuild) mirror = std::make_shared<GpuFtMirror>(numFields, std::move(devices));
+		mirror->SyncDocs(totalDocs, stats);
+		mirror->SyncWords(holder.GetWords());   // DataHolder<IdCont>::words_ (dataholder.h:186-207)
+	} catch (const std::exception& e) {
+		// the commit must not fail because the device copy could not follow: without a mirror TryMergeOnGpu declines and the CPU merger runs
+		std::fprintf(stderr, "rxgpu: ft_fast device mirror dropped, the CPU merger takes over: %s\n", e.what());
+		mirror.reset();
+	}
 }
 
 // Selector<IdCont>::mergeResults, GPU branch.  Returns false — and leaves everything untouched — when the CPU merger has to run.

@@ -599,6 +599,12 @@ class GpuHnswMap:
         if rc:
             _raise(rc)
 
+    def clear(self):
+        """Map::Clear (HnswIndexBase::clearMap)"""
+        rc = lib().rxhost_hnsw_clear(self.h)
+        if rc:
+            _raise(rc)
+
     def resize(self, n):
         rc = lib().rxhost_hnsw_resize(self.h, n)
         if rc:

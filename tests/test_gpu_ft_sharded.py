@@ -173,6 +173,51 @@ def test_more_shards_than_document_ranges_and_one_merger_many_shapes(hostapi, ft
     many.close()
 
 
+def test_sharded_index_grows_through_step_commits(rxgpu, hostapi, ft):
+    """IndexText::commitFulltextImpl calls SetDocs with a growing totalDocs and uploads only the words that changed (rx_ft_seam.h
+    SyncGpuFtMirror).  The cut of a sharded index must survive that: the fragments already on the shards stay where they are, the new
+    document ranges go to the last shard, and the merge stays the single index's — across an 8192-document boundary, twice."""
+    nf = 2
+    full_total = 70_000
+    _, words, avg, removed, excluded, terms, store = _multi_case(3131, nf, full_total, 900, (1, 1, 2), False, None, sizes=(4000, 15_000))
+    gterms = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+
+    def cut(s, total):   # the word as a commit that has seen `total` documents holds it
+        n = int(np.searchsorted(s["doc"], total))
+        po = s["pos_off"][:n + 1]
+        return dict(word=s["word"], doc=s["doc"][:n], pos_off=po, fpos=s["fpos"][:int(po[-1])], proc=s["proc"])
+
+    many = hostapi.GpuFtMerger(nf, devices=[0, 0, 0])
+    lib = rxgpu.lib()
+    lib.rxgpu_ft_shard_imbalance.restype = __import__("ctypes").c_double
+    sizes_seen = {}
+    for step, total in enumerate((7000, 30_000, full_total)):   # 1, 4, 9 document ranges
+        w_t, r_t = words[:total], removed[:total]
+        a_t = w_t[1:].mean(axis=0).astype(np.float32)
+        many.set_docs(w_t, a_t, r_t)
+        one = hostapi.GpuFtMerger(nf)
+        one.set_docs(w_t, a_t, r_t)
+        for s in store:
+            c = cut(s, total)
+            one.set_word_fpos(c["word"], c)
+            if sizes_seen.get(s["word"]) != len(c["doc"]):   # only the words that changed travel again
+                many.set_word_fpos(c["word"], c)
+                sizes_seen[s["word"]] = len(c["doc"])
+        cfg = ft.default_config(nf, merge_limit=900)
+        for exc in (None, excluded[:total]):
+            a = one.merge_query(cfg, gterms, exc, sort_by_rank=False)
+            b = many.merge_query(cfg, gterms, exc, sort_by_rank=False)
+            assert same(a, b), (step, total, len(a[0]), len(b[0]))
+        oterms = [dict(op=t["op"], opts=t["opts"], subs=[cut(s, total) for s in t["subs"]]) for t in terms]
+        w = ft.merge_query(cfg, oterms, total, w_t, a_t, r_t, None, sort_by_rank=False)
+        b = many.merge_query(cfg, gterms, None, sort_by_rank=False)
+        assert np.array_equal(b[0], w[0].astype(np.int32)) and np.array_equal(b[1].view(np.uint32), w[1].view(np.uint32)) and b[4] == w[4]
+        one.close()
+        imb = lib.rxgpu_ft_shard_imbalance(many.device_index)
+        assert imb == pytest.approx((1.0, 4 / (4 / 3), 7 / 3)[step]), (step, imb)   # cut fixed at 1 range per shard: the last one takes the rest
+    many.close()
+
+
 def test_what_a_sharded_ft_index_does_not_offer_says_so(rxgpu, hostapi, ft):
     nf = 1
     m = hostapi.GpuFtMerger(nf, devices=[0, 0])

@@ -45,10 +45,14 @@ def test_c_abi_sharded_hnsw_is_the_merge_of_the_per_shard_engines(rxgpu, hostapi
         monkeypatch.delenv("RXGPU_SHARD_MERGE", raising=False)
     n, d = 5000, 48
     rows = make_corpus(70 + metric, n, d)
-    for shards, fill in ((2, n), (3, n), (8, n), (4, 1400)):   # the last: shard 1 partial, shards 2 and 3 EMPTY
+    # (4, 1400): shard 1 partial, shards 2 and 3 EMPTY; (4, -30): shard 1 holds 30 rows — fewer than k, so its lists come back with a
+    # stride of 30 (the shard's search clamps k to its count) and the batched host merge must read them that way
+    for shards, fill in ((2, n), (3, n), (8, n), (4, 1400), (4, -30)):
         with rxgpu.ShardedVectorIndex(metric, d, n, [0] * shards) as sx:
             assert sx.merge_mode == mode
             sr = sx.shard_rows
+            if fill < 0:
+                fill = sr - fill
             graphs = []
             for s in range(shards):
                 lo, hi = s * sr, min(fill, (s + 1) * sr)
@@ -199,6 +203,41 @@ def test_map_over_a_device_list_equals_the_per_shard_engines(hostapi, oracle, me
     c.close()
     many.close()
     one.close()
+
+
+def test_clear_then_partial_refill_searches_only_what_is_there(hostapi, oracle):
+    """Map::Clear over a device list, then inserts that land in shard 0 only: the other shards' DEVICE indexes must be empty too (they get
+    no mirror call while they hold no points) — no stale rows of the first life of the Map may come back, under any label."""
+    n, d, k = 3000, 32, 10
+    rows = make_corpus(91, n, d)
+    labels = np.arange(n, dtype=np.uint64) + np.uint64(1000)
+    many = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=80, devices=[0, 0, 0])
+    many.add(rows, labels)
+    q = make_corpus(92, 5, d)
+    for qi in range(5):
+        gd, gl = many.search_knn(q[qi], k, 64)
+        assert len(gl) == k
+    many.clear()
+    assert many.count == 0 and [many.shard(s).count for s in range(3)] == [0, 0, 0]
+    few = 40   # all in shard 0
+    new_rows = make_corpus(93, few, d)
+    new_labels = np.arange(few, dtype=np.uint64) + np.uint64(50_000)
+    many.add(new_rows, new_labels)
+    assert [many.shard(s).count for s in range(3)] == [few, 0, 0]
+    one = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=80)
+    one.add(new_rows, new_labels)
+    for qi in range(5):
+        gd, gl = many.search_knn(q[qi], k, 64)
+        wd, wl = one.search_knn(q[qi], k, 64)
+        assert set(gl.tolist()) <= set(new_labels.tolist()), (qi, gl)
+        assert np.array_equal(np.sort(gl), np.sort(wl)) and np.array_equal(np.sort(bits(gd)), np.sort(bits(wd)))
+    # a label deleted and inserted again goes wherever there is room, not back to a slot that is gone
+    many.mark_delete(int(new_labels[3]))
+    many.add(new_rows[3:4], new_labels[3:4])
+    gd, gl = many.search_knn(new_rows[3], 1, 32)
+    assert gl.tolist() == [int(new_labels[3])]
+    one.close()
+    many.close()
 
 
 def test_map_shards_equal_the_reference_engine_built_over_the_same_points(hostapi, ref, oracle):
