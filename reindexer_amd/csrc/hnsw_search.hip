@@ -607,8 +607,38 @@ __device__ __forceinline__ void hnsw_enqueue_overflow(const HnswParams& p, uint3
 
 // One search by one wavefront: slot = its scratch (visited set, global heap), qi = the query.  hnsw_search_kernel runs it once per
 // workgroup, hnsw_helper_kernel in a loop over the overflow queue.
-template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0, bool kDel = false>
-__device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint32_t slot, const uint32_t qi) {
+// A TEAM search (kTeam > 1 wavefronts per query, small launches): wavefront 0 runs the search below unchanged — list, visited set, link
+// blocks — and the others only ever compute distances: at every distance batch the driver posts (ids, count) in the workgroup's box, all
+// wavefronts meet at a barrier, each takes a slice of the rows (four rows a 16-lane group step, two sets a trip: 32 rows of 3 KB in flight
+// per trip with four wavefronts instead of 8), and they meet again.  A hop's ~16 fresh neighbours are then ONE memory round trip instead of
+// two or three — the search is a chain of ~140 dependent hops, and with a handful of queries on the chip nothing else hides them.  The
+// driver's own LDS traffic is ordered wavefront-locally (HN_SYNC): the helpers do not take part in its barriers.
+struct HnswTeamBox {
+	const uint32_t* ids;
+	float* dists;
+	int cnt;   // < 0: the search is over
+};
+template <int kTeam>
+__device__ __forceinline__ void hn_sync() {
+	if constexpr (kTeam > 1) {
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+	} else {
+		__syncthreads();
+	}
+}
+// the rows wavefront `wave` of a team takes of a batch of cnt: [begin, begin + n), begin a multiple of 4
+template <int kTeam>
+__device__ __forceinline__ void team_slice(int cnt, int wave, int& begin, int& n) {
+	const int per = (((cnt + kTeam - 1) / kTeam) + 3) & ~3;
+	begin = wave * per;
+	n = cnt - begin < per ? cnt - begin : per;
+	if (n < 0) n = 0;
+}
+#define HN_SYNC() hn_sync<kTeam>()
+template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = false, int kSorted = 0, bool kDel = false, int kTeam = 1>
+__device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint32_t slot, const uint32_t qi, HnswTeamBox* box = nullptr) {
+	static_assert(kTeam == 1 || (NB > 0 && !kSq8 && !kGlobalCand), "the team form serves the fixed-dimension float search with its heaps in LDS");
 	static_assert(kSorted == 0 || !kGlobalCand, "the sorted-list search starts in LDS; its re-runs with a global heap are heap-kernel launches");
 	// dynamic LDS: [ef_cap] result heap (dist, id) then [lds_cand_cap] candidate heap (dist, id) — sized by the launcher so that
 	// small-ef searches keep more wavefronts resident per CU
@@ -626,7 +656,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 	__shared__ int s_flag;
 	__shared__ uint32_t s_pre[64];   // sorted-list search: the link block of the candidate next in line, fetched one hop ahead by LDS-DMA
 
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63;   // (a team's driver is wavefront 0)
 	const float* q = p.queries + size_t(qi) * p.dim;
 	uint32_t* visited = p.visited + size_t(slot) * p.visited_words;
 	uint2* cand = kGlobalCand ? p.gcand + size_t(slot) * p.gcand_cap : lcand;
@@ -655,13 +685,22 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 	if constexpr (NB > 0 && !kSq8) {
 		const float4* qp = reinterpret_cast<const float4*>(q);
 		for (int i = lane; i < NB * 16; i += 64) q_s[i] = qp[i];
-		__syncthreads();
+		HN_SYNC();
 	}
 	auto distances = [&](const uint32_t* ids, int cnt, float* dists) {
 		if constexpr (kSq8 && NB > 0) {
 			batch_distances_sq8_fixed<kMetric, NB>(p, sq_q, sq_qq, p.qcorr[qi], p.qnorm[qi], ids, cnt, dists, lane);
 		} else if constexpr (kSq8) {
 			batch_distances_sq8<kMetric>(p, p.qcodes + size_t(qi) * p.dim, p.qcorr[qi], p.qnorm[qi], ids, cnt, dists, lane);
+		} else if constexpr (NB > 0 && kTeam > 1) {
+			box->ids = ids;
+			box->dists = dists;
+			box->cnt = cnt;
+			__syncthreads();   // the whole team: the batch is posted (and everything the driver wrote to LDS before it is visible)
+			int b0, n0;
+			team_slice<kTeam>(cnt, 0, b0, n0);
+			batch_distances_fixed<kMetric, NB, kQLds, true>(p, qreg, q_s, ids + b0, n0, dists + b0, lane);
+			__syncthreads();   // ... every slice is written
 		} else if constexpr (NB > 0) {
 			batch_distances_fixed<kMetric, NB, kQLds, (kLatency || NB <= 8)>(p, qreg, q_s, ids, cnt, dists, lane);
 		} else {
@@ -683,21 +722,21 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 	// ---- upper levels: greedy descent (getLayer0EntryPoint)
 	uint32_t cur = p.entry;
 	if (lane == 0) nb_id[0] = cur;
-	__syncthreads();
+	HN_SYNC();
 	distances(nb_id, 1, nb_d);
-	__syncthreads();
+	HN_SYNC();
 	float curdist = nb_d[0];
 	ndist += 1;
 	for (int level = p.maxlevel; level > 0; --level) {
 		bool changed = true;
 		while (changed) {
-			__syncthreads();
+			HN_SYNC();
 			const uint32_t* ll = p.upper + (p.upper_off[cur] + uint64_t(level - 1)) * (1 + p.M);
 			const int cnt = int(ll[0]);
 			for (int j = lane; j < cnt; j += 64) nb_id[j] = ll[1 + j];
-			__syncthreads();
+			HN_SYNC();
 			distances(nb_id, cnt, nb_d);
-			__syncthreads();
+			HN_SYNC();
 			ndist += cnt;
 			changed = false;
 			for (int i = 0; i < cnt; ++i) {   // uniform scalar-style scan (every lane computes the same thing)
@@ -726,7 +765,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 		}
 		if (vis_hash) {   // the zeroing stores have landed before the first test-and-set
 			__threadfence();
-			__syncthreads();
+			HN_SYNC();
 		}
 		if (lane == 0) (void)hnsw_visit_sel<kLatency>(visited, lds_vis, vis_in_lds, vis_hash, cur);
 		// the link block of the candidate that is next in line, requested one hop ahead: it arrives while this hop's visited tests and row
@@ -779,13 +818,13 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 				if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
 				nfresh += __popcll(fm);
 			}
-			__syncthreads();
+			HN_SYNC();
 			if constexpr (kDel) {   // the delete marks travel while the distances are computed
 				for (int j = lane; j < nfresh; j += 64) nb_del[j] = p.deleted[nb_id[j]];
 			}
 			distances(nb_id, nfresh, nb_d);
 			ndist += nfresh;
-			__syncthreads();
+			HN_SYNC();
 			for (int base = 0; base < nfresh && !list.tie; base += 64) {   // runLayer0Step :932-960 in neighbour order; lane j carries neighbour base + j
 				const int j = base + lane;
 				const float dj = j < nfresh ? nb_d[j] : __builtin_inff();
@@ -805,7 +844,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 					}
 				}
 			}
-			__syncthreads();
+			HN_SYNC();
 		}
 		const int total = list.held();
 		const int keep = total < int(p.k) ? total : int(p.k);   // SearchKnn :1998-2000: the k nearest of top_candidates
@@ -860,7 +899,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 			for (uint64_t w = lane; w < p.visited_words; w += 64) visited[w] = 0u;
 		}
 		__threadfence();
-		__syncthreads();
+		HN_SYNC();
 		if (lane == 0 && p.stats) atomicAdd(&p.stats[2], 1ull);
 		ndist = ndist_upper;
 		hops = 0;
@@ -872,7 +911,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 	bool overflow = false;
 	if (vis_hash) {   // the zeroing stores (kernel start, or the restart above) have landed before the first test-and-set
 		__threadfence();
-		__syncthreads();
+		HN_SYNC();
 	}
 	{
 		const bool ep_ok = p.bare || !p.deleted[cur];
@@ -909,7 +948,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 			}
 			s_flag = flag;
 		}
-		__syncthreads();
+		HN_SYNC();
 		if (s_flag) break;
 		const uint32_t node = s_cur;
 		hops += 1;
@@ -930,13 +969,13 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 			if (fresh) nb_id[nfresh + __popcll(fm & ((1ull << lane) - 1))] = word;
 			nfresh += __popcll(fm);
 		}
-		__syncthreads();
+		HN_SYNC();
 		distances(nb_id, nfresh, nb_d);
 		if (!p.bare) {
 			for (int j = lane; j < nfresh; j += 64) nb_del[j] = p.deleted[nb_id[j]];
 		}
 		ndist += nfresh;
-		__syncthreads();
+		HN_SYNC();
 		if (lane == 0) {   // sequential heap updates in neighbour order (runLayer0Step :932-960)
 			for (int i = 0; i < nfresh; ++i) {
 				const float d = nb_d[i];
@@ -958,7 +997,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 				}
 			}
 		}
-		__syncthreads();
+		HN_SYNC();
 	}
 
 	if (lane == 0) {
@@ -977,6 +1016,38 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 			atomicAdd(&p.stats[0], ndist);
 			atomicAdd(&p.stats[1], hops);
 		}
+	}
+}
+
+#undef HN_SYNC
+
+// The other wavefronts of a team: distance batches until the driver says the search is over.
+template <int kMetric, int NB, int kTeam>
+__device__ __forceinline__ void hnsw_team_serve(const HnswParams& p, const HnswTeamBox* box) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char hnsw_lds[];
+	const float4* q_s = reinterpret_cast<const float4*>(reinterpret_cast<uint2*>(hnsw_lds) + p.ef_cap + p.lds_cand_cap);   // as hnsw_search_one lays it out
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	float4 qreg[1];
+	for (;;) {
+		__syncthreads();
+		const int cnt = box->cnt;
+		if (cnt < 0) return;
+		int b0, n0;
+		team_slice<kTeam>(cnt, wave, b0, n0);
+		if (n0 > 0) batch_distances_fixed<kMetric, NB, true, true>(p, qreg, q_s, box->ids + b0, n0, box->dists + b0, lane);
+		__syncthreads();
+	}
+}
+template <int kMetric, int NB, int kSorted, bool kDel, int kTeam>
+__global__ __launch_bounds__(64 * kTeam) void hnsw_team_kernel(HnswParams p) {
+	__shared__ HnswTeamBox box;
+	const uint32_t slot = blockIdx.x;
+	if (threadIdx.x < 64) {
+		hnsw_search_one<kMetric, false, NB, true, false, kSorted, kDel, kTeam>(p, slot, p.only ? p.only[slot] : slot, &box);
+		if (threadIdx.x == 0) box.cnt = -1;
+		__syncthreads();
+	} else {
+		hnsw_team_serve<kMetric, NB, kTeam>(p, &box);
 	}
 }
 
@@ -1024,6 +1095,24 @@ static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hip
 	size_t lds = (size_t(p.ef_cap) + (kGlobalCand ? 0 : p.lds_cand_cap)) * 8 + size_t(NB) * 256;   // heaps + the query fragment (NB*16 float4)
 	constexpr bool kHasLatencyVariant = NB > 8;
 	const bool latency = kHasLatencyVariant && blocks <= 3072;   // no more searches than the chip holds of this form (3 per SIMD): spend registers on fewer round trips
+	// a handful of searches (the Map's single queries and small coalesced batches): four wavefronts per search (hnsw_team_kernel)
+	if constexpr (!kGlobalCand && NB > 0 && kSorted > 0) {
+		if (p.team > 1 && blocks <= p.team_max) {
+			HnswParams pt = p;
+			size_t lds_t = lds;
+			if (p.vis_lds_log2 && (size_t(4) << p.vis_lds_log2) <= (32u << 10) && lds_t + (size_t(4) << p.vis_lds_log2) <= (60u << 10)) {
+				pt.vis_lds = 1;
+				pt.vis_hash_log2 = p.vis_lds_log2;
+				lds_t += size_t(4) << p.vis_lds_log2;
+			}
+			switch (metric) {
+				case kL2: hipLaunchKernelGGL((hnsw_team_kernel<kL2, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt); break;
+				case kIP: hipLaunchKernelGGL((hnsw_team_kernel<kIP, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt); break;
+				default: hipLaunchKernelGGL((hnsw_team_kernel<kCos, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt); break;
+			}
+			return;
+		}
+	}
 	// at most two searches per CU and a set of up to 32 KB: the visited set moves into LDS (dynamic LDS stays under the 64 KB a launch gets
 	// without an attribute)
 	HnswParams pl = p;

@@ -151,6 +151,7 @@ struct HnswParams {
 	uint32_t vis_lds_log2;
 	uint32_t vis_lds;
 	uint32_t prefetch_links;     // sorted-list search: fetch the link block of the candidate next in line one hop ahead (LDS-DMA)
+	uint32_t team, team_max;     // launches of up to team_max searches run `team` wavefronts per search (hnsw_team_kernel; team <= 1: off)
 	float* out_dist;          // [nq][k]
 	uint32_t* out_row;
 	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode), kHnswTie = re-run on the heaps

@@ -1,6 +1,8 @@
 // C-ABI implementation (include/rxgpu.h): index storage in HBM, search entry points, instrumentation.
 // Host-side plumbing only — all arithmetic is in the kernels.
+#include <unistd.h>   // environ
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1805,6 +1807,55 @@ int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* cor
 static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef,
 							float* out_dist, uint32_t* out_row, uint32_t* out_count, const rxgpu::HnswSink* sink = nullptr);
 
+extern "C++" {
+// The A/B and test hooks of the HNSW search (RXGPU_HNSW_*), read in ONE pass over the environment per call — a dozen getenv() lookups each
+// walked the whole environment, on the path of every single-query SearchKnn.  (Still the process environment: tests flip the hooks between
+// calls.  Not safe against a concurrent setenv, like getenv itself.)
+struct HnswKnobs {
+	const char* visited = nullptr;       // RXGPU_HNSW_VISITED = bitset | hash
+	int visited_log2 = -1;               // RXGPU_HNSW_VISITED_LOG2
+	int visited_lds = -1;                // RXGPU_HNSW_VISITED_LDS
+	int split_upload = -1;               // RXGPU_HNSW_SPLIT_UPLOAD
+	int prefetch = -1;                   // RXGPU_HNSW_PREFETCH
+	int lds_cand_cap = -1;               // RXGPU_HNSW_LDS_CAND_CAP
+	int helper = -1;                     // RXGPU_HNSW_HELPER
+	int restart_cand = -1;               // RXGPU_HNSW_RESTART_CAND
+	int sorted = -1;                     // RXGPU_HNSW_SORTED
+	int gcand_cap = -1;                  // RXGPU_HNSW_GCAND_CAP
+	int team = -1;                       // RXGPU_HNSW_TEAM: wavefronts per search of a small launch (1 = off)
+	int team_max = -1;                   // RXGPU_HNSW_TEAM_MAX: searches per launch up to which the team form is used
+	int zero_copy = -1;                  // RXGPU_HNSW_ZERO_COPY = 0: small calls copy their queries / results like large ones
+};
+static HnswKnobs read_hnsw_knobs() {
+	HnswKnobs k;
+	static const char kPrefix[] = "RXGPU_HNSW_";
+	for (char** e = environ; e && *e; ++e) {
+		const char* s = *e;
+		if (s[0] != 'R' || std::strncmp(s, kPrefix, sizeof(kPrefix) - 1) != 0) continue;
+		const char* name = s + sizeof(kPrefix) - 1;
+		const char* eq = std::strchr(name, '=');
+		if (!eq) continue;
+		const size_t n = size_t(eq - name);
+		const char* val = eq + 1;
+		auto is = [&](const char* want) { return std::strlen(want) == n && std::strncmp(name, want, n) == 0; };
+		if (is("VISITED")) k.visited = val;
+		else if (is("VISITED_LOG2")) k.visited_log2 = atoi(val);
+		else if (is("VISITED_LDS")) k.visited_lds = atoi(val);
+		else if (is("SPLIT_UPLOAD")) k.split_upload = atoi(val);
+		else if (is("PREFETCH")) k.prefetch = atoi(val);
+		else if (is("LDS_CAND_CAP")) k.lds_cand_cap = atoi(val);
+		else if (is("HELPER")) k.helper = atoi(val);
+		else if (is("RESTART_CAND")) k.restart_cand = atoi(val);
+		else if (is("SORTED")) k.sorted = atoi(val);
+		else if (is("GCAND_CAP")) k.gcand_cap = atoi(val);
+		else if (is("TEAM")) k.team = atoi(val);
+		else if (is("TEAM_MAX")) k.team_max = atoi(val);
+		else if (is("ZERO_COPY")) k.zero_copy = atoi(val);
+	}
+	return k;
+}
+}  // extern "C++"
+
 int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 						  uint32_t* out_count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
@@ -1868,8 +1919,9 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	const uint64_t words = (h->count + 31) / 32;
 	// visited bitsets are the memory hog (N / 8 bytes per resident search): a launch gets an eighth of the free HBM for them, between 2 and
 	// 16 GiB.  (A fixed 2 GiB held a 10M-node index to 1717 searches per launch — fewer than the chip keeps resident.)
+	// (a handful of searches never comes near the budget: no driver call on the path of a single-query SearchKnn)
 	size_t free_b = 0, total_b = 0;
-	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+	if (nq > 256 && hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
 	const uint64_t visited_budget = std::min<uint64_t>(16ull << 30, std::max<uint64_t>(2ull << 30, (uint64_t(free_b) + c->d_visited.bytes) / 8));
 	const uint64_t max_slots = std::max<uint64_t>(1, std::min<uint64_t>(32768, visited_budget / (words * 4)));
 	// The visited set of the first pass (and of the tie re-runs) is a HASH SET sized by ef, zeroed by the search itself — not a bitset over
@@ -1879,16 +1931,15 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// Graphs so small that the bitset is the smaller of the two keep it.  RXGPU_HNSW_VISITED=bitset: the former path (A/B, tests).
 	uint32_t vis_hash_log2 = 12;
 	while ((1ull << vis_hash_log2) < 64ull * ef && vis_hash_log2 < 18) ++vis_hash_log2;
-	if (const char* e = getenv("RXGPU_HNSW_VISITED_LOG2")) vis_hash_log2 = uint32_t(std::min(20, std::max(6, atoi(e))));   // test hook: force overflows
+	const HnswKnobs knobs = read_hnsw_knobs();
+	if (knobs.visited_log2 >= 0) vis_hash_log2 = uint32_t(std::min(20, std::max(6, knobs.visited_log2)));   // test hook: force overflows
 	// a handful of searches (the latency form of the kernel, at most two workgroups per CU): the same hash set in LDS, whatever the rule
 	// below picks for batches — the launcher decides (launch_hnsw_nb).  RXGPU_HNSW_VISITED_LDS=0: off (A/B)
 	uint32_t vis_lds_log2 = vis_hash_log2;
-	if (const char* e = getenv("RXGPU_HNSW_VISITED_LDS")) {
-		if (!atoi(e)) vis_lds_log2 = 0;
-	}
-	if (getenv("RXGPU_HNSW_VISITED")) vis_lds_log2 = 0;   // an explicit choice of the global form (A/B, tests) stands for every launch
+	if (knobs.visited_lds == 0) vis_lds_log2 = 0;
+	if (knobs.visited) vis_lds_log2 = 0;   // an explicit choice of the global form (A/B, tests) stands for every launch
 	{
-		const char* e = getenv("RXGPU_HNSW_VISITED");   // "bitset" / "hash": force one of the two (A/B, tests on small graphs)
+		const char* e = knobs.visited;   // "bitset" / "hash": force one of the two (A/B, tests on small graphs)
 		const bool force_hash = e && std::strcmp(e, "hash") == 0;
 		// Which one by default: the hash set costs a second dependent trip on the hops where a lane's first slot is taken (measured at 1M x 768,
 		// ef = 128, same box and graph: 1.28 - 1.33 M q/s against 1.43 - 1.46 M on the bitset, profiles/rd4f_hnsw_visited_ab.txt); the bitset
@@ -1897,7 +1948,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		if ((e && std::strcmp(e, "bitset") == 0) || (!force_hash && (16ull << vis_hash_log2) > words)) vis_hash_log2 = 0;
 		// in HBM the set gets twice the words (a quarter full at most): fewer second probes — 10M x 768, one graph and box, 16 384 queries:
 		// 2^13 words 469 k q/s kernels only, 2^14 498 k, 2^15 497 k, 2^16 483 k, bitset 472 k (profiles/rd4j_hnsw_10m_*.json)
-		if (vis_hash_log2 && !getenv("RXGPU_HNSW_VISITED_LOG2") && vis_hash_log2 < 18) vis_hash_log2 += 1;
+		if (vis_hash_log2 && knobs.visited_log2 < 0 && vis_hash_log2 < 18) vis_hash_log2 += 1;
 	}
 	const uint64_t vis_words = vis_hash_log2 ? (1ull << vis_hash_log2) : words;   // per search of the first pass
 	const uint64_t vis_slots = vis_hash_log2 ? std::max<uint64_t>(1, std::min<uint64_t>(32768, visited_budget / (vis_words * 4))) : max_slots;
@@ -1928,7 +1979,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// pageable memory keeps this thread until it is staged) runs while the first half's searches have started; the halves overlap on the
 	// device like the workgroups of one launch.  RXGPU_HNSW_SPLIT_UPLOAD=0: one upload, one launch.
 	bool split_upload = !big_ef && nq >= 8192 && uint64_t(nq) <= vis_slots;
-	if (const char* e = getenv("RXGPU_HNSW_SPLIT_UPLOAD")) split_upload = split_upload && atoi(e) != 0;
+	if (knobs.split_upload >= 0) split_upload = split_upload && knobs.split_upload != 0;
 	const uint32_t first_half = split_upload ? nq / 2 : nq;
 	if (split_upload) {
 		if (int rc = c->ensure_aux(); rc) return rc;
@@ -1946,9 +1997,19 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	uint32_t* dl_count = out_count;
 	float* dl_dist = out_dist;
 	uint32_t* dl_row = out_row;
+	// The Map's single queries and its small coalesced batches do not copy at all: the kernel reads the queries from the pinned buffer (once,
+	// into LDS or registers) and writes counts and lists there — a call is ONE launch and one wait instead of a launch between four copies
+	// (each an enqueue of its own on the path of a 0.5 ms search).  RXGPU_HNSW_ZERO_COPY=0: the copies (A/B).
+	const bool zero_copy = staged && to_host && !sq8 && nq <= 64 && knobs.zero_copy != 0;
+	char* zc_dev = nullptr;   // the pinned buffer as the device sees it
 	if (staged) {
 		if (int rc = c->ensure_pinned(st_end); rc) return rc;
 		char* hp = static_cast<char*>(c->h_pinned);
+		if (zero_copy) {
+			void* dv = nullptr;
+			RX_HIP(hipHostGetDevicePointer(&dv, hp, 0));
+			zc_dev = static_cast<char*>(dv);
+		}
 		std::memcpy(hp, queries, size_t(nq) * h->dim * qelem);
 		up_queries = hp;
 		if (sq8) {
@@ -1971,7 +2032,34 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		}
 		return RXGPU_OK;
 	};
-	RX_HIP(hipMemcpyAsync(c->d_queries.ptr, up_queries, size_t(first_half) * h->dim * qelem, hipMemcpyHostToDevice, c->stream));
+	void* const d_q = zero_copy ? static_cast<void*>(zc_dev) : c->d_queries.ptr;   // where the kernels read the queries
+	if (!zero_copy) RX_HIP(hipMemcpyAsync(c->d_queries.ptr, up_queries, size_t(first_half) * h->dim * qelem, hipMemcpyHostToDevice, c->stream));
+	// counts / lists back to the host (nothing to do when the kernels wrote them there), and the wait behind a small launch: polled — the
+	// wake-up out of hipStreamSynchronize alone is tens of microseconds
+	auto fetch_counts = [&]() -> int {
+		if (!zero_copy) RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		return RXGPU_OK;
+	};
+	auto fetch_lists = [&]() -> int {
+		if (!zero_copy) {
+			RX_HIP(hipMemcpyAsync(dl_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+			RX_HIP(hipMemcpyAsync(dl_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		}
+		return RXGPU_OK;
+	};
+	auto wait_stream = [&]() -> int {
+		if (nq <= 256) {
+			const auto t0 = std::chrono::steady_clock::now();
+			hipError_t q = hipStreamQuery(c->stream);
+			while (q == hipErrorNotReady && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 4000.0) q = hipStreamQuery(c->stream);
+			if (q != hipErrorNotReady) {
+				RX_HIP(q);
+				return RXGPU_OK;
+			}
+		}
+		RX_HIP(hipStreamSynchronize(c->stream));
+		return RXGPU_OK;
+	};
 	rxgpu::HnswParams p{};
 	if (sq8) {
 		char* qb = static_cast<char*>(c->d_queries.ptr);
@@ -2004,10 +2092,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	p.visited_words = words;
 	p.vis_lds_log2 = vis_lds_log2;
 	p.prefetch_links = 1;
-	if (const char* e = getenv("RXGPU_HNSW_PREFETCH")) p.prefetch_links = atoi(e) ? 1u : 0u;   // A/B hook
-	p.out_dist = static_cast<float*>(c->d_out_dist.ptr);
-	p.out_row = static_cast<uint32_t*>(c->d_out_row.ptr);
-	p.out_count = static_cast<uint32_t*>(c->d_out_count.ptr);
+	if (knobs.prefetch >= 0) p.prefetch_links = knobs.prefetch ? 1u : 0u;   // A/B hook
+	// a handful of searches on the chip: four wavefronts share a search's distance batches (RXGPU_HNSW_TEAM=1: off, RXGPU_HNSW_TEAM_MAX: up to
+	// how many searches per launch)
+	p.team = knobs.team >= 0 ? uint32_t(knobs.team) : 4u;
+	p.team_max = knobs.team_max >= 0 ? uint32_t(knobs.team_max) : 256u;
+	p.out_dist = zero_copy ? reinterpret_cast<float*>(zc_dev + st_dist) : static_cast<float*>(c->d_out_dist.ptr);
+	p.out_row = zero_copy ? reinterpret_cast<uint32_t*>(zc_dev + st_row) : static_cast<uint32_t*>(c->d_out_row.ptr);
+	p.out_count = zero_copy ? reinterpret_cast<uint32_t*>(zc_dev + st_count) : static_cast<uint32_t*>(c->d_out_count.ptr);
 	p.stats = h->d_hnsw_stats;
 	p.ef_cap = (ef + 63u) & ~63u;
 	auto to_sink = [&]() -> int {   // the finished lists into the exchange's send buffer (sharded HNSW), on this search's stream, drained
@@ -2019,8 +2111,8 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// typical candidate heaps stay within a few x ef.  Measured at 1M x 768, ef = 128: 512 entries overflow for a handful of queries and the
 	// global-heap re-run costs more than the extra occupancy brings (1.07 M q/s at 1024 against 0.43 M at 512 and 0.86 M at 768)
 	p.lds_cand_cap = ef <= 256 ? 1024u : uint32_t(rxgpu::kHnswCandLds);
-	if (const char* e = getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // test hook: force the global-heap re-run
-		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, atoi(e))));
+	if (knobs.lds_cand_cap >= 0) {   // test hook: force the global-heap re-run
+		p.lds_cand_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(1, knobs.lds_cand_cap)));
 	}
 	// Graphs without deleted nodes, ef <= 256: both queues as one sorted list in registers (hnsw_search.hip).  A query that meets equal
 	// distances there comes back as kHnswTie and takes the heap kernel, whose sift order is the reference's.
@@ -2034,15 +2126,15 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// Round 4: with helper workgroups beside the batch (below) an overflowing restart is no longer a launch behind the batch, and the area
 	// can shrink to what lets a CU hold 20 searches instead of 15 (LDS per workgroup 10.3 -> 7.6 KB): first pass of 16 384 queries at
 	// 1M x 768 11.9 -> 10.5 ms (profiles/rd4k_hnsw_1m_restart_caps.txt; without the helpers the one restart that overflows costs 2.5 ms).
-	const bool helper_wanted = nq >= 2048 && !big_ef && !(getenv("RXGPU_HNSW_HELPER") && atoi(getenv("RXGPU_HNSW_HELPER")) == 0);
+	const bool helper_wanted = nq >= 2048 && !big_ef && knobs.helper != 0;
 	// ... where a batch lasts long against one heap search: the overflowing searches now run beside the batch, but one that is queued late
 	// still sticks out by its own length (2.5 ms at 1M x 768, where the whole batch takes 10: 1.29 M q/s with the copies at 600 entries
 	// against 1.16 - 1.22 M at 256 although the first pass alone runs at 1.57 - 1.70 M; at 10M x 768: 495 k -> 586 k q/s,
 	// profiles/rd4l_hnsw_*.json).  Same size rule as the hash set.
 	if (helper_wanted && ef <= 128 && (16ull << 13) <= words) sorted_restart_cap = 256;
-	if (const char* e = getenv("RXGPU_HNSW_RESTART_CAND")) sorted_restart_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(std::max(0, atoi(e))));
-	if (const char* e = getenv("RXGPU_HNSW_SORTED")) {   // A/B and test hook: 0 = heaps only, 2 = list shifts through ds_bpermute instead of DPP
-		sorted_mode = uint32_t(std::max(0, atoi(e)));
+	if (knobs.restart_cand >= 0) sorted_restart_cap = std::min<uint32_t>(uint32_t(rxgpu::kHnswCandLds), uint32_t(knobs.restart_cand));
+	if (knobs.sorted >= 0) {   // A/B and test hook: 0 = heaps only, 2 = list shifts through ds_bpermute instead of DPP
+		sorted_mode = uint32_t(knobs.sorted);
 		use_sorted = use_sorted && sorted_mode != 0;
 	}
 	std::vector<uint32_t> redo;
@@ -2091,7 +2183,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 		auto launch_helpers = [&]() -> int {
 			const uint64_t words4 = (words + 3) & ~uint64_t(3);
 			rxgpu::HnswParams ph = p;
-			ph.queries = static_cast<const float*>(c->d_queries.ptr);
+			ph.queries = static_cast<const float*>(d_q);
 			ph.visited = static_cast<uint32_t*>(c->d_helper_bits.ptr);
 			ph.visited_words = words4;
 			ph.vis_hash_log2 = 0;
@@ -2120,7 +2212,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 				rxgpu::HnswParams pc = p;
 				pc.vis_hash_log2 = vis_hash_log2;
 				pc.visited_words = vis_words;
-				pc.queries = reinterpret_cast<const float*>(static_cast<const char*>(c->d_queries.ptr) + size_t(qa) * h->dim * qelem);
+				pc.queries = reinterpret_cast<const float*>(static_cast<const char*>(d_q) + size_t(qa) * h->dim * qelem);
 				if (sq8) {
 					pc.qcodes = p.qcodes + size_t(qa) * h->dim;
 					pc.qcorr = p.qcorr + qa;
@@ -2171,12 +2263,11 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			RX_HIP(hipMemcpyAsync(&helper_n, hq_words, sizeof(helper_n), hipMemcpyDeviceToHost, c->stream));
 		}
 		// counts and results travel together: a batch without re-runs (the common case for a handful of queries) is done after ONE wait
-		RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		if (int rc = fetch_counts(); rc) return rc;
 		if (to_host) {
-			RX_HIP(hipMemcpyAsync(dl_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-			RX_HIP(hipMemcpyAsync(dl_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			if (int rc = fetch_lists(); rc) return rc;
 		}
-		RX_HIP(hipStreamSynchronize(c->stream));
+		if (int rc = wait_stream(); rc) return rc;
 		const uint32_t helper_queued = std::min<uint32_t>(helper_n, kHelperCap);
 		h->hnsw_lds_reruns += helper_queued;
 		std::vector<uint32_t> ties;
@@ -2197,14 +2288,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 				rxgpu::HnswParams pc = p;
 				pc.vis_hash_log2 = vis_hash_log2;
 				pc.visited_words = vis_words;
-				pc.queries = static_cast<const float*>(c->d_queries.ptr);
+				pc.queries = static_cast<const float*>(d_q);
 				pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
 				pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;
 				ProfileScope ps(h, "hnsw_ties", c->stream);
 				rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 			}
 			RX_HIP(hipGetLastError());
-			RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			if (int rc = fetch_counts(); rc) return rc;
 			RX_HIP(hipStreamSynchronize(c->stream));
 		}
 		// Queries whose candidate heap outgrew its LDS area — 600 entries for a search that started over inside the sorted-list kernel, 1024 for
@@ -2216,7 +2307,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			if (dl_count[q] == rxgpu::kHnswOverflow) over.push_back(q);
 		}
 		const uint32_t first_cap = use_sorted ? sorted_restart_cap : p.lds_cand_cap;
-		if (!over.empty() && first_cap < uint32_t(rxgpu::kHnswCandLds) && !getenv("RXGPU_HNSW_LDS_CAND_CAP")) {   // (the hook forces the global tiers)
+		if (!over.empty() && first_cap < uint32_t(rxgpu::kHnswCandLds) && knobs.lds_cand_cap < 0) {   // (the hook forces the global tiers)
 			if (int rc = c->d_redo.ensure(over.size() * sizeof(uint32_t)); rc) return rc;
 			RX_HIP(hipMemcpyAsync(c->d_redo.ptr, over.data(), over.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 			for (size_t r0 = 0; r0 < over.size(); r0 += max_slots) {
@@ -2226,14 +2317,14 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 				rxgpu::HnswParams pc = p;
 				pc.lds_cand_cap = uint32_t(rxgpu::kHnswCandLds);
 				pc.vis_lds_log2 = 0;   // (a search that filled its hash set is among these)
-				pc.queries = static_cast<const float*>(c->d_queries.ptr);
+				pc.queries = static_cast<const float*>(d_q);
 				pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
 				pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;
 				ProfileScope ps(h, "hnsw_redo", c->stream);
 				rxgpu::launch_hnsw_search(h->metric, pc, cq, false, c->stream);
 			}
 			RX_HIP(hipGetLastError());
-			RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+			if (int rc = fetch_counts(); rc) return rc;
 			RX_HIP(hipStreamSynchronize(c->stream));
 			// searches the helpers had queued but not finished are in `over` again: counted once
 			h->hnsw_lds_reruns += over.size() > helper_queued ? over.size() - helper_queued : 0;
@@ -2247,7 +2338,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// launch), one entry per node — the bound that cannot overflow — only for what outgrows that.  (With the full bound from the start a
 	// 10M-node index allows 13 searches per launch: 39 overflowing queries out of 16 384 cost a quarter of the whole batch.)
 	uint64_t tier_cap[2] = {std::min<uint64_t>(h->count + 1, 65536), h->count + 1};
-	if (const char* e = getenv("RXGPU_HNSW_GCAND_CAP")) tier_cap[0] = std::min<uint64_t>(h->count + 1, uint64_t(std::max(1, atoi(e))));   // test hook
+	if (knobs.gcand_cap >= 0) tier_cap[0] = std::min<uint64_t>(h->count + 1, uint64_t(std::max(1, knobs.gcand_cap)));   // test hook
 	for (int tier = 0; tier < 2 && !redo.empty(); ++tier) {
 		if (tier == 1 && tier_cap[1] == tier_cap[0]) break;
 		const uint64_t gcap = tier_cap[tier];
@@ -2260,7 +2351,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			if (int rc = c->d_gcand_d.ensure(size_t(cq) * gcap * sizeof(uint2)); rc) return rc;
 			RX_HIP(hipMemsetAsync(c->d_visited.ptr, 0, size_t(cq) * words * 4, c->stream));
 			rxgpu::HnswParams pc = p;
-			pc.queries = static_cast<const float*>(c->d_queries.ptr);
+			pc.queries = static_cast<const float*>(d_q);
 			pc.visited = static_cast<uint32_t*>(c->d_visited.ptr);
 			pc.only = static_cast<const uint32_t*>(c->d_redo.ptr) + r0;
 			pc.gcand = static_cast<uint2*>(c->d_gcand_d.ptr);
@@ -2269,7 +2360,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			rxgpu::launch_hnsw_search(h->metric, pc, cq, true, c->stream);
 		}
 		RX_HIP(hipGetLastError());
-		RX_HIP(hipMemcpyAsync(dl_count, c->d_out_count.ptr, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+		if (int rc = fetch_counts(); rc) return rc;
 		RX_HIP(hipStreamSynchronize(c->stream));
 		std::vector<uint32_t> again;
 		for (const uint32_t q : redo) {
@@ -2279,8 +2370,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	}
 	RX_CHECK(redo.empty(), RXGPU_ERR_DEVICE, "rxgpu_hnsw_search_knn: a candidate heap of one entry per node overflowed");
 	if (!to_host) return to_sink();
-	RX_HIP(hipMemcpyAsync(dl_dist, c->d_out_dist.ptr, size_t(nq) * k * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-	RX_HIP(hipMemcpyAsync(dl_row, c->d_out_row.ptr, size_t(nq) * k * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	if (int rc = fetch_lists(); rc) return rc;
 	RX_HIP(hipStreamSynchronize(c->stream));
 	return done_host();
 }
