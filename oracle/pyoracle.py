@@ -1398,3 +1398,87 @@ class RefSelect:
 
 def ref_select_available() -> bool:
     return REF_SELECT_SO.exists()
+
+
+REF_KNN_SEAM_SO = HERE / "_ref" / "libref_knn_seam.so"
+
+
+class RefKnnSeam:
+    """_ref/libref_knn_seam.so (oracle/ref/ref_knn_seam_shim.cc): the reference's HnswIndexBase<Map> — its hnsw_index.cc with
+    integration/patches/0001 applied — over one of four Maps: kind 0 the reference's BruteforceSearch, 1 the MI355X brute-force Map, 2 the
+    reference's HierarchicalNSW (single-thread build), 3 the MI355X HNSW Map.  upsert / del / select / selectRaw / streaming as the planner
+    reaches them.  Kinds 1 and 3 need a GPU (the Maps are the product's, compiled against the reference's types)."""
+    KINDS = {"ref_bf": 0, "gpu_bf": 1, "ref_hnsw": 2, "gpu_hnsw": 3}
+
+    def __init__(self, kind: str, metric: int, dim: int, max_elements: int, is_array: bool = False, M: int = 16, ef_construction: int = 200):
+        if not REF_KNN_SEAM_SO.exists():
+            raise FileNotFoundError(REF_KNN_SEAM_SO)
+        L = self.L = C.CDLL(str(REF_KNN_SEAM_SO))
+        L.ref_knn_seam_error.restype = C.c_char_p
+        L.ref_knn_seam_create.restype = _vp
+        L.ref_knn_seam_create.argtypes = [_i, _i, _sz, _sz, _i, _sz, _sz]
+        L.ref_knn_seam_destroy.argtypes = [_vp]
+        for name, args in (("upsert", [_vp, _vp, _sz, _sz, _vp]), ("del", [_vp, C.c_uint64]), ("count", [_vp]),
+                           ("select", [_vp, _i, _vp, C.c_long, _i, _f, _sz, _i, _vp, _vp, _sz]),
+                           ("select_raw", [_vp, _i, _vp, C.c_long, _i, _f, _sz, _vp, _vp, _sz]),
+                           ("begin_streaming", [_vp, _vp, _sz]), ("continue_streaming", [_vp, _sz, _vp, _vp, _vp])):
+            f = getattr(L, "ref_knn_seam_" + name)
+            f.restype = C.c_long
+            f.argtypes = args
+        self.kind, self.dim, self.hnsw = kind, dim, int(self.KINDS[kind] >= 2)
+        self.h = L.ref_knn_seam_create(self.KINDS[kind], metric, dim, max_elements, int(is_array), M, ef_construction)
+        if not self.h:
+            raise RuntimeError("ref_knn_seam_create: " + L.ref_knn_seam_error().decode(errors="replace"))
+
+    def _check(self, rc):
+        if rc == -2:
+            raise RuntimeError(self.L.ref_knn_seam_error().decode(errors="replace"))
+        if rc < 0:
+            raise RuntimeError("ref_knn_seam: ids / ranks size mismatch")
+        return rc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ref_knn_seam_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def upsert(self, vecs, labels):
+        v, lab = _f32(vecs).reshape(-1, self.dim), np.ascontiguousarray(labels, np.uint64)
+        self._check(self.L.ref_knn_seam_upsert(self.h, v.ctypes.data, v.shape[0], self.dim, lab.ctypes.data))
+
+    def delete(self, label):
+        self._check(self.L.ref_knn_seam_del(self.h, int(label)))
+
+    @property
+    def count(self) -> int:
+        return int(self.L.ref_knn_seam_count(self.h))
+
+    def select(self, key, k=None, radius=None, ef=0, need_sort=True, cap=1 << 16):
+        key = _f32(key)
+        ids, ranks = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        n = self._check(self.L.ref_knn_seam_select(self.h, self.hnsw, key.ctypes.data, -1 if k is None else k, int(radius is not None),
+                                                   0.0 if radius is None else radius, ef, int(need_sort), ids.ctypes.data, ranks.ctypes.data, cap))
+        return ids[:n].copy(), ranks[:n].copy()
+
+    def select_raw(self, key, k=None, radius=None, ef=0, cap=1 << 16):
+        key = _f32(key)
+        ids, ranks = np.empty(cap, np.int32), np.empty(cap, np.float32)
+        n = self._check(self.L.ref_knn_seam_select_raw(self.h, self.hnsw, key.ctypes.data, -1 if k is None else k, int(radius is not None),
+                                                       0.0 if radius is None else radius, ef, ids.ctypes.data, ranks.ctypes.data, cap))
+        return ids[:n].copy(), ranks[:n].copy()
+
+    def begin_streaming(self, key, ef):
+        self._key = _f32(key)   # (the session of a non-cosine search keeps the caller's pointer)
+        self._check(self.L.ref_knn_seam_begin_streaming(self.h, self._key.ctypes.data, ef))
+
+    def continue_streaming(self, batch):
+        ids, ranks, ex = np.empty(batch, np.int32), np.empty(batch, np.float32), C.c_int(0)
+        n = self._check(self.L.ref_knn_seam_continue_streaming(self.h, batch, ids.ctypes.data, ranks.ctypes.data, C.byref(ex)))
+        return ids[:n].copy(), ranks[:n].copy(), bool(ex.value)
+
+
+def ref_knn_seam_available() -> bool:
+    return REF_KNN_SEAM_SO.exists()

@@ -32,6 +32,7 @@ HIP_FLAGS = [
     "-fno-gpu-flush-denormals-to-zero",  # x86 keeps f32 subnormals; so must the kernels
     "-Wall", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}",
 ]
+HIP_FLAGS += os.environ.get("RXGPU_HIP_DEFINES", "").split()   # e.g. -DRXGPU_HNSW_PHASES (a profiling build; not what ships)
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-ffp-contract=off", f"-I{INCLUDE}", f"-I{HOST}"]
 
 

@@ -522,17 +522,24 @@ __device__ __forceinline__ void batch_distances_fixed(const HnswParams& p, const
 #pragma unroll
 			for (int t = 0; t < NB; ++t) xb[t] = pb[16 * t];
 		}
+		// cosine: 1 / |row| of the epilogue travels WITH the rows — read behind the scheduling barrier it was a dependent round trip of its
+		// own at the end of every distance trip
+		float inva = 1.0f, invb = 1.0f;
+		if constexpr (kMetric == kCos) {
+			inva = p.inv_norms[ra];
+			if (second) invb = p.inv_norms[rb];
+		}
 		__builtin_amdgcn_sched_barrier(0);
 		float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
 		for (int t = 0; t < NB; ++t) chain_step<kMetric>(acc, Q(t), xa[t]);
-		const float da = 1.0f * metric_epilogue<kMetric>(fold_chains<false>(acc, nullptr, nullptr, 0, m) + 0.0f, p.inv_norms, ra);
+		const float da = 1.0f * metric_epilogue<kMetric>(fold_chains<false>(acc, nullptr, nullptr, 0, m) + 0.0f, &inva, 0);
 		if (oka && m == 0) dists[ia] = da;
 		if (second) {
 			acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
 			for (int t = 0; t < NB; ++t) chain_step<kMetric>(acc, Q(t), xb[t]);
-			const float db = 1.0f * metric_epilogue<kMetric>(fold_chains<false>(acc, nullptr, nullptr, 0, m) + 0.0f, p.inv_norms, rb);
+			const float db = 1.0f * metric_epilogue<kMetric>(fold_chains<false>(acc, nullptr, nullptr, 0, m) + 0.0f, &invb, 0);
 			if (okb && m == 0) dists[ib] = db;
 		}
 	}
@@ -772,6 +779,17 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 		// gathers are in flight, and saves the next hop its first dependent round trip whenever no nearer candidate turned up meanwhile
 		// (LDS-DMA: the block goes straight into s_pre, no register lives across the hop — the D = 768 kernel sits at its 96-VGPR budget)
 		uint32_t pre_node = 0xFFFFFFFFu;
+#ifdef RXGPU_HNSW_PHASES
+		unsigned long long ph_a = 0, ph_b = 0, ph_c = 0, ph_t = __builtin_readcyclecounter(), ph_start = ph_t;
+#define HN_PHASE(acc)                                              \
+	do {                                                           \
+		const unsigned long long now__ = __builtin_readcyclecounter(); \
+		acc += now__ - ph_t;                                       \
+		ph_t = now__;                                              \
+	} while (0)
+#else
+#define HN_PHASE(acc) do { } while (0)
+#endif
 		for (;;) {
 			if (ndist - ndist_upper + p.maxM0 > vis_limit) {   // the hash set would pass half full: this search goes to the bitset re-run
 				if (lane == 0) {
@@ -819,12 +837,14 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 				nfresh += __popcll(fm);
 			}
 			HN_SYNC();
+			HN_PHASE(ph_a);
 			if constexpr (kDel) {   // the delete marks travel while the distances are computed
 				for (int j = lane; j < nfresh; j += 64) nb_del[j] = p.deleted[nb_id[j]];
 			}
 			distances(nb_id, nfresh, nb_d);
 			ndist += nfresh;
 			HN_SYNC();
+			HN_PHASE(ph_b);
 			for (int base = 0; base < nfresh && !list.tie; base += 64) {   // runLayer0Step :932-960 in neighbour order; lane j carries neighbour base + j
 				const int j = base + lane;
 				const float dj = j < nfresh ? nb_d[j] : __builtin_inff();
@@ -845,7 +865,16 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 				}
 			}
 			HN_SYNC();
+			HN_PHASE(ph_c);
 		}
+#ifdef RXGPU_HNSW_PHASES
+		if (lane == 0 && p.stats) {
+			atomicAdd(&p.stats[4], ph_a);
+			atomicAdd(&p.stats[5], ph_b);
+			atomicAdd(&p.stats[6], ph_c);
+			atomicAdd(&p.stats[7], __builtin_readcyclecounter() - ph_start);
+		}
+#endif
 		const int total = list.held();
 		const int keep = total < int(p.k) ? total : int(p.k);   // SearchKnn :1998-2000: the k nearest of top_candidates
 		if constexpr (!kDel) {

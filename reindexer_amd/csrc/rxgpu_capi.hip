@@ -1617,8 +1617,8 @@ int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64
 	h->graph_upper_cap = upper_cap;
 	h->graph_upper_used = upper_blocks;
 	if (!h->d_hnsw_stats) {
-		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_hnsw_stats), 4 * sizeof(unsigned long long)));   // evals, hops, in-kernel restarts, spare
-		RX_HIP(hipMemset(h->d_hnsw_stats, 0, 4 * sizeof(unsigned long long)));
+		RX_HIP(hipMalloc(reinterpret_cast<void**>(&h->d_hnsw_stats), 8 * sizeof(unsigned long long)));   // evals, hops, in-kernel restarts, spare, [4..7] phase cycles (RXGPU_HNSW_PHASES builds)
+		RX_HIP(hipMemset(h->d_hnsw_stats, 0, 8 * sizeof(unsigned long long)));
 	}
 	h->graph_n = n;
 	h->graph_M = M;
@@ -2702,6 +2702,13 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 	RX_HIP(hipMemset(h->d_hnsw_stats, 0, sizeof(v)));
 	*distance_evals = v[0];
 	*hops = v[1];
+	if (std::getenv("RXGPU_HNSW_PHASES")) {   // a library built with -DRXGPU_HNSW_PHASES: shader cycles of the sorted-list search by phase
+		unsigned long long ph[4] = {0, 0, 0, 0};
+		RX_HIP(hipMemcpy(ph, h->d_hnsw_stats + 4, sizeof(ph), hipMemcpyDeviceToHost));
+		RX_HIP(hipMemset(h->d_hnsw_stats + 4, 0, sizeof(ph)));
+		std::fprintf(stderr, "[rxgpu hnsw phases] hops %llu evals %llu | cycles: pop+links+visited %llu  distances %llu  inserts %llu  layer0 total %llu\n", v[1], v[0], ph[0],
+					 ph[1], ph[2], ph[3]);
+	}
 	return RXGPU_OK;
 }
 

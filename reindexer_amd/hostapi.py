@@ -601,6 +601,7 @@ class GpuHnswMap:
 
     def clear(self):
         """Map::Clear (HnswIndexBase::clearMap)"""
+        lib().rxhost_hnsw_clear.argtypes = [_vp]
         rc = lib().rxhost_hnsw_clear(self.h)
         if rc:
             _raise(rc)

@@ -272,3 +272,67 @@ class ShardedBruteforceGpu:
         else:
             src = base
         capi.merge_shards_device(src, self.world, nq, self.kk, self.shard_rows, out_dist.data_ptr(), out_row.data_ptr(), None, stream)
+
+
+class ShardedFtExchange:
+    """ft_fast merge over DOCUMENT-RANGE shards, one rank per shard (SURVEY 8e "BM25"): what crosses the ranks, and what every rank derives
+    from it.  The same two exchanges rxgpu_ft_create_sharded runs between the kernels of its launch train inside one process
+    (rxgpu_ft_capi.hip, run_merge_sharded), here over torch.distributed — the one-process-per-GPU deployment; the local merger is injected
+    (on a GPU box the rank's rxgpu shard, in tests/test_sharded_gloo.py the CPU oracle), so the exchange logic runs unchanged under gloo.
+
+      1. every rank's pre-score histogram (65536 counters: documents of its range inside the restricting mask, not removed, by uint16
+         pre-score) and the popcount of its mask words  ->  ONE all_gather.  From the sums every rank takes the same decisions the single
+         index takes (mergerimpl.h:486-490, 433-446): does the preselect run, the threshold score, how many documents AT the threshold are
+         kept — and, because ties are kept in document order = shard order, its own share of that quota: what is left after the shards in front.
+      2. every rank's count of documents first met per sub-term row (addDoc order, merger.h:161-180)  ->  ONE all_gather.  The merge slot of
+         a document is (documents first met in an earlier row, anywhere) + (same row, shards in front) + (same row, same shard, smaller id):
+         every rank writes its documents at their GLOBAL slots, the union of the ranks' lists IS the single index's list."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.collectives = 0
+
+    def _all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t.unsqueeze(0)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(out, t, group=self.group)
+        self.collectives += 1
+        return torch.stack(out)
+
+    def preselect(self, local_hist: torch.Tensor, local_popcount: int, merge_limit: int, max_merged: int, host_gate: bool):
+        """local_hist: int64 [65536].  -> (on, min_score, quota): on = the preselect runs (the host half of the 2-phase gate held AND the summed
+        popcount exceeds mergeLimit); a rank then keeps its documents with a pre-score above min_score and the first `quota` of its
+        documents AT min_score, in document order."""
+        if not host_gate:
+            return False, 0, 0
+        payload = torch.cat([local_hist.to(torch.int64), torch.tensor([int(local_popcount)], dtype=torch.int64)])
+        g = self._all_gather(payload)
+        if int(g[:, 65536].sum()) <= merge_limit:
+            return False, 0, 0
+        hist = g[:, :65536]
+        total = hist.sum(dim=0)
+        # mergerimpl.h:433-446: walk the scores downwards until maxMergedDocs documents are covered
+        above = torch.flip(torch.cumsum(torch.flip(total, [0]), 0), [0]) - total   # documents strictly above every score
+        visited = (above < max_merged)
+        visited[0] = False   # the walk stops at score 1
+        idx = torch.nonzero(visited)
+        if idx.numel() == 0:
+            return True, 65535, 0
+        min_score = int(idx.min())
+        min_docs = max_merged - int(above[min_score])
+        used_in_front = int(hist[:self.rank, min_score].sum())
+        return True, min_score, max(0, min_docs - used_in_front)
+
+    def slot_bases(self, local_first_met: torch.Tensor):
+        """local_first_met: int64 [n_rows] = this shard's documents first met per sub-term row.  -> (bases int64 [n_rows]: the merge slot of this
+        shard's first document of every row, total documents the merge adds before the mergeLimit cut)"""
+        g = self._all_gather(local_first_met.to(torch.int64))   # [world, n_rows]
+        row_tot = g.sum(dim=0)
+        rows_before = torch.cumsum(row_tot, 0) - row_tot
+        shards_before = g[:self.rank].sum(dim=0) if self.rank else torch.zeros_like(row_tot)
+        return rows_before + shards_before, int(row_tot.sum())

@@ -271,3 +271,117 @@ def test_two_rank_label_search_replays_cross_shard_ties(oracle, k):
             alld = np.sort(oracle.dist_many(0, queries[qi], rows))
             ties_seen += int(alld[k - 1] == alld[k])
     assert ties_seen > 0
+
+
+# ---------------------------------------------------------------------------------------------- ft_fast over document-range shards
+def _ft_case():
+    from .test_bm25_oracle import _multi_case
+    nf, total = 1, 40_000
+    _, words, avg, removed, excluded, terms, store = _multi_case(6161, nf, total, 900, (1, 2, 1, 3), False, None, sizes=(3000, 14_000), nsub_range=(2, 4))
+    return nf, total, words, avg, removed, terms
+
+
+def _ft_worker(rank, world, port, limit, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.pyoracle import FtOracle, Oracle
+    from reindexer_amd.sharded import ShardedFtExchange
+    ft = FtOracle(Oracle())
+    nf, total, words, avg, removed, terms = _ft_case()
+    cfg = ft.default_config(nf, merge_limit=limit)
+    # this rank's documents: a contiguous run of 8192-document ranges, like rxgpu_ft_create_sharded cuts them
+    n_ranges = (total + 8191) // 8192
+    per = -(-n_ranges // world)
+    lo, hi = min(rank * per * 8192, total), min((rank + 1) * per * 8192, total)
+    # ---- local facts from the postings of MY documents (buildRestrictingBitmask, calcTermScores: every field has the same boost here)
+    mask = np.ones(total, bool)
+    score = np.zeros(total, np.int64)
+    first_row = np.full(total, -1, np.int64)
+    row, total_vids = 0, 0
+    for t in terms:
+        held = np.zeros(total, bool)
+        scored = np.zeros(total, bool)
+        for s in t["subs"]:
+            total_vids += len(s["doc"])
+            docs = s["doc"][(s["doc"] >= lo) & (s["doc"] < hi)]
+            held[docs] = True
+            if t["op"] != 3:
+                new = docs[~scored[docs]]
+                p16 = min(int(np.float32(s["proc"]) * np.float32(t["opts"]["field_boost"][0]) * np.float32(t["opts"]["boost"])) & 0xFFFF, 65535 // 4)
+                score[new] = np.minimum(score[new] + p16, 65535)
+                scored[new] = True
+                fresh = docs[first_row[docs] < 0]
+                first_row[fresh] = row
+                row += 1
+        if t["op"] == 2:
+            mask &= held
+        elif t["op"] == 3:
+            mask &= ~held
+    n_rows = row
+    mine = np.zeros(total, bool)
+    mine[lo:hi] = True
+    mask &= mine
+    elig = mask & (removed == 0)
+    score[~elig] = 0
+    hist = np.bincount(score[lo:hi][score[lo:hi] > 0], minlength=65536).astype(np.int64)
+    max_merged = min(limit, total_vids)
+    est_or = sum(sum(len(s["doc"]) for s in t["subs"]) for t in terms if t["op"] == 1)
+    est_and = min([sum(len(s["doc"]) for s in t["subs"]) for t in terms if t["op"] == 2] or [1 << 62])
+    host_gate = min(est_or, est_and, total) > limit and total > limit   # estimateNumDocsInMerge (merger.h:239-267) + mergerimpl.h:486-490
+    x = ShardedFtExchange()
+    on, min_score, quota = x.preselect(torch.from_numpy(hist), int(mask.sum()), limit, max_merged, host_gate)
+    kept = elig & (first_row >= 0)
+    if on:
+        ties = np.flatnonzero(elig & (score == min_score))
+        kept = elig & (score > min_score)
+        kept[ties[:quota]] = True
+        kept &= first_row >= 0
+    counts = np.bincount(first_row[kept], minlength=n_rows).astype(np.int64)
+    bases, total_docs = x.slot_bases(torch.from_numpy(counts))
+    # ---- the local merge of the kept documents: the oracle over the whole index with everything else excluded (ranks use the global N / df)
+    wd, wp, wf, wn, _ = ft.merge_query(ft.default_config(nf, merge_limit=1 << 30), terms, total, words, avg, removed, (~kept).astype(np.uint8), sort_by_rank=False)
+    # ... arrives in (row, document) order: the k-th document of row r sits at slot bases[r] + k
+    rows_of = first_row[wd.astype(np.int64)]
+    slots = np.empty(len(wd), np.int64)
+    for r in range(n_rows):
+        sel = np.flatnonzero(rows_of == r)
+        slots[sel] = int(bases[r]) + np.arange(len(sel))
+    out_q.put((rank, slots, wd.astype(np.int64), wp.copy(), wn.copy(), bool(on), total_docs, x.collectives))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("limit", [20000, 900, 150])
+def test_two_rank_ft_document_range_shards_equal_single_index(oracle, limit):
+    """SURVEY 8e "BM25" as a multi-process path: two ranks hold the postings of their document ranges, exchange the folded pre-score
+    histograms + mask popcounts and the first-met counts (reindexer_amd.sharded.ShardedFtExchange, two all_gathers), and write their documents
+    at global merge slots — the union is the single index's merge, slot for slot: documents, raw ranks, uint8 ranks, preselect flag (with the
+    ties at the threshold handed out in shard order: limit 900 / 150), the mergeLimit cut (limit 150)."""
+    from oracle.pyoracle import FtOracle
+    world = 2
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ft_worker, args=(r, world, port, limit, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out_q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ft = FtOracle(oracle)
+    nf, total, words, avg, removed, terms = _ft_case()
+    cfg = ft.default_config(nf, merge_limit=limit)
+    wd, wp, wf, wn, wpre = ft.merge_query(cfg, terms, total, words, avg, removed, None, sort_by_rank=False)
+    n = len(wd)
+    docs = np.full(n, -1, np.int64)
+    procs_ = np.zeros(n, np.float32)
+    for rank, slots, d, pr, nm, on, total_docs, collectives in results:
+        assert on == bool(wpre) and min(total_docs, limit) == n, (rank, on, wpre, total_docs, n)
+        assert collectives in (1, 2) and (collectives == 2 or not on)   # one all_gather for the slots, one more when the host gate held
+        keep = slots < n   # the mergeLimit cut: slots at or beyond maxMergedDocs are never added
+        docs[slots[keep]] = d[keep]
+        procs_[slots[keep]] = pr[keep]
+    assert np.array_equal(docs, wd.astype(np.int64))
+    assert np.array_equal(procs_.view(np.uint32), wp.view(np.uint32))
