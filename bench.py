@@ -117,7 +117,10 @@ _DROP_KEYS = {"note", "against", "host", "kernels", "builder", "params", "value_
 _KEEP_UNITS_AT = {"roofline", "cpu_baseline"}   # the contract's two objects keep every field the contract names
 
 
-def compact(obj, depth=0, top_key=None):
+_DROP_KEYS_TIGHT = {"deviations_from_survey_8d", "workload", "sample", "checked", "queries", "recall_queries", "equal_to_reference_checked", "device_batches"}
+
+
+def compact(obj, depth=0, top_key=None, tight=False):
     """The driver keeps the last 8 KB of stdout: the printed line carries every leg's numbers (frac, avg_ms, rates, parity flags), the prose
     and the per-launch byte counts stay in --full-json."""
     if isinstance(obj, dict):
@@ -125,14 +128,16 @@ def compact(obj, depth=0, top_key=None):
         for k, v in obj.items():
             if depth > 0 and k in _DROP_KEYS and not (depth == 1 and top_key in _KEEP_UNITS_AT and k not in {"note", "host", "index_load_seconds"}):
                 continue
-            out[k] = compact(v, depth + 1, k if depth == 0 else top_key)
+            if tight and depth > 1 and k in _DROP_KEYS_TIGHT and top_key not in _KEEP_UNITS_AT and top_key != "config":
+                continue
+            out[k] = compact(v, depth + 1, k if depth == 0 else top_key, tight)
         return out
     if isinstance(obj, list):
-        return [compact(v, depth + 1, top_key) for v in obj]
+        return [compact(v, depth + 1, top_key, tight) for v in obj]
     if isinstance(obj, float):
         return float(f"{obj:.5g}")
-    if isinstance(obj, str) and len(obj) > 110 and not (top_key == "cpu_baseline" and depth == 2):
-        return obj[:107] + "..."
+    if isinstance(obj, str) and len(obj) > (48 if tight and top_key not in _KEEP_UNITS_AT and top_key != "config" else 110) and not (top_key == "cpu_baseline" and depth == 2):
+        return obj[:(45 if tight and top_key not in _KEEP_UNITS_AT and top_key != "config" else 107)] + "..."
     return obj
 
 
@@ -147,6 +152,10 @@ def emit(result: dict, args) -> None:
     small = compact(result)
     small["full_json"] = os.path.relpath(args.full_json, ROOT) if str(args.full_json).startswith(str(ROOT)) else str(args.full_json)
     line = json.dumps(small, separators=(",", ":"))
+    if len(line) >= 7600:   # second pass: the numbers of every leg stay, counts / descriptions inside the legs go (they are in --full-json)
+        small = compact(result, tight=True)
+        small["full_json"] = os.path.relpath(args.full_json, ROOT) if str(args.full_json).startswith(str(ROOT)) else str(args.full_json)
+        line = json.dumps(small, separators=(",", ":"))
     for victim in ("ft_packed", "prefilter", "pruned_scan", "hybrid", "hnsw"):   # never reached at today's sizes (~5 KB); a hard guarantee anyway
         if len(line) < 7600:
             break

@@ -256,6 +256,20 @@ int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t n
  * The traversal replays the reference's heaps step for step, so on the same graph the sets are identical. */
 int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 						  uint32_t* out_count);
+/* ONE query through the index's RESIDENT search kernel — the planner's call: HnswIndexBase::select issues one SearchKnn per query from as
+ * many threads as there are connections (hnsw_index.cc:159-288; gtests/tests/unit/float_vector_index.cc:258-294 runs 16 of them).  The call
+ * claims a slot of a mailbox in pinned host memory, stores the query and polls the answer; the kernel behind the mailbox is launched by
+ * whichever caller finds none alive, serves every thread's requests side by side (one workgroup of four wavefronts per slot) and ends by
+ * itself — when the index is about to change (every mutating entry point tells it), after RXGPU_HNSW_SERVER_IDLE_US (2000) without a
+ * request, after RXGPU_HNSW_SERVER_LIFE_MS (50) in any case.  No launch, copy or completion signal lies on the path of a served query.
+ * *served = 1: out_* hold what rxgpu_hnsw_search_knn returns for this query (the same device code runs the search).  *served = 0: this query
+ * is not taken — every slot (RXGPU_HNSW_SERVER_SLOTS, 128) is busy, ef > 128 (96 on a graph with deleted nodes), a dimension other than
+ * 128 / 512 / 768, a profiled or sharded index, RXGPU_HNSW_SERVER=0, or the search needs the re-run tiers — and the caller uses
+ * rxgpu_hnsw_search_knn, which tries the mailbox itself for nq == 1 and launches otherwise. */
+int rxgpu_hnsw_search_knn_posted(rxgpu_index* h, const float* query, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count,
+								 int32_t* served);
+/* queries answered through the mailbox / resident kernels launched so far (instrumentation; 0 / 0 before the first such query) */
+int rxgpu_hnsw_server_stats(rxgpu_index* h, uint64_t* served, uint64_t* generations);
 
 /* SQ8 graphs — HierarchicalNSWImpl<uint8_t> after HnswIndexBase::Quantize (hnsw_index.cc:626-660, hnswalg.h:353-420): the level-0 payload
  * is one byte per component plus the row's corrective offset, distances are DistCalculator<uint8_t>::operator() (hnswlib.h:147-165) over

@@ -410,6 +410,43 @@ class RefHnsw:
                     links0=links0, upper_off=upper_off, upper=upper, levels=levels, labels=labels, deleted=deleted, vectors=vectors)
 
 
+def ref_hnsw_build_mt(ref: "Ref", metric: int, vecs, labels, M: int = 16, ef_construction: int = 200, threads: int = 16) -> dict:
+    """The reference's MULTITHREADED index build: HierarchicalNSW<Synchronization::OnInsertions> filled through AddPointConcurrent from
+    `threads` inserting threads (hnsw_index.cc:19, 105-111), exported as the flat graph RefHnsw.export returns."""
+    L = ref.L
+    L.ref_hnswmt_build.restype = _vp
+    L.ref_hnswmt_build.argtypes = [_i, _sz, _sz, _sz, _sz, _sz, _vp, _vp]
+    L.ref_hnswmt_destroy.argtypes = [_vp]
+    L.ref_hnswmt_info.argtypes = [_vp, _vp]
+    L.ref_hnswmt_export_level0.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+    L.ref_hnswmt_export_upper.restype = _sz
+    L.ref_hnswmt_export_upper.argtypes = [_vp, _vp, _vp]
+    vecs = _f32(vecs)
+    n, dim = vecs.shape
+    labels = np.ascontiguousarray(labels, np.uint64)
+    h = L.ref_hnswmt_build(metric, dim, n, M, ef_construction, threads, vecs.ctypes.data, labels.ctypes.data)
+    if not h:
+        raise RuntimeError(L.ref_last_error().decode())
+    try:
+        info = np.zeros(6, np.int64)
+        L.ref_hnswmt_info(h, info.ctypes.data)
+        n, M, maxM0, maxlevel, entry, ndel = (int(x) for x in info)
+        links0 = np.zeros((n, 1 + maxM0), np.uint32)
+        levels = np.zeros(n, np.int32)
+        out_labels = np.zeros(n, np.uint64)
+        deleted = np.zeros(n, np.uint8)
+        vectors = np.zeros((n, dim), np.float32)
+        L.ref_hnswmt_export_level0(h, links0.ctypes.data, levels.ctypes.data, out_labels.ctypes.data, deleted.ctypes.data, vectors.ctypes.data)
+        upper_off = np.zeros(n + 1, np.uint64)
+        blocks = L.ref_hnswmt_export_upper(h, upper_off.ctypes.data, None)
+        upper = np.zeros((max(blocks, 1), 1 + M), np.uint32)
+        L.ref_hnswmt_export_upper(h, upper_off.ctypes.data, upper.ctypes.data)
+    finally:
+        L.ref_hnswmt_destroy(h)
+    return dict(metric=metric, n=n, dim=dim, M=M, maxM0=maxM0, maxlevel=maxlevel, entry=entry, num_deleted=ndel, links0=links0, upper_off=upper_off,
+                upper=upper, levels=levels, labels=out_labels, deleted=deleted, vectors=vectors)
+
+
 def _hnsw_bind(L):
     L.orc_hnsw_search_knn.restype = _sz
     L.orc_hnsw_search_knn.argtypes = [_i, _sz, _sz, _sz, _sz, _i, C.c_uint32, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz, _vp, _vp]

@@ -12,6 +12,7 @@
 //     (constructed exactly like HierarchicalNSW<>::Impl::Impl, hnsw.cc:74-78: seed 100, ReplaceDeleted_True)
 // The same usage pattern as the reference's own engine-level test
 // gtests/tests/unit/hnsw_streaming_search_test.cc:22-25,38,53,161-162.
+#include <mutex>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -295,8 +296,9 @@ void ref_hnsw_stream_end(void* session) { delete static_cast<RefStream*>(session
 
 // Graph export (flat form shared by the C restatement and the GPU engine):
 //   info[0]=count info[1]=M info[2]=maxM0 info[3]=maxlevel info[4]=entrypoint info[5]=numDeleted
-void ref_hnsw_info(void* h, int64_t* info) {
-	auto* g = static_cast<HnswT*>(h);
+extern "C++" {
+template <typename G>
+static void exportInfo(G* g, int64_t* info) {
 	info[0] = int64_t(g->cur_element_count.load());
 	info[1] = int64_t(g->M_);
 	info[2] = int64_t(g->maxM0_);
@@ -304,10 +306,13 @@ void ref_hnsw_info(void* h, int64_t* info) {
 	info[4] = int64_t(g->enterpoint_node_);
 	info[5] = int64_t(g->num_deleted_);
 }
+}  // extern "C++"
+void ref_hnsw_info(void* h, int64_t* info) { exportInfo(static_cast<HnswT*>(h), info); }
 // links0: [count][1+maxM0] u32 (slot 0 = neighbour count), levels: [count] i32, labels: [count] u64,
 // deleted: [count] u8, vectors (optional): [count][dim] f32.
-void ref_hnsw_export_level0(void* h, uint32_t* links0, int32_t* levels, uint64_t* labels, uint8_t* deleted, float* vectors) {
-	auto* g = static_cast<HnswT*>(h);
+extern "C++" {
+template <typename G>
+static void exportLevel0(G* g, uint32_t* links0, int32_t* levels, uint64_t* labels, uint8_t* deleted, float* vectors) {
 	const size_t n = g->cur_element_count.load();
 	const size_t stride = 1 + g->maxM0_;
 	const size_t dim = g->fstdistfunc_.Dim();
@@ -322,10 +327,15 @@ void ref_hnsw_export_level0(void* h, uint32_t* links0, int32_t* levels, uint64_t
 		if (vectors) std::memcpy(vectors + i * dim, g->getDataByInternalId(hnswlib::tableint(i)), dim * sizeof(float));
 	}
 }
+}  // extern "C++"
+void ref_hnsw_export_level0(void* h, uint32_t* links0, int32_t* levels, uint64_t* labels, uint8_t* deleted, float* vectors) {
+	exportLevel0(static_cast<HnswT*>(h), links0, levels, labels, deleted, vectors);
+}
 // Upper levels as CSR: upperOff[i] = index (in units of blocks of 1+M u32) of node i's level-1 block;
 // node i owns levels[i] consecutive blocks.  Call with upper == nullptr to get the block count.
-size_t ref_hnsw_export_upper(void* h, uint64_t* upperOff, uint32_t* upper) {
-	auto* g = static_cast<HnswT*>(h);
+extern "C++" {
+template <typename G>
+static size_t exportUpper(G* g, uint64_t* upperOff, uint32_t* upper) {
 	const size_t n = g->cur_element_count.load();
 	const size_t stride = 1 + g->M_;
 	size_t blocks = 0;
@@ -342,6 +352,49 @@ size_t ref_hnsw_export_upper(void* h, uint64_t* upperOff, uint32_t* upper) {
 	if (upperOff) upperOff[n] = blocks;
 	return blocks;
 }
+}  // extern "C++"
+size_t ref_hnsw_export_upper(void* h, uint64_t* upperOff, uint32_t* upper) { return exportUpper(static_cast<HnswT*>(h), upperOff, upper); }
+
+// ---------------------------------------------------------------------- the reference's MULTITHREADED index build
+// HierarchicalNSW<Synchronization::OnInsertions> filled by `threads` inserting threads through AddPointConcurrent — what
+// HnswIndexBase<HierarchicalNSWMT>::upsertConcurrent does during the namespace's multithreaded index build (hnsw_index.cc:19, 105-111).
+// Points are handed out in label order from one atomic counter.  The graph is exported in the flat form above.
+using HnswMT = hnswlib::HierarchicalNSWImpl<float, hnswlib::Synchronization::OnInsertions>;
+void* ref_hnswmt_build(int metric, size_t dim, size_t n, size_t M, size_t efConstruction, size_t threads, const float* vecs, const uint64_t* labels) {
+	try {
+		auto g = std::make_unique<HnswMT>(toMetric(metric), dim, n, M, efConstruction, 100, reindexer::ReplaceDeleted_True);
+		std::atomic<size_t> next{0};
+		std::atomic<bool> failed{false};
+		std::string error;
+		std::mutex errMtx;
+		auto worker = [&] {
+			try {
+				for (size_t i = next.fetch_add(1); i < n && !failed.load(); i = next.fetch_add(1)) g->AddPointConcurrent(vecs + i * dim, labels[i]);
+			} catch (const std::exception& e) {
+				std::lock_guard<std::mutex> lk(errMtx);
+				error = e.what();
+				failed.store(true);
+			}
+		};
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < std::max<size_t>(1, threads); ++t) pool.emplace_back(worker);
+		for (auto& t : pool) t.join();
+		if (failed.load()) {
+			g_err = error;
+			return nullptr;
+		}
+		return g.release();
+	} catch (const std::exception& e) {
+		g_err = e.what();
+		return nullptr;
+	}
+}
+void ref_hnswmt_destroy(void* h) { delete static_cast<HnswMT*>(h); }
+void ref_hnswmt_info(void* h, int64_t* info) { exportInfo(static_cast<HnswMT*>(h), info); }
+void ref_hnswmt_export_level0(void* h, uint32_t* links0, int32_t* levels, uint64_t* labels, uint8_t* deleted, float* vectors) {
+	exportLevel0(static_cast<HnswMT*>(h), links0, levels, labels, deleted, vectors);
+}
+size_t ref_hnswmt_export_upper(void* h, uint64_t* upperOff, uint32_t* upper) { return exportUpper(static_cast<HnswMT*>(h), upperOff, upper); }
 
 // ---------------------------------------------------------------- timed multi-thread baselines (bench.py cpu_baseline legs)
 // The reference's concurrency model: T planner threads, each with its own query over the shared index

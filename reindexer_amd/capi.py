@@ -78,6 +78,8 @@ _SIGNATURES = {
     "rxgpu_hnsw_update_deleted": (_i, [_vp, _vp, _u64]),
     "rxgpu_hnsw_patch_graph": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp, C.c_int32, _u32, _u64]),
     "rxgpu_hnsw_search_knn": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
+    "rxgpu_hnsw_search_knn_posted": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    "rxgpu_hnsw_server_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_hnsw_attach_sq8": (_i, [_vp, _vp, _vp, _u64, _f]),
     "rxgpu_hnsw_upload_sq8_rows": (_i, [_vp, _u64, _u64, _vp, _vp, _f]),
     "rxgpu_hnsw_search_knn_sq8": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
@@ -411,6 +413,21 @@ class VectorIndex:
         cnt = np.zeros(nq, np.uint32)
         _check(lib().rxgpu_hnsw_search_knn(self._h, q.ctypes.data, nq, k, ef, dist.ctypes.data, row.ctypes.data, cnt.ctypes.data))
         return dist[:, :k], row[:, :k], cnt
+
+    def hnsw_search_knn_posted(self, query, k: int, ef: int = 0):
+        """One query through the index's resident search kernel (rxgpu_hnsw_search_knn_posted): (dist, row, count, served)."""
+        q = _f32c(query).reshape(self.dim)
+        dist = np.full(max(k, 1), np.inf, np.float32)
+        row = np.full(max(k, 1), 0xFFFFFFFF, np.uint32)
+        cnt = _u32(0)
+        served = C.c_int32(0)
+        _check(lib().rxgpu_hnsw_search_knn_posted(self._h, q.ctypes.data, k, ef, dist.ctypes.data, row.ctypes.data, C.addressof(cnt), C.byref(served)))
+        return dist[:k], row[:k], int(cnt.value), bool(served.value)
+
+    def hnsw_server_stats(self):
+        a, b = _u64(0), _u64(0)
+        _check(lib().rxgpu_hnsw_server_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def hnsw_attach_sq8(self, codes, corr, alpha_2: float) -> None:
         """SQ8 copy of the rows (Quantizer::Quantize, quantizer.h:93-124): codes [count][dim] u8, corr [count] f32."""

@@ -186,6 +186,22 @@ struct HnswHelper {
 	unsigned long long ticks_limit;   // wall_clock64 ticks (100 MHz) after which a helper gives up
 };
 
+// The resident search kernel of an index (hnsw_server_kernel): workgroup w serves slot w of a mailbox in pinned host memory.  A planner
+// thread's single-query SearchKnn is then a store into the mailbox and a poll of it — no launch, no copy, no completion signal on its path.
+// Every word has ONE writer: `post` / `req` / the query block / `stop` the host, `done` / `leaving` / the result block the device.
+struct HnswServer {
+	const uint32_t* post;      // [slots] sequence number of the slot's newest request (host)
+	uint32_t* done;            // [slots] sequence number of the slot's newest finished request (device, behind the results)
+	const uint32_t* req;       // [slots][2] k, ef of the request
+	const uint32_t* stop;      // host word: != 0 -> leave now (the index is about to change)
+	uint32_t* leaving;         // host word: this generation's number, written when it decides to leave (stop / idle / lifetime) — the host
+	                           // may enqueue the next generation at once: same stream, so it starts when this one is gone
+	unsigned long long* dev;   // device words: [0] leave flag, [1] wall clock of the last request taken
+	uint32_t generation;
+	uint32_t kcap;             // result entries per slot
+	unsigned long long idle_ticks, life_ticks;   // wall_clock64 ticks (100 MHz): leave after so long without a request / so long after the start
+};
+
 // In-place graph update (rxgpu_hnsw_patch_graph): one workgroup per touched node scatters its staged lists into the resident arrays
 struct HnswPatch {
 	const uint32_t* ids;          // [n_dirty] node ids

@@ -19,6 +19,15 @@ void set_error(const std::string& msg) { g_err = msg; }
 
 using rxgpu::set_error;
 
+namespace rxgpu {
+// hipDeviceSynchronize for a device that may hold resident search kernels (rxgpu_hnsw_server.hip): they are told to leave first — the wait
+// would otherwise last until their idle / lifetime limit
+hipError_t device_wait_all(int device) {
+	hnsw_servers_pause_device(device);
+	return hipDeviceSynchronize();
+}
+}  // namespace rxgpu
+
 #define RX_HIP(expr)                                                                                      \
 	do {                                                                                                  \
 		hipError_t e__ = (expr);                                                                          \
@@ -760,7 +769,8 @@ void rxgpu_index_destroy(rxgpu_index* h) {
 	}
 	unregister_live_index(h);   // from here on an ending thread leaves this index alone
 	DeviceGuard dg(h->device);
-	(void)hipDeviceSynchronize();
+	(void)rxgpu::device_wait_all(h->device);
+	rxgpu::hnsw_server_destroy(h);
 	for (auto& kv : h->resident_ctx) h->free_ctx.push_back(kv.second);
 	for (auto* c : h->free_ctx) {
 		c->release();
@@ -807,6 +817,7 @@ int rxgpu_index_reserve(rxgpu_index* h, uint64_t capacity) {
 	RX_CHECK(capacity >= h->count, RXGPU_ERR_PARAMS, "Cannot resize, max element is less than the current number of elements");
 	RX_CHECK(capacity < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "capacity must fit 32-bit rows");
 	if (capacity == h->capacity) return RXGPU_OK;
+	rxgpu::hnsw_server_quiesce(h);   // the resident search kernel reads what changes here
 	DeviceGuard dg(h->device);
 	float* nrows = nullptr;
 	float* nnorm = nullptr;
@@ -842,6 +853,7 @@ int rxgpu_index_upload_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, cons
 	RX_CHECK(first_row + n <= h->capacity, RXGPU_ERR_PARAMS, "The number of elements exceeds the specified limit");
 	RX_CHECK(h->metric != RXGPU_METRIC_COSINE || inv_norms, RXGPU_ERR_PARAMS, "cosine index requires inv_norms");
 	DeviceGuard dg(h->device);
+	rxgpu::hnsw_server_quiesce(h);   // the resident search kernel reads what changes here
 	float* dst = h->d_rows + first_row * h->stride;
 	if (h->stride == h->dim) {
 		RX_HIP(hipMemcpy(dst, rows, n * h->dim * sizeof(float), hipMemcpyHostToDevice));
@@ -888,6 +900,7 @@ int rxgpu_index_adopt_device_rows(rxgpu_index* h, const void* d_rows, uint64_t n
 	RX_CHECK(n < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, "n must fit 32-bit rows");
 	RX_CHECK(h->metric != RXGPU_METRIC_COSINE || d_inv_norms || n == 0, RXGPU_ERR_PARAMS, "cosine index requires d_inv_norms");
 	DeviceGuard dg(h->device);
+	rxgpu::hnsw_server_quiesce(h);   // the resident search kernel reads what changes here
 	if (!h->adopted) {
 		if (h->d_rows) (void)hipFree(h->d_rows);
 		if (h->d_inv_norms) (void)hipFree(h->d_inv_norms);
@@ -910,6 +923,7 @@ int rxgpu_index_move_row(rxgpu_index* h, uint64_t from, uint64_t to) {
 	RX_CHECK(from < h->count && to < h->count, RXGPU_ERR_PARAMS, "rxgpu_index_move_row: row out of range");
 	if (from == to) return RXGPU_OK;
 	DeviceGuard dg(h->device);
+	rxgpu::hnsw_server_quiesce(h);   // the resident search kernel reads what changes here
 	RX_HIP(hipMemcpy(h->d_rows + to * h->stride, h->d_rows + from * h->stride, h->stride * sizeof(float), hipMemcpyDeviceToDevice));
 	if (h->d_inv_norms) RX_HIP(hipMemcpy(h->d_inv_norms + to, h->d_inv_norms + from, sizeof(float), hipMemcpyDeviceToDevice));
 	std::lock_guard<std::mutex> lk(h->mtx);
@@ -942,6 +956,7 @@ int rxgpu_index_truncate(rxgpu_index* h, uint64_t count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	if (h->shard_set) return rxgpu::sharded_truncate(h, count);
 	RX_CHECK(count <= h->capacity, RXGPU_ERR_PARAMS, "rxgpu_index_truncate: count exceeds capacity");
+	rxgpu::hnsw_server_quiesce(h);   // the resident search kernel reads what changes here
 	// shrinking keeps the statistics (upper bounds stay upper bounds) and the shadow (rows past count are never read)
 	if (count > h->count) {
 		h->stats_valid = false;
@@ -1248,7 +1263,7 @@ int rxgpu_index_set_lists(rxgpu_index* h, uint32_t nlist, const uint64_t* list_o
 	RX_CHECK(total <= h->count && (total == 0 || list_rows), RXGPU_ERR_PARAMS, "rxgpu_index_set_lists: more listed rows than the index holds");
 	for (uint64_t i = 0; i < total; ++i) RX_CHECK(list_rows[i] < h->count, RXGPU_ERR_PARAMS, "rxgpu_index_set_lists: row out of range");
 	DeviceGuard dg(h->device);
-	RX_HIP(hipDeviceSynchronize());
+	RX_HIP(rxgpu::device_wait_all(h->device));
 	if (h->d_list_off) (void)hipFree(h->d_list_off);
 	if (h->d_list_rows) (void)hipFree(h->d_list_rows);
 	h->d_list_off = nullptr;
@@ -1594,7 +1609,7 @@ int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64
 			 "rxgpu_hnsw_attach_graph: the GPU engine supports M <= 64 (2*M <= 128)");
 	RX_CHECK(n == 0 || entry < n, RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_graph: entry point out of range");
 	DeviceGuard dg(h->device);
-	RX_HIP(hipDeviceSynchronize());
+	RX_HIP(rxgpu::device_wait_all(h->device));
 	// allocated for the index CAPACITY (and with headroom for upper-level blocks), so that rxgpu_hnsw_patch_graph can grow the graph in place
 	auto replace = [&](auto*& dst, const void* src, size_t bytes, size_t cap_bytes) -> int {
 		if (dst) (void)hipFree(dst);
@@ -1633,6 +1648,7 @@ int rxgpu_hnsw_attach_graph(rxgpu_index* h, const uint32_t* links0, const uint64
 int rxgpu_hnsw_patch_graph(rxgpu_index* h, uint32_t n_dirty, const uint32_t* dirty_ids, const uint32_t* links0_rows, const uint8_t* deleted_flags,
 						   const int32_t* levels, const uint32_t* upper_rows, int32_t maxlevel, uint32_t entry, uint64_t num_deleted) {
 	RX_CHECK(h && h->graph_attached, RXGPU_ERR_LOGIC, "rxgpu_hnsw_patch_graph: no graph attached");
+	rxgpu::hnsw_server_quiesce(h);   // the resident search kernel reads what changes here
 	RX_CHECK(n_dirty == 0 || (dirty_ids && links0_rows && deleted_flags && levels), RXGPU_ERR_PARAMS, "rxgpu_hnsw_patch_graph: null argument");
 	const uint64_t n_new = h->count;   // the rows were uploaded first (rxgpu_index_upload_rows)
 	RX_CHECK(n_new >= h->graph_n, RXGPU_ERR_LOGIC, "rxgpu_hnsw_patch_graph: the index shrank under the graph");
@@ -1674,7 +1690,7 @@ int rxgpu_hnsw_patch_graph(rxgpu_index* h, uint32_t n_dirty, const uint32_t* dir
 		rxgpu_search_ctx* c;
 		~Rel() { release_ctx(h, c); }
 	} rel{h, c};
-	RX_HIP(hipDeviceSynchronize());   // no search may be reading the lists while they change (the Map calls this under its writer lock)
+	RX_HIP(rxgpu::device_wait_all(h->device));   // no search may be reading the lists while they change (the Map calls this under its writer lock)
 	auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
 	const size_t o_ids = 0, o_at = al(o_ids + size_t(n_dirty) * 4), o_src = al(o_at + size_t(n_dirty) * 8), o_lv = al(o_src + size_t(n_dirty) * 4),
 				 o_l0 = al(o_lv + size_t(n_dirty) * 4), o_up = al(o_l0 + size_t(n_dirty) * stride0 * 4), o_del = al(o_up + staged_blocks * stride * 4),
@@ -1722,7 +1738,7 @@ int rxgpu_hnsw_update_deleted(rxgpu_index* h, const uint8_t* deleted, uint64_t n
 	RX_CHECK(h && h->graph_attached, RXGPU_ERR_LOGIC, "rxgpu_hnsw_update_deleted: no graph attached");
 	RX_CHECK(deleted || h->graph_n == 0, RXGPU_ERR_PARAMS, "rxgpu_hnsw_update_deleted: null argument");
 	DeviceGuard dg(h->device);
-	RX_HIP(hipDeviceSynchronize());
+	RX_HIP(rxgpu::device_wait_all(h->device));
 	if (h->graph_n) RX_HIP(hipMemcpy(h->d_deleted, deleted, h->graph_n, hipMemcpyHostToDevice));
 	h->graph_deleted = num_deleted;
 	return RXGPU_OK;
@@ -1743,7 +1759,7 @@ int rxgpu_hnsw_upload_sq8_rows(rxgpu_index* h, uint64_t first_row, uint64_t n, c
 	DeviceGuard dg(h->device);
 	const uint64_t cap = std::max<uint64_t>(h->capacity, h->count);
 	if (h->sq8_cap < first_row + n) {   // first rows, or the index was reserved larger since: a new table, the old rows copied over
-		RX_HIP(hipDeviceSynchronize());
+		RX_HIP(rxgpu::device_wait_all(h->device));
 		uint8_t* nc = nullptr;
 		float* nr = nullptr;
 		RX_HIP(hipMalloc(reinterpret_cast<void**>(&nc), size_t(cap) * h->dim + 4));
@@ -1778,7 +1794,7 @@ int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* cor
 	RX_CHECK(count == h->count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_sq8: one code row per index row");
 	RX_CHECK(count == 0 || (codes && corr), RXGPU_ERR_PARAMS, "rxgpu_hnsw_attach_sq8: null argument");
 	DeviceGuard dg(h->device);
-	RX_HIP(hipDeviceSynchronize());
+	RX_HIP(rxgpu::device_wait_all(h->device));
 	if (h->d_codes) (void)hipFree(h->d_codes);
 	if (h->d_corr) (void)hipFree(h->d_corr);
 	h->d_codes = nullptr;
@@ -1825,6 +1841,9 @@ struct HnswKnobs {
 	int team = -1;                       // RXGPU_HNSW_TEAM: wavefronts per search of a small launch (1 = off)
 	int team_max = -1;                   // RXGPU_HNSW_TEAM_MAX: searches per launch up to which the team form is used
 	int zero_copy = -1;                  // RXGPU_HNSW_ZERO_COPY = 0: small calls copy their queries / results like large ones
+	int server = -1;                     // RXGPU_HNSW_SERVER = 0: single queries take a launch each (no resident kernel)
+	int server_slots = -1, server_idle_us = -1, server_life_ms = -1;   // RXGPU_HNSW_SERVER_SLOTS / _IDLE_US / _LIFE_MS
+	bool names_a_kernel = false;         // a hook that picks a kernel form is set: the resident kernel (one form) stands aside
 };
 static HnswKnobs read_hnsw_knobs() {
 	HnswKnobs k;
@@ -1851,10 +1870,49 @@ static HnswKnobs read_hnsw_knobs() {
 		else if (is("TEAM")) k.team = atoi(val);
 		else if (is("TEAM_MAX")) k.team_max = atoi(val);
 		else if (is("ZERO_COPY")) k.zero_copy = atoi(val);
+		else if (is("SERVER")) k.server = atoi(val);
+		else if (is("SERVER_SLOTS")) k.server_slots = atoi(val);
+		else if (is("SERVER_IDLE_US")) k.server_idle_us = atoi(val);
+		else if (is("SERVER_LIFE_MS")) k.server_life_ms = atoi(val);
+		else continue;
+		if (!is("SERVER") && !is("SERVER_SLOTS") && !is("SERVER_IDLE_US") && !is("SERVER_LIFE_MS") && !is("SPLIT_UPLOAD") && !is("HELPER")) k.names_a_kernel = true;
 	}
 	return k;
 }
 }  // extern "C++"
+
+// 1: the index's resident kernel answered; 0: it does not take this query (the caller launches); otherwise an error code
+static int hnsw_try_server(rxgpu_index* h, const HnswKnobs& knobs, const float* query, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
+						   uint32_t* out_count) {
+	if (knobs.server == 0 || knobs.names_a_kernel) return 0;
+	rxgpu::HnswServerConfig cfg;
+	if (knobs.server_slots > 0) cfg.slots = uint32_t(knobs.server_slots);
+	if (knobs.server_idle_us > 0) cfg.idle_us = uint32_t(knobs.server_idle_us);
+	if (knobs.server_life_ms > 0) cfg.life_ms = uint32_t(knobs.server_life_ms);
+	return rxgpu::hnsw_server_search(h, cfg, query, k, ef, out_dist, out_row, out_count);
+}
+
+int rxgpu_hnsw_search_knn_posted(rxgpu_index* h, const float* query, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count,
+								 int32_t* served) {
+	RX_CHECK(h && query && out_dist && out_row && out_count && served, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn_posted: null argument");
+	*served = 0;
+	if (h->shard_set || h->count == 0 || k == 0 || !h->graph_attached || h->graph_n != h->count) return RXGPU_OK;   // the launching call says what is wrong
+	k = uint32_t(std::min<uint64_t>(k, h->count));
+	if (!ef) ef = k * 3 / 2;
+	if (!ef) ef = 1;
+	const int rc = hnsw_try_server(h, read_hnsw_knobs(), query, k, ef, out_dist, out_row, out_count);
+	if (rc == 1) {
+		*served = 1;
+		return RXGPU_OK;
+	}
+	return rc;
+}
+
+int rxgpu_hnsw_server_stats(rxgpu_index* h, uint64_t* served, uint64_t* generations) {
+	RX_CHECK(h && served && generations, RXGPU_ERR_PARAMS, "rxgpu_hnsw_server_stats: null argument");
+	rxgpu::hnsw_server_counters(h, served, generations);
+	return RXGPU_OK;
+}
 
 int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 						  uint32_t* out_count) {
@@ -1908,6 +1966,13 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	RX_CHECK(ef <= uint32_t(rxgpu::kHnswMaxEf), RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: ef must be <= 4096 on the GPU engine");
 	// ef > 1024: the result heap alone takes the LDS budget of a search — the candidate heap goes to global scratch from the start
 	const bool big_ef = ef > uint32_t(rxgpu::kHnswLdsCandEf);
+	const HnswKnobs knobs = read_hnsw_knobs();
+	// ONE query, the planner's call: through the mailbox of the index's resident kernel (rxgpu_hnsw_server.hip) — no launch on the path
+	if (nq == 1 && to_host && !sq8) {
+		const int served = hnsw_try_server(h, knobs, static_cast<const float*>(queries), k, ef, out_dist, out_row, out_count);
+		if (served == 1) return RXGPU_OK;
+		if (served != 0) return served;
+	}
 	DeviceGuard dg(h->device);
 	rxgpu_search_ctx* c = acquire_ctx(h);
 	if (!c) return RXGPU_ERR_DEVICE;
@@ -1931,7 +1996,6 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// Graphs so small that the bitset is the smaller of the two keep it.  RXGPU_HNSW_VISITED=bitset: the former path (A/B, tests).
 	uint32_t vis_hash_log2 = 12;
 	while ((1ull << vis_hash_log2) < 64ull * ef && vis_hash_log2 < 18) ++vis_hash_log2;
-	const HnswKnobs knobs = read_hnsw_knobs();
 	if (knobs.visited_log2 >= 0) vis_hash_log2 = uint32_t(std::min(20, std::max(6, knobs.visited_log2)));   // test hook: force overflows
 	// a handful of searches (the latency form of the kernel, at most two workgroups per CU): the same hash set in LDS, whatever the rule
 	// below picks for batches — the launcher decides (launch_hnsw_nb).  RXGPU_HNSW_VISITED_LDS=0: off (A/B)
@@ -1978,9 +2042,16 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// A large batch in ONE launch is searched in two halves on two streams: the upload of the second half of the query block (a copy from
 	// pageable memory keeps this thread until it is staged) runs while the first half's searches have started; the halves overlap on the
 	// device like the workgroups of one launch.  RXGPU_HNSW_SPLIT_UPLOAD=0: one upload, one launch.
-	bool split_upload = !big_ef && nq >= 8192 && uint64_t(nq) <= vis_slots;
-	if (knobs.split_upload >= 0) split_upload = split_upload && knobs.split_upload != 0;
-	const uint32_t first_half = split_upload ? nq / 2 : nq;
+	// Round 6: four parts from 2048 queries on (the first launch waits for a quarter of the block, three quarters of the upload run under
+	// searches), the parts alternating between the two streams; RXGPU_HNSW_SPLIT_UPLOAD = n: that many parts (0 / 1: one upload, one launch).
+	bool split_upload = !big_ef && nq >= 2048 && uint64_t(nq) <= vis_slots;
+	uint32_t split_parts = 4;
+	if (knobs.split_upload >= 0) {
+		split_upload = split_upload && knobs.split_upload > 1;
+		split_parts = uint32_t(std::min(16, std::max(2, knobs.split_upload)));
+	}
+	const uint32_t part_q = split_upload ? (nq + split_parts - 1) / split_parts : nq;
+	const uint32_t first_half = part_q;   // queries uploaded in front of the first launch
 	if (split_upload) {
 		if (int rc = c->ensure_aux(); rc) return rc;
 	}
@@ -2242,9 +2313,13 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 				RX_HIP(hipEventRecord(c->split_done, c->stream));
 				RX_HIP(hipStreamWaitEvent(sb, c->split_done, 0));
 				launch_part(0, first_half, 0, c->stream);
-				const size_t off = size_t(first_half) * h->dim * qelem;
-				RX_HIP(hipMemcpyAsync(static_cast<char*>(c->d_queries.ptr) + off, static_cast<const char*>(queries) + off, qbytes - off, hipMemcpyHostToDevice, sb));
-				launch_part(first_half, nq - first_half, first_half, sb);
+				for (uint32_t qa = first_half, part = 1; qa < nq; qa += part_q, ++part) {
+					const uint32_t cnt = std::min(part_q, nq - qa);
+					hipStream_t st = (part & 1u) ? sb : c->stream;
+					const size_t off = size_t(qa) * h->dim * qelem;
+					RX_HIP(hipMemcpyAsync(static_cast<char*>(c->d_queries.ptr) + off, static_cast<const char*>(queries) + off, size_t(cnt) * h->dim * qelem, hipMemcpyHostToDevice, st));
+					launch_part(qa, cnt, qa, st);
+				}
 				RX_HIP(hipEventRecord(c->split_done, sb));
 				RX_HIP(hipStreamWaitEvent(c->stream, c->split_done, 0));
 			} else {
@@ -2697,7 +2772,7 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 	if (!h->d_hnsw_stats) return RXGPU_OK;
 	DeviceGuard dg(h->device);
 	unsigned long long v[2] = {0, 0};
-	RX_HIP(hipDeviceSynchronize());
+	RX_HIP(rxgpu::device_wait_all(h->device));
 	RX_HIP(hipMemcpy(v, h->d_hnsw_stats, sizeof(v), hipMemcpyDeviceToHost));
 	RX_HIP(hipMemset(h->d_hnsw_stats, 0, sizeof(v)));
 	*distance_evals = v[0];
@@ -2742,7 +2817,7 @@ int rxgpu_hnsw_read_tie_reruns(rxgpu_index* h, uint64_t* reruns) {
 	if (h->d_hnsw_stats) {                      // ... and searches that started over on the heaps inside the sorted-list kernel
 		DeviceGuard dg(h->device);
 		unsigned long long v = 0;
-		RX_HIP(hipDeviceSynchronize());
+		RX_HIP(rxgpu::device_wait_all(h->device));
 		RX_HIP(hipMemcpy(&v, h->d_hnsw_stats + 2, sizeof(v), hipMemcpyDeviceToHost));
 		RX_HIP(hipMemset(h->d_hnsw_stats + 2, 0, sizeof(v)));
 		*reruns += v;

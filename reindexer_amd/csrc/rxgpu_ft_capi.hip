@@ -537,7 +537,7 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h) {
 		h->shard_set = nullptr;
 	}
 	DevGuard dg(h->device);
-	(void)hipDeviceSynchronize();
+	(void)rxgpu::device_wait_all(h->device);
 	for (auto& kv : h->words) kv.second.release();
 	for (void* p : {static_cast<void*>(h->d_words), static_cast<void*>(h->d_avg), static_cast<void*>(h->d_removed), static_cast<void*>(h->d_removed_bits)}) {
 		if (p) (void)hipFree(p);
@@ -3001,7 +3001,7 @@ int rxgpu_hybrid_fuse(int device, const rxgpu_hybrid_params* params, int metric,
 	a.state = reinterpret_cast<rxgpu::HybridFuseState*>(d + o_state);
 	RX_HIP(rxgpu::launch_hybrid_prepare(a, nullptr));
 	RX_HIP(rxgpu::launch_hybrid_join(a, nullptr));
-	RX_HIP(hipDeviceSynchronize());
+	RX_HIP(hipStreamSynchronize(nullptr));   // (the two launches above; not a device-wide wait — resident search kernels may be alive)
 	uint32_t hdr[4];
 	RX_HIP(hipMemcpy(hdr, d + o_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
 	const uint64_t n = hdr[0];

@@ -1,0 +1,308 @@
+// Host side of the resident HNSW search kernel (hnsw_server_kernel, hnsw_search.hip; protocol: HnswServer, knn_kernels.hip.h).
+//
+// The reference's planner issues ONE query per HnswIndexBase::select (hnsw_index.cc:159-288 -> hnswalg.h:1988-2012) from as many threads as
+// it has connections (gtests/tests/unit/float_vector_index.cc:258-294 runs 16).  As a launch per call that path was bound by everything
+// around the search: 9.9 k q/s at T = 16 over 10M x 768 against 18.6 k for the reference's 16 cores.  Here a call claims a slot of a mailbox in
+// pinned host memory, stores its query and a sequence number, and polls the slot's answer; the kernel that serves the mailbox is launched by
+// whichever caller finds none alive and ends by itself (stop word / idle / lifetime), so nothing on the device ever waits for the host.
+//
+// What is NOT served here (the caller takes the ordinary launches): batches, SQ8 graphs, ef above the two-entries-a-lane list (128; 96 with
+// deleted nodes), embedding sizes without a fixed-dimension distance batch, a profiled index, every RXGPU_HNSW_* A/B hook that names a
+// kernel form, and a search that comes back flagged (equal keys that the in-kernel restart could not settle, a visited set half full).
+#include <immintrin.h>
+#include <sched.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+
+#include "../../include/rxgpu.h"
+#include "knn_kernels.hip.h"
+#include "rxgpu_internal.h"
+
+namespace rxgpu {
+
+namespace {
+constexpr uint32_t kServerKcap = 128;       // result entries per slot (k <= ef <= 128)
+constexpr uint32_t kServerEfCap = 128;
+constexpr uint32_t kServerRestartCap = 600; // heap area of a search that starts over on the reference's heaps (as a team launch gets)
+constexpr uint32_t kServerVisLog2 = 13;     // 8192-word hash set in LDS: a search may mark 4096 nodes
+
+std::mutex g_servers_mtx;
+std::set<HnswServerState*> g_servers;
+
+inline uint32_t load_acq(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+inline void store_rel(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+}  // namespace
+
+struct HnswServerState {
+	std::mutex mtx;   // launches, quiesce, teardown
+	int device = 0;
+	hipStream_t stream = nullptr;
+	char* host = nullptr;               // the mailbox
+	char* dev_view = nullptr;           // ... as the device addresses it
+	unsigned long long* d_words = nullptr;
+	uint32_t slots = 0, dim = 0;
+	size_t o_post = 0, o_done = 0, o_req = 0, o_stop = 0, o_leaving = 0, o_count = 0, o_query = 0, o_dist = 0, o_row = 0, bytes = 0;
+	std::atomic<uint64_t> free_mask[4];
+	std::vector<uint32_t> seq;          // per slot; touched by the slot's holder only
+	std::atomic<uint32_t> launched{0};  // generation number of the newest launch
+	std::atomic<bool> broken{false};
+	std::atomic<bool> maybe_alive{false};   // a generation was launched since the stream was last seen idle
+	std::atomic<uint64_t> served{0}, generations{0};
+	unsigned long long idle_ticks = 0, life_ticks = 0;
+
+	uint32_t* post() const { return reinterpret_cast<uint32_t*>(host + o_post); }
+	uint32_t* done() const { return reinterpret_cast<uint32_t*>(host + o_done); }
+	uint32_t* req() const { return reinterpret_cast<uint32_t*>(host + o_req); }
+	uint32_t* stop() const { return reinterpret_cast<uint32_t*>(host + o_stop); }
+	uint32_t* leaving() const { return reinterpret_cast<uint32_t*>(host + o_leaving); }
+};
+
+static void server_free(HnswServerState* st) {
+	if (!st) return;
+	if (st->stream) (void)hipStreamDestroy(st->stream);
+	if (st->host) (void)hipHostFree(st->host);
+	if (st->d_words) (void)hipFree(st->d_words);
+	delete st;
+}
+
+// (under h->mtx) the index's mailbox, made at the first single query
+static HnswServerState* server_create(rxgpu_index* h, uint32_t slots, uint32_t idle_us, uint32_t life_ms) {
+	auto* st = new HnswServerState();
+	st->device = h->device;
+	st->slots = slots;
+	st->dim = h->dim;
+	st->idle_ticks = uint64_t(idle_us) * 100ull;
+	st->life_ticks = uint64_t(life_ms) * 100000ull;
+	auto take = [&](size_t bytes) {
+		const size_t at = st->bytes;
+		st->bytes += (bytes + 255) & ~size_t(255);
+		return at;
+	};
+	st->o_post = take(size_t(slots) * 4);
+	st->o_done = take(size_t(slots) * 4);
+	st->o_req = take(size_t(slots) * 8);
+	st->o_stop = take(4);
+	st->o_leaving = take(4);
+	st->o_count = take(size_t(slots) * 4);
+	st->o_query = take(size_t(slots) * h->dim * 4);
+	st->o_dist = take(size_t(slots) * kServerKcap * 4);
+	st->o_row = take(size_t(slots) * kServerKcap * 4);
+	int least = 0, greatest = 0;
+	void* dv = nullptr;
+	// a stream of the highest priority: the runtime keeps a pool of hardware queues per priority, so the resident kernel never sits in a
+	// queue in front of an ordinary stream's launches (which would wait for it to leave)
+	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+		hipStreamCreateWithPriority(&st->stream, hipStreamNonBlocking, greatest) != hipSuccess ||
+		hipHostMalloc(reinterpret_cast<void**>(&st->host), st->bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+		hipHostGetDevicePointer(&dv, st->host, 0) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&st->d_words), 2 * sizeof(unsigned long long)) != hipSuccess) {
+		(void)hipGetLastError();
+		server_free(st);
+		return nullptr;
+	}
+	st->dev_view = static_cast<char*>(dv);
+	std::memset(st->host, 0, st->bytes);
+	for (uint32_t w = 0; w < 4; ++w) {
+		const uint32_t lo = 64 * w;
+		st->free_mask[w].store(slots >= lo + 64 ? ~0ull : (slots > lo ? ((1ull << (slots - lo)) - 1ull) : 0ull));
+	}
+	st->seq.assign(slots, 0u);
+	std::lock_guard<std::mutex> lk(g_servers_mtx);
+	g_servers.insert(st);
+	return st;
+}
+
+// (under st->mtx) one more generation, if none is alive or queued
+static int server_launch(rxgpu_index* h, HnswServerState* st) {
+	if (load_acq(st->leaving()) != st->launched.load(std::memory_order_acquire)) return RXGPU_OK;   // another caller was first
+	if (load_acq(st->stop())) return RXGPU_OK;                                                        // the index is changing
+	HnswParams p{};
+	p.rows = h->d_rows;
+	p.inv_norms = h->d_inv_norms;
+	p.links0 = h->d_links0;
+	p.upper_off = h->d_upper_off;
+	p.upper = h->d_upper;
+	p.deleted = h->d_deleted;
+	p.n = h->count;
+	p.stride = h->stride;
+	p.dim = h->dim;
+	p.M = h->graph_M;
+	p.maxM0 = h->graph_maxM0;
+	p.maxlevel = h->graph_maxlevel;
+	p.entry = h->graph_entry;
+	p.bare = h->graph_deleted == 0;
+	p.nq = st->slots;
+	p.ef = 1;   // (per request; the launcher checks the class limits against what the host admits)
+	p.k = 1;
+	p.visited = nullptr;
+	p.visited_words = 0;
+	p.vis_hash_log2 = kServerVisLog2;
+	p.vis_lds_log2 = kServerVisLog2;
+	p.vis_lds = 1;
+	p.prefetch_links = 1;
+	p.team = 4;
+	p.team_max = st->slots;
+	p.queries = reinterpret_cast<const float*>(st->dev_view + st->o_query);
+	p.out_dist = reinterpret_cast<float*>(st->dev_view + st->o_dist);
+	p.out_row = reinterpret_cast<uint32_t*>(st->dev_view + st->o_row);
+	p.out_count = reinterpret_cast<uint32_t*>(st->dev_view + st->o_count);
+	p.stats = h->d_hnsw_stats;
+	p.ef_cap = kServerEfCap;
+	p.lds_cand_cap = kServerRestartCap;
+	p.sorted = 1;
+	HnswServer sv{};
+	sv.post = reinterpret_cast<const uint32_t*>(st->dev_view + st->o_post);
+	sv.done = reinterpret_cast<uint32_t*>(st->dev_view + st->o_done);
+	sv.req = reinterpret_cast<const uint32_t*>(st->dev_view + st->o_req);
+	sv.stop = reinterpret_cast<const uint32_t*>(st->dev_view + st->o_stop);
+	sv.leaving = reinterpret_cast<uint32_t*>(st->dev_view + st->o_leaving);
+	sv.dev = st->d_words;
+	sv.generation = st->launched.load(std::memory_order_relaxed) + 1u;
+	sv.kcap = kServerKcap;
+	sv.idle_ticks = st->idle_ticks;
+	sv.life_ticks = st->life_ticks;
+	if (hipMemsetAsync(st->d_words, 0, 2 * sizeof(unsigned long long), st->stream) != hipSuccess || !launch_hnsw_server(h->metric, p, sv, st->slots, st->stream) ||
+		hipGetLastError() != hipSuccess) {
+		(void)hipGetLastError();
+		st->broken.store(true);
+		set_error("hnsw server: launch failed");
+		return RXGPU_ERR_DEVICE;
+	}
+	st->maybe_alive.store(true, std::memory_order_release);
+	st->launched.store(sv.generation, std::memory_order_release);
+	st->generations.fetch_add(1, std::memory_order_relaxed);
+	return RXGPU_OK;
+}
+
+static void server_quiesce_state(HnswServerState* st) {
+	if (!st->maybe_alive.load(std::memory_order_acquire)) return;   // (mutators call this per row: no lock, no driver call when nothing ran)
+	std::lock_guard<std::mutex> lk(st->mtx);
+	if (!st->maybe_alive.load(std::memory_order_acquire)) return;
+	DeviceGuardLite dg(st->device);
+	store_rel(st->stop(), 1u);
+	(void)hipStreamSynchronize(st->stream);
+	store_rel(st->leaving(), st->launched.load());   // (a generation that ended on its wall-clock fallback never wrote it)
+	store_rel(st->stop(), 0u);
+	st->maybe_alive.store(false, std::memory_order_release);
+}
+
+void hnsw_server_quiesce(rxgpu_index* h) {
+	if (h && h->hnsw_server) server_quiesce_state(h->hnsw_server);
+}
+
+void hnsw_servers_pause_device(int device) {
+	std::lock_guard<std::mutex> lk(g_servers_mtx);
+	for (HnswServerState* st : g_servers) {
+		if (st->device == device) server_quiesce_state(st);
+	}
+}
+
+void hnsw_server_destroy(rxgpu_index* h) {
+	if (!h || !h->hnsw_server) return;
+	HnswServerState* st = h->hnsw_server;
+	server_quiesce_state(st);
+	{
+		std::lock_guard<std::mutex> lk(g_servers_mtx);
+		g_servers.erase(st);
+	}
+	h->hnsw_server = nullptr;
+	server_free(st);
+}
+
+void hnsw_server_counters(const rxgpu_index* h, uint64_t* served, uint64_t* generations) {
+	*served = *generations = 0;
+	if (h && h->hnsw_server) {
+		*served = h->hnsw_server->served.load();
+		*generations = h->hnsw_server->generations.load();
+	}
+}
+
+// 1: served (out_* hold the result), 0: not served — the caller takes the launches, < 0: an RXGPU error code
+int hnsw_server_search(rxgpu_index* h, const HnswServerConfig& cfg, const float* query, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
+					   uint32_t* out_count) {
+	if (h->profiling) return 0;
+	if (h->dim != 128 && h->dim != 512 && h->dim != 768) return 0;
+	if (ef > (h->graph_deleted == 0 ? 128u : 96u) || k > kServerKcap || k > ef) return 0;
+	HnswServerState* st = h->hnsw_server;
+	if (!st) {
+		std::lock_guard<std::mutex> lk(h->mtx);
+		if (!h->hnsw_server) {
+			if (h->hnsw_server_failed) return 0;
+			h->hnsw_server = server_create(h, std::min<uint32_t>(256u, std::max<uint32_t>(1u, cfg.slots)), cfg.idle_us, cfg.life_ms);
+			if (!h->hnsw_server) {
+				h->hnsw_server_failed = true;
+				return 0;
+			}
+		}
+		st = h->hnsw_server;
+	}
+	if (st->broken.load(std::memory_order_relaxed)) return 0;
+	// a free slot (none: every workgroup is busy — this query takes a launch of its own)
+	int slot = -1;
+	for (uint32_t w = 0; w < 4 && slot < 0; ++w) {
+		uint64_t m = st->free_mask[w].load(std::memory_order_relaxed);
+		while (m) {
+			const int b = __builtin_ctzll(m);
+			const uint64_t bit = 1ull << b;
+			if (st->free_mask[w].fetch_and(~bit, std::memory_order_acquire) & bit) {
+				slot = int(64 * w) + b;
+				break;
+			}
+			m = st->free_mask[w].load(std::memory_order_relaxed);
+		}
+	}
+	if (slot < 0) return 0;
+	struct Release {
+		HnswServerState* st;
+		int slot;
+		~Release() { st->free_mask[slot >> 6].fetch_or(1ull << (slot & 63), std::memory_order_release); }
+	} release{st, slot};
+	std::memcpy(st->host + st->o_query + size_t(slot) * st->dim * 4, query, size_t(st->dim) * 4);
+	st->req()[2 * slot] = k;
+	st->req()[2 * slot + 1] = ef;
+	const uint32_t seq = ++st->seq[slot];
+	store_rel(st->post() + slot, seq);
+	const uint32_t* done = st->done() + slot;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (uint32_t it = 0;; ++it) {
+		if (load_acq(done) == seq) break;
+		if ((it & 63u) == 0u) {
+			if (load_acq(st->leaving()) == st->launched.load(std::memory_order_acquire) && !load_acq(st->stop())) {   // no generation alive or queued
+				std::lock_guard<std::mutex> lk(st->mtx);
+				DeviceGuardLite dg(st->device);
+				if (int rc = server_launch(h, st); rc) return rc;
+			}
+			if ((it & 0xFFFFu) == 0u && it) {
+				const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+				if (waited > 0.02) {   // far beyond a search: did the generation end without saying so (its wall-clock fallback)?
+					std::lock_guard<std::mutex> lk(st->mtx);
+					if (load_acq(st->leaving()) != st->launched.load() && hipStreamQuery(st->stream) == hipSuccess) store_rel(st->leaving(), st->launched.load());
+				}
+				if (waited > 5.0) {
+					st->broken.store(true);
+					set_error("hnsw server: no answer within 5 s");
+					return RXGPU_ERR_DEVICE;
+				}
+			}
+		}
+		// a search takes some hundred microseconds: a short spin for the answer that is nearly there, then the core goes to whoever can use
+		// it between looks (more planner threads than cores: 64 spinning threads on 16 cores held each other's answers up)
+		if (it < 256u) {
+			_mm_pause();
+		} else {
+			sched_yield();
+		}
+	}
+	const uint32_t count = *reinterpret_cast<const volatile uint32_t*>(st->host + st->o_count + size_t(slot) * 4);
+	if (count == kHnswTie || count == kHnswOverflow || count > k) return 0;
+	std::memcpy(out_dist, st->host + st->o_dist + size_t(slot) * kServerKcap * 4, size_t(count) * 4);
+	std::memcpy(out_row, st->host + st->o_row + size_t(slot) * kServerKcap * 4, size_t(count) * 4);
+	*out_count = count;
+	st->served.fetch_add(1, std::memory_order_relaxed);
+	return 1;
+}
+
+}  // namespace rxgpu

@@ -83,6 +83,10 @@ struct HnswParams;
 void launch_hnsw_search(int metric, const HnswParams& p, uint32_t blocks, bool global_cand, hipStream_t s);
 struct HnswHelper;
 void launch_hnsw_helper(int metric, const HnswParams& p, const HnswHelper& hq, uint32_t groups, hipStream_t s);
+struct HnswServer;
+// the resident search kernel (one workgroup per mailbox slot); false: this (metric, dim, list size, deleted nodes) has no resident form
+bool launch_hnsw_server(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s);
+size_t hnsw_server_lds_bytes(const HnswParams& p);
 struct HnswPatch;
 void launch_hnsw_patch(const HnswPatch& p, uint32_t n_dirty, hipStream_t s);
 struct HnswStream;
@@ -451,6 +455,34 @@ int sharded_hnsw_search_range(struct ::rxgpu_index* h, const float* query, float
 							  uint64_t* out_total);
 }  // namespace rxgpu
 
+namespace rxgpu {
+// The resident HNSW search kernel of an index and its mailbox (rxgpu_hnsw_server.hip)
+struct HnswServerState;
+struct HnswServerConfig {
+	uint32_t slots = 128;      // RXGPU_HNSW_SERVER_SLOTS: workgroups = requests in flight
+	uint32_t idle_us = 2000;   // RXGPU_HNSW_SERVER_IDLE_US: the kernel leaves after so long without a request
+	uint32_t life_ms = 50;     // RXGPU_HNSW_SERVER_LIFE_MS: ... and after so long in any case (the next caller launches the next one)
+};
+// 1: served, 0: not served (the caller takes the launches), < 0: -(RXGPU error code is returned as is by the caller) — see the .hip
+int hnsw_server_search(struct ::rxgpu_index* h, const HnswServerConfig& cfg, const float* query, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
+					   uint32_t* out_count);
+void hnsw_server_quiesce(struct ::rxgpu_index* h);      // before the index changes: the resident kernel leaves, none is queued
+void hnsw_server_destroy(struct ::rxgpu_index* h);
+void hnsw_servers_pause_device(int device);             // before a device-wide wait: every index's resident kernel on that device leaves
+hipError_t device_wait_all(int device);                 // hipDeviceSynchronize behind hnsw_servers_pause_device
+void hnsw_server_counters(const struct ::rxgpu_index* h, uint64_t* served, uint64_t* generations);
+struct DeviceGuardLite {
+	int prev = -1;
+	explicit DeviceGuardLite(int dev) {
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		if (prev != dev) (void)hipSetDevice(dev);
+	}
+	~DeviceGuardLite() {
+		if (prev >= 0) (void)hipSetDevice(prev);
+	}
+};
+}  // namespace rxgpu
+
 struct rxgpu_index {
 	rxgpu::ShardSet* shard_set = nullptr;   // non-null: a row-range sharded index (rxgpu_sharded.hip); the fields below describe the whole
 	int metric = 0;
@@ -498,6 +530,8 @@ struct rxgpu_index {
 	uint32_t graph_entry = 0;
 	bool graph_attached = false;
 	unsigned long long* d_hnsw_stats = nullptr;
+	rxgpu::HnswServerState* hnsw_server = nullptr;   // the resident search kernel's mailbox (made at the first single query)
+	bool hnsw_server_failed = false;
 	std::atomic<uint64_t> hnsw_lds_reruns{0};   // searches whose candidate heap outgrew its first LDS area and were re-run with the largest one
 	std::atomic<uint64_t> hnsw_tie_reruns{0};   // queries the sorted-list search handed to the heap kernel (equal distances met)
 

@@ -492,6 +492,14 @@ struct GpuHnswMap::PendingQuery {
 
 void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* dist, uint32_t* row, uint32_t* count) const {
 	PendingQuery p{query, k, ef, dist, row, count, false, 0, {}};
+	{   // the index's resident search kernel first (rxgpu_hnsw_search_knn_posted): a store and a poll, side by side with every other thread's
+		int32_t served = 0;
+		if (rxgpu_hnsw_search_knn_posted(dev_, query, k, ef, dist, row, count, &served) != RXGPU_OK) throw std::runtime_error(std::string("SearchKnn: ") + rxgpu_last_error());
+		if (served) {
+			coPosted_.fetch_add(1, std::memory_order_relaxed);
+			return;
+		}
+	}
 	if (!coalesce_) {
 		p.rc = rxgpu_hnsw_search_knn(dev_, query, 1, k, ef, dist, row, count);
 		if (p.rc != RXGPU_OK) p.error = rxgpu_last_error();

@@ -105,6 +105,8 @@ public:
 	// one launch of the batched search kernel (a wavefront per query) instead of one single-wavefront launch each.
 	void EnableQueryCoalescing(bool on) noexcept { coalesce_ = on; }
 	size_t CoalescedBatches() const noexcept { return coBatches_; }
+	// one-shot searches answered through the index's resident search kernel (no launch, no batching: rxgpu_hnsw_search_knn_posted)
+	size_t PostedQueries() const noexcept { return coPosted_.load(); }
 	// device batches the coalescer keeps in flight at once (1 .. 64; default kMaxLeaders)
 	void SetCoalescerLanes(unsigned lanes) noexcept { coLanes_ = lanes < 1 ? 1 : (lanes > 64 ? 64 : lanes); }
 	// searches the device re-ran on its heap kernel because the sorted-list search met equal distances (rxgpu_hnsw_read_tie_reruns); resets
@@ -193,6 +195,7 @@ private:
 	unsigned coLanes_ = kMaxLeaders;
 	mutable unsigned coLeaders_ = 0;
 	mutable size_t coBatches_ = 0;
+	mutable std::atomic<size_t> coPosted_{0};
 	bool ownsDev_ = true;                 // false: a shard (the device index belongs to the sharded handle) or the Map over a device list itself
 	std::unique_ptr<ShardedState> sh_;    // non-null: the Map over a device list
 };

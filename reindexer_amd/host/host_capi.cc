@@ -474,6 +474,8 @@ long rxhost_hnsw_tie_reruns(void* h) {
 	guarded([&] { n = long(static_cast<const GpuHnswMap*>(h)->TieReruns()); });
 	return n;
 }
+// one-shot searches of this Map that the index's resident search kernel answered (GpuHnswMap::PostedQueries)
+long rxhost_hnsw_posted_queries(void* h) { return long(static_cast<const GpuHnswMap*>(h)->PostedQueries()); }
 long rxhost_hnsw_lds_reruns(void* h) {
 	long n = -1;
 	guarded([&] { n = long(static_cast<const GpuHnswMap*>(h)->LdsReruns()); });

@@ -524,6 +524,8 @@ class GpuHnswMap:
             L.rxhost_hnsw_search_range.argtypes = [_vp, _vp, _f, _sz, _vp, _vp, _sz]
             L.rxhost_hnsw_select.restype = _l
             L.rxhost_hnsw_select.argtypes = [_vp, _vp, _sz, _l, _sz, _i, _f, _i, _i, _vp, _vp, _sz]
+            L.rxhost_hnsw_posted_queries.restype = _l
+            L.rxhost_hnsw_posted_queries.argtypes = [_vp]
             L.rxhost_hnsw_tie_reruns.restype = _l
             L.rxhost_hnsw_tie_reruns.argtypes = [_vp]
             L.rxhost_hnsw_lds_reruns.restype = _l
@@ -626,6 +628,10 @@ class GpuHnswMap:
         if n < 0:
             _raise()
         return n
+
+    def posted_queries(self) -> int:
+        """One-shot searches answered through the index's resident search kernel so far (rxgpu_hnsw_search_knn_posted)."""
+        return int(lib().rxhost_hnsw_posted_queries(self.h))
 
     def tie_reruns(self) -> int:
         """Searches re-run on the heap kernel since the last call (the sorted-list search met equal distances)."""

@@ -1,0 +1,224 @@
+"""-m gpu: the RESIDENT HNSW search kernel (hnsw_server.hip / rxgpu_hnsw_server.hip): ONE query per call, the planner's concurrency model
+(hnsw_index.cc:159-288 -> hnswalg.h:1988-2012 from T threads, gtests/tests/unit/float_vector_index.cc:258-294).
+Bar: a query answered through the mailbox returns exactly what the launching path returns (same device code, itself pinned to the reference
+engine in test_gpu_hnsw.py) and what the restated engine returns — whatever the threads, the generations of the kernel and the mutations of
+the index in between."""
+import os
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from .conftest import make_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def pairs(dist, ids):
+    order = np.lexsort((ids, dist))
+    return bits(dist[order]), ids[order]
+
+
+class Env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        for k, v in self.kv.items():
+            os.environ[k] = str(v)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def build(oracle, metric, n, d, M=8, efc=100, seed=5, deleted=0):
+    from reindexer_amd import hostapi
+    rows = make_corpus(seed, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    m = hostapi.GpuHnswMap(metric, d, n, M=M, ef_construction=efc)
+    m.add(rows, labels)
+    if deleted:
+        for lab in labels[np.random.default_rng(seed).choice(n, deleted, replace=False)]:
+            m.mark_delete(lab)
+    g = m.export_graph(with_views=True)
+    return m, g, rows
+
+
+def queries_for(oracle, metric, d, count, seed=700):
+    q = make_corpus(seed, count, d)
+    if metric == 2:
+        q = np.stack([oracle.normalize_copy(x)[0] for x in q])
+    return q
+
+
+@pytest.mark.parametrize("metric,d,deleted", [(0, 128, 0), (1, 768, 0), (2, 768, 0), (2, 512, 0), (0, 128, 300), (2, 768, 200)])
+def test_posted_equals_launched_and_restated_engine(rxgpu, oracle, metric, d, deleted):
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    n = 6000 if d > 128 else 12000
+    m, g, rows = build(oracle, metric, n, d, deleted=deleted)
+    inv = oracle.l2_modules(rows) if metric == 2 else None
+    gg = dict(g)
+    gg["vectors"] = rows
+    q = queries_for(oracle, metric, d, 48)
+    with rxgpu.VectorIndex(metric, d, n) as ix:
+        ix.upload_rows(0, g["vectors"], g["inv_norms"] if metric == 2 else None)
+        ix.hnsw_attach_graph(g)
+        served = 0
+        for k, ef in ((10, 128 if not deleted else 96), (10, 10), (1, 0), (40, 64)):
+            for qi in range(q.shape[0]):
+                pd, pr, pc, ok = ix.hnsw_search_knn_posted(q[qi], k, ef)
+                with Env(RXGPU_HNSW_SERVER=0):
+                    ld, lr, lc = ix.hnsw_search_knn(q[qi][None, :], k, ef)
+                if ok:
+                    served += 1
+                    assert pc == int(lc[0]), (k, ef, qi)
+                    a, b = pairs(pd[:pc], pr[:pc]), pairs(ld[0, :pc], lr[0, :pc])
+                    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]), (k, ef, qi)
+                    if qi < 6:
+                        wd, wl = oracle_hnsw_search_knn(oracle, gg, q[qi], k, ef, inv)
+                        assert np.array_equal(np.sort(g["labels"][pr[:pc]]), np.sort(wl)), (k, ef, qi)
+                        assert np.array_equal(np.sort(bits(pd[:pc])), np.sort(bits(wd)))
+        got, gens = ix.hnsw_server_stats()
+        assert got == served and served >= 0.9 * 4 * q.shape[0], (got, served)   # (a search that met equal keys takes the launches)
+        assert gens >= 1
+        # what the mailbox does not take
+        _, _, _, ok = ix.hnsw_search_knn_posted(q[0], 10, 200)
+        assert not ok
+        with Env(RXGPU_HNSW_SERVER=0):
+            _, _, _, ok = ix.hnsw_search_knn_posted(q[0], 10, 64)
+        assert not ok
+    m.close()
+
+
+def test_generations_idle_exit_and_restart(rxgpu, oracle):
+    n, d = 8000, 128
+    m, g, rows = build(oracle, 0, n, d)
+    q = queries_for(oracle, 0, d, 8)
+    with Env(RXGPU_HNSW_SERVER_IDLE_US=300, RXGPU_HNSW_SERVER_LIFE_MS=5):
+        with rxgpu.VectorIndex(0, d, n) as ix:
+            ix.upload_rows(0, g["vectors"], None)
+            ix.hnsw_attach_graph(g)
+            want = [ix.hnsw_search_knn_posted(x, 10, 64) for x in q]
+            assert all(w[3] for w in want)
+            g0 = ix.hnsw_server_stats()[1]
+            for rnd in range(6):   # the kernel has left by itself each time: the next query launches the next generation
+                time.sleep(0.02)
+                for x, w in zip(q, want):
+                    pd, pr, pc, ok = ix.hnsw_search_knn_posted(x, 10, 64)
+                    assert ok and pc == w[2] and np.array_equal(pairs(pd, pr)[1], pairs(w[0], w[1])[1])
+            assert ix.hnsw_server_stats()[1] >= g0 + 6
+            # ... and a stream of queries longer than the lifetime crosses generations without a gap in the answers
+            t0 = time.perf_counter()
+            cnt = 0
+            while time.perf_counter() - t0 < 0.06:
+                pd, pr, pc, ok = ix.hnsw_search_knn_posted(q[cnt % 8], 10, 64)
+                w = want[cnt % 8]
+                assert pc == w[2] and np.array_equal(pairs(pd, pr)[1], pairs(w[0], w[1])[1])
+                cnt += 1
+            assert ix.hnsw_server_stats()[1] >= g0 + 8
+    m.close()
+
+
+@pytest.mark.parametrize("slots", [64, 3])
+def test_sixteen_threads_one_query_each(rxgpu, oracle, slots):
+    """The reference's runMultithreadQueries shape: T threads, one SearchKnn each at a time, over one index.  With 3 slots most calls find the
+    mailbox full and take a launch: same answers."""
+    n, d, T, per = 20000, 128, 16, 40
+    m, g, rows = build(oracle, 2, n, d, M=16, efc=200)
+    q = queries_for(oracle, 2, d, 64)
+    with Env(RXGPU_HNSW_SERVER_SLOTS=slots):
+        with rxgpu.VectorIndex(2, d, n) as ix:
+            ix.upload_rows(0, g["vectors"], g["inv_norms"])
+            ix.hnsw_attach_graph(g)
+            with Env(RXGPU_HNSW_SERVER=0):
+                want = [ix.hnsw_search_knn(x[None, :], 10, 128) for x in q]
+            errors = []
+
+            def worker(t):
+                try:
+                    for j in range(per):
+                        qi = (t * per + j) % q.shape[0]
+                        d_, r_, c_ = ix.hnsw_search_knn(q[qi][None, :], 10, 128)
+                        w = want[qi]
+                        if int(c_[0]) != int(w[2][0]) or not np.array_equal(pairs(d_[0], r_[0])[1], pairs(w[0][0], w[1][0])[1]) or \
+                                not np.array_equal(pairs(d_[0], r_[0])[0], pairs(w[0][0], w[1][0])[0]):
+                            errors.append((t, j))
+                except Exception as e:   # noqa: BLE001
+                    errors.append((t, repr(e)))
+
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            assert not errors, errors[:4]
+            served, _ = ix.hnsw_server_stats()
+            assert served > 0
+            if slots == 64:
+                assert served >= 0.9 * T * per
+    m.close()
+
+
+def test_map_mutations_between_posted_queries(rxgpu, oracle):
+    """Upserts, deletes and a resize between single queries through GpuHnswMap: every mutation makes the resident kernel leave before the
+    device arrays change, and the next query sees the new graph — equal to the restated engine over the Map's exported graph each time."""
+    from oracle.pyoracle import oracle_hnsw_search_knn
+    from reindexer_amd import hostapi
+    n, d = 6000, 128
+    rows = make_corpus(11, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    m = hostapi.GpuHnswMap(0, d, 3000, M=8, ef_construction=100)
+    q = queries_for(oracle, 0, d, 12)
+    at = 0
+    for step, upto in enumerate((1500, 3000, 4500, 6000)):
+        if upto > 3000 and step == 2:
+            m.resize(n)
+        m.add(rows[at:upto], labels[at:upto])
+        at = upto
+        if step == 3:
+            for lab in labels[100:160]:
+                m.mark_delete(lab)
+        g = m.export_graph()
+        g["vectors"] = rows[:upto]
+        for x in q:
+            gd, gl = m.search_knn(x, 10, 64)
+            wd, wl = oracle_hnsw_search_knn(oracle, g, x, 10, 64, None)
+            assert np.array_equal(gl, wl), step
+            assert np.array_equal(bits(gd), bits(wd))
+    assert m.posted_queries() >= 40   # the queries did go through the mailbox
+    m.close()
+
+
+def test_two_indexes_and_a_scan_beside_the_resident_kernels(rxgpu, oracle):
+    """Resident kernels of two indexes alive at once, a brute-force scan and a batch launch beside them: nothing waits for a kernel that
+    waits for the host."""
+    n, d = 8000, 128
+    ma, ga, rows_a = build(oracle, 0, n, d, seed=21)
+    mb, gb, rows_b = build(oracle, 1, n, d, seed=22)
+    q = queries_for(oracle, 0, d, 16)
+    with rxgpu.VectorIndex(0, d, n) as a, rxgpu.VectorIndex(1, d, n) as b:
+        a.upload_rows(0, ga["vectors"], None)
+        a.hnsw_attach_graph(ga)
+        b.upload_rows(0, gb["vectors"], None)
+        b.hnsw_attach_graph(gb)
+        t0 = time.perf_counter()
+        for x in q:
+            ra = a.hnsw_search_knn_posted(x, 10, 64)
+            rb = b.hnsw_search_knn_posted(x, 10, 64)
+            sd, sr, _ = a.search_knn(x, 11)             # a scan on an ordinary stream while both resident kernels are alive
+            bd, br, bc = b.hnsw_search_knn(q[:8], 10, 64)   # ... and a batch launch
+            assert ra[3] and rb[3]
+            assert set(ra[1][:ra[2]].tolist()) <= set(range(n)) and sr.shape[1] == 11 and int(bc[0]) == 10
+        assert time.perf_counter() - t0 < 5.0
+    ma.close()
+    mb.close()

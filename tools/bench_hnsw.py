@@ -250,9 +250,11 @@ def run(o) -> dict:
         for T in o.map_threads:
             T = T or ncpu
             m.search_knn_mt(queries, o.k, o.ef, T, 2, 10.0)   # warm-up: contexts and buffers of T concurrent callers
+            p0 = m.posted_queries()
             secs, done, batches = m.search_knn_mt(queries, o.k, o.ef, T, o.map_per_thread, 20.0)
-            out["gpu"]["map_threads"].append({"threads": T, "queries": done, "queries_per_sec": done / secs if secs else None,
-                                              "device_batches": batches, "avg_batch": done / batches if batches else None})
+            posted = m.posted_queries() - p0   # answered by the resident search kernel: no launch, no batch
+            out["gpu"]["map_threads"].append({"threads": T, "queries": done, "queries_per_sec": done / secs if secs else None, "posted": posted,
+                                              "device_batches": batches, "avg_batch": (done - posted) / batches if batches else None})
         sess = m.stream(queries[0], o.ef)   # a15: one streaming session, 10 batches of 10 (the planner's post-filter pattern)
         t0 = time.perf_counter()
         got = 0
