@@ -38,12 +38,17 @@ template <int kMetric, bool kGlobalCand, int NB, bool kLatency, bool kSq8 = fals
 __global__ __launch_bounds__(64, (kSorted == 2 && !kDel && !kLatency && !kSq8 && NB == 12) ? 5 : 1) void hnsw_search_kernel(HnswParams p) {
 	const uint32_t slot = blockIdx.x;
 	hnsw_search_one<kMetric, kGlobalCand, NB, kLatency, kSq8, kSorted, kDel>(p, slot, p.only ? p.only[slot] : slot);
+	if (p.helper_n) {   // a batch with helper workgroups: this search has ended, and what it queued for them is visible
+		__threadfence();
+		if (threadIdx.x == 0) atomicAdd(p.helper_n + 2, 1u);
+	}
 }
 
 // Helper workgroups of a batch: workgroup w serves entries w, w + G, ... of the overflow queue until the stop word is set (a 4-byte memset
 // behind the batch's last launch) and its next entry does not exist.  Every search runs on the heap kernel's code with the largest LDS heap
 // and the workgroup's own bitset (zeroed here); a search that overflows again keeps kHnswOverflow for the host's global-heap tiers.  A
-// wall-clock limit ends a helper that was never told to stop.
+// wall-clock limit remains as the last resort; the end of the batch itself is a count of finished searches in device memory (HnswHelper::
+// finished), which needs no memset or signal to get through a queue the helper may share.
 template <int kMetric, int NB, bool kSq8>
 __global__ __launch_bounds__(64) void hnsw_helper_kernel(HnswParams p, HnswHelper hq) {
 	const uint32_t w = blockIdx.x, G = gridDim.x;
@@ -55,7 +60,8 @@ __global__ __launch_bounds__(64) void hnsw_helper_kernel(HnswParams p, HnswHelpe
 		for (;;) {
 			id1 = __hip_atomic_load(&hq.ids[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 			if (id1) break;
-			if (__hip_atomic_load(hq.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) {   // the batch is over: the queue is final
+			if (__hip_atomic_load(hq.stop, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) ||
+				__hip_atomic_load(hq.finished, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= hq.expected) {   // the batch is over: the queue is final
 				const uint32_t n = __hip_atomic_load(hq.n, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 				if (s >= n) return;
 				id1 = __hip_atomic_load(&hq.ids[s], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -87,6 +93,14 @@ static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hip
 				pt.vis_lds = 1;
 				pt.vis_hash_log2 = p.vis_lds_log2;
 				lds_t += size_t(4) << p.vis_lds_log2;
+			}
+			if (!p.spec && p.maxM0 < 64u && lds_t + kHnswNblBytes <= (60u << 10)) {   // the link blocks of a hop's rows come along with the rows (hnsw_team_serve)
+				pt.nbl_off = uint32_t(lds_t);
+				lds_t += kHnswNblBytes;
+			}
+			if (p.spec && !kDel && p.maxM0 < 64u && lds_t + kHnswSpecBytes <= (60u << 10)) {   // distances of the next candidate's neighbours ride along (hnsw_search_core.hip.h)
+				pt.spec_off = uint32_t(lds_t);
+				lds_t += kHnswSpecBytes;
 			}
 			switch (metric) {
 				case kL2: hipLaunchKernelGGL((hnsw_team_kernel<kL2, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt); break;

@@ -654,7 +654,8 @@ __device__ __forceinline__ void hnsw_enqueue_overflow(const HnswParams& p, uint3
 struct HnswTeamBox {
 	const uint32_t* ids;
 	float* dists;
-	int cnt;   // < 0: the search is over
+	int cnt;     // < 0: the search is over
+	int links;   // the ids are a hop's fresh neighbours: the other wavefronts also fetch their link blocks into the team's block area (p.nbl_off)
 };
 template <int kTeam>
 __device__ __forceinline__ void hn_sync() {
@@ -695,6 +696,24 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 	__shared__ uint32_t s_pre[64];   // sorted-list search: the link block of the candidate next in line, fetched one hop ahead by LDS-DMA
 
 	const int lane = threadIdx.x & 63;   // (a team's driver is wavefront 0)
+	// the speculative team search (its hop below) keeps, at p.spec_off of the dynamic LDS: a direct-mapped table of distances computed ahead of
+	// time (keys = node + 1, values), the link blocks of the two nearest open candidates, and the id / distance / destination arrays of a trip
+	constexpr bool kSpecOk = kTeam > 1 && kSorted > 0 && !kDel && NB > 0 && !kSq8 && !kGlobalCand;
+	constexpr uint32_t kSpecLog2 = kHnswSpecLog2;
+	constexpr int kSpecRows = 8 * kTeam;   // rows of ONE distance trip of the team (two row sets of four rows a wavefront)
+	uint32_t* spec_key = reinterpret_cast<uint32_t*>(hnsw_lds + p.spec_off);
+	float* spec_val = reinterpret_cast<float*>(spec_key + (1u << kSpecLog2));
+	uint32_t* spec_pre = spec_key + (2u << kSpecLog2);
+	uint32_t* spec_id = spec_pre + 128;
+	float* spec_d = reinterpret_cast<float*>(spec_id + 64);
+	uint32_t* spec_dst = spec_id + 128;
+	bool use_spec = false;
+	if constexpr (kSpecOk) {
+		use_spec = p.spec_off != 0u && p.maxM0 < 64u;
+		if (use_spec) {
+			for (uint32_t i = lane; i < (1u << kSpecLog2); i += 64) spec_key[i] = 0u;
+		}
+	}
 	const float* q = p.queries + size_t(qi) * p.dim;
 	uint32_t* visited = p.visited + size_t(slot) * p.visited_words;
 	uint2* cand = kGlobalCand ? p.gcand + size_t(slot) * p.gcand_cap : lcand;
@@ -725,6 +744,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 		for (int i = lane; i < NB * 16; i += 64) q_s[i] = qp[i];
 		HN_SYNC();
 	}
+	int team_links = 0;   // (team searches) 1 while the batches are a hop's fresh neighbours, see HnswTeamBox::links
 	auto distances = [&](const uint32_t* ids, int cnt, float* dists) {
 		if constexpr (kSq8 && NB > 0) {
 			batch_distances_sq8_fixed<kMetric, NB>(p, sq_q, sq_qq, p.qcorr[qi], p.qnorm[qi], ids, cnt, dists, lane);
@@ -734,6 +754,7 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 			box->ids = ids;
 			box->dists = dists;
 			box->cnt = cnt;
+			box->links = team_links;
 			__syncthreads();   // the whole team: the batch is posted (and everything the driver wrote to LDS before it is visible)
 			int b0, n0;
 			team_slice<kTeam>(cnt, 0, b0, n0);
@@ -812,6 +833,8 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 		uint32_t pre_node = 0xFFFFFFFFu;
 		uint32_t pre_tag0 = 0xFFFFFFFFu, pre_tag1 = 0xFFFFFFFFu;   // speculative team search: the nodes whose link blocks sit in spec_pre[0] / [1]
 		unsigned long long spec_trips = 0;
+		int nbl_rows = 0;                   // team searches: rows of the last hop whose link blocks sit in the team's block area
+		unsigned long long nbl_hits = 0;
 #ifdef RXGPU_HNSW_PHASES
 		unsigned long long ph_a = 0, ph_b = 0, ph_c = 0, ph_t = __builtin_readcyclecounter(), ph_start = ph_t;
 #define HN_PHASE(acc)                                              \
@@ -845,6 +868,10 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 			if constexpr (kSpecOk) spec_hop = use_spec;
 			if (spec_hop) {
 				if constexpr (kSpecOk) {
+					// (RXGPU_HNSW_SPEC=1.  MEASURED, 1M x 768, ef = 128, one query at a time: 0.547 ms against 0.452 ms without it — only 23 % of the
+					// hops run without a trip (the candidate expanded next is more often one this very hop inserted than the one in line before
+					// it) and the bookkeeping below costs ~0.7 us a hop; profiles/rd6sp_single_1m.json.  Exact — fuzz and parity tests run it —
+					// but off by default.)
 					// ---- a hop of the SPECULATIVE team search.  The traversal is the reference's — pops, marks and insertions in its order, every
 					// distance the same bits — but a distance need not be computed in the hop that uses it: d(query, row) does not change during a
 					// search.  Each distance trip of the team (32 rows, four wavefronts) carries, next to the rows this hop must have, the unmarked
@@ -931,17 +958,19 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 					if (total > 0) {
 						distances(spec_id, total, spec_d);
 						HN_SYNC();
-						if (lane < total) {
-							const float dv = spec_d[lane];
-							const uint32_t dst = spec_dst[lane];
-							if (dst != 0xFFFFFFFFu) {
-								nb_d[dst] = dv;
-							} else {
-								const uint32_t id = spec_id[lane];
-								const uint32_t sl = (id * 2654435761u) >> (32u - kSpecLog2);
-								spec_val[sl] = dv;
-								spec_key[sl] = id + 1u;
-							}
+						{
+							const bool mine = lane < total;
+							const float dv = mine ? spec_d[lane] : 0.f;
+							const uint32_t dst = mine ? spec_dst[lane] : 0u;
+							const bool ahead = mine && dst == 0xFFFFFFFFu;
+							const uint32_t id = ahead ? spec_id[lane] : 0u;
+							const uint32_t sl = (id * 2654435761u) >> (32u - kSpecLog2);
+							if (mine && !ahead) nb_d[dst] = dv;
+							// two look-ahead rows of one trip may share a table slot: the key decides which of them the slot keeps, and only that
+							// lane writes the value (a key next to another row's value would be a wrong distance)
+							if (ahead) spec_key[sl] = id + 1u;
+							HN_SYNC();
+							if (ahead && spec_key[sl] == id + 1u) spec_val[sl] = dv;
 						}
 						spec_trips += 1;
 					}
@@ -952,9 +981,16 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 			} else {
 				const uint32_t* ll = p.links0 + size_t(node) * (1 + p.maxM0);
 				uint32_t first_word;
+				uint64_t came_along = 0ull;   // (team searches) the popped node was one of the last hop's rows: its block came with them
+				if constexpr (kTeam > 1) {
+					if (nbl_rows > 0 && node != pre_node) came_along = __ballot(lane < nbl_rows && nb_id[lane] == node);   // nb_id still holds the last hop's rows
+				}
 				if (node == pre_node) {   // uniform: the block was requested a hop ago and has landed (every load issued since has been waited for)
 					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 					first_word = s_pre[lane];
+				} else if (came_along) {
+					first_word = reinterpret_cast<const uint32_t*>(hnsw_lds + p.nbl_off)[64 * __builtin_ctzll(came_along) + lane];
+					nbl_hits += 1;
 				} else {
 					first_word = lane <= int(p.maxM0) ? ll[lane] : 0u;
 				}
@@ -983,7 +1019,12 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 				if constexpr (kDel) {   // the delete marks travel while the distances are computed
 					for (int j = lane; j < nfresh; j += 64) nb_del[j] = p.deleted[nb_id[j]];
 				}
+				if constexpr (kTeam > 1) {
+					team_links = (p.nbl_off != 0u && p.maxM0 < 64u) ? 1 : 0;
+					nbl_rows = (team_links && nfresh > 0) ? (nfresh < kHnswNblRows ? nfresh : kHnswNblRows) : 0;
+				}
 				distances(nb_id, nfresh, nb_d);
+				team_links = 0;
 				ndist += nfresh;
 				HN_SYNC();
 				HN_PHASE(ph_b);
@@ -1053,6 +1094,8 @@ __device__ __forceinline__ void hnsw_search_one(const HnswParams& p, const uint3
 				if (p.stats) {
 					atomicAdd(&p.stats[0], ndist);
 					atomicAdd(&p.stats[1], hops);
+					if (nbl_hits) atomicAdd(&p.stats[3], nbl_hits << 32);   // (high half: hops whose link block had come along with the previous hop's rows)
+					if (spec_trips) atomicAdd(&p.stats[3], spec_trips);   // distance trips of the speculative team search (< hops: the rest ran on distances computed ahead)
 				}
 			}
 			return;
@@ -1206,7 +1249,20 @@ __device__ __forceinline__ void hnsw_team_serve(const HnswParams& p, const HnswT
 		if (cnt < 0) return;
 		int b0, n0;
 		team_slice<kTeam>(cnt, wave, b0, n0);
+		// The candidate expanded next is, more often than not, one of the rows of THIS batch (a neighbour that turns out nearer than
+		// everything in line) — and the driver's one-hop-ahead prefetch knows only the line as it was.  So the link blocks of the batch's rows
+		// come along with the rows: these wavefronts have nothing else to issue, the blocks (33 words each) land in LDS with the distances,
+		// and the next hop finds its block there whichever row it pops.
+		if (box->links && p.nbl_off) {
+			uint32_t* nbl = reinterpret_cast<uint32_t*>(hnsw_lds + p.nbl_off);
+			const int rows = cnt < kHnswNblRows ? cnt : kHnswNblRows;
+			for (int j = wave - 1; j < rows; j += kTeam - 1) {
+				const uint32_t* src = p.links0 + size_t(box->ids[j]) * (1 + p.maxM0) + (lane <= int(p.maxM0) ? lane : int(p.maxM0));
+				__builtin_amdgcn_global_load_lds(src, (hnsw_lds_void*)(nbl + 64 * j), 4, 0, 0);
+			}
+		}
 		if (n0 > 0) batch_distances_fixed<kMetric, NB, true, true>(p, qreg, q_s, box->ids + b0, n0, box->dists + b0, lane);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a wavefront without rows of its own still has blocks in flight)
 		__syncthreads();
 	}
 }

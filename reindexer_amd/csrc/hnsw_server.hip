@@ -93,16 +93,32 @@ __global__ __launch_bounds__(64 * kTeam) void hnsw_server_kernel(HnswParams p, H
 
 // The resident kernel exists for the embedding sizes with a fixed-dimension distance batch and lists of two entries a lane (ef <= 128, with
 // deleted nodes <= 96); everything else keeps the launches.  p: ef_cap / lds_cand_cap as for a team launch, vis_lds_log2 = the hash set's size.
+// dynamic LDS of a server workgroup: heaps + query fragment + visited set, then (what fits under 60 KB) the link-block area and the look-ahead area
+static size_t server_layout(const HnswParams& p, uint32_t* nbl_off, uint32_t* spec_off) {
+	size_t at = (size_t(p.ef_cap) + p.lds_cand_cap) * 8 + size_t(p.dim / 64) * 256 + (size_t(4) << p.vis_lds_log2);
+	*nbl_off = *spec_off = 0u;
+	if (!p.spec && p.maxM0 < 64u && at + kHnswNblBytes <= (60u << 10)) {   // (the look-ahead experiment keeps link blocks of its own)
+		*nbl_off = uint32_t(at);
+		at += kHnswNblBytes;
+	}
+	if (p.spec && p.bare && p.maxM0 < 64u && at + kHnswSpecBytes <= (60u << 10)) {
+		*spec_off = uint32_t(at);
+		at += kHnswSpecBytes;
+	}
+	return at;
+}
 size_t hnsw_server_lds_bytes(const HnswParams& p) {
-	return (size_t(p.ef_cap) + p.lds_cand_cap) * 8 + size_t(p.dim / 64) * 256 + (size_t(4) << p.vis_lds_log2);
+	uint32_t a, b;
+	return server_layout(p, &a, &b);
 }
 template <int NB, bool kDel>
 static void launch_hnsw_server_nb(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {
-	const size_t lds = hnsw_server_lds_bytes(p);
+	HnswParams ps = p;
+	const size_t lds = server_layout(p, &ps.nbl_off, &ps.spec_off);
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_server_kernel<kL2, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, p, sv); break;
-		case kIP: hipLaunchKernelGGL((hnsw_server_kernel<kIP, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, p, sv); break;
-		default: hipLaunchKernelGGL((hnsw_server_kernel<kCos, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, p, sv); break;
+		case kL2: hipLaunchKernelGGL((hnsw_server_kernel<kL2, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
+		case kIP: hipLaunchKernelGGL((hnsw_server_kernel<kIP, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
+		default: hipLaunchKernelGGL((hnsw_server_kernel<kCos, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
 	}
 }
 bool launch_hnsw_server(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {

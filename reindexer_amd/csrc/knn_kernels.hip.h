@@ -121,6 +121,10 @@ constexpr int kHnswLdsCandEf = 1024;    // largest ef whose candidate heap is tr
 constexpr int kHnswCandLds = 2048;      // candidate-heap capacity in LDS
 constexpr int kHnswMaxNeighbors = 128;  // 2*M <= 128
 constexpr uint32_t kHnswOverflow = 0xFFFFFFFFu;
+constexpr uint32_t kHnswSpecLog2 = 11;   // speculative team search: 2048-entry direct-mapped table of distances computed ahead of time
+constexpr uint32_t kHnswSpecBytes = (2u << kHnswSpecLog2) * 4 + (128 + 3 * 64) * 4;   // table + two link blocks + the trip's id / distance / destination arrays
+constexpr int kHnswNblRows = 32;             // team searches: link blocks fetched along with a hop's rows (one 64-word slot each)
+constexpr uint32_t kHnswNblBytes = kHnswNblRows * 64 * 4;
 constexpr uint32_t kHnswTie = 0xFFFFFFFEu;        // sorted-list search met equal keys: re-run on the heap kernel
 constexpr int kHnswSortedMaxEf = 256;            // largest ef the sorted-list search holds in registers (4 entries a lane)
 constexpr int kHnswSortedMaxEfDel = 224;         // ... for a graph with deleted nodes: 32 entries of room for the deleted candidates in reach
@@ -152,6 +156,9 @@ struct HnswParams {
 	uint32_t vis_lds;
 	uint32_t prefetch_links;     // sorted-list search: fetch the link block of the candidate next in line one hop ahead (LDS-DMA)
 	uint32_t team, team_max;     // launches of up to team_max searches run `team` wavefronts per search (hnsw_team_kernel; team <= 1: off)
+	uint32_t nbl_off;            // team searches: byte offset of the link-block area (kHnswNblBytes) in the dynamic LDS, 0 = none (set by the launcher)
+	uint32_t spec_off;           // team searches: byte offset of the speculation area (kHnswSpecBytes) in the dynamic LDS, 0 = no speculation (set by the launcher)
+	uint32_t spec;               // what the caller allows (RXGPU_HNSW_SPEC=0: off)
 	float* out_dist;          // [nq][k]
 	uint32_t* out_row;
 	uint32_t* out_count;      // [nq]; kHnswOverflow = candidate heap did not fit LDS (re-run in global mode), kHnswTie = re-run on the heaps
@@ -182,6 +189,8 @@ struct HnswHelper {
 	const uint32_t* n;        // entries appended so far
 	const uint32_t* ids;      // [cap] query index + 1, 0 = not written yet
 	const uint32_t* stop;     // set behind the batch's last launch
+	const uint32_t* finished; // searches of the batch that have ended (every search workgroup adds one on its way out) ...
+	uint32_t expected;        // ... of so many: finished == expected ends the batch for the helpers without anything having to get through a queue
 	uint32_t cap;
 	unsigned long long ticks_limit;   // wall_clock64 ticks (100 MHz) after which a helper gives up
 };

@@ -1841,6 +1841,7 @@ struct HnswKnobs {
 	int team = -1;                       // RXGPU_HNSW_TEAM: wavefronts per search of a small launch (1 = off)
 	int team_max = -1;                   // RXGPU_HNSW_TEAM_MAX: searches per launch up to which the team form is used
 	int zero_copy = -1;                  // RXGPU_HNSW_ZERO_COPY = 0: small calls copy their queries / results like large ones
+	int spec = -1;                       // RXGPU_HNSW_SPEC = 1: team searches also evaluate the next candidate's neighbours in the hop's distance trip (an experiment, off by default)
 	int server = -1;                     // RXGPU_HNSW_SERVER = 0: single queries take a launch each (no resident kernel)
 	int server_slots = -1, server_idle_us = -1, server_life_ms = -1;   // RXGPU_HNSW_SERVER_SLOTS / _IDLE_US / _LIFE_MS
 	bool names_a_kernel = false;         // a hook that picks a kernel form is set: the resident kernel (one form) stands aside
@@ -1870,12 +1871,13 @@ static HnswKnobs read_hnsw_knobs() {
 		else if (is("TEAM")) k.team = atoi(val);
 		else if (is("TEAM_MAX")) k.team_max = atoi(val);
 		else if (is("ZERO_COPY")) k.zero_copy = atoi(val);
+		else if (is("SPEC")) k.spec = atoi(val);
 		else if (is("SERVER")) k.server = atoi(val);
 		else if (is("SERVER_SLOTS")) k.server_slots = atoi(val);
 		else if (is("SERVER_IDLE_US")) k.server_idle_us = atoi(val);
 		else if (is("SERVER_LIFE_MS")) k.server_life_ms = atoi(val);
 		else continue;
-		if (!is("SERVER") && !is("SERVER_SLOTS") && !is("SERVER_IDLE_US") && !is("SERVER_LIFE_MS") && !is("SPLIT_UPLOAD") && !is("HELPER")) k.names_a_kernel = true;
+		if (!is("SERVER") && !is("SERVER_SLOTS") && !is("SERVER_IDLE_US") && !is("SERVER_LIFE_MS") && !is("SPLIT_UPLOAD") && !is("HELPER") && !is("SPEC")) k.names_a_kernel = true;
 	}
 	return k;
 }
@@ -1889,6 +1891,7 @@ static int hnsw_try_server(rxgpu_index* h, const HnswKnobs& knobs, const float* 
 	if (knobs.server_slots > 0) cfg.slots = uint32_t(knobs.server_slots);
 	if (knobs.server_idle_us > 0) cfg.idle_us = uint32_t(knobs.server_idle_us);
 	if (knobs.server_life_ms > 0) cfg.life_ms = uint32_t(knobs.server_life_ms);
+	cfg.spec = knobs.spec > 0;
 	return rxgpu::hnsw_server_search(h, cfg, query, k, ef, out_dist, out_row, out_count);
 }
 
@@ -1920,16 +1923,20 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
 	RX_CHECK(queries, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
 	if (h->shard_set) {   // SURVEY 8(e) "HNSW": a graph per shard, the per-shard results meet in the same all-gather + merge as brute force
 		RX_CHECK(out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn: null argument");
-		return rxgpu::sharded_hnsw_search_knn(h, queries, nq, k, ef, out_dist, out_row, out_count);
+		return rxgpu::sharded_hnsw_search_knn(h, queries, nullptr, nullptr, nq, k, ef, out_dist, out_row, out_count);
 	}
 	return hnsw_search_impl(h, queries, nullptr, nullptr, nq, k, ef, out_dist, out_row, out_count);
 }
 
 extern "C++" {
 namespace rxgpu {
-int hnsw_search_to_sink(rxgpu_index* shard, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, const HnswSink& sink) {
+int hnsw_search_to_sink(rxgpu_index* shard, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef, const HnswSink& sink) {
 	std::vector<uint32_t> counts(nq);
-	return hnsw_search_impl(shard, queries, nullptr, nullptr, nq, k, ef, nullptr, nullptr, counts.data(), &sink);
+	if (qcorr && !(shard->d_codes && shard->sq8_n == shard->count)) {
+		set_error("rxgpu_hnsw_search_knn_sq8: SQ8 codes are not attached / out of date on a shard");
+		return RXGPU_ERR_LOGIC;
+	}
+	return hnsw_search_impl(shard, queries, qcorr, qnorm, nq, k, ef, nullptr, nullptr, counts.data(), &sink);
 }
 }  // namespace rxgpu
 }  // extern "C++"
@@ -1938,6 +1945,14 @@ int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const 
 							  uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
 	RX_CHECK(query_codes && query_corr && query_norm_coef, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn_sq8: null argument");
+	if (h->shard_set) {   // every shard searches the code table attached to ITS handle (rxgpu_hnsw_attach_sq8 on rxgpu_index_shard(h, s)); same exchange
+		RX_CHECK(out_dist && out_row && out_count, RXGPU_ERR_PARAMS, "rxgpu_hnsw_search_knn_sq8: null argument");
+		for (uint32_t s = 0; s < rxgpu_index_shard_count(h); ++s) {
+			const rxgpu_index* sh = rxgpu_index_shard(h, s);
+			RX_CHECK(sh->count == 0 || (sh->d_codes && sh->sq8_n == sh->count), RXGPU_ERR_LOGIC, "rxgpu_hnsw_search_knn_sq8: SQ8 codes are not attached / out of date on a shard");
+		}
+		return rxgpu::sharded_hnsw_search_knn(h, query_codes, query_corr, query_norm_coef, nq, k, ef, out_dist, out_row, out_count);
+	}
 	RX_CHECK(h->count == 0 || (h->d_codes && h->sq8_n == h->count), RXGPU_ERR_LOGIC,
 			 "rxgpu_hnsw_search_knn_sq8: SQ8 codes are not attached / out of date");
 	return hnsw_search_impl(h, query_codes, query_corr, query_norm_coef, nq, k, ef, out_dist, out_row, out_count);
@@ -2168,6 +2183,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// how many searches per launch)
 	p.team = knobs.team >= 0 ? uint32_t(knobs.team) : 4u;
 	p.team_max = knobs.team_max >= 0 ? uint32_t(knobs.team_max) : 256u;
+	p.spec = knobs.spec > 0 ? 1u : 0u;   // off by default: measured slower at 1M x 768 (profiles/rd6sp_single.json), see hnsw_search_core.hip.h
 	p.out_dist = zero_copy ? reinterpret_cast<float*>(zc_dev + st_dist) : static_cast<float*>(c->d_out_dist.ptr);
 	p.out_row = zero_copy ? reinterpret_cast<uint32_t*>(zc_dev + st_row) : static_cast<uint32_t*>(c->d_out_row.ptr);
 	p.out_count = zero_copy ? reinterpret_cast<uint32_t*>(zc_dev + st_count) : static_cast<uint32_t*>(c->d_out_count.ptr);
@@ -2234,7 +2250,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			helper_lease.held = helpers_in_flight.compare_exchange_strong(expected, true, std::memory_order_acq_rel);
 		}
 		const bool use_helper = helper_lease.held;
-		uint32_t* hq_words = nullptr;   // [0] entries appended, [1] stop, [16 ..] ids
+		uint32_t* hq_words = nullptr;   // [0] entries appended, [1] stop, [2] searches of the batch that have ended, [16 ..] ids
 		uint32_t helper_n = 0;
 		if (use_helper) {
 			const uint64_t words4 = (words + 3) & ~uint64_t(3);
@@ -2261,7 +2277,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 			ph.vis_lds_log2 = 0;
 			ph.lds_cand_cap = uint32_t(rxgpu::kHnswCandLds);
 			ph.sorted = 0;
-			rxgpu::HnswHelper hq{hq_words, hq_words + 16, hq_words + 1, kHelperCap, 300000000ull};   // gives up after 3 s
+			rxgpu::HnswHelper hq{hq_words, hq_words + 16, hq_words + 1, hq_words + 2, nq, kHelperCap, 100000000ull};   // (last resort: gives up after 1 s)
 			rxgpu::launch_hnsw_helper(h->metric, ph, hq, kHelperGroups, c->aux_stream);
 			RX_HIP(hipGetLastError());
 			return RXGPU_OK;
@@ -2771,12 +2787,13 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 	}
 	if (!h->d_hnsw_stats) return RXGPU_OK;
 	DeviceGuard dg(h->device);
-	unsigned long long v[2] = {0, 0};
+	unsigned long long v[4] = {0, 0, 0, 0};   // evals, hops, in-kernel restarts, distance trips of the speculative team searches
 	RX_HIP(rxgpu::device_wait_all(h->device));
 	RX_HIP(hipMemcpy(v, h->d_hnsw_stats, sizeof(v), hipMemcpyDeviceToHost));
 	RX_HIP(hipMemset(h->d_hnsw_stats, 0, sizeof(v)));
 	*distance_evals = v[0];
 	*hops = v[1];
+	if (std::getenv("RXGPU_HNSW_TRIPS")) std::fprintf(stderr, "[rxgpu hnsw] hops %llu evals %llu restarts %llu speculative-search distance trips %llu\n", v[1], v[0], v[2], v[3]);
 	if (std::getenv("RXGPU_HNSW_PHASES")) {   // a library built with -DRXGPU_HNSW_PHASES: shader cycles of the sorted-list search by phase
 		unsigned long long ph[4] = {0, 0, 0, 0};
 		RX_HIP(hipMemcpy(ph, h->d_hnsw_stats + 4, sizeof(ph), hipMemcpyDeviceToHost));
@@ -2784,6 +2801,19 @@ int rxgpu_hnsw_read_stats(rxgpu_index* h, uint64_t* distance_evals, uint64_t* ho
 		std::fprintf(stderr, "[rxgpu hnsw phases] hops %llu evals %llu | cycles: pop+links+visited %llu  distances %llu  inserts %llu  layer0 total %llu\n", v[1], v[0], ph[0],
 					 ph[1], ph[2], ph[3]);
 	}
+	return RXGPU_OK;
+}
+
+int rxgpu_hnsw_read_stats4(rxgpu_index* h, uint64_t* out4) {
+	RX_CHECK(h && out4, RXGPU_ERR_PARAMS, "rxgpu_hnsw_read_stats4: null argument");
+	out4[0] = out4[1] = out4[2] = out4[3] = 0;
+	if (h->shard_set || !h->d_hnsw_stats) return RXGPU_OK;
+	DeviceGuard dg(h->device);
+	unsigned long long v[4] = {0, 0, 0, 0};
+	RX_HIP(rxgpu::device_wait_all(h->device));
+	RX_HIP(hipMemcpy(v, h->d_hnsw_stats, sizeof(v), hipMemcpyDeviceToHost));
+	RX_HIP(hipMemset(h->d_hnsw_stats, 0, sizeof(v)));
+	for (int i = 0; i < 4; ++i) out4[i] = v[i];
 	return RXGPU_OK;
 }
 

@@ -448,9 +448,10 @@ struct HnswSink {
 	uint32_t* d_row;    // [nq][kk] shard-local rows, kInvalidRow past a query's count
 	uint32_t kk;
 };
-int hnsw_search_to_sink(struct ::rxgpu_index* shard, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, const HnswSink& sink);
-int sharded_hnsw_search_knn(struct ::rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
-							uint32_t* out_count);
+// queries: float rows, or (qcorr != null) SQ8 codes with their corrective offsets and normCoefs — the shard then searches its code table
+int hnsw_search_to_sink(struct ::rxgpu_index* shard, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef, const HnswSink& sink);
+int sharded_hnsw_search_knn(struct ::rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist,
+							uint32_t* out_row, uint32_t* out_count);
 int sharded_hnsw_search_range(struct ::rxgpu_index* h, const float* query, float radius, uint32_t ef, float* out_dist, uint32_t* out_row, uint64_t cap,
 							  uint64_t* out_total);
 }  // namespace rxgpu
@@ -461,6 +462,7 @@ struct HnswServerState;
 struct HnswServerConfig {
 	uint32_t slots = 128;      // RXGPU_HNSW_SERVER_SLOTS: workgroups = requests in flight
 	uint32_t idle_us = 2000;   // RXGPU_HNSW_SERVER_IDLE_US: the kernel leaves after so long without a request
+	bool spec = false;         // RXGPU_HNSW_SPEC=1: look-ahead distance batches (read when the index's mailbox is made; off by default)
 	uint32_t life_ms = 50;     // RXGPU_HNSW_SERVER_LIFE_MS: ... and after so long in any case (the next caller launches the next one)
 };
 // 1: served, 0: not served (the caller takes the launches), < 0: -(RXGPU error code is returned as is by the caller) — see the .hip

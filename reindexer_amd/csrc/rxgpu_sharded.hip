@@ -439,7 +439,7 @@ int exchange_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const flo
 // HNSW SearchKnn over every shard's own graph (SURVEY 8e "HNSW"): the searches run concurrently on the shards' worker threads — each is the
 // single-device search with its re-run tiers, driven from the host by the counts alone — and leave their lists in HBM, packed into the
 // shard's slot of the send buffer (HnswSink); then the same all-gather + merge as brute force (the lists are unordered sets: sorted = false).
-int exchange_hnsw_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist,
+int exchange_hnsw_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist,
 							 uint32_t* out_row, uint32_t* out_count) {
 	(void)h;
 	ShardExchange* x = ss->xch;
@@ -457,7 +457,7 @@ int exchange_hnsw_search_knn(rxgpu_index* h, ShardSet* ss, ExchangeLane* l, cons
 	const int rc = for_each_shard(ss, [&](size_t s) -> int {
 		if (rxgpu_index_count(ss->shards[s]) == 0) return RXGPU_OK;
 		uint32_t* dst = static_cast<uint32_t*>(l->d_local[x->shard_rank[s]].ptr) + list_words * x->shard_slot[s];
-		return hnsw_search_to_sink(ss->shards[s], queries, nq, k, ef, HnswSink{dst, dst + size_t(nq) * k, k});
+		return hnsw_search_to_sink(ss->shards[s], queries, qcorr, qnorm, nq, k, ef, HnswSink{dst, dst + size_t(nq) * k, k});
 	});
 	if (rc != RXGPU_OK) return rc;
 	return exchange_gather_merge(ss, l, nq, k, false, out_dist, out_row, out_count);
@@ -680,7 +680,8 @@ int sharded_search_range_impl(rxgpu_index* h, const float* query, float radius, 
 // rxgpu_hnsw_search_knn on a sharded handle: every shard searches its own graph (attached through rxgpu_index_shard(h, s)); the merged list
 // of a query = the k best of the union of the per-shard results under (dist, global row), global row = s * shard_rows + local row.
 // out_count[q] <= k entries, sorted (a superset of the single-device contract, which leaves them unordered).
-int sharded_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count) {
+int sharded_hnsw_search_knn(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
+							uint32_t* out_count) {
 	ShardSet* ss = h->shard_set;
 	const size_t ns = ss->shards.size();
 	if (nq == 0) return RXGPU_OK;
@@ -702,7 +703,7 @@ int sharded_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, u
 		if (!lane) {
 			if (int rc = new_lane(x, &lane); rc) return rc;
 		}
-		const int rc = exchange_hnsw_search_knn(h, ss, lane, queries, nq, k, ef, out_dist, out_row, out_count);
+		const int rc = exchange_hnsw_search_knn(h, ss, lane, queries, qcorr, qnorm, nq, k, ef, out_dist, out_row, out_count);
 		give_lane(x, lane, rc);
 		return rc;
 	}
@@ -713,7 +714,10 @@ int sharded_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, u
 		sr[s].assign(size_t(nq) * k, 0u);
 		sc[s].assign(nq, 0u);
 		if (rxgpu_index_count(ss->shards[s]) == 0) return RXGPU_OK;
-		return rxgpu_hnsw_search_knn(ss->shards[s], queries, nq, k, ef, sd[s].data(), sr[s].data(), sc[s].data());
+		if (qcorr) {
+			return rxgpu_hnsw_search_knn_sq8(ss->shards[s], static_cast<const uint8_t*>(queries), qcorr, qnorm, nq, k, ef, sd[s].data(), sr[s].data(), sc[s].data());
+		}
+		return rxgpu_hnsw_search_knn(ss->shards[s], static_cast<const float*>(queries), nq, k, ef, sd[s].data(), sr[s].data(), sc[s].data());
 	});
 	if (rc != RXGPU_OK) return rc;
 	std::vector<std::pair<float, uint32_t>> all;

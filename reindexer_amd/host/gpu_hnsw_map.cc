@@ -452,8 +452,10 @@ void GpuHnswMap::patchCodes(const std::vector<tableint>& dirty, size_t n) const 
 }
 
 void GpuHnswMap::Quantize(float minQ, float maxQ) {
-	if (sh_) throw std::logic_error("GpuHnswMap: SQ8 is not available for a Map over a device list");
 	if (!(maxQ > minQ)) throw std::runtime_error("Quantize: empty quantisation range");
+	if (sh_) {   // ONE quantiser for the whole Map (the reference quantises the index, not its parts): every shard codes its rows with it
+		for (const auto& m : sh_->maps) m->Quantize(minQ, maxQ);
+	}
 	sq8_ = Sq8Params::FromRange(minQ, maxQ, graph_.Dim());
 	pendingSq8_.reset();
 	quantized_ = true;
@@ -462,9 +464,18 @@ void GpuHnswMap::Quantize(float minQ, float maxQ) {
 }
 
 void GpuHnswMap::Quantize(const Sq8QuantizationConfig& config) {
-	if (sh_) throw std::logic_error("GpuHnswMap: SQ8 is not available for a Map over a device list");
 	if (quantized_ || pendingSq8_) throw std::logic_error("Quantize: the Map is quantised already");
-	const Sq8Params p = Sq8SampleParams(graph_.Count(), graph_.Dim(), config, [this](uint32_t id) { return graph_.Vector(tableint(id)); });
+	Sq8Params p;
+	if (sh_) {   // the sample runs over the points of all shards, numbered shard after shard (what internal ids are to a single graph)
+		std::vector<size_t> first(sh_->maps.size() + 1, 0);
+		for (size_t i = 0; i < sh_->maps.size(); ++i) first[i + 1] = first[i] + sh_->maps[i]->graph_.Count();
+		p = Sq8SampleParams(first.back(), graph_.Dim(), config, [this, &first](uint32_t id) {
+			const size_t sh = size_t(std::upper_bound(first.begin(), first.end(), size_t(id)) - first.begin()) - 1;
+			return sh_->maps[sh]->graph_.Vector(tableint(id - first[sh]));
+		});
+	} else {
+		p = Sq8SampleParams(graph_.Count(), graph_.Dim(), config, [this](uint32_t id) { return graph_.Vector(tableint(id)); });
+	}
 	if (!(p.maxQ > p.minQ)) throw std::runtime_error("Quantize: empty quantisation range");
 	sq8Config_ = config;
 	pendingSq8_ = p;
@@ -474,6 +485,9 @@ void GpuHnswMap::SwitchMapOnQuantized() {
 	if (!pendingSq8_) return;   // Impl::get(): nothing pending, nothing to swap in
 	sq8_ = *pendingSq8_;
 	pendingSq8_.reset();
+	if (sh_) {
+		for (const auto& m : sh_->maps) m->Quantize(sq8_.minQ, sq8_.maxQ);
+	}
 	quantized_ = true;
 	codesDirty_ = true;
 	graphDirty_ = true;
@@ -591,7 +605,16 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 		std::vector<float> dist(k);
 		std::vector<uint32_t> row(k);
 		uint32_t count = 0;
-		if (rxgpu_hnsw_search_knn(sh_->parent, queryDataRaw, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) throwDevice("SearchKnn");
+		if (quantized_) {   // every shard over its code table, the query quantised once (one quantiser for the Map)
+			float normCoef = 1.f;
+			std::vector<uint8_t> qcodes;
+			const float qcorr = quantizeQuery(queryDataRaw, queryDataNorm, qcodes, normCoef);
+			if (rxgpu_hnsw_search_knn_sq8(sh_->parent, qcodes.data(), &qcorr, &normCoef, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) {
+				throwDevice("SearchKnn");
+			}
+		} else if (rxgpu_hnsw_search_knn(sh_->parent, queryDataRaw, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) {
+			throwDevice("SearchKnn");
+		}
 		ReserveQueue(result, count);
 		for (uint32_t i = 0; i < count; ++i) result.emplace(dist[i], shLabel(row[i]));
 		return result;
@@ -631,6 +654,19 @@ uint64_t GpuHnswMap::LdsReruns() const {
 	return n;
 }
 
+// A session over a device list: one session per shard (each walks ITS graph exactly as a single-device Map's does) and, per shard, what that
+// session has delivered and the merged stream has not emitted yet.
+struct StreamingSearchSession::Sharded {
+	struct Part {
+		StreamingSearchSession session;
+		std::vector<std::pair<float, labeltype>> held;   // ascending (dist, label)
+		bool exhausted = false;
+	};
+	std::vector<Part> parts;
+};
+
+StreamingSearchSession::StreamingSearchSession() = default;
+StreamingSearchSession::StreamingSearchSession(StreamingSearchSession&& o) noexcept : impl_(o.impl_), graph_(o.graph_), sharded_(std::move(o.sharded_)) { o.impl_ = nullptr; }
 StreamingSearchSession::~StreamingSearchSession() {
 	if (impl_) rxgpu_hnsw_stream_end(impl_);
 }
@@ -639,6 +675,7 @@ StreamingSearchSession& StreamingSearchSession::operator=(StreamingSearchSession
 		if (impl_) rxgpu_hnsw_stream_end(impl_);
 		impl_ = o.impl_;
 		graph_ = o.graph_;
+		sharded_ = std::move(o.sharded_);
 		o.impl_ = nullptr;
 	}
 	return *this;
@@ -646,7 +683,21 @@ StreamingSearchSession& StreamingSearchSession::operator=(StreamingSearchSession
 
 // hnswalg.h:1865-1891
 StreamingSearchSession GpuHnswMap::BeginStreamingSearch(const float* queryDataRaw, std::optional<float> queryDataNorm, StreamingSearchOptions opts) const {
-	if (sh_) throw std::logic_error("GpuHnswMap: streaming sessions walk ONE graph — not available for a Map over a device list");
+	if (sh_) {   // a session per shard; ContinueStreamingSearch merges what they deliver
+		StreamingSearchSession session;
+		session.graph_ = this;
+		session.sharded_ = std::make_unique<StreamingSearchSession::Sharded>();
+		for (const auto& m : sh_->maps) {
+			StreamingSearchSession::Sharded::Part part;
+			if (m->graph_.Count()) {
+				part.session = m->BeginStreamingSearch(queryDataRaw, queryDataNorm, opts);
+			} else {
+				part.exhausted = true;
+			}
+			session.sharded_->parts.push_back(std::move(part));
+		}
+		return session;
+	}
 	StreamingSearchSession session;
 	session.graph_ = this;
 	syncDevice();
@@ -666,6 +717,43 @@ StreamingSearchSession GpuHnswMap::BeginStreamingSearch(const float* queryDataRa
 // hnswalg.h:1947-1975
 StreamingBatch GpuHnswMap::ContinueStreamingSearch(StreamingSearchSession& session, size_t batchSize) const {
 	StreamingBatch batch;
+	if (sh_) {
+		// The next batchSize results of the UNION of the shards' streams: every shard's session is asked for as many results as the batch
+		// could take from it (batchSize minus what it delivered earlier and is still held), then the batchSize nearest of everything held
+		// leave, (dist, label) ascending — each shard's own stream is the reference's (hnswalg.h:1947-1975) over that shard's graph.
+		if (session.graph_ != this || !session.sharded_) {
+			batch.exhausted = true;
+			return batch;
+		}
+		if (batchSize == 0) return batch;
+		auto& parts = session.sharded_->parts;
+		for (size_t i = 0; i < parts.size(); ++i) {
+			auto& part = parts[i];
+			if (part.exhausted || part.held.size() >= batchSize) continue;
+			StreamingBatch got = sh_->maps[i]->ContinueStreamingSearch(part.session, batchSize - part.held.size());
+			part.exhausted = got.exhausted;
+			for (; !got.results.empty(); got.results.pop()) part.held.emplace_back(got.results.top().first, got.results.top().second);
+			std::sort(part.held.begin(), part.held.end());
+		}
+		std::vector<size_t> at(parts.size(), 0);
+		ReserveQueue(batch.results, batchSize);
+		for (size_t n = 0; n < batchSize; ++n) {
+			int best = -1;
+			for (size_t i = 0; i < parts.size(); ++i) {
+				if (at[i] < parts[i].held.size() && (best < 0 || parts[i].held[at[i]] < parts[size_t(best)].held[at[size_t(best)]])) best = int(i);
+			}
+			if (best < 0) break;
+			const auto& e = parts[size_t(best)].held[at[size_t(best)]++];
+			batch.results.emplace(e.first, e.second);
+		}
+		bool all = true;
+		for (size_t i = 0; i < parts.size(); ++i) {
+			parts[i].held.erase(parts[i].held.begin(), parts[i].held.begin() + long(at[i]));
+			all = all && parts[i].exhausted && parts[i].held.empty();
+		}
+		batch.exhausted = all;
+		return batch;
+	}
 	if (session.graph_ != this || !session.impl_) {
 		batch.exhausted = true;
 		return batch;
@@ -689,6 +777,14 @@ StreamingBatch GpuHnswMap::ContinueStreamingSearch(StreamingSearchSession& sessi
 // the expansion is one launch of hnsw_range_kernel whatever its depth; the result is a set, its order does not depend on the walk).
 SearchResultQueue GpuHnswMap::SearchRange(const float* queryDataRaw, std::optional<float> queryDataNorm, float radius, size_t ef) const {
 	SearchResultQueue result;
+	if (sh_ && quantized_) {   // the shards' own (quantised) Maps one after the other: the result is a set, the union of theirs
+		for (const auto& m : sh_->maps) {
+			if (!m->graph_.Count()) continue;
+			SearchResultQueue part = m->SearchRange(queryDataRaw, queryDataNorm, radius, ef);
+			for (; !part.empty(); part.pop()) result.emplace(part.top().first, part.top().second);
+		}
+		return result;
+	}
 	if (sh_) {   // every shard's ef-search + closure (rxgpu_hnsw_search_range on the sharded handle), hits concatenated
 		const size_t total = shCount(false);
 		if (total == 0) return result;

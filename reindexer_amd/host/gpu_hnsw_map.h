@@ -37,8 +37,8 @@ struct StreamingBatch {
 };
 class StreamingSearchSession {
 public:
-	StreamingSearchSession() = default;
-	StreamingSearchSession(StreamingSearchSession&& o) noexcept : impl_(o.impl_), graph_(o.graph_) { o.impl_ = nullptr; }
+	StreamingSearchSession();
+	StreamingSearchSession(StreamingSearchSession&& o) noexcept;
 	StreamingSearchSession& operator=(StreamingSearchSession&& o) noexcept;
 	StreamingSearchSession(const StreamingSearchSession&) = delete;
 	~StreamingSearchSession();
@@ -47,6 +47,8 @@ private:
 	friend class GpuHnswMap;
 	rxgpu_hnsw_stream* impl_ = nullptr;
 	const void* graph_ = nullptr;   // the Map that began the session (hnswalg.h:1953-1956: a foreign session is reported exhausted)
+	struct Sharded;                 // a Map over a device list: one session per shard + what each has delivered and the merge not emitted
+	std::unique_ptr<Sharded> sharded_;
 };
 
 // hnswlib::Synchronization (hnswlib.h): None = HierarchicalNSWST (AddPointConcurrent throws), OnInsertions = HierarchicalNSWMT (the index
@@ -64,8 +66,9 @@ public:
 	// shard is a complete single-device Map of its own: its graph is what the reference builds over those points in that order, mirrored
 	// on that shard's GPU (one rxgpu_index_create_sharded handle owns the N device indexes).  SearchKnn runs every shard's search at once and
 	// the per-shard results meet in the same ncclAllGather + (dist, global row) merge as brute force (rxgpu_hnsw_search_knn on the sharded
-	// handle): the k best of the union of the per-shard engine results, recall >= the single graph's at equal ef.  Not available over a device
-	// list: SQ8, streaming sessions, the ANN disk cache (they throw / report "not available"; a single-device Map has them all).
+	// handle): the k best of the union of the per-shard engine results, recall >= the single graph's at equal ef.  SQ8 (one quantiser for the Map, a
+	// code table per shard) and streaming sessions (a session per shard, merged batch by batch) work over a device list too; the ANN disk
+	// cache does not (it reports "not available").
 	GpuHnswMap(VectorMetric metric, size_t dim, size_t maxElements, size_t M, size_t efConstruction, std::vector<int> devices,
 			   Synchronization synchronization = Synchronization::None);
 	GpuHnswMap(const GpuHnswMap& other, size_t newCapacity);

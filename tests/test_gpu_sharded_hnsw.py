@@ -288,9 +288,74 @@ def test_what_a_device_list_does_not_offer_says_so(hostapi):
     m = hostapi.GpuHnswMap(1, 16, 500, devices=[0, 0])
     m.add(make_corpus(1, 100, 16), np.arange(100, dtype=np.uint64) << np.uint64(32))
     with pytest.raises(Exception, match="device list"):
-        m.quantize(-1.0, 1.0)
-    with pytest.raises(Exception, match="device list"):
-        m.stream(np.zeros(16, np.float32), 16)
-    with pytest.raises(Exception, match="device list"):
         m.save_index()
     m.close()
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_sq8_over_a_device_list_is_the_merge_of_the_quantised_shards(hostapi, oracle, metric):
+    """Quantize on a Map over a device list: ONE quantiser (sampled over all points, numbered shard after shard = arrival order, so its
+    parameters are the single-device Map's), a code table per shard; SearchKnn = the k best of the union of the quantised shards' results
+    (each shard is a quantised single-device Map, pinned to HierarchicalNSWImpl<uint8_t> in test_gpu_sq8.py)."""
+    n, d, k = 3000, 128, 10
+    rows = make_corpus(55 + metric, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    many = hostapi.GpuHnswMap(metric, d, n, M=8, ef_construction=80, devices=[0, 0, 0])
+    one = hostapi.GpuHnswMap(metric, d, n, M=8, ef_construction=80)
+    many.add(rows, labels)
+    one.add(rows, labels)
+    p_many, p_one = many.quantize_config(sample_size=2000), one.quantize_config(sample_size=2000)
+    assert np.array_equal(p_many, p_one) and many.is_quantized and all(many.shard(s).is_quantized for s in range(3))
+    for qi in range(12):
+        q = make_corpus(300 + qi, 1, d)[0]
+        norm = None
+        if metric == 2:
+            q, inv = oracle.normalize_copy(q)
+            norm = 1.0 / inv
+        for ef in (64, 16):
+            gd, gl = many.search_knn_norm(q, k, ef, norm)
+            parts = [many.shard(s).search_knn_norm(q, k, ef, norm) for s in range(3)]
+            ad, al = np.concatenate([x[0] for x in parts]), np.concatenate([x[1] for x in parts])
+            order = np.lexsort((al, ad))[:k]
+            assert np.array_equal(np.sort(gl), np.sort(al[order])), (qi, ef)
+            assert np.array_equal(np.sort(gd).view(np.uint32), np.sort(ad[order]).view(np.uint32))
+        rd, rl = many.search_range(q, float(np.sort(ad)[5]), 32, norm=norm)
+        want = [many.shard(s).search_range(q, float(np.sort(ad)[5]), 32, norm=norm) for s in range(3)]
+        assert np.array_equal(np.sort(rl), np.sort(np.concatenate([w[1] for w in want])))
+    many.close()
+    one.close()
+
+
+@pytest.mark.parametrize("quantised", [False, True])
+def test_streaming_session_over_a_device_list_merges_the_shard_sessions(hostapi, oracle, quantised):
+    """BeginStreamingSearch / ContinueStreamingSearch over a device list: a session per shard (the reference's stream over that shard's graph,
+    hnswalg.h:1865-1975), merged batch by batch: every shard is asked for as many results as the batch may take from it, the batch takes the
+    nearest of everything delivered so far under (dist, label).  Replayed here from the shards' own sessions with the same rule."""
+    n, d = 2400, 128
+    rows = make_corpus(91, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    many = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=80, devices=[0, 0, 0])
+    many.add(rows, labels)
+    if quantised:
+        many.quantize(float(np.quantile(rows, 0.005)), float(np.quantile(rows, 0.995)))
+    for qi, plan in enumerate(([5, 5, 5, 20], [1, 2, 50, 3], [64] * 4, [7] * 9)):
+        q = make_corpus(400 + qi, 1, d)[0]
+        sess = many.stream(q, 32)
+        parts = [dict(s=many.shard(i).stream(q, 32), held=[], done=False) for i in range(3)]
+        for b in plan:
+            gd, gl, gex = sess.next(b)
+            for part in parts:
+                if not part["done"] and len(part["held"]) < b:
+                    d_, l_, ex = part["s"].next(b - len(part["held"]))
+                    part["held"] = sorted(part["held"] + list(zip(d_.view(np.uint32).tolist(), d_.tolist(), l_.tolist())), key=lambda e: (e[1], e[2]))
+                    part["done"] = ex
+            pool = sorted([(e[1], e[2], e[0], pi) for pi, part in enumerate(parts) for e in part["held"]])[:b]
+            for e in pool:
+                parts[e[3]]["held"].remove((e[2], e[0], e[1]))
+            assert sorted(gl.tolist()) == sorted(e[1] for e in pool), (qi, b)
+            assert sorted(gd.view(np.uint32).tolist()) == sorted(e[2] for e in pool)
+            assert gex == all(part["done"] and not part["held"] for part in parts)
+        sess.close()
+        for part in parts:
+            part["s"].close()
+    many.close()

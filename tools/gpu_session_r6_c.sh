@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round 6: sharded-Map feature tests (SQ8 + streaming over a device list), server tests, then configs[2] at 10M with the Map legs, and the
+# single-query variants (mailbox / launch, look-ahead on / off) on a 10M graph.
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R" && mkdir -p gpurun_out && export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_hnsw_server.py tests/test_gpu_sharded_hnsw.py tests/test_gpu_sharded_map.py tests/test_gpu_sq8.py -x -q -m gpu > gpurun_out/rd6c_tests.log 2>&1; tail -4 gpurun_out/rd6c_tests.log
+timeout 1500 python tools/bench_hnsw.py --rows 10000000 --queries 4096 --cpu-queries 256 --recall-queries 1000 --no-sq8 --map-threads 1,16,64,256 --map-per-thread 64 \
+  --out gpurun_out/rd6c_hnsw_10m.json > gpurun_out/rd6c_hnsw_10m.log 2>&1
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/rd6c_hnsw_10m.json')); g = d['gpu']
+print('10M batch q/s', round(g['queries_per_sec']), 'kernel-only', round(g['queries_per_sec_kernel_only']), 'single ms', round(g.get('map_single_query_latency_ms', 0), 3),
+      'map', [(t['threads'], round(t['queries_per_sec']), t.get('posted')) for t in g.get('map_threads', [])],
+      'cpu 1/all', round(d['cpu_baseline']['value']), round(d['cpu_baseline']['all_cores']['value']), 'equal', d.get('equal_to_reference_frac'))
+PY
