@@ -268,10 +268,10 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
  * rxgpu_hnsw_search_knn, which tries the mailbox itself for nq == 1 and launches otherwise. */
 int rxgpu_hnsw_search_knn_posted(rxgpu_index* h, const float* query, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row, uint32_t* out_count,
 								 int32_t* served);
-/* The search kernels' own counters since the last read (reset by the call, like rxgpu_hnsw_read_stats): out4 = distance evaluations the
- * traversal used, hops, searches that started over on the reference's heaps inside the kernel, and — for the team searches that evaluate the
- * next candidate's neighbours ahead of time (RXGPU_HNSW_SPEC=1, an experiment that is off by default; hnsw_search_core.hip.h) — the distance trips they made: hops - trips hops ran
- * without a memory round trip for rows. */
+/* The search kernels' own counters since the last read (reset by the call, like rxgpu_hnsw_read_stats): out4[0] = distance evaluations the
+ * traversal used, [1] = hops, [2] = searches that started over on the reference's heaps inside the kernel, [3] = two 32-bit counts of the team
+ * searches (small launches and the resident kernel): high half = hops that found their link block in LDS because it had come along with the
+ * previous hop's rows; low half = distance trips of the look-ahead experiment (RXGPU_HNSW_SPEC=1, off by default; hnsw_search_core.hip.h). */
 int rxgpu_hnsw_read_stats4(rxgpu_index* h, uint64_t* out4);
 /* queries answered through the mailbox / resident kernels launched so far (instrumentation; 0 / 0 before the first such query) */
 int rxgpu_hnsw_server_stats(rxgpu_index* h, uint64_t* served, uint64_t* generations);

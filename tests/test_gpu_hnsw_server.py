@@ -246,7 +246,9 @@ def test_lookahead_distance_batches_change_nothing_but_the_trips(rxgpu, oracle, 
         assert c == int(b[2][0])
         x, y = pairs(a[0][0, :c], a[1][0, :c]), pairs(b[0][0, :c], b[1][0, :c])
         assert np.array_equal(x[1], y[1]) and np.array_equal(x[0], y[0])
-    (e1, h1, r1, t1), (e0, h0, r0, t0) = got[1][1], got[0][1]
+    (e1, h1, r1, w1), (e0, h0, r0, w0) = got[1][1], got[0][1]
+    t1, t0 = w1 & 0xFFFFFFFF, w0 & 0xFFFFFFFF    # low half: distance trips of the look-ahead search; high half: hops whose link block came along
     assert (e1, h1, r1) == (e0, h0, r0)          # the same traversal, counted
+    assert 0 < (w0 >> 32) < h0                   # the plain team search found a good part of its link blocks among the previous hop's rows
     assert t0 == 0 and 0 < t1 < h1, (t1, h1)   # ... on fewer round trips (how many fewer depends on the graph: 8 % here, 23 % at 1M rows)
     m.close()
