@@ -94,7 +94,7 @@ static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hip
 				pt.vis_hash_log2 = p.vis_lds_log2;
 				lds_t += size_t(4) << p.vis_lds_log2;
 			}
-			if (!p.spec && p.maxM0 < 64u && lds_t + kHnswNblBytes <= (60u << 10)) {   // the link blocks of a hop's rows come along with the rows (hnsw_team_serve)
+			if (p.nbl && !p.spec && p.maxM0 < 64u && lds_t + kHnswNblBytes <= (60u << 10)) {   // the link blocks of a hop's rows come along with the rows (hnsw_team_serve)
 				pt.nbl_off = uint32_t(lds_t);
 				lds_t += kHnswNblBytes;
 			}

@@ -1249,10 +1249,12 @@ __device__ __forceinline__ void hnsw_team_serve(const HnswParams& p, const HnswT
 		if (cnt < 0) return;
 		int b0, n0;
 		team_slice<kTeam>(cnt, wave, b0, n0);
-		// The candidate expanded next is, more often than not, one of the rows of THIS batch (a neighbour that turns out nearer than
-		// everything in line) — and the driver's one-hop-ahead prefetch knows only the line as it was.  So the link blocks of the batch's rows
-		// come along with the rows: these wavefronts have nothing else to issue, the blocks (33 words each) land in LDS with the distances,
-		// and the next hop finds its block there whichever row it pops.
+		// (RXGPU_HNSW_NBL=1, an experiment that is OFF by default.)  The candidate expanded next is often one of the rows of THIS batch (a
+		// neighbour that turns out nearer than everything in line), which the driver's one-hop-ahead prefetch cannot know.  So the link blocks of
+		// the batch's rows come along with the rows and the next hop finds its block in LDS whichever row it pops.  MEASURED: 15 % of the hops
+		// at 1M x 768 find their block this way, but the 16 extra 132-byte gathers a hop delay the row gathers behind them: one query 0.452 ->
+		// 0.517 ms at 1M, 0.67 -> 1.05 ms at 10M rows, where every gather starts with a page walk and the walks are what a hop waits for
+		// (profiles/rd6d_*_linkblocks.json).
 		if (box->links && p.nbl_off) {
 			uint32_t* nbl = reinterpret_cast<uint32_t*>(hnsw_lds + p.nbl_off);
 			const int rows = cnt < kHnswNblRows ? cnt : kHnswNblRows;

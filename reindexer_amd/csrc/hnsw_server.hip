@@ -91,13 +91,13 @@ __global__ __launch_bounds__(64 * kTeam) void hnsw_server_kernel(HnswParams p, H
 	}
 }
 
-// The resident kernel exists for the embedding sizes with a fixed-dimension distance batch and lists of two entries a lane (ef <= 128, with
-// deleted nodes <= 96); everything else keeps the launches.  p: ef_cap / lds_cand_cap as for a team launch, vis_lds_log2 = the hash set's size.
+// The resident kernel exists for the embedding sizes with a fixed-dimension distance batch and ef <= 256 (224 with deleted nodes); everything
+// else keeps the launches.  p: ef_cap / lds_cand_cap as for a team launch, vis_lds_log2 = the size of a hash set in LDS (0: the set is in HBM).
 // dynamic LDS of a server workgroup: heaps + query fragment + visited set, then (what fits under 60 KB) the link-block area and the look-ahead area
 static size_t server_layout(const HnswParams& p, uint32_t* nbl_off, uint32_t* spec_off) {
-	size_t at = (size_t(p.ef_cap) + p.lds_cand_cap) * 8 + size_t(p.dim / 64) * 256 + (size_t(4) << p.vis_lds_log2);
+	size_t at = (size_t(p.ef_cap) + p.lds_cand_cap) * 8 + size_t(p.dim / 64) * 256 + (p.vis_lds_log2 ? (size_t(4) << p.vis_lds_log2) : 0);
 	*nbl_off = *spec_off = 0u;
-	if (!p.spec && p.maxM0 < 64u && at + kHnswNblBytes <= (60u << 10)) {   // (the look-ahead experiment keeps link blocks of its own)
+	if (p.nbl && !p.spec && p.maxM0 < 64u && at + kHnswNblBytes <= (60u << 10)) {   // (the look-ahead experiment keeps link blocks of its own)
 		*nbl_off = uint32_t(at);
 		at += kHnswNblBytes;
 	}
@@ -111,23 +111,35 @@ size_t hnsw_server_lds_bytes(const HnswParams& p) {
 	uint32_t a, b;
 	return server_layout(p, &a, &b);
 }
-template <int NB, bool kDel>
+template <int NB, int kSorted, bool kDel>
 static void launch_hnsw_server_nb(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {
 	HnswParams ps = p;
 	const size_t lds = server_layout(p, &ps.nbl_off, &ps.spec_off);
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_server_kernel<kL2, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
-		case kIP: hipLaunchKernelGGL((hnsw_server_kernel<kIP, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
-		default: hipLaunchKernelGGL((hnsw_server_kernel<kCos, NB, 2, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
+		case kL2: hipLaunchKernelGGL((hnsw_server_kernel<kL2, NB, kSorted, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
+		case kIP: hipLaunchKernelGGL((hnsw_server_kernel<kIP, NB, kSorted, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
+		default: hipLaunchKernelGGL((hnsw_server_kernel<kCos, NB, kSorted, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
 	}
 }
+template <int NB>
+static void launch_hnsw_server_dim(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {
+	const bool wide = p.ef_cap > 128u;   // the second mailbox of an index: lists of four entries a lane
+	if (p.bare) {
+		wide ? launch_hnsw_server_nb<NB, 4, false>(metric, p, sv, slots, s) : launch_hnsw_server_nb<NB, 2, false>(metric, p, sv, slots, s);
+	} else {
+		wide ? launch_hnsw_server_nb<NB, 4, true>(metric, p, sv, slots, s) : launch_hnsw_server_nb<NB, 2, true>(metric, p, sv, slots, s);
+	}
+}
+// Two classes of resident kernel (an index may have one of each, serving a mailbox of its own): ef <= 128 (96 with deleted nodes) — lists of
+// two entries a lane, the visited set in LDS — and ef <= 256 (224) — four entries a lane, the visited hash set of a slot in HBM
+// (p.visited: [slots][visited_words], zeroed by the search itself).  p.ef_cap says which: 128 or 256.
 bool launch_hnsw_server(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {
-	if (p.codes || !p.sorted || !p.vis_lds || p.vis_lds_log2 > 13 || hnsw_server_lds_bytes(p) > (60u << 10)) return false;
-	if (p.ef > (p.bare ? 128u : 96u)) return false;
+	if (p.codes || !p.sorted || hnsw_server_lds_bytes(p) > (60u << 10)) return false;
+	if (p.ef_cap <= 128u ? (!p.vis_lds || p.vis_lds_log2 > 13) : (p.vis_lds || p.vis_lds_log2 || !p.visited || p.vis_hash_log2 < 14)) return false;
 	switch (p.dim) {
-		case 128: p.bare ? launch_hnsw_server_nb<2, false>(metric, p, sv, slots, s) : launch_hnsw_server_nb<2, true>(metric, p, sv, slots, s); return true;
-		case 512: p.bare ? launch_hnsw_server_nb<8, false>(metric, p, sv, slots, s) : launch_hnsw_server_nb<8, true>(metric, p, sv, slots, s); return true;
-		case 768: p.bare ? launch_hnsw_server_nb<12, false>(metric, p, sv, slots, s) : launch_hnsw_server_nb<12, true>(metric, p, sv, slots, s); return true;
+		case 128: launch_hnsw_server_dim<2>(metric, p, sv, slots, s); return true;
+		case 512: launch_hnsw_server_dim<8>(metric, p, sv, slots, s); return true;
+		case 768: launch_hnsw_server_dim<12>(metric, p, sv, slots, s); return true;
 		default: return false;
 	}
 }

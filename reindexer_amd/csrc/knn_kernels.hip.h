@@ -157,6 +157,7 @@ struct HnswParams {
 	uint32_t prefetch_links;     // sorted-list search: fetch the link block of the candidate next in line one hop ahead (LDS-DMA)
 	uint32_t team, team_max;     // launches of up to team_max searches run `team` wavefronts per search (hnsw_team_kernel; team <= 1: off)
 	uint32_t nbl_off;            // team searches: byte offset of the link-block area (kHnswNblBytes) in the dynamic LDS, 0 = none (set by the launcher)
+	uint32_t nbl;                // what the caller allows (RXGPU_HNSW_NBL=1: link blocks come along with a hop's rows; off by default)
 	uint32_t spec_off;           // team searches: byte offset of the speculation area (kHnswSpecBytes) in the dynamic LDS, 0 = no speculation (set by the launcher)
 	uint32_t spec;               // what the caller allows (RXGPU_HNSW_SPEC=0: off)
 	float* out_dist;          // [nq][k]

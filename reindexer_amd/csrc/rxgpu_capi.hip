@@ -746,6 +746,10 @@ int rxgpu_index_create(int metric, uint32_t dim, uint64_t capacity, int device, 
 	h->metric = metric;
 	h->dim = dim;
 	h->stride = (dim + 3u) & ~3u;
+	if (const char* e = std::getenv("RXGPU_ROW_ALIGN")) {   // experiment: rows start on multiples of so many bytes (a 3 KB row then lies in ONE 4 KB page)
+		const uint32_t align = uint32_t(std::max(0, atoi(e)));
+		if (align >= 16u && (align & (align - 1u)) == 0u) h->stride = uint32_t(((uint64_t(h->stride) * 4u + align - 1u) & ~uint64_t(align - 1u)) / 4u);
+	}
 	h->device = device;
 	h->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	*out = h;
@@ -1841,6 +1845,7 @@ struct HnswKnobs {
 	int team = -1;                       // RXGPU_HNSW_TEAM: wavefronts per search of a small launch (1 = off)
 	int team_max = -1;                   // RXGPU_HNSW_TEAM_MAX: searches per launch up to which the team form is used
 	int zero_copy = -1;                  // RXGPU_HNSW_ZERO_COPY = 0: small calls copy their queries / results like large ones
+	int nbl = -1;                        // RXGPU_HNSW_NBL = 1: team searches fetch the link blocks of a hop's rows along with the rows (an experiment, off by default)
 	int spec = -1;                       // RXGPU_HNSW_SPEC = 1: team searches also evaluate the next candidate's neighbours in the hop's distance trip (an experiment, off by default)
 	int server = -1;                     // RXGPU_HNSW_SERVER = 0: single queries take a launch each (no resident kernel)
 	int server_slots = -1, server_idle_us = -1, server_life_ms = -1;   // RXGPU_HNSW_SERVER_SLOTS / _IDLE_US / _LIFE_MS
@@ -1872,12 +1877,13 @@ static HnswKnobs read_hnsw_knobs() {
 		else if (is("TEAM_MAX")) k.team_max = atoi(val);
 		else if (is("ZERO_COPY")) k.zero_copy = atoi(val);
 		else if (is("SPEC")) k.spec = atoi(val);
+		else if (is("NBL")) k.nbl = atoi(val);
 		else if (is("SERVER")) k.server = atoi(val);
 		else if (is("SERVER_SLOTS")) k.server_slots = atoi(val);
 		else if (is("SERVER_IDLE_US")) k.server_idle_us = atoi(val);
 		else if (is("SERVER_LIFE_MS")) k.server_life_ms = atoi(val);
 		else continue;
-		if (!is("SERVER") && !is("SERVER_SLOTS") && !is("SERVER_IDLE_US") && !is("SERVER_LIFE_MS") && !is("SPLIT_UPLOAD") && !is("HELPER") && !is("SPEC")) k.names_a_kernel = true;
+		if (!is("SERVER") && !is("SERVER_SLOTS") && !is("SERVER_IDLE_US") && !is("SERVER_LIFE_MS") && !is("SPLIT_UPLOAD") && !is("HELPER") && !is("SPEC") && !is("NBL")) k.names_a_kernel = true;
 	}
 	return k;
 }
@@ -1892,6 +1898,7 @@ static int hnsw_try_server(rxgpu_index* h, const HnswKnobs& knobs, const float* 
 	if (knobs.server_idle_us > 0) cfg.idle_us = uint32_t(knobs.server_idle_us);
 	if (knobs.server_life_ms > 0) cfg.life_ms = uint32_t(knobs.server_life_ms);
 	cfg.spec = knobs.spec > 0;
+	cfg.nbl = knobs.nbl > 0;
 	return rxgpu::hnsw_server_search(h, cfg, query, k, ef, out_dist, out_row, out_count);
 }
 
@@ -2183,6 +2190,7 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	// how many searches per launch)
 	p.team = knobs.team >= 0 ? uint32_t(knobs.team) : 4u;
 	p.team_max = knobs.team_max >= 0 ? uint32_t(knobs.team_max) : 256u;
+	p.nbl = knobs.nbl > 0 ? 1u : 0u;
 	p.spec = knobs.spec > 0 ? 1u : 0u;   // off by default: measured slower at 1M x 768 (profiles/rd6sp_single.json), see hnsw_search_core.hip.h
 	p.out_dist = zero_copy ? reinterpret_cast<float*>(zc_dev + st_dist) : static_cast<float*>(c->d_out_dist.ptr);
 	p.out_row = zero_copy ? reinterpret_cast<uint32_t*>(zc_dev + st_row) : static_cast<uint32_t*>(c->d_out_row.ptr);

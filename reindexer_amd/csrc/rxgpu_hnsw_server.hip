@@ -6,8 +6,8 @@
 // pinned host memory, stores its query and a sequence number, and polls the slot's answer; the kernel that serves the mailbox is launched by
 // whichever caller finds none alive and ends by itself (stop word / idle / lifetime), so nothing on the device ever waits for the host.
 //
-// What is NOT served here (the caller takes the ordinary launches): batches, SQ8 graphs, ef above the two-entries-a-lane list (128; 96 with
-// deleted nodes), embedding sizes without a fixed-dimension distance batch, a profiled index, every RXGPU_HNSW_* A/B hook that names a
+// What is NOT served here (the caller takes the ordinary launches): batches, SQ8 graphs, ef above 256 (224 with deleted nodes; an index has a
+// mailbox per list size: ef <= 128 / 96 and above), embedding sizes without a fixed-dimension distance batch, a profiled index, every RXGPU_HNSW_* A/B hook that names a
 // kernel form, and a search that comes back flagged (equal keys that the in-kernel restart could not settle, a visited set half full).
 #include <immintrin.h>
 #include <sched.h>
@@ -27,8 +27,8 @@
 namespace rxgpu {
 
 namespace {
-constexpr uint32_t kServerKcap = 128;       // result entries per slot (k <= ef <= 128)
-constexpr uint32_t kServerEfCap = 128;
+constexpr uint32_t kServerEfCapOf[2] = {128u, 256u};   // the two classes of resident kernel (hnsw_server.hip): lists of two / four entries a lane
+constexpr uint32_t kServerWideVisLog2 = 15;              // class 1: a slot's visited hash set in HBM, 2^15 words (as a launch of that ef gets)
 constexpr uint32_t kServerRestartCap = 600; // heap area of a search that starts over on the reference's heaps (as a team launch gets)
 constexpr uint32_t kServerVisLog2 = 13;     // 8192-word hash set in LDS: a search may mark 4096 nodes
 
@@ -46,7 +46,8 @@ struct HnswServerState {
 	char* host = nullptr;               // the mailbox
 	char* dev_view = nullptr;           // ... as the device addresses it
 	unsigned long long* d_words = nullptr;
-	uint32_t slots = 0, dim = 0;
+	uint32_t slots = 0, dim = 0, cls = 0, kcap = 128;
+	uint32_t* d_visited = nullptr;      // class 1: [slots][2^kServerWideVisLog2] words
 	size_t o_post = 0, o_done = 0, o_req = 0, o_stop = 0, o_leaving = 0, o_count = 0, o_query = 0, o_dist = 0, o_row = 0, bytes = 0;
 	std::atomic<uint64_t> free_mask[4];
 	std::vector<uint32_t> seq;          // per slot; touched by the slot's holder only
@@ -57,7 +58,7 @@ struct HnswServerState {
 	std::atomic<uint32_t> in_flight{0};   // requests posted and not yet answered
 	std::atomic<uint32_t> expect_us{0};   // running estimate of a request's duration (see the wait in hnsw_server_search)
 	unsigned long long idle_ticks = 0, life_ticks = 0;
-	bool spec = false;
+	bool spec = false, nbl = false;
 
 	uint32_t* post() const { return reinterpret_cast<uint32_t*>(host + o_post); }
 	uint32_t* done() const { return reinterpret_cast<uint32_t*>(host + o_done); }
@@ -71,13 +72,17 @@ static void server_free(HnswServerState* st) {
 	if (st->stream) (void)hipStreamDestroy(st->stream);
 	if (st->host) (void)hipHostFree(st->host);
 	if (st->d_words) (void)hipFree(st->d_words);
+	if (st->d_visited) (void)hipFree(st->d_visited);
 	delete st;
 }
 
 // (under h->mtx) the index's mailbox, made at the first single query
-static HnswServerState* server_create(rxgpu_index* h, uint32_t slots, uint32_t idle_us, uint32_t life_ms, bool spec) {
+static HnswServerState* server_create(rxgpu_index* h, uint32_t cls, uint32_t slots, uint32_t idle_us, uint32_t life_ms, bool spec, bool nbl) {
 	auto* st = new HnswServerState();
+	st->cls = cls;
+	st->kcap = kServerEfCapOf[cls];
 	st->spec = spec;
+	st->nbl = nbl;
 	st->device = h->device;
 	st->slots = slots;
 	st->dim = h->dim;
@@ -95,8 +100,8 @@ static HnswServerState* server_create(rxgpu_index* h, uint32_t slots, uint32_t i
 	st->o_leaving = take(4);
 	st->o_count = take(size_t(slots) * 4);
 	st->o_query = take(size_t(slots) * h->dim * 4);
-	st->o_dist = take(size_t(slots) * kServerKcap * 4);
-	st->o_row = take(size_t(slots) * kServerKcap * 4);
+	st->o_dist = take(size_t(slots) * st->kcap * 4);
+	st->o_row = take(size_t(slots) * st->kcap * 4);
 	int least = 0, greatest = 0;
 	void* dv = nullptr;
 	// a stream of the highest priority: the runtime keeps a pool of hardware queues per priority, so the resident kernel never sits in a
@@ -104,7 +109,8 @@ static HnswServerState* server_create(rxgpu_index* h, uint32_t slots, uint32_t i
 	if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
 		hipStreamCreateWithPriority(&st->stream, hipStreamNonBlocking, greatest) != hipSuccess ||
 		hipHostMalloc(reinterpret_cast<void**>(&st->host), st->bytes, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-		hipHostGetDevicePointer(&dv, st->host, 0) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&st->d_words), 2 * sizeof(unsigned long long)) != hipSuccess) {
+		hipHostGetDevicePointer(&dv, st->host, 0) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&st->d_words), 2 * sizeof(unsigned long long)) != hipSuccess ||
+		(cls == 1 && hipMalloc(reinterpret_cast<void**>(&st->d_visited), (size_t(slots) << kServerWideVisLog2) * 4) != hipSuccess)) {
 		(void)hipGetLastError();
 		server_free(st);
 		return nullptr;
@@ -143,21 +149,30 @@ static int server_launch(rxgpu_index* h, HnswServerState* st) {
 	p.nq = st->slots;
 	p.ef = 1;   // (per request; the launcher checks the class limits against what the host admits)
 	p.k = 1;
-	p.visited = nullptr;
-	p.visited_words = 0;
-	p.vis_hash_log2 = kServerVisLog2;
-	p.vis_lds_log2 = kServerVisLog2;
-	p.vis_lds = 1;
+	if (st->cls == 0) {   // the visited set of a search in the workgroup's LDS
+		p.visited = nullptr;
+		p.visited_words = 0;
+		p.vis_hash_log2 = kServerVisLog2;
+		p.vis_lds_log2 = kServerVisLog2;
+		p.vis_lds = 1;
+	} else {              // ... in the slot's part of an HBM table (64 ef words would not fit the LDS)
+		p.visited = st->d_visited;
+		p.visited_words = uint64_t(1) << kServerWideVisLog2;
+		p.vis_hash_log2 = kServerWideVisLog2;
+		p.vis_lds_log2 = 0;
+		p.vis_lds = 0;
+	}
 	p.prefetch_links = 1;
 	p.team = 4;
 	p.team_max = st->slots;
 	p.spec = st->spec ? 1u : 0u;
+	p.nbl = st->nbl ? 1u : 0u;
 	p.queries = reinterpret_cast<const float*>(st->dev_view + st->o_query);
 	p.out_dist = reinterpret_cast<float*>(st->dev_view + st->o_dist);
 	p.out_row = reinterpret_cast<uint32_t*>(st->dev_view + st->o_row);
 	p.out_count = reinterpret_cast<uint32_t*>(st->dev_view + st->o_count);
 	p.stats = h->d_hnsw_stats;
-	p.ef_cap = kServerEfCap;
+	p.ef_cap = kServerEfCapOf[st->cls];
 	p.lds_cand_cap = kServerRestartCap;
 	p.sorted = 1;
 	HnswServer sv{};
@@ -168,7 +183,7 @@ static int server_launch(rxgpu_index* h, HnswServerState* st) {
 	sv.leaving = reinterpret_cast<uint32_t*>(st->dev_view + st->o_leaving);
 	sv.dev = st->d_words;
 	sv.generation = st->launched.load(std::memory_order_relaxed) + 1u;
-	sv.kcap = kServerKcap;
+	sv.kcap = st->kcap;
 	sv.idle_ticks = st->idle_ticks;
 	sv.life_ticks = st->life_ticks;
 	if (hipMemsetAsync(st->d_words, 0, 2 * sizeof(unsigned long long), st->stream) != hipSuccess || !launch_hnsw_server(h->metric, p, sv, st->slots, st->stream) ||
@@ -197,7 +212,10 @@ static void server_quiesce_state(HnswServerState* st) {
 }
 
 void hnsw_server_quiesce(rxgpu_index* h) {
-	if (h && h->hnsw_server) server_quiesce_state(h->hnsw_server);
+	if (!h) return;
+	for (HnswServerState* st : h->hnsw_server) {
+		if (st) server_quiesce_state(st);
+	}
 }
 
 void hnsw_servers_pause_device(int device) {
@@ -208,22 +226,28 @@ void hnsw_servers_pause_device(int device) {
 }
 
 void hnsw_server_destroy(rxgpu_index* h) {
-	if (!h || !h->hnsw_server) return;
-	HnswServerState* st = h->hnsw_server;
-	server_quiesce_state(st);
-	{
-		std::lock_guard<std::mutex> lk(g_servers_mtx);
-		g_servers.erase(st);
+	if (!h) return;
+	for (HnswServerState*& slot : h->hnsw_server) {
+		HnswServerState* st = slot;
+		if (!st) continue;
+		server_quiesce_state(st);
+		{
+			std::lock_guard<std::mutex> lk(g_servers_mtx);
+			g_servers.erase(st);
+		}
+		slot = nullptr;
+		server_free(st);
 	}
-	h->hnsw_server = nullptr;
-	server_free(st);
 }
 
 void hnsw_server_counters(const rxgpu_index* h, uint64_t* served, uint64_t* generations) {
 	*served = *generations = 0;
-	if (h && h->hnsw_server) {
-		*served = h->hnsw_server->served.load();
-		*generations = h->hnsw_server->generations.load();
+	if (!h) return;
+	for (const HnswServerState* st : h->hnsw_server) {
+		if (st) {
+			*served += st->served.load();
+			*generations += st->generations.load();
+		}
 	}
 }
 
@@ -232,19 +256,22 @@ int hnsw_server_search(rxgpu_index* h, const HnswServerConfig& cfg, const float*
 					   uint32_t* out_count) {
 	if (h->profiling) return 0;
 	if (h->dim != 128 && h->dim != 512 && h->dim != 768) return 0;
-	if (ef > (h->graph_deleted == 0 ? 128u : 96u) || k > kServerKcap || k > ef) return 0;
-	HnswServerState* st = h->hnsw_server;
+	const bool bare = h->graph_deleted == 0;
+	if (ef > (bare ? 256u : 224u) || k > ef) return 0;
+	const uint32_t cls = ef > (bare ? 128u : 96u) ? 1u : 0u;
+	if (k > kServerEfCapOf[cls]) return 0;
+	HnswServerState* st = h->hnsw_server[cls];
 	if (!st) {
 		std::lock_guard<std::mutex> lk(h->mtx);
-		if (!h->hnsw_server) {
-			if (h->hnsw_server_failed) return 0;
-			h->hnsw_server = server_create(h, std::min<uint32_t>(256u, std::max<uint32_t>(1u, cfg.slots)), cfg.idle_us, cfg.life_ms, cfg.spec);
-			if (!h->hnsw_server) {
-				h->hnsw_server_failed = true;
+		if (!h->hnsw_server[cls]) {
+			if (h->hnsw_server_failed[cls]) return 0;
+			h->hnsw_server[cls] = server_create(h, cls, std::min<uint32_t>(256u, std::max<uint32_t>(1u, cfg.slots)), cfg.idle_us, cfg.life_ms, cfg.spec, cfg.nbl);
+			if (!h->hnsw_server[cls]) {
+				h->hnsw_server_failed[cls] = true;
 				return 0;
 			}
 		}
-		st = h->hnsw_server;
+		st = h->hnsw_server[cls];
 	}
 	if (st->broken.load(std::memory_order_relaxed)) return 0;
 	// a free slot (none: every workgroup is busy — this query takes a launch of its own)
@@ -346,8 +373,8 @@ int hnsw_server_search(rxgpu_index* h, const HnswServerConfig& cfg, const float*
 	}
 	const uint32_t count = *reinterpret_cast<const volatile uint32_t*>(st->host + st->o_count + size_t(slot) * 4);
 	if (count == kHnswTie || count == kHnswOverflow || count > k) return 0;
-	std::memcpy(out_dist, st->host + st->o_dist + size_t(slot) * kServerKcap * 4, size_t(count) * 4);
-	std::memcpy(out_row, st->host + st->o_row + size_t(slot) * kServerKcap * 4, size_t(count) * 4);
+	std::memcpy(out_dist, st->host + st->o_dist + size_t(slot) * st->kcap * 4, size_t(count) * 4);
+	std::memcpy(out_row, st->host + st->o_row + size_t(slot) * st->kcap * 4, size_t(count) * 4);
 	*out_count = count;
 	st->served.fetch_add(1, std::memory_order_relaxed);
 	return 1;

@@ -462,6 +462,7 @@ struct HnswServerState;
 struct HnswServerConfig {
 	uint32_t slots = 128;      // RXGPU_HNSW_SERVER_SLOTS: workgroups = requests in flight
 	uint32_t idle_us = 2000;   // RXGPU_HNSW_SERVER_IDLE_US: the kernel leaves after so long without a request
+	bool nbl = false;          // RXGPU_HNSW_NBL=1: link blocks come along with a hop's rows (read when the mailbox is made; off by default)
 	bool spec = false;         // RXGPU_HNSW_SPEC=1: look-ahead distance batches (read when the index's mailbox is made; off by default)
 	uint32_t life_ms = 50;     // RXGPU_HNSW_SERVER_LIFE_MS: ... and after so long in any case (the next caller launches the next one)
 };
@@ -532,8 +533,8 @@ struct rxgpu_index {
 	uint32_t graph_entry = 0;
 	bool graph_attached = false;
 	unsigned long long* d_hnsw_stats = nullptr;
-	rxgpu::HnswServerState* hnsw_server = nullptr;   // the resident search kernel's mailbox (made at the first single query)
-	bool hnsw_server_failed = false;
+	rxgpu::HnswServerState* hnsw_server[2] = {nullptr, nullptr};   // the resident search kernels' mailboxes: [0] ef <= 128, [1] ef <= 256 (made at the first single query of the class)
+	bool hnsw_server_failed[2] = {false, false};
 	std::atomic<uint64_t> hnsw_lds_reruns{0};   // searches whose candidate heap outgrew its first LDS area and were re-run with the largest one
 	std::atomic<uint64_t> hnsw_tie_reruns{0};   // queries the sorted-list search handed to the heap kernel (equal distances met)
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-query HNSW latency through the C-ABI, variant against variant on ONE graph: the resident kernel (mailbox) and the team launch, each
-with and without the look-ahead distance batches (RXGPU_HNSW_SPEC).  Every variant must return the same result sets (labels and distance
+with and without the link blocks that come along with a hop's rows (RXGPU_HNSW_NBL) and the look-ahead distance batches (RXGPU_HNSW_SPEC).  Every variant must return the same result sets (labels and distance
 bits); hops / evaluations / distance trips come from the kernel's counters (RXGPU_HNSW_TRIPS=1 prints them).
     python tools/bench_hnsw_single.py [--rows 1000000] [--queries 256] [--threads 16] [--out f.json]"""
 import argparse
@@ -25,6 +25,7 @@ ap.add_argument("--queries", type=int, default=256)
 ap.add_argument("--threads", type=int, default=16)
 ap.add_argument("--dim", type=int, default=768)
 ap.add_argument("--ef", type=int, default=128)
+ap.add_argument("--only", default=None, help="comma list of variant names")
 ap.add_argument("--out", default=None)
 a = ap.parse_args()
 d, k, ef = a.dim, 10, a.ef
@@ -39,9 +40,12 @@ g = m.export_graph(with_views=True)
 out = {"rows": a.rows, "dim": d, "ef": ef, "queries": a.queries, "variants": {}}
 base = None
 os.environ["RXGPU_HNSW_TRIPS"] = "1"
-for name, env in (("mailbox_plain", {}), ("mailbox_lookahead", {"RXGPU_HNSW_SPEC": "1"}), ("launch_plain", {"RXGPU_HNSW_SERVER": "0"}),
-                  ("launch_lookahead", {"RXGPU_HNSW_SERVER": "0", "RXGPU_HNSW_SPEC": "1"})):
-    for kk in ("RXGPU_HNSW_SPEC", "RXGPU_HNSW_SERVER"):
+VARIANTS = (("mailbox_plain", {}), ("mailbox_rows_page_aligned", {"RXGPU_ROW_ALIGN": "4096"}), ("mailbox_linkblocks", {"RXGPU_HNSW_NBL": "1"}), ("mailbox_lookahead", {"RXGPU_HNSW_SPEC": "1"}),
+            ("launch_plain", {"RXGPU_HNSW_SERVER": "0"}), ("launch_linkblocks", {"RXGPU_HNSW_SERVER": "0", "RXGPU_HNSW_NBL": "1"}))
+for name, env in VARIANTS:
+    if a.only and name not in a.only.split(","):
+        continue
+    for kk in ("RXGPU_HNSW_SPEC", "RXGPU_HNSW_SERVER", "RXGPU_HNSW_NBL", "RXGPU_ROW_ALIGN"):
         os.environ.pop(kk, None)
     os.environ.update(env)
     ix = capi.VectorIndex(2, d, a.rows)
