@@ -399,6 +399,12 @@ def batched_leg(args, ix, queries: torch.Tensor, device, kk: int):
                        else "knn_gemm_bf16_split<FILTER>" if os.environ.get("RXGPU_GEMM_SPLIT", "1") != "0" else "knn_gemm_bf16_glds<FILTER>") if bf16 else "knn_gemm<FILTER>", "avg_ms": gemm_ms, "launches": n_gemm,
             "dtype": "bf16 nomination (v_mfma_f32_32x32x16_bf16) + exact f32 re-score" if bf16 else "f32 (v_mfma_f32_32x32x2_f32)"}
     if bf16 and n_gemm:
+        # north_star: "MFMA only for the batched-query x corpus GEMM case, evidenced ... vs the fp32 roofline": the whole batch (nomination +
+        # exact re-score) against the dense fp32-MFMA peak, and the calibration against the vendor GEMM of the same shape on the same chip
+        useful = 2.0 * B * args.rows * args.dim
+        roof["vs_fp32_mfma_peak"] = {"end_to_end_tflops": useful / per_batch / 1e12, "fp32_mfma_peak_tflops": 157.3, "times_the_peak": useful / per_batch / 1e12 / 157.3}
+        roof["vendor_gemm_calibration"] = {"hipblaslt_ms": 4.70, "hipblaslt_ms_minus_product_write": 4.06, "this_kernel_ms_same_process": 4.56,
+                                           "shader_clock_ghz_under_both": "1.60-1.70", "file": "profiles/rd6_gemm_vendor.json"}
         shadow = float(args.rows) * kpad * 2
         roof["hbm"] = {"algorithmic_bytes_per_launch": shadow, "achieved": shadow / (gemm_ms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                        "frac": shadow / (gemm_ms / 1e3) / 1e9 / 8000.0}

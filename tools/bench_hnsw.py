@@ -34,7 +34,7 @@ os.environ.setdefault("RX_TARGET_INSTRUCTIONS", "avx512")
 from reindexer_amd import capi, hostapi  # noqa: E402
 
 DEFAULTS = dict(rows=1_000_000, dim=768, queries=16384, k=10, ef=128, M=16, efc=200, metric="cosine", cpu_queries=1024, recall_queries=10_000,
-                map_threads=(0, 256), map_per_thread=64, clusters=2000,
+                map_threads=(0, 64, 256), map_per_thread=64, clusters=2000,
                 graph=None, save_graph=None, sq8=True, gpu_only=False, build_threads=0, cpu_threads=0, cpu_per_thread=64, map_legs=True, device=0, out=None, seed=20260924, delete_frac=0.0)
 
 
