@@ -157,7 +157,8 @@ public:
 	// SURVEY 8(e) "BM25": the same merger over a DEVICE LIST — the index is cut into document-range shards (rxgpu_ft_create_sharded: every
 	// device holds the posting fragments of its documents, idf from the global N / df; the pre-score histograms and the admission table meet
 	// in one all-gather each) and every merge returns the single-device result bit for bit.  Queries of plain terms only: phrases,
-	// multi-word synonyms, areas, batches and resident (hybrid) merges need a single-device merger (ShardedSupports()).
+	// multi-word synonyms, areas and resident (hybrid) merges need a single-device merger (ShardedSupports()); MergeQueryBatch runs its
+	// merges one after the other there (each the single index's result).
 	GpuFtMerger(size_t numFields, std::vector<int> devices);
 	~GpuFtMerger();
 	bool Sharded() const noexcept { return sharded_; }

@@ -58,6 +58,23 @@ def main():
             ix.hnsw_search_knn(queries[(r * nq) % (nqmax - nq + 1):][:nq], a.k, a.ef)
         out["call_ms_by_nq"][nq] = (time.perf_counter() - t0) / reps * 1e3
         print("nq", nq, round(out["call_ms_by_nq"][nq], 3), "ms per call", flush=True)
+    # the same with ONE query repeated nq times: every search of the launch walks the same path, so the call lasts as long as one search
+    # does with nq - 1 others beside it — the device-side cost of concurrency without the max-over-different-queries effect
+    import os
+    os.environ["RXGPU_HNSW_SERVER"] = "0"   # (nq = 1 as a launch too)
+    out["same_query_call_ms_by_nq"] = {}
+    for nq in (1, 4, 16, 64, 128, 256):
+        tot = 0.0
+        for qi in range(12):
+            block = np.repeat(queries[qi:qi + 1], nq, axis=0)
+            ix.hnsw_search_knn(block, a.k, a.ef)
+            t0 = time.perf_counter()
+            for r in range(4):
+                ix.hnsw_search_knn(block, a.k, a.ef)
+            tot += (time.perf_counter() - t0) / 4
+        out["same_query_call_ms_by_nq"][nq] = tot / 12 * 1e3
+        print("same query x", nq, round(out["same_query_call_ms_by_nq"][nq], 3), "ms per call", flush=True)
+    del os.environ["RXGPU_HNSW_SERVER"]
     ix.close()
     m.search_knn(queries[0], a.k, a.ef)
     for lanes in [int(x) for x in a.lanes.split(",")]:
