@@ -276,6 +276,9 @@ int rxgpu_hnsw_search_knn_posted(rxgpu_index* h, const float* query, uint32_t k,
 int rxgpu_hnsw_read_stats4(rxgpu_index* h, uint64_t* out4);
 /* queries answered through the mailbox / resident kernels launched so far (instrumentation; 0 / 0 before the first such query) */
 int rxgpu_hnsw_server_stats(rxgpu_index* h, uint64_t* served, uint64_t* generations);
+/* ... and where their time went, summed over the queries answered so far: on the device (the search itself, by the kernel's wall clock) and at
+ * the caller (from the store of the request until the answer was seen: the search + the mailbox + the caller's wake-up) — microseconds */
+int rxgpu_hnsw_server_times(rxgpu_index* h, uint64_t* device_us, uint64_t* caller_us);
 
 /* SQ8 graphs — HierarchicalNSWImpl<uint8_t> after HnswIndexBase::Quantize (hnsw_index.cc:626-660, hnswalg.h:353-420): the level-0 payload
  * is one byte per component plus the row's corrective offset, distances are DistCalculator<uint8_t>::operator() (hnswlib.h:147-165) over

@@ -80,6 +80,7 @@ _SIGNATURES = {
     "rxgpu_hnsw_search_knn": (_i, [_vp, _vp, _u32, _u32, _u32, _vp, _vp, _vp]),
     "rxgpu_hnsw_search_knn_posted": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
     "rxgpu_hnsw_server_stats": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "rxgpu_hnsw_server_times": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rxgpu_hnsw_read_stats4": (_i, [_vp, _vp]),
     "rxgpu_hnsw_attach_sq8": (_i, [_vp, _vp, _vp, _u64, _f]),
     "rxgpu_hnsw_upload_sq8_rows": (_i, [_vp, _u64, _u64, _vp, _vp, _f]),
@@ -430,6 +431,12 @@ class VectorIndex:
         v = (_u64 * 4)()
         _check(lib().rxgpu_hnsw_read_stats4(self._h, C.addressof(v)))
         return tuple(int(x) for x in v)
+
+    def hnsw_server_times(self):
+        """(microseconds on the device, microseconds at the callers) summed over the queries the mailbox has answered."""
+        a, b = _u64(0), _u64(0)
+        _check(lib().rxgpu_hnsw_server_times(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def hnsw_server_stats(self):
         a, b = _u64(0), _u64(0)

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(64 * kTeam) void hnsw_server_kernel(HnswParams p, H
 		if (s_cmd[0] == 2u) return;
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // the query the host wrote in front of the sequence number, not a cached line of the slot's last one
 		const uint32_t seq = s_cmd[1];
+		const unsigned long long t_search = wall_clock64();
 		HnswParams pl = p;
 		pl.k = s_cmd[2];
 		pl.ef = s_cmd[3];
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(64 * kTeam) void hnsw_server_kernel(HnswParams p, H
 		hnsw_search_one<kMetric, false, NB, true, false, kSorted, kDel, kTeam>(pl, slot, 0u, &box);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // this wavefront's result stores are out before the sequence number
 		if (lane == 0) {
+			__hip_atomic_store(&sv.took[slot], uint32_t(wall_clock64() - t_search), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			__hip_atomic_store(&sv.done[slot], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 			box.cnt = -1;
 		}

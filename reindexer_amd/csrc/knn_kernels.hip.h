@@ -203,6 +203,7 @@ struct HnswServer {
 	const uint32_t* post;      // [slots] sequence number of the slot's newest request (host)
 	uint32_t* done;            // [slots] sequence number of the slot's newest finished request (device, behind the results)
 	const uint32_t* req;       // [slots][2] k, ef of the request
+	uint32_t* took;            // [slots] wall-clock ticks (100 MHz) the slot's newest search took on the device, written with its answer (device)
 	const uint32_t* stop;      // host word: != 0 -> leave now (the index is about to change)
 	uint32_t* leaving;         // host word: this generation's number, written when it decides to leave (stop / idle / lifetime) — the host
 	                           // may enqueue the next generation at once: same stream, so it starts when this one is gone

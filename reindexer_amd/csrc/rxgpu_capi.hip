@@ -1918,6 +1918,12 @@ int rxgpu_hnsw_search_knn_posted(rxgpu_index* h, const float* query, uint32_t k,
 	return rc;
 }
 
+int rxgpu_hnsw_server_times(rxgpu_index* h, uint64_t* device_us, uint64_t* caller_us) {
+	RX_CHECK(h && device_us && caller_us, RXGPU_ERR_PARAMS, "rxgpu_hnsw_server_times: null argument");
+	rxgpu::hnsw_server_times(h, device_us, caller_us);
+	return RXGPU_OK;
+}
+
 int rxgpu_hnsw_server_stats(rxgpu_index* h, uint64_t* served, uint64_t* generations) {
 	RX_CHECK(h && served && generations, RXGPU_ERR_PARAMS, "rxgpu_hnsw_server_stats: null argument");
 	rxgpu::hnsw_server_counters(h, served, generations);

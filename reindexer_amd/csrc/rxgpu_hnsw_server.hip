@@ -48,7 +48,7 @@ struct HnswServerState {
 	unsigned long long* d_words = nullptr;
 	uint32_t slots = 0, dim = 0, cls = 0, kcap = 128;
 	uint32_t* d_visited = nullptr;      // class 1: [slots][2^kServerWideVisLog2] words
-	size_t o_post = 0, o_done = 0, o_req = 0, o_stop = 0, o_leaving = 0, o_count = 0, o_query = 0, o_dist = 0, o_row = 0, bytes = 0;
+	size_t o_took = 0, o_post = 0, o_done = 0, o_req = 0, o_stop = 0, o_leaving = 0, o_count = 0, o_query = 0, o_dist = 0, o_row = 0, bytes = 0;
 	std::atomic<uint64_t> free_mask[4];
 	std::vector<uint32_t> seq;          // per slot; touched by the slot's holder only
 	std::atomic<uint32_t> launched{0};  // generation number of the newest launch
@@ -56,6 +56,7 @@ struct HnswServerState {
 	std::atomic<bool> maybe_alive{false};   // a generation was launched since the stream was last seen idle
 	std::atomic<uint64_t> served{0}, generations{0};
 	std::atomic<uint32_t> in_flight{0};   // requests posted and not yet answered
+	std::atomic<uint64_t> device_ticks{0}, caller_us{0};   // sums over the answered requests: the search on the device (100 MHz ticks) / post -> answer seen by the caller
 	std::atomic<uint32_t> expect_us{0};   // running estimate of a request's duration (see the wait in hnsw_server_search)
 	unsigned long long idle_ticks = 0, life_ticks = 0;
 	bool spec = false, nbl = false;
@@ -95,6 +96,7 @@ static HnswServerState* server_create(rxgpu_index* h, uint32_t cls, uint32_t slo
 	};
 	st->o_post = take(size_t(slots) * 4);
 	st->o_done = take(size_t(slots) * 4);
+	st->o_took = take(size_t(slots) * 4);
 	st->o_req = take(size_t(slots) * 8);
 	st->o_stop = take(4);
 	st->o_leaving = take(4);
@@ -178,6 +180,7 @@ static int server_launch(rxgpu_index* h, HnswServerState* st) {
 	HnswServer sv{};
 	sv.post = reinterpret_cast<const uint32_t*>(st->dev_view + st->o_post);
 	sv.done = reinterpret_cast<uint32_t*>(st->dev_view + st->o_done);
+	sv.took = reinterpret_cast<uint32_t*>(st->dev_view + st->o_took);
 	sv.req = reinterpret_cast<const uint32_t*>(st->dev_view + st->o_req);
 	sv.stop = reinterpret_cast<const uint32_t*>(st->dev_view + st->o_stop);
 	sv.leaving = reinterpret_cast<uint32_t*>(st->dev_view + st->o_leaving);
@@ -237,6 +240,17 @@ void hnsw_server_destroy(rxgpu_index* h) {
 		}
 		slot = nullptr;
 		server_free(st);
+	}
+}
+
+void hnsw_server_times(const rxgpu_index* h, uint64_t* device_us, uint64_t* caller_us) {
+	*device_us = *caller_us = 0;
+	if (!h) return;
+	for (const HnswServerState* st : h->hnsw_server) {
+		if (st) {
+			*device_us += st->device_ticks.load() / 100u;
+			*caller_us += st->caller_us.load();
+		}
 	}
 }
 
@@ -366,6 +380,8 @@ int hnsw_server_search(rxgpu_index* h, const HnswServerConfig& cfg, const float*
 			sched_yield();
 		}
 	}
+	st->device_ticks.fetch_add(*reinterpret_cast<const volatile uint32_t*>(st->host + st->o_took + size_t(slot) * 4), std::memory_order_relaxed);
+	st->caller_us.fetch_add(uint64_t(std::min(waited_us(), 1e9)), std::memory_order_relaxed);
 	{   // the estimate the sleepers use: never above what was just seen, one microsecond up per query (so it follows a growing index)
 		const uint32_t took = uint32_t(std::min(waited_us(), 1e6));
 		const uint32_t e = st->expect_us.load(std::memory_order_relaxed);

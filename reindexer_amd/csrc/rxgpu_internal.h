@@ -473,6 +473,7 @@ void hnsw_server_quiesce(struct ::rxgpu_index* h);      // before the index chan
 void hnsw_server_destroy(struct ::rxgpu_index* h);
 void hnsw_servers_pause_device(int device);             // before a device-wide wait: every index's resident kernel on that device leaves
 hipError_t device_wait_all(int device);                 // hipDeviceSynchronize behind hnsw_servers_pause_device
+void hnsw_server_times(const struct ::rxgpu_index* h, uint64_t* device_us, uint64_t* caller_us);
 void hnsw_server_counters(const struct ::rxgpu_index* h, uint64_t* served, uint64_t* generations);
 struct DeviceGuardLite {
 	int prev = -1;

@@ -60,6 +60,14 @@ def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
     return out
 
 
+def server_times(m):
+    """(us on the device, us at the callers) over the queries the Map's resident search kernel has answered so far."""
+    import ctypes as C
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    capi.lib().rxgpu_hnsw_server_times(m.device_index, C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
 def sq8_leg(o, ix, metric, g, queries, qnorms, trow, tq, nq, ncpu, ref_float) -> dict:
     """the same graph with SQ8 rows.  The reference's own Quantize() (HierarchicalNSWImpl<uint8_t> copy-built from the float
     engine, sampled minQ / maxQ) produces the codes; the device searches THOSE codes (rxgpu_hnsw_search_knn_sq8) and is compared, labels and
@@ -251,9 +259,13 @@ def run(o) -> dict:
             T = T or ncpu
             m.search_knn_mt(queries, o.k, o.ef, T, 2, 10.0)   # warm-up: contexts and buffers of T concurrent callers
             p0 = m.posted_queries()
+            tm0 = server_times(m)
             secs, done, batches = m.search_knn_mt(queries, o.k, o.ef, T, o.map_per_thread, 20.0)
             posted = m.posted_queries() - p0   # answered by the resident search kernel: no launch, no batch
+            tm1 = server_times(m)
             out["gpu"]["map_threads"].append({"threads": T, "queries": done, "queries_per_sec": done / secs if secs else None, "posted": posted,
+                                              "posted_ms_on_device": (tm1[0] - tm0[0]) / posted / 1e3 if posted else None,       # mean duration of a search on the chip
+                                              "posted_ms_at_caller": (tm1[1] - tm0[1]) / posted / 1e3 if posted else None,       # ... from the request's store to its answer seen
                                               "device_batches": batches, "avg_batch": (done - posted) / batches if batches else None})
         sess = m.stream(queries[0], o.ef)   # a15: one streaming session, 10 batches of 10 (the planner's post-filter pattern)
         t0 = time.perf_counter()
