@@ -96,14 +96,15 @@ __global__ __launch_bounds__(64 * kTeam) void hnsw_server_kernel(HnswParams p, H
 // The resident kernel exists for the embedding sizes with a fixed-dimension distance batch and ef <= 256 (224 with deleted nodes); everything
 // else keeps the launches.  p: ef_cap / lds_cand_cap as for a team launch, vis_lds_log2 = the size of a hash set in LDS (0: the set is in HBM).
 // dynamic LDS of a server workgroup: heaps + query fragment + visited set, then (what fits under 60 KB) the link-block area and the look-ahead area
+constexpr size_t kServerLdsLimit = size_t(150) << 10;   // one workgroup per CU: it may take most of the CU's 160 KB (the launcher raises the kernel's limit)
 static size_t server_layout(const HnswParams& p, uint32_t* nbl_off, uint32_t* spec_off) {
 	size_t at = (size_t(p.ef_cap) + p.lds_cand_cap) * 8 + size_t(p.dim / 64) * 256 + (p.vis_lds_log2 ? (size_t(4) << p.vis_lds_log2) : 0);
 	*nbl_off = *spec_off = 0u;
-	if (p.nbl && !p.spec && p.maxM0 < 64u && at + kHnswNblBytes <= (60u << 10)) {   // (the look-ahead experiment keeps link blocks of its own)
+	if (p.nbl && !p.spec && p.maxM0 < 64u && at + kHnswNblBytes <= kServerLdsLimit) {   // (the look-ahead experiment keeps link blocks of its own)
 		*nbl_off = uint32_t(at);
 		at += kHnswNblBytes;
 	}
-	if (p.spec && p.bare && p.maxM0 < 64u && at + kHnswSpecBytes <= (60u << 10)) {
+	if (p.spec && p.bare && p.maxM0 < 64u && at + kHnswSpecBytes <= kServerLdsLimit) {
 		*spec_off = uint32_t(at);
 		at += kHnswSpecBytes;
 	}
@@ -117,11 +118,18 @@ template <int NB, int kSorted, bool kDel>
 static void launch_hnsw_server_nb(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {
 	HnswParams ps = p;
 	const size_t lds = server_layout(p, &ps.nbl_off, &ps.spec_off);
+#define RX_SERVER(M)                                                                                                                       \
+	do {                                                                                                                                   \
+		static std::atomic<uint64_t> raised{0};                                                                                            \
+		if (lds > (size_t(60) << 10)) (void)raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&hnsw_server_kernel<M, NB, kSorted, kDel, 4>), kServerLdsLimit); \
+		hipLaunchKernelGGL((hnsw_server_kernel<M, NB, kSorted, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv);                          \
+	} while (0)
 	switch (metric) {
-		case kL2: hipLaunchKernelGGL((hnsw_server_kernel<kL2, NB, kSorted, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
-		case kIP: hipLaunchKernelGGL((hnsw_server_kernel<kIP, NB, kSorted, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
-		default: hipLaunchKernelGGL((hnsw_server_kernel<kCos, NB, kSorted, kDel, 4>), dim3(slots), dim3(256), lds, s, ps, sv); break;
+		case kL2: RX_SERVER(kL2); break;
+		case kIP: RX_SERVER(kIP); break;
+		default: RX_SERVER(kCos); break;
 	}
+#undef RX_SERVER
 }
 template <int NB>
 static void launch_hnsw_server_dim(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {
@@ -136,8 +144,8 @@ static void launch_hnsw_server_dim(int metric, const HnswParams& p, const HnswSe
 // two entries a lane, the visited set in LDS — and ef <= 256 (224) — four entries a lane, the visited hash set of a slot in HBM
 // (p.visited: [slots][visited_words], zeroed by the search itself).  p.ef_cap says which: 128 or 256.
 bool launch_hnsw_server(int metric, const HnswParams& p, const HnswServer& sv, uint32_t slots, hipStream_t s) {
-	if (p.codes || !p.sorted || hnsw_server_lds_bytes(p) > (60u << 10)) return false;
-	if (p.ef_cap <= 128u ? (!p.vis_lds || p.vis_lds_log2 > 13) : (p.vis_lds || p.vis_lds_log2 || !p.visited || p.vis_hash_log2 < 14)) return false;
+	if (p.codes || !p.sorted || hnsw_server_lds_bytes(p) > kServerLdsLimit) return false;
+	if (p.ef_cap <= 128u ? (!p.vis_lds || p.vis_lds_log2 > 14) : (p.vis_lds || p.vis_lds_log2 || !p.visited || p.vis_hash_log2 < 14)) return false;
 	switch (p.dim) {
 		case 128: launch_hnsw_server_dim<2>(metric, p, sv, slots, s); return true;
 		case 512: launch_hnsw_server_dim<8>(metric, p, sv, slots, s); return true;

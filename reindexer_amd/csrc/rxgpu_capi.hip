@@ -20,11 +20,58 @@ void set_error(const std::string& msg) { g_err = msg; }
 using rxgpu::set_error;
 
 namespace rxgpu {
-// hipDeviceSynchronize for a device that may hold resident search kernels (rxgpu_hnsw_server.hip): they are told to leave first — the wait
-// would otherwise last until their idle / lifetime limit
+// hipFree / hipHostFree wait for the whole device — and a resident search kernel (rxgpu_hnsw_server.hip) stays on it for up to its lifetime:
+// a scratch buffer that grew on some thread's launch path stalled that thread for tens of milliseconds (measured: T = 16 planner threads over
+// 10M rows, 7 of 1024 queries took the launches, the leg lasted 73 ms instead of 47).  While such a kernel may be alive, buffers that are
+// replaced are retired instead and freed at the next point that waits for the device anyway (a mutation, a quiesce, index destruction),
+// or when 256 MB have piled up.
+std::atomic<int> g_resident_kernels{0};
+namespace {
+std::mutex g_retired_mtx;
+std::vector<std::pair<void*, bool>> g_retired;   // (pointer, host memory?)
+size_t g_retired_bytes = 0;
+}  // namespace
+void drain_retired() {
+	std::vector<std::pair<void*, bool>> take;
+	{
+		std::lock_guard<std::mutex> lk(g_retired_mtx);
+		take.swap(g_retired);
+		g_retired_bytes = 0;
+	}
+	for (const auto& e : take) {
+		if (e.second) {
+			(void)hipHostFree(e.first);
+		} else {
+			(void)hipFree(e.first);
+		}
+	}
+}
+void free_or_retire(void* ptr, size_t bytes, bool host) {
+	if (!ptr) return;
+	if (g_resident_kernels.load(std::memory_order_acquire) <= 0) {
+		if (host) {
+			(void)hipHostFree(ptr);
+		} else {
+			(void)hipFree(ptr);
+		}
+		return;
+	}
+	bool drain = false;
+	{
+		std::lock_guard<std::mutex> lk(g_retired_mtx);
+		g_retired.emplace_back(ptr, host);
+		g_retired_bytes += bytes;
+		drain = g_retired_bytes > (size_t(256) << 20);
+	}
+	if (drain) drain_retired();
+}
+// hipDeviceSynchronize for a device that may hold resident search kernels: they are told to leave first — the wait would otherwise last
+// until their idle / lifetime limit
 hipError_t device_wait_all(int device) {
 	hnsw_servers_pause_device(device);
-	return hipDeviceSynchronize();
+	const hipError_t e = hipDeviceSynchronize();
+	drain_retired();
+	return e;
 }
 }  // namespace rxgpu
 
@@ -47,7 +94,7 @@ hipError_t device_wait_all(int device) {
 
 int rxgpu_devbuf::ensure(size_t need) {
 	if (need <= bytes) return RXGPU_OK;
-	if (ptr) (void)hipFree(ptr);
+	rxgpu::free_or_retire(ptr, bytes, false);
 	ptr = nullptr;
 	bytes = 0;
 	const size_t want = std::max<size_t>(need, 4096);
@@ -62,13 +109,13 @@ int rxgpu_devbuf::ensure(size_t need) {
 	return RXGPU_OK;
 }
 void rxgpu_devbuf::release() {
-	if (ptr) (void)hipFree(ptr);
+	rxgpu::free_or_retire(ptr, bytes, false);
 	ptr = nullptr;
 	bytes = 0;
 }
 int rxgpu_search_ctx::ensure_pinned(size_t need) {
 	if (need <= h_pinned_bytes) return RXGPU_OK;
-	if (h_pinned) (void)hipHostFree(h_pinned);
+	rxgpu::free_or_retire(h_pinned, h_pinned_bytes, true);
 	h_pinned = nullptr;
 	h_pinned_bytes = 0;
 	const size_t want = std::max<size_t>(need, 1 << 16);
@@ -1825,7 +1872,7 @@ int rxgpu_hnsw_attach_sq8(rxgpu_index* h, const uint8_t* codes, const float* cor
 // ([nq][kk] distances | [nq][kk] local rows, invalid entries past a query's count) instead of travelling to the host; only the counts
 // come back (the re-run tiers are driven by them).  The stream is drained before the call returns.
 static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef,
-							float* out_dist, uint32_t* out_row, uint32_t* out_count, const rxgpu::HnswSink* sink = nullptr);
+							float* out_dist, uint32_t* out_row, uint32_t* out_count, const rxgpu::HnswSink* sink = nullptr, bool try_server = true);
 
 extern "C++" {
 // The A/B and test hooks of the HNSW search (RXGPU_HNSW_*), read in ONE pass over the environment per call — a dozen getenv() lookups each
@@ -1915,6 +1962,11 @@ int rxgpu_hnsw_search_knn_posted(rxgpu_index* h, const float* query, uint32_t k,
 		*served = 1;
 		return RXGPU_OK;
 	}
+	if (rc == 2) {   // the mailbox took it and the search needs the re-run tiers: answered here by the launches, not offered to the mailbox again
+		const int r2 = hnsw_search_impl(h, query, nullptr, nullptr, 1, k, ef, out_dist, out_row, out_count, nullptr, false);
+		if (r2 == RXGPU_OK) *served = 1;
+		return r2;
+	}
 	return rc;
 }
 
@@ -1972,7 +2024,7 @@ int rxgpu_hnsw_search_knn_sq8(rxgpu_index* h, const uint8_t* query_codes, const 
 }
 
 static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qcorr, const float* qnorm, uint32_t nq, uint32_t k, uint32_t ef,
-							float* out_dist, uint32_t* out_row, uint32_t* out_count, const rxgpu::HnswSink* sink) {
+							float* out_dist, uint32_t* out_row, uint32_t* out_count, const rxgpu::HnswSink* sink, bool try_server) {
 	const bool sq8 = qcorr != nullptr;
 	const bool to_host = sink == nullptr;
 	RX_CHECK(h, RXGPU_ERR_PARAMS, "null index");
@@ -1996,10 +2048,10 @@ static int hnsw_search_impl(rxgpu_index* h, const void* queries, const float* qc
 	const bool big_ef = ef > uint32_t(rxgpu::kHnswLdsCandEf);
 	const HnswKnobs knobs = read_hnsw_knobs();
 	// ONE query, the planner's call: through the mailbox of the index's resident kernel (rxgpu_hnsw_server.hip) — no launch on the path
-	if (nq == 1 && to_host && !sq8) {
+	if (nq == 1 && to_host && !sq8 && try_server) {
 		const int served = hnsw_try_server(h, knobs, static_cast<const float*>(queries), k, ef, out_dist, out_row, out_count);
 		if (served == 1) return RXGPU_OK;
-		if (served != 0) return served;
+		if (served != 0 && served != 2) return served;   // (2: the search ran there and came back flagged — the tiers below answer it)
 	}
 	DeviceGuard dg(h->device);
 	rxgpu_search_ctx* c = acquire_ctx(h);

@@ -30,7 +30,8 @@ namespace {
 constexpr uint32_t kServerEfCapOf[2] = {128u, 256u};   // the two classes of resident kernel (hnsw_server.hip): lists of two / four entries a lane
 constexpr uint32_t kServerWideVisLog2 = 15;              // class 1: a slot's visited hash set in HBM, 2^15 words (as a launch of that ef gets)
 constexpr uint32_t kServerRestartCap = 600; // heap area of a search that starts over on the reference's heaps (as a team launch gets)
-constexpr uint32_t kServerVisLog2 = 13;     // 8192-word hash set in LDS: a search may mark 4096 nodes
+constexpr uint32_t kServerVisLog2 = 14;     // 16384-word hash set in LDS (64 KB of the CU's 160): a search may mark 8192 nodes — at 10M x 768, ef = 128, 0.7 % of
+                                            // the searches marked more than the 4096 a 32 KB set allows and went back to the launches
 
 std::mutex g_servers_mtx;
 std::set<HnswServerState*> g_servers;
@@ -196,7 +197,7 @@ static int server_launch(rxgpu_index* h, HnswServerState* st) {
 		set_error("hnsw server: launch failed");
 		return RXGPU_ERR_DEVICE;
 	}
-	st->maybe_alive.store(true, std::memory_order_release);
+	if (!st->maybe_alive.exchange(true, std::memory_order_acq_rel)) g_resident_kernels.fetch_add(1, std::memory_order_acq_rel);
 	st->launched.store(sv.generation, std::memory_order_release);
 	st->generations.fetch_add(1, std::memory_order_relaxed);
 	return RXGPU_OK;
@@ -212,6 +213,7 @@ static void server_quiesce_state(HnswServerState* st) {
 	store_rel(st->leaving(), st->launched.load());   // (a generation that ended on its wall-clock fallback never wrote it)
 	store_rel(st->stop(), 0u);
 	st->maybe_alive.store(false, std::memory_order_release);
+	if (g_resident_kernels.fetch_sub(1, std::memory_order_acq_rel) == 1) drain_retired();   // (no resident kernel left: what was put aside meanwhile goes now)
 }
 
 void hnsw_server_quiesce(rxgpu_index* h) {
@@ -265,7 +267,8 @@ void hnsw_server_counters(const rxgpu_index* h, uint64_t* served, uint64_t* gene
 	}
 }
 
-// 1: served (out_* hold the result), 0: not served — the caller takes the launches, < 0: an RXGPU error code
+// 1: served (out_* hold the result), 0: not taken — the caller takes the launches, 2: taken, but the search came back flagged (equal keys the
+// in-kernel restart could not settle, a visited set half full): the launches' re-run tiers answer it; any other value: an RXGPU error code
 int hnsw_server_search(rxgpu_index* h, const HnswServerConfig& cfg, const float* query, uint32_t k, uint32_t ef, float* out_dist, uint32_t* out_row,
 					   uint32_t* out_count) {
 	if (h->profiling) return 0;
@@ -388,7 +391,7 @@ int hnsw_server_search(rxgpu_index* h, const HnswServerConfig& cfg, const float*
 		st->expect_us.store(e == 0u ? took : std::min(e + 1u, took), std::memory_order_relaxed);
 	}
 	const uint32_t count = *reinterpret_cast<const volatile uint32_t*>(st->host + st->o_count + size_t(slot) * 4);
-	if (count == kHnswTie || count == kHnswOverflow || count > k) return 0;
+	if (count == kHnswTie || count == kHnswOverflow || count > k) return 2;   // the search ran and needs the re-run tiers: not a case for a second look at the mailbox
 	std::memcpy(out_dist, st->host + st->o_dist + size_t(slot) * st->kcap * 4, size_t(count) * 4);
 	std::memcpy(out_row, st->host + st->o_row + size_t(slot) * st->kcap * 4, size_t(count) * 4);
 	*out_count = count;

@@ -472,6 +472,9 @@ int hnsw_server_search(struct ::rxgpu_index* h, const HnswServerConfig& cfg, con
 void hnsw_server_quiesce(struct ::rxgpu_index* h);      // before the index changes: the resident kernel leaves, none is queued
 void hnsw_server_destroy(struct ::rxgpu_index* h);
 void hnsw_servers_pause_device(int device);             // before a device-wide wait: every index's resident kernel on that device leaves
+extern std::atomic<int> g_resident_kernels;             // resident search kernels that may be alive: frees are deferred meanwhile (rxgpu_capi.hip)
+void free_or_retire(void* ptr, size_t bytes, bool host);
+void drain_retired();
 hipError_t device_wait_all(int device);                 // hipDeviceSynchronize behind hnsw_servers_pause_device
 void hnsw_server_times(const struct ::rxgpu_index* h, uint64_t* device_us, uint64_t* caller_us);
 void hnsw_server_counters(const struct ::rxgpu_index* h, uint64_t* served, uint64_t* generations);

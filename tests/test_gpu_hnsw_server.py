@@ -90,7 +90,7 @@ def test_posted_equals_launched_and_restated_engine(rxgpu, oracle, metric, d, de
                         assert np.array_equal(np.sort(g["labels"][pr[:pc]]), np.sort(wl)), (k, ef, qi)
                         assert np.array_equal(np.sort(bits(pd[:pc])), np.sort(bits(wd)))
         got, gens = ix.hnsw_server_stats()
-        assert got == served and served >= 0.9 * len(plans) * q.shape[0], (got, served)   # (a search that met equal keys takes the launches)
+        assert got <= served and got >= 0.9 * len(plans) * q.shape[0], (got, served)   # (a search that comes back flagged is answered by the launches inside the same call)
         assert gens >= 1
         # what the mailbox does not take
         _, _, _, ok = ix.hnsw_search_knn_posted(q[0], 10, 300)

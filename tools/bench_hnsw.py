@@ -38,7 +38,7 @@ DEFAULTS = dict(rows=1_000_000, dim=768, queries=16384, k=10, ef=128, M=16, efc=
                 graph=None, save_graph=None, sq8=True, gpu_only=False, build_threads=0, cpu_threads=0, cpu_per_thread=64, map_legs=True, device=0, out=None, seed=20260924, delete_frac=0.0)
 
 
-def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
+def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int, return_pick: bool = False):
     """Synthetic corpus = cluster centre + noise (embedding-like: low intrinsic dimension); clusters == 0: i.i.d. N(0, 0.25^2), the
     distribution of the reference's tests (gtests/tools.h:121-129), on which ANY graph index has poor recall at 768 dims.
     Generated on the GPU (a 10M x 768 corpus takes numpy minutes), returned as a host array; deterministic per (seed, device type)."""
@@ -48,16 +48,18 @@ def make_clustered(rows: int, dim: int, clusters: int, seed: int, device: int):
     g.manual_seed(seed)
     centres = torch.empty((max(clusters, 1), dim), dtype=torch.float32, device=dev).normal_(0.0, 0.25, generator=g)
     out = np.empty((rows, dim), np.float32)
+    picks = np.zeros(rows, np.int32)
     chunk = 1 << 19
     for a in range(0, rows, chunk):
         n = min(chunk, rows - a)
         if clusters:
             pick = torch.randint(0, clusters, (n,), device=dev, generator=g)
+            picks[a:a + n] = pick.cpu().numpy()
             x = centres[pick] + torch.empty((n, dim), dtype=torch.float32, device=dev).normal_(0.0, 0.08, generator=g)
         else:
             x = torch.empty((n, dim), dtype=torch.float32, device=dev).normal_(0.0, 0.25, generator=g)
         out[a:a + n] = x.cpu().numpy()
-    return out
+    return (out, picks) if return_pick else out
 
 
 def server_times(m):
