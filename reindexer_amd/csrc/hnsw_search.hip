@@ -89,24 +89,38 @@ static void launch_hnsw_nb(int metric, const HnswParams& p, uint32_t blocks, hip
 		if (p.team > 1 && blocks <= p.team_max) {
 			HnswParams pt = p;
 			size_t lds_t = lds;
-			if (p.vis_lds_log2 && (size_t(4) << p.vis_lds_log2) <= (32u << 10) && lds_t + (size_t(4) << p.vis_lds_log2) <= (60u << 10)) {
-				pt.vis_lds = 1;
-				pt.vis_hash_log2 = p.vis_lds_log2;
-				lds_t += size_t(4) << p.vis_lds_log2;
+			// the visited set in LDS, one size up from what the caller allows where that stays within 64 KB (a handful of workgroups: each may take
+			// a large part of its CU's 160 KB): at 10M x 768, ef = 128, 0.7 % of the searches mark more than the 4096 nodes a 32 KB set holds, and
+			// every one of them costs a re-run launch with a bitset behind the batch
+			if (p.vis_lds_log2) {
+				uint32_t lg = p.vis_lds_log2;
+				if (lg >= 12u && lg < 14u) lg += 1u;   // (smaller sizes are the tests' way of forcing the re-run tiers: left as asked)
+				if ((size_t(4) << lg) <= (64u << 10)) {
+					pt.vis_lds = 1;
+					pt.vis_hash_log2 = lg;
+					lds_t += size_t(4) << lg;
+				}
 			}
-			if (p.nbl && !p.spec && p.maxM0 < 64u && lds_t + kHnswNblBytes <= (60u << 10)) {   // the link blocks of a hop's rows come along with the rows (hnsw_team_serve)
+			if (p.nbl && !p.spec && p.maxM0 < 64u && lds_t + kHnswNblBytes <= (150u << 10)) {   // the link blocks of a hop's rows come along with the rows (hnsw_team_serve)
 				pt.nbl_off = uint32_t(lds_t);
 				lds_t += kHnswNblBytes;
 			}
-			if (p.spec && !kDel && p.maxM0 < 64u && lds_t + kHnswSpecBytes <= (60u << 10)) {   // distances of the next candidate's neighbours ride along (hnsw_search_core.hip.h)
+			if (p.spec && !kDel && p.maxM0 < 64u && lds_t + kHnswSpecBytes <= (150u << 10)) {   // distances of the next candidate's neighbours ride along (hnsw_search_core.hip.h)
 				pt.spec_off = uint32_t(lds_t);
 				lds_t += kHnswSpecBytes;
 			}
+#define RX_TEAM(M)                                                                                                                         \
+	do {                                                                                                                                   \
+		static std::atomic<uint64_t> raised{0};                                                                                            \
+		if (lds_t > (size_t(60) << 10)) (void)raise_dynamic_lds_once(raised, reinterpret_cast<const void*>(&hnsw_team_kernel<M, NB, kSorted, kDel, 4>), size_t(150) << 10); \
+		hipLaunchKernelGGL((hnsw_team_kernel<M, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt);                             \
+	} while (0)
 			switch (metric) {
-				case kL2: hipLaunchKernelGGL((hnsw_team_kernel<kL2, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt); break;
-				case kIP: hipLaunchKernelGGL((hnsw_team_kernel<kIP, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt); break;
-				default: hipLaunchKernelGGL((hnsw_team_kernel<kCos, NB, kSorted, kDel, 4>), dim3(blocks), dim3(256), lds_t, s, pt); break;
+				case kL2: RX_TEAM(kL2); break;
+				case kIP: RX_TEAM(kIP); break;
+				default: RX_TEAM(kCos); break;
 			}
+#undef RX_TEAM
 			return;
 		}
 	}

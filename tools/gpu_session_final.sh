@@ -6,7 +6,7 @@ TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" && mkdir -p gpurun_out/prof && export TMPDIR=/tmp
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; tail -4 gpurun_out/${TAG}_smoke.log
-timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+timeout 1500 python -m pytest tests -q -m gpu --durations=10 > gpurun_out/${TAG}_pytest_gpu.log 2>&1
 tail -4 gpurun_out/${TAG}_pytest_gpu.log
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --full-json gpurun_out/${TAG}_bench_full.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_full.err
 tail -c 600 gpurun_out/${TAG}_bench_full.err
