@@ -1,14 +1,17 @@
-// Host side of the resident HNSW search kernel (hnsw_server_kernel, hnsw_search.hip; protocol: HnswServer, knn_kernels.hip.h).
+// Host side of the resident HNSW search kernel (hnsw_server_kernel, hnsw_server.hip; protocol: HnswServer, knn_kernels.hip.h).
 //
 // The reference's planner issues ONE query per HnswIndexBase::select (hnsw_index.cc:159-288 -> hnswalg.h:1988-2012) from as many threads as
 // it has connections (gtests/tests/unit/float_vector_index.cc:258-294 runs 16).  As a launch per call that path was bound by everything
 // around the search: 9.9 k q/s at T = 16 over 10M x 768 against 18.6 k for the reference's 16 cores.  Here a call claims a slot of a mailbox in
 // pinned host memory, stores its query and a sequence number, and polls the slot's answer; the kernel that serves the mailbox is launched by
 // whichever caller finds none alive and ends by itself (stop word / idle / lifetime), so nothing on the device ever waits for the host.
+// Measured at the end of round 6 (profiles/rd6zz_bench_full.json): T = 16 / 64 / 256 -> 21.9 k / 82.4 k / 175 k q/s over 10M x 768, every search
+// 0.67 - 0.69 ms on the device whatever T; the reference's 16 cores 19.1 k q/s.
 //
 // What is NOT served here (the caller takes the ordinary launches): batches, SQ8 graphs, ef above 256 (224 with deleted nodes; an index has a
 // mailbox per list size: ef <= 128 / 96 and above), embedding sizes without a fixed-dimension distance batch, a profiled index, every RXGPU_HNSW_* A/B hook that names a
-// kernel form, and a search that comes back flagged (equal keys that the in-kernel restart could not settle, a visited set half full).
+// kernel form.  A search that comes back flagged (equal keys that the in-kernel restart could not settle, a visited set half full) is
+// answered by the launches' re-run tiers inside the same call.
 #include <immintrin.h>
 #include <sched.h>
 #include <sys/prctl.h>
