@@ -263,7 +263,7 @@ int rxgpu_hnsw_search_knn(rxgpu_index* h, const float* queries, uint32_t nq, uin
  * itself — when the index is about to change (every mutating entry point tells it), after RXGPU_HNSW_SERVER_IDLE_US (2000) without a
  * request, after RXGPU_HNSW_SERVER_LIFE_MS (50) in any case.  No launch, copy or completion signal lies on the path of a served query.
  * *served = 1: out_* hold what rxgpu_hnsw_search_knn returns for this query (the same device code runs the search).  *served = 0: this query
- * is not taken — every slot (RXGPU_HNSW_SERVER_SLOTS, 128) is busy, ef > 256 (224 on a graph with deleted nodes; up to 128 / 96 and above
+ * is not taken — every slot (RXGPU_HNSW_SERVER_SLOTS, 256) is busy, ef > 256 (224 on a graph with deleted nodes; up to 128 / 96 and above
  * that are served by two resident kernels of their own), a dimension other than
  * 128 / 512 / 768, a profiled or sharded index, RXGPU_HNSW_SERVER=0, or the search needs the re-run tiers — and the caller uses
  * rxgpu_hnsw_search_knn, which tries the mailbox itself for nq == 1 and launches otherwise. */

@@ -52,11 +52,12 @@ __global__ __launch_bounds__(64 * kTeam) void hnsw_server_kernel(HnswParams p, H
 				} else if (__hip_atomic_load(&sv.dev[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull || now - t_start > 2ull * sv.life_ticks) {
 					cmd = 2u;   // (twice the lifetime: workgroup 0 never came to decide — e.g. it was not resident yet; the kernel ends anyway)
 				}
-				// every look is a read across PCIe: close together while requests keep coming, ~4 us apart once the slot has been quiet for a while
+				// every look is a read across PCIe: close together while requests keep coming, ~7 us apart once the slot has been quiet for a while
 				if (!cmd) {
 					if (++quiet < 64u) {
 						__builtin_amdgcn_s_sleep(24);
 					} else {
+						__builtin_amdgcn_s_sleep(127);
 						__builtin_amdgcn_s_sleep(127);
 					}
 				}

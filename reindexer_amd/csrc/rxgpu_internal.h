@@ -460,7 +460,7 @@ namespace rxgpu {
 // The resident HNSW search kernel of an index and its mailbox (rxgpu_hnsw_server.hip)
 struct HnswServerState;
 struct HnswServerConfig {
-	uint32_t slots = 128;      // RXGPU_HNSW_SERVER_SLOTS: workgroups = requests in flight
+	uint32_t slots = 256;      // RXGPU_HNSW_SERVER_SLOTS: workgroups = requests in flight (one per CU of an MI355X; an idle slot looks at its mailbox word every ~7 us)
 	uint32_t idle_us = 2000;   // RXGPU_HNSW_SERVER_IDLE_US: the kernel leaves after so long without a request
 	bool nbl = false;          // RXGPU_HNSW_NBL=1: link blocks come along with a hop's rows (read when the mailbox is made; off by default)
 	bool spec = false;         // RXGPU_HNSW_SPEC=1: look-ahead distance batches (read when the index's mailbox is made; off by default)
