@@ -58,9 +58,10 @@ def pmc_traffic(algo_bytes: float):
             summ = json.loads(p.read_text())
         except Exception:
             continue
+        # (a kernel launched over inputs of several sizes in the profiled command: the class of its largest launches, not the mean over all)
         for name, e in summ.get("kernels", {}).items():
-            t = e.get("hbm_traffic_bytes_per_launch")
-            if "knn_scan" in name and t and abs(t / algo_bytes - 1.0) < 0.25:
+            t = e.get("largest_class_hbm_traffic_bytes_per_launch") or e.get("hbm_traffic_bytes_per_launch")
+            if "knn_scan" in name and t and abs(t / algo_bytes - 1.0) < 0.05:
                 best = (t, f"profiles/{p.name}")
     return best
 
