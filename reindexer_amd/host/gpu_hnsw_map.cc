@@ -256,8 +256,17 @@ void GpuHnswMap::ResizeIndex(size_t newMaxElements) {
 	graphDirty_ = true;
 }
 
-void GpuHnswMap::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const {
-	if (sh_) throw std::logic_error("GpuHnswMap: the ANN cache stream holds ONE graph — not available for a Map over a device list");
+// The cache of a Map over a device list.  The reference's stream holds ONE graph (hnswalg.h:1213-1263); here there is a graph per shard, so
+// the stream says so in a way every single-graph reader understands: where one graph states its capacity and its element count, this one
+// states capacity 0 and count = the number of shards — HierarchicalNSWImpl's reader (hnswalg.h:297-306), HnswGraph::LoadIndex and a
+// single-device Map all stop at those two fields with "Current elements count is larger than max elements count", which
+// HnswIndexBase::LoadIndexCache (hnsw_index.cc:452-507) takes as a cache to drop and rebuild.  Behind them: format version, the Map's
+// capacity, the rows of a shard, then every shard's graph as HnswGraph::SaveIndex writes it.  Labels route back to their shard on load.
+namespace {
+constexpr uint64_t kShardedAnnCacheVersion = 1;
+}  // namespace
+
+void GpuHnswMap::saveQuantizingParams(AnnCacheWriter& writer) const {
 	// serializeQuantizingParams (hnsw.cc:56-62) + QuantizingParams::Serialize (quantization_params.h:83-96)
 	writer.PutVarUInt(uint32_t(quantized_ ? 1 : 0));
 	if (quantized_) {
@@ -272,40 +281,100 @@ void GpuHnswMap::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& ca
 		writer.PutFloat(sq8_.alpha_2);
 		writer.PutFloat(sq8_.delta);
 	}
+}
+
+void GpuHnswMap::SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const {
+	saveQuantizingParams(writer);
+	if (sh_) {
+		const ShardedState& S = *sh_;
+		writer.PutVarUInt(uint64_t(0));
+		writer.PutVarUInt(uint64_t(S.maps.size()));
+		writer.PutVarUInt(kShardedAnnCacheVersion);
+		writer.PutVarUInt(uint64_t(S.maxElements));
+		writer.PutVarUInt(uint64_t(S.shardRows));
+		for (const auto& m : S.maps) m->graph_.SaveIndex(writer, cancel);
+		return;
+	}
 	graph_.SaveIndex(writer, cancel);
 }
 
-void GpuHnswMap::LoadIndex(AnnCacheReader& reader) {
-	if (sh_) throw std::logic_error("GpuHnswMap: the ANN cache stream holds ONE graph — not available for a Map over a device list");
-	std::optional<Sq8Params> stored;
-	Sq8QuantizationConfig cfg;
-	if (reader.GetVarUInt() != 0) {   // deserializeQuantizingParams (hnsw.cc:64-72)
-		if (reader.GetVarUInt() != kAnnCacheQuantizationParamsVersion) throw std::runtime_error("Invalid quantization parameters version during deserialization");
-		if (reader.GetVarInt() != 0) throw std::runtime_error("Unsupported quantization type");
-		const float q = reader.GetFloat();   // QuantizationConfig::Deserialize (quantization_config.cc:30-41)
-		if (q >= 0.95f && q <= 1.f) {
-			cfg.quantile = q;
-		} else if (q != 0.f) {
-			throw std::runtime_error("Incorrect deserialized quantile value: must be within [0.95; 1.0]");
-		}
-		cfg.sampleSize = size_t(reader.GetVarUInt());
-		cfg.quantizationThreshold = size_t(reader.GetVarUInt());
-		Sq8Params p;
-		p.minQ = reader.GetFloat();
-		p.maxQ = reader.GetFloat();
-		p.alpha = reader.GetFloat();
-		p.alpha_2 = reader.GetFloat();
-		p.delta = reader.GetFloat();
-		stored = p;
+bool GpuHnswMap::loadQuantizingParams(AnnCacheReader& reader, Sq8Params& stored, Sq8QuantizationConfig& cfg) {
+	if (reader.GetVarUInt() == 0) return false;   // deserializeQuantizingParams (hnsw.cc:64-72)
+	if (reader.GetVarUInt() != kAnnCacheQuantizationParamsVersion) throw std::runtime_error("Invalid quantization parameters version during deserialization");
+	if (reader.GetVarInt() != 0) throw std::runtime_error("Unsupported quantization type");
+	const float q = reader.GetFloat();   // QuantizationConfig::Deserialize (quantization_config.cc:30-41)
+	if (q >= 0.95f && q <= 1.f) {
+		cfg.quantile = q;
+	} else if (q != 0.f) {
+		throw std::runtime_error("Incorrect deserialized quantile value: must be within [0.95; 1.0]");
 	}
+	cfg.sampleSize = size_t(reader.GetVarUInt());
+	cfg.quantizationThreshold = size_t(reader.GetVarUInt());
+	stored.minQ = reader.GetFloat();
+	stored.maxQ = reader.GetFloat();
+	stored.alpha = reader.GetFloat();
+	stored.alpha_2 = reader.GetFloat();
+	stored.delta = reader.GetFloat();
+	return true;
+}
+
+void GpuHnswMap::LoadIndex(AnnCacheReader& reader) {
+	Sq8Params stored;
+	Sq8QuantizationConfig cfg;
+	const bool hasParams = loadQuantizingParams(reader, stored, cfg);
 	LoadGraph(reader);
 	quantized_ = false;
 	pendingSq8_.reset();
-	if (stored && reader.WithQuantizer()) {   // hnsw.cc:47-53: Load<QuantizedHnswT> only then; else the float graph
-		sq8_ = *stored;
+	if (sh_) {
+		for (const auto& m : sh_->maps) {
+			m->quantized_ = false;
+			m->pendingSq8_.reset();
+		}
+	}
+	if (hasParams && reader.WithQuantizer()) {   // hnsw.cc:47-53: Load<QuantizedHnswT> only then; else the float graph
+		sq8_ = stored;
 		sq8Config_ = cfg;
 		quantized_ = true;
 		codesDirty_ = true;
+		if (sh_) {   // ONE quantiser, a code table per shard (Quantize above)
+			for (const auto& m : sh_->maps) m->Quantize(stored.minQ, stored.maxQ);
+		}
+	}
+}
+
+void GpuHnswMap::shLoadGraphs(AnnCacheReader& reader) {
+	ShardedState& S = *sh_;
+	if (shCount(false) != 0) throw std::logic_error("HnswGraph::LoadIndex: the graph is not empty");
+	if (reader.GetVarUInt() != 0) {
+		throw std::runtime_error("GpuHnswMap: the ANN cache holds one graph, this index is defined over a list of " + std::to_string(S.maps.size()) +
+								 " devices (a graph per shard)");
+	}
+	const uint64_t shards = reader.GetVarUInt();
+	if (shards != S.maps.size()) {
+		throw std::runtime_error("GpuHnswMap: the ANN cache was written over " + std::to_string(shards) + " shards, this index is defined over " +
+								 std::to_string(S.maps.size()));
+	}
+	if (reader.GetVarUInt() != kShardedAnnCacheVersion) throw std::runtime_error("GpuHnswMap: unknown version of the sharded ANN cache");
+	const uint64_t maxElements = reader.GetVarUInt(), shardRows = reader.GetVarUInt();
+	if (shardRows >= 0xFFFFFFFFull || maxElements > shardRows * S.maps.size()) throw std::runtime_error("GpuHnswMap: sharded ANN cache: sizes out of range");
+	if (shardRows > S.shardRows) {   // the writer's shards were larger: every range grows first (a global row is shard * shardRows + local)
+		if ((shardRows & 31) != 0) throw std::runtime_error("GpuHnswMap: sharded ANN cache: sizes out of range");
+		for (auto& m : S.maps) m->ResizeIndex(size_t(shardRows));
+		shCreateParent(size_t(shardRows));
+	}
+	S.maxElements = std::max(S.maxElements, size_t(maxElements));
+	for (auto& m : S.maps) {
+		m->LoadGraph(reader);   // (a failure leaves the earlier shards loaded: the caller clears the Map, HnswIndexBase::LoadIndexCache's clearMap())
+		if (m->graph_.MaxElements() > S.shardRows) throw std::runtime_error("GpuHnswMap: sharded ANN cache: a shard's graph is larger than the shard");
+	}
+	std::lock_guard<std::mutex> lk(S.routeMtx);
+	S.shardOf.clear();
+	for (size_t s = 0; s < S.maps.size(); ++s) {
+		const HnswGraph& g = S.maps[s]->graph_;
+		S.routed[s] = g.Count();   // slots in use, delete-marked ones included (they are recycled only when every range is full)
+		for (size_t i = 0; i < g.Count(); ++i) {
+			if (!g.IsDeleted(tableint(i))) S.shardOf[g.Label(tableint(i))] = uint32_t(s);
+		}
 	}
 }
 
@@ -328,7 +397,7 @@ void GpuHnswMap::Clear() {
 }
 
 void GpuHnswMap::LoadGraph(AnnCacheReader& reader) {
-	if (sh_) throw std::logic_error("GpuHnswMap: the ANN cache stream holds ONE graph — not available for a Map over a device list");
+	if (sh_) return shLoadGraphs(reader);
 	graph_.LoadIndex(reader);
 	graphDirty_ = true;
 	deletedDirty_ = true;

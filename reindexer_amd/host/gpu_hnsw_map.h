@@ -155,12 +155,18 @@ private:
 	const float* shFloatPtr(labeltype label) const;
 	GpuHnswMap& shRoute(labeltype label);
 	void shSyncAll() const;
+	void shLoadGraphs(AnnCacheReader& reader);                                               // the sharded ANN cache behind the quantising parameters
+	void saveQuantizingParams(AnnCacheWriter& writer) const;
+	static bool loadQuantizingParams(AnnCacheReader& reader, Sq8Params& stored, Sq8QuantizationConfig& cfg);
 public:
 	// The ANN disk cache (ann_cache.h): HierarchicalNSW::SaveIndex / LoadIndex (hnswlib/hnsw.cc:41-72).  The stream starts with the
 	// "quantised" flag; a quantised Map writes 1 + its QuantizingParams (version, QuantizationConfig, minQ, maxQ, alpha, alpha_2, delta:
 	// quantization_params.h:83-96, quantization_config.cc:44-49), a float graph 0.  LoadIndex reads them back: parameters in the stream and
 	// reader.WithQuantizer() -> the Map comes back QUANTISED with exactly those parameters (the codes are rebuilt from the rows: the cache holds
 	// links and keys); otherwise a float graph (hnsw.cc:47-53).  The Map must be empty; the next search uploads the whole graph to the device.
+	// A Map over a device list writes a stream of its own shape — a graph per shard behind a header that every single-graph reader (the
+	// reference's engine, a single-device Map) refuses at once with the reference's "Current elements count is larger than max elements count",
+	// i.e. a cache miss and a rebuild; it loads only into a Map over as many shards (gpu_hnsw_map.cc: shLoadGraphs).
 	void SaveIndex(AnnCacheWriter& writer, const std::atomic_int32_t& cancel) const;
 	void LoadIndex(AnnCacheReader& reader);
 	void LoadGraph(AnnCacheReader& reader);

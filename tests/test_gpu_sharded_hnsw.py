@@ -284,12 +284,148 @@ def test_in_tree_hnsw_shape_takes_its_device_list_from_the_environment(hostapi, 
     m.close()
 
 
-def test_what_a_device_list_does_not_offer_says_so(hostapi):
-    m = hostapi.GpuHnswMap(1, 16, 500, devices=[0, 0])
-    m.add(make_corpus(1, 100, 16), np.arange(100, dtype=np.uint64) << np.uint64(32))
-    with pytest.raises(Exception, match="device list"):
-        m.save_index()
-    m.close()
+def _knn_equal(a, b, q, k, ef, norm=None):
+    ad, al = a.search_knn_norm(q, k, ef, norm)
+    bd, bl = b.search_knn_norm(q, k, ef, norm)
+    oa, ob = np.lexsort((al, ad)), np.lexsort((bl, bd))
+    return np.array_equal(al[oa], bl[ob]) and np.array_equal(bits(ad[oa]), bits(bd[ob]))
+
+
+@pytest.mark.parametrize("metric", [0, 2])
+def test_ann_cache_of_a_map_over_a_device_list_round_trips(hostapi, oracle, metric):
+    """WriteIndexCache / LoadIndexCache (hnsw_index.cc:388-507) for the Map over a device list: a graph per shard behind a header no
+    single-graph reader accepts.  Loaded into an empty Map over as many shards: same counts, same shards, the same answers (labels and
+    distance bits), the same bytes written back, and the Map keeps growing like the one that built the graphs."""
+    n, d, k = 2600, 48, 10
+    rows = make_corpus(61 + metric, n, d)
+    labels = (np.arange(n, dtype=np.uint64) << np.uint64(32)) | np.uint64(5)
+    built = hostapi.GpuHnswMap(metric, d, 3000, M=8, ef_construction=80, devices=[0, 0, 0])
+    built.add(rows, labels)
+    for lab in labels[::41]:
+        built.mark_delete(int(lab))
+    cache = built.save_index()
+    loaded = hostapi.GpuHnswMap(metric, d, 3000, M=8, ef_construction=80, devices=[0, 0, 0])
+    loaded.load_index(cache, labels, rows)
+    assert loaded.count == built.count and loaded.deleted_count == built.deleted_count and loaded.shard_rows == built.shard_rows
+    for s in range(3):
+        assert loaded.shard(s).count == built.shard(s).count
+        assert loaded.shard(s).save_index() == built.shard(s).save_index()
+    for qi in range(16):
+        q = make_corpus(500 + qi, 1, d)[0]
+        norm = None
+        if metric == 2:
+            q, inv = oracle.normalize_copy(q)
+            norm = 1.0 / inv
+        assert _knn_equal(built, loaded, q, k, 64, norm), qi
+        assert _knn_equal(built, loaded, q, 3, 8, norm), qi
+    assert loaded.save_index() == cache
+    # routing came back with the labels: a delete finds its shard, a new label goes where the builder's Map puts it, an old one is updated in place
+    extra = make_corpus(62, 40, d)
+    extra_labels = (np.arange(n, n + 40, dtype=np.uint64) << np.uint64(32)) | np.uint64(5)
+    for m in (built, loaded):
+        m.mark_delete(int(labels[7]))
+        m.add(extra, extra_labels)
+        m.add(rows[100:101] * np.float32(0.5), labels[100:101])
+    assert loaded.count == built.count and loaded.deleted_count == built.deleted_count
+    for s in range(3):
+        assert loaded.shard(s).save_index() == built.shard(s).save_index(), s
+    q, norm = extra[3], None
+    if metric == 2:
+        q, inv = oracle.normalize_copy(q)
+        norm = 1.0 / inv
+    assert _knn_equal(built, loaded, q, k, 64, norm)
+    with pytest.raises(hostapi.HostError, match="not empty"):
+        loaded.load_index(cache, labels, rows)   # refused, and cleared as clearMap() does
+    assert loaded.count == 0
+    loaded.load_index(cache, labels, rows)       # ... an empty Map again: the cache loads
+    assert loaded.count == n
+    built.close()
+    loaded.close()
+
+
+def test_ann_cache_of_a_device_list_is_a_miss_for_every_other_reader(hostapi):
+    """The sharded stream into a single-graph reader — the reference's engine, the host graph, a single-device Map — and a single graph's
+    stream (or one written over another number of shards) into a Map over a device list: each refused with an error, the Map left empty
+    (what HnswIndexBase::LoadIndexCache turns into "drop the cache, rebuild")."""
+    from oracle import pyoracle
+    n, d = 900, 16
+    rows = make_corpus(71, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    two = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=60, devices=[0, 0])
+    two.add(rows, labels)
+    sharded_cache = two.save_index()
+    one = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=60)
+    one.add(rows, labels)
+    single_cache = one.save_index()
+    one.close()
+    fresh = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=60)
+    with pytest.raises(hostapi.HostError, match="larger than max elements"):
+        fresh.load_index(sharded_cache, labels, rows)
+    assert fresh.count == 0
+    fresh.load_index(single_cache, labels, rows)   # still usable
+    assert fresh.count == n
+    fresh.close()
+    g = hostapi.HnswGraph(0, d, n, M=8, ef_construction=60)
+    with pytest.raises(hostapi.HostError, match="larger than max elements"):
+        g.load_index(sharded_cache, labels, rows)
+    g.close()
+    engine = pyoracle.ref_or_none()
+    if engine is not None:   # the reference's own reader (hnswalg.h:297-306), where oracle/_ref travels
+        with pytest.raises(RuntimeError, match="larger than max elements"):
+            pyoracle.RefHnsw.load_index(engine, sharded_cache, 0, d, labels, rows)
+    three = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=60, devices=[0, 0, 0])
+    with pytest.raises(hostapi.HostError, match="written over 2 shards"):
+        three.load_index(sharded_cache, labels, rows)
+    assert three.count == 0
+    with pytest.raises(hostapi.HostError, match="holds one graph"):
+        three.load_index(single_cache, labels, rows)
+    assert three.count == 0
+    three.add(rows[:50], labels[:50])   # ... and the Map works on
+    assert three.search_knn(rows[7], 1, 16)[1].tolist() == [int(labels[7])]
+    three.close()
+    # a Map defined with a smaller capacity than the cache's: every range grows to the writer's shard size first
+    small = hostapi.GpuHnswMap(0, d, 64, M=8, ef_construction=60, devices=[0, 0])
+    with pytest.raises(hostapi.HostError):
+        small.load_index(sharded_cache[: len(sharded_cache) * 3 // 4], labels, rows)   # truncated inside the second shard's graph
+    assert small.count == 0
+    with pytest.raises(hostapi.HostError, match="no row with the stored key"):
+        small.load_index(sharded_cache, labels[:-1], rows[:-1])   # a key the namespace does not hold any more
+    assert small.count == 0
+    small.load_index(sharded_cache, labels, rows)
+    assert small.count == n and small.shard_rows == two.shard_rows
+    for qi in range(8):
+        assert _knn_equal(two, small, make_corpus(700 + qi, 1, d)[0], 5, 32)
+    small.close()
+    two.close()
+
+
+def test_quantised_ann_cache_of_a_device_list(hostapi):
+    """A quantised Map over a device list writes its QuantizingParams in front (hnsw.cc:56-62); LoadWithQuantizer brings it back quantised with
+    those parameters on every shard, without it the float graphs come back (hnsw.cc:47-53)."""
+    n, d, k = 2400, 64, 10
+    rows = make_corpus(81, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    flt = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=80, devices=[0, 0])
+    flt.add(rows, labels)
+    sq = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=80, devices=[0, 0])
+    sq.add(rows, labels)
+    params = sq.quantize_config(sample_size=2000)
+    cache = sq.save_index()
+    back = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=80, devices=[0, 0])
+    back.load_index(cache, labels, rows, with_quantizer=True)
+    assert back.is_quantized and np.array_equal(back.quantizing_params, params)
+    for s in range(2):
+        assert back.shard(s).is_quantized and np.array_equal(back.shard(s).quantizing_params, params)
+    plain = hostapi.GpuHnswMap(0, d, n, M=8, ef_construction=80, devices=[0, 0])
+    plain.load_index(cache, labels, rows)
+    assert not plain.is_quantized and not plain.shard(0).is_quantized
+    for qi in range(12):
+        q = make_corpus(600 + qi, 1, d)[0]
+        assert _knn_equal(sq, back, q, k, 64), qi
+        assert _knn_equal(flt, plain, q, k, 64), qi
+    assert back.save_index() == cache
+    for m in (flt, sq, back, plain):
+        m.close()
 
 
 @pytest.mark.parametrize("metric", [0, 2])
