@@ -327,13 +327,22 @@ def test_ann_cache_of_a_map_over_a_device_list_round_trips(hostapi, oracle, metr
         m.add(extra, extra_labels)
         m.add(rows[100:101] * np.float32(0.5), labels[100:101])
     assert loaded.count == built.count and loaded.deleted_count == built.deleted_count
-    for s in range(3):
-        assert loaded.shard(s).save_index() == built.shard(s).save_index(), s
-    q, norm = extra[3], None
-    if metric == 2:
-        q, inv = oracle.normalize_copy(q)
-        norm = 1.0 / inv
-    assert _knn_equal(built, loaded, q, k, 64, norm)
+    for s in range(3):   # the new labels went to the shards the builder's Map sent them to
+        assert loaded.shard(s).count == built.shard(s).count and loaded.shard(s).deleted_count == built.shard(s).deleted_count, s
+    # (the graphs themselves part ways from here: a loaded graph draws its levels from a freshly seeded generator, as the reference's reader
+    # constructor does — hnswalg.h:297-409; tests/test_ann_cache.py::test_loaded_graph_keeps_building_like_the_reference)
+    for m in (built, loaded):
+        for i in (0, 13, 39):
+            q, norm = extra[i], None
+            if metric == 2:
+                q, inv = oracle.normalize_copy(q)
+                norm = 1.0 / inv
+            assert m.search_knn_norm(q, 1, 64, norm)[1].tolist() == [int(extra_labels[i])]
+        q, norm = rows[7], None
+        if metric == 2:
+            q, inv = oracle.normalize_copy(q)
+            norm = 1.0 / inv
+        assert int(labels[7]) not in m.search_knn_norm(q, 5, 64, norm)[1].tolist()
     with pytest.raises(hostapi.HostError, match="not empty"):
         loaded.load_index(cache, labels, rows)   # refused, and cleared as clearMap() does
     assert loaded.count == 0
