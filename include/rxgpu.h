@@ -374,8 +374,10 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h);
  * an ncclAllGather over the listed devices (RCCL opened on demand; one communicator per index), a plain device copy when every shard lives on
  * one device; without RCCL on a multi-device node, or with RXGPU_SHARD_MERGE=host at creation, the pieces travel through the host
  * (rxgpu_ft_shard_exchange_mode 1 = on the devices, 0 = through the host).  The result is the single
- * index's, bit for bit, in merge order.  Phrases, multi-word synonyms, areas, packed uploads, batches and resident (hybrid) merges are
- * single-device features: RXGPU_ERR_LOGIC here. */
+ * index's, bit for bit, in merge order.  rxgpu_ft_merge_query2_raw's multi-word synonyms run there too (a synonym's mask, the term
+ * counting and the removal of documents that hold only parts of it, mergerimpl.h:347-361 / 509-555, are decided per document, and a
+ * document lies in one shard; the marked documents go after the union of the shards' slots).  Phrases, areas, packed uploads, batches and
+ * resident (hybrid) merges are single-device features: RXGPU_ERR_LOGIC here. */
 int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* devices, rxgpu_ft_index** out);
 uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h);           /* 0 for an unsharded index */
 /* The cut of a sharded index is fixed by the first rxgpu_ft_set_docs and kept while the shards hold words: an index that grows through

@@ -1160,6 +1160,9 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 
 	bool any_phrase = false;
 	for (const QueryPartIn& part : parts) any_phrase = any_phrase || part.phrase;
+	// (a document-range shard: a phrase's admission under mergeLimit runs over the whole first term, phrasemerger.h:341 — refused before any kernel runs)
+	RX_CHECK(h->sh_total <= 1 || !any_phrase, RXGPU_ERR_LOGIC,
+			 std::string(who) + ": a sharded ft index merges terms and multi-word synonyms (no phrases, areas or resident results)");
 	// the launch train: the sparse one for eligible queries whose postings lie on a fraction of the documents (or on request)
 	bool sparse = false;
 	{
@@ -1524,8 +1527,10 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 		}
 	}
 	if (h->sh_total > 1) {   // a document-range shard: its own ranges, the facts that span the shards arrive between the kernels
-		RX_CHECK(!resident && !nsyn && !max_areas && n_phrases == 0, RXGPU_ERR_LOGIC,
-				 std::string(who) + ": a sharded ft index merges plain terms (no phrases, multi-word synonyms, areas or resident results)");
+		// (multi-word synonyms are fine: their masks, term counts and the "only parts of a synonym" marks are facts of ONE document, and a
+		// document lies in one shard — ft_syn_masks sees this shard's fragments, the caller drops the marked documents after the union)
+		RX_CHECK(!resident && !max_areas && n_phrases == 0, RXGPU_ERR_LOGIC,
+				 std::string(who) + ": a sharded ft index merges terms and multi-word synonyms (no phrases, areas or resident results)");
 		p.range_begin = h->sh_range_begin;
 		p.range_count = h->sh_range_count;
 		p.shard_index = h->sh_index;
@@ -1696,7 +1701,7 @@ inline char* ft_send_ptr(rxgpu_ft_shard_set* ss, int k, size_t s, size_t bytes) 
 // between them, every shard's packed result, the slot-wise union.
 int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 					  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
-					  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who) {
+					  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, const SynonymsIn* synonyms = nullptr) {
 	rxgpu_ft_shard_set* ss = parent->shard_set;
 	const size_t S = ss->shards.size();
 	RX_CHECK(ss->n_ranges > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
@@ -1725,7 +1730,7 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 		active[s] = sh->sh_range_count != 0;
 		sh->sh_hist = static_cast<const uint32_t*>(ss->d_recv[0][ss->shard_rank[s]].ptr);
 		sh->sh_pos = ss->d_pos[ss->shard_rank[s]];
-		if (int rc = prepare_merge(sh, sh->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, nullptr, jobs[s], true, 0); rc) return rc;
+		if (int rc = prepare_merge(sh, sh->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, synonyms, jobs[s], true, 0); rc) return rc;
 		empty = empty || jobs[s].empty;
 		sh->clean_dirty = !jobs[s].empty;   // an error return from here on leaves the kept-clean tables in an unknown state
 	}
@@ -1826,6 +1831,18 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 		}
 	}
 	for (uint64_t i = 0; i < n; ++i) RX_CHECK(filled[i], RXGPU_ERR_DEVICE, std::string(who) + ": a merge slot no shard wrote");
+	if (n && jobs[0].nsyn && out_terms_counter) {   // the documents that hold only parts of a multi-word synonym go (mergerimpl.h:533-555), as in collect_merge
+		uint64_t kept = 0;
+		for (uint64_t i = 0; i < n; ++i) {
+			if (out_terms_counter[i] == 0xFFFFu) continue;
+			out_doc[kept] = out_doc[i];
+			out_proc[kept] = out_proc[i];
+			out_terms_counter[kept] = out_terms_counter[i];
+			out_field[kept] = out_field[i];
+			++kept;
+		}
+		n = kept;
+	}
 	*out_n = n;
 	if (out_preselected) *out_preselected = presel;
 	return RXGPU_OK;
@@ -1839,10 +1856,10 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 			  const AreasOut* areas = nullptr) {
 	using clk = std::chrono::steady_clock;
 	if (h->shard_set) {   // document-range shards: the same train on every shard, two exchanges between its pieces
-		RX_CHECK(!resident && !(synonyms && synonyms->nsyn) && !areas, RXGPU_ERR_LOGIC,
-				 std::string(who) + ": a sharded ft index merges plain terms (no multi-word synonyms, areas or resident results)");
+		RX_CHECK(!resident && !areas, RXGPU_ERR_LOGIC, std::string(who) + ": a sharded ft index merges terms and multi-word synonyms (no areas or resident results)");
 		RX_CHECK(out_doc && out_proc && out_field && (simple || out_terms_counter), RXGPU_ERR_OVERFLOW, std::string(who) + ": output buffers too small");
-		return run_merge_sharded(h, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who);
+		return run_merge_sharded(h, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who,
+								 synonyms);
 	}
 	if (int rc = finish_pending(h, who); rc) return rc;
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };

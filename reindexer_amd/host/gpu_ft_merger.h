@@ -156,9 +156,10 @@ public:
 	GpuFtMerger(size_t numFields, int device = 0);
 	// SURVEY 8(e) "BM25": the same merger over a DEVICE LIST — the index is cut into document-range shards (rxgpu_ft_create_sharded: every
 	// device holds the posting fragments of its documents, idf from the global N / df; the pre-score histograms and the admission table meet
-	// in one all-gather each) and every merge returns the single-device result bit for bit.  Queries of plain terms only: phrases,
-	// multi-word synonyms, areas and resident (hybrid) merges need a single-device merger (ShardedSupports()); MergeQueryBatch runs its
-	// merges one after the other there (each the single index's result).
+	// in one all-gather each) and every merge returns the single-device result bit for bit.  Queries of terms and multi-word synonyms
+	// (what a synonym decides — its mask, the term count, "only parts of it" — concerns one document, and a document lies in one shard);
+	// phrases, areas and resident (hybrid) merges need a single-device merger (ShardedSupports()); MergeQueryBatch runs its merges one
+	// after the other there (each the single index's result).
 	GpuFtMerger(size_t numFields, std::vector<int> devices);
 	~GpuFtMerger();
 	bool Sharded() const noexcept { return sharded_; }
@@ -166,8 +167,8 @@ public:
 	// pile up on the last shard (rxgpu_ft_shard_imbalance).  1.0 for an unsharded merger.
 	double ShardImbalance() const noexcept;
 	rxgpu_ft_index* DeviceIndex() const noexcept { return dev_; }
-	bool ShardedSupports(bool hasPhrases, bool hasSynonyms, int maxAreasInDoc = 0) const noexcept {
-		return !sharded_ || (!hasPhrases && !hasSynonyms && maxAreasInDoc == 0);
+	bool ShardedSupports(bool hasPhrases, bool /*hasSynonyms*/, int maxAreasInDoc = 0) const noexcept {
+		return !sharded_ || (!hasPhrases && maxAreasInDoc == 0);
 	}
 	GpuFtMerger(const GpuFtMerger&) = delete;
 

@@ -321,7 +321,7 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		QuerySynonyms synonyms;
 		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
 		if (!GpuFtMerger::SupportsAreas(terms.size(), hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;
-		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;   // a device list: plain terms, no areas
+		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;   // a device list: no phrases, no areas
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
 		if (docsExcluded.PopCount() != 0) {
@@ -347,7 +347,7 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		QuerySynonyms synonyms;
 		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
 		if (!GpuFtMerger::Supports(terms.size(), hasPhrases, !q.synonyms.empty())) return false;
-		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty())) return false;   // a device list: phrases and synonyms stay on the CPU merger
+		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty())) return false;   // a device list: phrases stay on the CPU merger
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
 		if (docsExcluded.PopCount() != 0) {

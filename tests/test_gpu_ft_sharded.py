@@ -223,7 +223,71 @@ def test_what_a_sharded_ft_index_does_not_offer_says_so(rxgpu, hostapi, ft):
     m = hostapi.GpuFtMerger(nf, devices=[0, 0])
     with pytest.raises(Exception, match="rxgpu_ft_set_docs first"):
         m.set_word_fpos(0, dict(doc=np.array([1], np.uint32), pos_off=np.array([0, 1], np.uint32), fpos=np.array([3], np.uint64), proc=1.0))
+    # a phrase needs a single-device merger (its admission under mergeLimit runs over the whole first term): refused, not answered wrongly
+    total = 20_000
+    _, words, avg, removed, excluded, terms, store = _multi_case(41, nf, total, 20000, (1, 1), False, None, sizes=(500, 2000))
+    load(m, words, avg, removed, store)
+    cfg = ft.default_config(nf, merge_limit=20000)
+    phrase = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]], phrase=0, distance=2) for t in terms]
+    with pytest.raises(Exception, match="no phrases"):
+        m.merge_query(cfg, phrase, None, sort_by_rank=False)
+    plain = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    assert len(m.merge_query(cfg, plain, None, sort_by_rank=False)[0]) > 0   # ... and the merger works on
     m.close()
+
+
+SHARDED_SYN_CASES = [
+    # (seed, limit, ops of the query parts, synonyms as lists of term counts, part -> synonym ids)
+    (301, 20000, (1,), [2], [[0]]),                          # one OR term with a two-word synonym
+    (302, 20000, (2, 1), [2], [[0], []]),                    # AND part: the synonym's mask is OR-ed into the restriction
+    (303, 20000, (2, 2), [2, 2, 2], [[0, 1], [2]]),          # two synonyms on one AND part
+    (304, 20000, (1, 3, 1), [2], [[0], [], []]),             # a NOT part among them
+    (305, 700, (1, 1), [2, 2], [[0], [1]]),                  # mergeLimit + the preselect path with synonym terms in the scores, ties across shards
+    (306, 450, (2, 1), [2], [[0], []]),                      # ... with an AND part
+    (307, 20000, (1, 1, 1), [3], [[], [0], []]),             # a three-word synonym on the middle part
+]
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+@pytest.mark.parametrize("seed,limit,ops,syn_sizes,part_syn", SHARDED_SYN_CASES)
+def test_multi_word_synonyms_over_document_range_shards(rxgpu, hostapi, ft, shards, seed, limit, ops, syn_sizes, part_syn):
+    """QueryMergeData::synonyms over a device list (mergerimpl.h:347-361, 509-555): a synonym's mask, the term counting, containsFullMultiWordSynonym
+    and the removal of the documents that hold only parts of a synonym are decided per DOCUMENT, and a document lies in one shard — the sharded
+    merge = the single-device merger's result (which tests/test_gpu_ft_synonyms.py holds to the real ft::Merger), merge order included."""
+    nf, total = 2, 50_000
+    n_syn_terms = sum(syn_sizes)
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, tuple(ops) + (1,) * n_syn_terms, False, None, sizes=(3000, 12_000),
+                                                                 nsub_range=(1, 4))
+
+    def conv(t, op=None):
+        return dict(op=t["op"] if op is None else op, opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]], phrase=-1, distance=1)
+
+    parts = [conv(t) for t in terms[:len(ops)]]
+    synonyms, at = [], len(ops)
+    owner_op = {sid: parts[pi]["op"] for pi, ids in enumerate(part_syn) for sid in ids}
+    for sid, k in enumerate(syn_sizes):
+        synonyms.append([conv(t, op=owner_op.get(sid, 1)) for t in terms[at:at + k]])
+        at += k
+    # a duplicate: the first synonym term also finds a word of the first query part (SupressDuplicatesInSynonyms marks that sub-term)
+    synonyms[0][0]["subs"] = sorted(synonyms[0][0]["subs"] + [(parts[0]["subs"][0][0], 21.0)], key=lambda x: -x[1])
+    one = hostapi.GpuFtMerger(nf)
+    many = hostapi.GpuFtMerger(nf, devices=[0] * shards)
+    load(one, words, avg, removed, store)
+    load(many, words, avg, removed, store)
+    most = removed_partial = 0
+    for variant, (dboost, dweight) in enumerate(((1.0, 0.5), (1.7, 0.8))):
+        cfg = ft.default_config(nf, merge_limit=limit, min_rank=5 if variant == 0 else 40)
+        cfg["distance_boost"], cfg["distance_weight"] = dboost, dweight
+        for exc in (None, excluded):
+            a = one.merge_query(cfg, parts, exc, sort_by_rank=False, synonyms=synonyms, part_synonyms=part_syn)
+            b = many.merge_query(cfg, parts, exc, sort_by_rank=False, synonyms=synonyms, part_synonyms=part_syn)
+            assert same(a, b), (variant, exc is not None, len(a[0]), len(b[0]))
+            plain = many.merge_query(cfg, parts, exc, sort_by_rank=False)
+            most = max(most, len(b[0]))
+            removed_partial += int(len(plain[0]) != len(b[0]) or not np.array_equal(plain[0], b[0]))
+    assert most > 0 and removed_partial > 0   # the synonyms changed the result
+    one.close()
+    many.close()
 
 
 def test_query_batch_over_a_device_list_equals_the_single_merges(hostapi, ft):
