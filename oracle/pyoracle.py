@@ -925,9 +925,16 @@ class RefFtSeam(RefFt):
         self.L.ref_seam_set_config(self.h, cfg_d.ctypes.data, cfg_i.ctypes.data, fc.ctypes.data,
                                    {"rx": 0, "classic": 1, "word_count": 2}[cfg.get("bm25_type", "rx")])
 
-    def commit(self, device: int = 0) -> int:
-        """The end of IndexText::commitFulltextImpl in the patched tree: statistics + changed words go to the device mirrors."""
-        n = self.L.ref_seam_commit(self.h, device)
+    def commit(self, device: int = 0, devices=None) -> int:
+        """The end of IndexText::commitFulltextImpl in the patched tree: statistics + changed words go to the device mirrors.
+        devices=[d0, d1, ...]: mirrors over a device list (document-range shards), what RX_GPU_FT_INDEXES=<list> makes the patched tree build."""
+        if devices is not None and len(devices) > 1:
+            dv = np.ascontiguousarray(devices, np.int32)
+            self.L.ref_seam_commit_devices.restype = C.c_long
+            self.L.ref_seam_commit_devices.argtypes = [_vp, _vp, _sz]
+            n = self.L.ref_seam_commit_devices(self.h, dv.ctypes.data, dv.shape[0])
+        else:
+            n = self.L.ref_seam_commit(self.h, device)
         if n < 0:
             raise RuntimeError(self.L.ref_seam_last_error(self.h).decode(errors="replace"))
         return n

@@ -320,13 +320,20 @@ void ref_seam_set_config(void* h, const double* cfgD, const int* cfgI, const dou
 
 // what the patched IndexText::commitFulltextImpl does at the end of a commit: mirror (re)created, statistics and changed words handed over.
 // Returns the number of words on the device, -1 on error (message in ref_seam_last_error).
-long ref_seam_commit(void* h, int device) {
+// n_devices > 1: the mirror over a device list (what RX_GPU_FT_INDEXES=0-7 makes SyncGpuFtMirror construct: document-range shards).
+long ref_seam_commit_devices(void* h, const int* devices, size_t n_devices) {
 	auto* f = static_cast<SeamRef*>(h);
 	try {
 		const Stats stats = f->stats();
 		for (int packed = 0; packed < 2; ++packed) {
 			auto& mirror = packed ? f->packedMirror : f->plainMirror;
-			if (!mirror) mirror = std::make_shared<rxgpu::host::GpuFtMirror>(f->nf, device);
+			if (!mirror) {
+				if (n_devices > 1) {
+					mirror = std::make_shared<rxgpu::host::GpuFtMirror>(f->nf, std::vector<int>(devices, devices + n_devices));
+				} else {
+					mirror = std::make_shared<rxgpu::host::GpuFtMirror>(f->nf, n_devices ? devices[0] : 0);
+				}
+			}
 			mirror->SyncDocs(f->totalDocs, stats);
 			if (packed) {
 				mirror->SyncWords(f->packedWords);
@@ -340,6 +347,7 @@ long ref_seam_commit(void* h, int device) {
 		return -1;
 	}
 }
+long ref_seam_commit(void* h, int device) { return ref_seam_commit_devices(h, &device, 1); }
 
 // packed: 1 = QueryMergeData<PackedIdRelVec>, 0 = <IdRelVec>; gpu: 1 = TryMergeOnGpu, 0 = the reference's ft::Merger.
 // Returns the result count, -1 on an exception, -2 when the GPU branch declined the query (the CPU merger would run).

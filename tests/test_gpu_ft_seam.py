@@ -237,3 +237,41 @@ def test_patched_merge_results_branch_takes_multi_word_synonyms(rxgpu, ft, ops, 
                 _same(got, want, (limit, packed))
                 assert len(want[0]) > 0
     seam.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ops,syn_sizes,part_syn", SYN_SHAPES)
+def test_patched_merge_results_branch_over_a_device_list(rxgpu, ft, ops, syn_sizes, part_syn):
+    """The patched Selector::mergeResults branch with the mirror over a DEVICE LIST (RX_GPU_FT_INDEXES=0,0,0: document-range shards, SURVEY 8e):
+    term queries and multi-word synonyms are merged on the shards — identical to the reference's merger, both containers; a phrase is declined
+    (ShardedSupports) and the CPU merger runs."""
+    nf, total = 2, 30_000
+    n_syn_terms = sum(syn_sizes)
+    _, words, avg, removed, excluded, terms, store = _multi_case(640 + len(ops), nf, total, 20000, tuple(ops) + (1,) * n_syn_terms, False, None,
+                                                                 sizes=(2000, 9000), nsub_range=(1, 4))
+
+    def cv(t, op=None):
+        return dict(op=t["op"] if op is None else op, opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]])
+
+    parts = [cv(t) for t in terms[:len(ops)]]
+    owner_op = {sid: parts[pi]["op"] for pi, ids in enumerate(part_syn) for sid in ids}
+    synonyms, at = [], len(ops)
+    for sid, k in enumerate(syn_sizes):
+        synonyms.append([cv(t, owner_op.get(sid, 1)) for t in terms[at:at + k]])
+        at += k
+    seam = _seam(nf, words, avg, removed, store)
+    assert seam.commit(devices=[0, 0, 0]) == len(store)
+    for limit in (20000, 400):
+        seam.set_config(ft.default_config(nf, merge_limit=limit))
+        for exc in (None, excluded):
+            for packed in (True, False):
+                for syn in (None, synonyms):
+                    kw = dict(synonyms=syn, part_synonyms=part_syn) if syn else {}
+                    want = seam.merge(parts, exc, rank_sort_type=1, packed=packed, gpu=False, **kw)
+                    got = seam.merge(parts, exc, rank_sort_type=1, packed=packed, gpu=True, **kw)
+                    _same(got, want, (limit, packed, syn is not None))
+                    assert len(want[0]) > 0
+    if len(parts) >= 2:
+        phrase = [dict(parts[0], phrase=0, distance=2), dict(parts[1], op=parts[0]["op"], phrase=0, distance=2)] + [dict(p, phrase=-1) for p in parts[2:]]
+        assert seam.merge(phrase, None, rank_sort_type=1, packed=True, gpu=True) is None   # declined: the reference's merger answers
+    seam.close()
