@@ -101,6 +101,7 @@ _SIGNATURES = {
     "rxgpu_ft_shard_exchange_mode": (_i, [_vp]),
     "rxgpu_ft_shard_collectives": (_u64, [_vp]),
     "rxgpu_ft_shard_ranges": (_i, [_vp, _u32, _vp, _vp]),
+    "rxgpu_ft_word_df": (_i, [_vp, _u32, C.POINTER(_u64)]),
     "rxgpu_ft_destroy": (None, [_vp]),
     "rxgpu_ft_set_docs": (_i, [_vp, _u64, _vp, _vp, _vp]),
     "rxgpu_ft_set_word": (_i, [_vp, _u32, _u64, _vp, _vp, _vp, _vp, _vp]),

@@ -760,8 +760,20 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 	std::vector<int32_t> distance(T);
 	std::vector<rxgpu::FtGridEntry> grid;
 	std::vector<uint32_t> row_sub;   // first term: position of the row's sub-term in the caller's list
-	uint64_t grid_blocks = 0, term0_vdocs = 0;
+	uint64_t grid_blocks = 0, term0_vdocs = 0, term0_df = 0;
 	long long sum_proc = 0;
+	// A document-range shard: the rows of the phrase are numbered alike on every shard — one per sub-term of the first term that
+	// holds postings ANYWHERE in the index (word_df), with or without postings in this shard's documents — because the sharded layer adds the
+	// shards' [rows][ranges] tables up.  shard_row_grid: the row's entry in `grid`, -1 when this shard holds none of its postings.
+	const bool shard = h->sh_total > 1;
+	std::vector<uint32_t> shard_row_sub;
+	std::vector<int32_t> shard_row_grid;
+	auto empty_row = [&](uint32_t si) {
+		rxgpu::FtPosSubterm row{};
+		row.proc = procs[si];
+		row.phrase = 1;
+		return row;
+	};
 	for (uint32_t k = 0; k < T; ++k) {
 		const QueryTermIn& qt = terms[part.t_begin + k];
 		bool same, all_pos;
@@ -775,7 +787,14 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 			RX_CHECK(w.n == 0 || w.fpos, RXGPU_ERR_LOGIC, std::string(who) + ": the word was uploaded without positions (rxgpu_ft_set_word_positions)");
 			RX_CHECK(si == qt.sub_begin || procs[si] <= procs[si - 1], RXGPU_ERR_PARAMS,
 					 std::string(who) + ": sub-terms must be sorted by proc, descending (SortSubterms)");
-			if (k == 0) term0_vdocs += w.n;
+			if (k == 0) {
+				term0_vdocs += w.n;
+				term0_df += word_df(w);
+				if (shard && word_df(w)) {
+					shard_row_sub.push_back(si);
+					shard_row_grid.push_back(w.n ? int32_t(grid.size()) : -1);
+				}
+			}
 			out.postings += w.n;
 			if (!w.n) continue;
 			rxgpu::FtPosSubterm ft = word_subterm(w, bm25_type, N, procs[si]);
@@ -793,8 +812,15 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 	RX_CHECK(sum_proc >= 0 && sum_proc < 65535, RXGPU_ERR_PARAMS, std::string(who) + ": the procs of a phrase's terms add up to 65535 or more");
 	out.proc16 = uint32_t(sum_proc);
 	const uint32_t n_rows0 = uint32_t(grid.size());
+	// the admission cut (phrasemerger.h:341: at most min(mergeLimit, the first term's documents) documents, in (row, document) order) runs over the
+	// WHOLE first term: over shards only a phrase that the cut cannot reach is merged — every shard then admits all of its candidates
+	RX_CHECK(!shard || term0_df <= cfg->merge_limit, RXGPU_ERR_LOGIC,
+			 std::string(who) + ": a sharded ft index merges a phrase whose first term holds at most mergeLimit documents (the admission cut spans the shards)");
 	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, term0_vdocs);   // phrasemerger.h:341
-	if (!n_rows0 || !max_merged) return RXGPU_OK;   // the first term matched nothing: no document holds the phrase
+	if (!n_rows0 || !max_merged) {   // the first term matched nothing (here): no document (of this shard) holds the phrase
+		for (const uint32_t si : shard_row_sub) out.rows.push_back(empty_row(si));
+		return RXGPU_OK;
+	}
 	RX_CHECK(grid_blocks * rxgpu::kFtBlockPostings < 0xFFFFFFFFull, RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^32 (padded) postings in one phrase term");
 	const uint32_t n_ranges = uint32_t((N + rxgpu::kFtRangeDocs - 1) / rxgpu::kFtRangeDocs);
 	const size_t M = size_t(max_merged);
@@ -918,6 +944,7 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 	const uint32_t* hdr = reinterpret_cast<const uint32_t*>(hp);
 	RX_CHECK(hdr[0] == admitted && hdr[2] <= admitted, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt phrase header");
 	size_t row_base = 0;
+	std::vector<rxgpu::FtPosSubterm> packed(n_rows0);   // by grid row; n == 0: the row came out empty
 	for (uint32_t r = 0; r < n_rows0; ++r) {
 		const uint32_t cnt = hdr[4 + r];
 		if (cnt) {
@@ -932,9 +959,14 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 			row.range_off = p.out_range_off + size_t(r) * (n_ranges + 1);
 			row.n_ranges = n_ranges;
 			row.phrase = 1;
-			out.rows.push_back(row);
+			packed[r] = row;
+			if (!shard) out.rows.push_back(row);
 		}
 		row_base += (size_t(cnt) + 1 + pad - 1) / pad * pad;
+	}
+	for (size_t j = 0; j < shard_row_sub.size(); ++j) {   // a shard: every row of the index, the empty ones included
+		const int32_t g = shard_row_grid[j];
+		out.rows.push_back(g >= 0 && packed[size_t(g)].n ? packed[size_t(g)] : empty_row(shard_row_sub[j]));
 	}
 	return RXGPU_OK;
 }
@@ -1093,7 +1125,9 @@ bool ft_sparse_eligible(const rxgpu_ft_index* h, const rxgpu_ft_config* cfg, con
 // enqueued on `st`: the lane's own stream for a single merge, the batch stream when Q lanes' merges go into one train.
 int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 				  const float* procs, const uint8_t* excluded, bool have_outs, uint64_t cap, const char* who, bool resident, const SynonymsIn* synonyms,
-				  MergeJob& job, bool import_now, uint32_t max_areas = 0) {
+				  MergeJob& job, bool import_now, uint32_t max_areas = 0, std::vector<PhraseRows>* shard_phrases = nullptr, int phrase_mode = 0) {
+	// shard_phrases / phrase_mode (document-range shards): 1 = run the query's phrases only and hand their rows out (nothing else is prepared);
+	// 2 = the rows come in, `admitted` holding the sum over the shards (the 2-phase estimate is a fact of the whole index).
 	using clk = std::chrono::steady_clock;
 	const auto t_begin = clk::now();
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
@@ -1160,9 +1194,6 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 
 	bool any_phrase = false;
 	for (const QueryPartIn& part : parts) any_phrase = any_phrase || part.phrase;
-	// (a document-range shard: a phrase's admission under mergeLimit runs over the whole first term, phrasemerger.h:341 — refused before any kernel runs)
-	RX_CHECK(h->sh_total <= 1 || !any_phrase, RXGPU_ERR_LOGIC,
-			 std::string(who) + ": a sharded ft index merges terms and multi-word synonyms (no phrases, areas or resident results)");
 	// the launch train: the sparse one for eligible queries whose postings lie on a fraction of the documents (or on request)
 	bool sparse = false;
 	{
@@ -1197,9 +1228,19 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	// ---- phrases first (Merger::init, merger.h:73-81): every PhraseMerger runs before the query parts are looked at
 	std::vector<PhraseRows> phrase_rows(nparts);
 	size_t n_phrases = 0;
-	for (uint32_t pi = 0; pi < nparts; ++pi) {
-		if (!parts[pi].phrase) continue;
-		if (int rc = run_phrase(h, cfg, terms, parts[pi], word_ids, procs, d_excluded, n_phrases++, phrase_rows[pi], who); rc) return rc;
+	if (phrase_mode == 2) {
+		RX_CHECK(shard_phrases && shard_phrases->size() == nparts, RXGPU_ERR_LOGIC, std::string(who) + ": phrase rows of another query");
+		phrase_rows = *shard_phrases;
+		for (uint32_t pi = 0; pi < nparts; ++pi) n_phrases += parts[pi].phrase ? 1 : 0;
+	} else {
+		for (uint32_t pi = 0; pi < nparts; ++pi) {
+			if (!parts[pi].phrase) continue;
+			if (int rc = run_phrase(h, cfg, terms, parts[pi], word_ids, procs, d_excluded, n_phrases++, phrase_rows[pi], who); rc) return rc;
+		}
+		if (phrase_mode == 1) {
+			*shard_phrases = std::move(phrase_rows);
+			return RXGPU_OK;
+		}
 	}
 
 	// 2-phase gate, host half (estimateNumDocsInMerge, merger.h:239-267; mergerimpl.h:486-490)
@@ -1529,8 +1570,8 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	if (h->sh_total > 1) {   // a document-range shard: its own ranges, the facts that span the shards arrive between the kernels
 		// (multi-word synonyms are fine: their masks, term counts and the "only parts of a synonym" marks are facts of ONE document, and a
 		// document lies in one shard — ft_syn_masks sees this shard's fragments, the caller drops the marked documents after the union)
-		RX_CHECK(!resident && !max_areas && n_phrases == 0, RXGPU_ERR_LOGIC,
-				 std::string(who) + ": a sharded ft index merges terms and multi-word synonyms (no phrases, areas or resident results)");
+		RX_CHECK(!resident && !max_areas, RXGPU_ERR_LOGIC, std::string(who) + ": a sharded ft index merges into the caller's lists (no areas or resident results)");
+		RX_CHECK(n_phrases == 0 || phrase_mode == 2, RXGPU_ERR_LOGIC, std::string(who) + ": a shard's phrases are run by the sharded layer");
 		p.range_begin = h->sh_range_begin;
 		p.range_count = h->sh_range_count;
 		p.shard_index = h->sh_index;
@@ -1723,14 +1764,44 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 	std::vector<bool> active(S, false);
 	bool empty = false;
 	for (size_t s = 0; s < S; ++s) {
+		locks.emplace_back(ss->shards[s]->mtx);
+		dicts.emplace_back(ss->shards[s]->dict_mtx);
+	}
+	// Phrases first, on every shard (Merger::init, merger.h:73-81): a phrase is decided inside a document, so every shard runs PhraseMerger over
+	// its own fragments; what spans the shards is NumDocsMerged() — the 2-phase estimate takes the sum — and the numbering of the phrase's rows.
+	bool any_phrase = false;
+	for (const QueryTermIn& t : terms) any_phrase = any_phrase || t.phrase_num >= 0;
+	std::vector<std::vector<PhraseRows>> phrases(S);
+	if (any_phrase) {
+		for (size_t s = 0; s < S; ++s) {
+			RX_HIP(hipSetDevice(ss->devices[s]));
+			MergeJob scratch;
+			if (int rc = prepare_merge(ss->shards[s], ss->shards[s]->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, synonyms,
+									   scratch, true, 0, &phrases[s], 1);
+				rc)
+				return rc;
+			if (scratch.empty) return RXGPU_OK;   // min(mergeLimit, totalORVids) == 0: alike on every shard
+		}
+		for (size_t pi = 0; pi < phrases[0].size(); ++pi) {
+			uint64_t admitted = 0;
+			for (size_t s = 0; s < S; ++s) {
+				RX_CHECK(phrases[s].size() == phrases[0].size() && phrases[s][pi].rows.size() == phrases[0][pi].rows.size(), RXGPU_ERR_LOGIC,
+						 std::string(who) + ": the shards disagree on the rows of a phrase");
+				admitted += phrases[s][pi].admitted;
+			}
+			for (size_t s = 0; s < S; ++s) phrases[s][pi].admitted = uint32_t(std::min<uint64_t>(admitted, 0xFFFFFFFFull));
+		}
+	}
+	for (size_t s = 0; s < S; ++s) {
 		rxgpu_ft_index* sh = ss->shards[s];
-		locks.emplace_back(sh->mtx);
-		dicts.emplace_back(sh->dict_mtx);
 		RX_HIP(hipSetDevice(ss->devices[s]));
 		active[s] = sh->sh_range_count != 0;
 		sh->sh_hist = static_cast<const uint32_t*>(ss->d_recv[0][ss->shard_rank[s]].ptr);
 		sh->sh_pos = ss->d_pos[ss->shard_rank[s]];
-		if (int rc = prepare_merge(sh, sh->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, synonyms, jobs[s], true, 0); rc) return rc;
+		if (int rc = prepare_merge(sh, sh->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, synonyms, jobs[s], true, 0,
+								   any_phrase ? &phrases[s] : nullptr, any_phrase ? 2 : 0);
+			rc)
+			return rc;
 		empty = empty || jobs[s].empty;
 		sh->clean_dirty = !jobs[s].empty;   // an error return from here on leaves the kept-clean tables in an unknown state
 	}
@@ -2337,6 +2408,20 @@ int rxgpu_ft_read_packed_wall(rxgpu_ft_index* h, double* wall_ms) {
 	std::lock_guard<std::mutex> lk(h->mtx);
 	*wall_ms = h->packed_wall_ms;
 	h->packed_wall_ms = 0.0;
+	return RXGPU_OK;
+}
+
+int rxgpu_ft_word_df(rxgpu_ft_index* h, uint32_t word_id, uint64_t* out_df) {
+	RX_CHECK(h && out_df, RXGPU_ERR_PARAMS, "rxgpu_ft_word_df: null argument");
+	*out_df = 0;
+	rxgpu_ft_index* src = h;
+	if (h->shard_set) {   // every shard keeps the word's entry with the whole list's length
+		if (h->shard_set->shards.empty()) return RXGPU_OK;
+		src = h->shard_set->shards[0];
+	}
+	std::shared_lock<std::shared_mutex> dict_lk(src->dict_mtx);
+	const auto it = src->words.find(word_id);
+	if (it != src->words.end()) *out_df = word_df(it->second);
 	return RXGPU_OK;
 }
 

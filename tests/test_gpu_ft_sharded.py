@@ -223,17 +223,80 @@ def test_what_a_sharded_ft_index_does_not_offer_says_so(rxgpu, hostapi, ft):
     m = hostapi.GpuFtMerger(nf, devices=[0, 0])
     with pytest.raises(Exception, match="rxgpu_ft_set_docs first"):
         m.set_word_fpos(0, dict(doc=np.array([1], np.uint32), pos_off=np.array([0, 1], np.uint32), fpos=np.array([3], np.uint64), proc=1.0))
-    # a phrase needs a single-device merger (its admission under mergeLimit runs over the whole first term): refused, not answered wrongly
+    # a phrase whose first term holds more documents than mergeLimit needs a single-device merger (the admission cut of the PhraseMerger,
+    # phrasemerger.h:341, runs over the whole first term): refused before any kernel runs, not answered wrongly
     total = 20_000
     _, words, avg, removed, excluded, terms, store = _multi_case(41, nf, total, 20000, (1, 1), False, None, sizes=(500, 2000))
     load(m, words, avg, removed, store)
-    cfg = ft.default_config(nf, merge_limit=20000)
     phrase = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]], phrase=0, distance=2) for t in terms]
-    with pytest.raises(Exception, match="no phrases"):
-        m.merge_query(cfg, phrase, None, sort_by_rank=False)
+    with pytest.raises(Exception, match="at most mergeLimit documents"):
+        m.merge_query(ft.default_config(nf, merge_limit=300), phrase, None, sort_by_rank=False)
     plain = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
-    assert len(m.merge_query(cfg, plain, None, sort_by_rank=False)[0]) > 0   # ... and the merger works on
+    assert len(m.merge_query(ft.default_config(nf, merge_limit=300), plain, None, sort_by_rank=False)[0]) > 0   # ... and the merger works on
+    assert len(m.merge_query(ft.default_config(nf, merge_limit=20000), phrase, None, sort_by_rank=False)[0]) >= 0
     m.close()
+
+
+SHARDED_PHRASE_CASES = [
+    # (seed, nf, limit, ops, phrases, distances, nsub_range)
+    (401, 1, 30000, (1, 1), (0, 0), (1, 8), (1, 4)),                          # the query IS one phrase
+    (402, 2, 30000, (1, 1, 1), (0, 0, 0), (1, 12, 12), (2, 5)),               # three terms, several sub-terms each
+    (403, 2, 30000, (1, 1, 1), (-1, 0, 0), (1, 1, 10), (1, 4)),               # term OR phrase
+    (404, 2, 30000, (2, 2, 1), (0, 0, -1), (1, 15, 1), (2, 4)),               # AND phrase: restricts the term
+    (405, 2, 30000, (1, 3, 3), (-1, 0, 0), (1, 1, 15), (2, 4)),               # NOT phrase
+    (406, 2, 30000, (1, 1, 1, 1, 1), (-1, 0, 0, -1, -1), (1, 1, 9, 1, 1), (1, 4)),   # terms around a phrase
+    (407, 2, 30000, (1, 1, 1, 1), (0, 0, 1, 1), (1, 9, 1, 14), (1, 4)),       # two phrases in a row
+]
+
+
+@pytest.mark.parametrize("shards", [2, 3])
+@pytest.mark.parametrize("seed,nf,limit,ops,phrases,distances,nsub", SHARDED_PHRASE_CASES)
+def test_phrases_over_document_range_shards(rxgpu, hostapi, ft, shards, seed, nf, limit, ops, phrases, distances, nsub):
+    """PhraseResults over a device list (phrasemergerimpl.h:161-329): a phrase is decided inside a document, so every shard runs PhraseMerger
+    over its fragments; the rows of the phrase are numbered alike on every shard and NumDocsMerged() (the 2-phase estimate) is the sum.  The
+    sharded merge = the single-device merger's (tests/test_gpu_ft_phrases.py holds that one to the real ft::Merger), merge order included.
+    One sub-term of the first phrase term lives in ONE shard only (an empty fragment on the other, active, shards)."""
+    total = 40_000
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, False, None, sizes=(2000, 6000), nsub_range=nsub)
+    first_phrase_term = next(i for i, ph in enumerate(phrases) if ph >= 0)
+    lone = terms[first_phrase_term]["subs"][-1]
+    keep = lone["doc"] < 8192   # the lowest-proc sub-term of the phrase's first term: postings in the first document range only
+    pos_off = lone["pos_off"]
+    sel = np.concatenate([np.arange(pos_off[i], pos_off[i + 1]) for i in np.flatnonzero(keep)]) if keep.any() else np.zeros(0, np.int64)
+    lens = (pos_off[1:] - pos_off[:-1])[keep]
+    lone["doc"], lone["fpos"] = lone["doc"][keep], lone["fpos"][sel.astype(np.int64)]
+    lone["pos_off"] = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    q = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]], phrase=int(ph), distance=int(d))
+         for t, ph, d in zip(terms, phrases, distances)]
+    one = hostapi.GpuFtMerger(nf)
+    many = hostapi.GpuFtMerger(nf, devices=[0] * shards)
+    load(one, words, avg, removed, store)
+    load(many, words, avg, removed, store)
+    import ctypes
+    for m in (one, many):   # the whole list's length on either handle (a shard holds a fragment)
+        for sub in (lone, terms[0]["subs"][0]):
+            df = ctypes.c_uint64(0)
+            assert rxgpu.lib().rxgpu_ft_word_df(m.device_index, sub["word"], ctypes.byref(df)) == 0 and df.value == len(sub["doc"])
+    most, differs = 0, False
+    for variant, (dboost, dweight) in enumerate(((1.0, 0.5), (1.7, 0.8))):
+        for lim in (limit, 2500):   # 2500: above every first phrase term's document count?  else the refusal is the expected answer
+            cfg = ft.default_config(nf, merge_limit=lim, min_rank=5 if variant == 0 else 40)
+            cfg["distance_boost"], cfg["distance_weight"] = dboost, dweight
+            for exc in (None, excluded):
+                a = one.merge_query(cfg, q, exc, sort_by_rank=False)
+                try:
+                    b = many.merge_query(cfg, q, exc, sort_by_rank=False)
+                except Exception as e:
+                    assert lim == 2500 and "at most mergeLimit documents" in str(e), (lim, e)
+                    continue
+                assert same(a, b), (variant, lim, exc is not None, len(a[0]), len(b[0]))
+                most = max(most, len(b[0]))
+                if variant == 0 and exc is None:   # the phrase is not the same query as its terms
+                    c = many.merge_query(cfg, [dict(t, phrase=-1) for t in q], exc, sort_by_rank=False)
+                    differs = differs or len(c[0]) != len(b[0]) or not np.array_equal(c[1].view(np.uint32), b[1].view(np.uint32))
+    assert most > 0 and differs
+    one.close()
+    many.close()
 
 
 SHARDED_SYN_CASES = [
