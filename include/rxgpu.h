@@ -379,8 +379,9 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h);
  * document lies in one shard; the marked documents go after the union of the shards' slots), and so do phrases (PhraseMerger runs on every
  * shard over its fragments — a phrase is decided inside a document —, the rows of a phrase are numbered alike on every shard, NumDocsMerged()
  * in the 2-phase estimate is the sum) as long as the phrase's first term holds at most merge_limit documents (rxgpu_ft_word_df): the
- * admission cut of phrasemerger.h:341 would span the shards, such a query returns RXGPU_ERR_LOGIC before any kernel runs.  Areas, packed
- * uploads, batches and resident (hybrid) merges are single-device features: RXGPU_ERR_LOGIC here. */
+ * admission cut of phrasemerger.h:341 would span the shards, such a query returns RXGPU_ERR_LOGIC before any kernel runs.
+ * rxgpu_ft_merge_query_areas_raw works there as well (a document's areas are built by the shard that holds it, at its global merge slot).
+ * Packed uploads, batches and resident (hybrid) merges are single-device features: RXGPU_ERR_LOGIC here. */
 int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* devices, rxgpu_ft_index** out);
 uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h);           /* 0 for an unsharded index */
 /* The cut of a sharded index is fixed by the first rxgpu_ft_set_docs and kept while the shards hold words: an index that grows through

@@ -1570,7 +1570,7 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	if (h->sh_total > 1) {   // a document-range shard: its own ranges, the facts that span the shards arrive between the kernels
 		// (multi-word synonyms are fine: their masks, term counts and the "only parts of a synonym" marks are facts of ONE document, and a
 		// document lies in one shard — ft_syn_masks sees this shard's fragments, the caller drops the marked documents after the union)
-		RX_CHECK(!resident && !max_areas, RXGPU_ERR_LOGIC, std::string(who) + ": a sharded ft index merges into the caller's lists (no areas or resident results)");
+		RX_CHECK(!resident, RXGPU_ERR_LOGIC, std::string(who) + ": a sharded ft index merges into the caller's lists (no resident results)");
 		RX_CHECK(n_phrases == 0 || phrase_mode == 2, RXGPU_ERR_LOGIC, std::string(who) + ": a shard's phrases are run by the sharded layer");
 		p.range_begin = h->sh_range_begin;
 		p.range_count = h->sh_range_count;
@@ -1742,8 +1742,10 @@ inline char* ft_send_ptr(rxgpu_ft_shard_set* ss, int k, size_t s, size_t bytes) 
 // between them, every shard's packed result, the slot-wise union.
 int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool simple, const std::vector<QueryTermIn>& terms, const uint32_t* word_ids,
 					  const float* procs, const uint8_t* excluded, uint32_t* out_doc, float* out_proc, uint8_t* out_field, uint16_t* out_terms_counter,
-					  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, const SynonymsIn* synonyms = nullptr) {
+					  uint64_t cap, uint64_t* out_n, int32_t* out_preselected, const char* who, const SynonymsIn* synonyms = nullptr,
+					  const AreasOut* areas = nullptr) {
 	rxgpu_ft_shard_set* ss = parent->shard_set;
+	const uint32_t max_areas = areas ? areas->max_areas : 0u;
 	const size_t S = ss->shards.size();
 	RX_CHECK(ss->n_ranges > 0, RXGPU_ERR_LOGIC, std::string(who) + ": rxgpu_ft_set_docs was not called");
 	int prev_dev = -1;
@@ -1777,7 +1779,7 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 			RX_HIP(hipSetDevice(ss->devices[s]));
 			MergeJob scratch;
 			if (int rc = prepare_merge(ss->shards[s], ss->shards[s]->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, synonyms,
-									   scratch, true, 0, &phrases[s], 1);
+									   scratch, true, max_areas, &phrases[s], 1);
 				rc)
 				return rc;
 			if (scratch.empty) return RXGPU_OK;   // min(mergeLimit, totalORVids) == 0: alike on every shard
@@ -1798,7 +1800,7 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 		active[s] = sh->sh_range_count != 0;
 		sh->sh_hist = static_cast<const uint32_t*>(ss->d_recv[0][ss->shard_rank[s]].ptr);
 		sh->sh_pos = ss->d_pos[ss->shard_rank[s]];
-		if (int rc = prepare_merge(sh, sh->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, synonyms, jobs[s], true, 0,
+		if (int rc = prepare_merge(sh, sh->stream, cfg, simple, terms, word_ids, procs, excluded, true, cfg->merge_limit, who, false, synonyms, jobs[s], true, max_areas,
 								   any_phrase ? &phrases[s] : nullptr, any_phrase ? 2 : 0);
 			rc)
 			return rc;
@@ -1862,6 +1864,18 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 		RX_HIP(hipSetDevice(ss->devices[s]));
 		RX_HIP(rxgpu::launch_ft_export(jobs[s].d_plan, &jobs[s].p, 1, ss->shards[s]->stream));
 	}
+	// MergeDataAreas: {held, insertions} per (merge slot, field) and the areas as every shard's replay left them — a document's areas are
+	// built where the document lies, at its GLOBAL merge slot, so the caller's arrays are the slot-wise union too
+	const size_t nf = parent->num_fields;
+	std::vector<std::vector<uint32_t>> area_hdr(areas ? S : 0), area_data(areas ? S : 0);
+	for (size_t s = 0; s < S && areas; ++s) {
+		if (!active[s]) continue;
+		RX_HIP(hipSetDevice(ss->devices[s]));
+		area_hdr[s].resize(size_t(M) * nf * 2);
+		area_data[s].resize(jobs[s].area_bytes / sizeof(uint32_t));
+		RX_HIP(hipMemcpyAsync(area_hdr[s].data(), jobs[s].p.area_hdr, area_hdr[s].size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ss->shards[s]->stream));
+		RX_HIP(hipMemcpyAsync(area_data[s].data(), jobs[s].p.out_areas, jobs[s].area_bytes, hipMemcpyDeviceToHost, ss->shards[s]->stream));
+	}
 	for (size_t s = 0; s < S; ++s) {
 		RX_HIP(hipSetDevice(ss->devices[s]));
 		RX_HIP(hipStreamSynchronize(ss->shards[s]->stream));
@@ -1899,6 +1913,11 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 			out_proc[i] = sp[i];
 			if (out_terms_counter) out_terms_counter[i] = st_[i];
 			out_field[i] = sf[i];
+			if (areas) {
+				const size_t per_doc = nf * size_t(max_areas) * 3;
+				for (size_t f = 0; f < nf; ++f) areas->cnt[i * nf + f] = area_hdr[s][(i * nf + f) * 2];
+				std::memcpy(areas->areas + i * per_doc, area_data[s].data() + i * per_doc, per_doc * sizeof(uint32_t));
+			}
 		}
 	}
 	for (uint64_t i = 0; i < n; ++i) RX_CHECK(filled[i], RXGPU_ERR_DEVICE, std::string(who) + ": a merge slot no shard wrote");
@@ -1927,10 +1946,10 @@ int run_merge(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, bool simple, const 
 			  const AreasOut* areas = nullptr) {
 	using clk = std::chrono::steady_clock;
 	if (h->shard_set) {   // document-range shards: the same train on every shard, two exchanges between its pieces
-		RX_CHECK(!resident && !areas, RXGPU_ERR_LOGIC, std::string(who) + ": a sharded ft index merges terms and multi-word synonyms (no areas or resident results)");
+		RX_CHECK(!resident, RXGPU_ERR_LOGIC, std::string(who) + ": a sharded ft index merges into the caller's lists (no resident results)");
 		RX_CHECK(out_doc && out_proc && out_field && (simple || out_terms_counter), RXGPU_ERR_OVERFLOW, std::string(who) + ": output buffers too small");
 		return run_merge_sharded(h, cfg, simple, terms, word_ids, procs, excluded, out_doc, out_proc, out_field, out_terms_counter, cap, out_n, out_preselected, who,
-								 synonyms);
+								 synonyms, areas);
 	}
 	if (int rc = finish_pending(h, who); rc) return rc;
 	auto since = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };

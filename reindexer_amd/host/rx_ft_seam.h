@@ -321,7 +321,7 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		QuerySynonyms synonyms;
 		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
 		if (!GpuFtMerger::SupportsAreas(terms.size(), hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;
-		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;   // a device list: no phrases, no areas
+		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty(), maxAreasInDoc)) return false;
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
 		if (docsExcluded.PopCount() != 0) {

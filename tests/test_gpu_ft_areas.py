@@ -119,3 +119,28 @@ def test_phrases_and_unlimited_areas_are_declined(rxgpu, ft):
     assert seam.merge_areas(plain, -1, None, gpu=True) is None            # maxAreasInDoc <= 0 (unlimited): CPU merger
     assert seam.merge_areas(plain, 5, None, gpu=True) is not None
     seam.close()
+
+
+@pytest.mark.parametrize("seed,nf,total,limit,ops,arr,max_areas,nsub", [
+    (21, 2, 30_000, 20000, (1,), False, 5, (2, 4)),           # Simple() with areas over three shards
+    (22, 2, 30_000, 20000, (1, 1, 1), False, 5, (2, 4)),      # OR terms: a document gathers areas from several terms, on the shard it lies in
+    (23, 3, 30_000, 20000, (2, 1, 1), True, 3, (1, 3)),       # AND restriction, array positions
+    (24, 2, 30_000, 900, (1, 1), False, 2, (2, 5)),           # mergeLimit cut + preselect across the shards, the circular overwrite
+])
+def test_areas_over_a_device_list_equal_the_real_merger(rxgpu, ft, seed, nf, total, limit, ops, arr, max_areas, nsub):
+    """MergeDataAreas<Area> with the mirror over a DEVICE LIST (document-range shards): a document's areas are built by the shard
+    that holds it, at the document's global merge slot — the slot-wise union of the shards' area arrays is the single merger's, i.e. the real
+    ft::Merger<IdCont, MergeDataAreas<Area>>'s, raw and committed."""
+    _, words, avg, removed, excluded, terms, store = _multi_case(seed, nf, total, limit, ops, arr, None, sizes=(2500, 11_000), nsub_range=nsub)
+    seam = _seam(nf, words, avg, removed, store)
+    seam.set_config(ft.default_config(nf, merge_limit=limit, min_rank=5))
+    assert seam.commit(devices=[0, 0, 0]) == len(store)
+    q = [dict(op=t["op"], opts=t["opts"], subs=[(s["word"], s["proc"]) for s in t["subs"]]) for t in terms]
+    total_areas = 0
+    for exc in (None, excluded):
+        for packed in (True, False):
+            want = seam.merge_areas(q, max_areas, exc, rank_sort_type=1, packed=packed, gpu=False, cap=1 << 15, area_cap=1 << 22)
+            got = seam.merge_areas(q, max_areas, exc, rank_sort_type=1, packed=packed, gpu=True, cap=1 << 15, area_cap=1 << 22)
+            total_areas += _same(got, want, (seed, packed, exc is not None))
+    assert total_areas > 0
+    seam.close()
