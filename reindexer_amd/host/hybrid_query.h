@@ -34,9 +34,9 @@ inline HybridFused HybridQueryResident(const GpuBruteforceMap& map, const GpuFtM
 		NormalizeCopyVector(key, int32_t(map.Dim()), normalized.data());
 		q = normalized.data();
 	}
-	// The resident KNN list holds at most 128 entries (k + 1 <= 128) and lives on ONE device: a wider k or a sharded mirror takes the host-side
-	// pieces below straight away (same result; the fusion kernel itself takes k <= 1024)
-	const bool residentFits = k + 1 <= 128 && !map.Sharded();
+	// The resident KNN list holds at most 128 entries (k + 1 <= 128) and lives on ONE device, the resident merge likewise: a wider k, a sharded
+	// mirror or a merger over a device list takes the host-side pieces below straight away (same result; the fusion kernel itself takes k <= 1024)
+	const bool residentFits = k + 1 <= 128 && !map.Sharded() && !ft.Sharded();
 	HybridFused fused;
 	if (residentFits) {
 	// FT half first: the merge train and the FT-only part of the fusion (postProcessResults, the sort by id, the class tables) are on the

@@ -81,6 +81,15 @@ def test_hybrid_resident_wide_k_and_sharded_mirror_take_the_host_pieces(rxgpu, o
     narrow = hostapi.hybrid_query_resident(one, ftm, cfg, terms, key, 50, kind="rrf", params=[60.0], union=True, desc=True)
     sharded = hostapi.hybrid_query_resident(many, ftm, cfg, terms, key, 50, kind="rrf", params=[60.0], union=True, desc=True)
     assert np.array_equal(narrow[0], sharded[0]) and np.array_equal(narrow[1].view(np.uint32), sharded[1].view(np.uint32))
+    # ... and with the text index over a device list (document-range shards): the FT half is merged over the shards, the fusion runs on the host
+    ftmany = hostapi.GpuFtMerger(1, devices=[0, 0])
+    ftmany.set_docs(words, avg, None)
+    for s in store:
+        ftmany.set_word_fpos(s["word"], s)
+    for vm in (one, many):
+        both = hostapi.hybrid_query_resident(vm, ftmany, cfg, terms, key, 50, kind="rrf", params=[60.0], union=True, desc=True)
+        assert np.array_equal(narrow[0], both[0]) and np.array_equal(narrow[1].view(np.uint32), both[1].view(np.uint32))
+    ftmany.close()
     for k in (127, 128, 300):
         wide = hostapi.hybrid_query_resident(one, ftm, cfg, terms, key, k, kind="rrf", params=[60.0], union=True, desc=True)
         # the same fusion from the separate product calls
