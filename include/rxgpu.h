@@ -376,10 +376,10 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h);
  * (rxgpu_ft_shard_exchange_mode 1 = on the devices, 0 = through the host).  The result is the single
  * index's, bit for bit, in merge order.  rxgpu_ft_merge_query2_raw's multi-word synonyms run there too (a synonym's mask, the term
  * counting and the removal of documents that hold only parts of it, mergerimpl.h:347-361 / 509-555, are decided per document, and a
- * document lies in one shard; the marked documents go after the union of the shards' slots), and so do phrases (PhraseMerger runs on every
- * shard over its fragments — a phrase is decided inside a document —, the rows of a phrase are numbered alike on every shard, NumDocsMerged()
- * in the 2-phase estimate is the sum) as long as the phrase's first term holds at most merge_limit documents (rxgpu_ft_word_df): the
- * admission cut of phrasemerger.h:341 would span the shards, such a query returns RXGPU_ERR_LOGIC before any kernel runs.
+ * document lies in one shard; the marked documents go after the union of the shards' slots), and so do phrases: PhraseMerger runs on every
+ * shard over its fragments — a phrase is decided inside a document —, the rows of a phrase are numbered alike on every shard, the admission
+ * cut of the whole index (at most merge_limit candidates of the first term in (row, document) order, phrasemerger.h:341) is settled between
+ * the shards' admission passes, NumDocsMerged() in the 2-phase estimate is the sum.
  * rxgpu_ft_merge_query_areas_raw works there as well (a document's areas are built by the shard that holds it, at its global merge slot).
  * Packed uploads, batches and resident (hybrid) merges are single-device features: RXGPU_ERR_LOGIC here. */
 int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* devices, rxgpu_ft_index** out);
@@ -392,8 +392,7 @@ int rxgpu_ft_shard_exchange_mode(const rxgpu_ft_index* h);        /* 1 on the de
 uint64_t rxgpu_ft_shard_collectives(const rxgpu_ft_index* h);     /* all-gathers issued so far */
 int rxgpu_ft_shard_ranges(const rxgpu_ft_index* h, uint32_t shard, uint32_t* range_begin, uint32_t* range_count);   /* the shard's run of 8192-document ranges */
 /* Documents that hold the word over the WHOLE index (a sharded handle: the length of the whole list, not of a shard's fragment); 0 for a
- * word the index does not know.  What a caller needs to tell whether a phrase can be merged over shards (its first term's documents must not
- * exceed mergeLimit: PhraseMerger's admission cut, phrasemerger.h:341, spans the shards). */
+ * word the index does not know (MaxVDocs of a sub-term: what the merge limits and the 2-phase estimate are computed from). */
 int rxgpu_ft_word_df(rxgpu_ft_index* h, uint32_t word_id, uint64_t* out_df);
 /* The DocsStatsGetter of IndexText (cpp_src/core/index/indextext/indextext.h:245-258): total_docs counts the empty sentinel
  * vdoc 0 ("first doc is always empty"); words_in_field [total_docs][num_fields] = VDoc::wordCounts_; avg_words [num_fields];

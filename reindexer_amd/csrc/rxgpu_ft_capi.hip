@@ -743,15 +743,29 @@ rxgpu::FtPosSubterm word_subterm(const rxgpu_ft_word& w, int bm25_type, uint64_t
 	return ft;
 }
 
+// A phrase between its admission pass and the rest (a document-range shard: the sharded layer settles the admission cut of the WHOLE index —
+// at most mergeLimit documents in (row, document) order, phrasemerger.h:341 — before any shard goes on; finish_phrase)
+struct PhraseCtx {
+	rxgpu::FtPhrasePlan p{};
+	std::vector<uint32_t> row_sub, shard_row_sub;
+	std::vector<int32_t> shard_row_grid;
+	std::vector<uint32_t> row_admitted;   // by the row numbering all shards share: documents this shard admitted for that row
+	uint32_t n_rows0 = 0, n_ranges = 0, admitted = 0;
+	uint64_t sum_caps = 0;
+	size_t phrase_index = 0;
+	bool shard = false;
+};
 // One phrase through ft_phrase.hip: the rows the main merge reads instead of words
 struct PhraseRows {
 	std::vector<rxgpu::FtPosSubterm> rows;   // non-empty rows, first-term sub-term order; device arrays live in the handle's phrase buffers
 	uint32_t admitted = 0;                   // PhraseMerger::NumDocsMerged()
 	uint32_t proc16 = 0;                     // PhraseResults::CalcProc16
 	uint64_t postings = 0;                   // postings of the phrase's words (statistics)
+	std::shared_ptr<PhraseCtx> pending;      // admission ran, finish_phrase has not yet (run_phrase(..., first_half_only))
 };
+int finish_phrase(rxgpu_ft_index* h, const float* procs, PhraseCtx& c, PhraseRows& out, const char* who);
 int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<QueryTermIn>& terms, const QueryPartIn& part, const uint32_t* word_ids,
-			   const float* procs, const uint8_t* d_excluded, size_t phrase_index, PhraseRows& out, const char* who) {
+			   const float* procs, const uint8_t* d_excluded, size_t phrase_index, PhraseRows& out, const char* who, bool first_half_only = false) {
 	const uint32_t nf = h->num_fields, T = part.t_end - part.t_begin;
 	const uint64_t N = h->total_docs;
 	const int bm25_type = cfg->bm25_type;
@@ -812,10 +826,7 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 	RX_CHECK(sum_proc >= 0 && sum_proc < 65535, RXGPU_ERR_PARAMS, std::string(who) + ": the procs of a phrase's terms add up to 65535 or more");
 	out.proc16 = uint32_t(sum_proc);
 	const uint32_t n_rows0 = uint32_t(grid.size());
-	// the admission cut (phrasemerger.h:341: at most min(mergeLimit, the first term's documents) documents, in (row, document) order) runs over the
-	// WHOLE first term: over shards only a phrase that the cut cannot reach is merged — every shard then admits all of its candidates
-	RX_CHECK(!shard || term0_df <= cfg->merge_limit, RXGPU_ERR_LOGIC,
-			 std::string(who) + ": a sharded ft index merges a phrase whose first term holds at most mergeLimit documents (the admission cut spans the shards)");
+	(void)term0_df;   // (the admission cut of the whole index — phrasemerger.h:341 — is settled by the sharded layer between the two halves)
 	const uint64_t max_merged = std::min<uint64_t>(cfg->merge_limit, term0_vdocs);   // phrasemerger.h:341
 	if (!n_rows0 || !max_merged) {   // the first term matched nothing (here): no document (of this shard) holds the phrase
 		for (const uint32_t si : shard_row_sub) out.rows.push_back(empty_row(si));
@@ -910,6 +921,56 @@ int run_phrase(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, const std::vector<
 	RX_CHECK(admitted <= max_merged, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt phrase admission count");
 	RX_CHECK(sum_caps < (1ull << 31), RXGPU_ERR_PARAMS, std::string(who) + ": more than 2^31 positions in the documents of one phrase (GPU engine limit)");
 	out.admitted = admitted;
+	auto ctx = std::make_shared<PhraseCtx>();
+	ctx->p = p;
+	ctx->row_sub = row_sub;
+	ctx->shard_row_sub = shard_row_sub;
+	ctx->shard_row_grid = shard_row_grid;
+	ctx->n_rows0 = n_rows0;
+	ctx->n_ranges = n_ranges;
+	ctx->admitted = admitted;
+	ctx->sum_caps = sum_caps;
+	ctx->phrase_index = phrase_index;
+	ctx->shard = shard;
+	if (first_half_only) {   // what this shard admitted, row by row (slot order IS (row, document) order): the sharded layer's cut needs it
+		std::vector<uint32_t> slot_row(admitted);
+		if (admitted) RX_HIP(hipMemcpy(slot_row.data(), p.slot_row, size_t(admitted) * 4, hipMemcpyDeviceToHost));
+		std::vector<uint32_t> by_grid(n_rows0, 0);
+		for (const uint32_t r : slot_row) {
+			RX_CHECK(r < n_rows0, RXGPU_ERR_DEVICE, std::string(who) + ": corrupt phrase admission rows");
+			++by_grid[r];
+		}
+		ctx->row_admitted.assign(shard_row_sub.size(), 0);
+		for (size_t j = 0; j < shard_row_sub.size(); ++j) {
+			if (shard_row_grid[j] >= 0) ctx->row_admitted[j] = by_grid[size_t(shard_row_grid[j])];
+		}
+		out.pending = std::move(ctx);
+		return RXGPU_OK;
+	}
+	return finish_phrase(h, procs, *ctx, out, who);
+}
+
+// The rest of a phrase behind its admission: the admitted documents term by term (ft_phrase_docs), the packed rows (ft_phrase_pack).
+// c.admitted may have been LOWERED by the sharded layer (the cut of the whole index fell inside or before this shard's documents): the
+// admitted documents are a prefix of the slots, so the count on the device is simply overwritten.
+int finish_phrase(rxgpu_ft_index* h, const float* procs, PhraseCtx& c, PhraseRows& out, const char* who) {
+	rxgpu::FtPhrasePlan& p = c.p;
+	const uint32_t admitted = c.admitted, n_rows0 = c.n_rows0, n_ranges = c.n_ranges;
+	const uint64_t sum_caps = c.sum_caps;
+	const size_t phrase_index = c.phrase_index;
+	const bool shard = c.shard;
+	const std::vector<uint32_t>&row_sub = c.row_sub, &shard_row_sub = c.shard_row_sub;
+	const std::vector<int32_t>& shard_row_grid = c.shard_row_grid;
+	hipStream_t st = h->stream;
+	char* hp = static_cast<char*>(h->h_pinned);
+	auto empty_row = [&](uint32_t si) {
+		rxgpu::FtPosSubterm row{};
+		row.proc = procs[si];
+		row.phrase = 1;
+		return row;
+	};
+	out.admitted = admitted;
+	if (shard) RX_HIP(hipMemcpyAsync(p.sync + 2, &c.admitted, 4, hipMemcpyHostToDevice, st));   // (c outlives the copy: the waits below)
 
 	// ---- workspace + packed rows, sized by what the admission found
 	const size_t pad = rxgpu::kFtPhraseRowPad;
@@ -1235,7 +1296,7 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	} else {
 		for (uint32_t pi = 0; pi < nparts; ++pi) {
 			if (!parts[pi].phrase) continue;
-			if (int rc = run_phrase(h, cfg, terms, parts[pi], word_ids, procs, d_excluded, n_phrases++, phrase_rows[pi], who); rc) return rc;
+			if (int rc = run_phrase(h, cfg, terms, parts[pi], word_ids, procs, d_excluded, n_phrases++, phrase_rows[pi], who, phrase_mode == 1); rc) return rc;
 		}
 		if (phrase_mode == 1) {
 			*shard_phrases = std::move(phrase_rows);
@@ -1783,6 +1844,39 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 				rc)
 				return rc;
 			if (scratch.empty) return RXGPU_OK;   // min(mergeLimit, totalORVids) == 0: alike on every shard
+		}
+		// the admission cut of the whole index (phrasemerger.h:341): the first mergeLimit candidates in (row, document) order — row by row,
+		// inside a row shard after shard (a shard's documents lie before the next one's).  What a shard keeps is a prefix of its own slots.
+		for (size_t pi = 0; pi < phrases[0].size(); ++pi) {
+			size_t n_rows = 0;
+			bool any_pending = false;
+			for (size_t s = 0; s < S; ++s) {
+				RX_CHECK(phrases[s].size() == phrases[0].size(), RXGPU_ERR_LOGIC, std::string(who) + ": the shards disagree on the parts of the query");
+				const PhraseRows& pr = phrases[s][pi];
+				const size_t r = pr.pending ? pr.pending->row_admitted.size() : pr.rows.size();
+				RX_CHECK(s == 0 || r == n_rows, RXGPU_ERR_LOGIC, std::string(who) + ": the shards disagree on the rows of a phrase");
+				n_rows = r;
+				any_pending = any_pending || pr.pending;
+			}
+			if (!any_pending) continue;
+			std::vector<uint64_t> keep(S, 0);
+			uint64_t taken = 0;
+			for (size_t j = 0; j < n_rows; ++j) {
+				for (size_t s = 0; s < S; ++s) {
+					const uint64_t c = phrases[s][pi].pending ? phrases[s][pi].pending->row_admitted[j] : 0;
+					const uint64_t take = std::min<uint64_t>(c, cfg->merge_limit > taken ? cfg->merge_limit - taken : 0);
+					keep[s] += take;
+					taken += take;
+				}
+			}
+			for (size_t s = 0; s < S; ++s) {
+				PhraseRows& pr = phrases[s][pi];
+				if (!pr.pending) continue;
+				pr.pending->admitted = uint32_t(std::min<uint64_t>(pr.pending->admitted, keep[s]));
+				RX_HIP(hipSetDevice(ss->devices[s]));
+				if (int rc = finish_phrase(ss->shards[s], procs, *pr.pending, pr, who); rc) return rc;
+				pr.pending.reset();
+			}
 		}
 		for (size_t pi = 0; pi < phrases[0].size(); ++pi) {
 			uint64_t admitted = 0;

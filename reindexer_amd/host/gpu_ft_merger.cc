@@ -110,27 +110,6 @@ GpuFtMerger::~GpuFtMerger() {
 
 double GpuFtMerger::ShardImbalance() const noexcept { return sharded_ ? rxgpu_ft_shard_imbalance(dev_) : 1.0; }
 
-bool GpuFtMerger::ShardedPhrasesFit(const std::vector<QueryTerm>& terms, size_t mergeLimit) const {
-	if (!sharded_) return true;
-	for (size_t t = 0; t < terms.size();) {
-		if (terms[t].phraseNum < 0) {
-			++t;
-			continue;
-		}
-		uint64_t docs = 0;   // the first term's MaxVDocs: the whole lists' lengths
-		for (const SubtermRef& sub : terms[t].subterms) {
-			uint64_t df = 0;
-			if (rxgpu_ft_word_df(dev_, sub.wordId, &df) != RXGPU_OK) return false;
-			docs += df;
-		}
-		if (docs > mergeLimit) return false;
-		size_t e = t + 1;
-		while (e < terms.size() && terms[e].phraseNum == terms[t].phraseNum) ++e;
-		t = e;
-	}
-	return true;
-}
-
 void GpuFtMerger::SetDocs(size_t totalDocs, const float* wordsInField, const float* avgWords, const uint8_t* removed) {
 	if (rxgpu_ft_set_docs(dev_, totalDocs, wordsInField, avgWords, removed) != RXGPU_OK) throwDevice("SetDocs");
 	totalDocs_ = totalDocs;

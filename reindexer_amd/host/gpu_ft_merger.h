@@ -158,8 +158,9 @@ public:
 	// device holds the posting fragments of its documents, idf from the global N / df; the pre-score histograms and the admission table meet
 	// in one all-gather each) and every merge returns the single-device result bit for bit.  Queries of terms and multi-word synonyms
 	// (what a synonym decides — its mask, the term count, "only parts of it" — concerns one document, and a document lies in one shard)
-	// and of phrases whose first term holds at most mergeLimit documents (ShardedPhrasesFit()), MergeQueryAreas included; resident (hybrid)
-	// merges need a single-device merger; MergeQueryBatch runs its merges one after the other there (each the single index's result).
+	// and of phrases (every shard runs PhraseMerger over its fragments; the admission cut, phrasemerger.h:341, is settled between the
+	// shards), MergeQueryAreas included; resident (hybrid) merges need a single-device merger; MergeQueryBatch runs its merges one after
+	// the other there (each the single index's result).
 	GpuFtMerger(size_t numFields, std::vector<int> devices);
 	~GpuFtMerger();
 	bool Sharded() const noexcept { return sharded_; }
@@ -167,12 +168,10 @@ public:
 	// pile up on the last shard (rxgpu_ft_shard_imbalance).  1.0 for an unsharded merger.
 	double ShardImbalance() const noexcept;
 	rxgpu_ft_index* DeviceIndex() const noexcept { return dev_; }
-	// (every query shape the single-device merger takes is merged over a device list as well — areas included: a document's areas are built
-	// where the document lies, at its global merge slot — except what ShardedPhrasesFit names and the resident, hybrid, form)
+	// (every query shape the single-device merger takes is merged over a device list as well — phrases: PhraseMerger per shard, the admission
+	// cut of the whole index settled between the shards; areas: built where the document lies, at its global merge slot — except the
+	// resident, hybrid, form: hybrid_query.h fuses on the host then)
 	bool ShardedSupports(bool /*hasPhrases*/, bool /*hasSynonyms*/, int /*maxAreasInDoc*/ = 0) const noexcept { return true; }
-	// ... and a phrase over a device list: PhraseMerger's admission cut (at most mergeLimit documents of the FIRST term, phrasemerger.h:341)
-	// would span the shards, so only a phrase whose first term holds at most mergeLimit documents is merged there (always true unsharded).
-	bool ShardedPhrasesFit(const std::vector<QueryTerm>& terms, size_t mergeLimit) const;
 	GpuFtMerger(const GpuFtMerger&) = delete;
 
 	// IndexText side (CommitFulltext): vdoc statistics and posting lists

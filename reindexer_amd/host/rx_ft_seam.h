@@ -348,8 +348,6 @@ bool TryMergeOnGpu(const GpuFtMirror* mirror, const reindexer::FTConfig& cfg, si
 		if (!ToGpuTerms(q, terms, &hasPhrases, &synonyms)) return false;
 		if (!GpuFtMerger::Supports(terms.size(), hasPhrases, !q.synonyms.empty())) return false;
 		if (!mirror->Merger().ShardedSupports(hasPhrases, !q.synonyms.empty())) return false;
-		// a device list: a phrase whose first term holds more documents than mergeLimit stays on the CPU merger (the admission cut spans the shards)
-		if (hasPhrases && !mirror->Merger().ShardedPhrasesFit(terms, cfg.mergeLimit)) return false;
 		std::vector<uint8_t> excluded;
 		const uint8_t* excludedPtr = nullptr;
 		if (docsExcluded.PopCount() != 0) {

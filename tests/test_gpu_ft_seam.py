@@ -243,8 +243,7 @@ def test_patched_merge_results_branch_takes_multi_word_synonyms(rxgpu, ft, ops, 
 @pytest.mark.parametrize("ops,syn_sizes,part_syn", SYN_SHAPES)
 def test_patched_merge_results_branch_over_a_device_list(rxgpu, ft, ops, syn_sizes, part_syn):
     """The patched Selector::mergeResults branch with the mirror over a DEVICE LIST (RX_GPU_FT_INDEXES=0,0,0: document-range shards, SURVEY 8e):
-    term queries, multi-word synonyms and phrases are merged on the shards — identical to the reference's merger, both containers; a phrase
-    whose first term holds more documents than mergeLimit is declined (ShardedPhrasesFit) and the CPU merger runs."""
+    term queries, multi-word synonyms and phrases are merged on the shards — identical to the reference's merger, both containers."""
     nf, total = 2, 30_000
     n_syn_terms = sum(syn_sizes)
     _, words, avg, removed, excluded, terms, store = _multi_case(640 + len(ops), nf, total, 20000, tuple(ops) + (1,) * n_syn_terms, False, None,
@@ -272,15 +271,13 @@ def test_patched_merge_results_branch_over_a_device_list(rxgpu, ft, ops, syn_siz
                     _same(got, want, (limit, packed, syn is not None))
                     assert len(want[0]) > 0
     if len(parts) >= 2:
-        # a phrase: merged over the shards while its first term holds at most mergeLimit documents (PhraseMerger's admission cut would span
-        # the shards otherwise: ShardedPhrasesFit declines and the reference's merger answers)
+        # a phrase: PhraseMerger runs on every shard, the admission cut of the whole index is settled between the shards
         phrase = [dict(parts[0], phrase=0, distance=12), dict(parts[1], op=parts[0]["op"], phrase=0, distance=12)] + [dict(p, phrase=-1) for p in parts[2:]]
-        seam.set_config(ft.default_config(nf, merge_limit=60000))
-        for packed in (True, False):
-            want = seam.merge(phrase, excluded, rank_sort_type=1, packed=packed, gpu=False)
-            got = seam.merge(phrase, excluded, rank_sort_type=1, packed=packed, gpu=True)
-            _same(got, want, ("phrase", packed))
-            assert len(want[0]) > 0
-        seam.set_config(ft.default_config(nf, merge_limit=400))
-        assert seam.merge(phrase, None, rank_sort_type=1, packed=True, gpu=True) is None
+        for limit in (60000, 400):   # 400: the PhraseMerger's admission cut falls inside the first term (settled between the shards)
+            seam.set_config(ft.default_config(nf, merge_limit=limit))
+            for packed in (True, False):
+                want = seam.merge(phrase, excluded, rank_sort_type=1, packed=packed, gpu=False)
+                got = seam.merge(phrase, excluded, rank_sort_type=1, packed=packed, gpu=True)
+                _same(got, want, ("phrase", limit, packed))
+                assert len(want[0]) > 0
     seam.close()
