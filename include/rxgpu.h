@@ -381,7 +381,8 @@ void rxgpu_ft_destroy(rxgpu_ft_index* h);
  * cut of the whole index (at most merge_limit candidates of the first term in (row, document) order, phrasemerger.h:341) is settled between
  * the shards' admission passes, NumDocsMerged() in the 2-phase estimate is the sum.
  * rxgpu_ft_merge_query_areas_raw works there as well (a document's areas are built by the shard that holds it, at its global merge slot).
- * Packed uploads, batches and resident (hybrid) merges are single-device features: RXGPU_ERR_LOGIC here. */
+ * rxgpu_ft_merge_batch_raw runs its merges one after the other there.  Packed uploads (the host decodes, GpuFtMerger::SetWordsPacked) and
+ * resident (hybrid) merges are single-device features: RXGPU_ERR_LOGIC here. */
 int rxgpu_ft_create_sharded(uint32_t num_fields, uint32_t n_devices, const int* devices, rxgpu_ft_index** out);
 uint32_t rxgpu_ft_shard_count(const rxgpu_ft_index* h);           /* 0 for an unsharded index */
 /* The cut of a sharded index is fixed by the first rxgpu_ft_set_docs and kept while the shards hold words: an index that grows through

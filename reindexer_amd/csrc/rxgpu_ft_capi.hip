@@ -2725,7 +2725,7 @@ int rxgpu_ft_merge_batch_raw(rxgpu_ft_index* h, const rxgpu_ft_config* cfg, uint
 		const rxgpu_ft_query& q = queries[i];
 		bool plain = q.nsyn == 0 && q.nsyn_terms == 0;
 		for (uint32_t t = 0; plain && q.phrase_num && t < q.nterms; ++t) plain = q.phrase_num[t] < 0;
-		if (plain) {
+		if (plain && !h->shard_set) {   // (a sharded index: every shard's handle runs one train and its exchanges at a time — the merges one by one)
 			batched.push_back(i);
 			continue;
 		}

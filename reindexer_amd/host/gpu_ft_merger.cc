@@ -571,15 +571,8 @@ std::vector<MergeData> GpuFtMerger::MergeQueryBatch(const FtConfig& cfg, std::ve
 	if (!nq || totalDocs_ == 0) return out;
 	if (cfg.fieldsCfg.size() != numFields_) throw std::logic_error("GpuFtMerger: field count mismatch");
 	if (!docsExcluded.empty() && docsExcluded.size() != nq) throw std::logic_error("GpuFtMerger::MergeQueryBatch: one docsExcluded per query (or none)");
-	if (sharded_) {   // over a device list a batch is its merges one after the other: every shard's handle runs one launch train (and its two
-		              // exchanges) at a time; each result is the single sharded merge's, i.e. the single index's
-		for (size_t i = 0; i < nq; ++i) {
-			bool pre = false;
-			out[i] = MergeQuery(cfg, std::move(queries[i]), docsExcluded.empty() ? nullptr : docsExcluded[i], rankSortType, &pre);
-			if (preselected) (*preselected)[i] = pre ? 1 : 0;
-		}
-		return out;
-	}
+	// (over a device list rxgpu_ft_merge_batch_raw runs the merges one after the other: every shard's handle runs one launch train and its
+	// exchanges at a time; each result is the single sharded merge's, i.e. the single index's)
 	std::vector<double> bm25Boost(numFields_), bm25Weight(numFields_), tlBoost(numFields_), tlWeight(numFields_), posBoost(numFields_), posWeight(numFields_);
 	for (size_t f = 0; f < numFields_; ++f) {
 		bm25Boost[f] = cfg.fieldsCfg[f].bm25Boost;
