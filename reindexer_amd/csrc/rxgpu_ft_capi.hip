@@ -19,6 +19,7 @@
 #include "../../include/rxgpu.h"
 #include "rccl_dyn.h"
 #include "rxgpu_internal.h"
+#include "ft_phrase_cut.h"
 #include "ft_rank.hip.h"
 
 using rxgpu::set_error;
@@ -1859,16 +1860,11 @@ int run_merge_sharded(rxgpu_ft_index* parent, const rxgpu_ft_config* cfg, bool s
 				any_pending = any_pending || pr.pending;
 			}
 			if (!any_pending) continue;
-			std::vector<uint64_t> keep(S, 0);
-			uint64_t taken = 0;
-			for (size_t j = 0; j < n_rows; ++j) {
-				for (size_t s = 0; s < S; ++s) {
-					const uint64_t c = phrases[s][pi].pending ? phrases[s][pi].pending->row_admitted[j] : 0;
-					const uint64_t take = std::min<uint64_t>(c, cfg->merge_limit > taken ? cfg->merge_limit - taken : 0);
-					keep[s] += take;
-					taken += take;
-				}
+			std::vector<std::vector<uint32_t>> counts(S);
+			for (size_t s = 0; s < S; ++s) {
+				if (phrases[s][pi].pending) counts[s] = phrases[s][pi].pending->row_admitted;
 			}
+			const std::vector<uint64_t> keep = rxgpu::ft_shard_phrase_cut(counts, n_rows, cfg->merge_limit);
 			for (size_t s = 0; s < S; ++s) {
 				PhraseRows& pr = phrases[s][pi];
 				if (!pr.pending) continue;

@@ -220,6 +220,19 @@ long rxhost_bf_select(void* h, const float* key, size_t dim, long k, int has_rad
 // ---------------------------------------------------------------------------------------------- HNSW graph builder
 #include "hnsw_graph.h"
 
+// ---- the admission cut of a phrase over document-range shards (csrc/ft_phrase_cut.h: what rxgpu_ft_capi.hip runs between the shards' admission
+// passes), for the CPU suite: counts [shards][rows] (a shard whose first entry is 0xFFFFFFFF admitted nothing), keep [shards] out.
+#include "../csrc/ft_phrase_cut.h"
+extern "C" void rxhost_ft_shard_phrase_cut(const uint32_t* counts, size_t shards, size_t rows, uint64_t mergeLimit, uint64_t* keep) {
+	std::vector<std::vector<uint32_t>> c(shards);
+	for (size_t s = 0; s < shards; ++s) {
+		if (rows && counts[s * rows] == 0xFFFFFFFFu) continue;
+		c[s].assign(counts + s * rows, counts + (s + 1) * rows);
+	}
+	const std::vector<uint64_t> k = rxgpu::ft_shard_phrase_cut(c, rows, mergeLimit);
+	for (size_t s = 0; s < shards; ++s) keep[s] = k[s];
+}
+
 // ---- the ANN disk cache through plain memory (tests, tools): fixed-width little-endian fields — 8 bytes per var-int, u64 length + bytes per
 // string, 4 bytes per float, the 8-byte label for a primary key (the reader resolves it against the (labels, vectors) table it was given).
 // oracle/ref/ref_shim.cc implements hnswlib::IWriter / IReader with the SAME encoding around the reference engine, so the two sides exchange
