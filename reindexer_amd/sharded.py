@@ -328,6 +328,19 @@ class ShardedFtExchange:
         used_in_front = int(hist[:self.rank, min_score].sum())
         return True, min_score, max(0, min_docs - used_in_front)
 
+    def phrase_cut(self, local_row_admitted: torch.Tensor, merge_limit: int):
+        """PhraseMerger's admission cut (phrasemerger.h:341: at most mergeLimit candidates of the phrase's first term, in (sub-term row, document)
+        order) over the ranks.  local_row_admitted: int64 [n_rows] = the candidates this rank admitted per row under its local bound  ->  ONE
+        all_gather; every rank derives the same cut (rows in order, inside a row the ranks in order: a rank's documents lie before the next
+        rank's) and returns (keep: how many of ITS admitted candidates stay — a prefix of its own slots, NumDocsMerged() of the whole index).
+        The same rule the library runs between its shards' admission passes (csrc/ft_phrase_cut.h)."""
+        g = self._all_gather(local_row_admitted.to(torch.int64))   # [world, n_rows]
+        flat = g.t().reshape(-1)                                   # (row, rank) order
+        before = torch.cumsum(flat, 0) - flat
+        take = torch.clamp(torch.minimum(flat, merge_limit - before), min=0)
+        take = take.reshape(g.shape[1], g.shape[0])
+        return int(take[:, self.rank].sum()), int(take.sum())
+
     def slot_bases(self, local_first_met: torch.Tensor):
         """local_first_met: int64 [n_rows] = this shard's documents first met per sub-term row.  -> (bases int64 [n_rows]: the merge slot of this
         shard's first document of every row, total documents the merge adds before the mergeLimit cut)"""

@@ -385,3 +385,68 @@ def test_two_rank_ft_document_range_shards_equal_single_index(oracle, limit):
         procs_[slots[keep]] = pr[keep]
     assert np.array_equal(docs, wd.astype(np.int64))
     assert np.array_equal(procs_.view(np.uint32), wp.view(np.uint32))
+
+
+def _phrase_cut_case(seed, world):
+    rng = np.random.default_rng(seed)
+    rows, docs_per_rank = 5, 300
+    total = world * docs_per_rank
+    postings = rng.random((rows, total)) < 0.4
+    candidate = postings & (rng.random((rows, total)) < 0.7)
+    seen = np.zeros(total, bool)
+    for r in range(rows):   # a document is added by the first row of the phrase's first term that can add it
+        candidate[r] &= ~seen
+        seen |= candidate[r]
+    return rows, docs_per_rank, postings, candidate
+
+
+def _phrase_cut_worker(rank, world, port, seed, limits, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from reindexer_amd.sharded import ShardedFtExchange
+    rows, per, postings, candidate = _phrase_cut_case(seed, world)
+    mine = slice(rank * per, (rank + 1) * per)
+    x = ShardedFtExchange()
+    got = []
+    for limit in limits:
+        left = min(limit, int(postings[:, mine].sum()))   # the rank's own admission stops at its local bound (ft_phrase_admit)
+        counts = np.zeros(rows, np.int64)
+        for r in range(rows):
+            counts[r] = min(int(candidate[r, mine].sum()), left)
+            left -= counts[r]
+        keep, merged = x.phrase_cut(torch.from_numpy(counts), limit)
+        got.append((keep, merged, int(counts.sum())))
+    out_q.put((rank, got, x.collectives))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_phrase_admission_cut_over_ranks_equals_the_plain_rule(world):
+    """PhraseMerger's admission cut (phrasemerger.h:341) as a multi-process exchange: every rank admits the candidates of its documents under its
+    local bound, ONE all_gather of the per-row counts, every rank derives what it keeps — a prefix of its own slots.  Against the plain rule:
+    the first mergeLimit candidates of the whole index in (row, document) order."""
+    seed = 99 + world
+    rows, per, postings, candidate = _phrase_cut_case(seed, world)
+    n_cand = int(candidate.sum())
+    limits = [1, 17, n_cand // 3, n_cand - 1, n_cand, n_cand + 9]
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_phrase_cut_worker, args=(r, world, port, seed, limits, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(out_q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    order = [(r, d) for r in range(rows) for d in np.flatnonzero(candidate[r])]
+    for li, limit in enumerate(limits):
+        want = np.zeros(world, np.int64)
+        for r, d in order[:limit]:
+            want[d // per] += 1
+        for rank, got, collectives in results:
+            keep, merged, admitted = got[li]
+            assert keep == want[rank] and merged == min(limit, n_cand) and keep <= admitted, (limit, rank, keep, want[rank])
+            assert collectives == len(limits)
