@@ -21,3 +21,4 @@ def test_preflight_says_ok_and_prints_one_json_line(rxgpu):
         assert out[leg].get("identical") is True, (leg, out[leg])
     assert out["devices_used"] == [0, 0] or len(out["devices_used"]) == out["visible_devices"]
     assert out["brute_force"]["collectives"] >= 1
+    assert out["bm25"]["phrase_identical"] and out["bm25"]["synonym_identical"] and out["bm25"]["phrase_documents"] > 0, out["bm25"]

@@ -143,6 +143,16 @@ def main() -> int:
         leg["collectives"] = int(lib.rxgpu_ft_shard_collectives(many.device_index)) - c0
         leg["identical"] = bool(np.array_equal(x[0], y[0]) and np.array_equal(x[1].view(np.uint32), y[1].view(np.uint32)) and x[4] == y[4])
         leg["merged_documents"] = int(len(x[0]))
+        # a phrase over the shards ("w0 w1"~30 OR w2; merge_limit 5000 < w0's 20 000 documents: PhraseMerger's admission cut is settled between the
+        # shards) and the same terms with a two-word synonym hung on the first one
+        phrase = [dict(terms[0], phrase=0, distance=30), dict(terms[1], phrase=0, distance=30), dict(terms[2], phrase=-1)]
+        x, y = one.merge_query(cfg, phrase, None, sort_by_rank=False), many.merge_query(cfg, phrase, None, sort_by_rank=False)
+        leg["phrase_identical"] = bool(np.array_equal(x[0], y[0]) and np.array_equal(x[1].view(np.uint32), y[1].view(np.uint32)))
+        leg["phrase_documents"] = int(len(x[0]))
+        syn = dict(synonyms=[[terms[1], terms[2]]], part_synonyms=[[0]])
+        x, y = one.merge_query(cfg, terms[:1], None, sort_by_rank=False, **syn), many.merge_query(cfg, terms[:1], None, sort_by_rank=False, **syn)
+        leg["synonym_identical"] = bool(np.array_equal(x[0], y[0]) and np.array_equal(x[1].view(np.uint32), y[1].view(np.uint32)))
+        leg["identical"] = bool(leg["identical"] and leg["phrase_identical"] and leg["synonym_identical"])
         one.close()
         many.close()
     except Exception as e:
