@@ -612,7 +612,7 @@ def sharded_in_process_leg(args, ix, corpus, d_inv, queries, device, kk):
             sx.shard(s).adopt_device_rows(corpus.data_ptr() + s * half * args.dim * esz, half, args.dim,
                                           d_inv.data_ptr() + s * half * esz if d_inv is not None else None)
         sx.sync_count()
-        steps = max(8, min(args.steps, 32))
+        steps = min(max(8, min(args.steps, 32)), int(queries.shape[0]) - 2)
         hq = queries[:steps + 2].cpu().numpy()
         for i in range(2):
             sx.search_knn(hq[i:i + 1], kk)
@@ -674,7 +674,8 @@ def main():
     total_q = args.steps + args.warmup
     gq = torch.Generator(device=device)
     gq.manual_seed(7)  # the same queries on every rank
-    queries = torch.empty((max(total_q, args.cpu_queries, args.batch), args.dim), dtype=torch.float32, device=device).normal_(0.0, 0.25, generator=gq)
+    # (34: the in-process sharded leg runs 2 + 8..32 queries whatever --steps says)
+    queries = torch.empty((max(total_q, args.cpu_queries, args.batch, 34), args.dim), dtype=torch.float32, device=device).normal_(0.0, 0.25, generator=gq)
     d_inv = None
     if metric_id == 2:
         d_inv = 1.0 / torch.linalg.vector_norm(corpus, dim=1)
