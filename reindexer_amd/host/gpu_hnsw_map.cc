@@ -575,16 +575,18 @@ struct GpuHnswMap::PendingQuery {
 
 void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* dist, uint32_t* row, uint32_t* count) const {
 	PendingQuery p{query, k, ef, dist, row, count, false, 0, {}};
-	{   // the index's resident search kernel first (rxgpu_hnsw_search_knn_posted): a store and a poll, side by side with every other thread's
+	// over a device list the queries of T planner threads meet here too: one fan-out + one all-gather per BATCH instead of one per query
+	rxgpu_index* const target = sh_ ? sh_->parent : dev_;
+	if (!sh_) {   // the index's resident search kernel first (rxgpu_hnsw_search_knn_posted): a store and a poll, side by side with every other thread's
 		int32_t served = 0;
-		if (rxgpu_hnsw_search_knn_posted(dev_, query, k, ef, dist, row, count, &served) != RXGPU_OK) throw std::runtime_error(std::string("SearchKnn: ") + rxgpu_last_error());
+		if (rxgpu_hnsw_search_knn_posted(target, query, k, ef, dist, row, count, &served) != RXGPU_OK) throw std::runtime_error(std::string("SearchKnn: ") + rxgpu_last_error());
 		if (served) {
 			coPosted_.fetch_add(1, std::memory_order_relaxed);
 			return;
 		}
 	}
 	if (!coalesce_) {
-		p.rc = rxgpu_hnsw_search_knn(dev_, query, 1, k, ef, dist, row, count);
+		p.rc = rxgpu_hnsw_search_knn(target, query, 1, k, ef, dist, row, count);
 		if (p.rc != RXGPU_OK) p.error = rxgpu_last_error();
 	} else {
 		std::unique_lock<std::mutex> lk(coMtx_);
@@ -618,12 +620,12 @@ void GpuHnswMap::fetchKnn(const float* query, uint32_t k, uint32_t ef, float* di
 			try {
 				if (nq == 1) {
 					PendingQuery& q = *batch[0];
-					rc = rxgpu_hnsw_search_knn(dev_, q.query, 1, bk, bef, q.dist, q.row, q.count);
+					rc = rxgpu_hnsw_search_knn(target, q.query, 1, bk, bef, q.dist, q.row, q.count);
 				} else {
 					std::vector<float> queries(nq * dim), d(nq * bk);
 					std::vector<uint32_t> r(nq * bk), c(nq);
 					for (size_t i = 0; i < nq; ++i) std::copy(batch[i]->query, batch[i]->query + dim, queries.begin() + i * dim);
-					rc = rxgpu_hnsw_search_knn(dev_, queries.data(), uint32_t(nq), bk, bef, d.data(), r.data(), c.data());
+					rc = rxgpu_hnsw_search_knn(target, queries.data(), uint32_t(nq), bk, bef, d.data(), r.data(), c.data());
 					if (rc == RXGPU_OK) {
 						for (size_t i = 0; i < nq; ++i) {
 							std::copy(d.begin() + i * bk, d.begin() + i * bk + c[i], batch[i]->dist);
@@ -681,8 +683,8 @@ SearchResultQueue GpuHnswMap::SearchKnn(const float* queryDataRaw, std::optional
 			if (rxgpu_hnsw_search_knn_sq8(sh_->parent, qcodes.data(), &qcorr, &normCoef, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) {
 				throwDevice("SearchKnn");
 			}
-		} else if (rxgpu_hnsw_search_knn(sh_->parent, queryDataRaw, 1, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count) != RXGPU_OK) {
-			throwDevice("SearchKnn");
+		} else {
+			fetchKnn(queryDataRaw, uint32_t(k), uint32_t(ef), dist.data(), row.data(), &count);   // the coalescer in front of the sharded handle
 		}
 		ReserveQueue(result, count);
 		for (uint32_t i = 0; i < count; ++i) result.emplace(dist[i], shLabel(row[i]));

@@ -507,3 +507,37 @@ def test_streaming_session_over_a_device_list_merges_the_shard_sessions(hostapi,
         for part in parts:
             part["s"].close()
     many.close()
+
+
+def test_planner_threads_over_a_device_list_are_served_in_batches(hostapi):
+    """T planner threads, one query per SearchKnn call each, on a Map over a device list: calls that arrive while the devices are busy leave as
+    ONE fan-out + ONE all-gather (the Map's coalescer in front of the sharded handle) — transparent: every call returns what it returns alone."""
+    import threading
+    n, d, k = 3000, 64, 10
+    rows = make_corpus(95, n, d)
+    labels = np.arange(n, dtype=np.uint64) << np.uint64(32)
+    many = hostapi.GpuHnswMap(1, d, n, M=8, ef_construction=80, devices=[0, 0, 0])
+    many.add(rows, labels)
+    queries = make_corpus(96, 96, d)
+    alone = [many.search_knn(queries[i], k if i % 3 else 4, 64 if i % 2 else 24) for i in range(96)]
+    out, errs = [None] * 96, []
+
+    def work(t):
+        try:
+            for i in range(t, 96, 12):
+                out[i] = many.search_knn(queries[i], k if i % 3 else 4, 64 if i % 2 else 24)
+        except Exception as e:   # noqa: BLE001
+            errs.append(repr(e))
+
+    for _ in range(3):
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(12)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert not errs, errs
+        for i in range(96):
+            a, b = alone[i], out[i]
+            oa, ob = np.lexsort((a[1], a[0])), np.lexsort((b[1], b[0]))
+            assert np.array_equal(a[1][oa], b[1][ob]) and np.array_equal(bits(a[0][oa]), bits(b[0][ob])), i
+    many.close()
