@@ -184,6 +184,28 @@ def test_load_errors(ref):
         x.close()
 
 
+def test_the_header_of_a_sharded_cache_is_refused_by_every_single_graph_reader(ref):
+    """The ANN cache of a Map over a device list (gpu_hnsw_map.cc, SaveIndex) opens — behind the quantisation flag — with capacity 0 and
+    count = the number of shards, where one graph states its capacity and its element count: the reference's reader constructor
+    (hnswalg.h:297-306) and the product's graph loader stop right there with the same error, which HnswIndexBase::LoadIndexCache turns into
+    "drop the cache and rebuild".  (The stream itself is written and read back on the GPU: tests/test_gpu_sharded_hnsw.py.)"""
+    import struct
+    from oracle.pyoracle import RefHnsw
+    from reindexer_amd import hostapi
+    d = 16
+    rows, labels = make_corpus(5, 10, d), np.arange(10, dtype=np.uint64)
+    for shards in (2, 8):
+        head = struct.pack("<QQQQQQ", 0, 0, shards, 1, 1000, 512)   # float graph; capacity 0, count = shards; version, Map capacity, shard rows
+        for stream in (head, head + b"\0" * 256):
+            g = hostapi.HnswGraph(1, d, 100, M=8, ef_construction=40)
+            with pytest.raises(hostapi.HostError, match="Current elements count is larger than max elements count"):
+                g.load_index(stream, labels, rows)
+            assert g.export()["n"] == 0
+            g.close()
+            with pytest.raises(RuntimeError, match="Current elements count is larger than max elements count"):
+                RefHnsw.load_index(ref, stream, 1, d, labels, rows)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("metric", [0, 1, 2])
 def test_gpu_map_serves_a_reference_cache(metric):
