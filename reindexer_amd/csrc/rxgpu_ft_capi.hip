@@ -1590,7 +1590,7 @@ int prepare_merge(rxgpu_ft_index* h, hipStream_t st, const rxgpu_ft_config* cfg,
 	p.e_idx = reinterpret_cast<uint32_t*>(base + o_eidx);
 	p.e_field = reinterpret_cast<uint8_t*>(base + o_efield);
 	p.sync = reinterpret_cast<uint32_t*>(cbase + o_sync);
-	const char* stamps_env = std::getenv("RXGPU_FT_STAMPS");
+	static const char* const stamps_env = std::getenv("RXGPU_FT_STAMPS");   // (a debugging hook: read once, not once per merge)
 	p.dbg = stamps_env ? reinterpret_cast<unsigned long long*>(cbase + o_dbg) : nullptr;
 	p.dbg_block = stamps_env ? uint32_t(std::atoi(stamps_env)) : 0;
 	p.out_header = reinterpret_cast<uint32_t*>(ob);
