@@ -241,6 +241,16 @@ def run(o) -> dict:
                              "note": "dependent random 3 KB row gathers; bytes = evals*D*4 + hops*(1+2M)*4 from the kernel's own counters"}},
         "recall_at_k_vs_exact": recall, "recall_queries": tq,
     }
+    # the same queries at wider candidate lists: where recall@k vs exact reaches the 0.99 north_star names (profiles/rd6_hnsw_evidence.json has
+    # the whole sweep at 1M rows); a failure here never takes the leg down
+    try:
+        by_ef = {str(o.ef): recall}
+        for ef2 in (2 * o.ef, 4 * o.ef):
+            _, r2, c2 = ix.hnsw_search_knn(queries[:tq], o.k, ef2)
+            by_ef[str(ef2)] = float(np.mean([len(set(trow[i].tolist()) & set(r2[i, :int(c2[i])].tolist())) / o.k for i in range(tq)]))
+        out["recall_at_k_vs_exact_by_ef"] = by_ef
+    except Exception as e:   # noqa: BLE001
+        out["recall_at_k_vs_exact_by_ef"] = {"error": repr(e)}
 
     if o.gpu_only:
         out["leg_seconds"] = time.perf_counter() - t_all
