@@ -118,7 +118,8 @@ _DROP_KEYS = {"note", "against", "host", "kernels", "builder", "params", "value_
 _KEEP_UNITS_AT = {"roofline", "cpu_baseline"}   # the contract's two objects keep every field the contract names
 
 
-_DROP_KEYS_TIGHT = {"deviations_from_survey_8d", "workload", "sample", "checked", "queries", "recall_queries", "equal_to_reference_checked", "device_batches"}
+_DROP_KEYS_TIGHT = {"deviations_from_survey_8d", "workload", "sample", "checked", "queries", "recall_queries", "equal_to_reference_checked", "device_batches",
+                    "avg_batch", "posted", "fusion_kernel_launches", "what"}
 
 
 def compact(obj, depth=0, top_key=None, tight=False):
